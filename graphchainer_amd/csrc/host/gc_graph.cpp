@@ -1,0 +1,696 @@
+// Host-side construction of the alignment graph ("A0" data).
+// Restates the behaviour of the reference's loaders; every function cites the lines it follows.
+#include "gc_graph.hpp"
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <deque>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <tuple>
+
+namespace gc {
+
+// ------------------------------------------------------------------ small utilities
+
+char Complement(char c)   // reference: src/CommonUtils.cpp:78-134
+{
+	switch (c) {
+		case 'A': case 'a': return 'T';
+		case 'C': case 'c': return 'G';
+		case 'G': case 'g': return 'C';
+		case 'T': case 't': case 'U': case 'u': return 'A';
+		case 'N': case 'n': return 'N';
+		case 'R': case 'r': return 'Y';
+		case 'Y': case 'y': return 'R';
+		case 'K': case 'k': return 'M';
+		case 'M': case 'm': return 'K';
+		case 'S': case 's': return 'S';
+		case 'W': case 'w': return 'W';
+		case 'B': case 'b': return 'V';
+		case 'V': case 'v': return 'B';
+		case 'D': case 'd': return 'H';
+		case 'H': case 'h': return 'D';
+	}
+	throw std::runtime_error(std::string("Complement: invalid nucleotide '") + c + "'");
+}
+
+std::string ReverseComplement(const std::string& s)   // reference: src/CommonUtils.cpp:67-76
+{
+	std::string out(s.size(), 'N');
+	for (size_t i = 0; i < s.size(); i++) out[i] = Complement(s[s.size() - 1 - i]);
+	return out;
+}
+
+// ------------------------------------------------------------------ GFA parsing
+
+// reference: src/GfaGraph.cpp:212-370 (LoadFromStream, called with allowVaryingOverlaps=true from
+// src/Aligner.cpp:1100). Segment names map to integer ids in order of first appearance on an S or
+// L line (getNameId, :146-156); numberBackToIntegers is disabled in the reference (:325-329).
+GfaGraph GfaGraph::LoadFromStream(std::istream& in)
+{
+	GfaGraph g;
+	std::unordered_map<std::string, int> ids;
+	auto nameId = [&ids](const std::string& name) {
+		auto it = ids.find(name);
+		if (it != ids.end()) return it->second;
+		int id = (int)ids.size();
+		ids[name] = id;
+		return id;
+	};
+	std::string line;
+	while (in.good()) {
+		std::getline(in, line);
+		if (!in.good()) break;   // like the reference (:219-223), a last line without '\n' is dropped
+		if (line.empty()) continue;
+		if (line[0] == 'S') {
+			std::stringstream ss(line);
+			std::string tag, name, seq;
+			ss >> tag >> name;
+			int id = nameId(name);
+			ss >> seq;
+			if (seq == "*") throw std::runtime_error("Nodes without sequence (*) are not currently supported (nodeid " + name + ")");
+			if (seq.empty()) throw std::runtime_error("empty S line for node " + name);
+			g.nodes[id] = seq;
+		} else if (line[0] == 'L') {
+			std::stringstream ss(line);
+			std::string tag, from, fromOri, to, toOri;
+			int overlap = 0;
+			char unit = 'M';
+			ss >> tag >> from;
+			int fromId = nameId(from);
+			ss >> fromOri >> to;
+			int toId = nameId(to);
+			ss >> toOri >> overlap >> unit;
+			if ((fromOri != "+" && fromOri != "-") || (toOri != "+" && toOri != "-")) throw std::runtime_error("bad L line orientation: " + line);
+			if (overlap < 0) throw std::runtime_error("Edge overlap cannot be negative. Fix the graph");
+			NodePos a { fromId, fromOri == "+" };
+			NodePos b { toId, toOri == "+" };
+			g.edges[a].push_back(b);
+			g.overlaps.push_back({ { a, b }, (size_t)overlap });
+		}
+	}
+	for (auto& kv : ids) g.originalNodeName[kv.second] = kv.first;
+	// edges that touch a segment without an S line are dropped (reference: src/GfaGraph.cpp:329-368)
+	std::vector<NodePos> orphanSources;
+	for (auto& e : g.edges) {
+		if (g.nodes.count(e.first.id) == 0) { orphanSources.push_back(e.first); continue; }
+		for (size_t i = e.second.size(); i-- > 0;)
+			if (g.nodes.count(e.second[i].id) == 0) e.second.erase(e.second.begin() + i);
+	}
+	for (auto& p : orphanSources) g.edges.erase(p);
+	return g;
+}
+
+GfaGraph GfaGraph::LoadFromFile(const std::string& path)
+{
+	std::ifstream f(path);
+	if (!f.good()) throw std::runtime_error("cannot open GFA file " + path);
+	return LoadFromStream(f);
+}
+
+// ------------------------------------------------------------------ bigraph -> split-node digraph
+
+static bool allowedNucleotide(char c)   // reference: src/BigraphToDigraph.cpp:9-47
+{
+	switch (c) {
+		case 'a': case 'A': case 'c': case 'C': case 'g': case 'G': case 't': case 'T': case 'u': case 'U':
+		case 'y': case 'Y': case 'r': case 'R': case 'w': case 'W': case 's': case 'S': case 'k': case 'K':
+		case 'm': case 'M': case 'd': case 'D': case 'v': case 'V': case 'h': case 'H': case 'b': case 'B':
+		case 'n': case 'N': return true;
+	}
+	return false;
+}
+
+// reference: src/BigraphToDigraph.cpp:215-267. GFA segment n becomes forward node 2n and
+// reverse-complement node 2n+1 (:101-104); link a(+/-) -> b(+/-) becomes two directed edges (:106-132).
+AlignmentGraph AlignmentGraph::BuildFromGFA(const GfaGraph& gfa)
+{
+	AlignmentGraph g;
+	for (auto& ov : gfa.overlaps)
+		if (ov.second != 0) throw std::runtime_error("edge overlaps other than 0M are outside this build's scope (variation-graph DAGs only)");
+	for (const auto& node : gfa.nodes) {    // libstdc++ unordered_map order == reference order
+		for (char c : node.second)
+			if (!allowedNucleotide(c)) throw std::runtime_error(std::string("Invalid sequence character: ") + c);
+		auto nameIt = gfa.originalNodeName.find(node.first);
+		std::string name = nameIt == gfa.originalNodeName.end() ? std::string() : nameIt->second;
+		std::vector<size_t> breakpoints { 0, node.second.size() };
+		g.AddNode(node.first * 2, node.second, name, false, breakpoints);
+		g.AddNode(node.first * 2 + 1, ReverseComplement(node.second), name, true, breakpoints);
+	}
+	for (const auto& edge : gfa.edges) {
+		for (const auto& target : edge.second) {
+			int from = edge.first.id, to = target.id;
+			// ConvertGFAEdgeToEdges, src/BigraphToDigraph.cpp:106-132
+			size_t fromLeft, fromRight, toLeft, toRight;
+			if (!edge.first.end) { fromLeft = from * 2; fromRight = from * 2 + 1; } else { fromLeft = from * 2 + 1; fromRight = from * 2; }
+			if (!target.end) { toLeft = to * 2; toRight = to * 2 + 1; } else { toLeft = to * 2 + 1; toRight = to * 2; }
+			g.AddEdgeNodeId((int)fromRight, (int)toRight, 0);
+			g.AddEdgeNodeId((int)toLeft, (int)fromLeft, 0);
+		}
+	}
+	g.Finalize();
+	return g;
+}
+
+// reference: src/AlignmentGraph.cpp:51-85. Cuts a bigraph node into <=64 bp pieces, chained by edges.
+void AlignmentGraph::AddNode(int nodeId, const std::string& sequence, const std::string& name, bool reverseNode, const std::vector<size_t>& breakpoints)
+{
+	if (nodeLookup.count(nodeId) != 0) return;
+	originalNodeSize[nodeId] = sequence.size();
+	originalNodeName[nodeId] = name;
+	for (size_t b = 1; b < breakpoints.size(); b++) {
+		if (breakpoints[b] == breakpoints[b - 1]) continue;
+		for (size_t offset = breakpoints[b - 1]; offset < breakpoints[b]; offset += SPLIT_NODE_SIZE) {
+			size_t size = std::min((size_t)SPLIT_NODE_SIZE, breakpoints[b] - offset);
+			AddSplitNode(nodeId, (int)offset, sequence.substr(offset, size), reverseNode);
+			if (offset > 0) {
+				size_t last = outNeighbors.size() - 1;
+				outNeighbors[last - 1].push_back(last);
+				inNeighbors[last].push_back(last - 1);
+			}
+		}
+	}
+}
+
+// reference: src/AlignmentGraph.cpp:87-231. Sequence packing: 2 bits per base, base i in word i/32 at
+// bit (i%32)*2, A=0 C=1 G=2 T/U=3; IUPAC codes make the node "ambiguous" (one-hot words instead).
+void AlignmentGraph::AddSplitNode(int nodeId, int offset, const std::string& sequence, bool reverseNode)
+{
+	assert(sequence.size() <= (size_t)SPLIT_NODE_SIZE);
+	bpSize += sequence.size();
+	nodeLookup[nodeId].push_back(nodeLength.size());
+	nodeLength.push_back(sequence.size());
+	nodeIDs.push_back(nodeId);
+	inNeighbors.emplace_back();
+	outNeighbors.emplace_back();
+	reverse.push_back(reverseNode);
+	nodeOffset.push_back(offset);
+	std::array<uint64_t, 2> packed { 0, 0 };
+	AmbiguousSeq amb { 0, 0, 0, 0 };
+	bool ambiguous = false;
+	for (size_t i = 0; i < sequence.size(); i++) {
+		uint64_t bit = (uint64_t)1 << i;
+		int code = -1;
+		bool a = false, c = false, gg = false, t = false;
+		switch (sequence[i]) {
+			case 'a': case 'A': a = true; code = 0; break;
+			case 'c': case 'C': c = true; code = 1; break;
+			case 'g': case 'G': gg = true; code = 2; break;
+			case 't': case 'T': case 'u': case 'U': t = true; code = 3; break;
+			case 'r': case 'R': a = gg = true; break;
+			case 'y': case 'Y': c = t = true; break;
+			case 's': case 'S': gg = c = true; break;
+			case 'w': case 'W': a = t = true; break;
+			case 'k': case 'K': gg = t = true; break;
+			case 'm': case 'M': a = c = true; break;
+			case 'b': case 'B': c = gg = t = true; break;
+			case 'd': case 'D': a = gg = t = true; break;
+			case 'h': case 'H': a = c = t = true; break;
+			case 'v': case 'V': a = c = gg = true; break;
+			case 'n': case 'N': a = c = gg = t = true; break;
+			default: throw std::runtime_error("invalid nucleotide in graph");
+		}
+		if (a) amb.A |= bit;
+		if (c) amb.C |= bit;
+		if (gg) amb.G |= bit;
+		if (t) amb.T |= bit;
+		if (code >= 0) packed[i / BP_IN_CHUNK] |= (uint64_t)code << ((i % BP_IN_CHUNK) * 2);
+		else ambiguous = true;
+	}
+	ambiguousNodes.push_back(ambiguous);
+	if (ambiguous) ambiguousNodeSequences.push_back(amb);
+	else nodeSequences.push_back(packed);
+}
+
+// reference: src/AlignmentGraph.cpp:233-253
+void AlignmentGraph::AddEdgeNodeId(int fromId, int toId, size_t startOffset)
+{
+	size_t from = nodeLookup.at(fromId).back();
+	size_t to = SIZE_MAX;
+	for (size_t node : nodeLookup.at(toId))
+		if (nodeOffset[node] == startOffset) to = node;
+	if (to == SIZE_MAX) throw std::runtime_error("edge target offset not found");
+	if (std::find(inNeighbors[to].begin(), inNeighbors[to].end(), from) == inNeighbors[to].end()) inNeighbors[to].push_back(from);
+	if (std::find(outNeighbors[from].begin(), outNeighbors[from].end(), to) == outNeighbors[from].end()) outNeighbors[from].push_back(to);
+}
+
+// reference: src/AlignmentGraph.cpp:255-307
+void AlignmentGraph::Finalize()
+{
+	RenumberAmbiguousToEnd();
+	ambiguousNodes.clear();
+	findLinearizable();
+	doComponentOrder();
+	findChains();
+	finalized = true;
+}
+
+// reference: src/AlignmentGraph.cpp:919-974 (+ the two helpers :885-917). Non-ambiguous nodes keep
+// their relative order; ambiguous node j (in creation order) moves to index N-1-j.
+void AlignmentGraph::RenumberAmbiguousToEnd()
+{
+	size_t n = ambiguousNodes.size();
+	std::vector<size_t> newIndex(n);
+	size_t plain = 0, amb = 0;
+	for (size_t i = 0; i < n; i++) {
+		if (!ambiguousNodes[i]) newIndex[i] = plain++;
+		else newIndex[i] = n - 1 - amb++;
+	}
+	firstAmbiguous = plain;
+	if (amb == 0) return;
+	std::reverse(ambiguousNodeSequences.begin(), ambiguousNodeSequences.end());
+	auto permute = [&](auto& vec) {
+		auto copy = vec;
+		for (size_t i = 0; i < n; i++) vec[newIndex[i]] = copy[i];
+	};
+	permute(nodeLength);
+	permute(nodeOffset);
+	permute(nodeIDs);
+	permute(inNeighbors);
+	permute(outNeighbors);
+	permute(reverse);
+	for (auto& kv : nodeLookup)
+		for (auto& v : kv.second) v = newIndex[v];
+	for (size_t i = 0; i < n; i++) {
+		for (auto& v : inNeighbors[i]) v = newIndex[v];
+		for (auto& v : outNeighbors[i]) v = newIndex[v];
+	}
+}
+
+// reference: src/AlignmentGraph.cpp:644-736. Restated literally, including the fact that the start
+// node is marked checked before the walk begins (:665), which makes the walk stop on its first
+// iteration (:689-701) for every in-degree-1 node: on any graph the result is all-false. The walk is
+// kept (instead of a constant) so a change in the reference's rule shows up as a diff here.
+void AlignmentGraph::findLinearizable()
+{
+	size_t n = nodeLength.size();
+	linearizable.assign(n, false);
+	std::vector<bool> checked(n, false), onStack(n, false);
+	std::vector<size_t> stack;
+	for (size_t node = 0; node < n; node++) {
+		if (checked[node]) continue;
+		checked[node] = true;
+		if (inNeighbors[node].size() != 1) continue;
+		stack.assign(1, node);
+		onStack[node] = true;
+		while (true) {
+			size_t top = stack.back();
+			if (inNeighbors[top].size() != 1 || checked[top]) {
+				for (size_t i = 0; i + 1 < stack.size(); i++) { checked[stack[i]] = true; linearizable[stack[i]] = true; onStack[stack[i]] = false; }
+				linearizable[top] = false; checked[top] = true; onStack[top] = false;
+				break;
+			}
+			size_t neighbor = inNeighbors[top][0];
+			if (neighbor == node || onStack[neighbor]) {
+				// only reachable on cyclic graphs, which the MPC build rejects (src/AlignmentGraph.cpp:1298)
+				for (size_t v : stack) { checked[v] = true; linearizable[v] = false; onStack[v] = false; }
+				break;
+			}
+			stack.push_back(neighbor);
+			onStack[neighbor] = true;
+		}
+		stack.clear();
+	}
+}
+
+// reference: src/AlignmentGraph.cpp:1008-1115. Tarjan SCC with roots in ascending node order and
+// children in outNeighbors order; components are numbered in completion order and then reversed so
+// that componentNumber is a topological rank (every edge goes to an equal-or-higher number).
+void AlignmentGraph::doComponentOrder()
+{
+	size_t n = nodeLength.size();
+	const size_t NONE = SIZE_MAX;
+	std::vector<size_t> index(n, NONE), lowlink(n, NONE), sccStack;
+	std::vector<bool> onStack(n, false);
+	std::vector<std::pair<size_t, size_t>> dfs;   // (node, next child position)
+	componentNumber.assign(n, NONE);
+	size_t counter = 0, nextComponent = 0;
+	for (size_t root = 0; root < n; root++) {
+		if (index[root] != NONE) continue;
+		dfs.emplace_back(root, 0);
+		index[root] = lowlink[root] = counter++;
+		sccStack.push_back(root);
+		onStack[root] = true;
+		while (!dfs.empty()) {
+			size_t v = dfs.back().first;
+			if (dfs.back().second < outNeighbors[v].size()) {
+				size_t w = outNeighbors[v][dfs.back().second++];
+				if (index[w] == NONE) {
+					index[w] = lowlink[w] = counter++;
+					sccStack.push_back(w);
+					onStack[w] = true;
+					dfs.emplace_back(w, 0);
+				} else if (onStack[w]) {
+					lowlink[v] = std::min(lowlink[v], index[w]);
+				}
+				continue;
+			}
+			dfs.pop_back();
+			if (!dfs.empty()) lowlink[dfs.back().first] = std::min(lowlink[dfs.back().first], lowlink[v]);
+			if (lowlink[v] == index[v]) {
+				size_t w;
+				do {
+					w = sccStack.back();
+					sccStack.pop_back();
+					onStack[w] = false;
+					componentNumber[w] = nextComponent;
+				} while (w != v);
+				nextComponent++;
+			}
+		}
+	}
+	for (size_t i = 0; i < n; i++) componentNumber[i] = nextComponent - 1 - componentNumber[i];
+}
+
+// reference: src/AlignmentGraph.cpp:583-642 (findChains) with chainTips :433-535, chainCycles :537-581,
+// chainBubble :378-405. On an acyclic graph every node is both a "forward tip" and a "backward tip"
+// (induction over the topological order in chainTips :445-462 and :473-490), so chainTips unions
+// every edge and each weakly connected component becomes one chain; all later unions stay inside a
+// component. Only the partition is consumed downstream (seed clustering, src/GraphAligner.h:261, and
+// fixChainApproxPos), never the representative, so the chain label here is the smallest node index of
+// the component. Cyclic graphs never reach alignment (rejected at src/AlignmentGraph.cpp:1298-1302).
+void AlignmentGraph::findChains()
+{
+	size_t n = nodeLength.size();
+	chainNumber.assign(n, SIZE_MAX);
+	std::vector<size_t> queue;
+	for (size_t s = 0; s < n; s++) {
+		if (chainNumber[s] != SIZE_MAX) continue;
+		chainNumber[s] = s;
+		queue.assign(1, s);
+		for (size_t qi = 0; qi < queue.size(); qi++) {
+			size_t v = queue[qi];
+			for (size_t u : outNeighbors[v]) if (chainNumber[u] == SIZE_MAX) { chainNumber[u] = s; queue.push_back(u); }
+			for (size_t u : inNeighbors[v]) if (chainNumber[u] == SIZE_MAX) { chainNumber[u] = s; queue.push_back(u); }
+		}
+	}
+	chainApproxPos.assign(n, SIZE_MAX);
+	for (size_t i = 0; i < n; i++)
+		if (chainApproxPos[i] == SIZE_MAX) fixChainApproxPos(i);
+}
+
+// reference: src/AlignmentGraph.cpp:407-431. Depth-first labelling with an explicit LIFO stack;
+// the first value that reaches a node wins, so the push order (out-neighbours, then in-neighbours,
+// each in adjacency order) is part of the result.
+void AlignmentGraph::fixChainApproxPos(size_t start)
+{
+	std::vector<std::pair<size_t, size_t>> stack;
+	size_t chain = chainNumber[start];
+	stack.emplace_back(start, (nodeLength.size() + 5) * SPLIT_NODE_SIZE);
+	while (!stack.empty()) {
+		auto [v, dist] = stack.back();
+		stack.pop_back();
+		if (chainApproxPos[v] != SIZE_MAX) continue;
+		chainApproxPos[v] = dist;
+		for (size_t u : outNeighbors[v]) {
+			if (chainNumber[u] != chain || chainApproxPos[u] != SIZE_MAX) continue;
+			stack.emplace_back(u, dist + nodeLength[u]);
+		}
+		for (size_t u : inNeighbors[v]) {
+			if (chainNumber[u] != chain || chainApproxPos[u] != SIZE_MAX) continue;
+			stack.emplace_back(u, dist - nodeLength[v]);
+		}
+	}
+}
+
+// ------------------------------------------------------------------ accessors
+
+char AlignmentGraph::NodeSequences(size_t node, size_t pos) const   // reference: src/AlignmentGraph.cpp:751-796
+{
+	if (node < firstAmbiguous) return "ACGT"[(nodeSequences[node][pos / BP_IN_CHUNK] >> ((pos % BP_IN_CHUNK) * 2)) & 3];
+	const AmbiguousSeq& s = ambiguousNodeSequences[node - firstAmbiguous];
+	int mask = (int)((s.A >> pos) & 1) | (int)(((s.C >> pos) & 1) << 1) | (int)(((s.G >> pos) & 1) << 2) | (int)(((s.T >> pos) & 1) << 3);
+	// index = A | C<<1 | G<<2 | T<<3
+	static const char iupac[16] = { 'N', 'A', 'C', 'M', 'G', 'R', 'S', 'V', 'T', 'W', 'Y', 'H', 'K', 'D', 'B', 'N' };
+	return iupac[mask];
+}
+
+size_t AlignmentGraph::GetUnitigNode(int nodeId, size_t offset) const   // reference: src/AlignmentGraph.cpp:832-848
+{
+	const auto& nodes = nodeLookup.at(nodeId);
+	size_t index = (size_t)(nodes.size() * ((double)offset / (double)originalNodeSize.at(nodeId)));
+	if (index >= nodes.size()) index = nodes.size() - 1;
+	while (index < nodes.size() - 1 && nodeOffset[nodes[index]] + nodeLength[nodes[index]] <= offset) index++;
+	while (index > 0 && nodeOffset[nodes[index]] > offset) index--;
+	return nodes[index];
+}
+
+std::pair<int, size_t> AlignmentGraph::GetReversePosition(int nodeId, size_t offset) const   // :850-868
+{
+	size_t originalSize = originalNodeSize.at(nodeId);
+	return { nodeId ^ 1, originalSize - offset - 1 };
+}
+
+std::string AlignmentGraph::OriginalNodeName(int nodeId) const
+{
+	auto it = originalNodeName.find(nodeId);
+	return it == originalNodeName.end() ? std::string() : it->second;
+}
+
+// ------------------------------------------------------------------ MPC index
+
+// reference: src/AlignmentGraph.cpp:1430-1463. Weakly connected components by BFS from ascending
+// seeds, expanding out-neighbours then in-neighbours; component ids and the in-component index of
+// each node (its BFS position) follow from that order.
+void AlignmentGraph::buildComponentsMap()
+{
+	size_t n = NodeSize();
+	component_map.assign(n, n + 1);
+	component_idx.assign(n, n + 1);
+	component_ids.clear();
+	std::vector<size_t> q;
+	for (size_t s = 0; s < n; s++) {
+		if (component_map[s] != n + 1) continue;
+		size_t c = component_ids.size();
+		q.assign(1, s);
+		component_map[s] = c;
+		component_idx[s] = 0;
+		for (size_t i = 0; i < q.size(); i++) {
+			size_t v = q[i];
+			for (size_t t : outNeighbors[v]) if (component_map[t] == n + 1) { component_map[t] = c; component_idx[t] = q.size(); q.push_back(t); }
+			for (size_t t : inNeighbors[v]) if (component_map[t] == n + 1) { component_map[t] = c; component_idx[t] = q.size(); q.push_back(t); }
+		}
+		component_ids.push_back(q);
+	}
+}
+
+// reference: src/AlignmentGraph.cpp:1267-1326. Repeatedly takes the source-to-sink path with the most
+// still-uncovered nodes (ties towards the larger (count, predecessor) pair), trimmed of covered ends.
+std::vector<std::vector<size_t>> AlignmentGraph::greedyCover(size_t cid) const
+{
+	const std::vector<size_t>& cids = component_ids[cid];
+	size_t n = cids.size();
+	std::vector<std::vector<size_t>> cover;
+	std::vector<size_t> coveredTimes(n, 0), indeg(n), order(n);
+	std::vector<std::pair<size_t, size_t>> best(n);   // (uncovered nodes on best path ending here, predecessor)
+	size_t coveredCount = 0;
+	while (coveredCount < n) {
+		size_t qn = 0;
+		for (size_t i = 0; i < n; i++) {
+			best[i] = { 0, i };
+			indeg[i] = inNeighbors[cids[i]].size();
+			if (indeg[i] == 0) order[qn++] = i;
+		}
+		std::pair<size_t, size_t> top { 0, 0 };
+		for (size_t qi = 0; qi < qn; qi++) {
+			size_t s = order[qi];
+			if (coveredTimes[s] == 0) best[s].first++;
+			top = std::max(top, std::make_pair(best[s].first, s));
+			for (size_t tid : outNeighbors[cids[s]]) {
+				size_t t = component_idx[tid];
+				best[t] = std::max(best[t], std::make_pair(best[s].first, s));
+				if (--indeg[t] == 0) order[qn++] = t;
+			}
+		}
+		if (qn < n) throw std::runtime_error("The input sequence graph has a directed cycle. The current version of GraphChainer only supports DAGs.");
+		std::vector<size_t> walk;
+		for (size_t i = top.second;; i = best[i].second) {
+			walk.push_back(i);
+			if (best[i].second == i) break;
+		}
+		std::reverse(walk.begin(), walk.end());
+		size_t l = 0, r = walk.size() - 1;
+		while (coveredTimes[walk[l]]) l++;
+		while (coveredTimes[walk[r]]) r--;
+		std::vector<size_t> path;
+		for (size_t i = l; i <= r; i++) {
+			path.push_back(cids[walk[i]]);
+			if (coveredTimes[walk[i]]++ == 0) coveredCount++;
+		}
+		cover.push_back(std::move(path));
+	}
+	return cover;
+}
+
+// reference: src/AlignmentGraph.cpp:1157-1265. Reduces a path cover to minimum width: min-flow with
+// lower bound 1 on every node, solved by cancelling flow along augmenting paths in the residual graph
+// of the cover, then decomposing the remaining flow into paths. The resulting cover may differ from
+// the reference's in which minimum cover is picked; chaining results do not depend on that choice
+// (any valid cover yields the same reachability).
+std::vector<std::vector<size_t>> AlignmentGraph::shrink(size_t cid, const std::vector<std::vector<size_t>>& pc)
+{
+	typedef long long LL;
+	const std::vector<size_t>& cids = component_ids[cid];
+	LL n = (LL)cids.size();
+	LL width = (LL)pc.size(), inf = (LL)pc.size();
+	std::vector<LL> nodeFlow(n, 0), startFlow(n, 0), endFlow(n, 0);
+	std::map<std::pair<LL, LL>, LL> edgeFlow;
+	for (const auto& path : pc) {
+		for (size_t i = 0; i < path.size(); i++) {
+			nodeFlow[component_idx[path[i]]]++;
+			if (i > 0) edgeFlow[{ (LL)component_idx[path[i - 1]], (LL)component_idx[path[i]] }]++;
+		}
+		startFlow[component_idx[path[0]]]++;
+		endFlow[component_idx[path.back()]]++;
+	}
+	// residual network: vertex i_in = i, i_out = i + n, S = 2n, T = 2n+1; arcs stored in pairs (e, e^1)
+	LL V = 2 * n + 2, S = 2 * n, T = 2 * n + 1;
+	std::vector<LL> head(V, 0), to(2, 0), next(2, 0), cap(2, 0);
+	auto addArc = [&](LL a, LL b, LL c) { to.push_back(b); next.push_back(head[a]); cap.push_back(c); head[a] = (LL)to.size() - 1; };
+	// arc e: capacity to *decrease* flow on (a,b) down to its lower bound; arc e^1: capacity to increase it
+	auto addEdge = [&](LL a, LL b, LL upper, LL lower, LL flow) { addArc(a, b, flow - lower); addArc(b, a, upper - flow); };
+	for (LL i = 0; i < n; i++)
+		for (size_t jid : outNeighbors[cids[i]]) {
+			LL j = (LL)component_idx[jid];
+			auto it = edgeFlow.find({ i, j });
+			addEdge(i + n, j, inf, 0, it == edgeFlow.end() ? 0 : it->second);
+		}
+	for (LL i = 0; i < n; i++) {
+		addEdge(i, i + n, inf, 1, nodeFlow[i]);
+		addEdge(S, i, inf, 0, startFlow[i]);
+		addEdge(i + n, T, inf, 0, endFlow[i]);
+	}
+	std::vector<LL> queue(V), via(V);
+	std::vector<char> seen(V);
+	while (true) {
+		std::fill(seen.begin(), seen.end(), 0);
+		std::fill(via.begin(), via.end(), -1);
+		LL qn = 0;
+		queue[qn++] = S;
+		seen[S] = 1;
+		for (LL qi = 0; qi < qn && !seen[T]; qi++) {
+			LL v = queue[qi];
+			for (LL e = head[v]; e; e = next[e])
+				if (cap[e] > 0 && !seen[to[e]]) { seen[to[e]] = 1; via[to[e]] = e; queue[qn++] = to[e]; }
+		}
+		if (!seen[T]) break;
+		LL push = cap[via[T]];
+		for (LL v = T; via[v] != -1; v = to[via[v] ^ 1]) push = std::min(push, cap[via[v]]);
+		for (LL v = T; via[v] != -1; v = to[via[v] ^ 1]) { cap[via[v]] -= push; cap[via[v] ^ 1] += push; }
+		if (push == 0) throw std::runtime_error("path cover shrink: zero augmentation");
+		width -= push;
+	}
+	std::vector<std::vector<size_t>> out;
+	for (LL it = 0; it < width; it++) {
+		std::vector<size_t> path;
+		for (LL v = S; v != T;) {
+			if (v >= 0 && v < n) path.push_back(cids[v]);
+			LL nxt = -1;
+			for (LL e = head[v]; e; e = next[e]) {
+				if (e & 1) continue;
+				LL remaining = cap[e] + ((v < n && to[e] == v + n) ? 1 : 0);   // remaining flow = residual + lower bound
+				if (remaining > 0) { nxt = to[e]; cap[e]--; break; }
+			}
+			if (nxt == -1) throw std::runtime_error("path cover shrink: flow decomposition failed");
+			v = nxt;
+		}
+		out.push_back(std::move(path));
+	}
+	return out;
+}
+
+// reference: src/AlignmentGraph.cpp:1328-1401. For every node v and path k: backwards[v] holds
+// (u, k) where u is the LAST node of path k that strictly reaches v; paths[v] lists the paths through v;
+// topo_ids is a Kahn order of the component (queue seeded with sources in in-component index order).
+void AlignmentGraph::computeMPCIndex(size_t cid, const std::vector<std::vector<size_t>>& pc)
+{
+	typedef long long LL;
+	const std::vector<size_t>& cids = component_ids[cid];
+	size_t n = cids.size();
+	size_t K = pc.size();
+	backwards[cid].assign(n, {});
+	paths[cid].assign(n, {});
+	std::vector<LL> last2reach(n * K, -1);
+	for (size_t k = 0; k < K; k++)
+		for (size_t j = 0; j < pc[k].size(); j++) {
+			size_t x = component_idx[pc[k][j]];
+			last2reach[x * K + k] = (LL)j;
+			paths[cid][x].push_back(k);
+		}
+	std::vector<size_t> indeg(n), order;
+	order.reserve(n);
+	for (size_t i = 0; i < n; i++) {
+		indeg[i] = inNeighbors[cids[i]].size();
+		if (indeg[i] == 0) order.push_back(i);
+	}
+	topo_ids[cid].assign(n, 0);
+	topo[cid].clear();
+	for (size_t qi = 0; qi < order.size(); qi++) {
+		size_t s = order[qi];
+		for (size_t tid : outNeighbors[cids[s]]) {
+			size_t t = component_idx[tid];
+			if (--indeg[t] == 0) order.push_back(t);
+		}
+		topo_ids[cid][s] = topo[cid].size();
+		topo[cid].push_back(s);
+	}
+	for (size_t i : order)
+		for (size_t jid : outNeighbors[cids[i]]) {
+			size_t j = component_idx[jid];
+			for (size_t k = 0; k < K; k++) last2reach[j * K + k] = std::max(last2reach[j * K + k], last2reach[i * K + k]);
+		}
+	for (size_t i = 0; i < n; i++)
+		for (size_t k = 0; k < K; k++) {
+			LL idx = last2reach[i * K + k];
+			if (idx != -1 && component_idx[pc[k][idx]] == i) idx--;
+			if (idx != -1) backwards[cid][i].push_back({ component_idx[pc[k][idx]], k });
+		}
+}
+
+void AlignmentGraph::buildMPC(bool shrinkToMinimum)   // reference: src/AlignmentGraph.cpp:1465-1489
+{
+	buildComponentsMap();
+	size_t C = component_ids.size();
+	mpc.assign(C, {});
+	topo.assign(C, {});
+	topo_ids.assign(C, {});
+	paths.assign(C, {});
+	backwards.assign(C, {});
+	for (size_t cid = 0; cid < C; cid++) {
+		mpc[cid] = greedyCover(cid);
+		if (shrinkToMinimum) mpc[cid] = shrink(cid, mpc[cid]);
+		computeMPCIndex(cid, mpc[cid]);
+	}
+}
+
+// reference: src/AlignmentGraph.cpp:1866-1916. Unweighted BFS (fewest hops) from S until T is seen;
+// nodes farther than sepLimit bp from S are not expanded. A negative sepLimit compares as a huge
+// unsigned value (size_t > long long promotion, :1897), i.e. no limit - kept on purpose.
+std::vector<size_t> AlignmentGraph::getChainPath(size_t S, size_t T, long long sepLimit) const
+{
+	size_t n = NodeSize();
+	static thread_local std::vector<size_t> vis, dis, pre, queue;
+	static thread_local size_t flag = 1;
+	if (vis.size() < n) { vis.assign(n, 0); pre.assign(n, 0); dis.assign(n, 0); flag = 1; }
+	queue.clear();
+	queue.push_back(S);
+	vis[S] = ++flag;
+	dis[S] = 0;
+	for (size_t i = 0; vis[T] != flag && i < queue.size(); i++) {
+		size_t s = queue[i];
+		if (dis[s] > (size_t)sepLimit) continue;
+		for (size_t t : outNeighbors[s])
+			if (vis[t] != flag) { queue.push_back(t); vis[t] = flag; dis[t] = dis[s] + nodeLength[t]; pre[t] = s; }
+	}
+	std::vector<size_t> out;
+	if (vis[T] != flag) return out;
+	for (size_t i = T; i != S; i = pre[i]) out.push_back(i);
+	out.push_back(S);
+	std::reverse(out.begin(), out.end());
+	return out;
+}
+
+} // namespace gc

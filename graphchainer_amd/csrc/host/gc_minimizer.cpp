@@ -1,0 +1,158 @@
+// Minimizer index construction (start-up, CPU). reference: src/MinimizerSeeder.cpp:104-189 (window
+// minimizers), :299-492 (initMinimizers), :557-575 (initMaxCount).
+//
+// The reference stores the index behind a BBHash MPHF + sdsl packed vectors (both un-vendored, see
+// SURVEY.md §8c). Only three observable properties of that storage matter for seeds and they are kept:
+//   1. which (k-mer -> positions) lists exist: every window minimizer of every bigraph node, all hash
+//      ties included;
+//   2. the order inside a k-mer's position list: filled back to front in arrival order (:473-482),
+//      i.e. REVERSE arrival order, arrival = nodeLookup iteration x position order at -t 1;
+//   3. maxCount = counts[floor(0.999*n)] + 1 over all keys except "the last MPHF index" (:564).
+//      Which key that is depends on the MPHF and is parity-unpinned; defined here as the largest k-mer.
+#include "gc_graph.hpp"
+#include <algorithm>
+#include <deque>
+#include <tuple>
+
+namespace gc {
+
+uint64_t minimizerHash(uint64_t key)   // reference: src/MinimizerSeeder.cpp:45-54
+{
+	key = (~key) + (key << 21);
+	key = key ^ (key >> 24);
+	key = (key + (key << 3)) + (key << 8);
+	key = key ^ (key >> 14);
+	key = (key + (key << 2)) + (key << 4);
+	key = key ^ (key >> 28);
+	key = key + (key << 31);
+	return key;
+}
+
+static inline int baseCode(char c)
+{
+	switch (c) {
+		case 'a': case 'A': return 0;
+		case 'c': case 'C': return 1;
+		case 'g': case 'G': return 2;
+		case 't': case 'T': return 3;
+	}
+	return -1;
+}
+
+// Sliding-window minimizers with a monotone deque, every tie reported once.
+// reference: src/MinimizerSeeder.cpp:104-189 (iterateMinimizersReal). Emission rules kept:
+//  - a run of valid (ACGT) characters shorter than the window yields nothing;
+//  - the first full window reports all entries equal to the window minimum, in position order;
+//  - afterwards a new report happens when the minimum changes (all ties), or when the newly
+//    entered k-mer ties the current minimum (that one k-mer only).
+template <typename F>
+static void forEachWindowMinimizer(const std::string& str, size_t k, size_t w, F&& emit)
+{
+	if (str.size() < k) return;
+	const size_t kmersPerWindow = w - k + 1;
+	const uint64_t mask = ~(~(uint64_t)0 << (k * 2));
+	struct Entry { size_t pos; uint64_t kmer, hash; };
+	std::deque<Entry> window;
+	size_t offset = 0;
+	while (true) {
+	restart:
+		while (offset < str.size() && baseCode(str[offset]) < 0) offset++;
+		if (offset + w > str.size()) return;
+		uint64_t kmer = 0;
+		for (size_t i = 0; i < k; i++) {
+			int c = baseCode(str[offset + i]);
+			if (c < 0) { offset += i; goto restart; }
+			kmer = (kmer << 2) | (uint64_t)c;
+		}
+		window.clear();
+		window.push_back({ offset + k - 1, kmer, minimizerHash(kmer) });
+		for (size_t i = k; i < k + kmersPerWindow; i++) {
+			int c = baseCode(str[offset + i]);
+			if (c < 0) { offset += i; goto restart; }
+			kmer = ((kmer << 2) & mask) | (uint64_t)c;
+			uint64_t h = minimizerHash(kmer);
+			while (!window.empty() && window.back().hash > h) window.pop_back();
+			window.push_back({ offset + i, kmer, h });
+		}
+		for (auto it = window.begin(); it != window.end() && it->hash == window.front().hash; ++it) emit(it->pos, it->kmer);
+		for (size_t i = k + kmersPerWindow; offset + i < str.size(); i++) {
+			int c = baseCode(str[offset + i]);
+			if (c < 0) { offset += i; goto restart; }
+			kmer = ((kmer << 2) & mask) | (uint64_t)c;
+			uint64_t h = minimizerHash(kmer);
+			uint64_t oldMinimum = window.front().hash;
+			bool frontPopped = false;
+			while (!window.empty() && window.front().pos <= offset + i - kmersPerWindow) { frontPopped = true; window.pop_front(); }
+			if (frontPopped)
+				while (window.size() >= 2 && window[0].hash == window[1].hash) window.pop_front();
+			while (!window.empty() && window.back().hash > h) window.pop_back();
+			window.push_back({ offset + i, kmer, h });
+			if (window.front().hash != oldMinimum) {
+				for (auto it = window.begin(); it != window.end() && it->hash == window.front().hash; ++it) emit(it->pos, it->kmer);
+			} else if (window.back().hash == window.front().hash) {
+				emit(window.back().pos, window.back().kmer);
+			}
+		}
+		return;
+	}
+}
+
+MinimizerIndex MinimizerIndex::Build(const AlignmentGraph& g, size_t k, size_t w, double keepLeastFrequentFraction)
+{
+	MinimizerIndex idx;
+	idx.k = k;
+	idx.w = w;
+	// minimizers that end inside an overlap prefix are skipped (:323-340,369); zero for 0M graphs
+	std::unordered_map<int, size_t> nodeMinimizerStart;
+	for (size_t i = 0; i < g.NodeSize(); i++) {
+		size_t& start = nodeMinimizerStart[g.nodeIDs[i]];
+		for (size_t nb : g.inNeighbors[i])
+			if (g.nodeIDs[nb] != g.nodeIDs[i]) { start = std::max(start, g.nodeOffset[i]); break; }
+	}
+	std::vector<std::pair<uint64_t, uint64_t>> arrivals;   // (kmer, packed position) in arrival order
+	std::string sequence;
+	for (const auto& entry : g.nodeLookup) {      // arrival order at -t 1: nodeLookup iteration order (:354-357)
+		int nodeId = entry.first;
+		sequence.resize(g.originalNodeSize.at(nodeId));
+		size_t at = 0;
+		for (size_t split : entry.second)
+			for (size_t j = 0; j < g.nodeLength[split]; j++) sequence[at++] = g.NodeSequences(split, j);
+		size_t minStart = nodeMinimizerStart.at(nodeId);
+		forEachWindowMinimizer(sequence, k, w, [&](size_t pos, uint64_t kmer) {
+			if (pos < minStart) return;
+			size_t split = g.GetUnitigNode(nodeId, pos);
+			arrivals.emplace_back(kmer, ((uint64_t)split << 6) + (pos - g.nodeOffset[split]));
+		});
+	}
+	// group by k-mer; inside a group the reference's list is the arrivals reversed (:473-482)
+	std::vector<size_t> order(arrivals.size());
+	for (size_t i = 0; i < order.size(); i++) order[i] = i;
+	std::sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+		if (arrivals[a].first != arrivals[b].first) return arrivals[a].first < arrivals[b].first;
+		return a > b;
+	});
+	idx.positions.reserve(order.size());
+	for (size_t i = 0; i < order.size(); i++) {
+		uint64_t kmer = arrivals[order[i]].first;
+		if (idx.kmers.empty() || idx.kmers.back() != kmer) {
+			idx.kmers.push_back(kmer);
+			idx.startPos.push_back(i);
+		}
+		idx.positions.push_back(arrivals[order[i]].second);
+	}
+	idx.startPos.push_back(order.size());
+	// reference: src/MinimizerSeeder.cpp:557-575
+	idx.maxCount = 0;
+	if (idx.kmers.size() >= 2) {
+		std::vector<size_t> counts;
+		counts.reserve(idx.kmers.size() - 1);
+		for (size_t i = 0; i + 1 < idx.kmers.size(); i++) counts.push_back(idx.startPos[i + 1] - idx.startPos[i]);
+		std::sort(counts.begin(), counts.end());
+		size_t at = (size_t)(counts.size() * keepLeastFrequentFraction);
+		if (at == counts.size()) at = counts.size() - 1;
+		idx.maxCount = counts[at] + 1;
+	}
+	return idx;
+}
+
+} // namespace gc

@@ -1,0 +1,134 @@
+"""ctypes bindings for the parity oracle. See oracle/__init__.py for who may import this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def build():
+    """Compile liboracle.so (and _ref/libref_units.so when /root/reference exists)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+
+
+def load_oracle_lib():
+    path = os.path.join(_HERE, "liboracle.so")
+    if not os.path.exists(path):
+        build()
+    lib = C.CDLL(path)
+    lib.gco_create.restype = C.c_void_p
+    lib.gco_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int]
+    lib.gco_error.restype = C.c_char_p
+    lib.gco_error.argtypes = [C.c_void_p]
+    lib.gco_destroy.argtypes = [C.c_void_p]
+    lib.gco_align.restype = C.c_int
+    lib.gco_align.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
+    lib.gco_array.restype = C.POINTER(C.c_int64)
+    lib.gco_array.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64)]
+    lib.gco_graph_array.restype = C.c_int
+    lib.gco_graph_array.argtypes = [C.c_void_p, C.c_char_p]
+    u64, i32 = C.c_uint64, C.c_int32
+    lib.gco_merge.argtypes = [u64, u64, i32, u64, u64, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(i32)]
+    lib.gco_changed_min_score.restype = i32
+    lib.gco_changed_min_score.argtypes = [u64, u64, i32, u64, u64, i32]
+    lib.gco_get_value.restype = i32
+    lib.gco_get_value.argtypes = [u64, u64, i32, C.c_int]
+    lib.gco_score_before_start.restype = i32
+    lib.gco_score_before_start.argtypes = [u64, u64, i32]
+    lib.gco_next_slice.argtypes = [u64, u64, u64, i32, u64, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(i32), C.POINTER(u64), C.POINTER(u64)]
+    lib.gco_correctness_series.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gco_edit_distance.restype = u64
+    lib.gco_edit_distance.argtypes = [C.c_char_p, u64, C.c_char_p, u64]
+    lib.gco_minimizer_hash.restype = u64
+    lib.gco_minimizer_hash.argtypes = [u64]
+    return lib
+
+
+RESULT_ARRAYS = [
+    "read_seed_off", "seed_node", "seed_offset", "seed_seqpos", "seed_goodness",
+    "read_frag_off", "frag_l", "frag_sl", "frag_sr",
+    "read_anchor_off", "anchor_x", "anchor_y", "anchor_path_off", "anchor_path",
+    "anchor_first_node", "anchor_first_offset", "anchor_first_seqpos",
+    "anchor_last_node", "anchor_last_offset", "anchor_last_seqpos", "anchor_score",
+    "anchor_trace_off", "anchor_trace_node", "anchor_trace_offset", "anchor_trace_seqpos", "anchor_trace_switch",
+    "read_chain_off", "chain", "chain_score",
+    "read_long_off", "long_start", "long_end", "long_score",
+    "read_longall_off", "longall_start", "longall_end", "longall_score",
+    "long_trace_off", "long_trace_node", "long_trace_offset", "long_trace_seqpos", "long_trace_switch",
+    "read_path_off", "path_node", "path_offset",
+    "long_edit_distance", "chain_edit_distance", "chained_better", "failed_assertion", "seeds_extended",
+    "counters", "stage_microseconds",
+]
+
+
+class Oracle:
+    """CPU restatement of the per-read hot path (reference defaults: src/AlignerMain.cpp:186-209)."""
+
+    def __init__(self, gfa_path, k=15, w=20, density=10.0, discard_fraction=0.001, bandwidth=10,
+                 split_len=35, split_gap=35, colinear_gap=10000, long_pass=True, shrink_mpc=True):
+        self.lib = load_oracle_lib()
+        self.h = self.lib.gco_create(gfa_path.encode(), k, w, density, discard_fraction, bandwidth,
+                                     split_len, split_gap, colinear_gap, int(long_pass), int(shrink_mpc))
+        err = self.lib.gco_error(self.h).decode()
+        if err:
+            raise RuntimeError(err)
+
+    def close(self):
+        if self.h:
+            self.lib.gco_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _array(self, name):
+        n = C.c_uint64()
+        p = self.lib.gco_array(self.h, name.encode(), C.byref(n))
+        if not p or n.value == 0:
+            return np.zeros(0, dtype=np.int64)
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+    def graph_array(self, name):
+        if self.lib.gco_graph_array(self.h, name.encode()) != 0:
+            raise KeyError(name)
+        return self._array("graph_" + name)
+
+    def align(self, reads):
+        """reads: list of str/bytes. Returns dict of flat int64 arrays (CSR layout, see oracle_capi.cpp)."""
+        bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+        off = np.zeros(len(bs) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(b) for b in bs])
+        blob = b"".join(bs)
+        rc = self.lib.gco_align(self.h, blob, off.ctypes.data, len(bs))
+        if rc != 0:
+            raise RuntimeError(self.lib.gco_error(self.h).decode())
+        return {name: self._array(name) for name in RESULT_ARRAYS}
+
+
+class RefUnits:
+    """The reference's own WordSlice.h / AlignmentCorrectnessEstimation.cpp / edlib, compiled unmodified."""
+
+    def __init__(self):
+        path = os.path.join(_HERE, "_ref", "libref_units.so")
+        if not os.path.exists(path):
+            build()
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        lib = C.CDLL(path)
+        u64, i32 = C.c_uint64, C.c_int32
+        lib.ref_merge.argtypes = [u64, u64, i32, u64, u64, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(i32)]
+        lib.ref_changed_min_score.restype = i32
+        lib.ref_changed_min_score.argtypes = [u64, u64, i32, u64, u64, i32]
+        lib.ref_get_value.restype = i32
+        lib.ref_get_value.argtypes = [u64, u64, i32, C.c_int]
+        lib.ref_score_before_start.restype = i32
+        lib.ref_score_before_start.argtypes = [u64, u64, i32]
+        lib.ref_correctness_series.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ref_edit_distance.restype = C.c_longlong
+        lib.ref_edit_distance.argtypes = [C.c_char_p, u64, C.c_char_p, u64]
+        self.lib = lib

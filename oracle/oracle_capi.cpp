@@ -1,0 +1,443 @@
+// ORACLE (test infrastructure, not product code): per-read driver restating src/Aligner.cpp:601-922 and a
+// small C interface so tests/, smoke() and bench.py's cpu_baseline leg can run it through ctypes.
+// Nothing in graphchainer_amd/ may link or call this file.
+#include "pipeline.hpp"
+#include <chrono>
+#include <cstring>
+#include <map>
+#include <sstream>
+
+namespace oracle {
+
+struct ReadResult {
+	std::vector<SeedHit> seeds;                 // fragment-pass order (after the seqPos sort, src/Aligner.cpp:667)
+	std::vector<std::array<size_t, 3>> fragments;   // (l, sl, sr) of every fragment that had seeds
+	std::vector<gc::Anchor> anchors;
+	std::vector<std::array<MatrixPosition, 2>> apos;   // first/last trace cell of each anchor, unitig coords (:722-728)
+	std::vector<std::vector<TraceItem>> anchorTraces;
+	std::vector<int32_t> anchorScores;
+	std::vector<size_t> chain;
+	size_t chainScore = 0;
+	std::vector<AlignmentItem> longAlignments;  // after GreedyLength selection (:638-640)
+	std::vector<AlignmentItem> longAll;         // before selection
+	std::vector<MatrixPosition> longest;        // stitched path cells (node = split node), :754-822
+	size_t longEditDistance = SIZE_MAX, chainEditDistance = SIZE_MAX;
+	bool chainedBetter = false;
+	bool failedAssertion = false;
+	size_t seedsExtended = 0;
+};
+
+// reference: src/AlignmentSelection.cpp (GreedySelectAlignments with alignmentLengthCompare, :42-50,
+// and the incompatibility rule :12-33)
+static std::vector<AlignmentItem> selectGreedyLength(const std::vector<AlignmentItem>& all)
+{
+	std::vector<AlignmentItem> sorted = all;
+	auto better = [](const AlignmentItem& l, const AlignmentItem& r) {
+		if ((l.alignmentEnd - l.alignmentStart) > (r.alignmentEnd - r.alignmentStart)) return true;
+		if ((r.alignmentEnd - r.alignmentStart) > (l.alignmentEnd - l.alignmentStart)) return false;
+		return l.alignmentScore < r.alignmentScore;
+	};
+	std::sort(sorted.begin(), sorted.end(), better);
+	auto incompatible = [](const AlignmentItem& l, const AlignmentItem& r) {
+		float minOverlapLen = std::min(l.alignmentEnd - l.alignmentStart, r.alignmentEnd - r.alignmentStart) * 0.05f;
+		size_t ls = l.alignmentStart, le = l.alignmentEnd, rs = r.alignmentStart, re = r.alignmentEnd;
+		if (ls > rs) { std::swap(ls, rs); std::swap(le, re); }
+		int overlap = 0;
+		if (le > rs) overlap = (int)(le - rs);
+		return overlap > minOverlapLen;
+	};
+	std::vector<AlignmentItem> result;
+	for (const auto& aln : sorted) {
+		bool ok = true;
+		for (const auto& kept : result) if (incompatible(aln, kept)) { ok = false; break; }
+		if (ok) result.push_back(aln);
+	}
+	return result;
+}
+
+// reference: src/Aligner.cpp:376-408,425-428 (traceToPoses / traceToSequence)
+static std::string traceToSequence(const AlignmentGraph& g, const AlignmentItem& aln)
+{
+	std::string ret;
+	const auto& trace = aln.trace->trace;
+	size_t lastNode = 0, lastOffset = 0, lastLength = 0;
+	for (size_t j = 0; j < trace.size(); j++) {
+		size_t node = g.GetUnitigNode((int)trace[j].DPposition.node, trace[j].DPposition.nodeOffset);
+		size_t off = trace[j].DPposition.nodeOffset - g.NodeOffset(node);
+		if (j == 0) {
+			lastNode = node; lastOffset = off; lastLength = g.NodeLength(node);
+			ret.push_back(g.NodeSequences(lastNode, lastOffset));
+			lastOffset++;
+		} else {
+			if (node != lastNode) {
+				while (lastOffset < lastLength) { ret.push_back(g.NodeSequences(lastNode, lastOffset)); lastOffset++; }
+				lastNode = node; lastLength = g.NodeLength(node); lastOffset = 0;
+			}
+			while (lastOffset <= off) { ret.push_back(g.NodeSequences(lastNode, lastOffset)); lastOffset++; }
+		}
+	}
+	return ret;
+}
+
+// reference: src/Aligner.cpp:409-424
+static std::vector<MatrixPosition> pathToTrace(const AlignmentGraph& g, const std::vector<size_t>& path, size_t firstNodeOffset, size_t lastNodeOffset)
+{
+	std::vector<MatrixPosition> ret;
+	for (size_t node : path) {
+		size_t S = 0, L = g.NodeLength(node);
+		if (node == path[0]) S = firstNodeOffset;
+		else if (node == path.back()) L = lastNodeOffset + 1;
+		for (size_t o = S; o < L; o++) ret.push_back(MatrixPosition { node, o, 0 });
+	}
+	return ret;
+}
+
+class Oracle {
+public:
+	gc::AlignmentGraph graph;
+	gc::MinimizerIndex index;
+	Params params;
+	AlignerCounters counters;
+	double stageSeconds[5] = { 0, 0, 0, 0, 0 };   // seed, long pass, fragments, chaining, stitch+edit distance
+
+	ReadResult alignRead(const std::string& sequence, AlignerState& state)
+	{
+		typedef std::chrono::steady_clock clk;
+		auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+		ReadResult res;
+		// ---- A. whole-read pass (src/Aligner.cpp:630-654 -> align_fn :531-594)
+		if (params.longPass) {
+			auto t0 = clk::now();
+			std::vector<SeedHit> seeds = getSeeds(graph, index, sequence, params.seedDensity);
+			auto t1 = clk::now();
+			stageSeconds[0] += secs(t0, t1);
+			if (!seeds.empty()) {
+				try {
+					orderSeedsByChaining(graph, seeds);
+					GraphAligner aligner(graph, params, true);
+					AlignmentResult r = aligner.AlignOneWay(sequence, seeds, state, 0, seeds.size(), 0);
+					res.longAll = r.alignments;
+				} catch (const AssertionFailure&) {
+					state.clear();
+					res.failedAssertion = true;
+					res.longAll.clear();
+				}
+			}
+			if (!res.longAll.empty()) res.longAlignments = selectGreedyLength(res.longAll);
+			if (!res.longAlignments.empty()) res.longEditDistance = editDistanceNW(traceToSequence(graph, res.longAlignments[0]), sequence);
+			stageSeconds[1] += secs(t1, clk::now());
+		}
+		// ---- B. fragment pass (:658-730)
+		auto t2 = clk::now();
+		res.seeds = getSeeds(graph, index, sequence, params.seedDensity);
+		auto t3 = clk::now();
+		stageSeconds[0] += secs(t2, t3);
+		if (res.seeds.empty()) return res;
+		orderSeedsByChaining(graph, res.seeds);
+		std::sort(res.seeds.begin(), res.seeds.end(), [](const SeedHit& l, const SeedHit& r) { return l.seqPos < r.seqPos; });
+		size_t len = params.splitLen, sep = params.splitGap;
+		size_t sl = 0, sr = 0;
+		bool cont = false;   // (sic) never reset once a fragment failed, src/Aligner.cpp:695-703
+		GraphAligner fragmentAligner(graph, params, false);
+		for (size_t l = 0; l + len <= sequence.size(); l += sep) {
+			while (sr < res.seeds.size() && res.seeds[sr].seqPos + res.seeds[sr].matchLen <= l + len) sr++;
+			while (sl < sr && res.seeds[sl].seqPos < l) sl++;
+			if (sl >= sr) continue;
+			res.fragments.push_back({ l, sl, sr });
+			std::string seq = sequence.substr(l, len);
+			AlignmentResult alignments;
+			try {
+				alignments = fragmentAligner.AlignOneWay(seq, res.seeds, state, sl, sr, l);
+			} catch (const AssertionFailure&) {
+				state.clear();
+				res.failedAssertion = true;
+				cont = true;
+			}
+			if (cont) continue;
+			res.seedsExtended += alignments.seedsExtended;
+			for (auto& alignment : alignments.alignments) {
+				if (alignment.alignmentFailed()) continue;
+				const auto& trace = alignment.trace->trace;
+				if (trace.empty()) continue;
+				gc::Anchor anchor { {}, l, l + len - 1 };
+				for (const TraceItem& t : trace) {
+					size_t node = graph.GetUnitigNode((int)t.DPposition.node, t.DPposition.nodeOffset);
+					if (anchor.path.empty() || node != anchor.path.back()) anchor.path.push_back(node);
+				}
+				res.anchors.push_back(anchor);
+				std::array<MatrixPosition, 2> ends { trace[0].DPposition, trace.back().DPposition };
+				for (auto& p : ends) {
+					p.seqPos += l;
+					size_t bigraphOffset = p.nodeOffset;
+					p.node = graph.GetUnitigNode((int)p.node, bigraphOffset);
+					p.nodeOffset = bigraphOffset - graph.NodeOffset(p.node);
+				}
+				res.apos.push_back(ends);
+				res.anchorTraces.push_back(trace);
+				res.anchorScores.push_back(alignment.trace->score);
+			}
+		}
+		auto t4 = clk::now();
+		stageSeconds[2] += secs(t3, t4);
+		// ---- chaining (:735)
+		auto chained = colinearChaining(graph, res.anchors);
+		res.chain = chained.first;
+		res.chainScore = chained.second;
+		auto t5 = clk::now();
+		stageSeconds[3] += secs(t4, t5);
+		// ---- C. chain -> path (:754-822)
+		stitch(res, sequence);
+		stageSeconds[4] += secs(t5, clk::now());
+		return res;
+	}
+
+private:
+	void stitch(ReadResult& res, const std::string& sequence)
+	{
+		const auto& A = res.anchors;
+		const auto& Apos = res.apos;
+		std::vector<MatrixPosition> longest, tmp;
+		std::vector<size_t> pos_path;
+		std::unordered_set<size_t> nodes;
+		size_t firstNodeOffset = 0, lastNodeOffset = 0;
+		for (size_t ai : res.chain) {
+			const gc::Anchor& anchor = A[ai];
+			if (pos_path.empty()) {
+				pos_path = anchor.path;
+				firstNodeOffset = Apos[ai][0].nodeOffset;
+				lastNodeOffset = Apos[ai][1].nodeOffset;
+				for (size_t j : pos_path) nodes.insert(j);
+			} else {
+				bool gap = anchor.path[0] == pos_path.back() && params.colinearGap != -1 && (long long)Apos[ai][0].nodeOffset - (long long)lastNodeOffset > params.colinearGap + 1;
+				std::vector<size_t> path;
+				if (!nodes.count(anchor.path[0]) && pos_path.back() != Apos[ai][0].node) {
+					long long gapLimit = params.colinearGap;
+					if (gapLimit != -1) gapLimit -= (long long)Apos[ai][0].nodeOffset + (long long)(graph.NodeLength(pos_path.back()) - (long long)lastNodeOffset - 1);
+					path = graph.getChainPath(pos_path.back(), Apos[ai][0].node, gapLimit);
+					if (path.empty()) gap = true;
+				}
+				if (gap) {
+					tmp = pathToTrace(graph, pos_path, firstNodeOffset, lastNodeOffset);
+					if (longest.size() < tmp.size()) longest.swap(tmp);
+					nodes.clear();
+					pos_path.clear();
+					firstNodeOffset = Apos[ai][0].nodeOffset;
+				} else {
+					for (size_t j : path) if (!nodes.count(j)) { nodes.insert(j); pos_path.push_back(j); }
+				}
+				for (size_t j : anchor.path) if (!nodes.count(j)) { nodes.insert(j); pos_path.push_back(j); }
+				lastNodeOffset = Apos[ai][1].nodeOffset;
+			}
+		}
+		if (!pos_path.empty()) {
+			tmp = pathToTrace(graph, pos_path, firstNodeOffset, lastNodeOffset);
+			if (longest.size() < tmp.size()) longest.swap(tmp);
+		}
+		res.longest = longest;
+		std::string pathseq;
+		for (const auto& p : longest) pathseq.push_back(graph.NodeSequences(p.node, p.nodeOffset));
+		// :845 edlibAlign(pathseq, read, NW). edlib rejects empty inputs? it returns distance = other length; an
+		// empty `longest` produces no alignment item anyway (:890), so the distance is only set when non-empty.
+		if (!longest.empty()) {
+			res.chainEditDistance = editDistanceNW(pathseq, sequence);
+			res.chainedBetter = res.longAlignments.empty() || res.longEditDistance > res.chainEditDistance;   // :905
+		}
+	}
+};
+
+// ---- flat export -----------------------------------------------------------------------------------
+
+struct Export {
+	std::map<std::string, std::vector<int64_t>> arrays;
+	void clear() { arrays.clear(); }
+	std::vector<int64_t>& operator[](const std::string& k) { return arrays[k]; }
+};
+
+} // namespace oracle
+
+using namespace oracle;
+
+struct OracleHandle {
+	Oracle o;
+	Export ex;
+	std::string error;
+};
+
+extern "C" {
+
+void* gco_create(const char* gfaPath, int k, int w, double density, double discardFraction, int bandwidth, int splitLen, int splitGap, long long colinearGap, int longPass, int shrinkMpc)
+{
+	OracleHandle* h = new OracleHandle();
+	try {
+		gc::GfaGraph gfa = gc::GfaGraph::LoadFromFile(gfaPath);
+		h->o.graph = gc::AlignmentGraph::BuildFromGFA(gfa);
+		h->o.graph.buildMPC(shrinkMpc != 0);
+		h->o.params.k = k; h->o.params.w = w; h->o.params.seedDensity = density;
+		h->o.params.discardMostNumerousFraction = discardFraction;
+		h->o.params.bandwidth = bandwidth; h->o.params.splitLen = splitLen; h->o.params.splitGap = splitGap;
+		h->o.params.colinearGap = colinearGap; h->o.params.longPass = longPass != 0;
+		h->o.index = gc::MinimizerIndex::Build(h->o.graph, k, w, 1.0 - discardFraction);
+	} catch (const std::exception& e) {
+		h->error = e.what();
+	}
+	return h;
+}
+
+const char* gco_error(void* hv) { return ((OracleHandle*)hv)->error.c_str(); }
+void gco_destroy(void* hv) { delete (OracleHandle*)hv; }
+
+// Aligns n reads (concatenated in `bases`, read i = [off[i], off[i+1])) and stores flat result arrays.
+int gco_align(void* hv, const char* bases, const uint64_t* off, int n)
+{
+	OracleHandle* h = (OracleHandle*)hv;
+	Export& ex = h->ex;
+	ex.clear();
+	AlignerState state(h->o.graph);
+	h->o.counters = AlignerCounters();
+	for (double& s : h->o.stageSeconds) s = 0;
+	const char* names[] = { "read_seed_off", "read_frag_off", "read_anchor_off", "read_chain_off", "read_long_off", "read_longall_off", "read_path_off", "anchor_path_off", "anchor_trace_off", "long_trace_off" };
+	for (const char* nm : names) ex[nm].push_back(0);
+	for (int r = 0; r < n; r++) {
+		std::string seq(bases + off[r], bases + off[r + 1]);
+		ReadResult res;
+		try {
+			res = h->o.alignRead(seq, state);
+		} catch (const std::exception& e) {
+			h->error = std::string("read ") + std::to_string(r) + ": " + e.what();
+			return 1;
+		}
+		for (const SeedHit& s : res.seeds) {
+			ex["seed_node"].push_back((int64_t)s.alignmentGraphNodeId);
+			ex["seed_offset"].push_back((int64_t)s.alignmentGraphNodeOffset);
+			ex["seed_seqpos"].push_back((int64_t)s.seqPos);
+			ex["seed_goodness"].push_back((int64_t)s.seedGoodness);
+		}
+		ex["read_seed_off"].push_back((int64_t)ex["seed_node"].size());
+		for (auto& f : res.fragments) { ex["frag_l"].push_back(f[0]); ex["frag_sl"].push_back(f[1]); ex["frag_sr"].push_back(f[2]); }
+		ex["read_frag_off"].push_back((int64_t)ex["frag_l"].size());
+		for (size_t a = 0; a < res.anchors.size(); a++) {
+			ex["anchor_x"].push_back(res.anchors[a].x);
+			ex["anchor_y"].push_back(res.anchors[a].y);
+			for (size_t p : res.anchors[a].path) ex["anchor_path"].push_back((int64_t)p);
+			ex["anchor_path_off"].push_back((int64_t)ex["anchor_path"].size());
+			for (int e = 0; e < 2; e++) {
+				ex[e ? "anchor_last_node" : "anchor_first_node"].push_back((int64_t)res.apos[a][e].node);
+				ex[e ? "anchor_last_offset" : "anchor_first_offset"].push_back((int64_t)res.apos[a][e].nodeOffset);
+				ex[e ? "anchor_last_seqpos" : "anchor_first_seqpos"].push_back((int64_t)res.apos[a][e].seqPos);
+			}
+			ex["anchor_score"].push_back(res.anchorScores[a]);
+			for (const TraceItem& t : res.anchorTraces[a]) {
+				ex["anchor_trace_node"].push_back((int64_t)t.DPposition.node);
+				ex["anchor_trace_offset"].push_back((int64_t)t.DPposition.nodeOffset);
+				ex["anchor_trace_seqpos"].push_back((int64_t)t.DPposition.seqPos);
+				ex["anchor_trace_switch"].push_back(t.nodeSwitch ? 1 : 0);
+			}
+			ex["anchor_trace_off"].push_back((int64_t)ex["anchor_trace_node"].size());
+		}
+		ex["read_anchor_off"].push_back((int64_t)ex["anchor_x"].size());
+		for (size_t c : res.chain) ex["chain"].push_back((int64_t)c);
+		ex["read_chain_off"].push_back((int64_t)ex["chain"].size());
+		ex["chain_score"].push_back((int64_t)res.chainScore);
+		auto dumpAlns = [&](const std::vector<AlignmentItem>& alns, const std::string& prefix, bool traces) {
+			for (const AlignmentItem& aln : alns) {
+				ex[prefix + "_start"].push_back((int64_t)aln.alignmentStart);
+				ex[prefix + "_end"].push_back((int64_t)aln.alignmentEnd);
+				ex[prefix + "_score"].push_back((int64_t)aln.alignmentScore);
+				if (!traces) continue;
+				for (const TraceItem& t : aln.trace->trace) {
+					ex["long_trace_node"].push_back((int64_t)t.DPposition.node);
+					ex["long_trace_offset"].push_back((int64_t)t.DPposition.nodeOffset);
+					ex["long_trace_seqpos"].push_back((int64_t)t.DPposition.seqPos);
+					ex["long_trace_switch"].push_back(t.nodeSwitch ? 1 : 0);
+				}
+				ex["long_trace_off"].push_back((int64_t)ex["long_trace_node"].size());
+			}
+		};
+		dumpAlns(res.longAlignments, "long", false);
+		ex["read_long_off"].push_back((int64_t)ex["long_start"].size());
+		dumpAlns(res.longAll, "longall", true);
+		ex["read_longall_off"].push_back((int64_t)ex["longall_start"].size());
+		for (const auto& p : res.longest) { ex["path_node"].push_back((int64_t)p.node); ex["path_offset"].push_back((int64_t)p.nodeOffset); }
+		ex["read_path_off"].push_back((int64_t)ex["path_node"].size());
+		ex["long_edit_distance"].push_back(res.longEditDistance == SIZE_MAX ? -1 : (int64_t)res.longEditDistance);
+		ex["chain_edit_distance"].push_back(res.chainEditDistance == SIZE_MAX ? -1 : (int64_t)res.chainEditDistance);
+		ex["chained_better"].push_back(res.chainedBetter ? 1 : 0);
+		ex["failed_assertion"].push_back(res.failedAssertion ? 1 : 0);
+		ex["seeds_extended"].push_back((int64_t)res.seedsExtended);
+	}
+	const AlignerCounters& c = state.counters;
+	ex["counters"] = { (int64_t)c.dpTiles, (int64_t)c.recomputeTiles, (int64_t)c.columnSteps, (int64_t)c.traceItems, (int64_t)c.extensions };
+	for (double s : h->o.stageSeconds) ex["stage_microseconds"].push_back((int64_t)(s * 1e6));
+	return 0;
+}
+
+const int64_t* gco_array(void* hv, const char* name, uint64_t* count)
+{
+	OracleHandle* h = (OracleHandle*)hv;
+	auto it = h->ex.arrays.find(name);
+	if (it == h->ex.arrays.end()) { *count = 0; return nullptr; }
+	*count = it->second.size();
+	return it->second.data();
+}
+
+// ---- graph introspection for tests (arrays of the A0 data) ------------------------------------------
+int gco_graph_array(void* hv, const char* name)
+{
+	OracleHandle* h = (OracleHandle*)hv;
+	const gc::AlignmentGraph& g = h->o.graph;
+	std::vector<int64_t>& out = h->ex[std::string("graph_") + name];
+	out.clear();
+	std::string nm = name;
+	size_t n = g.NodeSize();
+	if (nm == "nodeLength") for (size_t i = 0; i < n; i++) out.push_back(g.nodeLength[i]);
+	else if (nm == "nodeOffset") for (size_t i = 0; i < n; i++) out.push_back(g.nodeOffset[i]);
+	else if (nm == "nodeIDs") for (size_t i = 0; i < n; i++) out.push_back(g.nodeIDs[i]);
+	else if (nm == "reverse") for (size_t i = 0; i < n; i++) out.push_back(g.reverse[i]);
+	else if (nm == "linearizable") for (size_t i = 0; i < n; i++) out.push_back(g.linearizable[i]);
+	else if (nm == "componentNumber") for (size_t i = 0; i < n; i++) out.push_back(g.componentNumber[i]);
+	else if (nm == "chainNumber") for (size_t i = 0; i < n; i++) out.push_back(g.chainNumber[i]);
+	else if (nm == "chainApproxPos") for (size_t i = 0; i < n; i++) out.push_back(g.chainApproxPos[i]);
+	else if (nm == "component_map") for (size_t i = 0; i < n; i++) out.push_back(g.component_map[i]);
+	else if (nm == "out_off") { out.push_back(0); for (size_t i = 0; i < n; i++) out.push_back(out.back() + (int64_t)g.outNeighbors[i].size()); }
+	else if (nm == "out_adj") for (size_t i = 0; i < n; i++) for (size_t v : g.outNeighbors[i]) out.push_back(v);
+	else if (nm == "in_off") { out.push_back(0); for (size_t i = 0; i < n; i++) out.push_back(out.back() + (int64_t)g.inNeighbors[i].size()); }
+	else if (nm == "in_adj") for (size_t i = 0; i < n; i++) for (size_t v : g.inNeighbors[i]) out.push_back(v);
+	else if (nm == "sequence") for (size_t i = 0; i < n; i++) for (size_t j = 0; j < g.nodeLength[i]; j++) out.push_back(g.NodeSequences(i, j));
+	else if (nm == "mpc_width") for (size_t c = 0; c < g.mpc.size(); c++) out.push_back(g.mpc[c].size());
+	else if (nm == "index_kmers") for (uint64_t v : h->o.index.kmers) out.push_back((int64_t)v);
+	else if (nm == "index_start") for (uint64_t v : h->o.index.startPos) out.push_back((int64_t)v);
+	else if (nm == "index_positions") for (uint64_t v : h->o.index.positions) out.push_back((int64_t)v);
+	else if (nm == "index_maxcount") out.push_back((int64_t)h->o.index.maxCount);
+	else return 1;
+	return 0;
+}
+
+// ---- unit-level entry points (checked against oracle/_ref in tests/test_oracle_units.py) -----------
+void gco_merge(uint64_t avp, uint64_t avn, int32_t as, uint64_t bvp, uint64_t bvn, int32_t bs, uint64_t* vp, uint64_t* vn, int32_t* s)
+{
+	WordSlice r = mergeTwoSlices(WordSlice(avp, avn, as), WordSlice(bvp, bvn, bs));
+	*vp = r.VP; *vn = r.VN; *s = r.scoreEnd;
+}
+int32_t gco_changed_min_score(uint64_t avp, uint64_t avn, int32_t as, uint64_t bvp, uint64_t bvn, int32_t bs) { return changedMinScore(WordSlice(avp, avn, as), WordSlice(bvp, bvn, bs)); }
+int32_t gco_get_value(uint64_t vp, uint64_t vn, int32_t s, int row) { return WordSlice(vp, vn, s).getValue(row); }
+int32_t gco_score_before_start(uint64_t vp, uint64_t vn, int32_t s) { return WordSlice(vp, vn, s).getScoreBeforeStart(); }
+void gco_next_slice(uint64_t eq, uint64_t vp, uint64_t vn, int32_t s, uint64_t hinP, uint64_t hinN, uint64_t* ovp, uint64_t* ovn, int32_t* os, uint64_t* houtP, uint64_t* houtN)
+{
+	StepResult r = getNextSlice(eq, WordSlice(vp, vn, s), hinP, hinN);
+	*ovp = r.ws.VP; *ovn = r.ws.VN; *os = r.ws.scoreEnd; *houtP = r.houtP; *houtN = r.houtN;
+}
+// runs the correctness HMM over a series of per-slice mismatch counts; out[i] = {correctLogOdds, falseLogOdds, flags}
+void gco_correctness_series(const int* mismatches, int n, double* correct, double* wrong, int* flags)
+{
+	CorrectnessState st;
+	for (int i = 0; i < n; i++) {
+		st = st.NextState(mismatches[i]);
+		correct[i] = st.correctLogOdds;
+		wrong[i] = st.falseLogOdds;
+		flags[i] = (st.CurrentlyCorrect() ? 1 : 0) | (st.CorrectFromCorrect() ? 2 : 0) | (st.FalseFromCorrect() ? 4 : 0);
+	}
+}
+uint64_t gco_edit_distance(const char* a, uint64_t na, const char* b, uint64_t nb) { return editDistanceNW(std::string(a, a + na), std::string(b, b + nb)); }
+uint64_t gco_minimizer_hash(uint64_t k) { return gc::minimizerHash(k); }
+
+} // extern "C"
