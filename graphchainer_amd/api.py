@@ -1,0 +1,274 @@
+"""Python host side of the MI355X GraphChainer hot path.
+
+Thin ctypes layer over the C ABI (include/graphchainer_amd.h, built into graphchainer_amd/libgraphchainer_amd.so).
+Class and method names mirror the reference objects they stand in for:
+
+  AlignmentGraph   <- AlignmentGraph + buildMPC          (src/AlignmentGraph.h, src/Aligner.cpp:1137-1156)
+  MinimizerSeeder  <- MinimizerSeeder                    (src/MinimizerSeeder.h:32)
+  Aligner.align_reads(reads) <- the per-read body of runComponentMappings (src/Aligner.cpp:601-922), batched
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible these raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgraphchainer_amd.so")
+
+EXPORTED_SYMBOLS = [
+    "gc_params_default", "gc_graph_create_from_gfa", "gc_graph_create", "gc_graph_destroy", "gc_graph_num_nodes",
+    "gc_graph_size_bp", "gc_graph_array", "gc_seeder_create", "gc_seeder_destroy", "gc_seeder_array",
+    "gc_stream_create", "gc_stream_destroy", "gc_reads_upload", "gc_reads_destroy", "gc_align_batch",
+    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device",
+]
+
+
+class GcParams(C.Structure):
+    _fields_ = [("bandwidth", C.c_int32), ("split_len", C.c_int32), ("split_gap", C.c_int32), ("colinear_gap", C.c_int64),
+                ("seed_density", C.c_double), ("min_cluster_size", C.c_int32), ("long_pass", C.c_int32), ("keep_traces", C.c_int32)]
+
+
+_P = C.POINTER
+
+
+class GcResult(C.Structure):
+    _fields_ = [
+        ("n_reads", C.c_uint64),
+        ("read_seed_off", _P(C.c_uint64)), ("seed_node", _P(C.c_uint32)), ("seed_offset", _P(C.c_uint32)), ("seed_seqpos", _P(C.c_uint32)), ("seed_goodness", _P(C.c_uint64)),
+        ("read_anchor_off", _P(C.c_uint64)), ("anchor_x", _P(C.c_uint32)), ("anchor_y", _P(C.c_uint32)),
+        ("anchor_path_off", _P(C.c_uint64)), ("anchor_path", _P(C.c_uint32)),
+        ("anchor_first_node", _P(C.c_uint32)), ("anchor_first_offset", _P(C.c_uint32)), ("anchor_first_seqpos", _P(C.c_uint32)),
+        ("anchor_last_node", _P(C.c_uint32)), ("anchor_last_offset", _P(C.c_uint32)), ("anchor_last_seqpos", _P(C.c_uint32)),
+        ("anchor_score", _P(C.c_int32)),
+        ("anchor_trace_off", _P(C.c_uint64)), ("anchor_trace_node", _P(C.c_int32)), ("anchor_trace_offset", _P(C.c_uint32)),
+        ("anchor_trace_seqpos", _P(C.c_uint32)), ("anchor_trace_switch", _P(C.c_uint8)),
+        ("read_chain_off", _P(C.c_uint64)), ("chain", _P(C.c_uint32)), ("chain_score", _P(C.c_uint64)),
+        ("read_longall_off", _P(C.c_uint64)), ("longall_start", _P(C.c_uint32)), ("longall_end", _P(C.c_uint32)), ("longall_score", _P(C.c_uint32)),
+        ("long_trace_off", _P(C.c_uint64)), ("long_trace_node", _P(C.c_int32)), ("long_trace_offset", _P(C.c_uint32)),
+        ("long_trace_seqpos", _P(C.c_uint32)), ("long_trace_switch", _P(C.c_uint8)),
+        ("failed_assertion", _P(C.c_uint8)), ("seeds_extended", _P(C.c_uint64)),
+        ("counters", C.c_uint64 * 8), ("kernel_us", C.c_double * 8), ("host_us", C.c_double * 4),
+    ]
+
+
+_lib = None
+
+
+def load_library():
+    """Loads the in-tree HIP library; fails loudly if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C graphchainer_amd/csrc` (or __graft_entry__.build())")
+    lib = C.CDLL(LIB_PATH)
+    lib.gc_last_error.restype = C.c_char_p
+    lib.gc_graph_create_from_gfa.argtypes = [C.c_char_p, _P(C.c_void_p)]
+    lib.gc_graph_destroy.argtypes = [C.c_void_p]
+    lib.gc_graph_num_nodes.restype = C.c_uint64
+    lib.gc_graph_num_nodes.argtypes = [C.c_void_p]
+    lib.gc_graph_size_bp.restype = C.c_uint64
+    lib.gc_graph_size_bp.argtypes = [C.c_void_p]
+    lib.gc_graph_array.argtypes = [C.c_void_p, C.c_char_p, _P(_P(C.c_int64)), _P(C.c_uint64)]
+    lib.gc_seeder_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double, _P(C.c_void_p)]
+    lib.gc_seeder_destroy.argtypes = [C.c_void_p]
+    lib.gc_seeder_array.argtypes = [C.c_void_p, C.c_char_p, _P(_P(C.c_int64)), _P(C.c_uint64)]
+    lib.gc_stream_create.argtypes = [_P(C.c_void_p)]
+    lib.gc_stream_destroy.argtypes = [C.c_void_p]
+    lib.gc_reads_upload.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, _P(C.c_void_p)]
+    lib.gc_reads_destroy.argtypes = [C.c_void_p]
+    lib.gc_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(GcParams), _P(_P(GcResult))]
+    lib.gc_result_free.argtypes = [_P(GcResult)]
+    lib.gc_params_default.argtypes = [_P(GcParams)]
+    lib.gc_free.argtypes = [C.c_void_p]
+    lib.gc_set_device.argtypes = [C.c_int]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(f"graphchainer_amd error {rc}: {load_library().gc_last_error().decode()}")
+
+
+def device_count():
+    return load_library().gc_device_count()
+
+
+def set_device(index):
+    _check(load_library().gc_set_device(index))
+
+
+def _fetch_array(fn, handle, name):
+    lib = load_library()
+    ptr = _P(C.c_int64)()
+    n = C.c_uint64()
+    _check(fn(handle, name.encode(), C.byref(ptr), C.byref(n)))
+    out = np.ctypeslib.as_array(ptr, shape=(n.value,)).copy() if n.value else np.zeros(0, dtype=np.int64)
+    lib.gc_free(ptr)
+    return out
+
+
+class AlignmentGraph:
+    """Split-node DAG + MPC index resident in HBM (reference: AlignmentGraph, src/AlignmentGraph.h)."""
+
+    def __init__(self, gfa_path):
+        self.lib = load_library()
+        self.handle = C.c_void_p()
+        _check(self.lib.gc_graph_create_from_gfa(os.fsencode(gfa_path), C.byref(self.handle)))
+
+    def NodeSize(self):
+        return self.lib.gc_graph_num_nodes(self.handle)
+
+    def SizeInBP(self):
+        return self.lib.gc_graph_size_bp(self.handle)
+
+    def array(self, name):
+        return _fetch_array(self.lib.gc_graph_array, self.handle, name)
+
+    def close(self):
+        if self.handle:
+            self.lib.gc_graph_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MinimizerSeeder:
+    """reference: MinimizerSeeder(graph, k, w, threads, 1 - discardMostNumerousFraction), src/Aligner.cpp:1162"""
+
+    def __init__(self, graph, minimizer_length=15, window_size=20, keep_least_frequent_fraction=1 - 0.001):
+        self.lib = load_library()
+        self.graph = graph
+        self.handle = C.c_void_p()
+        _check(self.lib.gc_seeder_create(graph.handle, minimizer_length, window_size, keep_least_frequent_fraction, C.byref(self.handle)))
+
+    def array(self, name):
+        return _fetch_array(self.lib.gc_seeder_array, self.handle, name)
+
+    def close(self):
+        if self.handle:
+            self.lib.gc_seeder_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ReadBatch:
+    """A batch of reads resident in HBM."""
+
+    def __init__(self, reads):
+        self.lib = load_library()
+        bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+        self.lengths = np.array([len(b) for b in bs], dtype=np.uint64)
+        self.offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
+        self.offsets[1:] = np.cumsum(self.lengths)
+        blob = b"".join(bs)
+        self.handle = C.c_void_p()
+        _check(self.lib.gc_reads_upload(blob, self.offsets.ctypes.data, len(bs), C.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            self.lib.gc_reads_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_RESULT_FIELDS = {
+    # name: (count expression)
+    "read_seed_off": "n+1", "seed_node": "seeds", "seed_offset": "seeds", "seed_seqpos": "seeds", "seed_goodness": "seeds",
+    "read_anchor_off": "n+1", "anchor_x": "anchors", "anchor_y": "anchors", "anchor_path_off": "anchors+1", "anchor_path": "paths",
+    "anchor_first_node": "anchors", "anchor_first_offset": "anchors", "anchor_first_seqpos": "anchors",
+    "anchor_last_node": "anchors", "anchor_last_offset": "anchors", "anchor_last_seqpos": "anchors", "anchor_score": "anchors",
+    "read_chain_off": "n+1", "chain": "chains", "chain_score": "n",
+    "failed_assertion": "n", "seeds_extended": "n",
+}
+
+
+class Aligner:
+    """Batched stand-in for the reference's per-read hot path (src/Aligner.cpp:601-922)."""
+
+    def __init__(self, graph, seeder, bandwidth=10, split_len=35, split_gap=35, colinear_gap=10000, seed_density=10.0, keep_traces=False):
+        self.lib = load_library()
+        self.graph = graph
+        self.seeder = seeder
+        self.params = GcParams()
+        self.lib.gc_params_default(C.byref(self.params))
+        self.params.bandwidth = bandwidth
+        self.params.split_len = split_len
+        self.params.split_gap = split_gap
+        self.params.colinear_gap = colinear_gap
+        self.params.seed_density = seed_density
+        self.params.keep_traces = int(keep_traces)
+        self.stream = C.c_void_p()
+        _check(self.lib.gc_stream_create(C.byref(self.stream)))
+
+    def align_batch(self, batch):
+        """Runs seeding, fragment extension, anchor construction and chaining for a ReadBatch; returns a dict of arrays."""
+        res = _P(GcResult)()
+        _check(self.lib.gc_align_batch(self.graph.handle, self.seeder.handle, self.stream, batch.handle, C.byref(self.params), C.byref(res)))
+        try:
+            r = res.contents
+            n = int(r.n_reads)
+
+            def arr(ptr, count):
+                return np.ctypeslib.as_array(ptr, shape=(count,)).copy() if count else np.zeros(0, dtype=np.int64)
+
+            out = {}
+            out["read_seed_off"] = arr(r.read_seed_off, n + 1)
+            seeds = int(out["read_seed_off"][-1])
+            out["read_anchor_off"] = arr(r.read_anchor_off, n + 1)
+            anchors = int(out["read_anchor_off"][-1])
+            out["anchor_path_off"] = arr(r.anchor_path_off, anchors + 1)
+            paths = int(out["anchor_path_off"][-1])
+            out["read_chain_off"] = arr(r.read_chain_off, n + 1)
+            chains = int(out["read_chain_off"][-1])
+            counts = {"n": n, "seeds": seeds, "anchors": anchors, "paths": paths, "chains": chains}
+            for name, expr in _RESULT_FIELDS.items():
+                if name in out:
+                    continue
+                out[name] = arr(getattr(r, name), counts[expr])
+            if self.params.keep_traces:
+                out["anchor_trace_off"] = arr(r.anchor_trace_off, anchors + 1)
+                cells = int(out["anchor_trace_off"][-1])
+                for name in ("anchor_trace_node", "anchor_trace_offset", "anchor_trace_seqpos", "anchor_trace_switch"):
+                    out[name] = arr(getattr(r, name), cells)
+            out["counters"] = np.array(list(r.counters), dtype=np.uint64)
+            out["kernel_us"] = np.array(list(r.kernel_us))
+            out["host_us"] = np.array(list(r.host_us))
+            return {k: (v.astype(np.int64) if v.dtype.kind in "ui" and k not in ("counters",) else v) for k, v in out.items()}
+        finally:
+            self.lib.gc_result_free(res)
+
+    def align_reads(self, reads):
+        batch = ReadBatch(reads)
+        try:
+            return self.align_batch(batch)
+        finally:
+            batch.close()
+
+    def close(self):
+        if self.stream:
+            self.lib.gc_stream_destroy(self.stream)
+            self.stream = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

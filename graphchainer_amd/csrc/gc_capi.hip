@@ -1,0 +1,833 @@
+// C ABI of the MI355X GraphChainer hot path (include/graphchainer_amd.h) and the batched host pipeline that
+// drives the HIP kernels. No CPU fallback: every entry point that needs the device fails with GC_ERR_DEVICE
+// when HIP is unavailable.
+#include "../../include/graphchainer_amd.h"
+#include "hip/gc_kernels.hpp"
+#include "host/gc_graph.hpp"
+#include "host/gc_glue.hpp"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace gcdev;
+
+static thread_local std::string g_lastError;
+static int fail(int code, const std::string& msg) { g_lastError = msg; return code; }
+
+struct DeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
+#define HIP_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw DeviceError(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr); } while (0)
+
+namespace {
+
+template <typename T>
+T* uploadVector(const std::vector<T>& v)
+{
+	T* d = nullptr;
+	size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+	HIP_CHECK(hipMalloc((void**)&d, bytes));
+	if (!v.empty()) HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+	return d;
+}
+
+struct DeviceBuffer {   // growable device allocation owned by a stream object
+	void* ptr = nullptr;
+	size_t bytes = 0;
+	template <typename T> T* reserve(size_t count)
+	{
+		size_t need = std::max<size_t>(count, 1) * sizeof(T);
+		if (need > bytes) {
+			if (ptr) HIP_CHECK(hipFree(ptr));
+			ptr = nullptr;
+			bytes = 0;
+			size_t want = need + need / 8 + 256;
+			HIP_CHECK(hipMalloc(&ptr, want));
+			bytes = want;
+		}
+		return (T*)ptr;
+	}
+	~DeviceBuffer() { if (ptr) (void)hipFree(ptr); }
+};
+
+double nowUs() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+template <typename F>
+void parallelFor(size_t n, F&& body)
+{
+	unsigned hw = std::thread::hardware_concurrency();
+	size_t nThreads = std::min<size_t>(std::max(1u, hw), std::max<size_t>(1, n / 4));
+	if (const char* env = getenv("GC_HOST_THREADS")) nThreads = (size_t)std::max(1, atoi(env));
+	if (nThreads <= 1) { for (size_t i = 0; i < n; i++) body(i); return; }
+	std::atomic<size_t> next { 0 };
+	std::vector<std::thread> pool;
+	for (size_t t = 0; t < nThreads; t++)
+		pool.emplace_back([&]() { for (size_t i; (i = next.fetch_add(1)) < n;) body(i); });
+	for (auto& th : pool) th.join();
+}
+
+template <typename T> T* mallocArray(size_t n) { return (T*)malloc(std::max<size_t>(n, 1) * sizeof(T)); }
+
+} // namespace
+
+// ----------------------------------------------------------------------------------------------------
+struct gc_graph {
+	gc::AlignmentGraph host;
+	DGraph dev {};
+	std::vector<void*> allocations;
+	CorrectnessTables* devTables = nullptr;
+	uint8_t* devIupac = nullptr;
+	uint32_t maxMpcWidth = 0;
+	~gc_graph() { for (void* p : allocations) (void)hipFree(p); }
+	template <typename T> const T* up(const std::vector<T>& v) { T* d = uploadVector(v); allocations.push_back(d); return d; }
+};
+
+struct gc_seeder {
+	gc::MinimizerIndex host;
+	SeedIndex dev {};
+	std::vector<void*> allocations;
+	~gc_seeder() { for (void* p : allocations) (void)hipFree(p); }
+};
+
+struct gc_reads {
+	std::vector<uint64_t> offsets;   // host copy [n+1]
+	uint64_t totalBases = 0;
+	std::vector<uint8_t> invalid;    // read has a character outside the IUPAC alphabet (the reference's Complement() asserts)
+	char* devBases = nullptr;        // [2*totalBases]: all reads forward, then every read reverse-complemented in place
+	uint64_t* devOffsets = nullptr;
+	~gc_reads() { if (devBases) (void)hipFree(devBases); if (devOffsets) (void)hipFree(devOffsets); }
+};
+
+struct gc_stream {
+	hipStream_t stream = nullptr;
+	hipEvent_t ev[12] {};
+	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, work, results, scratch, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
+	~gc_stream()
+	{
+		for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+		if (stream) (void)hipStreamDestroy(stream);
+	}
+};
+
+// ----------------------------------------------------------------------------------------------------
+// reference: src/AlignmentCorrectnessEstimation.cpp:6-70,72-78. libm is only used here, on the host; the
+// device does +, max and >= on these doubles.
+static void buildCorrectnessTables(CorrectnessTables& t)
+{
+	const double correctMean = 0.1875, correctStddev = 0.0955, wrongMean = 0.5, wrongStddev = 0.0291;
+	const int wordSize = 64;
+	t.f2c = log(0.00001);
+	t.f2f = log(1.0 - 0.00001);
+	t.c2f = log(0.0000000001);
+	t.c2c = log(1.0 - 0.0000000001);
+	auto fill = [&](double* out, double mean, double stddev) {
+		std::vector<double> v;
+		for (int i = 0; i <= wordSize / 2; i++) { double val = i; v.push_back(-(val - mean) * (val - mean) / (2 * stddev * stddev)); }
+		double sum = 0;
+		for (double x : v) sum += exp(x);
+		double add = log(1.0 / sum);
+		for (double& x : v) x += add;
+		for (int i = wordSize / 2; i < wordSize; i++) v.push_back(v.back());
+		for (int i = 0; i < 64; i++) out[i] = v[i];
+	};
+	fill(t.correctOdds, correctMean * wordSize, correctStddev * wordSize);
+	fill(t.wrongOdds, wrongMean * wordSize, wrongStddev * wordSize);
+	t.initCorrect = log(0.8);
+	t.initFalse = log(0.2);
+}
+
+// set of bases (A=1,C=2,G=4,T=8) a read character can stand for; 0 = matches nothing.
+// reference: characterMatch / ambiguousMatch, src/GraphAlignerCommon.h:190-297
+static void buildIupacTable(uint8_t* t)
+{
+	memset(t, 0, 256);
+	auto set = [&](const char* chars, uint8_t m) { for (const char* c = chars; *c; c++) t[(uint8_t)*c] = m; };
+	set("Aa", 1); set("Cc", 2); set("Gg", 4); set("TtUu", 8);
+	set("Rr", 1 | 4); set("Yy", 2 | 8); set("Kk", 4 | 8); set("Mm", 1 | 2); set("Ss", 2 | 4); set("Ww", 1 | 8);
+	set("Bb", 2 | 4 | 8); set("Dd", 1 | 4 | 8); set("Hh", 1 | 2 | 8); set("Vv", 1 | 2 | 4); set("Nn", 15);
+}
+
+static void uploadGraph(gc_graph* G)
+{
+	const gc::AlignmentGraph& h = G->host;
+	size_t n = h.NodeSize();
+	if (n >= 0xfffffff0ull) throw std::runtime_error("graph too large for 32-bit node ids");
+	std::vector<uint8_t> nodeLength(n);
+	std::vector<uint32_t> nodeOffset(n), componentNumber(n), componentMap(n), topoId(n);
+	std::vector<int32_t> nodeIDs(n);
+	int maxId = -1;
+	for (size_t i = 0; i < n; i++) {
+		nodeLength[i] = (uint8_t)h.nodeLength[i];
+		nodeOffset[i] = (uint32_t)h.nodeOffset[i];
+		nodeIDs[i] = h.nodeIDs[i];
+		componentNumber[i] = (uint32_t)h.componentNumber[i];
+		componentMap[i] = (uint32_t)h.component_map[i];
+		topoId[i] = (uint32_t)h.topo_ids[h.component_map[i]][h.component_idx[i]];
+		maxId = std::max(maxId, h.nodeIDs[i]);
+	}
+	std::vector<uint64_t> nodeSeq(2 * h.firstAmbiguous), ambSeq(4 * (n - h.firstAmbiguous));
+	for (size_t i = 0; i < h.firstAmbiguous; i++) { nodeSeq[2 * i] = h.nodeSequences[i][0]; nodeSeq[2 * i + 1] = h.nodeSequences[i][1]; }
+	for (size_t i = h.firstAmbiguous; i < n; i++) {
+		const gc::AmbiguousSeq& s = h.ambiguousNodeSequences[i - h.firstAmbiguous];
+		size_t at = 4 * (i - h.firstAmbiguous);
+		ambSeq[at] = s.A; ambSeq[at + 1] = s.C; ambSeq[at + 2] = s.G; ambSeq[at + 3] = s.T;
+	}
+	auto csr = [&](const std::vector<std::vector<size_t>>& adj, std::vector<uint32_t>& off, std::vector<uint32_t>& flat) {
+		off.assign(n + 1, 0);
+		for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + (uint32_t)adj[i].size();
+		flat.clear();
+		flat.reserve(off[n]);
+		for (size_t i = 0; i < n; i++) for (size_t v : adj[i]) flat.push_back((uint32_t)v);
+	};
+	std::vector<uint32_t> inOff, inAdj, outOff, outAdj;
+	csr(h.inNeighbors, inOff, inAdj);
+	csr(h.outNeighbors, outOff, outAdj);
+	size_t nB = (size_t)maxId + 1;
+	std::vector<uint32_t> origSize(nB, 0), lookupOff(nB + 1, 0), lookup;
+	for (size_t id = 0; id < nB; id++) {
+		auto it = h.nodeLookup.find((int)id);
+		lookupOff[id + 1] = lookupOff[id] + (it == h.nodeLookup.end() ? 0 : (uint32_t)it->second.size());
+		if (it != h.nodeLookup.end()) {
+			origSize[id] = (uint32_t)h.originalNodeSize.at((int)id);
+			for (size_t s : it->second) lookup.push_back((uint32_t)s);
+		}
+	}
+	// MPC index, flattened to global node ids
+	std::vector<uint32_t> pathsOff(n + 1, 0), pathsFlat, backOff(n + 1, 0), backNode, backPath, mpcWidth(h.mpc.size());
+	for (size_t c = 0; c < h.mpc.size(); c++) { mpcWidth[c] = (uint32_t)h.mpc[c].size(); G->maxMpcWidth = std::max(G->maxMpcWidth, mpcWidth[c]); }
+	for (size_t i = 0; i < n; i++) {
+		size_t c = h.component_map[i], x = h.component_idx[i];
+		for (size_t k : h.paths[c][x]) pathsFlat.push_back((uint32_t)k);
+		pathsOff[i + 1] = (uint32_t)pathsFlat.size();
+		for (const auto& b : h.backwards[c][x]) { backNode.push_back((uint32_t)h.component_ids[c][b.first]); backPath.push_back((uint32_t)b.second); }
+		backOff[i + 1] = (uint32_t)backNode.size();
+	}
+	DGraph& d = G->dev;
+	d.nNodes = (uint32_t)n;
+	d.firstAmbiguous = (uint32_t)h.firstAmbiguous;
+	d.nodeLength = G->up(nodeLength);
+	d.nodeOffset = G->up(nodeOffset);
+	d.nodeIDs = G->up(nodeIDs);
+	d.nodeSeq = G->up(nodeSeq);
+	d.ambSeq = G->up(ambSeq);
+	d.inOff = G->up(inOff); d.inAdj = G->up(inAdj);
+	d.outOff = G->up(outOff); d.outAdj = G->up(outAdj);
+	d.componentNumber = G->up(componentNumber);
+	d.origSize = G->up(origSize); d.lookupOff = G->up(lookupOff); d.lookup = G->up(lookup);
+	d.componentMap = G->up(componentMap);
+	d.topoId = G->up(topoId);
+	d.pathsOff = G->up(pathsOff); d.paths = G->up(pathsFlat);
+	d.backOff = G->up(backOff); d.backNode = G->up(backNode); d.backPath = G->up(backPath);
+	d.mpcWidth = G->up(mpcWidth);
+	CorrectnessTables t;
+	buildCorrectnessTables(t);
+	HIP_CHECK(hipMalloc((void**)&G->devTables, sizeof(t)));
+	G->allocations.push_back(G->devTables);
+	HIP_CHECK(hipMemcpy(G->devTables, &t, sizeof(t), hipMemcpyHostToDevice));
+	uint8_t iupac[256];
+	buildIupacTable(iupac);
+	HIP_CHECK(hipMalloc((void**)&G->devIupac, 256));
+	G->allocations.push_back(G->devIupac);
+	HIP_CHECK(hipMemcpy(G->devIupac, iupac, 256, hipMemcpyHostToDevice));
+}
+
+template <typename F>
+static int guarded(F&& f)
+{
+	try {
+		return f();
+	} catch (const DeviceError& e) {
+		return fail(GC_ERR_DEVICE, e.what());
+	} catch (const std::exception& e) {
+		return fail(GC_ERR_INTERNAL, e.what());
+	}
+}
+
+static void requireDevice()
+{
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0) throw DeviceError("no HIP device available: the product path has no CPU fallback");
+}
+
+namespace {
+
+struct ReadGlue {
+	std::vector<gc::SeedRec> seeds;
+	std::vector<gc::FragmentWindow> windows;
+	bool failed = false;
+	uint64_t slotBegin = 0, fragBegin = 0;
+};
+
+template <typename T> T* copyOut(const std::vector<T>& v)
+{
+	T* p = mallocArray<T>(v.size());
+	if (!v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
+	return p;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* gc_last_error(void) { return g_lastError.c_str(); }
+void gc_free(void* p) { free(p); }
+
+int gc_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+int gc_set_device(int device)
+{
+	return guarded([&]() { HIP_CHECK(hipSetDevice(device)); return (int)GC_OK; });
+}
+
+void gc_params_default(gc_params* p)
+{
+	if (!p) return;
+	p->bandwidth = 10;
+	p->split_len = 35;
+	p->split_gap = 35;
+	p->colinear_gap = 10000;
+	p->seed_density = 10;
+	p->min_cluster_size = 1;
+	p->long_pass = 0;
+	p->keep_traces = 0;
+}
+
+int gc_graph_create_from_gfa(const char* gfa_path, gc_graph** out)
+{
+	if (!gfa_path || !out) return fail(GC_ERR_INVALID, "null argument");
+	*out = nullptr;
+	gc_graph* G = new gc_graph();
+	try {
+		requireDevice();
+		gc::GfaGraph gfa = gc::GfaGraph::LoadFromFile(gfa_path);
+		G->host = gc::AlignmentGraph::BuildFromGFA(gfa);
+		G->host.buildMPC(true);
+		uploadGraph(G);
+	} catch (const DeviceError& e) {
+		delete G;
+		return fail(GC_ERR_DEVICE, e.what());
+	} catch (const std::exception& e) {
+		delete G;
+		return fail(GC_ERR_GRAPH, e.what());
+	}
+	*out = G;
+	return GC_OK;
+}
+
+int gc_graph_create(const gc_graph_desc* desc, gc_graph** out)
+{
+	if (!desc || !out) return fail(GC_ERR_INVALID, "null argument");
+	*out = nullptr;
+	gc_graph* G = new gc_graph();
+	try {
+		requireDevice();
+		gc::AlignmentGraph& h = G->host;
+		size_t n = desc->n_nodes;
+		h.firstAmbiguous = desc->first_ambiguous;
+		h.nodeLength.resize(n); h.nodeOffset.resize(n); h.nodeIDs.resize(n); h.reverse.resize(n); h.linearizable.assign(n, false);
+		h.inNeighbors.resize(n); h.outNeighbors.resize(n);
+		h.componentNumber.resize(n); h.chainNumber.resize(n); h.chainApproxPos.resize(n);
+		for (size_t i = 0; i < n; i++) {
+			h.nodeLength[i] = desc->node_length[i];
+			h.nodeOffset[i] = desc->node_offset[i];
+			h.nodeIDs[i] = desc->node_ids[i];
+			h.reverse[i] = desc->node_ids[i] & 1;   // reverse-complement strand nodes have odd bigraph ids (src/BigraphToDigraph.cpp:101-104)
+			h.bpSize += desc->node_length[i];
+			for (uint64_t e = desc->in_off[i]; e < desc->in_off[i + 1]; e++) h.inNeighbors[i].push_back(desc->in_adj[e]);
+			for (uint64_t e = desc->out_off[i]; e < desc->out_off[i + 1]; e++) h.outNeighbors[i].push_back(desc->out_adj[e]);
+			h.componentNumber[i] = desc->component_number[i];
+			h.chainNumber[i] = desc->chain_number[i];
+			h.chainApproxPos[i] = desc->chain_approx_pos[i];
+		}
+		h.nodeSequences.resize(h.firstAmbiguous);
+		for (size_t i = 0; i < h.firstAmbiguous; i++) h.nodeSequences[i] = { desc->node_seq[2 * i], desc->node_seq[2 * i + 1] };
+		h.ambiguousNodeSequences.resize(n - h.firstAmbiguous);
+		for (size_t i = 0; i < n - h.firstAmbiguous; i++) h.ambiguousNodeSequences[i] = { desc->ambiguous_seq[4 * i], desc->ambiguous_seq[4 * i + 1], desc->ambiguous_seq[4 * i + 2], desc->ambiguous_seq[4 * i + 3] };
+		// nodeLookup: split nodes of each bigraph node in offset order
+		std::vector<size_t> order(n);
+		for (size_t i = 0; i < n; i++) order[i] = i;
+		std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return h.nodeIDs[a] != h.nodeIDs[b] ? h.nodeIDs[a] < h.nodeIDs[b] : h.nodeOffset[a] < h.nodeOffset[b]; });
+		for (size_t i : order) { h.nodeLookup[h.nodeIDs[i]].push_back(i); h.originalNodeSize[h.nodeIDs[i]] += h.nodeLength[i]; }
+		h.finalized = true;
+		h.buildMPC(true);
+		uploadGraph(G);
+	} catch (const DeviceError& e) {
+		delete G;
+		return fail(GC_ERR_DEVICE, e.what());
+	} catch (const std::exception& e) {
+		delete G;
+		return fail(GC_ERR_GRAPH, e.what());
+	}
+	*out = G;
+	return GC_OK;
+}
+
+void gc_graph_destroy(gc_graph* g) { delete g; }
+uint64_t gc_graph_num_nodes(const gc_graph* g) { return g ? g->host.NodeSize() : 0; }
+uint64_t gc_graph_size_bp(const gc_graph* g) { return g ? g->host.SizeInBP() : 0; }
+
+int gc_graph_array(const gc_graph* G, const char* name, int64_t** out, uint64_t* count)
+{
+	if (!G || !name || !out || !count) return fail(GC_ERR_INVALID, "null argument");
+	const gc::AlignmentGraph& g = G->host;
+	std::vector<int64_t> v;
+	std::string nm = name;
+	size_t n = g.NodeSize();
+	if (nm == "nodeLength") for (size_t i = 0; i < n; i++) v.push_back(g.nodeLength[i]);
+	else if (nm == "nodeOffset") for (size_t i = 0; i < n; i++) v.push_back(g.nodeOffset[i]);
+	else if (nm == "nodeIDs") for (size_t i = 0; i < n; i++) v.push_back(g.nodeIDs[i]);
+	else if (nm == "reverse") for (size_t i = 0; i < n; i++) v.push_back(g.reverse[i]);
+	else if (nm == "componentNumber") for (size_t i = 0; i < n; i++) v.push_back(g.componentNumber[i]);
+	else if (nm == "chainNumber") for (size_t i = 0; i < n; i++) v.push_back(g.chainNumber[i]);
+	else if (nm == "chainApproxPos") for (size_t i = 0; i < n; i++) v.push_back(g.chainApproxPos[i]);
+	else if (nm == "component_map") for (size_t i = 0; i < n; i++) v.push_back(g.component_map[i]);
+	else if (nm == "out_off") { v.push_back(0); for (size_t i = 0; i < n; i++) v.push_back(v.back() + (int64_t)g.outNeighbors[i].size()); }
+	else if (nm == "out_adj") for (size_t i = 0; i < n; i++) for (size_t x : g.outNeighbors[i]) v.push_back(x);
+	else if (nm == "in_off") { v.push_back(0); for (size_t i = 0; i < n; i++) v.push_back(v.back() + (int64_t)g.inNeighbors[i].size()); }
+	else if (nm == "in_adj") for (size_t i = 0; i < n; i++) for (size_t x : g.inNeighbors[i]) v.push_back(x);
+	else if (nm == "mpc_width") for (size_t c = 0; c < g.mpc.size(); c++) v.push_back(g.mpc[c].size());
+	else return fail(GC_ERR_INVALID, "unknown graph array " + nm);
+	*out = mallocArray<int64_t>(v.size());
+	memcpy(*out, v.data(), v.size() * sizeof(int64_t));
+	*count = v.size();
+	return GC_OK;
+}
+
+// ---- seeder -------------------------------------------------------------------------------------------
+static inline uint32_t hostHashKmer(uint64_t kmer) { kmer *= 0x9E3779B97F4A7C15ull; return (uint32_t)(kmer >> 32); }
+
+int gc_seeder_create(const gc_graph* g, int32_t k, int32_t w, double keepFraction, gc_seeder** out)
+{
+	if (!g || !out) return fail(GC_ERR_INVALID, "null argument");
+	if (k < 1 || k > 15 || w < k) return fail(GC_ERR_INVALID, "supported minimizer length is 1..15 (32-bit key slots) with w >= k");
+	*out = nullptr;
+	gc_seeder* S = new gc_seeder();
+	int rc = guarded([&]() {
+		requireDevice();
+		S->host = gc::MinimizerIndex::Build(g->host, (size_t)k, (size_t)w, keepFraction);
+		size_t nKeys = S->host.kmers.size();
+		size_t tableSize = 16;
+		while (tableSize < 2 * nKeys) tableSize <<= 1;
+		std::vector<uint64_t> table(tableSize, ~0ull);
+		for (size_t i = 0; i < nKeys; i++) {
+			uint32_t hsh = hostHashKmer(S->host.kmers[i]) & (uint32_t)(tableSize - 1);
+			while ((uint32_t)(table[hsh] >> 32) != 0xffffffffu) hsh = (hsh + 1) & (uint32_t)(tableSize - 1);
+			table[hsh] = (S->host.kmers[i] << 32) | (uint64_t)i;
+		}
+		uint64_t* dTable = uploadVector(table);
+		S->allocations.push_back(dTable);
+		uint64_t* dStart = uploadVector(S->host.startPos);
+		S->allocations.push_back(dStart);
+		S->dev.table = dTable;
+		S->dev.tableMask = (uint32_t)(tableSize - 1);
+		S->dev.startPos = dStart;
+		S->dev.nKeys = (uint32_t)nKeys;
+		S->dev.maxCount = (uint32_t)std::min<size_t>(S->host.maxCount, 0xffffffffu);
+		S->dev.k = k;
+		S->dev.w = w;
+		return (int)GC_OK;
+	});
+	if (rc != GC_OK) { delete S; return rc; }
+	*out = S;
+	return GC_OK;
+}
+
+void gc_seeder_destroy(gc_seeder* s) { delete s; }
+
+int gc_seeder_array(const gc_seeder* s, const char* name, int64_t** out, uint64_t* count)
+{
+	if (!s || !name || !out || !count) return fail(GC_ERR_INVALID, "null argument");
+	std::string nm = name;
+	const std::vector<uint64_t>* src = nullptr;
+	std::vector<uint64_t> single;
+	if (nm == "kmers") src = &s->host.kmers;
+	else if (nm == "start") src = &s->host.startPos;
+	else if (nm == "positions") src = &s->host.positions;
+	else if (nm == "maxcount") { single.push_back(s->host.maxCount); src = &single; }
+	else return fail(GC_ERR_INVALID, "unknown seeder array " + nm);
+	*out = mallocArray<int64_t>(src->size());
+	for (size_t i = 0; i < src->size(); i++) (*out)[i] = (int64_t)(*src)[i];
+	*count = src->size();
+	return GC_OK;
+}
+
+// ---- streams / reads ------------------------------------------------------------------------------------
+int gc_stream_create(gc_stream** out)
+{
+	if (!out) return fail(GC_ERR_INVALID, "null argument");
+	*out = nullptr;
+	gc_stream* st = new gc_stream();
+	int rc = guarded([&]() {
+		requireDevice();
+		HIP_CHECK(hipStreamCreate(&st->stream));
+		for (auto& e : st->ev) HIP_CHECK(hipEventCreate(&e));
+		return (int)GC_OK;
+	});
+	if (rc != GC_OK) { delete st; return rc; }
+	*out = st;
+	return GC_OK;
+}
+void gc_stream_destroy(gc_stream* st) { delete st; }
+
+int gc_reads_upload(const char* bases, const uint64_t* offsets, uint64_t n, gc_reads** out)
+{
+	if (!offsets || !out || (!bases && n > 0 && offsets[n] > 0)) return fail(GC_ERR_INVALID, "null argument");
+	*out = nullptr;
+	gc_reads* R = new gc_reads();
+	int rc = guarded([&]() {
+		requireDevice();
+		R->offsets.assign(offsets, offsets + n + 1);
+		R->totalBases = offsets[n];
+		R->invalid.assign(n, 0);
+		std::vector<char> both(2 * R->totalBases);
+		if (R->totalBases) memcpy(both.data(), bases, R->totalBases);
+		uint8_t iupac[256];
+		buildIupacTable(iupac);
+		for (uint64_t r = 0; r < n; r++) {
+			uint64_t a = offsets[r], b = offsets[r + 1];
+			for (uint64_t i = a; i < b; i++) {
+				char c = bases[i];
+				char rc = 'N';
+				if (iupac[(uint8_t)c] == 0) R->invalid[r] = 1;
+				else rc = gc::Complement(c);
+				both[R->totalBases + a + (b - 1 - i)] = rc;
+			}
+		}
+		HIP_CHECK(hipMalloc((void**)&R->devBases, std::max<size_t>(both.size(), 1)));
+		if (!both.empty()) HIP_CHECK(hipMemcpy(R->devBases, both.data(), both.size(), hipMemcpyHostToDevice));
+		HIP_CHECK(hipMalloc((void**)&R->devOffsets, (n + 1) * sizeof(uint64_t)));
+		HIP_CHECK(hipMemcpy(R->devOffsets, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+		return (int)GC_OK;
+	});
+	if (rc != GC_OK) { delete R; return rc; }
+	*out = R;
+	return GC_OK;
+}
+void gc_reads_destroy(gc_reads* r) { delete r; }
+
+// ---- the batch pipeline -----------------------------------------------------------------------------------
+
+void gc_result_free(gc_result* r)
+{
+	if (!r) return;
+	void* ptrs[] = { r->read_seed_off, r->seed_node, r->seed_offset, r->seed_seqpos, r->seed_goodness, r->read_anchor_off, r->anchor_x, r->anchor_y, r->anchor_path_off,
+		r->anchor_path, r->anchor_first_node, r->anchor_first_offset, r->anchor_first_seqpos, r->anchor_last_node, r->anchor_last_offset, r->anchor_last_seqpos, r->anchor_score,
+		r->anchor_trace_off, r->anchor_trace_node, r->anchor_trace_offset, r->anchor_trace_seqpos, r->anchor_trace_switch, r->read_chain_off, r->chain, r->chain_score,
+		r->read_longall_off, r->longall_start, r->longall_end, r->longall_score, r->long_trace_off, r->long_trace_node, r->long_trace_offset, r->long_trace_seqpos, r->long_trace_switch,
+		r->failed_assertion, r->seeds_extended };
+	for (void* p : ptrs) free(p);
+	free(r);
+}
+
+int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const gc_reads* R, const gc_params* P, gc_result** out)
+{
+	if (!G || !S || !st || !R || !P || !out) return fail(GC_ERR_INVALID, "null argument");
+	if (P->split_len < 16 || P->split_len > 64 || P->split_gap < 1) return fail(GC_ERR_INVALID, "split_len must be in [16,64] (one 64-row slice per fragment extension) and split_gap >= 1");
+	if (P->long_pass) return fail(GC_ERR_INVALID, "long_pass: the whole-read GraphAligner pass is not part of this build yet (SURVEY.md §8 row K3-long)");
+	*out = nullptr;
+	gc_result* res = (gc_result*)calloc(1, sizeof(gc_result));
+	int rc = guarded([&]() {
+		const uint64_t n = R->offsets.size() - 1;
+		const gc::AlignmentGraph& hg = G->host;
+		hipStream_t stream = st->stream;
+		res->n_reads = n;
+		int evIdx = 0;
+		auto mark = [&]() { HIP_CHECK(hipEventRecord(st->ev[evIdx++], stream)); };
+		auto elapsedUs = [&](int a, int b) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, st->ev[a], st->ev[b])); return (double)ms * 1000.0; };
+
+		// ---------------- K1: seed lookup
+		uint32_t* dTmp = st->tmp.reserve<uint32_t>(R->totalBases);
+		uint2* dMatches = st->matches.reserve<uint2>(R->totalBases);
+		uint32_t* dReadMatchOff = st->readMatchOff.reserve<uint32_t>(n);
+		uint32_t* dReadMatchCount = st->readMatchCount.reserve<uint32_t>(n);
+		unsigned long long* dCursors = st->cursors.reserve<unsigned long long>(8);
+		unsigned long long* dCounters = st->counters.reserve<unsigned long long>(8);
+		HIP_CHECK(hipMemsetAsync(dCursors, 0, 8 * sizeof(unsigned long long), stream));
+		HIP_CHECK(hipMemsetAsync(dCounters, 0, 8 * sizeof(unsigned long long), stream));
+		mark();   // 0
+		launchSeedLookup(stream, S->dev, R->devBases, R->devOffsets, (uint32_t)n, (uint64_t*)dCursors, dReadMatchOff, dReadMatchCount, dMatches, R->totalBases, dTmp);
+		mark();   // 1
+		std::vector<uint32_t> readMatchOff(n), readMatchCount(n);
+		unsigned long long cursors[8];
+		HIP_CHECK(hipMemcpyAsync(readMatchOff.data(), dReadMatchOff, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipMemcpyAsync(readMatchCount.data(), dReadMatchCount, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipMemcpyAsync(cursors, dCursors, sizeof(cursors), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		std::vector<gc::KmerMatch> matches(cursors[0]);
+		if (cursors[0]) HIP_CHECK(hipMemcpy(matches.data(), dMatches, cursors[0] * sizeof(uint2), hipMemcpyDeviceToHost));
+		res->kernel_us[0] = elapsedUs(0, 1);
+
+		// ---------------- host glue: order-critical sorts and fragment windows (see host/gc_glue.hpp)
+		double tGlue = nowUs();
+		std::vector<ReadGlue> glue(n);
+		parallelFor(n, [&](size_t r) {
+			ReadGlue& gl = glue[r];
+			size_t len = R->offsets[r + 1] - R->offsets[r];
+			if (R->invalid[r]) { gl.failed = true; return; }
+			gc::expandSeeds(S->host, matches.data() + readMatchOff[r], readMatchCount[r], len, P->seed_density, gl.seeds);
+			if (gl.seeds.empty()) return;
+			try {
+				gc::orderSeedsByChaining(hg, gl.seeds);
+			} catch (const std::exception&) {
+				gl.failed = true;
+				gl.seeds.clear();
+				return;
+			}
+			gc::fragmentWindows(gl.seeds, len, (size_t)P->split_len, (size_t)P->split_gap, gl.windows);
+		});
+		uint64_t nSlots = 0, nFrags = 0, nSeedsTotal = 0;
+		for (uint64_t r = 0; r < n; r++) {
+			glue[r].slotBegin = nSlots;
+			glue[r].fragBegin = nFrags;
+			for (const auto& w : glue[r].windows) nSlots += w.sr - w.sl;
+			nFrags += glue[r].windows.size();
+			nSeedsTotal += glue[r].seeds.size();
+		}
+		if (2 * nSlots >= 0xffffffffull) throw std::runtime_error("batch too large: more than 2^31 fragment seeds; split the batch");
+		std::vector<Fragment> frags(nFrags);
+		std::vector<FragSeed> fragSeeds(nSlots);
+		std::vector<ExtItem> work(2 * nSlots);
+		std::vector<ReadChainJob> jobs(n);
+		uint64_t traceBudget = 0;
+		ChainCaps caps { 1, 1, 1 };
+		parallelFor(n, [&](size_t r) {
+			const ReadGlue& gl = glue[r];
+			size_t len = R->offsets[r + 1] - R->offsets[r];
+			uint64_t slot = gl.slotBegin;
+			for (size_t f = 0; f < gl.windows.size(); f++) {
+				const gc::FragmentWindow& w = gl.windows[f];
+				Fragment& fr = frags[gl.fragBegin + f];
+				fr.read = (uint32_t)r;
+				fr.l = w.l;
+				fr.seedBegin = (uint32_t)slot;
+				for (uint32_t k = w.sl; k < w.sr; k++, slot++) {
+					const gc::SeedRec& s = gl.seeds[k];
+					fragSeeds[slot] = FragSeed { s.node, s.offset, s.seqPos, 0 };
+					uint32_t p = s.seqPos - w.l;
+					// backward: revcomp(fragment[0..p)) from the reverse-strand twin of the seed base (src/GraphAligner.h:499-505)
+					int id = hg.nodeIDs[s.node];
+					size_t orig = hg.nodeOffset[s.node] + s.offset;
+					auto rev = hg.GetReversePosition(id, orig);
+					size_t twin = hg.GetUnitigNode(rev.first, rev.second);
+					ExtItem& b = work[2 * slot];
+					b.seqOff = R->totalBases + R->offsets[r] + (len - w.l - p);
+					b.seqLen = p;
+					b.node = (uint32_t)twin;
+					b.offset = (uint32_t)(rev.second - hg.nodeOffset[twin]);
+					b.pad = 0;
+					// forward: fragment(p+1 ..] from the seed base (:506-511)
+					ExtItem& fw = work[2 * slot + 1];
+					fw.seqOff = R->offsets[r] + w.l + p + 1;
+					fw.seqLen = (uint32_t)P->split_len - 1 - p;
+					fw.node = s.node;
+					fw.offset = s.offset;
+					fw.pad = 0;
+				}
+				fr.seedEnd = (uint32_t)slot;
+			}
+			ReadChainJob& job = jobs[r];
+			job.slotBegin = (uint32_t)gl.slotBegin;
+			job.nSlots = (uint32_t)(slot - gl.slotBegin);
+			job.chainBegin = (uint32_t)gl.slotBegin;
+			job.nKeys = len >= (size_t)P->split_len ? (uint32_t)((len - P->split_len) / P->split_gap + 1) : 1;
+			job.fragBegin = (uint32_t)gl.fragBegin;
+			job.nFrags = (uint32_t)gl.windows.size();
+		});
+		for (uint64_t r = 0; r < n; r++) {
+			caps.capAnchors = std::max(caps.capAnchors, jobs[r].nSlots);
+			caps.capTable = std::max<uint32_t>(caps.capTable, std::max(1u, G->maxMpcWidth) * jobs[r].nKeys);
+		}
+		caps.capEndpoints = caps.capAnchors * (2 + std::max(1u, G->maxMpcWidth));
+		for (const ExtItem& it : work) traceBudget += it.seqLen ? it.seqLen + 24 : 0;
+		res->host_us[0] = nowUs() - tGlue;
+
+		// ---------------- K3: fragment seed extension
+		ExtendConfig cfg;
+		cfg.bandwidth = P->bandwidth;
+		cfg.maxSlices = 3;
+		cfg.maxItems = 72;
+		cfg.maxPending = 48;
+		cfg.maxTrace = 192;
+		if (const char* env = getenv("GC_EXT_MAX_ITEMS")) cfg.maxItems = (uint32_t)std::max(8, atoi(env));
+		if (const char* env = getenv("GC_EXT_MAX_PENDING")) cfg.maxPending = (uint32_t)std::max(8, atoi(env));
+		if (const char* env = getenv("GC_EXT_MAX_TRACE")) cfg.maxTrace = (uint32_t)std::max(64, atoi(env));
+		uint32_t nWork = (uint32_t)work.size();
+		uint64_t slabBytes = extendSlabBytes(cfg);
+		uint32_t lanes = extendGridLanes(nWork);
+		ExtItem* dWork = st->work.reserve<ExtItem>(nWork);
+		ExtResult* dResults = st->results.reserve<ExtResult>(nWork);
+		uint8_t* dScratch = st->scratch.reserve<uint8_t>((uint64_t)lanes * slabBytes);
+		TraceCell* dTrace = st->tracePool.reserve<TraceCell>(traceBudget);
+		Fragment* dFrags = st->frags.reserve<Fragment>(nFrags);
+		FragSeed* dFragSeeds = st->fragSeeds.reserve<FragSeed>(nSlots);
+		AnchorRec* dAnchors = st->anchors.reserve<AnchorRec>(nSlots);
+		uint32_t* dFragStatus = st->fragStatus.reserve<uint32_t>(nFrags);
+		uint32_t* dFragExtended = st->fragExtended.reserve<uint32_t>(nFrags);
+		uint64_t pathCapacity = nSlots * 16 + 1024;
+		uint32_t* dPathPool = st->pathPool.reserve<uint32_t>(pathCapacity);
+		ReadChainJob* dJobs = st->jobs.reserve<ReadChainJob>(n);
+		uint32_t* dChainOut = st->chainOut.reserve<uint32_t>(nSlots);
+		uint32_t* dChainLen = st->chainLen.reserve<uint32_t>(n);
+		unsigned long long* dChainScore = st->chainScore.reserve<unsigned long long>(n);
+		uint32_t* dChainStatus = st->chainStatus.reserve<uint32_t>(n);
+		uint32_t chainBlocks = chainGridBlocks((uint32_t)n);
+		uint8_t* dChainScratch = st->chainScratch.reserve<uint8_t>((uint64_t)std::max(1u, chainBlocks) * chainScratchBytes(caps));
+		if (nWork) HIP_CHECK(hipMemcpyAsync(dWork, work.data(), nWork * sizeof(ExtItem), hipMemcpyHostToDevice, stream));
+		if (nFrags) HIP_CHECK(hipMemcpyAsync(dFrags, frags.data(), nFrags * sizeof(Fragment), hipMemcpyHostToDevice, stream));
+		if (nSlots) HIP_CHECK(hipMemcpyAsync(dFragSeeds, fragSeeds.data(), nSlots * sizeof(FragSeed), hipMemcpyHostToDevice, stream));
+		HIP_CHECK(hipMemcpyAsync(dJobs, jobs.data(), n * sizeof(ReadChainJob), hipMemcpyHostToDevice, stream));
+		mark();   // 2
+		launchExtend(stream, G->dev, G->devTables, G->devIupac, cfg, dWork, nWork, R->devBases, dResults, dScratch, slabBytes, dTrace, dCursors + 1, traceBudget, dCounters);
+		mark();   // 3
+		launchBuildAnchors(stream, G->dev, dFrags, (uint32_t)nFrags, dFragSeeds, dResults, dTrace, P->split_len, dAnchors, dFragStatus, dFragExtended, dPathPool, dCursors + 2, pathCapacity);
+		mark();   // 4
+		launchChain(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, P->split_len, P->split_gap, caps, dChainScratch, dChainOut, dChainLen, dChainScore, dChainStatus);
+		mark();   // 5
+
+		// ---------------- results back
+		std::vector<AnchorRec> anchors(nSlots);
+		std::vector<uint32_t> fragStatus(nFrags), fragExtended(nFrags), chainOut(nSlots), chainLen(n), chainStatus(n);
+		std::vector<unsigned long long> chainScore(n);
+		unsigned long long counters[8];
+		if (nSlots) HIP_CHECK(hipMemcpyAsync(anchors.data(), dAnchors, nSlots * sizeof(AnchorRec), hipMemcpyDeviceToHost, stream));
+		if (nFrags) HIP_CHECK(hipMemcpyAsync(fragStatus.data(), dFragStatus, nFrags * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		if (nFrags) HIP_CHECK(hipMemcpyAsync(fragExtended.data(), dFragExtended, nFrags * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		if (nSlots) HIP_CHECK(hipMemcpyAsync(chainOut.data(), dChainOut, nSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipMemcpyAsync(chainLen.data(), dChainLen, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipMemcpyAsync(chainStatus.data(), dChainStatus, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipMemcpyAsync(chainScore.data(), dChainScore, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipMemcpyAsync(cursors, dCursors, sizeof(cursors), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipMemcpyAsync(counters, dCounters, sizeof(counters), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		res->kernel_us[1] = elapsedUs(2, 3);
+		res->kernel_us[2] = elapsedUs(3, 4);
+		res->kernel_us[3] = elapsedUs(4, 5);
+		for (int i = 0; i < 8; i++) res->counters[i] = counters[i];
+		if (cursors[1] > traceBudget) throw std::runtime_error("trace pool overflow (raise GC_EXT_MAX_TRACE / report)");
+		if (cursors[2] > pathCapacity) throw std::runtime_error("anchor path pool overflow");
+		std::vector<uint32_t> pathPool(cursors[2]);
+		if (cursors[2]) HIP_CHECK(hipMemcpy(pathPool.data(), dPathPool, cursors[2] * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		std::vector<ExtResult> extResults;
+		std::vector<TraceCell> tracePool;
+		if (P->keep_traces) {
+			extResults.resize(nWork);
+			tracePool.resize(cursors[1]);
+			if (nWork) HIP_CHECK(hipMemcpy(extResults.data(), dResults, nWork * sizeof(ExtResult), hipMemcpyDeviceToHost));
+			if (cursors[1]) HIP_CHECK(hipMemcpy(tracePool.data(), dTrace, cursors[1] * sizeof(TraceCell), hipMemcpyDeviceToHost));
+		}
+
+		// ---------------- assemble the flat result
+		double tAsm = nowUs();
+		for (uint64_t f = 0; f < nFrags; f++) if (fragStatus[f] == 2) throw std::runtime_error("extension capacity overflow in a fragment (raise GC_EXT_MAX_ITEMS / GC_EXT_MAX_PENDING / GC_EXT_MAX_TRACE)");
+		for (uint64_t r = 0; r < n; r++) if (chainStatus[r] != 0) throw std::runtime_error("chaining kernel failure (status " + std::to_string(chainStatus[r]) + ")");
+		std::vector<uint64_t> readSeedOff(n + 1, 0), readAnchorOff(n + 1, 0), readChainOff(n + 1, 0), anchorPathOff(1, 0), anchorTraceOff(1, 0), chainScoreOut(n), seedsExtended(n, 0);
+		std::vector<uint32_t> seedNode, seedOffset, seedSeqpos, ax, ay, apath, afn, afo, afs, aln, alo, als, chainFlat, atOffset, atSeqpos;
+		std::vector<uint64_t> seedGoodness;
+		std::vector<int32_t> ascore, atNode;
+		std::vector<uint8_t> atSwitch, failedAssertion(n, 0);
+		seedNode.reserve(nSeedsTotal); seedOffset.reserve(nSeedsTotal); seedSeqpos.reserve(nSeedsTotal); seedGoodness.reserve(nSeedsTotal);
+		for (uint64_t r = 0; r < n; r++) {
+			const ReadGlue& gl = glue[r];
+			for (const gc::SeedRec& s : gl.seeds) { seedNode.push_back(s.node); seedOffset.push_back(s.offset); seedSeqpos.push_back(s.seqPos); seedGoodness.push_back(s.goodness); }
+			readSeedOff[r + 1] = seedNode.size();
+			failedAssertion[r] = gl.failed ? 1 : 0;
+			// the reference never resets `cont` after a failing fragment: later fragments add no anchors (src/Aligner.cpp:695-703)
+			uint64_t slot = gl.slotBegin;
+			bool cont = false;
+			for (size_t f = 0; f < gl.windows.size(); f++) {
+				uint64_t F = gl.fragBegin + f;
+				uint32_t nS = frags[F].seedEnd - frags[F].seedBegin;
+				if (fragStatus[F] == 1) { cont = true; failedAssertion[r] = 1; }
+				if (!cont) {
+					seedsExtended[r] += fragExtended[F];
+					for (uint32_t k = 0; k < nS; k++) {
+						const AnchorRec& a = anchors[slot + k];
+						if (!a.valid) continue;
+						ax.push_back(a.x); ay.push_back(a.y);
+						for (uint32_t i = 0; i < a.pathLen; i++) apath.push_back(pathPool[a.pathOff + i]);
+						anchorPathOff.push_back(apath.size());
+						afn.push_back(a.firstNode); afo.push_back(a.firstOffset); afs.push_back(a.firstSeqPos + frags[F].l);
+						aln.push_back(a.lastNode); alo.push_back(a.lastOffset); als.push_back(a.lastSeqPos + frags[F].l);
+						ascore.push_back(a.score);
+						if (P->keep_traces) {
+							// merged trace in the reference's output coordinates (bigraph node id, offset in original node),
+							// src/GraphAligner.h:527-565,590-608
+							const ExtResult& eb = extResults[2 * (slot + k)];
+							const ExtResult& ef = extResults[2 * (slot + k) + 1];
+							uint32_t p = fragSeeds[slot + k].seqPos - frags[F].l;
+							bool hasB = p > 0 && eb.status == EXT_OK, hasF = p < (uint32_t)P->split_len - 1 && ef.status == EXT_OK;
+							if (hasB) {
+								uint32_t use = hasF ? eb.traceLen - 1 : eb.traceLen;
+								for (uint32_t i = 0; i < use; i++) {
+									const TraceCell& c = tracePool[eb.traceOff + i];
+									uint32_t off = c.offsetAndSwitch & 255u;
+									auto rev = hg.GetReversePosition(hg.nodeIDs[c.node], hg.nodeOffset[c.node] + off);
+									atNode.push_back(rev.first);
+									atOffset.push_back((uint32_t)rev.second);
+									atSeqpos.push_back((uint32_t)((int32_t)p - 1 - c.seqPos));
+									bool sw = i + 1 < eb.traceLen ? ((tracePool[eb.traceOff + i + 1].offsetAndSwitch >> 8) & 1) : false;
+									atSwitch.push_back(sw ? 1 : 0);
+								}
+							}
+							if (hasF) {
+								for (uint32_t i = ef.traceLen; i-- > 0;) {
+									const TraceCell& c = tracePool[ef.traceOff + i];
+									uint32_t off = c.offsetAndSwitch & 255u;
+									atNode.push_back(hg.nodeIDs[c.node]);
+									atOffset.push_back((uint32_t)(hg.nodeOffset[c.node] + off));
+									atSeqpos.push_back((uint32_t)((int32_t)p + 1 + c.seqPos));
+									atSwitch.push_back((c.offsetAndSwitch >> 8) & 1);
+								}
+							}
+							anchorTraceOff.push_back(atNode.size());
+						}
+					}
+				}
+				slot += nS;
+			}
+			readAnchorOff[r + 1] = ax.size();
+			for (uint32_t i = 0; i < chainLen[r]; i++) chainFlat.push_back(chainOut[jobs[r].chainBegin + i]);
+			readChainOff[r + 1] = chainFlat.size();
+			chainScoreOut[r] = chainScore[r];
+		}
+		res->read_seed_off = copyOut(readSeedOff);
+		res->seed_node = copyOut(seedNode); res->seed_offset = copyOut(seedOffset); res->seed_seqpos = copyOut(seedSeqpos); res->seed_goodness = copyOut(seedGoodness);
+		res->read_anchor_off = copyOut(readAnchorOff);
+		res->anchor_x = copyOut(ax); res->anchor_y = copyOut(ay);
+		res->anchor_path_off = copyOut(anchorPathOff); res->anchor_path = copyOut(apath);
+		res->anchor_first_node = copyOut(afn); res->anchor_first_offset = copyOut(afo); res->anchor_first_seqpos = copyOut(afs);
+		res->anchor_last_node = copyOut(aln); res->anchor_last_offset = copyOut(alo); res->anchor_last_seqpos = copyOut(als);
+		res->anchor_score = copyOut(ascore);
+		if (P->keep_traces) {
+			res->anchor_trace_off = copyOut(anchorTraceOff);
+			res->anchor_trace_node = copyOut(atNode); res->anchor_trace_offset = copyOut(atOffset); res->anchor_trace_seqpos = copyOut(atSeqpos); res->anchor_trace_switch = copyOut(atSwitch);
+		}
+		res->read_chain_off = copyOut(readChainOff);
+		res->chain = copyOut(chainFlat);
+		res->chain_score = copyOut(chainScoreOut);
+		std::vector<uint64_t> zeroOff(n + 1, 0), one(1, 0);
+		res->read_longall_off = copyOut(zeroOff);
+		res->long_trace_off = copyOut(one);
+		res->failed_assertion = copyOut(failedAssertion);
+		res->seeds_extended = copyOut(seedsExtended);
+		res->host_us[1] = nowUs() - tAsm;
+		return (int)GC_OK;
+	});
+	if (rc != GC_OK) { gc_result_free(res); return rc; }
+	*out = res;
+	return GC_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,710 @@
+// Device-side data layout and the banded bit-vector seed-extension core for gfx950 (MI355X).
+//
+// Mapping: one LANE per seed extension. The inner loop of the reference is a chain of
+// up to 63 dependent 64-bit Myers column steps per (node, 64-row slice) tile
+// (reference: src/GraphAlignerBitvectorCommon.h:1118-1161): rows are already packed in the 64-bit word, columns
+// are serial, slices are serial and the band of the next slice depends on this slice's minimum, so the
+// parallel axis is the pool of independent extensions (fragments x seeds x 2 directions x reads).
+// Integer/bitwise only: no MFMA.
+//
+// All graph arrays live in HBM (uploaded once); per-lane scratch is a slab of HBM indexed by the lane's
+// global id so a persistent grid can stride over any number of work items.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gcdev {
+
+struct DGraph {
+	uint32_t nNodes;
+	uint32_t firstAmbiguous;
+	const uint8_t*  nodeLength;       // [n]
+	const uint32_t* nodeOffset;       // [n] offset inside the original (bigraph) node
+	const int32_t*  nodeIDs;          // [n] bigraph node id
+	const uint64_t* nodeSeq;          // [2*firstAmbiguous]  2 bits / bp
+	const uint64_t* ambSeq;           // [4*(n-firstAmbiguous)]  A,C,G,T one-hot words
+	const uint32_t* inOff;  const uint32_t* inAdj;     // CSR, reference neighbour order
+	const uint32_t* outOff; const uint32_t* outAdj;
+	const uint32_t* componentNumber;  // topological rank
+	// reverse-strand twin lookup (GetReversePosition + GetUnitigNode, src/AlignmentGraph.cpp:832-868)
+	const uint32_t* origSize;         // [nBigraph] length of the original node
+	const uint32_t* lookupOff;        // [nBigraph+1] into lookup
+	const uint32_t* lookup;           // split nodes of each bigraph node in offset order
+	// MPC index, flattened over components
+	const uint32_t* componentMap;     // [n] weakly connected component id
+	const uint32_t* topoId;           // [n] topological position inside its component
+	const uint32_t* pathsOff; const uint32_t* paths;            // [n+1], path ids through node
+	const uint32_t* backOff;  const uint32_t* backNode; const uint32_t* backPath;   // [n+1]; (last node of path k reaching v, k)
+	const uint32_t* mpcWidth;         // [nComponents]
+};
+
+struct WS {   // one DP column over 64 read rows (reference: src/WordSlice.h:150-166)
+	uint64_t VP, VN;
+	int32_t score;   // score of row 63
+};
+
+__device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
+__device__ __forceinline__ int32_t wsBefore(const WS& w) { return w.score - popc64(w.VP) + popc64(w.VN); }
+__device__ __forceinline__ int32_t wsValue(const WS& w, int row)   // reference: src/WordSlice.h:177-186
+{
+	uint64_t above = row < 63 ? (~0ull << (row + 1)) : 0ull;
+	return w.score + popc64(w.VN & above) - popc64(w.VP & above);
+}
+
+// Pointwise minimum of two columns (reference: src/WordSlice.h:491-530). Walks only rows whose deltas differ.
+__device__ inline WS wsMerge(const WS& a, const WS& b)
+{
+	int32_t d = wsBefore(a) - wsBefore(b);
+	uint64_t takeB = 0, fixP = 0, fixN = 0, fixMask = 0;
+	uint64_t diff = (a.VP ^ b.VP) | (a.VN ^ b.VN);
+	int pos = 0;
+	while (diff) {
+		int r = __ffsll((long long)diff) - 1;
+		diff &= diff - 1;
+		uint64_t bit = 1ull << r;
+		if (d > 0 && r > pos) takeB |= (bit - 1) & ~((1ull << pos) - 1);
+		int da = (int)((a.VP >> r) & 1) - (int)((a.VN >> r) & 1);
+		int db = (int)((b.VP >> r) & 1) - (int)((b.VN >> r) & 1);
+		int nd = d + da - db;
+		bool before = d > 0, after = nd > 0;
+		if (before != after) {
+			int delta = after ? (db - d) : (da + d);
+			fixMask |= bit;
+			if (delta > 0) fixP |= bit;
+			if (delta < 0) fixN |= bit;
+		}
+		if (after) takeB |= bit;
+		d = nd;
+		pos = r + 1;
+	}
+	if (d > 0 && pos < 64) takeB |= ~((1ull << pos) - 1);
+	WS res;
+	res.VP = (((a.VP & ~takeB) | (b.VP & takeB)) & ~fixMask) | fixP;
+	res.VN = (((a.VN & ~takeB) | (b.VN & takeB)) & ~fixMask) | fixN;
+	res.score = a.score < b.score ? a.score : b.score;
+	return res;
+}
+
+// min over rows -1..63 of a column: what changedMinScore (src/WordSlice.h:252) returns against an absent
+// old column ({0,0,INT_MAX}), the only case that occurs when every node is computed once per slice (DAG).
+__device__ inline int32_t wsColumnMin(const WS& w)
+{
+	int32_t before = wsBefore(w);
+	int32_t best = before;
+	uint64_t vn = w.VN;
+	while (vn) {
+		int r = __ffsll((long long)vn) - 1;
+		// skip to the end of this run of VN bits: the value is lowest there
+		uint64_t run = vn & ~(vn + (1ull << r));   // the contiguous run starting at r
+		int last = 63 - __clzll((long long)run);
+		uint64_t upto = last < 63 ? ((1ull << (last + 1)) - 1) : ~0ull;
+		int32_t v = before + popc64(w.VP & upto) - popc64(w.VN & upto);
+		best = v < best ? v : best;
+		vn &= ~upto;
+	}
+	return best;
+}
+
+// Myers column step with carries (reference: src/GraphAlignerBitvectorCommon.h:243-263).
+__device__ __forceinline__ WS myersStep(uint64_t Eq, WS s, uint64_t hinP, uint64_t hinN, uint64_t& houtP, uint64_t& houtN)
+{
+	uint64_t Xv = Eq | s.VN;
+	Eq |= hinN;
+	uint64_t Xh = (((Eq & s.VP) + s.VP) ^ s.VP) | Eq;
+	uint64_t Ph = s.VN | ~(Xh | s.VP);
+	uint64_t Mh = s.VP & Xh;
+	uint64_t sMh = (Mh << 1) | hinN;
+	uint64_t sPh = (Ph << 1) | hinP;
+	houtN = Mh >> 63;
+	houtP = Ph >> 63;
+	WS r;
+	r.VP = sMh | ~(Xv | sPh);
+	r.VN = sPh & Xv;
+	r.score = s.score - (int32_t)houtN + (int32_t)houtP;
+	return r;
+}
+
+__device__ __forceinline__ WS wsSource(int32_t previousScore) { return WS { ~0ull, 0ull, previousScore + 64 }; }   // ...Common.h:806-810
+
+// ---- per-extension state kept in the lane's HBM slab ------------------------------------------------
+
+struct NodeItem {   // reference: src/NodeSlice.h:15-47 (80 B there, 64 B here)
+	uint64_t sVP, sVN, eVP, eVN, HP, HN;
+	int32_t sScore, eScore, minScore;
+	uint32_t node;
+};
+__device__ __forceinline__ WS itemStart(const NodeItem& it) { return WS { it.sVP, it.sVN, it.sScore }; }
+__device__ __forceinline__ WS itemEnd(const NodeItem& it) { return WS { it.eVP, it.eVN, it.eScore }; }
+
+struct SliceInfo {  // reference: DPSlice, src/GraphAlignerBitvectorCommon.h:138-214
+	int32_t minScore;
+	uint32_t minNode, minOffset;
+	uint32_t first, count;      // this slice's NodeItems are items[first .. first+count)
+	int32_t bandwidth;
+	int32_t j;                  // first read row of the slice (-64 for the initial slice)
+	uint32_t flags;             // bit0 currentlyCorrect, bit1 correctFromCorrect, bit2 falseFromCorrect
+	double correctLogOdds, falseLogOdds;
+};
+
+struct Pending {    // a node scheduled in the current slice with its incoming columns already folded
+	uint64_t VP, VN;
+	int32_t score;
+	uint32_t node;
+	uint32_t comp;
+	uint32_t hasIncoming;
+};
+
+struct TraceCell {  // one cell of a backtrace, split-node coordinates
+	uint32_t node;
+	int32_t seqPos;             // -1 for the row above the first slice
+	uint32_t offsetAndSwitch;   // offset in split node | nodeSwitch << 8
+};
+
+struct CorrectnessTables {   // reference: src/AlignmentCorrectnessEstimation.cpp:15-70, built on the host with libm
+	double correctOdds[64], wrongOdds[64];
+	double f2c, f2f, c2f, c2c;
+	double initCorrect, initFalse;
+};
+
+struct ExtendConfig {
+	int32_t bandwidth;
+	uint32_t maxItems;      // NodeItem capacity of a lane's slab
+	uint32_t maxSlices;     // SliceInfo capacity (>= numSlices+1)
+	uint32_t maxPending;
+	uint32_t maxTrace;
+};
+
+// status codes of one extension
+enum : uint32_t { EXT_OK = 0, EXT_FAILED = 1, EXT_ASSERT = 2, EXT_OVERFLOW = 3 };
+
+struct LaneScratch {
+	SliceInfo* slices;
+	NodeItem* items;
+	Pending* pending;
+	WS* columns;        // 64 entries: one node's recomputed columns for the backtrace
+	TraceCell* trace;
+};
+
+struct ExtCounters { unsigned long long dpTiles, recomputeTiles, columnSteps, traceItems, extensions; };
+
+// 4 match masks (A,C,G,T) of read rows j..j+63. reference: ...Common.h:280-319. iupac[c] = set of bases c matches.
+__device__ inline void eqVector(const char* seq, int len, int j, const uint8_t* iupac, uint64_t eq[4])
+{
+	eq[0] = eq[1] = eq[2] = eq[3] = 0;
+	int n = len - j;
+	if (n > 64) n = 64;
+	for (int i = 0; i < n; i++) {
+		uint8_t m = iupac[(uint8_t)seq[j + i]];
+		uint64_t bit = 1ull << i;
+		if (m & 1) eq[0] |= bit;
+		if (m & 2) eq[1] |= bit;
+		if (m & 4) eq[2] |= bit;
+		if (m & 8) eq[3] |= bit;
+	}
+}
+
+struct NodeSeq { uint64_t w0, w1, w2, w3; bool ambiguous; };
+__device__ __forceinline__ NodeSeq loadNodeSeq(const DGraph& g, uint32_t node)
+{
+	NodeSeq s;
+	if (node < g.firstAmbiguous) {
+		s.w0 = g.nodeSeq[2 * (size_t)node];
+		s.w1 = g.nodeSeq[2 * (size_t)node + 1];
+		s.w2 = s.w3 = 0;
+		s.ambiguous = false;
+	} else {
+		const uint64_t* p = g.ambSeq + 4 * (size_t)(node - g.firstAmbiguous);
+		s.w0 = p[0]; s.w1 = p[1]; s.w2 = p[2]; s.w3 = p[3];
+		s.ambiguous = true;
+	}
+	return s;
+}
+__device__ __forceinline__ uint64_t eqOfColumn(const uint64_t eq[4], const NodeSeq& s, int pos)
+{
+	if (!s.ambiguous) {
+		uint64_t w = pos < 32 ? s.w0 : s.w1;
+		int code = (int)((w >> ((pos & 31) * 2)) & 3);
+		// select without indexing a private array by a runtime value (keeps eq[] in registers)
+		uint64_t r = eq[0];
+		r = code == 1 ? eq[1] : r;
+		r = code == 2 ? eq[2] : r;
+		r = code == 3 ? eq[3] : r;
+		return r;
+	}
+	uint64_t r = 0;
+	if ((s.w0 >> pos) & 1) r |= eq[0];
+	if ((s.w1 >> pos) & 1) r |= eq[1];
+	if ((s.w2 >> pos) & 1) r |= eq[2];
+	if ((s.w3 >> pos) & 1) r |= eq[3];
+	return r;
+}
+
+__device__ inline int findItem(const NodeItem* items, const SliceInfo& sl, uint32_t node)
+{
+	for (uint32_t i = 0; i < sl.count; i++)
+		if (items[sl.first + i].node == node) return (int)(sl.first + i);
+	return -1;
+}
+
+// One (node, slice) tile: first column = `ws` (already merged over all incoming edges), then up to 63 Myers
+// steps. reference: src/GraphAlignerBitvectorCommon.h:1052-1167 for a node that is new in this slice.
+// If `columns` != nullptr every column is stored (backtrace recompute). If flatRows > 0 the minimum over
+// columns of the score at row flatRows-1 is tracked (fused flattenLastSliceEnd, ...Common.h:1210-1218).
+struct TileResult { int32_t minScore; uint32_t minOffset; int32_t flatMin; uint32_t flatOffset; };
+__device__ inline TileResult computeTile(const DGraph& g, uint32_t node, WS ws, bool prevExists, int32_t prevStartScore, uint64_t prevHP, uint64_t prevHN,
+	const uint64_t eq[4], NodeItem& out, WS* columns, int flatRows, uint32_t& status)
+{
+	int nodeLength = g.nodeLength[node];
+	NodeSeq seq = loadNodeSeq(g, node);
+	TileResult r;
+	r.minScore = ws.score;   // (sic) taken before the merge with the row above, ...Common.h:968 vs :1052-1058
+	r.minOffset = 0;
+	if (prevExists && wsBefore(ws) > prevStartScore) ws = wsMerge(ws, wsSource(prevStartScore));
+	int forceUntil = 0;
+	if (prevExists) {
+		int32_t scoreBefore = wsBefore(ws);
+		int32_t scoreComparison = prevStartScore;
+		if (scoreBefore > scoreComparison) status = EXT_ASSERT;
+		if (scoreBefore < scoreComparison) {
+			for (int fix = 1; fix < 64; fix++) {
+				int32_t next = scoreComparison + (int32_t)((prevHP >> fix) & 1) - (int32_t)((prevHN >> fix) & 1);
+				uint64_t mask = 1ull << fix;
+				if (scoreBefore > next) status = EXT_ASSERT;
+				if (scoreBefore < next) { prevHP |= mask; prevHN &= ~mask; forceUntil = fix; }
+				if (scoreBefore == next) { prevHP &= ~mask; prevHN &= ~mask; }
+				scoreBefore++;
+				scoreComparison = next;
+				if (scoreBefore >= scoreComparison) break;
+			}
+		}
+	} else {
+		forceUntil = nodeLength;
+	}
+	out.node = node;
+	out.sVP = ws.VP; out.sVN = ws.VN; out.sScore = ws.score;
+	uint64_t flatMask = flatRows > 0 ? ~(~0ull << flatRows) : 0;
+	r.flatMin = INT32_MAX;
+	r.flatOffset = 0;
+	if (flatRows > 0) r.flatMin = ws.score - popc64(ws.VP & ~flatMask) + popc64(ws.VN & ~flatMask);
+	if (columns) columns[0] = ws;
+	uint64_t forceEq = prevExists ? ~0ull : ~1ull;
+	uint64_t HP = 0, HN = 0;
+	for (int pos = 1; pos < nodeLength; pos++) {
+		uint64_t Eq = eqOfColumn(eq, seq, pos) & forceEq;
+		uint64_t hp, hn;
+		ws = myersStep(Eq, ws, (prevHP >> pos) & 1, (prevHN >> pos) & 1, hp, hn);
+		if (forceUntil >= pos) { ws.VP &= ~1ull; ws.VN |= 1ull; }
+		if (ws.score < r.minScore) { r.minScore = ws.score; r.minOffset = (uint32_t)pos; }
+		if (flatRows > 0) {
+			int32_t f = ws.score - popc64(ws.VP & ~flatMask) + popc64(ws.VN & ~flatMask);
+			if (f < r.flatMin) { r.flatMin = f; r.flatOffset = (uint32_t)pos; }
+		}
+		if (columns) columns[pos] = ws;
+		HP |= hp << pos;
+		HN |= hn << pos;
+	}
+	out.HP = HP; out.HN = HN;
+	out.eVP = ws.VP; out.eVN = ws.VN; out.eScore = ws.score;
+	return r;
+}
+
+// Folds one incoming edge into a pending node (creating it if needed).
+// reference: the per-edge part of calculateNodeInner, ...Common.h:903-964; edges coming from the previous slice
+// ("skipFirst") are merged as they are, edges from an in-neighbour are first stepped into the node's column 0.
+__device__ inline void pushEdge(const DGraph& g, Pending* pending, uint32_t& nPending, const ExtendConfig& cfg, uint32_t target, WS incoming, bool skipFirst,
+	const NodeItem* items, const SliceInfo& prevSlice, const uint64_t eq[4], uint32_t& status)
+{
+	uint32_t slot = nPending;
+	for (uint32_t i = 0; i < nPending; i++)
+		if (pending[i].node == target) { slot = i; break; }
+	WS add = incoming;
+	if (!skipFirst) {
+		int prevIdx = findItem(items, prevSlice, target);
+		uint64_t hinP, hinN;
+		bool prevExists = prevIdx >= 0;
+		int32_t prevStart = prevExists ? items[prevIdx].sScore : 0;
+		if (prevExists) {
+			int32_t before = wsBefore(incoming);
+			if (prevStart < before) { hinP = 0; hinN = 1; }
+			else if (prevStart > before) { hinP = 1; hinN = 0; }
+			else { hinP = 0; hinN = 0; }
+		} else { hinP = 1; hinN = 0; }
+		NodeSeq seq = loadNodeSeq(g, target);
+		uint64_t hp, hn;
+		add = myersStep(eqOfColumn(eq, seq, 0), incoming, hinP, hinN, hp, hn);
+		if (!prevExists || wsBefore(add) < prevStart) { add.VP &= ~1ull; add.VN |= 1ull; }
+	}
+	if (slot == nPending) {
+		if (nPending >= cfg.maxPending) { status = EXT_OVERFLOW; return; }
+		pending[slot].node = target;
+		pending[slot].comp = g.componentNumber[target];
+		pending[slot].VP = add.VP; pending[slot].VN = add.VN; pending[slot].score = add.score;
+		pending[slot].hasIncoming = 1;
+		nPending++;
+	} else {
+		WS cur { pending[slot].VP, pending[slot].VN, pending[slot].score };
+		WS m = wsMerge(cur, add);
+		pending[slot].VP = m.VP; pending[slot].VN = m.VN; pending[slot].score = m.score;
+	}
+}
+
+// Recomputes all columns of (slice s, node) into sc.columns. reference: recalcNodeWordslice, ...Common.h:828-852
+__device__ inline void recomputeColumns(const DGraph& g, const LaneScratch& sc, uint32_t s, int itemIdx, const uint64_t eq[4], uint32_t& status, ExtCounters& cnt)
+{
+	const NodeItem& it = sc.items[itemIdx];
+	int prevIdx = findItem(sc.items, sc.slices[s - 1], it.node);
+	bool prevExists = prevIdx >= 0;
+	NodeItem scratch;
+	computeTile(g, it.node, itemStart(it), prevExists, prevExists ? sc.items[prevIdx].sScore : 0,
+		prevExists ? sc.items[prevIdx].HP : ~0ull, prevExists ? sc.items[prevIdx].HN : 0ull, eq, scratch, sc.columns, 0, status);
+	if (scratch.eVP != it.eVP || scratch.eVN != it.eVN || scratch.eScore != it.eScore) status = EXT_ASSERT;   // sliceConsistency, :848-850
+	cnt.recomputeTiles++;
+	cnt.columnSteps += g.nodeLength[it.node];
+}
+
+struct Cell { uint32_t node; uint32_t offset; int32_t seqPos; };
+
+__device__ inline bool pushTrace(const LaneScratch& sc, const ExtendConfig& cfg, uint32_t& nTrace, Cell c, bool nodeSwitch, uint32_t& status)
+{
+	if (nTrace >= cfg.maxTrace) { status = EXT_OVERFLOW; return false; }
+	sc.trace[nTrace].node = c.node;
+	sc.trace[nTrace].seqPos = c.seqPos;
+	sc.trace[nTrace].offsetAndSwitch = c.offset | (nodeSwitch ? 256u : 0u);
+	nTrace++;
+	return true;
+}
+
+// reference: pickBacktraceCorner, ...Common.h:710-804 (scoresNotValid is never set: unlimited cells per slice)
+__device__ inline bool backtraceCorner(const DGraph& g, const LaneScratch& sc, uint32_t s, uint32_t node, int itemIdx, const uint64_t eq[4], Cell& out, bool& nodeSwitch)
+{
+	const SliceInfo& cur = sc.slices[s];
+	const SliceInfo& prev = sc.slices[s - 1];
+	int32_t j = cur.j;
+	int32_t quitScore = cur.minScore + cur.bandwidth;
+	int32_t previousQuitScore = prev.minScore + prev.bandwidth;
+	int32_t scoreHere = wsValue(itemStart(sc.items[itemIdx]), 0);
+	int prevSelf = findItem(sc.items, prev, node);
+	uint32_t inBegin = g.inOff[node], inEnd = g.inOff[node + 1];
+	if (scoreHere > quitScore) {
+		int32_t smallest = scoreHere + 1;
+		out = Cell { 0, 0, 0 };
+		nodeSwitch = false;
+		if (prevSelf >= 0) { smallest = sc.items[prevSelf].sScore; out = Cell { node, 0, j - 1 }; }
+		for (uint32_t e = inBegin; e < inEnd; e++) {
+			uint32_t nb = g.inAdj[e];
+			int p = findItem(sc.items, prev, nb);
+			if (p >= 0 && sc.items[p].eScore <= smallest) { smallest = sc.items[p].eScore; out = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, j - 1 }; nodeSwitch = true; }
+			int c = findItem(sc.items, cur, nb);
+			if (c >= 0 && nb != node) {
+				int32_t v = wsValue(itemEnd(sc.items[c]), 0);
+				if (v < smallest) { smallest = v; out = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, j }; nodeSwitch = true; }
+			}
+		}
+		return true;
+	}
+	NodeSeq seq = loadNodeSeq(g, node);
+	int eqBit = (int)(eqOfColumn(eq, seq, 0) & 1);   // sequence[j] vs first base of the node
+	if (prevSelf >= 0 && sc.items[prevSelf].sScore == scoreHere - 1) { out = Cell { node, 0, j - 1 }; nodeSwitch = false; return true; }
+	Cell bestInvalid { 0xffffffffu, 0xffffffffu, -1 };
+	int32_t bestInvalidScore = scoreHere + 1;
+	for (uint32_t e = inBegin; e < inEnd; e++) {
+		uint32_t nb = g.inAdj[e];
+		int c = findItem(sc.items, cur, nb);
+		if (c >= 0 && wsValue(itemEnd(sc.items[c]), 0) == scoreHere - 1) { out = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, j }; nodeSwitch = true; return true; }
+		int p = findItem(sc.items, prev, nb);
+		if (p >= 0) {
+			int32_t corner = sc.items[p].eScore;
+			if (corner > previousQuitScore) {
+				if (corner < bestInvalidScore) { bestInvalidScore = corner; bestInvalid = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, j - 1 }; }
+			} else if (corner == scoreHere - (eqBit ? 0 : 1)) {
+				out = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, j - 1 }; nodeSwitch = true; return true;
+			}
+		}
+	}
+	if (bestInvalidScore < scoreHere + 1) { out = bestInvalid; nodeSwitch = true; return true; }
+	return false;   // the reference asserts here
+}
+
+// Full seed extension: slices, correctness HMM, trimming, backtrace.
+// reference: getReverseTraceFromSeed, src/GraphAlignerBitvectorBanded.h:46-71. Returns status; on EXT_OK the
+// trace (start cell first, row -1 last) is in sc.trace[0..nTrace) and `score` is the alignment score.
+__device__ inline uint32_t extendSeed(const DGraph& g, const CorrectnessTables& ct, const uint8_t* iupac, const ExtendConfig& cfg, const LaneScratch& sc,
+	const char* seq, int len, uint32_t startNode, uint32_t startOffset, uint32_t& nTrace, int32_t& score, ExtCounters& cnt)
+{
+	uint32_t status = EXT_OK;
+	nTrace = 0;
+	score = 0;
+	cnt.extensions++;
+	int numSlices = (len + 63) / 64;
+	if ((uint32_t)numSlices + 1 > cfg.maxSlices) return EXT_OVERFLOW;
+	// ---- initial slice: row -1 scores are |column - startOffset| on the seed's split node (...Common.h:1243-1279)
+	{
+		int nl = g.nodeLength[startNode];
+		NodeItem& it = sc.items[0];
+		it.node = startNode;
+		it.sVP = it.sVN = it.eVP = it.eVN = 0;
+		it.sScore = (int32_t)startOffset;
+		it.eScore = nl - 1 - (int32_t)startOffset;
+		it.minScore = 0;
+		uint64_t upToOffset = startOffset >= 63 ? ~0ull : ((1ull << (startOffset + 1)) - 1);
+		uint64_t nodeMask = nl >= 64 ? ~0ull : ((1ull << nl) - 1);
+		it.HN = upToOffset & ~1ull;
+		it.HP = nodeMask & ~upToOffset;
+		SliceInfo& s0 = sc.slices[0];
+		s0.minScore = 0; s0.minNode = startNode; s0.minOffset = startOffset;
+		s0.first = 0; s0.count = 1; s0.bandwidth = 1; s0.j = -64;
+		s0.correctLogOdds = ct.initCorrect; s0.falseLogOdds = ct.initFalse;
+		s0.flags = 1;   // log(0.8) > log(0.2)
+	}
+	uint32_t nItems = 1;
+	uint32_t nSlices = 1;
+	uint64_t eq[4];
+	for (int slice = 0; slice < numSlices; slice++) {
+		const SliceInfo prev = sc.slices[nSlices - 1];
+		int j = prev.j + 64;
+		eqVector(seq, len, j, iupac, eq);
+		int32_t previousQuitScore = prev.minScore + prev.bandwidth;
+		int32_t previousMinScore = prev.minScore;
+		int bandwidth = cfg.bandwidth;
+		int flatRows = (j + 64 > len) ? (len - j) : 0;   // last partial slice (...Banded.h:414)
+		// seed the queue from the previous slice's in-band nodes (...Banded.h:235-277; linearizable is all-false)
+		uint32_t nPending = 0;
+		for (uint32_t i = 0; i < prev.count; i++) {
+			const NodeItem& it = sc.items[prev.first + i];
+			if (j != 0 && it.minScore > previousQuitScore) continue;
+			pushEdge(g, sc.pending, nPending, cfg, it.node, wsSource(it.sScore), true, sc.items, prev, eq, status);
+		}
+		if (status != EXT_OK) return status;
+		SliceInfo cur;
+		cur.first = nItems; cur.count = 0; cur.bandwidth = bandwidth; cur.j = j;
+		cur.minScore = INT32_MAX - bandwidth - 1; cur.minNode = 0xffffffffu; cur.minOffset = 0xffffffffu;
+		int32_t flatMin = INT32_MAX; uint32_t flatNode = 0xffffffffu, flatOffset = 0xffffffffu;
+		int32_t currentMin = cur.minScore;
+		while (nPending > 0) {
+			// pop the pending node with the lowest topological rank (ComponentPriorityQueue order on a DAG)
+			uint32_t best = 0;
+			for (uint32_t i = 1; i < nPending; i++) if (sc.pending[i].comp < sc.pending[best].comp) best = i;
+			Pending p = sc.pending[best];
+			sc.pending[best] = sc.pending[nPending - 1];
+			nPending--;
+			if (nItems >= cfg.maxItems) return EXT_OVERFLOW;
+			int prevIdx = findItem(sc.items, prev, p.node);
+			bool prevExists = prevIdx >= 0;
+			NodeItem& out = sc.items[nItems];
+			TileResult tr = computeTile(g, p.node, WS { p.VP, p.VN, p.score }, prevExists, prevExists ? sc.items[prevIdx].sScore : 0,
+				prevExists ? sc.items[prevIdx].HP : ~0ull, prevExists ? sc.items[prevIdx].HN : 0ull, eq, out, nullptr, flatRows, status);
+			if (status != EXT_OK) return status;
+			out.minScore = tr.minScore;
+			nItems++;
+			cur.count++;
+			cnt.dpTiles++;
+			cnt.columnSteps += g.nodeLength[p.node];
+			if (flatRows > 0) { cnt.recomputeTiles++; cnt.columnSteps += g.nodeLength[p.node]; }   // the reference recomputes the tile in flattenLastSliceEnd
+			if (tr.minScore > previousQuitScore + bandwidth + 128) return EXT_ASSERT;   // ...Banded.h:352
+			currentMin = tr.minScore < currentMin ? tr.minScore : currentMin;
+			if (tr.minScore < cur.minScore) { cur.minScore = tr.minScore; cur.minNode = p.node; cur.minOffset = tr.minOffset; }
+			if (flatRows > 0 && tr.flatMin < flatMin) { flatMin = tr.flatMin; flatNode = p.node; flatOffset = tr.flatOffset; }
+			WS newEnd = itemEnd(out);
+			int32_t newEndMin = wsColumnMin(newEnd);
+			if (newEndMin < previousMinScore) return EXT_ASSERT;   // ...Banded.h:368
+			if (newEndMin <= currentMin + bandwidth) {
+				for (uint32_t e = g.outOff[p.node]; e < g.outOff[p.node + 1]; e++) {
+					pushEdge(g, sc.pending, nPending, cfg, g.outAdj[e], newEnd, false, sc.items, prev, eq, status);
+					if (status != EXT_OK) return status;
+				}
+			}
+		}
+		if (cur.count == 0) return EXT_ASSERT;
+		if (flatRows > 0) { cur.minScore = flatMin; cur.minNode = flatNode; cur.minOffset = flatOffset; }
+		if (cur.minScore < prev.minScore) return EXT_ASSERT;   // ...Banded.h:463
+		// correctness HMM (src/AlignmentCorrectnessEstimation.cpp:105-129): +, max, >= only
+		{
+			int mm = cur.minScore - prev.minScore;
+			int idx = mm < 64 ? mm : 63;
+			bool cfc = prev.correctLogOdds + ct.c2c >= prev.falseLogOdds + ct.f2c;
+			bool ffc = prev.correctLogOdds + ct.c2f >= prev.falseLogOdds + ct.f2f;
+			double a = prev.correctLogOdds + ct.c2c, b = prev.falseLogOdds + ct.f2c;
+			double c = prev.correctLogOdds + ct.c2f, d = prev.falseLogOdds + ct.f2f;
+			cur.correctLogOdds = (a > b ? a : b) + ct.correctOdds[idx];
+			cur.falseLogOdds = (c > d ? c : d) + ct.wrongOdds[idx];
+			cur.flags = (cur.correctLogOdds > cur.falseLogOdds ? 1u : 0u) | (cfc ? 2u : 0u) | (ffc ? 4u : 0u);
+		}
+		if (!(cur.flags & 2u)) break;   // !CorrectFromCorrect: stop, slice not kept (...Banded.h:589-607)
+		sc.slices[nSlices++] = cur;
+	}
+	// removeWronglyAlignedEnd, ...Common.h:1231-1241
+	{
+		bool currentlyCorrect = (sc.slices[nSlices - 1].flags & 1u) != 0;
+		while (!currentlyCorrect) {
+			currentlyCorrect = (sc.slices[nSlices - 1].flags & 4u) != 0;
+			nSlices--;
+			if (nSlices == 0) break;
+		}
+	}
+	if (nSlices <= 1) return EXT_FAILED;
+	const SliceInfo& last = sc.slices[nSlices - 1];
+	if (last.minScore < 0 || last.minScore > len + 128) return EXT_ASSERT;
+	score = last.minScore;
+
+	// ---- backtrace (getReverseTraceFromTable, ...Common.h:392-544)
+	Cell here { last.minNode, last.minOffset, (last.j + 63 < len - 1) ? last.j + 63 : len - 1 };
+	if (!pushTrace(sc, cfg, nTrace, here, false, status)) return status;
+	uint32_t curSlice = 0xffffffffu, curNode = 0xffffffffu;
+	int curItem = -1;
+	while (here.seqPos != -1) {
+		uint32_t s = (uint32_t)(here.seqPos / 64) + 1;
+		if (s >= nSlices) return EXT_ASSERT;
+		if (s != curSlice || here.node != curNode) {
+			if (s != curSlice) eqVector(seq, len, sc.slices[s].j, iupac, eq);
+			curSlice = s;
+			curNode = here.node;
+			curItem = findItem(sc.items, sc.slices[s], curNode);
+			if (curItem < 0) return EXT_ASSERT;
+			recomputeColumns(g, sc, s, curItem, eq, status, cnt);
+			if (status != EXT_OK) return status;
+		}
+		const SliceInfo& cs = sc.slices[s];
+		const SliceInfo& ps = sc.slices[s - 1];
+		int row = here.seqPos & 63;
+		if (row == 0 && here.offset == 0) {
+			Cell nxt; bool sw;
+			if (!backtraceCorner(g, sc, s, curNode, curItem, eq, nxt, sw)) return EXT_ASSERT;
+			if (!pushTrace(sc, cfg, nTrace, nxt, sw, status)) return status;
+			here = nxt;
+			continue;
+		}
+		if (row == 0) {
+			// vertical crossing into the previous slice (...Common.h:451-477, pickBacktraceVerticalCrossing :665-708)
+			int prevIdx = findItem(sc.items, ps, curNode);
+			if (prevIdx < 0) {
+				here = Cell { curNode, 0, here.seqPos };
+				if (!pushTrace(sc, cfg, nTrace, here, false, status)) return status;
+				continue;
+			}
+			uint32_t off = here.offset;
+			while (off > 0 && wsValue(sc.columns[off - 1], 0) == wsValue(sc.columns[off], 0) - 1) {
+				off--;
+				if (!pushTrace(sc, cfg, nTrace, Cell { curNode, off, here.seqPos }, false, status)) return status;
+			}
+			here.offset = off;
+			if (off == 0) {
+				Cell nxt; bool sw;
+				if (!backtraceCorner(g, sc, s, curNode, curItem, eq, nxt, sw)) return EXT_ASSERT;
+				if (!pushTrace(sc, cfg, nTrace, nxt, sw, status)) return status;
+				here = nxt;
+				continue;
+			}
+			const NodeItem& pn = sc.items[prevIdx];
+			int32_t scoreHere = wsValue(sc.columns[off], 0);
+			int32_t scoreDiagonal = pn.sScore;
+			uint64_t lowMask = off >= 1 ? (((1ull << off) - 1) & ~1ull) : 0ull;   // bits 1..off-1
+			scoreDiagonal += popc64(pn.HP & lowMask) - popc64(pn.HN & lowMask);
+			int32_t scoreUp = scoreDiagonal + (int32_t)((pn.HP >> off) & 1) - (int32_t)((pn.HN >> off) & 1);
+			int32_t quitScore = cs.minScore + cs.bandwidth, previousQuitScore = ps.minScore + ps.bandwidth;
+			Cell nxt;
+			if (scoreHere > quitScore || scoreDiagonal > previousQuitScore || scoreUp > previousQuitScore) {
+				nxt = scoreDiagonal < scoreUp ? Cell { curNode, off - 1, here.seqPos - 1 } : Cell { curNode, off, here.seqPos - 1 };
+			} else {
+				NodeSeq nseq = loadNodeSeq(g, curNode);
+				int eqBit = (int)(eqOfColumn(eq, nseq, (int)off) & 1);
+				if (scoreUp == scoreHere - 1) nxt = Cell { curNode, off, here.seqPos - 1 };
+				else if (scoreDiagonal == scoreHere - (eqBit ? 0 : 1)) nxt = Cell { curNode, off - 1, here.seqPos - 1 };
+				else return EXT_ASSERT;
+			}
+			if (!pushTrace(sc, cfg, nTrace, nxt, false, status)) return status;
+			here = nxt;
+			continue;
+		}
+		if (here.offset == 0) {
+			// horizontal crossing into an in-neighbour (...Common.h:478-499, pickBacktraceHorizontalCrossing :599-663)
+			WS start = itemStart(sc.items[curItem]);
+			int32_t sp = here.seqPos;
+			while ((sp & 63) != 0 && (start.VP & (1ull << (sp & 63)))) {
+				sp--;
+				if (!pushTrace(sc, cfg, nTrace, Cell { curNode, 0, sp }, false, status)) return status;
+			}
+			here.seqPos = sp;
+			int offset = sp & 63;
+			if (offset == 0) {
+				Cell nxt; bool sw;
+				if (!backtraceCorner(g, sc, s, curNode, curItem, eq, nxt, sw)) return EXT_ASSERT;
+				if (!pushTrace(sc, cfg, nTrace, nxt, sw, status)) return status;
+				here = nxt;
+				continue;
+			}
+			NodeSeq nseq = loadNodeSeq(g, curNode);
+			int eqBit = (int)((eqOfColumn(eq, nseq, 0) >> offset) & 1);
+			int32_t scoreHere = wsValue(start, offset);
+			int32_t quitScore = cs.minScore + cs.bandwidth;
+			Cell nxt { 0, 0, 0 };
+			bool sw = false, found = false;
+			if (scoreHere > quitScore) {
+				int32_t smallest = wsValue(start, offset - 1);
+				nxt = Cell { curNode, 0, sp - 1 };
+				for (uint32_t e = g.inOff[curNode]; e < g.inOff[curNode + 1]; e++) {
+					uint32_t nb = g.inAdj[e];
+					int c = findItem(sc.items, cs, nb);
+					if (c < 0) continue;
+					WS ne = itemEnd(sc.items[c]);
+					if (wsValue(ne, offset - 1) <= smallest) { smallest = wsValue(ne, offset - 1); nxt = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, sp - 1 }; sw = true; }
+					if (wsValue(ne, offset) < smallest && nb != curNode) { smallest = wsValue(ne, offset); nxt = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, sp }; sw = true; }
+				}
+				found = true;
+			} else {
+				for (uint32_t e = g.inOff[curNode]; e < g.inOff[curNode + 1] && !found; e++) {
+					uint32_t nb = g.inAdj[e];
+					int c = findItem(sc.items, cs, nb);
+					if (c < 0) continue;
+					WS ne = itemEnd(sc.items[c]);
+					if (wsValue(ne, offset) == scoreHere - 1) { nxt = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, sp }; sw = true; found = true; }
+					else if (wsValue(ne, offset - 1) == scoreHere - (eqBit ? 0 : 1)) { nxt = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, sp - 1 }; sw = true; found = true; }
+				}
+			}
+			if (!found) return EXT_ASSERT;
+			if (!pushTrace(sc, cfg, nTrace, nxt, sw, status)) return status;
+			here = nxt;
+			continue;
+		}
+		// inside the tile (pickBacktraceInside, ...Common.h:556-597): vertical, then diagonal, then horizontal
+		{
+			uint32_t hori = here.offset;
+			int vert = row;
+			NodeSeq nseq = loadNodeSeq(g, curNode);
+			while (hori > 0 && vert > 0) {
+				int32_t scoreHere = wsValue(sc.columns[hori], vert);
+				int32_t vertical = wsValue(sc.columns[hori], vert - 1);
+				int32_t diagonal = wsValue(sc.columns[hori - 1], vert - 1);
+				int eqBit = (int)((eqOfColumn(eq, nseq, (int)hori) >> vert) & 1);
+				if (vertical == scoreHere - 1) { vert--; }
+				else if (diagonal == scoreHere - (eqBit ? 0 : 1)) { hori--; vert--; }
+				else {
+					if (wsValue(sc.columns[hori - 1], vert) != scoreHere - 1) return EXT_ASSERT;
+					hori--;
+				}
+				if (!pushTrace(sc, cfg, nTrace, Cell { curNode, hori, cs.j + vert }, false, status)) return status;
+			}
+			here = Cell { curNode, hori, cs.j + vert };
+		}
+	}
+	// row -1: walk left along the initial ramp, then maybe into an in-neighbour that is in the initial slice
+	// (...Common.h:508-542; the initial slice holds only the seed node)
+	{
+		const NodeItem& n0 = sc.items[0];
+		if (here.node != n0.node) return EXT_ASSERT;
+		uint32_t off = here.offset;
+		// before[i] = |i - startOffset|: decreasing towards startOffset from the right
+		while (true) {
+			int32_t b = (int32_t)off - (int32_t)startOffset; if (b < 0) b = -b;
+			int32_t bl = (int32_t)off - 1 - (int32_t)startOffset; if (bl < 0) bl = -bl;
+			if (!(b != 0 && off > 0 && bl == b - 1)) break;
+			off--;
+			if (!pushTrace(sc, cfg, nTrace, Cell { here.node, off, -1 }, false, status)) return status;
+		}
+		// the in-neighbour hop (:528-541) needs the neighbour inside slices[0], which only contains the seed node
+		// (a self-loop would be needed), so it cannot trigger on a DAG.
+	}
+	cnt.traceItems += nTrace;
+	return status;
+}
+
+} // namespace gcdev

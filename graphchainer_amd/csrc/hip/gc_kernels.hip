@@ -1,0 +1,604 @@
+// HIP kernels of the GraphChainer hot path for gfx950 (MI355X). See gc_device.hpp for the device data model
+// and DESIGN.md for the mapping rationale and the per-kernel roofline accounting.
+#include "gc_kernels.hpp"
+
+namespace gcdev {
+
+// =====================================================================================================
+// K1 - minimizer seed lookup. reference: MinimizerSeeder::getSeeds / iterateKmers,
+// src/MinimizerSeeder.cpp:59-102,522-544. One wave per read; lanes sweep 64 read positions at a time.
+// For every read position whose 15-mer is valid and indexed with count < maxCount, and that passes the
+// reference's "same k-mer as the previous position" thinning rule (:91), emits (pos, keyIndex).
+// Output order inside a read is by position (ballot-rank compaction), which the host's std::sort by count
+// then consumes exactly like the reference does (:497).
+// =====================================================================================================
+
+__device__ __forceinline__ int baseCode(uint8_t c)
+{
+	switch (c) {
+		case 'a': case 'A': return 0;
+		case 'c': case 'C': return 1;
+		case 'g': case 'G': return 2;
+		case 't': case 'T': return 3;
+	}
+	return -1;
+}
+
+__device__ __forceinline__ uint32_t hashKmer(uint64_t kmer)
+{
+	kmer *= 0x9E3779B97F4A7C15ull;
+	return (uint32_t)(kmer >> 32);
+}
+
+// returns key index or 0xffffffff. Open addressing, linear probing; slot = {kmer:32, index:32}.
+__device__ __forceinline__ uint32_t lookupKmer(const SeedIndex& idx, uint64_t kmer)
+{
+	uint32_t h = hashKmer(kmer) & idx.tableMask;
+	while (true) {
+		uint64_t slot = idx.table[h];
+		uint32_t key = (uint32_t)(slot >> 32);
+		if (key == 0xffffffffu) return 0xffffffffu;
+		if (key == (uint32_t)kmer) return (uint32_t)slot;
+		h = (h + 1) & idx.tableMask;
+	}
+}
+
+__global__ void __launch_bounds__(64) k_seed_lookup(SeedIndex idx, const char* __restrict__ bases, const uint64_t* __restrict__ readOff, uint32_t nReads,
+	uint64_t* __restrict__ matchCursor, uint32_t* __restrict__ readMatchOff, uint32_t* __restrict__ readMatchCount, uint2* __restrict__ matches, uint64_t matchCapacity, uint32_t* __restrict__ tmp)
+{
+	const int lane = threadIdx.x;
+	const int k = idx.k;
+	const int realWindow = idx.w - idx.k + 1;
+	const uint64_t mask = ~(~0ull << (2 * k));
+	for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
+		const char* seq = bases + readOff[r];
+		const int len = (int)(readOff[r + 1] - readOff[r]);
+		uint32_t* mine = tmp + readOff[r];
+		uint32_t total = 0;
+		// pass 1: per position, key index + 1 (0 = nothing to emit)
+		for (int base = 0; base < len; base += 64) {
+			int pos = base + lane;
+			uint32_t found = 0;
+			if (pos < len && pos >= k - 1) {
+				// k-mer ending at pos, and how far the run of valid characters extends to the left of it
+				uint64_t kmer = 0;
+				bool valid = true;
+				for (int i = pos - k + 1; i <= pos; i++) {
+					int c = baseCode((uint8_t)seq[i]);
+					if (c < 0) { valid = false; break; }
+					kmer = (kmer << 2) | (uint64_t)c;
+				}
+				if (valid) {
+					// thinning (:91): inside a streak of identical consecutive k-mers only every realWindow-th is emitted.
+					// Consecutive k-mers are identical only in a homopolymer; walk back to the streak start.
+					int streakStart = pos;
+					int c0 = baseCode((uint8_t)seq[pos]);
+					bool homopolymer = (kmer == (uint64_t)c0 * (mask / 3));
+					if (homopolymer) {
+						while (streakStart - k >= 0 && baseCode((uint8_t)seq[streakStart - k]) == c0) streakStart--;
+					}
+					bool emit = ((pos - streakStart) % realWindow) == 0;
+					if (emit) {
+						uint32_t key = lookupKmer(idx, kmer & mask);
+						if (key != 0xffffffffu) {
+							uint32_t count = (uint32_t)(idx.startPos[key + 1] - idx.startPos[key]);
+							if (count < idx.maxCount) found = key + 1;
+						}
+					}
+				}
+			}
+			if (pos < len) mine[pos] = found;
+			total += (uint32_t)__popcll(__ballot(found != 0));
+		}
+		// reserve a contiguous output range for this read
+		uint64_t outBase = 0;
+		if (lane == 0) outBase = atomicAdd((unsigned long long*)matchCursor, (unsigned long long)total);
+		outBase = __shfl(outBase, 0);
+		if (lane == 0) { readMatchOff[r] = (uint32_t)outBase; readMatchCount[r] = total; }
+		if (outBase + total > matchCapacity) continue;   // host checks the cursor and retries with a larger buffer
+		// pass 2: ordered compaction
+		uint32_t written = 0;
+		for (int base = 0; base < len; base += 64) {
+			int pos = base + lane;
+			uint32_t found = pos < len ? mine[pos] : 0;
+			unsigned long long ballot = __ballot(found != 0);
+			if (found) {
+				uint32_t rank = (uint32_t)__popcll(ballot & ((1ull << lane) - 1));
+				matches[outBase + written + rank] = make_uint2((uint32_t)pos, found - 1);
+			}
+			written += (uint32_t)__popcll(ballot);
+		}
+	}
+}
+
+// =====================================================================================================
+// K3 - seed extension. One lane per extension (see gc_device.hpp). A persistent grid strides over the work
+// items; every lane owns a scratch slab in HBM; finished traces are appended to a shared pool.
+// reference: GraphAlignerBitvectorBanded::getReverseTraceFromSeed, src/GraphAlignerBitvectorBanded.h:46-71.
+// =====================================================================================================
+
+__device__ __forceinline__ LaneScratch laneScratch(uint8_t* slab, const ExtendConfig& cfg)
+{
+	LaneScratch sc;
+	uint8_t* p = slab;
+	sc.slices = (SliceInfo*)p;   p += sizeof(SliceInfo) * cfg.maxSlices;
+	sc.items = (NodeItem*)p;     p += sizeof(NodeItem) * cfg.maxItems;
+	sc.pending = (Pending*)p;    p += sizeof(Pending) * cfg.maxPending;
+	sc.columns = (WS*)p;         p += sizeof(WS) * 64;
+	sc.trace = (TraceCell*)p;
+	return sc;
+}
+
+__global__ void __launch_bounds__(64) k_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg,
+	const ExtItem* __restrict__ work, uint32_t nWork, const char* __restrict__ bases, ExtResult* __restrict__ results,
+	uint8_t* __restrict__ scratch, uint64_t slabBytes, TraceCell* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity,
+	unsigned long long* __restrict__ counters)
+{
+	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t stride = gridDim.x * blockDim.x;
+	LaneScratch sc = laneScratch(scratch + (uint64_t)tid * slabBytes, cfg);
+	ExtCounters cnt { 0, 0, 0, 0, 0 };
+	for (uint32_t w = tid; w < nWork; w += stride) {
+		ExtItem it = work[w];
+		uint32_t nTrace = 0;
+		int32_t score = 0;
+		uint32_t status = extendSeed(g, *ct, iupac, cfg, sc, bases + it.seqOff, (int)it.seqLen, it.node, it.offset, nTrace, score, cnt);
+		ExtResult res;
+		res.status = status;
+		res.score = score;
+		res.traceLen = 0;
+		res.traceOff = 0;
+		if (status == EXT_OK) {
+			unsigned long long base = atomicAdd(traceCursor, (unsigned long long)nTrace);
+			if (base + nTrace <= traceCapacity) {
+				for (uint32_t i = 0; i < nTrace; i++) tracePool[base + i] = sc.trace[i];
+				res.traceOff = base;
+				res.traceLen = nTrace;
+			} else {
+				res.status = EXT_OVERFLOW;
+			}
+		}
+		results[w] = res;
+	}
+	// one set of atomics per lane that did work
+	if (cnt.extensions) {
+		atomicAdd(&counters[0], cnt.dpTiles);
+		atomicAdd(&counters[1], cnt.recomputeTiles);
+		atomicAdd(&counters[2], cnt.columnSteps);
+		atomicAdd(&counters[3], cnt.traceItems);
+		atomicAdd(&counters[4], cnt.extensions);
+	}
+}
+
+// =====================================================================================================
+// K3b - fragment post-pass: merges the two one-way traces of every seed, replays the reference's serial
+// "seed already lies on an earlier alignment" filter inside each fragment, and emits anchors.
+// reference: AlignOneWay src/GraphAligner.h:114-203 (non-sloppy), exactAlignmentPart :407-461,
+// getAlignmentFromSeed :567-626, anchor construction src/Aligner.cpp:706-729. One lane per fragment.
+// =====================================================================================================
+
+struct MergedView {   // virtual view of a seed's merged trace (backward cells, then forward cells) in forward-strand split coords
+	const TraceCell* bw; uint32_t nBw;   // backward device trace without its final row -1 cell (nBw cells used)
+	const TraceCell* fw; uint32_t nFw;   // forward device trace (used in reverse order)
+	int32_t p;                            // seed position inside the fragment
+	__device__ uint32_t size() const { return nBw + nFw; }
+};
+
+// cell i of the merged trace: (split node, offset in split node, seqPos in fragment)
+__device__ inline void mergedCell(const DGraph& g, const MergedView& v, uint32_t i, uint32_t& node, uint32_t& offset, int32_t& seqPos)
+{
+	if (i < v.nBw) {
+		const TraceCell& c = v.bw[i];
+		// backward rows count away from the seed: row b -> fragment position p-1-b (fixReverseTraceSeqPosAndOrder, :543-565)
+		seqPos = v.p - 1 - c.seqPos;
+		// reverse-strand twin of the cell (GetReversePosition + GetUnitigNode)
+		uint32_t off = c.offsetAndSwitch & 255u;
+		int32_t id = g.nodeIDs[c.node];
+		uint32_t orig = g.nodeOffset[c.node] + off;
+		uint32_t rev = g.origSize[id] - 1 - orig;
+		uint32_t twin = g.lookup[g.lookupOff[id ^ 1] + rev / 64];
+		node = twin;
+		offset = rev - g.nodeOffset[twin];
+	} else {
+		const TraceCell& c = v.fw[v.nFw - 1 - (i - v.nBw)];
+		seqPos = v.p + 1 + c.seqPos;   // row -1 -> p
+		node = c.node;
+		offset = c.offsetAndSwitch & 255u;
+	}
+}
+
+__global__ void __launch_bounds__(64) k_build_anchors(DGraph g, const Fragment* __restrict__ frags, uint32_t nFrags, const FragSeed* __restrict__ seeds,
+	const ExtResult* __restrict__ ext, const TraceCell* __restrict__ tracePool, int32_t splitLen,
+	AnchorRec* __restrict__ anchors, uint32_t* __restrict__ fragStatus, uint32_t* __restrict__ fragExtended,
+	uint32_t* __restrict__ pathPool, unsigned long long* __restrict__ pathCursor, uint64_t pathCapacity)
+{
+	uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= nFrags) return;
+	Fragment fr = frags[f];
+	uint32_t status = 0;       // 0 ok, 1 the reference would throw in this fragment, 2 capacity overflow
+	uint32_t extended = 0;
+	uint32_t nSeeds = fr.seedEnd - fr.seedBegin;
+	for (uint32_t k = 0; k < nSeeds; k++) anchors[fr.seedBegin + k].valid = 0;
+	for (uint32_t k = 0; k < nSeeds && status == 0; k++) {
+		uint32_t sIdx = fr.seedBegin + k;
+		FragSeed sd = seeds[sIdx];
+		int32_t p = (int32_t)sd.seqPos - (int32_t)fr.l;
+		// --- filter: does the seed cell lie on an earlier accepted alignment of this fragment? (:163-173)
+		bool skip = false;
+		for (uint32_t a = 0; a < k && !skip && status == 0; a++) {
+			const AnchorRec& prev = anchors[fr.seedBegin + a];
+			if (!prev.valid) continue;
+			if (!(prev.lastSeqPos > prev.firstSeqPos)) { status = 1; break; }   // assert at :412
+			if ((int32_t)prev.lastSeqPos < p || (int32_t)prev.firstSeqPos > p) continue;
+			FragSeed ps = seeds[fr.seedBegin + a];
+			const ExtResult& pb = ext[2 * (size_t)(fr.seedBegin + a)];
+			const ExtResult& pf = ext[2 * (size_t)(fr.seedBegin + a) + 1];
+			MergedView v;
+			v.p = (int32_t)ps.seqPos - (int32_t)fr.l;
+			bool hasB = pb.status == EXT_OK && v.p > 0, hasF = pf.status == EXT_OK && v.p < splitLen - 1;
+			v.bw = tracePool + pb.traceOff; v.nBw = hasB ? (hasF ? pb.traceLen - 1 : pb.traceLen) : 0;
+			v.fw = tracePool + pf.traceOff; v.nFw = hasF ? pf.traceLen : 0;
+			for (uint32_t i = 0; i < v.size(); i++) {
+				uint32_t node, off; int32_t sp;
+				mergedCell(g, v, i, node, off, sp);
+				if (sp == p && node == sd.node && off == sd.offset) { skip = true; break; }
+			}
+		}
+		if (skip || status != 0) continue;
+		extended++;
+		// --- this seed is extended: getAlignmentFromSeed (:567-626)
+		const ExtResult& eb = ext[2 * (size_t)sIdx];
+		const ExtResult& ef = ext[2 * (size_t)sIdx + 1];
+		bool runB = p > 0, runF = p < splitLen - 1;
+		if ((runB && eb.status == EXT_ASSERT) || (runF && ef.status == EXT_ASSERT)) { status = 1; break; }
+		if ((runB && eb.status == EXT_OVERFLOW) || (runF && ef.status == EXT_OVERFLOW)) { status = 2; break; }
+		bool hasB = runB && eb.status == EXT_OK, hasF = runF && ef.status == EXT_OK;
+		if (!hasB && !hasF) continue;   // emptyAlignment: alignmentFailed()
+		MergedView v;
+		v.p = p;
+		v.bw = tracePool + eb.traceOff; v.nBw = hasB ? (hasF ? eb.traceLen - 1 : eb.traceLen) : 0;
+		v.fw = tracePool + ef.traceOff; v.nFw = hasF ? ef.traceLen : 0;
+		uint32_t n = v.size();
+		// anchor path = distinct consecutive split nodes along the trace (src/Aligner.cpp:714-720)
+		uint32_t pathLen = 0, last = 0xffffffffu;
+		for (uint32_t i = 0; i < n; i++) {
+			uint32_t node, off; int32_t sp;
+			mergedCell(g, v, i, node, off, sp);
+			if (node != last) { pathLen++; last = node; }
+		}
+		unsigned long long base = atomicAdd(pathCursor, (unsigned long long)pathLen);
+		if (base + pathLen > pathCapacity) { status = 2; break; }
+		AnchorRec rec;
+		rec.valid = 1;
+		rec.x = fr.l;
+		rec.y = fr.l + (uint32_t)splitLen - 1;
+		rec.pad = 0;
+		rec.pathOff = base;
+		rec.pathLen = pathLen;
+		rec.score = (hasB ? eb.score : 0) + (hasF ? ef.score : 0);
+		uint32_t w = 0;
+		last = 0xffffffffu;
+		for (uint32_t i = 0; i < n; i++) {
+			uint32_t node, off; int32_t sp;
+			mergedCell(g, v, i, node, off, sp);
+			if (node != last) { pathPool[base + w++] = node; last = node; }
+			if (i == 0) { rec.firstNode = node; rec.firstOffset = off; rec.firstSeqPos = (uint32_t)sp; }
+			if (i == n - 1) { rec.lastNode = node; rec.lastOffset = off; rec.lastSeqPos = (uint32_t)sp; }
+		}
+		anchors[sIdx] = rec;
+	}
+	if (status != 0) for (uint32_t k = 0; k < nSeeds; k++) anchors[fr.seedBegin + k].valid = 0;   // a throwing AlignOneWay returns nothing
+	fragStatus[f] = status;
+	fragExtended[f] = extended;
+}
+
+// =====================================================================================================
+// K4 - co-linear chaining. reference: AlignmentGraph::colinearChaining / colinearChainingByComponent,
+// src/AlignmentGraph.cpp:1712-1863. One wave per read. Lanes cooperatively compact the read's valid
+// anchors; the DP - a sweep over anchor endpoints in topological order, sequential in the reference too -
+// runs on lane 0 against per-path range-max tables.
+//
+// Range-max tables replace the reference's treaps (:1600-1710; RMQ results do not depend on tree shape).
+// Anchor keys are y = l + splitLen - 1 with l a multiple of splitGap, so f = l / splitGap is a dense key
+// domain: T[k][f] / I[k][f] hold the max (value, anchor) seen for that key on path k, packed in one uint64 so
+// that integer max equals the reference's lexicographic pair max (ties towards the larger anchor index,
+// :1812,1849). 0 is "empty" and stands for the reference's default_value, which can never win (:1751-1754).
+// =====================================================================================================
+
+__device__ __forceinline__ unsigned long long packScore(long long score, long long anchor)
+{
+	return ((unsigned long long)(score + (1ll << 30)) << 32) | (unsigned long long)(uint32_t)(anchor + 1);
+}
+__device__ __forceinline__ long long unpackScore(unsigned long long v) { return (long long)(v >> 32) - (1ll << 30); }
+__device__ __forceinline__ long long unpackAnchor(unsigned long long v) { return (long long)(uint32_t)v - 1; }
+
+__device__ inline void heapSort(unsigned long long* a, uint32_t n)
+{
+	if (n < 2) return;
+	auto sift = [&](uint32_t root, uint32_t end) {
+		while (true) {
+			uint32_t child = 2 * root + 1;
+			if (child >= end) break;
+			if (child + 1 < end && a[child] < a[child + 1]) child++;
+			if (a[root] >= a[child]) break;
+			unsigned long long t = a[root]; a[root] = a[child]; a[child] = t;
+			root = child;
+		}
+	};
+	for (uint32_t i = n / 2; i-- > 0;) sift(i, n);
+	for (uint32_t end = n - 1; end > 0; end--) {
+		unsigned long long t = a[0]; a[0] = a[end]; a[end] = t;
+		sift(0, end);
+	}
+}
+
+struct ChainScratch {
+	uint32_t* compact;              // [capAnchors] compact anchor index -> slot
+	unsigned long long* C;          // [capAnchors] packed (coverage, predecessor)
+	unsigned long long* endpoints;  // [capEndpoints] (topoId << 32) | endpoint id
+	uint32_t* epAnchor;             // [capEndpoints]
+	uint32_t* epKind;               // [capEndpoints] 0xffffffff start, 0xfffffffe end, else path id
+	uint32_t* group;                // [capAnchors] anchors of the current node, sorted by (y, x, index)
+	unsigned long long* tables;     // [2 * capTable]
+};
+
+__device__ __forceinline__ ChainScratch chainScratch(uint8_t* base, const ChainCaps& caps)
+{
+	ChainScratch s;
+	uint8_t* p = base;
+	s.C = (unsigned long long*)p;          p += 8 * (size_t)caps.capAnchors;
+	s.endpoints = (unsigned long long*)p;  p += 8 * (size_t)caps.capEndpoints;
+	s.tables = (unsigned long long*)p;     p += 16 * (size_t)caps.capTable;
+	s.compact = (uint32_t*)p;              p += 4 * (size_t)caps.capAnchors;
+	s.epAnchor = (uint32_t*)p;             p += 4 * (size_t)caps.capEndpoints;
+	s.epKind = (uint32_t*)p;               p += 4 * (size_t)caps.capEndpoints;
+	s.group = (uint32_t*)p;
+	return s;
+}
+
+// DP for one component. Returns false on capacity overflow.
+__device__ inline bool chainComponent(const DGraph& g, const AnchorRec* anchors, const ChainScratch& sc, const ChainCaps& caps, uint32_t nA, uint32_t cid,
+	uint32_t nKeys, int32_t splitLen, int32_t splitGap, long long& bestScore, long long& bestAnchor)
+{
+	const uint32_t KIND_START = 0xffffffffu, KIND_END = 0xfffffffeu;
+	uint32_t K = g.mpcWidth[cid];
+	if ((uint64_t)K * nKeys > caps.capTable) return false;
+	unsigned long long* T = sc.tables;
+	unsigned long long* I = sc.tables + (size_t)K * nKeys;
+	for (size_t i = 0; i < (size_t)K * nKeys; i++) { T[i] = 0; I[i] = 0; }
+	uint32_t nE = 0;
+	for (uint32_t a = 0; a < nA; a++) {
+		const AnchorRec& an = anchors[sc.compact[a]];
+		if (g.componentMap[an.lastNode] != cid) continue;
+		uint32_t nBack = g.backOff[an.firstNode + 1] - g.backOff[an.firstNode];
+		if (nE + 2 + nBack > caps.capEndpoints) return false;
+		sc.endpoints[nE] = ((unsigned long long)g.topoId[an.firstNode] << 32) | nE; sc.epAnchor[nE] = a; sc.epKind[nE] = KIND_START; nE++;
+		sc.endpoints[nE] = ((unsigned long long)g.topoId[an.lastNode] << 32) | nE; sc.epAnchor[nE] = a; sc.epKind[nE] = KIND_END; nE++;
+		for (uint32_t b = g.backOff[an.firstNode]; b < g.backOff[an.firstNode + 1]; b++) {
+			sc.endpoints[nE] = ((unsigned long long)g.topoId[g.backNode[b]] << 32) | nE; sc.epAnchor[nE] = a; sc.epKind[nE] = g.backPath[b]; nE++;
+		}
+		sc.C[a] = packScore((long long)an.y - (long long)an.x + 1, -1);   // :1769
+	}
+	heapSort(sc.endpoints, nE);   // :1772 (order inside one node's group does not affect the result)
+	for (uint32_t vi = 0, ri = 0; vi < nE; vi = ri) {
+		uint32_t topo = (uint32_t)(sc.endpoints[vi] >> 32);
+		ri = vi + 1;
+		while (ri < nE && (uint32_t)(sc.endpoints[ri] >> 32) == topo) ri++;
+		// (1) anchors starting or ending at this node, ordered by (y, x, index), duplicates removed (:1781-1822)
+		uint32_t nG = 0;
+		for (uint32_t e = vi; e < ri; e++) {
+			uint32_t id = (uint32_t)sc.endpoints[e];
+			if (sc.epKind[id] < KIND_END) continue;
+			uint32_t a = sc.epAnchor[id];
+			const AnchorRec& an = anchors[sc.compact[a]];
+			// insertion sort; skip if already present
+			uint32_t pos = nG;
+			bool dup = false;
+			while (pos > 0) {
+				uint32_t b = sc.group[pos - 1];
+				if (b == a) { dup = true; break; }
+				const AnchorRec& bn = anchors[sc.compact[b]];
+				bool bBefore = bn.y < an.y || (bn.y == an.y && (bn.x < an.x || (bn.x == an.x && b < a)));
+				if (bBefore) break;
+				pos--;
+			}
+			if (!dup) {
+				// a duplicate can only sit at the insertion point's left neighbour (same (y,x,index) sorts adjacent)
+				for (uint32_t q = 0; q < nG && !dup; q++) if (sc.group[q] == a) dup = true;
+			}
+			if (dup) continue;
+			for (uint32_t q = nG; q > pos; q--) sc.group[q] = sc.group[q - 1];
+			sc.group[pos] = a;
+			nG++;
+		}
+		for (uint32_t gi = 0; gi < nG; gi++) {
+			uint32_t j = sc.group[gi];
+			const AnchorRec& an = anchors[sc.compact[j]];
+			if (g.topoId[an.firstNode] != topo) continue;
+			unsigned long long bestT = 0, bestI = 0;
+			for (uint32_t gq = 0; gq < gi; gq++) {   // earlier anchors of the group that END here are in the node-local tables
+				uint32_t i = sc.group[gq];
+				const AnchorRec& bn = anchors[sc.compact[i]];
+				if (g.topoId[bn.lastNode] != topo) continue;
+				long long ci = unpackScore(sc.C[i]);
+				if ((long long)bn.y <= (long long)an.x - 1) { unsigned long long v = packScore(ci, i); bestT = v > bestT ? v : bestT; }
+				if ((long long)bn.y >= (long long)an.x && (long long)bn.y <= (long long)an.y - 1) { unsigned long long v = packScore(ci - (long long)bn.y, i); bestI = v > bestI ? v : bestI; }
+			}
+			long long lenJ = (long long)an.y - (long long)an.x + 1;
+			if (bestT) { unsigned long long cand = packScore(lenJ + unpackScore(bestT), unpackAnchor(bestT)); if (cand > sc.C[j]) sc.C[j] = cand; }
+			if (bestI) { unsigned long long cand = packScore((long long)an.y + unpackScore(bestI), unpackAnchor(bestI)); if (cand > sc.C[j]) sc.C[j] = cand; }
+		}
+		// (2) anchors ending here enter the tables of every path through this node (:1823-1833)
+		for (uint32_t e = vi; e < ri; e++) {
+			uint32_t id = (uint32_t)sc.endpoints[e];
+			if (sc.epKind[id] != KIND_END) continue;
+			uint32_t a = sc.epAnchor[id];
+			const AnchorRec& an = anchors[sc.compact[a]];
+			uint32_t key = an.x / (uint32_t)splitGap;
+			if (key >= nKeys) return false;
+			long long ca = unpackScore(sc.C[a]);
+			unsigned long long vt = packScore(ca, a), vi2 = packScore(ca - (long long)an.y, a);
+			for (uint32_t pz = g.pathsOff[an.lastNode]; pz < g.pathsOff[an.lastNode + 1]; pz++) {
+				size_t at = (size_t)g.paths[pz] * nKeys + key;
+				if (vt > T[at]) T[at] = vt;
+				if (vi2 > I[at]) I[at] = vi2;
+			}
+		}
+		// (3) forwarded queries: this node is the last node of path k that strictly reaches start(j) (:1834-1845)
+		for (uint32_t e = vi; e < ri; e++) {
+			uint32_t id = (uint32_t)sc.endpoints[e];
+			uint32_t k = sc.epKind[id];
+			if (k >= KIND_END) continue;
+			uint32_t j = sc.epAnchor[id];
+			const AnchorRec& an = anchors[sc.compact[j]];
+			long long lenJ = (long long)an.y - (long long)an.x + 1;
+			unsigned long long bestT = 0, bestI = 0;
+			// T[k].RMQ(0, x-1): keys y' = l' + splitLen - 1 <= x - 1  <=>  l' <= x - splitLen
+			long long maxL = (long long)an.x - (long long)splitLen;
+			if (maxL >= 0) {
+				uint32_t hi = (uint32_t)(maxL / splitGap);
+				if (hi >= nKeys) hi = nKeys - 1;
+				for (uint32_t f = 0; f <= hi; f++) { unsigned long long v = T[(size_t)k * nKeys + f]; bestT = v > bestT ? v : bestT; }
+			}
+			// I[k].RMQ(x, y-1): x <= l' + splitLen - 1 <= y - 1  <=>  x - splitLen + 1 <= l' <= y - splitLen
+			long long lo = (long long)an.x - (long long)splitLen + 1, hiL = (long long)an.y - (long long)splitLen;
+			if (lo < 0) lo = 0;
+			if (hiL >= lo) {
+				uint32_t fLo = (uint32_t)((lo + splitGap - 1) / splitGap), fHi = (uint32_t)(hiL / splitGap);
+				if (fHi >= nKeys) fHi = nKeys - 1;
+				for (uint32_t f = fLo; f <= fHi; f++) { unsigned long long v = I[(size_t)k * nKeys + f]; bestI = v > bestI ? v : bestI; }
+			}
+			if (bestT) { unsigned long long cand = packScore(lenJ + unpackScore(bestT), unpackAnchor(bestT)); if (cand > sc.C[j]) sc.C[j] = cand; }
+			if (bestI) { unsigned long long cand = packScore((long long)an.y + unpackScore(bestI), unpackAnchor(bestI)); if (cand > sc.C[j]) sc.C[j] = cand; }
+		}
+	}
+	bestScore = 0;
+	bestAnchor = -1;
+	for (uint32_t a = 0; a < nA; a++) {   // :1847-1849, lexicographic max of (coverage, index)
+		if (g.componentMap[anchors[sc.compact[a]].lastNode] != cid) continue;
+		long long s = unpackScore(sc.C[a]);
+		if (s > bestScore || (s == bestScore && (long long)a > bestAnchor)) { bestScore = s; bestAnchor = a; }
+	}
+	return true;
+}
+
+__global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __restrict__ jobs, uint32_t nReads, const AnchorRec* __restrict__ anchors,
+	const Fragment* __restrict__ frags, const uint32_t* __restrict__ fragStatus, int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* __restrict__ scratch, uint64_t scratchStride,
+	uint32_t* __restrict__ chainOut, uint32_t* __restrict__ chainLen, unsigned long long* __restrict__ chainScore, uint32_t* __restrict__ chainStatus)
+{
+	const int lane = threadIdx.x;
+	ChainScratch sc = chainScratch(scratch + (uint64_t)blockIdx.x * scratchStride, caps);
+	for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
+		ReadChainJob job = jobs[r];
+		// the reference never resets its `cont` flag after a fragment whose extension threw, so fragments after the
+		// first failed one contribute no anchors (src/Aligner.cpp:695-703): slots from that fragment on are cut off
+		uint32_t cut = job.nSlots;
+		for (uint32_t f = lane; f < job.nFrags; f += 64)
+			if (fragStatus[job.fragBegin + f] == 1) { uint32_t c = frags[job.fragBegin + f].seedBegin - job.slotBegin; cut = c < cut ? c : cut; }
+		for (int d = 32; d > 0; d >>= 1) { uint32_t o = __shfl_xor(cut, d); cut = o < cut ? o : cut; }
+		// compact the read's valid anchors in slot order (== the order the reference pushes them, src/Aligner.cpp:706-721)
+		uint32_t nA = 0;
+		for (uint32_t s0 = 0; s0 < cut; s0 += 64) {
+			uint32_t s = s0 + lane;
+			bool valid = s < cut && anchors[job.slotBegin + s].valid != 0;
+			unsigned long long ballot = __ballot(valid);
+			if (valid) sc.compact[nA + (uint32_t)__popcll(ballot & ((1ull << lane) - 1))] = job.slotBegin + s;
+			nA += (uint32_t)__popcll(ballot);
+		}
+		__threadfence_block();
+		__syncthreads();
+		if (lane == 0) {
+			uint32_t status = 0;
+			long long best = 0; bool first = true;
+			uint32_t bestLen = 0;
+			uint32_t* out = chainOut + job.chainBegin;
+			long long lastCid = -1;
+			while (nA > 0) {   // components in ascending id; keep the first strictly greater score (:1713-1733)
+				long long cid = -1;
+				for (uint32_t a = 0; a < nA; a++) {
+					long long c = g.componentMap[anchors[sc.compact[a]].lastNode];
+					if (c > lastCid && (cid < 0 || c < cid)) cid = c;
+				}
+				if (cid < 0) break;
+				lastCid = cid;
+				long long score, anchor;
+				if (!chainComponent(g, anchors, sc, caps, nA, (uint32_t)cid, job.nKeys, splitLen, splitGap, score, anchor)) { status = 2; break; }
+				if (first || score > best) {
+					first = false;
+					best = score;
+					uint32_t n = 0;
+					for (long long i = anchor; i != -1; i = unpackAnchor(sc.C[i])) {   // :1851-1862
+						if (n >= job.nSlots) { status = 1; break; }
+						out[n++] = (uint32_t)i;
+					}
+					for (uint32_t i = 0; i < n / 2; i++) { uint32_t t = out[i]; out[i] = out[n - 1 - i]; out[n - 1 - i] = t; }
+					bestLen = n;
+				}
+			}
+			chainLen[r] = bestLen;
+			chainScore[r] = (unsigned long long)best;
+			chainStatus[r] = status;
+		}
+		__syncthreads();
+	}
+}
+
+// =====================================================================================================
+// launchers
+// =====================================================================================================
+
+void launchSeedLookup(hipStream_t stream, const SeedIndex& idx, const char* bases, const uint64_t* readOff, uint32_t nReads,
+	uint64_t* matchCursor, uint32_t* readMatchOff, uint32_t* readMatchCount, uint2* matches, uint64_t matchCapacity, uint32_t* tmp)
+{
+	if (nReads == 0) return;
+	uint32_t blocks = nReads < 16384 ? nReads : 16384;
+	hipLaunchKernelGGL(k_seed_lookup, dim3(blocks), dim3(64), 0, stream, idx, bases, readOff, nReads, matchCursor, readMatchOff, readMatchCount, matches, matchCapacity, tmp);
+}
+
+uint64_t extendSlabBytes(const ExtendConfig& cfg)
+{
+	uint64_t b = sizeof(SliceInfo) * (uint64_t)cfg.maxSlices + sizeof(NodeItem) * (uint64_t)cfg.maxItems + sizeof(Pending) * (uint64_t)cfg.maxPending + sizeof(WS) * 64 + sizeof(TraceCell) * (uint64_t)cfg.maxTrace;
+	return (b + 63) & ~63ull;
+}
+
+uint32_t extendGridLanes(uint32_t nWork)
+{
+	// 256 CUs x 16 resident waves is plenty to hide latency for this register-heavy kernel; never more lanes than work
+	uint32_t lanes = 256u * 16u * 64u;
+	uint32_t need = (nWork + 63) / 64 * 64;
+	return need < lanes ? need : lanes;
+}
+
+void launchExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg,
+	const ExtItem* work, uint32_t nWork, const char* bases, ExtResult* results, uint8_t* scratch, uint64_t slabBytes,
+	TraceCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters)
+{
+	if (nWork == 0) return;
+	uint32_t lanes = extendGridLanes(nWork);
+	hipLaunchKernelGGL(k_extend, dim3(lanes / 64), dim3(64), 0, stream, g, ct, iupac, cfg, work, nWork, bases, results, scratch, slabBytes, tracePool, traceCursor, traceCapacity, counters);
+}
+
+void launchBuildAnchors(hipStream_t stream, const DGraph& g, const Fragment* frags, uint32_t nFrags, const FragSeed* seeds, const ExtResult* ext,
+	const TraceCell* tracePool, int32_t splitLen, AnchorRec* anchors, uint32_t* fragStatus, uint32_t* fragExtended,
+	uint32_t* pathPool, unsigned long long* pathCursor, uint64_t pathCapacity)
+{
+	if (nFrags == 0) return;
+	hipLaunchKernelGGL(k_build_anchors, dim3((nFrags + 63) / 64), dim3(64), 0, stream, g, frags, nFrags, seeds, ext, tracePool, splitLen, anchors, fragStatus, fragExtended, pathPool, pathCursor, pathCapacity);
+}
+
+uint64_t chainScratchBytes(const ChainCaps& caps)
+{
+	uint64_t b = 8ull * caps.capAnchors + 8ull * caps.capEndpoints + 16ull * caps.capTable + 4ull * caps.capAnchors + 8ull * caps.capEndpoints + 4ull * caps.capAnchors;
+	return (b + 63) & ~63ull;
+}
+
+uint32_t chainGridBlocks(uint32_t nReads) { return nReads < 4096 ? nReads : 4096; }
+
+void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
+	int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* scratch, uint32_t* chainOut, uint32_t* chainLen, unsigned long long* chainScore, uint32_t* chainStatus)
+{
+	if (nReads == 0) return;
+	hipLaunchKernelGGL(k_chain, dim3(chainGridBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus);
+}
+
+} // namespace gcdev

@@ -1,0 +1,83 @@
+// Work-item / result records shared between the host pipeline and the HIP kernels, and the launch API.
+#pragma once
+#include "gc_device.hpp"
+
+namespace gcdev {
+
+struct SeedIndex {   // minimizer index in HBM (reference: MinimizerSeeder buckets, src/MinimizerSeeder.h:16-30)
+	const uint64_t* table;      // open addressing: (kmer << 32) | keyIndex, empty = all ones
+	uint32_t tableMask;
+	const uint64_t* startPos;   // [nKeys+1]
+	uint32_t nKeys;
+	uint32_t maxCount;
+	int32_t k, w;
+};
+
+struct ExtItem {     // one seed extension: align bases[seqOff .. seqOff+seqLen) starting just after (node, offset)
+	uint64_t seqOff;
+	uint32_t seqLen;
+	uint32_t node;
+	uint32_t offset;
+	uint32_t pad;
+};
+
+struct ExtResult {
+	uint64_t traceOff;
+	uint32_t traceLen;
+	uint32_t status;   // EXT_*
+	int32_t score;
+	uint32_t pad;
+};
+
+struct Fragment {    // one read fragment with its seed window [seedBegin, seedEnd) in the batch-wide seed array
+	uint32_t read;
+	uint32_t l;
+	uint32_t seedBegin, seedEnd;
+};
+
+struct FragSeed {    // a seed in fragment-pass order; node/offset = forward-strand split-node coordinates
+	uint32_t node, offset;
+	uint32_t seqPos;   // read position of the seed base
+	uint32_t pad;
+};
+
+struct AnchorRec {   // one slot per (fragment, seed); valid anchors are compacted per read by the chaining kernel
+	uint32_t valid;
+	uint32_t x, y;
+	uint32_t firstNode, firstOffset, firstSeqPos;   // Apos[0] (split node coords, seqPos inside the fragment)
+	uint32_t lastNode, lastOffset, lastSeqPos;      // Apos[1]
+	int32_t score;
+	uint32_t pathLen;
+	uint32_t pad;
+	uint64_t pathOff;
+};
+
+struct ReadChainJob {
+	uint32_t slotBegin, nSlots;   // this read's anchor slots
+	uint32_t chainBegin;          // where its chain goes in chainOut (capacity nSlots)
+	uint32_t nKeys;               // number of fragment positions of the read
+	uint32_t fragBegin, nFrags;   // this read's fragments (for the "no anchors after a failed fragment" rule)
+};
+
+struct ChainCaps { uint32_t capAnchors, capEndpoints, capTable; };
+
+// ---- launchers (all asynchronous on `stream`) ------------------------------------------------------
+void launchSeedLookup(hipStream_t stream, const SeedIndex& idx, const char* bases, const uint64_t* readOff, uint32_t nReads,
+	uint64_t* matchCursor, uint32_t* readMatchOff, uint32_t* readMatchCount, uint2* matches, uint64_t matchCapacity, uint32_t* tmp);
+
+uint64_t extendSlabBytes(const ExtendConfig& cfg);
+uint32_t extendGridLanes(uint32_t nWork);
+void launchExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg,
+	const ExtItem* work, uint32_t nWork, const char* bases, ExtResult* results, uint8_t* scratch, uint64_t slabBytes,
+	TraceCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters);
+
+void launchBuildAnchors(hipStream_t stream, const DGraph& g, const Fragment* frags, uint32_t nFrags, const FragSeed* seeds, const ExtResult* ext,
+	const TraceCell* tracePool, int32_t splitLen, AnchorRec* anchors, uint32_t* fragStatus, uint32_t* fragExtended,
+	uint32_t* pathPool, unsigned long long* pathCursor, uint64_t pathCapacity);
+
+uint64_t chainScratchBytes(const ChainCaps& caps);
+uint32_t chainGridBlocks(uint32_t nReads);
+void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
+	int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* scratch, uint32_t* chainOut, uint32_t* chainLen, unsigned long long* chainScore, uint32_t* chainStatus);
+
+} // namespace gcdev

@@ -1,0 +1,155 @@
+/* graphchainer_amd - C ABI of the MI355X-native GraphChainer hot path.
+ *
+ * The reference (algbio/GraphChainer) has no plugin/FFI layer; its de-facto seam is the free-function
+ * facade src/GraphAlignerWrapper.h:39-47 plus MinimizerSeeder::getSeeds (src/MinimizerSeeder.h:33) and
+ * AlignmentGraph::colinearChaining (src/AlignmentGraph.h:121), all called per read from
+ * runComponentMappings (src/Aligner.cpp:538,560,565,660,666,691,735). This library replaces that
+ * per-read call sequence with one batched call; every entry point cites what it stands in for.
+ * INTEGRATION.md shows the shim a maintainer would add to src/Aligner.cpp.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types. Every function returns 0 on success and
+ * a negative gc_status otherwise; gc_last_error() gives the message for the calling thread. Handles are
+ * immutable after creation and may be shared between threads; one gc_align_batch per gc_stream at a
+ * time (the reference's rule of one AlignerGraphsizedState per worker, src/Aligner.cpp:469).
+ * Per-read failures (the reference's per-read catch of AssertionFailure, src/Aligner.cpp:585-592) are
+ * reported in the result arrays, not as a call failure.
+ */
+#ifndef GRAPHCHAINER_AMD_H
+#define GRAPHCHAINER_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gc_status {
+	GC_OK = 0,
+	GC_ERR_INVALID = -1,      /* bad argument */
+	GC_ERR_GRAPH = -2,        /* invalid graph (reference: InvalidGraphException, cyclic graph) */
+	GC_ERR_DEVICE = -3,       /* HIP error or no device: the product path never falls back to the CPU */
+	GC_ERR_INTERNAL = -4
+} gc_status;
+
+typedef struct gc_graph gc_graph;     /* AlignmentGraph + MPC index, resident in HBM */
+typedef struct gc_seeder gc_seeder;   /* MinimizerSeeder index, resident in HBM */
+typedef struct gc_stream gc_stream;   /* per-worker reusable state (HIP stream + arenas) */
+typedef struct gc_reads gc_reads;     /* a batch of reads uploaded to HBM */
+
+/* Alignment parameters. Defaults = the reference's chaining-mode presets, src/AlignerMain.cpp:186-209. */
+typedef struct gc_params {
+	int32_t bandwidth;          /* -b, initialBandwidth (10) */
+	int32_t split_len;          /* --colinear-split-len (35) */
+	int32_t split_gap;          /* --colinear-split-gap (35); --sampling-step 0.5 == 18 */
+	int64_t colinear_gap;       /* --colinear-gap (10000) */
+	double  seed_density;       /* --seeds-minimizer-density (10) */
+	int32_t min_cluster_size;   /* --seeds-clustersize (1) */
+	int32_t long_pass;          /* 1: also run the whole-read GraphAligner pass (src/Aligner.cpp:630-654) */
+	int32_t keep_traces;        /* 1: return per-anchor traces (debug / parity tests) */
+} gc_params;
+
+void gc_params_default(gc_params* p);
+
+/* ---- graph (replaces getGraph + AlignmentGraph::buildMPC, src/Aligner.cpp:1137-1156) -------------- */
+
+/* Loads a GFA (S/L lines, 0M overlaps), builds the split-node DAG with the reference's node numbering,
+ * the MPC index, and uploads everything to the current HIP device. */
+int gc_graph_create_from_gfa(const char* gfa_path, gc_graph** out);
+
+/* Same, from arrays the existing C++ host already holds (src/AlignmentGraph.h:145-172): for a host that
+ * keeps its own AlignmentGraph. Adjacency is CSR in the reference's neighbour order. */
+typedef struct gc_graph_desc {
+	uint64_t n_nodes;                 /* split nodes */
+	uint64_t first_ambiguous;         /* nodes >= this index use ambiguous_seq */
+	const uint8_t*  node_length;      /* [n] 1..64 */
+	const uint32_t* node_offset;      /* [n] offset inside the original (bigraph) node */
+	const int32_t*  node_ids;         /* [n] bigraph node id (2*gfa_id + strand) */
+	const uint64_t* node_seq;         /* [2*first_ambiguous] 2 bits/bp */
+	const uint64_t* ambiguous_seq;    /* [4*(n-first_ambiguous)] one-hot A,T,C,G words */
+	const uint64_t* in_off;  const uint32_t* in_adj;    /* CSR [n+1], [m] */
+	const uint64_t* out_off; const uint32_t* out_adj;
+	const uint32_t* component_number; /* [n] topological rank (src/AlignmentGraph.cpp:1008) */
+	const uint32_t* chain_number;     /* [n] */
+	const uint64_t* chain_approx_pos; /* [n] */
+} gc_graph_desc;
+int gc_graph_create(const gc_graph_desc* desc, gc_graph** out);
+void gc_graph_destroy(gc_graph* g);
+
+/* Read-only views of the host copy (for parity tests and for hosts that want the numbering). */
+uint64_t gc_graph_num_nodes(const gc_graph* g);
+uint64_t gc_graph_size_bp(const gc_graph* g);
+/* name in {"nodeLength","nodeOffset","nodeIDs","reverse","componentNumber","chainNumber","chainApproxPos",
+ * "component_map","out_off","out_adj","in_off","in_adj","mpc_width"}; returns a malloc'd int64 array
+ * (free with gc_free). */
+int gc_graph_array(const gc_graph* g, const char* name, int64_t** out, uint64_t* count);
+
+/* ---- seeder (replaces MinimizerSeeder::MinimizerSeeder, src/Aligner.cpp:1162) --------------------- */
+int gc_seeder_create(const gc_graph* g, int32_t k, int32_t w, double keep_least_frequent_fraction, gc_seeder** out);
+void gc_seeder_destroy(gc_seeder* s);
+int gc_seeder_array(const gc_seeder* s, const char* name, int64_t** out, uint64_t* count);   /* "kmers","start","positions","maxcount" */
+
+/* ---- streams and read batches --------------------------------------------------------------------- */
+int gc_stream_create(gc_stream** out);
+void gc_stream_destroy(gc_stream* st);
+
+/* Uploads n reads (ASCII, concatenated; read i = bases[offsets[i] .. offsets[i+1])) to HBM. */
+int gc_reads_upload(const char* bases, const uint64_t* offsets, uint64_t n, gc_reads** out);
+void gc_reads_destroy(gc_reads* r);
+
+/* ---- the hot path ---------------------------------------------------------------------------------- */
+
+/* Flat (CSR) result of one batch. All arrays are host memory owned by the result; free with
+ * gc_result_free. Node ids are split-node indices unless stated otherwise. */
+typedef struct gc_result {
+	uint64_t n_reads;
+	/* seeds in fragment-pass order: MinimizerSeeder::getSeeds + OrderSeeds + sort by seqPos
+	 * (src/Aligner.cpp:660-667) */
+	uint64_t* read_seed_off;      /* [n_reads+1] */
+	uint32_t* seed_node; uint32_t* seed_offset; uint32_t* seed_seqpos; uint64_t* seed_goodness;
+	/* anchors = fragment alignments (src/Aligner.cpp:706-729) */
+	uint64_t* read_anchor_off;    /* [n_reads+1] */
+	uint32_t* anchor_x; uint32_t* anchor_y;
+	uint64_t* anchor_path_off;    /* [n_anchors+1] */
+	uint32_t* anchor_path;
+	uint32_t* anchor_first_node; uint32_t* anchor_first_offset; uint32_t* anchor_first_seqpos;
+	uint32_t* anchor_last_node;  uint32_t* anchor_last_offset;  uint32_t* anchor_last_seqpos;
+	int32_t*  anchor_score;
+	/* optional traces (keep_traces): bigraph node id, offset in original node, seqPos in the fragment */
+	uint64_t* anchor_trace_off;   /* [n_anchors+1] or NULL */
+	int32_t*  anchor_trace_node; uint32_t* anchor_trace_offset; uint32_t* anchor_trace_seqpos; uint8_t* anchor_trace_switch;
+	/* chain = AlignmentGraph::colinearChaining (src/Aligner.cpp:735): anchor indices local to the read */
+	uint64_t* read_chain_off;     /* [n_reads+1] */
+	uint32_t* chain;
+	uint64_t* chain_score;        /* [n_reads] covered read bases */
+	/* whole-read pass (long_pass): all alignments of AlignOneWay(sloppy), src/Aligner.cpp:565 */
+	uint64_t* read_longall_off;   /* [n_reads+1] */
+	uint32_t* longall_start; uint32_t* longall_end; uint32_t* longall_score;
+	uint64_t* long_trace_off;     /* [n_longall+1] */
+	int32_t*  long_trace_node; uint32_t* long_trace_offset; uint32_t* long_trace_seqpos; uint8_t* long_trace_switch;
+	/* per read flags */
+	uint8_t*  failed_assertion;   /* [n_reads] the reference would have thrown on this read */
+	uint64_t* seeds_extended;     /* [n_reads] */
+	/* work counters of this batch: dp tiles, recompute tiles, column steps, trace items, extensions */
+	uint64_t counters[8];
+	/* device time of each kernel of this batch in microseconds (HIP events on the stream):
+	 * [0] seed lookup, [1] fragment extension, [2] anchor build, [3] chaining, [4] long pass */
+	double kernel_us[8];
+	double host_us[4];            /* [0] seed glue, [1] result assembly */
+} gc_result;
+
+/* Runs seeding, fragment seed-extension, anchor construction and co-linear chaining (and, with
+ * params->long_pass, the whole-read pass) for every read of the batch. Replaces, per read:
+ * MinimizerSeeder::getSeeds, OrderSeeds, AlignOneWay, AlignmentGraph::colinearChaining. */
+int gc_align_batch(const gc_graph* g, const gc_seeder* s, gc_stream* st, const gc_reads* reads, const gc_params* params, gc_result** out);
+void gc_result_free(gc_result* r);
+
+const char* gc_last_error(void);
+void gc_free(void* p);
+int gc_device_count(void);
+int gc_set_device(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

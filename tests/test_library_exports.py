@@ -1,0 +1,47 @@
+"""CPU-side checks of the product library: it loads, exports every symbol of include/graphchainer_amd.h, and
+fails loudly (no fallback) when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import graphchainer_amd as gca
+    if not os.path.exists(gca.api.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return gca.load_library()
+
+
+def test_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "graphchainer_amd.h")).read()
+    declared = set(re.findall(r"\b(gc_[a-z_]+)\s*\(", header))
+    from graphchainer_amd.api import EXPORTED_SYMBOLS
+    assert declared == set(EXPORTED_SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_no_cpu_fallback_without_gpu(lib):
+    import graphchainer_amd as gca
+    if gca.device_count() > 0:
+        pytest.skip("a GPU is present")
+    handle = C.c_void_p()
+    rc = lib.gc_graph_create_from_gfa(os.path.join(ROOT, "tests", "golden", "ref_test_graph.gfa").encode(), C.byref(handle))
+    assert rc == -3   # GC_ERR_DEVICE
+    assert b"no CPU fallback" in lib.gc_last_error()
+
+
+def test_product_does_not_touch_the_oracle():
+    """The product sources must not include, link or import anything under oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "graphchainer_amd")):
+        for f in files:
+            if f.endswith((".so", ".pyc")):
+                continue
+            text = open(os.path.join(dirpath, f), errors="ignore").read()
+            assert "oracle/" not in text.replace("under oracle/", "") and "from oracle" not in text and "import oracle" not in text, os.path.join(dirpath, f)
