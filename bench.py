@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X GraphChainer hot path (BASELINE.json metric: reads/s and Gbp/s aligned).
+
+One "step" = one pass of the hot path (seed lookup -> seed ordering -> fragment seed-extension -> anchors ->
+co-linear chaining) over one batch of synthetic reads that is already resident in HBM.
+
+Workload at N=1 = BASELINE.json configs[1]: chr22-like graph (50.8 Mbp backbone, SNP/indel bubbles every ~45 bp,
+SURVEY.md §8d) and 10 000 simulated 10 kb ONT-like reads, reference defaults. For N>1 every rank aligns its own
+10 000-read shard against its own replica of the graph (read-parallel, no data-path collective): weak scaling.
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W]
+       (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_PER_TILE = 200           # algorithmic bytes of one (node, 64-row slice) tile
+BYTES_PER_BACKTRACE_TILE = 176  # 80 + 80 + 16 per (slice, node) visited by the backtrace
+BYTES_PER_TRACE_ITEM = 32
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--backbone", type=int, default=int(os.environ.get("GC_BENCH_BACKBONE", 50_800_000)))
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("GC_BENCH_READS", 10_000)))
+    ap.add_argument("--read-len", type=int, default=10_000)
+    ap.add_argument("--split-gap", type=int, default=35)
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("GC_BENCH_CPU_SAMPLE", 1500)), help="reads of the same workload timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import torch
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        # reads shard embarrassingly: the only cross-rank traffic is the barrier and the max-over-ranks of the step time
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(local_rank)
+
+    import graphchainer_amd as gca
+    from graphchainer_amd.synth import SynthGraph
+
+    if gca.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    gca.set_device(local_rank)
+
+    t0 = time.time()
+    tmp = tempfile.mkdtemp(prefix="gcbench_")
+    gfa = os.path.join(tmp, "graph.gfa")
+    sg = SynthGraph(args.backbone, seed=7)
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(args.reads, args.read_len, seed=11 + rank)   # every rank draws its own shard
+    t_gen = time.time() - t0
+    t0 = time.time()
+    graph = gca.AlignmentGraph(gfa)
+    t_graph = time.time() - t0
+    t0 = time.time()
+    seeder = gca.MinimizerSeeder(graph)
+    t_index = time.time() - t0
+    aligner = gca.Aligner(graph, seeder, split_gap=args.split_gap)
+    batch = gca.ReadBatch(reads)          # inputs resident in HBM before the timed region
+    total_bases = int(batch.lengths.sum())
+
+    def sync():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = aligner.align_batch(batch)
+    sync()
+    t_start = time.perf_counter()
+    kernel_us = np.zeros(8)
+    host_us = np.zeros(4)
+    counters = np.zeros(8, dtype=np.float64)
+    for _ in range(args.steps):
+        out = aligner.align_batch(batch)     # returns after the stream is drained (hipStreamSynchronize inside)
+        kernel_us += out["kernel_us"]
+        host_us += out["host_us"]
+        counters += out["counters"].astype(np.float64)
+    sync()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_us /= max(1, args.steps)
+    host_us /= max(1, args.steps)
+    counters /= max(1, args.steps)
+
+    chain_len = np.diff(out["read_chain_off"])
+    aligned_bases = int(batch.lengths[chain_len > 0].sum())
+    reads_total = args.reads * world * args.steps
+    reads_per_s = reads_total / elapsed
+    gbp_per_s = aligned_bases * world * args.steps / elapsed / 1e9
+
+    # roofline of the dominant kernel (k_extend): algorithmic bytes per launch / its HIP-event duration
+    dp_tiles, recompute_tiles, column_steps, trace_items, extensions, backtrace_tiles = counters[:6]
+    ext_bytes = BYTES_PER_TILE * (dp_tiles + recompute_tiles) + BYTES_PER_BACKTRACE_TILE * backtrace_tiles + BYTES_PER_TRACE_ITEM * trace_items
+    ext_seconds = kernel_us[1] * 1e-6
+    achieved = ext_bytes / ext_seconds / 1e9 if ext_seconds > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "algorithmic_bytes_per_launch": int(ext_bytes), "avg_launch_ms": round(kernel_us[1] / 1e3, 3),
+                "tiles_per_launch": int(dp_tiles + recompute_tiles), "column_steps_per_s": round(column_steps / ext_seconds / 1e9, 3) if ext_seconds > 0 else 0.0}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import Oracle   # the CPU baseline leg is the one place bench.py may touch the oracle
+        n_sample = min(args.cpu_sample, len(reads))
+        ora = Oracle(gfa, long_pass=False, split_gap=args.split_gap)
+        t0 = time.perf_counter()
+        ora.align(reads[:n_sample])
+        cpu_t = time.perf_counter() - t0
+        cpu_baseline = {"value": round(n_sample / cpu_t, 2), "unit": "reads/s", "cores": 1, "kind": "port",
+                        "sample": f"first {n_sample} reads of the same workload, same stages (seeding, fragment extension, anchors, chaining), 1 thread, {cpu_t:.1f} s"}
+
+    if rank == 0:
+        line = {
+            "metric": "reads_per_sec", "value": round(reads_per_s, 2), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "gbp_per_sec_aligned": round(gbp_per_s, 5),
+            "config": {"workload": f"BASELINE configs[1]: chr22-like synthetic DAG ({args.backbone} bp backbone, {graph.NodeSize()} split nodes), "
+                                   f"{args.reads} x {args.read_len} bp ONT-like reads per GPU, split_len 35 split_gap {args.split_gap} bandwidth 10",
+                       "stages": "seed lookup + seed ordering + fragment seed-extension + anchors + co-linear chaining (whole-read pass not included yet)",
+                       "reads_per_gpu": args.reads, "read_len": args.read_len, "parallelism": f"read-sharded x{world}, graph replicated, no collective"},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "stage_ms": {"k_seed_lookup": round(kernel_us[0] / 1e3, 3), "k_extend": round(kernel_us[1] / 1e3, 3), "k_build_anchors": round(kernel_us[2] / 1e3, 3),
+                         "k_chain": round(kernel_us[3] / 1e3, 3), "host_seed_glue": round(host_us[0] / 1e3, 3), "host_result_assembly": round(host_us[1] / 1e3, 3)},
+            "setup_s": {"generate": round(t_gen, 1), "graph_build_upload": round(t_graph, 1), "minimizer_index": round(t_index, 1)},
+            "reads_with_chain": int((chain_len > 0).sum()), "extensions_per_step": int(extensions),
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -185,7 +185,7 @@ struct LaneScratch {
 	TraceCell* trace;
 };
 
-struct ExtCounters { unsigned long long dpTiles, recomputeTiles, columnSteps, traceItems, extensions; };
+struct ExtCounters { unsigned long long dpTiles, recomputeTiles, columnSteps, traceItems, extensions, backtraceTiles; };
 
 // 4 match masks (A,C,G,T) of read rows j..j+63. reference: ...Common.h:280-319. iupac[c] = set of bases c matches.
 __device__ inline void eqVector(const char* seq, int len, int j, const uint8_t* iupac, uint64_t eq[4])
@@ -359,6 +359,7 @@ __device__ inline void recomputeColumns(const DGraph& g, const LaneScratch& sc, 
 		prevExists ? sc.items[prevIdx].HP : ~0ull, prevExists ? sc.items[prevIdx].HN : 0ull, eq, scratch, sc.columns, 0, status);
 	if (scratch.eVP != it.eVP || scratch.eVN != it.eVN || scratch.eScore != it.eScore) status = EXT_ASSERT;   // sliceConsistency, :848-850
 	cnt.recomputeTiles++;
+	cnt.backtraceTiles++;
 	cnt.columnSteps += g.nodeLength[it.node];
 }
 

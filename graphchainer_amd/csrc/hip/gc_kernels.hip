@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(64) k_extend(DGraph g, const CorrectnessTables
 	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t stride = gridDim.x * blockDim.x;
 	LaneScratch sc = laneScratch(scratch + (uint64_t)tid * slabBytes, cfg);
-	ExtCounters cnt { 0, 0, 0, 0, 0 };
+	ExtCounters cnt { 0, 0, 0, 0, 0, 0 };
 	for (uint32_t w = tid; w < nWork; w += stride) {
 		ExtItem it = work[w];
 		uint32_t nTrace = 0;
@@ -167,6 +167,7 @@ __global__ void __launch_bounds__(64) k_extend(DGraph g, const CorrectnessTables
 		atomicAdd(&counters[2], cnt.columnSteps);
 		atomicAdd(&counters[3], cnt.traceItems);
 		atomicAdd(&counters[4], cnt.extensions);
+		atomicAdd(&counters[5], cnt.backtraceTiles);
 	}
 }
 

@@ -130,7 +130,8 @@ typedef struct gc_result {
 	/* per read flags */
 	uint8_t*  failed_assertion;   /* [n_reads] the reference would have thrown on this read */
 	uint64_t* seeds_extended;     /* [n_reads] */
-	/* work counters of this batch: dp tiles, recompute tiles, column steps, trace items, extensions */
+	/* work counters of this batch: [0] dp tiles, [1] recompute tiles (last-slice flatten + backtrace), [2] column steps,
+	 * [3] trace items, [4] extensions, [5] backtrace tiles (subset of [1]) */
 	uint64_t counters[8];
 	/* device time of each kernel of this batch in microseconds (HIP events on the stream):
 	 * [0] seed lookup, [1] fragment extension, [2] anchor build, [3] chaining, [4] long pass */
