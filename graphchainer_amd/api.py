@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
 
 class GcParams(C.Structure):
     _fields_ = [("bandwidth", C.c_int32), ("split_len", C.c_int32), ("split_gap", C.c_int32), ("colinear_gap", C.c_int64),
-                ("seed_density", C.c_double), ("min_cluster_size", C.c_int32), ("long_pass", C.c_int32), ("keep_traces", C.c_int32)]
+                ("seed_density", C.c_double), ("min_cluster_size", C.c_int32), ("long_pass", C.c_int32), ("keep_traces", C.c_int32), ("keep_seeds", C.c_int32)]
 
 
 _P = C.POINTER
@@ -203,7 +203,7 @@ _RESULT_FIELDS = {
 class Aligner:
     """Batched stand-in for the reference's per-read hot path (src/Aligner.cpp:601-922)."""
 
-    def __init__(self, graph, seeder, bandwidth=10, split_len=35, split_gap=35, colinear_gap=10000, seed_density=10.0, keep_traces=False):
+    def __init__(self, graph, seeder, bandwidth=10, split_len=35, split_gap=35, colinear_gap=10000, seed_density=10.0, keep_traces=False, keep_seeds=False):
         self.lib = load_library()
         self.graph = graph
         self.seeder = seeder
@@ -215,6 +215,7 @@ class Aligner:
         self.params.colinear_gap = colinear_gap
         self.params.seed_density = seed_density
         self.params.keep_traces = int(keep_traces)
+        self.params.keep_seeds = int(keep_seeds)
         self.stream = C.c_void_p()
         _check(self.lib.gc_stream_create(C.byref(self.stream)))
 

@@ -8,6 +8,9 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -58,19 +61,92 @@ struct DeviceBuffer {   // growable device allocation owned by a stream object
 
 double nowUs() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-template <typename F>
-void parallelFor(size_t n, F&& body)
-{
-	unsigned hw = std::thread::hardware_concurrency();
-	size_t nThreads = std::min<size_t>(std::max(1u, hw), std::max<size_t>(1, n / 4));
-	if (const char* env = getenv("GC_HOST_THREADS")) nThreads = (size_t)std::max(1, atoi(env));
-	if (nThreads <= 1) { for (size_t i = 0; i < n; i++) body(i); return; }
+// Persistent worker pool for the per-read host glue (threads are created once per process).
+class WorkerPool {
+public:
+	static WorkerPool& instance() { static WorkerPool p; return p; }
+	size_t size() const { return workers.size() + 1; }
+	// runs body(i, worker) for i in [0, n); worker in [0, size())
+	void run(size_t n, const std::function<void(size_t, size_t)>& body)
+	{
+		if (n == 0) return;
+		if (workers.empty() || n < 4) { for (size_t i = 0; i < n; i++) body(i, 0); return; }
+		{
+			std::unique_lock<std::mutex> lock(mutex);
+			job = &body;
+			total = n;
+			next.store(0);
+			pending = workers.size();
+			generation++;
+		}
+		wake.notify_all();
+		work(0);
+		std::unique_lock<std::mutex> lock(mutex);
+		done.wait(lock, [&]() { return pending == 0; });
+		job = nullptr;
+	}
+private:
+	WorkerPool()
+	{
+		size_t n = std::max(1u, std::thread::hardware_concurrency());
+		n = std::min<size_t>(n, 96);   // the glue is memory-bound; more threads stop helping
+		if (const char* env = getenv("GC_HOST_THREADS")) n = (size_t)std::max(1, atoi(env));
+		for (size_t t = 1; t < n; t++) workers.emplace_back([this, t]() { loop(t); });
+	}
+	~WorkerPool()
+	{
+		{ std::unique_lock<std::mutex> lock(mutex); stop = true; generation++; }
+		wake.notify_all();
+		for (auto& w : workers) w.join();
+	}
+	void work(size_t id)
+	{
+		const size_t chunk = 4;
+		for (size_t i; (i = next.fetch_add(chunk)) < total;)
+			for (size_t k = i; k < std::min(total, i + chunk); k++) (*job)(k, id);
+	}
+	void loop(size_t id)
+	{
+		size_t seen = 0;
+		while (true) {
+			{
+				std::unique_lock<std::mutex> lock(mutex);
+				wake.wait(lock, [&]() { return generation != seen; });
+				seen = generation;
+				if (stop) return;
+			}
+			work(id);
+			std::unique_lock<std::mutex> lock(mutex);
+			if (--pending == 0) done.notify_one();
+		}
+	}
+	std::vector<std::thread> workers;
+	std::mutex mutex;
+	std::condition_variable wake, done;
+	const std::function<void(size_t, size_t)>* job = nullptr;
 	std::atomic<size_t> next { 0 };
-	std::vector<std::thread> pool;
-	for (size_t t = 0; t < nThreads; t++)
-		pool.emplace_back([&]() { for (size_t i; (i = next.fetch_add(1)) < n;) body(i); });
-	for (auto& th : pool) th.join();
-}
+	size_t total = 0, pending = 0, generation = 0;
+	bool stop = false;
+};
+
+struct PinnedBuffer {   // growable page-locked host staging buffer (full-rate PCIe copies)
+	void* ptr = nullptr;
+	size_t bytes = 0;
+	template <typename T> T* reserve(size_t count)
+	{
+		size_t need = std::max<size_t>(count, 1) * sizeof(T);
+		if (need > bytes) {
+			if (ptr) HIP_CHECK(hipHostFree(ptr));
+			ptr = nullptr;
+			bytes = 0;
+			size_t want = need + need / 8 + 4096;
+			HIP_CHECK(hipHostMalloc(&ptr, want, hipHostMallocDefault));
+			bytes = want;
+		}
+		return (T*)ptr;
+	}
+	~PinnedBuffer() { if (ptr) (void)hipHostFree(ptr); }
+};
 
 template <typename T> T* mallocArray(size_t n) { return (T*)malloc(std::max<size_t>(n, 1) * sizeof(T)); }
 
@@ -108,6 +184,7 @@ struct gc_stream {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[12] {};
 	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, work, results, scratch, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
+	PinnedBuffer hMatches, hWork, hFrags, hFragSeeds, hJobs, hAnchors, hFragStatus, hFragExtended, hChainOut, hChainLen, hChainScore, hChainStatus, hPathPool, hSmall;
 	~gc_stream()
 	{
 		for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -199,7 +276,7 @@ static void uploadGraph(gc_graph* G)
 		}
 	}
 	// MPC index, flattened to global node ids
-	std::vector<uint32_t> pathsOff(n + 1, 0), pathsFlat, backOff(n + 1, 0), backNode, backPath, mpcWidth(h.mpc.size());
+	std::vector<uint32_t> pathsOff(n + 1, 0), pathsFlat, pathsPos, backOff(n + 1, 0), backNode, backPath, backPos, mpcWidth(h.mpc.size());
 	for (size_t c = 0; c < h.mpc.size(); c++) { mpcWidth[c] = (uint32_t)h.mpc[c].size(); G->maxMpcWidth = std::max(G->maxMpcWidth, mpcWidth[c]); }
 	for (size_t i = 0; i < n; i++) {
 		size_t c = h.component_map[i], x = h.component_idx[i];
@@ -207,6 +284,24 @@ static void uploadGraph(gc_graph* G)
 		pathsOff[i + 1] = (uint32_t)pathsFlat.size();
 		for (const auto& b : h.backwards[c][x]) { backNode.push_back((uint32_t)h.component_ids[c][b.first]); backPath.push_back((uint32_t)b.second); }
 		backOff[i + 1] = (uint32_t)backNode.size();
+	}
+	// position of every node on every path through it (paths[v] lists path ids in ascending order, and a path visits
+	// its nodes in order, so walking path k in order fills the (v,k) entries)
+	pathsPos.assign(pathsFlat.size(), 0);
+	backPos.assign(backNode.size(), 0);
+	{
+		auto posOf = [&](uint32_t node, uint32_t k) -> uint32_t {
+			for (uint32_t e = pathsOff[node]; e < pathsOff[node + 1]; e++) if (pathsFlat[e] == k) return pathsPos[e];
+			throw std::runtime_error("MPC index: node not on path");
+		};
+		for (size_t c = 0; c < h.mpc.size(); c++)
+			for (size_t k = 0; k < h.mpc[c].size(); k++)
+				for (size_t j = 0; j < h.mpc[c][k].size(); j++) {
+					size_t node = h.mpc[c][k][j];
+					for (uint32_t e = pathsOff[node]; e < pathsOff[node + 1]; e++) if (pathsFlat[e] == k) pathsPos[e] = (uint32_t)j;   // last visit wins, as in last2reach (:1340-1345)
+				}
+		for (size_t i = 0; i < n; i++)
+			for (uint32_t e = backOff[i]; e < backOff[i + 1]; e++) backPos[e] = posOf(backNode[e], backPath[e]);
 	}
 	DGraph& d = G->dev;
 	d.nNodes = (uint32_t)n;
@@ -222,8 +317,8 @@ static void uploadGraph(gc_graph* G)
 	d.origSize = G->up(origSize); d.lookupOff = G->up(lookupOff); d.lookup = G->up(lookup);
 	d.componentMap = G->up(componentMap);
 	d.topoId = G->up(topoId);
-	d.pathsOff = G->up(pathsOff); d.paths = G->up(pathsFlat);
-	d.backOff = G->up(backOff); d.backNode = G->up(backNode); d.backPath = G->up(backPath);
+	d.pathsOff = G->up(pathsOff); d.paths = G->up(pathsFlat); d.pathsPos = G->up(pathsPos);
+	d.backOff = G->up(backOff); d.backNode = G->up(backNode); d.backPath = G->up(backPath); d.backPos = G->up(backPos);
 	d.mpcWidth = G->up(mpcWidth);
 	CorrectnessTables t;
 	buildCorrectnessTables(t);
@@ -263,6 +358,7 @@ struct ReadGlue {
 	std::vector<gc::FragmentWindow> windows;
 	bool failed = false;
 	uint64_t slotBegin = 0, fragBegin = 0;
+	uint64_t nAnchors = 0, nPath = 0, nTrace = 0, anchorBegin = 0, pathBegin = 0, traceBegin = 0, seedBegin = 0, chainBegin = 0;
 };
 
 template <typename T> T* copyOut(const std::vector<T>& v)
@@ -302,6 +398,7 @@ void gc_params_default(gc_params* p)
 	p->min_cluster_size = 1;
 	p->long_pass = 0;
 	p->keep_traces = 0;
+	p->keep_seeds = 0;
 }
 
 int gc_graph_create_from_gfa(const char* gfa_path, gc_graph** out)
@@ -542,10 +639,12 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		const uint64_t n = R->offsets.size() - 1;
 		const gc::AlignmentGraph& hg = G->host;
 		hipStream_t stream = st->stream;
+		WorkerPool& pool = WorkerPool::instance();
 		res->n_reads = n;
 		int evIdx = 0;
 		auto mark = [&]() { HIP_CHECK(hipEventRecord(st->ev[evIdx++], stream)); };
 		auto elapsedUs = [&](int a, int b) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, st->ev[a], st->ev[b])); return (double)ms * 1000.0; };
+		double tTotal = nowUs();
 
 		// ---------------- K1: seed lookup
 		uint32_t* dTmp = st->tmp.reserve<uint32_t>(R->totalBases);
@@ -554,33 +653,36 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		uint32_t* dReadMatchCount = st->readMatchCount.reserve<uint32_t>(n);
 		unsigned long long* dCursors = st->cursors.reserve<unsigned long long>(8);
 		unsigned long long* dCounters = st->counters.reserve<unsigned long long>(8);
+		unsigned long long* hSmall = st->hSmall.reserve<unsigned long long>(16 + 2 * n);
+		uint32_t* readMatchOff = (uint32_t*)(hSmall + 16);
+		uint32_t* readMatchCount = readMatchOff + n;
 		HIP_CHECK(hipMemsetAsync(dCursors, 0, 8 * sizeof(unsigned long long), stream));
 		HIP_CHECK(hipMemsetAsync(dCounters, 0, 8 * sizeof(unsigned long long), stream));
 		mark();   // 0
 		launchSeedLookup(stream, S->dev, R->devBases, R->devOffsets, (uint32_t)n, (uint64_t*)dCursors, dReadMatchOff, dReadMatchCount, dMatches, R->totalBases, dTmp);
 		mark();   // 1
-		std::vector<uint32_t> readMatchOff(n), readMatchCount(n);
-		unsigned long long cursors[8];
-		HIP_CHECK(hipMemcpyAsync(readMatchOff.data(), dReadMatchOff, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipMemcpyAsync(readMatchCount.data(), dReadMatchCount, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipMemcpyAsync(cursors, dCursors, sizeof(cursors), hipMemcpyDeviceToHost, stream));
+		if (n) HIP_CHECK(hipMemcpyAsync(readMatchOff, dReadMatchOff, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		if (n) HIP_CHECK(hipMemcpyAsync(readMatchCount, dReadMatchCount, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipMemcpyAsync(hSmall, dCursors, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		HIP_CHECK(hipStreamSynchronize(stream));
-		std::vector<gc::KmerMatch> matches(cursors[0]);
-		if (cursors[0]) HIP_CHECK(hipMemcpy(matches.data(), dMatches, cursors[0] * sizeof(uint2), hipMemcpyDeviceToHost));
+		uint64_t nMatches = hSmall[0];
+		gc::KmerMatch* matches = st->hMatches.reserve<gc::KmerMatch>(nMatches);
+		if (nMatches) HIP_CHECK(hipMemcpyAsync(matches, dMatches, nMatches * sizeof(uint2), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
 		res->kernel_us[0] = elapsedUs(0, 1);
+		res->host_us[2] = nowUs() - tTotal;   // K1 + its transfers, wall
 
 		// ---------------- host glue: order-critical sorts and fragment windows (see host/gc_glue.hpp)
 		double tGlue = nowUs();
 		std::vector<ReadGlue> glue(n);
-		parallelFor(n, [&](size_t r) {
+		std::vector<gc::GlueScratch> scratch(pool.size());
+		pool.run(n, [&](size_t r, size_t worker) {
 			ReadGlue& gl = glue[r];
 			size_t len = R->offsets[r + 1] - R->offsets[r];
 			if (R->invalid[r]) { gl.failed = true; return; }
-			gc::expandSeeds(S->host, matches.data() + readMatchOff[r], readMatchCount[r], len, P->seed_density, gl.seeds);
+			gc::expandSeeds(S->host, matches + readMatchOff[r], readMatchCount[r], len, P->seed_density, gl.seeds, scratch[worker]);
 			if (gl.seeds.empty()) return;
-			try {
-				gc::orderSeedsByChaining(hg, gl.seeds);
-			} catch (const std::exception&) {
+			if (!gc::orderSeedsByChaining(hg, gl.seeds, scratch[worker])) {
 				gl.failed = true;
 				gl.seeds.clear();
 				return;
@@ -591,21 +693,22 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		for (uint64_t r = 0; r < n; r++) {
 			glue[r].slotBegin = nSlots;
 			glue[r].fragBegin = nFrags;
+			glue[r].seedBegin = nSeedsTotal;
 			for (const auto& w : glue[r].windows) nSlots += w.sr - w.sl;
 			nFrags += glue[r].windows.size();
 			nSeedsTotal += glue[r].seeds.size();
 		}
 		if (2 * nSlots >= 0xffffffffull) throw std::runtime_error("batch too large: more than 2^31 fragment seeds; split the batch");
-		std::vector<Fragment> frags(nFrags);
-		std::vector<FragSeed> fragSeeds(nSlots);
-		std::vector<ExtItem> work(2 * nSlots);
-		std::vector<ReadChainJob> jobs(n);
-		uint64_t traceBudget = 0;
-		ChainCaps caps { 1, 1, 1 };
-		parallelFor(n, [&](size_t r) {
+		Fragment* frags = st->hFrags.reserve<Fragment>(nFrags);
+		FragSeed* fragSeeds = st->hFragSeeds.reserve<FragSeed>(nSlots);
+		ExtItem* work = st->hWork.reserve<ExtItem>(2 * nSlots);
+		ReadChainJob* jobs = st->hJobs.reserve<ReadChainJob>(n);
+		std::vector<uint64_t> traceBudgets(pool.size(), 0);
+		pool.run(n, [&](size_t r, size_t worker) {
 			const ReadGlue& gl = glue[r];
 			size_t len = R->offsets[r + 1] - R->offsets[r];
 			uint64_t slot = gl.slotBegin;
+			uint64_t budget = 0;
 			for (size_t f = 0; f < gl.windows.size(); f++) {
 				const gc::FragmentWindow& w = gl.windows[f];
 				Fragment& fr = frags[gl.fragBegin + f];
@@ -634,9 +737,11 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					fw.node = s.node;
 					fw.offset = s.offset;
 					fw.pad = 0;
+					budget += (b.seqLen ? b.seqLen + 24 : 0) + (fw.seqLen ? fw.seqLen + 24 : 0);
 				}
 				fr.seedEnd = (uint32_t)slot;
 			}
+			traceBudgets[worker] += budget;
 			ReadChainJob& job = jobs[r];
 			job.slotBegin = (uint32_t)gl.slotBegin;
 			job.nSlots = (uint32_t)(slot - gl.slotBegin);
@@ -645,15 +750,14 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			job.fragBegin = (uint32_t)gl.fragBegin;
 			job.nFrags = (uint32_t)gl.windows.size();
 		});
-		for (uint64_t r = 0; r < n; r++) {
-			caps.capAnchors = std::max(caps.capAnchors, jobs[r].nSlots);
-			caps.capTable = std::max<uint32_t>(caps.capTable, std::max(1u, G->maxMpcWidth) * jobs[r].nKeys);
-		}
-		caps.capEndpoints = caps.capAnchors * (2 + std::max(1u, G->maxMpcWidth));
-		for (const ExtItem& it : work) traceBudget += it.seqLen ? it.seqLen + 24 : 0;
+		uint64_t traceBudget = 0;
+		for (uint64_t b : traceBudgets) traceBudget += b;
+		ChainCaps caps { 1, 1, 1 };
+		for (uint64_t r = 0; r < n; r++) caps.capAnchors = std::max(caps.capAnchors, jobs[r].nSlots);
 		res->host_us[0] = nowUs() - tGlue;
 
-		// ---------------- K3: fragment seed extension
+		// ---------------- K3 / K3b / K4
+		double tDev = nowUs();
 		ExtendConfig cfg;
 		cfg.bandwidth = P->bandwidth;
 		cfg.maxSlices = 3;
@@ -663,7 +767,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		if (const char* env = getenv("GC_EXT_MAX_ITEMS")) cfg.maxItems = (uint32_t)std::max(8, atoi(env));
 		if (const char* env = getenv("GC_EXT_MAX_PENDING")) cfg.maxPending = (uint32_t)std::max(8, atoi(env));
 		if (const char* env = getenv("GC_EXT_MAX_TRACE")) cfg.maxTrace = (uint32_t)std::max(64, atoi(env));
-		uint32_t nWork = (uint32_t)work.size();
+		uint32_t nWork = (uint32_t)(2 * nSlots);
 		uint64_t slabBytes = extendSlabBytes(cfg);
 		uint32_t lanes = extendGridLanes(nWork);
 		ExtItem* dWork = st->work.reserve<ExtItem>(nWork);
@@ -684,10 +788,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		uint32_t* dChainStatus = st->chainStatus.reserve<uint32_t>(n);
 		uint32_t chainBlocks = chainGridBlocks((uint32_t)n);
 		uint8_t* dChainScratch = st->chainScratch.reserve<uint8_t>((uint64_t)std::max(1u, chainBlocks) * chainScratchBytes(caps));
-		if (nWork) HIP_CHECK(hipMemcpyAsync(dWork, work.data(), nWork * sizeof(ExtItem), hipMemcpyHostToDevice, stream));
-		if (nFrags) HIP_CHECK(hipMemcpyAsync(dFrags, frags.data(), nFrags * sizeof(Fragment), hipMemcpyHostToDevice, stream));
-		if (nSlots) HIP_CHECK(hipMemcpyAsync(dFragSeeds, fragSeeds.data(), nSlots * sizeof(FragSeed), hipMemcpyHostToDevice, stream));
-		HIP_CHECK(hipMemcpyAsync(dJobs, jobs.data(), n * sizeof(ReadChainJob), hipMemcpyHostToDevice, stream));
+		if (nWork) HIP_CHECK(hipMemcpyAsync(dWork, work, (size_t)nWork * sizeof(ExtItem), hipMemcpyHostToDevice, stream));
+		if (nFrags) HIP_CHECK(hipMemcpyAsync(dFrags, frags, nFrags * sizeof(Fragment), hipMemcpyHostToDevice, stream));
+		if (nSlots) HIP_CHECK(hipMemcpyAsync(dFragSeeds, fragSeeds, nSlots * sizeof(FragSeed), hipMemcpyHostToDevice, stream));
+		if (n) HIP_CHECK(hipMemcpyAsync(dJobs, jobs, n * sizeof(ReadChainJob), hipMemcpyHostToDevice, stream));
 		mark();   // 2
 		launchExtend(stream, G->dev, G->devTables, G->devIupac, cfg, dWork, nWork, R->devBases, dResults, dScratch, slabBytes, dTrace, dCursors + 1, traceBudget, dCounters);
 		mark();   // 3
@@ -696,132 +800,172 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		launchChain(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, P->split_len, P->split_gap, caps, dChainScratch, dChainOut, dChainLen, dChainScore, dChainStatus);
 		mark();   // 5
 
-		// ---------------- results back
-		std::vector<AnchorRec> anchors(nSlots);
-		std::vector<uint32_t> fragStatus(nFrags), fragExtended(nFrags), chainOut(nSlots), chainLen(n), chainStatus(n);
-		std::vector<unsigned long long> chainScore(n);
-		unsigned long long counters[8];
-		if (nSlots) HIP_CHECK(hipMemcpyAsync(anchors.data(), dAnchors, nSlots * sizeof(AnchorRec), hipMemcpyDeviceToHost, stream));
-		if (nFrags) HIP_CHECK(hipMemcpyAsync(fragStatus.data(), dFragStatus, nFrags * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		if (nFrags) HIP_CHECK(hipMemcpyAsync(fragExtended.data(), dFragExtended, nFrags * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		if (nSlots) HIP_CHECK(hipMemcpyAsync(chainOut.data(), dChainOut, nSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipMemcpyAsync(chainLen.data(), dChainLen, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipMemcpyAsync(chainStatus.data(), dChainStatus, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipMemcpyAsync(chainScore.data(), dChainScore, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipMemcpyAsync(cursors, dCursors, sizeof(cursors), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipMemcpyAsync(counters, dCounters, sizeof(counters), hipMemcpyDeviceToHost, stream));
+		// ---------------- results back (pinned staging)
+		AnchorRec* anchors = st->hAnchors.reserve<AnchorRec>(nSlots);
+		uint32_t* fragStatus = st->hFragStatus.reserve<uint32_t>(nFrags);
+		uint32_t* fragExtended = st->hFragExtended.reserve<uint32_t>(nFrags);
+		uint32_t* chainOut = st->hChainOut.reserve<uint32_t>(nSlots);
+		uint32_t* chainLen = st->hChainLen.reserve<uint32_t>(n);
+		unsigned long long* chainScore = st->hChainScore.reserve<unsigned long long>(n);
+		uint32_t* chainStatus = st->hChainStatus.reserve<uint32_t>(n);
+		if (nSlots) HIP_CHECK(hipMemcpyAsync(anchors, dAnchors, nSlots * sizeof(AnchorRec), hipMemcpyDeviceToHost, stream));
+		if (nFrags) HIP_CHECK(hipMemcpyAsync(fragStatus, dFragStatus, nFrags * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		if (nFrags) HIP_CHECK(hipMemcpyAsync(fragExtended, dFragExtended, nFrags * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		if (nSlots) HIP_CHECK(hipMemcpyAsync(chainOut, dChainOut, nSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		if (n) HIP_CHECK(hipMemcpyAsync(chainLen, dChainLen, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		if (n) HIP_CHECK(hipMemcpyAsync(chainStatus, dChainStatus, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		if (n) HIP_CHECK(hipMemcpyAsync(chainScore, dChainScore, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipMemcpyAsync(hSmall, dCursors, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipMemcpyAsync(hSmall + 8, dCounters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		HIP_CHECK(hipStreamSynchronize(stream));
 		res->kernel_us[1] = elapsedUs(2, 3);
 		res->kernel_us[2] = elapsedUs(3, 4);
 		res->kernel_us[3] = elapsedUs(4, 5);
-		for (int i = 0; i < 8; i++) res->counters[i] = counters[i];
-		if (cursors[1] > traceBudget) throw std::runtime_error("trace pool overflow (raise GC_EXT_MAX_TRACE / report)");
-		if (cursors[2] > pathCapacity) throw std::runtime_error("anchor path pool overflow");
-		std::vector<uint32_t> pathPool(cursors[2]);
-		if (cursors[2]) HIP_CHECK(hipMemcpy(pathPool.data(), dPathPool, cursors[2] * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		for (int i = 0; i < 8; i++) res->counters[i] = hSmall[8 + i];
+		uint64_t traceUsed = hSmall[1], pathUsed = hSmall[2];
+		if (traceUsed > traceBudget) throw std::runtime_error("trace pool overflow (raise GC_EXT_MAX_TRACE / report)");
+		if (pathUsed > pathCapacity) throw std::runtime_error("anchor path pool overflow");
+		uint32_t* pathPool = st->hPathPool.reserve<uint32_t>(pathUsed);
+		if (pathUsed) HIP_CHECK(hipMemcpyAsync(pathPool, dPathPool, pathUsed * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		std::vector<ExtResult> extResults;
 		std::vector<TraceCell> tracePool;
 		if (P->keep_traces) {
 			extResults.resize(nWork);
-			tracePool.resize(cursors[1]);
-			if (nWork) HIP_CHECK(hipMemcpy(extResults.data(), dResults, nWork * sizeof(ExtResult), hipMemcpyDeviceToHost));
-			if (cursors[1]) HIP_CHECK(hipMemcpy(tracePool.data(), dTrace, cursors[1] * sizeof(TraceCell), hipMemcpyDeviceToHost));
+			tracePool.resize(traceUsed);
+			if (nWork) HIP_CHECK(hipMemcpyAsync(extResults.data(), dResults, (size_t)nWork * sizeof(ExtResult), hipMemcpyDeviceToHost, stream));
+			if (traceUsed) HIP_CHECK(hipMemcpyAsync(tracePool.data(), dTrace, traceUsed * sizeof(TraceCell), hipMemcpyDeviceToHost, stream));
 		}
+		HIP_CHECK(hipStreamSynchronize(stream));
+		res->host_us[3] = nowUs() - tDev;   // K3..K4 + their transfers, wall
 
-		// ---------------- assemble the flat result
+		// ---------------- assemble the flat result: count per read, prefix-sum, fill in parallel
 		double tAsm = nowUs();
-		for (uint64_t f = 0; f < nFrags; f++) if (fragStatus[f] == 2) throw std::runtime_error("extension capacity overflow in a fragment (raise GC_EXT_MAX_ITEMS / GC_EXT_MAX_PENDING / GC_EXT_MAX_TRACE)");
-		for (uint64_t r = 0; r < n; r++) if (chainStatus[r] != 0) throw std::runtime_error("chaining kernel failure (status " + std::to_string(chainStatus[r]) + ")");
-		std::vector<uint64_t> readSeedOff(n + 1, 0), readAnchorOff(n + 1, 0), readChainOff(n + 1, 0), anchorPathOff(1, 0), anchorTraceOff(1, 0), chainScoreOut(n), seedsExtended(n, 0);
-		std::vector<uint32_t> seedNode, seedOffset, seedSeqpos, ax, ay, apath, afn, afo, afs, aln, alo, als, chainFlat, atOffset, atSeqpos;
-		std::vector<uint64_t> seedGoodness;
-		std::vector<int32_t> ascore, atNode;
-		std::vector<uint8_t> atSwitch, failedAssertion(n, 0);
-		seedNode.reserve(nSeedsTotal); seedOffset.reserve(nSeedsTotal); seedSeqpos.reserve(nSeedsTotal); seedGoodness.reserve(nSeedsTotal);
-		for (uint64_t r = 0; r < n; r++) {
+		std::atomic<int> overflow { 0 }, chainFailure { 0 };
+		std::vector<uint8_t> failedAssertion(n, 0);
+		std::vector<uint64_t> seedsExtended(n, 0);
+		auto forEachAnchor = [&](uint64_t r, auto&& visit) {   // visit(slotIndex, fragmentIndex) for every anchor the reference would keep
 			const ReadGlue& gl = glue[r];
-			for (const gc::SeedRec& s : gl.seeds) { seedNode.push_back(s.node); seedOffset.push_back(s.offset); seedSeqpos.push_back(s.seqPos); seedGoodness.push_back(s.goodness); }
-			readSeedOff[r + 1] = seedNode.size();
-			failedAssertion[r] = gl.failed ? 1 : 0;
-			// the reference never resets `cont` after a failing fragment: later fragments add no anchors (src/Aligner.cpp:695-703)
 			uint64_t slot = gl.slotBegin;
-			bool cont = false;
 			for (size_t f = 0; f < gl.windows.size(); f++) {
 				uint64_t F = gl.fragBegin + f;
 				uint32_t nS = frags[F].seedEnd - frags[F].seedBegin;
-				if (fragStatus[F] == 1) { cont = true; failedAssertion[r] = 1; }
-				if (!cont) {
-					seedsExtended[r] += fragExtended[F];
-					for (uint32_t k = 0; k < nS; k++) {
-						const AnchorRec& a = anchors[slot + k];
-						if (!a.valid) continue;
-						ax.push_back(a.x); ay.push_back(a.y);
-						for (uint32_t i = 0; i < a.pathLen; i++) apath.push_back(pathPool[a.pathOff + i]);
-						anchorPathOff.push_back(apath.size());
-						afn.push_back(a.firstNode); afo.push_back(a.firstOffset); afs.push_back(a.firstSeqPos + frags[F].l);
-						aln.push_back(a.lastNode); alo.push_back(a.lastOffset); als.push_back(a.lastSeqPos + frags[F].l);
-						ascore.push_back(a.score);
-						if (P->keep_traces) {
-							// merged trace in the reference's output coordinates (bigraph node id, offset in original node),
-							// src/GraphAligner.h:527-565,590-608
-							const ExtResult& eb = extResults[2 * (slot + k)];
-							const ExtResult& ef = extResults[2 * (slot + k) + 1];
-							uint32_t p = fragSeeds[slot + k].seqPos - frags[F].l;
-							bool hasB = p > 0 && eb.status == EXT_OK, hasF = p < (uint32_t)P->split_len - 1 && ef.status == EXT_OK;
-							if (hasB) {
-								uint32_t use = hasF ? eb.traceLen - 1 : eb.traceLen;
-								for (uint32_t i = 0; i < use; i++) {
-									const TraceCell& c = tracePool[eb.traceOff + i];
-									uint32_t off = c.offsetAndSwitch & 255u;
-									auto rev = hg.GetReversePosition(hg.nodeIDs[c.node], hg.nodeOffset[c.node] + off);
-									atNode.push_back(rev.first);
-									atOffset.push_back((uint32_t)rev.second);
-									atSeqpos.push_back((uint32_t)((int32_t)p - 1 - c.seqPos));
-									bool sw = i + 1 < eb.traceLen ? ((tracePool[eb.traceOff + i + 1].offsetAndSwitch >> 8) & 1) : false;
-									atSwitch.push_back(sw ? 1 : 0);
-								}
-							}
-							if (hasF) {
-								for (uint32_t i = ef.traceLen; i-- > 0;) {
-									const TraceCell& c = tracePool[ef.traceOff + i];
-									uint32_t off = c.offsetAndSwitch & 255u;
-									atNode.push_back(hg.nodeIDs[c.node]);
-									atOffset.push_back((uint32_t)(hg.nodeOffset[c.node] + off));
-									atSeqpos.push_back((uint32_t)((int32_t)p + 1 + c.seqPos));
-									atSwitch.push_back((c.offsetAndSwitch >> 8) & 1);
-								}
-							}
-							anchorTraceOff.push_back(atNode.size());
+				if (fragStatus[F] == 1) return;   // `cont` is never reset: later fragments add nothing (src/Aligner.cpp:695-703)
+				for (uint32_t k = 0; k < nS; k++) if (anchors[slot + k].valid) visit(slot + k, F);
+				slot += nS;
+			}
+		};
+		pool.run(n, [&](size_t r, size_t) {
+			ReadGlue& gl = glue[r];
+			failedAssertion[r] = gl.failed ? 1 : 0;
+			if (chainStatus[r] != 0) chainFailure = (int)chainStatus[r];
+			for (size_t f = 0; f < gl.windows.size(); f++) {
+				uint64_t F = gl.fragBegin + f;
+				if (fragStatus[F] == 2) overflow = 1;
+				if (fragStatus[F] == 1) { failedAssertion[r] = 1; break; }
+				seedsExtended[r] += fragExtended[F];
+			}
+			forEachAnchor(r, [&](uint64_t slot, uint64_t) {
+				gl.nAnchors++;
+				gl.nPath += anchors[slot].pathLen;
+				if (P->keep_traces) {
+					const ExtResult& eb = extResults[2 * slot];
+					const ExtResult& ef = extResults[2 * slot + 1];
+					uint32_t p = fragSeeds[slot].seqPos - (anchors[slot].x);
+					bool hasB = p > 0 && eb.status == EXT_OK, hasF = p < (uint32_t)P->split_len - 1 && ef.status == EXT_OK;
+					gl.nTrace += (hasB ? (hasF ? eb.traceLen - 1 : eb.traceLen) : 0) + (hasF ? ef.traceLen : 0);
+				}
+			});
+		});
+		if (overflow) throw std::runtime_error("extension capacity overflow in a fragment (raise GC_EXT_MAX_ITEMS / GC_EXT_MAX_PENDING / GC_EXT_MAX_TRACE)");
+		if (chainFailure) throw std::runtime_error("chaining kernel failure (status " + std::to_string((int)chainFailure) + ")");
+		uint64_t nAnchors = 0, nPath = 0, nTrace = 0, nChain = 0;
+		for (uint64_t r = 0; r < n; r++) {
+			glue[r].anchorBegin = nAnchors; glue[r].pathBegin = nPath; glue[r].traceBegin = nTrace; glue[r].chainBegin = nChain;
+			nAnchors += glue[r].nAnchors; nPath += glue[r].nPath; nTrace += glue[r].nTrace; nChain += chainLen[r];
+		}
+		const bool keepSeeds = P->keep_seeds != 0;
+		res->read_seed_off = mallocArray<uint64_t>(n + 1);
+		res->seed_node = mallocArray<uint32_t>(keepSeeds ? nSeedsTotal : 0); res->seed_offset = mallocArray<uint32_t>(keepSeeds ? nSeedsTotal : 0);
+		res->seed_seqpos = mallocArray<uint32_t>(keepSeeds ? nSeedsTotal : 0); res->seed_goodness = mallocArray<uint64_t>(keepSeeds ? nSeedsTotal : 0);
+		res->read_anchor_off = mallocArray<uint64_t>(n + 1);
+		res->anchor_x = mallocArray<uint32_t>(nAnchors); res->anchor_y = mallocArray<uint32_t>(nAnchors);
+		res->anchor_path_off = mallocArray<uint64_t>(nAnchors + 1); res->anchor_path = mallocArray<uint32_t>(nPath);
+		res->anchor_first_node = mallocArray<uint32_t>(nAnchors); res->anchor_first_offset = mallocArray<uint32_t>(nAnchors); res->anchor_first_seqpos = mallocArray<uint32_t>(nAnchors);
+		res->anchor_last_node = mallocArray<uint32_t>(nAnchors); res->anchor_last_offset = mallocArray<uint32_t>(nAnchors); res->anchor_last_seqpos = mallocArray<uint32_t>(nAnchors);
+		res->anchor_score = mallocArray<int32_t>(nAnchors);
+		if (P->keep_traces) {
+			res->anchor_trace_off = mallocArray<uint64_t>(nAnchors + 1);
+			res->anchor_trace_node = mallocArray<int32_t>(nTrace); res->anchor_trace_offset = mallocArray<uint32_t>(nTrace);
+			res->anchor_trace_seqpos = mallocArray<uint32_t>(nTrace); res->anchor_trace_switch = mallocArray<uint8_t>(nTrace);
+			res->anchor_trace_off[nAnchors] = nTrace;
+		}
+		res->read_chain_off = mallocArray<uint64_t>(n + 1);
+		res->chain = mallocArray<uint32_t>(nChain);
+		res->chain_score = mallocArray<uint64_t>(n);
+		res->read_longall_off = (uint64_t*)calloc(n + 1, sizeof(uint64_t));
+		res->long_trace_off = (uint64_t*)calloc(1, sizeof(uint64_t));
+		res->failed_assertion = mallocArray<uint8_t>(n);
+		res->seeds_extended = mallocArray<uint64_t>(n);
+		res->read_seed_off[n] = keepSeeds ? nSeedsTotal : 0; res->read_anchor_off[n] = nAnchors; res->anchor_path_off[nAnchors] = nPath; res->read_chain_off[n] = nChain;
+		pool.run(n, [&](size_t r, size_t) {
+			const ReadGlue& gl = glue[r];
+			res->read_seed_off[r] = keepSeeds ? gl.seedBegin : 0;
+			if (keepSeeds) {
+				uint64_t at = gl.seedBegin;
+				for (const gc::SeedRec& s : gl.seeds) { res->seed_node[at] = s.node; res->seed_offset[at] = s.offset; res->seed_seqpos[at] = s.seqPos; res->seed_goodness[at] = s.goodness; at++; }
+			}
+			res->read_anchor_off[r] = gl.anchorBegin;
+			res->read_chain_off[r] = gl.chainBegin;
+			res->chain_score[r] = chainScore[r];
+			res->failed_assertion[r] = failedAssertion[r];
+			res->seeds_extended[r] = seedsExtended[r];
+			for (uint32_t i = 0; i < chainLen[r]; i++) res->chain[gl.chainBegin + i] = chainOut[jobs[r].chainBegin + i];
+			uint64_t a = gl.anchorBegin, pathAt = gl.pathBegin, traceAt = gl.traceBegin;
+			forEachAnchor(r, [&](uint64_t slot, uint64_t F) {
+				const AnchorRec& rec = anchors[slot];
+				res->anchor_x[a] = rec.x; res->anchor_y[a] = rec.y;
+				res->anchor_path_off[a] = pathAt;
+				for (uint32_t i = 0; i < rec.pathLen; i++) res->anchor_path[pathAt++] = pathPool[rec.pathOff + i];
+				res->anchor_first_node[a] = rec.firstNode; res->anchor_first_offset[a] = rec.firstOffset; res->anchor_first_seqpos[a] = rec.firstSeqPos + frags[F].l;
+				res->anchor_last_node[a] = rec.lastNode; res->anchor_last_offset[a] = rec.lastOffset; res->anchor_last_seqpos[a] = rec.lastSeqPos + frags[F].l;
+				res->anchor_score[a] = rec.score;
+				if (P->keep_traces) {
+					// merged trace in the reference's output coordinates (bigraph node id, offset in original node),
+					// src/GraphAligner.h:527-565,590-608
+					res->anchor_trace_off[a] = traceAt;
+					const ExtResult& eb = extResults[2 * slot];
+					const ExtResult& ef = extResults[2 * slot + 1];
+					uint32_t p = fragSeeds[slot].seqPos - frags[F].l;
+					bool hasB = p > 0 && eb.status == EXT_OK, hasF = p < (uint32_t)P->split_len - 1 && ef.status == EXT_OK;
+					if (hasB) {
+						uint32_t use = hasF ? eb.traceLen - 1 : eb.traceLen;
+						for (uint32_t i = 0; i < use; i++) {
+							const TraceCell& c = tracePool[eb.traceOff + i];
+							uint32_t off = c.offsetAndSwitch & 255u;
+							auto rev = hg.GetReversePosition(hg.nodeIDs[c.node], hg.nodeOffset[c.node] + off);
+							res->anchor_trace_node[traceAt] = rev.first;
+							res->anchor_trace_offset[traceAt] = (uint32_t)rev.second;
+							res->anchor_trace_seqpos[traceAt] = (uint32_t)((int32_t)p - 1 - c.seqPos);
+							bool sw = i + 1 < eb.traceLen ? ((tracePool[eb.traceOff + i + 1].offsetAndSwitch >> 8) & 1) : false;
+							res->anchor_trace_switch[traceAt] = sw ? 1 : 0;
+							traceAt++;
+						}
+					}
+					if (hasF) {
+						for (uint32_t i = ef.traceLen; i-- > 0;) {
+							const TraceCell& c = tracePool[ef.traceOff + i];
+							uint32_t off = c.offsetAndSwitch & 255u;
+							res->anchor_trace_node[traceAt] = hg.nodeIDs[c.node];
+							res->anchor_trace_offset[traceAt] = (uint32_t)(hg.nodeOffset[c.node] + off);
+							res->anchor_trace_seqpos[traceAt] = (uint32_t)((int32_t)p + 1 + c.seqPos);
+							res->anchor_trace_switch[traceAt] = (c.offsetAndSwitch >> 8) & 1;
+							traceAt++;
 						}
 					}
 				}
-				slot += nS;
-			}
-			readAnchorOff[r + 1] = ax.size();
-			for (uint32_t i = 0; i < chainLen[r]; i++) chainFlat.push_back(chainOut[jobs[r].chainBegin + i]);
-			readChainOff[r + 1] = chainFlat.size();
-			chainScoreOut[r] = chainScore[r];
-		}
-		res->read_seed_off = copyOut(readSeedOff);
-		res->seed_node = copyOut(seedNode); res->seed_offset = copyOut(seedOffset); res->seed_seqpos = copyOut(seedSeqpos); res->seed_goodness = copyOut(seedGoodness);
-		res->read_anchor_off = copyOut(readAnchorOff);
-		res->anchor_x = copyOut(ax); res->anchor_y = copyOut(ay);
-		res->anchor_path_off = copyOut(anchorPathOff); res->anchor_path = copyOut(apath);
-		res->anchor_first_node = copyOut(afn); res->anchor_first_offset = copyOut(afo); res->anchor_first_seqpos = copyOut(afs);
-		res->anchor_last_node = copyOut(aln); res->anchor_last_offset = copyOut(alo); res->anchor_last_seqpos = copyOut(als);
-		res->anchor_score = copyOut(ascore);
-		if (P->keep_traces) {
-			res->anchor_trace_off = copyOut(anchorTraceOff);
-			res->anchor_trace_node = copyOut(atNode); res->anchor_trace_offset = copyOut(atOffset); res->anchor_trace_seqpos = copyOut(atSeqpos); res->anchor_trace_switch = copyOut(atSwitch);
-		}
-		res->read_chain_off = copyOut(readChainOff);
-		res->chain = copyOut(chainFlat);
-		res->chain_score = copyOut(chainScoreOut);
-		std::vector<uint64_t> zeroOff(n + 1, 0), one(1, 0);
-		res->read_longall_off = copyOut(zeroOff);
-		res->long_trace_off = copyOut(one);
-		res->failed_assertion = copyOut(failedAssertion);
-		res->seeds_extended = copyOut(seedsExtended);
+				a++;
+			});
+		});
 		res->host_us[1] = nowUs() - tAsm;
 		return (int)GC_OK;
 	});

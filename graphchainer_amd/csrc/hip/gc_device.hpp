@@ -33,8 +33,8 @@ struct DGraph {
 	// MPC index, flattened over components
 	const uint32_t* componentMap;     // [n] weakly connected component id
 	const uint32_t* topoId;           // [n] topological position inside its component
-	const uint32_t* pathsOff; const uint32_t* paths;            // [n+1], path ids through node
-	const uint32_t* backOff;  const uint32_t* backNode; const uint32_t* backPath;   // [n+1]; (last node of path k reaching v, k)
+	const uint32_t* pathsOff; const uint32_t* paths; const uint32_t* pathsPos;   // [n+1]; path ids through node (ascending) and the node's position on each
+	const uint32_t* backOff;  const uint32_t* backNode; const uint32_t* backPath; const uint32_t* backPos;   // [n+1]; (last node of path k strictly reaching v, k, its position on k)
 	const uint32_t* mpcWidth;         // [nComponents]
 };
 

@@ -295,15 +295,22 @@ __global__ void __launch_bounds__(64) k_build_anchors(DGraph g, const Fragment* 
 
 // =====================================================================================================
 // K4 - co-linear chaining. reference: AlignmentGraph::colinearChaining / colinearChainingByComponent,
-// src/AlignmentGraph.cpp:1712-1863. One wave per read. Lanes cooperatively compact the read's valid
-// anchors; the DP - a sweep over anchor endpoints in topological order, sequential in the reference too -
-// runs on lane 0 against per-path range-max tables.
+// src/AlignmentGraph.cpp:1712-1863. One wave per read.
 //
-// Range-max tables replace the reference's treaps (:1600-1710; RMQ results do not depend on tree shape).
-// Anchor keys are y = l + splitLen - 1 with l a multiple of splitGap, so f = l / splitGap is a dense key
-// domain: T[k][f] / I[k][f] hold the max (value, anchor) seen for that key on path k, packed in one uint64 so
-// that integer max equals the reference's lexicographic pair max (ties towards the larger anchor index,
-// :1812,1849). 0 is "empty" and stands for the reference's default_value, which can never win (:1751-1754).
+// The reference sweeps anchor endpoints in topological order and keeps, per path k of the minimum path cover,
+// two treaps keyed by read coordinate. What that sweep computes for anchor j is
+//     C[j] = max( (len_j, -1),
+//                 max_i (len_j + C[i].first, i)         over i with  y_i <  x_j      and  end(i) => start(j)
+//                 max_i (y_j - y_i + C[i].first, i)     over i with  x_j <= y_i < y_j and  end(i) => start(j) )
+// with lexicographic pair max (ties to the larger anchor index, :1812,1849) and  u => v  meaning "u strictly
+// reaches v" (looked up through backwards[v], :1766,1834-1845) or "u == v and i sorts before j by (y,x)"
+// (the node-local pass, :1785-1822). Both read conditions imply x_i < x_j, i.e. i belongs to an earlier
+// fragment, and C[i] is final before any j of a later fragment reads it. So the same maxima can be taken in
+// FRAGMENT order with a direct reachability test per pair, which needs no sort and no tables and is parallel
+// over i: lanes scan the earlier anchors, a wave max-reduction yields C[j]. Anchor slots are already in
+// fragment order. u strictly reaches v  <=>  some path k through u has pos_k(u) <= pos_k(last node of path k
+// that strictly reaches v) - exactly the (node, k) pairs of backwards[v] (computeMPCIndex, :1373-1384).
+// Cost O(n^2 K / 64) per read; n is a few hundred anchors.
 // =====================================================================================================
 
 __device__ __forceinline__ unsigned long long packScore(long long score, long long anchor)
@@ -313,182 +320,31 @@ __device__ __forceinline__ unsigned long long packScore(long long score, long lo
 __device__ __forceinline__ long long unpackScore(unsigned long long v) { return (long long)(v >> 32) - (1ll << 30); }
 __device__ __forceinline__ long long unpackAnchor(unsigned long long v) { return (long long)(uint32_t)v - 1; }
 
-__device__ inline void heapSort(unsigned long long* a, uint32_t n)
+// end(i) == u, start(j) == v, same weakly connected component already checked
+__device__ __forceinline__ bool reachesStrictly(const DGraph& g, uint32_t u, uint32_t v)
 {
-	if (n < 2) return;
-	auto sift = [&](uint32_t root, uint32_t end) {
-		while (true) {
-			uint32_t child = 2 * root + 1;
-			if (child >= end) break;
-			if (child + 1 < end && a[child] < a[child + 1]) child++;
-			if (a[root] >= a[child]) break;
-			unsigned long long t = a[root]; a[root] = a[child]; a[child] = t;
-			root = child;
-		}
-	};
-	for (uint32_t i = n / 2; i-- > 0;) sift(i, n);
-	for (uint32_t end = n - 1; end > 0; end--) {
-		unsigned long long t = a[0]; a[0] = a[end]; a[end] = t;
-		sift(0, end);
+	uint32_t pu = g.pathsOff[u], puEnd = g.pathsOff[u + 1];
+	uint32_t bv = g.backOff[v], bvEnd = g.backOff[v + 1];
+	while (pu < puEnd && bv < bvEnd) {   // both lists are ascending in path id
+		uint32_t ku = g.paths[pu], kv = g.backPath[bv];
+		if (ku == kv) {
+			if (g.pathsPos[pu] <= g.backPos[bv]) return true;
+			pu++; bv++;
+		} else if (ku < kv) pu++;
+		else bv++;
 	}
+	return false;
 }
 
-struct ChainScratch {
-	uint32_t* compact;              // [capAnchors] compact anchor index -> slot
-	unsigned long long* C;          // [capAnchors] packed (coverage, predecessor)
-	unsigned long long* endpoints;  // [capEndpoints] (topoId << 32) | endpoint id
-	uint32_t* epAnchor;             // [capEndpoints]
-	uint32_t* epKind;               // [capEndpoints] 0xffffffff start, 0xfffffffe end, else path id
-	uint32_t* group;                // [capAnchors] anchors of the current node, sorted by (y, x, index)
-	unsigned long long* tables;     // [2 * capTable]
-};
-
-__device__ __forceinline__ ChainScratch chainScratch(uint8_t* base, const ChainCaps& caps)
-{
-	ChainScratch s;
-	uint8_t* p = base;
-	s.C = (unsigned long long*)p;          p += 8 * (size_t)caps.capAnchors;
-	s.endpoints = (unsigned long long*)p;  p += 8 * (size_t)caps.capEndpoints;
-	s.tables = (unsigned long long*)p;     p += 16 * (size_t)caps.capTable;
-	s.compact = (uint32_t*)p;              p += 4 * (size_t)caps.capAnchors;
-	s.epAnchor = (uint32_t*)p;             p += 4 * (size_t)caps.capEndpoints;
-	s.epKind = (uint32_t*)p;               p += 4 * (size_t)caps.capEndpoints;
-	s.group = (uint32_t*)p;
-	return s;
-}
-
-// DP for one component. Returns false on capacity overflow.
-__device__ inline bool chainComponent(const DGraph& g, const AnchorRec* anchors, const ChainScratch& sc, const ChainCaps& caps, uint32_t nA, uint32_t cid,
-	uint32_t nKeys, int32_t splitLen, int32_t splitGap, long long& bestScore, long long& bestAnchor)
-{
-	const uint32_t KIND_START = 0xffffffffu, KIND_END = 0xfffffffeu;
-	uint32_t K = g.mpcWidth[cid];
-	if ((uint64_t)K * nKeys > caps.capTable) return false;
-	unsigned long long* T = sc.tables;
-	unsigned long long* I = sc.tables + (size_t)K * nKeys;
-	for (size_t i = 0; i < (size_t)K * nKeys; i++) { T[i] = 0; I[i] = 0; }
-	uint32_t nE = 0;
-	for (uint32_t a = 0; a < nA; a++) {
-		const AnchorRec& an = anchors[sc.compact[a]];
-		if (g.componentMap[an.lastNode] != cid) continue;
-		uint32_t nBack = g.backOff[an.firstNode + 1] - g.backOff[an.firstNode];
-		if (nE + 2 + nBack > caps.capEndpoints) return false;
-		sc.endpoints[nE] = ((unsigned long long)g.topoId[an.firstNode] << 32) | nE; sc.epAnchor[nE] = a; sc.epKind[nE] = KIND_START; nE++;
-		sc.endpoints[nE] = ((unsigned long long)g.topoId[an.lastNode] << 32) | nE; sc.epAnchor[nE] = a; sc.epKind[nE] = KIND_END; nE++;
-		for (uint32_t b = g.backOff[an.firstNode]; b < g.backOff[an.firstNode + 1]; b++) {
-			sc.endpoints[nE] = ((unsigned long long)g.topoId[g.backNode[b]] << 32) | nE; sc.epAnchor[nE] = a; sc.epKind[nE] = g.backPath[b]; nE++;
-		}
-		sc.C[a] = packScore((long long)an.y - (long long)an.x + 1, -1);   // :1769
-	}
-	heapSort(sc.endpoints, nE);   // :1772 (order inside one node's group does not affect the result)
-	for (uint32_t vi = 0, ri = 0; vi < nE; vi = ri) {
-		uint32_t topo = (uint32_t)(sc.endpoints[vi] >> 32);
-		ri = vi + 1;
-		while (ri < nE && (uint32_t)(sc.endpoints[ri] >> 32) == topo) ri++;
-		// (1) anchors starting or ending at this node, ordered by (y, x, index), duplicates removed (:1781-1822)
-		uint32_t nG = 0;
-		for (uint32_t e = vi; e < ri; e++) {
-			uint32_t id = (uint32_t)sc.endpoints[e];
-			if (sc.epKind[id] < KIND_END) continue;
-			uint32_t a = sc.epAnchor[id];
-			const AnchorRec& an = anchors[sc.compact[a]];
-			// insertion sort; skip if already present
-			uint32_t pos = nG;
-			bool dup = false;
-			while (pos > 0) {
-				uint32_t b = sc.group[pos - 1];
-				if (b == a) { dup = true; break; }
-				const AnchorRec& bn = anchors[sc.compact[b]];
-				bool bBefore = bn.y < an.y || (bn.y == an.y && (bn.x < an.x || (bn.x == an.x && b < a)));
-				if (bBefore) break;
-				pos--;
-			}
-			if (!dup) {
-				// a duplicate can only sit at the insertion point's left neighbour (same (y,x,index) sorts adjacent)
-				for (uint32_t q = 0; q < nG && !dup; q++) if (sc.group[q] == a) dup = true;
-			}
-			if (dup) continue;
-			for (uint32_t q = nG; q > pos; q--) sc.group[q] = sc.group[q - 1];
-			sc.group[pos] = a;
-			nG++;
-		}
-		for (uint32_t gi = 0; gi < nG; gi++) {
-			uint32_t j = sc.group[gi];
-			const AnchorRec& an = anchors[sc.compact[j]];
-			if (g.topoId[an.firstNode] != topo) continue;
-			unsigned long long bestT = 0, bestI = 0;
-			for (uint32_t gq = 0; gq < gi; gq++) {   // earlier anchors of the group that END here are in the node-local tables
-				uint32_t i = sc.group[gq];
-				const AnchorRec& bn = anchors[sc.compact[i]];
-				if (g.topoId[bn.lastNode] != topo) continue;
-				long long ci = unpackScore(sc.C[i]);
-				if ((long long)bn.y <= (long long)an.x - 1) { unsigned long long v = packScore(ci, i); bestT = v > bestT ? v : bestT; }
-				if ((long long)bn.y >= (long long)an.x && (long long)bn.y <= (long long)an.y - 1) { unsigned long long v = packScore(ci - (long long)bn.y, i); bestI = v > bestI ? v : bestI; }
-			}
-			long long lenJ = (long long)an.y - (long long)an.x + 1;
-			if (bestT) { unsigned long long cand = packScore(lenJ + unpackScore(bestT), unpackAnchor(bestT)); if (cand > sc.C[j]) sc.C[j] = cand; }
-			if (bestI) { unsigned long long cand = packScore((long long)an.y + unpackScore(bestI), unpackAnchor(bestI)); if (cand > sc.C[j]) sc.C[j] = cand; }
-		}
-		// (2) anchors ending here enter the tables of every path through this node (:1823-1833)
-		for (uint32_t e = vi; e < ri; e++) {
-			uint32_t id = (uint32_t)sc.endpoints[e];
-			if (sc.epKind[id] != KIND_END) continue;
-			uint32_t a = sc.epAnchor[id];
-			const AnchorRec& an = anchors[sc.compact[a]];
-			uint32_t key = an.x / (uint32_t)splitGap;
-			if (key >= nKeys) return false;
-			long long ca = unpackScore(sc.C[a]);
-			unsigned long long vt = packScore(ca, a), vi2 = packScore(ca - (long long)an.y, a);
-			for (uint32_t pz = g.pathsOff[an.lastNode]; pz < g.pathsOff[an.lastNode + 1]; pz++) {
-				size_t at = (size_t)g.paths[pz] * nKeys + key;
-				if (vt > T[at]) T[at] = vt;
-				if (vi2 > I[at]) I[at] = vi2;
-			}
-		}
-		// (3) forwarded queries: this node is the last node of path k that strictly reaches start(j) (:1834-1845)
-		for (uint32_t e = vi; e < ri; e++) {
-			uint32_t id = (uint32_t)sc.endpoints[e];
-			uint32_t k = sc.epKind[id];
-			if (k >= KIND_END) continue;
-			uint32_t j = sc.epAnchor[id];
-			const AnchorRec& an = anchors[sc.compact[j]];
-			long long lenJ = (long long)an.y - (long long)an.x + 1;
-			unsigned long long bestT = 0, bestI = 0;
-			// T[k].RMQ(0, x-1): keys y' = l' + splitLen - 1 <= x - 1  <=>  l' <= x - splitLen
-			long long maxL = (long long)an.x - (long long)splitLen;
-			if (maxL >= 0) {
-				uint32_t hi = (uint32_t)(maxL / splitGap);
-				if (hi >= nKeys) hi = nKeys - 1;
-				for (uint32_t f = 0; f <= hi; f++) { unsigned long long v = T[(size_t)k * nKeys + f]; bestT = v > bestT ? v : bestT; }
-			}
-			// I[k].RMQ(x, y-1): x <= l' + splitLen - 1 <= y - 1  <=>  x - splitLen + 1 <= l' <= y - splitLen
-			long long lo = (long long)an.x - (long long)splitLen + 1, hiL = (long long)an.y - (long long)splitLen;
-			if (lo < 0) lo = 0;
-			if (hiL >= lo) {
-				uint32_t fLo = (uint32_t)((lo + splitGap - 1) / splitGap), fHi = (uint32_t)(hiL / splitGap);
-				if (fHi >= nKeys) fHi = nKeys - 1;
-				for (uint32_t f = fLo; f <= fHi; f++) { unsigned long long v = I[(size_t)k * nKeys + f]; bestI = v > bestI ? v : bestI; }
-			}
-			if (bestT) { unsigned long long cand = packScore(lenJ + unpackScore(bestT), unpackAnchor(bestT)); if (cand > sc.C[j]) sc.C[j] = cand; }
-			if (bestI) { unsigned long long cand = packScore((long long)an.y + unpackScore(bestI), unpackAnchor(bestI)); if (cand > sc.C[j]) sc.C[j] = cand; }
-		}
-	}
-	bestScore = 0;
-	bestAnchor = -1;
-	for (uint32_t a = 0; a < nA; a++) {   // :1847-1849, lexicographic max of (coverage, index)
-		if (g.componentMap[anchors[sc.compact[a]].lastNode] != cid) continue;
-		long long s = unpackScore(sc.C[a]);
-		if (s > bestScore || (s == bestScore && (long long)a > bestAnchor)) { bestScore = s; bestAnchor = a; }
-	}
-	return true;
-}
+#define CHAIN_LDS_ANCHORS 1536
 
 __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __restrict__ jobs, uint32_t nReads, const AnchorRec* __restrict__ anchors,
 	const Fragment* __restrict__ frags, const uint32_t* __restrict__ fragStatus, int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* __restrict__ scratch, uint64_t scratchStride,
 	uint32_t* __restrict__ chainOut, uint32_t* __restrict__ chainLen, unsigned long long* __restrict__ chainScore, uint32_t* __restrict__ chainStatus)
 {
+	__shared__ uint32_t ldsStart[CHAIN_LDS_ANCHORS], ldsEnd[CHAIN_LDS_ANCHORS], ldsX[CHAIN_LDS_ANCHORS];
+	__shared__ unsigned long long ldsC[CHAIN_LDS_ANCHORS];
 	const int lane = threadIdx.x;
-	ChainScratch sc = chainScratch(scratch + (uint64_t)blockIdx.x * scratchStride, caps);
 	for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
 		ReadChainJob job = jobs[r];
 		// the reference never resets its `cont` flag after a fragment whose extension threw, so fragments after the
@@ -497,16 +353,62 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 		for (uint32_t f = lane; f < job.nFrags; f += 64)
 			if (fragStatus[job.fragBegin + f] == 1) { uint32_t c = frags[job.fragBegin + f].seedBegin - job.slotBegin; cut = c < cut ? c : cut; }
 		for (int d = 32; d > 0; d >>= 1) { uint32_t o = __shfl_xor(cut, d); cut = o < cut ? o : cut; }
+		// working arrays: LDS when the read's anchors fit, else this block's HBM scratch
+		uint32_t *aStart = ldsStart, *aEnd = ldsEnd, *aX = ldsX;
+		unsigned long long* C = ldsC;
+		if (cut > CHAIN_LDS_ANCHORS) {
+			uint8_t* base = scratch + (uint64_t)blockIdx.x * scratchStride;
+			C = (unsigned long long*)base;
+			aStart = (uint32_t*)(base + 8ull * caps.capAnchors);
+			aEnd = aStart + caps.capAnchors;
+			aX = aEnd + caps.capAnchors;
+		}
 		// compact the read's valid anchors in slot order (== the order the reference pushes them, src/Aligner.cpp:706-721)
 		uint32_t nA = 0;
 		for (uint32_t s0 = 0; s0 < cut; s0 += 64) {
 			uint32_t s = s0 + lane;
-			bool valid = s < cut && anchors[job.slotBegin + s].valid != 0;
+			bool valid = false;
+			AnchorRec rec;
+			if (s < cut) { rec = anchors[job.slotBegin + s]; valid = rec.valid != 0; }
 			unsigned long long ballot = __ballot(valid);
-			if (valid) sc.compact[nA + (uint32_t)__popcll(ballot & ((1ull << lane) - 1))] = job.slotBegin + s;
+			if (valid) {
+				uint32_t a = nA + (uint32_t)__popcll(ballot & ((1ull << lane) - 1));
+				aStart[a] = rec.firstNode;
+				aEnd[a] = rec.lastNode;
+				aX[a] = rec.x;
+				C[a] = packScore((long long)rec.y - (long long)rec.x + 1, -1);   // :1769
+			}
 			nA += (uint32_t)__popcll(ballot);
 		}
-		__threadfence_block();
+		__syncthreads();
+		// anchors are ordered by fragment start x; g0 = first anchor of j's fragment
+		uint32_t g0 = 0;
+		for (uint32_t j = 0; j < nA; j++) {
+			uint32_t xj = aX[j];
+			if (j > 0 && xj != aX[j - 1]) { g0 = j; __syncthreads(); }   // C of the previous fragment's anchors is now final and visible
+			if (g0 == 0) continue;
+			uint32_t v = aStart[j];
+			uint32_t compV = g.componentMap[v];
+			long long yj = (long long)xj + splitLen - 1;
+			unsigned long long best = 0;
+			for (uint32_t i = lane; i < g0; i += 64) {
+				uint32_t u = aEnd[i];
+				long long yi = (long long)aX[i] + splitLen - 1;
+				if (yi >= yj) continue;
+				if (g.componentMap[u] != compV) continue;
+				if (u != v && !reachesStrictly(g, u, v)) continue;
+				long long ci = unpackScore(C[i]);
+				unsigned long long cand;
+				if (yi <= (long long)xj - 1) cand = packScore((long long)splitLen + ci, i);
+				else cand = packScore(yj - yi + ci, i);   // x_j <= y_i <= y_j - 1
+				best = cand > best ? cand : best;
+			}
+			for (int d = 32; d > 0; d >>= 1) {
+				unsigned long long o = __shfl_xor(best, d);
+				best = o > best ? o : best;
+			}
+			if (lane == 0 && best > C[j]) C[j] = best;
+		}
 		__syncthreads();
 		if (lane == 0) {
 			uint32_t status = 0;
@@ -517,18 +419,22 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 			while (nA > 0) {   // components in ascending id; keep the first strictly greater score (:1713-1733)
 				long long cid = -1;
 				for (uint32_t a = 0; a < nA; a++) {
-					long long c = g.componentMap[anchors[sc.compact[a]].lastNode];
+					long long c = g.componentMap[aEnd[a]];
 					if (c > lastCid && (cid < 0 || c < cid)) cid = c;
 				}
 				if (cid < 0) break;
 				lastCid = cid;
-				long long score, anchor;
-				if (!chainComponent(g, anchors, sc, caps, nA, (uint32_t)cid, job.nKeys, splitLen, splitGap, score, anchor)) { status = 2; break; }
+				long long score = 0, anchor = -1;   // :1847-1849, lexicographic max of (coverage, index)
+				for (uint32_t a = 0; a < nA; a++) {
+					if ((long long)g.componentMap[aEnd[a]] != cid) continue;
+					long long sc = unpackScore(C[a]);
+					if (sc > score || (sc == score && (long long)a > anchor)) { score = sc; anchor = a; }
+				}
 				if (first || score > best) {
 					first = false;
 					best = score;
 					uint32_t n = 0;
-					for (long long i = anchor; i != -1; i = unpackAnchor(sc.C[i])) {   // :1851-1862
+					for (long long i = anchor; i != -1; i = unpackAnchor(C[i])) {   // :1851-1862
 						if (n >= job.nSlots) { status = 1; break; }
 						out[n++] = (uint32_t)i;
 					}
@@ -589,11 +495,12 @@ void launchBuildAnchors(hipStream_t stream, const DGraph& g, const Fragment* fra
 
 uint64_t chainScratchBytes(const ChainCaps& caps)
 {
-	uint64_t b = 8ull * caps.capAnchors + 8ull * caps.capEndpoints + 16ull * caps.capTable + 4ull * caps.capAnchors + 8ull * caps.capEndpoints + 4ull * caps.capAnchors;
+	if (caps.capAnchors <= CHAIN_LDS_ANCHORS) return 64;   // everything fits in LDS
+	uint64_t b = 8ull * caps.capAnchors + 12ull * caps.capAnchors;
 	return (b + 63) & ~63ull;
 }
 
-uint32_t chainGridBlocks(uint32_t nReads) { return nReads < 4096 ? nReads : 4096; }
+uint32_t chainGridBlocks(uint32_t nReads) { return nReads < 8192 ? nReads : 8192; }
 
 void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
 	int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* scratch, uint32_t* chainOut, uint32_t* chainLen, unsigned long long* chainScore, uint32_t* chainStatus)

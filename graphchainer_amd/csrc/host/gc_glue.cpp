@@ -1,35 +1,33 @@
 #include "gc_glue.hpp"
 #include <algorithm>
 #include <climits>
-#include <map>
-#include <stdexcept>
 
 namespace gc {
 
-void expandSeeds(const MinimizerIndex& index, const KmerMatch* matches, size_t nMatches, size_t readLength, double density, std::vector<SeedRec>& out)
+void expandSeeds(const MinimizerIndex& index, const KmerMatch* matches, size_t nMatches, size_t readLength, double density, std::vector<SeedRec>& out, GlueScratch& scratch)
 {
-	struct Match { size_t pos, start, count; };
-	std::vector<Match> m(nMatches);
+	auto& m = scratch.matches;
+	m.resize(nMatches);
 	for (size_t i = 0; i < nMatches; i++) {
-		size_t start = index.startPos[matches[i].key];
-		m[i] = { matches[i].pos, start, (size_t)(index.startPos[matches[i].key + 1] - start) };
+		uint64_t start = index.startPos[matches[i].key];
+		m[i] = { matches[i].pos, (uint32_t)(index.startPos[matches[i].key + 1] - start), start };
 	}
 	// "prefer less common minimizers": unstable sort by count alone, on the position-ordered list (:497)
-	std::sort(m.begin(), m.end(), [](const Match& l, const Match& r) { return l.count < r.count; });
+	std::sort(m.begin(), m.end(), [](const GlueScratch::Match& l, const GlueScratch::Match& r) { return l.count < r.count; });
 	size_t maxHits = (size_t)(readLength * density);
 	if (density == -1) maxHits = SIZE_MAX;
 	size_t seedsHere = 0, allowedCount = 0;
 	out.clear();
-	for (const Match& x : m) {
+	for (const auto& x : m) {
 		if (seedsHere >= maxHits && x.count > allowedCount) break;
 		allowedCount = x.count;
-		for (size_t i = x.start; i < x.start + x.count; i++) {
+		for (uint64_t i = x.start; i < x.start + x.count; i++) {
 			SeedRec s;
 			s.node = (uint32_t)(index.positions[i] >> 6);
-			s.offset = (uint32_t)(index.positions[i] & 63);
-			s.seqPos = (uint32_t)x.pos;
-			s.matchLen = (uint32_t)index.k;
-			s.rawGoodness = index.maxCount - x.count;
+			s.offset = (uint8_t)(index.positions[i] & 63);
+			s.seqPos = x.pos;
+			s.matchLen = (uint8_t)index.k;
+			s.rawGoodness = (uint32_t)(index.maxCount - x.count);
 			s.goodness = 0;
 			s.clusterSize = 0;
 			out.push_back(s);
@@ -38,50 +36,55 @@ void expandSeeds(const MinimizerIndex& index, const KmerMatch* matches, size_t n
 	}
 }
 
-void orderSeedsByChaining(const AlignmentGraph& graph, std::vector<SeedRec>& seeds)
+bool orderSeedsByChaining(const AlignmentGraph& graph, std::vector<SeedRec>& seeds, GlueScratch& scratch)
 {
-	// seeds of one chain are clustered by diagonal; chains are independent, so the container order is immaterial
-	std::map<size_t, std::vector<std::pair<size_t, size_t>>> byChain;
+	// Seeds of one chain are clustered by diagonal (gap <= 100). Chains are independent and a cluster's
+	// goodness depends only on the multiset of its seeds' read positions, so one sort by (chain, diagonal)
+	// replaces the reference's per-chain hash map + two unstable sorts without changing any value.
+	auto& d = scratch.diags;
+	d.resize(seeds.size());
 	for (size_t i = 0; i < seeds.size(); i++) {
-		size_t diagonalBase = graph.chainApproxPos[seeds[i].node] + seeds[i].offset;
-		if (diagonalBase < seeds[i].seqPos) throw std::runtime_error("seed before chain start");   // assert at :259
-		byChain[graph.chainNumber[seeds[i].node]].emplace_back(i, diagonalBase - seeds[i].seqPos);
+		uint64_t base = graph.chainApproxPos[seeds[i].node] + seeds[i].offset;
+		if (base < seeds[i].seqPos) return false;   // assert at :259
+		d[i] = { graph.chainNumber[seeds[i].node], base - seeds[i].seqPos, (uint32_t)i };
 	}
-	for (auto& entry : byChain) {
-		auto& v = entry.second;
-		std::sort(v.begin(), v.end(), [](std::pair<size_t, size_t> l, std::pair<size_t, size_t> r) { return l.second < r.second; });
-		size_t clusterStart = 0;
-		for (size_t i = 1; i <= v.size(); i++) {
-			if (i < v.size() && v[i].second <= v[i - 1].second + 100) continue;
-			std::sort(v.begin() + clusterStart, v.begin() + i, [&seeds](std::pair<size_t, size_t> l, std::pair<size_t, size_t> r) { return seeds[l.first].seqPos < seeds[r.first].seqPos; });
-			size_t matchingBps = 0;
-			int lastEnd = INT_MIN;
-			for (size_t j = clusterStart; j < i; j++) {
-				const SeedRec& s = seeds[v[j].first];
-				int thisStart = (int)s.seqPos - (int)s.matchLen + 1;
-				int thisEnd = (int)s.seqPos;
-				if (thisEnd < lastEnd || thisEnd <= thisStart) throw std::runtime_error("seed cluster order");   // asserts at :279-280
-				matchingBps += (size_t)(thisEnd - std::max(thisStart, lastEnd));
-				lastEnd = thisEnd;
-			}
-			for (size_t j = clusterStart; j < i; j++) {
-				seeds[v[j].first].goodness = matchingBps + seeds[v[j].first].rawGoodness;
-				seeds[v[j].first].clusterSize = i - clusterStart;
-			}
-			clusterStart = i;
+	std::sort(d.begin(), d.end(), [](const GlueScratch::Diag& l, const GlueScratch::Diag& r) { return l.chain != r.chain ? l.chain < r.chain : l.diagonal < r.diagonal; });
+	auto& pos = scratch.clusterPos;
+	size_t clusterStart = 0;
+	for (size_t i = 1; i <= d.size(); i++) {
+		if (i < d.size() && d[i].chain == d[i - 1].chain && d[i].diagonal <= d[i - 1].diagonal + 100) continue;
+		pos.clear();
+		for (size_t j = clusterStart; j < i; j++) pos.push_back(seeds[d[j].index].seqPos);
+		std::sort(pos.begin(), pos.end());
+		size_t matchingBps = 0;
+		int lastEnd = INT_MIN;
+		int matchLen = seeds[d[clusterStart].index].matchLen;
+		for (uint32_t p : pos) {
+			int thisStart = (int)p - matchLen + 1, thisEnd = (int)p;
+			if (thisEnd <= thisStart) return false;   // assert at :280
+			matchingBps += (size_t)(thisEnd - std::max(thisStart, lastEnd));
+			lastEnd = thisEnd;
 		}
+		size_t size = i - clusterStart;
+		for (size_t j = clusterStart; j < i; j++) {
+			SeedRec& s = seeds[d[j].index];
+			s.goodness = (uint32_t)(matchingBps + s.rawGoodness);
+			s.clusterSize = (uint16_t)std::min<size_t>(size, 65535);
+		}
+		clusterStart = i;
 	}
-	std::sort(seeds.begin(), seeds.end(), [](const SeedRec& l, const SeedRec& r) { return l.goodness < r.goodness; });
+	std::sort(seeds.begin(), seeds.end(), [](const SeedRec& l, const SeedRec& r) { return l.goodness < r.goodness; });   // :293, order-critical
 	std::reverse(seeds.begin(), seeds.end());
+	return true;
 }
 
 void fragmentWindows(std::vector<SeedRec>& seeds, size_t readLength, size_t splitLen, size_t splitGap, std::vector<FragmentWindow>& out)
 {
-	std::sort(seeds.begin(), seeds.end(), [](const SeedRec& l, const SeedRec& r) { return l.seqPos < r.seqPos; });
+	std::sort(seeds.begin(), seeds.end(), [](const SeedRec& l, const SeedRec& r) { return l.seqPos < r.seqPos; });   // src/Aligner.cpp:667, order-critical
 	out.clear();
 	size_t sl = 0, sr = 0;
 	for (size_t l = 0; l + splitLen <= readLength; l += splitGap) {
-		while (sr < seeds.size() && seeds[sr].seqPos + seeds[sr].matchLen <= l + splitLen) sr++;
+		while (sr < seeds.size() && (size_t)seeds[sr].seqPos + seeds[sr].matchLen <= l + splitLen) sr++;
 		while (sl < sr && seeds[sl].seqPos < l) sl++;
 		if (sl >= sr) continue;
 		out.push_back({ (uint32_t)l, (uint32_t)sl, (uint32_t)sr });

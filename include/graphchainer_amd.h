@@ -47,6 +47,7 @@ typedef struct gc_params {
 	int32_t min_cluster_size;   /* --seeds-clustersize (1) */
 	int32_t long_pass;          /* 1: also run the whole-read GraphAligner pass (src/Aligner.cpp:630-654) */
 	int32_t keep_traces;        /* 1: return per-anchor traces (debug / parity tests) */
+	int32_t keep_seeds;         /* 1: return the ordered seed list of every read (seed_* arrays; else they are empty) */
 } gc_params;
 
 void gc_params_default(gc_params* p);
@@ -136,7 +137,7 @@ typedef struct gc_result {
 	/* device time of each kernel of this batch in microseconds (HIP events on the stream):
 	 * [0] seed lookup, [1] fragment extension, [2] anchor build, [3] chaining, [4] long pass */
 	double kernel_us[8];
-	double host_us[4];            /* [0] seed glue, [1] result assembly */
+	double host_us[4];            /* wall time: [0] host seed glue, [1] result assembly, [2] seed lookup + transfers, [3] extension..chaining + transfers */
 } gc_result;
 
 /* Runs seeding, fragment seed-extension, anchor construction and co-linear chaining (and, with

@@ -37,7 +37,7 @@ def run_case(gca, gfa, reads, **kw):
     from oracle import Oracle
     graph = gca.AlignmentGraph(gfa)
     seeder = gca.MinimizerSeeder(graph)
-    aligner = gca.Aligner(graph, seeder, keep_traces=True, **kw)
+    aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, **kw)
     got = aligner.align_reads(reads)
     want = Oracle(gfa, long_pass=False, **kw).align(reads)
     return got, want
