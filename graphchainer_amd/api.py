@@ -48,7 +48,7 @@ class GcResult(C.Structure):
         ("read_longall_off", _P(C.c_uint64)), ("longall_start", _P(C.c_uint32)), ("longall_end", _P(C.c_uint32)), ("longall_score", _P(C.c_uint32)),
         ("long_trace_off", _P(C.c_uint64)), ("long_trace_node", _P(C.c_int32)), ("long_trace_offset", _P(C.c_uint32)),
         ("long_trace_seqpos", _P(C.c_uint32)), ("long_trace_switch", _P(C.c_uint8)),
-        ("failed_assertion", _P(C.c_uint8)), ("seeds_extended", _P(C.c_uint64)),
+        ("failed_assertion", _P(C.c_uint8)), ("seeds_extended", _P(C.c_uint64)), ("seeds_extended_long", _P(C.c_uint64)),
         ("counters", C.c_uint64 * 8), ("kernel_us", C.c_double * 8), ("host_us", C.c_double * 4),
     ]
 
@@ -196,14 +196,15 @@ _RESULT_FIELDS = {
     "anchor_first_node": "anchors", "anchor_first_offset": "anchors", "anchor_first_seqpos": "anchors",
     "anchor_last_node": "anchors", "anchor_last_offset": "anchors", "anchor_last_seqpos": "anchors", "anchor_score": "anchors",
     "read_chain_off": "n+1", "chain": "chains", "chain_score": "n",
-    "failed_assertion": "n", "seeds_extended": "n",
+    "failed_assertion": "n", "seeds_extended": "n", "seeds_extended_long": "n",
+    "read_longall_off": "n+1", "longall_start": "longs", "longall_end": "longs", "longall_score": "longs",
 }
 
 
 class Aligner:
     """Batched stand-in for the reference's per-read hot path (src/Aligner.cpp:601-922)."""
 
-    def __init__(self, graph, seeder, bandwidth=10, split_len=35, split_gap=35, colinear_gap=10000, seed_density=10.0, keep_traces=False, keep_seeds=False):
+    def __init__(self, graph, seeder, bandwidth=10, split_len=35, split_gap=35, colinear_gap=10000, seed_density=10.0, keep_traces=False, keep_seeds=False, long_pass=False):
         self.lib = load_library()
         self.graph = graph
         self.seeder = seeder
@@ -216,6 +217,7 @@ class Aligner:
         self.params.seed_density = seed_density
         self.params.keep_traces = int(keep_traces)
         self.params.keep_seeds = int(keep_seeds)
+        self.params.long_pass = int(long_pass)
         self.stream = C.c_void_p()
         _check(self.lib.gc_stream_create(C.byref(self.stream)))
 
@@ -239,12 +241,18 @@ class Aligner:
             paths = int(out["anchor_path_off"][-1])
             out["read_chain_off"] = arr(r.read_chain_off, n + 1)
             chains = int(out["read_chain_off"][-1])
-            counts = {"n": n, "seeds": seeds, "anchors": anchors, "paths": paths, "chains": chains}
+            out["read_longall_off"] = arr(r.read_longall_off, n + 1)
+            longs = int(out["read_longall_off"][-1])
+            counts = {"n": n, "n+1": n + 1, "seeds": seeds, "anchors": anchors, "paths": paths, "chains": chains, "longs": longs}
             for name, expr in _RESULT_FIELDS.items():
                 if name in out:
                     continue
                 out[name] = arr(getattr(r, name), counts[expr])
             if self.params.keep_traces:
+                out["long_trace_off"] = arr(r.long_trace_off, longs + 1)
+                lcells = int(out["long_trace_off"][-1]) if longs else 0
+                for name in ("long_trace_node", "long_trace_offset", "long_trace_seqpos", "long_trace_switch"):
+                    out[name] = arr(getattr(r, name), lcells)
                 out["anchor_trace_off"] = arr(r.anchor_trace_off, anchors + 1)
                 cells = int(out["anchor_trace_off"][-1])
                 for name in ("anchor_trace_node", "anchor_trace_offset", "anchor_trace_seqpos", "anchor_trace_switch"):

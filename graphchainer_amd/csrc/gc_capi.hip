@@ -185,10 +185,17 @@ struct gc_stream {
 	hipEvent_t ev[12] {};
 	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, work, results, scratch, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
 	PinnedBuffer hMatches, hWork, hFrags, hFragSeeds, hJobs, hAnchors, hFragStatus, hFragExtended, hChainOut, hChainLen, hChainScore, hChainStatus, hPathPool, hSmall;
+	// whole-read pass: runs on its own stream, concurrently with the fragment kernels
+	hipStream_t longStream = nullptr;
+	hipEvent_t longEv[2] {};
+	DeviceBuffer longSeeds, longJobs, longAlns, longResults, longScratch, longCells, longCursor;
+	PinnedBuffer hLongSeeds, hLongJobs, hLongAlns, hLongResults, hLongSmall;
 	~gc_stream()
 	{
 		for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+		for (auto& e : longEv) if (e) (void)hipEventDestroy(e);
 		if (stream) (void)hipStreamDestroy(stream);
+		if (longStream) (void)hipStreamDestroy(longStream);
 	}
 };
 
@@ -354,8 +361,11 @@ static void requireDevice()
 namespace {
 
 struct ReadGlue {
-	std::vector<gc::SeedRec> seeds;
+	std::vector<gc::SeedRec> seeds;       // fragment-pass order (by seqPos)
+	std::vector<gc::SeedRec> longSeeds;   // whole-read pass order (by goodness), only with long_pass
 	std::vector<gc::FragmentWindow> windows;
+	std::vector<LongAln> longAlns;        // final order (the reference's repeated sort by alignmentStart)
+	uint64_t longBegin = 0, longTraceBegin = 0, longSeedBegin = 0;
 	bool failed = false;
 	uint64_t slotBegin = 0, fragBegin = 0;
 	uint64_t nAnchors = 0, nPath = 0, nTrace = 0, anchorBegin = 0, pathBegin = 0, traceBegin = 0, seedBegin = 0, chainBegin = 0;
@@ -569,7 +579,9 @@ int gc_stream_create(gc_stream** out)
 	int rc = guarded([&]() {
 		requireDevice();
 		HIP_CHECK(hipStreamCreate(&st->stream));
+		HIP_CHECK(hipStreamCreate(&st->longStream));
 		for (auto& e : st->ev) HIP_CHECK(hipEventCreate(&e));
+		for (auto& e : st->longEv) HIP_CHECK(hipEventCreate(&e));
 		return (int)GC_OK;
 	});
 	if (rc != GC_OK) { delete st; return rc; }
@@ -623,7 +635,7 @@ void gc_result_free(gc_result* r)
 		r->anchor_path, r->anchor_first_node, r->anchor_first_offset, r->anchor_first_seqpos, r->anchor_last_node, r->anchor_last_offset, r->anchor_last_seqpos, r->anchor_score,
 		r->anchor_trace_off, r->anchor_trace_node, r->anchor_trace_offset, r->anchor_trace_seqpos, r->anchor_trace_switch, r->read_chain_off, r->chain, r->chain_score,
 		r->read_longall_off, r->longall_start, r->longall_end, r->longall_score, r->long_trace_off, r->long_trace_node, r->long_trace_offset, r->long_trace_seqpos, r->long_trace_switch,
-		r->failed_assertion, r->seeds_extended };
+		r->failed_assertion, r->seeds_extended, r->seeds_extended_long };
 	for (void* p : ptrs) free(p);
 	free(r);
 }
@@ -632,7 +644,6 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 {
 	if (!G || !S || !st || !R || !P || !out) return fail(GC_ERR_INVALID, "null argument");
 	if (P->split_len < 16 || P->split_len > 64 || P->split_gap < 1) return fail(GC_ERR_INVALID, "split_len must be in [16,64] (one 64-row slice per fragment extension) and split_gap >= 1");
-	if (P->long_pass) return fail(GC_ERR_INVALID, "long_pass: the whole-read GraphAligner pass is not part of this build yet (SURVEY.md §8 row K3-long)");
 	*out = nullptr;
 	gc_result* res = (gc_result*)calloc(1, sizeof(gc_result));
 	int rc = guarded([&]() {
@@ -687,6 +698,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				gl.seeds.clear();
 				return;
 			}
+			if (P->long_pass) gl.longSeeds = gl.seeds;
 			gc::fragmentWindows(gl.seeds, len, (size_t)P->split_len, (size_t)P->split_gap, gl.windows);
 		});
 		uint64_t nSlots = 0, nFrags = 0, nSeedsTotal = 0;
@@ -755,6 +767,68 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		ChainCaps caps { 1, 1, 1 };
 		for (uint64_t r = 0; r < n; r++) caps.capAnchors = std::max(caps.capAnchors, jobs[r].nSlots);
 		res->host_us[0] = nowUs() - tGlue;
+
+		// ---------------- K3-long: whole-read pass on its own stream (src/Aligner.cpp:630-654)
+		const uint32_t maxAlignments = 32;
+		uint64_t nLongSeeds = 0, maxReadLen = 1;
+		LongAln* hLongAlns = nullptr;
+		LongReadResult* hLongResults = nullptr;
+		unsigned long long* hLongSmall = nullptr;
+		LongCell* dLongCells = nullptr;
+		if (P->long_pass) {
+			for (uint64_t r = 0; r < n; r++) { glue[r].longSeedBegin = nLongSeeds; nLongSeeds += glue[r].longSeeds.size(); maxReadLen = std::max<uint64_t>(maxReadLen, R->offsets[r + 1] - R->offsets[r]); }
+			if (nLongSeeds >= 0xffffffffull) throw std::runtime_error("batch too large for the whole-read pass");
+			LongSeed* hSeeds = st->hLongSeeds.reserve<LongSeed>(nLongSeeds);
+			LongJob* hJobs = st->hLongJobs.reserve<LongJob>(n);
+			uint64_t cellBudget = 0;
+			for (uint64_t r = 0; r < n; r++) cellBudget += 3 * (R->offsets[r + 1] - R->offsets[r]) + 256;
+			pool.run(n, [&](size_t r, size_t) {
+				const ReadGlue& gl = glue[r];
+				uint64_t at = gl.longSeedBegin;
+				for (const gc::SeedRec& s : gl.longSeeds) {
+					int id = hg.nodeIDs[s.node];
+					auto rev = hg.GetReversePosition(id, hg.nodeOffset[s.node] + s.offset);
+					size_t twin = hg.GetUnitigNode(rev.first, rev.second);
+					hSeeds[at++] = LongSeed { s.node, s.offset, (uint32_t)twin, (uint32_t)(rev.second - hg.nodeOffset[twin]), s.seqPos, s.goodness, s.clusterSize, 0 };
+				}
+				LongJob& j = hJobs[r];
+				j.readOff = R->offsets[r];
+				j.readLen = (uint32_t)(R->offsets[r + 1] - R->offsets[r]);
+				j.seedBegin = (uint32_t)gl.longSeedBegin;
+				j.seedEnd = (uint32_t)at;
+				j.alnBegin = (uint32_t)(r * maxAlignments);
+			});
+			ExtendConfig lcfg;
+			lcfg.bandwidth = P->bandwidth;
+			lcfg.maxSlices = (uint32_t)(maxReadLen / 64 + 3);
+			lcfg.maxItems = 8192;
+			lcfg.maxPending = 96;
+			lcfg.maxTrace = (uint32_t)(maxReadLen + maxReadLen / 2 + 512);
+			if (const char* env = getenv("GC_LONG_MAX_ITEMS")) lcfg.maxItems = (uint32_t)std::max(64, atoi(env));
+			uint64_t lslab = longSlabBytes(lcfg);
+			uint64_t lanes = (n + 63) / 64 * 64;
+			LongSeed* dLongSeeds = st->longSeeds.reserve<LongSeed>(nLongSeeds);
+			LongJob* dLongJobs = st->longJobs.reserve<LongJob>(n);
+			LongAln* dLongAlns = st->longAlns.reserve<LongAln>(n * maxAlignments);
+			LongReadResult* dLongResults = st->longResults.reserve<LongReadResult>(n);
+			uint8_t* dLongScratch = st->longScratch.reserve<uint8_t>(lanes * lslab);
+			dLongCells = st->longCells.reserve<LongCell>(cellBudget);
+			unsigned long long* dLongCursor = st->longCursor.reserve<unsigned long long>(16);
+			hLongAlns = st->hLongAlns.reserve<LongAln>(n * maxAlignments);
+			hLongResults = st->hLongResults.reserve<LongReadResult>(n);
+			hLongSmall = st->hLongSmall.reserve<unsigned long long>(16);
+			hipStream_t ls = st->longStream;
+			HIP_CHECK(hipMemsetAsync(dLongCursor, 0, 16 * sizeof(unsigned long long), ls));
+			if (nLongSeeds) HIP_CHECK(hipMemcpyAsync(dLongSeeds, hSeeds, nLongSeeds * sizeof(LongSeed), hipMemcpyHostToDevice, ls));
+			if (n) HIP_CHECK(hipMemcpyAsync(dLongJobs, hJobs, n * sizeof(LongJob), hipMemcpyHostToDevice, ls));
+			HIP_CHECK(hipEventRecord(st->longEv[0], ls));
+			launchLongPass(ls, G->dev, G->devTables, G->devIupac, lcfg, dLongJobs, (uint32_t)n, dLongSeeds, R->devBases, R->totalBases, (uint32_t)P->min_cluster_size, maxAlignments,
+				dLongScratch, lslab, dLongCells, dLongCursor, cellBudget, dLongAlns, dLongResults, dLongCursor + 8);
+			HIP_CHECK(hipEventRecord(st->longEv[1], ls));
+			if (n) HIP_CHECK(hipMemcpyAsync(hLongAlns, dLongAlns, n * maxAlignments * sizeof(LongAln), hipMemcpyDeviceToHost, ls));
+			if (n) HIP_CHECK(hipMemcpyAsync(hLongResults, dLongResults, n * sizeof(LongReadResult), hipMemcpyDeviceToHost, ls));
+			HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
+		}
 
 		// ---------------- K3 / K3b / K4
 		double tDev = nowUs();
@@ -838,11 +912,28 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		HIP_CHECK(hipStreamSynchronize(stream));
 		res->host_us[3] = nowUs() - tDev;   // K3..K4 + their transfers, wall
 
+		// ---------------- whole-read pass results
+		std::vector<LongCell> longCells;
+		if (P->long_pass) {
+			HIP_CHECK(hipStreamSynchronize(st->longStream));
+			float ms = 0;
+			HIP_CHECK(hipEventElapsedTime(&ms, st->longEv[0], st->longEv[1]));
+			res->kernel_us[4] = (double)ms * 1000.0;
+			for (int i = 0; i < 6; i++) res->counters[i] += hLongSmall[8 + i];   // the long pass counts in the same units
+			res->counters[6] = hLongSmall[8 + 4];                                   // extensions of the long pass alone
+			res->counters[7] = hLongSmall[8 + 0] + hLongSmall[8 + 1];               // tiles of the long pass alone
+			for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status == 2) throw std::runtime_error("whole-read pass capacity overflow (raise GC_LONG_MAX_ITEMS)");
+			if (P->keep_traces) {
+				longCells.resize(hLongSmall[0]);
+				if (hLongSmall[0]) HIP_CHECK(hipMemcpy(longCells.data(), dLongCells, hLongSmall[0] * sizeof(LongCell), hipMemcpyDeviceToHost));
+			}
+		}
+
 		// ---------------- assemble the flat result: count per read, prefix-sum, fill in parallel
 		double tAsm = nowUs();
 		std::atomic<int> overflow { 0 }, chainFailure { 0 };
 		std::vector<uint8_t> failedAssertion(n, 0);
-		std::vector<uint64_t> seedsExtended(n, 0);
+		std::vector<uint64_t> seedsExtended(n, 0), seedsExtendedLong(n, 0);
 		auto forEachAnchor = [&](uint64_t r, auto&& visit) {   // visit(slotIndex, fragmentIndex) for every anchor the reference would keep
 			const ReadGlue& gl = glue[r];
 			uint64_t slot = gl.slotBegin;
@@ -864,6 +955,16 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				if (fragStatus[F] == 1) { failedAssertion[r] = 1; break; }
 				seedsExtended[r] += fragExtended[F];
 			}
+			if (P->long_pass) {
+				seedsExtendedLong[r] = hLongResults[r].seedsExtended;
+				if (hLongResults[r].status == 1) failedAssertion[r] = 1;
+				// the reference re-sorts its alignment list by alignmentStart after every accepted alignment
+				// (src/GraphAligner.h:183); replaying that on the acceptance-ordered list gives its final order
+				for (uint32_t a = 0; a < hLongResults[r].nAlignments; a++) {
+					gl.longAlns.push_back(hLongAlns[r * maxAlignments + a]);
+					std::sort(gl.longAlns.begin(), gl.longAlns.end(), [](const LongAln& l, const LongAln& rr) { return l.start < rr.start; });
+				}
+			}
 			forEachAnchor(r, [&](uint64_t slot, uint64_t) {
 				gl.nAnchors++;
 				gl.nPath += anchors[slot].pathLen;
@@ -878,10 +979,13 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		});
 		if (overflow) throw std::runtime_error("extension capacity overflow in a fragment (raise GC_EXT_MAX_ITEMS / GC_EXT_MAX_PENDING / GC_EXT_MAX_TRACE)");
 		if (chainFailure) throw std::runtime_error("chaining kernel failure (status " + std::to_string((int)chainFailure) + ")");
-		uint64_t nAnchors = 0, nPath = 0, nTrace = 0, nChain = 0;
+		uint64_t nAnchors = 0, nPath = 0, nTrace = 0, nChain = 0, nLong = 0, nLongTrace = 0;
 		for (uint64_t r = 0; r < n; r++) {
 			glue[r].anchorBegin = nAnchors; glue[r].pathBegin = nPath; glue[r].traceBegin = nTrace; glue[r].chainBegin = nChain;
+			glue[r].longBegin = nLong; glue[r].longTraceBegin = nLongTrace;
 			nAnchors += glue[r].nAnchors; nPath += glue[r].nPath; nTrace += glue[r].nTrace; nChain += chainLen[r];
+			nLong += glue[r].longAlns.size();
+			if (P->keep_traces) for (const LongAln& a : glue[r].longAlns) nLongTrace += a.traceLen;
 		}
 		const bool keepSeeds = P->keep_seeds != 0;
 		res->read_seed_off = mallocArray<uint64_t>(n + 1);
@@ -902,8 +1006,14 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		res->read_chain_off = mallocArray<uint64_t>(n + 1);
 		res->chain = mallocArray<uint32_t>(nChain);
 		res->chain_score = mallocArray<uint64_t>(n);
-		res->read_longall_off = (uint64_t*)calloc(n + 1, sizeof(uint64_t));
-		res->long_trace_off = (uint64_t*)calloc(1, sizeof(uint64_t));
+		res->read_longall_off = mallocArray<uint64_t>(n + 1);
+		res->read_longall_off[n] = nLong;
+		res->longall_start = mallocArray<uint32_t>(nLong); res->longall_end = mallocArray<uint32_t>(nLong); res->longall_score = mallocArray<uint32_t>(nLong);
+		res->long_trace_off = mallocArray<uint64_t>(nLong + 1);
+		res->long_trace_off[nLong] = nLongTrace;
+		res->long_trace_node = mallocArray<int32_t>(nLongTrace); res->long_trace_offset = mallocArray<uint32_t>(nLongTrace);
+		res->long_trace_seqpos = mallocArray<uint32_t>(nLongTrace); res->long_trace_switch = mallocArray<uint8_t>(nLongTrace);
+		res->seeds_extended_long = mallocArray<uint64_t>(n);
 		res->failed_assertion = mallocArray<uint8_t>(n);
 		res->seeds_extended = mallocArray<uint64_t>(n);
 		res->read_seed_off[n] = keepSeeds ? nSeedsTotal : 0; res->read_anchor_off[n] = nAnchors; res->anchor_path_off[nAnchors] = nPath; res->read_chain_off[n] = nChain;
@@ -919,6 +1029,20 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			res->chain_score[r] = chainScore[r];
 			res->failed_assertion[r] = failedAssertion[r];
 			res->seeds_extended[r] = seedsExtended[r];
+			res->seeds_extended_long[r] = seedsExtendedLong[r];
+			res->read_longall_off[r] = gl.longBegin;
+			{
+				uint64_t la = gl.longBegin, lt = gl.longTraceBegin;
+				for (const LongAln& al : gl.longAlns) {
+					res->longall_start[la] = al.start; res->longall_end[la] = al.end; res->longall_score[la] = al.score;
+					res->long_trace_off[la] = P->keep_traces ? lt : 0;
+					if (P->keep_traces) for (uint32_t i = 0; i < al.traceLen; i++, lt++) {
+						const LongCell& c = longCells[al.traceOff + i];
+						res->long_trace_node[lt] = c.node; res->long_trace_offset[lt] = c.offset; res->long_trace_seqpos[lt] = c.seqPos; res->long_trace_switch[lt] = (uint8_t)c.nodeSwitch;
+					}
+					la++;
+				}
+			}
 			for (uint32_t i = 0; i < chainLen[r]; i++) res->chain[gl.chainBegin + i] = chainOut[jobs[r].chainBegin + i];
 			uint64_t a = gl.anchorBegin, pathAt = gl.pathBegin, traceAt = gl.traceBegin;
 			forEachAnchor(r, [&](uint64_t slot, uint64_t F) {

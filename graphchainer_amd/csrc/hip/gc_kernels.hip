@@ -451,6 +451,175 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 }
 
 // =====================================================================================================
+// K3-long - the whole-read GraphAligner pass. reference: AlignOneWay with sloppyOptimizations,
+// src/GraphAligner.h:114-203 (called from src/Aligner.cpp:565), getAlignmentFromSeed :567-626,
+// exactAlignmentPart :407-461. The reference walks a read's seeds in goodness order and every decision
+// (skip because an earlier alignment covers the seed, stop because the read is aligned end to end)
+// depends on the alignments produced so far, so a read is one sequential unit: one lane per read, the
+// multi-slice extension core of gc_device.hpp does the work. All reads of a batch have similar length,
+// which keeps the lanes of a wave in step at slice granularity.
+// =====================================================================================================
+
+struct LongSlab { LaneScratch sc; TraceCell* traceB; };   // backward trace is parked while the forward extension reuses sc.trace
+
+__device__ __forceinline__ LongSlab longSlab(uint8_t* slab, const ExtendConfig& cfg)
+{
+	LongSlab ls;
+	ls.sc = laneScratch(slab, cfg);
+	ls.traceB = ls.sc.trace + cfg.maxTrace;
+	return ls;
+}
+
+// Is the seed's cell on this alignment's trace? (:407-461). Returns 1 yes, 0 no, 2 the reference asserts.
+__device__ inline int onTrace(const LongCell* trace, uint32_t n, uint32_t seqPos, int32_t compareNode, uint32_t nodeOffset)
+{
+	if (!(trace[n - 1].seqPos > trace[0].seqPos)) return 2;
+	if (trace[n - 1].seqPos < seqPos || trace[0].seqPos > seqPos) return 0;
+	uint32_t lo = 0, hi = n;   // first cell with seqPos >= target (seqPos is non-decreasing along the trace)
+	while (lo < hi) {
+		uint32_t mid = (lo + hi) / 2;
+		if (trace[mid].seqPos < seqPos) lo = mid + 1; else hi = mid;
+	}
+	for (uint32_t i = lo; i < n && trace[i].seqPos == seqPos; i++)
+		if (trace[i].node == compareNode && trace[i].offset == nodeOffset) return 1;
+	return 0;
+}
+
+__global__ void __launch_bounds__(64) k_long_pass(DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg,
+	const LongJob* __restrict__ jobs, uint32_t nReads, const LongSeed* __restrict__ seeds, const char* __restrict__ bases, uint64_t rcBase,
+	uint32_t minClusterSize, uint32_t maxAlignments, uint8_t* __restrict__ scratch, uint64_t slabBytes,
+	LongCell* __restrict__ cellPool, unsigned long long* __restrict__ cellCursor, uint64_t cellCapacity,
+	LongAln* __restrict__ alns, LongReadResult* __restrict__ results, unsigned long long* __restrict__ counters)
+{
+	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t stride = gridDim.x * blockDim.x;
+	LongSlab ls = longSlab(scratch + (uint64_t)tid * slabBytes, cfg);
+	ExtCounters cnt { 0, 0, 0, 0, 0, 0 };
+	for (uint32_t r = tid; r < nReads; r += stride) {
+		LongJob job = jobs[r];
+		LongAln* mine = alns + job.alnBegin;
+		uint32_t nAln = 0, extended = 0, status = 0;
+		uint32_t e2eScore = 0;   // seedScoreForEndToEndAln
+		const int L = (int)job.readLen;
+		for (uint32_t si = job.seedBegin; si < job.seedEnd && status == 0; si++) {
+			LongSeed sd = seeds[si];
+			if (sd.goodness < e2eScore) break;                       // aligned end to end, skip the rest (:127-131)
+			if (sd.clusterSize < minClusterSize) continue;            // :141-146
+			bool skip = false;
+			for (uint32_t a = 0; a < nAln; a++)                        // sloppy overlap rule (:147-161)
+				if (mine[a].start <= sd.seqPos && mine[a].end >= sd.seqPos && mine[a].goodness > sd.goodness) { skip = true; break; }
+			if (skip) continue;
+			int32_t compareNode = g.nodeIDs[sd.node];
+			uint32_t compareOffset = g.nodeOffset[sd.node] + sd.offset;
+			for (uint32_t a = 0; a < nAln && !skip; a++) {            // exactAlignmentPart (:163-173)
+				int on = onTrace(cellPool + mine[a].traceOff, mine[a].traceLen, sd.seqPos, compareNode, compareOffset);
+				if (on == 2) { status = 1; break; }
+				if (on == 1) skip = true;
+			}
+			if (skip || status) continue;
+			extended++;
+			// getAlignmentFromSeed (:567-626): backward on revcomp(read[0..p)), forward on read(p..]
+			const int p = (int)sd.seqPos;
+			uint32_t nB = 0, nF = 0;
+			int32_t scoreB = 0, scoreF = 0;
+			uint32_t stB = EXT_FAILED, stF = EXT_FAILED;
+			if (p > 0) {
+				stB = extendSeed(g, *ct, iupac, cfg, ls.sc, bases + rcBase + job.readOff + (uint64_t)(L - p), p, sd.twinNode, sd.twinOffset, nB, scoreB, cnt);
+				if (stB == EXT_OK) for (uint32_t i = 0; i < nB; i++) ls.traceB[i] = ls.sc.trace[i];
+			}
+			if (p < L - 1) stF = extendSeed(g, *ct, iupac, cfg, ls.sc, bases + job.readOff + (uint64_t)(p + 1), L - 1 - p, sd.node, sd.offset, nF, scoreF, cnt);
+			if (stB == EXT_ASSERT || stF == EXT_ASSERT) { status = 1; break; }
+			if (stB == EXT_OVERFLOW || stF == EXT_OVERFLOW) { status = 2; break; }
+			bool hasB = stB == EXT_OK, hasF = stF == EXT_OK;
+			if (!hasB && !hasF) continue;   // alignmentFailed()
+			if (nAln >= maxAlignments) { status = 2; break; }
+			uint32_t useB = hasB ? (hasF ? nB - 1 : nB) : 0;
+			uint32_t total = useB + (hasF ? nF : 0);
+			unsigned long long base = atomicAdd(cellCursor, (unsigned long long)total);
+			if (base + total > cellCapacity) { status = 2; break; }
+			LongCell* outCells = cellPool + base;
+			for (uint32_t i = 0; i < useB; i++) {   // fixReverseTraceSeqPosAndOrder (:543-565)
+				const TraceCell& c = ls.traceB[i];
+				uint32_t off = c.offsetAndSwitch & 255u;
+				int32_t id = g.nodeIDs[c.node];
+				uint32_t orig = g.nodeOffset[c.node] + off;
+				LongCell oc;
+				oc.node = id ^ 1;
+				oc.offset = g.origSize[id] - 1 - orig;
+				oc.seqPos = (uint32_t)(p - 1 - c.seqPos);
+				oc.nodeSwitch = (i + 1 < nB) ? ((ls.traceB[i + 1].offsetAndSwitch >> 8) & 1u) : 0u;
+				outCells[i] = oc;
+			}
+			if (hasF) for (uint32_t i = 0; i < nF; i++) {   // fixForwardTraceSeqPos (:527-540), device order reversed
+				const TraceCell& c = ls.sc.trace[nF - 1 - i];
+				LongCell oc;
+				oc.node = g.nodeIDs[c.node];
+				oc.offset = g.nodeOffset[c.node] + (c.offsetAndSwitch & 255u);
+				oc.seqPos = (uint32_t)(p + 1 + c.seqPos);
+				oc.nodeSwitch = (c.offsetAndSwitch >> 8) & 1u;
+				outCells[useB + i] = oc;
+			}
+			LongAln al;
+			al.start = outCells[0].seqPos;
+			al.end = outCells[total - 1].seqPos + 1;
+			al.score = (uint32_t)((hasB ? scoreB : 0) + (hasF ? scoreF : 0));
+			al.goodness = sd.goodness;
+			al.traceOff = base;
+			al.traceLen = total;
+			al.pad = 0;
+			mine[nAln++] = al;
+			// end-to-end test over the alignments sorted by start (:181-198); the union walk below is independent of
+			// the order among equal starts, so no sort is needed: repeatedly extend the contiguous prefix from 0
+			bool anyAtZero = false;
+			for (uint32_t a = 0; a < nAln; a++) if (mine[a].start == 0) anyAtZero = true;
+			if (anyAtZero) {
+				// the reference seeds the walk with alignments[0] of the sorted list: an alignment with start 0
+				uint32_t contiguousEnd = 0, minGoodness = 0xffffffffu;
+				bool grew = true;
+				// emulate the single left-to-right pass over the list sorted by start: an alignment joins iff its start
+				// <= the running end at the time it is visited; visiting in ascending start makes that a fixed point
+				// of "start <= current end", reached by iterating in start order
+				uint32_t lastStart = 0; bool firstPass = true;
+				while (grew) {
+					grew = false;
+					// pick unvisited alignments in ascending start order
+					uint32_t bestIdx = 0xffffffffu;
+					for (uint32_t a = 0; a < nAln; a++) {
+						if (mine[a].pad) continue;
+						if (bestIdx == 0xffffffffu || mine[a].start < mine[bestIdx].start) bestIdx = a;
+					}
+					if (bestIdx == 0xffffffffu) break;
+					mine[bestIdx].pad = 1;
+					grew = true;
+					if (firstPass) { contiguousEnd = mine[bestIdx].end; minGoodness = mine[bestIdx].goodness; firstPass = false; continue; }
+					if (mine[bestIdx].start <= contiguousEnd) {
+						minGoodness = mine[bestIdx].goodness < minGoodness ? mine[bestIdx].goodness : minGoodness;
+						contiguousEnd = mine[bestIdx].end > contiguousEnd ? mine[bestIdx].end : contiguousEnd;
+					}
+					(void)lastStart;
+				}
+				for (uint32_t a = 0; a < nAln; a++) mine[a].pad = 0;
+				if (contiguousEnd == (uint32_t)L) e2eScore = minGoodness;
+			}
+		}
+		LongReadResult rr;
+		rr.nAlignments = status == 1 ? 0 : nAln;   // a throwing AlignOneWay returns nothing (src/Aligner.cpp:585-592)
+		rr.seedsExtended = extended;
+		rr.status = status;
+		rr.pad = 0;
+		results[r] = rr;
+	}
+	if (cnt.extensions) {
+		atomicAdd(&counters[0], cnt.dpTiles);
+		atomicAdd(&counters[1], cnt.recomputeTiles);
+		atomicAdd(&counters[2], cnt.columnSteps);
+		atomicAdd(&counters[3], cnt.traceItems);
+		atomicAdd(&counters[4], cnt.extensions);
+		atomicAdd(&counters[5], cnt.backtraceTiles);
+	}
+}
+
+// =====================================================================================================
 // launchers
 // =====================================================================================================
 
@@ -507,6 +676,18 @@ void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, 
 {
 	if (nReads == 0) return;
 	hipLaunchKernelGGL(k_chain, dim3(chainGridBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus);
+}
+
+uint64_t longSlabBytes(const ExtendConfig& cfg) { return (extendSlabBytes(cfg) + sizeof(TraceCell) * (uint64_t)cfg.maxTrace + 63) & ~63ull; }
+
+void launchLongPass(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg, const LongJob* jobs, uint32_t nReads,
+	const LongSeed* seeds, const char* bases, uint64_t rcBase, uint32_t minClusterSize, uint32_t maxAlignments, uint8_t* scratch, uint64_t slabBytes,
+	LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity, LongAln* alns, LongReadResult* results, unsigned long long* counters)
+{
+	if (nReads == 0) return;
+	uint32_t blocks = (nReads + 63) / 64;
+	hipLaunchKernelGGL(k_long_pass, dim3(blocks), dim3(64), 0, stream, g, ct, iupac, cfg, jobs, nReads, seeds, bases, rcBase, minClusterSize, maxAlignments, scratch, slabBytes,
+		cellPool, cellCursor, cellCapacity, alns, results, counters);
 }
 
 } // namespace gcdev

@@ -61,6 +61,41 @@ struct ReadChainJob {
 
 struct ChainCaps { uint32_t capAnchors, capEndpoints, capTable; };
 
+// ---- whole-read pass (K3-long) ----
+struct LongSeed {    // a seed in goodness order (after OrderSeeds), with the backward start precomputed by the host
+	uint32_t node, offset;          // forward start: split node + offset of the seed base
+	uint32_t twinNode, twinOffset;  // backward start: reverse-strand twin position
+	uint32_t seqPos;
+	uint32_t goodness;
+	uint32_t clusterSize;
+	uint32_t pad;
+};
+
+struct LongJob {     // one read
+	uint64_t readOff;               // forward bases at bases[readOff..], reverse complement at bases[rcBase + readOff..]
+	uint32_t readLen;
+	uint32_t seedBegin, seedEnd;    // into the LongSeed array
+	uint32_t alnBegin;              // this read's slots in the alignment output (capacity maxAlignments)
+};
+
+struct LongCell {    // merged trace cell in the reference's output coordinates
+	int32_t node;                   // bigraph node id
+	uint32_t offset;                // offset in the original node
+	uint32_t seqPos;
+	uint32_t nodeSwitch;
+};
+
+struct LongAln {     // one accepted alignment, in acceptance order
+	uint32_t start, end;            // alignmentStart, alignmentEnd
+	uint32_t score;
+	uint32_t goodness;
+	uint64_t traceOff;
+	uint32_t traceLen;
+	uint32_t pad;
+};
+
+struct LongReadResult { uint32_t nAlignments, seedsExtended, status, pad; };
+
 // ---- launchers (all asynchronous on `stream`) ------------------------------------------------------
 void launchSeedLookup(hipStream_t stream, const SeedIndex& idx, const char* bases, const uint64_t* readOff, uint32_t nReads,
 	uint64_t* matchCursor, uint32_t* readMatchOff, uint32_t* readMatchCount, uint2* matches, uint64_t matchCapacity, uint32_t* tmp);
@@ -79,5 +114,10 @@ uint64_t chainScratchBytes(const ChainCaps& caps);
 uint32_t chainGridBlocks(uint32_t nReads);
 void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
 	int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* scratch, uint32_t* chainOut, uint32_t* chainLen, unsigned long long* chainScore, uint32_t* chainStatus);
+
+void launchLongPass(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg, const LongJob* jobs, uint32_t nReads,
+	const LongSeed* seeds, const char* bases, uint64_t rcBase, uint32_t minClusterSize, uint32_t maxAlignments, uint8_t* scratch, uint64_t slabBytes,
+	LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity, LongAln* alns, LongReadResult* results, unsigned long long* counters);
+uint64_t longSlabBytes(const ExtendConfig& cfg);
 
 } // namespace gcdev

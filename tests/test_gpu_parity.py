@@ -33,13 +33,17 @@ def gca():
     return g
 
 
-def run_case(gca, gfa, reads, **kw):
+LONG_KEYS = ["read_longall_off", "longall_start", "longall_end", "longall_score",
+             "long_trace_off", "long_trace_node", "long_trace_offset", "long_trace_seqpos", "long_trace_switch"]
+
+
+def run_case(gca, gfa, reads, long_pass=False, **kw):
     from oracle import Oracle
     graph = gca.AlignmentGraph(gfa)
     seeder = gca.MinimizerSeeder(graph)
-    aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, **kw)
+    aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, long_pass=long_pass, **kw)
     got = aligner.align_reads(reads)
-    want = Oracle(gfa, long_pass=False, **kw).align(reads)
+    want = Oracle(gfa, long_pass=long_pass, **kw).align(reads)
     return got, want
 
 
@@ -99,3 +103,18 @@ def test_counters_cover_oracle_work(gca, tmp_path):
     # ones, so device counts are >= oracle counts
     assert int(got["counters"][4]) >= int(want["counters"][4])
     assert int(got["counters"][2]) >= int(want["counters"][2])
+
+
+@pytest.mark.parametrize("backbone,n_reads,read_len", [(60_000, 6, 3000), (150_000, 8, 10_000)])
+def test_whole_read_pass_parity(gca, tmp_path, backbone, n_reads, read_len):
+    """The whole-read GraphAligner pass (multi-slice extensions, sloppy seed rules) against the oracle,
+    traces included; the fragment pass must be unaffected by running both."""
+    from graphchainer_amd.synth import SynthGraph
+    sg = SynthGraph(backbone, seed=5)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(n_reads, read_len, seed=21)
+    reads.append(reads[0][:700] + reads[1][300:1500])      # a chimeric read: more than one alignment
+    got, want = run_case(gca, gfa, reads, long_pass=True)
+    compare(got, want, COMPARE_KEYS + LONG_KEYS)
+    assert int(got["read_longall_off"][-1]) >= n_reads
