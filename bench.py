@@ -39,8 +39,9 @@ def parse_args():
     ap.add_argument("--reads", type=int, default=int(os.environ.get("GC_BENCH_READS", 10_000)))
     ap.add_argument("--read-len", type=int, default=10_000)
     ap.add_argument("--split-gap", type=int, default=35)
-    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("GC_BENCH_CPU_SAMPLE", 1500)), help="reads of the same workload timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("GC_BENCH_CPU_SAMPLE", 600)), help="reads of the same workload timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-long-pass", action="store_true", help="skip the whole-read GraphAligner pass (src/Aligner.cpp:630-654)")
     return ap.parse_args()
 
 
@@ -79,7 +80,8 @@ def main():
     t0 = time.time()
     seeder = gca.MinimizerSeeder(graph)
     t_index = time.time() - t0
-    aligner = gca.Aligner(graph, seeder, split_gap=args.split_gap)
+    long_pass = not args.no_long_pass
+    aligner = gca.Aligner(graph, seeder, split_gap=args.split_gap, long_pass=long_pass)
     batch = gca.ReadBatch(reads)          # inputs resident in HBM before the timed region
     total_bases = int(batch.lengths.sum())
 
@@ -96,11 +98,13 @@ def main():
     kernel_us = np.zeros(8)
     host_us = np.zeros(4)
     counters = np.zeros(8, dtype=np.float64)
+    counters_long = np.zeros(8, dtype=np.float64)
     for _ in range(args.steps):
         out = aligner.align_batch(batch)     # returns after the stream is drained (hipStreamSynchronize inside)
         kernel_us += out["kernel_us"]
         host_us += out["host_us"]
         counters += out["counters"].astype(np.float64)
+        counters_long += out["counters_long"].astype(np.float64)
     sync()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
@@ -111,33 +115,42 @@ def main():
     kernel_us /= max(1, args.steps)
     host_us /= max(1, args.steps)
     counters /= max(1, args.steps)
+    counters_long /= max(1, args.steps)
 
     chain_len = np.diff(out["read_chain_off"])
-    aligned_bases = int(batch.lengths[chain_len > 0].sum())
+    n_long = np.diff(out["read_longall_off"])
+    aligned_bases = int(batch.lengths[(chain_len > 0) | (n_long > 0)].sum())
     reads_total = args.reads * world * args.steps
     reads_per_s = reads_total / elapsed
     gbp_per_s = aligned_bases * world * args.steps / elapsed / 1e9
 
-    # roofline of the dominant kernel (k_extend): algorithmic bytes per launch / its HIP-event duration
-    dp_tiles, recompute_tiles, column_steps, trace_items, extensions, backtrace_tiles = counters[:6]
-    ext_bytes = BYTES_PER_TILE * (dp_tiles + recompute_tiles) + BYTES_PER_BACKTRACE_TILE * backtrace_tiles + BYTES_PER_TRACE_ITEM * trace_items
-    ext_seconds = kernel_us[1] * 1e-6
-    achieved = ext_bytes / ext_seconds / 1e9 if ext_seconds > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    # roofline of the dominant kernel (longest average launch: k_long_pass when the whole-read pass runs, else k_extend):
+    # algorithmic bytes per launch (SURVEY.md §8d unit x the counts the kernel reports) / its HIP-event duration
+    def kernel_roofline(name, cnt, us):
+        dp_tiles, recompute_tiles, column_steps, trace_items, _ext, backtrace_tiles = cnt[:6]
+        nbytes = BYTES_PER_TILE * (dp_tiles + recompute_tiles) + BYTES_PER_BACKTRACE_TILE * backtrace_tiles + BYTES_PER_TRACE_ITEM * trace_items
+        seconds = us * 1e-6
+        achieved = nbytes / seconds / 1e9 if seconds > 0 else 0.0
+        return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                "algorithmic_bytes_per_launch": int(ext_bytes), "avg_launch_ms": round(kernel_us[1] / 1e3, 3),
-                "tiles_per_launch": int(dp_tiles + recompute_tiles), "column_steps_per_s": round(column_steps / ext_seconds / 1e9, 3) if ext_seconds > 0 else 0.0}
+                "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(us / 1e3, 3),
+                "tiles_per_launch": int(dp_tiles + recompute_tiles), "column_steps_per_s_G": round(column_steps / seconds / 1e9, 3) if seconds > 0 else 0.0}
+
+    roof_extend = kernel_roofline("k_extend", counters, kernel_us[1])
+    roof_long = kernel_roofline("k_long_pass", counters_long, kernel_us[4]) if long_pass else None
+    roofline = roof_long if (long_pass and kernel_us[4] >= kernel_us[1]) else roof_extend
+    extensions = counters[4]
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import Oracle   # the CPU baseline leg is the one place bench.py may touch the oracle
         n_sample = min(args.cpu_sample, len(reads))
-        ora = Oracle(gfa, long_pass=False, split_gap=args.split_gap)
+        ora = Oracle(gfa, long_pass=long_pass, split_gap=args.split_gap)
         t0 = time.perf_counter()
         ora.align(reads[:n_sample])
         cpu_t = time.perf_counter() - t0
         cpu_baseline = {"value": round(n_sample / cpu_t, 2), "unit": "reads/s", "cores": 1, "kind": "port",
-                        "sample": f"first {n_sample} reads of the same workload, same stages (seeding, fragment extension, anchors, chaining), 1 thread, {cpu_t:.1f} s"}
+                        "sample": f"first {n_sample} reads of the same workload, same stages ({'whole-read pass, ' if long_pass else ''}seeding, fragment extension, anchors, chaining; plus chain stitching and two NW edit distances the GPU path does not do yet), 1 thread, {cpu_t:.1f} s"}
 
     if rank == 0:
         line = {
@@ -147,12 +160,13 @@ def main():
             "gbp_per_sec_aligned": round(gbp_per_s, 5),
             "config": {"workload": f"BASELINE configs[1]: chr22-like synthetic DAG ({args.backbone} bp backbone, {graph.NodeSize()} split nodes), "
                                    f"{args.reads} x {args.read_len} bp ONT-like reads per GPU, split_len 35 split_gap {args.split_gap} bandwidth 10",
-                       "stages": "seed lookup + seed ordering + fragment seed-extension + anchors + co-linear chaining (whole-read pass not included yet)",
+                       "stages": ("whole-read GraphAligner pass + " if long_pass else "") + "seed lookup + seed ordering + fragment seed-extension + anchors + co-linear chaining",
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "parallelism": f"read-sharded x{world}, graph replicated, no collective"},
             "roofline": roofline,
+            "roofline_other": roof_extend if roofline is roof_long else roof_long,
             "cpu_baseline": cpu_baseline,
             "stage_ms": {"k_seed_lookup": round(kernel_us[0] / 1e3, 3), "k_extend": round(kernel_us[1] / 1e3, 3), "k_build_anchors": round(kernel_us[2] / 1e3, 3),
-                         "k_chain": round(kernel_us[3] / 1e3, 3), "host_seed_glue": round(host_us[0] / 1e3, 3), "host_result_assembly": round(host_us[1] / 1e3, 3),
+                         "k_chain": round(kernel_us[3] / 1e3, 3), "k_long_pass": round(kernel_us[4] / 1e3, 3), "host_seed_glue": round(host_us[0] / 1e3, 3), "host_result_assembly": round(host_us[1] / 1e3, 3),
                          "wall_seed_lookup_and_copies": round(host_us[2] / 1e3, 3), "wall_extend_to_chain_and_copies": round(host_us[3] / 1e3, 3)},
             "setup_s": {"generate": round(t_gen, 1), "graph_build_upload": round(t_graph, 1), "minimizer_index": round(t_index, 1)},
             "reads_with_chain": int((chain_len > 0).sum()), "extensions_per_step": int(extensions),

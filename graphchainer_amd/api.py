@@ -49,7 +49,7 @@ class GcResult(C.Structure):
         ("long_trace_off", _P(C.c_uint64)), ("long_trace_node", _P(C.c_int32)), ("long_trace_offset", _P(C.c_uint32)),
         ("long_trace_seqpos", _P(C.c_uint32)), ("long_trace_switch", _P(C.c_uint8)),
         ("failed_assertion", _P(C.c_uint8)), ("seeds_extended", _P(C.c_uint64)), ("seeds_extended_long", _P(C.c_uint64)),
-        ("counters", C.c_uint64 * 8), ("kernel_us", C.c_double * 8), ("host_us", C.c_double * 4),
+        ("counters", C.c_uint64 * 8), ("counters_long", C.c_uint64 * 8), ("kernel_us", C.c_double * 8), ("host_us", C.c_double * 4),
     ]
 
 
@@ -258,9 +258,10 @@ class Aligner:
                 for name in ("anchor_trace_node", "anchor_trace_offset", "anchor_trace_seqpos", "anchor_trace_switch"):
                     out[name] = arr(getattr(r, name), cells)
             out["counters"] = np.array(list(r.counters), dtype=np.uint64)
+            out["counters_long"] = np.array(list(r.counters_long), dtype=np.uint64)
             out["kernel_us"] = np.array(list(r.kernel_us))
             out["host_us"] = np.array(list(r.host_us))
-            return {k: (v.astype(np.int64) if v.dtype.kind in "ui" and k not in ("counters",) else v) for k, v in out.items()}
+            return {k: (v.astype(np.int64) if v.dtype.kind in "ui" and k not in ("counters", "counters_long") else v) for k, v in out.items()}
         finally:
             self.lib.gc_result_free(res)
 

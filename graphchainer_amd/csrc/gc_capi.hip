@@ -781,7 +781,9 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			LongSeed* hSeeds = st->hLongSeeds.reserve<LongSeed>(nLongSeeds);
 			LongJob* hJobs = st->hLongJobs.reserve<LongJob>(n);
 			uint64_t cellBudget = 0;
-			for (uint64_t r = 0; r < n; r++) cellBudget += 3 * (R->offsets[r + 1] - R->offsets[r]) + 256;
+			uint64_t cellsPerBase = 8;   // room for several partial alignments per read before the end-to-end one
+			if (const char* env = getenv("GC_LONG_CELLS_PER_BASE")) cellsPerBase = (uint64_t)std::max(2, atoi(env));
+			for (uint64_t r = 0; r < n; r++) cellBudget += cellsPerBase * (R->offsets[r + 1] - R->offsets[r]) + 1024;
 			pool.run(n, [&](size_t r, size_t) {
 				const ReadGlue& gl = glue[r];
 				uint64_t at = gl.longSeedBegin;
@@ -919,10 +921,12 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			float ms = 0;
 			HIP_CHECK(hipEventElapsedTime(&ms, st->longEv[0], st->longEv[1]));
 			res->kernel_us[4] = (double)ms * 1000.0;
-			for (int i = 0; i < 6; i++) res->counters[i] += hLongSmall[8 + i];   // the long pass counts in the same units
-			res->counters[6] = hLongSmall[8 + 4];                                   // extensions of the long pass alone
-			res->counters[7] = hLongSmall[8 + 0] + hLongSmall[8 + 1];               // tiles of the long pass alone
-			for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status == 2) throw std::runtime_error("whole-read pass capacity overflow (raise GC_LONG_MAX_ITEMS)");
+			for (int i = 0; i < 8; i++) res->counters_long[i] = hLongSmall[8 + i];   // same units as counters[]
+			for (uint64_t r = 0; r < n; r++) {
+				if (hLongResults[r].status == 2) throw std::runtime_error("whole-read pass: extension scratch overflow (raise GC_LONG_MAX_ITEMS)");
+				if (hLongResults[r].status == 3) throw std::runtime_error("whole-read pass: more than 32 alignments for one read");
+				if (hLongResults[r].status == 4) throw std::runtime_error("whole-read pass: trace cell pool overflow (raise GC_LONG_CELLS_PER_BASE)");
+			}
 			if (P->keep_traces) {
 				longCells.resize(hLongSmall[0]);
 				if (hLongSmall[0]) HIP_CHECK(hipMemcpy(longCells.data(), dLongCells, hLongSmall[0] * sizeof(LongCell), hipMemcpyDeviceToHost));

@@ -532,11 +532,11 @@ __global__ void __launch_bounds__(64) k_long_pass(DGraph g, const CorrectnessTab
 			if (stB == EXT_OVERFLOW || stF == EXT_OVERFLOW) { status = 2; break; }
 			bool hasB = stB == EXT_OK, hasF = stF == EXT_OK;
 			if (!hasB && !hasF) continue;   // alignmentFailed()
-			if (nAln >= maxAlignments) { status = 2; break; }
+			if (nAln >= maxAlignments) { status = 3; break; }
 			uint32_t useB = hasB ? (hasF ? nB - 1 : nB) : 0;
 			uint32_t total = useB + (hasF ? nF : 0);
 			unsigned long long base = atomicAdd(cellCursor, (unsigned long long)total);
-			if (base + total > cellCapacity) { status = 2; break; }
+			if (base + total > cellCapacity) { status = 4; break; }
 			LongCell* outCells = cellPool + base;
 			for (uint32_t i = 0; i < useB; i++) {   // fixReverseTraceSeqPosAndOrder (:543-565)
 				const TraceCell& c = ls.traceB[i];

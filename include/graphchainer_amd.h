@@ -132,10 +132,10 @@ typedef struct gc_result {
 	uint8_t*  failed_assertion;   /* [n_reads] the reference would have thrown on this read */
 	uint64_t* seeds_extended;     /* [n_reads] fragment pass (stats.seedsExtended, src/Aligner.cpp:705) */
 	uint64_t* seeds_extended_long; /* [n_reads] whole-read pass (AlignmentResult::seedsExtended) */
-	/* work counters of this batch: [0] dp tiles, [1] recompute tiles (last-slice flatten + backtrace), [2] column steps,
-	 * [3] trace items, [4] extensions, [5] backtrace tiles (subset of [1]); with long_pass these include the whole-read
-	 * pass, whose own share is [6] extensions and [7] tiles */
+	/* work counters of the fragment pass: [0] dp tiles, [1] recompute tiles (last-slice flatten + backtrace),
+	 * [2] column steps, [3] trace items, [4] extensions, [5] backtrace tiles (subset of [1]) */
 	uint64_t counters[8];
+	uint64_t counters_long[8];    /* the same for the whole-read pass */
 	/* device time of each kernel of this batch in microseconds (HIP events on the stream):
 	 * [0] seed lookup, [1] fragment extension, [2] anchor build, [3] chaining, [4] whole-read pass (own stream, overlaps 1-3) */
 	double kernel_us[8];
