@@ -188,7 +188,7 @@ struct gc_stream {
 	// whole-read pass: runs on its own stream, concurrently with the fragment kernels
 	hipStream_t longStream = nullptr;
 	hipEvent_t longEv[2] {};
-	DeviceBuffer longSeeds, longJobs, longAlns, longResults, longScratch, longCells, longCursor;
+	DeviceBuffer longSeeds, longJobs, longAlns, longResults, longScratch, longCells, longCursor, longJobsFallback, longResultsFallback, longScratchFallback;
 	PinnedBuffer hLongSeeds, hLongJobs, hLongAlns, hLongResults, hLongSmall;
 	~gc_stream()
 	{
@@ -775,6 +775,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		LongReadResult* hLongResults = nullptr;
 		unsigned long long* hLongSmall = nullptr;
 		LongCell* dLongCells = nullptr;
+		std::function<uint64_t()> longFallback;
 		if (P->long_pass) {
 			for (uint64_t r = 0; r < n; r++) { glue[r].longSeedBegin = nLongSeeds; nLongSeeds += glue[r].longSeeds.size(); maxReadLen = std::max<uint64_t>(maxReadLen, R->offsets[r + 1] - R->offsets[r]); }
 			if (nLongSeeds >= 0xffffffffull) throw std::runtime_error("batch too large for the whole-read pass");
@@ -807,13 +808,13 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			lcfg.maxPending = 96;
 			lcfg.maxTrace = (uint32_t)(maxReadLen + maxReadLen / 2 + 512);
 			if (const char* env = getenv("GC_LONG_MAX_ITEMS")) lcfg.maxItems = (uint32_t)std::max(64, atoi(env));
-			uint64_t lslab = longSlabBytes(lcfg);
-			uint64_t lanes = (n + 63) / 64 * 64;
+			uint32_t waveBlocks = (uint32_t)((n + 63) / 64);
+			uint64_t waveWords = longWaveWordsPerLane(lcfg);
 			LongSeed* dLongSeeds = st->longSeeds.reserve<LongSeed>(nLongSeeds);
 			LongJob* dLongJobs = st->longJobs.reserve<LongJob>(n);
 			LongAln* dLongAlns = st->longAlns.reserve<LongAln>(n * maxAlignments);
 			LongReadResult* dLongResults = st->longResults.reserve<LongReadResult>(n);
-			uint8_t* dLongScratch = st->longScratch.reserve<uint8_t>(lanes * lslab);
+			unsigned long long* dLongScratch = st->longScratch.reserve<unsigned long long>((uint64_t)waveBlocks * waveWords * 64);
 			dLongCells = st->longCells.reserve<LongCell>(cellBudget);
 			unsigned long long* dLongCursor = st->longCursor.reserve<unsigned long long>(16);
 			hLongAlns = st->hLongAlns.reserve<LongAln>(n * maxAlignments);
@@ -824,12 +825,37 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			if (nLongSeeds) HIP_CHECK(hipMemcpyAsync(dLongSeeds, hSeeds, nLongSeeds * sizeof(LongSeed), hipMemcpyHostToDevice, ls));
 			if (n) HIP_CHECK(hipMemcpyAsync(dLongJobs, hJobs, n * sizeof(LongJob), hipMemcpyHostToDevice, ls));
 			HIP_CHECK(hipEventRecord(st->longEv[0], ls));
-			launchLongPass(ls, G->dev, G->devTables, G->devIupac, lcfg, dLongJobs, (uint32_t)n, dLongSeeds, R->devBases, R->totalBases, (uint32_t)P->min_cluster_size, maxAlignments,
-				dLongScratch, lslab, dLongCells, dLongCursor, cellBudget, dLongAlns, dLongResults, dLongCursor + 8);
+			launchLongPassWave(ls, G->dev, G->devTables, G->devIupac, lcfg, dLongJobs, (uint32_t)n, dLongSeeds, R->devBases, R->totalBases, (uint32_t)P->min_cluster_size, maxAlignments,
+				dLongScratch, waveBlocks, dLongCells, dLongCursor, cellBudget, dLongAlns, dLongResults, dLongCursor + 8);
 			HIP_CHECK(hipEventRecord(st->longEv[1], ls));
-			if (n) HIP_CHECK(hipMemcpyAsync(hLongAlns, dLongAlns, n * maxAlignments * sizeof(LongAln), hipMemcpyDeviceToHost, ls));
 			if (n) HIP_CHECK(hipMemcpyAsync(hLongResults, dLongResults, n * sizeof(LongReadResult), hipMemcpyDeviceToHost, ls));
-			HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
+			// reads whose band did not fit the LDS tables (status 5) are rerun with the plain-layout kernel
+			longFallback = [=, &glue]() {
+				HIP_CHECK(hipStreamSynchronize(ls));
+				std::vector<uint32_t> redo;
+				const bool forceAll = getenv("GC_LONG_FORCE_FALLBACK") != nullptr;   // test hook: run every read through the plain-layout kernel too
+				for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status == 5 || forceAll) redo.push_back((uint32_t)r);
+				if (!redo.empty()) {
+					std::vector<LongJob> subJobs(redo.size());
+					for (size_t i = 0; i < redo.size(); i++) subJobs[i] = hJobs[redo[i]];
+					uint64_t lslab = longSlabBytes(lcfg);
+					uint64_t lanes = (redo.size() + 63) / 64 * 64;
+					LongJob* dSubJobs = st->longJobsFallback.reserve<LongJob>(redo.size());
+					LongReadResult* dSubResults = st->longResultsFallback.reserve<LongReadResult>(redo.size());
+					uint8_t* dSlab = st->longScratchFallback.reserve<uint8_t>(lanes * lslab);
+					HIP_CHECK(hipMemcpyAsync(dSubJobs, subJobs.data(), redo.size() * sizeof(LongJob), hipMemcpyHostToDevice, ls));
+					launchLongPass(ls, G->dev, G->devTables, G->devIupac, lcfg, dSubJobs, (uint32_t)redo.size(), dLongSeeds, R->devBases, R->totalBases, (uint32_t)P->min_cluster_size, maxAlignments,
+						dSlab, lslab, dLongCells, dLongCursor, cellBudget, dLongAlns, dSubResults, dLongCursor + 8);
+					std::vector<LongReadResult> subResults(redo.size());
+					HIP_CHECK(hipMemcpyAsync(subResults.data(), dSubResults, redo.size() * sizeof(LongReadResult), hipMemcpyDeviceToHost, ls));
+					HIP_CHECK(hipStreamSynchronize(ls));
+					for (size_t i = 0; i < redo.size(); i++) hLongResults[redo[i]] = subResults[i];
+				}
+				if (n) HIP_CHECK(hipMemcpyAsync(hLongAlns, dLongAlns, n * maxAlignments * sizeof(LongAln), hipMemcpyDeviceToHost, ls));
+				HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
+				HIP_CHECK(hipStreamSynchronize(ls));
+				return (uint64_t)redo.size();
+			};
 		}
 
 		// ---------------- K3 / K3b / K4
@@ -917,11 +943,12 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		// ---------------- whole-read pass results
 		std::vector<LongCell> longCells;
 		if (P->long_pass) {
-			HIP_CHECK(hipStreamSynchronize(st->longStream));
+			uint64_t rerun = longFallback();
+			res->counters_long[7] = rerun;   // reads that needed the plain-layout fallback kernel
 			float ms = 0;
 			HIP_CHECK(hipEventElapsedTime(&ms, st->longEv[0], st->longEv[1]));
 			res->kernel_us[4] = (double)ms * 1000.0;
-			for (int i = 0; i < 8; i++) res->counters_long[i] = hLongSmall[8 + i];   // same units as counters[]
+			for (int i = 0; i < 7; i++) res->counters_long[i] = hLongSmall[8 + i];   // same units as counters[]
 			for (uint64_t r = 0; r < n; r++) {
 				if (hLongResults[r].status == 2) throw std::runtime_error("whole-read pass: extension scratch overflow (raise GC_LONG_MAX_ITEMS)");
 				if (hLongResults[r].status == 3) throw std::runtime_error("whole-read pass: more than 32 alignments for one read");

@@ -1,0 +1,572 @@
+// Wave-friendly variant of the seed-extension core (same algorithm and results as extendSeed in gc_device.hpp).
+//
+// Why: with one lane per extension every lane owns private state. In the plain layout a wave-level load of "my
+// item i" touches 64 different scratch slabs = 64 memory transactions; the whole-read pass, which has only one
+// lane per read and cannot hide that behind other waves, ran at 0.27 G column-steps/s. Here
+//   * the state that the slice loop reads and writes all the time - the previous slice's per-node summary
+//     (node, start score, min score, HP, HN), the current slice's, and the pending queue with its folded incoming
+//     columns - lives in LDS, lane-interleaved ([entry][lane], so lanes that are at the same entry hit 64
+//     consecutive banks);
+//   * the DP table kept for the backtrace (8 words per (slice,node) item), the per-slice records and the trace
+//     live in HBM, interleaved across the 64 lanes of the wave at 8-byte granularity (word w of lane l at
+//     base[w*64 + l]) so a wave-level access to the same logical word is one 512 B transaction;
+//   * the 64 recomputed columns of the backtrace reuse the LDS of the slice tables (the two phases do not overlap).
+// A slice that needs more than WAVE_CAP nodes does not fit: the extension returns EXT_LDS_CAP and the host reruns
+// that read with the plain-layout kernel.
+#pragma once
+#include "gc_device.hpp"
+
+namespace gcdev {
+
+enum : uint32_t { EXT_LDS_CAP = 5 };
+
+#ifndef WAVE_CAP
+#define WAVE_CAP 28
+#endif
+
+// LDS image of one wave: 4-byte words, lane-interleaved ([word][lane]: a wave-level access to the same logical word
+// hits 64 consecutive banks). Every lane owns the words [*][lane]; both phases of an extension use only the lane's own
+// words, so lanes of one wave may be in different phases. Per entry 7 words for each of: previous-slice table,
+// current-slice table (the two swap every slice) and pending queue -> 21 words; 28 entries = 588 words = 150.5 KB per wave.
+#define WAVE_ENTRY_WORDS 7
+#define WAVE_WORDS (3 * WAVE_CAP * WAVE_ENTRY_WORDS)
+struct WaveLds { uint32_t w[WAVE_WORDS][64]; };
+static_assert(sizeof(WaveLds) <= 160 * 1024, "WaveLds must fit the CU's LDS");
+static_assert(64 * 5 <= WAVE_WORDS, "the 64 backtrace columns (5 words each) alias the lane's table words");
+
+struct LaneLds {   // one lane's view
+	WaveLds* l;
+	uint32_t lane;
+	__device__ __forceinline__ uint32_t& W(uint32_t word) const { return l->w[word][lane]; }
+	__device__ __forceinline__ uint64_t ld64(uint32_t word) const { return (uint64_t)l->w[word][lane] | ((uint64_t)l->w[word + 1][lane] << 32); }
+	__device__ __forceinline__ void st64(uint32_t word, uint64_t v) const { l->w[word][lane] = (uint32_t)v; l->w[word + 1][lane] = (uint32_t)(v >> 32); }
+	// slice tables: buffer b (0/1), entry e: node, startScore, minScore, HP, HN
+	__device__ __forceinline__ uint32_t pBase(int b, uint32_t e) const { return ((uint32_t)b * WAVE_CAP + e) * WAVE_ENTRY_WORDS; }
+	__device__ __forceinline__ uint32_t pNode(int b, uint32_t e) const { return W(pBase(b, e)); }
+	__device__ __forceinline__ int32_t pStart(int b, uint32_t e) const { return (int32_t)W(pBase(b, e) + 1); }
+	__device__ __forceinline__ int32_t pMin(int b, uint32_t e) const { return (int32_t)W(pBase(b, e) + 2); }
+	__device__ __forceinline__ uint64_t pHP(int b, uint32_t e) const { return ld64(pBase(b, e) + 3); }
+	__device__ __forceinline__ uint64_t pHN(int b, uint32_t e) const { return ld64(pBase(b, e) + 5); }
+	__device__ __forceinline__ void pSet(int b, uint32_t e, uint32_t node, int32_t start, int32_t mn, uint64_t hp, uint64_t hn) const
+	{
+		uint32_t base = pBase(b, e);
+		W(base) = node; W(base + 1) = (uint32_t)start; W(base + 2) = (uint32_t)mn; st64(base + 3, hp); st64(base + 5, hn);
+	}
+	// pending queue entry e: node, comp, score, VP, VN
+	__device__ __forceinline__ uint32_t qBase(uint32_t e) const { return (2u * WAVE_CAP + e) * WAVE_ENTRY_WORDS; }
+	__device__ __forceinline__ uint32_t qNode(uint32_t e) const { return W(qBase(e)); }
+	__device__ __forceinline__ uint32_t qComp(uint32_t e) const { return W(qBase(e) + 1); }
+	__device__ __forceinline__ WS qWs(uint32_t e) const { uint32_t base = qBase(e); return WS { ld64(base + 3), ld64(base + 5), (int32_t)W(base + 2) }; }
+	__device__ __forceinline__ void qSetWs(uint32_t e, const WS& x) const { uint32_t base = qBase(e); W(base + 2) = (uint32_t)x.score; st64(base + 3, x.VP); st64(base + 5, x.VN); }
+	__device__ __forceinline__ void qSet(uint32_t e, uint32_t node, uint32_t comp, const WS& x) const { uint32_t base = qBase(e); W(base) = node; W(base + 1) = comp; qSetWs(e, x); }
+	__device__ __forceinline__ void qMove(uint32_t dst, uint32_t src) const { uint32_t d = qBase(dst), sb = qBase(src); for (int i = 0; i < WAVE_ENTRY_WORDS; i++) W(d + i) = W(sb + i); }
+	// backtrace columns (alias the table words): column c: VP, VN, score
+	__device__ __forceinline__ void colSet(uint32_t c, const WS& x) const { uint32_t base = c * 5; st64(base, x.VP); st64(base + 2, x.VN); W(base + 4) = (uint32_t)x.score; }
+	__device__ __forceinline__ WS col(uint32_t c) const { uint32_t base = c * 5; return WS { ld64(base), ld64(base + 2), (int32_t)W(base + 4) }; }
+};
+
+// HBM scratch of one wave, lane-interleaved 8-byte words
+struct WaveScratch {
+	unsigned long long* base;   // wave base
+	uint32_t lane;
+	uint32_t maxSlices, maxItems, maxTrace;
+	// word offsets (per lane) of the regions
+	__device__ __forceinline__ unsigned long long& word(uint64_t w) const { return base[w * 64 + lane]; }
+	__device__ __forceinline__ uint64_t sliceBase(uint32_t s) const { return (uint64_t)s * 4; }
+	__device__ __forceinline__ uint64_t itemBase(uint32_t i) const { return (uint64_t)maxSlices * 4 + (uint64_t)i * 8; }
+	__device__ __forceinline__ uint64_t traceBase(uint32_t t, uint32_t which) const { return (uint64_t)maxSlices * 4 + (uint64_t)maxItems * 8 + (uint64_t)which * maxTrace + t; }
+};
+__host__ __device__ inline uint64_t waveScratchWords(uint32_t maxSlices, uint32_t maxItems, uint32_t maxTrace) { return (uint64_t)maxSlices * 4 + (uint64_t)maxItems * 8 + 2ull * maxTrace; }
+
+struct WSlice { int32_t minScore; uint32_t minNode, minOffset, first, count; int32_t bandwidth; int32_t j; uint32_t flags; };
+
+__device__ __forceinline__ void storeSlice(const WaveScratch& ws, uint32_t s, const WSlice& x)
+{
+	uint64_t b = ws.sliceBase(s);
+	ws.word(b) = ((unsigned long long)(uint32_t)x.minScore << 32) | x.minNode;
+	ws.word(b + 1) = ((unsigned long long)x.minOffset << 32) | x.first;
+	ws.word(b + 2) = ((unsigned long long)x.count << 32) | (uint32_t)x.bandwidth;
+	ws.word(b + 3) = ((unsigned long long)(uint32_t)x.j << 32) | x.flags;
+}
+__device__ __forceinline__ WSlice loadSlice(const WaveScratch& ws, uint32_t s)
+{
+	uint64_t b = ws.sliceBase(s);
+	unsigned long long a = ws.word(b), c = ws.word(b + 1), d = ws.word(b + 2), e = ws.word(b + 3);
+	WSlice x;
+	x.minScore = (int32_t)(a >> 32); x.minNode = (uint32_t)a;
+	x.minOffset = (uint32_t)(c >> 32); x.first = (uint32_t)c;
+	x.count = (uint32_t)(d >> 32); x.bandwidth = (int32_t)(uint32_t)d;
+	x.j = (int32_t)(e >> 32); x.flags = (uint32_t)e;
+	return x;
+}
+__device__ __forceinline__ void storeItem(const WaveScratch& ws, uint32_t i, const NodeItem& it)
+{
+	uint64_t b = ws.itemBase(i);
+	ws.word(b) = it.sVP; ws.word(b + 1) = it.sVN; ws.word(b + 2) = it.eVP; ws.word(b + 3) = it.eVN; ws.word(b + 4) = it.HP; ws.word(b + 5) = it.HN;
+	ws.word(b + 6) = ((unsigned long long)(uint32_t)it.sScore << 32) | (uint32_t)it.eScore;
+	ws.word(b + 7) = ((unsigned long long)(uint32_t)it.minScore << 32) | it.node;
+}
+__device__ __forceinline__ NodeItem loadItem(const WaveScratch& ws, uint32_t i)
+{
+	uint64_t b = ws.itemBase(i);
+	NodeItem it;
+	it.sVP = ws.word(b); it.sVN = ws.word(b + 1); it.eVP = ws.word(b + 2); it.eVN = ws.word(b + 3); it.HP = ws.word(b + 4); it.HN = ws.word(b + 5);
+	unsigned long long s = ws.word(b + 6), m = ws.word(b + 7);
+	it.sScore = (int32_t)(s >> 32); it.eScore = (int32_t)(uint32_t)s;
+	it.minScore = (int32_t)(m >> 32); it.node = (uint32_t)m;
+	return it;
+}
+__device__ __forceinline__ uint32_t itemNode(const WaveScratch& ws, uint32_t i) { return (uint32_t)ws.word(ws.itemBase(i) + 7); }
+
+// table lookup for the backtrace: index of `node` among the items of a slice, or -1
+__device__ inline int findItemW(const WaveScratch& ws, const WSlice& sl, uint32_t node)
+{
+	for (uint32_t i = 0; i < sl.count; i++)
+		if (itemNode(ws, sl.first + i) == node) return (int)(sl.first + i);
+	return -1;
+}
+
+// one trace cell per 8-byte word: node | (seqPos+1) << 32 (24 bits) | offset << 56 (6 bits) | nodeSwitch << 62
+__device__ __forceinline__ unsigned long long packCell(Cell c, bool sw) { return (unsigned long long)c.node | ((unsigned long long)(uint32_t)(c.seqPos + 1) << 32) | ((unsigned long long)c.offset << 56) | ((unsigned long long)(sw ? 1 : 0) << 62); }
+__device__ __forceinline__ TraceCell unpackCell(unsigned long long w)
+{
+	TraceCell t;
+	t.node = (uint32_t)w;
+	t.seqPos = (int32_t)((w >> 32) & 0xffffffu) - 1;
+	t.offsetAndSwitch = (uint32_t)((w >> 56) & 63u) | (((w >> 62) & 1u) ? 256u : 0u);
+	return t;
+}
+
+// (node, slice) tile on a node that is new in this slice; same as computeTile but the previous-slice summary comes
+// in by value and columns (backtrace recompute) go to the LDS column view.
+__device__ inline TileResult computeTileW(const DGraph& g, uint32_t node, WS ws, bool prevExists, int32_t prevStartScore, uint64_t prevHP, uint64_t prevHN,
+	const uint64_t eq[4], NodeItem& out, const LaneLds* columns, int flatRows, uint32_t& status)
+{
+	int nodeLength = g.nodeLength[node];
+	NodeSeq seq = loadNodeSeq(g, node);
+	TileResult r;
+	r.minScore = ws.score;   // (sic) before the merge with the row above, ...Common.h:968 vs :1052-1058
+	r.minOffset = 0;
+	if (prevExists && wsBefore(ws) > prevStartScore) ws = wsMerge(ws, wsSource(prevStartScore));
+	int forceUntil = 0;
+	if (prevExists) {
+		int32_t scoreBefore = wsBefore(ws);
+		int32_t scoreComparison = prevStartScore;
+		if (scoreBefore > scoreComparison) status = EXT_ASSERT;
+		if (scoreBefore < scoreComparison) {
+			for (int fix = 1; fix < 64; fix++) {
+				int32_t next = scoreComparison + (int32_t)((prevHP >> fix) & 1) - (int32_t)((prevHN >> fix) & 1);
+				uint64_t mask = 1ull << fix;
+				if (scoreBefore > next) status = EXT_ASSERT;
+				if (scoreBefore < next) { prevHP |= mask; prevHN &= ~mask; forceUntil = fix; }
+				if (scoreBefore == next) { prevHP &= ~mask; prevHN &= ~mask; }
+				scoreBefore++;
+				scoreComparison = next;
+				if (scoreBefore >= scoreComparison) break;
+			}
+		}
+	} else {
+		forceUntil = nodeLength;
+	}
+	out.node = node;
+	out.sVP = ws.VP; out.sVN = ws.VN; out.sScore = ws.score;
+	uint64_t flatMask = flatRows > 0 ? ~(~0ull << flatRows) : 0;
+	r.flatMin = INT32_MAX;
+	r.flatOffset = 0;
+	if (flatRows > 0) r.flatMin = ws.score - popc64(ws.VP & ~flatMask) + popc64(ws.VN & ~flatMask);
+	if (columns) columns->colSet(0, ws);
+	uint64_t forceEq = prevExists ? ~0ull : ~1ull;
+	uint64_t HP = 0, HN = 0;
+	for (int pos = 1; pos < nodeLength; pos++) {
+		uint64_t Eq = eqOfColumn(eq, seq, pos) & forceEq;
+		uint64_t hp, hn;
+		ws = myersStep(Eq, ws, (prevHP >> pos) & 1, (prevHN >> pos) & 1, hp, hn);
+		if (forceUntil >= pos) { ws.VP &= ~1ull; ws.VN |= 1ull; }
+		if (ws.score < r.minScore) { r.minScore = ws.score; r.minOffset = (uint32_t)pos; }
+		if (flatRows > 0) {
+			int32_t f = ws.score - popc64(ws.VP & ~flatMask) + popc64(ws.VN & ~flatMask);
+			if (f < r.flatMin) { r.flatMin = f; r.flatOffset = (uint32_t)pos; }
+		}
+		if (columns) columns->colSet((uint32_t)pos, ws);
+		HP |= hp << pos;
+		HN |= hn << pos;
+	}
+	out.HP = HP; out.HN = HN;
+	out.eVP = ws.VP; out.eVN = ws.VN; out.eScore = ws.score;
+	return r;
+}
+
+
+// Full seed extension, wave layout. Trace goes to trace region `which` of the wave scratch (start cell first).
+__device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTables& ct, const uint8_t* iupac, int bandwidthCfg, WaveLds* lds, const WaveScratch& wsx,
+	const char* seq, int len, uint32_t startNode, uint32_t startOffset, uint32_t which, uint32_t& nTrace, int32_t& score, ExtCounters& cnt)
+{
+	const LaneLds L { lds, wsx.lane };
+	uint32_t status = EXT_OK;
+	nTrace = 0;
+	score = 0;
+	cnt.extensions++;
+	int numSlices = (len + 63) / 64;
+	if ((uint32_t)numSlices + 1 > wsx.maxSlices) return EXT_OVERFLOW;
+	// ---- initial slice (...Common.h:1243-1279)
+	int buf = 0;   // table buffer `buf` = previous slice
+	uint32_t nPrev = 1;
+	{
+		int nl = g.nodeLength[startNode];
+		NodeItem it;
+		it.node = startNode;
+		it.sVP = it.sVN = it.eVP = it.eVN = 0;
+		it.sScore = (int32_t)startOffset;
+		it.eScore = nl - 1 - (int32_t)startOffset;
+		it.minScore = 0;
+		uint64_t upToOffset = startOffset >= 63 ? ~0ull : ((1ull << (startOffset + 1)) - 1);
+		uint64_t nodeMask = nl >= 64 ? ~0ull : ((1ull << nl) - 1);
+		it.HN = upToOffset & ~1ull;
+		it.HP = nodeMask & ~upToOffset;
+		storeItem(wsx, 0, it);
+		L.pSet(0, 0, startNode, it.sScore, 0, it.HP, it.HN);
+		WSlice s0;
+		s0.minScore = 0; s0.minNode = startNode; s0.minOffset = startOffset; s0.first = 0; s0.count = 1; s0.bandwidth = 1; s0.j = -64; s0.flags = 1;
+		storeSlice(wsx, 0, s0);
+	}
+	uint32_t nItems = 1, nSlices = 1;
+	int32_t prevMinScore = 0, prevBandwidth = 1, prevJ = -64;
+	double prevCorrect = ct.initCorrect, prevFalse = ct.initFalse;
+	uint64_t eq[4];
+	for (int slice = 0; slice < numSlices; slice++) {
+		int j = prevJ + 64;
+		eqVector(seq, len, j, iupac, eq);
+		int32_t previousQuitScore = prevMinScore + prevBandwidth;
+		int bandwidth = bandwidthCfg;
+		int flatRows = (j + 64 > len) ? (len - j) : 0;
+		const int cb = buf ^ 1;   // table buffer `cb` = current slice
+		auto prevFind = [&](uint32_t node) -> int {
+			for (uint32_t i = 0; i < nPrev; i++) if (L.pNode(buf, i) == node) return (int)i;
+			return -1;
+		};
+		uint32_t nPending = 0;
+		auto pushEdge = [&](uint32_t target, WS incoming, bool skipFirst) {
+			uint32_t slot = nPending;
+			for (uint32_t i = 0; i < nPending; i++) if (L.qNode(i) == target) { slot = i; break; }
+			WS add = incoming;
+			if (!skipFirst) {
+				int pi = prevFind(target);
+				bool prevExists = pi >= 0;
+				int32_t prevStart = prevExists ? L.pStart(buf, (uint32_t)pi) : 0;
+				uint64_t hinP, hinN;
+				if (prevExists) {
+					int32_t before = wsBefore(incoming);
+					if (prevStart < before) { hinP = 0; hinN = 1; }
+					else if (prevStart > before) { hinP = 1; hinN = 0; }
+					else { hinP = 0; hinN = 0; }
+				} else { hinP = 1; hinN = 0; }
+				NodeSeq nseq = loadNodeSeq(g, target);
+				uint64_t hp, hn;
+				add = myersStep(eqOfColumn(eq, nseq, 0), incoming, hinP, hinN, hp, hn);
+				if (!prevExists || wsBefore(add) < prevStart) { add.VP &= ~1ull; add.VN |= 1ull; }
+			}
+			if (slot == nPending) {
+				if (nPending >= WAVE_CAP) { status = EXT_LDS_CAP; return; }
+				L.qSet(slot, target, g.componentNumber[target], add);
+				nPending++;
+			} else {
+				L.qSetWs(slot, wsMerge(L.qWs(slot), add));
+			}
+		};
+		for (uint32_t i = 0; i < nPrev; i++) {
+			if (j != 0 && L.pMin(buf, i) > previousQuitScore) continue;
+			pushEdge(L.pNode(buf, i), wsSource(L.pStart(buf, i)), true);
+		}
+		if (status != EXT_OK) return status;
+		WSlice cur;
+		cur.first = nItems; cur.count = 0; cur.bandwidth = bandwidth; cur.j = j;
+		cur.minScore = INT32_MAX - bandwidth - 1; cur.minNode = 0xffffffffu; cur.minOffset = 0xffffffffu;
+		int32_t flatMin = INT32_MAX; uint32_t flatNode = 0xffffffffu, flatOffset = 0xffffffffu;
+		int32_t currentMin = cur.minScore;
+		while (nPending > 0) {
+			uint32_t best = 0;
+			uint32_t bestComp = L.qComp(0);
+			for (uint32_t i = 1; i < nPending; i++) { uint32_t c = L.qComp(i); if (c < bestComp) { bestComp = c; best = i; } }
+			uint32_t pnode = L.qNode(best);
+			WS pws = L.qWs(best);
+			if (best != nPending - 1) L.qMove(best, nPending - 1);
+			nPending--;
+			if (nItems >= wsx.maxItems) return EXT_OVERFLOW;
+			if (cur.count >= WAVE_CAP) return EXT_LDS_CAP;
+			int pi = prevFind(pnode);
+			bool prevExists = pi >= 0;
+			NodeItem out;
+			TileResult tr = computeTileW(g, pnode, pws, prevExists, prevExists ? L.pStart(buf, (uint32_t)pi) : 0,
+				prevExists ? L.pHP(buf, (uint32_t)pi) : ~0ull, prevExists ? L.pHN(buf, (uint32_t)pi) : 0ull, eq, out, nullptr, flatRows, status);
+			if (status != EXT_OK) return status;
+			out.minScore = tr.minScore;
+			storeItem(wsx, nItems, out);
+			L.pSet(cb, cur.count, pnode, out.sScore, out.minScore, out.HP, out.HN);
+			nItems++;
+			cur.count++;
+			cnt.dpTiles++;
+			cnt.columnSteps += g.nodeLength[pnode];
+			if (flatRows > 0) { cnt.recomputeTiles++; cnt.columnSteps += g.nodeLength[pnode]; }
+			if (tr.minScore > previousQuitScore + bandwidth + 128) return EXT_ASSERT;
+			currentMin = tr.minScore < currentMin ? tr.minScore : currentMin;
+			if (tr.minScore < cur.minScore) { cur.minScore = tr.minScore; cur.minNode = pnode; cur.minOffset = tr.minOffset; }
+			if (flatRows > 0 && tr.flatMin < flatMin) { flatMin = tr.flatMin; flatNode = pnode; flatOffset = tr.flatOffset; }
+			WS newEnd = itemEnd(out);
+			int32_t newEndMin = wsColumnMin(newEnd);
+			if (newEndMin < prevMinScore) return EXT_ASSERT;
+			if (newEndMin <= currentMin + bandwidth) {
+				for (uint32_t e = g.outOff[pnode]; e < g.outOff[pnode + 1]; e++) {
+					pushEdge(g.outAdj[e], newEnd, false);
+					if (status != EXT_OK) return status;
+				}
+			}
+		}
+		if (cur.count == 0) return EXT_ASSERT;
+		if (flatRows > 0) { cur.minScore = flatMin; cur.minNode = flatNode; cur.minOffset = flatOffset; }
+		if (cur.minScore < prevMinScore) return EXT_ASSERT;
+		double curCorrect, curFalse;
+		{
+			int mm = cur.minScore - prevMinScore;
+			int idx = mm < 64 ? mm : 63;
+			bool cfc = prevCorrect + ct.c2c >= prevFalse + ct.f2c;
+			bool ffc = prevCorrect + ct.c2f >= prevFalse + ct.f2f;
+			double a = prevCorrect + ct.c2c, b = prevFalse + ct.f2c;
+			double c = prevCorrect + ct.c2f, d = prevFalse + ct.f2f;
+			curCorrect = (a > b ? a : b) + ct.correctOdds[idx];
+			curFalse = (c > d ? c : d) + ct.wrongOdds[idx];
+			cur.flags = (curCorrect > curFalse ? 1u : 0u) | (cfc ? 2u : 0u) | (ffc ? 4u : 0u);
+		}
+		if (!(cur.flags & 2u)) break;
+		storeSlice(wsx, nSlices++, cur);
+		prevMinScore = cur.minScore; prevBandwidth = cur.bandwidth; prevJ = cur.j; prevCorrect = curCorrect; prevFalse = curFalse;
+		nPrev = cur.count;
+		buf = cb;
+	}
+	// removeWronglyAlignedEnd
+	{
+		bool currentlyCorrect = (loadSlice(wsx, nSlices - 1).flags & 1u) != 0;
+		while (!currentlyCorrect) {
+			currentlyCorrect = (loadSlice(wsx, nSlices - 1).flags & 4u) != 0;
+			nSlices--;
+			if (nSlices == 0) break;
+		}
+	}
+	if (nSlices <= 1) return EXT_FAILED;
+	WSlice last = loadSlice(wsx, nSlices - 1);
+	if (last.minScore < 0 || last.minScore > len + 128) return EXT_ASSERT;
+	score = last.minScore;
+
+	// ---- backtrace. The LDS is reused for the recomputed columns of the current (slice, node).
+	const LaneLds* columns = &L;
+	auto pushTraceW = [&](Cell c, bool sw) -> bool {
+		if (nTrace >= wsx.maxTrace) { status = EXT_OVERFLOW; return false; }
+		wsx.word(wsx.traceBase(nTrace, which)) = packCell(c, sw);
+		nTrace++;
+		return true;
+	};
+	Cell here { last.minNode, last.minOffset, (last.j + 63 < len - 1) ? last.j + 63 : len - 1 };
+	if (!pushTraceW(here, false)) return status;
+	uint32_t curSliceIdx = 0xffffffffu, curNode = 0xffffffffu;
+	WSlice cs = last, ps = last;
+	NodeItem curIt {};
+	NodeItem prevIt {};
+	bool prevItExists = false;
+	// corner rule (pickBacktraceCorner, ...Common.h:710-804)
+	auto corner = [&](Cell& out, bool& nodeSwitch) -> bool {
+		int32_t j = cs.j;
+		int32_t quitScore = cs.minScore + cs.bandwidth;
+		int32_t previousQuitScore = ps.minScore + ps.bandwidth;
+		int32_t scoreHere = wsValue(itemStart(curIt), 0);
+		uint32_t inBegin = g.inOff[curNode], inEnd = g.inOff[curNode + 1];
+		if (scoreHere > quitScore) {
+			int32_t smallest = scoreHere + 1;
+			out = Cell { 0, 0, 0 };
+			nodeSwitch = false;
+			if (prevItExists) { smallest = prevIt.sScore; out = Cell { curNode, 0, j - 1 }; }
+			for (uint32_t e = inBegin; e < inEnd; e++) {
+				uint32_t nb = g.inAdj[e];
+				int p = findItemW(wsx, ps, nb);
+				if (p >= 0) { NodeItem pn = loadItem(wsx, (uint32_t)p); if (pn.eScore <= smallest) { smallest = pn.eScore; out = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, j - 1 }; nodeSwitch = true; } }
+				int c = findItemW(wsx, cs, nb);
+				if (c >= 0 && nb != curNode) {
+					int32_t v = wsValue(itemEnd(loadItem(wsx, (uint32_t)c)), 0);
+					if (v < smallest) { smallest = v; out = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, j }; nodeSwitch = true; }
+				}
+			}
+			return true;
+		}
+		NodeSeq nseq = loadNodeSeq(g, curNode);
+		int eqBit = (int)(eqOfColumn(eq, nseq, 0) & 1);
+		if (prevItExists && prevIt.sScore == scoreHere - 1) { out = Cell { curNode, 0, j - 1 }; nodeSwitch = false; return true; }
+		Cell bestInvalid { 0xffffffffu, 0xffffffffu, -1 };
+		int32_t bestInvalidScore = scoreHere + 1;
+		for (uint32_t e = inBegin; e < inEnd; e++) {
+			uint32_t nb = g.inAdj[e];
+			int c = findItemW(wsx, cs, nb);
+			if (c >= 0 && wsValue(itemEnd(loadItem(wsx, (uint32_t)c)), 0) == scoreHere - 1) { out = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, j }; nodeSwitch = true; return true; }
+			int p = findItemW(wsx, ps, nb);
+			if (p >= 0) {
+				int32_t cornerScore = loadItem(wsx, (uint32_t)p).eScore;
+				if (cornerScore > previousQuitScore) {
+					if (cornerScore < bestInvalidScore) { bestInvalidScore = cornerScore; bestInvalid = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, j - 1 }; }
+				} else if (cornerScore == scoreHere - (eqBit ? 0 : 1)) {
+					out = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, j - 1 }; nodeSwitch = true; return true;
+				}
+			}
+		}
+		if (bestInvalidScore < scoreHere + 1) { out = bestInvalid; nodeSwitch = true; return true; }
+		return false;
+	};
+	while (here.seqPos != -1) {
+		uint32_t s = (uint32_t)(here.seqPos / 64) + 1;
+		if (s >= nSlices) return EXT_ASSERT;
+		if (s != curSliceIdx || here.node != curNode) {
+			if (s != curSliceIdx) { cs = loadSlice(wsx, s); ps = loadSlice(wsx, s - 1); eqVector(seq, len, cs.j, iupac, eq); }
+			curSliceIdx = s;
+			curNode = here.node;
+			int ci = findItemW(wsx, cs, curNode);
+			if (ci < 0) return EXT_ASSERT;
+			curIt = loadItem(wsx, (uint32_t)ci);
+			int pi = findItemW(wsx, ps, curNode);
+			prevItExists = pi >= 0;
+			if (prevItExists) prevIt = loadItem(wsx, (uint32_t)pi);
+			NodeItem scratchItem;
+			computeTileW(g, curNode, itemStart(curIt), prevItExists, prevItExists ? prevIt.sScore : 0, prevItExists ? prevIt.HP : ~0ull, prevItExists ? prevIt.HN : 0ull,
+				eq, scratchItem, columns, 0, status);
+			if (scratchItem.eVP != curIt.eVP || scratchItem.eVN != curIt.eVN || scratchItem.eScore != curIt.eScore) status = EXT_ASSERT;
+			cnt.recomputeTiles++; cnt.backtraceTiles++; cnt.columnSteps += g.nodeLength[curNode];
+			if (status != EXT_OK) return status;
+		}
+		int row = here.seqPos & 63;
+		if (row == 0 && here.offset == 0) {
+			Cell nxt; bool sw;
+			if (!corner(nxt, sw)) return EXT_ASSERT;
+			if (!pushTraceW(nxt, sw)) return status;
+			here = nxt;
+			continue;
+		}
+		if (row == 0) {
+			if (!prevItExists) {
+				here = Cell { curNode, 0, here.seqPos };
+				if (!pushTraceW(here, false)) return status;
+				continue;
+			}
+			uint32_t off = here.offset;
+			while (off > 0 && wsValue(L.col(off - 1), 0) == wsValue(L.col(off), 0) - 1) {
+				off--;
+				if (!pushTraceW(Cell { curNode, off, here.seqPos }, false)) return status;
+			}
+			here.offset = off;
+			if (off == 0) {
+				Cell nxt; bool sw;
+				if (!corner(nxt, sw)) return EXT_ASSERT;
+				if (!pushTraceW(nxt, sw)) return status;
+				here = nxt;
+				continue;
+			}
+			int32_t scoreHere = wsValue(L.col(off), 0);
+			int32_t scoreDiagonal = prevIt.sScore;
+			uint64_t lowMask = ((1ull << off) - 1) & ~1ull;
+			scoreDiagonal += popc64(prevIt.HP & lowMask) - popc64(prevIt.HN & lowMask);
+			int32_t scoreUp = scoreDiagonal + (int32_t)((prevIt.HP >> off) & 1) - (int32_t)((prevIt.HN >> off) & 1);
+			int32_t quitScore = cs.minScore + cs.bandwidth, previousQuitScore = ps.minScore + ps.bandwidth;
+			Cell nxt;
+			if (scoreHere > quitScore || scoreDiagonal > previousQuitScore || scoreUp > previousQuitScore) {
+				nxt = scoreDiagonal < scoreUp ? Cell { curNode, off - 1, here.seqPos - 1 } : Cell { curNode, off, here.seqPos - 1 };
+			} else {
+				NodeSeq nseq = loadNodeSeq(g, curNode);
+				int eqBit = (int)(eqOfColumn(eq, nseq, (int)off) & 1);
+				if (scoreUp == scoreHere - 1) nxt = Cell { curNode, off, here.seqPos - 1 };
+				else if (scoreDiagonal == scoreHere - (eqBit ? 0 : 1)) nxt = Cell { curNode, off - 1, here.seqPos - 1 };
+				else return EXT_ASSERT;
+			}
+			if (!pushTraceW(nxt, false)) return status;
+			here = nxt;
+			continue;
+		}
+		if (here.offset == 0) {
+			WS start = itemStart(curIt);
+			int32_t sp = here.seqPos;
+			while ((sp & 63) != 0 && (start.VP & (1ull << (sp & 63)))) {
+				sp--;
+				if (!pushTraceW(Cell { curNode, 0, sp }, false)) return status;
+			}
+			here.seqPos = sp;
+			int offset = sp & 63;
+			if (offset == 0) {
+				Cell nxt; bool sw;
+				if (!corner(nxt, sw)) return EXT_ASSERT;
+				if (!pushTraceW(nxt, sw)) return status;
+				here = nxt;
+				continue;
+			}
+			NodeSeq nseq = loadNodeSeq(g, curNode);
+			int eqBit = (int)((eqOfColumn(eq, nseq, 0) >> offset) & 1);
+			int32_t scoreHere = wsValue(start, offset);
+			int32_t quitScore = cs.minScore + cs.bandwidth;
+			Cell nxt { 0, 0, 0 };
+			bool sw = false, found = false;
+			if (scoreHere > quitScore) {
+				int32_t smallest = wsValue(start, offset - 1);
+				nxt = Cell { curNode, 0, sp - 1 };
+				for (uint32_t e = g.inOff[curNode]; e < g.inOff[curNode + 1]; e++) {
+					uint32_t nb = g.inAdj[e];
+					int c = findItemW(wsx, cs, nb);
+					if (c < 0) continue;
+					WS ne = itemEnd(loadItem(wsx, (uint32_t)c));
+					if (wsValue(ne, offset - 1) <= smallest) { smallest = wsValue(ne, offset - 1); nxt = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, sp - 1 }; sw = true; }
+					if (wsValue(ne, offset) < smallest && nb != curNode) { smallest = wsValue(ne, offset); nxt = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, sp }; sw = true; }
+				}
+				found = true;
+			} else {
+				for (uint32_t e = g.inOff[curNode]; e < g.inOff[curNode + 1] && !found; e++) {
+					uint32_t nb = g.inAdj[e];
+					int c = findItemW(wsx, cs, nb);
+					if (c < 0) continue;
+					WS ne = itemEnd(loadItem(wsx, (uint32_t)c));
+					if (wsValue(ne, offset) == scoreHere - 1) { nxt = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, sp }; sw = true; found = true; }
+					else if (wsValue(ne, offset - 1) == scoreHere - (eqBit ? 0 : 1)) { nxt = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, sp - 1 }; sw = true; found = true; }
+				}
+			}
+			if (!found) return EXT_ASSERT;
+			if (!pushTraceW(nxt, sw)) return status;
+			here = nxt;
+			continue;
+		}
+		{
+			uint32_t hori = here.offset;
+			int vert = row;
+			NodeSeq nseq = loadNodeSeq(g, curNode);
+			while (hori > 0 && vert > 0) {
+				WS ch = L.col(hori), cl = L.col(hori - 1);
+				int32_t scoreHere = wsValue(ch, vert);
+				int32_t vertical = wsValue(ch, vert - 1);
+				int32_t diagonal = wsValue(cl, vert - 1);
+				int eqBit = (int)((eqOfColumn(eq, nseq, (int)hori) >> vert) & 1);
+				if (vertical == scoreHere - 1) { vert--; }
+				else if (diagonal == scoreHere - (eqBit ? 0 : 1)) { hori--; vert--; }
+				else {
+					if (wsValue(cl, vert) != scoreHere - 1) return EXT_ASSERT;
+					hori--;
+				}
+				if (!pushTraceW(Cell { curNode, hori, cs.j + vert }, false)) return status;
+			}
+			here = Cell { curNode, hori, cs.j + vert };
+		}
+	}
+	{
+		if (here.node != startNode) return EXT_ASSERT;
+		uint32_t off = here.offset;
+		while (true) {
+			int32_t b = (int32_t)off - (int32_t)startOffset; if (b < 0) b = -b;
+			int32_t bl = (int32_t)off - 1 - (int32_t)startOffset; if (bl < 0) bl = -bl;
+			if (!(b != 0 && off > 0 && bl == b - 1)) break;
+			off--;
+			if (!pushTraceW(Cell { here.node, off, -1 }, false)) return status;
+		}
+	}
+	cnt.traceItems += nTrace;
+	return status;
+}
+
+} // namespace gcdev

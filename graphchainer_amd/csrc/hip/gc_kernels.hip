@@ -1,6 +1,7 @@
 // HIP kernels of the GraphChainer hot path for gfx950 (MI355X). See gc_device.hpp for the device data model
 // and DESIGN.md for the mapping rationale and the per-kernel roofline accounting.
 #include "gc_kernels.hpp"
+#include "gc_device_wave.hpp"
 
 namespace gcdev {
 
@@ -485,6 +486,34 @@ __device__ inline int onTrace(const LongCell* trace, uint32_t n, uint32_t seqPos
 	return 0;
 }
 
+// seedScoreForEndToEndAln update after an alignment was added. reference: src/GraphAligner.h:181-198 - the list is
+// sorted by alignmentStart; if the first starts at 0, later alignments whose start is <= the running end extend it;
+// if the union reaches the read's end the minimum seedGoodness of the contributing alignments becomes the cut-off.
+// Visiting in ascending start makes the outcome independent of the order among equal starts, so no sort is needed.
+__device__ inline uint32_t endToEndScore(LongAln* mine, uint32_t nAln, uint32_t readLen, uint32_t current)
+{
+	bool anyAtZero = false;
+	for (uint32_t a = 0; a < nAln; a++) if (mine[a].start == 0) anyAtZero = true;
+	if (!anyAtZero) return current;
+	uint32_t contiguousEnd = 0, minGoodness = 0xffffffffu;
+	bool first = true;
+	for (uint32_t visited = 0; visited < nAln; visited++) {
+		uint32_t best = 0xffffffffu;
+		for (uint32_t a = 0; a < nAln; a++) {
+			if (mine[a].pad) continue;
+			if (best == 0xffffffffu || mine[a].start < mine[best].start) best = a;
+		}
+		mine[best].pad = 1;
+		if (first) { contiguousEnd = mine[best].end; minGoodness = mine[best].goodness; first = false; continue; }
+		if (mine[best].start <= contiguousEnd) {
+			minGoodness = mine[best].goodness < minGoodness ? mine[best].goodness : minGoodness;
+			contiguousEnd = mine[best].end > contiguousEnd ? mine[best].end : contiguousEnd;
+		}
+	}
+	for (uint32_t a = 0; a < nAln; a++) mine[a].pad = 0;
+	return contiguousEnd == readLen ? minGoodness : current;
+}
+
 __global__ void __launch_bounds__(64) k_long_pass(DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg,
 	const LongJob* __restrict__ jobs, uint32_t nReads, const LongSeed* __restrict__ seeds, const char* __restrict__ bases, uint64_t rcBase,
 	uint32_t minClusterSize, uint32_t maxAlignments, uint8_t* __restrict__ scratch, uint64_t slabBytes,
@@ -568,42 +597,116 @@ __global__ void __launch_bounds__(64) k_long_pass(DGraph g, const CorrectnessTab
 			al.traceLen = total;
 			al.pad = 0;
 			mine[nAln++] = al;
-			// end-to-end test over the alignments sorted by start (:181-198); the union walk below is independent of
-			// the order among equal starts, so no sort is needed: repeatedly extend the contiguous prefix from 0
-			bool anyAtZero = false;
-			for (uint32_t a = 0; a < nAln; a++) if (mine[a].start == 0) anyAtZero = true;
-			if (anyAtZero) {
-				// the reference seeds the walk with alignments[0] of the sorted list: an alignment with start 0
-				uint32_t contiguousEnd = 0, minGoodness = 0xffffffffu;
-				bool grew = true;
-				// emulate the single left-to-right pass over the list sorted by start: an alignment joins iff its start
-				// <= the running end at the time it is visited; visiting in ascending start makes that a fixed point
-				// of "start <= current end", reached by iterating in start order
-				uint32_t lastStart = 0; bool firstPass = true;
-				while (grew) {
-					grew = false;
-					// pick unvisited alignments in ascending start order
-					uint32_t bestIdx = 0xffffffffu;
-					for (uint32_t a = 0; a < nAln; a++) {
-						if (mine[a].pad) continue;
-						if (bestIdx == 0xffffffffu || mine[a].start < mine[bestIdx].start) bestIdx = a;
-					}
-					if (bestIdx == 0xffffffffu) break;
-					mine[bestIdx].pad = 1;
-					grew = true;
-					if (firstPass) { contiguousEnd = mine[bestIdx].end; minGoodness = mine[bestIdx].goodness; firstPass = false; continue; }
-					if (mine[bestIdx].start <= contiguousEnd) {
-						minGoodness = mine[bestIdx].goodness < minGoodness ? mine[bestIdx].goodness : minGoodness;
-						contiguousEnd = mine[bestIdx].end > contiguousEnd ? mine[bestIdx].end : contiguousEnd;
-					}
-					(void)lastStart;
-				}
-				for (uint32_t a = 0; a < nAln; a++) mine[a].pad = 0;
-				if (contiguousEnd == (uint32_t)L) e2eScore = minGoodness;
-			}
+			e2eScore = endToEndScore(mine, nAln, (uint32_t)L, e2eScore);
 		}
 		LongReadResult rr;
 		rr.nAlignments = status == 1 ? 0 : nAln;   // a throwing AlignOneWay returns nothing (src/Aligner.cpp:585-592)
+		rr.seedsExtended = extended;
+		rr.status = status;
+		rr.pad = 0;
+		results[r] = rr;
+	}
+	if (cnt.extensions) {
+		atomicAdd(&counters[0], cnt.dpTiles);
+		atomicAdd(&counters[1], cnt.recomputeTiles);
+		atomicAdd(&counters[2], cnt.columnSteps);
+		atomicAdd(&counters[3], cnt.traceItems);
+		atomicAdd(&counters[4], cnt.extensions);
+		atomicAdd(&counters[5], cnt.backtraceTiles);
+	}
+}
+
+// K3-long, wave layout: same per-read logic as k_long_pass, with the extension core of gc_device_wave.hpp
+// (hot slice state in LDS, DP table and traces lane-interleaved in HBM). One wave per block owns the CU's LDS.
+// A read whose band needs more than WAVE_CAP nodes in one slice is reported with status 5 and rerun by the host
+// with k_long_pass.
+__global__ void __launch_bounds__(64) k_long_pass_wave(DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg,
+	const LongJob* __restrict__ jobs, uint32_t nReads, const LongSeed* __restrict__ seeds, const char* __restrict__ bases, uint64_t rcBase,
+	uint32_t minClusterSize, uint32_t maxAlignments, unsigned long long* __restrict__ scratch, uint64_t wordsPerLane,
+	LongCell* __restrict__ cellPool, unsigned long long* __restrict__ cellCursor, uint64_t cellCapacity,
+	LongAln* __restrict__ alns, LongReadResult* __restrict__ results, unsigned long long* __restrict__ counters)
+{
+	__shared__ WaveLds lds;
+	const uint32_t lane = threadIdx.x;
+	WaveScratch wsx;
+	wsx.base = scratch + (uint64_t)blockIdx.x * wordsPerLane * 64;
+	wsx.lane = lane;
+	wsx.maxSlices = cfg.maxSlices; wsx.maxItems = cfg.maxItems; wsx.maxTrace = cfg.maxTrace;
+	ExtCounters cnt { 0, 0, 0, 0, 0, 0 };
+	for (uint32_t r = blockIdx.x * 64 + lane; r < nReads; r += gridDim.x * 64) {
+		LongJob job = jobs[r];
+		LongAln* mine = alns + job.alnBegin;
+		uint32_t nAln = 0, extended = 0, status = 0;
+		uint32_t e2eScore = 0;
+		const int L = (int)job.readLen;
+		for (uint32_t si = job.seedBegin; si < job.seedEnd && status == 0; si++) {
+			LongSeed sd = seeds[si];
+			if (sd.goodness < e2eScore) break;
+			if (sd.clusterSize < minClusterSize) continue;
+			bool skip = false;
+			for (uint32_t a = 0; a < nAln; a++)
+				if (mine[a].start <= sd.seqPos && mine[a].end >= sd.seqPos && mine[a].goodness > sd.goodness) { skip = true; break; }
+			if (skip) continue;
+			int32_t compareNode = g.nodeIDs[sd.node];
+			uint32_t compareOffset = g.nodeOffset[sd.node] + sd.offset;
+			for (uint32_t a = 0; a < nAln && !skip; a++) {
+				int on = onTrace(cellPool + mine[a].traceOff, mine[a].traceLen, sd.seqPos, compareNode, compareOffset);
+				if (on == 2) { status = 1; break; }
+				if (on == 1) skip = true;
+			}
+			if (skip || status) continue;
+			extended++;
+			const int p = (int)sd.seqPos;
+			uint32_t nB = 0, nF = 0;
+			int32_t scoreB = 0, scoreF = 0;
+			uint32_t stB = EXT_FAILED, stF = EXT_FAILED;
+			if (p > 0) stB = extendSeedWave(g, *ct, iupac, cfg.bandwidth, &lds, wsx, bases + rcBase + job.readOff + (uint64_t)(L - p), p, sd.twinNode, sd.twinOffset, 0, nB, scoreB, cnt);
+			if (p < L - 1) stF = extendSeedWave(g, *ct, iupac, cfg.bandwidth, &lds, wsx, bases + job.readOff + (uint64_t)(p + 1), L - 1 - p, sd.node, sd.offset, 1, nF, scoreF, cnt);
+			if (stB == EXT_ASSERT || stF == EXT_ASSERT) { status = 1; break; }
+			if (stB == EXT_OVERFLOW || stF == EXT_OVERFLOW) { status = 2; break; }
+			if (stB == EXT_LDS_CAP || stF == EXT_LDS_CAP) { status = 5; break; }
+			bool hasB = stB == EXT_OK, hasF = stF == EXT_OK;
+			if (!hasB && !hasF) continue;
+			if (nAln >= maxAlignments) { status = 3; break; }
+			uint32_t useB = hasB ? (hasF ? nB - 1 : nB) : 0;
+			uint32_t total = useB + (hasF ? nF : 0);
+			unsigned long long base = atomicAdd(cellCursor, (unsigned long long)total);
+			if (base + total > cellCapacity) { status = 4; break; }
+			LongCell* outCells = cellPool + base;
+			for (uint32_t i = 0; i < useB; i++) {
+				TraceCell c = unpackCell(wsx.word(wsx.traceBase(i, 0)));
+				uint32_t off = c.offsetAndSwitch & 255u;
+				int32_t id = g.nodeIDs[c.node];
+				uint32_t orig = g.nodeOffset[c.node] + off;
+				LongCell oc;
+				oc.node = id ^ 1;
+				oc.offset = g.origSize[id] - 1 - orig;
+				oc.seqPos = (uint32_t)(p - 1 - c.seqPos);
+				oc.nodeSwitch = (i + 1 < nB) ? ((unpackCell(wsx.word(wsx.traceBase(i + 1, 0))).offsetAndSwitch >> 8) & 1u) : 0u;
+				outCells[i] = oc;
+			}
+			if (hasF) for (uint32_t i = 0; i < nF; i++) {
+				TraceCell c = unpackCell(wsx.word(wsx.traceBase(nF - 1 - i, 1)));
+				LongCell oc;
+				oc.node = g.nodeIDs[c.node];
+				oc.offset = g.nodeOffset[c.node] + (c.offsetAndSwitch & 255u);
+				oc.seqPos = (uint32_t)(p + 1 + c.seqPos);
+				oc.nodeSwitch = (c.offsetAndSwitch >> 8) & 1u;
+				outCells[useB + i] = oc;
+			}
+			LongAln al;
+			al.start = outCells[0].seqPos;
+			al.end = outCells[total - 1].seqPos + 1;
+			al.score = (uint32_t)((hasB ? scoreB : 0) + (hasF ? scoreF : 0));
+			al.goodness = sd.goodness;
+			al.traceOff = base;
+			al.traceLen = total;
+			al.pad = 0;
+			mine[nAln++] = al;
+			e2eScore = endToEndScore(mine, nAln, (uint32_t)L, e2eScore);
+		}
+		LongReadResult rr;
+		rr.nAlignments = status == 1 ? 0 : nAln;
 		rr.seedsExtended = extended;
 		rr.status = status;
 		rr.pad = 0;
@@ -676,6 +779,17 @@ void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, 
 {
 	if (nReads == 0) return;
 	hipLaunchKernelGGL(k_chain, dim3(chainGridBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus);
+}
+
+uint64_t longWaveWordsPerLane(const ExtendConfig& cfg) { return waveScratchWords(cfg.maxSlices, cfg.maxItems, cfg.maxTrace); }
+
+void launchLongPassWave(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg, const LongJob* jobs, uint32_t nReads,
+	const LongSeed* seeds, const char* bases, uint64_t rcBase, uint32_t minClusterSize, uint32_t maxAlignments, unsigned long long* scratch, uint32_t blocks,
+	LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity, LongAln* alns, LongReadResult* results, unsigned long long* counters)
+{
+	if (nReads == 0) return;
+	hipLaunchKernelGGL(k_long_pass_wave, dim3(blocks), dim3(64), 0, stream, g, ct, iupac, cfg, jobs, nReads, seeds, bases, rcBase, minClusterSize, maxAlignments, scratch, longWaveWordsPerLane(cfg),
+		cellPool, cellCursor, cellCapacity, alns, results, counters);
 }
 
 uint64_t longSlabBytes(const ExtendConfig& cfg) { return (extendSlabBytes(cfg) + sizeof(TraceCell) * (uint64_t)cfg.maxTrace + 63) & ~63ull; }

@@ -119,5 +119,9 @@ void launchLongPass(hipStream_t stream, const DGraph& g, const CorrectnessTables
 	const LongSeed* seeds, const char* bases, uint64_t rcBase, uint32_t minClusterSize, uint32_t maxAlignments, uint8_t* scratch, uint64_t slabBytes,
 	LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity, LongAln* alns, LongReadResult* results, unsigned long long* counters);
 uint64_t longSlabBytes(const ExtendConfig& cfg);
+uint64_t longWaveWordsPerLane(const ExtendConfig& cfg);
+void launchLongPassWave(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg, const LongJob* jobs, uint32_t nReads,
+	const LongSeed* seeds, const char* bases, uint64_t rcBase, uint32_t minClusterSize, uint32_t maxAlignments, unsigned long long* scratch, uint32_t blocks,
+	LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity, LongAln* alns, LongReadResult* results, unsigned long long* counters);
 
 } // namespace gcdev

@@ -118,3 +118,16 @@ def test_whole_read_pass_parity(gca, tmp_path, backbone, n_reads, read_len):
     got, want = run_case(gca, gfa, reads, long_pass=True)
     compare(got, want, COMPARE_KEYS + LONG_KEYS)
     assert int(got["read_longall_off"][-1]) >= n_reads
+
+
+def test_whole_read_pass_plain_layout_fallback(gca, tmp_path, monkeypatch):
+    """Reads whose band does not fit the LDS tables are rerun with the plain-layout kernel; force that path for all."""
+    from graphchainer_amd.synth import SynthGraph
+    monkeypatch.setenv("GC_LONG_FORCE_FALLBACK", "1")
+    sg = SynthGraph(60_000, seed=8)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(5, 4000, seed=4)
+    got, want = run_case(gca, gfa, reads, long_pass=True)
+    compare(got, want, COMPARE_KEYS + LONG_KEYS)
+    assert int(got["counters_long"][7]) == len(reads)
