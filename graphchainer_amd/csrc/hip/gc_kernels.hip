@@ -530,22 +530,33 @@ __global__ void __launch_bounds__(64) k_long_pass(DGraph g, const CorrectnessTab
 		uint32_t nAln = 0, extended = 0, status = 0;
 		uint32_t e2eScore = 0;   // seedScoreForEndToEndAln
 		const int L = (int)job.readLen;
-		for (uint32_t si = job.seedBegin; si < job.seedEnd && status == 0; si++) {
-			LongSeed sd = seeds[si];
-			if (sd.goodness < e2eScore) break;                       // aligned end to end, skip the rest (:127-131)
-			if (sd.clusterSize < minClusterSize) continue;            // :141-146
-			bool skip = false;
-			for (uint32_t a = 0; a < nAln; a++)                        // sloppy overlap rule (:147-161)
-				if (mine[a].start <= sd.seqPos && mine[a].end >= sd.seqPos && mine[a].goodness > sd.goodness) { skip = true; break; }
-			if (skip) continue;
-			int32_t compareNode = g.nodeIDs[sd.node];
-			uint32_t compareOffset = g.nodeOffset[sd.node] + sd.offset;
-			for (uint32_t a = 0; a < nAln && !skip; a++) {            // exactAlignmentPart (:163-173)
-				int on = onTrace(cellPool + mine[a].traceOff, mine[a].traceLen, sd.seqPos, compareNode, compareOffset);
-				if (on == 2) { status = 1; break; }
-				if (on == 1) skip = true;
+		// Lanes of a wave must reach the expensive part (the extension) together: a plain loop over seeds would let
+		// every lane extend at a different iteration and serialise the wave's extensions. So each lane first advances
+		// to its next seed that needs extending (cheap, divergent), then all lanes that found one extend in step.
+		uint32_t si = job.seedBegin;
+		while (true) {
+			bool have = false;
+			LongSeed sd {};
+			for (; status == 0 && si < job.seedEnd && !have; si++) {
+				sd = seeds[si];
+				if (sd.goodness < e2eScore) { si = job.seedEnd; break; }   // aligned end to end, skip the rest (:127-131)
+				if (sd.clusterSize < minClusterSize) continue;              // :141-146
+				bool skip = false;
+				for (uint32_t a = 0; a < nAln; a++)                          // sloppy overlap rule (:147-161)
+					if (mine[a].start <= sd.seqPos && mine[a].end >= sd.seqPos && mine[a].goodness > sd.goodness) { skip = true; break; }
+				if (skip) continue;
+				int32_t compareNode = g.nodeIDs[sd.node];
+				uint32_t compareOffset = g.nodeOffset[sd.node] + sd.offset;
+				for (uint32_t a = 0; a < nAln && !skip; a++) {              // exactAlignmentPart (:163-173)
+					int on = onTrace(cellPool + mine[a].traceOff, mine[a].traceLen, sd.seqPos, compareNode, compareOffset);
+					if (on == 2) { status = 1; break; }
+					if (on == 1) skip = true;
+				}
+				if (skip || status) continue;
+				have = true;
 			}
-			if (skip || status) continue;
+			if (!__any(have)) break;
+			if (!have) continue;
 			extended++;
 			// getAlignmentFromSeed (:567-626): backward on revcomp(read[0..p)), forward on read(p..]
 			const int p = (int)sd.seqPos;
@@ -639,22 +650,33 @@ __global__ void __launch_bounds__(64) k_long_pass_wave(DGraph g, const Correctne
 		uint32_t nAln = 0, extended = 0, status = 0;
 		uint32_t e2eScore = 0;
 		const int L = (int)job.readLen;
-		for (uint32_t si = job.seedBegin; si < job.seedEnd && status == 0; si++) {
-			LongSeed sd = seeds[si];
-			if (sd.goodness < e2eScore) break;
-			if (sd.clusterSize < minClusterSize) continue;
-			bool skip = false;
-			for (uint32_t a = 0; a < nAln; a++)
-				if (mine[a].start <= sd.seqPos && mine[a].end >= sd.seqPos && mine[a].goodness > sd.goodness) { skip = true; break; }
-			if (skip) continue;
-			int32_t compareNode = g.nodeIDs[sd.node];
-			uint32_t compareOffset = g.nodeOffset[sd.node] + sd.offset;
-			for (uint32_t a = 0; a < nAln && !skip; a++) {
-				int on = onTrace(cellPool + mine[a].traceOff, mine[a].traceLen, sd.seqPos, compareNode, compareOffset);
-				if (on == 2) { status = 1; break; }
-				if (on == 1) skip = true;
+		// Lanes of a wave must reach the expensive part (the extension) together: a plain loop over seeds would let
+		// every lane extend at a different iteration and serialise the wave's extensions. So each lane first advances
+		// to its next seed that needs extending (cheap, divergent), then all lanes that found one extend in step.
+		uint32_t si = job.seedBegin;
+		while (true) {
+			bool have = false;
+			LongSeed sd {};
+			for (; status == 0 && si < job.seedEnd && !have; si++) {
+				sd = seeds[si];
+				if (sd.goodness < e2eScore) { si = job.seedEnd; break; }   // aligned end to end, skip the rest (:127-131)
+				if (sd.clusterSize < minClusterSize) continue;              // :141-146
+				bool skip = false;
+				for (uint32_t a = 0; a < nAln; a++)                          // sloppy overlap rule (:147-161)
+					if (mine[a].start <= sd.seqPos && mine[a].end >= sd.seqPos && mine[a].goodness > sd.goodness) { skip = true; break; }
+				if (skip) continue;
+				int32_t compareNode = g.nodeIDs[sd.node];
+				uint32_t compareOffset = g.nodeOffset[sd.node] + sd.offset;
+				for (uint32_t a = 0; a < nAln && !skip; a++) {              // exactAlignmentPart (:163-173)
+					int on = onTrace(cellPool + mine[a].traceOff, mine[a].traceLen, sd.seqPos, compareNode, compareOffset);
+					if (on == 2) { status = 1; break; }
+					if (on == 1) skip = true;
+				}
+				if (skip || status) continue;
+				have = true;
 			}
-			if (skip || status) continue;
+			if (!__any(have)) break;
+			if (!have) continue;
 			extended++;
 			const int p = (int)sd.seqPos;
 			uint32_t nB = 0, nF = 0;
