@@ -170,6 +170,8 @@ def main():
                          "wall_seed_lookup_and_copies": round(host_us[2] / 1e3, 3), "wall_extend_to_chain_and_copies": round(host_us[3] / 1e3, 3)},
             "setup_s": {"generate": round(t_gen, 1), "graph_build_upload": round(t_graph, 1), "minimizer_index": round(t_index, 1)},
             "reads_with_chain": int((chain_len > 0).sum()), "extensions_per_step": int(extensions),
+            "long_pass": {"reads_with_alignment": int((n_long > 0).sum()), "extensions_per_step": int(counters_long[4]), "plain_layout_reruns": int(counters_long[7]),
+                          "seeds_extended_mean": round(float(out["seeds_extended_long"].mean()), 2), "seeds_extended_max": int(out["seeds_extended_long"].max())} if long_pass else None,
         }
         print(json.dumps(line))
     if dist is not None:

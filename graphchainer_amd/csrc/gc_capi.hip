@@ -189,6 +189,7 @@ struct gc_stream {
 	hipStream_t longStream = nullptr;
 	hipEvent_t longEv[2] {};
 	DeviceBuffer longSeeds, longJobs, longAlns, longResults, longScratch, longCells, longCursor, longJobsFallback, longResultsFallback, longScratchFallback;
+	DeviceBuffer longState, longWork, longWorkResults, longRoundTrace;
 	PinnedBuffer hLongSeeds, hLongJobs, hLongAlns, hLongResults, hLongSmall;
 	~gc_stream()
 	{
@@ -776,6 +777,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		unsigned long long* hLongSmall = nullptr;
 		LongCell* dLongCells = nullptr;
 		std::function<uint64_t()> longFallback;
+		std::function<void()> runLongRounds;
 		if (P->long_pass) {
 			for (uint64_t r = 0; r < n; r++) { glue[r].longSeedBegin = nLongSeeds; nLongSeeds += glue[r].longSeeds.size(); maxReadLen = std::max<uint64_t>(maxReadLen, R->offsets[r + 1] - R->offsets[r]); }
 			if (nLongSeeds >= 0xffffffffull) throw std::runtime_error("batch too large for the whole-read pass");
@@ -814,7 +816,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			LongJob* dLongJobs = st->longJobs.reserve<LongJob>(n);
 			LongAln* dLongAlns = st->longAlns.reserve<LongAln>(n * maxAlignments);
 			LongReadResult* dLongResults = st->longResults.reserve<LongReadResult>(n);
-			unsigned long long* dLongScratch = st->longScratch.reserve<unsigned long long>((uint64_t)waveBlocks * waveWords * 64);
+			unsigned long long* dLongScratch = nullptr;
 			dLongCells = st->longCells.reserve<LongCell>(cellBudget);
 			unsigned long long* dLongCursor = st->longCursor.reserve<unsigned long long>(16);
 			hLongAlns = st->hLongAlns.reserve<LongAln>(n * maxAlignments);
@@ -824,11 +826,40 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			HIP_CHECK(hipMemsetAsync(dLongCursor, 0, 16 * sizeof(unsigned long long), ls));
 			if (nLongSeeds) HIP_CHECK(hipMemcpyAsync(dLongSeeds, hSeeds, nLongSeeds * sizeof(LongSeed), hipMemcpyHostToDevice, ls));
 			if (n) HIP_CHECK(hipMemcpyAsync(dLongJobs, hJobs, n * sizeof(LongJob), hipMemcpyHostToDevice, ls));
-			HIP_CHECK(hipEventRecord(st->longEv[0], ls));
-			launchLongPassWave(ls, G->dev, G->devTables, G->devIupac, lcfg, dLongJobs, (uint32_t)n, dLongSeeds, R->devBases, R->totalBases, (uint32_t)P->min_cluster_size, maxAlignments,
-				dLongScratch, waveBlocks, dLongCells, dLongCursor, cellBudget, dLongAlns, dLongResults, dLongCursor + 8);
-			HIP_CHECK(hipEventRecord(st->longEv[1], ls));
-			if (n) HIP_CHECK(hipMemcpyAsync(hLongResults, dLongResults, n * sizeof(LongReadResult), hipMemcpyDeviceToHost, ls));
+			// rounds: select -> extend -> merge until no read has a seed left to extend (see gc_kernels.hip, "K3-long in rounds")
+			LongState* dLongState = st->longState.reserve<LongState>(n);
+			LongWork* dLongWork = st->longWork.reserve<LongWork>(2 * n);
+			LongWorkResult* dLongWorkResults = st->longWorkResults.reserve<LongWorkResult>(2 * n);
+			uint64_t roundTraceBudget = 0;
+			for (uint64_t r = 0; r < n; r++) { uint64_t len = R->offsets[r + 1] - R->offsets[r]; roundTraceBudget += len + len / 2 + 1024; }
+			unsigned long long* dRoundTrace = st->longRoundTrace.reserve<unsigned long long>(roundTraceBudget);
+			uint32_t extendBlocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((2 * n + 63) / 64, 1024));
+			dLongScratch = st->longScratch.reserve<unsigned long long>((uint64_t)extendBlocks * waveWords * 64);
+			runLongRounds = [=]() {
+				launchLongInit(ls, dLongJobs, (uint32_t)n, dLongState);
+				double extendUs = 0;
+				for (int round = 0; round < 4096; round++) {
+					HIP_CHECK(hipMemsetAsync(dLongCursor + 1, 0, 2 * sizeof(unsigned long long), ls));   // [1] work count, [2] round trace cursor
+					launchLongSelect(ls, G->dev, dLongJobs, (uint32_t)n, dLongSeeds, R->totalBases, (uint32_t)P->min_cluster_size, dLongState, dLongAlns, dLongCells, dLongWork, dLongCursor + 1);
+					HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
+					HIP_CHECK(hipStreamSynchronize(ls));
+					uint32_t nWorkItems = (uint32_t)hLongSmall[1];
+					if (nWorkItems == 0) break;
+					uint32_t blocks = std::min<uint32_t>((nWorkItems + 63) / 64, extendBlocks);
+					HIP_CHECK(hipEventRecord(st->longEv[0], ls));
+					launchLongExtend(ls, G->dev, G->devTables, G->devIupac, lcfg, dLongWork, nWorkItems, R->devBases, dLongScratch, blocks, dRoundTrace, dLongCursor + 2, roundTraceBudget, dLongWorkResults, dLongCursor + 8);
+					HIP_CHECK(hipEventRecord(st->longEv[1], ls));
+					launchLongMerge(ls, G->dev, dLongJobs, dLongSeeds, dLongWork, dLongWorkResults, nWorkItems / 2, dRoundTrace, maxAlignments, dLongState, dLongAlns, dLongCells, dLongCursor, cellBudget);
+					HIP_CHECK(hipStreamSynchronize(ls));
+					float ms = 0;
+					HIP_CHECK(hipEventElapsedTime(&ms, st->longEv[0], st->longEv[1]));
+					extendUs += (double)ms * 1000.0;
+					res->counters_long[6]++;   // rounds
+				}
+				launchLongFinish(ls, (uint32_t)n, dLongState, dLongResults);
+				if (n) HIP_CHECK(hipMemcpyAsync(hLongResults, dLongResults, n * sizeof(LongReadResult), hipMemcpyDeviceToHost, ls));
+				res->kernel_us[4] = extendUs;
+			};
 			// reads whose band did not fit the LDS tables (status 5) are rerun with the plain-layout kernel
 			longFallback = [=, &glue]() {
 				HIP_CHECK(hipStreamSynchronize(ls));
@@ -901,6 +932,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		mark();   // 4
 		launchChain(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, P->split_len, P->split_gap, caps, dChainScratch, dChainOut, dChainLen, dChainScore, dChainStatus);
 		mark();   // 5
+		if (P->long_pass) runLongRounds();   // host drives the rounds on the long stream while the fragment kernels run on theirs
 
 		// ---------------- results back (pinned staging)
 		AnchorRec* anchors = st->hAnchors.reserve<AnchorRec>(nSlots);
@@ -945,10 +977,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		if (P->long_pass) {
 			uint64_t rerun = longFallback();
 			res->counters_long[7] = rerun;   // reads that needed the plain-layout fallback kernel
-			float ms = 0;
-			HIP_CHECK(hipEventElapsedTime(&ms, st->longEv[0], st->longEv[1]));
-			res->kernel_us[4] = (double)ms * 1000.0;
-			for (int i = 0; i < 7; i++) res->counters_long[i] = hLongSmall[8 + i];   // same units as counters[]
+			for (int i = 0; i < 6; i++) res->counters_long[i] = hLongSmall[8 + i];   // same units as counters[]
 			for (uint64_t r = 0; r < n; r++) {
 				if (hLongResults[r].status == 2) throw std::runtime_error("whole-read pass: extension scratch overflow (raise GC_LONG_MAX_ITEMS)");
 				if (hLongResults[r].status == 3) throw std::runtime_error("whole-read pass: more than 32 alignments for one read");

@@ -34,35 +34,49 @@ struct WaveLds { uint32_t w[WAVE_WORDS][64]; };
 static_assert(sizeof(WaveLds) <= 160 * 1024, "WaveLds must fit the CU's LDS");
 static_assert(64 * 5 <= WAVE_WORDS, "the 64 backtrace columns (5 words each) alias the lane's table words");
 
+// Entries beyond WAVE_CAP (rare: very dense variant clusters) spill to lane-interleaved HBM words, so a slice may hold
+// up to WAVE_CAP + WAVE_SPILL nodes before the extension gives up with EXT_LDS_CAP.
+#define WAVE_SPILL 228
+#define WAVE_MAX_ENTRIES (WAVE_CAP + WAVE_SPILL)
+#define WAVE_SPILL_WORDS (3 * WAVE_SPILL * WAVE_ENTRY_WORDS)
+
 struct LaneLds {   // one lane's view
 	WaveLds* l;
 	uint32_t lane;
-	__device__ __forceinline__ uint32_t& W(uint32_t word) const { return l->w[word][lane]; }
-	__device__ __forceinline__ uint64_t ld64(uint32_t word) const { return (uint64_t)l->w[word][lane] | ((uint64_t)l->w[word + 1][lane] << 32); }
-	__device__ __forceinline__ void st64(uint32_t word, uint64_t v) const { l->w[word][lane] = (uint32_t)v; l->w[word + 1][lane] = (uint32_t)(v >> 32); }
+	unsigned long long* spill;   // wave-interleaved: word w of this lane at spill[w*64 + lane]
+	// logical word index -> storage. Table words [0, WAVE_WORDS) are LDS; spill entries map behind them.
+	__device__ __forceinline__ uint32_t ldW(uint32_t word) const { return word < WAVE_WORDS ? l->w[word][lane] : (uint32_t)spill[(uint64_t)(word - WAVE_WORDS) * 64 + lane]; }
+	__device__ __forceinline__ void stW(uint32_t word, uint32_t v) const { if (word < WAVE_WORDS) l->w[word][lane] = v; else spill[(uint64_t)(word - WAVE_WORDS) * 64 + lane] = v; }
+	__device__ __forceinline__ uint64_t ld64(uint32_t word) const { return (uint64_t)ldW(word) | ((uint64_t)ldW(word + 1) << 32); }
+	__device__ __forceinline__ void st64(uint32_t word, uint64_t v) const { stW(word, (uint32_t)v); stW(word + 1, (uint32_t)(v >> 32)); }
+	// entry e of table t (0/1 = slice tables, 2 = pending queue) -> first logical word
+	__device__ __forceinline__ uint32_t entryBase(uint32_t t, uint32_t e) const
+	{
+		return e < WAVE_CAP ? (t * WAVE_CAP + e) * WAVE_ENTRY_WORDS : WAVE_WORDS + (t * WAVE_SPILL + (e - WAVE_CAP)) * WAVE_ENTRY_WORDS;
+	}
 	// slice tables: buffer b (0/1), entry e: node, startScore, minScore, HP, HN
-	__device__ __forceinline__ uint32_t pBase(int b, uint32_t e) const { return ((uint32_t)b * WAVE_CAP + e) * WAVE_ENTRY_WORDS; }
-	__device__ __forceinline__ uint32_t pNode(int b, uint32_t e) const { return W(pBase(b, e)); }
-	__device__ __forceinline__ int32_t pStart(int b, uint32_t e) const { return (int32_t)W(pBase(b, e) + 1); }
-	__device__ __forceinline__ int32_t pMin(int b, uint32_t e) const { return (int32_t)W(pBase(b, e) + 2); }
+	__device__ __forceinline__ uint32_t pBase(int b, uint32_t e) const { return entryBase((uint32_t)b, e); }
+	__device__ __forceinline__ uint32_t pNode(int b, uint32_t e) const { return ldW(pBase(b, e)); }
+	__device__ __forceinline__ int32_t pStart(int b, uint32_t e) const { return (int32_t)ldW(pBase(b, e) + 1); }
+	__device__ __forceinline__ int32_t pMin(int b, uint32_t e) const { return (int32_t)ldW(pBase(b, e) + 2); }
 	__device__ __forceinline__ uint64_t pHP(int b, uint32_t e) const { return ld64(pBase(b, e) + 3); }
 	__device__ __forceinline__ uint64_t pHN(int b, uint32_t e) const { return ld64(pBase(b, e) + 5); }
 	__device__ __forceinline__ void pSet(int b, uint32_t e, uint32_t node, int32_t start, int32_t mn, uint64_t hp, uint64_t hn) const
 	{
 		uint32_t base = pBase(b, e);
-		W(base) = node; W(base + 1) = (uint32_t)start; W(base + 2) = (uint32_t)mn; st64(base + 3, hp); st64(base + 5, hn);
+		stW(base, node); stW(base + 1, (uint32_t)start); stW(base + 2, (uint32_t)mn); st64(base + 3, hp); st64(base + 5, hn);
 	}
 	// pending queue entry e: node, comp, score, VP, VN
-	__device__ __forceinline__ uint32_t qBase(uint32_t e) const { return (2u * WAVE_CAP + e) * WAVE_ENTRY_WORDS; }
-	__device__ __forceinline__ uint32_t qNode(uint32_t e) const { return W(qBase(e)); }
-	__device__ __forceinline__ uint32_t qComp(uint32_t e) const { return W(qBase(e) + 1); }
-	__device__ __forceinline__ WS qWs(uint32_t e) const { uint32_t base = qBase(e); return WS { ld64(base + 3), ld64(base + 5), (int32_t)W(base + 2) }; }
-	__device__ __forceinline__ void qSetWs(uint32_t e, const WS& x) const { uint32_t base = qBase(e); W(base + 2) = (uint32_t)x.score; st64(base + 3, x.VP); st64(base + 5, x.VN); }
-	__device__ __forceinline__ void qSet(uint32_t e, uint32_t node, uint32_t comp, const WS& x) const { uint32_t base = qBase(e); W(base) = node; W(base + 1) = comp; qSetWs(e, x); }
-	__device__ __forceinline__ void qMove(uint32_t dst, uint32_t src) const { uint32_t d = qBase(dst), sb = qBase(src); for (int i = 0; i < WAVE_ENTRY_WORDS; i++) W(d + i) = W(sb + i); }
-	// backtrace columns (alias the table words): column c: VP, VN, score
-	__device__ __forceinline__ void colSet(uint32_t c, const WS& x) const { uint32_t base = c * 5; st64(base, x.VP); st64(base + 2, x.VN); W(base + 4) = (uint32_t)x.score; }
-	__device__ __forceinline__ WS col(uint32_t c) const { uint32_t base = c * 5; return WS { ld64(base), ld64(base + 2), (int32_t)W(base + 4) }; }
+	__device__ __forceinline__ uint32_t qBase(uint32_t e) const { return entryBase(2u, e); }
+	__device__ __forceinline__ uint32_t qNode(uint32_t e) const { return ldW(qBase(e)); }
+	__device__ __forceinline__ uint32_t qComp(uint32_t e) const { return ldW(qBase(e) + 1); }
+	__device__ __forceinline__ WS qWs(uint32_t e) const { uint32_t base = qBase(e); return WS { ld64(base + 3), ld64(base + 5), (int32_t)ldW(base + 2) }; }
+	__device__ __forceinline__ void qSetWs(uint32_t e, const WS& x) const { uint32_t base = qBase(e); stW(base + 2, (uint32_t)x.score); st64(base + 3, x.VP); st64(base + 5, x.VN); }
+	__device__ __forceinline__ void qSet(uint32_t e, uint32_t node, uint32_t comp, const WS& x) const { uint32_t base = qBase(e); stW(base, node); stW(base + 1, comp); qSetWs(e, x); }
+	__device__ __forceinline__ void qMove(uint32_t dst, uint32_t src) const { uint32_t d = qBase(dst), sb = qBase(src); for (int i = 0; i < WAVE_ENTRY_WORDS; i++) stW(d + i, ldW(sb + i)); }
+	// backtrace columns (alias the LDS table words): column c: VP, VN, score
+	__device__ __forceinline__ void colSet(uint32_t c, const WS& x) const { uint32_t base = c * 5; st64(base, x.VP); st64(base + 2, x.VN); stW(base + 4, (uint32_t)x.score); }
+	__device__ __forceinline__ WS col(uint32_t c) const { uint32_t base = c * 5; return WS { ld64(base), ld64(base + 2), (int32_t)ldW(base + 4) }; }
 };
 
 // HBM scratch of one wave, lane-interleaved 8-byte words
@@ -75,8 +89,9 @@ struct WaveScratch {
 	__device__ __forceinline__ uint64_t sliceBase(uint32_t s) const { return (uint64_t)s * 4; }
 	__device__ __forceinline__ uint64_t itemBase(uint32_t i) const { return (uint64_t)maxSlices * 4 + (uint64_t)i * 8; }
 	__device__ __forceinline__ uint64_t traceBase(uint32_t t, uint32_t which) const { return (uint64_t)maxSlices * 4 + (uint64_t)maxItems * 8 + (uint64_t)which * maxTrace + t; }
+	__device__ __forceinline__ unsigned long long* spillBase() const { return base + ((uint64_t)maxSlices * 4 + (uint64_t)maxItems * 8 + 2ull * maxTrace) * 64; }
 };
-__host__ __device__ inline uint64_t waveScratchWords(uint32_t maxSlices, uint32_t maxItems, uint32_t maxTrace) { return (uint64_t)maxSlices * 4 + (uint64_t)maxItems * 8 + 2ull * maxTrace; }
+__host__ __device__ inline uint64_t waveScratchWords(uint32_t maxSlices, uint32_t maxItems, uint32_t maxTrace) { return (uint64_t)maxSlices * 4 + (uint64_t)maxItems * 8 + 2ull * maxTrace + WAVE_SPILL_WORDS; }
 
 struct WSlice { int32_t minScore; uint32_t minNode, minOffset, first, count; int32_t bandwidth; int32_t j; uint32_t flags; };
 
@@ -201,7 +216,7 @@ __device__ inline TileResult computeTileW(const DGraph& g, uint32_t node, WS ws,
 __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTables& ct, const uint8_t* iupac, int bandwidthCfg, WaveLds* lds, const WaveScratch& wsx,
 	const char* seq, int len, uint32_t startNode, uint32_t startOffset, uint32_t which, uint32_t& nTrace, int32_t& score, ExtCounters& cnt)
 {
-	const LaneLds L { lds, wsx.lane };
+	const LaneLds L { lds, wsx.lane, wsx.spillBase() };
 	uint32_t status = EXT_OK;
 	nTrace = 0;
 	score = 0;
@@ -266,7 +281,7 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 				if (!prevExists || wsBefore(add) < prevStart) { add.VP &= ~1ull; add.VN |= 1ull; }
 			}
 			if (slot == nPending) {
-				if (nPending >= WAVE_CAP) { status = EXT_LDS_CAP; return; }
+				if (nPending >= WAVE_MAX_ENTRIES) { status = EXT_LDS_CAP; return; }
 				L.qSet(slot, target, g.componentNumber[target], add);
 				nPending++;
 			} else {
@@ -292,7 +307,7 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 			if (best != nPending - 1) L.qMove(best, nPending - 1);
 			nPending--;
 			if (nItems >= wsx.maxItems) return EXT_OVERFLOW;
-			if (cur.count >= WAVE_CAP) return EXT_LDS_CAP;
+			if (cur.count >= WAVE_MAX_ENTRIES) return EXT_LDS_CAP;
 			int pi = prevFind(pnode);
 			bool prevExists = pi >= 0;
 			NodeItem out;

@@ -745,6 +745,188 @@ __global__ void __launch_bounds__(64) k_long_pass_wave(DGraph g, const Correctne
 }
 
 // =====================================================================================================
+// K3-long in rounds. The monolithic kernels above keep a lane busy for as many rounds as its read needs while the
+// other 63 lanes of the wave wait (3.6 seeds are extended per read on average, up to 10). Here every round is
+//   select  - one lane per read: advance to the next seed that needs extending (the reference's skip rules), emit two
+//             work items (backward, forward);
+//   extend  - one lane per work item, densely packed waves, wave-layout extension core; the trace goes to a pool;
+//   merge   - one lane per seed: merge the two traces, append the alignment, update the end-to-end cut-off;
+// and the host launches rounds until no read emits work. Results are identical to the monolithic kernels.
+// =====================================================================================================
+
+__global__ void __launch_bounds__(256) k_long_init(const LongJob* __restrict__ jobs, uint32_t nReads, LongState* __restrict__ state)
+{
+	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= nReads) return;
+	LongState st { jobs[r].seedBegin, 0, 0, 0, 0, 0xffffffffu, 0, 0 };
+	state[r] = st;
+}
+
+__global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __restrict__ jobs, uint32_t nReads, const LongSeed* __restrict__ seeds, uint64_t rcBase, uint32_t minClusterSize,
+	LongState* __restrict__ state, const LongAln* __restrict__ alns, const LongCell* __restrict__ cellPool, LongWork* __restrict__ work, unsigned long long* __restrict__ workCount)
+{
+	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= nReads) return;
+	LongState st = state[r];
+	if (st.status != 0) return;
+	LongJob job = jobs[r];
+	const LongAln* mine = alns + job.alnBegin;
+	bool have = false;
+	LongSeed sd {};
+	uint32_t si = st.si;
+	for (; st.status == 0 && si < job.seedEnd && !have; si++) {
+		sd = seeds[si];
+		if (sd.goodness < st.e2eScore) { si = job.seedEnd; break; }   // aligned end to end (:127-131)
+		if (sd.clusterSize < minClusterSize) continue;                 // :141-146
+		bool skip = false;
+		for (uint32_t a = 0; a < st.nAln; a++)                           // sloppy overlap rule (:147-161)
+			if (mine[a].start <= sd.seqPos && mine[a].end >= sd.seqPos && mine[a].goodness > sd.goodness) { skip = true; break; }
+		if (skip) continue;
+		int32_t compareNode = g.nodeIDs[sd.node];
+		uint32_t compareOffset = g.nodeOffset[sd.node] + sd.offset;
+		for (uint32_t a = 0; a < st.nAln && !skip; a++) {               // exactAlignmentPart (:163-173)
+			int on = onTrace(cellPool + mine[a].traceOff, mine[a].traceLen, sd.seqPos, compareNode, compareOffset);
+			if (on == 2) { st.status = 1; break; }
+			if (on == 1) skip = true;
+		}
+		if (skip || st.status) continue;
+		have = true;
+	}
+	st.si = si;
+	st.curSeed = 0xffffffffu;
+	if (have) {
+		st.extended++;
+		st.curSeed = si - 1;
+		unsigned long long at = atomicAdd(workCount, 2ull);
+		const uint32_t L = job.readLen, p = sd.seqPos;
+		LongWork b { rcBase + job.readOff + (uint64_t)(L - p), p, sd.twinNode, sd.twinOffset, r };
+		LongWork f { job.readOff + (uint64_t)(p + 1), L - 1 - p, sd.node, sd.offset, r };
+		work[at] = b;
+		work[at + 1] = f;
+	}
+	state[r] = st;
+}
+
+__global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg,
+	const LongWork* __restrict__ work, uint32_t nWork, const char* __restrict__ bases, unsigned long long* __restrict__ scratch, uint64_t wordsPerLane,
+	unsigned long long* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, LongWorkResult* __restrict__ results, unsigned long long* __restrict__ counters)
+{
+	__shared__ WaveLds lds;
+	const uint32_t lane = threadIdx.x;
+	WaveScratch wsx;
+	wsx.base = scratch + (uint64_t)blockIdx.x * wordsPerLane * 64;
+	wsx.lane = lane;
+	wsx.maxSlices = cfg.maxSlices; wsx.maxItems = cfg.maxItems; wsx.maxTrace = cfg.maxTrace;
+	ExtCounters cnt { 0, 0, 0, 0, 0, 0 };
+	for (uint32_t w = blockIdx.x * 64 + lane; w < nWork; w += gridDim.x * 64) {
+		LongWork it = work[w];
+		LongWorkResult res { 0, 0, EXT_FAILED, 0, 0 };
+		if (it.seqLen > 0) {
+			uint32_t nTrace = 0;
+			int32_t score = 0;
+			res.status = extendSeedWave(g, *ct, iupac, cfg.bandwidth, &lds, wsx, bases + it.seqOff, (int)it.seqLen, it.node, it.offset, 0, nTrace, score, cnt);
+			res.score = score;
+			if (res.status == EXT_OK) {
+				unsigned long long base = atomicAdd(traceCursor, (unsigned long long)nTrace);
+				if (base + nTrace <= traceCapacity) {
+					for (uint32_t i = 0; i < nTrace; i++) tracePool[base + i] = wsx.word(wsx.traceBase(i, 0));
+					res.traceOff = base;
+					res.traceLen = nTrace;
+				} else res.status = EXT_OVERFLOW;
+			}
+		}
+		results[w] = res;
+	}
+	if (cnt.extensions) {
+		atomicAdd(&counters[0], cnt.dpTiles);
+		atomicAdd(&counters[1], cnt.recomputeTiles);
+		atomicAdd(&counters[2], cnt.columnSteps);
+		atomicAdd(&counters[3], cnt.traceItems);
+		atomicAdd(&counters[4], cnt.extensions);
+		atomicAdd(&counters[5], cnt.backtraceTiles);
+	}
+}
+
+__global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __restrict__ jobs, const LongSeed* __restrict__ seeds, const LongWork* __restrict__ work,
+	const LongWorkResult* __restrict__ results, uint32_t nPairs, const unsigned long long* __restrict__ tracePool, uint32_t maxAlignments,
+	LongState* __restrict__ state, LongAln* __restrict__ alns, LongCell* __restrict__ cellPool, unsigned long long* __restrict__ cellCursor, uint64_t cellCapacity)
+{
+	uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
+	if (pair >= nPairs) return;
+	const LongWork wb = work[2 * pair], wf = work[2 * pair + 1];
+	const LongWorkResult rb = results[2 * pair], rf = results[2 * pair + 1];
+	const uint32_t r = wb.read;
+	LongState st = state[r];
+	LongJob job = jobs[r];
+	LongSeed sd = seeds[st.curSeed];
+	LongAln* mine = alns + job.alnBegin;
+	const int p = (int)sd.seqPos;
+	const int L = (int)job.readLen;
+	bool runB = p > 0, runF = p < L - 1;
+	uint32_t stB = runB ? rb.status : EXT_FAILED, stF = runF ? rf.status : EXT_FAILED;
+	if (stB == EXT_ASSERT || stF == EXT_ASSERT) st.status = 1;          // getAlignmentFromSeed threw
+	else if (stB == EXT_OVERFLOW || stF == EXT_OVERFLOW) st.status = 2;
+	else if (stB == EXT_LDS_CAP || stF == EXT_LDS_CAP) st.status = 5;
+	else {
+		bool hasB = stB == EXT_OK, hasF = stF == EXT_OK;
+		if (hasB || hasF) {
+			uint32_t nB = rb.traceLen, nF = rf.traceLen;
+			uint32_t useB = hasB ? (hasF ? nB - 1 : nB) : 0;
+			uint32_t total = useB + (hasF ? nF : 0);
+			if (st.nAln >= maxAlignments) st.status = 3;
+			else {
+				unsigned long long base = atomicAdd(cellCursor, (unsigned long long)total);
+				if (base + total > cellCapacity) st.status = 4;
+				else {
+					LongCell* outCells = cellPool + base;
+					for (uint32_t i = 0; i < useB; i++) {   // fixReverseTraceSeqPosAndOrder (:543-565)
+						TraceCell c = unpackCell(tracePool[rb.traceOff + i]);
+						uint32_t off = c.offsetAndSwitch & 255u;
+						int32_t id = g.nodeIDs[c.node];
+						uint32_t orig = g.nodeOffset[c.node] + off;
+						LongCell oc;
+						oc.node = id ^ 1;
+						oc.offset = g.origSize[id] - 1 - orig;
+						oc.seqPos = (uint32_t)(p - 1 - c.seqPos);
+						oc.nodeSwitch = (i + 1 < nB) ? ((unpackCell(tracePool[rb.traceOff + i + 1]).offsetAndSwitch >> 8) & 1u) : 0u;
+						outCells[i] = oc;
+					}
+					if (hasF) for (uint32_t i = 0; i < nF; i++) {   // fixForwardTraceSeqPos (:527-540), device order reversed
+						TraceCell c = unpackCell(tracePool[rf.traceOff + (nF - 1 - i)]);
+						LongCell oc;
+						oc.node = g.nodeIDs[c.node];
+						oc.offset = g.nodeOffset[c.node] + (c.offsetAndSwitch & 255u);
+						oc.seqPos = (uint32_t)(p + 1 + c.seqPos);
+						oc.nodeSwitch = (c.offsetAndSwitch >> 8) & 1u;
+						outCells[useB + i] = oc;
+					}
+					LongAln al;
+					al.start = outCells[0].seqPos;
+					al.end = outCells[total - 1].seqPos + 1;
+					al.score = (uint32_t)((hasB ? rb.score : 0) + (hasF ? rf.score : 0));
+					al.goodness = sd.goodness;
+					al.traceOff = base;
+					al.traceLen = total;
+					al.pad = 0;
+					mine[st.nAln++] = al;
+					st.e2eScore = endToEndScore(mine, st.nAln, (uint32_t)L, st.e2eScore);
+				}
+			}
+		}
+	}
+	state[r] = st;
+}
+
+__global__ void __launch_bounds__(256) k_long_finish(uint32_t nReads, const LongState* __restrict__ state, LongReadResult* __restrict__ results)
+{
+	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= nReads) return;
+	LongState st = state[r];
+	LongReadResult rr { st.status == 1 ? 0u : st.nAln, st.extended, st.status, 0 };   // a throwing AlignOneWay returns nothing (src/Aligner.cpp:585-592)
+	results[r] = rr;
+}
+
+// =====================================================================================================
 // launchers
 // =====================================================================================================
 
@@ -812,6 +994,30 @@ void launchLongPassWave(hipStream_t stream, const DGraph& g, const CorrectnessTa
 	if (nReads == 0) return;
 	hipLaunchKernelGGL(k_long_pass_wave, dim3(blocks), dim3(64), 0, stream, g, ct, iupac, cfg, jobs, nReads, seeds, bases, rcBase, minClusterSize, maxAlignments, scratch, longWaveWordsPerLane(cfg),
 		cellPool, cellCursor, cellCapacity, alns, results, counters);
+}
+
+void launchLongInit(hipStream_t stream, const LongJob* jobs, uint32_t nReads, LongState* state)
+{
+	if (nReads) hipLaunchKernelGGL(k_long_init, dim3((nReads + 255) / 256), dim3(256), 0, stream, jobs, nReads, state);
+}
+void launchLongSelect(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, uint64_t rcBase, uint32_t minClusterSize,
+	LongState* state, const LongAln* alns, const LongCell* cellPool, LongWork* work, unsigned long long* workCount)
+{
+	if (nReads) hipLaunchKernelGGL(k_long_select, dim3((nReads + 63) / 64), dim3(64), 0, stream, g, jobs, nReads, seeds, rcBase, minClusterSize, state, alns, cellPool, work, workCount);
+}
+void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg, const LongWork* work, uint32_t nWork, const char* bases,
+	unsigned long long* scratch, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters)
+{
+	if (nWork) hipLaunchKernelGGL(k_long_extend, dim3(blocks), dim3(64), 0, stream, g, ct, iupac, cfg, work, nWork, bases, scratch, longWaveWordsPerLane(cfg), tracePool, traceCursor, traceCapacity, results, counters);
+}
+void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, const LongSeed* seeds, const LongWork* work, const LongWorkResult* results, uint32_t nPairs,
+	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity)
+{
+	if (nPairs) hipLaunchKernelGGL(k_long_merge, dim3((nPairs + 63) / 64), dim3(64), 0, stream, g, jobs, seeds, work, results, nPairs, tracePool, maxAlignments, state, alns, cellPool, cellCursor, cellCapacity);
+}
+void launchLongFinish(hipStream_t stream, uint32_t nReads, const LongState* state, LongReadResult* results)
+{
+	if (nReads) hipLaunchKernelGGL(k_long_finish, dim3((nReads + 255) / 256), dim3(256), 0, stream, nReads, state, results);
 }
 
 uint64_t longSlabBytes(const ExtendConfig& cfg) { return (extendSlabBytes(cfg) + sizeof(TraceCell) * (uint64_t)cfg.maxTrace + 63) & ~63ull; }

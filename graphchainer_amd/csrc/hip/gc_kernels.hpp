@@ -96,6 +96,15 @@ struct LongAln {     // one accepted alignment, in acceptance order
 
 struct LongReadResult { uint32_t nAlignments, seedsExtended, status, pad; };
 
+// round-based whole-read pass: per-read state carried between rounds, and the per-round work items
+struct LongState { uint32_t si, nAln, extended, status, e2eScore, curSeed, pad0, pad1; };
+struct LongWork {    // one direction of one seed extension
+	uint64_t seqOff;
+	uint32_t seqLen, node, offset;
+	uint32_t read;
+};
+struct LongWorkResult { uint64_t traceOff; uint32_t traceLen, status; int32_t score; uint32_t pad; };
+
 // ---- launchers (all asynchronous on `stream`) ------------------------------------------------------
 void launchSeedLookup(hipStream_t stream, const SeedIndex& idx, const char* bases, const uint64_t* readOff, uint32_t nReads,
 	uint64_t* matchCursor, uint32_t* readMatchOff, uint32_t* readMatchCount, uint2* matches, uint64_t matchCapacity, uint32_t* tmp);
@@ -120,6 +129,14 @@ void launchLongPass(hipStream_t stream, const DGraph& g, const CorrectnessTables
 	LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity, LongAln* alns, LongReadResult* results, unsigned long long* counters);
 uint64_t longSlabBytes(const ExtendConfig& cfg);
 uint64_t longWaveWordsPerLane(const ExtendConfig& cfg);
+void launchLongInit(hipStream_t stream, const LongJob* jobs, uint32_t nReads, LongState* state);
+void launchLongSelect(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, uint64_t rcBase, uint32_t minClusterSize,
+	LongState* state, const LongAln* alns, const LongCell* cellPool, LongWork* work, unsigned long long* workCount);
+void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg, const LongWork* work, uint32_t nWork, const char* bases,
+	unsigned long long* scratch, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters);
+void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, const LongSeed* seeds, const LongWork* work, const LongWorkResult* results, uint32_t nPairs,
+	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity);
+void launchLongFinish(hipStream_t stream, uint32_t nReads, const LongState* state, LongReadResult* results);
 void launchLongPassWave(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg, const LongJob* jobs, uint32_t nReads,
 	const LongSeed* seeds, const char* bases, uint64_t rcBase, uint32_t minClusterSize, uint32_t maxAlignments, unsigned long long* scratch, uint32_t blocks,
 	LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity, LongAln* alns, LongReadResult* results, unsigned long long* counters);
