@@ -833,8 +833,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			uint64_t roundTraceBudget = 0;
 			for (uint64_t r = 0; r < n; r++) { uint64_t len = R->offsets[r + 1] - R->offsets[r]; roundTraceBudget += len + len / 2 + 1024; }
 			unsigned long long* dRoundTrace = st->longRoundTrace.reserve<unsigned long long>(roundTraceBudget);
-			uint32_t extendBlocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((2 * n + 63) / 64, 1024));
-			dLongScratch = st->longScratch.reserve<unsigned long long>((uint64_t)extendBlocks * waveWords * 64);
+			// scratch for up to 2n work items in flight (one lane each), whatever the team size
+			dLongScratch = st->longScratch.reserve<unsigned long long>((2 * n + 64) * waveWords);
 			runLongRounds = [=]() {
 				launchLongInit(ls, dLongJobs, (uint32_t)n, dLongState);
 				double extendUs = 0;
@@ -845,9 +845,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					HIP_CHECK(hipStreamSynchronize(ls));
 					uint32_t nWorkItems = (uint32_t)hLongSmall[1];
 					if (nWorkItems == 0) break;
-					uint32_t blocks = std::min<uint32_t>((nWorkItems + 63) / 64, extendBlocks);
+					uint32_t team = longExtendTeamSize(nWorkItems);
+					uint32_t blocks = (nWorkItems + team - 1) / team;
 					HIP_CHECK(hipEventRecord(st->longEv[0], ls));
-					launchLongExtend(ls, G->dev, G->devTables, G->devIupac, lcfg, dLongWork, nWorkItems, R->devBases, dLongScratch, blocks, dRoundTrace, dLongCursor + 2, roundTraceBudget, dLongWorkResults, dLongCursor + 8);
+					launchLongExtend(ls, G->dev, G->devTables, G->devIupac, lcfg, dLongWork, nWorkItems, R->devBases, dLongScratch, team, blocks, dRoundTrace, dLongCursor + 2, roundTraceBudget, dLongWorkResults, dLongCursor + 8);
 					HIP_CHECK(hipEventRecord(st->longEv[1], ls));
 					launchLongMerge(ls, G->dev, dLongJobs, dLongSeeds, dLongWork, dLongWorkResults, nWorkItems / 2, dRoundTrace, maxAlignments, dLongState, dLongAlns, dLongCells, dLongCursor, cellBudget);
 					HIP_CHECK(hipStreamSynchronize(ls));

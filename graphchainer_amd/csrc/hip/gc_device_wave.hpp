@@ -30,7 +30,8 @@ enum : uint32_t { EXT_LDS_CAP = 5 };
 // current-slice table (the two swap every slice) and pending queue -> 21 words; 28 entries = 588 words = 150.5 KB per wave.
 #define WAVE_ENTRY_WORDS 7
 #define WAVE_WORDS (3 * WAVE_CAP * WAVE_ENTRY_WORDS)
-struct WaveLds { uint32_t w[WAVE_WORDS][64]; };
+template <int LANES> struct WaveLdsT { uint32_t w[WAVE_WORDS][LANES]; };
+typedef WaveLdsT<64> WaveLds;
 static_assert(sizeof(WaveLds) <= 160 * 1024, "WaveLds must fit the CU's LDS");
 static_assert(64 * 5 <= WAVE_WORDS, "the 64 backtrace columns (5 words each) alias the lane's table words");
 
@@ -38,58 +39,77 @@ static_assert(64 * 5 <= WAVE_WORDS, "the 64 backtrace columns (5 words each) ali
 // up to WAVE_CAP + WAVE_SPILL nodes before the extension gives up with EXT_LDS_CAP.
 #define WAVE_SPILL 228
 #define WAVE_MAX_ENTRIES (WAVE_CAP + WAVE_SPILL)
-#define WAVE_SPILL_WORDS (3 * WAVE_SPILL * WAVE_ENTRY_WORDS)
+#define WAVE_SPILL_WORDS (3 * WAVE_SPILL * 4)
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;   // keeps LDS accesses as ds_read/ds_write (a generic pointer compiles to flat_*)
 
 struct LaneLds {   // one lane's view
-	WaveLds* l;
-	uint32_t lane;
-	unsigned long long* spill;   // wave-interleaved: word w of this lane at spill[w*64 + lane]
-	// logical word index -> storage. Table words [0, WAVE_WORDS) are LDS; spill entries map behind them.
-	__device__ __forceinline__ uint32_t ldW(uint32_t word) const { return word < WAVE_WORDS ? l->w[word][lane] : (uint32_t)spill[(uint64_t)(word - WAVE_WORDS) * 64 + lane]; }
-	__device__ __forceinline__ void stW(uint32_t word, uint32_t v) const { if (word < WAVE_WORDS) l->w[word][lane] = v; else spill[(uint64_t)(word - WAVE_WORDS) * 64 + lane] = v; }
-	__device__ __forceinline__ uint64_t ld64(uint32_t word) const { return (uint64_t)ldW(word) | ((uint64_t)ldW(word + 1) << 32); }
-	__device__ __forceinline__ void st64(uint32_t word, uint64_t v) const { stW(word, (uint32_t)v); stW(word + 1, (uint32_t)(v >> 32)); }
-	// entry e of table t (0/1 = slice tables, 2 = pending queue) -> first logical word
-	__device__ __forceinline__ uint32_t entryBase(uint32_t t, uint32_t e) const
+	lds_u32* l;                  // LDS words of the team, [word][lanes]
+	uint32_t lane, lanes;        // this lane's index in its team and the team size (active lanes per wave)
+	unsigned long long* spill;   // team-interleaved HBM words for entries >= WAVE_CAP: word w of this lane at spill[w*lanes + lane]
+	__device__ __forceinline__ uint32_t ldL(uint32_t word) const { return l[word * lanes + lane]; }
+	__device__ __forceinline__ void stL(uint32_t word, uint32_t v) const { l[word * lanes + lane] = v; }
+	__device__ __forceinline__ uint64_t ldL64(uint32_t word) const { return (uint64_t)ldL(word) | ((uint64_t)ldL(word + 1) << 32); }
+	__device__ __forceinline__ void stL64(uint32_t word, uint64_t v) const { stL(word, (uint32_t)v); stL(word + 1, (uint32_t)(v >> 32)); }
+	__device__ __forceinline__ unsigned long long& S(uint32_t word) const { return spill[(uint64_t)word * lanes + lane]; }
+	// an entry of table t (0/1 = slice tables, 2 = pending queue): 7 words in LDS, or (spilled) 5 HBM words {w0|w1<<32, w2, 64-bit a, 64-bit b}
+	struct Entry { uint32_t w0, w1, w2; uint64_t a, b; };
+	__device__ __forceinline__ uint32_t ldsBase(uint32_t t, uint32_t e) const { return (t * WAVE_CAP + e) * WAVE_ENTRY_WORDS; }
+	__device__ __forceinline__ uint32_t spillBase(uint32_t t, uint32_t e) const { return (t * WAVE_SPILL + (e - WAVE_CAP)) * 4; }
+	__device__ __forceinline__ Entry get(uint32_t t, uint32_t e) const
 	{
-		return e < WAVE_CAP ? (t * WAVE_CAP + e) * WAVE_ENTRY_WORDS : WAVE_WORDS + (t * WAVE_SPILL + (e - WAVE_CAP)) * WAVE_ENTRY_WORDS;
+		Entry x;
+		if (e < WAVE_CAP) {
+			uint32_t base = ldsBase(t, e);
+			x.w0 = ldL(base); x.w1 = ldL(base + 1); x.w2 = ldL(base + 2); x.a = ldL64(base + 3); x.b = ldL64(base + 5);
+		} else {
+			uint32_t base = spillBase(t, e);
+			unsigned long long p = S(base);
+			x.w0 = (uint32_t)p; x.w1 = (uint32_t)(p >> 32); x.w2 = (uint32_t)S(base + 1); x.a = S(base + 2); x.b = S(base + 3);
+		}
+		return x;
 	}
+	__device__ __forceinline__ void set(uint32_t t, uint32_t e, const Entry& x) const
+	{
+		if (e < WAVE_CAP) {
+			uint32_t base = ldsBase(t, e);
+			stL(base, x.w0); stL(base + 1, x.w1); stL(base + 2, x.w2); stL64(base + 3, x.a); stL64(base + 5, x.b);
+		} else {
+			uint32_t base = spillBase(t, e);
+			S(base) = (unsigned long long)x.w0 | ((unsigned long long)x.w1 << 32); S(base + 1) = x.w2; S(base + 2) = x.a; S(base + 3) = x.b;
+		}
+	}
+	__device__ __forceinline__ uint32_t word0(uint32_t t, uint32_t e) const { return e < WAVE_CAP ? ldL(ldsBase(t, e)) : (uint32_t)S(spillBase(t, e)); }
+	__device__ __forceinline__ uint32_t word1(uint32_t t, uint32_t e) const { return e < WAVE_CAP ? ldL(ldsBase(t, e) + 1) : (uint32_t)(S(spillBase(t, e)) >> 32); }
+	__device__ __forceinline__ uint32_t word2(uint32_t t, uint32_t e) const { return e < WAVE_CAP ? ldL(ldsBase(t, e) + 2) : (uint32_t)S(spillBase(t, e) + 1); }
 	// slice tables: buffer b (0/1), entry e: node, startScore, minScore, HP, HN
-	__device__ __forceinline__ uint32_t pBase(int b, uint32_t e) const { return entryBase((uint32_t)b, e); }
-	__device__ __forceinline__ uint32_t pNode(int b, uint32_t e) const { return ldW(pBase(b, e)); }
-	__device__ __forceinline__ int32_t pStart(int b, uint32_t e) const { return (int32_t)ldW(pBase(b, e) + 1); }
-	__device__ __forceinline__ int32_t pMin(int b, uint32_t e) const { return (int32_t)ldW(pBase(b, e) + 2); }
-	__device__ __forceinline__ uint64_t pHP(int b, uint32_t e) const { return ld64(pBase(b, e) + 3); }
-	__device__ __forceinline__ uint64_t pHN(int b, uint32_t e) const { return ld64(pBase(b, e) + 5); }
-	__device__ __forceinline__ void pSet(int b, uint32_t e, uint32_t node, int32_t start, int32_t mn, uint64_t hp, uint64_t hn) const
-	{
-		uint32_t base = pBase(b, e);
-		stW(base, node); stW(base + 1, (uint32_t)start); stW(base + 2, (uint32_t)mn); st64(base + 3, hp); st64(base + 5, hn);
-	}
+	__device__ __forceinline__ uint32_t pNode(int b, uint32_t e) const { return word0((uint32_t)b, e); }
+	__device__ __forceinline__ int32_t pStart(int b, uint32_t e) const { return (int32_t)word1((uint32_t)b, e); }
+	__device__ __forceinline__ int32_t pMin(int b, uint32_t e) const { return (int32_t)word2((uint32_t)b, e); }
+	__device__ __forceinline__ void pSet(int b, uint32_t e, uint32_t node, int32_t start, int32_t mn, uint64_t hp, uint64_t hn) const { set((uint32_t)b, e, Entry { node, (uint32_t)start, (uint32_t)mn, hp, hn }); }
 	// pending queue entry e: node, comp, score, VP, VN
-	__device__ __forceinline__ uint32_t qBase(uint32_t e) const { return entryBase(2u, e); }
-	__device__ __forceinline__ uint32_t qNode(uint32_t e) const { return ldW(qBase(e)); }
-	__device__ __forceinline__ uint32_t qComp(uint32_t e) const { return ldW(qBase(e) + 1); }
-	__device__ __forceinline__ WS qWs(uint32_t e) const { uint32_t base = qBase(e); return WS { ld64(base + 3), ld64(base + 5), (int32_t)ldW(base + 2) }; }
-	__device__ __forceinline__ void qSetWs(uint32_t e, const WS& x) const { uint32_t base = qBase(e); stW(base + 2, (uint32_t)x.score); st64(base + 3, x.VP); st64(base + 5, x.VN); }
-	__device__ __forceinline__ void qSet(uint32_t e, uint32_t node, uint32_t comp, const WS& x) const { uint32_t base = qBase(e); stW(base, node); stW(base + 1, comp); qSetWs(e, x); }
-	__device__ __forceinline__ void qMove(uint32_t dst, uint32_t src) const { uint32_t d = qBase(dst), sb = qBase(src); for (int i = 0; i < WAVE_ENTRY_WORDS; i++) stW(d + i, ldW(sb + i)); }
-	// backtrace columns (alias the LDS table words): column c: VP, VN, score
-	__device__ __forceinline__ void colSet(uint32_t c, const WS& x) const { uint32_t base = c * 5; st64(base, x.VP); st64(base + 2, x.VN); stW(base + 4, (uint32_t)x.score); }
-	__device__ __forceinline__ WS col(uint32_t c) const { uint32_t base = c * 5; return WS { ld64(base), ld64(base + 2), (int32_t)ldW(base + 4) }; }
+	__device__ __forceinline__ uint32_t qNode(uint32_t e) const { return word0(2u, e); }
+	__device__ __forceinline__ uint32_t qComp(uint32_t e) const { return word1(2u, e); }
+	__device__ __forceinline__ WS qWs(uint32_t e) const { Entry x = get(2u, e); return WS { x.a, x.b, (int32_t)x.w2 }; }
+	__device__ __forceinline__ void qSet(uint32_t e, uint32_t node, uint32_t comp, const WS& x) const { set(2u, e, Entry { node, comp, (uint32_t)x.score, x.VP, x.VN }); }
+	__device__ __forceinline__ void qSetWs(uint32_t e, const WS& x) const { Entry old = get(2u, e); set(2u, e, Entry { old.w0, old.w1, (uint32_t)x.score, x.VP, x.VN }); }
+	__device__ __forceinline__ void qMove(uint32_t dst, uint32_t src) const { set(2u, dst, get(2u, src)); }
+	// backtrace columns (alias the LDS table words, LDS only): column c: VP, VN, score
+	__device__ __forceinline__ void colSet(uint32_t c, const WS& x) const { uint32_t base = c * 5; stL64(base, x.VP); stL64(base + 2, x.VN); stL(base + 4, (uint32_t)x.score); }
+	__device__ __forceinline__ WS col(uint32_t c) const { uint32_t base = c * 5; return WS { ldL64(base), ldL64(base + 2), (int32_t)ldL(base + 4) }; }
 };
 
 // HBM scratch of one wave, lane-interleaved 8-byte words
 struct WaveScratch {
-	unsigned long long* base;   // wave base
-	uint32_t lane;
+	unsigned long long* base;   // team base
+	uint32_t lane, lanes;
 	uint32_t maxSlices, maxItems, maxTrace;
 	// word offsets (per lane) of the regions
-	__device__ __forceinline__ unsigned long long& word(uint64_t w) const { return base[w * 64 + lane]; }
+	__device__ __forceinline__ unsigned long long& word(uint64_t w) const { return base[w * lanes + lane]; }
 	__device__ __forceinline__ uint64_t sliceBase(uint32_t s) const { return (uint64_t)s * 4; }
 	__device__ __forceinline__ uint64_t itemBase(uint32_t i) const { return (uint64_t)maxSlices * 4 + (uint64_t)i * 8; }
 	__device__ __forceinline__ uint64_t traceBase(uint32_t t, uint32_t which) const { return (uint64_t)maxSlices * 4 + (uint64_t)maxItems * 8 + (uint64_t)which * maxTrace + t; }
-	__device__ __forceinline__ unsigned long long* spillBase() const { return base + ((uint64_t)maxSlices * 4 + (uint64_t)maxItems * 8 + 2ull * maxTrace) * 64; }
+	__device__ __forceinline__ unsigned long long* spillBase() const { return base + ((uint64_t)maxSlices * 4 + (uint64_t)maxItems * 8 + 2ull * maxTrace) * lanes; }
 };
 __host__ __device__ inline uint64_t waveScratchWords(uint32_t maxSlices, uint32_t maxItems, uint32_t maxTrace) { return (uint64_t)maxSlices * 4 + (uint64_t)maxItems * 8 + 2ull * maxTrace + WAVE_SPILL_WORDS; }
 
@@ -213,10 +233,10 @@ __device__ inline TileResult computeTileW(const DGraph& g, uint32_t node, WS ws,
 
 
 // Full seed extension, wave layout. Trace goes to trace region `which` of the wave scratch (start cell first).
-__device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTables& ct, const uint8_t* iupac, int bandwidthCfg, WaveLds* lds, const WaveScratch& wsx,
+__device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTables& ct, const uint8_t* iupac, int bandwidthCfg, lds_u32* lds, const WaveScratch& wsx,
 	const char* seq, int len, uint32_t startNode, uint32_t startOffset, uint32_t which, uint32_t& nTrace, int32_t& score, ExtCounters& cnt)
 {
-	const LaneLds L { lds, wsx.lane, wsx.spillBase() };
+	const LaneLds L { lds, wsx.lane, wsx.lanes, wsx.spillBase() };
 	uint32_t status = EXT_OK;
 	nTrace = 0;
 	score = 0;
@@ -311,8 +331,9 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 			int pi = prevFind(pnode);
 			bool prevExists = pi >= 0;
 			NodeItem out;
-			TileResult tr = computeTileW(g, pnode, pws, prevExists, prevExists ? L.pStart(buf, (uint32_t)pi) : 0,
-				prevExists ? L.pHP(buf, (uint32_t)pi) : ~0ull, prevExists ? L.pHN(buf, (uint32_t)pi) : 0ull, eq, out, nullptr, flatRows, status);
+			LaneLds::Entry pe { 0, 0, 0, ~0ull, 0ull };
+			if (prevExists) pe = L.get((uint32_t)buf, (uint32_t)pi);
+			TileResult tr = computeTileW(g, pnode, pws, prevExists, (int32_t)pe.w1, pe.a, pe.b, eq, out, nullptr, flatRows, status);
 			if (status != EXT_OK) return status;
 			out.minScore = tr.minScore;
 			storeItem(wsx, nItems, out);

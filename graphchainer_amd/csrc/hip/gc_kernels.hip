@@ -2,6 +2,7 @@
 // and DESIGN.md for the mapping rationale and the per-kernel roofline accounting.
 #include "gc_kernels.hpp"
 #include "gc_device_wave.hpp"
+#include <cstdlib>
 
 namespace gcdev {
 
@@ -642,6 +643,7 @@ __global__ void __launch_bounds__(64) k_long_pass_wave(DGraph g, const Correctne
 	WaveScratch wsx;
 	wsx.base = scratch + (uint64_t)blockIdx.x * wordsPerLane * 64;
 	wsx.lane = lane;
+	wsx.lanes = 64;
 	wsx.maxSlices = cfg.maxSlices; wsx.maxItems = cfg.maxItems; wsx.maxTrace = cfg.maxTrace;
 	ExtCounters cnt { 0, 0, 0, 0, 0, 0 };
 	for (uint32_t r = blockIdx.x * 64 + lane; r < nReads; r += gridDim.x * 64) {
@@ -682,8 +684,8 @@ __global__ void __launch_bounds__(64) k_long_pass_wave(DGraph g, const Correctne
 			uint32_t nB = 0, nF = 0;
 			int32_t scoreB = 0, scoreF = 0;
 			uint32_t stB = EXT_FAILED, stF = EXT_FAILED;
-			if (p > 0) stB = extendSeedWave(g, *ct, iupac, cfg.bandwidth, &lds, wsx, bases + rcBase + job.readOff + (uint64_t)(L - p), p, sd.twinNode, sd.twinOffset, 0, nB, scoreB, cnt);
-			if (p < L - 1) stF = extendSeedWave(g, *ct, iupac, cfg.bandwidth, &lds, wsx, bases + job.readOff + (uint64_t)(p + 1), L - 1 - p, sd.node, sd.offset, 1, nF, scoreF, cnt);
+			if (p > 0) stB = extendSeedWave(g, *ct, iupac, cfg.bandwidth, (lds_u32*)&lds.w[0][0], wsx, bases + rcBase + job.readOff + (uint64_t)(L - p), p, sd.twinNode, sd.twinOffset, 0, nB, scoreB, cnt);
+			if (p < L - 1) stF = extendSeedWave(g, *ct, iupac, cfg.bandwidth, (lds_u32*)&lds.w[0][0], wsx, bases + job.readOff + (uint64_t)(p + 1), L - 1 - p, sd.node, sd.offset, 1, nF, scoreF, cnt);
 			if (stB == EXT_ASSERT || stF == EXT_ASSERT) { status = 1; break; }
 			if (stB == EXT_OVERFLOW || stF == EXT_OVERFLOW) { status = 2; break; }
 			if (stB == EXT_LDS_CAP || stF == EXT_LDS_CAP) { status = 5; break; }
@@ -807,24 +809,30 @@ __global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __r
 	state[r] = st;
 }
 
+// LANES = active lanes per wave ("team"). The pass is latency-bound and leaves most of the chip idle, so when there
+// are fewer work items than the chip has SIMDs x 64 lanes, running fewer lanes per wave shortens every wave: a wave's
+// instruction stream is the union of its lanes' divergent paths, and LDS per wave shrinks so more waves fit per CU.
+template <int LANES>
 __global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg,
 	const LongWork* __restrict__ work, uint32_t nWork, const char* __restrict__ bases, unsigned long long* __restrict__ scratch, uint64_t wordsPerLane,
 	unsigned long long* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, LongWorkResult* __restrict__ results, unsigned long long* __restrict__ counters)
 {
-	__shared__ WaveLds lds;
+	__shared__ WaveLdsT<LANES> lds;
 	const uint32_t lane = threadIdx.x;
+	if (lane >= LANES) return;
 	WaveScratch wsx;
-	wsx.base = scratch + (uint64_t)blockIdx.x * wordsPerLane * 64;
+	wsx.base = scratch + (uint64_t)blockIdx.x * wordsPerLane * LANES;
 	wsx.lane = lane;
+	wsx.lanes = LANES;
 	wsx.maxSlices = cfg.maxSlices; wsx.maxItems = cfg.maxItems; wsx.maxTrace = cfg.maxTrace;
 	ExtCounters cnt { 0, 0, 0, 0, 0, 0 };
-	for (uint32_t w = blockIdx.x * 64 + lane; w < nWork; w += gridDim.x * 64) {
+	for (uint32_t w = blockIdx.x * LANES + lane; w < nWork; w += gridDim.x * LANES) {
 		LongWork it = work[w];
 		LongWorkResult res { 0, 0, EXT_FAILED, 0, 0 };
 		if (it.seqLen > 0) {
 			uint32_t nTrace = 0;
 			int32_t score = 0;
-			res.status = extendSeedWave(g, *ct, iupac, cfg.bandwidth, &lds, wsx, bases + it.seqOff, (int)it.seqLen, it.node, it.offset, 0, nTrace, score, cnt);
+			res.status = extendSeedWave(g, *ct, iupac, cfg.bandwidth, (lds_u32*)&lds.w[0][0], wsx, bases + it.seqOff, (int)it.seqLen, it.node, it.offset, 0, nTrace, score, cnt);
 			res.score = score;
 			if (res.status == EXT_OK) {
 				unsigned long long base = atomicAdd(traceCursor, (unsigned long long)nTrace);
@@ -1005,10 +1013,29 @@ void launchLongSelect(hipStream_t stream, const DGraph& g, const LongJob* jobs, 
 {
 	if (nReads) hipLaunchKernelGGL(k_long_select, dim3((nReads + 63) / 64), dim3(64), 0, stream, g, jobs, nReads, seeds, rcBase, minClusterSize, state, alns, cellPool, work, workCount);
 }
-void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg, const LongWork* work, uint32_t nWork, const char* bases,
-	unsigned long long* scratch, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters)
+uint32_t longExtendTeamSize(uint32_t nWork)
 {
-	if (nWork) hipLaunchKernelGGL(k_long_extend, dim3(blocks), dim3(64), 0, stream, g, ct, iupac, cfg, work, nWork, bases, scratch, longWaveWordsPerLane(cfg), tracePool, traceCursor, traceCapacity, results, counters);
+	// smallest team that still fits the work into about 2048 resident waves
+	if (const char* env = getenv("GC_LONG_TEAM")) { int v = atoi(env); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return (uint32_t)v; }
+	const uint32_t targetWaves = 2048;
+	for (uint32_t lanes : { 8u, 16u, 32u }) if ((nWork + lanes - 1) / lanes <= targetWaves) return lanes;
+	return 64;
+}
+
+void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg, const LongWork* work, uint32_t nWork, const char* bases,
+	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters)
+{
+	if (!nWork) return;
+	uint64_t words = longWaveWordsPerLane(cfg);
+#define GC_LAUNCH_TEAM(N) hipLaunchKernelGGL(k_long_extend<N>, dim3(blocks), dim3(64), 0, stream, g, ct, iupac, cfg, work, nWork, bases, scratch, words, tracePool, traceCursor, traceCapacity, results, counters)
+	switch (lanes) {
+		case 4: GC_LAUNCH_TEAM(4); break;
+		case 8: GC_LAUNCH_TEAM(8); break;
+		case 16: GC_LAUNCH_TEAM(16); break;
+		case 32: GC_LAUNCH_TEAM(32); break;
+		default: GC_LAUNCH_TEAM(64); break;
+	}
+#undef GC_LAUNCH_TEAM
 }
 void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, const LongSeed* seeds, const LongWork* work, const LongWorkResult* results, uint32_t nPairs,
 	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity)

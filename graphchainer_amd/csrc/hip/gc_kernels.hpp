@@ -132,8 +132,9 @@ uint64_t longWaveWordsPerLane(const ExtendConfig& cfg);
 void launchLongInit(hipStream_t stream, const LongJob* jobs, uint32_t nReads, LongState* state);
 void launchLongSelect(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, uint64_t rcBase, uint32_t minClusterSize,
 	LongState* state, const LongAln* alns, const LongCell* cellPool, LongWork* work, unsigned long long* workCount);
+uint32_t longExtendTeamSize(uint32_t nWork);
 void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg, const LongWork* work, uint32_t nWork, const char* bases,
-	unsigned long long* scratch, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters);
+	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters);
 void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, const LongSeed* seeds, const LongWork* work, const LongWorkResult* results, uint32_t nPairs,
 	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity);
 void launchLongFinish(hipStream_t stream, uint32_t nReads, const LongState* state, LongReadResult* results);
