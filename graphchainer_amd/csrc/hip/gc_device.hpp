@@ -188,19 +188,23 @@ struct LaneScratch {
 struct ExtCounters { unsigned long long dpTiles, recomputeTiles, columnSteps, traceItems, extensions, backtraceTiles; };
 
 // 4 match masks (A,C,G,T) of read rows j..j+63. reference: ...Common.h:280-319. iupac[c] = set of bases c matches.
-__device__ inline void eqVector(const char* seq, int len, int j, const uint8_t* iupac, uint64_t eq[4])
+// Four named members, never an array: an array indexed by the node's 2-bit base code ends up in scratch (or LDS),
+// and the Myers column chain would then wait on a memory load at every step.
+struct Eq4 { uint64_t a, c, g, t; };
+__device__ inline void eqVector(const char* seq, int len, int j, const uint8_t* iupac, Eq4& eq)
 {
-	eq[0] = eq[1] = eq[2] = eq[3] = 0;
+	uint64_t a = 0, c = 0, g = 0, t = 0;
 	int n = len - j;
 	if (n > 64) n = 64;
 	for (int i = 0; i < n; i++) {
-		uint8_t m = iupac[(uint8_t)seq[j + i]];
+		uint32_t m = iupac[(uint8_t)seq[j + i]];
 		uint64_t bit = 1ull << i;
-		if (m & 1) eq[0] |= bit;
-		if (m & 2) eq[1] |= bit;
-		if (m & 4) eq[2] |= bit;
-		if (m & 8) eq[3] |= bit;
+		a |= (m & 1) ? bit : 0ull;
+		c |= (m & 2) ? bit : 0ull;
+		g |= (m & 4) ? bit : 0ull;
+		t |= (m & 8) ? bit : 0ull;
 	}
+	eq.a = a; eq.c = c; eq.g = g; eq.t = t;
 }
 
 struct NodeSeq { uint64_t w0, w1, w2, w3; bool ambiguous; };
@@ -219,23 +223,20 @@ __device__ __forceinline__ NodeSeq loadNodeSeq(const DGraph& g, uint32_t node)
 	}
 	return s;
 }
-__device__ __forceinline__ uint64_t eqOfColumn(const uint64_t eq[4], const NodeSeq& s, int pos)
+__device__ __forceinline__ uint64_t eqOfColumn(const Eq4& eq, const NodeSeq& s, int pos)
 {
 	if (!s.ambiguous) {
 		uint64_t w = pos < 32 ? s.w0 : s.w1;
-		int code = (int)((w >> ((pos & 31) * 2)) & 3);
-		// select without indexing a private array by a runtime value (keeps eq[] in registers)
-		uint64_t r = eq[0];
-		r = code == 1 ? eq[1] : r;
-		r = code == 2 ? eq[2] : r;
-		r = code == 3 ? eq[3] : r;
-		return r;
+		uint32_t code = (uint32_t)(w >> ((pos & 31) * 2));
+		uint64_t lo = (code & 1) ? eq.c : eq.a;   // codes 0/1
+		uint64_t hi = (code & 1) ? eq.t : eq.g;   // codes 2/3
+		return (code & 2) ? hi : lo;
 	}
 	uint64_t r = 0;
-	if ((s.w0 >> pos) & 1) r |= eq[0];
-	if ((s.w1 >> pos) & 1) r |= eq[1];
-	if ((s.w2 >> pos) & 1) r |= eq[2];
-	if ((s.w3 >> pos) & 1) r |= eq[3];
+	r |= ((s.w0 >> pos) & 1) ? eq.a : 0ull;
+	r |= ((s.w1 >> pos) & 1) ? eq.c : 0ull;
+	r |= ((s.w2 >> pos) & 1) ? eq.g : 0ull;
+	r |= ((s.w3 >> pos) & 1) ? eq.t : 0ull;
 	return r;
 }
 
@@ -252,7 +253,7 @@ __device__ inline int findItem(const NodeItem* items, const SliceInfo& sl, uint3
 // columns of the score at row flatRows-1 is tracked (fused flattenLastSliceEnd, ...Common.h:1210-1218).
 struct TileResult { int32_t minScore; uint32_t minOffset; int32_t flatMin; uint32_t flatOffset; };
 __device__ inline TileResult computeTile(const DGraph& g, uint32_t node, WS ws, bool prevExists, int32_t prevStartScore, uint64_t prevHP, uint64_t prevHN,
-	const uint64_t eq[4], NodeItem& out, WS* columns, int flatRows, uint32_t& status)
+	const Eq4& eq, NodeItem& out, WS* columns, int flatRows, uint32_t& status)
 {
 	int nodeLength = g.nodeLength[node];
 	NodeSeq seq = loadNodeSeq(g, node);
@@ -312,7 +313,7 @@ __device__ inline TileResult computeTile(const DGraph& g, uint32_t node, WS ws, 
 // reference: the per-edge part of calculateNodeInner, ...Common.h:903-964; edges coming from the previous slice
 // ("skipFirst") are merged as they are, edges from an in-neighbour are first stepped into the node's column 0.
 __device__ inline void pushEdge(const DGraph& g, Pending* pending, uint32_t& nPending, const ExtendConfig& cfg, uint32_t target, WS incoming, bool skipFirst,
-	const NodeItem* items, const SliceInfo& prevSlice, const uint64_t eq[4], uint32_t& status)
+	const NodeItem* items, const SliceInfo& prevSlice, const Eq4& eq, uint32_t& status)
 {
 	uint32_t slot = nPending;
 	for (uint32_t i = 0; i < nPending; i++)
@@ -349,7 +350,7 @@ __device__ inline void pushEdge(const DGraph& g, Pending* pending, uint32_t& nPe
 }
 
 // Recomputes all columns of (slice s, node) into sc.columns. reference: recalcNodeWordslice, ...Common.h:828-852
-__device__ inline void recomputeColumns(const DGraph& g, const LaneScratch& sc, uint32_t s, int itemIdx, const uint64_t eq[4], uint32_t& status, ExtCounters& cnt)
+__device__ inline void recomputeColumns(const DGraph& g, const LaneScratch& sc, uint32_t s, int itemIdx, const Eq4& eq, uint32_t& status, ExtCounters& cnt)
 {
 	const NodeItem& it = sc.items[itemIdx];
 	int prevIdx = findItem(sc.items, sc.slices[s - 1], it.node);
@@ -376,7 +377,7 @@ __device__ inline bool pushTrace(const LaneScratch& sc, const ExtendConfig& cfg,
 }
 
 // reference: pickBacktraceCorner, ...Common.h:710-804 (scoresNotValid is never set: unlimited cells per slice)
-__device__ inline bool backtraceCorner(const DGraph& g, const LaneScratch& sc, uint32_t s, uint32_t node, int itemIdx, const uint64_t eq[4], Cell& out, bool& nodeSwitch)
+__device__ inline bool backtraceCorner(const DGraph& g, const LaneScratch& sc, uint32_t s, uint32_t node, int itemIdx, const Eq4& eq, Cell& out, bool& nodeSwitch)
 {
 	const SliceInfo& cur = sc.slices[s];
 	const SliceInfo& prev = sc.slices[s - 1];
@@ -459,7 +460,7 @@ __device__ inline uint32_t extendSeed(const DGraph& g, const CorrectnessTables& 
 	}
 	uint32_t nItems = 1;
 	uint32_t nSlices = 1;
-	uint64_t eq[4];
+	Eq4 eq;
 	for (int slice = 0; slice < numSlices; slice++) {
 		const SliceInfo prev = sc.slices[nSlices - 1];
 		int j = prev.j + 64;

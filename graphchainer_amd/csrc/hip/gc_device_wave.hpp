@@ -175,7 +175,7 @@ __device__ __forceinline__ TraceCell unpackCell(unsigned long long w)
 // (node, slice) tile on a node that is new in this slice; same as computeTile but the previous-slice summary comes
 // in by value and columns (backtrace recompute) go to the LDS column view.
 __device__ inline TileResult computeTileW(const DGraph& g, uint32_t node, WS ws, bool prevExists, int32_t prevStartScore, uint64_t prevHP, uint64_t prevHN,
-	const uint64_t eq[4], NodeItem& out, const LaneLds* columns, int flatRows, uint32_t& status)
+	const Eq4& eq, NodeItem& out, const LaneLds* columns, int flatRows, uint32_t& status)
 {
 	int nodeLength = g.nodeLength[node];
 	NodeSeq seq = loadNodeSeq(g, node);
@@ -267,7 +267,7 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 	uint32_t nItems = 1, nSlices = 1;
 	int32_t prevMinScore = 0, prevBandwidth = 1, prevJ = -64;
 	double prevCorrect = ct.initCorrect, prevFalse = ct.initFalse;
-	uint64_t eq[4];
+	Eq4 eq;
 	for (int slice = 0; slice < numSlices; slice++) {
 		int j = prevJ + 64;
 		eqVector(seq, len, j, iupac, eq);
