@@ -189,7 +189,7 @@ struct gc_stream {
 	hipStream_t longStream = nullptr;
 	hipEvent_t longEv[2] {};
 	DeviceBuffer longSeeds, longJobs, longAlns, longResults, longScratch, longCells, longCursor, longJobsFallback, longResultsFallback, longScratchFallback;
-	DeviceBuffer longState, longWork, longWorkResults, longRoundTrace;
+	DeviceBuffer longState, longWork, longWorkResults, longRoundTrace, longCandSeed;
 	PinnedBuffer hLongSeeds, hLongJobs, hLongAlns, hLongResults, hLongSmall;
 	~gc_stream()
 	{
@@ -828,19 +828,28 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			if (n) HIP_CHECK(hipMemcpyAsync(dLongJobs, hJobs, n * sizeof(LongJob), hipMemcpyHostToDevice, ls));
 			// rounds: select -> extend -> merge until no read has a seed left to extend (see gc_kernels.hip, "K3-long in rounds")
 			LongState* dLongState = st->longState.reserve<LongState>(n);
-			LongWork* dLongWork = st->longWork.reserve<LongWork>(2 * n);
-			LongWorkResult* dLongWorkResults = st->longWorkResults.reserve<LongWorkResult>(2 * n);
+			const uint64_t workCapacity = 4 * n + 64;
+			LongWork* dLongWork = st->longWork.reserve<LongWork>(workCapacity);
+			LongWorkResult* dLongWorkResults = st->longWorkResults.reserve<LongWorkResult>(workCapacity);
+			uint32_t* dCandSeed = st->longCandSeed.reserve<uint32_t>(workCapacity);
 			uint64_t roundTraceBudget = 0;
 			for (uint64_t r = 0; r < n; r++) { uint64_t len = R->offsets[r + 1] - R->offsets[r]; roundTraceBudget += len + len / 2 + 1024; }
 			unsigned long long* dRoundTrace = st->longRoundTrace.reserve<unsigned long long>(roundTraceBudget);
 			// scratch for up to 2n work items in flight (one lane each), whatever the team size
-			dLongScratch = st->longScratch.reserve<unsigned long long>((2 * n + 64) * waveWords);
+			dLongScratch = st->longScratch.reserve<unsigned long long>((workCapacity + 64) * waveWords);
 			runLongRounds = [=]() {
 				launchLongInit(ls, dLongJobs, (uint32_t)n, dLongState);
 				double extendUs = 0;
+				uint32_t lastWork = 0xffffffffu;
 				for (int round = 0; round < 4096; round++) {
 					HIP_CHECK(hipMemsetAsync(dLongCursor + 1, 0, 2 * sizeof(unsigned long long), ls));   // [1] work count, [2] round trace cursor
-					launchLongSelect(ls, G->dev, dLongJobs, (uint32_t)n, dLongSeeds, R->totalBases, (uint32_t)P->min_cluster_size, dLongState, dLongAlns, dLongCells, dLongWork, dLongCursor + 1);
+					// tail rounds: once fewer than a quarter of the reads are still active the chip is mostly idle, so the
+					// remaining reads try several seeds per round (exact: k_long_merge re-checks them in order)
+					// (the number of work items stays below what round 0 had: active reads x candidates <= n)
+					uint32_t maxCand = 1;
+					if (round > 0 && lastWork > 0) maxCand = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (2 * n) / lastWork));
+					if (const char* env = getenv("GC_LONG_SPECULATE")) maxCand = (uint32_t)std::min(2, std::max(1, atoi(env)));   // test hook: speculate from round 0
+					launchLongSelect(ls, G->dev, dLongJobs, (uint32_t)n, dLongSeeds, R->totalBases, (uint32_t)P->min_cluster_size, maxCand, dLongState, dLongAlns, dLongCells, dLongWork, dCandSeed, dLongCursor + 1, workCapacity);
 					HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
 					HIP_CHECK(hipStreamSynchronize(ls));
 					uint32_t nWorkItems = (uint32_t)hLongSmall[1];
@@ -850,7 +859,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					HIP_CHECK(hipEventRecord(st->longEv[0], ls));
 					launchLongExtend(ls, G->dev, G->devTables, G->devIupac, lcfg, dLongWork, nWorkItems, R->devBases, dLongScratch, team, blocks, dRoundTrace, dLongCursor + 2, roundTraceBudget, dLongWorkResults, dLongCursor + 8);
 					HIP_CHECK(hipEventRecord(st->longEv[1], ls));
-					launchLongMerge(ls, G->dev, dLongJobs, dLongSeeds, dLongWork, dLongWorkResults, nWorkItems / 2, dRoundTrace, maxAlignments, dLongState, dLongAlns, dLongCells, dLongCursor, cellBudget);
+					launchLongMerge(ls, G->dev, dLongJobs, (uint32_t)n, dLongSeeds, dCandSeed, dLongWorkResults, dRoundTrace, maxAlignments, dLongState, dLongAlns, dLongCells, dLongCursor, cellBudget);
+					lastWork = nWorkItems;
 					HIP_CHECK(hipStreamSynchronize(ls));
 					float ms = 0;
 					HIP_CHECK(hipEventElapsedTime(&ms, st->longEv[0], st->longEv[1]));

@@ -760,51 +760,67 @@ __global__ void __launch_bounds__(256) k_long_init(const LongJob* __restrict__ j
 {
 	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= nReads) return;
-	LongState st { jobs[r].seedBegin, 0, 0, 0, 0, 0xffffffffu, 0, 0 };
+	LongState st { jobs[r].seedBegin, 0, 0, 0, 0, 0, 0, 0 };
 	state[r] = st;
 }
 
+// Skip rules of AlignOneWay for one seed against alignments [aFrom, aTo) of the read (:147-173).
+// Returns 0 extend, 1 skip, 2 the reference asserts.
+__device__ inline int seedSkipped(const DGraph& g, const LongSeed& sd, const LongAln* mine, uint32_t aFrom, uint32_t aTo, const LongCell* cellPool)
+{
+	for (uint32_t a = aFrom; a < aTo; a++)                          // sloppy overlap rule (:147-161)
+		if (mine[a].start <= sd.seqPos && mine[a].end >= sd.seqPos && mine[a].goodness > sd.goodness) return 1;
+	int32_t compareNode = g.nodeIDs[sd.node];
+	uint32_t compareOffset = g.nodeOffset[sd.node] + sd.offset;
+	for (uint32_t a = aFrom; a < aTo; a++) {                        // exactAlignmentPart (:163-173)
+		int on = onTrace(cellPool + mine[a].traceOff, mine[a].traceLen, sd.seqPos, compareNode, compareOffset);
+		if (on == 2) return 2;
+		if (on == 1) return 1;
+	}
+	return 0;
+}
+
+// One lane per read: advance to the next seed(s) that need extending and emit their work items. With
+// maxCandidates > 1 (used for the tail rounds, when few reads are still active and the chip is idle) further seeds are
+// emitted speculatively: they pass the skip rules against the alignments known now; k_long_merge re-checks each of
+// them against the alignments added before it in the same round, so the outcome equals one-seed-per-round.
+#define LONG_MAX_CANDIDATES 8
 __global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __restrict__ jobs, uint32_t nReads, const LongSeed* __restrict__ seeds, uint64_t rcBase, uint32_t minClusterSize,
-	LongState* __restrict__ state, const LongAln* __restrict__ alns, const LongCell* __restrict__ cellPool, LongWork* __restrict__ work, unsigned long long* __restrict__ workCount)
+	uint32_t maxCandidates, LongState* __restrict__ state, const LongAln* __restrict__ alns, const LongCell* __restrict__ cellPool, LongWork* __restrict__ work, uint32_t* __restrict__ candSeed,
+	unsigned long long* __restrict__ workCount, uint64_t workCapacity)
 {
 	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= nReads) return;
 	LongState st = state[r];
-	if (st.status != 0) return;
+	st.candCount = 0;
+	if (st.status != 0) { state[r] = st; return; }
 	LongJob job = jobs[r];
 	const LongAln* mine = alns + job.alnBegin;
-	bool have = false;
-	LongSeed sd {};
+	uint32_t cand[LONG_MAX_CANDIDATES];
+	uint32_t nCand = 0;
 	uint32_t si = st.si;
-	for (; st.status == 0 && si < job.seedEnd && !have; si++) {
-		sd = seeds[si];
+	for (; st.status == 0 && si < job.seedEnd && nCand < maxCandidates; si++) {
+		LongSeed sd = seeds[si];
 		if (sd.goodness < st.e2eScore) { si = job.seedEnd; break; }   // aligned end to end (:127-131)
 		if (sd.clusterSize < minClusterSize) continue;                 // :141-146
-		bool skip = false;
-		for (uint32_t a = 0; a < st.nAln; a++)                           // sloppy overlap rule (:147-161)
-			if (mine[a].start <= sd.seqPos && mine[a].end >= sd.seqPos && mine[a].goodness > sd.goodness) { skip = true; break; }
-		if (skip) continue;
-		int32_t compareNode = g.nodeIDs[sd.node];
-		uint32_t compareOffset = g.nodeOffset[sd.node] + sd.offset;
-		for (uint32_t a = 0; a < st.nAln && !skip; a++) {               // exactAlignmentPart (:163-173)
-			int on = onTrace(cellPool + mine[a].traceOff, mine[a].traceLen, sd.seqPos, compareNode, compareOffset);
-			if (on == 2) { st.status = 1; break; }
-			if (on == 1) skip = true;
-		}
-		if (skip || st.status) continue;
-		have = true;
+		int sk = seedSkipped(g, sd, mine, 0, st.nAln, cellPool);
+		if (sk == 2) { st.status = 1; break; }
+		if (sk == 1) continue;
+		cand[nCand++] = si;
 	}
 	st.si = si;
-	st.curSeed = 0xffffffffu;
-	if (have) {
-		st.extended++;
-		st.curSeed = si - 1;
-		unsigned long long at = atomicAdd(workCount, 2ull);
-		const uint32_t L = job.readLen, p = sd.seqPos;
-		LongWork b { rcBase + job.readOff + (uint64_t)(L - p), p, sd.twinNode, sd.twinOffset, r };
-		LongWork f { job.readOff + (uint64_t)(p + 1), L - 1 - p, sd.node, sd.offset, r };
-		work[at] = b;
-		work[at + 1] = f;
+	if (nCand > 0) {
+		unsigned long long at = atomicAdd(workCount, 2ull * nCand);
+		if (at + 2ull * nCand > workCapacity) { st.status = 2; nCand = 0; }
+		st.candBegin = (uint32_t)(at / 2);
+		st.candCount = nCand;
+		for (uint32_t c = 0; c < nCand; c++) {
+			LongSeed sd = seeds[cand[c]];
+			const uint32_t L = job.readLen, p = sd.seqPos;
+			work[at + 2 * c] = LongWork { rcBase + job.readOff + (uint64_t)(L - p), p, sd.twinNode, sd.twinOffset, r };
+			work[at + 2 * c + 1] = LongWork { job.readOff + (uint64_t)(p + 1), L - 1 - p, sd.node, sd.offset, r };
+			candSeed[at / 2 + c] = cand[c];
+		}
 	}
 	state[r] = st;
 }
@@ -855,73 +871,79 @@ __global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessT
 	}
 }
 
-__global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __restrict__ jobs, const LongSeed* __restrict__ seeds, const LongWork* __restrict__ work,
-	const LongWorkResult* __restrict__ results, uint32_t nPairs, const unsigned long long* __restrict__ tracePool, uint32_t maxAlignments,
+__global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __restrict__ jobs, uint32_t nReads, const LongSeed* __restrict__ seeds, const uint32_t* __restrict__ candSeed,
+	const LongWorkResult* __restrict__ results, const unsigned long long* __restrict__ tracePool, uint32_t maxAlignments,
 	LongState* __restrict__ state, LongAln* __restrict__ alns, LongCell* __restrict__ cellPool, unsigned long long* __restrict__ cellCursor, uint64_t cellCapacity)
 {
-	uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
-	if (pair >= nPairs) return;
-	const LongWork wb = work[2 * pair], wf = work[2 * pair + 1];
-	const LongWorkResult rb = results[2 * pair], rf = results[2 * pair + 1];
-	const uint32_t r = wb.read;
+	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= nReads) return;
 	LongState st = state[r];
+	if (st.candCount == 0 || st.status != 0) return;
 	LongJob job = jobs[r];
-	LongSeed sd = seeds[st.curSeed];
 	LongAln* mine = alns + job.alnBegin;
-	const int p = (int)sd.seqPos;
 	const int L = (int)job.readLen;
-	bool runB = p > 0, runF = p < L - 1;
-	uint32_t stB = runB ? rb.status : EXT_FAILED, stF = runF ? rf.status : EXT_FAILED;
-	if (stB == EXT_ASSERT || stF == EXT_ASSERT) st.status = 1;          // getAlignmentFromSeed threw
-	else if (stB == EXT_OVERFLOW || stF == EXT_OVERFLOW) st.status = 2;
-	else if (stB == EXT_LDS_CAP || stF == EXT_LDS_CAP) st.status = 5;
-	else {
-		bool hasB = stB == EXT_OK, hasF = stF == EXT_OK;
-		if (hasB || hasF) {
-			uint32_t nB = rb.traceLen, nF = rf.traceLen;
-			uint32_t useB = hasB ? (hasF ? nB - 1 : nB) : 0;
-			uint32_t total = useB + (hasF ? nF : 0);
-			if (st.nAln >= maxAlignments) st.status = 3;
-			else {
-				unsigned long long base = atomicAdd(cellCursor, (unsigned long long)total);
-				if (base + total > cellCapacity) st.status = 4;
-				else {
-					LongCell* outCells = cellPool + base;
-					for (uint32_t i = 0; i < useB; i++) {   // fixReverseTraceSeqPosAndOrder (:543-565)
-						TraceCell c = unpackCell(tracePool[rb.traceOff + i]);
-						uint32_t off = c.offsetAndSwitch & 255u;
-						int32_t id = g.nodeIDs[c.node];
-						uint32_t orig = g.nodeOffset[c.node] + off;
-						LongCell oc;
-						oc.node = id ^ 1;
-						oc.offset = g.origSize[id] - 1 - orig;
-						oc.seqPos = (uint32_t)(p - 1 - c.seqPos);
-						oc.nodeSwitch = (i + 1 < nB) ? ((unpackCell(tracePool[rb.traceOff + i + 1]).offsetAndSwitch >> 8) & 1u) : 0u;
-						outCells[i] = oc;
-					}
-					if (hasF) for (uint32_t i = 0; i < nF; i++) {   // fixForwardTraceSeqPos (:527-540), device order reversed
-						TraceCell c = unpackCell(tracePool[rf.traceOff + (nF - 1 - i)]);
-						LongCell oc;
-						oc.node = g.nodeIDs[c.node];
-						oc.offset = g.nodeOffset[c.node] + (c.offsetAndSwitch & 255u);
-						oc.seqPos = (uint32_t)(p + 1 + c.seqPos);
-						oc.nodeSwitch = (c.offsetAndSwitch >> 8) & 1u;
-						outCells[useB + i] = oc;
-					}
-					LongAln al;
-					al.start = outCells[0].seqPos;
-					al.end = outCells[total - 1].seqPos + 1;
-					al.score = (uint32_t)((hasB ? rb.score : 0) + (hasF ? rf.score : 0));
-					al.goodness = sd.goodness;
-					al.traceOff = base;
-					al.traceLen = total;
-					al.pad = 0;
-					mine[st.nAln++] = al;
-					st.e2eScore = endToEndScore(mine, st.nAln, (uint32_t)L, st.e2eScore);
-				}
-			}
+	const uint32_t nAlnAtSelect = st.nAln;
+	for (uint32_t c = 0; c < st.candCount && st.status == 0; c++) {
+		const uint32_t pair = st.candBegin + c;
+		const uint32_t seedIdx = candSeed[pair];
+		LongSeed sd = seeds[seedIdx];
+		if (c > 0) {
+			// re-check against what this round added before this candidate (the select kernel checked the older alignments)
+			if (sd.goodness < st.e2eScore) { st.si = job.seedEnd; break; }
+			int sk = seedSkipped(g, sd, mine, nAlnAtSelect, st.nAln, cellPool);
+			if (sk == 2) { st.status = 1; break; }
+			if (sk == 1) continue;
 		}
+		st.extended++;
+		const LongWorkResult rb = results[2 * pair], rf = results[2 * pair + 1];
+		const int p = (int)sd.seqPos;
+		bool runB = p > 0, runF = p < L - 1;
+		uint32_t stB = runB ? rb.status : EXT_FAILED, stF = runF ? rf.status : EXT_FAILED;
+		if (stB == EXT_ASSERT || stF == EXT_ASSERT) { st.status = 1; break; }          // getAlignmentFromSeed threw
+		if (stB == EXT_OVERFLOW || stF == EXT_OVERFLOW) { st.status = 2; break; }
+		if (stB == EXT_LDS_CAP || stF == EXT_LDS_CAP) { st.status = 5; break; }
+		bool hasB = stB == EXT_OK, hasF = stF == EXT_OK;
+		if (!hasB && !hasF) continue;   // alignmentFailed()
+		uint32_t nB = rb.traceLen, nF = rf.traceLen;
+		uint32_t useB = hasB ? (hasF ? nB - 1 : nB) : 0;
+		uint32_t total = useB + (hasF ? nF : 0);
+		if (st.nAln >= maxAlignments) { st.status = 3; break; }
+		unsigned long long base = atomicAdd(cellCursor, (unsigned long long)total);
+		if (base + total > cellCapacity) { st.status = 4; break; }
+		LongCell* outCells = cellPool + base;
+		for (uint32_t i = 0; i < useB; i++) {   // fixReverseTraceSeqPosAndOrder (:543-565)
+			TraceCell tc = unpackCell(tracePool[rb.traceOff + i]);
+			uint32_t off = tc.offsetAndSwitch & 255u;
+			int32_t id = g.nodeIDs[tc.node];
+			uint32_t orig = g.nodeOffset[tc.node] + off;
+			LongCell oc;
+			oc.node = id ^ 1;
+			oc.offset = g.origSize[id] - 1 - orig;
+			oc.seqPos = (uint32_t)(p - 1 - tc.seqPos);
+			oc.nodeSwitch = (i + 1 < nB) ? ((unpackCell(tracePool[rb.traceOff + i + 1]).offsetAndSwitch >> 8) & 1u) : 0u;
+			outCells[i] = oc;
+		}
+		if (hasF) for (uint32_t i = 0; i < nF; i++) {   // fixForwardTraceSeqPos (:527-540), device order reversed
+			TraceCell tc = unpackCell(tracePool[rf.traceOff + (nF - 1 - i)]);
+			LongCell oc;
+			oc.node = g.nodeIDs[tc.node];
+			oc.offset = g.nodeOffset[tc.node] + (tc.offsetAndSwitch & 255u);
+			oc.seqPos = (uint32_t)(p + 1 + tc.seqPos);
+			oc.nodeSwitch = (tc.offsetAndSwitch >> 8) & 1u;
+			outCells[useB + i] = oc;
+		}
+		LongAln al;
+		al.start = outCells[0].seqPos;
+		al.end = outCells[total - 1].seqPos + 1;
+		al.score = (uint32_t)((hasB ? rb.score : 0) + (hasF ? rf.score : 0));
+		al.goodness = sd.goodness;
+		al.traceOff = base;
+		al.traceLen = total;
+		al.pad = 0;
+		mine[st.nAln++] = al;
+		st.e2eScore = endToEndScore(mine, st.nAln, (uint32_t)L, st.e2eScore);
 	}
+	st.candCount = 0;
 	state[r] = st;
 }
 
@@ -1008,17 +1030,19 @@ void launchLongInit(hipStream_t stream, const LongJob* jobs, uint32_t nReads, Lo
 {
 	if (nReads) hipLaunchKernelGGL(k_long_init, dim3((nReads + 255) / 256), dim3(256), 0, stream, jobs, nReads, state);
 }
-void launchLongSelect(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, uint64_t rcBase, uint32_t minClusterSize,
-	LongState* state, const LongAln* alns, const LongCell* cellPool, LongWork* work, unsigned long long* workCount)
+void launchLongSelect(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, uint64_t rcBase, uint32_t minClusterSize, uint32_t maxCandidates,
+	LongState* state, const LongAln* alns, const LongCell* cellPool, LongWork* work, uint32_t* candSeed, unsigned long long* workCount, uint64_t workCapacity)
 {
-	if (nReads) hipLaunchKernelGGL(k_long_select, dim3((nReads + 63) / 64), dim3(64), 0, stream, g, jobs, nReads, seeds, rcBase, minClusterSize, state, alns, cellPool, work, workCount);
+	if (maxCandidates < 1) maxCandidates = 1;
+	if (maxCandidates > LONG_MAX_CANDIDATES) maxCandidates = LONG_MAX_CANDIDATES;
+	if (nReads) hipLaunchKernelGGL(k_long_select, dim3((nReads + 63) / 64), dim3(64), 0, stream, g, jobs, nReads, seeds, rcBase, minClusterSize, maxCandidates, state, alns, cellPool, work, candSeed, workCount, workCapacity);
 }
 uint32_t longExtendTeamSize(uint32_t nWork)
 {
 	// smallest team that still fits the work into about 2048 resident waves
 	if (const char* env = getenv("GC_LONG_TEAM")) { int v = atoi(env); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return (uint32_t)v; }
 	const uint32_t targetWaves = 2048;
-	for (uint32_t lanes : { 8u, 16u, 32u }) if ((nWork + lanes - 1) / lanes <= targetWaves) return lanes;
+	for (uint32_t lanes : { 4u, 8u, 16u, 32u }) if ((nWork + lanes - 1) / lanes <= targetWaves) return lanes;
 	return 64;
 }
 
@@ -1037,10 +1061,10 @@ void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTabl
 	}
 #undef GC_LAUNCH_TEAM
 }
-void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, const LongSeed* seeds, const LongWork* work, const LongWorkResult* results, uint32_t nPairs,
+void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, const uint32_t* candSeed, const LongWorkResult* results,
 	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity)
 {
-	if (nPairs) hipLaunchKernelGGL(k_long_merge, dim3((nPairs + 63) / 64), dim3(64), 0, stream, g, jobs, seeds, work, results, nPairs, tracePool, maxAlignments, state, alns, cellPool, cellCursor, cellCapacity);
+	if (nReads) hipLaunchKernelGGL(k_long_merge, dim3((nReads + 63) / 64), dim3(64), 0, stream, g, jobs, nReads, seeds, candSeed, results, tracePool, maxAlignments, state, alns, cellPool, cellCursor, cellCapacity);
 }
 void launchLongFinish(hipStream_t stream, uint32_t nReads, const LongState* state, LongReadResult* results)
 {

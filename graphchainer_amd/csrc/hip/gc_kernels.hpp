@@ -97,7 +97,7 @@ struct LongAln {     // one accepted alignment, in acceptance order
 struct LongReadResult { uint32_t nAlignments, seedsExtended, status, pad; };
 
 // round-based whole-read pass: per-read state carried between rounds, and the per-round work items
-struct LongState { uint32_t si, nAln, extended, status, e2eScore, curSeed, pad0, pad1; };
+struct LongState { uint32_t si, nAln, extended, status, e2eScore, candBegin, candCount, pad1; };   // candBegin/candCount: this round's candidate seeds (pairs of work items)
 struct LongWork {    // one direction of one seed extension
 	uint64_t seqOff;
 	uint32_t seqLen, node, offset;
@@ -130,12 +130,12 @@ void launchLongPass(hipStream_t stream, const DGraph& g, const CorrectnessTables
 uint64_t longSlabBytes(const ExtendConfig& cfg);
 uint64_t longWaveWordsPerLane(const ExtendConfig& cfg);
 void launchLongInit(hipStream_t stream, const LongJob* jobs, uint32_t nReads, LongState* state);
-void launchLongSelect(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, uint64_t rcBase, uint32_t minClusterSize,
-	LongState* state, const LongAln* alns, const LongCell* cellPool, LongWork* work, unsigned long long* workCount);
+void launchLongSelect(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, uint64_t rcBase, uint32_t minClusterSize, uint32_t maxCandidates,
+	LongState* state, const LongAln* alns, const LongCell* cellPool, LongWork* work, uint32_t* candSeed, unsigned long long* workCount, uint64_t workCapacity);
 uint32_t longExtendTeamSize(uint32_t nWork);
 void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg, const LongWork* work, uint32_t nWork, const char* bases,
 	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters);
-void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, const LongSeed* seeds, const LongWork* work, const LongWorkResult* results, uint32_t nPairs,
+void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, const uint32_t* candSeed, const LongWorkResult* results,
 	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity);
 void launchLongFinish(hipStream_t stream, uint32_t nReads, const LongState* state, LongReadResult* results);
 void launchLongPassWave(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg, const LongJob* jobs, uint32_t nReads,

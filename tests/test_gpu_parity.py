@@ -131,3 +131,16 @@ def test_whole_read_pass_plain_layout_fallback(gca, tmp_path, monkeypatch):
     got, want = run_case(gca, gfa, reads, long_pass=True)
     compare(got, want, COMPARE_KEYS + LONG_KEYS)
     assert int(got["counters_long"][7]) == len(reads)
+
+
+def test_whole_read_pass_speculative_rounds(gca, tmp_path, monkeypatch):
+    """Tail rounds extend several seeds of a read at once and re-check them in order; force that from round 0."""
+    from graphchainer_amd.synth import SynthGraph
+    monkeypatch.setenv("GC_LONG_SPECULATE", "2")
+    sg = SynthGraph(100_000, seed=12)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(10, 6000, seed=6)
+    reads.append(reads[2][:2500] + reads[5][1000:4000])
+    got, want = run_case(gca, gfa, reads, long_pass=True)
+    compare(got, want, COMPARE_KEYS + LONG_KEYS)
