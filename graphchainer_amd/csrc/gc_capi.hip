@@ -833,7 +833,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			LongWorkResult* dLongWorkResults = st->longWorkResults.reserve<LongWorkResult>(workCapacity);
 			uint32_t* dCandSeed = st->longCandSeed.reserve<uint32_t>(workCapacity);
 			uint64_t roundTraceBudget = 0;
-			for (uint64_t r = 0; r < n; r++) { uint64_t len = R->offsets[r + 1] - R->offsets[r]; roundTraceBudget += len + len / 2 + 1024; }
+			for (uint64_t r = 0; r < n; r++) { uint64_t len = R->offsets[r + 1] - R->offsets[r]; roundTraceBudget += 2 * (len + len / 2 + 1024); }   // up to two candidate seeds' worth per read (adaptive rounds never exceed one on average)
 			unsigned long long* dRoundTrace = st->longRoundTrace.reserve<unsigned long long>(roundTraceBudget);
 			// scratch for up to 2n work items in flight (one lane each), whatever the team size
 			dLongScratch = st->longScratch.reserve<unsigned long long>((workCapacity + 64) * waveWords);
