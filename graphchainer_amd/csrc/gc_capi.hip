@@ -177,7 +177,11 @@ struct gc_reads {
 	std::vector<uint8_t> invalid;    // read has a character outside the IUPAC alphabet (the reference's Complement() asserts)
 	char* devBases = nullptr;        // [2*totalBases]: all reads forward, then every read reverse-complemented in place
 	uint64_t* devOffsets = nullptr;
-	~gc_reads() { if (devBases) (void)hipFree(devBases); if (devOffsets) (void)hipFree(devOffsets); }
+	// per read: match-mask bit vectors [strand fwd/rc][A,C,G,T][words] (bit i set: read position i matches that base)
+	uint64_t* devMasks = nullptr;
+	std::vector<uint64_t> maskOff;   // [n] word offset of read r's masks
+	std::vector<uint32_t> maskWords; // [n] words per bit vector
+	~gc_reads() { if (devBases) (void)hipFree(devBases); if (devOffsets) (void)hipFree(devOffsets); if (devMasks) (void)hipFree(devMasks); }
 };
 
 struct gc_stream {
@@ -615,6 +619,29 @@ int gc_reads_upload(const char* bases, const uint64_t* offsets, uint64_t n, gc_r
 				both[R->totalBases + a + (b - 1 - i)] = rc;
 			}
 		}
+		// match-mask bit vectors of both strands
+		R->maskOff.assign(n, 0);
+		R->maskWords.assign(n, 0);
+		uint64_t totalWords = 0;
+		for (uint64_t r = 0; r < n; r++) { R->maskOff[r] = totalWords; R->maskWords[r] = (uint32_t)((offsets[r + 1] - offsets[r] + 63) / 64 + 1); totalWords += 8ull * R->maskWords[r]; }
+		std::vector<uint64_t> masks(totalWords, 0);
+		for (uint64_t r = 0; r < n; r++) {
+			uint64_t a = offsets[r], len = offsets[r + 1] - a, words = R->maskWords[r];
+			for (int strand = 0; strand < 2; strand++) {
+				const char* sq = both.data() + (strand ? R->totalBases : 0) + a;
+				uint64_t* m = masks.data() + R->maskOff[r] + (uint64_t)strand * 4 * words;
+				for (uint64_t i = 0; i < len; i++) {
+					uint8_t set = iupac[(uint8_t)sq[i]];
+					uint64_t bit = 1ull << (i & 63);
+					if (set & 1) m[i >> 6] |= bit;
+					if (set & 2) m[words + (i >> 6)] |= bit;
+					if (set & 4) m[2 * words + (i >> 6)] |= bit;
+					if (set & 8) m[3 * words + (i >> 6)] |= bit;
+				}
+			}
+		}
+		HIP_CHECK(hipMalloc((void**)&R->devMasks, std::max<size_t>(masks.size(), 1) * sizeof(uint64_t)));
+		if (!masks.empty()) HIP_CHECK(hipMemcpy(R->devMasks, masks.data(), masks.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
 		HIP_CHECK(hipMalloc((void**)&R->devBases, std::max<size_t>(both.size(), 1)));
 		if (!both.empty()) HIP_CHECK(hipMemcpy(R->devBases, both.data(), both.size(), hipMemcpyHostToDevice));
 		HIP_CHECK(hipMalloc((void**)&R->devOffsets, (n + 1) * sizeof(uint64_t)));
@@ -797,6 +824,9 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					hSeeds[at++] = LongSeed { s.node, s.offset, (uint32_t)twin, (uint32_t)(rev.second - hg.nodeOffset[twin]), s.seqPos, s.goodness, s.clusterSize, 0 };
 				}
 				LongJob& j = hJobs[r];
+				j.maskOff = R->maskOff[r];
+				j.maskWords = R->maskWords[r];
+				j.pad = 0;
 				j.readOff = R->offsets[r];
 				j.readLen = (uint32_t)(R->offsets[r + 1] - R->offsets[r]);
 				j.seedBegin = (uint32_t)gl.longSeedBegin;
@@ -810,7 +840,6 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			lcfg.maxPending = 96;
 			lcfg.maxTrace = (uint32_t)(maxReadLen + maxReadLen / 2 + 512);
 			if (const char* env = getenv("GC_LONG_MAX_ITEMS")) lcfg.maxItems = (uint32_t)std::max(64, atoi(env));
-			uint32_t waveBlocks = (uint32_t)((n + 63) / 64);
 			uint64_t waveWords = longWaveWordsPerLane(lcfg);
 			LongSeed* dLongSeeds = st->longSeeds.reserve<LongSeed>(nLongSeeds);
 			LongJob* dLongJobs = st->longJobs.reserve<LongJob>(n);
@@ -818,12 +847,12 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			LongReadResult* dLongResults = st->longResults.reserve<LongReadResult>(n);
 			unsigned long long* dLongScratch = nullptr;
 			dLongCells = st->longCells.reserve<LongCell>(cellBudget);
-			unsigned long long* dLongCursor = st->longCursor.reserve<unsigned long long>(16);
+			unsigned long long* dLongCursor = st->longCursor.reserve<unsigned long long>(32);
 			hLongAlns = st->hLongAlns.reserve<LongAln>(n * maxAlignments);
 			hLongResults = st->hLongResults.reserve<LongReadResult>(n);
-			hLongSmall = st->hLongSmall.reserve<unsigned long long>(16);
+			hLongSmall = st->hLongSmall.reserve<unsigned long long>(32);
 			hipStream_t ls = st->longStream;
-			HIP_CHECK(hipMemsetAsync(dLongCursor, 0, 16 * sizeof(unsigned long long), ls));
+			HIP_CHECK(hipMemsetAsync(dLongCursor, 0, 32 * sizeof(unsigned long long), ls));
 			if (nLongSeeds) HIP_CHECK(hipMemcpyAsync(dLongSeeds, hSeeds, nLongSeeds * sizeof(LongSeed), hipMemcpyHostToDevice, ls));
 			if (n) HIP_CHECK(hipMemcpyAsync(dLongJobs, hJobs, n * sizeof(LongJob), hipMemcpyHostToDevice, ls));
 			// rounds: select -> extend -> merge until no read has a seed left to extend (see gc_kernels.hip, "K3-long in rounds")
@@ -850,14 +879,14 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					if (round > 0 && lastWork > 0) maxCand = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (2 * n) / lastWork));
 					if (const char* env = getenv("GC_LONG_SPECULATE")) maxCand = (uint32_t)std::min(2, std::max(1, atoi(env)));   // test hook: speculate from round 0
 					launchLongSelect(ls, G->dev, dLongJobs, (uint32_t)n, dLongSeeds, R->totalBases, (uint32_t)P->min_cluster_size, maxCand, dLongState, dLongAlns, dLongCells, dLongWork, dCandSeed, dLongCursor + 1, workCapacity);
-					HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
+					HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
 					HIP_CHECK(hipStreamSynchronize(ls));
 					uint32_t nWorkItems = (uint32_t)hLongSmall[1];
 					if (nWorkItems == 0) break;
 					uint32_t team = longExtendTeamSize(nWorkItems);
 					uint32_t blocks = (nWorkItems + team - 1) / team;
 					HIP_CHECK(hipEventRecord(st->longEv[0], ls));
-					launchLongExtend(ls, G->dev, G->devTables, G->devIupac, lcfg, dLongWork, nWorkItems, R->devBases, dLongScratch, team, blocks, dRoundTrace, dLongCursor + 2, roundTraceBudget, dLongWorkResults, dLongCursor + 8);
+					launchLongExtend(ls, G->dev, G->devTables, R->devMasks, lcfg, dLongWork, nWorkItems, dLongScratch, team, blocks, dRoundTrace, dLongCursor + 2, roundTraceBudget, dLongWorkResults, dLongCursor + 8);
 					HIP_CHECK(hipEventRecord(st->longEv[1], ls));
 					launchLongMerge(ls, G->dev, dLongJobs, (uint32_t)n, dLongSeeds, dCandSeed, dLongWorkResults, dRoundTrace, maxAlignments, dLongState, dLongAlns, dLongCells, dLongCursor, cellBudget);
 					lastWork = nWorkItems;
@@ -894,7 +923,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					for (size_t i = 0; i < redo.size(); i++) hLongResults[redo[i]] = subResults[i];
 				}
 				if (n) HIP_CHECK(hipMemcpyAsync(hLongAlns, dLongAlns, n * maxAlignments * sizeof(LongAln), hipMemcpyDeviceToHost, ls));
-				HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
+				HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
 				HIP_CHECK(hipStreamSynchronize(ls));
 				return (uint64_t)redo.size();
 			};
@@ -989,6 +1018,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			uint64_t rerun = longFallback();
 			res->counters_long[7] = rerun;   // reads that needed the plain-layout fallback kernel
 			for (int i = 0; i < 6; i++) res->counters_long[i] = hLongSmall[8 + i];   // same units as counters[]
+			if (getenv("GC_DEBUG_STAMPS")) fprintf(stderr, "[gc stamps] long extend lane-cycles: slices %llu backtrace %llu | inside slices: columns %llu push %llu\n", hLongSmall[16], hLongSmall[17], hLongSmall[18], hLongSmall[19]);
 			for (uint64_t r = 0; r < n; r++) {
 				if (hLongResults[r].status == 2) throw std::runtime_error("whole-read pass: extension scratch overflow (raise GC_LONG_MAX_ITEMS)");
 				if (hLongResults[r].status == 3) throw std::runtime_error("whole-read pass: more than 32 alignments for one read");

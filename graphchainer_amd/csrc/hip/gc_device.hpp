@@ -185,7 +185,7 @@ struct LaneScratch {
 	TraceCell* trace;
 };
 
-struct ExtCounters { unsigned long long dpTiles, recomputeTiles, columnSteps, traceItems, extensions, backtraceTiles; };
+struct ExtCounters { unsigned long long dpTiles, recomputeTiles, columnSteps, traceItems, extensions, backtraceTiles; unsigned long long cycSlices, cycBacktrace, cycColumns, cycPush; };
 
 // 4 match masks (A,C,G,T) of read rows j..j+63. reference: ...Common.h:280-319. iupac[c] = set of bases c matches.
 // Four named members, never an array: an array indexed by the node's 2-bit base code ends up in scratch (or LDS),
@@ -205,6 +205,31 @@ __device__ inline void eqVector(const char* seq, int len, int j, const uint8_t* 
 		t |= (m & 8) ? bit : 0ull;
 	}
 	eq.a = a; eq.c = c; eq.g = g; eq.t = t;
+}
+
+// Match masks from per-read precomputed bit vectors: for each strand of each read four bit vectors (A,C,G,T) say which
+// bases a read position matches; the 64 rows of a slice are a 64-bit window of them (two words + a funnel shift)
+// instead of 64 dependent byte loads per slice.
+struct EqSource {
+	const uint64_t* masks;   // [4][words] for this read and strand
+	uint32_t words;          // words per bit vector
+	uint32_t startBit;       // read position of the extension's row 0
+};
+__device__ inline void eqVectorBits(const EqSource& src, int len, int j, Eq4& eq)
+{
+	int n = len - j;
+	if (n > 64) n = 64;
+	uint32_t bit = src.startBit + (uint32_t)j;
+	uint32_t w = bit >> 6, sh = bit & 63;
+	uint64_t keep = n >= 64 ? ~0ull : ((1ull << n) - 1);
+	uint64_t out[4];
+	for (int b = 0; b < 4; b++) {
+		const uint64_t* v = src.masks + (size_t)b * src.words;
+		uint64_t lo = v[w] >> sh;
+		uint64_t hi = (sh != 0 && w + 1 < src.words) ? (v[w + 1] << (64 - sh)) : 0ull;
+		out[b] = (lo | hi) & keep;
+	}
+	eq.a = out[0]; eq.c = out[1]; eq.g = out[2]; eq.t = out[3];
 }
 
 struct NodeSeq { uint64_t w0, w1, w2, w3; bool ambiguous; };

@@ -233,8 +233,8 @@ __device__ inline TileResult computeTileW(const DGraph& g, uint32_t node, WS ws,
 
 
 // Full seed extension, wave layout. Trace goes to trace region `which` of the wave scratch (start cell first).
-__device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTables& ct, const uint8_t* iupac, int bandwidthCfg, lds_u32* lds, const WaveScratch& wsx,
-	const char* seq, int len, uint32_t startNode, uint32_t startOffset, uint32_t which, uint32_t& nTrace, int32_t& score, ExtCounters& cnt)
+__device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTables& ct, const EqSource& eqSrc, int bandwidthCfg, lds_u32* lds, const WaveScratch& wsx,
+	int len, uint32_t startNode, uint32_t startOffset, uint32_t which, uint32_t& nTrace, int32_t& score, ExtCounters& cnt)
 {
 	const LaneLds L { lds, wsx.lane, wsx.lanes, wsx.spillBase() };
 	uint32_t status = EXT_OK;
@@ -265,12 +265,13 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 		storeSlice(wsx, 0, s0);
 	}
 	uint32_t nItems = 1, nSlices = 1;
+	const unsigned long long tSlices0 = clock64();
 	int32_t prevMinScore = 0, prevBandwidth = 1, prevJ = -64;
 	double prevCorrect = ct.initCorrect, prevFalse = ct.initFalse;
 	Eq4 eq;
 	for (int slice = 0; slice < numSlices; slice++) {
 		int j = prevJ + 64;
-		eqVector(seq, len, j, iupac, eq);
+		eqVectorBits(eqSrc, len, j, eq);
 		int32_t previousQuitScore = prevMinScore + prevBandwidth;
 		int bandwidth = bandwidthCfg;
 		int flatRows = (j + 64 > len) ? (len - j) : 0;
@@ -333,7 +334,9 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 			NodeItem out;
 			LaneLds::Entry pe { 0, 0, 0, ~0ull, 0ull };
 			if (prevExists) pe = L.get((uint32_t)buf, (uint32_t)pi);
+			const unsigned long long tCol0 = clock64();
 			TileResult tr = computeTileW(g, pnode, pws, prevExists, (int32_t)pe.w1, pe.a, pe.b, eq, out, nullptr, flatRows, status);
+			cnt.cycColumns += clock64() - tCol0;
 			if (status != EXT_OK) return status;
 			out.minScore = tr.minScore;
 			storeItem(wsx, nItems, out);
@@ -351,10 +354,12 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 			int32_t newEndMin = wsColumnMin(newEnd);
 			if (newEndMin < prevMinScore) return EXT_ASSERT;
 			if (newEndMin <= currentMin + bandwidth) {
+				const unsigned long long tPush0 = clock64();
 				for (uint32_t e = g.outOff[pnode]; e < g.outOff[pnode + 1]; e++) {
 					pushEdge(g.outAdj[e], newEnd, false);
 					if (status != EXT_OK) return status;
 				}
+				cnt.cycPush += clock64() - tPush0;
 			}
 		}
 		if (cur.count == 0) return EXT_ASSERT;
@@ -378,6 +383,8 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 		nPrev = cur.count;
 		buf = cb;
 	}
+	cnt.cycSlices += clock64() - tSlices0;
+	const unsigned long long tBack0 = clock64();
 	// removeWronglyAlignedEnd
 	{
 		bool currentlyCorrect = (loadSlice(wsx, nSlices - 1).flags & 1u) != 0;
@@ -404,6 +411,23 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 	if (!pushTraceW(here, false)) return status;
 	uint32_t curSliceIdx = 0xffffffffu, curNode = 0xffffffffu;
 	WSlice cs = last, ps = last;
+	// Node ids of the current and the previous slice, cached in the lane's LDS words behind the 64 columns: item lookups
+	// ("is this in-neighbour in the band of slice s / s-1?") are the backtrace's most frequent question, and answering
+	// them with a chain of dependent HBM loads per probe dominated the kernel. Slices with more than 64 nodes fall back
+	// to the HBM scan.
+	const uint32_t ID_CACHE = 64, idsCurBase = 64 * 5, idsPrevBase = 64 * 5 + ID_CACHE;
+	static_assert(64 * 5 + 2 * 64 <= WAVE_WORDS, "id caches must fit behind the backtrace columns");
+	auto fillIds = [&](const WSlice& sl, uint32_t base) {
+		uint32_t n = sl.count < ID_CACHE ? sl.count : ID_CACHE;
+		for (uint32_t i = 0; i < n; i++) L.stL(base + i, itemNode(wsx, sl.first + i));
+	};
+	auto findIn = [&](const WSlice& sl, uint32_t base, uint32_t node) -> int {
+		if (sl.count > ID_CACHE) return findItemW(wsx, sl, node);
+		for (uint32_t i = 0; i < sl.count; i++) if (L.ldL(base + i) == node) return (int)(sl.first + i);
+		return -1;
+	};
+	auto findCur = [&](uint32_t node) -> int { return findIn(cs, idsCurBase, node); };
+	auto findPrev = [&](uint32_t node) -> int { return findIn(ps, idsPrevBase, node); };
 	NodeItem curIt {};
 	NodeItem prevIt {};
 	bool prevItExists = false;
@@ -421,9 +445,9 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 			if (prevItExists) { smallest = prevIt.sScore; out = Cell { curNode, 0, j - 1 }; }
 			for (uint32_t e = inBegin; e < inEnd; e++) {
 				uint32_t nb = g.inAdj[e];
-				int p = findItemW(wsx, ps, nb);
+				int p = findPrev(nb);
 				if (p >= 0) { NodeItem pn = loadItem(wsx, (uint32_t)p); if (pn.eScore <= smallest) { smallest = pn.eScore; out = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, j - 1 }; nodeSwitch = true; } }
-				int c = findItemW(wsx, cs, nb);
+				int c = findCur(nb);
 				if (c >= 0 && nb != curNode) {
 					int32_t v = wsValue(itemEnd(loadItem(wsx, (uint32_t)c)), 0);
 					if (v < smallest) { smallest = v; out = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, j }; nodeSwitch = true; }
@@ -438,9 +462,9 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 		int32_t bestInvalidScore = scoreHere + 1;
 		for (uint32_t e = inBegin; e < inEnd; e++) {
 			uint32_t nb = g.inAdj[e];
-			int c = findItemW(wsx, cs, nb);
+			int c = findCur(nb);
 			if (c >= 0 && wsValue(itemEnd(loadItem(wsx, (uint32_t)c)), 0) == scoreHere - 1) { out = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, j }; nodeSwitch = true; return true; }
-			int p = findItemW(wsx, ps, nb);
+			int p = findPrev(nb);
 			if (p >= 0) {
 				int32_t cornerScore = loadItem(wsx, (uint32_t)p).eScore;
 				if (cornerScore > previousQuitScore) {
@@ -457,13 +481,13 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 		uint32_t s = (uint32_t)(here.seqPos / 64) + 1;
 		if (s >= nSlices) return EXT_ASSERT;
 		if (s != curSliceIdx || here.node != curNode) {
-			if (s != curSliceIdx) { cs = loadSlice(wsx, s); ps = loadSlice(wsx, s - 1); eqVector(seq, len, cs.j, iupac, eq); }
+			if (s != curSliceIdx) { cs = loadSlice(wsx, s); ps = loadSlice(wsx, s - 1); eqVectorBits(eqSrc, len, cs.j, eq); fillIds(cs, idsCurBase); fillIds(ps, idsPrevBase); }
 			curSliceIdx = s;
 			curNode = here.node;
-			int ci = findItemW(wsx, cs, curNode);
+			int ci = findCur(curNode);
 			if (ci < 0) return EXT_ASSERT;
 			curIt = loadItem(wsx, (uint32_t)ci);
-			int pi = findItemW(wsx, ps, curNode);
+			int pi = findPrev(curNode);
 			prevItExists = pi >= 0;
 			if (prevItExists) prevIt = loadItem(wsx, (uint32_t)pi);
 			NodeItem scratchItem;
@@ -547,7 +571,7 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 				nxt = Cell { curNode, 0, sp - 1 };
 				for (uint32_t e = g.inOff[curNode]; e < g.inOff[curNode + 1]; e++) {
 					uint32_t nb = g.inAdj[e];
-					int c = findItemW(wsx, cs, nb);
+					int c = findCur(nb);
 					if (c < 0) continue;
 					WS ne = itemEnd(loadItem(wsx, (uint32_t)c));
 					if (wsValue(ne, offset - 1) <= smallest) { smallest = wsValue(ne, offset - 1); nxt = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, sp - 1 }; sw = true; }
@@ -557,7 +581,7 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 			} else {
 				for (uint32_t e = g.inOff[curNode]; e < g.inOff[curNode + 1] && !found; e++) {
 					uint32_t nb = g.inAdj[e];
-					int c = findItemW(wsx, cs, nb);
+					int c = findCur(nb);
 					if (c < 0) continue;
 					WS ne = itemEnd(loadItem(wsx, (uint32_t)c));
 					if (wsValue(ne, offset) == scoreHere - 1) { nxt = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, sp }; sw = true; found = true; }
@@ -602,6 +626,7 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 		}
 	}
 	cnt.traceItems += nTrace;
+	cnt.cycBacktrace += clock64() - tBack0;
 	return status;
 }
 

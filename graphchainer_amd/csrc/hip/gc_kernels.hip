@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(64) k_extend(DGraph g, const CorrectnessTables
 	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t stride = gridDim.x * blockDim.x;
 	LaneScratch sc = laneScratch(scratch + (uint64_t)tid * slabBytes, cfg);
-	ExtCounters cnt { 0, 0, 0, 0, 0, 0 };
+	ExtCounters cnt { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	for (uint32_t w = tid; w < nWork; w += stride) {
 		ExtItem it = work[w];
 		uint32_t nTrace = 0;
@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(64) k_long_pass(DGraph g, const CorrectnessTab
 	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t stride = gridDim.x * blockDim.x;
 	LongSlab ls = longSlab(scratch + (uint64_t)tid * slabBytes, cfg);
-	ExtCounters cnt { 0, 0, 0, 0, 0, 0 };
+	ExtCounters cnt { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	for (uint32_t r = tid; r < nReads; r += stride) {
 		LongJob job = jobs[r];
 		LongAln* mine = alns + job.alnBegin;
@@ -628,124 +628,6 @@ __global__ void __launch_bounds__(64) k_long_pass(DGraph g, const CorrectnessTab
 	}
 }
 
-// K3-long, wave layout: same per-read logic as k_long_pass, with the extension core of gc_device_wave.hpp
-// (hot slice state in LDS, DP table and traces lane-interleaved in HBM). One wave per block owns the CU's LDS.
-// A read whose band needs more than WAVE_CAP nodes in one slice is reported with status 5 and rerun by the host
-// with k_long_pass.
-__global__ void __launch_bounds__(64) k_long_pass_wave(DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg,
-	const LongJob* __restrict__ jobs, uint32_t nReads, const LongSeed* __restrict__ seeds, const char* __restrict__ bases, uint64_t rcBase,
-	uint32_t minClusterSize, uint32_t maxAlignments, unsigned long long* __restrict__ scratch, uint64_t wordsPerLane,
-	LongCell* __restrict__ cellPool, unsigned long long* __restrict__ cellCursor, uint64_t cellCapacity,
-	LongAln* __restrict__ alns, LongReadResult* __restrict__ results, unsigned long long* __restrict__ counters)
-{
-	__shared__ WaveLds lds;
-	const uint32_t lane = threadIdx.x;
-	WaveScratch wsx;
-	wsx.base = scratch + (uint64_t)blockIdx.x * wordsPerLane * 64;
-	wsx.lane = lane;
-	wsx.lanes = 64;
-	wsx.maxSlices = cfg.maxSlices; wsx.maxItems = cfg.maxItems; wsx.maxTrace = cfg.maxTrace;
-	ExtCounters cnt { 0, 0, 0, 0, 0, 0 };
-	for (uint32_t r = blockIdx.x * 64 + lane; r < nReads; r += gridDim.x * 64) {
-		LongJob job = jobs[r];
-		LongAln* mine = alns + job.alnBegin;
-		uint32_t nAln = 0, extended = 0, status = 0;
-		uint32_t e2eScore = 0;
-		const int L = (int)job.readLen;
-		// Lanes of a wave must reach the expensive part (the extension) together: a plain loop over seeds would let
-		// every lane extend at a different iteration and serialise the wave's extensions. So each lane first advances
-		// to its next seed that needs extending (cheap, divergent), then all lanes that found one extend in step.
-		uint32_t si = job.seedBegin;
-		while (true) {
-			bool have = false;
-			LongSeed sd {};
-			for (; status == 0 && si < job.seedEnd && !have; si++) {
-				sd = seeds[si];
-				if (sd.goodness < e2eScore) { si = job.seedEnd; break; }   // aligned end to end, skip the rest (:127-131)
-				if (sd.clusterSize < minClusterSize) continue;              // :141-146
-				bool skip = false;
-				for (uint32_t a = 0; a < nAln; a++)                          // sloppy overlap rule (:147-161)
-					if (mine[a].start <= sd.seqPos && mine[a].end >= sd.seqPos && mine[a].goodness > sd.goodness) { skip = true; break; }
-				if (skip) continue;
-				int32_t compareNode = g.nodeIDs[sd.node];
-				uint32_t compareOffset = g.nodeOffset[sd.node] + sd.offset;
-				for (uint32_t a = 0; a < nAln && !skip; a++) {              // exactAlignmentPart (:163-173)
-					int on = onTrace(cellPool + mine[a].traceOff, mine[a].traceLen, sd.seqPos, compareNode, compareOffset);
-					if (on == 2) { status = 1; break; }
-					if (on == 1) skip = true;
-				}
-				if (skip || status) continue;
-				have = true;
-			}
-			if (!__any(have)) break;
-			if (!have) continue;
-			extended++;
-			const int p = (int)sd.seqPos;
-			uint32_t nB = 0, nF = 0;
-			int32_t scoreB = 0, scoreF = 0;
-			uint32_t stB = EXT_FAILED, stF = EXT_FAILED;
-			if (p > 0) stB = extendSeedWave(g, *ct, iupac, cfg.bandwidth, (lds_u32*)&lds.w[0][0], wsx, bases + rcBase + job.readOff + (uint64_t)(L - p), p, sd.twinNode, sd.twinOffset, 0, nB, scoreB, cnt);
-			if (p < L - 1) stF = extendSeedWave(g, *ct, iupac, cfg.bandwidth, (lds_u32*)&lds.w[0][0], wsx, bases + job.readOff + (uint64_t)(p + 1), L - 1 - p, sd.node, sd.offset, 1, nF, scoreF, cnt);
-			if (stB == EXT_ASSERT || stF == EXT_ASSERT) { status = 1; break; }
-			if (stB == EXT_OVERFLOW || stF == EXT_OVERFLOW) { status = 2; break; }
-			if (stB == EXT_LDS_CAP || stF == EXT_LDS_CAP) { status = 5; break; }
-			bool hasB = stB == EXT_OK, hasF = stF == EXT_OK;
-			if (!hasB && !hasF) continue;
-			if (nAln >= maxAlignments) { status = 3; break; }
-			uint32_t useB = hasB ? (hasF ? nB - 1 : nB) : 0;
-			uint32_t total = useB + (hasF ? nF : 0);
-			unsigned long long base = atomicAdd(cellCursor, (unsigned long long)total);
-			if (base + total > cellCapacity) { status = 4; break; }
-			LongCell* outCells = cellPool + base;
-			for (uint32_t i = 0; i < useB; i++) {
-				TraceCell c = unpackCell(wsx.word(wsx.traceBase(i, 0)));
-				uint32_t off = c.offsetAndSwitch & 255u;
-				int32_t id = g.nodeIDs[c.node];
-				uint32_t orig = g.nodeOffset[c.node] + off;
-				LongCell oc;
-				oc.node = id ^ 1;
-				oc.offset = g.origSize[id] - 1 - orig;
-				oc.seqPos = (uint32_t)(p - 1 - c.seqPos);
-				oc.nodeSwitch = (i + 1 < nB) ? ((unpackCell(wsx.word(wsx.traceBase(i + 1, 0))).offsetAndSwitch >> 8) & 1u) : 0u;
-				outCells[i] = oc;
-			}
-			if (hasF) for (uint32_t i = 0; i < nF; i++) {
-				TraceCell c = unpackCell(wsx.word(wsx.traceBase(nF - 1 - i, 1)));
-				LongCell oc;
-				oc.node = g.nodeIDs[c.node];
-				oc.offset = g.nodeOffset[c.node] + (c.offsetAndSwitch & 255u);
-				oc.seqPos = (uint32_t)(p + 1 + c.seqPos);
-				oc.nodeSwitch = (c.offsetAndSwitch >> 8) & 1u;
-				outCells[useB + i] = oc;
-			}
-			LongAln al;
-			al.start = outCells[0].seqPos;
-			al.end = outCells[total - 1].seqPos + 1;
-			al.score = (uint32_t)((hasB ? scoreB : 0) + (hasF ? scoreF : 0));
-			al.goodness = sd.goodness;
-			al.traceOff = base;
-			al.traceLen = total;
-			al.pad = 0;
-			mine[nAln++] = al;
-			e2eScore = endToEndScore(mine, nAln, (uint32_t)L, e2eScore);
-		}
-		LongReadResult rr;
-		rr.nAlignments = status == 1 ? 0 : nAln;
-		rr.seedsExtended = extended;
-		rr.status = status;
-		rr.pad = 0;
-		results[r] = rr;
-	}
-	if (cnt.extensions) {
-		atomicAdd(&counters[0], cnt.dpTiles);
-		atomicAdd(&counters[1], cnt.recomputeTiles);
-		atomicAdd(&counters[2], cnt.columnSteps);
-		atomicAdd(&counters[3], cnt.traceItems);
-		atomicAdd(&counters[4], cnt.extensions);
-		atomicAdd(&counters[5], cnt.backtraceTiles);
-	}
-}
-
 // =====================================================================================================
 // K3-long in rounds. The monolithic kernels above keep a lane busy for as many rounds as its read needs while the
 // other 63 lanes of the wave wait (3.6 seeds are extended per read on average, up to 10). Here every round is
@@ -817,8 +699,9 @@ __global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __r
 		for (uint32_t c = 0; c < nCand; c++) {
 			LongSeed sd = seeds[cand[c]];
 			const uint32_t L = job.readLen, p = sd.seqPos;
-			work[at + 2 * c] = LongWork { rcBase + job.readOff + (uint64_t)(L - p), p, sd.twinNode, sd.twinOffset, r };
-			work[at + 2 * c + 1] = LongWork { job.readOff + (uint64_t)(p + 1), L - 1 - p, sd.node, sd.offset, r };
+			// backward: rows are revcomp(read[0..p)) = reverse-complement strand from position L-p; forward: read(p..] from p+1
+			work[at + 2 * c] = LongWork { job.maskOff + 4ull * job.maskWords, job.maskWords, L - p, p, sd.twinNode, sd.twinOffset, r };
+			work[at + 2 * c + 1] = LongWork { job.maskOff, job.maskWords, p + 1, L - 1 - p, sd.node, sd.offset, r };
 			candSeed[at / 2 + c] = cand[c];
 		}
 	}
@@ -829,8 +712,8 @@ __global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __r
 // are fewer work items than the chip has SIMDs x 64 lanes, running fewer lanes per wave shortens every wave: a wave's
 // instruction stream is the union of its lanes' divergent paths, and LDS per wave shrinks so more waves fit per CU.
 template <int LANES>
-__global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg,
-	const LongWork* __restrict__ work, uint32_t nWork, const char* __restrict__ bases, unsigned long long* __restrict__ scratch, uint64_t wordsPerLane,
+__global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint64_t* __restrict__ masks, ExtendConfig cfg,
+	const LongWork* __restrict__ work, uint32_t nWork, unsigned long long* __restrict__ scratch, uint64_t wordsPerLane,
 	unsigned long long* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, LongWorkResult* __restrict__ results, unsigned long long* __restrict__ counters)
 {
 	__shared__ WaveLdsT<LANES> lds;
@@ -841,14 +724,15 @@ __global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessT
 	wsx.lane = lane;
 	wsx.lanes = LANES;
 	wsx.maxSlices = cfg.maxSlices; wsx.maxItems = cfg.maxItems; wsx.maxTrace = cfg.maxTrace;
-	ExtCounters cnt { 0, 0, 0, 0, 0, 0 };
+	ExtCounters cnt { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 	for (uint32_t w = blockIdx.x * LANES + lane; w < nWork; w += gridDim.x * LANES) {
 		LongWork it = work[w];
 		LongWorkResult res { 0, 0, EXT_FAILED, 0, 0 };
 		if (it.seqLen > 0) {
 			uint32_t nTrace = 0;
 			int32_t score = 0;
-			res.status = extendSeedWave(g, *ct, iupac, cfg.bandwidth, (lds_u32*)&lds.w[0][0], wsx, bases + it.seqOff, (int)it.seqLen, it.node, it.offset, 0, nTrace, score, cnt);
+			EqSource eqSrc { masks + it.maskOff, it.maskWords, it.startBit };
+			res.status = extendSeedWave(g, *ct, eqSrc, cfg.bandwidth, (lds_u32*)&lds.w[0][0], wsx, (int)it.seqLen, it.node, it.offset, 0, nTrace, score, cnt);
 			res.score = score;
 			if (res.status == EXT_OK) {
 				unsigned long long base = atomicAdd(traceCursor, (unsigned long long)nTrace);
@@ -868,6 +752,10 @@ __global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessT
 		atomicAdd(&counters[3], cnt.traceItems);
 		atomicAdd(&counters[4], cnt.extensions);
 		atomicAdd(&counters[5], cnt.backtraceTiles);
+		atomicAdd(&counters[8], cnt.cycSlices);
+		atomicAdd(&counters[9], cnt.cycBacktrace);
+		atomicAdd(&counters[10], cnt.cycColumns);
+		atomicAdd(&counters[11], cnt.cycPush);
 	}
 }
 
@@ -1017,15 +905,6 @@ void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, 
 
 uint64_t longWaveWordsPerLane(const ExtendConfig& cfg) { return waveScratchWords(cfg.maxSlices, cfg.maxItems, cfg.maxTrace); }
 
-void launchLongPassWave(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg, const LongJob* jobs, uint32_t nReads,
-	const LongSeed* seeds, const char* bases, uint64_t rcBase, uint32_t minClusterSize, uint32_t maxAlignments, unsigned long long* scratch, uint32_t blocks,
-	LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity, LongAln* alns, LongReadResult* results, unsigned long long* counters)
-{
-	if (nReads == 0) return;
-	hipLaunchKernelGGL(k_long_pass_wave, dim3(blocks), dim3(64), 0, stream, g, ct, iupac, cfg, jobs, nReads, seeds, bases, rcBase, minClusterSize, maxAlignments, scratch, longWaveWordsPerLane(cfg),
-		cellPool, cellCursor, cellCapacity, alns, results, counters);
-}
-
 void launchLongInit(hipStream_t stream, const LongJob* jobs, uint32_t nReads, LongState* state)
 {
 	if (nReads) hipLaunchKernelGGL(k_long_init, dim3((nReads + 255) / 256), dim3(256), 0, stream, jobs, nReads, state);
@@ -1046,12 +925,12 @@ uint32_t longExtendTeamSize(uint32_t nWork)
 	return 64;
 }
 
-void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg, const LongWork* work, uint32_t nWork, const char* bases,
+void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, uint32_t nWork,
 	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters)
 {
 	if (!nWork) return;
 	uint64_t words = longWaveWordsPerLane(cfg);
-#define GC_LAUNCH_TEAM(N) hipLaunchKernelGGL(k_long_extend<N>, dim3(blocks), dim3(64), 0, stream, g, ct, iupac, cfg, work, nWork, bases, scratch, words, tracePool, traceCursor, traceCapacity, results, counters)
+#define GC_LAUNCH_TEAM(N) hipLaunchKernelGGL(k_long_extend<N>, dim3(blocks), dim3(64), 0, stream, g, ct, masks, cfg, work, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters)
 	switch (lanes) {
 		case 4: GC_LAUNCH_TEAM(4); break;
 		case 8: GC_LAUNCH_TEAM(8); break;

@@ -72,6 +72,8 @@ struct LongSeed {    // a seed in goodness order (after OrderSeeds), with the ba
 };
 
 struct LongJob {     // one read
+	uint64_t maskOff;               // word offset of the read's match masks: [strand][base][maskWords]
+	uint32_t maskWords, pad;
 	uint64_t readOff;               // forward bases at bases[readOff..], reverse complement at bases[rcBase + readOff..]
 	uint32_t readLen;
 	uint32_t seedBegin, seedEnd;    // into the LongSeed array
@@ -99,7 +101,8 @@ struct LongReadResult { uint32_t nAlignments, seedsExtended, status, pad; };
 // round-based whole-read pass: per-read state carried between rounds, and the per-round work items
 struct LongState { uint32_t si, nAln, extended, status, e2eScore, candBegin, candCount, pad1; };   // candBegin/candCount: this round's candidate seeds (pairs of work items)
 struct LongWork {    // one direction of one seed extension
-	uint64_t seqOff;
+	uint64_t maskOff;             // word offset of this read+strand's four match-mask bit vectors
+	uint32_t maskWords, startBit; // words per bit vector; read position (on that strand) of row 0
 	uint32_t seqLen, node, offset;
 	uint32_t read;
 };
@@ -133,13 +136,11 @@ void launchLongInit(hipStream_t stream, const LongJob* jobs, uint32_t nReads, Lo
 void launchLongSelect(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, uint64_t rcBase, uint32_t minClusterSize, uint32_t maxCandidates,
 	LongState* state, const LongAln* alns, const LongCell* cellPool, LongWork* work, uint32_t* candSeed, unsigned long long* workCount, uint64_t workCapacity);
 uint32_t longExtendTeamSize(uint32_t nWork);
-void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg, const LongWork* work, uint32_t nWork, const char* bases,
+void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, uint32_t nWork,
 	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters);
 void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, const uint32_t* candSeed, const LongWorkResult* results,
 	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity);
 void launchLongFinish(hipStream_t stream, uint32_t nReads, const LongState* state, LongReadResult* results);
-void launchLongPassWave(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg, const LongJob* jobs, uint32_t nReads,
-	const LongSeed* seeds, const char* bases, uint64_t rcBase, uint32_t minClusterSize, uint32_t maxAlignments, unsigned long long* scratch, uint32_t blocks,
-	LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity, LongAln* alns, LongReadResult* results, unsigned long long* counters);
+
 
 } // namespace gcdev
