@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgraphchainer_amd.so")
+LIB_PATH = os.environ.get("GC_LIBRARY") or os.path.join(_HERE, "libgraphchainer_amd.so")   # GC_LIBRARY: profiling builds (make stamps)
 
 EXPORTED_SYMBOLS = [
     "gc_params_default", "gc_graph_create_from_gfa", "gc_graph_create", "gc_graph_destroy", "gc_graph_num_nodes",

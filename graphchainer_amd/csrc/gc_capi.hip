@@ -193,8 +193,8 @@ struct gc_stream {
 	hipStream_t longStream = nullptr;
 	hipEvent_t longEv[2] {};
 	DeviceBuffer longSeeds, longJobs, longAlns, longResults, longScratch, longCells, longCursor, longJobsFallback, longResultsFallback, longScratchFallback;
-	DeviceBuffer longState, longWork, longWorkResults, longRoundTrace, longCandSeed;
-	PinnedBuffer hLongSeeds, hLongJobs, hLongAlns, hLongResults, hLongSmall;
+	DeviceBuffer longState, longWork, longWorkResults, longRoundTrace, longCandSeed, longWorkLen, longOrder;
+	PinnedBuffer hLongSeeds, hLongJobs, hLongAlns, hLongResults, hLongSmall, hLongWorkLen, hLongOrder;
 	~gc_stream()
 	{
 		for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -861,6 +861,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			LongWork* dLongWork = st->longWork.reserve<LongWork>(workCapacity);
 			LongWorkResult* dLongWorkResults = st->longWorkResults.reserve<LongWorkResult>(workCapacity);
 			uint32_t* dCandSeed = st->longCandSeed.reserve<uint32_t>(workCapacity);
+			uint32_t* dWorkLen = st->longWorkLen.reserve<uint32_t>(workCapacity);
+			uint32_t* dOrder = st->longOrder.reserve<uint32_t>(workCapacity);
+			uint32_t* hWorkLen = st->hLongWorkLen.reserve<uint32_t>(workCapacity);
+			uint32_t* hOrder = st->hLongOrder.reserve<uint32_t>(workCapacity);
 			uint64_t roundTraceBudget = 0;
 			for (uint64_t r = 0; r < n; r++) { uint64_t len = R->offsets[r + 1] - R->offsets[r]; roundTraceBudget += 2 * (len + len / 2 + 1024); }   // up to two candidate seeds' worth per read (adaptive rounds never exceed one on average)
 			unsigned long long* dRoundTrace = st->longRoundTrace.reserve<unsigned long long>(roundTraceBudget);
@@ -878,15 +882,33 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					uint32_t maxCand = 1;
 					if (round > 0 && lastWork > 0) maxCand = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (2 * n) / lastWork));
 					if (const char* env = getenv("GC_LONG_SPECULATE")) maxCand = (uint32_t)std::min(2, std::max(1, atoi(env)));   // test hook: speculate from round 0
-					launchLongSelect(ls, G->dev, dLongJobs, (uint32_t)n, dLongSeeds, R->totalBases, (uint32_t)P->min_cluster_size, maxCand, dLongState, dLongAlns, dLongCells, dLongWork, dCandSeed, dLongCursor + 1, workCapacity);
+					launchLongSelect(ls, G->dev, dLongJobs, (uint32_t)n, dLongSeeds, R->totalBases, (uint32_t)P->min_cluster_size, maxCand, dLongState, dLongAlns, dLongCells, dLongWork, dWorkLen, dCandSeed, dLongCursor + 1, workCapacity);
 					HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
 					HIP_CHECK(hipStreamSynchronize(ls));
 					uint32_t nWorkItems = (uint32_t)hLongSmall[1];
 					if (nWorkItems == 0) break;
 					uint32_t team = longExtendTeamSize(nWorkItems);
 					uint32_t blocks = (nWorkItems + team - 1) / team;
+					// Execution order. A wave runs as long as its longest extension and every step costs the maximum over its
+					// lanes, so which extensions share a wave and which waves start first decides the round's critical path.
+					{
+						HIP_CHECK(hipMemcpyAsync(hWorkLen, dWorkLen, nWorkItems * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
+						HIP_CHECK(hipStreamSynchronize(ls));
+						for (uint32_t i = 0; i < nWorkItems; i++) hOrder[i] = i;
+						const char* mode = getenv("GC_LONG_ORDER");
+						int m = mode ? atoi(mode) : 1;
+						if (m >= 1) std::stable_sort(hOrder, hOrder + nWorkItems, [&](uint32_t a, uint32_t b) { return hWorkLen[a] > hWorkLen[b]; });
+						if (m == 2) {   // wave j gets sorted[j], sorted[j + blocks], ...: one extension of every length class per wave
+							std::vector<uint32_t> sorted(hOrder, hOrder + nWorkItems);
+							uint32_t at = 0;
+							for (uint32_t j = 0; j < blocks; j++)
+								for (uint32_t k = 0; k < team; k++) { uint64_t src = (uint64_t)k * blocks + j; if (src < nWorkItems) hOrder[at++] = sorted[src]; }
+							for (; at < nWorkItems; at++) hOrder[at] = sorted[at];   // (not reached: every source index below nWorkItems is visited once)
+						}
+						HIP_CHECK(hipMemcpyAsync(dOrder, hOrder, nWorkItems * sizeof(uint32_t), hipMemcpyHostToDevice, ls));
+					}
 					HIP_CHECK(hipEventRecord(st->longEv[0], ls));
-					launchLongExtend(ls, G->dev, G->devTables, R->devMasks, lcfg, dLongWork, nWorkItems, dLongScratch, team, blocks, dRoundTrace, dLongCursor + 2, roundTraceBudget, dLongWorkResults, dLongCursor + 8);
+					launchLongExtend(ls, G->dev, G->devTables, R->devMasks, lcfg, dLongWork, dOrder, nWorkItems, dLongScratch, team, blocks, dRoundTrace, dLongCursor + 2, roundTraceBudget, dLongWorkResults, dLongCursor + 8);
 					HIP_CHECK(hipEventRecord(st->longEv[1], ls));
 					launchLongMerge(ls, G->dev, dLongJobs, (uint32_t)n, dLongSeeds, dCandSeed, dLongWorkResults, dRoundTrace, maxAlignments, dLongState, dLongAlns, dLongCells, dLongCursor, cellBudget);
 					lastWork = nWorkItems;
@@ -1018,7 +1040,14 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			uint64_t rerun = longFallback();
 			res->counters_long[7] = rerun;   // reads that needed the plain-layout fallback kernel
 			for (int i = 0; i < 6; i++) res->counters_long[i] = hLongSmall[8 + i];   // same units as counters[]
-			if (getenv("GC_DEBUG_STAMPS")) fprintf(stderr, "[gc stamps] long extend lane-cycles: slices %llu backtrace %llu | inside slices: columns %llu push %llu\n", hLongSmall[16], hLongSmall[17], hLongSmall[18], hLongSmall[19]);
+#ifdef GC_STAMPS
+			{
+				static const char* names[11] = { "slice prologue", "pop+prev lookup", "tile columns", "item store", "edge pushes", "slice epilogue", "bt slice change", "bt item loads", "bt recompute", "bt corner", "bt walk" };
+				double total = 0;
+				for (int i = 0; i < 11; i++) total += (double)hLongSmall[16 + i];
+				for (int i = 0; i < 11; i++) fprintf(stderr, "[gc stamps] %-16s %6.2f%%  %.3e lane-cycles\n", names[i], 100.0 * hLongSmall[16 + i] / (total > 0 ? total : 1), (double)hLongSmall[16 + i]);
+			}
+#endif
 			for (uint64_t r = 0; r < n; r++) {
 				if (hLongResults[r].status == 2) throw std::runtime_error("whole-read pass: extension scratch overflow (raise GC_LONG_MAX_ITEMS)");
 				if (hLongResults[r].status == 3) throw std::runtime_error("whole-read pass: more than 32 alignments for one read");

@@ -185,7 +185,20 @@ struct LaneScratch {
 	TraceCell* trace;
 };
 
-struct ExtCounters { unsigned long long dpTiles, recomputeTiles, columnSteps, traceItems, extensions, backtraceTiles; unsigned long long cycSlices, cycBacktrace, cycColumns, cycPush; };
+struct ExtCounters {
+	unsigned long long dpTiles, recomputeTiles, columnSteps, traceItems, extensions, backtraceTiles;
+#ifdef GC_STAMPS
+	unsigned long long cyc[16], tMark;   // profiling build only (make stamps): lane-cycles per section of extendSeedWave
+#endif
+};
+// GC_MARK(i): everything since the previous mark is charged to bucket i. Compiles to nothing in the product build.
+#ifdef GC_STAMPS
+#define GC_MARK_START() (cnt.tMark = clock64())
+#define GC_MARK(i) do { unsigned long long now_ = clock64(); cnt.cyc[i] += now_ - cnt.tMark; cnt.tMark = now_; } while (0)
+#else
+#define GC_MARK_START() ((void)0)
+#define GC_MARK(i) ((void)0)
+#endif
 
 // 4 match masks (A,C,G,T) of read rows j..j+63. reference: ...Common.h:280-319. iupac[c] = set of bases c matches.
 // Four named members, never an array: an array indexed by the node's 2-bit base code ends up in scratch (or LDS),

@@ -265,7 +265,7 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 		storeSlice(wsx, 0, s0);
 	}
 	uint32_t nItems = 1, nSlices = 1;
-	const unsigned long long tSlices0 = clock64();
+	GC_MARK_START();
 	int32_t prevMinScore = 0, prevBandwidth = 1, prevJ = -64;
 	double prevCorrect = ct.initCorrect, prevFalse = ct.initFalse;
 	Eq4 eq;
@@ -314,6 +314,7 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 			pushEdge(L.pNode(buf, i), wsSource(L.pStart(buf, i)), true);
 		}
 		if (status != EXT_OK) return status;
+		GC_MARK(0);   // slice prologue: match masks + source pushes
 		WSlice cur;
 		cur.first = nItems; cur.count = 0; cur.bandwidth = bandwidth; cur.j = j;
 		cur.minScore = INT32_MAX - bandwidth - 1; cur.minNode = 0xffffffffu; cur.minOffset = 0xffffffffu;
@@ -334,9 +335,9 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 			NodeItem out;
 			LaneLds::Entry pe { 0, 0, 0, ~0ull, 0ull };
 			if (prevExists) pe = L.get((uint32_t)buf, (uint32_t)pi);
-			const unsigned long long tCol0 = clock64();
+			GC_MARK(1);   // pop + previous-slice lookup
 			TileResult tr = computeTileW(g, pnode, pws, prevExists, (int32_t)pe.w1, pe.a, pe.b, eq, out, nullptr, flatRows, status);
-			cnt.cycColumns += clock64() - tCol0;
+			GC_MARK(2);   // tile columns
 			if (status != EXT_OK) return status;
 			out.minScore = tr.minScore;
 			storeItem(wsx, nItems, out);
@@ -354,14 +355,15 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 			int32_t newEndMin = wsColumnMin(newEnd);
 			if (newEndMin < prevMinScore) return EXT_ASSERT;
 			if (newEndMin <= currentMin + bandwidth) {
-				const unsigned long long tPush0 = clock64();
+				GC_MARK(3);   // item store + bookkeeping
 				for (uint32_t e = g.outOff[pnode]; e < g.outOff[pnode + 1]; e++) {
 					pushEdge(g.outAdj[e], newEnd, false);
 					if (status != EXT_OK) return status;
 				}
-				cnt.cycPush += clock64() - tPush0;
-			}
+				GC_MARK(4);   // out-edge pushes
+			} else GC_MARK(3);
 		}
+		GC_MARK(1);
 		if (cur.count == 0) return EXT_ASSERT;
 		if (flatRows > 0) { cur.minScore = flatMin; cur.minNode = flatNode; cur.minOffset = flatOffset; }
 		if (cur.minScore < prevMinScore) return EXT_ASSERT;
@@ -382,9 +384,9 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 		prevMinScore = cur.minScore; prevBandwidth = cur.bandwidth; prevJ = cur.j; prevCorrect = curCorrect; prevFalse = curFalse;
 		nPrev = cur.count;
 		buf = cb;
+		GC_MARK(5);
 	}
-	cnt.cycSlices += clock64() - tSlices0;
-	const unsigned long long tBack0 = clock64();
+	GC_MARK(5);   // slice epilogue (HMM, slice record)
 	// removeWronglyAlignedEnd
 	{
 		bool currentlyCorrect = (loadSlice(wsx, nSlices - 1).flags & 1u) != 0;
@@ -433,6 +435,8 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 	bool prevItExists = false;
 	// corner rule (pickBacktraceCorner, ...Common.h:710-804)
 	auto corner = [&](Cell& out, bool& nodeSwitch) -> bool {
+		GC_MARK(10);
+		struct MarkOnExit { ExtCounters& cnt; __device__ ~MarkOnExit() { GC_MARK(9); } } markOnExit { cnt };   // bucket 9: corner rule
 		int32_t j = cs.j;
 		int32_t quitScore = cs.minScore + cs.bandwidth;
 		int32_t previousQuitScore = ps.minScore + ps.bandwidth;
@@ -481,7 +485,9 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 		uint32_t s = (uint32_t)(here.seqPos / 64) + 1;
 		if (s >= nSlices) return EXT_ASSERT;
 		if (s != curSliceIdx || here.node != curNode) {
+			GC_MARK(10);  // walking inside a tile / corner rules
 			if (s != curSliceIdx) { cs = loadSlice(wsx, s); ps = loadSlice(wsx, s - 1); eqVectorBits(eqSrc, len, cs.j, eq); fillIds(cs, idsCurBase); fillIds(ps, idsPrevBase); }
+			GC_MARK(6);   // backtrace: slice change
 			curSliceIdx = s;
 			curNode = here.node;
 			int ci = findCur(curNode);
@@ -490,12 +496,14 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 			int pi = findPrev(curNode);
 			prevItExists = pi >= 0;
 			if (prevItExists) prevIt = loadItem(wsx, (uint32_t)pi);
+			GC_MARK(7);   // backtrace: item lookups + loads
 			NodeItem scratchItem;
 			computeTileW(g, curNode, itemStart(curIt), prevItExists, prevItExists ? prevIt.sScore : 0, prevItExists ? prevIt.HP : ~0ull, prevItExists ? prevIt.HN : 0ull,
 				eq, scratchItem, columns, 0, status);
 			if (scratchItem.eVP != curIt.eVP || scratchItem.eVN != curIt.eVN || scratchItem.eScore != curIt.eScore) status = EXT_ASSERT;
 			cnt.recomputeTiles++; cnt.backtraceTiles++; cnt.columnSteps += g.nodeLength[curNode];
 			if (status != EXT_OK) return status;
+			GC_MARK(8);   // backtrace: column recompute
 		}
 		int row = here.seqPos & 63;
 		if (row == 0 && here.offset == 0) {
@@ -626,7 +634,7 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 		}
 	}
 	cnt.traceItems += nTrace;
-	cnt.cycBacktrace += clock64() - tBack0;
+	GC_MARK(10);
 	return status;
 }
 

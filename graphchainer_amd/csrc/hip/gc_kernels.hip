@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(64) k_extend(DGraph g, const CorrectnessTables
 	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t stride = gridDim.x * blockDim.x;
 	LaneScratch sc = laneScratch(scratch + (uint64_t)tid * slabBytes, cfg);
-	ExtCounters cnt { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	ExtCounters cnt {};
 	for (uint32_t w = tid; w < nWork; w += stride) {
 		ExtItem it = work[w];
 		uint32_t nTrace = 0;
@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(64) k_long_pass(DGraph g, const CorrectnessTab
 	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t stride = gridDim.x * blockDim.x;
 	LongSlab ls = longSlab(scratch + (uint64_t)tid * slabBytes, cfg);
-	ExtCounters cnt { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+	ExtCounters cnt {};
 	for (uint32_t r = tid; r < nReads; r += stride) {
 		LongJob job = jobs[r];
 		LongAln* mine = alns + job.alnBegin;
@@ -668,7 +668,7 @@ __device__ inline int seedSkipped(const DGraph& g, const LongSeed& sd, const Lon
 // them against the alignments added before it in the same round, so the outcome equals one-seed-per-round.
 #define LONG_MAX_CANDIDATES 8
 __global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __restrict__ jobs, uint32_t nReads, const LongSeed* __restrict__ seeds, uint64_t rcBase, uint32_t minClusterSize,
-	uint32_t maxCandidates, LongState* __restrict__ state, const LongAln* __restrict__ alns, const LongCell* __restrict__ cellPool, LongWork* __restrict__ work, uint32_t* __restrict__ candSeed,
+	uint32_t maxCandidates, LongState* __restrict__ state, const LongAln* __restrict__ alns, const LongCell* __restrict__ cellPool, LongWork* __restrict__ work, uint32_t* __restrict__ workLen, uint32_t* __restrict__ candSeed,
 	unsigned long long* __restrict__ workCount, uint64_t workCapacity)
 {
 	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -702,6 +702,8 @@ __global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __r
 			// backward: rows are revcomp(read[0..p)) = reverse-complement strand from position L-p; forward: read(p..] from p+1
 			work[at + 2 * c] = LongWork { job.maskOff + 4ull * job.maskWords, job.maskWords, L - p, p, sd.twinNode, sd.twinOffset, r };
 			work[at + 2 * c + 1] = LongWork { job.maskOff, job.maskWords, p + 1, L - 1 - p, sd.node, sd.offset, r };
+			workLen[at + 2 * c] = p;
+			workLen[at + 2 * c + 1] = L - 1 - p;
 			candSeed[at / 2 + c] = cand[c];
 		}
 	}
@@ -713,7 +715,7 @@ __global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __r
 // instruction stream is the union of its lanes' divergent paths, and LDS per wave shrinks so more waves fit per CU.
 template <int LANES>
 __global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint64_t* __restrict__ masks, ExtendConfig cfg,
-	const LongWork* __restrict__ work, uint32_t nWork, unsigned long long* __restrict__ scratch, uint64_t wordsPerLane,
+	const LongWork* __restrict__ work, const uint32_t* __restrict__ order, uint32_t nWork, unsigned long long* __restrict__ scratch, uint64_t wordsPerLane,
 	unsigned long long* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, LongWorkResult* __restrict__ results, unsigned long long* __restrict__ counters)
 {
 	__shared__ WaveLdsT<LANES> lds;
@@ -724,8 +726,9 @@ __global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessT
 	wsx.lane = lane;
 	wsx.lanes = LANES;
 	wsx.maxSlices = cfg.maxSlices; wsx.maxItems = cfg.maxItems; wsx.maxTrace = cfg.maxTrace;
-	ExtCounters cnt { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-	for (uint32_t w = blockIdx.x * LANES + lane; w < nWork; w += gridDim.x * LANES) {
+	ExtCounters cnt {};
+	for (uint32_t slot = blockIdx.x * LANES + lane; slot < nWork; slot += gridDim.x * LANES) {
+		const uint32_t w = order[slot];   // execution order (longest first / length-balanced waves), results stay indexed by work item
 		LongWork it = work[w];
 		LongWorkResult res { 0, 0, EXT_FAILED, 0, 0 };
 		if (it.seqLen > 0) {
@@ -752,10 +755,9 @@ __global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessT
 		atomicAdd(&counters[3], cnt.traceItems);
 		atomicAdd(&counters[4], cnt.extensions);
 		atomicAdd(&counters[5], cnt.backtraceTiles);
-		atomicAdd(&counters[8], cnt.cycSlices);
-		atomicAdd(&counters[9], cnt.cycBacktrace);
-		atomicAdd(&counters[10], cnt.cycColumns);
-		atomicAdd(&counters[11], cnt.cycPush);
+#ifdef GC_STAMPS
+		for (int i = 0; i < 16; i++) atomicAdd(&counters[8 + i], cnt.cyc[i]);
+#endif
 	}
 }
 
@@ -910,28 +912,31 @@ void launchLongInit(hipStream_t stream, const LongJob* jobs, uint32_t nReads, Lo
 	if (nReads) hipLaunchKernelGGL(k_long_init, dim3((nReads + 255) / 256), dim3(256), 0, stream, jobs, nReads, state);
 }
 void launchLongSelect(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, uint64_t rcBase, uint32_t minClusterSize, uint32_t maxCandidates,
-	LongState* state, const LongAln* alns, const LongCell* cellPool, LongWork* work, uint32_t* candSeed, unsigned long long* workCount, uint64_t workCapacity)
+	LongState* state, const LongAln* alns, const LongCell* cellPool, LongWork* work, uint32_t* workLen, uint32_t* candSeed, unsigned long long* workCount, uint64_t workCapacity)
 {
 	if (maxCandidates < 1) maxCandidates = 1;
 	if (maxCandidates > LONG_MAX_CANDIDATES) maxCandidates = LONG_MAX_CANDIDATES;
-	if (nReads) hipLaunchKernelGGL(k_long_select, dim3((nReads + 63) / 64), dim3(64), 0, stream, g, jobs, nReads, seeds, rcBase, minClusterSize, maxCandidates, state, alns, cellPool, work, candSeed, workCount, workCapacity);
+	if (nReads) hipLaunchKernelGGL(k_long_select, dim3((nReads + 63) / 64), dim3(64), 0, stream, g, jobs, nReads, seeds, rcBase, minClusterSize, maxCandidates, state, alns, cellPool, work, workLen, candSeed, workCount, workCapacity);
 }
 uint32_t longExtendTeamSize(uint32_t nWork)
 {
-	// smallest team that still fits the work into about 2048 resident waves
-	if (const char* env = getenv("GC_LONG_TEAM")) { int v = atoi(env); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return (uint32_t)v; }
-	const uint32_t targetWaves = 2048;
-	for (uint32_t lanes : { 4u, 8u, 16u, 32u }) if ((nWork + lanes - 1) / lanes <= targetWaves) return lanes;
-	return 64;
+	// Measured on MI355X (cfg2, 20k extensions in the first round): 1 lane per wave 260 ms, 2 lanes 352 ms, 4 lanes 397 ms,
+	// 8 lanes 555 ms for the whole pass. The extension core is branchy serial code; lanes sharing a wave pay for the
+	// union of their paths, and the chip has far more wave slots than a round has extensions. GC_LONG_TEAM overrides.
+	if (const char* env = getenv("GC_LONG_TEAM")) { int v = atoi(env); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return (uint32_t)v; }
+	(void)nWork;
+	return 1;
 }
 
-void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, uint32_t nWork,
+void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
 	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters)
 {
 	if (!nWork) return;
 	uint64_t words = longWaveWordsPerLane(cfg);
-#define GC_LAUNCH_TEAM(N) hipLaunchKernelGGL(k_long_extend<N>, dim3(blocks), dim3(64), 0, stream, g, ct, masks, cfg, work, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters)
+#define GC_LAUNCH_TEAM(N) hipLaunchKernelGGL(k_long_extend<N>, dim3(blocks), dim3(64), 0, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters)
 	switch (lanes) {
+		case 1: GC_LAUNCH_TEAM(1); break;
+		case 2: GC_LAUNCH_TEAM(2); break;
 		case 4: GC_LAUNCH_TEAM(4); break;
 		case 8: GC_LAUNCH_TEAM(8); break;
 		case 16: GC_LAUNCH_TEAM(16); break;
