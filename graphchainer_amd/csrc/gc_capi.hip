@@ -155,6 +155,17 @@ template <typename T> T* mallocArray(size_t n) { return (T*)malloc(std::max<size
 // ----------------------------------------------------------------------------------------------------
 struct gc_graph {
 	gc::AlignmentGraph host;
+	// dense-by-bigraph-node-id copies of the twin lookup tables (the same arrays the device gets): original node size, and the
+	// split nodes of every bigraph node in offset order (chunk k covers offsets [64k, 64k+64))
+	std::vector<uint32_t> hOrigSize, hLookupOff, hLookup;
+	// reverse-strand twin of (split node, offset): GetReversePosition + GetUnitigNode (src/AlignmentGraph.cpp:832-868) without the hash maps
+	inline void twinOf(uint32_t node, uint32_t offset, uint32_t& twinNode, uint32_t& twinOffset) const
+	{
+		uint32_t id = (uint32_t)host.nodeIDs[node];
+		uint32_t rev = hOrigSize[id] - 1 - ((uint32_t)host.nodeOffset[node] + offset);
+		twinNode = hLookup[hLookupOff[id ^ 1] + rev / 64];
+		twinOffset = rev - (uint32_t)host.nodeOffset[twinNode];
+	}
 	DGraph dev {};
 	std::vector<void*> allocations;
 	CorrectnessTables* devTables = nullptr;
@@ -287,6 +298,10 @@ static void uploadGraph(gc_graph* G)
 			for (size_t s : it->second) lookup.push_back((uint32_t)s);
 		}
 	}
+	for (size_t id = 0; id < nB; id++)
+		for (uint32_t k = lookupOff[id]; k < lookupOff[id + 1]; k++)
+			if (h.nodeOffset[lookup[k]] != 64ull * (k - lookupOff[id])) throw std::runtime_error("split nodes are not 64-aligned chunks of their original node");
+	G->hOrigSize = origSize; G->hLookupOff = lookupOff; G->hLookup = lookup;
 	// MPC index, flattened to global node ids
 	std::vector<uint32_t> pathsOff(n + 1, 0), pathsFlat, pathsPos, backOff(n + 1, 0), backNode, backPath, backPos, mpcWidth(h.mpc.size());
 	for (size_t c = 0; c < h.mpc.size(); c++) { mpcWidth[c] = (uint32_t)h.mpc[c].size(); G->maxMpcWidth = std::max(G->maxMpcWidth, mpcWidth[c]); }
@@ -727,75 +742,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				return;
 			}
 			if (P->long_pass) gl.longSeeds = gl.seeds;
-			gc::fragmentWindows(gl.seeds, len, (size_t)P->split_len, (size_t)P->split_gap, gl.windows);
 		});
-		uint64_t nSlots = 0, nFrags = 0, nSeedsTotal = 0;
-		for (uint64_t r = 0; r < n; r++) {
-			glue[r].slotBegin = nSlots;
-			glue[r].fragBegin = nFrags;
-			glue[r].seedBegin = nSeedsTotal;
-			for (const auto& w : glue[r].windows) nSlots += w.sr - w.sl;
-			nFrags += glue[r].windows.size();
-			nSeedsTotal += glue[r].seeds.size();
-		}
-		if (2 * nSlots >= 0xffffffffull) throw std::runtime_error("batch too large: more than 2^31 fragment seeds; split the batch");
-		Fragment* frags = st->hFrags.reserve<Fragment>(nFrags);
-		FragSeed* fragSeeds = st->hFragSeeds.reserve<FragSeed>(nSlots);
-		ExtItem* work = st->hWork.reserve<ExtItem>(2 * nSlots);
-		ReadChainJob* jobs = st->hJobs.reserve<ReadChainJob>(n);
-		std::vector<uint64_t> traceBudgets(pool.size(), 0);
-		pool.run(n, [&](size_t r, size_t worker) {
-			const ReadGlue& gl = glue[r];
-			size_t len = R->offsets[r + 1] - R->offsets[r];
-			uint64_t slot = gl.slotBegin;
-			uint64_t budget = 0;
-			for (size_t f = 0; f < gl.windows.size(); f++) {
-				const gc::FragmentWindow& w = gl.windows[f];
-				Fragment& fr = frags[gl.fragBegin + f];
-				fr.read = (uint32_t)r;
-				fr.l = w.l;
-				fr.seedBegin = (uint32_t)slot;
-				for (uint32_t k = w.sl; k < w.sr; k++, slot++) {
-					const gc::SeedRec& s = gl.seeds[k];
-					fragSeeds[slot] = FragSeed { s.node, s.offset, s.seqPos, 0 };
-					uint32_t p = s.seqPos - w.l;
-					// backward: revcomp(fragment[0..p)) from the reverse-strand twin of the seed base (src/GraphAligner.h:499-505)
-					int id = hg.nodeIDs[s.node];
-					size_t orig = hg.nodeOffset[s.node] + s.offset;
-					auto rev = hg.GetReversePosition(id, orig);
-					size_t twin = hg.GetUnitigNode(rev.first, rev.second);
-					ExtItem& b = work[2 * slot];
-					b.seqOff = R->totalBases + R->offsets[r] + (len - w.l - p);
-					b.seqLen = p;
-					b.node = (uint32_t)twin;
-					b.offset = (uint32_t)(rev.second - hg.nodeOffset[twin]);
-					b.pad = 0;
-					// forward: fragment(p+1 ..] from the seed base (:506-511)
-					ExtItem& fw = work[2 * slot + 1];
-					fw.seqOff = R->offsets[r] + w.l + p + 1;
-					fw.seqLen = (uint32_t)P->split_len - 1 - p;
-					fw.node = s.node;
-					fw.offset = s.offset;
-					fw.pad = 0;
-					budget += (b.seqLen ? b.seqLen + 24 : 0) + (fw.seqLen ? fw.seqLen + 24 : 0);
-				}
-				fr.seedEnd = (uint32_t)slot;
-			}
-			traceBudgets[worker] += budget;
-			ReadChainJob& job = jobs[r];
-			job.slotBegin = (uint32_t)gl.slotBegin;
-			job.nSlots = (uint32_t)(slot - gl.slotBegin);
-			job.chainBegin = (uint32_t)gl.slotBegin;
-			job.nKeys = len >= (size_t)P->split_len ? (uint32_t)((len - P->split_len) / P->split_gap + 1) : 1;
-			job.fragBegin = (uint32_t)gl.fragBegin;
-			job.nFrags = (uint32_t)gl.windows.size();
-		});
-		uint64_t traceBudget = 0;
-		for (uint64_t b : traceBudgets) traceBudget += b;
-		ChainCaps caps { 1, 1, 1 };
-		for (uint64_t r = 0; r < n; r++) caps.capAnchors = std::max(caps.capAnchors, jobs[r].nSlots);
-		res->host_us[0] = nowUs() - tGlue;
-
+		double tOrdered = nowUs();
 		// ---------------- K3-long: whole-read pass on its own stream (src/Aligner.cpp:630-654)
 		const uint32_t maxAlignments = 32;
 		uint64_t nLongSeeds = 0, maxReadLen = 1;
@@ -818,10 +766,9 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				const ReadGlue& gl = glue[r];
 				uint64_t at = gl.longSeedBegin;
 				for (const gc::SeedRec& s : gl.longSeeds) {
-					int id = hg.nodeIDs[s.node];
-					auto rev = hg.GetReversePosition(id, hg.nodeOffset[s.node] + s.offset);
-					size_t twin = hg.GetUnitigNode(rev.first, rev.second);
-					hSeeds[at++] = LongSeed { s.node, s.offset, (uint32_t)twin, (uint32_t)(rev.second - hg.nodeOffset[twin]), s.seqPos, s.goodness, s.clusterSize, 0 };
+					uint32_t twinNode, twinOffset;
+					G->twinOf(s.node, s.offset, twinNode, twinOffset);
+					hSeeds[at++] = LongSeed { s.node, s.offset, twinNode, twinOffset, s.seqPos, s.goodness, s.clusterSize, 0 };
 				}
 				LongJob& j = hJobs[r];
 				j.maskOff = R->maskOff[r];
@@ -950,6 +897,90 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				return (uint64_t)redo.size();
 			};
 		}
+		// The whole-read pass is the longest leg of the batch: its round loop runs on its own host thread and stream from
+		// here on, while this thread prepares and runs the fragment pipeline.
+		std::thread longThread;
+		std::exception_ptr longError;
+		struct JoinGuard { std::thread& t; ~JoinGuard() { if (t.joinable()) t.join(); } } joinGuard { longThread };
+		if (P->long_pass) {
+			int device = 0;
+			HIP_CHECK(hipGetDevice(&device));
+			longThread = std::thread([&, device]() {
+				try {
+					HIP_CHECK(hipSetDevice(device));
+					runLongRounds();
+				} catch (...) { longError = std::current_exception(); }
+			});
+		}
+
+		double tLongStarted = nowUs();
+		pool.run(n, [&](size_t r, size_t) {
+			ReadGlue& gl = glue[r];
+			if (gl.seeds.empty()) return;
+			gc::fragmentWindows(gl.seeds, R->offsets[r + 1] - R->offsets[r], (size_t)P->split_len, (size_t)P->split_gap, gl.windows);
+		});
+		uint64_t nSlots = 0, nFrags = 0, nSeedsTotal = 0;
+		for (uint64_t r = 0; r < n; r++) {
+			glue[r].slotBegin = nSlots;
+			glue[r].fragBegin = nFrags;
+			glue[r].seedBegin = nSeedsTotal;
+			for (const auto& w : glue[r].windows) nSlots += w.sr - w.sl;
+			nFrags += glue[r].windows.size();
+			nSeedsTotal += glue[r].seeds.size();
+		}
+		if (2 * nSlots >= 0xffffffffull) throw std::runtime_error("batch too large: more than 2^31 fragment seeds; split the batch");
+		Fragment* frags = st->hFrags.reserve<Fragment>(nFrags);
+		FragSeed* fragSeeds = st->hFragSeeds.reserve<FragSeed>(nSlots);
+		ExtItem* work = st->hWork.reserve<ExtItem>(2 * nSlots);
+		ReadChainJob* jobs = st->hJobs.reserve<ReadChainJob>(n);
+		std::vector<uint64_t> traceBudgets(pool.size(), 0);
+		pool.run(n, [&](size_t r, size_t worker) {
+			const ReadGlue& gl = glue[r];
+			size_t len = R->offsets[r + 1] - R->offsets[r];
+			uint64_t slot = gl.slotBegin;
+			uint64_t budget = 0;
+			for (size_t f = 0; f < gl.windows.size(); f++) {
+				const gc::FragmentWindow& w = gl.windows[f];
+				Fragment& fr = frags[gl.fragBegin + f];
+				fr.read = (uint32_t)r;
+				fr.l = w.l;
+				fr.seedBegin = (uint32_t)slot;
+				for (uint32_t k = w.sl; k < w.sr; k++, slot++) {
+					const gc::SeedRec& s = gl.seeds[k];
+					fragSeeds[slot] = FragSeed { s.node, s.offset, s.seqPos, 0 };
+					uint32_t p = s.seqPos - w.l;
+					// backward: revcomp(fragment[0..p)) from the reverse-strand twin of the seed base (src/GraphAligner.h:499-505)
+					ExtItem& b = work[2 * slot];
+					b.seqOff = R->totalBases + R->offsets[r] + (len - w.l - p);
+					b.seqLen = p;
+					G->twinOf(s.node, s.offset, b.node, b.offset);
+					b.pad = 0;
+					// forward: fragment(p+1 ..] from the seed base (:506-511)
+					ExtItem& fw = work[2 * slot + 1];
+					fw.seqOff = R->offsets[r] + w.l + p + 1;
+					fw.seqLen = (uint32_t)P->split_len - 1 - p;
+					fw.node = s.node;
+					fw.offset = s.offset;
+					fw.pad = 0;
+					budget += (b.seqLen ? b.seqLen + 24 : 0) + (fw.seqLen ? fw.seqLen + 24 : 0);
+				}
+				fr.seedEnd = (uint32_t)slot;
+			}
+			traceBudgets[worker] += budget;
+			ReadChainJob& job = jobs[r];
+			job.slotBegin = (uint32_t)gl.slotBegin;
+			job.nSlots = (uint32_t)(slot - gl.slotBegin);
+			job.chainBegin = (uint32_t)gl.slotBegin;
+			job.nKeys = len >= (size_t)P->split_len ? (uint32_t)((len - P->split_len) / P->split_gap + 1) : 1;
+			job.fragBegin = (uint32_t)gl.fragBegin;
+			job.nFrags = (uint32_t)gl.windows.size();
+		});
+		uint64_t traceBudget = 0;
+		for (uint64_t b : traceBudgets) traceBudget += b;
+		ChainCaps caps { 1, 1, 1 };
+		for (uint64_t r = 0; r < n; r++) caps.capAnchors = std::max(caps.capAnchors, jobs[r].nSlots);
+		res->host_us[0] = nowUs() - tGlue;
+		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] seed expand+order %.1f ms, whole-read setup %.1f ms, fragment windows+arrays %.1f ms\n", (tOrdered - tGlue) / 1e3, (tLongStarted - tOrdered) / 1e3, (nowUs() - tLongStarted) / 1e3);
 
 		// ---------------- K3 / K3b / K4
 		double tDev = nowUs();
@@ -994,7 +1025,6 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		mark();   // 4
 		launchChain(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, P->split_len, P->split_gap, caps, dChainScratch, dChainOut, dChainLen, dChainScore, dChainStatus);
 		mark();   // 5
-		if (P->long_pass) runLongRounds();   // host drives the rounds on the long stream while the fragment kernels run on theirs
 
 		// ---------------- results back (pinned staging)
 		AnchorRec* anchors = st->hAnchors.reserve<AnchorRec>(nSlots);
@@ -1037,6 +1067,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		// ---------------- whole-read pass results
 		std::vector<LongCell> longCells;
 		if (P->long_pass) {
+			longThread.join();
+			if (longError) std::rethrow_exception(longError);
 			uint64_t rerun = longFallback();
 			res->counters_long[7] = rerun;   // reads that needed the plain-layout fallback kernel
 			for (int i = 0; i < 6; i++) res->counters_long[i] = hLongSmall[8 + i];   // same units as counters[]

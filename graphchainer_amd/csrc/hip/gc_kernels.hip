@@ -761,11 +761,14 @@ __global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessT
 	}
 }
 
+// One wave per read: the decisions are taken redundantly by all lanes (uniform control flow, lane 0 does the single
+// writes), the trace -> cell conversion - the bulk of the work, ~1.5 cells per read base - runs 64 cells at a time.
 __global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __restrict__ jobs, uint32_t nReads, const LongSeed* __restrict__ seeds, const uint32_t* __restrict__ candSeed,
 	const LongWorkResult* __restrict__ results, const unsigned long long* __restrict__ tracePool, uint32_t maxAlignments,
-	LongState* __restrict__ state, LongAln* __restrict__ alns, LongCell* __restrict__ cellPool, unsigned long long* __restrict__ cellCursor, uint64_t cellCapacity)
+	LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* __restrict__ cellCursor, uint64_t cellCapacity)
 {
-	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t r = blockIdx.x;
+	const uint32_t lane = threadIdx.x;
 	if (r >= nReads) return;
 	LongState st = state[r];
 	if (st.candCount == 0 || st.status != 0) return;
@@ -798,10 +801,12 @@ __global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __re
 		uint32_t useB = hasB ? (hasF ? nB - 1 : nB) : 0;
 		uint32_t total = useB + (hasF ? nF : 0);
 		if (st.nAln >= maxAlignments) { st.status = 3; break; }
-		unsigned long long base = atomicAdd(cellCursor, (unsigned long long)total);
+		unsigned long long base = 0;
+		if (lane == 0) base = atomicAdd(cellCursor, (unsigned long long)total);
+		base = __shfl(base, 0);
 		if (base + total > cellCapacity) { st.status = 4; break; }
 		LongCell* outCells = cellPool + base;
-		for (uint32_t i = 0; i < useB; i++) {   // fixReverseTraceSeqPosAndOrder (:543-565)
+		for (uint32_t i = lane; i < useB; i += 64) {   // fixReverseTraceSeqPosAndOrder (:543-565)
 			TraceCell tc = unpackCell(tracePool[rb.traceOff + i]);
 			uint32_t off = tc.offsetAndSwitch & 255u;
 			int32_t id = g.nodeIDs[tc.node];
@@ -813,7 +818,7 @@ __global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __re
 			oc.nodeSwitch = (i + 1 < nB) ? ((unpackCell(tracePool[rb.traceOff + i + 1]).offsetAndSwitch >> 8) & 1u) : 0u;
 			outCells[i] = oc;
 		}
-		if (hasF) for (uint32_t i = 0; i < nF; i++) {   // fixForwardTraceSeqPos (:527-540), device order reversed
+		if (hasF) for (uint32_t i = lane; i < nF; i += 64) {   // fixForwardTraceSeqPos (:527-540), device order reversed
 			TraceCell tc = unpackCell(tracePool[rf.traceOff + (nF - 1 - i)]);
 			LongCell oc;
 			oc.node = g.nodeIDs[tc.node];
@@ -822,6 +827,8 @@ __global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __re
 			oc.nodeSwitch = (tc.offsetAndSwitch >> 8) & 1u;
 			outCells[useB + i] = oc;
 		}
+		__threadfence_block();
+		__syncthreads();   // the cells are read back below and by the next candidate's skip rules
 		LongAln al;
 		al.start = outCells[0].seqPos;
 		al.end = outCells[total - 1].seqPos + 1;
@@ -830,11 +837,18 @@ __global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __re
 		al.traceOff = base;
 		al.traceLen = total;
 		al.pad = 0;
-		mine[st.nAln++] = al;
-		st.e2eScore = endToEndScore(mine, st.nAln, (uint32_t)L, st.e2eScore);
+		uint32_t e2e = 0;
+		if (lane == 0) {
+			mine[st.nAln] = al;
+			e2e = endToEndScore(mine, st.nAln + 1, (uint32_t)L, st.e2eScore);
+		}
+		st.nAln++;
+		st.e2eScore = __shfl(e2e, 0);
+		__threadfence_block();
+		__syncthreads();
 	}
 	st.candCount = 0;
-	state[r] = st;
+	if (lane == 0) state[r] = st;
 }
 
 __global__ void __launch_bounds__(256) k_long_finish(uint32_t nReads, const LongState* __restrict__ state, LongReadResult* __restrict__ results)
@@ -948,7 +962,7 @@ void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTabl
 void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, const uint32_t* candSeed, const LongWorkResult* results,
 	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity)
 {
-	if (nReads) hipLaunchKernelGGL(k_long_merge, dim3((nReads + 63) / 64), dim3(64), 0, stream, g, jobs, nReads, seeds, candSeed, results, tracePool, maxAlignments, state, alns, cellPool, cellCursor, cellCapacity);
+	if (nReads) hipLaunchKernelGGL(k_long_merge, dim3(nReads), dim3(64), 0, stream, g, jobs, nReads, seeds, candSeed, results, tracePool, maxAlignments, state, alns, cellPool, cellCursor, cellCapacity);
 }
 void launchLongFinish(hipStream_t stream, uint32_t nReads, const LongState* state, LongReadResult* results)
 {
