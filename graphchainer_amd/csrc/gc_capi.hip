@@ -203,13 +203,17 @@ struct gc_stream {
 	// whole-read pass: runs on its own stream, concurrently with the fragment kernels
 	hipStream_t longStream = nullptr;
 	hipEvent_t longEv[2] {};
+	std::vector<hipStream_t> groupStreams;   // read groups of the whole-read pass run their round loops concurrently
+	std::vector<hipEvent_t> groupEvents;     // two per group
 	DeviceBuffer longSeeds, longJobs, longAlns, longResults, longScratch, longCells, longCursor, longJobsFallback, longResultsFallback, longScratchFallback;
-	DeviceBuffer longState, longWork, longWorkResults, longRoundTrace, longCandSeed, longWorkLen, longOrder;
+	DeviceBuffer longState, longWork, longWorkResults, longRoundTrace, longCandSeed;
 	PinnedBuffer hLongSeeds, hLongJobs, hLongAlns, hLongResults, hLongSmall, hLongWorkLen, hLongOrder;
 	~gc_stream()
 	{
 		for (auto& e : ev) if (e) (void)hipEventDestroy(e);
 		for (auto& e : longEv) if (e) (void)hipEventDestroy(e);
+		for (auto& e : groupEvents) if (e) (void)hipEventDestroy(e);
+		for (auto& q : groupStreams) if (q) (void)hipStreamDestroy(q);
 		if (stream) (void)hipStreamDestroy(stream);
 		if (longStream) (void)hipStreamDestroy(longStream);
 	}
@@ -752,7 +756,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		unsigned long long* hLongSmall = nullptr;
 		LongCell* dLongCells = nullptr;
 		std::function<uint64_t()> longFallback;
-		std::function<void()> runLongRounds;
+		std::function<void(uint32_t)> runLongGroup;
+		std::function<void()> finishLongGroups;
+		uint32_t longGroups = 0;
+		std::vector<double> groupExtendUs; std::vector<uint32_t> groupRounds; std::vector<uint64_t> groupBegin, groupTraceBegin;
 		if (P->long_pass) {
 			for (uint64_t r = 0; r < n; r++) { glue[r].longSeedBegin = nLongSeeds; nLongSeeds += glue[r].longSeeds.size(); maxReadLen = std::max<uint64_t>(maxReadLen, R->offsets[r + 1] - R->offsets[r]); }
 			if (nLongSeeds >= 0xffffffffull) throw std::runtime_error("batch too large for the whole-read pass");
@@ -794,80 +801,111 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			LongReadResult* dLongResults = st->longResults.reserve<LongReadResult>(n);
 			unsigned long long* dLongScratch = nullptr;
 			dLongCells = st->longCells.reserve<LongCell>(cellBudget);
-			unsigned long long* dLongCursor = st->longCursor.reserve<unsigned long long>(32);
+			// Read groups: the rounds of one group are serial (select -> extend -> merge, host decides when to stop). Groups can
+			// run their round loops concurrently, each on its own stream and host thread (GC_LONG_GROUPS). Measured on cfg2
+			// (10k reads): 1 group 367 ms/step, 2 groups 517, 4 groups 477, 8 groups 607 - the groups' big rounds coincide and
+			// their tails too, so nothing overlaps usefully and the kernels slow each other down. Default: one group.
+			uint32_t nGroups = 1;
+			if (const char* env = getenv("GC_LONG_GROUPS")) nGroups = (uint32_t)std::max(1, std::min(16, atoi(env)));
+			if (n < 64ull * nGroups) nGroups = 1;
+			while (st->groupStreams.size() < nGroups) {
+				hipStream_t q = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+				HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+				HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+				st->groupStreams.push_back(q); st->groupEvents.push_back(e0); st->groupEvents.push_back(e1);
+			}
+			// cursors: [0] cell pool, [8..15] counters (+ [16..31] profiling stamps), per group g at 32+8g: [+0] work count, [+1] round trace cursor
+			const uint32_t cursorWords = 32 + 8 * 16;
+			unsigned long long* dLongCursor = st->longCursor.reserve<unsigned long long>(cursorWords);
 			hLongAlns = st->hLongAlns.reserve<LongAln>(n * maxAlignments);
 			hLongResults = st->hLongResults.reserve<LongReadResult>(n);
-			hLongSmall = st->hLongSmall.reserve<unsigned long long>(32);
+			hLongSmall = st->hLongSmall.reserve<unsigned long long>(cursorWords);
 			hipStream_t ls = st->longStream;
-			HIP_CHECK(hipMemsetAsync(dLongCursor, 0, 32 * sizeof(unsigned long long), ls));
+			HIP_CHECK(hipMemsetAsync(dLongCursor, 0, cursorWords * sizeof(unsigned long long), ls));
 			if (nLongSeeds) HIP_CHECK(hipMemcpyAsync(dLongSeeds, hSeeds, nLongSeeds * sizeof(LongSeed), hipMemcpyHostToDevice, ls));
 			if (n) HIP_CHECK(hipMemcpyAsync(dLongJobs, hJobs, n * sizeof(LongJob), hipMemcpyHostToDevice, ls));
+			HIP_CHECK(hipStreamSynchronize(ls));   // the group streams start from uploaded inputs
 			// rounds: select -> extend -> merge until no read has a seed left to extend (see gc_kernels.hip, "K3-long in rounds")
 			LongState* dLongState = st->longState.reserve<LongState>(n);
-			const uint64_t workCapacity = 4 * n + 64;
+			const uint64_t workCapacity = 4 * n + 64ull * nGroups;   // all groups together; group g owns the slice for its reads
 			LongWork* dLongWork = st->longWork.reserve<LongWork>(workCapacity);
 			LongWorkResult* dLongWorkResults = st->longWorkResults.reserve<LongWorkResult>(workCapacity);
 			uint32_t* dCandSeed = st->longCandSeed.reserve<uint32_t>(workCapacity);
-			uint32_t* dWorkLen = st->longWorkLen.reserve<uint32_t>(workCapacity);
-			uint32_t* dOrder = st->longOrder.reserve<uint32_t>(workCapacity);
-			uint32_t* hWorkLen = st->hLongWorkLen.reserve<uint32_t>(workCapacity);
-			uint32_t* hOrder = st->hLongOrder.reserve<uint32_t>(workCapacity);
-			uint64_t roundTraceBudget = 0;
-			for (uint64_t r = 0; r < n; r++) { uint64_t len = R->offsets[r + 1] - R->offsets[r]; roundTraceBudget += 2 * (len + len / 2 + 1024); }   // up to two candidate seeds' worth per read (adaptive rounds never exceed one on average)
-			unsigned long long* dRoundTrace = st->longRoundTrace.reserve<unsigned long long>(roundTraceBudget);
-			// scratch for up to 2n work items in flight (one lane each), whatever the team size
+			uint32_t* hWorkLen = st->hLongWorkLen.reserve<uint32_t>(workCapacity);   // pinned host memory, written by k_long_select / read by k_long_extend directly:
+			uint32_t* hOrder = st->hLongOrder.reserve<uint32_t>(workCapacity);       // no copy-engine transfers inside the round loop (they queue behind the fragment pipeline's bulk uploads)
+			groupBegin.assign(nGroups + 1, 0); groupTraceBegin.assign(nGroups + 1, 0);
+			for (uint32_t g = 0; g <= nGroups; g++) groupBegin[g] = n * g / nGroups;
+			for (uint32_t g = 0; g < nGroups; g++) {
+				uint64_t budget = 0;
+				for (uint64_t r = groupBegin[g]; r < groupBegin[g + 1]; r++) { uint64_t len = R->offsets[r + 1] - R->offsets[r]; budget += 2 * (len + len / 2 + 1024); }   // up to two candidate seeds' worth per read (adaptive rounds never exceed one on average)
+				groupTraceBegin[g + 1] = groupTraceBegin[g] + budget;
+			}
+			unsigned long long* dRoundTrace = st->longRoundTrace.reserve<unsigned long long>(groupTraceBegin[nGroups]);
+			// extension scratch: one region per work item in flight
 			dLongScratch = st->longScratch.reserve<unsigned long long>((workCapacity + 64) * waveWords);
-			runLongRounds = [=]() {
-				launchLongInit(ls, dLongJobs, (uint32_t)n, dLongState);
-				double extendUs = 0;
+			groupExtendUs.assign(nGroups, 0.0);
+			groupRounds.assign(nGroups, 0);
+			double* groupExtendUsPtr = groupExtendUs.data();
+			uint32_t* groupRoundsPtr = groupRounds.data();
+			const uint64_t* groupBeginPtr = groupBegin.data();
+			const uint64_t* groupTraceBeginPtr = groupTraceBegin.data();
+			runLongGroup = [=](uint32_t g) {
+				const uint64_t r0 = groupBeginPtr[g], nG = groupBeginPtr[g + 1] - r0;
+				if (nG == 0) return;
+				hipStream_t q = st->groupStreams[g];
+				hipEvent_t ev0 = st->groupEvents[2 * g], ev1 = st->groupEvents[2 * g + 1];
+				const uint64_t w0 = 4 * r0 + 64ull * g, capacity = 4 * nG + 64;   // this group's slice of the work arrays
+				unsigned long long* cursor = dLongCursor + 32 + 8 * g;
+				volatile unsigned long long* hCursor = hLongSmall + 32 + 8 * g;
+				const uint64_t traceBudget = groupTraceBeginPtr[g + 1] - groupTraceBeginPtr[g];
+				launchLongInit(q, dLongJobs + r0, (uint32_t)nG, dLongState + r0);
 				uint32_t lastWork = 0xffffffffu;
 				for (int round = 0; round < 4096; round++) {
-					HIP_CHECK(hipMemsetAsync(dLongCursor + 1, 0, 2 * sizeof(unsigned long long), ls));   // [1] work count, [2] round trace cursor
+					HIP_CHECK(hipMemsetAsync(cursor, 0, 2 * sizeof(unsigned long long), q));   // [0] work count, [1] round trace cursor
 					// tail rounds: once fewer than a quarter of the reads are still active the chip is mostly idle, so the
 					// remaining reads try several seeds per round (exact: k_long_merge re-checks them in order)
 					// (the number of work items stays below what round 0 had: active reads x candidates <= n)
 					uint32_t maxCand = 1;
-					if (round > 0 && lastWork > 0) maxCand = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (2 * n) / lastWork));
+					if (round > 0 && lastWork > 0) maxCand = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (2 * nG) / lastWork));
 					if (const char* env = getenv("GC_LONG_SPECULATE")) maxCand = (uint32_t)std::min(2, std::max(1, atoi(env)));   // test hook: speculate from round 0
-					launchLongSelect(ls, G->dev, dLongJobs, (uint32_t)n, dLongSeeds, R->totalBases, (uint32_t)P->min_cluster_size, maxCand, dLongState, dLongAlns, dLongCells, dLongWork, dWorkLen, dCandSeed, dLongCursor + 1, workCapacity);
-					HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
-					HIP_CHECK(hipStreamSynchronize(ls));
-					uint32_t nWorkItems = (uint32_t)hLongSmall[1];
+					launchLongSelect(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, R->totalBases, (uint32_t)P->min_cluster_size, maxCand, dLongState + r0, dLongAlns, dLongCells, dLongWork + w0, hWorkLen + w0, dCandSeed + w0, cursor, capacity);
+					launchPublish(q, cursor, (unsigned long long*)hCursor, 2);
+					HIP_CHECK(hipStreamSynchronize(q));
+					uint32_t nWorkItems = (uint32_t)hCursor[0];
 					if (nWorkItems == 0) break;
 					uint32_t team = longExtendTeamSize(nWorkItems);
 					uint32_t blocks = (nWorkItems + team - 1) / team;
-					// Execution order. A wave runs as long as its longest extension and every step costs the maximum over its
-					// lanes, so which extensions share a wave and which waves start first decides the round's critical path.
+					// Execution order: longest extensions first, so the round's tail is made of short ones.
 					{
-						HIP_CHECK(hipMemcpyAsync(hWorkLen, dWorkLen, nWorkItems * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
-						HIP_CHECK(hipStreamSynchronize(ls));
-						for (uint32_t i = 0; i < nWorkItems; i++) hOrder[i] = i;
+						uint32_t* order = hOrder + w0;
+						const uint32_t* len = hWorkLen + w0;
+						for (uint32_t i = 0; i < nWorkItems; i++) order[i] = i;
 						const char* mode = getenv("GC_LONG_ORDER");
 						int m = mode ? atoi(mode) : 1;
-						if (m >= 1) std::stable_sort(hOrder, hOrder + nWorkItems, [&](uint32_t a, uint32_t b) { return hWorkLen[a] > hWorkLen[b]; });
-						if (m == 2) {   // wave j gets sorted[j], sorted[j + blocks], ...: one extension of every length class per wave
-							std::vector<uint32_t> sorted(hOrder, hOrder + nWorkItems);
-							uint32_t at = 0;
-							for (uint32_t j = 0; j < blocks; j++)
-								for (uint32_t k = 0; k < team; k++) { uint64_t src = (uint64_t)k * blocks + j; if (src < nWorkItems) hOrder[at++] = sorted[src]; }
-							for (; at < nWorkItems; at++) hOrder[at] = sorted[at];   // (not reached: every source index below nWorkItems is visited once)
-						}
-						HIP_CHECK(hipMemcpyAsync(dOrder, hOrder, nWorkItems * sizeof(uint32_t), hipMemcpyHostToDevice, ls));
+						if (m >= 1) std::stable_sort(order, order + nWorkItems, [&](uint32_t a, uint32_t b) { return len[a] > len[b]; });
 					}
-					HIP_CHECK(hipEventRecord(st->longEv[0], ls));
-					launchLongExtend(ls, G->dev, G->devTables, R->devMasks, lcfg, dLongWork, dOrder, nWorkItems, dLongScratch, team, blocks, dRoundTrace, dLongCursor + 2, roundTraceBudget, dLongWorkResults, dLongCursor + 8);
-					HIP_CHECK(hipEventRecord(st->longEv[1], ls));
-					launchLongMerge(ls, G->dev, dLongJobs, (uint32_t)n, dLongSeeds, dCandSeed, dLongWorkResults, dRoundTrace, maxAlignments, dLongState, dLongAlns, dLongCells, dLongCursor, cellBudget);
+					HIP_CHECK(hipEventRecord(ev0, q));
+					launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, hOrder + w0, nWorkItems, dLongScratch + (w0 + 64ull * g) * waveWords, team, blocks,
+						dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8);
+					HIP_CHECK(hipEventRecord(ev1, q));
+					launchLongMerge(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, dCandSeed + w0, dLongWorkResults + w0, dRoundTrace + groupTraceBeginPtr[g], maxAlignments, dLongState + r0, dLongAlns, dLongCells, dLongCursor, cellBudget);
 					lastWork = nWorkItems;
-					HIP_CHECK(hipStreamSynchronize(ls));
+					HIP_CHECK(hipStreamSynchronize(q));
 					float ms = 0;
-					HIP_CHECK(hipEventElapsedTime(&ms, st->longEv[0], st->longEv[1]));
-					extendUs += (double)ms * 1000.0;
-					res->counters_long[6]++;   // rounds
+					HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
+					groupExtendUsPtr[g] += (double)ms * 1000.0;
+					groupRoundsPtr[g]++;
 				}
-				launchLongFinish(ls, (uint32_t)n, dLongState, dLongResults);
-				if (n) HIP_CHECK(hipMemcpyAsync(hLongResults, dLongResults, n * sizeof(LongReadResult), hipMemcpyDeviceToHost, ls));
-				res->kernel_us[4] = extendUs;
+				launchLongFinish(q, (uint32_t)nG, dLongState + r0, dLongResults + r0);
+				HIP_CHECK(hipMemcpyAsync(hLongResults + r0, dLongResults + r0, nG * sizeof(LongReadResult), hipMemcpyDeviceToHost, q));
+				HIP_CHECK(hipStreamSynchronize(q));
+			};
+			longGroups = nGroups;
+			finishLongGroups = [=]() {   // after the group threads joined (vectors above are alive until the end of this call)
+				double us = 0; uint32_t rounds = 0;
+				for (uint32_t g = 0; g < nGroups; g++) { us += groupExtendUsPtr[g]; rounds = std::max(rounds, groupRoundsPtr[g]); }
+				res->kernel_us[4] = us;
+				res->counters_long[6] = rounds;
 			};
 			// reads whose band did not fit the LDS tables (status 5) are rerun with the plain-layout kernel
 			longFallback = [=, &glue]() {
@@ -899,20 +937,24 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		}
 		// The whole-read pass is the longest leg of the batch: its round loop runs on its own host thread and stream from
 		// here on, while this thread prepares and runs the fragment pipeline.
-		std::thread longThread;
-		std::exception_ptr longError;
-		struct JoinGuard { std::thread& t; ~JoinGuard() { if (t.joinable()) t.join(); } } joinGuard { longThread };
+		std::vector<std::thread> longThreads;
+		std::vector<std::exception_ptr> longErrors(16);
+		double tLongWall0 = nowUs();
+		std::atomic<double> longWallEndUs { 0.0 };
+		struct JoinGuard { std::vector<std::thread>& t; ~JoinGuard() { for (auto& x : t) if (x.joinable()) x.join(); } } joinGuard { longThreads };
 		if (P->long_pass) {
 			int device = 0;
 			HIP_CHECK(hipGetDevice(&device));
-			longThread = std::thread([&, device]() {
-				try {
-					HIP_CHECK(hipSetDevice(device));
-					runLongRounds();
-				} catch (...) { longError = std::current_exception(); }
-			});
+			for (uint32_t g = 0; g < longGroups; g++)
+				longThreads.emplace_back([&, device, g]() {
+					try {
+						HIP_CHECK(hipSetDevice(device));
+						runLongGroup(g);
+					} catch (...) { longErrors[g] = std::current_exception(); }
+					double now = nowUs(), seen = longWallEndUs.load();
+					while (now > seen && !longWallEndUs.compare_exchange_weak(seen, now)) {}
+				});
 		}
-
 		double tLongStarted = nowUs();
 		pool.run(n, [&](size_t r, size_t) {
 			ReadGlue& gl = glue[r];
@@ -1067,8 +1109,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		// ---------------- whole-read pass results
 		std::vector<LongCell> longCells;
 		if (P->long_pass) {
-			longThread.join();
-			if (longError) std::rethrow_exception(longError);
+			for (auto& t : longThreads) t.join();
+			for (auto& e : longErrors) if (e) std::rethrow_exception(e);
+			finishLongGroups();
+			res->kernel_us[5] = longWallEndUs.load() - tLongWall0;   // whole-read pass, wall clock from the first group's start to the last group's end
 			uint64_t rerun = longFallback();
 			res->counters_long[7] = rerun;   // reads that needed the plain-layout fallback kernel
 			for (int i = 0; i < 6; i++) res->counters_long[i] = hLongSmall[8 + i];   // same units as counters[]

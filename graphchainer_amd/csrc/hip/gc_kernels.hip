@@ -719,8 +719,9 @@ __global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessT
 	unsigned long long* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, LongWorkResult* __restrict__ results, unsigned long long* __restrict__ counters)
 {
 	__shared__ WaveLdsT<LANES> lds;
-	const uint32_t lane = threadIdx.x;
-	if (lane >= LANES) return;
+	if (threadIdx.x >= LANES) return;
+	// one extension per wave: nothing depends on the lane id, so the compiler can keep the extension's state in scalar registers
+	const uint32_t lane = LANES == 1 ? 0u : threadIdx.x;
 	WaveScratch wsx;
 	wsx.base = scratch + (uint64_t)blockIdx.x * wordsPerLane * LANES;
 	wsx.lane = lane;
@@ -851,6 +852,12 @@ __global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __re
 	if (lane == 0) state[r] = st;
 }
 
+// copies a few cursor words into pinned host memory through the compute queue (a copy-engine transfer would queue behind bulk uploads)
+__global__ void k_publish(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst, uint32_t nWords)
+{
+	if (threadIdx.x < nWords) { dst[threadIdx.x] = src[threadIdx.x]; __threadfence_system(); }
+}
+
 __global__ void __launch_bounds__(256) k_long_finish(uint32_t nReads, const LongState* __restrict__ state, LongReadResult* __restrict__ results)
 {
 	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -963,6 +970,10 @@ void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, u
 	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity)
 {
 	if (nReads) hipLaunchKernelGGL(k_long_merge, dim3(nReads), dim3(64), 0, stream, g, jobs, nReads, seeds, candSeed, results, tracePool, maxAlignments, state, alns, cellPool, cellCursor, cellCapacity);
+}
+void launchPublish(hipStream_t stream, const unsigned long long* src, unsigned long long* dst, uint32_t nWords)
+{
+	hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, stream, src, dst, nWords);
 }
 void launchLongFinish(hipStream_t stream, uint32_t nReads, const LongState* state, LongReadResult* results)
 {

@@ -137,7 +137,9 @@ typedef struct gc_result {
 	uint64_t counters[8];
 	uint64_t counters_long[8];    /* the same for the whole-read pass */
 	/* device time of each kernel of this batch in microseconds (HIP events on the stream):
-	 * [0] seed lookup, [1] fragment extension, [2] anchor build, [3] chaining, [4] whole-read pass (own stream, overlaps 1-3) */
+	 * [0] seed lookup, [1] fragment extension, [2] anchor build, [3] chaining, [4] whole-read extension kernels, summed over all
+	 * rounds of all read groups (the groups run concurrently on their own streams, so this can exceed the wall clock),
+	 * [5] whole-read pass wall clock, first group's start to last group's end (host clock; overlaps 1-3) */
 	double kernel_us[8];
 	double host_us[4];            /* wall time: [0] host seed glue, [1] result assembly, [2] seed lookup + transfers, [3] extension..chaining + transfers */
 } gc_result;

@@ -144,3 +144,17 @@ def test_whole_read_pass_speculative_rounds(gca, tmp_path, monkeypatch):
     reads.append(reads[2][:2500] + reads[5][1000:4000])
     got, want = run_case(gca, gfa, reads, long_pass=True)
     compare(got, want, COMPARE_KEYS + LONG_KEYS)
+
+
+@pytest.mark.parametrize("env", [{"GC_LONG_GROUPS": "2"}, {"GC_LONG_TEAM": "8"}, {"GC_LONG_TEAM": "64", "GC_LONG_ORDER": "0"}])
+def test_whole_read_pass_launch_shapes(gca, tmp_path, monkeypatch, env):
+    """Launch-shape knobs of the whole-read pass (concurrent read groups, lanes per wave, execution order) never change results."""
+    from graphchainer_amd.synth import SynthGraph
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sg = SynthGraph(120_000, seed=3)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(140, 2500, seed=9)
+    got, want = run_case(gca, gfa, reads, long_pass=True)
+    compare(got, want, COMPARE_KEYS + LONG_KEYS)
