@@ -662,52 +662,75 @@ __device__ inline int seedSkipped(const DGraph& g, const LongSeed& sd, const Lon
 	return 0;
 }
 
-// One lane per read: advance to the next seed(s) that need extending and emit their work items. With
-// maxCandidates > 1 (used for the tail rounds, when few reads are still active and the chip is idle) further seeds are
-// emitted speculatively: they pass the skip rules against the alignments known now; k_long_merge re-checks each of
-// them against the alignments added before it in the same round, so the outcome equals one-seed-per-round.
+// One wave per read: advance to the next seed(s) that need extending and emit their work items. The skip rules of 64
+// seeds are evaluated at once (each is a chain of dependent loads: a binary search in every alignment's trace), then
+// the reference's in-order scan is replayed on the ballot masks. With maxCandidates > 1 (used for the tail rounds,
+// when few reads are still active and the chip is idle) further seeds are emitted speculatively: they pass the skip
+// rules against the alignments known now; k_long_merge re-checks each of them against the alignments added before it
+// in the same round, so the outcome equals one-seed-per-round.
 #define LONG_MAX_CANDIDATES 8
 __global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __restrict__ jobs, uint32_t nReads, const LongSeed* __restrict__ seeds, uint64_t rcBase, uint32_t minClusterSize,
 	uint32_t maxCandidates, LongState* __restrict__ state, const LongAln* __restrict__ alns, const LongCell* __restrict__ cellPool, LongWork* __restrict__ work, uint32_t* __restrict__ workLen, uint32_t* __restrict__ candSeed,
 	unsigned long long* __restrict__ workCount, uint64_t workCapacity)
 {
-	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t r = blockIdx.x, lane = threadIdx.x;
 	if (r >= nReads) return;
 	LongState st = state[r];
 	st.candCount = 0;
-	if (st.status != 0) { state[r] = st; return; }
+	if (st.status != 0) { if (lane == 0) state[r] = st; return; }
 	LongJob job = jobs[r];
 	const LongAln* mine = alns + job.alnBegin;
 	uint32_t cand[LONG_MAX_CANDIDATES];
 	uint32_t nCand = 0;
 	uint32_t si = st.si;
-	for (; st.status == 0 && si < job.seedEnd && nCand < maxCandidates; si++) {
-		LongSeed sd = seeds[si];
-		if (sd.goodness < st.e2eScore) { si = job.seedEnd; break; }   // aligned end to end (:127-131)
-		if (sd.clusterSize < minClusterSize) continue;                 // :141-146
-		int sk = seedSkipped(g, sd, mine, 0, st.nAln, cellPool);
-		if (sk == 2) { st.status = 1; break; }
-		if (sk == 1) continue;
-		cand[nCand++] = si;
+	bool stop = false;
+	while (!stop && si < job.seedEnd) {
+		const uint32_t idx = si + lane;
+		const bool valid = idx < job.seedEnd;
+		LongSeed sd = seeds[valid ? idx : si];
+		const bool cut = valid && sd.goodness < st.e2eScore;                     // aligned end to end (:127-131)
+		const bool small = sd.clusterSize < minClusterSize;                       // :141-146
+		int sk = 1;
+		if (valid && !cut && !small) sk = seedSkipped(g, sd, mine, 0, st.nAln, cellPool);
+		const uint64_t cutMask = __ballot(cut), assertMask = __ballot(sk == 2), candMask = __ballot(sk == 0);
+		const uint32_t nValid = job.seedEnd - si < 64 ? job.seedEnd - si : 64;
+		const uint32_t firstCut = cutMask ? (uint32_t)__ffsll((unsigned long long)cutMask) - 1 : 64;
+		const uint32_t limit = firstCut < nValid ? firstCut : nValid;
+		uint32_t b = 0;
+		for (; b < limit; b++) {   // the reference's scan, in seed order (uniform across the wave)
+			if ((assertMask >> b) & 1) { st.status = 1; stop = true; break; }
+			if ((candMask >> b) & 1) {
+				for (uint32_t k = 0; k < LONG_MAX_CANDIDATES; k++) if (k == nCand) cand[k] = si + b;
+				nCand++;
+				if (nCand == maxCandidates) { b++; stop = true; break; }
+			}
+		}
+		si += b;
+		if (!stop && firstCut < nValid) { si = job.seedEnd; stop = true; }
 	}
 	st.si = si;
 	if (nCand > 0) {
-		unsigned long long at = atomicAdd(workCount, 2ull * nCand);
+		unsigned long long at = 0;
+		if (lane == 0) at = atomicAdd(workCount, 2ull * nCand);
+		at = __shfl(at, 0);
 		if (at + 2ull * nCand > workCapacity) { st.status = 2; nCand = 0; }
 		st.candBegin = (uint32_t)(at / 2);
 		st.candCount = nCand;
-		for (uint32_t c = 0; c < nCand; c++) {
-			LongSeed sd = seeds[cand[c]];
+		uint32_t myCand = 0;
+		for (uint32_t k = 0; k < LONG_MAX_CANDIDATES; k++) if (k == lane) myCand = cand[k];
+		if (lane < nCand) {
+			const uint32_t c = lane;
+			LongSeed sd = seeds[myCand];
 			const uint32_t L = job.readLen, p = sd.seqPos;
 			// backward: rows are revcomp(read[0..p)) = reverse-complement strand from position L-p; forward: read(p..] from p+1
 			work[at + 2 * c] = LongWork { job.maskOff + 4ull * job.maskWords, job.maskWords, L - p, p, sd.twinNode, sd.twinOffset, r };
 			work[at + 2 * c + 1] = LongWork { job.maskOff, job.maskWords, p + 1, L - 1 - p, sd.node, sd.offset, r };
 			workLen[at + 2 * c] = p;
 			workLen[at + 2 * c + 1] = L - 1 - p;
-			candSeed[at / 2 + c] = cand[c];
+			candSeed[at / 2 + c] = myCand;
 		}
 	}
-	state[r] = st;
+	if (lane == 0) state[r] = st;
 }
 
 // LANES = active lanes per wave ("team"). The pass is latency-bound and leaves most of the chip idle, so when there
@@ -937,7 +960,7 @@ void launchLongSelect(hipStream_t stream, const DGraph& g, const LongJob* jobs, 
 {
 	if (maxCandidates < 1) maxCandidates = 1;
 	if (maxCandidates > LONG_MAX_CANDIDATES) maxCandidates = LONG_MAX_CANDIDATES;
-	if (nReads) hipLaunchKernelGGL(k_long_select, dim3((nReads + 63) / 64), dim3(64), 0, stream, g, jobs, nReads, seeds, rcBase, minClusterSize, maxCandidates, state, alns, cellPool, work, workLen, candSeed, workCount, workCapacity);
+	if (nReads) hipLaunchKernelGGL(k_long_select, dim3(nReads), dim3(64), 0, stream, g, jobs, nReads, seeds, rcBase, minClusterSize, maxCandidates, state, alns, cellPool, work, workLen, candSeed, workCount, workCapacity);
 }
 uint32_t longExtendTeamSize(uint32_t nWork)
 {
