@@ -124,20 +124,23 @@ def main():
     reads_per_s = reads_total / elapsed
     gbp_per_s = aligned_bases * world * args.steps / elapsed / 1e9
 
-    # roofline of the dominant kernel (longest average launch: k_long_pass when the whole-read pass runs, else k_extend):
+    # roofline of the dominant kernel (most device time per step: k_long_extend when the whole-read pass runs, else k_extend):
     # algorithmic bytes per launch (SURVEY.md §8d unit x the counts the kernel reports) / its HIP-event duration
-    def kernel_roofline(name, cnt, us):
+    def kernel_roofline(name, cnt, us, launches=1.0):
+        # `us` = the kernel's HIP-event time summed over its launches of one step (k_long_extend: one launch per round)
         dp_tiles, recompute_tiles, column_steps, trace_items, _ext, backtrace_tiles = cnt[:6]
         nbytes = BYTES_PER_TILE * (dp_tiles + recompute_tiles) + BYTES_PER_BACKTRACE_TILE * backtrace_tiles + BYTES_PER_TRACE_ITEM * trace_items
         seconds = us * 1e-6
         achieved = nbytes / seconds / 1e9 if seconds > 0 else 0.0
+        launches = max(1.0, launches)
         return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": round(us / 1e3, 3),
-                "tiles_per_launch": int(dp_tiles + recompute_tiles), "column_steps_per_s_G": round(column_steps / seconds / 1e9, 3) if seconds > 0 else 0.0}
+                "launches_per_step": round(launches, 2),
+                "algorithmic_bytes_per_launch": int(nbytes / launches), "avg_launch_ms": round(us / 1e3 / launches, 3),
+                "tiles_per_launch": int((dp_tiles + recompute_tiles) / launches), "column_steps_per_s_G": round(column_steps / seconds / 1e9, 3) if seconds > 0 else 0.0}
 
     roof_extend = kernel_roofline("k_extend", counters, kernel_us[1])
-    roof_long = kernel_roofline("k_long_pass", counters_long, kernel_us[4]) if long_pass else None
+    roof_long = kernel_roofline("k_long_extend", counters_long, kernel_us[4], counters_long[6]) if long_pass else None
     roofline = roof_long if (long_pass and kernel_us[4] >= kernel_us[1]) else roof_extend
     extensions = counters[4]
 
@@ -166,11 +169,11 @@ def main():
             "roofline_other": roof_extend if roofline is roof_long else roof_long,
             "cpu_baseline": cpu_baseline,
             "stage_ms": {"k_seed_lookup": round(kernel_us[0] / 1e3, 3), "k_extend": round(kernel_us[1] / 1e3, 3), "k_build_anchors": round(kernel_us[2] / 1e3, 3),
-                         "k_chain": round(kernel_us[3] / 1e3, 3), "k_long_pass": round(kernel_us[4] / 1e3, 3), "host_seed_glue": round(host_us[0] / 1e3, 3), "host_result_assembly": round(host_us[1] / 1e3, 3),
+                         "k_chain": round(kernel_us[3] / 1e3, 3), "k_long_extend_all_rounds": round(kernel_us[4] / 1e3, 3), "whole_read_pass_wall": round(kernel_us[5] / 1e3, 3), "host_seed_glue": round(host_us[0] / 1e3, 3), "host_result_assembly": round(host_us[1] / 1e3, 3),
                          "wall_seed_lookup_and_copies": round(host_us[2] / 1e3, 3), "wall_extend_to_chain_and_copies": round(host_us[3] / 1e3, 3)},
             "setup_s": {"generate": round(t_gen, 1), "graph_build_upload": round(t_graph, 1), "minimizer_index": round(t_index, 1)},
             "reads_with_chain": int((chain_len > 0).sum()), "extensions_per_step": int(extensions),
-            "long_pass": {"reads_with_alignment": int((n_long > 0).sum()), "extensions_per_step": int(counters_long[4]), "plain_layout_reruns": int(counters_long[7]),
+            "long_pass": {"reads_with_alignment": int((n_long > 0).sum()), "extensions_per_step": int(counters_long[4]), "rounds": int(counters_long[6]), "plain_layout_reruns": int(counters_long[7]),
                           "seeds_extended_mean": round(float(out["seeds_extended_long"].mean()), 2), "seeds_extended_max": int(out["seeds_extended_long"].max())} if long_pass else None,
         }
         print(json.dumps(line))

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
 
 class GcParams(C.Structure):
     _fields_ = [("bandwidth", C.c_int32), ("split_len", C.c_int32), ("split_gap", C.c_int32), ("colinear_gap", C.c_int64),
-                ("seed_density", C.c_double), ("min_cluster_size", C.c_int32), ("long_pass", C.c_int32), ("keep_traces", C.c_int32), ("keep_seeds", C.c_int32)]
+                ("seed_density", C.c_double), ("min_cluster_size", C.c_int32), ("long_pass", C.c_int32), ("keep_traces", C.c_int32), ("keep_seeds", C.c_int32), ("stitch", C.c_int32)]
 
 
 _P = C.POINTER
@@ -49,6 +49,7 @@ class GcResult(C.Structure):
         ("long_trace_off", _P(C.c_uint64)), ("long_trace_node", _P(C.c_int32)), ("long_trace_offset", _P(C.c_uint32)),
         ("long_trace_seqpos", _P(C.c_uint32)), ("long_trace_switch", _P(C.c_uint8)),
         ("failed_assertion", _P(C.c_uint8)), ("seeds_extended", _P(C.c_uint64)), ("seeds_extended_long", _P(C.c_uint64)),
+        ("read_path_off", _P(C.c_uint64)), ("path_node", _P(C.c_uint32)), ("path_first_offset", _P(C.c_uint32)), ("path_last_offset", _P(C.c_uint32)), ("path_cells", _P(C.c_uint64)),
         ("counters", C.c_uint64 * 8), ("counters_long", C.c_uint64 * 8), ("kernel_us", C.c_double * 8), ("host_us", C.c_double * 4),
     ]
 
@@ -204,7 +205,7 @@ _RESULT_FIELDS = {
 class Aligner:
     """Batched stand-in for the reference's per-read hot path (src/Aligner.cpp:601-922)."""
 
-    def __init__(self, graph, seeder, bandwidth=10, split_len=35, split_gap=35, colinear_gap=10000, seed_density=10.0, keep_traces=False, keep_seeds=False, long_pass=False):
+    def __init__(self, graph, seeder, bandwidth=10, split_len=35, split_gap=35, colinear_gap=10000, seed_density=10.0, keep_traces=False, keep_seeds=False, long_pass=False, stitch=True):
         self.lib = load_library()
         self.graph = graph
         self.seeder = seeder
@@ -218,6 +219,7 @@ class Aligner:
         self.params.keep_traces = int(keep_traces)
         self.params.keep_seeds = int(keep_seeds)
         self.params.long_pass = int(long_pass)
+        self.params.stitch = int(stitch)
         self.stream = C.c_void_p()
         _check(self.lib.gc_stream_create(C.byref(self.stream)))
 
@@ -243,6 +245,12 @@ class Aligner:
             chains = int(out["read_chain_off"][-1])
             out["read_longall_off"] = arr(r.read_longall_off, n + 1)
             longs = int(out["read_longall_off"][-1])
+            out["read_path_off"] = arr(r.read_path_off, n + 1)
+            cells_path = int(out["read_path_off"][-1])
+            out["path_node"] = arr(r.path_node, cells_path)
+            out["path_first_offset"] = arr(r.path_first_offset, n)
+            out["path_last_offset"] = arr(r.path_last_offset, n)
+            out["path_cells"] = arr(r.path_cells, n)
             counts = {"n": n, "n+1": n + 1, "seeds": seeds, "anchors": anchors, "paths": paths, "chains": chains, "longs": longs}
             for name, expr in _RESULT_FIELDS.items():
                 if name in out:

@@ -18,6 +18,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 using namespace gcdev;
@@ -384,6 +385,8 @@ static void requireDevice()
 
 namespace {
 
+struct StitchedPath { std::vector<uint32_t> nodes; uint32_t firstOffset = 0, lastOffset = 0; uint64_t cells = 0; };
+
 struct ReadGlue {
 	std::vector<gc::SeedRec> seeds;       // fragment-pass order (by seqPos)
 	std::vector<gc::SeedRec> longSeeds;   // whole-read pass order (by goodness), only with long_pass
@@ -393,7 +396,69 @@ struct ReadGlue {
 	bool failed = false;
 	uint64_t slotBegin = 0, fragBegin = 0;
 	uint64_t nAnchors = 0, nPath = 0, nTrace = 0, anchorBegin = 0, pathBegin = 0, traceBegin = 0, seedBegin = 0, chainBegin = 0;
+	StitchedPath stitched;                // chain stitching result
+	uint64_t stitchedBegin = 0;
 };
+
+// Chain stitching, reference: src/Aligner.cpp:754-822 (+ pathToTrace :409-424, getChainPath src/AlignmentGraph.cpp:1866-1916).
+// The chain's anchor paths are concatenated; consecutive anchors that are not adjacent are bridged by the fewest-hops
+// path (bounded BFS); where no bridge exists within --colinear-gap the path is cut and the longest piece (most graph
+// bases, the size of the reference's pathToTrace vector) is kept. `slots` = this read's kept anchors in anchor-index
+// order. The piece is returned as its node path plus the offsets of its first and last base; pathToTrace's cell list
+// (one entry per base) follows from those and is not materialised here.
+static void stitchChain(const gc::AlignmentGraph& graph, long long colinearGap, const uint32_t* chain, uint32_t chainLen, const uint32_t* slots,
+	const AnchorRec* anchors, const uint32_t* pathPool, StitchedPath& longest)
+{
+	std::vector<size_t> posPath;
+	std::unordered_set<size_t> nodes;
+	size_t firstNodeOffset = 0, lastNodeOffset = 0;
+	longest = StitchedPath();
+	auto keepIfLonger = [&]() {
+		uint64_t cells = 0;   // size of pathToTrace(posPath, firstNodeOffset, lastNodeOffset), src/Aligner.cpp:409-424
+		for (size_t node : posPath) {
+			size_t S = 0, L = graph.NodeLength(node);
+			if (node == posPath[0]) S = firstNodeOffset;
+			else if (node == posPath.back()) L = lastNodeOffset + 1;
+			cells += L > S ? L - S : 0;
+		}
+		if (longest.cells < cells) {
+			longest.nodes.assign(posPath.begin(), posPath.end());
+			longest.firstOffset = (uint32_t)firstNodeOffset;
+			longest.lastOffset = (uint32_t)lastNodeOffset;
+			longest.cells = cells;
+		}
+	};
+	for (uint32_t c = 0; c < chainLen; c++) {
+		const AnchorRec& a = anchors[slots[chain[c]]];
+		const uint32_t* apath = pathPool + a.pathOff;
+		if (posPath.empty()) {
+			posPath.assign(apath, apath + a.pathLen);
+			firstNodeOffset = a.firstOffset;
+			lastNodeOffset = a.lastOffset;
+			for (size_t j : posPath) nodes.insert(j);
+		} else {
+			bool gap = apath[0] == posPath.back() && colinearGap != -1 && (long long)a.firstOffset - (long long)lastNodeOffset > colinearGap + 1;
+			std::vector<size_t> bridge;
+			if (!nodes.count(apath[0]) && posPath.back() != a.firstNode) {
+				long long gapLimit = colinearGap;
+				if (gapLimit != -1) gapLimit -= (long long)a.firstOffset + (long long)(graph.NodeLength(posPath.back()) - (long long)lastNodeOffset - 1);
+				bridge = graph.getChainPath(posPath.back(), a.firstNode, gapLimit);
+				if (bridge.empty()) gap = true;
+			}
+			if (gap) {
+				keepIfLonger();
+				nodes.clear();
+				posPath.clear();
+				firstNodeOffset = a.firstOffset;
+			} else {
+				for (size_t j : bridge) if (!nodes.count(j)) { nodes.insert(j); posPath.push_back(j); }
+			}
+			for (uint32_t k = 0; k < a.pathLen; k++) { size_t j = apath[k]; if (!nodes.count(j)) { nodes.insert(j); posPath.push_back(j); } }
+			lastNodeOffset = a.lastOffset;
+		}
+	}
+	if (!posPath.empty()) keepIfLonger();
+}
 
 template <typename T> T* copyOut(const std::vector<T>& v)
 {
@@ -433,6 +498,7 @@ void gc_params_default(gc_params* p)
 	p->long_pass = 0;
 	p->keep_traces = 0;
 	p->keep_seeds = 0;
+	p->stitch = 1;
 }
 
 int gc_graph_create_from_gfa(const char* gfa_path, gc_graph** out)
@@ -682,7 +748,7 @@ void gc_result_free(gc_result* r)
 		r->anchor_path, r->anchor_first_node, r->anchor_first_offset, r->anchor_first_seqpos, r->anchor_last_node, r->anchor_last_offset, r->anchor_last_seqpos, r->anchor_score,
 		r->anchor_trace_off, r->anchor_trace_node, r->anchor_trace_offset, r->anchor_trace_seqpos, r->anchor_trace_switch, r->read_chain_off, r->chain, r->chain_score,
 		r->read_longall_off, r->longall_start, r->longall_end, r->longall_score, r->long_trace_off, r->long_trace_node, r->long_trace_offset, r->long_trace_seqpos, r->long_trace_switch,
-		r->failed_assertion, r->seeds_extended, r->seeds_extended_long };
+		r->failed_assertion, r->seeds_extended, r->seeds_extended_long, r->read_path_off, r->path_node, r->path_first_offset, r->path_last_offset, r->path_cells };
 	for (void* p : ptrs) free(p);
 	free(r);
 }
@@ -1106,6 +1172,27 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		HIP_CHECK(hipStreamSynchronize(stream));
 		res->host_us[3] = nowUs() - tDev;   // K3..K4 + their transfers, wall
 
+		// ---------------- chain stitching (src/Aligner.cpp:754-822) on the host workers, while the whole-read pass still runs
+		double tStitch = nowUs();
+		if (P->stitch) {
+			pool.run(n, [&](size_t r, size_t) {
+				ReadGlue& gl = glue[r];
+				if (chainStatus[r] != 0 || chainLen[r] == 0) return;
+				std::vector<uint32_t> slots;
+				uint64_t slot = gl.slotBegin;
+				for (size_t f = 0; f < gl.windows.size(); f++) {
+					uint64_t F = gl.fragBegin + f;
+					uint32_t nS = frags[F].seedEnd - frags[F].seedBegin;
+					if (fragStatus[F] == 1) break;   // `cont` is never reset (src/Aligner.cpp:695-703)
+					for (uint32_t k = 0; k < nS; k++) if (anchors[slot + k].valid) slots.push_back((uint32_t)(slot + k - gl.slotBegin));
+					slot += nS;
+				}
+				stitchChain(hg, (long long)P->colinear_gap, chainOut + jobs[r].chainBegin, chainLen[r], slots.data(), anchors + gl.slotBegin, pathPool, gl.stitched);
+			});
+		}
+		double stitchUs = nowUs() - tStitch;
+		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] chain stitching %.1f ms\n", stitchUs / 1e3);
+
 		// ---------------- whole-read pass results
 		std::vector<LongCell> longCells;
 		if (P->long_pass) {
@@ -1185,12 +1272,13 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		});
 		if (overflow) throw std::runtime_error("extension capacity overflow in a fragment (raise GC_EXT_MAX_ITEMS / GC_EXT_MAX_PENDING / GC_EXT_MAX_TRACE)");
 		if (chainFailure) throw std::runtime_error("chaining kernel failure (status " + std::to_string((int)chainFailure) + ")");
-		uint64_t nAnchors = 0, nPath = 0, nTrace = 0, nChain = 0, nLong = 0, nLongTrace = 0;
+		uint64_t nAnchors = 0, nPath = 0, nTrace = 0, nChain = 0, nLong = 0, nLongTrace = 0, nStitched = 0;
 		for (uint64_t r = 0; r < n; r++) {
 			glue[r].anchorBegin = nAnchors; glue[r].pathBegin = nPath; glue[r].traceBegin = nTrace; glue[r].chainBegin = nChain;
 			glue[r].longBegin = nLong; glue[r].longTraceBegin = nLongTrace;
 			nAnchors += glue[r].nAnchors; nPath += glue[r].nPath; nTrace += glue[r].nTrace; nChain += chainLen[r];
 			nLong += glue[r].longAlns.size();
+			glue[r].stitchedBegin = nStitched; nStitched += glue[r].stitched.nodes.size();
 			if (P->keep_traces) for (const LongAln& a : glue[r].longAlns) nLongTrace += a.traceLen;
 		}
 		const bool keepSeeds = P->keep_seeds != 0;
@@ -1220,6 +1308,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		res->long_trace_node = mallocArray<int32_t>(nLongTrace); res->long_trace_offset = mallocArray<uint32_t>(nLongTrace);
 		res->long_trace_seqpos = mallocArray<uint32_t>(nLongTrace); res->long_trace_switch = mallocArray<uint8_t>(nLongTrace);
 		res->seeds_extended_long = mallocArray<uint64_t>(n);
+		res->read_path_off = mallocArray<uint64_t>(n + 1);
+		res->read_path_off[n] = nStitched;
+		res->path_node = mallocArray<uint32_t>(nStitched);
+		res->path_first_offset = mallocArray<uint32_t>(n); res->path_last_offset = mallocArray<uint32_t>(n); res->path_cells = mallocArray<uint64_t>(n);
 		res->failed_assertion = mallocArray<uint8_t>(n);
 		res->seeds_extended = mallocArray<uint64_t>(n);
 		res->read_seed_off[n] = keepSeeds ? nSeedsTotal : 0; res->read_anchor_off[n] = nAnchors; res->anchor_path_off[nAnchors] = nPath; res->read_chain_off[n] = nChain;
@@ -1237,6 +1329,9 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			res->seeds_extended[r] = seedsExtended[r];
 			res->seeds_extended_long[r] = seedsExtendedLong[r];
 			res->read_longall_off[r] = gl.longBegin;
+			res->read_path_off[r] = gl.stitchedBegin;
+			for (size_t i = 0; i < gl.stitched.nodes.size(); i++) res->path_node[gl.stitchedBegin + i] = gl.stitched.nodes[i];
+			res->path_first_offset[r] = gl.stitched.firstOffset; res->path_last_offset[r] = gl.stitched.lastOffset; res->path_cells[r] = gl.stitched.cells;
 			{
 				uint64_t la = gl.longBegin, lt = gl.longTraceBegin;
 				for (const LongAln& al : gl.longAlns) {

@@ -605,17 +605,26 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 			uint32_t hori = here.offset;
 			int vert = row;
 			NodeSeq nseq = loadNodeSeq(g, curNode);
+			// Values are tracked incrementally: a step up changes a column's value by its vertical delta bit, so the two
+			// columns are re-read (and one value recomputed from popcounts) only when the walk moves one column left.
+			WS ch = L.col(hori), cl = L.col(hori - 1);
+			int32_t scoreHere = wsValue(ch, vert), leftHere = wsValue(cl, vert);
 			while (hori > 0 && vert > 0) {
-				WS ch = L.col(hori), cl = L.col(hori - 1);
-				int32_t scoreHere = wsValue(ch, vert);
-				int32_t vertical = wsValue(ch, vert - 1);
-				int32_t diagonal = wsValue(cl, vert - 1);
+				int32_t vertical = scoreHere - (int32_t)((ch.VP >> vert) & 1) + (int32_t)((ch.VN >> vert) & 1);
+				int32_t diagonal = leftHere - (int32_t)((cl.VP >> vert) & 1) + (int32_t)((cl.VN >> vert) & 1);
 				int eqBit = (int)((eqOfColumn(eq, nseq, (int)hori) >> vert) & 1);
-				if (vertical == scoreHere - 1) { vert--; }
-				else if (diagonal == scoreHere - (eqBit ? 0 : 1)) { hori--; vert--; }
+				bool left = false;
+				if (vertical == scoreHere - 1) { vert--; scoreHere = vertical; leftHere = diagonal; }
+				else if (diagonal == scoreHere - (eqBit ? 0 : 1)) { hori--; vert--; scoreHere = diagonal; left = true; }
 				else {
-					if (wsValue(cl, vert) != scoreHere - 1) return EXT_ASSERT;
+					if (leftHere != scoreHere - 1) return EXT_ASSERT;
 					hori--;
+					scoreHere = leftHere;
+					left = true;
+				}
+				if (left) {
+					ch = cl;
+					if (hori > 0) { cl = L.col(hori - 1); leftHere = wsValue(cl, vert); }
 				}
 				if (!pushTraceW(Cell { curNode, hori, cs.j + vert }, false)) return status;
 			}

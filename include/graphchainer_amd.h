@@ -48,6 +48,7 @@ typedef struct gc_params {
 	int32_t long_pass;          /* 1: also run the whole-read GraphAligner pass (src/Aligner.cpp:630-654) */
 	int32_t keep_traces;        /* 1: return per-anchor traces (debug / parity tests) */
 	int32_t keep_seeds;         /* 1: return the ordered seed list of every read (seed_* arrays; else they are empty) */
+	int32_t stitch;             /* 1: stitch the chain into one path (src/Aligner.cpp:754-822): read_path_off / path_* */
 } gc_params;
 
 void gc_params_default(gc_params* p);
@@ -132,6 +133,13 @@ typedef struct gc_result {
 	uint8_t*  failed_assertion;   /* [n_reads] the reference would have thrown on this read */
 	uint64_t* seeds_extended;     /* [n_reads] fragment pass (stats.seedsExtended, src/Aligner.cpp:705) */
 	uint64_t* seeds_extended_long; /* [n_reads] whole-read pass (AlignmentResult::seedsExtended) */
+	/* chain stitching (stitch): the longest stitched piece of the chain (src/Aligner.cpp:754-822) as its split-node
+	 * path and the offsets of its first and last base. pathToTrace (src/Aligner.cpp:409-424) expands this to the
+	 * reference's `longest` vector, one (node, offset) cell per graph base; path_cells is that vector's size. */
+	uint64_t* read_path_off;      /* [n_reads+1] into path_node */
+	uint32_t* path_node;
+	uint32_t* path_first_offset; uint32_t* path_last_offset;   /* [n_reads] */
+	uint64_t* path_cells;         /* [n_reads] */
 	/* work counters of the fragment pass: [0] dp tiles, [1] recompute tiles (last-slice flatten + backtrace),
 	 * [2] column steps, [3] trace items, [4] extensions, [5] backtrace tiles (subset of [1]) */
 	uint64_t counters[8];

@@ -13,6 +13,7 @@ COMPARE_KEYS = [
     "anchor_last_node", "anchor_last_offset", "anchor_last_seqpos", "anchor_score",
     "anchor_trace_off", "anchor_trace_node", "anchor_trace_offset", "anchor_trace_seqpos", "anchor_trace_switch",
     "read_chain_off", "chain", "chain_score", "failed_assertion", "seeds_extended",
+    "read_path_off", "path_node", "path_offset",
 ]
 
 
@@ -43,8 +44,36 @@ def run_case(gca, gfa, reads, long_pass=False, **kw):
     seeder = gca.MinimizerSeeder(graph)
     aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, long_pass=long_pass, **kw)
     got = aligner.align_reads(reads)
+    expand_stitched_path(got, graph.array("nodeLength"))
     want = Oracle(gfa, long_pass=long_pass, **kw).align(reads)
     return got, want
+
+
+def expand_stitched_path(got, node_length):
+    """The C-ABI returns the stitched path as its node list + end offsets; expand it the way the reference's
+    pathToTrace does (src/Aligner.cpp:409-424: one (node, offset) cell per base, first node from its start offset,
+    last node - if it is not also the first - up to its last offset) so it compares with the oracle's `longest`."""
+    off = got["read_path_off"]
+    nodes_out, offs_out, read_off = [], [], [0]
+    for r in range(len(off) - 1):
+        path = got["path_node"][off[r]:off[r + 1]]
+        cells = 0
+        for node in path:
+            s, l = 0, int(node_length[node])
+            if node == path[0]:
+                s = int(got["path_first_offset"][r])
+            elif node == path[-1]:
+                l = int(got["path_last_offset"][r]) + 1
+            if l > s:
+                nodes_out.append(np.full(l - s, node, dtype=np.int64))
+                offs_out.append(np.arange(s, l, dtype=np.int64))
+                cells += l - s
+        assert cells == int(got["path_cells"][r])
+        read_off.append(read_off[-1] + cells)
+    got["path_nodes_raw"] = got["path_node"]
+    got["read_path_off"] = np.array(read_off, dtype=np.int64)
+    got["path_node"] = np.concatenate(nodes_out) if nodes_out else np.zeros(0, dtype=np.int64)
+    got["path_offset"] = np.concatenate(offs_out) if offs_out else np.zeros(0, dtype=np.int64)
 
 
 def test_reference_fixture(gca, golden_dir):
