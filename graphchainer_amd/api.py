@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "gc_params_default", "gc_graph_create_from_gfa", "gc_graph_create", "gc_graph_destroy", "gc_graph_num_nodes",
     "gc_graph_size_bp", "gc_graph_array", "gc_seeder_create", "gc_seeder_destroy", "gc_seeder_array",
     "gc_stream_create", "gc_stream_destroy", "gc_reads_upload", "gc_reads_destroy", "gc_align_batch",
-    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device",
+    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_edit_distance",
 ]
 
 
@@ -100,6 +100,24 @@ def device_count():
 
 def set_device(index):
     _check(load_library().gc_set_device(index))
+
+
+def edit_distance(a_list, b_list):
+    """Global (NW) edit distance of each (a, b) pair of byte strings on the GPU (edlib NW distance, src/Aligner.cpp:645,845)."""
+    assert len(a_list) == len(b_list)
+    lib = load_library()
+    n = len(a_list)
+    a = b"".join(a_list)
+    b = b"".join(b_list)
+    a_off = np.zeros(n + 1, dtype=np.uint64)
+    b_off = np.zeros(n + 1, dtype=np.uint64)
+    a_off[1:] = np.cumsum([len(x) for x in a_list], dtype=np.uint64) if n else []
+    b_off[1:] = np.cumsum([len(x) for x in b_list], dtype=np.uint64) if n else []
+    out = np.zeros(max(n, 1), dtype=np.int64)
+    lib.gc_edit_distance.restype = C.c_int
+    lib.gc_edit_distance.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    _check(lib.gc_edit_distance(a, a_off.ctypes.data, b, b_off.ctypes.data, n, out.ctypes.data))
+    return out[:n]
 
 
 def _fetch_array(fn, handle, name):

@@ -460,6 +460,52 @@ static void stitchChain(const gc::AlignmentGraph& graph, long long colinearGap, 
 	if (!posPath.empty()) keepIfLonger();
 }
 
+// Exact-match bit vectors of a read for the NW kernel: [A,C,G,T][words], bit i set when base i is exactly that letter.
+static void buildEqMasks(const char* seq, uint64_t len, uint64_t words, uint64_t* out)
+{
+	for (uint64_t i = 0; i < len; i++) {
+		int b = seq[i] == 'A' ? 0 : seq[i] == 'C' ? 1 : seq[i] == 'G' ? 2 : seq[i] == 'T' ? 3 : -1;
+		if (b >= 0) out[(uint64_t)b * words + (i >> 6)] |= 1ull << (i & 63);
+	}
+}
+
+// Runs the NW kernel over `pairs`, escalating the rows-per-lane unit (1, 2, 4, 8 blocks) for the pairs whose band does
+// not fit the smaller one. hPairs/hOut: pinned host staging; dPairs/dOut: device arrays of at least nPairs elements.
+static void runEditDistances(hipStream_t stream, EdPair* hPairs, int64_t* hOut, uint32_t nPairs, EdPair* dPairs, int64_t* dOut, const EdRead* dReads, const char* dBases,
+	const uint64_t* dEqMasks, const char* dLetters, const uint32_t* dLettersLen)
+{
+	if (!nPairs) return;
+	std::vector<uint32_t> todo(nPairs);
+	for (uint32_t i = 0; i < nPairs; i++) todo[i] = i;
+	std::vector<EdPair> sub;
+	std::vector<int64_t> subOut;
+	for (uint32_t unit = 1; unit <= 8 && !todo.empty(); unit *= 2) {
+		const bool all = todo.size() == nPairs;
+		if (all) {
+			HIP_CHECK(hipMemcpyAsync(dPairs, hPairs, (size_t)nPairs * sizeof(EdPair), hipMemcpyHostToDevice, stream));
+			launchEditDistance(stream, unit, dPairs, nPairs, dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut);
+			HIP_CHECK(hipMemcpyAsync(hOut, dOut, (size_t)nPairs * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipStreamSynchronize(stream));
+		} else {
+			sub.resize(todo.size());
+			subOut.resize(todo.size());
+			for (size_t i = 0; i < todo.size(); i++) sub[i] = hPairs[todo[i]];
+			HIP_CHECK(hipMemcpyAsync(dPairs, sub.data(), sub.size() * sizeof(EdPair), hipMemcpyHostToDevice, stream));
+			launchEditDistance(stream, unit, dPairs, (uint32_t)sub.size(), dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut);
+			HIP_CHECK(hipMemcpyAsync(subOut.data(), dOut, sub.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipStreamSynchronize(stream));
+			for (size_t i = 0; i < todo.size(); i++) hOut[todo[i]] = subOut[i];
+		}
+		std::vector<uint32_t> next;
+		for (uint32_t i : todo) {
+			if (hOut[i] == -3) throw std::runtime_error("path letters overflowed their slot");
+			if (hOut[i] == -2) next.push_back(i);
+		}
+		todo.swap(next);
+	}
+	if (!todo.empty()) throw std::runtime_error("edit distance band too wide for the NW kernel (more than 16128 edits on one read)");
+}
+
 template <typename T> T* copyOut(const std::vector<T>& v)
 {
 	T* p = mallocArray<T>(v.size());
@@ -473,6 +519,46 @@ extern "C" {
 
 const char* gc_last_error(void) { return g_lastError.c_str(); }
 void gc_free(void* p) { free(p); }
+
+// Global (NW) edit distances of n_pairs string pairs on the GPU: what edlibAlign(a, b, EDLIB_MODE_NW, EDLIB_TASK_DISTANCE)
+// returns at src/Aligner.cpp:645,845.
+int gc_edit_distance(const char* a, const uint64_t* a_off, const char* b, const uint64_t* b_off, uint64_t n_pairs, int64_t* out)
+{
+	if ((!a && n_pairs) || !a_off || (!b && n_pairs) || !b_off || !out) return fail(GC_ERR_INVALID, "null argument");
+	return guarded([&]() {
+		requireDevice();
+		if (n_pairs == 0) return (int)GC_OK;
+		if (n_pairs >= 0xffffffffull) throw std::runtime_error("too many pairs");
+		const uint64_t aBytes = a_off[n_pairs], bBytes = b_off[n_pairs];
+		std::vector<EdRead> reads(n_pairs);
+		uint64_t words = 0;
+		for (uint64_t i = 0; i < n_pairs; i++) {
+			uint64_t len = b_off[i + 1] - b_off[i];
+			if (len >= 0x7fffffffull || a_off[i + 1] - a_off[i] >= 0x7fffffffull) throw std::runtime_error("sequence too long");
+			reads[i] = EdRead { b_off[i], words, (uint32_t)len, (uint32_t)((len + 63) / 64 + 1) };
+			words += 4ull * reads[i].words;
+		}
+		std::vector<uint64_t> masks(words, 0);
+		for (uint64_t i = 0; i < n_pairs; i++) buildEqMasks(b + b_off[i], reads[i].len, reads[i].words, masks.data() + reads[i].eqOff);
+		std::vector<EdPair> pairs(n_pairs);
+		for (uint64_t i = 0; i < n_pairs; i++) {
+			uint32_t m = (uint32_t)(a_off[i + 1] - a_off[i]);
+			pairs[i] = EdPair { a_off[i], m, 0, (uint32_t)i, std::max<uint32_t>(64, (m + reads[i].len) / 16) };
+		}
+		DeviceBuffer dA, dB, dMasks, dReads, dPairs, dOut;
+		char* pa = dA.reserve<char>(aBytes); char* pb = dB.reserve<char>(bBytes);
+		uint64_t* pm = dMasks.reserve<uint64_t>(words);
+		EdRead* pr = dReads.reserve<EdRead>(n_pairs);
+		EdPair* pp = dPairs.reserve<EdPair>(n_pairs);
+		int64_t* po = dOut.reserve<int64_t>(n_pairs);
+		if (aBytes) HIP_CHECK(hipMemcpy(pa, a, aBytes, hipMemcpyHostToDevice));
+		if (bBytes) HIP_CHECK(hipMemcpy(pb, b, bBytes, hipMemcpyHostToDevice));
+		if (words) HIP_CHECK(hipMemcpy(pm, masks.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice));
+		HIP_CHECK(hipMemcpy(pr, reads.data(), n_pairs * sizeof(EdRead), hipMemcpyHostToDevice));
+		runEditDistances(nullptr, pairs.data(), out, (uint32_t)n_pairs, pp, po, pr, pb, pm, pa, nullptr);
+		return (int)GC_OK;
+	});
+}
 
 int gc_device_count(void)
 {

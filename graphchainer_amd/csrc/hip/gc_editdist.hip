@@ -1,0 +1,274 @@
+// Path sequences and global (NW) edit distances on the GPU - SURVEY.md §8 row f1.
+//
+// The reference decides between the whole-read alignment and the chained alignment by two edit distances per read:
+// edlibAlign(pathseq, read, EDLIB_MODE_NW) at src/Aligner.cpp:645 (path of the best whole-read alignment,
+// traceToSequence :376-408,425-428) and at :845 (path of the stitched chain). edlib itself (edlib/src/edlib.cpp,
+// Myers' bit-vector algorithm with Ukkonen's band) is a third-party component; only the VALUE it returns matters here,
+// and the global edit distance of two strings is unique, so any exact algorithm is a drop-in for it.
+//
+// k_edit_distance: one wave per (path, read) pair. Rows = read bases, 64 per 64-bit word ("block"), columns = path
+// letters. Lane l owns the units l, l+64, l+128, ... (unit = G consecutive blocks = 64G rows) and the wave sweeps the
+// matrix as a skewed wavefront: at step t unit B works on column t - B, so the horizontal delta leaving unit B-1
+// at column j is exactly what unit B needs one step later (one cross-lane shuffle per step). Only the cells with
+// |row - column| <= k are computed (Ukkonen): unit B is active for columns [64G*B - k, 64G*B + 64G - 1 + k], enters
+// with all-+1 vertical deltas below its upper neighbour and gets +1 as incoming horizontal delta when it is the top
+// of the band. Band values are upper bounds and exact along every path of cost <= k, so a result <= k is the edit
+// distance; otherwise k doubles and the pass repeats. k < 2016*G keeps a lane's consecutive units disjoint in time.
+#include "gc_kernels.hpp"
+#include <hip/hip_runtime.h>
+
+namespace gcdev {
+
+__device__ __forceinline__ char nodeLetter(const DGraph& g, uint32_t node, uint32_t pos)   // AlignmentGraph::NodeSequences, src/AlignmentGraph.cpp:751-796
+{
+	if (node < g.firstAmbiguous) {
+		uint64_t w = g.nodeSeq[2 * (size_t)node + (pos >> 5)];
+		const char acgt[4] = { 'A', 'C', 'G', 'T' };
+		return acgt[(w >> ((pos & 31) * 2)) & 3];
+	}
+	const uint64_t* p = g.ambSeq + 4 * (size_t)(node - g.firstAmbiguous);
+	uint32_t mask = (uint32_t)((p[0] >> pos) & 1) | (uint32_t)(((p[1] >> pos) & 1) << 1) | (uint32_t)(((p[2] >> pos) & 1) << 2) | (uint32_t)(((p[3] >> pos) & 1) << 3);
+	const char iupac[16] = { 'N', 'A', 'C', 'M', 'G', 'R', 'S', 'V', 'T', 'W', 'Y', 'H', 'K', 'D', 'B', 'N' };
+	return iupac[mask];
+}
+
+__device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, uint32_t lane)
+{
+	for (int d = 1; d < 64; d <<= 1) {
+		uint32_t o = __shfl_up(v, d);
+		if ((int)lane >= d) v += o;
+	}
+	return v;
+}
+
+// traceToSequence (src/Aligner.cpp:376-408,425-428) of one alignment per read: the letters of the path between the first
+// and the last trace cell. Cell j contributes the graph bases between the previous cell's position and its own, so the
+// counts are independent, a wave scan places them, and every lane copies its own run.
+__global__ void __launch_bounds__(64) k_long_pathseq(DGraph g, const PathSeqJob* __restrict__ jobs, uint32_t nJobs, const LongCell* __restrict__ cellPool,
+	char* __restrict__ letters, uint32_t* __restrict__ outLen)
+{
+	const uint32_t r = blockIdx.x, lane = threadIdx.x;
+	if (r >= nJobs) return;
+	const PathSeqJob job = jobs[r];
+	if (job.count == 0) { if (lane == 0) outLen[r] = 0; return; }
+	const LongCell* cells = cellPool + job.srcOff;
+	char* out = letters + job.outOff;
+	uint32_t total = 0;
+	bool overflow = false;
+	for (uint32_t base = 0; base < job.count; base += 64) {
+		const uint32_t j = base + lane;
+		uint32_t cnt = 0, node = 0, off = 0, prevNode = 0, prevOff = 0;
+		if (j < job.count) {
+			LongCell c = cells[j];
+			node = g.lookup[g.lookupOff[c.node] + c.offset / 64];
+			off = c.offset & 63u;
+			if (j == 0) cnt = 1;
+			else {
+				LongCell p = cells[j - 1];
+				prevNode = g.lookup[g.lookupOff[p.node] + p.offset / 64];
+				prevOff = p.offset & 63u;
+				if (node == prevNode) cnt = off > prevOff ? off - prevOff : 0;
+				else cnt = ((uint32_t)g.nodeLength[prevNode] - (prevOff + 1)) + (off + 1);
+			}
+		}
+		uint32_t incl = waveInclusiveScan(cnt, lane);
+		uint32_t at = total + incl - cnt;
+		if (at + cnt > job.outCap) overflow = true;
+		else if (cnt) {
+			uint32_t w = at;
+			if (j == 0) out[w++] = nodeLetter(g, node, off);
+			else if (node == prevNode) { for (uint32_t o = prevOff + 1; o <= off; o++) out[w++] = nodeLetter(g, node, o); }
+			else {
+				for (uint32_t o = prevOff + 1; o < g.nodeLength[prevNode]; o++) out[w++] = nodeLetter(g, prevNode, o);
+				for (uint32_t o = 0; o <= off; o++) out[w++] = nodeLetter(g, node, o);
+			}
+		}
+		total += __shfl(incl, 63);
+	}
+	if (__any(overflow)) total = 0xffffffffu;
+	if (lane == 0) outLen[r] = total;
+}
+
+// pathToTrace (src/Aligner.cpp:409-424) of the stitched chain, as letters: first node from its start offset, last node
+// (when it is not also the first) up to its last offset, whole nodes in between.
+__global__ void __launch_bounds__(64) k_chain_pathseq(DGraph g, const PathSeqJob* __restrict__ jobs, uint32_t nJobs, const uint32_t* __restrict__ pathNodes,
+	char* __restrict__ letters, uint32_t* __restrict__ outLen)
+{
+	const uint32_t r = blockIdx.x, lane = threadIdx.x;
+	if (r >= nJobs) return;
+	const PathSeqJob job = jobs[r];
+	if (job.count == 0) { if (lane == 0) outLen[r] = 0; return; }
+	const uint32_t* nodes = pathNodes + job.srcOff;
+	char* out = letters + job.outOff;
+	uint32_t total = 0;
+	bool overflow = false;
+	for (uint32_t base = 0; base < job.count; base += 64) {
+		const uint32_t i = base + lane;
+		uint32_t S = 0, L = 0, node = 0;
+		if (i < job.count) {
+			node = nodes[i];
+			L = g.nodeLength[node];
+			if (i == 0) S = job.firstOffset;
+			else if (i == job.count - 1) L = job.lastOffset + 1;
+		}
+		uint32_t cnt = L > S ? L - S : 0;
+		uint32_t incl = waveInclusiveScan(cnt, lane);
+		uint32_t at = total + incl - cnt;
+		if (at + cnt > job.outCap) overflow = true;
+		else for (uint32_t o = S; o < L; o++) out[at + (o - S)] = nodeLetter(g, node, o);
+		total += __shfl(incl, 63);
+	}
+	if (__any(overflow)) total = 0xffffffffu;
+	if (lane == 0) outLen[r] = total;
+}
+
+#define ED_RING 8192u
+
+template <int G>
+__global__ void __launch_bounds__(64) k_edit_distance(const EdPair* __restrict__ pairs, uint32_t nPairs, const EdRead* __restrict__ reads, const char* __restrict__ bases,
+	const uint64_t* __restrict__ eqMasks, const char* __restrict__ letters, const uint32_t* __restrict__ lettersLen, int64_t* __restrict__ outDistance)
+{
+	__shared__ uint8_t ring[ED_RING];
+	__shared__ int32_t resultSlot;
+	const uint32_t lane = threadIdx.x;
+	constexpr uint32_t RB = 64u * G;                 // rows per unit
+	constexpr uint32_t K_MAX = 2016u * G;
+	for (uint32_t pi = blockIdx.x; pi < nPairs; pi += gridDim.x) {
+		const EdPair pair = pairs[pi];
+		const EdRead rd = reads[pair.read];
+		const uint32_t n = rd.len;
+		const uint32_t m = lettersLen ? lettersLen[pair.lenIndex] : pair.m;
+		if (m == 0xffffffffu) { if (lane == 0) outDistance[pi] = -3; continue; }   // path letters overflowed their slot
+		if (n == 0 || m == 0) { if (lane == 0) outDistance[pi] = (int64_t)(n + m); continue; }
+		const char* path = letters + pair.lettersOff;
+		const uint64_t* masks = eqMasks + rd.eqOff;
+		const uint32_t nU = (n + RB - 1) / RB;
+		const uint32_t diff = n > m ? n - m : m - n;
+		const uint32_t cap = n > m ? n : m;
+		uint32_t k = pair.k > diff ? pair.k : diff;
+		if (k < 1) k = 1;
+		if (k > cap) k = cap;
+		int64_t answer = -2;                         // -2: this G cannot hold the band, the host retries with a larger one
+		if (nU + 1024 + 128 < ED_RING) while (true) {
+			if (k >= K_MAX) break;
+			// ---- one banded pass
+			uint64_t VP[G], VN[G], eqA[G], eqC[G], eqG[G], eqT[G];
+			uint32_t B = lane;                       // current unit of this lane
+			int32_t score = 0;
+			bool fresh = true;                       // unit state not initialised yet
+			uint32_t pack = 0;                       // published (score << 2) | (hout + 1)
+			uint32_t loadedEnd = 0;
+			if (lane == 0) resultSlot = -1;
+			const uint32_t steps = m + nU - 1;
+			for (uint32_t t = 0; t < steps; t++) {
+				if ((t & 1023u) == 0) {
+					uint32_t end = t + 2048 < m ? t + 2048 : m;
+					for (uint32_t c = loadedEnd + lane; c < end; c += 64) ring[c & (ED_RING - 1)] = (uint8_t)path[c];
+					loadedEnd = end > loadedEnd ? end : loadedEnd;
+					__syncthreads();
+				}
+				const uint32_t nbPack = __shfl(pack, (lane + 63) & 63);
+				// leave a finished unit
+				while (B < nU) {
+					const uint64_t c1 = (uint64_t)RB * B + RB - 1 + k;
+					const uint64_t lastCol = c1 < m - 1 ? c1 : m - 1;
+					if ((uint64_t)t > lastCol + B) { B += 64; fresh = true; } else break;
+				}
+				if (B >= nU) continue;
+				const int64_t c0s = (int64_t)RB * B - (int64_t)k;
+				const uint32_t c0 = c0s > 0 ? (uint32_t)c0s : 0;
+				if (t < B || t - B < c0) continue;
+				const uint32_t j = t - B;
+				if (fresh) {
+					fresh = false;
+					const uint32_t wordBase = (RB / 64) * B;
+					for (int q = 0; q < G; q++) {
+						VP[q] = ~0ull; VN[q] = 0;
+						const uint32_t w = wordBase + q;
+						const bool in = w < rd.words;
+						eqA[q] = in ? masks[w] : 0ull;
+						eqC[q] = in ? masks[rd.words + w] : 0ull;
+						eqG[q] = in ? masks[2ull * rd.words + w] : 0ull;
+						eqT[q] = in ? masks[3ull * rd.words + w] : 0ull;
+					}
+					if (j == 0) score = (int32_t)(RB * (B + 1));
+					else score = (int32_t)(nbPack >> 2) - ((int32_t)(nbPack & 3u) - 1) + (int32_t)RB;   // below the upper neighbour's previous column, all +1
+				}
+				const uint8_t letter = ring[j & (ED_RING - 1)];
+				int hin = 1;                         // top of the band (and row -1 of the matrix): +1 per column
+				if (B > 0 && (uint64_t)j <= (uint64_t)RB * B - 1 + k) hin = (int)(nbPack & 3u) - 1;
+				uint64_t hinP = hin > 0 ? 1 : 0, hinN = hin < 0 ? 1 : 0;
+				for (int q = 0; q < G; q++) {
+					uint64_t Eq;
+					if (letter == 'A') Eq = eqA[q];
+					else if (letter == 'C') Eq = eqC[q];
+					else if (letter == 'G') Eq = eqG[q];
+					else if (letter == 'T') Eq = eqT[q];
+					else {                           // any other letter: compare the 64 read bases of this block directly
+						Eq = 0;
+						const uint64_t row0 = (uint64_t)RB * B + 64ull * q;
+						for (uint32_t i = 0; i < 64 && row0 + i < n; i++) if ((uint8_t)bases[rd.readOff + row0 + i] == letter) Eq |= 1ull << i;
+					}
+					const uint64_t vp = VP[q], vn = VN[q];
+					const uint64_t Xv = Eq | vn;
+					Eq |= hinN;
+					const uint64_t Xh = (((Eq & vp) + vp) ^ vp) | Eq;
+					uint64_t Ph = vn | ~(Xh | vp);
+					uint64_t Mh = vp & Xh;
+					const uint64_t outP = Ph >> 63, outN = Mh >> 63;
+					Ph = (Ph << 1) | hinP;
+					Mh = (Mh << 1) | hinN;
+					VP[q] = Mh | ~(Xv | Ph);
+					VN[q] = Ph & Xv;
+					hinP = outP; hinN = outN;
+				}
+				const int hout = (int)hinP - (int)hinN;
+				score += hout;
+				pack = ((uint32_t)score << 2) | (uint32_t)(hout + 1);
+				if (j == m - 1 && B == (n - 1) / RB) {   // the cell (n-1, m-1): subtract the deltas of the padding rows below it
+					int32_t d = score;
+					for (int q = 0; q < G; q++) {
+						const uint64_t row0 = (uint64_t)RB * B + 64ull * q;
+						uint64_t pad = 0;
+						if (row0 >= n) pad = ~0ull;
+						else if (row0 + 64 > n) pad = ~0ull << (n - row0);
+						d -= __popcll(VP[q] & pad);
+						d += __popcll(VN[q] & pad);
+					}
+					resultSlot = d;
+				}
+			}
+			__syncthreads();
+			const int32_t d = resultSlot;
+			__syncthreads();
+			if (d >= 0 && (uint32_t)d <= k) { answer = d; break; }
+			if (k >= cap) { answer = d; break; }    // the band already covers the whole matrix
+			k = k * 2 < cap ? k * 2 : cap;
+		}
+		if (lane == 0) outDistance[pi] = answer;
+	}
+}
+
+void launchLongPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* jobs, uint32_t nJobs, const LongCell* cellPool, char* letters, uint32_t* outLen)
+{
+	if (nJobs) hipLaunchKernelGGL(k_long_pathseq, dim3(nJobs), dim3(64), 0, stream, g, jobs, nJobs, cellPool, letters, outLen);
+}
+void launchChainPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* jobs, uint32_t nJobs, const uint32_t* pathNodes, char* letters, uint32_t* outLen)
+{
+	if (nJobs) hipLaunchKernelGGL(k_chain_pathseq, dim3(nJobs), dim3(64), 0, stream, g, jobs, nJobs, pathNodes, letters, outLen);
+}
+uint32_t editDistanceMaxK(uint32_t unitBlocks) { return 2016u * unitBlocks; }
+void launchEditDistance(hipStream_t stream, uint32_t unitBlocks, const EdPair* pairs, uint32_t nPairs, const EdRead* reads, const char* bases, const uint64_t* eqMasks,
+	const char* letters, const uint32_t* lettersLen, int64_t* outDistance)
+{
+	if (!nPairs) return;
+	uint32_t blocks = nPairs < 65536 ? nPairs : 65536;
+	switch (unitBlocks) {
+		case 1: hipLaunchKernelGGL(k_edit_distance<1>, dim3(blocks), dim3(64), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance); break;
+		case 2: hipLaunchKernelGGL(k_edit_distance<2>, dim3(blocks), dim3(64), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance); break;
+		case 4: hipLaunchKernelGGL(k_edit_distance<4>, dim3(blocks), dim3(64), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance); break;
+		default: hipLaunchKernelGGL(k_edit_distance<8>, dim3(blocks), dim3(64), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance); break;
+	}
+}
+
+} // namespace gcdev

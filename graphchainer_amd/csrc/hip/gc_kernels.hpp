@@ -140,6 +140,27 @@ void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTabl
 	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters);
 void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, const uint32_t* candSeed, const LongWorkResult* results,
 	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity);
+// ---- path sequences + NW edit distances (gc_editdist.hip)
+struct PathSeqJob {   // one path to spell out as letters
+	uint64_t srcOff;              // first LongCell (whole-read alignment) or first path node (stitched chain)
+	uint64_t outOff;              // where its letters go
+	uint32_t count;               // cells / nodes
+	uint32_t outCap;              // letters reserved
+	uint32_t firstOffset, lastOffset;   // stitched chain only: offsets of the first and last base
+};
+struct EdRead { uint64_t readOff, eqOff; uint32_t len, words; };   // read bases + its exact-match masks [A,C,G,T][words]
+struct EdPair {
+	uint64_t lettersOff;          // path letters (matrix columns)
+	uint32_t m;                   // their number, unless a length array is given (then lengths[lenIndex])
+	uint32_t lenIndex;
+	uint32_t read;                // index into EdRead (matrix rows)
+	uint32_t k;                   // first band half-width to try
+};
+void launchLongPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* jobs, uint32_t nJobs, const LongCell* cellPool, char* letters, uint32_t* outLen);
+void launchChainPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* jobs, uint32_t nJobs, const uint32_t* pathNodes, char* letters, uint32_t* outLen);
+uint32_t editDistanceMaxK(uint32_t unitBlocks);
+void launchEditDistance(hipStream_t stream, uint32_t unitBlocks, const EdPair* pairs, uint32_t nPairs, const EdRead* reads, const char* bases, const uint64_t* eqMasks,
+	const char* letters, const uint32_t* lettersLen, int64_t* outDistance);
 void launchPublish(hipStream_t stream, const unsigned long long* src, unsigned long long* dst, uint32_t nWords);
 void launchLongFinish(hipStream_t stream, uint32_t nReads, const LongState* state, LongReadResult* results);
 

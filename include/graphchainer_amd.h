@@ -160,6 +160,11 @@ void gc_result_free(gc_result* r);
 
 const char* gc_last_error(void);
 void gc_free(void* p);
+/* Global (NW) edit distance of each pair (a[a_off[i]..a_off[i+1]), b[b_off[i]..b_off[i+1])) on the GPU: the value
+ * edlibAlign(a, |a|, b, |b|, edlibNewAlignConfig(-1, EDLIB_MODE_NW, EDLIB_TASK_DISTANCE, NULL, 0)).editDistance returns at
+ * src/Aligner.cpp:645 and :845 (characters compare by equality, as in edlib's default alphabet handling). */
+int gc_edit_distance(const char* a, const uint64_t* a_off, const char* b, const uint64_t* b_off, uint64_t n_pairs, int64_t* out);
+
 int gc_device_count(void);
 int gc_set_device(int device);
 

@@ -187,3 +187,43 @@ def test_whole_read_pass_launch_shapes(gca, tmp_path, monkeypatch, env):
     reads = sg.sample_reads(140, 2500, seed=9)
     got, want = run_case(gca, gfa, reads, long_pass=True)
     compare(got, want, COMPARE_KEYS + LONG_KEYS)
+
+
+def _mutate(rng, s, rate):
+    out = bytearray()
+    for ch in s:
+        x = rng.random()
+        if x < rate / 3:
+            continue                                   # deletion
+        if x < 2 * rate / 3:
+            out.append(rng.choice(b"ACGT"))            # substitution
+        else:
+            out.append(ch)
+        if rng.random() < rate / 3:
+            out.append(rng.choice(b"ACGT"))            # insertion
+    return bytes(out)
+
+
+def test_edit_distance_kernel(gca):
+    """NW edit distance kernel (banded Myers wavefront, k doubling, unit escalation) against the oracle's plain DP value,
+    which tests/test_oracle_units.py pins to edlib."""
+    import random
+    from oracle import Oracle  # noqa: F401  (builds the oracle library)
+    from oracle.binding import load_oracle_lib
+    import ctypes as C
+    lib = load_oracle_lib()
+    lib.gco_edit_distance.restype = C.c_uint64
+    lib.gco_edit_distance.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]
+    rng = random.Random(5)
+    pairs = []
+    for length, rate in [(1, 0.0), (63, 0.1), (64, 0.3), (65, 0.0), (700, 0.15), (3000, 0.05), (3000, 0.4), (10000, 0.12), (10000, 0.3), (20000, 0.25)]:
+        a = bytes(rng.choice(b"ACGT") for _ in range(length))
+        pairs.append((a, _mutate(rng, a, rate)))
+    pairs.append((b"ACGTNNRYACGT" * 30, b"ACGTNARYACGA" * 29))                     # letters outside ACGT compare by equality
+    pairs.append((bytes(rng.choice(b"ACGT") for _ in range(5000)), bytes(rng.choice(b"ACGT") for _ in range(4000))))   # unrelated: distance ~ half the length
+    pairs.append((b"A" * 300, b"ACGT" * 2000))                                      # very different lengths
+    pairs.append((b"", b"ACGT"))
+    pairs.append((b"ACGT", b""))
+    got = gca.edit_distance([p[0] for p in pairs], [p[1] for p in pairs])
+    want = [len(a) + len(b) if (not a or not b) else int(lib.gco_edit_distance(a, len(a), b, len(b))) for a, b in pairs]
+    assert list(map(int, got)) == want
