@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
 
 class GcParams(C.Structure):
     _fields_ = [("bandwidth", C.c_int32), ("split_len", C.c_int32), ("split_gap", C.c_int32), ("colinear_gap", C.c_int64),
-                ("seed_density", C.c_double), ("min_cluster_size", C.c_int32), ("long_pass", C.c_int32), ("keep_traces", C.c_int32), ("keep_seeds", C.c_int32), ("stitch", C.c_int32)]
+                ("seed_density", C.c_double), ("min_cluster_size", C.c_int32), ("long_pass", C.c_int32), ("keep_traces", C.c_int32), ("keep_seeds", C.c_int32), ("stitch", C.c_int32), ("edit_distances", C.c_int32)]
 
 
 _P = C.POINTER
@@ -50,6 +50,7 @@ class GcResult(C.Structure):
         ("long_trace_seqpos", _P(C.c_uint32)), ("long_trace_switch", _P(C.c_uint8)),
         ("failed_assertion", _P(C.c_uint8)), ("seeds_extended", _P(C.c_uint64)), ("seeds_extended_long", _P(C.c_uint64)),
         ("read_path_off", _P(C.c_uint64)), ("path_node", _P(C.c_uint32)), ("path_first_offset", _P(C.c_uint32)), ("path_last_offset", _P(C.c_uint32)), ("path_cells", _P(C.c_uint64)),
+        ("read_long_off", _P(C.c_uint64)), ("long_index", _P(C.c_uint32)), ("long_edit_distance", _P(C.c_int64)), ("chain_edit_distance", _P(C.c_int64)), ("chained_better", _P(C.c_uint8)),
         ("counters", C.c_uint64 * 8), ("counters_long", C.c_uint64 * 8), ("kernel_us", C.c_double * 8), ("host_us", C.c_double * 4),
     ]
 
@@ -223,7 +224,7 @@ _RESULT_FIELDS = {
 class Aligner:
     """Batched stand-in for the reference's per-read hot path (src/Aligner.cpp:601-922)."""
 
-    def __init__(self, graph, seeder, bandwidth=10, split_len=35, split_gap=35, colinear_gap=10000, seed_density=10.0, keep_traces=False, keep_seeds=False, long_pass=False, stitch=True):
+    def __init__(self, graph, seeder, bandwidth=10, split_len=35, split_gap=35, colinear_gap=10000, seed_density=10.0, keep_traces=False, keep_seeds=False, long_pass=False, stitch=True, edit_distances=True):
         self.lib = load_library()
         self.graph = graph
         self.seeder = seeder
@@ -238,6 +239,7 @@ class Aligner:
         self.params.keep_seeds = int(keep_seeds)
         self.params.long_pass = int(long_pass)
         self.params.stitch = int(stitch)
+        self.params.edit_distances = int(edit_distances)
         self.stream = C.c_void_p()
         _check(self.lib.gc_stream_create(C.byref(self.stream)))
 
@@ -269,6 +271,11 @@ class Aligner:
             out["path_first_offset"] = arr(r.path_first_offset, n)
             out["path_last_offset"] = arr(r.path_last_offset, n)
             out["path_cells"] = arr(r.path_cells, n)
+            out["read_long_off"] = arr(r.read_long_off, n + 1)
+            out["long_index"] = arr(r.long_index, int(out["read_long_off"][-1]))
+            out["long_edit_distance"] = arr(r.long_edit_distance, n)
+            out["chain_edit_distance"] = arr(r.chain_edit_distance, n)
+            out["chained_better"] = arr(r.chained_better, n)
             counts = {"n": n, "n+1": n + 1, "seeds": seeds, "anchors": anchors, "paths": paths, "chains": chains, "longs": longs}
             for name, expr in _RESULT_FIELDS.items():
                 if name in out:

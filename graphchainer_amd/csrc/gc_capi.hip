@@ -193,7 +193,10 @@ struct gc_reads {
 	uint64_t* devMasks = nullptr;
 	std::vector<uint64_t> maskOff;   // [n] word offset of read r's masks
 	std::vector<uint32_t> maskWords; // [n] words per bit vector
-	~gc_reads() { if (devBases) (void)hipFree(devBases); if (devOffsets) (void)hipFree(devOffsets); if (devMasks) (void)hipFree(devMasks); }
+	// exact-match bit vectors of the forward strand [A,C,G,T][words] and the per-read records of the NW kernel (rows = read bases)
+	uint64_t* devEqMasks = nullptr;
+	EdRead* devEdReads = nullptr;
+	~gc_reads() { if (devBases) (void)hipFree(devBases); if (devOffsets) (void)hipFree(devOffsets); if (devMasks) (void)hipFree(devMasks); if (devEqMasks) (void)hipFree(devEqMasks); if (devEdReads) (void)hipFree(devEdReads); }
 };
 
 struct gc_stream {
@@ -204,6 +207,8 @@ struct gc_stream {
 	// whole-read pass: runs on its own stream, concurrently with the fragment kernels
 	hipStream_t longStream = nullptr;
 	hipEvent_t longEv[2] {};
+	DeviceBuffer edPathNodes, edJobs, edLetters, edLettersLen, edPairs, edOut, edLongJobs, edLongLetters, edLongLettersLen, edLongPairs, edLongOut;
+	PinnedBuffer hEdPathNodes, hEdJobs, hEdPairs, hEdOut, hEdLongJobs, hEdLongPairs, hEdLongOut;
 	std::vector<hipStream_t> groupStreams;   // read groups of the whole-read pass run their round loops concurrently
 	std::vector<hipEvent_t> groupEvents;     // two per group
 	DeviceBuffer longSeeds, longJobs, longAlns, longResults, longScratch, longCells, longCursor, longJobsFallback, longResultsFallback, longScratchFallback;
@@ -398,6 +403,9 @@ struct ReadGlue {
 	uint64_t nAnchors = 0, nPath = 0, nTrace = 0, anchorBegin = 0, pathBegin = 0, traceBegin = 0, seedBegin = 0, chainBegin = 0;
 	StitchedPath stitched;                // chain stitching result
 	uint64_t stitchedBegin = 0;
+	std::vector<uint32_t> longSelected;   // GreedyLength selection (src/Aligner.cpp:636-639): indices into longAlns
+	uint64_t longSelectedBegin = 0;
+	int64_t longEditDistance = -1, chainEditDistance = -1;
 };
 
 // Chain stitching, reference: src/Aligner.cpp:754-822 (+ pathToTrace :409-424, getChainPath src/AlignmentGraph.cpp:1866-1916).
@@ -469,41 +477,53 @@ static void buildEqMasks(const char* seq, uint64_t len, uint64_t words, uint64_t
 	}
 }
 
-// Runs the NW kernel over `pairs`, escalating the rows-per-lane unit (1, 2, 4, 8 blocks) for the pairs whose band does
+// Runs the NW kernel over `pairs`, escalating the rows-per-lane unit (1, 2, 4, 8, 16 blocks) for the pairs whose band does
 // not fit the smaller one. hPairs/hOut: pinned host staging; dPairs/dOut: device arrays of at least nPairs elements.
-static void runEditDistances(hipStream_t stream, EdPair* hPairs, int64_t* hOut, uint32_t nPairs, EdPair* dPairs, int64_t* dOut, const EdRead* dReads, const char* dBases,
+// launchEditDistances queues the first attempt (unit 1) without waiting; finishEditDistances waits for it and reruns the rest.
+static void launchEditDistances(hipStream_t stream, EdPair* hPairs, int64_t* hOut, uint32_t nPairs, EdPair* dPairs, int64_t* dOut, const EdRead* dReads, const char* dBases,
 	const uint64_t* dEqMasks, const char* dLetters, const uint32_t* dLettersLen)
 {
 	if (!nPairs) return;
-	std::vector<uint32_t> todo(nPairs);
-	for (uint32_t i = 0; i < nPairs; i++) todo[i] = i;
-	std::vector<EdPair> sub;
-	std::vector<int64_t> subOut;
-	for (uint32_t unit = 1; unit <= 8 && !todo.empty(); unit *= 2) {
-		const bool all = todo.size() == nPairs;
-		if (all) {
-			HIP_CHECK(hipMemcpyAsync(dPairs, hPairs, (size_t)nPairs * sizeof(EdPair), hipMemcpyHostToDevice, stream));
-			launchEditDistance(stream, unit, dPairs, nPairs, dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut);
-			HIP_CHECK(hipMemcpyAsync(hOut, dOut, (size_t)nPairs * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-			HIP_CHECK(hipStreamSynchronize(stream));
-		} else {
-			sub.resize(todo.size());
-			subOut.resize(todo.size());
-			for (size_t i = 0; i < todo.size(); i++) sub[i] = hPairs[todo[i]];
-			HIP_CHECK(hipMemcpyAsync(dPairs, sub.data(), sub.size() * sizeof(EdPair), hipMemcpyHostToDevice, stream));
-			launchEditDistance(stream, unit, dPairs, (uint32_t)sub.size(), dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut);
-			HIP_CHECK(hipMemcpyAsync(subOut.data(), dOut, sub.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-			HIP_CHECK(hipStreamSynchronize(stream));
-			for (size_t i = 0; i < todo.size(); i++) hOut[todo[i]] = subOut[i];
-		}
+	HIP_CHECK(hipMemcpyAsync(dPairs, hPairs, (size_t)nPairs * sizeof(EdPair), hipMemcpyHostToDevice, stream));
+	launchEditDistance(stream, 1, dPairs, nPairs, dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut);
+	HIP_CHECK(hipMemcpyAsync(hOut, dOut, (size_t)nPairs * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+}
+static void finishEditDistances(hipStream_t stream, EdPair* hPairs, int64_t* hOut, uint32_t nPairs, EdPair* dPairs, int64_t* dOut, const EdRead* dReads, const char* dBases,
+	const uint64_t* dEqMasks, const char* dLetters, const uint32_t* dLettersLen)
+{
+	if (!nPairs) return;
+	HIP_CHECK(hipStreamSynchronize(stream));
+	std::vector<uint32_t> todo;
+	auto collect = [&](const std::vector<uint32_t>& from, bool all) {
 		std::vector<uint32_t> next;
-		for (uint32_t i : todo) {
+		auto visit = [&](uint32_t i) {
 			if (hOut[i] == -3) throw std::runtime_error("path letters overflowed their slot");
 			if (hOut[i] == -2) next.push_back(i);
-		}
-		todo.swap(next);
+		};
+		if (all) for (uint32_t i = 0; i < nPairs; i++) visit(i); else for (uint32_t i : from) visit(i);
+		return next;
+	};
+	todo = collect(todo, true);
+	std::vector<EdPair> sub;
+	std::vector<int64_t> subOut;
+	for (uint32_t unit = 2; unit <= 16 && !todo.empty(); unit *= 2) {
+		sub.resize(todo.size());
+		subOut.resize(todo.size());
+		for (size_t i = 0; i < todo.size(); i++) sub[i] = hPairs[todo[i]];
+		HIP_CHECK(hipMemcpyAsync(dPairs, sub.data(), sub.size() * sizeof(EdPair), hipMemcpyHostToDevice, stream));
+		launchEditDistance(stream, unit, dPairs, (uint32_t)sub.size(), dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut);
+		HIP_CHECK(hipMemcpyAsync(subOut.data(), dOut, sub.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		for (size_t i = 0; i < todo.size(); i++) hOut[todo[i]] = subOut[i];
+		todo = collect(todo, false);
 	}
-	if (!todo.empty()) throw std::runtime_error("edit distance band too wide for the NW kernel (more than 16128 edits on one read)");
+	if (!todo.empty()) throw std::runtime_error("edit distance band too wide for the NW kernel (a read longer than 65536 bases more than 32256 edits away from its path)");
+}
+static void runEditDistances(hipStream_t stream, EdPair* hPairs, int64_t* hOut, uint32_t nPairs, EdPair* dPairs, int64_t* dOut, const EdRead* dReads, const char* dBases,
+	const uint64_t* dEqMasks, const char* dLetters, const uint32_t* dLettersLen)
+{
+	launchEditDistances(stream, hPairs, hOut, nPairs, dPairs, dOut, dReads, dBases, dEqMasks, dLetters, dLettersLen);
+	finishEditDistances(stream, hPairs, hOut, nPairs, dPairs, dOut, dReads, dBases, dEqMasks, dLetters, dLettersLen);
 }
 
 template <typename T> T* copyOut(const std::vector<T>& v)
@@ -585,6 +605,7 @@ void gc_params_default(gc_params* p)
 	p->keep_traces = 0;
 	p->keep_seeds = 0;
 	p->stitch = 1;
+	p->edit_distances = 1;
 }
 
 int gc_graph_create_from_gfa(const char* gfa_path, gc_graph** out)
@@ -813,6 +834,17 @@ int gc_reads_upload(const char* bases, const uint64_t* offsets, uint64_t n, gc_r
 		}
 		HIP_CHECK(hipMalloc((void**)&R->devMasks, std::max<size_t>(masks.size(), 1) * sizeof(uint64_t)));
 		if (!masks.empty()) HIP_CHECK(hipMemcpy(R->devMasks, masks.data(), masks.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+		{
+			std::vector<EdRead> edReads(n);
+			uint64_t eqWords = 0;
+			for (uint64_t r = 0; r < n; r++) { edReads[r] = EdRead { offsets[r], eqWords, (uint32_t)(offsets[r + 1] - offsets[r]), R->maskWords[r] }; eqWords += 4ull * R->maskWords[r]; }
+			std::vector<uint64_t> eqMasks(eqWords, 0);
+			for (uint64_t r = 0; r < n; r++) buildEqMasks(bases + offsets[r], edReads[r].len, edReads[r].words, eqMasks.data() + edReads[r].eqOff);
+			HIP_CHECK(hipMalloc((void**)&R->devEqMasks, std::max<size_t>(eqWords, 1) * sizeof(uint64_t)));
+			if (eqWords) HIP_CHECK(hipMemcpy(R->devEqMasks, eqMasks.data(), eqWords * sizeof(uint64_t), hipMemcpyHostToDevice));
+			HIP_CHECK(hipMalloc((void**)&R->devEdReads, std::max<size_t>(n, 1) * sizeof(EdRead)));
+			if (n) HIP_CHECK(hipMemcpy(R->devEdReads, edReads.data(), n * sizeof(EdRead), hipMemcpyHostToDevice));
+		}
 		HIP_CHECK(hipMalloc((void**)&R->devBases, std::max<size_t>(both.size(), 1)));
 		if (!both.empty()) HIP_CHECK(hipMemcpy(R->devBases, both.data(), both.size(), hipMemcpyHostToDevice));
 		HIP_CHECK(hipMalloc((void**)&R->devOffsets, (n + 1) * sizeof(uint64_t)));
@@ -834,7 +866,8 @@ void gc_result_free(gc_result* r)
 		r->anchor_path, r->anchor_first_node, r->anchor_first_offset, r->anchor_first_seqpos, r->anchor_last_node, r->anchor_last_offset, r->anchor_last_seqpos, r->anchor_score,
 		r->anchor_trace_off, r->anchor_trace_node, r->anchor_trace_offset, r->anchor_trace_seqpos, r->anchor_trace_switch, r->read_chain_off, r->chain, r->chain_score,
 		r->read_longall_off, r->longall_start, r->longall_end, r->longall_score, r->long_trace_off, r->long_trace_node, r->long_trace_offset, r->long_trace_seqpos, r->long_trace_switch,
-		r->failed_assertion, r->seeds_extended, r->seeds_extended_long, r->read_path_off, r->path_node, r->path_first_offset, r->path_last_offset, r->path_cells };
+		r->failed_assertion, r->seeds_extended, r->seeds_extended_long, r->read_path_off, r->path_node, r->path_first_offset, r->path_last_offset, r->path_cells,
+		r->read_long_off, r->long_index, r->long_edit_distance, r->chain_edit_distance, r->chained_better };
 	for (void* p : ptrs) free(p);
 	free(r);
 }
@@ -1276,6 +1309,45 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				stitchChain(hg, (long long)P->colinear_gap, chainOut + jobs[r].chainBegin, chainLen[r], slots.data(), anchors + gl.slotBegin, pathPool, gl.stitched);
 			});
 		}
+		// ---------------- edit distance of the stitched path against the read (edlibAlign at src/Aligner.cpp:845, value only):
+		// path letters are spelled out on the device from the node path, then the NW kernel; still behind the whole-read pass
+		std::function<void()> finishChainEditDistances;
+		std::vector<uint32_t> pairRead;   // chain pairs -> read
+		if (P->stitch && P->edit_distances) {
+			uint64_t nNodesTotal = 0, nCells = 0;
+			uint32_t nPairs = 0;
+			for (uint64_t r = 0; r < n; r++) { glue[r].stitchedBegin = nNodesTotal; nNodesTotal += glue[r].stitched.nodes.size(); }
+			uint32_t* hNodes = st->hEdPathNodes.reserve<uint32_t>(nNodesTotal);
+			PathSeqJob* hJobsPS = st->hEdJobs.reserve<PathSeqJob>(n);
+			EdPair* hPairs = st->hEdPairs.reserve<EdPair>(n);
+			int64_t* hOut = st->hEdOut.reserve<int64_t>(n);
+			for (uint64_t r = 0; r < n; r++) {
+				const StitchedPath& sp = glue[r].stitched;
+				if (!sp.nodes.empty()) memcpy(hNodes + glue[r].stitchedBegin, sp.nodes.data(), sp.nodes.size() * sizeof(uint32_t));
+				if (sp.cells >= 0x7fffffffull) throw std::runtime_error("stitched path too long");
+				hJobsPS[r] = PathSeqJob { glue[r].stitchedBegin, nCells, (uint32_t)sp.nodes.size(), (uint32_t)sp.cells, sp.firstOffset, sp.lastOffset };
+				if (sp.cells) {
+					uint32_t len = (uint32_t)(R->offsets[r + 1] - R->offsets[r]);
+					hPairs[nPairs++] = EdPair { nCells, (uint32_t)sp.cells, (uint32_t)r, (uint32_t)r, std::max<uint32_t>(64, (uint32_t)((sp.cells + len) / 16)) };
+					pairRead.push_back((uint32_t)r);
+				}
+				nCells += sp.cells;
+			}
+			uint32_t* dNodes = st->edPathNodes.reserve<uint32_t>(nNodesTotal);
+			PathSeqJob* dJobsPS = st->edJobs.reserve<PathSeqJob>(n);
+			char* dLetters = st->edLetters.reserve<char>(nCells);
+			uint32_t* dLettersLen = st->edLettersLen.reserve<uint32_t>(n);
+			EdPair* dPairs = st->edPairs.reserve<EdPair>(n);
+			int64_t* dOut = st->edOut.reserve<int64_t>(n);
+			if (nNodesTotal) HIP_CHECK(hipMemcpyAsync(dNodes, hNodes, nNodesTotal * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+			if (n) HIP_CHECK(hipMemcpyAsync(dJobsPS, hJobsPS, n * sizeof(PathSeqJob), hipMemcpyHostToDevice, stream));
+			launchChainPathSeq(stream, G->dev, dJobsPS, (uint32_t)n, dNodes, dLetters, dLettersLen);
+			launchEditDistances(stream, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen);
+			finishChainEditDistances = [=, &glue, &pairRead]() {   // called once the whole-read pass is done; the kernel ran beside it
+				finishEditDistances(stream, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen);
+				for (uint32_t i = 0; i < nPairs; i++) glue[pairRead[i]].chainEditDistance = hOut[i];
+			};
+		}
 		double stitchUs = nowUs() - tStitch;
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] chain stitching %.1f ms\n", stitchUs / 1e3);
 
@@ -1302,11 +1374,76 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				if (hLongResults[r].status == 3) throw std::runtime_error("whole-read pass: more than 32 alignments for one read");
 				if (hLongResults[r].status == 4) throw std::runtime_error("whole-read pass: trace cell pool overflow (raise GC_LONG_CELLS_PER_BASE)");
 			}
+			// the reference re-sorts its alignment list by alignmentStart after every accepted alignment
+			// (src/GraphAligner.h:183); replaying that on the acceptance-ordered list gives its final order. Then the
+			// GreedyLength selection (src/Aligner.cpp:636-639, src/AlignmentSelection.cpp:12-50) with the same unstable sort.
+			pool.run(n, [&](size_t r, size_t) {
+				ReadGlue& gl = glue[r];
+				for (uint32_t a = 0; a < hLongResults[r].nAlignments; a++) {
+					gl.longAlns.push_back(hLongAlns[r * maxAlignments + a]);
+					std::sort(gl.longAlns.begin(), gl.longAlns.end(), [](const LongAln& l, const LongAln& rr) { return l.start < rr.start; });
+				}
+				struct Item { uint32_t start, end, score, index; };
+				std::vector<Item> sorted;
+				for (uint32_t a = 0; a < gl.longAlns.size(); a++) sorted.push_back(Item { gl.longAlns[a].start, gl.longAlns[a].end, gl.longAlns[a].score, a });
+				std::sort(sorted.begin(), sorted.end(), [](const Item& l, const Item& rr) {
+					if ((l.end - l.start) > (rr.end - rr.start)) return true;
+					if ((rr.end - rr.start) > (l.end - l.start)) return false;
+					return l.score < rr.score;
+				});
+				auto incompatible = [](const Item& l, const Item& rr) {
+					float minOverlapLen = std::min(l.end - l.start, rr.end - rr.start) * 0.05f;
+					size_t ls = l.start, le = l.end, rs = rr.start, re = rr.end;
+					if (ls > rs) { std::swap(ls, rs); std::swap(le, re); }
+					int overlap = 0;
+					if (le > rs) overlap = (int)(le - rs);
+					return overlap > minOverlapLen;
+				};
+				std::vector<Item> kept;
+				for (const Item& it : sorted) {
+					bool ok = true;
+					for (const Item& k : kept) if (incompatible(it, k)) { ok = false; break; }
+					if (ok) { kept.push_back(it); gl.longSelected.push_back(it.index); }
+				}
+			});
+			// edit distance of the best whole-read alignment's path against the read (edlibAlign at src/Aligner.cpp:645)
+			if (P->edit_distances) {
+				PathSeqJob* hJobsPS = st->hEdLongJobs.reserve<PathSeqJob>(n);
+				EdPair* hPairs = st->hEdLongPairs.reserve<EdPair>(n);
+				int64_t* hOut = st->hEdLongOut.reserve<int64_t>(n);
+				uint64_t nLetters = 0;
+				uint32_t nPairs = 0;
+				std::vector<uint32_t> pairRead;
+				for (uint64_t r = 0; r < n; r++) {
+					const ReadGlue& gl = glue[r];
+					if (gl.longSelected.empty()) { hJobsPS[r] = PathSeqJob { 0, nLetters, 0, 0, 0, 0 }; continue; }
+					const LongAln& al = gl.longAlns[gl.longSelected[0]];
+					uint32_t len = (uint32_t)(R->offsets[r + 1] - R->offsets[r]);
+					uint32_t cap = 2 * al.traceLen + 256;
+					hJobsPS[r] = PathSeqJob { al.traceOff, nLetters, al.traceLen, cap, 0, 0 };
+					// the alignment itself bounds the distance: its edits plus the unaligned read ends
+					hPairs[nPairs++] = EdPair { nLetters, 0, (uint32_t)r, (uint32_t)r, al.score + al.start + (len - std::min(len, al.end)) + 8 };
+					pairRead.push_back((uint32_t)r);
+					nLetters += cap;
+				}
+				PathSeqJob* dJobsPS = st->edLongJobs.reserve<PathSeqJob>(n);
+				char* dLetters = st->edLongLetters.reserve<char>(nLetters);
+				uint32_t* dLettersLen = st->edLongLettersLen.reserve<uint32_t>(n);
+				EdPair* dPairs = st->edLongPairs.reserve<EdPair>(n);
+				int64_t* dOut = st->edLongOut.reserve<int64_t>(n);
+				hipStream_t lq = st->longStream;
+				if (n) HIP_CHECK(hipMemcpyAsync(dJobsPS, hJobsPS, n * sizeof(PathSeqJob), hipMemcpyHostToDevice, lq));
+				launchLongPathSeq(lq, G->dev, dJobsPS, (uint32_t)n, dLongCells, dLetters, dLettersLen);
+				runEditDistances(lq, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen);
+				for (uint32_t i = 0; i < nPairs; i++) glue[pairRead[i]].longEditDistance = hOut[i];
+			}
 			if (P->keep_traces) {
 				longCells.resize(hLongSmall[0]);
 				if (hLongSmall[0]) HIP_CHECK(hipMemcpy(longCells.data(), dLongCells, hLongSmall[0] * sizeof(LongCell), hipMemcpyDeviceToHost));
 			}
 		}
+
+		if (finishChainEditDistances) finishChainEditDistances();
 
 		// ---------------- assemble the flat result: count per read, prefix-sum, fill in parallel
 		double tAsm = nowUs();
@@ -1337,12 +1474,6 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			if (P->long_pass) {
 				seedsExtendedLong[r] = hLongResults[r].seedsExtended;
 				if (hLongResults[r].status == 1) failedAssertion[r] = 1;
-				// the reference re-sorts its alignment list by alignmentStart after every accepted alignment
-				// (src/GraphAligner.h:183); replaying that on the acceptance-ordered list gives its final order
-				for (uint32_t a = 0; a < hLongResults[r].nAlignments; a++) {
-					gl.longAlns.push_back(hLongAlns[r * maxAlignments + a]);
-					std::sort(gl.longAlns.begin(), gl.longAlns.end(), [](const LongAln& l, const LongAln& rr) { return l.start < rr.start; });
-				}
 			}
 			forEachAnchor(r, [&](uint64_t slot, uint64_t) {
 				gl.nAnchors++;
@@ -1358,13 +1489,14 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		});
 		if (overflow) throw std::runtime_error("extension capacity overflow in a fragment (raise GC_EXT_MAX_ITEMS / GC_EXT_MAX_PENDING / GC_EXT_MAX_TRACE)");
 		if (chainFailure) throw std::runtime_error("chaining kernel failure (status " + std::to_string((int)chainFailure) + ")");
-		uint64_t nAnchors = 0, nPath = 0, nTrace = 0, nChain = 0, nLong = 0, nLongTrace = 0, nStitched = 0;
+		uint64_t nAnchors = 0, nPath = 0, nTrace = 0, nChain = 0, nLong = 0, nLongTrace = 0, nStitched = 0, nLongSelected = 0;
 		for (uint64_t r = 0; r < n; r++) {
 			glue[r].anchorBegin = nAnchors; glue[r].pathBegin = nPath; glue[r].traceBegin = nTrace; glue[r].chainBegin = nChain;
 			glue[r].longBegin = nLong; glue[r].longTraceBegin = nLongTrace;
 			nAnchors += glue[r].nAnchors; nPath += glue[r].nPath; nTrace += glue[r].nTrace; nChain += chainLen[r];
 			nLong += glue[r].longAlns.size();
 			glue[r].stitchedBegin = nStitched; nStitched += glue[r].stitched.nodes.size();
+			glue[r].longSelectedBegin = nLongSelected; nLongSelected += glue[r].longSelected.size();
 			if (P->keep_traces) for (const LongAln& a : glue[r].longAlns) nLongTrace += a.traceLen;
 		}
 		const bool keepSeeds = P->keep_seeds != 0;
@@ -1394,6 +1526,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		res->long_trace_node = mallocArray<int32_t>(nLongTrace); res->long_trace_offset = mallocArray<uint32_t>(nLongTrace);
 		res->long_trace_seqpos = mallocArray<uint32_t>(nLongTrace); res->long_trace_switch = mallocArray<uint8_t>(nLongTrace);
 		res->seeds_extended_long = mallocArray<uint64_t>(n);
+		res->read_long_off = mallocArray<uint64_t>(n + 1);
+		res->read_long_off[n] = nLongSelected;
+		res->long_index = mallocArray<uint32_t>(nLongSelected);
+		res->long_edit_distance = mallocArray<int64_t>(n); res->chain_edit_distance = mallocArray<int64_t>(n); res->chained_better = mallocArray<uint8_t>(n);
 		res->read_path_off = mallocArray<uint64_t>(n + 1);
 		res->read_path_off[n] = nStitched;
 		res->path_node = mallocArray<uint32_t>(nStitched);
@@ -1416,6 +1552,12 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			res->seeds_extended_long[r] = seedsExtendedLong[r];
 			res->read_longall_off[r] = gl.longBegin;
 			res->read_path_off[r] = gl.stitchedBegin;
+			res->read_long_off[r] = gl.longSelectedBegin;
+			for (size_t i = 0; i < gl.longSelected.size(); i++) res->long_index[gl.longSelectedBegin + i] = gl.longSelected[i];
+			res->long_edit_distance[r] = gl.longEditDistance;
+			res->chain_edit_distance[r] = gl.chainEditDistance;
+			// src/Aligner.cpp:901-905: the chained alignment wins when there is no whole-read alignment or its edit distance is larger
+			res->chained_better[r] = (gl.stitched.cells > 0 && gl.chainEditDistance >= 0 && (gl.longSelected.empty() || gl.longEditDistance > gl.chainEditDistance)) ? 1 : 0;
 			for (size_t i = 0; i < gl.stitched.nodes.size(); i++) res->path_node[gl.stitchedBegin + i] = gl.stitched.nodes[i];
 			res->path_first_offset[r] = gl.stitched.firstOffset; res->path_last_offset[r] = gl.stitched.lastOffset; res->path_cells[r] = gl.stitched.cells;
 			{

@@ -13,7 +13,8 @@
 // |row - column| <= k are computed (Ukkonen): unit B is active for columns [64G*B - k, 64G*B + 64G - 1 + k], enters
 // with all-+1 vertical deltas below its upper neighbour and gets +1 as incoming horizontal delta when it is the top
 // of the band. Band values are upper bounds and exact along every path of cost <= k, so a result <= k is the edit
-// distance; otherwise k doubles and the pass repeats. k < 2016*G keeps a lane's consecutive units disjoint in time.
+// distance; otherwise k doubles and the pass repeats. k < 2016*G keeps a lane's consecutive units disjoint in time
+// (no limit when the read has at most 64 units, i.e. up to 4096*G rows); the host escalates G = 1, 2, 4, 8, 16.
 #include "gc_kernels.hpp"
 #include <hip/hip_runtime.h>
 
@@ -150,7 +151,7 @@ __global__ void __launch_bounds__(64) k_edit_distance(const EdPair* __restrict__
 		if (k > cap) k = cap;
 		int64_t answer = -2;                         // -2: this G cannot hold the band, the host retries with a larger one
 		if (nU + 1024 + 128 < ED_RING) while (true) {
-			if (k >= K_MAX) break;
+			if (k >= K_MAX && nU > 64) break;   // (with at most one unit per lane there is nothing to keep disjoint: any band width works)
 			// ---- one banded pass
 			uint64_t VP[G], VN[G], eqA[G], eqC[G], eqG[G], eqT[G];
 			uint32_t B = lane;                       // current unit of this lane
@@ -158,26 +159,38 @@ __global__ void __launch_bounds__(64) k_edit_distance(const EdPair* __restrict__
 			bool fresh = true;                       // unit state not initialised yet
 			uint32_t pack = 0;                       // published (score << 2) | (hout + 1)
 			uint32_t loadedEnd = 0;
+			// per-unit step window, refreshed when the lane moves to its next unit
+			uint32_t tBegin = 0xffffffffu, tEnd = 0xffffffffu, tHinEnd = 0, finalStep = 0xffffffffu;
+			const uint32_t lastUnit = (n - 1) / RB;
+			auto enterUnit = [&](uint32_t b) {
+				B = b;
+				fresh = true;
+				if (b >= nU) { tBegin = 0xffffffffu; tEnd = 0xffffffffu; return; }
+				const uint64_t rowBase = (uint64_t)RB * b;
+				const uint64_t c0 = rowBase > k ? rowBase - k : 0;
+				const uint64_t c1 = rowBase + RB - 1 + k;
+				const uint64_t lastCol = c1 < m - 1 ? c1 : m - 1;
+				tBegin = c0 > lastCol ? 0xffffffffu : (uint32_t)(c0 + b);          // (a unit below the band at every column never runs)
+				tEnd = (uint32_t)(lastCol + b);
+				tHinEnd = b > 0 ? (uint32_t)(rowBase - 1 + k + b) : 0;              // last step whose column the upper neighbour also computes
+				finalStep = b == lastUnit ? m - 1 + b : 0xffffffffu;
+			};
+			enterUnit(lane);
 			if (lane == 0) resultSlot = -1;
 			const uint32_t steps = m + nU - 1;
 			for (uint32_t t = 0; t < steps; t++) {
 				if ((t & 1023u) == 0) {
 					uint32_t end = t + 2048 < m ? t + 2048 : m;
-					for (uint32_t c = loadedEnd + lane; c < end; c += 64) ring[c & (ED_RING - 1)] = (uint8_t)path[c];
+					for (uint32_t c = loadedEnd + lane; c < end; c += 64) {
+						const uint8_t ch = (uint8_t)path[c];
+						ring[c & (ED_RING - 1)] = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
+					}
 					loadedEnd = end > loadedEnd ? end : loadedEnd;
 					__syncthreads();
 				}
 				const uint32_t nbPack = __shfl(pack, (lane + 63) & 63);
-				// leave a finished unit
-				while (B < nU) {
-					const uint64_t c1 = (uint64_t)RB * B + RB - 1 + k;
-					const uint64_t lastCol = c1 < m - 1 ? c1 : m - 1;
-					if ((uint64_t)t > lastCol + B) { B += 64; fresh = true; } else break;
-				}
-				if (B >= nU) continue;
-				const int64_t c0s = (int64_t)RB * B - (int64_t)k;
-				const uint32_t c0 = c0s > 0 ? (uint32_t)c0s : 0;
-				if (t < B || t - B < c0) continue;
+				if (B < nU && t > tEnd) { do enterUnit(B + 64); while (B < nU && t > tEnd); }
+				if (t < tBegin) continue;
 				const uint32_t j = t - B;
 				if (fresh) {
 					fresh = false;
@@ -194,18 +207,18 @@ __global__ void __launch_bounds__(64) k_edit_distance(const EdPair* __restrict__
 					if (j == 0) score = (int32_t)(RB * (B + 1));
 					else score = (int32_t)(nbPack >> 2) - ((int32_t)(nbPack & 3u) - 1) + (int32_t)RB;   // below the upper neighbour's previous column, all +1
 				}
-				const uint8_t letter = ring[j & (ED_RING - 1)];
+				const uint32_t code = ring[j & (ED_RING - 1)];
 				int hin = 1;                         // top of the band (and row -1 of the matrix): +1 per column
-				if (B > 0 && (uint64_t)j <= (uint64_t)RB * B - 1 + k) hin = (int)(nbPack & 3u) - 1;
+				if (B > 0 && t <= tHinEnd) hin = (int)(nbPack & 3u) - 1;
 				uint64_t hinP = hin > 0 ? 1 : 0, hinN = hin < 0 ? 1 : 0;
 				for (int q = 0; q < G; q++) {
 					uint64_t Eq;
-					if (letter == 'A') Eq = eqA[q];
-					else if (letter == 'C') Eq = eqC[q];
-					else if (letter == 'G') Eq = eqG[q];
-					else if (letter == 'T') Eq = eqT[q];
-					else {                           // any other letter: compare the 64 read bases of this block directly
+					if (code < 4) {
+						const uint64_t lo = (code & 1) ? eqC[q] : eqA[q], hi = (code & 1) ? eqT[q] : eqG[q];
+						Eq = (code & 2) ? hi : lo;
+					} else {                         // any other letter: compare the 64 read bases of this block directly
 						Eq = 0;
+						const uint8_t letter = (uint8_t)path[j];
 						const uint64_t row0 = (uint64_t)RB * B + 64ull * q;
 						for (uint32_t i = 0; i < 64 && row0 + i < n; i++) if ((uint8_t)bases[rd.readOff + row0 + i] == letter) Eq |= 1ull << i;
 					}
@@ -225,7 +238,7 @@ __global__ void __launch_bounds__(64) k_edit_distance(const EdPair* __restrict__
 				const int hout = (int)hinP - (int)hinN;
 				score += hout;
 				pack = ((uint32_t)score << 2) | (uint32_t)(hout + 1);
-				if (j == m - 1 && B == (n - 1) / RB) {   // the cell (n-1, m-1): subtract the deltas of the padding rows below it
+				if (t == finalStep) {                // the cell (n-1, m-1): subtract the deltas of the padding rows below it
 					int32_t d = score;
 					for (int q = 0; q < G; q++) {
 						const uint64_t row0 = (uint64_t)RB * B + 64ull * q;
@@ -267,7 +280,8 @@ void launchEditDistance(hipStream_t stream, uint32_t unitBlocks, const EdPair* p
 		case 1: hipLaunchKernelGGL(k_edit_distance<1>, dim3(blocks), dim3(64), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance); break;
 		case 2: hipLaunchKernelGGL(k_edit_distance<2>, dim3(blocks), dim3(64), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance); break;
 		case 4: hipLaunchKernelGGL(k_edit_distance<4>, dim3(blocks), dim3(64), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance); break;
-		default: hipLaunchKernelGGL(k_edit_distance<8>, dim3(blocks), dim3(64), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance); break;
+		case 8: hipLaunchKernelGGL(k_edit_distance<8>, dim3(blocks), dim3(64), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance); break;
+		default: hipLaunchKernelGGL(k_edit_distance<16>, dim3(blocks), dim3(64), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance); break;
 	}
 }
 

@@ -49,6 +49,8 @@ typedef struct gc_params {
 	int32_t keep_traces;        /* 1: return per-anchor traces (debug / parity tests) */
 	int32_t keep_seeds;         /* 1: return the ordered seed list of every read (seed_* arrays; else they are empty) */
 	int32_t stitch;             /* 1: stitch the chain into one path (src/Aligner.cpp:754-822): read_path_off / path_* */
+	int32_t edit_distances;     /* 1: GreedyLength selection of the whole-read alignments and the two NW edit distances that pick
+	                             *    the winner (src/Aligner.cpp:636-654,845,901-905): read_long_off / long_index / *_edit_distance / chained_better */
 } gc_params;
 
 void gc_params_default(gc_params* p);
@@ -140,6 +142,13 @@ typedef struct gc_result {
 	uint32_t* path_node;
 	uint32_t* path_first_offset; uint32_t* path_last_offset;   /* [n_reads] */
 	uint64_t* path_cells;         /* [n_reads] */
+	/* decision (edit_distances): whole-read alignments kept by SelectAlignments(GreedyLength) (src/Aligner.cpp:636-639) as
+	 * indices into the read's longall_* list, best first; the NW edit distance of the best one's path against the read
+	 * (:645) and of the stitched path against the read (:845), -1 where there is none; and the test of :901-905 */
+	uint64_t* read_long_off;      /* [n_reads+1] */
+	uint32_t* long_index;
+	int64_t*  long_edit_distance; int64_t* chain_edit_distance;   /* [n_reads] */
+	uint8_t*  chained_better;     /* [n_reads] 1: the chained alignment is the read's result, 0: the selected whole-read alignments are */
 	/* work counters of the fragment pass: [0] dp tiles, [1] recompute tiles (last-slice flatten + backtrace),
 	 * [2] column steps, [3] trace items, [4] extensions, [5] backtrace tiles (subset of [1]) */
 	uint64_t counters[8];

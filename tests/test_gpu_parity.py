@@ -14,7 +14,7 @@ COMPARE_KEYS = [
     "anchor_trace_off", "anchor_trace_node", "anchor_trace_offset", "anchor_trace_seqpos", "anchor_trace_switch",
     "read_chain_off", "chain", "chain_score", "failed_assertion", "seeds_extended",
     "read_path_off", "path_node", "path_offset",
-]
+] + ["chain_edit_distance", "chained_better"]
 
 
 def compare(got, want, keys=COMPARE_KEYS):
@@ -34,7 +34,8 @@ def gca():
     return g
 
 
-LONG_KEYS = ["read_longall_off", "longall_start", "longall_end", "longall_score",
+LONG_KEYS = ["read_long_off", "long_start", "long_end", "long_score", "long_edit_distance",
+             "read_longall_off", "longall_start", "longall_end", "longall_score",
              "long_trace_off", "long_trace_node", "long_trace_offset", "long_trace_seqpos", "long_trace_switch"]
 
 
@@ -45,6 +46,10 @@ def run_case(gca, gfa, reads, long_pass=False, **kw):
     aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, long_pass=long_pass, **kw)
     got = aligner.align_reads(reads)
     expand_stitched_path(got, graph.array("nodeLength"))
+    # selected whole-read alignments come back as indices into the read's longall list
+    sel = np.repeat(got["read_longall_off"][:-1], np.diff(got["read_long_off"])) + got["long_index"]
+    for key in ("start", "end", "score"):
+        got["long_" + key] = got["longall_" + key][sel]
     want = Oracle(gfa, long_pass=long_pass, **kw).align(reads)
     return got, want
 
