@@ -294,7 +294,7 @@ class Aligner:
             out["counters_long"] = np.array(list(r.counters_long), dtype=np.uint64)
             out["kernel_us"] = np.array(list(r.kernel_us))
             out["host_us"] = np.array(list(r.host_us))
-            return {k: (v.astype(np.int64) if v.dtype.kind in "ui" and k not in ("counters", "counters_long") else v) for k, v in out.items()}
+            return out   # arrays keep the C ABI's dtypes (uint32/uint64/...): no widening copies on the hot path
         finally:
             self.lib.gc_result_free(res)
 

@@ -199,6 +199,14 @@ struct gc_reads {
 	~gc_reads() { if (devBases) (void)hipFree(devBases); if (devOffsets) (void)hipFree(devOffsets); if (devMasks) (void)hipFree(devMasks); if (devEqMasks) (void)hipFree(devEqMasks); if (devEdReads) (void)hipFree(devEdReads); }
 };
 
+struct EditDistanceRun {
+	hipStream_t streams[5] {};
+	hipEvent_t ready = nullptr;
+	std::vector<uint32_t> perm;        // position in the grouped order -> original pair index
+	std::vector<int64_t> grouped;      // results in grouped order (pinned not needed: small)
+	~EditDistanceRun() { for (auto& q : streams) if (q) (void)hipStreamDestroy(q); if (ready) (void)hipEventDestroy(ready); }
+};
+
 struct gc_stream {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[12] {};
@@ -209,6 +217,7 @@ struct gc_stream {
 	hipEvent_t longEv[2] {};
 	DeviceBuffer edPathNodes, edJobs, edLetters, edLettersLen, edPairs, edOut, edLongJobs, edLongLetters, edLongLettersLen, edLongPairs, edLongOut;
 	PinnedBuffer hEdPathNodes, hEdJobs, hEdPairs, hEdOut, hEdLongJobs, hEdLongPairs, hEdLongOut;
+	EditDistanceRun edChainRun, edLongRun;
 	std::vector<hipStream_t> groupStreams;   // read groups of the whole-read pass run their round loops concurrently
 	std::vector<hipEvent_t> groupEvents;     // two per group
 	DeviceBuffer longSeeds, longJobs, longAlns, longResults, longScratch, longCells, longCursor, longJobsFallback, longResultsFallback, longScratchFallback;
@@ -477,33 +486,62 @@ static void buildEqMasks(const char* seq, uint64_t len, uint64_t words, uint64_t
 	}
 }
 
-// Runs the NW kernel over `pairs`, escalating the rows-per-lane unit (1, 2, 4, 8, 16 blocks) for the pairs whose band does
-// not fit the smaller one. hPairs/hOut: pinned host staging; dPairs/dOut: device arrays of at least nPairs elements.
-// launchEditDistances queues the first attempt (unit 1) without waiting; finishEditDistances waits for it and reruns the rest.
-static void launchEditDistances(hipStream_t stream, EdPair* hPairs, int64_t* hOut, uint32_t nPairs, EdPair* dPairs, int64_t* dOut, const EdRead* dReads, const char* dBases,
-	const uint64_t* dEqMasks, const char* dLetters, const uint32_t* dLettersLen)
+// Runs the NW kernel over `pairs`. The rows-per-lane unit (1, 2, 4, 8, 16 blocks) a pair needs follows from its band
+// half-width k and its read length (gc_editdist.hip); pairs are grouped by unit, every group runs on its own stream (a
+// group of a few wide-band pairs is one long-running wave each and would otherwise hold up the others), and pairs
+// whose k had to grow past their unit's limit are rerun with the next unit.
+// hPairs/hOut: pinned host staging; dPairs/dOut: device arrays of at least nPairs elements; readLen: host read lengths.
+static uint32_t editDistanceUnit(uint32_t k, uint32_t readLen)
 {
-	if (!nPairs) return;
-	HIP_CHECK(hipMemcpyAsync(dPairs, hPairs, (size_t)nPairs * sizeof(EdPair), hipMemcpyHostToDevice, stream));
-	launchEditDistance(stream, 1, dPairs, nPairs, dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut);
-	HIP_CHECK(hipMemcpyAsync(hOut, dOut, (size_t)nPairs * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+	uint32_t unit = 1;
+	while (unit < 16 && k >= editDistanceMaxK(unit) && (readLen + 64 * unit - 1) / (64 * unit) > 64) unit *= 2;
+	return unit;
 }
-static void finishEditDistances(hipStream_t stream, EdPair* hPairs, int64_t* hOut, uint32_t nPairs, EdPair* dPairs, int64_t* dOut, const EdRead* dReads, const char* dBases,
+static void launchEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair* hPairs, int64_t* hOut, uint32_t nPairs, EdPair* dPairs, int64_t* dOut, const EdRead* dReads, const char* dBases,
+	const uint64_t* dEqMasks, const char* dLetters, const uint32_t* dLettersLen, const std::function<uint32_t(uint32_t)>& readLen)
+{
+	if (!nPairs) return;
+	if (!run.ready) {
+		HIP_CHECK(hipEventCreateWithFlags(&run.ready, hipEventDisableTiming));
+		for (auto& q : run.streams) HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+	}
+	std::vector<uint32_t> cls(nPairs);
+	uint32_t count[5] = { 0, 0, 0, 0, 0 }, begin[6];
+	for (uint32_t i = 0; i < nPairs; i++) {
+		uint32_t unit = editDistanceUnit(hPairs[i].k, readLen(hPairs[i].read)), c = 0;
+		while ((1u << c) < unit) c++;
+		cls[i] = c;
+		count[c]++;
+	}
+	begin[0] = 0;
+	for (int c = 0; c < 5; c++) begin[c + 1] = begin[c] + count[c];
+	run.perm.resize(nPairs);
+	{
+		uint32_t at[5] = { begin[0], begin[1], begin[2], begin[3], begin[4] };
+		std::vector<EdPair> grouped(nPairs);
+		for (uint32_t i = 0; i < nPairs; i++) { grouped[at[cls[i]]] = hPairs[i]; run.perm[at[cls[i]]++] = i; }
+		memcpy(hPairs, grouped.data(), (size_t)nPairs * sizeof(EdPair));   // hPairs is now in grouped order
+	}
+	HIP_CHECK(hipMemcpyAsync(dPairs, hPairs, (size_t)nPairs * sizeof(EdPair), hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipEventRecord(run.ready, stream));
+	for (int c = 0; c < 5; c++) {
+		if (!count[c]) continue;
+		HIP_CHECK(hipStreamWaitEvent(run.streams[c], run.ready, 0));
+		launchEditDistance(run.streams[c], 1u << c, dPairs + begin[c], count[c], dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut + begin[c]);
+		HIP_CHECK(hipMemcpyAsync(hOut + begin[c], dOut + begin[c], (size_t)count[c] * sizeof(int64_t), hipMemcpyDeviceToHost, run.streams[c]));
+	}
+}
+static void finishEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair* hPairs, int64_t* hOut, uint32_t nPairs, EdPair* dPairs, int64_t* dOut, const EdRead* dReads, const char* dBases,
 	const uint64_t* dEqMasks, const char* dLetters, const uint32_t* dLettersLen)
 {
 	if (!nPairs) return;
-	HIP_CHECK(hipStreamSynchronize(stream));
+	for (auto& q : run.streams) HIP_CHECK(hipStreamSynchronize(q));
+	// reruns for the pairs whose band outgrew their unit (grouped order throughout)
 	std::vector<uint32_t> todo;
-	auto collect = [&](const std::vector<uint32_t>& from, bool all) {
-		std::vector<uint32_t> next;
-		auto visit = [&](uint32_t i) {
-			if (hOut[i] == -3) throw std::runtime_error("path letters overflowed their slot");
-			if (hOut[i] == -2) next.push_back(i);
-		};
-		if (all) for (uint32_t i = 0; i < nPairs; i++) visit(i); else for (uint32_t i : from) visit(i);
-		return next;
-	};
-	todo = collect(todo, true);
+	for (uint32_t i = 0; i < nPairs; i++) {
+		if (hOut[i] == -3) throw std::runtime_error("path letters overflowed their slot");
+		if (hOut[i] == -2) todo.push_back(i);
+	}
 	std::vector<EdPair> sub;
 	std::vector<int64_t> subOut;
 	for (uint32_t unit = 2; unit <= 16 && !todo.empty(); unit *= 2) {
@@ -514,16 +552,14 @@ static void finishEditDistances(hipStream_t stream, EdPair* hPairs, int64_t* hOu
 		launchEditDistance(stream, unit, dPairs, (uint32_t)sub.size(), dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut);
 		HIP_CHECK(hipMemcpyAsync(subOut.data(), dOut, sub.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 		HIP_CHECK(hipStreamSynchronize(stream));
-		for (size_t i = 0; i < todo.size(); i++) hOut[todo[i]] = subOut[i];
-		todo = collect(todo, false);
+		std::vector<uint32_t> next;
+		for (size_t i = 0; i < todo.size(); i++) { hOut[todo[i]] = subOut[i]; if (subOut[i] == -2) next.push_back(todo[i]); }
+		todo.swap(next);
 	}
 	if (!todo.empty()) throw std::runtime_error("edit distance band too wide for the NW kernel (a read longer than 65536 bases more than 32256 edits away from its path)");
-}
-static void runEditDistances(hipStream_t stream, EdPair* hPairs, int64_t* hOut, uint32_t nPairs, EdPair* dPairs, int64_t* dOut, const EdRead* dReads, const char* dBases,
-	const uint64_t* dEqMasks, const char* dLetters, const uint32_t* dLettersLen)
-{
-	launchEditDistances(stream, hPairs, hOut, nPairs, dPairs, dOut, dReads, dBases, dEqMasks, dLetters, dLettersLen);
-	finishEditDistances(stream, hPairs, hOut, nPairs, dPairs, dOut, dReads, dBases, dEqMasks, dLetters, dLettersLen);
+	// back to the caller's order
+	run.grouped.assign(hOut, hOut + nPairs);
+	for (uint32_t i = 0; i < nPairs; i++) hOut[run.perm[i]] = run.grouped[i];
 }
 
 template <typename T> T* copyOut(const std::vector<T>& v)
@@ -575,7 +611,10 @@ int gc_edit_distance(const char* a, const uint64_t* a_off, const char* b, const 
 		if (bBytes) HIP_CHECK(hipMemcpy(pb, b, bBytes, hipMemcpyHostToDevice));
 		if (words) HIP_CHECK(hipMemcpy(pm, masks.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice));
 		HIP_CHECK(hipMemcpy(pr, reads.data(), n_pairs * sizeof(EdRead), hipMemcpyHostToDevice));
-		runEditDistances(nullptr, pairs.data(), out, (uint32_t)n_pairs, pp, po, pr, pb, pm, pa, nullptr);
+		EditDistanceRun run;
+		auto readLenOf = [&](uint32_t r) { return reads[r].len; };
+		launchEditDistances(run, nullptr, pairs.data(), out, (uint32_t)n_pairs, pp, po, pr, pb, pm, pa, nullptr, readLenOf);
+		finishEditDistances(run, nullptr, pairs.data(), out, (uint32_t)n_pairs, pp, po, pr, pb, pm, pa, nullptr);
 		return (int)GC_OK;
 	});
 }
@@ -1093,7 +1132,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				res->counters_long[6] = rounds;
 			};
 			// reads whose band did not fit the LDS tables (status 5) are rerun with the plain-layout kernel
-			longFallback = [=, &glue]() {
+			longFallback = [=]() {
 				HIP_CHECK(hipStreamSynchronize(ls));
 				std::vector<uint32_t> redo;
 				const bool forceAll = getenv("GC_LONG_FORCE_FALLBACK") != nullptr;   // test hook: run every read through the plain-layout kernel too
@@ -1328,7 +1367,9 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				hJobsPS[r] = PathSeqJob { glue[r].stitchedBegin, nCells, (uint32_t)sp.nodes.size(), (uint32_t)sp.cells, sp.firstOffset, sp.lastOffset };
 				if (sp.cells) {
 					uint32_t len = (uint32_t)(R->offsets[r + 1] - R->offsets[r]);
-					hPairs[nPairs++] = EdPair { nCells, (uint32_t)sp.cells, (uint32_t)r, (uint32_t)r, std::max<uint32_t>(64, (uint32_t)((sp.cells + len) / 16)) };
+					// first band: the length difference plus ~14 % of the shorter sequence (ONT-like error rates pass in one sweep)
+					uint32_t cells = (uint32_t)sp.cells, shorter = std::min(cells, len), longer = std::max(cells, len);
+					hPairs[nPairs++] = EdPair { nCells, cells, (uint32_t)r, (uint32_t)r, (longer - shorter) + std::max<uint32_t>(64, shorter / 7) };
 					pairRead.push_back((uint32_t)r);
 				}
 				nCells += sp.cells;
@@ -1342,19 +1383,25 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			if (nNodesTotal) HIP_CHECK(hipMemcpyAsync(dNodes, hNodes, nNodesTotal * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 			if (n) HIP_CHECK(hipMemcpyAsync(dJobsPS, hJobsPS, n * sizeof(PathSeqJob), hipMemcpyHostToDevice, stream));
 			launchChainPathSeq(stream, G->dev, dJobsPS, (uint32_t)n, dNodes, dLetters, dLettersLen);
-			launchEditDistances(stream, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen);
-			finishChainEditDistances = [=, &glue, &pairRead]() {   // called once the whole-read pass is done; the kernel ran beside it
-				finishEditDistances(stream, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen);
+			auto readLenOf = [R](uint32_t r) { return (uint32_t)(R->offsets[r + 1] - R->offsets[r]); };
+			launchEditDistances(st->edChainRun, stream, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen, readLenOf);
+			finishChainEditDistances = [=, &glue, &pairRead]() {   // waits for the kernels (they run beside the whole-read pass) and reruns the few pairs that need a wider band
+				finishEditDistances(st->edChainRun, stream, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen);
 				for (uint32_t i = 0; i < nPairs; i++) glue[pairRead[i]].chainEditDistance = hOut[i];
 			};
 		}
+		if (finishChainEditDistances) finishChainEditDistances();   // this thread would only wait for the whole-read pass otherwise
 		double stitchUs = nowUs() - tStitch;
-		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] chain stitching %.1f ms\n", stitchUs / 1e3);
+		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] chain stitching + its edit distances %.1f ms\n", stitchUs / 1e3);
 
 		// ---------------- whole-read pass results
+		double tJoined = nowUs();
 		std::vector<LongCell> longCells;
 		if (P->long_pass) {
+			double tJoin0 = nowUs();
 			for (auto& t : longThreads) t.join();
+			tJoined = nowUs();
+			if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] main thread waited %.1f ms for the whole-read pass\n", (tJoined - tJoin0) / 1e3);
 			for (auto& e : longErrors) if (e) std::rethrow_exception(e);
 			finishLongGroups();
 			res->kernel_us[5] = longWallEndUs.load() - tLongWall0;   // whole-read pass, wall clock from the first group's start to the last group's end
@@ -1434,7 +1481,9 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				hipStream_t lq = st->longStream;
 				if (n) HIP_CHECK(hipMemcpyAsync(dJobsPS, hJobsPS, n * sizeof(PathSeqJob), hipMemcpyHostToDevice, lq));
 				launchLongPathSeq(lq, G->dev, dJobsPS, (uint32_t)n, dLongCells, dLetters, dLettersLen);
-				runEditDistances(lq, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen);
+				auto readLenOf = [R](uint32_t r) { return (uint32_t)(R->offsets[r + 1] - R->offsets[r]); };
+				launchEditDistances(st->edLongRun, lq, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen, readLenOf);
+				finishEditDistances(st->edLongRun, lq, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen);
 				for (uint32_t i = 0; i < nPairs; i++) glue[pairRead[i]].longEditDistance = hOut[i];
 			}
 			if (P->keep_traces) {
@@ -1443,7 +1492,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			}
 		}
 
-		if (finishChainEditDistances) finishChainEditDistances();
+		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] after the whole-read pass: selection + its edit distances %.1f ms\n", (nowUs() - tJoined) / 1e3);
 
 		// ---------------- assemble the flat result: count per read, prefix-sum, fill in parallel
 		double tAsm = nowUs();

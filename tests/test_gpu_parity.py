@@ -44,7 +44,7 @@ def run_case(gca, gfa, reads, long_pass=False, **kw):
     graph = gca.AlignmentGraph(gfa)
     seeder = gca.MinimizerSeeder(graph)
     aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, long_pass=long_pass, **kw)
-    got = aligner.align_reads(reads)
+    got = {k: (v.astype(np.int64) if v.dtype.kind in "ui" and k not in ("counters", "counters_long") else v) for k, v in aligner.align_reads(reads).items()}
     expand_stitched_path(got, graph.array("nodeLength"))
     # selected whole-read alignments come back as indices into the read's longall list
     sel = np.repeat(got["read_longall_off"][:-1], np.diff(got["read_long_off"])) + got["long_index"]
