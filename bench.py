@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X GraphChainer hot path (BASELINE.json metric: reads/s and Gbp/s aligned).
 
-One "step" = one pass of the hot path (seed lookup -> seed ordering -> fragment seed-extension -> anchors ->
-co-linear chaining) over one batch of synthetic reads that is already resident in HBM.
+One "step" = one pass of the hot path (whole-read GraphAligner pass; seed lookup -> seed ordering -> fragment
+seed-extension -> anchors -> co-linear chaining -> chain stitching; NW edit distances and the chained-vs-whole-read
+decision) over one batch of synthetic reads that is already resident in HBM.
 
 Workload at N=1 = BASELINE.json configs[1]: chr22-like graph (50.8 Mbp backbone, SNP/indel bubbles every ~45 bp,
 SURVEY.md §8d) and 10 000 simulated 10 kb ONT-like reads, reference defaults. For N>1 every rank aligns its own
@@ -153,7 +154,7 @@ def main():
         ora.align(reads[:n_sample])
         cpu_t = time.perf_counter() - t0
         cpu_baseline = {"value": round(n_sample / cpu_t, 2), "unit": "reads/s", "cores": 1, "kind": "port",
-                        "sample": f"first {n_sample} reads of the same workload, same stages ({'whole-read pass, ' if long_pass else ''}seeding, fragment extension, anchors, chaining; plus chain stitching and two NW edit distances the GPU path does not do yet), 1 thread, {cpu_t:.1f} s"}
+                        "sample": f"first {n_sample} reads of the same workload, same stages ({'whole-read pass + selection, ' if long_pass else ''}seeding, fragment extension, anchors, chaining, chain stitching, NW edit distances), 1 thread, {cpu_t:.1f} s"}
 
     if rank == 0:
         line = {
@@ -163,7 +164,7 @@ def main():
             "gbp_per_sec_aligned": round(gbp_per_s, 5),
             "config": {"workload": f"BASELINE configs[1]: chr22-like synthetic DAG ({args.backbone} bp backbone, {graph.NodeSize()} split nodes), "
                                    f"{args.reads} x {args.read_len} bp ONT-like reads per GPU, split_len 35 split_gap {args.split_gap} bandwidth 10",
-                       "stages": ("whole-read GraphAligner pass + " if long_pass else "") + "seed lookup + seed ordering + fragment seed-extension + anchors + co-linear chaining",
+                       "stages": ("whole-read GraphAligner pass + selection + " if long_pass else "") + "seed lookup + seed ordering + fragment seed-extension + anchors + co-linear chaining + chain stitching + NW edit distances + chained-vs-whole-read decision",
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "parallelism": f"read-sharded x{world}, graph replicated, no collective"},
             "roofline": roofline,
             "roofline_other": roof_extend if roofline is roof_long else roof_long,
@@ -173,6 +174,8 @@ def main():
                          "wall_seed_lookup_and_copies": round(host_us[2] / 1e3, 3), "wall_extend_to_chain_and_copies": round(host_us[3] / 1e3, 3)},
             "setup_s": {"generate": round(t_gen, 1), "graph_build_upload": round(t_graph, 1), "minimizer_index": round(t_index, 1)},
             "reads_with_chain": int((chain_len > 0).sum()), "extensions_per_step": int(extensions),
+            "decision": {"chained_better": int(np.sum(out["chained_better"])), "mean_long_edit_distance": round(float(np.mean(out["long_edit_distance"][out["long_edit_distance"] >= 0])), 1) if long_pass and (out["long_edit_distance"] >= 0).any() else None,
+                         "mean_chain_edit_distance": round(float(np.mean(out["chain_edit_distance"][out["chain_edit_distance"] >= 0])), 1) if (out["chain_edit_distance"] >= 0).any() else None},
             "long_pass": {"reads_with_alignment": int((n_long > 0).sum()), "extensions_per_step": int(counters_long[4]), "rounds": int(counters_long[6]), "plain_layout_reruns": int(counters_long[7]),
                           "seeds_extended_mean": round(float(out["seeds_extended_long"].mean()), 2), "seeds_extended_max": int(out["seeds_extended_long"].max())} if long_pass else None,
         }
