@@ -13,6 +13,7 @@ Usage: python bench.py [--gpus N] [--steps K] [--warmup W]
        (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -140,9 +141,23 @@ def main():
                 "algorithmic_bytes_per_launch": int(nbytes / launches), "avg_launch_ms": round(us / 1e3 / launches, 3),
                 "tiles_per_launch": int((dp_tiles + recompute_tiles) / launches), "column_steps_per_s_G": round(column_steps / seconds / 1e9, 3) if seconds > 0 else 0.0}
 
+    def measured_traffic(kernel, launches):
+        """HBM bytes per launch from the newest committed PMC pass (profiles/rNN_pmc_traffic.json: rocprofv3 FETCH_SIZE + WRITE_SIZE,
+        separate passes over this same bench command); None when no profile is committed."""
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        if not files:
+            return None
+        with open(files[-1]) as f:
+            prof = json.load(f)
+        for name, rec in prof.get("kernels", {}).items():
+            if name.split("<")[0] == kernel and "FETCH_SIZE_KB_per_step" in rec and "WRITE_SIZE_KB_per_step" in rec:
+                return int((rec["FETCH_SIZE_KB_per_step"] + rec["WRITE_SIZE_KB_per_step"]) * 1024 / max(1.0, launches))
+        return None
+
     roof_extend = kernel_roofline("k_extend", counters, kernel_us[1])
     roof_long = kernel_roofline("k_long_extend", counters_long, kernel_us[4], counters_long[6]) if long_pass else None
     roofline = roof_long if (long_pass and kernel_us[4] >= kernel_us[1]) else roof_extend
+    roofline["traffic"] = measured_traffic(roofline["kernel"], roofline["launches_per_step"])
     extensions = counters[4]
 
     cpu_baseline = None
