@@ -1065,8 +1065,9 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				groupTraceBegin[g + 1] = groupTraceBegin[g] + budget;
 			}
 			unsigned long long* dRoundTrace = st->longRoundTrace.reserve<unsigned long long>(groupTraceBegin[nGroups]);
-			// extension scratch: one region per work item in flight
-			dLongScratch = st->longScratch.reserve<unsigned long long>((workCapacity + 64) * waveWords);
+			// extension scratch: one region per lane of a resident wave (persistent waves fetch work items), per read group
+			const uint64_t scratchLanes = std::min<uint64_t>(workCapacity + 64, 65536 + 64);
+			dLongScratch = st->longScratch.reserve<unsigned long long>((uint64_t)nGroups * scratchLanes * waveWords);
 			groupExtendUs.assign(nGroups, 0.0);
 			groupRounds.assign(nGroups, 0);
 			double* groupExtendUsPtr = groupExtendUs.data();
@@ -1085,7 +1086,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				launchLongInit(q, dLongJobs + r0, (uint32_t)nG, dLongState + r0);
 				uint32_t lastWork = 0xffffffffu;
 				for (int round = 0; round < 4096; round++) {
-					HIP_CHECK(hipMemsetAsync(cursor, 0, 2 * sizeof(unsigned long long), q));   // [0] work count, [1] round trace cursor
+					HIP_CHECK(hipMemsetAsync(cursor, 0, 3 * sizeof(unsigned long long), q));   // [0] work count, [1] round trace cursor, [2] next work slot
 					// tail rounds: once fewer than a quarter of the reads are still active the chip is mostly idle, so the
 					// remaining reads try several seeds per round (exact: k_long_merge re-checks them in order)
 					// (the number of work items stays below what round 0 had: active reads x candidates <= n)
@@ -1098,7 +1099,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					uint32_t nWorkItems = (uint32_t)hCursor[0];
 					if (nWorkItems == 0) break;
 					uint32_t team = longExtendTeamSize(nWorkItems);
-					uint32_t blocks = (nWorkItems + team - 1) / team;
+					uint32_t blocks = std::min((nWorkItems + team - 1) / team, longExtendMaxBlocks(team));
+					if (const char* env = getenv("GC_LONG_MAX_BLOCKS")) blocks = std::min<uint32_t>(blocks, (uint32_t)std::max(1, atoi(env)));   // test hook: force persistent waves
 					// Execution order: longest extensions first, so the round's tail is made of short ones.
 					{
 						uint32_t* order = hOrder + w0;
@@ -1109,8 +1111,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 						if (m >= 1) std::stable_sort(order, order + nWorkItems, [&](uint32_t a, uint32_t b) { return len[a] > len[b]; });
 					}
 					HIP_CHECK(hipEventRecord(ev0, q));
-					launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, hOrder + w0, nWorkItems, dLongScratch + (w0 + 64ull * g) * waveWords, team, blocks,
-						dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8);
+					launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, hOrder + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, team, blocks,
+						dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2);
 					HIP_CHECK(hipEventRecord(ev1, q));
 					launchLongMerge(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, dCandSeed + w0, dLongWorkResults + w0, dRoundTrace + groupTraceBeginPtr[g], maxAlignments, dLongState + r0, dLongAlns, dLongCells, dLongCursor, cellBudget);
 					lastWork = nWorkItems;

@@ -736,10 +736,11 @@ __global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __r
 // LANES = active lanes per wave ("team"). The pass is latency-bound and leaves most of the chip idle, so when there
 // are fewer work items than the chip has SIMDs x 64 lanes, running fewer lanes per wave shortens every wave: a wave's
 // instruction stream is the union of its lanes' divergent paths, and LDS per wave shrinks so more waves fit per CU.
-template <int LANES>
+template <int LANES, bool PERSISTENT>
 __global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint64_t* __restrict__ masks, ExtendConfig cfg,
 	const LongWork* __restrict__ work, const uint32_t* __restrict__ order, uint32_t nWork, unsigned long long* __restrict__ scratch, uint64_t wordsPerLane,
-	unsigned long long* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, LongWorkResult* __restrict__ results, unsigned long long* __restrict__ counters)
+	unsigned long long* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, LongWorkResult* __restrict__ results, unsigned long long* __restrict__ counters,
+	unsigned long long* __restrict__ nextSlot)
 {
 	__shared__ WaveLdsT<LANES> lds;
 	if (threadIdx.x >= LANES) return;
@@ -751,7 +752,21 @@ __global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessT
 	wsx.lanes = LANES;
 	wsx.maxSlices = cfg.maxSlices; wsx.maxItems = cfg.maxItems; wsx.maxTrace = cfg.maxTrace;
 	ExtCounters cnt {};
-	for (uint32_t slot = blockIdx.x * LANES + lane; slot < nWork; slot += gridDim.x * LANES) {
+	// One work item per wave while the launch fits the scratch (65536 lanes in flight, ~52 GB); larger rounds run
+	// persistent waves that fetch work items in execution order (longest first). The two are separate instantiations:
+	// the fetch loop costs the common case 6 % (265 vs 283 ms on cfg2) in register pressure.
+	bool done = false;
+	while (true) {
+		unsigned long long first = 0;
+		if (!PERSISTENT) { if (done) break; done = true; first = (unsigned long long)blockIdx.x * LANES; }
+		else {
+			if (lane == 0) first = atomicAdd(nextSlot, (unsigned long long)LANES);
+			if (LANES > 1) first = __shfl(first, 0);
+			else first = (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)first) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(first >> 32)) << 32);   // an atomic's result is per-lane to the compiler: say it is uniform so the extension state stays in scalar registers
+		}
+		if (first >= nWork) break;
+		const uint32_t slot = (uint32_t)first + lane;
+		if (slot >= nWork) break;
 		const uint32_t w = order[slot];   // execution order (longest first / length-balanced waves), results stay indexed by work item
 		LongWork it = work[w];
 		LongWorkResult res { 0, 0, EXT_FAILED, 0, 0 };
@@ -972,12 +987,23 @@ uint32_t longExtendTeamSize(uint32_t nWork)
 	return 1;
 }
 
+uint32_t longExtendMaxBlocks(uint32_t lanes)
+{
+	// 65536 lanes in flight bound the extension scratch at ~52 GB; up to that many work items every wave takes exactly one
+	// (measured faster than fewer, looping waves: 272 vs 286 ms on cfg2, and the fragment kernels get their share of the chip)
+	uint32_t byLanes = 65536u / (lanes ? lanes : 1);
+	return byLanes ? byLanes : 1;
+}
+
 void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
-	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters)
+	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters,
+	unsigned long long* nextSlot)
 {
 	if (!nWork) return;
 	uint64_t words = longWaveWordsPerLane(cfg);
-#define GC_LAUNCH_TEAM(N) hipLaunchKernelGGL(k_long_extend<N>, dim3(blocks), dim3(64), 0, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters)
+	const bool persistent = (uint64_t)blocks * lanes < nWork;   // fewer lanes than work items: waves loop and fetch
+#define GC_LAUNCH_TEAM(N) do { if (persistent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, true>), dim3(blocks), dim3(64), 0, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot); \
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, false>), dim3(blocks), dim3(64), 0, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot); } while (0)
 	switch (lanes) {
 		case 1: GC_LAUNCH_TEAM(1); break;
 		case 2: GC_LAUNCH_TEAM(2); break;
