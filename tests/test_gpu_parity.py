@@ -232,3 +232,36 @@ def test_edit_distance_kernel(gca):
     got = gca.edit_distance([p[0] for p in pairs], [p[1] for p in pairs])
     want = [len(a) + len(b) if (not a or not b) else int(lib.gco_edit_distance(a, len(a), b, len(b))) for a, b in pairs]
     assert list(map(int, got)) == want
+
+
+def _revcomp(s):
+    return s[::-1].translate(bytes.maketrans(b"ACGTacgtNn", b"TGCAtgcaNn"))
+
+
+def test_edge_cases_whole_read(gca, tmp_path):
+    """Whole-read pass, stitching and the decision on awkward input: empty / tiny reads, N runs, homopolymers, lower case,
+    reverse-strand reads, and a graph whose segments carry IUPAC letters (ambiguous split nodes)."""
+    from graphchainer_amd.synth import SynthGraph
+    sg = SynthGraph(50_000, seed=13)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    # sprinkle IUPAC letters over a few segments
+    lines = open(gfa).read().split("\n")
+    touched = 0
+    for i, line in enumerate(lines):
+        if line.startswith("S\t") and touched < 12:
+            f = line.split("\t")
+            if len(f[2]) >= 20 and i % 7 == 0:
+                seq = bytearray(f[2].encode())
+                seq[len(seq) // 2] = ord("NRYKMSW"[touched % 7])
+                f[2] = seq.decode()
+                lines[i] = "\t".join(f)
+                touched += 1
+    assert touched > 0
+    open(gfa, "w").write("\n".join(lines))
+    base = sg.sample_reads(6, 2500, seed=17)
+    with_n = bytearray(base[0])
+    with_n[300:340] = b"N" * 40
+    reads = [b"", b"ACGTACGTAC", bytes(with_n), b"A" * 600, base[1], base[2].lower(), _revcomp(base[3]), _revcomp(base[4])[:1800], base[5][:40]]
+    got, want = run_case(gca, gfa, reads, long_pass=True)
+    compare(got, want, COMPARE_KEYS + LONG_KEYS)
