@@ -43,7 +43,16 @@ static_assert(64 * 5 <= WAVE_WORDS, "the 64 backtrace columns (5 words each) ali
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;   // keeps LDS accesses as ds_read/ds_write (a generic pointer compiles to flat_*)
 
-struct LaneLds {   // one lane's view
+// REGCOLS (one extension per wave, all 64 lanes alive and running the same uniform code): the 64 recomputed columns of
+// the backtrace live in five VGPRs, column c in lane c (v_writelane / v_readlane with a uniform index) instead of LDS.
+// (this clang has no writelane builtin; "mine if my lane id equals c" is one compare and five selects, as cheap)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GC_READLANE(reg, lane) __builtin_amdgcn_readlane((int)(reg), (int)(lane))
+#else
+#define GC_READLANE(reg, lane) ((int)(reg))
+#endif
+template <bool REGCOLS>
+struct LaneLdsT {   // one lane's view
 	lds_u32* l;                  // LDS words of the team, [word][lanes]
 	uint32_t lane, lanes;        // this lane's index in its team and the team size (active lanes per wave)
 	unsigned long long* spill;   // team-interleaved HBM words for entries >= WAVE_CAP: word w of this lane at spill[w*lanes + lane]
@@ -94,16 +103,39 @@ struct LaneLds {   // one lane's view
 	__device__ __forceinline__ void qSet(uint32_t e, uint32_t node, uint32_t comp, const WS& x) const { set(2u, e, Entry { node, comp, (uint32_t)x.score, x.VP, x.VN }); }
 	__device__ __forceinline__ void qSetWs(uint32_t e, const WS& x) const { Entry old = get(2u, e); set(2u, e, Entry { old.w0, old.w1, (uint32_t)x.score, x.VP, x.VN }); }
 	__device__ __forceinline__ void qMove(uint32_t dst, uint32_t src) const { set(2u, dst, get(2u, src)); }
-	// backtrace columns (alias the LDS table words, LDS only): column c: VP, VN, score
-	__device__ __forceinline__ void colSet(uint32_t c, const WS& x) const { uint32_t base = c * 5; stL64(base, x.VP); stL64(base + 2, x.VN); stL(base + 4, (uint32_t)x.score); }
-	__device__ __forceinline__ WS col(uint32_t c) const { uint32_t base = c * 5; return WS { ldL64(base), ldL64(base + 2), (int32_t)ldL(base + 4) }; }
+	// backtrace columns (alias the LDS table words, or registers across the lanes): column c: VP, VN, score
+	mutable uint32_t cr[5];
+	__device__ __forceinline__ void colSet(uint32_t c, const WS& x) const
+	{
+		if (REGCOLS) {
+			const bool mine = threadIdx.x == c;
+			cr[0] = mine ? (uint32_t)x.VP : cr[0];
+			cr[1] = mine ? (uint32_t)(x.VP >> 32) : cr[1];
+			cr[2] = mine ? (uint32_t)x.VN : cr[2];
+			cr[3] = mine ? (uint32_t)(x.VN >> 32) : cr[3];
+			cr[4] = mine ? (uint32_t)x.score : cr[4];
+		} else { uint32_t base = c * 5; stL64(base, x.VP); stL64(base + 2, x.VN); stL(base + 4, (uint32_t)x.score); }
+	}
+	__device__ __forceinline__ WS col(uint32_t c) const
+	{
+		if (REGCOLS) {
+			uint32_t a0 = (uint32_t)GC_READLANE((int)cr[0], (int)c), a1 = (uint32_t)GC_READLANE((int)cr[1], (int)c);
+			uint32_t b0 = (uint32_t)GC_READLANE((int)cr[2], (int)c), b1 = (uint32_t)GC_READLANE((int)cr[3], (int)c);
+			return WS { (uint64_t)a0 | ((uint64_t)a1 << 32), (uint64_t)b0 | ((uint64_t)b1 << 32), GC_READLANE((int)cr[4], (int)c) };
+		}
+		uint32_t base = c * 5;
+		return WS { ldL64(base), ldL64(base + 2), (int32_t)ldL(base + 4) };
+	}
 };
+typedef LaneLdsT<false> LaneLds;
 
 // HBM scratch of one wave, lane-interleaved 8-byte words
 struct WaveScratch {
 	unsigned long long* base;   // team base
 	uint32_t lane, lanes;
 	uint32_t maxSlices, maxItems, maxTrace;
+	bool allLanes;              // all 64 lanes run one extension (identical values): single-record stores go through lane 0 only
+	__device__ __forceinline__ bool storer() const { return !allLanes || threadIdx.x == 0; }
 	// word offsets (per lane) of the regions
 	__device__ __forceinline__ unsigned long long& word(uint64_t w) const { return base[w * lanes + lane]; }
 	__device__ __forceinline__ uint64_t sliceBase(uint32_t s) const { return (uint64_t)s * 4; }
@@ -118,6 +150,7 @@ struct WSlice { int32_t minScore; uint32_t minNode, minOffset, first, count; int
 __device__ __forceinline__ void storeSlice(const WaveScratch& ws, uint32_t s, const WSlice& x)
 {
 	uint64_t b = ws.sliceBase(s);
+	if (!ws.storer()) return;
 	ws.word(b) = ((unsigned long long)(uint32_t)x.minScore << 32) | x.minNode;
 	ws.word(b + 1) = ((unsigned long long)x.minOffset << 32) | x.first;
 	ws.word(b + 2) = ((unsigned long long)x.count << 32) | (uint32_t)x.bandwidth;
@@ -137,6 +170,7 @@ __device__ __forceinline__ WSlice loadSlice(const WaveScratch& ws, uint32_t s)
 __device__ __forceinline__ void storeItem(const WaveScratch& ws, uint32_t i, const NodeItem& it)
 {
 	uint64_t b = ws.itemBase(i);
+	if (!ws.storer()) return;
 	ws.word(b) = it.sVP; ws.word(b + 1) = it.sVN; ws.word(b + 2) = it.eVP; ws.word(b + 3) = it.eVN; ws.word(b + 4) = it.HP; ws.word(b + 5) = it.HN;
 	ws.word(b + 6) = ((unsigned long long)(uint32_t)it.sScore << 32) | (uint32_t)it.eScore;
 	ws.word(b + 7) = ((unsigned long long)(uint32_t)it.minScore << 32) | it.node;
@@ -174,8 +208,9 @@ __device__ __forceinline__ TraceCell unpackCell(unsigned long long w)
 
 // (node, slice) tile on a node that is new in this slice; same as computeTile but the previous-slice summary comes
 // in by value and columns (backtrace recompute) go to the LDS column view.
+template <typename LANE_TABLES>
 __device__ inline TileResult computeTileW(const DGraph& g, uint32_t node, WS ws, bool prevExists, int32_t prevStartScore, uint64_t prevHP, uint64_t prevHN,
-	const Eq4& eq, NodeItem& out, const LaneLds* columns, int flatRows, uint32_t& status)
+	const Eq4& eq, NodeItem& out, const LANE_TABLES* columns, int flatRows, uint32_t& status)
 {
 	int nodeLength = g.nodeLength[node];
 	NodeSeq seq = loadNodeSeq(g, node);
@@ -233,10 +268,11 @@ __device__ inline TileResult computeTileW(const DGraph& g, uint32_t node, WS ws,
 
 
 // Full seed extension, wave layout. Trace goes to trace region `which` of the wave scratch (start cell first).
+template <bool REGCOLS>
 __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTables& ct, const EqSource& eqSrc, int bandwidthCfg, lds_u32* lds, const WaveScratch& wsx,
 	int len, uint32_t startNode, uint32_t startOffset, uint32_t which, uint32_t& nTrace, int32_t& score, ExtCounters& cnt)
 {
-	const LaneLds L { lds, wsx.lane, wsx.lanes, wsx.spillBase() };
+	const LaneLdsT<REGCOLS> L { lds, wsx.lane, wsx.lanes, wsx.spillBase(), { 0, 0, 0, 0, 0 } };
 	uint32_t status = EXT_OK;
 	nTrace = 0;
 	score = 0;
@@ -333,10 +369,10 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 			int pi = prevFind(pnode);
 			bool prevExists = pi >= 0;
 			NodeItem out;
-			LaneLds::Entry pe { 0, 0, 0, ~0ull, 0ull };
+			typename LaneLdsT<REGCOLS>::Entry pe { 0, 0, 0, ~0ull, 0ull };
 			if (prevExists) pe = L.get((uint32_t)buf, (uint32_t)pi);
 			GC_MARK(1);   // pop + previous-slice lookup
-			TileResult tr = computeTileW(g, pnode, pws, prevExists, (int32_t)pe.w1, pe.a, pe.b, eq, out, nullptr, flatRows, status);
+			TileResult tr = computeTileW<LaneLdsT<REGCOLS>>(g, pnode, pws, prevExists, (int32_t)pe.w1, pe.a, pe.b, eq, out, nullptr, flatRows, status);
 			GC_MARK(2);   // tile columns
 			if (status != EXT_OK) return status;
 			out.minScore = tr.minScore;
@@ -402,11 +438,26 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 	score = last.minScore;
 
 	// ---- backtrace. The LDS is reused for the recomputed columns of the current (slice, node).
-	const LaneLds* columns = &L;
+	const LaneLdsT<REGCOLS>* columns = &L;
+	// REGCOLS: trace cells are collected 64 at a time in a register pair across the lanes (cell i of the current group in
+	// lane i) and flushed with one coalesced 512 B store, instead of one 8 B store per cell from 64 identical lanes.
+	uint32_t tbLo = 0, tbHi = 0;
+	auto flushTrace = [&](uint32_t count) {   // the last `count` (1..64) cells pushed
+		if (REGCOLS && count && threadIdx.x < count) wsx.base[(wsx.traceBase(nTrace - count, which)) * wsx.lanes + wsx.lane + threadIdx.x] = (unsigned long long)tbLo | ((unsigned long long)tbHi << 32);
+	};
 	auto pushTraceW = [&](Cell c, bool sw) -> bool {
 		if (nTrace >= wsx.maxTrace) { status = EXT_OVERFLOW; return false; }
-		wsx.word(wsx.traceBase(nTrace, which)) = packCell(c, sw);
-		nTrace++;
+		const unsigned long long cell = packCell(c, sw);
+		if (REGCOLS) {
+			const bool mine = threadIdx.x == (nTrace & 63u);
+			tbLo = mine ? (uint32_t)cell : tbLo;
+			tbHi = mine ? (uint32_t)(cell >> 32) : tbHi;
+			nTrace++;
+			if ((nTrace & 63u) == 0) flushTrace(64);
+		} else {
+			wsx.word(wsx.traceBase(nTrace, which)) = cell;
+			nTrace++;
+		}
 		return true;
 	};
 	Cell here { last.minNode, last.minOffset, (last.j + 63 < len - 1) ? last.j + 63 : len - 1 };
@@ -642,6 +693,7 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 			if (!pushTraceW(Cell { here.node, off, -1 }, false)) return status;
 		}
 	}
+	flushTrace(nTrace & 63u);
 	cnt.traceItems += nTrace;
 	GC_MARK(10);
 	return status;

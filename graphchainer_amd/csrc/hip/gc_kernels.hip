@@ -743,14 +743,18 @@ __global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessT
 	unsigned long long* __restrict__ nextSlot)
 {
 	__shared__ WaveLdsT<LANES> lds;
-	if (threadIdx.x >= LANES) return;
-	// one extension per wave: nothing depends on the lane id, so the compiler can keep the extension's state in scalar registers
+	// One extension per wave (LANES == 1): all 64 lanes stay alive and run the same code on the same values - nothing depends
+	// on the lane id, so the compiler keeps the extension's state in scalar registers - and the lanes' VGPRs hold the 64
+	// backtrace columns. Stores hit one address with one value; atomics and the result record go through lane 0 only.
+	if (LANES > 1 && threadIdx.x >= LANES) return;
 	const uint32_t lane = LANES == 1 ? 0u : threadIdx.x;
+	const bool leader = LANES > 1 || threadIdx.x == 0;
 	WaveScratch wsx;
 	wsx.base = scratch + (uint64_t)blockIdx.x * wordsPerLane * LANES;
 	wsx.lane = lane;
 	wsx.lanes = LANES;
 	wsx.maxSlices = cfg.maxSlices; wsx.maxItems = cfg.maxItems; wsx.maxTrace = cfg.maxTrace;
+	wsx.allLanes = LANES == 1;
 	ExtCounters cnt {};
 	// One work item per wave while the launch fits the scratch (65536 lanes in flight, ~52 GB); larger rounds run
 	// persistent waves that fetch work items in execution order (longest first). The two are separate instantiations:
@@ -760,7 +764,7 @@ __global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessT
 		unsigned long long first = 0;
 		if (!PERSISTENT) { if (done) break; done = true; first = (unsigned long long)blockIdx.x * LANES; }
 		else {
-			if (lane == 0) first = atomicAdd(nextSlot, (unsigned long long)LANES);
+			if (threadIdx.x == 0) first = atomicAdd(nextSlot, (unsigned long long)LANES);
 			if (LANES > 1) first = __shfl(first, 0);
 			else first = (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)first) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(first >> 32)) << 32);   // an atomic's result is per-lane to the compiler: say it is uniform so the extension state stays in scalar registers
 		}
@@ -774,20 +778,23 @@ __global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessT
 			uint32_t nTrace = 0;
 			int32_t score = 0;
 			EqSource eqSrc { masks + it.maskOff, it.maskWords, it.startBit };
-			res.status = extendSeedWave(g, *ct, eqSrc, cfg.bandwidth, (lds_u32*)&lds.w[0][0], wsx, (int)it.seqLen, it.node, it.offset, 0, nTrace, score, cnt);
+			res.status = extendSeedWave<LANES == 1>(g, *ct, eqSrc, cfg.bandwidth, (lds_u32*)&lds.w[0][0], wsx, (int)it.seqLen, it.node, it.offset, 0, nTrace, score, cnt);
 			res.score = score;
 			if (res.status == EXT_OK) {
-				unsigned long long base = atomicAdd(traceCursor, (unsigned long long)nTrace);
+				unsigned long long base = 0;
+				if (leader) base = atomicAdd(traceCursor, (unsigned long long)nTrace);
+				if (LANES == 1) base = (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)base) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32);
 				if (base + nTrace <= traceCapacity) {
-					for (uint32_t i = 0; i < nTrace; i++) tracePool[base + i] = wsx.word(wsx.traceBase(i, 0));
+					if (LANES == 1) { for (uint32_t i = threadIdx.x; i < nTrace; i += 64) tracePool[base + i] = wsx.word(wsx.traceBase(i, 0)); }
+					else for (uint32_t i = 0; i < nTrace; i++) tracePool[base + i] = wsx.word(wsx.traceBase(i, 0));
 					res.traceOff = base;
 					res.traceLen = nTrace;
 				} else res.status = EXT_OVERFLOW;
 			}
 		}
-		results[w] = res;
+		if (leader) results[w] = res;
 	}
-	if (cnt.extensions) {
+	if (cnt.extensions && leader) {
 		atomicAdd(&counters[0], cnt.dpTiles);
 		atomicAdd(&counters[1], cnt.recomputeTiles);
 		atomicAdd(&counters[2], cnt.columnSteps);
