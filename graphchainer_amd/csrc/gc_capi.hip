@@ -1051,7 +1051,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			HIP_CHECK(hipStreamSynchronize(ls));   // the group streams start from uploaded inputs
 			// rounds: select -> extend -> merge until no read has a seed left to extend (see gc_kernels.hip, "K3-long in rounds")
 			LongState* dLongState = st->longState.reserve<LongState>(n);
-			const uint64_t workCapacity = 4 * n + 64ull * nGroups;   // all groups together; group g owns the slice for its reads
+			const uint64_t workCapacity = 8 * n + 64ull * nGroups;   // all groups together; group g owns the slice for its reads
 			LongWork* dLongWork = st->longWork.reserve<LongWork>(workCapacity);
 			LongWorkResult* dLongWorkResults = st->longWorkResults.reserve<LongWorkResult>(workCapacity);
 			uint32_t* dCandSeed = st->longCandSeed.reserve<uint32_t>(workCapacity);
@@ -1061,7 +1061,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			for (uint32_t g = 0; g <= nGroups; g++) groupBegin[g] = n * g / nGroups;
 			for (uint32_t g = 0; g < nGroups; g++) {
 				uint64_t budget = 0;
-				for (uint64_t r = groupBegin[g]; r < groupBegin[g + 1]; r++) { uint64_t len = R->offsets[r + 1] - R->offsets[r]; budget += 2 * (len + len / 2 + 1024); }   // up to two candidate seeds' worth per read (adaptive rounds never exceed one on average)
+				for (uint64_t r = groupBegin[g]; r < groupBegin[g + 1]; r++) { uint64_t len = R->offsets[r + 1] - R->offsets[r]; budget += 4 * (len + len / 2 + 1024); }   // up to four candidate seeds' worth per read (the speculation rule below keeps rounds within it)
 				groupTraceBegin[g + 1] = groupTraceBegin[g] + budget;
 			}
 			unsigned long long* dRoundTrace = st->longRoundTrace.reserve<unsigned long long>(groupTraceBegin[nGroups]);
@@ -1079,7 +1079,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				if (nG == 0) return;
 				hipStream_t q = st->groupStreams[g];
 				hipEvent_t ev0 = st->groupEvents[2 * g], ev1 = st->groupEvents[2 * g + 1];
-				const uint64_t w0 = 4 * r0 + 64ull * g, capacity = 4 * nG + 64;   // this group's slice of the work arrays
+				const uint64_t w0 = 8 * r0 + 64ull * g, capacity = 8 * nG + 64;   // this group's slice of the work arrays
 				unsigned long long* cursor = dLongCursor + 32 + 8 * g;
 				volatile unsigned long long* hCursor = hLongSmall + 32 + 8 * g;
 				const uint64_t traceBudget = groupTraceBeginPtr[g + 1] - groupTraceBeginPtr[g];
@@ -1092,6 +1092,9 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					// (the number of work items stays below what round 0 had: active reads x candidates <= n)
 					uint32_t maxCand = 1;
 					if (round > 0 && lastWork > 0) maxCand = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (2 * nG) / lastWork));
+					if (round > 0 && lastWork < 8192) maxCand = 8;   // fewer work items than wave slots: the round costs one extension's latency whatever it holds
+					// at most lastWork/2 reads are still active, so this keeps the round within the work arrays (8 per read) and the trace budget (4 seeds' worth per read)
+					if (round > 0 && lastWork > 0) maxCand = (uint32_t)std::min<uint64_t>(maxCand, std::max<uint64_t>(1, (8 * nG) / lastWork));
 					if (const char* env = getenv("GC_LONG_SPECULATE")) maxCand = (uint32_t)std::min(2, std::max(1, atoi(env)));   // test hook: speculate from round 0
 					launchLongSelect(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, R->totalBases, (uint32_t)P->min_cluster_size, maxCand, dLongState + r0, dLongAlns, dLongCells, dLongWork + w0, hWorkLen + w0, dCandSeed + w0, cursor, capacity);
 					launchPublish(q, cursor, (unsigned long long*)hCursor, 2);
