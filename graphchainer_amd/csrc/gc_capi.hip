@@ -72,6 +72,7 @@ public:
 	{
 		if (n == 0) return;
 		if (workers.empty() || n < 4) { for (size_t i = 0; i < n; i++) body(i, 0); return; }
+		std::lock_guard<std::mutex> oneJob(runMutex);   // batches in flight on different gc_streams take turns on the pool
 		{
 			std::unique_lock<std::mutex> lock(mutex);
 			job = &body;
@@ -122,7 +123,7 @@ private:
 		}
 	}
 	std::vector<std::thread> workers;
-	std::mutex mutex;
+	std::mutex mutex, runMutex;
 	std::condition_variable wake, done;
 	const std::function<void(size_t, size_t)>* job = nullptr;
 	std::atomic<size_t> next { 0 };
@@ -208,6 +209,7 @@ struct EditDistanceRun {
 };
 
 struct gc_stream {
+	int device = 0;             // the device the stream was created on; gc_align_batch selects it for the calling thread
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[12] {};
 	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, work, results, scratch, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
@@ -814,6 +816,7 @@ int gc_stream_create(gc_stream** out)
 	gc_stream* st = new gc_stream();
 	int rc = guarded([&]() {
 		requireDevice();
+		HIP_CHECK(hipGetDevice(&st->device));
 		HIP_CHECK(hipStreamCreate(&st->stream));
 		HIP_CHECK(hipStreamCreate(&st->longStream));
 		for (auto& e : st->ev) HIP_CHECK(hipEventCreate(&e));
@@ -918,6 +921,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 	*out = nullptr;
 	gc_result* res = (gc_result*)calloc(1, sizeof(gc_result));
 	int rc = guarded([&]() {
+		HIP_CHECK(hipSetDevice(st->device));   // the current device is per host thread
 		const uint64_t n = R->offsets.size() - 1;
 		const gc::AlignmentGraph& hg = G->host;
 		hipStream_t stream = st->stream;
