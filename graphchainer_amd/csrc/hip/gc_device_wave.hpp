@@ -65,9 +65,19 @@ struct LaneLdsT {   // one lane's view
 	struct Entry { uint32_t w0, w1, w2; uint64_t a, b; };
 	__device__ __forceinline__ uint32_t ldsBase(uint32_t t, uint32_t e) const { return (t * WAVE_CAP + e) * WAVE_ENTRY_WORDS; }
 	__device__ __forceinline__ uint32_t spillBase(uint32_t t, uint32_t e) const { return (t * WAVE_SPILL + (e - WAVE_CAP)) * 4; }
+	// REGCOLS: the three tables live in registers across the lanes as well - entry e of table t in lane e (64 entries, no spill):
+	// reads are v_readlane with a uniform index, writes one compare + selects, "find node" one compare + ballot.
+	mutable uint32_t tw[3][7];
+	__device__ __forceinline__ uint32_t maxEntries() const { return REGCOLS ? 64u : (uint32_t)WAVE_MAX_ENTRIES; }
 	__device__ __forceinline__ Entry get(uint32_t t, uint32_t e) const
 	{
 		Entry x;
+		if (REGCOLS) {
+			x.w0 = (uint32_t)GC_READLANE(tw[t][0], e); x.w1 = (uint32_t)GC_READLANE(tw[t][1], e); x.w2 = (uint32_t)GC_READLANE(tw[t][2], e);
+			x.a = (uint64_t)(uint32_t)GC_READLANE(tw[t][3], e) | ((uint64_t)(uint32_t)GC_READLANE(tw[t][4], e) << 32);
+			x.b = (uint64_t)(uint32_t)GC_READLANE(tw[t][5], e) | ((uint64_t)(uint32_t)GC_READLANE(tw[t][6], e) << 32);
+			return x;
+		}
 		if (e < WAVE_CAP) {
 			uint32_t base = ldsBase(t, e);
 			x.w0 = ldL(base); x.w1 = ldL(base + 1); x.w2 = ldL(base + 2); x.a = ldL64(base + 3); x.b = ldL64(base + 5);
@@ -80,6 +90,13 @@ struct LaneLdsT {   // one lane's view
 	}
 	__device__ __forceinline__ void set(uint32_t t, uint32_t e, const Entry& x) const
 	{
+		if (REGCOLS) {
+			const bool mine = threadIdx.x == e;
+			tw[t][0] = mine ? x.w0 : tw[t][0]; tw[t][1] = mine ? x.w1 : tw[t][1]; tw[t][2] = mine ? x.w2 : tw[t][2];
+			tw[t][3] = mine ? (uint32_t)x.a : tw[t][3]; tw[t][4] = mine ? (uint32_t)(x.a >> 32) : tw[t][4];
+			tw[t][5] = mine ? (uint32_t)x.b : tw[t][5]; tw[t][6] = mine ? (uint32_t)(x.b >> 32) : tw[t][6];
+			return;
+		}
 		if (e < WAVE_CAP) {
 			uint32_t base = ldsBase(t, e);
 			stL(base, x.w0); stL(base + 1, x.w1); stL(base + 2, x.w2); stL64(base + 3, x.a); stL64(base + 5, x.b);
@@ -88,9 +105,22 @@ struct LaneLdsT {   // one lane's view
 			S(base) = (unsigned long long)x.w0 | ((unsigned long long)x.w1 << 32); S(base + 1) = x.w2; S(base + 2) = x.a; S(base + 3) = x.b;
 		}
 	}
-	__device__ __forceinline__ uint32_t word0(uint32_t t, uint32_t e) const { return e < WAVE_CAP ? ldL(ldsBase(t, e)) : (uint32_t)S(spillBase(t, e)); }
-	__device__ __forceinline__ uint32_t word1(uint32_t t, uint32_t e) const { return e < WAVE_CAP ? ldL(ldsBase(t, e) + 1) : (uint32_t)(S(spillBase(t, e)) >> 32); }
-	__device__ __forceinline__ uint32_t word2(uint32_t t, uint32_t e) const { return e < WAVE_CAP ? ldL(ldsBase(t, e) + 2) : (uint32_t)S(spillBase(t, e) + 1); }
+	// REGCOLS: table 1 (the slice just finished) becomes table 0 (the previous slice)
+	__device__ __forceinline__ void rotate() const { for (int k = 0; k < 7; k++) tw[0][k] = tw[1][k]; }
+	__device__ __forceinline__ uint32_t word0(uint32_t t, uint32_t e) const { if (REGCOLS) return (uint32_t)GC_READLANE(tw[t][0], e); return e < WAVE_CAP ? ldL(ldsBase(t, e)) : (uint32_t)S(spillBase(t, e)); }
+	__device__ __forceinline__ uint32_t word1(uint32_t t, uint32_t e) const { if (REGCOLS) return (uint32_t)GC_READLANE(tw[t][1], e); return e < WAVE_CAP ? ldL(ldsBase(t, e) + 1) : (uint32_t)(S(spillBase(t, e)) >> 32); }
+	__device__ __forceinline__ uint32_t word2(uint32_t t, uint32_t e) const { if (REGCOLS) return (uint32_t)GC_READLANE(tw[t][2], e); return e < WAVE_CAP ? ldL(ldsBase(t, e) + 2) : (uint32_t)S(spillBase(t, e) + 1); }
+	// index of the entry of table t (first n entries) whose word 0 (the node) equals `node`, or -1
+	__device__ __forceinline__ int find(uint32_t t, uint32_t n, uint32_t node) const
+	{
+		if (REGCOLS) {
+			unsigned long long m = __ballot(tw[t][0] == node);
+			if (n < 64) m &= (1ull << n) - 1;
+			return m ? __ffsll((long long)m) - 1 : -1;
+		}
+		for (uint32_t i = 0; i < n; i++) if (word0(t, i) == node) return (int)i;
+		return -1;
+	}
 	// slice tables: buffer b (0/1), entry e: node, startScore, minScore, HP, HN
 	__device__ __forceinline__ uint32_t pNode(int b, uint32_t e) const { return word0((uint32_t)b, e); }
 	__device__ __forceinline__ int32_t pStart(int b, uint32_t e) const { return (int32_t)word1((uint32_t)b, e); }
@@ -105,6 +135,7 @@ struct LaneLdsT {   // one lane's view
 	__device__ __forceinline__ void qMove(uint32_t dst, uint32_t src) const { set(2u, dst, get(2u, src)); }
 	// backtrace columns (alias the LDS table words, or registers across the lanes): column c: VP, VN, score
 	mutable uint32_t cr[5];
+	mutable uint32_t idCur, idPrev;   // REGCOLS: node ids of the items of the backtrace's current / previous slice, item i in lane i
 	__device__ __forceinline__ void colSet(uint32_t c, const WS& x) const
 	{
 		if (REGCOLS) {
@@ -209,7 +240,7 @@ __device__ __forceinline__ TraceCell unpackCell(unsigned long long w)
 // (node, slice) tile on a node that is new in this slice; same as computeTile but the previous-slice summary comes
 // in by value and columns (backtrace recompute) go to the LDS column view.
 template <typename LANE_TABLES>
-__device__ inline TileResult computeTileW(const DGraph& g, uint32_t node, WS ws, bool prevExists, int32_t prevStartScore, uint64_t prevHP, uint64_t prevHN,
+__device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t node, WS ws, bool prevExists, int32_t prevStartScore, uint64_t prevHP, uint64_t prevHN,
 	const Eq4& eq, NodeItem& out, const LANE_TABLES* columns, int flatRows, uint32_t& status)
 {
 	int nodeLength = g.nodeLength[node];
@@ -269,10 +300,10 @@ __device__ inline TileResult computeTileW(const DGraph& g, uint32_t node, WS ws,
 
 // Full seed extension, wave layout. Trace goes to trace region `which` of the wave scratch (start cell first).
 template <bool REGCOLS>
-__device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTables& ct, const EqSource& eqSrc, int bandwidthCfg, lds_u32* lds, const WaveScratch& wsx,
+__device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const CorrectnessTables& ct, const EqSource& eqSrc, int bandwidthCfg, lds_u32* lds, const WaveScratch& wsx,
 	int len, uint32_t startNode, uint32_t startOffset, uint32_t which, uint32_t& nTrace, int32_t& score, ExtCounters& cnt)
 {
-	const LaneLdsT<REGCOLS> L { lds, wsx.lane, wsx.lanes, wsx.spillBase(), { 0, 0, 0, 0, 0 } };
+	const LaneLdsT<REGCOLS> L { lds, wsx.lane, wsx.lanes, wsx.spillBase(), {}, { 0, 0, 0, 0, 0 }, 0, 0 };
 	uint32_t status = EXT_OK;
 	nTrace = 0;
 	score = 0;
@@ -280,7 +311,7 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 	int numSlices = (len + 63) / 64;
 	if ((uint32_t)numSlices + 1 > wsx.maxSlices) return EXT_OVERFLOW;
 	// ---- initial slice (...Common.h:1243-1279)
-	int buf = 0;   // table buffer `buf` = previous slice
+	int buf = 0;   // table buffer `buf` = previous slice (LDS tables swap roles every slice; register tables rotate instead and stay 0/1)
 	uint32_t nPrev = 1;
 	{
 		int nl = g.nodeLength[startNode];
@@ -311,15 +342,12 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 		int32_t previousQuitScore = prevMinScore + prevBandwidth;
 		int bandwidth = bandwidthCfg;
 		int flatRows = (j + 64 > len) ? (len - j) : 0;
-		const int cb = buf ^ 1;   // table buffer `cb` = current slice
-		auto prevFind = [&](uint32_t node) -> int {
-			for (uint32_t i = 0; i < nPrev; i++) if (L.pNode(buf, i) == node) return (int)i;
-			return -1;
-		};
+		const int cb = REGCOLS ? 1 : (buf ^ 1);   // table buffer `cb` = current slice
+		auto prevFind = [&](uint32_t node) __attribute__((always_inline)) -> int { return L.find((uint32_t)(REGCOLS ? 0 : buf), nPrev, node); };
 		uint32_t nPending = 0;
-		auto pushEdge = [&](uint32_t target, WS incoming, bool skipFirst) {
-			uint32_t slot = nPending;
-			for (uint32_t i = 0; i < nPending; i++) if (L.qNode(i) == target) { slot = i; break; }
+		auto pushEdge = [&](uint32_t target, WS incoming, bool skipFirst) __attribute__((always_inline)) {
+			int found = L.find(2u, nPending, target);
+			uint32_t slot = found >= 0 ? (uint32_t)found : nPending;
 			WS add = incoming;
 			if (!skipFirst) {
 				int pi = prevFind(target);
@@ -338,7 +366,7 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 				if (!prevExists || wsBefore(add) < prevStart) { add.VP &= ~1ull; add.VN |= 1ull; }
 			}
 			if (slot == nPending) {
-				if (nPending >= WAVE_MAX_ENTRIES) { status = EXT_LDS_CAP; return; }
+				if (nPending >= L.maxEntries()) { status = EXT_LDS_CAP; return; }
 				L.qSet(slot, target, g.componentNumber[target], add);
 				nPending++;
 			} else {
@@ -365,7 +393,7 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 			if (best != nPending - 1) L.qMove(best, nPending - 1);
 			nPending--;
 			if (nItems >= wsx.maxItems) return EXT_OVERFLOW;
-			if (cur.count >= WAVE_MAX_ENTRIES) return EXT_LDS_CAP;
+			if (cur.count >= L.maxEntries()) return EXT_LDS_CAP;
 			int pi = prevFind(pnode);
 			bool prevExists = pi >= 0;
 			NodeItem out;
@@ -419,7 +447,7 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 		storeSlice(wsx, nSlices++, cur);
 		prevMinScore = cur.minScore; prevBandwidth = cur.bandwidth; prevJ = cur.j; prevCorrect = curCorrect; prevFalse = curFalse;
 		nPrev = cur.count;
-		buf = cb;
+		if (REGCOLS) L.rotate(); else buf = cb;
 		GC_MARK(5);
 	}
 	GC_MARK(5);   // slice epilogue (HMM, slice record)
@@ -442,10 +470,10 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 	// REGCOLS: trace cells are collected 64 at a time in a register pair across the lanes (cell i of the current group in
 	// lane i) and flushed with one coalesced 512 B store, instead of one 8 B store per cell from 64 identical lanes.
 	uint32_t tbLo = 0, tbHi = 0;
-	auto flushTrace = [&](uint32_t count) {   // the last `count` (1..64) cells pushed
+	auto flushTrace = [&](uint32_t count) __attribute__((always_inline)) {   // the last `count` (1..64) cells pushed
 		if (REGCOLS && count && threadIdx.x < count) wsx.base[(wsx.traceBase(nTrace - count, which)) * wsx.lanes + wsx.lane + threadIdx.x] = (unsigned long long)tbLo | ((unsigned long long)tbHi << 32);
 	};
-	auto pushTraceW = [&](Cell c, bool sw) -> bool {
+	auto pushTraceW = [&](Cell c, bool sw) __attribute__((always_inline)) -> bool {
 		if (nTrace >= wsx.maxTrace) { status = EXT_OVERFLOW; return false; }
 		const unsigned long long cell = packCell(c, sw);
 		if (REGCOLS) {
@@ -470,22 +498,33 @@ __device__ inline uint32_t extendSeedWave(const DGraph& g, const CorrectnessTabl
 	// to the HBM scan.
 	const uint32_t ID_CACHE = 64, idsCurBase = 64 * 5, idsPrevBase = 64 * 5 + ID_CACHE;
 	static_assert(64 * 5 + 2 * 64 <= WAVE_WORDS, "id caches must fit behind the backtrace columns");
-	auto fillIds = [&](const WSlice& sl, uint32_t base) {
+	auto fillIds = [&](const WSlice& sl, uint32_t base) __attribute__((always_inline)) {
+		if (REGCOLS) {   // one strided load: lane i fetches the node of item i (a register-table slice has at most 64)
+			uint32_t id = 0xffffffffu;
+			if (threadIdx.x < sl.count) id = (uint32_t)wsx.base[(wsx.itemBase(sl.first + threadIdx.x) + 7) * wsx.lanes + wsx.lane];
+			if (base == idsCurBase) L.idCur = id; else L.idPrev = id;
+			return;
+		}
 		uint32_t n = sl.count < ID_CACHE ? sl.count : ID_CACHE;
 		for (uint32_t i = 0; i < n; i++) L.stL(base + i, itemNode(wsx, sl.first + i));
 	};
-	auto findIn = [&](const WSlice& sl, uint32_t base, uint32_t node) -> int {
+	auto findIn = [&](const WSlice& sl, uint32_t base, uint32_t node) __attribute__((always_inline)) -> int {
+		if (REGCOLS) {
+			unsigned long long m = base == idsCurBase ? __ballot(L.idCur == node) : __ballot(L.idPrev == node);
+			if (sl.count < 64) m &= (1ull << sl.count) - 1;
+			return m ? (int)(sl.first + (uint32_t)__ffsll((long long)m) - 1) : -1;
+		}
 		if (sl.count > ID_CACHE) return findItemW(wsx, sl, node);
 		for (uint32_t i = 0; i < sl.count; i++) if (L.ldL(base + i) == node) return (int)(sl.first + i);
 		return -1;
 	};
-	auto findCur = [&](uint32_t node) -> int { return findIn(cs, idsCurBase, node); };
-	auto findPrev = [&](uint32_t node) -> int { return findIn(ps, idsPrevBase, node); };
+	auto findCur = [&](uint32_t node) __attribute__((always_inline)) -> int { return findIn(cs, idsCurBase, node); };
+	auto findPrev = [&](uint32_t node) __attribute__((always_inline)) -> int { return findIn(ps, idsPrevBase, node); };
 	NodeItem curIt {};
 	NodeItem prevIt {};
 	bool prevItExists = false;
 	// corner rule (pickBacktraceCorner, ...Common.h:710-804)
-	auto corner = [&](Cell& out, bool& nodeSwitch) -> bool {
+	auto corner = [&](Cell& out, bool& nodeSwitch) __attribute__((always_inline)) -> bool {
 		GC_MARK(10);
 		struct MarkOnExit { ExtCounters& cnt; __device__ ~MarkOnExit() { GC_MARK(9); } } markOnExit { cnt };   // bucket 9: corner rule
 		int32_t j = cs.j;
