@@ -239,9 +239,9 @@ __device__ __forceinline__ TraceCell unpackCell(unsigned long long w)
 
 // (node, slice) tile on a node that is new in this slice; same as computeTile but the previous-slice summary comes
 // in by value and columns (backtrace recompute) go to the LDS column view.
-template <typename LANE_TABLES>
+template <bool COLUMNS, typename LANE_TABLES>
 __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t node, WS ws, bool prevExists, int32_t prevStartScore, uint64_t prevHP, uint64_t prevHN,
-	const Eq4& eq, NodeItem& out, const LANE_TABLES* columns, int flatRows, uint32_t& status)
+	const Eq4& eq, NodeItem& out, const LANE_TABLES& tables, int flatRows, uint32_t& status)
 {
 	int nodeLength = g.nodeLength[node];
 	NodeSeq seq = loadNodeSeq(g, node);
@@ -275,7 +275,7 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 	r.flatMin = INT32_MAX;
 	r.flatOffset = 0;
 	if (flatRows > 0) r.flatMin = ws.score - popc64(ws.VP & ~flatMask) + popc64(ws.VN & ~flatMask);
-	if (columns) columns->colSet(0, ws);
+	if (COLUMNS) tables.colSet(0, ws);
 	uint64_t forceEq = prevExists ? ~0ull : ~1ull;
 	uint64_t HP = 0, HN = 0;
 	for (int pos = 1; pos < nodeLength; pos++) {
@@ -288,7 +288,7 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 			int32_t f = ws.score - popc64(ws.VP & ~flatMask) + popc64(ws.VN & ~flatMask);
 			if (f < r.flatMin) { r.flatMin = f; r.flatOffset = (uint32_t)pos; }
 		}
-		if (columns) columns->colSet((uint32_t)pos, ws);
+		if (COLUMNS) tables.colSet((uint32_t)pos, ws);
 		HP |= hp << pos;
 		HN |= hn << pos;
 	}
@@ -400,7 +400,7 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 			typename LaneLdsT<REGCOLS>::Entry pe { 0, 0, 0, ~0ull, 0ull };
 			if (prevExists) pe = L.get((uint32_t)buf, (uint32_t)pi);
 			GC_MARK(1);   // pop + previous-slice lookup
-			TileResult tr = computeTileW<LaneLdsT<REGCOLS>>(g, pnode, pws, prevExists, (int32_t)pe.w1, pe.a, pe.b, eq, out, nullptr, flatRows, status);
+			TileResult tr = computeTileW<false>(g, pnode, pws, prevExists, (int32_t)pe.w1, pe.a, pe.b, eq, out, L, flatRows, status);
 			GC_MARK(2);   // tile columns
 			if (status != EXT_OK) return status;
 			out.minScore = tr.minScore;
@@ -466,7 +466,6 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 	score = last.minScore;
 
 	// ---- backtrace. The LDS is reused for the recomputed columns of the current (slice, node).
-	const LaneLdsT<REGCOLS>* columns = &L;
 	// REGCOLS: trace cells are collected 64 at a time in a register pair across the lanes (cell i of the current group in
 	// lane i) and flushed with one coalesced 512 B store, instead of one 8 B store per cell from 64 identical lanes.
 	uint32_t tbLo = 0, tbHi = 0;
@@ -588,8 +587,8 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 			if (prevItExists) prevIt = loadItem(wsx, (uint32_t)pi);
 			GC_MARK(7);   // backtrace: item lookups + loads
 			NodeItem scratchItem;
-			computeTileW(g, curNode, itemStart(curIt), prevItExists, prevItExists ? prevIt.sScore : 0, prevItExists ? prevIt.HP : ~0ull, prevItExists ? prevIt.HN : 0ull,
-				eq, scratchItem, columns, 0, status);
+			computeTileW<true>(g, curNode, itemStart(curIt), prevItExists, prevItExists ? prevIt.sScore : 0, prevItExists ? prevIt.HP : ~0ull, prevItExists ? prevIt.HN : 0ull,
+				eq, scratchItem, L, 0, status);
 			if (scratchItem.eVP != curIt.eVP || scratchItem.eVN != curIt.eVN || scratchItem.eScore != curIt.eScore) status = EXT_ASSERT;
 			cnt.recomputeTiles++; cnt.backtraceTiles++; cnt.columnSteps += g.nodeLength[curNode];
 			if (status != EXT_OK) return status;
