@@ -1022,6 +1022,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			lcfg.maxPending = 96;
 			lcfg.maxTrace = (uint32_t)(maxReadLen + maxReadLen / 2 + 512);
 			if (const char* env = getenv("GC_LONG_MAX_ITEMS")) lcfg.maxItems = (uint32_t)std::max(64, atoi(env));
+			if (const char* env = getenv("GC_LONG_REG_CAP")) lcfg.regCap = (uint32_t)std::max(1, std::min(64, atoi(env)));   // test hook: force the LDS-table retry
 			uint64_t waveWords = longWaveWordsPerLane(lcfg);
 			LongSeed* dLongSeeds = st->longSeeds.reserve<LongSeed>(nLongSeeds);
 			LongJob* dLongJobs = st->longJobs.reserve<LongJob>(n);
@@ -1120,6 +1121,14 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					HIP_CHECK(hipEventRecord(ev0, q));
 					launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, hOrder + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, team, blocks,
 						dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2);
+					if (team == 1) {
+						// extensions whose band outgrew the 64-entry register tables: second try with the LDS/HBM tables (two lanes per wave,
+						// 28 + 228 entries); waves whose items are fine leave at once. Beyond that the read goes to the plain-layout fallback.
+						HIP_CHECK(hipMemsetAsync(cursor + 2, 0, sizeof(unsigned long long), q));
+						uint32_t retryBlocks = std::min((nWorkItems + 1) / 2, longExtendMaxBlocks(2));
+						launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, hOrder + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 2, retryBlocks,
+							dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, EXT_LDS_CAP);
+					}
 					HIP_CHECK(hipEventRecord(ev1, q));
 					launchLongMerge(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, dCandSeed + w0, dLongWorkResults + w0, dRoundTrace + groupTraceBeginPtr[g], maxAlignments, dLongState + r0, dLongAlns, dLongCells, dLongCursor, cellBudget);
 					lastWork = nWorkItems;

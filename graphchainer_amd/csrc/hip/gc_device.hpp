@@ -172,10 +172,12 @@ struct ExtendConfig {
 	uint32_t maxSlices;     // SliceInfo capacity (>= numSlices+1)
 	uint32_t maxPending;
 	uint32_t maxTrace;
+	uint32_t regCap = 64;   // whole-read pass, register tables: nodes per slice before the extension is retried with the LDS/HBM tables (test hook, <= 64)
 };
 
 // status codes of one extension
 enum : uint32_t { EXT_OK = 0, EXT_FAILED = 1, EXT_ASSERT = 2, EXT_OVERFLOW = 3 };
+enum : uint32_t { EXT_LDS_CAP = 5 };   // whole-read pass: a slice has more nodes than the wave tables hold (retried with larger tables, then the plain layout)
 
 struct LaneScratch {
 	SliceInfo* slices;

@@ -18,7 +18,6 @@
 
 namespace gcdev {
 
-enum : uint32_t { EXT_LDS_CAP = 5 };
 
 #ifndef WAVE_CAP
 #define WAVE_CAP 28
@@ -68,7 +67,8 @@ struct LaneLdsT {   // one lane's view
 	// REGCOLS: the three tables live in registers across the lanes as well - entry e of table t in lane e (64 entries, no spill):
 	// reads are v_readlane with a uniform index, writes one compare + selects, "find node" one compare + ballot.
 	mutable uint32_t tw[3][7];
-	__device__ __forceinline__ uint32_t maxEntries() const { return REGCOLS ? 64u : (uint32_t)WAVE_MAX_ENTRIES; }
+	uint32_t regCap;
+	__device__ __forceinline__ uint32_t maxEntries() const { return REGCOLS ? regCap : (uint32_t)WAVE_MAX_ENTRIES; }
 	__device__ __forceinline__ Entry get(uint32_t t, uint32_t e) const
 	{
 		Entry x;
@@ -165,6 +165,7 @@ struct WaveScratch {
 	unsigned long long* base;   // team base
 	uint32_t lane, lanes;
 	uint32_t maxSlices, maxItems, maxTrace;
+	uint32_t regCap;            // register tables: entries per table (<= 64)
 	bool allLanes;              // all 64 lanes run one extension (identical values): single-record stores go through lane 0 only
 	__device__ __forceinline__ bool storer() const { return !allLanes || threadIdx.x == 0; }
 	// word offsets (per lane) of the regions
@@ -303,7 +304,7 @@ template <bool REGCOLS>
 __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const CorrectnessTables& ct, const EqSource& eqSrc, int bandwidthCfg, lds_u32* lds, const WaveScratch& wsx,
 	int len, uint32_t startNode, uint32_t startOffset, uint32_t which, uint32_t& nTrace, int32_t& score, ExtCounters& cnt)
 {
-	const LaneLdsT<REGCOLS> L { lds, wsx.lane, wsx.lanes, wsx.spillBase(), {}, { 0, 0, 0, 0, 0 }, 0, 0 };
+	const LaneLdsT<REGCOLS> L { lds, wsx.lane, wsx.lanes, wsx.spillBase(), {}, wsx.regCap < 64 ? wsx.regCap : 64u, { 0, 0, 0, 0, 0 }, 0, 0 };
 	uint32_t status = EXT_OK;
 	nTrace = 0;
 	score = 0;

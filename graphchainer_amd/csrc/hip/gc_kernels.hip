@@ -740,7 +740,7 @@ template <int LANES, bool PERSISTENT>
 __global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint64_t* __restrict__ masks, ExtendConfig cfg,
 	const LongWork* __restrict__ work, const uint32_t* __restrict__ order, uint32_t nWork, unsigned long long* __restrict__ scratch, uint64_t wordsPerLane,
 	unsigned long long* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, LongWorkResult* __restrict__ results, unsigned long long* __restrict__ counters,
-	unsigned long long* __restrict__ nextSlot)
+	unsigned long long* __restrict__ nextSlot, uint32_t retryStatus)
 {
 	__shared__ WaveLdsT<LANES> lds;
 	// One extension per wave (LANES == 1): all 64 lanes stay alive and run the same code on the same values - nothing depends
@@ -755,6 +755,7 @@ __global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessT
 	wsx.lanes = LANES;
 	wsx.maxSlices = cfg.maxSlices; wsx.maxItems = cfg.maxItems; wsx.maxTrace = cfg.maxTrace;
 	wsx.allLanes = LANES == 1;
+	wsx.regCap = cfg.regCap;
 	ExtCounters cnt {};
 	// One work item per wave while the launch fits the scratch (65536 lanes in flight, ~52 GB); larger rounds run
 	// persistent waves that fetch work items in execution order (longest first). The two are separate instantiations:
@@ -772,6 +773,7 @@ __global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessT
 		const uint32_t slot = (uint32_t)first + lane;
 		if (slot >= nWork) break;
 		const uint32_t w = order[slot];   // execution order (longest first / length-balanced waves), results stay indexed by work item
+		if (retryStatus != 0 && results[w].status != retryStatus) { if (PERSISTENT) continue; else break; }   // retry launch: only the items the first launch gave up on
 		LongWork it = work[w];
 		LongWorkResult res { 0, 0, EXT_FAILED, 0, 0 };
 		if (it.seqLen > 0) {
@@ -1004,13 +1006,13 @@ uint32_t longExtendMaxBlocks(uint32_t lanes)
 
 void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
 	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters,
-	unsigned long long* nextSlot)
+	unsigned long long* nextSlot, uint32_t retryStatus)
 {
 	if (!nWork) return;
 	uint64_t words = longWaveWordsPerLane(cfg);
 	const bool persistent = (uint64_t)blocks * lanes < nWork;   // fewer lanes than work items: waves loop and fetch
-#define GC_LAUNCH_TEAM(N) do { if (persistent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, true>), dim3(blocks), dim3(64), 0, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot); \
-	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, false>), dim3(blocks), dim3(64), 0, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot); } while (0)
+#define GC_LAUNCH_TEAM(N) do { if (persistent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, true>), dim3(blocks), dim3(64), 0, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot, retryStatus); \
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, false>), dim3(blocks), dim3(64), 0, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot, retryStatus); } while (0)
 	switch (lanes) {
 		case 1: GC_LAUNCH_TEAM(1); break;
 		case 2: GC_LAUNCH_TEAM(2); break;

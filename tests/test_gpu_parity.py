@@ -180,9 +180,9 @@ def test_whole_read_pass_speculative_rounds(gca, tmp_path, monkeypatch):
     compare(got, want, COMPARE_KEYS + LONG_KEYS)
 
 
-@pytest.mark.parametrize("env", [{"GC_LONG_GROUPS": "2"}, {"GC_LONG_TEAM": "8"}, {"GC_LONG_TEAM": "64", "GC_LONG_ORDER": "0"}, {"GC_LONG_MAX_BLOCKS": "7"}, {"GC_LONG_MAX_BLOCKS": "3", "GC_LONG_TEAM": "4"}])
+@pytest.mark.parametrize("env", [{"GC_LONG_GROUPS": "2"}, {"GC_LONG_TEAM": "8"}, {"GC_LONG_TEAM": "64", "GC_LONG_ORDER": "0"}, {"GC_LONG_MAX_BLOCKS": "7"}, {"GC_LONG_MAX_BLOCKS": "3", "GC_LONG_TEAM": "4"}, {"GC_LONG_REG_CAP": "3"}, {"GC_LONG_REG_CAP": "6", "GC_LONG_MAX_BLOCKS": "5"}])
 def test_whole_read_pass_launch_shapes(gca, tmp_path, monkeypatch, env):
-    """Launch-shape knobs of the whole-read pass (concurrent read groups, lanes per wave, execution order, persistent waves) never change results."""
+    """Launch-shape knobs of the whole-read pass (concurrent read groups, lanes per wave, execution order, persistent waves, register-table cap -> LDS-table retry) never change results."""
     from graphchainer_amd.synth import SynthGraph
     for k, v in env.items():
         monkeypatch.setenv(k, v)
