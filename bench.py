@@ -64,6 +64,9 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         torch.cuda.set_device(local_rank)
 
+    if world > 1 and "GC_HOST_THREADS" not in os.environ:
+        # ranks share the host: split its cores between their worker pools (read by the library when it first loads)
+        os.environ["GC_HOST_THREADS"] = str(max(8, min(96, (os.cpu_count() or 8) // world)))
     import graphchainer_amd as gca
     from graphchainer_amd.synth import SynthGraph
 
