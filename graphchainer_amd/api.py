@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "gc_params_default", "gc_graph_create_from_gfa", "gc_graph_create", "gc_graph_destroy", "gc_graph_num_nodes",
     "gc_graph_size_bp", "gc_graph_array", "gc_seeder_create", "gc_seeder_destroy", "gc_seeder_array",
     "gc_stream_create", "gc_stream_destroy", "gc_reads_upload", "gc_reads_destroy", "gc_align_batch",
-    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_edit_distance",
+    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_edit_distance", "gc_format_gaf",
 ]
 
 
@@ -194,6 +194,7 @@ class ReadBatch:
         self.offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
         self.offsets[1:] = np.cumsum(self.lengths)
         blob = b"".join(bs)
+        self.blob = blob               # host copy: the output encoders read bases next to the device results
         self.handle = C.c_void_p()
         _check(self.lib.gc_reads_upload(blob, self.offsets.ctypes.data, len(bs), C.byref(self.handle)))
 
@@ -243,11 +244,22 @@ class Aligner:
         self.stream = C.c_void_p()
         _check(self.lib.gc_stream_create(C.byref(self.stream)))
 
-    def align_batch(self, batch):
-        """Runs seeding, fragment extension, anchor construction and chaining for a ReadBatch; returns a dict of arrays."""
+    def align_batch(self, batch, gaf_names=None, cigar_match_mismatch_merge=False):
+        """Runs the hot path for a ReadBatch; returns a dict of arrays. With gaf_names (one id per read; needs long_pass and
+        keep_traces) the dict also holds "gaf" (bytes: the reference's GAF lines) and "gaf_chained_skipped"."""
         res = _P(GcResult)()
         _check(self.lib.gc_align_batch(self.graph.handle, self.seeder.handle, self.stream, batch.handle, C.byref(self.params), C.byref(res)))
         try:
+            gaf = None
+            if gaf_names is not None:
+                names = (C.c_char_p * len(gaf_names))(*[n.encode() if isinstance(n, str) else bytes(n) for n in gaf_names])
+                text, length, skipped = C.c_void_p(), C.c_uint64(), C.c_uint64()
+                self.lib.gc_format_gaf.restype = C.c_int
+                self.lib.gc_format_gaf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+                _check(self.lib.gc_format_gaf(self.graph.handle, res, names, batch.blob, batch.offsets.ctypes.data, int(cigar_match_mismatch_merge),
+                                              C.byref(text), C.byref(length), C.byref(skipped)))
+                gaf = (C.string_at(text.value, length.value), int(skipped.value))
+                self.lib.gc_free(text)
             r = res.contents
             n = int(r.n_reads)
 
@@ -294,14 +306,16 @@ class Aligner:
             out["counters_long"] = np.array(list(r.counters_long), dtype=np.uint64)
             out["kernel_us"] = np.array(list(r.kernel_us))
             out["host_us"] = np.array(list(r.host_us))
+            if gaf is not None:
+                out["gaf"], out["gaf_chained_skipped"] = gaf
             return out   # arrays keep the C ABI's dtypes (uint32/uint64/...): no widening copies on the hot path
         finally:
             self.lib.gc_result_free(res)
 
-    def align_reads(self, reads):
+    def align_reads(self, reads, **kw):
         batch = ReadBatch(reads)
         try:
-            return self.align_batch(batch)
+            return self.align_batch(batch, **kw)
         finally:
             batch.close()
 

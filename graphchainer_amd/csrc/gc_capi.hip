@@ -5,6 +5,7 @@
 #include "hip/gc_kernels.hpp"
 #include "host/gc_graph.hpp"
 #include "host/gc_glue.hpp"
+#include "host/gc_output.hpp"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
@@ -617,6 +618,50 @@ int gc_edit_distance(const char* a, const uint64_t* a_off, const char* b, const 
 		auto readLenOf = [&](uint32_t r) { return reads[r].len; };
 		launchEditDistances(run, nullptr, pairs.data(), out, (uint32_t)n_pairs, pp, po, pr, pb, pm, pa, nullptr, readLenOf);
 		finishEditDistances(run, nullptr, pairs.data(), out, (uint32_t)n_pairs, pp, po, pr, pb, pm, pa, nullptr);
+		return (int)GC_OK;
+	});
+}
+
+// GAF text of a batch's final alignments (src/Aligner.cpp:1015-1022,300-311: AddGAFLine per alignment, the list sorted by
+// alignmentStart, one line each). Needs a result produced with keep_traces and edit_distances. Reads whose chained
+// alignment won (chained_better) are skipped and counted: their final trace comes from edlib's path mode, which this
+// library does not restate.
+int gc_format_gaf(const gc_graph* G, const gc_result* r, const char* const* read_names, const char* bases, const uint64_t* offsets, int cigar_match_mismatch_merge,
+	char** out_text, uint64_t* out_len, uint64_t* n_chained_skipped)
+{
+	if (!G || !r || !read_names || !offsets || !out_text || !out_len) return fail(GC_ERR_INVALID, "null argument");
+	if (!r->long_trace_off || !r->read_long_off || !r->long_index) return fail(GC_ERR_INVALID, "gc_format_gaf needs a result with long_pass, keep_traces and edit_distances");
+	return guarded([&]() {
+		const uint64_t n = r->n_reads;
+		std::vector<std::string> perRead(n);
+		std::atomic<uint64_t> skipped { 0 };
+		WorkerPool::instance().run(n, [&](size_t i, size_t) {
+			if (r->chained_better[i]) { skipped++; return; }
+			struct Item { uint32_t start; uint64_t aln; };
+			std::vector<Item> items;
+			for (uint64_t k = r->read_long_off[i]; k < r->read_long_off[i + 1]; k++) {
+				uint64_t a = r->read_longall_off[i] + r->long_index[k];
+				items.push_back(Item { r->longall_start[a], a });
+			}
+			std::sort(items.begin(), items.end(), [](const Item& l, const Item& rr) { return l.start < rr.start; });   // src/Aligner.cpp:1022
+			std::string& text = perRead[i];
+			for (const Item& it : items) {
+				uint64_t t0 = r->long_trace_off[it.aln], t1 = r->long_trace_off[it.aln + 1];
+				gc::TraceView tv { r->long_trace_node + t0, r->long_trace_offset + t0, r->long_trace_seqpos + t0, r->long_trace_switch + t0, t1 - t0 };
+				text += gc::formatGafLine(G->host, read_names[i] ? read_names[i] : "", bases + offsets[i], offsets[i + 1] - offsets[i], tv, cigar_match_mismatch_merge != 0);
+				text += '\n';
+			}
+		});
+		uint64_t total = 0;
+		for (const auto& t : perRead) total += t.size();
+		char* buf = (char*)malloc(total + 1);
+		if (!buf) throw std::runtime_error("out of memory");
+		uint64_t at = 0;
+		for (const auto& t : perRead) { memcpy(buf + at, t.data(), t.size()); at += t.size(); }
+		buf[total] = 0;
+		*out_text = buf;
+		*out_len = total;
+		if (n_chained_skipped) *n_chained_skipped = skipped.load();
 		return (int)GC_OK;
 	});
 }

@@ -174,6 +174,17 @@ void gc_free(void* p);
  * src/Aligner.cpp:645 and :845 (characters compare by equality, as in edlib's default alphabet handling). */
 int gc_edit_distance(const char* a, const uint64_t* a_off, const char* b, const uint64_t* b_off, uint64_t n_pairs, int64_t* out);
 
+/* ---- output ------------------------------------------------------------------------ */
+
+/* GAF text of the batch's final alignments, one line per alignment in the reference's order (AddGAFLine +
+ * GraphAlignerGAFAlignment::traceToAlignment, src/GraphAlignerGAFAlignment.h:38-196; the per-read list sorted by
+ * alignmentStart, src/Aligner.cpp:1022, written by writeGAFToQueue :300-311). `result` must come from gc_align_batch with
+ * long_pass, keep_traces and edit_distances; bases/offsets are the read batch as given to gc_reads_upload; read_names[i]
+ * is the FASTQ id. Reads whose chained alignment won (chained_better) are skipped and counted in n_chained_skipped: their
+ * final trace needs edlib's path mode. *out_text is malloc'd (gc_free), NUL-terminated, *out_len bytes long. */
+int gc_format_gaf(const gc_graph* g, const gc_result* result, const char* const* read_names, const char* bases, const uint64_t* offsets,
+                  int cigar_match_mismatch_merge, char** out_text, uint64_t* out_len, uint64_t* n_chained_skipped);
+
 int gc_device_count(void);
 int gc_set_device(int device);
 

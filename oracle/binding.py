@@ -109,6 +109,12 @@ class Oracle:
             raise RuntimeError(self.lib.gco_error(self.h).decode())
         return {name: self._array(name) for name in RESULT_ARRAYS}
 
+    def gaf(self, merge=False):
+        """GAF text of the last align() call (read ids r0, r1, ...), the reference's writer restated (oracle/output.hpp)."""
+        self.lib.gco_gaf.restype = C.c_char_p
+        self.lib.gco_gaf.argtypes = [C.c_void_p, C.c_int]
+        return self.lib.gco_gaf(self.h, int(merge))
+
 
 class RefUnits:
     """The reference's own WordSlice.h / AlignmentCorrectnessEstimation.cpp / edlib, compiled unmodified."""

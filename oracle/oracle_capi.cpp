@@ -2,6 +2,7 @@
 // small C interface so tests/, smoke() and bench.py's cpu_baseline leg can run it through ctypes.
 // Nothing in graphchainer_amd/ may link or call this file.
 #include "pipeline.hpp"
+#include "output.hpp"
 #include <chrono>
 #include <cstring>
 #include <map>
@@ -260,6 +261,7 @@ using namespace oracle;
 struct OracleHandle {
 	Oracle o;
 	Export ex;
+	std::string gaf[2];   // GAF text of the last gco_align call (read ids r0, r1, ...): [0] =/X cigar, [1] merged M cigar
 	std::string error;
 };
 
@@ -295,6 +297,7 @@ int gco_align(void* hv, const char* bases, const uint64_t* off, int n)
 	AlignerState state(h->o.graph);
 	h->o.counters = AlignerCounters();
 	for (double& s : h->o.stageSeconds) s = 0;
+	h->gaf[0].clear(); h->gaf[1].clear();
 	const char* names[] = { "read_seed_off", "read_frag_off", "read_anchor_off", "read_chain_off", "read_long_off", "read_longall_off", "read_path_off", "anchor_path_off", "anchor_trace_off", "long_trace_off" };
 	for (const char* nm : names) ex[nm].push_back(0);
 	for (int r = 0; r < n; r++) {
@@ -338,6 +341,18 @@ int gco_align(void* hv, const char* bases, const uint64_t* off, int n)
 		for (size_t c : res.chain) ex["chain"].push_back((int64_t)c);
 		ex["read_chain_off"].push_back((int64_t)ex["chain"].size());
 		ex["chain_score"].push_back((int64_t)res.chainScore);
+		// final alignments of the read (src/Aligner.cpp:901-911): the selected whole-read alignments unless the chained one
+		// won (its trace comes from edlib's path mode and is not restated); AddGAFLine each (:1015-1019), sort by
+		// alignmentStart (:1022), one line each (:300-311)
+		if (!res.chainedBetter) {
+			std::vector<AlignmentItem> finalAlns = res.longAlignments;
+			for (int m = 0; m < 2; m++) {
+				std::vector<std::pair<size_t, std::string>> lines;
+				for (const AlignmentItem& a : finalAlns) lines.push_back({ a.alignmentStart, traceToGaf(h->o.graph, "r" + std::to_string(r), seq, *a.trace, m == 1) });
+				std::sort(lines.begin(), lines.end(), [](const std::pair<size_t, std::string>& l, const std::pair<size_t, std::string>& rr) { return l.first < rr.first; });
+				for (const auto& l : lines) { h->gaf[m] += l.second; h->gaf[m] += '\n'; }
+			}
+		}
 		auto dumpAlns = [&](const std::vector<AlignmentItem>& alns, const std::string& prefix, bool traces) {
 			for (const AlignmentItem& aln : alns) {
 				ex[prefix + "_start"].push_back((int64_t)aln.alignmentStart);
@@ -370,6 +385,8 @@ int gco_align(void* hv, const char* bases, const uint64_t* off, int n)
 	for (double s : h->o.stageSeconds) ex["stage_microseconds"].push_back((int64_t)(s * 1e6));
 	return 0;
 }
+
+const char* gco_gaf(void* hv, int merge) { return ((OracleHandle*)hv)->gaf[merge ? 1 : 0].c_str(); }
 
 const int64_t* gco_array(void* hv, const char* name, uint64_t* count)
 {

@@ -265,3 +265,39 @@ def test_edge_cases_whole_read(gca, tmp_path):
     reads = [b"", b"ACGTACGTAC", bytes(with_n), b"A" * 600, base[1], base[2].lower(), _revcomp(base[3]), _revcomp(base[4])[:1800], base[5][:40]]
     got, want = run_case(gca, gfa, reads, long_pass=True)
     compare(got, want, COMPARE_KEYS + LONG_KEYS)
+
+
+@pytest.mark.parametrize("merge", [False, True])
+def test_gaf_output(gca, tmp_path, merge):
+    """GAF lines of the final alignments (node path with original names, cigar, NM/dv/id tags, per-read order) against the
+    oracle's restatement of GraphAlignerGAFAlignment.h; graph with IUPAC letters, reverse-strand and chimeric reads."""
+    from graphchainer_amd.synth import SynthGraph
+    from oracle import Oracle
+    sg = SynthGraph(80_000, seed=21)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    lines = open(gfa).read().split("\n")
+    touched = 0
+    for i, line in enumerate(lines):
+        if line.startswith("S\t") and touched < 8 and i % 11 == 0:
+            f = line.split("\t")
+            if len(f[2]) >= 20:
+                seq = bytearray(f[2].encode())
+                seq[len(seq) // 3] = ord("NRYK"[touched % 4])
+                f[2] = seq.decode()
+                lines[i] = "\t".join(f)
+                touched += 1
+    open(gfa, "w").write("\n".join(lines))
+    reads = sg.sample_reads(8, 3000, seed=2)
+    reads.append(_revcomp(reads[0]))
+    reads.append(reads[1][:900] + reads[2][400:1700])
+    graph = gca.AlignmentGraph(gfa)
+    seeder = gca.MinimizerSeeder(graph)
+    aligner = gca.Aligner(graph, seeder, keep_traces=True, long_pass=True)
+    got = aligner.align_reads(reads, gaf_names=[f"r{i}" for i in range(len(reads))], cigar_match_mismatch_merge=merge)
+    ora = Oracle(gfa, long_pass=True)
+    ora.align(reads)
+    want = ora.gaf(merge)
+    assert got["gaf"] == want
+    assert got["gaf"].count(b"\n") >= len(reads) - got["gaf_chained_skipped"] - 1
+    assert b"cg:Z:" in got["gaf"]
