@@ -131,7 +131,9 @@ __device__ __forceinline__ LaneScratch laneScratch(uint8_t* slab, const ExtendCo
 	return sc;
 }
 
-__global__ void __launch_bounds__(64) k_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg,
+// 4 waves per SIMD (<= 128 VGPRs; the kernel wanted 131 and ran 3): it waits on memory 56 % of the time, so the extra wave
+// pays for the 4 spilled registers: 34.2 -> 29.0 ms alone on cfg2 (5 or 6 waves spill 57 / 196 registers and lose).
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg,
 	const ExtItem* __restrict__ work, uint32_t nWork, const char* __restrict__ bases, ExtResult* __restrict__ results,
 	uint8_t* __restrict__ scratch, uint64_t slabBytes, TraceCell* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity,
 	unsigned long long* __restrict__ counters)
