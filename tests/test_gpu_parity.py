@@ -301,3 +301,34 @@ def test_gaf_output(gca, tmp_path, merge):
     assert got["gaf"] == want
     assert got["gaf"].count(b"\n") >= len(reads) - got["gaf_chained_skipped"] - 1
     assert b"cg:Z:" in got["gaf"]
+
+
+def test_chained_alignment_wins(gca, tmp_path):
+    """Reads with a 1.5 kb deletion: the whole-read aligner stops at the breakpoint, the chain bridges it (stitching with a
+    BFS bridge), and the edit distances make the chained alignment the read's result (src/Aligner.cpp:901-905)."""
+    from graphchainer_amd.synth import SynthGraph
+    from oracle import Oracle
+    sg = SynthGraph(200_000, seed=19)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    bb = sg.backbone.tobytes()
+    reads = [bb[x:x + 3000] + bb[x + 4500:x + 7500] for x in (10_000, 60_000, 120_000)]
+    reads += [_revcomp(reads[0])]
+    reads += sg.sample_reads(3, 4000, seed=8)
+    graph = gca.AlignmentGraph(gfa)
+    seeder = gca.MinimizerSeeder(graph)
+    aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, long_pass=True)
+    names = [f"r{i}" for i in range(len(reads))]
+    raw = aligner.align_reads(reads, gaf_names=names)
+    got = {k: (v.astype(np.int64) if isinstance(v, np.ndarray) and v.dtype.kind in "ui" and k not in ("counters", "counters_long") else v) for k, v in raw.items()}
+    expand_stitched_path(got, graph.array("nodeLength"))
+    sel = np.repeat(got["read_longall_off"][:-1], np.diff(got["read_long_off"])) + got["long_index"]
+    for key in ("start", "end", "score"):
+        got["long_" + key] = got["longall_" + key][sel]
+    ora = Oracle(gfa, long_pass=True)
+    want = ora.align(reads)
+    compare(got, want, COMPARE_KEYS + LONG_KEYS)
+    assert int(np.sum(got["chained_better"][:4])) >= 3          # the deletion reads
+    assert int(np.sum(got["chained_better"][4:])) == 0           # ordinary reads keep their whole-read alignment
+    assert raw["gaf_chained_skipped"] == int(np.sum(got["chained_better"]))
+    assert raw["gaf"] == ora.gaf(False)
