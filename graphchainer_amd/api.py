@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "gc_params_default", "gc_graph_create_from_gfa", "gc_graph_create", "gc_graph_destroy", "gc_graph_num_nodes",
     "gc_graph_size_bp", "gc_graph_array", "gc_seeder_create", "gc_seeder_destroy", "gc_seeder_array",
     "gc_stream_create", "gc_stream_destroy", "gc_reads_upload", "gc_reads_destroy", "gc_align_batch",
-    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_edit_distance", "gc_format_gaf",
+    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_edit_distance", "gc_format_gaf", "gc_format_json", "gc_format_gam",
 ]
 
 
@@ -244,22 +244,29 @@ class Aligner:
         self.stream = C.c_void_p()
         _check(self.lib.gc_stream_create(C.byref(self.stream)))
 
-    def align_batch(self, batch, gaf_names=None, cigar_match_mismatch_merge=False):
+    def align_batch(self, batch, gaf_names=None, cigar_match_mismatch_merge=False, other_formats=False):
         """Runs the hot path for a ReadBatch; returns a dict of arrays. With gaf_names (one id per read; needs long_pass and
-        keep_traces) the dict also holds "gaf" (bytes: the reference's GAF lines) and "gaf_chained_skipped"."""
+        keep_traces) the dict also holds "gaf" (bytes: the reference's GAF lines) and "gaf_chained_skipped"; with other_formats also "json" (JSON
+        lines) and "gam" (gzip members of framed vg::Alignment messages)."""
         res = _P(GcResult)()
         _check(self.lib.gc_align_batch(self.graph.handle, self.seeder.handle, self.stream, batch.handle, C.byref(self.params), C.byref(res)))
         try:
             gaf = None
             if gaf_names is not None:
                 names = (C.c_char_p * len(gaf_names))(*[n.encode() if isinstance(n, str) else bytes(n) for n in gaf_names])
-                text, length, skipped = C.c_void_p(), C.c_uint64(), C.c_uint64()
-                self.lib.gc_format_gaf.restype = C.c_int
-                self.lib.gc_format_gaf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-                _check(self.lib.gc_format_gaf(self.graph.handle, res, names, batch.blob, batch.offsets.ctypes.data, int(cigar_match_mismatch_merge),
-                                              C.byref(text), C.byref(length), C.byref(skipped)))
-                gaf = (C.string_at(text.value, length.value), int(skipped.value))
-                self.lib.gc_free(text)
+
+                def encode(fn, *extra):
+                    text, length, skipped = C.c_void_p(), C.c_uint64(), C.c_uint64()
+                    fn.restype = C.c_int
+                    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p] + [C.c_int] * len(extra) + [C.c_void_p, C.c_void_p, C.c_void_p]
+                    _check(fn(self.graph.handle, res, names, batch.blob, batch.offsets.ctypes.data, *extra, C.byref(text), C.byref(length), C.byref(skipped)))
+                    data = C.string_at(text.value, length.value)
+                    self.lib.gc_free(text)
+                    return data, int(skipped.value)
+
+                gaf = encode(self.lib.gc_format_gaf, int(cigar_match_mismatch_merge))
+                if other_formats:
+                    gaf = gaf + (encode(self.lib.gc_format_json)[0], encode(self.lib.gc_format_gam)[0])
             r = res.contents
             n = int(r.n_reads)
 
@@ -307,7 +314,9 @@ class Aligner:
             out["kernel_us"] = np.array(list(r.kernel_us))
             out["host_us"] = np.array(list(r.host_us))
             if gaf is not None:
-                out["gaf"], out["gaf_chained_skipped"] = gaf
+                out["gaf"], out["gaf_chained_skipped"] = gaf[0], gaf[1]
+                if len(gaf) > 2:
+                    out["json"], out["gam"] = gaf[2], gaf[3]
             return out   # arrays keep the C ABI's dtypes (uint32/uint64/...): no widening copies on the hot path
         finally:
             self.lib.gc_result_free(res)

@@ -622,15 +622,17 @@ int gc_edit_distance(const char* a, const uint64_t* a_off, const char* b, const 
 	});
 }
 
-// GAF text of a batch's final alignments (src/Aligner.cpp:1015-1022,300-311: AddGAFLine per alignment, the list sorted by
-// alignmentStart, one line each). Needs a result produced with keep_traces and edit_distances. Reads whose chained
+// Output of a batch's final alignments in the reference's formats (src/Aligner.cpp:1003-1023: the read's list sorted by
+// alignmentStart, AddAlignment / AddGAFLine per alignment, sorted again; writeGAMToQueue :261-281, writeJSONToQueue :283-298,
+// writeGAFToQueue :300-311). Needs a result produced with long_pass, keep_traces and edit_distances. Reads whose chained
 // alignment won (chained_better) are skipped and counted: their final trace comes from edlib's path mode, which this
 // library does not restate.
-int gc_format_gaf(const gc_graph* G, const gc_result* r, const char* const* read_names, const char* bases, const uint64_t* offsets, int cigar_match_mismatch_merge,
+enum OutputKind { OUT_GAF, OUT_JSON, OUT_GAM };
+static int formatBatch(const gc_graph* G, const gc_result* r, const char* const* read_names, const char* bases, const uint64_t* offsets, OutputKind kind, int cigar_match_mismatch_merge,
 	char** out_text, uint64_t* out_len, uint64_t* n_chained_skipped)
 {
 	if (!G || !r || !read_names || !offsets || !out_text || !out_len) return fail(GC_ERR_INVALID, "null argument");
-	if (!r->long_trace_off || !r->read_long_off || !r->long_index) return fail(GC_ERR_INVALID, "gc_format_gaf needs a result with long_pass, keep_traces and edit_distances");
+	if (!r->long_trace_off || !r->read_long_off || !r->long_index) return fail(GC_ERR_INVALID, "the output encoders need a result with long_pass, keep_traces and edit_distances");
 	return guarded([&]() {
 		const uint64_t n = r->n_reads;
 		std::vector<std::string> perRead(n);
@@ -643,14 +645,27 @@ int gc_format_gaf(const gc_graph* G, const gc_result* r, const char* const* read
 				uint64_t a = r->read_longall_off[i] + r->long_index[k];
 				items.push_back(Item { r->longall_start[a], a });
 			}
-			std::sort(items.begin(), items.end(), [](const Item& l, const Item& rr) { return l.start < rr.start; });   // src/Aligner.cpp:1022
+			if (items.empty()) return;
+			auto byStart = [](const Item& l, const Item& rr) { return l.start < rr.start; };
+			std::sort(items.begin(), items.end(), byStart);   // src/Aligner.cpp:1003
+			std::sort(items.begin(), items.end(), byStart);   // :1023 (an unstable sort may move ties even in a sorted list)
 			std::string& text = perRead[i];
+			std::vector<std::string> messages;
+			const std::string name = read_names[i] ? read_names[i] : "";
+			const uint64_t len = offsets[i + 1] - offsets[i];
 			for (const Item& it : items) {
 				uint64_t t0 = r->long_trace_off[it.aln], t1 = r->long_trace_off[it.aln + 1];
 				gc::TraceView tv { r->long_trace_node + t0, r->long_trace_offset + t0, r->long_trace_seqpos + t0, r->long_trace_switch + t0, t1 - t0 };
-				text += gc::formatGafLine(G->host, read_names[i] ? read_names[i] : "", bases + offsets[i], offsets[i + 1] - offsets[i], tv, cigar_match_mismatch_merge != 0);
-				text += '\n';
+				if (kind == OUT_GAF) {
+					text += gc::formatGafLine(G->host, name, bases + offsets[i], len, tv, cigar_match_mismatch_merge != 0);
+					text += '\n';
+				} else {
+					gc::VgAlignment aln = gc::buildVgAlignment(G->host, name, bases + offsets[i], len, tv, (int32_t)r->longall_score[it.aln], r->longall_start[it.aln], r->longall_end[it.aln]);
+					if (kind == OUT_JSON) { text += gc::vgToJson(aln); text += '\n'; }
+					else messages.push_back(gc::vgToProtobuf(aln));
+				}
 			}
+			if (kind == OUT_GAM) text = gc::gamGroup(messages);
 		});
 		uint64_t total = 0;
 		for (const auto& t : perRead) total += t.size();
@@ -664,6 +679,20 @@ int gc_format_gaf(const gc_graph* G, const gc_result* r, const char* const* read
 		if (n_chained_skipped) *n_chained_skipped = skipped.load();
 		return (int)GC_OK;
 	});
+}
+
+int gc_format_gaf(const gc_graph* G, const gc_result* r, const char* const* read_names, const char* bases, const uint64_t* offsets, int cigar_match_mismatch_merge,
+	char** out_text, uint64_t* out_len, uint64_t* n_chained_skipped)
+{
+	return formatBatch(G, r, read_names, bases, offsets, OUT_GAF, cigar_match_mismatch_merge, out_text, out_len, n_chained_skipped);
+}
+int gc_format_json(const gc_graph* G, const gc_result* r, const char* const* read_names, const char* bases, const uint64_t* offsets, char** out_text, uint64_t* out_len, uint64_t* n_chained_skipped)
+{
+	return formatBatch(G, r, read_names, bases, offsets, OUT_JSON, 0, out_text, out_len, n_chained_skipped);
+}
+int gc_format_gam(const gc_graph* G, const gc_result* r, const char* const* read_names, const char* bases, const uint64_t* offsets, char** out_bytes, uint64_t* out_len, uint64_t* n_chained_skipped)
+{
+	return formatBatch(G, r, read_names, bases, offsets, OUT_GAM, 0, out_bytes, out_len, n_chained_skipped);
 }
 
 int gc_device_count(void)

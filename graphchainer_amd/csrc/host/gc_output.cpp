@@ -1,5 +1,10 @@
 #include "gc_output.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <sstream>
+#include <stdexcept>
+#include <zlib.h>
 
 namespace gc {
 
@@ -119,6 +124,225 @@ std::string formatGafLine(const AlignmentGraph& graph, const std::string& readNa
 	out << "\t" << "id:f:" << ((double)matches / (double)all);
 	out << "\t" << "cg:Z:" << cigar.str();
 	return out.str();
+}
+
+VgAlignment buildVgAlignment(const AlignmentGraph& graph, const std::string& readName, const char* sequence, uint64_t readLength, const TraceView& trace,
+	int32_t score, uint64_t alignmentStart, uint64_t alignmentEnd)
+{
+	VgAlignment aln;
+	if (trace.size == 0) return aln;
+	auto graphChar = [&](uint64_t i) {
+		size_t split = graph.GetUnitigNode(trace.node[i], trace.offset[i]);
+		return graph.NodeSequences(split, trace.offset[i] - graph.NodeOffset(split));
+	};
+	auto readChar = [&](uint64_t i) { return trace.seqPos[i] < readLength ? sequence[trace.seqPos[i]] : '-'; };
+	aln.name = readName;
+	aln.score = score;
+	uint64_t matches = 0, mismatches = 0, insertions = 0, deletions = 0;
+	int currentNode = trace.node[0];
+	uint32_t currentOffset = trace.offset[0];
+	int64_t rank = 0;
+	auto newMapping = [&](int node, uint32_t offset) {
+		VgMapping m;
+		m.nodeId = node;                 // digraph id for now; replaced below
+		m.isReverse = (node % 2) == 1;
+		m.offset = offset;
+		m.rank = rank;
+		m.edits.emplace_back();
+		aln.mappings.push_back(m);
+	};
+	enum class E { Match, Mismatch, Insertion, Deletion, Empty } currentEdit;
+	newMapping(currentNode, currentOffset);
+	{
+		VgEdit& e = aln.mappings.back().edits.back();
+		e.fromLength++; e.toLength++;
+		if (characterMatch(readChar(0), graphChar(0))) { currentEdit = E::Match; matches++; }
+		else { currentEdit = E::Mismatch; e.sequence = std::string(1, sequence[0]); mismatches++; }   // (sic) sequence[0], src/GraphAlignerVGAlignment.h:73
+	}
+	for (uint64_t pos = 1; pos < trace.size; pos++) {
+		const int newNode = trace.node[pos];
+		const uint32_t newOffset = trace.offset[pos];
+		const bool insideNode = !trace.nodeSwitch[pos - 1] || (newNode == currentNode && newOffset > currentOffset);
+		if (!insideNode) {
+			rank++;
+			currentNode = newNode;
+			currentOffset = newOffset;
+			newMapping(currentNode, currentOffset);
+			currentEdit = E::Empty;
+		}
+		auto edit = [&](E kind) -> VgEdit& {
+			if (currentEdit == E::Empty) currentEdit = kind;
+			if (currentEdit != kind) { aln.mappings.back().edits.emplace_back(); currentEdit = kind; }
+			return aln.mappings.back().edits.back();
+		};
+		if (trace.seqPos[pos - 1] == trace.seqPos[pos]) { edit(E::Deletion).fromLength++; deletions++; }
+		else if (insideNode && trace.offset[pos - 1] == trace.offset[pos]) { VgEdit& e = edit(E::Insertion); e.toLength++; e.sequence += readChar(pos); insertions++; }
+		else if (characterMatch(readChar(pos), graphChar(pos))) { VgEdit& e = edit(E::Match); e.fromLength++; e.toLength++; matches++; }
+		else { VgEdit& e = edit(E::Mismatch); e.fromLength++; e.toLength++; e.sequence += readChar(pos); mismatches++; }
+	}
+	aln.identity = (double)matches / (double)(matches + mismatches + insertions + deletions);
+	// AddAlignment: the aligned part of the read and where it starts
+	aln.sequence = std::string(sequence + alignmentStart, sequence + alignmentEnd);
+	aln.queryPosition = (int32_t)alignmentStart;
+	// replaceDigraphNodeIdsWithOriginalNodeIds
+	for (VgMapping& m : aln.mappings) {
+		int digraphNodeId = (int)m.nodeId;
+		m.nodeId = digraphNodeId / 2;
+		m.name = graph.OriginalNodeName(digraphNodeId);
+	}
+	return aln;
+}
+
+// ---- JSON (protobuf's json_util conventions: fields in number order, proto3 defaults omitted, 64-bit integers as strings)
+
+namespace {
+
+void jsonString(std::string& out, const std::string& s)
+{
+	static const char* hex = "0123456789abcdef";
+	out += '"';
+	for (unsigned char c : s) {
+		switch (c) {
+			case '"': out += "\\\""; break;
+			case '\\': out += "\\\\"; break;
+			case '\b': out += "\\b"; break;
+			case '\f': out += "\\f"; break;
+			case '\n': out += "\\n"; break;
+			case '\r': out += "\\r"; break;
+			case '\t': out += "\\t"; break;
+			case '<': out += "\\u003c"; break;
+			case '>': out += "\\u003e"; break;
+			default:
+				if (c < 0x20 || c == 0x7f) { out += "\\u00"; out += hex[c >> 4]; out += hex[c & 15]; }
+				else out += (char)c;
+		}
+	}
+	out += '"';
+}
+
+std::string jsonDouble(double v)
+{
+	char buf[40];
+	snprintf(buf, sizeof buf, "%.15g", v);
+	if (strtod(buf, nullptr) != v) snprintf(buf, sizeof buf, "%.17g", v);
+	return buf;
+}
+
+struct JsonObject {   // "{" field, field, ... "}"
+	std::string& out;
+	bool first = true;
+	explicit JsonObject(std::string& o) : out(o) { out += '{'; }
+	void key(const char* k) { if (!first) out += ','; first = false; out += '"'; out += k; out += "\":"; }
+	void close() { out += '}'; }
+};
+
+// wire format helpers
+void putVarint(std::string& out, uint64_t v) { while (v >= 0x80) { out += (char)(v | 0x80); v >>= 7; } out += (char)v; }
+void putTag(std::string& out, uint32_t field, uint32_t wireType) { putVarint(out, ((uint64_t)field << 3) | wireType); }
+void putBytes(std::string& out, uint32_t field, const std::string& s) { putTag(out, field, 2); putVarint(out, s.size()); out += s; }
+
+} // namespace
+
+std::string vgToJson(const VgAlignment& aln)
+{
+	std::string out;
+	JsonObject a(out);
+	if (!aln.sequence.empty()) { a.key("sequence"); jsonString(out, aln.sequence); }
+	{
+		a.key("path");
+		JsonObject p(out);
+		if (!aln.mappings.empty()) {
+			p.key("mapping");
+			out += '[';
+			for (size_t i = 0; i < aln.mappings.size(); i++) {
+				const VgMapping& m = aln.mappings[i];
+				if (i) out += ',';
+				JsonObject mo(out);
+				mo.key("position");
+				{
+					JsonObject po(out);
+					if (m.nodeId != 0) { po.key("node_id"); out += '"'; out += std::to_string(m.nodeId); out += '"'; }
+					if (m.offset != 0) { po.key("offset"); out += '"'; out += std::to_string(m.offset); out += '"'; }
+					if (m.isReverse) { po.key("is_reverse"); out += "true"; }
+					if (!m.name.empty()) { po.key("name"); jsonString(out, m.name); }
+					po.close();
+				}
+				if (!m.edits.empty()) {
+					mo.key("edit");
+					out += '[';
+					for (size_t e = 0; e < m.edits.size(); e++) {
+						if (e) out += ',';
+						JsonObject eo(out);
+						if (m.edits[e].fromLength != 0) { eo.key("from_length"); out += std::to_string(m.edits[e].fromLength); }
+						if (m.edits[e].toLength != 0) { eo.key("to_length"); out += std::to_string(m.edits[e].toLength); }
+						if (!m.edits[e].sequence.empty()) { eo.key("sequence"); jsonString(out, m.edits[e].sequence); }
+						eo.close();
+					}
+					out += ']';
+				}
+				if (m.rank != 0) { mo.key("rank"); out += '"'; out += std::to_string(m.rank); out += '"'; }
+				mo.close();
+			}
+			out += ']';
+		}
+		p.close();
+	}
+	if (!aln.name.empty()) { a.key("name"); jsonString(out, aln.name); }
+	if (aln.score != 0) { a.key("score"); out += std::to_string(aln.score); }
+	if (aln.queryPosition != 0) { a.key("query_position"); out += std::to_string(aln.queryPosition); }
+	if (aln.identity != 0) { a.key("identity"); out += jsonDouble(aln.identity); }
+	a.close();
+	return out;
+}
+
+std::string vgToProtobuf(const VgAlignment& aln)
+{
+	std::string path;
+	for (const VgMapping& m : aln.mappings) {
+		std::string pos;
+		if (m.nodeId != 0) { putTag(pos, 1, 0); putVarint(pos, (uint64_t)m.nodeId); }
+		if (m.offset != 0) { putTag(pos, 2, 0); putVarint(pos, (uint64_t)m.offset); }
+		if (m.isReverse) { putTag(pos, 4, 0); putVarint(pos, 1); }
+		if (!m.name.empty()) putBytes(pos, 5, m.name);
+		std::string mapping;
+		putBytes(mapping, 1, pos);          // position is always present (set_allocated_position), even when empty
+		for (const VgEdit& e : m.edits) {
+			std::string ed;
+			if (e.fromLength != 0) { putTag(ed, 1, 0); putVarint(ed, (uint64_t)(int64_t)e.fromLength); }
+			if (e.toLength != 0) { putTag(ed, 2, 0); putVarint(ed, (uint64_t)(int64_t)e.toLength); }
+			if (!e.sequence.empty()) putBytes(ed, 3, e.sequence);
+			putBytes(mapping, 2, ed);
+		}
+		if (m.rank != 0) { putTag(mapping, 5, 0); putVarint(mapping, (uint64_t)m.rank); }
+		putBytes(path, 2, mapping);
+	}
+	std::string out;
+	if (!aln.sequence.empty()) putBytes(out, 1, aln.sequence);
+	putBytes(out, 2, path);                 // path is always present (set_allocated_path)
+	if (!aln.name.empty()) putBytes(out, 3, aln.name);
+	if (aln.score != 0) { putTag(out, 6, 0); putVarint(out, (uint64_t)(int64_t)aln.score); }
+	if (aln.queryPosition != 0) { putTag(out, 7, 0); putVarint(out, (uint64_t)(int64_t)aln.queryPosition); }
+	if (aln.identity != 0) { putTag(out, 16, 1); uint64_t bits; memcpy(&bits, &aln.identity, 8); for (int i = 0; i < 8; i++) out += (char)(bits >> (8 * i)); }
+	return out;
+}
+
+std::string gamGroup(const std::vector<std::string>& messages)
+{
+	std::string raw;
+	putVarint(raw, messages.size());
+	for (const std::string& m : messages) { putVarint(raw, m.size()); raw += m; }
+	// one gzip member (protobuf's GzipOutputStream defaults: gzip format, default compression level and strategy)
+	z_stream zs;
+	memset(&zs, 0, sizeof zs);
+	if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 | 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("zlib deflateInit2 failed");
+	std::string out(deflateBound(&zs, raw.size()) + 64, '\0');
+	zs.next_in = (Bytef*)raw.data(); zs.avail_in = (uInt)raw.size();
+	zs.next_out = (Bytef*)&out[0]; zs.avail_out = (uInt)out.size();
+	int rc = deflate(&zs, Z_FINISH);
+	deflateEnd(&zs);
+	if (rc != Z_STREAM_END) throw std::runtime_error("zlib deflate failed");
+	out.resize(zs.total_out);
+	return out;
 }
 
 } // namespace gc

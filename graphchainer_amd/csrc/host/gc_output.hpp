@@ -3,6 +3,7 @@
 #include "gc_graph.hpp"
 #include <cstdint>
 #include <string>
+#include <vector>
 
 namespace gc {
 
@@ -23,5 +24,24 @@ bool characterMatch(char sequenceCharacter, char graphCharacter);
 // GAF line of one alignment (no trailing newline). reference: GraphAlignerGAFAlignment::traceToAlignment,
 // src/GraphAlignerGAFAlignment.h:38-196 (called through AddGAFLine, src/GraphAlignerWrapper.cpp:38-43).
 std::string formatGafLine(const AlignmentGraph& graph, const std::string& readName, const char* sequence, uint64_t readLength, const TraceView& trace, bool cigarMatchMismatchMerge);
+
+// vg::Alignment as the reference fills it (GraphAlignerVGAlignment::traceToAlignment, src/GraphAlignerVGAlignment.h:36-163,
+// AddAlignment src/GraphAligner.h:205-212, replaceDigraphNodeIdsWithOriginalNodeIds src/Aligner.cpp:152-165); only the
+// fields the reference sets. Messages and field numbers: src/vg.proto:52-56 (Edit), :62-66 (Mapping), :89-94 (Position),
+// :104-109 (Path), :113-154 (Alignment).
+struct VgEdit { int32_t fromLength = 0, toLength = 0; std::string sequence; };
+struct VgMapping { int64_t nodeId = 0, offset = 0; bool isReverse = false; std::string name; std::vector<VgEdit> edits; int64_t rank = 0; };
+struct VgAlignment { std::string sequence, name; int32_t score = 0, queryPosition = 0; double identity = 0; std::vector<VgMapping> mappings; };
+
+VgAlignment buildVgAlignment(const AlignmentGraph& graph, const std::string& readName, const char* sequence, uint64_t readLength, const TraceView& trace,
+	int32_t score, uint64_t alignmentStart, uint64_t alignmentEnd);
+
+// google::protobuf::util::MessageToJsonString with preserve_proto_field_names (src/Aligner.cpp:283-298): one compact JSON object.
+std::string vgToJson(const VgAlignment& aln);
+// proto3 wire format of the message (what Alignment::SerializeToString writes, src/Aligner.cpp:273).
+std::string vgToProtobuf(const VgAlignment& aln);
+// One GAM group as writeGAMToQueue frames it (src/Aligner.cpp:261-281): varint64 message count, then per message varint32
+// size + bytes, the whole group one gzip member.
+std::string gamGroup(const std::vector<std::string>& messages);
 
 } // namespace gc

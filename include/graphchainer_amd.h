@@ -185,6 +185,16 @@ int gc_edit_distance(const char* a, const uint64_t* a_off, const char* b, const 
 int gc_format_gaf(const gc_graph* g, const gc_result* result, const char* const* read_names, const char* bases, const uint64_t* offsets,
                   int cigar_match_mismatch_merge, char** out_text, uint64_t* out_len, uint64_t* n_chained_skipped);
 
+/* The same alignments as vg::Alignment messages (GraphAlignerVGAlignment::traceToAlignment + AddAlignment +
+ * replaceDigraphNodeIdsWithOriginalNodeIds): JSON lines as MessageToJsonString(preserve_proto_field_names) prints them
+ * (writeJSONToQueue, src/Aligner.cpp:283-298), or GAM: per read one gzip member holding varint count + (varint size, proto3
+ * bytes) per alignment (writeGAMToQueue, src/Aligner.cpp:261-281; the gzip bytes depend on the zlib build, the inflated
+ * stream is the reference's). */
+int gc_format_json(const gc_graph* g, const gc_result* result, const char* const* read_names, const char* bases, const uint64_t* offsets,
+                   char** out_text, uint64_t* out_len, uint64_t* n_chained_skipped);
+int gc_format_gam(const gc_graph* g, const gc_result* result, const char* const* read_names, const char* bases, const uint64_t* offsets,
+                  char** out_bytes, uint64_t* out_len, uint64_t* n_chained_skipped);
+
 int gc_device_count(void);
 int gc_set_device(int device);
 

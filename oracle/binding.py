@@ -115,6 +115,12 @@ class Oracle:
         self.lib.gco_gaf.argtypes = [C.c_void_p, C.c_int]
         return self.lib.gco_gaf(self.h, int(merge))
 
+    def json(self):
+        """JSON lines (vg::Alignment via protobuf's JSON mapping) of the last align() call's final alignments."""
+        self.lib.gco_json.restype = C.c_char_p
+        self.lib.gco_json.argtypes = [C.c_void_p]
+        return self.lib.gco_json(self.h)
+
 
 class RefUnits:
     """The reference's own WordSlice.h / AlignmentCorrectnessEstimation.cpp / edlib, compiled unmodified."""

@@ -262,6 +262,7 @@ struct OracleHandle {
 	Oracle o;
 	Export ex;
 	std::string gaf[2];   // GAF text of the last gco_align call (read ids r0, r1, ...): [0] =/X cigar, [1] merged M cigar
+	std::string json;     // JSON lines of the same alignments
 	std::string error;
 };
 
@@ -297,7 +298,7 @@ int gco_align(void* hv, const char* bases, const uint64_t* off, int n)
 	AlignerState state(h->o.graph);
 	h->o.counters = AlignerCounters();
 	for (double& s : h->o.stageSeconds) s = 0;
-	h->gaf[0].clear(); h->gaf[1].clear();
+	h->gaf[0].clear(); h->gaf[1].clear(); h->json.clear();
 	const char* names[] = { "read_seed_off", "read_frag_off", "read_anchor_off", "read_chain_off", "read_long_off", "read_longall_off", "read_path_off", "anchor_path_off", "anchor_trace_off", "long_trace_off" };
 	for (const char* nm : names) ex[nm].push_back(0);
 	for (int r = 0; r < n; r++) {
@@ -344,13 +345,15 @@ int gco_align(void* hv, const char* bases, const uint64_t* off, int n)
 		// final alignments of the read (src/Aligner.cpp:901-911): the selected whole-read alignments unless the chained one
 		// won (its trace comes from edlib's path mode and is not restated); AddGAFLine each (:1015-1019), sort by
 		// alignmentStart (:1022), one line each (:300-311)
-		if (!res.chainedBetter) {
+		if (!res.chainedBetter && !res.longAlignments.empty()) {
 			std::vector<AlignmentItem> finalAlns = res.longAlignments;
-			for (int m = 0; m < 2; m++) {
-				std::vector<std::pair<size_t, std::string>> lines;
-				for (const AlignmentItem& a : finalAlns) lines.push_back({ a.alignmentStart, traceToGaf(h->o.graph, "r" + std::to_string(r), seq, *a.trace, m == 1) });
-				std::sort(lines.begin(), lines.end(), [](const std::pair<size_t, std::string>& l, const std::pair<size_t, std::string>& rr) { return l.first < rr.first; });
-				for (const auto& l : lines) { h->gaf[m] += l.second; h->gaf[m] += '\n'; }
+			auto byStart = [](const AlignmentItem& l, const AlignmentItem& rr) { return l.alignmentStart < rr.alignmentStart; };
+			std::sort(finalAlns.begin(), finalAlns.end(), byStart);   // :1003
+			std::sort(finalAlns.begin(), finalAlns.end(), byStart);   // :1023 (AddAlignment / AddGAFLine in between do not reorder)
+			for (const AlignmentItem& a : finalAlns) {
+				for (int m = 0; m < 2; m++) { h->gaf[m] += traceToGaf(h->o.graph, "r" + std::to_string(r), seq, *a.trace, m == 1); h->gaf[m] += '\n'; }
+				h->json += alignmentToJson(h->o.graph, "r" + std::to_string(r), seq, a);
+				h->json += '\n';
 			}
 		}
 		auto dumpAlns = [&](const std::vector<AlignmentItem>& alns, const std::string& prefix, bool traces) {
@@ -387,6 +390,7 @@ int gco_align(void* hv, const char* bases, const uint64_t* off, int n)
 }
 
 const char* gco_gaf(void* hv, int merge) { return ((OracleHandle*)hv)->gaf[merge ? 1 : 0].c_str(); }
+const char* gco_json(void* hv) { return ((OracleHandle*)hv)->json.c_str(); }
 
 const int64_t* gco_array(void* hv, const char* name, uint64_t* count)
 {

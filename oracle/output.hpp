@@ -4,8 +4,12 @@
 // be built here, so no reference-produced GAF exists to check this against.
 #pragma once
 #include "bitvector_aligner.hpp"
+#include "pipeline.hpp"
+#include <cstdio>
+#include <cstdlib>
 #include <sstream>
 #include <string>
+#include <vector>
 
 namespace oracle {
 
@@ -100,6 +104,137 @@ inline std::string traceToGaf(const AlignmentGraph& graph, const std::string& se
 	sstr << "\t" << "id:f:" << ((double)matches / (double)(matches + mismatches + deletions + insertions));
 	sstr << "\t" << "cg:Z:" << cigar.str();
 	return sstr.str();
+}
+
+// ---- vg::Alignment -> JSON. reference: GraphAlignerVGAlignment::traceToAlignment (src/GraphAlignerVGAlignment.h:36-163),
+// AddAlignment (src/GraphAligner.h:205-212), replaceDigraphNodeIdsWithOriginalNodeIds (src/Aligner.cpp:152-165),
+// writeJSONToQueue (src/Aligner.cpp:283-298: MessageToJsonString, preserve_proto_field_names). The JSON text follows
+// protobuf 3's json_util: fields in field-number order (src/vg.proto:52-154), proto3 defaults omitted, int64 as strings,
+// doubles with the shortest of %.15g / %.17g that round-trips. Parity unpinned (no protobuf C++ runtime on this box); the
+// tests cross-check the same alignments against the protobuf Python runtime through the GAM bytes.
+struct OraEdit { int from_length = 0, to_length = 0; std::string sequence; };
+struct OraMapping { long long node_id = 0, offset = 0; bool is_reverse = false; std::string name; std::vector<OraEdit> edit; long long rank = 0; };
+
+inline std::string oraJsonEscape(const std::string& in)
+{
+	std::string out = "\"";
+	char tmp[8];
+	for (unsigned char c : in) {
+		if (c == '"') out += "\\\"";
+		else if (c == '\\') out += "\\\\";
+		else if (c == '\n') out += "\\n";
+		else if (c == '\r') out += "\\r";
+		else if (c == '\t') out += "\\t";
+		else if (c == '\b') out += "\\b";
+		else if (c == '\f') out += "\\f";
+		else if (c == '<' || c == '>' || c < 0x20 || c == 0x7f) { snprintf(tmp, sizeof tmp, "\\u%04x", c); out += tmp; }
+		else out += (char)c;
+	}
+	return out + "\"";
+}
+
+inline std::string alignmentToJson(const AlignmentGraph& graph, const std::string& seq_id, const std::string& sequence, const AlignmentItem& item)
+{
+	const auto& trace = item.trace->trace;
+	std::vector<OraMapping> mapping;
+	enum { Match, Mismatch, Insertion, Deletion, Empty } currentEdit = Empty;
+	size_t mismatches = 0, deletions = 0, insertions = 0, matches = 0;
+	int curNode = (int)trace[0].DPposition.node;
+	size_t curOffset = trace[0].DPposition.nodeOffset;
+	int rank = 0;
+	mapping.push_back(OraMapping { curNode, (long long)curOffset, (curNode % 2) == 1, "", { OraEdit() }, rank });
+	OraEdit* edit = &mapping.back().edit.back();
+	if (characterMatch(trace[0].sequenceCharacter, trace[0].graphCharacter)) {
+		currentEdit = Match; edit->from_length++; edit->to_length++; matches++;
+	} else {
+		currentEdit = Mismatch; edit->from_length++; edit->to_length++; edit->sequence = std::string { sequence[0] }; mismatches++;
+	}
+	for (size_t pos = 1; pos < trace.size(); pos++) {
+		int newNode = (int)trace[pos].DPposition.node;
+		size_t newOffset = trace[pos].DPposition.nodeOffset;
+		bool insideNode = !trace[pos - 1].nodeSwitch || (newNode == curNode && newOffset > curOffset);
+		if (!insideNode) {
+			rank++;
+			curNode = newNode; curOffset = newOffset;
+			mapping.push_back(OraMapping { curNode, (long long)curOffset, (curNode % 2) == 1, "", { OraEdit() }, rank });
+			edit = &mapping.back().edit.back();
+			currentEdit = Empty;
+		}
+		if (trace[pos - 1].DPposition.seqPos == trace[pos].DPposition.seqPos) {
+			if (currentEdit == Empty) currentEdit = Deletion;
+			if (currentEdit != Deletion) { mapping.back().edit.push_back(OraEdit()); edit = &mapping.back().edit.back(); currentEdit = Deletion; }
+			edit->from_length++; deletions++;
+		} else if (insideNode && trace[pos - 1].DPposition.nodeOffset == trace[pos].DPposition.nodeOffset) {
+			if (currentEdit == Empty) currentEdit = Insertion;
+			if (currentEdit != Insertion) { mapping.back().edit.push_back(OraEdit()); edit = &mapping.back().edit.back(); currentEdit = Insertion; }
+			edit->to_length++; edit->sequence += trace[pos].sequenceCharacter; insertions++;
+		} else if (characterMatch(trace[pos].sequenceCharacter, trace[pos].graphCharacter)) {
+			if (currentEdit == Empty) currentEdit = Match;
+			if (currentEdit != Match) { mapping.back().edit.push_back(OraEdit()); edit = &mapping.back().edit.back(); currentEdit = Match; }
+			edit->from_length++; edit->to_length++; matches++;
+		} else {
+			if (currentEdit == Empty) currentEdit = Mismatch;
+			if (currentEdit != Mismatch) { mapping.back().edit.push_back(OraEdit()); edit = &mapping.back().edit.back(); currentEdit = Mismatch; }
+			edit->from_length++; edit->to_length++; edit->sequence += trace[pos].sequenceCharacter; mismatches++;
+		}
+	}
+	double identity = (double)matches / (double)(matches + mismatches + insertions + deletions);
+	for (OraMapping& m : mapping) {
+		int digraphNodeId = (int)m.node_id;
+		m.node_id = digraphNodeId / 2;
+		m.name = graph.OriginalNodeName(digraphNodeId);
+	}
+	std::string alignedSequence = sequence.substr(item.alignmentStart, item.alignmentEnd - item.alignmentStart);
+	// print
+	std::string js = "{";
+	auto field = [&](std::string& s, bool& first, const std::string& key) { if (!first) s += ","; first = false; s += "\"" + key + "\":"; };
+	bool first = true;
+	if (!alignedSequence.empty()) { field(js, first, "sequence"); js += oraJsonEscape(alignedSequence); }
+	field(js, first, "path");
+	js += "{";
+	if (!mapping.empty()) {
+		js += "\"mapping\":[";
+		for (size_t i = 0; i < mapping.size(); i++) {
+			const OraMapping& m = mapping[i];
+			if (i) js += ",";
+			js += "{\"position\":{";
+			bool pf = true;
+			if (m.node_id) { field(js, pf, "node_id"); js += "\"" + std::to_string(m.node_id) + "\""; }
+			if (m.offset) { field(js, pf, "offset"); js += "\"" + std::to_string(m.offset) + "\""; }
+			if (m.is_reverse) { field(js, pf, "is_reverse"); js += "true"; }
+			if (!m.name.empty()) { field(js, pf, "name"); js += oraJsonEscape(m.name); }
+			js += "}";
+			if (!m.edit.empty()) {
+				js += ",\"edit\":[";
+				for (size_t e = 0; e < m.edit.size(); e++) {
+					if (e) js += ",";
+					js += "{";
+					bool ef = true;
+					if (m.edit[e].from_length) { field(js, ef, "from_length"); js += std::to_string(m.edit[e].from_length); }
+					if (m.edit[e].to_length) { field(js, ef, "to_length"); js += std::to_string(m.edit[e].to_length); }
+					if (!m.edit[e].sequence.empty()) { field(js, ef, "sequence"); js += oraJsonEscape(m.edit[e].sequence); }
+					js += "}";
+				}
+				js += "]";
+			}
+			if (m.rank) js += ",\"rank\":\"" + std::to_string(m.rank) + "\"";
+			js += "}";
+		}
+		js += "]";
+	}
+	js += "}";
+	if (!seq_id.empty()) { field(js, first, "name"); js += oraJsonEscape(seq_id); }
+	int score = item.trace->score;
+	if (score) { field(js, first, "score"); js += std::to_string(score); }
+	if (item.alignmentStart) { field(js, first, "query_position"); js += std::to_string((int)item.alignmentStart); }
+	if (identity != 0) {
+		char buf[40];
+		snprintf(buf, sizeof buf, "%.15g", identity);
+		if (strtod(buf, nullptr) != identity) snprintf(buf, sizeof buf, "%.17g", identity);
+		field(js, first, "identity"); js += buf;
+	}
+	js += "}";
+	return js;
 }
 
 } // namespace oracle

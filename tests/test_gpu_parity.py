@@ -332,3 +332,83 @@ def test_chained_alignment_wins(gca, tmp_path):
     assert int(np.sum(got["chained_better"][4:])) == 0           # ordinary reads keep their whole-read alignment
     assert raw["gaf_chained_skipped"] == int(np.sum(got["chained_better"]))
     assert raw["gaf"] == ora.gaf(False)
+
+
+def _vg_alignment_class():
+    """vg::Alignment (the fields the reference sets, src/vg.proto:52-154) built for the protobuf Python runtime."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    F = descriptor_pb2.FieldDescriptorProto
+    fdp = descriptor_pb2.FileDescriptorProto(name="vg_subset_for_tests.proto", package="vgtest", syntax="proto3")
+
+    def message(name, fields):
+        m = fdp.message_type.add(name=name)
+        for fname, number, ftype, label, type_name in fields:
+            f = m.field.add(name=fname, number=number, type=ftype, label=label)
+            if type_name:
+                f.type_name = ".vgtest." + type_name
+    opt, rep = F.LABEL_OPTIONAL, F.LABEL_REPEATED
+    message("Edit", [("from_length", 1, F.TYPE_INT32, opt, None), ("to_length", 2, F.TYPE_INT32, opt, None), ("sequence", 3, F.TYPE_STRING, opt, None)])
+    message("Position", [("node_id", 1, F.TYPE_INT64, opt, None), ("offset", 2, F.TYPE_INT64, opt, None), ("is_reverse", 4, F.TYPE_BOOL, opt, None), ("name", 5, F.TYPE_STRING, opt, None)])
+    message("Mapping", [("position", 1, F.TYPE_MESSAGE, opt, "Position"), ("edit", 2, F.TYPE_MESSAGE, rep, "Edit"), ("rank", 5, F.TYPE_INT64, opt, None)])
+    message("Path", [("name", 1, F.TYPE_STRING, opt, None), ("mapping", 2, F.TYPE_MESSAGE, rep, "Mapping"), ("is_circular", 3, F.TYPE_BOOL, opt, None), ("length", 4, F.TYPE_INT64, opt, None)])
+    message("Alignment", [("sequence", 1, F.TYPE_STRING, opt, None), ("path", 2, F.TYPE_MESSAGE, opt, "Path"), ("name", 3, F.TYPE_STRING, opt, None),
+                          ("score", 6, F.TYPE_INT32, opt, None), ("query_position", 7, F.TYPE_INT32, opt, None), ("identity", 16, F.TYPE_DOUBLE, opt, None)])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fdp)
+    desc = pool.FindMessageTypeByName("vgtest.Alignment")
+    try:
+        return message_factory.GetMessageClass(desc)
+    except AttributeError:
+        return message_factory.MessageFactory(pool).GetPrototype(desc)
+
+
+def _read_varint(buf, at):
+    value, shift = 0, 0
+    while True:
+        b = buf[at]
+        at += 1
+        value |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return value, at
+        shift += 7
+
+
+def test_json_and_gam_output(gca, tmp_path):
+    """vg::Alignment output: JSON lines against the oracle's restatement, and the GAM bytes (gzip members of framed proto3
+    messages) decoded with the protobuf Python runtime against those same JSON objects."""
+    import gzip
+    import json
+    from google.protobuf import json_format
+    from graphchainer_amd.synth import SynthGraph
+    from oracle import Oracle
+    sg = SynthGraph(80_000, seed=23)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(6, 2500, seed=4)
+    reads.append(_revcomp(reads[0]))
+    reads.append(reads[1][:800] + reads[2][300:1500])
+    reads.append(b"ACGTACGT")                      # no alignment: no output
+    graph = gca.AlignmentGraph(gfa)
+    seeder = gca.MinimizerSeeder(graph)
+    aligner = gca.Aligner(graph, seeder, keep_traces=True, long_pass=True)
+    got = aligner.align_reads(reads, gaf_names=[f"r{i}" for i in range(len(reads))], other_formats=True)
+    ora = Oracle(gfa, long_pass=True)
+    ora.align(reads)
+    assert got["json"] == ora.json()
+    objects = [json.loads(line) for line in got["json"].decode().splitlines()]
+    assert len(objects) >= 7 and all(o["path"]["mapping"] for o in objects)
+    # GAM: inflate all members, walk the groups, parse every message with protobuf itself
+    Alignment = _vg_alignment_class()
+    raw = gzip.decompress(got["gam"])
+    decoded, at = [], 0
+    while at < len(raw):
+        count, at = _read_varint(raw, at)
+        assert count >= 1
+        for _ in range(count):
+            size, at = _read_varint(raw, at)
+            msg = Alignment()
+            msg.ParseFromString(raw[at:at + size])
+            at += size
+            assert msg.SerializeToString() == raw[at - size:at]          # canonical proto3 bytes, nothing unknown
+            decoded.append(json_format.MessageToDict(msg, preserving_proto_field_name=True))
+    assert decoded == objects
