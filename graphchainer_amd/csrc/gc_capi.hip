@@ -1092,7 +1092,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			ExtendConfig lcfg;
 			lcfg.bandwidth = P->bandwidth;
 			lcfg.maxSlices = (uint32_t)(maxReadLen / 64 + 3);
-			lcfg.maxItems = 8192;
+			lcfg.maxItems = (uint32_t)std::max<uint64_t>(8192, (maxReadLen / 64 + 3) * 24);   // (slice, node) tiles of one extension: ~8 per slice on cfg2, room for 24
 			lcfg.maxPending = 96;
 			lcfg.maxTrace = (uint32_t)(maxReadLen + maxReadLen / 2 + 512);
 			if (const char* env = getenv("GC_LONG_MAX_ITEMS")) lcfg.maxItems = (uint32_t)std::max(64, atoi(env));
@@ -1145,7 +1145,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			}
 			unsigned long long* dRoundTrace = st->longRoundTrace.reserve<unsigned long long>(groupTraceBegin[nGroups]);
 			// extension scratch: one region per lane of a resident wave (persistent waves fetch work items), per read group
-			const uint64_t scratchLanes = std::min<uint64_t>(workCapacity + 64, 65536 + 64);
+			// (bounded by a memory budget: 0.8 MB per lane for 10 kb reads, 2.4 MB for 50 kb reads; GC_LONG_SCRATCH_GB overrides the 48 GB)
+			uint64_t scratchBudget = 48ull << 30;
+			if (const char* env = getenv("GC_LONG_SCRATCH_GB")) scratchBudget = (uint64_t)std::max(1, atoi(env)) << 30;
+			const uint64_t scratchLanes = std::min<uint64_t>(workCapacity + 64, std::max<uint64_t>(2048, std::min<uint64_t>(65536 + 64, scratchBudget / (waveWords * 8))));
 			dLongScratch = st->longScratch.reserve<unsigned long long>((uint64_t)nGroups * scratchLanes * waveWords);
 			groupExtendUs.assign(nGroups, 0.0);
 			groupRounds.assign(nGroups, 0);
@@ -1181,7 +1184,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					uint32_t nWorkItems = (uint32_t)hCursor[0];
 					if (nWorkItems == 0) break;
 					uint32_t team = longExtendTeamSize(nWorkItems);
-					uint32_t blocks = std::min((nWorkItems + team - 1) / team, longExtendMaxBlocks(team));
+					uint32_t blocks = std::min<uint32_t>((nWorkItems + team - 1) / team, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / team));
 					if (const char* env = getenv("GC_LONG_MAX_BLOCKS")) blocks = std::min<uint32_t>(blocks, (uint32_t)std::max(1, atoi(env)));   // test hook: force persistent waves
 					// Execution order: longest extensions first, so the round's tail is made of short ones.
 					{
@@ -1199,7 +1202,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 						// extensions whose band outgrew the 64-entry register tables: second try with the LDS/HBM tables (two lanes per wave,
 						// 28 + 228 entries); waves whose items are fine leave at once. Beyond that the read goes to the plain-layout fallback.
 						HIP_CHECK(hipMemsetAsync(cursor + 2, 0, sizeof(unsigned long long), q));
-						uint32_t retryBlocks = std::min((nWorkItems + 1) / 2, longExtendMaxBlocks(2));
+						uint32_t retryBlocks = std::min<uint32_t>((nWorkItems + 1) / 2, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / 2));
 						launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, hOrder + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 2, retryBlocks,
 							dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, EXT_LDS_CAP);
 					}

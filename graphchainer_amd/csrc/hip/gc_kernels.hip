@@ -759,7 +759,7 @@ __global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessT
 	wsx.allLanes = LANES == 1;
 	wsx.regCap = cfg.regCap;
 	ExtCounters cnt {};
-	// One work item per wave while the launch fits the scratch (65536 lanes in flight, ~52 GB); larger rounds run
+	// One work item per wave while the launch fits the scratch (the host sizes it for up to 65536 lanes in flight under a memory budget); larger rounds run
 	// persistent waves that fetch work items in execution order (longest first). The two are separate instantiations:
 	// the fetch loop costs the common case 6 % (265 vs 283 ms on cfg2) in register pressure.
 	bool done = false;
@@ -996,14 +996,6 @@ uint32_t longExtendTeamSize(uint32_t nWork)
 	if (const char* env = getenv("GC_LONG_TEAM")) { int v = atoi(env); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return (uint32_t)v; }
 	(void)nWork;
 	return 1;
-}
-
-uint32_t longExtendMaxBlocks(uint32_t lanes)
-{
-	// 65536 lanes in flight bound the extension scratch at ~52 GB; up to that many work items every wave takes exactly one
-	// (measured faster than fewer, looping waves: 272 vs 286 ms on cfg2, and the fragment kernels get their share of the chip)
-	uint32_t byLanes = 65536u / (lanes ? lanes : 1);
-	return byLanes ? byLanes : 1;
 }
 
 void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,

@@ -412,3 +412,18 @@ def test_json_and_gam_output(gca, tmp_path):
             assert msg.SerializeToString() == raw[at - size:at]          # canonical proto3 bytes, nothing unknown
             decoded.append(json_format.MessageToDict(msg, preserving_proto_field_name=True))
     assert decoded == objects
+
+
+def test_long_reads(gca, tmp_path, monkeypatch):
+    """30 kb reads: per-extension scratch scales with the read length, persistent waves under a small scratch budget,
+    edit-distance bands that need more than one block per lane."""
+    from graphchainer_amd.synth import SynthGraph
+    monkeypatch.setenv("GC_LONG_SCRATCH_GB", "1")
+    sg = SynthGraph(300_000, seed=29)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(3, 30_000, seed=3, p_del=0.05, p_sub=0.06, p_ins=0.05)
+    reads.append(sg.sample_reads(1, 30_000, seed=5)[0][:21_000])
+    got, want = run_case(gca, gfa, reads, long_pass=True)
+    compare(got, want, COMPARE_KEYS + LONG_KEYS)
+    assert int(np.max(got["long_edit_distance"])) > 2016          # a band wider than one 64-row block per lane can hold
