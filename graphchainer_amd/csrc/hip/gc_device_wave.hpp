@@ -1,18 +1,19 @@
-// Wave-friendly variant of the seed-extension core (same algorithm and results as extendSeed in gc_device.hpp).
+// Whole-read variant of the seed-extension core (same algorithm and results as extendSeed in gc_device.hpp), in two
+// instantiations of one template:
 //
-// Why: with one lane per extension every lane owns private state. In the plain layout a wave-level load of "my
-// item i" touches 64 different scratch slabs = 64 memory transactions; the whole-read pass, which has only one
-// lane per read and cannot hide that behind other waves, ran at 0.27 G column-steps/s. Here
-//   * the state that the slice loop reads and writes all the time - the previous slice's per-node summary
-//     (node, start score, min score, HP, HN), the current slice's, and the pending queue with its folded incoming
-//     columns - lives in LDS, lane-interleaved ([entry][lane], so lanes that are at the same entry hit 64
-//     consecutive banks);
-//   * the DP table kept for the backtrace (8 words per (slice,node) item), the per-slice records and the trace
-//     live in HBM, interleaved across the 64 lanes of the wave at 8-byte granularity (word w of lane l at
-//     base[w*64 + l]) so a wave-level access to the same logical word is one 512 B transaction;
-//   * the 64 recomputed columns of the backtrace reuse the LDS of the slice tables (the two phases do not overlap).
-// A slice that needs more than WAVE_CAP nodes does not fit: the extension returns EXT_LDS_CAP and the host reruns
-// that read with the plain-layout kernel.
+//  * REGCOLS = true - one extension per wave (k_long_extend<1>, the production path). All 64 lanes run the same uniform
+//    code, so the extension's state sits in scalar registers, and the lanes' VGPRs carry the per-entry data: the band
+//    tables (previous slice, current slice, pending queue: entry e in lane e, 64 entries), the 64 recomputed columns of
+//    the backtrace (column c in lane c), the node ids of the backtrace's current/previous slice and the trace cells on
+//    their way out (64 at a time). No LDS.
+//  * REGCOLS = false - LANES extensions per wave, one per lane (experiments, and the retry for slices with more than 64
+//    nodes): the tables live in LDS, lane-interleaved ([word][lane]), 28 entries each with a spill area of 228 more in
+//    HBM; the backtrace columns and id lists alias the table words (the two phases do not overlap in time).
+//
+// In both, the DP table kept for the backtrace (8 words per (slice,node) item), the per-slice records and the trace live
+// in HBM, interleaved across the lanes of the team at 8-byte granularity (word w of lane l at base[w*lanes + l]).
+// A slice that needs more nodes than the tables hold ends the extension with EXT_LDS_CAP (see k_long_extend's retry and
+// the plain-layout fallback k_long_pass).
 #pragma once
 #include "gc_device.hpp"
 

@@ -631,12 +631,12 @@ __global__ void __launch_bounds__(64) k_long_pass(DGraph g, const CorrectnessTab
 }
 
 // =====================================================================================================
-// K3-long in rounds. The monolithic kernels above keep a lane busy for as many rounds as its read needs while the
+// K3-long in rounds. The monolithic kernel above keeps a lane busy for as many rounds as its read needs while the
 // other 63 lanes of the wave wait (3.6 seeds are extended per read on average, up to 10). Here every round is
-//   select  - one lane per read: advance to the next seed that needs extending (the reference's skip rules), emit two
-//             work items (backward, forward);
-//   extend  - one lane per work item, densely packed waves, wave-layout extension core; the trace goes to a pool;
-//   merge   - one lane per seed: merge the two traces, append the alignment, update the end-to-end cut-off;
+//   select  - one wave per read: the reference's skip rules for 64 seeds at once, then its in-order scan on the ballot
+//             masks; emits two work items (backward, forward) per chosen seed;
+//   extend  - one wave per work item (k_long_extend<1>), longest first; the trace goes to a pool;
+//   merge   - one wave per read: joins the two traces 64 cells at a time, appends the alignment, updates the cut-off;
 // and the host launches rounds until no read emits work. Results are identical to the monolithic kernels.
 // =====================================================================================================
 
