@@ -62,7 +62,6 @@ def main():
         dist = dist_mod
         # reads shard embarrassingly: the only cross-rank traffic is the barrier and the max-over-ranks of the step time
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        torch.cuda.set_device(local_rank)
 
     if world > 1 and "GC_HOST_THREADS" not in os.environ:
         # ranks share the host: split its cores between their worker pools (read by the library when it first loads)
@@ -72,7 +71,16 @@ def main():
 
     if gca.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    gca.set_device(local_rank)
+    device = local_rank
+    if device >= gca.device_count():
+        # dry run of the multi-rank path on a box with fewer GPUs than ranks (not a measurement): ranks share devices
+        if not os.environ.get("GC_BENCH_ALLOW_SHARED_GPU"):
+            raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU of its own ({gca.device_count()} visible)")
+        device = local_rank % gca.device_count()
+    gca.set_device(device)
+    if dist is not None:
+        import torch
+        torch.cuda.set_device(device)
 
     t0 = time.time()
     tmp = tempfile.mkdtemp(prefix="gcbench_")
