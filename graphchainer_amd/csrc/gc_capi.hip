@@ -224,8 +224,8 @@ struct gc_stream {
 	std::vector<hipStream_t> groupStreams;   // read groups of the whole-read pass run their round loops concurrently
 	std::vector<hipEvent_t> groupEvents;     // two per group
 	DeviceBuffer longSeeds, longJobs, longAlns, longResults, longScratch, longCells, longCursor, longJobsFallback, longResultsFallback, longScratchFallback;
-	DeviceBuffer longState, longWork, longWorkResults, longRoundTrace, longCandSeed;
-	PinnedBuffer hLongSeeds, hLongJobs, hLongAlns, hLongResults, hLongSmall, hLongWorkLen, hLongOrder;
+	DeviceBuffer longState, longWork, longWorkResults, longRoundTrace, longCandSeed, longWorkLen, longOrder;
+	PinnedBuffer hLongSeeds, hLongJobs, hLongAlns, hLongResults, hLongSmall;
 	~gc_stream()
 	{
 		for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -1134,8 +1134,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			LongWork* dLongWork = st->longWork.reserve<LongWork>(workCapacity);
 			LongWorkResult* dLongWorkResults = st->longWorkResults.reserve<LongWorkResult>(workCapacity);
 			uint32_t* dCandSeed = st->longCandSeed.reserve<uint32_t>(workCapacity);
-			uint32_t* hWorkLen = st->hLongWorkLen.reserve<uint32_t>(workCapacity);   // pinned host memory, written by k_long_select / read by k_long_extend directly:
-			uint32_t* hOrder = st->hLongOrder.reserve<uint32_t>(workCapacity);       // no copy-engine transfers inside the round loop (they queue behind the fragment pipeline's bulk uploads)
+			uint32_t* dWorkLen = st->longWorkLen.reserve<uint32_t>(workCapacity);   // written by k_long_select, sorted into dOrder by k_long_order: the host only
+			uint32_t* dOrder = st->longOrder.reserve<uint32_t>(workCapacity);       // learns the round's work count (k_publish: no copy-engine transfer in the round loop)
 			groupBegin.assign(nGroups + 1, 0); groupTraceBegin.assign(nGroups + 1, 0);
 			for (uint32_t g = 0; g <= nGroups; g++) groupBegin[g] = n * g / nGroups;
 			for (uint32_t g = 0; g < nGroups; g++) {
@@ -1178,7 +1178,12 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					// at most lastWork/2 reads are still active, so this keeps the round within the work arrays (8 per read) and the trace budget (4 seeds' worth per read)
 					if (round > 0 && lastWork > 0) maxCand = (uint32_t)std::min<uint64_t>(maxCand, std::max<uint64_t>(1, (8 * nG) / lastWork));
 					if (const char* env = getenv("GC_LONG_SPECULATE")) maxCand = (uint32_t)std::min(2, std::max(1, atoi(env)));   // test hook: speculate from round 0
-					launchLongSelect(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, R->totalBases, (uint32_t)P->min_cluster_size, maxCand, dLongState + r0, dLongAlns, dLongCells, dLongWork + w0, hWorkLen + w0, dCandSeed + w0, cursor, capacity);
+					launchLongSelect(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, R->totalBases, (uint32_t)P->min_cluster_size, maxCand, dLongState + r0, dLongAlns, dLongCells, dLongWork + w0, dWorkLen + w0, dCandSeed + w0, cursor, capacity);
+					{
+						// execution order: longest extensions first, so the round's tail is made of short ones (GC_LONG_ORDER=0: as emitted)
+						const char* mode = getenv("GC_LONG_ORDER");
+						launchLongOrder(q, dWorkLen + w0, cursor, dOrder + w0, (uint32_t)maxReadLen, mode ? (uint32_t)atoi(mode) : 1u);
+					}
 					launchPublish(q, cursor, (unsigned long long*)hCursor, 2);
 					HIP_CHECK(hipStreamSynchronize(q));
 					uint32_t nWorkItems = (uint32_t)hCursor[0];
@@ -1186,24 +1191,15 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					uint32_t team = longExtendTeamSize(nWorkItems);
 					uint32_t blocks = std::min<uint32_t>((nWorkItems + team - 1) / team, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / team));
 					if (const char* env = getenv("GC_LONG_MAX_BLOCKS")) blocks = std::min<uint32_t>(blocks, (uint32_t)std::max(1, atoi(env)));   // test hook: force persistent waves
-					// Execution order: longest extensions first, so the round's tail is made of short ones.
-					{
-						uint32_t* order = hOrder + w0;
-						const uint32_t* len = hWorkLen + w0;
-						for (uint32_t i = 0; i < nWorkItems; i++) order[i] = i;
-						const char* mode = getenv("GC_LONG_ORDER");
-						int m = mode ? atoi(mode) : 1;
-						if (m >= 1) std::stable_sort(order, order + nWorkItems, [&](uint32_t a, uint32_t b) { return len[a] > len[b]; });
-					}
 					HIP_CHECK(hipEventRecord(ev0, q));
-					launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, hOrder + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, team, blocks,
+					launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, team, blocks,
 						dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2);
 					if (team == 1) {
 						// extensions whose band outgrew the 64-entry register tables: second try with the LDS/HBM tables (two lanes per wave,
 						// 28 + 228 entries); waves whose items are fine leave at once. Beyond that the read goes to the plain-layout fallback.
 						HIP_CHECK(hipMemsetAsync(cursor + 2, 0, sizeof(unsigned long long), q));
 						uint32_t retryBlocks = std::min<uint32_t>((nWorkItems + 1) / 2, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / 2));
-						launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, hOrder + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 2, retryBlocks,
+						launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 2, retryBlocks,
 							dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, EXT_LDS_CAP);
 					}
 					HIP_CHECK(hipEventRecord(ev1, q));

@@ -901,6 +901,23 @@ __global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __re
 	if (lane == 0) state[r] = st;
 }
 
+// Execution order of a round's work items: longest extensions first (a counting sort over 1024 length classes, one block;
+// the order inside a class is whatever the atomics give - results do not depend on it). mode 0: identity.
+__global__ void __launch_bounds__(1024) k_long_order(const uint32_t* __restrict__ workLen, const unsigned long long* __restrict__ workCount, uint32_t* __restrict__ order, uint32_t shift, uint32_t mode)
+{
+	__shared__ uint32_t hist[1024];
+	__shared__ uint32_t start[1024];
+	const uint32_t n = (uint32_t)*workCount, tid = threadIdx.x;
+	if (mode == 0) { for (uint32_t i = tid; i < n; i += 1024) order[i] = i; return; }
+	hist[tid] = 0;
+	__syncthreads();
+	for (uint32_t i = tid; i < n; i += 1024) { uint32_t b = workLen[i] >> shift; atomicAdd(&hist[1023 - (b < 1023 ? b : 1023)], 1u); }
+	__syncthreads();
+	if (tid == 0) { uint32_t at = 0; for (uint32_t b = 0; b < 1024; b++) { start[b] = at; at += hist[b]; } }
+	__syncthreads();
+	for (uint32_t i = tid; i < n; i += 1024) { uint32_t b = workLen[i] >> shift; order[atomicAdd(&start[1023 - (b < 1023 ? b : 1023)], 1u)] = i; }
+}
+
 // copies a few cursor words into pinned host memory through the compute queue (a copy-engine transfer would queue behind bulk uploads)
 __global__ void k_publish(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst, uint32_t nWords)
 {
@@ -1022,6 +1039,12 @@ void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, u
 	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity)
 {
 	if (nReads) hipLaunchKernelGGL(k_long_merge, dim3(nReads), dim3(64), 0, stream, g, jobs, nReads, seeds, candSeed, results, tracePool, maxAlignments, state, alns, cellPool, cellCursor, cellCapacity);
+}
+void launchLongOrder(hipStream_t stream, const uint32_t* workLen, const unsigned long long* workCount, uint32_t* order, uint32_t maxLen, uint32_t mode)
+{
+	uint32_t shift = 0;
+	while ((maxLen >> shift) > 1023) shift++;
+	hipLaunchKernelGGL(k_long_order, dim3(1), dim3(1024), 0, stream, workLen, workCount, order, shift, mode);
 }
 void launchPublish(hipStream_t stream, const unsigned long long* src, unsigned long long* dst, uint32_t nWords)
 {
