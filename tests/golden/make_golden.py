@@ -3,6 +3,7 @@
   ref_test_*      - the reference's own data files test/graph.gfa + test/read.fa (data, copied verbatim)
   syn20k.gfa/.fa  - a 20 kbp synthetic SNP/indel-bubble graph with 6 reads of 2 kb (seeded generator)
   *.expected.npz  - the oracle's flat result arrays for those inputs
+  syn20k.expected.{gaf,merged.gaf,json} - the oracle's output-encoder text for the synthetic reads
 
 The reference ships no expected outputs and cannot be built here, so these vectors pin the
 oracle against regressions, not against the reference; the one reference-derived value is the anchor recorded
@@ -25,8 +26,16 @@ def main():
     sg.write_gfa(os.path.join(HERE, "syn20k.gfa"))
     reads = sg.sample_reads(6, 2000, seed=11)
     write_fasta(os.path.join(HERE, "syn20k.fa"), reads)
-    res = Oracle(os.path.join(HERE, "syn20k.gfa")).align(reads)
+    ora = Oracle(os.path.join(HERE, "syn20k.gfa"))
+    res = ora.align(reads)
     np.savez_compressed(os.path.join(HERE, "syn20k.expected.npz"), **{k: v for k, v in res.items() if k != "stage_microseconds"})
+    # the output encoders' text for the same reads (read ids r0..r5): GAF with =/X and with M cigars, protobuf-JSON lines
+    with open(os.path.join(HERE, "syn20k.expected.gaf"), "wb") as f:
+        f.write(ora.gaf(False))
+    with open(os.path.join(HERE, "syn20k.expected.merged.gaf"), "wb") as f:
+        f.write(ora.gaf(True))
+    with open(os.path.join(HERE, "syn20k.expected.json"), "wb") as f:
+        f.write(ora.json())
     read = open(os.path.join(HERE, "ref_test_read.fa")).read().split("\n")[1]
     res = Oracle(os.path.join(HERE, "ref_test_graph.gfa")).align([read])
     np.savez_compressed(os.path.join(HERE, "ref_test.expected.npz"), **{k: v for k, v in res.items() if k != "stage_microseconds"})

@@ -427,3 +427,19 @@ def test_long_reads(gca, tmp_path, monkeypatch):
     got, want = run_case(gca, gfa, reads, long_pass=True)
     compare(got, want, COMPARE_KEYS + LONG_KEYS)
     assert int(np.max(got["long_edit_distance"])) > 2016          # a band wider than one 64-row block per lane can hold
+
+
+def test_output_against_golden_files(gca, golden_dir):
+    """The encoders' output for the committed synthetic fixture against the committed text (tests/golden/syn20k.expected.*)."""
+    reads = []
+    for line in open(os.path.join(golden_dir, "syn20k.fa")):
+        if not line.startswith(">"):
+            reads.append(line.strip().encode())
+    graph = gca.AlignmentGraph(os.path.join(golden_dir, "syn20k.gfa"))
+    seeder = gca.MinimizerSeeder(graph)
+    names = [f"r{i}" for i in range(len(reads))]
+    out = gca.Aligner(graph, seeder, keep_traces=True, long_pass=True).align_reads(reads, gaf_names=names, other_formats=True)
+    assert out["gaf"] == open(os.path.join(golden_dir, "syn20k.expected.gaf"), "rb").read()
+    assert out["json"] == open(os.path.join(golden_dir, "syn20k.expected.json"), "rb").read()
+    merged = gca.Aligner(graph, seeder, keep_traces=True, long_pass=True).align_reads(reads, gaf_names=names, cigar_match_mismatch_merge=True)
+    assert merged["gaf"] == open(os.path.join(golden_dir, "syn20k.expected.merged.gaf"), "rb").read()

@@ -39,6 +39,26 @@ def test_synthetic_golden():
     for k in want.files:
         assert np.array_equal(res[k], want[k]), k
     assert int(res["read_chain_off"][-1]) > 0 and not res["failed_assertion"].any()
+    # output encoders (GAF both cigar styles, protobuf-JSON): frozen text, plus self-consistency of every GAF line
+    assert o.gaf(False) == open(os.path.join(GOLD, "syn20k.expected.gaf"), "rb").read()
+    assert o.gaf(True) == open(os.path.join(GOLD, "syn20k.expected.merged.gaf"), "rb").read()
+    assert o.json() == open(os.path.join(GOLD, "syn20k.expected.json"), "rb").read()
+    import json
+    import re
+    lines = o.gaf(False).decode().splitlines()
+    objs = [json.loads(x) for x in o.json().decode().splitlines()]
+    assert len(lines) == len(objs) >= 6
+    for line, obj in zip(lines, objs):
+        f = line.split("\t")
+        cigar = re.findall(r"(\d+)([=XIDM])", f[-1][len("cg:Z:"):])
+        on_read = sum(int(n) for n, op in cigar if op in "=XI")
+        on_path = sum(int(n) for n, op in cigar if op in "=XD")
+        assert on_read == int(f[3]) - int(f[2]) == len(obj["sequence"])            # read span = aligned sequence
+        assert on_path == int(f[8]) - int(f[7])                                      # path span
+        assert int(f[9]) == sum(int(n) for n, op in cigar if op == "=")             # matches
+        assert len(re.findall(r"[<>]", f[5])) == len(obj["path"]["mapping"])         # one mapping per path step
+        edits = [e for m in obj["path"]["mapping"] for e in m["edit"]]
+        assert sum(e.get("to_length", 0) for e in edits) == on_read and sum(e.get("from_length", 0) for e in edits) == on_path
 
 
 # ---- graph structure properties ---------------------------------------------------------------------
