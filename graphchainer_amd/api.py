@@ -222,6 +222,27 @@ _RESULT_FIELDS = {
 }
 
 
+class _ResultHolder:
+    """Owns one gc_result; frees it when the last reference goes away."""
+
+    def __init__(self, lib, res):
+        self.lib, self.res = lib, res
+
+    def __del__(self):
+        try:
+            if self.res:
+                self.lib.gc_result_free(self.res)
+                self.res = None
+        except Exception:
+            pass
+
+
+class BatchResult(dict):
+    """dict of numpy arrays that are VIEWS of the C result (no copies on the hot path); the C memory lives as long as this
+    dict does - copy an array (`.copy()`) to keep it longer."""
+    _holder = None
+
+
 class Aligner:
     """Batched stand-in for the reference's per-read hot path (src/Aligner.cpp:601-922)."""
 
@@ -250,7 +271,8 @@ class Aligner:
         lines) and "gam" (gzip members of framed vg::Alignment messages)."""
         res = _P(GcResult)()
         _check(self.lib.gc_align_batch(self.graph.handle, self.seeder.handle, self.stream, batch.handle, C.byref(self.params), C.byref(res)))
-        try:
+        holder = _ResultHolder(self.lib, res)
+        if True:
             gaf = None
             if gaf_names is not None:
                 names = (C.c_char_p * len(gaf_names))(*[n.encode() if isinstance(n, str) else bytes(n) for n in gaf_names])
@@ -271,9 +293,10 @@ class Aligner:
             n = int(r.n_reads)
 
             def arr(ptr, count):
-                return np.ctypeslib.as_array(ptr, shape=(count,)).copy() if count else np.zeros(0, dtype=np.int64)
+                return np.ctypeslib.as_array(ptr, shape=(count,)) if count else np.zeros(0, dtype=np.int64)
 
-            out = {}
+            out = BatchResult()
+            out._holder = holder
             out["read_seed_off"] = arr(r.read_seed_off, n + 1)
             seeds = int(out["read_seed_off"][-1])
             out["read_anchor_off"] = arr(r.read_anchor_off, n + 1)
@@ -317,9 +340,7 @@ class Aligner:
                 out["gaf"], out["gaf_chained_skipped"] = gaf[0], gaf[1]
                 if len(gaf) > 2:
                     out["json"], out["gam"] = gaf[2], gaf[3]
-            return out   # arrays keep the C ABI's dtypes (uint32/uint64/...): no widening copies on the hot path
-        finally:
-            self.lib.gc_result_free(res)
+            return out   # arrays keep the C ABI's dtypes (uint32/uint64/...) and are views: no copies on the hot path
 
     def align_reads(self, reads, **kw):
         batch = ReadBatch(reads)
