@@ -201,6 +201,37 @@ struct gc_reads {
 	~gc_reads() { if (devBases) (void)hipFree(devBases); if (devOffsets) (void)hipFree(devOffsets); if (devMasks) (void)hipFree(devMasks); if (devEqMasks) (void)hipFree(devEqMasks); if (devEdReads) (void)hipFree(devEdReads); }
 };
 
+struct StitchedPath { std::vector<uint32_t> nodes; uint32_t firstOffset = 0, lastOffset = 0; uint64_t cells = 0; };
+
+struct ReadGlue {
+	std::vector<gc::SeedRec> seeds;       // fragment-pass order (by seqPos)
+	std::vector<gc::SeedRec> longSeeds;   // whole-read pass order (by goodness), only with long_pass
+	std::vector<gc::FragmentWindow> windows;
+	std::vector<LongAln> longAlns;        // final order (the reference's repeated sort by alignmentStart)
+	uint64_t longBegin = 0, longTraceBegin = 0, longSeedBegin = 0;
+	bool failed = false;
+	uint64_t slotBegin = 0, fragBegin = 0;
+	uint64_t nAnchors = 0, nPath = 0, nTrace = 0, anchorBegin = 0, pathBegin = 0, traceBegin = 0, seedBegin = 0, chainBegin = 0;
+	StitchedPath stitched;                // chain stitching result
+	uint64_t stitchedBegin = 0;
+	std::vector<uint32_t> longSelected;   // GreedyLength selection (src/Aligner.cpp:636-639): indices into longAlns
+	uint64_t longSelectedBegin = 0;
+	int64_t longEditDistance = -1, chainEditDistance = -1;
+	// back to the state of a fresh record, keeping the vectors' storage: the records live in the gc_stream and are reused by
+	// every batch (allocating and destroying 10 k x 6 vectors per batch cost ~10 ms of teardown plus the allocations)
+	void reset()
+	{
+		seeds.clear(); longSeeds.clear(); windows.clear(); longAlns.clear(); longSelected.clear();
+		stitched.nodes.clear(); stitched.firstOffset = stitched.lastOffset = 0; stitched.cells = 0;
+		longBegin = longTraceBegin = longSeedBegin = 0;
+		failed = false;
+		slotBegin = fragBegin = 0;
+		nAnchors = nPath = nTrace = anchorBegin = pathBegin = traceBegin = seedBegin = chainBegin = 0;
+		stitchedBegin = longSelectedBegin = 0;
+		longEditDistance = chainEditDistance = -1;
+	}
+};
+
 struct EditDistanceRun {
 	hipStream_t streams[5] {};
 	hipEvent_t ready = nullptr;
@@ -210,6 +241,7 @@ struct EditDistanceRun {
 };
 
 struct gc_stream {
+	std::vector<ReadGlue> glue;   // per-read host records of the batch in flight (storage reused)
 	int device = 0;             // the device the stream was created on; gc_align_batch selects it for the calling thread
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[12] {};
@@ -401,24 +433,6 @@ static void requireDevice()
 }
 
 namespace {
-
-struct StitchedPath { std::vector<uint32_t> nodes; uint32_t firstOffset = 0, lastOffset = 0; uint64_t cells = 0; };
-
-struct ReadGlue {
-	std::vector<gc::SeedRec> seeds;       // fragment-pass order (by seqPos)
-	std::vector<gc::SeedRec> longSeeds;   // whole-read pass order (by goodness), only with long_pass
-	std::vector<gc::FragmentWindow> windows;
-	std::vector<LongAln> longAlns;        // final order (the reference's repeated sort by alignmentStart)
-	uint64_t longBegin = 0, longTraceBegin = 0, longSeedBegin = 0;
-	bool failed = false;
-	uint64_t slotBegin = 0, fragBegin = 0;
-	uint64_t nAnchors = 0, nPath = 0, nTrace = 0, anchorBegin = 0, pathBegin = 0, traceBegin = 0, seedBegin = 0, chainBegin = 0;
-	StitchedPath stitched;                // chain stitching result
-	uint64_t stitchedBegin = 0;
-	std::vector<uint32_t> longSelected;   // GreedyLength selection (src/Aligner.cpp:636-639): indices into longAlns
-	uint64_t longSelectedBegin = 0;
-	int64_t longEditDistance = -1, chainEditDistance = -1;
-};
 
 // Chain stitching, reference: src/Aligner.cpp:754-822 (+ pathToTrace :409-424, getChainPath src/AlignmentGraph.cpp:1866-1916).
 // The chain's anchor paths are concatenated; consecutive anchors that are not adjacent are bridged by the fewest-hops
@@ -993,6 +1007,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 	if (!G || !S || !st || !R || !P || !out) return fail(GC_ERR_INVALID, "null argument");
 	if (P->split_len < 16 || P->split_len > 64 || P->split_gap < 1) return fail(GC_ERR_INVALID, "split_len must be in [16,64] (one 64-row slice per fragment extension) and split_gap >= 1");
 	*out = nullptr;
+	const double tCall = nowUs();
 	gc_result* res = (gc_result*)calloc(1, sizeof(gc_result));
 	int rc = guarded([&]() {
 		HIP_CHECK(hipSetDevice(st->device));   // the current device is per host thread
@@ -1034,7 +1049,9 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 
 		// ---------------- host glue: order-critical sorts and fragment windows (see host/gc_glue.hpp)
 		double tGlue = nowUs();
-		std::vector<ReadGlue> glue(n);
+		std::vector<ReadGlue>& glue = st->glue;   // per-read host records, storage reused across batches
+		if (glue.size() < n) glue.resize(n);
+		pool.run(n, [&](size_t r, size_t) { glue[r].reset(); });
 		std::vector<gc::GlueScratch> scratch(pool.size());
 		pool.run(n, [&](size_t r, size_t worker) {
 			ReadGlue& gl = glue[r];
@@ -1760,8 +1777,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			});
 		});
 		res->host_us[1] = nowUs() - tAsm;
+		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] batch timeline (ms from the call): whole-read pass started %.1f, joined %.1f, assembly began %.1f, done %.1f\n", (tLongWall0 - tTotal) / 1e3, (tJoined - tTotal) / 1e3, (tAsm - tTotal) / 1e3, (nowUs() - tTotal) / 1e3);
 		return (int)GC_OK;
 	});
+	if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] gc_align_batch returned after %.1f ms\n", (nowUs() - tCall) / 1e3);
 	if (rc != GC_OK) { gc_result_free(res); return rc; }
 	*out = res;
 	return GC_OK;
