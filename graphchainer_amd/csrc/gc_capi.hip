@@ -1092,9 +1092,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				const ReadGlue& gl = glue[r];
 				uint64_t at = gl.longSeedBegin;
 				for (const gc::SeedRec& s : gl.longSeeds) {
-					uint32_t twinNode, twinOffset;
-					G->twinOf(s.node, s.offset, twinNode, twinOffset);
-					hSeeds[at++] = LongSeed { s.node, s.offset, twinNode, twinOffset, s.seqPos, s.goodness, s.clusterSize, 0 };
+					hSeeds[at++] = LongSeed { s.node, s.seqPos, s.goodness, s.clusterSize, s.offset, 0 };
 				}
 				LongJob& j = hJobs[r];
 				j.maskOff = R->maskOff[r];

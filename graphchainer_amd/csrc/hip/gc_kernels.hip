@@ -474,6 +474,15 @@ __device__ __forceinline__ LongSlab longSlab(uint8_t* slab, const ExtendConfig& 
 	return ls;
 }
 
+// reverse-strand twin of (split node, offset): GetReversePosition + GetUnitigNode (src/AlignmentGraph.cpp:832-868)
+__device__ __forceinline__ void twinOf(const DGraph& g, uint32_t node, uint32_t offset, uint32_t& twinNode, uint32_t& twinOffset)
+{
+	const int32_t id = g.nodeIDs[node];
+	const uint32_t rev = g.origSize[id] - 1 - (g.nodeOffset[node] + offset);
+	twinNode = g.lookup[g.lookupOff[id ^ 1] + rev / 64];
+	twinOffset = rev - g.nodeOffset[twinNode];
+}
+
 // Is the seed's cell on this alignment's trace? (:407-461). Returns 1 yes, 0 no, 2 the reference asserts.
 __device__ inline int onTrace(const LongCell* trace, uint32_t n, uint32_t seqPos, int32_t compareNode, uint32_t nodeOffset)
 {
@@ -567,7 +576,9 @@ __global__ void __launch_bounds__(64) k_long_pass(DGraph g, const CorrectnessTab
 			int32_t scoreB = 0, scoreF = 0;
 			uint32_t stB = EXT_FAILED, stF = EXT_FAILED;
 			if (p > 0) {
-				stB = extendSeed(g, *ct, iupac, cfg, ls.sc, bases + rcBase + job.readOff + (uint64_t)(L - p), p, sd.twinNode, sd.twinOffset, nB, scoreB, cnt);
+				uint32_t twinNode, twinOffset;
+				twinOf(g, sd.node, sd.offset, twinNode, twinOffset);
+				stB = extendSeed(g, *ct, iupac, cfg, ls.sc, bases + rcBase + job.readOff + (uint64_t)(L - p), p, twinNode, twinOffset, nB, scoreB, cnt);
 				if (stB == EXT_OK) for (uint32_t i = 0; i < nB; i++) ls.traceB[i] = ls.sc.trace[i];
 			}
 			if (p < L - 1) stF = extendSeed(g, *ct, iupac, cfg, ls.sc, bases + job.readOff + (uint64_t)(p + 1), L - 1 - p, sd.node, sd.offset, nF, scoreF, cnt);
@@ -725,7 +736,9 @@ __global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __r
 			LongSeed sd = seeds[myCand];
 			const uint32_t L = job.readLen, p = sd.seqPos;
 			// backward: rows are revcomp(read[0..p)) = reverse-complement strand from position L-p; forward: read(p..] from p+1
-			work[at + 2 * c] = LongWork { job.maskOff + 4ull * job.maskWords, job.maskWords, L - p, p, sd.twinNode, sd.twinOffset, r };
+			uint32_t twinNode, twinOffset;
+			twinOf(g, sd.node, sd.offset, twinNode, twinOffset);
+			work[at + 2 * c] = LongWork { job.maskOff + 4ull * job.maskWords, job.maskWords, L - p, p, twinNode, twinOffset, r };
 			work[at + 2 * c + 1] = LongWork { job.maskOff, job.maskWords, p + 1, L - 1 - p, sd.node, sd.offset, r };
 			workLen[at + 2 * c] = p;
 			workLen[at + 2 * c + 1] = L - 1 - p;

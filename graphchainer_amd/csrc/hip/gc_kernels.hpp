@@ -62,13 +62,13 @@ struct ReadChainJob {
 struct ChainCaps { uint32_t capAnchors, capEndpoints, capTable; };
 
 // ---- whole-read pass (K3-long) ----
-struct LongSeed {    // a seed in goodness order (after OrderSeeds), with the backward start precomputed by the host
-	uint32_t node, offset;          // forward start: split node + offset of the seed base
-	uint32_t twinNode, twinOffset;  // backward start: reverse-strand twin position
+struct LongSeed {    // a seed in goodness order (after OrderSeeds); 16 bytes: 3 M of them go up per 10 k-read batch
+	uint32_t node;                  // forward start: split node of the seed base
 	uint32_t seqPos;
 	uint32_t goodness;
-	uint32_t clusterSize;
-	uint32_t pad;
+	uint16_t clusterSize;           // saturated (only compared with --seeds-clustersize)
+	uint8_t offset;                 // offset of the seed base in the split node
+	uint8_t pad;
 };
 
 struct LongJob {     // one read
