@@ -211,7 +211,7 @@ def main():
             "roofline": roofline,
             "roofline_other": roof_extend if roofline is roof_long else roof_long,
             "cpu_baseline": cpu_baseline,
-            "stage_ms": {"k_seed_lookup": round(kernel_us[0] / 1e3, 3), "k_extend": round(kernel_us[1] / 1e3, 3), "k_build_anchors": round(kernel_us[2] / 1e3, 3),
+            "stage_ms": {"k_seed_probe+compact": round(kernel_us[0] / 1e3, 3), "k_extend": round(kernel_us[1] / 1e3, 3), "k_build_anchors": round(kernel_us[2] / 1e3, 3),
                          "k_chain": round(kernel_us[3] / 1e3, 3), "k_long_extend_all_rounds": round(kernel_us[4] / 1e3, 3), "whole_read_pass_wall": round(kernel_us[5] / 1e3, 3), "host_seed_glue": round(host_us[0] / 1e3, 3), "host_result_assembly": round(host_us[1] / 1e3, 3),
                          "wall_seed_lookup_and_copies": round(host_us[2] / 1e3, 3), "wall_extend_to_chain_and_copies": round(host_us[3] / 1e3, 3)},
             "setup_s": {"generate": round(t_gen, 1), "graph_build_upload": round(t_graph, 1), "minimizer_index": round(t_index, 1)},

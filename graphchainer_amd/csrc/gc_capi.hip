@@ -861,6 +861,11 @@ int gc_seeder_create(const gc_graph* g, int32_t k, int32_t w, double keepFractio
 		}
 		uint64_t* dTable = uploadVector(table);
 		S->allocations.push_back(dTable);
+		std::vector<uint32_t> filter((1u << 28) / 32, 0);   // see filterBit in gc_kernels.hip
+		for (size_t i = 0; i < nKeys; i++) { uint32_t fb = (uint32_t)((S->host.kmers[i] * 0xD6E8FEB86659FD93ull) >> 36); filter[fb >> 5] |= 1u << (fb & 31); }
+		uint32_t* dFilter = uploadVector(filter);
+		S->allocations.push_back(dFilter);
+		S->dev.filter = dFilter;
 		uint64_t* dStart = uploadVector(S->host.startPos);
 		S->allocations.push_back(dStart);
 		S->dev.table = dTable;
@@ -1034,7 +1039,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		HIP_CHECK(hipMemsetAsync(dCursors, 0, 8 * sizeof(unsigned long long), stream));
 		HIP_CHECK(hipMemsetAsync(dCounters, 0, 8 * sizeof(unsigned long long), stream));
 		mark();   // 0
-		launchSeedLookup(stream, S->dev, R->devBases, R->devOffsets, (uint32_t)n, (uint64_t*)dCursors, dReadMatchOff, dReadMatchCount, dMatches, R->totalBases, dTmp);
+		launchSeedLookup(stream, S->dev, R->devBases, R->devOffsets, (uint32_t)n, (uint64_t*)dCursors, dReadMatchOff, dReadMatchCount, dMatches, R->totalBases, dTmp, R->totalBases);
 		mark();   // 1
 		if (n) HIP_CHECK(hipMemcpyAsync(readMatchOff, dReadMatchOff, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		if (n) HIP_CHECK(hipMemcpyAsync(readMatchCount, dReadMatchCount, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

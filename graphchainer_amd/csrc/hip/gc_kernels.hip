@@ -32,9 +32,15 @@ __device__ __forceinline__ uint32_t hashKmer(uint64_t kmer)
 	return (uint32_t)(kmer >> 32);
 }
 
+// 9 of 10 read k-mers are not graph minimizers; a probe of the 0.1-0.5 GB table is a random HBM access each, a bit of the
+// 32 MB filter is a cache hit. A clear bit proves the k-mer is not a key (a set bit proves nothing: ~2 % false positives).
+__device__ __forceinline__ uint32_t filterBit(uint64_t kmer) { return (uint32_t)((kmer * 0xD6E8FEB86659FD93ull) >> 36); }
+
 // returns key index or 0xffffffff. Open addressing, linear probing; slot = {kmer:32, index:32}.
 __device__ __forceinline__ uint32_t lookupKmer(const SeedIndex& idx, uint64_t kmer)
 {
+	const uint32_t fb = filterBit(kmer);
+	if (!((idx.filter[fb >> 5] >> (fb & 31)) & 1u)) return 0xffffffffu;
 	uint32_t h = hashKmer(kmer) & idx.tableMask;
 	while (true) {
 		uint64_t slot = idx.table[h];
@@ -45,52 +51,64 @@ __device__ __forceinline__ uint32_t lookupKmer(const SeedIndex& idx, uint64_t km
 	}
 }
 
-__global__ void __launch_bounds__(64) k_seed_lookup(SeedIndex idx, const char* __restrict__ bases, const uint64_t* __restrict__ readOff, uint32_t nReads,
-	uint64_t* __restrict__ matchCursor, uint32_t* __restrict__ readMatchOff, uint32_t* __restrict__ readMatchCount, uint2* __restrict__ matches, uint64_t matchCapacity, uint32_t* __restrict__ tmp)
+// K1a: one thread per read base. For the k-mer that ends at the base: the reference's thinning rule, the index probe and the
+// frequency cut; writes key index + 1 (0 = nothing to emit) into tmp[global position].
+__global__ void __launch_bounds__(256) k_seed_probe(SeedIndex idx, const char* __restrict__ bases, const uint64_t* __restrict__ readOff, uint32_t nReads, uint64_t totalBases, uint32_t* __restrict__ tmp)
 {
-	const int lane = threadIdx.x;
 	const int k = idx.k;
 	const int realWindow = idx.w - idx.k + 1;
 	const uint64_t mask = ~(~0ull << (2 * k));
-	for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
-		const char* seq = bases + readOff[r];
-		const int len = (int)(readOff[r + 1] - readOff[r]);
-		uint32_t* mine = tmp + readOff[r];
-		uint32_t total = 0;
-		// pass 1: per position, key index + 1 (0 = nothing to emit)
-		for (int base = 0; base < len; base += 64) {
-			int pos = base + lane;
-			uint32_t found = 0;
-			if (pos < len && pos >= k - 1) {
-				// k-mer ending at pos, and how far the run of valid characters extends to the left of it
-				uint64_t kmer = 0;
-				bool valid = true;
-				for (int i = pos - k + 1; i <= pos; i++) {
-					int c = baseCode((uint8_t)seq[i]);
-					if (c < 0) { valid = false; break; }
-					kmer = (kmer << 2) | (uint64_t)c;
+	for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < totalBases; p += (uint64_t)gridDim.x * blockDim.x) {
+		// the read this base belongs to: last r with readOff[r] <= p
+		uint32_t lo = 0, hi = nReads;
+		while (hi - lo > 1) { uint32_t mid = (lo + hi) / 2; if (readOff[mid] <= p) lo = mid; else hi = mid; }
+		const char* seq = bases + readOff[lo];
+		const int pos = (int)(p - readOff[lo]);
+		uint32_t found = 0;
+		if (pos >= k - 1) {
+			// k-mer ending at pos
+			uint64_t kmer = 0;
+			bool valid = true;
+			for (int i = pos - k + 1; i <= pos; i++) {
+				int c = baseCode((uint8_t)seq[i]);
+				if (c < 0) { valid = false; break; }
+				kmer = (kmer << 2) | (uint64_t)c;
+			}
+			if (valid) {
+				// thinning (:91): inside a streak of identical consecutive k-mers only every realWindow-th is emitted.
+				// Consecutive k-mers are identical only in a homopolymer; walk back to the streak start.
+				int streakStart = pos;
+				int c0 = baseCode((uint8_t)seq[pos]);
+				bool homopolymer = (kmer == (uint64_t)c0 * (mask / 3));
+				if (homopolymer) {
+					while (streakStart - k >= 0 && baseCode((uint8_t)seq[streakStart - k]) == c0) streakStart--;
 				}
-				if (valid) {
-					// thinning (:91): inside a streak of identical consecutive k-mers only every realWindow-th is emitted.
-					// Consecutive k-mers are identical only in a homopolymer; walk back to the streak start.
-					int streakStart = pos;
-					int c0 = baseCode((uint8_t)seq[pos]);
-					bool homopolymer = (kmer == (uint64_t)c0 * (mask / 3));
-					if (homopolymer) {
-						while (streakStart - k >= 0 && baseCode((uint8_t)seq[streakStart - k]) == c0) streakStart--;
-					}
-					bool emit = ((pos - streakStart) % realWindow) == 0;
-					if (emit) {
-						uint32_t key = lookupKmer(idx, kmer & mask);
-						if (key != 0xffffffffu) {
-							uint32_t count = (uint32_t)(idx.startPos[key + 1] - idx.startPos[key]);
-							if (count < idx.maxCount) found = key + 1;
-						}
+				bool emit = ((pos - streakStart) % realWindow) == 0;
+				if (emit) {
+					uint32_t key = lookupKmer(idx, kmer & mask);
+					if (key != 0xffffffffu) {
+						uint32_t count = (uint32_t)(idx.startPos[key + 1] - idx.startPos[key]);
+						if (count < idx.maxCount) found = key + 1;
 					}
 				}
 			}
-			if (pos < len) mine[pos] = found;
-			total += (uint32_t)__popcll(__ballot(found != 0));
+		}
+		tmp[p] = found;
+	}
+}
+
+// K1b: one wave per read: counts the read's hits, reserves a contiguous output range and compacts them in position order.
+__global__ void __launch_bounds__(64) k_seed_compact(const uint64_t* __restrict__ readOff, uint32_t nReads, const uint32_t* __restrict__ tmp,
+	uint64_t* __restrict__ matchCursor, uint32_t* __restrict__ readMatchOff, uint32_t* __restrict__ readMatchCount, uint2* __restrict__ matches, uint64_t matchCapacity)
+{
+	const int lane = threadIdx.x;
+	for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
+		const int len = (int)(readOff[r + 1] - readOff[r]);
+		const uint32_t* mine = tmp + readOff[r];
+		uint32_t total = 0;
+		for (int base = 0; base < len; base += 64) {
+			int pos = base + lane;
+			total += (uint32_t)__popcll(__ballot(pos < len && mine[pos] != 0));
 		}
 		// reserve a contiguous output range for this read
 		uint64_t outBase = 0;
@@ -98,7 +116,6 @@ __global__ void __launch_bounds__(64) k_seed_lookup(SeedIndex idx, const char* _
 		outBase = __shfl(outBase, 0);
 		if (lane == 0) { readMatchOff[r] = (uint32_t)outBase; readMatchCount[r] = total; }
 		if (outBase + total > matchCapacity) continue;   // host checks the cursor and retries with a larger buffer
-		// pass 2: ordered compaction
 		uint32_t written = 0;
 		for (int base = 0; base < len; base += 64) {
 			int pos = base + lane;
@@ -951,11 +968,14 @@ __global__ void __launch_bounds__(256) k_long_finish(uint32_t nReads, const Long
 // =====================================================================================================
 
 void launchSeedLookup(hipStream_t stream, const SeedIndex& idx, const char* bases, const uint64_t* readOff, uint32_t nReads,
-	uint64_t* matchCursor, uint32_t* readMatchOff, uint32_t* readMatchCount, uint2* matches, uint64_t matchCapacity, uint32_t* tmp)
+	uint64_t* matchCursor, uint32_t* readMatchOff, uint32_t* readMatchCount, uint2* matches, uint64_t matchCapacity, uint32_t* tmp, uint64_t totalBases)
 {
 	if (nReads == 0) return;
+	uint64_t probeBlocks = (totalBases + 255) / 256;
+	if (probeBlocks > 65536) probeBlocks = 65536;
+	if (probeBlocks) hipLaunchKernelGGL(k_seed_probe, dim3((uint32_t)probeBlocks), dim3(256), 0, stream, idx, bases, readOff, nReads, totalBases, tmp);
 	uint32_t blocks = nReads < 16384 ? nReads : 16384;
-	hipLaunchKernelGGL(k_seed_lookup, dim3(blocks), dim3(64), 0, stream, idx, bases, readOff, nReads, matchCursor, readMatchOff, readMatchCount, matches, matchCapacity, tmp);
+	hipLaunchKernelGGL(k_seed_compact, dim3(blocks), dim3(64), 0, stream, readOff, nReads, tmp, matchCursor, readMatchOff, readMatchCount, matches, matchCapacity);
 }
 
 uint64_t extendSlabBytes(const ExtendConfig& cfg)
