@@ -250,9 +250,17 @@ struct gc_stream {
 	// whole-read pass: runs on its own stream, concurrently with the fragment kernels
 	hipStream_t longStream = nullptr;
 	hipEvent_t longEv[2] {};
-	DeviceBuffer edPathNodes, edJobs, edLetters, edLettersLen, edPairs, edOut, edLongJobs, edLongLetters, edLongLettersLen, edLongPairs, edLongOut;
-	PinnedBuffer hEdPathNodes, hEdJobs, hEdPairs, hEdOut, hEdLongJobs, hEdLongPairs, hEdLongOut;
-	EditDistanceRun edChainRun, edLongRun;
+	DeviceBuffer edPathNodes, edJobs, edLetters, edLettersLen, edPairs, edOut;
+	PinnedBuffer hEdPathNodes, hEdJobs, hEdPairs, hEdOut;
+	EditDistanceRun edChainRun;
+	// whole-read decision (selection + edit distance of the best alignment)
+	struct LongDecision {
+		PinnedBuffer hJobs, hPairs, hOut;
+		DeviceBuffer jobs, letters, lettersLen, pairs, out;
+		EditDistanceRun run;
+		std::vector<uint32_t> pairRead;
+		uint32_t nPairs = 0;
+	} edLong[2];
 	std::vector<hipStream_t> groupStreams;   // read groups of the whole-read pass run their round loops concurrently
 	std::vector<hipEvent_t> groupEvents;     // two per group
 	DeviceBuffer longSeeds, longJobs, longAlns, longResults, longScratch, longCells, longCursor, longJobsFallback, longResultsFallback, longScratchFallback;
@@ -1084,6 +1092,93 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		std::function<void()> finishLongGroups;
 		uint32_t longGroups = 0;
 		std::vector<double> groupExtendUs; std::vector<uint32_t> groupRounds; std::vector<uint64_t> groupBegin, groupTraceBegin;
+		// Decision for a set of reads whose whole-read alignments are final: the reference's alignment order, the GreedyLength
+		// selection, and (queued, not awaited) the path letters + NW edit distance of the best alignment. (Tried: deciding the
+		// reads that are already finished when the rounds turn latency-bound, so these kernels run beside the last rounds - the
+		// rounds slow down by more than the 11 ms the tail saves: 304-319 -> 318-337 ms per batch. So: all reads, after the rounds.)
+		struct DecisionPointers { EdPair* hPairs = nullptr; int64_t* hOut = nullptr; EdPair* dPairs = nullptr; int64_t* dOut = nullptr; char* dLetters = nullptr; uint32_t* dLettersLen = nullptr; } decisionPtr[2];
+		auto decideLongReads = [&](const std::vector<uint32_t>& subset, int slot, hipStream_t q, const std::function<uint32_t(uint32_t)>& nAlnOf, bool usePool = true) {
+			// the reference re-sorts its alignment list by alignmentStart after every accepted alignment
+			// (src/GraphAligner.h:183); replaying that on the acceptance-ordered list gives its final order. Then the
+			// GreedyLength selection (src/Aligner.cpp:636-639, src/AlignmentSelection.cpp:12-50) with the same unstable sort.
+			auto selectOne = [&](size_t i, size_t) {
+				const uint32_t r = subset[i];
+				ReadGlue& gl = glue[r];
+				gl.longAlns.clear();
+				gl.longSelected.clear();
+				const uint32_t nAln = nAlnOf(r);
+				for (uint32_t a = 0; a < nAln; a++) {
+					gl.longAlns.push_back(hLongAlns[(uint64_t)r * maxAlignments + a]);
+					std::sort(gl.longAlns.begin(), gl.longAlns.end(), [](const LongAln& l, const LongAln& rr) { return l.start < rr.start; });
+				}
+				struct Item { uint32_t start, end, score, index; };
+				std::vector<Item> sorted;
+				for (uint32_t a = 0; a < gl.longAlns.size(); a++) sorted.push_back(Item { gl.longAlns[a].start, gl.longAlns[a].end, gl.longAlns[a].score, a });
+				std::sort(sorted.begin(), sorted.end(), [](const Item& l, const Item& rr) {
+					if ((l.end - l.start) > (rr.end - rr.start)) return true;
+					if ((rr.end - rr.start) > (l.end - l.start)) return false;
+					return l.score < rr.score;
+				});
+				auto incompatible = [](const Item& l, const Item& rr) {
+					float minOverlapLen = std::min(l.end - l.start, rr.end - rr.start) * 0.05f;
+					size_t ls = l.start, le = l.end, rs = rr.start, re = rr.end;
+					if (ls > rs) { std::swap(ls, rs); std::swap(le, re); }
+					int overlap = 0;
+					if (le > rs) overlap = (int)(le - rs);
+					return overlap > minOverlapLen;
+				};
+				std::vector<Item> kept;
+				for (const Item& it : sorted) {
+					bool ok = true;
+					for (const Item& k : kept) if (incompatible(it, k)) { ok = false; break; }
+					if (ok) { kept.push_back(it); gl.longSelected.push_back(it.index); }
+				}
+			};
+			if (usePool) pool.run(subset.size(), selectOne); else for (size_t i = 0; i < subset.size(); i++) selectOne(i, 0);
+			auto& D = st->edLong[slot];
+			D.nPairs = 0;
+			D.pairRead.clear();
+			if (!P->edit_distances || subset.empty()) return;
+			// edit distance of the best whole-read alignment's path against the read (edlibAlign at src/Aligner.cpp:645)
+			const size_t m = subset.size();
+			PathSeqJob* hJobsPS = D.hJobs.reserve<PathSeqJob>(m);
+			EdPair* hPairs = D.hPairs.reserve<EdPair>(m);
+			int64_t* hOut = D.hOut.reserve<int64_t>(m);
+			uint64_t nLetters = 0;
+			uint32_t nPairs = 0;
+			for (size_t i = 0; i < m; i++) {
+				const uint32_t r = subset[i];
+				const ReadGlue& gl = glue[r];
+				if (gl.longSelected.empty()) { hJobsPS[i] = PathSeqJob { 0, nLetters, 0, 0, 0, 0 }; continue; }
+				const LongAln& al = gl.longAlns[gl.longSelected[0]];
+				uint32_t len = (uint32_t)(R->offsets[r + 1] - R->offsets[r]);
+				uint32_t cap = 2 * al.traceLen + 256;
+				hJobsPS[i] = PathSeqJob { al.traceOff, nLetters, al.traceLen, cap, 0, 0 };
+				// the alignment itself bounds the distance: its edits plus the unaligned read ends
+				hPairs[nPairs++] = EdPair { nLetters, 0, (uint32_t)i, r, al.score + al.start + (len - std::min(len, al.end)) + 8 };
+				D.pairRead.push_back(r);
+				nLetters += cap;
+			}
+			PathSeqJob* dJobsPS = D.jobs.reserve<PathSeqJob>(m);
+			char* dLetters = D.letters.reserve<char>(nLetters);
+			uint32_t* dLettersLen = D.lettersLen.reserve<uint32_t>(m);
+			EdPair* dPairs = D.pairs.reserve<EdPair>(m);
+			int64_t* dOut = D.out.reserve<int64_t>(m);
+			HIP_CHECK(hipMemcpyAsync(dJobsPS, hJobsPS, m * sizeof(PathSeqJob), hipMemcpyHostToDevice, q));
+			launchLongPathSeq(q, G->dev, dJobsPS, (uint32_t)m, dLongCells, dLetters, dLettersLen);
+			auto readLenOf = [R](uint32_t r) { return (uint32_t)(R->offsets[r + 1] - R->offsets[r]); };
+			launchEditDistances(D.run, q, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen, readLenOf);
+			D.nPairs = nPairs;
+			decisionPtr[slot] = DecisionPointers { hPairs, hOut, dPairs, dOut, dLetters, dLettersLen };
+		};
+		auto finishLongDecision = [&](int slot) {
+			auto& D = st->edLong[slot];
+			if (!D.nPairs) return;
+			const DecisionPointers& p = decisionPtr[slot];
+			finishEditDistances(D.run, st->longStream, p.hPairs, p.hOut, D.nPairs, p.dPairs, p.dOut, R->devEdReads, R->devBases, R->devEqMasks, p.dLetters, p.dLettersLen);
+			for (uint32_t i = 0; i < D.nPairs; i++) glue[D.pairRead[i]].longEditDistance = p.hOut[i];
+			D.nPairs = 0;
+		};
 		if (P->long_pass) {
 			for (uint64_t r = 0; r < n; r++) { glue[r].longSeedBegin = nLongSeeds; nLongSeeds += glue[r].longSeeds.size(); maxReadLen = std::max<uint64_t>(maxReadLen, R->offsets[r + 1] - R->offsets[r]); }
 			if (nLongSeeds >= 0xffffffffull) throw std::runtime_error("batch too large for the whole-read pass");
@@ -1187,6 +1282,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				const uint64_t traceBudget = groupTraceBeginPtr[g + 1] - groupTraceBeginPtr[g];
 				launchLongInit(q, dLongJobs + r0, (uint32_t)nG, dLongState + r0);
 				uint32_t lastWork = 0xffffffffu;
+
 				for (int round = 0; round < 4096; round++) {
 					HIP_CHECK(hipMemsetAsync(cursor, 0, 3 * sizeof(unsigned long long), q));   // [0] work count, [1] round trace cursor, [2] next work slot
 					// tail rounds: once fewer than a quarter of the reads are still active the chip is mostly idle, so the
@@ -1532,70 +1628,11 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				if (hLongResults[r].status == 3) throw std::runtime_error("whole-read pass: more than 32 alignments for one read");
 				if (hLongResults[r].status == 4) throw std::runtime_error("whole-read pass: trace cell pool overflow (raise GC_LONG_CELLS_PER_BASE)");
 			}
-			// the reference re-sorts its alignment list by alignmentStart after every accepted alignment
-			// (src/GraphAligner.h:183); replaying that on the acceptance-ordered list gives its final order. Then the
-			// GreedyLength selection (src/Aligner.cpp:636-639, src/AlignmentSelection.cpp:12-50) with the same unstable sort.
-			pool.run(n, [&](size_t r, size_t) {
-				ReadGlue& gl = glue[r];
-				for (uint32_t a = 0; a < hLongResults[r].nAlignments; a++) {
-					gl.longAlns.push_back(hLongAlns[r * maxAlignments + a]);
-					std::sort(gl.longAlns.begin(), gl.longAlns.end(), [](const LongAln& l, const LongAln& rr) { return l.start < rr.start; });
-				}
-				struct Item { uint32_t start, end, score, index; };
-				std::vector<Item> sorted;
-				for (uint32_t a = 0; a < gl.longAlns.size(); a++) sorted.push_back(Item { gl.longAlns[a].start, gl.longAlns[a].end, gl.longAlns[a].score, a });
-				std::sort(sorted.begin(), sorted.end(), [](const Item& l, const Item& rr) {
-					if ((l.end - l.start) > (rr.end - rr.start)) return true;
-					if ((rr.end - rr.start) > (l.end - l.start)) return false;
-					return l.score < rr.score;
-				});
-				auto incompatible = [](const Item& l, const Item& rr) {
-					float minOverlapLen = std::min(l.end - l.start, rr.end - rr.start) * 0.05f;
-					size_t ls = l.start, le = l.end, rs = rr.start, re = rr.end;
-					if (ls > rs) { std::swap(ls, rs); std::swap(le, re); }
-					int overlap = 0;
-					if (le > rs) overlap = (int)(le - rs);
-					return overlap > minOverlapLen;
-				};
-				std::vector<Item> kept;
-				for (const Item& it : sorted) {
-					bool ok = true;
-					for (const Item& k : kept) if (incompatible(it, k)) { ok = false; break; }
-					if (ok) { kept.push_back(it); gl.longSelected.push_back(it.index); }
-				}
-			});
-			// edit distance of the best whole-read alignment's path against the read (edlibAlign at src/Aligner.cpp:645)
-			if (P->edit_distances) {
-				PathSeqJob* hJobsPS = st->hEdLongJobs.reserve<PathSeqJob>(n);
-				EdPair* hPairs = st->hEdLongPairs.reserve<EdPair>(n);
-				int64_t* hOut = st->hEdLongOut.reserve<int64_t>(n);
-				uint64_t nLetters = 0;
-				uint32_t nPairs = 0;
-				std::vector<uint32_t> pairRead;
-				for (uint64_t r = 0; r < n; r++) {
-					const ReadGlue& gl = glue[r];
-					if (gl.longSelected.empty()) { hJobsPS[r] = PathSeqJob { 0, nLetters, 0, 0, 0, 0 }; continue; }
-					const LongAln& al = gl.longAlns[gl.longSelected[0]];
-					uint32_t len = (uint32_t)(R->offsets[r + 1] - R->offsets[r]);
-					uint32_t cap = 2 * al.traceLen + 256;
-					hJobsPS[r] = PathSeqJob { al.traceOff, nLetters, al.traceLen, cap, 0, 0 };
-					// the alignment itself bounds the distance: its edits plus the unaligned read ends
-					hPairs[nPairs++] = EdPair { nLetters, 0, (uint32_t)r, (uint32_t)r, al.score + al.start + (len - std::min(len, al.end)) + 8 };
-					pairRead.push_back((uint32_t)r);
-					nLetters += cap;
-				}
-				PathSeqJob* dJobsPS = st->edLongJobs.reserve<PathSeqJob>(n);
-				char* dLetters = st->edLongLetters.reserve<char>(nLetters);
-				uint32_t* dLettersLen = st->edLongLettersLen.reserve<uint32_t>(n);
-				EdPair* dPairs = st->edLongPairs.reserve<EdPair>(n);
-				int64_t* dOut = st->edLongOut.reserve<int64_t>(n);
-				hipStream_t lq = st->longStream;
-				if (n) HIP_CHECK(hipMemcpyAsync(dJobsPS, hJobsPS, n * sizeof(PathSeqJob), hipMemcpyHostToDevice, lq));
-				launchLongPathSeq(lq, G->dev, dJobsPS, (uint32_t)n, dLongCells, dLetters, dLettersLen);
-				auto readLenOf = [R](uint32_t r) { return (uint32_t)(R->offsets[r + 1] - R->offsets[r]); };
-				launchEditDistances(st->edLongRun, lq, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen, readLenOf);
-				finishEditDistances(st->edLongRun, lq, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen);
-				for (uint32_t i = 0; i < nPairs; i++) glue[pairRead[i]].longEditDistance = hOut[i];
+			{
+				std::vector<uint32_t> all(n);
+				for (uint64_t r = 0; r < n; r++) all[r] = (uint32_t)r;
+				decideLongReads(all, 0, st->longStream, [&](uint32_t r) { return hLongResults[r].nAlignments; });
+				finishLongDecision(0);
 			}
 			if (P->keep_traces) {
 				longCells.resize(hLongSmall[0]);
