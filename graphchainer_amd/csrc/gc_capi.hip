@@ -198,7 +198,10 @@ struct gc_reads {
 	// exact-match bit vectors of the forward strand [A,C,G,T][words] and the per-read records of the NW kernel (rows = read bases)
 	uint64_t* devEqMasks = nullptr;
 	EdRead* devEdReads = nullptr;
-	~gc_reads() { if (devBases) (void)hipFree(devBases); if (devOffsets) (void)hipFree(devOffsets); if (devMasks) (void)hipFree(devMasks); if (devEqMasks) (void)hipFree(devEqMasks); if (devEdReads) (void)hipFree(devEdReads); }
+	uint32_t* devChunkRead = nullptr;   // read containing the first base of every 64-base chunk of the concatenated forward bases
+	uint64_t* devPacked = nullptr;      // the forward bases, 2 bits each, big-endian inside 64-bit words (for the seed kernel's k-mers)
+	uint64_t* devInvalid = nullptr;     // one bit per forward base: not A, C, G or T (same big-endian convention)
+	~gc_reads() { if (devBases) (void)hipFree(devBases); if (devOffsets) (void)hipFree(devOffsets); if (devMasks) (void)hipFree(devMasks); if (devEqMasks) (void)hipFree(devEqMasks); if (devEdReads) (void)hipFree(devEdReads); if (devChunkRead) (void)hipFree(devChunkRead); if (devPacked) (void)hipFree(devPacked); if (devInvalid) (void)hipFree(devInvalid); }
 };
 
 struct StitchedPath { std::vector<uint32_t> nodes; uint32_t firstOffset = 0, lastOffset = 0; uint64_t cells = 0; };
@@ -869,8 +872,14 @@ int gc_seeder_create(const gc_graph* g, int32_t k, int32_t w, double keepFractio
 		}
 		uint64_t* dTable = uploadVector(table);
 		S->allocations.push_back(dTable);
-		std::vector<uint32_t> filter((1u << 28) / 32, 0);   // see filterBit in gc_kernels.hip
-		for (size_t i = 0; i < nKeys; i++) { uint32_t fb = (uint32_t)((S->host.kmers[i] * 0xD6E8FEB86659FD93ull) >> 36); filter[fb >> 5] |= 1u << (fb & 31); }
+		// membership filter in front of the table (see filterBit in gc_kernels.hip): ~8 bits per key, at most 2^28 bits; on cfg2 (5 M keys)
+		// 2^25 bits = 4 MB, which stays in every XCD's L2 (a 32 MB filter missed to the fabric on every probe)
+		uint32_t filterBits = 20;
+		while (filterBits < 28 && (1ull << filterBits) < 8 * nKeys) filterBits++;
+		if (const char* env = getenv("GC_SEED_FILTER_BITS")) filterBits = (uint32_t)std::max(10, std::min(30, atoi(env)));
+		std::vector<uint32_t> filter((1ull << filterBits) / 32, 0);
+		for (size_t i = 0; i < nKeys; i++) { uint32_t fb = (uint32_t)((S->host.kmers[i] * 0xD6E8FEB86659FD93ull) >> (64 - filterBits)); filter[fb >> 5] |= 1u << (fb & 31); }
+		S->dev.filterShift = 64 - filterBits;
 		uint32_t* dFilter = uploadVector(filter);
 		S->allocations.push_back(dFilter);
 		S->dev.filter = dFilter;
@@ -985,6 +994,24 @@ int gc_reads_upload(const char* bases, const uint64_t* offsets, uint64_t n, gc_r
 			for (uint64_t r = 0; r < n; r++) buildEqMasks(bases + offsets[r], edReads[r].len, edReads[r].words, eqMasks.data() + edReads[r].eqOff);
 			HIP_CHECK(hipMalloc((void**)&R->devEqMasks, std::max<size_t>(eqWords, 1) * sizeof(uint64_t)));
 			if (eqWords) HIP_CHECK(hipMemcpy(R->devEqMasks, eqMasks.data(), eqWords * sizeof(uint64_t), hipMemcpyHostToDevice));
+			{
+				std::vector<uint32_t> chunkRead((R->totalBases >> 6) + 1, 0);
+				uint64_t r = 0;
+				for (uint64_t c = 0; c < chunkRead.size(); c++) { uint64_t p = c << 6; while (r + 1 < n && offsets[r + 1] <= p) r++; chunkRead[c] = (uint32_t)r; }
+				std::vector<uint64_t> packed((R->totalBases >> 5) + 1, 0), invalidBits((R->totalBases >> 6) + 1, 0);
+				for (uint64_t p = 0; p < R->totalBases; p++) {
+					int c = -1;
+					switch (bases[p]) { case 'a': case 'A': c = 0; break; case 'c': case 'C': c = 1; break; case 'g': case 'G': c = 2; break; case 't': case 'T': c = 3; break; }
+					if (c < 0) invalidBits[p >> 6] |= 1ull << (63 - (p & 63));
+					else packed[p >> 5] |= (uint64_t)c << (2 * (31 - (p & 31)));
+				}
+				HIP_CHECK(hipMalloc((void**)&R->devPacked, packed.size() * sizeof(uint64_t)));
+				HIP_CHECK(hipMemcpy(R->devPacked, packed.data(), packed.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+				HIP_CHECK(hipMalloc((void**)&R->devInvalid, invalidBits.size() * sizeof(uint64_t)));
+				HIP_CHECK(hipMemcpy(R->devInvalid, invalidBits.data(), invalidBits.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+				HIP_CHECK(hipMalloc((void**)&R->devChunkRead, chunkRead.size() * sizeof(uint32_t)));
+				HIP_CHECK(hipMemcpy(R->devChunkRead, chunkRead.data(), chunkRead.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+			}
 			HIP_CHECK(hipMalloc((void**)&R->devEdReads, std::max<size_t>(n, 1) * sizeof(EdRead)));
 			if (n) HIP_CHECK(hipMemcpy(R->devEdReads, edReads.data(), n * sizeof(EdRead), hipMemcpyHostToDevice));
 		}
@@ -1047,7 +1074,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		HIP_CHECK(hipMemsetAsync(dCursors, 0, 8 * sizeof(unsigned long long), stream));
 		HIP_CHECK(hipMemsetAsync(dCounters, 0, 8 * sizeof(unsigned long long), stream));
 		mark();   // 0
-		launchSeedLookup(stream, S->dev, R->devBases, R->devOffsets, (uint32_t)n, (uint64_t*)dCursors, dReadMatchOff, dReadMatchCount, dMatches, R->totalBases, dTmp, R->totalBases);
+		launchSeedLookup(stream, S->dev, R->devBases, R->devOffsets, (uint32_t)n, (uint64_t*)dCursors, dReadMatchOff, dReadMatchCount, dMatches, R->totalBases, dTmp, R->totalBases, R->devChunkRead, R->devPacked, R->devInvalid);
 		mark();   // 1
 		if (n) HIP_CHECK(hipMemcpyAsync(readMatchOff, dReadMatchOff, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		if (n) HIP_CHECK(hipMemcpyAsync(readMatchCount, dReadMatchCount, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

@@ -34,12 +34,12 @@ __device__ __forceinline__ uint32_t hashKmer(uint64_t kmer)
 
 // 9 of 10 read k-mers are not graph minimizers; a probe of the 0.1-0.5 GB table is a random HBM access each, a bit of the
 // 32 MB filter is a cache hit. A clear bit proves the k-mer is not a key (a set bit proves nothing: ~2 % false positives).
-__device__ __forceinline__ uint32_t filterBit(uint64_t kmer) { return (uint32_t)((kmer * 0xD6E8FEB86659FD93ull) >> 36); }
+__device__ __forceinline__ uint32_t filterBit(uint64_t kmer, uint32_t shift) { return (uint32_t)((kmer * 0xD6E8FEB86659FD93ull) >> shift); }
 
 // returns key index or 0xffffffff. Open addressing, linear probing; slot = {kmer:32, index:32}.
 __device__ __forceinline__ uint32_t lookupKmer(const SeedIndex& idx, uint64_t kmer)
 {
-	const uint32_t fb = filterBit(kmer);
+	const uint32_t fb = filterBit(kmer, idx.filterShift);
 	if (!((idx.filter[fb >> 5] >> (fb & 31)) & 1u)) return 0xffffffffu;
 	uint32_t h = hashKmer(kmer) & idx.tableMask;
 	while (true) {
@@ -53,27 +53,30 @@ __device__ __forceinline__ uint32_t lookupKmer(const SeedIndex& idx, uint64_t km
 
 // K1a: one thread per read base. For the k-mer that ends at the base: the reference's thinning rule, the index probe and the
 // frequency cut; writes key index + 1 (0 = nothing to emit) into tmp[global position].
-__global__ void __launch_bounds__(256) k_seed_probe(SeedIndex idx, const char* __restrict__ bases, const uint64_t* __restrict__ readOff, uint32_t nReads, uint64_t totalBases, uint32_t* __restrict__ tmp)
+__global__ void __launch_bounds__(256) k_seed_probe(SeedIndex idx, const char* __restrict__ bases, const uint64_t* __restrict__ readOff, const uint32_t* __restrict__ chunkRead, const uint64_t* __restrict__ packed, const uint64_t* __restrict__ invalid, uint32_t nReads, uint64_t totalBases, uint32_t* __restrict__ tmp)
 {
 	const int k = idx.k;
 	const int realWindow = idx.w - idx.k + 1;
 	const uint64_t mask = ~(~0ull << (2 * k));
 	for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < totalBases; p += (uint64_t)gridDim.x * blockDim.x) {
-		// the read this base belongs to: last r with readOff[r] <= p
-		uint32_t lo = 0, hi = nReads;
-		while (hi - lo > 1) { uint32_t mid = (lo + hi) / 2; if (readOff[mid] <= p) lo = mid; else hi = mid; }
+		// the read this base belongs to: last r with readOff[r] <= p (chunkRead: the read of the first base of every 64-base chunk)
+		uint32_t lo = chunkRead[p >> 6];
+		while (lo + 1 < nReads && readOff[lo + 1] <= p) lo++;
 		const char* seq = bases + readOff[lo];
 		const int pos = (int)(p - readOff[lo]);
 		uint32_t found = 0;
 		if (pos >= k - 1) {
-			// k-mer ending at pos
-			uint64_t kmer = 0;
-			bool valid = true;
-			for (int i = pos - k + 1; i <= pos; i++) {
-				int c = baseCode((uint8_t)seq[i]);
-				if (c < 0) { valid = false; break; }
-				kmer = (kmer << 2) | (uint64_t)c;
-			}
+			// k-mer ending at pos, from the 2-bit big-endian packing of the concatenated reads (base j in bits 63-2(j%32), 62-2(j%32)
+			// of word j/32): the k bases are one bit field of a two-word window; a second bit vector marks the non-ACGT bases
+			const uint64_t w = p >> 5;
+			const uint64_t lo64 = packed[w], hi64 = w ? packed[w - 1] : 0ull;
+			const uint32_t sh = 2u * (31u - (uint32_t)(p & 31));
+			const uint64_t kmer = (sh ? ((lo64 >> sh) | (hi64 << (64 - sh))) : lo64) & mask;
+			const uint64_t iw = p >> 6;
+			const uint64_t ilo = invalid[iw], ihi = iw ? invalid[iw - 1] : 0ull;
+			const uint32_t ish = 63u - (uint32_t)(p & 63);   // same big-endian convention: base j in bit 63-(j%64)
+			const uint64_t window = ish ? ((ilo >> ish) | (ihi << (64 - ish))) : ilo;
+			const bool valid = (window & ((1ull << k) - 1)) == 0;
 			if (valid) {
 				// thinning (:91): inside a streak of identical consecutive k-mers only every realWindow-th is emitted.
 				// Consecutive k-mers are identical only in a homopolymer; walk back to the streak start.
@@ -85,7 +88,7 @@ __global__ void __launch_bounds__(256) k_seed_probe(SeedIndex idx, const char* _
 				}
 				bool emit = ((pos - streakStart) % realWindow) == 0;
 				if (emit) {
-					uint32_t key = lookupKmer(idx, kmer & mask);
+					uint32_t key = lookupKmer(idx, kmer);
 					if (key != 0xffffffffu) {
 						uint32_t count = (uint32_t)(idx.startPos[key + 1] - idx.startPos[key]);
 						if (count < idx.maxCount) found = key + 1;
@@ -968,12 +971,12 @@ __global__ void __launch_bounds__(256) k_long_finish(uint32_t nReads, const Long
 // =====================================================================================================
 
 void launchSeedLookup(hipStream_t stream, const SeedIndex& idx, const char* bases, const uint64_t* readOff, uint32_t nReads,
-	uint64_t* matchCursor, uint32_t* readMatchOff, uint32_t* readMatchCount, uint2* matches, uint64_t matchCapacity, uint32_t* tmp, uint64_t totalBases)
+	uint64_t* matchCursor, uint32_t* readMatchOff, uint32_t* readMatchCount, uint2* matches, uint64_t matchCapacity, uint32_t* tmp, uint64_t totalBases, const uint32_t* chunkRead, const uint64_t* packed, const uint64_t* invalid)
 {
 	if (nReads == 0) return;
 	uint64_t probeBlocks = (totalBases + 255) / 256;
 	if (probeBlocks > 65536) probeBlocks = 65536;
-	if (probeBlocks) hipLaunchKernelGGL(k_seed_probe, dim3((uint32_t)probeBlocks), dim3(256), 0, stream, idx, bases, readOff, nReads, totalBases, tmp);
+	if (probeBlocks) hipLaunchKernelGGL(k_seed_probe, dim3((uint32_t)probeBlocks), dim3(256), 0, stream, idx, bases, readOff, chunkRead, packed, invalid, nReads, totalBases, tmp);
 	uint32_t blocks = nReads < 16384 ? nReads : 16384;
 	hipLaunchKernelGGL(k_seed_compact, dim3(blocks), dim3(64), 0, stream, readOff, nReads, tmp, matchCursor, readMatchOff, readMatchCount, matches, matchCapacity);
 }

@@ -7,7 +7,8 @@ namespace gcdev {
 struct SeedIndex {   // minimizer index in HBM (reference: MinimizerSeeder buckets, src/MinimizerSeeder.h:16-30)
 	const uint64_t* table;      // open addressing: (kmer << 32) | keyIndex, empty = all ones
 	uint32_t tableMask;
-	const uint32_t* filter;     // 2^28-bit membership filter over the keys (32 MB: cache resident): bit filterBit(kmer) is set for every key
+	const uint32_t* filter;     // 2^filterBits-bit membership filter over the keys: bit filterBit(kmer) is set for every key
+	uint32_t filterShift;       // 64 - filterBits
 	const uint64_t* startPos;   // [nKeys+1]
 	uint32_t nKeys;
 	uint32_t maxCount;
@@ -111,7 +112,7 @@ struct LongWorkResult { uint64_t traceOff; uint32_t traceLen, status; int32_t sc
 
 // ---- launchers (all asynchronous on `stream`) ------------------------------------------------------
 void launchSeedLookup(hipStream_t stream, const SeedIndex& idx, const char* bases, const uint64_t* readOff, uint32_t nReads,
-	uint64_t* matchCursor, uint32_t* readMatchOff, uint32_t* readMatchCount, uint2* matches, uint64_t matchCapacity, uint32_t* tmp, uint64_t totalBases);
+	uint64_t* matchCursor, uint32_t* readMatchOff, uint32_t* readMatchCount, uint2* matches, uint64_t matchCapacity, uint32_t* tmp, uint64_t totalBases, const uint32_t* chunkRead, const uint64_t* packed, const uint64_t* invalid);
 
 uint64_t extendSlabBytes(const ExtendConfig& cfg);
 uint32_t extendGridLanes(uint32_t nWork);
