@@ -62,7 +62,12 @@ void gc_params_default(gc_params* p);
 int gc_graph_create_from_gfa(const char* gfa_path, gc_graph** out);
 
 /* Same, from arrays the existing C++ host already holds (src/AlignmentGraph.h:145-172): for a host that
- * keeps its own AlignmentGraph. Adjacency is CSR in the reference's neighbour order. */
+ * keeps its own AlignmentGraph. Adjacency is CSR in the reference's neighbour order.
+ * Caveat: the minimizer index built on such a graph enumerates bigraph nodes in ascending id, whereas the reference
+ * enumerates its nodeLookup hash map (src/MinimizerSeeder.cpp:299-365); the two orders can differ, and with them the order of
+ * a k-mer's position list and so tie-breaks among equally good seeds. gc_graph_create_from_gfa reproduces the reference's
+ * order (same container, same insertion sequence) and is the path the parity tests cover; node names are also only known
+ * there (the output encoders print numeric ids otherwise). */
 typedef struct gc_graph_desc {
 	uint64_t n_nodes;                 /* split nodes */
 	uint64_t first_ambiguous;         /* nodes >= this index use ambiguous_seq */
