@@ -22,6 +22,7 @@ EXPORTED_SYMBOLS = [
     "gc_graph_size_bp", "gc_graph_array", "gc_seeder_create", "gc_seeder_destroy", "gc_seeder_array",
     "gc_stream_create", "gc_stream_destroy", "gc_reads_upload", "gc_reads_destroy", "gc_align_batch",
     "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_edit_distance", "gc_format_gaf", "gc_format_json", "gc_format_gam",
+    "gc_index_build", "gc_index_save", "gc_index_load", "gc_index_check",
 ]
 
 
@@ -86,6 +87,10 @@ def load_library():
     lib.gc_params_default.argtypes = [_P(GcParams)]
     lib.gc_free.argtypes = [C.c_void_p]
     lib.gc_set_device.argtypes = [C.c_int]
+    lib.gc_index_build.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_double, C.c_char_p]
+    lib.gc_index_save.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
+    lib.gc_index_load.argtypes = [C.c_char_p, _P(C.c_void_p), _P(C.c_void_p)]
+    lib.gc_index_check.argtypes = [C.c_char_p, _P(C.c_uint64)]
     _lib = lib
     return lib
 
@@ -131,12 +136,43 @@ def _fetch_array(fn, handle, name):
     return out
 
 
+def build_index_cache(gfa_path, cache_path, minimizer_length=15, window_size=20, keep_least_frequent_fraction=1 - 0.001):
+    """Builds graph + MPC index (+ minimizer index unless minimizer_length is 0) on the host and writes the cache file;
+    needs no GPU (the reference's saveMPC, src/AlignmentGraph.h:96, is an empty stub)."""
+    _check(load_library().gc_index_build(os.fsencode(gfa_path), minimizer_length, window_size, keep_least_frequent_fraction, os.fsencode(cache_path)))
+
+
+def save_index_cache(graph, seeder, cache_path):
+    _check(load_library().gc_index_save(graph.handle, seeder.handle if seeder is not None else None, os.fsencode(cache_path)))
+
+
+def check_index_cache(cache_path):
+    """Verifies a cache file on the host and returns what it holds; raises RuntimeError for a damaged or foreign file."""
+    info = (C.c_uint64 * 8)()
+    _check(load_library().gc_index_check(os.fsencode(cache_path), info))
+    keys = ["version", "nodes", "bp", "has_seeder", "k", "w", "kmers", "positions"]
+    return {k: int(v) for k, v in zip(keys, info)}
+
+
+def load_index_cache(cache_path):
+    """-> (AlignmentGraph, MinimizerSeeder or None) uploaded to the current device from a cache file."""
+    lib = load_library()
+    g, s = C.c_void_p(), C.c_void_p()
+    _check(lib.gc_index_load(os.fsencode(cache_path), C.byref(g), C.byref(s)))
+    graph = AlignmentGraph(None, _handle=g)
+    seeder = MinimizerSeeder(graph, _handle=s) if s else None
+    return graph, seeder
+
+
 class AlignmentGraph:
     """Split-node DAG + MPC index resident in HBM (reference: AlignmentGraph, src/AlignmentGraph.h)."""
 
-    def __init__(self, gfa_path):
+    def __init__(self, gfa_path, _handle=None):
         self.lib = load_library()
         self.handle = C.c_void_p()
+        if _handle is not None:
+            self.handle = _handle
+            return
         _check(self.lib.gc_graph_create_from_gfa(os.fsencode(gfa_path), C.byref(self.handle)))
 
     def NodeSize(self):
@@ -163,10 +199,13 @@ class AlignmentGraph:
 class MinimizerSeeder:
     """reference: MinimizerSeeder(graph, k, w, threads, 1 - discardMostNumerousFraction), src/Aligner.cpp:1162"""
 
-    def __init__(self, graph, minimizer_length=15, window_size=20, keep_least_frequent_fraction=1 - 0.001):
+    def __init__(self, graph, minimizer_length=15, window_size=20, keep_least_frequent_fraction=1 - 0.001, _handle=None):
         self.lib = load_library()
         self.graph = graph
         self.handle = C.c_void_p()
+        if _handle is not None:
+            self.handle = _handle
+            return
         _check(self.lib.gc_seeder_create(graph.handle, minimizer_length, window_size, keep_least_frequent_fraction, C.byref(self.handle)))
 
     def array(self, name):

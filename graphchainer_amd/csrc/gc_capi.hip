@@ -6,6 +6,7 @@
 #include "host/gc_graph.hpp"
 #include "host/gc_glue.hpp"
 #include "host/gc_output.hpp"
+#include "host/gc_index_cache.hpp"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
@@ -852,50 +853,138 @@ int gc_graph_array(const gc_graph* G, const char* name, int64_t** out, uint64_t*
 // ---- seeder -------------------------------------------------------------------------------------------
 static inline uint32_t hostHashKmer(uint64_t kmer) { kmer *= 0x9E3779B97F4A7C15ull; return (uint32_t)(kmer >> 32); }
 
+// hash table, membership filter and start offsets of a built minimizer index -> HBM
+static void uploadSeeder(gc_seeder* S)
+{
+	size_t nKeys = S->host.kmers.size();
+	size_t tableSize = 16;
+	while (tableSize < 2 * nKeys) tableSize <<= 1;
+	std::vector<uint64_t> table(tableSize, ~0ull);
+	for (size_t i = 0; i < nKeys; i++) {
+		uint32_t hsh = hostHashKmer(S->host.kmers[i]) & (uint32_t)(tableSize - 1);
+		while ((uint32_t)(table[hsh] >> 32) != 0xffffffffu) hsh = (hsh + 1) & (uint32_t)(tableSize - 1);
+		table[hsh] = (S->host.kmers[i] << 32) | (uint64_t)i;
+	}
+	uint64_t* dTable = uploadVector(table);
+	S->allocations.push_back(dTable);
+	// membership filter in front of the table (see filterBit in gc_kernels.hip): ~8 bits per key, at most 2^28 bits; on cfg2 (5 M keys)
+	// 2^25 bits = 4 MB, which stays in every XCD's L2 (a 32 MB filter missed to the fabric on every probe)
+	uint32_t filterBits = 20;
+	while (filterBits < 28 && (1ull << filterBits) < 8 * nKeys) filterBits++;
+	if (const char* env = getenv("GC_SEED_FILTER_BITS")) filterBits = (uint32_t)std::max(10, std::min(30, atoi(env)));
+	std::vector<uint32_t> filter((1ull << filterBits) / 32, 0);
+	for (size_t i = 0; i < nKeys; i++) { uint32_t fb = (uint32_t)((S->host.kmers[i] * 0xD6E8FEB86659FD93ull) >> (64 - filterBits)); filter[fb >> 5] |= 1u << (fb & 31); }
+	S->dev.filterShift = 64 - filterBits;
+	uint32_t* dFilter = uploadVector(filter);
+	S->allocations.push_back(dFilter);
+	S->dev.filter = dFilter;
+	uint64_t* dStart = uploadVector(S->host.startPos);
+	S->allocations.push_back(dStart);
+	S->dev.table = dTable;
+	S->dev.tableMask = (uint32_t)(tableSize - 1);
+	S->dev.startPos = dStart;
+	S->dev.nKeys = (uint32_t)nKeys;
+	S->dev.maxCount = (uint32_t)std::min<size_t>(S->host.maxCount, 0xffffffffu);
+	S->dev.k = (int32_t)S->host.k;
+	S->dev.w = (int32_t)S->host.w;
+}
+
+static bool seederShapeOk(int64_t k, int64_t w) { return k >= 1 && k <= 15 && w >= k; }
+
 int gc_seeder_create(const gc_graph* g, int32_t k, int32_t w, double keepFraction, gc_seeder** out)
 {
 	if (!g || !out) return fail(GC_ERR_INVALID, "null argument");
-	if (k < 1 || k > 15 || w < k) return fail(GC_ERR_INVALID, "supported minimizer length is 1..15 (32-bit key slots) with w >= k");
+	if (!seederShapeOk(k, w)) return fail(GC_ERR_INVALID, "supported minimizer length is 1..15 (32-bit key slots) with w >= k");
 	*out = nullptr;
 	gc_seeder* S = new gc_seeder();
 	int rc = guarded([&]() {
 		requireDevice();
 		S->host = gc::MinimizerIndex::Build(g->host, (size_t)k, (size_t)w, keepFraction);
-		size_t nKeys = S->host.kmers.size();
-		size_t tableSize = 16;
-		while (tableSize < 2 * nKeys) tableSize <<= 1;
-		std::vector<uint64_t> table(tableSize, ~0ull);
-		for (size_t i = 0; i < nKeys; i++) {
-			uint32_t hsh = hostHashKmer(S->host.kmers[i]) & (uint32_t)(tableSize - 1);
-			while ((uint32_t)(table[hsh] >> 32) != 0xffffffffu) hsh = (hsh + 1) & (uint32_t)(tableSize - 1);
-			table[hsh] = (S->host.kmers[i] << 32) | (uint64_t)i;
-		}
-		uint64_t* dTable = uploadVector(table);
-		S->allocations.push_back(dTable);
-		// membership filter in front of the table (see filterBit in gc_kernels.hip): ~8 bits per key, at most 2^28 bits; on cfg2 (5 M keys)
-		// 2^25 bits = 4 MB, which stays in every XCD's L2 (a 32 MB filter missed to the fabric on every probe)
-		uint32_t filterBits = 20;
-		while (filterBits < 28 && (1ull << filterBits) < 8 * nKeys) filterBits++;
-		if (const char* env = getenv("GC_SEED_FILTER_BITS")) filterBits = (uint32_t)std::max(10, std::min(30, atoi(env)));
-		std::vector<uint32_t> filter((1ull << filterBits) / 32, 0);
-		for (size_t i = 0; i < nKeys; i++) { uint32_t fb = (uint32_t)((S->host.kmers[i] * 0xD6E8FEB86659FD93ull) >> (64 - filterBits)); filter[fb >> 5] |= 1u << (fb & 31); }
-		S->dev.filterShift = 64 - filterBits;
-		uint32_t* dFilter = uploadVector(filter);
-		S->allocations.push_back(dFilter);
-		S->dev.filter = dFilter;
-		uint64_t* dStart = uploadVector(S->host.startPos);
-		S->allocations.push_back(dStart);
-		S->dev.table = dTable;
-		S->dev.tableMask = (uint32_t)(tableSize - 1);
-		S->dev.startPos = dStart;
-		S->dev.nKeys = (uint32_t)nKeys;
-		S->dev.maxCount = (uint32_t)std::min<size_t>(S->host.maxCount, 0xffffffffu);
-		S->dev.k = k;
-		S->dev.w = w;
+		uploadSeeder(S);
 		return (int)GC_OK;
 	});
 	if (rc != GC_OK) { delete S; return rc; }
 	*out = S;
+	return GC_OK;
+}
+
+// ---- index cache (host/gc_index_cache.hpp) -----------------------------------------------
+int gc_index_build(const char* gfa_path, int32_t k, int32_t w, double keepFraction, const char* cache_path)
+{
+	if (!gfa_path || !cache_path) return fail(GC_ERR_INVALID, "null argument");
+	if (k > 0 && !seederShapeOk(k, w)) return fail(GC_ERR_INVALID, "supported minimizer length is 1..15 (32-bit key slots) with w >= k");
+	try {
+		gc::GfaGraph gfa = gc::GfaGraph::LoadFromFile(gfa_path);
+		gc::AlignmentGraph graph = gc::AlignmentGraph::BuildFromGFA(gfa);
+		graph.buildMPC(true);
+		if (k > 0) {
+			gc::MinimizerIndex idx = gc::MinimizerIndex::Build(graph, (size_t)k, (size_t)w, keepFraction);
+			gc::SaveIndexCache(cache_path, graph, &idx);
+		} else {
+			gc::SaveIndexCache(cache_path, graph, nullptr);
+		}
+	} catch (const std::exception& e) {
+		return fail(GC_ERR_GRAPH, e.what());
+	}
+	return GC_OK;
+}
+
+int gc_index_save(const gc_graph* g, const gc_seeder* s, const char* cache_path)
+{
+	if (!g || !cache_path) return fail(GC_ERR_INVALID, "null argument");
+	try {
+		gc::SaveIndexCache(cache_path, g->host, s ? &s->host : nullptr);
+	} catch (const std::exception& e) {
+		return fail(GC_ERR_GRAPH, e.what());
+	}
+	return GC_OK;
+}
+
+static void fillIndexInfo(const gc::IndexCacheInfo& info, uint64_t* out)
+{
+	if (!out) return;
+	out[0] = gc::INDEX_CACHE_VERSION; out[1] = info.nodes; out[2] = info.bp; out[3] = info.hasSeeder ? 1 : 0;
+	out[4] = info.k; out[5] = info.w; out[6] = info.kmers; out[7] = info.positions;
+}
+
+int gc_index_check(const char* cache_path, uint64_t* info8)
+{
+	if (!cache_path) return fail(GC_ERR_INVALID, "null argument");
+	try {
+		fillIndexInfo(gc::CheckIndexCache(cache_path), info8);
+	} catch (const std::exception& e) {
+		return fail(GC_ERR_GRAPH, e.what());
+	}
+	return GC_OK;
+}
+
+int gc_index_load(const char* cache_path, gc_graph** graph_out, gc_seeder** seeder_out)
+{
+	if (!cache_path || !graph_out) return fail(GC_ERR_INVALID, "null argument");
+	*graph_out = nullptr;
+	if (seeder_out) *seeder_out = nullptr;
+	gc_graph* G = new gc_graph();
+	gc_seeder* S = new gc_seeder();
+	try {
+		requireDevice();
+		gc::IndexCacheInfo info = gc::LoadIndexCache(cache_path, G->host, S->host);
+		uploadGraph(G);
+		if (info.hasSeeder && seeder_out) {
+			if (!seederShapeOk((int64_t)S->host.k, (int64_t)S->host.w)) throw std::runtime_error("index cache holds a minimizer index this library cannot run");
+			uploadSeeder(S);
+		} else {
+			delete S;
+			S = nullptr;
+		}
+	} catch (const DeviceError& e) {
+		delete G; delete S;
+		return fail(GC_ERR_DEVICE, e.what());
+	} catch (const std::exception& e) {
+		delete G; delete S;
+		return fail(GC_ERR_GRAPH, e.what());
+	}
+	*graph_out = G;
+	if (seeder_out) *seeder_out = S;
 	return GC_OK;
 }
 

@@ -79,6 +79,9 @@ public:
 	std::unordered_map<int, std::vector<size_t>> nodeLookup;
 	std::unordered_map<int, size_t> originalNodeSize;
 	std::unordered_map<int, std::string> originalNodeName;
+	// iteration order of nodeLookup as it was when the graph was built; set only on a graph loaded from the index cache
+	// (gc_index_cache.hpp), where re-inserting the keys would not reproduce the order MinimizerIndex::Build follows
+	std::vector<int> nodeLookupOrder;
 	std::vector<size_t> nodeOffset;
 	std::vector<int> nodeIDs;
 	std::vector<std::vector<size_t>> inNeighbors;

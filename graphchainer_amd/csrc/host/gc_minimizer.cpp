@@ -111,11 +111,13 @@ MinimizerIndex MinimizerIndex::Build(const AlignmentGraph& g, size_t k, size_t w
 	}
 	std::vector<std::pair<uint64_t, uint64_t>> arrivals;   // (kmer, packed position) in arrival order
 	std::string sequence;
-	for (const auto& entry : g.nodeLookup) {      // arrival order at -t 1: nodeLookup iteration order (:354-357)
-		int nodeId = entry.first;
+	std::vector<int> idOrder = g.nodeLookupOrder;   // arrival order at -t 1: nodeLookup iteration order (:354-357)
+	if (idOrder.empty()) for (const auto& entry : g.nodeLookup) idOrder.push_back(entry.first);
+	for (int nodeId : idOrder) {
+		const std::vector<size_t>& splitNodes = g.nodeLookup.at(nodeId);
 		sequence.resize(g.originalNodeSize.at(nodeId));
 		size_t at = 0;
-		for (size_t split : entry.second)
+		for (size_t split : splitNodes)
 			for (size_t j = 0; j < g.nodeLength[split]; j++) sequence[at++] = g.NodeSequences(split, j);
 		size_t minStart = nodeMinimizerStart.at(nodeId);
 		forEachWindowMinimizer(sequence, k, w, [&](size_t pos, uint64_t kmer) {

@@ -98,6 +98,23 @@ int gc_seeder_create(const gc_graph* g, int32_t k, int32_t w, double keep_least_
 void gc_seeder_destroy(gc_seeder* s);
 int gc_seeder_array(const gc_seeder* s, const char* name, int64_t** out, uint64_t* count);   /* "kmers","start","positions","maxcount" */
 
+/* ---- index cache --------------------------------------------------------------
+ * The start-up work above (GFA parse, node splitting, topological order, greedy path cover + max-flow shrink, MPC index,
+ * minimizer scan: src/AlignmentGraph.cpp:1267-1391,1465-1495, src/MinimizerSeeder.cpp:299-492) written once to a file and
+ * loaded instead of recomputed. The reference declares saveMPC/loadMPC (src/AlignmentGraph.h:96-97) with empty bodies and
+ * rebuilds everything on every run; these entry points are what those two would bind. The file is checksummed and
+ * versioned; a damaged, truncated or other-version file is refused (GC_ERR_GRAPH), never used.
+ *   gc_index_build  host only, no HIP device needed: builds graph + MPC (+ minimizer index when k > 0) and writes the cache.
+ *   gc_index_save   writes the cache from objects already built (seeder may be NULL).
+ *   gc_index_load   reads the cache and uploads to the current device; *seeder_out is NULL when the file holds no
+ *                   minimizer index (seeder_out may itself be NULL to skip it). Results are identical to the built objects'.
+ *   gc_index_check  host only: verifies the file (checksum, bounds, re-serialises to the same bytes) and reports
+ *                   info8 = {version, split nodes, bp, has seeder, k, w, distinct k-mers, positions} (info8 may be NULL). */
+int gc_index_build(const char* gfa_path, int32_t k, int32_t w, double keep_least_frequent_fraction, const char* cache_path);
+int gc_index_save(const gc_graph* g, const gc_seeder* s, const char* cache_path);
+int gc_index_load(const char* cache_path, gc_graph** graph_out, gc_seeder** seeder_out);
+int gc_index_check(const char* cache_path, uint64_t* info8);
+
 /* ---- streams and read batches --------------------------------------------------------------------- */
 int gc_stream_create(gc_stream** out);
 void gc_stream_destroy(gc_stream* st);

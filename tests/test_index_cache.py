@@ -1,0 +1,122 @@
+"""Index cache: host-side build / verify on CPU, and load parity on the GPU.
+
+The reference has no cache (saveMPC/loadMPC are empty, src/AlignmentGraph.h:96-97), so the property tested is that a graph
+and minimizer index loaded from the file are indistinguishable from the ones built from the GFA: same arrays, same
+alignments, and the same minimizer index when it is rebuilt on the loaded graph."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+GRAPH_ARRAYS = ["nodeLength", "nodeOffset", "nodeIDs", "reverse", "componentNumber", "chainNumber", "chainApproxPos",
+                "component_map", "out_off", "out_adj", "in_off", "in_adj", "mpc_width"]
+
+
+@pytest.fixture(scope="module")
+def gca():
+    import graphchainer_amd as gca
+    if not os.path.exists(gca.api.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    gca.load_library()
+    return gca
+
+
+@pytest.mark.parametrize("gfa", ["ref_test_graph.gfa", "syn20k.gfa"])
+def test_build_is_deterministic_and_verifies(gca, tmp_path, gfa):
+    a, b = str(tmp_path / "a.gcidx"), str(tmp_path / "b.gcidx")
+    gca.api.build_index_cache(os.path.join(GOLD, gfa), a, 15, 20)
+    gca.api.build_index_cache(os.path.join(GOLD, gfa), b, 15, 20)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    info = gca.api.check_index_cache(a)
+    assert info["version"] == 1 and info["has_seeder"] == 1 and (info["k"], info["w"]) == (15, 20)
+    assert info["nodes"] > 0 and info["bp"] > 0 and info["positions"] >= info["kmers"] > 0
+    # against the oracle's own graph build (same host code, separate library): node and base-pair counts
+    from oracle import Oracle
+    lengths = Oracle(os.path.join(GOLD, gfa)).graph_array("nodeLength")
+    assert info["nodes"] == len(lengths) and info["bp"] == int(np.sum(lengths))
+
+
+def test_graph_only_cache(gca, tmp_path):
+    path = str(tmp_path / "g.gcidx")
+    gca.api.build_index_cache(os.path.join(GOLD, "ref_test_graph.gfa"), path, 0, 0)
+    info = gca.api.check_index_cache(path)
+    assert info["has_seeder"] == 0 and info["kmers"] == 0
+
+
+def test_damaged_files_are_refused(gca, tmp_path):
+    path = str(tmp_path / "a.gcidx")
+    gca.api.build_index_cache(os.path.join(GOLD, "ref_test_graph.gfa"), path, 15, 20)
+    data = bytearray(open(path, "rb").read())
+    cases = {
+        "flip": bytes(data[:len(data) // 2]) + bytes([data[len(data) // 2] ^ 0x40]) + bytes(data[len(data) // 2 + 1:]),
+        "truncated": bytes(data[:-9]),
+        "magic": b"NOTCACHE" + bytes(data[8:]),
+        "short": b"GCAMDIDX",
+        "version": bytes(data[:8]) + bytes([data[8] + 1]) + bytes(data[9:]),
+    }
+    for name, blob in cases.items():
+        bad = str(tmp_path / (name + ".gcidx"))
+        open(bad, "wb").write(blob)
+        with pytest.raises(RuntimeError):
+            gca.api.check_index_cache(bad)
+    with pytest.raises(RuntimeError):
+        gca.api.check_index_cache(str(tmp_path / "missing.gcidx"))
+    with pytest.raises(RuntimeError):
+        gca.api.build_index_cache(os.path.join(GOLD, "ref_test_graph.gfa"), str(tmp_path / "k.gcidx"), 16, 20)
+
+
+def test_load_needs_a_device(gca, tmp_path):
+    if gca.device_count() > 0:
+        pytest.skip("a GPU is present")
+    path = str(tmp_path / "a.gcidx")
+    gca.api.build_index_cache(os.path.join(GOLD, "ref_test_graph.gfa"), path, 15, 20)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gca.api.load_index_cache(path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["ref_test", "syn20k"])
+def test_loaded_index_matches_built_index(gca, tmp_path, case):
+    from test_oracle_golden import read_fasta
+    gfa = os.path.join(GOLD, "ref_test_graph.gfa" if case == "ref_test" else "syn20k.gfa")
+    fasta = os.path.join(GOLD, "ref_test_read.fa" if case == "ref_test" else "syn20k.fa")
+    built_graph = gca.AlignmentGraph(gfa)
+    built_seeder = gca.MinimizerSeeder(built_graph, 15, 20)
+    host_path, dev_path = str(tmp_path / "host.gcidx"), str(tmp_path / "dev.gcidx")
+    gca.api.build_index_cache(gfa, host_path, 15, 20)      # host-only builder
+    gca.api.save_index_cache(built_graph, built_seeder, dev_path)   # from the live objects
+    assert open(host_path, "rb").read() == open(dev_path, "rb").read()
+    graph, seeder = gca.api.load_index_cache(host_path)
+    assert seeder is not None
+    for name in GRAPH_ARRAYS:
+        assert np.array_equal(graph.array(name), built_graph.array(name)), name
+    for name in ["kmers", "start", "positions", "maxcount"]:
+        assert np.array_equal(seeder.array(name), built_seeder.array(name)), name
+    # a minimizer index rebuilt on the loaded graph follows the same node order as on the built one
+    rebuilt = gca.MinimizerSeeder(graph, 15, 20)
+    assert np.array_equal(rebuilt.array("positions"), built_seeder.array("positions"))
+    # a saved loaded index is the same file again
+    again = str(tmp_path / "again.gcidx")
+    gca.api.save_index_cache(graph, seeder, again)
+    assert open(again, "rb").read() == open(host_path, "rb").read()
+    # and the alignments are the same, field for field
+    reads = read_fasta(fasta)
+    names = [f"r{i}" for i in range(len(reads))]
+    results = []
+    for g, s in ((built_graph, built_seeder), (graph, seeder)):
+        aligner = gca.Aligner(g, s, long_pass=True, keep_traces=True)
+        results.append(aligner.align_batch(gca.ReadBatch(reads), gaf_names=names))
+    a, b = results
+    assert a["gaf"] == b["gaf"]
+    for key in a:
+        if isinstance(a[key], np.ndarray) and key not in ("kernel_us", "host_us"):
+            assert np.array_equal(a[key], b[key]), key
+    # graph-only cache: the seeder comes back as None
+    only = str(tmp_path / "only.gcidx")
+    gca.api.save_index_cache(built_graph, None, only)
+    g2, s2 = gca.api.load_index_cache(only)
+    assert s2 is None and g2.NodeSize() == built_graph.NodeSize()
