@@ -217,6 +217,7 @@ struct ReadGlue {
 	uint64_t slotBegin = 0, fragBegin = 0;
 	uint64_t nAnchors = 0, nPath = 0, nTrace = 0, anchorBegin = 0, pathBegin = 0, traceBegin = 0, seedBegin = 0, chainBegin = 0;
 	StitchedPath stitched;                // chain stitching result
+	bool stitchedOnDevice = false;        // its nodes are also in the device's stitch regions
 	uint64_t stitchedBegin = 0;
 	std::vector<uint32_t> longSelected;   // GreedyLength selection (src/Aligner.cpp:636-639): indices into longAlns
 	uint64_t longSelectedBegin = 0;
@@ -256,6 +257,8 @@ struct gc_stream {
 	hipEvent_t longEv[2] {};
 	DeviceBuffer edPathNodes, edJobs, edLetters, edLettersLen, edPairs, edOut;
 	PinnedBuffer hEdPathNodes, hEdJobs, hEdPairs, hEdOut;
+	DeviceBuffer stitchSlotOf, stitchNodes, stitchInfo;   // chain stitching on the device (gc_stitch.hip)
+	PinnedBuffer hStitchNodes, hStitchInfo;
 	EditDistanceRun edChainRun;
 	// whole-read decision (selection + edit distance of the best alignment)
 	struct LongDecision {
@@ -1614,6 +1617,24 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		mark();   // 4
 		launchChain(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, P->split_len, P->split_gap, caps, dChainScratch, dChainOut, dChainLen, dChainScore, dChainStatus);
 		mark();   // 5
+		// chain stitching (src/Aligner.cpp:754-822) on the device, right behind the chaining kernel; GC_HOST_STITCH=1 keeps it on the
+		// host workers (the path also taken by reads that do not fit the kernel's tables)
+		const bool deviceStitch = P->stitch && n > 0 && !(getenv("GC_HOST_STITCH") && atoi(getenv("GC_HOST_STITCH")) != 0);
+		StitchInfo* stitchInfo = nullptr;
+		uint32_t* hStitchNodes = nullptr;
+		uint32_t* dStitchNodes = nullptr;
+		if (deviceStitch) {
+			uint64_t regionWords = stitchRegionWords(nSlots, n);
+			uint32_t* dSlotOf = st->stitchSlotOf.reserve<uint32_t>(std::max<uint64_t>(1, nSlots));
+			dStitchNodes = st->stitchNodes.reserve<uint32_t>(regionWords);
+			StitchInfo* dStitchInfo = st->stitchInfo.reserve<StitchInfo>(n);
+			stitchInfo = st->hStitchInfo.reserve<StitchInfo>(n);
+			hStitchNodes = st->hStitchNodes.reserve<uint32_t>(regionWords);
+			launchStitch(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, dChainOut, dChainLen, dChainStatus, dPathPool, pathCapacity, (long long)P->colinear_gap, dSlotOf, dStitchNodes, dStitchInfo,
+				getenv("GC_STITCH_SET_MAX") ? (uint32_t)atoi(getenv("GC_STITCH_SET_MAX")) : 0, getenv("GC_STITCH_BFS_CAP") ? (uint32_t)atoi(getenv("GC_STITCH_BFS_CAP")) : 0);
+			HIP_CHECK(hipMemcpyAsync(stitchInfo, dStitchInfo, n * sizeof(StitchInfo), hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipMemcpyAsync(hStitchNodes, dStitchNodes, regionWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		}
 
 		// ---------------- results back (pinned staging)
 		AnchorRec* anchors = st->hAnchors.reserve<AnchorRec>(nSlots);
@@ -1655,10 +1676,20 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 
 		// ---------------- chain stitching (src/Aligner.cpp:754-822) on the host workers, while the whole-read pass still runs
 		double tStitch = nowUs();
+		std::atomic<uint64_t> hostStitched { 0 };
 		if (P->stitch) {
 			pool.run(n, [&](size_t r, size_t) {
 				ReadGlue& gl = glue[r];
+				gl.stitchedOnDevice = false;
 				if (chainStatus[r] != 0 || chainLen[r] == 0) return;
+				if (deviceStitch && stitchInfo[r].status == 0) {
+					const StitchInfo& si = stitchInfo[r];
+					gl.stitched.nodes.assign(hStitchNodes + si.start, hStitchNodes + si.start + si.len);
+					gl.stitched.firstOffset = si.firstOffset; gl.stitched.lastOffset = si.lastOffset; gl.stitched.cells = si.cells;
+					gl.stitchedOnDevice = true;
+					return;
+				}
+				hostStitched++;
 				std::vector<uint32_t> slots;
 				uint64_t slot = gl.slotBegin;
 				for (size_t f = 0; f < gl.windows.size(); f++) {
@@ -1678,16 +1709,18 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		if (P->stitch && P->edit_distances) {
 			uint64_t nNodesTotal = 0, nCells = 0;
 			uint32_t nPairs = 0;
-			for (uint64_t r = 0; r < n; r++) { glue[r].stitchedBegin = nNodesTotal; nNodesTotal += glue[r].stitched.nodes.size(); }
+			// node paths stitched on the device are read where k_stitch left them; only the ones stitched here go up
+			for (uint64_t r = 0; r < n; r++) { glue[r].stitchedBegin = nNodesTotal; if (!glue[r].stitchedOnDevice) nNodesTotal += glue[r].stitched.nodes.size(); }
 			uint32_t* hNodes = st->hEdPathNodes.reserve<uint32_t>(nNodesTotal);
 			PathSeqJob* hJobsPS = st->hEdJobs.reserve<PathSeqJob>(n);
 			EdPair* hPairs = st->hEdPairs.reserve<EdPair>(n);
 			int64_t* hOut = st->hEdOut.reserve<int64_t>(n);
 			for (uint64_t r = 0; r < n; r++) {
 				const StitchedPath& sp = glue[r].stitched;
-				if (!sp.nodes.empty()) memcpy(hNodes + glue[r].stitchedBegin, sp.nodes.data(), sp.nodes.size() * sizeof(uint32_t));
+				const bool onDevice = glue[r].stitchedOnDevice;
+				if (!onDevice && !sp.nodes.empty()) memcpy(hNodes + glue[r].stitchedBegin, sp.nodes.data(), sp.nodes.size() * sizeof(uint32_t));
 				if (sp.cells >= 0x7fffffffull) throw std::runtime_error("stitched path too long");
-				hJobsPS[r] = PathSeqJob { glue[r].stitchedBegin, nCells, (uint32_t)sp.nodes.size(), (uint32_t)sp.cells, sp.firstOffset, sp.lastOffset };
+				hJobsPS[r] = PathSeqJob { onDevice ? stitchInfo[r].start : ((1ull << 63) | glue[r].stitchedBegin), nCells, (uint32_t)sp.nodes.size(), (uint32_t)sp.cells, sp.firstOffset, sp.lastOffset };
 				if (sp.cells) {
 					uint32_t len = (uint32_t)(R->offsets[r + 1] - R->offsets[r]);
 					// first band: the length difference plus ~14 % of the shorter sequence (ONT-like error rates pass in one sweep)
@@ -1705,7 +1738,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			int64_t* dOut = st->edOut.reserve<int64_t>(n);
 			if (nNodesTotal) HIP_CHECK(hipMemcpyAsync(dNodes, hNodes, nNodesTotal * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 			if (n) HIP_CHECK(hipMemcpyAsync(dJobsPS, hJobsPS, n * sizeof(PathSeqJob), hipMemcpyHostToDevice, stream));
-			launchChainPathSeq(stream, G->dev, dJobsPS, (uint32_t)n, dNodes, dLetters, dLettersLen);
+			launchChainPathSeq(stream, G->dev, dJobsPS, (uint32_t)n, dStitchNodes, dNodes, dLetters, dLettersLen);
 			auto readLenOf = [R](uint32_t r) { return (uint32_t)(R->offsets[r + 1] - R->offsets[r]); };
 			launchEditDistances(st->edChainRun, stream, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen, readLenOf);
 			finishChainEditDistances = [=, &glue, &pairRead]() {   // waits for the kernels (they run beside the whole-read pass) and reruns the few pairs that need a wider band
@@ -1715,7 +1748,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		}
 		if (finishChainEditDistances) finishChainEditDistances();   // this thread would only wait for the whole-read pass otherwise
 		double stitchUs = nowUs() - tStitch;
-		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] chain stitching + its edit distances %.1f ms\n", stitchUs / 1e3);
+		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] chain stitching + its edit distances %.1f ms (%llu reads stitched on the host)\n", stitchUs / 1e3, (unsigned long long)hostStitched.load());
+		res->counters[7] = hostStitched.load();   // reads whose chain was stitched on the host
 
 		// ---------------- whole-read pass results
 		double tJoined = nowUs();

@@ -93,13 +93,13 @@ __global__ void __launch_bounds__(64) k_long_pathseq(DGraph g, const PathSeqJob*
 // pathToTrace (src/Aligner.cpp:409-424) of the stitched chain, as letters: first node from its start offset, last node
 // (when it is not also the first) up to its last offset, whole nodes in between.
 __global__ void __launch_bounds__(64) k_chain_pathseq(DGraph g, const PathSeqJob* __restrict__ jobs, uint32_t nJobs, const uint32_t* __restrict__ pathNodes,
-	char* __restrict__ letters, uint32_t* __restrict__ outLen)
+	const uint32_t* __restrict__ altNodes, char* __restrict__ letters, uint32_t* __restrict__ outLen)
 {
 	const uint32_t r = blockIdx.x, lane = threadIdx.x;
 	if (r >= nJobs) return;
 	const PathSeqJob job = jobs[r];
 	if (job.count == 0) { if (lane == 0) outLen[r] = 0; return; }
-	const uint32_t* nodes = pathNodes + job.srcOff;
+	const uint32_t* nodes = (job.srcOff >> 63) ? altNodes + (job.srcOff & ~(1ull << 63)) : pathNodes + job.srcOff;   // bit 63: stitched on the host
 	char* out = letters + job.outOff;
 	uint32_t total = 0;
 	bool overflow = false;
@@ -266,9 +266,9 @@ void launchLongPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* jo
 {
 	if (nJobs) hipLaunchKernelGGL(k_long_pathseq, dim3(nJobs), dim3(64), 0, stream, g, jobs, nJobs, cellPool, letters, outLen);
 }
-void launchChainPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* jobs, uint32_t nJobs, const uint32_t* pathNodes, char* letters, uint32_t* outLen)
+void launchChainPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* jobs, uint32_t nJobs, const uint32_t* pathNodes, const uint32_t* altNodes, char* letters, uint32_t* outLen)
 {
-	if (nJobs) hipLaunchKernelGGL(k_chain_pathseq, dim3(nJobs), dim3(64), 0, stream, g, jobs, nJobs, pathNodes, letters, outLen);
+	if (nJobs) hipLaunchKernelGGL(k_chain_pathseq, dim3(nJobs), dim3(64), 0, stream, g, jobs, nJobs, pathNodes, altNodes, letters, outLen);
 }
 uint32_t editDistanceMaxK(uint32_t unitBlocks) { return 2016u * unitBlocks; }
 void launchEditDistance(hipStream_t stream, uint32_t unitBlocks, const EdPair* pairs, uint32_t nPairs, const EdRead* reads, const char* bases, const uint64_t* eqMasks,

@@ -1,0 +1,204 @@
+// Chain stitching on the GPU - SURVEY.md §8 row f3.
+//
+// Reference: the stitching loop of runComponentMappings (src/Aligner.cpp:754-822), AlignmentGraph::getChainPath
+// (src/AlignmentGraph.cpp:1866-1916) and the size of pathToTrace's result (src/Aligner.cpp:409-424).
+//   - the node paths of the chain's anchors are appended in chain order, every node at most once per piece;
+//   - when the next anchor starts in a node that is neither on the piece nor its last node, the two are bridged by the
+//     fewest-hops path: a BFS over outNeighbors in adjacency order from the piece's last node, which stops expanding
+//     nodes further than the remaining --colinear-gap budget in bp and stops when the target has been reached. The
+//     predecessor of a node is the first node that reached it, so the path depends on the visiting order, which is
+//     kept: queue order = insertion order, neighbours in CSR order;
+//   - no bridge (or a jump of more than the gap inside the same node) ends the piece; the piece with the most bases
+//     (pathToTrace length, strictly more to replace an earlier one) is the result.
+// The reference's budget test compares an unsigned distance with (size_t)sepLimit, so a negative remaining budget
+// (other than the -1 "no limit") also means "no limit"; kept as is.
+//
+// k_stitch: one wave per read. The lanes together find the cut-off after a failed fragment, number the read's valid
+// anchors (the chain holds indices into that numbering, as in k_chain) and clear the LDS tables; lane 0 then runs the
+// inherently sequential loop. The piece's node set and the BFS's visited map / queue live in LDS; pieces are written
+// one after the other into the read's region of `nodesOut`, and the result is (start, length) of the best one.
+// Anything that does not fit - more than STITCH_SET_MAX nodes on a piece, a BFS that visits more than STITCH_BFS_CAP
+// nodes, a full region - sets status 1 and the host stitches that read with the same algorithm (gc_capi.hip).
+#include "gc_kernels.hpp"
+#include <hip/hip_runtime.h>
+
+namespace gcdev {
+
+#define STITCH_SET_SIZE 4096u    // open-addressing slots for the nodes of the current piece
+#define STITCH_SET_MAX 2048u
+#define STITCH_BFS_CAP 1024u     // visited nodes per bridge search
+#define STITCH_BFS_TABLE 2048u
+#define STITCH_EMPTY 0xffffffffu
+
+__device__ __forceinline__ uint32_t stitchHash(uint32_t node, uint32_t mask) { return (node * 2654435761u >> 12) & mask; }
+
+__global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __restrict__ jobs, uint32_t nReads, const AnchorRec* __restrict__ anchors,
+	const Fragment* __restrict__ frags, const uint32_t* __restrict__ fragStatus, const uint32_t* __restrict__ chainOut, const uint32_t* __restrict__ chainLen,
+	const uint32_t* __restrict__ chainStatus, const uint32_t* __restrict__ pathPool, uint64_t pathCapacity, long long colinearGap, uint32_t setMax, uint32_t bfsCap, uint32_t* __restrict__ slotOf,
+	uint32_t* __restrict__ nodesOut, StitchInfo* __restrict__ info)
+{
+	__shared__ uint32_t setKey[STITCH_SET_SIZE];
+	__shared__ uint32_t bfsTable[STITCH_BFS_TABLE];   // (generation << 11) | (queue index + 1)
+	__shared__ uint32_t qNode[STITCH_BFS_CAP], qDis[STITCH_BFS_CAP], bridge[STITCH_BFS_CAP];
+	__shared__ uint16_t qPre[STITCH_BFS_CAP];
+	const uint32_t lane = threadIdx.x;
+	for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
+		const ReadChainJob job = jobs[r];
+		const uint32_t len = chainLen[r];
+		StitchInfo result = { 0, 0, 0, 0, 0, 0 };
+		if (chainStatus[r] != 0 || len == 0) { if (lane == 0) info[r] = result; continue; }
+		// ---- all lanes: cut-off after the first failed fragment, numbering of the valid anchors (same as k_chain), clear tables
+		uint32_t cut = job.nSlots;
+		for (uint32_t f = lane; f < job.nFrags; f += 64)
+			if (fragStatus[job.fragBegin + f] == 1) { uint32_t c = frags[job.fragBegin + f].seedBegin - job.slotBegin; cut = c < cut ? c : cut; }
+		for (int d = 32; d > 0; d >>= 1) { uint32_t o = __shfl_xor(cut, d); cut = o < cut ? o : cut; }
+		uint32_t nA = 0;
+		for (uint32_t s0 = 0; s0 < cut; s0 += 64) {
+			uint32_t s = s0 + lane;
+			bool valid = s < cut && anchors[job.slotBegin + s].valid != 0;
+			unsigned long long ballot = __ballot(valid);
+			if (valid) slotOf[job.slotBegin + nA + (uint32_t)__popcll(ballot & ((1ull << lane) - 1))] = s;
+			nA += (uint32_t)__popcll(ballot);
+		}
+		for (uint32_t i = lane; i < STITCH_SET_SIZE; i += 64) setKey[i] = STITCH_EMPTY;
+		for (uint32_t i = lane; i < STITCH_BFS_TABLE; i += 64) bfsTable[i] = 0;
+		__syncthreads();
+		if (lane == 0) {
+			const uint64_t regionBase = 2ull * job.slotBegin + 64ull * r;
+			const uint32_t regionCap = 2u * job.nSlots + 64u;
+			uint32_t* region = nodesOut + regionBase;
+			uint32_t pieceStart = 0, posLen = 0, setCount = 0, generation = 0;
+			uint32_t firstOffset = 0, lastOffset = 0, backNode = 0, firstLen = 0;
+			uint64_t sumLen = 0;
+			bool overflow = false;
+			auto contains = [&](uint32_t node) {
+				for (uint32_t h = stitchHash(node, STITCH_SET_SIZE - 1);; h = (h + 1) & (STITCH_SET_SIZE - 1)) {
+					uint32_t k = setKey[h];
+					if (k == node) return true;
+					if (k == STITCH_EMPTY) return false;
+				}
+			};
+			// appends a node that is known not to be on the piece
+			auto push = [&](uint32_t node) {
+				if (setCount >= setMax || pieceStart + posLen >= regionCap) { overflow = true; return; }
+				uint32_t h = stitchHash(node, STITCH_SET_SIZE - 1);
+				while (setKey[h] != STITCH_EMPTY) h = (h + 1) & (STITCH_SET_SIZE - 1);
+				setKey[h] = node;
+				setCount++;
+				region[pieceStart + posLen] = node;
+				uint32_t nodeLen = g.nodeLength[node];
+				if (posLen == 0) firstLen = nodeLen;
+				posLen++;
+				sumLen += nodeLen;
+				backNode = node;
+			};
+			// length of pathToTrace(posPath, firstOffset, lastOffset): first node from firstOffset, last node (when it is not
+			// the first) up to lastOffset, whole nodes between them
+			auto keepIfLonger = [&]() {
+				uint64_t cells = firstLen > firstOffset ? firstLen - firstOffset : 0;
+				if (posLen > 1) cells += (sumLen - firstLen - g.nodeLength[backNode]) + lastOffset + 1;
+				if (result.cells < cells) {
+					result.start = regionBase + pieceStart;
+					result.len = posLen;
+					result.firstOffset = firstOffset;
+					result.lastOffset = lastOffset;
+					result.cells = cells;
+				}
+			};
+			// getChainPath(S, T, sepLimit): fills bridge[0..n) with the path S..T, returns n (0: not reached)
+			auto findBridge = [&](uint32_t S, uint32_t T, long long sepLimit) -> uint32_t {
+				generation++;
+				const uint32_t tag = generation << 11;
+				auto lookup = [&](uint32_t node, bool insert, uint32_t index) -> uint32_t {   // queue index + 1, or 0
+					for (uint32_t h = stitchHash(node, STITCH_BFS_TABLE - 1);; h = (h + 1) & (STITCH_BFS_TABLE - 1)) {
+						uint32_t e = bfsTable[h];
+						if ((e >> 11) != generation) { if (insert) bfsTable[h] = tag | (index + 1); return 0; }
+						if (qNode[(e & 2047u) - 1] == node) return e & 2047u;
+					}
+				};
+				uint32_t qLen = 1, found = 0;
+				qNode[0] = S; qDis[0] = 0; qPre[0] = 0;
+				lookup(S, true, 0);
+				for (uint32_t i = 0; !found && i < qLen; i++) {
+					uint32_t s = qNode[i];
+					if ((unsigned long long)qDis[i] > (unsigned long long)sepLimit) continue;
+					for (uint32_t e = g.outOff[s]; e < g.outOff[s + 1]; e++) {
+						uint32_t t = g.outAdj[e];
+						if (qLen >= bfsCap) { overflow = true; return 0; }
+						if (lookup(t, true, qLen)) continue;
+						qNode[qLen] = t; qDis[qLen] = qDis[i] + g.nodeLength[t]; qPre[qLen] = (uint16_t)i;
+						qLen++;
+						// the reference finishes s's neighbours before it notices that T was reached; the ones after T cannot
+						// change pre[T] or anything before it on the path, so the search can stop here
+						if (t == T) { found = qLen; break; }
+					}
+				}
+				if (!found) return 0;
+				uint32_t hops = 0;
+				for (uint32_t i = found - 1; i != 0; i = qPre[i]) hops++;
+				uint32_t at = hops;
+				for (uint32_t i = found - 1; i != 0; i = qPre[i]) bridge[at--] = qNode[i];
+				bridge[0] = S;
+				return hops + 1;
+			};
+			const uint32_t* chain = chainOut + job.chainBegin;
+			for (uint32_t c = 0; c < len && !overflow; c++) {
+				uint32_t index = chain[c];
+				if (index >= nA) { overflow = true; break; }   // cannot happen; leaves the read to the host rather than reading outside
+				const AnchorRec a = anchors[job.slotBegin + slotOf[job.slotBegin + index]];
+				if (a.pathLen == 0 || a.pathOff + a.pathLen > pathCapacity) { overflow = true; break; }   // anchor path pool overflow: the host reports it
+				const uint32_t* apath = pathPool + a.pathOff;
+				if (posLen == 0) {
+					for (uint32_t k = 0; k < a.pathLen && !overflow; k++) push(apath[k]);   // anchor paths are simple: assign == push each
+					firstOffset = a.firstOffset;
+					lastOffset = a.lastOffset;
+					continue;
+				}
+				const uint32_t head = apath[0];
+				bool gap = head == backNode && colinearGap != -1 && (long long)a.firstOffset - (long long)lastOffset > colinearGap + 1;
+				uint32_t nBridge = 0;
+				if (!contains(head) && backNode != a.firstNode) {
+					long long gapLimit = colinearGap;
+					if (gapLimit != -1) gapLimit -= (long long)a.firstOffset + ((long long)g.nodeLength[backNode] - (long long)lastOffset - 1);
+					nBridge = findBridge(backNode, a.firstNode, gapLimit);
+					if (overflow) break;
+					if (nBridge == 0) gap = true;
+				}
+				if (gap) {
+					keepIfLonger();
+					for (uint32_t i = 0; i < STITCH_SET_SIZE; i++) setKey[i] = STITCH_EMPTY;
+					setCount = 0;
+					pieceStart += posLen;
+					posLen = 0;
+					sumLen = 0;
+					firstOffset = a.firstOffset;
+				} else {
+					for (uint32_t k = 0; k < nBridge && !overflow; k++) if (!contains(bridge[k])) push(bridge[k]);
+				}
+				for (uint32_t k = 0; k < a.pathLen && !overflow; k++) if (!contains(apath[k])) push(apath[k]);
+				lastOffset = a.lastOffset;
+			}
+			if (overflow) {
+				result = StitchInfo { 0, 0, 0, 0, 0, 1 };
+			} else if (posLen > 0) {
+				keepIfLonger();
+			}
+			info[r] = result;
+		}
+		__syncthreads();   // the next read's table clears must not overtake lane 0
+	}
+}
+
+void launchStitch(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
+	const uint32_t* chainOut, const uint32_t* chainLen, const uint32_t* chainStatus, const uint32_t* pathPool, uint64_t pathCapacity, long long colinearGap, uint32_t* slotOf, uint32_t* nodesOut, StitchInfo* info, uint32_t setMax, uint32_t bfsCap)
+{
+	if (!nReads) return;
+	setMax = setMax && setMax < STITCH_SET_MAX ? setMax : STITCH_SET_MAX;
+	bfsCap = bfsCap && bfsCap < STITCH_BFS_CAP ? bfsCap : STITCH_BFS_CAP;
+	uint32_t blocks = nReads < 16384u ? nReads : 16384u;
+	hipLaunchKernelGGL(k_stitch, dim3(blocks), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, chainOut, chainLen, chainStatus, pathPool, pathCapacity, colinearGap, setMax, bfsCap, slotOf, nodesOut, info);
+}
+
+uint64_t stitchRegionWords(uint64_t totalSlots, uint64_t nReads) { return 2 * totalSlots + 64 * nReads; }
+
+} // namespace gcdev

@@ -172,7 +172,8 @@ typedef struct gc_result {
 	int64_t*  long_edit_distance; int64_t* chain_edit_distance;   /* [n_reads] */
 	uint8_t*  chained_better;     /* [n_reads] 1: the chained alignment is the read's result, 0: the selected whole-read alignments are */
 	/* work counters of the fragment pass: [0] dp tiles, [1] recompute tiles (last-slice flatten + backtrace),
-	 * [2] column steps, [3] trace items, [4] extensions, [5] backtrace tiles (subset of [1]) */
+	 * [2] column steps, [3] trace items, [4] extensions, [5] backtrace tiles (subset of [1]);
+	 * [7] reads whose chain was stitched on the host because it did not fit the stitching kernel's tables */
 	uint64_t counters[8];
 	uint64_t counters_long[8];    /* the same for the whole-read pass */
 	/* device time of each kernel of this batch in microseconds (HIP events on the stream):

@@ -443,3 +443,38 @@ def test_output_against_golden_files(gca, golden_dir):
     assert out["json"] == open(os.path.join(golden_dir, "syn20k.expected.json"), "rb").read()
     merged = gca.Aligner(graph, seeder, keep_traces=True, long_pass=True).align_reads(reads, gaf_names=names, cigar_match_mismatch_merge=True)
     assert merged["gaf"] == open(os.path.join(golden_dir, "syn20k.expected.merged.gaf"), "rb").read()
+
+
+@pytest.mark.parametrize("env,kw,host_expected", [
+    ({}, {}, "none"),
+    ({"GC_HOST_STITCH": "1"}, {}, "all"),
+    ({"GC_STITCH_BFS_CAP": "2"}, {}, "some"),        # a bridge search may visit 2 nodes: most reads fall back to the host
+    ({"GC_STITCH_SET_MAX": "40"}, {}, "some"),       # a piece may hold 40 nodes
+    ({}, {"colinear_gap": 150}, "none"),             # small --colinear-gap: bridges fail, chains break into pieces
+    ({}, {"colinear_gap": -1}, "any"),               # no limit: a search for an unreachable anchor walks the whole graph downstream, on the host
+    ({"GC_STITCH_BFS_CAP": "6"}, {"colinear_gap": 150}, "some"),
+])
+def test_chain_stitching_device_and_host(gca, tmp_path, monkeypatch, env, kw, host_expected):
+    """Row f3: k_stitch against the oracle's stitching (src/Aligner.cpp:754-822); the host path that takes the reads the
+    kernel's tables cannot hold gives the same paths, whichever reads it gets. Chimeric reads and a small --colinear-gap
+    produce chains that break into several pieces."""
+    from graphchainer_amd.synth import SynthGraph
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sg = SynthGraph(150_000, seed=17)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(24, 4000, seed=31)
+    reads.append(reads[0][:1500] + reads[1][500:2500])
+    reads.append(reads[2][:900] + reads[3][2000:3500] + reads[4][100:1200])
+    got, want = run_case(gca, gfa, reads, **kw)
+    compare(got, want)
+    chained = int(np.count_nonzero(np.diff(got["read_chain_off"])))
+    on_host = int(got["counters"][7])
+    assert chained >= 24
+    if host_expected == "none":
+        assert on_host == 0
+    elif host_expected == "all":
+        assert on_host == chained
+    elif host_expected == "some":
+        assert 0 < on_host <= chained
