@@ -257,8 +257,8 @@ struct gc_stream {
 	hipEvent_t longEv[2] {};
 	DeviceBuffer edPathNodes, edJobs, edLetters, edLettersLen, edPairs, edOut;
 	PinnedBuffer hEdPathNodes, hEdJobs, hEdPairs, hEdOut;
-	DeviceBuffer stitchSlotOf, stitchNodes, stitchInfo;   // chain stitching on the device (gc_stitch.hip)
-	PinnedBuffer hStitchNodes, hStitchInfo;
+	DeviceBuffer stitchSlotOf, stitchRegions, stitchNodes, stitchInfo, stitchCursor;   // chain stitching on the device (gc_stitch.hip)
+	PinnedBuffer hStitchNodes, hStitchInfo, hStitchCursor;
 	EditDistanceRun edChainRun;
 	// whole-read decision (selection + edit distance of the best alignment)
 	struct LongDecision {
@@ -1623,17 +1623,23 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		StitchInfo* stitchInfo = nullptr;
 		uint32_t* hStitchNodes = nullptr;
 		uint32_t* dStitchNodes = nullptr;
+		uint64_t stitchDenseCap = 0;
+		unsigned long long* hStitchCursor = nullptr;
 		if (deviceStitch) {
-			uint64_t regionWords = stitchRegionWords(nSlots, n);
+			stitchDenseCap = stitchDenseWords(nSlots, n);
 			uint32_t* dSlotOf = st->stitchSlotOf.reserve<uint32_t>(std::max<uint64_t>(1, nSlots));
-			dStitchNodes = st->stitchNodes.reserve<uint32_t>(regionWords);
+			uint32_t* dRegions = st->stitchRegions.reserve<uint32_t>(stitchRegionWords(nSlots, n));
+			dStitchNodes = st->stitchNodes.reserve<uint32_t>(stitchDenseCap);
 			StitchInfo* dStitchInfo = st->stitchInfo.reserve<StitchInfo>(n);
+			unsigned long long* dCursor = st->stitchCursor.reserve<unsigned long long>(1);
 			stitchInfo = st->hStitchInfo.reserve<StitchInfo>(n);
-			hStitchNodes = st->hStitchNodes.reserve<uint32_t>(regionWords);
-			launchStitch(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, dChainOut, dChainLen, dChainStatus, dPathPool, pathCapacity, (long long)P->colinear_gap, dSlotOf, dStitchNodes, dStitchInfo,
+			hStitchCursor = st->hStitchCursor.reserve<unsigned long long>(1);
+			HIP_CHECK(hipMemsetAsync(dCursor, 0, sizeof(unsigned long long), stream));
+			launchStitch(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, dChainOut, dChainLen, dChainStatus, dPathPool, pathCapacity, (long long)P->colinear_gap, dSlotOf,
+				dRegions, dStitchNodes, stitchDenseCap, dCursor, dStitchInfo,
 				getenv("GC_STITCH_SET_MAX") ? (uint32_t)atoi(getenv("GC_STITCH_SET_MAX")) : 0, getenv("GC_STITCH_BFS_CAP") ? (uint32_t)atoi(getenv("GC_STITCH_BFS_CAP")) : 0);
 			HIP_CHECK(hipMemcpyAsync(stitchInfo, dStitchInfo, n * sizeof(StitchInfo), hipMemcpyDeviceToHost, stream));
-			HIP_CHECK(hipMemcpyAsync(hStitchNodes, dStitchNodes, regionWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipMemcpyAsync(hStitchCursor, dCursor, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		}
 
 		// ---------------- results back (pinned staging)
@@ -1673,6 +1679,14 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		}
 		HIP_CHECK(hipStreamSynchronize(stream));
 		res->host_us[3] = nowUs() - tDev;   // K3..K4 + their transfers, wall
+		// the stitched node paths come down behind the kernels that follow on this stream; they are only needed for the result arrays
+		bool stitchNodesPending = false;
+		if (deviceStitch) {
+			uint64_t used = std::min<uint64_t>(*hStitchCursor, stitchDenseCap);
+			hStitchNodes = st->hStitchNodes.reserve<uint32_t>(std::max<uint64_t>(1, used));
+			if (used) HIP_CHECK(hipMemcpyAsync(hStitchNodes, dStitchNodes, used * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+			stitchNodesPending = true;
+		}
 
 		// ---------------- chain stitching (src/Aligner.cpp:754-822) on the host workers, while the whole-read pass still runs
 		double tStitch = nowUs();
@@ -1684,12 +1698,13 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				if (chainStatus[r] != 0 || chainLen[r] == 0) return;
 				if (deviceStitch && stitchInfo[r].status == 0) {
 					const StitchInfo& si = stitchInfo[r];
-					gl.stitched.nodes.assign(hStitchNodes + si.start, hStitchNodes + si.start + si.len);
+					gl.stitched.nodes.clear();   // filled once the download has finished (below)
 					gl.stitched.firstOffset = si.firstOffset; gl.stitched.lastOffset = si.lastOffset; gl.stitched.cells = si.cells;
 					gl.stitchedOnDevice = true;
 					return;
 				}
 				hostStitched++;
+				if (deviceStitch && getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc stitch] read %zu goes to the host: reason %u, chain of %u anchors\n", r, stitchInfo[r].status, chainLen[r]);
 				std::vector<uint32_t> slots;
 				uint64_t slot = gl.slotBegin;
 				for (size_t f = 0; f < gl.windows.size(); f++) {
@@ -1720,7 +1735,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				const bool onDevice = glue[r].stitchedOnDevice;
 				if (!onDevice && !sp.nodes.empty()) memcpy(hNodes + glue[r].stitchedBegin, sp.nodes.data(), sp.nodes.size() * sizeof(uint32_t));
 				if (sp.cells >= 0x7fffffffull) throw std::runtime_error("stitched path too long");
-				hJobsPS[r] = PathSeqJob { onDevice ? stitchInfo[r].start : ((1ull << 63) | glue[r].stitchedBegin), nCells, (uint32_t)sp.nodes.size(), (uint32_t)sp.cells, sp.firstOffset, sp.lastOffset };
+				hJobsPS[r] = PathSeqJob { onDevice ? stitchInfo[r].start : ((1ull << 63) | glue[r].stitchedBegin), nCells, onDevice ? stitchInfo[r].len : (uint32_t)sp.nodes.size(), (uint32_t)sp.cells, sp.firstOffset, sp.lastOffset };
 				if (sp.cells) {
 					uint32_t len = (uint32_t)(R->offsets[r + 1] - R->offsets[r]);
 					// first band: the length difference plus ~14 % of the shorter sequence (ONT-like error rates pass in one sweep)
@@ -1747,6 +1762,14 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			};
 		}
 		if (finishChainEditDistances) finishChainEditDistances();   // this thread would only wait for the whole-read pass otherwise
+		if (stitchNodesPending) {
+			HIP_CHECK(hipStreamSynchronize(stream));
+			pool.run(n, [&](size_t r, size_t) {
+				if (!glue[r].stitchedOnDevice) return;
+				const StitchInfo& si = stitchInfo[r];
+				glue[r].stitched.nodes.assign(hStitchNodes + si.start, hStitchNodes + si.start + si.len);
+			});
+		}
 		double stitchUs = nowUs() - tStitch;
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] chain stitching + its edit distances %.1f ms (%llu reads stitched on the host)\n", stitchUs / 1e3, (unsigned long long)hostStitched.load());
 		res->counters[7] = hostStitched.load();   // reads whose chain was stitched on the host

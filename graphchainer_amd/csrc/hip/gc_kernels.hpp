@@ -162,17 +162,21 @@ struct EdPair {
 void launchLongPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* jobs, uint32_t nJobs, const LongCell* cellPool, char* letters, uint32_t* outLen);
 // ---- chain stitching on the device (gc_stitch.hip) ----
 struct StitchInfo {   // the longest stitched piece of a read's chain
-	uint64_t start;               // its first node in nodesOut
+	uint64_t start;               // its first node in the dense output
 	uint64_t cells;               // bases on it (size of pathToTrace's result); 0: no chain
 	uint32_t len;                 // nodes
 	uint32_t firstOffset, lastOffset;
-	uint32_t status;              // 1: did not fit the kernel's tables, the host stitches this read
+	uint32_t status;              // != 0: did not fit the kernel's tables (1 piece or region full, 2 bridge search too wide, 3 unusable anchor
+	                              // record, 4 output array full), the host stitches this read
 };
-// slotOf: [total anchor slots] scratch; nodesOut: stitchRegionWords(total slots, reads) words
+// slotOf: [total anchor slots] scratch; regions: stitchRegionWords(total slots, reads) words of scratch; dense: the results,
+// stitchDenseWords(...) words, filled from *denseCursor (zeroed by the caller) upwards; StitchInfo.start indexes dense
 void launchStitch(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
-	const uint32_t* chainOut, const uint32_t* chainLen, const uint32_t* chainStatus, const uint32_t* pathPool, uint64_t pathCapacity, long long colinearGap, uint32_t* slotOf, uint32_t* nodesOut, StitchInfo* info,
+	const uint32_t* chainOut, const uint32_t* chainLen, const uint32_t* chainStatus, const uint32_t* pathPool, uint64_t pathCapacity, long long colinearGap, uint32_t* slotOf,
+	uint32_t* regions, uint32_t* dense, uint64_t denseCap, unsigned long long* denseCursor, StitchInfo* info,
 	uint32_t setMax = 0, uint32_t bfsCap = 0);   // smaller table limits (tests: forces reads onto the host path); 0 = the kernel's own
 uint64_t stitchRegionWords(uint64_t totalSlots, uint64_t nReads);
+uint64_t stitchDenseWords(uint64_t totalSlots, uint64_t nReads);
 // srcOff with bit 63 set reads its nodes from altNodes (host-stitched reads) instead of pathNodes
 void launchChainPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* jobs, uint32_t nJobs, const uint32_t* pathNodes, const uint32_t* altNodes, char* letters, uint32_t* outLen);
 uint32_t editDistanceMaxK(uint32_t unitBlocks);

@@ -15,32 +15,53 @@
 //
 // k_stitch: one wave per read. The lanes together find the cut-off after a failed fragment, number the read's valid
 // anchors (the chain holds indices into that numbering, as in k_chain) and clear the LDS tables; lane 0 then runs the
-// inherently sequential loop. The piece's node set and the BFS's visited map / queue live in LDS; pieces are written
-// one after the other into the read's region of `nodesOut`, and the result is (start, length) of the best one.
+// inherently sequential loop. Its inputs are staged 64 chain anchors at a time: every lane loads one anchor record, the
+// first nodes of its path with their lengths, and tests whether the anchor starts in an out-neighbour of the previous
+// anchor's last node (then the BFS is known to return that one hop), so lane 0 works from LDS and touches global memory
+// only for a longer bridge search. The piece's node set and the BFS's visited map / queue live in LDS; pieces are
+// written one after the other into the read's scratch region, and the best one is copied by all lanes into a dense
+// output array (position from an atomic cursor; StitchInfo.start says where).
 // Anything that does not fit - more than STITCH_SET_MAX nodes on a piece, a BFS that visits more than STITCH_BFS_CAP
-// nodes, a full region - sets status 1 and the host stitches that read with the same algorithm (gc_capi.hip).
+// nodes, a full region or output array - sets status 1 and the host stitches that read with the same algorithm
+// (gc_capi.hip).
 #include "gc_kernels.hpp"
 #include <hip/hip_runtime.h>
 
 namespace gcdev {
 
-#define STITCH_SET_SIZE 4096u    // open-addressing slots for the nodes of the current piece
-#define STITCH_SET_MAX 2048u
-#define STITCH_BFS_CAP 1024u     // visited nodes per bridge search
+#define STITCH_SET_SIZE 2048u     // open-addressing slots for the nodes of the current piece
+#define STITCH_SET_MAX 1024u
+#define STITCH_BFS_CAP 1024u      // visited nodes per bridge search
 #define STITCH_BFS_TABLE 2048u
 #define STITCH_EMPTY 0xffffffffu
+#define STITCH_PF_NODES 4u        // path nodes of an anchor staged in LDS (35 bp paths have 1-3)
 
 __device__ __forceinline__ uint32_t stitchHash(uint32_t node, uint32_t mask) { return (node * 2654435761u >> 12) & mask; }
 
+// One chain anchor as lane 0 needs it, staged in LDS by the lane that loaded it.
+struct StitchAnchor {
+	uint32_t firstNode, firstOffset, lastOffset, pathLen;
+	uint32_t pathOffLo, pathOffHi;
+	uint32_t node[STITCH_PF_NODES];
+	uint32_t nodeLen;             // lengths of node[0..3], one byte each
+	uint32_t prevLast;            // last path node of the previous chain anchor
+	uint32_t flags;               // 1: firstNode is an out-neighbour of prevLast, 2: unusable record (the host stitches the read)
+};
+
 __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __restrict__ jobs, uint32_t nReads, const AnchorRec* __restrict__ anchors,
 	const Fragment* __restrict__ frags, const uint32_t* __restrict__ fragStatus, const uint32_t* __restrict__ chainOut, const uint32_t* __restrict__ chainLen,
-	const uint32_t* __restrict__ chainStatus, const uint32_t* __restrict__ pathPool, uint64_t pathCapacity, long long colinearGap, uint32_t setMax, uint32_t bfsCap, uint32_t* __restrict__ slotOf,
-	uint32_t* __restrict__ nodesOut, StitchInfo* __restrict__ info)
+	const uint32_t* __restrict__ chainStatus, const uint32_t* __restrict__ pathPool, uint64_t pathCapacity, long long colinearGap, uint32_t setMax, uint32_t bfsCap,
+	uint32_t* __restrict__ slotOf, uint32_t* __restrict__ regions, uint32_t* __restrict__ dense, uint64_t denseCap, unsigned long long* __restrict__ denseCursor,
+	StitchInfo* __restrict__ info)
 {
 	__shared__ uint32_t setKey[STITCH_SET_SIZE];
 	__shared__ uint32_t bfsTable[STITCH_BFS_TABLE];   // (generation << 11) | (queue index + 1)
-	__shared__ uint32_t qNode[STITCH_BFS_CAP], qDis[STITCH_BFS_CAP], bridge[STITCH_BFS_CAP];
+	__shared__ uint32_t qNode[STITCH_BFS_CAP], qDis[STITCH_BFS_CAP];
 	__shared__ uint16_t qPre[STITCH_BFS_CAP];
+	uint32_t* const bridge = qDis;   // the path is written out when the search is over and the distances are no longer needed
+	__shared__ StitchAnchor staged[64];
+	__shared__ uint32_t sOverflow, sBestStart, sBestLen;
+	__shared__ unsigned long long sDenseAt;
 	const uint32_t lane = threadIdx.x;
 	for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
 		const ReadChainJob job = jobs[r];
@@ -62,143 +83,211 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 		}
 		for (uint32_t i = lane; i < STITCH_SET_SIZE; i += 64) setKey[i] = STITCH_EMPTY;
 		for (uint32_t i = lane; i < STITCH_BFS_TABLE; i += 64) bfsTable[i] = 0;
+		if (lane == 0) sOverflow = 0;
 		__syncthreads();
-		if (lane == 0) {
-			const uint64_t regionBase = 2ull * job.slotBegin + 64ull * r;
-			const uint32_t regionCap = 2u * job.nSlots + 64u;
-			uint32_t* region = nodesOut + regionBase;
-			uint32_t pieceStart = 0, posLen = 0, setCount = 0, generation = 0;
-			uint32_t firstOffset = 0, lastOffset = 0, backNode = 0, firstLen = 0;
-			uint64_t sumLen = 0;
-			bool overflow = false;
-			auto contains = [&](uint32_t node) {
-				for (uint32_t h = stitchHash(node, STITCH_SET_SIZE - 1);; h = (h + 1) & (STITCH_SET_SIZE - 1)) {
-					uint32_t k = setKey[h];
-					if (k == node) return true;
-					if (k == STITCH_EMPTY) return false;
+
+		// ---- lane 0's state: the current piece and the best one so far
+		const uint64_t regionBase = 2ull * job.slotBegin + 64ull * r;
+		const uint32_t regionCap = 2u * job.nSlots + 64u;
+		uint32_t* region = regions + regionBase;
+		uint32_t pieceStart = 0, posLen = 0, setCount = 0, generation = 0;
+		uint32_t firstOffset = 0, lastOffset = 0, backNode = 0, backLen = 0, firstLen = 0, bestStart = 0;
+		uint64_t sumLen = 0;
+		bool overflow = false;
+		uint32_t why = 0;   // 1 piece/region full, 2 bridge search too wide, 3 unusable anchor record, 4 output array full
+		auto contains = [&](uint32_t node) {
+			for (uint32_t h = stitchHash(node, STITCH_SET_SIZE - 1);; h = (h + 1) & (STITCH_SET_SIZE - 1)) {
+				uint32_t k = setKey[h];
+				if (k == node) return true;
+				if (k == STITCH_EMPTY) return false;
+			}
+		};
+		// appends a node that is known not to be on the piece; nodeLen 0 = not known
+		auto push = [&](uint32_t node, uint32_t nodeLen) {
+			if (setCount >= setMax || pieceStart + posLen >= regionCap) { overflow = true; why = 1; return; }
+			uint32_t h = stitchHash(node, STITCH_SET_SIZE - 1);
+			while (setKey[h] != STITCH_EMPTY) h = (h + 1) & (STITCH_SET_SIZE - 1);
+			setKey[h] = node;
+			setCount++;
+			region[pieceStart + posLen] = node;
+			if (nodeLen == 0) nodeLen = g.nodeLength[node];
+			if (posLen == 0) firstLen = nodeLen;
+			posLen++;
+			sumLen += nodeLen;
+			backNode = node;
+			backLen = nodeLen;
+		};
+		// length of pathToTrace(posPath, firstOffset, lastOffset): first node from firstOffset, last node (when it is not
+		// the first) up to lastOffset, whole nodes between them
+		auto keepIfLonger = [&]() {
+			uint64_t cells = firstLen > firstOffset ? firstLen - firstOffset : 0;
+			if (posLen > 1) cells += (sumLen - firstLen - backLen) + lastOffset + 1;
+			if (result.cells < cells) {
+				bestStart = pieceStart;
+				result.len = posLen;
+				result.firstOffset = firstOffset;
+				result.lastOffset = lastOffset;
+				result.cells = cells;
+			}
+		};
+		// getChainPath(S, T, sepLimit): fills bridge[0..n) with the path S..T, returns n (0: not reached)
+		auto findBridge = [&](uint32_t S, uint32_t T, long long sepLimit) -> uint32_t {
+			generation++;
+			const uint32_t tag = generation << 11;
+			auto visit = [&](uint32_t node, uint32_t index) -> bool {   // true: seen before; otherwise recorded as queue entry `index`
+				for (uint32_t h = stitchHash(node, STITCH_BFS_TABLE - 1);; h = (h + 1) & (STITCH_BFS_TABLE - 1)) {
+					uint32_t e = bfsTable[h];
+					if ((e >> 11) != generation) { bfsTable[h] = tag | (index + 1); return false; }
+					if (qNode[(e & 2047u) - 1] == node) return true;
 				}
 			};
-			// appends a node that is known not to be on the piece
-			auto push = [&](uint32_t node) {
-				if (setCount >= setMax || pieceStart + posLen >= regionCap) { overflow = true; return; }
-				uint32_t h = stitchHash(node, STITCH_SET_SIZE - 1);
-				while (setKey[h] != STITCH_EMPTY) h = (h + 1) & (STITCH_SET_SIZE - 1);
-				setKey[h] = node;
-				setCount++;
-				region[pieceStart + posLen] = node;
-				uint32_t nodeLen = g.nodeLength[node];
-				if (posLen == 0) firstLen = nodeLen;
-				posLen++;
-				sumLen += nodeLen;
-				backNode = node;
-			};
-			// length of pathToTrace(posPath, firstOffset, lastOffset): first node from firstOffset, last node (when it is not
-			// the first) up to lastOffset, whole nodes between them
-			auto keepIfLonger = [&]() {
-				uint64_t cells = firstLen > firstOffset ? firstLen - firstOffset : 0;
-				if (posLen > 1) cells += (sumLen - firstLen - g.nodeLength[backNode]) + lastOffset + 1;
-				if (result.cells < cells) {
-					result.start = regionBase + pieceStart;
-					result.len = posLen;
-					result.firstOffset = firstOffset;
-					result.lastOffset = lastOffset;
-					result.cells = cells;
+			uint32_t qLen = 1, found = 0;
+			qNode[0] = S; qDis[0] = 0; qPre[0] = 0;
+			visit(S, 0);
+			for (uint32_t i = 0; !found && i < qLen; i++) {
+				uint32_t s = qNode[i];
+				if ((unsigned long long)qDis[i] > (unsigned long long)sepLimit) continue;
+				for (uint32_t e = g.outOff[s]; e < g.outOff[s + 1]; e++) {
+					uint32_t t = g.outAdj[e];
+					if (qLen >= bfsCap) { overflow = true; why = 2; return 0; }
+					if (visit(t, qLen)) continue;
+					qNode[qLen] = t; qDis[qLen] = qDis[i] + g.nodeLength[t]; qPre[qLen] = (uint16_t)i;
+					qLen++;
+					// the reference finishes s's neighbours before it notices that T was reached; the ones after T cannot
+					// change pre[T] or anything before it on the path, so the search can stop here
+					if (t == T) { found = qLen; break; }
 				}
-			};
-			// getChainPath(S, T, sepLimit): fills bridge[0..n) with the path S..T, returns n (0: not reached)
-			auto findBridge = [&](uint32_t S, uint32_t T, long long sepLimit) -> uint32_t {
-				generation++;
-				const uint32_t tag = generation << 11;
-				auto lookup = [&](uint32_t node, bool insert, uint32_t index) -> uint32_t {   // queue index + 1, or 0
-					for (uint32_t h = stitchHash(node, STITCH_BFS_TABLE - 1);; h = (h + 1) & (STITCH_BFS_TABLE - 1)) {
-						uint32_t e = bfsTable[h];
-						if ((e >> 11) != generation) { if (insert) bfsTable[h] = tag | (index + 1); return 0; }
-						if (qNode[(e & 2047u) - 1] == node) return e & 2047u;
-					}
-				};
-				uint32_t qLen = 1, found = 0;
-				qNode[0] = S; qDis[0] = 0; qPre[0] = 0;
-				lookup(S, true, 0);
-				for (uint32_t i = 0; !found && i < qLen; i++) {
-					uint32_t s = qNode[i];
-					if ((unsigned long long)qDis[i] > (unsigned long long)sepLimit) continue;
-					for (uint32_t e = g.outOff[s]; e < g.outOff[s + 1]; e++) {
-						uint32_t t = g.outAdj[e];
-						if (qLen >= bfsCap) { overflow = true; return 0; }
-						if (lookup(t, true, qLen)) continue;
-						qNode[qLen] = t; qDis[qLen] = qDis[i] + g.nodeLength[t]; qPre[qLen] = (uint16_t)i;
-						qLen++;
-						// the reference finishes s's neighbours before it notices that T was reached; the ones after T cannot
-						// change pre[T] or anything before it on the path, so the search can stop here
-						if (t == T) { found = qLen; break; }
-					}
-				}
-				if (!found) return 0;
-				uint32_t hops = 0;
-				for (uint32_t i = found - 1; i != 0; i = qPre[i]) hops++;
-				uint32_t at = hops;
-				for (uint32_t i = found - 1; i != 0; i = qPre[i]) bridge[at--] = qNode[i];
-				bridge[0] = S;
-				return hops + 1;
-			};
-			const uint32_t* chain = chainOut + job.chainBegin;
-			for (uint32_t c = 0; c < len && !overflow; c++) {
+			}
+			if (!found) return 0;
+			uint32_t hops = 0;
+			for (uint32_t i = found - 1; i != 0; i = qPre[i]) hops++;
+			uint32_t at = hops;
+			for (uint32_t i = found - 1; i != 0; i = qPre[i]) bridge[at--] = qNode[i];
+			bridge[0] = S;
+			return hops + 1;
+		};
+
+		const uint32_t* chain = chainOut + job.chainBegin;
+		uint32_t carryLast = 0;   // last path node of the anchor before this batch
+		for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+			// ---- all lanes: stage the next 64 chain anchors (record, first path nodes and their lengths, and whether the
+			// anchor starts in an out-neighbour of the previous anchor's last node - the common bridge, one hop)
+			const uint32_t c = c0 + lane;
+			uint32_t myLast = 0;
+			StitchAnchor sa = {};
+			if (c < len) {
 				uint32_t index = chain[c];
-				if (index >= nA) { overflow = true; break; }   // cannot happen; leaves the read to the host rather than reading outside
-				const AnchorRec a = anchors[job.slotBegin + slotOf[job.slotBegin + index]];
-				if (a.pathLen == 0 || a.pathOff + a.pathLen > pathCapacity) { overflow = true; break; }   // anchor path pool overflow: the host reports it
-				const uint32_t* apath = pathPool + a.pathOff;
-				if (posLen == 0) {
-					for (uint32_t k = 0; k < a.pathLen && !overflow; k++) push(apath[k]);   // anchor paths are simple: assign == push each
-					firstOffset = a.firstOffset;
+				if (index >= nA) sa.flags = 2;   // cannot happen; leaves the read to the host rather than reading outside
+				else {
+					const AnchorRec a = anchors[job.slotBegin + slotOf[job.slotBegin + index]];
+					sa.firstNode = a.firstNode; sa.firstOffset = a.firstOffset; sa.lastOffset = a.lastOffset; sa.pathLen = a.pathLen;
+					sa.pathOffLo = (uint32_t)a.pathOff; sa.pathOffHi = (uint32_t)(a.pathOff >> 32);
+					if (a.pathLen == 0 || a.pathOff + a.pathLen > pathCapacity) sa.flags = 2;   // anchor path pool overflow: the host reports it
+					else {
+#pragma unroll
+						for (uint32_t k = 0; k < STITCH_PF_NODES; k++)
+							if (k < a.pathLen) {
+								uint32_t node = pathPool[a.pathOff + k];
+								sa.node[k] = node;
+								sa.nodeLen |= (uint32_t)g.nodeLength[node] << (8 * k);
+							}
+						myLast = pathPool[a.pathOff + a.pathLen - 1];
+					}
+				}
+			}
+			uint32_t prevLast = __shfl_up(myLast, 1);
+			if (lane == 0) prevLast = carryLast;
+			carryLast = __shfl(myLast, 63);
+			if (c < len && c > 0 && sa.flags == 0) {
+				sa.prevLast = prevLast;
+				if (prevLast != sa.firstNode)
+					for (uint32_t e = g.outOff[prevLast]; e < g.outOff[prevLast + 1]; e++) if (g.outAdj[e] == sa.firstNode) { sa.flags = 1; break; }
+			}
+			staged[lane] = sa;
+			__syncthreads();
+			if (lane == 0) {
+				const uint32_t batch = len - c0 < 64u ? len - c0 : 64u;
+				for (uint32_t i = 0; i < batch && !overflow; i++) {
+					const StitchAnchor& a = staged[i];
+					if (a.flags & 2) { overflow = true; why = 3; break; }
+					const uint32_t* apath = pathPool + (((uint64_t)a.pathOffHi << 32) | a.pathOffLo);
+					auto pathNode = [&](uint32_t k) { return k < STITCH_PF_NODES ? a.node[k] : apath[k]; };
+					auto pathNodeLen = [&](uint32_t k) { return k < STITCH_PF_NODES ? (a.nodeLen >> (8 * k)) & 255u : 0u; };
+					if (posLen == 0) {
+						for (uint32_t k = 0; k < a.pathLen && !overflow; k++) push(pathNode(k), pathNodeLen(k));   // anchor paths are simple: assign == push each
+						firstOffset = a.firstOffset;
+						lastOffset = a.lastOffset;
+						continue;
+					}
+					const uint32_t head = a.node[0];
+					bool gap = head == backNode && colinearGap != -1 && (long long)a.firstOffset - (long long)lastOffset > colinearGap + 1;
+					uint32_t nBridge = 0;
+					if (!contains(head) && backNode != a.firstNode) {
+						if ((a.flags & 1) && a.prevLast == backNode) {
+							// the target is an out-neighbour of the start: the search expands the start whatever the budget (its
+							// distance is 0) and reaches the target at once
+							bridge[0] = backNode; bridge[1] = a.firstNode;
+							nBridge = 2;
+						} else {
+							long long gapLimit = colinearGap;
+							if (gapLimit != -1) gapLimit -= (long long)a.firstOffset + ((long long)backLen - (long long)lastOffset - 1);
+							nBridge = findBridge(backNode, a.firstNode, gapLimit);
+							if (overflow) break;
+							if (nBridge == 0) gap = true;
+						}
+					}
+					if (gap) {
+						keepIfLonger();
+						for (uint32_t k = 0; k < STITCH_SET_SIZE; k++) setKey[k] = STITCH_EMPTY;
+						setCount = 0;
+						pieceStart += posLen;
+						posLen = 0;
+						sumLen = 0;
+						firstOffset = a.firstOffset;
+					} else {
+						for (uint32_t k = 0; k < nBridge && !overflow; k++) if (!contains(bridge[k])) push(bridge[k], bridge[k] == head ? pathNodeLen(0) : 0u);
+					}
+					for (uint32_t k = 0; k < a.pathLen && !overflow; k++) { uint32_t node = pathNode(k); if (!contains(node)) push(node, pathNodeLen(k)); }
 					lastOffset = a.lastOffset;
-					continue;
 				}
-				const uint32_t head = apath[0];
-				bool gap = head == backNode && colinearGap != -1 && (long long)a.firstOffset - (long long)lastOffset > colinearGap + 1;
-				uint32_t nBridge = 0;
-				if (!contains(head) && backNode != a.firstNode) {
-					long long gapLimit = colinearGap;
-					if (gapLimit != -1) gapLimit -= (long long)a.firstOffset + ((long long)g.nodeLength[backNode] - (long long)lastOffset - 1);
-					nBridge = findBridge(backNode, a.firstNode, gapLimit);
-					if (overflow) break;
-					if (nBridge == 0) gap = true;
-				}
-				if (gap) {
-					keepIfLonger();
-					for (uint32_t i = 0; i < STITCH_SET_SIZE; i++) setKey[i] = STITCH_EMPTY;
-					setCount = 0;
-					pieceStart += posLen;
-					posLen = 0;
-					sumLen = 0;
-					firstOffset = a.firstOffset;
-				} else {
-					for (uint32_t k = 0; k < nBridge && !overflow; k++) if (!contains(bridge[k])) push(bridge[k]);
-				}
-				for (uint32_t k = 0; k < a.pathLen && !overflow; k++) if (!contains(apath[k])) push(apath[k]);
-				lastOffset = a.lastOffset;
+				if (overflow) sOverflow = 1;
 			}
-			if (overflow) {
-				result = StitchInfo { 0, 0, 0, 0, 0, 1 };
-			} else if (posLen > 0) {
-				keepIfLonger();
+			__syncthreads();
+			if (sOverflow) break;
+		}
+		// ---- lane 0 closes the last piece and reserves room in the dense output; all lanes copy the best piece there
+		if (lane == 0) {
+			if (!overflow && posLen > 0) keepIfLonger();
+			unsigned long long at = 0;
+			if (!overflow) {
+				at = atomicAdd(denseCursor, (unsigned long long)result.len);
+				if (at + result.len > denseCap) { overflow = true; why = 4; }
 			}
+			if (overflow) { result = StitchInfo { 0, 0, 0, 0, 0, why }; sBestLen = 0; }
+			else { result.start = at; sBestLen = result.len; }
+			sBestStart = bestStart;
+			sDenseAt = at;
 			info[r] = result;
 		}
-		__syncthreads();   // the next read's table clears must not overtake lane 0
+		__syncthreads();   // also orders lane 0's region writes before the copy, and the next read's table clears after lane 0
+		for (uint32_t i = lane; i < sBestLen; i += 64) dense[sDenseAt + i] = region[sBestStart + i];
+		__syncthreads();
 	}
 }
 
 void launchStitch(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
-	const uint32_t* chainOut, const uint32_t* chainLen, const uint32_t* chainStatus, const uint32_t* pathPool, uint64_t pathCapacity, long long colinearGap, uint32_t* slotOf, uint32_t* nodesOut, StitchInfo* info, uint32_t setMax, uint32_t bfsCap)
+	const uint32_t* chainOut, const uint32_t* chainLen, const uint32_t* chainStatus, const uint32_t* pathPool, uint64_t pathCapacity, long long colinearGap, uint32_t* slotOf,
+	uint32_t* regions, uint32_t* dense, uint64_t denseCap, unsigned long long* denseCursor, StitchInfo* info, uint32_t setMax, uint32_t bfsCap)
 {
 	if (!nReads) return;
 	setMax = setMax && setMax < STITCH_SET_MAX ? setMax : STITCH_SET_MAX;
 	bfsCap = bfsCap && bfsCap < STITCH_BFS_CAP ? bfsCap : STITCH_BFS_CAP;
 	uint32_t blocks = nReads < 16384u ? nReads : 16384u;
-	hipLaunchKernelGGL(k_stitch, dim3(blocks), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, chainOut, chainLen, chainStatus, pathPool, pathCapacity, colinearGap, setMax, bfsCap, slotOf, nodesOut, info);
+	hipLaunchKernelGGL(k_stitch, dim3(blocks), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, chainOut, chainLen, chainStatus, pathPool, pathCapacity, colinearGap, setMax, bfsCap,
+		slotOf, regions, dense, denseCap, denseCursor, info);
 }
 
 uint64_t stitchRegionWords(uint64_t totalSlots, uint64_t nReads) { return 2 * totalSlots + 64 * nReads; }
+uint64_t stitchDenseWords(uint64_t totalSlots, uint64_t nReads) { return stitchRegionWords(totalSlots, nReads); }   // a piece is at most its read's region; only the used part is downloaded
 
 } // namespace gcdev
