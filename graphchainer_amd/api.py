@@ -136,6 +136,13 @@ def _fetch_array(fn, handle, name):
     return out
 
 
+class GcGraphDesc(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("first_ambiguous", C.c_uint64), ("node_length", C.c_void_p), ("node_offset", C.c_void_p),
+                ("node_ids", C.c_void_p), ("node_seq", C.c_void_p), ("ambiguous_seq", C.c_void_p), ("in_off", C.c_void_p), ("in_adj", C.c_void_p),
+                ("out_off", C.c_void_p), ("out_adj", C.c_void_p), ("component_number", C.c_void_p), ("chain_number", C.c_void_p),
+                ("chain_approx_pos", C.c_void_p), ("lookup_order", C.c_void_p), ("n_lookup", C.c_uint64)]
+
+
 def build_index_cache(gfa_path, cache_path, minimizer_length=15, window_size=20, keep_least_frequent_fraction=1 - 0.001):
     """Builds graph + MPC index (+ minimizer index unless minimizer_length is 0) on the host and writes the cache file;
     needs no GPU (the reference's saveMPC, src/AlignmentGraph.h:96, is an empty stub)."""
@@ -174,6 +181,37 @@ class AlignmentGraph:
             self.handle = _handle
             return
         _check(self.lib.gc_graph_create_from_gfa(os.fsencode(gfa_path), C.byref(self.handle)))
+
+    @classmethod
+    def from_arrays(cls, arrays, with_lookup_order=True):
+        """gc_graph_create: a graph from the arrays a host that keeps its own AlignmentGraph would hand over (the names are
+        those of gc_graph_array)."""
+        lib = load_library()
+        keep = {
+            "node_length": np.ascontiguousarray(arrays["nodeLength"], dtype=np.uint8),
+            "node_offset": np.ascontiguousarray(arrays["nodeOffset"], dtype=np.uint32),
+            "node_ids": np.ascontiguousarray(arrays["nodeIDs"], dtype=np.int32),
+            "node_seq": np.ascontiguousarray(arrays["nodeSeq"]).view(np.uint64) if len(arrays["nodeSeq"]) else np.zeros(1, dtype=np.uint64),
+            "ambiguous_seq": np.ascontiguousarray(arrays["ambiguousSeq"]).view(np.uint64) if len(arrays["ambiguousSeq"]) else np.zeros(1, dtype=np.uint64),
+            "in_off": np.ascontiguousarray(arrays["in_off"], dtype=np.uint64), "in_adj": np.ascontiguousarray(arrays["in_adj"], dtype=np.uint32),
+            "out_off": np.ascontiguousarray(arrays["out_off"], dtype=np.uint64), "out_adj": np.ascontiguousarray(arrays["out_adj"], dtype=np.uint32),
+            "component_number": np.ascontiguousarray(arrays["componentNumber"], dtype=np.uint32),
+            "chain_number": np.ascontiguousarray(arrays["chainNumber"], dtype=np.uint32),
+            "chain_approx_pos": np.ascontiguousarray(arrays["chainApproxPos"], dtype=np.uint64),
+            "lookup_order": np.ascontiguousarray(arrays["lookupOrder"], dtype=np.int32),
+        }
+        desc = GcGraphDesc()
+        desc.n_nodes = len(keep["node_length"])
+        desc.first_ambiguous = int(arrays["firstAmbiguous"][0])
+        for name, arr in keep.items():
+            setattr(desc, name, arr.ctypes.data)
+        desc.n_lookup = len(keep["lookup_order"])
+        if not with_lookup_order:
+            desc.lookup_order, desc.n_lookup = None, 0
+        handle = C.c_void_p()
+        lib.gc_graph_create.argtypes = [_P(GcGraphDesc), _P(C.c_void_p)]
+        _check(lib.gc_graph_create(C.byref(desc), C.byref(handle)))
+        return cls(None, _handle=handle)
 
     def NodeSize(self):
         return self.lib.gc_graph_num_nodes(self.handle)

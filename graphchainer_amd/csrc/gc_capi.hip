@@ -808,6 +808,14 @@ int gc_graph_create(const gc_graph_desc* desc, gc_graph** out)
 		for (size_t i = 0; i < n; i++) order[i] = i;
 		std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return h.nodeIDs[a] != h.nodeIDs[b] ? h.nodeIDs[a] < h.nodeIDs[b] : h.nodeOffset[a] < h.nodeOffset[b]; });
 		for (size_t i : order) { h.nodeLookup[h.nodeIDs[i]].push_back(i); h.originalNodeSize[h.nodeIDs[i]] += h.nodeLength[i]; }
+		if (desc->lookup_order) {
+			// the host's nodeLookup iteration order: the minimizer index enumerates nodes in it (src/MinimizerSeeder.cpp:354-357)
+			if (desc->n_lookup != h.nodeLookup.size()) throw std::runtime_error("lookup_order must list every bigraph node id once");
+			std::unordered_set<int> seen;
+			for (uint64_t i = 0; i < desc->n_lookup; i++)
+				if (!h.nodeLookup.count(desc->lookup_order[i]) || !seen.insert(desc->lookup_order[i]).second) throw std::runtime_error("lookup_order must list every bigraph node id once");
+			h.nodeLookupOrder.assign(desc->lookup_order, desc->lookup_order + desc->n_lookup);
+		}
 		h.finalized = true;
 		h.buildMPC(true);
 		uploadGraph(G);
@@ -846,6 +854,10 @@ int gc_graph_array(const gc_graph* G, const char* name, int64_t** out, uint64_t*
 	else if (nm == "in_off") { v.push_back(0); for (size_t i = 0; i < n; i++) v.push_back(v.back() + (int64_t)g.inNeighbors[i].size()); }
 	else if (nm == "in_adj") for (size_t i = 0; i < n; i++) for (size_t x : g.inNeighbors[i]) v.push_back(x);
 	else if (nm == "mpc_width") for (size_t c = 0; c < g.mpc.size(); c++) v.push_back(g.mpc[c].size());
+	else if (nm == "firstAmbiguous") v.push_back((int64_t)std::min(g.firstAmbiguous, n));
+	else if (nm == "nodeSeq") for (size_t i = 0; i < n && i < g.firstAmbiguous; i++) { v.push_back((int64_t)g.nodeSequences[i][0]); v.push_back((int64_t)g.nodeSequences[i][1]); }   // bit patterns
+	else if (nm == "ambiguousSeq") for (const gc::AmbiguousSeq& a : g.ambiguousNodeSequences) { v.push_back((int64_t)a.A); v.push_back((int64_t)a.T); v.push_back((int64_t)a.C); v.push_back((int64_t)a.G); }
+	else if (nm == "lookupOrder") { if (!g.nodeLookupOrder.empty()) for (int id : g.nodeLookupOrder) v.push_back(id); else for (const auto& kv : g.nodeLookup) v.push_back(kv.first); }
 	else return fail(GC_ERR_INVALID, "unknown graph array " + nm);
 	*out = mallocArray<int64_t>(v.size());
 	memcpy(*out, v.data(), v.size() * sizeof(int64_t));

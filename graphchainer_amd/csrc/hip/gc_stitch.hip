@@ -17,8 +17,8 @@
 // anchors (the chain holds indices into that numbering, as in k_chain) and clear the LDS tables; lane 0 then runs the
 // inherently sequential loop. Its inputs are staged 64 chain anchors at a time: every lane loads one anchor record, the
 // first nodes of its path with their lengths, and tests whether the anchor starts in an out-neighbour of the previous
-// anchor's last node (then the BFS is known to return that one hop), so lane 0 works from LDS and touches global memory
-// only for a longer bridge search. The piece's node set and the BFS's visited map / queue live in LDS; pieces are
+// anchor's last node (then the BFS is known to return that one hop), so lane 0 works from LDS. A longer bridge search is
+// run by the whole wave (adjacency loads in parallel, insertions replayed in the sequential order). The piece's node set and the BFS's visited map / queue live in LDS; pieces are
 // written one after the other into the read's scratch region, and the best one is copied by all lanes into a dense
 // output array (position from an atomic cursor; StitchInfo.start says where).
 // Anything that does not fit - more than STITCH_SET_MAX nodes on a piece, a BFS that visits more than STITCH_BFS_CAP
@@ -60,7 +60,8 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 	__shared__ uint16_t qPre[STITCH_BFS_CAP];
 	uint32_t* const bridge = qDis;   // the path is written out when the search is over and the distances are no longer needed
 	__shared__ StitchAnchor staged[64];
-	__shared__ uint32_t sOverflow, sBestStart, sBestLen;
+	__shared__ uint32_t sOverflow, sBestStart, sBestLen, sSearchFrom;
+	__shared__ long long sSearchLimit;
 	__shared__ unsigned long long sDenseAt;
 	const uint32_t lane = threadIdx.x;
 	for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
@@ -130,8 +131,12 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 				result.cells = cells;
 			}
 		};
-		// getChainPath(S, T, sepLimit): fills bridge[0..n) with the path S..T, returns n (0: not reached)
-		auto findBridge = [&](uint32_t S, uint32_t T, long long sepLimit) -> uint32_t {
+		// getChainPath(S, T, sepLimit) by the whole wave: fills bridge[0..n) with the path S..T, returns n (0: not reached).
+		// Queue entries are expanded 64 at a time: every lane loads the adjacency of one entry (the slow part: dependent global
+		// loads), then all lanes replay the insertions in the reference's order - entry by entry, neighbours in CSR order -
+		// executing the same LDS operations on the same values, so the visiting order, and with it every predecessor, is the
+		// sequential one. Entries appended during a batch are expanded in a later batch, which is still queue order.
+		auto findBridge = [&](uint32_t S, uint32_t T, long long sepLimit, bool& tooWide) -> uint32_t {
 			generation++;
 			const uint32_t tag = generation << 11;
 			auto visit = [&](uint32_t node, uint32_t index) -> bool {   // true: seen before; otherwise recorded as queue entry `index`
@@ -141,21 +146,48 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 					if (qNode[(e & 2047u) - 1] == node) return true;
 				}
 			};
+			// Pruning that cannot change the result: componentNumber never decreases along an edge (it is the topological rank of
+			// the node's strongly connected component, src/AlignmentGraph.cpp:1008), so a node with a larger number than T's has
+			// no path to T, and neither has anything reached through it; and no node that can reach T is ever first discovered
+			// from such a node. Leaving them out of the queue keeps the order, distances and predecessors of all the others, and
+			// ends the common failing search - the next anchor lies upstream of the piece's end - after one expansion.
+			const uint32_t rankT = g.componentNumber[T];
+			if (g.componentNumber[S] > rankT) return 0;
 			uint32_t qLen = 1, found = 0;
 			qNode[0] = S; qDis[0] = 0; qPre[0] = 0;
 			visit(S, 0);
-			for (uint32_t i = 0; !found && i < qLen; i++) {
-				uint32_t s = qNode[i];
-				if ((unsigned long long)qDis[i] > (unsigned long long)sepLimit) continue;
-				for (uint32_t e = g.outOff[s]; e < g.outOff[s + 1]; e++) {
-					uint32_t t = g.outAdj[e];
-					if (qLen >= bfsCap) { overflow = true; why = 2; return 0; }
-					if (visit(t, qLen)) continue;
-					qNode[qLen] = t; qDis[qLen] = qDis[i] + g.nodeLength[t]; qPre[qLen] = (uint16_t)i;
-					qLen++;
-					// the reference finishes s's neighbours before it notices that T was reached; the ones after T cannot
-					// change pre[T] or anything before it on the path, so the search can stop here
-					if (t == T) { found = qLen; break; }
+			for (uint32_t i0 = 0, batch = 0; !found && i0 < qLen; i0 += batch) {
+				batch = qLen - i0 < 64u ? qLen - i0 : 64u;   // the entries that exist now; the ones they append come in a later batch
+				uint32_t deg = 0, e0 = 0, dis = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0, lens = 0, keep = 0;
+				if (lane < batch) {
+					uint32_t s = qNode[i0 + lane];
+					dis = qDis[i0 + lane];
+					if (!((unsigned long long)dis > (unsigned long long)sepLimit)) {
+						e0 = g.outOff[s];
+						deg = g.outOff[s + 1] - e0;
+						if (deg > 0) { t0 = g.outAdj[e0]; lens |= (uint32_t)g.nodeLength[t0]; keep |= g.componentNumber[t0] <= rankT ? 1u : 0u; }
+						if (deg > 1) { t1 = g.outAdj[e0 + 1]; lens |= (uint32_t)g.nodeLength[t1] << 8; keep |= g.componentNumber[t1] <= rankT ? 2u : 0u; }
+						if (deg > 2) { t2 = g.outAdj[e0 + 2]; lens |= (uint32_t)g.nodeLength[t2] << 16; keep |= g.componentNumber[t2] <= rankT ? 4u : 0u; }
+						if (deg > 3) { t3 = g.outAdj[e0 + 3]; lens |= (uint32_t)g.nodeLength[t3] << 24; keep |= g.componentNumber[t3] <= rankT ? 8u : 0u; }
+					}
+				}
+				for (uint32_t l = 0; l < batch && !found; l++) {
+					const uint32_t d = __shfl(deg, l);
+					if (d == 0) continue;
+					const uint32_t dl = __shfl(dis, l), el = __shfl(e0, l), ll = __shfl(lens, l), kp = __shfl(keep, l);
+					const uint32_t n0 = __shfl(t0, l), n1 = __shfl(t1, l), n2 = __shfl(t2, l), n3 = __shfl(t3, l);
+					for (uint32_t k = 0; k < d; k++) {
+						uint32_t t, tLen;
+						if (k < 4) { if (!((kp >> k) & 1u)) continue; t = k == 0 ? n0 : k == 1 ? n1 : k == 2 ? n2 : n3; tLen = (ll >> (8 * k)) & 255u; }
+						else { t = g.outAdj[el + k]; if (g.componentNumber[t] > rankT) continue; tLen = g.nodeLength[t]; }
+						if (qLen >= bfsCap) { tooWide = true; return 0; }
+						if (visit(t, qLen)) continue;
+						qNode[qLen] = t; qDis[qLen] = dl + tLen; qPre[qLen] = (uint16_t)(i0 + l);
+						qLen++;
+						// the reference finishes s's neighbours before it notices that T was reached; the ones after T cannot
+						// change pre[T] or anything before it on the path, so the search can stop here
+						if (t == T) { found = qLen; break; }
+					}
 				}
 			}
 			if (!found) return 0;
@@ -205,37 +237,53 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 			}
 			staged[lane] = sa;
 			__syncthreads();
-			if (lane == 0) {
-				const uint32_t batch = len - c0 < 64u ? len - c0 : 64u;
-				for (uint32_t i = 0; i < batch && !overflow; i++) {
-					const StitchAnchor& a = staged[i];
-					if (a.flags & 2) { overflow = true; why = 3; break; }
-					const uint32_t* apath = pathPool + (((uint64_t)a.pathOffHi << 32) | a.pathOffLo);
-					auto pathNode = [&](uint32_t k) { return k < STITCH_PF_NODES ? a.node[k] : apath[k]; };
-					auto pathNodeLen = [&](uint32_t k) { return k < STITCH_PF_NODES ? (a.nodeLen >> (8 * k)) & 255u : 0u; };
-					if (posLen == 0) {
+			const uint32_t batch = len - c0 < 64u ? len - c0 : 64u;
+			for (uint32_t i = 0; i < batch; i++) {
+				// lane 0, first half: everything up to the point where a bridge search is needed
+				const StitchAnchor& a = staged[i];
+				const uint32_t* apath = pathPool + (((uint64_t)a.pathOffHi << 32) | a.pathOffLo);
+				auto pathNode = [&](uint32_t k) { return k < STITCH_PF_NODES ? a.node[k] : apath[k]; };
+				auto pathNodeLen = [&](uint32_t k) { return k < STITCH_PF_NODES ? (a.nodeLen >> (8 * k)) & 255u : 0u; };
+				const uint32_t head = a.node[0];
+				bool gap = false, search = false, rest = false;
+				uint32_t nBridge = 0;
+				if (lane == 0 && !overflow) {
+					if (a.flags & 2) { overflow = true; why = 3; }
+					else if (posLen == 0) {
 						for (uint32_t k = 0; k < a.pathLen && !overflow; k++) push(pathNode(k), pathNodeLen(k));   // anchor paths are simple: assign == push each
 						firstOffset = a.firstOffset;
 						lastOffset = a.lastOffset;
-						continue;
-					}
-					const uint32_t head = a.node[0];
-					bool gap = head == backNode && colinearGap != -1 && (long long)a.firstOffset - (long long)lastOffset > colinearGap + 1;
-					uint32_t nBridge = 0;
-					if (!contains(head) && backNode != a.firstNode) {
-						if ((a.flags & 1) && a.prevLast == backNode) {
-							// the target is an out-neighbour of the start: the search expands the start whatever the budget (its
-							// distance is 0) and reaches the target at once
-							bridge[0] = backNode; bridge[1] = a.firstNode;
-							nBridge = 2;
-						} else {
-							long long gapLimit = colinearGap;
-							if (gapLimit != -1) gapLimit -= (long long)a.firstOffset + ((long long)backLen - (long long)lastOffset - 1);
-							nBridge = findBridge(backNode, a.firstNode, gapLimit);
-							if (overflow) break;
-							if (nBridge == 0) gap = true;
+					} else {
+						rest = true;
+						gap = head == backNode && colinearGap != -1 && (long long)a.firstOffset - (long long)lastOffset > colinearGap + 1;
+						if (!contains(head) && backNode != a.firstNode) {
+							if ((a.flags & 1) && a.prevLast == backNode) {
+								// the target is an out-neighbour of the start: the search expands the start whatever the budget (its
+								// distance is 0) and reaches the target at once
+								bridge[0] = backNode; bridge[1] = a.firstNode;
+								nBridge = 2;
+							} else {
+								long long gapLimit = colinearGap;
+								if (gapLimit != -1) gapLimit -= (long long)a.firstOffset + ((long long)backLen - (long long)lastOffset - 1);
+								sSearchFrom = backNode; sSearchLimit = gapLimit;
+								search = true;
+							}
 						}
 					}
+				}
+				// all lanes: the bridge search, when lane 0 asked for one
+				if (__shfl((uint32_t)search, 0)) {
+					__syncthreads();
+					bool tooWide = false;
+					uint32_t n = findBridge(sSearchFrom, a.firstNode, sSearchLimit, tooWide);
+					if (lane == 0) {
+						nBridge = n;
+						if (tooWide) { overflow = true; why = 2; }
+						else if (n == 0) gap = true;
+					}
+				}
+				// lane 0, second half
+				if (lane == 0 && rest && !overflow) {
 					if (gap) {
 						keepIfLonger();
 						for (uint32_t k = 0; k < STITCH_SET_SIZE; k++) setKey[k] = STITCH_EMPTY;
@@ -250,8 +298,9 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 					for (uint32_t k = 0; k < a.pathLen && !overflow; k++) { uint32_t node = pathNode(k); if (!contains(node)) push(node, pathNodeLen(k)); }
 					lastOffset = a.lastOffset;
 				}
-				if (overflow) sOverflow = 1;
+				if (__shfl((uint32_t)overflow, 0)) break;
 			}
+			if (lane == 0 && overflow) sOverflow = 1;
 			__syncthreads();
 			if (sOverflow) break;
 		}

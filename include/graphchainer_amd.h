@@ -63,11 +63,12 @@ int gc_graph_create_from_gfa(const char* gfa_path, gc_graph** out);
 
 /* Same, from arrays the existing C++ host already holds (src/AlignmentGraph.h:145-172): for a host that
  * keeps its own AlignmentGraph. Adjacency is CSR in the reference's neighbour order.
- * Caveat: the minimizer index built on such a graph enumerates bigraph nodes in ascending id, whereas the reference
- * enumerates its nodeLookup hash map (src/MinimizerSeeder.cpp:299-365); the two orders can differ, and with them the order of
- * a k-mer's position list and so tie-breaks among equally good seeds. gc_graph_create_from_gfa reproduces the reference's
- * order (same container, same insertion sequence) and is the path the parity tests cover; node names are also only known
- * there (the output encoders print numeric ids otherwise). */
+ * lookup_order (optional): the bigraph node ids in the iteration order of the host's nodeLookup hash map. The reference's
+ * minimizer index enumerates nodes in that order (src/MinimizerSeeder.cpp:299-365), and the order of a k-mer's position
+ * list - and with it tie-breaks among equally good seeds - follows from it; with it the index built on this graph is
+ * identical to the one built on the gc_graph_create_from_gfa graph (tested). Without it (NULL) nodes are enumerated in
+ * ascending id, which can order position lists differently. Node names are only known to gc_graph_create_from_gfa (the
+ * output encoders print numeric ids otherwise). */
 typedef struct gc_graph_desc {
 	uint64_t n_nodes;                 /* split nodes */
 	uint64_t first_ambiguous;         /* nodes >= this index use ambiguous_seq */
@@ -81,6 +82,8 @@ typedef struct gc_graph_desc {
 	const uint32_t* component_number; /* [n] topological rank (src/AlignmentGraph.cpp:1008) */
 	const uint32_t* chain_number;     /* [n] */
 	const uint64_t* chain_approx_pos; /* [n] */
+	const int32_t*  lookup_order;     /* [n_lookup] or NULL, see above */
+	uint64_t n_lookup;
 } gc_graph_desc;
 int gc_graph_create(const gc_graph_desc* desc, gc_graph** out);
 void gc_graph_destroy(gc_graph* g);
@@ -89,7 +92,8 @@ void gc_graph_destroy(gc_graph* g);
 uint64_t gc_graph_num_nodes(const gc_graph* g);
 uint64_t gc_graph_size_bp(const gc_graph* g);
 /* name in {"nodeLength","nodeOffset","nodeIDs","reverse","componentNumber","chainNumber","chainApproxPos",
- * "component_map","out_off","out_adj","in_off","in_adj","mpc_width"}; returns a malloc'd int64 array
+ * "component_map","out_off","out_adj","in_off","in_adj","mpc_width","firstAmbiguous","nodeSeq","ambiguousSeq" (64-bit
+ * patterns, gc_graph_desc layout),"lookupOrder"}; returns a malloc'd int64 array
  * (free with gc_free). */
 int gc_graph_array(const gc_graph* g, const char* name, int64_t** out, uint64_t* count);
 

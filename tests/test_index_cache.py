@@ -120,3 +120,59 @@ def test_loaded_index_matches_built_index(gca, tmp_path, case):
     gca.api.save_index_cache(built_graph, None, only)
     g2, s2 = gca.api.load_index_cache(only)
     assert s2 is None and g2.NodeSize() == built_graph.NodeSize()
+
+
+DESC_ARRAYS = ["nodeLength", "nodeOffset", "nodeIDs", "nodeSeq", "ambiguousSeq", "in_off", "in_adj", "out_off", "out_adj", "componentNumber",
+               "chainNumber", "chainApproxPos", "lookupOrder", "firstAmbiguous"]
+
+
+@pytest.mark.gpu
+def test_graph_from_host_arrays_matches_graph_from_gfa(gca, tmp_path):
+    """gc_graph_create (the entry point for a host that keeps its own AlignmentGraph): handing over the arrays of a graph gives
+    the same MPC index, the same minimizer index (thanks to lookup_order) and the same alignments as building from the GFA.
+    The graph carries IUPAC letters, so both sequence encodings are exercised."""
+    from graphchainer_amd.synth import SynthGraph
+    sg = SynthGraph(60_000, seed=23)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    lines = open(gfa).read().split("\n")
+    touched = 0
+    for i, line in enumerate(lines):
+        if line.startswith("S\t") and touched < 10 and i % 5 == 0:
+            f = line.split("\t")
+            if len(f[2]) >= 20:
+                seq = bytearray(f[2].encode())
+                seq[len(seq) // 3] = ord("NRYKMSW"[touched % 7])
+                f[2] = seq.decode()
+                lines[i] = "\t".join(f)
+                touched += 1
+    assert touched > 0
+    open(gfa, "w").write("\n".join(lines))
+    reads = sg.sample_reads(10, 3000, seed=3)
+    built = gca.AlignmentGraph(gfa)
+    arrays = {name: built.array(name) for name in DESC_ARRAYS}
+    assert int(arrays["firstAmbiguous"][0]) < built.NodeSize()
+    handed = gca.AlignmentGraph.from_arrays(arrays)
+    for name in GRAPH_ARRAYS + DESC_ARRAYS:
+        assert np.array_equal(handed.array(name), built.array(name)), name
+    built_seeder, handed_seeder = gca.MinimizerSeeder(built, 15, 20), gca.MinimizerSeeder(handed, 15, 20)
+    for name in ["kmers", "start", "positions", "maxcount"]:
+        assert np.array_equal(handed_seeder.array(name), built_seeder.array(name)), name
+    results = []
+    for g, s in ((built, built_seeder), (handed, handed_seeder)):
+        results.append(gca.Aligner(g, s, long_pass=True, keep_traces=True).align_batch(gca.ReadBatch(reads)))
+    a, b = results
+    assert int(a["read_chain_off"][-1]) > 0
+    for key in a:
+        if isinstance(a[key], np.ndarray) and key not in ("kernel_us", "host_us"):
+            assert np.array_equal(a[key], b[key]), key
+    # without lookup_order the graph and the k-mer set are still the same; only the order inside position lists may differ
+    plain = gca.AlignmentGraph.from_arrays(arrays, with_lookup_order=False)
+    plain_seeder = gca.MinimizerSeeder(plain, 15, 20)
+    assert np.array_equal(plain_seeder.array("kmers"), built_seeder.array("kmers"))
+    assert np.array_equal(np.sort(plain_seeder.array("positions")), np.sort(built_seeder.array("positions")))
+    # a malformed order is refused
+    bad = dict(arrays)
+    bad["lookupOrder"] = arrays["lookupOrder"][:-1]
+    with pytest.raises(RuntimeError):
+        gca.AlignmentGraph.from_arrays(bad)
