@@ -282,19 +282,24 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 						else if (n == 0) gap = true;
 					}
 				}
-				// lane 0, second half
+				// a gap ends the piece: lane 0 scores it, all lanes empty the node set (pieces end often - every failed bridge -
+				// and one lane clearing 2048 slots each time was most of the kernel's instructions)
+				const bool newPiece = lane == 0 && rest && !overflow && gap;
+				if (newPiece) {
+					keepIfLonger();
+					setCount = 0;
+					pieceStart += posLen;
+					posLen = 0;
+					sumLen = 0;
+					firstOffset = a.firstOffset;
+				}
+				if (__shfl((uint32_t)newPiece, 0)) {
+					for (uint32_t k = lane; k < STITCH_SET_SIZE; k += 64) setKey[k] = STITCH_EMPTY;
+					__syncthreads();
+				}
+				// lane 0, second half: the bridge (when the piece goes on) and the anchor's own path
 				if (lane == 0 && rest && !overflow) {
-					if (gap) {
-						keepIfLonger();
-						for (uint32_t k = 0; k < STITCH_SET_SIZE; k++) setKey[k] = STITCH_EMPTY;
-						setCount = 0;
-						pieceStart += posLen;
-						posLen = 0;
-						sumLen = 0;
-						firstOffset = a.firstOffset;
-					} else {
-						for (uint32_t k = 0; k < nBridge && !overflow; k++) if (!contains(bridge[k])) push(bridge[k], bridge[k] == head ? pathNodeLen(0) : 0u);
-					}
+					if (!gap) for (uint32_t k = 0; k < nBridge && !overflow; k++) if (!contains(bridge[k])) push(bridge[k], bridge[k] == head ? pathNodeLen(0) : 0u);
 					for (uint32_t k = 0; k < a.pathLen && !overflow; k++) { uint32_t node = pathNode(k); if (!contains(node)) push(node, pathNodeLen(k)); }
 					lastOffset = a.lastOffset;
 				}
