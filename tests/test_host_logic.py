@@ -67,3 +67,33 @@ def test_two_rank_gloo_sharding(tmp_path):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29571", str(script)],
                          capture_output=True, text=True, env=env, timeout=300)
     assert "SHARD_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_two_rank_index_cache_handoff(tmp_path):
+    """bench.py's start-up on N > 1 ranks: rank 0 builds the index cache on the host, the others wait at a barrier and take the
+    file (here they verify it on the host; loading it needs a GPU and is covered by the gpu tests)."""
+    script = tmp_path / "worker.py"
+    cache = tmp_path / "shared.gcidx"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        import torch.distributed as dist
+        import graphchainer_amd as gca
+        from graphchainer_amd.sharding import sum_over_ranks
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        gfa = os.path.join({ROOT!r}, "tests", "golden", "syn20k.gfa")
+        if rank == 0:
+            gca.api.build_index_cache(gfa, {str(cache)!r}, 15, 20)
+        dist.barrier()
+        info = gca.api.check_index_cache({str(cache)!r})
+        nodes = sum_over_ranks(info["nodes"], dist)
+        if rank == 0:
+            assert nodes == world * info["nodes"] and info["has_seeder"] == 1
+            print("CACHE_OK")
+        dist.destroy_process_group()
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29573")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29573", str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert "CACHE_OK" in out.stdout, out.stdout + out.stderr
