@@ -196,3 +196,167 @@ def test_fragment_scores_match_unbanded_dp(syn):
         if score == opt:
             exact += 1
     assert exact >= 6
+
+
+# ---- chain stitching against an independent model ---------------------------------------------------------
+
+def _bridge(out_off, out_adj, node_length, start, target, sep_limit):
+    """AlignmentGraph::getChainPath (src/AlignmentGraph.cpp:1866-1916) in plain Python: fewest-hops path by BFS, nodes further
+    than sep_limit bp are not expanded; the distance is compared as an unsigned 64-bit number, so a negative limit is none."""
+    limit = sep_limit % (1 << 64)
+    queue, dist, pre = [start], {start: 0}, {}
+    i = 0
+    while target not in dist and i < len(queue):
+        s = queue[i]
+        i += 1
+        if dist[s] > limit:
+            continue
+        for t in out_adj[out_off[s]:out_off[s + 1]]:
+            t = int(t)
+            if t not in dist:
+                dist[t] = dist[s] + int(node_length[t])
+                pre[t] = s
+                queue.append(t)
+    if target not in dist:
+        return []
+    path = [target]
+    while path[-1] != start:
+        path.append(pre[path[-1]])
+    return path[::-1]
+
+
+def _stitch(arrays, anchors, chain, colinear_gap):
+    """The stitching loop of src/Aligner.cpp:754-822 + the length of pathToTrace (:409-424); returns the cells (node, offset)
+    of the longest piece."""
+    node_length, out_off, out_adj = arrays["nodeLength"], arrays["out_off"], arrays["out_adj"]
+    best, pos_path, nodes, first_off, last_off = [], [], set(), 0, 0
+
+    def cells_of(path, first, last):
+        out = []
+        for node in path:
+            s, l = 0, int(node_length[node])
+            if node == path[0]:
+                s = first
+            elif node == path[-1]:
+                l = last + 1
+            out.extend((node, o) for o in range(s, l))
+        return out
+
+    def keep():
+        nonlocal best
+        c = cells_of(pos_path, first_off, last_off)
+        if len(best) < len(c):
+            best = c
+
+    for index in chain:
+        a = anchors[index]
+        if not pos_path:
+            pos_path = list(a["path"])
+            first_off, last_off = a["first_offset"], a["last_offset"]
+            nodes = set(pos_path)
+            continue
+        gap = a["path"][0] == pos_path[-1] and colinear_gap != -1 and a["first_offset"] - last_off > colinear_gap + 1
+        bridge = []
+        if a["path"][0] not in nodes and pos_path[-1] != a["first_node"]:
+            limit = colinear_gap
+            if limit != -1:
+                limit -= a["first_offset"] + (int(node_length[pos_path[-1]]) - last_off - 1)
+            bridge = _bridge(out_off, out_adj, node_length, pos_path[-1], a["first_node"], limit)
+            if not bridge:
+                gap = True
+        if gap:
+            keep()
+            nodes, pos_path = set(), []
+            first_off = a["first_offset"]
+        else:
+            for j in bridge:
+                if j not in nodes:
+                    nodes.add(j)
+                    pos_path.append(j)
+        for j in a["path"]:
+            if j not in nodes:
+                nodes.add(j)
+                pos_path.append(j)
+        last_off = a["last_offset"]
+    if pos_path:
+        keep()
+    return best
+
+
+@pytest.mark.parametrize("colinear_gap", [10000, 120, -1])
+def test_stitched_paths_match_independent_model(colinear_gap):
+    """The oracle's stitched path of every read (reads of the golden set plus chimeras of them, whose chains break) against a
+    plain-Python restatement of the loop and of the bridge search, written from the same reference lines."""
+    gfa = os.path.join(GOLD, "syn20k.gfa")
+    reads = read_fasta(os.path.join(GOLD, "syn20k.fa"))
+    reads += [reads[0][:900] + reads[1][400:1500], reads[2][:700] + reads[3][1200:2000] + reads[4][:600]]
+    o = Oracle(gfa, colinear_gap=colinear_gap, long_pass=False)
+    res = o.align(reads)
+    arrays = {k: o.graph_array(k) for k in ["nodeLength", "out_off", "out_adj"]}
+    pieces = 0
+    for r in range(len(reads)):
+        a0, a1 = int(res["read_anchor_off"][r]), int(res["read_anchor_off"][r + 1])
+        anchors = []
+        for a in range(a0, a1):
+            p0, p1 = int(res["anchor_path_off"][a]), int(res["anchor_path_off"][a + 1])
+            anchors.append({"path": [int(x) for x in res["anchor_path"][p0:p1]], "first_node": int(res["anchor_first_node"][a]),
+                            "first_offset": int(res["anchor_first_offset"][a]), "last_offset": int(res["anchor_last_offset"][a])})
+        chain = [int(x) for x in res["chain"][int(res["read_chain_off"][r]):int(res["read_chain_off"][r + 1])]]
+        want = _stitch(arrays, anchors, chain, colinear_gap)
+        c0, c1 = int(res["read_path_off"][r]), int(res["read_path_off"][r + 1])
+        got = list(zip((int(x) for x in res["path_node"][c0:c1]), (int(x) for x in res["path_offset"][c0:c1])))
+        assert got == want, f"read {r}: {len(got)} cells, model {len(want)}"
+        pieces += bool(want)
+    assert pieces >= 6
+
+
+def test_bridge_search_rank_pruning_changes_nothing(syn):
+    """k_stitch leaves nodes whose componentNumber exceeds the target's out of its bridge search (gc_stitch.hip). That must not
+    change any result: same path (or same failure) as the plain search, for targets ahead, behind, on the other strand, with
+    and without a budget."""
+    _, arrays = syn
+    node_length, out_off, out_adj, rank = arrays["nodeLength"], arrays["out_off"], arrays["out_adj"], arrays["componentNumber"]
+
+    def pruned(start, target, sep_limit):
+        limit = sep_limit % (1 << 64)
+        if rank[start] > rank[target]:
+            return []
+        queue, dist, pre = [start], {start: 0}, {}
+        i = 0
+        while target not in dist and i < len(queue):
+            s = queue[i]
+            i += 1
+            if dist[s] > limit:
+                continue
+            for t in out_adj[out_off[s]:out_off[s + 1]]:
+                t = int(t)
+                if rank[t] > rank[target] or t in dist:
+                    continue
+                dist[t] = dist[s] + int(node_length[t])
+                pre[t] = s
+                queue.append(t)
+        if target not in dist:
+            return []
+        path = [target]
+        while path[-1] != start:
+            path.append(pre[path[-1]])
+        return path[::-1]
+
+    rng = random.Random(5)
+    n = len(node_length)
+    by_rank = sorted(range(n), key=lambda v: int(rank[v]))
+    found = 0
+    for trial in range(400):
+        s = rng.randrange(n)
+        if trial % 2:
+            t = rng.randrange(n)                                   # anywhere: mostly unreachable
+        else:
+            at = min(n - 1, max(0, by_rank.index(s) + rng.randrange(-20, 120)))
+            t = by_rank[at]                                        # near in topological order: often reachable
+        if s == t:
+            continue
+        for limit in (rng.randrange(0, 3000), -1, -7):
+            want = _bridge(out_off, out_adj, node_length, s, t, limit)
+            assert pruned(s, t, limit) == want, (s, t, limit)
+            found += bool(want)
+    assert found > 50
