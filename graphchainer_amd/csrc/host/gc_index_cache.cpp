@@ -218,6 +218,63 @@ struct Mapping {
 	~Mapping() { if (p) munmap((void*)p, n); }
 };
 
+// Every index stored in the file is checked against the array it points into, so that a file that passes is safe to use
+// without further bounds checks (uploadGraph and the stitching code index these arrays directly).
+void validateGraph(const AlignmentGraph& g, const GraphTables& t)
+{
+	auto bad = [](const char* what) { throw std::runtime_error(std::string("index cache: ") + what); };
+	const size_t n = g.nodeLength.size();
+	if (g.linearizable.size() != n || g.chainNumber.size() != n || g.chainApproxPos.size() != n) bad("inconsistent per-node arrays");
+	const size_t plain = std::min(g.firstAmbiguous, n);
+	if (g.nodeSequences.size() != plain || g.ambiguousNodeSequences.size() != n - plain) bad("sequence arrays do not match the node count");
+	for (size_t i = 0; i < n; i++) {
+		if (g.nodeLength[i] < 1 || g.nodeLength[i] > (size_t)AlignmentGraph::SPLIT_NODE_SIZE) bad("node length outside 1..64");
+		for (size_t v : g.inNeighbors[i]) if (v >= n) bad("in-neighbour outside the graph");
+		for (size_t v : g.outNeighbors[i]) if (v >= n) bad("out-neighbour outside the graph");
+	}
+	const size_t nComp = g.component_ids.size();
+	if (g.topo.size() != nComp || g.topo_ids.size() != nComp || g.mpc.size() != nComp || g.paths.size() != nComp || g.backwards.size() != nComp) bad("inconsistent component tables");
+	size_t members = 0;
+	for (size_t c = 0; c < nComp; c++) {
+		const size_t m = g.component_ids[c].size(), width = g.mpc[c].size();
+		members += m;
+		if (g.topo[c].size() != m || g.topo_ids[c].size() != m || g.paths[c].size() != m || g.backwards[c].size() != m) bad("inconsistent tables inside a component");
+		for (size_t v : g.component_ids[c]) if (v >= n) bad("component member outside the graph");
+		for (size_t v : g.topo[c]) if (v >= m) bad("topological order entry outside its component");
+		for (size_t v : g.topo_ids[c]) if (v >= m) bad("topological position outside its component");
+		for (const auto& path : g.mpc[c]) for (size_t v : path) if (v >= n) bad("path cover node outside the graph");
+		for (const auto& through : g.paths[c]) for (size_t k : through) if (k >= width) bad("path id outside the cover");
+		for (const auto& back : g.backwards[c]) for (const auto& b : back) if (b.first >= m || b.second >= width) bad("backward link outside its component");
+	}
+	if (members != n) bad("components do not partition the graph");
+	for (size_t i = 0; i < n; i++) {
+		if (g.component_map[i] >= nComp) bad("component id outside the table");
+		if (g.component_idx[i] >= g.component_ids[g.component_map[i]].size() || g.component_ids[g.component_map[i]][g.component_idx[i]] != i) bad("component index does not point back at its node");
+	}
+	size_t listed = 0;
+	for (size_t k = 0; k < t.ids.size(); k++) {
+		if (t.ids[k] < 0) bad("negative node id");
+		size_t expect = 0, bp = 0;
+		for (size_t v : t.splitNodes[k]) {
+			if (v >= n || g.nodeIDs[v] != t.ids[k] || g.nodeOffset[v] != expect) bad("split nodes do not tile their original node");
+			expect += (size_t)AlignmentGraph::SPLIT_NODE_SIZE;
+			bp += g.nodeLength[v];
+		}
+		if (bp != t.sizes[k]) bad("original node size does not match its split nodes");
+		listed += t.splitNodes[k].size();
+	}
+	if (listed != n) bad("node lookup does not cover the graph");
+}
+
+void validateSeeder(const MinimizerIndex& idx, size_t nodes)
+{
+	auto bad = [](const char* what) { throw std::runtime_error(std::string("index cache: ") + what); };
+	if (idx.startPos.size() != idx.kmers.size() + 1 || idx.startPos.front() != 0 || idx.startPos.back() != idx.positions.size()) bad("inconsistent minimizer index");
+	for (size_t i = 0; i + 1 < idx.startPos.size(); i++) if (idx.startPos[i] > idx.startPos[i + 1]) bad("minimizer offsets are not monotone");
+	for (size_t i = 0; i + 1 < idx.kmers.size(); i++) if (idx.kmers[i] >= idx.kmers[i + 1]) bad("minimizer k-mers are not sorted");
+	for (uint64_t p : idx.positions) if ((p >> 6) >= nodes) bad("minimizer position outside the graph");
+}
+
 IndexCacheInfo parse(const Mapping& file, AlignmentGraph& g, MinimizerIndex& idx)
 {
 	if (memcmp(file.p, MAGIC, 8) != 0) throw std::runtime_error("not an index cache (bad magic)");
@@ -237,6 +294,7 @@ IndexCacheInfo parse(const Mapping& file, AlignmentGraph& g, MinimizerIndex& idx
 	if (g.nodeOffset.size() != n || g.nodeIDs.size() != n || g.inNeighbors.size() != n || g.outNeighbors.size() != n || g.reverse.size() != n
 		|| g.componentNumber.size() != n || g.component_map.size() != n || g.component_idx.size() != n || !g.finalized)
 		throw std::runtime_error("index cache: inconsistent graph arrays");
+	validateGraph(g, t);
 	g.nodeLookup.reserve(t.ids.size()); g.originalNodeSize.reserve(t.ids.size()); g.originalNodeName.reserve(t.ids.size());
 	for (size_t i = 0; i < t.ids.size(); i++) {
 		g.nodeLookup[t.ids[i]] = std::move(t.splitNodes[i]);
@@ -250,7 +308,7 @@ IndexCacheInfo parse(const Mapping& file, AlignmentGraph& g, MinimizerIndex& idx
 	idx = MinimizerIndex();
 	if (info.hasSeeder) {
 		seederFields(in, idx);
-		if (idx.startPos.size() != idx.kmers.size() + 1 || idx.startPos.back() != idx.positions.size()) throw std::runtime_error("index cache: inconsistent minimizer index");
+		validateSeeder(idx, n);
 	}
 	if (in.at != payload) throw std::runtime_error("index cache: trailing bytes");
 	info.nodes = n; info.bp = g.bpSize; info.kmers = idx.kmers.size(); info.positions = idx.positions.size();

@@ -176,3 +176,54 @@ def test_graph_from_host_arrays_matches_graph_from_gfa(gca, tmp_path):
     bad["lookupOrder"] = arrays["lookupOrder"][:-1]
     with pytest.raises(RuntimeError):
         gca.AlignmentGraph.from_arrays(bad)
+
+
+def test_corrupt_payload_with_valid_checksum_never_crashes(gca, tmp_path):
+    """The checksum stops accidental damage; behind it the parser bounds every count by the file size and the validator checks
+    every stored index against the array it points into. Files with a mutated payload and a recomputed checksum must be
+    refused or - when the mutation happens to be consistent - accepted, but never crash or hang the process. Run in a child
+    process so that a crash is a test failure, not a dead test runner."""
+    import subprocess
+    import sys
+    import textwrap
+    path = str(tmp_path / "a.gcidx")
+    gca.api.build_index_cache(os.path.join(GOLD, "ref_test_graph.gfa"), path, 15, 20)
+    script = tmp_path / "fuzz.py"
+    script.write_text(textwrap.dedent(f"""
+        import random, sys
+        sys.path.insert(0, {ROOT!r})
+        import graphchainer_amd as gca
+        data = bytearray(open({path!r}, "rb").read())
+        def fnv(b):
+            h = 0xcbf29ce484222325
+            for x in b:
+                h = ((h ^ x) * 0x100000001b3) & 0xffffffffffffffff
+            return h
+        assert fnv(data[:-8]) == int.from_bytes(data[-8:], "little")
+        rng = random.Random(1)
+        refused = accepted = 0
+        for trial in range(300):
+            blob = bytearray(data[:-8])
+            kind = trial % 3
+            at = rng.randrange(9, len(blob))
+            if kind == 0:
+                blob[at] ^= 1 << rng.randrange(8)
+            elif kind == 1:
+                blob[at] = rng.choice([0, 0x7f, 0x80, 0xff])
+            else:
+                del blob[at:at + rng.randrange(1, 9)]
+            blob += fnv(blob).to_bytes(8, "little")
+            open({str(tmp_path / "m.gcidx")!r}, "wb").write(blob)
+            try:
+                gca.api.check_index_cache({str(tmp_path / "m.gcidx")!r})
+                accepted += 1
+            except RuntimeError:
+                refused += 1
+        print("FUZZ_OK", refused, accepted)
+    """))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "FUZZ_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    refused, accepted = int(out.stdout.split()[-2]), int(out.stdout.split()[-1])
+    # most mutations break a structural invariant; the rest change data no invariant covers (a base, a chain label, a k-mer that
+    # stays sorted) - catching those is the checksum's job
+    assert refused + accepted == 300 and refused >= 150
