@@ -1,6 +1,10 @@
 // Host-side construction of the alignment graph ("A0" data).
 // Restates the behaviour of the reference's loaders; every function cites the lines it follows.
 #include "gc_graph.hpp"
+#include <atomic>
+#include <cstdlib>
+#include <exception>
+#include <thread>
 #include <algorithm>
 #include <cassert>
 #include <cmath>
@@ -650,6 +654,12 @@ void AlignmentGraph::computeMPCIndex(size_t cid, const std::vector<std::vector<s
 		}
 }
 
+size_t buildThreads()
+{
+	if (const char* env = getenv("GC_BUILD_THREADS")) { long v = atol(env); if (v >= 1) return (size_t)v; }
+	return std::max(1u, std::thread::hardware_concurrency());
+}
+
 void AlignmentGraph::buildMPC(bool shrinkToMinimum)   // reference: src/AlignmentGraph.cpp:1465-1489
 {
 	buildComponentsMap();
@@ -659,11 +669,31 @@ void AlignmentGraph::buildMPC(bool shrinkToMinimum)   // reference: src/Alignmen
 	topo_ids.assign(C, {});
 	paths.assign(C, {});
 	backwards.assign(C, {});
-	for (size_t cid = 0; cid < C; cid++) {
+	// Components are independent (forward and reverse strand of a connected graph are two) and every step below touches
+	// only its own component's slots, so they are built side by side; the result does not depend on the schedule.
+	auto buildComponent = [&](size_t cid) {
 		mpc[cid] = greedyCover(cid);
 		if (shrinkToMinimum) mpc[cid] = shrink(cid, mpc[cid]);
 		computeMPCIndex(cid, mpc[cid]);
+	};
+	size_t workers = std::min<size_t>(C, buildThreads());
+	if (workers <= 1) {
+		for (size_t cid = 0; cid < C; cid++) buildComponent(cid);
+		return;
 	}
+	std::atomic<size_t> next { 0 };
+	std::vector<std::exception_ptr> errors(workers);
+	std::vector<std::thread> threads;
+	for (size_t t = 0; t < workers; t++)
+		threads.emplace_back([&, t]() {
+			try {
+				for (size_t cid = next++; cid < C; cid = next++) buildComponent(cid);
+			} catch (...) {
+				errors[t] = std::current_exception();
+			}
+		});
+	for (auto& th : threads) th.join();
+	for (auto& e : errors) if (e) std::rethrow_exception(e);
 }
 
 // reference: src/AlignmentGraph.cpp:1866-1916. Unweighted BFS (fewest hops) from S until T is seen;

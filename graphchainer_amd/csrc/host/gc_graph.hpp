@@ -130,6 +130,10 @@ struct MinimizerIndex {
 	static MinimizerIndex Build(const AlignmentGraph& g, size_t k, size_t w, double keepLeastFrequentFraction);
 };
 
+// Threads the start-up builders may use (components of the MPC index, node chunks of the minimizer scan): GC_BUILD_THREADS,
+// default = hardware threads. The results do not depend on it.
+size_t buildThreads();
+
 // 2-bit hash used to pick window minimizers. reference: src/MinimizerSeeder.cpp:45-54
 uint64_t minimizerHash(uint64_t key);
 std::string ReverseComplement(const std::string& s);   // reference: src/CommonUtils.cpp:67-134

@@ -10,6 +10,8 @@
 //   3. maxCount = counts[floor(0.999*n)] + 1 over all keys except "the last MPHF index" (:564).
 //      Which key that is depends on the MPHF and is parity-unpinned; defined here as the largest k-mer.
 #include "gc_graph.hpp"
+#include <exception>
+#include <thread>
 #include <algorithm>
 #include <deque>
 #include <tuple>
@@ -109,22 +111,49 @@ MinimizerIndex MinimizerIndex::Build(const AlignmentGraph& g, size_t k, size_t w
 		for (size_t nb : g.inNeighbors[i])
 			if (g.nodeIDs[nb] != g.nodeIDs[i]) { start = std::max(start, g.nodeOffset[i]); break; }
 	}
-	std::vector<std::pair<uint64_t, uint64_t>> arrivals;   // (kmer, packed position) in arrival order
-	std::string sequence;
 	std::vector<int> idOrder = g.nodeLookupOrder;   // arrival order at -t 1: nodeLookup iteration order (:354-357)
 	if (idOrder.empty()) for (const auto& entry : g.nodeLookup) idOrder.push_back(entry.first);
-	for (int nodeId : idOrder) {
-		const std::vector<size_t>& splitNodes = g.nodeLookup.at(nodeId);
-		sequence.resize(g.originalNodeSize.at(nodeId));
-		size_t at = 0;
-		for (size_t split : splitNodes)
-			for (size_t j = 0; j < g.nodeLength[split]; j++) sequence[at++] = g.NodeSequences(split, j);
-		size_t minStart = nodeMinimizerStart.at(nodeId);
-		forEachWindowMinimizer(sequence, k, w, [&](size_t pos, uint64_t kmer) {
-			if (pos < minStart) return;
-			size_t split = g.GetUnitigNode(nodeId, pos);
-			arrivals.emplace_back(kmer, ((uint64_t)split << 6) + (pos - g.nodeOffset[split]));
-		});
+	// The nodes are scanned in contiguous chunks of that order by several threads; joining the chunks' lists in chunk order
+	// gives the single-threaded arrival order.
+	auto scan = [&](size_t from, size_t to, std::vector<std::pair<uint64_t, uint64_t>>& out) {   // (kmer, packed position)
+		std::string sequence;
+		for (size_t at = from; at < to; at++) {
+			int nodeId = idOrder[at];
+			const std::vector<size_t>& splitNodes = g.nodeLookup.at(nodeId);
+			sequence.resize(g.originalNodeSize.at(nodeId));
+			size_t filled = 0;
+			for (size_t split : splitNodes)
+				for (size_t j = 0; j < g.nodeLength[split]; j++) sequence[filled++] = g.NodeSequences(split, j);
+			size_t minStart = nodeMinimizerStart.at(nodeId);
+			forEachWindowMinimizer(sequence, k, w, [&](size_t pos, uint64_t kmer) {
+				if (pos < minStart) return;
+				size_t split = g.GetUnitigNode(nodeId, pos);
+				out.emplace_back(kmer, ((uint64_t)split << 6) + (pos - g.nodeOffset[split]));
+			});
+		}
+	};
+	std::vector<std::pair<uint64_t, uint64_t>> arrivals;
+	size_t workers = std::min<size_t>(buildThreads(), std::max<size_t>(1, idOrder.size() / 4096));
+	if (workers <= 1) {
+		scan(0, idOrder.size(), arrivals);
+	} else {
+		std::vector<std::vector<std::pair<uint64_t, uint64_t>>> parts(workers);
+		std::vector<std::exception_ptr> errors(workers);
+		std::vector<std::thread> threads;
+		for (size_t t = 0; t < workers; t++)
+			threads.emplace_back([&, t]() {
+				try {
+					scan(idOrder.size() * t / workers, idOrder.size() * (t + 1) / workers, parts[t]);
+				} catch (...) {
+					errors[t] = std::current_exception();
+				}
+			});
+		for (auto& th : threads) th.join();
+		for (auto& e : errors) if (e) std::rethrow_exception(e);
+		size_t total = 0;
+		for (const auto& part : parts) total += part.size();
+		arrivals.reserve(total);
+		for (auto& part : parts) { arrivals.insert(arrivals.end(), part.begin(), part.end()); std::vector<std::pair<uint64_t, uint64_t>>().swap(part); }
 	}
 	// group by k-mer; inside a group the reference's list is the arrivals reversed (:473-482)
 	std::vector<size_t> order(arrivals.size());

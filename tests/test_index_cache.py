@@ -227,3 +227,21 @@ def test_corrupt_payload_with_valid_checksum_never_crashes(gca, tmp_path):
     # most mutations break a structural invariant; the rest change data no invariant covers (a base, a chain label, a k-mer that
     # stays sorted) - catching those is the checksum's job
     assert refused + accepted == 300 and refused >= 150
+
+
+def test_threaded_build_equals_serial_build(gca, tmp_path, monkeypatch):
+    """The start-up builders run MPC components and minimizer node chunks on several threads; the cache they produce is
+    byte-identical to the single-threaded one (a 1.5 Mbp graph: two components, ~130 k bigraph nodes, all threads used)."""
+    from graphchainer_amd.synth import SynthGraph
+    sg = SynthGraph(1_500_000, seed=29)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    monkeypatch.setenv("GC_BUILD_THREADS", "1")
+    gca.api.build_index_cache(gfa, str(tmp_path / "serial.gcidx"), 15, 20)
+    blobs = [open(str(tmp_path / "serial.gcidx"), "rb").read()]
+    for threads in ("2", "5", "8"):
+        monkeypatch.setenv("GC_BUILD_THREADS", threads)
+        gca.api.build_index_cache(gfa, str(tmp_path / "threaded.gcidx"), 15, 20)
+        blobs.append(open(str(tmp_path / "threaded.gcidx"), "rb").read())
+    assert all(b == blobs[0] for b in blobs[1:])
+    assert gca.api.check_index_cache(str(tmp_path / "serial.gcidx"))["kmers"] > 100_000
