@@ -360,3 +360,60 @@ def test_bridge_search_rank_pruning_changes_nothing(syn):
             assert pruned(s, t, limit) == want, (s, t, limit)
             found += bool(want)
     assert found > 50
+
+
+def test_minimizer_index_properties(syn):
+    """The minimizer index against its definition rather than against another sliding-window implementation (k = 15, w = 20,
+    src/MinimizerSeeder.cpp:104-189): (1) every indexed (k-mer, position) is the k-mer that ends there in its node, (2) it has the
+    smallest hash of some window of w - k + 1 consecutive k-mers that contains it (w - k + 2 for a node's first window, as in the
+    reference), (3) every window of w - k + 2 consecutive k-mers holds at least one indexed position - the guarantee seeding
+    relies on, (4) k-mers are sorted and distinct and the position lists partition the positions."""
+    o, arrays = syn
+    k, w = 15, 20
+    per_window = w - k + 1
+    kmers, start, positions = (o.graph_array(n).astype(np.uint64) for n in ("index_kmers", "index_start", "index_positions"))
+    assert np.all(kmers[1:] > kmers[:-1]) and start[0] == 0 and start[-1] == len(positions) and np.all(np.diff(start.astype(np.int64)) > 0)
+    node_ids, node_offset, node_length = arrays["nodeIDs"], arrays["nodeOffset"], arrays["nodeLength"]
+    seq_off = np.concatenate([[0], np.cumsum(node_length)])
+    letters = arrays["sequence"]
+    # original (bigraph) node sequences from their split nodes
+    originals = {}
+    for v in np.argsort(node_ids * (1 << 20) + node_offset, kind="stable"):
+        originals.setdefault(int(node_ids[v]), []).append(bytes(int(c) for c in letters[seq_off[v]:seq_off[v + 1]]))
+    originals = {i: b"".join(parts) for i, parts in originals.items()}
+    code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3}
+    hashed = {}   # node id -> list over end positions of (kmer, hash) or None
+    for i, s in originals.items():
+        row = [None] * len(s)
+        for end in range(k - 1, len(s)):
+            word = s[end - k + 1:end + 1]
+            if all(c in code for c in word):
+                value = 0
+                for c in word:
+                    value = (value << 2) | code[c]
+                row[end] = (value, int(o.lib.gco_minimizer_hash(value)))
+        hashed[i] = row
+    indexed = {i: set() for i in originals}
+    for ki in range(len(kmers)):
+        for p in positions[int(start[ki]):int(start[ki + 1])]:
+            split, off = int(p) >> 6, int(p) & 63
+            i, end = int(node_ids[split]), int(node_offset[split]) + off
+            assert hashed[i][end] is not None and hashed[i][end][0] == int(kmers[ki])            # (1)
+            indexed[i].add(end)
+    checked_windows = 0
+    for i, row in hashed.items():
+        for end in indexed[i]:                                                                   # (2)
+            h = row[end][1]
+            ok = False
+            for size in (per_window, per_window + 1):
+                for first in range(end - size + 1, end + 1):
+                    window = row[max(first, 0):first + size] if first >= 0 else []
+                    if len(window) == size and all(x is not None for x in window) and min(x[1] for x in window) == h:
+                        ok = True
+            assert ok, (i, end)
+        for first in range(k - 1, len(row) - per_window):                                      # (3)
+            window = row[first:first + per_window + 1]
+            if all(x is not None for x in window):
+                assert any(e in indexed[i] for e in range(first, first + per_window + 1)), (i, first)
+                checked_windows += 1
+    assert checked_windows > 10_000 and sum(len(v) for v in indexed.values()) == len(positions)  # (4)
