@@ -417,3 +417,58 @@ def test_minimizer_index_properties(syn):
                 assert any(e in indexed[i] for e in range(first, first + per_window + 1)), (i, first)
                 checked_windows += 1
     assert checked_windows > 10_000 and sum(len(v) for v in indexed.values()) == len(positions)  # (4)
+
+
+def test_whole_read_traces_are_walks_in_the_graph():
+    """Every whole-read alignment trace, read as the reference's output coordinates (bigraph node id, offset in the original
+    node, read position): consecutive cells stay put, advance one base inside the node, or cross a graph edge from a node's
+    last base to the next node's first; read positions advance by 0 or 1 and never both stand still; the trace spans exactly
+    the alignment's read interval; and its unit-cost edit count is the NM the GAF line reports and at least the DP score."""
+    import re
+    gfa = os.path.join(GOLD, "syn20k.gfa")
+    reads = read_fasta(os.path.join(GOLD, "syn20k.fa"))
+    reads.append(reads[0][:900] + reads[1][400:1500])
+    o = Oracle(gfa, long_pass=True)
+    res = o.align(reads)
+    arrays = {k: o.graph_array(k) for k in ["nodeLength", "nodeIDs", "nodeOffset", "sequence", "out_off", "out_adj"]}
+    seq_off = np.concatenate([[0], np.cumsum(arrays["nodeLength"])])
+    original, last_split = {}, {}
+    for v in np.argsort(arrays["nodeIDs"] * (1 << 20) + arrays["nodeOffset"], kind="stable"):
+        i = int(arrays["nodeIDs"][v])
+        original[i] = original.get(i, "") + "".join(chr(c) for c in arrays["sequence"][seq_off[v]:seq_off[v + 1]])
+        last_split[i] = int(v)
+    edges = set()
+    for i, v in last_split.items():
+        for t in arrays["out_adj"][arrays["out_off"][v]:arrays["out_off"][v + 1]]:
+            if int(arrays["nodeIDs"][t]) != i:
+                edges.add((i, int(arrays["nodeIDs"][t])))
+    off, per_read = res["long_trace_off"], res["read_longall_off"]
+    costs = {}
+    for r, read in enumerate(reads):
+        for a in range(int(per_read[r]), int(per_read[r + 1])):
+            n, f, s = (res[k][off[a]:off[a + 1]] for k in ("long_trace_node", "long_trace_offset", "long_trace_seqpos"))
+            assert int(s[0]) == int(res["longall_start"][a]) and int(s[-1]) == int(res["longall_end"][a]) - 1
+            cost = int(original[int(n[0])][f[0]] != read[s[0]])
+            for i in range(1, len(n)):
+                same_place = n[i] == n[i - 1] and f[i] == f[i - 1]
+                read_step = int(s[i]) - int(s[i - 1])
+                assert read_step in (0, 1) and not (same_place and read_step == 0)
+                if not same_place:
+                    if n[i] == n[i - 1]:
+                        assert f[i] == f[i - 1] + 1
+                    else:
+                        assert f[i] == 0 and f[i - 1] == len(original[int(n[i - 1])]) - 1 and (int(n[i - 1]), int(n[i])) in edges
+                cost += 1 if (same_place or read_step == 0) else int(original[int(n[i])][f[i]] != read[s[i]])
+            assert cost >= int(res["longall_score"][a])
+            costs.setdefault((r, int(res["longall_start"][a]), int(res["longall_end"][a])), []).append(cost)
+    assert sum(len(v) for v in costs.values()) >= 8
+    # the GAF lines of the selected alignments report the same edit counts
+    seen = 0
+    for line in o.gaf(False).decode().splitlines():
+        fields = line.split("\t")
+        nm = int(next(x for x in fields if x.startswith("NM:i:"))[5:])
+        key = (int(fields[0][1:]), int(fields[2]), int(fields[3]))
+        if key in costs:
+            seen += 1
+            assert nm in costs[key]   # several alignments of a read can share an interval
+    assert seen >= 6
