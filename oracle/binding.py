@@ -14,9 +14,11 @@ def build():
 
 
 def load_oracle_lib():
-    path = os.path.join(_HERE, "liboracle.so")
-    if not os.path.exists(path):
-        build()
+    path = os.environ.get("GC_ORACLE_LIBRARY")   # a sanitizer build of the oracle (scripts/sanitize_host.sh)
+    if not path:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
     lib = C.CDLL(path)
     lib.gco_create.restype = C.c_void_p
     lib.gco_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int]
