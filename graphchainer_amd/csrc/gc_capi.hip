@@ -214,6 +214,7 @@ struct ReadGlue {
 	std::vector<LongAln> longAlns;        // final order (the reference's repeated sort by alignmentStart)
 	uint64_t longBegin = 0, longTraceBegin = 0, longSeedBegin = 0;
 	bool failed = false;
+	bool longFailed = false;              // the whole-read pass asserted: no anchors, chain or alignment for this read
 	uint64_t slotBegin = 0, fragBegin = 0;
 	uint64_t nAnchors = 0, nPath = 0, nTrace = 0, anchorBegin = 0, pathBegin = 0, traceBegin = 0, seedBegin = 0, chainBegin = 0;
 	StitchedPath stitched;                // chain stitching result
@@ -229,7 +230,7 @@ struct ReadGlue {
 		seeds.clear(); longSeeds.clear(); windows.clear(); longAlns.clear(); longSelected.clear();
 		stitched.nodes.clear(); stitched.firstOffset = stitched.lastOffset = 0; stitched.cells = 0;
 		longBegin = longTraceBegin = longSeedBegin = 0;
-		failed = false;
+		failed = longFailed = false;
 		slotBegin = fragBegin = 0;
 		nAnchors = nPath = nTrace = anchorBegin = pathBegin = traceBegin = seedBegin = chainBegin = 0;
 		stitchedBegin = longSelectedBegin = 0;
@@ -1808,6 +1809,14 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				for (int i = 0; i < 11; i++) fprintf(stderr, "[gc stamps] %-16s %6.2f%%  %.3e lane-cycles\n", names[i], 100.0 * hLongSmall[16 + i] / (total > 0 ? total : 1), (double)hLongSmall[16 + i]);
 			}
 #endif
+			if (const char* env = getenv("GC_TEST_FAIL_LONG")) {   // test hook shared with the oracle: this read's whole-read pass "asserts"
+				long idx = atol(env);
+				if (idx >= 0 && (uint64_t)idx < n) hLongResults[idx].status = 1;
+			}
+			// A whole-read pass that trips one of the reference's live asserts leaves the read with nothing: align_fn's catch sets
+			// `cont` (src/Aligner.cpp:591), which is declared once per read (:529) and makes the fragment loop skip every anchor
+			// (:702-703); the alignments found before the throw are lost with the exception.
+			for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status == 1) { hLongResults[r].nAlignments = 0; glue[r].longFailed = true; }
 			for (uint64_t r = 0; r < n; r++) {
 				if (hLongResults[r].status == 2) throw std::runtime_error("whole-read pass: extension scratch overflow (raise GC_LONG_MAX_ITEMS)");
 				if (hLongResults[r].status == 3) throw std::runtime_error("whole-read pass: more than 32 alignments for one read");
@@ -1834,6 +1843,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		std::vector<uint64_t> seedsExtended(n, 0), seedsExtendedLong(n, 0);
 		auto forEachAnchor = [&](uint64_t r, auto&& visit) {   // visit(slotIndex, fragmentIndex) for every anchor the reference would keep
 			const ReadGlue& gl = glue[r];
+			if (gl.longFailed) return;   // `cont` was already set by the whole-read pass (src/Aligner.cpp:529,591,702)
 			uint64_t slot = gl.slotBegin;
 			for (size_t f = 0; f < gl.windows.size(); f++) {
 				uint64_t F = gl.fragBegin + f;
@@ -1846,6 +1856,14 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		pool.run(n, [&](size_t r, size_t) {
 			ReadGlue& gl = glue[r];
 			failedAssertion[r] = gl.failed ? 1 : 0;
+			if (gl.longFailed) {   // the fragment pipeline ran beside the whole-read pass; what it found for this read is dropped
+				failedAssertion[r] = 1;
+				chainLen[r] = 0; chainScore[r] = 0; chainStatus[r] = 0;
+				gl.stitched = StitchedPath();
+				gl.chainEditDistance = -1;
+				if (P->long_pass) seedsExtendedLong[r] = hLongResults[r].seedsExtended;
+				return;
+			}
 			if (chainStatus[r] != 0) chainFailure = (int)chainStatus[r];
 			for (size_t f = 0; f < gl.windows.size(); f++) {
 				uint64_t F = gl.fragBegin + f;

@@ -101,11 +101,15 @@ public:
 	AlignerCounters counters;
 	double stageSeconds[5] = { 0, 0, 0, 0, 0 };   // seed, long pass, fragments, chaining, stitch+edit distance
 
-	ReadResult alignRead(const std::string& sequence, AlignerState& state)
+	// forceLongAssertion: test hook, makes the whole-read pass end as if one of the reference's live asserts had thrown
+	ReadResult alignRead(const std::string& sequence, AlignerState& state, bool forceLongAssertion = false)
 	{
 		typedef std::chrono::steady_clock clk;
 		auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 		ReadResult res;
+		// `cont` is declared once per read (src/Aligner.cpp:529), set by align_fn's catch (:591) and by "no seed hits" (:551), and
+		// tested after every fragment (:702-703): once the whole-read pass has thrown, no fragment of the read adds an anchor.
+		bool cont = false;
 		// ---- A. whole-read pass (src/Aligner.cpp:630-654 -> align_fn :531-594)
 		if (params.longPass) {
 			auto t0 = clk::now();
@@ -117,13 +121,15 @@ public:
 					orderSeedsByChaining(graph, seeds);
 					GraphAligner aligner(graph, params, true);
 					AlignmentResult r = aligner.AlignOneWay(sequence, seeds, state, 0, seeds.size(), 0);
+					if (forceLongAssertion) throw AssertionFailure("forced by the test hook");
 					res.longAll = r.alignments;
 				} catch (const AssertionFailure&) {
 					state.clear();
 					res.failedAssertion = true;
 					res.longAll.clear();
+					cont = true;   // :591
 				}
-			}
+			} else cont = true;   // :551
 			if (!res.longAll.empty()) res.longAlignments = selectGreedyLength(res.longAll);
 			if (!res.longAlignments.empty()) res.longEditDistance = editDistanceNW(traceToSequence(graph, res.longAlignments[0]), sequence);
 			stageSeconds[1] += secs(t1, clk::now());
@@ -138,7 +144,7 @@ public:
 		std::sort(res.seeds.begin(), res.seeds.end(), [](const SeedHit& l, const SeedHit& r) { return l.seqPos < r.seqPos; });
 		size_t len = params.splitLen, sep = params.splitGap;
 		size_t sl = 0, sr = 0;
-		bool cont = false;   // (sic) never reset once a fragment failed, src/Aligner.cpp:695-703
+		// (cont is also never reset once a fragment has failed, src/Aligner.cpp:695-703)
 		GraphAligner fragmentAligner(graph, params, false);
 		for (size_t l = 0; l + len <= sequence.size(); l += sep) {
 			while (sr < res.seeds.size() && res.seeds[sr].seqPos + res.seeds[sr].matchLen <= l + len) sr++;
@@ -305,7 +311,8 @@ int gco_align(void* hv, const char* bases, const uint64_t* off, int n)
 		std::string seq(bases + off[r], bases + off[r + 1]);
 		ReadResult res;
 		try {
-			res = h->o.alignRead(seq, state);
+			const char* failLong = getenv("GC_TEST_FAIL_LONG");   // test hook shared with the product: index of a read whose whole-read pass "asserts"
+			res = h->o.alignRead(seq, state, failLong && atoi(failLong) == r);
 		} catch (const std::exception& e) {
 			h->error = std::string("read ") + std::to_string(r) + ": " + e.what();
 			return 1;

@@ -180,6 +180,25 @@ def test_whole_read_pass_speculative_rounds(gca, tmp_path, monkeypatch):
     compare(got, want, COMPARE_KEYS + LONG_KEYS)
 
 
+def test_whole_read_assertion_drops_the_read(gca, tmp_path, monkeypatch):
+    """`cont` is one flag per read in the reference (src/Aligner.cpp:529): set by the whole-read pass's catch (:591) it
+    makes the fragment loop skip every anchor (:702), so such a read has no anchors, no chain and no alignment at all.
+    GC_TEST_FAIL_LONG=<read> makes that read's whole-read pass "assert" in the product and in the oracle."""
+    from graphchainer_amd.synth import SynthGraph
+    sg = SynthGraph(60_000, seed=21)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(5, 3000, seed=2)
+    monkeypatch.setenv("GC_TEST_FAIL_LONG", "3")
+    got, want = run_case(gca, gfa, reads, long_pass=True)
+    compare(got, want, COMPARE_KEYS + LONG_KEYS)
+    for key in ("read_anchor_off", "read_chain_off", "read_longall_off", "read_long_off", "read_path_off"):
+        assert got[key][4] == got[key][3], key            # nothing for read 3 ...
+        assert got[key][3] > got[key][2] and got[key][5] > got[key][4], key   # ... and its neighbours are untouched
+    assert list(got["failed_assertion"]) == [0, 0, 0, 1, 0]
+    assert got["chained_better"][3] == 0 and got["chain_edit_distance"][3] == -1 and got["long_edit_distance"][3] == -1
+
+
 @pytest.mark.parametrize("env", [{"GC_LONG_GROUPS": "2"}, {"GC_LONG_TEAM": "8"}, {"GC_LONG_TEAM": "64", "GC_LONG_ORDER": "0"}, {"GC_LONG_MAX_BLOCKS": "7"}, {"GC_LONG_MAX_BLOCKS": "3", "GC_LONG_TEAM": "4"}, {"GC_LONG_REG_CAP": "3"}, {"GC_LONG_REG_CAP": "6", "GC_LONG_MAX_BLOCKS": "5"}])
 def test_whole_read_pass_launch_shapes(gca, tmp_path, monkeypatch, env):
     """Launch-shape knobs of the whole-read pass (concurrent read groups, lanes per wave, execution order, persistent waves, register-table cap -> LDS-table retry) never change results."""

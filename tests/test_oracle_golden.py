@@ -61,6 +61,29 @@ def test_synthetic_golden():
         assert sum(e.get("to_length", 0) for e in edits) == on_read and sum(e.get("from_length", 0) for e in edits) == on_path
 
 
+def test_whole_read_assertion_leaves_the_read_with_nothing(monkeypatch, tmp_path):
+    """src/Aligner.cpp:529,591,702: `cont` is declared once per read; after the whole-read pass has thrown, the fragment loop
+    still runs but keeps no anchor, so the read ends with no anchors, no chain and no alignment. The other reads of the run are
+    unaffected (same arrays as without the hook)."""
+    from graphchainer_amd.synth import SynthGraph
+    sg = SynthGraph(40_000, seed=5)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(3, 2000, seed=3)
+    base = Oracle(gfa, long_pass=True).align(reads)
+    monkeypatch.setenv("GC_TEST_FAIL_LONG", "1")
+    hook = Oracle(gfa, long_pass=True).align(reads)
+    assert list(hook["failed_assertion"]) == [0, 1, 0]
+    for off, keys in (("read_anchor_off", ["anchor_x", "anchor_score", "anchor_first_node"]), ("read_chain_off", ["chain"]),
+                      ("read_longall_off", ["longall_start", "longall_end", "longall_score"]), ("read_path_off", ["path_node", "path_offset"])):
+        assert hook[off][2] == hook[off][1], off
+        assert base[off][2] > base[off][1], off
+        for k in keys:
+            kept = np.concatenate([base[k][:base[off][1]], base[k][base[off][2]:]])
+            assert np.array_equal(hook[k], kept), k
+    assert hook["chain_edit_distance"][1] == -1 and hook["long_edit_distance"][1] == -1 and hook["chained_better"][1] == 0
+
+
 # ---- graph structure properties ---------------------------------------------------------------------
 
 @pytest.fixture(scope="module")
