@@ -45,6 +45,10 @@ def load_oracle_lib():
     lib.gco_edit_distance.argtypes = [C.c_char_p, u64, C.c_char_p, u64]
     lib.gco_minimizer_hash.restype = u64
     lib.gco_minimizer_hash.argtypes = [u64]
+    lib.gco_edit_path.restype = C.c_longlong
+    lib.gco_edit_path.argtypes = [C.c_char_p, u64, C.c_char_p, u64, C.c_void_p, u64, C.POINTER(C.c_longlong)]
+    lib.gco_evalue.argtypes = [C.c_double, u64, u64, u64, u64, C.c_void_p]
+    lib.gco_set_e_cutoff.argtypes = [C.c_void_p, C.c_double]
     return lib
 
 
@@ -61,6 +65,8 @@ RESULT_ARRAYS = [
     "long_trace_off", "long_trace_node", "long_trace_offset", "long_trace_seqpos", "long_trace_switch",
     "read_path_off", "path_node", "path_offset",
     "long_edit_distance", "chain_edit_distance", "chained_better", "failed_assertion", "seeds_extended",
+    "read_chain_ops_off", "chain_ops", "read_chain_trace_off", "chain_trace_node", "chain_trace_offset", "chain_trace_seqpos", "chain_trace_switch",
+    "chain_aln_start", "chain_aln_end",
     "counters", "stage_microseconds",
 ]
 
@@ -69,13 +75,14 @@ class Oracle:
     """CPU restatement of the per-read hot path (reference defaults: src/AlignerMain.cpp:186-209)."""
 
     def __init__(self, gfa_path, k=15, w=20, density=10.0, discard_fraction=0.001, bandwidth=10,
-                 split_len=35, split_gap=35, colinear_gap=10000, long_pass=True, shrink_mpc=True):
+                 split_len=35, split_gap=35, colinear_gap=10000, long_pass=True, shrink_mpc=True, e_cutoff=-1.0):
         self.lib = load_oracle_lib()
         self.h = self.lib.gco_create(gfa_path.encode(), k, w, density, discard_fraction, bandwidth,
                                      split_len, split_gap, colinear_gap, int(long_pass), int(shrink_mpc))
         err = self.lib.gco_error(self.h).decode()
         if err:
             raise RuntimeError(err)
+        self.lib.gco_set_e_cutoff(self.h, float(e_cutoff))
 
     def close(self):
         if self.h:
@@ -145,4 +152,36 @@ class RefUnits:
         lib.ref_correctness_series.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.ref_edit_distance.restype = C.c_longlong
         lib.ref_edit_distance.argtypes = [C.c_char_p, u64, C.c_char_p, u64]
+        lib.ref_edit_path.restype = C.c_longlong
+        lib.ref_edit_path.argtypes = [C.c_char_p, u64, C.c_char_p, u64, C.c_void_p, u64, C.POINTER(C.c_longlong)]
+        lib.ref_evalue.argtypes = [C.c_double, u64, u64, u64, u64, C.c_void_p]
         self.lib = lib
+
+    def edit_path(self, a, b):
+        """edlibAlign(a, b, NW, PATH) of the real edlib: (distance, op string as uint8 array)."""
+        return _edit_path(self.lib.ref_edit_path, a, b)
+
+    def evalue(self, min_identity, database_size, query_size, alignment_length, num_edits):
+        out = np.zeros(2, dtype=np.float64)
+        self.lib.ref_evalue(min_identity, database_size, query_size, alignment_length, num_edits, out.ctypes.data)
+        return out
+
+
+def _edit_path(fn, a, b):
+    buf = np.zeros(len(a) + len(b) + 8, dtype=np.uint8)
+    d = C.c_longlong(-1)
+    n = fn(a, len(a), b, len(b), buf.ctypes.data, len(buf), C.byref(d))
+    if n < 0:
+        raise RuntimeError(f"edit path failed ({n})")
+    return int(d.value), buf[:n].copy()
+
+
+def oracle_edit_path(a, b):
+    """The oracle's restatement of the same call (oracle/edlib_path.hpp)."""
+    return _edit_path(load_oracle_lib().gco_edit_path, a, b)
+
+
+def oracle_evalue(min_identity, database_size, query_size, alignment_length, num_edits):
+    out = np.zeros(2, dtype=np.float64)
+    load_oracle_lib().gco_evalue(min_identity, database_size, query_size, alignment_length, num_edits, out.ctypes.data)
+    return out

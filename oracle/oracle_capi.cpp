@@ -3,6 +3,9 @@
 // Nothing in graphchainer_amd/ may link or call this file.
 #include "pipeline.hpp"
 #include "output.hpp"
+#include "edlib_path.hpp"
+#include "evalue.hpp"
+#include <cstdlib>
 #include <chrono>
 #include <cstring>
 #include <map>
@@ -23,6 +26,8 @@ struct ReadResult {
 	std::vector<AlignmentItem> longAll;         // before selection
 	std::vector<MatrixPosition> longest;        // stitched path cells (node = split node), :754-822
 	size_t longEditDistance = SIZE_MAX, chainEditDistance = SIZE_MAX;
+	std::vector<unsigned char> chainOps;        // edlib's op string for (stitched path, read), :845
+	std::vector<AlignmentItem> chainAlignments; // the chained alignment (:878-897), after the selection of :904
 	bool chainedBetter = false;
 	bool failedAssertion = false;
 	size_t seedsExtended = 0;
@@ -30,6 +35,15 @@ struct ReadResult {
 
 // reference: src/AlignmentSelection.cpp (GreedySelectAlignments with alignmentLengthCompare, :42-50,
 // and the incompatibility rule :12-33)
+// reference: SelectECutoff, src/AlignmentSelection.cpp:91-99 (first step of SelectAlignments when --E-cutoff is given, :57-61)
+static std::vector<AlignmentItem> selectECutoff(const std::vector<AlignmentItem>& all, size_t graphSize, size_t readSize, double cutoff, const EValueCalc& calc)
+{
+	if (cutoff == -1) return all;
+	std::vector<AlignmentItem> result;
+	for (const auto& aln : all) if (calc.getEValue(graphSize, readSize, aln.alignmentEnd - aln.alignmentStart, aln.alignmentScore) <= cutoff) result.push_back(aln);
+	return result;
+}
+
 static std::vector<AlignmentItem> selectGreedyLength(const std::vector<AlignmentItem>& all)
 {
 	std::vector<AlignmentItem> sorted = all;
@@ -99,6 +113,7 @@ public:
 	gc::MinimizerIndex index;
 	Params params;
 	AlignerCounters counters;
+	EValueCalc evalueCalc { .7 };   // src/Aligner.cpp:478-482 (precise clipping off)
 	double stageSeconds[5] = { 0, 0, 0, 0, 0 };   // seed, long pass, fragments, chaining, stitch+edit distance
 
 	// forceLongAssertion: test hook, makes the whole-read pass end as if one of the reference's live asserts had thrown
@@ -130,7 +145,7 @@ public:
 					cont = true;   // :591
 				}
 			} else cont = true;   // :551
-			if (!res.longAll.empty()) res.longAlignments = selectGreedyLength(res.longAll);
+			if (!res.longAll.empty()) res.longAlignments = selectGreedyLength(selectECutoff(res.longAll, graph.SizeInBP(), sequence.size(), params.eCutoff, evalueCalc));
 			if (!res.longAlignments.empty()) res.longEditDistance = editDistanceNW(traceToSequence(graph, res.longAlignments[0]), sequence);
 			stageSeconds[1] += secs(t1, clk::now());
 		}
@@ -243,11 +258,38 @@ private:
 		res.longest = longest;
 		std::string pathseq;
 		for (const auto& p : longest) pathseq.push_back(graph.NodeSequences(p.node, p.nodeOffset));
-		// :845 edlibAlign(pathseq, read, NW). edlib rejects empty inputs? it returns distance = other length; an
-		// empty `longest` produces no alignment item anyway (:890), so the distance is only set when non-empty.
+		// :845 edlibAlign(pathseq, read, NW, PATH) -> :848-876 the op string walked over `longest` and the read (indices clamped to the
+		// last valid cell) -> :878-897 trace items in output coordinates, the alignment item -> :901-905 selection and the decision.
+		// edlibAlign on an empty path returns no alignment; an empty `longest` produces no alignment item anyway (:890).
 		if (!longest.empty()) {
-			res.chainEditDistance = editDistanceNW(pathseq, sequence);
-			res.chainedBetter = res.longAlignments.empty() || res.longEditDistance > res.chainEditDistance;   // :905
+			res.chainEditDistance = (size_t)edlibPathNW(pathseq, sequence, res.chainOps);
+			std::vector<MatrixPosition> cells;
+			size_t pos_i = 0, seq_i = 0;
+			for (unsigned char c : res.chainOps) {
+				cells.push_back(MatrixPosition { longest[pos_i].node, longest[pos_i].nodeOffset, seq_i });
+				if (c == 0 || c == 3) { pos_i++; seq_i++; }
+				else if (c == 1) pos_i++;
+				else if (c == 2) seq_i++;
+				seq_i = std::min(seq_i, sequence.size() - 1);
+				pos_i = std::min(pos_i, longest.size() - 1);
+			}
+			auto trace = std::make_shared<OnewayTrace>();   // trace.score stays 0: the reference never sets it (:739,891-893)
+			for (size_t i = 0; i < cells.size(); i++) {
+				bool nodeSwitch = i + 1 < cells.size() && cells[i].node != cells[i + 1].node;
+				TraceItem item { cells[i], nodeSwitch, cells[i].seqPos < sequence.size() ? sequence[cells[i].seqPos] : '-', graph.NodeSequences(cells[i].node, cells[i].nodeOffset) };
+				item.DPposition.nodeOffset += graph.NodeOffset(item.DPposition.node);
+				item.DPposition.node = (size_t)graph.nodeIDs[item.DPposition.node];
+				trace->trace.push_back(item);
+			}
+			if (!trace->trace.empty()) {
+				AlignmentItem item;
+				item.trace = trace;
+				item.alignmentScore = res.chainEditDistance;
+				item.alignmentStart = trace->trace[0].DPposition.seqPos;
+				item.alignmentEnd = trace->trace.back().DPposition.seqPos + 1;
+				res.chainAlignments = selectECutoff({ item }, graph.SizeInBP(), sequence.size(), params.eCutoff, evalueCalc);   // :904, method All
+			}
+			if (!res.chainAlignments.empty()) res.chainedBetter = res.longAlignments.empty() || res.longEditDistance > res.chainAlignments.front().alignmentScore;   // :905
 		}
 	}
 };
@@ -305,7 +347,7 @@ int gco_align(void* hv, const char* bases, const uint64_t* off, int n)
 	h->o.counters = AlignerCounters();
 	for (double& s : h->o.stageSeconds) s = 0;
 	h->gaf[0].clear(); h->gaf[1].clear(); h->json.clear();
-	const char* names[] = { "read_seed_off", "read_frag_off", "read_anchor_off", "read_chain_off", "read_long_off", "read_longall_off", "read_path_off", "anchor_path_off", "anchor_trace_off", "long_trace_off" };
+	const char* names[] = { "read_seed_off", "read_frag_off", "read_anchor_off", "read_chain_off", "read_long_off", "read_longall_off", "read_path_off", "anchor_path_off", "anchor_trace_off", "long_trace_off", "read_chain_ops_off", "read_chain_trace_off" };
 	for (const char* nm : names) ex[nm].push_back(0);
 	for (int r = 0; r < n; r++) {
 		std::string seq(bases + off[r], bases + off[r + 1]);
@@ -349,11 +391,10 @@ int gco_align(void* hv, const char* bases, const uint64_t* off, int n)
 		for (size_t c : res.chain) ex["chain"].push_back((int64_t)c);
 		ex["read_chain_off"].push_back((int64_t)ex["chain"].size());
 		ex["chain_score"].push_back((int64_t)res.chainScore);
-		// final alignments of the read (src/Aligner.cpp:901-911): the selected whole-read alignments unless the chained one
-		// won (its trace comes from edlib's path mode and is not restated); AddGAFLine each (:1015-1019), sort by
-		// alignmentStart (:1022), one line each (:300-311)
-		if (!res.chainedBetter && !res.longAlignments.empty()) {
-			std::vector<AlignmentItem> finalAlns = res.longAlignments;
+		// final alignments of the read (src/Aligner.cpp:901-920): the chained alignment when it won, else the selected whole-read
+		// alignments; AddAlignment / AddGAFLine each (:1006-1019), sorted by alignmentStart (:1003,:1023), one line each (:300-311)
+		{
+			std::vector<AlignmentItem> finalAlns = res.chainedBetter ? res.chainAlignments : res.longAlignments;
 			auto byStart = [](const AlignmentItem& l, const AlignmentItem& rr) { return l.alignmentStart < rr.alignmentStart; };
 			std::sort(finalAlns.begin(), finalAlns.end(), byStart);   // :1003
 			std::sort(finalAlns.begin(), finalAlns.end(), byStart);   // :1023 (AddAlignment / AddGAFLine in between do not reorder)
@@ -363,6 +404,19 @@ int gco_align(void* hv, const char* bases, const uint64_t* off, int n)
 				h->json += '\n';
 			}
 		}
+		for (unsigned char c : res.chainOps) ex["chain_ops"].push_back(c);
+		ex["read_chain_ops_off"].push_back((int64_t)ex["chain_ops"].size());
+		for (const AlignmentItem& a : res.chainAlignments) {
+			for (const TraceItem& t : a.trace->trace) {
+				ex["chain_trace_node"].push_back((int64_t)t.DPposition.node);
+				ex["chain_trace_offset"].push_back((int64_t)t.DPposition.nodeOffset);
+				ex["chain_trace_seqpos"].push_back((int64_t)t.DPposition.seqPos);
+				ex["chain_trace_switch"].push_back(t.nodeSwitch ? 1 : 0);
+			}
+		}
+		ex["read_chain_trace_off"].push_back((int64_t)ex["chain_trace_node"].size());
+		ex["chain_aln_start"].push_back(res.chainAlignments.empty() ? -1 : (int64_t)res.chainAlignments[0].alignmentStart);
+		ex["chain_aln_end"].push_back(res.chainAlignments.empty() ? -1 : (int64_t)res.chainAlignments[0].alignmentEnd);
 		auto dumpAlns = [&](const std::vector<AlignmentItem>& alns, const std::string& prefix, bool traces) {
 			for (const AlignmentItem& aln : alns) {
 				ex[prefix + "_start"].push_back((int64_t)aln.alignmentStart);
@@ -465,6 +519,22 @@ void gco_correctness_series(const int* mismatches, int n, double* correct, doubl
 		flags[i] = (st.CurrentlyCorrect() ? 1 : 0) | (st.CorrectFromCorrect() ? 2 : 0) | (st.FalseFromCorrect() ? 4 : 0);
 	}
 }
+// edlibAlign(a, b, NW, PATH) restated (oracle/edlib_path.hpp): returns the op count (0 when no alignment), -2 if cap is too small
+long long gco_edit_path(const char* a, uint64_t na, const char* b, uint64_t nb, unsigned char* ops, uint64_t cap, long long* distance)
+{
+	std::vector<unsigned char> v;
+	*distance = edlibPathNW(std::string(a, a + na), std::string(b, b + nb), v);
+	if (v.size() > cap) return -2;
+	std::copy(v.begin(), v.end(), ops);
+	return (long long)v.size();
+}
+void gco_evalue(double minIdentity, uint64_t databaseSize, uint64_t querySize, uint64_t alignmentLength, uint64_t numEdits, double* out)
+{
+	EValueCalc calc(minIdentity);
+	out[0] = calc.getAlignmentScore(alignmentLength, numEdits);
+	out[1] = calc.getEValue(databaseSize, querySize, alignmentLength, numEdits);
+}
+void gco_set_e_cutoff(void* hv, double cutoff) { ((OracleHandle*)hv)->o.params.eCutoff = cutoff; }
 uint64_t gco_edit_distance(const char* a, uint64_t na, const char* b, uint64_t nb) { return editDistanceNW(std::string(a, a + na), std::string(b, b + nb)); }
 uint64_t gco_minimizer_hash(uint64_t k) { return gc::minimizerHash(k); }
 

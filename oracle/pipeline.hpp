@@ -56,6 +56,7 @@ struct Params {   // defaults: src/AlignerMain.cpp:186-209
 	size_t splitLen = 35, splitGap = 35;
 	long long colinearGap = 10000;
 	bool longPass = true;       // run the whole-read GraphAligner pass (src/Aligner.cpp:630-654)
+	double eCutoff = -1;        // --E-cutoff (src/AlignerMain.cpp:159,271-274): -1 = keep every alignment
 };
 
 // ------------------------------------------------------------------ seeding (K1)

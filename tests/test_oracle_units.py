@@ -149,3 +149,88 @@ def test_edit_distance_matches_edlib(libs):
                 b.insert(i, rng.choice("ACGT"))
         b = "".join(b) or "A"
         assert ora.gco_edit_distance(a.encode(), len(a), b.encode(), len(b)) == ref.ref_edit_distance(a.encode(), len(a), b.encode(), len(b))
+
+
+# ---- edlib PATH mode (src/Aligner.cpp:845) and the E-value (src/EValue.cpp) ----------------------------------------
+
+def _mut(rng, s, rate):
+    out = bytearray()
+    for ch in s:
+        x = rng.random()
+        if x < rate / 3:
+            continue
+        out.append(rng.choice(b"ACGT") if x < 2 * rate / 3 else ch)
+        if rng.random() < rate / 3:
+            out.append(rng.choice(b"ACGT"))
+    return bytes(out)
+
+
+def _rand(rng, n, alphabet=b"ACGT"):
+    return bytes(rng.choice(alphabet) for _ in range(n))
+
+
+def _path_cases(rng):
+    """(query = path letters, target = read): the shapes the chained alignment meets - similar strings, a path that covers
+    only the left / right / middle part of the read (stitching keeps the longest piece), a path with a stretch the read
+    lacks, unrelated strings, repeats (many equally good alignments), IUPAC letters, tiny and empty sides."""
+    for n in (0, 1, 2, 63, 64, 65, 200):
+        q = _rand(rng, n)
+        yield q, _mut(rng, q, 0.15)
+        yield q, _rand(rng, rng.randint(0, 130))
+    for _ in range(30):
+        q = _rand(rng, rng.randint(100, 900))
+        yield q, _mut(rng, q, rng.choice([0.02, 0.1, 0.3]))
+        yield q, _rand(rng, 400) + _mut(rng, q, 0.1)
+        yield q, _mut(rng, q, 0.1) + _rand(rng, 350)
+        yield q, _rand(rng, 150) + _mut(rng, q, 0.08) + _rand(rng, 220)
+        yield q, _mut(rng, q[:len(q) // 3], 0.1) + _mut(rng, q[2 * len(q) // 3:], 0.1)
+    for _ in range(10):
+        unit = _rand(rng, rng.randint(1, 7))
+        q = (unit * 200)[:rng.randint(50, 600)]
+        yield q, _mut(rng, q, 0.1)
+        yield _rand(rng, 300, b"AC"), _rand(rng, 280, b"AC")
+    q = _rand(rng, 500, b"ACGTNRY")
+    yield q, _mut(rng, q, 0.1)
+    # above edlib's 1 MB limit: Hirschberg splits (edlib/src/edlib.cpp:1204-1212), incl. splits on the matrix border
+    for qn in (1500, 2600, 4200):
+        q = _rand(rng, qn)
+        yield q, _mut(rng, q, 0.12)
+        yield q, _rand(rng, 3000) + _mut(rng, q, 0.1)
+        yield q, _mut(rng, q, 0.1) + _rand(rng, 3300)
+        yield q, _rand(rng, 2000) + _mut(rng, q, 0.08) + _rand(rng, 2500)
+        yield q, _mut(rng, q[:qn // 3], 0.1) + _mut(rng, q[2 * qn // 3:], 0.1)
+        yield q[:300], _rand(rng, 9000)
+        yield (b"ACG" * 2000)[:qn], _mut(rng, (b"ACG" * 2000)[:qn], 0.05)
+
+
+def test_edit_path_matches_edlib_op_for_op():
+    """oracle/edlib_path.hpp against the real edlib (oracle/_ref): same distance, same op string, same "no alignment" cases."""
+    from oracle.binding import oracle_edit_path
+    ref = RefUnits()
+    rng = random.Random(2024)
+    n = hirschberg = 0
+    for q, t in _path_cases(rng):
+        want_d, want_ops = ref.edit_path(q, t)
+        got_d, got_ops = oracle_edit_path(q, t)
+        assert got_d == want_d, (len(q), len(t))
+        assert np.array_equal(got_ops, want_ops), (len(q), len(t), want_d)
+        if len(want_ops):
+            # an op string is an alignment: it consumes both strings and costs the distance
+            assert np.sum(want_ops != 2) == len(q) and np.sum(want_ops != 1) == len(t) and np.sum(want_ops != 0) == want_d
+        n += 1
+        hirschberg += (20 * ((len(q) + 63) // 64) + 8) * len(t) >= 1 << 20
+    assert n > 200 and hirschberg >= 15
+
+
+def test_evalue_matches_reference_bitwise():
+    from oracle.binding import oracle_evalue
+    ref = RefUnits()
+    rng = random.Random(7)
+    for _ in range(300):
+        ident = rng.choice([0.7, 0.5, 0.66, 0.9, rng.uniform(0.05, 0.95)])
+        db, q = rng.randint(1, 10**10), rng.randint(1, 10**5)
+        length = rng.randint(0, 60000)
+        edits = rng.randint(0, max(1, length))
+        want = ref.evalue(ident, db, q, length, edits)
+        got = oracle_evalue(ident, db, q, length, edits)
+        assert want.tobytes() == got.tobytes(), (ident, db, q, length, edits, want, got)
