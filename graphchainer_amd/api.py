@@ -21,14 +21,15 @@ EXPORTED_SYMBOLS = [
     "gc_params_default", "gc_graph_create_from_gfa", "gc_graph_create", "gc_graph_destroy", "gc_graph_num_nodes",
     "gc_graph_size_bp", "gc_graph_array", "gc_seeder_create", "gc_seeder_destroy", "gc_seeder_array",
     "gc_stream_create", "gc_stream_destroy", "gc_reads_upload", "gc_reads_destroy", "gc_align_batch",
-    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_edit_distance", "gc_format_gaf", "gc_format_json", "gc_format_gam",
+    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_edit_distance", "gc_edit_path", "gc_evalue", "gc_format_gaf", "gc_format_json", "gc_format_gam",
     "gc_index_build", "gc_index_save", "gc_index_load", "gc_index_check",
 ]
 
 
 class GcParams(C.Structure):
     _fields_ = [("bandwidth", C.c_int32), ("split_len", C.c_int32), ("split_gap", C.c_int32), ("colinear_gap", C.c_int64),
-                ("seed_density", C.c_double), ("min_cluster_size", C.c_int32), ("long_pass", C.c_int32), ("keep_traces", C.c_int32), ("keep_seeds", C.c_int32), ("stitch", C.c_int32), ("edit_distances", C.c_int32)]
+                ("seed_density", C.c_double), ("min_cluster_size", C.c_int32), ("long_pass", C.c_int32), ("keep_traces", C.c_int32), ("keep_seeds", C.c_int32), ("stitch", C.c_int32), ("edit_distances", C.c_int32),
+                ("chain_traces", C.c_int32), ("e_cutoff", C.c_double)]
 
 
 _P = C.POINTER
@@ -52,6 +53,8 @@ class GcResult(C.Structure):
         ("failed_assertion", _P(C.c_uint8)), ("seeds_extended", _P(C.c_uint64)), ("seeds_extended_long", _P(C.c_uint64)),
         ("read_path_off", _P(C.c_uint64)), ("path_node", _P(C.c_uint32)), ("path_first_offset", _P(C.c_uint32)), ("path_last_offset", _P(C.c_uint32)), ("path_cells", _P(C.c_uint64)),
         ("read_long_off", _P(C.c_uint64)), ("long_index", _P(C.c_uint32)), ("long_edit_distance", _P(C.c_int64)), ("chain_edit_distance", _P(C.c_int64)), ("chained_better", _P(C.c_uint8)),
+        ("read_chain_trace_off", _P(C.c_uint64)), ("chain_trace_node", _P(C.c_int32)), ("chain_trace_offset", _P(C.c_uint32)), ("chain_trace_seqpos", _P(C.c_uint32)), ("chain_trace_switch", _P(C.c_uint8)),
+        ("chain_aln_start", _P(C.c_uint32)), ("chain_aln_end", _P(C.c_uint32)),
         ("counters", C.c_uint64 * 8), ("counters_long", C.c_uint64 * 8), ("kernel_us", C.c_double * 8), ("host_us", C.c_double * 4),
     ]
 
@@ -124,6 +127,37 @@ def edit_distance(a_list, b_list):
     lib.gc_edit_distance.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p]
     _check(lib.gc_edit_distance(a, a_off.ctypes.data, b, b_off.ctypes.data, n, out.ctypes.data))
     return out[:n]
+
+
+def edit_path(a_list, b_list):
+    """edlibAlign(a, b, NW, EDLIB_TASK_PATH) of each pair on the GPU (src/Aligner.cpp:845): returns (distances, [op arrays]);
+    ops: 0 match, 1 letter of a alone, 2 letter of b alone, 3 mismatch."""
+    assert len(a_list) == len(b_list)
+    lib = load_library()
+    n = len(a_list)
+    a, b = b"".join(a_list), b"".join(b_list)
+    a_off = np.zeros(n + 1, dtype=np.uint64)
+    b_off = np.zeros(n + 1, dtype=np.uint64)
+    a_off[1:] = np.cumsum([len(x) for x in a_list], dtype=np.uint64) if n else []
+    b_off[1:] = np.cumsum([len(x) for x in b_list], dtype=np.uint64) if n else []
+    ops_off = (a_off + b_off).astype(np.uint64)
+    ops = np.zeros(max(int(ops_off[-1]), 1), dtype=np.uint8)
+    ops_len = np.zeros(max(n, 1), dtype=np.uint32)
+    dist = np.zeros(max(n, 1), dtype=np.int64)
+    lib.gc_edit_path.restype = C.c_int
+    lib.gc_edit_path.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(lib.gc_edit_path(a, a_off.ctypes.data, b, b_off.ctypes.data, n, ops_off.ctypes.data, ops.ctypes.data, ops_len.ctypes.data, dist.ctypes.data))
+    return dist[:n], [ops[int(ops_off[i]):int(ops_off[i]) + int(ops_len[i])].copy() for i in range(n)]
+
+
+def evalue(min_identity, database_size, query_size, alignment_length, num_edits):
+    """{alignment score, E-value} of the --E-cutoff model (host only)."""
+    lib = load_library()
+    out = np.zeros(2, dtype=np.float64)
+    lib.gc_evalue.restype = C.c_int
+    lib.gc_evalue.argtypes = [C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+    _check(lib.gc_evalue(min_identity, database_size, query_size, alignment_length, num_edits, out.ctypes.data))
+    return out
 
 
 def _fetch_array(fn, handle, name):
@@ -314,16 +348,22 @@ class _ResultHolder:
             pass
 
 
+class _ResultArray(np.ndarray):
+    """ndarray view of C memory that keeps the owning gc_result alive: every array (and every slice or view made from one, through
+    numpy's .base chain) references the holder, so `x = aligner.align_batch(b)["chain"]` stays valid after the dict is gone."""
+    _holder = None
+
+
 class BatchResult(dict):
-    """dict of numpy arrays that are VIEWS of the C result (no copies on the hot path); the C memory lives as long as this
-    dict does - copy an array (`.copy()`) to keep it longer."""
+    """dict of numpy arrays that are VIEWS of the C result (no copies on the hot path). Each array keeps the C result alive
+    (see _ResultArray); the memory is freed when the last of them goes away."""
     _holder = None
 
 
 class Aligner:
     """Batched stand-in for the reference's per-read hot path (src/Aligner.cpp:601-922)."""
 
-    def __init__(self, graph, seeder, bandwidth=10, split_len=35, split_gap=35, colinear_gap=10000, seed_density=10.0, keep_traces=False, keep_seeds=False, long_pass=False, stitch=True, edit_distances=True):
+    def __init__(self, graph, seeder, bandwidth=10, split_len=35, split_gap=35, colinear_gap=10000, seed_density=10.0, keep_traces=False, keep_seeds=False, long_pass=False, stitch=True, edit_distances=True, chain_traces=1, e_cutoff=-1.0):
         self.lib = load_library()
         self.graph = graph
         self.seeder = seeder
@@ -339,6 +379,8 @@ class Aligner:
         self.params.long_pass = int(long_pass)
         self.params.stitch = int(stitch)
         self.params.edit_distances = int(edit_distances)
+        self.params.chain_traces = int(chain_traces)
+        self.params.e_cutoff = float(e_cutoff)
         self.stream = C.c_void_p()
         _check(self.lib.gc_stream_create(C.byref(self.stream)))
 
@@ -370,7 +412,11 @@ class Aligner:
             n = int(r.n_reads)
 
             def arr(ptr, count):
-                return np.ctypeslib.as_array(ptr, shape=(count,)) if count else np.zeros(0, dtype=np.int64)
+                if not count:
+                    return np.zeros(0, dtype=np.int64)
+                a = np.ctypeslib.as_array(ptr, shape=(count,)).view(_ResultArray)
+                a._holder = holder
+                return a
 
             out = BatchResult()
             out._holder = holder
@@ -395,6 +441,12 @@ class Aligner:
             out["long_edit_distance"] = arr(r.long_edit_distance, n)
             out["chain_edit_distance"] = arr(r.chain_edit_distance, n)
             out["chained_better"] = arr(r.chained_better, n)
+            out["read_chain_trace_off"] = arr(r.read_chain_trace_off, n + 1)
+            ctrace = int(out["read_chain_trace_off"][-1])
+            for name in ("chain_trace_node", "chain_trace_offset", "chain_trace_seqpos", "chain_trace_switch"):
+                out[name] = arr(getattr(r, name), ctrace)
+            out["chain_aln_start"] = arr(r.chain_aln_start, n)
+            out["chain_aln_end"] = arr(r.chain_aln_end, n)
             counts = {"n": n, "n+1": n + 1, "seeds": seeds, "anchors": anchors, "paths": paths, "chains": chains, "longs": longs}
             for name, expr in _RESULT_FIELDS.items():
                 if name in out:

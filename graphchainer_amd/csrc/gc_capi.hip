@@ -223,6 +223,11 @@ struct ReadGlue {
 	std::vector<uint32_t> longSelected;   // GreedyLength selection (src/Aligner.cpp:636-639): indices into longAlns
 	uint64_t longSelectedBegin = 0;
 	int64_t longEditDistance = -1, chainEditDistance = -1;
+	// the chained alignment (src/Aligner.cpp:845-897): trace in output coordinates, alignmentStart / alignmentEnd
+	std::vector<int32_t> chainTraceNode; std::vector<uint32_t> chainTraceOffset, chainTraceSeqPos; std::vector<uint8_t> chainTraceSwitch;
+	uint32_t chainAlnStart = 0, chainAlnEnd = 0;
+	bool hasChainAlignment = false, chainWins = false;
+	uint64_t chainTraceBegin = 0;
 	// back to the state of a fresh record, keeping the vectors' storage: the records live in the gc_stream and are reused by
 	// every batch (allocating and destroying 10 k x 6 vectors per batch cost ~10 ms of teardown plus the allocations)
 	void reset()
@@ -235,6 +240,10 @@ struct ReadGlue {
 		nAnchors = nPath = nTrace = anchorBegin = pathBegin = traceBegin = seedBegin = chainBegin = 0;
 		stitchedBegin = longSelectedBegin = 0;
 		longEditDistance = chainEditDistance = -1;
+		chainTraceNode.clear(); chainTraceOffset.clear(); chainTraceSeqPos.clear(); chainTraceSwitch.clear();
+		chainAlnStart = chainAlnEnd = 0;
+		hasChainAlignment = chainWins = false;
+		chainTraceBegin = 0;
 	}
 };
 
@@ -261,6 +270,8 @@ struct gc_stream {
 	DeviceBuffer stitchSlotOf, stitchRegions, stitchNodes, stitchInfo, stitchCursor;   // chain stitching on the device (gc_stitch.hip)
 	PinnedBuffer hStitchNodes, hStitchInfo, hStitchCursor;
 	EditDistanceRun edChainRun;
+	DeviceBuffer edPathJobs, edPathOps, edPathLen, edPathScratch;   // alignment path of the chained alignment (gc_edpath.hip)
+	PinnedBuffer hEdPathJobs, hEdPathOps, hEdPathLen;
 	// whole-read decision (selection + edit distance of the best alignment)
 	struct LongDecision {
 		PinnedBuffer hJobs, hPairs, hOut;
@@ -652,11 +663,58 @@ int gc_edit_distance(const char* a, const uint64_t* a_off, const char* b, const 
 	});
 }
 
+// The alignment path edlib returns for EDLIB_TASK_PATH (src/Aligner.cpp:845), for arbitrary string pairs: k_edit_distance for the
+// distance, k_edit_path for the ops. Rows = a (the reference passes the path letters first), columns = b (the read).
+int gc_edit_path(const char* a, const uint64_t* a_off, const char* b, const uint64_t* b_off, uint64_t n_pairs, const uint64_t* ops_off, uint8_t* ops, uint32_t* ops_len, int64_t* distance)
+{
+	if ((!a && n_pairs) || !a_off || (!b && n_pairs) || !b_off || !ops_off || !ops || !ops_len || !distance) return fail(GC_ERR_INVALID, "null argument");
+	int rc = gc_edit_distance(a, a_off, b, b_off, n_pairs, distance);
+	if (rc != GC_OK) return rc;
+	return guarded([&]() {
+		if (n_pairs == 0) return (int)GC_OK;
+		const uint64_t aBytes = a_off[n_pairs], bBytes = b_off[n_pairs];
+		std::vector<EdPathJob> jobs(n_pairs);
+		uint32_t maxQ = 1, maxT = 1;
+		uint64_t opsEnd = 0;
+		for (uint64_t i = 0; i < n_pairs; i++) {
+			const uint32_t q = (uint32_t)(a_off[i + 1] - a_off[i]), t = (uint32_t)(b_off[i + 1] - b_off[i]);
+			jobs[i] = EdPathJob { a_off[i], b_off[i], ops_off[i], q, t, (int32_t)distance[i], 0 };
+			maxQ = std::max(maxQ, q); maxT = std::max(maxT, t);
+			opsEnd = std::max<uint64_t>(opsEnd, ops_off[i] + q + t);
+		}
+		DeviceBuffer dA, dB, dJobs, dOps, dLen, dScratch;
+		char* pa = dA.reserve<char>(aBytes); char* pb = dB.reserve<char>(bBytes);
+		EdPathJob* pj = dJobs.reserve<EdPathJob>(n_pairs);
+		uint8_t* po = dOps.reserve<uint8_t>(opsEnd);
+		uint32_t* pl = dLen.reserve<uint32_t>(n_pairs);
+		uint8_t* ps = dScratch.reserve<uint8_t>((uint64_t)editPathGridBlocks((uint32_t)n_pairs) * editPathScratchBytes(maxQ, maxT));
+		if (aBytes) HIP_CHECK(hipMemcpy(pa, a, aBytes, hipMemcpyHostToDevice));
+		if (bBytes) HIP_CHECK(hipMemcpy(pb, b, bBytes, hipMemcpyHostToDevice));
+		HIP_CHECK(hipMemcpy(pj, jobs.data(), n_pairs * sizeof(EdPathJob), hipMemcpyHostToDevice));
+		launchEditPath(nullptr, pj, (uint32_t)n_pairs, pa, pb, ps, maxQ, maxT, po, pl);
+		HIP_CHECK(hipDeviceSynchronize());
+		HIP_CHECK(hipMemcpy(ops_len, pl, n_pairs * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		if (opsEnd) HIP_CHECK(hipMemcpy(ops, po, opsEnd, hipMemcpyDeviceToHost));
+		return (int)GC_OK;
+	});
+}
+
+// E-value model of --E-cutoff (host only): out2 = {alignment score, E-value}; what SelectECutoff compares with the cut-off
+// (src/AlignmentSelection.cpp:91-99, src/EValue.cpp:35-48).
+int gc_evalue(double min_identity, uint64_t database_size, uint64_t query_size, uint64_t alignment_length, uint64_t num_edits, double* out2)
+{
+	if (!out2) return fail(GC_ERR_INVALID, "null argument");
+	gc::EValueModel model(min_identity);
+	out2[0] = model.alignmentScore(alignment_length, num_edits);
+	out2[1] = model.evalue(database_size, query_size, alignment_length, num_edits);
+	return GC_OK;
+}
+
 // Output of a batch's final alignments in the reference's formats (src/Aligner.cpp:1003-1023: the read's list sorted by
 // alignmentStart, AddAlignment / AddGAFLine per alignment, sorted again; writeGAMToQueue :261-281, writeJSONToQueue :283-298,
-// writeGAFToQueue :300-311). Needs a result produced with long_pass, keep_traces and edit_distances. Reads whose chained
-// alignment won (chained_better) are skipped and counted: their final trace comes from edlib's path mode, which this
-// library does not restate.
+// writeGAFToQueue :300-311). Needs a result produced with long_pass, keep_traces and edit_distances; a read whose chained
+// alignment won (chained_better) is written from its chain_trace_* arrays (chain_traces >= 1), and counted as skipped only
+// when the result carries no trace for it.
 enum OutputKind { OUT_GAF, OUT_JSON, OUT_GAM };
 static int formatBatch(const gc_graph* G, const gc_result* r, const char* const* read_names, const char* bases, const uint64_t* offsets, OutputKind kind, int cigar_match_mismatch_merge,
 	char** out_text, uint64_t* out_len, uint64_t* n_chained_skipped)
@@ -668,7 +726,25 @@ static int formatBatch(const gc_graph* G, const gc_result* r, const char* const*
 		std::vector<std::string> perRead(n);
 		std::atomic<uint64_t> skipped { 0 };
 		WorkerPool::instance().run(n, [&](size_t i, size_t) {
-			if (r->chained_better[i]) { skipped++; return; }
+			std::string& text = perRead[i];
+			std::vector<std::string> messages;
+			const std::string name = read_names[i] ? read_names[i] : "";
+			const uint64_t len = offsets[i + 1] - offsets[i];
+			if (r->chained_better[i]) {
+				// the chained alignment replaces the whole-read ones (src/Aligner.cpp:901-920): a single item, trace score 0
+				const uint64_t t0 = r->read_chain_trace_off ? r->read_chain_trace_off[i] : 0, t1 = r->read_chain_trace_off ? r->read_chain_trace_off[i + 1] : 0;
+				if (t1 == t0) { skipped++; return; }   // result produced without chain_traces
+				gc::TraceView tv { r->chain_trace_node + t0, r->chain_trace_offset + t0, r->chain_trace_seqpos + t0, r->chain_trace_switch + t0, t1 - t0 };
+				if (kind == OUT_GAF) {
+					text += gc::formatGafLine(G->host, name, bases + offsets[i], len, tv, cigar_match_mismatch_merge != 0);
+					text += '\n';
+				} else {
+					gc::VgAlignment aln = gc::buildVgAlignment(G->host, name, bases + offsets[i], len, tv, 0, r->chain_aln_start[i], r->chain_aln_end[i]);
+					if (kind == OUT_JSON) { text += gc::vgToJson(aln); text += '\n'; }
+					else text = gc::gamGroup({ gc::vgToProtobuf(aln) });
+				}
+				return;
+			}
 			struct Item { uint32_t start; uint64_t aln; };
 			std::vector<Item> items;
 			for (uint64_t k = r->read_long_off[i]; k < r->read_long_off[i + 1]; k++) {
@@ -679,10 +755,6 @@ static int formatBatch(const gc_graph* G, const gc_result* r, const char* const*
 			auto byStart = [](const Item& l, const Item& rr) { return l.start < rr.start; };
 			std::sort(items.begin(), items.end(), byStart);   // src/Aligner.cpp:1003
 			std::sort(items.begin(), items.end(), byStart);   // :1023 (an unstable sort may move ties even in a sorted list)
-			std::string& text = perRead[i];
-			std::vector<std::string> messages;
-			const std::string name = read_names[i] ? read_names[i] : "";
-			const uint64_t len = offsets[i + 1] - offsets[i];
 			for (const Item& it : items) {
 				uint64_t t0 = r->long_trace_off[it.aln], t1 = r->long_trace_off[it.aln + 1];
 				gc::TraceView tv { r->long_trace_node + t0, r->long_trace_offset + t0, r->long_trace_seqpos + t0, r->long_trace_switch + t0, t1 - t0 };
@@ -751,6 +823,8 @@ void gc_params_default(gc_params* p)
 	p->keep_seeds = 0;
 	p->stitch = 1;
 	p->edit_distances = 1;
+	p->chain_traces = 1;
+	p->e_cutoff = -1;
 }
 
 int gc_graph_create_from_gfa(const char* gfa_path, gc_graph** out)
@@ -1142,7 +1216,8 @@ void gc_result_free(gc_result* r)
 		r->anchor_trace_off, r->anchor_trace_node, r->anchor_trace_offset, r->anchor_trace_seqpos, r->anchor_trace_switch, r->read_chain_off, r->chain, r->chain_score,
 		r->read_longall_off, r->longall_start, r->longall_end, r->longall_score, r->long_trace_off, r->long_trace_node, r->long_trace_offset, r->long_trace_seqpos, r->long_trace_switch,
 		r->failed_assertion, r->seeds_extended, r->seeds_extended_long, r->read_path_off, r->path_node, r->path_first_offset, r->path_last_offset, r->path_cells,
-		r->read_long_off, r->long_index, r->long_edit_distance, r->chain_edit_distance, r->chained_better };
+		r->read_long_off, r->long_index, r->long_edit_distance, r->chain_edit_distance, r->chained_better,
+		r->read_chain_trace_off, r->chain_trace_node, r->chain_trace_offset, r->chain_trace_seqpos, r->chain_trace_switch, r->chain_aln_start, r->chain_aln_end };
 	for (void* p : ptrs) free(p);
 	free(r);
 }
@@ -1228,6 +1303,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		// selection, and (queued, not awaited) the path letters + NW edit distance of the best alignment. (Tried: deciding the
 		// reads that are already finished when the rounds turn latency-bound, so these kernels run beside the last rounds - the
 		// rounds slow down by more than the 11 ms the tail saves: 304-319 -> 318-337 ms per batch. So: all reads, after the rounds.)
+		const gc::EValueModel evalueModel(0.7);   // src/Aligner.cpp:478-482 (precise clipping is out of scope)
 		struct DecisionPointers { EdPair* hPairs = nullptr; int64_t* hOut = nullptr; EdPair* dPairs = nullptr; int64_t* dOut = nullptr; char* dLetters = nullptr; uint32_t* dLettersLen = nullptr; } decisionPtr[2];
 		auto decideLongReads = [&](const std::vector<uint32_t>& subset, int slot, hipStream_t q, const std::function<uint32_t(uint32_t)>& nAlnOf, bool usePool = true) {
 			// the reference re-sorts its alignment list by alignmentStart after every accepted alignment
@@ -1245,7 +1321,12 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				}
 				struct Item { uint32_t start, end, score, index; };
 				std::vector<Item> sorted;
-				for (uint32_t a = 0; a < gl.longAlns.size(); a++) sorted.push_back(Item { gl.longAlns[a].start, gl.longAlns[a].end, gl.longAlns[a].score, a });
+				const size_t readLen = R->offsets[r + 1] - R->offsets[r];
+				for (uint32_t a = 0; a < gl.longAlns.size(); a++) {
+					// --E-cutoff: SelectECutoff runs before the greedy selection and keeps the list's order (src/AlignmentSelection.cpp:57-61,91-99)
+					if (!evalueModel.keeps(P->e_cutoff, hg.SizeInBP(), readLen, gl.longAlns[a].end - gl.longAlns[a].start, gl.longAlns[a].score)) continue;
+					sorted.push_back(Item { gl.longAlns[a].start, gl.longAlns[a].end, gl.longAlns[a].score, a });
+				}
 				std::sort(sorted.begin(), sorted.end(), [](const Item& l, const Item& rr) {
 					if ((l.end - l.start) > (rr.end - rr.start)) return true;
 					if ((rr.end - rr.start) > (l.end - l.start)) return false;
@@ -1734,6 +1815,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		// path letters are spelled out on the device from the node path, then the NW kernel; still behind the whole-read pass
 		std::function<void()> finishChainEditDistances;
 		std::vector<uint32_t> pairRead;   // chain pairs -> read
+		const PathSeqJob* chainLetterJobs = nullptr;   // per read: where its stitched path's letters are in dChainLetters
+		const char* dChainLetters = nullptr;
 		if (P->stitch && P->edit_distances) {
 			uint64_t nNodesTotal = 0, nCells = 0;
 			uint32_t nPairs = 0;
@@ -1767,6 +1850,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			if (nNodesTotal) HIP_CHECK(hipMemcpyAsync(dNodes, hNodes, nNodesTotal * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 			if (n) HIP_CHECK(hipMemcpyAsync(dJobsPS, hJobsPS, n * sizeof(PathSeqJob), hipMemcpyHostToDevice, stream));
 			launchChainPathSeq(stream, G->dev, dJobsPS, (uint32_t)n, dStitchNodes, dNodes, dLetters, dLettersLen);
+			chainLetterJobs = hJobsPS;
+			dChainLetters = dLetters;
 			auto readLenOf = [R](uint32_t r) { return (uint32_t)(R->offsets[r + 1] - R->offsets[r]); };
 			launchEditDistances(st->edChainRun, stream, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen, readLenOf);
 			finishChainEditDistances = [=, &glue, &pairRead]() {   // waits for the kernels (they run beside the whole-read pass) and reruns the few pairs that need a wider band
@@ -1836,6 +1921,92 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] after the whole-read pass: selection + its edit distances %.1f ms\n", (nowUs() - tJoined) / 1e3);
 
+		// ---------------- the chained alignment (src/Aligner.cpp:845-905): edlib's alignment path of (stitched path, read) from k_edit_path,
+		// walked over the path cells and the read into the trace; then the decision. Only reads whose chained alignment can still win
+		// (or all with chain_traces == 2) are traced: the path does not change the edit distance that decides.
+		double tChainTrace = nowUs();
+		uint64_t nChainTraced = 0;
+		if (P->stitch && P->edit_distances && chainLetterJobs) {
+			auto beats = [&](const ReadGlue& gl) { return gl.longSelected.empty() || gl.longEditDistance > gl.chainEditDistance; };   // :905
+			std::vector<uint32_t> cand;
+			for (uint64_t r = 0; r < n; r++) {
+				const ReadGlue& gl = glue[r];
+				if (gl.longFailed || gl.stitched.cells == 0 || gl.chainEditDistance < 0) continue;
+				if (P->chain_traces >= 2 || (P->chain_traces == 1 && beats(gl))) cand.push_back((uint32_t)r);
+			}
+			nChainTraced = cand.size();
+			if (!cand.empty()) {
+				const size_t m = cand.size();
+				EdPathJob* hJobsEP = st->hEdPathJobs.reserve<EdPathJob>(m);
+				uint64_t opsTotal = 0;
+				uint32_t maxQ = 1, maxT = 1;
+				for (size_t i = 0; i < m; i++) {
+					const uint32_t r = cand[i];
+					const uint32_t q = (uint32_t)glue[r].stitched.cells, t = (uint32_t)(R->offsets[r + 1] - R->offsets[r]);
+					hJobsEP[i] = EdPathJob { chainLetterJobs[r].outOff, R->offsets[r], opsTotal, q, t, (int32_t)glue[r].chainEditDistance, 0 };
+					opsTotal += (uint64_t)q + t;
+					maxQ = std::max(maxQ, q); maxT = std::max(maxT, t);
+				}
+				EdPathJob* dJobsEP = st->edPathJobs.reserve<EdPathJob>(m);
+				uint8_t* dOps = st->edPathOps.reserve<uint8_t>(opsTotal);
+				uint32_t* dOpsLen = st->edPathLen.reserve<uint32_t>(m);
+				uint8_t* dScratchEP = st->edPathScratch.reserve<uint8_t>((uint64_t)editPathGridBlocks((uint32_t)m) * editPathScratchBytes(maxQ, maxT));
+				uint8_t* hOps = st->hEdPathOps.reserve<uint8_t>(opsTotal);
+				uint32_t* hOpsLen = st->hEdPathLen.reserve<uint32_t>(m);
+				HIP_CHECK(hipMemcpyAsync(dJobsEP, hJobsEP, m * sizeof(EdPathJob), hipMemcpyHostToDevice, stream));
+				launchEditPath(stream, dJobsEP, (uint32_t)m, dChainLetters, R->devBases, dScratchEP, maxQ, maxT, dOps, dOpsLen);
+				HIP_CHECK(hipMemcpyAsync(hOpsLen, dOpsLen, m * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+				HIP_CHECK(hipMemcpyAsync(hOps, dOps, opsTotal, hipMemcpyDeviceToHost, stream));
+				HIP_CHECK(hipStreamSynchronize(stream));
+				pool.run(m, [&](size_t i, size_t) {
+					const uint32_t r = cand[i];
+					ReadGlue& gl = glue[r];
+					const uint64_t readLen = R->offsets[r + 1] - R->offsets[r];
+					// `longest`: one (node, offset) per base of the stitched piece (pathToTrace, src/Aligner.cpp:409-424)
+					std::vector<std::pair<uint32_t, uint32_t>> cells;
+					cells.reserve(gl.stitched.cells);
+					for (uint32_t node : gl.stitched.nodes) {
+						uint32_t S = 0, L = (uint32_t)hg.NodeLength(node);
+						if (node == gl.stitched.nodes[0]) S = gl.stitched.firstOffset;
+						else if (node == gl.stitched.nodes.back()) L = gl.stitched.lastOffset + 1;
+						for (uint32_t o = S; o < L; o++) cells.emplace_back(node, o);
+					}
+					const uint8_t* ops = hOps + hJobsEP[i].opsOff;
+					const uint32_t nOps = hOpsLen[i];
+					if (cells.empty() || nOps == 0) return;   // no alignment from edlib: no chained alignment item (:890)
+					// :848-876: one trace cell per op, recorded before the op advances; indices clamped to the last cell / base
+					uint64_t pos_i = 0, seq_i = 0;
+					gl.chainTraceNode.resize(nOps); gl.chainTraceOffset.resize(nOps); gl.chainTraceSeqPos.resize(nOps); gl.chainTraceSwitch.assign(nOps, 0);
+					uint32_t prevSplit = 0;
+					for (uint32_t j = 0; j < nOps; j++) {
+						const uint32_t node = cells[pos_i].first, off = cells[pos_i].second;
+						gl.chainTraceNode[j] = hg.nodeIDs[node];                       // :886-887 output coordinates
+						gl.chainTraceOffset[j] = (uint32_t)(off + hg.nodeOffset[node]);
+						gl.chainTraceSeqPos[j] = (uint32_t)seq_i;
+						if (j > 0 && node != prevSplit) gl.chainTraceSwitch[j - 1] = 1;      // :880-882 (split nodes compared)
+						prevSplit = node;
+						const uint8_t c = ops[j];
+						if (c == 0 || c == 3) { pos_i++; seq_i++; }
+						else if (c == 1) pos_i++;
+						else if (c == 2) seq_i++;
+						seq_i = std::min<uint64_t>(seq_i, readLen - 1);
+						pos_i = std::min<uint64_t>(pos_i, cells.size() - 1);
+					}
+					gl.chainAlnStart = gl.chainTraceSeqPos[0];
+					gl.chainAlnEnd = gl.chainTraceSeqPos[nOps - 1] + 1;
+					// :904 SelectAlignments(method All) still applies --E-cutoff; :905 the decision
+					gl.hasChainAlignment = evalueModel.keeps(P->e_cutoff, hg.SizeInBP(), readLen, gl.chainAlnEnd - gl.chainAlnStart, (size_t)gl.chainEditDistance);
+					if (!gl.hasChainAlignment) { gl.chainTraceNode.clear(); gl.chainTraceOffset.clear(); gl.chainTraceSeqPos.clear(); gl.chainTraceSwitch.clear(); gl.chainAlnStart = gl.chainAlnEnd = 0; }
+					gl.chainWins = gl.hasChainAlignment && beats(gl);
+				});
+			}
+			if (P->chain_traces == 0) {
+				// no traces asked for: the decision from the distances alone (an alignment edlib cannot build or --E-cutoff drops would differ)
+				for (uint64_t r = 0; r < n; r++) { ReadGlue& gl = glue[r]; gl.chainWins = !gl.longFailed && gl.stitched.cells > 0 && gl.chainEditDistance >= 0 && beats(gl); }
+			}
+		}
+		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] chained alignment traces: %llu reads, %.1f ms\n", (unsigned long long)nChainTraced, (nowUs() - tChainTrace) / 1e3);
+
 		// ---------------- assemble the flat result: count per read, prefix-sum, fill in parallel
 		double tAsm = nowUs();
 		std::atomic<int> overflow { 0 }, chainFailure { 0 };
@@ -1889,7 +2060,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		});
 		if (overflow) throw std::runtime_error("extension capacity overflow in a fragment (raise GC_EXT_MAX_ITEMS / GC_EXT_MAX_PENDING / GC_EXT_MAX_TRACE)");
 		if (chainFailure) throw std::runtime_error("chaining kernel failure (status " + std::to_string((int)chainFailure) + ")");
-		uint64_t nAnchors = 0, nPath = 0, nTrace = 0, nChain = 0, nLong = 0, nLongTrace = 0, nStitched = 0, nLongSelected = 0;
+		uint64_t nAnchors = 0, nPath = 0, nTrace = 0, nChain = 0, nLong = 0, nLongTrace = 0, nStitched = 0, nLongSelected = 0, nChainTrace = 0;
 		for (uint64_t r = 0; r < n; r++) {
 			glue[r].anchorBegin = nAnchors; glue[r].pathBegin = nPath; glue[r].traceBegin = nTrace; glue[r].chainBegin = nChain;
 			glue[r].longBegin = nLong; glue[r].longTraceBegin = nLongTrace;
@@ -1897,6 +2068,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			nLong += glue[r].longAlns.size();
 			glue[r].stitchedBegin = nStitched; nStitched += glue[r].stitched.nodes.size();
 			glue[r].longSelectedBegin = nLongSelected; nLongSelected += glue[r].longSelected.size();
+			glue[r].chainTraceBegin = nChainTrace; nChainTrace += glue[r].chainTraceNode.size();
 			if (P->keep_traces) for (const LongAln& a : glue[r].longAlns) nLongTrace += a.traceLen;
 		}
 		const bool keepSeeds = P->keep_seeds != 0;
@@ -1934,6 +2106,11 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		res->read_path_off[n] = nStitched;
 		res->path_node = mallocArray<uint32_t>(nStitched);
 		res->path_first_offset = mallocArray<uint32_t>(n); res->path_last_offset = mallocArray<uint32_t>(n); res->path_cells = mallocArray<uint64_t>(n);
+		res->read_chain_trace_off = mallocArray<uint64_t>(n + 1);
+		res->read_chain_trace_off[n] = nChainTrace;
+		res->chain_trace_node = mallocArray<int32_t>(nChainTrace); res->chain_trace_offset = mallocArray<uint32_t>(nChainTrace);
+		res->chain_trace_seqpos = mallocArray<uint32_t>(nChainTrace); res->chain_trace_switch = mallocArray<uint8_t>(nChainTrace);
+		res->chain_aln_start = mallocArray<uint32_t>(n); res->chain_aln_end = mallocArray<uint32_t>(n);
 		res->failed_assertion = mallocArray<uint8_t>(n);
 		res->seeds_extended = mallocArray<uint64_t>(n);
 		res->read_seed_off[n] = keepSeeds ? nSeedsTotal : 0; res->read_anchor_off[n] = nAnchors; res->anchor_path_off[nAnchors] = nPath; res->read_chain_off[n] = nChain;
@@ -1957,7 +2134,15 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			res->long_edit_distance[r] = gl.longEditDistance;
 			res->chain_edit_distance[r] = gl.chainEditDistance;
 			// src/Aligner.cpp:901-905: the chained alignment wins when there is no whole-read alignment or its edit distance is larger
-			res->chained_better[r] = (gl.stitched.cells > 0 && gl.chainEditDistance >= 0 && (gl.longSelected.empty() || gl.longEditDistance > gl.chainEditDistance)) ? 1 : 0;
+			res->chained_better[r] = gl.chainWins ? 1 : 0;
+			res->read_chain_trace_off[r] = gl.chainTraceBegin;
+			if (!gl.chainTraceNode.empty()) {
+				memcpy(res->chain_trace_node + gl.chainTraceBegin, gl.chainTraceNode.data(), gl.chainTraceNode.size() * sizeof(int32_t));
+				memcpy(res->chain_trace_offset + gl.chainTraceBegin, gl.chainTraceOffset.data(), gl.chainTraceOffset.size() * sizeof(uint32_t));
+				memcpy(res->chain_trace_seqpos + gl.chainTraceBegin, gl.chainTraceSeqPos.data(), gl.chainTraceSeqPos.size() * sizeof(uint32_t));
+				memcpy(res->chain_trace_switch + gl.chainTraceBegin, gl.chainTraceSwitch.data(), gl.chainTraceSwitch.size());
+			}
+			res->chain_aln_start[r] = gl.chainAlnStart; res->chain_aln_end[r] = gl.chainAlnEnd;
 			for (size_t i = 0; i < gl.stitched.nodes.size(); i++) res->path_node[gl.stitchedBegin + i] = gl.stitched.nodes[i];
 			res->path_first_offset[r] = gl.stitched.firstOffset; res->path_last_offset[r] = gl.stitched.lastOffset; res->path_cells[r] = gl.stitched.cells;
 			{

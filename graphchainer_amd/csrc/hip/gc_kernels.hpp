@@ -182,6 +182,21 @@ void launchChainPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* j
 uint32_t editDistanceMaxK(uint32_t unitBlocks);
 void launchEditDistance(hipStream_t stream, uint32_t unitBlocks, const EdPair* pairs, uint32_t nPairs, const EdRead* reads, const char* bases, const uint64_t* eqMasks,
 	const char* letters, const uint32_t* lettersLen, int64_t* outDistance);
+// ---- alignment path of (stitched chain path, read): edlib's EDLIB_TASK_PATH (gc_edpath.hip) ----
+struct EdPathJob {
+	uint64_t queryOff;            // path letters (rows), in `letters`
+	uint64_t targetOff;           // read bases (columns), in `bases`
+	uint64_t opsOff;              // where the op string goes (capacity queryLen + targetLen)
+	uint32_t queryLen, targetLen;
+	int32_t best;                 // their NW edit distance (from k_edit_distance)
+	uint32_t pad;
+};
+#define ED_PATH_LEAF_CELLS 52432ull   // blocks x columns of a directly traced sub-problem: 20 * cells + 8 * columns < 1 MB (edlib/src/edlib.cpp:1204-1207)
+uint64_t editPathScratchBytes(uint32_t maxQ, uint32_t maxT);   // per resident wave
+uint32_t editPathGridBlocks(uint32_t nJobs);
+// ops: 0 match, 1 path letter alone, 2 read base alone, 3 mismatch; opsLen[i] = 0 when edlib would return no alignment
+void launchEditPath(hipStream_t stream, const EdPathJob* jobs, uint32_t nJobs, const char* letters, const char* bases, uint8_t* scratch, uint32_t maxQ, uint32_t maxT,
+	uint8_t* opsOut, uint32_t* opsLen);
 void launchLongOrder(hipStream_t stream, const uint32_t* workLen, const unsigned long long* workCount, uint32_t* order, uint32_t maxLen, uint32_t mode);
 void launchPublish(hipStream_t stream, const unsigned long long* src, unsigned long long* dst, uint32_t nWords);
 void launchLongFinish(hipStream_t stream, uint32_t nReads, const LongState* state, LongReadResult* results);

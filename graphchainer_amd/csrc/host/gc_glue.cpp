@@ -1,6 +1,7 @@
 #include "gc_glue.hpp"
 #include <algorithm>
 #include <climits>
+#include <cmath>
 
 namespace gc {
 
@@ -89,6 +90,49 @@ void fragmentWindows(std::vector<SeedRec>& seeds, size_t readLength, size_t spli
 		if (sl >= sr) continue;
 		out.push_back({ (uint32_t)l, (uint32_t)sl, (uint32_t)sr });
 	}
+}
+
+static const double kEuler = 2.71828182845904523536028747135266249775724709369995;
+
+EValueModel::EValueModel(double minIdentity) : match(1), mismatch(-minIdentity / (1.0 - minIdentity)), lambda(-1), K(-1)
+{
+	// lambda solves E[e^(lambda * score)] = 1 for a fair match / mismatch coin; bisection on (0, 0.7) (src/EValue.cpp:50-76)
+	double below = 0, above = 0.7;
+	for (int step = 0; step < 100 && below != above; step++) {
+		const double mid = (below + above) * 0.5;
+		const double f = pow(kEuler, mid * match) * .5 + pow(kEuler, mid * mismatch) * 0.5 - 1;
+		if (f < 0) below = mid;
+		else if (f > 0) above = mid;
+		else { below = above = mid; }
+	}
+	lambda = (below + above) / 2;
+	// K from nine terms of the series over binomially distributed scores (src/EValue.cpp:78-105)
+	double series = 0;
+	std::vector<size_t> binom { 1 };
+	for (int k = 1; k < 10; k++) {
+		binom.push_back(0);
+		for (size_t j = binom.size() - 1; j > 0; j--) binom[j] += binom[j - 1];   // next row of Pascal's triangle, in place
+		size_t rowSum = 0;
+		for (size_t n : binom) rowSum += n;
+		double negativePart = 0, nonNegativeMass = 0;
+		for (size_t j = 0; j < binom.size(); j++) {
+			const double score = (double)j * match + (double)(binom.size() - 1 - j) * mismatch;
+			const double p = (double)binom[j] / (double)rowSum;
+			if (score < 0) negativePart += pow(kEuler, lambda * score) * p;
+			if (score >= 0) nonNegativeMass += p;
+		}
+		series += (negativePart + nonNegativeMass) / (double)k;
+	}
+	const double meanWeighted = .5 * match * pow(kEuler, lambda * match) + .5 * mismatch * pow(kEuler, lambda * mismatch);
+	const double cStar = pow(kEuler, -2 * series) / (lambda * meanWeighted);
+	K = cStar * lambda / (1.0 - pow(kEuler, -lambda));
+}
+
+double EValueModel::alignmentScore(size_t alignmentLength, size_t numEdits) const { return alignmentLength * match - numEdits * (mismatch - match); }
+
+double EValueModel::evalue(size_t databaseSize, size_t querySize, size_t alignmentLength, size_t numEdits) const
+{
+	return K * databaseSize * querySize * pow(kEuler, -lambda * alignmentScore(alignmentLength, numEdits));
 }
 
 } // namespace gc

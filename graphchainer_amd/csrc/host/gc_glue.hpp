@@ -43,4 +43,17 @@ bool orderSeedsByChaining(const AlignmentGraph& graph, std::vector<SeedRec>& see
 // reference: the fragment loop of src/Aligner.cpp:667-679 (sort by seqPos, then the two-pointer window)
 void fragmentWindows(std::vector<SeedRec>& seeds, size_t readLength, size_t splitLen, size_t splitGap, std::vector<FragmentWindow>& out);
 
+// E-value of an alignment for --E-cutoff (reference: EValueCalculator, src/EValue.cpp:16-105; used by SelectECutoff,
+// src/AlignmentSelection.cpp:91-99, with the 70 % identity model of src/Aligner.cpp:478-482). Doubles, the reference's operation
+// order and the same libm, so the keep / drop decision is the reference's.
+class EValueModel {
+public:
+	explicit EValueModel(double minIdentity = 0.7);
+	double alignmentScore(size_t alignmentLength, size_t numEdits) const;
+	double evalue(size_t databaseSize, size_t querySize, size_t alignmentLength, size_t numEdits) const;
+	bool keeps(double cutoff, size_t databaseSize, size_t querySize, size_t alignmentLength, size_t numEdits) const { return cutoff == -1 || evalue(databaseSize, querySize, alignmentLength, numEdits) <= cutoff; }
+private:
+	double match, mismatch, lambda, K;
+};
+
 } // namespace gc

@@ -51,6 +51,11 @@ typedef struct gc_params {
 	int32_t stitch;             /* 1: stitch the chain into one path (src/Aligner.cpp:754-822): read_path_off / path_* */
 	int32_t edit_distances;     /* 1: GreedyLength selection of the whole-read alignments and the two NW edit distances that pick
 	                             *    the winner (src/Aligner.cpp:636-654,845,901-905): read_long_off / long_index / *_edit_distance / chained_better */
+	int32_t chain_traces;       /* the chained alignment's trace (edlibAlign(pathseq, read, NW, EDLIB_TASK_PATH) walked over the stitched path,
+	                             *    src/Aligner.cpp:845-897): 0 none, 1 for the reads whose chained alignment wins (default; what the output
+	                             *    encoders need), 2 for every read with a stitched path. Needs stitch and edit_distances. */
+	double  e_cutoff;           /* --E-cutoff (src/AlignerMain.cpp:159,271-274; SelectECutoff src/AlignmentSelection.cpp:57-61,91-99):
+	                             *    alignments with a larger E-value are dropped before selection; -1 (default) keeps all */
 } gc_params;
 
 void gc_params_default(gc_params* p);
@@ -175,6 +180,12 @@ typedef struct gc_result {
 	uint32_t* long_index;
 	int64_t*  long_edit_distance; int64_t* chain_edit_distance;   /* [n_reads] */
 	uint8_t*  chained_better;     /* [n_reads] 1: the chained alignment is the read's result, 0: the selected whole-read alignments are */
+	/* the chained alignment (chain_traces): its trace in output coordinates like long_trace_* (bigraph node id, offset in the original
+	 * node, read position, "next cell is in another split node"), one cell per op of edlib's alignment (src/Aligner.cpp:855-887);
+	 * alignmentStart / alignmentEnd (:894-895). Its alignmentScore is chain_edit_distance, its trace score 0 (never set, :739,891). */
+	uint64_t* read_chain_trace_off; /* [n_reads+1] */
+	int32_t*  chain_trace_node; uint32_t* chain_trace_offset; uint32_t* chain_trace_seqpos; uint8_t* chain_trace_switch;
+	uint32_t* chain_aln_start; uint32_t* chain_aln_end;   /* [n_reads]; 0,0 where there is no chained alignment */
 	/* work counters of the fragment pass: [0] dp tiles, [1] recompute tiles (last-slice flatten + backtrace),
 	 * [2] column steps, [3] trace items, [4] extensions, [5] backtrace tiles (subset of [1]);
 	 * [7] reads whose chain was stitched on the host because it did not fit the stitching kernel's tables */
@@ -200,15 +211,26 @@ void gc_free(void* p);
  * edlibAlign(a, |a|, b, |b|, edlibNewAlignConfig(-1, EDLIB_MODE_NW, EDLIB_TASK_DISTANCE, NULL, 0)).editDistance returns at
  * src/Aligner.cpp:645 and :845 (characters compare by equality, as in edlib's default alphabet handling). */
 int gc_edit_distance(const char* a, const uint64_t* a_off, const char* b, const uint64_t* b_off, uint64_t n_pairs, int64_t* out);
+/* The alignment edlibAlign(a, |a|, b, |b|, edlibNewAlignConfig(-1, EDLIB_MODE_NW, EDLIB_TASK_PATH, NULL, 0)) returns at src/Aligner.cpp:845
+ * for each pair, on the GPU: distance[i] = editDistance, ops (0 match, 1 letter of a alone, 2 letter of b alone, 3 mismatch) of pair i at
+ * ops[ops_off[i] .. ops_off[i] + ops_len[i]); the caller provides ops_off with room for |a_i| + |b_i| ops per pair. ops_len[i] = 0 where
+ * edlib returns no alignment (an empty side). edlib's own choice among the optimal alignments is reproduced (Hirschberg split order and
+ * traceback preference, edlib/src/edlib.cpp:917-1419). */
+int gc_edit_path(const char* a, const uint64_t* a_off, const char* b, const uint64_t* b_off, uint64_t n_pairs, const uint64_t* ops_off, uint8_t* ops, uint32_t* ops_len, int64_t* distance);
+
+/* The E-value --E-cutoff compares (EValueCalculator, src/EValue.cpp; host only, no device needed): out2 = {alignment score, E-value}
+ * of an alignment of alignment_length read bases with num_edits edits, for a graph of database_size bp and a read of query_size bp. */
+int gc_evalue(double min_identity, uint64_t database_size, uint64_t query_size, uint64_t alignment_length, uint64_t num_edits, double* out2);
 
 /* ---- output ------------------------------------------------------------------------ */
 
 /* GAF text of the batch's final alignments, one line per alignment in the reference's order (AddGAFLine +
  * GraphAlignerGAFAlignment::traceToAlignment, src/GraphAlignerGAFAlignment.h:38-196; the per-read list sorted by
  * alignmentStart, src/Aligner.cpp:1022, written by writeGAFToQueue :300-311). `result` must come from gc_align_batch with
- * long_pass, keep_traces and edit_distances; bases/offsets are the read batch as given to gc_reads_upload; read_names[i]
- * is the FASTQ id. Reads whose chained alignment won (chained_better) are skipped and counted in n_chained_skipped: their
- * final trace needs edlib's path mode. *out_text is malloc'd (gc_free), NUL-terminated, *out_len bytes long. */
+ * long_pass, keep_traces, edit_distances and chain_traces >= 1; bases/offsets are the read batch as given to gc_reads_upload;
+ * read_names[i] is the FASTQ id. A read whose chained alignment won (chained_better) is written from its chain_trace_*
+ * (src/Aligner.cpp:901-920); n_chained_skipped counts winners the result holds no trace for (0 unless chain_traces was 0).
+ * *out_text is malloc'd (gc_free), NUL-terminated, *out_len bytes long. */
 int gc_format_gaf(const gc_graph* g, const gc_result* result, const char* const* read_names, const char* bases, const uint64_t* offsets,
                   int cigar_match_mismatch_merge, char** out_text, uint64_t* out_len, uint64_t* n_chained_skipped);
 

@@ -14,7 +14,10 @@ COMPARE_KEYS = [
     "anchor_trace_off", "anchor_trace_node", "anchor_trace_offset", "anchor_trace_seqpos", "anchor_trace_switch",
     "read_chain_off", "chain", "chain_score", "failed_assertion", "seeds_extended",
     "read_path_off", "path_node", "path_offset",
-] + ["chain_edit_distance", "chained_better"]
+] + ["chain_edit_distance", "chained_better"] + [
+    # the chained alignment's trace = edlib's alignment path walked over the stitched path (src/Aligner.cpp:845-897); run_case asks for it for every read
+    "read_chain_trace_off", "chain_trace_node", "chain_trace_offset", "chain_trace_seqpos", "chain_trace_switch", "chain_aln_start", "chain_aln_end",
+]
 
 
 def compare(got, want, keys=COMPARE_KEYS):
@@ -43,15 +46,23 @@ def run_case(gca, gfa, reads, long_pass=False, **kw):
     from oracle import Oracle
     graph = gca.AlignmentGraph(gfa)
     seeder = gca.MinimizerSeeder(graph)
-    aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, long_pass=long_pass, **kw)
+    aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, long_pass=long_pass, chain_traces=2, **kw)
     got = {k: (v.astype(np.int64) if v.dtype.kind in "ui" and k not in ("counters", "counters_long") else v) for k, v in aligner.align_reads(reads).items()}
     expand_stitched_path(got, graph.array("nodeLength"))
+    mark_missing_chain_alignments(got)
     # selected whole-read alignments come back as indices into the read's longall list
     sel = np.repeat(got["read_longall_off"][:-1], np.diff(got["read_long_off"])) + got["long_index"]
     for key in ("start", "end", "score"):
         got["long_" + key] = got["longall_" + key][sel]
     want = Oracle(gfa, long_pass=long_pass, **kw).align(reads)
     return got, want
+
+
+def mark_missing_chain_alignments(got):
+    """The C ABI reports alignmentStart / alignmentEnd as 0, 0 for a read without a chained alignment; the oracle says -1."""
+    none = np.diff(got["read_chain_trace_off"]) == 0
+    for key in ("chain_aln_start", "chain_aln_end"):
+        got[key] = np.where(none, -1, got[key])
 
 
 def expand_stitched_path(got, node_length):
@@ -336,21 +347,95 @@ def test_chained_alignment_wins(gca, tmp_path):
     reads += sg.sample_reads(3, 4000, seed=8)
     graph = gca.AlignmentGraph(gfa)
     seeder = gca.MinimizerSeeder(graph)
-    aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, long_pass=True)
+    aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, long_pass=True)     # chain_traces = 1: winners only
     names = [f"r{i}" for i in range(len(reads))]
-    raw = aligner.align_reads(reads, gaf_names=names)
+    raw = aligner.align_reads(reads, gaf_names=names, other_formats=True)
     got = {k: (v.astype(np.int64) if isinstance(v, np.ndarray) and v.dtype.kind in "ui" and k not in ("counters", "counters_long") else v) for k, v in raw.items()}
     expand_stitched_path(got, graph.array("nodeLength"))
+    mark_missing_chain_alignments(got)
     sel = np.repeat(got["read_longall_off"][:-1], np.diff(got["read_long_off"])) + got["long_index"]
     for key in ("start", "end", "score"):
         got["long_" + key] = got["longall_" + key][sel]
     ora = Oracle(gfa, long_pass=True)
     want = ora.align(reads)
-    compare(got, want, COMPARE_KEYS + LONG_KEYS)
+    winners = want["chained_better"].astype(bool)
+    # the oracle traces every read, this run only the winners: compare the winners' traces, everything else as usual
+    trace_keys = [k for k in COMPARE_KEYS if k.startswith(("read_chain_trace", "chain_trace", "chain_aln"))]
+    compare(got, want, [k for k in COMPARE_KEYS + LONG_KEYS if k not in trace_keys])
+    assert np.array_equal(np.diff(got["read_chain_trace_off"]) > 0, winners)
+    for r in np.nonzero(winners)[0]:
+        g0, g1 = got["read_chain_trace_off"][r], got["read_chain_trace_off"][r + 1]
+        w0, w1 = want["read_chain_trace_off"][r], want["read_chain_trace_off"][r + 1]
+        for k in ("chain_trace_node", "chain_trace_offset", "chain_trace_seqpos", "chain_trace_switch"):
+            assert np.array_equal(got[k][g0:g1], want[k][w0:w1]), (k, r)
+        assert got["chain_aln_start"][r] == want["chain_aln_start"][r] and got["chain_aln_end"][r] == want["chain_aln_end"][r]
     assert int(np.sum(got["chained_better"][:4])) >= 3          # the deletion reads
     assert int(np.sum(got["chained_better"][4:])) == 0           # ordinary reads keep their whole-read alignment
-    assert raw["gaf_chained_skipped"] == int(np.sum(got["chained_better"]))
+    # output: every read is written, the winners from their chained alignment (src/Aligner.cpp:901-920)
+    assert raw["gaf_chained_skipped"] == 0
     assert raw["gaf"] == ora.gaf(False)
+    assert raw["json"] == ora.json()
+    assert raw["gaf"].count(b"\n") >= len(reads)
+    import gzip
+    assert gzip.decompress(raw["gam"])   # framed messages decode (content is checked against the JSON in test_json_and_gam_output)
+
+
+def _path_pairs(rng):
+    """(path letters, read) shapes the chained alignment meets: similar strings, a path covering only part of the read, a path
+    with a stretch the read lacks, unrelated strings, repeats (many optimal alignments), other letters, tiny / empty sides,
+    and sizes on both sides of edlib's 1 MB traceback limit (Hirschberg splits, edlib/src/edlib.cpp:1204-1212)."""
+    rand = lambda n, alphabet=b"ACGT": bytes(rng.choice(alphabet) for _ in range(n))
+    for n in (0, 1, 2, 63, 64, 65, 200):
+        q = rand(n)
+        yield q, _mutate(rng, q, 0.15)
+        yield q, rand(rng.randint(0, 130))
+    for _ in range(12):
+        q = rand(rng.randint(100, 900))
+        yield q, _mutate(rng, q, rng.choice([0.02, 0.1, 0.3]))
+        yield q, rand(400) + _mutate(rng, q, 0.1)
+        yield q, _mutate(rng, q, 0.1) + rand(350)
+        yield q, _mutate(rng, q[:len(q) // 3], 0.1) + _mutate(rng, q[2 * len(q) // 3:], 0.1)
+    unit = rand(5)
+    q = (unit * 200)[:700]
+    yield q, _mutate(rng, q, 0.1)
+    yield rand(300, b"AC"), rand(280, b"AC")
+    q = rand(500, b"ACGTNRY")
+    yield q, _mutate(rng, q, 0.1)
+    yield rand(400), _mutate(rng, rand(400), 0.1).lower()
+    for qn in (1500, 2600, 4200, 10_000):
+        q = rand(qn)
+        yield q, _mutate(rng, q, 0.12)
+        yield q, rand(3000) + _mutate(rng, q, 0.1)
+        yield q, _mutate(rng, q, 0.1) + rand(3300)
+        yield q, rand(2000) + _mutate(rng, q, 0.08) + rand(2500)
+        yield q, _mutate(rng, q[:qn // 3], 0.1) + _mutate(rng, q[2 * qn // 3:], 0.1)
+        yield q[:300], rand(9000)
+        yield (b"ACG" * 4000)[:qn], _mutate(rng, (b"ACG" * 4000)[:qn], 0.05)
+
+
+def test_edit_path_kernel(gca):
+    """k_edit_path (gc_edit_path) against the real edlib's EDLIB_TASK_PATH output (oracle/_ref) and the oracle's restatement:
+    same distance, same op string, op for op."""
+    import random
+    from oracle import RefUnits
+    from oracle.binding import oracle_edit_path
+    rng = random.Random(99)
+    pairs = list(_path_pairs(rng))
+    dist, ops = gca.api.edit_path([a for a, _ in pairs], [b for _, b in pairs])
+    try:
+        ref = RefUnits()
+    except (FileNotFoundError, OSError):
+        ref = None
+    hirschberg = 0
+    for (a, b), d, o in zip(pairs, dist, ops):
+        want_d, want_ops = oracle_edit_path(a, b)
+        assert d == want_d, (len(a), len(b))
+        assert np.array_equal(o, want_ops), (len(a), len(b), d, len(o), len(want_ops))
+        if ref is not None:
+            ref_d, ref_ops = ref.edit_path(a, b)
+            assert d == ref_d and np.array_equal(o, ref_ops), (len(a), len(b))
+        hirschberg += (20 * ((len(a) + 63) // 64) + 8) * len(b) >= 1 << 20
+    assert hirschberg >= 15 and ref is not None
 
 
 def _vg_alignment_class():
