@@ -932,6 +932,18 @@ int gc_graph_array(const gc_graph* G, const char* name, int64_t** out, uint64_t*
 	else if (nm == "firstAmbiguous") v.push_back((int64_t)std::min(g.firstAmbiguous, n));
 	else if (nm == "nodeSeq") for (size_t i = 0; i < n && i < g.firstAmbiguous; i++) { v.push_back((int64_t)g.nodeSequences[i][0]); v.push_back((int64_t)g.nodeSequences[i][1]); }   // bit patterns
 	else if (nm == "ambiguousSeq") for (const gc::AmbiguousSeq& a : g.ambiguousNodeSequences) { v.push_back((int64_t)a.A); v.push_back((int64_t)a.T); v.push_back((int64_t)a.C); v.push_back((int64_t)a.G); }
+	else if (nm == "component_idx") for (size_t i = 0; i < n; i++) v.push_back(g.component_idx[i]);
+	else if (nm == "topo_id") for (size_t i = 0; i < n; i++) v.push_back(g.topo_ids[g.component_map[i]][g.component_idx[i]]);
+	// the path cover: mpc_path_comp[p] = component of path p, mpc_path_off / mpc_path_nodes = its nodes (global ids) in order
+	else if (nm == "mpc_path_comp") { for (size_t c = 0; c < g.mpc.size(); c++) for (size_t k = 0; k < g.mpc[c].size(); k++) v.push_back(c); }
+	else if (nm == "mpc_path_off") { v.push_back(0); for (size_t c = 0; c < g.mpc.size(); c++) for (const auto& p : g.mpc[c]) v.push_back(v.back() + (int64_t)p.size()); }
+	else if (nm == "mpc_path_nodes") { for (size_t c = 0; c < g.mpc.size(); c++) for (const auto& p : g.mpc[c]) for (size_t x : p) v.push_back(x); }
+	// per node (global id): the path ids through it (local to its component), and the backward links (node = global id, path id)
+	else if (nm == "paths_off") { v.push_back(0); for (size_t i = 0; i < n; i++) v.push_back(v.back() + (int64_t)g.paths[g.component_map[i]][g.component_idx[i]].size()); }
+	else if (nm == "paths") { for (size_t i = 0; i < n; i++) for (size_t k : g.paths[g.component_map[i]][g.component_idx[i]]) v.push_back(k); }
+	else if (nm == "back_off") { v.push_back(0); for (size_t i = 0; i < n; i++) v.push_back(v.back() + (int64_t)g.backwards[g.component_map[i]][g.component_idx[i]].size()); }
+	else if (nm == "back_node") { for (size_t i = 0; i < n; i++) for (const auto& b : g.backwards[g.component_map[i]][g.component_idx[i]]) v.push_back(g.component_ids[g.component_map[i]][b.first]); }
+	else if (nm == "back_path") { for (size_t i = 0; i < n; i++) for (const auto& b : g.backwards[g.component_map[i]][g.component_idx[i]]) v.push_back(b.second); }
 	else if (nm == "lookupOrder") { if (!g.nodeLookupOrder.empty()) for (int id : g.nodeLookupOrder) v.push_back(id); else for (const auto& kv : g.nodeLookup) v.push_back(kv.first); }
 	else return fail(GC_ERR_INVALID, "unknown graph array " + nm);
 	*out = mallocArray<int64_t>(v.size());

@@ -6,6 +6,12 @@ graph = random ACGT backbone cut at variant sites (Poisson, mean spacing 45 bp; 
 with integer names in file order; reads = random haplotype walks, either strand, fixed length, i.i.d.
 ONT-like errors (3 % deletion, 4 % substitution, 3 % 1-bp insertion). The read model follows the spirit
 of the reference's src/SimulateReads.cpp:13-42 (uniform start, per-base error draws).
+
+Optional structure for the configurations a plain SNP/indel chain does not reach (all off by default, so the default graphs
+and reads are unchanged): multi-allelic SNP sites (3-4 parallel allele nodes: path-cover width > 2), nested bubbles (an
+insertion that itself carries a SNP), links written from the reverse strand ("L b - a -"), repeats (copies of a few
+windows pasted elsewhere in the backbone with a little divergence: many seeds per fragment), and SynthGenome: several
+such chromosomes in one GFA (separate weakly connected components, BASELINE config 5's shape).
 """
 import numpy as np
 
@@ -18,9 +24,25 @@ for _a, _b in zip(b"ACGT", b"TGCA"):
 class SynthGraph:
     """Backbone + variant sites; can write itself as GFA and sample haplotype reads."""
 
-    def __init__(self, backbone_len, seed=7, mean_spacing=45.0, snp_fraction=0.85, max_indel=20):
+    def __init__(self, backbone_len, seed=7, mean_spacing=45.0, snp_fraction=0.85, max_indel=20,
+                 multi_allelic=0.0, nested=0.0, repeats=0, repeat_len=2000, repeat_divergence=0.02, minus_links=0.0):
         rng = np.random.default_rng(seed)
         self.backbone = _BASES[rng.integers(0, 4, size=backbone_len)]
+        self.minus_links = minus_links
+        self.seed = seed
+        if repeats:
+            # paste diverged copies of a few source windows elsewhere (own generator: the default graph's draws are untouched)
+            rrng = np.random.default_rng(seed + 1000003)
+            repeat_len = min(repeat_len, backbone_len // 4)
+            n_sources = max(1, repeats // 3)
+            sources = rrng.integers(0, backbone_len - repeat_len, size=n_sources)
+            for c in range(repeats):
+                src = int(sources[c % n_sources])
+                dst = int(rrng.integers(0, backbone_len - repeat_len))
+                copy = self.backbone[src:src + repeat_len].copy()
+                hit = rrng.random(repeat_len) < repeat_divergence
+                copy[hit] = _BASES[rrng.integers(0, 4, size=int(hit.sum()))]
+                self.backbone[dst:dst + repeat_len] = copy
         # variant site positions: gaps ~ 1 + geometric with the requested mean
         n_est = int(backbone_len / mean_spacing * 1.2) + 16
         gaps = rng.geometric(1.0 / mean_spacing, size=n_est) + 1
@@ -40,41 +62,73 @@ class SynthGraph:
         self.seg_start = np.concatenate([[0], pos + consumed])
         self.seg_end = np.concatenate([pos, [backbone_len]])
         self.backbone_len = backbone_len
+        # optional site structure, from a generator of its own
+        xrng = np.random.default_rng(seed + 2000003)
+        extra = np.where(self.is_snp & (xrng.random(n) < multi_allelic), xrng.integers(1, 3, size=n), 0)   # 1-2 further alleles
+        self.n_alleles = (2 + extra).astype(np.int64)                                                          # SNP sites: 2..4 allele nodes
+        ref_code = np.searchsorted(_BASES, self.backbone[pos])
+        shift = (alt - ref_code) % 4                                                                           # 1..3: the first alt allele
+        self.snp_alts = np.stack([_BASES[(ref_code + ((shift - 1 + k) % 3) + 1) % 4] for k in range(3)], axis=1)   # all three non-reference bases, first = snp_alt
+        self.nested = (~self.is_snp) & (self.indel_len >= 3) & (xrng.random(n) < nested)                       # insertion with a SNP inside it
+        self.nested_at = np.where(self.nested, 1 + xrng.integers(0, 1 << 30, size=n) % np.maximum(self.indel_len - 2, 1), 0)
+        self.nested_alt = _BASES[xrng.integers(0, 4, size=n)]
 
-    def write_gfa(self, path):
-        """Segments are named 1..N in file order; links carry 0M overlaps."""
+    def gfa_lines(self, first_id=1):
+        """(segment lines, link lines, next free id). Segments are named first_id.. in file order; links carry 0M overlaps."""
         bb = self.backbone.tobytes()
         ins = self.indel_seq.tobytes()
         out = []
         links = []
-        next_id = 1
+        next_id = first_id
         prev = None
         n = len(self.site_pos)
-        for i in range(n + 1):
-            seg = bb[self.seg_start[i]:self.seg_end[i]]
-            sid = next_id
+        lrng = np.random.default_rng(self.seed + 3000003)
+        flip = lrng.random(8 * (n + 2)) < self.minus_links if self.minus_links > 0 else None
+        n_links = 0
+
+        def link(a, b):
+            nonlocal n_links
+            if flip is not None and flip[n_links % len(flip)]:
+                links.append(b"L\t%d\t-\t%d\t-\t0M\n" % (b, a))     # the same adjacency written from the reverse strand
+            else:
+                links.append(b"L\t%d\t+\t%d\t+\t0M\n" % (a, b))
+            n_links += 1
+
+        def node(seq):
+            nonlocal next_id
+            out.append(b"S\t%d\t%s\n" % (next_id, seq))
             next_id += 1
-            out.append(b"S\t%d\t%s\n" % (sid, seg))
+            return next_id - 1
+
+        for i in range(n + 1):
+            sid = node(bb[self.seg_start[i]:self.seg_end[i]])
             if prev is not None:
                 for p in prev:
-                    links.append(b"L\t%d\t+\t%d\t+\t0M\n" % (p, sid))
+                    link(p, sid)
             if i == n:
                 break
             if self.is_snp[i]:
-                a, b = next_id, next_id + 1
-                next_id += 2
                 p = int(self.site_pos[i])
-                out.append(b"S\t%d\t%s\n" % (a, bb[p:p + 1]))
-                out.append(b"S\t%d\t%s\n" % (b, bytes([int(self.snp_alt[i])])))
-                links.append(b"L\t%d\t+\t%d\t+\t0M\n" % (sid, a))
-                links.append(b"L\t%d\t+\t%d\t+\t0M\n" % (sid, b))
-                prev = (a, b)
+                alleles = [node(bb[p:p + 1])] + [node(bytes([int(self.snp_alts[i, k])])) for k in range(int(self.n_alleles[i]) - 1)]
+                for a in alleles:
+                    link(sid, a)
+                prev = tuple(alleles)
+            elif self.nested[i]:
+                seq = ins[self.indel_off[i]:self.indel_off[i + 1]]
+                at = int(self.nested_at[i])
+                pre, post = node(seq[:at]), None
+                x, y = node(seq[at:at + 1]), node(bytes([int(self.nested_alt[i])]))
+                post = node(seq[at + 1:])
+                link(sid, pre); link(pre, x); link(pre, y); link(x, post); link(y, post)
+                prev = (sid, post)
             else:
-                a = next_id
-                next_id += 1
-                out.append(b"S\t%d\t%s\n" % (a, ins[self.indel_off[i]:self.indel_off[i + 1]]))
-                links.append(b"L\t%d\t+\t%d\t+\t0M\n" % (sid, a))
+                a = node(ins[self.indel_off[i]:self.indel_off[i + 1]])
+                link(sid, a)
                 prev = (sid, a)
+        return out, links, next_id
+
+    def write_gfa(self, path):
+        out, links, next_id = self.gfa_lines(1)
         with open(path, "wb") as f:
             f.writelines(out)
             f.writelines(links)
@@ -96,11 +150,18 @@ class SynthGraph:
             if self.is_snp[i]:
                 if rng.random() < 0.5:
                     pieces.append(self.backbone[self.site_pos[i]:self.site_pos[i] + 1])
-                else:
+                elif self.n_alleles[i] == 2:
                     pieces.append(self.snp_alt[i:i + 1])
+                else:
+                    k = int(rng.integers(0, self.n_alleles[i] - 1))
+                    pieces.append(self.snp_alts[i, k:k + 1])
                 total += 1
             elif rng.random() < 0.5:
-                pieces.append(self.indel_seq[self.indel_off[i]:self.indel_off[i + 1]])
+                seq = self.indel_seq[self.indel_off[i]:self.indel_off[i + 1]]
+                if self.nested[i] and rng.random() < 0.5:
+                    seq = seq.copy()
+                    seq[int(self.nested_at[i])] = self.nested_alt[i]
+                pieces.append(seq)
                 total += int(self.indel_len[i])
             i += 1
             at = int(self.seg_start[i])
@@ -132,6 +193,33 @@ class SynthGraph:
                 seq = _COMP[seq[::-1]]
             reads.append(seq.tobytes())
         return reads
+
+
+class SynthGenome:
+    """Several SynthGraph chromosomes in one GFA: separate weakly connected components (two per chromosome, one per strand)."""
+
+    def __init__(self, n_chromosomes, backbone_len, seed=7, **kw):
+        self.chromosomes = [SynthGraph(backbone_len, seed=seed + 7919 * c, **kw) for c in range(n_chromosomes)]
+        self.backbone_len = backbone_len
+
+    def write_gfa(self, path):
+        first = 1
+        segs, links = [], []
+        for chrom in self.chromosomes:
+            s, l, first = chrom.gfa_lines(first)
+            segs.extend(s); links.extend(l)
+        with open(path, "wb") as f:
+            f.writelines(segs)
+            f.writelines(links)
+        return first - 1
+
+    def sample_reads(self, n_reads, read_len, seed=11, **kw):
+        """Reads drawn round-robin from the chromosomes (each with its own stream)."""
+        per = [c.sample_reads((n_reads - i + len(self.chromosomes) - 1) // len(self.chromosomes), read_len, seed=seed + 31 * i, **kw) for i, c in enumerate(self.chromosomes)]
+        out = []
+        for k in range(n_reads):
+            out.append(per[k % len(per)][k // len(per)])
+        return out
 
 
 def write_fasta(path, reads):

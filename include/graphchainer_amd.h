@@ -98,7 +98,8 @@ uint64_t gc_graph_num_nodes(const gc_graph* g);
 uint64_t gc_graph_size_bp(const gc_graph* g);
 /* name in {"nodeLength","nodeOffset","nodeIDs","reverse","componentNumber","chainNumber","chainApproxPos",
  * "component_map","out_off","out_adj","in_off","in_adj","mpc_width","firstAmbiguous","nodeSeq","ambiguousSeq" (64-bit
- * patterns, gc_graph_desc layout),"lookupOrder"}; returns a malloc'd int64 array
+ * patterns, gc_graph_desc layout),"lookupOrder", and the MPC index in global node ids: "component_idx","topo_id","mpc_path_comp",
+ * "mpc_path_off","mpc_path_nodes","paths_off","paths","back_off","back_node","back_path"}; returns a malloc'd int64 array
  * (free with gc_free). */
 int gc_graph_array(const gc_graph* g, const char* name, int64_t** out, uint64_t* count);
 

@@ -486,6 +486,18 @@ int gco_graph_array(void* hv, const char* name)
 	else if (nm == "in_adj") for (size_t i = 0; i < n; i++) for (size_t v : g.inNeighbors[i]) out.push_back(v);
 	else if (nm == "sequence") for (size_t i = 0; i < n; i++) for (size_t j = 0; j < g.nodeLength[i]; j++) out.push_back(g.NodeSequences(i, j));
 	else if (nm == "mpc_width") for (size_t c = 0; c < g.mpc.size(); c++) out.push_back(g.mpc[c].size());
+	else if (nm == "component_idx") for (size_t i = 0; i < n; i++) out.push_back(g.component_idx[i]);
+	else if (nm == "topo_id") for (size_t i = 0; i < n; i++) out.push_back(g.topo_ids[g.component_map[i]][g.component_idx[i]]);
+	// the path cover: mpc_path_comp[p] = component of path p, mpc_path_off / mpc_path_nodes = its nodes (global ids) in order
+	else if (nm == "mpc_path_comp") { for (size_t c = 0; c < g.mpc.size(); c++) for (size_t k = 0; k < g.mpc[c].size(); k++) out.push_back(c); }
+	else if (nm == "mpc_path_off") { out.push_back(0); for (size_t c = 0; c < g.mpc.size(); c++) for (const auto& p : g.mpc[c]) out.push_back(out.back() + (int64_t)p.size()); }
+	else if (nm == "mpc_path_nodes") { for (size_t c = 0; c < g.mpc.size(); c++) for (const auto& p : g.mpc[c]) for (size_t x : p) out.push_back(x); }
+	// per node (global id): the path ids through it (local to its component), and the backward links (node = global id, path id)
+	else if (nm == "paths_off") { out.push_back(0); for (size_t i = 0; i < n; i++) out.push_back(out.back() + (int64_t)g.paths[g.component_map[i]][g.component_idx[i]].size()); }
+	else if (nm == "paths") { for (size_t i = 0; i < n; i++) for (size_t k : g.paths[g.component_map[i]][g.component_idx[i]]) out.push_back(k); }
+	else if (nm == "back_off") { out.push_back(0); for (size_t i = 0; i < n; i++) out.push_back(out.back() + (int64_t)g.backwards[g.component_map[i]][g.component_idx[i]].size()); }
+	else if (nm == "back_node") { for (size_t i = 0; i < n; i++) for (const auto& b : g.backwards[g.component_map[i]][g.component_idx[i]]) out.push_back(g.component_ids[g.component_map[i]][b.first]); }
+	else if (nm == "back_path") { for (size_t i = 0; i < n; i++) for (const auto& b : g.backwards[g.component_map[i]][g.component_idx[i]]) out.push_back(b.second); }
 	else if (nm == "index_kmers") for (uint64_t v : h->o.index.kmers) out.push_back((int64_t)v);
 	else if (nm == "index_start") for (uint64_t v : h->o.index.startPos) out.push_back((int64_t)v);
 	else if (nm == "index_positions") for (uint64_t v : h->o.index.positions) out.push_back((int64_t)v);

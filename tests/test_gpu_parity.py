@@ -380,6 +380,66 @@ def test_chained_alignment_wins(gca, tmp_path):
     assert gzip.decompress(raw["gam"])   # framed messages decode (content is checked against the JSON in test_json_and_gam_output)
 
 
+def test_config5_shape(gca, tmp_path):
+    """BASELINE config 5 in miniature: several chromosomes in one GFA (6 weakly connected components: the cross-component rule of
+    src/AlignmentGraph.cpp:1722-1733), path-cover width > 2 (multi-allelic and nested bubbles), links written from the reverse
+    strand, repeats, 50 kb reads at PacBio-CLR-like error rates (4 % deletions, 2 % substitutions, 9 % insertions),
+    --colinear-gap 50000, whole-read pass on."""
+    from graphchainer_amd.synth import SynthGenome
+    gen = SynthGenome(3, 300_000, seed=41, multi_allelic=0.25, nested=0.3, minus_links=0.3, repeats=8, repeat_len=3000)
+    gfa = str(tmp_path / "g.gfa")
+    gen.write_gfa(gfa)
+    reads = gen.sample_reads(5, 50_000, seed=6, p_del=0.04, p_sub=0.02, p_ins=0.09)
+    reads.append(reads[0][:20_000] + reads[1][:25_000])      # a read spanning two chromosomes
+    got, want = run_case(gca, gfa, reads, long_pass=True, colinear_gap=50000)
+    compare(got, want, COMPARE_KEYS + LONG_KEYS)
+    graph = gca.AlignmentGraph(gfa)
+    assert len(graph.array("mpc_width")) == 6 and int(graph.array("mpc_width").max()) >= 3
+    assert int(got["read_chain_off"][-1]) > 1000 and int(got["read_longall_off"][-1]) >= 5
+
+
+def test_config3_shape_with_whole_read_pass(gca, tmp_path):
+    """BASELINE config 3 in miniature: 10 kb reads, --colinear-split-gap 18 (the reference's spelling of --sampling-step 0.5:
+    overlapping fragments, twice the anchors, the overlap branch of the chaining DP), whole-read pass on, a graph with repeats."""
+    from graphchainer_amd.synth import SynthGraph
+    sg = SynthGraph(400_000, seed=43, repeats=6, repeat_len=2500, multi_allelic=0.1)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(24, 10_000, seed=8)
+    got, want = run_case(gca, gfa, reads, long_pass=True, split_gap=18)
+    compare(got, want, COMPARE_KEYS + LONG_KEYS)
+    assert int(got["read_anchor_off"][-1]) > 24 * 200
+
+
+def test_chain_kernel_against_bruteforce(gca, tmp_path):
+    """k_chain's chains against the quadratic DP over BFS reachability of tests/graph_model.py (independent of the oracle and of
+    the MPC index): several components, wide covers, overlapping fragments."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from graph_model import GraphModel, chain_bruteforce
+    from graphchainer_amd.synth import SynthGenome
+    gen = SynthGenome(2, 50_000, seed=23, multi_allelic=0.3, nested=0.4, minus_links=0.3, repeats=4, repeat_len=1500)
+    gfa = str(tmp_path / "g.gfa")
+    gen.write_gfa(gfa)
+    reads = gen.sample_reads(6, 3000, seed=3)
+    reads.append(reads[0][:1500] + reads[1][:1500])
+    model = GraphModel(open(gfa).read())
+    comp, _, _ = model.weak_components()
+    graph = gca.AlignmentGraph(gfa)
+    assert list(graph.array("nodeIDs")) == model.ids           # the product's numbering is the model's
+    seeder = gca.MinimizerSeeder(graph)
+    for kw in ({}, {"split_gap": 18}):
+        res = gca.Aligner(graph, seeder, **kw).align_reads(reads)
+        for r in range(len(reads)):
+            a0, a1 = int(res["read_anchor_off"][r]), int(res["read_anchor_off"][r + 1])
+            anchors = [([int(v) for v in res["anchor_path"][int(res["anchor_path_off"][a]):int(res["anchor_path_off"][a + 1])]], int(res["anchor_x"][a]), int(res["anchor_y"][a])) for a in range(a0, a1)]
+            if not anchors:
+                continue
+            chain, score = chain_bruteforce(model.out, model.inn, comp, anchors)
+            assert [int(c) for c in res["chain"][int(res["read_chain_off"][r]):int(res["read_chain_off"][r + 1])]] == chain, (kw, r)
+            assert int(res["chain_score"][r]) == score
+
+
 def _path_pairs(rng):
     """(path letters, read) shapes the chained alignment meets: similar strings, a path covering only part of the read, a path
     with a stretch the read lacks, unrelated strings, repeats (many optimal alignments), other letters, tiny / empty sides,
