@@ -2,14 +2,19 @@
 """Benchmark of the MI355X GraphChainer hot path (BASELINE.json metric: reads/s and Gbp/s aligned).
 
 One "step" = one pass of the hot path (whole-read GraphAligner pass; seed lookup -> seed ordering -> fragment
-seed-extension -> anchors -> co-linear chaining -> chain stitching; NW edit distances and the chained-vs-whole-read
-decision) over one batch of synthetic reads that is already resident in HBM.
+seed-extension -> anchors -> co-linear chaining -> chain stitching; NW edit distances, the chained-vs-whole-read
+decision and the chained alignment's trace for the reads that take it) over the rank's reads, which are already
+resident in HBM when the timed region starts.
 
-Workload at N=1 = BASELINE.json configs[1]: chr22-like graph (50.8 Mbp backbone, SNP/indel bubbles every ~45 bp,
-SURVEY.md §8d) and 10 000 simulated 10 kb ONT-like reads, reference defaults. For N>1 every rank aligns its own
-10 000-read shard against its own replica of the graph (read-parallel, no data-path collective): weak scaling.
+--config 2 (default) = BASELINE.json configs[1]: chr22-like graph (50.8 Mbp backbone, SNP/indel bubbles every ~45 bp,
+SURVEY.md §8d), 10 000 simulated 10 kb ONT-like reads, reference defaults; one batch per step.
+--config 3 = configs[2]: the same graph, 100 000 reads in batches of 10 000, --colinear-split-gap 18 (the reference's
+spelling of --sampling-step 0.5): one step = all ten batches.
+For N>1 (weak scaling) every rank aligns its own reads against its own replica of the graph, no data-path collective;
+--strong divides one read set over the ranks instead (BASELINE config 4's shape) with the product's work queue
+(graphchainer_amd/workqueue.py): length-sorted batches handed out dynamically.
 
-Usage: python bench.py [--gpus N] [--steps K] [--warmup W]
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3] [--sv-fraction F]
        (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 """
 import argparse
@@ -37,16 +42,57 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=int(os.environ.get("GC_BENCH_CONFIG", 2)), choices=[2, 3])
     ap.add_argument("--backbone", type=int, default=int(os.environ.get("GC_BENCH_BACKBONE", 50_800_000)))
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("GC_BENCH_READS", 10_000)))
+    ap.add_argument("--reads", type=int, default=None, help="reads per rank and step (default: 10 000 for config 2, 100 000 for config 3)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("GC_BENCH_BATCH", 10_000)), help="reads per gc_align_batch call")
     ap.add_argument("--read-len", type=int, default=10_000)
-    ap.add_argument("--split-gap", type=int, default=35)
-    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("GC_BENCH_CPU_SAMPLE", 600)), help="reads of the same workload timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--split-gap", type=int, default=None)
+    ap.add_argument("--sv-fraction", type=float, default=float(os.environ.get("GC_BENCH_SV_FRACTION", 0.0)),
+                    help="fraction of the reads that carry a 1.5 kb deletion the graph does not hold: the reads whose chained alignment wins (decision.chained_better > 0)")
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("GC_BENCH_CPU_SAMPLE", 600)), help="reads of the same workload timed on ONE thread of the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("GC_BENCH_CPU_THREADS", 0)), help="worker threads of the all-core CPU leg (0 = all host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-long-pass", action="store_true", help="skip the whole-read GraphAligner pass (src/Aligner.cpp:630-654)")
+    ap.add_argument("--strong", action="store_true", help="N>1: one read set divided over the ranks through the work queue (strong scaling)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("GC_BENCH_INFLIGHT", 1)),
-                    help="batches in flight per GPU, each on its own gc_stream and host thread (like the reference's -t worker threads); every step still runs the whole hot path on the whole batch. Measured on cfg2: 1 -> 339, 2 -> 332, 3 -> 337 ms/step: the GPU is the bottleneck, so the default stays 1")
-    return ap.parse_args()
+                    help="batches in flight per GPU, each on its own gc_stream and host thread (like the reference's -t worker threads)")
+    args = ap.parse_args()
+    if args.reads is None:
+        args.reads = 100_000 if args.config == 3 else 10_000
+    if args.split_gap is None:
+        args.split_gap = 18 if args.config == 3 else 35
+    return args
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_leg(args, gfa, reads, long_pass):
+    """The CPU restatement (oracle/) timed on the host cores of this box, BEFORE this process touches the GPU: one thread on a
+    bounded sample, then one worker per core over a shared read queue (the reference's -t model, src/Aligner.cpp:1267-1270)."""
+    from oracle import Oracle   # the CPU baseline leg is the one place bench.py may touch the oracle
+    threads = args.cpu_threads or (os.cpu_count() or 1)
+    ora = Oracle(gfa, long_pass=long_pass, split_gap=args.split_gap)
+    n1 = min(args.cpu_sample, len(reads))
+    wall1, stage1 = ora.align_timed(reads[:n1], 1)
+    n_all = min(len(reads), max(n1, 40 * threads))
+    wall_all, _ = ora.align_timed(reads[:n_all], threads)
+    ora.close()
+    stage_names = ["seeding", "whole_read_pass", "fragment_extension+anchors", "chaining", "stitching+edlib"]
+    total = float(stage1.sum()) or 1.0
+    return {"value": round(n_all / wall_all, 2), "unit": "reads/s", "cores": threads, "kind": "port",
+            "sample": f"first {n_all} reads of the same workload, same stages, {threads} worker threads over a shared read queue, {wall_all:.1f} s; one thread: first {n1} reads, {wall1:.1f} s",
+            "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+            "single_thread_reads_per_s": round(n1 / wall1, 2),
+            "single_thread_stage_share": {k: round(float(v) / total, 3) for k, v in zip(stage_names, stage1)}}
 
 
 def main():
@@ -54,20 +100,36 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    long_pass = not args.no_long_pass
+
+    from graphchainer_amd.synth import SynthGraph
+    t0 = time.time()
+    tmp = tempfile.mkdtemp(prefix="gcbench_")
+    gfa = os.path.join(tmp, "graph.gfa")
+    sg = SynthGraph(args.backbone, seed=7)
+    sg.write_gfa(gfa)
+    strong = args.strong and world > 1
+    # weak scaling: every rank draws its own reads; strong scaling: all ranks draw the same set and the work queue divides it
+    reads = sg.sample_reads(args.reads, args.read_len, seed=11 + (0 if strong else rank), sv_fraction=args.sv_fraction)
+    t_gen = time.time() - t0
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = cpu_baseline_leg(args, gfa, reads, long_pass)   # before any HIP call of this process
+
     dist = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import torch
         import torch.distributed as dist_mod
         dist = dist_mod
-        # reads shard embarrassingly: the only cross-rank traffic is the barrier and the max-over-ranks of the step time
+        # reads shard embarrassingly: the only cross-rank traffic is the barrier, the max-over-ranks of the step time and (strong) the queue cursor
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-
     if world > 1 and "GC_HOST_THREADS" not in os.environ:
         # ranks share the host: split its cores between their worker pools (read by the library when it first loads)
         os.environ["GC_HOST_THREADS"] = str(max(8, min(96, (os.cpu_count() or 8) // world)))
     import graphchainer_amd as gca
-    from graphchainer_amd.synth import SynthGraph
+    from graphchainer_amd.workqueue import ReadQueue, length_sorted_batches, run_queue
 
     if gca.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -82,17 +144,11 @@ def main():
         import torch
         torch.cuda.set_device(device)
 
-    t0 = time.time()
-    tmp = tempfile.mkdtemp(prefix="gcbench_")
-    gfa = os.path.join(tmp, "graph.gfa")
-    sg = SynthGraph(args.backbone, seed=7)
-    sg.write_gfa(gfa)
-    reads = sg.sample_reads(args.reads, args.read_len, seed=11 + rank)   # every rank draws its own shard
-    t_gen = time.time() - t0
     # Start-up: rank 0 builds the graph, MPC index and minimizer index from the GFA and writes the index cache;
     # the other ranks load that file instead of repeating the build. Rank 0 also loads it once, to report the load time.
     cache = os.path.join(tempfile.gettempdir(), f"gcbench_{os.environ.get('MASTER_PORT', 'single')}_{os.getuid()}.gcidx")
     t_graph = t_index = t_save = t_load = 0.0
+    cache_bytes = 0
     if rank == 0:
         t0 = time.time()
         graph = gca.AlignmentGraph(gfa)
@@ -120,11 +176,17 @@ def main():
         dist.barrier()
     if rank == 0:
         os.remove(cache)
-    long_pass = not args.no_long_pass
-    inflight = max(1, min(args.inflight, max(1, args.steps)))
+
+    inflight = max(1, args.inflight)
     aligners = [gca.Aligner(graph, seeder, split_gap=args.split_gap, long_pass=long_pass) for _ in range(inflight)]
-    batch = gca.ReadBatch(reads)          # inputs resident in HBM before the timed region
-    total_bases = int(batch.lengths.sum())
+    # the rank's reads as length-sorted batches (one batch for config 2), uploaded before the timed region; the upload itself
+    # (2-bit packing, reverse complement, match-mask bit vectors, PCIe) is timed here and reported beside the step time
+    chunks = length_sorted_batches(reads, args.batch)
+    t0 = time.perf_counter()
+    batches = [gca.ReadBatch([reads[i] for i in idx]) for idx in chunks]
+    upload_s = time.perf_counter() - t0
+    total_bases = int(sum(int(b.lengths.sum()) for b in batches))
+    queue = ReadQueue(len(batches), rank, world, dist if strong else None)
 
     def sync():
         if dist is not None:
@@ -132,19 +194,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=inflight)
-
     def run_steps(count):
-        """`count` passes over the batch; worker i takes passes i, i+inflight, ... on its own stream. Returns the per-pass results."""
-        def worker(i):
-            return [aligners[i].align_batch(batch) for _ in range(i, count, inflight)]   # returns after its streams are drained
-        outs = []
-        for part in pool.map(worker, range(inflight)):
-            outs.extend(part)
-        return outs
+        """`count` passes over the rank's batches: `inflight` host threads (one gc_stream each, like the reference's -t workers) pull
+        (step, batch) items from one queue, so with more than one batch in flight consecutive steps overlap - a stream of batches."""
+        queue.reset(count * len(batches))
+        return run_queue(queue, lambda i, item: (item % len(batches), aligners[i].align_batch(batches[item % len(batches)])), inflight)   # align_batch returns after its streams are drained
 
-    warmup_done = max(args.warmup, inflight if args.warmup else 0)   # every stream allocates its arenas before the timed region
+    warmup_done = max(args.warmup, 1 if args.warmup and inflight > 1 else 0)
     run_steps(warmup_done)
     sync()
     t_start = time.perf_counter()
@@ -155,33 +211,45 @@ def main():
     host_us = np.zeros(4)
     counters = np.zeros(8, dtype=np.float64)
     counters_long = np.zeros(8, dtype=np.float64)
-    for out in outs:
+    reads_done = aligned_bases = chained_better = reads_with_chain = reads_with_long = 0
+    long_ed, chain_ed, seeds_ext_long = [], [], []
+    for _item, (b, out) in outs:
         kernel_us += out["kernel_us"]
         host_us += out["host_us"]
         counters += out["counters"].astype(np.float64)
         counters_long += out["counters_long"].astype(np.float64)
-    out = outs[-1]
+        chain_len = np.diff(out["read_chain_off"])
+        n_long = np.diff(out["read_longall_off"])
+        reads_done += len(chain_len)
+        aligned_bases += int(batches[b].lengths[(chain_len > 0) | (n_long > 0)].sum())
+        chained_better += int(np.sum(out["chained_better"]))
+        reads_with_chain += int((chain_len > 0).sum())
+        reads_with_long += int((n_long > 0).sum())
+        long_ed.append(out["long_edit_distance"][out["long_edit_distance"] >= 0].astype(np.float64))
+        chain_ed.append(out["chain_edit_distance"][out["chain_edit_distance"] >= 0].astype(np.float64))
+        seeds_ext_long.append(np.asarray(out["seeds_extended_long"], dtype=np.float64))
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_us /= max(1, args.steps)
-    host_us /= max(1, args.steps)
-    counters /= max(1, args.steps)
-    counters_long /= max(1, args.steps)
-
-    chain_len = np.diff(out["read_chain_off"])
-    n_long = np.diff(out["read_longall_off"])
-    aligned_bases = int(batch.lengths[(chain_len > 0) | (n_long > 0)].sum())
-    reads_total = args.reads * world * args.steps
+        tot = torch.tensor([reads_done, aligned_bases], dtype=torch.float64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        reads_total, aligned_total = float(tot[0].item()), float(tot[1].item())
+    else:
+        reads_total, aligned_total = float(reads_done), float(aligned_bases)
+    steps = max(1, args.steps)
+    kernel_us /= steps
+    host_us /= steps
+    counters /= steps
+    counters_long /= steps
     reads_per_s = reads_total / elapsed
-    gbp_per_s = aligned_bases * world * args.steps / elapsed / 1e9
+    gbp_per_s = aligned_total / elapsed / 1e9
 
     # roofline of the dominant kernel (most device time per step: k_long_extend when the whole-read pass runs, else k_extend):
     # algorithmic bytes per launch (SURVEY.md §8d unit x the counts the kernel reports) / its HIP-event duration
     def kernel_roofline(name, cnt, us, launches=1.0):
-        # `us` = the kernel's HIP-event time summed over its launches of one step (k_long_extend: one launch per round)
+        # `us` = the kernel's HIP-event time summed over its launches of one step (k_long_extend: one launch per round and batch)
         dp_tiles, recompute_tiles, column_steps, trace_items, _ext, backtrace_tiles = cnt[:6]
         nbytes = BYTES_PER_TILE * (dp_tiles + recompute_tiles) + BYTES_PER_BACKTRACE_TILE * backtrace_tiles + BYTES_PER_TRACE_ITEM * trace_items
         seconds = us * 1e-6
@@ -198,54 +266,50 @@ def main():
         separate passes over this same bench command); None when no profile is committed."""
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
         if not files:
-            return None
+            return None, None
         with open(files[-1]) as f:
             prof = json.load(f)
         for name, rec in prof.get("kernels", {}).items():
             if name.split("<")[0] == kernel and "FETCH_SIZE_KB_per_step" in rec and "WRITE_SIZE_KB_per_step" in rec:
-                return int((rec["FETCH_SIZE_KB_per_step"] + rec["WRITE_SIZE_KB_per_step"]) * 1024 / max(1.0, launches))
-        return None
+                return int((rec["FETCH_SIZE_KB_per_step"] + rec["WRITE_SIZE_KB_per_step"]) * 1024 / max(1.0, launches)), os.path.basename(files[-1])
+        return None, None
 
-    roof_extend = kernel_roofline("k_extend", counters, kernel_us[1])
+    n_batches_step = len(outs) / steps
+    roof_extend = kernel_roofline("k_extend", counters, kernel_us[1], n_batches_step)
     roof_long = kernel_roofline("k_long_extend", counters_long, kernel_us[4], counters_long[6]) if long_pass else None
     roofline = roof_long if (long_pass and kernel_us[4] >= kernel_us[1]) else roof_extend
-    roofline["traffic"] = measured_traffic(roofline["kernel"], roofline["launches_per_step"])
-    extensions = counters[4]
-
-    cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import Oracle   # the CPU baseline leg is the one place bench.py may touch the oracle
-        n_sample = min(args.cpu_sample, len(reads))
-        ora = Oracle(gfa, long_pass=long_pass, split_gap=args.split_gap)
-        t0 = time.perf_counter()
-        ora.align(reads[:n_sample])
-        cpu_t = time.perf_counter() - t0
-        cpu_baseline = {"value": round(n_sample / cpu_t, 2), "unit": "reads/s", "cores": 1, "kind": "port",
-                        "sample": f"first {n_sample} reads of the same workload, same stages ({'whole-read pass + selection, ' if long_pass else ''}seeding, fragment extension, anchors, chaining, chain stitching, NW edit distances), 1 thread, {cpu_t:.1f} s"}
+    if args.config == 2 and args.reads == 10_000:
+        roofline["traffic"], roofline["traffic_source"] = measured_traffic(roofline["kernel"], roofline["launches_per_step"])
 
     if rank == 0:
+        cat = lambda parts: np.concatenate(parts) if parts else np.zeros(0)
+        long_ed, chain_ed, seeds_ext_long = cat(long_ed), cat(chain_ed), cat(seeds_ext_long)
         line = {
             "metric": "reads_per_sec", "value": round(reads_per_s, 2), "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": warmup_done,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(elapsed / steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "gbp_per_sec_aligned": round(gbp_per_s, 5),
-            "config": {"workload": f"BASELINE configs[1]: chr22-like synthetic DAG ({args.backbone} bp backbone, {graph.NodeSize()} split nodes), "
-                                   f"{args.reads} x {args.read_len} bp ONT-like reads per GPU, split_len 35 split_gap {args.split_gap} bandwidth 10",
-                       "stages": ("whole-read GraphAligner pass + selection + " if long_pass else "") + "seed lookup + seed ordering + fragment seed-extension + anchors + co-linear chaining + chain stitching + NW edit distances + chained-vs-whole-read decision",
-                       "reads_per_gpu": args.reads, "read_len": args.read_len, "batches_in_flight_per_gpu": inflight, "parallelism": f"read-sharded x{world}, graph replicated, no collective"},
+            "config": {"workload": f"BASELINE configs[{args.config - 1}]: chr22-like synthetic DAG ({args.backbone} bp backbone, {graph.NodeSize()} split nodes), "
+                                   f"{args.reads} x {args.read_len} bp ONT-like reads {'in total' if strong else 'per GPU'} in batches of {args.batch}, split_len 35 split_gap {args.split_gap} bandwidth 10"
+                                   + (f", {args.sv_fraction:.0%} of the reads with a 1.5 kb deletion" if args.sv_fraction > 0 else ""),
+                       "stages": ("whole-read GraphAligner pass + selection + " if long_pass else "") + "seed lookup + seed ordering + fragment seed-extension + anchors + co-linear chaining + chain stitching + NW edit distances + chained-vs-whole-read decision + chained alignment trace (edlib path) for its winners",
+                       "reads_per_gpu": args.reads if not strong else None, "read_len": args.read_len, "batch": args.batch, "batches_in_flight_per_gpu": inflight,
+                       "parallelism": f"read-sharded x{world} ({'dynamic work queue over one read set' if strong else 'own reads per rank'}), graph replicated, no collective"},
             "roofline": roofline,
             "roofline_other": roof_extend if roofline is roof_long else roof_long,
             "cpu_baseline": cpu_baseline,
+            # inputs are resident before the timed region; what putting them there costs (host-side packing + PCIe), and the rate with it included
+            "reads_upload": {"ms_per_step": round(upload_s * 1e3, 2), "bases": total_bases, "reads_per_s_including_upload": round(reads_total / (elapsed + upload_s * steps * (1 if not strong else 1)), 2)},
             "stage_ms": {"k_seed_probe+compact": round(kernel_us[0] / 1e3, 3), "k_extend": round(kernel_us[1] / 1e3, 3), "k_build_anchors": round(kernel_us[2] / 1e3, 3),
                          "k_chain": round(kernel_us[3] / 1e3, 3), "k_long_extend_all_rounds": round(kernel_us[4] / 1e3, 3), "whole_read_pass_wall": round(kernel_us[5] / 1e3, 3), "host_seed_glue": round(host_us[0] / 1e3, 3), "host_result_assembly": round(host_us[1] / 1e3, 3),
                          "wall_seed_lookup_and_copies": round(host_us[2] / 1e3, 3), "wall_extend_to_chain_and_copies": round(host_us[3] / 1e3, 3)},
             "setup_s": {"generate": round(t_gen, 1), "graph_build_upload": round(t_graph, 1), "minimizer_index": round(t_index, 1),
                         "index_cache_save": round(t_save, 1), "index_cache_load_upload": round(t_load, 1), "index_cache_bytes": cache_bytes},
-            "reads_with_chain": int((chain_len > 0).sum()), "extensions_per_step": int(extensions),
-            "decision": {"chained_better": int(np.sum(out["chained_better"])), "mean_long_edit_distance": round(float(np.mean(out["long_edit_distance"][out["long_edit_distance"] >= 0])), 1) if long_pass and (out["long_edit_distance"] >= 0).any() else None,
-                         "mean_chain_edit_distance": round(float(np.mean(out["chain_edit_distance"][out["chain_edit_distance"] >= 0])), 1) if (out["chain_edit_distance"] >= 0).any() else None},
-            "long_pass": {"reads_with_alignment": int((n_long > 0).sum()), "extensions_per_step": int(counters_long[4]), "rounds": int(counters_long[6]), "plain_layout_reruns": int(counters_long[7]),
-                          "seeds_extended_mean": round(float(out["seeds_extended_long"].mean()), 2), "seeds_extended_max": int(out["seeds_extended_long"].max())} if long_pass else None,
+            "reads_with_chain": int(reads_with_chain / steps), "extensions_per_step": int(counters[4]),
+            "decision": {"chained_better": int(chained_better / steps), "mean_long_edit_distance": round(float(long_ed.mean()), 1) if len(long_ed) else None,
+                         "mean_chain_edit_distance": round(float(chain_ed.mean()), 1) if len(chain_ed) else None},
+            "long_pass": {"reads_with_alignment": int(reads_with_long / steps), "extensions_per_step": int(counters_long[4]), "rounds": int(counters_long[6]), "plain_layout_reruns": int(counters_long[7]),
+                          "seeds_extended_mean": round(float(seeds_ext_long.mean()), 2) if len(seeds_ext_long) else None, "seeds_extended_max": int(seeds_ext_long.max()) if len(seeds_ext_long) else None} if long_pass else None,
         }
         print(json.dumps(line))
     if dist is not None:

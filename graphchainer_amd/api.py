@@ -50,7 +50,7 @@ class GcResult(C.Structure):
         ("read_longall_off", _P(C.c_uint64)), ("longall_start", _P(C.c_uint32)), ("longall_end", _P(C.c_uint32)), ("longall_score", _P(C.c_uint32)),
         ("long_trace_off", _P(C.c_uint64)), ("long_trace_node", _P(C.c_int32)), ("long_trace_offset", _P(C.c_uint32)),
         ("long_trace_seqpos", _P(C.c_uint32)), ("long_trace_switch", _P(C.c_uint8)),
-        ("failed_assertion", _P(C.c_uint8)), ("seeds_extended", _P(C.c_uint64)), ("seeds_extended_long", _P(C.c_uint64)),
+        ("failed_assertion", _P(C.c_uint8)), ("capacity_exceeded", _P(C.c_uint8)), ("seeds_extended", _P(C.c_uint64)), ("seeds_extended_long", _P(C.c_uint64)),
         ("read_path_off", _P(C.c_uint64)), ("path_node", _P(C.c_uint32)), ("path_first_offset", _P(C.c_uint32)), ("path_last_offset", _P(C.c_uint32)), ("path_cells", _P(C.c_uint64)),
         ("read_long_off", _P(C.c_uint64)), ("long_index", _P(C.c_uint32)), ("long_edit_distance", _P(C.c_int64)), ("chain_edit_distance", _P(C.c_int64)), ("chained_better", _P(C.c_uint8)),
         ("read_chain_trace_off", _P(C.c_uint64)), ("chain_trace_node", _P(C.c_int32)), ("chain_trace_offset", _P(C.c_uint32)), ("chain_trace_seqpos", _P(C.c_uint32)), ("chain_trace_switch", _P(C.c_uint8)),
@@ -328,7 +328,7 @@ _RESULT_FIELDS = {
     "anchor_first_node": "anchors", "anchor_first_offset": "anchors", "anchor_first_seqpos": "anchors",
     "anchor_last_node": "anchors", "anchor_last_offset": "anchors", "anchor_last_seqpos": "anchors", "anchor_score": "anchors",
     "read_chain_off": "n+1", "chain": "chains", "chain_score": "n",
-    "failed_assertion": "n", "seeds_extended": "n", "seeds_extended_long": "n",
+    "failed_assertion": "n", "capacity_exceeded": "n", "seeds_extended": "n", "seeds_extended_long": "n",
     "read_longall_off": "n+1", "longall_start": "longs", "longall_end": "longs", "longall_score": "longs",
 }
 

@@ -62,6 +62,12 @@ struct DeviceBuffer {   // growable device allocation owned by a stream object
 	~DeviceBuffer() { if (ptr) (void)hipFree(ptr); }
 };
 
+// One whole-read pass at a time per device: its rounds saturate the scalar issue ports of the whole chip, so two passes side by side
+// (two batches in flight on two gc_streams) only take turns at a finer grain and both finish late. With the token the second batch's
+// seeding, host glue and fragment pipeline overlap the first batch's whole-read pass, and its own pass starts the moment the first
+// one ends - a software pipeline over batches (GC_LONG_TOKEN=0 turns it off).
+std::mutex g_longPassToken[16];
+
 double nowUs() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Persistent worker pool for the per-read host glue (threads are created once per process).
@@ -215,6 +221,7 @@ struct ReadGlue {
 	uint64_t longBegin = 0, longTraceBegin = 0, longSeedBegin = 0;
 	bool failed = false;
 	bool longFailed = false;              // the whole-read pass asserted: no anchors, chain or alignment for this read
+	bool capacityExceeded = false;        // a capacity of this library (not of the reference) was exceeded while processing this read
 	uint64_t slotBegin = 0, fragBegin = 0;
 	uint64_t nAnchors = 0, nPath = 0, nTrace = 0, anchorBegin = 0, pathBegin = 0, traceBegin = 0, seedBegin = 0, chainBegin = 0;
 	StitchedPath stitched;                // chain stitching result
@@ -235,7 +242,7 @@ struct ReadGlue {
 		seeds.clear(); longSeeds.clear(); windows.clear(); longAlns.clear(); longSelected.clear();
 		stitched.nodes.clear(); stitched.firstOffset = stitched.lastOffset = 0; stitched.cells = 0;
 		longBegin = longTraceBegin = longSeedBegin = 0;
-		failed = longFailed = false;
+		failed = longFailed = capacityExceeded = false;
 		slotBegin = fragBegin = 0;
 		nAnchors = nPath = nTrace = anchorBegin = pathBegin = traceBegin = seedBegin = chainBegin = 0;
 		stitchedBegin = longSelectedBegin = 0;
@@ -260,7 +267,7 @@ struct gc_stream {
 	int device = 0;             // the device the stream was created on; gc_align_batch selects it for the calling thread
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[12] {};
-	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, work, results, scratch, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
+	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, work, results, scratch, scratchRetry, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
 	PinnedBuffer hMatches, hWork, hFrags, hFragSeeds, hJobs, hAnchors, hFragStatus, hFragExtended, hChainOut, hChainLen, hChainScore, hChainStatus, hPathPool, hSmall;
 	// whole-read pass: runs on its own stream, concurrently with the fragment kernels
 	hipStream_t longStream = nullptr;
@@ -583,8 +590,7 @@ static void finishEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 	// reruns for the pairs whose band outgrew their unit (grouped order throughout)
 	std::vector<uint32_t> todo;
 	for (uint32_t i = 0; i < nPairs; i++) {
-		if (hOut[i] == -3) throw std::runtime_error("path letters overflowed their slot");
-		if (hOut[i] == -2) todo.push_back(i);
+		if (hOut[i] == -2) todo.push_back(i);   // (-3: the path letters overflowed their slot - stays, the caller flags the read)
 	}
 	std::vector<EdPair> sub;
 	std::vector<int64_t> subOut;
@@ -600,7 +606,7 @@ static void finishEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 		for (size_t i = 0; i < todo.size(); i++) { hOut[todo[i]] = subOut[i]; if (subOut[i] == -2) next.push_back(todo[i]); }
 		todo.swap(next);
 	}
-	if (!todo.empty()) throw std::runtime_error("edit distance band too wide for the NW kernel (a read longer than 65536 bases more than 32256 edits away from its path)");
+	// still -2: the band is too wide for the NW kernel (a read longer than 65536 bases more than 32256 edits away from its path); the caller flags the read
 	// back to the caller's order
 	run.grouped.assign(hOut, hOut + nPairs);
 	for (uint32_t i = 0; i < nPairs; i++) hOut[run.perm[i]] = run.grouped[i];
@@ -1139,77 +1145,47 @@ int gc_reads_upload(const char* bases, const uint64_t* offsets, uint64_t n, gc_r
 		requireDevice();
 		R->offsets.assign(offsets, offsets + n + 1);
 		R->totalBases = offsets[n];
-		R->invalid.assign(n, 0);
-		std::vector<char> both(2 * R->totalBases);
-		if (R->totalBases) memcpy(both.data(), bases, R->totalBases);
-		uint8_t iupac[256];
-		buildIupacTable(iupac);
-		for (uint64_t r = 0; r < n; r++) {
-			uint64_t a = offsets[r], b = offsets[r + 1];
-			for (uint64_t i = a; i < b; i++) {
-				char c = bases[i];
-				char rc = 'N';
-				if (iupac[(uint8_t)c] == 0) R->invalid[r] = 1;
-				else rc = gc::Complement(c);
-				both[R->totalBases + a + (b - 1 - i)] = rc;
-			}
-		}
-		// match-mask bit vectors of both strands
+		if (n >= 0xffffffffull) throw std::runtime_error("too many reads in one batch");
+		// per-read layout of the bit vectors (host, O(n)); everything per base is derived on the device from one copy of the raw bases
 		R->maskOff.assign(n, 0);
 		R->maskWords.assign(n, 0);
-		uint64_t totalWords = 0;
-		for (uint64_t r = 0; r < n; r++) { R->maskOff[r] = totalWords; R->maskWords[r] = (uint32_t)((offsets[r + 1] - offsets[r] + 63) / 64 + 1); totalWords += 8ull * R->maskWords[r]; }
-		std::vector<uint64_t> masks(totalWords, 0);
+		std::vector<EdRead> edReads(n);
+		std::vector<uint64_t> eqOff(n);
+		uint64_t totalWords = 0, eqWords = 0;
 		for (uint64_t r = 0; r < n; r++) {
-			uint64_t a = offsets[r], len = offsets[r + 1] - a, words = R->maskWords[r];
-			for (int strand = 0; strand < 2; strand++) {
-				const char* sq = both.data() + (strand ? R->totalBases : 0) + a;
-				uint64_t* m = masks.data() + R->maskOff[r] + (uint64_t)strand * 4 * words;
-				for (uint64_t i = 0; i < len; i++) {
-					uint8_t set = iupac[(uint8_t)sq[i]];
-					uint64_t bit = 1ull << (i & 63);
-					if (set & 1) m[i >> 6] |= bit;
-					if (set & 2) m[words + (i >> 6)] |= bit;
-					if (set & 4) m[2 * words + (i >> 6)] |= bit;
-					if (set & 8) m[3 * words + (i >> 6)] |= bit;
-				}
-			}
+			R->maskOff[r] = totalWords;
+			R->maskWords[r] = (uint32_t)((offsets[r + 1] - offsets[r] + 63) / 64 + 1);
+			totalWords += 8ull * R->maskWords[r];
+			edReads[r] = EdRead { offsets[r], eqWords, (uint32_t)(offsets[r + 1] - offsets[r]), R->maskWords[r] };
+			eqOff[r] = eqWords;
+			eqWords += 4ull * R->maskWords[r];
 		}
-		HIP_CHECK(hipMalloc((void**)&R->devMasks, std::max<size_t>(masks.size(), 1) * sizeof(uint64_t)));
-		if (!masks.empty()) HIP_CHECK(hipMemcpy(R->devMasks, masks.data(), masks.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-		{
-			std::vector<EdRead> edReads(n);
-			uint64_t eqWords = 0;
-			for (uint64_t r = 0; r < n; r++) { edReads[r] = EdRead { offsets[r], eqWords, (uint32_t)(offsets[r + 1] - offsets[r]), R->maskWords[r] }; eqWords += 4ull * R->maskWords[r]; }
-			std::vector<uint64_t> eqMasks(eqWords, 0);
-			for (uint64_t r = 0; r < n; r++) buildEqMasks(bases + offsets[r], edReads[r].len, edReads[r].words, eqMasks.data() + edReads[r].eqOff);
-			HIP_CHECK(hipMalloc((void**)&R->devEqMasks, std::max<size_t>(eqWords, 1) * sizeof(uint64_t)));
-			if (eqWords) HIP_CHECK(hipMemcpy(R->devEqMasks, eqMasks.data(), eqWords * sizeof(uint64_t), hipMemcpyHostToDevice));
-			{
-				std::vector<uint32_t> chunkRead((R->totalBases >> 6) + 1, 0);
-				uint64_t r = 0;
-				for (uint64_t c = 0; c < chunkRead.size(); c++) { uint64_t p = c << 6; while (r + 1 < n && offsets[r + 1] <= p) r++; chunkRead[c] = (uint32_t)r; }
-				std::vector<uint64_t> packed((R->totalBases >> 5) + 1, 0), invalidBits((R->totalBases >> 6) + 1, 0);
-				for (uint64_t p = 0; p < R->totalBases; p++) {
-					int c = -1;
-					switch (bases[p]) { case 'a': case 'A': c = 0; break; case 'c': case 'C': c = 1; break; case 'g': case 'G': c = 2; break; case 't': case 'T': c = 3; break; }
-					if (c < 0) invalidBits[p >> 6] |= 1ull << (63 - (p & 63));
-					else packed[p >> 5] |= (uint64_t)c << (2 * (31 - (p & 31)));
-				}
-				HIP_CHECK(hipMalloc((void**)&R->devPacked, packed.size() * sizeof(uint64_t)));
-				HIP_CHECK(hipMemcpy(R->devPacked, packed.data(), packed.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-				HIP_CHECK(hipMalloc((void**)&R->devInvalid, invalidBits.size() * sizeof(uint64_t)));
-				HIP_CHECK(hipMemcpy(R->devInvalid, invalidBits.data(), invalidBits.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-				HIP_CHECK(hipMalloc((void**)&R->devChunkRead, chunkRead.size() * sizeof(uint32_t)));
-				HIP_CHECK(hipMemcpy(R->devChunkRead, chunkRead.data(), chunkRead.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-			}
-			HIP_CHECK(hipMalloc((void**)&R->devEdReads, std::max<size_t>(n, 1) * sizeof(EdRead)));
-			if (n) HIP_CHECK(hipMemcpy(R->devEdReads, edReads.data(), n * sizeof(EdRead), hipMemcpyHostToDevice));
-		}
-		HIP_CHECK(hipMalloc((void**)&R->devBases, std::max<size_t>(both.size(), 1)));
-		if (!both.empty()) HIP_CHECK(hipMemcpy(R->devBases, both.data(), both.size(), hipMemcpyHostToDevice));
+		const uint64_t total = R->totalBases;
+		HIP_CHECK(hipMalloc((void**)&R->devBases, std::max<size_t>(2 * total, 1)));
 		HIP_CHECK(hipMalloc((void**)&R->devOffsets, (n + 1) * sizeof(uint64_t)));
+		HIP_CHECK(hipMalloc((void**)&R->devMasks, std::max<size_t>(totalWords, 1) * sizeof(uint64_t)));
+		HIP_CHECK(hipMalloc((void**)&R->devEqMasks, std::max<size_t>(eqWords, 1) * sizeof(uint64_t)));
+		HIP_CHECK(hipMalloc((void**)&R->devEdReads, std::max<size_t>(n, 1) * sizeof(EdRead)));
+		HIP_CHECK(hipMalloc((void**)&R->devPacked, ((total >> 5) + 1) * sizeof(uint64_t)));
+		HIP_CHECK(hipMalloc((void**)&R->devInvalid, ((total >> 6) + 1) * sizeof(uint64_t)));
+		HIP_CHECK(hipMalloc((void**)&R->devChunkRead, ((total >> 6) + 1) * sizeof(uint32_t)));
+		DeviceBuffer dMaskOff, dMaskWords, dEqOff, dReadInvalid;
+		uint64_t* pMaskOff = dMaskOff.reserve<uint64_t>(n);
+		uint32_t* pMaskWords = dMaskWords.reserve<uint32_t>(n);
+		uint64_t* pEqOff = dEqOff.reserve<uint64_t>(n);
+		uint8_t* pInvalid = dReadInvalid.reserve<uint8_t>(n);
+		if (total) HIP_CHECK(hipMemcpy(R->devBases, bases, total, hipMemcpyHostToDevice));
 		HIP_CHECK(hipMemcpy(R->devOffsets, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+		if (n) {
+			HIP_CHECK(hipMemcpy(pMaskOff, R->maskOff.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
+			HIP_CHECK(hipMemcpy(pMaskWords, R->maskWords.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+			HIP_CHECK(hipMemcpy(pEqOff, eqOff.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
+			HIP_CHECK(hipMemcpy(R->devEdReads, edReads.data(), n * sizeof(EdRead), hipMemcpyHostToDevice));
+		}
+		launchPackReads(nullptr, R->devOffsets, (uint32_t)n, total, R->devBases, pMaskOff, pMaskWords, R->devMasks, pEqOff, R->devEqMasks, pInvalid, R->devPacked, R->devInvalid, R->devChunkRead);
+		R->invalid.assign(n, 0);
+		if (n) HIP_CHECK(hipMemcpy(R->invalid.data(), pInvalid, n, hipMemcpyDeviceToHost));   // (synchronises with the kernels on the null stream)
+		else HIP_CHECK(hipDeviceSynchronize());
 		return (int)GC_OK;
 	});
 	if (rc != GC_OK) { delete R; return rc; }
@@ -1229,7 +1205,7 @@ void gc_result_free(gc_result* r)
 		r->read_longall_off, r->longall_start, r->longall_end, r->longall_score, r->long_trace_off, r->long_trace_node, r->long_trace_offset, r->long_trace_seqpos, r->long_trace_switch,
 		r->failed_assertion, r->seeds_extended, r->seeds_extended_long, r->read_path_off, r->path_node, r->path_first_offset, r->path_last_offset, r->path_cells,
 		r->read_long_off, r->long_index, r->long_edit_distance, r->chain_edit_distance, r->chained_better,
-		r->read_chain_trace_off, r->chain_trace_node, r->chain_trace_offset, r->chain_trace_seqpos, r->chain_trace_switch, r->chain_aln_start, r->chain_aln_end };
+		r->capacity_exceeded, r->read_chain_trace_off, r->chain_trace_node, r->chain_trace_offset, r->chain_trace_seqpos, r->chain_trace_switch, r->chain_aln_start, r->chain_aln_end };
 	for (void* p : ptrs) free(p);
 	free(r);
 }
@@ -1300,8 +1276,11 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		});
 		double tOrdered = nowUs();
 		// ---------------- K3-long: whole-read pass on its own stream (src/Aligner.cpp:630-654)
-		const uint32_t maxAlignments = 32;
 		uint64_t nLongSeeds = 0, maxReadLen = 1;
+		for (uint64_t r = 0; r < n; r++) maxReadLen = std::max<uint64_t>(maxReadLen, R->offsets[r + 1] - R->offsets[r]);
+		// alignments kept per read: the reference has no limit; 32 is far above what 10 kb reads produce (3.6 seeds extended on average), longer
+		// and noisier reads get room in proportion. A read that still exceeds it is flagged (capacity_exceeded), the batch goes on.
+		const uint32_t maxAlignments = (uint32_t)std::max<uint64_t>(32, maxReadLen / 512);
 		LongAln* hLongAlns = nullptr;
 		LongReadResult* hLongResults = nullptr;
 		unsigned long long* hLongSmall = nullptr;
@@ -1401,11 +1380,15 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			if (!D.nPairs) return;
 			const DecisionPointers& p = decisionPtr[slot];
 			finishEditDistances(D.run, st->longStream, p.hPairs, p.hOut, D.nPairs, p.dPairs, p.dOut, R->devEdReads, R->devBases, R->devEqMasks, p.dLetters, p.dLettersLen);
-			for (uint32_t i = 0; i < D.nPairs; i++) glue[D.pairRead[i]].longEditDistance = p.hOut[i];
+			for (uint32_t i = 0; i < D.nPairs; i++) {
+				ReadGlue& gl = glue[D.pairRead[i]];
+				gl.longEditDistance = p.hOut[i];
+				if (p.hOut[i] < -1) { gl.longEditDistance = -1; gl.capacityExceeded = true; }   // outside the NW kernel's range: flagged, no distance
+			}
 			D.nPairs = 0;
 		};
 		if (P->long_pass) {
-			for (uint64_t r = 0; r < n; r++) { glue[r].longSeedBegin = nLongSeeds; nLongSeeds += glue[r].longSeeds.size(); maxReadLen = std::max<uint64_t>(maxReadLen, R->offsets[r + 1] - R->offsets[r]); }
+			for (uint64_t r = 0; r < n; r++) { glue[r].longSeedBegin = nLongSeeds; nLongSeeds += glue[r].longSeeds.size(); }
 			if (nLongSeeds >= 0xffffffffull) throw std::runtime_error("batch too large for the whole-read pass");
 			LongSeed* hSeeds = st->hLongSeeds.reserve<LongSeed>(nLongSeeds);
 			LongJob* hJobs = st->hLongJobs.reserve<LongJob>(n);
@@ -1509,7 +1492,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				uint32_t lastWork = 0xffffffffu;
 
 				for (int round = 0; round < 4096; round++) {
-					HIP_CHECK(hipMemsetAsync(cursor, 0, 3 * sizeof(unsigned long long), q));   // [0] work count, [1] round trace cursor, [2] next work slot
+					launchZeroWords(q, cursor, 3);   // [0] work count, [1] round trace cursor, [2] next work slot
 					// tail rounds: once fewer than a quarter of the reads are still active the chip is mostly idle, so the
 					// remaining reads try several seeds per round (exact: k_long_merge re-checks them in order)
 					// (the number of work items stays below what round 0 had: active reads x candidates <= n)
@@ -1538,7 +1521,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					if (team == 1) {
 						// extensions whose band outgrew the 64-entry register tables: second try with the LDS/HBM tables (two lanes per wave,
 						// 28 + 228 entries); waves whose items are fine leave at once. Beyond that the read goes to the plain-layout fallback.
-						HIP_CHECK(hipMemsetAsync(cursor + 2, 0, sizeof(unsigned long long), q));
+						launchZeroWords(q, cursor + 2, 1);
 						uint32_t retryBlocks = std::min<uint32_t>((nWorkItems + 1) / 2, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / 2));
 						launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 2, retryBlocks,
 							dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, EXT_LDS_CAP);
@@ -1568,17 +1551,21 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				HIP_CHECK(hipStreamSynchronize(ls));
 				std::vector<uint32_t> redo;
 				const bool forceAll = getenv("GC_LONG_FORCE_FALLBACK") != nullptr;   // test hook: run every read through the plain-layout kernel too
-				for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status == 5 || forceAll) redo.push_back((uint32_t)r);
+				// status 5: a slice with more nodes than the wave tables hold; status 2: an extension with more tiles / trace cells than its scratch
+				// (the plain-layout kernel below gets four times the room)
+				for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status == 5 || hLongResults[r].status == 2 || forceAll) redo.push_back((uint32_t)r);
 				if (!redo.empty()) {
 					std::vector<LongJob> subJobs(redo.size());
 					for (size_t i = 0; i < redo.size(); i++) subJobs[i] = hJobs[redo[i]];
-					uint64_t lslab = longSlabBytes(lcfg);
+					ExtendConfig fcfg = lcfg;
+					fcfg.maxItems = 4 * lcfg.maxItems; fcfg.maxTrace = 2 * lcfg.maxTrace; fcfg.maxPending = 4 * lcfg.maxPending;
+					uint64_t lslab = longSlabBytes(fcfg);
 					uint64_t lanes = (redo.size() + 63) / 64 * 64;
 					LongJob* dSubJobs = st->longJobsFallback.reserve<LongJob>(redo.size());
 					LongReadResult* dSubResults = st->longResultsFallback.reserve<LongReadResult>(redo.size());
 					uint8_t* dSlab = st->longScratchFallback.reserve<uint8_t>(lanes * lslab);
 					HIP_CHECK(hipMemcpyAsync(dSubJobs, subJobs.data(), redo.size() * sizeof(LongJob), hipMemcpyHostToDevice, ls));
-					launchLongPass(ls, G->dev, G->devTables, G->devIupac, lcfg, dSubJobs, (uint32_t)redo.size(), dLongSeeds, R->devBases, R->totalBases, (uint32_t)P->min_cluster_size, maxAlignments,
+					launchLongPass(ls, G->dev, G->devTables, G->devIupac, fcfg, dSubJobs, (uint32_t)redo.size(), dLongSeeds, R->devBases, R->totalBases, (uint32_t)P->min_cluster_size, maxAlignments,
 						dSlab, lslab, dLongCells, dLongCursor, cellBudget, dLongAlns, dSubResults, dLongCursor + 8);
 					std::vector<LongReadResult> subResults(redo.size());
 					HIP_CHECK(hipMemcpyAsync(subResults.data(), dSubResults, redo.size() * sizeof(LongReadResult), hipMemcpyDeviceToHost, ls));
@@ -1596,6 +1583,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		std::vector<std::thread> longThreads;
 		std::vector<std::exception_ptr> longErrors(16);
 		double tLongWall0 = nowUs();
+		std::atomic<double> longWallBeginUs { 0.0 };   // when the pass got the device's token (waiting for another batch's pass is not its own time)
 		std::atomic<double> longWallEndUs { 0.0 };
 		struct JoinGuard { std::vector<std::thread>& t; ~JoinGuard() { for (auto& x : t) if (x.joinable()) x.join(); } } joinGuard { longThreads };
 		if (P->long_pass) {
@@ -1605,6 +1593,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				longThreads.emplace_back([&, device, g]() {
 					try {
 						HIP_CHECK(hipSetDevice(device));
+						static const bool useToken = !(getenv("GC_LONG_TOKEN") && atoi(getenv("GC_LONG_TOKEN")) == 0);
+						std::unique_lock<std::mutex> token(g_longPassToken[device & 15], std::defer_lock);
+						if (useToken && longGroups == 1) token.lock();
+						{ double now = nowUs(), seen = longWallBeginUs.load(); while ((seen == 0.0 || now < seen) && !longWallBeginUs.compare_exchange_weak(seen, now)) {} }
 						runLongGroup(g);
 					} catch (...) { longErrors[g] = std::current_exception(); }
 					double now = nowUs(), seen = longWallEndUs.load();
@@ -1675,6 +1667,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		});
 		uint64_t traceBudget = 0;
 		for (uint64_t b : traceBudgets) traceBudget += b;
+		traceBudget += traceBudget / 4 + (1u << 20);   // room for the extensions that only fit the retry launch's larger trace buffers
 		ChainCaps caps { 1, 1, 1 };
 		for (uint64_t r = 0; r < n; r++) caps.capAnchors = std::max(caps.capAnchors, jobs[r].nSlots);
 		res->host_us[0] = nowUs() - tGlue;
@@ -1703,7 +1696,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		AnchorRec* dAnchors = st->anchors.reserve<AnchorRec>(nSlots);
 		uint32_t* dFragStatus = st->fragStatus.reserve<uint32_t>(nFrags);
 		uint32_t* dFragExtended = st->fragExtended.reserve<uint32_t>(nFrags);
-		uint64_t pathCapacity = nSlots * 16 + 1024;
+		uint64_t pathCapacity = nSlots * 24 + 4096;
 		uint32_t* dPathPool = st->pathPool.reserve<uint32_t>(pathCapacity);
 		ReadChainJob* dJobs = st->jobs.reserve<ReadChainJob>(n);
 		uint32_t* dChainOut = st->chainOut.reserve<uint32_t>(nSlots);
@@ -1718,6 +1711,17 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		if (n) HIP_CHECK(hipMemcpyAsync(dJobs, jobs, n * sizeof(ReadChainJob), hipMemcpyHostToDevice, stream));
 		mark();   // 2
 		launchExtend(stream, G->dev, G->devTables, G->devIupac, cfg, dWork, nWork, R->devBases, dResults, dScratch, slabBytes, dTrace, dCursors + 1, traceBudget, dCounters);
+		{
+			// extensions that outgrew their slab (a dense variant cluster: more tiles, queue entries or trace cells than the common case is sized
+			// for) run again in a small grid with 16x the room; lanes whose items are fine only read the status array. What overflows even
+			// that is flagged per read (capacity_exceeded), never a failed call.
+			ExtendConfig big = cfg;
+			big.maxItems = 16 * cfg.maxItems; big.maxPending = 16 * cfg.maxPending; big.maxTrace = 16 * cfg.maxTrace; big.maxSlices = cfg.maxSlices;
+			if (const char* env = getenv("GC_EXT_RETRY_MAX_ITEMS")) big.maxItems = (uint32_t)std::max(8, atoi(env));   // test hook: make the retry overflow too
+			const uint32_t retryLanes = 2048;
+			uint8_t* dRetryScratch = st->scratchRetry.reserve<uint8_t>((uint64_t)retryLanes * extendSlabBytes(big));
+			launchExtend(stream, G->dev, G->devTables, G->devIupac, big, dWork, nWork, R->devBases, dResults, dRetryScratch, extendSlabBytes(big), dTrace, dCursors + 1, traceBudget, dCounters, EXT_OVERFLOW, retryLanes);
+		}
 		mark();   // 3
 		launchBuildAnchors(stream, G->dev, dFrags, (uint32_t)nFrags, dFragSeeds, dResults, dTrace, P->split_len, dAnchors, dFragStatus, dFragExtended, dPathPool, dCursors + 2, pathCapacity);
 		mark();   // 4
@@ -1770,9 +1774,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		res->kernel_us[2] = elapsedUs(3, 4);
 		res->kernel_us[3] = elapsedUs(4, 5);
 		for (int i = 0; i < 8; i++) res->counters[i] = hSmall[8 + i];
-		uint64_t traceUsed = hSmall[1], pathUsed = hSmall[2];
-		if (traceUsed > traceBudget) throw std::runtime_error("trace pool overflow (raise GC_EXT_MAX_TRACE / report)");
-		if (pathUsed > pathCapacity) throw std::runtime_error("anchor path pool overflow");
+		// (the cursors overshoot when a pool is full: the extensions / fragments that did not fit carry an overflow status and their reads are flagged)
+		uint64_t traceUsed = std::min<uint64_t>(hSmall[1], traceBudget), pathUsed = std::min<uint64_t>(hSmall[2], pathCapacity);
 		uint32_t* pathPool = st->hPathPool.reserve<uint32_t>(pathUsed);
 		if (pathUsed) HIP_CHECK(hipMemcpyAsync(pathPool, dPathPool, pathUsed * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		std::vector<ExtResult> extResults;
@@ -1868,7 +1871,11 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			launchEditDistances(st->edChainRun, stream, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen, readLenOf);
 			finishChainEditDistances = [=, &glue, &pairRead]() {   // waits for the kernels (they run beside the whole-read pass) and reruns the few pairs that need a wider band
 				finishEditDistances(st->edChainRun, stream, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen);
-				for (uint32_t i = 0; i < nPairs; i++) glue[pairRead[i]].chainEditDistance = hOut[i];
+				for (uint32_t i = 0; i < nPairs; i++) {
+					ReadGlue& gl = glue[pairRead[i]];
+					gl.chainEditDistance = hOut[i];
+					if (hOut[i] < -1) { gl.chainEditDistance = -1; gl.capacityExceeded = true; }
+				}
 			};
 		}
 		if (finishChainEditDistances) finishChainEditDistances();   // this thread would only wait for the whole-read pass otherwise
@@ -1894,7 +1901,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] main thread waited %.1f ms for the whole-read pass\n", (tJoined - tJoin0) / 1e3);
 			for (auto& e : longErrors) if (e) std::rethrow_exception(e);
 			finishLongGroups();
-			res->kernel_us[5] = longWallEndUs.load() - tLongWall0;   // whole-read pass, wall clock from the first group's start to the last group's end
+			res->kernel_us[5] = longWallEndUs.load() - (longWallBeginUs.load() > 0.0 ? longWallBeginUs.load() : tLongWall0);   // whole-read pass, wall clock from the first group's start to the last group's end
 			uint64_t rerun = longFallback();
 			res->counters_long[7] = rerun;   // reads that needed the plain-layout fallback kernel
 			for (int i = 0; i < 6; i++) res->counters_long[i] = hLongSmall[8 + i];   // same units as counters[]
@@ -1914,11 +1921,9 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			// `cont` (src/Aligner.cpp:591), which is declared once per read (:529) and makes the fragment loop skip every anchor
 			// (:702-703); the alignments found before the throw are lost with the exception.
 			for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status == 1) { hLongResults[r].nAlignments = 0; glue[r].longFailed = true; }
-			for (uint64_t r = 0; r < n; r++) {
-				if (hLongResults[r].status == 2) throw std::runtime_error("whole-read pass: extension scratch overflow (raise GC_LONG_MAX_ITEMS)");
-				if (hLongResults[r].status == 3) throw std::runtime_error("whole-read pass: more than 32 alignments for one read");
-				if (hLongResults[r].status == 4) throw std::runtime_error("whole-read pass: trace cell pool overflow (raise GC_LONG_CELLS_PER_BASE)");
-			}
+			// capacities of this library, not of the reference: 2 extension scratch (even with the fallback's four-fold room), 3 more alignments than
+			// maxAlignments, 4 the merged-trace cell pool (GC_LONG_CELLS_PER_BASE). The read keeps what was found up to there and is flagged.
+			for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status >= 2 && hLongResults[r].status <= 4) glue[r].capacityExceeded = true;
 			{
 				std::vector<uint32_t> all(n);
 				for (uint64_t r = 0; r < n; r++) all[r] = (uint32_t)r;
@@ -2021,7 +2026,6 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 
 		// ---------------- assemble the flat result: count per read, prefix-sum, fill in parallel
 		double tAsm = nowUs();
-		std::atomic<int> overflow { 0 }, chainFailure { 0 };
 		std::vector<uint8_t> failedAssertion(n, 0);
 		std::vector<uint64_t> seedsExtended(n, 0), seedsExtendedLong(n, 0);
 		auto forEachAnchor = [&](uint64_t r, auto&& visit) {   // visit(slotIndex, fragmentIndex) for every anchor the reference would keep
@@ -2047,10 +2051,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				if (P->long_pass) seedsExtendedLong[r] = hLongResults[r].seedsExtended;
 				return;
 			}
-			if (chainStatus[r] != 0) chainFailure = (int)chainStatus[r];
+			if (chainStatus[r] != 0) { gl.capacityExceeded = true; chainLen[r] = 0; chainScore[r] = 0; }
 			for (size_t f = 0; f < gl.windows.size(); f++) {
 				uint64_t F = gl.fragBegin + f;
-				if (fragStatus[F] == 2) overflow = 1;
+				if (fragStatus[F] == 2) gl.capacityExceeded = true;   // an extension or the anchor path pool overflowed even in the retry: this fragment gave no anchors
 				if (fragStatus[F] == 1) { failedAssertion[r] = 1; break; }
 				seedsExtended[r] += fragExtended[F];
 			}
@@ -2070,8 +2074,6 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				}
 			});
 		});
-		if (overflow) throw std::runtime_error("extension capacity overflow in a fragment (raise GC_EXT_MAX_ITEMS / GC_EXT_MAX_PENDING / GC_EXT_MAX_TRACE)");
-		if (chainFailure) throw std::runtime_error("chaining kernel failure (status " + std::to_string((int)chainFailure) + ")");
 		uint64_t nAnchors = 0, nPath = 0, nTrace = 0, nChain = 0, nLong = 0, nLongTrace = 0, nStitched = 0, nLongSelected = 0, nChainTrace = 0;
 		for (uint64_t r = 0; r < n; r++) {
 			glue[r].anchorBegin = nAnchors; glue[r].pathBegin = nPath; glue[r].traceBegin = nTrace; glue[r].chainBegin = nChain;
@@ -2124,6 +2126,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		res->chain_trace_seqpos = mallocArray<uint32_t>(nChainTrace); res->chain_trace_switch = mallocArray<uint8_t>(nChainTrace);
 		res->chain_aln_start = mallocArray<uint32_t>(n); res->chain_aln_end = mallocArray<uint32_t>(n);
 		res->failed_assertion = mallocArray<uint8_t>(n);
+		res->capacity_exceeded = mallocArray<uint8_t>(n);
 		res->seeds_extended = mallocArray<uint64_t>(n);
 		res->read_seed_off[n] = keepSeeds ? nSeedsTotal : 0; res->read_anchor_off[n] = nAnchors; res->anchor_path_off[nAnchors] = nPath; res->read_chain_off[n] = nChain;
 		pool.run(n, [&](size_t r, size_t) {
@@ -2137,6 +2140,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			res->read_chain_off[r] = gl.chainBegin;
 			res->chain_score[r] = chainScore[r];
 			res->failed_assertion[r] = failedAssertion[r];
+			res->capacity_exceeded[r] = gl.capacityExceeded ? 1 : 0;
 			res->seeds_extended[r] = seedsExtended[r];
 			res->seeds_extended_long[r] = seedsExtendedLong[r];
 			res->read_longall_off[r] = gl.longBegin;

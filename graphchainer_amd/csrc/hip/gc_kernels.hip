@@ -156,13 +156,14 @@ __device__ __forceinline__ LaneScratch laneScratch(uint8_t* slab, const ExtendCo
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg,
 	const ExtItem* __restrict__ work, uint32_t nWork, const char* __restrict__ bases, ExtResult* __restrict__ results,
 	uint8_t* __restrict__ scratch, uint64_t slabBytes, TraceCell* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity,
-	unsigned long long* __restrict__ counters)
+	unsigned long long* __restrict__ counters, uint32_t retryStatus)
 {
 	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t stride = gridDim.x * blockDim.x;
 	LaneScratch sc = laneScratch(scratch + (uint64_t)tid * slabBytes, cfg);
 	ExtCounters cnt {};
 	for (uint32_t w = tid; w < nWork; w += stride) {
+		if (retryStatus != 0 && results[w].status != retryStatus) continue;   // retry launch (larger slabs): only the items the first launch gave up on
 		ExtItem it = work[w];
 		uint32_t nTrace = 0;
 		int32_t score = 0;
@@ -771,8 +772,11 @@ __global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __r
 // LANES = active lanes per wave ("team"). The pass is latency-bound and leaves most of the chip idle, so when there
 // are fewer work items than the chip has SIMDs x 64 lanes, running fewer lanes per wave shortens every wave: a wave's
 // instruction stream is the union of its lanes' divergent paths, and LDS per wave shrinks so more waves fit per CU.
+#ifndef GC_LONG_MIN_WAVES
+#define GC_LONG_MIN_WAVES 1
+#endif
 template <int LANES, bool PERSISTENT>
-__global__ void __launch_bounds__(64) k_long_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint64_t* __restrict__ masks, ExtendConfig cfg,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_LONG_MIN_WAVES, 8))) k_long_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint64_t* __restrict__ masks, ExtendConfig cfg,
 	const LongWork* __restrict__ work, const uint32_t* __restrict__ order, uint32_t nWork, unsigned long long* __restrict__ scratch, uint64_t wordsPerLane,
 	unsigned long long* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, LongWorkResult* __restrict__ results, unsigned long long* __restrict__ counters,
 	unsigned long long* __restrict__ nextSlot, uint32_t retryStatus)
@@ -957,6 +961,13 @@ __global__ void k_publish(const unsigned long long* __restrict__ src, unsigned l
 	if (threadIdx.x < nWords) { dst[threadIdx.x] = src[threadIdx.x]; __threadfence_system(); }
 }
 
+// a few words set to zero by a kernel: a hipMemsetAsync inside the round loop may go through a copy engine and queue behind another
+// batch's bulk uploads
+__global__ void k_zero_words(unsigned long long* __restrict__ dst, uint32_t nWords)
+{
+	if (threadIdx.x < nWords) dst[threadIdx.x] = 0;
+}
+
 __global__ void __launch_bounds__(256) k_long_finish(uint32_t nReads, const LongState* __restrict__ state, LongReadResult* __restrict__ results)
 {
 	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -997,11 +1008,11 @@ uint32_t extendGridLanes(uint32_t nWork)
 
 void launchExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg,
 	const ExtItem* work, uint32_t nWork, const char* bases, ExtResult* results, uint8_t* scratch, uint64_t slabBytes,
-	TraceCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters)
+	TraceCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters, uint32_t retryStatus, uint32_t retryLanes)
 {
 	if (nWork == 0) return;
-	uint32_t lanes = extendGridLanes(nWork);
-	hipLaunchKernelGGL(k_extend, dim3(lanes / 64), dim3(64), 0, stream, g, ct, iupac, cfg, work, nWork, bases, results, scratch, slabBytes, tracePool, traceCursor, traceCapacity, counters);
+	uint32_t lanes = retryStatus ? retryLanes : extendGridLanes(nWork);
+	hipLaunchKernelGGL(k_extend, dim3(lanes / 64), dim3(64), 0, stream, g, ct, iupac, cfg, work, nWork, bases, results, scratch, slabBytes, tracePool, traceCursor, traceCapacity, counters, retryStatus);
 }
 
 void launchBuildAnchors(hipStream_t stream, const DGraph& g, const Fragment* frags, uint32_t nFrags, const FragSeed* seeds, const ExtResult* ext,
@@ -1085,6 +1096,10 @@ void launchLongOrder(hipStream_t stream, const uint32_t* workLen, const unsigned
 void launchPublish(hipStream_t stream, const unsigned long long* src, unsigned long long* dst, uint32_t nWords)
 {
 	hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, stream, src, dst, nWords);
+}
+void launchZeroWords(hipStream_t stream, unsigned long long* dst, uint32_t nWords)
+{
+	hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, dst, nWords);
 }
 void launchLongFinish(hipStream_t stream, uint32_t nReads, const LongState* state, LongReadResult* results)
 {

@@ -118,7 +118,8 @@ uint64_t extendSlabBytes(const ExtendConfig& cfg);
 uint32_t extendGridLanes(uint32_t nWork);
 void launchExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg,
 	const ExtItem* work, uint32_t nWork, const char* bases, ExtResult* results, uint8_t* scratch, uint64_t slabBytes,
-	TraceCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters);
+	TraceCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters,
+	uint32_t retryStatus = 0, uint32_t retryLanes = 4096);   // retryStatus != 0: a small grid of `retryLanes` lanes reruns only the items whose result has that status (with the larger slabs of `cfg`)
 
 void launchBuildAnchors(hipStream_t stream, const DGraph& g, const Fragment* frags, uint32_t nFrags, const FragSeed* seeds, const ExtResult* ext,
 	const TraceCell* tracePool, int32_t splitLen, AnchorRec* anchors, uint32_t* fragStatus, uint32_t* fragExtended,
@@ -182,6 +183,9 @@ void launchChainPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* j
 uint32_t editDistanceMaxK(uint32_t unitBlocks);
 void launchEditDistance(hipStream_t stream, uint32_t unitBlocks, const EdPair* pairs, uint32_t nPairs, const EdRead* reads, const char* bases, const uint64_t* eqMasks,
 	const char* letters, const uint32_t* lettersLen, int64_t* outDistance);
+// ---- read batch preparation (gc_reads.hip): reverse-complement strand, match-mask / exact-match bit vectors, 2-bit packing, all from the raw bases
+void launchPackReads(hipStream_t stream, const uint64_t* readOff, uint32_t nReads, uint64_t totalBases, char* bases, const uint64_t* maskOff, const uint32_t* maskWords, uint64_t* masks,
+	const uint64_t* eqOff, uint64_t* eqMasks, uint8_t* readInvalid, uint64_t* packed, uint64_t* invalidBits, uint32_t* chunkRead);
 // ---- alignment path of (stitched chain path, read): edlib's EDLIB_TASK_PATH (gc_edpath.hip) ----
 struct EdPathJob {
 	uint64_t queryOff;            // path letters (rows), in `letters`
@@ -199,6 +203,7 @@ void launchEditPath(hipStream_t stream, const EdPathJob* jobs, uint32_t nJobs, c
 	uint8_t* opsOut, uint32_t* opsLen);
 void launchLongOrder(hipStream_t stream, const uint32_t* workLen, const unsigned long long* workCount, uint32_t* order, uint32_t maxLen, uint32_t mode);
 void launchPublish(hipStream_t stream, const unsigned long long* src, unsigned long long* dst, uint32_t nWords);
+void launchZeroWords(hipStream_t stream, unsigned long long* dst, uint32_t nWords);   // nWords <= 64
 void launchLongFinish(hipStream_t stream, uint32_t nReads, const LongState* state, LongReadResult* results);
 
 

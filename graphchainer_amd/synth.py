@@ -167,14 +167,21 @@ class SynthGraph:
             at = int(self.seg_start[i])
         return np.concatenate(pieces)[:length] if pieces else np.zeros(0, dtype=np.uint8)
 
-    def sample_reads(self, n_reads, read_len, seed=11, p_del=0.03, p_sub=0.04, p_ins=0.03):
-        """Returns a list of bytes. ONT-like defaults; CLR-like is (0.04, 0.02, 0.09)."""
+    def sample_reads(self, n_reads, read_len, seed=11, p_del=0.03, p_sub=0.04, p_ins=0.03, sv_fraction=0.0, sv_len=1500):
+        """Returns a list of bytes. ONT-like defaults; CLR-like is (0.04, 0.02, 0.09). sv_fraction of the reads carry a deletion of
+        sv_len graph bases in their middle (a structural variant the graph does not hold): the whole-read aligner stops at the
+        breakpoint while the chain bridges it - the reads GraphChainer's chained alignment is for."""
         rng = np.random.default_rng(seed)
+        sv_rng = np.random.default_rng(seed + 4000003) if sv_fraction > 0 else None
         reads = []
         span = int(read_len * 1.15) + 64
         for _ in range(n_reads):
-            start = int(rng.integers(0, max(1, self.backbone_len - span)))
-            hap = self.haplotype_window(rng, start, span)
+            with_sv = sv_rng is not None and sv_rng.random() < sv_fraction
+            take = span + (sv_len if with_sv else 0)
+            start = int(rng.integers(0, max(1, self.backbone_len - take)))
+            hap = self.haplotype_window(rng, start, take)
+            if with_sv and len(hap) > read_len // 2 + sv_len:
+                hap = np.concatenate([hap[:read_len // 2], hap[read_len // 2 + sv_len:]])
             u = rng.random(len(hap))
             keep = u >= p_del
             sub = (u >= p_del) & (u < p_del + p_sub)

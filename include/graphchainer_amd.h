@@ -11,8 +11,9 @@
  * a negative gc_status otherwise; gc_last_error() gives the message for the calling thread. Handles are
  * immutable after creation and may be shared between threads; one gc_align_batch per gc_stream at a
  * time (the reference's rule of one AlignerGraphsizedState per worker, src/Aligner.cpp:469).
- * Per-read failures (the reference's per-read catch of AssertionFailure, src/Aligner.cpp:585-592) are
- * reported in the result arrays, not as a call failure.
+ * Per-read failures (the reference's per-read catch of AssertionFailure, src/Aligner.cpp:585-592) and per-read
+ * capacity overflows of this library are reported in the result arrays (failed_assertion, capacity_exceeded),
+ * never as a call failure.
  */
 #ifndef GRAPHCHAINER_AMD_H
 #define GRAPHCHAINER_AMD_H
@@ -165,6 +166,10 @@ typedef struct gc_result {
 	int32_t*  long_trace_node; uint32_t* long_trace_offset; uint32_t* long_trace_seqpos; uint8_t* long_trace_switch;
 	/* per read flags */
 	uint8_t*  failed_assertion;   /* [n_reads] the reference would have thrown on this read */
+	uint8_t*  capacity_exceeded;  /* [n_reads] 1: a capacity of THIS library was exceeded for the read (an extension with more tiles than even the
+	                               *    retry launch holds, more whole-read alignments than max(32, longest read / 512), a full cell pool, an NW band
+	                               *    beyond the kernel's range): its results are incomplete. The reference has no such limits; the batch always
+	                               *    completes and every other read is unaffected. */
 	uint64_t* seeds_extended;     /* [n_reads] fragment pass (stats.seedsExtended, src/Aligner.cpp:705) */
 	uint64_t* seeds_extended_long; /* [n_reads] whole-read pass (AlignmentResult::seedsExtended) */
 	/* chain stitching (stitch): the longest stitched piece of the chain (src/Aligner.cpp:754-822) as its split-node

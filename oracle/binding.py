@@ -49,6 +49,8 @@ def load_oracle_lib():
     lib.gco_edit_path.argtypes = [C.c_char_p, u64, C.c_char_p, u64, C.c_void_p, u64, C.POINTER(C.c_longlong)]
     lib.gco_evalue.argtypes = [C.c_double, u64, u64, u64, u64, C.c_void_p]
     lib.gco_set_e_cutoff.argtypes = [C.c_void_p, C.c_double]
+    lib.gco_align_timed.restype = C.c_double
+    lib.gco_align_timed.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     return lib
 
 
@@ -117,6 +119,16 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(self.lib.gco_error(self.h).decode())
         return {name: self._array(name) for name in RESULT_ARRAYS}
+
+    def align_timed(self, reads, threads=1):
+        """CPU baseline: aligns `reads` with `threads` workers over a shared queue (the reference's -t model), results discarded.
+        Returns (wall seconds, per-stage CPU seconds [seed, whole-read pass, fragments, chaining, stitch + edlib])."""
+        bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+        off = np.zeros(len(bs) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(b) for b in bs])
+        stage = np.zeros(5, dtype=np.float64)
+        wall = self.lib.gco_align_timed(self.h, b"".join(bs), off.ctypes.data, len(bs), int(threads), stage.ctypes.data)
+        return float(wall), stage
 
     def gaf(self, merge=False):
         """GAF text of the last align() call (read ids r0, r1, ...), the reference's writer restated (oracle/output.hpp)."""

@@ -6,6 +6,8 @@
 #include "edlib_path.hpp"
 #include "evalue.hpp"
 #include <cstdlib>
+#include <atomic>
+#include <thread>
 #include <chrono>
 #include <cstring>
 #include <map>
@@ -117,8 +119,9 @@ public:
 	double stageSeconds[5] = { 0, 0, 0, 0, 0 };   // seed, long pass, fragments, chaining, stitch+edit distance
 
 	// forceLongAssertion: test hook, makes the whole-read pass end as if one of the reference's live asserts had thrown
-	ReadResult alignRead(const std::string& sequence, AlignerState& state, bool forceLongAssertion = false)
+	ReadResult alignRead(const std::string& sequence, AlignerState& state, bool forceLongAssertion = false, double* stageOut = nullptr)
 	{
+		double* stageSeconds = stageOut ? stageOut : this->stageSeconds;
 		typedef std::chrono::steady_clock clk;
 		auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 		ReadResult res;
@@ -448,6 +451,32 @@ int gco_align(void* hv, const char* bases, const uint64_t* off, int n)
 	ex["counters"] = { (int64_t)c.dpTiles, (int64_t)c.recomputeTiles, (int64_t)c.columnSteps, (int64_t)c.traceItems, (int64_t)c.extensions };
 	for (double s : h->o.stageSeconds) ex["stage_microseconds"].push_back((int64_t)(s * 1e6));
 	return 0;
+}
+
+// CPU baseline leg of bench.py: the reference's threading model (src/Aligner.cpp:1267-1270: one worker per thread over a shared
+// read queue, each with its own reusable state), results discarded. Returns the wall seconds; stage5 (may be NULL) receives
+// the per-stage CPU seconds summed over the workers, in the order seed / whole-read pass / fragments / chaining / stitch + edlib.
+double gco_align_timed(void* hv, const char* bases, const uint64_t* off, int n, int threads, double* stage5)
+{
+	OracleHandle* h = (OracleHandle*)hv;
+	if (threads < 1) threads = 1;
+	std::atomic<int> next { 0 };
+	std::vector<std::array<double, 5>> stages(threads, std::array<double, 5> { 0, 0, 0, 0, 0 });
+	auto t0 = std::chrono::steady_clock::now();
+	auto worker = [&](int t) {
+		AlignerState state(h->o.graph);
+		for (int r; (r = next.fetch_add(1)) < n;) {
+			std::string seq(bases + off[r], bases + off[r + 1]);
+			try { h->o.alignRead(seq, state, false, stages[t].data()); } catch (const std::exception&) { state.clear(); }
+		}
+	};
+	std::vector<std::thread> pool;
+	for (int t = 1; t < threads; t++) pool.emplace_back(worker, t);
+	worker(0);
+	for (auto& th : pool) th.join();
+	double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	if (stage5) for (int k = 0; k < 5; k++) { stage5[k] = 0; for (int t = 0; t < threads; t++) stage5[k] += stages[t][k]; }
+	return wall;
 }
 
 const char* gco_gaf(void* hv, int merge) { return ((OracleHandle*)hv)->gaf[merge ? 1 : 0].c_str(); }

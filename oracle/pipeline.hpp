@@ -15,6 +15,7 @@
 // only by independent brute-force models in tests/.
 #pragma once
 #include "bitvector_aligner.hpp"
+#include "edlib_path.hpp"
 #include <algorithm>
 #include <map>
 #include <memory>
@@ -479,42 +480,8 @@ inline std::pair<std::vector<size_t>, size_t> colinearChaining(const AlignmentGr
 
 // ------------------------------------------------------------------ edit distance (for the selection rule)
 
-// Plain Levenshtein (global) distance; the value is what edlibAlign(..., EDLIB_MODE_NW, EDLIB_TASK_DISTANCE)
-// returns at src/Aligner.cpp:645,845. Bit-parallel over the first string (Myers/Hyyro, multi-word).
-inline size_t editDistanceNW(const std::string& a, const std::string& b)
-{
-	if (a.empty()) return b.size();
-	if (b.empty()) return a.size();
-	size_t words = (a.size() + 63) / 64;
-	std::vector<uint64_t> peq(256 * words, 0);
-	for (size_t i = 0; i < a.size(); i++) peq[(unsigned char)a[i] * words + i / 64] |= (uint64_t)1 << (i % 64);
-	std::vector<uint64_t> VP(words, ~(uint64_t)0), VN(words, 0);
-	size_t score = a.size();
-	uint64_t lastBit = (uint64_t)1 << ((a.size() - 1) % 64);
-	for (size_t j = 0; j < b.size(); j++) {
-		uint64_t hinP = 1, hinN = 0;   // top row of the NW matrix increases by one per column
-		for (size_t wd = 0; wd < words; wd++) {
-			uint64_t Eq = peq[(unsigned char)b[j] * words + wd];
-			uint64_t vp = VP[wd], vn = VN[wd];
-			uint64_t Xv = Eq | vn;
-			Eq |= hinN;
-			uint64_t Xh = (((Eq & vp) + vp) ^ vp) | Eq;
-			uint64_t Ph = vn | ~(Xh | vp);
-			uint64_t Mh = vp & Xh;
-			if (wd == words - 1) {
-				if (Ph & lastBit) score++;
-				if (Mh & lastBit) score--;
-			}
-			uint64_t outP = Ph >> 63, outN = Mh >> 63;
-			Ph = (Ph << 1) | hinP;
-			Mh = (Mh << 1) | hinN;
-			VP[wd] = Mh | ~(Xv | Ph);
-			VN[wd] = Ph & Xv;
-			hinP = outP;
-			hinN = outN;
-		}
-	}
-	return score;
-}
+// Global (NW) edit distance: the value edlibAlign(..., EDLIB_MODE_NW, EDLIB_TASK_DISTANCE) returns at src/Aligner.cpp:645,845,
+// computed like edlib does (banded, k doubling): oracle/edlib_path.hpp.
+inline size_t editDistanceNW(const std::string& a, const std::string& b) { return (size_t)editDistanceBanded(a, b); }
 
 } // namespace oracle

@@ -440,6 +440,80 @@ def test_chain_kernel_against_bruteforce(gca, tmp_path):
             assert int(res["chain_score"][r]) == score
 
 
+def _per_read(res, off_key, key, r):
+    return np.asarray(res[key][int(res[off_key][r]):int(res[off_key][r + 1])], dtype=np.int64)
+
+
+def test_fragment_overflow_is_retried(gca, tmp_path, monkeypatch):
+    """Slabs far too small for most fragment extensions (8 tiles, 8 queue entries): the retry launch with 16x the room recovers every
+    one of them - same results as the oracle, nothing flagged."""
+    from graphchainer_amd.synth import SynthGraph
+    monkeypatch.setenv("GC_EXT_MAX_ITEMS", "8")
+    monkeypatch.setenv("GC_EXT_MAX_PENDING", "8")
+    sg = SynthGraph(80_000, seed=51, multi_allelic=0.3, nested=0.3)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(8, 3000, seed=2)
+    got, want = run_case(gca, gfa, reads)
+    compare(got, want)
+    assert not got["capacity_exceeded"].any()
+
+
+def test_capacity_overflow_flags_the_read_not_the_batch(gca, tmp_path, monkeypatch):
+    """Capacities shrunk until even the retries overflow (fragment slabs, whole-read extension scratch, the whole-read cell pool): the
+    call succeeds, the reads that hit a limit are flagged in capacity_exceeded, and every other read has exactly the oracle's
+    results (the reference's convention: a problem with one read never costs the others, src/Aligner.cpp:585-592,695-703)."""
+    from graphchainer_amd.synth import SynthGraph
+    from oracle import Oracle
+    sg = SynthGraph(80_000, seed=53, multi_allelic=0.3, nested=0.3)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(10, 3000, seed=4)
+    reads.append(reads[0][:300])                     # a short read: few fragments, likely untouched by the fragment limits
+    graph = gca.AlignmentGraph(gfa)
+    seeder = gca.MinimizerSeeder(graph)
+    want = Oracle(gfa, long_pass=True).align(reads)
+    flagged_total = 0
+    for env in ({"GC_EXT_MAX_ITEMS": "8", "GC_EXT_RETRY_MAX_ITEMS": "10"}, {"GC_LONG_MAX_ITEMS": "64"}, {"GC_LONG_CELLS_PER_BASE": "2"}):
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            got = gca.Aligner(graph, seeder, long_pass=True).align_reads(reads)     # must not raise
+        flagged = np.asarray(got["capacity_exceeded"]).astype(bool)
+        flagged_total += int(flagged.sum())
+        for r in np.nonzero(~flagged)[0]:
+            for off, key in (("read_anchor_off", "anchor_x"), ("read_anchor_off", "anchor_score"), ("read_chain_off", "chain"), ("read_longall_off", "longall_start"), ("read_longall_off", "longall_score")):
+                assert np.array_equal(_per_read(got, off, key, r), _per_read(want, off, key, r)), (env, r, key)
+            assert int(got["chain_edit_distance"][r]) == int(want["chain_edit_distance"][r]) and int(got["long_edit_distance"][r]) == int(want["long_edit_distance"][r])
+    assert flagged_total >= 3
+
+
+def test_shim_replays_the_reference_call_sequence(gca, tmp_path, golden_dir):
+    """tests/shim/shim_test.cpp drives getSeeds -> OrderSeeds -> AlignOneWay (whole read, then every fragment) -> colinearChaining with the
+    reference's signatures through include/graphchainer_amd_shim.hpp; what it sees equals the batch API's result for the same reads."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_library_exports import _build_shim_test
+    exe = _build_shim_test(tmp_path)
+    gfa = os.path.join(golden_dir, "syn20k.gfa")
+    reads = [l.strip() for l in open(os.path.join(golden_dir, "syn20k.fa")) if not l.startswith(">")][:4]
+    out = subprocess.run([exe, gfa] + reads, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    graph = gca.AlignmentGraph(gfa)
+    res = gca.Aligner(graph, gca.MinimizerSeeder(graph), long_pass=True, keep_seeds=True).align_reads([r.encode() for r in reads])
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == len(reads)
+    for r, line in enumerate(lines):
+        head, chain = line.split(":", 2)[1:]
+        f = head.split()
+        n_seeds, n_long, n_anchors, n_chain = int(f[1]), int(f[3]), int(f[5]), int(f[7])
+        assert n_seeds == res["read_seed_off"][r + 1] - res["read_seed_off"][r]
+        assert n_long == res["read_longall_off"][r + 1] - res["read_longall_off"][r]
+        assert n_anchors == res["read_anchor_off"][r + 1] - res["read_anchor_off"][r]
+        assert [int(x) for x in chain.split()] == [int(c) for c in res["chain"][int(res["read_chain_off"][r]):int(res["read_chain_off"][r + 1])]] and n_chain == len(chain.split())
+
+
 def _path_pairs(rng):
     """(path letters, read) shapes the chained alignment meets: similar strings, a path covering only part of the read, a path
     with a stretch the read lacks, unrelated strings, repeats (many optimal alignments), other letters, tiny / empty sides,

@@ -1,5 +1,5 @@
-"""Host-side logic that needs no GPU: synthetic generator determinism, shard bounds, a 2-rank gloo run of
-the read-sharded layout (each rank aligns its shard with the oracle; the union must equal the unsharded run)."""
+"""Host-side logic that needs no GPU: synthetic generator determinism, the multi-GPU work queue (in one process, and across two
+gloo ranks with the aligner mocked: the queue, the batch hand-out and the result merge are the product's own code paths)."""
 import os
 import subprocess
 import sys
@@ -7,22 +7,37 @@ import textwrap
 
 import numpy as np
 
-from graphchainer_amd.sharding import shard_bounds
 from graphchainer_amd.synth import SynthGraph
+from graphchainer_amd.workqueue import ReadQueue, length_sorted_batches, merge_read_results, run_queue
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_shard_bounds_partition():
-    for n in (0, 1, 7, 10, 1001):
-        for world in (1, 2, 3, 8):
-            cover = []
-            for r in range(world):
-                lo, hi = shard_bounds(n, r, world)
-                cover.extend(range(lo, hi))
-            assert cover == list(range(n))
-            sizes = [shard_bounds(n, r, world)[1] - shard_bounds(n, r, world)[0] for r in range(world)]
-            assert max(sizes) - min(sizes) <= 1
+def test_length_sorted_batches_cover_every_read_once():
+    import random
+    rng = random.Random(3)
+    for n, batch in ((0, 4), (1, 4), (10, 3), (1001, 64), (50, 100)):
+        reads = [b"A" * rng.randint(1, 500) for _ in range(n)]
+        batches = length_sorted_batches(reads, batch)
+        flat = [i for b in batches for i in b]
+        assert sorted(flat) == list(range(n)) and all(len(b) <= batch for b in batches)
+        lens = [len(reads[i]) for i in flat]
+        assert lens == sorted(lens, reverse=True)                       # longest first: a batch holds reads of similar length
+    same = length_sorted_batches([b"ACGT"] * 9, 4)
+    assert same == [[0, 1, 2, 3], [4, 5, 6, 7], [8]]                    # equal lengths keep their order (BASELINE config 2)
+
+
+def test_queue_hands_every_batch_to_one_worker():
+    reads = [bytes([65 + i % 4]) * (1 + i % 37) for i in range(500)]
+    batches = length_sorted_batches(reads, 16)
+    queue = ReadQueue(len(batches))
+    for _ in range(3):                                                   # three "steps"
+        queue.reset()
+        parts = run_queue(queue, lambda worker, b: {"len": [len(reads[i]) for i in batches[b]], "worker": worker}, workers=4)
+        assert sorted(b for b, _ in parts) == list(range(len(batches)))
+        merged = merge_read_results(parts, batches, len(reads), "len", fill=-1)
+        assert list(merged) == [len(r) for r in reads]
+    assert queue.next() is None
 
 
 def test_synthetic_generator_is_deterministic(tmp_path):
@@ -37,36 +52,51 @@ def test_synthetic_generator_is_deterministic(tmp_path):
     assert set(b"".join(ra)) <= set(b"ACGT")
 
 
-def test_two_rank_gloo_sharding(tmp_path):
+def test_two_rank_gloo_work_queue(tmp_path):
+    """BASELINE config 4's shape on two gloo ranks: ONE read set, the product's queue hands its length-sorted batches to whichever
+    rank asks next (flock'ed counter file, no collective on the data path), every rank runs run_queue with two worker threads
+    (gc_streams) and a mocked aligner, the per-read results merged over the ranks equal the unsharded run, over several steps."""
     script = tmp_path / "worker.py"
     script.write_text(textwrap.dedent(f"""
-        import os, sys
+        import os, sys, time
         sys.path.insert(0, {ROOT!r})
         import numpy as np
+        import torch
         import torch.distributed as dist
-        from graphchainer_amd.sharding import shard_bounds, sum_over_ranks, max_over_ranks
-        from oracle import Oracle
+        from graphchainer_amd.workqueue import ReadQueue, length_sorted_batches, merge_read_results, run_queue
         rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        gold = os.path.join({ROOT!r}, "tests", "golden")
-        reads = [l.strip() for l in open(os.path.join(gold, "syn20k.fa")) if not l.startswith(">")]
-        lo, hi = shard_bounds(len(reads), rank, world)
-        res = Oracle(os.path.join(gold, "syn20k.gfa"), long_pass=False).align(reads[lo:hi])
-        dist.barrier()
-        total = sum_over_ranks(int(res["chain_score"].sum()), dist)
-        n = sum_over_ranks(hi - lo, dist)
-        slowest = max_over_ranks(float(rank + 1), dist)
+        rng = np.random.default_rng(5)                                   # the same read set on every rank
+        reads = [bytes(rng.integers(65, 69, size=int(n)).astype(np.uint8)) for n in rng.integers(20, 400, size=333)]
+        batches = length_sorted_batches(reads, 16)
+        queue = ReadQueue(len(batches), rank, world, dist, path={str(tmp_path / "queue.bin")!r})
+
+        def mock_align(worker, b):                                       # stands in for Aligner.align_batch on a CPU-only box
+            time.sleep(0.002 * (1 + rank))                               # rank 1 is slower: the queue gives it fewer batches
+            return {{"score": [sum(reads[i]) % 1009 for i in batches[b]]}}
+        for step in range(3):
+            queue.reset()
+            parts = run_queue(queue, mock_align, workers=2)
+            mine = merge_read_results(parts, batches, len(reads), "score", fill=0)
+            count = torch.tensor([len(parts)], dtype=torch.int64)
+            merged = torch.from_numpy(mine)
+            dist.all_reduce(count); dist.all_reduce(merged)
+            got_batches = [None] * world
+            dist.all_gather_object(got_batches, sorted(b for b, _ in parts))
+            if rank == 0:
+                assert int(count.item()) == len(batches), (int(count.item()), len(batches))
+                assert sorted(b for part in got_batches for b in part) == list(range(len(batches)))      # each batch exactly once
+                assert merged.tolist() == [sum(r) % 1009 for r in reads]
+                assert len(got_batches[0]) > len(got_batches[1])           # dynamic: the faster rank took more
+        queue.close()
         if rank == 0:
-            want = np.load(os.path.join(gold, "syn20k.expected.npz"))
-            assert total == int(want["chain_score"].sum()), (total, int(want["chain_score"].sum()))
-            assert n == len(reads) and slowest == float(world)
-            print("SHARD_OK")
+            print("QUEUE_OK")
         dist.destroy_process_group()
     """))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29571", str(script)],
                          capture_output=True, text=True, env=env, timeout=300)
-    assert "SHARD_OK" in out.stdout, out.stdout + out.stderr
+    assert "QUEUE_OK" in out.stdout, out.stdout + out.stderr
 
 
 def test_two_rank_index_cache_handoff(tmp_path):
@@ -79,7 +109,7 @@ def test_two_rank_index_cache_handoff(tmp_path):
         sys.path.insert(0, {ROOT!r})
         import torch.distributed as dist
         import graphchainer_amd as gca
-        from graphchainer_amd.sharding import sum_over_ranks
+        import torch
         rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         gfa = os.path.join({ROOT!r}, "tests", "golden", "syn20k.gfa")
@@ -87,7 +117,9 @@ def test_two_rank_index_cache_handoff(tmp_path):
             gca.api.build_index_cache(gfa, {str(cache)!r}, 15, 20)
         dist.barrier()
         info = gca.api.check_index_cache({str(cache)!r})
-        nodes = sum_over_ranks(info["nodes"], dist)
+        t = torch.tensor([int(info["nodes"])], dtype=torch.int64)
+        dist.all_reduce(t)
+        nodes = int(t.item())
         if rank == 0:
             assert nodes == world * info["nodes"] and info["has_seeder"] == 1
             print("CACHE_OK")

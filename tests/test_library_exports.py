@@ -45,3 +45,28 @@ def test_product_does_not_touch_the_oracle():
                 continue
             text = open(os.path.join(dirpath, f), errors="ignore").read()
             assert "oracle/" not in text.replace("under oracle/", "") and "from oracle" not in text and "import oracle" not in text, os.path.join(dirpath, f)
+
+
+def _build_shim_test(tmp_path):
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "shim_test")
+    lib_dir = os.path.join(ROOT, "graphchainer_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "tests", "shim", "shim_test.cpp"),
+                           "-L" + lib_dir, "-lgraphchainer_amd", "-Wl,-rpath," + lib_dir])
+    return exe
+
+
+def test_shim_header_compiles_against_the_reference_type_names(tmp_path):
+    """include/graphchainer_amd_shim.hpp (the reference's AlignOneWay / OrderSeeds / getSeeds / colinearChaining signatures over the C ABI)
+    builds against minimal definitions of the reference's types and links with the library; without a GPU the program stops at graph
+    creation (no CPU fallback)."""
+    import subprocess
+    import graphchainer_amd as gca
+    exe = _build_shim_test(tmp_path)
+    if gca.device_count() > 0:
+        pytest.skip("a GPU is present: the gpu test runs the program")
+    out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "ref_test_graph.gfa"), "ACGTACGT"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "NO_DEVICE", out.stdout + out.stderr
