@@ -20,6 +20,12 @@
 namespace gcdev {
 
 
+// Experiment (r2): the column's match mask fetched with two v_readlane from lanes 0-3 instead of eight scalar selects: 10 scalar
+// instructions fewer per column (66 -> 56), yet the kernel measured 239 ms against 231-235 (two more VGPRs, longer dependent
+// chain through the vector pipe). Off.
+#ifndef GC_EQ_IN_LANES
+#define GC_EQ_IN_LANES 0
+#endif
 #ifndef WAVE_CAP
 #define WAVE_CAP 28
 #endif
@@ -136,7 +142,16 @@ struct LaneLdsT {   // one lane's view
 	__device__ __forceinline__ void qMove(uint32_t dst, uint32_t src) const { set(2u, dst, get(2u, src)); }
 	// backtrace columns (alias the LDS table words, or registers across the lanes): column c: VP, VN, score
 	mutable uint32_t cr[5];
-	mutable uint32_t idCur, idPrev;   // REGCOLS: node ids of the items of the backtrace's current / previous slice, item i in lane i
+	mutable uint32_t idCur, idPrev;
+	// REGCOLS: the slice's four match masks (A, C, G, T) in lanes 0-3
+	static constexpr bool eqInLanes = REGCOLS;
+	mutable uint32_t eqLo = 0, eqHi = 0;
+	__device__ __forceinline__ void setEq(uint64_t a, uint64_t c, uint64_t g, uint64_t t) const
+	{
+		const uint32_t l = threadIdx.x;
+		const uint64_t v = l == 0 ? a : l == 1 ? c : l == 2 ? g : t;
+		eqLo = (uint32_t)v; eqHi = (uint32_t)(v >> 32);
+	}   // REGCOLS: node ids of the items of the backtrace's current / previous slice, item i in lane i
 	__device__ __forceinline__ void colSet(uint32_t c, const WS& x) const
 	{
 		if (REGCOLS) {
@@ -281,10 +296,20 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 	uint64_t forceEq = prevExists ? ~0ull : ~1ull;
 	uint64_t HP = 0, HN = 0;
 	for (int pos = 1; pos < nodeLength; pos++) {
-		uint64_t Eq = eqOfColumn(eq, seq, pos) & forceEq;
+		uint64_t Eq;
+#if GC_EQ_IN_LANES
+		// one extension per wave: the four match masks sit in lanes 0-3 of a register pair and the column's mask is two v_readlane with
+		// the base code as lane index (vector pipe, idle here) instead of a chain of eight scalar selects
+		if (LANE_TABLES::eqInLanes && !seq.ambiguous) {
+			const uint32_t code = (uint32_t)((pos < 32 ? seq.w0 : seq.w1) >> ((pos & 31) * 2)) & 3u;
+			Eq = (uint64_t)(uint32_t)GC_READLANE(tables.eqLo, code) | ((uint64_t)(uint32_t)GC_READLANE(tables.eqHi, code) << 32);
+		} else
+#endif
+		Eq = eqOfColumn(eq, seq, pos);
+		Eq &= forceEq;
 		uint64_t hp, hn;
 		ws = myersStep(Eq, ws, (prevHP >> pos) & 1, (prevHN >> pos) & 1, hp, hn);
-		if (forceUntil >= pos) { ws.VP &= ~1ull; ws.VN |= 1ull; }
+		{ const uint64_t f = (uint64_t)((uint32_t)(pos - forceUntil - 1) >> 31); ws.VP &= ~f; ws.VN |= f; }   // forceUntil >= pos, as the sign bit of a difference (a compare would go through the vector pipe here)
 		if (ws.score < r.minScore) { r.minScore = ws.score; r.minOffset = (uint32_t)pos; }
 		if (flatRows > 0) {
 			int32_t f = ws.score - popc64(ws.VP & ~flatMask) + popc64(ws.VN & ~flatMask);
@@ -341,6 +366,7 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 	for (int slice = 0; slice < numSlices; slice++) {
 		int j = prevJ + 64;
 		eqVectorBits(eqSrc, len, j, eq);
+		if (REGCOLS) L.setEq(eq.a, eq.c, eq.g, eq.t);
 		int32_t previousQuitScore = prevMinScore + prevBandwidth;
 		int bandwidth = bandwidthCfg;
 		int flatRows = (j + 64 > len) ? (len - j) : 0;
@@ -577,7 +603,7 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 		if (s >= nSlices) return EXT_ASSERT;
 		if (s != curSliceIdx || here.node != curNode) {
 			GC_MARK(10);  // walking inside a tile / corner rules
-			if (s != curSliceIdx) { cs = loadSlice(wsx, s); ps = loadSlice(wsx, s - 1); eqVectorBits(eqSrc, len, cs.j, eq); fillIds(cs, idsCurBase); fillIds(ps, idsPrevBase); }
+			if (s != curSliceIdx) { cs = loadSlice(wsx, s); ps = loadSlice(wsx, s - 1); eqVectorBits(eqSrc, len, cs.j, eq); if (REGCOLS) L.setEq(eq.a, eq.c, eq.g, eq.t); fillIds(cs, idsCurBase); fillIds(ps, idsPrevBase); }
 			GC_MARK(6);   // backtrace: slice change
 			curSliceIdx = s;
 			curNode = here.node;

@@ -44,7 +44,8 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 
 // Column sweep of query (rows) against the first `cols` letters of target. colScores != nullptr: scores of the last
 // column, colScores[r + 1] = D(r, cols - 1), [0] = cols. store: every column's block state goes to S.P / S.M / S.top.
-__device__ void sweepColumns(const Seg& query, const Seg& target, uint32_t cols, const EdPathScratch& S, int32_t* colScores, bool store)
+#define ED_PATH_RING 4096u
+__device__ void sweepColumns(const Seg& query, const Seg& target, uint32_t cols, const EdPathScratch& S, int32_t* colScores, bool store, uint8_t* ringChar, uint8_t* ringCarry)
 {
 	const uint32_t lane = threadIdx.x;
 	const uint32_t Q = query.n;
@@ -73,19 +74,26 @@ __device__ void sweepColumns(const Seg& query, const Seg& target, uint32_t cols,
 		int32_t houtPrev = 0;
 		const bool carryOut = s + 1 < nStrips;
 		const uint32_t steps = cols + lanesHere - 1;
-		// the column letter is fetched one step ahead: its load latency would otherwise sit on every step's dependent chain
-		char chNext = (active && lane == 0 && cols > 0) ? target.at(0) : 'A';
+		// Column letters (and, below the first strip, the deltas coming down from the strip above) go through LDS rings refilled 2048 ahead
+		// every 1024 steps by all lanes: a global load per step sat on the step's dependent chain (~0.85 us per step measured).
+		uint32_t loadedEnd = 0;
 		for (uint32_t t = 0; t < steps; t++) {
+			if ((t & 1023u) == 0) {
+				const uint32_t end = t + 2048 < cols ? t + 2048 : cols;
+				for (uint32_t c = loadedEnd + lane; c < end; c += 64) {
+					ringChar[c & (ED_PATH_RING - 1)] = (uint8_t)target.at(c);
+					if (s > 0) ringCarry[c & (ED_PATH_RING - 1)] = S.carry[c];
+				}
+				loadedEnd = end > loadedEnd ? end : loadedEnd;
+				__syncthreads();
+			}
 			const int32_t fromAbove = __shfl_up(houtPrev, 1);
 			const uint32_t j = t - lane;
-			const char ch = chNext;
-			{
-				const uint32_t jn = t + 1 - lane;
-				if (active && t + 1 >= lane && jn < cols) chNext = target.at(jn);
-			}
+			const char ch = (char)ringChar[j & (ED_PATH_RING - 1)];
+			const uint8_t carryIn = ringCarry[j & (ED_PATH_RING - 1)];
 			if (!active || t < lane || j >= cols) continue;
 			int32_t hin = fromAbove;
-			if (lane == 0) hin = s == 0 ? 1 : (int32_t)S.carry[j] - 1;
+			if (lane == 0) hin = s == 0 ? 1 : (int32_t)carryIn - 1;
 			uint64_t Eq;
 			if (ch == 'A') Eq = eqA; else if (ch == 'C') Eq = eqC; else if (ch == 'G') Eq = eqG; else if (ch == 'T') Eq = eqT;
 			else {
@@ -106,7 +114,7 @@ __device__ void sweepColumns(const Seg& query, const Seg& target, uint32_t cols,
 			VN = Ph & Xv;
 			top += hin;
 			if (store) {
-				const uint64_t at = (uint64_t)j * nBlocks + b;
+				const uint64_t at = (uint64_t)b * cols + j;   // [block][column]: the walk back reads runs of columns of one block
 				S.P[at] = VP; S.M[at] = VN; S.top[at] = top;
 			}
 			if (carryOut && lane == 63) S.carry[j] = (uint8_t)(houtPrev + 1);
@@ -133,26 +141,39 @@ __device__ __forceinline__ int32_t cellValue(const BlockCol& x, uint32_t i)   //
 }
 
 // obtainAlignmentTraceback (edlib/src/edlib.cpp:917-1170) over the stored columns; returns the number of ops written to
-// S.tmpOps, last op first.
+// S.tmpOps, last op first. The walk is one dependent chain; what it reads is kept in registers across the wave: a window of
+// 64 columns of the current block (column w0 - l in lane l, three coalesced loads per refill), read with v_readlane.
 __device__ uint32_t walkBack(uint32_t Q, uint32_t T, const EdPathScratch& S)
 {
-	const uint32_t nBlocks = (Q + 63) / 64;
-	auto load = [&](uint32_t b, uint32_t c) __attribute__((always_inline)) -> BlockCol {
-		const uint64_t at = (uint64_t)c * nBlocks + b;
-		BlockCol x;
-		x.P = S.P[at]; x.M = S.M[at]; x.top = S.top[at];
-		// the walk is the same in every lane: keep its state in scalar registers
-		x.P = (uint64_t)uni((uint32_t)x.P) | ((uint64_t)uni((uint32_t)(x.P >> 32)) << 32);
-		x.M = (uint64_t)uni((uint32_t)x.M) | ((uint64_t)uni((uint32_t)(x.M >> 32)) << 32);
-		x.top = (int32_t)uni((uint32_t)x.top);
-		return x;
-	};
+	const uint32_t lane = threadIdx.x;
 	int32_t r = (int32_t)Q - 1, c = (int32_t)T - 1;
 	uint32_t n = 0;
-	const bool writer = threadIdx.x == 0;
-	BlockCol cur = load((uint32_t)r / 64, (uint32_t)c), lft { 0, 0, 0 };
-	if (c > 0) lft = load((uint32_t)r / 64, (uint32_t)c - 1);
+	const bool writer = lane == 0;
+	uint32_t wb = (uint32_t)r / 64;
+	int32_t w0 = c;
+	uint32_t wPlo = 0, wPhi = 0, wMlo = 0, wMhi = 0, wTop = 0;
+	auto refill = [&]() __attribute__((always_inline)) {
+		const int32_t col = w0 - (int32_t)lane;
+		if (col >= 0) {
+			const uint64_t at = (uint64_t)wb * T + (uint32_t)col;
+			const uint64_t p = S.P[at], m = S.M[at];
+			wPlo = (uint32_t)p; wPhi = (uint32_t)(p >> 32); wMlo = (uint32_t)m; wMhi = (uint32_t)(m >> 32); wTop = (uint32_t)S.top[at];
+		}
+	};
+	auto column = [&](uint32_t idx) __attribute__((always_inline)) -> BlockCol {   // idx: uniform lane index
+		BlockCol x;
+		x.P = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wPlo, (int)idx) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wPhi, (int)idx) << 32);
+		x.M = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wMlo, (int)idx) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)wMhi, (int)idx) << 32);
+		x.top = __builtin_amdgcn_readlane((int)wTop, (int)idx);
+		return x;
+	};
+	refill();
 	while (r >= 0 && c >= 0) {
+		if (w0 - c > 62) { w0 = c; refill(); }   // column c - 1 must be in the window too
+		const uint32_t idx = uni((uint32_t)(w0 - c));
+		const BlockCol cur = column(idx);
+		BlockCol lft { 0, 0, 0 };
+		if (c > 0) lft = column(idx + 1);
 		const uint32_t i = (uint32_t)r & 63u;
 		const int32_t here = cellValue(cur, i);
 		const int32_t up = i > 0 ? cellValue(cur, i - 1) : cur.top;
@@ -165,13 +186,11 @@ __device__ uint32_t walkBack(uint32_t Q, uint32_t T, const EdPathScratch& S)
 		else { op = diag == here ? 0 : 3; goUp = goLeft = true; }
 		if (writer) S.tmpOps[n] = op;
 		n++;
-		const uint32_t oldBlock = (uint32_t)r / 64;
 		if (goUp) r--;
 		if (goLeft) c--;
 		if (r < 0 || c < 0) break;
 		const uint32_t nb = (uint32_t)r / 64;
-		if (nb != oldBlock) { cur = load(nb, (uint32_t)c); if (c > 0) lft = load(nb, (uint32_t)c - 1); }
-		else if (goLeft) { cur = lft; if (c > 0) lft = load(nb, (uint32_t)c - 1); }
+		if (nb != wb) { wb = nb; w0 = c; refill(); }
 	}
 	// on a border only one kind of move is left (:1043-1048,1067-1073)
 	while (r >= 0) { if (writer) S.tmpOps[n] = 1; n++; r--; }
@@ -185,6 +204,7 @@ __global__ void __launch_bounds__(64) k_edit_path(const EdPathJob* __restrict__ 
 	uint8_t* __restrict__ scratch, uint64_t scratchBytes, uint32_t maxQ, uint32_t maxT, uint8_t* __restrict__ opsOut, uint32_t* __restrict__ opsLen)
 {
 	__shared__ uint32_t stack[64][5];
+	__shared__ uint8_t ringChar[ED_PATH_RING], ringCarry[ED_PATH_RING];
 	const uint32_t lane = threadIdx.x;
 	EdPathScratch S;
 	{
@@ -229,7 +249,7 @@ __global__ void __launch_bounds__(64) k_edit_path(const EdPathJob* __restrict__ 
 			const uint64_t dataSize = 20ull * nBlocks * T + 8ull * T;   // edlib/src/edlib.cpp:1204-1205
 			const Seg qf { query + q0, Q, false }, tf { target + t0, T, false };
 			if (dataSize < 1024ull * 1024ull) {
-				sweepColumns(qf, tf, T, S, nullptr, true);
+				sweepColumns(qf, tf, T, S, nullptr, true, ringChar, ringCarry);
 				const uint32_t n = walkBack(Q, T, S);
 				__syncthreads();
 				for (uint32_t i = lane; i < n; i += 64) out[nOps + i] = S.tmpOps[n - 1 - i];
@@ -238,9 +258,9 @@ __global__ void __launch_bounds__(64) k_edit_path(const EdPathJob* __restrict__ 
 				continue;
 			}
 			const uint32_t leftW = T / 2, rightW = T - leftW;
-			sweepColumns(qf, tf, leftW, S, S.colLeft, false);
+			sweepColumns(qf, tf, leftW, S, S.colLeft, false, ringChar, ringCarry);
 			const Seg qr { query + q0, Q, true }, tr { target + t0, T, true };
-			sweepColumns(qr, tr, rightW, S, S.colRight, false);
+			sweepColumns(qr, tr, rightW, S, S.colRight, false, ringChar, ringCarry);
 			// first row whose left score plus the score below-right of it is the optimum (:1339-1351), then the borders (:1353-1372)
 			int32_t split = -2, leftScore = 0, rightScore = 0;
 			for (uint32_t r0 = 0; r0 + 1 < Q; r0 += 64) {

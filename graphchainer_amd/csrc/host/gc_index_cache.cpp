@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
+#include <unordered_map>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -264,15 +265,28 @@ void validateGraph(const AlignmentGraph& g, const GraphTables& t)
 		listed += t.splitNodes[k].size();
 	}
 	if (listed != n) bad("node lookup does not cover the graph");
+	// the reverse-strand twin of every position is looked up as lookup[id ^ 1][(size - 1 - offset) / 64] (twinOf in the host pipeline and on the
+	// device): every bigraph node needs its twin, listed once, with the same size
+	if (g.firstAmbiguous > n) bad("first ambiguous node outside the graph");
+	std::unordered_map<int, size_t> sizeOf;
+	sizeOf.reserve(t.ids.size());
+	for (size_t k = 0; k < t.ids.size(); k++) if (!sizeOf.emplace(t.ids[k], t.sizes[k]).second) bad("a node id is listed twice");
+	for (size_t k = 0; k < t.ids.size(); k++) {
+		auto twin = sizeOf.find(t.ids[k] ^ 1);
+		if (twin == sizeOf.end() || twin->second != t.sizes[k]) bad("a node has no reverse-strand twin of the same size");
+	}
 }
 
-void validateSeeder(const MinimizerIndex& idx, size_t nodes)
+void validateSeeder(const MinimizerIndex& idx, const AlignmentGraph& g)
 {
+	const size_t nodes = g.nodeLength.size();
 	auto bad = [](const char* what) { throw std::runtime_error(std::string("index cache: ") + what); };
 	if (idx.startPos.size() != idx.kmers.size() + 1 || idx.startPos.front() != 0 || idx.startPos.back() != idx.positions.size()) bad("inconsistent minimizer index");
 	for (size_t i = 0; i + 1 < idx.startPos.size(); i++) if (idx.startPos[i] > idx.startPos[i + 1]) bad("minimizer offsets are not monotone");
 	for (size_t i = 0; i + 1 < idx.kmers.size(); i++) if (idx.kmers[i] >= idx.kmers[i + 1]) bad("minimizer k-mers are not sorted");
-	for (uint64_t p : idx.positions) if ((p >> 6) >= nodes) bad("minimizer position outside the graph");
+	for (uint64_t p : idx.positions) if ((p >> 6) >= nodes || (p & 63) >= g.nodeLength[p >> 6]) bad("minimizer position outside the graph");
+	if (idx.k < 1 || idx.k > 31) bad("minimizer length outside 1..31");
+	if (!idx.kmers.empty() && (idx.kmers.back() >> (2 * idx.k)) != 0) bad("k-mer wider than 2k bits");
 }
 
 IndexCacheInfo parse(const Mapping& file, AlignmentGraph& g, MinimizerIndex& idx)
@@ -308,7 +322,7 @@ IndexCacheInfo parse(const Mapping& file, AlignmentGraph& g, MinimizerIndex& idx
 	idx = MinimizerIndex();
 	if (info.hasSeeder) {
 		seederFields(in, idx);
-		validateSeeder(idx, n);
+		validateSeeder(idx, g);
 	}
 	if (in.at != payload) throw std::runtime_error("index cache: trailing bytes");
 	info.nodes = n; info.bp = g.bpSize; info.kmers = idx.kmers.size(); info.positions = idx.positions.size();

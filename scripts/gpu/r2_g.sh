@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 2, call G: column-loop changes of the whole-read kernel, faster alignment-path kernel
+mkdir -p gpurun_out/r2g
+timeout 1500 python -m pytest tests -m gpu -q -x > gpurun_out/r2g/pytest_all.log 2>&1; echo "rc $?" >> gpurun_out/r2g/pytest_all.log
+tail -5 gpurun_out/r2g/pytest_all.log
+timeout 500 python bench.py --steps 8 --warmup 3 --no-cpu-baseline > gpurun_out/r2g/bench_cfg2.json 2> gpurun_out/r2g/bench_cfg2.err
+GC_DEBUG_TIMES=1 timeout 400 python bench.py --steps 3 --warmup 1 --sv-fraction 0.2 --no-cpu-baseline > gpurun_out/r2g/bench_cfg2_sv20.json 2> gpurun_out/r2g/bench_cfg2_sv20.err
+for f in gpurun_out/r2g/*.json; do echo $f; python - "$f" <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(d["value"], d["ms_per_step"], d["stage_ms"], d["roofline"]["frac"], d["decision"])
+except Exception as e: print("ERR", e)
+PY
+done
+grep "chained alignment traces" gpurun_out/r2g/bench_cfg2_sv20.err | tail -3

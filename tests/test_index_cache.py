@@ -229,6 +229,61 @@ def test_corrupt_payload_with_valid_checksum_never_crashes(gca, tmp_path):
     assert refused + accepted == 300 and refused >= 150
 
 
+@pytest.mark.gpu
+def test_accepted_mutated_caches_load_and_align_without_crashing(gca, tmp_path):
+    """A mutated file that passes validation (recomputed checksum, consistent structure) is then USED: loaded, uploaded to the device and
+    aligned against. The validator promises that nothing it accepts can index out of bounds later (twin lookups, minimizer positions,
+    adjacency, path cover); here that promise is exercised end to end, in a child process so that a crash is a test failure."""
+    import subprocess
+    import sys
+    import textwrap
+    path = str(tmp_path / "a.gcidx")
+    gfa = os.path.join(GOLD, "syn20k.gfa")
+    gca.api.build_index_cache(gfa, path, 15, 20)
+    reads = [l.strip() for l in open(os.path.join(GOLD, "syn20k.fa")) if not l.startswith(">")][:3]
+    script = tmp_path / "fuzz_use.py"
+    script.write_text(textwrap.dedent(f"""
+        import random, sys
+        sys.path.insert(0, {ROOT!r})
+        import graphchainer_amd as gca
+        data = bytearray(open({path!r}, "rb").read())
+        def fnv(b):
+            h = 0xcbf29ce484222325
+            for x in b:
+                h = ((h ^ x) * 0x100000001b3) & 0xffffffffffffffff
+            return h
+        rng = random.Random(7)
+        reads = {[r.encode() for r in reads]!r}
+        used = refused = 0
+        for trial in range(120):
+            blob = bytearray(data[:-8])
+            at = rng.randrange(9, len(blob))
+            if trial % 2 == 0:
+                blob[at] ^= 1 << rng.randrange(8)
+            else:
+                blob[at] = rng.choice([0, 1, 0x3f, 0x40, 0x7f])
+            blob += fnv(blob).to_bytes(8, "little")
+            m = {str(tmp_path / "m.gcidx")!r}
+            open(m, "wb").write(blob)
+            try:
+                graph, seeder = gca.api.load_index_cache(m)
+            except RuntimeError:
+                refused += 1
+                continue
+            try:
+                out = gca.Aligner(graph, seeder, long_pass=True).align_reads(reads)   # may differ from the true result, must not crash
+                assert len(out["read_chain_off"]) == len(reads) + 1
+            except RuntimeError:
+                pass                                                                  # a clean error is fine too
+            used += 1
+            seeder.close(); graph.close()
+        print("FUZZ_USE_OK", used, refused)
+    """))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0 and "FUZZ_USE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert int(out.stdout.split()[-2]) >= 5
+
+
 def test_threaded_build_equals_serial_build(gca, tmp_path, monkeypatch):
     """The start-up builders run MPC components and minimizer node chunks on several threads; the cache they produce is
     byte-identical to the single-threaded one (a 1.5 Mbp graph: two components, ~130 k bigraph nodes, all threads used)."""
