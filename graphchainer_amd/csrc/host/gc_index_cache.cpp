@@ -233,6 +233,16 @@ void validateGraph(const AlignmentGraph& g, const GraphTables& t)
 		for (size_t v : g.inNeighbors[i]) if (v >= n) bad("in-neighbour outside the graph");
 		for (size_t v : g.outNeighbors[i]) if (v >= n) bad("out-neighbour outside the graph");
 	}
+	// the kernels walk the graph in componentNumber order and terminate because it is a topological rank (src/AlignmentGraph.cpp:1100-1105 on
+	// a DAG): an edge that does not go strictly upwards (a cycle, or a damaged rank) would let a device loop run forever - refuse it here.
+	// Adjacency must also be symmetric: the backtrace reads in-neighbours, the forward pass out-neighbours.
+	for (size_t i = 0; i < n; i++) {
+		for (size_t v : g.outNeighbors[i]) {
+			if (!(g.componentNumber[v] > g.componentNumber[i])) bad("an edge does not follow the topological rank (cyclic graph or damaged rank)");
+			if (std::find(g.inNeighbors[v].begin(), g.inNeighbors[v].end(), i) == g.inNeighbors[v].end()) bad("an edge is missing from its target's in-neighbours");
+		}
+		for (size_t u : g.inNeighbors[i]) if (std::find(g.outNeighbors[u].begin(), g.outNeighbors[u].end(), i) == g.outNeighbors[u].end()) bad("an edge is missing from its source's out-neighbours");
+	}
 	const size_t nComp = g.component_ids.size();
 	if (g.topo.size() != nComp || g.topo_ids.size() != nComp || g.mpc.size() != nComp || g.paths.size() != nComp || g.backwards.size() != nComp) bad("inconsistent component tables");
 	size_t members = 0;
