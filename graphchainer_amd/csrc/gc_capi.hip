@@ -180,7 +180,7 @@ struct gc_graph {
 	std::vector<void*> allocations;
 	CorrectnessTables* devTables = nullptr;
 	uint8_t* devIupac = nullptr;
-	uint32_t maxMpcWidth = 0;
+	uint32_t maxMpcWidth = 0, maxPathsPerNode = 1, maxBackPerNode = 1;
 	~gc_graph() { for (void* p : allocations) (void)hipFree(p); }
 	template <typename T> const T* up(const std::vector<T>& v) { T* d = uploadVector(v); allocations.push_back(d); return d; }
 };
@@ -397,8 +397,10 @@ static void uploadGraph(gc_graph* G)
 		size_t c = h.component_map[i], x = h.component_idx[i];
 		for (size_t k : h.paths[c][x]) pathsFlat.push_back((uint32_t)k);
 		pathsOff[i + 1] = (uint32_t)pathsFlat.size();
+		G->maxPathsPerNode = std::max(G->maxPathsPerNode, pathsOff[i + 1] - pathsOff[i]);
 		for (const auto& b : h.backwards[c][x]) { backNode.push_back((uint32_t)h.component_ids[c][b.first]); backPath.push_back((uint32_t)b.second); }
 		backOff[i + 1] = (uint32_t)backNode.size();
+		G->maxBackPerNode = std::max(G->maxBackPerNode, backOff[i + 1] - backOff[i]);
 	}
 	// position of every node on every path through it (paths[v] lists path ids in ascending order, and a path visits
 	// its nodes in order, so walking path k in order fills the (v,k) entries)
@@ -1668,8 +1670,11 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		uint64_t traceBudget = 0;
 		for (uint64_t b : traceBudgets) traceBudget += b;
 		traceBudget += traceBudget / 4 + (1u << 20);   // room for the extensions that only fit the retry launch's larger trace buffers
-		ChainCaps caps { 1, 1, 1 };
+		ChainCaps caps { 1, 1, 1, 1 };
 		for (uint64_t r = 0; r < n; r++) caps.capAnchors = std::max(caps.capAnchors, jobs[r].nSlots);
+		caps.capEndpoints = (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)caps.capAnchors * G->maxPathsPerNode);   // entries: one per path through an anchor's end node
+		caps.capTable = std::max(1u, G->maxMpcWidth);
+		caps.capBack = (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)caps.capAnchors * ((uint64_t)G->maxBackPerNode + G->maxPathsPerNode));   // threshold lists: backward links + paths of the start node
 		res->host_us[0] = nowUs() - tGlue;
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] seed expand+order %.1f ms, whole-read setup %.1f ms, fragment windows+arrays %.1f ms\n", (tOrdered - tGlue) / 1e3, (tLongStarted - tOrdered) / 1e3, (nowUs() - tLongStarted) / 1e3);
 
@@ -1703,7 +1708,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		uint32_t* dChainLen = st->chainLen.reserve<uint32_t>(n);
 		unsigned long long* dChainScore = st->chainScore.reserve<unsigned long long>(n);
 		uint32_t* dChainStatus = st->chainStatus.reserve<uint32_t>(n);
-		uint32_t chainBlocks = chainGridBlocks((uint32_t)n);
+		uint32_t chainBlocks = std::max(chainGridBlocks((uint32_t)n), chainScratchBlocks((uint32_t)n));   // both launches index the scratch by block
 		uint8_t* dChainScratch = st->chainScratch.reserve<uint8_t>((uint64_t)std::max(1u, chainBlocks) * chainScratchBytes(caps));
 		if (nWork) HIP_CHECK(hipMemcpyAsync(dWork, work, (size_t)nWork * sizeof(ExtItem), hipMemcpyHostToDevice, stream));
 		if (nFrags) HIP_CHECK(hipMemcpyAsync(dFrags, frags, nFrags * sizeof(Fragment), hipMemcpyHostToDevice, stream));
@@ -1725,7 +1730,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		mark();   // 3
 		launchBuildAnchors(stream, G->dev, dFrags, (uint32_t)nFrags, dFragSeeds, dResults, dTrace, P->split_len, dAnchors, dFragStatus, dFragExtended, dPathPool, dCursors + 2, pathCapacity);
 		mark();   // 4
-		launchChain(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, P->split_len, P->split_gap, caps, dChainScratch, dChainOut, dChainLen, dChainScore, dChainStatus);
+		launchChain(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, P->split_len, P->split_gap, caps, dChainScratch, dChainOut, dChainLen, dChainScore, dChainStatus, getenv("GC_CHAIN_FORCE_SCRATCH") != nullptr);
 		mark();   // 5
 		// chain stitching (src/Aligner.cpp:754-822) on the device, right behind the chaining kernel; GC_HOST_STITCH=1 keeps it on the
 		// host workers (the path also taken by reads that do not fit the kernel's tables)

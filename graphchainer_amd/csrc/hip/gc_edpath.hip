@@ -45,7 +45,7 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 // Column sweep of query (rows) against the first `cols` letters of target. colScores != nullptr: scores of the last
 // column, colScores[r + 1] = D(r, cols - 1), [0] = cols. store: every column's block state goes to S.P / S.M / S.top.
 #define ED_PATH_RING 4096u
-__device__ void sweepColumns(const Seg& query, const Seg& target, uint32_t cols, const EdPathScratch& S, int32_t* colScores, bool store, uint8_t* ringChar, uint8_t* ringCarry)
+__device__ void sweepColumns(const Seg& query, const Seg& target, uint32_t cols, const EdPathScratch& S, int32_t* colScores, bool store, uint8_t* ringChar, uint8_t* ringCarry, uint8_t* ringOut)
 {
 	const uint32_t lane = threadIdx.x;
 	const uint32_t Q = query.n;
@@ -76,9 +76,17 @@ __device__ void sweepColumns(const Seg& query, const Seg& target, uint32_t cols,
 		const uint32_t steps = cols + lanesHere - 1;
 		// Column letters (and, below the first strip, the deltas coming down from the strip above) go through LDS rings refilled 2048 ahead
 		// every 1024 steps by all lanes: a global load per step sat on the step's dependent chain (~0.85 us per step measured).
-		uint32_t loadedEnd = 0;
+		// The deltas leaving the strip's last block take the same route in the other direction: an LDS ring written every step, flushed to
+		// the byte array at the refill points - a global store per step made every following step wait for it (the compiler guards the
+		// store's registers with s_waitcnt vmcnt(0): ~1 us per step, 66 ms per 10 kb pair).
+		uint32_t loadedEnd = 0, flushedEnd = 0;
 		for (uint32_t t = 0; t < steps; t++) {
 			if ((t & 1023u) == 0) {
+				if (carryOut && t >= 64) {   // columns below t - 63 have left lane 63
+					__syncthreads();
+					for (uint32_t c = flushedEnd + lane; c < t - 63; c += 64) S.carry[c] = ringOut[c & (ED_PATH_RING - 1)];
+					flushedEnd = t - 63;
+				}
 				const uint32_t end = t + 2048 < cols ? t + 2048 : cols;
 				for (uint32_t c = loadedEnd + lane; c < end; c += 64) {
 					ringChar[c & (ED_PATH_RING - 1)] = (uint8_t)target.at(c);
@@ -117,7 +125,11 @@ __device__ void sweepColumns(const Seg& query, const Seg& target, uint32_t cols,
 				const uint64_t at = (uint64_t)b * cols + j;   // [block][column]: the walk back reads runs of columns of one block
 				S.P[at] = VP; S.M[at] = VN; S.top[at] = top;
 			}
-			if (carryOut && lane == 63) S.carry[j] = (uint8_t)(houtPrev + 1);
+			if (carryOut && lane == 63) ringOut[j & (ED_PATH_RING - 1)] = (uint8_t)(houtPrev + 1);
+		}
+		if (carryOut) {
+			__syncthreads();
+			for (uint32_t c = flushedEnd + lane; c < cols; c += 64) S.carry[c] = ringOut[c & (ED_PATH_RING - 1)];
 		}
 		if (colScores && active) {
 			int32_t v = top;
@@ -204,7 +216,7 @@ __global__ void __launch_bounds__(64) k_edit_path(const EdPathJob* __restrict__ 
 	uint8_t* __restrict__ scratch, uint64_t scratchBytes, uint32_t maxQ, uint32_t maxT, uint8_t* __restrict__ opsOut, uint32_t* __restrict__ opsLen)
 {
 	__shared__ uint32_t stack[64][5];
-	__shared__ uint8_t ringChar[ED_PATH_RING], ringCarry[ED_PATH_RING];
+	__shared__ uint8_t ringChar[ED_PATH_RING], ringCarry[ED_PATH_RING], ringOut[ED_PATH_RING];
 	const uint32_t lane = threadIdx.x;
 	EdPathScratch S;
 	{
@@ -249,7 +261,7 @@ __global__ void __launch_bounds__(64) k_edit_path(const EdPathJob* __restrict__ 
 			const uint64_t dataSize = 20ull * nBlocks * T + 8ull * T;   // edlib/src/edlib.cpp:1204-1205
 			const Seg qf { query + q0, Q, false }, tf { target + t0, T, false };
 			if (dataSize < 1024ull * 1024ull) {
-				sweepColumns(qf, tf, T, S, nullptr, true, ringChar, ringCarry);
+				sweepColumns(qf, tf, T, S, nullptr, true, ringChar, ringCarry, ringOut);
 				const uint32_t n = walkBack(Q, T, S);
 				__syncthreads();
 				for (uint32_t i = lane; i < n; i += 64) out[nOps + i] = S.tmpOps[n - 1 - i];
@@ -258,9 +270,9 @@ __global__ void __launch_bounds__(64) k_edit_path(const EdPathJob* __restrict__ 
 				continue;
 			}
 			const uint32_t leftW = T / 2, rightW = T - leftW;
-			sweepColumns(qf, tf, leftW, S, S.colLeft, false, ringChar, ringCarry);
+			sweepColumns(qf, tf, leftW, S, S.colLeft, false, ringChar, ringCarry, ringOut);
 			const Seg qr { query + q0, Q, true }, tr { target + t0, T, true };
-			sweepColumns(qr, tr, rightW, S, S.colRight, false, ringChar, ringCarry);
+			sweepColumns(qr, tr, rightW, S, S.colRight, false, ringChar, ringCarry, ringOut);
 			// first row whose left score plus the score below-right of it is the optimum (:1339-1351), then the borders (:1353-1372)
 			int32_t split = -2, leftScore = 0, rightScore = 0;
 			for (uint32_t r0 = 0; r0 + 1 < Q; r0 += 64) {
@@ -299,7 +311,7 @@ uint64_t editPathScratchBytes(uint32_t maxQ, uint32_t maxT)
 	return (b + 255) & ~255ull;
 }
 
-uint32_t editPathGridBlocks(uint32_t nJobs) { return nJobs < 2048 ? nJobs : 2048; }
+uint32_t editPathGridBlocks(uint32_t nJobs) { return nJobs < 6144 ? nJobs : 6144; }   // one pair is one long dependent chain: six waves per SIMD hide each other's latency (1.2 MB of scratch per wave)
 
 void launchEditPath(hipStream_t stream, const EdPathJob* jobs, uint32_t nJobs, const char* letters, const char* bases, uint8_t* scratch, uint32_t maxQ, uint32_t maxT,
 	uint8_t* opsOut, uint32_t* opsLen)

@@ -338,6 +338,8 @@ __global__ void __launch_bounds__(64) k_build_anchors(DGraph g, const Fragment* 
 // Cost O(n^2 K / 64) per read; n is a few hundred anchors.
 // =====================================================================================================
 
+#define CHAIN_NEEDS_SCRATCH 9u   // chainStatus between the two launches
+
 __device__ __forceinline__ unsigned long long packScore(long long score, long long anchor)
 {
 	return ((unsigned long long)(score + (1ll << 30)) << 32) | (unsigned long long)(uint32_t)(anchor + 1);
@@ -362,69 +364,146 @@ __device__ __forceinline__ bool reachesStrictly(const DGraph& g, uint32_t u, uin
 }
 
 #define CHAIN_LDS_ANCHORS 1536
+#define CHAIN_LDS_ENTRIES 2304
+#define CHAIN_LDS_WIDTH 512
 
+// Same maxima, without a reachability test per pair (r2). "end(i) strictly reaches start(j)" means: some path k of the cover runs
+// through end(i) at a position <= the position of the last node of k that reaches start(j) - the (k, position) pairs of
+// backwards[start(j)] (computeMPCIndex, :1373-1384). So every anchor i leaves one ENTRY (k, position of end(i) on k) per path
+// through its end node, kept in LDS in anchor (= fragment) order, and anchor j is answered by one scan of the entries of earlier
+// fragments against a small table thr[k] = position from backwards[start(j)] (-1 elsewhere): the reference's per-path treaps keyed
+// by read coordinate, with the sweep order turned from topological to fragment order so that "earlier in the read" is a prefix.
+// No global loads inside the DP loop (the pair-wise version fetched ~20x its input: two sorted lists merged per pair): entries and
+// threshold lists of all anchors are laid out in LDS by the set-up pass, lanes in parallel.
+struct ChainEntry { uint32_t pos; uint16_t k, anchor; };   // an anchor's end node on path k at position pos
+
+struct ChainArrays {   // one read's working set: LDS (template LDS) or this block's HBM scratch
+	uint32_t* aStart; unsigned long long* C;
+	uint16_t* aFrag; uint16_t* aComp; uint16_t* entBegin; uint32_t* backBegin;
+	ChainEntry* ent; uint2* back; int32_t* thr;   // back: the anchors' threshold lists (path, position), always in this block's HBM scratch (a wide cover makes them long)
+};
+
+template <bool LDS>
 __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __restrict__ jobs, uint32_t nReads, const AnchorRec* __restrict__ anchors,
 	const Fragment* __restrict__ frags, const uint32_t* __restrict__ fragStatus, int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* __restrict__ scratch, uint64_t scratchStride,
-	uint32_t* __restrict__ chainOut, uint32_t* __restrict__ chainLen, unsigned long long* __restrict__ chainScore, uint32_t* __restrict__ chainStatus)
+	uint32_t* __restrict__ chainOut, uint32_t* __restrict__ chainLen, unsigned long long* __restrict__ chainScore, uint32_t* __restrict__ chainStatus, uint32_t forceScratch)
 {
-	__shared__ uint32_t ldsStart[CHAIN_LDS_ANCHORS], ldsEnd[CHAIN_LDS_ANCHORS], ldsX[CHAIN_LDS_ANCHORS];
-	__shared__ unsigned long long ldsC[CHAIN_LDS_ANCHORS];
+	__shared__ uint32_t sStart[LDS ? CHAIN_LDS_ANCHORS : 1];
+	__shared__ unsigned long long sC[LDS ? CHAIN_LDS_ANCHORS : 1];
+	__shared__ uint16_t sFrag[LDS ? CHAIN_LDS_ANCHORS : 1], sComp[LDS ? CHAIN_LDS_ANCHORS : 1], sEntBegin[LDS ? CHAIN_LDS_ANCHORS + 1 : 1];
+	__shared__ uint32_t sBackBegin[LDS ? CHAIN_LDS_ANCHORS + 1 : 1];
+	__shared__ ChainEntry sEnt[LDS ? CHAIN_LDS_ENTRIES : 1];
+	__shared__ int32_t sThr[LDS ? CHAIN_LDS_WIDTH : 1];
 	const int lane = threadIdx.x;
+	// (16-bit indices: at most 65535 anchors, entries and threshold-list items per read, cover width and components below 65536; beyond that the read is flagged)
+	const uint32_t capA = LDS ? CHAIN_LDS_ANCHORS : (caps.capAnchors < 65535u ? caps.capAnchors : 65535u);
+	const uint32_t capE = LDS ? CHAIN_LDS_ENTRIES : (caps.capEndpoints < 65535u ? caps.capEndpoints : 65535u);
+	const uint32_t capB = caps.capBack;
+	const uint32_t capW = LDS ? CHAIN_LDS_WIDTH : (caps.capTable < 65535u ? caps.capTable : 65535u);
+	ChainArrays A;
+	uint8_t* base = scratch + (uint64_t)blockIdx.x * scratchStride;
+	A.back = (uint2*)base; base += 8ull * capB;
+	if (LDS) { A.aStart = sStart; A.C = sC; A.aFrag = sFrag; A.aComp = sComp; A.entBegin = sEntBegin; A.backBegin = sBackBegin; A.ent = sEnt; A.thr = sThr; }
+	else {
+		A.C = (unsigned long long*)base; base += 8ull * capA;
+		A.ent = (ChainEntry*)base; base += 8ull * capE;
+		A.aStart = (uint32_t*)base; base += 4ull * capA;
+		A.backBegin = (uint32_t*)base; base += 4ull * (capA + 1);
+		A.thr = (int32_t*)base; base += 4ull * capW;
+		A.aFrag = (uint16_t*)base; base += 2ull * capA;
+		A.aComp = (uint16_t*)base; base += 2ull * capA;
+		A.entBegin = (uint16_t*)base;
+	}
+	for (uint32_t w = lane; w < capW; w += 64) A.thr[w] = -1;
+	__syncthreads();
 	for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
 		ReadChainJob job = jobs[r];
+		if (!LDS && chainStatus[r] != CHAIN_NEEDS_SCRATCH) continue;   // second launch: only the reads the LDS launch passed on
 		// the reference never resets its `cont` flag after a fragment whose extension threw, so fragments after the
 		// first failed one contribute no anchors (src/Aligner.cpp:695-703): slots from that fragment on are cut off
 		uint32_t cut = job.nSlots;
 		for (uint32_t f = lane; f < job.nFrags; f += 64)
 			if (fragStatus[job.fragBegin + f] == 1) { uint32_t c = frags[job.fragBegin + f].seedBegin - job.slotBegin; cut = c < cut ? c : cut; }
 		for (int d = 32; d > 0; d >>= 1) { uint32_t o = __shfl_xor(cut, d); cut = o < cut ? o : cut; }
-		// working arrays: LDS when the read's anchors fit, else this block's HBM scratch
-		uint32_t *aStart = ldsStart, *aEnd = ldsEnd, *aX = ldsX;
-		unsigned long long* C = ldsC;
-		if (cut > CHAIN_LDS_ANCHORS) {
-			uint8_t* base = scratch + (uint64_t)blockIdx.x * scratchStride;
-			C = (unsigned long long*)base;
-			aStart = (uint32_t*)(base + 8ull * caps.capAnchors);
-			aEnd = aStart + caps.capAnchors;
-			aX = aEnd + caps.capAnchors;
-		}
-		// compact the read's valid anchors in slot order (== the order the reference pushes them, src/Aligner.cpp:706-721)
-		uint32_t nA = 0;
-		for (uint32_t s0 = 0; s0 < cut; s0 += 64) {
+		// Compact the read's valid anchors in slot order (== the order the reference pushes them, src/Aligner.cpp:706-721). Every anchor gets
+		// its entries (one per path through its END node) and its threshold list: for its START node v, per path k the last position on k
+		// that may precede it - backwards[v] (strict reachability, :1373-1384) plus (k, position of v) for the paths through v itself,
+		// which adds "same node" (:1785-1822: an anchor of an earlier fragment ending in v sorts before j by (y, x)).
+		uint32_t nA = 0, nE = 0, nB = 0;
+		bool fits = !(LDS && forceScratch);   // test hook: every read through the scratch launch
+		for (uint32_t s0 = 0; s0 < cut && fits; s0 += 64) {
 			uint32_t s = s0 + lane;
 			bool valid = false;
 			AnchorRec rec;
+			uint32_t pBegin = 0, pCount = 0, bBegin = 0, bCount = 0, vBegin = 0, vCount = 0, comp = 0;
 			if (s < cut) { rec = anchors[job.slotBegin + s]; valid = rec.valid != 0; }
-			unsigned long long ballot = __ballot(valid);
 			if (valid) {
-				uint32_t a = nA + (uint32_t)__popcll(ballot & ((1ull << lane) - 1));
-				aStart[a] = rec.firstNode;
-				aEnd[a] = rec.lastNode;
-				aX[a] = rec.x;
-				C[a] = packScore((long long)rec.y - (long long)rec.x + 1, -1);   // :1769
+				pBegin = g.pathsOff[rec.lastNode]; pCount = g.pathsOff[rec.lastNode + 1] - pBegin;
+				bBegin = g.backOff[rec.firstNode]; bCount = g.backOff[rec.firstNode + 1] - bBegin;
+				vBegin = g.pathsOff[rec.firstNode]; vCount = g.pathsOff[rec.firstNode + 1] - vBegin;
+				comp = g.componentMap[rec.lastNode];
 			}
-			nA += (uint32_t)__popcll(ballot);
+			unsigned long long ballot = __ballot(valid);
+			uint32_t inclE = pCount, inclB = bCount + vCount;
+			for (int d = 1; d < 64; d <<= 1) {
+				uint32_t oe = __shfl_up(inclE, d), ob = __shfl_up(inclB, d);
+				if (lane >= d) { inclE += oe; inclB += ob; }
+			}
+			const uint32_t chunkE = __shfl(inclE, 63), chunkB = __shfl(inclB, 63), chunkA = (uint32_t)__popcll(ballot);
+			const bool wide = valid && (comp > 65535u || g.mpcWidth[comp] > capW || rec.x / (uint32_t)splitGap > 65535u);
+			if (nA + chunkA > capA || nE + chunkE > capE || nB + chunkB > capB || __any(wide)) { fits = false; break; }
+			if (valid) {
+				const uint32_t a = nA + (uint32_t)__popcll(ballot & ((1ull << lane) - 1));
+				const uint32_t e0 = nE + inclE - pCount, t0 = nB + inclB - (bCount + vCount);
+				A.aStart[a] = rec.firstNode;
+				A.aFrag[a] = (uint16_t)(rec.x / (uint32_t)splitGap);   // fragment starts are multiples of the step: x and the index order alike
+				A.aComp[a] = (uint16_t)comp;
+				A.C[a] = packScore((long long)rec.y - (long long)rec.x + 1, -1);   // :1769
+				A.entBegin[a] = (uint16_t)e0;
+				A.backBegin[a] = t0;
+				for (uint32_t i = 0; i < pCount; i++) A.ent[e0 + i] = ChainEntry { g.pathsPos[pBegin + i], (uint16_t)g.paths[pBegin + i], (uint16_t)a };
+				for (uint32_t i = 0; i < bCount; i++) A.back[t0 + i] = make_uint2(g.backPath[bBegin + i], g.backPos[bBegin + i]);
+				for (uint32_t i = 0; i < vCount; i++) A.back[t0 + bCount + i] = make_uint2(g.paths[vBegin + i], g.pathsPos[vBegin + i]);
+			}
+			nA += chunkA; nE += chunkE; nB += chunkB;
 		}
+		if (!fits) {
+			if (lane == 0) { chainStatus[r] = LDS ? CHAIN_NEEDS_SCRATCH : 1u; chainLen[r] = 0; chainScore[r] = 0; }
+			__syncthreads();
+			continue;
+		}
+		if (lane == 0) { A.entBegin[nA] = (uint16_t)nE; A.backBegin[nA] = nB; }
 		__syncthreads();
-		// anchors are ordered by fragment start x; g0 = first anchor of j's fragment
-		uint32_t g0 = 0;
+		// anchors are ordered by fragment; g0 = first anchor of j's fragment, the entries of anchors < g0 are a prefix. The threshold lists
+		// of consecutive anchors are consecutive in `back`: a 64-item window of them is kept in registers (item w0 + lane), refilled with one
+		// coalesced load when an anchor's list runs past it - the only global access of the DP loop, a few times per hundred anchors on a narrow cover.
+		uint32_t g0 = 0, entPrefix = 0;
+		uint32_t w0 = 0;
+		uint2 win = (uint32_t)lane < nB ? A.back[lane] : make_uint2(0, 0);
 		for (uint32_t j = 0; j < nA; j++) {
-			uint32_t xj = aX[j];
-			if (j > 0 && xj != aX[j - 1]) { g0 = j; __syncthreads(); }   // C of the previous fragment's anchors is now final and visible
+			const uint32_t fj = A.aFrag[j];
+			if (j > 0 && fj != A.aFrag[j - 1]) { g0 = j; entPrefix = A.entBegin[j]; __syncthreads(); }   // C of the previous fragment's anchors is now final and visible
 			if (g0 == 0) continue;
-			uint32_t v = aStart[j];
-			uint32_t compV = g.componentMap[v];
-			long long yj = (long long)xj + splitLen - 1;
+			const uint32_t b0 = A.backBegin[j], b1 = A.backBegin[j + 1];
+			// thr[k] = last position on path k that may precede start(j)
+			if (b1 <= w0 + 64 || (b1 - b0 <= 64 && (w0 = b0, win = b0 + lane < nB ? A.back[b0 + lane] : make_uint2(0, 0), true))) {
+				const uint32_t t = w0 + lane;
+				if (t >= b0 && t < b1) atomicMax(&A.thr[win.x], (int32_t)win.y);
+			} else {
+				for (uint32_t t = b0 + lane; t < b1; t += 64) { const uint2 it = A.back[t]; atomicMax(&A.thr[it.x], (int32_t)it.y); }   // a list longer than the window (wide cover)
+			}
+			__syncthreads();
+			const uint32_t compV = A.aComp[j];
+			const long long xj = (long long)fj * splitGap, yj = xj + splitLen - 1;
 			unsigned long long best = 0;
-			for (uint32_t i = lane; i < g0; i += 64) {
-				uint32_t u = aEnd[i];
-				long long yi = (long long)aX[i] + splitLen - 1;
-				if (yi >= yj) continue;
-				if (g.componentMap[u] != compV) continue;
-				if (u != v && !reachesStrictly(g, u, v)) continue;
-				long long ci = unpackScore(C[i]);
+			for (uint32_t e = lane; e < entPrefix; e += 64) {
+				const ChainEntry en = A.ent[e];
+				const uint32_t i = en.anchor;
+				if (A.aComp[i] != compV || (int32_t)en.pos > A.thr[en.k]) continue;   // (path ids are per component)
+				const long long yi = (long long)A.aFrag[i] * splitGap + splitLen - 1;
+				const long long ci = unpackScore(A.C[i]);
 				unsigned long long cand;
-				if (yi <= (long long)xj - 1) cand = packScore((long long)splitLen + ci, i);
+				if (yi <= xj - 1) cand = packScore((long long)splitLen + ci, i);
 				else cand = packScore(yj - yi + ci, i);   // x_j <= y_i <= y_j - 1
 				best = cand > best ? cand : best;
 			}
@@ -432,7 +511,14 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 				unsigned long long o = __shfl_xor(best, d);
 				best = o > best ? o : best;
 			}
-			if (lane == 0 && best > C[j]) C[j] = best;
+			if (lane == 0 && best > A.C[j]) A.C[j] = best;
+			__syncthreads();
+			if (b1 <= w0 + 64 && b0 >= w0) {
+				const uint32_t t = w0 + lane;
+				if (t >= b0 && t < b1) A.thr[win.x] = -1;
+			} else {
+				for (uint32_t t = b0 + lane; t < b1; t += 64) A.thr[A.back[t].x] = -1;
+			}
 		}
 		__syncthreads();
 		if (lane == 0) {
@@ -444,22 +530,22 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 			while (nA > 0) {   // components in ascending id; keep the first strictly greater score (:1713-1733)
 				long long cid = -1;
 				for (uint32_t a = 0; a < nA; a++) {
-					long long c = g.componentMap[aEnd[a]];
+					long long c = A.aComp[a];
 					if (c > lastCid && (cid < 0 || c < cid)) cid = c;
 				}
 				if (cid < 0) break;
 				lastCid = cid;
 				long long score = 0, anchor = -1;   // :1847-1849, lexicographic max of (coverage, index)
 				for (uint32_t a = 0; a < nA; a++) {
-					if ((long long)g.componentMap[aEnd[a]] != cid) continue;
-					long long sc = unpackScore(C[a]);
+					if ((long long)A.aComp[a] != cid) continue;
+					long long sc = unpackScore(A.C[a]);
 					if (sc > score || (sc == score && (long long)a > anchor)) { score = sc; anchor = a; }
 				}
 				if (first || score > best) {
 					first = false;
 					best = score;
 					uint32_t n = 0;
-					for (long long i = anchor; i != -1; i = unpackAnchor(C[i])) {   // :1851-1862
+					for (long long i = anchor; i != -1; i = unpackAnchor(A.C[i])) {   // :1851-1862
 						if (n >= job.nSlots) { status = 1; break; }
 						out[n++] = (uint32_t)i;
 					}
@@ -1025,18 +1111,21 @@ void launchBuildAnchors(hipStream_t stream, const DGraph& g, const Fragment* fra
 
 uint64_t chainScratchBytes(const ChainCaps& caps)
 {
-	if (caps.capAnchors <= CHAIN_LDS_ANCHORS) return 64;   // everything fits in LDS
-	uint64_t b = 8ull * caps.capAnchors + 12ull * caps.capAnchors;
+	// the scratch launch's arrays for one read: anchors (capAnchors), entries (capEndpoints), threshold table (capTable)
+	uint64_t b = 8ull * caps.capBack + 8ull * caps.capAnchors + 8ull * caps.capEndpoints + 4ull * caps.capAnchors + 4ull * (caps.capAnchors + 1) + 4ull * caps.capTable + 6ull * (caps.capAnchors + 1) + 256;
 	return (b + 63) & ~63ull;
 }
 
-uint32_t chainGridBlocks(uint32_t nReads) { return nReads < 8192 ? nReads : 8192; }
+uint32_t chainGridBlocks(uint32_t nReads) { return nReads < 2048 ? nReads : 2048; }   // three blocks fit a CU (LDS); every block owns a threshold-list region in HBM
+uint32_t chainScratchBlocks(uint32_t nReads) { return nReads < 256 ? nReads : 256; }   // the reads that do not fit the LDS tables are few
 
 void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
-	int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* scratch, uint32_t* chainOut, uint32_t* chainLen, unsigned long long* chainScore, uint32_t* chainStatus)
+	int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* scratch, uint32_t* chainOut, uint32_t* chainLen, unsigned long long* chainScore, uint32_t* chainStatus, bool forceScratch)
 {
 	if (nReads == 0) return;
-	hipLaunchKernelGGL(k_chain, dim3(chainGridBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true>), dim3(chainGridBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, forceScratch ? 1u : 0u);
+	// reads with more anchors / entries than the LDS tables hold, or on a cover wider than the LDS threshold table (waves whose read is done leave at once)
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<false>), dim3(chainScratchBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, 0u);
 }
 
 uint64_t longWaveWordsPerLane(const ExtendConfig& cfg) { return waveScratchWords(cfg.maxSlices, cfg.maxItems, cfg.maxTrace); }

@@ -61,7 +61,7 @@ struct ReadChainJob {
 	uint32_t fragBegin, nFrags;   // this read's fragments (for the "no anchors after a failed fragment" rule)
 };
 
-struct ChainCaps { uint32_t capAnchors, capEndpoints, capTable; };
+struct ChainCaps { uint32_t capAnchors, capEndpoints, capTable, capBack; };   // most anchors of a read; most entries (anchor x paths through its end node); widest path cover
 
 // ---- whole-read pass (K3-long) ----
 struct LongSeed {    // a seed in goodness order (after OrderSeeds); 16 bytes: 3 M of them go up per 10 k-read batch
@@ -127,8 +127,9 @@ void launchBuildAnchors(hipStream_t stream, const DGraph& g, const Fragment* fra
 
 uint64_t chainScratchBytes(const ChainCaps& caps);
 uint32_t chainGridBlocks(uint32_t nReads);
+uint32_t chainScratchBlocks(uint32_t nReads);
 void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
-	int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* scratch, uint32_t* chainOut, uint32_t* chainLen, unsigned long long* chainScore, uint32_t* chainStatus);
+	int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* scratch, uint32_t* chainOut, uint32_t* chainLen, unsigned long long* chainScore, uint32_t* chainStatus, bool forceScratch = false);
 
 void launchLongPass(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg, const LongJob* jobs, uint32_t nReads,
 	const LongSeed* seeds, const char* bases, uint64_t rcBase, uint32_t minClusterSize, uint32_t maxAlignments, uint8_t* scratch, uint64_t slabBytes,

@@ -411,6 +411,19 @@ def test_config3_shape_with_whole_read_pass(gca, tmp_path):
     assert int(got["read_anchor_off"][-1]) > 24 * 200
 
 
+def test_chain_kernel_scratch_path(gca, tmp_path, monkeypatch):
+    """k_chain keeps a read's anchors and path entries in LDS; reads beyond those tables (or on a cover wider than the LDS threshold
+    table) run in a second launch with the same code on HBM scratch. Forced for every read here."""
+    from graphchainer_amd.synth import SynthGenome
+    monkeypatch.setenv("GC_CHAIN_FORCE_SCRATCH", "1")
+    gen = SynthGenome(2, 60_000, seed=29, multi_allelic=0.3, nested=0.3, repeats=4, repeat_len=1500)
+    gfa = str(tmp_path / "g.gfa")
+    gen.write_gfa(gfa)
+    reads = gen.sample_reads(300, 1200, seed=5)          # more reads than the scratch launch has blocks
+    got, want = run_case(gca, gfa, reads, split_gap=18)
+    compare(got, want)
+
+
 def test_chain_kernel_against_bruteforce(gca, tmp_path):
     """k_chain's chains against the quadratic DP over BFS reachability of tests/graph_model.py (independent of the oracle and of
     the MPC index): several components, wide covers, overlapping fragments."""
