@@ -1,6 +1,9 @@
 // Host-side construction of the alignment graph ("A0" data).
 // Restates the behaviour of the reference's loaders; every function cites the lines it follows.
 #include "gc_graph.hpp"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <atomic>
 #include <cstdlib>
 #include <exception>
@@ -48,6 +51,20 @@ std::string ReverseComplement(const std::string& s)   // reference: src/CommonUt
 	return out;
 }
 
+namespace {
+// start-up stage timing on stderr (GC_DEBUG_TIMES)
+struct StageClock {
+	std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+	const bool on = getenv("GC_DEBUG_TIMES") != nullptr;
+	void lap(const char* what)
+	{
+		auto now = std::chrono::steady_clock::now();
+		if (on) fprintf(stderr, "[gc build] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+		t = now;
+	}
+};
+}
+
 // ------------------------------------------------------------------ GFA parsing
 
 // reference: src/GfaGraph.cpp:212-370 (LoadFromStream, called with allowVaryingOverlaps=true from
@@ -65,29 +82,45 @@ GfaGraph GfaGraph::LoadFromStream(std::istream& in)
 		return id;
 	};
 	std::string line;
+	// whitespace-separated fields of `line`, like operator>> on a stringstream (the reference's tokenizer) without building one per line:
+	// the stream objects were a third of the start-up time on a 7 M-segment graph
+	size_t cursor = 0;
+	auto nextField = [&]() -> std::string {
+		while (cursor < line.size() && (line[cursor] == ' ' || line[cursor] == '\t' || line[cursor] == '\r' || line[cursor] == '\v' || line[cursor] == '\f')) cursor++;
+		size_t begin = cursor;
+		while (cursor < line.size() && !(line[cursor] == ' ' || line[cursor] == '\t' || line[cursor] == '\r' || line[cursor] == '\v' || line[cursor] == '\f')) cursor++;
+		return line.substr(begin, cursor - begin);
+	};
 	while (in.good()) {
 		std::getline(in, line);
 		if (!in.good()) break;   // like the reference (:219-223), a last line without '\n' is dropped
 		if (line.empty()) continue;
+		cursor = 0;
 		if (line[0] == 'S') {
-			std::stringstream ss(line);
-			std::string tag, name, seq;
-			ss >> tag >> name;
+			std::string tag = nextField(), name = nextField();
 			int id = nameId(name);
-			ss >> seq;
+			std::string seq = nextField();
 			if (seq == "*") throw std::runtime_error("Nodes without sequence (*) are not currently supported (nodeid " + name + ")");
 			if (seq.empty()) throw std::runtime_error("empty S line for node " + name);
-			g.nodes[id] = seq;
+			g.nodes[id] = std::move(seq);
 		} else if (line[0] == 'L') {
-			std::stringstream ss(line);
-			std::string tag, from, fromOri, to, toOri;
+			std::string tag = nextField(), from = nextField();
+			int fromId = nameId(from);
+			std::string fromOri = nextField(), to = nextField();
+			int toId = nameId(to);
+			std::string toOri = nextField(), cigar = nextField();
 			int overlap = 0;
 			char unit = 'M';
-			ss >> tag >> from;
-			int fromId = nameId(from);
-			ss >> fromOri >> to;
-			int toId = nameId(to);
-			ss >> toOri >> overlap >> unit;
+			{   // "<int><unit>" as `ss >> overlap >> unit` reads it (a missing or malformed number leaves 0, as a failed extraction does)
+				size_t at = 0;
+				bool negative = false;
+				if (at < cigar.size() && (cigar[at] == '-' || cigar[at] == '+')) { negative = cigar[at] == '-'; at++; }
+				long long value = 0;
+				bool digits = false;
+				while (at < cigar.size() && cigar[at] >= '0' && cigar[at] <= '9') { value = value * 10 + (cigar[at] - '0'); if (value > 2000000000ll) value = 2000000000ll; at++; digits = true; }
+				if (digits) { overlap = (int)(negative ? -value : value); if (at < cigar.size()) unit = cigar[at]; }
+			}
+			(void)unit;
 			if ((fromOri != "+" && fromOri != "-") || (toOri != "+" && toOri != "-")) throw std::runtime_error("bad L line orientation: " + line);
 			if (overlap < 0) throw std::runtime_error("Edge overlap cannot be negative. Fix the graph");
 			NodePos a { fromId, fromOri == "+" };
@@ -112,7 +145,10 @@ GfaGraph GfaGraph::LoadFromFile(const std::string& path)
 {
 	std::ifstream f(path);
 	if (!f.good()) throw std::runtime_error("cannot open GFA file " + path);
-	return LoadFromStream(f);
+	auto t0 = std::chrono::steady_clock::now();
+	GfaGraph g = LoadFromStream(f);
+	if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc build] %-28s %8.1f ms\n", "GFA parse", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+	return g;
 }
 
 // ------------------------------------------------------------------ bigraph -> split-node digraph
@@ -132,6 +168,7 @@ static bool allowedNucleotide(char c)   // reference: src/BigraphToDigraph.cpp:9
 // reverse-complement node 2n+1 (:101-104); link a(+/-) -> b(+/-) becomes two directed edges (:106-132).
 AlignmentGraph AlignmentGraph::BuildFromGFA(const GfaGraph& gfa)
 {
+	StageClock clock;
 	AlignmentGraph g;
 	for (auto& ov : gfa.overlaps)
 		if (ov.second != 0) throw std::runtime_error("edge overlaps other than 0M are outside this build's scope (variation-graph DAGs only)");
@@ -144,6 +181,7 @@ AlignmentGraph AlignmentGraph::BuildFromGFA(const GfaGraph& gfa)
 		g.AddNode(node.first * 2, node.second, name, false, breakpoints);
 		g.AddNode(node.first * 2 + 1, ReverseComplement(node.second), name, true, breakpoints);
 	}
+	clock.lap("split nodes");
 	for (const auto& edge : gfa.edges) {
 		for (const auto& target : edge.second) {
 			int from = edge.first.id, to = target.id;
@@ -155,6 +193,7 @@ AlignmentGraph AlignmentGraph::BuildFromGFA(const GfaGraph& gfa)
 			g.AddEdgeNodeId((int)toLeft, (int)fromLeft, 0);
 		}
 	}
+	clock.lap("edges");
 	g.Finalize();
 	return g;
 }
@@ -244,11 +283,16 @@ void AlignmentGraph::AddEdgeNodeId(int fromId, int toId, size_t startOffset)
 // reference: src/AlignmentGraph.cpp:255-307
 void AlignmentGraph::Finalize()
 {
+	StageClock clock;
 	RenumberAmbiguousToEnd();
 	ambiguousNodes.clear();
+	clock.lap("renumber ambiguous");
 	findLinearizable();
+	clock.lap("linearizable");
 	doComponentOrder();
+	clock.lap("component order (Tarjan)");
 	findChains();
+	clock.lap("chains");
 	finalized = true;
 }
 
@@ -672,9 +716,13 @@ void AlignmentGraph::buildMPC(bool shrinkToMinimum)   // reference: src/Alignmen
 	// Components are independent (forward and reverse strand of a connected graph are two) and every step below touches
 	// only its own component's slots, so they are built side by side; the result does not depend on the schedule.
 	auto buildComponent = [&](size_t cid) {
+		StageClock clock;
 		mpc[cid] = greedyCover(cid);
+		clock.lap("greedy path cover");
 		if (shrinkToMinimum) mpc[cid] = shrink(cid, mpc[cid]);
+		clock.lap("shrink (max flow)");
 		computeMPCIndex(cid, mpc[cid]);
+		clock.lap("MPC index");
 	};
 	size_t workers = std::min<size_t>(C, buildThreads());
 	if (workers <= 1) {
