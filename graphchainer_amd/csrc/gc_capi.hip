@@ -999,6 +999,47 @@ static void uploadSeeder(gc_seeder* S)
 	S->dev.w = (int32_t)S->host.w;
 }
 
+// The minimizer index built by the device (gc_minimizer.hip): window scan per bigraph node, one radix sort; the host only cuts the sorted
+// pairs into the k-mer groups. Same index as gc::MinimizerIndex::Build (tests/test_index_cache.py compares them array by array).
+// false = not applicable here (deque longer than the kernel's ring, GC_SEEDER_BUILD=host), the caller builds on the host.
+static bool buildSeederOnDevice(const gc_graph* G, gc_seeder* S, size_t k, size_t w, double keepLeastFrequentFraction)
+{
+	if (const char* env = getenv("GC_SEEDER_BUILD")) if (!strcmp(env, "host")) return false;
+	if (w - k + 2 > 32) return false;
+	const gc::AlignmentGraph& h = G->host;
+	// minimizers ending inside an overlap prefix are skipped (src/MinimizerSeeder.cpp:323-340,369): never the case for the 0M graphs the
+	// library loads, checked rather than assumed
+	for (size_t i = 0; i < h.NodeSize(); i++) {
+		if (h.nodeOffset[i] == 0) continue;
+		for (size_t nb : h.inNeighbors[i]) if (h.nodeIDs[nb] != h.nodeIDs[i]) return false;
+	}
+	std::vector<int32_t> idOrder(h.nodeLookupOrder.begin(), h.nodeLookupOrder.end());   // arrival order at -t 1: nodeLookup iteration order (:354-357)
+	if (idOrder.empty()) for (const auto& entry : h.nodeLookup) idOrder.push_back(entry.first);
+	if (idOrder.empty()) return false;
+	int32_t* dOrder = uploadVector(idOrder);
+	uint64_t *dKeys = nullptr, *dValues = nullptr;
+	uint64_t n = gcdev::buildMinimizerPairsDevice(G->dev, dOrder, (uint32_t)idOrder.size(), (uint32_t)k, (uint32_t)w, &dKeys, &dValues);
+	(void)hipFree(dOrder);
+	if (n == ~0ull) { (void)hipGetLastError(); return false; }
+	std::vector<uint64_t> keys(n);
+	gc::MinimizerIndex& idx = S->host;
+	idx = gc::MinimizerIndex();
+	idx.k = k; idx.w = w;
+	idx.positions.resize(n);
+	if (n) {
+		HIP_CHECK(hipMemcpy(keys.data(), dKeys, n * 8, hipMemcpyDeviceToHost));
+		HIP_CHECK(hipMemcpy(idx.positions.data(), dValues, n * 8, hipMemcpyDeviceToHost));
+		(void)hipFree(dKeys); (void)hipFree(dValues);
+	}
+	for (size_t i = 0; i < n; i++) {
+		uint64_t kmer = keys[i] >> 34;
+		if (idx.kmers.empty() || idx.kmers.back() != kmer) { idx.kmers.push_back(kmer); idx.startPos.push_back(i); }
+	}
+	idx.startPos.push_back(n);
+	idx.maxCount = gc::minimizerMaxCount(idx.startPos, keepLeastFrequentFraction);
+	return true;
+}
+
 static bool seederShapeOk(int64_t k, int64_t w) { return k >= 1 && k <= 15 && w >= k; }
 
 int gc_seeder_create(const gc_graph* g, int32_t k, int32_t w, double keepFraction, gc_seeder** out)
@@ -1009,7 +1050,7 @@ int gc_seeder_create(const gc_graph* g, int32_t k, int32_t w, double keepFractio
 	gc_seeder* S = new gc_seeder();
 	int rc = guarded([&]() {
 		requireDevice();
-		S->host = gc::MinimizerIndex::Build(g->host, (size_t)k, (size_t)w, keepFraction);
+		if (!buildSeederOnDevice(g, S, (size_t)k, (size_t)w, keepFraction)) S->host = gc::MinimizerIndex::Build(g->host, (size_t)k, (size_t)w, keepFraction);
 		uploadSeeder(S);
 		return (int)GC_OK;
 	});

@@ -184,6 +184,9 @@ void launchChainPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* j
 uint32_t editDistanceMaxK(uint32_t unitBlocks);
 void launchEditDistance(hipStream_t stream, uint32_t unitBlocks, const EdPair* pairs, uint32_t nPairs, const EdRead* reads, const char* bases, const uint64_t* eqMasks,
 	const char* letters, const uint32_t* lettersLen, int64_t* outDistance);
+// ---- minimizer index construction on the device (gc_minimizer.hip): the graph's window minimizers as (k-mer << 34 | reversed
+// arrival index, packed position) pairs, sorted; returns their number (~0 on failure: the caller builds on the host), arrays are hipMalloc'd
+uint64_t buildMinimizerPairsDevice(const DGraph& g, const int32_t* idOrderDev, uint32_t nIds, uint32_t k, uint32_t w, uint64_t** outKeys, uint64_t** outValues);
 // ---- read batch preparation (gc_reads.hip): reverse-complement strand, match-mask / exact-match bit vectors, 2-bit packing, all from the raw bases
 void launchPackReads(hipStream_t stream, const uint64_t* readOff, uint32_t nReads, uint64_t totalBases, char* bases, const uint64_t* maskOff, const uint32_t* maskWords, uint64_t* masks,
 	const uint64_t* eqOff, uint64_t* eqMasks, uint8_t* readInvalid, uint64_t* packed, uint64_t* invalidBits, uint32_t* chunkRead);

@@ -130,6 +130,8 @@ struct MinimizerIndex {
 	static MinimizerIndex Build(const AlignmentGraph& g, size_t k, size_t w, double keepLeastFrequentFraction);
 };
 
+size_t minimizerMaxCount(const std::vector<uint64_t>& startPos, double keepLeastFrequentFraction);   // src/MinimizerSeeder.cpp:557-575
+
 // Threads the start-up builders may use (components of the MPC index, node chunks of the minimizer scan): GC_BUILD_THREADS,
 // default = hardware threads. The results do not depend on it.
 size_t buildThreads();

@@ -172,18 +172,22 @@ MinimizerIndex MinimizerIndex::Build(const AlignmentGraph& g, size_t k, size_t w
 		idx.positions.push_back(arrivals[order[i]].second);
 	}
 	idx.startPos.push_back(order.size());
-	// reference: src/MinimizerSeeder.cpp:557-575
-	idx.maxCount = 0;
-	if (idx.kmers.size() >= 2) {
-		std::vector<size_t> counts;
-		counts.reserve(idx.kmers.size() - 1);
-		for (size_t i = 0; i + 1 < idx.kmers.size(); i++) counts.push_back(idx.startPos[i + 1] - idx.startPos[i]);
-		std::sort(counts.begin(), counts.end());
-		size_t at = (size_t)(counts.size() * keepLeastFrequentFraction);
-		if (at == counts.size()) at = counts.size() - 1;
-		idx.maxCount = counts[at] + 1;
-	}
+	idx.maxCount = minimizerMaxCount(idx.startPos, keepLeastFrequentFraction);
 	return idx;
+}
+
+// reference: src/MinimizerSeeder.cpp:557-575 (the last k-mer's list is left out of the quantile there, and so here)
+size_t minimizerMaxCount(const std::vector<uint64_t>& startPos, double keepLeastFrequentFraction)
+{
+	size_t nKmers = startPos.empty() ? 0 : startPos.size() - 1;
+	if (nKmers < 2) return 0;
+	std::vector<size_t> counts;
+	counts.reserve(nKmers - 1);
+	for (size_t i = 0; i + 1 < nKmers; i++) counts.push_back(startPos[i + 1] - startPos[i]);
+	std::sort(counts.begin(), counts.end());
+	size_t at = (size_t)(counts.size() * keepLeastFrequentFraction);
+	if (at == counts.size()) at = counts.size() - 1;
+	return counts[at] + 1;
 }
 
 } // namespace gc

@@ -300,3 +300,45 @@ def test_threaded_build_equals_serial_build(gca, tmp_path, monkeypatch):
         blobs.append(open(str(tmp_path / "threaded.gcidx"), "rb").read())
     assert all(b == blobs[0] for b in blobs[1:])
     assert gca.api.check_index_cache(str(tmp_path / "serial.gcidx"))["kmers"] > 100_000
+
+
+@pytest.mark.gpu
+def test_device_built_minimizer_index_equals_host_built(gca, tmp_path, monkeypatch):
+    """gc_seeder_create builds the minimizer index on the device (gc_minimizer.hip: window scan per bigraph node + one radix sort);
+    gc_index_build and GC_SEEDER_BUILD=host run the host builder (host/gc_minimizer.cpp). Same k-mers, same lists in the same order,
+    same frequency cutoff - over the golden graphs, graphs with IUPAC letters (windows restart after them), short nodes (< w), and
+    window shapes from w = k to the longest deque the kernel holds; beyond that the library falls back to the host builder."""
+    import random
+    from test_graph_model import random_dag_gfa
+    from graphchainer_amd.synth import SynthGenome
+    paths = [os.path.join(GOLD, "ref_test_graph.gfa"), os.path.join(GOLD, "syn20k.gfa")]
+    p = str(tmp_path / "genome.gfa")
+    SynthGenome(2, 30000, seed=5, multi_allelic=0.3, nested=0.5, minus_links=0.4, repeats=3, repeat_len=500).write_gfa(p)
+    paths.append(p)
+    rng = random.Random(77)
+    for i in range(4):
+        p = str(tmp_path / f"rand{i}.gfa")
+        open(p, "w").write(random_dag_gfa(rng, 150, iupac=True))
+        paths.append(p)
+    # one long segment with runs of IUPAC letters: restarts in the middle of a window, at the node's end, back to back
+    seq = "".join(rng.choice("ACGT") for _ in range(5000))
+    seq = bytearray(seq.encode())
+    for at in (0, 1, 17, 18, 19, 40, 700, 701, 702, 760, 2000, 4979, 4999):
+        seq[at] = ord("N")
+    p = str(tmp_path / "longn.gfa")
+    open(p, "w").write("S\t1\t" + seq.decode() + "\nS\t2\tACGTNACGTACGTACGTACGTACGATCGATCGACTAGCTAGCATCGACTAGCTACGACTAGCATCGACTAC\nL\t1\t+\t2\t+\t0M\n")
+    paths.append(p)
+    shapes = [(15, 20), (11, 15), (5, 5), (15, 44), (3, 8), (15, 60)]     # (15, 60): deque of 47 > 32, host fallback on both sides
+    total = 0
+    for path in paths:
+        graph = gca.AlignmentGraph(path)
+        for k, w in shapes:
+            monkeypatch.delenv("GC_SEEDER_BUILD", raising=False)
+            dev = gca.MinimizerSeeder(graph, k, w)
+            monkeypatch.setenv("GC_SEEDER_BUILD", "host")
+            host = gca.MinimizerSeeder(graph, k, w)
+            for name in ["kmers", "start", "positions", "maxcount"]:
+                a, b = dev.array(name), host.array(name)
+                assert np.array_equal(a, b), (path, k, w, name, len(a), len(b))
+            total += len(host.array("positions"))
+    assert total > 50000
