@@ -222,6 +222,7 @@ struct ReadGlue {
 	bool failed = false;
 	bool longFailed = false;              // the whole-read pass asserted: no anchors, chain or alignment for this read
 	bool capacityExceeded = false;        // a capacity of this library (not of the reference) was exceeded while processing this read
+	bool capacityExceededLong = false;    // same, raised by the whole-read pass (its own thread; joined into capacityExceeded after the pass)
 	uint64_t slotBegin = 0, fragBegin = 0;
 	uint64_t nAnchors = 0, nPath = 0, nTrace = 0, anchorBegin = 0, pathBegin = 0, traceBegin = 0, seedBegin = 0, chainBegin = 0;
 	StitchedPath stitched;                // chain stitching result
@@ -242,7 +243,7 @@ struct ReadGlue {
 		seeds.clear(); longSeeds.clear(); windows.clear(); longAlns.clear(); longSelected.clear();
 		stitched.nodes.clear(); stitched.firstOffset = stitched.lastOffset = 0; stitched.cells = 0;
 		longBegin = longTraceBegin = longSeedBegin = 0;
-		failed = longFailed = capacityExceeded = false;
+		failed = longFailed = capacityExceeded = capacityExceededLong = false;
 		slotBegin = fragBegin = 0;
 		nAnchors = nPath = nTrace = anchorBegin = pathBegin = traceBegin = seedBegin = chainBegin = 0;
 		stitchedBegin = longSelectedBegin = 0;
@@ -550,13 +551,28 @@ static uint32_t editDistanceUnit(uint32_t k, uint32_t readLen)
 	while (unit < 16 && k >= editDistanceMaxK(unit) && (readLen + 64 * unit - 1) / (64 * unit) > 64) unit *= 2;
 	return unit;
 }
+// Streams of the fragment pipeline / the edit distances (role 0) and of the whole-read rounds (role 1). GC_STREAM_PRIORITY=frag|long raises one
+// side's queue priority (experiment): the whole-read kernel holds 7 of a SIMD's 8 wave slots for milliseconds per wave, so
+// whatever shares the device with it runs on what is left.
+static void createStream(hipStream_t* q, int role)
+{
+	static const int mode = []() { const char* e = getenv("GC_STREAM_PRIORITY"); return !e ? 0 : !strcmp(e, "frag") ? 1 : !strcmp(e, "long") ? 2 : 0; }();
+	int least = 0, greatest = 0;
+	if (mode && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+		const bool high = (mode == 1 && role == 0) || (mode == 2 && role == 1);
+		HIP_CHECK(hipStreamCreateWithPriority(q, hipStreamNonBlocking, high ? greatest : least));
+		return;
+	}
+	HIP_CHECK(hipStreamCreateWithFlags(q, hipStreamNonBlocking));
+}
+
 static void launchEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair* hPairs, int64_t* hOut, uint32_t nPairs, EdPair* dPairs, int64_t* dOut, const EdRead* dReads, const char* dBases,
 	const uint64_t* dEqMasks, const char* dLetters, const uint32_t* dLettersLen, const std::function<uint32_t(uint32_t)>& readLen)
 {
 	if (!nPairs) return;
 	if (!run.ready) {
 		HIP_CHECK(hipEventCreateWithFlags(&run.ready, hipEventDisableTiming));
-		for (auto& q : run.streams) HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+		for (auto& q : run.streams) createStream(&q, 0);
 	}
 	std::vector<uint32_t> cls(nPairs);
 	uint32_t count[5] = { 0, 0, 0, 0, 0 }, begin[6];
@@ -1167,8 +1183,8 @@ int gc_stream_create(gc_stream** out)
 	int rc = guarded([&]() {
 		requireDevice();
 		HIP_CHECK(hipGetDevice(&st->device));
-		HIP_CHECK(hipStreamCreate(&st->stream));
-		HIP_CHECK(hipStreamCreate(&st->longStream));
+		createStream(&st->stream, 0);       // non-blocking: uploads of another batch on the null stream do not serialise with this one
+		createStream(&st->longStream, 0);
 		for (auto& e : st->ev) HIP_CHECK(hipEventCreate(&e));
 		for (auto& e : st->longEv) HIP_CHECK(hipEventCreate(&e));
 		return (int)GC_OK;
@@ -1426,7 +1442,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			for (uint32_t i = 0; i < D.nPairs; i++) {
 				ReadGlue& gl = glue[D.pairRead[i]];
 				gl.longEditDistance = p.hOut[i];
-				if (p.hOut[i] < -1) { gl.longEditDistance = -1; gl.capacityExceeded = true; }   // outside the NW kernel's range: flagged, no distance
+				if (p.hOut[i] < -1) { gl.longEditDistance = -1; gl.capacityExceededLong = true; }   // outside the NW kernel's range: flagged, no distance
 			}
 			D.nPairs = 0;
 		};
@@ -1479,7 +1495,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			if (n < 64ull * nGroups) nGroups = 1;
 			while (st->groupStreams.size() < nGroups) {
 				hipStream_t q = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
-				HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+				createStream(&q, 1);
 				HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
 				st->groupStreams.push_back(q); st->groupEvents.push_back(e0); st->groupEvents.push_back(e1);
 			}
@@ -1621,6 +1637,41 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				return (uint64_t)redo.size();
 			};
 		}
+		// What follows the rounds: fallback reruns, the reference's `cont` rule, selection and the NW distance of the best whole-read alignment.
+		// With one read group it runs on the pass's own thread right after the rounds, beside the tail of the fragment pipeline (which ends
+		// 20-30 ms after the pass on cfg2, starved by it), instead of after the join: 16 ms off the batch's critical path.
+		// It writes the reads' long* fields and capacityExceededLong only; the fragment pipeline does not touch those.
+		const bool longPostInThread = P->long_pass && longGroups == 1;
+		std::function<void()> afterLongPass = [&]() {
+			uint64_t rerun = longFallback();
+			res->counters_long[7] = rerun;   // reads that needed the plain-layout fallback kernel
+			for (int i = 0; i < 6; i++) res->counters_long[i] = hLongSmall[8 + i];   // same units as counters[]
+#ifdef GC_STAMPS
+			{
+				static const char* names[11] = { "slice prologue", "pop+prev lookup", "tile columns", "item store", "edge pushes", "slice epilogue", "bt slice change", "bt item loads", "bt recompute", "bt corner", "bt walk" };
+				double total = 0;
+				for (int i = 0; i < 11; i++) total += (double)hLongSmall[16 + i];
+				for (int i = 0; i < 11; i++) fprintf(stderr, "[gc stamps] %-16s %6.2f%%  %.3e lane-cycles\n", names[i], 100.0 * hLongSmall[16 + i] / (total > 0 ? total : 1), (double)hLongSmall[16 + i]);
+			}
+#endif
+			if (const char* env = getenv("GC_TEST_FAIL_LONG")) {   // test hook shared with the oracle: this read's whole-read pass "asserts"
+				long idx = atol(env);
+				if (idx >= 0 && (uint64_t)idx < n) hLongResults[idx].status = 1;
+			}
+			// A whole-read pass that trips one of the reference's live asserts leaves the read with nothing: align_fn's catch sets
+			// `cont` (src/Aligner.cpp:591), which is declared once per read (:529) and makes the fragment loop skip every anchor
+			// (:702-703); the alignments found before the throw are lost with the exception.
+			for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status == 1) { hLongResults[r].nAlignments = 0; glue[r].longFailed = true; }
+			// capacities of this library, not of the reference: 2 extension scratch (even with the fallback's four-fold room), 3 more alignments than
+			// maxAlignments, 4 the merged-trace cell pool (GC_LONG_CELLS_PER_BASE). The read keeps what was found up to there and is flagged.
+			for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status >= 2 && hLongResults[r].status <= 4) glue[r].capacityExceededLong = true;
+			{
+				std::vector<uint32_t> all(n);
+				for (uint64_t r = 0; r < n; r++) all[r] = (uint32_t)r;
+				decideLongReads(all, 0, st->longStream, [&](uint32_t r) { return hLongResults[r].nAlignments; });
+				finishLongDecision(0);
+			}
+		};
 		// The whole-read pass is the longest leg of the batch: its round loop runs on its own host thread and stream from
 		// here on, while this thread prepares and runs the fragment pipeline.
 		std::vector<std::thread> longThreads;
@@ -1641,9 +1692,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 						if (useToken && longGroups == 1) token.lock();
 						{ double now = nowUs(), seen = longWallBeginUs.load(); while ((seen == 0.0 || now < seen) && !longWallBeginUs.compare_exchange_weak(seen, now)) {} }
 						runLongGroup(g);
+						{ double now = nowUs(), seen = longWallEndUs.load(); while (now > seen && !longWallEndUs.compare_exchange_weak(seen, now)) {} }
+						if (token.owns_lock()) token.unlock();   // the next batch's pass may start; what follows is this batch's own tail
+						if (longPostInThread) afterLongPass();
 					} catch (...) { longErrors[g] = std::current_exception(); }
-					double now = nowUs(), seen = longWallEndUs.load();
-					while (now > seen && !longWallEndUs.compare_exchange_weak(seen, now)) {}
 				});
 		}
 		double tLongStarted = nowUs();
@@ -1948,34 +2000,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			for (auto& e : longErrors) if (e) std::rethrow_exception(e);
 			finishLongGroups();
 			res->kernel_us[5] = longWallEndUs.load() - (longWallBeginUs.load() > 0.0 ? longWallBeginUs.load() : tLongWall0);   // whole-read pass, wall clock from the first group's start to the last group's end
-			uint64_t rerun = longFallback();
-			res->counters_long[7] = rerun;   // reads that needed the plain-layout fallback kernel
-			for (int i = 0; i < 6; i++) res->counters_long[i] = hLongSmall[8 + i];   // same units as counters[]
-#ifdef GC_STAMPS
-			{
-				static const char* names[11] = { "slice prologue", "pop+prev lookup", "tile columns", "item store", "edge pushes", "slice epilogue", "bt slice change", "bt item loads", "bt recompute", "bt corner", "bt walk" };
-				double total = 0;
-				for (int i = 0; i < 11; i++) total += (double)hLongSmall[16 + i];
-				for (int i = 0; i < 11; i++) fprintf(stderr, "[gc stamps] %-16s %6.2f%%  %.3e lane-cycles\n", names[i], 100.0 * hLongSmall[16 + i] / (total > 0 ? total : 1), (double)hLongSmall[16 + i]);
-			}
-#endif
-			if (const char* env = getenv("GC_TEST_FAIL_LONG")) {   // test hook shared with the oracle: this read's whole-read pass "asserts"
-				long idx = atol(env);
-				if (idx >= 0 && (uint64_t)idx < n) hLongResults[idx].status = 1;
-			}
-			// A whole-read pass that trips one of the reference's live asserts leaves the read with nothing: align_fn's catch sets
-			// `cont` (src/Aligner.cpp:591), which is declared once per read (:529) and makes the fragment loop skip every anchor
-			// (:702-703); the alignments found before the throw are lost with the exception.
-			for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status == 1) { hLongResults[r].nAlignments = 0; glue[r].longFailed = true; }
-			// capacities of this library, not of the reference: 2 extension scratch (even with the fallback's four-fold room), 3 more alignments than
-			// maxAlignments, 4 the merged-trace cell pool (GC_LONG_CELLS_PER_BASE). The read keeps what was found up to there and is flagged.
-			for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status >= 2 && hLongResults[r].status <= 4) glue[r].capacityExceeded = true;
-			{
-				std::vector<uint32_t> all(n);
-				for (uint64_t r = 0; r < n; r++) all[r] = (uint32_t)r;
-				decideLongReads(all, 0, st->longStream, [&](uint32_t r) { return hLongResults[r].nAlignments; });
-				finishLongDecision(0);
-			}
+			if (!longPostInThread) afterLongPass();
+			for (uint64_t r = 0; r < n; r++) if (glue[r].capacityExceededLong) glue[r].capacityExceeded = true;
 			if (P->keep_traces) {
 				longCells.resize(hLongSmall[0]);
 				if (hLongSmall[0]) HIP_CHECK(hipMemcpy(longCells.data(), dLongCells, hLongSmall[0] * sizeof(LongCell), hipMemcpyDeviceToHost));

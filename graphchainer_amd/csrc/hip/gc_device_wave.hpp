@@ -26,6 +26,9 @@ namespace gcdev {
 #ifndef GC_EQ_IN_LANES
 #define GC_EQ_IN_LANES 0
 #endif
+#ifndef GC_LEAN_COLUMNS
+#define GC_LEAN_COLUMNS 1
+#endif
 #ifndef WAVE_CAP
 #define WAVE_CAP 28
 #endif
@@ -294,6 +297,61 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 	if (flatRows > 0) r.flatMin = ws.score - popc64(ws.VP & ~flatMask) + popc64(ws.VN & ~flatMask);
 	if (COLUMNS) tables.colSet(0, ws);
 	uint64_t forceEq = prevExists ? ~0ull : ~1ull;
+#if GC_LEAN_COLUMNS && defined(__HIP_DEVICE_COMPILE__)
+	// One extension per wave: every value below is uniform and the loop is the kernel's scalar-issue bottleneck (80 % of its SALU
+	// instructions, 60 per column as the compiler writes the generic loop further down). Same arithmetic with the per-column overhead cut:
+	// the match mask picked by three s_cselect_b64 on the running 2-bit code (instead of eight 32-bit selects), the carries of the row above
+	// and the forced-first-row flag fetched with one s_bfe_u64 each on a running field descriptor, loop-invariant masks folded into the four
+	// match masks, and the bottom row's horizontal deltas parked in lane `pos` of a VGPR (one v_writelane per column, two ballots per tile)
+	// instead of two 64-bit shift-or pairs. Not taken for IUPAC nodes and for the read's last slice (row-limited minimum).
+	if (LANE_TABLES::eqInLanes && !seq.ambiguous && flatRows <= 0) {
+		const uint64_t eA = eq.a & forceEq, eC = eq.c & forceEq, eG = eq.g & forceEq, eT = eq.t & forceEq;
+		const uint64_t forced = forceUntil >= 63 ? ~0ull : ((2ull << forceUntil) - 1);   // columns 1..forceUntil: first row forced
+		uint64_t VP = ws.VP, VN = ws.VN;
+		int32_t score = ws.score;
+		uint32_t minKey = ((uint32_t)r.minScore << 6);   // (score << 6) | column: the smallest key is the first column with the smallest score
+		uint32_t deltas = 0;                             // lane pos: bit 0 = +1, bit 1 = -1 leaving the bottom row of column pos
+		int pos = 1;
+#pragma unroll 1
+		for (int half = 0; half < 2; half++) {
+			uint64_t codes = half ? seq.w1 : (seq.w0 >> 2);
+			const int end = half ? nodeLength : (nodeLength < 32 ? nodeLength : 32);
+#pragma unroll 1
+			for (; pos < end; pos++) {
+				uint64_t lo, hi, Eq, hinP, hinN, f;
+				const uint32_t desc = (uint32_t)pos | (1u << 16);
+				asm("s_bitcmp1_b32 %3, 0\n\ts_cselect_b64 %0, %5, %4\n\ts_cselect_b64 %1, %7, %6\n\ts_bitcmp1_b32 %3, 1\n\ts_cselect_b64 %2, %1, %0"
+					: "=&s"(lo), "=&s"(hi), "=&s"(Eq) : "s"((uint32_t)codes), "s"(eA), "s"(eC), "s"(eG), "s"(eT) : "scc");
+				asm("s_bfe_u64 %0, %1, %2" : "=s"(hinP) : "s"(prevHP), "s"(desc) : "scc");
+				asm("s_bfe_u64 %0, %1, %2" : "=s"(hinN) : "s"(prevHN), "s"(desc) : "scc");
+				asm("s_bfe_u64 %0, %1, %2" : "=s"(f) : "s"(forced), "s"(desc) : "scc");
+				codes >>= 2;
+				const uint64_t Xv = Eq | VN;
+				Eq |= hinN;
+				const uint64_t Xh = (((Eq & VP) + VP) ^ VP) | Eq;
+				const uint64_t Ph = VN | ~(Xh | VP);
+				const uint64_t Mh = VP & Xh;
+				const uint32_t outP = (uint32_t)(Ph >> 63), outN = (uint32_t)(Mh >> 63);
+				const uint64_t sPh = (Ph << 1) | hinP, sMh = (Mh << 1) | hinN;
+				VP = (sMh | ~(Xv | sPh)) & ~f;
+				VN = (sPh & Xv) | f;
+				score += (int32_t)outP - (int32_t)outN;
+				const uint32_t key = ((uint32_t)score << 6) | (uint32_t)pos;
+				minKey = key < minKey ? key : minKey;
+				uint32_t both;   // (outN << 1) + outP, made by the scalar unit: v_writelane takes its data from an SGPR
+				asm("s_lshl1_add_u32 %0, %1, %2" : "=s"(both) : "s"(outN), "s"(outP) : "scc");
+				asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(deltas) : "s"(both), "s"(pos) : "m0");   // (two SGPR operands exceed gfx9's constant bus; M0 as lane select does not count)
+				if (COLUMNS) tables.colSet((uint32_t)pos, WS { VP, VN, score });
+			}
+		}
+		r.minScore = (int32_t)(minKey >> 6);
+		r.minOffset = minKey & 63u;
+		out.HP = __ballot((deltas & 1u) != 0);
+		out.HN = __ballot((deltas & 2u) != 0);
+		out.eVP = VP; out.eVN = VN; out.eScore = score;
+		return r;
+	}
+#endif
 	uint64_t HP = 0, HN = 0;
 	for (int pos = 1; pos < nodeLength; pos++) {
 		uint64_t Eq;

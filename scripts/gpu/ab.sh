@@ -1,0 +1,22 @@
+#!/bin/bash
+# A/B on one box: bench.py with the production library and with named variants (graphchainer_amd/libgraphchainer_amd_<name>.so), interleaved.
+# usage: bash scripts/gpu/ab.sh <outdir-tag> <rounds> <variant> [<variant> ...]      ("prod" = the production library)
+tag=$1; rounds=$2; shift 2
+out=$GRAFT_REPO_ROOT/gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+for r in $(seq 1 $rounds); do
+  for v in "$@"; do
+    lib=$GRAFT_REPO_ROOT/graphchainer_amd/libgraphchainer_amd_$v.so
+    if [ "$v" = prod ]; then lib=$GRAFT_REPO_ROOT/graphchainer_amd/libgraphchainer_amd.so; fi
+    GC_LIBRARY=$lib timeout 600 python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 5 --warmup 2 $AB_BENCH_ARGS > $out/${v}_$r.json 2> $out/${v}_$r.err
+    python3 - $out/${v}_$r.json $v <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[2], d["value"], d["ms_per_step"], d["stage_ms"]["k_long_extend_all_rounds"], d["stage_ms"]["whole_read_pass_wall"])
+except Exception as e:
+    print(sys.argv[2], "failed", e)
+PY
+  done
+done
