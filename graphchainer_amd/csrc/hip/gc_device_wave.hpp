@@ -29,6 +29,9 @@ namespace gcdev {
 #ifndef GC_LEAN_COLUMNS
 #define GC_LEAN_COLUMNS 1
 #endif
+#ifndef GC_LEAN_WALK
+#define GC_LEAN_WALK 1
+#endif
 #ifndef WAVE_CAP
 #define WAVE_CAP 28
 #endif
@@ -60,6 +63,15 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;   // keeps LDS acces
 #else
 #define GC_READLANE(reg, lane) ((int)(reg))
 #endif
+// A uniform 64-bit value as an SGPR pair (inline asm with "s" operands must not be handed a VGPR; free when the value already is scalar)
+__device__ __forceinline__ uint64_t gcUniform64(uint64_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32);
+#else
+	return x;
+#endif
+}
 template <bool REGCOLS>
 struct LaneLdsT {   // one lane's view
 	lds_u32* l;                  // LDS words of the team, [word][lanes]
@@ -155,6 +167,42 @@ struct LaneLdsT {   // one lane's view
 		const uint64_t v = l == 0 ? a : l == 1 ? c : l == 2 ? g : t;
 		eqLo = (uint32_t)v; eqHi = (uint32_t)(v >> 32);
 	}   // REGCOLS: node ids of the items of the backtrace's current / previous slice, item i in lane i
+	// REGCOLS backtrace: per column c >= 1 of the recomputed tile (lane c), for all 64 rows at once: "the diagonal predecessor fits" and
+	// "the left predecessor fits" (see setWalkMasks); valid only after a recompute that went through the lean column loop
+	mutable uint32_t wm[4] = { 0, 0, 0, 0 };
+	mutable bool walkMasks = false;
+	// The walk inside a tile asks three things per cell (src/GraphAlignerBitvectorCommon.h:555-708): is the cell above one less (the column's VP
+	// bit), is the diagonal cell equal / one less depending on the match bit, is the left cell one less. Cell values of neighbouring columns
+	// differ by the horizontal deltas Ph / Mh of the Myers step that produced the column from its left neighbour - an identity of the step
+	// itself, for any input column: value(r,c) - value(r,c-1) = Ph_r - Mh_r, hence value(r,c) - value(r-1,c-1) = (Ph_r - Mh_r) + (VP_r - VN_r of
+	// column c-1) for r >= 1. Both columns are in the lanes (column c in lane c), so one vector pass redoes the horizontal part of every
+	// column's step at once (lane c reads column c-1 from its neighbour) and leaves two row masks per column; the scalar walk then tests bits.
+#if defined(__HIP_DEVICE_COMPILE__)
+	__device__ __forceinline__ void setWalkMasks(uint64_t codes0, uint64_t codes1, const Eq4& eq, uint64_t forceEq, uint64_t prevHN) const
+	{
+		const uint32_t c = threadIdx.x;
+		const uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cr[0], 0x138, 0xf, 0xf, false), p1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cr[1], 0x138, 0xf, 0xf, false);
+		const uint32_t n0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cr[2], 0x138, 0xf, 0xf, false), n1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cr[3], 0x138, 0xf, 0xf, false);
+		const uint64_t pVP = (uint64_t)p0 | ((uint64_t)p1 << 32), pVN = (uint64_t)n0 | ((uint64_t)n1 << 32);   // column c - 1 (wave_shr:1)
+		const uint32_t code = (uint32_t)((c < 32 ? codes0 : codes1) >> ((c & 31u) * 2)) & 3u;
+		const uint64_t rawEq = code == 0 ? eq.a : code == 1 ? eq.c : code == 2 ? eq.g : eq.t;
+		const uint64_t Eq = (rawEq & forceEq) | ((prevHN >> c) & 1ull);
+		const uint64_t Xh = (((Eq & pVP) + pVP) ^ pVP) | Eq;
+		const uint64_t Ph = pVN | ~(Xh | pVP), Mh = pVP & Xh;
+		const uint64_t flat = ~(Ph | Mh), level = ~(pVP | pVN);
+		const uint64_t same = (flat & level) | (Ph & pVN) | (Mh & pVP);   // value(r,c) == value(r-1,c-1)
+		const uint64_t more = (Ph & level) | (flat & pVP);                // value(r,c) == value(r-1,c-1) + 1
+		const uint64_t diag = (same & rawEq) | (more & ~rawEq);
+		wm[0] = (uint32_t)diag; wm[1] = (uint32_t)(diag >> 32); wm[2] = (uint32_t)Ph; wm[3] = (uint32_t)(Ph >> 32);
+		walkMasks = true;
+	}
+	__device__ __forceinline__ void loadWalkMasks(uint32_t c, uint64_t& up, uint64_t& diag, uint64_t& left) const
+	{
+		up = (uint64_t)(uint32_t)GC_READLANE(cr[0], c) | ((uint64_t)(uint32_t)GC_READLANE(cr[1], c) << 32);
+		diag = (uint64_t)(uint32_t)GC_READLANE(wm[0], c) | ((uint64_t)(uint32_t)GC_READLANE(wm[1], c) << 32);
+		left = (uint64_t)(uint32_t)GC_READLANE(wm[2], c) | ((uint64_t)(uint32_t)GC_READLANE(wm[3], c) << 32);
+	}
+#endif
 	__device__ __forceinline__ void colSet(uint32_t c, const WS& x) const
 	{
 		if (REGCOLS) {
@@ -305,8 +353,9 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 	// match masks, and the bottom row's horizontal deltas parked in lane `pos` of a VGPR (one v_writelane per column, two ballots per tile)
 	// instead of two 64-bit shift-or pairs. Not taken for IUPAC nodes and for the read's last slice (row-limited minimum).
 	if (LANE_TABLES::eqInLanes && !seq.ambiguous && flatRows <= 0) {
-		const uint64_t eA = eq.a & forceEq, eC = eq.c & forceEq, eG = eq.g & forceEq, eT = eq.t & forceEq;
-		const uint64_t forced = forceUntil >= 63 ? ~0ull : ((2ull << forceUntil) - 1);   // columns 1..forceUntil: first row forced
+		const uint64_t eA = gcUniform64(eq.a & forceEq), eC = gcUniform64(eq.c & forceEq), eG = gcUniform64(eq.g & forceEq), eT = gcUniform64(eq.t & forceEq);
+		const uint64_t forced = gcUniform64(forceUntil >= 63 ? ~0ull : ((2ull << forceUntil) - 1));   // columns 1..forceUntil: first row forced
+		prevHP = gcUniform64(prevHP); prevHN = gcUniform64(prevHN);
 		uint64_t VP = ws.VP, VN = ws.VN;
 		int32_t score = ws.score;
 		uint32_t minKey = ((uint32_t)r.minScore << 6);   // (score << 6) | column: the smallest key is the first column with the smallest score
@@ -315,11 +364,13 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 #pragma unroll 1
 		for (int half = 0; half < 2; half++) {
 			uint64_t codes = half ? seq.w1 : (seq.w0 >> 2);
+			codes = gcUniform64(codes);
 			const int end = half ? nodeLength : (nodeLength < 32 ? nodeLength : 32);
 #pragma unroll 1
 			for (; pos < end; pos++) {
 				uint64_t lo, hi, Eq, hinP, hinN, f;
-				const uint32_t desc = (uint32_t)pos | (1u << 16);
+				const uint32_t posS = (uint32_t)__builtin_amdgcn_readfirstlane(pos);
+				const uint32_t desc = posS | (1u << 16);
 				asm("s_bitcmp1_b32 %3, 0\n\ts_cselect_b64 %0, %5, %4\n\ts_cselect_b64 %1, %7, %6\n\ts_bitcmp1_b32 %3, 1\n\ts_cselect_b64 %2, %1, %0"
 					: "=&s"(lo), "=&s"(hi), "=&s"(Eq) : "s"((uint32_t)codes), "s"(eA), "s"(eC), "s"(eG), "s"(eT) : "scc");
 				asm("s_bfe_u64 %0, %1, %2" : "=s"(hinP) : "s"(prevHP), "s"(desc) : "scc");
@@ -338,10 +389,20 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 				score += (int32_t)outP - (int32_t)outN;
 				const uint32_t key = ((uint32_t)score << 6) | (uint32_t)pos;
 				minKey = key < minKey ? key : minKey;
-				uint32_t both;   // (outN << 1) + outP, made by the scalar unit: v_writelane takes its data from an SGPR
-				asm("s_lshl1_add_u32 %0, %1, %2" : "=s"(both) : "s"(outN), "s"(outP) : "scc");
-				asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(deltas) : "s"(both), "s"(pos) : "m0");   // (two SGPR operands exceed gfx9's constant bus; M0 as lane select does not count)
-				if (COLUMNS) tables.colSet((uint32_t)pos, WS { VP, VN, score });
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+				if (!COLUMNS) {
+					uint32_t both;   // (outN << 1) + outP, made by the scalar unit: v_writelane takes its data from an SGPR
+					asm("s_lshl1_add_u32 %0, %1, %2" : "=s"(both) : "s"(outN), "s"(outP) : "scc");
+					// (two SGPR operands exceed gfx9's constant bus; M0 as lane select does not count)
+					asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(deltas) : "s"(both), "s"(posS) : "m0");
+				} else {
+					// backtrace recompute: the column itself goes to lane pos of the five column registers
+					asm("s_mov_b32 m0, %5\n\tv_writelane_b32 %0, %6, m0\n\tv_writelane_b32 %1, %7, m0\n\tv_writelane_b32 %2, %8, m0\n\tv_writelane_b32 %3, %9, m0\n\tv_writelane_b32 %4, %10, m0"
+						: "+v"(tables.cr[0]), "+v"(tables.cr[1]), "+v"(tables.cr[2]), "+v"(tables.cr[3]), "+v"(tables.cr[4])
+						: "s"(posS), "s"((uint32_t)VP), "s"((uint32_t)(VP >> 32)), "s"((uint32_t)VN), "s"((uint32_t)(VN >> 32)), "s"((uint32_t)score) : "m0");
+				}
+#pragma clang diagnostic pop
 			}
 		}
 		r.minScore = (int32_t)(minKey >> 6);
@@ -349,8 +410,12 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 		out.HP = __ballot((deltas & 1u) != 0);
 		out.HN = __ballot((deltas & 2u) != 0);
 		out.eVP = VP; out.eVN = VN; out.eScore = score;
+#if GC_LEAN_WALK
+		if (COLUMNS) tables.setWalkMasks(seq.w0, seq.w1, eq, forceEq, prevHN);
+#endif
 		return r;
 	}
+	if (COLUMNS && LANE_TABLES::eqInLanes) tables.walkMasks = false;
 #endif
 	uint64_t HP = 0, HN = 0;
 	for (int pos = 1; pos < nodeLength; pos++) {
@@ -776,6 +841,66 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 			here = nxt;
 			continue;
 		}
+#if GC_LEAN_WALK && defined(__HIP_DEVICE_COMPILE__)
+		if (REGCOLS && L.walkMasks) {
+			// (row masks of the tile's columns are in the lanes, see setWalkMasks: the walk only tests bits)
+			uint32_t hori = here.offset;
+			int vert = row;
+			uint64_t up, diag, left;
+			L.loadWalkMasks(hori, up, diag, left);
+			while (hori > 0 && vert > 0) {
+				const uint64_t bit = 1ull << vert;
+				if (up & bit) vert--;                                        // vertical == scoreHere - 1
+				else {
+					if (diag & bit) vert--;                                  // diagonal == scoreHere - (match ? 0 : 1)
+					else if (!(left & bit)) return EXT_ASSERT;               // else the left cell must be one less
+					hori--;
+					if (hori > 0) L.loadWalkMasks(hori, up, diag, left);
+				}
+				if (!pushTraceW(Cell { curNode, hori, cs.j + vert }, false)) return status;
+			}
+			here = Cell { curNode, hori, cs.j + vert };
+		} else if (REGCOLS) {
+			// Tiles recomputed by the generic column loop (IUPAC nodes): the same three tests on cell values, all rows of a column pair at once.
+			// One extension per wave: the walk inside a tile costs scalar instructions per cell (the kernel's bound), and its three tests compare
+			// cell values of two neighbouring columns. The 64 lanes hold one row each, so for a column pair all rows are compared at once: lane r
+			// computes value(r, hori) and value(r, hori - 1) from the stored columns (two masked popcounts), fetches value(r - 1, hori - 1) from its
+			// neighbour lane (wave_shr), and four ballots give, for every row, "a step up is taken" (the column's VP itself), "the diagonal
+			// predecessor fits with / without a match", "the left predecessor fits". The scalar side then only tests bits: 90 -> about 25
+			// scalar instructions per cell. Same comparisons on the same values as the loop below (src/GraphAlignerBitvectorCommon.h:555-708).
+			uint32_t hori = here.offset;
+			int vert = row;
+			const NodeSeq nseq = loadNodeSeq(g, curNode);
+			const uint32_t laneRow = threadIdx.x;
+			const uint64_t above = ~1ull << laneRow;   // rows below this lane's row in the word (bits > r)
+			auto rowValues = [&](const WS& c) __attribute__((always_inline)) -> int32_t { return c.score - popc64(c.VP & above) + popc64(c.VN & above); };
+			WS ch = L.col(hori);
+			int32_t av = rowValues(ch);
+			while (hori > 0 && vert > 0) {
+				const WS cl = L.col(hori - 1);
+				const int32_t bv = rowValues(cl);
+				const int32_t bUp = __builtin_amdgcn_update_dpp(0, bv, 0x138, 0xf, 0xf, false);   // wave_shr:1: value(r - 1, hori - 1)
+				const uint64_t diagSame = __ballot(bUp == av), diagLess = __ballot(bUp == av - 1), leftFits = __ballot(bv == av - 1);
+				uint64_t eqColumn = eqOfColumn(eq, nseq, (int)hori);
+				eqColumn = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)eqColumn) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(eqColumn >> 32)) << 32);   // (uniform; keeps the tests below on the scalar unit)
+				const uint64_t diagFits = (diagSame & eqColumn) | (diagLess & ~eqColumn);
+				bool moved = false;
+				do {
+					const uint64_t bit = 1ull << vert;
+					if (ch.VP & bit) vert--;                                 // vertical == scoreHere - 1
+					else if (diagFits & bit) { hori--; vert--; moved = true; }   // diagonal == scoreHere - (match ? 0 : 1)
+					else {
+						if (!(leftFits & bit)) return EXT_ASSERT;
+						hori--;
+						moved = true;
+					}
+					if (!pushTraceW(Cell { curNode, hori, cs.j + vert }, false)) return status;
+				} while (!moved && vert > 0);
+				if (moved) { ch = cl; av = bv; }
+			}
+			here = Cell { curNode, hori, cs.j + vert };
+		} else
+#endif
 		{
 			uint32_t hori = here.offset;
 			int vert = row;
