@@ -75,22 +75,42 @@ def cpu_model():
     return "unknown"
 
 
+def usable_cpus():
+    """CPUs this process can actually use: the affinity mask, cut to the cgroup's CPU bandwidth quota when there is one (a container may see
+    all 256 hardware threads of the box and be allowed 16 CPUs' worth of time: cpu.max = "1600000 100000")."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline_leg(args, gfa, reads, long_pass):
     """The CPU restatement (oracle/) timed on the host cores of this box, BEFORE this process touches the GPU: one thread on a
-    bounded sample, then one worker per core over a shared read queue (the reference's -t model, src/Aligner.cpp:1267-1270)."""
+    bounded sample, then one worker per usable CPU (affinity mask and cgroup quota) over a shared read queue (the reference's -t model,
+    src/Aligner.cpp:1267-1270)."""
     from oracle import Oracle   # the CPU baseline leg is the one place bench.py may touch the oracle
-    threads = args.cpu_threads or (os.cpu_count() or 1)
+    threads = args.cpu_threads or usable_cpus()
     ora = Oracle(gfa, long_pass=long_pass, split_gap=args.split_gap)
     n1 = min(args.cpu_sample, len(reads))
     wall1, stage1 = ora.align_timed(reads[:n1], 1)
-    n_all = min(len(reads), max(n1, 40 * threads))
+    n_all = min(len(reads), max(n1, 250 * threads))   # ~10-15 s at the ~20 reads/s a core does
     wall_all, _ = ora.align_timed(reads[:n_all], threads)
     ora.close()
     stage_names = ["seeding", "whole_read_pass", "fragment_extension+anchors", "chaining", "stitching+edlib"]
     total = float(stage1.sum()) or 1.0
     return {"value": round(n_all / wall_all, 2), "unit": "reads/s", "cores": threads, "kind": "port",
             "sample": f"first {n_all} reads of the same workload, same stages, {threads} worker threads over a shared read queue, {wall_all:.1f} s; one thread: first {n1} reads, {wall1:.1f} s",
-            "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+            "cpu_model": cpu_model(), "host_hardware_threads": os.cpu_count(), "usable_cpus": usable_cpus(),
             "single_thread_reads_per_s": round(n1 / wall1, 2),
             "single_thread_stage_share": {k: round(float(v) / total, 3) for k, v in zip(stage_names, stage1)}}
 
@@ -127,7 +147,7 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     if world > 1 and "GC_HOST_THREADS" not in os.environ:
         # ranks share the host: split its cores between their worker pools (read by the library when it first loads)
-        os.environ["GC_HOST_THREADS"] = str(max(8, min(96, (os.cpu_count() or 8) // world)))
+        os.environ["GC_HOST_THREADS"] = str(max(4, min(96, 2 * usable_cpus() // world)))
     import graphchainer_amd as gca
     from graphchainer_amd.workqueue import ReadQueue, length_sorted_batches, run_queue
 

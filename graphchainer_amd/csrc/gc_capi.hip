@@ -71,6 +71,29 @@ std::mutex g_longPassToken[16];
 double nowUs() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Persistent worker pool for the per-read host glue (threads are created once per process).
+// CPUs' worth of bandwidth the cgroup grants this process (cgroup v2 cpu.max, v1 cfs quota / period); 0 = no limit known
+static double cpuQuota()
+{
+	auto readNumbers = [](const char* path, double& a, double& b) -> int {
+		FILE* f = fopen(path, "r");
+		if (!f) return 0;
+		char first[64] = { 0 };
+		int got = fscanf(f, "%63s %lf", first, &b);
+		fclose(f);
+		if (got < 1 || !strcmp(first, "max")) return -1;
+		a = atof(first);
+		return got;
+	};
+	double quota = 0, period = 0;
+	int got = readNumbers("/sys/fs/cgroup/cpu.max", quota, period);
+	if (got == 2 && quota > 0 && period > 0) return quota / period;
+	if (got == 0) {
+		double q = 0, p = 0, unused = 0;
+		if (readNumbers("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", q, unused) >= 1 && q > 0 && readNumbers("/sys/fs/cgroup/cpu/cpu.cfs_period_us", p, unused) >= 1 && p > 0) return q / p;
+	}
+	return 0;
+}
+
 class WorkerPool {
 public:
 	static WorkerPool& instance() { static WorkerPool p; return p; }
@@ -100,6 +123,11 @@ private:
 	{
 		size_t n = std::max(1u, std::thread::hardware_concurrency());
 		n = std::min<size_t>(n, 96);   // the glue is memory-bound; more threads stop helping
+		// A container with a CPU bandwidth quota (cgroup cpu.max) shows all of the machine's threads but is throttled for the rest of the
+		// 100 ms period once a burst of workers has spent the quota - measured on a 16-CPU quota: 96 workers finish a stage in 10 ms and the
+		// whole process (the whole-read pass's round loop included) then stalls for 50-60 ms. Twice the quota keeps the bursts inside it.
+		const double quota = cpuQuota();
+		if (quota > 0) n = std::min<size_t>(n, std::max<size_t>(4, (size_t)(2 * quota + 0.5)));
 		if (const char* env = getenv("GC_HOST_THREADS")) n = (size_t)std::max(1, atoi(env));
 		for (size_t t = 1; t < n; t++) workers.emplace_back([this, t]() { loop(t); });
 	}
@@ -268,8 +296,8 @@ struct gc_stream {
 	int device = 0;             // the device the stream was created on; gc_align_batch selects it for the calling thread
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[12] {};
-	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, work, results, scratch, scratchRetry, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
-	PinnedBuffer hMatches, hWork, hFrags, hFragSeeds, hJobs, hAnchors, hFragStatus, hFragExtended, hChainOut, hChainLen, hChainScore, hChainStatus, hPathPool, hSmall;
+	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, readSeeds, fragFirstSeed, work, results, scratch, scratchRetry, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
+	PinnedBuffer hMatches, hReadSeeds, hFragFirstSeed, hFrags, hJobs, hAnchors, hFragStatus, hFragExtended, hChainOut, hChainLen, hChainScore, hChainStatus, hPathPool, hSmall;
 	// whole-read pass: runs on its own stream, concurrently with the fragment kernels
 	hipStream_t longStream = nullptr;
 	hipEvent_t longEv[2] {};
@@ -1704,6 +1732,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			if (gl.seeds.empty()) return;
 			gc::fragmentWindows(gl.seeds, R->offsets[r + 1] - R->offsets[r], (size_t)P->split_len, (size_t)P->split_gap, gl.windows);
 		});
+		double tWindows = nowUs();
 		uint64_t nSlots = 0, nFrags = 0, nSeedsTotal = 0;
 		for (uint64_t r = 0; r < n; r++) {
 			glue[r].slotBegin = nSlots;
@@ -1714,14 +1743,18 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			nSeedsTotal += glue[r].seeds.size();
 		}
 		if (2 * nSlots >= 0xffffffffull) throw std::runtime_error("batch too large: more than 2^31 fragment seeds; split the batch");
+		// The per-slot records (seed in fragment order + its two extensions) are expanded on the device (k_build_fragment_work) from what the
+		// host decides: the read's seeds in the reference's order after its sort by position, and the windows.
 		Fragment* frags = st->hFrags.reserve<Fragment>(nFrags);
-		FragSeed* fragSeeds = st->hFragSeeds.reserve<FragSeed>(nSlots);
-		ExtItem* work = st->hWork.reserve<ExtItem>(2 * nSlots);
+		uint32_t* fragFirstSeed = st->hFragFirstSeed.reserve<uint32_t>(nFrags);
+		FragSeed* readSeeds = st->hReadSeeds.reserve<FragSeed>(nSeedsTotal);
 		ReadChainJob* jobs = st->hJobs.reserve<ReadChainJob>(n);
 		std::vector<uint64_t> traceBudgets(pool.size(), 0);
+		double tReserved = nowUs();
 		pool.run(n, [&](size_t r, size_t worker) {
 			const ReadGlue& gl = glue[r];
 			size_t len = R->offsets[r + 1] - R->offsets[r];
+			for (size_t k = 0; k < gl.seeds.size(); k++) readSeeds[gl.seedBegin + k] = FragSeed { gl.seeds[k].node, gl.seeds[k].offset, gl.seeds[k].seqPos, 0 };
 			uint64_t slot = gl.slotBegin;
 			uint64_t budget = 0;
 			for (size_t f = 0; f < gl.windows.size(); f++) {
@@ -1730,24 +1763,11 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				fr.read = (uint32_t)r;
 				fr.l = w.l;
 				fr.seedBegin = (uint32_t)slot;
+				fragFirstSeed[gl.fragBegin + f] = (uint32_t)(gl.seedBegin + w.sl);
 				for (uint32_t k = w.sl; k < w.sr; k++, slot++) {
-					const gc::SeedRec& s = gl.seeds[k];
-					fragSeeds[slot] = FragSeed { s.node, s.offset, s.seqPos, 0 };
-					uint32_t p = s.seqPos - w.l;
-					// backward: revcomp(fragment[0..p)) from the reverse-strand twin of the seed base (src/GraphAligner.h:499-505)
-					ExtItem& b = work[2 * slot];
-					b.seqOff = R->totalBases + R->offsets[r] + (len - w.l - p);
-					b.seqLen = p;
-					G->twinOf(s.node, s.offset, b.node, b.offset);
-					b.pad = 0;
-					// forward: fragment(p+1 ..] from the seed base (:506-511)
-					ExtItem& fw = work[2 * slot + 1];
-					fw.seqOff = R->offsets[r] + w.l + p + 1;
-					fw.seqLen = (uint32_t)P->split_len - 1 - p;
-					fw.node = s.node;
-					fw.offset = s.offset;
-					fw.pad = 0;
-					budget += (b.seqLen ? b.seqLen + 24 : 0) + (fw.seqLen ? fw.seqLen + 24 : 0);
+					// trace cells the two extensions of this seed may need: backward p rows, forward split_len - 1 - p (src/GraphAligner.h:499-511)
+					const uint32_t p = gl.seeds[k].seqPos - w.l, q = (uint32_t)P->split_len - 1 - p;
+					budget += (p ? p + 24 : 0) + (q ? q + 24 : 0);
 				}
 				fr.seedEnd = (uint32_t)slot;
 			}
@@ -1769,7 +1789,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		caps.capTable = std::max(1u, G->maxMpcWidth);
 		caps.capBack = (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)caps.capAnchors * ((uint64_t)G->maxBackPerNode + G->maxPathsPerNode));   // threshold lists: backward links + paths of the start node
 		res->host_us[0] = nowUs() - tGlue;
-		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] seed expand+order %.1f ms, whole-read setup %.1f ms, fragment windows+arrays %.1f ms\n", (tOrdered - tGlue) / 1e3, (tLongStarted - tOrdered) / 1e3, (nowUs() - tLongStarted) / 1e3);
+		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] seed expand+order %.1f ms, whole-read setup %.1f ms, fragment windows+arrays %.1f ms (windows %.1f, sizes+buffers %.1f, arrays %.1f)\n", (tOrdered - tGlue) / 1e3, (tLongStarted - tOrdered) / 1e3, (nowUs() - tLongStarted) / 1e3,
+			(tWindows - tLongStarted) / 1e3, (tReserved - tWindows) / 1e3, (nowUs() - tReserved) / 1e3);
 
 		// ---------------- K3 / K3b / K4
 		double tDev = nowUs();
@@ -1803,9 +1824,12 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		uint32_t* dChainStatus = st->chainStatus.reserve<uint32_t>(n);
 		uint32_t chainBlocks = std::max(chainGridBlocks((uint32_t)n), chainScratchBlocks((uint32_t)n));   // both launches index the scratch by block
 		uint8_t* dChainScratch = st->chainScratch.reserve<uint8_t>((uint64_t)std::max(1u, chainBlocks) * chainScratchBytes(caps));
-		if (nWork) HIP_CHECK(hipMemcpyAsync(dWork, work, (size_t)nWork * sizeof(ExtItem), hipMemcpyHostToDevice, stream));
+		FragSeed* dReadSeeds = st->readSeeds.reserve<FragSeed>(nSeedsTotal);
+		uint32_t* dFragFirstSeed = st->fragFirstSeed.reserve<uint32_t>(nFrags);
 		if (nFrags) HIP_CHECK(hipMemcpyAsync(dFrags, frags, nFrags * sizeof(Fragment), hipMemcpyHostToDevice, stream));
-		if (nSlots) HIP_CHECK(hipMemcpyAsync(dFragSeeds, fragSeeds, nSlots * sizeof(FragSeed), hipMemcpyHostToDevice, stream));
+		if (nFrags) HIP_CHECK(hipMemcpyAsync(dFragFirstSeed, fragFirstSeed, nFrags * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+		if (nSeedsTotal) HIP_CHECK(hipMemcpyAsync(dReadSeeds, readSeeds, nSeedsTotal * sizeof(FragSeed), hipMemcpyHostToDevice, stream));
+		launchBuildFragmentWork(stream, G->dev, dFrags, dFragFirstSeed, (uint32_t)nFrags, dReadSeeds, R->devOffsets, R->totalBases, (uint32_t)P->split_len, dFragSeeds, dWork);
 		if (n) HIP_CHECK(hipMemcpyAsync(dJobs, jobs, n * sizeof(ReadChainJob), hipMemcpyHostToDevice, stream));
 		mark();   // 2
 		launchExtend(stream, G->dev, G->devTables, G->devIupac, cfg, dWork, nWork, R->devBases, dResults, dScratch, slabBytes, dTrace, dCursors + 1, traceBudget, dCounters);
@@ -2100,6 +2124,11 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		double tAsm = nowUs();
 		std::vector<uint8_t> failedAssertion(n, 0);
 		std::vector<uint64_t> seedsExtended(n, 0), seedsExtendedLong(n, 0);
+		// read position of the seed in a fragment-pass slot (the device holds the per-slot records; the host keeps seeds and windows)
+		auto slotSeqPos = [&](uint64_t r, uint64_t slot, uint64_t F) -> uint32_t {
+			const ReadGlue& gl = glue[r];
+			return gl.seeds[gl.windows[F - gl.fragBegin].sl + (slot - frags[F].seedBegin)].seqPos;
+		};
 		auto forEachAnchor = [&](uint64_t r, auto&& visit) {   // visit(slotIndex, fragmentIndex) for every anchor the reference would keep
 			const ReadGlue& gl = glue[r];
 			if (gl.longFailed) return;   // `cont` was already set by the whole-read pass (src/Aligner.cpp:529,591,702)
@@ -2134,13 +2163,13 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				seedsExtendedLong[r] = hLongResults[r].seedsExtended;
 				if (hLongResults[r].status == 1) failedAssertion[r] = 1;
 			}
-			forEachAnchor(r, [&](uint64_t slot, uint64_t) {
+			forEachAnchor(r, [&](uint64_t slot, uint64_t F) {
 				gl.nAnchors++;
 				gl.nPath += anchors[slot].pathLen;
 				if (P->keep_traces) {
 					const ExtResult& eb = extResults[2 * slot];
 					const ExtResult& ef = extResults[2 * slot + 1];
-					uint32_t p = fragSeeds[slot].seqPos - (anchors[slot].x);
+					uint32_t p = slotSeqPos(r, slot, F) - (anchors[slot].x);
 					bool hasB = p > 0 && eb.status == EXT_OK, hasF = p < (uint32_t)P->split_len - 1 && ef.status == EXT_OK;
 					gl.nTrace += (hasB ? (hasF ? eb.traceLen - 1 : eb.traceLen) : 0) + (hasF ? ef.traceLen : 0);
 				}
@@ -2261,7 +2290,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					res->anchor_trace_off[a] = traceAt;
 					const ExtResult& eb = extResults[2 * slot];
 					const ExtResult& ef = extResults[2 * slot + 1];
-					uint32_t p = fragSeeds[slot].seqPos - frags[F].l;
+					uint32_t p = slotSeqPos(r, slot, F) - frags[F].l;
 					bool hasB = p > 0 && eb.status == EXT_OK, hasF = p < (uint32_t)P->split_len - 1 && ef.status == EXT_OK;
 					if (hasB) {
 						uint32_t use = hasF ? eb.traceLen - 1 : eb.traceLen;

@@ -32,6 +32,9 @@ namespace gcdev {
 #ifndef GC_LEAN_WALK
 #define GC_LEAN_WALK 1
 #endif
+#ifndef GC_LEAN_PUSH
+#define GC_LEAN_PUSH 1
+#endif
 #ifndef WAVE_CAP
 #define WAVE_CAP 28
 #endif
@@ -624,6 +627,25 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 		if (REGCOLS && count && threadIdx.x < count) wsx.base[(wsx.traceBase(nTrace - count, which)) * wsx.lanes + wsx.lane + threadIdx.x] = (unsigned long long)tbLo | ((unsigned long long)tbHi << 32);
 	};
 	auto pushTraceW = [&](Cell c, bool sw) __attribute__((always_inline)) -> bool {
+#if GC_LEAN_WALK && GC_LEAN_PUSH && defined(__HIP_DEVICE_COMPILE__)
+		if (REGCOLS) {
+			// cell into lane (nTrace mod 64) of the register pair; the room check happens once per 64 cells, at the flush (a trace that
+			// outgrows its buffer is noticed at the block's end or at the final flush instead of at the cell - same verdict, EXT_OVERFLOW)
+			const unsigned long long cell = packCell(c, sw);
+			const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nTrace & 63u));
+			const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cell), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cell >> 32));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+			asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0" : "+v"(tbLo), "+v"(tbHi) : "s"(slot), "s"(lo), "s"(hi) : "m0");
+#pragma clang diagnostic pop
+			nTrace++;
+			if ((nTrace & 63u) == 0) {
+				if (nTrace > wsx.maxTrace) { status = EXT_OVERFLOW; return false; }
+				wsx.base[(wsx.traceBase(nTrace - 64, which)) * wsx.lanes + wsx.lane + threadIdx.x] = (unsigned long long)tbLo | ((unsigned long long)tbHi << 32);
+			}
+			return true;
+		}
+#endif
 		if (nTrace >= wsx.maxTrace) { status = EXT_OVERFLOW; return false; }
 		const unsigned long long cell = packCell(c, sw);
 		if (REGCOLS) {
@@ -942,6 +964,7 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 			if (!pushTraceW(Cell { here.node, off, -1 }, false)) return status;
 		}
 	}
+	if (REGCOLS && nTrace > wsx.maxTrace) return EXT_OVERFLOW;
 	flushTrace(nTrace & 63u);
 	cnt.traceItems += nTrace;
 	GC_MARK(10);

@@ -1158,8 +1158,12 @@ void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTabl
 	if (!nWork) return;
 	uint64_t words = longWaveWordsPerLane(cfg);
 	const bool persistent = (uint64_t)blocks * lanes < nWork;   // fewer lanes than work items: waves loop and fetch
-#define GC_LAUNCH_TEAM(N) do { if (persistent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, true>), dim3(blocks), dim3(64), 0, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot, retryStatus); \
-	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, false>), dim3(blocks), dim3(64), 0, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot, retryStatus); } while (0)
+	// GC_LONG_WAVES_PER_SIMD=w (experiment): an unused dynamic LDS allocation per wave caps the kernel at w waves per SIMD, leaving wave slots
+	// and registers to the fragment pipeline's kernels that share the device with it
+	static const uint32_t ldsPad = []() { const char* e = getenv("GC_LONG_WAVES_PER_SIMD"); int w = e ? atoi(e) : 0; return (w >= 1 && w <= 7) ? (uint32_t)((160u * 1024u / (4u * (uint32_t)w)) & ~255u) : 0u; }();
+	const uint32_t pad = lanes == 1 ? ldsPad : 0;
+#define GC_LAUNCH_TEAM(N) do { if (persistent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, true>), dim3(blocks), dim3(64), pad, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot, retryStatus); \
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, false>), dim3(blocks), dim3(64), pad, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot, retryStatus); } while (0)
 	switch (lanes) {
 		case 1: GC_LAUNCH_TEAM(1); break;
 		case 2: GC_LAUNCH_TEAM(2); break;
@@ -1170,6 +1174,43 @@ void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTabl
 		default: GC_LAUNCH_TEAM(64); break;
 	}
 #undef GC_LAUNCH_TEAM
+}
+// Work items of the fragment pass, built where they are used (src/GraphAligner.h:499-511 per seed of a fragment window): the host sorts each
+// read's seeds and cuts the windows (order-critical, host/gc_glue.cpp) and hands over 16 B per fragment and per seed; one thread per fragment
+// expands its seed window into the per-slot records - the seed in fragment order and the two extensions (backward: reverse complement of the
+// fragment's prefix from the seed's reverse-strand twin; forward: the suffix from the seed). On the host this was 70 ms per 10 k reads
+// (345 MB of records through pinned memory, a twin lookup per slot) on the fragment pipeline's critical path, plus the upload.
+__global__ void __launch_bounds__(256) k_build_fragment_work(DGraph g, const Fragment* __restrict__ frags, const uint32_t* __restrict__ fragFirstSeed, uint32_t nFrags,
+	const FragSeed* __restrict__ readSeeds, const uint64_t* __restrict__ readOffsets, uint64_t totalBases, uint32_t splitLen, FragSeed* __restrict__ fragSeeds, ExtItem* __restrict__ work)
+{
+	const uint32_t F = blockIdx.x * 256 + threadIdx.x;
+	if (F >= nFrags) return;
+	const Fragment fr = frags[F];
+	const uint64_t readOff = readOffsets[fr.read], len = readOffsets[fr.read + 1] - readOff;
+	const FragSeed* seeds = readSeeds + fragFirstSeed[F];
+	for (uint32_t k = 0; k < fr.seedEnd - fr.seedBegin; k++) {
+		const FragSeed s = seeds[k];
+		const uint32_t slot = fr.seedBegin + k, p = s.seqPos - fr.l;
+		fragSeeds[slot] = s;
+		ExtItem b;
+		b.seqOff = totalBases + readOff + (len - fr.l - p);
+		b.seqLen = p;
+		twinOf(g, s.node, s.offset, b.node, b.offset);
+		b.pad = 0;
+		ExtItem f;
+		f.seqOff = readOff + fr.l + p + 1;
+		f.seqLen = splitLen - 1 - p;
+		f.node = s.node;
+		f.offset = s.offset;
+		f.pad = 0;
+		work[2 * (size_t)slot] = b;
+		work[2 * (size_t)slot + 1] = f;
+	}
+}
+void launchBuildFragmentWork(hipStream_t stream, const DGraph& g, const Fragment* frags, const uint32_t* fragFirstSeed, uint32_t nFrags, const FragSeed* readSeeds, const uint64_t* readOffsets,
+	uint64_t totalBases, uint32_t splitLen, FragSeed* fragSeeds, ExtItem* work)
+{
+	if (nFrags) hipLaunchKernelGGL(k_build_fragment_work, dim3((nFrags + 255) / 256), dim3(256), 0, stream, g, frags, fragFirstSeed, nFrags, readSeeds, readOffsets, totalBases, splitLen, fragSeeds, work);
 }
 void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, const uint32_t* candSeed, const LongWorkResult* results,
 	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity)

@@ -187,6 +187,9 @@ void launchEditDistance(hipStream_t stream, uint32_t unitBlocks, const EdPair* p
 // ---- minimizer index construction on the device (gc_minimizer.hip): the graph's window minimizers as (k-mer << 34 | reversed
 // arrival index, packed position) pairs, sorted; returns their number (~0 on failure: the caller builds on the host), arrays are hipMalloc'd
 uint64_t buildMinimizerPairsDevice(const DGraph& g, const int32_t* idOrderDev, uint32_t nIds, uint32_t k, uint32_t w, uint64_t** outKeys, uint64_t** outValues);
+// ---- fragment pass work items from the host's sorted seeds and windows (gc_kernels.hip)
+void launchBuildFragmentWork(hipStream_t stream, const DGraph& g, const Fragment* frags, const uint32_t* fragFirstSeed, uint32_t nFrags, const FragSeed* readSeeds, const uint64_t* readOffsets,
+	uint64_t totalBases, uint32_t splitLen, FragSeed* fragSeeds, ExtItem* work);
 // ---- read batch preparation (gc_reads.hip): reverse-complement strand, match-mask / exact-match bit vectors, 2-bit packing, all from the raw bases
 void launchPackReads(hipStream_t stream, const uint64_t* readOff, uint32_t nReads, uint64_t totalBases, char* bases, const uint64_t* maskOff, const uint32_t* maskWords, uint64_t* masks,
 	const uint64_t* eqOff, uint64_t* eqMasks, uint8_t* readInvalid, uint64_t* packed, uint64_t* invalidBits, uint32_t* chunkRead);
