@@ -35,6 +35,9 @@ namespace gcdev {
 #ifndef GC_LEAN_PUSH
 #define GC_LEAN_PUSH 1
 #endif
+#ifndef GC_LEAN_TABLES
+#define GC_LEAN_TABLES 1
+#endif
 #ifndef WAVE_CAP
 #define WAVE_CAP 28
 #endif
@@ -115,6 +118,20 @@ struct LaneLdsT {   // one lane's view
 	}
 	__device__ __forceinline__ void set(uint32_t t, uint32_t e, const Entry& x) const
 	{
+#if GC_LEAN_TABLES && defined(__HIP_DEVICE_COMPILE__)
+		if (REGCOLS) {   // seven v_writelane with the entry index in M0 (the values are uniform: straight from SGPRs, no compare, no moves)
+			const uint32_t es = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
+			const uint32_t v0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)x.w0), v1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)x.w1), v2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)x.w2);
+			const uint64_t a = gcUniform64(x.a), b = gcUniform64(x.b);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+			asm("s_mov_b32 m0, %7\n\tv_writelane_b32 %0, %8, m0\n\tv_writelane_b32 %1, %9, m0\n\tv_writelane_b32 %2, %10, m0\n\tv_writelane_b32 %3, %11, m0\n\tv_writelane_b32 %4, %12, m0\n\tv_writelane_b32 %5, %13, m0\n\tv_writelane_b32 %6, %14, m0"
+				: "+v"(tw[t][0]), "+v"(tw[t][1]), "+v"(tw[t][2]), "+v"(tw[t][3]), "+v"(tw[t][4]), "+v"(tw[t][5]), "+v"(tw[t][6])
+				: "s"(es), "s"(v0), "s"(v1), "s"(v2), "s"((uint32_t)a), "s"((uint32_t)(a >> 32)), "s"((uint32_t)b), "s"((uint32_t)(b >> 32)) : "m0");
+#pragma clang diagnostic pop
+			return;
+		}
+#endif
 		if (REGCOLS) {
 			const bool mine = threadIdx.x == e;
 			tw[t][0] = mine ? x.w0 : tw[t][0]; tw[t][1] = mine ? x.w1 : tw[t][1]; tw[t][2] = mine ? x.w2 : tw[t][2];
@@ -360,9 +377,10 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 		const uint64_t forced = gcUniform64(forceUntil >= 63 ? ~0ull : ((2ull << forceUntil) - 1));   // columns 1..forceUntil: first row forced
 		prevHP = gcUniform64(prevHP); prevHN = gcUniform64(prevHN);
 		uint64_t VP = ws.VP, VN = ws.VN;
-		int32_t score = ws.score;
-		uint32_t minKey = ((uint32_t)r.minScore << 6);   // (score << 6) | column: the smallest key is the first column with the smallest score
-		uint32_t deltas = 0;                             // lane pos: bit 0 = +1, bit 1 = -1 leaving the bottom row of column pos
+		// The bottom row's horizontal deltas (bit 63 of Ph / Mh) go to lane pos of two VGPRs, words as they are; everything that follows from
+		// them - HP / HN, the column scores, their minimum and where, the end score - is made once per tile by the vector pipe (ballots, a
+		// wave prefix sum, a wave minimum): eight scalar instructions per column less, about thirty vector instructions per tile more.
+		uint32_t plusWord = 0, minusWord = 0;
 		int pos = 1;
 #pragma unroll 1
 		for (int half = 0; half < 2; half++) {
@@ -385,34 +403,53 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 				const uint64_t Xh = (((Eq & VP) + VP) ^ VP) | Eq;
 				const uint64_t Ph = VN | ~(Xh | VP);
 				const uint64_t Mh = VP & Xh;
-				const uint32_t outP = (uint32_t)(Ph >> 63), outN = (uint32_t)(Mh >> 63);
 				const uint64_t sPh = (Ph << 1) | hinP, sMh = (Mh << 1) | hinN;
 				VP = (sMh | ~(Xv | sPh)) & ~f;
 				VN = (sPh & Xv) | f;
-				score += (int32_t)outP - (int32_t)outN;
-				const uint32_t key = ((uint32_t)score << 6) | (uint32_t)pos;
-				minKey = key < minKey ? key : minKey;
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
+				// (two SGPR operands exceed gfx9's constant bus; M0 as lane select does not count)
 				if (!COLUMNS) {
-					uint32_t both;   // (outN << 1) + outP, made by the scalar unit: v_writelane takes its data from an SGPR
-					asm("s_lshl1_add_u32 %0, %1, %2" : "=s"(both) : "s"(outN), "s"(outP) : "scc");
-					// (two SGPR operands exceed gfx9's constant bus; M0 as lane select does not count)
-					asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(deltas) : "s"(both), "s"(posS) : "m0");
+					asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0" : "+v"(plusWord), "+v"(minusWord) : "s"(posS), "s"((uint32_t)(Ph >> 32)), "s"((uint32_t)(Mh >> 32)) : "m0");
 				} else {
-					// backtrace recompute: the column itself goes to lane pos of the five column registers
-					asm("s_mov_b32 m0, %5\n\tv_writelane_b32 %0, %6, m0\n\tv_writelane_b32 %1, %7, m0\n\tv_writelane_b32 %2, %8, m0\n\tv_writelane_b32 %3, %9, m0\n\tv_writelane_b32 %4, %10, m0"
-						: "+v"(tables.cr[0]), "+v"(tables.cr[1]), "+v"(tables.cr[2]), "+v"(tables.cr[3]), "+v"(tables.cr[4])
-						: "s"(posS), "s"((uint32_t)VP), "s"((uint32_t)(VP >> 32)), "s"((uint32_t)VN), "s"((uint32_t)(VN >> 32)), "s"((uint32_t)score) : "m0");
+					// backtrace recompute: the column itself goes to lane pos of the column registers (its score follows after the loop)
+					asm("s_mov_b32 m0, %6\n\tv_writelane_b32 %0, %7, m0\n\tv_writelane_b32 %1, %8, m0\n\tv_writelane_b32 %2, %9, m0\n\tv_writelane_b32 %3, %10, m0\n\tv_writelane_b32 %4, %11, m0\n\tv_writelane_b32 %5, %12, m0"
+						: "+v"(tables.cr[0]), "+v"(tables.cr[1]), "+v"(tables.cr[2]), "+v"(tables.cr[3]), "+v"(plusWord), "+v"(minusWord)
+						: "s"(posS), "s"((uint32_t)VP), "s"((uint32_t)(VP >> 32)), "s"((uint32_t)VN), "s"((uint32_t)(VN >> 32)), "s"((uint32_t)(Ph >> 32)), "s"((uint32_t)(Mh >> 32)) : "m0");
 				}
 #pragma clang diagnostic pop
 			}
 		}
-		r.minScore = (int32_t)(minKey >> 6);
-		r.minOffset = minKey & 63u;
-		out.HP = __ballot((deltas & 1u) != 0);
-		out.HN = __ballot((deltas & 2u) != 0);
-		out.eVP = VP; out.eVN = VN; out.eScore = score;
+		const uint64_t HP = __ballot((int32_t)plusWord < 0), HN = __ballot((int32_t)minusWord < 0);   // lanes 0 and >= nodeLength still hold 0
+		out.HP = HP; out.HN = HN;
+		out.eVP = VP; out.eVN = VN; out.eScore = ws.score + popc64(HP) - popc64(HN);
+		if (nodeLength > 1) {
+			// column scores: prefix sum of the deltas across the lanes (row_shr 1, 2, 4, 8 inside a row of 16, then the rows' totals)
+			int32_t run = (int32_t)(plusWord >> 31) - (int32_t)(minusWord >> 31);
+			run += __builtin_amdgcn_update_dpp(0, run, 0x111, 0xf, 0xf, false);
+			run += __builtin_amdgcn_update_dpp(0, run, 0x112, 0xf, 0xf, false);
+			run += __builtin_amdgcn_update_dpp(0, run, 0x114, 0xf, 0xf, false);
+			run += __builtin_amdgcn_update_dpp(0, run, 0x118, 0xf, 0xf, false);
+			run += __builtin_amdgcn_update_dpp(0, run, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+			run += __builtin_amdgcn_update_dpp(0, run, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+			const int32_t columnScore = ws.score + run;
+			if (COLUMNS) {
+				if (threadIdx.x >= 1 && threadIdx.x < (uint32_t)nodeLength) tables.cr[4] = (uint32_t)columnScore;
+			} else {
+				// (score << 6) | column: the smallest key is the first column with the smallest score; column 0 enters with the tile's starting minimum
+				uint32_t key = threadIdx.x == 0 ? ((uint32_t)r.minScore << 6) : threadIdx.x < (uint32_t)nodeLength ? (((uint32_t)columnScore << 6) | threadIdx.x) : 0xffffffffu;
+				auto lower = [](uint32_t a, uint32_t b) { return a < b ? a : b; };
+				key = lower(key, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)key, 0x111, 0xf, 0xf, false));
+				key = lower(key, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)key, 0x112, 0xf, 0xf, false));
+				key = lower(key, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)key, 0x114, 0xf, 0xf, false));
+				key = lower(key, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)key, 0x118, 0xf, 0xf, false));
+				key = lower(key, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)key, 0x142, 0xa, 0xf, false));
+				key = lower(key, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)key, 0x143, 0xc, 0xf, false));
+				const uint32_t minKey = (uint32_t)GC_READLANE(key, 63);
+				r.minScore = (int32_t)(minKey >> 6);
+				r.minOffset = minKey & 63u;
+			}
+		}
 #if GC_LEAN_WALK
 		if (COLUMNS) tables.setWalkMasks(seq.w0, seq.w1, eq, forceEq, prevHN);
 #endif
@@ -870,17 +907,15 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 			int vert = row;
 			uint64_t up, diag, left;
 			L.loadWalkMasks(hori, up, diag, left);
+			uint32_t unfit = 0;   // a cell none of whose three predecessors fits: the reference's assertion; reported after the tile's walk
 			while (hori > 0 && vert > 0) {
-				const uint64_t bit = 1ull << vert;
-				if (up & bit) vert--;                                        // vertical == scoreHere - 1
-				else {
-					if (diag & bit) vert--;                                  // diagonal == scoreHere - (match ? 0 : 1)
-					else if (!(left & bit)) return EXT_ASSERT;               // else the left cell must be one less
-					hori--;
-					if (hori > 0) L.loadWalkMasks(hori, up, diag, left);
-				}
+				const uint32_t u = (uint32_t)(up >> vert) & 1u, d = (uint32_t)(diag >> vert) & 1u, l = (uint32_t)(left >> vert) & 1u;
+				unfit |= (u | d | l) ^ 1u;
+				vert -= (int)(u | d);                                        // up: vertical == scoreHere - 1; else diagonal == scoreHere - (match ? 0 : 1)
+				if (!u) { hori--; L.loadWalkMasks(hori, up, diag, left); }   // diagonal, or left (the left cell must then be one less)
 				if (!pushTraceW(Cell { curNode, hori, cs.j + vert }, false)) return status;
 			}
+			if (unfit) return EXT_ASSERT;
 			here = Cell { curNode, hori, cs.j + vert };
 		} else if (REGCOLS) {
 			// Tiles recomputed by the generic column loop (IUPAC nodes): the same three tests on cell values, all rows of a column pair at once.

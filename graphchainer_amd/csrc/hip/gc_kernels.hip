@@ -862,7 +862,7 @@ __global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __r
 #define GC_LONG_MIN_WAVES 1
 #endif
 template <int LANES, bool PERSISTENT>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GC_LONG_MIN_WAVES, 8))) k_long_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint64_t* __restrict__ masks, ExtendConfig cfg,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LANES == 1 ? 8 : GC_LONG_MIN_WAVES, 8))) k_long_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint64_t* __restrict__ masks, ExtendConfig cfg,
 	const LongWork* __restrict__ work, const uint32_t* __restrict__ order, uint32_t nWork, unsigned long long* __restrict__ scratch, uint64_t wordsPerLane,
 	unsigned long long* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, LongWorkResult* __restrict__ results, unsigned long long* __restrict__ counters,
 	unsigned long long* __restrict__ nextSlot, uint32_t retryStatus)
