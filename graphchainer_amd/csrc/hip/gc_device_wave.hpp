@@ -38,6 +38,9 @@ namespace gcdev {
 #ifndef GC_LEAN_TABLES
 #define GC_LEAN_TABLES 1
 #endif
+#ifndef GC_LEAN_COLMIN
+#define GC_LEAN_COLMIN 1
+#endif
 #ifndef WAVE_CAP
 #define WAVE_CAP 28
 #endif
@@ -607,7 +610,27 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 			if (tr.minScore < cur.minScore) { cur.minScore = tr.minScore; cur.minNode = pnode; cur.minOffset = tr.minOffset; }
 			if (flatRows > 0 && tr.flatMin < flatMin) { flatMin = tr.flatMin; flatNode = pnode; flatOffset = tr.flatOffset; }
 			WS newEnd = itemEnd(out);
+#if GC_LEAN_COLUMNS && GC_LEAN_COLMIN && defined(__HIP_DEVICE_COMPILE__)
+			int32_t newEndMin;
+			if (REGCOLS) {
+				// minimum over rows -1..63 of the tile's end column, all rows at once (lane r: the value of row r from two masked popcounts; wave
+				// minimum by DPP) instead of a scalar loop over the column's runs of -1 deltas
+				const uint64_t upTo = ~(~1ull << threadIdx.x);   // bits 0..r
+				const int32_t before = wsBefore(newEnd);
+				uint32_t v = (uint32_t)(before + popc64(newEnd.VP & upTo) - popc64(newEnd.VN & upTo));
+				auto lower = [](uint32_t a, uint32_t b) { return (int32_t)a < (int32_t)b ? a : b; };
+				v = lower(v, (uint32_t)__builtin_amdgcn_update_dpp(0x7fffffff, (int)v, 0x111, 0xf, 0xf, false));
+				v = lower(v, (uint32_t)__builtin_amdgcn_update_dpp(0x7fffffff, (int)v, 0x112, 0xf, 0xf, false));
+				v = lower(v, (uint32_t)__builtin_amdgcn_update_dpp(0x7fffffff, (int)v, 0x114, 0xf, 0xf, false));
+				v = lower(v, (uint32_t)__builtin_amdgcn_update_dpp(0x7fffffff, (int)v, 0x118, 0xf, 0xf, false));
+				v = lower(v, (uint32_t)__builtin_amdgcn_update_dpp(0x7fffffff, (int)v, 0x142, 0xa, 0xf, false));
+				v = lower(v, (uint32_t)__builtin_amdgcn_update_dpp(0x7fffffff, (int)v, 0x143, 0xc, 0xf, false));
+				const int32_t rowsMin = (int32_t)GC_READLANE(v, 63);
+				newEndMin = rowsMin < before ? rowsMin : before;
+			} else newEndMin = wsColumnMin(newEnd);
+#else
 			int32_t newEndMin = wsColumnMin(newEnd);
+#endif
 			if (newEndMin < prevMinScore) return EXT_ASSERT;
 			if (newEndMin <= currentMin + bandwidth) {
 				GC_MARK(3);   // item store + bookkeeping
