@@ -41,6 +41,9 @@ namespace gcdev {
 #ifndef GC_LEAN_COLMIN
 #define GC_LEAN_COLMIN 1
 #endif
+#ifndef GC_LEAN_MERGE
+#define GC_LEAN_MERGE 1
+#endif
 #ifndef WAVE_CAP
 #define WAVE_CAP 28
 #endif
@@ -328,6 +331,28 @@ __device__ __forceinline__ TraceCell unpackCell(unsigned long long w)
 	return t;
 }
 
+// Pointwise minimum of two columns (src/WordSlice.h:491-530) for the one-extension-per-wave layout: lane r takes the smaller of the two
+// values of row r (two masked popcounts each), fetches row r-1's minimum from its neighbour lane, and two ballots over the differences are
+// the merged column's deltas. Same column as wsMerge (the pointwise minimum is unique), without its scalar loop over the differing rows.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ WS wsMergeWave(const WS& a, const WS& b)
+{
+	const uint64_t upTo = ~(~1ull << threadIdx.x);   // bits 0..r
+	const int32_t beforeA = wsBefore(a), beforeB = wsBefore(b);
+	const int32_t va = beforeA + popc64(a.VP & upTo) - popc64(a.VN & upTo);
+	const int32_t vb = beforeB + popc64(b.VP & upTo) - popc64(b.VN & upTo);
+	const int32_t m = va < vb ? va : vb;
+	const int32_t beforeMin = beforeA < beforeB ? beforeA : beforeB;
+	int32_t above = __builtin_amdgcn_update_dpp(0, m, 0x138, 0xf, 0xf, false);   // wave_shr:1: row r - 1
+	if (threadIdx.x == 0) above = beforeMin;
+	WS res;
+	res.VP = __ballot(m == above + 1);
+	res.VN = __ballot(m == above - 1);
+	res.score = a.score < b.score ? a.score : b.score;
+	return res;
+}
+#endif
+
 // (node, slice) tile on a node that is new in this slice; same as computeTile but the previous-slice summary comes
 // in by value and columns (backtrace recompute) go to the LDS column view.
 template <bool COLUMNS, typename LANE_TABLES>
@@ -339,7 +364,11 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 	TileResult r;
 	r.minScore = ws.score;   // (sic) before the merge with the row above, ...Common.h:968 vs :1052-1058
 	r.minOffset = 0;
+#if GC_LEAN_MERGE && defined(__HIP_DEVICE_COMPILE__)
+	if (prevExists && wsBefore(ws) > prevStartScore) ws = LANE_TABLES::eqInLanes ? wsMergeWave(ws, wsSource(prevStartScore)) : wsMerge(ws, wsSource(prevStartScore));
+#else
 	if (prevExists && wsBefore(ws) > prevStartScore) ws = wsMerge(ws, wsSource(prevStartScore));
+#endif
 	int forceUntil = 0;
 	if (prevExists) {
 		int32_t scoreBefore = wsBefore(ws);
@@ -564,7 +593,11 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 				L.qSet(slot, target, g.componentNumber[target], add);
 				nPending++;
 			} else {
+#if GC_LEAN_MERGE && defined(__HIP_DEVICE_COMPILE__)
+				L.qSetWs(slot, REGCOLS ? wsMergeWave(L.qWs(slot), add) : wsMerge(L.qWs(slot), add));
+#else
 				L.qSetWs(slot, wsMerge(L.qWs(slot), add));
+#endif
 			}
 		};
 		for (uint32_t i = 0; i < nPrev; i++) {
