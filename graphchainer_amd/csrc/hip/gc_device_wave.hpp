@@ -16,6 +16,7 @@
 // the plain-layout fallback k_long_pass).
 #pragma once
 #include "gc_device.hpp"
+#include <type_traits>
 
 namespace gcdev {
 
@@ -43,6 +44,9 @@ namespace gcdev {
 #endif
 #ifndef GC_LEAN_MERGE
 #define GC_LEAN_MERGE 1
+#endif
+#ifndef GC_LEAN_FORCE_SPLIT
+#define GC_LEAN_FORCE_SPLIT 0   // (two copies of the column loop, with / without the forced first row: 184.4 -> 183.2 ms, not worth the spills)
 #endif
 #ifndef WAVE_CAP
 #define WAVE_CAP 28
@@ -413,6 +417,9 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 		// them - HP / HN, the column scores, their minimum and where, the end score - is made once per tile by the vector pipe (ballots, a
 		// wave prefix sum, a wave minimum): eight scalar instructions per column less, about thirty vector instructions per tile more.
 		uint32_t plusWord = 0, minusWord = 0;
+		// two copies of the loop: most tiles sit on a node that was in the previous slice with nothing to repair (forceUntil == 0), and their
+		// columns carry no forced first row - three scalar instructions per column less than the general copy
+		auto columnLoop = [&, &plusWord = plusWord, &minusWord = minusWord, &tables = tables](auto withForce) __attribute__((always_inline)) {   // (explicit captures: asm operands alone do not make a generic lambda capture)
 		int pos = 1;
 #pragma unroll 1
 		for (int half = 0; half < 2; half++) {
@@ -428,7 +435,8 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 					: "=&s"(lo), "=&s"(hi), "=&s"(Eq) : "s"((uint32_t)codes), "s"(eA), "s"(eC), "s"(eG), "s"(eT) : "scc");
 				asm("s_bfe_u64 %0, %1, %2" : "=s"(hinP) : "s"(prevHP), "s"(desc) : "scc");
 				asm("s_bfe_u64 %0, %1, %2" : "=s"(hinN) : "s"(prevHN), "s"(desc) : "scc");
-				asm("s_bfe_u64 %0, %1, %2" : "=s"(f) : "s"(forced), "s"(desc) : "scc");
+				if (decltype(withForce)::value) asm("s_bfe_u64 %0, %1, %2" : "=s"(f) : "s"(forced), "s"(desc) : "scc");
+				else f = 0;
 				codes >>= 2;
 				const uint64_t Xv = Eq | VN;
 				Eq |= hinN;
@@ -452,6 +460,12 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 #pragma clang diagnostic pop
 			}
 		}
+		};
+#if GC_LEAN_FORCE_SPLIT
+		if (forceUntil == 0) columnLoop(std::false_type()); else columnLoop(std::true_type());
+#else
+		columnLoop(std::true_type());
+#endif
 		const uint64_t HP = __ballot((int32_t)plusWord < 0), HN = __ballot((int32_t)minusWord < 0);   // lanes 0 and >= nodeLength still hold 0
 		out.HP = HP; out.HN = HN;
 		out.eVP = VP; out.eVN = VN; out.eScore = ws.score + popc64(HP) - popc64(HN);
