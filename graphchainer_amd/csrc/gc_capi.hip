@@ -71,29 +71,6 @@ std::mutex g_longPassToken[16];
 double nowUs() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Persistent worker pool for the per-read host glue (threads are created once per process).
-// CPUs' worth of bandwidth the cgroup grants this process (cgroup v2 cpu.max, v1 cfs quota / period); 0 = no limit known
-static double cpuQuota()
-{
-	auto readNumbers = [](const char* path, double& a, double& b) -> int {
-		FILE* f = fopen(path, "r");
-		if (!f) return 0;
-		char first[64] = { 0 };
-		int got = fscanf(f, "%63s %lf", first, &b);
-		fclose(f);
-		if (got < 1 || !strcmp(first, "max")) return -1;
-		a = atof(first);
-		return got;
-	};
-	double quota = 0, period = 0;
-	int got = readNumbers("/sys/fs/cgroup/cpu.max", quota, period);
-	if (got == 2 && quota > 0 && period > 0) return quota / period;
-	if (got == 0) {
-		double q = 0, p = 0, unused = 0;
-		if (readNumbers("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", q, unused) >= 1 && q > 0 && readNumbers("/sys/fs/cgroup/cpu/cpu.cfs_period_us", p, unused) >= 1 && p > 0) return q / p;
-	}
-	return 0;
-}
-
 class WorkerPool {
 public:
 	static WorkerPool& instance() { static WorkerPool p; return p; }
@@ -126,7 +103,7 @@ private:
 		// A container with a CPU bandwidth quota (cgroup cpu.max) shows all of the machine's threads but is throttled for the rest of the
 		// 100 ms period once a burst of workers has spent the quota - measured on a 16-CPU quota: 96 workers finish a stage in 10 ms and the
 		// whole process (the whole-read pass's round loop included) then stalls for 50-60 ms. Twice the quota keeps the bursts inside it.
-		const double quota = cpuQuota();
+		const double quota = gc::cpuQuota();
 		if (quota > 0) n = std::min<size_t>(n, std::max<size_t>(4, (size_t)(2 * quota + 0.5)));
 		if (const char* env = getenv("GC_HOST_THREADS")) n = (size_t)std::max(1, atoi(env));
 		for (size_t t = 1; t < n; t++) workers.emplace_back([this, t]() { loop(t); });

@@ -1,6 +1,8 @@
 // Host-side construction of the alignment graph ("A0" data).
 // Restates the behaviour of the reference's loaders; every function cites the lines it follows.
 #include "gc_graph.hpp"
+#include <cstring>
+#include <cstdio>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -698,10 +700,37 @@ void AlignmentGraph::computeMPCIndex(size_t cid, const std::vector<std::vector<s
 		}
 }
 
+// CPUs' worth of bandwidth the cgroup grants this process (cgroup v2 cpu.max, v1 cfs quota / period); 0 = no limit known.
+// A container may show all hardware threads of the box and be throttled once a burst of workers has spent the period's quota.
+double cpuQuota()
+{
+	auto readNumbers = [](const char* path, double& a, double& b) -> int {
+		FILE* f = fopen(path, "r");
+		if (!f) return 0;
+		char first[64] = { 0 };
+		int got = fscanf(f, "%63s %lf", first, &b);
+		fclose(f);
+		if (got < 1 || !strcmp(first, "max")) return -1;
+		a = atof(first);
+		return got;
+	};
+	double quota = 0, period = 0;
+	int got = readNumbers("/sys/fs/cgroup/cpu.max", quota, period);
+	if (got == 2 && quota > 0 && period > 0) return quota / period;
+	if (got == 0) {
+		double q = 0, p = 0, unused = 0;
+		if (readNumbers("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", q, unused) >= 1 && q > 0 && readNumbers("/sys/fs/cgroup/cpu/cpu.cfs_period_us", p, unused) >= 1 && p > 0) return q / p;
+	}
+	return 0;
+}
+
 size_t buildThreads()
 {
 	if (const char* env = getenv("GC_BUILD_THREADS")) { long v = atol(env); if (v >= 1) return (size_t)v; }
-	return std::max(1u, std::thread::hardware_concurrency());
+	size_t n = std::max(1u, std::thread::hardware_concurrency());
+	const double quota = cpuQuota();
+	if (quota > 0) n = std::min<size_t>(n, std::max<size_t>(1, (size_t)(quota + 0.5)));
+	return n;
 }
 
 void AlignmentGraph::buildMPC(bool shrinkToMinimum)   // reference: src/AlignmentGraph.cpp:1465-1489

@@ -135,6 +135,7 @@ size_t minimizerMaxCount(const std::vector<uint64_t>& startPos, double keepLeast
 // Threads the start-up builders may use (components of the MPC index, node chunks of the minimizer scan): GC_BUILD_THREADS,
 // default = hardware threads. The results do not depend on it.
 size_t buildThreads();
+double cpuQuota();   // CPUs' worth of time the cgroup grants (cpu.max), 0 = unlimited / unknown
 
 // 2-bit hash used to pick window minimizers. reference: src/MinimizerSeeder.cpp:45-54
 uint64_t minimizerHash(uint64_t key);
