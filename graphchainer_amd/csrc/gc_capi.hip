@@ -268,6 +268,7 @@ struct EditDistanceRun {
 	~EditDistanceRun() { for (auto& q : streams) if (q) (void)hipStreamDestroy(q); if (ready) (void)hipEventDestroy(ready); }
 };
 
+static const int LONG_EVENT_RING = 8;
 struct gc_stream {
 	std::vector<ReadGlue> glue;   // per-read host records of the batch in flight (storage reused)
 	int device = 0;             // the device the stream was created on; gc_align_batch selects it for the calling thread
@@ -294,7 +295,7 @@ struct gc_stream {
 		uint32_t nPairs = 0;
 	} edLong[2];
 	std::vector<hipStream_t> groupStreams;   // read groups of the whole-read pass run their round loops concurrently
-	std::vector<hipEvent_t> groupEvents;     // two per group
+	std::vector<hipEvent_t> groupEvents;     // 2 * LONG_EVENT_RING per group
 	DeviceBuffer longSeeds, longJobs, longAlns, longResults, longScratch, longCells, longCursor, longJobsFallback, longResultsFallback, longScratchFallback;
 	DeviceBuffer longState, longWork, longWorkResults, longRoundTrace, longCandSeed, longWorkLen, longOrder;
 	PinnedBuffer hLongSeeds, hLongJobs, hLongAlns, hLongResults, hLongSmall;
@@ -1499,10 +1500,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			if (const char* env = getenv("GC_LONG_GROUPS")) nGroups = (uint32_t)std::max(1, std::min(16, atoi(env)));
 			if (n < 64ull * nGroups) nGroups = 1;
 			while (st->groupStreams.size() < nGroups) {
-				hipStream_t q = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+				hipStream_t q = nullptr;
 				createStream(&q, 1);
-				HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
-				st->groupStreams.push_back(q); st->groupEvents.push_back(e0); st->groupEvents.push_back(e1);
+				st->groupStreams.push_back(q);
+				for (int k = 0; k < 2 * LONG_EVENT_RING; k++) { hipEvent_t e = nullptr; HIP_CHECK(hipEventCreate(&e)); st->groupEvents.push_back(e); }   // a ring of (begin, end) pairs around the rounds' extension launches
 			}
 			// cursors: [0] cell pool, [8..15] counters (+ [16..31] profiling stamps), per group g at 32+8g: [+0] work count, [+1] round trace cursor
 			const uint32_t cursorWords = 32 + 8 * 16;
@@ -1547,7 +1548,11 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				const uint64_t r0 = groupBeginPtr[g], nG = groupBeginPtr[g + 1] - r0;
 				if (nG == 0) return;
 				hipStream_t q = st->groupStreams[g];
-				hipEvent_t ev0 = st->groupEvents[2 * g], ev1 = st->groupEvents[2 * g + 1];
+				hipEvent_t* ring = st->groupEvents.data() + (size_t)2 * LONG_EVENT_RING * g;
+				// the rounds' extension time: read a ring slot's pair before the slot is reused (its round is complete by then: every round's
+				// work count has been awaited since) and what is left after the last round
+				auto collect = [&](int slot) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ring[2 * slot], ring[2 * slot + 1])); groupExtendUsPtr[g] += (double)ms * 1000.0; };
+				int timedRounds = 0;
 				const uint64_t w0 = 8 * r0 + 64ull * g, capacity = 8 * nG + 64;   // this group's slice of the work arrays
 				unsigned long long* cursor = dLongCursor + 32 + 8 * g;
 				volatile unsigned long long* hCursor = hLongSmall + 32 + 8 * g;
@@ -1579,6 +1584,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					uint32_t team = longExtendTeamSize(nWorkItems);
 					uint32_t blocks = std::min<uint32_t>((nWorkItems + team - 1) / team, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / team));
 					if (const char* env = getenv("GC_LONG_MAX_BLOCKS")) blocks = std::min<uint32_t>(blocks, (uint32_t)std::max(1, atoi(env)));   // test hook: force persistent waves
+					if (timedRounds >= LONG_EVENT_RING) collect(timedRounds % LONG_EVENT_RING);
+					hipEvent_t ev0 = ring[2 * (timedRounds % LONG_EVENT_RING)], ev1 = ring[2 * (timedRounds % LONG_EVENT_RING) + 1];
 					HIP_CHECK(hipEventRecord(ev0, q));
 					launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, team, blocks,
 						dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2);
@@ -1593,15 +1600,16 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					HIP_CHECK(hipEventRecord(ev1, q));
 					launchLongMerge(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, dCandSeed + w0, dLongWorkResults + w0, dRoundTrace + groupTraceBeginPtr[g], maxAlignments, dLongState + r0, dLongAlns, dLongCells, dLongCursor, cellBudget);
 					lastWork = nWorkItems;
-					HIP_CHECK(hipStreamSynchronize(q));
-					float ms = 0;
-					HIP_CHECK(hipEventElapsedTime(&ms, ev0, ev1));
-					groupExtendUsPtr[g] += (double)ms * 1000.0;
+					// no wait here: the next round's select / order / publish queue up right behind the merge, and the only host round trip per
+					// round is the work count above (with a second wait after the merge the stream drained twice per round, and each refill
+					// waited behind whatever other batches had queued on the device)
+					timedRounds++;
 					groupRoundsPtr[g]++;
 				}
 				launchLongFinish(q, (uint32_t)nG, dLongState + r0, dLongResults + r0);
 				HIP_CHECK(hipMemcpyAsync(hLongResults + r0, dLongResults + r0, nG * sizeof(LongReadResult), hipMemcpyDeviceToHost, q));
 				HIP_CHECK(hipStreamSynchronize(q));
+				for (int k = std::max(0, timedRounds - LONG_EVENT_RING); k < timedRounds; k++) collect(k % LONG_EVENT_RING);
 			};
 			longGroups = nGroups;
 			finishLongGroups = [=]() {   // after the group threads joined (vectors above are alive until the end of this call)
