@@ -70,6 +70,22 @@ std::mutex g_longPassToken[16];
 
 double nowUs() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// Waiting for a stream: hipStreamSynchronize spins, and a batch has two host threads waiting most of its 250 ms. GC_SPIN_SYNC=0 waits on
+// an event created with hipEventBlockingSync instead (the thread sleeps until the interrupt) - for hosts where the CPUs are scarcer than
+// on this pool's boxes; measured here (16-CPU quota, one rank) the sleeping wait costs more than the spinning one: 255 against 237 ms per batch.
+static void syncStream(hipStream_t q)
+{
+	static const bool spin = !(getenv("GC_SPIN_SYNC") && atoi(getenv("GC_SPIN_SYNC")) == 0);
+	if (spin) { HIP_CHECK(hipStreamSynchronize(q)); return; }
+	static thread_local hipEvent_t events[16] = {};   // one per device this thread has waited on (created once, kept for the thread's life)
+	int device = 0;
+	HIP_CHECK(hipGetDevice(&device));
+	hipEvent_t& e = events[device & 15];
+	if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventBlockingSync | hipEventDisableTiming));
+	HIP_CHECK(hipEventRecord(e, q));
+	HIP_CHECK(hipEventSynchronize(e));
+}
+
 // Persistent worker pool for the per-read host glue (threads are created once per process).
 class WorkerPool {
 public:
@@ -610,7 +626,7 @@ static void finishEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 	const uint64_t* dEqMasks, const char* dLetters, const uint32_t* dLettersLen)
 {
 	if (!nPairs) return;
-	for (auto& q : run.streams) HIP_CHECK(hipStreamSynchronize(q));
+	for (auto& q : run.streams) syncStream(q);
 	// reruns for the pairs whose band outgrew their unit (grouped order throughout)
 	std::vector<uint32_t> todo;
 	for (uint32_t i = 0; i < nPairs; i++) {
@@ -625,7 +641,7 @@ static void finishEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 		HIP_CHECK(hipMemcpyAsync(dPairs, sub.data(), sub.size() * sizeof(EdPair), hipMemcpyHostToDevice, stream));
 		launchEditDistance(stream, unit, dPairs, (uint32_t)sub.size(), dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut);
 		HIP_CHECK(hipMemcpyAsync(subOut.data(), dOut, sub.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipStreamSynchronize(stream));
+		syncStream(stream);
 		std::vector<uint32_t> next;
 		for (size_t i = 0; i < todo.size(); i++) { hOut[todo[i]] = subOut[i]; if (subOut[i] == -2) next.push_back(todo[i]); }
 		todo.swap(next);
@@ -1312,11 +1328,11 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		if (n) HIP_CHECK(hipMemcpyAsync(readMatchOff, dReadMatchOff, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		if (n) HIP_CHECK(hipMemcpyAsync(readMatchCount, dReadMatchCount, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		HIP_CHECK(hipMemcpyAsync(hSmall, dCursors, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipStreamSynchronize(stream));
+		syncStream(stream);
 		uint64_t nMatches = hSmall[0];
 		gc::KmerMatch* matches = st->hMatches.reserve<gc::KmerMatch>(nMatches);
 		if (nMatches) HIP_CHECK(hipMemcpyAsync(matches, dMatches, nMatches * sizeof(uint2), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipStreamSynchronize(stream));
+		syncStream(stream);
 		res->kernel_us[0] = elapsedUs(0, 1);
 		res->host_us[2] = nowUs() - tTotal;   // K1 + its transfers, wall
 
@@ -1515,7 +1531,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			HIP_CHECK(hipMemsetAsync(dLongCursor, 0, cursorWords * sizeof(unsigned long long), ls));
 			if (nLongSeeds) HIP_CHECK(hipMemcpyAsync(dLongSeeds, hSeeds, nLongSeeds * sizeof(LongSeed), hipMemcpyHostToDevice, ls));
 			if (n) HIP_CHECK(hipMemcpyAsync(dLongJobs, hJobs, n * sizeof(LongJob), hipMemcpyHostToDevice, ls));
-			HIP_CHECK(hipStreamSynchronize(ls));   // the group streams start from uploaded inputs
+			syncStream(ls);   // the group streams start from uploaded inputs
 			// rounds: select -> extend -> merge until no read has a seed left to extend (see gc_kernels.hip, "K3-long in rounds")
 			LongState* dLongState = st->longState.reserve<LongState>(n);
 			const uint64_t workCapacity = 8 * n + 64ull * nGroups;   // all groups together; group g owns the slice for its reads
@@ -1559,6 +1575,12 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				const uint64_t traceBudget = groupTraceBeginPtr[g + 1] - groupTraceBeginPtr[g];
 				launchLongInit(q, dLongJobs + r0, (uint32_t)nG, dLongState + r0);
 				uint32_t lastWork = 0xffffffffu;
+				// GC_LONG_TOKEN=2 (experiment): the token is held per round - from the moment a round's extension kernel is queued until the wait
+				// that proves it finished - so that the rounds of two batches in flight alternate instead of whole passes
+				int deviceNow = 0;
+				HIP_CHECK(hipGetDevice(&deviceNow));
+				static const bool roundToken = getenv("GC_LONG_TOKEN") && atoi(getenv("GC_LONG_TOKEN")) == 2;
+				std::unique_lock<std::mutex> roundLock(g_longPassToken[deviceNow & 15], std::defer_lock);
 
 				for (int round = 0; round < 4096; round++) {
 					launchZeroWords(q, cursor, 3);   // [0] work count, [1] round trace cursor, [2] next work slot
@@ -1578,9 +1600,11 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 						launchLongOrder(q, dWorkLen + w0, cursor, dOrder + w0, (uint32_t)maxReadLen, mode ? (uint32_t)atoi(mode) : 1u);
 					}
 					launchPublish(q, cursor, (unsigned long long*)hCursor, 2);
-					HIP_CHECK(hipStreamSynchronize(q));
+					syncStream(q);
+					if (roundLock.owns_lock()) roundLock.unlock();   // the previous round's extension kernel has finished
 					uint32_t nWorkItems = (uint32_t)hCursor[0];
 					if (nWorkItems == 0) break;
+					if (roundToken && nGroups == 1) roundLock.lock();
 					uint32_t team = longExtendTeamSize(nWorkItems);
 					uint32_t blocks = std::min<uint32_t>((nWorkItems + team - 1) / team, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / team));
 					if (const char* env = getenv("GC_LONG_MAX_BLOCKS")) blocks = std::min<uint32_t>(blocks, (uint32_t)std::max(1, atoi(env)));   // test hook: force persistent waves
@@ -1608,7 +1632,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				}
 				launchLongFinish(q, (uint32_t)nG, dLongState + r0, dLongResults + r0);
 				HIP_CHECK(hipMemcpyAsync(hLongResults + r0, dLongResults + r0, nG * sizeof(LongReadResult), hipMemcpyDeviceToHost, q));
-				HIP_CHECK(hipStreamSynchronize(q));
+				syncStream(q);
 				for (int k = std::max(0, timedRounds - LONG_EVENT_RING); k < timedRounds; k++) collect(k % LONG_EVENT_RING);
 			};
 			longGroups = nGroups;
@@ -1620,7 +1644,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			};
 			// reads whose band did not fit the LDS tables (status 5) are rerun with the plain-layout kernel
 			longFallback = [=]() {
-				HIP_CHECK(hipStreamSynchronize(ls));
+				syncStream(ls);
 				std::vector<uint32_t> redo;
 				const bool forceAll = getenv("GC_LONG_FORCE_FALLBACK") != nullptr;   // test hook: run every read through the plain-layout kernel too
 				// status 5: a slice with more nodes than the wave tables hold; status 2: an extension with more tiles / trace cells than its scratch
@@ -1641,12 +1665,12 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 						dSlab, lslab, dLongCells, dLongCursor, cellBudget, dLongAlns, dSubResults, dLongCursor + 8);
 					std::vector<LongReadResult> subResults(redo.size());
 					HIP_CHECK(hipMemcpyAsync(subResults.data(), dSubResults, redo.size() * sizeof(LongReadResult), hipMemcpyDeviceToHost, ls));
-					HIP_CHECK(hipStreamSynchronize(ls));
+					syncStream(ls);
 					for (size_t i = 0; i < redo.size(); i++) hLongResults[redo[i]] = subResults[i];
 				}
 				if (n) HIP_CHECK(hipMemcpyAsync(hLongAlns, dLongAlns, n * maxAlignments * sizeof(LongAln), hipMemcpyDeviceToHost, ls));
 				HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
-				HIP_CHECK(hipStreamSynchronize(ls));
+				syncStream(ls);
 				return (uint64_t)redo.size();
 			};
 		}
@@ -1700,9 +1724,9 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				longThreads.emplace_back([&, device, g]() {
 					try {
 						HIP_CHECK(hipSetDevice(device));
-						static const bool useToken = !(getenv("GC_LONG_TOKEN") && atoi(getenv("GC_LONG_TOKEN")) == 0);
+						static const int tokenMode = getenv("GC_LONG_TOKEN") ? atoi(getenv("GC_LONG_TOKEN")) : 1;   // 0 none, 1 one pass at a time, 2 one round's extension kernel at a time
 						std::unique_lock<std::mutex> token(g_longPassToken[device & 15], std::defer_lock);
-						if (useToken && longGroups == 1) token.lock();
+						if (tokenMode == 1 && longGroups == 1) token.lock();
 						{ double now = nowUs(), seen = longWallBeginUs.load(); while ((seen == 0.0 || now < seen) && !longWallBeginUs.compare_exchange_weak(seen, now)) {} }
 						runLongGroup(g);
 						{ double now = nowUs(), seen = longWallEndUs.load(); while (now > seen && !longWallEndUs.compare_exchange_weak(seen, now)) {} }
@@ -1876,7 +1900,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		if (n) HIP_CHECK(hipMemcpyAsync(chainScore, dChainScore, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		HIP_CHECK(hipMemcpyAsync(hSmall, dCursors, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		HIP_CHECK(hipMemcpyAsync(hSmall + 8, dCounters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipStreamSynchronize(stream));
+		syncStream(stream);
 		res->kernel_us[1] = elapsedUs(2, 3);
 		res->kernel_us[2] = elapsedUs(3, 4);
 		res->kernel_us[3] = elapsedUs(4, 5);
@@ -1893,7 +1917,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			if (nWork) HIP_CHECK(hipMemcpyAsync(extResults.data(), dResults, (size_t)nWork * sizeof(ExtResult), hipMemcpyDeviceToHost, stream));
 			if (traceUsed) HIP_CHECK(hipMemcpyAsync(tracePool.data(), dTrace, traceUsed * sizeof(TraceCell), hipMemcpyDeviceToHost, stream));
 		}
-		HIP_CHECK(hipStreamSynchronize(stream));
+		syncStream(stream);
 		res->host_us[3] = nowUs() - tDev;   // K3..K4 + their transfers, wall
 		// the stitched node paths come down behind the kernels that follow on this stream; they are only needed for the result arrays
 		bool stitchNodesPending = false;
@@ -1987,7 +2011,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		}
 		if (finishChainEditDistances) finishChainEditDistances();   // this thread would only wait for the whole-read pass otherwise
 		if (stitchNodesPending) {
-			HIP_CHECK(hipStreamSynchronize(stream));
+			syncStream(stream);
 			pool.run(n, [&](size_t r, size_t) {
 				if (!glue[r].stitchedOnDevice) return;
 				const StitchInfo& si = stitchInfo[r];
@@ -2055,7 +2079,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				launchEditPath(stream, dJobsEP, (uint32_t)m, dChainLetters, R->devBases, dScratchEP, maxQ, maxT, dOps, dOpsLen);
 				HIP_CHECK(hipMemcpyAsync(hOpsLen, dOpsLen, m * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 				HIP_CHECK(hipMemcpyAsync(hOps, dOps, opsTotal, hipMemcpyDeviceToHost, stream));
-				HIP_CHECK(hipStreamSynchronize(stream));
+				syncStream(stream);
 				pool.run(m, [&](size_t i, size_t) {
 					const uint32_t r = cand[i];
 					ReadGlue& gl = glue[r];
