@@ -420,17 +420,19 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 		// two copies of the loop: most tiles sit on a node that was in the previous slice with nothing to repair (forceUntil == 0), and their
 		// columns carry no forced first row - three scalar instructions per column less than the general copy
 		auto columnLoop = [&, &plusWord = plusWord, &minusWord = minusWord, &tables = tables](auto withForce) __attribute__((always_inline)) {   // (explicit captures: asm operands alone do not make a generic lambda capture)
-		int pos = 1;
+		// the column counter carries the field width of s_bfe_u64's descriptor in bit 16 (offset = bits 5:0, width = bits 22:16), and goes into M0
+		// as it is: v_writelane takes the lane from M0's low six bits
+		int pos = 1 | (1 << 16);
 #pragma unroll 1
 		for (int half = 0; half < 2; half++) {
 			uint64_t codes = half ? seq.w1 : (seq.w0 >> 2);
 			codes = gcUniform64(codes);
-			const int end = half ? nodeLength : (nodeLength < 32 ? nodeLength : 32);
+			const int end = (half ? nodeLength : (nodeLength < 32 ? nodeLength : 32)) | (1 << 16);
 #pragma unroll 1
 			for (; pos < end; pos++) {
 				uint64_t lo, hi, Eq, hinP, hinN, f;
 				const uint32_t posS = (uint32_t)__builtin_amdgcn_readfirstlane(pos);
-				const uint32_t desc = posS | (1u << 16);
+				const uint32_t desc = posS;
 				asm("s_bitcmp1_b32 %3, 0\n\ts_cselect_b64 %0, %5, %4\n\ts_cselect_b64 %1, %7, %6\n\ts_bitcmp1_b32 %3, 1\n\ts_cselect_b64 %2, %1, %0"
 					: "=&s"(lo), "=&s"(hi), "=&s"(Eq) : "s"((uint32_t)codes), "s"(eA), "s"(eC), "s"(eG), "s"(eT) : "scc");
 				asm("s_bfe_u64 %0, %1, %2" : "=s"(hinP) : "s"(prevHP), "s"(desc) : "scc");
