@@ -188,7 +188,9 @@ struct LaneScratch {
 };
 
 struct ExtCounters {
-	unsigned long long dpTiles, recomputeTiles, columnSteps, traceItems, extensions, backtraceTiles;
+	// 32-bit: they are per lane (per wave in the whole-read kernel) and flushed with one 64-bit atomic each at the kernel's end; in the
+	// whole-read kernel they live in scalar registers for the kernel's whole life, where every pair of them is one more spill
+	uint32_t dpTiles, recomputeTiles, columnSteps, traceItems, extensions, backtraceTiles;
 #ifdef GC_STAMPS
 	unsigned long long cyc[16], tMark;   // profiling build only (make stamps): lane-cycles per section of extendSeedWave
 #endif
