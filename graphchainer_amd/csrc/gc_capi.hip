@@ -290,7 +290,7 @@ struct gc_stream {
 	int device = 0;             // the device the stream was created on; gc_align_batch selects it for the calling thread
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[12] {};
-	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, readSeeds, fragFirstSeed, work, results, scratch, scratchRetry, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
+	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, readSeeds, fragFirstSeed, extLists, pendingFrags, fragNext, roundCounts, work, results, scratch, scratchRetry, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
 	PinnedBuffer hMatches, hReadSeeds, hFragFirstSeed, hFrags, hJobs, hAnchors, hFragStatus, hFragExtended, hChainOut, hChainLen, hChainScore, hChainStatus, hPathPool, hSmall;
 	// whole-read pass: runs on its own stream, concurrently with the fragment kernels
 	hipStream_t longStream = nullptr;
@@ -1838,23 +1838,61 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		if (nFrags) HIP_CHECK(hipMemcpyAsync(dFrags, frags, nFrags * sizeof(Fragment), hipMemcpyHostToDevice, stream));
 		if (nFrags) HIP_CHECK(hipMemcpyAsync(dFragFirstSeed, fragFirstSeed, nFrags * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 		if (nSeedsTotal) HIP_CHECK(hipMemcpyAsync(dReadSeeds, readSeeds, nSeedsTotal * sizeof(FragSeed), hipMemcpyHostToDevice, stream));
-		launchBuildFragmentWork(stream, G->dev, dFrags, dFragFirstSeed, (uint32_t)nFrags, dReadSeeds, R->devOffsets, R->totalBases, (uint32_t)P->split_len, dFragSeeds, dWork);
+		// Lazy extension (default): a seed is extended only when the reference would extend it - when it does not lie on an earlier alignment of its
+		// fragment (src/GraphAligner.h:163-173). Round 0 extends every fragment's first seed; k_build_anchors parks the fragments that reach another
+		// seed they must extend and queues that seed for the next round (the launches size themselves from counts on the device, no host round
+		// trip); three rounds at most, the last parking round queues everything its fragments have left. On cfg2 the reference extends 47 % of the
+		// seeds the windows hold. GC_EXT_LAZY=0: every seed is extended up front.
+		uint32_t maxWindowSeeds = 0;
+		for (uint64_t F = 0; F < nFrags; F++) maxWindowSeeds = std::max(maxWindowSeeds, frags[F].seedEnd - frags[F].seedBegin);
+		const bool lazyExtend = !(getenv("GC_EXT_LAZY") && atoi(getenv("GC_EXT_LAZY")) == 0) && nFrags > 0;
+		launchBuildFragmentWork(stream, G->dev, dFrags, dFragFirstSeed, (uint32_t)nFrags, dReadSeeds, R->devOffsets, R->totalBases, (uint32_t)P->split_len, dFragSeeds, dWork, lazyExtend ? dResults : nullptr);
 		if (n) HIP_CHECK(hipMemcpyAsync(dJobs, jobs, n * sizeof(ReadChainJob), hipMemcpyHostToDevice, stream));
 		mark();   // 2
-		launchExtend(stream, G->dev, G->devTables, G->devIupac, cfg, dWork, nWork, R->devBases, dResults, dScratch, slabBytes, dTrace, dCursors + 1, traceBudget, dCounters);
-		{
-			// extensions that outgrew their slab (a dense variant cluster: more tiles, queue entries or trace cells than the common case is sized
-			// for) run again in a small grid with 16x the room; lanes whose items are fine only read the status array. What overflows even
-			// that is flagged per read (capacity_exceeded), never a failed call.
-			ExtendConfig big = cfg;
-			big.maxItems = 16 * cfg.maxItems; big.maxPending = 16 * cfg.maxPending; big.maxTrace = 16 * cfg.maxTrace; big.maxSlices = cfg.maxSlices;
-			if (const char* env = getenv("GC_EXT_RETRY_MAX_ITEMS")) big.maxItems = (uint32_t)std::max(8, atoi(env));   // test hook: make the retry overflow too
-			const uint32_t retryLanes = 2048;
-			uint8_t* dRetryScratch = st->scratchRetry.reserve<uint8_t>((uint64_t)retryLanes * extendSlabBytes(big));
-			launchExtend(stream, G->dev, G->devTables, G->devIupac, big, dWork, nWork, R->devBases, dResults, dRetryScratch, extendSlabBytes(big), dTrace, dCursors + 1, traceBudget, dCounters, EXT_OVERFLOW, retryLanes);
+		// extensions that outgrew their slab (a dense variant cluster: more tiles, queue entries or trace cells than the common case is sized
+		// for) run again in a small grid with 16x the room; lanes whose items are fine only read the status array. What overflows even
+		// that is flagged per read (capacity_exceeded), never a failed call.
+		ExtendConfig big = cfg;
+		big.maxItems = 16 * cfg.maxItems; big.maxPending = 16 * cfg.maxPending; big.maxTrace = 16 * cfg.maxTrace; big.maxSlices = cfg.maxSlices;
+		if (const char* env = getenv("GC_EXT_RETRY_MAX_ITEMS")) big.maxItems = (uint32_t)std::max(8, atoi(env));   // test hook: make the retry overflow too
+		const uint32_t retryLanes = 2048;
+		uint8_t* dRetryScratch = st->scratchRetry.reserve<uint8_t>((uint64_t)retryLanes * extendSlabBytes(big));
+		auto extendRound = [&](const ExtSelection& sel) {
+			launchExtend(stream, G->dev, G->devTables, G->devIupac, cfg, dWork, nWork, R->devBases, dResults, dScratch, slabBytes, dTrace, dCursors + 1, traceBudget, dCounters, 0, 4096, sel);
+			launchExtend(stream, G->dev, G->devTables, G->devIupac, big, dWork, nWork, R->devBases, dResults, dRetryScratch, extendSlabBytes(big), dTrace, dCursors + 1, traceBudget, dCounters, EXT_OVERFLOW, retryLanes, sel);
+		};
+		if (!lazyExtend) {
+			extendRound(ExtSelection());
+			mark();   // 3
+			launchBuildAnchors(stream, G->dev, dFrags, (uint32_t)nFrags, dFragSeeds, dResults, dTrace, P->split_len, dAnchors, dFragStatus, dFragExtended, dPathPool, dCursors + 2, pathCapacity);
+		} else {
+			uint32_t* dLists = st->extLists.reserve<uint32_t>(2ull * nWork);           // two work lists, used in turn
+			uint32_t* dPending = st->pendingFrags.reserve<uint32_t>(2ull * nFrags);     // two pending-fragment lists
+			uint32_t* dFragNext = st->fragNext.reserve<uint32_t>(nFrags);
+			unsigned long long* dRoundCounts = st->roundCounts.reserve<unsigned long long>(4);   // [2k] work list k, [2k+1] pending list k
+			launchZeroWords(stream, dRoundCounts, 4);
+			ExtSelection first;
+			first.mode = 1; first.frags = dFrags; first.nFrags = (uint32_t)nFrags;
+			extendRound(first);
+			mark();   // 3 (round 0's extensions; the later rounds are charged to the anchors stage)
+			const uint32_t nRounds = std::min<uint32_t>(maxWindowSeeds, 3);   // first seeds; the next seed each parked fragment needs; then all that is left of the few still parked
+			for (uint32_t round = 0; round < nRounds; round++) {
+				const uint32_t cur = round & 1u, nxt = cur ^ 1u;
+				if (round > 0) {
+					ExtSelection sel;
+					sel.mode = 2; sel.list = dLists + (uint64_t)cur * nWork; sel.listCount = dRoundCounts + 2 * cur;
+					extendRound(sel);
+				}
+				launchZeroWords(stream, dRoundCounts + 2 * nxt, 2);
+				AnchorRounds ar;
+				ar.lazy = 1; ar.round = round; ar.parkAll = round + 2 >= nRounds ? 1 : 0;
+				ar.pending = dPending + (uint64_t)cur * nFrags; ar.pendingCount = dRoundCounts + 2 * cur + 1;
+				ar.nextList = dLists + (uint64_t)nxt * nWork; ar.nextListCount = dRoundCounts + 2 * nxt;
+				ar.nextPending = dPending + (uint64_t)nxt * nFrags; ar.nextPendingCount = dRoundCounts + 2 * nxt + 1;
+				ar.fragNext = dFragNext;
+				launchBuildAnchors(stream, G->dev, dFrags, (uint32_t)nFrags, dFragSeeds, dResults, dTrace, P->split_len, dAnchors, dFragStatus, dFragExtended, dPathPool, dCursors + 2, pathCapacity, ar);
+			}
 		}
-		mark();   // 3
-		launchBuildAnchors(stream, G->dev, dFrags, (uint32_t)nFrags, dFragSeeds, dResults, dTrace, P->split_len, dAnchors, dFragStatus, dFragExtended, dPathPool, dCursors + 2, pathCapacity);
 		mark();   // 4
 		launchChain(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, P->split_len, P->split_gap, caps, dChainScratch, dChainOut, dChainLen, dChainScore, dChainStatus, getenv("GC_CHAIN_FORCE_SCRATCH") != nullptr);
 		mark();   // 5

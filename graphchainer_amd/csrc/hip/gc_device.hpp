@@ -177,6 +177,7 @@ struct ExtendConfig {
 
 // status codes of one extension
 enum : uint32_t { EXT_OK = 0, EXT_FAILED = 1, EXT_ASSERT = 2, EXT_OVERFLOW = 3 };
+enum : uint32_t { EXT_NOT_RUN = 7 };   // fragment pass with lazy extension: the work item has not been run (yet)
 enum : uint32_t { EXT_LDS_CAP = 5 };   // whole-read pass: a slice has more nodes than the wave tables hold (retried with larger tables, then the plain layout)
 
 struct LaneScratch {

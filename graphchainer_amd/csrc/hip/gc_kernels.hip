@@ -156,13 +156,16 @@ __device__ __forceinline__ LaneScratch laneScratch(uint8_t* slab, const ExtendCo
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg,
 	const ExtItem* __restrict__ work, uint32_t nWork, const char* __restrict__ bases, ExtResult* __restrict__ results,
 	uint8_t* __restrict__ scratch, uint64_t slabBytes, TraceCell* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity,
-	unsigned long long* __restrict__ counters, uint32_t retryStatus)
+	unsigned long long* __restrict__ counters, uint32_t retryStatus, ExtSelection sel)
 {
 	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t stride = gridDim.x * blockDim.x;
 	LaneScratch sc = laneScratch(scratch + (uint64_t)tid * slabBytes, cfg);
 	ExtCounters cnt {};
-	for (uint32_t w = tid; w < nWork; w += stride) {
+	// which work items: all of them, the two extensions of every fragment's first seed, or a list written by k_build_anchors (count on the device)
+	const uint32_t nSelected = sel.mode == 0 ? nWork : sel.mode == 1 ? 2 * sel.nFrags : (uint32_t)*sel.listCount;
+	for (uint32_t at = tid; at < nSelected; at += stride) {
+		const uint32_t w = sel.mode == 0 ? at : sel.mode == 1 ? 2 * sel.frags[at >> 1].seedBegin + (at & 1u) : sel.list[at];
 		if (retryStatus != 0 && results[w].status != retryStatus) continue;   // retry launch (larger slabs): only the items the first launch gave up on
 		ExtItem it = work[w];
 		uint32_t nTrace = 0;
@@ -236,16 +239,25 @@ __device__ inline void mergedCell(const DGraph& g, const MergedView& v, uint32_t
 __global__ void __launch_bounds__(64) k_build_anchors(DGraph g, const Fragment* __restrict__ frags, uint32_t nFrags, const FragSeed* __restrict__ seeds,
 	const ExtResult* __restrict__ ext, const TraceCell* __restrict__ tracePool, int32_t splitLen,
 	AnchorRec* __restrict__ anchors, uint32_t* __restrict__ fragStatus, uint32_t* __restrict__ fragExtended,
-	uint32_t* __restrict__ pathPool, unsigned long long* __restrict__ pathCursor, uint64_t pathCapacity)
+	uint32_t* __restrict__ pathPool, unsigned long long* __restrict__ pathCursor, uint64_t pathCapacity, AnchorRounds rounds)
 {
+	// Lazy extension (rounds.lazy): a seed's two extensions run only when the reference would run them, i.e. when the seed does not lie on an
+	// earlier alignment of its fragment (on cfg2 more than half of the seeds do). Round 0 has the first seed of every fragment extended and
+	// walks all fragments; a fragment that reaches a seed it must extend and whose extensions have not run yet parks itself - the seed's
+	// two work items go to the next round's list, the fragment to the next round's pending list - and resumes there in the next round.
 	uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-	if (f >= nFrags) return;
+	if (rounds.lazy && rounds.round > 0) {
+		if (f >= (uint32_t)*rounds.pendingCount) return;
+		f = rounds.pending[f];
+	} else if (f >= nFrags) return;
 	Fragment fr = frags[f];
 	uint32_t status = 0;       // 0 ok, 1 the reference would throw in this fragment, 2 capacity overflow
 	uint32_t extended = 0;
 	uint32_t nSeeds = fr.seedEnd - fr.seedBegin;
-	for (uint32_t k = 0; k < nSeeds; k++) anchors[fr.seedBegin + k].valid = 0;
-	for (uint32_t k = 0; k < nSeeds && status == 0; k++) {
+	uint32_t firstSeed = 0;
+	if (rounds.lazy && rounds.round > 0) { firstSeed = rounds.fragNext[f]; extended = fragExtended[f]; }
+	else for (uint32_t k = 0; k < nSeeds; k++) anchors[fr.seedBegin + k].valid = 0;
+	for (uint32_t k = firstSeed; k < nSeeds && status == 0; k++) {
 		uint32_t sIdx = fr.seedBegin + k;
 		FragSeed sd = seeds[sIdx];
 		int32_t p = (int32_t)sd.seqPos - (int32_t)fr.l;
@@ -271,10 +283,24 @@ __global__ void __launch_bounds__(64) k_build_anchors(DGraph g, const Fragment* 
 			}
 		}
 		if (skip || status != 0) continue;
-		extended++;
 		// --- this seed is extended: getAlignmentFromSeed (:567-626)
 		const ExtResult& eb = ext[2 * (size_t)sIdx];
 		const ExtResult& ef = ext[2 * (size_t)sIdx + 1];
+		if (rounds.lazy && eb.status == EXT_NOT_RUN) {   // (both directions are queued together, so one test covers both)
+			// (the last parking round queues all the seeds the fragment has left: the few fragments that get this far then finish in one more
+			// round, at the price of some extensions the reference would not have run)
+			const uint32_t nQueued = rounds.parkAll ? nSeeds - k : 1u;
+			const unsigned long long at = atomicAdd(rounds.nextListCount, 2ull * nQueued);
+			for (uint32_t q = 0; q < nQueued; q++) {
+				rounds.nextList[at + 2 * q] = 2 * (sIdx + q);
+				rounds.nextList[at + 2 * q + 1] = 2 * (sIdx + q) + 1;
+			}
+			rounds.nextPending[atomicAdd(rounds.nextPendingCount, 1ull)] = f;
+			rounds.fragNext[f] = k;
+			fragExtended[f] = extended;
+			return;
+		}
+		extended++;
 		bool runB = p > 0, runF = p < splitLen - 1;
 		if ((runB && eb.status == EXT_ASSERT) || (runF && ef.status == EXT_ASSERT)) { status = 1; break; }
 		if ((runB && eb.status == EXT_OVERFLOW) || (runF && ef.status == EXT_OVERFLOW)) { status = 2; break; }
@@ -1094,19 +1120,20 @@ uint32_t extendGridLanes(uint32_t nWork)
 
 void launchExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg,
 	const ExtItem* work, uint32_t nWork, const char* bases, ExtResult* results, uint8_t* scratch, uint64_t slabBytes,
-	TraceCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters, uint32_t retryStatus, uint32_t retryLanes)
+	TraceCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters, uint32_t retryStatus, uint32_t retryLanes, ExtSelection sel)
 {
 	if (nWork == 0) return;
-	uint32_t lanes = retryStatus ? retryLanes : extendGridLanes(nWork);
-	hipLaunchKernelGGL(k_extend, dim3(lanes / 64), dim3(64), 0, stream, g, ct, iupac, cfg, work, nWork, bases, results, scratch, slabBytes, tracePool, traceCursor, traceCapacity, counters, retryStatus);
+	const uint32_t upper = sel.mode == 1 ? 2 * sel.nFrags : nWork;   // (a device-side list holds at most nWork items; waves beyond its count leave at once)
+	uint32_t lanes = retryStatus ? retryLanes : extendGridLanes(upper);
+	hipLaunchKernelGGL(k_extend, dim3(lanes / 64), dim3(64), 0, stream, g, ct, iupac, cfg, work, nWork, bases, results, scratch, slabBytes, tracePool, traceCursor, traceCapacity, counters, retryStatus, sel);
 }
 
 void launchBuildAnchors(hipStream_t stream, const DGraph& g, const Fragment* frags, uint32_t nFrags, const FragSeed* seeds, const ExtResult* ext,
 	const TraceCell* tracePool, int32_t splitLen, AnchorRec* anchors, uint32_t* fragStatus, uint32_t* fragExtended,
-	uint32_t* pathPool, unsigned long long* pathCursor, uint64_t pathCapacity)
+	uint32_t* pathPool, unsigned long long* pathCursor, uint64_t pathCapacity, AnchorRounds rounds)
 {
 	if (nFrags == 0) return;
-	hipLaunchKernelGGL(k_build_anchors, dim3((nFrags + 63) / 64), dim3(64), 0, stream, g, frags, nFrags, seeds, ext, tracePool, splitLen, anchors, fragStatus, fragExtended, pathPool, pathCursor, pathCapacity);
+	hipLaunchKernelGGL(k_build_anchors, dim3((nFrags + 63) / 64), dim3(64), 0, stream, g, frags, nFrags, seeds, ext, tracePool, splitLen, anchors, fragStatus, fragExtended, pathPool, pathCursor, pathCapacity, rounds);
 }
 
 uint64_t chainScratchBytes(const ChainCaps& caps)
@@ -1181,7 +1208,8 @@ void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTabl
 // fragment's prefix from the seed's reverse-strand twin; forward: the suffix from the seed). On the host this was 70 ms per 10 k reads
 // (345 MB of records through pinned memory, a twin lookup per slot) on the fragment pipeline's critical path, plus the upload.
 __global__ void __launch_bounds__(256) k_build_fragment_work(DGraph g, const Fragment* __restrict__ frags, const uint32_t* __restrict__ fragFirstSeed, uint32_t nFrags,
-	const FragSeed* __restrict__ readSeeds, const uint64_t* __restrict__ readOffsets, uint64_t totalBases, uint32_t splitLen, FragSeed* __restrict__ fragSeeds, ExtItem* __restrict__ work)
+	const FragSeed* __restrict__ readSeeds, const uint64_t* __restrict__ readOffsets, uint64_t totalBases, uint32_t splitLen, FragSeed* __restrict__ fragSeeds, ExtItem* __restrict__ work,
+	ExtResult* __restrict__ results)
 {
 	const uint32_t F = blockIdx.x * 256 + threadIdx.x;
 	if (F >= nFrags) return;
@@ -1205,12 +1233,16 @@ __global__ void __launch_bounds__(256) k_build_fragment_work(DGraph g, const Fra
 		f.pad = 0;
 		work[2 * (size_t)slot] = b;
 		work[2 * (size_t)slot + 1] = f;
+		if (results) {   // lazy extension: nothing has run yet
+			results[2 * (size_t)slot] = ExtResult { 0, 0, EXT_NOT_RUN, 0, 0 };
+			results[2 * (size_t)slot + 1] = ExtResult { 0, 0, EXT_NOT_RUN, 0, 0 };
+		}
 	}
 }
 void launchBuildFragmentWork(hipStream_t stream, const DGraph& g, const Fragment* frags, const uint32_t* fragFirstSeed, uint32_t nFrags, const FragSeed* readSeeds, const uint64_t* readOffsets,
-	uint64_t totalBases, uint32_t splitLen, FragSeed* fragSeeds, ExtItem* work)
+	uint64_t totalBases, uint32_t splitLen, FragSeed* fragSeeds, ExtItem* work, ExtResult* results)
 {
-	if (nFrags) hipLaunchKernelGGL(k_build_fragment_work, dim3((nFrags + 255) / 256), dim3(256), 0, stream, g, frags, fragFirstSeed, nFrags, readSeeds, readOffsets, totalBases, splitLen, fragSeeds, work);
+	if (nFrags) hipLaunchKernelGGL(k_build_fragment_work, dim3((nFrags + 255) / 256), dim3(256), 0, stream, g, frags, fragFirstSeed, nFrags, readSeeds, readOffsets, totalBases, splitLen, fragSeeds, work, results);
 }
 void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, const uint32_t* candSeed, const LongWorkResult* results,
 	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity)

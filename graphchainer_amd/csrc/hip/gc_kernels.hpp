@@ -31,6 +31,17 @@ struct ExtResult {
 	uint32_t pad;
 };
 
+struct Fragment;
+// which work items a k_extend launch runs: all (mode 0), the two extensions of every fragment's first seed (1), a list with its count on the device (2)
+struct ExtSelection { uint32_t mode = 0; const Fragment* frags = nullptr; uint32_t nFrags = 0; const uint32_t* list = nullptr; const unsigned long long* listCount = nullptr; };
+// lazy extension rounds of k_build_anchors (see the kernel): this round's pending fragments in, next round's work list and pending fragments out
+struct AnchorRounds {
+	uint32_t lazy = 0, round = 0, parkAll = 0;
+	const uint32_t* pending = nullptr; const unsigned long long* pendingCount = nullptr;
+	uint32_t* nextList = nullptr; unsigned long long* nextListCount = nullptr;
+	uint32_t* nextPending = nullptr; unsigned long long* nextPendingCount = nullptr;
+	uint32_t* fragNext = nullptr;
+};
 struct Fragment {    // one read fragment with its seed window [seedBegin, seedEnd) in the batch-wide seed array
 	uint32_t read;
 	uint32_t l;
@@ -119,11 +130,11 @@ uint32_t extendGridLanes(uint32_t nWork);
 void launchExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg,
 	const ExtItem* work, uint32_t nWork, const char* bases, ExtResult* results, uint8_t* scratch, uint64_t slabBytes,
 	TraceCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters,
-	uint32_t retryStatus = 0, uint32_t retryLanes = 4096);   // retryStatus != 0: a small grid of `retryLanes` lanes reruns only the items whose result has that status (with the larger slabs of `cfg`)
+	uint32_t retryStatus = 0, uint32_t retryLanes = 4096, ExtSelection sel = ExtSelection());   // retryStatus != 0: a small grid of `retryLanes` lanes reruns only the items whose result has that status (with the larger slabs of `cfg`)
 
 void launchBuildAnchors(hipStream_t stream, const DGraph& g, const Fragment* frags, uint32_t nFrags, const FragSeed* seeds, const ExtResult* ext,
 	const TraceCell* tracePool, int32_t splitLen, AnchorRec* anchors, uint32_t* fragStatus, uint32_t* fragExtended,
-	uint32_t* pathPool, unsigned long long* pathCursor, uint64_t pathCapacity);
+	uint32_t* pathPool, unsigned long long* pathCursor, uint64_t pathCapacity, AnchorRounds rounds = AnchorRounds());
 
 uint64_t chainScratchBytes(const ChainCaps& caps);
 uint32_t chainGridBlocks(uint32_t nReads);
@@ -189,7 +200,7 @@ void launchEditDistance(hipStream_t stream, uint32_t unitBlocks, const EdPair* p
 uint64_t buildMinimizerPairsDevice(const DGraph& g, const int32_t* idOrderDev, uint32_t nIds, uint32_t k, uint32_t w, uint64_t** outKeys, uint64_t** outValues);
 // ---- fragment pass work items from the host's sorted seeds and windows (gc_kernels.hip)
 void launchBuildFragmentWork(hipStream_t stream, const DGraph& g, const Fragment* frags, const uint32_t* fragFirstSeed, uint32_t nFrags, const FragSeed* readSeeds, const uint64_t* readOffsets,
-	uint64_t totalBases, uint32_t splitLen, FragSeed* fragSeeds, ExtItem* work);
+	uint64_t totalBases, uint32_t splitLen, FragSeed* fragSeeds, ExtItem* work, ExtResult* results = nullptr);
 // ---- read batch preparation (gc_reads.hip): reverse-complement strand, match-mask / exact-match bit vectors, 2-bit packing, all from the raw bases
 void launchPackReads(hipStream_t stream, const uint64_t* readOff, uint32_t nReads, uint64_t totalBases, char* bases, const uint64_t* maskOff, const uint32_t* maskWords, uint64_t* masks,
 	const uint64_t* eqOff, uint64_t* eqMasks, uint8_t* readInvalid, uint64_t* packed, uint64_t* invalidBits, uint32_t* chunkRead);
