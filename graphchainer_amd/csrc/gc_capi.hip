@@ -1759,6 +1759,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		FragSeed* readSeeds = st->hReadSeeds.reserve<FragSeed>(nSeedsTotal);
 		ReadChainJob* jobs = st->hJobs.reserve<ReadChainJob>(n);
 		std::vector<uint64_t> traceBudgets(pool.size(), 0);
+		std::vector<uint32_t> windowSeeds(pool.size(), 0);   // per worker: the most seeds a window holds
 		double tReserved = nowUs();
 		pool.run(n, [&](size_t r, size_t worker) {
 			const ReadGlue& gl = glue[r];
@@ -1779,6 +1780,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					budget += (p ? p + 24 : 0) + (q ? q + 24 : 0);
 				}
 				fr.seedEnd = (uint32_t)slot;
+				windowSeeds[worker] = std::max(windowSeeds[worker], w.sr - w.sl);
 			}
 			traceBudgets[worker] += budget;
 			ReadChainJob& job = jobs[r];
@@ -1844,7 +1846,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		// trip); three rounds at most, the last parking round queues everything its fragments have left. On cfg2 the reference extends 47 % of the
 		// seeds the windows hold. GC_EXT_LAZY=0: every seed is extended up front.
 		uint32_t maxWindowSeeds = 0;
-		for (uint64_t F = 0; F < nFrags; F++) maxWindowSeeds = std::max(maxWindowSeeds, frags[F].seedEnd - frags[F].seedBegin);
+		for (uint32_t m : windowSeeds) maxWindowSeeds = std::max(maxWindowSeeds, m);
 		const bool lazyExtend = !(getenv("GC_EXT_LAZY") && atoi(getenv("GC_EXT_LAZY")) == 0) && nFrags > 0;
 		launchBuildFragmentWork(stream, G->dev, dFrags, dFragFirstSeed, (uint32_t)nFrags, dReadSeeds, R->devOffsets, R->totalBases, (uint32_t)P->split_len, dFragSeeds, dWork, lazyExtend ? dResults : nullptr);
 		if (n) HIP_CHECK(hipMemcpyAsync(dJobs, jobs, n * sizeof(ReadChainJob), hipMemcpyHostToDevice, stream));
