@@ -472,6 +472,36 @@ def test_fragment_overflow_is_retried(gca, tmp_path, monkeypatch):
     assert not got["capacity_exceeded"].any()
 
 
+def test_lazy_fragment_extension_equals_eager(gca, tmp_path, monkeypatch):
+    """The fragment pass extends a seed only when the reference would (lazy rounds: first seeds, then the seeds parked fragments ask for);
+    GC_EXT_LAZY=0 extends every seed of every window up front and filters afterwards. Same anchors, chains, traces and statistics either
+    way - on a graph with repeats and nested bubbles (windows with many seeds, several of them needing an extension) - and fewer
+    extensions run in the lazy mode; the lazy run also equals the oracle."""
+    from graphchainer_amd.synth import SynthGenome
+    gfa = str(tmp_path / "g.gfa")
+    genome = SynthGenome(2, 60_000, seed=9, multi_allelic=0.3, nested=0.5, minus_links=0.3, repeats=6, repeat_len=400, repeat_divergence=0.03)
+    genome.write_gfa(gfa)
+    reads = genome.sample_reads(60, 4000, seed=3)
+    graph = gca.AlignmentGraph(gfa)
+    seeder = gca.MinimizerSeeder(graph)
+    runs = {}
+    for mode in ("0", "1"):
+        with monkeypatch.context() as m:
+            m.setenv("GC_EXT_LAZY", mode)
+            runs[mode] = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, long_pass=False).align_reads(reads)
+    eager, lazy = runs["0"], runs["1"]
+    for key in eager:
+        if key in ("kernel_us", "host_us", "counters", "counters_long"):
+            continue
+        a, b = eager[key], lazy[key]
+        if isinstance(a, np.ndarray):
+            assert np.array_equal(a, b), key
+    assert int(lazy["counters"][4]) < int(eager["counters"][4])          # extensions run
+    assert int(lazy["counters"][4]) >= 2 * int(lazy["seeds_extended"].sum())   # every seed the reference extends ran both directions
+    got, want = run_case(gca, gfa, reads)
+    compare(got, want)
+
+
 def test_capacity_overflow_flags_the_read_not_the_batch(gca, tmp_path, monkeypatch):
     """Capacities shrunk until even the retries overflow (fragment slabs, whole-read extension scratch, the whole-read cell pool): the
     call succeeds, the reads that hit a limit are flagged in capacity_exceeded, and every other read has exactly the oracle's
