@@ -601,7 +601,19 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 				} else { hinP = 1; hinN = 0; }
 				NodeSeq nseq = loadNodeSeq(g, target);
 				uint64_t hp, hn;
+#if GC_LEAN_COLUMNS && defined(__HIP_DEVICE_COMPILE__)
+				uint64_t eqFirst;
+				if (REGCOLS && !nseq.ambiguous) {   // the first column's match mask by the same three scalar selects as in the column loop
+					uint64_t lo, hi;
+					const uint32_t code = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nseq.w0);
+					const uint64_t mA = gcUniform64(eq.a), mC = gcUniform64(eq.c), mG = gcUniform64(eq.g), mT = gcUniform64(eq.t);
+					asm("s_bitcmp1_b32 %3, 0\n\ts_cselect_b64 %0, %5, %4\n\ts_cselect_b64 %1, %7, %6\n\ts_bitcmp1_b32 %3, 1\n\ts_cselect_b64 %2, %1, %0"
+						: "=&s"(lo), "=&s"(hi), "=&s"(eqFirst) : "s"(code), "s"(mA), "s"(mC), "s"(mG), "s"(mT) : "scc");
+				} else eqFirst = eqOfColumn(eq, nseq, 0);
+				add = myersStep(eqFirst, incoming, hinP, hinN, hp, hn);
+#else
 				add = myersStep(eqOfColumn(eq, nseq, 0), incoming, hinP, hinN, hp, hn);
+#endif
 				if (!prevExists || wsBefore(add) < prevStart) { add.VP &= ~1ull; add.VN |= 1ull; }
 			}
 			if (slot == nPending) {
