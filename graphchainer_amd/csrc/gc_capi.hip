@@ -1291,6 +1291,14 @@ void gc_result_free(gc_result* r)
 	free(r);
 }
 
+// One batch through the whole path. The function is long because the stages share a hundred buffers and sizes; it reads top to bottom as the
+// batch's timeline, every stage under a "// ----------------" header:
+//   K1 seed lookup -> host glue (expand, order) -> K3-long set-up: buffers, the round loop (runLongGroup), the after-pass stage (fallback reruns,
+//   selection, whole-read edit distances: afterLongPass), all of which then run on the pass's own host thread -> [main thread, meanwhile]
+//   fragment windows, k_build_fragment_work, K3 / K3b in lazy rounds, K4, k_stitch -> results back -> host stitching of what the kernel
+//   declined -> chain edit distances -> join with the whole-read pass -> chained alignment paths and traces (k_edit_path) -> flat result.
+// Capacities are per read (flags in the result), errors of the reference's own making per read or fragment (failed_assertion); only
+// invalid arguments and device errors fail the call.
 int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const gc_reads* R, const gc_params* P, gc_result** out)
 {
 	if (!G || !S || !st || !R || !P || !out) return fail(GC_ERR_INVALID, "null argument");
