@@ -149,6 +149,12 @@ def main():
     if world > 1 and "GC_HOST_THREADS" not in os.environ:
         # ranks share the host: split its cores between their worker pools (read by the library when it first loads)
         os.environ["GC_HOST_THREADS"] = str(max(4, min(96, 2 * usable_cpus() // world)))
+    if world > 1 and usable_cpus() < 6 * world:
+        # every batch in flight keeps two host threads waiting on the device; when the ranks together would spin on more CPUs than the
+        # host grants, let them sleep in the waits instead (GC_SPIN_SYNC=0) and keep one batch in flight per GPU
+        os.environ.setdefault("GC_SPIN_SYNC", "0")
+        if "GC_BENCH_INFLIGHT" not in os.environ and not any(a.startswith("--inflight") for a in sys.argv[1:]):
+            args.inflight = 1
     import graphchainer_amd as gca
     from graphchainer_amd.workqueue import ReadQueue, length_sorted_batches, run_queue
 
