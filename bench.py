@@ -227,13 +227,25 @@ def main():
         queue.reset(count * len(batches))
         return run_queue(queue, lambda i, item: (item % len(batches), aligners[i].align_batch(batches[item % len(batches)])), inflight)   # align_batch returns after its streams are drained
 
+    def cpu_seconds():
+        """CPU time of this container so far (cgroup v2 cpu.stat), or of this process when there is no such file."""
+        try:
+            for line in open("/sys/fs/cgroup/cpu.stat"):
+                if line.startswith("usage_usec"):
+                    return int(line.split()[1]) / 1e6
+        except OSError:
+            pass
+        return time.process_time()
+
     warmup_done = max(args.warmup, 1 if args.warmup and inflight > 1 else 0)
     run_steps(warmup_done)
     sync()
+    cpu_start = cpu_seconds()
     t_start = time.perf_counter()
     outs = run_steps(args.steps)
     sync()
     elapsed = time.perf_counter() - t_start
+    host_cpu_s = cpu_seconds() - cpu_start
     kernel_us = np.zeros(8)
     host_us = np.zeros(4)
     counters = np.zeros(8, dtype=np.float64)
@@ -327,6 +339,7 @@ def main():
             "cpu_baseline": cpu_baseline,
             # inputs are resident before the timed region; what putting them there costs (host-side packing + PCIe), and the rate with it included
             "reads_upload": {"ms_per_step": round(upload_s * 1e3, 2), "bases": total_bases, "reads_per_s_including_upload": round(reads_total / (elapsed + upload_s * steps * (1 if not strong else 1)), 2)},
+            "host_cpu_s_per_step": round(host_cpu_s / max(1, args.steps), 3),   # CPU time the container spent per step (all threads, this rank's box)
             "stage_ms": {"k_seed_probe+compact": round(kernel_us[0] / 1e3, 3), "k_extend": round(kernel_us[1] / 1e3, 3), "k_build_anchors": round(kernel_us[2] / 1e3, 3),
                          "k_chain": round(kernel_us[3] / 1e3, 3), "k_long_extend_all_rounds": round(kernel_us[4] / 1e3, 3), "whole_read_pass_wall": round(kernel_us[5] / 1e3, 3), "host_seed_glue": round(host_us[0] / 1e3, 3), "host_result_assembly": round(host_us[1] / 1e3, 3),
                          "wall_seed_lookup_and_copies": round(host_us[2] / 1e3, 3), "wall_extend_to_chain_and_copies": round(host_us[3] / 1e3, 3)},
