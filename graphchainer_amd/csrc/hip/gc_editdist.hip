@@ -10,10 +10,11 @@
 // letters. Lane l owns the units l, l+64, l+128, ... (unit = G consecutive blocks = 64G rows) and the wave sweeps the
 // matrix as a skewed wavefront: at step t unit B works on column t - B, so the horizontal delta leaving unit B-1
 // at column j is exactly what unit B needs one step later (one cross-lane shuffle per step). Only the cells with
-// |row - column| <= k are computed (Ukkonen): unit B is active for columns [64G*B - k, 64G*B + 64G - 1 + k], enters
+// Ukkonen's corridor are computed (the diagonals d = row - column with |d| + |(n - m) - d| <= k, about k of them): unit B is active
+// for columns [64G*B - reachRight, 64G*B + 64G - 1 + reachLeft], enters
 // with all-+1 vertical deltas below its upper neighbour and gets +1 as incoming horizontal delta when it is the top
 // of the band. Band values are upper bounds and exact along every path of cost <= k, so a result <= k is the edit
-// distance; otherwise k doubles and the pass repeats. k < 2016*G keeps a lane's consecutive units disjoint in time
+// distance; otherwise k doubles and the pass repeats. k < 4000*G keeps a lane's consecutive units disjoint in time
 // (no limit when the read has at most 64 units, i.e. up to 4096*G rows); the host escalates G = 1, 2, 4, 8, 16.
 #include "gc_kernels.hpp"
 #include <hip/hip_runtime.h>
@@ -133,7 +134,7 @@ __global__ void __launch_bounds__(64) k_edit_distance(const EdPair* __restrict__
 	__shared__ int32_t resultSlot;
 	const uint32_t lane = threadIdx.x;
 	constexpr uint32_t RB = 64u * G;                 // rows per unit
-	constexpr uint32_t K_MAX = 2016u * G;
+	constexpr uint32_t K_MAX = 4000u * G;             // the corridor is about k diagonals wide: a lane's consecutive units (64 units = 4096 G rows apart) stay disjoint in time
 	for (uint32_t pi = blockIdx.x; pi < nPairs; pi += gridDim.x) {
 		const EdPair pair = pairs[pi];
 		const EdRead rd = reads[pair.read];
@@ -162,17 +163,23 @@ __global__ void __launch_bounds__(64) k_edit_distance(const EdPair* __restrict__
 			// per-unit step window, refreshed when the lane moves to its next unit
 			uint32_t tBegin = 0xffffffffu, tEnd = 0xffffffffu, tHinEnd = 0, finalStep = 0xffffffffu;
 			const uint32_t lastUnit = (n - 1) / RB;
+			// Ukkonen's corridor: a path of cost <= k from (0,0) to (n-1,m-1) spends at least |row - column| to get where it is and at least
+			// |(n - m) - (row - column)| to get home, so it only visits diagonals with |d| + |(n - m) - d| <= k: from min(0, n-m) - a to
+			// max(0, n-m) + a with a = (k - |n-m|) / 2 - about k diagonals, half of the symmetric |row - column| <= k
+			const uint32_t slack = (k - diff) / 2;
+			const uint64_t reachRight = (uint64_t)(n > m ? n - m : 0) + slack;   // row - column at most this: columns from rowBase - reachRight
+			const uint64_t reachLeft = (uint64_t)(m > n ? m - n : 0) + slack;    // column - row at most this: columns to row + reachLeft
 			auto enterUnit = [&](uint32_t b) {
 				B = b;
 				fresh = true;
 				if (b >= nU) { tBegin = 0xffffffffu; tEnd = 0xffffffffu; return; }
 				const uint64_t rowBase = (uint64_t)RB * b;
-				const uint64_t c0 = rowBase > k ? rowBase - k : 0;
-				const uint64_t c1 = rowBase + RB - 1 + k;
+				const uint64_t c0 = rowBase > reachRight ? rowBase - reachRight : 0;
+				const uint64_t c1 = rowBase + RB - 1 + reachLeft;
 				const uint64_t lastCol = c1 < m - 1 ? c1 : m - 1;
 				tBegin = c0 > lastCol ? 0xffffffffu : (uint32_t)(c0 + b);          // (a unit below the band at every column never runs)
 				tEnd = (uint32_t)(lastCol + b);
-				tHinEnd = b > 0 ? (uint32_t)(rowBase - 1 + k + b) : 0;              // last step whose column the upper neighbour also computes
+				tHinEnd = b > 0 ? (uint32_t)(rowBase - 1 + reachLeft + b) : 0;      // last step whose column the upper neighbour also computes
 				finalStep = b == lastUnit ? m - 1 + b : 0xffffffffu;
 			};
 			enterUnit(lane);
@@ -270,7 +277,7 @@ void launchChainPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* j
 {
 	if (nJobs) hipLaunchKernelGGL(k_chain_pathseq, dim3(nJobs), dim3(64), 0, stream, g, jobs, nJobs, pathNodes, altNodes, letters, outLen);
 }
-uint32_t editDistanceMaxK(uint32_t unitBlocks) { return 2016u * unitBlocks; }
+uint32_t editDistanceMaxK(uint32_t unitBlocks) { return 4000u * unitBlocks; }
 void launchEditDistance(hipStream_t stream, uint32_t unitBlocks, const EdPair* pairs, uint32_t nPairs, const EdRead* reads, const char* bases, const uint64_t* eqMasks,
 	const char* letters, const uint32_t* lettersLen, int64_t* outDistance)
 {
