@@ -277,7 +277,7 @@ struct ReadGlue {
 };
 
 struct EditDistanceRun {
-	hipStream_t streams[5] {};
+	hipStream_t streams[6] {};         // one per kernel class: two pairs per wave, then units of 1, 2, 4, 8, 16 blocks
 	hipEvent_t ready = nullptr;
 	std::vector<uint32_t> perm;        // position in the grouped order -> original pair index
 	std::vector<int64_t> grouped;      // results in grouped order (pinned not needed: small)
@@ -597,28 +597,32 @@ static void launchEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 		for (auto& q : run.streams) createStream(&q, 0);
 	}
 	std::vector<uint32_t> cls(nPairs);
-	uint32_t count[5] = { 0, 0, 0, 0, 0 }, begin[6];
+	uint32_t count[6] = { 0, 0, 0, 0, 0, 0 }, begin[7];
+	static const bool halfWaves = !(getenv("GC_ED_HALF") && atoi(getenv("GC_ED_HALF")) == 0);
 	for (uint32_t i = 0; i < nPairs; i++) {
-		uint32_t unit = editDistanceUnit(hPairs[i].k, readLen(hPairs[i].read)), c = 0;
+		const uint32_t len = readLen(hPairs[i].read);
+		uint32_t unit = editDistanceUnit(hPairs[i].k, len), c = 0;
 		while ((1u << c) < unit) c++;
+		c++;                                                                  // classes 1..5: one pair per wave, units of 1..16 blocks
+		if (halfWaves && unit == 1 && hPairs[i].k < editDistanceMaxK(0) && len < 150000) c = 0;   // class 0: two pairs per wave (small first band)
 		cls[i] = c;
 		count[c]++;
 	}
 	begin[0] = 0;
-	for (int c = 0; c < 5; c++) begin[c + 1] = begin[c] + count[c];
+	for (int c = 0; c < 6; c++) begin[c + 1] = begin[c] + count[c];
 	run.perm.resize(nPairs);
 	{
-		uint32_t at[5] = { begin[0], begin[1], begin[2], begin[3], begin[4] };
+		uint32_t at[6] = { begin[0], begin[1], begin[2], begin[3], begin[4], begin[5] };
 		std::vector<EdPair> grouped(nPairs);
 		for (uint32_t i = 0; i < nPairs; i++) { grouped[at[cls[i]]] = hPairs[i]; run.perm[at[cls[i]]++] = i; }
 		memcpy(hPairs, grouped.data(), (size_t)nPairs * sizeof(EdPair));   // hPairs is now in grouped order
 	}
 	HIP_CHECK(hipMemcpyAsync(dPairs, hPairs, (size_t)nPairs * sizeof(EdPair), hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipEventRecord(run.ready, stream));
-	for (int c = 0; c < 5; c++) {
+	for (int c = 0; c < 6; c++) {
 		if (!count[c]) continue;
 		HIP_CHECK(hipStreamWaitEvent(run.streams[c], run.ready, 0));
-		launchEditDistance(run.streams[c], 1u << c, dPairs + begin[c], count[c], dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut + begin[c]);
+		launchEditDistance(run.streams[c], c == 0 ? 0u : 1u << (c - 1), dPairs + begin[c], count[c], dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut + begin[c]);
 		HIP_CHECK(hipMemcpyAsync(hOut + begin[c], dOut + begin[c], (size_t)count[c] * sizeof(int64_t), hipMemcpyDeviceToHost, run.streams[c]));
 	}
 }
@@ -634,7 +638,7 @@ static void finishEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 	}
 	std::vector<EdPair> sub;
 	std::vector<int64_t> subOut;
-	for (uint32_t unit = 2; unit <= 16 && !todo.empty(); unit *= 2) {
+	for (uint32_t unit = 1; unit <= 16 && !todo.empty(); unit *= 2) {   // (unit 1 again for what the two-pairs-per-wave kernel handed back)
 		sub.resize(todo.size());
 		subOut.resize(todo.size());
 		for (size_t i = 0; i < todo.size(); i++) sub[i] = hPairs[todo[i]];

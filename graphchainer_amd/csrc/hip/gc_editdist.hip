@@ -269,6 +269,157 @@ __global__ void __launch_bounds__(64) k_edit_distance(const EdPair* __restrict__
 	}
 }
 
+// Two pairs per wave (unit of one block, bands up to k = 1900): the corridor of a 10 kb pair is about 23 units wide, so a wave with one pair
+// keeps a third of its lanes busy and its time is set by the number of steps (columns + units), not by the band. Each half of the wave
+// (32 lanes) sweeps its own pair - lane l of a half owns the units l, l + 32, ...; the neighbour shuffle stays inside the half; each half has
+// its own letter ring and result slot - and the two halves step together (a half that is done, or has the shorter pair, idles). Same
+// arithmetic as k_edit_distance<1>; a pair whose band would outgrow the half (k >= 1900 with more than 32 units) answers -2 and is rerun
+// by the host with the wider kernels.
+#define ED_HALF_RING 4096u
+#define ED_HALF_KMAX 1900u
+__global__ void __launch_bounds__(64) k_edit_distance_half(const EdPair* __restrict__ pairs, uint32_t nPairs, const EdRead* __restrict__ reads, const char* __restrict__ bases,
+	const uint64_t* __restrict__ eqMasks, const char* __restrict__ letters, const uint32_t* __restrict__ lettersLen, int64_t* __restrict__ outDistance)
+{
+	__shared__ uint8_t ringAll[2 * ED_HALF_RING];
+	__shared__ int32_t resultSlot[2];
+	const uint32_t lane = threadIdx.x, half = lane >> 5, l = lane & 31u;
+	uint8_t* ring = ringAll + half * ED_HALF_RING;
+	constexpr uint32_t RB = 64u;
+	for (uint32_t base = blockIdx.x * 2; base < nPairs; base += gridDim.x * 2) {
+		const uint32_t pi = base + half;
+		const bool valid = pi < nPairs;
+		EdPair pair {};
+		EdRead rd {};
+		uint32_t n = 0, m = 0;
+		if (valid) {
+			pair = pairs[pi];
+			rd = reads[pair.read];
+			n = rd.len;
+			m = lettersLen ? lettersLen[pair.lenIndex] : pair.m;
+		}
+		int64_t answer = -2;
+		bool more = valid;
+		if (valid && m == 0xffffffffu) { answer = -3; more = false; }            // path letters overflowed their slot
+		else if (valid && (n == 0 || m == 0)) { answer = (int64_t)(n + m); more = false; }
+		const char* path = letters + pair.lettersOff;
+		const uint64_t* masks = eqMasks + rd.eqOff;
+		const uint32_t nU = (n + RB - 1) / RB;
+		const uint32_t diff = n > m ? n - m : m - n;
+		const uint32_t cap = n > m ? n : m;
+		uint32_t k = pair.k > diff ? pair.k : diff;
+		if (k < 1) k = 1;
+		if (k > cap) k = cap;
+		if (more && !(nU + 1024 + 128 < ED_HALF_RING)) more = false;           // (-2: the wider kernels take it)
+		while (__any(more)) {
+			if (more && k >= ED_HALF_KMAX && nU > 32) more = false;              // -2
+			// ---- one banded pass of every half that still has one to do
+			uint64_t VP = ~0ull, VN = 0, eqA = 0, eqC = 0, eqG = 0, eqT = 0;
+			uint32_t B = l;
+			int32_t score = 0;
+			bool fresh = true;
+			uint32_t pack = 0, loadedEnd = 0;
+			uint32_t tBegin = 0xffffffffu, tEnd = 0xffffffffu, tHinEnd = 0, finalStep = 0xffffffffu;
+			const uint32_t lastUnit = n ? (n - 1) / RB : 0;
+			const uint32_t slack = more ? (k - diff) / 2 : 0;
+			const uint64_t reachRight = (uint64_t)(n > m ? n - m : 0) + slack;
+			const uint64_t reachLeft = (uint64_t)(m > n ? m - n : 0) + slack;
+			auto enterUnit = [&](uint32_t b) {
+				B = b;
+				fresh = true;
+				if (!more || b >= nU) { tBegin = 0xffffffffu; tEnd = 0xffffffffu; return; }
+				const uint64_t rowBase = (uint64_t)RB * b;
+				const uint64_t c0 = rowBase > reachRight ? rowBase - reachRight : 0;
+				const uint64_t c1 = rowBase + RB - 1 + reachLeft;
+				const uint64_t lastCol = c1 < m - 1 ? c1 : m - 1;
+				tBegin = c0 > lastCol ? 0xffffffffu : (uint32_t)(c0 + b);
+				tEnd = (uint32_t)(lastCol + b);
+				tHinEnd = b > 0 ? (uint32_t)(rowBase - 1 + reachLeft + b) : 0;
+				finalStep = b == lastUnit ? m - 1 + b : 0xffffffffu;
+			};
+			enterUnit(l);
+			if (l == 0) resultSlot[half] = -1;
+			const uint32_t steps = more ? m + nU - 1 : 0;
+			const uint32_t otherSteps = (uint32_t)__shfl((int)steps, (int)(lane ^ 32u));
+			const uint32_t allSteps = steps > otherSteps ? steps : otherSteps;
+			for (uint32_t t = 0; t < allSteps; t++) {
+				if ((t & 1023u) == 0) {
+					if (more) {
+						const uint32_t end = t + 2048 < m ? t + 2048 : m;
+						for (uint32_t c = loadedEnd + l; c < end; c += 32) {
+							const uint8_t ch = (uint8_t)path[c];
+							ring[c & (ED_HALF_RING - 1)] = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
+						}
+						loadedEnd = end > loadedEnd ? end : loadedEnd;
+					}
+					__syncthreads();
+				}
+				const uint32_t nbPack = (uint32_t)__shfl((int)pack, (int)((lane & 32u) | ((l + 31u) & 31u)));
+				if (B < nU && t > tEnd) { do enterUnit(B + 32); while (B < nU && t > tEnd); }
+				if (t < tBegin || t >= steps) continue;
+				const uint32_t j = t - B;
+				if (fresh) {
+					fresh = false;
+					const uint32_t w = B;
+					const bool in = w < rd.words;
+					VP = ~0ull; VN = 0;
+					eqA = in ? masks[w] : 0ull;
+					eqC = in ? masks[rd.words + w] : 0ull;
+					eqG = in ? masks[2ull * rd.words + w] : 0ull;
+					eqT = in ? masks[3ull * rd.words + w] : 0ull;
+					if (j == 0) score = (int32_t)(RB * (B + 1));
+					else score = (int32_t)(nbPack >> 2) - ((int32_t)(nbPack & 3u) - 1) + (int32_t)RB;
+				}
+				const uint32_t code = ring[j & (ED_HALF_RING - 1)];
+				int hin = 1;
+				if (B > 0 && t <= tHinEnd) hin = (int)(nbPack & 3u) - 1;
+				uint64_t hinP = hin > 0 ? 1 : 0, hinN = hin < 0 ? 1 : 0;
+				uint64_t Eq;
+				if (code < 4) {
+					const uint64_t lo = (code & 1) ? eqC : eqA, hi = (code & 1) ? eqT : eqG;
+					Eq = (code & 2) ? hi : lo;
+				} else {
+					Eq = 0;
+					const uint8_t letter = (uint8_t)path[j];
+					const uint64_t row0 = (uint64_t)RB * B;
+					for (uint32_t i = 0; i < 64 && row0 + i < n; i++) if ((uint8_t)bases[rd.readOff + row0 + i] == letter) Eq |= 1ull << i;
+				}
+				const uint64_t Xv = Eq | VN;
+				Eq |= hinN;
+				const uint64_t Xh = (((Eq & VP) + VP) ^ VP) | Eq;
+				uint64_t Ph = VN | ~(Xh | VP);
+				uint64_t Mh = VP & Xh;
+				const uint64_t outP = Ph >> 63, outN = Mh >> 63;
+				Ph = (Ph << 1) | hinP;
+				Mh = (Mh << 1) | hinN;
+				VP = Mh | ~(Xv | Ph);
+				VN = Ph & Xv;
+				const int hout = (int)outP - (int)outN;
+				score += hout;
+				pack = ((uint32_t)score << 2) | (uint32_t)(hout + 1);
+				if (t == finalStep) {
+					int32_t d = score;
+					const uint64_t row0 = (uint64_t)RB * B;
+					uint64_t pad = 0;
+					if (row0 >= n) pad = ~0ull;
+					else if (row0 + 64 > n) pad = ~0ull << (n - row0);
+					d -= __popcll(VP & pad);
+					d += __popcll(VN & pad);
+					resultSlot[half] = d;
+				}
+			}
+			__syncthreads();
+			const int32_t d = resultSlot[half];
+			__syncthreads();
+			if (more) {
+				if (d >= 0 && (uint32_t)d <= k) { answer = d; more = false; }
+				else if (k >= cap) { answer = d; more = false; }
+				else k = k * 2 < cap ? k * 2 : cap;
+			}
+		}
+		if (l == 0 && valid) outDistance[pi] = answer;
+	}
+}
+
 void launchLongPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* jobs, uint32_t nJobs, const LongCell* cellPool, char* letters, uint32_t* outLen)
 {
 	if (nJobs) hipLaunchKernelGGL(k_long_pathseq, dim3(nJobs), dim3(64), 0, stream, g, jobs, nJobs, cellPool, letters, outLen);
@@ -277,12 +428,17 @@ void launchChainPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* j
 {
 	if (nJobs) hipLaunchKernelGGL(k_chain_pathseq, dim3(nJobs), dim3(64), 0, stream, g, jobs, nJobs, pathNodes, altNodes, letters, outLen);
 }
-uint32_t editDistanceMaxK(uint32_t unitBlocks) { return 4000u * unitBlocks; }
+uint32_t editDistanceMaxK(uint32_t unitBlocks) { return unitBlocks == 0 ? ED_HALF_KMAX : 4000u * unitBlocks; }   // unit 0: the two-pairs-per-wave kernel
 void launchEditDistance(hipStream_t stream, uint32_t unitBlocks, const EdPair* pairs, uint32_t nPairs, const EdRead* reads, const char* bases, const uint64_t* eqMasks,
 	const char* letters, const uint32_t* lettersLen, int64_t* outDistance)
 {
 	if (!nPairs) return;
 	uint32_t blocks = nPairs < 65536 ? nPairs : 65536;
+	if (unitBlocks == 0) {   // two pairs per wave (launchEditDistances sends the pairs with a small first band here)
+		blocks = (nPairs + 1) / 2 < 65536 ? (nPairs + 1) / 2 : 65536;
+		hipLaunchKernelGGL(k_edit_distance_half, dim3(blocks), dim3(64), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance);
+		return;
+	}
 	switch (unitBlocks) {
 		case 1: hipLaunchKernelGGL(k_edit_distance<1>, dim3(blocks), dim3(64), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance); break;
 		case 2: hipLaunchKernelGGL(k_edit_distance<2>, dim3(blocks), dim3(64), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance); break;
