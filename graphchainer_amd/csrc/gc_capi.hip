@@ -2032,9 +2032,14 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				hJobsPS[r] = PathSeqJob { onDevice ? stitchInfo[r].start : ((1ull << 63) | glue[r].stitchedBegin), nCells, onDevice ? stitchInfo[r].len : (uint32_t)sp.nodes.size(), (uint32_t)sp.cells, sp.firstOffset, sp.lastOffset };
 				if (sp.cells) {
 					uint32_t len = (uint32_t)(R->offsets[r + 1] - R->offsets[r]);
-					// first band: the length difference plus ~14 % of the shorter sequence (ONT-like error rates pass in one sweep)
+					// first band: the length difference plus ~14 % of the shorter sequence (ONT-like error rates pass in one sweep) - widened to 20 %
+					// where that still fits the two-pairs-per-wave kernel: a wave's time follows the number of columns, not the band, so the wider
+					// band is free there and spares the pairs above 14 % their second sweep
 					uint32_t cells = (uint32_t)sp.cells, shorter = std::min(cells, len), longer = std::max(cells, len);
-					hPairs[nPairs++] = EdPair { nCells, cells, (uint32_t)r, (uint32_t)r, (longer - shorter) + std::max<uint32_t>(64, shorter / 7) };
+					uint32_t firstBand = (longer - shorter) + std::max<uint32_t>(64, shorter / 7);
+					const uint32_t halfLimit = editDistanceMaxK(0);
+					if (firstBand < halfLimit) firstBand = std::max(firstBand, std::min<uint32_t>(halfLimit - 1, (longer - shorter) + shorter / 5));
+					hPairs[nPairs++] = EdPair { nCells, cells, (uint32_t)r, (uint32_t)r, firstBand };
 					pairRead.push_back((uint32_t)r);
 				}
 				nCells += sp.cells;
