@@ -69,6 +69,8 @@ struct DeviceBuffer {   // growable device allocation owned by a stream object
 std::mutex g_longPassToken[16];
 
 double nowUs() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// CPU time of the whole process (all threads), for GC_DEBUG_TIMES' host budget lines
+static double processCpuMs() { timespec ts {}; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; }
 
 // Waiting for a stream: hipStreamSynchronize spins, and a batch has two host threads waiting most of its 250 ms. GC_SPIN_SYNC=0 waits on
 // an event created with hipEventBlockingSync instead (the thread sleeps until the interrupt) - for hosts where the CPUs are scarcer than
@@ -1309,6 +1311,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 	if (P->split_len < 16 || P->split_len > 64 || P->split_gap < 1) return fail(GC_ERR_INVALID, "split_len must be in [16,64] (one 64-row slice per fragment extension) and split_gap >= 1");
 	*out = nullptr;
 	const double tCall = nowUs();
+	const double cpuCall = processCpuMs();
+	double cpuJoined = cpuCall;
 	gc_result* res = (gc_result*)calloc(1, sizeof(gc_result));
 	int rc = guarded([&]() {
 		HIP_CHECK(hipSetDevice(st->device));   // the current device is per host thread
@@ -1812,6 +1816,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		caps.capTable = std::max(1u, G->maxMpcWidth);
 		caps.capBack = (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)caps.capAnchors * ((uint64_t)G->maxBackPerNode + G->maxPathsPerNode));   // threshold lists: backward links + paths of the start node
 		res->host_us[0] = nowUs() - tGlue;
+		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc cpu] %.0f ms of process CPU up to the end of the host glue\n", processCpuMs() - cpuCall);
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] seed expand+order %.1f ms, whole-read setup %.1f ms, fragment windows+arrays %.1f ms (windows %.1f, sizes+buffers %.1f, arrays %.1f)\n", (tOrdered - tGlue) / 1e3, (tLongStarted - tOrdered) / 1e3, (nowUs() - tLongStarted) / 1e3,
 			(tWindows - tLongStarted) / 1e3, (tReserved - tWindows) / 1e3, (nowUs() - tReserved) / 1e3);
 
@@ -2076,6 +2081,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			});
 		}
 		double stitchUs = nowUs() - tStitch;
+		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc cpu] %.0f ms up to the end of stitching + chain edit distances\n", processCpuMs() - cpuCall);
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] chain stitching + its edit distances %.1f ms (%llu reads stitched on the host)\n", stitchUs / 1e3, (unsigned long long)hostStitched.load());
 		res->counters[7] = hostStitched.load();   // reads whose chain was stitched on the host
 
@@ -2086,6 +2092,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			double tJoin0 = nowUs();
 			for (auto& t : longThreads) t.join();
 			tJoined = nowUs();
+			cpuJoined = processCpuMs();
 			if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] main thread waited %.1f ms for the whole-read pass\n", (tJoined - tJoin0) / 1e3);
 			for (auto& e : longErrors) if (e) std::rethrow_exception(e);
 			finishLongGroups();
@@ -2388,6 +2395,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			});
 		});
 		res->host_us[1] = nowUs() - tAsm;
+		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc cpu] %.0f ms up to the end of the batch (the join came at %.0f)\n", processCpuMs() - cpuCall, cpuJoined - cpuCall);
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] batch timeline (ms from the call): whole-read pass started %.1f, joined %.1f, assembly began %.1f, done %.1f\n", (tLongWall0 - tTotal) / 1e3, (tJoined - tTotal) / 1e3, (tAsm - tTotal) / 1e3, (nowUs() - tTotal) / 1e3);
 		return (int)GC_OK;
 	});
