@@ -292,7 +292,7 @@ struct gc_stream {
 	int device = 0;             // the device the stream was created on; gc_align_batch selects it for the calling thread
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[12] {};
-	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, readSeeds, fragFirstSeed, extLists, pendingFrags, fragNext, roundCounts, work, results, scratch, scratchRetry, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
+	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, readSeeds, fragFirstSeed, longRetryList, extLists, pendingFrags, fragNext, roundCounts, work, results, scratch, scratchRetry, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
 	PinnedBuffer hMatches, hReadSeeds, hFragFirstSeed, hFrags, hJobs, hAnchors, hFragStatus, hFragExtended, hChainOut, hChainLen, hChainScore, hChainStatus, hPathPool, hSmall;
 	// whole-read pass: runs on its own stream, concurrently with the fragment kernels
 	hipStream_t longStream = nullptr;
@@ -1555,6 +1555,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			LongWorkResult* dLongWorkResults = st->longWorkResults.reserve<LongWorkResult>(workCapacity);
 			uint32_t* dCandSeed = st->longCandSeed.reserve<uint32_t>(workCapacity);
 			uint32_t* dWorkLen = st->longWorkLen.reserve<uint32_t>(workCapacity);   // written by k_long_select, sorted into dOrder by k_long_order: the host only
+			uint32_t* dRetryList = st->longRetryList.reserve<uint32_t>(workCapacity);   // work items whose band outgrew the register tables (per round)
 			uint32_t* dOrder = st->longOrder.reserve<uint32_t>(workCapacity);       // learns the round's work count (k_publish: no copy-engine transfer in the round loop)
 			groupBegin.assign(nGroups + 1, 0); groupTraceBegin.assign(nGroups + 1, 0);
 			for (uint32_t g = 0; g <= nGroups; g++) groupBegin[g] = n * g / nGroups;
@@ -1632,10 +1633,13 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					if (team == 1) {
 						// extensions whose band outgrew the 64-entry register tables: second try with the LDS/HBM tables (two lanes per wave,
 						// 28 + 228 entries); waves whose items are fine leave at once. Beyond that the read goes to the plain-layout fallback.
-						launchZeroWords(q, cursor + 2, 1);
-						uint32_t retryBlocks = std::min<uint32_t>((nWorkItems + 1) / 2, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / 2));
-						launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 2, retryBlocks,
-							dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, EXT_LDS_CAP);
+						// (those items are listed first - almost always none - so that the retry is a handful of waves that fetch from the list, not
+						// one wave per pair of work items that looks at a status and leaves: that cost 0.5-2 ms of every round)
+						launchZeroWords(q, cursor + 2, 2);   // [2] next slot, [3] length of the retry list
+						launchLongRetryList(q, dLongWorkResults + w0, nWorkItems, EXT_LDS_CAP, dRetryList + w0, cursor + 3);
+						uint32_t retryBlocks = std::min<uint32_t>(256, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / 2));
+						launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dRetryList + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 2, retryBlocks,
+							dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, EXT_LDS_CAP, cursor + 3);
 					}
 					HIP_CHECK(hipEventRecord(ev1, q));
 					launchLongMerge(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, dCandSeed + w0, dLongWorkResults + w0, dRoundTrace + groupTraceBeginPtr[g], maxAlignments, dLongState + r0, dLongAlns, dLongCells, dLongCursor, cellBudget);

@@ -891,9 +891,10 @@ template <int LANES, bool PERSISTENT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LANES == 1 ? 8 : GC_LONG_MIN_WAVES, 8))) k_long_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint64_t* __restrict__ masks, ExtendConfig cfg,
 	const LongWork* __restrict__ work, const uint32_t* __restrict__ order, uint32_t nWork, unsigned long long* __restrict__ scratch, uint64_t wordsPerLane,
 	unsigned long long* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, LongWorkResult* __restrict__ results, unsigned long long* __restrict__ counters,
-	unsigned long long* __restrict__ nextSlot, uint32_t retryStatus)
+	unsigned long long* __restrict__ nextSlot, uint32_t retryStatus, const unsigned long long* __restrict__ nWorkOnDevice)
 {
 	__shared__ WaveLdsT<LANES> lds;
+	if (nWorkOnDevice) nWork = (uint32_t)*nWorkOnDevice;   // (the retry launch: its items are a list another kernel has just written)
 	// One extension per wave (LANES == 1): all 64 lanes stay alive and run the same code on the same values - nothing depends
 	// on the lane id, so the compiler keeps the extension's state in scalar registers - and the lanes' VGPRs hold the 64
 	// backtrace columns. Stores hit one address with one value; atomics and the result record go through lane 0 only.
@@ -1180,17 +1181,17 @@ uint32_t longExtendTeamSize(uint32_t nWork)
 
 void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
 	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters,
-	unsigned long long* nextSlot, uint32_t retryStatus)
+	unsigned long long* nextSlot, uint32_t retryStatus, const unsigned long long* nWorkOnDevice)
 {
 	if (!nWork) return;
 	uint64_t words = longWaveWordsPerLane(cfg);
-	const bool persistent = (uint64_t)blocks * lanes < nWork;   // fewer lanes than work items: waves loop and fetch
+	const bool persistent = nWorkOnDevice || (uint64_t)blocks * lanes < nWork;   // fewer lanes than work items (or a count only the device knows): waves loop and fetch
 	// GC_LONG_WAVES_PER_SIMD=w (experiment): an unused dynamic LDS allocation per wave caps the kernel at w waves per SIMD, leaving wave slots
 	// and registers to the fragment pipeline's kernels that share the device with it
 	static const uint32_t ldsPad = []() { const char* e = getenv("GC_LONG_WAVES_PER_SIMD"); int w = e ? atoi(e) : 0; return (w >= 1 && w <= 7) ? (uint32_t)((160u * 1024u / (4u * (uint32_t)w)) & ~255u) : 0u; }();
 	const uint32_t pad = lanes == 1 ? ldsPad : 0;
-#define GC_LAUNCH_TEAM(N) do { if (persistent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, true>), dim3(blocks), dim3(64), pad, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot, retryStatus); \
-	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, false>), dim3(blocks), dim3(64), pad, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot, retryStatus); } while (0)
+#define GC_LAUNCH_TEAM(N) do { if (persistent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, true>), dim3(blocks), dim3(64), pad, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot, retryStatus, nWorkOnDevice); \
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, false>), dim3(blocks), dim3(64), pad, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot, retryStatus, nWorkOnDevice); } while (0)
 	switch (lanes) {
 		case 1: GC_LAUNCH_TEAM(1); break;
 		case 2: GC_LAUNCH_TEAM(2); break;
@@ -1243,6 +1244,17 @@ void launchBuildFragmentWork(hipStream_t stream, const DGraph& g, const Fragment
 	uint64_t totalBases, uint32_t splitLen, FragSeed* fragSeeds, ExtItem* work, ExtResult* results)
 {
 	if (nFrags) hipLaunchKernelGGL(k_build_fragment_work, dim3((nFrags + 255) / 256), dim3(256), 0, stream, g, frags, fragFirstSeed, nFrags, readSeeds, readOffsets, totalBases, splitLen, fragSeeds, work, results);
+}
+// work items of a round whose extension ended with `status` (EXT_LDS_CAP: the band outgrew the register tables), as a list for the retry launch:
+// almost always empty, so the retry costs one small kernel and a handful of waves instead of one wave per pair of work items
+__global__ void __launch_bounds__(256) k_long_retry_list(const LongWorkResult* __restrict__ results, uint32_t nWork, uint32_t status, uint32_t* __restrict__ list, unsigned long long* __restrict__ listCount)
+{
+	const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+	if (w < nWork && results[w].status == status) list[atomicAdd(listCount, 1ull)] = w;
+}
+void launchLongRetryList(hipStream_t stream, const LongWorkResult* results, uint32_t nWork, uint32_t status, uint32_t* list, unsigned long long* listCount)
+{
+	if (nWork) hipLaunchKernelGGL(k_long_retry_list, dim3((nWork + 255) / 256), dim3(256), 0, stream, results, nWork, status, list, listCount);
 }
 void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, const uint32_t* candSeed, const LongWorkResult* results,
 	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity)

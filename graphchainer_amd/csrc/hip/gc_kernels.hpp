@@ -153,7 +153,8 @@ void launchLongSelect(hipStream_t stream, const DGraph& g, const LongJob* jobs, 
 uint32_t longExtendTeamSize(uint32_t nWork);
 void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
 	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters,
-	unsigned long long* nextSlot, uint32_t retryStatus = 0);   // retryStatus != 0: only work items whose result has that status (e.g. EXT_LDS_CAP) are run
+	unsigned long long* nextSlot, uint32_t retryStatus = 0, const unsigned long long* nWorkOnDevice = nullptr);   // nWorkOnDevice: `order` is a list whose length only the device knows (then nWork is its upper bound)
+void launchLongRetryList(hipStream_t stream, const LongWorkResult* results, uint32_t nWork, uint32_t status, uint32_t* list, unsigned long long* listCount);   // retryStatus != 0: only work items whose result has that status (e.g. EXT_LDS_CAP) are run
 void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, const uint32_t* candSeed, const LongWorkResult* results,
 	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity);
 // ---- path sequences + NW edit distances (gc_editdist.hip)
