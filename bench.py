@@ -237,7 +237,10 @@ def main():
             pass
         return time.process_time()
 
-    warmup_done = max(args.warmup, 1 if args.warmup and inflight > 1 else 0)
+    # every stream in flight allocates its buffers (tens of GB of extension scratch, pinned staging) in its first batch: with W > 0 each of
+    # them gets a warm-up batch, or the second stream's allocations would fall into the timed steps (W=1 with two streams measured 875 ms
+    # per batch instead of 230)
+    warmup_done = max(args.warmup, inflight) if args.warmup else 0
     run_steps(warmup_done)
     sync()
     cpu_start = cpu_seconds()
