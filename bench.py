@@ -105,7 +105,9 @@ def cpu_baseline_leg(args, gfa, reads, long_pass):
     n1 = min(args.cpu_sample, len(reads))
     wall1, stage1 = ora.align_timed(reads[:n1], 1)
     n_all = min(len(reads), max(n1, 250 * threads))   # ~10-15 s at the ~20 reads/s a core does
-    wall_all, _ = ora.align_timed(reads[:n_all], threads)
+    # the same run keeps 12 values per read (chain, chain score, both NW distances, the decision, the whole-read alignments and the
+    # selection): main() compares them with the timed GPU output after the timed region ("parity_check")
+    wall_all, _, summary = ora.align_summary(reads[:n_all], threads)
     ora.close()
     stage_names = ["seeding", "whole_read_pass", "fragment_extension+anchors", "chaining", "stitching+edlib"]
     total = float(stage1.sum()) or 1.0
@@ -113,7 +115,7 @@ def cpu_baseline_leg(args, gfa, reads, long_pass):
             "sample": f"first {n_all} reads of the same workload, same stages, {threads} worker threads over a shared read queue, {wall_all:.1f} s; one thread: first {n1} reads, {wall1:.1f} s",
             "cpu_model": cpu_model(), "host_hardware_threads": os.cpu_count(), "usable_cpus": usable_cpus(),
             "single_thread_reads_per_s": round(n1 / wall1, 2),
-            "single_thread_stage_share": {k: round(float(v) / total, 3) for k, v in zip(stage_names, stage1)}}
+            "single_thread_stage_share": {k: round(float(v) / total, 3) for k, v in zip(stage_names, stage1)}}, summary
 
 
 def main():
@@ -134,9 +136,9 @@ def main():
     reads = sg.sample_reads(args.reads, args.read_len, seed=11 + (0 if strong else rank), sv_fraction=args.sv_fraction)
     t_gen = time.time() - t0
 
-    cpu_baseline = None
+    cpu_baseline = cpu_summary = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = cpu_baseline_leg(args, gfa, reads, long_pass)   # before any HIP call of this process
+        cpu_baseline, cpu_summary = cpu_baseline_leg(args, gfa, reads, long_pass)   # before any HIP call of this process
 
     dist = None
     if world > 1:
@@ -156,7 +158,7 @@ def main():
         if "GC_BENCH_INFLIGHT" not in os.environ and not any(a.startswith("--inflight") for a in sys.argv[1:]):
             args.inflight = 1
     import graphchainer_amd as gca
-    from graphchainer_amd.workqueue import ReadQueue, length_sorted_batches, run_queue
+    from graphchainer_amd.workqueue import SUMMARY_FIELDS, ReadQueue, length_sorted_batches, read_summary, run_queue
 
     if gca.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -241,7 +243,13 @@ def main():
     # them gets a warm-up batch, or the second stream's allocations would fall into the timed steps (W=1 with two streams measured 875 ms
     # per batch instead of 230)
     warmup_done = max(args.warmup, inflight) if args.warmup else 0
-    run_steps(warmup_done)
+    if warmup_done:
+        # static hand-out, outside the (possibly cross-rank) queue: stream i of this rank runs warm-up items i, i + inflight, ... so that
+        # every stream of every rank has done its first-batch allocations before the timed steps, whatever the dynamic queue would do
+        from concurrent.futures import ThreadPoolExecutor
+        n_items = warmup_done * (1 if strong else len(batches))
+        with ThreadPoolExecutor(max_workers=inflight) as warm:
+            list(warm.map(lambda i: [aligners[i].align_batch(batches[(item + rank) % len(batches)]) and None for item in range(i, n_items, inflight)], range(inflight)))
     sync()
     cpu_start = cpu_seconds()
     t_start = time.perf_counter()
@@ -249,6 +257,28 @@ def main():
     sync()
     elapsed = time.perf_counter() - t_start
     host_cpu_s = cpu_seconds() - cpu_start
+    # Parity of the timed mode (src/Aligner.cpp:630-654,735,901-905): the reads the CPU leg aligned with the oracle are compared, value
+    # for value, with what EVERY timed batch returned for them - chain, chain score, both NW distances, the decision, the whole-read
+    # alignments and the selection. Outside the timed region; a mismatch fails the run.
+    parity_check = None
+    if cpu_summary is not None:
+        mismatches, checked, fields_bad = 0, 0, {}
+        for _item, (b, out) in outs:
+            original = np.asarray(chunks[b], dtype=np.int64)
+            rows = np.nonzero(original < len(cpu_summary))[0]
+            if not len(rows):
+                continue
+            got = read_summary(out)[rows]
+            bad = got != cpu_summary[original[rows]]
+            checked += len(rows)
+            mismatches += int(bad.any(axis=1).sum())
+            for k in np.nonzero(bad.any(axis=0))[0]:
+                fields_bad[SUMMARY_FIELDS[k]] = fields_bad.get(SUMMARY_FIELDS[k], 0) + int(bad[:, k].sum())
+        parity_check = {"reads": int(len(cpu_summary)), "timed_batches_checked": len(outs), "read_results_compared": checked, "mismatches": mismatches,
+                        "fields": "anchors, chain, chain score, whole-read and chain NW distance, chained_better, whole-read alignments (start, end, score), selection, failed_assertion",
+                        "against": "oracle (CPU leg of this run), same reads"}
+        if mismatches:
+            parity_check["fields_with_mismatches"] = fields_bad
     kernel_us = np.zeros(8)
     host_us = np.zeros(4)
     counters = np.zeros(8, dtype=np.float64)
@@ -340,6 +370,7 @@ def main():
             "roofline": roofline,
             "roofline_other": roof_extend if roofline is roof_long else roof_long,
             "cpu_baseline": cpu_baseline,
+            "parity_check": parity_check,
             # inputs are resident before the timed region; what putting them there costs (host-side packing + PCIe), and the rate with it included
             "reads_upload": {"ms_per_step": round(upload_s * 1e3, 2), "bases": total_bases, "reads_per_s_including_upload": round(reads_total / (elapsed + upload_s * steps * (1 if not strong else 1)), 2)},
             "host_cpu_s_per_step": round(host_cpu_s / max(1, args.steps), 3),   # CPU time the container spent per step (all threads, this rank's box)
@@ -355,9 +386,12 @@ def main():
                           "seeds_extended_mean": round(float(seeds_ext_long.mean()), 2) if len(seeds_ext_long) else None, "seeds_extended_max": int(seeds_ext_long.max()) if len(seeds_ext_long) else None} if long_pass else None,
         }
         print(json.dumps(line))
+    queue.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_check is not None and parity_check["mismatches"]:
+        raise SystemExit(f"parity check failed: {parity_check['mismatches']} of {parity_check['read_results_compared']} timed read results differ from the oracle")
 
 
 if __name__ == "__main__":

@@ -363,7 +363,7 @@ class BatchResult(dict):
 class Aligner:
     """Batched stand-in for the reference's per-read hot path (src/Aligner.cpp:601-922)."""
 
-    def __init__(self, graph, seeder, bandwidth=10, split_len=35, split_gap=35, colinear_gap=10000, seed_density=10.0, keep_traces=False, keep_seeds=False, long_pass=False, stitch=True, edit_distances=True, chain_traces=1, e_cutoff=-1.0):
+    def __init__(self, graph, seeder, bandwidth=10, split_len=35, split_gap=35, colinear_gap=10000, seed_density=10.0, keep_traces=False, keep_seeds=False, long_pass=False, stitch=True, edit_distances=True, chain_traces=None, e_cutoff=-1.0):
         self.lib = load_library()
         self.graph = graph
         self.seeder = seeder
@@ -379,7 +379,10 @@ class Aligner:
         self.params.long_pass = int(long_pass)
         self.params.stitch = int(stitch)
         self.params.edit_distances = int(edit_distances)
-        self.params.chain_traces = int(chain_traces)
+        # the chained alignment's trace costs a k_edit_path run, the op strings coming down and ~13 B per trace cell of result memory; without
+        # the whole-read pass EVERY read with a stitched path "wins" (src/Aligner.cpp:905: nothing to beat), so a caller that only wants anchors
+        # and chains (long_pass=False) gets none unless it asks (chain_traces=1: winners, 2: every read)
+        self.params.chain_traces = int(chain_traces) if chain_traces is not None else (1 if long_pass else 0)
         self.params.e_cutoff = float(e_cutoff)
         self.stream = C.c_void_p()
         _check(self.lib.gc_stream_create(C.byref(self.stream)))

@@ -79,10 +79,12 @@ static void syncStream(hipStream_t q)
 {
 	static const bool spin = !(getenv("GC_SPIN_SYNC") && atoi(getenv("GC_SPIN_SYNC")) == 0);
 	if (spin) { HIP_CHECK(hipStreamSynchronize(q)); return; }
-	static thread_local hipEvent_t events[16] = {};   // one per device this thread has waited on (created once, kept for the thread's life)
+	// one blocking-sync event per device this thread has waited on, destroyed with the thread (the whole-read pass threads live for one batch)
+	struct Events { hipEvent_t e[16] = {}; ~Events() { for (auto& x : e) if (x) (void)hipEventDestroy(x); } };
+	static thread_local Events events;
 	int device = 0;
 	HIP_CHECK(hipGetDevice(&device));
-	hipEvent_t& e = events[device & 15];
+	hipEvent_t& e = events.e[device & 15];
 	if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventBlockingSync | hipEventDisableTiming));
 	HIP_CHECK(hipEventRecord(e, q));
 	HIP_CHECK(hipEventSynchronize(e));
@@ -606,7 +608,7 @@ static void launchEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 		uint32_t unit = editDistanceUnit(hPairs[i].k, len), c = 0;
 		while ((1u << c) < unit) c++;
 		c++;                                                                  // classes 1..5: one pair per wave, units of 1..16 blocks
-		if (halfWaves && unit == 1 && hPairs[i].k < editDistanceMaxK(0) && len < 150000) c = 0;   // class 0: two pairs per wave (small first band)
+		if (halfWaves && unit == 1 && hPairs[i].k < editDistanceMaxK(0) && len <= 131072) c = 0;   // class 0: two pairs per wave (small first band)
 		cls[i] = c;
 		count[c]++;
 	}
@@ -696,6 +698,7 @@ int gc_edit_distance(const char* a, const uint64_t* a_off, const char* b, const 
 		for (uint64_t i = 0; i < n_pairs; i++) {
 			uint32_t m = (uint32_t)(a_off[i + 1] - a_off[i]);
 			pairs[i] = EdPair { a_off[i], m, 0, (uint32_t)i, std::max<uint32_t>(64, (m + reads[i].len) / 16) };
+			if (const char* env = getenv("GC_ED_FIRST_K")) pairs[i].k = (uint32_t)std::max(1, atoi(env));   // test hook: the first band, as small as a whole-read alignment's own bound (score + clipped ends + 8)
 		}
 		DeviceBuffer dA, dB, dMasks, dReads, dPairs, dOut;
 		char* pa = dA.reserve<char>(aBytes); char* pb = dB.reserve<char>(bBytes);
@@ -1596,7 +1599,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				// that proves it finished - so that the rounds of two batches in flight alternate instead of whole passes
 				int deviceNow = 0;
 				HIP_CHECK(hipGetDevice(&deviceNow));
-				static const bool roundToken = getenv("GC_LONG_TOKEN") && atoi(getenv("GC_LONG_TOKEN")) == 2;
+				const bool roundToken = getenv("GC_LONG_TOKEN") && atoi(getenv("GC_LONG_TOKEN")) == 2;   // (read per batch: the tests switch modes inside one process)
 				std::unique_lock<std::mutex> roundLock(g_longPassToken[deviceNow & 15], std::defer_lock);
 
 				for (int round = 0; round < 4096; round++) {
@@ -1744,7 +1747,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				longThreads.emplace_back([&, device, g]() {
 					try {
 						HIP_CHECK(hipSetDevice(device));
-						static const int tokenMode = getenv("GC_LONG_TOKEN") ? atoi(getenv("GC_LONG_TOKEN")) : 1;   // 0 none, 1 one pass at a time, 2 one round's extension kernel at a time
+						const int tokenMode = getenv("GC_LONG_TOKEN") ? atoi(getenv("GC_LONG_TOKEN")) : 1;   // 0 none, 1 one pass at a time, 2 one round's extension kernel at a time
 						std::unique_lock<std::mutex> token(g_longPassToken[device & 15], std::defer_lock);
 						if (tokenMode == 1 && longGroups == 1) token.lock();
 						{ double now = nowUs(), seen = longWallBeginUs.load(); while ((seen == 0.0 || now < seen) && !longWallBeginUs.compare_exchange_weak(seen, now)) {} }

@@ -151,7 +151,9 @@ __global__ void __launch_bounds__(64) k_edit_distance(const EdPair* __restrict__
 		if (k < 1) k = 1;
 		if (k > cap) k = cap;
 		int64_t answer = -2;                         // -2: this G cannot hold the band, the host retries with a larger one
-		if (nU + 1024 + 128 < ED_RING) while (true) {
+		// the letter ring is refilled every 1024 steps up to column t + 2048, so it holds the columns from t + 2048 - ED_RING on; unit B reads
+		// column t' - B for t' < t + 1024: every unit's column is still there iff nU - 1 + 2048 <= ED_RING - 1 (larger pairs: the next unit size)
+		if (nU + 2048 <= ED_RING) while (true) {
 			if (k >= K_MAX && nU > 64) break;   // (with at most one unit per lane there is nothing to keep disjoint: any band width works)
 			// ---- one banded pass
 			uint64_t VP[G], VN[G], eqA[G], eqC[G], eqG[G], eqT[G];
@@ -309,7 +311,7 @@ __global__ void __launch_bounds__(64) k_edit_distance_half(const EdPair* __restr
 		uint32_t k = pair.k > diff ? pair.k : diff;
 		if (k < 1) k = 1;
 		if (k > cap) k = cap;
-		if (more && !(nU + 1024 + 128 < ED_HALF_RING)) more = false;           // (-2: the wider kernels take it)
+		if (more && !(nU + 2048 <= ED_HALF_RING)) more = false;                // the ring must still hold column t - (nU - 1) when it is refilled up to t + 2048 (-2: the wider kernels take it)
 		while (__any(more)) {
 			if (more && k >= ED_HALF_KMAX && nU > 32) more = false;              // -2
 			// ---- one banded pass of every half that still has one to do

@@ -13,7 +13,9 @@ so a rank that finishes early takes more:
         to exactly one rank; torch.distributed (gloo) only synchronises the reset between steps.
   run_queue(queue, align_fn, workers)  -> drives `workers` threads (one gc_stream each) over the queue and returns
         [(batch index, result)] - what bench.py times, and what tests drive with a mocked align_fn on CPU-only boxes.
-  merge_read_results(parts, n_reads, order) -> per-read values back in the caller's read order.
+  merge_read_results(parts, batches, n_reads, key) -> per-read values back in the caller's read order.
+  read_summary(result)                 -> 12 values per read of a batch result (what must match the CPU path read for read:
+        anchors, chain, chain score, both NW distances, the decision, the whole-read alignments and the selection).
 """
 import fcntl
 import os
@@ -39,14 +41,22 @@ class ReadQueue:
         self.lock = threading.Lock()
         self.cursor = 0
         self.shared = dist is not None and world > 1
+        self.fd = None
         if self.shared:
-            # one counter file per job on the node-local temp dir; rank 0 creates it, the others open it after a barrier
-            self.path = path or os.path.join(tempfile.gettempdir(), f"gc_queue_{os.environ.get('MASTER_PORT', 'x')}_{os.getuid()}.bin")
+            # one counter file per job on the node-local temp dir: rank 0 creates it exclusively under a fresh name (mkstemp: O_EXCL, so
+            # nothing pre-placed at a guessable path is written through) and tells the others the path; `path` is for tests
+            names = [None]
             if rank == 0:
-                with open(self.path, "wb") as f:
-                    f.write(struct.pack("<q", 0))
-            dist.barrier()
-            self.fd = os.open(self.path, os.O_RDWR)
+                if path is None:
+                    fd, path = tempfile.mkstemp(prefix="gc_queue_", suffix=".bin")
+                else:
+                    fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+                os.pwrite(fd, struct.pack("<q", 0), 0)
+                os.close(fd)
+                names = [path]
+            dist.broadcast_object_list(names, src=0)
+            self.path = names[0]
+            self.fd = os.open(self.path, os.O_RDWR | getattr(os, "O_NOFOLLOW", 0))
 
     def reset(self, n_items=None):
         """Start of a pass: every rank has drained the queue (barrier), rank 0 rewinds it, everyone sees the rewound cursor.
@@ -81,8 +91,9 @@ class ReadQueue:
             return self.cursor - 1
 
     def close(self):
-        if self.shared:
+        if self.shared and self.fd is not None:
             os.close(self.fd)
+            self.fd = None
             if self.rank == 0:
                 try:
                     os.remove(self.path)
@@ -116,3 +127,51 @@ def merge_read_results(parts, batches, n_reads, key, fill=0):
     for b, res in parts:
         out[np.asarray(batches[b], dtype=np.int64)] = np.asarray(res[key], dtype=np.int64)
     return out
+
+
+SUMMARY_FIELDS = ["anchors", "chain_len", "chain_hash", "chain_score", "long_edit_distance", "chain_edit_distance", "chained_better",
+                  "longall", "longall_hash", "selected", "selected_hash", "failed_assertion"]
+
+
+def _list_hash(values, offsets):
+    """Per segment [offsets[r], offsets[r+1]) of `values`: sum (v[i] + 1) * (i + 1) * 2654435761 mod 2^64, i counted inside the segment."""
+    offsets = np.asarray(offsets, dtype=np.int64)
+    n = len(offsets) - 1
+    v = np.asarray(values, dtype=np.int64).astype(np.uint64)
+    if len(v) == 0:
+        return np.zeros(n, dtype=np.int64)
+    local = np.arange(len(v), dtype=np.int64) - np.repeat(offsets[:-1], np.diff(offsets))
+    with np.errstate(over="ignore"):
+        terms = (v + np.uint64(1)) * ((local.astype(np.uint64) + np.uint64(1)) * np.uint64(2654435761))
+        csum = np.concatenate([np.zeros(1, dtype=np.uint64), np.cumsum(terms, dtype=np.uint64)])
+        return (csum[offsets[1:]] - csum[offsets[:-1]]).view(np.int64)
+
+
+def read_summary(out):
+    """[n, 12] int64: SUMMARY_FIELDS of every read of a batch result (a dict as Aligner.align_batch returns it; the selected whole-read
+    alignments either as `long_index` into the read's alignment list or as `long_start/end/score`). The chain and alignment lists enter
+    as order-sensitive 64-bit hashes, so two results agree on a read iff its chain, scores, distances, decision and alignments agree."""
+    i64 = lambda k: np.asarray(out[k]).astype(np.int64)
+    chain_off, anchor_off, all_off, sel_off = i64("read_chain_off"), i64("read_anchor_off"), i64("read_longall_off"), i64("read_long_off")
+    n = len(chain_off) - 1
+    triples = lambda s, e, c: np.stack([s, e, c], axis=1).reshape(-1)
+    everything = triples(i64("longall_start"), i64("longall_end"), i64("longall_score"))
+    if "long_index" in out:
+        sel = np.repeat(all_off[:-1], np.diff(sel_off)) + i64("long_index")
+        selected = triples(i64("longall_start")[sel], i64("longall_end")[sel], i64("longall_score")[sel])
+    else:
+        selected = triples(i64("long_start"), i64("long_end"), i64("long_score"))
+    s = np.zeros((n, 12), dtype=np.int64)
+    s[:, 0] = np.diff(anchor_off)
+    s[:, 1] = np.diff(chain_off)
+    s[:, 2] = _list_hash(i64("chain"), chain_off)
+    s[:, 3] = i64("chain_score")
+    s[:, 4] = i64("long_edit_distance")
+    s[:, 5] = i64("chain_edit_distance")
+    s[:, 6] = i64("chained_better")
+    s[:, 7] = np.diff(all_off)
+    s[:, 8] = _list_hash(everything, 3 * all_off)
+    s[:, 9] = np.diff(sel_off)
+    s[:, 10] = _list_hash(selected, 3 * sel_off)
+    s[:, 11] = i64("failed_assertion")
+    return s

@@ -54,7 +54,10 @@ typedef struct gc_params {
 	                             *    the winner (src/Aligner.cpp:636-654,845,901-905): read_long_off / long_index / *_edit_distance / chained_better */
 	int32_t chain_traces;       /* the chained alignment's trace (edlibAlign(pathseq, read, NW, EDLIB_TASK_PATH) walked over the stitched path,
 	                             *    src/Aligner.cpp:845-897): 0 none, 1 for the reads whose chained alignment wins (default; what the output
-	                             *    encoders need), 2 for every read with a stitched path. Needs stitch and edit_distances. */
+	                             *    encoders need), 2 for every read with a stitched path. Needs stitch and edit_distances. Cost: one k_edit_path
+	                             *    pair per traced read plus ~13 B of result memory per trace cell; with long_pass == 0 every read with a stitched
+	                             *    path counts as a winner (nothing to beat, src/Aligner.cpp:905), i.e. mode 1 then traces them all - pass 0 when
+	                             *    only anchors and chains are wanted. */
 	double  e_cutoff;           /* --E-cutoff (src/AlignerMain.cpp:159,271-274; SelectECutoff src/AlignmentSelection.cpp:57-61,91-99):
 	                             *    alignments with a larger E-value are dropped before selection; -1 (default) keeps all */
 } gc_params;

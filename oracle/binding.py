@@ -51,6 +51,8 @@ def load_oracle_lib():
     lib.gco_set_e_cutoff.argtypes = [C.c_void_p, C.c_double]
     lib.gco_align_timed.restype = C.c_double
     lib.gco_align_timed.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.gco_align_summary.restype = C.c_double
+    lib.gco_align_summary.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     return lib
 
 
@@ -129,6 +131,20 @@ class Oracle:
         stage = np.zeros(5, dtype=np.float64)
         wall = self.lib.gco_align_timed(self.h, b"".join(bs), off.ctypes.data, len(bs), int(threads), stage.ctypes.data)
         return float(wall), stage
+
+    SUMMARY_FIELDS = ["anchors", "chain_len", "chain_hash", "chain_score", "long_edit_distance", "chain_edit_distance", "chained_better",
+                      "longall", "longall_hash", "selected", "selected_hash", "failed_assertion"]
+
+    def align_summary(self, reads, threads=1):
+        """align_timed that keeps 12 values per read (SUMMARY_FIELDS; see gco_align_summary) for bench.py's parity sample.
+        Returns (wall seconds, stage seconds, int64 array [n, 12])."""
+        bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+        off = np.zeros(len(bs) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(b) for b in bs])
+        stage = np.zeros(5, dtype=np.float64)
+        summary = np.zeros((len(bs), 12), dtype=np.int64)
+        wall = self.lib.gco_align_summary(self.h, b"".join(bs), off.ctypes.data, len(bs), int(threads), stage.ctypes.data, summary.ctypes.data)
+        return float(wall), stage, summary
 
     def gaf(self, merge=False):
         """GAF text of the last align() call (read ids r0, r1, ...), the reference's writer restated (oracle/output.hpp)."""

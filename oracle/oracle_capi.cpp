@@ -454,9 +454,14 @@ int gco_align(void* hv, const char* bases, const uint64_t* off, int n)
 }
 
 // CPU baseline leg of bench.py: the reference's threading model (src/Aligner.cpp:1267-1270: one worker per thread over a shared
-// read queue, each with its own reusable state), results discarded. Returns the wall seconds; stage5 (may be NULL) receives
-// the per-stage CPU seconds summed over the workers, in the order seed / whole-read pass / fragments / chaining / stitch + edlib.
-double gco_align_timed(void* hv, const char* bases, const uint64_t* off, int n, int threads, double* stage5)
+// read queue, each with its own reusable state). Returns the wall seconds; stage5 (may be NULL) receives the per-stage CPU seconds
+// summed over the workers, in the order seed / whole-read pass / fragments / chaining / stitch + edlib. `summary` (may be NULL)
+// receives 12 values per read - what bench.py's parity sample compares with the timed GPU output after the timed region
+// (src/Aligner.cpp:630-654,735,901-905): anchors, chain length, chain hash, chain score, whole-read NW distance, chain NW distance,
+// chained_better, whole-read alignments, their (start, end, score) hash, selected alignments, their hash, failed assertion.
+// hash of a list v[0..m) = sum (v[i] + 1) * (i + 1) * 2654435761 mod 2^64 (bench.py computes the same with numpy).
+static uint64_t listHashStep(uint64_t h, uint64_t index, int64_t v) { return h + ((uint64_t)v + 1) * ((index + 1) * 2654435761ull); }
+double gco_align_summary(void* hv, const char* bases, const uint64_t* off, int n, int threads, double* stage5, int64_t* summary)
 {
 	OracleHandle* h = (OracleHandle*)hv;
 	if (threads < 1) threads = 1;
@@ -467,7 +472,24 @@ double gco_align_timed(void* hv, const char* bases, const uint64_t* off, int n, 
 		AlignerState state(h->o.graph);
 		for (int r; (r = next.fetch_add(1)) < n;) {
 			std::string seq(bases + off[r], bases + off[r + 1]);
-			try { h->o.alignRead(seq, state, false, stages[t].data()); } catch (const std::exception&) { state.clear(); }
+			int64_t* out = summary ? summary + 12 * (size_t)r : nullptr;
+			try {
+				ReadResult res = h->o.alignRead(seq, state, false, stages[t].data());
+				if (!out) continue;
+				uint64_t hc = 0, ha = 0, hs = 0;
+				for (size_t i = 0; i < res.chain.size(); i++) hc = listHashStep(hc, i, (int64_t)res.chain[i]);
+				auto alnHash = [](const std::vector<AlignmentItem>& alns) {
+					uint64_t x = 0;
+					for (size_t i = 0; i < alns.size(); i++) { x = listHashStep(x, 3 * i, (int64_t)alns[i].alignmentStart); x = listHashStep(x, 3 * i + 1, (int64_t)alns[i].alignmentEnd); x = listHashStep(x, 3 * i + 2, (int64_t)alns[i].alignmentScore); }
+					return x;
+				};
+				ha = alnHash(res.longAll); hs = alnHash(res.longAlignments);
+				out[0] = (int64_t)res.anchors.size(); out[1] = (int64_t)res.chain.size(); out[2] = (int64_t)hc; out[3] = (int64_t)res.chainScore;
+				out[4] = res.longEditDistance == SIZE_MAX ? -1 : (int64_t)res.longEditDistance;
+				out[5] = res.chainEditDistance == SIZE_MAX ? -1 : (int64_t)res.chainEditDistance;
+				out[6] = res.chainedBetter ? 1 : 0; out[7] = (int64_t)res.longAll.size(); out[8] = (int64_t)ha;
+				out[9] = (int64_t)res.longAlignments.size(); out[10] = (int64_t)hs; out[11] = res.failedAssertion ? 1 : 0;
+			} catch (const std::exception&) { state.clear(); if (out) { for (int k = 0; k < 12; k++) out[k] = 0; out[11] = 2; } }
 		}
 	};
 	std::vector<std::thread> pool;
@@ -478,6 +500,7 @@ double gco_align_timed(void* hv, const char* bases, const uint64_t* off, int n, 
 	if (stage5) for (int k = 0; k < 5; k++) { stage5[k] = 0; for (int t = 0; t < threads; t++) stage5[k] += stages[t][k]; }
 	return wall;
 }
+double gco_align_timed(void* hv, const char* bases, const uint64_t* off, int n, int threads, double* stage5) { return gco_align_summary(hv, bases, off, n, threads, stage5, nullptr); }
 
 const char* gco_gaf(void* hv, int merge) { return ((OracleHandle*)hv)->gaf[merge ? 1 : 0].c_str(); }
 const char* gco_json(void* hv) { return ((OracleHandle*)hv)->json.c_str(); }

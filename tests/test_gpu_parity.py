@@ -264,6 +264,30 @@ def test_edit_distance_kernel(gca):
     assert list(map(int, got)) == want
 
 
+def test_edit_distance_long_low_error_pairs(gca, monkeypatch):
+    """pairs of 131-150 kb at < 1 % error entered the two-pairs-per-wave kernel with k < 1900 (a whole-read alignment's own bound)
+    and read letters from ring slots already overwritten (units beyond 2048 behind a refill that runs 2048 ahead); k_edit_distance<1> had the
+    same window with 8192 slots. GC_ED_FIRST_K makes gc_edit_distance start from such a small band."""
+    import random
+    from oracle.binding import RefUnits, load_oracle_lib
+    try:
+        ref = RefUnits().lib.ref_edit_distance          # the real edlib, compiled from /root/reference where it lies
+    except (FileNotFoundError, OSError):
+        ref = load_oracle_lib().gco_edit_distance
+    rng = random.Random(17)
+    pairs = []
+    for length, rate in [(140_000, 0.006), (149_000, 0.004), (131_072, 0.008), (120_000, 0.01), (400_000, 0.004)]:
+        a = bytes(rng.choice(b"ACGT") for _ in range(length))
+        pairs.append((a, _mutate(rng, a, rate)))
+    want = [int(ref(a, len(a), b, len(b))) for a, b in pairs]
+    for first_k in ("1200", "1850", "3900"):
+        monkeypatch.setenv("GC_ED_FIRST_K", first_k)
+        got = gca.edit_distance([p[0] for p in pairs], [p[1] for p in pairs])
+        assert list(map(int, got)) == want, first_k
+        got = gca.edit_distance([p[1] for p in pairs], [p[0] for p in pairs])
+        assert list(map(int, got)) == want, first_k
+
+
 def _revcomp(s):
     return s[::-1].translate(bytes.maketrans(b"ACGTacgtNn", b"TGCAtgcaNn"))
 
@@ -759,3 +783,132 @@ def test_chain_stitching_device_and_host(gca, tmp_path, monkeypatch, env, kw, ho
         assert on_host == chained
     elif host_expected == "some":
         assert 0 < on_host <= chained
+
+
+def _normalise(out, node_length):
+    got = {k: (v.astype(np.int64) if v.dtype.kind in "ui" and k not in ("counters", "counters_long") else v) for k, v in out.items()}
+    expand_stitched_path(got, node_length)
+    mark_missing_chain_alignments(got)
+    sel = np.repeat(got["read_longall_off"][:-1], np.diff(got["read_long_off"])) + got["long_index"]
+    for key in ("start", "end", "score"):
+        got["long_" + key] = got["longall_" + key][sel]
+    return got
+
+
+@pytest.mark.parametrize("token", ["0", "1", "2"])
+def test_batches_in_flight_equal_serial_and_oracle(gca, tmp_path, monkeypatch, token):
+    """The mode bench.py times: several gc_align_batch calls in flight on ONE device, each on its own gc_stream and host thread
+    (run_queue with workers > 1, the reference's -t workers over one queue, src/Aligner.cpp:1267-1270), whole-read pass on, with the
+    three settings of the per-device whole-read token (none / per pass / per round). Four different read sets go through three
+    Aligners concurrently, twice each; every result array must equal the oracle's AND the same Aligner's serial answer."""
+    from graphchainer_amd.synth import SynthGraph
+    from graphchainer_amd.workqueue import ReadQueue, run_queue
+    from oracle import Oracle
+    monkeypatch.setenv("GC_LONG_TOKEN", token)
+    sg = SynthGraph(300_000, seed=17, repeats=3, repeat_len=1500)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    read_sets = [sg.sample_reads(90, 4000, seed=31), sg.sample_reads(70, 6000, seed=32),
+                 sg.sample_reads(40, 10_000, seed=33, sv_fraction=0.3), sg.sample_reads(120, 2500, seed=34)]
+    read_sets[1].append(read_sets[1][0][:2000] + read_sets[1][3][1000:4000])      # a chimera: several whole-read alignments
+    graph = gca.AlignmentGraph(gfa)
+    seeder = gca.MinimizerSeeder(graph)
+    node_length = graph.array("nodeLength")
+    kw = dict(keep_traces=True, keep_seeds=True, long_pass=True, chain_traces=2)
+    ora = Oracle(gfa, long_pass=True)
+    want = [ora.align(rs) for rs in read_sets]
+    batches = [gca.ReadBatch(rs) for rs in read_sets]
+    aligners = [gca.Aligner(graph, seeder, **kw) for _ in range(3)]
+    serial = [_normalise(aligners[0].align_batch(b), node_length) for b in batches]
+    for s, w in zip(serial, want):
+        compare(s, w, COMPARE_KEYS + LONG_KEYS)
+    items = 2 * len(batches)
+    queue = ReadQueue(items)
+    outs = run_queue(queue, lambda worker, item: aligners[worker].align_batch(batches[item % len(batches)]), workers=3)
+    assert sorted(i for i, _ in outs) == list(range(items))
+    for item, out in outs:
+        got = _normalise(out, node_length)
+        compare(got, want[item % len(batches)], COMPARE_KEYS + LONG_KEYS)
+        compare(got, serial[item % len(batches)], COMPARE_KEYS + LONG_KEYS)
+    assert sum(int(np.sum(w["chained_better"])) for w in want) > 0
+
+
+def test_two_ranks_real_aligner_strong_queue(gca, tmp_path):
+    """BASELINE configs[3]'s shape with the REAL aligner: two ranks (torch.distributed.run, gloo for the barrier and the queue
+    reset only), ONE read set divided by the product's flock'ed work queue, every rank running gc_align_batch on its own
+    gc_streams (both ranks share this box's one GPU: a dry run of the launch path, not a measurement), per-read results merged
+    over the ranks and compared with the oracle's. The launcher starts before anything touches the GPU."""
+    import subprocess
+    import sys
+    import textwrap
+    from graphchainer_amd.synth import SynthGraph
+    from oracle import Oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sg = SynthGraph(200_000, seed=23)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(60, 3000, seed=5) + sg.sample_reads(40, 6000, seed=6, sv_fraction=0.25)
+    want = Oracle(gfa, long_pass=True).align(reads)
+    np.savez(tmp_path / "reads.npz", blob=np.frombuffer(b"".join(reads), dtype=np.uint8), lens=np.array([len(r) for r in reads]))
+    script = tmp_path / "rank.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {root!r})
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        import graphchainer_amd as gca
+        from graphchainer_amd.workqueue import ReadQueue, length_sorted_batches, merge_read_results, run_queue
+        gca.set_device(0)
+        z = np.load({str(tmp_path / "reads.npz")!r})
+        cuts = np.concatenate([[0], np.cumsum(z["lens"])])
+        blob = z["blob"].tobytes()
+        reads = [blob[cuts[i]:cuts[i + 1]] for i in range(len(z["lens"]))]
+        graph = gca.AlignmentGraph({gfa!r})
+        seeder = gca.MinimizerSeeder(graph)
+        aligners = [gca.Aligner(graph, seeder, long_pass=True) for _ in range(2)]
+        chunks = length_sorted_batches(reads, 16)
+        batches = [gca.ReadBatch([reads[i] for i in idx]) for idx in chunks]
+        queue = ReadQueue(len(batches), rank, world, dist, path={str(tmp_path / "queue.bin")!r})
+        keys = ["chain_score", "chain_edit_distance", "long_edit_distance", "chained_better", "n_chain", "n_anchor", "n_long", "long_sum"]
+        for step in range(2):
+            queue.reset()
+            parts = []
+            for b, out in run_queue(queue, lambda w, b: aligners[w].align_batch(batches[b]), workers=2):
+                rec = {{k: np.asarray(out[k]).astype(np.int64) for k in keys[:4]}}
+                rec["n_chain"] = np.diff(out["read_chain_off"].astype(np.int64))
+                rec["n_anchor"] = np.diff(out["read_anchor_off"].astype(np.int64))
+                off = out["read_longall_off"].astype(np.int64)
+                rec["n_long"] = np.diff(off)
+                csum = np.concatenate([[0], np.cumsum(out["longall_start"].astype(np.int64) * 3 + out["longall_end"].astype(np.int64) * 5 + out["longall_score"].astype(np.int64) * 7)])
+                rec["long_sum"] = csum[off[1:]] - csum[off[:-1]]
+                parts.append((b, rec))
+            merged = np.stack([merge_read_results(parts, chunks, len(reads), k, fill=0) for k in keys])
+            # every read is aligned by exactly one rank: the other rank's rows are the fill value 0, so a sum over ranks reassembles
+            # them (the -1 "no distance" values survive: one rank reports -1, the other 0)
+            t = torch.from_numpy(merged.copy())
+            count = torch.tensor([len(parts)])
+            dist.all_reduce(t); dist.all_reduce(count)
+            if rank == 0:
+                assert int(count.item()) == len(batches)
+                np.save({str(tmp_path)!r} + f"/merged{{step}}.npy", t.numpy())
+        queue.close()
+        dist.barrier()
+        if rank == 0:
+            print("RANKS_OK")
+        dist.destroy_process_group()
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", GC_HOST_THREADS="4")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29577", str(script)],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert "RANKS_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    off = want["read_longall_off"]
+    csum = np.concatenate([[0], np.cumsum(want["longall_start"] * 3 + want["longall_end"] * 5 + want["longall_score"] * 7)])
+    expect = np.stack([want["chain_score"], want["chain_edit_distance"], want["long_edit_distance"], want["chained_better"],
+                       np.diff(want["read_chain_off"]), np.diff(want["read_anchor_off"]), np.diff(off), csum[off[1:]] - csum[off[:-1]]])
+    for step in range(2):
+        merged = np.load(tmp_path / f"merged{step}.npy")
+        assert np.array_equal(merged, expect), f"step {step}: rows {np.nonzero((merged != expect).any(axis=1))[0]} differ from the oracle"
+    assert int(np.sum(want["chained_better"])) > 0 and int(np.diff(want["read_chain_off"]).min()) >= 0
