@@ -7,6 +7,7 @@
 #include "host/gc_glue.hpp"
 #include "host/gc_output.hpp"
 #include "host/gc_index_cache.hpp"
+#include "host/gc_correctness.hpp"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
@@ -331,32 +332,6 @@ struct gc_stream {
 };
 
 // ----------------------------------------------------------------------------------------------------
-// reference: src/AlignmentCorrectnessEstimation.cpp:6-70,72-78. libm is only used here, on the host; the
-// device does +, max and >= on these doubles.
-static void buildCorrectnessTables(CorrectnessTables& t)
-{
-	const double correctMean = 0.1875, correctStddev = 0.0955, wrongMean = 0.5, wrongStddev = 0.0291;
-	const int wordSize = 64;
-	t.f2c = log(0.00001);
-	t.f2f = log(1.0 - 0.00001);
-	t.c2f = log(0.0000000001);
-	t.c2c = log(1.0 - 0.0000000001);
-	auto fill = [&](double* out, double mean, double stddev) {
-		std::vector<double> v;
-		for (int i = 0; i <= wordSize / 2; i++) { double val = i; v.push_back(-(val - mean) * (val - mean) / (2 * stddev * stddev)); }
-		double sum = 0;
-		for (double x : v) sum += exp(x);
-		double add = log(1.0 / sum);
-		for (double& x : v) x += add;
-		for (int i = wordSize / 2; i < wordSize; i++) v.push_back(v.back());
-		for (int i = 0; i < 64; i++) out[i] = v[i];
-	};
-	fill(t.correctOdds, correctMean * wordSize, correctStddev * wordSize);
-	fill(t.wrongOdds, wrongMean * wordSize, wrongStddev * wordSize);
-	t.initCorrect = log(0.8);
-	t.initFalse = log(0.2);
-}
-
 // set of bases (A=1,C=2,G=4,T=8) a read character can stand for; 0 = matches nothing.
 // reference: characterMatch / ambiguousMatch, src/GraphAlignerCommon.h:190-297
 static void buildIupacTable(uint8_t* t)
@@ -1631,6 +1606,19 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					if (timedRounds >= LONG_EVENT_RING) collect(timedRounds % LONG_EVENT_RING);
 					hipEvent_t ev0 = ring[2 * (timedRounds % LONG_EVENT_RING)], ev1 = ring[2 * (timedRounds % LONG_EVENT_RING) + 1];
 					HIP_CHECK(hipEventRecord(ev0, q));
+					// one extension per LANE as per-lane state machines (k_long_extend_sm, gc_sm.hip) unless a test asks for a team size or GC_LONG_SM=0;
+					// what outgrows that layout's tables (EXT_SM_DECLINED: more than 32 nodes in a slice, 16 pending, no room for the reserved trace)
+					// is listed and rerun one extension per wave, like the register-table overflows below
+					const bool useSm = team == 1 && !(getenv("GC_LONG_SM") && atoi(getenv("GC_LONG_SM")) == 0);
+					if (useSm) {
+						launchLongExtendSm(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, (uint8_t*)(dLongScratch + (uint64_t)g * scratchLanes * waveWords), scratchLanes * waveWords * 8,
+							dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2);
+						launchZeroWords(q, cursor + 2, 2);   // [2] next slot, [3] length of the list
+						launchLongRetryList(q, dLongWorkResults + w0, nWorkItems, 6u /* EXT_SM_DECLINED */, dRetryList + w0, cursor + 3);
+						const uint32_t declinedBlocks = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nWorkItems, 8192), std::max<uint64_t>(1, scratchLanes - 64));
+						launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dRetryList + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 1, declinedBlocks,
+							dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, 6u, cursor + 3);
+					} else
 					launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, team, blocks,
 						dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2);
 					if (team == 1) {
@@ -1712,6 +1700,15 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				double total = 0;
 				for (int i = 0; i < 11; i++) total += (double)hLongSmall[16 + i];
 				for (int i = 0; i < 11; i++) fprintf(stderr, "[gc stamps] %-16s %6.2f%%  %.3e lane-cycles\n", names[i], 100.0 * hLongSmall[16 + i] / (total > 0 ? total : 1), (double)hLongSmall[16 + i]);
+			}
+#endif
+#ifdef GC_SM_STAMPS
+			{
+				static const char* names[5] = { "B (tile boundary)", "COL (column)", "BT (bt boundary)", "WALK (cell)", "housekeeping+vote" };
+				double total = 0;
+				for (int i = 0; i < 5; i++) total += (double)hLongSmall[16 + i];
+				for (int i = 0; i < 5; i++) fprintf(stderr, "[gc sm stamps] %-18s %6.2f%% of wave-cycles, %.3e executions, %.0f cycles each, %.2f lanes served per execution\n", names[i], 100.0 * hLongSmall[16 + i] / (total > 0 ? total : 1),
+					(double)hLongSmall[21 + i], (double)hLongSmall[16 + i] / std::max<double>(1, (double)hLongSmall[21 + i]), (double)hLongSmall[26 + i] / std::max<double>(1, (double)hLongSmall[21 + i]));
 			}
 #endif
 			if (const char* env = getenv("GC_TEST_FAIL_LONG")) {   // test hook shared with the oracle: this read's whole-read pass "asserts"

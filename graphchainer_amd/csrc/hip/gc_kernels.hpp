@@ -154,6 +154,10 @@ uint32_t longExtendTeamSize(uint32_t nWork);
 void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
 	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters,
 	unsigned long long* nextSlot, uint32_t retryStatus = 0, const unsigned long long* nWorkOnDevice = nullptr);   // nWorkOnDevice: `order` is a list whose length only the device knows (then nWork is its upper bound)
+// the same extensions one per LANE as per-lane state machines (gc_sm.hip); what outgrows its tables answers EXT_SM_DECLINED (6) and is rerun by launchLongExtend
+uint64_t longSmSlabBytes(const ExtendConfig& cfg);
+void launchLongExtendSm(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
+	uint8_t* scratch, uint64_t scratchBytes, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters, unsigned long long* nextSlot);
 void launchLongRetryList(hipStream_t stream, const LongWorkResult* results, uint32_t nWork, uint32_t status, uint32_t* list, unsigned long long* listCount);   // retryStatus != 0: only work items whose result has that status (e.g. EXT_LDS_CAP) are run
 void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, const uint32_t* candSeed, const LongWorkResult* results,
 	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity);
