@@ -69,6 +69,7 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C graphchainer_amd/csrc` (or __graft_entry__.build())")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # see gcDefaultHardwareQueues (gc_capi.hip): must be in place before the first HIP call
     lib = C.CDLL(LIB_PATH)
     lib.gc_last_error.restype = C.c_char_p
     lib.gc_graph_create_from_gfa.argtypes = [C.c_char_p, _P(C.c_void_p)]

@@ -32,6 +32,13 @@ static int fail(int code, const std::string& msg) { g_lastError = msg; return co
 struct DeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
 #define HIP_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw DeviceError(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr); } while (0)
 
+// HIP maps its streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and kernels of different streams that share a hardware queue
+// run one after the other. A batch in flight uses a dozen streams (fragment pipeline, whole-read rounds, edit-distance classes), two batches
+// twice that: on 4 queues the whole-read pass's rounds wait behind the other batch's k_extend / k_chain / k_stitch (kernel trace: 60 ms of
+// foreign kernels between two rounds). 16 queues: 228 -> 209 ms per batch on cfg2; 32 oversubscribe the command processor (290 ms).
+// Set when the library is loaded - before the HIP runtime reads its flags at the first HIP call - and only if the user has not chosen.
+__attribute__((constructor)) static void gcDefaultHardwareQueues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 namespace {
 
 template <typename T>
@@ -1493,6 +1500,11 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			lcfg.maxItems = (uint32_t)std::max<uint64_t>(8192, (maxReadLen / 64 + 3) * 24);   // (slice, node) tiles of one extension: ~8 per slice on cfg2, room for 24
 			lcfg.maxPending = 96;
 			lcfg.maxTrace = (uint32_t)(maxReadLen + maxReadLen / 2 + 512);
+			// column store of the one-extension-per-wave kernel: the DP keeps every column (16 B) so that the backtrace loads its tiles' columns back instead of
+			// recomputing them (45 % of the kernel's column steps). ~2.1 columns per read row on cfg2; an extension that needs more than this room ends
+			// with EXT_OVERFLOW and its read goes to the plain-layout kernel, which recomputes. GC_LONG_MAX_COLS=0: no store (the r2 behaviour).
+			lcfg.maxCols = (uint32_t)(3 * maxReadLen + 4096);
+			if (const char* env = getenv("GC_LONG_MAX_COLS")) lcfg.maxCols = (uint32_t)std::max(0, atoi(env));
 			if (const char* env = getenv("GC_LONG_MAX_ITEMS")) lcfg.maxItems = (uint32_t)std::max(64, atoi(env));
 			if (const char* env = getenv("GC_LONG_REG_CAP")) lcfg.regCap = (uint32_t)std::max(1, std::min(64, atoi(env)));   // test hook: force the LDS-table retry
 			uint64_t waveWords = longWaveWordsPerLane(lcfg);

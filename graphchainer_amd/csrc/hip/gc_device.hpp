@@ -172,6 +172,7 @@ struct ExtendConfig {
 	uint32_t maxSlices;     // SliceInfo capacity (>= numSlices+1)
 	uint32_t maxPending;
 	uint32_t maxTrace;
+	uint32_t maxCols = 0;   // whole-read pass, one extension per wave: columns of the DP kept for the backtrace (0: the backtrace recomputes its tiles)
 	uint32_t regCap = 64;   // whole-read pass, register tables: nodes per slice before the extension is retried with the LDS/HBM tables (test hook, <= 64)
 };
 

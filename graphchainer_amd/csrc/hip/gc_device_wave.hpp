@@ -262,6 +262,7 @@ struct WaveScratch {
 	unsigned long long* base;   // team base
 	uint32_t lane, lanes;
 	uint32_t maxSlices, maxItems, maxTrace;
+	uint32_t maxCols;           // one extension per wave: room for the DP's columns (VP, VN: two words each), kept so that the backtrace need not recompute its tiles; 0 = recompute
 	uint32_t regCap;            // register tables: entries per table (<= 64)
 	bool allLanes;              // all 64 lanes run one extension (identical values): single-record stores go through lane 0 only
 	__device__ __forceinline__ bool storer() const { return !allLanes || threadIdx.x == 0; }
@@ -270,9 +271,10 @@ struct WaveScratch {
 	__device__ __forceinline__ uint64_t sliceBase(uint32_t s) const { return (uint64_t)s * 4; }
 	__device__ __forceinline__ uint64_t itemBase(uint32_t i) const { return (uint64_t)maxSlices * 4 + (uint64_t)i * 8; }
 	__device__ __forceinline__ uint64_t traceBase(uint32_t t, uint32_t which) const { return (uint64_t)maxSlices * 4 + (uint64_t)maxItems * 8 + (uint64_t)which * maxTrace + t; }
-	__device__ __forceinline__ unsigned long long* spillBase() const { return base + ((uint64_t)maxSlices * 4 + (uint64_t)maxItems * 8 + 2ull * maxTrace) * lanes; }
+	__device__ __forceinline__ uint64_t colBase() const { return (uint64_t)maxSlices * 4 + (uint64_t)maxItems * 8 + 2ull * maxTrace; }   // (lanes == 1 whenever maxCols > 0)
+	__device__ __forceinline__ unsigned long long* spillBase() const { return base + ((uint64_t)maxSlices * 4 + (uint64_t)maxItems * 8 + 2ull * maxTrace + 2ull * maxCols) * lanes; }
 };
-__host__ __device__ inline uint64_t waveScratchWords(uint32_t maxSlices, uint32_t maxItems, uint32_t maxTrace) { return (uint64_t)maxSlices * 4 + (uint64_t)maxItems * 8 + 2ull * maxTrace + WAVE_SPILL_WORDS; }
+__host__ __device__ inline uint64_t waveScratchWords(uint32_t maxSlices, uint32_t maxItems, uint32_t maxTrace, uint32_t maxCols = 0) { return (uint64_t)maxSlices * 4 + (uint64_t)maxItems * 8 + 2ull * maxTrace + 2ull * maxCols + WAVE_SPILL_WORDS; }
 
 struct WSlice { int32_t minScore; uint32_t minNode, minOffset, first, count; int32_t bandwidth; int32_t j; uint32_t flags; };
 
@@ -359,10 +361,16 @@ __device__ __forceinline__ WS wsMergeWave(const WS& a, const WS& b)
 
 // (node, slice) tile on a node that is new in this slice; same as computeTile but the previous-slice summary comes
 // in by value and columns (backtrace recompute) go to the LDS column view.
-template <bool COLUMNS, typename LANE_TABLES>
+// MODE 0: DP tile. MODE 1: the backtrace's recompute (columns, their scores and the walk masks stay in the lanes). MODE 2: DP tile whose
+// columns are also left in the lanes' column registers (column c in lane c) for the caller to store: the backtrace then loads them back
+// instead of running the column loop a second time (one extension per wave with a column store, WaveScratch::maxCols).
+// What the preamble leaves for the caller of MODE 2 / the stored-column backtrace: the repaired carries of the row above.
+struct TilePreamble { uint64_t prevHP, prevHN, forceEq; int forceUntil; };
+template <int MODE, typename LANE_TABLES>
 __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t node, WS ws, bool prevExists, int32_t prevStartScore, uint64_t prevHP, uint64_t prevHN,
-	const Eq4& eq, NodeItem& out, const LANE_TABLES& tables, int flatRows, uint32_t& status)
+	const Eq4& eq, NodeItem& out, const LANE_TABLES& tables, int flatRows, uint32_t& status, TilePreamble* preambleOnly = nullptr)
 {
+	constexpr bool COLUMNS = MODE == 1;
 	int nodeLength = g.nodeLength[node];
 	NodeSeq seq = loadNodeSeq(g, node);
 	TileResult r;
@@ -401,6 +409,7 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 	if (flatRows > 0) r.flatMin = ws.score - popc64(ws.VP & ~flatMask) + popc64(ws.VN & ~flatMask);
 	if (COLUMNS) tables.colSet(0, ws);
 	uint64_t forceEq = prevExists ? ~0ull : ~1ull;
+	if (preambleOnly) { preambleOnly->prevHP = prevHP; preambleOnly->prevHN = prevHN; preambleOnly->forceEq = forceEq; preambleOnly->forceUntil = forceUntil; return r; }   // (stored-column backtrace: no column loop)
 #if GC_LEAN_COLUMNS && defined(__HIP_DEVICE_COMPILE__)
 	// One extension per wave: every value below is uniform and the loop is the kernel's scalar-issue bottleneck (80 % of its SALU
 	// instructions, 60 per column as the compiler writes the generic loop further down). Same arithmetic with the per-column overhead cut:
@@ -451,7 +460,7 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 				// (two SGPR operands exceed gfx9's constant bus; M0 as lane select does not count)
-				if (!COLUMNS) {
+				if (MODE == 0) {
 					asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0" : "+v"(plusWord), "+v"(minusWord) : "s"(posS), "s"((uint32_t)(Ph >> 32)), "s"((uint32_t)(Mh >> 32)) : "m0");
 				} else {
 					// backtrace recompute: the column itself goes to lane pos of the column registers (its score follows after the loop)
@@ -526,7 +535,7 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 			int32_t f = ws.score - popc64(ws.VP & ~flatMask) + popc64(ws.VN & ~flatMask);
 			if (f < r.flatMin) { r.flatMin = f; r.flatOffset = (uint32_t)pos; }
 		}
-		if (COLUMNS) tables.colSet((uint32_t)pos, ws);
+		if (MODE != 0) tables.colSet((uint32_t)pos, ws);
 		HP |= hp << pos;
 		HN |= hn << pos;
 	}
@@ -570,6 +579,8 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 		storeSlice(wsx, 0, s0);
 	}
 	uint32_t nItems = 1, nSlices = 1;
+	const bool storeCols = REGCOLS && wsx.maxCols > 0;
+	uint32_t nCols = 0;   // columns in the column store so far
 	GC_MARK_START();
 	int32_t prevMinScore = 0, prevBandwidth = 1, prevJ = -64;
 	double prevCorrect = ct.initCorrect, prevFalse = ct.initFalse;
@@ -655,11 +666,27 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 			typename LaneLdsT<REGCOLS>::Entry pe { 0, 0, 0, ~0ull, 0ull };
 			if (prevExists) pe = L.get((uint32_t)buf, (uint32_t)pi);
 			GC_MARK(1);   // pop + previous-slice lookup
-			TileResult tr = computeTileW<false>(g, pnode, pws, prevExists, (int32_t)pe.w1, pe.a, pe.b, eq, out, L, flatRows, status);
+			const uint32_t tileLength = g.nodeLength[pnode];
+			if (storeCols && nCols + tileLength - 1 > wsx.maxCols) return EXT_OVERFLOW;
+			TileResult tr = storeCols ? computeTileW<2>(g, pnode, pws, prevExists, (int32_t)pe.w1, pe.a, pe.b, eq, out, L, flatRows, status)
+				: computeTileW<0>(g, pnode, pws, prevExists, (int32_t)pe.w1, pe.a, pe.b, eq, out, L, flatRows, status);
 			GC_MARK(2);   // tile columns
 			if (status != EXT_OK) return status;
 			out.minScore = tr.minScore;
-			storeItem(wsx, nItems, out);
+			if (storeCols) {
+				// columns 1 .. length-1 (VP, VN; column c sits in lane c) go to the column store in one coalesced 16 B-per-lane store; the item record
+				// carries their offset in the slot of its minimum (the band tables hold that, the slab's copy is never read in this layout)
+				if (threadIdx.x >= 1 && threadIdx.x < tileLength) {
+					ulonglong2 v;
+					v.x = (unsigned long long)L.cr[0] | ((unsigned long long)L.cr[1] << 32);
+					v.y = (unsigned long long)L.cr[2] | ((unsigned long long)L.cr[3] << 32);
+					*(ulonglong2*)(wsx.base + wsx.colBase() + 2ull * (nCols + threadIdx.x - 1)) = v;
+				}
+				NodeItem stored = out;
+				stored.minScore = (int32_t)nCols;
+				storeItem(wsx, nItems, stored);
+				nCols += tileLength - 1;
+			} else storeItem(wsx, nItems, out);
 			L.pSet(cb, cur.count, pnode, out.sScore, out.minScore, out.HP, out.HN);
 			nItems++;
 			cur.count++;
@@ -881,10 +908,38 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 			if (prevItExists) prevIt = loadItem(wsx, (uint32_t)pi);
 			GC_MARK(7);   // backtrace: item lookups + loads
 			NodeItem scratchItem;
-			computeTileW<true>(g, curNode, itemStart(curIt), prevItExists, prevItExists ? prevIt.sScore : 0, prevItExists ? prevIt.HP : ~0ull, prevItExists ? prevIt.HN : 0ull,
-				eq, scratchItem, L, 0, status);
-			if (scratchItem.eVP != curIt.eVP || scratchItem.eVN != curIt.eVN || scratchItem.eScore != curIt.eScore) status = EXT_ASSERT;
-			cnt.recomputeTiles++; cnt.backtraceTiles++; cnt.columnSteps += g.nodeLength[curNode];
+#if defined(__HIP_DEVICE_COMPILE__)
+			if (storeCols) {
+				// The DP kept this tile's columns: load them back (column c into lane c; column 0 is the item's start column), rebuild the column
+				// scores from the item's bottom-row deltas (score of column c = start score + HP bits 1..c - HN bits 1..c) and make the walk masks -
+				// the tile's column loop is not run a second time (45 % of the kernel's column steps were these recomputes). The preamble (merge with
+				// the row above, first-row repair) is redone because the masks need its carries.
+				TilePreamble pre;
+				computeTileW<1>(g, curNode, itemStart(curIt), prevItExists, prevItExists ? prevIt.sScore : 0, prevItExists ? prevIt.HP : ~0ull, prevItExists ? prevIt.HN : 0ull,
+					eq, scratchItem, L, 0, status, &pre);
+				const uint32_t tileLength = g.nodeLength[curNode];
+				const uint32_t c = threadIdx.x;
+				unsigned long long vp = curIt.sVP, vn = curIt.sVN;
+				if (c >= 1 && c < tileLength) {
+					const ulonglong2 v = *(const ulonglong2*)(wsx.base + wsx.colBase() + 2ull * ((uint32_t)curIt.minScore + c - 1));
+					vp = v.x; vn = v.y;
+				}
+				L.cr[0] = (uint32_t)vp; L.cr[1] = (uint32_t)(vp >> 32); L.cr[2] = (uint32_t)vn; L.cr[3] = (uint32_t)(vn >> 32);
+				const uint64_t upToC = (c >= 63 ? ~0ull : ((2ull << c) - 1)) & ~1ull;   // bits 1..c
+				L.cr[4] = (uint32_t)(curIt.sScore + popc64(curIt.HP & upToC) - popc64(curIt.HN & upToC));
+				const NodeSeq seq = loadNodeSeq(g, curNode);
+				L.walkMasks = false;
+#if GC_LEAN_WALK
+				if (!seq.ambiguous) L.setWalkMasks(seq.w0, seq.w1, eq, pre.forceEq, pre.prevHN);
+#endif
+			} else
+#endif
+			{
+				computeTileW<1>(g, curNode, itemStart(curIt), prevItExists, prevItExists ? prevIt.sScore : 0, prevItExists ? prevIt.HP : ~0ull, prevItExists ? prevIt.HN : 0ull,
+					eq, scratchItem, L, 0, status);
+				if (scratchItem.eVP != curIt.eVP || scratchItem.eVN != curIt.eVN || scratchItem.eScore != curIt.eScore) status = EXT_ASSERT;
+			}
+			cnt.recomputeTiles++; cnt.backtraceTiles++; cnt.columnSteps += g.nodeLength[curNode];   // (the reference's units: it does recompute)
 			if (status != EXT_OK) return status;
 			GC_MARK(8);   // backtrace: column recompute
 		}

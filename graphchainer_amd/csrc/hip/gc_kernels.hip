@@ -906,6 +906,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LANES =
 	wsx.lane = lane;
 	wsx.lanes = LANES;
 	wsx.maxSlices = cfg.maxSlices; wsx.maxItems = cfg.maxItems; wsx.maxTrace = cfg.maxTrace;
+	wsx.maxCols = LANES == 1 ? cfg.maxCols : 0;   // (the column store is laid out for one extension per wave; the region is reserved for every team size)
 	wsx.allLanes = LANES == 1;
 	wsx.regCap = cfg.regCap;
 	ExtCounters cnt {};
@@ -1156,7 +1157,7 @@ void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, 
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<false>), dim3(chainScratchBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, 0u);
 }
 
-uint64_t longWaveWordsPerLane(const ExtendConfig& cfg) { return waveScratchWords(cfg.maxSlices, cfg.maxItems, cfg.maxTrace); }
+uint64_t longWaveWordsPerLane(const ExtendConfig& cfg) { return waveScratchWords(cfg.maxSlices, cfg.maxItems, cfg.maxTrace, cfg.maxCols); }
 
 void launchLongInit(hipStream_t stream, const LongJob* jobs, uint32_t nReads, LongState* state)
 {
