@@ -154,7 +154,7 @@ def main():
     if world > 1 and usable_cpus() < 6 * world:
         # every batch in flight keeps two host threads waiting on the device; when the ranks together would spin on more CPUs than the
         # host grants, let them sleep in the waits instead (GC_SPIN_SYNC=0) and keep one batch in flight per GPU
-        os.environ.setdefault("GC_SPIN_SYNC", "0")
+        os.environ.setdefault("GC_SPIN_SYNC", "2")
         if "GC_BENCH_INFLIGHT" not in os.environ and not any(a.startswith("--inflight") for a in sys.argv[1:]):
             args.inflight = 1
     import graphchainer_amd as gca

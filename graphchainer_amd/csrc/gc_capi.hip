@@ -80,13 +80,23 @@ double nowUs() { return std::chrono::duration<double, std::micro>(std::chrono::s
 // CPU time of the whole process (all threads), for GC_DEBUG_TIMES' host budget lines
 static double processCpuMs() { timespec ts {}; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; }
 
-// Waiting for a stream: hipStreamSynchronize spins, and a batch has two host threads waiting most of its 250 ms. GC_SPIN_SYNC=0 waits on
-// an event created with hipEventBlockingSync instead (the thread sleeps until the interrupt) - for hosts where the CPUs are scarcer than
-// on this pool's boxes; measured here (16-CPU quota, one rank) the sleeping wait costs more than the spinning one: 255 against 237 ms per batch.
+// Waiting for a stream. hipStreamSynchronize spins on a CPU, and a batch has two host threads waiting most of its 200 ms (two batches in
+// flight: four CPUs' worth of spinning, half of what a batch costs the host). Modes (GC_SPIN_SYNC): 2 (default) polls hipStreamQuery and
+// sleeps 40 us between polls - the waits are tens of microseconds late and cost next to no CPU; 1 spins (the r2 behaviour); 0 sleeps on a
+// hipEventBlockingSync event (interrupt-driven; measured slower than spinning on this pool's boxes: 255 against 237 ms per batch).
 static void syncStream(hipStream_t q)
 {
-	static const bool spin = !(getenv("GC_SPIN_SYNC") && atoi(getenv("GC_SPIN_SYNC")) == 0);
-	if (spin) { HIP_CHECK(hipStreamSynchronize(q)); return; }
+	static const int mode = getenv("GC_SPIN_SYNC") ? atoi(getenv("GC_SPIN_SYNC")) : 2;
+	if (mode == 1) { HIP_CHECK(hipStreamSynchronize(q)); return; }
+	if (mode == 2) {
+		static const int pollUs = getenv("GC_SYNC_POLL_US") ? std::max(1, atoi(getenv("GC_SYNC_POLL_US"))) : 40;
+		for (int spins = 0;; spins++) {
+			const hipError_t e = hipStreamQuery(q);
+			if (e == hipSuccess) return;
+			if (e != hipErrorNotReady) HIP_CHECK(e);
+			if (spins >= 4) std::this_thread::sleep_for(std::chrono::microseconds(pollUs));   // (the first few polls back to back: many waits are for kernels of a few microseconds)
+		}
+	}
 	// one blocking-sync event per device this thread has waited on, destroyed with the thread (the whole-read pass threads live for one batch)
 	struct Events { hipEvent_t e[16] = {}; ~Events() { for (auto& x : e) if (x) (void)hipEventDestroy(x); } };
 	static thread_local Events events;
@@ -241,7 +251,8 @@ struct gc_reads {
 	uint32_t* devChunkRead = nullptr;   // read containing the first base of every 64-base chunk of the concatenated forward bases
 	uint64_t* devPacked = nullptr;      // the forward bases, 2 bits each, big-endian inside 64-bit words (for the seed kernel's k-mers)
 	uint64_t* devInvalid = nullptr;     // one bit per forward base: not A, C, G or T (same big-endian convention)
-	~gc_reads() { if (devBases) (void)hipFree(devBases); if (devOffsets) (void)hipFree(devOffsets); if (devMasks) (void)hipFree(devMasks); if (devEqMasks) (void)hipFree(devEqMasks); if (devEdReads) (void)hipFree(devEdReads); if (devChunkRead) (void)hipFree(devChunkRead); if (devPacked) (void)hipFree(devPacked); if (devInvalid) (void)hipFree(devInvalid); }
+	uint8_t* devReadInvalid = nullptr;  // [n] the device's copy of `invalid`
+	~gc_reads() { if (devBases) (void)hipFree(devBases); if (devOffsets) (void)hipFree(devOffsets); if (devMasks) (void)hipFree(devMasks); if (devEqMasks) (void)hipFree(devEqMasks); if (devEdReads) (void)hipFree(devEdReads); if (devChunkRead) (void)hipFree(devChunkRead); if (devPacked) (void)hipFree(devPacked); if (devInvalid) (void)hipFree(devInvalid); if (devReadInvalid) (void)hipFree(devReadInvalid); }
 };
 
 struct StitchedPath { std::vector<uint32_t> nodes; uint32_t firstOffset = 0, lastOffset = 0; uint64_t cells = 0; };
@@ -257,6 +268,7 @@ struct ReadGlue {
 	bool capacityExceeded = false;        // a capacity of this library (not of the reference) was exceeded while processing this read
 	bool capacityExceededLong = false;    // same, raised by the whole-read pass (its own thread; joined into capacityExceeded after the pass)
 	uint64_t slotBegin = 0, fragBegin = 0;
+	uint32_t nSeedsR = 0, nWindows = 0;   // seeds of the read (fragment order, at seedBegin) and fragments that hold seeds
 	uint64_t nAnchors = 0, nPath = 0, nTrace = 0, anchorBegin = 0, pathBegin = 0, traceBegin = 0, seedBegin = 0, chainBegin = 0;
 	StitchedPath stitched;                // chain stitching result
 	bool stitchedOnDevice = false;        // its nodes are also in the device's stitch regions
@@ -278,6 +290,7 @@ struct ReadGlue {
 		longBegin = longTraceBegin = longSeedBegin = 0;
 		failed = longFailed = capacityExceeded = capacityExceededLong = false;
 		slotBegin = fragBegin = 0;
+		nSeedsR = nWindows = 0;
 		nAnchors = nPath = nTrace = anchorBegin = pathBegin = traceBegin = seedBegin = chainBegin = 0;
 		stitchedBegin = longSelectedBegin = 0;
 		longEditDistance = chainEditDistance = -1;
@@ -325,6 +338,8 @@ struct gc_stream {
 	std::vector<hipStream_t> groupStreams;   // read groups of the whole-read pass run their round loops concurrently
 	std::vector<hipEvent_t> groupEvents;     // 2 * LONG_EVENT_RING per group
 	DeviceBuffer longSeeds, longJobs, longAlns, longResults, longScratch, longCells, longCursor, longJobsFallback, longResultsFallback, longScratchFallback;
+	DeviceBuffer gluePerRead, glueCursors, glueOut, glueSeedCap, glueSeedOff, glueWinCapOff, glueU32[8], glueSort, gluePos, glueWin;   // seed glue on the device (gc_seedglue.hip)
+	PinnedBuffer hGlueOut, hGlueWinCapOff, hGlueSmall;
 	DeviceBuffer longState, longWork, longWorkResults, longRoundTrace, longCandSeed, longWorkLen, longOrder;
 	PinnedBuffer hLongSeeds, hLongJobs, hLongAlns, hLongResults, hLongSmall;
 	~gc_stream()
@@ -446,6 +461,17 @@ static void uploadGraph(gc_graph* G)
 	d.pathsOff = G->up(pathsOff); d.paths = G->up(pathsFlat); d.pathsPos = G->up(pathsPos);
 	d.backOff = G->up(backOff); d.backNode = G->up(backNode); d.backPath = G->up(backPath); d.backPos = G->up(backPos);
 	d.mpcWidth = G->up(mpcWidth);
+	{
+		std::vector<uint32_t> chainNumber(n);
+		std::vector<uint64_t> chainApproxPos(n);
+		for (size_t i = 0; i < n; i++) {
+			if (h.chainNumber[i] >= 0xffffffffull) throw std::runtime_error("too many chains for 32-bit chain numbers");
+			chainNumber[i] = (uint32_t)h.chainNumber[i];
+			chainApproxPos[i] = (uint64_t)h.chainApproxPos[i];
+		}
+		d.chainNumber = G->up(chainNumber);
+		d.chainApproxPos = G->up(chainApproxPos);
+	}
 	CorrectnessTables t;
 	buildCorrectnessTables(t);
 	HIP_CHECK(hipMalloc((void**)&G->devTables, sizeof(t)));
@@ -1022,6 +1048,9 @@ static void uploadSeeder(gc_seeder* S)
 	S->dev.table = dTable;
 	S->dev.tableMask = (uint32_t)(tableSize - 1);
 	S->dev.startPos = dStart;
+	uint64_t* dPositions = uploadVector(S->host.positions);   // the occurrence lists: the device expands the seeds itself (gc_seedglue.hip)
+	S->allocations.push_back(dPositions);
+	S->dev.positions = dPositions;
 	S->dev.nKeys = (uint32_t)nKeys;
 	S->dev.maxCount = (uint32_t)std::min<size_t>(S->host.maxCount, 0xffffffffu);
 	S->dev.k = (int32_t)S->host.k;
@@ -1241,11 +1270,12 @@ int gc_reads_upload(const char* bases, const uint64_t* offsets, uint64_t n, gc_r
 		HIP_CHECK(hipMalloc((void**)&R->devPacked, ((total >> 5) + 1) * sizeof(uint64_t)));
 		HIP_CHECK(hipMalloc((void**)&R->devInvalid, ((total >> 6) + 1) * sizeof(uint64_t)));
 		HIP_CHECK(hipMalloc((void**)&R->devChunkRead, ((total >> 6) + 1) * sizeof(uint32_t)));
-		DeviceBuffer dMaskOff, dMaskWords, dEqOff, dReadInvalid;
+		DeviceBuffer dMaskOff, dMaskWords, dEqOff;
 		uint64_t* pMaskOff = dMaskOff.reserve<uint64_t>(n);
 		uint32_t* pMaskWords = dMaskWords.reserve<uint32_t>(n);
 		uint64_t* pEqOff = dEqOff.reserve<uint64_t>(n);
-		uint8_t* pInvalid = dReadInvalid.reserve<uint8_t>(n);
+		HIP_CHECK(hipMalloc((void**)&R->devReadInvalid, std::max<size_t>(n, 1)));
+		uint8_t* pInvalid = R->devReadInvalid;
 		if (total) HIP_CHECK(hipMemcpy(R->devBases, bases, total, hipMemcpyHostToDevice));
 		HIP_CHECK(hipMemcpy(R->devOffsets, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
 		if (n) {
@@ -1326,21 +1356,107 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		mark();   // 0
 		launchSeedLookup(stream, S->dev, R->devBases, R->devOffsets, (uint32_t)n, (uint64_t*)dCursors, dReadMatchOff, dReadMatchCount, dMatches, R->totalBases, dTmp, R->totalBases, R->devChunkRead, R->devPacked, R->devInvalid);
 		mark();   // 1
+		// The glue between the seed lookup and the extension kernels (hit expansion, seed ordering, fragment windows) runs on the device
+		// (gc_seedglue.hip: one wave per read, the reference's three unstable sorts replayed with libstdc++'s own algorithm); GC_DEVICE_GLUE=0
+		// keeps the r2 host path (host/gc_glue.cpp: same results, 1 CPU-second and two bulk transfers per 10 k reads).
+		const bool deviceGlue = !(getenv("GC_DEVICE_GLUE") && atoi(getenv("GC_DEVICE_GLUE")) == 0);
+		std::vector<ReadGlue>& glue = st->glue;   // per-read host records, storage reused across batches
+		if (glue.size() < n) glue.resize(n);
+		gc::KmerMatch* matches = nullptr;
+		double tGlue = 0;
+		// what both paths leave behind for the rest of the batch
+		uint64_t nSlots = 0, nFrags = 0, nSeedsTotal = 0, traceBudget = 0;
+		uint32_t maxSlotsPerRead = 1, maxWindowSeeds = 0;
+		Fragment* frags = nullptr; ReadChainJob* jobs = nullptr;                 // host copies
+		FragSeed* readSeeds = nullptr; uint32_t* fragFirstSeed = nullptr;        // host copies (device glue: only with keep_seeds / keep_traces)
+		Fragment* dFrags = nullptr; uint32_t* dFragFirstSeed = nullptr; FragSeed* dReadSeeds = nullptr; ReadChainJob* dJobs = nullptr;
+		LongSeed* dLongSeeds = nullptr;
+		hipEvent_t glueCopied = nullptr;   // device glue: the host copies of frags / seeds have arrived (waited for before the result assembly)
+		if (deviceGlue) {
+			unsigned long long* dGlueCursors = st->glueCursors.reserve<unsigned long long>(8);
+			uint32_t* dSeedCap = st->glueSeedCap.reserve<uint32_t>(n);
+			uint32_t* dSeedOff = st->glueSeedOff.reserve<uint32_t>(n + 1);
+			unsigned long long* hGlueSmall = st->hGlueSmall.reserve<unsigned long long>(8);
+			HIP_CHECK(hipMemsetAsync(dGlueCursors, 0, 8 * sizeof(unsigned long long), stream));
+			launchSeedCaps(stream, S->dev, (uint32_t)n, R->devReadInvalid, dMatches, dReadMatchOff, dReadMatchCount, dSeedCap, dSeedOff, dGlueCursors + 5);
+			HIP_CHECK(hipMemcpyAsync(hSmall, dCursors, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipMemcpyAsync(hGlueSmall, dGlueCursors, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+			// capacity of the per-read window staging: one window per fragment position (host: the lengths are known)
+			uint32_t* hWinCapOff = st->hGlueWinCapOff.reserve<uint32_t>(n + 1);
+			uint64_t winCap = 0;
+			for (uint64_t r = 0; r < n; r++) {
+				const uint64_t len = R->offsets[r + 1] - R->offsets[r];
+				hWinCapOff[r] = (uint32_t)winCap;
+				winCap += len >= (uint64_t)P->split_len ? (len - P->split_len) / P->split_gap + 1 : 1;
+			}
+			hWinCapOff[n] = (uint32_t)winCap;
+			if (winCap >= 0xffffffffull) throw std::runtime_error("batch too large: more than 2^32 fragment positions; split the batch");
+			uint32_t* dWinCapOff = st->glueWinCapOff.reserve<uint32_t>(n + 1);
+			HIP_CHECK(hipMemcpyAsync(dWinCapOff, hWinCapOff, (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+			syncStream(stream);
+			res->kernel_us[0] = elapsedUs(0, 1);
+			res->host_us[2] = nowUs() - tTotal;   // K1 + its transfers, wall
+			tGlue = nowUs();
+			const uint64_t nMatchesDev = hSmall[0], seedCap = hGlueSmall[5];
+			if (nMatchesDev > R->totalBases) throw std::runtime_error("seed lookup overflowed its buffer");
+			if (seedCap >= 0xfffffff0ull) throw std::runtime_error("batch too large: more than 2^32 seed occurrences; split the batch");
+			nSeedsTotal = seedCap;
+			GlueStaging stg;
+			uint32_t** u32s[8] = { &stg.mPos, &stg.mStartLo, &stg.mStartHi, &stg.sSeqPos, &stg.sNode, &stg.sOffset, &stg.sGood, &stg.sCluster };
+			for (int k = 0; k < 8; k++) *u32s[k] = st->glueU32[k].reserve<uint32_t>(seedCap);
+			stg.sortBuf = (GlueElem*)st->glueSort.reserve<uint8_t>(seedCap * glueElemBytes());
+			stg.posBuf = st->gluePos.reserve<uint32_t>(seedCap);
+			stg.winBuf = st->glueWin.reserve<uint32_t>(4 * winCap);
+			dLongSeeds = st->longSeeds.reserve<LongSeed>(P->long_pass ? seedCap : 0);
+			dReadSeeds = st->readSeeds.reserve<FragSeed>(seedCap);
+			dFrags = st->frags.reserve<Fragment>(winCap);
+			dFragFirstSeed = st->fragFirstSeed.reserve<uint32_t>(winCap);
+			dJobs = st->jobs.reserve<ReadChainJob>(n);
+			GlueRead* dGlueOut = st->glueOut.reserve<GlueRead>(n);
+			GlueRead* hGlueOut = st->hGlueOut.reserve<GlueRead>(n);
+			jobs = st->hJobs.reserve<ReadChainJob>(n);
+			launchSeedGlue(stream, S->dev, G->dev, R->devOffsets, (uint32_t)n, R->devReadInvalid, dMatches, dReadMatchOff, dReadMatchCount, dSeedOff, dWinCapOff, P->seed_density,
+				(uint32_t)P->split_len, (uint32_t)P->split_gap, P->long_pass != 0, stg, st->gluePerRead.reserve<uint32_t>(6 * (n + 1)), dLongSeeds, dReadSeeds, dFrags, dFragFirstSeed, dJobs, dGlueOut, dGlueCursors);
+			if (n) HIP_CHECK(hipMemcpyAsync(hGlueOut, dGlueOut, n * sizeof(GlueRead), hipMemcpyDeviceToHost, stream));
+			if (n) HIP_CHECK(hipMemcpyAsync(jobs, dJobs, n * sizeof(ReadChainJob), hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipMemcpyAsync(hGlueSmall, dGlueCursors, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+			syncStream(stream);
+			nFrags = hGlueSmall[0]; nSlots = hGlueSmall[1]; traceBudget = hGlueSmall[2];
+			maxSlotsPerRead = (uint32_t)std::max<uint64_t>(1, hGlueSmall[3]); maxWindowSeeds = (uint32_t)hGlueSmall[4];
+			for (uint64_t r = 0; r < n; r++) {
+				ReadGlue& gl = glue[r];
+				gl.reset();
+				const GlueRead& g = hGlueOut[r];
+				gl.failed = g.failed != 0;
+				gl.nSeedsR = g.nSeeds; gl.nWindows = g.nFrags;
+				gl.seedBegin = g.seedOff; gl.longSeedBegin = g.seedOff;
+				gl.fragBegin = g.fragBegin; gl.slotBegin = g.slotBegin;
+			}
+			// host copies for the result assembly: the fragments always; the seeds only for the seed_* arrays / the anchor traces
+			frags = st->hFrags.reserve<Fragment>(nFrags);
+			if (nFrags) HIP_CHECK(hipMemcpyAsync(frags, dFrags, nFrags * sizeof(Fragment), hipMemcpyDeviceToHost, stream));
+			if (P->keep_seeds || P->keep_traces) {
+				readSeeds = st->hReadSeeds.reserve<FragSeed>(seedCap);
+				fragFirstSeed = st->hFragFirstSeed.reserve<uint32_t>(nFrags);
+				if (seedCap) HIP_CHECK(hipMemcpyAsync(readSeeds, dReadSeeds, seedCap * sizeof(FragSeed), hipMemcpyDeviceToHost, stream));
+				if (nFrags) HIP_CHECK(hipMemcpyAsync(fragFirstSeed, dFragFirstSeed, nFrags * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+			}
+			glueCopied = st->ev[11];
+			HIP_CHECK(hipEventRecord(glueCopied, stream));
+		} else {
 		if (n) HIP_CHECK(hipMemcpyAsync(readMatchOff, dReadMatchOff, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		if (n) HIP_CHECK(hipMemcpyAsync(readMatchCount, dReadMatchCount, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		HIP_CHECK(hipMemcpyAsync(hSmall, dCursors, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		syncStream(stream);
 		uint64_t nMatches = hSmall[0];
-		gc::KmerMatch* matches = st->hMatches.reserve<gc::KmerMatch>(nMatches);
+		matches = st->hMatches.reserve<gc::KmerMatch>(nMatches);
 		if (nMatches) HIP_CHECK(hipMemcpyAsync(matches, dMatches, nMatches * sizeof(uint2), hipMemcpyDeviceToHost, stream));
 		syncStream(stream);
 		res->kernel_us[0] = elapsedUs(0, 1);
 		res->host_us[2] = nowUs() - tTotal;   // K1 + its transfers, wall
 
 		// ---------------- host glue: order-critical sorts and fragment windows (see host/gc_glue.hpp)
-		double tGlue = nowUs();
-		std::vector<ReadGlue>& glue = st->glue;   // per-read host records, storage reused across batches
-		if (glue.size() < n) glue.resize(n);
+		tGlue = nowUs();
 		pool.run(n, [&](size_t r, size_t) { glue[r].reset(); });
 		std::vector<gc::GlueScratch> scratch(pool.size());
 		pool.run(n, [&](size_t r, size_t worker) {
@@ -1356,6 +1472,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			}
 			if (P->long_pass) gl.longSeeds = gl.seeds;
 		});
+		}
 		double tOrdered = nowUs();
 		// ---------------- K3-long: whole-read pass on its own stream (src/Aligner.cpp:630-654)
 		uint64_t nLongSeeds = 0, maxReadLen = 1;
@@ -1470,9 +1587,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			D.nPairs = 0;
 		};
 		if (P->long_pass) {
-			for (uint64_t r = 0; r < n; r++) { glue[r].longSeedBegin = nLongSeeds; nLongSeeds += glue[r].longSeeds.size(); }
+			if (deviceGlue) nLongSeeds = nSeedsTotal;   // (the device's seed lists sit at the reads' capacity offsets)
+			else for (uint64_t r = 0; r < n; r++) { glue[r].longSeedBegin = nLongSeeds; nLongSeeds += glue[r].longSeeds.size(); }
 			if (nLongSeeds >= 0xffffffffull) throw std::runtime_error("batch too large for the whole-read pass");
-			LongSeed* hSeeds = st->hLongSeeds.reserve<LongSeed>(nLongSeeds);
+			LongSeed* hSeeds = st->hLongSeeds.reserve<LongSeed>(deviceGlue ? 0 : nLongSeeds);
 			LongJob* hJobs = st->hLongJobs.reserve<LongJob>(n);
 			uint64_t cellBudget = 0;
 			uint64_t cellsPerBase = 8;   // room for several partial alignments per read before the end-to-end one
@@ -1481,7 +1599,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			pool.run(n, [&](size_t r, size_t) {
 				const ReadGlue& gl = glue[r];
 				uint64_t at = gl.longSeedBegin;
-				for (const gc::SeedRec& s : gl.longSeeds) {
+				if (deviceGlue) at += gl.nSeedsR;
+				else for (const gc::SeedRec& s : gl.longSeeds) {
 					hSeeds[at++] = LongSeed { s.node, s.seqPos, s.goodness, s.clusterSize, s.offset, 0 };
 				}
 				LongJob& j = hJobs[r];
@@ -1508,7 +1627,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			if (const char* env = getenv("GC_LONG_MAX_ITEMS")) lcfg.maxItems = (uint32_t)std::max(64, atoi(env));
 			if (const char* env = getenv("GC_LONG_REG_CAP")) lcfg.regCap = (uint32_t)std::max(1, std::min(64, atoi(env)));   // test hook: force the LDS-table retry
 			uint64_t waveWords = longWaveWordsPerLane(lcfg);
-			LongSeed* dLongSeeds = st->longSeeds.reserve<LongSeed>(nLongSeeds);
+			if (!deviceGlue) dLongSeeds = st->longSeeds.reserve<LongSeed>(nLongSeeds);
 			LongJob* dLongJobs = st->longJobs.reserve<LongJob>(n);
 			LongAln* dLongAlns = st->longAlns.reserve<LongAln>(n * maxAlignments);
 			LongReadResult* dLongResults = st->longResults.reserve<LongReadResult>(n);
@@ -1535,7 +1654,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			hLongSmall = st->hLongSmall.reserve<unsigned long long>(cursorWords);
 			hipStream_t ls = st->longStream;
 			HIP_CHECK(hipMemsetAsync(dLongCursor, 0, cursorWords * sizeof(unsigned long long), ls));
-			if (nLongSeeds) HIP_CHECK(hipMemcpyAsync(dLongSeeds, hSeeds, nLongSeeds * sizeof(LongSeed), hipMemcpyHostToDevice, ls));
+			if (nLongSeeds && !deviceGlue) HIP_CHECK(hipMemcpyAsync(dLongSeeds, hSeeds, nLongSeeds * sizeof(LongSeed), hipMemcpyHostToDevice, ls));
 			if (n) HIP_CHECK(hipMemcpyAsync(dLongJobs, hJobs, n * sizeof(LongJob), hipMemcpyHostToDevice, ls));
 			syncStream(ls);   // the group streams start from uploaded inputs
 			// rounds: select -> extend -> merge until no read has a seed left to extend (see gc_kernels.hip, "K3-long in rounds")
@@ -1618,10 +1737,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					if (timedRounds >= LONG_EVENT_RING) collect(timedRounds % LONG_EVENT_RING);
 					hipEvent_t ev0 = ring[2 * (timedRounds % LONG_EVENT_RING)], ev1 = ring[2 * (timedRounds % LONG_EVENT_RING) + 1];
 					HIP_CHECK(hipEventRecord(ev0, q));
-					// one extension per LANE as per-lane state machines (k_long_extend_sm, gc_sm.hip) unless a test asks for a team size or GC_LONG_SM=0;
+					// GC_LONG_SM=1 (experiment, off by default: 6x slower as measured): one extension per LANE as per-lane state machines (k_long_extend_sm, gc_sm.hip);
 					// what outgrows that layout's tables (EXT_SM_DECLINED: more than 32 nodes in a slice, 16 pending, no room for the reserved trace)
 					// is listed and rerun one extension per wave, like the register-table overflows below
-					const bool useSm = team == 1 && !(getenv("GC_LONG_SM") && atoi(getenv("GC_LONG_SM")) == 0);
+					const bool useSm = team == 1 && getenv("GC_LONG_SM") && atoi(getenv("GC_LONG_SM")) == 1;
 					if (useSm) {
 						launchLongExtendSm(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, (uint8_t*)(dLongScratch + (uint64_t)g * scratchLanes * waveWords), scratchLanes * waveWords * 8,
 							dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2);
@@ -1768,35 +1887,37 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				});
 		}
 		double tLongStarted = nowUs();
+		double tWindows = tLongStarted, tReserved = tLongStarted;
+		if (!deviceGlue) {
 		pool.run(n, [&](size_t r, size_t) {
 			ReadGlue& gl = glue[r];
 			if (gl.seeds.empty()) return;
 			gc::fragmentWindows(gl.seeds, R->offsets[r + 1] - R->offsets[r], (size_t)P->split_len, (size_t)P->split_gap, gl.windows);
 		});
-		double tWindows = nowUs();
-		uint64_t nSlots = 0, nFrags = 0, nSeedsTotal = 0;
+		tWindows = nowUs();
 		for (uint64_t r = 0; r < n; r++) {
 			glue[r].slotBegin = nSlots;
 			glue[r].fragBegin = nFrags;
 			glue[r].seedBegin = nSeedsTotal;
+			glue[r].nSeedsR = (uint32_t)glue[r].seeds.size();
+			glue[r].nWindows = (uint32_t)glue[r].windows.size();
 			for (const auto& w : glue[r].windows) nSlots += w.sr - w.sl;
 			nFrags += glue[r].windows.size();
 			nSeedsTotal += glue[r].seeds.size();
 		}
-		if (2 * nSlots >= 0xffffffffull) throw std::runtime_error("batch too large: more than 2^31 fragment seeds; split the batch");
 		// The per-slot records (seed in fragment order + its two extensions) are expanded on the device (k_build_fragment_work) from what the
 		// host decides: the read's seeds in the reference's order after its sort by position, and the windows.
-		Fragment* frags = st->hFrags.reserve<Fragment>(nFrags);
-		uint32_t* fragFirstSeed = st->hFragFirstSeed.reserve<uint32_t>(nFrags);
-		FragSeed* readSeeds = st->hReadSeeds.reserve<FragSeed>(nSeedsTotal);
-		ReadChainJob* jobs = st->hJobs.reserve<ReadChainJob>(n);
+		frags = st->hFrags.reserve<Fragment>(nFrags);
+		fragFirstSeed = st->hFragFirstSeed.reserve<uint32_t>(nFrags);
+		readSeeds = st->hReadSeeds.reserve<FragSeed>(nSeedsTotal);
+		jobs = st->hJobs.reserve<ReadChainJob>(n);
 		std::vector<uint64_t> traceBudgets(pool.size(), 0);
 		std::vector<uint32_t> windowSeeds(pool.size(), 0);   // per worker: the most seeds a window holds
-		double tReserved = nowUs();
+		tReserved = nowUs();
 		pool.run(n, [&](size_t r, size_t worker) {
 			const ReadGlue& gl = glue[r];
 			size_t len = R->offsets[r + 1] - R->offsets[r];
-			for (size_t k = 0; k < gl.seeds.size(); k++) readSeeds[gl.seedBegin + k] = FragSeed { gl.seeds[k].node, gl.seeds[k].offset, gl.seeds[k].seqPos, 0 };
+			for (size_t k = 0; k < gl.seeds.size(); k++) readSeeds[gl.seedBegin + k] = FragSeed { gl.seeds[k].node, gl.seeds[k].offset, gl.seeds[k].seqPos, gl.seeds[k].goodness };
 			uint64_t slot = gl.slotBegin;
 			uint64_t budget = 0;
 			for (size_t f = 0; f < gl.windows.size(); f++) {
@@ -1823,11 +1944,14 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			job.fragBegin = (uint32_t)gl.fragBegin;
 			job.nFrags = (uint32_t)gl.windows.size();
 		});
-		uint64_t traceBudget = 0;
 		for (uint64_t b : traceBudgets) traceBudget += b;
+		for (uint32_t m : windowSeeds) maxWindowSeeds = std::max(maxWindowSeeds, m);
+		for (uint64_t r = 0; r < n; r++) maxSlotsPerRead = std::max(maxSlotsPerRead, jobs[r].nSlots);
+		}
+		if (2 * nSlots >= 0xffffffffull) throw std::runtime_error("batch too large: more than 2^31 fragment seeds; split the batch");
 		traceBudget += traceBudget / 4 + (1u << 20);   // room for the extensions that only fit the retry launch's larger trace buffers
 		ChainCaps caps { 1, 1, 1, 1 };
-		for (uint64_t r = 0; r < n; r++) caps.capAnchors = std::max(caps.capAnchors, jobs[r].nSlots);
+		caps.capAnchors = std::max(1u, maxSlotsPerRead);
 		caps.capEndpoints = (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)caps.capAnchors * G->maxPathsPerNode);   // entries: one per path through an anchor's end node
 		caps.capTable = std::max(1u, G->maxMpcWidth);
 		caps.capBack = (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)caps.capAnchors * ((uint64_t)G->maxBackPerNode + G->maxPathsPerNode));   // threshold lists: backward links + paths of the start node
@@ -1854,35 +1978,35 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		ExtResult* dResults = st->results.reserve<ExtResult>(nWork);
 		uint8_t* dScratch = st->scratch.reserve<uint8_t>((uint64_t)lanes * slabBytes);
 		TraceCell* dTrace = st->tracePool.reserve<TraceCell>(traceBudget);
-		Fragment* dFrags = st->frags.reserve<Fragment>(nFrags);
+		if (!deviceGlue) dFrags = st->frags.reserve<Fragment>(nFrags);
 		FragSeed* dFragSeeds = st->fragSeeds.reserve<FragSeed>(nSlots);
 		AnchorRec* dAnchors = st->anchors.reserve<AnchorRec>(nSlots);
 		uint32_t* dFragStatus = st->fragStatus.reserve<uint32_t>(nFrags);
 		uint32_t* dFragExtended = st->fragExtended.reserve<uint32_t>(nFrags);
 		uint64_t pathCapacity = nSlots * 24 + 4096;
 		uint32_t* dPathPool = st->pathPool.reserve<uint32_t>(pathCapacity);
-		ReadChainJob* dJobs = st->jobs.reserve<ReadChainJob>(n);
+		if (!deviceGlue) dJobs = st->jobs.reserve<ReadChainJob>(n);
 		uint32_t* dChainOut = st->chainOut.reserve<uint32_t>(nSlots);
 		uint32_t* dChainLen = st->chainLen.reserve<uint32_t>(n);
 		unsigned long long* dChainScore = st->chainScore.reserve<unsigned long long>(n);
 		uint32_t* dChainStatus = st->chainStatus.reserve<uint32_t>(n);
 		uint32_t chainBlocks = std::max(chainGridBlocks((uint32_t)n), chainScratchBlocks((uint32_t)n));   // both launches index the scratch by block
 		uint8_t* dChainScratch = st->chainScratch.reserve<uint8_t>((uint64_t)std::max(1u, chainBlocks) * chainScratchBytes(caps));
-		FragSeed* dReadSeeds = st->readSeeds.reserve<FragSeed>(nSeedsTotal);
-		uint32_t* dFragFirstSeed = st->fragFirstSeed.reserve<uint32_t>(nFrags);
-		if (nFrags) HIP_CHECK(hipMemcpyAsync(dFrags, frags, nFrags * sizeof(Fragment), hipMemcpyHostToDevice, stream));
-		if (nFrags) HIP_CHECK(hipMemcpyAsync(dFragFirstSeed, fragFirstSeed, nFrags * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-		if (nSeedsTotal) HIP_CHECK(hipMemcpyAsync(dReadSeeds, readSeeds, nSeedsTotal * sizeof(FragSeed), hipMemcpyHostToDevice, stream));
+		if (!deviceGlue) {
+			dReadSeeds = st->readSeeds.reserve<FragSeed>(nSeedsTotal);
+			dFragFirstSeed = st->fragFirstSeed.reserve<uint32_t>(nFrags);
+			if (nFrags) HIP_CHECK(hipMemcpyAsync(dFrags, frags, nFrags * sizeof(Fragment), hipMemcpyHostToDevice, stream));
+			if (nFrags) HIP_CHECK(hipMemcpyAsync(dFragFirstSeed, fragFirstSeed, nFrags * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+			if (nSeedsTotal) HIP_CHECK(hipMemcpyAsync(dReadSeeds, readSeeds, nSeedsTotal * sizeof(FragSeed), hipMemcpyHostToDevice, stream));
+		}
 		// Lazy extension (default): a seed is extended only when the reference would extend it - when it does not lie on an earlier alignment of its
 		// fragment (src/GraphAligner.h:163-173). Round 0 extends every fragment's first seed; k_build_anchors parks the fragments that reach another
 		// seed they must extend and queues that seed for the next round (the launches size themselves from counts on the device, no host round
 		// trip); three rounds at most, the last parking round queues everything its fragments have left. On cfg2 the reference extends 47 % of the
 		// seeds the windows hold. GC_EXT_LAZY=0: every seed is extended up front.
-		uint32_t maxWindowSeeds = 0;
-		for (uint32_t m : windowSeeds) maxWindowSeeds = std::max(maxWindowSeeds, m);
 		const bool lazyExtend = !(getenv("GC_EXT_LAZY") && atoi(getenv("GC_EXT_LAZY")) == 0) && nFrags > 0;
 		launchBuildFragmentWork(stream, G->dev, dFrags, dFragFirstSeed, (uint32_t)nFrags, dReadSeeds, R->devOffsets, R->totalBases, (uint32_t)P->split_len, dFragSeeds, dWork, lazyExtend ? dResults : nullptr);
-		if (n) HIP_CHECK(hipMemcpyAsync(dJobs, jobs, n * sizeof(ReadChainJob), hipMemcpyHostToDevice, stream));
+		if (n && !deviceGlue) HIP_CHECK(hipMemcpyAsync(dJobs, jobs, n * sizeof(ReadChainJob), hipMemcpyHostToDevice, stream));
 		mark();   // 2
 		// extensions that outgrew their slab (a dense variant cluster: more tiles, queue entries or trace cells than the common case is sized
 		// for) run again in a small grid with 16x the room; lanes whose items are fine only read the status array. What overflows even
@@ -2020,7 +2144,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				if (deviceStitch && getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc stitch] read %zu goes to the host: reason %u, chain of %u anchors\n", r, stitchInfo[r].status, chainLen[r]);
 				std::vector<uint32_t> slots;
 				uint64_t slot = gl.slotBegin;
-				for (size_t f = 0; f < gl.windows.size(); f++) {
+				for (size_t f = 0; f < gl.nWindows; f++) {
 					uint64_t F = gl.fragBegin + f;
 					uint32_t nS = frags[F].seedEnd - frags[F].seedBegin;
 					if (fragStatus[F] == 1) break;   // `cont` is never reset (src/Aligner.cpp:695-703)
@@ -2211,18 +2335,19 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 
 		// ---------------- assemble the flat result: count per read, prefix-sum, fill in parallel
 		double tAsm = nowUs();
+		if (glueCopied) HIP_CHECK(hipEventSynchronize(glueCopied));   // (long since done: the copies were queued before the fragment pipeline)
 		std::vector<uint8_t> failedAssertion(n, 0);
 		std::vector<uint64_t> seedsExtended(n, 0), seedsExtendedLong(n, 0);
 		// read position of the seed in a fragment-pass slot (the device holds the per-slot records; the host keeps seeds and windows)
 		auto slotSeqPos = [&](uint64_t r, uint64_t slot, uint64_t F) -> uint32_t {
-			const ReadGlue& gl = glue[r];
-			return gl.seeds[gl.windows[F - gl.fragBegin].sl + (slot - frags[F].seedBegin)].seqPos;
+			(void)r;
+			return readSeeds[fragFirstSeed[F] + (slot - frags[F].seedBegin)].seqPos;   // (host copies: kept whenever keep_traces asks for this)
 		};
 		auto forEachAnchor = [&](uint64_t r, auto&& visit) {   // visit(slotIndex, fragmentIndex) for every anchor the reference would keep
 			const ReadGlue& gl = glue[r];
 			if (gl.longFailed) return;   // `cont` was already set by the whole-read pass (src/Aligner.cpp:529,591,702)
 			uint64_t slot = gl.slotBegin;
-			for (size_t f = 0; f < gl.windows.size(); f++) {
+			for (size_t f = 0; f < gl.nWindows; f++) {
 				uint64_t F = gl.fragBegin + f;
 				uint32_t nS = frags[F].seedEnd - frags[F].seedBegin;
 				if (fragStatus[F] == 1) return;   // `cont` is never reset: later fragments add nothing (src/Aligner.cpp:695-703)
@@ -2242,7 +2367,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				return;
 			}
 			if (chainStatus[r] != 0) { gl.capacityExceeded = true; chainLen[r] = 0; chainScore[r] = 0; }
-			for (size_t f = 0; f < gl.windows.size(); f++) {
+			for (size_t f = 0; f < gl.nWindows; f++) {
 				uint64_t F = gl.fragBegin + f;
 				if (fragStatus[F] == 2) gl.capacityExceeded = true;   // an extension or the anchor path pool overflowed even in the retry: this fragment gave no anchors
 				if (fragStatus[F] == 1) { failedAssertion[r] = 1; break; }
@@ -2276,9 +2401,12 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			if (P->keep_traces) for (const LongAln& a : glue[r].longAlns) nLongTrace += a.traceLen;
 		}
 		const bool keepSeeds = P->keep_seeds != 0;
+		std::vector<uint64_t> seedOutBegin(n + 1, 0);   // the result's seed lists are dense (the device's sit at capacity offsets)
+		for (uint64_t r = 0; r < n; r++) seedOutBegin[r + 1] = seedOutBegin[r] + (keepSeeds ? glue[r].nSeedsR : 0);
+		const uint64_t nSeedsOut = seedOutBegin[n];
 		res->read_seed_off = mallocArray<uint64_t>(n + 1);
-		res->seed_node = mallocArray<uint32_t>(keepSeeds ? nSeedsTotal : 0); res->seed_offset = mallocArray<uint32_t>(keepSeeds ? nSeedsTotal : 0);
-		res->seed_seqpos = mallocArray<uint32_t>(keepSeeds ? nSeedsTotal : 0); res->seed_goodness = mallocArray<uint64_t>(keepSeeds ? nSeedsTotal : 0);
+		res->seed_node = mallocArray<uint32_t>(nSeedsOut); res->seed_offset = mallocArray<uint32_t>(nSeedsOut);
+		res->seed_seqpos = mallocArray<uint32_t>(nSeedsOut); res->seed_goodness = mallocArray<uint64_t>(nSeedsOut);
 		res->read_anchor_off = mallocArray<uint64_t>(n + 1);
 		res->anchor_x = mallocArray<uint32_t>(nAnchors); res->anchor_y = mallocArray<uint32_t>(nAnchors);
 		res->anchor_path_off = mallocArray<uint64_t>(nAnchors + 1); res->anchor_path = mallocArray<uint32_t>(nPath);
@@ -2318,13 +2446,16 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		res->failed_assertion = mallocArray<uint8_t>(n);
 		res->capacity_exceeded = mallocArray<uint8_t>(n);
 		res->seeds_extended = mallocArray<uint64_t>(n);
-		res->read_seed_off[n] = keepSeeds ? nSeedsTotal : 0; res->read_anchor_off[n] = nAnchors; res->anchor_path_off[nAnchors] = nPath; res->read_chain_off[n] = nChain;
+		res->read_seed_off[n] = nSeedsOut; res->read_anchor_off[n] = nAnchors; res->anchor_path_off[nAnchors] = nPath; res->read_chain_off[n] = nChain;
 		pool.run(n, [&](size_t r, size_t) {
 			const ReadGlue& gl = glue[r];
-			res->read_seed_off[r] = keepSeeds ? gl.seedBegin : 0;
+			res->read_seed_off[r] = seedOutBegin[r];
 			if (keepSeeds) {
-				uint64_t at = gl.seedBegin;
-				for (const gc::SeedRec& s : gl.seeds) { res->seed_node[at] = s.node; res->seed_offset[at] = s.offset; res->seed_seqpos[at] = s.seqPos; res->seed_goodness[at] = s.goodness; at++; }
+				uint64_t at = seedOutBegin[r];
+				for (uint32_t k = 0; k < gl.nSeedsR; k++, at++) {
+					const FragSeed& s = readSeeds[gl.seedBegin + k];   // fragment-pass order; pad = seedGoodness
+					res->seed_node[at] = s.node; res->seed_offset[at] = s.offset; res->seed_seqpos[at] = s.seqPos; res->seed_goodness[at] = s.pad;
+				}
 			}
 			res->read_anchor_off[r] = gl.anchorBegin;
 			res->read_chain_off[r] = gl.chainBegin;

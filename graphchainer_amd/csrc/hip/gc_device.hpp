@@ -36,6 +36,9 @@ struct DGraph {
 	const uint32_t* pathsOff; const uint32_t* paths; const uint32_t* pathsPos;   // [n+1]; path ids through node (ascending) and the node's position on each
 	const uint32_t* backOff;  const uint32_t* backNode; const uint32_t* backPath; const uint32_t* backPos;   // [n+1]; (last node of path k strictly reaching v, k, its position on k)
 	const uint32_t* mpcWidth;         // [nComponents]
+	// seed clustering (orderSeedsByChaining, src/GraphAligner.h:245-262): chain of every split node and its approximate position on it
+	const uint32_t* chainNumber;      // [n]
+	const uint64_t* chainApproxPos;   // [n]
 };
 
 struct WS {   // one DP column over 64 read rows (reference: src/WordSlice.h:150-166)

@@ -45,8 +45,11 @@ namespace gcdev {
 #ifndef GC_LEAN_MERGE
 #define GC_LEAN_MERGE 1
 #endif
-#ifndef GC_LEAN_FORCE_SPLIT
-#define GC_LEAN_FORCE_SPLIT 0   // (two copies of the column loop, with / without the forced first row: 184.4 -> 183.2 ms, not worth the spills)
+#ifndef GC_LEAN_KINDS
+#define GC_LEAN_KINDS 1   // three copies of the column loop: general / node in the previous slice with nothing forced / node new in this slice (constant carries)
+#endif
+#ifndef GC_LEAN_UNROLL
+#define GC_LEAN_UNROLL 1
 #endif
 #ifndef WAVE_CAP
 #define WAVE_CAP 28
@@ -428,7 +431,11 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 		uint32_t plusWord = 0, minusWord = 0;
 		// two copies of the loop: most tiles sit on a node that was in the previous slice with nothing to repair (forceUntil == 0), and their
 		// columns carry no forced first row - three scalar instructions per column less than the general copy
-		auto columnLoop = [&, &plusWord = plusWord, &minusWord = minusWord, &tables = tables](auto withForce) __attribute__((always_inline)) {   // (explicit captures: asm operands alone do not make a generic lambda capture)
+		// KIND 0: the general copy. KIND 1: the node was in the previous slice and nothing had to be repaired (forceUntil == 0): no forced first row.
+		// KIND 2: the node is new in this slice (47 % of the DP's columns on cfg2): the row above contributes the constant carries (+1, 0) and
+		// every column's first row is forced - three s_bfe_u64 and two ORs less per column.
+		auto columnLoop = [&, &plusWord = plusWord, &minusWord = minusWord, &tables = tables](auto kindTag) __attribute__((always_inline)) {   // (explicit captures: asm operands alone do not make a generic lambda capture)
+		constexpr int KIND = decltype(kindTag)::value;
 		// the column counter carries the field width of s_bfe_u64's descriptor in bit 16 (offset = bits 5:0, width = bits 22:16), and goes into M0
 		// as it is: v_writelane takes the lane from M0's low six bits
 		int pos = 1 | (1 << 16);
@@ -437,33 +444,35 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 			uint64_t codes = half ? seq.w1 : (seq.w0 >> 2);
 			codes = gcUniform64(codes);
 			const int end = (half ? nodeLength : (nodeLength < 32 ? nodeLength : 32)) | (1 << 16);
-#pragma unroll 1
+#pragma unroll GC_LEAN_UNROLL
 			for (; pos < end; pos++) {
-				uint64_t lo, hi, Eq, hinP, hinN, f;
+				uint64_t lo, hi, Eq, hinP = 1, hinN = 0, f = 0;
 				const uint32_t posS = (uint32_t)__builtin_amdgcn_readfirstlane(pos);
 				const uint32_t desc = posS;
 				asm("s_bitcmp1_b32 %3, 0\n\ts_cselect_b64 %0, %5, %4\n\ts_cselect_b64 %1, %7, %6\n\ts_bitcmp1_b32 %3, 1\n\ts_cselect_b64 %2, %1, %0"
 					: "=&s"(lo), "=&s"(hi), "=&s"(Eq) : "s"((uint32_t)codes), "s"(eA), "s"(eC), "s"(eG), "s"(eT) : "scc");
-				asm("s_bfe_u64 %0, %1, %2" : "=s"(hinP) : "s"(prevHP), "s"(desc) : "scc");
-				asm("s_bfe_u64 %0, %1, %2" : "=s"(hinN) : "s"(prevHN), "s"(desc) : "scc");
-				if (decltype(withForce)::value) asm("s_bfe_u64 %0, %1, %2" : "=s"(f) : "s"(forced), "s"(desc) : "scc");
-				else f = 0;
+				if (KIND != 2) {
+					asm("s_bfe_u64 %0, %1, %2" : "=s"(hinP) : "s"(prevHP), "s"(desc) : "scc");
+					asm("s_bfe_u64 %0, %1, %2" : "=s"(hinN) : "s"(prevHN), "s"(desc) : "scc");
+				}
+				if (KIND == 0) asm("s_bfe_u64 %0, %1, %2" : "=s"(f) : "s"(forced), "s"(desc) : "scc");
 				codes >>= 2;
 				const uint64_t Xv = Eq | VN;
-				Eq |= hinN;
+				if (KIND != 2) Eq |= hinN;
 				const uint64_t Xh = (((Eq & VP) + VP) ^ VP) | Eq;
 				const uint64_t Ph = VN | ~(Xh | VP);
 				const uint64_t Mh = VP & Xh;
-				const uint64_t sPh = (Ph << 1) | hinP, sMh = (Mh << 1) | hinN;
-				VP = (sMh | ~(Xv | sPh)) & ~f;
-				VN = (sPh & Xv) | f;
+				const uint64_t sPh = (Ph << 1) | hinP, sMh = KIND != 2 ? ((Mh << 1) | hinN) : (Mh << 1);
+				if (KIND == 0) { VP = (sMh | ~(Xv | sPh)) & ~f; VN = (sPh & Xv) | f; }
+				else if (KIND == 1) { VP = sMh | ~(Xv | sPh); VN = sPh & Xv; }
+				else { VP = (sMh | ~(Xv | sPh)) & ~1ull; VN = (sPh & Xv) | 1ull; }
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 				// (two SGPR operands exceed gfx9's constant bus; M0 as lane select does not count)
 				if (MODE == 0) {
 					asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0" : "+v"(plusWord), "+v"(minusWord) : "s"(posS), "s"((uint32_t)(Ph >> 32)), "s"((uint32_t)(Mh >> 32)) : "m0");
 				} else {
-					// backtrace recompute: the column itself goes to lane pos of the column registers (its score follows after the loop)
+					// backtrace recompute / column store: the column itself goes to lane pos of the column registers (its score follows after the loop)
 					asm("s_mov_b32 m0, %6\n\tv_writelane_b32 %0, %7, m0\n\tv_writelane_b32 %1, %8, m0\n\tv_writelane_b32 %2, %9, m0\n\tv_writelane_b32 %3, %10, m0\n\tv_writelane_b32 %4, %11, m0\n\tv_writelane_b32 %5, %12, m0"
 						: "+v"(tables.cr[0]), "+v"(tables.cr[1]), "+v"(tables.cr[2]), "+v"(tables.cr[3]), "+v"(plusWord), "+v"(minusWord)
 						: "s"(posS), "s"((uint32_t)VP), "s"((uint32_t)(VP >> 32)), "s"((uint32_t)VN), "s"((uint32_t)(VN >> 32)), "s"((uint32_t)(Ph >> 32)), "s"((uint32_t)(Mh >> 32)) : "m0");
@@ -472,10 +481,12 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 			}
 		}
 		};
-#if GC_LEAN_FORCE_SPLIT
-		if (forceUntil == 0) columnLoop(std::false_type()); else columnLoop(std::true_type());
+#if GC_LEAN_KINDS
+		if (!prevExists) columnLoop(std::integral_constant<int, 2>());
+		else if (forceUntil == 0) columnLoop(std::integral_constant<int, 1>());
+		else columnLoop(std::integral_constant<int, 0>());
 #else
-		columnLoop(std::true_type());
+		columnLoop(std::integral_constant<int, 0>());
 #endif
 		const uint64_t HP = __ballot((int32_t)plusWord < 0), HN = __ballot((int32_t)minusWord < 0);   // lanes 0 and >= nodeLength still hold 0
 		out.HP = HP; out.HN = HN;

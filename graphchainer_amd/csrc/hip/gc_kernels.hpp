@@ -10,6 +10,7 @@ struct SeedIndex {   // minimizer index in HBM (reference: MinimizerSeeder bucke
 	const uint32_t* filter;     // 2^filterBits-bit membership filter over the keys: bit filterBit(kmer) is set for every key
 	uint32_t filterShift;       // 64 - filterBits
 	const uint64_t* startPos;   // [nKeys+1]
+	const uint64_t* positions;  // [startPos[nKeys]] occurrences: (split node << 6) | offset of the k-mer's last base, every k-mer's list in the reference's order
 	uint32_t nKeys;
 	uint32_t maxCount;
 	int32_t k, w;
@@ -74,6 +75,16 @@ struct ReadChainJob {
 
 struct ChainCaps { uint32_t capAnchors, capEndpoints, capTable, capBack; };   // most anchors of a read; most entries (anchor x paths through its end node); widest path cover
 
+// ---- seed glue on the device (gc_seedglue.hip) ----
+struct GlueRead { uint32_t nSeeds, seedOff, nFrags, fragBegin, nSlots, slotBegin, failed, pad; };   // per read: where its seeds / fragments / anchor slots are
+struct GlueElem;
+struct GlueStaging {   // per-seed staging arrays (capacity: the sum over reads of their hits' occurrence counts), per-read window staging
+	uint32_t *mPos, *mStartLo, *mStartHi;                       // per hit (a read's hits use the first slots of its seed range)
+	uint32_t *sSeqPos, *sNode, *sOffset, *sGood, *sCluster;     // per seed, expansion order
+	GlueElem* sortBuf; uint32_t* posBuf;                        // sort arrays of reads beyond the LDS capacity
+	uint32_t* winBuf;                                           // (l, sl, sr, first slot) per window, at 4 * winCapOff[read]
+};
+
 // ---- whole-read pass (K3-long) ----
 struct LongSeed {    // a seed in goodness order (after OrderSeeds); 16 bytes: 3 M of them go up per 10 k-read batch
 	uint32_t node;                  // forward start: split node of the seed base
@@ -124,6 +135,16 @@ struct LongWorkResult { uint64_t traceOff; uint32_t traceLen, status; int32_t sc
 // ---- launchers (all asynchronous on `stream`) ------------------------------------------------------
 void launchSeedLookup(hipStream_t stream, const SeedIndex& idx, const char* bases, const uint64_t* readOff, uint32_t nReads,
 	uint64_t* matchCursor, uint32_t* readMatchOff, uint32_t* readMatchCount, uint2* matches, uint64_t matchCapacity, uint32_t* tmp, uint64_t totalBases, const uint32_t* chunkRead, const uint64_t* packed, const uint64_t* invalid);
+
+// per read the capacity bound of its seed list and the exclusive scan of those bounds (readSeedOff[nReads + 1]); *total = their sum
+void launchSeedCaps(hipStream_t stream, const SeedIndex& idx, uint32_t nReads, const uint8_t* invalidRead, const uint2* matches, const uint32_t* readMatchOff, const uint32_t* readMatchCount,
+	uint32_t* readSeedCap, uint32_t* readSeedOff, unsigned long long* total);
+// addMinimizers + orderSeedsByChaining + the sort by position + the fragment windows, one wave per read (cursors: [0] fragments, [1] anchor slots,
+// [2] trace cells the fragment extensions may need, [3] most slots of a read, [4] most seeds of a window)
+void launchSeedGlue(hipStream_t stream, const SeedIndex& idx, const DGraph& g, const uint64_t* readOff, uint32_t nReads, const uint8_t* invalidRead, const uint2* matches, const uint32_t* readMatchOff,
+	const uint32_t* readMatchCount, const uint32_t* readSeedOff, const uint32_t* winCapOff, double density, uint32_t splitLen, uint32_t splitGap, bool longPass, const GlueStaging& st,
+	uint32_t* perRead /* 6 x (nReads + 1) words of scratch */, LongSeed* longSeeds, FragSeed* readSeeds, Fragment* frags, uint32_t* fragFirstSeed, ReadChainJob* jobs, GlueRead* out, unsigned long long* cursors);
+uint64_t glueElemBytes();
 
 uint64_t extendSlabBytes(const ExtendConfig& cfg);
 uint32_t extendGridLanes(uint32_t nWork);
