@@ -55,6 +55,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-long-pass", action="store_true", help="skip the whole-read GraphAligner pass (src/Aligner.cpp:630-654)")
     ap.add_argument("--strong", action="store_true", help="N>1: one read set divided over the ranks through the work queue (strong scaling)")
+    ap.add_argument("--e2e-steps", type=int, default=int(os.environ.get("GC_BENCH_E2E_STEPS", 3)),
+                    help="after the timed steps (N=1): this many steps with the read upload (gc_reads_upload) and the GAF encoding of every batch inside the step "
+                         "(the whole boundary: host bases in, GAF text out); 0 skips it")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("GC_BENCH_INFLIGHT", 2)),
                     help="batches in flight per GPU, each on its own gc_stream and host thread (like the reference's -t worker threads); with two, one "
                          "batch's seeding, host glue and fragment pipeline run beside the other's whole-read pass (measured: 1 -> 285, 2 -> 255, 3 -> 486 ms per batch)")
@@ -279,6 +282,33 @@ def main():
                         "against": "oracle (CPU leg of this run), same reads"}
         if mismatches:
             parity_check["fields_with_mismatches"] = fields_bad
+    # End to end (outside the headline figure): host bases in, GAF text out - gc_reads_upload, the hot path with the traces kept for the
+    # writer, and gc_format_gaf of every batch inside the step, `inflight` batches overlapping as in the timed region (src/Aligner.cpp:261-311).
+    e2e = None
+    if world == 1 and args.e2e_steps > 0 and long_pass:
+        e2e_aligners = aligners                                   # the same gc_streams (a third and fourth would not fit the HBM beside them)
+        for a in e2e_aligners:
+            a.params.keep_traces = 1
+        names = [[f"read{i}" for i in idx] for idx in chunks]
+
+        def e2e_item(worker, item):
+            b = item % len(chunks)
+            batch = gca.ReadBatch([reads[i] for i in chunks[b]])
+            out = e2e_aligners[worker].align_batch(batch, gaf_names=names[b])
+            n_bytes, skipped = len(out["gaf"]), out["gaf_chained_skipped"]
+            batch.close()
+            return n_bytes, skipped
+        queue.reset(max(inflight, 1) * len(chunks))
+        run_queue(queue, e2e_item, inflight)                      # first-batch allocations of the new streams
+        queue.reset(args.e2e_steps * len(chunks))
+        t0 = time.perf_counter()
+        done = run_queue(queue, e2e_item, inflight)
+        dt = time.perf_counter() - t0
+        e2e = {"reads_per_s": round(args.e2e_steps * len(reads) / dt, 2), "ms_per_step": round(dt / args.e2e_steps * 1e3, 2), "steps": args.e2e_steps,
+               "gaf_bytes_per_step": int(sum(n for _i, (n, _s) in done) / args.e2e_steps), "chained_winners_without_trace": int(sum(s for _i, (_n, s) in done)),
+               "includes": "gc_reads_upload (PCIe + packing kernels) + hot path with traces kept + gc_format_gaf of every batch"}
+        for a in e2e_aligners:
+            a.params.keep_traces = 0
     kernel_us = np.zeros(8)
     host_us = np.zeros(4)
     counters = np.zeros(8, dtype=np.float64)
@@ -371,11 +401,12 @@ def main():
             "roofline_other": roof_extend if roofline is roof_long else roof_long,
             "cpu_baseline": cpu_baseline,
             "parity_check": parity_check,
+            "e2e": e2e,
             # inputs are resident before the timed region; what putting them there costs (host-side packing + PCIe), and the rate with it included
             "reads_upload": {"ms_per_step": round(upload_s * 1e3, 2), "bases": total_bases, "reads_per_s_including_upload": round(reads_total / (elapsed + upload_s * steps * (1 if not strong else 1)), 2)},
             "host_cpu_s_per_step": round(host_cpu_s / max(1, args.steps), 3),   # CPU time the container spent per step (all threads, this rank's box)
             "stage_ms": {"k_seed_probe+compact": round(kernel_us[0] / 1e3, 3), "k_extend": round(kernel_us[1] / 1e3, 3), "k_build_anchors": round(kernel_us[2] / 1e3, 3),
-                         "k_chain": round(kernel_us[3] / 1e3, 3), "k_long_extend_all_rounds": round(kernel_us[4] / 1e3, 3), "whole_read_pass_wall": round(kernel_us[5] / 1e3, 3), "host_seed_glue": round(host_us[0] / 1e3, 3), "host_result_assembly": round(host_us[1] / 1e3, 3),
+                         "k_chain": round(kernel_us[3] / 1e3, 3), "k_long_extend_all_rounds": round(kernel_us[4] / 1e3, 3), "whole_read_pass_wall": round(kernel_us[5] / 1e3, 3), "seed_glue_wall": round(host_us[0] / 1e3, 3), "host_result_assembly": round(host_us[1] / 1e3, 3),
                          "wall_seed_lookup_and_copies": round(host_us[2] / 1e3, 3), "wall_extend_to_chain_and_copies": round(host_us[3] / 1e3, 3)},
             "setup_s": {"generate": round(t_gen, 1), "graph_build_upload": round(t_graph, 1), "minimizer_index": round(t_index, 1),
                         "index_cache_save": round(t_save, 1), "index_cache_load_upload": round(t_load, 1), "index_cache_bytes": cache_bytes},

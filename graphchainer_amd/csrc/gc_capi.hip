@@ -604,10 +604,9 @@ static void launchEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 	const uint64_t* dEqMasks, const char* dLetters, const uint32_t* dLettersLen, const std::function<uint32_t(uint32_t)>& readLen)
 {
 	if (!nPairs) return;
-	if (!run.ready) {
-		HIP_CHECK(hipEventCreateWithFlags(&run.ready, hipEventDisableTiming));
-		for (auto& q : run.streams) createStream(&q, 0);
-	}
+	if (!run.ready) HIP_CHECK(hipEventCreateWithFlags(&run.ready, hipEventDisableTiming));
+	// (a class's stream is created when the class is first used: the batch's streams share the device's 16 hardware queues, and on cfg2 only the
+	// two-pairs-per-wave class and the one-block class ever hold pairs)
 	std::vector<uint32_t> cls(nPairs);
 	uint32_t count[6] = { 0, 0, 0, 0, 0, 0 }, begin[7];
 	static const bool halfWaves = !(getenv("GC_ED_HALF") && atoi(getenv("GC_ED_HALF")) == 0);
@@ -633,6 +632,7 @@ static void launchEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 	HIP_CHECK(hipEventRecord(run.ready, stream));
 	for (int c = 0; c < 6; c++) {
 		if (!count[c]) continue;
+		if (!run.streams[c]) createStream(&run.streams[c], 0);
 		HIP_CHECK(hipStreamWaitEvent(run.streams[c], run.ready, 0));
 		launchEditDistance(run.streams[c], c == 0 ? 0u : 1u << (c - 1), dPairs + begin[c], count[c], dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut + begin[c]);
 		HIP_CHECK(hipMemcpyAsync(hOut + begin[c], dOut + begin[c], (size_t)count[c] * sizeof(int64_t), hipMemcpyDeviceToHost, run.streams[c]));
@@ -642,7 +642,7 @@ static void finishEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 	const uint64_t* dEqMasks, const char* dLetters, const uint32_t* dLettersLen)
 {
 	if (!nPairs) return;
-	for (auto& q : run.streams) syncStream(q);
+	for (auto& q : run.streams) if (q) syncStream(q);
 	// reruns for the pairs whose band outgrew their unit (grouped order throughout)
 	std::vector<uint32_t> todo;
 	for (uint32_t i = 0; i < nPairs; i++) {
@@ -1699,6 +1699,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				unsigned long long* cursor = dLongCursor + 32 + 8 * g;
 				volatile unsigned long long* hCursor = hLongSmall + 32 + 8 * g;
 				const uint64_t traceBudget = groupTraceBeginPtr[g + 1] - groupTraceBeginPtr[g];
+				double dbgWaitUs = 0;
+				const double dbgT0 = nowUs();
 				launchLongInit(q, dLongJobs + r0, (uint32_t)nG, dLongState + r0);
 				uint32_t lastWork = 0xffffffffu;
 				// GC_LONG_TOKEN=2 (experiment): the token is held per round - from the moment a round's extension kernel is queued until the wait
@@ -1726,7 +1728,9 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 						launchLongOrder(q, dWorkLen + w0, cursor, dOrder + w0, (uint32_t)maxReadLen, mode ? (uint32_t)atoi(mode) : 1u);
 					}
 					launchPublish(q, cursor, (unsigned long long*)hCursor, 2);
+					const double tWait0 = nowUs();
 					syncStream(q);
+					dbgWaitUs += nowUs() - tWait0;
 					if (roundLock.owns_lock()) roundLock.unlock();   // the previous round's extension kernel has finished
 					uint32_t nWorkItems = (uint32_t)hCursor[0];
 					if (nWorkItems == 0) break;
@@ -1772,9 +1776,12 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					timedRounds++;
 					groupRoundsPtr[g]++;
 				}
-				launchLongFinish(q, (uint32_t)nG, dLongState + r0, dLongResults + r0);
-				HIP_CHECK(hipMemcpyAsync(hLongResults + r0, dLongResults + r0, nG * sizeof(LongReadResult), hipMemcpyDeviceToHost, q));
+				// the per-read results go straight into pinned host memory (the kernel writes them across PCIe): a copy-engine transfer here queued behind
+				// the other batch's bulk downloads for 30-50 ms while this pass still held the device's whole-read token
+				launchLongFinish(q, (uint32_t)nG, dLongState + r0, hLongResults + r0);
+				const double dbgT1 = nowUs();
 				syncStream(q);
+				if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] whole-read rounds: %.1f ms in all, %.1f ms waiting for the rounds' work counts, %.1f ms in the last wait, %d rounds\n", (nowUs() - dbgT0) / 1e3, dbgWaitUs / 1e3, (nowUs() - dbgT1) / 1e3, timedRounds);
 				for (int k = std::max(0, timedRounds - LONG_EVENT_RING); k < timedRounds; k++) collect(k % LONG_EVENT_RING);
 			};
 			longGroups = nGroups;
@@ -1877,10 +1884,13 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 						HIP_CHECK(hipSetDevice(device));
 						const int tokenMode = getenv("GC_LONG_TOKEN") ? atoi(getenv("GC_LONG_TOKEN")) : 1;   // 0 none, 1 one pass at a time, 2 one round's extension kernel at a time
 						std::unique_lock<std::mutex> token(g_longPassToken[device & 15], std::defer_lock);
+						const double tTokenAsk = nowUs();
 						if (tokenMode == 1 && longGroups == 1) token.lock();
+						if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc token] stream %p asked %.1f got %.1f (call began %.1f)\n", (void*)st, tTokenAsk / 1e3, nowUs() / 1e3, tCall / 1e3);
 						{ double now = nowUs(), seen = longWallBeginUs.load(); while ((seen == 0.0 || now < seen) && !longWallBeginUs.compare_exchange_weak(seen, now)) {} }
 						runLongGroup(g);
 						{ double now = nowUs(), seen = longWallEndUs.load(); while (now > seen && !longWallEndUs.compare_exchange_weak(seen, now)) {} }
+						if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc token] stream %p released %.1f\n", (void*)st, nowUs() / 1e3);
 						if (token.owns_lock()) token.unlock();   // the next batch's pass may start; what follows is this batch's own tail
 						if (longPostInThread) afterLongPass();
 					} catch (...) { longErrors[g] = std::current_exception(); }
@@ -2547,6 +2557,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		return (int)GC_OK;
 	});
 	if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] gc_align_batch returned after %.1f ms\n", (nowUs() - tCall) / 1e3);
+	if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc token] stream %p call returned %.1f\n", (void*)st, nowUs() / 1e3);
 	if (rc != GC_OK) { gc_result_free(res); return rc; }
 	*out = res;
 	return GC_OK;

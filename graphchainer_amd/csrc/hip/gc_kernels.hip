@@ -206,6 +206,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 // getAlignmentFromSeed :567-626, anchor construction src/Aligner.cpp:706-729. One lane per fragment.
 // =====================================================================================================
 
+__device__ __forceinline__ void twinOf(const DGraph& g, uint32_t node, uint32_t offset, uint32_t& twinNode, uint32_t& twinOffset);
+
 struct MergedView {   // virtual view of a seed's merged trace (backward cells, then forward cells) in forward-strand split coords
 	const TraceCell* bw; uint32_t nBw;   // backward device trace without its final row -1 cell (nBw cells used)
 	const TraceCell* fw; uint32_t nFw;   // forward device trace (used in reverse order)
@@ -262,7 +264,8 @@ __global__ void __launch_bounds__(64) k_build_anchors(DGraph g, const Fragment* 
 		FragSeed sd = seeds[sIdx];
 		int32_t p = (int32_t)sd.seqPos - (int32_t)fr.l;
 		// --- filter: does the seed cell lie on an earlier accepted alignment of this fragment? (:163-173)
-		bool skip = false;
+		bool skip = false, haveTwin = false;
+		uint32_t twinNode = 0, twinOffset = 0;
 		for (uint32_t a = 0; a < k && !skip && status == 0; a++) {
 			const AnchorRec& prev = anchors[fr.seedBegin + a];
 			if (!prev.valid) continue;
@@ -276,10 +279,30 @@ __global__ void __launch_bounds__(64) k_build_anchors(DGraph g, const Fragment* 
 			bool hasB = pb.status == EXT_OK && v.p > 0, hasF = pf.status == EXT_OK && v.p < splitLen - 1;
 			v.bw = tracePool + pb.traceOff; v.nBw = hasB ? (hasF ? pb.traceLen - 1 : pb.traceLen) : 0;
 			v.fw = tracePool + pf.traceOff; v.nFw = hasF ? pf.traceLen : 0;
-			for (uint32_t i = 0; i < v.size(); i++) {
-				uint32_t node, off; int32_t sp;
-				mergedCell(g, v, i, node, off, sp);
-				if (sp == p && node == sd.node && off == sd.offset) { skip = true; break; }
+			// Is (seed node, seed offset, p) a cell of this alignment? Only the cells of read position p can be, and a one-way trace's rows never
+			// increase along it: a binary search finds them (the reference searches by seqPos too, :415-437; r2 walked every cell of every earlier
+			// alignment - 23 GB fetched per 10 k reads, each backward cell through the five gathers of the strand flip). Backward cells are
+			// compared on their own strand, against the seed's reverse-strand twin (the flip is a bijection), computed once per seed.
+			if (v.nBw > 0) {
+				const int32_t row = v.p - 1 - p;   // backward row of read position p
+				if (!haveTwin) { twinOf(g, sd.node, sd.offset, twinNode, twinOffset); haveTwin = true; }
+				uint32_t lo = 0, hi = v.nBw;      // first cell with seqPos <= row
+				while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (v.bw[mid].seqPos > row) lo = mid + 1; else hi = mid; }
+				for (uint32_t i = lo; i < v.nBw && !skip; i++) {
+					const TraceCell c = v.bw[i];
+					if (c.seqPos != row) break;
+					if (c.node == twinNode && (c.offsetAndSwitch & 255u) == twinOffset) skip = true;
+				}
+			}
+			if (v.nFw > 0 && !skip) {
+				const int32_t row = p - v.p - 1;   // forward row of read position p (row -1 is the seed's own position)
+				uint32_t lo = 0, hi = v.nFw;
+				while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (v.fw[mid].seqPos > row) lo = mid + 1; else hi = mid; }
+				for (uint32_t i = lo; i < v.nFw && !skip; i++) {
+					const TraceCell c = v.fw[i];
+					if (c.seqPos != row) break;
+					if (c.node == sd.node && (c.offsetAndSwitch & 255u) == sd.offset) skip = true;
+				}
 			}
 		}
 		if (skip || status != 0) continue;

@@ -14,6 +14,6 @@ for t in 8 16 32 96; do
   echo "threads $t"; grep "seed expand" $out/times_t$t.err | tail -3; grep "timeline" $out/times_t$t.err | tail -3
   python3 -c "
 import json,sys
-d=json.loads(open('$out/bench_t$t.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['stage_ms']['host_seed_glue'], d['stage_ms']['host_result_assembly'])"
+d=json.loads(open('$out/bench_t$t.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['stage_ms']['seed_glue_wall'], d['stage_ms']['host_result_assembly'])"
 done
 cat /sys/fs/cgroup/cpu.stat 2>/dev/null | head -8

@@ -8,7 +8,7 @@ run() { # name, env..., -- bench args
   env "$@" timeout 600 python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 8 --warmup 2 $BARGS > $out/$name.json 2> $out/$name.err
   python3 -c "
 import json
-d=json.loads(open('$out/$name.json').read().strip().splitlines()[-1]); print('$name', d['value'], d['ms_per_step'], 'cpu s/step', d['host_cpu_s_per_step'], 'glue', d['stage_ms']['host_seed_glue'], 'asm', d['stage_ms']['host_result_assembly'])"
+d=json.loads(open('$out/$name.json').read().strip().splitlines()[-1]); print('$name', d['value'], d['ms_per_step'], 'cpu s/step', d['host_cpu_s_per_step'], 'glue', d['stage_ms']['seed_glue_wall'], 'asm', d['stage_ms']['host_result_assembly'])"
 }
 BARGS="--inflight 2" run inf2_spin GC_SPIN_SYNC=1
 BARGS="--inflight 2" run inf2_sleep GC_SPIN_SYNC=0

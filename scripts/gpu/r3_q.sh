@@ -1,9 +1,6 @@
 #!/bin/bash
-# device seed glue: parity tests, then A/B bench -> gpurun_out/$1
 out=$GRAFT_REPO_ROOT/gpurun_out/$1
 mkdir -p $out
-timeout 1500 python -m pytest tests -q -m gpu -x > $out/pytest.log 2>&1
-tail -8 $out/pytest.log
 cd /tmp && export TMPDIR=/tmp
 run() { name=$1; shift
   env "$@" timeout 600 python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 3 > $out/bench_$name.json 2> $out/bench_$name.err
@@ -14,9 +11,11 @@ try:
 except Exception as e: print('$name failed', e)
 "
   tail -2 $out/bench_$name.err; }
-run hostglue GC_DEVICE_GLUE=0
-run devglue X=1
-run devglue3 GC_BENCH_INFLIGHT=3
-run devglue_spin GC_SPIN_SYNC=1
-run hostglue_spin GC_DEVICE_GLUE=0 GC_SPIN_SYNC=1
-run devglue1 GC_BENCH_INFLIGHT=1
+run base X=1
+run prio_long GC_STREAM_PRIORITY=long
+run prio_frag GC_STREAM_PRIORITY=frag
+run hwq24 GPU_MAX_HW_QUEUES=24
+run hwq12 GPU_MAX_HW_QUEUES=12
+run inflight3 GC_BENCH_INFLIGHT=3
+run inflight3_prio GC_BENCH_INFLIGHT=3 GC_STREAM_PRIORITY=long
+run poll10 GC_SYNC_POLL_US=10

@@ -129,3 +129,37 @@ def test_two_rank_index_cache_handoff(tmp_path):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29573", str(script)],
                          capture_output=True, text=True, env=env, timeout=300)
     assert "CACHE_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_stdsort_clone_equals_libstdcxx(tmp_path):
+    """The device replays the reference's three unstable std::sort calls with libstdc++'s own algorithm (graphchainer_amd/csrc/hip/gc_stdsort.hpp);
+    tests/stdsort/stdsort_test.cpp compiles that header with g++ and compares it, permutation for permutation, with the local libstdc++ on
+    20 000 arrays with many ties, on saw-tooth inputs of up to 100 000 elements, and - through libstdc++'s own __introsort_loop with a small depth
+    limit - on the heapsort path."""
+    exe = tmp_path / "stdsort_test"
+    src = os.path.join(ROOT, "tests", "stdsort", "stdsort_test.cpp")
+    subprocess.run(["g++", "-std=c++17", "-O2", src, "-o", str(exe)], check=True, timeout=300)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "STDSORT_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_state_machine_extension_core_equals_oracle(tmp_path):
+    """The per-lane state machine of the experimental kernel k_long_extend_sm (graphchainer_amd/csrc/hip/gc_sm_core.hpp) is plain C++:
+    tests/sm_host/sm_host_test.cpp compiles its phase functions with g++, drives ONE lane on the CPU and compares status, score and every trace
+    cell of several hundred extensions (10 kb ONT-like reads on a graph with repeats and multi-allelic sites, both directions, two band
+    widths) with the oracle's getReverseTraceFromSeed."""
+    exe = tmp_path / "sm_host_test"
+    src = os.path.join(ROOT, "tests", "sm_host", "sm_host_test.cpp")
+    host = os.path.join(ROOT, "graphchainer_amd", "csrc", "host")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-w", "-I/opt/rocm/include", src, os.path.join(host, "gc_graph.cpp"), os.path.join(host, "gc_minimizer.cpp"), "-o", str(exe), "-lpthread"], check=True, timeout=600)
+    sg = SynthGraph(300_000, seed=43, repeats=4, repeat_len=2000, multi_allelic=0.1)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(10, 8000, seed=8) + sg.sample_reads(3, 8000, seed=9, sv_fraction=1.0)
+    (tmp_path / "reads.txt").write_bytes(b"\n".join(reads) + b"\n")
+    for args in (["4"], ["3", "5"]):
+        out = subprocess.run([str(exe), gfa, str(tmp_path / "reads.txt")] + args, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "SM_HOST_OK" in out.stdout, out.stdout + out.stderr
+        fields = out.stdout.split()
+        equal = int(fields[fields.index("equal") + 1])
+        assert equal > 60, out.stdout
