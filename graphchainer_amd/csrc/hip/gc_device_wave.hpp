@@ -51,6 +51,9 @@ namespace gcdev {
 #ifndef GC_LEAN_UNROLL
 #define GC_LEAN_UNROLL 1
 #endif
+#ifndef GC_LEAN_DIAGRUN
+#define GC_LEAN_DIAGRUN 1   // the backtrace's diagonal runs inside a tile resolved by one ballot and emitted by the vector pipe
+#endif
 #ifndef WAVE_CAP
 #define WAVE_CAP 28
 #endif
@@ -1059,6 +1062,42 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 			L.loadWalkMasks(hori, up, diag, left);
 			uint32_t unfit = 0;   // a cell none of whose three predecessors fits: the reference's assertion; reported after the tile's walk
 			while (hori > 0 && vert > 0) {
+#if GC_LEAN_DIAGRUN
+				// Most steps are diagonal, in runs: from (hori, vert) the walk goes diagonally as long as, in column hori - i, the cell of row vert - i
+				// has no step up and a fitting diagonal predecessor. Column c keeps its masks in lane c, so lane c tests its own bit c - (hori - vert)
+				// and one ballot shows the whole run; its cells (node, hori - 1 - k, row vert - 1 - k) are written by the lanes of the trace staging
+				// registers that they fall into - one vector pass per run instead of ~25 scalar instructions per cell.
+				{
+					const int dgn = (int)hori - vert;
+					const int myRow = (int)threadIdx.x - dgn;
+					const uint64_t myUp = (uint64_t)L.cr[0] | ((uint64_t)L.cr[1] << 32), myDiag = (uint64_t)L.wm[0] | ((uint64_t)L.wm[1] << 32);
+					const bool diagonalStep = threadIdx.x >= 1 && myRow >= 1 && myRow < 64 && ((myDiag >> (myRow & 63)) & 1ull) && !((myUp >> (myRow & 63)) & 1ull);
+					const uint64_t runMask = __ballot(diagonalStep);
+					const uint64_t stops = ~runMask & (hori >= 63 ? ~0ull : ((2ull << hori) - 1));   // columns <= hori where the run cannot continue (bit 0 always)
+					const uint32_t firstStop = 63u - (uint32_t)__builtin_clzll(stops);
+					const uint32_t run = hori - firstStop;
+					if (run > 0) {
+						uint32_t remaining = run, k0 = 0;
+						while (remaining) {
+							const uint32_t slot0 = nTrace & 63u;
+							const uint32_t take = remaining < 64u - slot0 ? remaining : 64u - slot0;
+							if (threadIdx.x >= slot0 && threadIdx.x < slot0 + take) {
+								const uint32_t k = k0 + (threadIdx.x - slot0);
+								const unsigned long long cell = packCell(Cell { curNode, hori - 1 - k, cs.j + vert - 1 - (int)k }, false);
+								tbLo = (uint32_t)cell; tbHi = (uint32_t)(cell >> 32);
+							}
+							nTrace += take; remaining -= take; k0 += take;
+							if ((nTrace & 63u) == 0) {
+								if (nTrace > wsx.maxTrace) return EXT_OVERFLOW;
+								wsx.base[(wsx.traceBase(nTrace - 64, which)) * wsx.lanes + wsx.lane + threadIdx.x] = (unsigned long long)tbLo | ((unsigned long long)tbHi << 32);
+							}
+						}
+						hori -= run; vert -= (int)run;
+						if (hori > 0 && vert > 0) L.loadWalkMasks(hori, up, diag, left);
+						continue;
+					}
+				}
+#endif
 				const uint32_t u = (uint32_t)(up >> vert) & 1u, d = (uint32_t)(diag >> vert) & 1u, l = (uint32_t)(left >> vert) & 1u;
 				unfit |= (u | d | l) ^ 1u;
 				vert -= (int)(u | d);                                        // up: vertical == scoreHere - 1; else diagonal == scoreHere - (match ? 0 : 1)
