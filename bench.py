@@ -58,7 +58,7 @@ def parse_args():
     ap.add_argument("--e2e-steps", type=int, default=int(os.environ.get("GC_BENCH_E2E_STEPS", 3)),
                     help="after the timed steps (N=1): this many steps with the read upload (gc_reads_upload) and the GAF encoding of every batch inside the step "
                          "(the whole boundary: host bases in, GAF text out); 0 skips it")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("GC_BENCH_INFLIGHT", 2)),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("GC_BENCH_INFLIGHT", 3)),
                     help="batches in flight per GPU, each on its own gc_stream and host thread (like the reference's -t worker threads); with two, one "
                          "batch's seeding, host glue and fragment pipeline run beside the other's whole-read pass (measured: 1 -> 285, 2 -> 255, 3 -> 486 ms per batch)")
     args = ap.parse_args()
