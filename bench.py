@@ -288,7 +288,7 @@ def main():
     if world == 1 and args.e2e_steps > 0 and long_pass:
         e2e_aligners = aligners                                   # the same gc_streams (a third and fourth would not fit the HBM beside them)
         for a in e2e_aligners:
-            a.params.keep_traces = 1
+            a.params.keep_traces = 2                               # the alignments' traces (what the writer reads), not the anchors'
         names = [[f"read{i}" for i in idx] for idx in chunks]
 
         def e2e_item(worker, item):

@@ -461,6 +461,7 @@ class Aligner:
                 lcells = int(out["long_trace_off"][-1]) if longs else 0
                 for name in ("long_trace_node", "long_trace_offset", "long_trace_seqpos", "long_trace_switch"):
                     out[name] = arr(getattr(r, name), lcells)
+            if self.params.keep_traces == 1:   # (2: the alignments' traces only)
                 out["anchor_trace_off"] = arr(r.anchor_trace_off, anchors + 1)
                 cells = int(out["anchor_trace_off"][-1])
                 for name in ("anchor_trace_node", "anchor_trace_offset", "anchor_trace_seqpos", "anchor_trace_switch"):

@@ -341,7 +341,7 @@ struct gc_stream {
 	DeviceBuffer gluePerRead, glueCursors, glueOut, glueSeedCap, glueSeedOff, glueWinCapOff, glueU32[8], glueSort, gluePos, glueWin;   // seed glue on the device (gc_seedglue.hip)
 	PinnedBuffer hGlueOut, hGlueWinCapOff, hGlueSmall;
 	DeviceBuffer longState, longWork, longWorkResults, longRoundTrace, longCandSeed, longWorkLen, longOrder;
-	PinnedBuffer hLongSeeds, hLongJobs, hLongAlns, hLongResults, hLongSmall;
+	PinnedBuffer hLongSeeds, hLongJobs, hLongAlns, hLongResults, hLongSmall, hLongCells;
 	~gc_stream()
 	{
 		for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -1435,7 +1435,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			// host copies for the result assembly: the fragments always; the seeds only for the seed_* arrays / the anchor traces
 			frags = st->hFrags.reserve<Fragment>(nFrags);
 			if (nFrags) HIP_CHECK(hipMemcpyAsync(frags, dFrags, nFrags * sizeof(Fragment), hipMemcpyDeviceToHost, stream));
-			if (P->keep_seeds || P->keep_traces) {
+			if (P->keep_seeds || P->keep_traces == 1) {
 				readSeeds = st->hReadSeeds.reserve<FragSeed>(seedCap);
 				fragFirstSeed = st->hFragFirstSeed.reserve<uint32_t>(nFrags);
 				if (seedCap) HIP_CHECK(hipMemcpyAsync(readSeeds, dReadSeeds, seedCap * sizeof(FragSeed), hipMemcpyDeviceToHost, stream));
@@ -2118,7 +2118,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		if (pathUsed) HIP_CHECK(hipMemcpyAsync(pathPool, dPathPool, pathUsed * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		std::vector<ExtResult> extResults;
 		std::vector<TraceCell> tracePool;
-		if (P->keep_traces) {
+		const bool anchorTraces = P->keep_traces == 1;   // (keep_traces == 2: the alignments' traces only - what the output encoders read)
+		if (anchorTraces) {
 			extResults.resize(nWork);
 			tracePool.resize(traceUsed);
 			if (nWork) HIP_CHECK(hipMemcpyAsync(extResults.data(), dResults, (size_t)nWork * sizeof(ExtResult), hipMemcpyDeviceToHost, stream));
@@ -2237,7 +2238,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 
 		// ---------------- whole-read pass results
 		double tJoined = nowUs();
-		std::vector<LongCell> longCells;
+		const LongCell* longCells = nullptr;   // keep_traces: the merged traces in pinned staging (a pageable destination made this copy 2-3 s per 10 k reads)
 		if (P->long_pass) {
 			double tJoin0 = nowUs();
 			for (auto& t : longThreads) t.join();
@@ -2250,8 +2251,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			if (!longPostInThread) afterLongPass();
 			for (uint64_t r = 0; r < n; r++) if (glue[r].capacityExceededLong) glue[r].capacityExceeded = true;
 			if (P->keep_traces) {
-				longCells.resize(hLongSmall[0]);
-				if (hLongSmall[0]) HIP_CHECK(hipMemcpy(longCells.data(), dLongCells, hLongSmall[0] * sizeof(LongCell), hipMemcpyDeviceToHost));
+				LongCell* staged = st->hLongCells.reserve<LongCell>(hLongSmall[0]);
+				if (hLongSmall[0]) HIP_CHECK(hipMemcpyAsync(staged, dLongCells, hLongSmall[0] * sizeof(LongCell), hipMemcpyDeviceToHost, st->longStream));
+				syncStream(st->longStream);
+				longCells = staged;
 			}
 		}
 
@@ -2390,7 +2393,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			forEachAnchor(r, [&](uint64_t slot, uint64_t F) {
 				gl.nAnchors++;
 				gl.nPath += anchors[slot].pathLen;
-				if (P->keep_traces) {
+				if (anchorTraces) {
 					const ExtResult& eb = extResults[2 * slot];
 					const ExtResult& ef = extResults[2 * slot + 1];
 					uint32_t p = slotSeqPos(r, slot, F) - (anchors[slot].x);
@@ -2423,7 +2426,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		res->anchor_first_node = mallocArray<uint32_t>(nAnchors); res->anchor_first_offset = mallocArray<uint32_t>(nAnchors); res->anchor_first_seqpos = mallocArray<uint32_t>(nAnchors);
 		res->anchor_last_node = mallocArray<uint32_t>(nAnchors); res->anchor_last_offset = mallocArray<uint32_t>(nAnchors); res->anchor_last_seqpos = mallocArray<uint32_t>(nAnchors);
 		res->anchor_score = mallocArray<int32_t>(nAnchors);
-		if (P->keep_traces) {
+		if (anchorTraces) {
 			res->anchor_trace_off = mallocArray<uint64_t>(nAnchors + 1);
 			res->anchor_trace_node = mallocArray<int32_t>(nTrace); res->anchor_trace_offset = mallocArray<uint32_t>(nTrace);
 			res->anchor_trace_seqpos = mallocArray<uint32_t>(nTrace); res->anchor_trace_switch = mallocArray<uint8_t>(nTrace);
@@ -2514,7 +2517,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				res->anchor_first_node[a] = rec.firstNode; res->anchor_first_offset[a] = rec.firstOffset; res->anchor_first_seqpos[a] = rec.firstSeqPos + frags[F].l;
 				res->anchor_last_node[a] = rec.lastNode; res->anchor_last_offset[a] = rec.lastOffset; res->anchor_last_seqpos[a] = rec.lastSeqPos + frags[F].l;
 				res->anchor_score[a] = rec.score;
-				if (P->keep_traces) {
+				if (anchorTraces) {
 					// merged trace in the reference's output coordinates (bigraph node id, offset in original node),
 					// src/GraphAligner.h:527-565,590-608
 					res->anchor_trace_off[a] = traceAt;

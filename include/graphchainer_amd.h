@@ -47,7 +47,8 @@ typedef struct gc_params {
 	double  seed_density;       /* --seeds-minimizer-density (10) */
 	int32_t min_cluster_size;   /* --seeds-clustersize (1) */
 	int32_t long_pass;          /* 1: also run the whole-read GraphAligner pass (src/Aligner.cpp:630-654) */
-	int32_t keep_traces;        /* 1: return per-anchor traces (debug / parity tests) */
+	int32_t keep_traces;        /* 1: return the traces of every anchor and of every whole-read alignment (parity tests); 2: the alignments' traces only
+	                             *    (long_trace_*: what gc_format_gaf / _json / _gam read; the anchors' traces - 13 B x ~37 cells per anchor - stay on the device) */
 	int32_t keep_seeds;         /* 1: return the ordered seed list of every read (seed_* arrays; else they are empty) */
 	int32_t stitch;             /* 1: stitch the chain into one path (src/Aligner.cpp:754-822): read_path_off / path_* */
 	int32_t edit_distances;     /* 1: GreedyLength selection of the whole-read alignments and the two NW edit distances that pick
