@@ -42,11 +42,13 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=int(os.environ.get("GC_BENCH_CONFIG", 2)), choices=[2, 3])
-    ap.add_argument("--backbone", type=int, default=int(os.environ.get("GC_BENCH_BACKBONE", 50_800_000)))
+    ap.add_argument("--config", type=int, default=int(os.environ.get("GC_BENCH_CONFIG", 2)), choices=[2, 3, 5])
+    ap.add_argument("--chromosomes", type=int, default=24, help="config 5: weakly connected chromosome graphs in the GFA (two components each, one per strand)")
+    ap.add_argument("--backbone", type=int, default=int(os.environ.get("GC_BENCH_BACKBONE", 0)), help="backbone bp (config 2 / 3: 50.8 Mbp; config 5: 8 Mbp per chromosome)")
     ap.add_argument("--reads", type=int, default=None, help="reads per rank and step (default: 10 000 for config 2, 100 000 for config 3)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("GC_BENCH_BATCH", 10_000)), help="reads per gc_align_batch call")
-    ap.add_argument("--read-len", type=int, default=10_000)
+    ap.add_argument("--read-len", type=int, default=None)
+    ap.add_argument("--colinear-gap", type=int, default=None)
     ap.add_argument("--split-gap", type=int, default=None)
     ap.add_argument("--sv-fraction", type=float, default=float(os.environ.get("GC_BENCH_SV_FRACTION", 0.0)),
                     help="fraction of the reads that carry a 1.5 kb deletion the graph does not hold: the reads whose chained alignment wins (decision.chained_better > 0)")
@@ -62,8 +64,17 @@ def parse_args():
                     help="batches in flight per GPU, each on its own gc_stream and host thread (like the reference's -t worker threads); with two, one "
                          "batch's seeding, host glue and fragment pipeline run beside the other's whole-read pass (measured: 1 -> 285, 2 -> 255, 3 -> 486 ms per batch)")
     args = ap.parse_args()
+    # config 5 on one GPU (BASELINE configs[4] is the whole genome over eight): 24 chromosome graphs, 2 000 CLR-like 50 kb reads, --colinear-gap 50000
     if args.reads is None:
-        args.reads = 100_000 if args.config == 3 else 10_000
+        args.reads = 100_000 if args.config == 3 else 2_000 if args.config == 5 else 10_000
+    if args.read_len is None:
+        args.read_len = 50_000 if args.config == 5 else 10_000
+    if args.colinear_gap is None:
+        args.colinear_gap = 50_000 if args.config == 5 else 10_000
+    if not args.backbone:
+        args.backbone = 8_000_000 if args.config == 5 else 50_800_000
+    if args.config == 5 and args.batch == 10_000:
+        args.batch = 2_000
     if args.split_gap is None:
         args.split_gap = 18 if args.config == 3 else 35
     return args
@@ -104,10 +115,12 @@ def cpu_baseline_leg(args, gfa, reads, long_pass):
     src/Aligner.cpp:1267-1270)."""
     from oracle import Oracle   # the CPU baseline leg is the one place bench.py may touch the oracle
     threads = args.cpu_threads or usable_cpus()
-    ora = Oracle(gfa, long_pass=long_pass, split_gap=args.split_gap)
+    ora = Oracle(gfa, long_pass=long_pass, split_gap=args.split_gap, colinear_gap=args.colinear_gap)
     n1 = min(args.cpu_sample, len(reads))
+    if args.config == 5:
+        n1 = min(n1, 40)                                   # (50 kb reads: a core does one or two per second)
     wall1, stage1 = ora.align_timed(reads[:n1], 1)
-    n_all = min(len(reads), max(n1, 250 * threads))   # ~10-15 s at the ~20 reads/s a core does
+    n_all = min(len(reads), max(n1, (20 if args.config == 5 else 250) * threads))   # ~10-15 s at the ~20 reads/s a core does (10 kb reads)
     # the same run keeps 12 values per read (chain, chain score, both NW distances, the decision, the whole-read alignments and the
     # selection): main() compares them with the timed GPU output after the timed region ("parity_check")
     wall_all, _, summary = ora.align_summary(reads[:n_all], threads)
@@ -128,15 +141,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     long_pass = not args.no_long_pass
 
-    from graphchainer_amd.synth import SynthGraph
+    from graphchainer_amd.synth import SynthGenome, SynthGraph
     t0 = time.time()
     tmp = tempfile.mkdtemp(prefix="gcbench_")
     gfa = os.path.join(tmp, "graph.gfa")
-    sg = SynthGraph(args.backbone, seed=7)
-    sg.write_gfa(gfa)
     strong = args.strong and world > 1
-    # weak scaling: every rank draws its own reads; strong scaling: all ranks draw the same set and the work queue divides it
-    reads = sg.sample_reads(args.reads, args.read_len, seed=11 + (0 if strong else rank), sv_fraction=args.sv_fraction)
+    if args.config == 5:
+        # several chromosomes in one GFA (the cross-component rule of src/AlignmentGraph.cpp:1722-1733), multi-allelic and nested sites (cover width > 2),
+        # reverse-strand links, repeats; reads at PacBio-CLR-like error rates
+        sg = SynthGenome(args.chromosomes, args.backbone, seed=7, multi_allelic=0.1, nested=0.1, minus_links=0.3, repeats=4, repeat_len=3000)
+        sg.write_gfa(gfa)
+        reads = sg.sample_reads(args.reads, args.read_len, seed=11 + (0 if strong else rank), p_del=0.04, p_sub=0.02, p_ins=0.09)
+    else:
+        sg = SynthGraph(args.backbone, seed=7)
+        sg.write_gfa(gfa)
+        # weak scaling: every rank draws its own reads; strong scaling: all ranks draw the same set and the work queue divides it
+        reads = sg.sample_reads(args.reads, args.read_len, seed=11 + (0 if strong else rank), sv_fraction=args.sv_fraction)
     t_gen = time.time() - t0
 
     cpu_baseline = cpu_summary = None
@@ -210,7 +230,8 @@ def main():
         os.remove(cache)
 
     inflight = max(1, args.inflight)
-    aligners = [gca.Aligner(graph, seeder, split_gap=args.split_gap, long_pass=long_pass) for _ in range(inflight)]
+    mem_free_start, mem_total = gca.device_memory()
+    aligners = [gca.Aligner(graph, seeder, split_gap=args.split_gap, colinear_gap=args.colinear_gap, long_pass=long_pass) for _ in range(inflight)]
     # the rank's reads as length-sorted batches (one batch for config 2), uploaded before the timed region; the upload itself
     # (2-bit packing, reverse complement, match-mask bit vectors, PCIe) is timed here and reported beside the step time
     chunks = length_sorted_batches(reads, args.batch)
@@ -260,6 +281,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t_start
     host_cpu_s = cpu_seconds() - cpu_start
+    mem_free_end, _ = gca.device_memory()
     # Parity of the timed mode (src/Aligner.cpp:630-654,735,901-905): the reads the CPU leg aligned with the oracle are compared, value
     # for value, with what EVERY timed batch returned for them - chain, chain score, both NW distances, the decision, the whole-read
     # alignments and the selection. Outside the timed region; a mismatch fails the run.
@@ -391,8 +413,9 @@ def main():
             "ms_per_step": round(elapsed / steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "gbp_per_sec_aligned": round(gbp_per_s, 5),
-            "config": {"workload": f"BASELINE configs[{args.config - 1}]: chr22-like synthetic DAG ({args.backbone} bp backbone, {graph.NodeSize()} split nodes), "
-                                   f"{args.reads} x {args.read_len} bp ONT-like reads {'in total' if strong else 'per GPU'} in batches of {args.batch}, split_len 35 split_gap {args.split_gap} bandwidth 10"
+            "config": {"workload": (f"BASELINE configs[4] sized for one GPU: {args.chromosomes} chromosome graphs x {args.backbone} bp ({graph.NodeSize()} split nodes, {2 * args.chromosomes} components), CLR-like errors, colinear_gap {args.colinear_gap}, " if args.config == 5 else
+                                    f"BASELINE configs[{args.config - 1}]: chr22-like synthetic DAG ({args.backbone} bp backbone, {graph.NodeSize()} split nodes), ")
+                                   + f"{args.reads} x {args.read_len} bp {'CLR' if args.config == 5 else 'ONT'}-like reads {'in total' if strong else 'per GPU'} in batches of {args.batch}, split_len 35 split_gap {args.split_gap} bandwidth 10"
                                    + (f", {args.sv_fraction:.0%} of the reads with a 1.5 kb deletion" if args.sv_fraction > 0 else ""),
                        "stages": ("whole-read GraphAligner pass + selection + " if long_pass else "") + "seed lookup + seed ordering + fragment seed-extension + anchors + co-linear chaining + chain stitching + NW edit distances + chained-vs-whole-read decision + chained alignment trace (edlib path) for its winners",
                        "reads_per_gpu": args.reads if not strong else None, "read_len": args.read_len, "batch": args.batch, "batches_in_flight_per_gpu": inflight,
@@ -408,6 +431,7 @@ def main():
             "stage_ms": {"k_seed_probe+compact": round(kernel_us[0] / 1e3, 3), "k_extend": round(kernel_us[1] / 1e3, 3), "k_build_anchors": round(kernel_us[2] / 1e3, 3),
                          "k_chain": round(kernel_us[3] / 1e3, 3), "k_long_extend_all_rounds": round(kernel_us[4] / 1e3, 3), "whole_read_pass_wall": round(kernel_us[5] / 1e3, 3), "seed_glue_wall": round(host_us[0] / 1e3, 3), "host_result_assembly": round(host_us[1] / 1e3, 3),
                          "wall_seed_lookup_and_copies": round(host_us[2] / 1e3, 3), "wall_extend_to_chain_and_copies": round(host_us[3] / 1e3, 3)},
+            "device_memory_gb": {"total": round(mem_total / 2**30, 1), "graph_and_index": round((mem_total - mem_free_start) / 2**30, 1), "in_use_after_timed_steps": round((mem_total - mem_free_end) / 2**30, 1)},
             "setup_s": {"generate": round(t_gen, 1), "graph_build_upload": round(t_graph, 1), "minimizer_index": round(t_index, 1),
                         "index_cache_save": round(t_save, 1), "index_cache_load_upload": round(t_load, 1), "index_cache_bytes": cache_bytes},
             "reads_with_chain": int(reads_with_chain / steps), "extensions_per_step": int(counters[4]),

@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "gc_params_default", "gc_graph_create_from_gfa", "gc_graph_create", "gc_graph_destroy", "gc_graph_num_nodes",
     "gc_graph_size_bp", "gc_graph_array", "gc_seeder_create", "gc_seeder_destroy", "gc_seeder_array",
     "gc_stream_create", "gc_stream_destroy", "gc_reads_upload", "gc_reads_destroy", "gc_align_batch",
-    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_edit_distance", "gc_edit_path", "gc_evalue", "gc_format_gaf", "gc_format_json", "gc_format_gam",
+    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_device_memory", "gc_edit_distance", "gc_edit_path", "gc_evalue", "gc_format_gaf", "gc_format_json", "gc_format_gam",
     "gc_index_build", "gc_index_save", "gc_index_load", "gc_index_check",
 ]
 
@@ -106,6 +106,15 @@ def _check(rc):
 
 def device_count():
     return load_library().gc_device_count()
+
+
+def device_memory():
+    """(free, total) bytes of the current device's memory."""
+    lib = load_library()
+    free, total = C.c_uint64(), C.c_uint64()
+    lib.gc_device_memory.argtypes = [_P(C.c_uint64), _P(C.c_uint64)]
+    _check(lib.gc_device_memory(C.byref(free), C.byref(total)))
+    return int(free.value), int(total.value)
 
 
 def set_device(index):

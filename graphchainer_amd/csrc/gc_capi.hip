@@ -335,6 +335,7 @@ struct gc_stream {
 		std::vector<uint32_t> pairRead;
 		uint32_t nPairs = 0;
 	} edLong[2];
+	uint64_t longCellsPerBase = 8;           // merged-trace cells per read base the whole-read pass reserves (grows when a batch needs more)
 	std::vector<hipStream_t> groupStreams;   // read groups of the whole-read pass run their round loops concurrently
 	std::vector<hipEvent_t> groupEvents;     // 2 * LONG_EVENT_RING per group
 	DeviceBuffer longSeeds, longJobs, longAlns, longResults, longScratch, longCells, longCursor, longJobsFallback, longResultsFallback, longScratchFallback;
@@ -865,6 +866,19 @@ int gc_device_count(void)
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
 	return n;
+}
+
+// free and total bytes of the current device's memory (hipMemGetInfo): what a host sizing its batches - or a benchmark reporting its peak - needs
+int gc_device_memory(uint64_t* free_bytes, uint64_t* total_bytes)
+{
+	if (!free_bytes || !total_bytes) return fail(GC_ERR_INVALID, "null argument");
+	return guarded([&]() {
+		requireDevice();
+		size_t f = 0, t = 0;
+		HIP_CHECK(hipMemGetInfo(&f, &t));
+		*free_bytes = f; *total_bytes = t;
+		return (int)GC_OK;
+	});
 }
 
 int gc_set_device(int device)
@@ -1484,6 +1498,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		LongReadResult* hLongResults = nullptr;
 		unsigned long long* hLongSmall = nullptr;
 		LongCell* dLongCells = nullptr;
+		uint64_t cellBudget = 0;                      // capacity of the merged-trace cell pool (grown and the pass rerun when a batch overflows it)
+		std::function<bool()> growLongCells;          // whole-read pass thread: the pool was too small -> enlarge it, reset the pass's cursors; false when it cannot grow
 		std::function<uint64_t()> longFallback;
 		std::function<void(uint32_t)> runLongGroup;
 		std::function<void()> finishLongGroups;
@@ -1592,10 +1608,13 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			if (nLongSeeds >= 0xffffffffull) throw std::runtime_error("batch too large for the whole-read pass");
 			LongSeed* hSeeds = st->hLongSeeds.reserve<LongSeed>(deviceGlue ? 0 : nLongSeeds);
 			LongJob* hJobs = st->hLongJobs.reserve<LongJob>(n);
-			uint64_t cellBudget = 0;
-			uint64_t cellsPerBase = 8;   // room for several partial alignments per read before the end-to-end one
+			// merged-trace cells per read base: 8 hold the few partial alignments a 10 kb ONT read collects before its end-to-end one (cfg2 uses ~1.1);
+			// noisy 50 kb CLR reads on a genome with repeats collect 8-9 alignments each and overflowed it (a quarter of the reads flagged, which reads
+			// depending on timing). The stream remembers what its batches needed, and a batch that overflows reruns its pass with three times the room.
+			uint64_t cellsPerBase = st->longCellsPerBase;
 			if (const char* env = getenv("GC_LONG_CELLS_PER_BASE")) cellsPerBase = (uint64_t)std::max(2, atoi(env));
-			for (uint64_t r = 0; r < n; r++) cellBudget += cellsPerBase * (R->offsets[r + 1] - R->offsets[r]) + 1024;
+			auto budgetFor = [R, n](uint64_t perBase) { uint64_t b = 0; for (uint64_t r = 0; r < n; r++) b += perBase * (R->offsets[r + 1] - R->offsets[r]) + 1024; return b; };
+			cellBudget = budgetFor(cellsPerBase);
 			pool.run(n, [&](size_t r, size_t) {
 				const ReadGlue& gl = glue[r];
 				uint64_t at = gl.longSeedBegin;
@@ -1686,7 +1705,20 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			uint32_t* groupRoundsPtr = groupRounds.data();
 			const uint64_t* groupBeginPtr = groupBegin.data();
 			const uint64_t* groupTraceBeginPtr = groupTraceBegin.data();
-			runLongGroup = [=](uint32_t g) {
+			growLongCells = [=, &dLongCells, &cellBudget]() mutable {
+				bool overflowed = false;
+				for (uint64_t r = 0; r < n && !overflowed; r++) overflowed = hLongResults[r].status == 4;
+				if (!overflowed || getenv("GC_LONG_CELLS_PER_BASE")) return false;   // (a fixed pool is a test's way to provoke the flag)
+				const uint64_t next = st->longCellsPerBase * 3;
+				if (next > 256 || budgetFor(next) * sizeof(LongCell) > (64ull << 30)) return false;
+				st->longCellsPerBase = next;
+				cellBudget = budgetFor(next);
+				dLongCells = st->longCells.reserve<LongCell>(cellBudget);
+				HIP_CHECK(hipMemsetAsync(dLongCursor, 0, cursorWords * sizeof(unsigned long long), ls));
+				syncStream(ls);
+				return true;
+			};
+			runLongGroup = [=, &dLongCells, &cellBudget](uint32_t g) {
 				const uint64_t r0 = groupBeginPtr[g], nG = groupBeginPtr[g + 1] - r0;
 				if (nG == 0) return;
 				hipStream_t q = st->groupStreams[g];
@@ -1711,7 +1743,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				std::unique_lock<std::mutex> roundLock(g_longPassToken[deviceNow & 15], std::defer_lock);
 
 				for (int round = 0; round < 4096; round++) {
-					launchZeroWords(q, cursor, 3);   // [0] work count, [1] round trace cursor, [2] next work slot
+					launchZeroWords(q, cursor, 4);   // [0] work count, [1] round trace cursor, [2] next work slot, [3] length of the retry list
 					// tail rounds: once fewer than a quarter of the reads are still active the chip is mostly idle, so the
 					// remaining reads try several seeds per round (exact: k_long_merge re-checks them in order)
 					// (the number of work items stays below what round 0 had: active reads x candidates <= n)
@@ -1755,15 +1787,17 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 							dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, 6u, cursor + 3);
 					} else
 					launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, team, blocks,
-						dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2);
+						dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, 0, nullptr, team == 1 ? dRetryList + w0 : nullptr, cursor + 3);
 					if (team == 1) {
 						// extensions whose band outgrew the 64-entry register tables: second try with the LDS/HBM tables (two lanes per wave,
 						// 28 + 228 entries); waves whose items are fine leave at once. Beyond that the read goes to the plain-layout fallback.
 						// (those items are listed first - almost always none - so that the retry is a handful of waves that fetch from the list, not
 						// one wave per pair of work items that looks at a status and leaves: that cost 0.5-2 ms of every round)
-						launchZeroWords(q, cursor + 2, 2);   // [2] next slot, [3] length of the retry list
-						launchLongRetryList(q, dLongWorkResults + w0, nWorkItems, EXT_LDS_CAP, dRetryList + w0, cursor + 3);
-						uint32_t retryBlocks = std::min<uint32_t>(256, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / 2));
+						if (useSm || (uint64_t)blocks * team < nWorkItems) {   // (the list is the extension kernel's own, unless the state-machine path or persistent waves used the slot counter)
+							launchZeroWords(q, cursor + 2, useSm ? 2 : 1);   // [2] next slot, [3] length of the retry list
+							if (useSm) launchLongRetryList(q, dLongWorkResults + w0, nWorkItems, EXT_LDS_CAP, dRetryList + w0, cursor + 3);
+						}
+						uint32_t retryBlocks = std::min<uint32_t>(16, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / 2));   // (persistent waves over a list that is almost always empty)
 						launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dRetryList + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 2, retryBlocks,
 							dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, EXT_LDS_CAP, cursor + 3);
 					}
@@ -1792,7 +1826,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				res->counters_long[6] = rounds;
 			};
 			// reads whose band did not fit the LDS tables (status 5) are rerun with the plain-layout kernel
-			longFallback = [=]() {
+			longFallback = [=, &dLongCells, &cellBudget]() {
 				syncStream(ls);
 				std::vector<uint32_t> redo;
 				const bool forceAll = getenv("GC_LONG_FORCE_FALLBACK") != nullptr;   // test hook: run every read through the plain-layout kernel too
@@ -1889,6 +1923,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 						if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc token] stream %p asked %.1f got %.1f (call began %.1f)\n", (void*)st, tTokenAsk / 1e3, nowUs() / 1e3, tCall / 1e3);
 						{ double now = nowUs(), seen = longWallBeginUs.load(); while ((seen == 0.0 || now < seen) && !longWallBeginUs.compare_exchange_weak(seen, now)) {} }
 						runLongGroup(g);
+						while (longGroups == 1 && growLongCells && growLongCells()) runLongGroup(g);   // the cell pool overflowed: again, with room
 						{ double now = nowUs(), seen = longWallEndUs.load(); while (now > seen && !longWallEndUs.compare_exchange_weak(seen, now)) {} }
 						if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc token] stream %p released %.1f\n", (void*)st, nowUs() / 1e3);
 						if (token.owns_lock()) token.unlock();   // the next batch's pass may start; what follows is this batch's own tail

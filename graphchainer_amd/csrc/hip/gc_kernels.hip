@@ -914,7 +914,7 @@ template <int LANES, bool PERSISTENT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LANES == 1 ? 8 : GC_LONG_MIN_WAVES, 8))) k_long_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint64_t* __restrict__ masks, ExtendConfig cfg,
 	const LongWork* __restrict__ work, const uint32_t* __restrict__ order, uint32_t nWork, unsigned long long* __restrict__ scratch, uint64_t wordsPerLane,
 	unsigned long long* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, LongWorkResult* __restrict__ results, unsigned long long* __restrict__ counters,
-	unsigned long long* __restrict__ nextSlot, uint32_t retryStatus, const unsigned long long* __restrict__ nWorkOnDevice)
+	unsigned long long* __restrict__ nextSlot, uint32_t retryStatus, const unsigned long long* __restrict__ nWorkOnDevice, uint32_t* __restrict__ capListOut, unsigned long long* __restrict__ capCountOut)
 {
 	__shared__ WaveLdsT<LANES> lds;
 	if (nWorkOnDevice) nWork = (uint32_t)*nWorkOnDevice;   // (the retry launch: its items are a list another kernel has just written)
@@ -971,6 +971,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LANES =
 			}
 		}
 		if (leader) results[w] = res;
+		// (the work items whose band outgrew this layout's tables go on the list of the retry launch: almost always none - the list saves a kernel
+		// that looked at every result, and the retry is a handful of waves)
+		if (leader && capListOut && res.status == EXT_LDS_CAP) capListOut[atomicAdd(capCountOut, 1ull)] = w;
 	}
 	if (cnt.extensions && leader) {
 		atomicAdd(&counters[0], cnt.dpTiles);
@@ -1169,7 +1172,7 @@ uint64_t chainScratchBytes(const ChainCaps& caps)
 }
 
 uint32_t chainGridBlocks(uint32_t nReads) { return nReads < 2048 ? nReads : 2048; }   // three blocks fit a CU (LDS); every block owns a threshold-list region in HBM
-uint32_t chainScratchBlocks(uint32_t nReads) { return nReads < 256 ? nReads : 256; }   // the reads that do not fit the LDS tables are few
+uint32_t chainScratchBlocks(uint32_t nReads) { return nReads < 2048 ? nReads : 2048; }   // reads that do not fit the LDS tables: few on 10 kb reads (waves whose read is done leave at once), ALL of them on 50 kb reads (config 5: 256 blocks took 727 ms per 2 000 reads)
 
 void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
 	int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* scratch, uint32_t* chainOut, uint32_t* chainLen, unsigned long long* chainScore, uint32_t* chainStatus, bool forceScratch)
@@ -1205,7 +1208,7 @@ uint32_t longExtendTeamSize(uint32_t nWork)
 
 void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
 	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters,
-	unsigned long long* nextSlot, uint32_t retryStatus, const unsigned long long* nWorkOnDevice)
+	unsigned long long* nextSlot, uint32_t retryStatus, const unsigned long long* nWorkOnDevice, uint32_t* capListOut, unsigned long long* capCountOut)
 {
 	if (!nWork) return;
 	uint64_t words = longWaveWordsPerLane(cfg);
@@ -1214,8 +1217,8 @@ void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTabl
 	// and registers to the fragment pipeline's kernels that share the device with it
 	static const uint32_t ldsPad = []() { const char* e = getenv("GC_LONG_WAVES_PER_SIMD"); int w = e ? atoi(e) : 0; return (w >= 1 && w <= 7) ? (uint32_t)((160u * 1024u / (4u * (uint32_t)w)) & ~255u) : 0u; }();
 	const uint32_t pad = lanes == 1 ? ldsPad : 0;
-#define GC_LAUNCH_TEAM(N) do { if (persistent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, true>), dim3(blocks), dim3(64), pad, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot, retryStatus, nWorkOnDevice); \
-	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, false>), dim3(blocks), dim3(64), pad, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot, retryStatus, nWorkOnDevice); } while (0)
+#define GC_LAUNCH_TEAM(N) do { if (persistent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, true>), dim3(blocks), dim3(64), pad, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot, retryStatus, nWorkOnDevice, capListOut, capCountOut); \
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, false>), dim3(blocks), dim3(64), pad, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot, retryStatus, nWorkOnDevice, capListOut, capCountOut); } while (0)
 	switch (lanes) {
 		case 1: GC_LAUNCH_TEAM(1); break;
 		case 2: GC_LAUNCH_TEAM(2); break;

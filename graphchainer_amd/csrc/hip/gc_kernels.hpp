@@ -174,7 +174,7 @@ void launchLongSelect(hipStream_t stream, const DGraph& g, const LongJob* jobs, 
 uint32_t longExtendTeamSize(uint32_t nWork);
 void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
 	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters,
-	unsigned long long* nextSlot, uint32_t retryStatus = 0, const unsigned long long* nWorkOnDevice = nullptr);   // nWorkOnDevice: `order` is a list whose length only the device knows (then nWork is its upper bound)
+	unsigned long long* nextSlot, uint32_t retryStatus = 0, const unsigned long long* nWorkOnDevice = nullptr, uint32_t* capListOut = nullptr, unsigned long long* capCountOut = nullptr);   // nWorkOnDevice: `order` is a list whose length only the device knows (then nWork is its upper bound)
 // the same extensions one per LANE as per-lane state machines (gc_sm.hip); what outgrows its tables answers EXT_SM_DECLINED (6) and is rerun by launchLongExtend
 uint64_t longSmSlabBytes(const ExtendConfig& cfg);
 void launchLongExtendSm(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,

@@ -256,6 +256,8 @@ int gc_format_gam(const gc_graph* g, const gc_result* result, const char* const*
 
 int gc_device_count(void);
 int gc_set_device(int device);
+/* free / total bytes of the current device's memory (a host that sizes its batches: a 10 k x 10 kb batch in flight holds ~75 GB of scratch) */
+int gc_device_memory(uint64_t* free_bytes, uint64_t* total_bytes);
 
 #ifdef __cplusplus
 }
