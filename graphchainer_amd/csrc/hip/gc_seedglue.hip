@@ -15,7 +15,6 @@
 
 namespace gcdev {
 
-#define GLUE_LDS_ELEMS 1024
 
 struct GlueElem { uint32_t k0, k1lo, k1hi, id; };
 
@@ -85,6 +84,11 @@ __device__ __forceinline__ void glueWindows(Key key, uint32_t nS, uint32_t len, 
 	nFout = nF; slotsOut = slots; budgetOut = budget; widestOut = widest;
 }
 
+// Two instantiations: GLUE_LDS_ELEMS = 1024 (24 KB of LDS, six blocks per CU) takes the reads whose seed bound fits it - every 10 kb read; the other one
+// (no LDS image, so as many blocks per CU as wave slots) takes the rest on HBM arrays (50 kb reads carry ~2 200 seeds). The serial sorts are bound by
+// the latency of a lane's dependent accesses, so what counts for the long reads is how many run at once: a 4096-element LDS image (96 KB, one block
+// per CU) measured 820 ms per 2 000 x 50 kb reads against 231 ms for the HBM arrays at six blocks per CU.
+template <uint32_t GLUE_LDS_ELEMS, uint32_t SKIP_UP_TO>
 __global__ void __launch_bounds__(64) k_seed_glue(SeedIndex idx, DGraph g, const uint64_t* __restrict__ readOff, uint32_t nReads, const uint8_t* __restrict__ invalidRead,
 	const uint2* __restrict__ matches, const uint32_t* __restrict__ readMatchOff, const uint32_t* __restrict__ readMatchCount, const uint32_t* __restrict__ readSeedOff, const uint32_t* __restrict__ winCapOff,
 	double density, uint32_t splitLen, uint32_t splitGap, uint32_t longPass, GlueStaging st,
@@ -109,6 +113,7 @@ __global__ void __launch_bounds__(64) k_seed_glue(SeedIndex idx, DGraph g, const
 		const uint32_t nM = invalidRead[r] ? 0u : readMatchCount[r];
 		const uint32_t mOff = readMatchOff[r], sOff = readSeedOff[r];
 		const uint32_t cap = readSeedOff[r + 1] - sOff;   // bound of the read's seed list: the sum of its hits' occurrence counts
+		if (SKIP_UP_TO ? cap <= SKIP_UP_TO : cap > GLUE_LDS_ELEMS) continue;   // (the other instantiation's read)
 		uint32_t* const win = st.winBuf + 4ull * winCapOff[r];
 		uint32_t nS = 0, nF = 0, slots = 0, widest = 0;
 		unsigned long long budget = 0;
@@ -455,7 +460,9 @@ void launchSeedGlue(hipStream_t stream, const SeedIndex& idx, const DGraph& g, c
 	GlueCounts counts { perRead, perRead + stride, perRead + 2 * stride, perRead + 3 * stride };
 	uint32_t* fragOff = perRead + 4 * stride;
 	uint32_t* slotOff = perRead + 5 * stride;
-	hipLaunchKernelGGL(k_seed_glue, dim3(blocks), dim3(64), 0, stream, idx, g, readOff, nReads, invalidRead, matches, readMatchOff, readMatchCount, readSeedOff, winCapOff, density, splitLen, splitGap, longPass ? 1u : 0u, st,
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seed_glue<1024, 0>), dim3(blocks), dim3(64), 0, stream, idx, g, readOff, nReads, invalidRead, matches, readMatchOff, readMatchCount, readSeedOff, winCapOff, density, splitLen, splitGap, longPass ? 1u : 0u, st,
+		longSeeds, readSeeds, counts, cursors);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seed_glue<1, 1024>), dim3(blocks), dim3(64), 0, stream, idx, g, readOff, nReads, invalidRead, matches, readMatchOff, readMatchCount, readSeedOff, winCapOff, density, splitLen, splitGap, longPass ? 1u : 0u, st,
 		longSeeds, readSeeds, counts, cursors);
 	// where every read's fragments and anchor slots begin: exclusive scans in read order (cursors[0] = fragments, [1] = slots of the batch)
 	hipLaunchKernelGGL(k_exclusive_scan_u32, dim3(2), dim3(1024), 0, stream, (const uint32_t*)counts.nFrags, nReads, fragOff, cursors, (const uint32_t*)counts.nSlots, slotOff, cursors + 1);
