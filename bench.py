@@ -75,6 +75,8 @@ def parse_args():
         args.backbone = 8_000_000 if args.config == 5 else 50_800_000
     if args.config == 5 and args.batch == 10_000:
         args.batch = 2_000
+    if args.config == 5 and "GC_BENCH_INFLIGHT" not in os.environ and not any(a.startswith("--inflight") for a in sys.argv[1:]):
+        args.inflight = 2                                  # a 2 000 x 50 kb batch in flight holds ~90 GB of scratch: three fill the 288 GB
     if args.split_gap is None:
         args.split_gap = 18 if args.config == 3 else 35
     return args

@@ -1041,8 +1041,15 @@ static void uploadSeeder(gc_seeder* S)
 	std::vector<uint64_t> table(tableSize, ~0ull);
 	for (size_t i = 0; i < nKeys; i++) {
 		uint32_t hsh = hostHashKmer(S->host.kmers[i]) & (uint32_t)(tableSize - 1);
-		while ((uint32_t)(table[hsh] >> 32) != 0xffffffffu) hsh = (hsh + 1) & (uint32_t)(tableSize - 1);
-		table[hsh] = (S->host.kmers[i] << 32) | (uint64_t)i;
+		while (table[hsh] != ~0ull) hsh = (hsh + 1) & (uint32_t)(tableSize - 1);
+		table[hsh] = ((S->host.kmers[i] & 0xffffffffull) << 32) | (uint64_t)i;   // (k <= 15: the whole k-mer; longer ones are verified against wideKmers)
+	}
+	if (nKeys >= 0xffffffffull) throw std::runtime_error("minimizer index too large for 32-bit key indices");
+	S->dev.wideKmers = nullptr;
+	if (S->host.k > 15) {
+		uint64_t* dKmers = uploadVector(S->host.kmers);
+		S->allocations.push_back(dKmers);
+		S->dev.wideKmers = dKmers;
 	}
 	uint64_t* dTable = uploadVector(table);
 	S->allocations.push_back(dTable);
@@ -1077,7 +1084,7 @@ static void uploadSeeder(gc_seeder* S)
 static bool buildSeederOnDevice(const gc_graph* G, gc_seeder* S, size_t k, size_t w, double keepLeastFrequentFraction)
 {
 	if (const char* env = getenv("GC_SEEDER_BUILD")) if (!strcmp(env, "host")) return false;
-	if (w - k + 2 > 32) return false;
+	if (w - k + 2 > 32 || k > 15) return false;   // (the device build packs the k-mer into 30 bits of its sort key: longer minimizers are built on the host)
 	const gc::AlignmentGraph& h = G->host;
 	// minimizers ending inside an overlap prefix are skipped (src/MinimizerSeeder.cpp:323-340,369): never the case for the 0M graphs the
 	// library loads, checked rather than assumed
@@ -1112,12 +1119,12 @@ static bool buildSeederOnDevice(const gc_graph* G, gc_seeder* S, size_t k, size_
 	return true;
 }
 
-static bool seederShapeOk(int64_t k, int64_t w) { return k >= 1 && k <= 15 && w >= k; }
+static bool seederShapeOk(int64_t k, int64_t w) { return k >= 1 && k <= 31 && w >= k; }   // (the reference's range: src/AlignerMain.cpp:221,390)
 
 int gc_seeder_create(const gc_graph* g, int32_t k, int32_t w, double keepFraction, gc_seeder** out)
 {
 	if (!g || !out) return fail(GC_ERR_INVALID, "null argument");
-	if (!seederShapeOk(k, w)) return fail(GC_ERR_INVALID, "supported minimizer length is 1..15 (32-bit key slots) with w >= k");
+	if (!seederShapeOk(k, w)) return fail(GC_ERR_INVALID, "supported minimizer length is 1..31 with w >= k");
 	*out = nullptr;
 	gc_seeder* S = new gc_seeder();
 	int rc = guarded([&]() {
@@ -1135,7 +1142,7 @@ int gc_seeder_create(const gc_graph* g, int32_t k, int32_t w, double keepFractio
 int gc_index_build(const char* gfa_path, int32_t k, int32_t w, double keepFraction, const char* cache_path)
 {
 	if (!gfa_path || !cache_path) return fail(GC_ERR_INVALID, "null argument");
-	if (k > 0 && !seederShapeOk(k, w)) return fail(GC_ERR_INVALID, "supported minimizer length is 1..15 (32-bit key slots) with w >= k");
+	if (k > 0 && !seederShapeOk(k, w)) return fail(GC_ERR_INVALID, "supported minimizer length is 1..31 with w >= k");
 	try {
 		gc::GfaGraph gfa = gc::GfaGraph::LoadFromFile(gfa_path);
 		gc::AlignmentGraph graph = gc::AlignmentGraph::BuildFromGFA(gfa);

@@ -44,9 +44,8 @@ __device__ __forceinline__ uint32_t lookupKmer(const SeedIndex& idx, uint64_t km
 	uint32_t h = hashKmer(kmer) & idx.tableMask;
 	while (true) {
 		uint64_t slot = idx.table[h];
-		uint32_t key = (uint32_t)(slot >> 32);
-		if (key == 0xffffffffu) return 0xffffffffu;
-		if (key == (uint32_t)kmer) return (uint32_t)slot;
+		if (slot == ~0ull) return 0xffffffffu;
+		if ((uint32_t)(slot >> 32) == (uint32_t)kmer && (!idx.wideKmers || idx.wideKmers[(uint32_t)slot] == kmer)) return (uint32_t)slot;
 		h = (h + 1) & idx.tableMask;
 	}
 }

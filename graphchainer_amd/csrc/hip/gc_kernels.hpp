@@ -5,7 +5,9 @@
 namespace gcdev {
 
 struct SeedIndex {   // minimizer index in HBM (reference: MinimizerSeeder buckets, src/MinimizerSeeder.h:16-30)
-	const uint64_t* table;      // open addressing: (kmer << 32) | keyIndex, empty = all ones
+	const uint64_t* table;      // open addressing: (low 32 bits of the k-mer << 32) | keyIndex, empty = all ones
+	const uint64_t* wideKmers;  // k > 15 (the reference takes minimizer lengths up to 31, src/MinimizerSeeder.cpp:63): the k-mer of every key, checked when a slot's
+	                            // 32-bit tag matches; null for k <= 15, where the tag is the whole k-mer
 	uint32_t tableMask;
 	const uint32_t* filter;     // 2^filterBits-bit membership filter over the keys: bit filterBit(kmer) is set for every key
 	uint32_t filterShift;       // 64 - filterBits

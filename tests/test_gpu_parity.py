@@ -912,3 +912,23 @@ def test_two_ranks_real_aligner_strong_queue(gca, tmp_path):
         merged = np.load(tmp_path / f"merged{step}.npy")
         assert np.array_equal(merged, expect), f"step {step}: rows {np.nonzero((merged != expect).any(axis=1))[0]} differ from the oracle"
     assert int(np.sum(want["chained_better"])) > 0 and int(np.diff(want["read_chain_off"]).min()) >= 0
+
+
+@pytest.mark.parametrize("k,w", [(19, 30), (31, 31), (16, 25)])
+def test_minimizer_lengths_above_15(gca, tmp_path, k, w):
+    """--seeds-minimizer-length goes up to 31 in the reference (src/AlignerMain.cpp:221,390, src/MinimizerSeeder.cpp:63): k-mers beyond 30 bits are
+    looked up through the 32-bit tag of the hash slot plus a check of the key's whole k-mer; the index for them is built on the host. Seeds,
+    anchors, chains and whole-read alignments against the oracle run with the same k and w."""
+    from graphchainer_amd.synth import SynthGraph
+    from oracle import Oracle
+    sg = SynthGraph(150_000, seed=19)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(10, 6000, seed=4, p_del=0.01, p_sub=0.015, p_ins=0.01)   # (long k-mers need cleaner reads to hit)
+    graph = gca.AlignmentGraph(gfa)
+    seeder = gca.MinimizerSeeder(graph, minimizer_length=k, window_size=w)
+    aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, long_pass=True, chain_traces=2)
+    got = _normalise(aligner.align_reads(reads), graph.array("nodeLength"))
+    want = Oracle(gfa, k=k, w=w, long_pass=True).align(reads)
+    compare(got, want, COMPARE_KEYS + LONG_KEYS)
+    assert int(got["read_seed_off"][-1]) > 50
