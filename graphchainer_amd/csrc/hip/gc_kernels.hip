@@ -1178,8 +1178,11 @@ void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, 
 {
 	if (nReads == 0) return;
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true>), dim3(chainGridBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, forceScratch ? 1u : 0u);
-	// reads with more anchors / entries than the LDS tables hold, or on a cover wider than the LDS threshold table (waves whose read is done leave at once)
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<false>), dim3(chainScratchBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, 0u);
+	// reads with more anchors / entries than the LDS tables hold, or on a cover wider than the LDS threshold table (waves whose read is done leave at once).
+	// The batch's bounds tell when no read can need it (cfg2: 400 slots per read at most, cover width 2): 2 048 waves that look and leave cost 7 ms of queueing per batch.
+	// (it is then a safety net of eight waves for what the bounds do not show - a graph with more than 65 535 components, a read beyond 65 535 fragment positions)
+	const bool cannotBeNeeded = !forceScratch && caps.capAnchors <= CHAIN_LDS_ANCHORS && caps.capEndpoints <= CHAIN_LDS_ENTRIES && caps.capTable <= CHAIN_LDS_WIDTH;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<false>), dim3(cannotBeNeeded ? (nReads < 8 ? nReads : 8) : chainScratchBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, 0u);
 }
 
 uint64_t longWaveWordsPerLane(const ExtendConfig& cfg) { return waveScratchWords(cfg.maxSlices, cfg.maxItems, cfg.maxTrace, cfg.maxCols); }
