@@ -66,7 +66,7 @@ def test_damaged_files_are_refused(gca, tmp_path):
     with pytest.raises(RuntimeError):
         gca.api.check_index_cache(str(tmp_path / "missing.gcidx"))
     with pytest.raises(RuntimeError):
-        gca.api.build_index_cache(os.path.join(GOLD, "ref_test_graph.gfa"), str(tmp_path / "k.gcidx"), 16, 20)
+        gca.api.build_index_cache(os.path.join(GOLD, "ref_test_graph.gfa"), str(tmp_path / "k.gcidx"), 32, 40)   # (minimizer lengths run to 31, src/MinimizerSeeder.cpp:63)
 
 
 def test_load_needs_a_device(gca, tmp_path):
