@@ -49,6 +49,8 @@ def load_oracle_lib():
     lib.gco_edit_path.argtypes = [C.c_char_p, u64, C.c_char_p, u64, C.c_void_p, u64, C.POINTER(C.c_longlong)]
     lib.gco_evalue.argtypes = [C.c_double, u64, u64, u64, u64, C.c_void_p]
     lib.gco_set_e_cutoff.argtypes = [C.c_void_p, C.c_double]
+    lib.gco_extend.restype = C.c_int
+    lib.gco_extend.argtypes = [C.c_void_p, C.c_char_p, u64, C.c_int, u64]
     lib.gco_align_timed.restype = C.c_double
     lib.gco_align_timed.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.gco_align_summary.restype = C.c_double
@@ -145,6 +147,24 @@ class Oracle:
         summary = np.zeros((len(bs), 12), dtype=np.int64)
         wall = self.lib.gco_align_summary(self.h, b"".join(bs), off.ctypes.data, len(bs), int(threads), stage.ctypes.data, summary.ctypes.data)
         return float(wall), stage, summary
+
+    def extend(self, sequence, bigraph_node_id, node_offset):
+        """One seed extension (src/GraphAlignerBitvectorBanded.h:46-71) laid open: per kept slice its minimum, minimum cell and node set, and the trace.
+        Returns None when the extension trips one of the reference's assertions."""
+        b = sequence.encode() if isinstance(sequence, str) else bytes(sequence)
+        rc = self.lib.gco_extend(self.h, b, len(b), int(bigraph_node_id), int(node_offset))
+        if rc == 2:
+            return None
+        off = self._array("ext_slice_off")
+        nodes = self._array("ext_slice_nodes")
+        return {
+            "failed": rc == 1,
+            "slice_min": self._array("ext_slice_min").tolist(),
+            "slice_min_cell": list(zip(self._array("ext_slice_minnode").tolist(), self._array("ext_slice_minoffset").tolist())),
+            "slice_nodes": [nodes[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)],
+            "score": None if rc == 1 else int(self._array("ext_score")[0]),
+            "trace": [] if rc == 1 else [tuple(x) for x in self._array("ext_trace").reshape(-1, 3).tolist()],
+        }
 
     def gaf(self, merge=False):
         """GAF text of the last align() call (read ids r0, r1, ...), the reference's writer restated (oracle/output.hpp)."""

@@ -562,6 +562,7 @@ private:
 	static void checkBacktraceCircularity(const OnewayTrace& result);
 
 public:
+	DPSlice initialSlice(int bigraphNodeId, size_t offset) const { return getInitialSliceExactPosition(bigraphNodeId, offset); }   // (for gco_extend)
 	DPTable getViterbiSlices(std::string_view sequence, const DPSlice& initialSlice, size_t numSlices, AlignerState& state) const;
 	static void removeWronglyAlignedEnd(DPTable& table);
 	OnewayTrace getReverseTraceFromTable(std::string_view sequence, const DPTable& slice, MatrixPosition startPos, int32_t startScore, AlignerState& state) const;

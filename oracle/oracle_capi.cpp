@@ -598,6 +598,46 @@ void gco_evalue(double minIdentity, uint64_t databaseSize, uint64_t querySize, u
 	out[0] = calc.getAlignmentScore(alignmentLength, numEdits);
 	out[1] = calc.getEValue(databaseSize, querySize, alignmentLength, numEdits);
 }
+// One extension (src/GraphAlignerBitvectorBanded.h:46-71) laid open for tests/extension_model.py: per kept slice (initial slice first, after the trim of
+// ...Common.h:1231-1241) its minimum score, minimum cell and node set, and the trace cells. Returns 0, 1 = the extension failed (no slice survived), 2 = assertion.
+int gco_extend(void* hv, const char* seq, uint64_t len, int bigraphNodeId, uint64_t nodeOffset)
+{
+	OracleHandle* h = (OracleHandle*)hv;
+	for (const char* name : { "ext_slice_min", "ext_slice_minnode", "ext_slice_minoffset", "ext_slice_off", "ext_slice_nodes", "ext_trace", "ext_score" }) h->ex[name].clear();
+	try {
+		BitvectorAligner bv(h->o.graph, h->o.params.bandwidth);
+		AlignerState state(h->o.graph);
+		std::string_view sequence(seq, len);
+		size_t numSlices = (len + 63) / 64;
+		// the same three calls getReverseTraceFromSeed makes, with the table kept
+		OnewayTrace whole = bv.getReverseTraceFromSeed(sequence, bigraphNodeId, nodeOffset, state);
+		AlignerState state2(h->o.graph);
+		DPTable table = bv.getViterbiSlices(sequence, bv.initialSlice(bigraphNodeId, nodeOffset), numSlices, state2);
+		BitvectorAligner::removeWronglyAlignedEnd(table);
+		h->ex["ext_slice_off"].push_back(0);
+		for (const DPSlice& sl : table.slices) {
+			h->ex["ext_slice_min"].push_back(sl.minScore);
+			h->ex["ext_slice_minnode"].push_back((int64_t)sl.minScoreNode);
+			h->ex["ext_slice_minoffset"].push_back((int64_t)sl.minScoreNodeOffset);
+			std::vector<int64_t> nodes;
+			for (const auto& item : sl.scores.items) nodes.push_back((int64_t)item.first);
+			std::sort(nodes.begin(), nodes.end());
+			for (int64_t x : nodes) h->ex["ext_slice_nodes"].push_back(x);
+			h->ex["ext_slice_off"].push_back((int64_t)h->ex["ext_slice_nodes"].size());
+		}
+		if (whole.failed()) return 1;
+		h->ex["ext_score"].push_back(whole.score);
+		for (const TraceItem& t : whole.trace) {
+			h->ex["ext_trace"].push_back((int64_t)t.DPposition.node);
+			h->ex["ext_trace"].push_back((int64_t)t.DPposition.nodeOffset);
+			h->ex["ext_trace"].push_back((int64_t)t.DPposition.seqPos);   // (size_t)-1 -> -1
+		}
+		return 0;
+	} catch (const AssertionFailure& e) {
+		h->error = e.what();
+		return 2;
+	}
+}
 void gco_set_e_cutoff(void* hv, double cutoff) { ((OracleHandle*)hv)->o.params.eCutoff = cutoff; }
 uint64_t gco_edit_distance(const char* a, uint64_t na, const char* b, uint64_t nb) { return editDistanceNW(std::string(a, a + na), std::string(b, b + nb)); }
 uint64_t gco_minimizer_hash(uint64_t k) { return gc::minimizerHash(k); }

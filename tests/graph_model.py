@@ -335,3 +335,41 @@ def chain_bruteforce(out_adj, in_adj, component_of, anchors):
         if first or end[0] > best_score:
             first, best_chain, best_score = False, chain, end[0]
     return best_chain, best_score
+
+
+def find_linearizable(inn):
+    """AlignmentGraph::findLinearizable, src/AlignmentGraph.cpp:644-735, statement for statement. The start node is marked `checked` before the walk begins (:662), so the walk's
+    own "already checked" exit (:684-697) fires on the first iteration and clears the flag of the only node on the stack: the result is all False on every graph."""
+    n = len(inn)
+    linearizable, checked, on_stack = [False] * n, [False] * n, [False] * n
+    for node in range(n):
+        if checked[node]:
+            continue
+        checked[node] = True
+        if len(inn[node]) != 1:
+            continue
+        stack = [node]
+        on_stack[node] = True
+        while True:
+            back = stack[-1]
+            if len(inn[back]) != 1 or checked[back]:
+                for v in stack[:-1]:
+                    checked[v], linearizable[v], on_stack[v] = True, True, False
+                linearizable[back], checked[back], on_stack[back] = False, True, False
+                break
+            neighbor = inn[back][0]
+            if neighbor == node:
+                for v in stack:
+                    checked[v], linearizable[v], on_stack[v] = True, False, False
+                break
+            if on_stack[neighbor]:
+                i = len(stack) - 1
+                while i > 0 and stack[i] != neighbor:
+                    checked[stack[i]], linearizable[stack[i]], on_stack[stack[i]] = True, False, False
+                    i -= 1
+                for v in stack[:i]:
+                    checked[v], linearizable[v], on_stack[v] = True, True, False
+                break
+            stack.append(neighbor)
+            on_stack[neighbor] = True
+    return linearizable
