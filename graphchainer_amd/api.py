@@ -26,10 +26,16 @@ EXPORTED_SYMBOLS = [
 ]
 
 
+class GcCapacities(C.Structure):
+    """gc_capacities (include/graphchainer_amd.h): sizes of the device-side tables; 0 = automatic."""
+    _fields_ = [("ext_max_items", C.c_int64), ("ext_max_pending", C.c_int64), ("ext_max_trace", C.c_int64), ("long_max_items", C.c_int64), ("long_column_store", C.c_int64),
+                ("long_cells_per_base", C.c_int64), ("long_scratch_bytes", C.c_int64), ("stitch_set_max", C.c_int64), ("stitch_bfs_cap", C.c_int64), ("reserved", C.c_int64 * 3)]
+
+
 class GcParams(C.Structure):
     _fields_ = [("bandwidth", C.c_int32), ("split_len", C.c_int32), ("split_gap", C.c_int32), ("colinear_gap", C.c_int64),
                 ("seed_density", C.c_double), ("min_cluster_size", C.c_int32), ("long_pass", C.c_int32), ("keep_traces", C.c_int32), ("keep_seeds", C.c_int32), ("stitch", C.c_int32), ("edit_distances", C.c_int32),
-                ("chain_traces", C.c_int32), ("e_cutoff", C.c_double)]
+                ("chain_traces", C.c_int32), ("e_cutoff", C.c_double), ("capacity", GcCapacities)]
 
 
 _P = C.POINTER
@@ -373,7 +379,8 @@ class BatchResult(dict):
 class Aligner:
     """Batched stand-in for the reference's per-read hot path (src/Aligner.cpp:601-922)."""
 
-    def __init__(self, graph, seeder, bandwidth=10, split_len=35, split_gap=35, colinear_gap=10000, seed_density=10.0, keep_traces=False, keep_seeds=False, long_pass=False, stitch=True, edit_distances=True, chain_traces=None, e_cutoff=-1.0):
+    def __init__(self, graph, seeder, bandwidth=10, split_len=35, split_gap=35, colinear_gap=10000, seed_density=10.0, keep_traces=False, keep_seeds=False, long_pass=False, stitch=True, edit_distances=True, chain_traces=None, e_cutoff=-1.0, capacities=None):
+        """capacities: {field of gc_capacities: value} for the device-side tables (default: all automatic)."""
         self.lib = load_library()
         self.graph = graph
         self.seeder = seeder
@@ -394,6 +401,10 @@ class Aligner:
         # and chains (long_pass=False) gets none unless it asks (chain_traces=1: winners, 2: every read)
         self.params.chain_traces = int(chain_traces) if chain_traces is not None else (1 if long_pass else 0)
         self.params.e_cutoff = float(e_cutoff)
+        for name, value in (capacities or {}).items():
+            if name not in dict(GcCapacities._fields_) or name == "reserved":
+                raise ValueError("no such capacity: " + name)
+            setattr(self.params.capacity, name, int(value))
         self.stream = C.c_void_p()
         _check(self.lib.gc_stream_create(C.byref(self.stream)))
 

@@ -902,6 +902,14 @@ void gc_params_default(gc_params* p)
 	p->edit_distances = 1;
 	p->chain_traces = 1;
 	p->e_cutoff = -1;
+	memset(&p->capacity, 0, sizeof(p->capacity));   // automatic
+}
+
+// One capacity: the GC_* environment variable (experiments, test hooks) wins over gc_params::capacity, 0 there means automatic.
+static int64_t capacityOr(const char* envName, int64_t param, int64_t automatic)
+{
+	if (const char* env = getenv(envName)) return atoll(env);
+	return param != 0 ? param : automatic;
 }
 
 int gc_graph_create_from_gfa(const char* gfa_path, gc_graph** out)
@@ -1345,6 +1353,13 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 {
 	if (!G || !S || !st || !R || !P || !out) return fail(GC_ERR_INVALID, "null argument");
 	if (P->split_len < 16 || P->split_len > 64 || P->split_gap < 1) return fail(GC_ERR_INVALID, "split_len must be in [16,64] (one 64-row slice per fragment extension) and split_gap >= 1");
+	{
+		const gc_capacities& c = P->capacity;
+		if (c.reserved[0] || c.reserved[1] || c.reserved[2]) return fail(GC_ERR_INVALID, "gc_params::capacity.reserved must be 0 (was the struct initialised with gc_params_default?)");
+		const int64_t v[] = { c.ext_max_items, c.ext_max_pending, c.ext_max_trace, c.long_max_items, c.long_cells_per_base, c.long_scratch_bytes, c.stitch_set_max, c.stitch_bfs_cap };
+		for (int64_t x : v) if (x < 0 || x > (1ll << 40)) return fail(GC_ERR_INVALID, "gc_params::capacity: a size is negative or absurd (0 = automatic)");
+		if (c.long_column_store < -1 || c.long_column_store > (1ll << 31)) return fail(GC_ERR_INVALID, "gc_params::capacity.long_column_store: -1 (none), 0 (automatic) or a column count");
+	}
 	*out = nullptr;
 	const double tCall = nowUs();
 	const double cpuCall = processCpuMs();
@@ -1618,8 +1633,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			// merged-trace cells per read base: 8 hold the few partial alignments a 10 kb ONT read collects before its end-to-end one (cfg2 uses ~1.1);
 			// noisy 50 kb CLR reads on a genome with repeats collect 8-9 alignments each and overflowed it (a quarter of the reads flagged, which reads
 			// depending on timing). The stream remembers what its batches needed, and a batch that overflows reruns its pass with three times the room.
-			uint64_t cellsPerBase = st->longCellsPerBase;
-			if (const char* env = getenv("GC_LONG_CELLS_PER_BASE")) cellsPerBase = (uint64_t)std::max(2, atoi(env));
+			const bool cellPoolPinned = getenv("GC_LONG_CELLS_PER_BASE") || P->capacity.long_cells_per_base > 0;
+			const uint64_t cellsPerBase = (uint64_t)std::max<int64_t>(2, capacityOr("GC_LONG_CELLS_PER_BASE", P->capacity.long_cells_per_base, (int64_t)st->longCellsPerBase));
 			auto budgetFor = [R, n](uint64_t perBase) { uint64_t b = 0; for (uint64_t r = 0; r < n; r++) b += perBase * (R->offsets[r + 1] - R->offsets[r]) + 1024; return b; };
 			cellBudget = budgetFor(cellsPerBase);
 			pool.run(n, [&](size_t r, size_t) {
@@ -1648,9 +1663,8 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			// column store of the one-extension-per-wave kernel: the DP keeps every column (16 B) so that the backtrace loads its tiles' columns back instead of
 			// recomputing them (45 % of the kernel's column steps). ~2.1 columns per read row on cfg2; an extension that needs more than this room ends
 			// with EXT_OVERFLOW and its read goes to the plain-layout kernel, which recomputes. GC_LONG_MAX_COLS=0: no store (the r2 behaviour).
-			lcfg.maxCols = (uint32_t)(3 * maxReadLen + 4096);
-			if (const char* env = getenv("GC_LONG_MAX_COLS")) lcfg.maxCols = (uint32_t)std::max(0, atoi(env));
-			if (const char* env = getenv("GC_LONG_MAX_ITEMS")) lcfg.maxItems = (uint32_t)std::max(64, atoi(env));
+			lcfg.maxCols = (uint32_t)std::max<int64_t>(0, capacityOr("GC_LONG_MAX_COLS", P->capacity.long_column_store, (int64_t)(3 * maxReadLen + 4096)));   // (-1 in the parameters, 0 in the environment: no store)
+			lcfg.maxItems = (uint32_t)std::max<int64_t>(64, capacityOr("GC_LONG_MAX_ITEMS", P->capacity.long_max_items, lcfg.maxItems));
 			if (const char* env = getenv("GC_LONG_REG_CAP")) lcfg.regCap = (uint32_t)std::max(1, std::min(64, atoi(env)));   // test hook: force the LDS-table retry
 			uint64_t waveWords = longWaveWordsPerLane(lcfg);
 			if (!deviceGlue) dLongSeeds = st->longSeeds.reserve<LongSeed>(nLongSeeds);
@@ -1702,7 +1716,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			unsigned long long* dRoundTrace = st->longRoundTrace.reserve<unsigned long long>(groupTraceBegin[nGroups]);
 			// extension scratch: one region per lane of a resident wave (persistent waves fetch work items), per read group
 			// (bounded by a memory budget: 0.8 MB per lane for 10 kb reads, 2.4 MB for 50 kb reads; GC_LONG_SCRATCH_GB overrides the 48 GB)
-			uint64_t scratchBudget = 48ull << 30;
+			uint64_t scratchBudget = P->capacity.long_scratch_bytes > 0 ? (uint64_t)P->capacity.long_scratch_bytes : 48ull << 30;
 			if (const char* env = getenv("GC_LONG_SCRATCH_GB")) scratchBudget = (uint64_t)std::max(1, atoi(env)) << 30;
 			const uint64_t scratchLanes = std::min<uint64_t>(workCapacity + 64, std::max<uint64_t>(2048, std::min<uint64_t>(65536 + 64, scratchBudget / (waveWords * 8))));
 			dLongScratch = st->longScratch.reserve<unsigned long long>((uint64_t)nGroups * scratchLanes * waveWords);
@@ -1715,7 +1729,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			growLongCells = [=, &dLongCells, &cellBudget]() mutable {
 				bool overflowed = false;
 				for (uint64_t r = 0; r < n && !overflowed; r++) overflowed = hLongResults[r].status == 4;
-				if (!overflowed || getenv("GC_LONG_CELLS_PER_BASE")) return false;   // (a fixed pool is a test's way to provoke the flag)
+				if (!overflowed || cellPoolPinned) return false;   // (a pinned pool flags the reads instead: the caller asked for that much and no more)
 				const uint64_t next = st->longCellsPerBase * 3;
 				if (next > 256 || budgetFor(next) * sizeof(LongCell) > (64ull << 30)) return false;
 				st->longCellsPerBase = next;
@@ -2020,9 +2034,9 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		cfg.maxItems = 72;
 		cfg.maxPending = 48;
 		cfg.maxTrace = 192;
-		if (const char* env = getenv("GC_EXT_MAX_ITEMS")) cfg.maxItems = (uint32_t)std::max(8, atoi(env));
-		if (const char* env = getenv("GC_EXT_MAX_PENDING")) cfg.maxPending = (uint32_t)std::max(8, atoi(env));
-		if (const char* env = getenv("GC_EXT_MAX_TRACE")) cfg.maxTrace = (uint32_t)std::max(64, atoi(env));
+		cfg.maxItems = (uint32_t)std::max<int64_t>(8, capacityOr("GC_EXT_MAX_ITEMS", P->capacity.ext_max_items, cfg.maxItems));
+		cfg.maxPending = (uint32_t)std::max<int64_t>(8, capacityOr("GC_EXT_MAX_PENDING", P->capacity.ext_max_pending, cfg.maxPending));
+		cfg.maxTrace = (uint32_t)std::max<int64_t>(64, capacityOr("GC_EXT_MAX_TRACE", P->capacity.ext_max_trace, cfg.maxTrace));
 		uint32_t nWork = (uint32_t)(2 * nSlots);
 		uint64_t slabBytes = extendSlabBytes(cfg);
 		uint32_t lanes = extendGridLanes(nWork);
@@ -2127,7 +2141,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			HIP_CHECK(hipMemsetAsync(dCursor, 0, sizeof(unsigned long long), stream));
 			launchStitch(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, dChainOut, dChainLen, dChainStatus, dPathPool, pathCapacity, (long long)P->colinear_gap, dSlotOf,
 				dRegions, dStitchNodes, stitchDenseCap, dCursor, dStitchInfo,
-				getenv("GC_STITCH_SET_MAX") ? (uint32_t)atoi(getenv("GC_STITCH_SET_MAX")) : 0, getenv("GC_STITCH_BFS_CAP") ? (uint32_t)atoi(getenv("GC_STITCH_BFS_CAP")) : 0);
+				(uint32_t)capacityOr("GC_STITCH_SET_MAX", P->capacity.stitch_set_max, 0), (uint32_t)capacityOr("GC_STITCH_BFS_CAP", P->capacity.stitch_bfs_cap, 0));
 			HIP_CHECK(hipMemcpyAsync(stitchInfo, dStitchInfo, n * sizeof(StitchInfo), hipMemcpyDeviceToHost, stream));
 			HIP_CHECK(hipMemcpyAsync(hStitchCursor, dCursor, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		}

@@ -46,7 +46,8 @@ def run_case(gca, gfa, reads, long_pass=False, **kw):
     from oracle import Oracle
     graph = gca.AlignmentGraph(gfa)
     seeder = gca.MinimizerSeeder(graph)
-    aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, long_pass=long_pass, chain_traces=2, **kw)
+    capacities = kw.pop("capacities", None)
+    aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, long_pass=long_pass, chain_traces=2, capacities=capacities, **kw)
     got = {k: (v.astype(np.int64) if v.dtype.kind in "ui" and k not in ("counters", "counters_long") else v) for k, v in aligner.align_reads(reads).items()}
     expand_stitched_path(got, graph.array("nodeLength"))
     mark_missing_chain_alignments(got)
@@ -481,19 +482,39 @@ def _per_read(res, off_key, key, r):
     return np.asarray(res[key][int(res[off_key][r]):int(res[off_key][r + 1])], dtype=np.int64)
 
 
-def test_fragment_overflow_is_retried(gca, tmp_path, monkeypatch):
-    """Slabs far too small for most fragment extensions (8 tiles, 8 queue entries): the retry launch with 16x the room recovers every
+def test_fragment_overflow_is_retried(gca, tmp_path):
+    """Slabs far too small for most fragment extensions (gc_params::capacity: 8 tiles, 8 queue entries): the retry launch with 16x the room recovers every
     one of them - same results as the oracle, nothing flagged."""
     from graphchainer_amd.synth import SynthGraph
-    monkeypatch.setenv("GC_EXT_MAX_ITEMS", "8")
-    monkeypatch.setenv("GC_EXT_MAX_PENDING", "8")
     sg = SynthGraph(80_000, seed=51, multi_allelic=0.3, nested=0.3)
     gfa = str(tmp_path / "g.gfa")
     sg.write_gfa(gfa)
     reads = sg.sample_reads(8, 3000, seed=2)
-    got, want = run_case(gca, gfa, reads)
+    got, want = run_case(gca, gfa, reads, capacities={"ext_max_items": 8, "ext_max_pending": 8})
     compare(got, want)
     assert not got["capacity_exceeded"].any()
+
+
+def test_capacity_block_is_validated_and_the_column_store_is_optional(gca, tmp_path):
+    """gc_params::capacity: nonsense is refused before anything runs; long_column_store = -1 (the backtrace recomputes its tiles, as in r2) and a store too small for
+    most extensions (they fall back to the recomputing layout) give the same answers as the default."""
+    from graphchainer_amd.synth import SynthGraph
+    sg = SynthGraph(60_000, seed=52)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(6, 4000, seed=3)
+    graph = gca.AlignmentGraph(gfa)
+    seeder = gca.MinimizerSeeder(graph)
+    with pytest.raises(RuntimeError):
+        gca.Aligner(graph, seeder, capacities={"ext_max_items": -5}).align_reads(reads)
+    with pytest.raises(ValueError):
+        gca.Aligner(graph, seeder, capacities={"no_such_table": 1})
+    base = gca.Aligner(graph, seeder, long_pass=True, keep_traces=True).align_reads(reads)
+    for cap in ({"long_column_store": -1}, {"long_column_store": 700}):
+        got = gca.Aligner(graph, seeder, long_pass=True, keep_traces=True, capacities=cap).align_reads(reads)
+        for key in base:
+            if key not in ("counters", "counters_long", "kernel_us", "host_us"):
+                assert np.array_equal(np.asarray(got[key]), np.asarray(base[key])), (cap, key)
 
 
 def test_lazy_fragment_extension_equals_eager(gca, tmp_path, monkeypatch):
@@ -541,11 +562,13 @@ def test_capacity_overflow_flags_the_read_not_the_batch(gca, tmp_path, monkeypat
     seeder = gca.MinimizerSeeder(graph)
     want = Oracle(gfa, long_pass=True).align(reads)
     flagged_total = 0
-    for env in ({"GC_EXT_MAX_ITEMS": "8", "GC_EXT_RETRY_MAX_ITEMS": "10"}, {"GC_LONG_MAX_ITEMS": "64"}, {"GC_LONG_CELLS_PER_BASE": "2"}):
+    # (gc_params::capacity where the knob is public; the retry's own size is a test hook in the environment)
+    for env, cap in (({"GC_EXT_RETRY_MAX_ITEMS": "10"}, {"ext_max_items": 8}), ({}, {"long_max_items": 64}), ({}, {"long_cells_per_base": 2})):
         with monkeypatch.context() as m:
             for k, v in env.items():
                 m.setenv(k, v)
-            got = gca.Aligner(graph, seeder, long_pass=True).align_reads(reads)     # must not raise
+            got = gca.Aligner(graph, seeder, long_pass=True, capacities=cap).align_reads(reads)     # must not raise
+        env = (env, cap)
         flagged = np.asarray(got["capacity_exceeded"]).astype(bool)
         flagged_total += int(flagged.sum())
         for r in np.nonzero(~flagged)[0]:
