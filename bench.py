@@ -40,7 +40,7 @@ BYTES_PER_TRACE_ITEM = 32
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=int(os.environ.get("GC_BENCH_CONFIG", 2)), choices=[2, 3, 5])
     ap.add_argument("--chromosomes", type=int, default=24, help="config 5: weakly connected chromosome graphs in the GFA (two components each, one per strand)")
@@ -60,9 +60,10 @@ def parse_args():
     ap.add_argument("--e2e-steps", type=int, default=int(os.environ.get("GC_BENCH_E2E_STEPS", 3)),
                     help="after the timed steps (N=1): this many steps with the read upload (gc_reads_upload) and the GAF encoding of every batch inside the step "
                          "(the whole boundary: host bases in, GAF text out); 0 skips it")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("GC_BENCH_INFLIGHT", 3)),
-                    help="batches in flight per GPU, each on its own gc_stream and host thread (like the reference's -t worker threads); with two, one "
-                         "batch's seeding, host glue and fragment pipeline run beside the other's whole-read pass (measured: 1 -> 285, 2 -> 255, 3 -> 486 ms per batch)")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("GC_BENCH_INFLIGHT", 5)),
+                    help="batches in flight per GPU, each on its own gc_stream and host thread (like the reference's -t worker threads): one batch's seeding, fragment "
+                         "pipeline, distances and assembly run beside another's whole-read pass (r3, ms per 10 k x 10 kb batch: 1 -> 204, 2 -> 189, 3 -> 173, 4 -> 165, 5 -> 157, 6 -> 159; "
+                         "a batch in flight holds 31 GB of device memory, the whole-read scratch of 48 GB is shared per device)")
     args = ap.parse_args()
     # config 5 on one GPU (BASELINE configs[4] is the whole genome over eight): 24 chromosome graphs, 2 000 CLR-like 50 kb reads, --colinear-gap 50000
     if args.reads is None:
@@ -76,7 +77,7 @@ def parse_args():
     if args.config == 5 and args.batch == 10_000:
         args.batch = 2_000
     if args.config == 5 and "GC_BENCH_INFLIGHT" not in os.environ and not any(a.startswith("--inflight") for a in sys.argv[1:]):
-        args.inflight = 2                                  # a 2 000 x 50 kb batch in flight holds ~90 GB of scratch: three fill the 288 GB
+        args.inflight = 2                                  # (r3 measured with two; a 2 000 x 50 kb batch in flight held ~90 GB before the whole-read scratch was shared)
     if args.split_gap is None:
         args.split_gap = 18 if args.config == 3 else 35
     return args

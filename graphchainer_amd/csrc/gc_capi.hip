@@ -67,6 +67,7 @@ struct DeviceBuffer {   // growable device allocation owned by a stream object
 		}
 		return (T*)ptr;
 	}
+	void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
 	~DeviceBuffer() { if (ptr) (void)hipFree(ptr); }
 };
 
@@ -75,6 +76,12 @@ struct DeviceBuffer {   // growable device allocation owned by a stream object
 // seeding, host glue and fragment pipeline overlap the first batch's whole-read pass, and its own pass starts the moment the first
 // one ends - a software pipeline over batches (GC_LONG_TOKEN=0 turns it off).
 std::mutex g_longPassToken[16];
+// The pass's extension scratch (up to 48 GB: one region per resident wave) is only touched while the token is held, so the gc_streams of a device share ONE
+// (r3: 85 -> 37 GB per stream for 10 k x 10 kb batches, which is what lets five batches be in flight on a 288 GB device instead of three). It belongs to the
+// token: reserved (grown) by the pass that holds it, freed when the device's last gc_stream goes.
+struct SharedLongScratch { DeviceBuffer buffer; int streams = 0; };
+SharedLongScratch g_longScratch[16];
+std::mutex g_longScratchCount;
 
 double nowUs() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // CPU time of the whole process (all threads), for GC_DEBUG_TIMES' host budget lines
@@ -1261,10 +1268,24 @@ int gc_stream_create(gc_stream** out)
 		return (int)GC_OK;
 	});
 	if (rc != GC_OK) { delete st; return rc; }
+	{ std::lock_guard<std::mutex> lock(g_longScratchCount); g_longScratch[st->device & 15].streams++; }
 	*out = st;
 	return GC_OK;
 }
-void gc_stream_destroy(gc_stream* st) { delete st; }
+void gc_stream_destroy(gc_stream* st)
+{
+	if (!st) return;
+	{
+		std::lock_guard<std::mutex> count(g_longScratchCount);
+		SharedLongScratch& shared = g_longScratch[st->device & 15];
+		if (--shared.streams == 0) {   // the device's last stream: nobody can hold the token any more
+			std::lock_guard<std::mutex> token(g_longPassToken[st->device & 15]);
+			int current = 0;
+			if (hipGetDevice(&current) == hipSuccess) { (void)hipSetDevice(st->device); shared.buffer.release(); (void)hipSetDevice(current); }
+		}
+	}
+	delete st;
+}
 
 int gc_reads_upload(const char* bases, const uint64_t* offsets, uint64_t n, gc_reads** out)
 {
@@ -1524,6 +1545,9 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		std::function<bool()> growLongCells;          // whole-read pass thread: the pool was too small -> enlarge it, reset the pass's cursors; false when it cannot grow
 		std::function<uint64_t()> longFallback;
 		std::function<void(uint32_t)> runLongGroup;
+		unsigned long long* longScratchOfToken = nullptr;   // the device's shared extension scratch, set by the pass once it holds the token
+		uint64_t longScratchWords = 0;
+		bool shareLongScratch = false;
 		std::function<void()> finishLongGroups;
 		uint32_t longGroups = 0;
 		std::vector<double> groupExtendUs; std::vector<uint32_t> groupRounds; std::vector<uint64_t> groupBegin, groupTraceBegin;
@@ -1671,7 +1695,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			LongJob* dLongJobs = st->longJobs.reserve<LongJob>(n);
 			LongAln* dLongAlns = st->longAlns.reserve<LongAln>(n * maxAlignments);
 			LongReadResult* dLongResults = st->longResults.reserve<LongReadResult>(n);
-			unsigned long long* dLongScratch = nullptr;
+			unsigned long long* dLongScratchOwn = nullptr;   // (this stream's own scratch: only without the one-pass-at-a-time token)
 			dLongCells = st->longCells.reserve<LongCell>(cellBudget);
 			// Read groups: the rounds of one group are serial (select -> extend -> merge, host decides when to stop). Groups can
 			// run their round loops concurrently, each on its own stream and host thread (GC_LONG_GROUPS). Measured on cfg2
@@ -1719,7 +1743,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			uint64_t scratchBudget = P->capacity.long_scratch_bytes > 0 ? (uint64_t)P->capacity.long_scratch_bytes : 48ull << 30;
 			if (const char* env = getenv("GC_LONG_SCRATCH_GB")) scratchBudget = (uint64_t)std::max(1, atoi(env)) << 30;
 			const uint64_t scratchLanes = std::min<uint64_t>(workCapacity + 64, std::max<uint64_t>(2048, std::min<uint64_t>(65536 + 64, scratchBudget / (waveWords * 8))));
-			dLongScratch = st->longScratch.reserve<unsigned long long>((uint64_t)nGroups * scratchLanes * waveWords);
+			// one pass at a time (the default) works in the device's shared scratch; the experiments that let passes overlap keep a scratch per stream
+			longScratchWords = (uint64_t)nGroups * scratchLanes * waveWords;
+			shareLongScratch = nGroups == 1 && (getenv("GC_LONG_TOKEN") ? atoi(getenv("GC_LONG_TOKEN")) : 1) == 1;
+			if (!shareLongScratch) dLongScratchOwn = st->longScratch.reserve<unsigned long long>(longScratchWords);
 			groupExtendUs.assign(nGroups, 0.0);
 			groupRounds.assign(nGroups, 0);
 			double* groupExtendUsPtr = groupExtendUs.data();
@@ -1739,9 +1766,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				syncStream(ls);
 				return true;
 			};
-			runLongGroup = [=, &dLongCells, &cellBudget](uint32_t g) {
+			runLongGroup = [=, &dLongCells, &cellBudget, &longScratchOfToken](uint32_t g) {
 				const uint64_t r0 = groupBeginPtr[g], nG = groupBeginPtr[g + 1] - r0;
 				if (nG == 0) return;
+				unsigned long long* const dLongScratch = shareLongScratch ? longScratchOfToken : dLongScratchOwn;
 				hipStream_t q = st->groupStreams[g];
 				hipEvent_t* ring = st->groupEvents.data() + (size_t)2 * LONG_EVENT_RING * g;
 				// the rounds' extension time: read a ring slot's pair before the slot is reused (its round is complete by then: every round's
@@ -1941,6 +1969,10 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 						std::unique_lock<std::mutex> token(g_longPassToken[device & 15], std::defer_lock);
 						const double tTokenAsk = nowUs();
 						if (tokenMode == 1 && longGroups == 1) token.lock();
+						if (shareLongScratch) {
+							if (!token.owns_lock()) throw std::runtime_error("internal: shared whole-read scratch without the token");
+							longScratchOfToken = g_longScratch[device & 15].buffer.reserve<unsigned long long>(longScratchWords);
+						}
 						if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc token] stream %p asked %.1f got %.1f (call began %.1f)\n", (void*)st, tTokenAsk / 1e3, nowUs() / 1e3, tCall / 1e3);
 						{ double now = nowUs(), seen = longWallBeginUs.load(); while ((seen == 0.0 || now < seen) && !longWallBeginUs.compare_exchange_weak(seen, now)) {} }
 						runLongGroup(g);

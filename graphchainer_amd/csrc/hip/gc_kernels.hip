@@ -333,16 +333,59 @@ __global__ void __launch_bounds__(64) k_build_anchors(DGraph g, const Fragment* 
 		v.bw = tracePool + eb.traceOff; v.nBw = hasB ? (hasF ? eb.traceLen - 1 : eb.traceLen) : 0;
 		v.fw = tracePool + ef.traceOff; v.nFw = hasF ? ef.traceLen : 0;
 		uint32_t n = v.size();
-		// anchor path = distinct consecutive split nodes along the trace (src/Aligner.cpp:714-720)
+		// anchor path = distinct consecutive split nodes along the trace (src/Aligner.cpp:714-720). ONE pass over the two traces (r3): a 35-row fragment crosses one to three
+		// split nodes, so the path collects in six registers and only a longer one walks the traces a second time; the cells are fetched eight at a time (twelve-byte cells at a
+		// per-lane stride: the eight loads of a group go out together and use a cache line while it is there - issued one per iteration, every load found its line evicted by the
+		// other waves' lines and the kernel fetched 20 GB per 10 k reads for 2.5 GB of cells); the strand flip of a backward cell keeps its node's four table values while the
+		// node stays the same.
+		constexpr uint32_t PATH_REGS = 6;
+		uint32_t pn0 = 0, pn1 = 0, pn2 = 0, pn3 = 0, pn4 = 0, pn5 = 0;
 		uint32_t pathLen = 0, last = 0xffffffffu;
-		for (uint32_t i = 0; i < n; i++) {
-			uint32_t node, off; int32_t sp;
-			mergedCell(g, v, i, node, off, sp);
-			if (node != last) { pathLen++; last = node; }
+		AnchorRec rec;
+		rec.firstNode = rec.firstOffset = rec.firstSeqPos = 0;
+		rec.lastNode = rec.lastOffset = rec.lastSeqPos = 0;
+		bool haveFirst = false;
+		auto visit = [&](uint32_t node, uint32_t off, int32_t sp) __attribute__((always_inline)) {
+			if (node != last) {
+				switch (pathLen) { case 0: pn0 = node; break; case 1: pn1 = node; break; case 2: pn2 = node; break; case 3: pn3 = node; break; case 4: pn4 = node; break; case 5: pn5 = node; break; default: break; }
+				pathLen++; last = node;
+			}
+			if (!haveFirst) { rec.firstNode = node; rec.firstOffset = off; rec.firstSeqPos = (uint32_t)sp; haveFirst = true; }
+			rec.lastNode = node; rec.lastOffset = off; rec.lastSeqPos = (uint32_t)sp;
+		};
+		{
+			uint32_t cachedNode = 0xffffffffu, nodeOff = 0, origSz = 0, lookupBase = 0, cachedBlock = 0xffffffffu, twin = 0, twinBase = 0;
+			for (uint32_t i0 = 0; i0 < v.nBw; i0 += 8) {
+				TraceCell c[8];
+#pragma unroll
+				for (uint32_t u = 0; u < 8; u++) c[u] = v.bw[min(i0 + u, v.nBw - 1)];
+#pragma unroll
+				for (uint32_t u = 0; u < 8; u++) {
+					if (i0 + u >= v.nBw) break;
+					if (c[u].node != cachedNode) {
+						cachedNode = c[u].node;
+						const int32_t id = g.nodeIDs[cachedNode];
+						nodeOff = g.nodeOffset[cachedNode]; origSz = g.origSize[id]; lookupBase = g.lookupOff[id ^ 1];
+						cachedBlock = 0xffffffffu;
+					}
+					const uint32_t rev = origSz - 1 - (nodeOff + (c[u].offsetAndSwitch & 255u));   // GetReversePosition + GetUnitigNode, as in mergedCell
+					if (rev / 64 != cachedBlock) { cachedBlock = rev / 64; twin = g.lookup[lookupBase + cachedBlock]; twinBase = g.nodeOffset[twin]; }
+					visit(twin, rev - twinBase, v.p - 1 - c[u].seqPos);
+				}
+			}
+			for (uint32_t i0 = 0; i0 < v.nFw; i0 += 8) {   // the forward trace runs towards the seed: used back to front
+				TraceCell c[8];
+#pragma unroll
+				for (uint32_t u = 0; u < 8; u++) c[u] = v.fw[v.nFw - 1 - min(i0 + u, v.nFw - 1)];
+#pragma unroll
+				for (uint32_t u = 0; u < 8; u++) {
+					if (i0 + u >= v.nFw) break;
+					visit(c[u].node, c[u].offsetAndSwitch & 255u, v.p + 1 + c[u].seqPos);
+				}
+			}
 		}
 		unsigned long long base = atomicAdd(pathCursor, (unsigned long long)pathLen);
 		if (base + pathLen > pathCapacity) { status = 2; break; }
-		AnchorRec rec;
 		rec.valid = 1;
 		rec.x = fr.l;
 		rec.y = fr.l + (uint32_t)splitLen - 1;
@@ -350,14 +393,21 @@ __global__ void __launch_bounds__(64) k_build_anchors(DGraph g, const Fragment* 
 		rec.pathOff = base;
 		rec.pathLen = pathLen;
 		rec.score = (hasB ? eb.score : 0) + (hasF ? ef.score : 0);
-		uint32_t w = 0;
-		last = 0xffffffffu;
-		for (uint32_t i = 0; i < n; i++) {
-			uint32_t node, off; int32_t sp;
-			mergedCell(g, v, i, node, off, sp);
-			if (node != last) { pathPool[base + w++] = node; last = node; }
-			if (i == 0) { rec.firstNode = node; rec.firstOffset = off; rec.firstSeqPos = (uint32_t)sp; }
-			if (i == n - 1) { rec.lastNode = node; rec.lastOffset = off; rec.lastSeqPos = (uint32_t)sp; }
+		if (pathLen <= PATH_REGS) {
+			if (pathLen > 0) pathPool[base] = pn0;
+			if (pathLen > 1) pathPool[base + 1] = pn1;
+			if (pathLen > 2) pathPool[base + 2] = pn2;
+			if (pathLen > 3) pathPool[base + 3] = pn3;
+			if (pathLen > 4) pathPool[base + 4] = pn4;
+			if (pathLen > 5) pathPool[base + 5] = pn5;
+		} else {
+			uint32_t w = 0;
+			last = 0xffffffffu;
+			for (uint32_t i = 0; i < n; i++) {
+				uint32_t node, off; int32_t sp;
+				mergedCell(g, v, i, node, off, sp);
+				if (node != last) { pathPool[base + w++] = node; last = node; }
+			}
 		}
 		anchors[sIdx] = rec;
 	}
