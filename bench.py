@@ -77,7 +77,7 @@ def parse_args():
     if args.config == 5 and args.batch == 10_000:
         args.batch = 2_000
     if args.config == 5 and "GC_BENCH_INFLIGHT" not in os.environ and not any(a.startswith("--inflight") for a in sys.argv[1:]):
-        args.inflight = 2                                  # (r3 measured with two; a 2 000 x 50 kb batch in flight held ~90 GB before the whole-read scratch was shared)
+        args.inflight = 4                                  # 2 000 x 50 kb batches: 42 GB each + the shared 48 GB whole-read scratch (r3: 2 -> 1 355, 3 -> 795, 4 -> 685 ms per batch)
     if args.split_gap is None:
         args.split_gap = 18 if args.config == 3 else 35
     return args

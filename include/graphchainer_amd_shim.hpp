@@ -35,6 +35,7 @@
 #include <cstdint>
 #include <memory>
 #include <stdexcept>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -140,9 +141,18 @@ inline void OrderSeeds(const AlignmentGraph&, std::vector<SeedHit>&) {}
 
 // AlignOneWay, src/GraphAlignerWrapper.h:41. l < 0: the whole read (sloppy pass, src/Aligner.cpp:565); otherwise the fragment that
 // starts at `offset` (src/Aligner.cpp:691): `sequence` is then the fragment, and the read it belongs to is the one getSeeds saw last.
-inline AlignmentResult AlignOneWay(const AlignmentGraph&, const std::string& /*seq_id*/, const std::string& sequence, size_t, size_t, size_t, bool, bool, const std::vector<SeedHit>&,
-	Common::AlignerGraphsizedState&, bool, bool, bool, size_t, double, bool, double, int, long long l = -1, long long /*r*/ = -1, long long offset = 0, const std::string* wholeRead = nullptr)
+inline AlignmentResult AlignOneWay(const AlignmentGraph&, const std::string& /*seq_id*/, const std::string& sequence, size_t initialBandwidth, size_t rampBandwidth, size_t maxCellsPerSlice, bool /*quietMode*/,
+	bool /*sloppyOptimizations: implied by l < 0, as at src/Aligner.cpp:565,684*/, const std::vector<SeedHit>&, Common::AlignerGraphsizedState&, bool /*lowMemory*/, bool forceGlobal, bool preciseClipping,
+	size_t /*minClusterSize, seedExtendDensity: fixed at bind() time*/, double, bool /*nondeterministicOptimizations*/, double /*preciseClippingIdentityCutoff*/, int Xdropcutoff,
+	long long l = -1, long long /*r*/ = -1, long long offset = 0, const std::string* wholeRead = nullptr)
 {
+	// Options of this signature the kernels do not implement are refused, not ignored: a caller that asks for them would silently get the default behaviour otherwise.
+	// (--ramp-bandwidth: src/GraphAlignerBitvectorBanded.h:544,608-644; --precise-clipping / X-drop: :61-68,703-; forceGlobal: :587; a finite maxCellsPerSlice: :405,581.)
+	if (rampBandwidth > initialBandwidth) throw std::invalid_argument("gcshim::AlignOneWay: --ramp-bandwidth is not built (DESIGN.md section 9)");
+	if (preciseClipping || Xdropcutoff > 0) throw std::invalid_argument("gcshim::AlignOneWay: --precise-clipping / X-drop are not built (DESIGN.md section 9)");
+	if (forceGlobal) throw std::invalid_argument("gcshim::AlignOneWay: forced global alignment is not built (DESIGN.md section 9)");
+	if (maxCellsPerSlice != std::numeric_limits<size_t>::max()) throw std::invalid_argument("gcshim::AlignOneWay: a cell limit per slice (--tangle-effort) is not built (DESIGN.md section 9)");
+	if ((int64_t)initialBandwidth != (int64_t)binding().params.bandwidth) throw std::invalid_argument("gcshim::AlignOneWay: the bandwidth differs from the one given to gcshim::bind()");
 	AlignmentResult out;
 	if (l < 0) {
 		const gc_result& r = session().of(sequence);

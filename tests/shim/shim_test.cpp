@@ -59,7 +59,18 @@ int main(int argc, char** argv)
 		std::vector<SeedHit> seeds = gcshim::getSeeds(sequence, 10);                                   // :538 / :660
 		gcshim::currentRead() = sequence;
 		OrderSeeds(alignmentGraph, seeds);                                                             // :560 / :666
-		AlignmentResult longAlignments = AlignOneWay(alignmentGraph, "r", sequence, 10, 0, 0, true, true, seeds, reusableState, true, false, false, 1, -1, false, 0.5, 0, -1, -1, 0);   // :565
+		AlignmentResult longAlignments = AlignOneWay(alignmentGraph, "r", sequence, 10, 0, std::numeric_limits<size_t>::max(), true, true, seeds, reusableState, true, false, false, 1, -1, false, 0.5, 0, -1, -1, 0);   // :565
+		if (a == 2) {
+			// options of the signature that are not built are refused, not ignored: --ramp-bandwidth, --precise-clipping, a forced global alignment, a cell limit per slice
+			int refused = 0;
+			const size_t unlimited = std::numeric_limits<size_t>::max();
+			try { AlignOneWay(alignmentGraph, "r", sequence, 10, 20, unlimited, true, true, seeds, reusableState, true, false, false, 1, -1, false, 0.5, 0, -1, -1, 0); } catch (const std::invalid_argument&) { refused++; }
+			try { AlignOneWay(alignmentGraph, "r", sequence, 10, 0, unlimited, true, true, seeds, reusableState, true, false, true, 1, -1, false, 0.5, 0, -1, -1, 0); } catch (const std::invalid_argument&) { refused++; }
+			try { AlignOneWay(alignmentGraph, "r", sequence, 10, 0, unlimited, true, true, seeds, reusableState, true, true, false, 1, -1, false, 0.5, 0, -1, -1, 0); } catch (const std::invalid_argument&) { refused++; }
+			try { AlignOneWay(alignmentGraph, "r", sequence, 10, 0, 5000, true, true, seeds, reusableState, true, false, false, 1, -1, false, 0.5, 0, -1, -1, 0); } catch (const std::invalid_argument&) { refused++; }
+			try { AlignOneWay(alignmentGraph, "r", sequence, 35, 0, unlimited, true, true, seeds, reusableState, true, false, false, 1, -1, false, 0.5, 0, -1, -1, 0); } catch (const std::invalid_argument&) { refused++; }
+			if (refused != 5) { fprintf(stderr, "the shim accepted %d of 5 calls with options that are not built\n", 5 - refused); return 1; }
+		}
 		std::vector<AlignmentGraph::Anchor> A;
 		const size_t len = 35, sep = 35;
 		size_t sl = 0, sr = 0;
@@ -67,7 +78,7 @@ int main(int argc, char** argv)
 			while (sr < seeds.size() && seeds[sr].seqPos + seeds[sr].matchLen <= l + len) sr++;
 			while (sl < sr && seeds[sl].seqPos < l) sl++;
 			if (sl >= sr) continue;
-			AlignmentResult alignments = AlignOneWay(alignmentGraph, "f", sequence.substr(l, len), 10, 0, 0, true, false, seeds, reusableState, true, false, false, 1, -1, false, 0.5, 0, (long long)sl, (long long)sr, (long long)l);
+			AlignmentResult alignments = AlignOneWay(alignmentGraph, "f", sequence.substr(l, len), 10, 0, std::numeric_limits<size_t>::max(), true, false, seeds, reusableState, true, false, false, 1, -1, false, 0.5, 0, (long long)sl, (long long)sr, (long long)l);
 			for (auto& alignment : alignments.alignments) {
 				if (alignment.alignmentFailed() || alignment.trace->trace.empty()) continue;
 				AlignmentGraph::Anchor anchor { {}, l, l + len - 1 };
