@@ -115,6 +115,18 @@ static void syncStream(hipStream_t q)
 	HIP_CHECK(hipEventSynchronize(e));
 }
 
+// The same for one event (the round token of the whole-read pass is released the moment its extension kernel has finished).
+static void syncEvent(hipEvent_t ev)
+{
+	static const int pollUs = getenv("GC_SYNC_POLL_US") ? std::max(1, atoi(getenv("GC_SYNC_POLL_US"))) : 40;
+	for (int spins = 0;; spins++) {
+		const hipError_t e = hipEventQuery(ev);
+		if (e == hipSuccess) return;
+		if (e != hipErrorNotReady) HIP_CHECK(e);
+		if (spins >= 4) std::this_thread::sleep_for(std::chrono::microseconds(pollUs));
+	}
+}
+
 // Persistent worker pool for the per-read host glue (threads are created once per process).
 class WorkerPool {
 public:
@@ -1745,7 +1757,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			const uint64_t scratchLanes = std::min<uint64_t>(workCapacity + 64, std::max<uint64_t>(2048, std::min<uint64_t>(65536 + 64, scratchBudget / (waveWords * 8))));
 			// one pass at a time (the default) works in the device's shared scratch; the experiments that let passes overlap keep a scratch per stream
 			longScratchWords = (uint64_t)nGroups * scratchLanes * waveWords;
-			shareLongScratch = nGroups == 1 && (getenv("GC_LONG_TOKEN") ? atoi(getenv("GC_LONG_TOKEN")) : 1) == 1;
+			shareLongScratch = nGroups == 1 && (getenv("GC_LONG_TOKEN") ? atoi(getenv("GC_LONG_TOKEN")) : 1) >= 1;   // (token per pass or per round: whoever holds it owns the scratch)
 			if (!shareLongScratch) dLongScratchOwn = st->longScratch.reserve<unsigned long long>(longScratchWords);
 			groupExtendUs.assign(nGroups, 0.0);
 			groupRounds.assign(nGroups, 0);
@@ -1769,7 +1781,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			runLongGroup = [=, &dLongCells, &cellBudget, &longScratchOfToken](uint32_t g) {
 				const uint64_t r0 = groupBeginPtr[g], nG = groupBeginPtr[g + 1] - r0;
 				if (nG == 0) return;
-				unsigned long long* const dLongScratch = shareLongScratch ? longScratchOfToken : dLongScratchOwn;
+				unsigned long long* dLongScratch = shareLongScratch ? longScratchOfToken : dLongScratchOwn;   // (round token: set under the lock, every round)
 				hipStream_t q = st->groupStreams[g];
 				hipEvent_t* ring = st->groupEvents.data() + (size_t)2 * LONG_EVENT_RING * g;
 				// the rounds' extension time: read a ring slot's pair before the slot is reused (its round is complete by then: every round's
@@ -1784,12 +1796,13 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				const double dbgT0 = nowUs();
 				launchLongInit(q, dLongJobs + r0, (uint32_t)nG, dLongState + r0);
 				uint32_t lastWork = 0xffffffffu;
-				// GC_LONG_TOKEN=2 (experiment): the token is held per round - from the moment a round's extension kernel is queued until the wait
-				// that proves it finished - so that the rounds of two batches in flight alternate instead of whole passes
+				// GC_LONG_TOKEN=2: the token (and with it the device's extension scratch) is held per round - from the moment a round's extension kernel is queued until
+				// that kernel has finished - so that the small kernels and the host round trip between two rounds of one batch run beside another batch's extension kernel
 				int deviceNow = 0;
 				HIP_CHECK(hipGetDevice(&deviceNow));
 				const bool roundToken = getenv("GC_LONG_TOKEN") && atoi(getenv("GC_LONG_TOKEN")) == 2;   // (read per batch: the tests switch modes inside one process)
 				std::unique_lock<std::mutex> roundLock(g_longPassToken[deviceNow & 15], std::defer_lock);
+				hipEvent_t roundExtendDone = nullptr;
 
 				for (int round = 0; round < 4096; round++) {
 					launchZeroWords(q, cursor, 4);   // [0] work count, [1] round trace cursor, [2] next work slot, [3] length of the retry list
@@ -1810,12 +1823,15 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					}
 					launchPublish(q, cursor, (unsigned long long*)hCursor, 2);
 					const double tWait0 = nowUs();
+					if (roundLock.owns_lock()) { syncEvent(roundExtendDone); roundLock.unlock(); }   // the previous round's extension kernel has finished: the merge and this round's set-up need no token
 					syncStream(q);
 					dbgWaitUs += nowUs() - tWait0;
-					if (roundLock.owns_lock()) roundLock.unlock();   // the previous round's extension kernel has finished
 					uint32_t nWorkItems = (uint32_t)hCursor[0];
 					if (nWorkItems == 0) break;
-					if (roundToken && nGroups == 1) roundLock.lock();
+					if (roundToken && nGroups == 1) {
+						roundLock.lock();
+						if (shareLongScratch) dLongScratch = g_longScratch[deviceNow & 15].buffer.reserve<unsigned long long>(longScratchWords);
+					}
 					uint32_t team = longExtendTeamSize(nWorkItems);
 					uint32_t blocks = std::min<uint32_t>((nWorkItems + team - 1) / team, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / team));
 					if (const char* env = getenv("GC_LONG_MAX_BLOCKS")) blocks = std::min<uint32_t>(blocks, (uint32_t)std::max(1, atoi(env)));   // test hook: force persistent waves
@@ -1851,6 +1867,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 							dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, EXT_LDS_CAP, cursor + 3);
 					}
 					HIP_CHECK(hipEventRecord(ev1, q));
+					roundExtendDone = ev1;
 					launchLongMerge(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, dCandSeed + w0, dLongWorkResults + w0, dRoundTrace + groupTraceBeginPtr[g], maxAlignments, dLongState + r0, dLongAlns, dLongCells, dLongCursor, cellBudget);
 					lastWork = nWorkItems;
 					// no wait here: the next round's select / order / publish queue up right behind the merge, and the only host round trip per
@@ -1969,7 +1986,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 						std::unique_lock<std::mutex> token(g_longPassToken[device & 15], std::defer_lock);
 						const double tTokenAsk = nowUs();
 						if (tokenMode == 1 && longGroups == 1) token.lock();
-						if (shareLongScratch) {
+						if (shareLongScratch && tokenMode == 1) {
 							if (!token.owns_lock()) throw std::runtime_error("internal: shared whole-read scratch without the token");
 							longScratchOfToken = g_longScratch[device & 15].buffer.reserve<unsigned long long>(longScratchWords);
 						}
