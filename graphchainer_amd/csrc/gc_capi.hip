@@ -222,6 +222,50 @@ struct PinnedBuffer {   // growable page-locked host staging buffer (full-rate P
 
 template <typename T> T* mallocArray(size_t n) { return (T*)malloc(std::max<size_t>(n, 1) * sizeof(T)); }
 
+// The arrays of a gc_result. The big ones (the trace arrays of keep_traces: 0.1-0.5 GB each for 10 k x 10 kb reads) come from a small cache of blocks that
+// gc_result_free gives back: fresh memory of that size is mapped and zero-filled page by page on first touch, every batch again (r3: ~1.5 of the 3.4 CPU-seconds the
+// assembly of a traced batch cost). Every array carries a 64-byte header with its size, so gc_result_free knows what it holds.
+struct ResultBlockCache {
+	static constexpr size_t HEADER = 64, BIG = 32ull << 20, MAX_HELD = 24ull << 30;
+	std::mutex mutex;
+	std::vector<std::pair<char*, size_t>> blocks;   // (base, capacity in bytes without the header)
+	size_t held = 0;
+	void* get(size_t bytes)
+	{
+		if (bytes >= BIG) {
+			std::lock_guard<std::mutex> lock(mutex);
+			size_t best = blocks.size();
+			for (size_t i = 0; i < blocks.size(); i++)
+				if (blocks[i].second >= bytes && blocks[i].second <= 2 * bytes && (best == blocks.size() || blocks[i].second < blocks[best].second)) best = i;
+			if (best < blocks.size()) {
+				char* base = blocks[best].first;
+				held -= blocks[best].second;
+				blocks.erase(blocks.begin() + (long)best);
+				return base + HEADER;
+			}
+		}
+		const size_t capacity = bytes >= BIG ? bytes + bytes / 16 : bytes;   // (a little slack: the next batch's arrays are about, not exactly, this size)
+		char* base = (char*)malloc(capacity + HEADER);
+		if (!base) throw std::bad_alloc();
+		*(size_t*)base = capacity;
+		return base + HEADER;
+	}
+	void put(void* p)
+	{
+		if (!p) return;
+		char* base = (char*)p - HEADER;
+		const size_t capacity = *(size_t*)base;
+		if (capacity >= BIG) {
+			std::lock_guard<std::mutex> lock(mutex);
+			if (held + capacity <= MAX_HELD && blocks.size() < 64) { blocks.emplace_back(base, capacity); held += capacity; return; }
+		}
+		free(base);
+	}
+	~ResultBlockCache() { for (auto& b : blocks) free(b.first); }
+};
+ResultBlockCache g_resultBlocks;
+template <typename T> T* resultArray(size_t n) { return (T*)g_resultBlocks.get(std::max<size_t>(n, 1) * sizeof(T)); }
+
 } // namespace
 
 // ----------------------------------------------------------------------------------------------------
@@ -1370,7 +1414,7 @@ void gc_result_free(gc_result* r)
 		r->failed_assertion, r->seeds_extended, r->seeds_extended_long, r->read_path_off, r->path_node, r->path_first_offset, r->path_last_offset, r->path_cells,
 		r->read_long_off, r->long_index, r->long_edit_distance, r->chain_edit_distance, r->chained_better,
 		r->capacity_exceeded, r->read_chain_trace_off, r->chain_trace_node, r->chain_trace_offset, r->chain_trace_seqpos, r->chain_trace_switch, r->chain_aln_start, r->chain_aln_end };
-	for (void* p : ptrs) free(p);
+	for (void* p : ptrs) g_resultBlocks.put(p);
 	free(r);
 }
 
@@ -2522,48 +2566,48 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		std::vector<uint64_t> seedOutBegin(n + 1, 0);   // the result's seed lists are dense (the device's sit at capacity offsets)
 		for (uint64_t r = 0; r < n; r++) seedOutBegin[r + 1] = seedOutBegin[r] + (keepSeeds ? glue[r].nSeedsR : 0);
 		const uint64_t nSeedsOut = seedOutBegin[n];
-		res->read_seed_off = mallocArray<uint64_t>(n + 1);
-		res->seed_node = mallocArray<uint32_t>(nSeedsOut); res->seed_offset = mallocArray<uint32_t>(nSeedsOut);
-		res->seed_seqpos = mallocArray<uint32_t>(nSeedsOut); res->seed_goodness = mallocArray<uint64_t>(nSeedsOut);
-		res->read_anchor_off = mallocArray<uint64_t>(n + 1);
-		res->anchor_x = mallocArray<uint32_t>(nAnchors); res->anchor_y = mallocArray<uint32_t>(nAnchors);
-		res->anchor_path_off = mallocArray<uint64_t>(nAnchors + 1); res->anchor_path = mallocArray<uint32_t>(nPath);
-		res->anchor_first_node = mallocArray<uint32_t>(nAnchors); res->anchor_first_offset = mallocArray<uint32_t>(nAnchors); res->anchor_first_seqpos = mallocArray<uint32_t>(nAnchors);
-		res->anchor_last_node = mallocArray<uint32_t>(nAnchors); res->anchor_last_offset = mallocArray<uint32_t>(nAnchors); res->anchor_last_seqpos = mallocArray<uint32_t>(nAnchors);
-		res->anchor_score = mallocArray<int32_t>(nAnchors);
+		res->read_seed_off = resultArray<uint64_t>(n + 1);
+		res->seed_node = resultArray<uint32_t>(nSeedsOut); res->seed_offset = resultArray<uint32_t>(nSeedsOut);
+		res->seed_seqpos = resultArray<uint32_t>(nSeedsOut); res->seed_goodness = resultArray<uint64_t>(nSeedsOut);
+		res->read_anchor_off = resultArray<uint64_t>(n + 1);
+		res->anchor_x = resultArray<uint32_t>(nAnchors); res->anchor_y = resultArray<uint32_t>(nAnchors);
+		res->anchor_path_off = resultArray<uint64_t>(nAnchors + 1); res->anchor_path = resultArray<uint32_t>(nPath);
+		res->anchor_first_node = resultArray<uint32_t>(nAnchors); res->anchor_first_offset = resultArray<uint32_t>(nAnchors); res->anchor_first_seqpos = resultArray<uint32_t>(nAnchors);
+		res->anchor_last_node = resultArray<uint32_t>(nAnchors); res->anchor_last_offset = resultArray<uint32_t>(nAnchors); res->anchor_last_seqpos = resultArray<uint32_t>(nAnchors);
+		res->anchor_score = resultArray<int32_t>(nAnchors);
 		if (anchorTraces) {
-			res->anchor_trace_off = mallocArray<uint64_t>(nAnchors + 1);
-			res->anchor_trace_node = mallocArray<int32_t>(nTrace); res->anchor_trace_offset = mallocArray<uint32_t>(nTrace);
-			res->anchor_trace_seqpos = mallocArray<uint32_t>(nTrace); res->anchor_trace_switch = mallocArray<uint8_t>(nTrace);
+			res->anchor_trace_off = resultArray<uint64_t>(nAnchors + 1);
+			res->anchor_trace_node = resultArray<int32_t>(nTrace); res->anchor_trace_offset = resultArray<uint32_t>(nTrace);
+			res->anchor_trace_seqpos = resultArray<uint32_t>(nTrace); res->anchor_trace_switch = resultArray<uint8_t>(nTrace);
 			res->anchor_trace_off[nAnchors] = nTrace;
 		}
-		res->read_chain_off = mallocArray<uint64_t>(n + 1);
-		res->chain = mallocArray<uint32_t>(nChain);
-		res->chain_score = mallocArray<uint64_t>(n);
-		res->read_longall_off = mallocArray<uint64_t>(n + 1);
+		res->read_chain_off = resultArray<uint64_t>(n + 1);
+		res->chain = resultArray<uint32_t>(nChain);
+		res->chain_score = resultArray<uint64_t>(n);
+		res->read_longall_off = resultArray<uint64_t>(n + 1);
 		res->read_longall_off[n] = nLong;
-		res->longall_start = mallocArray<uint32_t>(nLong); res->longall_end = mallocArray<uint32_t>(nLong); res->longall_score = mallocArray<uint32_t>(nLong);
-		res->long_trace_off = mallocArray<uint64_t>(nLong + 1);
+		res->longall_start = resultArray<uint32_t>(nLong); res->longall_end = resultArray<uint32_t>(nLong); res->longall_score = resultArray<uint32_t>(nLong);
+		res->long_trace_off = resultArray<uint64_t>(nLong + 1);
 		res->long_trace_off[nLong] = nLongTrace;
-		res->long_trace_node = mallocArray<int32_t>(nLongTrace); res->long_trace_offset = mallocArray<uint32_t>(nLongTrace);
-		res->long_trace_seqpos = mallocArray<uint32_t>(nLongTrace); res->long_trace_switch = mallocArray<uint8_t>(nLongTrace);
-		res->seeds_extended_long = mallocArray<uint64_t>(n);
-		res->read_long_off = mallocArray<uint64_t>(n + 1);
+		res->long_trace_node = resultArray<int32_t>(nLongTrace); res->long_trace_offset = resultArray<uint32_t>(nLongTrace);
+		res->long_trace_seqpos = resultArray<uint32_t>(nLongTrace); res->long_trace_switch = resultArray<uint8_t>(nLongTrace);
+		res->seeds_extended_long = resultArray<uint64_t>(n);
+		res->read_long_off = resultArray<uint64_t>(n + 1);
 		res->read_long_off[n] = nLongSelected;
-		res->long_index = mallocArray<uint32_t>(nLongSelected);
-		res->long_edit_distance = mallocArray<int64_t>(n); res->chain_edit_distance = mallocArray<int64_t>(n); res->chained_better = mallocArray<uint8_t>(n);
-		res->read_path_off = mallocArray<uint64_t>(n + 1);
+		res->long_index = resultArray<uint32_t>(nLongSelected);
+		res->long_edit_distance = resultArray<int64_t>(n); res->chain_edit_distance = resultArray<int64_t>(n); res->chained_better = resultArray<uint8_t>(n);
+		res->read_path_off = resultArray<uint64_t>(n + 1);
 		res->read_path_off[n] = nStitched;
-		res->path_node = mallocArray<uint32_t>(nStitched);
-		res->path_first_offset = mallocArray<uint32_t>(n); res->path_last_offset = mallocArray<uint32_t>(n); res->path_cells = mallocArray<uint64_t>(n);
-		res->read_chain_trace_off = mallocArray<uint64_t>(n + 1);
+		res->path_node = resultArray<uint32_t>(nStitched);
+		res->path_first_offset = resultArray<uint32_t>(n); res->path_last_offset = resultArray<uint32_t>(n); res->path_cells = resultArray<uint64_t>(n);
+		res->read_chain_trace_off = resultArray<uint64_t>(n + 1);
 		res->read_chain_trace_off[n] = nChainTrace;
-		res->chain_trace_node = mallocArray<int32_t>(nChainTrace); res->chain_trace_offset = mallocArray<uint32_t>(nChainTrace);
-		res->chain_trace_seqpos = mallocArray<uint32_t>(nChainTrace); res->chain_trace_switch = mallocArray<uint8_t>(nChainTrace);
-		res->chain_aln_start = mallocArray<uint32_t>(n); res->chain_aln_end = mallocArray<uint32_t>(n);
-		res->failed_assertion = mallocArray<uint8_t>(n);
-		res->capacity_exceeded = mallocArray<uint8_t>(n);
-		res->seeds_extended = mallocArray<uint64_t>(n);
+		res->chain_trace_node = resultArray<int32_t>(nChainTrace); res->chain_trace_offset = resultArray<uint32_t>(nChainTrace);
+		res->chain_trace_seqpos = resultArray<uint32_t>(nChainTrace); res->chain_trace_switch = resultArray<uint8_t>(nChainTrace);
+		res->chain_aln_start = resultArray<uint32_t>(n); res->chain_aln_end = resultArray<uint32_t>(n);
+		res->failed_assertion = resultArray<uint8_t>(n);
+		res->capacity_exceeded = resultArray<uint8_t>(n);
+		res->seeds_extended = resultArray<uint64_t>(n);
 		res->read_seed_off[n] = nSeedsOut; res->read_anchor_off[n] = nAnchors; res->anchor_path_off[nAnchors] = nPath; res->read_chain_off[n] = nChain;
 		pool.run(n, [&](size_t r, size_t) {
 			const ReadGlue& gl = glue[r];

@@ -33,6 +33,37 @@ inline unsigned baseSet(char c)
 	return 0;
 }
 
+// The graph letter under a trace cell (bigraph node id, offset in the original node): GetUnitigNode + NodeSequences as the reference's TraceItem constructor does
+// (src/GraphAlignerCommon.h:148-153), but remembering the split node of the last cell - consecutive cells of a trace sit in the same 64-letter split node or the next, and
+// GetUnitigNode costs two hash look-ups and a division per call (r3: 105 M cells per 10 k reads went through it, most of gc_format_gaf's 9 CPU-seconds).
+class GraphLetters {
+public:
+	explicit GraphLetters(const AlignmentGraph& graph) : graph(graph) {}
+	char at(int nodeId, size_t offset)
+	{
+		if (nodeId != currentId || !nodes) {
+			nodes = &graph.nodeLookup.at(nodeId);
+			currentId = nodeId;
+			index = (size_t)(nodes->size() * ((double)offset / (double)graph.originalNodeSize.at(nodeId)));
+			if (index >= nodes->size()) index = nodes->size() - 1;
+		} else if (offset >= lo && offset < hi) {
+			return graph.NodeSequences(split, offset - lo);
+		}
+		// the split nodes of one original node partition its letters: the one that holds `offset` is unique, whichever index the search starts from
+		while (index < nodes->size() - 1 && graph.nodeOffset[(*nodes)[index]] + graph.nodeLength[(*nodes)[index]] <= offset) index++;
+		while (index > 0 && graph.nodeOffset[(*nodes)[index]] > offset) index--;
+		split = (*nodes)[index];
+		lo = graph.nodeOffset[split];
+		hi = lo + graph.nodeLength[split];
+		return graph.NodeSequences(split, offset - lo);
+	}
+private:
+	const AlignmentGraph& graph;
+	const std::vector<size_t>* nodes = nullptr;
+	int currentId = 0;
+	size_t index = 0, split = 0, lo = 0, hi = 0;
+};
+
 enum class Edit { Match, Mismatch, MatchOrMismatch, Insertion, Deletion, Empty };
 
 inline void addCigarItem(std::ostringstream& str, uint64_t length, Edit type)
@@ -63,10 +94,8 @@ bool characterMatch(char sequenceCharacter, char graphCharacter)
 std::string formatGafLine(const AlignmentGraph& graph, const std::string& readName, const char* sequence, uint64_t readLength, const TraceView& trace, bool merge)
 {
 	if (trace.size == 0) return std::string();
-	auto graphChar = [&](uint64_t i) {
-		size_t split = graph.GetUnitigNode(trace.node[i], trace.offset[i]);
-		return graph.NodeSequences(split, trace.offset[i] - graph.NodeOffset(split));
-	};
+	GraphLetters letters(graph);
+	auto graphChar = [&](uint64_t i) { return letters.at(trace.node[i], trace.offset[i]); };
 	auto readChar = [&](uint64_t i) { return trace.seqPos[i] < readLength ? sequence[trace.seqPos[i]] : '-'; };
 	auto originalSize = [&](int nodeId) { return graph.originalNodeSize.at(nodeId); };
 	std::ostringstream cigar, nodePath;
@@ -131,10 +160,8 @@ VgAlignment buildVgAlignment(const AlignmentGraph& graph, const std::string& rea
 {
 	VgAlignment aln;
 	if (trace.size == 0) return aln;
-	auto graphChar = [&](uint64_t i) {
-		size_t split = graph.GetUnitigNode(trace.node[i], trace.offset[i]);
-		return graph.NodeSequences(split, trace.offset[i] - graph.NodeOffset(split));
-	};
+	GraphLetters letters(graph);
+	auto graphChar = [&](uint64_t i) { return letters.at(trace.node[i], trace.offset[i]); };
 	auto readChar = [&](uint64_t i) { return trace.seqPos[i] < readLength ? sequence[trace.seqPos[i]] : '-'; };
 	aln.name = readName;
 	aln.score = score;
