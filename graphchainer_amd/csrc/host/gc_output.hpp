@@ -18,6 +18,37 @@ struct TraceView {
 	uint64_t size;
 };
 
+// The graph letter under a trace cell (bigraph node id, offset in the original node): GetUnitigNode + NodeSequences as the reference's TraceItem constructor does
+// (src/GraphAlignerCommon.h:148-153), but remembering the split node of the last cell - consecutive cells of a trace sit in the same 64-letter split node or the next, and
+// GetUnitigNode costs two hash look-ups and a division per call (r3: 105 M cells per 10 k reads went through it, most of gc_format_gaf's 9 CPU-seconds).
+class GraphLetters {
+public:
+	explicit GraphLetters(const AlignmentGraph& graph) : graph(graph) {}
+	char at(int nodeId, size_t offset)
+	{
+		if (nodeId != currentId || !nodes) {
+			nodes = &graph.nodeLookup.at(nodeId);
+			currentId = nodeId;
+			index = (size_t)(nodes->size() * ((double)offset / (double)graph.originalNodeSize.at(nodeId)));
+			if (index >= nodes->size()) index = nodes->size() - 1;
+		} else if (offset >= lo && offset < hi) {
+			return graph.NodeSequences(split, offset - lo);
+		}
+		// the split nodes of one original node partition its letters: the one that holds `offset` is unique, whichever index the search starts from
+		while (index < nodes->size() - 1 && graph.nodeOffset[(*nodes)[index]] + graph.nodeLength[(*nodes)[index]] <= offset) index++;
+		while (index > 0 && graph.nodeOffset[(*nodes)[index]] > offset) index--;
+		split = (*nodes)[index];
+		lo = graph.nodeOffset[split];
+		hi = lo + graph.nodeLength[split];
+		return graph.NodeSequences(split, offset - lo);
+	}
+private:
+	const AlignmentGraph& graph;
+	const std::vector<size_t>* nodes = nullptr;
+	int currentId = 0;
+	size_t index = 0, split = 0, lo = 0, hi = 0;
+};
+
 // IUPAC-aware base comparison, reference: GraphAlignerCommon::characterMatch, src/GraphAlignerCommon.h:190-297.
 bool characterMatch(char sequenceCharacter, char graphCharacter);
 

@@ -143,6 +143,23 @@ def test_stdsort_clone_equals_libstdcxx(tmp_path):
     assert out.returncode == 0 and "STDSORT_OK" in out.stdout, out.stdout + out.stderr
 
 
+def test_encoder_letter_cursor_equals_the_graph_lookups(tmp_path):
+    """The output encoders read the graph letter under every trace cell through gc::GraphLetters (csrc/host/gc_output.hpp), a cursor that remembers the last cell's split
+    node; tests/output_host/letters_test.cpp compares it with GetUnitigNode + NodeSequences (what the reference does per cell, src/GraphAlignerCommon.h:148-153) on every
+    letter of every original node - forwards, backwards, and in random jumps with node changes - of the golden graphs and of a graph with IUPAC letters and long nodes."""
+    exe = tmp_path / "letters_test"
+    host = os.path.join(ROOT, "graphchainer_amd", "csrc", "host")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-I" + host, os.path.join(ROOT, "tests", "output_host", "letters_test.cpp"), os.path.join(host, "gc_output.cpp"), os.path.join(host, "gc_graph.cpp"),
+                    "-o", str(exe), "-lpthread", "-lz"], check=True, timeout=600)
+    rng = np.random.default_rng(5)
+    mixed = tmp_path / "iupac.gfa"
+    segs = ["".join(rng.choice(list("ACGTACGTACGTNRYKM"), size=int(n))) for n in (1, 63, 64, 65, 200, 1000, 129, 5)]
+    mixed.write_text("".join(f"S\t{i + 1}\t{s}\n" for i, s in enumerate(segs)) + "".join(f"L\t{i + 1}\t+\t{i + 2}\t+\t0M\n" for i in range(len(segs) - 1)))
+    for gfa in (os.path.join(ROOT, "tests", "golden", "syn20k.gfa"), os.path.join(ROOT, "tests", "golden", "ref_test_graph.gfa"), str(mixed)):
+        out = subprocess.run([str(exe), gfa], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and out.stdout.startswith("OK"), (gfa, out.stdout + out.stderr)
+
+
 def test_state_machine_extension_core_equals_oracle(tmp_path):
     """The per-lane state machine of the experimental kernel k_long_extend_sm (graphchainer_amd/csrc/hip/gc_sm_core.hpp) is plain C++:
     tests/sm_host/sm_host_test.cpp compiles its phase functions with g++, drives ONE lane on the CPU and compares status, score and every trace
