@@ -1418,50 +1418,140 @@ void gc_result_free(gc_result* r)
 	free(r);
 }
 
-// One batch through the whole path. The function is long because the stages share a hundred buffers and sizes; it reads top to bottom as the
-// batch's timeline, every stage under a "// ----------------" header:
-//   K1 seed lookup -> host glue (expand, order) -> K3-long set-up: buffers, the round loop (runLongGroup), the after-pass stage (fallback reruns,
-//   selection, whole-read edit distances: afterLongPass), all of which then run on the pass's own host thread -> [main thread, meanwhile]
-//   fragment windows, k_build_fragment_work, K3 / K3b in lazy rounds, K4, k_stitch -> results back -> host stitching of what the kernel
-//   declined -> chain edit distances -> join with the whole-read pass -> chained alignment paths and traces (k_edit_path) -> flat result.
-// Capacities are per read (flags in the result), errors of the reference's own making per read or fragment (failed_assertion); only
-// invalid arguments and device errors fail the call.
-int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const gc_reads* R, const gc_params* P, gc_result** out)
-{
-	if (!G || !S || !st || !R || !P || !out) return fail(GC_ERR_INVALID, "null argument");
-	if (P->split_len < 16 || P->split_len > 64 || P->split_gap < 1) return fail(GC_ERR_INVALID, "split_len must be in [16,64] (one 64-row slice per fragment extension) and split_gap >= 1");
-	{
-		const gc_capacities& c = P->capacity;
-		if (c.reserved[0] || c.reserved[1] || c.reserved[2]) return fail(GC_ERR_INVALID, "gc_params::capacity.reserved must be 0 (was the struct initialised with gc_params_default?)");
-		const int64_t v[] = { c.ext_max_items, c.ext_max_pending, c.ext_max_trace, c.long_max_items, c.long_cells_per_base, c.long_scratch_bytes, c.stitch_set_max, c.stitch_bfs_cap };
-		for (int64_t x : v) if (x < 0 || x > (1ll << 40)) return fail(GC_ERR_INVALID, "gc_params::capacity: a size is negative or absurd (0 = automatic)");
-		if (c.long_column_store < -1 || c.long_column_store > (1ll << 31)) return fail(GC_ERR_INVALID, "gc_params::capacity.long_column_store: -1 (none), 0 (automatic) or a column count");
-	}
-	*out = nullptr;
-	const double tCall = nowUs();
-	const double cpuCall = processCpuMs();
-	double cpuJoined = cpuCall;
-	gc_result* res = (gc_result*)calloc(1, sizeof(gc_result));
-	int rc = guarded([&]() {
-		HIP_CHECK(hipSetDevice(st->device));   // the current device is per host thread
-		const uint64_t n = R->offsets.size() - 1;
-		const gc::AlignmentGraph& hg = G->host;
-		hipStream_t stream = st->stream;
-		WorkerPool& pool = WorkerPool::instance();
-		res->n_reads = n;
-		int evIdx = 0;
-		auto mark = [&]() { HIP_CHECK(hipEventRecord(st->ev[evIdx++], stream)); };
-		auto elapsedUs = [&](int a, int b) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, st->ev[a], st->ev[b])); return (double)ms * 1000.0; };
-		double tTotal = nowUs();
+// One batch through the whole path, stage by stage (r3: this was one 1 200-line function). A BatchRun holds what the stages share - the call's arguments, the sizes the seed
+// stage leaves behind, the device and pinned-host buffers a later stage reads again - and every stage is one member function, in the batch's order:
+//   seeds -> prepareWholeReadPass -> startWholeReadPass (the pass runs on its own host thread and stream from there: runLongGroup, then afterLongPass) -> [main thread, meanwhile]
+//   fragmentPipeline -> resultsBack -> stitchAndChainDistances -> joinWholeReadPass -> chainedAlignments -> assemble.
+// Capacities are per read (flags in the result), errors of the reference's own making per read or fragment (failed_assertion); only invalid arguments and device errors fail
+// the call (they throw; gc_align_batch turns that into its return code, and ~BatchRun joins the pass thread first).
+struct BatchRun {
+	// ---- the call
+	const gc_graph* const G; const gc_seeder* const S; gc_stream* const st; const gc_reads* const R; const gc_params* const P; gc_result* const res;
+	const double tCall, cpuCall;
+	double cpuJoined;
+	const uint64_t n;                        // reads in the batch
+	const gc::AlignmentGraph& hg;
+	WorkerPool& pool;
+	std::vector<ReadGlue>& glue;             // per-read host records, storage reused across batches
+	const hipStream_t stream;                // the fragment pipeline's stream (the whole-read pass has st->longStream / st->groupStreams)
+	int evIdx = 0;
+	double tTotal = 0;
+	// ---- what the stages hand on (set by the stage named in the comment of each group)
+	// seeds()
+	bool deviceGlue = true;
+	double tGlue = 0;
+	uint64_t nSlots = 0, nFrags = 0, nSeedsTotal = 0, traceBudget = 0;
+	uint32_t maxSlotsPerRead = 1, maxWindowSeeds = 0;
+	Fragment* frags = nullptr; ReadChainJob* jobs = nullptr;                 // host copies
+	FragSeed* readSeeds = nullptr; uint32_t* fragFirstSeed = nullptr;        // host copies (device glue: only with keep_seeds / keep_traces)
+	Fragment* dFrags = nullptr; uint32_t* dFragFirstSeed = nullptr; FragSeed* dReadSeeds = nullptr; ReadChainJob* dJobs = nullptr;
+	LongSeed* dLongSeeds = nullptr;
+	hipEvent_t glueCopied = nullptr;   // device glue: the host copies of frags / seeds have arrived (waited for before the result assembly)
+	double tOrdered = 0;
+	unsigned long long* hSmall = nullptr;
+	unsigned long long* dCursors = nullptr;
+	unsigned long long* dCounters = nullptr;
+	// prepareWholeReadPass()
+	uint32_t maxAlignments = 0;
+	LongAln* hLongAlns = nullptr;
+	unsigned long long* hLongSmall = nullptr;
+	LongReadResult* hLongResults = nullptr;
+	LongCell* dLongCells = nullptr;
+	uint64_t cellBudget = 0;                      // capacity of the merged-trace cell pool (grown and the pass rerun when a batch overflows it)
+	std::function<bool()> growLongCells;          // whole-read pass thread: the pool was too small -> enlarge it, reset the pass's cursors; false when it cannot grow
+	std::function<uint64_t()> longFallback;
+	std::function<void(uint32_t)> runLongGroup;
+	unsigned long long* longScratchOfToken = nullptr;   // the device's shared extension scratch, set by the pass once it holds the token
+	uint64_t longScratchWords = 0;
+	bool shareLongScratch = false;
+	std::function<void()> finishLongGroups;
+	uint32_t longGroups = 0;
+	std::vector<double> groupExtendUs; std::vector<uint32_t> groupRounds; std::vector<uint64_t> groupBegin, groupTraceBegin;   // (the pass thread works through pointers into these)
+	const gc::EValueModel evalueModel { 0.7 };   // src/Aligner.cpp:478-482 (precise clipping is out of scope)
+	struct DecisionPointers { EdPair* hPairs = nullptr; int64_t* hOut = nullptr; EdPair* dPairs = nullptr; int64_t* dOut = nullptr; char* dLetters = nullptr; uint32_t* dLettersLen = nullptr; } decisionPtr[2];
+	bool longPostInThread = false;
+	// startWholeReadPass()
+	std::vector<std::thread> longThreads;
+	std::vector<std::exception_ptr> longErrors;
+	double tLongWall0 = 0;
+	std::atomic<double> longWallBeginUs { 0.0 };   // when the pass got the device's token (waiting for another batch's pass is not its own time)
+	std::atomic<double> longWallEndUs { 0.0 };
+	// fragmentPipeline()
+	double tDev = 0;
+	uint32_t nWork = 0;
+	ExtResult* dResults = nullptr;
+	TraceCell* dTrace = nullptr;
+	AnchorRec* dAnchors = nullptr;
+	uint32_t* dFragStatus = nullptr;
+	uint32_t* dFragExtended = nullptr;
+	uint64_t pathCapacity = 0;
+	uint32_t* dPathPool = nullptr;
+	uint32_t* dChainOut = nullptr;
+	uint32_t* dChainLen = nullptr;
+	unsigned long long* dChainScore = nullptr;
+	uint32_t* dChainStatus = nullptr;
+	bool deviceStitch = false;
+	StitchInfo* stitchInfo = nullptr;
+	uint32_t* hStitchNodes = nullptr;
+	uint32_t* dStitchNodes = nullptr;
+	uint64_t stitchDenseCap = 0;
+	unsigned long long* hStitchCursor = nullptr;
+	// resultsBack()
+	AnchorRec* anchors = nullptr;
+	uint32_t* fragStatus = nullptr;
+	uint32_t* fragExtended = nullptr;
+	uint32_t* chainOut = nullptr;
+	uint32_t* chainLen = nullptr;
+	unsigned long long* chainScore = nullptr;
+	uint32_t* chainStatus = nullptr;
+	uint32_t* pathPool = nullptr;
+	std::vector<ExtResult> extResults;
+	std::vector<TraceCell> tracePool;
+	bool anchorTraces = false;
+	bool stitchNodesPending = false;
+	// stitchAndChainDistances()
+	const PathSeqJob* chainLetterJobs = nullptr;   // per read: where its stitched path's letters are in dChainLetters
+	const char* dChainLetters = nullptr;
+	// joinWholeReadPass()
+	double tJoined = 0;
+	const LongCell* longCells = nullptr;   // keep_traces: the merged traces in pinned staging (a pageable destination made this copy 2-3 s per 10 k reads)
 
+	BatchRun(const gc_graph* G, const gc_seeder* S, gc_stream* st, const gc_reads* R, const gc_params* P, gc_result* res, double tCall, double cpuCall)
+		: G(G), S(S), st(st), R(R), P(P), res(res), tCall(tCall), cpuCall(cpuCall), cpuJoined(cpuCall), n(R->offsets.size() - 1), hg(G->host), pool(WorkerPool::instance()), glue(st->glue),
+		  stream(st->stream), longErrors(16) {}
+	~BatchRun() { for (auto& t : longThreads) if (t.joinable()) t.join(); }   // (an exception on the main thread must not leave the pass thread behind with dangling state)
+	BatchRun(const BatchRun&) = delete;
+	BatchRun& operator=(const BatchRun&) = delete;
+
+	void mark() { HIP_CHECK(hipEventRecord(st->ev[evIdx++], stream)); }
+	double elapsedUs(int a, int b) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, st->ev[a], st->ev[b])); return (double)ms * 1000.0; }
+
+	void run()
+	{
+		res->n_reads = n;
+		tTotal = nowUs();
+		seeds();
+		prepareWholeReadPass();
+		startWholeReadPass();
+		fragmentPipeline();
+		resultsBack();
+		stitchAndChainDistances();
+		joinWholeReadPass();
+		chainedAlignments();
+		assemble();
+	}
+
+	// ---------------- K1 seed lookup, then the glue between it and the extension kernels (on the device; GC_DEVICE_GLUE=0: on the host)
+	void seeds()
+	{
 		// ---------------- K1: seed lookup
 		uint32_t* dTmp = st->tmp.reserve<uint32_t>(R->totalBases);
 		uint2* dMatches = st->matches.reserve<uint2>(R->totalBases);
 		uint32_t* dReadMatchOff = st->readMatchOff.reserve<uint32_t>(n);
 		uint32_t* dReadMatchCount = st->readMatchCount.reserve<uint32_t>(n);
-		unsigned long long* dCursors = st->cursors.reserve<unsigned long long>(8);
-		unsigned long long* dCounters = st->counters.reserve<unsigned long long>(8);
-		unsigned long long* hSmall = st->hSmall.reserve<unsigned long long>(16 + 2 * n);
+		dCursors = st->cursors.reserve<unsigned long long>(8);
+		dCounters = st->counters.reserve<unsigned long long>(8);
+		hSmall = st->hSmall.reserve<unsigned long long>(16 + 2 * n);
 		uint32_t* readMatchOff = (uint32_t*)(hSmall + 16);
 		uint32_t* readMatchCount = readMatchOff + n;
 		HIP_CHECK(hipMemsetAsync(dCursors, 0, 8 * sizeof(unsigned long long), stream));
@@ -1472,19 +1562,11 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		// The glue between the seed lookup and the extension kernels (hit expansion, seed ordering, fragment windows) runs on the device
 		// (gc_seedglue.hip: one wave per read, the reference's three unstable sorts replayed with libstdc++'s own algorithm); GC_DEVICE_GLUE=0
 		// keeps the r2 host path (host/gc_glue.cpp: same results, 1 CPU-second and two bulk transfers per 10 k reads).
-		const bool deviceGlue = !(getenv("GC_DEVICE_GLUE") && atoi(getenv("GC_DEVICE_GLUE")) == 0);
-		std::vector<ReadGlue>& glue = st->glue;   // per-read host records, storage reused across batches
+		deviceGlue = !(getenv("GC_DEVICE_GLUE") && atoi(getenv("GC_DEVICE_GLUE")) == 0);
 		if (glue.size() < n) glue.resize(n);
 		gc::KmerMatch* matches = nullptr;
-		double tGlue = 0;
+		tGlue = 0;
 		// what both paths leave behind for the rest of the batch
-		uint64_t nSlots = 0, nFrags = 0, nSeedsTotal = 0, traceBudget = 0;
-		uint32_t maxSlotsPerRead = 1, maxWindowSeeds = 0;
-		Fragment* frags = nullptr; ReadChainJob* jobs = nullptr;                 // host copies
-		FragSeed* readSeeds = nullptr; uint32_t* fragFirstSeed = nullptr;        // host copies (device glue: only with keep_seeds / keep_traces)
-		Fragment* dFrags = nullptr; uint32_t* dFragFirstSeed = nullptr; FragSeed* dReadSeeds = nullptr; ReadChainJob* dJobs = nullptr;
-		LongSeed* dLongSeeds = nullptr;
-		hipEvent_t glueCopied = nullptr;   // device glue: the host copies of frags / seeds have arrived (waited for before the result assembly)
 		if (deviceGlue) {
 			unsigned long long* dGlueCursors = st->glueCursors.reserve<unsigned long long>(8);
 			uint32_t* dSeedCap = st->glueSeedCap.reserve<uint32_t>(n);
@@ -1586,124 +1668,22 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			if (P->long_pass) gl.longSeeds = gl.seeds;
 		});
 		}
-		double tOrdered = nowUs();
+		tOrdered = nowUs();
+	}
+
+	// ---------------- K3-long set-up: buffers, the round loop (runLongGroup), the rerun rules; nothing runs yet
+	void prepareWholeReadPass()
+	{
 		// ---------------- K3-long: whole-read pass on its own stream (src/Aligner.cpp:630-654)
 		uint64_t nLongSeeds = 0, maxReadLen = 1;
 		for (uint64_t r = 0; r < n; r++) maxReadLen = std::max<uint64_t>(maxReadLen, R->offsets[r + 1] - R->offsets[r]);
 		// alignments kept per read: the reference has no limit; 32 is far above what 10 kb reads produce (3.6 seeds extended on average), longer
 		// and noisier reads get room in proportion. A read that still exceeds it is flagged (capacity_exceeded), the batch goes on.
-		const uint32_t maxAlignments = (uint32_t)std::max<uint64_t>(32, maxReadLen / 512);
-		LongAln* hLongAlns = nullptr;
-		LongReadResult* hLongResults = nullptr;
-		unsigned long long* hLongSmall = nullptr;
-		LongCell* dLongCells = nullptr;
-		uint64_t cellBudget = 0;                      // capacity of the merged-trace cell pool (grown and the pass rerun when a batch overflows it)
-		std::function<bool()> growLongCells;          // whole-read pass thread: the pool was too small -> enlarge it, reset the pass's cursors; false when it cannot grow
-		std::function<uint64_t()> longFallback;
-		std::function<void(uint32_t)> runLongGroup;
-		unsigned long long* longScratchOfToken = nullptr;   // the device's shared extension scratch, set by the pass once it holds the token
-		uint64_t longScratchWords = 0;
-		bool shareLongScratch = false;
-		std::function<void()> finishLongGroups;
-		uint32_t longGroups = 0;
-		std::vector<double> groupExtendUs; std::vector<uint32_t> groupRounds; std::vector<uint64_t> groupBegin, groupTraceBegin;
+		maxAlignments = (uint32_t)std::max<uint64_t>(32, maxReadLen / 512);
 		// Decision for a set of reads whose whole-read alignments are final: the reference's alignment order, the GreedyLength
 		// selection, and (queued, not awaited) the path letters + NW edit distance of the best alignment. (Tried: deciding the
 		// reads that are already finished when the rounds turn latency-bound, so these kernels run beside the last rounds - the
 		// rounds slow down by more than the 11 ms the tail saves: 304-319 -> 318-337 ms per batch. So: all reads, after the rounds.)
-		const gc::EValueModel evalueModel(0.7);   // src/Aligner.cpp:478-482 (precise clipping is out of scope)
-		struct DecisionPointers { EdPair* hPairs = nullptr; int64_t* hOut = nullptr; EdPair* dPairs = nullptr; int64_t* dOut = nullptr; char* dLetters = nullptr; uint32_t* dLettersLen = nullptr; } decisionPtr[2];
-		auto decideLongReads = [&](const std::vector<uint32_t>& subset, int slot, hipStream_t q, const std::function<uint32_t(uint32_t)>& nAlnOf, bool usePool = true) {
-			// the reference re-sorts its alignment list by alignmentStart after every accepted alignment
-			// (src/GraphAligner.h:183); replaying that on the acceptance-ordered list gives its final order. Then the
-			// GreedyLength selection (src/Aligner.cpp:636-639, src/AlignmentSelection.cpp:12-50) with the same unstable sort.
-			auto selectOne = [&](size_t i, size_t) {
-				const uint32_t r = subset[i];
-				ReadGlue& gl = glue[r];
-				gl.longAlns.clear();
-				gl.longSelected.clear();
-				const uint32_t nAln = nAlnOf(r);
-				for (uint32_t a = 0; a < nAln; a++) {
-					gl.longAlns.push_back(hLongAlns[(uint64_t)r * maxAlignments + a]);
-					std::sort(gl.longAlns.begin(), gl.longAlns.end(), [](const LongAln& l, const LongAln& rr) { return l.start < rr.start; });
-				}
-				struct Item { uint32_t start, end, score, index; };
-				std::vector<Item> sorted;
-				const size_t readLen = R->offsets[r + 1] - R->offsets[r];
-				for (uint32_t a = 0; a < gl.longAlns.size(); a++) {
-					// --E-cutoff: SelectECutoff runs before the greedy selection and keeps the list's order (src/AlignmentSelection.cpp:57-61,91-99)
-					if (!evalueModel.keeps(P->e_cutoff, hg.SizeInBP(), readLen, gl.longAlns[a].end - gl.longAlns[a].start, gl.longAlns[a].score)) continue;
-					sorted.push_back(Item { gl.longAlns[a].start, gl.longAlns[a].end, gl.longAlns[a].score, a });
-				}
-				std::sort(sorted.begin(), sorted.end(), [](const Item& l, const Item& rr) {
-					if ((l.end - l.start) > (rr.end - rr.start)) return true;
-					if ((rr.end - rr.start) > (l.end - l.start)) return false;
-					return l.score < rr.score;
-				});
-				auto incompatible = [](const Item& l, const Item& rr) {
-					float minOverlapLen = std::min(l.end - l.start, rr.end - rr.start) * 0.05f;
-					size_t ls = l.start, le = l.end, rs = rr.start, re = rr.end;
-					if (ls > rs) { std::swap(ls, rs); std::swap(le, re); }
-					int overlap = 0;
-					if (le > rs) overlap = (int)(le - rs);
-					return overlap > minOverlapLen;
-				};
-				std::vector<Item> kept;
-				for (const Item& it : sorted) {
-					bool ok = true;
-					for (const Item& k : kept) if (incompatible(it, k)) { ok = false; break; }
-					if (ok) { kept.push_back(it); gl.longSelected.push_back(it.index); }
-				}
-			};
-			if (usePool) pool.run(subset.size(), selectOne); else for (size_t i = 0; i < subset.size(); i++) selectOne(i, 0);
-			auto& D = st->edLong[slot];
-			D.nPairs = 0;
-			D.pairRead.clear();
-			if (!P->edit_distances || subset.empty()) return;
-			// edit distance of the best whole-read alignment's path against the read (edlibAlign at src/Aligner.cpp:645)
-			const size_t m = subset.size();
-			PathSeqJob* hJobsPS = D.hJobs.reserve<PathSeqJob>(m);
-			EdPair* hPairs = D.hPairs.reserve<EdPair>(m);
-			int64_t* hOut = D.hOut.reserve<int64_t>(m);
-			uint64_t nLetters = 0;
-			uint32_t nPairs = 0;
-			for (size_t i = 0; i < m; i++) {
-				const uint32_t r = subset[i];
-				const ReadGlue& gl = glue[r];
-				if (gl.longSelected.empty()) { hJobsPS[i] = PathSeqJob { 0, nLetters, 0, 0, 0, 0 }; continue; }
-				const LongAln& al = gl.longAlns[gl.longSelected[0]];
-				uint32_t len = (uint32_t)(R->offsets[r + 1] - R->offsets[r]);
-				uint32_t cap = 2 * al.traceLen + 256;
-				hJobsPS[i] = PathSeqJob { al.traceOff, nLetters, al.traceLen, cap, 0, 0 };
-				// the alignment itself bounds the distance: its edits plus the unaligned read ends
-				hPairs[nPairs++] = EdPair { nLetters, 0, (uint32_t)i, r, al.score + al.start + (len - std::min(len, al.end)) + 8 };
-				D.pairRead.push_back(r);
-				nLetters += cap;
-			}
-			PathSeqJob* dJobsPS = D.jobs.reserve<PathSeqJob>(m);
-			char* dLetters = D.letters.reserve<char>(nLetters);
-			uint32_t* dLettersLen = D.lettersLen.reserve<uint32_t>(m);
-			EdPair* dPairs = D.pairs.reserve<EdPair>(m);
-			int64_t* dOut = D.out.reserve<int64_t>(m);
-			HIP_CHECK(hipMemcpyAsync(dJobsPS, hJobsPS, m * sizeof(PathSeqJob), hipMemcpyHostToDevice, q));
-			launchLongPathSeq(q, G->dev, dJobsPS, (uint32_t)m, dLongCells, dLetters, dLettersLen);
-			auto readLenOf = [R](uint32_t r) { return (uint32_t)(R->offsets[r + 1] - R->offsets[r]); };
-			launchEditDistances(D.run, q, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen, readLenOf);
-			D.nPairs = nPairs;
-			decisionPtr[slot] = DecisionPointers { hPairs, hOut, dPairs, dOut, dLetters, dLettersLen };
-		};
-		auto finishLongDecision = [&](int slot) {
-			auto& D = st->edLong[slot];
-			if (!D.nPairs) return;
-			const DecisionPointers& p = decisionPtr[slot];
-			finishEditDistances(D.run, st->longStream, p.hPairs, p.hOut, D.nPairs, p.dPairs, p.dOut, R->devEdReads, R->devBases, R->devEqMasks, p.dLetters, p.dLettersLen);
-			for (uint32_t i = 0; i < D.nPairs; i++) {
-				ReadGlue& gl = glue[D.pairRead[i]];
-				gl.longEditDistance = p.hOut[i];
-				if (p.hOut[i] < -1) { gl.longEditDistance = -1; gl.capacityExceededLong = true; }   // outside the NW kernel's range: flagged, no distance
-			}
-			D.nPairs = 0;
-		};
 		if (P->long_pass) {
 			if (deviceGlue) nLongSeeds = nSeedsTotal;   // (the device's seed lists sit at the reads' capacity offsets)
 			else for (uint64_t r = 0; r < n; r++) { glue[r].longSeedBegin = nLongSeeds; nLongSeeds += glue[r].longSeeds.size(); }
@@ -1715,7 +1695,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			// depending on timing). The stream remembers what its batches needed, and a batch that overflows reruns its pass with three times the room.
 			const bool cellPoolPinned = getenv("GC_LONG_CELLS_PER_BASE") || P->capacity.long_cells_per_base > 0;
 			const uint64_t cellsPerBase = (uint64_t)std::max<int64_t>(2, capacityOr("GC_LONG_CELLS_PER_BASE", P->capacity.long_cells_per_base, (int64_t)st->longCellsPerBase));
-			auto budgetFor = [R, n](uint64_t perBase) { uint64_t b = 0; for (uint64_t r = 0; r < n; r++) b += perBase * (R->offsets[r + 1] - R->offsets[r]) + 1024; return b; };
+			auto budgetFor = [R = R, n = n](uint64_t perBase) { uint64_t b = 0; for (uint64_t r = 0; r < n; r++) b += perBase * (R->offsets[r + 1] - R->offsets[r]) + 1024; return b; };
 			cellBudget = budgetFor(cellsPerBase);
 			pool.run(n, [&](size_t r, size_t) {
 				const ReadGlue& gl = glue[r];
@@ -1809,7 +1789,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			uint32_t* groupRoundsPtr = groupRounds.data();
 			const uint64_t* groupBeginPtr = groupBegin.data();
 			const uint64_t* groupTraceBeginPtr = groupTraceBegin.data();
-			growLongCells = [=, &dLongCells, &cellBudget]() mutable {
+			growLongCells = [=]() mutable {
 				bool overflowed = false;
 				for (uint64_t r = 0; r < n && !overflowed; r++) overflowed = hLongResults[r].status == 4;
 				if (!overflowed || cellPoolPinned) return false;   // (a pinned pool flags the reads instead: the caller asked for that much and no more)
@@ -1822,7 +1802,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				syncStream(ls);
 				return true;
 			};
-			runLongGroup = [=, &dLongCells, &cellBudget, &longScratchOfToken](uint32_t g) {
+			runLongGroup = [=](uint32_t g) {
 				const uint64_t r0 = groupBeginPtr[g], nG = groupBeginPtr[g + 1] - r0;
 				if (nG == 0) return;
 				unsigned long long* dLongScratch = shareLongScratch ? longScratchOfToken : dLongScratchOwn;   // (round token: set under the lock, every round)
@@ -1936,7 +1916,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 				res->counters_long[6] = rounds;
 			};
 			// reads whose band did not fit the LDS tables (status 5) are rerun with the plain-layout kernel
-			longFallback = [=, &dLongCells, &cellBudget]() {
+			longFallback = [=]() {
 				syncStream(ls);
 				std::vector<uint32_t> redo;
 				const bool forceAll = getenv("GC_LONG_FORCE_FALLBACK") != nullptr;   // test hook: run every read through the plain-layout kernel too
@@ -1971,54 +1951,154 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		// With one read group it runs on the pass's own thread right after the rounds, beside the tail of the fragment pipeline (which ends
 		// 20-30 ms after the pass on cfg2, starved by it), instead of after the join: 16 ms off the batch's critical path.
 		// It writes the reads' long* fields and capacityExceededLong only; the fragment pipeline does not touch those.
-		const bool longPostInThread = P->long_pass && longGroups == 1;
-		std::function<void()> afterLongPass = [&]() {
-			uint64_t rerun = longFallback();
-			res->counters_long[7] = rerun;   // reads that needed the plain-layout fallback kernel
-			for (int i = 0; i < 6; i++) res->counters_long[i] = hLongSmall[8 + i];   // same units as counters[]
-#ifdef GC_STAMPS
-			{
-				static const char* names[11] = { "slice prologue", "pop+prev lookup", "tile columns", "item store", "edge pushes", "slice epilogue", "bt slice change", "bt item loads", "bt recompute", "bt corner", "bt walk" };
-				double total = 0;
-				for (int i = 0; i < 11; i++) total += (double)hLongSmall[16 + i];
-				for (int i = 0; i < 11; i++) fprintf(stderr, "[gc stamps] %-16s %6.2f%%  %.3e lane-cycles\n", names[i], 100.0 * hLongSmall[16 + i] / (total > 0 ? total : 1), (double)hLongSmall[16 + i]);
-			}
-#endif
-#ifdef GC_SM_STAMPS
-			{
-				static const char* names[5] = { "B (tile boundary)", "COL (column)", "BT (bt boundary)", "WALK (cell)", "housekeeping+vote" };
-				double total = 0;
-				for (int i = 0; i < 5; i++) total += (double)hLongSmall[16 + i];
-				for (int i = 0; i < 5; i++) fprintf(stderr, "[gc sm stamps] %-18s %6.2f%% of wave-cycles, %.3e executions, %.0f cycles each, %.2f lanes served per execution\n", names[i], 100.0 * hLongSmall[16 + i] / (total > 0 ? total : 1),
-					(double)hLongSmall[21 + i], (double)hLongSmall[16 + i] / std::max<double>(1, (double)hLongSmall[21 + i]), (double)hLongSmall[26 + i] / std::max<double>(1, (double)hLongSmall[21 + i]));
-			}
-#endif
-			if (const char* env = getenv("GC_TEST_FAIL_LONG")) {   // test hook shared with the oracle: this read's whole-read pass "asserts"
-				long idx = atol(env);
-				if (idx >= 0 && (uint64_t)idx < n) hLongResults[idx].status = 1;
-			}
-			// A whole-read pass that trips one of the reference's live asserts leaves the read with nothing: align_fn's catch sets
-			// `cont` (src/Aligner.cpp:591), which is declared once per read (:529) and makes the fragment loop skip every anchor
-			// (:702-703); the alignments found before the throw are lost with the exception.
-			for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status == 1) { hLongResults[r].nAlignments = 0; glue[r].longFailed = true; }
-			// capacities of this library, not of the reference: 2 extension scratch (even with the fallback's four-fold room), 3 more alignments than
-			// maxAlignments, 4 the merged-trace cell pool (GC_LONG_CELLS_PER_BASE). The read keeps what was found up to there and is flagged.
-			for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status >= 2 && hLongResults[r].status <= 4) glue[r].capacityExceededLong = true;
-			{
-				std::vector<uint32_t> all(n);
-				for (uint64_t r = 0; r < n; r++) all[r] = (uint32_t)r;
-				decideLongReads(all, 0, st->longStream, [&](uint32_t r) { return hLongResults[r].nAlignments; });
-				finishLongDecision(0);
-			}
-		};
+		longPostInThread = P->long_pass && longGroups == 1;
 		// The whole-read pass is the longest leg of the batch: its round loop runs on its own host thread and stream from
 		// here on, while this thread prepares and runs the fragment pipeline.
-		std::vector<std::thread> longThreads;
-		std::vector<std::exception_ptr> longErrors(16);
-		double tLongWall0 = nowUs();
-		std::atomic<double> longWallBeginUs { 0.0 };   // when the pass got the device's token (waiting for another batch's pass is not its own time)
-		std::atomic<double> longWallEndUs { 0.0 };
-		struct JoinGuard { std::vector<std::thread>& t; ~JoinGuard() { for (auto& x : t) if (x.joinable()) x.join(); } } joinGuard { longThreads };
+	}
+
+	// selection of a subset of reads' whole-read alignments and the NW distance of the best one (src/Aligner.cpp:636-654): launch ...
+	void decideLongReads(const std::vector<uint32_t>& subset, int slot, hipStream_t q, const std::function<uint32_t(uint32_t)>& nAlnOf, bool usePool = true)
+	{
+		// the reference re-sorts its alignment list by alignmentStart after every accepted alignment
+		// (src/GraphAligner.h:183); replaying that on the acceptance-ordered list gives its final order. Then the
+		// GreedyLength selection (src/Aligner.cpp:636-639, src/AlignmentSelection.cpp:12-50) with the same unstable sort.
+		auto selectOne = [&](size_t i, size_t) {
+			const uint32_t r = subset[i];
+			ReadGlue& gl = glue[r];
+			gl.longAlns.clear();
+			gl.longSelected.clear();
+			const uint32_t nAln = nAlnOf(r);
+			for (uint32_t a = 0; a < nAln; a++) {
+				gl.longAlns.push_back(hLongAlns[(uint64_t)r * maxAlignments + a]);
+				std::sort(gl.longAlns.begin(), gl.longAlns.end(), [](const LongAln& l, const LongAln& rr) { return l.start < rr.start; });
+			}
+			struct Item { uint32_t start, end, score, index; };
+			std::vector<Item> sorted;
+			const size_t readLen = R->offsets[r + 1] - R->offsets[r];
+			for (uint32_t a = 0; a < gl.longAlns.size(); a++) {
+				// --E-cutoff: SelectECutoff runs before the greedy selection and keeps the list's order (src/AlignmentSelection.cpp:57-61,91-99)
+				if (!evalueModel.keeps(P->e_cutoff, hg.SizeInBP(), readLen, gl.longAlns[a].end - gl.longAlns[a].start, gl.longAlns[a].score)) continue;
+				sorted.push_back(Item { gl.longAlns[a].start, gl.longAlns[a].end, gl.longAlns[a].score, a });
+			}
+			std::sort(sorted.begin(), sorted.end(), [](const Item& l, const Item& rr) {
+				if ((l.end - l.start) > (rr.end - rr.start)) return true;
+				if ((rr.end - rr.start) > (l.end - l.start)) return false;
+				return l.score < rr.score;
+			});
+			auto incompatible = [](const Item& l, const Item& rr) {
+				float minOverlapLen = std::min(l.end - l.start, rr.end - rr.start) * 0.05f;
+				size_t ls = l.start, le = l.end, rs = rr.start, re = rr.end;
+				if (ls > rs) { std::swap(ls, rs); std::swap(le, re); }
+				int overlap = 0;
+				if (le > rs) overlap = (int)(le - rs);
+				return overlap > minOverlapLen;
+			};
+			std::vector<Item> kept;
+			for (const Item& it : sorted) {
+				bool ok = true;
+				for (const Item& k : kept) if (incompatible(it, k)) { ok = false; break; }
+				if (ok) { kept.push_back(it); gl.longSelected.push_back(it.index); }
+			}
+		};
+		if (usePool) pool.run(subset.size(), selectOne); else for (size_t i = 0; i < subset.size(); i++) selectOne(i, 0);
+		auto& D = st->edLong[slot];
+		D.nPairs = 0;
+		D.pairRead.clear();
+		if (!P->edit_distances || subset.empty()) return;
+		// edit distance of the best whole-read alignment's path against the read (edlibAlign at src/Aligner.cpp:645)
+		const size_t m = subset.size();
+		PathSeqJob* hJobsPS = D.hJobs.reserve<PathSeqJob>(m);
+		EdPair* hPairs = D.hPairs.reserve<EdPair>(m);
+		int64_t* hOut = D.hOut.reserve<int64_t>(m);
+		uint64_t nLetters = 0;
+		uint32_t nPairs = 0;
+		for (size_t i = 0; i < m; i++) {
+			const uint32_t r = subset[i];
+			const ReadGlue& gl = glue[r];
+			if (gl.longSelected.empty()) { hJobsPS[i] = PathSeqJob { 0, nLetters, 0, 0, 0, 0 }; continue; }
+			const LongAln& al = gl.longAlns[gl.longSelected[0]];
+			uint32_t len = (uint32_t)(R->offsets[r + 1] - R->offsets[r]);
+			uint32_t cap = 2 * al.traceLen + 256;
+			hJobsPS[i] = PathSeqJob { al.traceOff, nLetters, al.traceLen, cap, 0, 0 };
+			// the alignment itself bounds the distance: its edits plus the unaligned read ends
+			hPairs[nPairs++] = EdPair { nLetters, 0, (uint32_t)i, r, al.score + al.start + (len - std::min(len, al.end)) + 8 };
+			D.pairRead.push_back(r);
+			nLetters += cap;
+		}
+		PathSeqJob* dJobsPS = D.jobs.reserve<PathSeqJob>(m);
+		char* dLetters = D.letters.reserve<char>(nLetters);
+		uint32_t* dLettersLen = D.lettersLen.reserve<uint32_t>(m);
+		EdPair* dPairs = D.pairs.reserve<EdPair>(m);
+		int64_t* dOut = D.out.reserve<int64_t>(m);
+		HIP_CHECK(hipMemcpyAsync(dJobsPS, hJobsPS, m * sizeof(PathSeqJob), hipMemcpyHostToDevice, q));
+		launchLongPathSeq(q, G->dev, dJobsPS, (uint32_t)m, dLongCells, dLetters, dLettersLen);
+		auto readLenOf = [R = R](uint32_t r) { return (uint32_t)(R->offsets[r + 1] - R->offsets[r]); };
+		launchEditDistances(D.run, q, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen, readLenOf);
+		D.nPairs = nPairs;
+		decisionPtr[slot] = DecisionPointers { hPairs, hOut, dPairs, dOut, dLetters, dLettersLen };
+	}
+
+	// ... and collect
+	void finishLongDecision(int slot)
+	{
+		auto& D = st->edLong[slot];
+		if (!D.nPairs) return;
+		const DecisionPointers& p = decisionPtr[slot];
+		finishEditDistances(D.run, st->longStream, p.hPairs, p.hOut, D.nPairs, p.dPairs, p.dOut, R->devEdReads, R->devBases, R->devEqMasks, p.dLetters, p.dLettersLen);
+		for (uint32_t i = 0; i < D.nPairs; i++) {
+			ReadGlue& gl = glue[D.pairRead[i]];
+			gl.longEditDistance = p.hOut[i];
+			if (p.hOut[i] < -1) { gl.longEditDistance = -1; gl.capacityExceededLong = true; }   // outside the NW kernel's range: flagged, no distance
+		}
+		D.nPairs = 0;
+	}
+
+	// What follows the rounds: fallback reruns, the reference's `cont` rule, selection and the NW distance of the best whole-read alignment.
+	void afterLongPass()
+	{
+		uint64_t rerun = longFallback();
+		res->counters_long[7] = rerun;   // reads that needed the plain-layout fallback kernel
+		for (int i = 0; i < 6; i++) res->counters_long[i] = hLongSmall[8 + i];   // same units as counters[]
+#ifdef GC_STAMPS
+		{
+			static const char* names[11] = { "slice prologue", "pop+prev lookup", "tile columns", "item store", "edge pushes", "slice epilogue", "bt slice change", "bt item loads", "bt recompute", "bt corner", "bt walk" };
+			double total = 0;
+			for (int i = 0; i < 11; i++) total += (double)hLongSmall[16 + i];
+			for (int i = 0; i < 11; i++) fprintf(stderr, "[gc stamps] %-16s %6.2f%%  %.3e lane-cycles\n", names[i], 100.0 * hLongSmall[16 + i] / (total > 0 ? total : 1), (double)hLongSmall[16 + i]);
+		}
+#endif
+#ifdef GC_SM_STAMPS
+		{
+			static const char* names[5] = { "B (tile boundary)", "COL (column)", "BT (bt boundary)", "WALK (cell)", "housekeeping+vote" };
+			double total = 0;
+			for (int i = 0; i < 5; i++) total += (double)hLongSmall[16 + i];
+			for (int i = 0; i < 5; i++) fprintf(stderr, "[gc sm stamps] %-18s %6.2f%% of wave-cycles, %.3e executions, %.0f cycles each, %.2f lanes served per execution\n", names[i], 100.0 * hLongSmall[16 + i] / (total > 0 ? total : 1),
+				(double)hLongSmall[21 + i], (double)hLongSmall[16 + i] / std::max<double>(1, (double)hLongSmall[21 + i]), (double)hLongSmall[26 + i] / std::max<double>(1, (double)hLongSmall[21 + i]));
+		}
+#endif
+		if (const char* env = getenv("GC_TEST_FAIL_LONG")) {   // test hook shared with the oracle: this read's whole-read pass "asserts"
+			long idx = atol(env);
+			if (idx >= 0 && (uint64_t)idx < n) hLongResults[idx].status = 1;
+		}
+		// A whole-read pass that trips one of the reference's live asserts leaves the read with nothing: align_fn's catch sets
+		// `cont` (src/Aligner.cpp:591), which is declared once per read (:529) and makes the fragment loop skip every anchor
+		// (:702-703); the alignments found before the throw are lost with the exception.
+		for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status == 1) { hLongResults[r].nAlignments = 0; glue[r].longFailed = true; }
+		// capacities of this library, not of the reference: 2 extension scratch (even with the fallback's four-fold room), 3 more alignments than
+		// maxAlignments, 4 the merged-trace cell pool (GC_LONG_CELLS_PER_BASE). The read keeps what was found up to there and is flagged.
+		for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status >= 2 && hLongResults[r].status <= 4) glue[r].capacityExceededLong = true;
+		{
+			std::vector<uint32_t> all(n);
+			for (uint64_t r = 0; r < n; r++) all[r] = (uint32_t)r;
+			decideLongReads(all, 0, st->longStream, [&](uint32_t r) { return hLongResults[r].nAlignments; });
+			finishLongDecision(0);
+		}
+	}
+
+	// ---------------- the pass gets its own host thread and stream from here on
+	void startWholeReadPass()
+	{
+		tLongWall0 = nowUs();
 		if (P->long_pass) {
 			int device = 0;
 			HIP_CHECK(hipGetDevice(&device));
@@ -2045,6 +2125,11 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 					} catch (...) { longErrors[g] = std::current_exception(); }
 				});
 		}
+	}
+
+	// ---------------- fragment windows, k_build_fragment_work, K3 / K3b in lazy rounds, K4, k_stitch - queued on the main stream
+	void fragmentPipeline()
+	{
 		double tLongStarted = nowUs();
 		double tWindows = tLongStarted, tReserved = tLongStarted;
 		if (!deviceGlue) {
@@ -2120,7 +2205,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			(tWindows - tLongStarted) / 1e3, (tReserved - tWindows) / 1e3, (nowUs() - tReserved) / 1e3);
 
 		// ---------------- K3 / K3b / K4
-		double tDev = nowUs();
+		tDev = nowUs();
 		ExtendConfig cfg;
 		cfg.bandwidth = P->bandwidth;
 		cfg.maxSlices = 3;
@@ -2130,25 +2215,25 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		cfg.maxItems = (uint32_t)std::max<int64_t>(8, capacityOr("GC_EXT_MAX_ITEMS", P->capacity.ext_max_items, cfg.maxItems));
 		cfg.maxPending = (uint32_t)std::max<int64_t>(8, capacityOr("GC_EXT_MAX_PENDING", P->capacity.ext_max_pending, cfg.maxPending));
 		cfg.maxTrace = (uint32_t)std::max<int64_t>(64, capacityOr("GC_EXT_MAX_TRACE", P->capacity.ext_max_trace, cfg.maxTrace));
-		uint32_t nWork = (uint32_t)(2 * nSlots);
+		nWork = (uint32_t)(2 * nSlots);
 		uint64_t slabBytes = extendSlabBytes(cfg);
 		uint32_t lanes = extendGridLanes(nWork);
 		ExtItem* dWork = st->work.reserve<ExtItem>(nWork);
-		ExtResult* dResults = st->results.reserve<ExtResult>(nWork);
+		dResults = st->results.reserve<ExtResult>(nWork);
 		uint8_t* dScratch = st->scratch.reserve<uint8_t>((uint64_t)lanes * slabBytes);
-		TraceCell* dTrace = st->tracePool.reserve<TraceCell>(traceBudget);
+		dTrace = st->tracePool.reserve<TraceCell>(traceBudget);
 		if (!deviceGlue) dFrags = st->frags.reserve<Fragment>(nFrags);
 		FragSeed* dFragSeeds = st->fragSeeds.reserve<FragSeed>(nSlots);
-		AnchorRec* dAnchors = st->anchors.reserve<AnchorRec>(nSlots);
-		uint32_t* dFragStatus = st->fragStatus.reserve<uint32_t>(nFrags);
-		uint32_t* dFragExtended = st->fragExtended.reserve<uint32_t>(nFrags);
-		uint64_t pathCapacity = nSlots * 24 + 4096;
-		uint32_t* dPathPool = st->pathPool.reserve<uint32_t>(pathCapacity);
+		dAnchors = st->anchors.reserve<AnchorRec>(nSlots);
+		dFragStatus = st->fragStatus.reserve<uint32_t>(nFrags);
+		dFragExtended = st->fragExtended.reserve<uint32_t>(nFrags);
+		pathCapacity = nSlots * 24 + 4096;
+		dPathPool = st->pathPool.reserve<uint32_t>(pathCapacity);
 		if (!deviceGlue) dJobs = st->jobs.reserve<ReadChainJob>(n);
-		uint32_t* dChainOut = st->chainOut.reserve<uint32_t>(nSlots);
-		uint32_t* dChainLen = st->chainLen.reserve<uint32_t>(n);
-		unsigned long long* dChainScore = st->chainScore.reserve<unsigned long long>(n);
-		uint32_t* dChainStatus = st->chainStatus.reserve<uint32_t>(n);
+		dChainOut = st->chainOut.reserve<uint32_t>(nSlots);
+		dChainLen = st->chainLen.reserve<uint32_t>(n);
+		dChainScore = st->chainScore.reserve<unsigned long long>(n);
+		dChainStatus = st->chainStatus.reserve<uint32_t>(n);
 		uint32_t chainBlocks = std::max(chainGridBlocks((uint32_t)n), chainScratchBlocks((uint32_t)n));   // both launches index the scratch by block
 		uint8_t* dChainScratch = st->chainScratch.reserve<uint8_t>((uint64_t)std::max(1u, chainBlocks) * chainScratchBytes(caps));
 		if (!deviceGlue) {
@@ -2216,12 +2301,7 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		mark();   // 5
 		// chain stitching (src/Aligner.cpp:754-822) on the device, right behind the chaining kernel; GC_HOST_STITCH=1 keeps it on the
 		// host workers (the path also taken by reads that do not fit the kernel's tables)
-		const bool deviceStitch = P->stitch && n > 0 && !(getenv("GC_HOST_STITCH") && atoi(getenv("GC_HOST_STITCH")) != 0);
-		StitchInfo* stitchInfo = nullptr;
-		uint32_t* hStitchNodes = nullptr;
-		uint32_t* dStitchNodes = nullptr;
-		uint64_t stitchDenseCap = 0;
-		unsigned long long* hStitchCursor = nullptr;
+		deviceStitch = P->stitch && n > 0 && !(getenv("GC_HOST_STITCH") && atoi(getenv("GC_HOST_STITCH")) != 0);
 		if (deviceStitch) {
 			stitchDenseCap = stitchDenseWords(nSlots, n);
 			uint32_t* dSlotOf = st->stitchSlotOf.reserve<uint32_t>(std::max<uint64_t>(1, nSlots));
@@ -2239,14 +2319,19 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			HIP_CHECK(hipMemcpyAsync(hStitchCursor, dCursor, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		}
 
+	}
+
+	// ---------------- anchors, chains and stitched paths come down (pinned staging)
+	void resultsBack()
+	{
 		// ---------------- results back (pinned staging)
-		AnchorRec* anchors = st->hAnchors.reserve<AnchorRec>(nSlots);
-		uint32_t* fragStatus = st->hFragStatus.reserve<uint32_t>(nFrags);
-		uint32_t* fragExtended = st->hFragExtended.reserve<uint32_t>(nFrags);
-		uint32_t* chainOut = st->hChainOut.reserve<uint32_t>(nSlots);
-		uint32_t* chainLen = st->hChainLen.reserve<uint32_t>(n);
-		unsigned long long* chainScore = st->hChainScore.reserve<unsigned long long>(n);
-		uint32_t* chainStatus = st->hChainStatus.reserve<uint32_t>(n);
+		anchors = st->hAnchors.reserve<AnchorRec>(nSlots);
+		fragStatus = st->hFragStatus.reserve<uint32_t>(nFrags);
+		fragExtended = st->hFragExtended.reserve<uint32_t>(nFrags);
+		chainOut = st->hChainOut.reserve<uint32_t>(nSlots);
+		chainLen = st->hChainLen.reserve<uint32_t>(n);
+		chainScore = st->hChainScore.reserve<unsigned long long>(n);
+		chainStatus = st->hChainStatus.reserve<uint32_t>(n);
 		if (nSlots) HIP_CHECK(hipMemcpyAsync(anchors, dAnchors, nSlots * sizeof(AnchorRec), hipMemcpyDeviceToHost, stream));
 		if (nFrags) HIP_CHECK(hipMemcpyAsync(fragStatus, dFragStatus, nFrags * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		if (nFrags) HIP_CHECK(hipMemcpyAsync(fragExtended, dFragExtended, nFrags * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -2263,11 +2348,9 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		for (int i = 0; i < 8; i++) res->counters[i] = hSmall[8 + i];
 		// (the cursors overshoot when a pool is full: the extensions / fragments that did not fit carry an overflow status and their reads are flagged)
 		uint64_t traceUsed = std::min<uint64_t>(hSmall[1], traceBudget), pathUsed = std::min<uint64_t>(hSmall[2], pathCapacity);
-		uint32_t* pathPool = st->hPathPool.reserve<uint32_t>(pathUsed);
+		pathPool = st->hPathPool.reserve<uint32_t>(pathUsed);
 		if (pathUsed) HIP_CHECK(hipMemcpyAsync(pathPool, dPathPool, pathUsed * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		std::vector<ExtResult> extResults;
-		std::vector<TraceCell> tracePool;
-		const bool anchorTraces = P->keep_traces == 1;   // (keep_traces == 2: the alignments' traces only - what the output encoders read)
+		anchorTraces = P->keep_traces == 1;   // (keep_traces == 2: the alignments' traces only - what the output encoders read)
 		if (anchorTraces) {
 			extResults.resize(nWork);
 			tracePool.resize(traceUsed);
@@ -2277,7 +2360,6 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		syncStream(stream);
 		res->host_us[3] = nowUs() - tDev;   // K3..K4 + their transfers, wall
 		// the stitched node paths come down behind the kernels that follow on this stream; they are only needed for the result arrays
-		bool stitchNodesPending = false;
 		if (deviceStitch) {
 			uint64_t used = std::min<uint64_t>(*hStitchCursor, stitchDenseCap);
 			hStitchNodes = st->hStitchNodes.reserve<uint32_t>(std::max<uint64_t>(1, used));
@@ -2285,6 +2367,11 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			stitchNodesPending = true;
 		}
 
+	}
+
+	// ---------------- host stitching of what the kernel declined; NW distance of every stitched path against its read
+	void stitchAndChainDistances()
+	{
 		// ---------------- chain stitching (src/Aligner.cpp:754-822) on the host workers, while the whole-read pass still runs
 		double tStitch = nowUs();
 		std::atomic<uint64_t> hostStitched { 0 };
@@ -2318,8 +2405,6 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		// path letters are spelled out on the device from the node path, then the NW kernel; still behind the whole-read pass
 		std::function<void()> finishChainEditDistances;
 		std::vector<uint32_t> pairRead;   // chain pairs -> read
-		const PathSeqJob* chainLetterJobs = nullptr;   // per read: where its stitched path's letters are in dChainLetters
-		const char* dChainLetters = nullptr;
 		if (P->stitch && P->edit_distances) {
 			uint64_t nNodesTotal = 0, nCells = 0;
 			uint32_t nPairs = 0;
@@ -2360,9 +2445,9 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 			launchChainPathSeq(stream, G->dev, dJobsPS, (uint32_t)n, dStitchNodes, dNodes, dLetters, dLettersLen);
 			chainLetterJobs = hJobsPS;
 			dChainLetters = dLetters;
-			auto readLenOf = [R](uint32_t r) { return (uint32_t)(R->offsets[r + 1] - R->offsets[r]); };
+			auto readLenOf = [R = R](uint32_t r) { return (uint32_t)(R->offsets[r + 1] - R->offsets[r]); };
 			launchEditDistances(st->edChainRun, stream, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen, readLenOf);
-			finishChainEditDistances = [=, &glue, &pairRead]() {   // waits for the kernels (they run beside the whole-read pass) and reruns the few pairs that need a wider band
+			finishChainEditDistances = [=, &pairRead]() {   // waits for the kernels (they run beside the whole-read pass) and reruns the few pairs that need a wider band
 				finishEditDistances(st->edChainRun, stream, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen);
 				for (uint32_t i = 0; i < nPairs; i++) {
 					ReadGlue& gl = glue[pairRead[i]];
@@ -2385,9 +2470,13 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] chain stitching + its edit distances %.1f ms (%llu reads stitched on the host)\n", stitchUs / 1e3, (unsigned long long)hostStitched.load());
 		res->counters[7] = hostStitched.load();   // reads whose chain was stitched on the host
 
+	}
+
+	// ---------------- the pass thread ends (its after-pass stage included unless it ran on this thread)
+	void joinWholeReadPass()
+	{
 		// ---------------- whole-read pass results
-		double tJoined = nowUs();
-		const LongCell* longCells = nullptr;   // keep_traces: the merged traces in pinned staging (a pageable destination made this copy 2-3 s per 10 k reads)
+		tJoined = nowUs();
 		if (P->long_pass) {
 			double tJoin0 = nowUs();
 			for (auto& t : longThreads) t.join();
@@ -2409,6 +2498,11 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] after the whole-read pass: selection + its edit distances %.1f ms\n", (nowUs() - tJoined) / 1e3);
 
+	}
+
+	// ---------------- edlib path + trace of the chained alignments that are wanted (src/Aligner.cpp:845-905)
+	void chainedAlignments()
+	{
 		// ---------------- the chained alignment (src/Aligner.cpp:845-905): edlib's alignment path of (stitched path, read) from k_edit_path,
 		// walked over the path cells and the read into the trace; then the decision. Only reads whose chained alignment can still win
 		// (or all with chain_traces == 2) are traced: the path does not change the edit distance that decides.
@@ -2495,6 +2589,11 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		}
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] chained alignment traces: %llu reads, %.1f ms\n", (unsigned long long)nChainTraced, (nowUs() - tChainTrace) / 1e3);
 
+	}
+
+	// ---------------- the flat result: count per read, prefix-sum, fill in parallel
+	void assemble()
+	{
 		// ---------------- assemble the flat result: count per read, prefix-sum, fill in parallel
 		double tAsm = nowUs();
 		if (glueCopied) HIP_CHECK(hipEventSynchronize(glueCopied));   // (long since done: the copies were queued before the fragment pipeline)
@@ -2706,6 +2805,28 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		res->host_us[1] = nowUs() - tAsm;
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc cpu] %.0f ms up to the end of the batch (the join came at %.0f)\n", processCpuMs() - cpuCall, cpuJoined - cpuCall);
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] batch timeline (ms from the call): whole-read pass started %.1f, joined %.1f, assembly began %.1f, done %.1f\n", (tLongWall0 - tTotal) / 1e3, (tJoined - tTotal) / 1e3, (tAsm - tTotal) / 1e3, (nowUs() - tTotal) / 1e3);
+	}
+};
+
+int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const gc_reads* R, const gc_params* P, gc_result** out)
+{
+	if (!G || !S || !st || !R || !P || !out) return fail(GC_ERR_INVALID, "null argument");
+	if (P->split_len < 16 || P->split_len > 64 || P->split_gap < 1) return fail(GC_ERR_INVALID, "split_len must be in [16,64] (one 64-row slice per fragment extension) and split_gap >= 1");
+	{
+		const gc_capacities& c = P->capacity;
+		if (c.reserved[0] || c.reserved[1] || c.reserved[2]) return fail(GC_ERR_INVALID, "gc_params::capacity.reserved must be 0 (was the struct initialised with gc_params_default?)");
+		const int64_t v[] = { c.ext_max_items, c.ext_max_pending, c.ext_max_trace, c.long_max_items, c.long_cells_per_base, c.long_scratch_bytes, c.stitch_set_max, c.stitch_bfs_cap };
+		for (int64_t x : v) if (x < 0 || x > (1ll << 40)) return fail(GC_ERR_INVALID, "gc_params::capacity: a size is negative or absurd (0 = automatic)");
+		if (c.long_column_store < -1 || c.long_column_store > (1ll << 31)) return fail(GC_ERR_INVALID, "gc_params::capacity.long_column_store: -1 (none), 0 (automatic) or a column count");
+	}
+	*out = nullptr;
+	const double tCall = nowUs();
+	const double cpuCall = processCpuMs();
+	gc_result* res = (gc_result*)calloc(1, sizeof(gc_result));
+	int rc = guarded([&]() {
+		HIP_CHECK(hipSetDevice(st->device));   // the current device is per host thread
+		BatchRun batch(G, S, st, R, P, res, tCall, cpuCall);
+		batch.run();
 		return (int)GC_OK;
 	});
 	if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] gc_align_batch returned after %.1f ms\n", (nowUs() - tCall) / 1e3);
