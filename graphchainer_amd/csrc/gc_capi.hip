@@ -226,7 +226,11 @@ template <typename T> T* mallocArray(size_t n) { return (T*)malloc(std::max<size
 // gc_result_free gives back: fresh memory of that size is mapped and zero-filled page by page on first touch, every batch again (r3: ~1.5 of the 3.4 CPU-seconds the
 // assembly of a traced batch cost). Every array carries a 64-byte header with its size, so gc_result_free knows what it holds.
 struct ResultBlockCache {
-	static constexpr size_t HEADER = 64, BIG = 32ull << 20, MAX_HELD = 24ull << 30;
+	static constexpr size_t HEADER = 64, MAX_HELD = 24ull << 30;
+	// test hooks: GC_RESULT_CACHE_MIN=bytes recycles arrays from that size on (default 32 MB), GC_RESULT_CACHE_POISON=1 fills every array with 0xA5 when it is handed out -
+	// together they show any reader that counts on an array's unwritten part being zero (fresh pages are, recycled ones are not)
+	const size_t BIG = getenv("GC_RESULT_CACHE_MIN") ? (size_t)std::max(1ll, atoll(getenv("GC_RESULT_CACHE_MIN"))) : (32ull << 20);
+	const bool poison = getenv("GC_RESULT_CACHE_POISON") != nullptr;
 	std::mutex mutex;
 	std::vector<std::pair<char*, size_t>> blocks;   // (base, capacity in bytes without the header)
 	size_t held = 0;
@@ -240,7 +244,9 @@ struct ResultBlockCache {
 			if (best < blocks.size()) {
 				char* base = blocks[best].first;
 				held -= blocks[best].second;
+				const size_t capacityHeld = blocks[best].second;
 				blocks.erase(blocks.begin() + (long)best);
+				if (poison) memset(base + HEADER, 0xA5, capacityHeld);
 				return base + HEADER;
 			}
 		}
@@ -248,6 +254,7 @@ struct ResultBlockCache {
 		char* base = (char*)malloc(capacity + HEADER);
 		if (!base) throw std::bad_alloc();
 		*(size_t*)base = capacity;
+		if (poison) memset(base + HEADER, 0xA5, capacity);
 		return base + HEADER;
 	}
 	void put(void* p)
