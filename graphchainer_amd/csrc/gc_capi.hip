@@ -1465,18 +1465,36 @@ struct BatchRun {
 	LongReadResult* hLongResults = nullptr;
 	LongCell* dLongCells = nullptr;
 	uint64_t cellBudget = 0;                      // capacity of the merged-trace cell pool (grown and the pass rerun when a batch overflows it)
-	std::function<bool()> growLongCells;          // whole-read pass thread: the pool was too small -> enlarge it, reset the pass's cursors; false when it cannot grow
-	std::function<uint64_t()> longFallback;
-	std::function<void(uint32_t)> runLongGroup;
 	unsigned long long* longScratchOfToken = nullptr;   // the device's shared extension scratch, set by the pass once it holds the token
 	uint64_t longScratchWords = 0;
 	bool shareLongScratch = false;
-	std::function<void()> finishLongGroups;
 	uint32_t longGroups = 0;
 	std::vector<double> groupExtendUs; std::vector<uint32_t> groupRounds; std::vector<uint64_t> groupBegin, groupTraceBegin;   // (the pass thread works through pointers into these)
 	const gc::EValueModel evalueModel { 0.7 };   // src/Aligner.cpp:478-482 (precise clipping is out of scope)
 	struct DecisionPointers { EdPair* hPairs = nullptr; int64_t* hOut = nullptr; EdPair* dPairs = nullptr; int64_t* dOut = nullptr; char* dLetters = nullptr; uint32_t* dLettersLen = nullptr; } decisionPtr[2];
 	bool longPostInThread = false;
+	// ... the whole-read pass's own buffers and sizes (prepareWholeReadPass sets them; runLongGroup / growLongCells / longFallback / finishLongGroups run on the pass thread)
+	LongJob* hJobs = nullptr;
+	bool cellPoolPinned = 0;
+	uint64_t waveWords = 0;
+	LongJob* dLongJobs = nullptr;
+	LongAln* dLongAlns = nullptr;
+	uint32_t nGroups = 0;
+	uint32_t cursorWords = 0;
+	unsigned long long* dLongCursor = nullptr;
+	LongState* dLongState = nullptr;
+	LongWork* dLongWork = nullptr;
+	LongWorkResult* dLongWorkResults = nullptr;
+	uint32_t* dCandSeed = nullptr;
+	uint32_t* dWorkLen = nullptr;
+	uint32_t* dRetryList = nullptr;
+	uint32_t* dOrder = nullptr;
+	unsigned long long* dRoundTrace = nullptr;
+	uint64_t scratchLanes = 0;
+	hipStream_t ls = nullptr;
+	ExtendConfig lcfg;
+	unsigned long long* dLongScratchOwn = nullptr;   // (this stream's own scratch: only without the one-pass-at-a-time token)
+	uint64_t maxReadLen = 1;
 	// startWholeReadPass()
 	std::vector<std::thread> longThreads;
 	std::vector<std::exception_ptr> longErrors;
@@ -1682,7 +1700,8 @@ struct BatchRun {
 	void prepareWholeReadPass()
 	{
 		// ---------------- K3-long: whole-read pass on its own stream (src/Aligner.cpp:630-654)
-		uint64_t nLongSeeds = 0, maxReadLen = 1;
+		uint64_t nLongSeeds = 0;
+		maxReadLen = 1;
 		for (uint64_t r = 0; r < n; r++) maxReadLen = std::max<uint64_t>(maxReadLen, R->offsets[r + 1] - R->offsets[r]);
 		// alignments kept per read: the reference has no limit; 32 is far above what 10 kb reads produce (3.6 seeds extended on average), longer
 		// and noisier reads get room in proportion. A read that still exceeds it is flagged (capacity_exceeded), the batch goes on.
@@ -1696,14 +1715,13 @@ struct BatchRun {
 			else for (uint64_t r = 0; r < n; r++) { glue[r].longSeedBegin = nLongSeeds; nLongSeeds += glue[r].longSeeds.size(); }
 			if (nLongSeeds >= 0xffffffffull) throw std::runtime_error("batch too large for the whole-read pass");
 			LongSeed* hSeeds = st->hLongSeeds.reserve<LongSeed>(deviceGlue ? 0 : nLongSeeds);
-			LongJob* hJobs = st->hLongJobs.reserve<LongJob>(n);
+			hJobs = st->hLongJobs.reserve<LongJob>(n);
 			// merged-trace cells per read base: 8 hold the few partial alignments a 10 kb ONT read collects before its end-to-end one (cfg2 uses ~1.1);
 			// noisy 50 kb CLR reads on a genome with repeats collect 8-9 alignments each and overflowed it (a quarter of the reads flagged, which reads
 			// depending on timing). The stream remembers what its batches needed, and a batch that overflows reruns its pass with three times the room.
-			const bool cellPoolPinned = getenv("GC_LONG_CELLS_PER_BASE") || P->capacity.long_cells_per_base > 0;
+			cellPoolPinned = getenv("GC_LONG_CELLS_PER_BASE") || P->capacity.long_cells_per_base > 0;
 			const uint64_t cellsPerBase = (uint64_t)std::max<int64_t>(2, capacityOr("GC_LONG_CELLS_PER_BASE", P->capacity.long_cells_per_base, (int64_t)st->longCellsPerBase));
-			auto budgetFor = [R = R, n = n](uint64_t perBase) { uint64_t b = 0; for (uint64_t r = 0; r < n; r++) b += perBase * (R->offsets[r + 1] - R->offsets[r]) + 1024; return b; };
-			cellBudget = budgetFor(cellsPerBase);
+			cellBudget = cellBudgetFor(cellsPerBase);
 			pool.run(n, [&](size_t r, size_t) {
 				const ReadGlue& gl = glue[r];
 				uint64_t at = gl.longSeedBegin;
@@ -1721,7 +1739,6 @@ struct BatchRun {
 				j.seedEnd = (uint32_t)at;
 				j.alnBegin = (uint32_t)(r * maxAlignments);
 			});
-			ExtendConfig lcfg;
 			lcfg.bandwidth = P->bandwidth;
 			lcfg.maxSlices = (uint32_t)(maxReadLen / 64 + 3);
 			lcfg.maxItems = (uint32_t)std::max<uint64_t>(8192, (maxReadLen / 64 + 3) * 24);   // (slice, node) tiles of one extension: ~8 per slice on cfg2, room for 24
@@ -1733,18 +1750,17 @@ struct BatchRun {
 			lcfg.maxCols = (uint32_t)std::max<int64_t>(0, capacityOr("GC_LONG_MAX_COLS", P->capacity.long_column_store, (int64_t)(3 * maxReadLen + 4096)));   // (-1 in the parameters, 0 in the environment: no store)
 			lcfg.maxItems = (uint32_t)std::max<int64_t>(64, capacityOr("GC_LONG_MAX_ITEMS", P->capacity.long_max_items, lcfg.maxItems));
 			if (const char* env = getenv("GC_LONG_REG_CAP")) lcfg.regCap = (uint32_t)std::max(1, std::min(64, atoi(env)));   // test hook: force the LDS-table retry
-			uint64_t waveWords = longWaveWordsPerLane(lcfg);
+			waveWords = longWaveWordsPerLane(lcfg);
 			if (!deviceGlue) dLongSeeds = st->longSeeds.reserve<LongSeed>(nLongSeeds);
-			LongJob* dLongJobs = st->longJobs.reserve<LongJob>(n);
-			LongAln* dLongAlns = st->longAlns.reserve<LongAln>(n * maxAlignments);
+			dLongJobs = st->longJobs.reserve<LongJob>(n);
+			dLongAlns = st->longAlns.reserve<LongAln>(n * maxAlignments);
 			LongReadResult* dLongResults = st->longResults.reserve<LongReadResult>(n);
-			unsigned long long* dLongScratchOwn = nullptr;   // (this stream's own scratch: only without the one-pass-at-a-time token)
 			dLongCells = st->longCells.reserve<LongCell>(cellBudget);
 			// Read groups: the rounds of one group are serial (select -> extend -> merge, host decides when to stop). Groups can
 			// run their round loops concurrently, each on its own stream and host thread (GC_LONG_GROUPS). Measured on cfg2
 			// (10k reads): 1 group 367 ms/step, 2 groups 517, 4 groups 477, 8 groups 607 - the groups' big rounds coincide and
 			// their tails too, so nothing overlaps usefully and the kernels slow each other down. Default: one group.
-			uint32_t nGroups = 1;
+			nGroups = 1;
 			if (const char* env = getenv("GC_LONG_GROUPS")) nGroups = (uint32_t)std::max(1, std::min(16, atoi(env)));
 			if (n < 64ull * nGroups) nGroups = 1;
 			while (st->groupStreams.size() < nGroups) {
@@ -1754,25 +1770,25 @@ struct BatchRun {
 				for (int k = 0; k < 2 * LONG_EVENT_RING; k++) { hipEvent_t e = nullptr; HIP_CHECK(hipEventCreate(&e)); st->groupEvents.push_back(e); }   // a ring of (begin, end) pairs around the rounds' extension launches
 			}
 			// cursors: [0] cell pool, [8..15] counters (+ [16..31] profiling stamps), per group g at 32+8g: [+0] work count, [+1] round trace cursor
-			const uint32_t cursorWords = 32 + 8 * 16;
-			unsigned long long* dLongCursor = st->longCursor.reserve<unsigned long long>(cursorWords);
+			cursorWords = 32 + 8 * 16;
+			dLongCursor = st->longCursor.reserve<unsigned long long>(cursorWords);
 			hLongAlns = st->hLongAlns.reserve<LongAln>(n * maxAlignments);
 			hLongResults = st->hLongResults.reserve<LongReadResult>(n);
 			hLongSmall = st->hLongSmall.reserve<unsigned long long>(cursorWords);
-			hipStream_t ls = st->longStream;
+			ls = st->longStream;
 			HIP_CHECK(hipMemsetAsync(dLongCursor, 0, cursorWords * sizeof(unsigned long long), ls));
 			if (nLongSeeds && !deviceGlue) HIP_CHECK(hipMemcpyAsync(dLongSeeds, hSeeds, nLongSeeds * sizeof(LongSeed), hipMemcpyHostToDevice, ls));
 			if (n) HIP_CHECK(hipMemcpyAsync(dLongJobs, hJobs, n * sizeof(LongJob), hipMemcpyHostToDevice, ls));
 			syncStream(ls);   // the group streams start from uploaded inputs
 			// rounds: select -> extend -> merge until no read has a seed left to extend (see gc_kernels.hip, "K3-long in rounds")
-			LongState* dLongState = st->longState.reserve<LongState>(n);
+			dLongState = st->longState.reserve<LongState>(n);
 			const uint64_t workCapacity = 8 * n + 64ull * nGroups;   // all groups together; group g owns the slice for its reads
-			LongWork* dLongWork = st->longWork.reserve<LongWork>(workCapacity);
-			LongWorkResult* dLongWorkResults = st->longWorkResults.reserve<LongWorkResult>(workCapacity);
-			uint32_t* dCandSeed = st->longCandSeed.reserve<uint32_t>(workCapacity);
-			uint32_t* dWorkLen = st->longWorkLen.reserve<uint32_t>(workCapacity);   // written by k_long_select, sorted into dOrder by k_long_order: the host only
-			uint32_t* dRetryList = st->longRetryList.reserve<uint32_t>(workCapacity);   // work items whose band outgrew the register tables (per round)
-			uint32_t* dOrder = st->longOrder.reserve<uint32_t>(workCapacity);       // learns the round's work count (k_publish: no copy-engine transfer in the round loop)
+			dLongWork = st->longWork.reserve<LongWork>(workCapacity);
+			dLongWorkResults = st->longWorkResults.reserve<LongWorkResult>(workCapacity);
+			dCandSeed = st->longCandSeed.reserve<uint32_t>(workCapacity);
+			dWorkLen = st->longWorkLen.reserve<uint32_t>(workCapacity);   // written by k_long_select, sorted into dOrder by k_long_order: the host only
+			dRetryList = st->longRetryList.reserve<uint32_t>(workCapacity);   // work items whose band outgrew the register tables (per round)
+			dOrder = st->longOrder.reserve<uint32_t>(workCapacity);       // learns the round's work count (k_publish: no copy-engine transfer in the round loop)
 			groupBegin.assign(nGroups + 1, 0); groupTraceBegin.assign(nGroups + 1, 0);
 			for (uint32_t g = 0; g <= nGroups; g++) groupBegin[g] = n * g / nGroups;
 			for (uint32_t g = 0; g < nGroups; g++) {
@@ -1780,179 +1796,20 @@ struct BatchRun {
 				for (uint64_t r = groupBegin[g]; r < groupBegin[g + 1]; r++) { uint64_t len = R->offsets[r + 1] - R->offsets[r]; budget += 4 * (len + len / 2 + 1024); }   // up to four candidate seeds' worth per read (the speculation rule below keeps rounds within it)
 				groupTraceBegin[g + 1] = groupTraceBegin[g] + budget;
 			}
-			unsigned long long* dRoundTrace = st->longRoundTrace.reserve<unsigned long long>(groupTraceBegin[nGroups]);
+			dRoundTrace = st->longRoundTrace.reserve<unsigned long long>(groupTraceBegin[nGroups]);
 			// extension scratch: one region per lane of a resident wave (persistent waves fetch work items), per read group
 			// (bounded by a memory budget: 0.8 MB per lane for 10 kb reads, 2.4 MB for 50 kb reads; GC_LONG_SCRATCH_GB overrides the 48 GB)
 			uint64_t scratchBudget = P->capacity.long_scratch_bytes > 0 ? (uint64_t)P->capacity.long_scratch_bytes : 48ull << 30;
 			if (const char* env = getenv("GC_LONG_SCRATCH_GB")) scratchBudget = (uint64_t)std::max(1, atoi(env)) << 30;
-			const uint64_t scratchLanes = std::min<uint64_t>(workCapacity + 64, std::max<uint64_t>(2048, std::min<uint64_t>(65536 + 64, scratchBudget / (waveWords * 8))));
+			scratchLanes = std::min<uint64_t>(workCapacity + 64, std::max<uint64_t>(2048, std::min<uint64_t>(65536 + 64, scratchBudget / (waveWords * 8))));
 			// one pass at a time (the default) works in the device's shared scratch; the experiments that let passes overlap keep a scratch per stream
 			longScratchWords = (uint64_t)nGroups * scratchLanes * waveWords;
 			shareLongScratch = nGroups == 1 && (getenv("GC_LONG_TOKEN") ? atoi(getenv("GC_LONG_TOKEN")) : 1) >= 1;   // (token per pass or per round: whoever holds it owns the scratch)
 			if (!shareLongScratch) dLongScratchOwn = st->longScratch.reserve<unsigned long long>(longScratchWords);
 			groupExtendUs.assign(nGroups, 0.0);
 			groupRounds.assign(nGroups, 0);
-			double* groupExtendUsPtr = groupExtendUs.data();
-			uint32_t* groupRoundsPtr = groupRounds.data();
-			const uint64_t* groupBeginPtr = groupBegin.data();
-			const uint64_t* groupTraceBeginPtr = groupTraceBegin.data();
-			growLongCells = [=]() mutable {
-				bool overflowed = false;
-				for (uint64_t r = 0; r < n && !overflowed; r++) overflowed = hLongResults[r].status == 4;
-				if (!overflowed || cellPoolPinned) return false;   // (a pinned pool flags the reads instead: the caller asked for that much and no more)
-				const uint64_t next = st->longCellsPerBase * 3;
-				if (next > 256 || budgetFor(next) * sizeof(LongCell) > (64ull << 30)) return false;
-				st->longCellsPerBase = next;
-				cellBudget = budgetFor(next);
-				dLongCells = st->longCells.reserve<LongCell>(cellBudget);
-				HIP_CHECK(hipMemsetAsync(dLongCursor, 0, cursorWords * sizeof(unsigned long long), ls));
-				syncStream(ls);
-				return true;
-			};
-			runLongGroup = [=](uint32_t g) {
-				const uint64_t r0 = groupBeginPtr[g], nG = groupBeginPtr[g + 1] - r0;
-				if (nG == 0) return;
-				unsigned long long* dLongScratch = shareLongScratch ? longScratchOfToken : dLongScratchOwn;   // (round token: set under the lock, every round)
-				hipStream_t q = st->groupStreams[g];
-				hipEvent_t* ring = st->groupEvents.data() + (size_t)2 * LONG_EVENT_RING * g;
-				// the rounds' extension time: read a ring slot's pair before the slot is reused (its round is complete by then: every round's
-				// work count has been awaited since) and what is left after the last round
-				auto collect = [&](int slot) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ring[2 * slot], ring[2 * slot + 1])); groupExtendUsPtr[g] += (double)ms * 1000.0; };
-				int timedRounds = 0;
-				const uint64_t w0 = 8 * r0 + 64ull * g, capacity = 8 * nG + 64;   // this group's slice of the work arrays
-				unsigned long long* cursor = dLongCursor + 32 + 8 * g;
-				volatile unsigned long long* hCursor = hLongSmall + 32 + 8 * g;
-				const uint64_t traceBudget = groupTraceBeginPtr[g + 1] - groupTraceBeginPtr[g];
-				double dbgWaitUs = 0;
-				const double dbgT0 = nowUs();
-				launchLongInit(q, dLongJobs + r0, (uint32_t)nG, dLongState + r0);
-				uint32_t lastWork = 0xffffffffu;
-				// GC_LONG_TOKEN=2: the token (and with it the device's extension scratch) is held per round - from the moment a round's extension kernel is queued until
-				// that kernel has finished - so that the small kernels and the host round trip between two rounds of one batch run beside another batch's extension kernel
-				int deviceNow = 0;
-				HIP_CHECK(hipGetDevice(&deviceNow));
-				const bool roundToken = getenv("GC_LONG_TOKEN") && atoi(getenv("GC_LONG_TOKEN")) == 2;   // (read per batch: the tests switch modes inside one process)
-				std::unique_lock<std::mutex> roundLock(g_longPassToken[deviceNow & 15], std::defer_lock);
-				hipEvent_t roundExtendDone = nullptr;
-
-				for (int round = 0; round < 4096; round++) {
-					launchZeroWords(q, cursor, 4);   // [0] work count, [1] round trace cursor, [2] next work slot, [3] length of the retry list
-					// tail rounds: once fewer than a quarter of the reads are still active the chip is mostly idle, so the
-					// remaining reads try several seeds per round (exact: k_long_merge re-checks them in order)
-					// (the number of work items stays below what round 0 had: active reads x candidates <= n)
-					uint32_t maxCand = 1;
-					if (round > 0 && lastWork > 0) maxCand = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (2 * nG) / lastWork));
-					if (round > 0 && lastWork < 8192) maxCand = 8;   // fewer work items than wave slots: the round costs one extension's latency whatever it holds
-					// at most lastWork/2 reads are still active, so this keeps the round within the work arrays (8 per read) and the trace budget (4 seeds' worth per read)
-					if (round > 0 && lastWork > 0) maxCand = (uint32_t)std::min<uint64_t>(maxCand, std::max<uint64_t>(1, (8 * nG) / lastWork));
-					if (const char* env = getenv("GC_LONG_SPECULATE")) maxCand = (uint32_t)std::min(2, std::max(1, atoi(env)));   // test hook: speculate from round 0
-					launchLongSelect(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, R->totalBases, (uint32_t)P->min_cluster_size, maxCand, dLongState + r0, dLongAlns, dLongCells, dLongWork + w0, dWorkLen + w0, dCandSeed + w0, cursor, capacity);
-					{
-						// execution order: longest extensions first, so the round's tail is made of short ones (GC_LONG_ORDER=0: as emitted)
-						const char* mode = getenv("GC_LONG_ORDER");
-						launchLongOrder(q, dWorkLen + w0, cursor, dOrder + w0, (uint32_t)maxReadLen, mode ? (uint32_t)atoi(mode) : 1u);
-					}
-					launchPublish(q, cursor, (unsigned long long*)hCursor, 2);
-					const double tWait0 = nowUs();
-					if (roundLock.owns_lock()) { syncEvent(roundExtendDone); roundLock.unlock(); }   // the previous round's extension kernel has finished: the merge and this round's set-up need no token
-					syncStream(q);
-					dbgWaitUs += nowUs() - tWait0;
-					uint32_t nWorkItems = (uint32_t)hCursor[0];
-					if (nWorkItems == 0) break;
-					if (roundToken && nGroups == 1) {
-						roundLock.lock();
-						if (shareLongScratch) dLongScratch = g_longScratch[deviceNow & 15].buffer.reserve<unsigned long long>(longScratchWords);
-					}
-					uint32_t team = longExtendTeamSize(nWorkItems);
-					uint32_t blocks = std::min<uint32_t>((nWorkItems + team - 1) / team, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / team));
-					if (const char* env = getenv("GC_LONG_MAX_BLOCKS")) blocks = std::min<uint32_t>(blocks, (uint32_t)std::max(1, atoi(env)));   // test hook: force persistent waves
-					if (timedRounds >= LONG_EVENT_RING) collect(timedRounds % LONG_EVENT_RING);
-					hipEvent_t ev0 = ring[2 * (timedRounds % LONG_EVENT_RING)], ev1 = ring[2 * (timedRounds % LONG_EVENT_RING) + 1];
-					HIP_CHECK(hipEventRecord(ev0, q));
-					// GC_LONG_SM=1 (experiment, off by default: 6x slower as measured): one extension per LANE as per-lane state machines (k_long_extend_sm, gc_sm.hip);
-					// what outgrows that layout's tables (EXT_SM_DECLINED: more than 32 nodes in a slice, 16 pending, no room for the reserved trace)
-					// is listed and rerun one extension per wave, like the register-table overflows below
-					const bool useSm = team == 1 && getenv("GC_LONG_SM") && atoi(getenv("GC_LONG_SM")) == 1;
-					if (useSm) {
-						launchLongExtendSm(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, (uint8_t*)(dLongScratch + (uint64_t)g * scratchLanes * waveWords), scratchLanes * waveWords * 8,
-							dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2);
-						launchZeroWords(q, cursor + 2, 2);   // [2] next slot, [3] length of the list
-						launchLongRetryList(q, dLongWorkResults + w0, nWorkItems, 6u /* EXT_SM_DECLINED */, dRetryList + w0, cursor + 3);
-						const uint32_t declinedBlocks = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nWorkItems, 8192), std::max<uint64_t>(1, scratchLanes - 64));
-						launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dRetryList + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 1, declinedBlocks,
-							dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, 6u, cursor + 3);
-					} else
-					launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, team, blocks,
-						dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, 0, nullptr, team == 1 ? dRetryList + w0 : nullptr, cursor + 3);
-					if (team == 1) {
-						// extensions whose band outgrew the 64-entry register tables: second try with the LDS/HBM tables (two lanes per wave,
-						// 28 + 228 entries); waves whose items are fine leave at once. Beyond that the read goes to the plain-layout fallback.
-						// (those items are listed first - almost always none - so that the retry is a handful of waves that fetch from the list, not
-						// one wave per pair of work items that looks at a status and leaves: that cost 0.5-2 ms of every round)
-						if (useSm || (uint64_t)blocks * team < nWorkItems) {   // (the list is the extension kernel's own, unless the state-machine path or persistent waves used the slot counter)
-							launchZeroWords(q, cursor + 2, useSm ? 2 : 1);   // [2] next slot, [3] length of the retry list
-							if (useSm) launchLongRetryList(q, dLongWorkResults + w0, nWorkItems, EXT_LDS_CAP, dRetryList + w0, cursor + 3);
-						}
-						uint32_t retryBlocks = std::min<uint32_t>(16, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / 2));   // (persistent waves over a list that is almost always empty)
-						launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dRetryList + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 2, retryBlocks,
-							dRoundTrace + groupTraceBeginPtr[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, EXT_LDS_CAP, cursor + 3);
-					}
-					HIP_CHECK(hipEventRecord(ev1, q));
-					roundExtendDone = ev1;
-					launchLongMerge(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, dCandSeed + w0, dLongWorkResults + w0, dRoundTrace + groupTraceBeginPtr[g], maxAlignments, dLongState + r0, dLongAlns, dLongCells, dLongCursor, cellBudget);
-					lastWork = nWorkItems;
-					// no wait here: the next round's select / order / publish queue up right behind the merge, and the only host round trip per
-					// round is the work count above (with a second wait after the merge the stream drained twice per round, and each refill
-					// waited behind whatever other batches had queued on the device)
-					timedRounds++;
-					groupRoundsPtr[g]++;
-				}
-				// the per-read results go straight into pinned host memory (the kernel writes them across PCIe): a copy-engine transfer here queued behind
-				// the other batch's bulk downloads for 30-50 ms while this pass still held the device's whole-read token
-				launchLongFinish(q, (uint32_t)nG, dLongState + r0, hLongResults + r0);
-				const double dbgT1 = nowUs();
-				syncStream(q);
-				if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] whole-read rounds: %.1f ms in all, %.1f ms waiting for the rounds' work counts, %.1f ms in the last wait, %d rounds\n", (nowUs() - dbgT0) / 1e3, dbgWaitUs / 1e3, (nowUs() - dbgT1) / 1e3, timedRounds);
-				for (int k = std::max(0, timedRounds - LONG_EVENT_RING); k < timedRounds; k++) collect(k % LONG_EVENT_RING);
-			};
 			longGroups = nGroups;
-			finishLongGroups = [=]() {   // after the group threads joined (vectors above are alive until the end of this call)
-				double us = 0; uint32_t rounds = 0;
-				for (uint32_t g = 0; g < nGroups; g++) { us += groupExtendUsPtr[g]; rounds = std::max(rounds, groupRoundsPtr[g]); }
-				res->kernel_us[4] = us;
-				res->counters_long[6] = rounds;
-			};
 			// reads whose band did not fit the LDS tables (status 5) are rerun with the plain-layout kernel
-			longFallback = [=]() {
-				syncStream(ls);
-				std::vector<uint32_t> redo;
-				const bool forceAll = getenv("GC_LONG_FORCE_FALLBACK") != nullptr;   // test hook: run every read through the plain-layout kernel too
-				// status 5: a slice with more nodes than the wave tables hold; status 2: an extension with more tiles / trace cells than its scratch
-				// (the plain-layout kernel below gets four times the room)
-				for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status == 5 || hLongResults[r].status == 2 || forceAll) redo.push_back((uint32_t)r);
-				if (!redo.empty()) {
-					std::vector<LongJob> subJobs(redo.size());
-					for (size_t i = 0; i < redo.size(); i++) subJobs[i] = hJobs[redo[i]];
-					ExtendConfig fcfg = lcfg;
-					fcfg.maxItems = 4 * lcfg.maxItems; fcfg.maxTrace = 2 * lcfg.maxTrace; fcfg.maxPending = 4 * lcfg.maxPending;
-					uint64_t lslab = longSlabBytes(fcfg);
-					uint64_t lanes = (redo.size() + 63) / 64 * 64;
-					LongJob* dSubJobs = st->longJobsFallback.reserve<LongJob>(redo.size());
-					LongReadResult* dSubResults = st->longResultsFallback.reserve<LongReadResult>(redo.size());
-					uint8_t* dSlab = st->longScratchFallback.reserve<uint8_t>(lanes * lslab);
-					HIP_CHECK(hipMemcpyAsync(dSubJobs, subJobs.data(), redo.size() * sizeof(LongJob), hipMemcpyHostToDevice, ls));
-					launchLongPass(ls, G->dev, G->devTables, G->devIupac, fcfg, dSubJobs, (uint32_t)redo.size(), dLongSeeds, R->devBases, R->totalBases, (uint32_t)P->min_cluster_size, maxAlignments,
-						dSlab, lslab, dLongCells, dLongCursor, cellBudget, dLongAlns, dSubResults, dLongCursor + 8);
-					std::vector<LongReadResult> subResults(redo.size());
-					HIP_CHECK(hipMemcpyAsync(subResults.data(), dSubResults, redo.size() * sizeof(LongReadResult), hipMemcpyDeviceToHost, ls));
-					syncStream(ls);
-					for (size_t i = 0; i < redo.size(); i++) hLongResults[redo[i]] = subResults[i];
-				}
-				if (n) HIP_CHECK(hipMemcpyAsync(hLongAlns, dLongAlns, n * maxAlignments * sizeof(LongAln), hipMemcpyDeviceToHost, ls));
-				HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
-				syncStream(ls);
-				return (uint64_t)redo.size();
-			};
 		}
 		// What follows the rounds: fallback reruns, the reference's `cont` rule, selection and the NW distance of the best whole-read alignment.
 		// With one read group it runs on the pass's own thread right after the rounds, beside the tail of the fragment pipeline (which ends
@@ -1961,6 +1818,171 @@ struct BatchRun {
 		longPostInThread = P->long_pass && longGroups == 1;
 		// The whole-read pass is the longest leg of the batch: its round loop runs on its own host thread and stream from
 		// here on, while this thread prepares and runs the fragment pipeline.
+	}
+
+	uint64_t cellBudgetFor(uint64_t perBase) const { uint64_t b = 0; for (uint64_t r = 0; r < n; r++) b += perBase * (R->offsets[r + 1] - R->offsets[r]) + 1024; return b; }   // the merged-trace cell pool: cells per read base + slack per read
+
+	bool growLongCells()   // whole-read pass thread: the cell pool was too small -> enlarge it, reset the pass's cursors; false when it cannot grow
+	{
+		bool overflowed = false;
+		for (uint64_t r = 0; r < n && !overflowed; r++) overflowed = hLongResults[r].status == 4;
+		if (!overflowed || cellPoolPinned) return false;   // (a pinned pool flags the reads instead: the caller asked for that much and no more)
+		const uint64_t next = st->longCellsPerBase * 3;
+		if (next > 256 || cellBudgetFor(next) * sizeof(LongCell) > (64ull << 30)) return false;
+		st->longCellsPerBase = next;
+		cellBudget = cellBudgetFor(next);
+		dLongCells = st->longCells.reserve<LongCell>(cellBudget);
+		HIP_CHECK(hipMemsetAsync(dLongCursor, 0, cursorWords * sizeof(unsigned long long), ls));
+		syncStream(ls);
+		return true;
+	}
+
+	void runLongGroup(uint32_t g)   // the round loop of one read group: select -> extend -> merge until no read has a seed left to extend (see gc_kernels.hip, "K3-long in rounds")
+	{
+		const uint64_t r0 = groupBegin[g], nG = groupBegin[g + 1] - r0;
+		if (nG == 0) return;
+		unsigned long long* dLongScratch = shareLongScratch ? longScratchOfToken : dLongScratchOwn;   // (round token: set under the lock, every round)
+		hipStream_t q = st->groupStreams[g];
+		hipEvent_t* ring = st->groupEvents.data() + (size_t)2 * LONG_EVENT_RING * g;
+		// the rounds' extension time: read a ring slot's pair before the slot is reused (its round is complete by then: every round's
+		// work count has been awaited since) and what is left after the last round
+		auto collect = [&](int slot) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ring[2 * slot], ring[2 * slot + 1])); groupExtendUs[g] += (double)ms * 1000.0; };
+		int timedRounds = 0;
+		const uint64_t w0 = 8 * r0 + 64ull * g, capacity = 8 * nG + 64;   // this group's slice of the work arrays
+		unsigned long long* cursor = dLongCursor + 32 + 8 * g;
+		volatile unsigned long long* hCursor = hLongSmall + 32 + 8 * g;
+		const uint64_t traceBudget = groupTraceBegin[g + 1] - groupTraceBegin[g];
+		double dbgWaitUs = 0;
+		const double dbgT0 = nowUs();
+		launchLongInit(q, dLongJobs + r0, (uint32_t)nG, dLongState + r0);
+		uint32_t lastWork = 0xffffffffu;
+		// GC_LONG_TOKEN=2: the token (and with it the device's extension scratch) is held per round - from the moment a round's extension kernel is queued until
+		// that kernel has finished - so that the small kernels and the host round trip between two rounds of one batch run beside another batch's extension kernel
+		int deviceNow = 0;
+		HIP_CHECK(hipGetDevice(&deviceNow));
+		const bool roundToken = getenv("GC_LONG_TOKEN") && atoi(getenv("GC_LONG_TOKEN")) == 2;   // (read per batch: the tests switch modes inside one process)
+		std::unique_lock<std::mutex> roundLock(g_longPassToken[deviceNow & 15], std::defer_lock);
+		hipEvent_t roundExtendDone = nullptr;
+
+		for (int round = 0; round < 4096; round++) {
+			launchZeroWords(q, cursor, 4);   // [0] work count, [1] round trace cursor, [2] next work slot, [3] length of the retry list
+			// tail rounds: once fewer than a quarter of the reads are still active the chip is mostly idle, so the
+			// remaining reads try several seeds per round (exact: k_long_merge re-checks them in order)
+			// (the number of work items stays below what round 0 had: active reads x candidates <= n)
+			uint32_t maxCand = 1;
+			if (round > 0 && lastWork > 0) maxCand = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (2 * nG) / lastWork));
+			if (round > 0 && lastWork < 8192) maxCand = 8;   // fewer work items than wave slots: the round costs one extension's latency whatever it holds
+			// at most lastWork/2 reads are still active, so this keeps the round within the work arrays (8 per read) and the trace budget (4 seeds' worth per read)
+			if (round > 0 && lastWork > 0) maxCand = (uint32_t)std::min<uint64_t>(maxCand, std::max<uint64_t>(1, (8 * nG) / lastWork));
+			if (const char* env = getenv("GC_LONG_SPECULATE")) maxCand = (uint32_t)std::min(2, std::max(1, atoi(env)));   // test hook: speculate from round 0
+			launchLongSelect(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, R->totalBases, (uint32_t)P->min_cluster_size, maxCand, dLongState + r0, dLongAlns, dLongCells, dLongWork + w0, dWorkLen + w0, dCandSeed + w0, cursor, capacity);
+			{
+				// execution order: longest extensions first, so the round's tail is made of short ones (GC_LONG_ORDER=0: as emitted)
+				const char* mode = getenv("GC_LONG_ORDER");
+				launchLongOrder(q, dWorkLen + w0, cursor, dOrder + w0, (uint32_t)maxReadLen, mode ? (uint32_t)atoi(mode) : 1u);
+			}
+			launchPublish(q, cursor, (unsigned long long*)hCursor, 2);
+			const double tWait0 = nowUs();
+			if (roundLock.owns_lock()) { syncEvent(roundExtendDone); roundLock.unlock(); }   // the previous round's extension kernel has finished: the merge and this round's set-up need no token
+			syncStream(q);
+			dbgWaitUs += nowUs() - tWait0;
+			uint32_t nWorkItems = (uint32_t)hCursor[0];
+			if (nWorkItems == 0) break;
+			if (roundToken && nGroups == 1) {
+				roundLock.lock();
+				if (shareLongScratch) dLongScratch = g_longScratch[deviceNow & 15].buffer.reserve<unsigned long long>(longScratchWords);
+			}
+			uint32_t team = longExtendTeamSize(nWorkItems);
+			uint32_t blocks = std::min<uint32_t>((nWorkItems + team - 1) / team, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / team));
+			if (const char* env = getenv("GC_LONG_MAX_BLOCKS")) blocks = std::min<uint32_t>(blocks, (uint32_t)std::max(1, atoi(env)));   // test hook: force persistent waves
+			if (timedRounds >= LONG_EVENT_RING) collect(timedRounds % LONG_EVENT_RING);
+			hipEvent_t ev0 = ring[2 * (timedRounds % LONG_EVENT_RING)], ev1 = ring[2 * (timedRounds % LONG_EVENT_RING) + 1];
+			HIP_CHECK(hipEventRecord(ev0, q));
+			// GC_LONG_SM=1 (experiment, off by default: 6x slower as measured): one extension per LANE as per-lane state machines (k_long_extend_sm, gc_sm.hip);
+			// what outgrows that layout's tables (EXT_SM_DECLINED: more than 32 nodes in a slice, 16 pending, no room for the reserved trace)
+			// is listed and rerun one extension per wave, like the register-table overflows below
+			const bool useSm = team == 1 && getenv("GC_LONG_SM") && atoi(getenv("GC_LONG_SM")) == 1;
+			if (useSm) {
+				launchLongExtendSm(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, (uint8_t*)(dLongScratch + (uint64_t)g * scratchLanes * waveWords), scratchLanes * waveWords * 8,
+					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2);
+				launchZeroWords(q, cursor + 2, 2);   // [2] next slot, [3] length of the list
+				launchLongRetryList(q, dLongWorkResults + w0, nWorkItems, 6u /* EXT_SM_DECLINED */, dRetryList + w0, cursor + 3);
+				const uint32_t declinedBlocks = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nWorkItems, 8192), std::max<uint64_t>(1, scratchLanes - 64));
+				launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dRetryList + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 1, declinedBlocks,
+					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, 6u, cursor + 3);
+			} else
+			launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, team, blocks,
+				dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, 0, nullptr, team == 1 ? dRetryList + w0 : nullptr, cursor + 3);
+			if (team == 1) {
+				// extensions whose band outgrew the 64-entry register tables: second try with the LDS/HBM tables (two lanes per wave,
+				// 28 + 228 entries); waves whose items are fine leave at once. Beyond that the read goes to the plain-layout fallback.
+				// (those items are listed first - almost always none - so that the retry is a handful of waves that fetch from the list, not
+				// one wave per pair of work items that looks at a status and leaves: that cost 0.5-2 ms of every round)
+				if (useSm || (uint64_t)blocks * team < nWorkItems) {   // (the list is the extension kernel's own, unless the state-machine path or persistent waves used the slot counter)
+					launchZeroWords(q, cursor + 2, useSm ? 2 : 1);   // [2] next slot, [3] length of the retry list
+					if (useSm) launchLongRetryList(q, dLongWorkResults + w0, nWorkItems, EXT_LDS_CAP, dRetryList + w0, cursor + 3);
+				}
+				uint32_t retryBlocks = std::min<uint32_t>(16, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / 2));   // (persistent waves over a list that is almost always empty)
+				launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dRetryList + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 2, retryBlocks,
+					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, EXT_LDS_CAP, cursor + 3);
+			}
+			HIP_CHECK(hipEventRecord(ev1, q));
+			roundExtendDone = ev1;
+			launchLongMerge(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, dCandSeed + w0, dLongWorkResults + w0, dRoundTrace + groupTraceBegin[g], maxAlignments, dLongState + r0, dLongAlns, dLongCells, dLongCursor, cellBudget);
+			lastWork = nWorkItems;
+			// no wait here: the next round's select / order / publish queue up right behind the merge, and the only host round trip per
+			// round is the work count above (with a second wait after the merge the stream drained twice per round, and each refill
+			// waited behind whatever other batches had queued on the device)
+			timedRounds++;
+			groupRounds[g]++;
+		}
+		// the per-read results go straight into pinned host memory (the kernel writes them across PCIe): a copy-engine transfer here queued behind
+		// the other batch's bulk downloads for 30-50 ms while this pass still held the device's whole-read token
+		launchLongFinish(q, (uint32_t)nG, dLongState + r0, hLongResults + r0);
+		const double dbgT1 = nowUs();
+		syncStream(q);
+		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] whole-read rounds: %.1f ms in all, %.1f ms waiting for the rounds' work counts, %.1f ms in the last wait, %d rounds\n", (nowUs() - dbgT0) / 1e3, dbgWaitUs / 1e3, (nowUs() - dbgT1) / 1e3, timedRounds);
+		for (int k = std::max(0, timedRounds - LONG_EVENT_RING); k < timedRounds; k++) collect(k % LONG_EVENT_RING);
+	}
+
+	void finishLongGroups()   // after the group threads joined
+	{
+		double us = 0; uint32_t rounds = 0;
+		for (uint32_t g = 0; g < nGroups; g++) { us += groupExtendUs[g]; rounds = std::max(rounds, groupRounds[g]); }
+		res->kernel_us[4] = us;
+		res->counters_long[6] = rounds;
+	}
+
+	uint64_t longFallback()   // reads whose band did not fit the wave layout's tables are rerun with the plain-layout kernel; returns how many
+	{
+		syncStream(ls);
+		std::vector<uint32_t> redo;
+		const bool forceAll = getenv("GC_LONG_FORCE_FALLBACK") != nullptr;   // test hook: run every read through the plain-layout kernel too
+		// status 5: a slice with more nodes than the wave tables hold; status 2: an extension with more tiles / trace cells than its scratch
+		// (the plain-layout kernel below gets four times the room)
+		for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status == 5 || hLongResults[r].status == 2 || forceAll) redo.push_back((uint32_t)r);
+		if (!redo.empty()) {
+			std::vector<LongJob> subJobs(redo.size());
+			for (size_t i = 0; i < redo.size(); i++) subJobs[i] = hJobs[redo[i]];
+			ExtendConfig fcfg = lcfg;
+			fcfg.maxItems = 4 * lcfg.maxItems; fcfg.maxTrace = 2 * lcfg.maxTrace; fcfg.maxPending = 4 * lcfg.maxPending;
+			uint64_t lslab = longSlabBytes(fcfg);
+			uint64_t lanes = (redo.size() + 63) / 64 * 64;
+			LongJob* dSubJobs = st->longJobsFallback.reserve<LongJob>(redo.size());
+			LongReadResult* dSubResults = st->longResultsFallback.reserve<LongReadResult>(redo.size());
+			uint8_t* dSlab = st->longScratchFallback.reserve<uint8_t>(lanes * lslab);
+			HIP_CHECK(hipMemcpyAsync(dSubJobs, subJobs.data(), redo.size() * sizeof(LongJob), hipMemcpyHostToDevice, ls));
+			launchLongPass(ls, G->dev, G->devTables, G->devIupac, fcfg, dSubJobs, (uint32_t)redo.size(), dLongSeeds, R->devBases, R->totalBases, (uint32_t)P->min_cluster_size, maxAlignments,
+				dSlab, lslab, dLongCells, dLongCursor, cellBudget, dLongAlns, dSubResults, dLongCursor + 8);
+			std::vector<LongReadResult> subResults(redo.size());
+			HIP_CHECK(hipMemcpyAsync(subResults.data(), dSubResults, redo.size() * sizeof(LongReadResult), hipMemcpyDeviceToHost, ls));
+			syncStream(ls);
+			for (size_t i = 0; i < redo.size(); i++) hLongResults[redo[i]] = subResults[i];
+		}
+		if (n) HIP_CHECK(hipMemcpyAsync(hLongAlns, dLongAlns, n * maxAlignments * sizeof(LongAln), hipMemcpyDeviceToHost, ls));
+		HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
+		syncStream(ls);
+		return (uint64_t)redo.size();
 	}
 
 	// selection of a subset of reads' whole-read alignments and the NW distance of the best one (src/Aligner.cpp:636-654): launch ...
@@ -2124,7 +2146,7 @@ struct BatchRun {
 						if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc token] stream %p asked %.1f got %.1f (call began %.1f)\n", (void*)st, tTokenAsk / 1e3, nowUs() / 1e3, tCall / 1e3);
 						{ double now = nowUs(), seen = longWallBeginUs.load(); while ((seen == 0.0 || now < seen) && !longWallBeginUs.compare_exchange_weak(seen, now)) {} }
 						runLongGroup(g);
-						while (longGroups == 1 && growLongCells && growLongCells()) runLongGroup(g);   // the cell pool overflowed: again, with room
+						while (longGroups == 1 && growLongCells()) runLongGroup(g);   // the cell pool overflowed: again, with room
 						{ double now = nowUs(), seen = longWallEndUs.load(); while (now > seen && !longWallEndUs.compare_exchange_weak(seen, now)) {} }
 						if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc token] stream %p released %.1f\n", (void*)st, nowUs() / 1e3);
 						if (token.owns_lock()) token.unlock();   // the next batch's pass may start; what follows is this batch's own tail
