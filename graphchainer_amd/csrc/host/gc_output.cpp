@@ -35,7 +35,16 @@ inline unsigned baseSet(char c)
 
 enum class Edit { Match, Mismatch, MatchOrMismatch, Insertion, Deletion, Empty };
 
-inline void addCigarItem(std::ostringstream& str, uint64_t length, Edit type)
+// decimal digits of v appended to out (what `stream << v` writes for an unsigned integer; a CIGAR of a 10 kb read has ~2 000 runs and a stream insertion costs ~20x this)
+inline void appendUint(std::string& out, uint64_t v)
+{
+	char buf[24];
+	int at = 24;
+	do { buf[--at] = (char)('0' + v % 10); v /= 10; } while (v);
+	out.append(buf + at, buf + 24);
+}
+
+inline void addCigarItem(std::string& str, uint64_t length, Edit type)
 {
 	if (length == 0) return;
 	char op = 0;
@@ -47,8 +56,8 @@ inline void addCigarItem(std::ostringstream& str, uint64_t length, Edit type)
 		case Edit::Deletion: op = 'D'; break;
 		case Edit::Empty: break;
 	}
-	str << length;            // (the reference writes the length first and then returns without an op for Empty)
-	if (op) str << op;
+	appendUint(str, length);  // (the reference writes the length first and then returns without an op for Empty)
+	if (op) str += op;
 }
 
 } // namespace
@@ -67,11 +76,12 @@ std::string formatGafLine(const AlignmentGraph& graph, const std::string& readNa
 	auto graphChar = [&](uint64_t i) { return letters.at(trace.node[i], trace.offset[i]); };
 	auto readChar = [&](uint64_t i) { return trace.seqPos[i] < readLength ? sequence[trace.seqPos[i]] : '-'; };
 	auto originalSize = [&](int nodeId) { return graph.originalNodeSize.at(nodeId); };
-	std::ostringstream cigar, nodePath;
+	std::string cigar, nodePath;
+	cigar.reserve(trace.size / 4 + 16);
 	auto addNode = [&](int nodeId) {
-		nodePath << ((nodeId % 2) == 1 ? "<" : ">");
+		nodePath += (nodeId % 2) == 1 ? '<' : '>';
 		std::string name = graph.OriginalNodeName(nodeId);
-		if (name.empty()) nodePath << nodeId / 2; else nodePath << name;
+		if (name.empty()) { if (nodeId < 0) { nodePath += '-'; appendUint(nodePath, (uint64_t)(-(int64_t)(nodeId / 2))); } else appendUint(nodePath, (uint64_t)(nodeId / 2)); } else nodePath += name;
 	};
 	const uint64_t readStart = trace.seqPos[0], readEnd = (uint64_t)trace.seqPos[trace.size - 1] + 1;
 	uint64_t nodePathLen = 0, matches = 0, mismatches = 0, deletions = 0, insertions = 0, editLength = 1;
@@ -115,12 +125,12 @@ std::string formatGafLine(const AlignmentGraph& graph, const std::string& readNa
 	const uint64_t nodePathEnd = nodePathLen - (originalSize(trace.node[trace.size - 1]) - 1 - trace.offset[trace.size - 1]);
 	const uint64_t all = matches + mismatches + deletions + insertions;
 	std::ostringstream out;
-	out << readName << "\t" << readLength << "\t" << readStart << "\t" << readEnd << "\t" << "+" << "\t" << nodePath.str() << "\t" << nodePathLen << "\t" << nodePathStart << "\t" << nodePathEnd
+	out << readName << "\t" << readLength << "\t" << readStart << "\t" << readEnd << "\t" << "+" << "\t" << nodePath << "\t" << nodePathLen << "\t" << nodePathStart << "\t" << nodePathEnd
 		<< "\t" << matches << "\t" << trace.size << "\t" << 255;
 	out << "\t" << "NM:i:" << (mismatches + deletions + insertions);
 	out << "\t" << "dv:f:" << 1.0 - ((double)matches / (double)all);
 	out << "\t" << "id:f:" << ((double)matches / (double)all);
-	out << "\t" << "cg:Z:" << cigar.str();
+	out << "\t" << "cg:Z:" << cigar;
 	return out.str();
 }
 
