@@ -686,7 +686,13 @@ static void launchEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 		uint32_t unit = editDistanceUnit(hPairs[i].k, len), c = 0;
 		while ((1u << c) < unit) c++;
 		c++;                                                                  // classes 1..5: one pair per wave, units of 1..16 blocks
-		if (halfWaves && unit == 1 && hPairs[i].k < editDistanceMaxK(0) && len <= 131072) c = 0;   // class 0: two pairs per wave (small first band)
+		if (halfWaves && unit == 1 && hPairs[i].k < editDistanceMaxK(0) && len <= 131072) {   // class 0: two pairs per wave (small first band)
+			c = 0;
+			// a sweep of that kernel takes columns + units steps whatever the band, as long as the band fits its 32 lanes - so the first guess may as well be the widest band that
+			// does (any k >= the distance gives the distance): a chain pair whose guess (length difference + 14 %) was a little short used to pay a failed sweep here, a second
+			// failed sweep with the same guess in the one-pair-per-wave kernel and a third with the doubled band (r3)
+			hPairs[i].k = std::max(hPairs[i].k, editDistanceMaxK(0) - 1);
+		}
 		cls[i] = c;
 		count[c]++;
 	}
@@ -724,7 +730,9 @@ static void finishEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 	for (uint32_t unit = 1; unit <= 16 && !todo.empty(); unit *= 2) {   // (unit 1 again for what the two-pairs-per-wave kernel handed back)
 		sub.resize(todo.size());
 		subOut.resize(todo.size());
-		for (size_t i = 0; i < todo.size(); i++) sub[i] = hPairs[todo[i]];
+		// (what reaches unit U has failed every band below it: the two-pairs-per-wave kernel's limit for U = 1, the limit of unit U / 2 otherwise - start there, not at the first guess)
+		const uint32_t failedBelow = unit == 1 ? editDistanceMaxK(0) : editDistanceMaxK(unit / 2);
+		for (size_t i = 0; i < todo.size(); i++) { sub[i] = hPairs[todo[i]]; sub[i].k = std::max(sub[i].k, failedBelow); }
 		HIP_CHECK(hipMemcpyAsync(dPairs, sub.data(), sub.size() * sizeof(EdPair), hipMemcpyHostToDevice, stream));
 		launchEditDistance(stream, unit, dPairs, (uint32_t)sub.size(), dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut);
 		HIP_CHECK(hipMemcpyAsync(subOut.data(), dOut, sub.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
