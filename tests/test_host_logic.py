@@ -160,6 +160,46 @@ def test_encoder_letter_cursor_equals_the_graph_lookups(tmp_path):
         assert out.returncode == 0 and out.stdout.startswith("OK"), (gfa, out.stdout + out.stderr)
 
 
+def test_gaf_encoder_equals_oracle_encoder_on_the_cpu(tmp_path):
+    """The product's GAF encoder (gc::formatGafLine, csrc/host/gc_output.cpp: the reference's GraphAlignerGAFAlignment::traceToAlignment, src/GraphAlignerGAFAlignment.h:38-196) is
+    host code: tests/output_host/gaf_test.cpp runs it on the CPU over the oracle's whole-read alignments (their traces are what gc_align_batch returns, array for array, in the GPU
+    tests) and the text must equal the oracle's own encoder's - both CIGAR styles. (JSON and GAM share its trace walk through buildVgAlignment; their bytes are compared in the GPU tests.)"""
+    from oracle import Oracle
+    exe = tmp_path / "gaf_test"
+    host = os.path.join(ROOT, "graphchainer_amd", "csrc", "host")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-I" + host, os.path.join(ROOT, "tests", "output_host", "gaf_test.cpp"), os.path.join(host, "gc_output.cpp"), os.path.join(host, "gc_graph.cpp"),
+                    "-o", str(exe), "-lpthread", "-lz"], check=True, timeout=600)
+    gold = os.path.join(ROOT, "tests", "golden")
+    gfa = os.path.join(gold, "syn20k.gfa")
+    reads = [l.strip() for l in open(os.path.join(gold, "syn20k.fa")) if not l.startswith(">")]
+    oracle = Oracle(gfa, long_pass=True)
+    w = oracle.align(reads)
+    for merge in (0, 1):
+        dump, expected_reads = [], 0
+        for r, read in enumerate(reads):
+            all_lo, all_hi = int(w["read_longall_off"][r]), int(w["read_longall_off"][r + 1])
+            picked = []
+            for k in range(int(w["read_long_off"][r]), int(w["read_long_off"][r + 1])):      # the selected alignments, found again in the read's full list
+                key = (int(w["long_start"][k]), int(w["long_end"][k]), int(w["long_score"][k]))
+                match = [a for a in range(all_lo, all_hi) if (int(w["longall_start"][a]), int(w["longall_end"][a]), int(w["longall_score"][a])) == key and a not in picked]
+                assert match, (r, key)
+                picked.append(match[0])
+            if int(w["chained_better"][r]):
+                continue                                                                      # (the chained alignment replaces them in the output; none on this fixture)
+            picked.sort(key=lambda a: int(w["longall_start"][a]))                             # src/Aligner.cpp:1003,1023
+            expected_reads += bool(picked)
+            for a in picked:
+                t0, t1 = int(w["long_trace_off"][a]), int(w["long_trace_off"][a + 1])
+                rows = " ".join(f"{int(w['long_trace_node'][i])} {int(w['long_trace_offset'][i])} {int(w['long_trace_seqpos'][i])} {int(w['long_trace_switch'][i])}" for i in range(t0, t1))
+                dump.append(f"r{r} {merge} {t1 - t0} {read}\n{rows}\n")
+        path = tmp_path / f"alignments{merge}.txt"
+        path.write_text("".join(dump))
+        out = subprocess.run([str(exe), gfa, str(path)], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr
+        want = oracle.gaf(merge=bool(merge)).decode()
+        assert expected_reads >= 5 and out.stdout == want, (merge, out.stdout[:200], want[:200])
+
+
 def test_state_machine_extension_core_equals_oracle(tmp_path):
     """The per-lane state machine of the experimental kernel k_long_extend_sm (graphchainer_amd/csrc/hip/gc_sm_core.hpp) is plain C++:
     tests/sm_host/sm_host_test.cpp compiles its phase functions with g++, drives ONE lane on the CPU and compares status, score and every trace
