@@ -160,7 +160,7 @@ def test_encoder_letter_cursor_equals_the_graph_lookups(tmp_path):
         assert out.returncode == 0 and out.stdout.startswith("OK"), (gfa, out.stdout + out.stderr)
 
 
-def test_gaf_encoder_equals_oracle_encoder_on_the_cpu(tmp_path):
+def test_gaf_and_json_encoders_equal_the_oracle_encoders_on_the_cpu(tmp_path):
     """The product's GAF encoder (gc::formatGafLine, csrc/host/gc_output.cpp: the reference's GraphAlignerGAFAlignment::traceToAlignment, src/GraphAlignerGAFAlignment.h:38-196) is
     host code: tests/output_host/gaf_test.cpp runs it on the CPU over the oracle's whole-read alignments (their traces are what gc_align_batch returns, array for array, in the GPU
     tests) and the text must equal the oracle's own encoder's - both CIGAR styles. (JSON and GAM share its trace walk through buildVgAlignment; their bytes are compared in the GPU tests.)"""
@@ -174,7 +174,7 @@ def test_gaf_encoder_equals_oracle_encoder_on_the_cpu(tmp_path):
     reads = [l.strip() for l in open(os.path.join(gold, "syn20k.fa")) if not l.startswith(">")]
     oracle = Oracle(gfa, long_pass=True)
     w = oracle.align(reads)
-    for merge in (0, 1):
+    for merge in (0, 1, 2):
         dump, expected_reads = [], 0
         for r, read in enumerate(reads):
             all_lo, all_hi = int(w["read_longall_off"][r]), int(w["read_longall_off"][r + 1])
@@ -191,12 +191,12 @@ def test_gaf_encoder_equals_oracle_encoder_on_the_cpu(tmp_path):
             for a in picked:
                 t0, t1 = int(w["long_trace_off"][a]), int(w["long_trace_off"][a + 1])
                 rows = " ".join(f"{int(w['long_trace_node'][i])} {int(w['long_trace_offset'][i])} {int(w['long_trace_seqpos'][i])} {int(w['long_trace_switch'][i])}" for i in range(t0, t1))
-                dump.append(f"r{r} {merge} {t1 - t0} {read}\n{rows}\n")
+                dump.append(f"r{r} {merge} {t1 - t0} {int(w['longall_score'][a])} {int(w['longall_start'][a])} {int(w['longall_end'][a])} {read}\n{rows}\n")
         path = tmp_path / f"alignments{merge}.txt"
         path.write_text("".join(dump))
         out = subprocess.run([str(exe), gfa, str(path)], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr
-        want = oracle.gaf(merge=bool(merge)).decode()
+        want = oracle.json().decode() if merge == 2 else oracle.gaf(merge=bool(merge)).decode()
         assert expected_reads >= 5 and out.stdout == want, (merge, out.stdout[:200], want[:200])
 
 
