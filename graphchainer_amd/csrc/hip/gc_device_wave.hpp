@@ -45,6 +45,9 @@ namespace gcdev {
 #ifndef GC_LEAN_MERGE
 #define GC_LEAN_MERGE 1
 #endif
+#ifndef GC_LEAN_POP
+#define GC_LEAN_POP 1   // the pop of the pending queue as a wave minimum over the lanes' component numbers (r3)
+#endif
 #ifndef GC_LEAN_KINDS
 #define GC_LEAN_KINDS 1   // three copies of the column loop: general / node in the previous slice with nothing forced / node new in this slice (constant carries)
 #endif
@@ -191,6 +194,31 @@ struct LaneLdsT {   // one lane's view
 	__device__ __forceinline__ void qSet(uint32_t e, uint32_t node, uint32_t comp, const WS& x) const { set(2u, e, Entry { node, comp, (uint32_t)x.score, x.VP, x.VN }); }
 	__device__ __forceinline__ void qSetWs(uint32_t e, const WS& x) const { Entry old = get(2u, e); set(2u, e, Entry { old.w0, old.w1, (uint32_t)x.score, x.VP, x.VN }); }
 	__device__ __forceinline__ void qMove(uint32_t dst, uint32_t src) const { set(2u, dst, get(2u, src)); }
+	// the pending entry with the smallest componentNumber (the reference's priority queue pops by it, src/ComponentPriorityQueue.h; the first of equals, as the scalar scan picks)
+	__device__ __forceinline__ uint32_t qArgMin(uint32_t n) const
+	{
+#if GC_LEAN_POP && defined(__HIP_DEVICE_COMPILE__)
+		if (REGCOLS) {
+			// entry e sits in lane e: a wave minimum by DPP and one ballot instead of a scalar loop of readlane / compare / select per entry (~25 scalar instructions per tile on cfg2)
+			const uint32_t mine = threadIdx.x < n ? tw[2][1] : 0xffffffffu;
+			uint32_t v = mine;
+			auto lower = [](uint32_t a, uint32_t b) { return a < b ? a : b; };
+			v = lower(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x111, 0xf, 0xf, false));
+			v = lower(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x112, 0xf, 0xf, false));
+			v = lower(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x114, 0xf, 0xf, false));
+			v = lower(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x118, 0xf, 0xf, false));
+			v = lower(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x142, 0xa, 0xf, false));
+			v = lower(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x143, 0xc, 0xf, false));
+			const uint32_t smallest = (uint32_t)GC_READLANE(v, 63);
+			const unsigned long long at = __ballot(mine == smallest && threadIdx.x < n);
+			return (uint32_t)__ffsll((long long)at) - 1u;
+		}
+#endif
+		uint32_t best = 0;
+		uint32_t bestComp = qComp(0);
+		for (uint32_t i = 1; i < n; i++) { uint32_t c = qComp(i); if (c < bestComp) { bestComp = c; best = i; } }
+		return best;
+	}
 	// backtrace columns (alias the LDS table words, or registers across the lanes): column c: VP, VN, score
 	mutable uint32_t cr[5];
 	mutable uint32_t idCur, idPrev;
@@ -665,9 +693,7 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 		int32_t flatMin = INT32_MAX; uint32_t flatNode = 0xffffffffu, flatOffset = 0xffffffffu;
 		int32_t currentMin = cur.minScore;
 		while (nPending > 0) {
-			uint32_t best = 0;
-			uint32_t bestComp = L.qComp(0);
-			for (uint32_t i = 1; i < nPending; i++) { uint32_t c = L.qComp(i); if (c < bestComp) { bestComp = c; best = i; } }
+			const uint32_t best = L.qArgMin(nPending);
 			uint32_t pnode = L.qNode(best);
 			WS pws = L.qWs(best);
 			if (best != nPending - 1) L.qMove(best, nPending - 1);
