@@ -146,6 +146,34 @@ def test_extension_model_equals_oracle_on_a_tangle(tmp_path):
         assert fired.get(rule, 0) > 0, rule
 
 
+def test_extension_model_equals_oracle_with_iupac_letters(tmp_path):
+    """Ambiguous graph letters (nodes kept as four match masks, src/AlignmentGraph.h AmbiguousChunkSequence) and N in the reads: the model matches letters by their IUPAC sets
+    (src/GraphAlignerCommon.h:190-297), the oracle and the kernels through the masks."""
+    global GOLD
+    rng = random.Random(11)
+    lines = []
+    for line in tangle_gfa(rng, 120).splitlines():
+        if line.startswith("S\t"):
+            f = line.split("\t")
+            f[2] = "".join(rng.choice("NRYKMSWBDHV") if rng.random() < 0.03 else c for c in f[2])
+            line = "\t".join(f)
+        lines.append(line)
+    (tmp_path / "amb.gfa").write_text("\n".join(lines) + "\n")
+    compared = 0
+    for bandwidth in (10, 2):
+        gold, GOLD = GOLD, str(tmp_path)
+        try:
+            o, g = load("amb.gfa", bandwidth)
+        finally:
+            GOLD = gold
+        assert sum(any(c not in "ACGT" for c in s) for s in g.sequence) > 50
+        model = ExtensionModel(g, bandwidth)
+        for big, offset, text in cases(g, random.Random(3 + bandwidth), 60, 400):
+            text = "".join("N" if rng.random() < 0.02 else c for c in text)
+            compared += compare(o, model, big, offset, text) is not None
+    assert compared >= 100
+
+
 @pytest.mark.parametrize("gfa,bandwidth,count,max_len,seed", [
     ("ref_test_graph.gfa", 10, 40, 400, 1),
     ("syn20k.gfa", 10, 60, 1500, 2),
