@@ -35,7 +35,7 @@ class GcCapacities(C.Structure):
 class GcParams(C.Structure):
     _fields_ = [("bandwidth", C.c_int32), ("split_len", C.c_int32), ("split_gap", C.c_int32), ("colinear_gap", C.c_int64),
                 ("seed_density", C.c_double), ("min_cluster_size", C.c_int32), ("long_pass", C.c_int32), ("keep_traces", C.c_int32), ("keep_seeds", C.c_int32), ("stitch", C.c_int32), ("edit_distances", C.c_int32),
-                ("chain_traces", C.c_int32), ("e_cutoff", C.c_double), ("capacity", GcCapacities)]
+                ("chain_traces", C.c_int32), ("device_output", C.c_int32), ("e_cutoff", C.c_double), ("capacity", GcCapacities)]
 
 
 _P = C.POINTER
@@ -62,6 +62,9 @@ class GcResult(C.Structure):
         ("read_chain_trace_off", _P(C.c_uint64)), ("chain_trace_node", _P(C.c_int32)), ("chain_trace_offset", _P(C.c_uint32)), ("chain_trace_seqpos", _P(C.c_uint32)), ("chain_trace_switch", _P(C.c_uint8)),
         ("chain_aln_start", _P(C.c_uint32)), ("chain_aln_end", _P(C.c_uint32)),
         ("counters", C.c_uint64 * 8), ("counters_long", C.c_uint64 * 8), ("kernel_us", C.c_double * 8), ("host_us", C.c_double * 4),
+        ("read_out_off", _P(C.c_uint64)), ("out_source", _P(C.c_uint8)), ("out_numbers", _P(C.c_uint64)),
+        ("out_path_off", _P(C.c_uint64)), ("out_path_text", _P(C.c_char)), ("out_cigar_off", _P(C.c_uint64)), ("out_cigar_text", _P(C.c_char)),
+        ("out_vg_off", _P(C.c_uint64)), ("out_vg_path", _P(C.c_uint8)),
     ]
 
 
@@ -379,8 +382,10 @@ class BatchResult(dict):
 class Aligner:
     """Batched stand-in for the reference's per-read hot path (src/Aligner.cpp:601-922)."""
 
-    def __init__(self, graph, seeder, bandwidth=10, split_len=35, split_gap=35, colinear_gap=10000, seed_density=10.0, keep_traces=False, keep_seeds=False, long_pass=False, stitch=True, edit_distances=True, chain_traces=None, e_cutoff=-1.0, capacities=None):
-        """capacities: {field of gc_capacities: value} for the device-side tables (default: all automatic)."""
+    def __init__(self, graph, seeder, bandwidth=10, split_len=35, split_gap=35, colinear_gap=10000, seed_density=10.0, keep_traces=False, keep_seeds=False, long_pass=False, stitch=True, edit_distances=True, chain_traces=None, e_cutoff=-1.0, capacities=None, device_output=0):
+        """capacities: {field of gc_capacities: value} for the device-side tables (default: all automatic).
+        device_output: gc_params::device_output - 1 / 2: the final alignments' GAF path and CIGAR text (= / X or M items), + 4: their vg::Path bytes, written
+        by the device from the traces it holds; align_batch(gaf_names=...) then needs no keep_traces."""
         self.lib = load_library()
         self.graph = graph
         self.seeder = seeder
@@ -401,6 +406,7 @@ class Aligner:
         # and chains (long_pass=False) gets none unless it asks (chain_traces=1: winners, 2: every read)
         self.params.chain_traces = int(chain_traces) if chain_traces is not None else (1 if long_pass else 0)
         self.params.e_cutoff = float(e_cutoff)
+        self.params.device_output = int(device_output)
         for name, value in (capacities or {}).items():
             if name not in dict(GcCapacities._fields_) or name == "reserved":
                 raise ValueError("no such capacity: " + name)
@@ -410,7 +416,7 @@ class Aligner:
 
     def align_batch(self, batch, gaf_names=None, cigar_match_mismatch_merge=False, other_formats=False):
         """Runs the hot path for a ReadBatch; returns a dict of arrays. With gaf_names (one id per read; needs long_pass and
-        keep_traces) the dict also holds "gaf" (bytes: the reference's GAF lines) and "gaf_chained_skipped"; with other_formats also "json" (JSON
+        keep_traces or device_output) the dict also holds "gaf" (bytes: the reference's GAF lines) and "gaf_chained_skipped"; with other_formats also "json" (JSON
         lines) and "gam" (gzip members of framed vg::Alignment messages)."""
         res = _P(GcResult)()
         _check(self.lib.gc_align_batch(self.graph.handle, self.seeder.handle, self.stream, batch.handle, C.byref(self.params), C.byref(res)))
@@ -486,6 +492,13 @@ class Aligner:
                 cells = int(out["anchor_trace_off"][-1])
                 for name in ("anchor_trace_node", "anchor_trace_offset", "anchor_trace_seqpos", "anchor_trace_switch"):
                     out[name] = arr(getattr(r, name), cells)
+            if self.params.device_output:
+                out["read_out_off"] = arr(r.read_out_off, n + 1)
+                n_out = int(out["read_out_off"][-1])
+                out["out_source"] = arr(r.out_source, n_out)
+                out["out_numbers"] = arr(r.out_numbers, 12 * n_out)
+                for name in ("out_path_off", "out_cigar_off", "out_vg_off"):
+                    out[name] = arr(getattr(r, name), n_out + 1)
             out["counters"] = np.array(list(r.counters), dtype=np.uint64)
             out["counters_long"] = np.array(list(r.counters_long), dtype=np.uint64)
             out["kernel_us"] = np.array(list(r.kernel_us))

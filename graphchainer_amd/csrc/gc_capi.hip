@@ -290,6 +290,7 @@ struct gc_graph {
 		twinOffset = rev - (uint32_t)host.nodeOffset[twinNode];
 	}
 	DGraph dev {};
+	OutNames devNames {};            // GFA segment names by bigraph node id (output encoding on the device, gc_output.hip)
 	std::vector<void*> allocations;
 	CorrectnessTables* devTables = nullptr;
 	uint8_t* devIupac = nullptr;
@@ -392,6 +393,8 @@ struct gc_stream {
 	hipEvent_t longEv[2] {};
 	DeviceBuffer edPathNodes, edJobs, edLetters, edLettersLen, edPairs, edOut;
 	PinnedBuffer hEdPathNodes, hEdJobs, hEdPairs, hEdOut;
+	DeviceBuffer outJobs, outRecs, outOffsets, outMapSizes, outPathText, outCigarText, outVgBytes, outTotals;   // output encoding on the device (gc_output.hip)
+	PinnedBuffer hOutJobs, hOutRecs, hOutOffsets, hOutPathText, hOutCigarText, hOutVgBytes, hOutTotals;
 	DeviceBuffer stitchSlotOf, stitchRegions, stitchNodes, stitchInfo, stitchCursor;   // chain stitching on the device (gc_stitch.hip)
 	PinnedBuffer hStitchNodes, hStitchInfo, hStitchCursor;
 	EditDistanceRun edChainRun;
@@ -542,6 +545,20 @@ static void uploadGraph(gc_graph* G)
 		}
 		d.chainNumber = G->up(chainNumber);
 		d.chainApproxPos = G->up(chainApproxPos);
+	}
+	{
+		// the names the output encoders print (OriginalNodeName; empty: they print id / 2), by bigraph node id
+		std::vector<uint32_t> nameOff(nB + 1, 0);
+		std::vector<char> nameBytes;
+		for (size_t id = 0; id < nB; id++) {
+			auto it = h.originalNodeName.find((int)id);
+			if (it != h.originalNodeName.end()) nameBytes.insert(nameBytes.end(), it->second.begin(), it->second.end());
+			if (nameBytes.size() >= 0xffffffffull) throw std::runtime_error("node names exceed 4 GB");
+			nameOff[id + 1] = (uint32_t)nameBytes.size();
+		}
+		nameBytes.push_back(0);
+		G->devNames.nameOff = G->up(nameOff);
+		G->devNames.nameBytes = G->up(nameBytes);
 	}
 	CorrectnessTables t;
 	buildCorrectnessTables(t);
@@ -862,7 +879,13 @@ static int formatBatch(const gc_graph* G, const gc_result* r, const char* const*
 	char** out_text, uint64_t* out_len, uint64_t* n_chained_skipped)
 {
 	if (!G || !r || !read_names || !offsets || !out_text || !out_len) return fail(GC_ERR_INVALID, "null argument");
-	if (!r->long_trace_off || !r->read_long_off || !r->long_index) return fail(GC_ERR_INVALID, "the output encoders need a result with long_pass, keep_traces and edit_distances");
+	const bool pieces = r->read_out_off != nullptr;   // the result carries the alignments as the device encoded them (gc_params::device_output)
+	if (pieces) {
+		if (kind == OUT_GAF && !r->out_cigar_off) return fail(GC_ERR_INVALID, "the result holds no GAF pieces");
+		if (kind == OUT_GAF && r->out_cigar_off[r->read_out_off[r->n_reads]] == 0 && r->out_vg_off[r->read_out_off[r->n_reads]] != 0) return fail(GC_ERR_INVALID, "the result was produced without the GAF pieces (gc_params::device_output & 3)");
+		if (kind != OUT_GAF && r->out_vg_off[r->read_out_off[r->n_reads]] == 0 && r->out_cigar_off[r->read_out_off[r->n_reads]] != 0) return fail(GC_ERR_INVALID, "the result was produced without the vg::Path bytes (gc_params::device_output & 4)");
+	}
+	if (!pieces && (!r->long_trace_off || !r->read_long_off || !r->long_index)) return fail(GC_ERR_INVALID, "the output encoders need a result with long_pass, keep_traces and edit_distances");
 	return guarded([&]() {
 		const uint64_t n = r->n_reads;
 		std::vector<std::string> perRead(n);
@@ -872,6 +895,27 @@ static int formatBatch(const gc_graph* G, const gc_result* r, const char* const*
 			std::vector<std::string> messages;
 			const std::string name = read_names[i] ? read_names[i] : "";
 			const uint64_t len = offsets[i + 1] - offsets[i];
+			if (pieces && !r->chained_better[i]) {
+				// put together from what the device wrote: the path and CIGAR columns, or the vg::Path bytes, plus the numbers of the other columns / fields
+				for (uint64_t e = r->read_out_off[i]; e < r->read_out_off[i + 1]; e++) {
+					const uint64_t* num = r->out_numbers + 12 * e;
+					gc::EncodedAlignment ea;
+					ea.nodePathLen = num[0]; ea.nodePathStart = num[1]; ea.nodePathEnd = num[2]; ea.matches = num[3]; ea.mismatches = num[4]; ea.insertions = num[5]; ea.deletions = num[6];
+					ea.cells = num[7]; ea.alignmentStart = num[8]; ea.alignmentEnd = num[9]; ea.score = (int32_t)num[11];
+					if (kind == OUT_GAF) {
+						ea.path = r->out_path_text + r->out_path_off[e]; ea.pathLen = r->out_path_off[e + 1] - r->out_path_off[e];
+						ea.cigar = r->out_cigar_text + r->out_cigar_off[e]; ea.cigarLen = r->out_cigar_off[e + 1] - r->out_cigar_off[e];
+						gc::appendGafLine(text, name, len, ea);
+						text += '\n';
+					} else {
+						ea.vgPath = r->out_vg_path + r->out_vg_off[e]; ea.vgPathLen = r->out_vg_off[e + 1] - r->out_vg_off[e];
+						if (kind == OUT_JSON) { text += gc::vgToJson(gc::vgFromEncoded(name, bases + offsets[i], ea)); text += '\n'; }
+						else messages.push_back(gc::vgProtobufFromEncoded(name, bases + offsets[i], ea));
+					}
+				}
+				if (kind == OUT_GAM && !messages.empty()) text = gc::gamGroup(messages);
+				return;
+			}
 			if (r->chained_better[i]) {
 				// the chained alignment replaces the whole-read ones (src/Aligner.cpp:901-920): a single item, trace score 0
 				const uint64_t t0 = r->read_chain_trace_off ? r->read_chain_trace_off[i] : 0, t1 = r->read_chain_trace_off ? r->read_chain_trace_off[i + 1] : 0;
@@ -887,6 +931,7 @@ static int formatBatch(const gc_graph* G, const gc_result* r, const char* const*
 				}
 				return;
 			}
+			if (pieces) return;   // (a read without alignments)
 			struct Item { uint32_t start; uint64_t aln; };
 			std::vector<Item> items;
 			for (uint64_t k = r->read_long_off[i]; k < r->read_long_off[i + 1]; k++) {
@@ -979,6 +1024,7 @@ void gc_params_default(gc_params* p)
 	p->stitch = 1;
 	p->edit_distances = 1;
 	p->chain_traces = 1;
+	p->device_output = 0;
 	p->e_cutoff = -1;
 	memset(&p->capacity, 0, sizeof(p->capacity));   // automatic
 }
@@ -1428,7 +1474,8 @@ void gc_result_free(gc_result* r)
 		r->read_longall_off, r->longall_start, r->longall_end, r->longall_score, r->long_trace_off, r->long_trace_node, r->long_trace_offset, r->long_trace_seqpos, r->long_trace_switch,
 		r->failed_assertion, r->seeds_extended, r->seeds_extended_long, r->read_path_off, r->path_node, r->path_first_offset, r->path_last_offset, r->path_cells,
 		r->read_long_off, r->long_index, r->long_edit_distance, r->chain_edit_distance, r->chained_better,
-		r->capacity_exceeded, r->read_chain_trace_off, r->chain_trace_node, r->chain_trace_offset, r->chain_trace_seqpos, r->chain_trace_switch, r->chain_aln_start, r->chain_aln_end };
+		r->capacity_exceeded, r->read_chain_trace_off, r->chain_trace_node, r->chain_trace_offset, r->chain_trace_seqpos, r->chain_trace_switch, r->chain_aln_start, r->chain_aln_end,
+		r->read_out_off, r->out_source, r->out_numbers, r->out_path_off, r->out_path_text, r->out_cigar_off, r->out_cigar_text, r->out_vg_off, r->out_vg_path };
 	for (void* p : ptrs) g_resultBlocks.put(p);
 	free(r);
 }
@@ -1571,6 +1618,7 @@ struct BatchRun {
 		stitchAndChainDistances();
 		joinWholeReadPass();
 		chainedAlignments();
+		encodeOutput();
 		assemble();
 	}
 
@@ -1910,6 +1958,8 @@ struct BatchRun {
 			// what outgrows that layout's tables (EXT_SM_DECLINED: more than 32 nodes in a slice, 16 pending, no room for the reserved trace)
 			// is listed and rerun one extension per wave, like the register-table overflows below
 			const bool useSm = team == 1 && getenv("GC_LONG_SM") && atoi(getenv("GC_LONG_SM")) == 1;
+			// GC_LONG_LANE=1 (measurement, off by default): one extension per LANE with the plain-layout core and its band state in a per-lane HBM slab
+			const bool useLane = !useSm && team == 1 && getenv("GC_LONG_LANE") && atoi(getenv("GC_LONG_LANE")) == 1;
 			if (useSm) {
 				launchLongExtendSm(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, (uint8_t*)(dLongScratch + (uint64_t)g * scratchLanes * waveWords), scratchLanes * waveWords * 8,
 					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2);
@@ -1918,10 +1968,13 @@ struct BatchRun {
 				const uint32_t declinedBlocks = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nWorkItems, 8192), std::max<uint64_t>(1, scratchLanes - 64));
 				launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dRetryList + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 1, declinedBlocks,
 					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, 6u, cursor + 3);
+			} else if (useLane) {
+				launchLongExtendLane(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, (uint8_t*)(dLongScratch + (uint64_t)g * scratchLanes * waveWords), scratchLanes * waveWords * 8,
+					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8);
 			} else
 			launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, team, blocks,
 				dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, 0, nullptr, team == 1 ? dRetryList + w0 : nullptr, cursor + 3);
-			if (team == 1) {
+			if (team == 1 && !useLane) {
 				// extensions whose band outgrew the 64-entry register tables: second try with the LDS/HBM tables (two lanes per wave,
 				// 28 + 228 entries); waves whose items are fine leave at once. Beyond that the read goes to the plain-layout fallback.
 				// (those items are listed first - almost always none - so that the retry is a handful of waves that fetch from the list, not
@@ -2628,6 +2681,125 @@ struct BatchRun {
 
 	}
 
+	// ---------------- the final alignments encoded where their traces are (params->device_output; gc_output.hip): the GAF path / CIGAR text and the vg::Path bytes of
+	// every alignment the reference would write for the batch (src/Aligner.cpp:901-920,1003-1023), so that no trace cell has to come down for the writers
+	struct OutEntry { uint32_t read, aln; uint8_t source; };   // aln: index into the read's longAlns (source 0); source 1: the read's chained alignment, encoded by the host from its trace
+	std::vector<OutEntry> outEntries;
+	std::vector<uint64_t> readOutOff;
+	const OutRec* hOutRecs = nullptr; const uint64_t* hOutOffsets = nullptr;
+	const char* hOutPath = nullptr; const char* hOutCigar = nullptr; const uint8_t* hOutVg = nullptr;
+	uint64_t nOutJobs = 0;
+	std::vector<uint64_t> outJobOfEntry;
+	void encodeOutput()
+	{
+		if (!P->device_output) return;
+		const double t0 = nowUs();
+		readOutOff.assign(n + 1, 0);
+		outEntries.clear();
+		for (uint64_t r = 0; r < n; r++) {
+			const ReadGlue& gl = glue[r];
+			readOutOff[r] = outEntries.size();
+			if (gl.longFailed) continue;
+			if (gl.chainWins) { outEntries.push_back(OutEntry { (uint32_t)r, 0, 1 }); continue; }
+			struct Item { uint32_t start; uint32_t aln; };
+			std::vector<Item> items;
+			for (uint32_t k : gl.longSelected) items.push_back(Item { gl.longAlns[k].start, k });
+			auto byStart = [](const Item& l, const Item& rr) { return l.start < rr.start; };
+			std::sort(items.begin(), items.end(), byStart);   // src/Aligner.cpp:1003
+			std::sort(items.begin(), items.end(), byStart);   // :1023 (an unstable sort may move ties even in a sorted list)
+			for (const Item& it : items) outEntries.push_back(OutEntry { (uint32_t)r, it.aln, 0 });
+		}
+		readOutOff[n] = outEntries.size();
+		outJobOfEntry.assign(outEntries.size(), ~0ull);
+		OutJob* hJobsOut = st->hOutJobs.reserve<OutJob>(outEntries.size());
+		nOutJobs = 0;
+		const uint32_t flags = ((P->device_output & 2) ? 1u : 0u) | ((P->device_output & 3) ? 2u : 0u) | ((P->device_output & 4) ? 4u : 0u);
+		for (size_t e = 0; e < outEntries.size(); e++) {
+			if (outEntries[e].source != 0) continue;
+			const uint32_t r = outEntries[e].read;
+			const LongAln& al = glue[r].longAlns[outEntries[e].aln];
+			hJobsOut[nOutJobs] = OutJob { al.traceOff, R->offsets[r], al.traceLen, (uint32_t)(R->offsets[r + 1] - R->offsets[r]), flags, 0 };
+			outJobOfEntry[e] = nOutJobs++;
+		}
+		if (nOutJobs == 0) return;
+		if (nOutJobs >= 0xffffffffull) throw std::runtime_error("too many alignments in one batch for the output encoder");
+		hipStream_t q = st->longStream;   // (idle by now: the pass and its decision are done)
+		OutJob* dJobsOut = st->outJobs.reserve<OutJob>(nOutJobs);
+		OutRec* dRecs = st->outRecs.reserve<OutRec>(nOutJobs);
+		uint64_t* dOffsets = st->outOffsets.reserve<uint64_t>(3 * (nOutJobs + 1));
+		unsigned long long* dTotals = st->outTotals.reserve<unsigned long long>(4);
+		uint32_t* dMapSizes = (P->device_output & 4) ? st->outMapSizes.reserve<uint32_t>(std::max<uint64_t>(1, hLongSmall[0]))   /* one word per cell of the pool in use */ : nullptr;
+		unsigned long long* hTotals = st->hOutTotals.reserve<unsigned long long>(4);
+		HIP_CHECK(hipMemcpyAsync(dJobsOut, hJobsOut, nOutJobs * sizeof(OutJob), hipMemcpyHostToDevice, q));
+		launchOutCount(q, G->dev, G->devNames, G->devIupac, dJobsOut, (uint32_t)nOutJobs, dLongCells, R->devBases, dRecs, dOffsets, dMapSizes, dTotals);
+		HIP_CHECK(hipMemcpyAsync(hTotals, dTotals, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, q));
+		syncStream(q);
+		const uint64_t pathBytes = hTotals[0], cigarBytes = hTotals[1], vgBytes = hTotals[2];
+		char* dPath = st->outPathText.reserve<char>(pathBytes + 1);
+		char* dCigar = st->outCigarText.reserve<char>(cigarBytes + 1);
+		uint8_t* dVg = st->outVgBytes.reserve<uint8_t>(vgBytes + 1);
+		launchOutWrite(q, G->dev, G->devNames, G->devIupac, dJobsOut, (uint32_t)nOutJobs, dLongCells, R->devBases, dRecs, dOffsets, dMapSizes, dPath, dCigar, dVg);
+		OutRec* recs = st->hOutRecs.reserve<OutRec>(nOutJobs);
+		uint64_t* offs = st->hOutOffsets.reserve<uint64_t>(3 * (nOutJobs + 1));
+		char* pathText = st->hOutPathText.reserve<char>(pathBytes + 1);
+		char* cigarText = st->hOutCigarText.reserve<char>(cigarBytes + 1);
+		uint8_t* vg = st->hOutVgBytes.reserve<uint8_t>(vgBytes + 1);
+		HIP_CHECK(hipMemcpyAsync(recs, dRecs, nOutJobs * sizeof(OutRec), hipMemcpyDeviceToHost, q));
+		HIP_CHECK(hipMemcpyAsync(offs, dOffsets, 3 * (nOutJobs + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, q));
+		if (pathBytes) HIP_CHECK(hipMemcpyAsync(pathText, dPath, pathBytes, hipMemcpyDeviceToHost, q));
+		if (cigarBytes) HIP_CHECK(hipMemcpyAsync(cigarText, dCigar, cigarBytes, hipMemcpyDeviceToHost, q));
+		if (vgBytes) HIP_CHECK(hipMemcpyAsync(vg, dVg, vgBytes, hipMemcpyDeviceToHost, q));
+		syncStream(q);
+		for (uint64_t k = 0; k < nOutJobs; k++) if (recs[k].steps == 0xffffffffu) throw std::runtime_error("internal: the output encoder's two passes disagree on an alignment's size");
+		hOutRecs = recs; hOutOffsets = offs; hOutPath = pathText; hOutCigar = cigarText; hOutVg = vg;
+		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] output encoding on the device: %llu alignments, %.1f MB of path text, %.1f MB of CIGAR, %.1f MB of vg::Path bytes, %.1f ms\n",
+			(unsigned long long)nOutJobs, pathBytes / 1e6, cigarBytes / 1e6, vgBytes / 1e6, (nowUs() - t0) / 1e3);
+	}
+
+	void assembleOutput()   // the pieces into the result (entries of chained winners stay empty: source 1)
+	{
+		if (!P->device_output) return;
+		const uint64_t nOut = outEntries.size();
+		res->read_out_off = resultArray<uint64_t>(n + 1);
+		memcpy(res->read_out_off, readOutOff.data(), (n + 1) * sizeof(uint64_t));
+		res->out_source = resultArray<uint8_t>(nOut);
+		res->out_numbers = resultArray<uint64_t>(12 * nOut);
+		res->out_path_off = resultArray<uint64_t>(nOut + 1); res->out_cigar_off = resultArray<uint64_t>(nOut + 1); res->out_vg_off = resultArray<uint64_t>(nOut + 1);
+		const uint64_t stride = nOutJobs + 1;
+		const uint64_t pathBytes = nOutJobs ? hOutOffsets[nOutJobs] : 0, cigarBytes = nOutJobs ? hOutOffsets[stride + nOutJobs] : 0, vgBytes = nOutJobs ? hOutOffsets[2 * stride + nOutJobs] : 0;
+		res->out_path_text = resultArray<char>(pathBytes + 1); res->out_cigar_text = resultArray<char>(cigarBytes + 1); res->out_vg_path = resultArray<uint8_t>(vgBytes + 1);
+		// the device wrote the jobs' pieces back to back in entry order, so the bytes copy over as they are
+		const size_t parts = 16;
+		pool.run(3 * parts, [&](size_t i, size_t) {
+			const size_t which = i / parts, part = i % parts;
+			const uint64_t total = which == 0 ? pathBytes : which == 1 ? cigarBytes : vgBytes;
+			const char* src = which == 0 ? hOutPath : which == 1 ? hOutCigar : (const char*)hOutVg;
+			char* dst = which == 0 ? res->out_path_text : which == 1 ? res->out_cigar_text : (char*)res->out_vg_path;
+			const uint64_t b = total * part / parts, e = total * (part + 1) / parts;
+			if (e > b) memcpy(dst + b, src + b, e - b);
+		});
+		res->out_path_text[pathBytes] = 0; res->out_cigar_text[cigarBytes] = 0;
+		uint64_t jobsSeen = 0;
+		for (uint64_t e = 0; e < nOut; e++) {
+			const OutEntry& en = outEntries[e];
+			res->out_source[e] = en.source;
+			uint64_t* num = res->out_numbers + 12 * e;
+			if (en.source == 0) {
+				const uint64_t k = outJobOfEntry[e];
+				const OutRec& rec = hOutRecs[k];
+				const LongAln& al = glue[en.read].longAlns[en.aln];
+				num[0] = rec.nodePathLen; num[1] = rec.nodePathStart; num[2] = rec.nodePathEnd; num[3] = rec.matches; num[4] = rec.mismatches; num[5] = rec.insertions; num[6] = rec.deletions;
+				num[7] = al.traceLen; num[8] = al.start; num[9] = al.end; num[10] = rec.steps; num[11] = al.score;
+				res->out_path_off[e] = hOutOffsets[k]; res->out_cigar_off[e] = hOutOffsets[stride + k]; res->out_vg_off[e] = hOutOffsets[2 * stride + k];
+				jobsSeen = k + 1;
+			} else {
+				for (int i = 0; i < 12; i++) num[i] = 0;
+				res->out_path_off[e] = nOutJobs ? hOutOffsets[jobsSeen] : 0; res->out_cigar_off[e] = nOutJobs ? hOutOffsets[stride + jobsSeen] : 0; res->out_vg_off[e] = nOutJobs ? hOutOffsets[2 * stride + jobsSeen] : 0;
+			}
+		}
+		res->out_path_off[nOut] = pathBytes; res->out_cigar_off[nOut] = cigarBytes; res->out_vg_off[nOut] = vgBytes;
+	}
+
 	// ---------------- the flat result: count per read, prefix-sum, fill in parallel
 	void assemble()
 	{
@@ -2839,6 +3011,7 @@ struct BatchRun {
 				a++;
 			});
 		});
+		assembleOutput();
 		res->host_us[1] = nowUs() - tAsm;
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc cpu] %.0f ms up to the end of the batch (the join came at %.0f)\n", processCpuMs() - cpuCall, cpuJoined - cpuCall);
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] batch timeline (ms from the call): whole-read pass started %.1f, joined %.1f, assembly began %.1f, done %.1f\n", (tLongWall0 - tTotal) / 1e3, (tJoined - tTotal) / 1e3, (tAsm - tTotal) / 1e3, (nowUs() - tTotal) / 1e3);
@@ -2856,13 +3029,19 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		for (int64_t x : v) if (x < 0 || x > (1ll << 40)) return fail(GC_ERR_INVALID, "gc_params::capacity: a size is negative or absurd (0 = automatic)");
 		if (c.long_column_store < -1 || c.long_column_store > (1ll << 31)) return fail(GC_ERR_INVALID, "gc_params::capacity.long_column_store: -1 (none), 0 (automatic) or a column count");
 	}
+	if (P->device_output < 0 || P->device_output > 7 || (P->device_output & 3) == 3) return fail(GC_ERR_INVALID, "gc_params::device_output: 1 or 2 (GAF pieces with = / X or with M), optionally + 4 (vg::Path bytes)");
+	if (P->device_output && !(P->long_pass && P->edit_distances)) return fail(GC_ERR_INVALID, "gc_params::device_output needs long_pass and edit_distances (the final alignments are what it encodes)");
 	*out = nullptr;
 	const double tCall = nowUs();
 	const double cpuCall = processCpuMs();
 	gc_result* res = (gc_result*)calloc(1, sizeof(gc_result));
 	int rc = guarded([&]() {
 		HIP_CHECK(hipSetDevice(st->device));   // the current device is per host thread
-		BatchRun batch(G, S, st, R, P, res, tCall, cpuCall);
+		// without the chained alignment's trace the decision comes from the two distances alone, which skips --E-cutoff's test of the chained alignment
+		// (src/Aligner.cpp:904): with a cut-off set the traces are made whatever chain_traces says
+		gc_params effective = *P;
+		if (effective.chain_traces == 0 && effective.e_cutoff >= 0 && effective.stitch && effective.edit_distances) effective.chain_traces = 1;
+		BatchRun batch(G, S, st, R, &effective, res, tCall, cpuCall);
 		batch.run();
 		return (int)GC_OK;
 	});

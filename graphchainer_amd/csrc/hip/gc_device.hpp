@@ -236,6 +236,7 @@ struct EqSource {
 	const uint64_t* masks;   // [4][words] for this read and strand
 	uint32_t words;          // words per bit vector
 	uint32_t startBit;       // read position of the extension's row 0
+	__device__ __forceinline__ void rows(int len, int j, Eq4& eq) const;
 };
 __device__ inline void eqVectorBits(const EqSource& src, int len, int j, Eq4& eq)
 {
@@ -253,6 +254,7 @@ __device__ inline void eqVectorBits(const EqSource& src, int len, int j, Eq4& eq
 	}
 	eq.a = out[0]; eq.c = out[1]; eq.g = out[2]; eq.t = out[3];
 }
+__device__ __forceinline__ void EqSource::rows(int len, int j, Eq4& eq) const { eqVectorBits(*this, len, j, eq); }
 
 struct NodeSeq { uint64_t w0, w1, w2, w3; bool ambiguous; };
 __device__ __forceinline__ NodeSeq loadNodeSeq(const DGraph& g, uint32_t node)
@@ -477,8 +479,14 @@ __device__ inline bool backtraceCorner(const DGraph& g, const LaneScratch& sc, u
 // Full seed extension: slices, correctness HMM, trimming, backtrace.
 // reference: getReverseTraceFromSeed, src/GraphAlignerBitvectorBanded.h:46-71. Returns status; on EXT_OK the
 // trace (start cell first, row -1 last) is in sc.trace[0..nTrace) and `score` is the alignment score.
-__device__ inline uint32_t extendSeed(const DGraph& g, const CorrectnessTables& ct, const uint8_t* iupac, const ExtendConfig& cfg, const LaneScratch& sc,
-	const char* seq, int len, uint32_t startNode, uint32_t startOffset, uint32_t& nTrace, int32_t& score, ExtCounters& cnt)
+// The match masks of a slice come from `eqs` (EqFromBases: the read's letters; EqSource: the per-read bit vectors built at upload).
+struct EqFromBases {
+	const char* seq; const uint8_t* iupac;
+	__device__ __forceinline__ void rows(int len, int j, Eq4& eq) const { eqVector(seq, len, j, iupac, eq); }
+};
+template <class EQS>
+__device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables& ct, const EQS& eqs, const ExtendConfig& cfg, const LaneScratch& sc,
+	int len, uint32_t startNode, uint32_t startOffset, uint32_t& nTrace, int32_t& score, ExtCounters& cnt)
 {
 	uint32_t status = EXT_OK;
 	nTrace = 0;
@@ -511,7 +519,7 @@ __device__ inline uint32_t extendSeed(const DGraph& g, const CorrectnessTables& 
 	for (int slice = 0; slice < numSlices; slice++) {
 		const SliceInfo prev = sc.slices[nSlices - 1];
 		int j = prev.j + 64;
-		eqVector(seq, len, j, iupac, eq);
+		eqs.rows(len, j, eq);
 		int32_t previousQuitScore = prev.minScore + prev.bandwidth;
 		int32_t previousMinScore = prev.minScore;
 		int bandwidth = cfg.bandwidth;
@@ -604,7 +612,7 @@ __device__ inline uint32_t extendSeed(const DGraph& g, const CorrectnessTables& 
 		uint32_t s = (uint32_t)(here.seqPos / 64) + 1;
 		if (s >= nSlices) return EXT_ASSERT;
 		if (s != curSlice || here.node != curNode) {
-			if (s != curSlice) eqVector(seq, len, sc.slices[s].j, iupac, eq);
+			if (s != curSlice) eqs.rows(len, sc.slices[s].j, eq);
 			curSlice = s;
 			curNode = here.node;
 			curItem = findItem(sc.items, sc.slices[s], curNode);
@@ -754,6 +762,12 @@ __device__ inline uint32_t extendSeed(const DGraph& g, const CorrectnessTables& 
 	}
 	cnt.traceItems += nTrace;
 	return status;
+}
+
+__device__ inline uint32_t extendSeed(const DGraph& g, const CorrectnessTables& ct, const uint8_t* iupac, const ExtendConfig& cfg, const LaneScratch& sc,
+	const char* seq, int len, uint32_t startNode, uint32_t startOffset, uint32_t& nTrace, int32_t& score, ExtCounters& cnt)
+{
+	return extendSeedT(g, ct, EqFromBases { seq, iupac }, cfg, sc, len, startNode, startOffset, nTrace, score, cnt);
 }
 
 } // namespace gcdev

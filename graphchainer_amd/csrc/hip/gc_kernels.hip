@@ -1037,6 +1037,52 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LANES =
 	}
 }
 
+// The measurement VERDICT r3 asked for (GC_LONG_LANE=1, off by default): the same rounds, but every LANE takes one work item and runs the
+// plain-layout core (extendSeedT, gc_device.hpp: the core of k_extend and k_long_pass) with its band state in a per-lane HBM slab - no LDS tables, no
+// state machine, <= 128 VGPRs (4 waves per SIMD). Work items arrive longest first (k_long_order), so a wave's 64 extensions have about the same number of
+// slices. What outgrows the slab answers EXT_OVERFLOW and its read goes to the plain-layout fallback like any other overflow.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_long_extend_lane(DGraph g, const CorrectnessTables* __restrict__ ct, const uint64_t* __restrict__ masks, ExtendConfig cfg,
+	const LongWork* __restrict__ work, const uint32_t* __restrict__ order, uint32_t nWork, uint8_t* __restrict__ scratch, uint64_t slabBytes,
+	unsigned long long* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, LongWorkResult* __restrict__ results, unsigned long long* __restrict__ counters)
+{
+	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t stride = gridDim.x * blockDim.x;
+	LaneScratch sc = laneScratch(scratch + (uint64_t)tid * slabBytes, cfg);
+	ExtCounters cnt {};
+	for (uint32_t slot = tid; slot < nWork; slot += stride) {
+		const uint32_t w = order[slot];
+		LongWork it = work[w];
+		LongWorkResult res { 0, 0, EXT_FAILED, 0, 0 };
+		if (it.seqLen > 0) {
+			uint32_t nTrace = 0;
+			int32_t score = 0;
+			EqSource eqSrc { masks + it.maskOff, it.maskWords, it.startBit };
+			res.status = extendSeedT(g, *ct, eqSrc, cfg, sc, (int)it.seqLen, it.node, it.offset, nTrace, score, cnt);
+			res.score = score;
+			if (res.status == EXT_OK) {
+				unsigned long long base = atomicAdd(traceCursor, (unsigned long long)nTrace);
+				if (base + nTrace <= traceCapacity) {
+					for (uint32_t i = 0; i < nTrace; i++) {
+						const TraceCell c = sc.trace[i];
+						tracePool[base + i] = packCell(Cell { c.node, c.offsetAndSwitch & 255u, c.seqPos }, (c.offsetAndSwitch >> 8) & 1u);
+					}
+					res.traceOff = base;
+					res.traceLen = nTrace;
+				} else res.status = EXT_OVERFLOW;
+			}
+		}
+		results[w] = res;
+	}
+	if (cnt.extensions) {
+		atomicAdd(&counters[0], cnt.dpTiles);
+		atomicAdd(&counters[1], cnt.recomputeTiles);
+		atomicAdd(&counters[2], cnt.columnSteps);
+		atomicAdd(&counters[3], cnt.traceItems);
+		atomicAdd(&counters[4], cnt.extensions);
+		atomicAdd(&counters[5], cnt.backtraceTiles);
+	}
+}
+
 // One wave per read: the decisions are taken redundantly by all lanes (uniform control flow, lane 0 does the single
 // writes), the trace -> cell conversion - the bulk of the work, ~1.5 cells per read base - runs 64 cells at a time.
 __global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __restrict__ jobs, uint32_t nReads, const LongSeed* __restrict__ seeds, const uint32_t* __restrict__ candSeed,
@@ -1281,6 +1327,18 @@ void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTabl
 		default: GC_LAUNCH_TEAM(64); break;
 	}
 #undef GC_LAUNCH_TEAM
+}
+void launchLongExtendLane(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
+	uint8_t* scratch, uint64_t scratchBytes, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters)
+{
+	if (!nWork) return;
+	const uint64_t slab = extendSlabBytes(cfg);
+	uint64_t lanes = ((uint64_t)nWork + 63) / 64 * 64;
+	const uint64_t fit = scratchBytes / slab / 64 * 64;   // lanes whose slabs fit the scratch: a larger round strides
+	if (lanes > fit) lanes = fit;
+	if (lanes > 256ull * 16 * 64) lanes = 256ull * 16 * 64;
+	if (lanes == 0) return;
+	hipLaunchKernelGGL(k_long_extend_lane, dim3((uint32_t)(lanes / 64)), dim3(64), 0, stream, g, ct, masks, cfg, work, order, nWork, scratch, slab, tracePool, traceCursor, traceCapacity, results, counters);
 }
 // Work items of the fragment pass, built where they are used (src/GraphAligner.h:499-511 per seed of a fragment window): the host sorts each
 // read's seeds and cuts the windows (order-critical, host/gc_glue.cpp) and hands over 16 B per fragment and per seed; one thread per fragment

@@ -177,6 +177,9 @@ uint32_t longExtendTeamSize(uint32_t nWork);
 void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
 	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters,
 	unsigned long long* nextSlot, uint32_t retryStatus = 0, const unsigned long long* nWorkOnDevice = nullptr, uint32_t* capListOut = nullptr, unsigned long long* capCountOut = nullptr);   // nWorkOnDevice: `order` is a list whose length only the device knows (then nWork is its upper bound)
+// the same extensions one per LANE with the plain-layout core and a per-lane HBM slab (k_long_extend_lane: the layout measurement of DESIGN.md §4e, GC_LONG_LANE=1)
+void launchLongExtendLane(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
+	uint8_t* scratch, uint64_t scratchBytes, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters);
 // the same extensions one per LANE as per-lane state machines (gc_sm.hip); what outgrows its tables answers EXT_SM_DECLINED (6) and is rerun by launchLongExtend
 uint64_t longSmSlabBytes(const ExtendConfig& cfg);
 void launchLongExtendSm(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
@@ -223,6 +226,26 @@ void launchChainPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* j
 uint32_t editDistanceMaxK(uint32_t unitBlocks);
 void launchEditDistance(hipStream_t stream, uint32_t unitBlocks, const EdPair* pairs, uint32_t nPairs, const EdRead* reads, const char* bases, const uint64_t* eqMasks,
 	const char* letters, const uint32_t* lettersLen, int64_t* outDistance);
+// ---- output encoding on the device (gc_output.hip): GAF path + CIGAR text and the vg::Path wire bytes of final alignments
+struct OutNames { const uint32_t* nameOff; const char* nameBytes; };   // [bigraph node ids + 1]: the GFA name of every node's segment (empty: the encoders print id / 2)
+struct OutJob {      // one final alignment
+	uint64_t cellOff;             // its merged trace in the LongCell pool
+	uint64_t readOff;             // the read's forward bases
+	uint32_t cellLen, readLen;
+	uint32_t flags;               // 1: CIGAR with M instead of = / X, 2: GAF pieces wanted, 4: vg::Path bytes wanted
+	uint32_t pad;
+};
+struct OutRec {      // what the counting pass leaves per job (the writing pass sets steps = ~0 when it did not land on these sizes)
+	uint64_t nodePathLen, nodePathStart, nodePathEnd;
+	uint32_t pathTextLen, cigarLen, vgLen, steps;
+	uint32_t matches, mismatches, insertions, deletions;
+	uint32_t readStart, readEnd;
+};
+// counting pass + placement: recs, offsets[3][nJobs + 1] (path text, CIGAR, vg bytes; the last entries and totals[0..2] are the sums); mapSizeAtCell: one word per pool cell
+void launchOutCount(hipStream_t stream, const DGraph& g, const OutNames& names, const uint8_t* iupac, const OutJob* jobs, uint32_t nJobs, const LongCell* cellPool, const char* bases,
+	OutRec* recs, uint64_t* offsets, uint32_t* mapSizeAtCell, unsigned long long* totals);
+void launchOutWrite(hipStream_t stream, const DGraph& g, const OutNames& names, const uint8_t* iupac, const OutJob* jobs, uint32_t nJobs, const LongCell* cellPool, const char* bases,
+	OutRec* recs, const uint64_t* offsets, uint32_t* mapSizeAtCell, char* pathText, char* cigarText, uint8_t* vgBytes);
 // ---- minimizer index construction on the device (gc_minimizer.hip): the graph's window minimizers as (k-mer << 34 | reversed
 // arrival index, packed position) pairs, sorted; returns their number (~0 on failure: the caller builds on the host), arrays are hipMalloc'd
 uint64_t buildMinimizerPairsDevice(const DGraph& g, const int32_t* idOrderDev, uint32_t nIds, uint32_t k, uint32_t w, uint64_t** outKeys, uint64_t** outValues);

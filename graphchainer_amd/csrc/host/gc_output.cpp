@@ -332,6 +332,92 @@ std::string vgToProtobuf(const VgAlignment& aln)
 	return out;
 }
 
+// ---- alignments encoded on the device: the host's part of the line / message
+
+void appendGafLine(std::string& out, const std::string& readName, uint64_t readLength, const EncodedAlignment& a)
+{
+	// the columns of formatGafLine above; `stream << double` is printf's %g
+	const uint64_t all = a.matches + a.mismatches + a.deletions + a.insertions;
+	const double identity = (double)a.matches / (double)all;
+	char num[64];
+	out += readName; out += '\t'; appendUint(out, readLength); out += '\t'; appendUint(out, a.alignmentStart); out += '\t'; appendUint(out, a.alignmentEnd); out += "\t+\t";
+	out.append(a.path, a.pathLen);
+	out += '\t'; appendUint(out, a.nodePathLen); out += '\t'; appendUint(out, a.nodePathStart); out += '\t'; appendUint(out, a.nodePathEnd);
+	out += '\t'; appendUint(out, a.matches); out += '\t'; appendUint(out, a.cells); out += "\t255\tNM:i:"; appendUint(out, a.mismatches + a.deletions + a.insertions);
+	snprintf(num, sizeof num, "%g", 1.0 - identity); out += "\tdv:f:"; out += num;
+	snprintf(num, sizeof num, "%g", identity); out += "\tid:f:"; out += num;
+	out += "\tcg:Z:";
+	out.append(a.cigar, a.cigarLen);
+}
+
+std::string vgProtobufFromEncoded(const std::string& readName, const char* sequence, const EncodedAlignment& a)
+{
+	// vgToProtobuf's fields around the path the device wrote
+	std::string out;
+	out.reserve(a.vgPathLen + (a.alignmentEnd - a.alignmentStart) + readName.size() + 48);
+	if (a.alignmentEnd > a.alignmentStart) { putTag(out, 1, 2); putVarint(out, a.alignmentEnd - a.alignmentStart); out.append(sequence + a.alignmentStart, sequence + a.alignmentEnd); }
+	putTag(out, 2, 2); putVarint(out, a.vgPathLen); out.append((const char*)a.vgPath, a.vgPathLen);
+	if (!readName.empty()) putBytes(out, 3, readName);
+	if (a.score != 0) { putTag(out, 6, 0); putVarint(out, (uint64_t)(int64_t)a.score); }
+	if ((int32_t)a.alignmentStart != 0) { putTag(out, 7, 0); putVarint(out, (uint64_t)(int64_t)(int32_t)a.alignmentStart); }
+	const double identity = (double)a.matches / (double)(a.matches + a.mismatches + a.insertions + a.deletions);
+	if (identity != 0) { putTag(out, 16, 1); uint64_t bits; memcpy(&bits, &identity, 8); for (int i = 0; i < 8; i++) out += (char)(bits >> (8 * i)); }
+	return out;
+}
+
+namespace {
+struct WireReader {
+	const uint8_t* p; const uint8_t* end;
+	bool done() const { return p >= end; }
+	uint64_t varint() { uint64_t v = 0; int shift = 0; while (p < end) { uint8_t b = *p++; v |= (uint64_t)(b & 0x7f) << shift; if (!(b & 0x80)) return v; shift += 7; } throw std::runtime_error("truncated vg::Path bytes"); }
+	WireReader sub() { uint64_t len = varint(); if ((uint64_t)(end - p) < len) throw std::runtime_error("truncated vg::Path bytes"); WireReader r { p, p + len }; p += len; return r; }
+};
+}
+
+VgAlignment vgFromEncoded(const std::string& readName, const char* sequence, const EncodedAlignment& a)
+{
+	VgAlignment aln;
+	aln.name = readName;
+	aln.score = a.score;
+	aln.identity = (double)a.matches / (double)(a.matches + a.mismatches + a.insertions + a.deletions);
+	aln.sequence = std::string(sequence + a.alignmentStart, sequence + a.alignmentEnd);
+	aln.queryPosition = (int32_t)a.alignmentStart;
+	WireReader path { a.vgPath, a.vgPath + a.vgPathLen };
+	while (!path.done()) {
+		if (path.varint() != ((2u << 3) | 2u)) throw std::runtime_error("unexpected field in vg::Path bytes");
+		WireReader m = path.sub();
+		VgMapping mapping;
+		while (!m.done()) {
+			const uint64_t tag = m.varint();
+			if (tag == ((1u << 3) | 2u)) {
+				WireReader pos = m.sub();
+				while (!pos.done()) {
+					const uint64_t t = pos.varint();
+					if (t == (1u << 3)) mapping.nodeId = (int64_t)pos.varint();
+					else if (t == (2u << 3)) mapping.offset = (int64_t)pos.varint();
+					else if (t == (4u << 3)) mapping.isReverse = pos.varint() != 0;
+					else if (t == ((5u << 3) | 2u)) { WireReader nm = pos.sub(); mapping.name.assign((const char*)nm.p, (const char*)nm.end); }
+					else throw std::runtime_error("unexpected field in vg::Position bytes");
+				}
+			} else if (tag == ((2u << 3) | 2u)) {
+				WireReader e = m.sub();
+				VgEdit edit;
+				while (!e.done()) {
+					const uint64_t t = e.varint();
+					if (t == (1u << 3)) edit.fromLength = (int32_t)e.varint();
+					else if (t == (2u << 3)) edit.toLength = (int32_t)e.varint();
+					else if (t == ((3u << 3) | 2u)) { WireReader sq = e.sub(); edit.sequence.assign((const char*)sq.p, (const char*)sq.end); }
+					else throw std::runtime_error("unexpected field in vg::Edit bytes");
+				}
+				mapping.edits.push_back(edit);
+			} else if (tag == (5u << 3)) mapping.rank = (int64_t)m.varint();
+			else throw std::runtime_error("unexpected field in vg::Mapping bytes");
+		}
+		aln.mappings.push_back(mapping);
+	}
+	return aln;
+}
+
 std::string gamGroup(const std::vector<std::string>& messages)
 {
 	std::string raw;

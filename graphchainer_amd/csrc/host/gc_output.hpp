@@ -71,6 +71,20 @@ VgAlignment buildVgAlignment(const AlignmentGraph& graph, const std::string& rea
 std::string vgToJson(const VgAlignment& aln);
 // proto3 wire format of the message (what Alignment::SerializeToString writes, src/Aligner.cpp:273).
 std::string vgToProtobuf(const VgAlignment& aln);
+// An alignment whose trace walk ran on the device (hip/gc_output.hip): the GAF path and CIGAR columns as text, or its vg::Path in wire format, and the counts
+// the remaining columns / fields are made of. appendGafLine writes the line formatGafLine would (no newline); vgProtobufFromEncoded the message
+// vgToProtobuf(buildVgAlignment(...)) would; vgFromEncoded decodes the path bytes back into the struct (for the JSON printer).
+struct EncodedAlignment {
+	const char* path = nullptr; uint64_t pathLen = 0;
+	const char* cigar = nullptr; uint64_t cigarLen = 0;
+	const uint8_t* vgPath = nullptr; uint64_t vgPathLen = 0;
+	uint64_t nodePathLen = 0, nodePathStart = 0, nodePathEnd = 0, matches = 0, mismatches = 0, insertions = 0, deletions = 0, cells = 0, alignmentStart = 0, alignmentEnd = 0;
+	int32_t score = 0;
+};
+void appendGafLine(std::string& out, const std::string& readName, uint64_t readLength, const EncodedAlignment& a);
+std::string vgProtobufFromEncoded(const std::string& readName, const char* sequence, const EncodedAlignment& a);
+VgAlignment vgFromEncoded(const std::string& readName, const char* sequence, const EncodedAlignment& a);
+
 // One GAM group as writeGAMToQueue frames it (src/Aligner.cpp:261-281): varint64 message count, then per message varint32
 // size + bytes, the whole group one gzip member.
 std::string gamGroup(const std::vector<std::string>& messages);

@@ -78,6 +78,11 @@ typedef struct gc_params {
 	                             *    pair per traced read plus ~13 B of result memory per trace cell; with long_pass == 0 every read with a stitched
 	                             *    path counts as a winner (nothing to beat, src/Aligner.cpp:905), i.e. mode 1 then traces them all - pass 0 when
 	                             *    only anchors and chains are wanted. */
+	int32_t device_output;      /* r4: encode the final alignments on the device, where their traces already are, instead of bringing the traces down (keep_traces)
+	                             *    for gc_format_*: bit 0 (1) the GAF path and cg:Z: CIGAR text with = / X items, bit 1 (2) the same with M items
+	                             *    (--cigar-match-mismatch merge; give one of the two), bit 2 (4) the vg::Path wire bytes that gc_format_gam / _json wrap.
+	                             *    Fills gc_result::read_out_off / out_*; needs long_pass and edit_distances. (Sits in what used to be padding: the layout of the
+	                             *    other fields is unchanged.) */
 	double  e_cutoff;           /* --E-cutoff (src/AlignerMain.cpp:159,271-274; SelectECutoff src/AlignmentSelection.cpp:57-61,91-99):
 	                             *    alignments with a larger E-value are dropped before selection; -1 (default) keeps all */
 	gc_capacities capacity;     /* sizes of the device-side tables (all 0 = automatic: sized from the batch) */
@@ -227,6 +232,18 @@ typedef struct gc_result {
 	 * [5] whole-read pass wall clock, first group's start to last group's end (host clock; overlaps 1-3) */
 	double kernel_us[8];
 	double host_us[4];            /* wall time: [0] host seed glue, [1] result assembly, [2] seed lookup + transfers, [3] extension..chaining + transfers */
+	/* Final alignments encoded on the device (params->device_output; NULL otherwise): one entry per alignment the reference would write, in its order
+	 * (src/Aligner.cpp:901-920,1003-1023: the chained alignment when it won, else the selected whole-read alignments sorted by alignmentStart).
+	 * out_source[k] = 0: the pieces below hold it (GraphAlignerGAFAlignment::traceToAlignment / GraphAlignerVGAlignment::traceToAlignment run on the device);
+	 * 1: it is the read's chained alignment, whose trace the host builds (chain_trace_*): the gc_format_* functions encode it from there.
+	 * out_numbers[12 k ..]: node path length, start, end (GAF columns 7-9), matches, mismatches, insertions, deletions, trace cells (column 11), alignmentStart,
+	 * alignmentEnd, path steps (mappings), alignmentScore. */
+	uint64_t* read_out_off;       /* [n_reads+1] */
+	uint8_t*  out_source;         /* [n_out] */
+	uint64_t* out_numbers;        /* [12 * n_out] */
+	uint64_t* out_path_off;  char* out_path_text;     /* [n_out+1]; GAF column 6, e.g. ">12>13<7" (device_output & 3) */
+	uint64_t* out_cigar_off; char* out_cigar_text;    /* [n_out+1]; the cg:Z: value (device_output & 3) */
+	uint64_t* out_vg_off;    uint8_t* out_vg_path;    /* [n_out+1]; the alignment's vg::Path in proto3 wire format, src/vg.proto:52-109 (device_output & 4) */
 } gc_result;
 
 /* Runs seeding, fragment seed-extension, anchor construction and co-linear chaining (and, with
@@ -258,6 +275,7 @@ int gc_evalue(double min_identity, uint64_t database_size, uint64_t query_size, 
  * GraphAlignerGAFAlignment::traceToAlignment, src/GraphAlignerGAFAlignment.h:38-196; the per-read list sorted by
  * alignmentStart, src/Aligner.cpp:1022, written by writeGAFToQueue :300-311). `result` must come from gc_align_batch with
  * long_pass, keep_traces, edit_distances and chain_traces >= 1; bases/offsets are the read batch as given to gc_reads_upload;
+ * (or, r4, with device_output instead of keep_traces: the lines are then put together from the pieces the device wrote - no trace comes down);
  * read_names[i] is the FASTQ id. A read whose chained alignment won (chained_better) is written from its chain_trace_*
  * (src/Aligner.cpp:901-920); n_chained_skipped counts winners the result holds no trace for (0 unless chain_traces was 0).
  * *out_text is malloc'd (gc_free), NUL-terminated, *out_len bytes long. */
@@ -276,7 +294,7 @@ int gc_format_gam(const gc_graph* g, const gc_result* result, const char* const*
 
 int gc_device_count(void);
 int gc_set_device(int device);
-/* free / total bytes of the current device's memory (a host that sizes its batches: a 10 k x 10 kb batch in flight holds ~75 GB of scratch) */
+/* free / total bytes of the current device's memory (a host that sizes its batches: a 10 k x 10 kb batch in flight holds ~31 GB, beside the device's one shared whole-read scratch of up to 48 GB) */
 int gc_device_memory(uint64_t* free_bytes, uint64_t* total_bytes);
 
 #ifdef __cplusplus

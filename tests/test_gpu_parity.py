@@ -356,6 +356,12 @@ def test_gaf_output(gca, tmp_path, merge):
     assert got["gaf"] == want
     assert got["gaf"].count(b"\n") >= len(reads) - got["gaf_chained_skipped"] - 1
     assert b"cg:Z:" in got["gaf"]
+    # r4: the same lines put together from what the device wrote (k_out_encode: path and CIGAR text, the counts of the other columns) - no trace comes down
+    dev = gca.Aligner(graph, seeder, long_pass=True, device_output=2 if merge else 1)
+    got_dev = dev.align_reads(reads, gaf_names=[f"r{i}" for i in range(len(reads))], cigar_match_mismatch_merge=merge)
+    assert "long_trace_off" not in got_dev
+    assert got_dev["gaf"] == want
+    assert int(got_dev["read_out_off"][-1]) == want.count(b"\n")
 
 
 def test_chained_alignment_wins(gca, tmp_path):
@@ -403,6 +409,10 @@ def test_chained_alignment_wins(gca, tmp_path):
     assert raw["gaf"].count(b"\n") >= len(reads)
     import gzip
     assert gzip.decompress(raw["gam"])   # framed messages decode (content is checked against the JSON in test_json_and_gam_output)
+    # r4: with the output encoded on the device the winners' entries are marked for the host (their trace is built there), everything else comes as pieces
+    dev = gca.Aligner(graph, seeder, long_pass=True, device_output=1 | 4).align_reads(reads, gaf_names=names, other_formats=True)
+    assert dev["gaf"] == raw["gaf"] and dev["json"] == raw["json"] and gzip.decompress(dev["gam"]) == gzip.decompress(raw["gam"])
+    assert int(np.sum(dev["out_source"])) == int(np.sum(got["chained_better"]))
 
 
 def test_config5_shape(gca, tmp_path):
@@ -740,6 +750,12 @@ def test_json_and_gam_output(gca, tmp_path):
             assert msg.SerializeToString() == raw[at - size:at]          # canonical proto3 bytes, nothing unknown
             decoded.append(json_format.MessageToDict(msg, preserving_proto_field_name=True))
     assert decoded == objects
+    # r4: vg::Path bytes written by the device (gc_params::device_output & 4), wrapped by the host: the same inflated GAM stream byte for byte, the same JSON
+    dev = gca.Aligner(graph, seeder, long_pass=True, device_output=1 | 4)
+    got_dev = dev.align_reads(reads, gaf_names=[f"r{i}" for i in range(len(reads))], other_formats=True)
+    assert gzip.decompress(got_dev["gam"]) == raw
+    assert got_dev["json"] == got["json"]
+    assert got_dev["gaf"] == got["gaf"]
 
 
 def test_long_reads(gca, tmp_path, monkeypatch):
@@ -771,6 +787,12 @@ def test_output_against_golden_files(gca, golden_dir):
     assert out["json"] == open(os.path.join(golden_dir, "syn20k.expected.json"), "rb").read()
     merged = gca.Aligner(graph, seeder, keep_traces=True, long_pass=True).align_reads(reads, gaf_names=names, cigar_match_mismatch_merge=True)
     assert merged["gaf"] == open(os.path.join(golden_dir, "syn20k.expected.merged.gaf"), "rb").read()
+    # r4: encoded on the device
+    import gzip
+    dev = gca.Aligner(graph, seeder, long_pass=True, device_output=1 | 4).align_reads(reads, gaf_names=names, other_formats=True)
+    assert dev["gaf"] == out["gaf"] and dev["json"] == out["json"] and gzip.decompress(dev["gam"]) == gzip.decompress(out["gam"])
+    dev_merged = gca.Aligner(graph, seeder, long_pass=True, device_output=2).align_reads(reads, gaf_names=names, cigar_match_mismatch_merge=True)
+    assert dev_merged["gaf"] == merged["gaf"]
 
 
 @pytest.mark.parametrize("env,kw,host_expected", [
