@@ -60,6 +60,12 @@ def parse_args():
     ap.add_argument("--e2e-steps", type=int, default=int(os.environ.get("GC_BENCH_E2E_STEPS", 3)),
                     help="after the timed steps (N=1): this many steps with the read upload (gc_reads_upload) and the GAF encoding of every batch inside the step "
                          "(the whole boundary: host bases in, GAF text out); 0 skips it")
+    ap.add_argument("--e2e-formats", default=os.environ.get("GC_BENCH_E2E_FORMATS", "gaf,gam"), help="end-to-end legs to run: gaf, gam (comma separated)")
+    ap.add_argument("--sv-leg-steps", type=int, default=int(os.environ.get("GC_BENCH_SV_STEPS", 3)),
+                    help="after the timed steps (N=1, config 2): this many steps over reads of which 20 %% carry a 1.5 kb deletion - the reads whose chained alignment wins "
+                         "(k_edit_path, chained traces, the winners' output), with the oracle's summary of the first 1 000 for the parity check; 0 skips it")
+    ap.add_argument("--repeats-leg-steps", type=int, default=int(os.environ.get("GC_BENCH_REPEATS_STEPS", 3)),
+                    help="after that: this many steps on a second graph with pasted repeats (several seeds per fragment window), a quarter of the backbone; 0 skips it")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("GC_BENCH_INFLIGHT", 5)),
                     help="batches in flight per GPU, each on its own gc_stream and host thread (like the reference's -t worker threads): one batch's seeding, fragment "
                          "pipeline, distances and assembly run beside another's whole-read pass (r3, ms per 10 k x 10 kb batch: 1 -> 204, 2 -> 189, 3 -> 173, 4 -> 165, 5 -> 157, 6 -> 159; "
@@ -112,6 +118,24 @@ def usable_cpus():
     return max(1, n)
 
 
+# Host CPU a batch costs and the batch period by batches in flight (r3 measurements on this pool's boxes, 10 k x 10 kb: host_cpu_s_per_step and the --inflight sweep):
+# a rank keeps k batches in flight fed when it has HOST_CPU_S_PER_BATCH / period(k) CPUs to itself.
+HOST_CPU_S_PER_BATCH = 0.41
+BATCH_MS_BY_INFLIGHT = {1: 204.0, 2: 189.0, 3: 173.0, 4: 165.0, 5: 157.0}
+
+
+def choose_inflight(asked, cpus, world):
+    """Batches in flight per GPU from the CPU budget of a rank (usable CPUs / ranks): the largest count whose host work fits, at least 2 when that
+    leaves the host as the bound anyway (the second batch costs no more CPU per batch - its waits sleep - and lets host work overlap device work)."""
+    per_rank = cpus / max(1, world)
+    demand = lambda k: HOST_CPU_S_PER_BATCH / (BATCH_MS_BY_INFLIGHT[min(k, 5)] / 1e3)
+    fit = [k for k in range(1, asked + 1) if demand(k) <= per_rank]
+    chosen = max(fit) if fit else min(asked, 2)
+    why = (f"{chosen} in flight need {demand(chosen):.1f} CPUs of the {per_rank:.1f} a rank has ({cpus} usable / {world} ranks)" if fit else
+           f"host-bound: even one batch in flight needs {demand(1):.1f} CPUs and a rank has {per_rank:.1f} ({cpus} usable / {world} ranks); {chosen} in flight so that host work overlaps device work")
+    return chosen, {"asked": asked, "chosen": chosen, "cpus_per_rank": round(per_rank, 2), "cpu_demand_at_chosen": round(demand(chosen), 2), "why": why}
+
+
 def cpu_baseline_leg(args, gfa, reads, long_pass):
     """The CPU restatement (oracle/) timed on the host cores of this box, BEFORE this process touches the GPU: one thread on a
     bounded sample, then one worker per usable CPU (affinity mask and cgroup quota) over a shared read queue (the reference's -t model,
@@ -126,19 +150,30 @@ def cpu_baseline_leg(args, gfa, reads, long_pass):
     n_all = min(len(reads), max(n1, (20 if args.config == 5 else 250) * threads))   # ~10-15 s at the ~20 reads/s a core does (10 kb reads)
     # the same run keeps 12 values per read (chain, chain score, both NW distances, the decision, the whole-read alignments and the
     # selection): main() compares them with the timed GPU output after the timed region ("parity_check")
-    wall_all, _, summary = ora.align_summary(reads[:n_all], threads)
+    wall_all, _, summary = ora.align_summary(reads[:n_all], threads, gaf_hash=True)   # (13th column: the hash of the read's GAF lines, for the end-to-end leg)
+    extra = {}
+    for name, more in (getattr(args, "extra_cpu_reads", None) or {}).items():           # the same oracle over the first reads of the SV leg (same graph)
+        extra[name] = ora.align_summary(more, threads, gaf_hash=True)[2]
     ora.close()
+    for name, (other_gfa, more) in (getattr(args, "extra_cpu_graphs", None) or {}).items():   # and an oracle of its own for the leg on the graph with repeats
+        other = Oracle(other_gfa, long_pass=long_pass, split_gap=args.split_gap, colinear_gap=args.colinear_gap)
+        extra[name] = other.align_summary(more, threads, gaf_hash=True)[2]
+        other.close()
+    args.extra_cpu_summaries = extra
     stage_names = ["seeding", "whole_read_pass", "fragment_extension+anchors", "chaining", "stitching+edlib"]
     total = float(stage1.sum()) or 1.0
     return {"value": round(n_all / wall_all, 2), "unit": "reads/s", "cores": threads, "kind": "port",
             "sample": f"first {n_all} reads of the same workload, same stages, {threads} worker threads over a shared read queue, {wall_all:.1f} s; one thread: first {n1} reads, {wall1:.1f} s",
             "cpu_model": cpu_model(), "host_hardware_threads": os.cpu_count(), "usable_cpus": usable_cpus(),
             "single_thread_reads_per_s": round(n1 / wall1, 2),
+            "build": "g++ -O3; the restatement holds no assert() - the reference's assertions are restated as its throwing checks, which stay in - so an -DNDEBUG build is the same code (BASELINE.md §3 planned both figures)",
+            "includes_output": "the GAF lines of every read are formatted and hashed inside the timed loop (the reference writes its output in the worker, src/Aligner.cpp:1003-1049)",
             "single_thread_stage_share": {k: round(float(v) / total, 3) for k, v in zip(stage_names, stage1)}}, summary
 
 
 def main():
     args = parse_args()
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before anything touches HIP: a batch in flight uses a dozen streams, five batches share the device
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,10 +192,24 @@ def main():
         reads = sg.sample_reads(args.reads, args.read_len, seed=11 + (0 if strong else rank), p_del=0.04, p_sub=0.02, p_ins=0.09)
     else:
         sg = SynthGraph(args.backbone, seed=7)
-        sg.write_gfa(gfa)
+        if rank == 0:
+            sg.write_gfa(gfa)                              # only rank 0 builds from the GFA; the others load its index cache
         # weak scaling: every rank draws its own reads; strong scaling: all ranks draw the same set and the work queue divides it
         reads = sg.sample_reads(args.reads, args.read_len, seed=11 + (0 if strong else rank), sv_fraction=args.sv_fraction)
     t_gen = time.time() - t0
+    # two short legs after the headline (N=1, config 2, outside `value`): reads whose chained alignment wins, and a graph with repeats
+    legs = world == 1 and args.config == 2 and long_pass and not args.no_cpu_baseline
+    sv_reads = rep_reads = rep_gfa = None
+    if legs and args.sv_leg_steps > 0:
+        sv_reads = sg.sample_reads(args.reads, args.read_len, seed=13, sv_fraction=0.2)
+        args.extra_cpu_reads = {"sv": sv_reads[:1000]}
+    if legs and args.repeats_leg_steps > 0:
+        rep_sg = SynthGraph(max(2_000_000, args.backbone // 4), seed=9, repeats=600, repeat_len=3000)
+        rep_gfa = os.path.join(tmp, "repeats.gfa")
+        rep_sg.write_gfa(rep_gfa)
+        rep_reads = rep_sg.sample_reads(args.reads, args.read_len, seed=17)
+        args.extra_cpu_graphs = {"repeats": (rep_gfa, rep_reads[:1000])}
+        del rep_sg
 
     cpu_baseline = cpu_summary = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -177,14 +226,15 @@ def main():
     if world > 1 and "GC_HOST_THREADS" not in os.environ:
         # ranks share the host: split its cores between their worker pools (read by the library when it first loads)
         os.environ["GC_HOST_THREADS"] = str(max(4, min(96, 2 * usable_cpus() // world)))
-    if world > 1 and usable_cpus() < 6 * world:
-        # every batch in flight keeps two host threads waiting on the device; when the ranks together would spin on more CPUs than the
-        # host grants, let them sleep in the waits instead (GC_SPIN_SYNC=0) and keep one batch in flight per GPU
+    inflight_choice = None
+    if world > 1:
+        # ranks share the host's CPUs: the waits sleep between polls (GC_SPIN_SYNC=2, the library's default) and the number of batches in flight per GPU follows
+        # from what a batch costs the host (r3: 0.41 CPU-s per 10 k x 10 kb batch) - unless the caller chose
         os.environ.setdefault("GC_SPIN_SYNC", "2")
         if "GC_BENCH_INFLIGHT" not in os.environ and not any(a.startswith("--inflight") for a in sys.argv[1:]):
-            args.inflight = 1
+            args.inflight, inflight_choice = choose_inflight(max(1, args.inflight), usable_cpus(), world)
     import graphchainer_amd as gca
-    from graphchainer_amd.workqueue import SUMMARY_FIELDS, ReadQueue, length_sorted_batches, read_summary, run_queue
+    from graphchainer_amd.workqueue import SUMMARY_FIELDS, ReadQueue, gaf_read_hashes, length_sorted_batches, read_summary, run_queue
 
     if gca.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -279,61 +329,131 @@ def main():
             list(warm.map(lambda i: [aligners[i].align_batch(batches[(item + rank) % len(batches)]) and None for item in range(i, n_items, inflight)], range(inflight)))
     sync()
     cpu_start = cpu_seconds()
+    rank_cpu_start = time.process_time()
     t_start = time.perf_counter()
     outs = run_steps(args.steps)
     sync()
     elapsed = time.perf_counter() - t_start
     host_cpu_s = cpu_seconds() - cpu_start
+    rank_cpu_s = time.process_time() - rank_cpu_start               # this rank's process alone (the cgroup figure above is the whole container's)
     mem_free_end, _ = gca.device_memory()
     # Parity of the timed mode (src/Aligner.cpp:630-654,735,901-905): the reads the CPU leg aligned with the oracle are compared, value
     # for value, with what EVERY timed batch returned for them - chain, chain score, both NW distances, the decision, the whole-read
     # alignments and the selection. Outside the timed region; a mismatch fails the run.
-    parity_check = None
-    if cpu_summary is not None:
+    def summary_check(results, chunk_list, summary):
+        """results: [(item, (batch index, out))] as run_queue returns them; summary: the oracle's rows for the first reads of the set the chunks index"""
         mismatches, checked, fields_bad = 0, 0, {}
-        for _item, (b, out) in outs:
-            original = np.asarray(chunks[b], dtype=np.int64)
-            rows = np.nonzero(original < len(cpu_summary))[0]
+        for _item, (b, out) in results:
+            original = np.asarray(chunk_list[b], dtype=np.int64)
+            rows = np.nonzero(original < len(summary))[0]
             if not len(rows):
                 continue
             got = read_summary(out)[rows]
-            bad = got != cpu_summary[original[rows]]
+            bad = got != summary[original[rows], :12]
             checked += len(rows)
             mismatches += int(bad.any(axis=1).sum())
             for k in np.nonzero(bad.any(axis=0))[0]:
                 fields_bad[SUMMARY_FIELDS[k]] = fields_bad.get(SUMMARY_FIELDS[k], 0) + int(bad[:, k].sum())
-        parity_check = {"reads": int(len(cpu_summary)), "timed_batches_checked": len(outs), "read_results_compared": checked, "mismatches": mismatches,
-                        "fields": "anchors, chain, chain score, whole-read and chain NW distance, chained_better, whole-read alignments (start, end, score), selection, failed_assertion",
-                        "against": "oracle (CPU leg of this run), same reads"}
+        rec = {"reads": int(len(summary)), "timed_batches_checked": len(results), "read_results_compared": checked, "mismatches": mismatches,
+               "fields": "anchors, chain, chain score, whole-read and chain NW distance, chained_better, whole-read alignments (start, end, score), selection, failed_assertion",
+               "against": "oracle (CPU leg of this run), same reads"}
         if mismatches:
-            parity_check["fields_with_mismatches"] = fields_bad
-    # End to end (outside the headline figure): host bases in, GAF text out - gc_reads_upload, the hot path with the traces kept for the
-    # writer, and gc_format_gaf of every batch inside the step, `inflight` batches overlapping as in the timed region (src/Aligner.cpp:261-311).
+            rec["fields_with_mismatches"] = fields_bad
+        return rec
+
+    def gaf_check(text, out, chunk, summary):
+        """(reads compared, reads whose GAF lines differ from the oracle's): the text gc_format_gaf returned for a batch against the 13th column of the CPU leg's summary"""
+        original = np.asarray(chunk, dtype=np.int64)
+        rows = np.nonzero(original < len(summary))[0]
+        if not len(rows):
+            return 0, 0
+        hashes = gaf_read_hashes(text, np.diff(np.asarray(out["read_out_off"]).astype(np.int64)))
+        return len(rows), int((hashes[rows] != summary[original[rows], 12]).sum())
+
+    parity_check = summary_check(outs, chunks, cpu_summary) if cpu_summary is not None else None
+    failures = []
+    if parity_check is not None and parity_check["mismatches"]:
+        failures.append(f"parity check failed: {parity_check['mismatches']} of {parity_check['read_results_compared']} timed read results differ from the oracle")
+
+    # End to end (outside the headline figure): host bases in, GAF text / GAM bytes out - gc_reads_upload, the hot path with the final alignments encoded on the
+    # device (gc_params::device_output: no trace comes down), and gc_format_gaf / gc_format_gam of every batch inside the step, `inflight` batches overlapping
+    # as in the timed region (src/Aligner.cpp:261-311). The GAF leg's text is compared with the oracle's, read by read (hash of its lines).
     e2e = None
     if world == 1 and args.e2e_steps > 0 and long_pass:
-        e2e_aligners = aligners                                   # the same gc_streams (a third and fourth would not fit the HBM beside them)
-        for a in e2e_aligners:
-            a.params.keep_traces = 2                               # the alignments' traces (what the writer reads), not the anchors'
+        e2e = {}
         names = [[f"read{i}" for i in idx] for idx in chunks]
+        for fmt in [f for f in args.e2e_formats.split(",") if f in ("gaf", "gam")]:
+            for a in aligners:
+                a.params.device_output = 1 if fmt == "gaf" else 4
+            kept, checking = {}, [True]
 
-        def e2e_item(worker, item):
-            b = item % len(chunks)
-            batch = gca.ReadBatch([reads[i] for i in chunks[b]])
-            out = e2e_aligners[worker].align_batch(batch, gaf_names=names[b])
-            n_bytes, skipped = len(out["gaf"]), out["gaf_chained_skipped"]
-            batch.close()
-            return n_bytes, skipped
-        queue.reset(max(inflight, 1) * len(chunks))
-        run_queue(queue, e2e_item, inflight)                      # first-batch allocations of the new streams
-        queue.reset(args.e2e_steps * len(chunks))
+            def e2e_item(worker, item, fmt=fmt, kept=kept, checking=checking):
+                b = item % len(chunks)
+                batch = gca.ReadBatch([reads[i] for i in chunks[b]])
+                out = aligners[worker].align_batch(batch, gaf_names=names[b], formats=(fmt,))
+                n_bytes, skipped = len(out[fmt]), out["gaf_chained_skipped"]
+                if checking[0] and fmt == "gaf" and cpu_summary is not None:
+                    kept[item] = gaf_check(out["gaf"], out, chunks[b], cpu_summary)
+                batch.close()
+                return n_bytes, skipped
+            queue.reset(max(inflight, 1) * len(chunks))
+            run_queue(queue, e2e_item, inflight)                      # first-batch allocations of the encoder's buffers; these batches' text is what the check reads
+            checking[0] = False                                       # (the same `inflight` batches overlapping as in the timed steps, the hashing kept out of the timing)
+            queue.reset(args.e2e_steps * len(chunks))
+            cpu0 = cpu_seconds()
+            t0 = time.perf_counter()
+            done = run_queue(queue, e2e_item, inflight)
+            dt = time.perf_counter() - t0
+            rec = {"reads_per_s": round(args.e2e_steps * len(reads) / dt, 2), "ms_per_step": round(dt / args.e2e_steps * 1e3, 2), "steps": args.e2e_steps,
+                   "host_cpu_s_per_step": round((cpu_seconds() - cpu0) / args.e2e_steps, 3),
+                   "bytes_per_step": int(sum(n for _i, (n, _s) in done) / args.e2e_steps), "chained_winners_without_trace": int(sum(s for _i, (_n, s) in done)),
+                   "includes": f"gc_reads_upload (PCIe + packing kernels) + hot path + output encoding on the device (k_out_encode) + gc_format_{fmt} of every batch"}
+            if fmt == "gaf" and kept:
+                compared, bad = sum(c for c, _ in kept.values()), sum(m for _, m in kept.values())
+                rec["gaf_check"] = {"reads_compared": compared, "reads_with_different_lines": bad, "against": "the oracle's GAF lines of the same reads (hash per read, CPU leg of this run)"}
+                if bad:
+                    failures.append(f"end-to-end GAF check failed: the lines of {bad} of {compared} reads differ from the oracle's")
+            e2e[fmt] = rec
+        for a in aligners:
+            a.params.device_output = 0
+        if "gaf" in e2e:                                              # (the r3 line's keys, for the GAF leg)
+            e2e.update({k: e2e["gaf"][k] for k in ("reads_per_s", "ms_per_step", "steps", "host_cpu_s_per_step")})
+
+    # The chained branch under the driver (VERDICT r3 item 4): the same graph, reads of which 20 % carry a 1.5 kb deletion - k_edit_path, the chained traces and the
+    # winners' output run - a few steps with every batch compared with the oracle's summary of the first 1 000 reads, then one batch written as GAF and compared line by line
+    def side_leg(leg_reads, leg_aligners, summary, steps, label):
+        leg_chunks = length_sorted_batches(leg_reads, args.batch)
+        leg_batches = [gca.ReadBatch([leg_reads[i] for i in idx]) for idx in leg_chunks]
+        n_streams = len(leg_aligners)
+        leg_queue = ReadQueue(len(leg_batches), 0, 1, None)
+        run = lambda count: (leg_queue.reset(count * len(leg_batches)), run_queue(leg_queue, lambda i, item: (item % len(leg_batches), leg_aligners[i].align_batch(leg_batches[item % len(leg_batches)])), n_streams))[1]
+        run(n_streams)                                                # every stream once: buffers sized for these reads
         t0 = time.perf_counter()
-        done = run_queue(queue, e2e_item, inflight)
+        leg_outs = run(steps)
         dt = time.perf_counter() - t0
-        e2e = {"reads_per_s": round(args.e2e_steps * len(reads) / dt, 2), "ms_per_step": round(dt / args.e2e_steps * 1e3, 2), "steps": args.e2e_steps,
-               "gaf_bytes_per_step": int(sum(n for _i, (n, _s) in done) / args.e2e_steps), "chained_winners_without_trace": int(sum(s for _i, (_n, s) in done)),
-               "includes": "gc_reads_upload (PCIe + packing kernels) + hot path with traces kept + gc_format_gaf of every batch"}
-        for a in e2e_aligners:
-            a.params.keep_traces = 0
+        rec = {"reads_per_s": round(steps * len(leg_reads) / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "batches_in_flight": n_streams,
+               "chained_better": int(sum(int(np.sum(o["chained_better"])) for _i, (_b, o) in leg_outs) / steps),
+               "seeds_extended_per_read_fragment_pass": round(float(np.mean(np.concatenate([np.asarray(o["seeds_extended"], dtype=np.float64) for _i, (_b, o) in leg_outs]))), 1),
+               "parity_check": summary_check(leg_outs, leg_chunks, summary)}
+        if rec["parity_check"]["mismatches"]:
+            failures.append(f"{label}: {rec['parity_check']['mismatches']} read results differ from the oracle")
+        leg_aligners[0].params.device_output = 1
+        out = leg_aligners[0].align_batch(leg_batches[0], gaf_names=[f"read{i}" for i in leg_chunks[0]], formats=("gaf",))
+        leg_aligners[0].params.device_output = 0
+        compared, bad = gaf_check(out["gaf"], out, leg_chunks[0], summary)
+        rec["gaf_check"] = {"reads_compared": compared, "reads_with_different_lines": bad, "chained_winners_without_trace": int(out["gaf_chained_skipped"])}
+        if bad:
+            failures.append(f"{label}: the GAF lines of {bad} of {compared} reads differ from the oracle's")
+        for b in leg_batches:
+            b.close()
+        leg_queue.close()
+        return rec
+
+    extra = getattr(args, "extra_cpu_summaries", {})
+    sv_leg = repeats_leg = None
+    if sv_reads is not None and "sv" in extra:
+        sv_leg = side_leg(sv_reads, aligners, extra["sv"], args.sv_leg_steps, "sv leg")
+        sv_leg["workload"] = f"{len(sv_reads)} x {args.read_len} bp reads on the same graph, 20 % with a 1.5 kb deletion the graph does not hold"
     kernel_us = np.zeros(8)
     host_us = np.zeros(4)
     counters = np.zeros(8, dtype=np.float64)
@@ -355,6 +475,13 @@ def main():
         long_ed.append(out["long_edit_distance"][out["long_edit_distance"] >= 0].astype(np.float64))
         chain_ed.append(out["chain_edit_distance"][out["chain_edit_distance"] >= 0].astype(np.float64))
         seeds_ext_long.append(np.asarray(out["seeds_extended_long"], dtype=np.float64))
+    per_rank = None
+    if dist is not None:
+        mine = {"rank": rank, "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 2), "host_cpu_s_per_step": round(rank_cpu_s / max(1, args.steps), 3),
+                "reads": int(reads_done), "batches_in_flight": inflight}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered                                         # (a host-bound curve shows here: CPU seconds per step against the step time, rank by rank)
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -408,6 +535,27 @@ def main():
     if args.config == 2 and args.reads == 10_000:
         roofline["traffic"], roofline["traffic_source"] = measured_traffic(roofline["kernel"], roofline["launches_per_step"])
 
+    graph_nodes = graph.NodeSize()
+    if rep_reads is not None and "repeats" in extra:
+        # a second graph (pasted repeats: several seeds per fragment window, clusters to order): this run's streams and graph go first - HBM holds one set
+        for a in aligners:
+            a.close()
+        for b in batches:
+            b.close()
+        seeder.close()
+        graph.close()
+        t0 = time.time()
+        rep_graph = gca.AlignmentGraph(rep_gfa)
+        rep_seeder = gca.MinimizerSeeder(rep_graph)
+        rep_setup = time.time() - t0
+        rep_aligners = [gca.Aligner(rep_graph, rep_seeder, split_gap=args.split_gap, colinear_gap=args.colinear_gap, long_pass=long_pass) for _ in range(min(inflight, 3))]
+        repeats_leg = side_leg(rep_reads, rep_aligners, extra["repeats"], args.repeats_leg_steps, "repeats leg")
+        repeats_leg["workload"] = f"{len(rep_reads)} x {args.read_len} bp reads on a {max(2_000_000, args.backbone // 4)} bp backbone with 600 pasted 3 kb repeats ({rep_graph.NodeSize()} split nodes); set-up {rep_setup:.1f} s"
+        for a in rep_aligners:
+            a.close()
+        rep_seeder.close()
+        rep_graph.close()
+
     if rank == 0:
         cat = lambda parts: np.concatenate(parts) if parts else np.zeros(0)
         long_ed, chain_ed, seeds_ext_long = cat(long_ed), cat(chain_ed), cat(seeds_ext_long)
@@ -416,8 +564,8 @@ def main():
             "ms_per_step": round(elapsed / steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "gbp_per_sec_aligned": round(gbp_per_s, 5),
-            "config": {"workload": (f"BASELINE configs[4] sized for one GPU: {args.chromosomes} chromosome graphs x {args.backbone} bp ({graph.NodeSize()} split nodes, {2 * args.chromosomes} components), CLR-like errors, colinear_gap {args.colinear_gap}, " if args.config == 5 else
-                                    f"BASELINE configs[{args.config - 1}]: chr22-like synthetic DAG ({args.backbone} bp backbone, {graph.NodeSize()} split nodes), ")
+            "config": {"workload": (f"BASELINE configs[4] sized for one GPU: {args.chromosomes} chromosome graphs x {args.backbone} bp ({graph_nodes} split nodes, {2 * args.chromosomes} components), CLR-like errors, colinear_gap {args.colinear_gap}, " if args.config == 5 else
+                                    f"BASELINE configs[{args.config - 1}]: chr22-like synthetic DAG ({args.backbone} bp backbone, {graph_nodes} split nodes), ")
                                    + f"{args.reads} x {args.read_len} bp {'CLR' if args.config == 5 else 'ONT'}-like reads {'in total' if strong else 'per GPU'} in batches of {args.batch}, split_len 35 split_gap {args.split_gap} bandwidth 10"
                                    + (f", {args.sv_fraction:.0%} of the reads with a 1.5 kb deletion" if args.sv_fraction > 0 else ""),
                        "stages": ("whole-read GraphAligner pass + selection + " if long_pass else "") + "seed lookup + seed ordering + fragment seed-extension + anchors + co-linear chaining + chain stitching + NW edit distances + chained-vs-whole-read decision + chained alignment trace (edlib path) for its winners",
@@ -428,6 +576,10 @@ def main():
             "cpu_baseline": cpu_baseline,
             "parity_check": parity_check,
             "e2e": e2e,
+            "sv_leg": sv_leg,
+            "repeats_leg": repeats_leg,
+            "inflight_choice": inflight_choice,
+            "per_rank": per_rank,
             # inputs are resident before the timed region; what putting them there costs (host-side packing + PCIe), and the rate with it included
             "reads_upload": {"ms_per_step": round(upload_s * 1e3, 2), "bases": total_bases, "reads_per_s_including_upload": round(reads_total / (elapsed + upload_s * steps * (1 if not strong else 1)), 2)},
             "host_cpu_s_per_step": round(host_cpu_s / max(1, args.steps), 3),   # CPU time the container spent per step (all threads, this rank's box)
@@ -448,8 +600,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if parity_check is not None and parity_check["mismatches"]:
-        raise SystemExit(f"parity check failed: {parity_check['mismatches']} of {parity_check['read_results_compared']} timed read results differ from the oracle")
+    if failures:
+        raise SystemExit("; ".join(failures))
 
 
 if __name__ == "__main__":

@@ -36,8 +36,15 @@ struct DeviceError : std::runtime_error { using std::runtime_error::runtime_erro
 // run one after the other. A batch in flight uses a dozen streams (fragment pipeline, whole-read rounds, edit-distance classes), two batches
 // twice that: on 4 queues the whole-read pass's rounds wait behind the other batch's k_extend / k_chain / k_stitch (kernel trace: 60 ms of
 // foreign kernels between two rounds). 16 queues: 228 -> 209 ms per batch on cfg2; 32 oversubscribe the command processor (290 ms).
-// Set when the library is loaded - before the HIP runtime reads its flags at the first HIP call - and only if the user has not chosen.
-__attribute__((constructor)) static void gcDefaultHardwareQueues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// The HIP runtime reads the variable at its first call and it configures the whole process, so it is the HOST's to set (bench.py and the
+// scripts set GPU_MAX_HW_QUEUES=16 before anything touches HIP); the library only says so, once, when a second stream is created without it.
+static void noteHardwareQueues(int streamsAlive)
+{
+	static std::atomic<bool> said { false };
+	const char* e = getenv("GPU_MAX_HW_QUEUES");
+	if (streamsAlive >= 2 && (!e || atoi(e) < 8) && !said.exchange(true))
+		fprintf(stderr, "[graphchainer_amd] note: GPU_MAX_HW_QUEUES is %s; with several gc_streams per device set it to 16 before the process's first HIP call (INTEGRATION.md §7), or batches in flight serialise on HIP's 4 default hardware queues\n", e ? e : "unset");
+}
 
 namespace {
 
@@ -268,9 +275,16 @@ struct ResultBlockCache {
 		}
 		free(base);
 	}
-	~ResultBlockCache() { for (auto& b : blocks) free(b.first); }
+	void trim()   // gives every held block back to the allocator (gc_result_cache_trim)
+	{
+		std::lock_guard<std::mutex> lock(mutex);
+		for (auto& b : blocks) free(b.first);
+		blocks.clear();
+		held = 0;
+	}
 };
-ResultBlockCache g_resultBlocks;
+// deliberately never destroyed: a language runtime's finalizers may still call gc_result_free while the process's static destructors run
+ResultBlockCache& g_resultBlocks = *new ResultBlockCache();
 template <typename T> T* resultArray(size_t n) { return (T*)g_resultBlocks.get(std::max<size_t>(n, 1) * sizeof(T)); }
 
 } // namespace
@@ -381,6 +395,9 @@ struct EditDistanceRun {
 };
 
 static const int LONG_EVENT_RING = 8;
+#ifndef GC_LONG_PLAN_DEFAULT
+#define GC_LONG_PLAN_DEFAULT "1"   // candidates per read and round of the whole-read pass (GC_LONG_PLAN; see runLongGroup)
+#endif
 struct gc_stream {
 	std::vector<ReadGlue> glue;   // per-read host records of the batch in flight (storage reused)
 	int device = 0;             // the device the stream was created on; gc_align_batch selects it for the calling thread
@@ -984,6 +1001,9 @@ int gc_format_gam(const gc_graph* G, const gc_result* r, const char* const* read
 	return formatBatch(G, r, read_names, bases, offsets, OUT_GAM, 0, out_bytes, out_len, n_chained_skipped);
 }
 
+// gc_result_free keeps the large arrays of freed results (up to 24 GB) for the next batch instead of returning them to the allocator; this returns them.
+void gc_result_cache_trim(void) { g_resultBlocks.trim(); }
+
 int gc_device_count(void)
 {
 	int n = 0;
@@ -1378,6 +1398,7 @@ int gc_stream_create(gc_stream** out)
 	int rc = guarded([&]() {
 		requireDevice();
 		HIP_CHECK(hipGetDevice(&st->device));
+		if (st->device < 0 || st->device >= 16) throw std::runtime_error("gc_stream_create: device index beyond the 16 per-device slots of the whole-read token and scratch");
 		createStream(&st->stream, 0);       // non-blocking: uploads of another batch on the null stream do not serialise with this one
 		createStream(&st->longStream, 0);
 		for (auto& e : st->ev) HIP_CHECK(hipEventCreate(&e));
@@ -1385,7 +1406,7 @@ int gc_stream_create(gc_stream** out)
 		return (int)GC_OK;
 	});
 	if (rc != GC_OK) { delete st; return rc; }
-	{ std::lock_guard<std::mutex> lock(g_longScratchCount); g_longScratch[st->device & 15].streams++; }
+	{ std::lock_guard<std::mutex> lock(g_longScratchCount); noteHardwareQueues(++g_longScratch[st->device & 15].streams); }
 	*out = st;
 	return GC_OK;
 }
@@ -1931,6 +1952,16 @@ struct BatchRun {
 			// at most lastWork/2 reads are still active, so this keeps the round within the work arrays (8 per read) and the trace budget (4 seeds' worth per read)
 			if (round > 0 && lastWork > 0) maxCand = (uint32_t)std::min<uint64_t>(maxCand, std::max<uint64_t>(1, (8 * nG) / lastWork));
 			if (const char* env = getenv("GC_LONG_SPECULATE")) maxCand = (uint32_t)std::min(2, std::max(1, atoi(env)));   // test hook: speculate from round 0
+			// speculation plan (r4): candidates per read in rounds 0, 1, 2, ... (the last entry repeats), a floor under the rule above; still bounded by the work arrays
+			// and the trace budget (at most nG / 2... reads x candidates <= 4 nG). Why: rounds 3-5 of cfg2 hold fewer work items than the chip has wave slots and cost one
+			// extension's latency (~17 ms) each - 98 % of the reads extend a second seed and 81 % a third, so asking for two seeds per read from round 0 on
+			// merges rounds at a few per cent of wasted extensions (k_long_merge drops a candidate that an alignment accepted before it explains).
+			{
+				static const std::vector<int> plan = []() { std::vector<int> v; const char* e = getenv("GC_LONG_PLAN"); std::string t = e ? e : GC_LONG_PLAN_DEFAULT; size_t at = 0; while (at < t.size()) { v.push_back(std::max(1, std::min(8, atoi(t.c_str() + at)))); size_t c = t.find(',', at); if (c == std::string::npos) break; at = c + 1; } if (v.empty()) v.push_back(1); return v; }();
+				const uint32_t floorCand = (uint32_t)plan[std::min<size_t>((size_t)round, plan.size() - 1)];
+				const uint64_t active = round == 0 ? nG : std::max<uint64_t>(1, std::min<uint64_t>(nG, lastWork / 2));
+				if (!getenv("GC_LONG_SPECULATE")) maxCand = (uint32_t)std::min<uint64_t>(std::max(maxCand, floorCand), std::max<uint64_t>(1, (4 * nG) / active));
+			}
 			launchLongSelect(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, R->totalBases, (uint32_t)P->min_cluster_size, maxCand, dLongState + r0, dLongAlns, dLongCells, dLongWork + w0, dWorkLen + w0, dCandSeed + w0, cursor, capacity);
 			{
 				// execution order: longest extensions first, so the round's tail is made of short ones (GC_LONG_ORDER=0: as emitted)
@@ -2194,10 +2225,11 @@ struct BatchRun {
 			HIP_CHECK(hipGetDevice(&device));
 			for (uint32_t g = 0; g < longGroups; g++)
 				longThreads.emplace_back([&, device, g]() {
+					// (declared outside the try block: on an exception the catch below waits for the pass's kernels BEFORE the token - and with it the device's shared scratch - is released)
+					std::unique_lock<std::mutex> token(g_longPassToken[device & 15], std::defer_lock);
 					try {
 						HIP_CHECK(hipSetDevice(device));
 						const int tokenMode = getenv("GC_LONG_TOKEN") ? atoi(getenv("GC_LONG_TOKEN")) : 1;   // 0 none, 1 one pass at a time, 2 one round's extension kernel at a time
-						std::unique_lock<std::mutex> token(g_longPassToken[device & 15], std::defer_lock);
 						const double tTokenAsk = nowUs();
 						if (tokenMode == 1 && longGroups == 1) token.lock();
 						if (shareLongScratch && tokenMode == 1) {
@@ -2212,7 +2244,12 @@ struct BatchRun {
 						if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc token] stream %p released %.1f\n", (void*)st, nowUs() / 1e3);
 						if (token.owns_lock()) token.unlock();   // the next batch's pass may start; what follows is this batch's own tail
 						if (longPostInThread) afterLongPass();
-					} catch (...) { longErrors[g] = std::current_exception(); }
+					} catch (...) {
+						longErrors[g] = std::current_exception();
+						// the token is released when this lambda returns: a kernel of this pass may still be writing to the shared scratch
+						if (g < st->groupStreams.size()) (void)hipStreamSynchronize(st->groupStreams[g]);
+						(void)hipStreamSynchronize(st->longStream);
+					}
 				});
 		}
 	}
@@ -2346,7 +2383,8 @@ struct BatchRun {
 		// for) run again in a small grid with 16x the room; lanes whose items are fine only read the status array. What overflows even
 		// that is flagged per read (capacity_exceeded), never a failed call.
 		ExtendConfig big = cfg;
-		big.maxItems = 16 * cfg.maxItems; big.maxPending = 16 * cfg.maxPending; big.maxTrace = 16 * cfg.maxTrace; big.maxSlices = cfg.maxSlices;
+		auto times16 = [](uint32_t v) { return (uint32_t)std::min<uint64_t>(16ull * v, 0xffffffffull); };   // (saturating: the GC_EXT_* variables are not range-checked like gc_params::capacity)
+		big.maxItems = times16(cfg.maxItems); big.maxPending = times16(cfg.maxPending); big.maxTrace = times16(cfg.maxTrace); big.maxSlices = cfg.maxSlices;
 		if (const char* env = getenv("GC_EXT_RETRY_MAX_ITEMS")) big.maxItems = (uint32_t)std::max(8, atoi(env));   // test hook: make the retry overflow too
 		const uint32_t retryLanes = 2048;
 		uint8_t* dRetryScratch = st->scratchRetry.reserve<uint8_t>((uint64_t)retryLanes * extendSlabBytes(big));
@@ -3027,6 +3065,11 @@ int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const g
 		if (c.reserved[0] || c.reserved[1] || c.reserved[2]) return fail(GC_ERR_INVALID, "gc_params::capacity.reserved must be 0 (was the struct initialised with gc_params_default?)");
 		const int64_t v[] = { c.ext_max_items, c.ext_max_pending, c.ext_max_trace, c.long_max_items, c.long_cells_per_base, c.long_scratch_bytes, c.stitch_set_max, c.stitch_bfs_cap };
 		for (int64_t x : v) if (x < 0 || x > (1ll << 40)) return fail(GC_ERR_INVALID, "gc_params::capacity: a size is negative or absurd (0 = automatic)");
+		// what the consumers can hold: the tables are indexed with 32 bits, and the retry launch takes 16x the fragment sizes
+		if (c.ext_max_items > (1ll << 24) || c.ext_max_pending > (1ll << 24) || c.ext_max_trace > (1ll << 24)) return fail(GC_ERR_INVALID, "gc_params::capacity.ext_*: at most 2^24 (the retry launch reserves 16x)");
+		if (c.long_max_items > (1ll << 28)) return fail(GC_ERR_INVALID, "gc_params::capacity.long_max_items: at most 2^28");
+		if (c.long_cells_per_base > 4096) return fail(GC_ERR_INVALID, "gc_params::capacity.long_cells_per_base: at most 4096");
+		if (c.stitch_set_max > (1ll << 31) - 1 || c.stitch_bfs_cap > (1ll << 31) - 1) return fail(GC_ERR_INVALID, "gc_params::capacity.stitch_*: at most 2^31 - 1");
 		if (c.long_column_store < -1 || c.long_column_store > (1ll << 31)) return fail(GC_ERR_INVALID, "gc_params::capacity.long_column_store: -1 (none), 0 (automatic) or a column count");
 	}
 	if (P->device_output < 0 || P->device_output > 7 || (P->device_output & 3) == 3) return fail(GC_ERR_INVALID, "gc_params::device_output: 1 or 2 (GAF pieces with = / X or with M), optionally + 4 (vg::Path bytes)");

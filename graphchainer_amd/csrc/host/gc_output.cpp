@@ -81,7 +81,7 @@ std::string formatGafLine(const AlignmentGraph& graph, const std::string& readNa
 	auto addNode = [&](int nodeId) {
 		nodePath += (nodeId % 2) == 1 ? '<' : '>';
 		std::string name = graph.OriginalNodeName(nodeId);
-		if (name.empty()) { if (nodeId < 0) { nodePath += '-'; appendUint(nodePath, (uint64_t)(-(int64_t)(nodeId / 2))); } else appendUint(nodePath, (uint64_t)(nodeId / 2)); } else nodePath += name;
+		if (name.empty()) { const int64_t half = (int64_t)(nodeId / 2); if (half < 0) { nodePath += '-'; appendUint(nodePath, (uint64_t)(-half)); } else appendUint(nodePath, (uint64_t)half); } else nodePath += name;   // (`stream << nodeId / 2`)
 	};
 	const uint64_t readStart = trace.seqPos[0], readEnd = (uint64_t)trace.seqPos[trace.size - 1] + 1;
 	uint64_t nodePathLen = 0, matches = 0, mismatches = 0, deletions = 0, insertions = 0, editLength = 1;

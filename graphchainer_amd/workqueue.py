@@ -147,6 +147,28 @@ def _list_hash(values, offsets):
         return (csum[offsets[1:]] - csum[offsets[:-1]]).view(np.int64)
 
 
+def gaf_read_hashes(text, lines_per_read):
+    """Per read the hash of its GAF lines as the CPU leg's summary holds it (oracle: gco_align_summary2): every line from its first TAB to its
+    newline (the read name left out), line hash = list hash of the bytes, read hash = list hash of its lines' hashes. `text` = what
+    gc_format_gaf returned for a batch, lines_per_read[r] = final alignments of read r (its lines are consecutive, reads in batch order)."""
+    lines_per_read = np.asarray(lines_per_read, dtype=np.int64)
+    a = np.frombuffer(text, dtype=np.uint8)
+    nl = np.flatnonzero(a == 10)
+    if len(nl) != int(lines_per_read.sum()):
+        raise ValueError(f"GAF text has {len(nl)} lines, the result says {int(lines_per_read.sum())}")
+    read_off = np.concatenate([np.zeros(1, dtype=np.int64), np.cumsum(lines_per_read)])
+    if len(nl) == 0:
+        return np.zeros(len(lines_per_read), dtype=np.int64)
+    starts = np.concatenate([np.zeros(1, dtype=np.int64), nl[:-1] + 1])
+    tabs = np.flatnonzero(a == 9)
+    first_tab = tabs[np.searchsorted(tabs, starts)]
+    seg_len = nl - first_tab + 1
+    seg_off = np.concatenate([np.zeros(1, dtype=np.int64), np.cumsum(seg_len)])
+    idx = np.repeat(first_tab - seg_off[:-1], seg_len) + np.arange(int(seg_off[-1]), dtype=np.int64)
+    line_hash = _list_hash(a[idx], seg_off)
+    return _list_hash(line_hash, read_off)
+
+
 def read_summary(out):
     """[n, 12] int64: SUMMARY_FIELDS of every read of a batch result (a dict as Aligner.align_batch returns it; the selected whole-read
     alignments either as `long_index` into the read's alignment list or as `long_start/end/score`). The chain and alignment lists enter

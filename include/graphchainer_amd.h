@@ -252,6 +252,10 @@ typedef struct gc_result {
 int gc_align_batch(const gc_graph* g, const gc_seeder* s, gc_stream* st, const gc_reads* reads, const gc_params* params, gc_result** out);
 void gc_result_free(gc_result* r);
 
+/* gc_result_free keeps the large arrays of freed results (trace cells, output text: up to 24 GB in all) for the next batch's result - fresh memory of that size is
+ * mapped and zero-filled page by page every batch otherwise; gc_result_cache_trim gives what is held back to the allocator (e.g. when a host stops aligning). */
+void gc_result_cache_trim(void);
+
 const char* gc_last_error(void);
 void gc_free(void* p);
 /* Global (NW) edit distance of each pair (a[a_off[i]..a_off[i+1]), b[b_off[i]..b_off[i+1])) on the GPU: the value

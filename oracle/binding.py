@@ -55,6 +55,8 @@ def load_oracle_lib():
     lib.gco_align_timed.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.gco_align_summary.restype = C.c_double
     lib.gco_align_summary.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.gco_align_summary2.restype = C.c_double
+    lib.gco_align_summary2.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
 
 
@@ -137,15 +139,19 @@ class Oracle:
     SUMMARY_FIELDS = ["anchors", "chain_len", "chain_hash", "chain_score", "long_edit_distance", "chain_edit_distance", "chained_better",
                       "longall", "longall_hash", "selected", "selected_hash", "failed_assertion"]
 
-    def align_summary(self, reads, threads=1):
+    def align_summary(self, reads, threads=1, gaf_hash=False):
         """align_timed that keeps 12 values per read (SUMMARY_FIELDS; see gco_align_summary) for bench.py's parity sample.
-        Returns (wall seconds, stage seconds, int64 array [n, 12])."""
+        Returns (wall seconds, stage seconds, int64 array [n, 12]); with gaf_hash a 13th column: the hash of the GAF lines the
+        reference would write for the read (gco_align_summary2), which bench.py's end-to-end leg compares with the product's text."""
         bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
         off = np.zeros(len(bs) + 1, dtype=np.uint64)
         off[1:] = np.cumsum([len(b) for b in bs])
         stage = np.zeros(5, dtype=np.float64)
         summary = np.zeros((len(bs), 12), dtype=np.int64)
-        wall = self.lib.gco_align_summary(self.h, b"".join(bs), off.ctypes.data, len(bs), int(threads), stage.ctypes.data, summary.ctypes.data)
+        hashes = np.zeros(len(bs), dtype=np.int64)
+        wall = self.lib.gco_align_summary2(self.h, b"".join(bs), off.ctypes.data, len(bs), int(threads), stage.ctypes.data, summary.ctypes.data, hashes.ctypes.data if gaf_hash else None)
+        if gaf_hash:
+            summary = np.concatenate([summary, hashes[:, None]], axis=1)
         return float(wall), stage, summary
 
     def extend(self, sequence, bigraph_node_id, node_offset):

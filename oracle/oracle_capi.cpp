@@ -461,7 +461,12 @@ int gco_align(void* hv, const char* bases, const uint64_t* off, int n)
 // chained_better, whole-read alignments, their (start, end, score) hash, selected alignments, their hash, failed assertion.
 // hash of a list v[0..m) = sum (v[i] + 1) * (i + 1) * 2654435761 mod 2^64 (bench.py computes the same with numpy).
 static uint64_t listHashStep(uint64_t h, uint64_t index, int64_t v) { return h + ((uint64_t)v + 1) * ((index + 1) * 2654435761ull); }
-double gco_align_summary(void* hv, const char* bases, const uint64_t* off, int n, int threads, double* stage5, int64_t* summary)
+// gafHash (optional, r4): per read one more value - the hash of the GAF lines the reference would write for it (the final alignments in output order, =/X CIGAR;
+// every line from its first TAB to its newline, i.e. without the read name): line hash = list hash of its bytes, read hash = list hash of its lines' hashes.
+// bench.py compares it with the text gc_format_gaf returns in the end-to-end leg: traces, paths and CIGARs of the timed mode, not just summary values.
+double gco_align_summary2(void* hv, const char* bases, const uint64_t* off, int n, int threads, double* stage5, int64_t* summary, int64_t* gafHash);
+double gco_align_summary(void* hv, const char* bases, const uint64_t* off, int n, int threads, double* stage5, int64_t* summary) { return gco_align_summary2(hv, bases, off, n, threads, stage5, summary, nullptr); }
+double gco_align_summary2(void* hv, const char* bases, const uint64_t* off, int n, int threads, double* stage5, int64_t* summary, int64_t* gafHash)
 {
 	OracleHandle* h = (OracleHandle*)hv;
 	if (threads < 1) threads = 1;
@@ -475,6 +480,21 @@ double gco_align_summary(void* hv, const char* bases, const uint64_t* off, int n
 			int64_t* out = summary ? summary + 12 * (size_t)r : nullptr;
 			try {
 				ReadResult res = h->o.alignRead(seq, state, false, stages[t].data());
+				if (gafHash) {
+					std::vector<AlignmentItem> finalAlns = res.chainedBetter ? res.chainAlignments : res.longAlignments;
+					auto byStart = [](const AlignmentItem& l, const AlignmentItem& rr) { return l.alignmentStart < rr.alignmentStart; };
+					std::sort(finalAlns.begin(), finalAlns.end(), byStart);   // src/Aligner.cpp:1003
+					std::sort(finalAlns.begin(), finalAlns.end(), byStart);   // :1023
+					uint64_t readHash = 0, line = 0;
+					for (const AlignmentItem& a : finalAlns) {
+						std::string text = traceToGaf(h->o.graph, "r", seq, *a.trace, false);
+						text += '\n';
+						uint64_t lineHash = 0;
+						for (size_t i = text.find('\t'), k = 0; i < text.size(); i++, k++) lineHash = listHashStep(lineHash, k, (int64_t)(unsigned char)text[i]);
+						readHash = listHashStep(readHash, line++, (int64_t)lineHash);
+					}
+					gafHash[r] = (int64_t)readHash;
+				}
 				if (!out) continue;
 				uint64_t hc = 0, ha = 0, hs = 0;
 				for (size_t i = 0; i < res.chain.size(); i++) hc = listHashStep(hc, i, (int64_t)res.chain[i]);
@@ -489,7 +509,7 @@ double gco_align_summary(void* hv, const char* bases, const uint64_t* off, int n
 				out[5] = res.chainEditDistance == SIZE_MAX ? -1 : (int64_t)res.chainEditDistance;
 				out[6] = res.chainedBetter ? 1 : 0; out[7] = (int64_t)res.longAll.size(); out[8] = (int64_t)ha;
 				out[9] = (int64_t)res.longAlignments.size(); out[10] = (int64_t)hs; out[11] = res.failedAssertion ? 1 : 0;
-			} catch (const std::exception&) { state.clear(); if (out) { for (int k = 0; k < 12; k++) out[k] = 0; out[11] = 2; } }
+			} catch (const std::exception&) { state.clear(); if (out) { for (int k = 0; k < 12; k++) out[k] = 0; out[11] = 2; } if (gafHash) gafHash[r] = 0; }
 		}
 	};
 	std::vector<std::thread> pool;

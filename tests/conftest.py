@@ -8,6 +8,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # the host's to set, before the process's first HIP call: the in-flight tests keep several gc_streams busy
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
