@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "gc_params_default", "gc_graph_create_from_gfa", "gc_graph_create", "gc_graph_destroy", "gc_graph_num_nodes",
     "gc_graph_size_bp", "gc_graph_array", "gc_seeder_create", "gc_seeder_destroy", "gc_seeder_array",
     "gc_stream_create", "gc_stream_destroy", "gc_reads_upload", "gc_reads_destroy", "gc_align_batch",
-    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_device_memory", "gc_edit_distance", "gc_edit_path", "gc_evalue", "gc_format_gaf", "gc_format_json", "gc_format_gam",
+    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_device_memory", "gc_edit_distance", "gc_edit_path", "gc_evalue", "gc_format_gaf", "gc_format_json", "gc_format_gam", "gc_format_gam_level",
     "gc_index_build", "gc_index_save", "gc_index_load", "gc_index_check", "gc_result_cache_trim",
 ]
 
@@ -423,26 +423,9 @@ class Aligner:
         if True:
             gaf = None
             if gaf_names is not None:
-                names = (C.c_char_p * len(gaf_names))(*[n.encode() if isinstance(n, str) else bytes(n) for n in gaf_names])
-
-                def encode(fn, *extra):
-                    text, length, skipped = C.c_void_p(), C.c_uint64(), C.c_uint64()
-                    fn.restype = C.c_int
-                    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p] + [C.c_int] * len(extra) + [C.c_void_p, C.c_void_p, C.c_void_p]
-                    _check(fn(self.graph.handle, res, names, batch.blob, batch.offsets.ctypes.data, *extra, C.byref(text), C.byref(length), C.byref(skipped)))
-                    data = C.string_at(text.value, length.value)
-                    self.lib.gc_free(text)
-                    return data, int(skipped.value)
-
                 # formats: which of "gaf", "json", "gam" to produce (default: GAF, all three with other_formats)
                 want = tuple(formats) if formats is not None else (("gaf", "json", "gam") if other_formats else ("gaf",))
-                texts, skipped = {}, 0
-                for fmt in want:
-                    if fmt == "gaf":
-                        texts[fmt], skipped = encode(self.lib.gc_format_gaf, int(cigar_match_mismatch_merge))
-                    else:
-                        texts[fmt], skipped = encode(self.lib.gc_format_json if fmt == "json" else self.lib.gc_format_gam)
-                gaf = (texts, skipped)
+                gaf = self._format(res, batch, gaf_names, want, cigar_match_mismatch_merge)
             r = res.contents
             n = int(r.n_reads)
 
@@ -512,6 +495,35 @@ class Aligner:
                 out.update(gaf[0])
                 out["gaf_chained_skipped"] = gaf[1]
             return out   # arrays keep the C ABI's dtypes (uint32/uint64/...) and are views: no copies on the hot path
+
+    def _format(self, res, batch, names, formats, cigar_match_mismatch_merge=False, gam_level=None):
+        if not isinstance(names, C.Array):
+            names = (C.c_char_p * len(names))(*[n.encode() if isinstance(n, str) else bytes(n) for n in names])
+
+        def encode(fn, *extra):
+            text, length, skipped = C.c_void_p(), C.c_uint64(), C.c_uint64()
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p] + [C.c_int] * len(extra) + [C.c_void_p, C.c_void_p, C.c_void_p]
+            _check(fn(self.graph.handle, res, names, batch.blob, batch.offsets.ctypes.data, *extra, C.byref(text), C.byref(length), C.byref(skipped)))
+            data = C.string_at(text.value, length.value)
+            self.lib.gc_free(text)
+            return data, int(skipped.value)
+
+        texts, skipped = {}, 0
+        for fmt in formats:
+            if fmt == "gaf":
+                texts[fmt], skipped = encode(self.lib.gc_format_gaf, int(cigar_match_mismatch_merge))
+            elif fmt == "gam" and gam_level is not None:
+                texts[fmt], skipped = encode(self.lib.gc_format_gam_level, int(gam_level))
+            else:
+                texts[fmt], skipped = encode(self.lib.gc_format_json if fmt == "json" else self.lib.gc_format_gam)
+        return texts, skipped
+
+    def format_batch(self, out, batch, names, formats=("gaf",), cigar_match_mismatch_merge=False, gam_level=None):
+        """The writers on a result align_batch returned earlier (gc_format_gaf / _json / _gam): needs the graph and the result, not the stream - a host can
+        format one batch while the stream aligns the next. names: one id per read, or a prebuilt ctypes array of them. gam_level: zlib level of the GAM's gzip
+        members (default: the reference's, Z_DEFAULT_COMPRESSION). Returns ({format: bytes}, chained winners the result held no trace for)."""
+        return self._format(out._holder.res, batch, names, tuple(formats), cigar_match_mismatch_merge, gam_level)
 
     def align_reads(self, reads, **kw):
         batch = ReadBatch(reads)

@@ -431,7 +431,8 @@ struct gc_stream {
 	DeviceBuffer longSeeds, longJobs, longAlns, longResults, longScratch, longCells, longCursor, longJobsFallback, longResultsFallback, longScratchFallback;
 	DeviceBuffer gluePerRead, glueCursors, glueOut, glueSeedCap, glueSeedOff, glueWinCapOff, glueU32[8], glueSort, gluePos, glueWin;   // seed glue on the device (gc_seedglue.hip)
 	PinnedBuffer hGlueOut, hGlueWinCapOff, hGlueSmall;
-	DeviceBuffer longState, longWork, longWorkResults, longRoundTrace, longCandSeed, longWorkLen, longOrder;
+	DeviceBuffer longState, longWork, longWorkResults, longRoundTrace, longCandSeed, longWorkLen, longOrder, longRoundInfo;
+	PinnedBuffer hLongRoundInfo;
 	PinnedBuffer hLongSeeds, hLongJobs, hLongAlns, hLongResults, hLongSmall, hLongCells;
 	~gc_stream()
 	{
@@ -893,7 +894,7 @@ int gc_evalue(double min_identity, uint64_t database_size, uint64_t query_size, 
 // when the result carries no trace for it.
 enum OutputKind { OUT_GAF, OUT_JSON, OUT_GAM };
 static int formatBatch(const gc_graph* G, const gc_result* r, const char* const* read_names, const char* bases, const uint64_t* offsets, OutputKind kind, int cigar_match_mismatch_merge,
-	char** out_text, uint64_t* out_len, uint64_t* n_chained_skipped)
+	char** out_text, uint64_t* out_len, uint64_t* n_chained_skipped, int gamLevel = -1)
 {
 	if (!G || !r || !read_names || !offsets || !out_text || !out_len) return fail(GC_ERR_INVALID, "null argument");
 	const bool pieces = r->read_out_off != nullptr;   // the result carries the alignments as the device encoded them (gc_params::device_output)
@@ -930,7 +931,7 @@ static int formatBatch(const gc_graph* G, const gc_result* r, const char* const*
 						else messages.push_back(gc::vgProtobufFromEncoded(name, bases + offsets[i], ea));
 					}
 				}
-				if (kind == OUT_GAM && !messages.empty()) text = gc::gamGroup(messages);
+				if (kind == OUT_GAM && !messages.empty()) text = gc::gamGroup(messages, gamLevel);
 				return;
 			}
 			if (r->chained_better[i]) {
@@ -944,7 +945,7 @@ static int formatBatch(const gc_graph* G, const gc_result* r, const char* const*
 				} else {
 					gc::VgAlignment aln = gc::buildVgAlignment(G->host, name, bases + offsets[i], len, tv, 0, r->chain_aln_start[i], r->chain_aln_end[i]);
 					if (kind == OUT_JSON) { text += gc::vgToJson(aln); text += '\n'; }
-					else text = gc::gamGroup({ gc::vgToProtobuf(aln) });
+					else text = gc::gamGroup({ gc::vgToProtobuf(aln) }, gamLevel);
 				}
 				return;
 			}
@@ -971,7 +972,7 @@ static int formatBatch(const gc_graph* G, const gc_result* r, const char* const*
 					else messages.push_back(gc::vgToProtobuf(aln));
 				}
 			}
-			if (kind == OUT_GAM) text = gc::gamGroup(messages);
+			if (kind == OUT_GAM) text = gc::gamGroup(messages, gamLevel);
 		});
 		uint64_t total = 0;
 		for (const auto& t : perRead) total += t.size();
@@ -1003,6 +1004,12 @@ int gc_format_gam(const gc_graph* G, const gc_result* r, const char* const* read
 
 // gc_result_free keeps the large arrays of freed results (up to 24 GB) for the next batch instead of returning them to the allocator; this returns them.
 void gc_result_cache_trim(void) { g_resultBlocks.trim(); }
+
+int gc_format_gam_level(const gc_graph* G, const gc_result* r, const char* const* read_names, const char* bases, const uint64_t* offsets, int level, char** out_bytes, uint64_t* out_len, uint64_t* n_chained_skipped)
+{
+	if (level < -1 || level > 9) return fail(GC_ERR_INVALID, "gc_format_gam_level: zlib levels are -1 (default) and 0..9");
+	return formatBatch(G, r, read_names, bases, offsets, OUT_GAM, 0, out_bytes, out_len, n_chained_skipped, level);
+}
 
 int gc_device_count(void)
 {
@@ -1914,10 +1921,90 @@ struct BatchRun {
 		return true;
 	}
 
+	// The round loop without a host round trip per round (r4, the default): per round ONE kernel between two extension launches - k_long_round: the previous round's merge,
+	// this round's select, the execution order, the work count to the device and to pinned host memory - and the extension kernel takes its item count from the device
+	// (its grid is sized by a bound: 2 items per read, which the device-side speculation rule respects). Rounds are queued several at a time; the host looks at the published
+	// counts only at the end of a chunk (a round after the last one finds nothing to do and costs a few empty launches). r3's loop queued zero / select / order / publish,
+	// waited for the count, then extend / retry / merge: with five batches in flight each of those launches waited for a wave slot among the other batches' kernels and the
+	// pass took 149 ms for 121 ms of extension kernels.
+	bool roundsOnDevice(uint32_t g) const
+	{
+		if (nGroups != 1 || longExtendTeamSize(1) != 1) return false;
+		for (const char* name : { "GC_LONG_SM", "GC_LONG_LANE", "GC_LONG_MAX_BLOCKS", "GC_LONG_PLAN" }) if (getenv(name)) return false;   // experiments and test hooks of the host-driven loop
+		if (getenv("GC_LONG_TOKEN") && atoi(getenv("GC_LONG_TOKEN")) == 2) return false;
+		if (getenv("GC_LONG_ROUNDS") && atoi(getenv("GC_LONG_ROUNDS")) == 0) return false;   // GC_LONG_ROUNDS=0: r3's host-driven loop (same results)
+		(void)g;
+		return true;
+	}
+	void runLongGroupOnDevice(uint32_t g)
+	{
+		const uint64_t r0 = groupBegin[g], nG = groupBegin[g + 1] - r0;
+		unsigned long long* dLongScratch = shareLongScratch ? longScratchOfToken : dLongScratchOwn;
+		hipStream_t q = st->groupStreams[g];
+		hipEvent_t* ring = st->groupEvents.data() + (size_t)2 * LONG_EVENT_RING * g;
+		auto collect = [&](int slot) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ring[2 * slot], ring[2 * slot + 1])); groupExtendUs[g] += (double)ms * 1000.0; };
+		const uint64_t w0 = 8 * r0 + 64ull * g, capacity = 8 * nG + 64;
+		unsigned long long* cursorSets = dLongCursor + 32 + 8 * g;   // two sets of four words: [0] work count, [1] round trace cursor, [2] next work slot, [3] length of the retry list
+		const uint64_t traceBudget = groupTraceBegin[g + 1] - groupTraceBegin[g];
+		const int MAX_ROUNDS = 250;
+		unsigned long long* dRoundInfo = st->longRoundInfo.reserve<unsigned long long>(MAX_ROUNDS + 8);   // [0] ticket, [1 + round] work items of the round
+		volatile unsigned long long* hInfo = st->hLongRoundInfo.reserve<unsigned long long>(MAX_ROUNDS + 8);   // [0] rounds published, [2 + round] work items of the round
+		hInfo[0] = 0;
+		const double dbgT0 = nowUs();
+		double dbgWaitUs = 0;
+		launchLongInit(q, dLongJobs + r0, (uint32_t)nG, dLongState + r0);
+		launchZeroWords(q, dRoundInfo, 1);
+		launchZeroWords(q, cursorSets, 8);
+		// the extension launch's grid: two items per read cover every round (a round never holds more items than the one before it unless the rule below speculates, and
+		// the device-side rule keeps speculation within gridLimit); a batch whose 2 nG exceed the scratch's lanes runs persistent waves instead
+		const uint64_t laneLimit = std::max<uint64_t>(1, scratchLanes - 64);
+		const bool gridCovers = 2 * nG <= laneLimit;
+		const uint32_t gridLimit = (uint32_t)std::min<uint64_t>(2 * nG, laneLimit);
+		uint32_t forceCand = 0;
+		if (const char* env = getenv("GC_LONG_SPECULATE")) forceCand = (uint32_t)std::min(2, std::max(1, atoi(env)));   // test hook: speculate from round 0
+		const char* orderEnv = getenv("GC_LONG_ORDER");
+		const uint32_t orderMode = orderEnv ? (uint32_t)atoi(orderEnv) : 1u;
+		int queued = 0, timed = 0, done = -1;
+		while (done < 0 && queued < MAX_ROUNDS) {
+			const int chunk = queued == 0 ? 6 : 2;   // cfg2 needs six rounds; beyond that two at a time
+			for (int k = 0; k < chunk && queued < MAX_ROUNDS; k++, queued++) {
+				const uint32_t round = (uint32_t)queued;
+				unsigned long long* cur = cursorSets + 4 * (round & 1u);
+				launchLongRound(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, (uint32_t)P->min_cluster_size, round, forceCand, gridLimit, dLongState + r0, dLongAlns, dLongCells, dLongCursor, cellBudget, maxAlignments,
+					dLongWork + w0, dWorkLen + w0, dCandSeed + w0, dLongWorkResults + w0, dRoundTrace + groupTraceBegin[g], cursorSets, dRoundInfo + 1, dRoundInfo, dOrder + w0, (uint32_t)maxReadLen, orderMode,
+					(unsigned long long*)hInfo, capacity);
+				if (timed >= LONG_EVENT_RING) collect(timed % LONG_EVENT_RING);
+				hipEvent_t ev0 = ring[2 * (timed % LONG_EVENT_RING)], ev1 = ring[2 * (timed % LONG_EVENT_RING) + 1];
+				HIP_CHECK(hipEventRecord(ev0, q));
+				launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, gridCovers ? gridLimit : (uint32_t)std::min<uint64_t>(capacity, 0xffffffffull), dLongScratch + (uint64_t)g * scratchLanes * waveWords, 1, gridLimit,
+					dRoundTrace + groupTraceBegin[g], cur + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cur + 2, 0, cur, dRetryList + w0, cur + 3, gridCovers);
+				// extensions whose band outgrew the 64-entry register tables: second try with the LDS/HBM tables (two lanes per wave); the list is almost always empty
+				if (!gridCovers) launchZeroWords(q, cur + 2, 1);   // (persistent waves used the slot counter)
+				const uint32_t retryBlocks = std::min<uint32_t>(16, (uint32_t)std::max<uint64_t>(1, laneLimit / 2));
+				launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dRetryList + w0, (uint32_t)std::min<uint64_t>(capacity, 0xffffffffull), dLongScratch + (uint64_t)g * scratchLanes * waveWords, 2, retryBlocks,
+					dRoundTrace + groupTraceBegin[g], cur + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cur + 2, EXT_LDS_CAP, cur + 3);
+				HIP_CHECK(hipEventRecord(ev1, q));
+				timed++;
+			}
+			const double tWait0 = nowUs();
+			syncStream(q);
+			dbgWaitUs += nowUs() - tWait0;
+			if ((int)hInfo[0] != queued) throw std::runtime_error("internal: the whole-read rounds did not publish their counts");
+			for (int r = 0; r < queued && done < 0; r++) if (hInfo[2 + r] == 0) done = r;   // round `done` found no seed left to extend (its merge of the round before ran)
+		}
+		if (done < 0) throw std::runtime_error("whole-read pass: more rounds than the round loop queues");
+		groupRounds[g] += (uint32_t)done;
+		launchLongFinish(q, (uint32_t)nG, dLongState + r0, hLongResults + r0);
+		syncStream(q);
+		for (int k = std::max(0, timed - LONG_EVENT_RING); k < timed; k++) collect(k % LONG_EVENT_RING);
+		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] whole-read rounds (queued ahead): %.1f ms in all, %.1f ms waiting at the chunks' ends, %d rounds with work, %d queued\n", (nowUs() - dbgT0) / 1e3, dbgWaitUs / 1e3, done, queued);
+	}
+
 	void runLongGroup(uint32_t g)   // the round loop of one read group: select -> extend -> merge until no read has a seed left to extend (see gc_kernels.hip, "K3-long in rounds")
 	{
 		const uint64_t r0 = groupBegin[g], nG = groupBegin[g + 1] - r0;
 		if (nG == 0) return;
+		if (roundsOnDevice(g)) { runLongGroupOnDevice(g); return; }
 		unsigned long long* dLongScratch = shareLongScratch ? longScratchOfToken : dLongScratchOwn;   // (round token: set under the lock, every round)
 		hipStream_t q = st->groupStreams[g];
 		hipEvent_t* ring = st->groupEvents.data() + (size_t)2 * LONG_EVENT_RING * g;
@@ -2442,7 +2529,8 @@ struct BatchRun {
 			HIP_CHECK(hipMemsetAsync(dCursor, 0, sizeof(unsigned long long), stream));
 			launchStitch(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, dChainOut, dChainLen, dChainStatus, dPathPool, pathCapacity, (long long)P->colinear_gap, dSlotOf,
 				dRegions, dStitchNodes, stitchDenseCap, dCursor, dStitchInfo,
-				(uint32_t)capacityOr("GC_STITCH_SET_MAX", P->capacity.stitch_set_max, 0), (uint32_t)capacityOr("GC_STITCH_BFS_CAP", P->capacity.stitch_bfs_cap, 0));
+				(uint32_t)capacityOr("GC_STITCH_SET_MAX", P->capacity.stitch_set_max, 0), (uint32_t)capacityOr("GC_STITCH_BFS_CAP", P->capacity.stitch_bfs_cap, 0),
+				maxReadLen <= 16384 && !(getenv("GC_STITCH_LARGE") && atoi(getenv("GC_STITCH_LARGE"))));   // (GC_STITCH_LARGE=1: the large tables for every batch, as in r3)
 			HIP_CHECK(hipMemcpyAsync(stitchInfo, dStitchInfo, n * sizeof(StitchInfo), hipMemcpyDeviceToHost, stream));
 			HIP_CHECK(hipMemcpyAsync(hStitchCursor, dCursor, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		}

@@ -887,12 +887,10 @@ __device__ inline int seedSkipped(const DGraph& g, const LongSeed& sd, const Lon
 // rules against the alignments known now; k_long_merge re-checks each of them against the alignments added before it
 // in the same round, so the outcome equals one-seed-per-round.
 #define LONG_MAX_CANDIDATES 8
-__global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __restrict__ jobs, uint32_t nReads, const LongSeed* __restrict__ seeds, uint64_t rcBase, uint32_t minClusterSize,
+__device__ __forceinline__ void longSelectRead(const DGraph& g, const uint32_t r, const uint32_t lane, const LongJob* __restrict__ jobs, const LongSeed* __restrict__ seeds, uint32_t minClusterSize,
 	uint32_t maxCandidates, LongState* __restrict__ state, const LongAln* __restrict__ alns, const LongCell* __restrict__ cellPool, LongWork* __restrict__ work, uint32_t* __restrict__ workLen, uint32_t* __restrict__ candSeed,
 	unsigned long long* __restrict__ workCount, uint64_t workCapacity)
 {
-	const uint32_t r = blockIdx.x, lane = threadIdx.x;
-	if (r >= nReads) return;
 	LongState st = state[r];
 	st.candCount = 0;
 	if (st.status != 0) { if (lane == 0) state[r] = st; return; }
@@ -951,6 +949,14 @@ __global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __r
 		}
 	}
 	if (lane == 0) state[r] = st;
+}
+__global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __restrict__ jobs, uint32_t nReads, const LongSeed* __restrict__ seeds, uint64_t rcBase, uint32_t minClusterSize,
+	uint32_t maxCandidates, LongState* __restrict__ state, const LongAln* __restrict__ alns, const LongCell* __restrict__ cellPool, LongWork* __restrict__ work, uint32_t* __restrict__ workLen, uint32_t* __restrict__ candSeed,
+	unsigned long long* __restrict__ workCount, uint64_t workCapacity)
+{
+	const uint32_t r = blockIdx.x, lane = threadIdx.x;
+	if (r >= nReads) return;
+	longSelectRead(g, r, lane, jobs, seeds, minClusterSize, maxCandidates, state, alns, cellPool, work, workLen, candSeed, workCount, workCapacity);
 }
 
 // LANES = active lanes per wave ("team"). The pass is latency-bound and leaves most of the chip idle, so when there
@@ -1085,13 +1091,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 
 // One wave per read: the decisions are taken redundantly by all lanes (uniform control flow, lane 0 does the single
 // writes), the trace -> cell conversion - the bulk of the work, ~1.5 cells per read base - runs 64 cells at a time.
-__global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __restrict__ jobs, uint32_t nReads, const LongSeed* __restrict__ seeds, const uint32_t* __restrict__ candSeed,
+__device__ __forceinline__ void longMergeRead(const DGraph& g, const uint32_t r, const uint32_t lane, const LongJob* __restrict__ jobs, const LongSeed* __restrict__ seeds, const uint32_t* __restrict__ candSeed,
 	const LongWorkResult* __restrict__ results, const unsigned long long* __restrict__ tracePool, uint32_t maxAlignments,
 	LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* __restrict__ cellCursor, uint64_t cellCapacity)
 {
-	const uint32_t r = blockIdx.x;
-	const uint32_t lane = threadIdx.x;
-	if (r >= nReads) return;
 	LongState st = state[r];
 	if (st.candCount == 0 || st.status != 0) return;
 	LongJob job = jobs[r];
@@ -1149,8 +1152,7 @@ __global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __re
 			oc.nodeSwitch = (tc.offsetAndSwitch >> 8) & 1u;
 			outCells[useB + i] = oc;
 		}
-		__threadfence_block();
-		__syncthreads();   // the cells are read back below and by the next candidate's skip rules
+		__threadfence_block();   // the cells are read back below and by the next candidate's skip rules (one wave per read: the fence orders its own stores and loads)
 		LongAln al;
 		al.start = outCells[0].seqPos;
 		al.end = outCells[total - 1].seqPos + 1;
@@ -1167,10 +1169,18 @@ __global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __re
 		st.nAln++;
 		st.e2eScore = __shfl(e2e, 0);
 		__threadfence_block();
-		__syncthreads();
 	}
 	st.candCount = 0;
 	if (lane == 0) state[r] = st;
+}
+
+__global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __restrict__ jobs, uint32_t nReads, const LongSeed* __restrict__ seeds, const uint32_t* __restrict__ candSeed,
+	const LongWorkResult* __restrict__ results, const unsigned long long* __restrict__ tracePool, uint32_t maxAlignments,
+	LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* __restrict__ cellCursor, uint64_t cellCapacity)
+{
+	const uint32_t r = blockIdx.x;
+	if (r >= nReads) return;
+	longMergeRead(g, r, threadIdx.x, jobs, seeds, candSeed, results, tracePool, maxAlignments, state, alns, cellPool, cellCursor, cellCapacity);
 }
 
 // Execution order of a round's work items: longest extensions first (a counting sort over 1024 length classes, one block;
@@ -1188,6 +1198,76 @@ __global__ void __launch_bounds__(1024) k_long_order(const uint32_t* __restrict_
 	if (tid == 0) { uint32_t at = 0; for (uint32_t b = 0; b < 1024; b++) { start[b] = at; at += hist[b]; } }
 	__syncthreads();
 	for (uint32_t i = tid; i < n; i += 1024) { uint32_t b = workLen[i] >> shift; order[atomicAdd(&start[1023 - (b < 1023 ? b : 1023)], 1u)] = i; }
+}
+
+// One launch per round instead of five (r4): the previous round's merge, this round's select, the execution order and the hand-over of the round's work count.
+// One wave per read runs the read's merge and then its select (both only touch that read's state); every wave then takes a ticket, and the wave that takes the
+// last one - all work items of the round are in place by then - sorts them into execution order (longest first, 64 lanes over an LDS histogram of 1024 length
+// classes) and publishes the count: to the device (roundInfo[round]: the next round's speculation rule reads it, and the extension kernel takes its item count from the
+// round's cursor set) and to pinned host memory. The cursors come in two sets that alternate with the round's parity; a round zeroes the NEXT round's set (its last
+// users - the previous round's select and extension kernels - are complete in stream order). With that the host can queue several rounds without waiting for any
+// count: between two extension kernels of a pass sit this kernel and the (almost always empty) retry, not zero / select / order / publish / host round trip / merge,
+// each of which waited for a wave slot among the other batches' kernels (r3: 28 ms of a pass's 149 with five batches in flight).
+__global__ void __launch_bounds__(64) k_long_round(DGraph g, const LongJob* __restrict__ jobs, uint32_t nReads, const LongSeed* __restrict__ seeds, uint32_t minClusterSize, uint32_t round, uint32_t forceCand,
+	uint32_t gridLimit, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity, uint32_t maxAlignments,
+	LongWork* work, uint32_t* workLen, uint32_t* candSeed, const LongWorkResult* results, const unsigned long long* tracePool,
+	unsigned long long* cursorSets, unsigned long long* roundInfo, unsigned long long* ticket, uint32_t* order, uint32_t orderShift, uint32_t orderMode,
+	volatile unsigned long long* hostInfo, uint64_t workCapacity)
+{
+	__shared__ uint32_t hist[1024];
+	const uint32_t r = blockIdx.x, lane = threadIdx.x;
+	unsigned long long* cur = cursorSets + 4 * (round & 1u);
+	unsigned long long* next = cursorSets + 4 * ((round + 1u) & 1u);
+	if (r == 0 && lane < 4) next[lane] = 0;
+	// candidates per read (the host loop's rule, on the device): one; several once few reads are still active (exact: the merge re-checks them in order), within
+	// what the work arrays, the trace budget (four seeds' worth per read) and the extension launch's grid hold
+	uint32_t maxCand = 1;
+	if (round > 0) {
+		const uint64_t lastWork = roundInfo[round - 1];
+		if (lastWork > 0) {
+			maxCand = (uint32_t)min((uint64_t)8, max((uint64_t)1, (2ull * nReads) / lastWork));
+			if (lastWork < 8192) maxCand = 8;
+			maxCand = (uint32_t)min((uint64_t)maxCand, max((uint64_t)1, (8ull * nReads) / lastWork));
+			maxCand = (uint32_t)min((uint64_t)maxCand, max((uint64_t)1, (uint64_t)gridLimit / lastWork));   // at most lastWork / 2 reads are active: 2 x maxCand items each
+		}
+	}
+	if (forceCand) maxCand = forceCand;
+	if (r < nReads) {
+		if (round > 0) { longMergeRead(g, r, lane, jobs, seeds, candSeed, results, tracePool, maxAlignments, state, alns, cellPool, cellCursor, cellCapacity); __threadfence_block(); }
+		longSelectRead(g, r, lane, jobs, seeds, minClusterSize, maxCand, state, alns, cellPool, work, workLen, candSeed, cur, workCapacity);
+	}
+	__threadfence();   // this wave's work items before its ticket
+	uint32_t last = 0;
+	if (lane == 0) last = atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1 ? 1u : 0u;
+	last = __shfl(last, 0);
+	if (!last) return;
+	__threadfence();
+	const uint32_t n = (uint32_t)atomicAdd(cur, 0ull);
+	const volatile uint32_t* lens = workLen;
+	if (orderMode == 0) { for (uint32_t i = lane; i < n; i += 64) order[i] = i; }
+	else {
+		for (uint32_t b = lane; b < 1024; b += 64) hist[b] = 0;
+		__syncthreads();
+		for (uint32_t i = lane; i < n; i += 64) { const uint32_t b = lens[i] >> orderShift; atomicAdd(&hist[1023 - (b < 1023 ? b : 1023)], 1u); }
+		__syncthreads();
+		// exclusive scan of the 1024 classes: 16 per lane, a wave scan of the lanes' sums
+		uint32_t mine[16], sum = 0;
+		for (int k = 0; k < 16; k++) { mine[k] = hist[lane * 16 + k]; sum += mine[k]; }
+		uint32_t incl = sum;
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if ((int)lane >= d) incl += o; }
+		uint32_t at = incl - sum;
+		for (int k = 0; k < 16; k++) { hist[lane * 16 + k] = at; at += mine[k]; }
+		__syncthreads();
+		for (uint32_t i = lane; i < n; i += 64) { const uint32_t b = lens[i] >> orderShift; order[atomicAdd(&hist[1023 - (b < 1023 ? b : 1023)], 1u)] = i; }
+	}
+	if (lane == 0) {
+		roundInfo[round] = n;
+		*ticket = 0;
+		hostInfo[2 + round] = n;
+		__threadfence_system();
+		hostInfo[0] = round + 1;   // rounds published so far
+		__threadfence_system();
+	}
 }
 
 // copies a few cursor words into pinned host memory through the compute queue (a copy-engine transfer would queue behind bulk uploads)
@@ -1306,11 +1386,13 @@ uint32_t longExtendTeamSize(uint32_t nWork)
 
 void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
 	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters,
-	unsigned long long* nextSlot, uint32_t retryStatus, const unsigned long long* nWorkOnDevice, uint32_t* capListOut, unsigned long long* capCountOut)
+	unsigned long long* nextSlot, uint32_t retryStatus, const unsigned long long* nWorkOnDevice, uint32_t* capListOut, unsigned long long* capCountOut, bool gridCoversCount)
 {
 	if (!nWork) return;
 	uint64_t words = longWaveWordsPerLane(cfg);
-	const bool persistent = nWorkOnDevice || (uint64_t)blocks * lanes < nWork;   // fewer lanes than work items (or a count only the device knows): waves loop and fetch
+	// fewer lanes than work items (or a count only the device knows): waves loop and fetch - unless the caller vouches that the grid covers whatever the count turns out to be
+	// (gridCoversCount: the sync-free round loop, whose launches are sized by a bound; waves beyond the count leave at once)
+	const bool persistent = (nWorkOnDevice && !gridCoversCount) || (uint64_t)blocks * lanes < nWork;
 	// GC_LONG_WAVES_PER_SIMD=w (experiment): an unused dynamic LDS allocation per wave caps the kernel at w waves per SIMD, leaving wave slots
 	// and registers to the fragment pipeline's kernels that share the device with it
 	static const uint32_t ldsPad = []() { const char* e = getenv("GC_LONG_WAVES_PER_SIMD"); int w = e ? atoi(e) : 0; return (w >= 1 && w <= 7) ? (uint32_t)((160u * 1024u / (4u * (uint32_t)w)) & ~255u) : 0u; }();
@@ -1397,6 +1479,17 @@ void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, u
 	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity)
 {
 	if (nReads) hipLaunchKernelGGL(k_long_merge, dim3(nReads), dim3(64), 0, stream, g, jobs, nReads, seeds, candSeed, results, tracePool, maxAlignments, state, alns, cellPool, cellCursor, cellCapacity);
+}
+void launchLongRound(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, uint32_t minClusterSize, uint32_t round, uint32_t forceCand, uint32_t gridLimit,
+	LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity, uint32_t maxAlignments, LongWork* work, uint32_t* workLen, uint32_t* candSeed,
+	const LongWorkResult* results, const unsigned long long* tracePool, unsigned long long* cursorSets, unsigned long long* roundInfo, unsigned long long* ticket, uint32_t* order, uint32_t maxLen, uint32_t orderMode,
+	unsigned long long* hostInfo, uint64_t workCapacity)
+{
+	if (!nReads) return;
+	uint32_t shift = 0;
+	while ((maxLen >> shift) > 1023) shift++;
+	hipLaunchKernelGGL(k_long_round, dim3(nReads), dim3(64), 0, stream, g, jobs, nReads, seeds, minClusterSize, round, forceCand, gridLimit, state, alns, cellPool, cellCursor, cellCapacity, maxAlignments,
+		work, workLen, candSeed, results, tracePool, cursorSets, roundInfo, ticket, order, shift, orderMode, (volatile unsigned long long*)hostInfo, workCapacity);
 }
 void launchLongOrder(hipStream_t stream, const uint32_t* workLen, const unsigned long long* workCount, uint32_t* order, uint32_t maxLen, uint32_t mode)
 {

@@ -176,7 +176,13 @@ void launchLongSelect(hipStream_t stream, const DGraph& g, const LongJob* jobs, 
 uint32_t longExtendTeamSize(uint32_t nWork);
 void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
 	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters,
-	unsigned long long* nextSlot, uint32_t retryStatus = 0, const unsigned long long* nWorkOnDevice = nullptr, uint32_t* capListOut = nullptr, unsigned long long* capCountOut = nullptr);   // nWorkOnDevice: `order` is a list whose length only the device knows (then nWork is its upper bound)
+	unsigned long long* nextSlot, uint32_t retryStatus = 0, const unsigned long long* nWorkOnDevice = nullptr, uint32_t* capListOut = nullptr, unsigned long long* capCountOut = nullptr,
+	bool gridCoversCount = false);   // nWorkOnDevice: `order` is a list whose length only the device knows (then nWork is its upper bound; gridCoversCount: blocks x lanes >= that bound, no fetch loop needed)
+// the whole inter-round step in one launch: merge of the previous round + select + execution order + work count to device and host (k_long_round)
+void launchLongRound(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, uint32_t minClusterSize, uint32_t round, uint32_t forceCand, uint32_t gridLimit,
+	LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity, uint32_t maxAlignments, LongWork* work, uint32_t* workLen, uint32_t* candSeed,
+	const LongWorkResult* results, const unsigned long long* tracePool, unsigned long long* cursorSets, unsigned long long* roundInfo, unsigned long long* ticket, uint32_t* order, uint32_t maxLen, uint32_t orderMode,
+	unsigned long long* hostInfo, uint64_t workCapacity);
 // the same extensions one per LANE with the plain-layout core and a per-lane HBM slab (k_long_extend_lane: the layout measurement of DESIGN.md §4e, GC_LONG_LANE=1)
 void launchLongExtendLane(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
 	uint8_t* scratch, uint64_t scratchBytes, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters);
@@ -218,7 +224,7 @@ struct StitchInfo {   // the longest stitched piece of a read's chain
 void launchStitch(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
 	const uint32_t* chainOut, const uint32_t* chainLen, const uint32_t* chainStatus, const uint32_t* pathPool, uint64_t pathCapacity, long long colinearGap, uint32_t* slotOf,
 	uint32_t* regions, uint32_t* dense, uint64_t denseCap, unsigned long long* denseCursor, StitchInfo* info,
-	uint32_t setMax = 0, uint32_t bfsCap = 0);   // smaller table limits (tests: forces reads onto the host path); 0 = the kernel's own
+	uint32_t setMax = 0, uint32_t bfsCap = 0, bool smallTables = false);   // smaller table limits (tests: forces reads onto the host path); 0 = the kernel's own. smallTables: the half-size LDS class (reads up to 16 kb)
 uint64_t stitchRegionWords(uint64_t totalSlots, uint64_t nReads);
 uint64_t stitchDenseWords(uint64_t totalSlots, uint64_t nReads);
 // srcOff with bit 63 set reads its nodes from altNodes (host-stitched reads) instead of pathNodes

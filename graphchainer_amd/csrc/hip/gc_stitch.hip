@@ -21,7 +21,7 @@
 // run by the whole wave (adjacency loads in parallel, insertions replayed in the sequential order). The piece's node set and the BFS's visited map / queue live in LDS; pieces are
 // written one after the other into the read's scratch region, and the best one is copied by all lanes into a dense
 // output array (position from an atomic cursor; StitchInfo.start says where).
-// Anything that does not fit - more than STITCH_SET_MAX nodes on a piece, a BFS that visits more than STITCH_BFS_CAP
+// Anything that does not fit - more nodes on a piece than half the set's slots, a BFS that visits more than STITCH_BFS_CAP
 // nodes, a full region or output array - sets status 1 and the host stitches that read with the same algorithm
 // (gc_capi.hip).
 #include "gc_kernels.hpp"
@@ -29,10 +29,11 @@
 
 namespace gcdev {
 
-#define STITCH_SET_SIZE 2048u     // open-addressing slots for the nodes of the current piece
-#define STITCH_SET_MAX 1024u
-#define STITCH_BFS_CAP 1024u      // visited nodes per bridge search
-#define STITCH_BFS_TABLE 2048u
+// Two size classes of the LDS tables (r4): a piece of a 10 kb read holds ~250 split nodes and a bridge search visits a handful, so reads up to 16 kb run with half the
+// tables - 16.6 KB per wave instead of 29.5, nine waves per CU instead of five for a kernel that is all latency - and longer reads (config 5's 50 kb: ~1 000 nodes per
+// piece) keep the large ones. What outgrows a table goes to the host's stitching either way.
+#define STITCH_SET_SIZE_LARGE 2048u   // open-addressing slots for the nodes of the current piece; at most half of them are used (STITCH_SET_MAX)
+#define STITCH_BFS_CAP_LARGE 1024u    // visited nodes per bridge search; its hash table has twice the slots
 #define STITCH_EMPTY 0xffffffffu
 #define STITCH_PF_NODES 4u        // path nodes of an anchor staged in LDS (35 bp paths have 1-3)
 
@@ -48,12 +49,14 @@ struct StitchAnchor {
 	uint32_t flags;               // 1: firstNode is an out-neighbour of prevLast, 2: unusable record (the host stitches the read)
 };
 
+template <uint32_t STITCH_SET_SIZE, uint32_t STITCH_BFS_CAP>
 __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __restrict__ jobs, uint32_t nReads, const AnchorRec* __restrict__ anchors,
 	const Fragment* __restrict__ frags, const uint32_t* __restrict__ fragStatus, const uint32_t* __restrict__ chainOut, const uint32_t* __restrict__ chainLen,
 	const uint32_t* __restrict__ chainStatus, const uint32_t* __restrict__ pathPool, uint64_t pathCapacity, long long colinearGap, uint32_t setMax, uint32_t bfsCap,
 	uint32_t* __restrict__ slotOf, uint32_t* __restrict__ regions, uint32_t* __restrict__ dense, uint64_t denseCap, unsigned long long* __restrict__ denseCursor,
 	StitchInfo* __restrict__ info)
 {
+	constexpr uint32_t STITCH_BFS_TABLE = 2 * STITCH_BFS_CAP;
 	__shared__ uint32_t setKey[STITCH_SET_SIZE];
 	__shared__ uint32_t bfsTable[STITCH_BFS_TABLE];   // (generation << 11) | (queue index + 1)
 	__shared__ uint32_t qNode[STITCH_BFS_CAP], qDis[STITCH_BFS_CAP];
@@ -331,13 +334,16 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 
 void launchStitch(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
 	const uint32_t* chainOut, const uint32_t* chainLen, const uint32_t* chainStatus, const uint32_t* pathPool, uint64_t pathCapacity, long long colinearGap, uint32_t* slotOf,
-	uint32_t* regions, uint32_t* dense, uint64_t denseCap, unsigned long long* denseCursor, StitchInfo* info, uint32_t setMax, uint32_t bfsCap)
+	uint32_t* regions, uint32_t* dense, uint64_t denseCap, unsigned long long* denseCursor, StitchInfo* info, uint32_t setMax, uint32_t bfsCap, bool smallTables)
 {
 	if (!nReads) return;
-	setMax = setMax && setMax < STITCH_SET_MAX ? setMax : STITCH_SET_MAX;
-	bfsCap = bfsCap && bfsCap < STITCH_BFS_CAP ? bfsCap : STITCH_BFS_CAP;
+	const uint32_t setSize = smallTables ? STITCH_SET_SIZE_LARGE / 2 : STITCH_SET_SIZE_LARGE, capBfs = smallTables ? STITCH_BFS_CAP_LARGE / 2 : STITCH_BFS_CAP_LARGE;
+	setMax = setMax && setMax < setSize / 2 ? setMax : setSize / 2;
+	bfsCap = bfsCap && bfsCap < capBfs ? bfsCap : capBfs;
 	uint32_t blocks = nReads < 16384u ? nReads : 16384u;
-	hipLaunchKernelGGL(k_stitch, dim3(blocks), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, chainOut, chainLen, chainStatus, pathPool, pathCapacity, colinearGap, setMax, bfsCap,
+	if (smallTables) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stitch<STITCH_SET_SIZE_LARGE / 2, STITCH_BFS_CAP_LARGE / 2>), dim3(blocks), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, chainOut, chainLen, chainStatus, pathPool, pathCapacity, colinearGap, setMax, bfsCap,
+		slotOf, regions, dense, denseCap, denseCursor, info);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stitch<STITCH_SET_SIZE_LARGE, STITCH_BFS_CAP_LARGE>), dim3(blocks), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, chainOut, chainLen, chainStatus, pathPool, pathCapacity, colinearGap, setMax, bfsCap,
 		slotOf, regions, dense, denseCap, denseCursor, info);
 }
 

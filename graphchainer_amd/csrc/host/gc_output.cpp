@@ -418,7 +418,7 @@ VgAlignment vgFromEncoded(const std::string& readName, const char* sequence, con
 	return aln;
 }
 
-std::string gamGroup(const std::vector<std::string>& messages)
+std::string gamGroup(const std::vector<std::string>& messages, int level)
 {
 	std::string raw;
 	putVarint(raw, messages.size());
@@ -426,7 +426,7 @@ std::string gamGroup(const std::vector<std::string>& messages)
 	// one gzip member (protobuf's GzipOutputStream defaults: gzip format, default compression level and strategy)
 	z_stream zs;
 	memset(&zs, 0, sizeof zs);
-	if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 | 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("zlib deflateInit2 failed");
+	if (deflateInit2(&zs, level, Z_DEFLATED, 15 | 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("zlib deflateInit2 failed");
 	std::string out(deflateBound(&zs, raw.size()) + 64, '\0');
 	zs.next_in = (Bytef*)raw.data(); zs.avail_in = (uInt)raw.size();
 	zs.next_out = (Bytef*)&out[0]; zs.avail_out = (uInt)out.size();

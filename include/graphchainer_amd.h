@@ -296,6 +296,12 @@ int gc_format_json(const gc_graph* g, const gc_result* result, const char* const
 int gc_format_gam(const gc_graph* g, const gc_result* result, const char* const* read_names, const char* bases, const uint64_t* offsets,
                   char** out_bytes, uint64_t* out_len, uint64_t* n_chained_skipped);
 
+/* gc_format_gam with the zlib level of the gzip members chosen by the caller (-1 = Z_DEFAULT_COMPRESSION, what the reference's GzipOutputStream uses and gc_format_gam
+ * gives; 0..9). The inflated stream is the same at every level; deflate at the default level costs ~1 ms of CPU per 10 kb read - more than the whole alignment costs the
+ * GPU - so a host that writes GAM at the hot path's rate wants level 1 (or its own compressor on the bytes of level 0). */
+int gc_format_gam_level(const gc_graph* g, const gc_result* result, const char* const* read_names, const char* bases, const uint64_t* offsets, int level,
+                        char** out_bytes, uint64_t* out_len, uint64_t* n_chained_skipped);
+
 int gc_device_count(void);
 int gc_set_device(int device);
 /* free / total bytes of the current device's memory (a host that sizes its batches: a 10 k x 10 kb batch in flight holds ~31 GB, beside the device's one shared whole-read scratch of up to 48 GB) */

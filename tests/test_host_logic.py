@@ -220,3 +220,46 @@ def test_state_machine_extension_core_equals_oracle(tmp_path):
         fields = out.stdout.split()
         equal = int(fields[fields.index("equal") + 1])
         assert equal > 60, out.stdout
+
+
+def test_bench_inflight_rule_follows_the_cpu_budget():
+    """bench.py's batches-in-flight rule: from the host CPU a batch costs and the batch period, not from a fixed ranks-to-CPUs ratio.
+    Two ranks on a 16-CPU box keep five batches in flight each; eight ranks there are host-bound whatever they do and keep two (host work overlapping
+    device work) instead of the one the old rule forced; the record says why."""
+    sys.path.insert(0, ROOT)
+    import bench
+    k, rec = bench.choose_inflight(5, 16, 2)
+    assert k == 5 and rec["chosen"] == 5 and rec["cpus_per_rank"] == 8.0 and "5 in flight need" in rec["why"]
+    k, rec = bench.choose_inflight(5, 16, 8)
+    assert k == 2 and "host-bound" in rec["why"]
+    k, rec = bench.choose_inflight(5, 64, 8)
+    assert k == 5
+    k, rec = bench.choose_inflight(5, 18, 8)          # 2.25 CPUs per rank: two in flight need 2.17
+    assert k == 2 and "host-bound" not in rec["why"]
+    k, rec = bench.choose_inflight(1, 256, 1)
+    assert k == 1
+
+
+def test_gaf_hash_of_the_bench_check_equals_the_oracles():
+    """The end-to-end leg of bench.py compares, per read, a hash of the GAF lines the product wrote with the one the CPU leg's oracle run kept
+    (gco_align_summary2). Here both sides are the oracle's own text: the numpy hash over the text blob must equal the C one, and a one-letter change in
+    one CIGAR must change exactly that read's hash."""
+    from graphchainer_amd.workqueue import gaf_read_hashes
+    from oracle import Oracle
+    gold = os.path.join(ROOT, "tests", "golden")
+    reads = [l.strip() for l in open(os.path.join(gold, "syn20k.fa")) if not l.startswith(">")]
+    oracle = Oracle(os.path.join(gold, "syn20k.gfa"), long_pass=True)
+    w = oracle.align(reads)
+    text = oracle.gaf(False)
+    _, _, summary = oracle.align_summary(reads, 2, gaf_hash=True)
+    lines = np.where(w["chained_better"] > 0, 1, np.diff(w["read_long_off"]))
+    hashes = gaf_read_hashes(text, lines)
+    assert summary.shape[1] == 13 and np.array_equal(hashes, summary[:, 12]) and len(set(hashes.tolist())) > len(reads) // 2
+    # names do not enter: other read ids, same hashes
+    renamed = b"\n".join(b"someothername" + l[l.index(b"\t"):] for l in text.split(b"\n") if l) + b"\n"
+    assert np.array_equal(gaf_read_hashes(renamed, lines), hashes)
+    at = text.index(b"cg:Z:") + 6
+    changed = text[:at] + (b"9" if text[at:at + 1] != b"9" else b"8") + text[at + 1:]
+    diff = np.nonzero(gaf_read_hashes(changed, lines) != hashes)[0]
+    first_with_lines = int(np.nonzero(lines > 0)[0][0])
+    assert diff.tolist() == [first_with_lines]
