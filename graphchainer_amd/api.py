@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "gc_params_default", "gc_graph_create_from_gfa", "gc_graph_create", "gc_graph_destroy", "gc_graph_num_nodes",
     "gc_graph_size_bp", "gc_graph_array", "gc_seeder_create", "gc_seeder_destroy", "gc_seeder_array",
     "gc_stream_create", "gc_stream_destroy", "gc_reads_upload", "gc_reads_destroy", "gc_align_batch",
-    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_device_memory", "gc_edit_distance", "gc_edit_path", "gc_evalue", "gc_format_gaf", "gc_format_json", "gc_format_gam", "gc_format_gam_level",
+    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_device_memory", "gc_edit_distance", "gc_edit_path", "gc_evalue", "gc_format_gaf", "gc_format_json", "gc_format_gam", "gc_format_gam_level", "gc_format_gaf_trace", "gc_format_vg_trace", "gc_graph_letters",
     "gc_index_build", "gc_index_save", "gc_index_load", "gc_index_check", "gc_result_cache_trim",
 ]
 

@@ -151,6 +151,7 @@ public:
 			total = n;
 			next.store(0);
 			pending = workers.size();
+			failure = nullptr;
 			generation++;
 		}
 		wake.notify_all();
@@ -158,6 +159,7 @@ public:
 		std::unique_lock<std::mutex> lock(mutex);
 		done.wait(lock, [&]() { return pending == 0; });
 		job = nullptr;
+		if (failure) { std::exception_ptr e = failure; failure = nullptr; std::rethrow_exception(e); }   // (an exception in a pool thread used to end the process)
 	}
 private:
 	WorkerPool()
@@ -181,8 +183,14 @@ private:
 	void work(size_t id)
 	{
 		const size_t chunk = 4;
-		for (size_t i; (i = next.fetch_add(chunk)) < total;)
-			for (size_t k = i; k < std::min(total, i + chunk); k++) (*job)(k, id);
+		try {
+			for (size_t i; (i = next.fetch_add(chunk)) < total;)
+				for (size_t k = i; k < std::min(total, i + chunk); k++) (*job)(k, id);
+		} catch (...) {
+			next.store(total);   // the first failure ends the job: the other threads stop fetching, the caller rethrows
+			std::unique_lock<std::mutex> lock(mutex);
+			if (!failure) failure = std::current_exception();
+		}
 	}
 	void loop(size_t id)
 	{
@@ -205,6 +213,7 @@ private:
 	const std::function<void(size_t, size_t)>* job = nullptr;
 	std::atomic<size_t> next { 0 };
 	size_t total = 0, pending = 0, generation = 0;
+	std::exception_ptr failure;
 	bool stop = false;
 };
 
@@ -1005,6 +1014,54 @@ int gc_format_gam(const gc_graph* G, const gc_result* r, const char* const* read
 // gc_result_free keeps the large arrays of freed results (up to 24 GB) for the next batch instead of returning them to the allocator; this returns them.
 void gc_result_cache_trim(void) { g_resultBlocks.trim(); }
 
+// One alignment at a time, for a host that keeps the reference's own per-alignment calls (include/graphchainer_amd_shim.hpp: AddGAFLine / AddAlignment,
+// src/GraphAlignerWrapper.h:43-44): the trace in output coordinates in, the GAF line / the vg::Alignment message out. Host code (no device work).
+int gc_format_gaf_trace(const gc_graph* G, const char* read_name, const char* sequence, uint64_t sequence_len, const int32_t* node, const uint32_t* offset, const uint32_t* seqpos, const uint8_t* node_switch,
+	uint64_t n, int cigar_match_mismatch_merge, char** out_text, uint64_t* out_len)
+{
+	if (!G || !sequence || !out_text || !out_len || (n && (!node || !offset || !seqpos || !node_switch))) return fail(GC_ERR_INVALID, "null argument");
+	return guarded([&]() {
+		gc::TraceView tv { node, offset, seqpos, node_switch, n };
+		const std::string line = gc::formatGafLine(G->host, read_name ? read_name : "", sequence, sequence_len, tv, cigar_match_mismatch_merge != 0);
+		char* buf = (char*)malloc(line.size() + 1);
+		if (!buf) throw std::runtime_error("out of memory");
+		memcpy(buf, line.data(), line.size());
+		buf[line.size()] = 0;
+		*out_text = buf; *out_len = line.size();
+		return (int)GC_OK;
+	});
+}
+int gc_format_vg_trace(const gc_graph* G, const char* read_name, const char* sequence, uint64_t sequence_len, const int32_t* node, const uint32_t* offset, const uint32_t* seqpos, const uint8_t* node_switch,
+	uint64_t n, int32_t score, uint64_t alignment_start, uint64_t alignment_end, char** out_bytes, uint64_t* out_len)
+{
+	if (!G || !sequence || !out_bytes || !out_len || (n && (!node || !offset || !seqpos || !node_switch))) return fail(GC_ERR_INVALID, "null argument");
+	if (alignment_end < alignment_start || alignment_end > sequence_len) return fail(GC_ERR_INVALID, "gc_format_vg_trace: alignment_start / alignment_end outside the read");
+	return guarded([&]() {
+		gc::TraceView tv { node, offset, seqpos, node_switch, n };
+		const std::string msg = gc::vgToProtobuf(gc::buildVgAlignment(G->host, read_name ? read_name : "", sequence, sequence_len, tv, score, alignment_start, alignment_end));
+		char* buf = (char*)malloc(msg.size() + 1);
+		if (!buf) throw std::runtime_error("out of memory");
+		memcpy(buf, msg.data(), msg.size());
+		buf[msg.size()] = 0;
+		*out_bytes = buf; *out_len = msg.size();
+		return (int)GC_OK;
+	});
+}
+// The graph letter under each (bigraph node id, offset in the original node): what the reference's TraceItem constructor looks up (src/GraphAlignerCommon.h:148-153)
+int gc_graph_letters(const gc_graph* G, const int32_t* node, const uint32_t* offset, uint64_t n, char* out)
+{
+	if (!G || !out || (n && (!node || !offset))) return fail(GC_ERR_INVALID, "null argument");
+	return guarded([&]() {
+		gc::GraphLetters letters(G->host);
+		for (uint64_t i = 0; i < n; i++) {
+			auto it = G->host.originalNodeSize.find(node[i]);
+			if (it == G->host.originalNodeSize.end() || offset[i] >= it->second) throw std::runtime_error("gc_graph_letters: no such node / offset");
+			out[i] = letters.at(node[i], offset[i]);
+		}
+		return (int)GC_OK;
+	});
+}
+
 int gc_format_gam_level(const gc_graph* G, const gc_result* r, const char* const* read_names, const char* bases, const uint64_t* offsets, int level, char** out_bytes, uint64_t* out_len, uint64_t* n_chained_skipped)
 {
 	if (level < -1 || level > 9) return fail(GC_ERR_INVALID, "gc_format_gam_level: zlib levels are -1 (default) and 0..9");
@@ -1389,6 +1446,8 @@ int gc_seeder_array(const gc_seeder* s, const char* name, int64_t** out, uint64_
 	else if (nm == "start") src = &s->host.startPos;
 	else if (nm == "positions") src = &s->host.positions;
 	else if (nm == "maxcount") { single.push_back(s->host.maxCount); src = &single; }
+	else if (nm == "k") { single.push_back((uint64_t)s->dev.k); src = &single; }
+	else if (nm == "w") { single.push_back((uint64_t)s->dev.w); src = &single; }
 	else return fail(GC_ERR_INVALID, "unknown seeder array " + nm);
 	*out = mallocArray<int64_t>(src->size());
 	for (size_t i = 0; i < src->size(); i++) (*out)[i] = (int64_t)(*src)[i];
@@ -1869,7 +1928,7 @@ struct BatchRun {
 			const uint64_t workCapacity = 8 * n + 64ull * nGroups;   // all groups together; group g owns the slice for its reads
 			dLongWork = st->longWork.reserve<LongWork>(workCapacity);
 			dLongWorkResults = st->longWorkResults.reserve<LongWorkResult>(workCapacity);
-			dCandSeed = st->longCandSeed.reserve<uint32_t>(workCapacity);
+			dCandSeed = st->longCandSeed.reserve<uint32_t>(2 * workCapacity);   // (two halves: k_long_round alternates them by the round's parity)
 			dWorkLen = st->longWorkLen.reserve<uint32_t>(workCapacity);   // written by k_long_select, sorted into dOrder by k_long_order: the host only
 			dRetryList = st->longRetryList.reserve<uint32_t>(workCapacity);   // work items whose band outgrew the register tables (per round)
 			dOrder = st->longOrder.reserve<uint32_t>(workCapacity);       // learns the round's work count (k_publish: no copy-engine transfer in the round loop)
@@ -1955,11 +2014,11 @@ struct BatchRun {
 		launchLongInit(q, dLongJobs + r0, (uint32_t)nG, dLongState + r0);
 		launchZeroWords(q, dRoundInfo, 1);
 		launchZeroWords(q, cursorSets, 8);
-		// the extension launch's grid: two items per read cover every round (a round never holds more items than the one before it unless the rule below speculates, and
-		// the device-side rule keeps speculation within gridLimit); a batch whose 2 nG exceed the scratch's lanes runs persistent waves instead
+		// the extension launch's grid: every lane of the scratch. Two items per read cover a round without speculation (a round never holds more items than the one before it),
+		// and the device-side rule keeps speculation within gridLimit; a batch whose 2 nG exceed the scratch's lanes runs persistent waves instead
 		const uint64_t laneLimit = std::max<uint64_t>(1, scratchLanes - 64);
 		const bool gridCovers = 2 * nG <= laneLimit;
-		const uint32_t gridLimit = (uint32_t)std::min<uint64_t>(2 * nG, laneLimit);
+		const uint32_t gridLimit = (uint32_t)std::min<uint64_t>(capacity, laneLimit);   // (as many lanes as the scratch has: the late rounds' speculation rule may use them)
 		uint32_t forceCand = 0;
 		if (const char* env = getenv("GC_LONG_SPECULATE")) forceCand = (uint32_t)std::min(2, std::max(1, atoi(env)));   // test hook: speculate from round 0
 		const char* orderEnv = getenv("GC_LONG_ORDER");

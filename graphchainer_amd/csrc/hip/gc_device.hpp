@@ -184,12 +184,21 @@ enum : uint32_t { EXT_OK = 0, EXT_FAILED = 1, EXT_ASSERT = 2, EXT_OVERFLOW = 3 }
 enum : uint32_t { EXT_NOT_RUN = 7 };   // fragment pass with lazy extension: the work item has not been run (yet)
 enum : uint32_t { EXT_LDS_CAP = 5 };   // whole-read pass: a slice has more nodes than the wave tables hold (retried with larger tables, then the plain layout)
 
+// One recomputed column of the backtrace's current tile: the vertical deltas only (16 B; r4: was the whole WS, 24 B). Its score - the value of row 63 - follows from the tile's
+// start score and the bottom row's horizontal deltas, which the recompute leaves in registers (ColumnScores): 4.4 M fragment extensions x 2-3 tiles x up to 64 columns go through
+// the per-lane slab twice (written by the recompute, read by the walk), the largest part of what k_extend moves beyond its algorithmic bytes.
+struct WCol { uint64_t VP, VN; };
+struct ColumnScores {
+	int32_t start; uint64_t HP, HN;   // score of column 0; bit c: the bottom row steps +1 / -1 from column c - 1 to c
+	__device__ __forceinline__ int32_t at(uint32_t c) const { const uint64_t m = (c >= 63 ? ~0ull : ((2ull << c) - 1)) & ~1ull; return start + popc64(HP & m) - popc64(HN & m); }
+};
 struct LaneScratch {
 	SliceInfo* slices;
 	NodeItem* items;
 	Pending* pending;
-	WS* columns;        // 64 entries: one node's recomputed columns for the backtrace
+	WCol* columns;      // 64 entries: one node's recomputed columns for the backtrace
 	TraceCell* trace;
+	uint32_t* itemNodes; // the items' node ids again, packed (r4): "is this node in that slice" scans 4 B per item instead of pulling a 64 B item record per probe
 };
 
 struct ExtCounters {
@@ -289,10 +298,10 @@ __device__ __forceinline__ uint64_t eqOfColumn(const Eq4& eq, const NodeSeq& s, 
 	return r;
 }
 
-__device__ inline int findItem(const NodeItem* items, const SliceInfo& sl, uint32_t node)
+__device__ inline int findItem(const uint32_t* itemNodes, const SliceInfo& sl, uint32_t node)
 {
 	for (uint32_t i = 0; i < sl.count; i++)
-		if (items[sl.first + i].node == node) return (int)(sl.first + i);
+		if (itemNodes[sl.first + i] == node) return (int)(sl.first + i);
 	return -1;
 }
 
@@ -302,7 +311,7 @@ __device__ inline int findItem(const NodeItem* items, const SliceInfo& sl, uint3
 // columns of the score at row flatRows-1 is tracked (fused flattenLastSliceEnd, ...Common.h:1210-1218).
 struct TileResult { int32_t minScore; uint32_t minOffset; int32_t flatMin; uint32_t flatOffset; };
 __device__ inline TileResult computeTile(const DGraph& g, uint32_t node, WS ws, bool prevExists, int32_t prevStartScore, uint64_t prevHP, uint64_t prevHN,
-	const Eq4& eq, NodeItem& out, WS* columns, int flatRows, uint32_t& status)
+	const Eq4& eq, NodeItem& out, WCol* columns, int flatRows, uint32_t& status)
 {
 	int nodeLength = g.nodeLength[node];
 	NodeSeq seq = loadNodeSeq(g, node);
@@ -336,7 +345,7 @@ __device__ inline TileResult computeTile(const DGraph& g, uint32_t node, WS ws, 
 	r.flatMin = INT32_MAX;
 	r.flatOffset = 0;
 	if (flatRows > 0) r.flatMin = ws.score - popc64(ws.VP & ~flatMask) + popc64(ws.VN & ~flatMask);
-	if (columns) columns[0] = ws;
+	if (columns) columns[0] = WCol { ws.VP, ws.VN };
 	uint64_t forceEq = prevExists ? ~0ull : ~1ull;
 	uint64_t HP = 0, HN = 0;
 	for (int pos = 1; pos < nodeLength; pos++) {
@@ -349,7 +358,7 @@ __device__ inline TileResult computeTile(const DGraph& g, uint32_t node, WS ws, 
 			int32_t f = ws.score - popc64(ws.VP & ~flatMask) + popc64(ws.VN & ~flatMask);
 			if (f < r.flatMin) { r.flatMin = f; r.flatOffset = (uint32_t)pos; }
 		}
-		if (columns) columns[pos] = ws;
+		if (columns) columns[pos] = WCol { ws.VP, ws.VN };
 		HP |= hp << pos;
 		HN |= hn << pos;
 	}
@@ -362,14 +371,14 @@ __device__ inline TileResult computeTile(const DGraph& g, uint32_t node, WS ws, 
 // reference: the per-edge part of calculateNodeInner, ...Common.h:903-964; edges coming from the previous slice
 // ("skipFirst") are merged as they are, edges from an in-neighbour are first stepped into the node's column 0.
 __device__ inline void pushEdge(const DGraph& g, Pending* pending, uint32_t& nPending, const ExtendConfig& cfg, uint32_t target, WS incoming, bool skipFirst,
-	const NodeItem* items, const SliceInfo& prevSlice, const Eq4& eq, uint32_t& status)
+	const NodeItem* items, const uint32_t* itemNodes, const SliceInfo& prevSlice, const Eq4& eq, uint32_t& status)
 {
 	uint32_t slot = nPending;
 	for (uint32_t i = 0; i < nPending; i++)
 		if (pending[i].node == target) { slot = i; break; }
 	WS add = incoming;
 	if (!skipFirst) {
-		int prevIdx = findItem(items, prevSlice, target);
+		int prevIdx = findItem(itemNodes, prevSlice, target);
 		uint64_t hinP, hinN;
 		bool prevExists = prevIdx >= 0;
 		int32_t prevStart = prevExists ? items[prevIdx].sScore : 0;
@@ -399,10 +408,10 @@ __device__ inline void pushEdge(const DGraph& g, Pending* pending, uint32_t& nPe
 }
 
 // Recomputes all columns of (slice s, node) into sc.columns. reference: recalcNodeWordslice, ...Common.h:828-852
-__device__ inline void recomputeColumns(const DGraph& g, const LaneScratch& sc, uint32_t s, int itemIdx, const Eq4& eq, uint32_t& status, ExtCounters& cnt)
+__device__ inline ColumnScores recomputeColumns(const DGraph& g, const LaneScratch& sc, uint32_t s, int itemIdx, const Eq4& eq, uint32_t& status, ExtCounters& cnt)
 {
 	const NodeItem& it = sc.items[itemIdx];
-	int prevIdx = findItem(sc.items, sc.slices[s - 1], it.node);
+	int prevIdx = findItem(sc.itemNodes, sc.slices[s - 1], it.node);
 	bool prevExists = prevIdx >= 0;
 	NodeItem scratch;
 	computeTile(g, it.node, itemStart(it), prevExists, prevExists ? sc.items[prevIdx].sScore : 0,
@@ -411,6 +420,7 @@ __device__ inline void recomputeColumns(const DGraph& g, const LaneScratch& sc, 
 	cnt.recomputeTiles++;
 	cnt.backtraceTiles++;
 	cnt.columnSteps += g.nodeLength[it.node];
+	return ColumnScores { scratch.sScore, scratch.HP, scratch.HN };
 }
 
 struct Cell { uint32_t node; uint32_t offset; int32_t seqPos; };
@@ -434,7 +444,7 @@ __device__ inline bool backtraceCorner(const DGraph& g, const LaneScratch& sc, u
 	int32_t quitScore = cur.minScore + cur.bandwidth;
 	int32_t previousQuitScore = prev.minScore + prev.bandwidth;
 	int32_t scoreHere = wsValue(itemStart(sc.items[itemIdx]), 0);
-	int prevSelf = findItem(sc.items, prev, node);
+	int prevSelf = findItem(sc.itemNodes, prev, node);
 	uint32_t inBegin = g.inOff[node], inEnd = g.inOff[node + 1];
 	if (scoreHere > quitScore) {
 		int32_t smallest = scoreHere + 1;
@@ -443,9 +453,9 @@ __device__ inline bool backtraceCorner(const DGraph& g, const LaneScratch& sc, u
 		if (prevSelf >= 0) { smallest = sc.items[prevSelf].sScore; out = Cell { node, 0, j - 1 }; }
 		for (uint32_t e = inBegin; e < inEnd; e++) {
 			uint32_t nb = g.inAdj[e];
-			int p = findItem(sc.items, prev, nb);
+			int p = findItem(sc.itemNodes, prev, nb);
 			if (p >= 0 && sc.items[p].eScore <= smallest) { smallest = sc.items[p].eScore; out = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, j - 1 }; nodeSwitch = true; }
-			int c = findItem(sc.items, cur, nb);
+			int c = findItem(sc.itemNodes, cur, nb);
 			if (c >= 0 && nb != node) {
 				int32_t v = wsValue(itemEnd(sc.items[c]), 0);
 				if (v < smallest) { smallest = v; out = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, j }; nodeSwitch = true; }
@@ -460,9 +470,9 @@ __device__ inline bool backtraceCorner(const DGraph& g, const LaneScratch& sc, u
 	int32_t bestInvalidScore = scoreHere + 1;
 	for (uint32_t e = inBegin; e < inEnd; e++) {
 		uint32_t nb = g.inAdj[e];
-		int c = findItem(sc.items, cur, nb);
+		int c = findItem(sc.itemNodes, cur, nb);
 		if (c >= 0 && wsValue(itemEnd(sc.items[c]), 0) == scoreHere - 1) { out = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, j }; nodeSwitch = true; return true; }
-		int p = findItem(sc.items, prev, nb);
+		int p = findItem(sc.itemNodes, prev, nb);
 		if (p >= 0) {
 			int32_t corner = sc.items[p].eScore;
 			if (corner > previousQuitScore) {
@@ -499,6 +509,7 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 		int nl = g.nodeLength[startNode];
 		NodeItem& it = sc.items[0];
 		it.node = startNode;
+		sc.itemNodes[0] = startNode;
 		it.sVP = it.sVN = it.eVP = it.eVN = 0;
 		it.sScore = (int32_t)startOffset;
 		it.eScore = nl - 1 - (int32_t)startOffset;
@@ -529,7 +540,7 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 		for (uint32_t i = 0; i < prev.count; i++) {
 			const NodeItem& it = sc.items[prev.first + i];
 			if (j != 0 && it.minScore > previousQuitScore) continue;
-			pushEdge(g, sc.pending, nPending, cfg, it.node, wsSource(it.sScore), true, sc.items, prev, eq, status);
+			pushEdge(g, sc.pending, nPending, cfg, it.node, wsSource(it.sScore), true, sc.items, sc.itemNodes, prev, eq, status);
 		}
 		if (status != EXT_OK) return status;
 		SliceInfo cur;
@@ -545,13 +556,14 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 			sc.pending[best] = sc.pending[nPending - 1];
 			nPending--;
 			if (nItems >= cfg.maxItems) return EXT_OVERFLOW;
-			int prevIdx = findItem(sc.items, prev, p.node);
+			int prevIdx = findItem(sc.itemNodes, prev, p.node);
 			bool prevExists = prevIdx >= 0;
 			NodeItem& out = sc.items[nItems];
 			TileResult tr = computeTile(g, p.node, WS { p.VP, p.VN, p.score }, prevExists, prevExists ? sc.items[prevIdx].sScore : 0,
 				prevExists ? sc.items[prevIdx].HP : ~0ull, prevExists ? sc.items[prevIdx].HN : 0ull, eq, out, nullptr, flatRows, status);
 			if (status != EXT_OK) return status;
 			out.minScore = tr.minScore;
+			sc.itemNodes[nItems] = p.node;
 			nItems++;
 			cur.count++;
 			cnt.dpTiles++;
@@ -566,7 +578,7 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 			if (newEndMin < previousMinScore) return EXT_ASSERT;   // ...Banded.h:368
 			if (newEndMin <= currentMin + bandwidth) {
 				for (uint32_t e = g.outOff[p.node]; e < g.outOff[p.node + 1]; e++) {
-					pushEdge(g, sc.pending, nPending, cfg, g.outAdj[e], newEnd, false, sc.items, prev, eq, status);
+					pushEdge(g, sc.pending, nPending, cfg, g.outAdj[e], newEnd, false, sc.items, sc.itemNodes, prev, eq, status);
 					if (status != EXT_OK) return status;
 				}
 			}
@@ -608,6 +620,8 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 	if (!pushTrace(sc, cfg, nTrace, here, false, status)) return status;
 	uint32_t curSlice = 0xffffffffu, curNode = 0xffffffffu;
 	int curItem = -1;
+	ColumnScores colScores { 0, 0, 0 };
+	auto column = [&](uint32_t c) -> WS { const WCol w = sc.columns[c]; return WS { w.VP, w.VN, colScores.at(c) }; };
 	while (here.seqPos != -1) {
 		uint32_t s = (uint32_t)(here.seqPos / 64) + 1;
 		if (s >= nSlices) return EXT_ASSERT;
@@ -615,9 +629,9 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 			if (s != curSlice) eqs.rows(len, sc.slices[s].j, eq);
 			curSlice = s;
 			curNode = here.node;
-			curItem = findItem(sc.items, sc.slices[s], curNode);
+			curItem = findItem(sc.itemNodes, sc.slices[s], curNode);
 			if (curItem < 0) return EXT_ASSERT;
-			recomputeColumns(g, sc, s, curItem, eq, status, cnt);
+			colScores = recomputeColumns(g, sc, s, curItem, eq, status, cnt);
 			if (status != EXT_OK) return status;
 		}
 		const SliceInfo& cs = sc.slices[s];
@@ -632,14 +646,14 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 		}
 		if (row == 0) {
 			// vertical crossing into the previous slice (...Common.h:451-477, pickBacktraceVerticalCrossing :665-708)
-			int prevIdx = findItem(sc.items, ps, curNode);
+			int prevIdx = findItem(sc.itemNodes, ps, curNode);
 			if (prevIdx < 0) {
 				here = Cell { curNode, 0, here.seqPos };
 				if (!pushTrace(sc, cfg, nTrace, here, false, status)) return status;
 				continue;
 			}
 			uint32_t off = here.offset;
-			while (off > 0 && wsValue(sc.columns[off - 1], 0) == wsValue(sc.columns[off], 0) - 1) {
+			while (off > 0 && wsValue(column(off - 1), 0) == wsValue(column(off), 0) - 1) {
 				off--;
 				if (!pushTrace(sc, cfg, nTrace, Cell { curNode, off, here.seqPos }, false, status)) return status;
 			}
@@ -652,7 +666,7 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 				continue;
 			}
 			const NodeItem& pn = sc.items[prevIdx];
-			int32_t scoreHere = wsValue(sc.columns[off], 0);
+			int32_t scoreHere = wsValue(column(off), 0);
 			int32_t scoreDiagonal = pn.sScore;
 			uint64_t lowMask = off >= 1 ? (((1ull << off) - 1) & ~1ull) : 0ull;   // bits 1..off-1
 			scoreDiagonal += popc64(pn.HP & lowMask) - popc64(pn.HN & lowMask);
@@ -700,7 +714,7 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 				nxt = Cell { curNode, 0, sp - 1 };
 				for (uint32_t e = g.inOff[curNode]; e < g.inOff[curNode + 1]; e++) {
 					uint32_t nb = g.inAdj[e];
-					int c = findItem(sc.items, cs, nb);
+					int c = findItem(sc.itemNodes, cs, nb);
 					if (c < 0) continue;
 					WS ne = itemEnd(sc.items[c]);
 					if (wsValue(ne, offset - 1) <= smallest) { smallest = wsValue(ne, offset - 1); nxt = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, sp - 1 }; sw = true; }
@@ -710,7 +724,7 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 			} else {
 				for (uint32_t e = g.inOff[curNode]; e < g.inOff[curNode + 1] && !found; e++) {
 					uint32_t nb = g.inAdj[e];
-					int c = findItem(sc.items, cs, nb);
+					int c = findItem(sc.itemNodes, cs, nb);
 					if (c < 0) continue;
 					WS ne = itemEnd(sc.items[c]);
 					if (wsValue(ne, offset) == scoreHere - 1) { nxt = Cell { nb, (uint32_t)g.nodeLength[nb] - 1, sp }; sw = true; found = true; }
@@ -728,14 +742,15 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 			int vert = row;
 			NodeSeq nseq = loadNodeSeq(g, curNode);
 			while (hori > 0 && vert > 0) {
-				int32_t scoreHere = wsValue(sc.columns[hori], vert);
-				int32_t vertical = wsValue(sc.columns[hori], vert - 1);
-				int32_t diagonal = wsValue(sc.columns[hori - 1], vert - 1);
+				const WS colHere = column(hori), colLeft = column(hori - 1);
+				int32_t scoreHere = wsValue(colHere, vert);
+				int32_t vertical = wsValue(colHere, vert - 1);
+				int32_t diagonal = wsValue(colLeft, vert - 1);
 				int eqBit = (int)((eqOfColumn(eq, nseq, (int)hori) >> vert) & 1);
 				if (vertical == scoreHere - 1) { vert--; }
 				else if (diagonal == scoreHere - (eqBit ? 0 : 1)) { hori--; vert--; }
 				else {
-					if (wsValue(sc.columns[hori - 1], vert) != scoreHere - 1) return EXT_ASSERT;
+					if (wsValue(colLeft, vert) != scoreHere - 1) return EXT_ASSERT;
 					hori--;
 				}
 				if (!pushTrace(sc, cfg, nTrace, Cell { curNode, hori, cs.j + vert }, false, status)) return status;

@@ -145,8 +145,9 @@ __device__ __forceinline__ LaneScratch laneScratch(uint8_t* slab, const ExtendCo
 	sc.slices = (SliceInfo*)p;   p += sizeof(SliceInfo) * cfg.maxSlices;
 	sc.items = (NodeItem*)p;     p += sizeof(NodeItem) * cfg.maxItems;
 	sc.pending = (Pending*)p;    p += sizeof(Pending) * cfg.maxPending;
-	sc.columns = (WS*)p;         p += sizeof(WS) * 64;
-	sc.trace = (TraceCell*)p;
+	sc.columns = (WCol*)p;       p += sizeof(WCol) * 64;
+	sc.trace = (TraceCell*)p;    p += sizeof(TraceCell) * cfg.maxTrace;
+	sc.itemNodes = (uint32_t*)p;
 	return sc;
 }
 
@@ -675,7 +676,7 @@ __device__ __forceinline__ LongSlab longSlab(uint8_t* slab, const ExtendConfig& 
 {
 	LongSlab ls;
 	ls.sc = laneScratch(slab, cfg);
-	ls.traceB = ls.sc.trace + cfg.maxTrace;
+	ls.traceB = (TraceCell*)(ls.sc.itemNodes + cfg.maxItems);   // (behind the lane's extension slab)
 	return ls;
 }
 
@@ -1233,8 +1234,10 @@ __global__ void __launch_bounds__(64) k_long_round(DGraph g, const LongJob* __re
 	}
 	if (forceCand) maxCand = forceCand;
 	if (r < nReads) {
-		if (round > 0) { longMergeRead(g, r, lane, jobs, seeds, candSeed, results, tracePool, maxAlignments, state, alns, cellPool, cellCursor, cellCapacity); __threadfence_block(); }
-		longSelectRead(g, r, lane, jobs, seeds, minClusterSize, maxCand, state, alns, cellPool, work, workLen, candSeed, cur, workCapacity);
+		// the candidates' seed indices are double-buffered by the round's parity: this read's select writes the new round's list while other reads' merges still read the previous round's
+		// (everything else a select writes - work items, lengths - no merge reads; the extension results and traces a merge reads are written by the extension kernels, between the rounds)
+		if (round > 0) { longMergeRead(g, r, lane, jobs, seeds, candSeed + (uint64_t)((round - 1u) & 1u) * workCapacity, results, tracePool, maxAlignments, state, alns, cellPool, cellCursor, cellCapacity); __threadfence_block(); }
+		longSelectRead(g, r, lane, jobs, seeds, minClusterSize, maxCand, state, alns, cellPool, work, workLen, candSeed + (uint64_t)(round & 1u) * workCapacity, cur, workCapacity);
 	}
 	__threadfence();   // this wave's work items before its ticket
 	uint32_t last = 0;
@@ -1309,7 +1312,7 @@ void launchSeedLookup(hipStream_t stream, const SeedIndex& idx, const char* base
 
 uint64_t extendSlabBytes(const ExtendConfig& cfg)
 {
-	uint64_t b = sizeof(SliceInfo) * (uint64_t)cfg.maxSlices + sizeof(NodeItem) * (uint64_t)cfg.maxItems + sizeof(Pending) * (uint64_t)cfg.maxPending + sizeof(WS) * 64 + sizeof(TraceCell) * (uint64_t)cfg.maxTrace;
+	uint64_t b = sizeof(SliceInfo) * (uint64_t)cfg.maxSlices + sizeof(NodeItem) * (uint64_t)cfg.maxItems + sizeof(Pending) * (uint64_t)cfg.maxPending + sizeof(WCol) * 64 + sizeof(TraceCell) * (uint64_t)cfg.maxTrace + sizeof(uint32_t) * (uint64_t)cfg.maxItems;
 	return (b + 63) & ~63ull;
 }
 

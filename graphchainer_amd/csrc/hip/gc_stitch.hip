@@ -29,9 +29,10 @@
 
 namespace gcdev {
 
-// Two size classes of the LDS tables (r4): a piece of a 10 kb read holds ~250 split nodes and a bridge search visits a handful, so reads up to 16 kb run with half the
-// tables - 16.6 KB per wave instead of 29.5, nine waves per CU instead of five for a kernel that is all latency - and longer reads (config 5's 50 kb: ~1 000 nodes per
-// piece) keep the large ones. What outgrows a table goes to the host's stitching either way.
+// Two size classes of the LDS tables (r4): a bridge search visits a handful of nodes, so reads up to 16 kb run with half the search tables (queue, predecessors, visited
+// map: 512 / 1 024 slots) - 20 KB per wave instead of 29.5, seven waves per CU instead of five for a kernel that is all latency. The node set of a piece keeps its 2 048 slots:
+// a 10 kb read on a graph with a variant site every 45 bp crosses ~450 split nodes, and with 1 024 slots (512 nodes) a fifth of cfg2's reads went to the host's stitching
+// (host CPU per batch 0.36 -> 0.8 s, `gpurun_out/r4_rounds`). Longer reads (config 5's 50 kb) keep the large search tables too. What outgrows a table goes to the host either way.
 #define STITCH_SET_SIZE_LARGE 2048u   // open-addressing slots for the nodes of the current piece; at most half of them are used (STITCH_SET_MAX)
 #define STITCH_BFS_CAP_LARGE 1024u    // visited nodes per bridge search; its hash table has twice the slots
 #define STITCH_EMPTY 0xffffffffu
@@ -337,11 +338,11 @@ void launchStitch(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs,
 	uint32_t* regions, uint32_t* dense, uint64_t denseCap, unsigned long long* denseCursor, StitchInfo* info, uint32_t setMax, uint32_t bfsCap, bool smallTables)
 {
 	if (!nReads) return;
-	const uint32_t setSize = smallTables ? STITCH_SET_SIZE_LARGE / 2 : STITCH_SET_SIZE_LARGE, capBfs = smallTables ? STITCH_BFS_CAP_LARGE / 2 : STITCH_BFS_CAP_LARGE;
+	const uint32_t setSize = STITCH_SET_SIZE_LARGE, capBfs = smallTables ? STITCH_BFS_CAP_LARGE / 2 : STITCH_BFS_CAP_LARGE;
 	setMax = setMax && setMax < setSize / 2 ? setMax : setSize / 2;
 	bfsCap = bfsCap && bfsCap < capBfs ? bfsCap : capBfs;
 	uint32_t blocks = nReads < 16384u ? nReads : 16384u;
-	if (smallTables) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stitch<STITCH_SET_SIZE_LARGE / 2, STITCH_BFS_CAP_LARGE / 2>), dim3(blocks), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, chainOut, chainLen, chainStatus, pathPool, pathCapacity, colinearGap, setMax, bfsCap,
+	if (smallTables) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stitch<STITCH_SET_SIZE_LARGE, STITCH_BFS_CAP_LARGE / 2>), dim3(blocks), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, chainOut, chainLen, chainStatus, pathPool, pathCapacity, colinearGap, setMax, bfsCap,
 		slotOf, regions, dense, denseCap, denseCursor, info);
 	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stitch<STITCH_SET_SIZE_LARGE, STITCH_BFS_CAP_LARGE>), dim3(blocks), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, chainOut, chainLen, chainStatus, pathPool, pathCapacity, colinearGap, setMax, bfsCap,
 		slotOf, regions, dense, denseCap, denseCursor, info);

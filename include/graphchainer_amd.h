@@ -136,7 +136,7 @@ int gc_graph_array(const gc_graph* g, const char* name, int64_t** out, uint64_t*
 /* ---- seeder (replaces MinimizerSeeder::MinimizerSeeder, src/Aligner.cpp:1162) --------------------- */
 int gc_seeder_create(const gc_graph* g, int32_t k, int32_t w, double keep_least_frequent_fraction, gc_seeder** out);
 void gc_seeder_destroy(gc_seeder* s);
-int gc_seeder_array(const gc_seeder* s, const char* name, int64_t** out, uint64_t* count);   /* "kmers","start","positions","maxcount" */
+int gc_seeder_array(const gc_seeder* s, const char* name, int64_t** out, uint64_t* count);   /* "kmers","start","positions","maxcount","k","w" */
 
 /* ---- index cache --------------------------------------------------------------
  * The start-up work above (GFA parse, node splitting, topological order, greedy path cover + max-flow shrink, MPC index,
@@ -295,6 +295,19 @@ int gc_format_json(const gc_graph* g, const gc_result* result, const char* const
                    char** out_text, uint64_t* out_len, uint64_t* n_chained_skipped);
 int gc_format_gam(const gc_graph* g, const gc_result* result, const char* const* read_names, const char* bases, const uint64_t* offsets,
                   char** out_bytes, uint64_t* out_len, uint64_t* n_chained_skipped);
+
+/* One alignment at a time, for a host that keeps the reference's per-alignment output calls (src/GraphAlignerWrapper.h:43-44; include/graphchainer_amd_shim.hpp
+ * forwards AddGAFLine / AddAlignment here). The trace is in output coordinates (bigraph node id, offset in the original node, read position, "the next cell is in
+ * another split node": long_trace_* / chain_trace_* / anchor_trace_* of a gc_result, or a reference OnewayTrace). Host code, no device work; free the output with gc_free.
+ *   gc_format_gaf_trace  GraphAlignerGAFAlignment::traceToAlignment (src/GraphAlignerGAFAlignment.h:38-196): the GAF line, no newline.
+ *   gc_format_vg_trace   GraphAlignerVGAlignment::traceToAlignment + AddAlignment's sequence / query_position + replaceDigraphNodeIdsWithOriginalNodeIds
+ *                        (src/GraphAlignerVGAlignment.h:36-163, src/GraphAligner.h:205-212, src/Aligner.cpp:152-165): the vg::Alignment message, proto3 wire bytes.
+ *   gc_graph_letters     the graph letter under each (node id, offset): TraceItem's graphCharacter (src/GraphAlignerCommon.h:148-153). */
+int gc_format_gaf_trace(const gc_graph* g, const char* read_name, const char* sequence, uint64_t sequence_len, const int32_t* node, const uint32_t* offset, const uint32_t* seqpos,
+                        const uint8_t* node_switch, uint64_t n, int cigar_match_mismatch_merge, char** out_text, uint64_t* out_len);
+int gc_format_vg_trace(const gc_graph* g, const char* read_name, const char* sequence, uint64_t sequence_len, const int32_t* node, const uint32_t* offset, const uint32_t* seqpos,
+                       const uint8_t* node_switch, uint64_t n, int32_t score, uint64_t alignment_start, uint64_t alignment_end, char** out_bytes, uint64_t* out_len);
+int gc_graph_letters(const gc_graph* g, const int32_t* node, const uint32_t* offset, uint64_t n, char* out);
 
 /* gc_format_gam with the zlib level of the gzip members chosen by the caller (-1 = Z_DEFAULT_COMPRESSION, what the reference's GzipOutputStream uses and gc_format_gam
  * gives; 0..9). The inflated stream is the same at every level; deflate at the default level costs ~1 ms of CPU per 10 kb read - more than the whole alignment costs the

@@ -6,7 +6,8 @@
 //   AlignOneWay (whole read, sloppy)     src/GraphAlignerWrapper.h:41    (:565)
 //   AlignOneWay (fragment, l / r / offset)                               (:691)
 //   AlignmentGraph::colinearChaining     src/AlignmentGraph.h:121        (:735)
-// This header gives those five calls, with the reference's signatures, on top of include/graphchainer_amd.h, so the
+//   AddAlignment / AddGAFLine / AddCorrected   src/GraphAlignerWrapper.h:43-45   (:1006-1019)   (r4)
+// This header gives those calls, with the reference's signatures, on top of include/graphchainer_amd.h, so the
 // reference's own src/Aligner.cpp can link against libgraphchainer_amd.so instead of GraphAlignerWrapper.cpp /
 // MinimizerSeeder.cpp / the chaining part of AlignmentGraph.cpp where its tool-chain exists.
 //
@@ -48,6 +49,7 @@ struct Binding {
 	gc_seeder* seeder = nullptr;
 	gc_params params {};
 	std::vector<int64_t> nodeIDs, nodeOffset;   // split node -> bigraph node id, offset in the original node
+	size_t minimizerLength = 15;                // the seeder's k: SeedHit::matchLen (src/MinimizerSeeder.cpp:549)
 };
 inline Binding& binding() { static Binding b; return b; }
 
@@ -69,6 +71,12 @@ inline void bind(gc_graph* graph, gc_seeder* seeder, gc_params params)
 	params.long_pass = 1; params.keep_traces = 1; params.keep_seeds = 1; params.stitch = 1; params.edit_distances = 1;
 	b.params = params;
 	b.nodeIDs = graphArray(graph, "nodeIDs"); b.nodeOffset = graphArray(graph, "nodeOffset");
+	{
+		int64_t* p = nullptr; uint64_t n = 0;
+		if (gc_seeder_array(seeder, "k", &p, &n) != GC_OK || n != 1) throw std::runtime_error(gc_last_error());
+		b.minimizerLength = (size_t)p[0];
+		gc_free(p);
+	}
 }
 
 // One per worker thread: the stand-in for AlignerGraphsizedState (src/Aligner.cpp:469).
@@ -103,6 +111,8 @@ template <typename TraceVector>
 inline void fillTrace(TraceVector& out, const std::string& sequence, const int32_t* node, const uint32_t* offset, const uint32_t* seqPos, const uint8_t* nodeSwitch, uint64_t n, size_t seqBase)
 {
 	out.reserve(n);
+	std::vector<char> letters(n);   // TraceItem's graphCharacter (src/GraphAlignerCommon.h:148-153), so that the reference's own AddAlignment / AddGAFLine / AddCorrected can read a shim trace
+	if (n && gc_graph_letters(binding().graph, node, offset, n, letters.data()) != GC_OK) throw std::runtime_error(gc_last_error());
 	for (uint64_t i = 0; i < n; i++) {
 		typename TraceVector::value_type item;
 		item.DPposition.node = (size_t)node[i];
@@ -111,8 +121,58 @@ inline void fillTrace(TraceVector& out, const std::string& sequence, const int32
 		item.nodeSwitch = nodeSwitch[i] != 0;
 		const size_t at = seqBase + seqPos[i];
 		item.sequenceCharacter = at < sequence.size() ? sequence[at] : '-';
-		item.graphCharacter = '-';   // output goes through gc_format_gaf / json / gam; AddAlignment on a shim trace would need the graph letters
+		item.graphCharacter = letters[i];
 		out.push_back(item);
+	}
+}
+
+// a OnewayTrace as the four arrays the C ABI's per-trace encoders take
+struct TraceArrays {
+	std::vector<int32_t> node; std::vector<uint32_t> offset, seqPos; std::vector<uint8_t> nodeSwitch;
+	template <typename TraceVector> explicit TraceArrays(const TraceVector& t)
+	{
+		node.reserve(t.size()); offset.reserve(t.size()); seqPos.reserve(t.size()); nodeSwitch.reserve(t.size());
+		for (const auto& item : t) { node.push_back((int32_t)item.DPposition.node); offset.push_back((uint32_t)item.DPposition.nodeOffset); seqPos.push_back((uint32_t)item.DPposition.seqPos); nodeSwitch.push_back(item.nodeSwitch ? 1 : 0); }
+	}
+};
+
+// AddGAFLine, src/GraphAlignerWrapper.h:44 (GraphAligner::AddGAFLine, src/GraphAligner.h:214-218): alignment.GAFline = the line of the alignment's trace
+inline void AddGAFLine(const AlignmentGraph&, const std::string& seq_id, const std::string& sequence, AlignmentResult::AlignmentItem& alignment, bool cigarMatchMismatchMerge)
+{
+	if (!alignment.trace || alignment.trace->trace.empty()) throw std::logic_error("gcshim::AddGAFLine: the alignment has no trace");
+	const TraceArrays t(alignment.trace->trace);
+	char* text = nullptr; uint64_t len = 0;
+	if (gc_format_gaf_trace(binding().graph, seq_id.c_str(), sequence.data(), sequence.size(), t.node.data(), t.offset.data(), t.seqPos.data(), t.nodeSwitch.data(), t.node.size(), cigarMatchMismatchMerge ? 1 : 0, &text, &len) != GC_OK)
+		throw std::runtime_error(gc_last_error());
+	alignment.GAFline.assign(text, len);
+	gc_free(text);
+}
+
+// AddAlignment, src/GraphAlignerWrapper.h:43 (GraphAligner::AddAlignment, src/GraphAligner.h:205-212, followed by replaceDigraphNodeIdsWithOriginalNodeIds, src/Aligner.cpp:152-165,1009):
+// alignment.alignment = the vg::Alignment of the trace, parsed from the message bytes the library builds (the reference's vg::Alignment is a protobuf message)
+inline void AddAlignment(const std::string& seq_id, const std::string& sequence, AlignmentResult::AlignmentItem& alignment)
+{
+	if (!alignment.trace || alignment.trace->trace.empty()) throw std::logic_error("gcshim::AddAlignment: the alignment has no trace");
+	const TraceArrays t(alignment.trace->trace);
+	char* bytes = nullptr; uint64_t len = 0;
+	if (gc_format_vg_trace(binding().graph, seq_id.c_str(), sequence.data(), sequence.size(), t.node.data(), t.offset.data(), t.seqPos.data(), t.nodeSwitch.data(), t.node.size(), (int32_t)alignment.trace->score,
+			alignment.alignmentStart, alignment.alignmentEnd, &bytes, &len) != GC_OK)
+		throw std::runtime_error(gc_last_error());
+	alignment.alignment = std::make_shared<typename decltype(alignment.alignment)::element_type>();
+	const bool parsed = alignment.alignment->ParseFromString(std::string(bytes, len));
+	gc_free(bytes);
+	if (!parsed) throw std::runtime_error("gcshim::AddAlignment: the vg::Alignment bytes did not parse");
+}
+
+// AddCorrected, src/GraphAlignerWrapper.h:45 (src/GraphAligner.h:220-231): the graph letters along the trace, one per graph position
+inline void AddCorrected(AlignmentResult::AlignmentItem& alignment)
+{
+	if (!alignment.trace || alignment.trace->trace.empty()) throw std::logic_error("gcshim::AddCorrected: the alignment has no trace");
+	const auto& t = alignment.trace->trace;
+	alignment.corrected.assign(1, t[0].graphCharacter);
+	for (size_t i = 1; i < t.size(); i++) {
+		if (!t[i - 1].nodeSwitch && t[i].DPposition.nodeOffset == t[i - 1].DPposition.nodeOffset && t[i].DPposition.node == t[i - 1].DPposition.node) continue;
+		alignment.corrected += t[i].graphCharacter;
 	}
 }
 
@@ -126,7 +186,7 @@ inline std::vector<SeedHit> getSeeds(const std::string& sequence, double /*densi
 	for (uint64_t i = r.read_seed_off[0]; i < r.read_seed_off[1]; i++) {
 		const uint32_t node = r.seed_node[i];
 		const int bigraph = (int)b.nodeIDs[node];
-		SeedHit s(bigraph / 2, (size_t)b.nodeOffset[node] + r.seed_offset[i], r.seed_seqpos[i], (size_t)15, 0, (bigraph & 1) != 0);
+		SeedHit s(bigraph / 2, (size_t)b.nodeOffset[node] + r.seed_offset[i], r.seed_seqpos[i], b.minimizerLength, 0, (bigraph & 1) != 0);
 		s.alignmentGraphNodeId = node;
 		s.alignmentGraphNodeOffset = r.seed_offset[i];
 		s.seedGoodness = r.seed_goodness[i];
@@ -210,6 +270,9 @@ AlignmentResult AlignOneWay(const AlignmentGraph& graph, const std::string& seq_
 	return gcshim::AlignOneWay(graph, seq_id, sequence, initialBandwidth, rampBandwidth, maxCellsPerSlice, quietMode, sloppyOptimizations, seedHits, reusableState, lowMemory, forceGlobal, preciseClipping, minClusterSize, seedExtendDensity, nondeterministicOptimizations, preciseClippingIdentityCutoff, Xdropcutoff, l, r, offset, l < 0 ? nullptr : &gcshim::currentRead());
 }
 void OrderSeeds(const AlignmentGraph& graph, std::vector<SeedHit>& seedHits) { gcshim::OrderSeeds(graph, seedHits); }
+void AddAlignment(const std::string& seq_id, const std::string& sequence, AlignmentResult::AlignmentItem& alignment) { gcshim::AddAlignment(seq_id, sequence, alignment); }
+void AddGAFLine(const AlignmentGraph& graph, const std::string& seq_id, const std::string& sequence, AlignmentResult::AlignmentItem& alignment, bool cigarMatchMismatchMerge) { gcshim::AddGAFLine(graph, seq_id, sequence, alignment, cigarMatchMismatchMerge); }
+void AddCorrected(AlignmentResult::AlignmentItem& alignment) { gcshim::AddCorrected(alignment); }
 #endif
 
 #endif

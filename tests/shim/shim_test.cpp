@@ -18,6 +18,7 @@ struct GraphAlignerCommon {
 	struct OnewayTrace { std::vector<TraceItem> trace; ScoreType score = 0; };
 	struct AlignerGraphsizedState {};
 };
+namespace vg { struct Alignment { std::string bytes; bool ParseFromString(const std::string& s) { bytes = s; return true; } }; }
 struct SeedHit {
 	SeedHit(int nodeID, size_t nodeOffset, size_t seqPos, size_t matchLen, size_t rawSeedGoodness, bool reverse) : nodeID(nodeID), nodeOffset(nodeOffset), seqPos(seqPos), matchLen(matchLen), reverse(reverse),
 		alignmentGraphNodeId(std::numeric_limits<size_t>::max()), alignmentGraphNodeOffset(std::numeric_limits<size_t>::max()), rawSeedGoodness(rawSeedGoodness), seedGoodness(0), seedClusterSize(0) {}
@@ -30,6 +31,8 @@ struct AlignmentResult {
 		{ trace = std::make_shared<GraphAlignerCommon<size_t, int32_t, uint64_t>::OnewayTrace>(); *trace = std::move(t); }
 		bool alignmentFailed() const { return alignmentEnd == alignmentStart; }
 		std::shared_ptr<GraphAlignerCommon<size_t, int32_t, uint64_t>::OnewayTrace> trace;
+		std::shared_ptr<vg::Alignment> alignment;   // (the reference's is the protobuf message; here: a holder of its bytes)
+		std::string GAFline, corrected;
 		size_t seedGoodness = 0, cellsProcessed = 0, elapsedMilliseconds = 0, alignmentStart = 0, alignmentEnd = 0, alignmentScore = std::numeric_limits<size_t>::max();
 	};
 	std::vector<AlignmentItem> alignments;
@@ -85,6 +88,16 @@ int main(int argc, char** argv)
 				for (auto& t : alignment.trace->trace) if (anchor.path.empty() || t.DPposition.node != anchor.path.back()) anchor.path.push_back(t.DPposition.node);   // (bigraph ids here; the reference maps to split nodes with GetUnitigNode)
 				A.push_back(anchor);
 			}
+		}
+		// output of the whole-read alignments through the reference's calls (src/Aligner.cpp:1006-1019): AddGAFLine / AddAlignment on the shim's items
+		for (size_t i = 0; i < longAlignments.alignments.size(); i++) {
+			auto& item = longAlignments.alignments[i];
+			AddGAFLine(alignmentGraph, "r" + std::to_string(a - 2), sequence, item, false);
+			AddAlignment("r" + std::to_string(a - 2), sequence, item);
+			AddCorrected(item);
+			unsigned long long h = 1469598103934665603ull;
+			for (unsigned char c : item.alignment->bytes) { h ^= c; h *= 1099511628211ull; }
+			printf("gaf %d %zu %zu %zu %016llx %zu\t%s\n", a - 2, i, item.alignmentStart, item.alignmentEnd, h, item.corrected.size(), item.GAFline.c_str());
 		}
 		std::vector<size_t> ids = gcshim::colinearChaining(sequence, A, 10000);                        // :735
 		printf("read %d: seeds %zu long %zu anchors %zu chain %zu :", a - 2, seeds.size(), longAlignments.alignments.size(), A.size(), ids.size());

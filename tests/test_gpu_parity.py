@@ -602,7 +602,19 @@ def test_shim_replays_the_reference_call_sequence(gca, tmp_path, golden_dir):
     assert out.returncode == 0, out.stdout + out.stderr
     graph = gca.AlignmentGraph(gfa)
     res = gca.Aligner(graph, gca.MinimizerSeeder(graph), long_pass=True, keep_seeds=True).align_reads([r.encode() for r in reads])
-    lines = out.stdout.strip().splitlines()
+    all_lines = out.stdout.strip().splitlines()
+    # r4: AddGAFLine / AddAlignment / AddCorrected on the shim's items (src/GraphAlignerWrapper.h:43-45): every whole-read alignment's GAF line through the shim; the ones
+    # the reference would write (the selection) must be the lines gc_format_gaf returns for the batch, and the vg message / corrected sequence exist for each
+    gaf_lines = [l for l in all_lines if l.startswith("gaf ")]
+    lines = [l for l in all_lines if l.startswith("read ")]
+    traced = gca.Aligner(graph, gca.MinimizerSeeder(graph), long_pass=True, keep_traces=True).align_reads([r.encode() for r in reads], gaf_names=[f"r{i}" for i in range(len(reads))])
+    shim_text = {l.split("\t", 1)[1] for l in gaf_lines}
+    batch_lines = [l for l in traced["gaf"].decode().splitlines() if l]
+    assert batch_lines and all(l in shim_text for l in batch_lines)
+    assert len(gaf_lines) == int(traced["read_longall_off"][-1])
+    for l in gaf_lines:
+        head = l.split("\t", 1)[0].split()
+        assert int(head[6]) > 0 and len(head[5]) == 16           # corrected letters; hash of the message bytes
     assert len(lines) == len(reads)
     for r, line in enumerate(lines):
         head, chain = line.split(":", 2)[1:]
@@ -878,10 +890,11 @@ def test_batches_in_flight_equal_serial_and_oracle(gca, tmp_path, monkeypatch, t
     assert sum(int(np.sum(w["chained_better"])) for w in want) > 0
 
 
-def test_two_ranks_real_aligner_strong_queue(gca, tmp_path):
-    """BASELINE configs[3]'s shape with the REAL aligner: two ranks (torch.distributed.run, gloo for the barrier and the queue
-    reset only), ONE read set divided by the product's flock'ed work queue, every rank running gc_align_batch on its own
-    gc_streams (both ranks share this box's one GPU: a dry run of the launch path, not a measurement), per-read results merged
+@pytest.mark.parametrize("n_ranks", [2, 4])
+def test_two_ranks_real_aligner_strong_queue(gca, tmp_path, n_ranks):
+    """BASELINE configs[3]'s shape with the REAL aligner: two (r4: and four) ranks (torch.distributed.run, gloo for the barrier and the queue
+    reset only), ONE read set divided by the product's flock'ed work queue, every rank running gc_align_batch on its own two
+    gc_streams (the ranks share this box's one GPU: a dry run of the launch path, not a measurement), per-read results merged
     over the ranks and compared with the oracle's. The launcher starts before anything touches the GPU."""
     import subprocess
     import sys
@@ -945,8 +958,9 @@ def test_two_ranks_real_aligner_strong_queue(gca, tmp_path):
             print("RANKS_OK")
         dist.destroy_process_group()
     """))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", GC_HOST_THREADS="4")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29577", str(script)],
+    port = str(29577 + n_ranks)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, GC_HOST_THREADS="4", GPU_MAX_HW_QUEUES="16")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                          capture_output=True, text=True, env=env, timeout=900)
     assert "RANKS_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
     off = want["read_longall_off"]
