@@ -57,7 +57,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-long-pass", action="store_true", help="skip the whole-read GraphAligner pass (src/Aligner.cpp:630-654)")
     ap.add_argument("--strong", action="store_true", help="N>1: one read set divided over the ranks through the work queue (strong scaling)")
-    ap.add_argument("--e2e-steps", type=int, default=int(os.environ.get("GC_BENCH_E2E_STEPS", 3)),
+    ap.add_argument("--e2e-steps", type=int, default=int(os.environ.get("GC_BENCH_E2E_STEPS", 16)),
                     help="after the timed steps (N=1): this many steps with the read upload (gc_reads_upload) and the GAF encoding of every batch inside the step "
                          "(the whole boundary: host bases in, GAF text out); 0 skips it")
     ap.add_argument("--e2e-formats", default=os.environ.get("GC_BENCH_E2E_FORMATS", "gaf,gam"), help="end-to-end legs to run: gaf, gam (comma separated)")
@@ -399,17 +399,26 @@ def main():
                 free_streams.put(a)
             kept, checking = {}, [True]
 
-            def e2e_item(worker, item, fmt=fmt, level=level, kept=kept, checking=checking, free_streams=free_streams):
+            spent = np.zeros(4)                                       # seconds in: upload, waiting for a stream, gc_align_batch, formatting (summed over the timed batches)
+
+            def e2e_item(worker, item, fmt=fmt, level=level, kept=kept, checking=checking, free_streams=free_streams, spent=spent):
                 b = item % len(chunks)
+                t_a = time.perf_counter()
                 batch = gca.ReadBatch([reads[i] for i in chunks[b]])
+                t_b = time.perf_counter()
                 aligner = free_streams.get()
+                t_c = time.perf_counter()
                 try:
                     out = aligner.align_batch(batch)
                 finally:
                     free_streams.put(aligner)
+                t_d = time.perf_counter()
                 texts, skipped = aligner.format_batch(out, batch, names[b], formats=(fmt,), gam_level=level)
+                t_e = time.perf_counter()
                 if checking[0] and fmt == "gaf" and cpu_summary is not None:
                     kept[item] = gaf_check(texts["gaf"], out, chunks[b], cpu_summary)
+                elif not checking[0]:
+                    spent += (t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d)   # (float adds under the GIL)
                 batch.close()
                 return len(texts[fmt]), skipped
             queue.reset(e2e_workers * len(chunks))
@@ -423,6 +432,7 @@ def main():
             rec = {"reads_per_s": round(args.e2e_steps * len(reads) / dt, 2), "ms_per_step": round(dt / args.e2e_steps * 1e3, 2), "steps": args.e2e_steps,
                    "host_cpu_s_per_step": round((cpu_seconds() - cpu0) / args.e2e_steps, 3), "host_threads": e2e_workers, "streams": inflight,
                    "bytes_per_step": int(sum(n for _i, (n, _s) in done) / args.e2e_steps), "chained_winners_without_trace": int(sum(s for _i, (_n, s) in done)),
+                   "ms_per_batch_in": dict(zip(("upload", "waiting_for_a_stream", "gc_align_batch", "format"), (np.round(spent / max(1, len(done)) * 1e3, 1)).tolist())),
                    "includes": f"gc_reads_upload (PCIe + packing kernels) + hot path + output encoding on the device (k_out_encode) + gc_format_{fmt}" + (f"_level(level {level})" if level is not None else "") + " of every batch"}
             if fmt == "gam":
                 rec["gzip"] = "zlib level " + ("default (6), as the reference's GzipOutputStream" if level is None else str(level)) + ": deflate is host work the reference pays too, ~1 ms of CPU per 10 kb read at the default level"

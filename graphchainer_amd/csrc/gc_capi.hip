@@ -2358,6 +2358,7 @@ struct BatchRun {
 			std::vector<uint32_t> all(n);
 			for (uint64_t r = 0; r < n; r++) all[r] = (uint32_t)r;
 			decideLongReads(all, 0, st->longStream, [&](uint32_t r) { return hLongResults[r].nAlignments; });
+			encodeOutputStart();   // (the selection is known; its waits overlap the NW kernels the decision has just queued)
 			finishLongDecision(0);
 		}
 	}
@@ -2875,40 +2876,43 @@ struct BatchRun {
 	const char* hOutPath = nullptr; const char* hOutCigar = nullptr; const uint8_t* hOutVg = nullptr;
 	uint64_t nOutJobs = 0;
 	std::vector<uint64_t> outJobOfEntry;
-	void encodeOutput()
+	// Started by the whole-read pass's own thread as soon as the selection is known (the end of afterLongPass): the main thread is still in the fragment pipeline, the stitching and the
+	// chain distances then, so the two passes of the encoder, their two waits and the download of the text overlap that work instead of following it (r4: with the encoder after the
+	// join, every batch's latency grew by the encoder's launches waiting for wave slots among the other batches' kernels, and five streams in flight completed a batch every 255-268 ms
+	// end to end against 160 for the hot path). Every read's selected alignments are encoded; a read whose chained alignment wins in the end (known only after the join) drops its pieces
+	// in encodeOutput - wasted work in proportion to the winners.
+	std::vector<uint64_t> readJobBegin;   // first job of every read (jobs of a read: its selected alignments sorted by alignmentStart); [n] = number of jobs
+	std::vector<uint32_t> jobAln;         // the alignment (index into the read's longAlns) of every job
+	void encodeOutputStart()
 	{
 		if (!P->device_output) return;
 		const double t0 = nowUs();
-		readOutOff.assign(n + 1, 0);
-		outEntries.clear();
+		readJobBegin.assign(n + 1, 0);
+		jobAln.clear();
 		for (uint64_t r = 0; r < n; r++) {
 			const ReadGlue& gl = glue[r];
-			readOutOff[r] = outEntries.size();
+			readJobBegin[r] = jobAln.size();
 			if (gl.longFailed) continue;
-			if (gl.chainWins) { outEntries.push_back(OutEntry { (uint32_t)r, 0, 1 }); continue; }
 			struct Item { uint32_t start; uint32_t aln; };
 			std::vector<Item> items;
 			for (uint32_t k : gl.longSelected) items.push_back(Item { gl.longAlns[k].start, k });
 			auto byStart = [](const Item& l, const Item& rr) { return l.start < rr.start; };
 			std::sort(items.begin(), items.end(), byStart);   // src/Aligner.cpp:1003
 			std::sort(items.begin(), items.end(), byStart);   // :1023 (an unstable sort may move ties even in a sorted list)
-			for (const Item& it : items) outEntries.push_back(OutEntry { (uint32_t)r, it.aln, 0 });
+			for (const Item& it : items) jobAln.push_back(it.aln);
 		}
-		readOutOff[n] = outEntries.size();
-		outJobOfEntry.assign(outEntries.size(), ~0ull);
-		OutJob* hJobsOut = st->hOutJobs.reserve<OutJob>(outEntries.size());
-		nOutJobs = 0;
-		const uint32_t flags = ((P->device_output & 2) ? 1u : 0u) | ((P->device_output & 3) ? 2u : 0u) | ((P->device_output & 4) ? 4u : 0u);
-		for (size_t e = 0; e < outEntries.size(); e++) {
-			if (outEntries[e].source != 0) continue;
-			const uint32_t r = outEntries[e].read;
-			const LongAln& al = glue[r].longAlns[outEntries[e].aln];
-			hJobsOut[nOutJobs] = OutJob { al.traceOff, R->offsets[r], al.traceLen, (uint32_t)(R->offsets[r + 1] - R->offsets[r]), flags, 0 };
-			outJobOfEntry[e] = nOutJobs++;
-		}
+		readJobBegin[n] = jobAln.size();
+		nOutJobs = jobAln.size();
 		if (nOutJobs == 0) return;
 		if (nOutJobs >= 0xffffffffull) throw std::runtime_error("too many alignments in one batch for the output encoder");
-		hipStream_t q = st->longStream;   // (idle by now: the pass and its decision are done)
+		OutJob* hJobsOut = st->hOutJobs.reserve<OutJob>(nOutJobs);
+		const uint32_t flags = ((P->device_output & 2) ? 1u : 0u) | ((P->device_output & 3) ? 2u : 0u) | ((P->device_output & 4) ? 4u : 0u);
+		for (uint64_t r = 0; r < n; r++)
+			for (uint64_t k = readJobBegin[r]; k < readJobBegin[r + 1]; k++) {
+				const LongAln& al = glue[r].longAlns[jobAln[k]];
+				hJobsOut[k] = OutJob { al.traceOff, R->offsets[r], al.traceLen, (uint32_t)(R->offsets[r + 1] - R->offsets[r]), flags, 0 };
+			}
+		hipStream_t q = st->longStream;   // (the pass and its decision are done with it)
 		OutJob* dJobsOut = st->outJobs.reserve<OutJob>(nOutJobs);
 		OutRec* dRecs = st->outRecs.reserve<OutRec>(nOutJobs);
 		uint64_t* dOffsets = st->outOffsets.reserve<uint64_t>(3 * (nOutJobs + 1));
@@ -2937,8 +2941,25 @@ struct BatchRun {
 		syncStream(q);
 		for (uint64_t k = 0; k < nOutJobs; k++) if (recs[k].steps == 0xffffffffu) throw std::runtime_error("internal: the output encoder's two passes disagree on an alignment's size");
 		hOutRecs = recs; hOutOffsets = offs; hOutPath = pathText; hOutCigar = cigarText; hOutVg = vg;
-		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] output encoding on the device: %llu alignments, %.1f MB of path text, %.1f MB of CIGAR, %.1f MB of vg::Path bytes, %.1f ms\n",
+		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] output encoding on the device: %llu alignments, %.1f MB of path text, %.1f MB of CIGAR, %.1f MB of vg::Path bytes, %.1f ms (on the whole-read pass's thread, beside the fragment pipeline)\n",
 			(unsigned long long)nOutJobs, pathBytes / 1e6, cigarBytes / 1e6, vgBytes / 1e6, (nowUs() - t0) / 1e3);
+	}
+
+	// After the decision: which of the encoded alignments are the batch's output, in the reference's order
+	void encodeOutput()
+	{
+		if (!P->device_output) return;
+		readOutOff.assign(n + 1, 0);
+		outEntries.clear();
+		outJobOfEntry.clear();
+		for (uint64_t r = 0; r < n; r++) {
+			const ReadGlue& gl = glue[r];
+			readOutOff[r] = outEntries.size();
+			if (gl.longFailed) continue;
+			if (gl.chainWins) { outEntries.push_back(OutEntry { (uint32_t)r, 0, 1 }); outJobOfEntry.push_back(~0ull); continue; }
+			for (uint64_t k = readJobBegin[r]; k < readJobBegin[r + 1]; k++) { outEntries.push_back(OutEntry { (uint32_t)r, jobAln[k], 0 }); outJobOfEntry.push_back(k); }
+		}
+		readOutOff[n] = outEntries.size();
 	}
 
 	void assembleOutput()   // the pieces into the result (entries of chained winners stay empty: source 1)
@@ -2951,11 +2972,19 @@ struct BatchRun {
 		res->out_numbers = resultArray<uint64_t>(12 * nOut);
 		res->out_path_off = resultArray<uint64_t>(nOut + 1); res->out_cigar_off = resultArray<uint64_t>(nOut + 1); res->out_vg_off = resultArray<uint64_t>(nOut + 1);
 		const uint64_t stride = nOutJobs + 1;
-		const uint64_t pathBytes = nOutJobs ? hOutOffsets[nOutJobs] : 0, cigarBytes = nOutJobs ? hOutOffsets[stride + nOutJobs] : 0, vgBytes = nOutJobs ? hOutOffsets[2 * stride + nOutJobs] : 0;
+		// where every entry's pieces go: the kept jobs' bytes back to back (all of them, in order, unless chained alignments won)
+		uint64_t pathBytes = 0, cigarBytes = 0, vgBytes = 0;
+		for (uint64_t e = 0; e < nOut; e++) {
+			res->out_path_off[e] = pathBytes; res->out_cigar_off[e] = cigarBytes; res->out_vg_off[e] = vgBytes;
+			const uint64_t k = outJobOfEntry[e];
+			if (k == ~0ull) continue;
+			pathBytes += hOutOffsets[k + 1] - hOutOffsets[k]; cigarBytes += hOutOffsets[stride + k + 1] - hOutOffsets[stride + k]; vgBytes += hOutOffsets[2 * stride + k + 1] - hOutOffsets[2 * stride + k];
+		}
+		res->out_path_off[nOut] = pathBytes; res->out_cigar_off[nOut] = cigarBytes; res->out_vg_off[nOut] = vgBytes;
 		res->out_path_text = resultArray<char>(pathBytes + 1); res->out_cigar_text = resultArray<char>(cigarBytes + 1); res->out_vg_path = resultArray<uint8_t>(vgBytes + 1);
-		// the device wrote the jobs' pieces back to back in entry order, so the bytes copy over as they are
+		const bool allKept = nOut == nOutJobs;   // (no chained winner: the device's blobs are the result's)
 		const size_t parts = 16;
-		pool.run(3 * parts, [&](size_t i, size_t) {
+		if (allKept) pool.run(3 * parts, [&](size_t i, size_t) {
 			const size_t which = i / parts, part = i % parts;
 			const uint64_t total = which == 0 ? pathBytes : which == 1 ? cigarBytes : vgBytes;
 			const char* src = which == 0 ? hOutPath : which == 1 ? hOutCigar : (const char*)hOutVg;
@@ -2963,26 +2992,25 @@ struct BatchRun {
 			const uint64_t b = total * part / parts, e = total * (part + 1) / parts;
 			if (e > b) memcpy(dst + b, src + b, e - b);
 		});
+		else pool.run(nOut, [&](size_t e, size_t) {
+			const uint64_t k = outJobOfEntry[e];
+			if (k == ~0ull) return;
+			memcpy(res->out_path_text + res->out_path_off[e], hOutPath + hOutOffsets[k], hOutOffsets[k + 1] - hOutOffsets[k]);
+			memcpy(res->out_cigar_text + res->out_cigar_off[e], hOutCigar + hOutOffsets[stride + k], hOutOffsets[stride + k + 1] - hOutOffsets[stride + k]);
+			memcpy(res->out_vg_path + res->out_vg_off[e], hOutVg + hOutOffsets[2 * stride + k], hOutOffsets[2 * stride + k + 1] - hOutOffsets[2 * stride + k]);
+		});
 		res->out_path_text[pathBytes] = 0; res->out_cigar_text[cigarBytes] = 0;
-		uint64_t jobsSeen = 0;
 		for (uint64_t e = 0; e < nOut; e++) {
 			const OutEntry& en = outEntries[e];
 			res->out_source[e] = en.source;
 			uint64_t* num = res->out_numbers + 12 * e;
 			if (en.source == 0) {
-				const uint64_t k = outJobOfEntry[e];
-				const OutRec& rec = hOutRecs[k];
+				const OutRec& rec = hOutRecs[outJobOfEntry[e]];
 				const LongAln& al = glue[en.read].longAlns[en.aln];
 				num[0] = rec.nodePathLen; num[1] = rec.nodePathStart; num[2] = rec.nodePathEnd; num[3] = rec.matches; num[4] = rec.mismatches; num[5] = rec.insertions; num[6] = rec.deletions;
 				num[7] = al.traceLen; num[8] = al.start; num[9] = al.end; num[10] = rec.steps; num[11] = al.score;
-				res->out_path_off[e] = hOutOffsets[k]; res->out_cigar_off[e] = hOutOffsets[stride + k]; res->out_vg_off[e] = hOutOffsets[2 * stride + k];
-				jobsSeen = k + 1;
-			} else {
-				for (int i = 0; i < 12; i++) num[i] = 0;
-				res->out_path_off[e] = nOutJobs ? hOutOffsets[jobsSeen] : 0; res->out_cigar_off[e] = nOutJobs ? hOutOffsets[stride + jobsSeen] : 0; res->out_vg_off[e] = nOutJobs ? hOutOffsets[2 * stride + jobsSeen] : 0;
-			}
+			} else for (int i = 0; i < 12; i++) num[i] = 0;
 		}
-		res->out_path_off[nOut] = pathBytes; res->out_cigar_off[nOut] = cigarBytes; res->out_vg_off[nOut] = vgBytes;
 	}
 
 	// ---------------- the flat result: count per read, prefix-sum, fill in parallel

@@ -482,23 +482,26 @@ struct ChainArrays {   // one read's working set: LDS (template LDS) or this blo
 	ChainEntry* ent; uint2* back; int32_t* thr;   // back: the anchors' threshold lists (path, position), always in this block's HBM scratch (a wide cover makes them long)
 };
 
-template <bool LDS>
+// LDS == 0: the working set in this block's HBM scratch; 1: in LDS, the large class (53 KB: three blocks per CU); 2 (r4): in LDS, half the size (26.5 KB, six blocks per CU) - what a
+// 10 kb read needs (~300 anchors, ~600 entries, cover width of a few) and the class launchChain picks when the batch's largest read fits it; a read that outgrows its class goes to the scratch launch
+template <int LDS>
 __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __restrict__ jobs, uint32_t nReads, const AnchorRec* __restrict__ anchors,
 	const Fragment* __restrict__ frags, const uint32_t* __restrict__ fragStatus, int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* __restrict__ scratch, uint64_t scratchStride,
 	uint32_t* __restrict__ chainOut, uint32_t* __restrict__ chainLen, unsigned long long* __restrict__ chainScore, uint32_t* __restrict__ chainStatus, uint32_t forceScratch)
 {
-	__shared__ uint32_t sStart[LDS ? CHAIN_LDS_ANCHORS : 1];
-	__shared__ unsigned long long sC[LDS ? CHAIN_LDS_ANCHORS : 1];
-	__shared__ uint16_t sFrag[LDS ? CHAIN_LDS_ANCHORS : 1], sComp[LDS ? CHAIN_LDS_ANCHORS : 1], sEntBegin[LDS ? CHAIN_LDS_ANCHORS + 1 : 1];
-	__shared__ uint32_t sBackBegin[LDS ? CHAIN_LDS_ANCHORS + 1 : 1];
-	__shared__ ChainEntry sEnt[LDS ? CHAIN_LDS_ENTRIES : 1];
-	__shared__ int32_t sThr[LDS ? CHAIN_LDS_WIDTH : 1];
+	constexpr uint32_t LDS_ANCHORS = LDS == 2 ? CHAIN_LDS_ANCHORS / 2 : CHAIN_LDS_ANCHORS, LDS_ENTRIES = LDS == 2 ? CHAIN_LDS_ENTRIES / 2 : CHAIN_LDS_ENTRIES, LDS_WIDTH = LDS == 2 ? CHAIN_LDS_WIDTH / 2 : CHAIN_LDS_WIDTH;
+	__shared__ uint32_t sStart[LDS ? LDS_ANCHORS : 1];
+	__shared__ unsigned long long sC[LDS ? LDS_ANCHORS : 1];
+	__shared__ uint16_t sFrag[LDS ? LDS_ANCHORS : 1], sComp[LDS ? LDS_ANCHORS : 1], sEntBegin[LDS ? LDS_ANCHORS + 1 : 1];
+	__shared__ uint32_t sBackBegin[LDS ? LDS_ANCHORS + 1 : 1];
+	__shared__ ChainEntry sEnt[LDS ? LDS_ENTRIES : 1];
+	__shared__ int32_t sThr[LDS ? LDS_WIDTH : 1];
 	const int lane = threadIdx.x;
 	// (16-bit indices: at most 65535 anchors, entries and threshold-list items per read, cover width and components below 65536; beyond that the read is flagged)
-	const uint32_t capA = LDS ? CHAIN_LDS_ANCHORS : (caps.capAnchors < 65535u ? caps.capAnchors : 65535u);
-	const uint32_t capE = LDS ? CHAIN_LDS_ENTRIES : (caps.capEndpoints < 65535u ? caps.capEndpoints : 65535u);
+	const uint32_t capA = LDS ? LDS_ANCHORS : (caps.capAnchors < 65535u ? caps.capAnchors : 65535u);
+	const uint32_t capE = LDS ? LDS_ENTRIES : (caps.capEndpoints < 65535u ? caps.capEndpoints : 65535u);
 	const uint32_t capB = caps.capBack;
-	const uint32_t capW = LDS ? CHAIN_LDS_WIDTH : (caps.capTable < 65535u ? caps.capTable : 65535u);
+	const uint32_t capW = LDS ? LDS_WIDTH : (caps.capTable < 65535u ? caps.capTable : 65535u);
 	ChainArrays A;
 	uint8_t* base = scratch + (uint64_t)blockIdx.x * scratchStride;
 	A.back = (uint2*)base; base += 8ull * capB;
@@ -1356,12 +1359,16 @@ void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, 
 	int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* scratch, uint32_t* chainOut, uint32_t* chainLen, unsigned long long* chainScore, uint32_t* chainStatus, bool forceScratch)
 {
 	if (nReads == 0) return;
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<true>), dim3(chainGridBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, forceScratch ? 1u : 0u);
+	// the half-size LDS class when the batch's largest read fits it (its entries are checked per read: a read with more goes to the scratch launch below)
+	static const bool largeOnly = getenv("GC_CHAIN_LARGE") && atoi(getenv("GC_CHAIN_LARGE"));   // (the r3 launch, for A/B)
+	const bool small = !largeOnly && caps.capAnchors <= CHAIN_LDS_ANCHORS / 2 && caps.capTable <= CHAIN_LDS_WIDTH / 2;
+	if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<2>), dim3(chainGridBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, forceScratch ? 1u : 0u);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<1>), dim3(chainGridBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, forceScratch ? 1u : 0u);
 	// reads with more anchors / entries than the LDS tables hold, or on a cover wider than the LDS threshold table (waves whose read is done leave at once).
 	// The batch's bounds tell when no read can need it (cfg2: 400 slots per read at most, cover width 2): 2 048 waves that look and leave cost 7 ms of queueing per batch.
 	// (it is then a safety net of eight waves for what the bounds do not show - a graph with more than 65 535 components, a read beyond 65 535 fragment positions)
-	const bool cannotBeNeeded = !forceScratch && caps.capAnchors <= CHAIN_LDS_ANCHORS && caps.capEndpoints <= CHAIN_LDS_ENTRIES && caps.capTable <= CHAIN_LDS_WIDTH;
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<false>), dim3(cannotBeNeeded ? (nReads < 8 ? nReads : 8) : chainScratchBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, 0u);
+	const bool cannotBeNeeded = !forceScratch && caps.capAnchors <= CHAIN_LDS_ANCHORS / (small ? 2 : 1) && caps.capEndpoints <= CHAIN_LDS_ENTRIES / (small ? 2 : 1) && caps.capTable <= CHAIN_LDS_WIDTH / (small ? 2 : 1);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<0>), dim3(cannotBeNeeded ? (nReads < 8 ? nReads : 8) : chainScratchBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, 0u);
 }
 
 uint64_t longWaveWordsPerLane(const ExtendConfig& cfg) { return waveScratchWords(cfg.maxSlices, cfg.maxItems, cfg.maxTrace, cfg.maxCols); }
