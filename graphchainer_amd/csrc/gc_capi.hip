@@ -329,7 +329,46 @@ struct gc_seeder {
 	~gc_seeder() { for (void* p : allocations) (void)hipFree(p); }
 };
 
+// Device and pinned blocks of read batches, kept for the next batch (r4). gc_reads_upload used to hipMalloc nine arrays per batch and gc_reads_destroy to hipFree them:
+// hipFree waits for the device to drain, so with five batches in flight every destroy stalled its host thread for the length of whatever was queued (and the upload of the
+// next batch behind it: 245 ms per batch in the end-to-end leg, `gpurun_out/r4_ab3`). One block per batch now, carved into the arrays, returned to a small cache.
+struct BlockCache {
+	bool pinned;
+	std::mutex mutex;
+	struct Block { void* ptr; size_t bytes; int device; };
+	std::vector<Block> blocks;
+	static constexpr size_t MAX_BLOCKS = 12;
+	explicit BlockCache(bool pinned) : pinned(pinned) {}
+	void* get(size_t bytes, int device, size_t& capacity)
+	{
+		{
+			std::lock_guard<std::mutex> lock(mutex);
+			size_t best = blocks.size();
+			for (size_t i = 0; i < blocks.size(); i++)
+				if (blocks[i].device == device && blocks[i].bytes >= bytes && blocks[i].bytes <= 2 * bytes + (1u << 20) && (best == blocks.size() || blocks[i].bytes < blocks[best].bytes)) best = i;
+			if (best < blocks.size()) { Block b = blocks[best]; blocks.erase(blocks.begin() + (long)best); capacity = b.bytes; return b.ptr; }
+		}
+		capacity = bytes + bytes / 8 + 4096;   // (a little slack: the next batch is about, not exactly, this size)
+		void* p = nullptr;
+		if (pinned) HIP_CHECK(hipHostMalloc(&p, capacity, hipHostMallocDefault));
+		else HIP_CHECK(hipMalloc(&p, capacity));
+		return p;
+	}
+	void put(void* p, size_t bytes, int device)
+	{
+		if (!p) return;
+		{
+			std::lock_guard<std::mutex> lock(mutex);
+			if (blocks.size() < MAX_BLOCKS) { blocks.push_back(Block { p, bytes, device }); return; }
+		}
+		if (pinned) (void)hipHostFree(p); else (void)hipFree(p);
+	}
+};
+static BlockCache& g_readDeviceBlocks = *new BlockCache(false);   // (leaked on purpose, like the result cache: finalizers may run late)
+static BlockCache& g_readPinnedBlocks = *new BlockCache(true);
+
 struct gc_reads {
+	void* deviceBlock = nullptr; size_t deviceBlockBytes = 0; int device = 0;   // every device array below is carved from this one block
 	std::vector<uint64_t> offsets;   // host copy [n+1]
 	uint64_t totalBases = 0;
 	std::vector<uint8_t> invalid;    // read has a character outside the IUPAC alphabet (the reference's Complement() asserts)
@@ -346,7 +385,7 @@ struct gc_reads {
 	uint64_t* devPacked = nullptr;      // the forward bases, 2 bits each, big-endian inside 64-bit words (for the seed kernel's k-mers)
 	uint64_t* devInvalid = nullptr;     // one bit per forward base: not A, C, G or T (same big-endian convention)
 	uint8_t* devReadInvalid = nullptr;  // [n] the device's copy of `invalid`
-	~gc_reads() { if (devBases) (void)hipFree(devBases); if (devOffsets) (void)hipFree(devOffsets); if (devMasks) (void)hipFree(devMasks); if (devEqMasks) (void)hipFree(devEqMasks); if (devEdReads) (void)hipFree(devEdReads); if (devChunkRead) (void)hipFree(devChunkRead); if (devPacked) (void)hipFree(devPacked); if (devInvalid) (void)hipFree(devInvalid); if (devReadInvalid) (void)hipFree(devReadInvalid); }
+	~gc_reads() { g_readDeviceBlocks.put(deviceBlock, deviceBlockBytes, device); }
 };
 
 struct StitchedPath { std::vector<uint32_t> nodes; uint32_t firstOffset = 0, lastOffset = 0; uint64_t cells = 0; };
@@ -1516,32 +1555,51 @@ int gc_reads_upload(const char* bases, const uint64_t* offsets, uint64_t n, gc_r
 			eqWords += 4ull * R->maskWords[r];
 		}
 		const uint64_t total = R->totalBases;
-		HIP_CHECK(hipMalloc((void**)&R->devBases, std::max<size_t>(2 * total, 1)));
-		HIP_CHECK(hipMalloc((void**)&R->devOffsets, (n + 1) * sizeof(uint64_t)));
-		HIP_CHECK(hipMalloc((void**)&R->devMasks, std::max<size_t>(totalWords, 1) * sizeof(uint64_t)));
-		HIP_CHECK(hipMalloc((void**)&R->devEqMasks, std::max<size_t>(eqWords, 1) * sizeof(uint64_t)));
-		HIP_CHECK(hipMalloc((void**)&R->devEdReads, std::max<size_t>(n, 1) * sizeof(EdRead)));
-		HIP_CHECK(hipMalloc((void**)&R->devPacked, ((total >> 5) + 1) * sizeof(uint64_t)));
-		HIP_CHECK(hipMalloc((void**)&R->devInvalid, ((total >> 6) + 1) * sizeof(uint64_t)));
-		HIP_CHECK(hipMalloc((void**)&R->devChunkRead, ((total >> 6) + 1) * sizeof(uint32_t)));
-		DeviceBuffer dMaskOff, dMaskWords, dEqOff;
-		uint64_t* pMaskOff = dMaskOff.reserve<uint64_t>(n);
-		uint32_t* pMaskWords = dMaskWords.reserve<uint32_t>(n);
-		uint64_t* pEqOff = dEqOff.reserve<uint64_t>(n);
-		HIP_CHECK(hipMalloc((void**)&R->devReadInvalid, std::max<size_t>(n, 1)));
+		// one device block for everything (256-byte aligned parts), one pinned block for what goes up; both come from small caches (see BlockCache)
+		HIP_CHECK(hipGetDevice(&R->device));
+		size_t at = 0;
+		auto part = [&](size_t bytes) { const size_t here = at; at += (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; return here; };
+		const size_t oBases = part(2 * total), oOffsets = part((n + 1) * sizeof(uint64_t)), oMasks = part(totalWords * sizeof(uint64_t)), oEqMasks = part(eqWords * sizeof(uint64_t)),
+			oEdReads = part(n * sizeof(EdRead)), oPacked = part(((total >> 5) + 1) * sizeof(uint64_t)), oInvalid = part(((total >> 6) + 1) * sizeof(uint64_t)), oChunkRead = part(((total >> 6) + 1) * sizeof(uint32_t)),
+			oMaskOff = part(n * sizeof(uint64_t)), oMaskWords = part(n * sizeof(uint32_t)), oEqOff = part(n * sizeof(uint64_t)), oReadInvalid = part(n);
+		R->deviceBlock = g_readDeviceBlocks.get(at, R->device, R->deviceBlockBytes);
+		char* D = (char*)R->deviceBlock;
+		R->devBases = D + oBases; R->devOffsets = (uint64_t*)(D + oOffsets); R->devMasks = (uint64_t*)(D + oMasks); R->devEqMasks = (uint64_t*)(D + oEqMasks); R->devEdReads = (EdRead*)(D + oEdReads);
+		R->devPacked = (uint64_t*)(D + oPacked); R->devInvalid = (uint64_t*)(D + oInvalid); R->devChunkRead = (uint32_t*)(D + oChunkRead); R->devReadInvalid = (uint8_t*)(D + oReadInvalid);
+		uint64_t* pMaskOff = (uint64_t*)(D + oMaskOff);
+		uint32_t* pMaskWords = (uint32_t*)(D + oMaskWords);
+		uint64_t* pEqOff = (uint64_t*)(D + oEqOff);
 		uint8_t* pInvalid = R->devReadInvalid;
-		if (total) HIP_CHECK(hipMemcpy(R->devBases, bases, total, hipMemcpyHostToDevice));
-		HIP_CHECK(hipMemcpy(R->devOffsets, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+		// staging: the bases and the five small arrays in one pinned block, copied asynchronously on a stream of the calling thread's own (a synchronous copy from pageable
+		// memory goes through the runtime's bounce buffers at a few GB/s and its null-stream semantics)
+		size_t hat = 0;
+		auto hpart = [&](size_t bytes) { const size_t here = hat; hat += (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; return here; };
+		const size_t hBases = hpart(total), hOffsets = hpart((n + 1) * sizeof(uint64_t)), hMaskOff = hpart(n * sizeof(uint64_t)), hMaskWords = hpart(n * sizeof(uint32_t)), hEqOff = hpart(n * sizeof(uint64_t)),
+			hEdReads = hpart(n * sizeof(EdRead)), hInvalidBack = hpart(n);
+		size_t pinnedBytes = 0;
+		char* H = (char*)g_readPinnedBlocks.get(hat, R->device, pinnedBytes);
+		struct PinnedReturn { char* p; size_t bytes; int device; ~PinnedReturn() { g_readPinnedBlocks.put(p, bytes, device); } } pinnedReturn { H, pinnedBytes, R->device };
+		static thread_local struct UploadStream { hipStream_t q = nullptr; int device = -1; ~UploadStream() { if (q) (void)hipStreamDestroy(q); } } up;
+		if (!up.q || up.device != R->device) { if (up.q) (void)hipStreamDestroy(up.q); up.q = nullptr; HIP_CHECK(hipStreamCreateWithFlags(&up.q, hipStreamNonBlocking)); up.device = R->device; }
+		if (total) memcpy(H + hBases, bases, total);
+		memcpy(H + hOffsets, offsets, (n + 1) * sizeof(uint64_t));
 		if (n) {
-			HIP_CHECK(hipMemcpy(pMaskOff, R->maskOff.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
-			HIP_CHECK(hipMemcpy(pMaskWords, R->maskWords.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
-			HIP_CHECK(hipMemcpy(pEqOff, eqOff.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice));
-			HIP_CHECK(hipMemcpy(R->devEdReads, edReads.data(), n * sizeof(EdRead), hipMemcpyHostToDevice));
+			memcpy(H + hMaskOff, R->maskOff.data(), n * sizeof(uint64_t)); memcpy(H + hMaskWords, R->maskWords.data(), n * sizeof(uint32_t));
+			memcpy(H + hEqOff, eqOff.data(), n * sizeof(uint64_t)); memcpy(H + hEdReads, edReads.data(), n * sizeof(EdRead));
 		}
-		launchPackReads(nullptr, R->devOffsets, (uint32_t)n, total, R->devBases, pMaskOff, pMaskWords, R->devMasks, pEqOff, R->devEqMasks, pInvalid, R->devPacked, R->devInvalid, R->devChunkRead);
+		if (total) HIP_CHECK(hipMemcpyAsync(R->devBases, H + hBases, total, hipMemcpyHostToDevice, up.q));
+		HIP_CHECK(hipMemcpyAsync(R->devOffsets, H + hOffsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, up.q));
+		if (n) {
+			HIP_CHECK(hipMemcpyAsync(pMaskOff, H + hMaskOff, n * sizeof(uint64_t), hipMemcpyHostToDevice, up.q));
+			HIP_CHECK(hipMemcpyAsync(pMaskWords, H + hMaskWords, n * sizeof(uint32_t), hipMemcpyHostToDevice, up.q));
+			HIP_CHECK(hipMemcpyAsync(pEqOff, H + hEqOff, n * sizeof(uint64_t), hipMemcpyHostToDevice, up.q));
+			HIP_CHECK(hipMemcpyAsync(R->devEdReads, H + hEdReads, n * sizeof(EdRead), hipMemcpyHostToDevice, up.q));
+		}
+		launchPackReads(up.q, R->devOffsets, (uint32_t)n, total, R->devBases, pMaskOff, pMaskWords, R->devMasks, pEqOff, R->devEqMasks, pInvalid, R->devPacked, R->devInvalid, R->devChunkRead);
 		R->invalid.assign(n, 0);
-		if (n) HIP_CHECK(hipMemcpy(R->invalid.data(), pInvalid, n, hipMemcpyDeviceToHost));   // (synchronises with the kernels on the null stream)
-		else HIP_CHECK(hipDeviceSynchronize());
+		if (n) HIP_CHECK(hipMemcpyAsync(H + hInvalidBack, pInvalid, n, hipMemcpyDeviceToHost, up.q));
+		HIP_CHECK(hipStreamSynchronize(up.q));
+		if (n) memcpy(R->invalid.data(), H + hInvalidBack, n);
 		return (int)GC_OK;
 	});
 	if (rc != GC_OK) { delete R; return rc; }
@@ -1980,7 +2038,7 @@ struct BatchRun {
 		return true;
 	}
 
-	// The round loop without a host round trip per round (r4, the default): per round ONE kernel between two extension launches - k_long_round: the previous round's merge,
+	// The round loop without a host round trip per round (r4; an experiment, GC_LONG_ROUNDS=1 - see roundsOnDevice): per round ONE kernel between two extension launches - k_long_round: the previous round's merge,
 	// this round's select, the execution order, the work count to the device and to pinned host memory - and the extension kernel takes its item count from the device
 	// (its grid is sized by a bound: 2 items per read, which the device-side speculation rule respects). Rounds are queued several at a time; the host looks at the published
 	// counts only at the end of a chunk (a round after the last one finds nothing to do and costs a few empty launches). r3's loop queued zero / select / order / publish,
@@ -1991,7 +2049,7 @@ struct BatchRun {
 		if (nGroups != 1 || longExtendTeamSize(1) != 1) return false;
 		for (const char* name : { "GC_LONG_SM", "GC_LONG_LANE", "GC_LONG_MAX_BLOCKS", "GC_LONG_PLAN" }) if (getenv(name)) return false;   // experiments and test hooks of the host-driven loop
 		if (getenv("GC_LONG_TOKEN") && atoi(getenv("GC_LONG_TOKEN")) == 2) return false;
-		if (getenv("GC_LONG_ROUNDS") && atoi(getenv("GC_LONG_ROUNDS")) == 0) return false;   // GC_LONG_ROUNDS=0: r3's host-driven loop (same results)
+		if (!(getenv("GC_LONG_ROUNDS") && atoi(getenv("GC_LONG_ROUNDS")) == 1)) return false;   // GC_LONG_ROUNDS=1 selects it: measured 4-6 % SLOWER than the host-driven loop, which stays the default
 		(void)g;
 		return true;
 	}
@@ -2590,7 +2648,7 @@ struct BatchRun {
 			launchStitch(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, dChainOut, dChainLen, dChainStatus, dPathPool, pathCapacity, (long long)P->colinear_gap, dSlotOf,
 				dRegions, dStitchNodes, stitchDenseCap, dCursor, dStitchInfo,
 				(uint32_t)capacityOr("GC_STITCH_SET_MAX", P->capacity.stitch_set_max, 0), (uint32_t)capacityOr("GC_STITCH_BFS_CAP", P->capacity.stitch_bfs_cap, 0),
-				maxReadLen <= 16384 && !(getenv("GC_STITCH_LARGE") && atoi(getenv("GC_STITCH_LARGE"))));   // (GC_STITCH_LARGE=1: the large tables for every batch, as in r3)
+				getenv("GC_STITCH_SMALL") && atoi(getenv("GC_STITCH_SMALL")) && maxReadLen <= 16384);   // (GC_STITCH_SMALL=1: the half-size search tables, measured in r4 and not kept - see gc_stitch.hip)
 			HIP_CHECK(hipMemcpyAsync(stitchInfo, dStitchInfo, n * sizeof(StitchInfo), hipMemcpyDeviceToHost, stream));
 			HIP_CHECK(hipMemcpyAsync(hStitchCursor, dCursor, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		}

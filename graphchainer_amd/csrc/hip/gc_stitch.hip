@@ -29,10 +29,10 @@
 
 namespace gcdev {
 
-// Two size classes of the LDS tables (r4): a bridge search visits a handful of nodes, so reads up to 16 kb run with half the search tables (queue, predecessors, visited
-// map: 512 / 1 024 slots) - 20 KB per wave instead of 29.5, seven waves per CU instead of five for a kernel that is all latency. The node set of a piece keeps its 2 048 slots:
-// a 10 kb read on a graph with a variant site every 45 bp crosses ~450 split nodes, and with 1 024 slots (512 nodes) a fifth of cfg2's reads went to the host's stitching
-// (host CPU per batch 0.36 -> 0.8 s, `gpurun_out/r4_rounds`). Longer reads (config 5's 50 kb) keep the large search tables too. What outgrows a table goes to the host either way.
+// A second, smaller size class of the search tables was measured in r4 and is NOT the default (GC_STITCH_SMALL=1 selects it for reads up to 16 kb): with 512 instead of 1 024
+// visited nodes per bridge search (20 KB of LDS per wave instead of 29.5, seven waves per CU instead of five) 39 % of cfg2's reads overflowed the search and went to the
+// host's stitching (3 915 of 10 000: a failed search for an upstream anchor walks several hundred nodes before the rank pruning ends it), and with a 1 024-slot node set as well
+// a piece's ~450 split nodes no longer fitted: host CPU per batch 0.36 -> 0.8-0.9 s for 2-3 % of batch time (`gpurun_out/r4_rounds`, `r4_rounds2`, `r4_e2etimes`).
 #define STITCH_SET_SIZE_LARGE 2048u   // open-addressing slots for the nodes of the current piece; at most half of them are used (STITCH_SET_MAX)
 #define STITCH_BFS_CAP_LARGE 1024u    // visited nodes per bridge search; its hash table has twice the slots
 #define STITCH_EMPTY 0xffffffffu

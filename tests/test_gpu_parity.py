@@ -808,12 +808,12 @@ def test_output_against_golden_files(gca, golden_dir):
 
 
 @pytest.mark.parametrize("env,kw,host_expected", [
-    ({"GC_STITCH_LARGE": "1"}, {}, "none"),      # the large search tables (r3's, and what reads beyond 16 kb get): every read fits
-    ({}, {}, "few"),                             # r4: the half-size search tables of reads up to 16 kb - a chimeric read's search for an unreachable anchor may outgrow them
+    ({}, {}, "none"),
+    ({"GC_STITCH_SMALL": "1"}, {}, "few"),       # r4 experiment: half-size search tables - a chimeric read's search for an unreachable anchor may outgrow them
     ({"GC_HOST_STITCH": "1"}, {}, "all"),
     ({"GC_STITCH_BFS_CAP": "2"}, {}, "some"),        # a bridge search may visit 2 nodes: most reads fall back to the host
     ({"GC_STITCH_SET_MAX": "40"}, {}, "some"),       # a piece may hold 40 nodes
-    ({}, {"colinear_gap": 150}, "few"),              # small --colinear-gap: bridges fail, chains break into pieces
+    ({}, {"colinear_gap": 150}, "none"),             # small --colinear-gap: bridges fail, chains break into pieces
     ({}, {"colinear_gap": -1}, "any"),               # no limit: a search for an unreachable anchor walks the whole graph downstream, on the host
     ({"GC_STITCH_BFS_CAP": "6"}, {"colinear_gap": 150}, "some"),
 ])
