@@ -2192,9 +2192,15 @@ struct BatchRun {
 			// GC_LONG_SM=1 (experiment, off by default: 6x slower as measured): one extension per LANE as per-lane state machines (k_long_extend_sm, gc_sm.hip);
 			// what outgrows that layout's tables (EXT_SM_DECLINED: more than 32 nodes in a slice, 16 pending, no room for the reserved trace)
 			// is listed and rerun one extension per wave, like the register-table overflows below
+#ifdef GC_EXPERIMENTS
 			const bool useSm = team == 1 && getenv("GC_LONG_SM") && atoi(getenv("GC_LONG_SM")) == 1;
+#else
+			const bool useSm = false;   // (the state-machine kernel is not part of the product library since r4: `make -C graphchainer_amd/csrc experiments` builds libgraphchainer_amd_exp.so with it)
+			if (getenv("GC_LONG_SM") && atoi(getenv("GC_LONG_SM")) == 1) throw std::runtime_error("GC_LONG_SM=1: the state-machine experiment is not in this build (make -C graphchainer_amd/csrc experiments; GC_LIBRARY=.../libgraphchainer_amd_exp.so)");
+#endif
 			// GC_LONG_LANE=1 (measurement, off by default): one extension per LANE with the plain-layout core and its band state in a per-lane HBM slab
 			const bool useLane = !useSm && team == 1 && getenv("GC_LONG_LANE") && atoi(getenv("GC_LONG_LANE")) == 1;
+#ifdef GC_EXPERIMENTS
 			if (useSm) {
 				launchLongExtendSm(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, (uint8_t*)(dLongScratch + (uint64_t)g * scratchLanes * waveWords), scratchLanes * waveWords * 8,
 					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2);
@@ -2203,7 +2209,9 @@ struct BatchRun {
 				const uint32_t declinedBlocks = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nWorkItems, 8192), std::max<uint64_t>(1, scratchLanes - 64));
 				launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dRetryList + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 1, declinedBlocks,
 					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, 6u, cursor + 3);
-			} else if (useLane) {
+			} else
+#endif
+			if (useLane) {
 				launchLongExtendLane(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, (uint8_t*)(dLongScratch + (uint64_t)g * scratchLanes * waveWords), scratchLanes * waveWords * 8,
 					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8);
 			} else
