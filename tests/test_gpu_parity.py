@@ -433,6 +433,65 @@ def test_config5_shape(gca, tmp_path):
     assert int(got["read_chain_off"][-1]) > 1000 and int(got["read_longall_off"][-1]) >= 5
 
 
+def test_device_output_equals_host_encoders_on_varied_inputs(gca, tmp_path):
+    """k_out_encode (gc_params::device_output) against the host encoders walking the downloaded traces, byte for byte in all three formats and both CIGAR styles, on inputs that
+    stretch the walk: several chromosomes with long unsplit segments (mappings spanning many 64-cell chunks), multi-allelic and nested bubbles (one-base nodes: many path steps per
+    chunk), links written from the reverse strand, repeats, non-numeric segment names, IUPAC letters in the graph, N runs and lower-case letters in the reads, reverse-strand and
+    chimeric reads, reads of 1-70 bases, 50 kb CLR-like reads with long insertion / deletion runs."""
+    import gzip
+    from graphchainer_amd.synth import SynthGenome
+    gen = SynthGenome(2, 150_000, seed=47, multi_allelic=0.25, nested=0.3, minus_links=0.3, repeats=4, repeat_len=2000)
+    gfa = str(tmp_path / "g.gfa")
+    gen.write_gfa(gfa)
+    # rename a third of the segments (names are what the path column and the mapping positions print) and put IUPAC letters into some
+    lines = open(gfa).read().split("\n")
+    names, touched = {}, 0
+    for i, line in enumerate(lines):
+        if line.startswith("S\t"):
+            f = line.split("\t")
+            if i % 3 == 0:
+                names[f[1]] = "seg_" + f[1] + ("x" * (i % 5))
+            if len(f[2]) >= 30 and i % 17 == 0 and touched < 40:
+                seq = bytearray(f[2].encode())
+                seq[len(seq) // 2] = ord("NRYKMSW"[touched % 7])
+                f[2] = seq.decode()
+                touched += 1
+            lines[i] = "\t".join(f)
+    for i, line in enumerate(lines):
+        f = line.split("\t")
+        if f[0] == "S":
+            f[1] = names.get(f[1], f[1])
+        elif f[0] == "L":
+            f[1], f[3] = names.get(f[1], f[1]), names.get(f[3], f[3])
+        lines[i] = "\t".join(f)
+    open(gfa, "w").write("\n".join(lines))
+    reads = gen.sample_reads(6, 6000, seed=3) + gen.sample_reads(2, 50_000, seed=4, p_del=0.04, p_sub=0.02, p_ins=0.09)
+    with_n = bytearray(reads[0])
+    with_n[700:760] = b"N" * 60
+    reads += [bytes(with_n), reads[1].lower(), _revcomp(reads[2]), reads[3][:2500] + _revcomp(reads[4])[1000:4000], reads[5][:70], reads[5][100:135], b"A", b"ACGTTGCA"]
+    graph = gca.AlignmentGraph(gfa)
+    seeder = gca.MinimizerSeeder(graph)
+    ids = [f"read/{i}" for i in range(len(reads))]
+    host = gca.Aligner(graph, seeder, keep_traces=2, long_pass=True, colinear_gap=50000).align_reads(reads, gaf_names=ids, other_formats=True)
+    dev = gca.Aligner(graph, seeder, long_pass=True, colinear_gap=50000, device_output=1 | 4).align_reads(reads, gaf_names=ids, other_formats=True)
+    assert dev["gaf"] == host["gaf"] and dev["gaf"].count(b"\n") >= 10
+    assert dev["json"] == host["json"]
+    assert gzip.decompress(dev["gam"]) == gzip.decompress(host["gam"])
+    assert b"seg_" in dev["gaf"] and b"<" in dev["gaf"]
+    host_m = gca.Aligner(graph, seeder, keep_traces=2, long_pass=True, colinear_gap=50000).align_reads(reads, gaf_names=ids, cigar_match_mismatch_merge=True)
+    dev_m = gca.Aligner(graph, seeder, long_pass=True, colinear_gap=50000, device_output=2).align_reads(reads, gaf_names=ids, cigar_match_mismatch_merge=True)
+    assert dev_m["gaf"] == host_m["gaf"] and dev_m["gaf"] != dev["gaf"]
+    # the counts the device reports are the lines' own columns
+    numbers = np.asarray(dev["out_numbers"]).reshape(-1, 12)
+    lines_out = [l for l in dev["gaf"].decode().splitlines() if l]
+    assert len(lines_out) == len(numbers)
+    for line, num, source in zip(lines_out, numbers, np.asarray(dev["out_source"])):
+        if source != 0:
+            continue                                                        # (a chained winner: written by the host encoder, no counts from the device)
+        col = line.split("\t")
+        assert (int(col[2]), int(col[3]), int(col[6]), int(col[7]), int(col[8]), int(col[9]), int(col[10])) == (int(num[8]), int(num[9]), int(num[0]), int(num[1]), int(num[2]), int(num[3]), int(num[7]))
+
+
 def test_config3_shape_with_whole_read_pass(gca, tmp_path):
     """BASELINE config 3 in miniature: 10 kb reads, --colinear-split-gap 18 (the reference's spelling of --sampling-step 0.5:
     overlapping fragments, twice the anchors, the overlap branch of the chaining DP), whole-read pass on, a graph with repeats."""
