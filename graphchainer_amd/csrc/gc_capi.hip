@@ -3048,7 +3048,8 @@ struct BatchRun {
 		}
 		res->out_path_off[nOut] = pathBytes; res->out_cigar_off[nOut] = cigarBytes; res->out_vg_off[nOut] = vgBytes;
 		res->out_path_text = resultArray<char>(pathBytes + 1); res->out_cigar_text = resultArray<char>(cigarBytes + 1); res->out_vg_path = resultArray<uint8_t>(vgBytes + 1);
-		const bool allKept = nOut == nOutJobs;   // (no chained winner: the device's blobs are the result's)
+		bool allKept = nOut == nOutJobs;   // no chained winner: the device's blobs are the result's, job k is entry k
+		for (uint64_t e = 0; e < nOut && allKept; e++) allKept = outJobOfEntry[e] == e;   // (a winner's one entry can stand where a read's one dropped job was: the counts alone do not tell)
 		const size_t parts = 16;
 		if (allKept) pool.run(3 * parts, [&](size_t i, size_t) {
 			const size_t which = i / parts, part = i % parts;

@@ -54,6 +54,9 @@ namespace gcdev {
 #ifndef GC_LEAN_UNROLL
 #define GC_LEAN_UNROLL 1
 #endif
+#ifndef GC_LEAN_EDGES
+#define GC_LEAN_EDGES 0   // r4, measured and off: a tile's first two out-edges fetched together before they are pushed - 162-166 ms per batch against 152-155 (seven more spilled VGPRs under the 64-register cap)
+#endif
 #ifndef GC_LEAN_DIAGRUN
 #define GC_LEAN_DIAGRUN 1   // the backtrace's diagonal runs inside a tile resolved by one ballot and emitted by the vector pipe
 #endif
@@ -332,9 +335,31 @@ __device__ __forceinline__ WSlice loadSlice(const WaveScratch& ws, uint32_t s)
 	x.j = (int32_t)(e >> 32); x.flags = (uint32_t)e;
 	return x;
 }
+#ifndef GC_LEAN_ITEMSTORE
+#define GC_LEAN_ITEMSTORE 0   // r4, measured and off: the 64-byte item record as ONE store from lanes 0-7 (sixteen v_writelane) instead of eight 8-byte stores from lane 0 - 192-202 ms per batch against 152-155: 65 spilled VGPRs instead of 35
+#endif
 __device__ __forceinline__ void storeItem(const WaveScratch& ws, uint32_t i, const NodeItem& it)
 {
 	uint64_t b = ws.itemBase(i);
+#if GC_LEAN_ITEMSTORE && defined(__HIP_DEVICE_COMPILE__)
+	if (ws.allLanes && ws.lanes == 1) {
+		// the eight words are uniform (scalar registers): word l goes to lane l of a register pair with v_writelane (the lane select is an inline constant), lanes 0-7 store 8 bytes each
+		const uint64_t w0 = gcUniform64(it.sVP), w1 = gcUniform64(it.sVN), w2 = gcUniform64(it.eVP), w3 = gcUniform64(it.eVN), w4 = gcUniform64(it.HP), w5 = gcUniform64(it.HN);
+		const uint64_t w6 = gcUniform64(((unsigned long long)(uint32_t)it.sScore << 32) | (uint32_t)it.eScore), w7 = gcUniform64(((unsigned long long)(uint32_t)it.minScore << 32) | it.node);
+		uint32_t lo = (uint32_t)w0, hi = (uint32_t)(w0 >> 32);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+		asm("v_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %1, %3, 1\n\tv_writelane_b32 %0, %4, 2\n\tv_writelane_b32 %1, %5, 2\n\tv_writelane_b32 %0, %6, 3\n\tv_writelane_b32 %1, %7, 3\n\t"
+			"v_writelane_b32 %0, %8, 4\n\tv_writelane_b32 %1, %9, 4\n\tv_writelane_b32 %0, %10, 5\n\tv_writelane_b32 %1, %11, 5\n\tv_writelane_b32 %0, %12, 6\n\tv_writelane_b32 %1, %13, 6\n\t"
+			"v_writelane_b32 %0, %14, 7\n\tv_writelane_b32 %1, %15, 7"
+			: "+v"(lo), "+v"(hi)
+			: "s"((uint32_t)w1), "s"((uint32_t)(w1 >> 32)), "s"((uint32_t)w2), "s"((uint32_t)(w2 >> 32)), "s"((uint32_t)w3), "s"((uint32_t)(w3 >> 32)), "s"((uint32_t)w4), "s"((uint32_t)(w4 >> 32)),
+			  "s"((uint32_t)w5), "s"((uint32_t)(w5 >> 32)), "s"((uint32_t)w6), "s"((uint32_t)(w6 >> 32)), "s"((uint32_t)w7), "s"((uint32_t)(w7 >> 32)));
+#pragma clang diagnostic pop
+		if (threadIdx.x < 8) ws.base[b + threadIdx.x] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+		return;
+	}
+#endif
 	if (!ws.storer()) return;
 	ws.word(b) = it.sVP; ws.word(b + 1) = it.sVN; ws.word(b + 2) = it.eVP; ws.word(b + 3) = it.eVN; ws.word(b + 4) = it.HP; ws.word(b + 5) = it.HN;
 	ws.word(b + 6) = ((unsigned long long)(uint32_t)it.sScore << 32) | (uint32_t)it.eScore;
@@ -637,7 +662,8 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 		const int cb = REGCOLS ? 1 : (buf ^ 1);   // table buffer `cb` = current slice
 		auto prevFind = [&](uint32_t node) __attribute__((always_inline)) -> int { return L.find((uint32_t)(REGCOLS ? 0 : buf), nPrev, node); };
 		uint32_t nPending = 0;
-		auto pushEdge = [&](uint32_t target, WS incoming, bool skipFirst) __attribute__((always_inline)) {
+		// (preSeq / preComp: the target's sequence words and topological rank when the caller has already fetched them - the tile's out-edges are loaded together, see below)
+		auto pushEdge = [&](uint32_t target, WS incoming, bool skipFirst, const NodeSeq* preSeq = nullptr, uint32_t preComp = 0) __attribute__((always_inline)) {
 			int found = L.find(2u, nPending, target);
 			uint32_t slot = found >= 0 ? (uint32_t)found : nPending;
 			WS add = incoming;
@@ -652,7 +678,7 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 					else if (prevStart > before) { hinP = 1; hinN = 0; }
 					else { hinP = 0; hinN = 0; }
 				} else { hinP = 1; hinN = 0; }
-				NodeSeq nseq = loadNodeSeq(g, target);
+				NodeSeq nseq = preSeq ? *preSeq : loadNodeSeq(g, target);
 				uint64_t hp, hn;
 #if GC_LEAN_COLUMNS && defined(__HIP_DEVICE_COMPILE__)
 				uint64_t eqFirst;
@@ -671,7 +697,7 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 			}
 			if (slot == nPending) {
 				if (nPending >= L.maxEntries()) { status = EXT_LDS_CAP; return; }
-				L.qSet(slot, target, g.componentNumber[target], add);
+				L.qSet(slot, target, preSeq ? preComp : g.componentNumber[target], add);
 				nPending++;
 			} else {
 #if GC_LEAN_MERGE && defined(__HIP_DEVICE_COMPILE__)
@@ -762,10 +788,28 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 			if (newEndMin < prevMinScore) return EXT_ASSERT;
 			if (newEndMin <= currentMin + bandwidth) {
 				GC_MARK(3);   // item store + bookkeeping
+#if GC_LEAN_EDGES
+				{
+					// the first two out-edges' targets, sequence words and ranks are fetched TOGETHER before either edge is pushed (r4): a bubble's node has two
+					// successors, and edge by edge their loads - adjacency entry, then the target's sequence and rank - were two dependent chains one after the other
+					const uint32_t e0 = g.outOff[pnode], e1 = g.outOff[pnode + 1];
+					const uint32_t nE = e1 - e0;
+					const uint32_t tA = nE > 0 ? g.outAdj[e0] : pnode, tB = nE > 1 ? g.outAdj[e0 + 1] : pnode;
+					const NodeSeq sA = loadNodeSeq(g, tA), sB = loadNodeSeq(g, tB);
+					const uint32_t cA = g.componentNumber[tA], cB = g.componentNumber[tB];
+					if (nE > 0) { pushEdge(tA, newEnd, false, &sA, cA); if (status != EXT_OK) return status; }
+					if (nE > 1) { pushEdge(tB, newEnd, false, &sB, cB); if (status != EXT_OK) return status; }
+					for (uint32_t e = e0 + 2; e < e1; e++) {
+						pushEdge(g.outAdj[e], newEnd, false);
+						if (status != EXT_OK) return status;
+					}
+				}
+#else
 				for (uint32_t e = g.outOff[pnode]; e < g.outOff[pnode + 1]; e++) {
 					pushEdge(g.outAdj[e], newEnd, false);
 					if (status != EXT_OK) return status;
 				}
+#endif
 				GC_MARK(4);   // out-edge pushes
 			} else GC_MARK(3);
 		}
