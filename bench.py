@@ -390,7 +390,8 @@ def main():
         e2e_workers = inflight + 3
         legs = [("gaf", "gaf", None)] if "gaf" in args.e2e_formats.split(",") else []
         if "gam" in args.e2e_formats.split(","):
-            legs += [("gam", "gam", None), ("gam_level1", "gam", 1)]
+            legs += [("gam", "gam", None), ("gam_level1", "gam", 1), ("gam_device_huffman", "gam", gca.GAM_DEVICE_HUFFMAN)]
+        gam_inflated = {}                                             # leg -> (bytes, CRC-32) of batch 0's inflated GAM stream: the same at every level
         for leg, fmt, level in legs:
             for a in aligners:
                 a.params.device_output = 1 if fmt == "gaf" else 4
@@ -401,7 +402,7 @@ def main():
 
             spent = np.zeros(4)                                       # seconds in: upload, waiting for a stream, gc_align_batch, formatting (summed over the timed batches)
 
-            def e2e_item(worker, item, fmt=fmt, level=level, kept=kept, checking=checking, free_streams=free_streams, spent=spent):
+            def e2e_item(worker, item, leg=leg, fmt=fmt, level=level, kept=kept, checking=checking, free_streams=free_streams, spent=spent):
                 b = item % len(chunks)
                 t_a = time.perf_counter()
                 batch = gca.ReadBatch([reads[i] for i in chunks[b]])
@@ -417,6 +418,11 @@ def main():
                 t_e = time.perf_counter()
                 if checking[0] and fmt == "gaf" and cpu_summary is not None:
                     kept[item] = gaf_check(texts["gaf"], out, chunks[b], cpu_summary)
+                elif checking[0] and fmt == "gam" and item == 0:
+                    import gzip
+                    import zlib
+                    inflated = gzip.decompress(texts["gam"])
+                    gam_inflated[leg] = (len(inflated), zlib.crc32(inflated))
                 elif not checking[0]:
                     spent += (t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d)   # (float adds under the GIL)
                 batch.close()
@@ -435,13 +441,23 @@ def main():
                    "ms_per_batch_in": dict(zip(("upload", "waiting_for_a_stream", "gc_align_batch", "format"), (np.round(spent / max(1, len(done)) * 1e3, 1)).tolist())),
                    "includes": f"gc_reads_upload (PCIe + packing kernels) + hot path + output encoding on the device (k_out_encode) + gc_format_{fmt}" + (f"_level(level {level})" if level is not None else "") + " of every batch"}
             if fmt == "gam":
-                rec["gzip"] = "zlib level " + ("default (6), as the reference's GzipOutputStream" if level is None else str(level)) + ": deflate is host work the reference pays too, ~1 ms of CPU per 10 kb read at the default level"
+                if level == gca.GAM_DEVICE_HUFFMAN:
+                    rec["gzip"] = "deflated on the device (hip/gc_deflate.hip: one dynamic-Huffman block of literals per read, no LZ77 matches); the host frames the members and computes their CRC-32s"
+                else:
+                    rec["gzip"] = "zlib level " + ("default (6), as the reference's GzipOutputStream" if level is None else str(level)) + ": deflate is host work the reference pays too, ~1 ms of CPU per 10 kb read at the default level"
+                if leg in gam_inflated:
+                    rec["inflated_bytes_batch0"], rec["inflated_crc32_batch0"] = gam_inflated[leg]
             if fmt == "gaf" and kept:
                 compared, bad = sum(c for c, _ in kept.values()), sum(m for _, m in kept.values())
                 rec["gaf_check"] = {"reads_compared": compared, "reads_with_different_lines": bad, "against": "the oracle's GAF lines of the same reads (hash per read, CPU leg of this run)"}
                 if bad:
                     failures.append(f"end-to-end GAF check failed: the lines of {bad} of {compared} reads differ from the oracle's")
             e2e[leg] = rec
+        if len(gam_inflated) > 1:
+            same = len(set(gam_inflated.values())) == 1
+            e2e["gam_check"] = {"legs": sorted(gam_inflated), "same_inflated_stream": same, "what": "batch 0's GAM bytes of every leg inflated with zlib: length and CRC-32 of the stream"}
+            if not same:
+                failures.append("end-to-end GAM check failed: the legs' inflated streams differ")
         for a in aligners:
             a.params.device_output = 0
         if "gaf" in e2e:                                              # (the r3 line's keys, for the GAF leg)

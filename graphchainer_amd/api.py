@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "gc_params_default", "gc_graph_create_from_gfa", "gc_graph_create", "gc_graph_destroy", "gc_graph_num_nodes",
     "gc_graph_size_bp", "gc_graph_array", "gc_seeder_create", "gc_seeder_destroy", "gc_seeder_array",
     "gc_stream_create", "gc_stream_destroy", "gc_reads_upload", "gc_reads_destroy", "gc_align_batch",
-    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_device_memory", "gc_edit_distance", "gc_edit_path", "gc_evalue", "gc_format_gaf", "gc_format_json", "gc_format_gam", "gc_format_gam_level", "gc_format_gaf_trace", "gc_format_vg_trace", "gc_graph_letters",
+    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_device_memory", "gc_edit_distance", "gc_edit_path", "gc_evalue", "gc_format_gaf", "gc_format_json", "gc_format_gam", "gc_format_gam_level", "gc_gzip_streams", "gc_format_gaf_trace", "gc_format_vg_trace", "gc_graph_letters",
     "gc_index_build", "gc_index_save", "gc_index_load", "gc_index_check", "gc_result_cache_trim",
 ]
 
@@ -166,6 +166,26 @@ def edit_path(a_list, b_list):
     lib.gc_edit_path.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _check(lib.gc_edit_path(a, a_off.ctypes.data, b, b_off.ctypes.data, n, ops_off.ctypes.data, ops.ctypes.data, ops_len.ctypes.data, dist.ctypes.data))
     return dist[:n], [ops[int(ops_off[i]):int(ops_off[i]) + int(ops_len[i])].copy() for i in range(n)]
+
+
+GAM_DEVICE_HUFFMAN = 100   # GC_GAM_DEVICE_HUFFMAN: gam_level value that has the gzip members deflated on the device
+
+
+def gzip_streams(streams):
+    """One gzip member per byte string, deflated on the GPU as one dynamic-Huffman block of literals (what gam_level=GAM_DEVICE_HUFFMAN does with a batch's GAM groups)."""
+    lib = load_library()
+    n = len(streams)
+    raw = b"".join(streams)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in streams], dtype=np.uint64) if n else []
+    out_off = np.zeros(n + 1, dtype=np.uint64)
+    ptr = C.c_void_p()
+    lib.gc_gzip_streams.restype = C.c_int
+    lib.gc_gzip_streams.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, _P(C.c_void_p), C.c_void_p]
+    _check(lib.gc_gzip_streams(raw, off.ctypes.data, n, C.byref(ptr), out_off.ctypes.data))
+    data = C.string_at(ptr.value, int(out_off[n]))
+    lib.gc_free(ptr)
+    return [data[int(out_off[i]):int(out_off[i + 1])] for i in range(n)]
 
 
 def evalue(min_identity, database_size, query_size, alignment_length, num_edits):
@@ -413,10 +433,10 @@ class Aligner:
         self.stream = C.c_void_p()
         _check(self.lib.gc_stream_create(C.byref(self.stream)))
 
-    def align_batch(self, batch, gaf_names=None, cigar_match_mismatch_merge=False, other_formats=False, formats=None):
+    def align_batch(self, batch, gaf_names=None, cigar_match_mismatch_merge=False, other_formats=False, formats=None, gam_level=None):
         """Runs the hot path for a ReadBatch; returns a dict of arrays. With gaf_names (one id per read; needs long_pass and
         keep_traces or device_output) the dict also holds "gaf" (bytes: the reference's GAF lines) and "gaf_chained_skipped"; with other_formats also "json" (JSON
-        lines) and "gam" (gzip members of framed vg::Alignment messages)."""
+        lines) and "gam" (gzip members of framed vg::Alignment messages; gam_level: their zlib level, or GAM_DEVICE_HUFFMAN for the device's deflate)."""
         res = _P(GcResult)()
         _check(self.lib.gc_align_batch(self.graph.handle, self.seeder.handle, self.stream, batch.handle, C.byref(self.params), C.byref(res)))
         holder = _ResultHolder(self.lib, res)
@@ -425,7 +445,7 @@ class Aligner:
             if gaf_names is not None:
                 # formats: which of "gaf", "json", "gam" to produce (default: GAF, all three with other_formats)
                 want = tuple(formats) if formats is not None else (("gaf", "json", "gam") if other_formats else ("gaf",))
-                gaf = self._format(res, batch, gaf_names, want, cigar_match_mismatch_merge)
+                gaf = self._format(res, batch, gaf_names, want, cigar_match_mismatch_merge, gam_level)
             r = res.contents
             n = int(r.n_reads)
 

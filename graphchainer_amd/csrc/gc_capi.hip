@@ -367,6 +367,14 @@ struct BlockCache {
 static BlockCache& g_readDeviceBlocks = *new BlockCache(false);   // (leaked on purpose, like the result cache: finalizers may run late)
 static BlockCache& g_readPinnedBlocks = *new BlockCache(true);
 
+// a stream of the calling thread's own for its uploads and small jobs (created on first use, recreated when the thread changes device)
+static hipStream_t threadStream(int device)
+{
+	static thread_local struct ThreadStream { hipStream_t q = nullptr; int device = -1; ~ThreadStream() { if (q) (void)hipStreamDestroy(q); } } ts;
+	if (!ts.q || ts.device != device) { if (ts.q) (void)hipStreamDestroy(ts.q); ts.q = nullptr; HIP_CHECK(hipStreamCreateWithFlags(&ts.q, hipStreamNonBlocking)); ts.device = device; }
+	return ts.q;
+}
+
 struct gc_reads {
 	void* deviceBlock = nullptr; size_t deviceBlockBytes = 0; int device = 0;   // every device array below is carved from this one block
 	std::vector<uint64_t> offsets;   // host copy [n+1]
@@ -941,6 +949,52 @@ int gc_evalue(double min_identity, uint64_t database_size, uint64_t query_size, 
 // alignment won (chained_better) is written from its chain_trace_* arrays (chain_traces >= 1), and counted as skipped only
 // when the result carries no trace for it.
 enum OutputKind { OUT_GAF, OUT_JSON, OUT_GAM };
+
+// GC_GAM_DEVICE_HUFFMAN: every non-empty element of `groups` (a read's uncompressed group) becomes its gzip member, deflated on the device (hip/gc_deflate.hip: one
+// dynamic-Huffman block of literals per read). The host stages the bytes in pinned memory, frames the members and computes their CRC-32s.
+static void gzipGroupsOnDevice(std::vector<std::string>& groups, bool skipEmpty = true)
+{
+	std::vector<uint32_t> which;
+	std::vector<uint64_t> rawOff { 0 };
+	for (size_t i = 0; i < groups.size(); i++) if (!skipEmpty || !groups[i].empty()) { which.push_back((uint32_t)i); rawOff.push_back(rawOff.back() + groups[i].size()); }
+	const size_t m = which.size();
+	if (!m) return;
+	const uint64_t rawTotal = rawOff.back();
+	requireDevice();
+	int device = 0;
+	HIP_CHECK(hipGetDevice(&device));
+	const uint64_t outBound = rawTotal + 5 * (rawTotal / 65535 + m) + 4 * m;   // stored blocks are the worst case the plan accepts; 4-byte placement
+	size_t at = 0;
+	auto part = [&](size_t bytes) { const size_t here = at; at += (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; return here; };
+	const size_t oRaw = part(rawTotal), oRawOff = part((m + 1) * sizeof(uint64_t)), oLens = part(m * 260), oPlan = part(m * sizeof(uint2)), oOutOff = part((m + 1) * sizeof(uint64_t)), oOut = part(outBound);
+	size_t deviceBytes = 0, pinnedBytes = 0;
+	char* D = (char*)g_readDeviceBlocks.get(at, device, deviceBytes);
+	struct DeviceReturn { char* p; size_t bytes; int device; ~DeviceReturn() { g_readDeviceBlocks.put(p, bytes, device); } } deviceReturn { D, deviceBytes, device };
+	size_t hat = 0;
+	auto hpart = [&](size_t bytes) { const size_t here = hat; hat += (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; return here; };
+	const size_t hRaw = hpart(std::max<uint64_t>(rawTotal, outBound)), hRawOff = hpart((m + 1) * sizeof(uint64_t)), hPlan = hpart(m * sizeof(uint2)), hOutOff = hpart((m + 1) * sizeof(uint64_t));
+	char* H = (char*)g_readPinnedBlocks.get(hat, device, pinnedBytes);
+	struct PinnedReturn { char* p; size_t bytes; int device; ~PinnedReturn() { g_readPinnedBlocks.put(p, bytes, device); } } pinnedReturn { H, pinnedBytes, device };
+	hipStream_t q = threadStream(device);
+	WorkerPool::instance().run(m, [&](size_t k, size_t) { memcpy(H + hRaw + rawOff[k], groups[which[k]].data(), groups[which[k]].size()); });
+	memcpy(H + hRawOff, rawOff.data(), (m + 1) * sizeof(uint64_t));
+	if (rawTotal) HIP_CHECK(hipMemcpyAsync(D + oRaw, H + hRaw, rawTotal, hipMemcpyHostToDevice, q));
+	HIP_CHECK(hipMemcpyAsync(D + oRawOff, H + hRawOff, (m + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, q));
+	launchDeflatePlan(q, (const uint8_t*)(D + oRaw), (const uint64_t*)(D + oRawOff), (uint32_t)m, (uint8_t*)(D + oLens), (uint2*)(D + oPlan));
+	HIP_CHECK(hipMemcpyAsync(H + hPlan, D + oPlan, m * sizeof(uint2), hipMemcpyDeviceToHost, q));
+	HIP_CHECK(hipStreamSynchronize(q));
+	const uint2* plan = (const uint2*)(H + hPlan);
+	uint64_t* outOff = (uint64_t*)(H + hOutOff);
+	outOff[0] = 0;
+	for (size_t k = 0; k < m; k++) outOff[k + 1] = outOff[k] + (((uint64_t)plan[k].x + 3) & ~(uint64_t)3);
+	if (outOff[m] > outBound) throw std::runtime_error("device deflate: planned sizes exceed the bound");
+	HIP_CHECK(hipMemcpyAsync(D + oOutOff, outOff, (m + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, q));
+	launchDeflateWrite(q, (const uint8_t*)(D + oRaw), (const uint64_t*)(D + oRawOff), (uint32_t)m, (const uint8_t*)(D + oLens), (const uint2*)(D + oPlan), (uint8_t*)(D + oOut), (const uint64_t*)(D + oOutOff));
+	HIP_CHECK(hipMemcpyAsync(H + hRaw, D + oOut, outOff[m], hipMemcpyDeviceToHost, q));
+	HIP_CHECK(hipStreamSynchronize(q));
+	WorkerPool::instance().run(m, [&](size_t k, size_t) { std::string& g = groups[which[k]]; g = gc::gzipMember((const uint8_t*)(H + hRaw + outOff[k]), plan[k].x, g); });
+}
+
 static int formatBatch(const gc_graph* G, const gc_result* r, const char* const* read_names, const char* bases, const uint64_t* offsets, OutputKind kind, int cigar_match_mismatch_merge,
 	char** out_text, uint64_t* out_len, uint64_t* n_chained_skipped, int gamLevel = -1)
 {
@@ -956,6 +1010,8 @@ static int formatBatch(const gc_graph* G, const gc_result* r, const char* const*
 		const uint64_t n = r->n_reads;
 		std::vector<std::string> perRead(n);
 		std::atomic<uint64_t> skipped { 0 };
+		const bool onDevice = gamLevel == GC_GAM_DEVICE_HUFFMAN;
+		auto group = [&](const std::vector<std::string>& messages) { return onDevice ? gc::gamGroupRaw(messages) : gc::gamGroup(messages, gamLevel); };
 		WorkerPool::instance().run(n, [&](size_t i, size_t) {
 			std::string& text = perRead[i];
 			std::vector<std::string> messages;
@@ -979,7 +1035,7 @@ static int formatBatch(const gc_graph* G, const gc_result* r, const char* const*
 						else messages.push_back(gc::vgProtobufFromEncoded(name, bases + offsets[i], ea));
 					}
 				}
-				if (kind == OUT_GAM && !messages.empty()) text = gc::gamGroup(messages, gamLevel);
+				if (kind == OUT_GAM && !messages.empty()) text = group(messages);
 				return;
 			}
 			if (r->chained_better[i]) {
@@ -993,7 +1049,7 @@ static int formatBatch(const gc_graph* G, const gc_result* r, const char* const*
 				} else {
 					gc::VgAlignment aln = gc::buildVgAlignment(G->host, name, bases + offsets[i], len, tv, 0, r->chain_aln_start[i], r->chain_aln_end[i]);
 					if (kind == OUT_JSON) { text += gc::vgToJson(aln); text += '\n'; }
-					else text = gc::gamGroup({ gc::vgToProtobuf(aln) }, gamLevel);
+					else text = group({ gc::vgToProtobuf(aln) });
 				}
 				return;
 			}
@@ -1020,8 +1076,9 @@ static int formatBatch(const gc_graph* G, const gc_result* r, const char* const*
 					else messages.push_back(gc::vgToProtobuf(aln));
 				}
 			}
-			if (kind == OUT_GAM) text = gc::gamGroup(messages, gamLevel);
+			if (kind == OUT_GAM) text = group(messages);
 		});
+		if (kind == OUT_GAM && onDevice) gzipGroupsOnDevice(perRead);
 		uint64_t total = 0;
 		for (const auto& t : perRead) total += t.size();
 		char* buf = (char*)malloc(total + 1);
@@ -1103,8 +1160,27 @@ int gc_graph_letters(const gc_graph* G, const int32_t* node, const uint32_t* off
 
 int gc_format_gam_level(const gc_graph* G, const gc_result* r, const char* const* read_names, const char* bases, const uint64_t* offsets, int level, char** out_bytes, uint64_t* out_len, uint64_t* n_chained_skipped)
 {
-	if (level < -1 || level > 9) return fail(GC_ERR_INVALID, "gc_format_gam_level: zlib levels are -1 (default) and 0..9");
+	if ((level < -1 || level > 9) && level != GC_GAM_DEVICE_HUFFMAN) return fail(GC_ERR_INVALID, "gc_format_gam_level: zlib levels are -1 (default) and 0..9, or GC_GAM_DEVICE_HUFFMAN");
 	return formatBatch(G, r, read_names, bases, offsets, OUT_GAM, 0, out_bytes, out_len, n_chained_skipped, level);
+}
+
+// gzip members of independent byte streams, deflated on the device as GC_GAM_DEVICE_HUFFMAN does for the GAM groups (an empty stream gives an empty member)
+int gc_gzip_streams(const uint8_t* bytes, const uint64_t* offsets, uint64_t n, char** out_bytes, uint64_t* out_offsets)
+{
+	if (!offsets || !out_bytes || !out_offsets || (offsets[n] && !bytes)) return fail(GC_ERR_INVALID, "null argument");
+	for (uint64_t i = 0; i < n; i++) if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] >= (1ull << 32)) return fail(GC_ERR_INVALID, "gc_gzip_streams: offsets must ascend, streams below 4 GB");
+	return guarded([&]() {
+		std::vector<std::string> groups(n);
+		for (uint64_t i = 0; i < n; i++) groups[i].assign((const char*)bytes + offsets[i], (const char*)bytes + offsets[i + 1]);
+		gzipGroupsOnDevice(groups, false);
+		out_offsets[0] = 0;
+		for (uint64_t i = 0; i < n; i++) out_offsets[i + 1] = out_offsets[i] + groups[i].size();
+		char* buf = (char*)malloc(out_offsets[n] + 1);
+		if (!buf) throw std::runtime_error("out of memory");
+		for (uint64_t i = 0; i < n; i++) memcpy(buf + out_offsets[i], groups[i].data(), groups[i].size());
+		*out_bytes = buf;
+		return (int)GC_OK;
+	});
 }
 
 int gc_device_count(void)
@@ -1579,8 +1655,7 @@ int gc_reads_upload(const char* bases, const uint64_t* offsets, uint64_t n, gc_r
 		size_t pinnedBytes = 0;
 		char* H = (char*)g_readPinnedBlocks.get(hat, R->device, pinnedBytes);
 		struct PinnedReturn { char* p; size_t bytes; int device; ~PinnedReturn() { g_readPinnedBlocks.put(p, bytes, device); } } pinnedReturn { H, pinnedBytes, R->device };
-		static thread_local struct UploadStream { hipStream_t q = nullptr; int device = -1; ~UploadStream() { if (q) (void)hipStreamDestroy(q); } } up;
-		if (!up.q || up.device != R->device) { if (up.q) (void)hipStreamDestroy(up.q); up.q = nullptr; HIP_CHECK(hipStreamCreateWithFlags(&up.q, hipStreamNonBlocking)); up.device = R->device; }
+		struct { hipStream_t q; } up { threadStream(R->device) };
 		if (total) memcpy(H + hBases, bases, total);
 		memcpy(H + hOffsets, offsets, (n + 1) * sizeof(uint64_t));
 		if (n) {

@@ -970,7 +970,11 @@ __global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __r
 #define GC_LONG_MIN_WAVES 1
 #endif
 template <int LANES, bool PERSISTENT>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LANES == 1 ? 8 : GC_LONG_MIN_WAVES, 8))) k_long_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint64_t* __restrict__ masks, ExtendConfig cfg,
+#ifndef GC_LONG_WAVES_ONE
+#define GC_LONG_WAVES_ONE 5   // waves per SIMD the one-extension-per-wave instantiation is compiled for. 8: 64 VGPRs, 35 of them spilled to 112 B of scratch per lane; 7: 72 / 80 B; 6: 80 / 48 B;
+                              // 5 (and 4): 87 VGPRs, no scratch. The kernel is bound by the CU's scalar unit, not by latency: all five measure the same, so the build without scratch is kept
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LANES == 1 ? GC_LONG_WAVES_ONE : GC_LONG_MIN_WAVES, 8))) k_long_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint64_t* __restrict__ masks, ExtendConfig cfg,
 	const LongWork* __restrict__ work, const uint32_t* __restrict__ order, uint32_t nWork, unsigned long long* __restrict__ scratch, uint64_t wordsPerLane,
 	unsigned long long* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, LongWorkResult* __restrict__ results, unsigned long long* __restrict__ counters,
 	unsigned long long* __restrict__ nextSlot, uint32_t retryStatus, const unsigned long long* __restrict__ nWorkOnDevice, uint32_t* __restrict__ capListOut, unsigned long long* __restrict__ capCountOut)

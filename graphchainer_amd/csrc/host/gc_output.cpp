@@ -418,11 +418,35 @@ VgAlignment vgFromEncoded(const std::string& readName, const char* sequence, con
 	return aln;
 }
 
-std::string gamGroup(const std::vector<std::string>& messages, int level)
+std::string gamGroupRaw(const std::vector<std::string>& messages)
 {
 	std::string raw;
+	size_t bytes = 10;
+	for (const std::string& m : messages) bytes += m.size() + 10;
+	raw.reserve(bytes);
 	putVarint(raw, messages.size());
 	for (const std::string& m : messages) { putVarint(raw, m.size()); raw += m; }
+	return raw;
+}
+
+// RFC 1952 framing of a deflate stream produced elsewhere (the device: hip/gc_deflate.hip): header without name or time, the deflate bytes, CRC-32 and length of the input
+std::string gzipMember(const uint8_t* deflated, size_t deflatedBytes, const std::string& raw)
+{
+	std::string out;
+	out.reserve(deflatedBytes + 18);
+	const unsigned char header[10] = { 0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3 };
+	out.append((const char*)header, 10);
+	out.append((const char*)deflated, deflatedBytes);
+	uLong crc = crc32(0L, Z_NULL, 0);
+	crc = crc32(crc, (const Bytef*)raw.data(), (uInt)raw.size());
+	for (int i = 0; i < 4; i++) out += (char)((crc >> (8 * i)) & 255);
+	for (int i = 0; i < 4; i++) out += (char)((raw.size() >> (8 * i)) & 255);
+	return out;
+}
+
+std::string gamGroup(const std::vector<std::string>& messages, int level)
+{
+	const std::string raw = gamGroupRaw(messages);
 	// one gzip member (protobuf's GzipOutputStream defaults: gzip format, default compression level and strategy)
 	z_stream zs;
 	memset(&zs, 0, sizeof zs);

@@ -87,6 +87,8 @@ VgAlignment vgFromEncoded(const std::string& readName, const char* sequence, con
 
 // One GAM group as writeGAMToQueue frames it (src/Aligner.cpp:261-281): varint64 message count, then per message varint32
 // size + bytes, the whole group one gzip member.
+std::string gamGroupRaw(const std::vector<std::string>& messages);   // the group before compression: varint count, then varint size + message each
+std::string gzipMember(const uint8_t* deflated, size_t deflatedBytes, const std::string& raw);   // gzip framing of a deflate stream of `raw` made elsewhere
 std::string gamGroup(const std::vector<std::string>& messages, int level = -1);   // level: zlib's (-1 = Z_DEFAULT_COMPRESSION, what GzipOutputStream uses)
 
 } // namespace gc

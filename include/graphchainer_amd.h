@@ -311,9 +311,16 @@ int gc_graph_letters(const gc_graph* g, const int32_t* node, const uint32_t* off
 
 /* gc_format_gam with the zlib level of the gzip members chosen by the caller (-1 = Z_DEFAULT_COMPRESSION, what the reference's GzipOutputStream uses and gc_format_gam
  * gives; 0..9). The inflated stream is the same at every level; deflate at the default level costs ~1 ms of CPU per 10 kb read - more than the whole alignment costs the
- * GPU - so a host that writes GAM at the hot path's rate wants level 1 (or its own compressor on the bytes of level 0). */
+ * GPU - so a host that writes GAM at the hot path's rate wants level 1 (or its own compressor on the bytes of level 0), or GC_GAM_DEVICE_HUFFMAN: the members are then
+ * deflated on the device, every read's group as one dynamic-Huffman block of literals (no LZ77 matches: a larger file than zlib's, the same inflated stream, and the host
+ * only frames the members and computes their CRC-32s). */
+#define GC_GAM_DEVICE_HUFFMAN 100
 int gc_format_gam_level(const gc_graph* g, const gc_result* result, const char* const* read_names, const char* bases, const uint64_t* offsets, int level,
                         char** out_bytes, uint64_t* out_len, uint64_t* n_chained_skipped);
+
+/* The device deflate behind GC_GAM_DEVICE_HUFFMAN on the caller's own byte streams: stream i = bytes[offsets[i] .. offsets[i+1]) becomes the gzip member
+ * out_bytes[out_offsets[i] .. out_offsets[i+1]) (out_offsets: n + 1 entries, caller's; out_bytes: gc_free). */
+int gc_gzip_streams(const uint8_t* bytes, const uint64_t* offsets, uint64_t n, char** out_bytes, uint64_t* out_offsets);
 
 int gc_device_count(void);
 int gc_set_device(int device);

@@ -829,6 +829,54 @@ def test_json_and_gam_output(gca, tmp_path):
     assert got_dev["gaf"] == got["gaf"]
 
 
+def test_device_deflate_streams(gca):
+    """hip/gc_deflate.hip through gc_gzip_streams: every member inflates (zlib's own inflate, CRC and length checked by gzip) to the stream it was made from - empty and
+    one-byte streams, one repeated symbol, text-like and base-like streams (dynamic Huffman block), random bytes (stored blocks, more than one above 65535 bytes), and
+    Fibonacci-weighted symbols whose Huffman code would be deeper than deflate's 15 bits (stored)."""
+    import gzip
+    import zlib
+    rng = np.random.default_rng(5)
+    fib = [1, 1]
+    while len(fib) < 24:
+        fib.append(fib[-1] + fib[-2])
+    deep = b"".join(bytes([i]) * f for i, f in enumerate(fib))
+    streams = [b"", b"A", b"AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA", b"AB" * 40, bytes(rng.integers(0, 256, 70_000, dtype=np.uint8)), bytes(rng.integers(0, 256, 131_071, dtype=np.uint8)),
+               bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 50_001)), b"the quick brown fox jumps over the lazy dog " * 300, deep, bytes(range(256)) * 3,
+               bytes(rng.choice(np.arange(256, dtype=np.uint8), 200_003, p=np.arange(1, 257) / np.arange(1, 257).sum()))]
+    streams += [bytes(rng.choice(np.frombuffer(b"ACGTN\x08\x10\x12\x1a", dtype=np.uint8), int(n))) for n in rng.integers(1, 3000, 300)]
+    members = gca.gzip_streams(streams)
+    assert len(members) == len(streams)
+    for raw, member in zip(streams, members):
+        assert gzip.decompress(member) == raw
+        d = zlib.decompressobj(31)
+        assert d.decompress(member) == raw and d.eof and not d.unused_data     # exactly one member, nothing after it
+    assert gzip.decompress(b"".join(members)) == b"".join(streams)              # concatenated members: what the GAM file is
+    # the Huffman stage earns its keep on bases (2 bits per letter, 3 for the one that shares its subtree with the end-of-block symbol), random bytes are stored at 5 bytes per 65535
+    assert len(members[6]) < 0.3 * 50_001 + 200 and len(members[4]) <= 70_000 + 10 + 18
+    assert len(members[8]) <= len(deep) + 5 * (len(deep) // 65535 + 1) + 18      # the too-deep code fell back to stored blocks
+
+
+def test_gam_deflated_on_device(gca, tmp_path):
+    """gam_level = GC_GAM_DEVICE_HUFFMAN: the same inflated stream as the default level's, for host-encoded and device-encoded alignments and a chained winner."""
+    import gzip
+    from graphchainer_amd.synth import SynthGraph
+    sg = SynthGraph(80_000, seed=23)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(12, 2500, seed=4)
+    reads.append(reads[1][:800] + reads[2][300:1500])
+    reads.append(b"ACGTACGT")                      # no alignment: no member
+    names = [f"r{i}" for i in range(len(reads))]
+    graph = gca.AlignmentGraph(gfa)
+    seeder = gca.MinimizerSeeder(graph)
+    for kw in ({"keep_traces": True}, {"device_output": 1 | 4}):
+        aligner = gca.Aligner(graph, seeder, long_pass=True, **kw)
+        want = aligner.align_reads(reads, gaf_names=names, formats=("gam",))["gam"]
+        got = aligner.align_reads(reads, gaf_names=names, formats=("gam",), gam_level=gca.GAM_DEVICE_HUFFMAN)["gam"]
+        assert got != want and gzip.decompress(got) == gzip.decompress(want) and len(gzip.decompress(got)) > 30_000
+        assert len(got) < 0.6 * len(gzip.decompress(got))
+
+
 def test_long_reads(gca, tmp_path, monkeypatch):
     """30 kb reads: per-extension scratch scales with the read length, persistent waves under a small scratch budget,
     edit-distance bands that need more than one block per lane."""
