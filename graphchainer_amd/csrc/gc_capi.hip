@@ -4,6 +4,7 @@
 #include "../../include/graphchainer_amd.h"
 #include "hip/gc_kernels.hpp"
 #include "host/gc_graph.hpp"
+#include "host/gc_hashorder.hpp"
 #include "host/gc_glue.hpp"
 #include "host/gc_output.hpp"
 #include "host/gc_index_cache.hpp"
@@ -82,11 +83,39 @@ struct DeviceBuffer {   // growable device allocation owned by a stream object
 // (two batches in flight on two gc_streams) only take turns at a finer grain and both finish late. With the token the second batch's
 // seeding, host glue and fragment pipeline overlap the first batch's whole-read pass, and its own pass starts the moment the first
 // one ends - a software pipeline over batches (GC_LONG_TOKEN=0 turns it off).
-std::mutex g_longPassToken[16];
+// r4: GC_LONG_TOKENS=2 (experiment) - two tokens per device, each with a scratch of its own (half the budget): a pass's tail rounds hold fewer extensions than the chip has wave
+// slots and cost one extension's latency each; a second pass side by side fills them (measured: DESIGN.md §4)
+static const int LONG_TOKENS_MAX = 2;
+struct PassTokens {
+	std::mutex m;
+	std::condition_variable cv;
+	bool busy[LONG_TOKENS_MAX] = { false, false };
+	int acquire(int n)
+	{
+		std::unique_lock<std::mutex> l(m);
+		int slot = -1;
+		cv.wait(l, [&]() { for (int s = 0; s < n; s++) if (!busy[s]) { slot = s; return true; } return false; });
+		busy[slot] = true;
+		return slot;
+	}
+	void release(int slot) { { std::lock_guard<std::mutex> l(m); busy[slot] = false; } cv.notify_all(); }
+};
+PassTokens g_longPassToken[16];
+// what std::unique_lock was for the single token: released when the holder goes out of scope
+struct TokenHold {
+	PassTokens* tokens = nullptr;
+	int slot = -1;
+	void lock(PassTokens& t, int n) { tokens = &t; slot = t.acquire(n); }
+	bool owns_lock() const { return slot >= 0; }
+	void unlock() { if (slot >= 0) { tokens->release(slot); slot = -1; } }
+	~TokenHold() { unlock(); }
+};
+static int longTokenCount() { const char* e = getenv("GC_LONG_TOKENS"); return e ? std::max(1, std::min(LONG_TOKENS_MAX, atoi(e))) : 1; }   // (read per use: the tests switch inside one process)
+std::mutex g_longRoundToken[16];   // GC_LONG_TOKEN=2 (experiment): the token handed over per round
 // The pass's extension scratch (up to 48 GB: one region per resident wave) is only touched while the token is held, so the gc_streams of a device share ONE
 // (r3: 85 -> 37 GB per stream for 10 k x 10 kb batches, which is what lets five batches be in flight on a 288 GB device instead of three). It belongs to the
 // token: reserved (grown) by the pass that holds it, freed when the device's last gc_stream goes.
-struct SharedLongScratch { DeviceBuffer buffer; int streams = 0; };
+struct SharedLongScratch { DeviceBuffer buffer[LONG_TOKENS_MAX]; int streams = 0; };
 SharedLongScratch g_longScratch[16];
 std::mutex g_longScratchCount;
 
@@ -443,7 +472,8 @@ struct ReadGlue {
 };
 
 struct EditDistanceRun {
-	hipStream_t streams[6] {};         // one per kernel class: two pairs per wave, then units of 1, 2, 4, 8, 16 blocks
+	hipStream_t streams[7] {};         // one per kernel class: three pairs per wave, two pairs per wave, then units of 1, 2, 4, 8, 16 blocks
+	uint32_t begin[8] {};              // the classes' ranges in the grouped order
 	hipEvent_t ready = nullptr;
 	std::vector<uint32_t> perm;        // position in the grouped order -> original pair index
 	std::vector<int64_t> grouped;      // results in grouped order (pinned not needed: small)
@@ -551,11 +581,11 @@ static void uploadGraph(gc_graph* G)
 	size_t nB = (size_t)maxId + 1;
 	std::vector<uint32_t> origSize(nB, 0), lookupOff(nB + 1, 0), lookup;
 	for (size_t id = 0; id < nB; id++) {
-		auto it = h.nodeLookup.find((int)id);
-		lookupOff[id + 1] = lookupOff[id] + (it == h.nodeLookup.end() ? 0 : (uint32_t)it->second.size());
-		if (it != h.nodeLookup.end()) {
+		const bool known = h.nodeLookup.contains((int)id);
+		lookupOff[id + 1] = lookupOff[id] + (known ? (uint32_t)h.nodeLookup.at((int)id).size() : 0u);
+		if (known) {
 			origSize[id] = (uint32_t)h.originalNodeSize.at((int)id);
-			for (size_t s : it->second) lookup.push_back((uint32_t)s);
+			for (size_t s : h.nodeLookup.at((int)id)) lookup.push_back((uint32_t)s);
 		}
 	}
 	for (size_t id = 0; id < nB; id++)
@@ -625,8 +655,8 @@ static void uploadGraph(gc_graph* G)
 		std::vector<uint32_t> nameOff(nB + 1, 0);
 		std::vector<char> nameBytes;
 		for (size_t id = 0; id < nB; id++) {
-			auto it = h.originalNodeName.find((int)id);
-			if (it != h.originalNodeName.end()) nameBytes.insert(nameBytes.end(), it->second.begin(), it->second.end());
+			const std::string* name = h.originalNodeName.find((int)id);
+			if (name) nameBytes.insert(nameBytes.end(), name->begin(), name->end());
 			if (nameBytes.size() >= 0xffffffffull) throw std::runtime_error("node names exceed 4 GB");
 			nameOff[id + 1] = (uint32_t)nameBytes.size();
 		}
@@ -763,48 +793,56 @@ static void createStream(hipStream_t* q, int role)
 }
 
 static void launchEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair* hPairs, int64_t* hOut, uint32_t nPairs, EdPair* dPairs, int64_t* dOut, const EdRead* dReads, const char* dBases,
-	const uint64_t* dEqMasks, const char* dLetters, const uint32_t* dLettersLen, const std::function<uint32_t(uint32_t)>& readLen)
+	const uint64_t* dEqMasks, const char* dLetters, const uint32_t* dLettersLen, const std::function<uint32_t(uint32_t)>& readLen, bool kIsBound = false)
 {
 	if (!nPairs) return;
 	if (!run.ready) HIP_CHECK(hipEventCreateWithFlags(&run.ready, hipEventDisableTiming));
 	// (a class's stream is created when the class is first used: the batch's streams share the device's 16 hardware queues, and on cfg2 only the
 	// two-pairs-per-wave class and the one-block class ever hold pairs)
 	std::vector<uint32_t> cls(nPairs);
-	uint32_t count[6] = { 0, 0, 0, 0, 0, 0 }, begin[7];
+	uint32_t count[7] = { 0, 0, 0, 0, 0, 0, 0 };
+	uint32_t* begin = run.begin;
 	static const bool halfWaves = !(getenv("GC_ED_HALF") && atoi(getenv("GC_ED_HALF")) == 0);
+	static const bool thirdWaves = halfWaves && !(getenv("GC_ED_THIRD") && atoi(getenv("GC_ED_THIRD")) == 0);
 	for (uint32_t i = 0; i < nPairs; i++) {
 		const uint32_t len = readLen(hPairs[i].read);
 		uint32_t unit = editDistanceUnit(hPairs[i].k, len), c = 0;
 		while ((1u << c) < unit) c++;
-		c++;                                                                  // classes 1..5: one pair per wave, units of 1..16 blocks
-		if (halfWaves && unit == 1 && hPairs[i].k < editDistanceMaxK(0) && len <= 131072) {   // class 0: two pairs per wave (small first band)
-			c = 0;
-			// a sweep of that kernel takes columns + units steps whatever the band, as long as the band fits its 32 lanes - so the first guess may as well be the widest band that
+		c += 2;                                                               // classes 2..6: one pair per wave, units of 1..16 blocks
+		if (halfWaves && unit == 1 && hPairs[i].k < editDistanceMaxK(0) && len <= 131072) {   // class 1: two pairs per wave (small first band)
+			c = 1;
+			// class 0 (r4): three pairs per wave, bands below 1290 - for pairs whose k is a bound (a whole-read pair's k comes from the alignment itself: one sweep, always enough).
+			// A chain pair's k is a guess; tried there whenever length difference + 10 % of the shorter sequence fit, 45 % of cfg2's chain pairs (distances 1 100-1 300) came back
+			// for a second sweep and the two kernels together took 352 ms per nine batches against 311 (`gpurun_out/r4_ring`): chain pairs stay with two per wave
+			if (thirdWaves && kIsBound && len <= 65536 && hPairs[i].k < editDistanceTeamMaxK(3)) c = 0;
+			// a sweep of these kernels takes columns + units steps whatever the band, as long as the band fits the team's lanes - so the first guess may as well be the widest band that
 			// does (any k >= the distance gives the distance): a chain pair whose guess (length difference + 14 %) was a little short used to pay a failed sweep here, a second
 			// failed sweep with the same guess in the one-pair-per-wave kernel and a third with the doubled band (r3)
-			hPairs[i].k = std::max(hPairs[i].k, editDistanceMaxK(0) - 1);
+			hPairs[i].k = c == 0 ? editDistanceTeamMaxK(3) - 1 : std::max(hPairs[i].k, editDistanceMaxK(0) - 1);
 		}
 		cls[i] = c;
 		count[c]++;
 	}
 	begin[0] = 0;
-	for (int c = 0; c < 6; c++) begin[c + 1] = begin[c] + count[c];
+	for (int c = 0; c < 7; c++) begin[c + 1] = begin[c] + count[c];
 	run.perm.resize(nPairs);
 	{
-		uint32_t at[6] = { begin[0], begin[1], begin[2], begin[3], begin[4], begin[5] };
+		uint32_t at[7] = { begin[0], begin[1], begin[2], begin[3], begin[4], begin[5], begin[6] };
 		std::vector<EdPair> grouped(nPairs);
 		for (uint32_t i = 0; i < nPairs; i++) { grouped[at[cls[i]]] = hPairs[i]; run.perm[at[cls[i]]++] = i; }
 		memcpy(hPairs, grouped.data(), (size_t)nPairs * sizeof(EdPair));   // hPairs is now in grouped order
 	}
 	HIP_CHECK(hipMemcpyAsync(dPairs, hPairs, (size_t)nPairs * sizeof(EdPair), hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipEventRecord(run.ready, stream));
-	for (int c = 0; c < 6; c++) {
+	for (int c = 0; c < 7; c++) {
 		if (!count[c]) continue;
 		if (!run.streams[c]) createStream(&run.streams[c], 0);
 		HIP_CHECK(hipStreamWaitEvent(run.streams[c], run.ready, 0));
-		launchEditDistance(run.streams[c], c == 0 ? 0u : 1u << (c - 1), dPairs + begin[c], count[c], dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut + begin[c]);
+		if (c < 2) launchEditDistanceTeam(run.streams[c], c == 0 ? 3u : 2u, dPairs + begin[c], count[c], dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut + begin[c]);
+		else launchEditDistance(run.streams[c], 1u << (c - 2), dPairs + begin[c], count[c], dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut + begin[c]);
 		HIP_CHECK(hipMemcpyAsync(hOut + begin[c], dOut + begin[c], (size_t)count[c] * sizeof(int64_t), hipMemcpyDeviceToHost, run.streams[c]));
 	}
+	if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] edit distance classes (3 per wave, 2 per wave, units 1..16): %u %u %u %u %u %u %u\n", count[0], count[1], count[2], count[3], count[4], count[5], count[6]);
 }
 static void finishEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair* hPairs, int64_t* hOut, uint32_t nPairs, EdPair* dPairs, int64_t* dOut, const EdRead* dReads, const char* dBases,
 	const uint64_t* dEqMasks, const char* dLetters, const uint32_t* dLettersLen)
@@ -818,11 +856,20 @@ static void finishEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 	}
 	std::vector<EdPair> sub;
 	std::vector<int64_t> subOut;
-	for (uint32_t unit = 1; unit <= 16 && !todo.empty(); unit *= 2) {   // (unit 1 again for what the two-pairs-per-wave kernel handed back)
+	if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] edit distance reruns: %zu of %u pairs\n", todo.size(), nPairs);
+	// unit 0 here: the two-pairs-per-wave kernel for what the three-pairs-per-wave kernel handed back (its pairs come first in the grouped order)
+	for (uint32_t unit = 0; unit <= 16 && !todo.empty(); unit = unit ? unit * 2 : 1) {   // (unit 1 for what the two-pairs-per-wave kernel handed back)
+		std::vector<uint32_t> later;
+		if (unit == 0) {
+			std::vector<uint32_t> now;
+			for (uint32_t i : todo) (i < run.begin[1] ? now : later).push_back(i);
+			todo.swap(now);
+			if (todo.empty()) { todo.swap(later); continue; }
+		}
 		sub.resize(todo.size());
 		subOut.resize(todo.size());
-		// (what reaches unit U has failed every band below it: the two-pairs-per-wave kernel's limit for U = 1, the limit of unit U / 2 otherwise - start there, not at the first guess)
-		const uint32_t failedBelow = unit == 1 ? editDistanceMaxK(0) : editDistanceMaxK(unit / 2);
+		// (what reaches unit U has failed every band below it: the team kernels' limits for U = 0 and 1, the limit of unit U / 2 otherwise - start there, not at the first guess)
+		const uint32_t failedBelow = unit == 0 ? editDistanceMaxK(0) - 1 : unit == 1 ? editDistanceMaxK(0) : editDistanceMaxK(unit / 2);
 		for (size_t i = 0; i < todo.size(); i++) { sub[i] = hPairs[todo[i]]; sub[i].k = std::max(sub[i].k, failedBelow); }
 		HIP_CHECK(hipMemcpyAsync(dPairs, sub.data(), sub.size() * sizeof(EdPair), hipMemcpyHostToDevice, stream));
 		launchEditDistance(stream, unit, dPairs, (uint32_t)sub.size(), dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut);
@@ -831,6 +878,7 @@ static void finishEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 		std::vector<uint32_t> next;
 		for (size_t i = 0; i < todo.size(); i++) { hOut[todo[i]] = subOut[i]; if (subOut[i] == -2) next.push_back(todo[i]); }
 		todo.swap(next);
+		todo.insert(todo.end(), later.begin(), later.end());
 	}
 	// still -2: the band is too wide for the NW kernel (a read longer than 65536 bases more than 32256 edits away from its path); the caller flags the read
 	// back to the caller's order
@@ -890,7 +938,7 @@ int gc_edit_distance(const char* a, const uint64_t* a_off, const char* b, const 
 		HIP_CHECK(hipMemcpy(pr, reads.data(), n_pairs * sizeof(EdRead), hipMemcpyHostToDevice));
 		EditDistanceRun run;
 		auto readLenOf = [&](uint32_t r) { return reads[r].len; };
-		launchEditDistances(run, nullptr, pairs.data(), out, (uint32_t)n_pairs, pp, po, pr, pb, pm, pa, nullptr, readLenOf);
+		launchEditDistances(run, nullptr, pairs.data(), out, (uint32_t)n_pairs, pp, po, pr, pb, pm, pa, nullptr, readLenOf, getenv("GC_ED_FIRST_K") != nullptr);   // (the test hook's band picks the kernel class as a whole-read pair's own bound does)
 		finishEditDistances(run, nullptr, pairs.data(), out, (uint32_t)n_pairs, pp, po, pr, pb, pm, pa, nullptr);
 		return (int)GC_OK;
 	});
@@ -1150,8 +1198,8 @@ int gc_graph_letters(const gc_graph* G, const int32_t* node, const uint32_t* off
 	return guarded([&]() {
 		gc::GraphLetters letters(G->host);
 		for (uint64_t i = 0; i < n; i++) {
-			auto it = G->host.originalNodeSize.find(node[i]);
-			if (it == G->host.originalNodeSize.end() || offset[i] >= it->second) throw std::runtime_error("gc_graph_letters: no such node / offset");
+			const size_t* size = G->host.originalNodeSize.find(node[i]);
+			if (!size || offset[i] >= *size) throw std::runtime_error("gc_graph_letters: no such node / offset");
 			out[i] = letters.at(node[i], offset[i]);
 		}
 		return (int)GC_OK;
@@ -1290,7 +1338,19 @@ int gc_graph_create(const gc_graph_desc* desc, gc_graph** out)
 		std::vector<size_t> order(n);
 		for (size_t i = 0; i < n; i++) order[i] = i;
 		std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return h.nodeIDs[a] != h.nodeIDs[b] ? h.nodeIDs[a] < h.nodeIDs[b] : h.nodeOffset[a] < h.nodeOffset[b]; });
-		for (size_t i : order) { h.nodeLookup[h.nodeIDs[i]].push_back(i); h.originalNodeSize[h.nodeIDs[i]] += h.nodeLength[i]; }
+		// (without a lookup_order from the caller the minimizer index follows the order an unordered_map filled with the ids in ascending order iterates in - as r1-r3 built it)
+		gc::HashOrder ascending;
+		std::vector<int> ascendingIds;
+		for (size_t at = 0; at < n;) {
+			size_t end = at;
+			while (end < n && h.nodeIDs[order[end]] == h.nodeIDs[order[at]]) end++;
+			h.nodeLookup.add(h.nodeIDs[order[at]], order.data() + at, end - at);
+			for (size_t k = at; k < end; k++) h.originalNodeSize[h.nodeIDs[order[at]]] += h.nodeLength[order[k]];
+			ascending.insert(std::hash<int>()(h.nodeIDs[order[at]]));
+			ascendingIds.push_back(h.nodeIDs[order[at]]);
+			at = end;
+		}
+		for (uint32_t e : ascending.order()) h.nodeLookupOrder.push_back(ascendingIds[e]);
 		if (desc->lookup_order) {
 			// the host's nodeLookup iteration order: the minimizer index enumerates nodes in it (src/MinimizerSeeder.cpp:354-357)
 			if (desc->n_lookup != h.nodeLookup.size()) throw std::runtime_error("lookup_order must list every bigraph node id once");
@@ -1352,7 +1412,7 @@ int gc_graph_array(const gc_graph* G, const char* name, int64_t** out, uint64_t*
 	else if (nm == "back_off") { v.push_back(0); for (size_t i = 0; i < n; i++) v.push_back(v.back() + (int64_t)g.backwards[g.component_map[i]][g.component_idx[i]].size()); }
 	else if (nm == "back_node") { for (size_t i = 0; i < n; i++) for (const auto& b : g.backwards[g.component_map[i]][g.component_idx[i]]) v.push_back(g.component_ids[g.component_map[i]][b.first]); }
 	else if (nm == "back_path") { for (size_t i = 0; i < n; i++) for (const auto& b : g.backwards[g.component_map[i]][g.component_idx[i]]) v.push_back(b.second); }
-	else if (nm == "lookupOrder") { if (!g.nodeLookupOrder.empty()) for (int id : g.nodeLookupOrder) v.push_back(id); else for (const auto& kv : g.nodeLookup) v.push_back(kv.first); }
+	else if (nm == "lookupOrder") { for (int id : g.nodeLookupOrder) v.push_back(id); }
 	else return fail(GC_ERR_INVALID, "unknown graph array " + nm);
 	*out = mallocArray<int64_t>(v.size());
 	memcpy(*out, v.data(), v.size() * sizeof(int64_t));
@@ -1424,7 +1484,6 @@ static bool buildSeederOnDevice(const gc_graph* G, gc_seeder* S, size_t k, size_
 		for (size_t nb : h.inNeighbors[i]) if (h.nodeIDs[nb] != h.nodeIDs[i]) return false;
 	}
 	std::vector<int32_t> idOrder(h.nodeLookupOrder.begin(), h.nodeLookupOrder.end());   // arrival order at -t 1: nodeLookup iteration order (:354-357)
-	if (idOrder.empty()) for (const auto& entry : h.nodeLookup) idOrder.push_back(entry.first);
 	if (idOrder.empty()) return false;
 	int32_t* dOrder = uploadVector(idOrder);
 	uint64_t *dKeys = nullptr, *dValues = nullptr;
@@ -1598,9 +1657,10 @@ void gc_stream_destroy(gc_stream* st)
 		std::lock_guard<std::mutex> count(g_longScratchCount);
 		SharedLongScratch& shared = g_longScratch[st->device & 15];
 		if (--shared.streams == 0) {   // the device's last stream: nobody can hold the token any more
-			std::lock_guard<std::mutex> token(g_longPassToken[st->device & 15]);
+			TokenHold tokens[LONG_TOKENS_MAX];
+			for (int t = 0; t < longTokenCount(); t++) tokens[t].lock(g_longPassToken[st->device & 15], longTokenCount());
 			int current = 0;
-			if (hipGetDevice(&current) == hipSuccess) { (void)hipSetDevice(st->device); shared.buffer.release(); (void)hipSetDevice(current); }
+			if (hipGetDevice(&current) == hipSuccess) { (void)hipSetDevice(st->device); for (auto& b : shared.buffer) b.release(); (void)hipSetDevice(current); }
 		}
 	}
 	delete st;
@@ -1741,6 +1801,10 @@ struct BatchRun {
 	LongCell* dLongCells = nullptr;
 	uint64_t cellBudget = 0;                      // capacity of the merged-trace cell pool (grown and the pass rerun when a batch overflows it)
 	unsigned long long* longScratchOfToken = nullptr;   // the device's shared extension scratch, set by the pass once it holds the token
+	// r4: the token is taken when the pass's FIRST extension kernel is about to be queued and given back when the last round's count (zero) has come down: a pass's first
+	// init / select / order / publish and the host's wait for the work count (each a launch that queues among the other batches' kernels), and its k_long_finish at the
+	// end, no longer sit between two passes' extension kernels (GC_LONG_TOKEN_EARLY=1: around the whole pass, as before)
+	std::function<void()> longTokenTake, longTokenDrop;
 	uint64_t longScratchWords = 0;
 	bool shareLongScratch = false;
 	uint32_t longGroups = 0;
@@ -2075,7 +2139,7 @@ struct BatchRun {
 			dRoundTrace = st->longRoundTrace.reserve<unsigned long long>(groupTraceBegin[nGroups]);
 			// extension scratch: one region per lane of a resident wave (persistent waves fetch work items), per read group
 			// (bounded by a memory budget: 0.8 MB per lane for 10 kb reads, 2.4 MB for 50 kb reads; GC_LONG_SCRATCH_GB overrides the 48 GB)
-			uint64_t scratchBudget = P->capacity.long_scratch_bytes > 0 ? (uint64_t)P->capacity.long_scratch_bytes : 48ull << 30;
+			uint64_t scratchBudget = P->capacity.long_scratch_bytes > 0 ? (uint64_t)P->capacity.long_scratch_bytes : (48ull << 30) / (uint64_t)longTokenCount();
 			if (const char* env = getenv("GC_LONG_SCRATCH_GB")) scratchBudget = (uint64_t)std::max(1, atoi(env)) << 30;
 			scratchLanes = std::min<uint64_t>(workCapacity + 64, std::max<uint64_t>(2048, std::min<uint64_t>(65536 + 64, scratchBudget / (waveWords * 8))));
 			// one pass at a time (the default) works in the device's shared scratch; the experiments that let passes overlap keep a scratch per stream
@@ -2131,6 +2195,7 @@ struct BatchRun {
 	void runLongGroupOnDevice(uint32_t g)
 	{
 		const uint64_t r0 = groupBegin[g], nG = groupBegin[g + 1] - r0;
+		if (longTokenTake) longTokenTake();   // (rounds are queued ahead here: the token covers the whole loop)
 		unsigned long long* dLongScratch = shareLongScratch ? longScratchOfToken : dLongScratchOwn;
 		hipStream_t q = st->groupStreams[g];
 		hipEvent_t* ring = st->groupEvents.data() + (size_t)2 * LONG_EVENT_RING * g;
@@ -2197,7 +2262,7 @@ struct BatchRun {
 		const uint64_t r0 = groupBegin[g], nG = groupBegin[g + 1] - r0;
 		if (nG == 0) return;
 		if (roundsOnDevice(g)) { runLongGroupOnDevice(g); return; }
-		unsigned long long* dLongScratch = shareLongScratch ? longScratchOfToken : dLongScratchOwn;   // (round token: set under the lock, every round)
+		unsigned long long* dLongScratch = nullptr;   // (set when the token is taken - before the first extension launch; round token: under the lock, every round)
 		hipStream_t q = st->groupStreams[g];
 		hipEvent_t* ring = st->groupEvents.data() + (size_t)2 * LONG_EVENT_RING * g;
 		// the rounds' extension time: read a ring slot's pair before the slot is reused (its round is complete by then: every round's
@@ -2217,7 +2282,7 @@ struct BatchRun {
 		int deviceNow = 0;
 		HIP_CHECK(hipGetDevice(&deviceNow));
 		const bool roundToken = getenv("GC_LONG_TOKEN") && atoi(getenv("GC_LONG_TOKEN")) == 2;   // (read per batch: the tests switch modes inside one process)
-		std::unique_lock<std::mutex> roundLock(g_longPassToken[deviceNow & 15], std::defer_lock);
+		std::unique_lock<std::mutex> roundLock(g_longRoundToken[deviceNow & 15], std::defer_lock);
 		hipEvent_t roundExtendDone = nullptr;
 
 		for (int round = 0; round < 4096; round++) {
@@ -2254,9 +2319,13 @@ struct BatchRun {
 			dbgWaitUs += nowUs() - tWait0;
 			uint32_t nWorkItems = (uint32_t)hCursor[0];
 			if (nWorkItems == 0) break;
+			if (!dLongScratch) {
+				if (longTokenTake) longTokenTake();
+				dLongScratch = shareLongScratch ? longScratchOfToken : dLongScratchOwn;
+			}
 			if (roundToken && nGroups == 1) {
 				roundLock.lock();
-				if (shareLongScratch) dLongScratch = g_longScratch[deviceNow & 15].buffer.reserve<unsigned long long>(longScratchWords);
+				if (shareLongScratch) dLongScratch = g_longScratch[deviceNow & 15].buffer[0].reserve<unsigned long long>(longScratchWords);
 			}
 			uint32_t team = longExtendTeamSize(nWorkItems);
 			uint32_t blocks = std::min<uint32_t>((nWorkItems + team - 1) / team, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / team));
@@ -2315,6 +2384,8 @@ struct BatchRun {
 			timedRounds++;
 			groupRounds[g]++;
 		}
+		// (the last round's count has come down: every extension kernel of the pass is complete, the scratch is free)
+		if (longTokenDrop) longTokenDrop();
 		// the per-read results go straight into pinned host memory (the kernel writes them across PCIe): a copy-engine transfer here queued behind
 		// the other batch's bulk downloads for 30-50 ms while this pass still held the device's whole-read token
 		launchLongFinish(q, (uint32_t)nG, dLongState + r0, hLongResults + r0);
@@ -2441,7 +2512,7 @@ struct BatchRun {
 		HIP_CHECK(hipMemcpyAsync(dJobsPS, hJobsPS, m * sizeof(PathSeqJob), hipMemcpyHostToDevice, q));
 		launchLongPathSeq(q, G->dev, dJobsPS, (uint32_t)m, dLongCells, dLetters, dLettersLen);
 		auto readLenOf = [R = R](uint32_t r) { return (uint32_t)(R->offsets[r + 1] - R->offsets[r]); };
-		launchEditDistances(D.run, q, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen, readLenOf);
+		launchEditDistances(D.run, q, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen, readLenOf, true);   // (k: the alignment's own bound)
 		D.nPairs = nPairs;
 		decisionPtr[slot] = DecisionPointers { hPairs, hOut, dPairs, dOut, dLetters, dLettersLen };
 	}
@@ -2514,26 +2585,45 @@ struct BatchRun {
 			for (uint32_t g = 0; g < longGroups; g++)
 				longThreads.emplace_back([&, device, g]() {
 					// (declared outside the try block: on an exception the catch below waits for the pass's kernels BEFORE the token - and with it the device's shared scratch - is released)
-					std::unique_lock<std::mutex> token(g_longPassToken[device & 15], std::defer_lock);
+					TokenHold token;
 					try {
 						HIP_CHECK(hipSetDevice(device));
 						const int tokenMode = getenv("GC_LONG_TOKEN") ? atoi(getenv("GC_LONG_TOKEN")) : 1;   // 0 none, 1 one pass at a time, 2 one round's extension kernel at a time
 						const double tTokenAsk = nowUs();
-						if (tokenMode == 1 && longGroups == 1) token.lock();
-						if (shareLongScratch && tokenMode == 1) {
-							if (!token.owns_lock()) throw std::runtime_error("internal: shared whole-read scratch without the token");
-							longScratchOfToken = g_longScratch[device & 15].buffer.reserve<unsigned long long>(longScratchWords);
-						}
-						if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc token] stream %p asked %.1f got %.1f (call began %.1f)\n", (void*)st, tTokenAsk / 1e3, nowUs() / 1e3, tCall / 1e3);
-						{ double now = nowUs(), seen = longWallBeginUs.load(); while ((seen == 0.0 || now < seen) && !longWallBeginUs.compare_exchange_weak(seen, now)) {} }
+						const bool early = getenv("GC_LONG_TOKEN_EARLY") && atoi(getenv("GC_LONG_TOKEN_EARLY")) == 1;
+						bool held = false;   // between take and drop (with or without a token to hold: GC_LONG_TOKEN=0 has none)
+						auto stampBegin = [&]() { double now = nowUs(), seen = longWallBeginUs.load(); while ((seen == 0.0 || now < seen) && !longWallBeginUs.compare_exchange_weak(seen, now)) {} };
+						auto stampEnd = [&]() { double now = nowUs(), seen = longWallEndUs.load(); while (now > seen && !longWallEndUs.compare_exchange_weak(seen, now)) {} };
+						auto take = [&, device, tokenMode, tTokenAsk]() {
+							if (held) return;
+							const double tAsk = nowUs();
+							if (tokenMode == 1 && longGroups == 1) token.lock(g_longPassToken[device & 15], longTokenCount());
+							if (shareLongScratch && tokenMode == 1) {
+								if (!token.owns_lock()) throw std::runtime_error("internal: shared whole-read scratch without the token");
+								longScratchOfToken = g_longScratch[device & 15].buffer[token.slot].reserve<unsigned long long>(longScratchWords);
+							}
+							held = true;
+							if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc token] stream %p pass began %.1f asked %.1f got %.1f (call began %.1f)\n", (void*)st, tTokenAsk / 1e3, tAsk / 1e3, nowUs() / 1e3, tCall / 1e3);
+							stampBegin();   // (whole_read_pass_wall: from the token to its release)
+						};
+						auto drop = [&]() {
+							if (!held) return;
+							held = false;
+							stampEnd();
+							if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc token] stream %p released %.1f\n", (void*)st, nowUs() / 1e3);
+							token.unlock();   // the next batch's pass may start; what follows is this batch's own tail
+						};
+						if (longGroups == 1 && !early) { longTokenTake = take; longTokenDrop = drop; }
+						else if (longGroups == 1) take();
+						else stampBegin();
 						runLongGroup(g);
 						while (longGroups == 1 && growLongCells()) runLongGroup(g);   // the cell pool overflowed: again, with room
-						{ double now = nowUs(), seen = longWallEndUs.load(); while (now > seen && !longWallEndUs.compare_exchange_weak(seen, now)) {} }
-						if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc token] stream %p released %.1f\n", (void*)st, nowUs() / 1e3);
-						if (token.owns_lock()) token.unlock();   // the next batch's pass may start; what follows is this batch's own tail
+						if (longGroups == 1) { longTokenTake = nullptr; longTokenDrop = nullptr; drop(); }
+						else stampEnd();
 						if (longPostInThread) afterLongPass();
 					} catch (...) {
 						longErrors[g] = std::current_exception();
+						if (longGroups == 1) { longTokenTake = nullptr; longTokenDrop = nullptr; }   // (they refer to this thread's locals)
 						// the token is released when this lambda returns: a kernel of this pass may still be writing to the shared scratch
 						if (g < st->groupStreams.size()) (void)hipStreamSynchronize(st->groupStreams[g]);
 						(void)hipStreamSynchronize(st->longStream);

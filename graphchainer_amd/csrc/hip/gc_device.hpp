@@ -196,7 +196,9 @@ struct LaneScratch {
 	SliceInfo* slices;
 	NodeItem* items;
 	Pending* pending;
-	WCol* columns;      // 64 entries: one node's recomputed columns for the backtrace
+	WCol* columns;      // one node's recomputed columns for the backtrace: column c at columns[(c & colMask) * colStride]
+	uint32_t colMask;   // 63: the whole tile (per-lane slab in HBM). Smaller (r4, k_extend): a ring of the last colMask + 1 columns in LDS - the walk only moves left, and when it leaves
+	uint32_t colStride; // the ring the tile is recomputed up to the column it stands on
 	TraceCell* trace;
 	uint32_t* itemNodes; // the items' node ids again, packed (r4): "is this node in that slice" scans 4 B per item instead of pulling a 64 B item record per probe
 };
@@ -311,9 +313,10 @@ __device__ inline int findItem(const uint32_t* itemNodes, const SliceInfo& sl, u
 // columns of the score at row flatRows-1 is tracked (fused flattenLastSliceEnd, ...Common.h:1210-1218).
 struct TileResult { int32_t minScore; uint32_t minOffset; int32_t flatMin; uint32_t flatOffset; };
 __device__ inline TileResult computeTile(const DGraph& g, uint32_t node, WS ws, bool prevExists, int32_t prevStartScore, uint64_t prevHP, uint64_t prevHN,
-	const Eq4& eq, NodeItem& out, WCol* columns, int flatRows, uint32_t& status)
+	const Eq4& eq, NodeItem& out, WCol* columns, int flatRows, uint32_t& status, uint32_t colMask = 63, uint32_t colStride = 1, int lastColumn = 63)
 {
 	int nodeLength = g.nodeLength[node];
+	if (lastColumn + 1 < nodeLength) nodeLength = lastColumn + 1;   // (backtrace ring refill: the columns up to the one the walk stands on; `out`'s end column is then that column)
 	NodeSeq seq = loadNodeSeq(g, node);
 	TileResult r;
 	r.minScore = ws.score;   // (sic) taken before the merge with the row above, ...Common.h:968 vs :1052-1058
@@ -345,7 +348,7 @@ __device__ inline TileResult computeTile(const DGraph& g, uint32_t node, WS ws, 
 	r.flatMin = INT32_MAX;
 	r.flatOffset = 0;
 	if (flatRows > 0) r.flatMin = ws.score - popc64(ws.VP & ~flatMask) + popc64(ws.VN & ~flatMask);
-	if (columns) columns[0] = WCol { ws.VP, ws.VN };
+	if (columns) columns[0] = WCol { ws.VP, ws.VN };   // ((0 & colMask) * colStride)
 	uint64_t forceEq = prevExists ? ~0ull : ~1ull;
 	uint64_t HP = 0, HN = 0;
 	for (int pos = 1; pos < nodeLength; pos++) {
@@ -358,7 +361,7 @@ __device__ inline TileResult computeTile(const DGraph& g, uint32_t node, WS ws, 
 			int32_t f = ws.score - popc64(ws.VP & ~flatMask) + popc64(ws.VN & ~flatMask);
 			if (f < r.flatMin) { r.flatMin = f; r.flatOffset = (uint32_t)pos; }
 		}
-		if (columns) columns[pos] = WCol { ws.VP, ws.VN };
+		if (columns) columns[((uint32_t)pos & colMask) * colStride] = WCol { ws.VP, ws.VN };
 		HP |= hp << pos;
 		HN |= hn << pos;
 	}
@@ -408,18 +411,23 @@ __device__ inline void pushEdge(const DGraph& g, Pending* pending, uint32_t& nPe
 }
 
 // Recomputes all columns of (slice s, node) into sc.columns. reference: recalcNodeWordslice, ...Common.h:828-852
-__device__ inline ColumnScores recomputeColumns(const DGraph& g, const LaneScratch& sc, uint32_t s, int itemIdx, const Eq4& eq, uint32_t& status, ExtCounters& cnt)
+// `upTo`: the last column wanted (a ring keeps the colMask + 1 columns that end there); `entering`: the walk's first visit of the tile - counted, in the reference's units (it recomputes
+// the whole tile once) - as opposed to a refill of the ring
+__device__ inline ColumnScores recomputeColumns(const DGraph& g, const LaneScratch& sc, uint32_t s, int itemIdx, const Eq4& eq, uint32_t& status, ExtCounters& cnt, uint32_t upTo = 63, bool entering = true)
 {
 	const NodeItem& it = sc.items[itemIdx];
 	int prevIdx = findItem(sc.itemNodes, sc.slices[s - 1], it.node);
 	bool prevExists = prevIdx >= 0;
 	NodeItem scratch;
+	const int nodeLength = g.nodeLength[it.node];
 	computeTile(g, it.node, itemStart(it), prevExists, prevExists ? sc.items[prevIdx].sScore : 0,
-		prevExists ? sc.items[prevIdx].HP : ~0ull, prevExists ? sc.items[prevIdx].HN : 0ull, eq, scratch, sc.columns, 0, status);
-	if (scratch.eVP != it.eVP || scratch.eVN != it.eVN || scratch.eScore != it.eScore) status = EXT_ASSERT;   // sliceConsistency, :848-850
-	cnt.recomputeTiles++;
-	cnt.backtraceTiles++;
-	cnt.columnSteps += g.nodeLength[it.node];
+		prevExists ? sc.items[prevIdx].HP : ~0ull, prevExists ? sc.items[prevIdx].HN : 0ull, eq, scratch, sc.columns, 0, status, sc.colMask, sc.colStride, (int)upTo);
+	if ((int)upTo + 1 >= nodeLength && (scratch.eVP != it.eVP || scratch.eVN != it.eVN || scratch.eScore != it.eScore)) status = EXT_ASSERT;   // sliceConsistency, :848-850 (whole tiles only)
+	if (entering) {
+		cnt.recomputeTiles++;
+		cnt.backtraceTiles++;
+		cnt.columnSteps += nodeLength;
+	}
 	return ColumnScores { scratch.sScore, scratch.HP, scratch.HN };
 }
 
@@ -621,17 +629,29 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 	uint32_t curSlice = 0xffffffffu, curNode = 0xffffffffu;
 	int curItem = -1;
 	ColumnScores colScores { 0, 0, 0 };
-	auto column = [&](uint32_t c) -> WS { const WCol w = sc.columns[c]; return WS { w.VP, w.VN, colScores.at(c) }; };
+	uint32_t ringLo = 0;          // the lowest column the store holds (0 with a whole-tile store)
+	auto column = [&](uint32_t c) -> WS { const WCol w = sc.columns[(c & sc.colMask) * sc.colStride]; return WS { w.VP, w.VN, colScores.at(c) }; };
+	// a walk that is about to read columns c and c - 1 of a ring that no longer holds c - 1 sets refillTo = c and goes back to the top of the loop, where the tile is recomputed up to c
+	// (ONE call site of the recompute: a second inlined copy of the tile loop costs the kernel 90 spilled registers)
+	const uint32_t NO_REFILL = 0xffffffffu;
+	uint32_t refillTo = NO_REFILL;
 	while (here.seqPos != -1) {
 		uint32_t s = (uint32_t)(here.seqPos / 64) + 1;
 		if (s >= nSlices) return EXT_ASSERT;
-		if (s != curSlice || here.node != curNode) {
+		const bool entering = s != curSlice || here.node != curNode;
+		if (entering) {
 			if (s != curSlice) eqs.rows(len, sc.slices[s].j, eq);
 			curSlice = s;
 			curNode = here.node;
 			curItem = findItem(sc.itemNodes, sc.slices[s], curNode);
 			if (curItem < 0) return EXT_ASSERT;
-			colScores = recomputeColumns(g, sc, s, curItem, eq, status, cnt);
+		}
+		if (entering || refillTo != NO_REFILL) {
+			// a whole-tile store takes the whole tile (and checks it against the DP's end column, as the reference does); a ring starts at the column the walk enters at - it only moves left
+			const uint32_t upTo = entering ? (sc.colMask >= 63 ? 63u : here.offset) : refillTo;
+			colScores = recomputeColumns(g, sc, s, curItem, eq, status, cnt, upTo, entering);
+			ringLo = upTo > sc.colMask ? upTo - sc.colMask : 0;
+			refillTo = NO_REFILL;
 			if (status != EXT_OK) return status;
 		}
 		const SliceInfo& cs = sc.slices[s];
@@ -653,11 +673,14 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 				continue;
 			}
 			uint32_t off = here.offset;
-			while (off > 0 && wsValue(column(off - 1), 0) == wsValue(column(off), 0) - 1) {
+			while (off > 0) {
+				if (off - 1 < ringLo) { refillTo = off; break; }
+				if (wsValue(column(off - 1), 0) != wsValue(column(off), 0) - 1) break;
 				off--;
 				if (!pushTrace(sc, cfg, nTrace, Cell { curNode, off, here.seqPos }, false, status)) return status;
 			}
 			here.offset = off;
+			if (refillTo != NO_REFILL) continue;
 			if (off == 0) {
 				Cell nxt; bool sw;
 				if (!backtraceCorner(g, sc, s, curNode, curItem, eq, nxt, sw)) return EXT_ASSERT;
@@ -742,6 +765,7 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 			int vert = row;
 			NodeSeq nseq = loadNodeSeq(g, curNode);
 			while (hori > 0 && vert > 0) {
+				if (hori - 1 < ringLo) { refillTo = hori; break; }
 				const WS colHere = column(hori), colLeft = column(hori - 1);
 				int32_t scoreHere = wsValue(colHere, vert);
 				int32_t vertical = wsValue(colHere, vert - 1);

@@ -271,25 +271,29 @@ __global__ void __launch_bounds__(64) k_edit_distance(const EdPair* __restrict__
 	}
 }
 
-// Two pairs per wave (unit of one block, bands up to k = 1900): the corridor of a 10 kb pair is about 23 units wide, so a wave with one pair
-// keeps a third of its lanes busy and its time is set by the number of steps (columns + units), not by the band. Each half of the wave
-// (32 lanes) sweeps its own pair - lane l of a half owns the units l, l + 32, ...; the neighbour shuffle stays inside the half; each half has
-// its own letter ring and result slot - and the two halves step together (a half that is done, or has the shorter pair, idles). Same
-// arithmetic as k_edit_distance<1>; a pair whose band would outgrow the half (k >= 1900 with more than 32 units) answers -2 and is rerun
-// by the host with the wider kernels.
-#define ED_HALF_RING 4096u
+// Several pairs per wave (unit of one block): the corridor of a 10 kb pair is 16-23 units wide, so a wave with one pair keeps a third of its
+// lanes busy and its time is set by the number of steps (columns + units), not by the band. The wave is cut into teams of TEAM lanes - 32: two
+// pairs, bands up to k = 1900; 21: three pairs (one lane idles), bands up to k = 1290, which a 10 kb read's whole-read pair and most chain pairs
+// fit (r4) - and every team sweeps its own pair: lane l of a team owns the units l, l + TEAM, ... (a lane's consecutive units are disjoint in
+// time while k < 65 TEAM - 63), the neighbour shuffle stays inside the team, each team has its own letter ring and result slot, and the teams
+// step together (a team that is done, or has a shorter pair, idles). Same arithmetic as k_edit_distance<1>; a pair whose band would outgrow the
+// team answers -2 and is rerun by the host with the wider kernels.
 #define ED_HALF_KMAX 1900u
-__global__ void __launch_bounds__(64) k_edit_distance_half(const EdPair* __restrict__ pairs, uint32_t nPairs, const EdRead* __restrict__ reads, const char* __restrict__ bases,
+#define ED_THIRD_KMAX 1290u
+template <uint32_t TEAM, uint32_t RING>
+__global__ void __launch_bounds__(64) k_edit_distance_team(const EdPair* __restrict__ pairs, uint32_t nPairs, const EdRead* __restrict__ reads, const char* __restrict__ bases,
 	const uint64_t* __restrict__ eqMasks, const char* __restrict__ letters, const uint32_t* __restrict__ lettersLen, int64_t* __restrict__ outDistance)
 {
-	__shared__ uint8_t ringAll[2 * ED_HALF_RING];
-	__shared__ int32_t resultSlot[2];
-	const uint32_t lane = threadIdx.x, half = lane >> 5, l = lane & 31u;
-	uint8_t* ring = ringAll + half * ED_HALF_RING;
+	constexpr uint32_t PAIRS = 64u / TEAM, KMAX = TEAM >= 32 ? ED_HALF_KMAX : ED_THIRD_KMAX, AHEAD = RING / 2, PERIOD = RING / 4;
+	static_assert(KMAX < 65 * TEAM - 63, "a lane's consecutive units must stay disjoint in time");
+	__shared__ uint8_t ringAll[(PAIRS + 1) * RING];   // (+ 1: the lanes beyond the last whole team address a ring of their own and never touch it)
+	__shared__ int32_t resultSlot[PAIRS + 1];
+	const uint32_t lane = threadIdx.x, half = lane / TEAM, l = lane - half * TEAM;
+	uint8_t* ring = ringAll + half * RING;
 	constexpr uint32_t RB = 64u;
-	for (uint32_t base = blockIdx.x * 2; base < nPairs; base += gridDim.x * 2) {
+	for (uint32_t base = blockIdx.x * PAIRS; base < nPairs; base += gridDim.x * PAIRS) {
 		const uint32_t pi = base + half;
-		const bool valid = pi < nPairs;
+		const bool valid = half < PAIRS && pi < nPairs;
 		EdPair pair {};
 		EdRead rd {};
 		uint32_t n = 0, m = 0;
@@ -311,9 +315,9 @@ __global__ void __launch_bounds__(64) k_edit_distance_half(const EdPair* __restr
 		uint32_t k = pair.k > diff ? pair.k : diff;
 		if (k < 1) k = 1;
 		if (k > cap) k = cap;
-		if (more && !(nU + 2048 <= ED_HALF_RING)) more = false;                // the ring must still hold column t - (nU - 1) when it is refilled up to t + 2048 (-2: the wider kernels take it)
+		if (more && !(nU + AHEAD <= RING)) more = false;                       // the ring must still hold column t - (nU - 1) when it is refilled up to t + AHEAD (-2: the wider kernels take it)
 		while (__any(more)) {
-			if (more && k >= ED_HALF_KMAX && nU > 32) more = false;              // -2
+			if (more && k >= KMAX && nU > TEAM) more = false;                    // -2
 			// ---- one banded pass of every half that still has one to do
 			uint64_t VP = ~0ull, VN = 0, eqA = 0, eqC = 0, eqG = 0, eqT = 0;
 			uint32_t B = l;
@@ -339,24 +343,25 @@ __global__ void __launch_bounds__(64) k_edit_distance_half(const EdPair* __restr
 				finalStep = b == lastUnit ? m - 1 + b : 0xffffffffu;
 			};
 			enterUnit(l);
-			if (l == 0) resultSlot[half] = -1;
+			if (l == 0 && half < PAIRS) resultSlot[half] = -1;
 			const uint32_t steps = more ? m + nU - 1 : 0;
-			const uint32_t otherSteps = (uint32_t)__shfl((int)steps, (int)(lane ^ 32u));
-			const uint32_t allSteps = steps > otherSteps ? steps : otherSteps;
+			uint32_t allSteps = steps;
+			for (int d = 32; d >= 1; d >>= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)allSteps, d); allSteps = other > allSteps ? other : allSteps; }
+			const int neighbour = (int)(half * TEAM + (l + TEAM - 1) % TEAM);
 			for (uint32_t t = 0; t < allSteps; t++) {
-				if ((t & 1023u) == 0) {
+				if ((t & (PERIOD - 1)) == 0) {
 					if (more) {
-						const uint32_t end = t + 2048 < m ? t + 2048 : m;
-						for (uint32_t c = loadedEnd + l; c < end; c += 32) {
+						const uint32_t end = t + AHEAD < m ? t + AHEAD : m;
+						for (uint32_t c = loadedEnd + l; c < end; c += TEAM) {
 							const uint8_t ch = (uint8_t)path[c];
-							ring[c & (ED_HALF_RING - 1)] = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
+							ring[c & (RING - 1)] = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
 						}
 						loadedEnd = end > loadedEnd ? end : loadedEnd;
 					}
 					__syncthreads();
 				}
-				const uint32_t nbPack = (uint32_t)__shfl((int)pack, (int)((lane & 32u) | ((l + 31u) & 31u)));
-				if (B < nU && t > tEnd) { do enterUnit(B + 32); while (B < nU && t > tEnd); }
+				const uint32_t nbPack = (uint32_t)__shfl((int)pack, neighbour);
+				if (B < nU && t > tEnd) { do enterUnit(B + TEAM); while (B < nU && t > tEnd); }
 				if (t < tBegin || t >= steps) continue;
 				const uint32_t j = t - B;
 				if (fresh) {
@@ -371,7 +376,7 @@ __global__ void __launch_bounds__(64) k_edit_distance_half(const EdPair* __restr
 					if (j == 0) score = (int32_t)(RB * (B + 1));
 					else score = (int32_t)(nbPack >> 2) - ((int32_t)(nbPack & 3u) - 1) + (int32_t)RB;
 				}
-				const uint32_t code = ring[j & (ED_HALF_RING - 1)];
+				const uint32_t code = ring[j & (RING - 1)];
 				int hin = 1;
 				if (B > 0 && t <= tHinEnd) hin = (int)(nbPack & 3u) - 1;
 				uint64_t hinP = hin > 0 ? 1 : 0, hinN = hin < 0 ? 1 : 0;
@@ -431,16 +436,21 @@ void launchChainPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* j
 	if (nJobs) hipLaunchKernelGGL(k_chain_pathseq, dim3(nJobs), dim3(64), 0, stream, g, jobs, nJobs, pathNodes, altNodes, letters, outLen);
 }
 uint32_t editDistanceMaxK(uint32_t unitBlocks) { return unitBlocks == 0 ? ED_HALF_KMAX : 4000u * unitBlocks; }   // unit 0: the two-pairs-per-wave kernel
+uint32_t editDistanceTeamMaxK(uint32_t pairsPerWave) { return pairsPerWave == 3 ? ED_THIRD_KMAX : ED_HALF_KMAX; }
+void launchEditDistanceTeam(hipStream_t stream, uint32_t pairsPerWave, const EdPair* pairs, uint32_t nPairs, const EdRead* reads, const char* bases, const uint64_t* eqMasks,
+	const char* letters, const uint32_t* lettersLen, int64_t* outDistance)
+{
+	if (!nPairs) return;
+	const uint32_t waves = (nPairs + pairsPerWave - 1) / pairsPerWave, blocks = waves < 65536 ? waves : 65536;
+	if (pairsPerWave == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edit_distance_team<21, 2048>), dim3(blocks), dim3(64), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance);
+	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edit_distance_team<32, 4096>), dim3(blocks), dim3(64), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance);
+}
 void launchEditDistance(hipStream_t stream, uint32_t unitBlocks, const EdPair* pairs, uint32_t nPairs, const EdRead* reads, const char* bases, const uint64_t* eqMasks,
 	const char* letters, const uint32_t* lettersLen, int64_t* outDistance)
 {
 	if (!nPairs) return;
 	uint32_t blocks = nPairs < 65536 ? nPairs : 65536;
-	if (unitBlocks == 0) {   // two pairs per wave (launchEditDistances sends the pairs with a small first band here)
-		blocks = (nPairs + 1) / 2 < 65536 ? (nPairs + 1) / 2 : 65536;
-		hipLaunchKernelGGL(k_edit_distance_half, dim3(blocks), dim3(64), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance);
-		return;
-	}
+	if (unitBlocks == 0) { launchEditDistanceTeam(stream, 2, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance); return; }   // two pairs per wave (launchEditDistances sends the pairs with a small first band here)
 	switch (unitBlocks) {
 		case 1: hipLaunchKernelGGL(k_edit_distance<1>, dim3(blocks), dim3(64), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance); break;
 		case 2: hipLaunchKernelGGL(k_edit_distance<2>, dim3(blocks), dim3(64), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance); break;

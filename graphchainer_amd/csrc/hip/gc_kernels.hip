@@ -146,11 +146,15 @@ __device__ __forceinline__ LaneScratch laneScratch(uint8_t* slab, const ExtendCo
 	sc.items = (NodeItem*)p;     p += sizeof(NodeItem) * cfg.maxItems;
 	sc.pending = (Pending*)p;    p += sizeof(Pending) * cfg.maxPending;
 	sc.columns = (WCol*)p;       p += sizeof(WCol) * 64;
+	sc.colMask = 63; sc.colStride = 1;
 	sc.trace = (TraceCell*)p;    p += sizeof(TraceCell) * cfg.maxTrace;
 	sc.itemNodes = (uint32_t*)p;
 	return sc;
 }
 
+#ifndef GC_EXTEND_RING
+#define GC_EXTEND_RING 8   // columns per lane of the backtrace ring in LDS (power of two; 0: the whole tile in the lane's HBM slab, as before r4)
+#endif
 // 4 waves per SIMD (<= 128 VGPRs; the kernel wanted 131 and ran 3): it waits on memory 56 % of the time, so the extra wave
 // pays for the 4 spilled registers: 34.2 -> 29.0 ms alone on cfg2 (5 or 6 waves spill 57 / 196 registers and lose).
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg,
@@ -161,6 +165,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t stride = gridDim.x * blockDim.x;
 	LaneScratch sc = laneScratch(scratch + (uint64_t)tid * slabBytes, cfg);
+#if GC_EXTEND_RING
+	// r4: the backtrace's recomputed columns in LDS - a ring of the last GC_EXTEND_RING columns per lane, lane-interleaved - instead of 64 columns in the lane's HBM slab
+	__shared__ WCol columnRing[GC_EXTEND_RING * 64];
+	sc.columns = columnRing + threadIdx.x;
+	sc.colMask = GC_EXTEND_RING - 1; sc.colStride = 64;
+#endif
 	ExtCounters cnt {};
 	// which work items: all of them, the two extensions of every fragment's first seed, or a list written by k_build_anchors (count on the device)
 	const uint32_t nSelected = sel.mode == 0 ? nWork : sel.mode == 1 ? 2 * sel.nFrags : (uint32_t)*sel.listCount;

@@ -174,6 +174,12 @@ AlignmentGraph AlignmentGraph::BuildFromGFA(const GfaGraph& gfa)
 	AlignmentGraph g;
 	for (auto& ov : gfa.overlaps)
 		if (ov.second != 0) throw std::runtime_error("edge overlaps other than 0M are outside this build's scope (variation-graph DAGs only)");
+	{
+		int maxId = -1;
+		for (const auto& node : gfa.nodes) maxId = std::max(maxId, node.first);
+		const size_t ids = 2 * ((size_t)(maxId + 1));   // (the id-keyed tables are vectors: sized up front, the ids come in hash order)
+		g.nodeLookup.denseUpTo(ids); g.originalNodeSize.denseUpTo(ids); g.originalNodeName.denseUpTo(ids);
+	}
 	for (const auto& node : gfa.nodes) {    // libstdc++ unordered_map order == reference order
 		for (char c : node.second)
 			if (!allowedNucleotide(c)) throw std::runtime_error(std::string("Invalid sequence character: ") + c);
@@ -196,6 +202,12 @@ AlignmentGraph AlignmentGraph::BuildFromGFA(const GfaGraph& gfa)
 		}
 	}
 	clock.lap("edges");
+	// the reference's container into the product's flat storage, its iteration order recorded (what MinimizerIndex::Build follows)
+	for (const auto& kv : g.buildLookup) {
+		g.nodeLookupOrder.push_back(kv.first);
+		g.nodeLookup.add(kv.first, kv.second.data(), kv.second.size());
+	}
+	g.buildLookup = std::unordered_map<int, std::vector<size_t>>();
 	g.Finalize();
 	return g;
 }
@@ -203,7 +215,7 @@ AlignmentGraph AlignmentGraph::BuildFromGFA(const GfaGraph& gfa)
 // reference: src/AlignmentGraph.cpp:51-85. Cuts a bigraph node into <=64 bp pieces, chained by edges.
 void AlignmentGraph::AddNode(int nodeId, const std::string& sequence, const std::string& name, bool reverseNode, const std::vector<size_t>& breakpoints)
 {
-	if (nodeLookup.count(nodeId) != 0) return;
+	if (buildLookup.count(nodeId) != 0) return;
 	originalNodeSize[nodeId] = sequence.size();
 	originalNodeName[nodeId] = name;
 	for (size_t b = 1; b < breakpoints.size(); b++) {
@@ -226,7 +238,7 @@ void AlignmentGraph::AddSplitNode(int nodeId, int offset, const std::string& seq
 {
 	assert(sequence.size() <= (size_t)SPLIT_NODE_SIZE);
 	bpSize += sequence.size();
-	nodeLookup[nodeId].push_back(nodeLength.size());
+	buildLookup[nodeId].push_back(nodeLength.size());
 	nodeLength.push_back(sequence.size());
 	nodeIDs.push_back(nodeId);
 	inNeighbors.emplace_back();
@@ -273,9 +285,9 @@ void AlignmentGraph::AddSplitNode(int nodeId, int offset, const std::string& seq
 // reference: src/AlignmentGraph.cpp:233-253
 void AlignmentGraph::AddEdgeNodeId(int fromId, int toId, size_t startOffset)
 {
-	size_t from = nodeLookup.at(fromId).back();
+	size_t from = buildLookup.at(fromId).back();
 	size_t to = SIZE_MAX;
-	for (size_t node : nodeLookup.at(toId))
+	for (size_t node : buildLookup.at(toId))
 		if (nodeOffset[node] == startOffset) to = node;
 	if (to == SIZE_MAX) throw std::runtime_error("edge target offset not found");
 	if (std::find(inNeighbors[to].begin(), inNeighbors[to].end(), from) == inNeighbors[to].end()) inNeighbors[to].push_back(from);
@@ -322,8 +334,7 @@ void AlignmentGraph::RenumberAmbiguousToEnd()
 	permute(inNeighbors);
 	permute(outNeighbors);
 	permute(reverse);
-	for (auto& kv : nodeLookup)
-		for (auto& v : kv.second) v = newIndex[v];
+	for (size_t& v : nodeLookup.nodes()) v = newIndex[v];
 	for (size_t i = 0; i < n; i++) {
 		for (auto& v : inNeighbors[i]) v = newIndex[v];
 		for (auto& v : outNeighbors[i]) v = newIndex[v];
@@ -480,7 +491,7 @@ char AlignmentGraph::NodeSequences(size_t node, size_t pos) const   // reference
 
 size_t AlignmentGraph::GetUnitigNode(int nodeId, size_t offset) const   // reference: src/AlignmentGraph.cpp:832-848
 {
-	const auto& nodes = nodeLookup.at(nodeId);
+	const NodeLookup::Span nodes = nodeLookup.at(nodeId);
 	size_t index = (size_t)(nodes.size() * ((double)offset / (double)originalNodeSize.at(nodeId)));
 	if (index >= nodes.size()) index = nodes.size() - 1;
 	while (index < nodes.size() - 1 && nodeOffset[nodes[index]] + nodeLength[nodes[index]] <= offset) index++;
@@ -496,8 +507,8 @@ std::pair<int, size_t> AlignmentGraph::GetReversePosition(int nodeId, size_t off
 
 std::string AlignmentGraph::OriginalNodeName(int nodeId) const
 {
-	auto it = originalNodeName.find(nodeId);
-	return it == originalNodeName.end() ? std::string() : it->second;
+	const std::string* name = originalNodeName.find(nodeId);
+	return name ? *name : std::string();
 }
 
 // ------------------------------------------------------------------ MPC index

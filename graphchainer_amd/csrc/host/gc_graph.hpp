@@ -6,9 +6,13 @@
 // and the minimizer index. It is built once on the CPU and uploaded to HBM.
 //
 // Numbering parity with the reference depends on libstdc++ unordered_map iteration
-// order (reference: src/BigraphToDigraph.cpp:229,251, src/AlignmentGraph.cpp:583),
-// so the same container types and insertion sequences are used on purpose.
+// order (reference: src/BigraphToDigraph.cpp:229,251, src/AlignmentGraph.cpp:583).
+// Two builders: LoadFromFile + BuildFromGFA use the same container types and insertion
+// sequences as the reference (the literal restatement; tests compare the other one with it),
+// BuildFromGFAFile (r4) replays the containers' order (gc_hashorder.hpp) over flat arrays
+// filled by several threads - what gc_graph_create_from_gfa and gc_index_build run.
 #pragma once
+#include "gc_idmap.hpp"
 #include <cstdint>
 #include <cstddef>
 #include <array>
@@ -54,6 +58,7 @@ public:
 
 	// ---- construction (reference: src/AlignmentGraph.cpp:51-307) ----
 	static AlignmentGraph BuildFromGFA(const GfaGraph& gfa);   // reference: src/BigraphToDigraph.cpp:215-267
+	static AlignmentGraph BuildFromGFAFile(const std::string& path);   // GfaGraph::LoadFromFile + BuildFromGFA in one, flat and threaded (gc_graph_fast.cpp); GC_BUILD_REFERENCE_CONTAINERS=1: the two above
 	void AddNode(int nodeId, const std::string& sequence, const std::string& name, bool reverseNode, const std::vector<size_t>& breakpoints);
 	void AddEdgeNodeId(int from, int to, size_t startOffset);
 	void Finalize();
@@ -76,11 +81,11 @@ public:
 
 	// ---- data (reference: src/AlignmentGraph.h:145-172) ----
 	std::vector<size_t> nodeLength;
-	std::unordered_map<int, std::vector<size_t>> nodeLookup;
-	std::unordered_map<int, size_t> originalNodeSize;
-	std::unordered_map<int, std::string> originalNodeName;
-	// iteration order of nodeLookup as it was when the graph was built; set only on a graph loaded from the index cache
-	// (gc_index_cache.hpp), where re-inserting the keys would not reproduce the order MinimizerIndex::Build follows
+	NodeLookup nodeLookup;                         // (gc_idmap.hpp: flat storage; the reference's is an unordered_map<int, vector<size_t>>)
+	DenseIdMap<size_t> originalNodeSize;
+	DenseIdMap<std::string> originalNodeName;
+	// the iteration order of the reference's nodeLookup (an unordered_map) as it is when the graph has been built: what MinimizerIndex::Build follows
+	// (src/MinimizerSeeder.cpp:354-357). Always set: by the builders, by the index cache, by gc_graph_create.
 	std::vector<int> nodeLookupOrder;
 	std::vector<size_t> nodeOffset;
 	std::vector<int> nodeIDs;
@@ -106,6 +111,8 @@ public:
 	std::vector<std::vector<std::vector<std::pair<size_t, size_t>>>> backwards;
 
 private:
+	// the literal builder's nodeLookup, the reference's container (AddNode / AddEdgeNodeId work on it); BuildFromGFA turns it into nodeLookup + nodeLookupOrder
+	std::unordered_map<int, std::vector<size_t>> buildLookup;
 	void AddSplitNode(int nodeId, int offset, const std::string& sequence, bool reverseNode);
 	void RenumberAmbiguousToEnd();
 	void findLinearizable();

@@ -186,14 +186,14 @@ void serialise(Sink& sink, const AlignmentGraph& g, const MinimizerIndex* idx)
 	out.raw(MAGIC, 8);
 	out.num(INDEX_CACHE_VERSION);
 	GraphTables t;
-	if (!g.nodeLookupOrder.empty()) t.ids = g.nodeLookupOrder;
-	else for (const auto& kv : g.nodeLookup) t.ids.push_back(kv.first);
+	t.ids = g.nodeLookupOrder;
 	if (t.ids.size() != g.nodeLookup.size()) throw std::runtime_error("node lookup order is out of date");
 	for (int id : t.ids) {
-		t.splitNodes.push_back(g.nodeLookup.at(id));
+		const NodeLookup::Span nodes = g.nodeLookup.at(id);
+		t.splitNodes.emplace_back(nodes.begin(), nodes.end());
 		t.sizes.push_back(g.originalNodeSize.at(id));
-		auto name = g.originalNodeName.find(id);
-		t.names.push_back(name == g.originalNodeName.end() ? std::string() : name->second);
+		const std::string* name = g.originalNodeName.find(id);
+		t.names.push_back(name ? *name : std::string());
 	}
 	graphFields(out, g, t);
 	out.num(idx ? 1 : 0);
@@ -319,9 +319,9 @@ IndexCacheInfo parse(const Mapping& file, AlignmentGraph& g, MinimizerIndex& idx
 		|| g.componentNumber.size() != n || g.component_map.size() != n || g.component_idx.size() != n || !g.finalized)
 		throw std::runtime_error("index cache: inconsistent graph arrays");
 	validateGraph(g, t);
-	g.nodeLookup.reserve(t.ids.size()); g.originalNodeSize.reserve(t.ids.size()); g.originalNodeName.reserve(t.ids.size());
+	g.nodeLookup.reserve(t.ids.size(), n); g.originalNodeSize.reserve(t.ids.size()); g.originalNodeName.reserve(t.ids.size());
 	for (size_t i = 0; i < t.ids.size(); i++) {
-		g.nodeLookup[t.ids[i]] = std::move(t.splitNodes[i]);
+		g.nodeLookup.add(t.ids[i], t.splitNodes[i].data(), t.splitNodes[i].size());
 		g.originalNodeSize[t.ids[i]] = t.sizes[i];
 		if (!t.names[i].empty()) g.originalNodeName[t.ids[i]] = std::move(t.names[i]);
 	}

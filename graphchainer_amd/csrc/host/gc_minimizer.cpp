@@ -111,15 +111,15 @@ MinimizerIndex MinimizerIndex::Build(const AlignmentGraph& g, size_t k, size_t w
 		for (size_t nb : g.inNeighbors[i])
 			if (g.nodeIDs[nb] != g.nodeIDs[i]) { start = std::max(start, g.nodeOffset[i]); break; }
 	}
-	std::vector<int> idOrder = g.nodeLookupOrder;   // arrival order at -t 1: nodeLookup iteration order (:354-357)
-	if (idOrder.empty()) for (const auto& entry : g.nodeLookup) idOrder.push_back(entry.first);
+	const std::vector<int>& idOrder = g.nodeLookupOrder;   // arrival order at -t 1: nodeLookup iteration order (:354-357)
+	if (idOrder.size() != g.nodeLookup.size()) throw std::runtime_error("MinimizerIndex::Build: the graph's node lookup order is missing");
 	// The nodes are scanned in contiguous chunks of that order by several threads; joining the chunks' lists in chunk order
 	// gives the single-threaded arrival order.
 	auto scan = [&](size_t from, size_t to, std::vector<std::pair<uint64_t, uint64_t>>& out) {   // (kmer, packed position)
 		std::string sequence;
 		for (size_t at = from; at < to; at++) {
 			int nodeId = idOrder[at];
-			const std::vector<size_t>& splitNodes = g.nodeLookup.at(nodeId);
+			const NodeLookup::Span splitNodes = g.nodeLookup.at(nodeId);
 			sequence.resize(g.originalNodeSize.at(nodeId));
 			size_t filled = 0;
 			for (size_t split : splitNodes)

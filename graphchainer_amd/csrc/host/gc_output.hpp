@@ -26,25 +26,27 @@ public:
 	explicit GraphLetters(const AlignmentGraph& graph) : graph(graph) {}
 	char at(int nodeId, size_t offset)
 	{
-		if (nodeId != currentId || !nodes) {
-			nodes = &graph.nodeLookup.at(nodeId);
+		if (nodeId != currentId || !known) {
+			nodes = graph.nodeLookup.at(nodeId);
+			known = true;
 			currentId = nodeId;
-			index = (size_t)(nodes->size() * ((double)offset / (double)graph.originalNodeSize.at(nodeId)));
-			if (index >= nodes->size()) index = nodes->size() - 1;
+			index = (size_t)(nodes.size() * ((double)offset / (double)graph.originalNodeSize.at(nodeId)));
+			if (index >= nodes.size()) index = nodes.size() - 1;
 		} else if (offset >= lo && offset < hi) {
 			return graph.NodeSequences(split, offset - lo);
 		}
 		// the split nodes of one original node partition its letters: the one that holds `offset` is unique, whichever index the search starts from
-		while (index < nodes->size() - 1 && graph.nodeOffset[(*nodes)[index]] + graph.nodeLength[(*nodes)[index]] <= offset) index++;
-		while (index > 0 && graph.nodeOffset[(*nodes)[index]] > offset) index--;
-		split = (*nodes)[index];
+		while (index < nodes.size() - 1 && graph.nodeOffset[nodes[index]] + graph.nodeLength[nodes[index]] <= offset) index++;
+		while (index > 0 && graph.nodeOffset[nodes[index]] > offset) index--;
+		split = nodes[index];
 		lo = graph.nodeOffset[split];
 		hi = lo + graph.nodeLength[split];
 		return graph.NodeSequences(split, offset - lo);
 	}
 private:
 	const AlignmentGraph& graph;
-	const std::vector<size_t>* nodes = nullptr;
+	NodeLookup::Span nodes { nullptr, nullptr };
+	bool known = false;
 	int currentId = 0;
 	size_t index = 0, split = 0, lo = 0, hi = 0;
 };

@@ -11,7 +11,8 @@ int main(int argc, char** argv)
 	gc::GfaGraph gfa = gc::GfaGraph::LoadFromFile(argv[1]);
 	gc::AlignmentGraph graph = gc::AlignmentGraph::BuildFromGFA(gfa);
 	auto plain = [&](int id, size_t offset) { size_t split = graph.GetUnitigNode(id, offset); return graph.NodeSequences(split, offset - graph.NodeOffset(split)); };
-	std::vector<std::pair<int, size_t>> nodes(graph.originalNodeSize.begin(), graph.originalNodeSize.end());
+	std::vector<std::pair<int, size_t>> nodes;
+	graph.originalNodeSize.forEach([&](int id, size_t size) { nodes.emplace_back(id, size); });
 	size_t checked = 0;
 	gc::GraphLetters cursor(graph);
 	for (const auto& node : nodes) {

@@ -252,7 +252,10 @@ def test_edit_distance_kernel(gca):
     lib.gco_edit_distance.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]
     rng = random.Random(5)
     pairs = []
-    for length, rate in [(1, 0.0), (63, 0.1), (64, 0.3), (65, 0.0), (700, 0.15), (3000, 0.05), (3000, 0.4), (10000, 0.12), (10000, 0.3), (20000, 0.25)]:
+    # (r4: the 5-10 kb pairs below ~12 % share waves three at a time - teams of 21 lanes, bands below 1290 -, the 10 kb pair at 12.6 % is handed on to the two-per-wave kernel,
+    # the one at 30 % from there to the one-pair kernels)
+    for length, rate in [(1, 0.0), (63, 0.1), (64, 0.3), (65, 0.0), (700, 0.15), (3000, 0.05), (3000, 0.4), (10000, 0.12), (10000, 0.3), (20000, 0.25),
+                         (5000, 0.1), (8000, 0.11), (10000, 0.05), (10000, 0.126), (9000, 0.02), (1400, 0.5), (12000, 0.1)]:
         a = bytes(rng.choice(b"ACGT") for _ in range(length))
         pairs.append((a, _mutate(rng, a, rate)))
     pairs.append((b"ACGTNNRYACGT" * 30, b"ACGTNARYACGA" * 29))                     # letters outside ACGT compare by equality
@@ -277,7 +280,8 @@ def test_edit_distance_long_low_error_pairs(gca, monkeypatch):
         ref = load_oracle_lib().gco_edit_distance
     rng = random.Random(17)
     pairs = []
-    for length, rate in [(140_000, 0.006), (149_000, 0.004), (131_072, 0.008), (120_000, 0.01), (400_000, 0.004)]:
+    # (r4: the three-pairs-per-wave kernel's ring holds 2048 letters and is refilled 1024 ahead: reads up to 65536 bases go there, the next length must not)
+    for length, rate in [(140_000, 0.006), (149_000, 0.004), (131_072, 0.008), (120_000, 0.01), (400_000, 0.004), (60_000, 0.012), (65_536, 0.01), (65_537, 0.01)]:
         a = bytes(rng.choice(b"ACGT") for _ in range(length))
         pairs.append((a, _mutate(rng, a, rate)))
     want = [int(ref(a, len(a), b, len(b))) for a, b in pairs]
@@ -962,16 +966,18 @@ def _normalise(out, node_length):
     return got
 
 
-@pytest.mark.parametrize("token", ["0", "1", "2"])
+@pytest.mark.parametrize("token", ["0", "1", "2", "two"])
 def test_batches_in_flight_equal_serial_and_oracle(gca, tmp_path, monkeypatch, token):
     """The mode bench.py times: several gc_align_batch calls in flight on ONE device, each on its own gc_stream and host thread
     (run_queue with workers > 1, the reference's -t workers over one queue, src/Aligner.cpp:1267-1270), whole-read pass on, with the
-    three settings of the per-device whole-read token (none / per pass / per round). Four different read sets go through three
+    three settings of the per-device whole-read token (none / per pass / per round; r4 "two": two tokens, each with a scratch of its own - GC_LONG_TOKENS=2). Four different read sets go through three
     Aligners concurrently, twice each; every result array must equal the oracle's AND the same Aligner's serial answer."""
     from graphchainer_amd.synth import SynthGraph
     from graphchainer_amd.workqueue import ReadQueue, run_queue
     from oracle import Oracle
-    monkeypatch.setenv("GC_LONG_TOKEN", token)
+    monkeypatch.setenv("GC_LONG_TOKEN", "1" if token == "two" else token)
+    if token == "two":
+        monkeypatch.setenv("GC_LONG_TOKENS", "2")
     sg = SynthGraph(300_000, seed=17, repeats=3, repeat_len=1500)
     gfa = str(tmp_path / "g.gfa")
     sg.write_gfa(gfa)

@@ -143,6 +143,17 @@ def test_stdsort_clone_equals_libstdcxx(tmp_path):
     assert out.returncode == 0 and "STDSORT_OK" in out.stdout, out.stdout + out.stderr
 
 
+def test_hash_order_replays_the_libstdcxx_containers(tmp_path):
+    """gc::HashOrder (csrc/host/gc_hashorder.hpp) gives the iteration order of a libstdc++ unordered container from the sequence of its keys' hash values: the split-node numbering,
+    the edge order and the minimizer index's node order all follow such an order (src/BigraphToDigraph.cpp:229,251, src/MinimizerSeeder.cpp:354-357). tests/hashorder/hashorder_test.cpp
+    compares it with the real std::unordered_map for the three key types, 0 to 2 M keys (ascending, shuffled, strided, clustered, negative, the 2 id / 2 id + 1 pairs), and with erased keys."""
+    exe = tmp_path / "hashorder_test"
+    host = os.path.join(ROOT, "graphchainer_amd", "csrc", "host")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-I" + host, os.path.join(ROOT, "tests", "hashorder", "hashorder_test.cpp"), "-o", str(exe)], check=True, timeout=600)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
+
+
 def test_encoder_letter_cursor_equals_the_graph_lookups(tmp_path):
     """The output encoders read the graph letter under every trace cell through gc::GraphLetters (csrc/host/gc_output.hpp), a cursor that remembers the last cell's split
     node; tests/output_host/letters_test.cpp compares it with GetUnitigNode + NodeSequences (what the reference does per cell, src/GraphAlignerCommon.h:148-153) on every
