@@ -1290,8 +1290,7 @@ int gc_graph_create_from_gfa(const char* gfa_path, gc_graph** out)
 	gc_graph* G = new gc_graph();
 	try {
 		requireDevice();
-		gc::GfaGraph gfa = gc::GfaGraph::LoadFromFile(gfa_path);
-		G->host = gc::AlignmentGraph::BuildFromGFA(gfa);
+		G->host = gc::AlignmentGraph::BuildFromGFAFile(gfa_path);
 		G->host.buildMPC(true);
 		uploadGraph(G);
 	} catch (const DeviceError& e) {
@@ -1534,8 +1533,7 @@ int gc_index_build(const char* gfa_path, int32_t k, int32_t w, double keepFracti
 	if (!gfa_path || !cache_path) return fail(GC_ERR_INVALID, "null argument");
 	if (k > 0 && !seederShapeOk(k, w)) return fail(GC_ERR_INVALID, "supported minimizer length is 1..31 with w >= k");
 	try {
-		gc::GfaGraph gfa = gc::GfaGraph::LoadFromFile(gfa_path);
-		gc::AlignmentGraph graph = gc::AlignmentGraph::BuildFromGFA(gfa);
+		gc::AlignmentGraph graph = gc::AlignmentGraph::BuildFromGFAFile(gfa_path);
 		graph.buildMPC(true);
 		if (k > 0) {
 			gc::MinimizerIndex idx = gc::MinimizerIndex::Build(graph, (size_t)k, (size_t)w, keepFraction);

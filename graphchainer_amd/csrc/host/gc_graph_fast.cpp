@@ -1,0 +1,521 @@
+// AlignmentGraph::BuildFromGFAFile - the first build of a graph from its GFA file, flat and threaded (r4; VERDICT r3 "accelerated first build").
+//
+// Same result as GfaGraph::LoadFromFile + AlignmentGraph::BuildFromGFA (gc_graph.cpp: the literal restatement of src/GfaGraph.cpp:212-370 and
+// src/BigraphToDigraph.cpp:215-267 on the reference's own container types), array for array - tests/test_graph_build.py compares the two on the golden
+// graphs, synthetic genomes and a set of awkward files. What differs is how the three hash-ordered iterations are obtained: the literal builder fills
+// std::unordered_map<int, std::string> (segments), std::unordered_map<NodePos, std::vector<NodePos>> (links) and std::unordered_map<int, std::vector<size_t>>
+// (nodeLookup) with one heap node per key - 0.45 s per million segments for the parse, 0.9 s for the split nodes, serial - and iterates them; this one keeps
+// the segments and links in flat arrays over the file's bytes and asks gc::HashOrder (gc_hashorder.hpp) for the order the containers would iterate in.
+// Stages: (1) the file into memory, line starts and fields by all threads; (2) segment names to numbers in order of first appearance (serial: one pass over
+// the name tokens; canonical decimal names through a direct table, others through an open-addressing table over the file's bytes); (3) the three orders;
+// (4) split nodes - lengths, offsets, ids, 2-bit / one-hot sequences of both strands - by all threads into their final positions; (5) the links' edges
+// in the order AddEdgeNodeId would be called, adjacency lists filled by node range on all threads; (6) Finalize() as before.
+#include "gc_graph.hpp"
+#include "gc_hashorder.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace gc {
+
+namespace {
+
+struct Clock {
+	std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+	const bool on = getenv("GC_DEBUG_TIMES") != nullptr;
+	void lap(const char* what)
+	{
+		auto now = std::chrono::steady_clock::now();
+		if (on) fprintf(stderr, "[gc build] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+		t = now;
+	}
+};
+
+// body(begin, end, worker) over [0, n) in contiguous shares, one per thread; the first exception is rethrown
+void parallelRanges(size_t n, size_t threads, const std::function<void(size_t, size_t, size_t)>& body)
+{
+	threads = std::max<size_t>(1, std::min(threads, n ? n : 1));
+	if (threads == 1) { body(0, n, 0); return; }
+	std::vector<std::thread> pool;
+	std::vector<std::exception_ptr> errors(threads);
+	for (size_t t = 0; t < threads; t++)
+		pool.emplace_back([&, t]() {
+			try { body(n * t / threads, n * (t + 1) / threads, t); } catch (...) { errors[t] = std::current_exception(); }
+		});
+	for (auto& th : pool) th.join();
+	for (auto& e : errors) if (e) std::rethrow_exception(e);
+}
+
+inline bool isBlank(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+
+struct Token { uint64_t off; uint32_t len; };
+
+// One line of the file as LoadFromStream reads it (src/GfaGraph.cpp:212-327): kind and fields; errors are kept per line and raised by the serial pass, in file order
+enum LineKind : uint8_t { LINE_OTHER = 0, LINE_S = 1, LINE_L = 2 };
+enum LineError : uint8_t { ERR_NONE = 0, ERR_STAR = 1, ERR_EMPTY_SEQ = 2, ERR_ORIENTATION = 3, ERR_NEGATIVE_OVERLAP = 4 };
+struct LineRec {
+	uint64_t nameOff, name2Off, seqOff;
+	uint32_t nameLen, name2Len, seqLen;
+	uint8_t kind, error, fromPlus, toPlus, overlapNonZero;
+};
+
+inline Token nextField(const char* buf, uint64_t& at, uint64_t end)
+{
+	while (at < end && isBlank(buf[at])) at++;
+	const uint64_t begin = at;
+	while (at < end && !isBlank(buf[at])) at++;
+	return Token { begin, (uint32_t)std::min<uint64_t>(at - begin, 0xffffffffu) };
+}
+
+LineRec parseLine(const char* buf, uint64_t begin, uint64_t end)
+{
+	LineRec r {};
+	if (begin == end) return r;
+	uint64_t at = begin;
+	if (buf[begin] == 'S') {
+		r.kind = LINE_S;
+		nextField(buf, at, end);
+		const Token name = nextField(buf, at, end), seq = nextField(buf, at, end);
+		r.nameOff = name.off; r.nameLen = name.len; r.seqOff = seq.off; r.seqLen = seq.len;
+		if (seq.len == 1 && buf[seq.off] == '*') r.error = ERR_STAR;
+		else if (seq.len == 0) r.error = ERR_EMPTY_SEQ;
+	} else if (buf[begin] == 'L') {
+		r.kind = LINE_L;
+		nextField(buf, at, end);
+		const Token from = nextField(buf, at, end), fromOri = nextField(buf, at, end), to = nextField(buf, at, end), toOri = nextField(buf, at, end), cigar = nextField(buf, at, end);
+		r.nameOff = from.off; r.nameLen = from.len; r.name2Off = to.off; r.name2Len = to.len;
+		// "<int><unit>" as `ss >> overlap >> unit` reads it (a missing or malformed number leaves 0)
+		long long value = 0;
+		bool negative = false, digits = false;
+		{
+			uint64_t c = cigar.off;
+			const uint64_t cEnd = cigar.off + cigar.len;
+			if (c < cEnd && (buf[c] == '-' || buf[c] == '+')) { negative = buf[c] == '-'; c++; }
+			while (c < cEnd && buf[c] >= '0' && buf[c] <= '9') { value = value * 10 + (buf[c] - '0'); if (value > 2000000000ll) value = 2000000000ll; c++; digits = true; }
+		}
+		const long long overlap = digits ? (negative ? -value : value) : 0;
+		const bool fromOk = fromOri.len == 1 && (buf[fromOri.off] == '+' || buf[fromOri.off] == '-'), toOk = toOri.len == 1 && (buf[toOri.off] == '+' || buf[toOri.off] == '-');
+		if (!fromOk || !toOk) r.error = ERR_ORIENTATION;
+		else if (overlap < 0) r.error = ERR_NEGATIVE_OVERLAP;
+		r.fromPlus = fromOk && buf[fromOri.off] == '+';
+		r.toPlus = toOk && buf[toOri.off] == '+';
+		r.overlapNonZero = overlap != 0;
+	}
+	return r;
+}
+
+// Segment names -> numbers in order of first appearance (getNameId, src/GfaGraph.cpp:146-156)
+class NameTable {
+public:
+	NameTable(const char* buf, size_t expectedNames, uint64_t maxCanonicalNumber, size_t tokens) : buf(buf)
+	{
+		// canonical decimal names (no sign, no leading zero, below 2^31) index a direct table when the largest is not far beyond the number of tokens
+		if (maxCanonicalNumber != ~0ull && maxCanonicalNumber <= 4ull * tokens + (1u << 20)) direct.assign(maxCanonicalNumber + 1, -1);
+		size_t cap = 64;
+		while (cap < 2 * expectedNames + 16) cap <<= 1;
+		slots.assign(cap, Slot { 0, 0, -1 });
+		mask = cap - 1;
+	}
+	static bool canonicalNumber(const char* s, uint32_t len, uint64_t& value)
+	{
+		if (len == 0 || len > 10 || (len > 1 && s[0] == '0')) return false;
+		uint64_t v = 0;
+		for (uint32_t i = 0; i < len; i++) { if (s[i] < '0' || s[i] > '9') return false; v = v * 10 + (uint64_t)(s[i] - '0'); }
+		if (v > 0x7fffffffull) return false;
+		value = v;
+		return true;
+	}
+	int idOf(uint64_t off, uint32_t len)
+	{
+		uint64_t number;
+		if (!direct.empty() && canonicalNumber(buf + off, len, number) && number < direct.size()) {
+			int& id = direct[number];
+			if (id < 0) { id = (int)firstToken.size(); firstToken.push_back(Token { off, len }); }
+			return id;
+		}
+		uint64_t h = 1469598103934665603ull;
+		for (uint32_t i = 0; i < len; i++) { h ^= (uint8_t)buf[off + i]; h *= 1099511628211ull; }
+		h ^= h >> 29;
+		for (size_t s = (size_t)h & mask;; s = (s + 1) & mask) {
+			Slot& slot = slots[s];
+			if (slot.id < 0) {
+				if (used * 2 >= slots.size()) { grow(); return idOf(off, len); }
+				slot = Slot { off, len, (int)firstToken.size() };
+				used++;
+				firstToken.push_back(Token { off, len });
+				return slot.id;
+			}
+			if (slot.len == len && memcmp(buf + slot.off, buf + off, len) == 0) return slot.id;
+		}
+	}
+	std::vector<Token> firstToken;   // per id: where its name stands in the file
+
+private:
+	struct Slot { uint64_t off; uint32_t len; int id; };
+	void grow()
+	{
+		std::vector<Slot> old;
+		old.swap(slots);
+		slots.assign(old.size() * 2, Slot { 0, 0, -1 });
+		mask = slots.size() - 1;
+		for (const Slot& e : old) {
+			if (e.id < 0) continue;
+			uint64_t h = 1469598103934665603ull;
+			for (uint32_t i = 0; i < e.len; i++) { h ^= (uint8_t)buf[e.off + i]; h *= 1099511628211ull; }
+			h ^= h >> 29;
+			size_t s = (size_t)h & mask;
+			while (slots[s].id >= 0) s = (s + 1) & mask;
+			slots[s] = e;
+		}
+	}
+	const char* buf;
+	std::vector<int> direct;
+	std::vector<Slot> slots;
+	size_t mask = 0, used = 0;
+};
+
+inline bool allowedNucleotide(char c)   // src/BigraphToDigraph.cpp:9-47
+{
+	switch (c) {
+		case 'a': case 'A': case 'c': case 'C': case 'g': case 'G': case 't': case 'T': case 'u': case 'U':
+		case 'y': case 'Y': case 'r': case 'R': case 'w': case 'W': case 's': case 'S': case 'k': case 'K':
+		case 'm': case 'M': case 'd': case 'D': case 'v': case 'V': case 'h': case 'H': case 'b': case 'B':
+		case 'n': case 'N': return true;
+	}
+	return false;
+}
+
+// one-hot base set of a letter (bit 0 A, 1 C, 2 G, 3 T) as AddSplitNode's switch has it (src/AlignmentGraph.cpp:110-195); 0: not a nucleotide
+inline uint32_t baseSet(char c)
+{
+	switch (c) {
+		case 'a': case 'A': return 1;
+		case 'c': case 'C': return 2;
+		case 'g': case 'G': return 4;
+		case 't': case 'T': case 'u': case 'U': return 8;
+		case 'r': case 'R': return 1 | 4;
+		case 'y': case 'Y': return 2 | 8;
+		case 's': case 'S': return 4 | 2;
+		case 'w': case 'W': return 1 | 8;
+		case 'k': case 'K': return 4 | 8;
+		case 'm': case 'M': return 1 | 2;
+		case 'b': case 'B': return 2 | 4 | 8;
+		case 'd': case 'D': return 1 | 4 | 8;
+		case 'h': case 'H': return 1 | 2 | 8;
+		case 'v': case 'V': return 1 | 2 | 4;
+		case 'n': case 'N': return 15;
+	}
+	return 0;
+}
+// (the complement's set: A <-> T, C <-> G - what Complement() followed by the switch gives)
+inline uint32_t complementSet(uint32_t s) { return ((s & 1) << 3) | ((s & 2) << 1) | ((s & 4) >> 1) | ((s & 8) >> 3); }
+
+} // namespace
+
+AlignmentGraph AlignmentGraph::BuildFromGFAFile(const std::string& path)
+{
+	if (const char* env = getenv("GC_BUILD_REFERENCE_CONTAINERS")) if (atoi(env) == 1) { GfaGraph gfa = GfaGraph::LoadFromFile(path); return BuildFromGFA(gfa); }
+	Clock clock;
+	const size_t threads = buildThreads();
+	// ---- (1) the file, its lines, their fields
+	std::vector<char> file;
+	{
+		FILE* f = fopen(path.c_str(), "rb");
+		if (!f) throw std::runtime_error("cannot open GFA file " + path);
+		if (fseek(f, 0, SEEK_END) != 0) { fclose(f); throw std::runtime_error("cannot read GFA file " + path); }
+		const long size = ftell(f);
+		if (size < 0) { fclose(f); throw std::runtime_error("cannot read GFA file " + path); }
+		rewind(f);
+		file.resize((size_t)size);
+		size_t got = 0;
+		while (got < file.size()) { const size_t n = fread(file.data() + got, 1, file.size() - got, f); if (n == 0) break; got += n; }
+		fclose(f);
+		if (got != file.size()) throw std::runtime_error("cannot read GFA file " + path);
+	}
+	const char* buf = file.data();
+	const uint64_t fileSize = file.size();
+	clock.lap("GFA read");
+	// a line ends at its '\n'; like the reference's getline loop (src/GfaGraph.cpp:219-223) a last line without one is dropped
+	std::vector<uint64_t> lineEnd;
+	{
+		std::vector<std::vector<uint64_t>> parts(threads);
+		parallelRanges(fileSize, threads, [&](size_t b, size_t e, size_t t) {
+			std::vector<uint64_t>& out = parts[t];
+			const char* p = buf + b;
+			const char* const last = buf + e;
+			while (p < last) { p = (const char*)memchr(p, '\n', (size_t)(last - p)); if (!p) break; out.push_back((uint64_t)(p - buf)); p++; }
+		});
+		size_t total = 0;
+		for (auto& p : parts) total += p.size();
+		lineEnd.reserve(total);
+		for (auto& p : parts) lineEnd.insert(lineEnd.end(), p.begin(), p.end());
+	}
+	const size_t nLines = lineEnd.size();
+	std::vector<LineRec> lines(nLines);
+	std::vector<uint64_t> maxNumberOf(threads, 0);
+	std::vector<uint8_t> numbersOnly(threads, 1);
+	std::vector<size_t> sLinesOf(threads, 0), lLinesOf(threads, 0);
+	parallelRanges(nLines, threads, [&](size_t b, size_t e, size_t t) {
+		for (size_t i = b; i < e; i++) {
+			const uint64_t begin = i == 0 ? 0 : lineEnd[i - 1] + 1;
+			lines[i] = parseLine(buf, begin, lineEnd[i]);
+			const LineRec& r = lines[i];
+			if (r.kind == LINE_OTHER) continue;
+			(r.kind == LINE_S ? sLinesOf : lLinesOf)[t]++;
+			uint64_t v;
+			if (NameTable::canonicalNumber(buf + r.nameOff, r.nameLen, v)) maxNumberOf[t] = std::max(maxNumberOf[t], v); else numbersOnly[t] = 0;
+			if (r.kind == LINE_L) { if (NameTable::canonicalNumber(buf + r.name2Off, r.name2Len, v)) maxNumberOf[t] = std::max(maxNumberOf[t], v); else numbersOnly[t] = 0; }
+		}
+	});
+	size_t sLines = 0, lLines = 0;
+	uint64_t maxNumber = 0;
+	for (size_t t = 0; t < threads; t++) { sLines += sLinesOf[t]; lLines += lLinesOf[t]; maxNumber = std::max(maxNumber, maxNumberOf[t]); }
+	clock.lap("GFA lines and fields");
+
+	// ---- (2) names -> ids in order of first appearance; segments; link sources in the order their keys enter the reference's `edges`
+	const bool allNumbers = std::all_of(numbersOnly.begin(), numbersOnly.end(), [](uint8_t v) { return v != 0; });
+	NameTable names(buf, allNumbers ? 16 : sLines + 16, maxNumber, sLines + 1);   // (the direct table is worth its memory while the largest number is within a few times the number of segments)
+	std::vector<uint64_t> seqOff; std::vector<uint32_t> seqLen;      // per id: the segment's letters (its last S line's), 0 length: no S line
+	std::vector<uint8_t> hasSegment;
+	std::vector<int> segmentArrival;                                   // ids in the order their first S line comes: the insertion sequence of `nodes`
+	struct Link { int from, to; uint8_t fromPlus, toPlus; };
+	std::vector<Link> links;
+	links.reserve(lLines);
+	bool nonZeroOverlap = false;
+	auto ensure = [&](int id) { if ((size_t)id >= hasSegment.size()) { hasSegment.resize((size_t)id + 1, 0); seqOff.resize((size_t)id + 1, 0); seqLen.resize((size_t)id + 1, 0); } };
+	for (size_t i = 0; i < nLines; i++) {
+		const LineRec& r = lines[i];
+		if (r.kind == LINE_S) {
+			const int id = names.idOf(r.nameOff, r.nameLen);
+			if (r.error == ERR_STAR) throw std::runtime_error("Nodes without sequence (*) are not currently supported (nodeid " + std::string(buf + r.nameOff, r.nameLen) + ")");
+			if (r.error == ERR_EMPTY_SEQ) throw std::runtime_error("empty S line for node " + std::string(buf + r.nameOff, r.nameLen));
+			ensure(id);
+			if (!hasSegment[(size_t)id]) { hasSegment[(size_t)id] = 1; segmentArrival.push_back(id); }
+			seqOff[(size_t)id] = r.seqOff; seqLen[(size_t)id] = r.seqLen;
+		} else if (r.kind == LINE_L) {
+			const int from = names.idOf(r.nameOff, r.nameLen);
+			const int to = names.idOf(r.name2Off, r.name2Len);
+			if (r.error == ERR_ORIENTATION) { const uint64_t begin = i == 0 ? 0 : lineEnd[i - 1] + 1; throw std::runtime_error("bad L line orientation: " + std::string(buf + begin, lineEnd[i] - begin)); }
+			if (r.error == ERR_NEGATIVE_OVERLAP) throw std::runtime_error("Edge overlap cannot be negative. Fix the graph");
+			links.push_back(Link { from, to, r.fromPlus, r.toPlus });
+			nonZeroOverlap = nonZeroOverlap || r.overlapNonZero;
+		}
+	}
+	std::vector<LineRec>().swap(lines);
+	std::vector<uint64_t>().swap(lineEnd);
+	const size_t nIds = names.firstToken.size();
+	ensure(nIds ? (int)nIds - 1 : 0);
+	clock.lap("segment names");
+	if (nonZeroOverlap) throw std::runtime_error("edge overlaps other than 0M are outside this build's scope (variation-graph DAGs only)");
+
+	// ---- (3) the order `for (node : gfa.nodes)` visits the segments in (src/BigraphToDigraph.cpp:229), the first invalid letter in that order
+	std::vector<int> segmentOrder;
+	{
+		HashOrder nodesMap;
+		for (int id : segmentArrival) nodesMap.insert(std::hash<int>()(id));
+		segmentOrder.reserve(segmentArrival.size());
+		for (uint32_t e : nodesMap.order()) segmentOrder.push_back(segmentArrival[e]);
+	}
+	const size_t nSegments = segmentOrder.size();
+	{
+		std::vector<size_t> firstBad(threads, nSegments);
+		parallelRanges(nSegments, threads, [&](size_t b, size_t e, size_t t) {
+			for (size_t k = b; k < e && firstBad[t] == nSegments; k++) {
+				const char* s = buf + seqOff[(size_t)segmentOrder[k]];
+				for (uint32_t i = 0, n = seqLen[(size_t)segmentOrder[k]]; i < n; i++) if (!allowedNucleotide(s[i])) { firstBad[t] = k; break; }
+			}
+		});
+		const size_t bad = *std::min_element(firstBad.begin(), firstBad.end());
+		if (bad < nSegments) {
+			const char* s = buf + seqOff[(size_t)segmentOrder[bad]];
+			for (uint32_t i = 0;; i++) if (!allowedNucleotide(s[i])) throw std::runtime_error(std::string("Invalid sequence character: ") + s[i]);
+		}
+	}
+	// split-node numbers: forward strand of a segment (bigraph node 2 id), then its reverse strand (2 id + 1), in that order (AddNode twice per segment)
+	AlignmentGraph g;
+	std::vector<uint64_t> firstSplit(2 * nIds + 1, 0);   // per bigraph node id: its first split node (creation order); pieces follow consecutively
+	std::vector<uint64_t> orderFirst(nSegments + 1, 0);  // per position in segmentOrder
+	for (size_t k = 0; k < nSegments; k++) orderFirst[k + 1] = orderFirst[k] + 2ull * ((seqLen[(size_t)segmentOrder[k]] + SPLIT_NODE_SIZE - 1) / SPLIT_NODE_SIZE);
+	const size_t n = orderFirst[nSegments];
+	g.nodeLookupOrder.reserve(2 * nSegments);
+	{
+		HashOrder lookupMap;
+		for (size_t k = 0; k < nSegments; k++) { lookupMap.insert(std::hash<int>()(2 * segmentOrder[k])); lookupMap.insert(std::hash<int>()(2 * segmentOrder[k] + 1)); }
+		for (uint32_t e : lookupMap.order()) g.nodeLookupOrder.push_back(2 * segmentOrder[e >> 1] + (int)(e & 1u));
+	}
+	clock.lap("container orders");
+
+	// ---- (4) the split nodes, by all threads, into their final places
+	g.nodeLength.assign(n, 0); g.nodeOffset.assign(n, 0); g.nodeIDs.assign(n, 0);
+	g.inNeighbors.assign(n, {}); g.outNeighbors.assign(n, {});
+	std::vector<uint8_t> isReverse(n, 0), isAmbiguous(n, 0);
+	g.nodeLookup.assignDense(2 * nIds, n);
+	g.originalNodeSize.assignDense(2 * nIds);
+	g.originalNodeName.assignDense(2 * nIds);
+	{
+		// (ids without an S line have no entry: the dense tables mark them absent below)
+		std::vector<NodeLookup::Range>& ranges = g.nodeLookup.denseRanges();
+		std::vector<size_t>& pool = g.nodeLookup.nodes();
+		std::vector<size_t>& sizes = g.originalNodeSize.denseValues();
+		std::vector<std::string>& nodeNames = g.originalNodeName.denseValues();
+		parallelRanges(nSegments, threads, [&](size_t b, size_t e, size_t) {
+			for (size_t k = b; k < e; k++) {
+				const int id = segmentOrder[k];
+				const uint32_t len = seqLen[(size_t)id];
+				const uint64_t pieces = (len + SPLIT_NODE_SIZE - 1) / SPLIT_NODE_SIZE;
+				const char* s = buf + seqOff[(size_t)id];
+				const Token nameTok = names.firstToken[(size_t)id];
+				for (int strand = 0; strand < 2; strand++) {
+					const int nodeId = 2 * id + strand;
+					const uint64_t first = orderFirst[k] + (uint64_t)strand * pieces;
+					firstSplit[(size_t)nodeId] = first;
+					ranges[(size_t)nodeId] = NodeLookup::Range { first, (uint32_t)pieces };
+					sizes[(size_t)nodeId] = len;
+					nodeNames[(size_t)nodeId].assign(buf + nameTok.off, nameTok.len);
+					for (uint64_t p = 0; p < pieces; p++) {
+						const uint64_t idx = first + p;
+						const uint32_t offset = (uint32_t)(p * SPLIT_NODE_SIZE), size = std::min<uint32_t>((uint32_t)SPLIT_NODE_SIZE, len - offset);
+						pool[idx] = idx;
+						g.nodeLength[idx] = size; g.nodeOffset[idx] = offset; g.nodeIDs[idx] = nodeId;
+						isReverse[idx] = (uint8_t)strand;
+						bool ambiguous = false;
+						for (uint32_t i = 0; i < size && !ambiguous; i++) {
+							const char c = strand == 0 ? s[offset + i] : s[len - 1 - (offset + i)];
+							const uint32_t set = baseSet(c);
+							ambiguous = (set & (set - 1)) != 0;
+						}
+						isAmbiguous[idx] = ambiguous;
+						if (p > 0) { g.outNeighbors[idx - 1].push_back(idx); g.inNeighbors[idx].push_back(idx - 1); }
+					}
+				}
+			}
+		});
+	}
+	// sequences: plain nodes and ambiguous nodes each in creation order (nodeSequences / ambiguousNodeSequences are appended to as the nodes are made)
+	{
+		const size_t chunks = std::max<size_t>(1, threads);
+		std::vector<size_t> ambBefore(chunks + 1, 0);
+		parallelRanges(n, chunks, [&](size_t b, size_t e, size_t t) { size_t c = 0; for (size_t i = b; i < e; i++) c += isAmbiguous[i]; ambBefore[t + 1] = c; });
+		for (size_t t = 0; t < chunks; t++) ambBefore[t + 1] += ambBefore[t];
+		const size_t nAmbiguous = ambBefore[chunks];
+		g.nodeSequences.assign(n - nAmbiguous, { 0, 0 });
+		g.ambiguousNodeSequences.assign(nAmbiguous, AmbiguousSeq { 0, 0, 0, 0 });
+		parallelRanges(n, chunks, [&](size_t b, size_t e, size_t t) {
+			size_t amb = ambBefore[t];
+			for (size_t idx = b; idx < e; idx++) {
+				const int nodeId = g.nodeIDs[idx];
+				const int id = nodeId >> 1;
+				const bool strand = (nodeId & 1) != 0;
+				const char* s = buf + seqOff[(size_t)id];
+				const uint32_t len = seqLen[(size_t)id], offset = (uint32_t)g.nodeOffset[idx], size = (uint32_t)g.nodeLength[idx];
+				if (!isAmbiguous[idx]) {
+					std::array<uint64_t, 2> packed { 0, 0 };
+					for (uint32_t i = 0; i < size; i++) {
+						uint32_t set = baseSet(strand ? s[len - 1 - (offset + i)] : s[offset + i]);
+						if (strand) set = complementSet(set);
+						const uint64_t code = set == 1 ? 0 : set == 2 ? 1 : set == 4 ? 2 : 3;
+						packed[i / BP_IN_CHUNK] |= code << ((i % BP_IN_CHUNK) * 2);
+					}
+					g.nodeSequences[idx - amb] = packed;
+				} else {
+					AmbiguousSeq a { 0, 0, 0, 0 };
+					for (uint32_t i = 0; i < size; i++) {
+						uint32_t set = baseSet(strand ? s[len - 1 - (offset + i)] : s[offset + i]);
+						if (strand) set = complementSet(set);
+						const uint64_t bit = (uint64_t)1 << i;
+						if (set & 1) a.A |= bit;
+						if (set & 2) a.C |= bit;
+						if (set & 4) a.G |= bit;
+						if (set & 8) a.T |= bit;
+					}
+					g.ambiguousNodeSequences[amb++] = a;
+				}
+			}
+		});
+		g.reverse.assign(n, false); g.ambiguousNodes.assign(n, false);
+		for (size_t i = 0; i < n; i++) { if (isReverse[i]) g.reverse[i] = true; if (isAmbiguous[i]) g.ambiguousNodes[i] = true; }
+	}
+	for (size_t k = 0; k < nSegments; k++) g.bpSize += 2ull * seqLen[(size_t)segmentOrder[k]];
+	// ids that only links mention have no tables' entry (the reference never calls AddNode for them)
+	if (nSegments != nIds) {
+		NodeLookup lookup; DenseIdMap<size_t> sizes; DenseIdMap<std::string> nodeNames;
+		lookup.denseUpTo(2 * nIds); sizes.denseUpTo(2 * nIds); nodeNames.denseUpTo(2 * nIds);
+		for (size_t id = 0; id < nIds; id++) {
+			if (!hasSegment[id]) continue;
+			for (int strand = 0; strand < 2; strand++) {
+				const int nodeId = 2 * (int)id + strand;
+				const NodeLookup::Span sp = g.nodeLookup.at(nodeId);
+				lookup.add(nodeId, sp.begin(), sp.size());
+				sizes[nodeId] = g.originalNodeSize.at(nodeId);
+				nodeNames[nodeId] = g.originalNodeName.at(nodeId);
+			}
+		}
+		g.nodeLookup = std::move(lookup); g.originalNodeSize = std::move(sizes); g.originalNodeName = std::move(nodeNames);
+	}
+	clock.lap("split nodes");
+
+	// ---- (5) edges: `for (edge : gfa.edges) for (target : edge.second)` (src/BigraphToDigraph.cpp:251-257) as a flat call list, then the adjacency lists by node range
+	{
+		// link sources in the order their keys entered the map; a source without a segment is erased after parsing, targets without one are dropped (src/GfaGraph.cpp:329-368)
+		std::vector<int32_t> slotOf(2 * nIds, -1);
+		HashOrder edgesMap;
+		std::vector<uint32_t> perSlot;
+		std::vector<uint32_t> linkSlot(links.size());
+		for (size_t k = 0; k < links.size(); k++) {
+			const Link& l = links[k];
+			int32_t& slot = slotOf[2 * (size_t)l.from + l.fromPlus];
+			if (slot < 0) { slot = (int32_t)edgesMap.insert(NodePosHash()(NodePos { l.from, l.fromPlus != 0 })); perSlot.push_back(0); }
+			linkSlot[k] = (uint32_t)slot;
+			perSlot[(size_t)slot]++;
+		}
+		const size_t nSlots = perSlot.size();
+		std::vector<uint64_t> slotBegin(nSlots + 1, 0);
+		for (size_t s = 0; s < nSlots; s++) slotBegin[s + 1] = slotBegin[s] + perSlot[s];
+		std::vector<uint32_t> bySlot(links.size());
+		{
+			std::vector<uint64_t> at(slotBegin.begin(), slotBegin.end() - 1);
+			for (size_t k = 0; k < links.size(); k++) bySlot[at[linkSlot[k]]++] = (uint32_t)k;
+		}
+		// the calls AddEdgeNodeId(fromRight, toRight) and AddEdgeNodeId(toLeft, fromLeft) of every kept link, in order: (last split node of the first, first split node of the second)
+		std::vector<std::pair<uint64_t, uint64_t>> calls;
+		calls.reserve(2 * links.size());
+		auto lastSplit = [&](int nodeId) { const NodeLookup::Span sp = g.nodeLookup.at(nodeId); return (uint64_t)sp.back(); };
+		auto firstOf = [&](int nodeId) { return (uint64_t)firstSplit[(size_t)nodeId]; };
+		for (uint32_t slot : edgesMap.order()) {
+			for (uint64_t k = slotBegin[slot]; k < slotBegin[slot + 1]; k++) {
+				const Link& l = links[bySlot[k]];
+				if (!hasSegment[(size_t)l.from]) break;       // an orphan source: the whole key goes
+				if (!hasSegment[(size_t)l.to]) continue;
+				const int from = l.from, to = l.to;
+				int fromLeft, fromRight, toLeft, toRight;
+				if (!l.fromPlus) { fromLeft = from * 2; fromRight = from * 2 + 1; } else { fromLeft = from * 2 + 1; fromRight = from * 2; }
+				if (!l.toPlus) { toLeft = to * 2; toRight = to * 2 + 1; } else { toLeft = to * 2 + 1; toRight = to * 2; }
+				calls.emplace_back(lastSplit(fromRight), firstOf(toRight));
+				calls.emplace_back(lastSplit(toLeft), firstOf(fromLeft));
+			}
+		}
+		std::vector<Link>().swap(links);
+		// every thread walks the whole list and keeps the calls of its node range: out-lists by the first node, in-lists by the second (duplicates skipped, as AddEdgeNodeId does)
+		parallelRanges(n, threads, [&](size_t b, size_t e, size_t) {
+			for (const auto& c : calls) {
+				if (c.first >= b && c.first < e) { auto& out = g.outNeighbors[c.first]; if (std::find(out.begin(), out.end(), (size_t)c.second) == out.end()) out.push_back((size_t)c.second); }
+				if (c.second >= b && c.second < e) { auto& in = g.inNeighbors[c.second]; if (std::find(in.begin(), in.end(), (size_t)c.first) == in.end()) in.push_back((size_t)c.first); }
+			}
+		});
+	}
+	clock.lap("edges");
+	g.Finalize();
+	return g;
+}
+
+} // namespace gc
