@@ -284,6 +284,14 @@ def main():
 
     inflight = max(1, args.inflight)
     mem_free_start, mem_total = gca.device_memory()
+    # batches in flight that fit the device beside the graph and the index: a batch in flight holds ~450 bytes per read base (r3 / r4: 31 GB for 10 k x 10 kb, 42 GB for
+    # 2 k x 50 kb), the device's one whole-read scratch up to 48 GB
+    batch_bytes = 450 * min(args.batch, args.reads) * args.read_len
+    fit = int((mem_free_start - (56 << 30)) // max(1, batch_bytes))
+    memory_choice = None
+    if fit < inflight:
+        memory_choice = {"asked": inflight, "chosen": max(1, fit), "free_gb_after_graph_and_index": round(mem_free_start / 2**30, 1), "estimated_gb_per_batch_in_flight": round(batch_bytes / 2**30, 1)}
+        inflight = max(1, fit)
     aligners = [gca.Aligner(graph, seeder, split_gap=args.split_gap, colinear_gap=args.colinear_gap, long_pass=long_pass) for _ in range(inflight)]
     # the rank's reads as length-sorted batches (one batch for config 2), uploaded before the timed region; the upload itself
     # (2-bit packing, reverse complement, match-mask bit vectors, PCIe) is timed here and reported beside the step time
@@ -324,9 +332,23 @@ def main():
         # static hand-out, outside the (possibly cross-rank) queue: stream i of this rank runs warm-up items i, i + inflight, ... so that
         # every stream of every rank has done its first-batch allocations before the timed steps, whatever the dynamic queue would do
         from concurrent.futures import ThreadPoolExecutor
-        n_items = warmup_done * (1 if strong else len(batches))
-        with ThreadPoolExecutor(max_workers=inflight) as warm:
-            list(warm.map(lambda i: [aligners[i].align_batch(batches[(item + rank) % len(batches)]) and None for item in range(i, n_items, inflight)], range(inflight)))
+        while True:
+            n_items = max(args.warmup, inflight) * (1 if strong else len(batches))
+            try:
+                with ThreadPoolExecutor(max_workers=inflight) as warm:
+                    list(warm.map(lambda i: [aligners[i].align_batch(batches[(item + rank) % len(batches)]) and None for item in range(i, n_items, inflight)], range(inflight)))
+                break
+            except RuntimeError as e:
+                # the streams' first batches size their buffers: when they do not all fit the device beside the graph and the index, one batch fewer is kept in flight
+                # (config 5 on a 1 Gbp graph: 41 GB of graph and index, ~40 GB per 2 000 x 50 kb batch in flight, the 48 GB whole-read scratch)
+                if "out of memory" not in str(e) or inflight <= 1:
+                    raise
+                for a in aligners:
+                    a.close()
+                gca.load_library().gc_result_cache_trim()
+                memory_choice = {"asked": (memory_choice or {}).get("asked", inflight), "chosen": inflight - 1, "why": "the first batches of that many streams did not fit the device's memory"}
+                inflight -= 1
+                aligners[:] = [gca.Aligner(graph, seeder, split_gap=args.split_gap, colinear_gap=args.colinear_gap, long_pass=long_pass) for _ in range(inflight)]
     sync()
     cpu_start = cpu_seconds()
     rank_cpu_start = time.process_time()
@@ -633,6 +655,8 @@ def main():
             "device_memory_gb": {"total": round(mem_total / 2**30, 1), "graph_and_index": round((mem_total - mem_free_start) / 2**30, 1), "in_use_after_timed_steps": round((mem_total - mem_free_end) / 2**30, 1)},
             "setup_s": {"generate": round(t_gen, 1), "graph_build_upload": round(t_graph, 1), "minimizer_index": round(t_index, 1),
                         "index_cache_save": round(t_save, 1), "index_cache_load_upload": round(t_load, 1), "index_cache_bytes": cache_bytes},
+            "inflight_for_device_memory": memory_choice,
+            "host_peak_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 2**20, 1),   # (this process: the GFA in memory, the host graph and index, the batches)
             "reads_with_chain": int(reads_with_chain / steps), "extensions_per_step": int(counters[4]),
             "decision": {"chained_better": int(chained_better / steps), "mean_long_edit_distance": round(float(long_ed.mean()), 1) if len(long_ed) else None,
                          "mean_chain_edit_distance": round(float(chain_ed.mean()), 1) if len(chain_ed) else None},

@@ -2819,7 +2819,10 @@ struct BatchRun {
 			launchStitch(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, dChainOut, dChainLen, dChainStatus, dPathPool, pathCapacity, (long long)P->colinear_gap, dSlotOf,
 				dRegions, dStitchNodes, stitchDenseCap, dCursor, dStitchInfo,
 				(uint32_t)capacityOr("GC_STITCH_SET_MAX", P->capacity.stitch_set_max, 0), (uint32_t)capacityOr("GC_STITCH_BFS_CAP", P->capacity.stitch_bfs_cap, 0),
-				getenv("GC_STITCH_SMALL") && atoi(getenv("GC_STITCH_SMALL")) && maxReadLen <= 16384);   // (GC_STITCH_SMALL=1: the half-size search tables, measured in r4 and not kept - see gc_stitch.hip)
+				// (GC_STITCH_SMALL=1: the half-size search tables, measured in r4 and not kept - see gc_stitch.hip. GC_STITCH_LARGE=1: the large tables for reads beyond 16 kb - a 50 kb
+				// read's piece holds more split nodes than the default node set, so config 5's reads are all stitched by the host; with 107 KB of LDS one wave runs per CU and a batch's
+				// 2 000 reads take 1.1 s there against 1-2 s of 16 host threads that overlap the other batches' kernels: 2 541 reads/s against 2 676, measured, not kept)
+				(getenv("GC_STITCH_LARGE") && atoi(getenv("GC_STITCH_LARGE")) == 1 && maxReadLen > 16384) ? 2 : (getenv("GC_STITCH_SMALL") && atoi(getenv("GC_STITCH_SMALL")) && maxReadLen <= 16384 ? 1 : 0));
 			HIP_CHECK(hipMemcpyAsync(stitchInfo, dStitchInfo, n * sizeof(StitchInfo), hipMemcpyDeviceToHost, stream));
 			HIP_CHECK(hipMemcpyAsync(hStitchCursor, dCursor, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		}

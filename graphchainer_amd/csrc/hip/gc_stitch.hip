@@ -58,8 +58,10 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 	StitchInfo* __restrict__ info)
 {
 	constexpr uint32_t STITCH_BFS_TABLE = 2 * STITCH_BFS_CAP;
+	constexpr uint32_t INDEX_BITS = STITCH_BFS_CAP <= 1024 ? 11u : 13u, INDEX_MASK = (1u << INDEX_BITS) - 1u;   // a table entry: (generation << INDEX_BITS) | (queue index + 1)
+	static_assert(STITCH_BFS_CAP < (1u << INDEX_BITS), "queue index + 1 must fit its bits");
 	__shared__ uint32_t setKey[STITCH_SET_SIZE];
-	__shared__ uint32_t bfsTable[STITCH_BFS_TABLE];   // (generation << 11) | (queue index + 1)
+	__shared__ uint32_t bfsTable[STITCH_BFS_TABLE];   // (generation << INDEX_BITS) | (queue index + 1)
 	__shared__ uint32_t qNode[STITCH_BFS_CAP], qDis[STITCH_BFS_CAP];
 	__shared__ uint16_t qPre[STITCH_BFS_CAP];
 	uint32_t* const bridge = qDis;   // the path is written out when the search is over and the distances are no longer needed
@@ -142,12 +144,12 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 		// sequential one. Entries appended during a batch are expanded in a later batch, which is still queue order.
 		auto findBridge = [&](uint32_t S, uint32_t T, long long sepLimit, bool& tooWide) -> uint32_t {
 			generation++;
-			const uint32_t tag = generation << 11;
+			const uint32_t tag = generation << INDEX_BITS;
 			auto visit = [&](uint32_t node, uint32_t index) -> bool {   // true: seen before; otherwise recorded as queue entry `index`
 				for (uint32_t h = stitchHash(node, STITCH_BFS_TABLE - 1);; h = (h + 1) & (STITCH_BFS_TABLE - 1)) {
 					uint32_t e = bfsTable[h];
-					if ((e >> 11) != generation) { bfsTable[h] = tag | (index + 1); return false; }
-					if (qNode[(e & 2047u) - 1] == node) return true;
+					if ((e >> INDEX_BITS) != generation) { bfsTable[h] = tag | (index + 1); return false; }
+					if (qNode[(e & INDEX_MASK) - 1] == node) return true;
 				}
 			};
 			// Pruning that cannot change the result: componentNumber never decreases along an edge (it is the topological rank of
@@ -333,19 +335,23 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 	}
 }
 
+// sizeClass: 0 the default tables (2 048-slot node set, 1 024 visited nodes per bridge search), 1 the half-size search (measured in r4, not kept), 2 (r4) the tables of long reads -
+// 8 192 slots and 4 095 visited nodes, 107 KB of LDS, one wave per CU: a 50 kb read's piece holds ~2 500 split nodes and its failed searches walk as many
 void launchStitch(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
 	const uint32_t* chainOut, const uint32_t* chainLen, const uint32_t* chainStatus, const uint32_t* pathPool, uint64_t pathCapacity, long long colinearGap, uint32_t* slotOf,
-	uint32_t* regions, uint32_t* dense, uint64_t denseCap, unsigned long long* denseCursor, StitchInfo* info, uint32_t setMax, uint32_t bfsCap, bool smallTables)
+	uint32_t* regions, uint32_t* dense, uint64_t denseCap, unsigned long long* denseCursor, StitchInfo* info, uint32_t setMax, uint32_t bfsCap, int sizeClass)
 {
 	if (!nReads) return;
-	const uint32_t setSize = STITCH_SET_SIZE_LARGE, capBfs = smallTables ? STITCH_BFS_CAP_LARGE / 2 : STITCH_BFS_CAP_LARGE;
+	const uint32_t setSize = sizeClass == 2 ? 4 * STITCH_SET_SIZE_LARGE : STITCH_SET_SIZE_LARGE, capBfs = sizeClass == 2 ? 4 * STITCH_BFS_CAP_LARGE - 1 : sizeClass == 1 ? STITCH_BFS_CAP_LARGE / 2 : STITCH_BFS_CAP_LARGE;
 	setMax = setMax && setMax < setSize / 2 ? setMax : setSize / 2;
 	bfsCap = bfsCap && bfsCap < capBfs ? bfsCap : capBfs;
 	uint32_t blocks = nReads < 16384u ? nReads : 16384u;
-	if (smallTables) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stitch<STITCH_SET_SIZE_LARGE, STITCH_BFS_CAP_LARGE / 2>), dim3(blocks), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, chainOut, chainLen, chainStatus, pathPool, pathCapacity, colinearGap, setMax, bfsCap,
-		slotOf, regions, dense, denseCap, denseCursor, info);
-	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stitch<STITCH_SET_SIZE_LARGE, STITCH_BFS_CAP_LARGE>), dim3(blocks), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, chainOut, chainLen, chainStatus, pathPool, pathCapacity, colinearGap, setMax, bfsCap,
-		slotOf, regions, dense, denseCap, denseCursor, info);
+#define GC_LAUNCH_STITCH(SET, CAP) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stitch<SET, CAP>), dim3(blocks), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, chainOut, chainLen, chainStatus, pathPool, pathCapacity, colinearGap, setMax, bfsCap, \
+		slotOf, regions, dense, denseCap, denseCursor, info)
+	if (sizeClass == 2) GC_LAUNCH_STITCH(4 * STITCH_SET_SIZE_LARGE, 4 * STITCH_BFS_CAP_LARGE);
+	else if (sizeClass == 1) GC_LAUNCH_STITCH(STITCH_SET_SIZE_LARGE, STITCH_BFS_CAP_LARGE / 2);
+	else GC_LAUNCH_STITCH(STITCH_SET_SIZE_LARGE, STITCH_BFS_CAP_LARGE);
+#undef GC_LAUNCH_STITCH
 }
 
 uint64_t stitchRegionWords(uint64_t totalSlots, uint64_t nReads) { return 2 * totalSlots + 64 * nReads; }

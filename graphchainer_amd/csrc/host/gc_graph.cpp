@@ -789,24 +789,56 @@ void AlignmentGraph::buildMPC(bool shrinkToMinimum)   // reference: src/Alignmen
 // unsigned value (size_t > long long promotion, :1897), i.e. no limit - kept on purpose.
 std::vector<size_t> AlignmentGraph::getChainPath(size_t S, size_t T, long long sepLimit) const
 {
-	size_t n = NodeSize();
-	static thread_local std::vector<size_t> vis, dis, pre, queue;
-	static thread_local size_t flag = 1;
-	if (vis.size() < n) { vis.assign(n, 0); pre.assign(n, 0); dis.assign(n, 0); flag = 1; }
-	queue.clear();
-	queue.push_back(S);
-	vis[S] = ++flag;
-	dis[S] = 0;
-	for (size_t i = 0; vis[T] != flag && i < queue.size(); i++) {
-		size_t s = queue[i];
-		if (dis[s] > (size_t)sepLimit) continue;
-		for (size_t t : outNeighbors[s])
-			if (vis[t] != flag) { queue.push_back(t); vis[t] = flag; dis[t] = dis[s] + nodeLength[t]; pre[t] = s; }
-	}
+	// The reference marks visited nodes in arrays as long as the graph (src/AlignmentGraph.cpp:1866-1916). Here (r4) they live in a per-thread open-addressing table that
+	// grows with the search - three graph-sized arrays per host thread are 3.5 GB each on a 1 Gbp graph - and the search leaves out what cannot reach T: componentNumber
+	// never decreases along an edge (it is the topological rank of the node's strongly connected component, :1008), so a node ranked above T has no path to T, nor has
+	// anything first discovered through it. The queue order, distances and predecessors of all other nodes are unchanged (k_stitch prunes the same way).
+	struct Seen { size_t node, dis; uint32_t pre, generation; };   // pre: queue index of the node it was first reached from
+	static thread_local std::vector<Seen> table;
+	static thread_local std::vector<uint32_t> queueSlot;           // queue position -> table slot
+	static thread_local uint32_t generation = 0;
 	std::vector<size_t> out;
-	if (vis[T] != flag) return out;
-	for (size_t i = T; i != S; i = pre[i]) out.push_back(i);
-	out.push_back(S);
+	const size_t rankT = componentNumber.empty() ? SIZE_MAX : componentNumber[T];
+	if (!componentNumber.empty() && componentNumber[S] > rankT) return out;
+	if (table.empty()) table.assign(1024, Seen { 0, 0, 0, 0 });
+	if (++generation == 0) { for (Seen& e : table) e.generation = 0; generation = 1; }
+	queueSlot.clear();
+	size_t mask = table.size() - 1;
+	auto slotOf = [&](size_t node) -> size_t {   // the slot that holds `node`, or the empty slot where it goes
+		for (size_t h = (node * 0x9E3779B97F4A7C15ull >> 20) & mask;; h = (h + 1) & mask) if (table[h].generation != generation || table[h].node == node) return h;
+	};
+	auto grow = [&]() {
+		std::vector<Seen> old(table.size() * 2, Seen { 0, 0, 0, 0 });
+		old.swap(table);
+		mask = table.size() - 1;
+		for (uint32_t& q : queueSlot) { const Seen e = old[q]; const size_t h = slotOf(e.node); table[h] = e; q = (uint32_t)h; }
+	};
+	auto add = [&](size_t node, size_t dis, uint32_t pre) {
+		if (2 * (queueSlot.size() + 1) > table.size()) grow();
+		const size_t h = slotOf(node);
+		table[h] = Seen { node, dis, pre, generation };
+		queueSlot.push_back((uint32_t)h);
+	};
+	add(S, 0, 0);
+	bool found = S == T;
+	for (size_t i = 0; !found && i < queueSlot.size(); i++) {
+		const Seen s = table[queueSlot[i]];
+		if (s.dis > (size_t)sepLimit) continue;
+		for (size_t t : outNeighbors[s.node]) {
+			if (!componentNumber.empty() && componentNumber[t] > rankT) continue;
+			const size_t h = slotOf(t);
+			if (table[h].generation == generation) continue;   // seen before
+			add(t, s.dis + nodeLength[t], (uint32_t)i);
+			if (t == T) { found = true; break; }                // (the reference's loop ends once T has been discovered; what it still adds from this node's list changes nothing)
+		}
+	}
+	if (!found) return out;
+	for (size_t q = queueSlot.size() - 1;;) {   // T is the last entry
+		const Seen& e = table[queueSlot[q]];
+		out.push_back(e.node);
+		if (e.node == S) break;
+		q = e.pre;
+	}
 	std::reverse(out.begin(), out.end());
 	return out;
 }

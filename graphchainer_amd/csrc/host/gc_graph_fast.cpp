@@ -362,6 +362,7 @@ AlignmentGraph AlignmentGraph::BuildFromGFAFile(const std::string& path)
 	g.nodeLookup.assignDense(2 * nIds, n);
 	g.originalNodeSize.assignDense(2 * nIds);
 	g.originalNodeName.assignDense(2 * nIds);
+	clock.lap("  split: tables sized");
 	{
 		// (ids without an S line have no entry: the dense tables mark them absent below)
 		std::vector<NodeLookup::Range>& ranges = g.nodeLookup.denseRanges();
@@ -401,6 +402,7 @@ AlignmentGraph AlignmentGraph::BuildFromGFAFile(const std::string& path)
 			}
 		});
 	}
+	clock.lap("  split: node fields");
 	// sequences: plain nodes and ambiguous nodes each in creation order (nodeSequences / ambiguousNodeSequences are appended to as the nodes are made)
 	{
 		const size_t chunks = std::max<size_t>(1, threads);
@@ -442,6 +444,7 @@ AlignmentGraph AlignmentGraph::BuildFromGFAFile(const std::string& path)
 				}
 			}
 		});
+		clock.lap("  split: sequences");
 		g.reverse.assign(n, false); g.ambiguousNodes.assign(n, false);
 		for (size_t i = 0; i < n; i++) { if (isReverse[i]) g.reverse[i] = true; if (isAmbiguous[i]) g.ambiguousNodes[i] = true; }
 	}
@@ -486,24 +489,42 @@ AlignmentGraph AlignmentGraph::BuildFromGFAFile(const std::string& path)
 			std::vector<uint64_t> at(slotBegin.begin(), slotBegin.end() - 1);
 			for (size_t k = 0; k < links.size(); k++) bySlot[at[linkSlot[k]]++] = (uint32_t)k;
 		}
-		// the calls AddEdgeNodeId(fromRight, toRight) and AddEdgeNodeId(toLeft, fromLeft) of every kept link, in order: (last split node of the first, first split node of the second)
-		std::vector<std::pair<uint64_t, uint64_t>> calls;
-		calls.reserve(2 * links.size());
-		auto lastSplit = [&](int nodeId) { const NodeLookup::Span sp = g.nodeLookup.at(nodeId); return (uint64_t)sp.back(); };
-		auto firstOf = [&](int nodeId) { return (uint64_t)firstSplit[(size_t)nodeId]; };
-		for (uint32_t slot : edgesMap.order()) {
-			for (uint64_t k = slotBegin[slot]; k < slotBegin[slot + 1]; k++) {
-				const Link& l = links[bySlot[k]];
-				if (!hasSegment[(size_t)l.from]) break;       // an orphan source: the whole key goes
-				if (!hasSegment[(size_t)l.to]) continue;
-				const int from = l.from, to = l.to;
-				int fromLeft, fromRight, toLeft, toRight;
-				if (!l.fromPlus) { fromLeft = from * 2; fromRight = from * 2 + 1; } else { fromLeft = from * 2 + 1; fromRight = from * 2; }
-				if (!l.toPlus) { toLeft = to * 2; toRight = to * 2 + 1; } else { toLeft = to * 2 + 1; toRight = to * 2; }
-				calls.emplace_back(lastSplit(fromRight), firstOf(toRight));
-				calls.emplace_back(lastSplit(toLeft), firstOf(fromLeft));
+		// the calls AddEdgeNodeId(fromRight, toRight) and AddEdgeNodeId(toLeft, fromLeft) of every kept link, in order: (last split node of the first, first split node of the second).
+		// Per key in the map's order: how many of its links stay, then every key's calls written to their place by all threads
+		const std::vector<uint32_t> slotOrder = edgesMap.order();
+		std::vector<uint64_t> callBegin(nSlots + 1, 0);
+		parallelRanges(nSlots, threads, [&](size_t b, size_t e, size_t) {
+			for (size_t q = b; q < e; q++) {
+				const uint32_t slot = slotOrder[q];
+				uint64_t kept = 0;
+				for (uint64_t k = slotBegin[slot]; k < slotBegin[slot + 1]; k++) {
+					const Link& l = links[bySlot[k]];
+					if (!hasSegment[(size_t)l.from]) break;       // an orphan source: the whole key goes
+					if (hasSegment[(size_t)l.to]) kept++;
+				}
+				callBegin[q + 1] = 2 * kept;
 			}
-		}
+		});
+		for (size_t q = 0; q < nSlots; q++) callBegin[q + 1] += callBegin[q];
+		std::vector<std::pair<uint64_t, uint64_t>> calls(callBegin[nSlots]);
+		auto firstOf = [&](int nodeId) { return (uint64_t)firstSplit[(size_t)nodeId]; };
+		auto lastSplit = [&](int nodeId) { return (uint64_t)firstSplit[(size_t)nodeId] + (seqLen[(size_t)(nodeId >> 1)] + SPLIT_NODE_SIZE - 1) / SPLIT_NODE_SIZE - 1; };
+		parallelRanges(nSlots, threads, [&](size_t b, size_t e, size_t) {
+			for (size_t q = b; q < e; q++) {
+				const uint32_t slot = slotOrder[q];
+				uint64_t at = callBegin[q];
+				for (uint64_t k = slotBegin[slot]; k < slotBegin[slot + 1] && at < callBegin[q + 1]; k++) {
+					const Link& l = links[bySlot[k]];
+					if (!hasSegment[(size_t)l.to]) continue;
+					const int from = l.from, to = l.to;
+					int fromLeft, fromRight, toLeft, toRight;
+					if (!l.fromPlus) { fromLeft = from * 2; fromRight = from * 2 + 1; } else { fromLeft = from * 2 + 1; fromRight = from * 2; }
+					if (!l.toPlus) { toLeft = to * 2; toRight = to * 2 + 1; } else { toLeft = to * 2 + 1; toRight = to * 2; }
+					calls[at++] = { lastSplit(fromRight), firstOf(toRight) };
+					calls[at++] = { lastSplit(toLeft), firstOf(fromLeft) };
+				}
+			}
+		});
 		std::vector<Link>().swap(links);
 		// every thread walks the whole list and keeps the calls of its node range: out-lists by the first node, in-lists by the second (duplicates skipped, as AddEdgeNodeId does)
 		parallelRanges(n, threads, [&](size_t b, size_t e, size_t) {
