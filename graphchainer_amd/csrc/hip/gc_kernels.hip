@@ -490,7 +490,14 @@ struct ChainArrays {   // one read's working set: LDS (template LDS) or this blo
 	uint32_t* aStart; unsigned long long* C;
 	uint16_t* aFrag; uint16_t* aComp; uint16_t* entBegin; uint32_t* backBegin;
 	ChainEntry* ent; uint2* back; int32_t* thr;   // back: the anchors' threshold lists (path, position), always in this block's HBM scratch (a wide cover makes them long)
+	ChainEntry* entByComp; uint16_t* aBucket; uint16_t* entByCompBegin;   // scratch launch only (r4): the entries grouped by weakly connected component, see CHAIN_BUCKETS
 };
+// r4, the scratch launch (reads with more anchors than the LDS classes hold - every 50 kb read): an anchor is only ever chained to anchors of its own weakly connected component, but the scan
+// above visits the entries of ALL earlier anchors and drops the others one by one. On a 1 Gbp graph a 15-mer has a chance hit somewhere in the genome as often as not: a 50 kb read brings ~10 000
+// anchors, most of them strays spread over the other chromosomes' components, and the scan was 3.1 s per 2 000 reads (`gpurun_out/r4_cfg5z`). The entries are therefore regrouped by component -
+// component -> bucket through a 512-slot table, a counting sort that keeps the anchor order inside a bucket - and anchor j scans the part of its own bucket that earlier fragments filled.
+// A read that touches more than 256 components keeps the plain scan.
+#define CHAIN_BUCKETS 512u
 
 // LDS == 0: the working set in this block's HBM scratch; 1: in LDS, the large class (53 KB: three blocks per CU); 2 (r4): in LDS, half the size (26.5 KB, six blocks per CU) - what a
 // 10 kb read needs (~300 anchors, ~600 entries, cover width of a few) and the class launchChain picks when the batch's largest read fits it; a read that outgrows its class goes to the scratch launch
@@ -506,6 +513,7 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 	__shared__ uint32_t sBackBegin[LDS ? LDS_ANCHORS + 1 : 1];
 	__shared__ ChainEntry sEnt[LDS ? LDS_ENTRIES : 1];
 	__shared__ int32_t sThr[LDS ? LDS_WIDTH : 1];
+	__shared__ uint32_t bKey[LDS ? 1 : CHAIN_BUCKETS], bStart[LDS ? 1 : CHAIN_BUCKETS + 1], bFilled[LDS ? 1 : CHAIN_BUCKETS], bUsed;   // bucket -> component, first entry, entries of earlier fragments
 	const int lane = threadIdx.x;
 	// (16-bit indices: at most 65535 anchors, entries and threshold-list items per read, cover width and components below 65536; beyond that the read is flagged)
 	const uint32_t capA = LDS ? LDS_ANCHORS : (caps.capAnchors < 65535u ? caps.capAnchors : 65535u);
@@ -524,7 +532,11 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 		A.thr = (int32_t*)base; base += 4ull * capW;
 		A.aFrag = (uint16_t*)base; base += 2ull * capA;
 		A.aComp = (uint16_t*)base; base += 2ull * capA;
-		A.entBegin = (uint16_t*)base;
+		A.entBegin = (uint16_t*)base; base += 2ull * (capA + 1);
+		A.aBucket = (uint16_t*)base; base += 2ull * (capA + 1);
+		A.entByCompBegin = (uint16_t*)base; base += 2ull * (capA + 1);
+		base = (uint8_t*)(((uintptr_t)base + 7) & ~(uintptr_t)7);
+		A.entByComp = (ChainEntry*)base;
 	}
 	for (uint32_t w = lane; w < capW; w += 64) A.thr[w] = -1;
 	__syncthreads();
@@ -586,6 +598,45 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 		}
 		if (lane == 0) { A.entBegin[nA] = (uint16_t)nE; A.backBegin[nA] = nB; }
 		__syncthreads();
+		bool bucketed = false;
+		if (LDS == 0) {
+			for (uint32_t b = lane; b < CHAIN_BUCKETS; b += 64) { bKey[b] = 0xffffffffu; bStart[b] = 0; bFilled[b] = 0; }
+			if (lane == 0) { bUsed = 0; bStart[CHAIN_BUCKETS] = 0; }
+			__syncthreads();
+			// component -> bucket (the slot its id hashes to), entries per bucket
+			for (uint32_t a = lane; a < nA; a += 64) {
+				const uint32_t comp = A.aComp[a];
+				uint32_t slot = (comp * 2654435761u >> 16) & (CHAIN_BUCKETS - 1);
+				for (uint32_t probes = 0; probes < CHAIN_BUCKETS; probes++, slot = (slot + 1) & (CHAIN_BUCKETS - 1)) {
+					const uint32_t seen = atomicCAS(&bKey[slot], 0xffffffffu, comp);
+					if (seen == 0xffffffffu) atomicAdd(&bUsed, 1u);
+					if (seen == 0xffffffffu || seen == comp) break;
+				}
+				A.aBucket[a] = (uint16_t)slot;
+				atomicAdd(&bStart[slot], (uint32_t)A.entBegin[a + 1] - (uint32_t)A.entBegin[a]);
+			}
+			__syncthreads();
+			bucketed = bUsed <= CHAIN_BUCKETS / 2 && !(forceScratch & 2u);   // (beyond that the probing may have wrapped: plain scan; bit 1 of forceScratch: test hook, plain scan)
+			if (bucketed) {
+				// exclusive scan of the counts (one wave, eight buckets per lane), then every anchor's place in its bucket in anchor order - lane 0, one pass
+				uint32_t mine[CHAIN_BUCKETS / 64], sum = 0;
+				for (uint32_t k = 0; k < CHAIN_BUCKETS / 64; k++) { mine[k] = bStart[lane * (CHAIN_BUCKETS / 64) + k]; sum += mine[k]; }
+				uint32_t incl = sum;
+				for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+				uint32_t at = incl - sum;
+				__syncthreads();
+				for (uint32_t k = 0; k < CHAIN_BUCKETS / 64; k++) { bStart[lane * (CHAIN_BUCKETS / 64) + k] = at; at += mine[k]; }
+				__syncthreads();
+				if (lane == 0) {
+					for (uint32_t a = 0; a < nA; a++) { const uint32_t slot = A.aBucket[a]; A.entByCompBegin[a] = (uint16_t)(bStart[slot] + bFilled[slot]); bFilled[slot] += (uint32_t)A.entBegin[a + 1] - (uint32_t)A.entBegin[a]; }
+					for (uint32_t b = 0; b < CHAIN_BUCKETS; b++) bFilled[b] = 0;
+				}
+				__syncthreads();
+				for (uint32_t a = lane; a < nA; a += 64)
+					for (uint32_t e = A.entBegin[a], to = A.entByCompBegin[a]; e < A.entBegin[a + 1]; e++, to++) A.entByComp[to] = A.ent[e];
+				__syncthreads();
+			}
+		}
 		// anchors are ordered by fragment; g0 = first anchor of j's fragment, the entries of anchors < g0 are a prefix. The threshold lists
 		// of consecutive anchors are consecutive in `back`: a 64-item window of them is kept in registers (item w0 + lane), refilled with one
 		// coalesced load when an anchor's list runs past it - the only global access of the DP loop, a few times per hundred anchors on a narrow cover.
@@ -594,7 +645,10 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 		uint2 win = (uint32_t)lane < nB ? A.back[lane] : make_uint2(0, 0);
 		for (uint32_t j = 0; j < nA; j++) {
 			const uint32_t fj = A.aFrag[j];
-			if (j > 0 && fj != A.aFrag[j - 1]) { g0 = j; entPrefix = A.entBegin[j]; __syncthreads(); }   // C of the previous fragment's anchors is now final and visible
+			if (j > 0 && fj != A.aFrag[j - 1]) {
+				if (LDS == 0 && bucketed) for (uint32_t a = g0 + lane; a < j; a += 64) atomicAdd(&bFilled[A.aBucket[a]], (uint32_t)A.entBegin[a + 1] - (uint32_t)A.entBegin[a]);   // the fragment that just ended joins its buckets' prefixes
+				g0 = j; entPrefix = A.entBegin[j]; __syncthreads();   // C of the previous fragment's anchors is now final and visible
+			}
 			if (g0 == 0) continue;
 			const uint32_t b0 = A.backBegin[j], b1 = A.backBegin[j + 1];
 			// thr[k] = last position on path k that may precede start(j)
@@ -608,8 +662,11 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 			const uint32_t compV = A.aComp[j];
 			const long long xj = (long long)fj * splitGap, yj = xj + splitLen - 1;
 			unsigned long long best = 0;
-			for (uint32_t e = lane; e < entPrefix; e += 64) {
-				const ChainEntry en = A.ent[e];
+			const ChainEntry* entries = A.ent;
+			uint32_t scanBegin = 0, scanEnd = entPrefix;
+			if (LDS == 0 && bucketed) { const uint32_t slot = A.aBucket[j]; entries = A.entByComp; scanBegin = bStart[slot]; scanEnd = scanBegin + bFilled[slot]; }
+			for (uint32_t e = scanBegin + lane; e < scanEnd; e += 64) {
+				const ChainEntry en = entries[e];
 				const uint32_t i = en.anchor;
 				if (A.aComp[i] != compV || (int32_t)en.pos > A.thr[en.k]) continue;   // (path ids are per component)
 				const long long yi = (long long)A.aFrag[i] * splitGap + splitLen - 1;
@@ -1363,6 +1420,7 @@ uint64_t chainScratchBytes(const ChainCaps& caps)
 {
 	// the scratch launch's arrays for one read: anchors (capAnchors), entries (capEndpoints), threshold table (capTable)
 	uint64_t b = 8ull * caps.capBack + 8ull * caps.capAnchors + 8ull * caps.capEndpoints + 4ull * caps.capAnchors + 4ull * (caps.capAnchors + 1) + 4ull * caps.capTable + 6ull * (caps.capAnchors + 1) + 256;
+	b += 4ull * (caps.capAnchors + 1) + 8ull * caps.capEndpoints + 64;   // r4: bucket of every anchor, its entries' place by component, the entries in that order
 	return (b + 63) & ~63ull;
 }
 
@@ -1382,7 +1440,7 @@ void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, 
 	// The batch's bounds tell when no read can need it (cfg2: 400 slots per read at most, cover width 2): 2 048 waves that look and leave cost 7 ms of queueing per batch.
 	// (it is then a safety net of eight waves for what the bounds do not show - a graph with more than 65 535 components, a read beyond 65 535 fragment positions)
 	const bool cannotBeNeeded = !forceScratch && caps.capAnchors <= CHAIN_LDS_ANCHORS / (small ? 2 : 1) && caps.capEndpoints <= CHAIN_LDS_ENTRIES / (small ? 2 : 1) && caps.capTable <= CHAIN_LDS_WIDTH / (small ? 2 : 1);
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<0>), dim3(cannotBeNeeded ? (nReads < 8 ? nReads : 8) : chainScratchBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, 0u);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<0>), dim3(cannotBeNeeded ? (nReads < 8 ? nReads : 8) : chainScratchBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, (getenv("GC_CHAIN_PLAIN_SCAN") && atoi(getenv("GC_CHAIN_PLAIN_SCAN")) == 1) ? 2u : 0u);
 }
 
 uint64_t longWaveWordsPerLane(const ExtendConfig& cfg) { return waveScratchWords(cfg.maxSlices, cfg.maxItems, cfg.maxTrace, cfg.maxCols); }

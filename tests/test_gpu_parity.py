@@ -509,15 +509,20 @@ def test_config3_shape_with_whole_read_pass(gca, tmp_path):
     assert int(got["read_anchor_off"][-1]) > 24 * 200
 
 
-def test_chain_kernel_scratch_path(gca, tmp_path, monkeypatch):
+@pytest.mark.parametrize("plain_scan", ["0", "1"])
+def test_chain_kernel_scratch_path(gca, tmp_path, monkeypatch, plain_scan):
     """k_chain keeps a read's anchors and path entries in LDS; reads beyond those tables (or on a cover wider than the LDS threshold
-    table) run in a second launch with the same code on HBM scratch. Forced for every read here."""
+    table) run in a second launch with the same code on HBM scratch. Forced for every read here. r4: that launch scans the entries grouped by
+    weakly connected component (the default) or all earlier entries (GC_CHAIN_PLAIN_SCAN=1: what a read touching more than 256 components gets);
+    chimeric reads put anchors of several components into one read."""
     from graphchainer_amd.synth import SynthGenome
     monkeypatch.setenv("GC_CHAIN_FORCE_SCRATCH", "1")
-    gen = SynthGenome(2, 60_000, seed=29, multi_allelic=0.3, nested=0.3, repeats=4, repeat_len=1500)
+    monkeypatch.setenv("GC_CHAIN_PLAIN_SCAN", plain_scan)
+    gen = SynthGenome(6, 20_000, seed=29, multi_allelic=0.3, nested=0.3, repeats=4, repeat_len=1500)
     gfa = str(tmp_path / "g.gfa")
     gen.write_gfa(gfa)
     reads = gen.sample_reads(300, 1200, seed=5)          # more reads than the scratch launch has blocks
+    reads += [reads[i][:500] + reads[i + 1][200:700] + reads[i + 2][:400] for i in range(0, 60, 3)]   # pieces of three places: several components per read
     got, want = run_case(gca, gfa, reads, split_gap=18)
     compare(got, want)
 
