@@ -1,899 +1,5 @@
-// C ABI of the MI355X GraphChainer hot path (include/graphchainer_amd.h) and the batched host pipeline that
-// drives the HIP kernels. No CPU fallback: every entry point that needs the device fails with GC_ERR_DEVICE
-// when HIP is unavailable.
-#include "../../include/graphchainer_amd.h"
-#include "hip/gc_kernels.hpp"
-#include "host/gc_graph.hpp"
-#include "host/gc_hashorder.hpp"
-#include "host/gc_glue.hpp"
-#include "host/gc_output.hpp"
-#include "host/gc_index_cache.hpp"
-#include "host/gc_correctness.hpp"
-#include <hip/hip_runtime.h>
-#include <algorithm>
-#include <atomic>
-#include <condition_variable>
-#include <functional>
-#include <mutex>
-#include <chrono>
-#include <cmath>
-#include <cstdlib>
-#include <cstring>
-#include <stdexcept>
-#include <string>
-#include <thread>
-#include <unordered_set>
-#include <vector>
-
-using namespace gcdev;
-
-static thread_local std::string g_lastError;
-static int fail(int code, const std::string& msg) { g_lastError = msg; return code; }
-
-struct DeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
-#define HIP_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw DeviceError(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr); } while (0)
-
-// HIP maps its streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and kernels of different streams that share a hardware queue
-// run one after the other. A batch in flight uses a dozen streams (fragment pipeline, whole-read rounds, edit-distance classes), two batches
-// twice that: on 4 queues the whole-read pass's rounds wait behind the other batch's k_extend / k_chain / k_stitch (kernel trace: 60 ms of
-// foreign kernels between two rounds). 16 queues: 228 -> 209 ms per batch on cfg2; 32 oversubscribe the command processor (290 ms).
-// The HIP runtime reads the variable at its first call and it configures the whole process, so it is the HOST's to set (bench.py and the
-// scripts set GPU_MAX_HW_QUEUES=16 before anything touches HIP); the library only says so, once, when a second stream is created without it.
-static void noteHardwareQueues(int streamsAlive)
-{
-	static std::atomic<bool> said { false };
-	const char* e = getenv("GPU_MAX_HW_QUEUES");
-	if (streamsAlive >= 2 && (!e || atoi(e) < 8) && !said.exchange(true))
-		fprintf(stderr, "[graphchainer_amd] note: GPU_MAX_HW_QUEUES is %s; with several gc_streams per device set it to 16 before the process's first HIP call (INTEGRATION.md §7), or batches in flight serialise on HIP's 4 default hardware queues\n", e ? e : "unset");
-}
-
-namespace {
-
-template <typename T>
-T* uploadVector(const std::vector<T>& v)
-{
-	T* d = nullptr;
-	size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
-	HIP_CHECK(hipMalloc((void**)&d, bytes));
-	if (!v.empty()) HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-	return d;
-}
-
-struct DeviceBuffer {   // growable device allocation owned by a stream object
-	void* ptr = nullptr;
-	size_t bytes = 0;
-	template <typename T> T* reserve(size_t count)
-	{
-		size_t need = std::max<size_t>(count, 1) * sizeof(T);
-		if (need > bytes) {
-			if (ptr) HIP_CHECK(hipFree(ptr));
-			ptr = nullptr;
-			bytes = 0;
-			size_t want = need + need / 8 + 256;
-			HIP_CHECK(hipMalloc(&ptr, want));
-			bytes = want;
-		}
-		return (T*)ptr;
-	}
-	void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
-	~DeviceBuffer() { if (ptr) (void)hipFree(ptr); }
-};
-
-// One whole-read pass at a time per device: its rounds saturate the scalar issue ports of the whole chip, so two passes side by side
-// (two batches in flight on two gc_streams) only take turns at a finer grain and both finish late. With the token the second batch's
-// seeding, host glue and fragment pipeline overlap the first batch's whole-read pass, and its own pass starts the moment the first
-// one ends - a software pipeline over batches (GC_LONG_TOKEN=0 turns it off).
-// r4: GC_LONG_TOKENS=2 (experiment) - two tokens per device, each with a scratch of its own (half the budget): a pass's tail rounds hold fewer extensions than the chip has wave
-// slots and cost one extension's latency each; a second pass side by side fills them (measured: DESIGN.md §4)
-static const int LONG_TOKENS_MAX = 2;
-struct PassTokens {
-	std::mutex m;
-	std::condition_variable cv;
-	bool busy[LONG_TOKENS_MAX] = { false, false };
-	int acquire(int n)
-	{
-		std::unique_lock<std::mutex> l(m);
-		int slot = -1;
-		cv.wait(l, [&]() { for (int s = 0; s < n; s++) if (!busy[s]) { slot = s; return true; } return false; });
-		busy[slot] = true;
-		return slot;
-	}
-	void release(int slot) { { std::lock_guard<std::mutex> l(m); busy[slot] = false; } cv.notify_all(); }
-};
-PassTokens g_longPassToken[16];
-// what std::unique_lock was for the single token: released when the holder goes out of scope
-struct TokenHold {
-	PassTokens* tokens = nullptr;
-	int slot = -1;
-	void lock(PassTokens& t, int n) { tokens = &t; slot = t.acquire(n); }
-	bool owns_lock() const { return slot >= 0; }
-	void unlock() { if (slot >= 0) { tokens->release(slot); slot = -1; } }
-	~TokenHold() { unlock(); }
-};
-static int longTokenCount() { const char* e = getenv("GC_LONG_TOKENS"); return e ? std::max(1, std::min(LONG_TOKENS_MAX, atoi(e))) : 1; }   // (read per use: the tests switch inside one process)
-std::mutex g_longRoundToken[16];   // GC_LONG_TOKEN=2 (experiment): the token handed over per round
-// The pass's extension scratch (up to 48 GB: one region per resident wave) is only touched while the token is held, so the gc_streams of a device share ONE
-// (r3: 85 -> 37 GB per stream for 10 k x 10 kb batches, which is what lets five batches be in flight on a 288 GB device instead of three). It belongs to the
-// token: reserved (grown) by the pass that holds it, freed when the device's last gc_stream goes.
-struct SharedLongScratch { DeviceBuffer buffer[LONG_TOKENS_MAX]; int streams = 0; };
-SharedLongScratch g_longScratch[16];
-std::mutex g_longScratchCount;
-
-double nowUs() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-// CPU time of the whole process (all threads), for GC_DEBUG_TIMES' host budget lines
-static double processCpuMs() { timespec ts {}; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; }
-
-// Waiting for a stream. hipStreamSynchronize spins on a CPU, and a batch has two host threads waiting most of its 200 ms (two batches in
-// flight: four CPUs' worth of spinning, half of what a batch costs the host). Modes (GC_SPIN_SYNC): 2 (default) polls hipStreamQuery and
-// sleeps 40 us between polls - the waits are tens of microseconds late and cost next to no CPU; 1 spins (the r2 behaviour); 0 sleeps on a
-// hipEventBlockingSync event (interrupt-driven; measured slower than spinning on this pool's boxes: 255 against 237 ms per batch).
-static void syncStream(hipStream_t q)
-{
-	static const int mode = getenv("GC_SPIN_SYNC") ? atoi(getenv("GC_SPIN_SYNC")) : 2;
-	if (mode == 1) { HIP_CHECK(hipStreamSynchronize(q)); return; }
-	if (mode == 2) {
-		static const int pollUs = getenv("GC_SYNC_POLL_US") ? std::max(1, atoi(getenv("GC_SYNC_POLL_US"))) : 40;
-		for (int spins = 0;; spins++) {
-			const hipError_t e = hipStreamQuery(q);
-			if (e == hipSuccess) return;
-			if (e != hipErrorNotReady) HIP_CHECK(e);
-			if (spins >= 4) std::this_thread::sleep_for(std::chrono::microseconds(pollUs));   // (the first few polls back to back: many waits are for kernels of a few microseconds)
-		}
-	}
-	// one blocking-sync event per device this thread has waited on, destroyed with the thread (the whole-read pass threads live for one batch)
-	struct Events { hipEvent_t e[16] = {}; ~Events() { for (auto& x : e) if (x) (void)hipEventDestroy(x); } };
-	static thread_local Events events;
-	int device = 0;
-	HIP_CHECK(hipGetDevice(&device));
-	hipEvent_t& e = events.e[device & 15];
-	if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventBlockingSync | hipEventDisableTiming));
-	HIP_CHECK(hipEventRecord(e, q));
-	HIP_CHECK(hipEventSynchronize(e));
-}
-
-// The same for one event (the round token of the whole-read pass is released the moment its extension kernel has finished).
-static void syncEvent(hipEvent_t ev)
-{
-	static const int pollUs = getenv("GC_SYNC_POLL_US") ? std::max(1, atoi(getenv("GC_SYNC_POLL_US"))) : 40;
-	for (int spins = 0;; spins++) {
-		const hipError_t e = hipEventQuery(ev);
-		if (e == hipSuccess) return;
-		if (e != hipErrorNotReady) HIP_CHECK(e);
-		if (spins >= 4) std::this_thread::sleep_for(std::chrono::microseconds(pollUs));
-	}
-}
-
-// Persistent worker pool for the per-read host glue (threads are created once per process).
-class WorkerPool {
-public:
-	static WorkerPool& instance() { static WorkerPool p; return p; }
-	size_t size() const { return workers.size() + 1; }
-	// runs body(i, worker) for i in [0, n); worker in [0, size())
-	void run(size_t n, const std::function<void(size_t, size_t)>& body)
-	{
-		if (n == 0) return;
-		if (workers.empty() || n < 4) { for (size_t i = 0; i < n; i++) body(i, 0); return; }
-		std::lock_guard<std::mutex> oneJob(runMutex);   // batches in flight on different gc_streams take turns on the pool
-		{
-			std::unique_lock<std::mutex> lock(mutex);
-			job = &body;
-			total = n;
-			next.store(0);
-			pending = workers.size();
-			failure = nullptr;
-			generation++;
-		}
-		wake.notify_all();
-		work(0);
-		std::unique_lock<std::mutex> lock(mutex);
-		done.wait(lock, [&]() { return pending == 0; });
-		job = nullptr;
-		if (failure) { std::exception_ptr e = failure; failure = nullptr; std::rethrow_exception(e); }   // (an exception in a pool thread used to end the process)
-	}
-private:
-	WorkerPool()
-	{
-		size_t n = std::max(1u, std::thread::hardware_concurrency());
-		n = std::min<size_t>(n, 96);   // the glue is memory-bound; more threads stop helping
-		// A container with a CPU bandwidth quota (cgroup cpu.max) shows all of the machine's threads but is throttled for the rest of the
-		// 100 ms period once a burst of workers has spent the quota - measured on a 16-CPU quota: 96 workers finish a stage in 10 ms and the
-		// whole process (the whole-read pass's round loop included) then stalls for 50-60 ms. Twice the quota keeps the bursts inside it.
-		const double quota = gc::cpuQuota();
-		if (quota > 0) n = std::min<size_t>(n, std::max<size_t>(4, (size_t)(2 * quota + 0.5)));
-		if (const char* env = getenv("GC_HOST_THREADS")) n = (size_t)std::max(1, atoi(env));
-		for (size_t t = 1; t < n; t++) workers.emplace_back([this, t]() { loop(t); });
-	}
-	~WorkerPool()
-	{
-		{ std::unique_lock<std::mutex> lock(mutex); stop = true; generation++; }
-		wake.notify_all();
-		for (auto& w : workers) w.join();
-	}
-	void work(size_t id)
-	{
-		const size_t chunk = 4;
-		try {
-			for (size_t i; (i = next.fetch_add(chunk)) < total;)
-				for (size_t k = i; k < std::min(total, i + chunk); k++) (*job)(k, id);
-		} catch (...) {
-			next.store(total);   // the first failure ends the job: the other threads stop fetching, the caller rethrows
-			std::unique_lock<std::mutex> lock(mutex);
-			if (!failure) failure = std::current_exception();
-		}
-	}
-	void loop(size_t id)
-	{
-		size_t seen = 0;
-		while (true) {
-			{
-				std::unique_lock<std::mutex> lock(mutex);
-				wake.wait(lock, [&]() { return generation != seen; });
-				seen = generation;
-				if (stop) return;
-			}
-			work(id);
-			std::unique_lock<std::mutex> lock(mutex);
-			if (--pending == 0) done.notify_one();
-		}
-	}
-	std::vector<std::thread> workers;
-	std::mutex mutex, runMutex;
-	std::condition_variable wake, done;
-	const std::function<void(size_t, size_t)>* job = nullptr;
-	std::atomic<size_t> next { 0 };
-	size_t total = 0, pending = 0, generation = 0;
-	std::exception_ptr failure;
-	bool stop = false;
-};
-
-struct PinnedBuffer {   // growable page-locked host staging buffer (full-rate PCIe copies)
-	void* ptr = nullptr;
-	size_t bytes = 0;
-	template <typename T> T* reserve(size_t count)
-	{
-		size_t need = std::max<size_t>(count, 1) * sizeof(T);
-		if (need > bytes) {
-			if (ptr) HIP_CHECK(hipHostFree(ptr));
-			ptr = nullptr;
-			bytes = 0;
-			size_t want = need + need / 8 + 4096;
-			HIP_CHECK(hipHostMalloc(&ptr, want, hipHostMallocDefault));
-			bytes = want;
-		}
-		return (T*)ptr;
-	}
-	~PinnedBuffer() { if (ptr) (void)hipHostFree(ptr); }
-};
-
-template <typename T> T* mallocArray(size_t n) { return (T*)malloc(std::max<size_t>(n, 1) * sizeof(T)); }
-
-// The arrays of a gc_result. The big ones (the trace arrays of keep_traces: 0.1-0.5 GB each for 10 k x 10 kb reads) come from a small cache of blocks that
-// gc_result_free gives back: fresh memory of that size is mapped and zero-filled page by page on first touch, every batch again (r3: ~1.5 of the 3.4 CPU-seconds the
-// assembly of a traced batch cost). Every array carries a 64-byte header with its size, so gc_result_free knows what it holds.
-struct ResultBlockCache {
-	static constexpr size_t HEADER = 64, MAX_HELD = 24ull << 30;
-	// test hooks: GC_RESULT_CACHE_MIN=bytes recycles arrays from that size on (default 32 MB), GC_RESULT_CACHE_POISON=1 fills every array with 0xA5 when it is handed out -
-	// together they show any reader that counts on an array's unwritten part being zero (fresh pages are, recycled ones are not)
-	const size_t BIG = getenv("GC_RESULT_CACHE_MIN") ? (size_t)std::max(1ll, atoll(getenv("GC_RESULT_CACHE_MIN"))) : (32ull << 20);
-	const bool poison = getenv("GC_RESULT_CACHE_POISON") != nullptr;
-	std::mutex mutex;
-	std::vector<std::pair<char*, size_t>> blocks;   // (base, capacity in bytes without the header)
-	size_t held = 0;
-	void* get(size_t bytes)
-	{
-		if (bytes >= BIG) {
-			std::lock_guard<std::mutex> lock(mutex);
-			size_t best = blocks.size();
-			for (size_t i = 0; i < blocks.size(); i++)
-				if (blocks[i].second >= bytes && blocks[i].second <= 2 * bytes && (best == blocks.size() || blocks[i].second < blocks[best].second)) best = i;
-			if (best < blocks.size()) {
-				char* base = blocks[best].first;
-				held -= blocks[best].second;
-				const size_t capacityHeld = blocks[best].second;
-				blocks.erase(blocks.begin() + (long)best);
-				if (poison) memset(base + HEADER, 0xA5, capacityHeld);
-				return base + HEADER;
-			}
-		}
-		const size_t capacity = bytes >= BIG ? bytes + bytes / 16 : bytes;   // (a little slack: the next batch's arrays are about, not exactly, this size)
-		char* base = (char*)malloc(capacity + HEADER);
-		if (!base) throw std::bad_alloc();
-		*(size_t*)base = capacity;
-		if (poison) memset(base + HEADER, 0xA5, capacity);
-		return base + HEADER;
-	}
-	void put(void* p)
-	{
-		if (!p) return;
-		char* base = (char*)p - HEADER;
-		const size_t capacity = *(size_t*)base;
-		if (capacity >= BIG) {
-			std::lock_guard<std::mutex> lock(mutex);
-			if (held + capacity <= MAX_HELD && blocks.size() < 64) { blocks.emplace_back(base, capacity); held += capacity; return; }
-		}
-		free(base);
-	}
-	void trim()   // gives every held block back to the allocator (gc_result_cache_trim)
-	{
-		std::lock_guard<std::mutex> lock(mutex);
-		for (auto& b : blocks) free(b.first);
-		blocks.clear();
-		held = 0;
-	}
-};
-// deliberately never destroyed: a language runtime's finalizers may still call gc_result_free while the process's static destructors run
-ResultBlockCache& g_resultBlocks = *new ResultBlockCache();
-template <typename T> T* resultArray(size_t n) { return (T*)g_resultBlocks.get(std::max<size_t>(n, 1) * sizeof(T)); }
-
-} // namespace
-
-// ----------------------------------------------------------------------------------------------------
-struct gc_graph {
-	gc::AlignmentGraph host;
-	// dense-by-bigraph-node-id copies of the twin lookup tables (the same arrays the device gets): original node size, and the
-	// split nodes of every bigraph node in offset order (chunk k covers offsets [64k, 64k+64))
-	std::vector<uint32_t> hOrigSize, hLookupOff, hLookup;
-	// reverse-strand twin of (split node, offset): GetReversePosition + GetUnitigNode (src/AlignmentGraph.cpp:832-868) without the hash maps
-	inline void twinOf(uint32_t node, uint32_t offset, uint32_t& twinNode, uint32_t& twinOffset) const
-	{
-		uint32_t id = (uint32_t)host.nodeIDs[node];
-		uint32_t rev = hOrigSize[id] - 1 - ((uint32_t)host.nodeOffset[node] + offset);
-		twinNode = hLookup[hLookupOff[id ^ 1] + rev / 64];
-		twinOffset = rev - (uint32_t)host.nodeOffset[twinNode];
-	}
-	DGraph dev {};
-	OutNames devNames {};            // GFA segment names by bigraph node id (output encoding on the device, gc_output.hip)
-	std::vector<void*> allocations;
-	CorrectnessTables* devTables = nullptr;
-	uint8_t* devIupac = nullptr;
-	uint32_t maxMpcWidth = 0, maxPathsPerNode = 1, maxBackPerNode = 1;
-	~gc_graph() { for (void* p : allocations) (void)hipFree(p); }
-	template <typename T> const T* up(const std::vector<T>& v) { T* d = uploadVector(v); allocations.push_back(d); return d; }
-};
-
-struct gc_seeder {
-	gc::MinimizerIndex host;
-	SeedIndex dev {};
-	std::vector<void*> allocations;
-	~gc_seeder() { for (void* p : allocations) (void)hipFree(p); }
-};
-
-// Device and pinned blocks of read batches, kept for the next batch (r4). gc_reads_upload used to hipMalloc nine arrays per batch and gc_reads_destroy to hipFree them:
-// hipFree waits for the device to drain, so with five batches in flight every destroy stalled its host thread for the length of whatever was queued (and the upload of the
-// next batch behind it: 245 ms per batch in the end-to-end leg, `gpurun_out/r4_ab3`). One block per batch now, carved into the arrays, returned to a small cache.
-struct BlockCache {
-	bool pinned;
-	std::mutex mutex;
-	struct Block { void* ptr; size_t bytes; int device; };
-	std::vector<Block> blocks;
-	static constexpr size_t MAX_BLOCKS = 12;
-	explicit BlockCache(bool pinned) : pinned(pinned) {}
-	void* get(size_t bytes, int device, size_t& capacity)
-	{
-		{
-			std::lock_guard<std::mutex> lock(mutex);
-			size_t best = blocks.size();
-			for (size_t i = 0; i < blocks.size(); i++)
-				if (blocks[i].device == device && blocks[i].bytes >= bytes && blocks[i].bytes <= 2 * bytes + (1u << 20) && (best == blocks.size() || blocks[i].bytes < blocks[best].bytes)) best = i;
-			if (best < blocks.size()) { Block b = blocks[best]; blocks.erase(blocks.begin() + (long)best); capacity = b.bytes; return b.ptr; }
-		}
-		capacity = bytes + bytes / 8 + 4096;   // (a little slack: the next batch is about, not exactly, this size)
-		void* p = nullptr;
-		if (pinned) HIP_CHECK(hipHostMalloc(&p, capacity, hipHostMallocDefault));
-		else HIP_CHECK(hipMalloc(&p, capacity));
-		return p;
-	}
-	void put(void* p, size_t bytes, int device)
-	{
-		if (!p) return;
-		{
-			std::lock_guard<std::mutex> lock(mutex);
-			if (blocks.size() < MAX_BLOCKS) { blocks.push_back(Block { p, bytes, device }); return; }
-		}
-		if (pinned) (void)hipHostFree(p); else (void)hipFree(p);
-	}
-};
-static BlockCache& g_readDeviceBlocks = *new BlockCache(false);   // (leaked on purpose, like the result cache: finalizers may run late)
-static BlockCache& g_readPinnedBlocks = *new BlockCache(true);
-
-// a stream of the calling thread's own for its uploads and small jobs (created on first use, recreated when the thread changes device)
-static hipStream_t threadStream(int device)
-{
-	static thread_local struct ThreadStream { hipStream_t q = nullptr; int device = -1; ~ThreadStream() { if (q) (void)hipStreamDestroy(q); } } ts;
-	if (!ts.q || ts.device != device) { if (ts.q) (void)hipStreamDestroy(ts.q); ts.q = nullptr; HIP_CHECK(hipStreamCreateWithFlags(&ts.q, hipStreamNonBlocking)); ts.device = device; }
-	return ts.q;
-}
-
-struct gc_reads {
-	void* deviceBlock = nullptr; size_t deviceBlockBytes = 0; int device = 0;   // every device array below is carved from this one block
-	std::vector<uint64_t> offsets;   // host copy [n+1]
-	uint64_t totalBases = 0;
-	std::vector<uint8_t> invalid;    // read has a character outside the IUPAC alphabet (the reference's Complement() asserts)
-	char* devBases = nullptr;        // [2*totalBases]: all reads forward, then every read reverse-complemented in place
-	uint64_t* devOffsets = nullptr;
-	// per read: match-mask bit vectors [strand fwd/rc][A,C,G,T][words] (bit i set: read position i matches that base)
-	uint64_t* devMasks = nullptr;
-	std::vector<uint64_t> maskOff;   // [n] word offset of read r's masks
-	std::vector<uint32_t> maskWords; // [n] words per bit vector
-	// exact-match bit vectors of the forward strand [A,C,G,T][words] and the per-read records of the NW kernel (rows = read bases)
-	uint64_t* devEqMasks = nullptr;
-	EdRead* devEdReads = nullptr;
-	uint32_t* devChunkRead = nullptr;   // read containing the first base of every 64-base chunk of the concatenated forward bases
-	uint64_t* devPacked = nullptr;      // the forward bases, 2 bits each, big-endian inside 64-bit words (for the seed kernel's k-mers)
-	uint64_t* devInvalid = nullptr;     // one bit per forward base: not A, C, G or T (same big-endian convention)
-	uint8_t* devReadInvalid = nullptr;  // [n] the device's copy of `invalid`
-	~gc_reads() { g_readDeviceBlocks.put(deviceBlock, deviceBlockBytes, device); }
-};
-
-struct StitchedPath { std::vector<uint32_t> nodes; uint32_t firstOffset = 0, lastOffset = 0; uint64_t cells = 0; };
-
-struct ReadGlue {
-	std::vector<gc::SeedRec> seeds;       // fragment-pass order (by seqPos)
-	std::vector<gc::SeedRec> longSeeds;   // whole-read pass order (by goodness), only with long_pass
-	std::vector<gc::FragmentWindow> windows;
-	std::vector<LongAln> longAlns;        // final order (the reference's repeated sort by alignmentStart)
-	uint64_t longBegin = 0, longTraceBegin = 0, longSeedBegin = 0;
-	bool failed = false;
-	bool longFailed = false;              // the whole-read pass asserted: no anchors, chain or alignment for this read
-	bool capacityExceeded = false;        // a capacity of this library (not of the reference) was exceeded while processing this read
-	bool capacityExceededLong = false;    // same, raised by the whole-read pass (its own thread; joined into capacityExceeded after the pass)
-	uint64_t slotBegin = 0, fragBegin = 0;
-	uint32_t nSeedsR = 0, nWindows = 0;   // seeds of the read (fragment order, at seedBegin) and fragments that hold seeds
-	uint64_t nAnchors = 0, nPath = 0, nTrace = 0, anchorBegin = 0, pathBegin = 0, traceBegin = 0, seedBegin = 0, chainBegin = 0;
-	StitchedPath stitched;                // chain stitching result
-	bool stitchedOnDevice = false;        // its nodes are also in the device's stitch regions
-	uint64_t stitchedBegin = 0;
-	std::vector<uint32_t> longSelected;   // GreedyLength selection (src/Aligner.cpp:636-639): indices into longAlns
-	uint64_t longSelectedBegin = 0;
-	int64_t longEditDistance = -1, chainEditDistance = -1;
-	// the chained alignment (src/Aligner.cpp:845-897): trace in output coordinates, alignmentStart / alignmentEnd
-	std::vector<int32_t> chainTraceNode; std::vector<uint32_t> chainTraceOffset, chainTraceSeqPos; std::vector<uint8_t> chainTraceSwitch;
-	uint32_t chainAlnStart = 0, chainAlnEnd = 0;
-	bool hasChainAlignment = false, chainWins = false;
-	uint64_t chainTraceBegin = 0;
-	// back to the state of a fresh record, keeping the vectors' storage: the records live in the gc_stream and are reused by
-	// every batch (allocating and destroying 10 k x 6 vectors per batch cost ~10 ms of teardown plus the allocations)
-	void reset()
-	{
-		seeds.clear(); longSeeds.clear(); windows.clear(); longAlns.clear(); longSelected.clear();
-		stitched.nodes.clear(); stitched.firstOffset = stitched.lastOffset = 0; stitched.cells = 0;
-		longBegin = longTraceBegin = longSeedBegin = 0;
-		failed = longFailed = capacityExceeded = capacityExceededLong = false;
-		slotBegin = fragBegin = 0;
-		nSeedsR = nWindows = 0;
-		nAnchors = nPath = nTrace = anchorBegin = pathBegin = traceBegin = seedBegin = chainBegin = 0;
-		stitchedBegin = longSelectedBegin = 0;
-		longEditDistance = chainEditDistance = -1;
-		chainTraceNode.clear(); chainTraceOffset.clear(); chainTraceSeqPos.clear(); chainTraceSwitch.clear();
-		chainAlnStart = chainAlnEnd = 0;
-		hasChainAlignment = chainWins = false;
-		chainTraceBegin = 0;
-	}
-};
-
-struct EditDistanceRun {
-	hipStream_t streams[7] {};         // one per kernel class: three pairs per wave, two pairs per wave, then units of 1, 2, 4, 8, 16 blocks
-	uint32_t begin[8] {};              // the classes' ranges in the grouped order
-	hipEvent_t ready = nullptr;
-	std::vector<uint32_t> perm;        // position in the grouped order -> original pair index
-	std::vector<int64_t> grouped;      // results in grouped order (pinned not needed: small)
-	~EditDistanceRun() { for (auto& q : streams) if (q) (void)hipStreamDestroy(q); if (ready) (void)hipEventDestroy(ready); }
-};
-
-static const int LONG_EVENT_RING = 8;
-#ifndef GC_LONG_PLAN_DEFAULT
-#define GC_LONG_PLAN_DEFAULT "1"   // candidates per read and round of the whole-read pass (GC_LONG_PLAN; see runLongGroup)
-#endif
-struct gc_stream {
-	std::vector<ReadGlue> glue;   // per-read host records of the batch in flight (storage reused)
-	int device = 0;             // the device the stream was created on; gc_align_batch selects it for the calling thread
-	hipStream_t stream = nullptr;
-	hipEvent_t ev[12] {};
-	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, readSeeds, fragFirstSeed, longRetryList, extLists, pendingFrags, fragNext, roundCounts, work, results, scratch, scratchRetry, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
-	PinnedBuffer hMatches, hReadSeeds, hFragFirstSeed, hFrags, hJobs, hAnchors, hFragStatus, hFragExtended, hChainOut, hChainLen, hChainScore, hChainStatus, hPathPool, hSmall;
-	// whole-read pass: runs on its own stream, concurrently with the fragment kernels
-	hipStream_t longStream = nullptr;
-	hipEvent_t longEv[2] {};
-	DeviceBuffer edPathNodes, edJobs, edLetters, edLettersLen, edPairs, edOut;
-	PinnedBuffer hEdPathNodes, hEdJobs, hEdPairs, hEdOut;
-	DeviceBuffer outJobs, outRecs, outOffsets, outMapSizes, outPathText, outCigarText, outVgBytes, outTotals;   // output encoding on the device (gc_output.hip)
-	PinnedBuffer hOutJobs, hOutRecs, hOutOffsets, hOutPathText, hOutCigarText, hOutVgBytes, hOutTotals;
-	DeviceBuffer stitchSlotOf, stitchRegions, stitchNodes, stitchInfo, stitchCursor;   // chain stitching on the device (gc_stitch.hip)
-	PinnedBuffer hStitchNodes, hStitchInfo, hStitchCursor;
-	EditDistanceRun edChainRun;
-	DeviceBuffer edPathJobs, edPathOps, edPathLen, edPathScratch;   // alignment path of the chained alignment (gc_edpath.hip)
-	PinnedBuffer hEdPathJobs, hEdPathOps, hEdPathLen;
-	// whole-read decision (selection + edit distance of the best alignment)
-	struct LongDecision {
-		PinnedBuffer hJobs, hPairs, hOut;
-		DeviceBuffer jobs, letters, lettersLen, pairs, out;
-		EditDistanceRun run;
-		std::vector<uint32_t> pairRead;
-		uint32_t nPairs = 0;
-	} edLong[2];
-	uint64_t longCellsPerBase = 8;           // merged-trace cells per read base the whole-read pass reserves (grows when a batch needs more)
-	std::vector<hipStream_t> groupStreams;   // read groups of the whole-read pass run their round loops concurrently
-	std::vector<hipEvent_t> groupEvents;     // 2 * LONG_EVENT_RING per group
-	DeviceBuffer longSeeds, longJobs, longAlns, longResults, longScratch, longCells, longCursor, longJobsFallback, longResultsFallback, longScratchFallback;
-	DeviceBuffer gluePerRead, glueCursors, glueOut, glueSeedCap, glueSeedOff, glueWinCapOff, glueU32[8], glueSort, gluePos, glueWin;   // seed glue on the device (gc_seedglue.hip)
-	PinnedBuffer hGlueOut, hGlueWinCapOff, hGlueSmall;
-	DeviceBuffer longState, longWork, longWorkResults, longRoundTrace, longCandSeed, longWorkLen, longOrder, longRoundInfo;
-	PinnedBuffer hLongRoundInfo;
-	PinnedBuffer hLongSeeds, hLongJobs, hLongAlns, hLongResults, hLongSmall, hLongCells;
-	~gc_stream()
-	{
-		for (auto& e : ev) if (e) (void)hipEventDestroy(e);
-		for (auto& e : longEv) if (e) (void)hipEventDestroy(e);
-		for (auto& e : groupEvents) if (e) (void)hipEventDestroy(e);
-		for (auto& q : groupStreams) if (q) (void)hipStreamDestroy(q);
-		if (stream) (void)hipStreamDestroy(stream);
-		if (longStream) (void)hipStreamDestroy(longStream);
-	}
-};
-
-// ----------------------------------------------------------------------------------------------------
-// set of bases (A=1,C=2,G=4,T=8) a read character can stand for; 0 = matches nothing.
-// reference: characterMatch / ambiguousMatch, src/GraphAlignerCommon.h:190-297
-static void buildIupacTable(uint8_t* t)
-{
-	memset(t, 0, 256);
-	auto set = [&](const char* chars, uint8_t m) { for (const char* c = chars; *c; c++) t[(uint8_t)*c] = m; };
-	set("Aa", 1); set("Cc", 2); set("Gg", 4); set("TtUu", 8);
-	set("Rr", 1 | 4); set("Yy", 2 | 8); set("Kk", 4 | 8); set("Mm", 1 | 2); set("Ss", 2 | 4); set("Ww", 1 | 8);
-	set("Bb", 2 | 4 | 8); set("Dd", 1 | 4 | 8); set("Hh", 1 | 2 | 8); set("Vv", 1 | 2 | 4); set("Nn", 15);
-}
-
-static void uploadGraph(gc_graph* G)
-{
-	const gc::AlignmentGraph& h = G->host;
-	size_t n = h.NodeSize();
-	if (n >= 0xfffffff0ull) throw std::runtime_error("graph too large for 32-bit node ids");
-	std::vector<uint8_t> nodeLength(n);
-	std::vector<uint32_t> nodeOffset(n), componentNumber(n), componentMap(n), topoId(n);
-	std::vector<int32_t> nodeIDs(n);
-	int maxId = -1;
-	for (size_t i = 0; i < n; i++) {
-		nodeLength[i] = (uint8_t)h.nodeLength[i];
-		nodeOffset[i] = (uint32_t)h.nodeOffset[i];
-		nodeIDs[i] = h.nodeIDs[i];
-		componentNumber[i] = (uint32_t)h.componentNumber[i];
-		componentMap[i] = (uint32_t)h.component_map[i];
-		topoId[i] = (uint32_t)h.topo_ids[h.component_map[i]][h.component_idx[i]];
-		maxId = std::max(maxId, h.nodeIDs[i]);
-	}
-	std::vector<uint64_t> nodeSeq(2 * h.firstAmbiguous), ambSeq(4 * (n - h.firstAmbiguous));
-	for (size_t i = 0; i < h.firstAmbiguous; i++) { nodeSeq[2 * i] = h.nodeSequences[i][0]; nodeSeq[2 * i + 1] = h.nodeSequences[i][1]; }
-	for (size_t i = h.firstAmbiguous; i < n; i++) {
-		const gc::AmbiguousSeq& s = h.ambiguousNodeSequences[i - h.firstAmbiguous];
-		size_t at = 4 * (i - h.firstAmbiguous);
-		ambSeq[at] = s.A; ambSeq[at + 1] = s.C; ambSeq[at + 2] = s.G; ambSeq[at + 3] = s.T;
-	}
-	auto csr = [&](const std::vector<std::vector<size_t>>& adj, std::vector<uint32_t>& off, std::vector<uint32_t>& flat) {
-		off.assign(n + 1, 0);
-		for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + (uint32_t)adj[i].size();
-		flat.clear();
-		flat.reserve(off[n]);
-		for (size_t i = 0; i < n; i++) for (size_t v : adj[i]) flat.push_back((uint32_t)v);
-	};
-	std::vector<uint32_t> inOff, inAdj, outOff, outAdj;
-	csr(h.inNeighbors, inOff, inAdj);
-	csr(h.outNeighbors, outOff, outAdj);
-	size_t nB = (size_t)maxId + 1;
-	std::vector<uint32_t> origSize(nB, 0), lookupOff(nB + 1, 0), lookup;
-	for (size_t id = 0; id < nB; id++) {
-		const bool known = h.nodeLookup.contains((int)id);
-		lookupOff[id + 1] = lookupOff[id] + (known ? (uint32_t)h.nodeLookup.at((int)id).size() : 0u);
-		if (known) {
-			origSize[id] = (uint32_t)h.originalNodeSize.at((int)id);
-			for (size_t s : h.nodeLookup.at((int)id)) lookup.push_back((uint32_t)s);
-		}
-	}
-	for (size_t id = 0; id < nB; id++)
-		for (uint32_t k = lookupOff[id]; k < lookupOff[id + 1]; k++)
-			if (h.nodeOffset[lookup[k]] != 64ull * (k - lookupOff[id])) throw std::runtime_error("split nodes are not 64-aligned chunks of their original node");
-	G->hOrigSize = origSize; G->hLookupOff = lookupOff; G->hLookup = lookup;
-	// MPC index, flattened to global node ids
-	std::vector<uint32_t> pathsOff(n + 1, 0), pathsFlat, pathsPos, backOff(n + 1, 0), backNode, backPath, backPos, mpcWidth(h.mpc.size());
-	for (size_t c = 0; c < h.mpc.size(); c++) { mpcWidth[c] = (uint32_t)h.mpc[c].size(); G->maxMpcWidth = std::max(G->maxMpcWidth, mpcWidth[c]); }
-	for (size_t i = 0; i < n; i++) {
-		size_t c = h.component_map[i], x = h.component_idx[i];
-		for (size_t k : h.paths[c][x]) pathsFlat.push_back((uint32_t)k);
-		pathsOff[i + 1] = (uint32_t)pathsFlat.size();
-		G->maxPathsPerNode = std::max(G->maxPathsPerNode, pathsOff[i + 1] - pathsOff[i]);
-		for (const auto& b : h.backwards[c][x]) { backNode.push_back((uint32_t)h.component_ids[c][b.first]); backPath.push_back((uint32_t)b.second); }
-		backOff[i + 1] = (uint32_t)backNode.size();
-		G->maxBackPerNode = std::max(G->maxBackPerNode, backOff[i + 1] - backOff[i]);
-	}
-	// position of every node on every path through it (paths[v] lists path ids in ascending order, and a path visits
-	// its nodes in order, so walking path k in order fills the (v,k) entries)
-	pathsPos.assign(pathsFlat.size(), 0);
-	backPos.assign(backNode.size(), 0);
-	{
-		auto posOf = [&](uint32_t node, uint32_t k) -> uint32_t {
-			for (uint32_t e = pathsOff[node]; e < pathsOff[node + 1]; e++) if (pathsFlat[e] == k) return pathsPos[e];
-			throw std::runtime_error("MPC index: node not on path");
-		};
-		for (size_t c = 0; c < h.mpc.size(); c++)
-			for (size_t k = 0; k < h.mpc[c].size(); k++)
-				for (size_t j = 0; j < h.mpc[c][k].size(); j++) {
-					size_t node = h.mpc[c][k][j];
-					for (uint32_t e = pathsOff[node]; e < pathsOff[node + 1]; e++) if (pathsFlat[e] == k) pathsPos[e] = (uint32_t)j;   // last visit wins, as in last2reach (:1340-1345)
-				}
-		for (size_t i = 0; i < n; i++)
-			for (uint32_t e = backOff[i]; e < backOff[i + 1]; e++) backPos[e] = posOf(backNode[e], backPath[e]);
-	}
-	DGraph& d = G->dev;
-	d.nNodes = (uint32_t)n;
-	d.firstAmbiguous = (uint32_t)h.firstAmbiguous;
-	d.nodeLength = G->up(nodeLength);
-	d.nodeOffset = G->up(nodeOffset);
-	d.nodeIDs = G->up(nodeIDs);
-	d.nodeSeq = G->up(nodeSeq);
-	d.ambSeq = G->up(ambSeq);
-	d.inOff = G->up(inOff); d.inAdj = G->up(inAdj);
-	d.outOff = G->up(outOff); d.outAdj = G->up(outAdj);
-	d.componentNumber = G->up(componentNumber);
-	d.origSize = G->up(origSize); d.lookupOff = G->up(lookupOff); d.lookup = G->up(lookup);
-	d.componentMap = G->up(componentMap);
-	d.topoId = G->up(topoId);
-	d.pathsOff = G->up(pathsOff); d.paths = G->up(pathsFlat); d.pathsPos = G->up(pathsPos);
-	d.backOff = G->up(backOff); d.backNode = G->up(backNode); d.backPath = G->up(backPath); d.backPos = G->up(backPos);
-	d.mpcWidth = G->up(mpcWidth);
-	{
-		std::vector<uint32_t> chainNumber(n);
-		std::vector<uint64_t> chainApproxPos(n);
-		for (size_t i = 0; i < n; i++) {
-			if (h.chainNumber[i] >= 0xffffffffull) throw std::runtime_error("too many chains for 32-bit chain numbers");
-			chainNumber[i] = (uint32_t)h.chainNumber[i];
-			chainApproxPos[i] = (uint64_t)h.chainApproxPos[i];
-		}
-		d.chainNumber = G->up(chainNumber);
-		d.chainApproxPos = G->up(chainApproxPos);
-	}
-	{
-		// the names the output encoders print (OriginalNodeName; empty: they print id / 2), by bigraph node id
-		std::vector<uint32_t> nameOff(nB + 1, 0);
-		std::vector<char> nameBytes;
-		for (size_t id = 0; id < nB; id++) {
-			const std::string* name = h.originalNodeName.find((int)id);
-			if (name) nameBytes.insert(nameBytes.end(), name->begin(), name->end());
-			if (nameBytes.size() >= 0xffffffffull) throw std::runtime_error("node names exceed 4 GB");
-			nameOff[id + 1] = (uint32_t)nameBytes.size();
-		}
-		nameBytes.push_back(0);
-		G->devNames.nameOff = G->up(nameOff);
-		G->devNames.nameBytes = G->up(nameBytes);
-	}
-	CorrectnessTables t;
-	buildCorrectnessTables(t);
-	HIP_CHECK(hipMalloc((void**)&G->devTables, sizeof(t)));
-	G->allocations.push_back(G->devTables);
-	HIP_CHECK(hipMemcpy(G->devTables, &t, sizeof(t), hipMemcpyHostToDevice));
-	uint8_t iupac[256];
-	buildIupacTable(iupac);
-	HIP_CHECK(hipMalloc((void**)&G->devIupac, 256));
-	G->allocations.push_back(G->devIupac);
-	HIP_CHECK(hipMemcpy(G->devIupac, iupac, 256, hipMemcpyHostToDevice));
-}
-
-template <typename F>
-static int guarded(F&& f)
-{
-	try {
-		return f();
-	} catch (const DeviceError& e) {
-		return fail(GC_ERR_DEVICE, e.what());
-	} catch (const std::exception& e) {
-		return fail(GC_ERR_INTERNAL, e.what());
-	}
-}
-
-static void requireDevice()
-{
-	int n = 0;
-	hipError_t e = hipGetDeviceCount(&n);
-	if (e != hipSuccess || n <= 0) throw DeviceError("no HIP device available: the product path has no CPU fallback");
-}
-
-namespace {
-
-// Chain stitching, reference: src/Aligner.cpp:754-822 (+ pathToTrace :409-424, getChainPath src/AlignmentGraph.cpp:1866-1916).
-// The chain's anchor paths are concatenated; consecutive anchors that are not adjacent are bridged by the fewest-hops
-// path (bounded BFS); where no bridge exists within --colinear-gap the path is cut and the longest piece (most graph
-// bases, the size of the reference's pathToTrace vector) is kept. `slots` = this read's kept anchors in anchor-index
-// order. The piece is returned as its node path plus the offsets of its first and last base; pathToTrace's cell list
-// (one entry per base) follows from those and is not materialised here.
-static void stitchChain(const gc::AlignmentGraph& graph, long long colinearGap, const uint32_t* chain, uint32_t chainLen, const uint32_t* slots,
-	const AnchorRec* anchors, const uint32_t* pathPool, StitchedPath& longest)
-{
-	std::vector<size_t> posPath;
-	std::unordered_set<size_t> nodes;
-	size_t firstNodeOffset = 0, lastNodeOffset = 0;
-	longest = StitchedPath();
-	auto keepIfLonger = [&]() {
-		uint64_t cells = 0;   // size of pathToTrace(posPath, firstNodeOffset, lastNodeOffset), src/Aligner.cpp:409-424
-		for (size_t node : posPath) {
-			size_t S = 0, L = graph.NodeLength(node);
-			if (node == posPath[0]) S = firstNodeOffset;
-			else if (node == posPath.back()) L = lastNodeOffset + 1;
-			cells += L > S ? L - S : 0;
-		}
-		if (longest.cells < cells) {
-			longest.nodes.assign(posPath.begin(), posPath.end());
-			longest.firstOffset = (uint32_t)firstNodeOffset;
-			longest.lastOffset = (uint32_t)lastNodeOffset;
-			longest.cells = cells;
-		}
-	};
-	for (uint32_t c = 0; c < chainLen; c++) {
-		const AnchorRec& a = anchors[slots[chain[c]]];
-		const uint32_t* apath = pathPool + a.pathOff;
-		if (posPath.empty()) {
-			posPath.assign(apath, apath + a.pathLen);
-			firstNodeOffset = a.firstOffset;
-			lastNodeOffset = a.lastOffset;
-			for (size_t j : posPath) nodes.insert(j);
-		} else {
-			bool gap = apath[0] == posPath.back() && colinearGap != -1 && (long long)a.firstOffset - (long long)lastNodeOffset > colinearGap + 1;
-			std::vector<size_t> bridge;
-			if (!nodes.count(apath[0]) && posPath.back() != a.firstNode) {
-				long long gapLimit = colinearGap;
-				if (gapLimit != -1) gapLimit -= (long long)a.firstOffset + (long long)(graph.NodeLength(posPath.back()) - (long long)lastNodeOffset - 1);
-				bridge = graph.getChainPath(posPath.back(), a.firstNode, gapLimit);
-				if (bridge.empty()) gap = true;
-			}
-			if (gap) {
-				keepIfLonger();
-				nodes.clear();
-				posPath.clear();
-				firstNodeOffset = a.firstOffset;
-			} else {
-				for (size_t j : bridge) if (!nodes.count(j)) { nodes.insert(j); posPath.push_back(j); }
-			}
-			for (uint32_t k = 0; k < a.pathLen; k++) { size_t j = apath[k]; if (!nodes.count(j)) { nodes.insert(j); posPath.push_back(j); } }
-			lastNodeOffset = a.lastOffset;
-		}
-	}
-	if (!posPath.empty()) keepIfLonger();
-}
-
-// Exact-match bit vectors of a read for the NW kernel: [A,C,G,T][words], bit i set when base i is exactly that letter.
-static void buildEqMasks(const char* seq, uint64_t len, uint64_t words, uint64_t* out)
-{
-	for (uint64_t i = 0; i < len; i++) {
-		int b = seq[i] == 'A' ? 0 : seq[i] == 'C' ? 1 : seq[i] == 'G' ? 2 : seq[i] == 'T' ? 3 : -1;
-		if (b >= 0) out[(uint64_t)b * words + (i >> 6)] |= 1ull << (i & 63);
-	}
-}
-
-// Runs the NW kernel over `pairs`. The rows-per-lane unit (1, 2, 4, 8, 16 blocks) a pair needs follows from its band
-// half-width k and its read length (gc_editdist.hip); pairs are grouped by unit, every group runs on its own stream (a
-// group of a few wide-band pairs is one long-running wave each and would otherwise hold up the others), and pairs
-// whose k had to grow past their unit's limit are rerun with the next unit.
-// hPairs/hOut: pinned host staging; dPairs/dOut: device arrays of at least nPairs elements; readLen: host read lengths.
-static uint32_t editDistanceUnit(uint32_t k, uint32_t readLen)
-{
-	uint32_t unit = 1;
-	while (unit < 16 && k >= editDistanceMaxK(unit) && (readLen + 64 * unit - 1) / (64 * unit) > 64) unit *= 2;
-	return unit;
-}
-// Streams of the fragment pipeline / the edit distances (role 0) and of the whole-read rounds (role 1). GC_STREAM_PRIORITY=frag|long raises one
-// side's queue priority (experiment): the whole-read kernel holds 7 of a SIMD's 8 wave slots for milliseconds per wave, so
-// whatever shares the device with it runs on what is left.
-static void createStream(hipStream_t* q, int role)
-{
-	static const int mode = []() { const char* e = getenv("GC_STREAM_PRIORITY"); return !e ? 0 : !strcmp(e, "frag") ? 1 : !strcmp(e, "long") ? 2 : 0; }();
-	int least = 0, greatest = 0;
-	if (mode && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
-		const bool high = (mode == 1 && role == 0) || (mode == 2 && role == 1);
-		HIP_CHECK(hipStreamCreateWithPriority(q, hipStreamNonBlocking, high ? greatest : least));
-		return;
-	}
-	HIP_CHECK(hipStreamCreateWithFlags(q, hipStreamNonBlocking));
-}
-
-static void launchEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair* hPairs, int64_t* hOut, uint32_t nPairs, EdPair* dPairs, int64_t* dOut, const EdRead* dReads, const char* dBases,
-	const uint64_t* dEqMasks, const char* dLetters, const uint32_t* dLettersLen, const std::function<uint32_t(uint32_t)>& readLen, bool kIsBound = false)
-{
-	if (!nPairs) return;
-	if (!run.ready) HIP_CHECK(hipEventCreateWithFlags(&run.ready, hipEventDisableTiming));
-	// (a class's stream is created when the class is first used: the batch's streams share the device's 16 hardware queues, and on cfg2 only the
-	// two-pairs-per-wave class and the one-block class ever hold pairs)
-	std::vector<uint32_t> cls(nPairs);
-	uint32_t count[7] = { 0, 0, 0, 0, 0, 0, 0 };
-	uint32_t* begin = run.begin;
-	static const bool halfWaves = !(getenv("GC_ED_HALF") && atoi(getenv("GC_ED_HALF")) == 0);
-	static const bool thirdWaves = halfWaves && !(getenv("GC_ED_THIRD") && atoi(getenv("GC_ED_THIRD")) == 0);
-	for (uint32_t i = 0; i < nPairs; i++) {
-		const uint32_t len = readLen(hPairs[i].read);
-		uint32_t unit = editDistanceUnit(hPairs[i].k, len), c = 0;
-		while ((1u << c) < unit) c++;
-		c += 2;                                                               // classes 2..6: one pair per wave, units of 1..16 blocks
-		if (halfWaves && unit == 1 && hPairs[i].k < editDistanceMaxK(0) && len <= 131072) {   // class 1: two pairs per wave (small first band)
-			c = 1;
-			// class 0 (r4): three pairs per wave, bands below 1290 - for pairs whose k is a bound (a whole-read pair's k comes from the alignment itself: one sweep, always enough).
-			// A chain pair's k is a guess; tried there whenever length difference + 10 % of the shorter sequence fit, 45 % of cfg2's chain pairs (distances 1 100-1 300) came back
-			// for a second sweep and the two kernels together took 352 ms per nine batches against 311 (`gpurun_out/r4_ring`): chain pairs stay with two per wave
-			if (thirdWaves && kIsBound && len <= 65536 && hPairs[i].k < editDistanceTeamMaxK(3)) c = 0;
-			// a sweep of these kernels takes columns + units steps whatever the band, as long as the band fits the team's lanes - so the first guess may as well be the widest band that
-			// does (any k >= the distance gives the distance): a chain pair whose guess (length difference + 14 %) was a little short used to pay a failed sweep here, a second
-			// failed sweep with the same guess in the one-pair-per-wave kernel and a third with the doubled band (r3)
-			hPairs[i].k = c == 0 ? editDistanceTeamMaxK(3) - 1 : std::max(hPairs[i].k, editDistanceMaxK(0) - 1);
-		}
-		cls[i] = c;
-		count[c]++;
-	}
-	begin[0] = 0;
-	for (int c = 0; c < 7; c++) begin[c + 1] = begin[c] + count[c];
-	run.perm.resize(nPairs);
-	{
-		uint32_t at[7] = { begin[0], begin[1], begin[2], begin[3], begin[4], begin[5], begin[6] };
-		std::vector<EdPair> grouped(nPairs);
-		for (uint32_t i = 0; i < nPairs; i++) { grouped[at[cls[i]]] = hPairs[i]; run.perm[at[cls[i]]++] = i; }
-		memcpy(hPairs, grouped.data(), (size_t)nPairs * sizeof(EdPair));   // hPairs is now in grouped order
-	}
-	HIP_CHECK(hipMemcpyAsync(dPairs, hPairs, (size_t)nPairs * sizeof(EdPair), hipMemcpyHostToDevice, stream));
-	HIP_CHECK(hipEventRecord(run.ready, stream));
-	for (int c = 0; c < 7; c++) {
-		if (!count[c]) continue;
-		if (!run.streams[c]) createStream(&run.streams[c], 0);
-		HIP_CHECK(hipStreamWaitEvent(run.streams[c], run.ready, 0));
-		if (c < 2) launchEditDistanceTeam(run.streams[c], c == 0 ? 3u : 2u, dPairs + begin[c], count[c], dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut + begin[c]);
-		else launchEditDistance(run.streams[c], 1u << (c - 2), dPairs + begin[c], count[c], dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut + begin[c]);
-		HIP_CHECK(hipMemcpyAsync(hOut + begin[c], dOut + begin[c], (size_t)count[c] * sizeof(int64_t), hipMemcpyDeviceToHost, run.streams[c]));
-	}
-	if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] edit distance classes (3 per wave, 2 per wave, units 1..16): %u %u %u %u %u %u %u\n", count[0], count[1], count[2], count[3], count[4], count[5], count[6]);
-}
-static void finishEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair* hPairs, int64_t* hOut, uint32_t nPairs, EdPair* dPairs, int64_t* dOut, const EdRead* dReads, const char* dBases,
-	const uint64_t* dEqMasks, const char* dLetters, const uint32_t* dLettersLen)
-{
-	if (!nPairs) return;
-	for (auto& q : run.streams) if (q) syncStream(q);
-	// reruns for the pairs whose band outgrew their unit (grouped order throughout)
-	std::vector<uint32_t> todo;
-	for (uint32_t i = 0; i < nPairs; i++) {
-		if (hOut[i] == -2) todo.push_back(i);   // (-3: the path letters overflowed their slot - stays, the caller flags the read)
-	}
-	std::vector<EdPair> sub;
-	std::vector<int64_t> subOut;
-	if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] edit distance reruns: %zu of %u pairs\n", todo.size(), nPairs);
-	// unit 0 here: the two-pairs-per-wave kernel for what the three-pairs-per-wave kernel handed back (its pairs come first in the grouped order)
-	for (uint32_t unit = 0; unit <= 16 && !todo.empty(); unit = unit ? unit * 2 : 1) {   // (unit 1 for what the two-pairs-per-wave kernel handed back)
-		std::vector<uint32_t> later;
-		if (unit == 0) {
-			std::vector<uint32_t> now;
-			for (uint32_t i : todo) (i < run.begin[1] ? now : later).push_back(i);
-			todo.swap(now);
-			if (todo.empty()) { todo.swap(later); continue; }
-		}
-		sub.resize(todo.size());
-		subOut.resize(todo.size());
-		// (what reaches unit U has failed every band below it: the team kernels' limits for U = 0 and 1, the limit of unit U / 2 otherwise - start there, not at the first guess)
-		const uint32_t failedBelow = unit == 0 ? editDistanceMaxK(0) - 1 : unit == 1 ? editDistanceMaxK(0) : editDistanceMaxK(unit / 2);
-		for (size_t i = 0; i < todo.size(); i++) { sub[i] = hPairs[todo[i]]; sub[i].k = std::max(sub[i].k, failedBelow); }
-		HIP_CHECK(hipMemcpyAsync(dPairs, sub.data(), sub.size() * sizeof(EdPair), hipMemcpyHostToDevice, stream));
-		launchEditDistance(stream, unit, dPairs, (uint32_t)sub.size(), dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut);
-		HIP_CHECK(hipMemcpyAsync(subOut.data(), dOut, sub.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-		syncStream(stream);
-		std::vector<uint32_t> next;
-		for (size_t i = 0; i < todo.size(); i++) { hOut[todo[i]] = subOut[i]; if (subOut[i] == -2) next.push_back(todo[i]); }
-		todo.swap(next);
-		todo.insert(todo.end(), later.begin(), later.end());
-	}
-	// still -2: the band is too wide for the NW kernel (a read longer than 65536 bases more than 32256 edits away from its path); the caller flags the read
-	// back to the caller's order
-	run.grouped.assign(hOut, hOut + nPairs);
-	for (uint32_t i = 0; i < nPairs; i++) hOut[run.perm[i]] = run.grouped[i];
-}
-
-template <typename T> T* copyOut(const std::vector<T>& v)
-{
-	T* p = mallocArray<T>(v.size());
-	if (!v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
-	return p;
-}
-
-} // namespace
+// The C entry points of include/graphchainer_amd.h except gc_align_batch (gc_batch.hip): graphs, seeders, index cache, read batches, streams, edit distances, output formats.
+#include "gc_runtime.hpp"
 
 extern "C" {
 
@@ -1274,13 +380,6 @@ void gc_params_default(gc_params* p)
 	p->device_output = 0;
 	p->e_cutoff = -1;
 	memset(&p->capacity, 0, sizeof(p->capacity));   // automatic
-}
-
-// One capacity: the GC_* environment variable (experiments, test hooks) wins over gc_params::capacity, 0 there means automatic.
-static int64_t capacityOr(const char* envName, int64_t param, int64_t automatic)
-{
-	if (const char* env = getenv(envName)) return atoll(env);
-	return param != 0 ? param : automatic;
 }
 
 int gc_graph_create_from_gfa(const char* gfa_path, gc_graph** out)
@@ -1764,1743 +863,5 @@ void gc_result_free(gc_result* r)
 //   fragmentPipeline -> resultsBack -> stitchAndChainDistances -> joinWholeReadPass -> chainedAlignments -> assemble.
 // Capacities are per read (flags in the result), errors of the reference's own making per read or fragment (failed_assertion); only invalid arguments and device errors fail
 // the call (they throw; gc_align_batch turns that into its return code, and ~BatchRun joins the pass thread first).
-struct BatchRun {
-	// ---- the call
-	const gc_graph* const G; const gc_seeder* const S; gc_stream* const st; const gc_reads* const R; const gc_params* const P; gc_result* const res;
-	const double tCall, cpuCall;
-	double cpuJoined;
-	const uint64_t n;                        // reads in the batch
-	const gc::AlignmentGraph& hg;
-	WorkerPool& pool;
-	std::vector<ReadGlue>& glue;             // per-read host records, storage reused across batches
-	const hipStream_t stream;                // the fragment pipeline's stream (the whole-read pass has st->longStream / st->groupStreams)
-	int evIdx = 0;
-	double tTotal = 0;
-	// ---- what the stages hand on (set by the stage named in the comment of each group)
-	// seeds()
-	bool deviceGlue = true;
-	double tGlue = 0;
-	uint64_t nSlots = 0, nFrags = 0, nSeedsTotal = 0, traceBudget = 0;
-	uint32_t maxSlotsPerRead = 1, maxWindowSeeds = 0;
-	Fragment* frags = nullptr; ReadChainJob* jobs = nullptr;                 // host copies
-	FragSeed* readSeeds = nullptr; uint32_t* fragFirstSeed = nullptr;        // host copies (device glue: only with keep_seeds / keep_traces)
-	Fragment* dFrags = nullptr; uint32_t* dFragFirstSeed = nullptr; FragSeed* dReadSeeds = nullptr; ReadChainJob* dJobs = nullptr;
-	LongSeed* dLongSeeds = nullptr;
-	hipEvent_t glueCopied = nullptr;   // device glue: the host copies of frags / seeds have arrived (waited for before the result assembly)
-	double tOrdered = 0;
-	unsigned long long* hSmall = nullptr;
-	unsigned long long* dCursors = nullptr;
-	unsigned long long* dCounters = nullptr;
-	// prepareWholeReadPass()
-	uint32_t maxAlignments = 0;
-	LongAln* hLongAlns = nullptr;
-	unsigned long long* hLongSmall = nullptr;
-	LongReadResult* hLongResults = nullptr;
-	LongCell* dLongCells = nullptr;
-	uint64_t cellBudget = 0;                      // capacity of the merged-trace cell pool (grown and the pass rerun when a batch overflows it)
-	unsigned long long* longScratchOfToken = nullptr;   // the device's shared extension scratch, set by the pass once it holds the token
-	// r4: the token is taken when the pass's FIRST extension kernel is about to be queued and given back when the last round's count (zero) has come down: a pass's first
-	// init / select / order / publish and the host's wait for the work count (each a launch that queues among the other batches' kernels), and its k_long_finish at the
-	// end, no longer sit between two passes' extension kernels (GC_LONG_TOKEN_EARLY=1: around the whole pass, as before)
-	std::function<void()> longTokenTake, longTokenDrop;
-	uint64_t longScratchWords = 0;
-	bool shareLongScratch = false;
-	uint32_t longGroups = 0;
-	std::vector<double> groupExtendUs; std::vector<uint32_t> groupRounds; std::vector<uint64_t> groupBegin, groupTraceBegin;   // (the pass thread works through pointers into these)
-	const gc::EValueModel evalueModel { 0.7 };   // src/Aligner.cpp:478-482 (precise clipping is out of scope)
-	struct DecisionPointers { EdPair* hPairs = nullptr; int64_t* hOut = nullptr; EdPair* dPairs = nullptr; int64_t* dOut = nullptr; char* dLetters = nullptr; uint32_t* dLettersLen = nullptr; } decisionPtr[2];
-	bool longPostInThread = false;
-	// ... the whole-read pass's own buffers and sizes (prepareWholeReadPass sets them; runLongGroup / growLongCells / longFallback / finishLongGroups run on the pass thread)
-	LongJob* hJobs = nullptr;
-	bool cellPoolPinned = 0;
-	uint64_t waveWords = 0;
-	LongJob* dLongJobs = nullptr;
-	LongAln* dLongAlns = nullptr;
-	uint32_t nGroups = 0;
-	uint32_t cursorWords = 0;
-	unsigned long long* dLongCursor = nullptr;
-	LongState* dLongState = nullptr;
-	LongWork* dLongWork = nullptr;
-	LongWorkResult* dLongWorkResults = nullptr;
-	uint32_t* dCandSeed = nullptr;
-	uint32_t* dWorkLen = nullptr;
-	uint32_t* dRetryList = nullptr;
-	uint32_t* dOrder = nullptr;
-	unsigned long long* dRoundTrace = nullptr;
-	uint64_t scratchLanes = 0;
-	hipStream_t ls = nullptr;
-	ExtendConfig lcfg;
-	unsigned long long* dLongScratchOwn = nullptr;   // (this stream's own scratch: only without the one-pass-at-a-time token)
-	uint64_t maxReadLen = 1;
-	// startWholeReadPass()
-	std::vector<std::thread> longThreads;
-	std::vector<std::exception_ptr> longErrors;
-	double tLongWall0 = 0;
-	std::atomic<double> longWallBeginUs { 0.0 };   // when the pass got the device's token (waiting for another batch's pass is not its own time)
-	std::atomic<double> longWallEndUs { 0.0 };
-	// fragmentPipeline()
-	double tDev = 0;
-	uint32_t nWork = 0;
-	ExtResult* dResults = nullptr;
-	TraceCell* dTrace = nullptr;
-	AnchorRec* dAnchors = nullptr;
-	uint32_t* dFragStatus = nullptr;
-	uint32_t* dFragExtended = nullptr;
-	uint64_t pathCapacity = 0;
-	uint32_t* dPathPool = nullptr;
-	uint32_t* dChainOut = nullptr;
-	uint32_t* dChainLen = nullptr;
-	unsigned long long* dChainScore = nullptr;
-	uint32_t* dChainStatus = nullptr;
-	bool deviceStitch = false;
-	StitchInfo* stitchInfo = nullptr;
-	uint32_t* hStitchNodes = nullptr;
-	uint32_t* dStitchNodes = nullptr;
-	uint64_t stitchDenseCap = 0;
-	unsigned long long* hStitchCursor = nullptr;
-	// resultsBack()
-	AnchorRec* anchors = nullptr;
-	uint32_t* fragStatus = nullptr;
-	uint32_t* fragExtended = nullptr;
-	uint32_t* chainOut = nullptr;
-	uint32_t* chainLen = nullptr;
-	unsigned long long* chainScore = nullptr;
-	uint32_t* chainStatus = nullptr;
-	uint32_t* pathPool = nullptr;
-	std::vector<ExtResult> extResults;
-	std::vector<TraceCell> tracePool;
-	bool anchorTraces = false;
-	bool stitchNodesPending = false;
-	// stitchAndChainDistances()
-	const PathSeqJob* chainLetterJobs = nullptr;   // per read: where its stitched path's letters are in dChainLetters
-	const char* dChainLetters = nullptr;
-	// joinWholeReadPass()
-	double tJoined = 0;
-	const LongCell* longCells = nullptr;   // keep_traces: the merged traces in pinned staging (a pageable destination made this copy 2-3 s per 10 k reads)
-
-	BatchRun(const gc_graph* G, const gc_seeder* S, gc_stream* st, const gc_reads* R, const gc_params* P, gc_result* res, double tCall, double cpuCall)
-		: G(G), S(S), st(st), R(R), P(P), res(res), tCall(tCall), cpuCall(cpuCall), cpuJoined(cpuCall), n(R->offsets.size() - 1), hg(G->host), pool(WorkerPool::instance()), glue(st->glue),
-		  stream(st->stream), longErrors(16) {}
-	~BatchRun() { for (auto& t : longThreads) if (t.joinable()) t.join(); }   // (an exception on the main thread must not leave the pass thread behind with dangling state)
-	BatchRun(const BatchRun&) = delete;
-	BatchRun& operator=(const BatchRun&) = delete;
-
-	void mark() { HIP_CHECK(hipEventRecord(st->ev[evIdx++], stream)); }
-	double elapsedUs(int a, int b) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, st->ev[a], st->ev[b])); return (double)ms * 1000.0; }
-
-	void run()
-	{
-		res->n_reads = n;
-		tTotal = nowUs();
-		seeds();
-		prepareWholeReadPass();
-		startWholeReadPass();
-		fragmentPipeline();
-		resultsBack();
-		stitchAndChainDistances();
-		joinWholeReadPass();
-		chainedAlignments();
-		encodeOutput();
-		assemble();
-	}
-
-	// ---------------- K1 seed lookup, then the glue between it and the extension kernels (on the device; GC_DEVICE_GLUE=0: on the host)
-	void seeds()
-	{
-		// ---------------- K1: seed lookup
-		uint32_t* dTmp = st->tmp.reserve<uint32_t>(R->totalBases);
-		uint2* dMatches = st->matches.reserve<uint2>(R->totalBases);
-		uint32_t* dReadMatchOff = st->readMatchOff.reserve<uint32_t>(n);
-		uint32_t* dReadMatchCount = st->readMatchCount.reserve<uint32_t>(n);
-		dCursors = st->cursors.reserve<unsigned long long>(8);
-		dCounters = st->counters.reserve<unsigned long long>(8);
-		hSmall = st->hSmall.reserve<unsigned long long>(16 + 2 * n);
-		uint32_t* readMatchOff = (uint32_t*)(hSmall + 16);
-		uint32_t* readMatchCount = readMatchOff + n;
-		HIP_CHECK(hipMemsetAsync(dCursors, 0, 8 * sizeof(unsigned long long), stream));
-		HIP_CHECK(hipMemsetAsync(dCounters, 0, 8 * sizeof(unsigned long long), stream));
-		mark();   // 0
-		launchSeedLookup(stream, S->dev, R->devBases, R->devOffsets, (uint32_t)n, (uint64_t*)dCursors, dReadMatchOff, dReadMatchCount, dMatches, R->totalBases, dTmp, R->totalBases, R->devChunkRead, R->devPacked, R->devInvalid);
-		mark();   // 1
-		// The glue between the seed lookup and the extension kernels (hit expansion, seed ordering, fragment windows) runs on the device
-		// (gc_seedglue.hip: one wave per read, the reference's three unstable sorts replayed with libstdc++'s own algorithm); GC_DEVICE_GLUE=0
-		// keeps the r2 host path (host/gc_glue.cpp: same results, 1 CPU-second and two bulk transfers per 10 k reads).
-		deviceGlue = !(getenv("GC_DEVICE_GLUE") && atoi(getenv("GC_DEVICE_GLUE")) == 0);
-		if (glue.size() < n) glue.resize(n);
-		gc::KmerMatch* matches = nullptr;
-		tGlue = 0;
-		// what both paths leave behind for the rest of the batch
-		if (deviceGlue) {
-			unsigned long long* dGlueCursors = st->glueCursors.reserve<unsigned long long>(8);
-			uint32_t* dSeedCap = st->glueSeedCap.reserve<uint32_t>(n);
-			uint32_t* dSeedOff = st->glueSeedOff.reserve<uint32_t>(n + 1);
-			unsigned long long* hGlueSmall = st->hGlueSmall.reserve<unsigned long long>(8);
-			HIP_CHECK(hipMemsetAsync(dGlueCursors, 0, 8 * sizeof(unsigned long long), stream));
-			launchSeedCaps(stream, S->dev, (uint32_t)n, R->devReadInvalid, dMatches, dReadMatchOff, dReadMatchCount, dSeedCap, dSeedOff, dGlueCursors + 5);
-			HIP_CHECK(hipMemcpyAsync(hSmall, dCursors, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-			HIP_CHECK(hipMemcpyAsync(hGlueSmall, dGlueCursors, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-			// capacity of the per-read window staging: one window per fragment position (host: the lengths are known)
-			uint32_t* hWinCapOff = st->hGlueWinCapOff.reserve<uint32_t>(n + 1);
-			uint64_t winCap = 0;
-			for (uint64_t r = 0; r < n; r++) {
-				const uint64_t len = R->offsets[r + 1] - R->offsets[r];
-				hWinCapOff[r] = (uint32_t)winCap;
-				winCap += len >= (uint64_t)P->split_len ? (len - P->split_len) / P->split_gap + 1 : 1;
-			}
-			hWinCapOff[n] = (uint32_t)winCap;
-			if (winCap >= 0xffffffffull) throw std::runtime_error("batch too large: more than 2^32 fragment positions; split the batch");
-			uint32_t* dWinCapOff = st->glueWinCapOff.reserve<uint32_t>(n + 1);
-			HIP_CHECK(hipMemcpyAsync(dWinCapOff, hWinCapOff, (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-			syncStream(stream);
-			res->kernel_us[0] = elapsedUs(0, 1);
-			res->host_us[2] = nowUs() - tTotal;   // K1 + its transfers, wall
-			tGlue = nowUs();
-			const uint64_t nMatchesDev = hSmall[0], seedCap = hGlueSmall[5];
-			if (nMatchesDev > R->totalBases) throw std::runtime_error("seed lookup overflowed its buffer");
-			if (seedCap >= 0xfffffff0ull) throw std::runtime_error("batch too large: more than 2^32 seed occurrences; split the batch");
-			nSeedsTotal = seedCap;
-			GlueStaging stg;
-			uint32_t** u32s[8] = { &stg.mPos, &stg.mStartLo, &stg.mStartHi, &stg.sSeqPos, &stg.sNode, &stg.sOffset, &stg.sGood, &stg.sCluster };
-			for (int k = 0; k < 8; k++) *u32s[k] = st->glueU32[k].reserve<uint32_t>(seedCap);
-			stg.sortBuf = (GlueElem*)st->glueSort.reserve<uint8_t>(seedCap * glueElemBytes());
-			stg.posBuf = st->gluePos.reserve<uint32_t>(seedCap);
-			stg.winBuf = st->glueWin.reserve<uint32_t>(4 * winCap);
-			dLongSeeds = st->longSeeds.reserve<LongSeed>(P->long_pass ? seedCap : 0);
-			dReadSeeds = st->readSeeds.reserve<FragSeed>(seedCap);
-			dFrags = st->frags.reserve<Fragment>(winCap);
-			dFragFirstSeed = st->fragFirstSeed.reserve<uint32_t>(winCap);
-			dJobs = st->jobs.reserve<ReadChainJob>(n);
-			GlueRead* dGlueOut = st->glueOut.reserve<GlueRead>(n);
-			GlueRead* hGlueOut = st->hGlueOut.reserve<GlueRead>(n);
-			jobs = st->hJobs.reserve<ReadChainJob>(n);
-			launchSeedGlue(stream, S->dev, G->dev, R->devOffsets, (uint32_t)n, R->devReadInvalid, dMatches, dReadMatchOff, dReadMatchCount, dSeedOff, dWinCapOff, P->seed_density,
-				(uint32_t)P->split_len, (uint32_t)P->split_gap, P->long_pass != 0, stg, st->gluePerRead.reserve<uint32_t>(6 * (n + 1)), dLongSeeds, dReadSeeds, dFrags, dFragFirstSeed, dJobs, dGlueOut, dGlueCursors);
-			if (n) HIP_CHECK(hipMemcpyAsync(hGlueOut, dGlueOut, n * sizeof(GlueRead), hipMemcpyDeviceToHost, stream));
-			if (n) HIP_CHECK(hipMemcpyAsync(jobs, dJobs, n * sizeof(ReadChainJob), hipMemcpyDeviceToHost, stream));
-			HIP_CHECK(hipMemcpyAsync(hGlueSmall, dGlueCursors, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-			syncStream(stream);
-			nFrags = hGlueSmall[0]; nSlots = hGlueSmall[1]; traceBudget = hGlueSmall[2];
-			maxSlotsPerRead = (uint32_t)std::max<uint64_t>(1, hGlueSmall[3]); maxWindowSeeds = (uint32_t)hGlueSmall[4];
-			for (uint64_t r = 0; r < n; r++) {
-				ReadGlue& gl = glue[r];
-				gl.reset();
-				const GlueRead& g = hGlueOut[r];
-				gl.failed = g.failed != 0;
-				gl.nSeedsR = g.nSeeds; gl.nWindows = g.nFrags;
-				gl.seedBegin = g.seedOff; gl.longSeedBegin = g.seedOff;
-				gl.fragBegin = g.fragBegin; gl.slotBegin = g.slotBegin;
-			}
-			// host copies for the result assembly: the fragments always; the seeds only for the seed_* arrays / the anchor traces
-			frags = st->hFrags.reserve<Fragment>(nFrags);
-			if (nFrags) HIP_CHECK(hipMemcpyAsync(frags, dFrags, nFrags * sizeof(Fragment), hipMemcpyDeviceToHost, stream));
-			if (P->keep_seeds || P->keep_traces == 1) {
-				readSeeds = st->hReadSeeds.reserve<FragSeed>(seedCap);
-				fragFirstSeed = st->hFragFirstSeed.reserve<uint32_t>(nFrags);
-				if (seedCap) HIP_CHECK(hipMemcpyAsync(readSeeds, dReadSeeds, seedCap * sizeof(FragSeed), hipMemcpyDeviceToHost, stream));
-				if (nFrags) HIP_CHECK(hipMemcpyAsync(fragFirstSeed, dFragFirstSeed, nFrags * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-			}
-			glueCopied = st->ev[11];
-			HIP_CHECK(hipEventRecord(glueCopied, stream));
-		} else {
-		if (n) HIP_CHECK(hipMemcpyAsync(readMatchOff, dReadMatchOff, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		if (n) HIP_CHECK(hipMemcpyAsync(readMatchCount, dReadMatchCount, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipMemcpyAsync(hSmall, dCursors, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-		syncStream(stream);
-		uint64_t nMatches = hSmall[0];
-		matches = st->hMatches.reserve<gc::KmerMatch>(nMatches);
-		if (nMatches) HIP_CHECK(hipMemcpyAsync(matches, dMatches, nMatches * sizeof(uint2), hipMemcpyDeviceToHost, stream));
-		syncStream(stream);
-		res->kernel_us[0] = elapsedUs(0, 1);
-		res->host_us[2] = nowUs() - tTotal;   // K1 + its transfers, wall
-
-		// ---------------- host glue: order-critical sorts and fragment windows (see host/gc_glue.hpp)
-		tGlue = nowUs();
-		pool.run(n, [&](size_t r, size_t) { glue[r].reset(); });
-		std::vector<gc::GlueScratch> scratch(pool.size());
-		pool.run(n, [&](size_t r, size_t worker) {
-			ReadGlue& gl = glue[r];
-			size_t len = R->offsets[r + 1] - R->offsets[r];
-			if (R->invalid[r]) { gl.failed = true; return; }
-			gc::expandSeeds(S->host, matches + readMatchOff[r], readMatchCount[r], len, P->seed_density, gl.seeds, scratch[worker]);
-			if (gl.seeds.empty()) return;
-			if (!gc::orderSeedsByChaining(hg, gl.seeds, scratch[worker])) {
-				gl.failed = true;
-				gl.seeds.clear();
-				return;
-			}
-			if (P->long_pass) gl.longSeeds = gl.seeds;
-		});
-		}
-		tOrdered = nowUs();
-	}
-
-	// ---------------- K3-long set-up: buffers, the round loop (runLongGroup), the rerun rules; nothing runs yet
-	void prepareWholeReadPass()
-	{
-		// ---------------- K3-long: whole-read pass on its own stream (src/Aligner.cpp:630-654)
-		uint64_t nLongSeeds = 0;
-		maxReadLen = 1;
-		for (uint64_t r = 0; r < n; r++) maxReadLen = std::max<uint64_t>(maxReadLen, R->offsets[r + 1] - R->offsets[r]);
-		// alignments kept per read: the reference has no limit; 32 is far above what 10 kb reads produce (3.6 seeds extended on average), longer
-		// and noisier reads get room in proportion. A read that still exceeds it is flagged (capacity_exceeded), the batch goes on.
-		maxAlignments = (uint32_t)std::max<uint64_t>(32, maxReadLen / 512);
-		// Decision for a set of reads whose whole-read alignments are final: the reference's alignment order, the GreedyLength
-		// selection, and (queued, not awaited) the path letters + NW edit distance of the best alignment. (Tried: deciding the
-		// reads that are already finished when the rounds turn latency-bound, so these kernels run beside the last rounds - the
-		// rounds slow down by more than the 11 ms the tail saves: 304-319 -> 318-337 ms per batch. So: all reads, after the rounds.)
-		if (P->long_pass) {
-			if (deviceGlue) nLongSeeds = nSeedsTotal;   // (the device's seed lists sit at the reads' capacity offsets)
-			else for (uint64_t r = 0; r < n; r++) { glue[r].longSeedBegin = nLongSeeds; nLongSeeds += glue[r].longSeeds.size(); }
-			if (nLongSeeds >= 0xffffffffull) throw std::runtime_error("batch too large for the whole-read pass");
-			LongSeed* hSeeds = st->hLongSeeds.reserve<LongSeed>(deviceGlue ? 0 : nLongSeeds);
-			hJobs = st->hLongJobs.reserve<LongJob>(n);
-			// merged-trace cells per read base: 8 hold the few partial alignments a 10 kb ONT read collects before its end-to-end one (cfg2 uses ~1.1);
-			// noisy 50 kb CLR reads on a genome with repeats collect 8-9 alignments each and overflowed it (a quarter of the reads flagged, which reads
-			// depending on timing). The stream remembers what its batches needed, and a batch that overflows reruns its pass with three times the room.
-			cellPoolPinned = getenv("GC_LONG_CELLS_PER_BASE") || P->capacity.long_cells_per_base > 0;
-			const uint64_t cellsPerBase = (uint64_t)std::max<int64_t>(2, capacityOr("GC_LONG_CELLS_PER_BASE", P->capacity.long_cells_per_base, (int64_t)st->longCellsPerBase));
-			cellBudget = cellBudgetFor(cellsPerBase);
-			pool.run(n, [&](size_t r, size_t) {
-				const ReadGlue& gl = glue[r];
-				uint64_t at = gl.longSeedBegin;
-				if (deviceGlue) at += gl.nSeedsR;
-				else for (const gc::SeedRec& s : gl.longSeeds) {
-					hSeeds[at++] = LongSeed { s.node, s.seqPos, s.goodness, s.clusterSize, s.offset, 0 };
-				}
-				LongJob& j = hJobs[r];
-				j.maskOff = R->maskOff[r];
-				j.maskWords = R->maskWords[r];
-				j.pad = 0;
-				j.readOff = R->offsets[r];
-				j.readLen = (uint32_t)(R->offsets[r + 1] - R->offsets[r]);
-				j.seedBegin = (uint32_t)gl.longSeedBegin;
-				j.seedEnd = (uint32_t)at;
-				j.alnBegin = (uint32_t)(r * maxAlignments);
-			});
-			lcfg.bandwidth = P->bandwidth;
-			lcfg.maxSlices = (uint32_t)(maxReadLen / 64 + 3);
-			lcfg.maxItems = (uint32_t)std::max<uint64_t>(8192, (maxReadLen / 64 + 3) * 24);   // (slice, node) tiles of one extension: ~8 per slice on cfg2, room for 24
-			lcfg.maxPending = 96;
-			lcfg.maxTrace = (uint32_t)(maxReadLen + maxReadLen / 2 + 512);
-			// column store of the one-extension-per-wave kernel: the DP keeps every column (16 B) so that the backtrace loads its tiles' columns back instead of
-			// recomputing them (45 % of the kernel's column steps). ~2.1 columns per read row on cfg2; an extension that needs more than this room ends
-			// with EXT_OVERFLOW and its read goes to the plain-layout kernel, which recomputes. GC_LONG_MAX_COLS=0: no store (the r2 behaviour).
-			lcfg.maxCols = (uint32_t)std::max<int64_t>(0, capacityOr("GC_LONG_MAX_COLS", P->capacity.long_column_store, (int64_t)(3 * maxReadLen + 4096)));   // (-1 in the parameters, 0 in the environment: no store)
-			lcfg.maxItems = (uint32_t)std::max<int64_t>(64, capacityOr("GC_LONG_MAX_ITEMS", P->capacity.long_max_items, lcfg.maxItems));
-			if (const char* env = getenv("GC_LONG_REG_CAP")) lcfg.regCap = (uint32_t)std::max(1, std::min(64, atoi(env)));   // test hook: force the LDS-table retry
-			waveWords = longWaveWordsPerLane(lcfg);
-			if (!deviceGlue) dLongSeeds = st->longSeeds.reserve<LongSeed>(nLongSeeds);
-			dLongJobs = st->longJobs.reserve<LongJob>(n);
-			dLongAlns = st->longAlns.reserve<LongAln>(n * maxAlignments);
-			LongReadResult* dLongResults = st->longResults.reserve<LongReadResult>(n);
-			dLongCells = st->longCells.reserve<LongCell>(cellBudget);
-			// Read groups: the rounds of one group are serial (select -> extend -> merge, host decides when to stop). Groups can
-			// run their round loops concurrently, each on its own stream and host thread (GC_LONG_GROUPS). Measured on cfg2
-			// (10k reads): 1 group 367 ms/step, 2 groups 517, 4 groups 477, 8 groups 607 - the groups' big rounds coincide and
-			// their tails too, so nothing overlaps usefully and the kernels slow each other down. Default: one group.
-			nGroups = 1;
-			if (const char* env = getenv("GC_LONG_GROUPS")) nGroups = (uint32_t)std::max(1, std::min(16, atoi(env)));
-			if (n < 64ull * nGroups) nGroups = 1;
-			while (st->groupStreams.size() < nGroups) {
-				hipStream_t q = nullptr;
-				createStream(&q, 1);
-				st->groupStreams.push_back(q);
-				for (int k = 0; k < 2 * LONG_EVENT_RING; k++) { hipEvent_t e = nullptr; HIP_CHECK(hipEventCreate(&e)); st->groupEvents.push_back(e); }   // a ring of (begin, end) pairs around the rounds' extension launches
-			}
-			// cursors: [0] cell pool, [8..15] counters (+ [16..31] profiling stamps), per group g at 32+8g: [+0] work count, [+1] round trace cursor
-			cursorWords = 32 + 8 * 16;
-			dLongCursor = st->longCursor.reserve<unsigned long long>(cursorWords);
-			hLongAlns = st->hLongAlns.reserve<LongAln>(n * maxAlignments);
-			hLongResults = st->hLongResults.reserve<LongReadResult>(n);
-			hLongSmall = st->hLongSmall.reserve<unsigned long long>(cursorWords);
-			ls = st->longStream;
-			HIP_CHECK(hipMemsetAsync(dLongCursor, 0, cursorWords * sizeof(unsigned long long), ls));
-			if (nLongSeeds && !deviceGlue) HIP_CHECK(hipMemcpyAsync(dLongSeeds, hSeeds, nLongSeeds * sizeof(LongSeed), hipMemcpyHostToDevice, ls));
-			if (n) HIP_CHECK(hipMemcpyAsync(dLongJobs, hJobs, n * sizeof(LongJob), hipMemcpyHostToDevice, ls));
-			syncStream(ls);   // the group streams start from uploaded inputs
-			// rounds: select -> extend -> merge until no read has a seed left to extend (see gc_kernels.hip, "K3-long in rounds")
-			dLongState = st->longState.reserve<LongState>(n);
-			const uint64_t workCapacity = 8 * n + 64ull * nGroups;   // all groups together; group g owns the slice for its reads
-			dLongWork = st->longWork.reserve<LongWork>(workCapacity);
-			dLongWorkResults = st->longWorkResults.reserve<LongWorkResult>(workCapacity);
-			dCandSeed = st->longCandSeed.reserve<uint32_t>(2 * workCapacity);   // (two halves: k_long_round alternates them by the round's parity)
-			dWorkLen = st->longWorkLen.reserve<uint32_t>(workCapacity);   // written by k_long_select, sorted into dOrder by k_long_order: the host only
-			dRetryList = st->longRetryList.reserve<uint32_t>(workCapacity);   // work items whose band outgrew the register tables (per round)
-			dOrder = st->longOrder.reserve<uint32_t>(workCapacity);       // learns the round's work count (k_publish: no copy-engine transfer in the round loop)
-			groupBegin.assign(nGroups + 1, 0); groupTraceBegin.assign(nGroups + 1, 0);
-			for (uint32_t g = 0; g <= nGroups; g++) groupBegin[g] = n * g / nGroups;
-			for (uint32_t g = 0; g < nGroups; g++) {
-				uint64_t budget = 0;
-				for (uint64_t r = groupBegin[g]; r < groupBegin[g + 1]; r++) { uint64_t len = R->offsets[r + 1] - R->offsets[r]; budget += 4 * (len + len / 2 + 1024); }   // up to four candidate seeds' worth per read (the speculation rule below keeps rounds within it)
-				groupTraceBegin[g + 1] = groupTraceBegin[g] + budget;
-			}
-			dRoundTrace = st->longRoundTrace.reserve<unsigned long long>(groupTraceBegin[nGroups]);
-			// extension scratch: one region per lane of a resident wave (persistent waves fetch work items), per read group
-			// (bounded by a memory budget: 0.8 MB per lane for 10 kb reads, 2.4 MB for 50 kb reads; GC_LONG_SCRATCH_GB overrides the 48 GB)
-			uint64_t scratchBudget = P->capacity.long_scratch_bytes > 0 ? (uint64_t)P->capacity.long_scratch_bytes : (48ull << 30) / (uint64_t)longTokenCount();
-			if (const char* env = getenv("GC_LONG_SCRATCH_GB")) scratchBudget = (uint64_t)std::max(1, atoi(env)) << 30;
-			scratchLanes = std::min<uint64_t>(workCapacity + 64, std::max<uint64_t>(2048, std::min<uint64_t>(65536 + 64, scratchBudget / (waveWords * 8))));
-			// one pass at a time (the default) works in the device's shared scratch; the experiments that let passes overlap keep a scratch per stream
-			longScratchWords = (uint64_t)nGroups * scratchLanes * waveWords;
-			shareLongScratch = nGroups == 1 && (getenv("GC_LONG_TOKEN") ? atoi(getenv("GC_LONG_TOKEN")) : 1) >= 1;   // (token per pass or per round: whoever holds it owns the scratch)
-			if (!shareLongScratch) dLongScratchOwn = st->longScratch.reserve<unsigned long long>(longScratchWords);
-			groupExtendUs.assign(nGroups, 0.0);
-			groupRounds.assign(nGroups, 0);
-			longGroups = nGroups;
-			// reads whose band did not fit the LDS tables (status 5) are rerun with the plain-layout kernel
-		}
-		// What follows the rounds: fallback reruns, the reference's `cont` rule, selection and the NW distance of the best whole-read alignment.
-		// With one read group it runs on the pass's own thread right after the rounds, beside the tail of the fragment pipeline (which ends
-		// 20-30 ms after the pass on cfg2, starved by it), instead of after the join: 16 ms off the batch's critical path.
-		// It writes the reads' long* fields and capacityExceededLong only; the fragment pipeline does not touch those.
-		longPostInThread = P->long_pass && longGroups == 1;
-		// The whole-read pass is the longest leg of the batch: its round loop runs on its own host thread and stream from
-		// here on, while this thread prepares and runs the fragment pipeline.
-	}
-
-	uint64_t cellBudgetFor(uint64_t perBase) const { uint64_t b = 0; for (uint64_t r = 0; r < n; r++) b += perBase * (R->offsets[r + 1] - R->offsets[r]) + 1024; return b; }   // the merged-trace cell pool: cells per read base + slack per read
-
-	bool growLongCells()   // whole-read pass thread: the cell pool was too small -> enlarge it, reset the pass's cursors; false when it cannot grow
-	{
-		bool overflowed = false;
-		for (uint64_t r = 0; r < n && !overflowed; r++) overflowed = hLongResults[r].status == 4;
-		if (!overflowed || cellPoolPinned) return false;   // (a pinned pool flags the reads instead: the caller asked for that much and no more)
-		const uint64_t next = st->longCellsPerBase * 3;
-		if (next > 256 || cellBudgetFor(next) * sizeof(LongCell) > (64ull << 30)) return false;
-		st->longCellsPerBase = next;
-		cellBudget = cellBudgetFor(next);
-		dLongCells = st->longCells.reserve<LongCell>(cellBudget);
-		HIP_CHECK(hipMemsetAsync(dLongCursor, 0, cursorWords * sizeof(unsigned long long), ls));
-		syncStream(ls);
-		return true;
-	}
-
-	// The round loop without a host round trip per round (r4; an experiment, GC_LONG_ROUNDS=1 - see roundsOnDevice): per round ONE kernel between two extension launches - k_long_round: the previous round's merge,
-	// this round's select, the execution order, the work count to the device and to pinned host memory - and the extension kernel takes its item count from the device
-	// (its grid is sized by a bound: 2 items per read, which the device-side speculation rule respects). Rounds are queued several at a time; the host looks at the published
-	// counts only at the end of a chunk (a round after the last one finds nothing to do and costs a few empty launches). r3's loop queued zero / select / order / publish,
-	// waited for the count, then extend / retry / merge: with five batches in flight each of those launches waited for a wave slot among the other batches' kernels and the
-	// pass took 149 ms for 121 ms of extension kernels.
-	bool roundsOnDevice(uint32_t g) const
-	{
-		if (nGroups != 1 || longExtendTeamSize(1) != 1) return false;
-		for (const char* name : { "GC_LONG_SM", "GC_LONG_LANE", "GC_LONG_MAX_BLOCKS", "GC_LONG_PLAN" }) if (getenv(name)) return false;   // experiments and test hooks of the host-driven loop
-		if (getenv("GC_LONG_TOKEN") && atoi(getenv("GC_LONG_TOKEN")) == 2) return false;
-		if (!(getenv("GC_LONG_ROUNDS") && atoi(getenv("GC_LONG_ROUNDS")) == 1)) return false;   // GC_LONG_ROUNDS=1 selects it: measured 4-6 % SLOWER than the host-driven loop, which stays the default
-		(void)g;
-		return true;
-	}
-	void runLongGroupOnDevice(uint32_t g)
-	{
-		const uint64_t r0 = groupBegin[g], nG = groupBegin[g + 1] - r0;
-		if (longTokenTake) longTokenTake();   // (rounds are queued ahead here: the token covers the whole loop)
-		unsigned long long* dLongScratch = shareLongScratch ? longScratchOfToken : dLongScratchOwn;
-		hipStream_t q = st->groupStreams[g];
-		hipEvent_t* ring = st->groupEvents.data() + (size_t)2 * LONG_EVENT_RING * g;
-		auto collect = [&](int slot) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ring[2 * slot], ring[2 * slot + 1])); groupExtendUs[g] += (double)ms * 1000.0; };
-		const uint64_t w0 = 8 * r0 + 64ull * g, capacity = 8 * nG + 64;
-		unsigned long long* cursorSets = dLongCursor + 32 + 8 * g;   // two sets of four words: [0] work count, [1] round trace cursor, [2] next work slot, [3] length of the retry list
-		const uint64_t traceBudget = groupTraceBegin[g + 1] - groupTraceBegin[g];
-		const int MAX_ROUNDS = 250;
-		unsigned long long* dRoundInfo = st->longRoundInfo.reserve<unsigned long long>(MAX_ROUNDS + 8);   // [0] ticket, [1 + round] work items of the round
-		volatile unsigned long long* hInfo = st->hLongRoundInfo.reserve<unsigned long long>(MAX_ROUNDS + 8);   // [0] rounds published, [2 + round] work items of the round
-		hInfo[0] = 0;
-		const double dbgT0 = nowUs();
-		double dbgWaitUs = 0;
-		launchLongInit(q, dLongJobs + r0, (uint32_t)nG, dLongState + r0);
-		launchZeroWords(q, dRoundInfo, 1);
-		launchZeroWords(q, cursorSets, 8);
-		// the extension launch's grid: every lane of the scratch. Two items per read cover a round without speculation (a round never holds more items than the one before it),
-		// and the device-side rule keeps speculation within gridLimit; a batch whose 2 nG exceed the scratch's lanes runs persistent waves instead
-		const uint64_t laneLimit = std::max<uint64_t>(1, scratchLanes - 64);
-		const bool gridCovers = 2 * nG <= laneLimit;
-		const uint32_t gridLimit = (uint32_t)std::min<uint64_t>(capacity, laneLimit);   // (as many lanes as the scratch has: the late rounds' speculation rule may use them)
-		uint32_t forceCand = 0;
-		if (const char* env = getenv("GC_LONG_SPECULATE")) forceCand = (uint32_t)std::min(2, std::max(1, atoi(env)));   // test hook: speculate from round 0
-		const char* orderEnv = getenv("GC_LONG_ORDER");
-		const uint32_t orderMode = orderEnv ? (uint32_t)atoi(orderEnv) : 1u;
-		int queued = 0, timed = 0, done = -1;
-		while (done < 0 && queued < MAX_ROUNDS) {
-			const int chunk = queued == 0 ? 6 : 2;   // cfg2 needs six rounds; beyond that two at a time
-			for (int k = 0; k < chunk && queued < MAX_ROUNDS; k++, queued++) {
-				const uint32_t round = (uint32_t)queued;
-				unsigned long long* cur = cursorSets + 4 * (round & 1u);
-				launchLongRound(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, (uint32_t)P->min_cluster_size, round, forceCand, gridLimit, dLongState + r0, dLongAlns, dLongCells, dLongCursor, cellBudget, maxAlignments,
-					dLongWork + w0, dWorkLen + w0, dCandSeed + w0, dLongWorkResults + w0, dRoundTrace + groupTraceBegin[g], cursorSets, dRoundInfo + 1, dRoundInfo, dOrder + w0, (uint32_t)maxReadLen, orderMode,
-					(unsigned long long*)hInfo, capacity);
-				if (timed >= LONG_EVENT_RING) collect(timed % LONG_EVENT_RING);
-				hipEvent_t ev0 = ring[2 * (timed % LONG_EVENT_RING)], ev1 = ring[2 * (timed % LONG_EVENT_RING) + 1];
-				HIP_CHECK(hipEventRecord(ev0, q));
-				launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, gridCovers ? gridLimit : (uint32_t)std::min<uint64_t>(capacity, 0xffffffffull), dLongScratch + (uint64_t)g * scratchLanes * waveWords, 1, gridLimit,
-					dRoundTrace + groupTraceBegin[g], cur + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cur + 2, 0, cur, dRetryList + w0, cur + 3, gridCovers);
-				// extensions whose band outgrew the 64-entry register tables: second try with the LDS/HBM tables (two lanes per wave); the list is almost always empty
-				if (!gridCovers) launchZeroWords(q, cur + 2, 1);   // (persistent waves used the slot counter)
-				const uint32_t retryBlocks = std::min<uint32_t>(16, (uint32_t)std::max<uint64_t>(1, laneLimit / 2));
-				launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dRetryList + w0, (uint32_t)std::min<uint64_t>(capacity, 0xffffffffull), dLongScratch + (uint64_t)g * scratchLanes * waveWords, 2, retryBlocks,
-					dRoundTrace + groupTraceBegin[g], cur + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cur + 2, EXT_LDS_CAP, cur + 3);
-				HIP_CHECK(hipEventRecord(ev1, q));
-				timed++;
-			}
-			const double tWait0 = nowUs();
-			syncStream(q);
-			dbgWaitUs += nowUs() - tWait0;
-			if ((int)hInfo[0] != queued) throw std::runtime_error("internal: the whole-read rounds did not publish their counts");
-			for (int r = 0; r < queued && done < 0; r++) if (hInfo[2 + r] == 0) done = r;   // round `done` found no seed left to extend (its merge of the round before ran)
-		}
-		if (done < 0) throw std::runtime_error("whole-read pass: more rounds than the round loop queues");
-		groupRounds[g] += (uint32_t)done;
-		launchLongFinish(q, (uint32_t)nG, dLongState + r0, hLongResults + r0);
-		syncStream(q);
-		for (int k = std::max(0, timed - LONG_EVENT_RING); k < timed; k++) collect(k % LONG_EVENT_RING);
-		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] whole-read rounds (queued ahead): %.1f ms in all, %.1f ms waiting at the chunks' ends, %d rounds with work, %d queued\n", (nowUs() - dbgT0) / 1e3, dbgWaitUs / 1e3, done, queued);
-	}
-
-	void runLongGroup(uint32_t g)   // the round loop of one read group: select -> extend -> merge until no read has a seed left to extend (see gc_kernels.hip, "K3-long in rounds")
-	{
-		const uint64_t r0 = groupBegin[g], nG = groupBegin[g + 1] - r0;
-		if (nG == 0) return;
-		if (roundsOnDevice(g)) { runLongGroupOnDevice(g); return; }
-		unsigned long long* dLongScratch = nullptr;   // (set when the token is taken - before the first extension launch; round token: under the lock, every round)
-		hipStream_t q = st->groupStreams[g];
-		hipEvent_t* ring = st->groupEvents.data() + (size_t)2 * LONG_EVENT_RING * g;
-		// the rounds' extension time: read a ring slot's pair before the slot is reused (its round is complete by then: every round's
-		// work count has been awaited since) and what is left after the last round
-		auto collect = [&](int slot) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ring[2 * slot], ring[2 * slot + 1])); groupExtendUs[g] += (double)ms * 1000.0; };
-		int timedRounds = 0;
-		const uint64_t w0 = 8 * r0 + 64ull * g, capacity = 8 * nG + 64;   // this group's slice of the work arrays
-		unsigned long long* cursor = dLongCursor + 32 + 8 * g;
-		volatile unsigned long long* hCursor = hLongSmall + 32 + 8 * g;
-		const uint64_t traceBudget = groupTraceBegin[g + 1] - groupTraceBegin[g];
-		double dbgWaitUs = 0;
-		const double dbgT0 = nowUs();
-		launchLongInit(q, dLongJobs + r0, (uint32_t)nG, dLongState + r0);
-		uint32_t lastWork = 0xffffffffu;
-		// GC_LONG_TOKEN=2: the token (and with it the device's extension scratch) is held per round - from the moment a round's extension kernel is queued until
-		// that kernel has finished - so that the small kernels and the host round trip between two rounds of one batch run beside another batch's extension kernel
-		int deviceNow = 0;
-		HIP_CHECK(hipGetDevice(&deviceNow));
-		const bool roundToken = getenv("GC_LONG_TOKEN") && atoi(getenv("GC_LONG_TOKEN")) == 2;   // (read per batch: the tests switch modes inside one process)
-		std::unique_lock<std::mutex> roundLock(g_longRoundToken[deviceNow & 15], std::defer_lock);
-		hipEvent_t roundExtendDone = nullptr;
-
-		for (int round = 0; round < 4096; round++) {
-			launchZeroWords(q, cursor, 4);   // [0] work count, [1] round trace cursor, [2] next work slot, [3] length of the retry list
-			// tail rounds: once fewer than a quarter of the reads are still active the chip is mostly idle, so the
-			// remaining reads try several seeds per round (exact: k_long_merge re-checks them in order)
-			// (the number of work items stays below what round 0 had: active reads x candidates <= n)
-			uint32_t maxCand = 1;
-			if (round > 0 && lastWork > 0) maxCand = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, (2 * nG) / lastWork));
-			if (round > 0 && lastWork < 8192) maxCand = 8;   // fewer work items than wave slots: the round costs one extension's latency whatever it holds
-			// at most lastWork/2 reads are still active, so this keeps the round within the work arrays (8 per read) and the trace budget (4 seeds' worth per read)
-			if (round > 0 && lastWork > 0) maxCand = (uint32_t)std::min<uint64_t>(maxCand, std::max<uint64_t>(1, (8 * nG) / lastWork));
-			if (const char* env = getenv("GC_LONG_SPECULATE")) maxCand = (uint32_t)std::min(2, std::max(1, atoi(env)));   // test hook: speculate from round 0
-			// speculation plan (r4): candidates per read in rounds 0, 1, 2, ... (the last entry repeats), a floor under the rule above; still bounded by the work arrays
-			// and the trace budget (at most nG / 2... reads x candidates <= 4 nG). Why: rounds 3-5 of cfg2 hold fewer work items than the chip has wave slots and cost one
-			// extension's latency (~17 ms) each - 98 % of the reads extend a second seed and 81 % a third, so asking for two seeds per read from round 0 on
-			// merges rounds at a few per cent of wasted extensions (k_long_merge drops a candidate that an alignment accepted before it explains).
-			{
-				static const std::vector<int> plan = []() { std::vector<int> v; const char* e = getenv("GC_LONG_PLAN"); std::string t = e ? e : GC_LONG_PLAN_DEFAULT; size_t at = 0; while (at < t.size()) { v.push_back(std::max(1, std::min(8, atoi(t.c_str() + at)))); size_t c = t.find(',', at); if (c == std::string::npos) break; at = c + 1; } if (v.empty()) v.push_back(1); return v; }();
-				const uint32_t floorCand = (uint32_t)plan[std::min<size_t>((size_t)round, plan.size() - 1)];
-				const uint64_t active = round == 0 ? nG : std::max<uint64_t>(1, std::min<uint64_t>(nG, lastWork / 2));
-				if (!getenv("GC_LONG_SPECULATE")) maxCand = (uint32_t)std::min<uint64_t>(std::max(maxCand, floorCand), std::max<uint64_t>(1, (4 * nG) / active));
-			}
-			launchLongSelect(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, R->totalBases, (uint32_t)P->min_cluster_size, maxCand, dLongState + r0, dLongAlns, dLongCells, dLongWork + w0, dWorkLen + w0, dCandSeed + w0, cursor, capacity);
-			{
-				// execution order: longest extensions first, so the round's tail is made of short ones (GC_LONG_ORDER=0: as emitted)
-				const char* mode = getenv("GC_LONG_ORDER");
-				launchLongOrder(q, dWorkLen + w0, cursor, dOrder + w0, (uint32_t)maxReadLen, mode ? (uint32_t)atoi(mode) : 1u);
-			}
-			launchPublish(q, cursor, (unsigned long long*)hCursor, 2);
-			const double tWait0 = nowUs();
-			if (roundLock.owns_lock()) { syncEvent(roundExtendDone); roundLock.unlock(); }   // the previous round's extension kernel has finished: the merge and this round's set-up need no token
-			syncStream(q);
-			dbgWaitUs += nowUs() - tWait0;
-			uint32_t nWorkItems = (uint32_t)hCursor[0];
-			if (nWorkItems == 0) break;
-			if (!dLongScratch) {
-				if (longTokenTake) longTokenTake();
-				dLongScratch = shareLongScratch ? longScratchOfToken : dLongScratchOwn;
-			}
-			if (roundToken && nGroups == 1) {
-				roundLock.lock();
-				if (shareLongScratch) dLongScratch = g_longScratch[deviceNow & 15].buffer[0].reserve<unsigned long long>(longScratchWords);
-			}
-			uint32_t team = longExtendTeamSize(nWorkItems);
-			uint32_t blocks = std::min<uint32_t>((nWorkItems + team - 1) / team, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / team));
-			if (const char* env = getenv("GC_LONG_MAX_BLOCKS")) blocks = std::min<uint32_t>(blocks, (uint32_t)std::max(1, atoi(env)));   // test hook: force persistent waves
-			if (timedRounds >= LONG_EVENT_RING) collect(timedRounds % LONG_EVENT_RING);
-			hipEvent_t ev0 = ring[2 * (timedRounds % LONG_EVENT_RING)], ev1 = ring[2 * (timedRounds % LONG_EVENT_RING) + 1];
-			HIP_CHECK(hipEventRecord(ev0, q));
-			// GC_LONG_SM=1 (experiment, off by default: 6x slower as measured): one extension per LANE as per-lane state machines (k_long_extend_sm, gc_sm.hip);
-			// what outgrows that layout's tables (EXT_SM_DECLINED: more than 32 nodes in a slice, 16 pending, no room for the reserved trace)
-			// is listed and rerun one extension per wave, like the register-table overflows below
-#ifdef GC_EXPERIMENTS
-			const bool useSm = team == 1 && getenv("GC_LONG_SM") && atoi(getenv("GC_LONG_SM")) == 1;
-#else
-			const bool useSm = false;   // (the state-machine kernel is not part of the product library since r4: `make -C graphchainer_amd/csrc experiments` builds libgraphchainer_amd_exp.so with it)
-			if (getenv("GC_LONG_SM") && atoi(getenv("GC_LONG_SM")) == 1) throw std::runtime_error("GC_LONG_SM=1: the state-machine experiment is not in this build (make -C graphchainer_amd/csrc experiments; GC_LIBRARY=.../libgraphchainer_amd_exp.so)");
-#endif
-			// GC_LONG_LANE=1 (measurement, off by default): one extension per LANE with the plain-layout core and its band state in a per-lane HBM slab
-			const bool useLane = !useSm && team == 1 && getenv("GC_LONG_LANE") && atoi(getenv("GC_LONG_LANE")) == 1;
-#ifdef GC_EXPERIMENTS
-			if (useSm) {
-				launchLongExtendSm(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, (uint8_t*)(dLongScratch + (uint64_t)g * scratchLanes * waveWords), scratchLanes * waveWords * 8,
-					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2);
-				launchZeroWords(q, cursor + 2, 2);   // [2] next slot, [3] length of the list
-				launchLongRetryList(q, dLongWorkResults + w0, nWorkItems, 6u /* EXT_SM_DECLINED */, dRetryList + w0, cursor + 3);
-				const uint32_t declinedBlocks = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nWorkItems, 8192), std::max<uint64_t>(1, scratchLanes - 64));
-				launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dRetryList + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 1, declinedBlocks,
-					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, 6u, cursor + 3);
-			} else
-#endif
-			if (useLane) {
-				launchLongExtendLane(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, (uint8_t*)(dLongScratch + (uint64_t)g * scratchLanes * waveWords), scratchLanes * waveWords * 8,
-					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8);
-			} else
-			launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, team, blocks,
-				dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, 0, nullptr, team == 1 ? dRetryList + w0 : nullptr, cursor + 3);
-			if (team == 1 && !useLane) {
-				// extensions whose band outgrew the 64-entry register tables: second try with the LDS/HBM tables (two lanes per wave,
-				// 28 + 228 entries); waves whose items are fine leave at once. Beyond that the read goes to the plain-layout fallback.
-				// (those items are listed first - almost always none - so that the retry is a handful of waves that fetch from the list, not
-				// one wave per pair of work items that looks at a status and leaves: that cost 0.5-2 ms of every round)
-				if (useSm || (uint64_t)blocks * team < nWorkItems) {   // (the list is the extension kernel's own, unless the state-machine path or persistent waves used the slot counter)
-					launchZeroWords(q, cursor + 2, useSm ? 2 : 1);   // [2] next slot, [3] length of the retry list
-					if (useSm) launchLongRetryList(q, dLongWorkResults + w0, nWorkItems, EXT_LDS_CAP, dRetryList + w0, cursor + 3);
-				}
-				uint32_t retryBlocks = std::min<uint32_t>(16, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / 2));   // (persistent waves over a list that is almost always empty)
-				launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dRetryList + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 2, retryBlocks,
-					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, EXT_LDS_CAP, cursor + 3);
-			}
-			HIP_CHECK(hipEventRecord(ev1, q));
-			roundExtendDone = ev1;
-			launchLongMerge(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, dCandSeed + w0, dLongWorkResults + w0, dRoundTrace + groupTraceBegin[g], maxAlignments, dLongState + r0, dLongAlns, dLongCells, dLongCursor, cellBudget);
-			lastWork = nWorkItems;
-			// no wait here: the next round's select / order / publish queue up right behind the merge, and the only host round trip per
-			// round is the work count above (with a second wait after the merge the stream drained twice per round, and each refill
-			// waited behind whatever other batches had queued on the device)
-			timedRounds++;
-			groupRounds[g]++;
-		}
-		// (the last round's count has come down: every extension kernel of the pass is complete, the scratch is free)
-		if (longTokenDrop) longTokenDrop();
-		// the per-read results go straight into pinned host memory (the kernel writes them across PCIe): a copy-engine transfer here queued behind
-		// the other batch's bulk downloads for 30-50 ms while this pass still held the device's whole-read token
-		launchLongFinish(q, (uint32_t)nG, dLongState + r0, hLongResults + r0);
-		const double dbgT1 = nowUs();
-		syncStream(q);
-		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] whole-read rounds: %.1f ms in all, %.1f ms waiting for the rounds' work counts, %.1f ms in the last wait, %d rounds\n", (nowUs() - dbgT0) / 1e3, dbgWaitUs / 1e3, (nowUs() - dbgT1) / 1e3, timedRounds);
-		for (int k = std::max(0, timedRounds - LONG_EVENT_RING); k < timedRounds; k++) collect(k % LONG_EVENT_RING);
-	}
-
-	void finishLongGroups()   // after the group threads joined
-	{
-		double us = 0; uint32_t rounds = 0;
-		for (uint32_t g = 0; g < nGroups; g++) { us += groupExtendUs[g]; rounds = std::max(rounds, groupRounds[g]); }
-		res->kernel_us[4] = us;
-		res->counters_long[6] = rounds;
-	}
-
-	uint64_t longFallback()   // reads whose band did not fit the wave layout's tables are rerun with the plain-layout kernel; returns how many
-	{
-		syncStream(ls);
-		std::vector<uint32_t> redo;
-		const bool forceAll = getenv("GC_LONG_FORCE_FALLBACK") != nullptr;   // test hook: run every read through the plain-layout kernel too
-		// status 5: a slice with more nodes than the wave tables hold; status 2: an extension with more tiles / trace cells than its scratch
-		// (the plain-layout kernel below gets four times the room)
-		for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status == 5 || hLongResults[r].status == 2 || forceAll) redo.push_back((uint32_t)r);
-		if (!redo.empty()) {
-			std::vector<LongJob> subJobs(redo.size());
-			for (size_t i = 0; i < redo.size(); i++) subJobs[i] = hJobs[redo[i]];
-			ExtendConfig fcfg = lcfg;
-			fcfg.maxItems = 4 * lcfg.maxItems; fcfg.maxTrace = 2 * lcfg.maxTrace; fcfg.maxPending = 4 * lcfg.maxPending;
-			uint64_t lslab = longSlabBytes(fcfg);
-			uint64_t lanes = (redo.size() + 63) / 64 * 64;
-			LongJob* dSubJobs = st->longJobsFallback.reserve<LongJob>(redo.size());
-			LongReadResult* dSubResults = st->longResultsFallback.reserve<LongReadResult>(redo.size());
-			uint8_t* dSlab = st->longScratchFallback.reserve<uint8_t>(lanes * lslab);
-			HIP_CHECK(hipMemcpyAsync(dSubJobs, subJobs.data(), redo.size() * sizeof(LongJob), hipMemcpyHostToDevice, ls));
-			launchLongPass(ls, G->dev, G->devTables, G->devIupac, fcfg, dSubJobs, (uint32_t)redo.size(), dLongSeeds, R->devBases, R->totalBases, (uint32_t)P->min_cluster_size, maxAlignments,
-				dSlab, lslab, dLongCells, dLongCursor, cellBudget, dLongAlns, dSubResults, dLongCursor + 8);
-			std::vector<LongReadResult> subResults(redo.size());
-			HIP_CHECK(hipMemcpyAsync(subResults.data(), dSubResults, redo.size() * sizeof(LongReadResult), hipMemcpyDeviceToHost, ls));
-			syncStream(ls);
-			for (size_t i = 0; i < redo.size(); i++) hLongResults[redo[i]] = subResults[i];
-		}
-		if (n) HIP_CHECK(hipMemcpyAsync(hLongAlns, dLongAlns, n * maxAlignments * sizeof(LongAln), hipMemcpyDeviceToHost, ls));
-		HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
-		syncStream(ls);
-		return (uint64_t)redo.size();
-	}
-
-	// selection of a subset of reads' whole-read alignments and the NW distance of the best one (src/Aligner.cpp:636-654): launch ...
-	void decideLongReads(const std::vector<uint32_t>& subset, int slot, hipStream_t q, const std::function<uint32_t(uint32_t)>& nAlnOf, bool usePool = true)
-	{
-		// the reference re-sorts its alignment list by alignmentStart after every accepted alignment
-		// (src/GraphAligner.h:183); replaying that on the acceptance-ordered list gives its final order. Then the
-		// GreedyLength selection (src/Aligner.cpp:636-639, src/AlignmentSelection.cpp:12-50) with the same unstable sort.
-		auto selectOne = [&](size_t i, size_t) {
-			const uint32_t r = subset[i];
-			ReadGlue& gl = glue[r];
-			gl.longAlns.clear();
-			gl.longSelected.clear();
-			const uint32_t nAln = nAlnOf(r);
-			for (uint32_t a = 0; a < nAln; a++) {
-				gl.longAlns.push_back(hLongAlns[(uint64_t)r * maxAlignments + a]);
-				std::sort(gl.longAlns.begin(), gl.longAlns.end(), [](const LongAln& l, const LongAln& rr) { return l.start < rr.start; });
-			}
-			struct Item { uint32_t start, end, score, index; };
-			std::vector<Item> sorted;
-			const size_t readLen = R->offsets[r + 1] - R->offsets[r];
-			for (uint32_t a = 0; a < gl.longAlns.size(); a++) {
-				// --E-cutoff: SelectECutoff runs before the greedy selection and keeps the list's order (src/AlignmentSelection.cpp:57-61,91-99)
-				if (!evalueModel.keeps(P->e_cutoff, hg.SizeInBP(), readLen, gl.longAlns[a].end - gl.longAlns[a].start, gl.longAlns[a].score)) continue;
-				sorted.push_back(Item { gl.longAlns[a].start, gl.longAlns[a].end, gl.longAlns[a].score, a });
-			}
-			std::sort(sorted.begin(), sorted.end(), [](const Item& l, const Item& rr) {
-				if ((l.end - l.start) > (rr.end - rr.start)) return true;
-				if ((rr.end - rr.start) > (l.end - l.start)) return false;
-				return l.score < rr.score;
-			});
-			auto incompatible = [](const Item& l, const Item& rr) {
-				float minOverlapLen = std::min(l.end - l.start, rr.end - rr.start) * 0.05f;
-				size_t ls = l.start, le = l.end, rs = rr.start, re = rr.end;
-				if (ls > rs) { std::swap(ls, rs); std::swap(le, re); }
-				int overlap = 0;
-				if (le > rs) overlap = (int)(le - rs);
-				return overlap > minOverlapLen;
-			};
-			std::vector<Item> kept;
-			for (const Item& it : sorted) {
-				bool ok = true;
-				for (const Item& k : kept) if (incompatible(it, k)) { ok = false; break; }
-				if (ok) { kept.push_back(it); gl.longSelected.push_back(it.index); }
-			}
-		};
-		if (usePool) pool.run(subset.size(), selectOne); else for (size_t i = 0; i < subset.size(); i++) selectOne(i, 0);
-		auto& D = st->edLong[slot];
-		D.nPairs = 0;
-		D.pairRead.clear();
-		if (!P->edit_distances || subset.empty()) return;
-		// edit distance of the best whole-read alignment's path against the read (edlibAlign at src/Aligner.cpp:645)
-		const size_t m = subset.size();
-		PathSeqJob* hJobsPS = D.hJobs.reserve<PathSeqJob>(m);
-		EdPair* hPairs = D.hPairs.reserve<EdPair>(m);
-		int64_t* hOut = D.hOut.reserve<int64_t>(m);
-		uint64_t nLetters = 0;
-		uint32_t nPairs = 0;
-		for (size_t i = 0; i < m; i++) {
-			const uint32_t r = subset[i];
-			const ReadGlue& gl = glue[r];
-			if (gl.longSelected.empty()) { hJobsPS[i] = PathSeqJob { 0, nLetters, 0, 0, 0, 0 }; continue; }
-			const LongAln& al = gl.longAlns[gl.longSelected[0]];
-			uint32_t len = (uint32_t)(R->offsets[r + 1] - R->offsets[r]);
-			uint32_t cap = 2 * al.traceLen + 256;
-			hJobsPS[i] = PathSeqJob { al.traceOff, nLetters, al.traceLen, cap, 0, 0 };
-			// the alignment itself bounds the distance: its edits plus the unaligned read ends
-			hPairs[nPairs++] = EdPair { nLetters, 0, (uint32_t)i, r, al.score + al.start + (len - std::min(len, al.end)) + 8 };
-			D.pairRead.push_back(r);
-			nLetters += cap;
-		}
-		PathSeqJob* dJobsPS = D.jobs.reserve<PathSeqJob>(m);
-		char* dLetters = D.letters.reserve<char>(nLetters);
-		uint32_t* dLettersLen = D.lettersLen.reserve<uint32_t>(m);
-		EdPair* dPairs = D.pairs.reserve<EdPair>(m);
-		int64_t* dOut = D.out.reserve<int64_t>(m);
-		HIP_CHECK(hipMemcpyAsync(dJobsPS, hJobsPS, m * sizeof(PathSeqJob), hipMemcpyHostToDevice, q));
-		launchLongPathSeq(q, G->dev, dJobsPS, (uint32_t)m, dLongCells, dLetters, dLettersLen);
-		auto readLenOf = [R = R](uint32_t r) { return (uint32_t)(R->offsets[r + 1] - R->offsets[r]); };
-		launchEditDistances(D.run, q, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen, readLenOf, true);   // (k: the alignment's own bound)
-		D.nPairs = nPairs;
-		decisionPtr[slot] = DecisionPointers { hPairs, hOut, dPairs, dOut, dLetters, dLettersLen };
-	}
-
-	// ... and collect
-	void finishLongDecision(int slot)
-	{
-		auto& D = st->edLong[slot];
-		if (!D.nPairs) return;
-		const DecisionPointers& p = decisionPtr[slot];
-		finishEditDistances(D.run, st->longStream, p.hPairs, p.hOut, D.nPairs, p.dPairs, p.dOut, R->devEdReads, R->devBases, R->devEqMasks, p.dLetters, p.dLettersLen);
-		for (uint32_t i = 0; i < D.nPairs; i++) {
-			ReadGlue& gl = glue[D.pairRead[i]];
-			gl.longEditDistance = p.hOut[i];
-			if (p.hOut[i] < -1) { gl.longEditDistance = -1; gl.capacityExceededLong = true; }   // outside the NW kernel's range: flagged, no distance
-		}
-		D.nPairs = 0;
-	}
-
-	// What follows the rounds: fallback reruns, the reference's `cont` rule, selection and the NW distance of the best whole-read alignment.
-	void afterLongPass()
-	{
-		uint64_t rerun = longFallback();
-		res->counters_long[7] = rerun;   // reads that needed the plain-layout fallback kernel
-		for (int i = 0; i < 6; i++) res->counters_long[i] = hLongSmall[8 + i];   // same units as counters[]
-#ifdef GC_STAMPS
-		{
-			static const char* names[11] = { "slice prologue", "pop+prev lookup", "tile columns", "item store", "edge pushes", "slice epilogue", "bt slice change", "bt item loads", "bt recompute", "bt corner", "bt walk" };
-			double total = 0;
-			for (int i = 0; i < 11; i++) total += (double)hLongSmall[16 + i];
-			for (int i = 0; i < 11; i++) fprintf(stderr, "[gc stamps] %-16s %6.2f%%  %.3e lane-cycles\n", names[i], 100.0 * hLongSmall[16 + i] / (total > 0 ? total : 1), (double)hLongSmall[16 + i]);
-		}
-#endif
-#ifdef GC_SM_STAMPS
-		{
-			static const char* names[5] = { "B (tile boundary)", "COL (column)", "BT (bt boundary)", "WALK (cell)", "housekeeping+vote" };
-			double total = 0;
-			for (int i = 0; i < 5; i++) total += (double)hLongSmall[16 + i];
-			for (int i = 0; i < 5; i++) fprintf(stderr, "[gc sm stamps] %-18s %6.2f%% of wave-cycles, %.3e executions, %.0f cycles each, %.2f lanes served per execution\n", names[i], 100.0 * hLongSmall[16 + i] / (total > 0 ? total : 1),
-				(double)hLongSmall[21 + i], (double)hLongSmall[16 + i] / std::max<double>(1, (double)hLongSmall[21 + i]), (double)hLongSmall[26 + i] / std::max<double>(1, (double)hLongSmall[21 + i]));
-		}
-#endif
-		if (const char* env = getenv("GC_TEST_FAIL_LONG")) {   // test hook shared with the oracle: this read's whole-read pass "asserts"
-			long idx = atol(env);
-			if (idx >= 0 && (uint64_t)idx < n) hLongResults[idx].status = 1;
-		}
-		// A whole-read pass that trips one of the reference's live asserts leaves the read with nothing: align_fn's catch sets
-		// `cont` (src/Aligner.cpp:591), which is declared once per read (:529) and makes the fragment loop skip every anchor
-		// (:702-703); the alignments found before the throw are lost with the exception.
-		for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status == 1) { hLongResults[r].nAlignments = 0; glue[r].longFailed = true; }
-		// capacities of this library, not of the reference: 2 extension scratch (even with the fallback's four-fold room), 3 more alignments than
-		// maxAlignments, 4 the merged-trace cell pool (GC_LONG_CELLS_PER_BASE). The read keeps what was found up to there and is flagged.
-		for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status >= 2 && hLongResults[r].status <= 4) glue[r].capacityExceededLong = true;
-		{
-			std::vector<uint32_t> all(n);
-			for (uint64_t r = 0; r < n; r++) all[r] = (uint32_t)r;
-			decideLongReads(all, 0, st->longStream, [&](uint32_t r) { return hLongResults[r].nAlignments; });
-			encodeOutputStart();   // (the selection is known; its waits overlap the NW kernels the decision has just queued)
-			finishLongDecision(0);
-		}
-	}
-
-	// ---------------- the pass gets its own host thread and stream from here on
-	void startWholeReadPass()
-	{
-		tLongWall0 = nowUs();
-		if (P->long_pass) {
-			int device = 0;
-			HIP_CHECK(hipGetDevice(&device));
-			for (uint32_t g = 0; g < longGroups; g++)
-				longThreads.emplace_back([&, device, g]() {
-					// (declared outside the try block: on an exception the catch below waits for the pass's kernels BEFORE the token - and with it the device's shared scratch - is released)
-					TokenHold token;
-					try {
-						HIP_CHECK(hipSetDevice(device));
-						const int tokenMode = getenv("GC_LONG_TOKEN") ? atoi(getenv("GC_LONG_TOKEN")) : 1;   // 0 none, 1 one pass at a time, 2 one round's extension kernel at a time
-						const double tTokenAsk = nowUs();
-						const bool early = getenv("GC_LONG_TOKEN_EARLY") && atoi(getenv("GC_LONG_TOKEN_EARLY")) == 1;
-						bool held = false;   // between take and drop (with or without a token to hold: GC_LONG_TOKEN=0 has none)
-						auto stampBegin = [&]() { double now = nowUs(), seen = longWallBeginUs.load(); while ((seen == 0.0 || now < seen) && !longWallBeginUs.compare_exchange_weak(seen, now)) {} };
-						auto stampEnd = [&]() { double now = nowUs(), seen = longWallEndUs.load(); while (now > seen && !longWallEndUs.compare_exchange_weak(seen, now)) {} };
-						auto take = [&, device, tokenMode, tTokenAsk]() {
-							if (held) return;
-							const double tAsk = nowUs();
-							if (tokenMode == 1 && longGroups == 1) token.lock(g_longPassToken[device & 15], longTokenCount());
-							if (shareLongScratch && tokenMode == 1) {
-								if (!token.owns_lock()) throw std::runtime_error("internal: shared whole-read scratch without the token");
-								longScratchOfToken = g_longScratch[device & 15].buffer[token.slot].reserve<unsigned long long>(longScratchWords);
-							}
-							held = true;
-							if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc token] stream %p pass began %.1f asked %.1f got %.1f (call began %.1f)\n", (void*)st, tTokenAsk / 1e3, tAsk / 1e3, nowUs() / 1e3, tCall / 1e3);
-							stampBegin();   // (whole_read_pass_wall: from the token to its release)
-						};
-						auto drop = [&]() {
-							if (!held) return;
-							held = false;
-							stampEnd();
-							if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc token] stream %p released %.1f\n", (void*)st, nowUs() / 1e3);
-							token.unlock();   // the next batch's pass may start; what follows is this batch's own tail
-						};
-						if (longGroups == 1 && !early) { longTokenTake = take; longTokenDrop = drop; }
-						else if (longGroups == 1) take();
-						else stampBegin();
-						runLongGroup(g);
-						while (longGroups == 1 && growLongCells()) runLongGroup(g);   // the cell pool overflowed: again, with room
-						if (longGroups == 1) { longTokenTake = nullptr; longTokenDrop = nullptr; drop(); }
-						else stampEnd();
-						if (longPostInThread) afterLongPass();
-					} catch (...) {
-						longErrors[g] = std::current_exception();
-						if (longGroups == 1) { longTokenTake = nullptr; longTokenDrop = nullptr; }   // (they refer to this thread's locals)
-						// the token is released when this lambda returns: a kernel of this pass may still be writing to the shared scratch
-						if (g < st->groupStreams.size()) (void)hipStreamSynchronize(st->groupStreams[g]);
-						(void)hipStreamSynchronize(st->longStream);
-					}
-				});
-		}
-	}
-
-	// ---------------- fragment windows, k_build_fragment_work, K3 / K3b in lazy rounds, K4, k_stitch - queued on the main stream
-	void fragmentPipeline()
-	{
-		double tLongStarted = nowUs();
-		double tWindows = tLongStarted, tReserved = tLongStarted;
-		if (!deviceGlue) {
-		pool.run(n, [&](size_t r, size_t) {
-			ReadGlue& gl = glue[r];
-			if (gl.seeds.empty()) return;
-			gc::fragmentWindows(gl.seeds, R->offsets[r + 1] - R->offsets[r], (size_t)P->split_len, (size_t)P->split_gap, gl.windows);
-		});
-		tWindows = nowUs();
-		for (uint64_t r = 0; r < n; r++) {
-			glue[r].slotBegin = nSlots;
-			glue[r].fragBegin = nFrags;
-			glue[r].seedBegin = nSeedsTotal;
-			glue[r].nSeedsR = (uint32_t)glue[r].seeds.size();
-			glue[r].nWindows = (uint32_t)glue[r].windows.size();
-			for (const auto& w : glue[r].windows) nSlots += w.sr - w.sl;
-			nFrags += glue[r].windows.size();
-			nSeedsTotal += glue[r].seeds.size();
-		}
-		// The per-slot records (seed in fragment order + its two extensions) are expanded on the device (k_build_fragment_work) from what the
-		// host decides: the read's seeds in the reference's order after its sort by position, and the windows.
-		frags = st->hFrags.reserve<Fragment>(nFrags);
-		fragFirstSeed = st->hFragFirstSeed.reserve<uint32_t>(nFrags);
-		readSeeds = st->hReadSeeds.reserve<FragSeed>(nSeedsTotal);
-		jobs = st->hJobs.reserve<ReadChainJob>(n);
-		std::vector<uint64_t> traceBudgets(pool.size(), 0);
-		std::vector<uint32_t> windowSeeds(pool.size(), 0);   // per worker: the most seeds a window holds
-		tReserved = nowUs();
-		pool.run(n, [&](size_t r, size_t worker) {
-			const ReadGlue& gl = glue[r];
-			size_t len = R->offsets[r + 1] - R->offsets[r];
-			for (size_t k = 0; k < gl.seeds.size(); k++) readSeeds[gl.seedBegin + k] = FragSeed { gl.seeds[k].node, gl.seeds[k].offset, gl.seeds[k].seqPos, gl.seeds[k].goodness };
-			uint64_t slot = gl.slotBegin;
-			uint64_t budget = 0;
-			for (size_t f = 0; f < gl.windows.size(); f++) {
-				const gc::FragmentWindow& w = gl.windows[f];
-				Fragment& fr = frags[gl.fragBegin + f];
-				fr.read = (uint32_t)r;
-				fr.l = w.l;
-				fr.seedBegin = (uint32_t)slot;
-				fragFirstSeed[gl.fragBegin + f] = (uint32_t)(gl.seedBegin + w.sl);
-				for (uint32_t k = w.sl; k < w.sr; k++, slot++) {
-					// trace cells the two extensions of this seed may need: backward p rows, forward split_len - 1 - p (src/GraphAligner.h:499-511)
-					const uint32_t p = gl.seeds[k].seqPos - w.l, q = (uint32_t)P->split_len - 1 - p;
-					budget += (p ? p + 24 : 0) + (q ? q + 24 : 0);
-				}
-				fr.seedEnd = (uint32_t)slot;
-				windowSeeds[worker] = std::max(windowSeeds[worker], w.sr - w.sl);
-			}
-			traceBudgets[worker] += budget;
-			ReadChainJob& job = jobs[r];
-			job.slotBegin = (uint32_t)gl.slotBegin;
-			job.nSlots = (uint32_t)(slot - gl.slotBegin);
-			job.chainBegin = (uint32_t)gl.slotBegin;
-			job.nKeys = len >= (size_t)P->split_len ? (uint32_t)((len - P->split_len) / P->split_gap + 1) : 1;
-			job.fragBegin = (uint32_t)gl.fragBegin;
-			job.nFrags = (uint32_t)gl.windows.size();
-		});
-		for (uint64_t b : traceBudgets) traceBudget += b;
-		for (uint32_t m : windowSeeds) maxWindowSeeds = std::max(maxWindowSeeds, m);
-		for (uint64_t r = 0; r < n; r++) maxSlotsPerRead = std::max(maxSlotsPerRead, jobs[r].nSlots);
-		}
-		if (2 * nSlots >= 0xffffffffull) throw std::runtime_error("batch too large: more than 2^31 fragment seeds; split the batch");
-		traceBudget += traceBudget / 4 + (1u << 20);   // room for the extensions that only fit the retry launch's larger trace buffers
-		ChainCaps caps { 1, 1, 1, 1 };
-		caps.capAnchors = std::max(1u, maxSlotsPerRead);
-		caps.capEndpoints = (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)caps.capAnchors * G->maxPathsPerNode);   // entries: one per path through an anchor's end node
-		caps.capTable = std::max(1u, G->maxMpcWidth);
-		caps.capBack = (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)caps.capAnchors * ((uint64_t)G->maxBackPerNode + G->maxPathsPerNode));   // threshold lists: backward links + paths of the start node
-		res->host_us[0] = nowUs() - tGlue;
-		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc cpu] %.0f ms of process CPU up to the end of the host glue\n", processCpuMs() - cpuCall);
-		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] seed expand+order %.1f ms, whole-read setup %.1f ms, fragment windows+arrays %.1f ms (windows %.1f, sizes+buffers %.1f, arrays %.1f)\n", (tOrdered - tGlue) / 1e3, (tLongStarted - tOrdered) / 1e3, (nowUs() - tLongStarted) / 1e3,
-			(tWindows - tLongStarted) / 1e3, (tReserved - tWindows) / 1e3, (nowUs() - tReserved) / 1e3);
-
-		// ---------------- K3 / K3b / K4
-		tDev = nowUs();
-		ExtendConfig cfg;
-		cfg.bandwidth = P->bandwidth;
-		cfg.maxSlices = 3;
-		cfg.maxItems = 72;
-		cfg.maxPending = 48;
-		cfg.maxTrace = 192;
-		cfg.maxItems = (uint32_t)std::max<int64_t>(8, capacityOr("GC_EXT_MAX_ITEMS", P->capacity.ext_max_items, cfg.maxItems));
-		cfg.maxPending = (uint32_t)std::max<int64_t>(8, capacityOr("GC_EXT_MAX_PENDING", P->capacity.ext_max_pending, cfg.maxPending));
-		cfg.maxTrace = (uint32_t)std::max<int64_t>(64, capacityOr("GC_EXT_MAX_TRACE", P->capacity.ext_max_trace, cfg.maxTrace));
-		nWork = (uint32_t)(2 * nSlots);
-		uint64_t slabBytes = extendSlabBytes(cfg);
-		uint32_t lanes = extendGridLanes(nWork);
-		ExtItem* dWork = st->work.reserve<ExtItem>(nWork);
-		dResults = st->results.reserve<ExtResult>(nWork);
-		uint8_t* dScratch = st->scratch.reserve<uint8_t>((uint64_t)lanes * slabBytes);
-		dTrace = st->tracePool.reserve<TraceCell>(traceBudget);
-		if (!deviceGlue) dFrags = st->frags.reserve<Fragment>(nFrags);
-		FragSeed* dFragSeeds = st->fragSeeds.reserve<FragSeed>(nSlots);
-		dAnchors = st->anchors.reserve<AnchorRec>(nSlots);
-		dFragStatus = st->fragStatus.reserve<uint32_t>(nFrags);
-		dFragExtended = st->fragExtended.reserve<uint32_t>(nFrags);
-		pathCapacity = nSlots * 24 + 4096;
-		dPathPool = st->pathPool.reserve<uint32_t>(pathCapacity);
-		if (!deviceGlue) dJobs = st->jobs.reserve<ReadChainJob>(n);
-		dChainOut = st->chainOut.reserve<uint32_t>(nSlots);
-		dChainLen = st->chainLen.reserve<uint32_t>(n);
-		dChainScore = st->chainScore.reserve<unsigned long long>(n);
-		dChainStatus = st->chainStatus.reserve<uint32_t>(n);
-		uint32_t chainBlocks = std::max(chainGridBlocks((uint32_t)n), chainScratchBlocks((uint32_t)n));   // both launches index the scratch by block
-		uint8_t* dChainScratch = st->chainScratch.reserve<uint8_t>((uint64_t)std::max(1u, chainBlocks) * chainScratchBytes(caps));
-		if (!deviceGlue) {
-			dReadSeeds = st->readSeeds.reserve<FragSeed>(nSeedsTotal);
-			dFragFirstSeed = st->fragFirstSeed.reserve<uint32_t>(nFrags);
-			if (nFrags) HIP_CHECK(hipMemcpyAsync(dFrags, frags, nFrags * sizeof(Fragment), hipMemcpyHostToDevice, stream));
-			if (nFrags) HIP_CHECK(hipMemcpyAsync(dFragFirstSeed, fragFirstSeed, nFrags * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-			if (nSeedsTotal) HIP_CHECK(hipMemcpyAsync(dReadSeeds, readSeeds, nSeedsTotal * sizeof(FragSeed), hipMemcpyHostToDevice, stream));
-		}
-		// Lazy extension (default): a seed is extended only when the reference would extend it - when it does not lie on an earlier alignment of its
-		// fragment (src/GraphAligner.h:163-173). Round 0 extends every fragment's first seed; k_build_anchors parks the fragments that reach another
-		// seed they must extend and queues that seed for the next round (the launches size themselves from counts on the device, no host round
-		// trip); three rounds at most, the last parking round queues everything its fragments have left. On cfg2 the reference extends 47 % of the
-		// seeds the windows hold. GC_EXT_LAZY=0: every seed is extended up front.
-		const bool lazyExtend = !(getenv("GC_EXT_LAZY") && atoi(getenv("GC_EXT_LAZY")) == 0) && nFrags > 0;
-		launchBuildFragmentWork(stream, G->dev, dFrags, dFragFirstSeed, (uint32_t)nFrags, dReadSeeds, R->devOffsets, R->totalBases, (uint32_t)P->split_len, dFragSeeds, dWork, lazyExtend ? dResults : nullptr);
-		if (n && !deviceGlue) HIP_CHECK(hipMemcpyAsync(dJobs, jobs, n * sizeof(ReadChainJob), hipMemcpyHostToDevice, stream));
-		mark();   // 2
-		// extensions that outgrew their slab (a dense variant cluster: more tiles, queue entries or trace cells than the common case is sized
-		// for) run again in a small grid with 16x the room; lanes whose items are fine only read the status array. What overflows even
-		// that is flagged per read (capacity_exceeded), never a failed call.
-		ExtendConfig big = cfg;
-		auto times16 = [](uint32_t v) { return (uint32_t)std::min<uint64_t>(16ull * v, 0xffffffffull); };   // (saturating: the GC_EXT_* variables are not range-checked like gc_params::capacity)
-		big.maxItems = times16(cfg.maxItems); big.maxPending = times16(cfg.maxPending); big.maxTrace = times16(cfg.maxTrace); big.maxSlices = cfg.maxSlices;
-		if (const char* env = getenv("GC_EXT_RETRY_MAX_ITEMS")) big.maxItems = (uint32_t)std::max(8, atoi(env));   // test hook: make the retry overflow too
-		const uint32_t retryLanes = 2048;
-		uint8_t* dRetryScratch = st->scratchRetry.reserve<uint8_t>((uint64_t)retryLanes * extendSlabBytes(big));
-		auto extendRound = [&](const ExtSelection& sel) {
-			launchExtend(stream, G->dev, G->devTables, G->devIupac, cfg, dWork, nWork, R->devBases, dResults, dScratch, slabBytes, dTrace, dCursors + 1, traceBudget, dCounters, 0, 4096, sel);
-			launchExtend(stream, G->dev, G->devTables, G->devIupac, big, dWork, nWork, R->devBases, dResults, dRetryScratch, extendSlabBytes(big), dTrace, dCursors + 1, traceBudget, dCounters, EXT_OVERFLOW, retryLanes, sel);
-		};
-		if (!lazyExtend) {
-			extendRound(ExtSelection());
-			mark();   // 3
-			launchBuildAnchors(stream, G->dev, dFrags, (uint32_t)nFrags, dFragSeeds, dResults, dTrace, P->split_len, dAnchors, dFragStatus, dFragExtended, dPathPool, dCursors + 2, pathCapacity);
-		} else {
-			uint32_t* dLists = st->extLists.reserve<uint32_t>(2ull * nWork);           // two work lists, used in turn
-			uint32_t* dPending = st->pendingFrags.reserve<uint32_t>(2ull * nFrags);     // two pending-fragment lists
-			uint32_t* dFragNext = st->fragNext.reserve<uint32_t>(nFrags);
-			unsigned long long* dRoundCounts = st->roundCounts.reserve<unsigned long long>(4);   // [2k] work list k, [2k+1] pending list k
-			launchZeroWords(stream, dRoundCounts, 4);
-			ExtSelection first;
-			first.mode = 1; first.frags = dFrags; first.nFrags = (uint32_t)nFrags;
-			extendRound(first);
-			mark();   // 3 (round 0's extensions; the later rounds are charged to the anchors stage)
-			const uint32_t nRounds = std::min<uint32_t>(maxWindowSeeds, 3);   // first seeds; the next seed each parked fragment needs; then all that is left of the few still parked
-			for (uint32_t round = 0; round < nRounds; round++) {
-				const uint32_t cur = round & 1u, nxt = cur ^ 1u;
-				if (round > 0) {
-					ExtSelection sel;
-					sel.mode = 2; sel.list = dLists + (uint64_t)cur * nWork; sel.listCount = dRoundCounts + 2 * cur;
-					extendRound(sel);
-				}
-				launchZeroWords(stream, dRoundCounts + 2 * nxt, 2);
-				AnchorRounds ar;
-				ar.lazy = 1; ar.round = round; ar.parkAll = round + 2 >= nRounds ? 1 : 0;
-				ar.pending = dPending + (uint64_t)cur * nFrags; ar.pendingCount = dRoundCounts + 2 * cur + 1;
-				ar.nextList = dLists + (uint64_t)nxt * nWork; ar.nextListCount = dRoundCounts + 2 * nxt;
-				ar.nextPending = dPending + (uint64_t)nxt * nFrags; ar.nextPendingCount = dRoundCounts + 2 * nxt + 1;
-				ar.fragNext = dFragNext;
-				launchBuildAnchors(stream, G->dev, dFrags, (uint32_t)nFrags, dFragSeeds, dResults, dTrace, P->split_len, dAnchors, dFragStatus, dFragExtended, dPathPool, dCursors + 2, pathCapacity, ar);
-			}
-		}
-		mark();   // 4
-		launchChain(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, P->split_len, P->split_gap, caps, dChainScratch, dChainOut, dChainLen, dChainScore, dChainStatus, getenv("GC_CHAIN_FORCE_SCRATCH") != nullptr);
-		mark();   // 5
-		// chain stitching (src/Aligner.cpp:754-822) on the device, right behind the chaining kernel; GC_HOST_STITCH=1 keeps it on the
-		// host workers (the path also taken by reads that do not fit the kernel's tables)
-		deviceStitch = P->stitch && n > 0 && !(getenv("GC_HOST_STITCH") && atoi(getenv("GC_HOST_STITCH")) != 0);
-		if (deviceStitch) {
-			stitchDenseCap = stitchDenseWords(nSlots, n);
-			uint32_t* dSlotOf = st->stitchSlotOf.reserve<uint32_t>(std::max<uint64_t>(1, nSlots));
-			uint32_t* dRegions = st->stitchRegions.reserve<uint32_t>(stitchRegionWords(nSlots, n));
-			dStitchNodes = st->stitchNodes.reserve<uint32_t>(stitchDenseCap);
-			StitchInfo* dStitchInfo = st->stitchInfo.reserve<StitchInfo>(n);
-			unsigned long long* dCursor = st->stitchCursor.reserve<unsigned long long>(1);
-			stitchInfo = st->hStitchInfo.reserve<StitchInfo>(n);
-			hStitchCursor = st->hStitchCursor.reserve<unsigned long long>(1);
-			HIP_CHECK(hipMemsetAsync(dCursor, 0, sizeof(unsigned long long), stream));
-			launchStitch(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, dChainOut, dChainLen, dChainStatus, dPathPool, pathCapacity, (long long)P->colinear_gap, dSlotOf,
-				dRegions, dStitchNodes, stitchDenseCap, dCursor, dStitchInfo,
-				(uint32_t)capacityOr("GC_STITCH_SET_MAX", P->capacity.stitch_set_max, 0), (uint32_t)capacityOr("GC_STITCH_BFS_CAP", P->capacity.stitch_bfs_cap, 0),
-				// (GC_STITCH_SMALL=1: the half-size search tables, measured in r4 and not kept - see gc_stitch.hip. GC_STITCH_LARGE=1: the large tables for reads beyond 16 kb - a 50 kb
-				// read's piece holds more split nodes than the default node set, so config 5's reads are all stitched by the host; with 107 KB of LDS one wave runs per CU and a batch's
-				// 2 000 reads take 1.1 s there against 1-2 s of 16 host threads that overlap the other batches' kernels: 2 541 reads/s against 2 676, measured, not kept)
-				(getenv("GC_STITCH_LARGE") && atoi(getenv("GC_STITCH_LARGE")) == 1 && maxReadLen > 16384) ? 2 : (getenv("GC_STITCH_SMALL") && atoi(getenv("GC_STITCH_SMALL")) && maxReadLen <= 16384 ? 1 : 0));
-			HIP_CHECK(hipMemcpyAsync(stitchInfo, dStitchInfo, n * sizeof(StitchInfo), hipMemcpyDeviceToHost, stream));
-			HIP_CHECK(hipMemcpyAsync(hStitchCursor, dCursor, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-		}
-
-	}
-
-	// ---------------- anchors, chains and stitched paths come down (pinned staging)
-	void resultsBack()
-	{
-		// ---------------- results back (pinned staging)
-		anchors = st->hAnchors.reserve<AnchorRec>(nSlots);
-		fragStatus = st->hFragStatus.reserve<uint32_t>(nFrags);
-		fragExtended = st->hFragExtended.reserve<uint32_t>(nFrags);
-		chainOut = st->hChainOut.reserve<uint32_t>(nSlots);
-		chainLen = st->hChainLen.reserve<uint32_t>(n);
-		chainScore = st->hChainScore.reserve<unsigned long long>(n);
-		chainStatus = st->hChainStatus.reserve<uint32_t>(n);
-		if (nSlots) HIP_CHECK(hipMemcpyAsync(anchors, dAnchors, nSlots * sizeof(AnchorRec), hipMemcpyDeviceToHost, stream));
-		if (nFrags) HIP_CHECK(hipMemcpyAsync(fragStatus, dFragStatus, nFrags * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		if (nFrags) HIP_CHECK(hipMemcpyAsync(fragExtended, dFragExtended, nFrags * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		if (nSlots) HIP_CHECK(hipMemcpyAsync(chainOut, dChainOut, nSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		if (n) HIP_CHECK(hipMemcpyAsync(chainLen, dChainLen, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		if (n) HIP_CHECK(hipMemcpyAsync(chainStatus, dChainStatus, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		if (n) HIP_CHECK(hipMemcpyAsync(chainScore, dChainScore, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipMemcpyAsync(hSmall, dCursors, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipMemcpyAsync(hSmall + 8, dCounters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-		syncStream(stream);
-		res->kernel_us[1] = elapsedUs(2, 3);
-		res->kernel_us[2] = elapsedUs(3, 4);
-		res->kernel_us[3] = elapsedUs(4, 5);
-		for (int i = 0; i < 8; i++) res->counters[i] = hSmall[8 + i];
-		// (the cursors overshoot when a pool is full: the extensions / fragments that did not fit carry an overflow status and their reads are flagged)
-		uint64_t traceUsed = std::min<uint64_t>(hSmall[1], traceBudget), pathUsed = std::min<uint64_t>(hSmall[2], pathCapacity);
-		pathPool = st->hPathPool.reserve<uint32_t>(pathUsed);
-		if (pathUsed) HIP_CHECK(hipMemcpyAsync(pathPool, dPathPool, pathUsed * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		anchorTraces = P->keep_traces == 1;   // (keep_traces == 2: the alignments' traces only - what the output encoders read)
-		if (anchorTraces) {
-			extResults.resize(nWork);
-			tracePool.resize(traceUsed);
-			if (nWork) HIP_CHECK(hipMemcpyAsync(extResults.data(), dResults, (size_t)nWork * sizeof(ExtResult), hipMemcpyDeviceToHost, stream));
-			if (traceUsed) HIP_CHECK(hipMemcpyAsync(tracePool.data(), dTrace, traceUsed * sizeof(TraceCell), hipMemcpyDeviceToHost, stream));
-		}
-		syncStream(stream);
-		res->host_us[3] = nowUs() - tDev;   // K3..K4 + their transfers, wall
-		// the stitched node paths come down behind the kernels that follow on this stream; they are only needed for the result arrays
-		if (deviceStitch) {
-			uint64_t used = std::min<uint64_t>(*hStitchCursor, stitchDenseCap);
-			hStitchNodes = st->hStitchNodes.reserve<uint32_t>(std::max<uint64_t>(1, used));
-			if (used) HIP_CHECK(hipMemcpyAsync(hStitchNodes, dStitchNodes, used * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-			stitchNodesPending = true;
-		}
-
-	}
-
-	// ---------------- host stitching of what the kernel declined; NW distance of every stitched path against its read
-	void stitchAndChainDistances()
-	{
-		// ---------------- chain stitching (src/Aligner.cpp:754-822) on the host workers, while the whole-read pass still runs
-		double tStitch = nowUs();
-		std::atomic<uint64_t> hostStitched { 0 };
-		if (P->stitch) {
-			pool.run(n, [&](size_t r, size_t) {
-				ReadGlue& gl = glue[r];
-				gl.stitchedOnDevice = false;
-				if (chainStatus[r] != 0 || chainLen[r] == 0) return;
-				if (deviceStitch && stitchInfo[r].status == 0) {
-					const StitchInfo& si = stitchInfo[r];
-					gl.stitched.nodes.clear();   // filled once the download has finished (below)
-					gl.stitched.firstOffset = si.firstOffset; gl.stitched.lastOffset = si.lastOffset; gl.stitched.cells = si.cells;
-					gl.stitchedOnDevice = true;
-					return;
-				}
-				hostStitched++;
-				if (deviceStitch && getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc stitch] read %zu goes to the host: reason %u, chain of %u anchors\n", r, stitchInfo[r].status, chainLen[r]);
-				std::vector<uint32_t> slots;
-				uint64_t slot = gl.slotBegin;
-				for (size_t f = 0; f < gl.nWindows; f++) {
-					uint64_t F = gl.fragBegin + f;
-					uint32_t nS = frags[F].seedEnd - frags[F].seedBegin;
-					if (fragStatus[F] == 1) break;   // `cont` is never reset (src/Aligner.cpp:695-703)
-					for (uint32_t k = 0; k < nS; k++) if (anchors[slot + k].valid) slots.push_back((uint32_t)(slot + k - gl.slotBegin));
-					slot += nS;
-				}
-				stitchChain(hg, (long long)P->colinear_gap, chainOut + jobs[r].chainBegin, chainLen[r], slots.data(), anchors + gl.slotBegin, pathPool, gl.stitched);
-			});
-		}
-		// ---------------- edit distance of the stitched path against the read (edlibAlign at src/Aligner.cpp:845, value only):
-		// path letters are spelled out on the device from the node path, then the NW kernel; still behind the whole-read pass
-		std::function<void()> finishChainEditDistances;
-		std::vector<uint32_t> pairRead;   // chain pairs -> read
-		if (P->stitch && P->edit_distances) {
-			uint64_t nNodesTotal = 0, nCells = 0;
-			uint32_t nPairs = 0;
-			// node paths stitched on the device are read where k_stitch left them; only the ones stitched here go up
-			for (uint64_t r = 0; r < n; r++) { glue[r].stitchedBegin = nNodesTotal; if (!glue[r].stitchedOnDevice) nNodesTotal += glue[r].stitched.nodes.size(); }
-			uint32_t* hNodes = st->hEdPathNodes.reserve<uint32_t>(nNodesTotal);
-			PathSeqJob* hJobsPS = st->hEdJobs.reserve<PathSeqJob>(n);
-			EdPair* hPairs = st->hEdPairs.reserve<EdPair>(n);
-			int64_t* hOut = st->hEdOut.reserve<int64_t>(n);
-			for (uint64_t r = 0; r < n; r++) {
-				const StitchedPath& sp = glue[r].stitched;
-				const bool onDevice = glue[r].stitchedOnDevice;
-				if (!onDevice && !sp.nodes.empty()) memcpy(hNodes + glue[r].stitchedBegin, sp.nodes.data(), sp.nodes.size() * sizeof(uint32_t));
-				if (sp.cells >= 0x7fffffffull) throw std::runtime_error("stitched path too long");
-				hJobsPS[r] = PathSeqJob { onDevice ? stitchInfo[r].start : ((1ull << 63) | glue[r].stitchedBegin), nCells, onDevice ? stitchInfo[r].len : (uint32_t)sp.nodes.size(), (uint32_t)sp.cells, sp.firstOffset, sp.lastOffset };
-				if (sp.cells) {
-					uint32_t len = (uint32_t)(R->offsets[r + 1] - R->offsets[r]);
-					// first band: the length difference plus ~14 % of the shorter sequence (ONT-like error rates pass in one sweep) - widened to 20 %
-					// where that still fits the two-pairs-per-wave kernel: a wave's time follows the number of columns, not the band, so the wider
-					// band is free there and spares the pairs above 14 % their second sweep
-					uint32_t cells = (uint32_t)sp.cells, shorter = std::min(cells, len), longer = std::max(cells, len);
-					uint32_t firstBand = (longer - shorter) + std::max<uint32_t>(64, shorter / 7);
-					const uint32_t halfLimit = editDistanceMaxK(0);
-					if (firstBand < halfLimit) firstBand = std::max(firstBand, std::min<uint32_t>(halfLimit - 1, (longer - shorter) + shorter / 5));
-					hPairs[nPairs++] = EdPair { nCells, cells, (uint32_t)r, (uint32_t)r, firstBand };
-					pairRead.push_back((uint32_t)r);
-				}
-				nCells += sp.cells;
-			}
-			uint32_t* dNodes = st->edPathNodes.reserve<uint32_t>(nNodesTotal);
-			PathSeqJob* dJobsPS = st->edJobs.reserve<PathSeqJob>(n);
-			char* dLetters = st->edLetters.reserve<char>(nCells);
-			uint32_t* dLettersLen = st->edLettersLen.reserve<uint32_t>(n);
-			EdPair* dPairs = st->edPairs.reserve<EdPair>(n);
-			int64_t* dOut = st->edOut.reserve<int64_t>(n);
-			if (nNodesTotal) HIP_CHECK(hipMemcpyAsync(dNodes, hNodes, nNodesTotal * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-			if (n) HIP_CHECK(hipMemcpyAsync(dJobsPS, hJobsPS, n * sizeof(PathSeqJob), hipMemcpyHostToDevice, stream));
-			launchChainPathSeq(stream, G->dev, dJobsPS, (uint32_t)n, dStitchNodes, dNodes, dLetters, dLettersLen);
-			chainLetterJobs = hJobsPS;
-			dChainLetters = dLetters;
-			auto readLenOf = [R = R](uint32_t r) { return (uint32_t)(R->offsets[r + 1] - R->offsets[r]); };
-			launchEditDistances(st->edChainRun, stream, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen, readLenOf);
-			finishChainEditDistances = [=, &pairRead]() {   // waits for the kernels (they run beside the whole-read pass) and reruns the few pairs that need a wider band
-				finishEditDistances(st->edChainRun, stream, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen);
-				for (uint32_t i = 0; i < nPairs; i++) {
-					ReadGlue& gl = glue[pairRead[i]];
-					gl.chainEditDistance = hOut[i];
-					if (hOut[i] < -1) { gl.chainEditDistance = -1; gl.capacityExceeded = true; }
-				}
-			};
-		}
-		if (finishChainEditDistances) finishChainEditDistances();   // this thread would only wait for the whole-read pass otherwise
-		if (stitchNodesPending) {
-			syncStream(stream);
-			pool.run(n, [&](size_t r, size_t) {
-				if (!glue[r].stitchedOnDevice) return;
-				const StitchInfo& si = stitchInfo[r];
-				glue[r].stitched.nodes.assign(hStitchNodes + si.start, hStitchNodes + si.start + si.len);
-			});
-		}
-		double stitchUs = nowUs() - tStitch;
-		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc cpu] %.0f ms up to the end of stitching + chain edit distances\n", processCpuMs() - cpuCall);
-		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] chain stitching + its edit distances %.1f ms (%llu reads stitched on the host)\n", stitchUs / 1e3, (unsigned long long)hostStitched.load());
-		res->counters[7] = hostStitched.load();   // reads whose chain was stitched on the host
-
-	}
-
-	// ---------------- the pass thread ends (its after-pass stage included unless it ran on this thread)
-	void joinWholeReadPass()
-	{
-		// ---------------- whole-read pass results
-		tJoined = nowUs();
-		if (P->long_pass) {
-			double tJoin0 = nowUs();
-			for (auto& t : longThreads) t.join();
-			tJoined = nowUs();
-			cpuJoined = processCpuMs();
-			if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] main thread waited %.1f ms for the whole-read pass\n", (tJoined - tJoin0) / 1e3);
-			for (auto& e : longErrors) if (e) std::rethrow_exception(e);
-			finishLongGroups();
-			res->kernel_us[5] = longWallEndUs.load() - (longWallBeginUs.load() > 0.0 ? longWallBeginUs.load() : tLongWall0);   // whole-read pass, wall clock from the first group's start to the last group's end
-			if (!longPostInThread) afterLongPass();
-			for (uint64_t r = 0; r < n; r++) if (glue[r].capacityExceededLong) glue[r].capacityExceeded = true;
-			if (P->keep_traces) {
-				LongCell* staged = st->hLongCells.reserve<LongCell>(hLongSmall[0]);
-				if (hLongSmall[0]) HIP_CHECK(hipMemcpyAsync(staged, dLongCells, hLongSmall[0] * sizeof(LongCell), hipMemcpyDeviceToHost, st->longStream));
-				syncStream(st->longStream);
-				longCells = staged;
-			}
-		}
-
-		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] after the whole-read pass: selection + its edit distances %.1f ms\n", (nowUs() - tJoined) / 1e3);
-
-	}
-
-	// ---------------- edlib path + trace of the chained alignments that are wanted (src/Aligner.cpp:845-905)
-	void chainedAlignments()
-	{
-		// ---------------- the chained alignment (src/Aligner.cpp:845-905): edlib's alignment path of (stitched path, read) from k_edit_path,
-		// walked over the path cells and the read into the trace; then the decision. Only reads whose chained alignment can still win
-		// (or all with chain_traces == 2) are traced: the path does not change the edit distance that decides.
-		double tChainTrace = nowUs();
-		uint64_t nChainTraced = 0;
-		if (P->stitch && P->edit_distances && chainLetterJobs) {
-			auto beats = [&](const ReadGlue& gl) { return gl.longSelected.empty() || gl.longEditDistance > gl.chainEditDistance; };   // :905
-			std::vector<uint32_t> cand;
-			for (uint64_t r = 0; r < n; r++) {
-				const ReadGlue& gl = glue[r];
-				if (gl.longFailed || gl.stitched.cells == 0 || gl.chainEditDistance < 0) continue;
-				if (P->chain_traces >= 2 || (P->chain_traces == 1 && beats(gl))) cand.push_back((uint32_t)r);
-			}
-			nChainTraced = cand.size();
-			if (!cand.empty()) {
-				const size_t m = cand.size();
-				EdPathJob* hJobsEP = st->hEdPathJobs.reserve<EdPathJob>(m);
-				uint64_t opsTotal = 0;
-				uint32_t maxQ = 1, maxT = 1;
-				for (size_t i = 0; i < m; i++) {
-					const uint32_t r = cand[i];
-					const uint32_t q = (uint32_t)glue[r].stitched.cells, t = (uint32_t)(R->offsets[r + 1] - R->offsets[r]);
-					hJobsEP[i] = EdPathJob { chainLetterJobs[r].outOff, R->offsets[r], opsTotal, q, t, (int32_t)glue[r].chainEditDistance, 0 };
-					opsTotal += (uint64_t)q + t;
-					maxQ = std::max(maxQ, q); maxT = std::max(maxT, t);
-				}
-				EdPathJob* dJobsEP = st->edPathJobs.reserve<EdPathJob>(m);
-				uint8_t* dOps = st->edPathOps.reserve<uint8_t>(opsTotal);
-				uint32_t* dOpsLen = st->edPathLen.reserve<uint32_t>(m);
-				uint8_t* dScratchEP = st->edPathScratch.reserve<uint8_t>((uint64_t)editPathGridBlocks((uint32_t)m) * editPathScratchBytes(maxQ, maxT));
-				uint8_t* hOps = st->hEdPathOps.reserve<uint8_t>(opsTotal);
-				uint32_t* hOpsLen = st->hEdPathLen.reserve<uint32_t>(m);
-				HIP_CHECK(hipMemcpyAsync(dJobsEP, hJobsEP, m * sizeof(EdPathJob), hipMemcpyHostToDevice, stream));
-				launchEditPath(stream, dJobsEP, (uint32_t)m, dChainLetters, R->devBases, dScratchEP, maxQ, maxT, dOps, dOpsLen);
-				HIP_CHECK(hipMemcpyAsync(hOpsLen, dOpsLen, m * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-				HIP_CHECK(hipMemcpyAsync(hOps, dOps, opsTotal, hipMemcpyDeviceToHost, stream));
-				syncStream(stream);
-				pool.run(m, [&](size_t i, size_t) {
-					const uint32_t r = cand[i];
-					ReadGlue& gl = glue[r];
-					const uint64_t readLen = R->offsets[r + 1] - R->offsets[r];
-					// `longest`: one (node, offset) per base of the stitched piece (pathToTrace, src/Aligner.cpp:409-424)
-					std::vector<std::pair<uint32_t, uint32_t>> cells;
-					cells.reserve(gl.stitched.cells);
-					for (uint32_t node : gl.stitched.nodes) {
-						uint32_t S = 0, L = (uint32_t)hg.NodeLength(node);
-						if (node == gl.stitched.nodes[0]) S = gl.stitched.firstOffset;
-						else if (node == gl.stitched.nodes.back()) L = gl.stitched.lastOffset + 1;
-						for (uint32_t o = S; o < L; o++) cells.emplace_back(node, o);
-					}
-					const uint8_t* ops = hOps + hJobsEP[i].opsOff;
-					const uint32_t nOps = hOpsLen[i];
-					if (cells.empty() || nOps == 0) return;   // no alignment from edlib: no chained alignment item (:890)
-					// :848-876: one trace cell per op, recorded before the op advances; indices clamped to the last cell / base
-					uint64_t pos_i = 0, seq_i = 0;
-					gl.chainTraceNode.resize(nOps); gl.chainTraceOffset.resize(nOps); gl.chainTraceSeqPos.resize(nOps); gl.chainTraceSwitch.assign(nOps, 0);
-					uint32_t prevSplit = 0;
-					for (uint32_t j = 0; j < nOps; j++) {
-						const uint32_t node = cells[pos_i].first, off = cells[pos_i].second;
-						gl.chainTraceNode[j] = hg.nodeIDs[node];                       // :886-887 output coordinates
-						gl.chainTraceOffset[j] = (uint32_t)(off + hg.nodeOffset[node]);
-						gl.chainTraceSeqPos[j] = (uint32_t)seq_i;
-						if (j > 0 && node != prevSplit) gl.chainTraceSwitch[j - 1] = 1;      // :880-882 (split nodes compared)
-						prevSplit = node;
-						const uint8_t c = ops[j];
-						if (c == 0 || c == 3) { pos_i++; seq_i++; }
-						else if (c == 1) pos_i++;
-						else if (c == 2) seq_i++;
-						seq_i = std::min<uint64_t>(seq_i, readLen - 1);
-						pos_i = std::min<uint64_t>(pos_i, cells.size() - 1);
-					}
-					gl.chainAlnStart = gl.chainTraceSeqPos[0];
-					gl.chainAlnEnd = gl.chainTraceSeqPos[nOps - 1] + 1;
-					// :904 SelectAlignments(method All) still applies --E-cutoff; :905 the decision
-					gl.hasChainAlignment = evalueModel.keeps(P->e_cutoff, hg.SizeInBP(), readLen, gl.chainAlnEnd - gl.chainAlnStart, (size_t)gl.chainEditDistance);
-					if (!gl.hasChainAlignment) { gl.chainTraceNode.clear(); gl.chainTraceOffset.clear(); gl.chainTraceSeqPos.clear(); gl.chainTraceSwitch.clear(); gl.chainAlnStart = gl.chainAlnEnd = 0; }
-					gl.chainWins = gl.hasChainAlignment && beats(gl);
-				});
-			}
-			if (P->chain_traces == 0) {
-				// no traces asked for: the decision from the distances alone (an alignment edlib cannot build or --E-cutoff drops would differ)
-				for (uint64_t r = 0; r < n; r++) { ReadGlue& gl = glue[r]; gl.chainWins = !gl.longFailed && gl.stitched.cells > 0 && gl.chainEditDistance >= 0 && beats(gl); }
-			}
-		}
-		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] chained alignment traces: %llu reads, %.1f ms\n", (unsigned long long)nChainTraced, (nowUs() - tChainTrace) / 1e3);
-
-	}
-
-	// ---------------- the final alignments encoded where their traces are (params->device_output; gc_output.hip): the GAF path / CIGAR text and the vg::Path bytes of
-	// every alignment the reference would write for the batch (src/Aligner.cpp:901-920,1003-1023), so that no trace cell has to come down for the writers
-	struct OutEntry { uint32_t read, aln; uint8_t source; };   // aln: index into the read's longAlns (source 0); source 1: the read's chained alignment, encoded by the host from its trace
-	std::vector<OutEntry> outEntries;
-	std::vector<uint64_t> readOutOff;
-	const OutRec* hOutRecs = nullptr; const uint64_t* hOutOffsets = nullptr;
-	const char* hOutPath = nullptr; const char* hOutCigar = nullptr; const uint8_t* hOutVg = nullptr;
-	uint64_t nOutJobs = 0;
-	std::vector<uint64_t> outJobOfEntry;
-	// Started by the whole-read pass's own thread as soon as the selection is known (the end of afterLongPass): the main thread is still in the fragment pipeline, the stitching and the
-	// chain distances then, so the two passes of the encoder, their two waits and the download of the text overlap that work instead of following it (r4: with the encoder after the
-	// join, every batch's latency grew by the encoder's launches waiting for wave slots among the other batches' kernels, and five streams in flight completed a batch every 255-268 ms
-	// end to end against 160 for the hot path). Every read's selected alignments are encoded; a read whose chained alignment wins in the end (known only after the join) drops its pieces
-	// in encodeOutput - wasted work in proportion to the winners.
-	std::vector<uint64_t> readJobBegin;   // first job of every read (jobs of a read: its selected alignments sorted by alignmentStart); [n] = number of jobs
-	std::vector<uint32_t> jobAln;         // the alignment (index into the read's longAlns) of every job
-	void encodeOutputStart()
-	{
-		if (!P->device_output) return;
-		const double t0 = nowUs();
-		readJobBegin.assign(n + 1, 0);
-		jobAln.clear();
-		for (uint64_t r = 0; r < n; r++) {
-			const ReadGlue& gl = glue[r];
-			readJobBegin[r] = jobAln.size();
-			if (gl.longFailed) continue;
-			struct Item { uint32_t start; uint32_t aln; };
-			std::vector<Item> items;
-			for (uint32_t k : gl.longSelected) items.push_back(Item { gl.longAlns[k].start, k });
-			auto byStart = [](const Item& l, const Item& rr) { return l.start < rr.start; };
-			std::sort(items.begin(), items.end(), byStart);   // src/Aligner.cpp:1003
-			std::sort(items.begin(), items.end(), byStart);   // :1023 (an unstable sort may move ties even in a sorted list)
-			for (const Item& it : items) jobAln.push_back(it.aln);
-		}
-		readJobBegin[n] = jobAln.size();
-		nOutJobs = jobAln.size();
-		if (nOutJobs == 0) return;
-		if (nOutJobs >= 0xffffffffull) throw std::runtime_error("too many alignments in one batch for the output encoder");
-		OutJob* hJobsOut = st->hOutJobs.reserve<OutJob>(nOutJobs);
-		const uint32_t flags = ((P->device_output & 2) ? 1u : 0u) | ((P->device_output & 3) ? 2u : 0u) | ((P->device_output & 4) ? 4u : 0u);
-		for (uint64_t r = 0; r < n; r++)
-			for (uint64_t k = readJobBegin[r]; k < readJobBegin[r + 1]; k++) {
-				const LongAln& al = glue[r].longAlns[jobAln[k]];
-				hJobsOut[k] = OutJob { al.traceOff, R->offsets[r], al.traceLen, (uint32_t)(R->offsets[r + 1] - R->offsets[r]), flags, 0 };
-			}
-		hipStream_t q = st->longStream;   // (the pass and its decision are done with it)
-		OutJob* dJobsOut = st->outJobs.reserve<OutJob>(nOutJobs);
-		OutRec* dRecs = st->outRecs.reserve<OutRec>(nOutJobs);
-		uint64_t* dOffsets = st->outOffsets.reserve<uint64_t>(3 * (nOutJobs + 1));
-		unsigned long long* dTotals = st->outTotals.reserve<unsigned long long>(4);
-		uint32_t* dMapSizes = (P->device_output & 4) ? st->outMapSizes.reserve<uint32_t>(std::max<uint64_t>(1, hLongSmall[0]))   /* one word per cell of the pool in use */ : nullptr;
-		unsigned long long* hTotals = st->hOutTotals.reserve<unsigned long long>(4);
-		HIP_CHECK(hipMemcpyAsync(dJobsOut, hJobsOut, nOutJobs * sizeof(OutJob), hipMemcpyHostToDevice, q));
-		launchOutCount(q, G->dev, G->devNames, G->devIupac, dJobsOut, (uint32_t)nOutJobs, dLongCells, R->devBases, dRecs, dOffsets, dMapSizes, dTotals);
-		HIP_CHECK(hipMemcpyAsync(hTotals, dTotals, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, q));
-		syncStream(q);
-		const uint64_t pathBytes = hTotals[0], cigarBytes = hTotals[1], vgBytes = hTotals[2];
-		char* dPath = st->outPathText.reserve<char>(pathBytes + 1);
-		char* dCigar = st->outCigarText.reserve<char>(cigarBytes + 1);
-		uint8_t* dVg = st->outVgBytes.reserve<uint8_t>(vgBytes + 1);
-		launchOutWrite(q, G->dev, G->devNames, G->devIupac, dJobsOut, (uint32_t)nOutJobs, dLongCells, R->devBases, dRecs, dOffsets, dMapSizes, dPath, dCigar, dVg);
-		OutRec* recs = st->hOutRecs.reserve<OutRec>(nOutJobs);
-		uint64_t* offs = st->hOutOffsets.reserve<uint64_t>(3 * (nOutJobs + 1));
-		char* pathText = st->hOutPathText.reserve<char>(pathBytes + 1);
-		char* cigarText = st->hOutCigarText.reserve<char>(cigarBytes + 1);
-		uint8_t* vg = st->hOutVgBytes.reserve<uint8_t>(vgBytes + 1);
-		HIP_CHECK(hipMemcpyAsync(recs, dRecs, nOutJobs * sizeof(OutRec), hipMemcpyDeviceToHost, q));
-		HIP_CHECK(hipMemcpyAsync(offs, dOffsets, 3 * (nOutJobs + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, q));
-		if (pathBytes) HIP_CHECK(hipMemcpyAsync(pathText, dPath, pathBytes, hipMemcpyDeviceToHost, q));
-		if (cigarBytes) HIP_CHECK(hipMemcpyAsync(cigarText, dCigar, cigarBytes, hipMemcpyDeviceToHost, q));
-		if (vgBytes) HIP_CHECK(hipMemcpyAsync(vg, dVg, vgBytes, hipMemcpyDeviceToHost, q));
-		syncStream(q);
-		for (uint64_t k = 0; k < nOutJobs; k++) if (recs[k].steps == 0xffffffffu) throw std::runtime_error("internal: the output encoder's two passes disagree on an alignment's size");
-		hOutRecs = recs; hOutOffsets = offs; hOutPath = pathText; hOutCigar = cigarText; hOutVg = vg;
-		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] output encoding on the device: %llu alignments, %.1f MB of path text, %.1f MB of CIGAR, %.1f MB of vg::Path bytes, %.1f ms (on the whole-read pass's thread, beside the fragment pipeline)\n",
-			(unsigned long long)nOutJobs, pathBytes / 1e6, cigarBytes / 1e6, vgBytes / 1e6, (nowUs() - t0) / 1e3);
-	}
-
-	// After the decision: which of the encoded alignments are the batch's output, in the reference's order
-	void encodeOutput()
-	{
-		if (!P->device_output) return;
-		readOutOff.assign(n + 1, 0);
-		outEntries.clear();
-		outJobOfEntry.clear();
-		for (uint64_t r = 0; r < n; r++) {
-			const ReadGlue& gl = glue[r];
-			readOutOff[r] = outEntries.size();
-			if (gl.longFailed) continue;
-			if (gl.chainWins) { outEntries.push_back(OutEntry { (uint32_t)r, 0, 1 }); outJobOfEntry.push_back(~0ull); continue; }
-			for (uint64_t k = readJobBegin[r]; k < readJobBegin[r + 1]; k++) { outEntries.push_back(OutEntry { (uint32_t)r, jobAln[k], 0 }); outJobOfEntry.push_back(k); }
-		}
-		readOutOff[n] = outEntries.size();
-	}
-
-	void assembleOutput()   // the pieces into the result (entries of chained winners stay empty: source 1)
-	{
-		if (!P->device_output) return;
-		const uint64_t nOut = outEntries.size();
-		res->read_out_off = resultArray<uint64_t>(n + 1);
-		memcpy(res->read_out_off, readOutOff.data(), (n + 1) * sizeof(uint64_t));
-		res->out_source = resultArray<uint8_t>(nOut);
-		res->out_numbers = resultArray<uint64_t>(12 * nOut);
-		res->out_path_off = resultArray<uint64_t>(nOut + 1); res->out_cigar_off = resultArray<uint64_t>(nOut + 1); res->out_vg_off = resultArray<uint64_t>(nOut + 1);
-		const uint64_t stride = nOutJobs + 1;
-		// where every entry's pieces go: the kept jobs' bytes back to back (all of them, in order, unless chained alignments won)
-		uint64_t pathBytes = 0, cigarBytes = 0, vgBytes = 0;
-		for (uint64_t e = 0; e < nOut; e++) {
-			res->out_path_off[e] = pathBytes; res->out_cigar_off[e] = cigarBytes; res->out_vg_off[e] = vgBytes;
-			const uint64_t k = outJobOfEntry[e];
-			if (k == ~0ull) continue;
-			pathBytes += hOutOffsets[k + 1] - hOutOffsets[k]; cigarBytes += hOutOffsets[stride + k + 1] - hOutOffsets[stride + k]; vgBytes += hOutOffsets[2 * stride + k + 1] - hOutOffsets[2 * stride + k];
-		}
-		res->out_path_off[nOut] = pathBytes; res->out_cigar_off[nOut] = cigarBytes; res->out_vg_off[nOut] = vgBytes;
-		res->out_path_text = resultArray<char>(pathBytes + 1); res->out_cigar_text = resultArray<char>(cigarBytes + 1); res->out_vg_path = resultArray<uint8_t>(vgBytes + 1);
-		bool allKept = nOut == nOutJobs;   // no chained winner: the device's blobs are the result's, job k is entry k
-		for (uint64_t e = 0; e < nOut && allKept; e++) allKept = outJobOfEntry[e] == e;   // (a winner's one entry can stand where a read's one dropped job was: the counts alone do not tell)
-		const size_t parts = 16;
-		if (allKept) pool.run(3 * parts, [&](size_t i, size_t) {
-			const size_t which = i / parts, part = i % parts;
-			const uint64_t total = which == 0 ? pathBytes : which == 1 ? cigarBytes : vgBytes;
-			const char* src = which == 0 ? hOutPath : which == 1 ? hOutCigar : (const char*)hOutVg;
-			char* dst = which == 0 ? res->out_path_text : which == 1 ? res->out_cigar_text : (char*)res->out_vg_path;
-			const uint64_t b = total * part / parts, e = total * (part + 1) / parts;
-			if (e > b) memcpy(dst + b, src + b, e - b);
-		});
-		else pool.run(nOut, [&](size_t e, size_t) {
-			const uint64_t k = outJobOfEntry[e];
-			if (k == ~0ull) return;
-			memcpy(res->out_path_text + res->out_path_off[e], hOutPath + hOutOffsets[k], hOutOffsets[k + 1] - hOutOffsets[k]);
-			memcpy(res->out_cigar_text + res->out_cigar_off[e], hOutCigar + hOutOffsets[stride + k], hOutOffsets[stride + k + 1] - hOutOffsets[stride + k]);
-			memcpy(res->out_vg_path + res->out_vg_off[e], hOutVg + hOutOffsets[2 * stride + k], hOutOffsets[2 * stride + k + 1] - hOutOffsets[2 * stride + k]);
-		});
-		res->out_path_text[pathBytes] = 0; res->out_cigar_text[cigarBytes] = 0;
-		for (uint64_t e = 0; e < nOut; e++) {
-			const OutEntry& en = outEntries[e];
-			res->out_source[e] = en.source;
-			uint64_t* num = res->out_numbers + 12 * e;
-			if (en.source == 0) {
-				const OutRec& rec = hOutRecs[outJobOfEntry[e]];
-				const LongAln& al = glue[en.read].longAlns[en.aln];
-				num[0] = rec.nodePathLen; num[1] = rec.nodePathStart; num[2] = rec.nodePathEnd; num[3] = rec.matches; num[4] = rec.mismatches; num[5] = rec.insertions; num[6] = rec.deletions;
-				num[7] = al.traceLen; num[8] = al.start; num[9] = al.end; num[10] = rec.steps; num[11] = al.score;
-			} else for (int i = 0; i < 12; i++) num[i] = 0;
-		}
-	}
-
-	// ---------------- the flat result: count per read, prefix-sum, fill in parallel
-	void assemble()
-	{
-		// ---------------- assemble the flat result: count per read, prefix-sum, fill in parallel
-		double tAsm = nowUs();
-		if (glueCopied) HIP_CHECK(hipEventSynchronize(glueCopied));   // (long since done: the copies were queued before the fragment pipeline)
-		std::vector<uint8_t> failedAssertion(n, 0);
-		std::vector<uint64_t> seedsExtended(n, 0), seedsExtendedLong(n, 0);
-		// read position of the seed in a fragment-pass slot (the device holds the per-slot records; the host keeps seeds and windows)
-		auto slotSeqPos = [&](uint64_t r, uint64_t slot, uint64_t F) -> uint32_t {
-			(void)r;
-			return readSeeds[fragFirstSeed[F] + (slot - frags[F].seedBegin)].seqPos;   // (host copies: kept whenever keep_traces asks for this)
-		};
-		auto forEachAnchor = [&](uint64_t r, auto&& visit) {   // visit(slotIndex, fragmentIndex) for every anchor the reference would keep
-			const ReadGlue& gl = glue[r];
-			if (gl.longFailed) return;   // `cont` was already set by the whole-read pass (src/Aligner.cpp:529,591,702)
-			uint64_t slot = gl.slotBegin;
-			for (size_t f = 0; f < gl.nWindows; f++) {
-				uint64_t F = gl.fragBegin + f;
-				uint32_t nS = frags[F].seedEnd - frags[F].seedBegin;
-				if (fragStatus[F] == 1) return;   // `cont` is never reset: later fragments add nothing (src/Aligner.cpp:695-703)
-				for (uint32_t k = 0; k < nS; k++) if (anchors[slot + k].valid) visit(slot + k, F);
-				slot += nS;
-			}
-		};
-		pool.run(n, [&](size_t r, size_t) {
-			ReadGlue& gl = glue[r];
-			failedAssertion[r] = gl.failed ? 1 : 0;
-			if (gl.longFailed) {   // the fragment pipeline ran beside the whole-read pass; what it found for this read is dropped
-				failedAssertion[r] = 1;
-				chainLen[r] = 0; chainScore[r] = 0; chainStatus[r] = 0;
-				gl.stitched = StitchedPath();
-				gl.chainEditDistance = -1;
-				if (P->long_pass) seedsExtendedLong[r] = hLongResults[r].seedsExtended;
-				return;
-			}
-			if (chainStatus[r] != 0) { gl.capacityExceeded = true; chainLen[r] = 0; chainScore[r] = 0; }
-			for (size_t f = 0; f < gl.nWindows; f++) {
-				uint64_t F = gl.fragBegin + f;
-				if (fragStatus[F] == 2) gl.capacityExceeded = true;   // an extension or the anchor path pool overflowed even in the retry: this fragment gave no anchors
-				if (fragStatus[F] == 1) { failedAssertion[r] = 1; break; }
-				seedsExtended[r] += fragExtended[F];
-			}
-			if (P->long_pass) {
-				seedsExtendedLong[r] = hLongResults[r].seedsExtended;
-				if (hLongResults[r].status == 1) failedAssertion[r] = 1;
-			}
-			forEachAnchor(r, [&](uint64_t slot, uint64_t F) {
-				gl.nAnchors++;
-				gl.nPath += anchors[slot].pathLen;
-				if (anchorTraces) {
-					const ExtResult& eb = extResults[2 * slot];
-					const ExtResult& ef = extResults[2 * slot + 1];
-					uint32_t p = slotSeqPos(r, slot, F) - (anchors[slot].x);
-					bool hasB = p > 0 && eb.status == EXT_OK, hasF = p < (uint32_t)P->split_len - 1 && ef.status == EXT_OK;
-					gl.nTrace += (hasB ? (hasF ? eb.traceLen - 1 : eb.traceLen) : 0) + (hasF ? ef.traceLen : 0);
-				}
-			});
-		});
-		uint64_t nAnchors = 0, nPath = 0, nTrace = 0, nChain = 0, nLong = 0, nLongTrace = 0, nStitched = 0, nLongSelected = 0, nChainTrace = 0;
-		for (uint64_t r = 0; r < n; r++) {
-			glue[r].anchorBegin = nAnchors; glue[r].pathBegin = nPath; glue[r].traceBegin = nTrace; glue[r].chainBegin = nChain;
-			glue[r].longBegin = nLong; glue[r].longTraceBegin = nLongTrace;
-			nAnchors += glue[r].nAnchors; nPath += glue[r].nPath; nTrace += glue[r].nTrace; nChain += chainLen[r];
-			nLong += glue[r].longAlns.size();
-			glue[r].stitchedBegin = nStitched; nStitched += glue[r].stitched.nodes.size();
-			glue[r].longSelectedBegin = nLongSelected; nLongSelected += glue[r].longSelected.size();
-			glue[r].chainTraceBegin = nChainTrace; nChainTrace += glue[r].chainTraceNode.size();
-			if (P->keep_traces) for (const LongAln& a : glue[r].longAlns) nLongTrace += a.traceLen;
-		}
-		const bool keepSeeds = P->keep_seeds != 0;
-		std::vector<uint64_t> seedOutBegin(n + 1, 0);   // the result's seed lists are dense (the device's sit at capacity offsets)
-		for (uint64_t r = 0; r < n; r++) seedOutBegin[r + 1] = seedOutBegin[r] + (keepSeeds ? glue[r].nSeedsR : 0);
-		const uint64_t nSeedsOut = seedOutBegin[n];
-		res->read_seed_off = resultArray<uint64_t>(n + 1);
-		res->seed_node = resultArray<uint32_t>(nSeedsOut); res->seed_offset = resultArray<uint32_t>(nSeedsOut);
-		res->seed_seqpos = resultArray<uint32_t>(nSeedsOut); res->seed_goodness = resultArray<uint64_t>(nSeedsOut);
-		res->read_anchor_off = resultArray<uint64_t>(n + 1);
-		res->anchor_x = resultArray<uint32_t>(nAnchors); res->anchor_y = resultArray<uint32_t>(nAnchors);
-		res->anchor_path_off = resultArray<uint64_t>(nAnchors + 1); res->anchor_path = resultArray<uint32_t>(nPath);
-		res->anchor_first_node = resultArray<uint32_t>(nAnchors); res->anchor_first_offset = resultArray<uint32_t>(nAnchors); res->anchor_first_seqpos = resultArray<uint32_t>(nAnchors);
-		res->anchor_last_node = resultArray<uint32_t>(nAnchors); res->anchor_last_offset = resultArray<uint32_t>(nAnchors); res->anchor_last_seqpos = resultArray<uint32_t>(nAnchors);
-		res->anchor_score = resultArray<int32_t>(nAnchors);
-		if (anchorTraces) {
-			res->anchor_trace_off = resultArray<uint64_t>(nAnchors + 1);
-			res->anchor_trace_node = resultArray<int32_t>(nTrace); res->anchor_trace_offset = resultArray<uint32_t>(nTrace);
-			res->anchor_trace_seqpos = resultArray<uint32_t>(nTrace); res->anchor_trace_switch = resultArray<uint8_t>(nTrace);
-			res->anchor_trace_off[nAnchors] = nTrace;
-		}
-		res->read_chain_off = resultArray<uint64_t>(n + 1);
-		res->chain = resultArray<uint32_t>(nChain);
-		res->chain_score = resultArray<uint64_t>(n);
-		res->read_longall_off = resultArray<uint64_t>(n + 1);
-		res->read_longall_off[n] = nLong;
-		res->longall_start = resultArray<uint32_t>(nLong); res->longall_end = resultArray<uint32_t>(nLong); res->longall_score = resultArray<uint32_t>(nLong);
-		res->long_trace_off = resultArray<uint64_t>(nLong + 1);
-		res->long_trace_off[nLong] = nLongTrace;
-		res->long_trace_node = resultArray<int32_t>(nLongTrace); res->long_trace_offset = resultArray<uint32_t>(nLongTrace);
-		res->long_trace_seqpos = resultArray<uint32_t>(nLongTrace); res->long_trace_switch = resultArray<uint8_t>(nLongTrace);
-		res->seeds_extended_long = resultArray<uint64_t>(n);
-		res->read_long_off = resultArray<uint64_t>(n + 1);
-		res->read_long_off[n] = nLongSelected;
-		res->long_index = resultArray<uint32_t>(nLongSelected);
-		res->long_edit_distance = resultArray<int64_t>(n); res->chain_edit_distance = resultArray<int64_t>(n); res->chained_better = resultArray<uint8_t>(n);
-		res->read_path_off = resultArray<uint64_t>(n + 1);
-		res->read_path_off[n] = nStitched;
-		res->path_node = resultArray<uint32_t>(nStitched);
-		res->path_first_offset = resultArray<uint32_t>(n); res->path_last_offset = resultArray<uint32_t>(n); res->path_cells = resultArray<uint64_t>(n);
-		res->read_chain_trace_off = resultArray<uint64_t>(n + 1);
-		res->read_chain_trace_off[n] = nChainTrace;
-		res->chain_trace_node = resultArray<int32_t>(nChainTrace); res->chain_trace_offset = resultArray<uint32_t>(nChainTrace);
-		res->chain_trace_seqpos = resultArray<uint32_t>(nChainTrace); res->chain_trace_switch = resultArray<uint8_t>(nChainTrace);
-		res->chain_aln_start = resultArray<uint32_t>(n); res->chain_aln_end = resultArray<uint32_t>(n);
-		res->failed_assertion = resultArray<uint8_t>(n);
-		res->capacity_exceeded = resultArray<uint8_t>(n);
-		res->seeds_extended = resultArray<uint64_t>(n);
-		res->read_seed_off[n] = nSeedsOut; res->read_anchor_off[n] = nAnchors; res->anchor_path_off[nAnchors] = nPath; res->read_chain_off[n] = nChain;
-		pool.run(n, [&](size_t r, size_t) {
-			const ReadGlue& gl = glue[r];
-			res->read_seed_off[r] = seedOutBegin[r];
-			if (keepSeeds) {
-				uint64_t at = seedOutBegin[r];
-				for (uint32_t k = 0; k < gl.nSeedsR; k++, at++) {
-					const FragSeed& s = readSeeds[gl.seedBegin + k];   // fragment-pass order; pad = seedGoodness
-					res->seed_node[at] = s.node; res->seed_offset[at] = s.offset; res->seed_seqpos[at] = s.seqPos; res->seed_goodness[at] = s.pad;
-				}
-			}
-			res->read_anchor_off[r] = gl.anchorBegin;
-			res->read_chain_off[r] = gl.chainBegin;
-			res->chain_score[r] = chainScore[r];
-			res->failed_assertion[r] = failedAssertion[r];
-			res->capacity_exceeded[r] = gl.capacityExceeded ? 1 : 0;
-			res->seeds_extended[r] = seedsExtended[r];
-			res->seeds_extended_long[r] = seedsExtendedLong[r];
-			res->read_longall_off[r] = gl.longBegin;
-			res->read_path_off[r] = gl.stitchedBegin;
-			res->read_long_off[r] = gl.longSelectedBegin;
-			for (size_t i = 0; i < gl.longSelected.size(); i++) res->long_index[gl.longSelectedBegin + i] = gl.longSelected[i];
-			res->long_edit_distance[r] = gl.longEditDistance;
-			res->chain_edit_distance[r] = gl.chainEditDistance;
-			// src/Aligner.cpp:901-905: the chained alignment wins when there is no whole-read alignment or its edit distance is larger
-			res->chained_better[r] = gl.chainWins ? 1 : 0;
-			res->read_chain_trace_off[r] = gl.chainTraceBegin;
-			if (!gl.chainTraceNode.empty()) {
-				memcpy(res->chain_trace_node + gl.chainTraceBegin, gl.chainTraceNode.data(), gl.chainTraceNode.size() * sizeof(int32_t));
-				memcpy(res->chain_trace_offset + gl.chainTraceBegin, gl.chainTraceOffset.data(), gl.chainTraceOffset.size() * sizeof(uint32_t));
-				memcpy(res->chain_trace_seqpos + gl.chainTraceBegin, gl.chainTraceSeqPos.data(), gl.chainTraceSeqPos.size() * sizeof(uint32_t));
-				memcpy(res->chain_trace_switch + gl.chainTraceBegin, gl.chainTraceSwitch.data(), gl.chainTraceSwitch.size());
-			}
-			res->chain_aln_start[r] = gl.chainAlnStart; res->chain_aln_end[r] = gl.chainAlnEnd;
-			for (size_t i = 0; i < gl.stitched.nodes.size(); i++) res->path_node[gl.stitchedBegin + i] = gl.stitched.nodes[i];
-			res->path_first_offset[r] = gl.stitched.firstOffset; res->path_last_offset[r] = gl.stitched.lastOffset; res->path_cells[r] = gl.stitched.cells;
-			{
-				uint64_t la = gl.longBegin, lt = gl.longTraceBegin;
-				for (const LongAln& al : gl.longAlns) {
-					res->longall_start[la] = al.start; res->longall_end[la] = al.end; res->longall_score[la] = al.score;
-					res->long_trace_off[la] = P->keep_traces ? lt : 0;
-					if (P->keep_traces) for (uint32_t i = 0; i < al.traceLen; i++, lt++) {
-						const LongCell& c = longCells[al.traceOff + i];
-						res->long_trace_node[lt] = c.node; res->long_trace_offset[lt] = c.offset; res->long_trace_seqpos[lt] = c.seqPos; res->long_trace_switch[lt] = (uint8_t)c.nodeSwitch;
-					}
-					la++;
-				}
-			}
-			for (uint32_t i = 0; i < chainLen[r]; i++) res->chain[gl.chainBegin + i] = chainOut[jobs[r].chainBegin + i];
-			uint64_t a = gl.anchorBegin, pathAt = gl.pathBegin, traceAt = gl.traceBegin;
-			forEachAnchor(r, [&](uint64_t slot, uint64_t F) {
-				const AnchorRec& rec = anchors[slot];
-				res->anchor_x[a] = rec.x; res->anchor_y[a] = rec.y;
-				res->anchor_path_off[a] = pathAt;
-				for (uint32_t i = 0; i < rec.pathLen; i++) res->anchor_path[pathAt++] = pathPool[rec.pathOff + i];
-				res->anchor_first_node[a] = rec.firstNode; res->anchor_first_offset[a] = rec.firstOffset; res->anchor_first_seqpos[a] = rec.firstSeqPos + frags[F].l;
-				res->anchor_last_node[a] = rec.lastNode; res->anchor_last_offset[a] = rec.lastOffset; res->anchor_last_seqpos[a] = rec.lastSeqPos + frags[F].l;
-				res->anchor_score[a] = rec.score;
-				if (anchorTraces) {
-					// merged trace in the reference's output coordinates (bigraph node id, offset in original node),
-					// src/GraphAligner.h:527-565,590-608
-					res->anchor_trace_off[a] = traceAt;
-					const ExtResult& eb = extResults[2 * slot];
-					const ExtResult& ef = extResults[2 * slot + 1];
-					uint32_t p = slotSeqPos(r, slot, F) - frags[F].l;
-					bool hasB = p > 0 && eb.status == EXT_OK, hasF = p < (uint32_t)P->split_len - 1 && ef.status == EXT_OK;
-					if (hasB) {
-						uint32_t use = hasF ? eb.traceLen - 1 : eb.traceLen;
-						for (uint32_t i = 0; i < use; i++) {
-							const TraceCell& c = tracePool[eb.traceOff + i];
-							uint32_t off = c.offsetAndSwitch & 255u;
-							auto rev = hg.GetReversePosition(hg.nodeIDs[c.node], hg.nodeOffset[c.node] + off);
-							res->anchor_trace_node[traceAt] = rev.first;
-							res->anchor_trace_offset[traceAt] = (uint32_t)rev.second;
-							res->anchor_trace_seqpos[traceAt] = (uint32_t)((int32_t)p - 1 - c.seqPos);
-							bool sw = i + 1 < eb.traceLen ? ((tracePool[eb.traceOff + i + 1].offsetAndSwitch >> 8) & 1) : false;
-							res->anchor_trace_switch[traceAt] = sw ? 1 : 0;
-							traceAt++;
-						}
-					}
-					if (hasF) {
-						for (uint32_t i = ef.traceLen; i-- > 0;) {
-							const TraceCell& c = tracePool[ef.traceOff + i];
-							uint32_t off = c.offsetAndSwitch & 255u;
-							res->anchor_trace_node[traceAt] = hg.nodeIDs[c.node];
-							res->anchor_trace_offset[traceAt] = (uint32_t)(hg.nodeOffset[c.node] + off);
-							res->anchor_trace_seqpos[traceAt] = (uint32_t)((int32_t)p + 1 + c.seqPos);
-							res->anchor_trace_switch[traceAt] = (c.offsetAndSwitch >> 8) & 1;
-							traceAt++;
-						}
-					}
-				}
-				a++;
-			});
-		});
-		assembleOutput();
-		res->host_us[1] = nowUs() - tAsm;
-		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc cpu] %.0f ms up to the end of the batch (the join came at %.0f)\n", processCpuMs() - cpuCall, cpuJoined - cpuCall);
-		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] batch timeline (ms from the call): whole-read pass started %.1f, joined %.1f, assembly began %.1f, done %.1f\n", (tLongWall0 - tTotal) / 1e3, (tJoined - tTotal) / 1e3, (tAsm - tTotal) / 1e3, (nowUs() - tTotal) / 1e3);
-	}
-};
-
-int gc_align_batch(const gc_graph* G, const gc_seeder* S, gc_stream* st, const gc_reads* R, const gc_params* P, gc_result** out)
-{
-	if (!G || !S || !st || !R || !P || !out) return fail(GC_ERR_INVALID, "null argument");
-	if (P->split_len < 16 || P->split_len > 64 || P->split_gap < 1) return fail(GC_ERR_INVALID, "split_len must be in [16,64] (one 64-row slice per fragment extension) and split_gap >= 1");
-	{
-		const gc_capacities& c = P->capacity;
-		if (c.reserved[0] || c.reserved[1] || c.reserved[2]) return fail(GC_ERR_INVALID, "gc_params::capacity.reserved must be 0 (was the struct initialised with gc_params_default?)");
-		const int64_t v[] = { c.ext_max_items, c.ext_max_pending, c.ext_max_trace, c.long_max_items, c.long_cells_per_base, c.long_scratch_bytes, c.stitch_set_max, c.stitch_bfs_cap };
-		for (int64_t x : v) if (x < 0 || x > (1ll << 40)) return fail(GC_ERR_INVALID, "gc_params::capacity: a size is negative or absurd (0 = automatic)");
-		// what the consumers can hold: the tables are indexed with 32 bits, and the retry launch takes 16x the fragment sizes
-		if (c.ext_max_items > (1ll << 24) || c.ext_max_pending > (1ll << 24) || c.ext_max_trace > (1ll << 24)) return fail(GC_ERR_INVALID, "gc_params::capacity.ext_*: at most 2^24 (the retry launch reserves 16x)");
-		if (c.long_max_items > (1ll << 28)) return fail(GC_ERR_INVALID, "gc_params::capacity.long_max_items: at most 2^28");
-		if (c.long_cells_per_base > 4096) return fail(GC_ERR_INVALID, "gc_params::capacity.long_cells_per_base: at most 4096");
-		if (c.stitch_set_max > (1ll << 31) - 1 || c.stitch_bfs_cap > (1ll << 31) - 1) return fail(GC_ERR_INVALID, "gc_params::capacity.stitch_*: at most 2^31 - 1");
-		if (c.long_column_store < -1 || c.long_column_store > (1ll << 31)) return fail(GC_ERR_INVALID, "gc_params::capacity.long_column_store: -1 (none), 0 (automatic) or a column count");
-	}
-	if (P->device_output < 0 || P->device_output > 7 || (P->device_output & 3) == 3) return fail(GC_ERR_INVALID, "gc_params::device_output: 1 or 2 (GAF pieces with = / X or with M), optionally + 4 (vg::Path bytes)");
-	if (P->device_output && !(P->long_pass && P->edit_distances)) return fail(GC_ERR_INVALID, "gc_params::device_output needs long_pass and edit_distances (the final alignments are what it encodes)");
-	*out = nullptr;
-	const double tCall = nowUs();
-	const double cpuCall = processCpuMs();
-	gc_result* res = (gc_result*)calloc(1, sizeof(gc_result));
-	int rc = guarded([&]() {
-		HIP_CHECK(hipSetDevice(st->device));   // the current device is per host thread
-		// without the chained alignment's trace the decision comes from the two distances alone, which skips --E-cutoff's test of the chained alignment
-		// (src/Aligner.cpp:904): with a cut-off set the traces are made whatever chain_traces says
-		gc_params effective = *P;
-		if (effective.chain_traces == 0 && effective.e_cutoff >= 0 && effective.stitch && effective.edit_distances) effective.chain_traces = 1;
-		BatchRun batch(G, S, st, R, &effective, res, tCall, cpuCall);
-		batch.run();
-		return (int)GC_OK;
-	});
-	if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] gc_align_batch returned after %.1f ms\n", (nowUs() - tCall) / 1e3);
-	if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc token] stream %p call returned %.1f\n", (void*)st, nowUs() / 1e3);
-	if (rc != GC_OK) { gc_result_free(res); return rc; }
-	*out = res;
-	return GC_OK;
-}
 
 } // extern "C"

@@ -11,7 +11,7 @@
 // lane-interleaved ([word][lane]): the pending queue (16 entries: node, componentNumber, column) and the node tables of the current and the
 // previous slice (32 entries: node, start score, minimum). The trace goes straight into the round's trace pool, into a slot reserved when the
 // extension starts (its length is bounded by 1.5 x rows + 512, the bound the host sizes the pool by).
-// An extension that outgrows a table answers EXT_SM_DECLINED and is rerun by k_long_extend<1> (gc_capi.hip: runLongGroup).
+// An extension that outgrows a table answers EXT_SM_DECLINED and is rerun by k_long_extend<1> (gc_batch.hip: runLongGroup).
 #include "gc_kernels.hpp"
 #include "gc_sm_core.hpp"
 

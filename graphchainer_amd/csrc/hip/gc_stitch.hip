@@ -23,7 +23,7 @@
 // output array (position from an atomic cursor; StitchInfo.start says where).
 // Anything that does not fit - more nodes on a piece than half the set's slots, a BFS that visits more than STITCH_BFS_CAP
 // nodes, a full region or output array - sets status 1 and the host stitches that read with the same algorithm
-// (gc_capi.hip).
+// (gc_runtime.hpp: stitchChain).
 #include "gc_kernels.hpp"
 #include <hip/hip_runtime.h>
 
