@@ -4,6 +4,7 @@
 #   TSan:         the threaded start-up builders (MPC index per component, minimizer scan per node chunk) with 8 threads
 #   ASan + UBSan: the oracle itself (whole pipeline, stitching, encoders) under its golden and unit tests
 #   ASan + UBSan: the encoders' split-node cursor over every letter of a graph
+#   TSan, ASan + UBSan (r4): the flat first build of a graph on 8 threads against the literal builder; the hash-order replay against the real containers
 # Usage (repo root): bash scripts/sanitize_host.sh
 set -eu
 root=$(cd "$(dirname "$0")/.." && pwd)
@@ -19,4 +20,12 @@ g++ -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer
 (cd $root && GC_ORACLE_LIBRARY=$work/liboracle_asan.so ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) python3 -m pytest tests/test_oracle_golden.py tests/test_oracle_units.py -x -q)
 g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I$H $root/tests/output_host/letters_test.cpp $H/gc_output.cpp $H/gc_graph.cpp -o $work/letters_test -lpthread -lz
 ASAN_OPTIONS=detect_leaks=0 $work/letters_test $root/tests/golden/syn20k.gfa
+# r4: the flat, threaded first build (gc_graph_fast.cpp) against the literal one - TSan with 8 threads over a synthetic genome, ASan + UBSan over the same and the golden graphs; gc::HashOrder against the real containers
+(cd $root && python3 -c "from graphchainer_amd.synth import SynthGenome; SynthGenome(6, 120_000, seed=9, multi_allelic=0.1, nested=0.1, minus_links=0.3, repeats=2, repeat_len=1200).write_gfa('$work/genome.gfa')")
+g++ -O1 -g -std=c++17 -fsanitize=thread -I$H $root/tests/graph_build/build_compare.cpp $H/gc_graph.cpp $H/gc_graph_fast.cpp -o $work/build_compare_tsan -lpthread
+GC_BUILD_THREADS=8 $work/build_compare_tsan $work/genome.gfa
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I$H $root/tests/graph_build/build_compare.cpp $H/gc_graph.cpp $H/gc_graph_fast.cpp -o $work/build_compare_asan -lpthread
+for f in $work/genome.gfa $root/tests/golden/syn20k.gfa $root/tests/golden/ref_test_graph.gfa; do GC_BUILD_THREADS=8 ASAN_OPTIONS=detect_leaks=0 $work/build_compare_asan $f; done
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I$H $root/tests/hashorder/hashorder_test.cpp -o $work/hashorder_asan
+ASAN_OPTIONS=detect_leaks=0 $work/hashorder_asan
 echo "sanitizers: clean"
