@@ -477,8 +477,8 @@ struct ReadGlue {
 };
 
 struct EditDistanceRun {
-	hipStream_t streams[7] {};         // one per kernel class: three pairs per wave, two pairs per wave, then units of 1, 2, 4, 8, 16 blocks
-	uint32_t begin[8] {};              // the classes' ranges in the grouped order
+	hipStream_t streams[8] {};         // one per kernel class: three pairs per wave, two pairs per wave, units of 1, 2, 4, 8, 16 blocks, a workgroup per pair (the whole matrix)
+	uint32_t begin[9] {};              // the classes' ranges in the grouped order
 	hipEvent_t ready = nullptr;
 	std::vector<uint32_t> perm;        // position in the grouped order -> original pair index
 	std::vector<int64_t> grouped;      // results in grouped order (pinned not needed: small)
@@ -812,7 +812,8 @@ inline void launchEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 	// (a class's stream is created when the class is first used: the batch's streams share the device's 16 hardware queues, and on cfg2 only the
 	// two-pairs-per-wave class and the one-block class ever hold pairs)
 	std::vector<uint32_t> cls(nPairs);
-	uint32_t count[7] = { 0, 0, 0, 0, 0, 0, 0 };
+	uint32_t count[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	uint32_t blockThreads = 64;        // class 7: threads of a workgroup = the 64-row blocks of the class's longest read
 	uint32_t* begin = run.begin;
 	static const bool halfWaves = !(getenv("GC_ED_HALF") && atoi(getenv("GC_ED_HALF")) == 0);
 	static const bool thirdWaves = halfWaves && !(getenv("GC_ED_THIRD") && atoi(getenv("GC_ED_THIRD")) == 0);
@@ -832,29 +833,34 @@ inline void launchEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 			// failed sweep with the same guess in the one-pair-per-wave kernel and a third with the doubled band (r3)
 			hPairs[i].k = c == 0 ? editDistanceTeamMaxK(3) - 1 : std::max(hPairs[i].k, editDistanceMaxK(0) - 1);
 		}
+		// class 7 (r4): a band of half the read or more covers most of the matrix - a chain whose path spells a fraction of its read, a whole-read alignment of a sliver: the pair
+		// gets a workgroup with one thread per 64-row block and the whole matrix (exact, no retry) instead of one wave with up to sixteen blocks per lane and step
+		static const bool blockPairs = !(getenv("GC_ED_BLOCK") && atoi(getenv("GC_ED_BLOCK")) == 0);
+		if (blockPairs && len >= 1 && len <= editDistanceBlockMaxRows() && 2ull * hPairs[i].k >= len) { c = 7; blockThreads = std::max(blockThreads, (len + 63u) / 64u); }
 		cls[i] = c;
 		count[c]++;
 	}
 	begin[0] = 0;
-	for (int c = 0; c < 7; c++) begin[c + 1] = begin[c] + count[c];
+	for (int c = 0; c < 8; c++) begin[c + 1] = begin[c] + count[c];
 	run.perm.resize(nPairs);
 	{
-		uint32_t at[7] = { begin[0], begin[1], begin[2], begin[3], begin[4], begin[5], begin[6] };
+		uint32_t at[8] = { begin[0], begin[1], begin[2], begin[3], begin[4], begin[5], begin[6], begin[7] };
 		std::vector<EdPair> grouped(nPairs);
 		for (uint32_t i = 0; i < nPairs; i++) { grouped[at[cls[i]]] = hPairs[i]; run.perm[at[cls[i]]++] = i; }
 		memcpy(hPairs, grouped.data(), (size_t)nPairs * sizeof(EdPair));   // hPairs is now in grouped order
 	}
 	HIP_CHECK(hipMemcpyAsync(dPairs, hPairs, (size_t)nPairs * sizeof(EdPair), hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipEventRecord(run.ready, stream));
-	for (int c = 0; c < 7; c++) {
+	for (int c = 0; c < 8; c++) {
 		if (!count[c]) continue;
 		if (!run.streams[c]) createStream(&run.streams[c], 0);
 		HIP_CHECK(hipStreamWaitEvent(run.streams[c], run.ready, 0));
-		if (c < 2) launchEditDistanceTeam(run.streams[c], c == 0 ? 3u : 2u, dPairs + begin[c], count[c], dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut + begin[c]);
+		if (c == 7) launchEditDistanceBlock(run.streams[c], blockThreads, dPairs + begin[c], count[c], dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut + begin[c]);
+		else if (c < 2) launchEditDistanceTeam(run.streams[c], c == 0 ? 3u : 2u, dPairs + begin[c], count[c], dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut + begin[c]);
 		else launchEditDistance(run.streams[c], 1u << (c - 2), dPairs + begin[c], count[c], dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut + begin[c]);
 		HIP_CHECK(hipMemcpyAsync(hOut + begin[c], dOut + begin[c], (size_t)count[c] * sizeof(int64_t), hipMemcpyDeviceToHost, run.streams[c]));
 	}
-	if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] edit distance classes (3 per wave, 2 per wave, units 1..16): %u %u %u %u %u %u %u\n", count[0], count[1], count[2], count[3], count[4], count[5], count[6]);
+	if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] edit distance classes (3 per wave, 2 per wave, units 1..16, workgroup per pair): %u %u %u %u %u %u %u %u\n", count[0], count[1], count[2], count[3], count[4], count[5], count[6], count[7]);
 }
 inline void finishEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair* hPairs, int64_t* hOut, uint32_t nPairs, EdPair* dPairs, int64_t* dOut, const EdRead* dReads, const char* dBases,
 	const uint64_t* dEqMasks, const char* dLetters, const uint32_t* dLettersLen)

@@ -427,6 +427,92 @@ __global__ void __launch_bounds__(64) k_edit_distance_team(const EdPair* __restr
 	}
 }
 
+// The whole matrix by one WORKGROUP (r4): thread B owns the 64 rows of block B for every column, the threads sweep the matrix as one skewed wavefront (block B is on column t - B at
+// step t) and hand the horizontal delta of their bottom row to the next thread through LDS, one barrier per step. For the pairs whose band would cover most of the matrix anyway - a
+// chain whose path spells a fraction of its read (distance >= the length difference), a whole-read alignment of a sliver of its read: the banded kernels give such a pair ONE wave
+// with up to sixteen blocks per lane and step (config 5: a 50 000 x 1 000 pair held its stream for 385 ms; cfg2: ~800 pairs per batch in k_edit_distance<4>, 11.8 ms alone). Here a
+// pair takes columns + blocks steps of one block each: ~1 ms for the former, and every pair of the latter kind gets its own three waves. No band, no retry: the result is exact.
+#define ED_BLOCK_THREADS 1024u
+__global__ void __launch_bounds__(ED_BLOCK_THREADS) k_edit_distance_block(const EdPair* __restrict__ pairs, uint32_t nPairs, const EdRead* __restrict__ reads, const char* __restrict__ bases,
+	const uint64_t* __restrict__ eqMasks, const char* __restrict__ letters, const uint32_t* __restrict__ lettersLen, int64_t* __restrict__ outDistance)
+{
+	__shared__ int8_t hand[2][ED_BLOCK_THREADS];   // the horizontal delta leaving block B's bottom row at the column it has just computed, double-buffered by step parity
+	__shared__ int32_t resultSlot;
+	const uint32_t B = threadIdx.x;
+	for (uint32_t pi = blockIdx.x; pi < nPairs; pi += gridDim.x) {
+		const EdPair pair = pairs[pi];
+		const EdRead rd = reads[pair.read];
+		const uint32_t n = rd.len;
+		const uint32_t m = lettersLen ? lettersLen[pair.lenIndex] : pair.m;
+		if (m == 0xffffffffu) { if (B == 0) outDistance[pi] = -3; continue; }   // path letters overflowed their slot
+		if (n == 0 || m == 0) { if (B == 0) outDistance[pi] = (int64_t)(n + m); continue; }
+		const uint32_t nU = (n + 63u) / 64u;
+		if (nU > blockDim.x) { if (B == 0) outDistance[pi] = -2; continue; }       // (the host sends only pairs that fit: -2 = the banded kernels take it)
+		const char* path = letters + pair.lettersOff;
+		const uint64_t* masks = eqMasks + rd.eqOff;
+		const bool mine = B < nU;
+		const bool in = mine && B < rd.words;
+		const uint64_t eqA = in ? masks[B] : 0ull, eqC = in ? masks[rd.words + B] : 0ull, eqG = in ? masks[2ull * rd.words + B] : 0ull, eqT = in ? masks[3ull * rd.words + B] : 0ull;
+		uint64_t VP = ~0ull, VN = 0;
+		int32_t score = (int32_t)(64u * (B + 1));                                  // the bottom row of the block in the column before the first: D[i][-1] = i + 1
+		const uint32_t lastUnit = (n - 1) / 64u;
+		const uint32_t steps = m + nU - 1;
+		if (B == 0) resultSlot = -1;
+		__syncthreads();
+		uint8_t chNext = mine && B == 0 ? (uint8_t)path[0] : 0;                      // the letter of the NEXT step is fetched a step ahead: its latency hides behind this step's work and barrier
+		for (uint32_t t = 0; t < steps; t++) {
+			const uint32_t j = t - B;
+			const uint8_t ch = chNext;
+			if (mine && t + 1 >= B && j + 1 < m) chNext = (uint8_t)path[j + 1];
+			if (mine && t >= B && j < m) {
+				const int hin = B > 0 ? (int)hand[(t + 1) & 1][B - 1] : 1;              // (the row above the matrix climbs by one per column)
+				uint64_t Eq;
+				if (ch == 'A') Eq = eqA; else if (ch == 'C') Eq = eqC; else if (ch == 'G') Eq = eqG; else if (ch == 'T') Eq = eqT;
+				else {
+					Eq = 0;
+					const uint64_t row0 = 64ull * B;
+					for (uint32_t i = 0; i < 64 && row0 + i < n; i++) if ((uint8_t)bases[rd.readOff + row0 + i] == ch) Eq |= 1ull << i;
+				}
+				const uint64_t hinP = hin > 0 ? 1 : 0, hinN = hin < 0 ? 1 : 0;
+				const uint64_t Xv = Eq | VN;
+				Eq |= hinN;
+				const uint64_t Xh = (((Eq & VP) + VP) ^ VP) | Eq;
+				uint64_t Ph = VN | ~(Xh | VP);
+				uint64_t Mh = VP & Xh;
+				const int hout = (int)(Ph >> 63) - (int)(Mh >> 63);
+				Ph = (Ph << 1) | hinP;
+				Mh = (Mh << 1) | hinN;
+				VP = Mh | ~(Xv | Ph);
+				VN = Ph & Xv;
+				score += hout;
+				hand[t & 1][B] = (int8_t)hout;
+				if (B == lastUnit && j == m - 1) {
+					int32_t d = score;
+					const uint64_t row0 = 64ull * B;
+					uint64_t pad = 0;
+					if (row0 + 64 > n) pad = ~0ull << (n - row0);                        // rows of the block beyond the read: step back up to row n - 1
+					d -= __popcll(VP & pad);
+					d += __popcll(VN & pad);
+					resultSlot = d;
+				}
+			}
+			__syncthreads();
+		}
+		if (B == 0) outDistance[pi] = (int64_t)resultSlot;
+		__syncthreads();
+	}
+}
+
+void launchEditDistanceBlock(hipStream_t stream, uint32_t threads, const EdPair* pairs, uint32_t nPairs, const EdRead* reads, const char* bases, const uint64_t* eqMasks,
+	const char* letters, const uint32_t* lettersLen, int64_t* outDistance)
+{
+	if (!nPairs) return;
+	threads = ((threads < 64u ? 64u : threads) + 63u) & ~63u;
+	if (threads > ED_BLOCK_THREADS) threads = ED_BLOCK_THREADS;
+	hipLaunchKernelGGL(k_edit_distance_block, dim3(nPairs < 65536u ? nPairs : 65536u), dim3(threads), 0, stream, pairs, nPairs, reads, bases, eqMasks, letters, lettersLen, outDistance);
+}
+uint32_t editDistanceBlockMaxRows() { return 64u * ED_BLOCK_THREADS; }
+
 void launchLongPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* jobs, uint32_t nJobs, const LongCell* cellPool, char* letters, uint32_t* outLen)
 {
 	if (nJobs) hipLaunchKernelGGL(k_long_pathseq, dim3(nJobs), dim3(64), 0, stream, g, jobs, nJobs, cellPool, letters, outLen);

@@ -230,6 +230,10 @@ uint64_t stitchDenseWords(uint64_t totalSlots, uint64_t nReads);
 // srcOff with bit 63 set reads its nodes from altNodes (host-stitched reads) instead of pathNodes
 void launchChainPathSeq(hipStream_t stream, const DGraph& g, const PathSeqJob* jobs, uint32_t nJobs, const uint32_t* pathNodes, const uint32_t* altNodes, char* letters, uint32_t* outLen);
 uint32_t editDistanceMaxK(uint32_t unitBlocks);
+// the whole matrix by one workgroup of `threads` (>= the read's 64-row blocks, <= editDistanceBlockMaxRows() / 64): pairs whose band would cover most of it
+void launchEditDistanceBlock(hipStream_t stream, uint32_t threads, const EdPair* pairs, uint32_t nPairs, const EdRead* reads, const char* bases, const uint64_t* eqMasks,
+	const char* letters, const uint32_t* lettersLen, int64_t* outDistance);
+uint32_t editDistanceBlockMaxRows();
 // several pairs per wave (2: teams of 32 lanes, 3: teams of 21), unit of one block; editDistanceTeamMaxK: the first band that no longer fits the team
 uint32_t editDistanceTeamMaxK(uint32_t pairsPerWave);
 void launchEditDistanceTeam(hipStream_t stream, uint32_t pairsPerWave, const EdPair* pairs, uint32_t nPairs, const EdRead* reads, const char* bases, const uint64_t* eqMasks,

@@ -240,7 +240,7 @@ def _mutate(rng, s, rate):
     return bytes(out)
 
 
-def test_edit_distance_kernel(gca):
+def test_edit_distance_kernel(gca, monkeypatch):
     """NW edit distance kernel (banded Myers wavefront, k doubling, unit escalation) against the oracle's plain DP value,
     which tests/test_oracle_units.py pins to edlib."""
     import random
@@ -266,6 +266,10 @@ def test_edit_distance_kernel(gca):
     got = gca.edit_distance([p[0] for p in pairs], [p[1] for p in pairs])
     want = [len(a) + len(b) if (not a or not b) else int(lib.gco_edit_distance(a, len(a), b, len(b))) for a, b in pairs]
     assert list(map(int, got)) == want
+    # r4: a first band of half the read or more sends the pair to k_edit_distance_block (a workgroup per pair, the whole matrix): here every pair, both ways round
+    monkeypatch.setenv("GC_ED_FIRST_K", "30000")
+    assert list(map(int, gca.edit_distance([p[0] for p in pairs], [p[1] for p in pairs]))) == want
+    assert list(map(int, gca.edit_distance([p[1] for p in pairs], [p[0] for p in pairs]))) == want
 
 
 def test_edit_distance_long_low_error_pairs(gca, monkeypatch):
@@ -291,6 +295,14 @@ def test_edit_distance_long_low_error_pairs(gca, monkeypatch):
         assert list(map(int, got)) == want, first_k
         got = gca.edit_distance([p[1] for p in pairs], [p[0] for p in pairs])
         assert list(map(int, got)) == want, first_k
+    # r4: a first band of half the read or more sends a read of up to 65536 bases to k_edit_distance_block (a workgroup per pair: 938 and 1024 threads here), the next length to the widest unit
+    monkeypatch.setenv("GC_ED_FIRST_K", "40000")
+    short = [i for i, (a, b) in enumerate(pairs) if len(a) <= 65_537]
+    assert len(short) == 3
+    got = gca.edit_distance([pairs[i][0] for i in short], [pairs[i][1] for i in short])
+    assert list(map(int, got)) == [want[i] for i in short]
+    got = gca.edit_distance([pairs[i][1] for i in short], [pairs[i][0] for i in short])
+    assert list(map(int, got)) == [want[i] for i in short]
 
 
 def _revcomp(s):
