@@ -423,9 +423,10 @@ __global__ void __launch_bounds__(1024) k_exclusive_scan_u32(const uint32_t* __r
 	const uint32_t* in = blockIdx.x ? in1 : in0;   // (two arrays in one launch: block 0 / block 1)
 	uint32_t* out = blockIdx.x ? out1 : out0;
 	unsigned long long* total = blockIdx.x ? total1 : total0;
+	// (256 threads, r4: a 1 024-thread block needs sixteen free wave slots on ONE CU, and waited 16 ms for them among config 5's long-running whole-read waves - for a scan of 2 000 numbers)
 	__shared__ unsigned long long part[1024];
-	const uint32_t t = threadIdx.x;
-	const uint32_t per = (n + 1023) / 1024;
+	const uint32_t t = threadIdx.x, T = blockDim.x;
+	const uint32_t per = (n + T - 1) / T;
 	const uint32_t b = t * per, e = b + per < n ? b + per : n;
 	unsigned long long s = 0;
 	for (uint32_t i = b; i < e; i++) s += in[i];
@@ -433,7 +434,7 @@ __global__ void __launch_bounds__(1024) k_exclusive_scan_u32(const uint32_t* __r
 	__syncthreads();
 	if (t == 0) {
 		unsigned long long run = 0;
-		for (uint32_t i = 0; i < 1024; i++) { const unsigned long long v = part[i]; part[i] = run; run += v; }
+		for (uint32_t i = 0; i < T; i++) { const unsigned long long v = part[i]; part[i] = run; run += v; }
 		*total = run;
 		out[n] = (uint32_t)(run > 0xffffffffull ? 0xffffffffull : run);   // (the host refuses a batch whose total does not fit 32 bits)
 	}
@@ -447,7 +448,7 @@ void launchSeedCaps(hipStream_t stream, const SeedIndex& idx, uint32_t nReads, c
 {
 	if (!nReads) return;
 	hipLaunchKernelGGL(k_seed_caps, dim3(nReads < 16384 ? nReads : 16384), dim3(64), 0, stream, idx, nReads, invalidRead, matches, readMatchOff, readMatchCount, readSeedCap);
-	hipLaunchKernelGGL(k_exclusive_scan_u32, dim3(1), dim3(1024), 0, stream, (const uint32_t*)readSeedCap, nReads, readSeedOff, total, (const uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr);
+	hipLaunchKernelGGL(k_exclusive_scan_u32, dim3(1), dim3(256), 0, stream, (const uint32_t*)readSeedCap, nReads, readSeedOff, total, (const uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr);
 }
 
 void launchSeedGlue(hipStream_t stream, const SeedIndex& idx, const DGraph& g, const uint64_t* readOff, uint32_t nReads, const uint8_t* invalidRead, const uint2* matches, const uint32_t* readMatchOff,
@@ -465,7 +466,7 @@ void launchSeedGlue(hipStream_t stream, const SeedIndex& idx, const DGraph& g, c
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seed_glue<1, 1024>), dim3(blocks), dim3(64), 0, stream, idx, g, readOff, nReads, invalidRead, matches, readMatchOff, readMatchCount, readSeedOff, winCapOff, density, splitLen, splitGap, longPass ? 1u : 0u, st,
 		longSeeds, readSeeds, counts, cursors);
 	// where every read's fragments and anchor slots begin: exclusive scans in read order (cursors[0] = fragments, [1] = slots of the batch)
-	hipLaunchKernelGGL(k_exclusive_scan_u32, dim3(2), dim3(1024), 0, stream, (const uint32_t*)counts.nFrags, nReads, fragOff, cursors, (const uint32_t*)counts.nSlots, slotOff, cursors + 1);
+	hipLaunchKernelGGL(k_exclusive_scan_u32, dim3(2), dim3(256), 0, stream, (const uint32_t*)counts.nFrags, nReads, fragOff, cursors, (const uint32_t*)counts.nSlots, slotOff, cursors + 1);
 	hipLaunchKernelGGL(k_glue_emit, dim3(blocks), dim3(64), 0, stream, readOff, nReads, readSeedOff, winCapOff, (const uint32_t*)st.winBuf, counts, (const uint32_t*)fragOff, (const uint32_t*)slotOff, splitLen, splitGap, frags, fragFirstSeed, jobs, out);
 }
 
