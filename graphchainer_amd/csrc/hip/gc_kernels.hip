@@ -253,6 +253,7 @@ __global__ void __launch_bounds__(64) k_build_anchors(DGraph g, const Fragment* 
 	AnchorRec* __restrict__ anchors, uint32_t* __restrict__ fragStatus, uint32_t* __restrict__ fragExtended,
 	uint32_t* __restrict__ pathPool, unsigned long long* __restrict__ pathCursor, uint64_t pathCapacity, AnchorRounds rounds)
 {
+	GC_RAISE_PRIO();
 	// Lazy extension (rounds.lazy): a seed's two extensions run only when the reference would run them, i.e. when the seed does not lie on an
 	// earlier alignment of its fragment (on cfg2 more than half of the seeds do). Round 0 has the first seed of every fragment extended and
 	// walks all fragments; a fragment that reaches a seed it must extend and whose extensions have not run yet parks itself - the seed's
@@ -506,6 +507,7 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 	const Fragment* __restrict__ frags, const uint32_t* __restrict__ fragStatus, int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* __restrict__ scratch, uint64_t scratchStride,
 	uint32_t* __restrict__ chainOut, uint32_t* __restrict__ chainLen, unsigned long long* __restrict__ chainScore, uint32_t* __restrict__ chainStatus, uint32_t forceScratch)
 {
+	GC_RAISE_PRIO();
 	constexpr uint32_t LDS_ANCHORS = LDS == 2 ? CHAIN_LDS_ANCHORS / 2 : CHAIN_LDS_ANCHORS, LDS_ENTRIES = LDS == 2 ? CHAIN_LDS_ENTRIES / 2 : CHAIN_LDS_ENTRIES, LDS_WIDTH = LDS == 2 ? CHAIN_LDS_WIDTH / 2 : CHAIN_LDS_WIDTH;
 	__shared__ uint32_t sStart[LDS ? LDS_ANCHORS : 1];
 	__shared__ unsigned long long sC[LDS ? LDS_ANCHORS : 1];
@@ -929,6 +931,7 @@ __global__ void __launch_bounds__(64) k_long_pass(DGraph g, const CorrectnessTab
 
 __global__ void __launch_bounds__(256) k_long_init(const LongJob* __restrict__ jobs, uint32_t nReads, LongState* __restrict__ state)
 {
+	GC_RAISE_PRIO();
 	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= nReads) return;
 	LongState st { jobs[r].seedBegin, 0, 0, 0, 0, 0, 0, 0 };
@@ -1025,6 +1028,7 @@ __global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __r
 	uint32_t maxCandidates, LongState* __restrict__ state, const LongAln* __restrict__ alns, const LongCell* __restrict__ cellPool, LongWork* __restrict__ work, uint32_t* __restrict__ workLen, uint32_t* __restrict__ candSeed,
 	unsigned long long* __restrict__ workCount, uint64_t workCapacity)
 {
+	GC_RAISE_PRIO();
 	const uint32_t r = blockIdx.x, lane = threadIdx.x;
 	if (r >= nReads) return;
 	longSelectRead(g, r, lane, jobs, seeds, minClusterSize, maxCandidates, state, alns, cellPool, work, workLen, candSeed, workCount, workCapacity);
@@ -1253,6 +1257,7 @@ __global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __re
 	const LongWorkResult* __restrict__ results, const unsigned long long* __restrict__ tracePool, uint32_t maxAlignments,
 	LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* __restrict__ cellCursor, uint64_t cellCapacity)
 {
+	GC_RAISE_PRIO();
 	const uint32_t r = blockIdx.x;
 	if (r >= nReads) return;
 	longMergeRead(g, r, threadIdx.x, jobs, seeds, candSeed, results, tracePool, maxAlignments, state, alns, cellPool, cellCursor, cellCapacity);
@@ -1262,6 +1267,7 @@ __global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __re
 // the order inside a class is whatever the atomics give - results do not depend on it). mode 0: identity.
 __global__ void __launch_bounds__(1024) k_long_order(const uint32_t* __restrict__ workLen, const unsigned long long* __restrict__ workCount, uint32_t* __restrict__ order, uint32_t shift, uint32_t mode)
 {
+	GC_RAISE_PRIO();
 	__shared__ uint32_t hist[1024];
 	__shared__ uint32_t start[1024];
 	const uint32_t n = (uint32_t)*workCount, tid = threadIdx.x;
@@ -1350,6 +1356,7 @@ __global__ void __launch_bounds__(64) k_long_round(DGraph g, const LongJob* __re
 // copies a few cursor words into pinned host memory through the compute queue (a copy-engine transfer would queue behind bulk uploads)
 __global__ void k_publish(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst, uint32_t nWords)
 {
+	GC_RAISE_PRIO();
 	if (threadIdx.x < nWords) { dst[threadIdx.x] = src[threadIdx.x]; __threadfence_system(); }
 }
 
@@ -1357,11 +1364,13 @@ __global__ void k_publish(const unsigned long long* __restrict__ src, unsigned l
 // batch's bulk uploads
 __global__ void k_zero_words(unsigned long long* __restrict__ dst, uint32_t nWords)
 {
+	GC_RAISE_PRIO();
 	if (threadIdx.x < nWords) dst[threadIdx.x] = 0;
 }
 
 __global__ void __launch_bounds__(256) k_long_finish(uint32_t nReads, const LongState* __restrict__ state, LongReadResult* __restrict__ results)
 {
+	GC_RAISE_PRIO();
 	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= nReads) return;
 	LongState st = state[r];

@@ -2,6 +2,18 @@
 #pragma once
 #include "gc_device.hpp"
 
+// Issue priority of the latency-bound helper kernels' waves (s_setprio, 0-3): the round loop's small kernels, the seed glue, chaining, stitching. They issue a few per cent of a batch's
+// instructions and waited for their turn behind the whole-read kernel's waves when five batches are in flight. r4, five in flight, average per launch: k_stitch 109 -> 41 ms, k_chain<2> 31 -> 17,
+// k_seed_glue 50 -> 45; the step 152.4 -> 151.2 ms (three interleaved pairs, `gpurun_out/r4_prio`): the whole-read kernel does not notice what they take. -DGC_HELPER_PRIO=0 turns it off.
+#ifndef GC_HELPER_PRIO
+#define GC_HELPER_PRIO 3
+#endif
+#if GC_HELPER_PRIO
+#define GC_RAISE_PRIO() __builtin_amdgcn_s_setprio(GC_HELPER_PRIO)
+#else
+#define GC_RAISE_PRIO() ((void)0)
+#endif
+
 namespace gcdev {
 
 struct SeedIndex {   // minimizer index in HBM (reference: MinimizerSeeder buckets, src/MinimizerSeeder.h:16-30)

@@ -94,6 +94,7 @@ __global__ void __launch_bounds__(64) k_seed_glue(SeedIndex idx, DGraph g, const
 	double density, uint32_t splitLen, uint32_t splitGap, uint32_t longPass, GlueStaging st,
 	LongSeed* __restrict__ longSeeds, FragSeed* __restrict__ readSeeds, GlueCounts counts, unsigned long long* __restrict__ cursors)
 {
+	GC_RAISE_PRIO();
 	// one LDS image, reused along the read's pass: [0] k0 (offsets of the kept hits / chain / cluster id), [1] k1, [2] k2 (diagonal; the 8-byte
 	// elements of the three order-critical sorts alias these two), [3] id, [4] cluster sums (first: cluster ids in sorted order), [5] cluster sizes
 	__shared__ uint32_t lds[6 * GLUE_LDS_ELEMS];
@@ -385,6 +386,7 @@ __global__ void __launch_bounds__(64) k_glue_emit(const uint64_t* __restrict__ r
 	GlueCounts counts, const uint32_t* __restrict__ fragOff, const uint32_t* __restrict__ slotOff, uint32_t splitLen, uint32_t splitGap,
 	Fragment* __restrict__ frags, uint32_t* __restrict__ fragFirstSeed, ReadChainJob* __restrict__ jobs, GlueRead* __restrict__ out)
 {
+	GC_RAISE_PRIO();
 	const uint32_t lane = threadIdx.x;
 	for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
 		const uint32_t nF = counts.nFrags[r], fragBegin = fragOff[r], slotBegin = slotOff[r], sOff = readSeedOff[r];
@@ -407,6 +409,7 @@ __global__ void __launch_bounds__(64) k_glue_emit(const uint64_t* __restrict__ r
 __global__ void __launch_bounds__(64) k_seed_caps(SeedIndex idx, uint32_t nReads, const uint8_t* __restrict__ invalidRead, const uint2* __restrict__ matches, const uint32_t* __restrict__ readMatchOff,
 	const uint32_t* __restrict__ readMatchCount, uint32_t* __restrict__ readSeedCap)
 {
+	GC_RAISE_PRIO();
 	const uint32_t lane = threadIdx.x;
 	for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
 		const uint32_t nM = invalidRead[r] ? 0u : readMatchCount[r], mOff = readMatchOff[r];
@@ -420,6 +423,7 @@ __global__ void __launch_bounds__(64) k_seed_caps(SeedIndex idx, uint32_t nReads
 __global__ void __launch_bounds__(1024) k_exclusive_scan_u32(const uint32_t* __restrict__ in0, uint32_t n, uint32_t* __restrict__ out0, unsigned long long* __restrict__ total0,
 	const uint32_t* __restrict__ in1, uint32_t* __restrict__ out1, unsigned long long* __restrict__ total1)
 {
+	GC_RAISE_PRIO();
 	const uint32_t* in = blockIdx.x ? in1 : in0;   // (two arrays in one launch: block 0 / block 1)
 	uint32_t* out = blockIdx.x ? out1 : out0;
 	unsigned long long* total = blockIdx.x ? total1 : total0;

@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 	uint32_t* __restrict__ slotOf, uint32_t* __restrict__ regions, uint32_t* __restrict__ dense, uint64_t denseCap, unsigned long long* __restrict__ denseCursor,
 	StitchInfo* __restrict__ info)
 {
+	GC_RAISE_PRIO();
 	constexpr uint32_t STITCH_BFS_TABLE = 2 * STITCH_BFS_CAP;
 	constexpr uint32_t INDEX_BITS = STITCH_BFS_CAP <= 1024 ? 11u : 13u, INDEX_MASK = (1u << INDEX_BITS) - 1u;   // a table entry: (generation << INDEX_BITS) | (queue index + 1)
 	static_assert(STITCH_BFS_CAP < (1u << INDEX_BITS), "queue index + 1 must fit its bits");
