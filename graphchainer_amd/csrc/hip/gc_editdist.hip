@@ -49,6 +49,7 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v, uint32_t lane)
 __global__ void __launch_bounds__(64) k_long_pathseq(DGraph g, const PathSeqJob* __restrict__ jobs, uint32_t nJobs, const LongCell* __restrict__ cellPool,
 	char* __restrict__ letters, uint32_t* __restrict__ outLen)
 {
+	GC_RAISE_ED_PRIO();
 	const uint32_t r = blockIdx.x, lane = threadIdx.x;
 	if (r >= nJobs) return;
 	const PathSeqJob job = jobs[r];
@@ -96,6 +97,7 @@ __global__ void __launch_bounds__(64) k_long_pathseq(DGraph g, const PathSeqJob*
 __global__ void __launch_bounds__(64) k_chain_pathseq(DGraph g, const PathSeqJob* __restrict__ jobs, uint32_t nJobs, const uint32_t* __restrict__ pathNodes,
 	const uint32_t* __restrict__ altNodes, char* __restrict__ letters, uint32_t* __restrict__ outLen)
 {
+	GC_RAISE_ED_PRIO();
 	const uint32_t r = blockIdx.x, lane = threadIdx.x;
 	if (r >= nJobs) return;
 	const PathSeqJob job = jobs[r];
@@ -130,6 +132,7 @@ template <int G>
 __global__ void __launch_bounds__(64) k_edit_distance(const EdPair* __restrict__ pairs, uint32_t nPairs, const EdRead* __restrict__ reads, const char* __restrict__ bases,
 	const uint64_t* __restrict__ eqMasks, const char* __restrict__ letters, const uint32_t* __restrict__ lettersLen, int64_t* __restrict__ outDistance)
 {
+	GC_RAISE_ED_PRIO();
 	__shared__ uint8_t ring[ED_RING];
 	__shared__ int32_t resultSlot;
 	const uint32_t lane = threadIdx.x;
@@ -284,6 +287,7 @@ template <uint32_t TEAM, uint32_t RING>
 __global__ void __launch_bounds__(64) k_edit_distance_team(const EdPair* __restrict__ pairs, uint32_t nPairs, const EdRead* __restrict__ reads, const char* __restrict__ bases,
 	const uint64_t* __restrict__ eqMasks, const char* __restrict__ letters, const uint32_t* __restrict__ lettersLen, int64_t* __restrict__ outDistance)
 {
+	GC_RAISE_ED_PRIO();
 	constexpr uint32_t PAIRS = 64u / TEAM, KMAX = TEAM >= 32 ? ED_HALF_KMAX : ED_THIRD_KMAX, AHEAD = RING / 2, PERIOD = RING / 4;
 	static_assert(KMAX < 65 * TEAM - 63, "a lane's consecutive units must stay disjoint in time");
 	__shared__ uint8_t ringAll[(PAIRS + 1) * RING];   // (+ 1: the lanes beyond the last whole team address a ring of their own and never touch it)
@@ -436,6 +440,7 @@ __global__ void __launch_bounds__(64) k_edit_distance_team(const EdPair* __restr
 __global__ void __launch_bounds__(ED_BLOCK_THREADS) k_edit_distance_block(const EdPair* __restrict__ pairs, uint32_t nPairs, const EdRead* __restrict__ reads, const char* __restrict__ bases,
 	const uint64_t* __restrict__ eqMasks, const char* __restrict__ letters, const uint32_t* __restrict__ lettersLen, int64_t* __restrict__ outDistance)
 {
+	GC_RAISE_ED_PRIO();
 	__shared__ int8_t hand[2][ED_BLOCK_THREADS];   // the horizontal delta leaving block B's bottom row at the column it has just computed, double-buffered by step parity
 	__shared__ int32_t resultSlot;
 	const uint32_t B = threadIdx.x;

@@ -13,6 +13,15 @@
 #else
 #define GC_RAISE_PRIO() ((void)0)
 #endif
+// the same for the edit-distance and path-letter kernels (vector work beside the scalar-bound whole-read kernel): experiment, -DGC_ED_PRIO=3
+#ifndef GC_ED_PRIO
+#define GC_ED_PRIO 0
+#endif
+#if GC_ED_PRIO
+#define GC_RAISE_ED_PRIO() __builtin_amdgcn_s_setprio(GC_ED_PRIO)
+#else
+#define GC_RAISE_ED_PRIO() ((void)0)
+#endif
 
 namespace gcdev {
 
