@@ -13,7 +13,7 @@
 #else
 #define GC_RAISE_PRIO() ((void)0)
 #endif
-// the same for the edit-distance and path-letter kernels (vector work beside the scalar-bound whole-read kernel): experiment, -DGC_ED_PRIO=3
+// the same for the edit-distance and path-letter kernels (vector work beside the scalar-bound whole-read kernel): -DGC_ED_PRIO=3, measured and off - 148.9 / 147.1 / 152.9 ms per batch against 149.2 / 151.1 / 150.8 (`gpurun_out/r4_edprio`)
 #ifndef GC_ED_PRIO
 #define GC_ED_PRIO 0
 #endif
