@@ -162,6 +162,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 	uint8_t* __restrict__ scratch, uint64_t slabBytes, TraceCell* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity,
 	unsigned long long* __restrict__ counters, uint32_t retryStatus, ExtSelection sel)
 {
+#if defined(GC_EXTEND_PRIO) && GC_EXTEND_PRIO
+	__builtin_amdgcn_s_setprio(GC_EXTEND_PRIO);   // (experiment, -DGC_EXTEND_PRIO=3: the fragment extension's waves ahead of the whole-read kernel's - 149.9 / 149.2 / 152.3 ms per batch against 154.0 / 147.2 / 151.6, `gpurun_out/r4_extprio`: no effect, off)
+#endif
 	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t stride = gridDim.x * blockDim.x;
 	LaneScratch sc = laneScratch(scratch + (uint64_t)tid * slabBytes, cfg);
