@@ -35,6 +35,7 @@ __device__ __forceinline__ uint32_t scanInclusiveU32(uint32_t v, uint32_t lane)
 // plan[stream] = { compressed bytes (without gzip framing), mode (0 dynamic Huffman block, 1 stored blocks) }; lens[stream * 260 + symbol] = code length (mode 0)
 __global__ void __launch_bounds__(64) k_deflate_plan(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ rawOff, uint32_t nStreams, uint8_t* __restrict__ lens, uint2* __restrict__ plan)
 {
+	GC_RAISE_PRIO();
 	__shared__ uint32_t hist[DEFLATE_SYMS];
 	__shared__ uint32_t sortedSym[DEFLATE_SYMS];      // used symbols by ascending (count, symbol)
 	__shared__ uint32_t sortedW[DEFLATE_SYMS];
@@ -100,6 +101,7 @@ __global__ void __launch_bounds__(64) k_deflate_plan(const uint8_t* __restrict__
 __global__ void __launch_bounds__(64) k_deflate_write(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ rawOff, uint32_t nStreams, const uint8_t* __restrict__ lens, const uint2* __restrict__ plan,
 	uint8_t* __restrict__ out, const uint64_t* __restrict__ outOff)
 {
+	GC_RAISE_PRIO();
 	__shared__ uint32_t code[DEFLATE_SYMS];           // (reversed code << 8) | length
 	__shared__ uint32_t window[40];                    // bit window of the packer: up to 31 carried bits + 64 x 15 new ones
 	__shared__ uint32_t headerItem[DEFLATE_HEADER_ITEMS];

@@ -215,6 +215,7 @@ __device__ uint32_t walkBack(uint32_t Q, uint32_t T, const EdPathScratch& S)
 __global__ void __launch_bounds__(64) k_edit_path(const EdPathJob* __restrict__ jobs, uint32_t nJobs, const char* __restrict__ letters, const char* __restrict__ bases,
 	uint8_t* __restrict__ scratch, uint64_t scratchBytes, uint32_t maxQ, uint32_t maxT, uint8_t* __restrict__ opsOut, uint32_t* __restrict__ opsLen)
 {
+	GC_RAISE_PRIO();
 	__shared__ uint32_t stack[64][5];
 	__shared__ uint8_t ringChar[ED_PATH_RING], ringCarry[ED_PATH_RING], ringOut[ED_PATH_RING];
 	const uint32_t lane = threadIdx.x;

@@ -71,6 +71,7 @@ template <bool WRITE>
 __global__ void __launch_bounds__(64) k_out_encode(DGraph g, OutNames names, const uint8_t* __restrict__ iupac, const OutJob* __restrict__ jobs, uint32_t nJobs, const LongCell* __restrict__ cellPool,
 	const char* __restrict__ bases, OutRec* __restrict__ recs, const uint64_t* __restrict__ offsets, uint32_t* __restrict__ mapSizeAtCell, char* __restrict__ pathText, char* __restrict__ cigarText, uint8_t* __restrict__ vgBytes)
 {
+	GC_RAISE_PRIO();
 	const uint32_t j = blockIdx.x, lane = threadIdx.x;
 	if (j >= nJobs) return;
 	const OutJob job = jobs[j];
@@ -303,6 +304,7 @@ __global__ void __launch_bounds__(64) k_out_encode(DGraph g, OutNames names, con
 // exclusive scans of the three byte counts over the jobs -> offsets[3][nJobs + 1] (last entries = totals); one block
 __global__ void __launch_bounds__(1024) k_out_place(const OutRec* __restrict__ recs, uint32_t nJobs, uint64_t* __restrict__ offsets, unsigned long long* __restrict__ totals)
 {
+	GC_RAISE_PRIO();
 	__shared__ unsigned long long part[3][1024];
 	const uint32_t t = threadIdx.x;
 	const uint32_t per = (nJobs + 1023) / 1024;

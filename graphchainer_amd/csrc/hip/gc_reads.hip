@@ -43,6 +43,7 @@ __global__ void __launch_bounds__(64) k_pack_read_masks(const uint64_t* __restri
 	const uint64_t* __restrict__ maskOff, const uint32_t* __restrict__ maskWords, uint64_t* __restrict__ masks, const uint64_t* __restrict__ eqOff, uint64_t* __restrict__ eqMasks,
 	uint8_t* __restrict__ readInvalid)
 {
+	GC_RAISE_PRIO();
 	const uint32_t r = blockIdx.x, lane = threadIdx.x;
 	if (r >= nReads) return;
 	const uint64_t a = readOff[r], len = readOff[r + 1] - a;
@@ -82,6 +83,7 @@ __global__ void __launch_bounds__(64) k_pack_read_masks(const uint64_t* __restri
 __global__ void __launch_bounds__(256) k_pack_read_kmers(const char* __restrict__ bases, uint64_t totalBases, const uint64_t* __restrict__ readOff, uint32_t nReads,
 	uint64_t* __restrict__ packed, uint64_t* __restrict__ invalidBits, uint32_t* __restrict__ chunkRead)
 {
+	GC_RAISE_PRIO();
 	const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t nChunks = (totalBases >> 6) + 1;
 	if (c >= nChunks) return;
