@@ -1268,20 +1268,34 @@ __global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __re
 
 // Execution order of a round's work items: longest extensions first (a counting sort over 1024 length classes, one block;
 // the order inside a class is whatever the atomics give - results do not depend on it). mode 0: identity.
-__global__ void __launch_bounds__(1024) k_long_order(const uint32_t* __restrict__ workLen, const unsigned long long* __restrict__ workCount, uint32_t* __restrict__ order, uint32_t shift, uint32_t mode)
+#ifndef GC_ORDER_THREADS
+#define GC_ORDER_THREADS 1024   // threads of the ordering block (-DGC_ORDER_THREADS=256: a wave scan of the histogram and a block that finds its wave slots sooner among five batches' kernels - measured, 147.8 / 151.7 / 150.5 ms per batch against 150.8 / 150.2 / 149.8, `gpurun_out/r4_ord`: no effect)
+#endif
+__global__ void __launch_bounds__(GC_ORDER_THREADS) k_long_order(const uint32_t* __restrict__ workLen, const unsigned long long* __restrict__ workCount, uint32_t* __restrict__ order, uint32_t shift, uint32_t mode)
 {
 	GC_RAISE_PRIO();
 	__shared__ uint32_t hist[1024];
 	__shared__ uint32_t start[1024];
-	const uint32_t n = (uint32_t)*workCount, tid = threadIdx.x;
-	if (mode == 0) { for (uint32_t i = tid; i < n; i += 1024) order[i] = i; return; }
-	hist[tid] = 0;
+	const uint32_t n = (uint32_t)*workCount, tid = threadIdx.x, T = GC_ORDER_THREADS;
+	if (mode == 0) { for (uint32_t i = tid; i < n; i += T) order[i] = i; return; }
+	for (uint32_t b = tid; b < 1024; b += T) hist[b] = 0;
 	__syncthreads();
-	for (uint32_t i = tid; i < n; i += 1024) { uint32_t b = workLen[i] >> shift; atomicAdd(&hist[1023 - (b < 1023 ? b : 1023)], 1u); }
+	for (uint32_t i = tid; i < n; i += T) { uint32_t b = workLen[i] >> shift; atomicAdd(&hist[1023 - (b < 1023 ? b : 1023)], 1u); }
 	__syncthreads();
+#if GC_ORDER_THREADS == 1024
 	if (tid == 0) { uint32_t at = 0; for (uint32_t b = 0; b < 1024; b++) { start[b] = at; at += hist[b]; } }
+#else
+	if (tid < 64) {   // the first wave: sixteen classes per lane, a wave scan of the lanes' sums
+		uint32_t mine[16], sum = 0;
+		for (uint32_t k = 0; k < 16; k++) { mine[k] = hist[tid * 16 + k]; sum += mine[k]; }
+		uint32_t incl = sum;
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if ((int)tid >= d) incl += o; }
+		uint32_t at = incl - sum;
+		for (uint32_t k = 0; k < 16; k++) { start[tid * 16 + k] = at; at += mine[k]; }
+	}
+#endif
 	__syncthreads();
-	for (uint32_t i = tid; i < n; i += 1024) { uint32_t b = workLen[i] >> shift; order[atomicAdd(&start[1023 - (b < 1023 ? b : 1023)], 1u)] = i; }
+	for (uint32_t i = tid; i < n; i += T) { uint32_t b = workLen[i] >> shift; order[atomicAdd(&start[1023 - (b < 1023 ? b : 1023)], 1u)] = i; }
 }
 
 // One launch per round instead of five (r4): the previous round's merge, this round's select, the execution order and the hand-over of the round's work count.
@@ -1589,7 +1603,7 @@ void launchLongOrder(hipStream_t stream, const uint32_t* workLen, const unsigned
 {
 	uint32_t shift = 0;
 	while ((maxLen >> shift) > 1023) shift++;
-	hipLaunchKernelGGL(k_long_order, dim3(1), dim3(1024), 0, stream, workLen, workCount, order, shift, mode);
+	hipLaunchKernelGGL(k_long_order, dim3(1), dim3(GC_ORDER_THREADS), 0, stream, workLen, workCount, order, shift, mode);
 }
 void launchPublish(hipStream_t stream, const unsigned long long* src, unsigned long long* dst, uint32_t nWords)
 {
