@@ -21,6 +21,7 @@
 #include <cstring>
 #include <exception>
 #include <functional>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -228,7 +229,8 @@ AlignmentGraph AlignmentGraph::BuildFromGFAFile(const std::string& path)
 	Clock clock;
 	const size_t threads = buildThreads();
 	// ---- (1) the file, its lines, their fields
-	std::vector<char> file;
+	std::unique_ptr<char[]> file;   // (not a vector: resize() would fill 3.8 GB with zeros at 960 Mbp before fread overwrites them)
+	size_t fileBytes = 0;
 	{
 		FILE* f = fopen(path.c_str(), "rb");
 		if (!f) throw std::runtime_error("cannot open GFA file " + path);
@@ -236,14 +238,15 @@ AlignmentGraph AlignmentGraph::BuildFromGFAFile(const std::string& path)
 		const long size = ftell(f);
 		if (size < 0) { fclose(f); throw std::runtime_error("cannot read GFA file " + path); }
 		rewind(f);
-		file.resize((size_t)size);
+		fileBytes = (size_t)size;
+		file.reset(new char[fileBytes + 1]);
 		size_t got = 0;
-		while (got < file.size()) { const size_t n = fread(file.data() + got, 1, file.size() - got, f); if (n == 0) break; got += n; }
+		while (got < fileBytes) { const size_t n = fread(file.get() + got, 1, fileBytes - got, f); if (n == 0) break; got += n; }
 		fclose(f);
-		if (got != file.size()) throw std::runtime_error("cannot read GFA file " + path);
+		if (got != fileBytes) throw std::runtime_error("cannot read GFA file " + path);
 	}
-	const char* buf = file.data();
-	const uint64_t fileSize = file.size();
+	const char* buf = file.get();
+	const uint64_t fileSize = fileBytes;
 	clock.lap("GFA read");
 	// a line ends at its '\n'; like the reference's getline loop (src/GfaGraph.cpp:219-223) a last line without one is dropped
 	std::vector<uint64_t> lineEnd;
@@ -261,7 +264,7 @@ AlignmentGraph AlignmentGraph::BuildFromGFAFile(const std::string& path)
 		for (auto& p : parts) lineEnd.insert(lineEnd.end(), p.begin(), p.end());
 	}
 	const size_t nLines = lineEnd.size();
-	std::vector<LineRec> lines(nLines);
+	std::unique_ptr<LineRec[]> lines(new LineRec[nLines ? nLines : 1]);   // (every record is written by the parse below: no zero fill of 7 GB at 960 Mbp)
 	std::vector<uint64_t> maxNumberOf(threads, 0);
 	std::vector<uint8_t> numbersOnly(threads, 1);
 	std::vector<size_t> sLinesOf(threads, 0), lLinesOf(threads, 0);
@@ -311,7 +314,7 @@ AlignmentGraph AlignmentGraph::BuildFromGFAFile(const std::string& path)
 			nonZeroOverlap = nonZeroOverlap || r.overlapNonZero;
 		}
 	}
-	std::vector<LineRec>().swap(lines);
+	lines.reset();
 	std::vector<uint64_t>().swap(lineEnd);
 	const size_t nIds = names.firstToken.size();
 	ensure(nIds ? (int)nIds - 1 : 0);
