@@ -1,7 +1,9 @@
 // Index cache; see gc_index_cache.hpp for the format.
 #include "gc_index_cache.hpp"
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <unordered_map>
@@ -299,13 +301,26 @@ void validateSeeder(const MinimizerIndex& idx, const AlignmentGraph& g)
 	if (!idx.kmers.empty() && (idx.kmers.back() >> (2 * idx.k)) != 0) bad("k-mer wider than 2k bits");
 }
 
+struct LoadClock {   // GC_DEBUG_TIMES: the stages of a load on stderr
+	std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+	const bool on = getenv("GC_DEBUG_TIMES") != nullptr;
+	void lap(const char* what)
+	{
+		auto now = std::chrono::steady_clock::now();
+		if (on) fprintf(stderr, "[gc cache] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+		t = now;
+	}
+};
+
 IndexCacheInfo parse(const Mapping& file, AlignmentGraph& g, MinimizerIndex& idx)
 {
+	LoadClock clock;
 	if (memcmp(file.p, MAGIC, 8) != 0) throw std::runtime_error("not an index cache (bad magic)");
 	size_t payload = file.n - 8;
 	uint64_t stored = 0;
 	for (int i = 0; i < 8; i++) stored |= (uint64_t)file.p[payload + i] << (8 * i);
 	if (fnv(FNV_SEED, file.p, payload) != stored) throw std::runtime_error("index cache checksum mismatch (truncated or damaged file)");
+	clock.lap("checksum");
 	In in(file.p, payload);
 	in.at = 8;
 	uint64_t version = in.num();
@@ -313,12 +328,14 @@ IndexCacheInfo parse(const Mapping& file, AlignmentGraph& g, MinimizerIndex& idx
 	g = AlignmentGraph();
 	GraphTables t;
 	graphFields(in, g, t);
+	clock.lap("graph fields");
 	size_t n = g.nodeLength.size();
 	if (t.splitNodes.size() != t.ids.size() || t.sizes.size() != t.ids.size() || t.names.size() != t.ids.size()) throw std::runtime_error("index cache: inconsistent node tables");
 	if (g.nodeOffset.size() != n || g.nodeIDs.size() != n || g.inNeighbors.size() != n || g.outNeighbors.size() != n || g.reverse.size() != n
 		|| g.componentNumber.size() != n || g.component_map.size() != n || g.component_idx.size() != n || !g.finalized)
 		throw std::runtime_error("index cache: inconsistent graph arrays");
 	validateGraph(g, t);
+	clock.lap("graph validation");
 	g.nodeLookup.reserve(t.ids.size(), n); g.originalNodeSize.reserve(t.ids.size()); g.originalNodeName.reserve(t.ids.size());
 	for (size_t i = 0; i < t.ids.size(); i++) {
 		g.nodeLookup.add(t.ids[i], t.splitNodes[i].data(), t.splitNodes[i].size());
@@ -327,12 +344,15 @@ IndexCacheInfo parse(const Mapping& file, AlignmentGraph& g, MinimizerIndex& idx
 	}
 	if (g.nodeLookup.size() != t.ids.size()) throw std::runtime_error("index cache: duplicate node id");
 	g.nodeLookupOrder = std::move(t.ids);
+	clock.lap("node tables");
 	IndexCacheInfo info;
 	info.hasSeeder = in.num() != 0;
 	idx = MinimizerIndex();
 	if (info.hasSeeder) {
 		seederFields(in, idx);
+		clock.lap("minimizer index fields");
 		validateSeeder(idx, g);
+		clock.lap("minimizer index validation");
 	}
 	if (in.at != payload) throw std::runtime_error("index cache: trailing bytes");
 	info.nodes = n; info.bp = g.bpSize; info.kmers = idx.kmers.size(); info.positions = idx.positions.size();
