@@ -479,6 +479,7 @@ struct ReadGlue {
 struct EditDistanceRun {
 	hipStream_t streams[8] {};         // one per kernel class: three pairs per wave, two pairs per wave, units of 1, 2, 4, 8, 16 blocks, a workgroup per pair (the whole matrix)
 	uint32_t begin[9] {};              // the classes' ranges in the grouped order
+	std::vector<uint32_t> lens;        // the pairs' read lengths, grouped order (the reruns choose their kernel by them)
 	hipEvent_t ready = nullptr;
 	std::vector<uint32_t> perm;        // position in the grouped order -> original pair index
 	std::vector<int64_t> grouped;      // results in grouped order (pinned not needed: small)
@@ -811,7 +812,7 @@ inline void launchEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 	if (!run.ready) HIP_CHECK(hipEventCreateWithFlags(&run.ready, hipEventDisableTiming));
 	// (a class's stream is created when the class is first used: the batch's streams share the device's 16 hardware queues, and on cfg2 only the
 	// two-pairs-per-wave class and the one-block class ever hold pairs)
-	std::vector<uint32_t> cls(nPairs);
+	std::vector<uint32_t> cls(nPairs), lenOf(nPairs);
 	uint32_t count[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	uint32_t blockThreads = 64;        // class 7: threads of a workgroup = the 64-row blocks of the class's longest read
 	uint32_t* begin = run.begin;
@@ -819,6 +820,7 @@ inline void launchEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 	static const bool thirdWaves = halfWaves && !(getenv("GC_ED_THIRD") && atoi(getenv("GC_ED_THIRD")) == 0);
 	for (uint32_t i = 0; i < nPairs; i++) {
 		const uint32_t len = readLen(hPairs[i].read);
+		lenOf[i] = len;
 		uint32_t unit = editDistanceUnit(hPairs[i].k, len), c = 0;
 		while ((1u << c) < unit) c++;
 		c += 2;                                                               // classes 2..6: one pair per wave, units of 1..16 blocks
@@ -846,7 +848,8 @@ inline void launchEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 	{
 		uint32_t at[8] = { begin[0], begin[1], begin[2], begin[3], begin[4], begin[5], begin[6], begin[7] };
 		std::vector<EdPair> grouped(nPairs);
-		for (uint32_t i = 0; i < nPairs; i++) { grouped[at[cls[i]]] = hPairs[i]; run.perm[at[cls[i]]++] = i; }
+		run.lens.resize(nPairs);
+		for (uint32_t i = 0; i < nPairs; i++) { grouped[at[cls[i]]] = hPairs[i]; run.lens[at[cls[i]]] = lenOf[i]; run.perm[at[cls[i]]++] = i; }
 		memcpy(hPairs, grouped.data(), (size_t)nPairs * sizeof(EdPair));   // hPairs is now in grouped order
 	}
 	HIP_CHECK(hipMemcpyAsync(dPairs, hPairs, (size_t)nPairs * sizeof(EdPair), hipMemcpyHostToDevice, stream));
@@ -883,6 +886,29 @@ inline void finishEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 			for (uint32_t i : todo) (i < run.begin[1] ? now : later).push_back(i);
 			todo.swap(now);
 			if (todo.empty()) { todo.swap(later); continue; }
+		}
+		// r4: from unit 4 on a rerun goes to the workgroup-per-pair kernel when the read fits it (<= 65 536 bases): columns + blocks steps whatever the band, exact - a pair that has failed the
+		// narrower bands is far from its path, and the wide units give it one wave with 4-16 blocks per lane and step (config 5: 145 ms at unit 8, 304 ms at unit 16 per launch)
+		static const bool blockReruns = !(getenv("GC_ED_BLOCK") && atoi(getenv("GC_ED_BLOCK")) == 0);
+		if (unit >= 4 && blockReruns) {
+			std::vector<uint32_t> wide, rest;
+			uint32_t threads = 64;
+			for (uint32_t i : todo) {
+				if (run.lens[i] >= 1 && run.lens[i] <= editDistanceBlockMaxRows()) { wide.push_back(i); threads = std::max(threads, (run.lens[i] + 63u) / 64u); }
+				else rest.push_back(i);
+			}
+			if (!wide.empty()) {
+				sub.resize(wide.size());
+				subOut.resize(wide.size());
+				for (size_t i = 0; i < wide.size(); i++) sub[i] = hPairs[wide[i]];
+				HIP_CHECK(hipMemcpyAsync(dPairs, sub.data(), sub.size() * sizeof(EdPair), hipMemcpyHostToDevice, stream));
+				launchEditDistanceBlock(stream, threads, dPairs, (uint32_t)sub.size(), dReads, dBases, dEqMasks, dLetters, dLettersLen, dOut);
+				HIP_CHECK(hipMemcpyAsync(subOut.data(), dOut, sub.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+				syncStream(stream);
+				for (size_t i = 0; i < wide.size(); i++) hOut[wide[i]] = subOut[i];
+			}
+			todo.swap(rest);
+			if (todo.empty()) break;
 		}
 		sub.resize(todo.size());
 		subOut.resize(todo.size());
