@@ -150,7 +150,7 @@ def cpu_baseline_leg(args, gfa, reads, long_pass):
     n_all = min(len(reads), max(n1, (20 if args.config == 5 else 250) * threads))   # ~10-15 s at the ~20 reads/s a core does (10 kb reads)
     # the same run keeps 12 values per read (chain, chain score, both NW distances, the decision, the whole-read alignments and the
     # selection): main() compares them with the timed GPU output after the timed region ("parity_check")
-    wall_all, _, summary = ora.align_summary(reads[:n_all], threads, gaf_hash=True)   # (13th column: the hash of the read's GAF lines, for the end-to-end leg)
+    wall_all, _, summary = ora.align_summary(reads[:n_all], threads, gaf_hash=True)   # (last column: the hash of the read's GAF lines, for the end-to-end leg)
     extra = {}
     for name, more in (getattr(args, "extra_cpu_reads", None) or {}).items():           # the same oracle over the first reads of the SV leg (same graph)
         extra[name] = ora.align_summary(more, threads, gaf_hash=True)[2]
@@ -234,7 +234,7 @@ def main():
         if "GC_BENCH_INFLIGHT" not in os.environ and not any(a.startswith("--inflight") for a in sys.argv[1:]):
             args.inflight, inflight_choice = choose_inflight(max(1, args.inflight), usable_cpus(), world)
     import graphchainer_amd as gca
-    from graphchainer_amd.workqueue import SUMMARY_FIELDS, ReadQueue, gaf_read_hashes, length_sorted_batches, read_summary, run_queue
+    from graphchainer_amd.workqueue import SUMMARY_FIELDS, SUMMARY_WIDTH, ReadQueue, gaf_read_hashes, length_sorted_batches, read_summary, run_queue
 
     if gca.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -371,13 +371,13 @@ def main():
             if not len(rows):
                 continue
             got = read_summary(out)[rows]
-            bad = got != summary[original[rows], :12]
+            bad = got != summary[original[rows], :SUMMARY_WIDTH]
             checked += len(rows)
             mismatches += int(bad.any(axis=1).sum())
             for k in np.nonzero(bad.any(axis=0))[0]:
                 fields_bad[SUMMARY_FIELDS[k]] = fields_bad.get(SUMMARY_FIELDS[k], 0) + int(bad[:, k].sum())
         rec = {"reads": int(len(summary)), "timed_batches_checked": len(results), "read_results_compared": checked, "mismatches": mismatches,
-               "fields": "anchors, chain, chain score, whole-read and chain NW distance, chained_better, whole-read alignments (start, end, score), selection, failed_assertion",
+               "fields": "anchors, chain, chain score, whole-read and chain NW distance, chained_better, whole-read alignments (start, end, score), selection, failed_assertion, flatten ties (fragments, whole read)",
                "against": "oracle (CPU leg of this run), same reads"}
         if mismatches:
             rec["fields_with_mismatches"] = fields_bad
@@ -390,7 +390,7 @@ def main():
         if not len(rows):
             return 0, 0
         hashes = gaf_read_hashes(text, np.diff(np.asarray(out["read_out_off"]).astype(np.int64)))
-        return len(rows), int((hashes[rows] != summary[original[rows], 12]).sum())
+        return len(rows), int((hashes[rows] != summary[original[rows], SUMMARY_WIDTH]).sum())
 
     parity_check = summary_check(outs, chunks, cpu_summary) if cpu_summary is not None else None
     failures = []
@@ -526,6 +526,7 @@ def main():
     counters_long = np.zeros(8, dtype=np.float64)
     reads_done = aligned_bases = chained_better = reads_with_chain = reads_with_long = 0
     long_ed, chain_ed, seeds_ext_long = [], [], []
+    tie_reads = tie_reads_output = tie_extensions = 0
     for _item, (b, out) in outs:
         kernel_us += out["kernel_us"]
         host_us += out["host_us"]
@@ -541,6 +542,12 @@ def main():
         long_ed.append(out["long_edit_distance"][out["long_edit_distance"] >= 0].astype(np.float64))
         chain_ed.append(out["chain_edit_distance"][out["chain_edit_distance"] >= 0].astype(np.float64))
         seeds_ext_long.append(np.asarray(out["seeds_extended_long"], dtype=np.float64))
+        # the one rule this build defines instead of reproducing (flattenLastSliceEnd's tie order): reads that met it at all, and reads whose OUTPUT can depend on it -
+        # a tie in the whole-read pass when the whole-read alignments are the output, a tie among the fragments' extensions when the chained alignment is
+        ties_frag, ties_long = np.asarray(out["flatten_ties"], dtype=np.int64), np.asarray(out["flatten_ties_long"], dtype=np.int64)
+        tie_reads += int(((ties_frag + ties_long) > 0).sum())
+        tie_reads_output += int(np.where(np.asarray(out["chained_better"]) > 0, ties_frag > 0, ties_long > 0).sum())
+        tie_extensions += int(ties_frag.sum() + ties_long.sum())
     per_rank = None
     if dist is not None:
         mine = {"rank": rank, "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 2), "host_cpu_s_per_step": round(rank_cpu_s / max(1, args.steps), 3),
@@ -641,6 +648,9 @@ def main():
             "roofline_other": roof_extend if roofline is roof_long else roof_long,
             "cpu_baseline": cpu_baseline,
             "parity_check": parity_check,
+            "unpinned_tie_reads": {"reads_with_a_tie_per_step": int(tie_reads / steps), "reads_whose_output_pass_had_a_tie_per_step": int(tie_reads_output / steps), "tied_extensions_per_step": int(tie_extensions / steps),
+                                   "of_reads": int(reads_done / steps), "of_extensions": int(counters[4] + counters_long[4]),
+                                   "what": "extensions whose backtrace started from a last-slice minimum attained in more than one node: the reference picks by parallel-hashmap iteration order (absent here), this build by band-entry order (DESIGN.md §7); compared with the oracle's count in parity_check"},
             "e2e": e2e,
             "sv_leg": sv_leg,
             "repeats_leg": repeats_leg,

@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "gc_params_default", "gc_graph_create_from_gfa", "gc_graph_create", "gc_graph_destroy", "gc_graph_num_nodes",
     "gc_graph_size_bp", "gc_graph_array", "gc_seeder_create", "gc_seeder_destroy", "gc_seeder_array",
     "gc_stream_create", "gc_stream_destroy", "gc_reads_upload", "gc_reads_destroy", "gc_align_batch",
-    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_device_memory", "gc_edit_distance", "gc_edit_path", "gc_evalue", "gc_format_gaf", "gc_format_json", "gc_format_gam", "gc_format_gam_level", "gc_gzip_streams", "gc_format_gaf_trace", "gc_format_vg_trace", "gc_graph_letters",
+    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_device_memory", "gc_edit_distance", "gc_edit_path", "gc_evalue", "gc_format_gaf", "gc_format_json", "gc_format_gam", "gc_format_gam_level", "gc_gzip_streams", "gc_format_gaf_trace", "gc_format_vg_trace", "gc_format_vg_trace_digraph", "gc_graph_letters",
     "gc_index_build", "gc_index_save", "gc_index_load", "gc_index_check", "gc_result_cache_trim",
 ]
 
@@ -65,6 +65,7 @@ class GcResult(C.Structure):
         ("read_out_off", _P(C.c_uint64)), ("out_source", _P(C.c_uint8)), ("out_numbers", _P(C.c_uint64)),
         ("out_path_off", _P(C.c_uint64)), ("out_path_text", _P(C.c_char)), ("out_cigar_off", _P(C.c_uint64)), ("out_cigar_text", _P(C.c_char)),
         ("out_vg_off", _P(C.c_uint64)), ("out_vg_path", _P(C.c_uint8)),
+        ("flatten_ties", _P(C.c_uint32)), ("flatten_ties_long", _P(C.c_uint32)), ("device_output", C.c_int32),
     ]
 
 
@@ -366,7 +367,7 @@ _RESULT_FIELDS = {
     "anchor_first_node": "anchors", "anchor_first_offset": "anchors", "anchor_first_seqpos": "anchors",
     "anchor_last_node": "anchors", "anchor_last_offset": "anchors", "anchor_last_seqpos": "anchors", "anchor_score": "anchors",
     "read_chain_off": "n+1", "chain": "chains", "chain_score": "n",
-    "failed_assertion": "n", "capacity_exceeded": "n", "seeds_extended": "n", "seeds_extended_long": "n",
+    "failed_assertion": "n", "capacity_exceeded": "n", "seeds_extended": "n", "seeds_extended_long": "n", "flatten_ties": "n", "flatten_ties_long": "n",
     "read_longall_off": "n+1", "longall_start": "longs", "longall_end": "longs", "longall_score": "longs",
 }
 

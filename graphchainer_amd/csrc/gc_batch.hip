@@ -85,6 +85,7 @@ struct BatchRun {
 	AnchorRec* dAnchors = nullptr;
 	uint32_t* dFragStatus = nullptr;
 	uint32_t* dFragExtended = nullptr;
+	uint32_t* dReadTies = nullptr;     // per read: fragment extensions whose flattenLastSliceEnd minimum was tied between nodes (k_build_anchors adds them up; gc_result::flatten_ties)
 	uint64_t pathCapacity = 0;
 	uint32_t* dPathPool = nullptr;
 	uint32_t* dChainOut = nullptr;
@@ -101,6 +102,7 @@ struct BatchRun {
 	AnchorRec* anchors = nullptr;
 	uint32_t* fragStatus = nullptr;
 	uint32_t* fragExtended = nullptr;
+	uint32_t* readTies = nullptr;
 	uint32_t* chainOut = nullptr;
 	uint32_t* chainLen = nullptr;
 	unsigned long long* chainScore = nullptr;
@@ -969,6 +971,8 @@ struct BatchRun {
 		dAnchors = st->anchors.reserve<AnchorRec>(nSlots);
 		dFragStatus = st->fragStatus.reserve<uint32_t>(nFrags);
 		dFragExtended = st->fragExtended.reserve<uint32_t>(nFrags);
+		dReadTies = st->readTies.reserve<uint32_t>(n);
+		if (n) HIP_CHECK(hipMemsetAsync(dReadTies, 0, n * sizeof(uint32_t), stream));
 		pathCapacity = nSlots * 24 + 4096;
 		dPathPool = st->pathPool.reserve<uint32_t>(pathCapacity);
 		if (!deviceGlue) dJobs = st->jobs.reserve<ReadChainJob>(n);
@@ -1010,7 +1014,7 @@ struct BatchRun {
 		if (!lazyExtend) {
 			extendRound(ExtSelection());
 			mark();   // 3
-			launchBuildAnchors(stream, G->dev, dFrags, (uint32_t)nFrags, dFragSeeds, dResults, dTrace, P->split_len, dAnchors, dFragStatus, dFragExtended, dPathPool, dCursors + 2, pathCapacity);
+			launchBuildAnchors(stream, G->dev, dFrags, (uint32_t)nFrags, dFragSeeds, dResults, dTrace, P->split_len, dAnchors, dFragStatus, dFragExtended, dPathPool, dCursors + 2, pathCapacity, AnchorRounds(), dReadTies);
 		} else {
 			uint32_t* dLists = st->extLists.reserve<uint32_t>(2ull * nWork);           // two work lists, used in turn
 			uint32_t* dPending = st->pendingFrags.reserve<uint32_t>(2ull * nFrags);     // two pending-fragment lists
@@ -1036,7 +1040,7 @@ struct BatchRun {
 				ar.nextList = dLists + (uint64_t)nxt * nWork; ar.nextListCount = dRoundCounts + 2 * nxt;
 				ar.nextPending = dPending + (uint64_t)nxt * nFrags; ar.nextPendingCount = dRoundCounts + 2 * nxt + 1;
 				ar.fragNext = dFragNext;
-				launchBuildAnchors(stream, G->dev, dFrags, (uint32_t)nFrags, dFragSeeds, dResults, dTrace, P->split_len, dAnchors, dFragStatus, dFragExtended, dPathPool, dCursors + 2, pathCapacity, ar);
+				launchBuildAnchors(stream, G->dev, dFrags, (uint32_t)nFrags, dFragSeeds, dResults, dTrace, P->split_len, dAnchors, dFragStatus, dFragExtended, dPathPool, dCursors + 2, pathCapacity, ar, dReadTies);
 			}
 		}
 		mark();   // 4
@@ -1075,6 +1079,7 @@ struct BatchRun {
 		anchors = st->hAnchors.reserve<AnchorRec>(nSlots);
 		fragStatus = st->hFragStatus.reserve<uint32_t>(nFrags);
 		fragExtended = st->hFragExtended.reserve<uint32_t>(nFrags);
+		readTies = st->hReadTies.reserve<uint32_t>(n);
 		chainOut = st->hChainOut.reserve<uint32_t>(nSlots);
 		chainLen = st->hChainLen.reserve<uint32_t>(n);
 		chainScore = st->hChainScore.reserve<unsigned long long>(n);
@@ -1082,6 +1087,7 @@ struct BatchRun {
 		if (nSlots) HIP_CHECK(hipMemcpyAsync(anchors, dAnchors, nSlots * sizeof(AnchorRec), hipMemcpyDeviceToHost, stream));
 		if (nFrags) HIP_CHECK(hipMemcpyAsync(fragStatus, dFragStatus, nFrags * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		if (nFrags) HIP_CHECK(hipMemcpyAsync(fragExtended, dFragExtended, nFrags * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		if (n) HIP_CHECK(hipMemcpyAsync(readTies, dReadTies, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		if (nSlots) HIP_CHECK(hipMemcpyAsync(chainOut, dChainOut, nSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		if (n) HIP_CHECK(hipMemcpyAsync(chainLen, dChainLen, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		if (n) HIP_CHECK(hipMemcpyAsync(chainStatus, dChainStatus, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -1435,6 +1441,7 @@ struct BatchRun {
 
 	void assembleOutput()   // the pieces into the result (entries of chained winners stay empty: source 1)
 	{
+		res->device_output = P->device_output;
 		if (!P->device_output) return;
 		const uint64_t nOut = outEntries.size();
 		res->read_out_off = resultArray<uint64_t>(n + 1);
@@ -1601,6 +1608,7 @@ struct BatchRun {
 		res->failed_assertion = resultArray<uint8_t>(n);
 		res->capacity_exceeded = resultArray<uint8_t>(n);
 		res->seeds_extended = resultArray<uint64_t>(n);
+		res->flatten_ties = resultArray<uint32_t>(n); res->flatten_ties_long = resultArray<uint32_t>(n);
 		res->read_seed_off[n] = nSeedsOut; res->read_anchor_off[n] = nAnchors; res->anchor_path_off[nAnchors] = nPath; res->read_chain_off[n] = nChain;
 		pool.run(n, [&](size_t r, size_t) {
 			const ReadGlue& gl = glue[r];
@@ -1619,6 +1627,8 @@ struct BatchRun {
 			res->capacity_exceeded[r] = gl.capacityExceeded ? 1 : 0;
 			res->seeds_extended[r] = seedsExtended[r];
 			res->seeds_extended_long[r] = seedsExtendedLong[r];
+			res->flatten_ties[r] = readTies[r];                                        // (counted for every extension the reference would have run, whatever became of the read)
+			res->flatten_ties_long[r] = P->long_pass ? hLongResults[r].pad : 0;
 			res->read_longall_off[r] = gl.longBegin;
 			res->read_path_off[r] = gl.stitchedBegin;
 			res->read_long_off[r] = gl.longSelectedBegin;

@@ -122,14 +122,16 @@ static void gzipGroupsOnDevice(std::vector<std::string>& groups, bool skipEmpty 
 	auto part = [&](size_t bytes) { const size_t here = at; at += (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; return here; };
 	const size_t oRaw = part(rawTotal), oRawOff = part((m + 1) * sizeof(uint64_t)), oLens = part(m * 260), oPlan = part(m * sizeof(uint2)), oOutOff = part((m + 1) * sizeof(uint64_t)), oOut = part(outBound);
 	size_t deviceBytes = 0, pinnedBytes = 0;
-	char* D = (char*)g_readDeviceBlocks.get(at, device, deviceBytes);
-	struct DeviceReturn { char* p; size_t bytes; int device; ~DeviceReturn() { g_readDeviceBlocks.put(p, bytes, device); } } deviceReturn { D, deviceBytes, device };
+	hipStream_t q = threadStream(device);
+	// (the guards wait for the stream before a block goes back to its cache: on an exception between a launch and the wait below the block would otherwise be handed to the next caller
+	// while this thread's copies and kernels still use it - ADVICE r4)
+	char* D = (char*)g_deflateDeviceBlocks.get(at, device, deviceBytes);
+	struct DeviceReturn { char* p; size_t bytes; int device; hipStream_t q; ~DeviceReturn() { (void)hipStreamSynchronize(q); g_deflateDeviceBlocks.put(p, bytes, device); } } deviceReturn { D, deviceBytes, device, q };
 	size_t hat = 0;
 	auto hpart = [&](size_t bytes) { const size_t here = hat; hat += (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; return here; };
 	const size_t hRaw = hpart(std::max<uint64_t>(rawTotal, outBound)), hRawOff = hpart((m + 1) * sizeof(uint64_t)), hPlan = hpart(m * sizeof(uint2)), hOutOff = hpart((m + 1) * sizeof(uint64_t));
-	char* H = (char*)g_readPinnedBlocks.get(hat, device, pinnedBytes);
-	struct PinnedReturn { char* p; size_t bytes; int device; ~PinnedReturn() { g_readPinnedBlocks.put(p, bytes, device); } } pinnedReturn { H, pinnedBytes, device };
-	hipStream_t q = threadStream(device);
+	char* H = (char*)g_deflatePinnedBlocks.get(hat, device, pinnedBytes);
+	struct PinnedReturn { char* p; size_t bytes; int device; hipStream_t q; ~PinnedReturn() { (void)hipStreamSynchronize(q); g_deflatePinnedBlocks.put(p, bytes, device); } } pinnedReturn { H, pinnedBytes, device, q };
 	WorkerPool::instance().run(m, [&](size_t k, size_t) { memcpy(H + hRaw + rawOff[k], groups[which[k]].data(), groups[which[k]].size()); });
 	memcpy(H + hRawOff, rawOff.data(), (m + 1) * sizeof(uint64_t));
 	if (rawTotal) HIP_CHECK(hipMemcpyAsync(D + oRaw, H + hRaw, rawTotal, hipMemcpyHostToDevice, q));
@@ -155,6 +157,10 @@ static int formatBatch(const gc_graph* G, const gc_result* r, const char* const*
 	if (!G || !r || !read_names || !offsets || !out_text || !out_len) return fail(GC_ERR_INVALID, "null argument");
 	const bool pieces = r->read_out_off != nullptr;   // the result carries the alignments as the device encoded them (gc_params::device_output)
 	if (pieces) {
+		// the pieces' CIGAR style (= / X or M) was fixed when the batch was aligned (device_output bit 0 / 1); a call that asks for the other style would get the device's pieces in one
+		// style and the chained winners' lines (encoded here, on the host) in the other: refused
+		if (kind == OUT_GAF && (r->device_output & 3) && ((r->device_output & 2) != 0) != (cigar_match_mismatch_merge != 0))
+			return fail(GC_ERR_INVALID, "gc_format_gaf: cigar_match_mismatch_merge differs from the style the result's pieces were encoded in (gc_params::device_output 1: = / X, 2: M)");
 		if (kind == OUT_GAF && !r->out_cigar_off) return fail(GC_ERR_INVALID, "the result holds no GAF pieces");
 		if (kind == OUT_GAF && r->out_cigar_off[r->read_out_off[r->n_reads]] == 0 && r->out_vg_off[r->read_out_off[r->n_reads]] != 0) return fail(GC_ERR_INVALID, "the result was produced without the GAF pieces (gc_params::device_output & 3)");
 		if (kind != OUT_GAF && r->out_vg_off[r->read_out_off[r->n_reads]] == 0 && r->out_cigar_off[r->read_out_off[r->n_reads]] != 0) return fail(GC_ERR_INVALID, "the result was produced without the vg::Path bytes (gc_params::device_output & 4)");
@@ -262,7 +268,12 @@ int gc_format_gam(const gc_graph* G, const gc_result* r, const char* const* read
 }
 
 // gc_result_free keeps the large arrays of freed results (up to 24 GB) for the next batch instead of returning them to the allocator; this returns them.
-void gc_result_cache_trim(void) { g_resultBlocks.trim(); }
+void gc_result_cache_trim(void)
+{
+	g_resultBlocks.trim();
+	// r5: the device / pinned blocks held back by gc_reads_destroy and by the device deflate's staging as well (blocks in use are not in the caches and are unaffected)
+	g_readDeviceBlocks.trim(); g_readPinnedBlocks.trim(); g_deflateDeviceBlocks.trim(); g_deflatePinnedBlocks.trim();
+}
 
 // One alignment at a time, for a host that keeps the reference's own per-alignment calls (include/graphchainer_amd_shim.hpp: AddGAFLine / AddAlignment,
 // src/GraphAlignerWrapper.h:43-44): the trace in output coordinates in, the GAF line / the vg::Alignment message out. Host code (no device work).
@@ -281,14 +292,30 @@ int gc_format_gaf_trace(const gc_graph* G, const char* read_name, const char* se
 		return (int)GC_OK;
 	});
 }
+static int formatVgTrace(const gc_graph* G, const char* read_name, const char* sequence, uint64_t sequence_len, const int32_t* node, const uint32_t* offset, const uint32_t* seqpos, const uint8_t* node_switch,
+	uint64_t n, int32_t score, uint64_t alignment_start, uint64_t alignment_end, char** out_bytes, uint64_t* out_len, bool digraphIds);
 int gc_format_vg_trace(const gc_graph* G, const char* read_name, const char* sequence, uint64_t sequence_len, const int32_t* node, const uint32_t* offset, const uint32_t* seqpos, const uint8_t* node_switch,
 	uint64_t n, int32_t score, uint64_t alignment_start, uint64_t alignment_end, char** out_bytes, uint64_t* out_len)
+{
+	return formatVgTrace(G, read_name, sequence, sequence_len, node, offset, seqpos, node_switch, n, score, alignment_start, alignment_end, out_bytes, out_len, false);
+}
+// the message as AddAlignment leaves it (src/GraphAligner.h:205-212): digraph node ids (2 x segment index + strand), no names - for a host that calls
+// replaceDigraphNodeIdsWithOriginalNodeIds itself right after (src/Aligner.cpp:1009), as the reference's own loop does
+int gc_format_vg_trace_digraph(const gc_graph* G, const char* read_name, const char* sequence, uint64_t sequence_len, const int32_t* node, const uint32_t* offset, const uint32_t* seqpos, const uint8_t* node_switch,
+	uint64_t n, int32_t score, uint64_t alignment_start, uint64_t alignment_end, char** out_bytes, uint64_t* out_len)
+{
+	return formatVgTrace(G, read_name, sequence, sequence_len, node, offset, seqpos, node_switch, n, score, alignment_start, alignment_end, out_bytes, out_len, true);
+}
+static int formatVgTrace(const gc_graph* G, const char* read_name, const char* sequence, uint64_t sequence_len, const int32_t* node, const uint32_t* offset, const uint32_t* seqpos, const uint8_t* node_switch,
+	uint64_t n, int32_t score, uint64_t alignment_start, uint64_t alignment_end, char** out_bytes, uint64_t* out_len, bool digraphIds)
 {
 	if (!G || !sequence || !out_bytes || !out_len || (n && (!node || !offset || !seqpos || !node_switch))) return fail(GC_ERR_INVALID, "null argument");
 	if (alignment_end < alignment_start || alignment_end > sequence_len) return fail(GC_ERR_INVALID, "gc_format_vg_trace: alignment_start / alignment_end outside the read");
 	return guarded([&]() {
 		gc::TraceView tv { node, offset, seqpos, node_switch, n };
-		const std::string msg = gc::vgToProtobuf(gc::buildVgAlignment(G->host, read_name ? read_name : "", sequence, sequence_len, tv, score, alignment_start, alignment_end));
+		gc::VgAlignment aln = gc::buildVgAlignment(G->host, read_name ? read_name : "", sequence, sequence_len, tv, score, alignment_start, alignment_end);
+		if (digraphIds) for (gc::VgMapping& m : aln.mappings) { m.nodeId = 2 * m.nodeId + (m.isReverse ? 1 : 0); m.name.clear(); }   // the inverse of replaceDigraphNodeIdsWithOriginalNodeIds (src/Aligner.cpp:152-165)
+		const std::string msg = gc::vgToProtobuf(aln);
 		char* buf = (char*)malloc(msg.size() + 1);
 		if (!buf) throw std::runtime_error("out of memory");
 		memcpy(buf, msg.data(), msg.size());
@@ -768,6 +795,7 @@ int gc_reads_upload(const char* bases, const uint64_t* offsets, uint64_t n, gc_r
 	if (!offsets || !out || (!bases && n > 0 && offsets[n] > 0)) return fail(GC_ERR_INVALID, "null argument");
 	*out = nullptr;
 	gc_reads* R = new gc_reads();
+	hipStream_t uploadStream = nullptr;
 	int rc = guarded([&]() {
 		requireDevice();
 		R->offsets.assign(offsets, offsets + n + 1);
@@ -810,9 +838,11 @@ int gc_reads_upload(const char* bases, const uint64_t* offsets, uint64_t n, gc_r
 		const size_t hBases = hpart(total), hOffsets = hpart((n + 1) * sizeof(uint64_t)), hMaskOff = hpart(n * sizeof(uint64_t)), hMaskWords = hpart(n * sizeof(uint32_t)), hEqOff = hpart(n * sizeof(uint64_t)),
 			hEdReads = hpart(n * sizeof(EdRead)), hInvalidBack = hpart(n);
 		size_t pinnedBytes = 0;
-		char* H = (char*)g_readPinnedBlocks.get(hat, R->device, pinnedBytes);
-		struct PinnedReturn { char* p; size_t bytes; int device; ~PinnedReturn() { g_readPinnedBlocks.put(p, bytes, device); } } pinnedReturn { H, pinnedBytes, R->device };
 		struct { hipStream_t q; } up { threadStream(R->device) };
+		uploadStream = up.q;
+		char* H = (char*)g_readPinnedBlocks.get(hat, R->device, pinnedBytes);
+		// (waits for the stream before the block goes back: after an exception between the copies / kernels and the wait below they may still be reading it - ADVICE r4)
+		struct PinnedReturn { char* p; size_t bytes; int device; hipStream_t q; ~PinnedReturn() { (void)hipStreamSynchronize(q); g_readPinnedBlocks.put(p, bytes, device); } } pinnedReturn { H, pinnedBytes, R->device, up.q };
 		if (total) memcpy(H + hBases, bases, total);
 		memcpy(H + hOffsets, offsets, (n + 1) * sizeof(uint64_t));
 		if (n) {
@@ -834,7 +864,11 @@ int gc_reads_upload(const char* bases, const uint64_t* offsets, uint64_t n, gc_r
 		if (n) memcpy(R->invalid.data(), H + hInvalidBack, n);
 		return (int)GC_OK;
 	});
-	if (rc != GC_OK) { delete R; return rc; }
+	if (rc != GC_OK) {
+		if (uploadStream) (void)hipStreamSynchronize(uploadStream);   // ~gc_reads returns the device block to its cache: nothing of this call may still be writing to it
+		delete R;
+		return rc;
+	}
 	*out = R;
 	return GC_OK;
 }
@@ -852,7 +886,7 @@ void gc_result_free(gc_result* r)
 		r->failed_assertion, r->seeds_extended, r->seeds_extended_long, r->read_path_off, r->path_node, r->path_first_offset, r->path_last_offset, r->path_cells,
 		r->read_long_off, r->long_index, r->long_edit_distance, r->chain_edit_distance, r->chained_better,
 		r->capacity_exceeded, r->read_chain_trace_off, r->chain_trace_node, r->chain_trace_offset, r->chain_trace_seqpos, r->chain_trace_switch, r->chain_aln_start, r->chain_aln_end,
-		r->read_out_off, r->out_source, r->out_numbers, r->out_path_off, r->out_path_text, r->out_cigar_off, r->out_cigar_text, r->out_vg_off, r->out_vg_path };
+		r->read_out_off, r->out_source, r->out_numbers, r->out_path_off, r->out_path_text, r->out_cigar_off, r->out_cigar_text, r->out_vg_off, r->out_vg_path, r->flatten_ties, r->flatten_ties_long };
 	for (void* p : ptrs) g_resultBlocks.put(p);
 	free(r);
 }

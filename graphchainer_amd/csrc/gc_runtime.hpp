@@ -372,7 +372,9 @@ struct BlockCache {
 	struct Block { void* ptr; size_t bytes; int device; };
 	std::vector<Block> blocks;
 	static constexpr size_t MAX_BLOCKS = 12;
-	explicit BlockCache(bool pinned) : pinned(pinned) {}
+	size_t maxBytes;          // r5: the cache holds back at most this many bytes in all (a block that would exceed it is freed instead)
+	size_t heldBytes = 0;
+	explicit BlockCache(bool pinned, size_t maxBytes = (size_t)24 << 30) : pinned(pinned), maxBytes(maxBytes) {}
 	void* get(size_t bytes, int device, size_t& capacity)
 	{
 		{
@@ -380,7 +382,7 @@ struct BlockCache {
 			size_t best = blocks.size();
 			for (size_t i = 0; i < blocks.size(); i++)
 				if (blocks[i].device == device && blocks[i].bytes >= bytes && blocks[i].bytes <= 2 * bytes + (1u << 20) && (best == blocks.size() || blocks[i].bytes < blocks[best].bytes)) best = i;
-			if (best < blocks.size()) { Block b = blocks[best]; blocks.erase(blocks.begin() + (long)best); capacity = b.bytes; return b.ptr; }
+			if (best < blocks.size()) { Block b = blocks[best]; blocks.erase(blocks.begin() + (long)best); heldBytes -= b.bytes; capacity = b.bytes; return b.ptr; }
 		}
 		capacity = bytes + bytes / 8 + 4096;   // (a little slack: the next batch is about, not exactly, this size)
 		void* p = nullptr;
@@ -393,13 +395,23 @@ struct BlockCache {
 		if (!p) return;
 		{
 			std::lock_guard<std::mutex> lock(mutex);
-			if (blocks.size() < MAX_BLOCKS) { blocks.push_back(Block { p, bytes, device }); return; }
+			if (blocks.size() < MAX_BLOCKS && heldBytes + bytes <= maxBytes) { blocks.push_back(Block { p, bytes, device }); heldBytes += bytes; return; }
 		}
 		if (pinned) (void)hipHostFree(p); else (void)hipFree(p);
+	}
+	void trim()   // gives everything held back to the allocator (gc_result_cache_trim)
+	{
+		std::vector<Block> mine;
+		{ std::lock_guard<std::mutex> lock(mutex); mine.swap(blocks); heldBytes = 0; }
+		for (const Block& b : mine) { if (pinned) (void)hipHostFree(b.ptr); else (void)hipFree(b.ptr); }
 	}
 };
 inline BlockCache& g_readDeviceBlocks = *new BlockCache(false);   // (leaked on purpose, like the result cache: finalizers may run late)
 inline BlockCache& g_readPinnedBlocks = *new BlockCache(true);
+// r5: the GAM deflate's staging (a batch's inflated groups plus the output bound: hundreds of MB) has caches of its own - in the read batches' caches its other
+// size class evicted read blocks, and an evicted block is a hipFree / hipHostFree: the device-wide stall the caches exist to avoid
+inline BlockCache& g_deflateDeviceBlocks = *new BlockCache(false, (size_t)4 << 30);
+inline BlockCache& g_deflatePinnedBlocks = *new BlockCache(true, (size_t)4 << 30);
 
 // a stream of the calling thread's own for its uploads and small jobs (created on first use, recreated when the thread changes device)
 inline hipStream_t threadStream(int device)
@@ -495,8 +507,8 @@ struct gc_stream {
 	int device = 0;             // the device the stream was created on; gc_align_batch selects it for the calling thread
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[12] {};
-	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, readSeeds, fragFirstSeed, longRetryList, extLists, pendingFrags, fragNext, roundCounts, work, results, scratch, scratchRetry, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
-	PinnedBuffer hMatches, hReadSeeds, hFragFirstSeed, hFrags, hJobs, hAnchors, hFragStatus, hFragExtended, hChainOut, hChainLen, hChainScore, hChainStatus, hPathPool, hSmall;
+	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, readSeeds, fragFirstSeed, longRetryList, extLists, pendingFrags, fragNext, roundCounts, work, results, scratch, scratchRetry, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, readTies, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
+	PinnedBuffer hMatches, hReadSeeds, hFragFirstSeed, hFrags, hJobs, hAnchors, hFragStatus, hFragExtended, hReadTies, hChainOut, hChainLen, hChainScore, hChainStatus, hPathPool, hSmall;
 	// whole-read pass: runs on its own stream, concurrently with the fragment kernels
 	hipStream_t longStream = nullptr;
 	hipEvent_t longEv[2] {};
@@ -821,6 +833,7 @@ inline void launchEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 	for (uint32_t i = 0; i < nPairs; i++) {
 		const uint32_t len = readLen(hPairs[i].read);
 		lenOf[i] = len;
+		const uint32_t askedK = hPairs[i].k;   // the caller's band, before the team classes widen it to what their lanes hold anyway (class 7 below is judged on this one: ADVICE r4)
 		uint32_t unit = editDistanceUnit(hPairs[i].k, len), c = 0;
 		while ((1u << c) < unit) c++;
 		c += 2;                                                               // classes 2..6: one pair per wave, units of 1..16 blocks
@@ -838,7 +851,7 @@ inline void launchEditDistances(EditDistanceRun& run, hipStream_t stream, EdPair
 		// class 7 (r4): a band of half the read or more covers most of the matrix - a chain whose path spells a fraction of its read, a whole-read alignment of a sliver: the pair
 		// gets a workgroup with one thread per 64-row block and the whole matrix (exact, no retry) instead of one wave with up to sixteen blocks per lane and step
 		static const bool blockPairs = !(getenv("GC_ED_BLOCK") && atoi(getenv("GC_ED_BLOCK")) == 0);
-		if (blockPairs && len >= 1 && len <= editDistanceBlockMaxRows() && 2ull * hPairs[i].k >= len) { c = 7; blockThreads = std::max(blockThreads, (len + 63u) / 64u); }
+		if (blockPairs && len >= 1 && len <= editDistanceBlockMaxRows() && 2ull * askedK >= len) { hPairs[i].k = askedK; c = 7; blockThreads = std::max(blockThreads, (len + 63u) / 64u); }
 		cls[i] = c;
 		count[c]++;
 	}

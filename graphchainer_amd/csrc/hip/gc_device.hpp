@@ -207,6 +207,10 @@ struct ExtCounters {
 	// 32-bit: they are per lane (per wave in the whole-read kernel) and flushed with one 64-bit atomic each at the kernel's end; in the
 	// whole-read kernel they live in scalar registers for the kernel's whole life, where every pair of them is one more spill
 	uint32_t dpTiles, recomputeTiles, columnSteps, traceItems, extensions, backtraceTiles;
+	// r5, per extension (set by the core, read by the kernel right after it): 1 when the extension produced a trace whose backtrace started in the last partial slice and that slice's
+	// minimum (the fused flattenLastSliceEnd) was attained in more than one node - the one place where the reference's parallel-hashmap iteration order, which this build replaces by
+	// band-entry order, can pick another cell (gc_result::flatten_ties)
+	uint32_t flattenTie;
 #ifdef GC_STAMPS
 	unsigned long long cyc[16], tMark;   // profiling build only (make stamps): lane-cycles per section of extendSeedWave
 #endif
@@ -510,6 +514,7 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 	nTrace = 0;
 	score = 0;
 	cnt.extensions++;
+	cnt.flattenTie = 0;
 	int numSlices = (len + 63) / 64;
 	if ((uint32_t)numSlices + 1 > cfg.maxSlices) return EXT_OVERFLOW;
 	// ---- initial slice: row -1 scores are |column - startOffset| on the seed's split node (...Common.h:1243-1279)
@@ -580,7 +585,10 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 			if (tr.minScore > previousQuitScore + bandwidth + 128) return EXT_ASSERT;   // ...Banded.h:352
 			currentMin = tr.minScore < currentMin ? tr.minScore : currentMin;
 			if (tr.minScore < cur.minScore) { cur.minScore = tr.minScore; cur.minNode = p.node; cur.minOffset = tr.minOffset; }
-			if (flatRows > 0 && tr.flatMin < flatMin) { flatMin = tr.flatMin; flatNode = p.node; flatOffset = tr.flatOffset; }
+			if (flatRows > 0) {   // strict '<' in pop order = band-entry order (the defined tie order); a second node AT the minimum is the tie gc_result::flatten_ties counts (bit 31 of flatOffset: no register of its own)
+				if (tr.flatMin < flatMin) { flatMin = tr.flatMin; flatNode = p.node; flatOffset = tr.flatOffset; }
+				else if (tr.flatMin == flatMin) flatOffset |= 0x80000000u;
+			}
 			WS newEnd = itemEnd(out);
 			int32_t newEndMin = wsColumnMin(newEnd);
 			if (newEndMin < previousMinScore) return EXT_ASSERT;   // ...Banded.h:368
@@ -592,7 +600,8 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 			}
 		}
 		if (cur.count == 0) return EXT_ASSERT;
-		if (flatRows > 0) { cur.minScore = flatMin; cur.minNode = flatNode; cur.minOffset = flatOffset; }
+		const uint32_t flatTie = flatRows > 0 ? (flatOffset >> 31) << 3 : 0u;   // kept in the slice's flags (bit 3)
+		if (flatRows > 0) { cur.minScore = flatMin; cur.minNode = flatNode; cur.minOffset = flatOffset & 0x7fffffffu; }
 		if (cur.minScore < prev.minScore) return EXT_ASSERT;   // ...Banded.h:463
 		// correctness HMM (src/AlignmentCorrectnessEstimation.cpp:105-129): +, max, >= only
 		{
@@ -604,7 +613,7 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 			double c = prev.correctLogOdds + ct.c2f, d = prev.falseLogOdds + ct.f2f;
 			cur.correctLogOdds = (a > b ? a : b) + ct.correctOdds[idx];
 			cur.falseLogOdds = (c > d ? c : d) + ct.wrongOdds[idx];
-			cur.flags = (cur.correctLogOdds > cur.falseLogOdds ? 1u : 0u) | (cfc ? 2u : 0u) | (ffc ? 4u : 0u);
+			cur.flags = (cur.correctLogOdds > cur.falseLogOdds ? 1u : 0u) | (cfc ? 2u : 0u) | (ffc ? 4u : 0u) | flatTie;
 		}
 		if (!(cur.flags & 2u)) break;   // !CorrectFromCorrect: stop, slice not kept (...Banded.h:589-607)
 		sc.slices[nSlices++] = cur;
@@ -800,6 +809,7 @@ __device__ inline uint32_t extendSeedT(const DGraph& g, const CorrectnessTables&
 		// (a self-loop would be needed), so it cannot trigger on a DAG.
 	}
 	cnt.traceItems += nTrace;
+	cnt.flattenTie = (sc.slices[nSlices - 1].flags >> 3) & 1u;   // the backtrace started in a flattened slice whose minimum was tied between nodes (read back here: no register held across the walk)
 	return status;
 }
 

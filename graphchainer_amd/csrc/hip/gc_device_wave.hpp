@@ -622,6 +622,7 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 	nTrace = 0;
 	score = 0;
 	cnt.extensions++;
+	cnt.flattenTie = 0;
 	int numSlices = (len + 63) / 64;
 	if ((uint32_t)numSlices + 1 > wsx.maxSlices) return EXT_OVERFLOW;
 	// ---- initial slice (...Common.h:1243-1279)
@@ -762,7 +763,10 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 			if (tr.minScore > previousQuitScore + bandwidth + 128) return EXT_ASSERT;
 			currentMin = tr.minScore < currentMin ? tr.minScore : currentMin;
 			if (tr.minScore < cur.minScore) { cur.minScore = tr.minScore; cur.minNode = pnode; cur.minOffset = tr.minOffset; }
-			if (flatRows > 0 && tr.flatMin < flatMin) { flatMin = tr.flatMin; flatNode = pnode; flatOffset = tr.flatOffset; }
+			if (flatRows > 0) {   // (as in extendSeedT: a second node AT the minimum is the tie gc_result::flatten_ties_long counts; bit 31 of flatOffset carries it to the slice's flags)
+				if (tr.flatMin < flatMin) { flatMin = tr.flatMin; flatNode = pnode; flatOffset = tr.flatOffset; }
+				else if (tr.flatMin == flatMin) flatOffset |= 0x80000000u;
+			}
 			WS newEnd = itemEnd(out);
 #if GC_LEAN_COLUMNS && GC_LEAN_COLMIN && defined(__HIP_DEVICE_COMPILE__)
 			int32_t newEndMin;
@@ -815,7 +819,8 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 		}
 		GC_MARK(1);
 		if (cur.count == 0) return EXT_ASSERT;
-		if (flatRows > 0) { cur.minScore = flatMin; cur.minNode = flatNode; cur.minOffset = flatOffset; }
+		const uint32_t flatTie = flatRows > 0 ? (flatOffset >> 31) << 3 : 0u;
+		if (flatRows > 0) { cur.minScore = flatMin; cur.minNode = flatNode; cur.minOffset = flatOffset & 0x7fffffffu; }
 		if (cur.minScore < prevMinScore) return EXT_ASSERT;
 		double curCorrect, curFalse;
 		{
@@ -827,7 +832,7 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 			double c = prevCorrect + ct.c2f, d = prevFalse + ct.f2f;
 			curCorrect = (a > b ? a : b) + ct.correctOdds[idx];
 			curFalse = (c > d ? c : d) + ct.wrongOdds[idx];
-			cur.flags = (curCorrect > curFalse ? 1u : 0u) | (cfc ? 2u : 0u) | (ffc ? 4u : 0u);
+			cur.flags = (curCorrect > curFalse ? 1u : 0u) | (cfc ? 2u : 0u) | (ffc ? 4u : 0u) | flatTie;
 		}
 		if (!(cur.flags & 2u)) break;
 		storeSlice(wsx, nSlices++, cur);
@@ -1261,6 +1266,7 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 	if (REGCOLS && nTrace > wsx.maxTrace) return EXT_OVERFLOW;
 	flushTrace(nTrace & 63u);
 	cnt.traceItems += nTrace;
+	cnt.flattenTie = (loadSlice(wsx, nSlices - 1).flags >> 3) & 1u;   // (see extendSeedT)
 	GC_MARK(10);
 	return status;
 }

@@ -189,6 +189,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 		res.score = score;
 		res.traceLen = 0;
 		res.traceOff = 0;
+		res.pad = cnt.flattenTie;   // r5: the extension's last-slice minimum was attained in more than one node (k_build_anchors sums what the reference would have run, per read)
 		if (status == EXT_OK) {
 			unsigned long long base = atomicAdd(traceCursor, (unsigned long long)nTrace);
 			if (base + nTrace <= traceCapacity) {
@@ -254,7 +255,7 @@ __device__ inline void mergedCell(const DGraph& g, const MergedView& v, uint32_t
 __global__ void __launch_bounds__(64) k_build_anchors(DGraph g, const Fragment* __restrict__ frags, uint32_t nFrags, const FragSeed* __restrict__ seeds,
 	const ExtResult* __restrict__ ext, const TraceCell* __restrict__ tracePool, int32_t splitLen,
 	AnchorRec* __restrict__ anchors, uint32_t* __restrict__ fragStatus, uint32_t* __restrict__ fragExtended,
-	uint32_t* __restrict__ pathPool, unsigned long long* __restrict__ pathCursor, uint64_t pathCapacity, AnchorRounds rounds)
+	uint32_t* __restrict__ pathPool, unsigned long long* __restrict__ pathCursor, uint64_t pathCapacity, AnchorRounds rounds, uint32_t* __restrict__ readTies)
 {
 	GC_RAISE_PRIO();
 	// Lazy extension (rounds.lazy): a seed's two extensions run only when the reference would run them, i.e. when the seed does not lie on an
@@ -269,6 +270,7 @@ __global__ void __launch_bounds__(64) k_build_anchors(DGraph g, const Fragment* 
 	Fragment fr = frags[f];
 	uint32_t status = 0;       // 0 ok, 1 the reference would throw in this fragment, 2 capacity overflow
 	uint32_t extended = 0;
+	uint32_t ties = 0;         // extensions consumed in this launch whose flattenLastSliceEnd minimum was tied between nodes (ExtResult::pad), added to the read's count on the way out
 	uint32_t nSeeds = fr.seedEnd - fr.seedBegin;
 	uint32_t firstSeed = 0;
 	if (rounds.lazy && rounds.round > 0) { firstSeed = rounds.fragNext[f]; extended = fragExtended[f]; }
@@ -335,10 +337,14 @@ __global__ void __launch_bounds__(64) k_build_anchors(DGraph g, const Fragment* 
 			rounds.nextPending[atomicAdd(rounds.nextPendingCount, 1ull)] = f;
 			rounds.fragNext[f] = k;
 			fragExtended[f] = extended;
+			if (ties && readTies) atomicAdd(&readTies[fr.read], ties);
 			return;
 		}
 		extended++;
 		bool runB = p > 0, runF = p < splitLen - 1;
+		// (the reference runs the backward extension first and the forward one only if that did not throw, src/GraphAligner.h:499-511)
+		if (runB) ties += eb.pad & 1u;
+		if (runF && !(runB && eb.status == EXT_ASSERT)) ties += ef.pad & 1u;
 		if ((runB && eb.status == EXT_ASSERT) || (runF && ef.status == EXT_ASSERT)) { status = 1; break; }
 		if ((runB && eb.status == EXT_OVERFLOW) || (runF && ef.status == EXT_OVERFLOW)) { status = 2; break; }
 		bool hasB = runB && eb.status == EXT_OK, hasF = runF && ef.status == EXT_OK;
@@ -429,6 +435,7 @@ __global__ void __launch_bounds__(64) k_build_anchors(DGraph g, const Fragment* 
 	if (status != 0) for (uint32_t k = 0; k < nSeeds; k++) anchors[fr.seedBegin + k].valid = 0;   // a throwing AlignOneWay returns nothing
 	fragStatus[f] = status;
 	fragExtended[f] = extended;
+	if (ties && readTies) atomicAdd(&readTies[fr.read], ties);
 }
 
 // =====================================================================================================
@@ -820,7 +827,7 @@ __global__ void __launch_bounds__(64) k_long_pass(DGraph g, const CorrectnessTab
 	for (uint32_t r = tid; r < nReads; r += stride) {
 		LongJob job = jobs[r];
 		LongAln* mine = alns + job.alnBegin;
-		uint32_t nAln = 0, extended = 0, status = 0;
+		uint32_t nAln = 0, extended = 0, status = 0, ties = 0;
 		uint32_t e2eScore = 0;   // seedScoreForEndToEndAln
 		const int L = (int)job.readLen;
 		// Lanes of a wave must reach the expensive part (the extension) together: a plain loop over seeds would let
@@ -860,9 +867,10 @@ __global__ void __launch_bounds__(64) k_long_pass(DGraph g, const CorrectnessTab
 				uint32_t twinNode, twinOffset;
 				twinOf(g, sd.node, sd.offset, twinNode, twinOffset);
 				stB = extendSeed(g, *ct, iupac, cfg, ls.sc, bases + rcBase + job.readOff + (uint64_t)(L - p), p, twinNode, twinOffset, nB, scoreB, cnt);
+				ties += cnt.flattenTie;
 				if (stB == EXT_OK) for (uint32_t i = 0; i < nB; i++) ls.traceB[i] = ls.sc.trace[i];
 			}
-			if (p < L - 1) stF = extendSeed(g, *ct, iupac, cfg, ls.sc, bases + job.readOff + (uint64_t)(p + 1), L - 1 - p, sd.node, sd.offset, nF, scoreF, cnt);
+			if (p < L - 1 && stB != EXT_ASSERT) { stF = extendSeed(g, *ct, iupac, cfg, ls.sc, bases + job.readOff + (uint64_t)(p + 1), L - 1 - p, sd.node, sd.offset, nF, scoreF, cnt); ties += cnt.flattenTie; }   // (a throwing backward extension ends getAlignmentFromSeed before the forward one runs)
 			if (stB == EXT_ASSERT || stF == EXT_ASSERT) { status = 1; break; }
 			if (stB == EXT_OVERFLOW || stF == EXT_OVERFLOW) { status = 2; break; }
 			bool hasB = stB == EXT_OK, hasF = stF == EXT_OK;
@@ -909,7 +917,7 @@ __global__ void __launch_bounds__(64) k_long_pass(DGraph g, const CorrectnessTab
 		rr.nAlignments = status == 1 ? 0 : nAln;   // a throwing AlignOneWay returns nothing (src/Aligner.cpp:585-592)
 		rr.seedsExtended = extended;
 		rr.status = status;
-		rr.pad = 0;
+		rr.pad = ties;
 		results[r] = rr;
 	}
 	if (cnt.extensions) {
@@ -1095,6 +1103,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LANES =
 			EqSource eqSrc { masks + it.maskOff, it.maskWords, it.startBit };
 			res.status = extendSeedWave<LANES == 1>(g, *ct, eqSrc, cfg.bandwidth, (lds_u32*)&lds.w[0][0], wsx, (int)it.seqLen, it.node, it.offset, 0, nTrace, score, cnt);
 			res.score = score;
+			res.pad = cnt.flattenTie;   // (k_long_merge adds the flags of the extensions the reference would have run to the read's count)
 			if (res.status == EXT_OK) {
 				unsigned long long base = 0;
 				if (leader) base = atomicAdd(traceCursor, (unsigned long long)nTrace);
@@ -1147,6 +1156,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 			EqSource eqSrc { masks + it.maskOff, it.maskWords, it.startBit };
 			res.status = extendSeedT(g, *ct, eqSrc, cfg, sc, (int)it.seqLen, it.node, it.offset, nTrace, score, cnt);
 			res.score = score;
+			res.pad = cnt.flattenTie;
 			if (res.status == EXT_OK) {
 				unsigned long long base = atomicAdd(traceCursor, (unsigned long long)nTrace);
 				if (base + nTrace <= traceCapacity) {
@@ -1199,6 +1209,8 @@ __device__ __forceinline__ void longMergeRead(const DGraph& g, const uint32_t r,
 		const int p = (int)sd.seqPos;
 		bool runB = p > 0, runF = p < L - 1;
 		uint32_t stB = runB ? rb.status : EXT_FAILED, stF = runF ? rf.status : EXT_FAILED;
+		if (runB) st.pad1 += rb.pad & 1u;                                              // LongState::pad1 = the read's flatten ties (gc_result::flatten_ties_long)
+		if (runF && stB != EXT_ASSERT) st.pad1 += rf.pad & 1u;                         // (the forward extension only runs when the backward one did not throw)
 		if (stB == EXT_ASSERT || stF == EXT_ASSERT) { st.status = 1; break; }          // getAlignmentFromSeed threw
 		if (stB == EXT_OVERFLOW || stF == EXT_OVERFLOW) { st.status = 2; break; }
 		if (stB == EXT_LDS_CAP || stF == EXT_LDS_CAP) { st.status = 5; break; }
@@ -1391,7 +1403,7 @@ __global__ void __launch_bounds__(256) k_long_finish(uint32_t nReads, const Long
 	uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= nReads) return;
 	LongState st = state[r];
-	LongReadResult rr { st.status == 1 ? 0u : st.nAln, st.extended, st.status, 0 };   // a throwing AlignOneWay returns nothing (src/Aligner.cpp:585-592)
+	LongReadResult rr { st.status == 1 ? 0u : st.nAln, st.extended, st.status, st.pad1 };   // pad = the read's flatten ties   // a throwing AlignOneWay returns nothing (src/Aligner.cpp:585-592)
 	results[r] = rr;
 }
 
@@ -1436,10 +1448,10 @@ void launchExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* 
 
 void launchBuildAnchors(hipStream_t stream, const DGraph& g, const Fragment* frags, uint32_t nFrags, const FragSeed* seeds, const ExtResult* ext,
 	const TraceCell* tracePool, int32_t splitLen, AnchorRec* anchors, uint32_t* fragStatus, uint32_t* fragExtended,
-	uint32_t* pathPool, unsigned long long* pathCursor, uint64_t pathCapacity, AnchorRounds rounds)
+	uint32_t* pathPool, unsigned long long* pathCursor, uint64_t pathCapacity, AnchorRounds rounds, uint32_t* readTies)
 {
 	if (nFrags == 0) return;
-	hipLaunchKernelGGL(k_build_anchors, dim3((nFrags + 63) / 64), dim3(64), 0, stream, g, frags, nFrags, seeds, ext, tracePool, splitLen, anchors, fragStatus, fragExtended, pathPool, pathCursor, pathCapacity, rounds);
+	hipLaunchKernelGGL(k_build_anchors, dim3((nFrags + 63) / 64), dim3(64), 0, stream, g, frags, nFrags, seeds, ext, tracePool, splitLen, anchors, fragStatus, fragExtended, pathPool, pathCursor, pathCapacity, rounds, readTies);
 }
 
 uint64_t chainScratchBytes(const ChainCaps& caps)

@@ -52,7 +52,7 @@ struct ExtResult {
 	uint32_t traceLen;
 	uint32_t status;   // EXT_*
 	int32_t score;
-	uint32_t pad;
+	uint32_t pad;      // bit 0 (r5): the last-slice minimum was attained in more than one node (ExtCounters::flattenTie)
 };
 
 struct Fragment;
@@ -143,7 +143,7 @@ struct LongAln {     // one accepted alignment, in acceptance order
 	uint32_t pad;
 };
 
-struct LongReadResult { uint32_t nAlignments, seedsExtended, status, pad; };
+struct LongReadResult { uint32_t nAlignments, seedsExtended, status, pad; };   // pad (r5): the read's flatten ties (extensions whose last-slice minimum was tied between nodes)
 
 // round-based whole-read pass: per-read state carried between rounds, and the per-round work items
 struct LongState { uint32_t si, nAln, extended, status, e2eScore, candBegin, candCount, pad1; };   // candBegin/candCount: this round's candidate seeds (pairs of work items)
@@ -153,7 +153,7 @@ struct LongWork {    // one direction of one seed extension
 	uint32_t seqLen, node, offset;
 	uint32_t read;
 };
-struct LongWorkResult { uint64_t traceOff; uint32_t traceLen, status; int32_t score; uint32_t pad; };
+struct LongWorkResult { uint64_t traceOff; uint32_t traceLen, status; int32_t score; uint32_t pad; };   // pad bit 0: as ExtResult::pad
 
 // ---- launchers (all asynchronous on `stream`) ------------------------------------------------------
 void launchSeedLookup(hipStream_t stream, const SeedIndex& idx, const char* bases, const uint64_t* readOff, uint32_t nReads,
@@ -178,7 +178,7 @@ void launchExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* 
 
 void launchBuildAnchors(hipStream_t stream, const DGraph& g, const Fragment* frags, uint32_t nFrags, const FragSeed* seeds, const ExtResult* ext,
 	const TraceCell* tracePool, int32_t splitLen, AnchorRec* anchors, uint32_t* fragStatus, uint32_t* fragExtended,
-	uint32_t* pathPool, unsigned long long* pathCursor, uint64_t pathCapacity, AnchorRounds rounds = AnchorRounds());
+	uint32_t* pathPool, unsigned long long* pathCursor, uint64_t pathCapacity, AnchorRounds rounds = AnchorRounds(), uint32_t* readTies = nullptr);   // readTies [reads], zeroed by the caller: += the ExtResult::pad flags of the extensions the reference would have run
 
 uint64_t chainScratchBytes(const ChainCaps& caps);
 uint32_t chainGridBlocks(uint32_t nReads);

@@ -130,7 +130,8 @@ def merge_read_results(parts, batches, n_reads, key, fill=0):
 
 
 SUMMARY_FIELDS = ["anchors", "chain_len", "chain_hash", "chain_score", "long_edit_distance", "chain_edit_distance", "chained_better",
-                  "longall", "longall_hash", "selected", "selected_hash", "failed_assertion"]
+                  "longall", "longall_hash", "selected", "selected_hash", "failed_assertion", "flatten_ties", "flatten_ties_long"]
+SUMMARY_WIDTH = len(SUMMARY_FIELDS)
 
 
 def _list_hash(values, offsets):
@@ -170,7 +171,7 @@ def gaf_read_hashes(text, lines_per_read):
 
 
 def read_summary(out):
-    """[n, 12] int64: SUMMARY_FIELDS of every read of a batch result (a dict as Aligner.align_batch returns it; the selected whole-read
+    """[n, 14] int64: SUMMARY_FIELDS of every read of a batch result (a dict as Aligner.align_batch returns it; the selected whole-read
     alignments either as `long_index` into the read's alignment list or as `long_start/end/score`). The chain and alignment lists enter
     as order-sensitive 64-bit hashes, so two results agree on a read iff its chain, scores, distances, decision and alignments agree."""
     i64 = lambda k: np.asarray(out[k]).astype(np.int64)
@@ -183,7 +184,7 @@ def read_summary(out):
         selected = triples(i64("longall_start")[sel], i64("longall_end")[sel], i64("longall_score")[sel])
     else:
         selected = triples(i64("long_start"), i64("long_end"), i64("long_score"))
-    s = np.zeros((n, 12), dtype=np.int64)
+    s = np.zeros((n, SUMMARY_WIDTH), dtype=np.int64)
     s[:, 0] = np.diff(anchor_off)
     s[:, 1] = np.diff(chain_off)
     s[:, 2] = _list_hash(i64("chain"), chain_off)
@@ -196,4 +197,6 @@ def read_summary(out):
     s[:, 9] = np.diff(sel_off)
     s[:, 10] = _list_hash(selected, 3 * sel_off)
     s[:, 11] = i64("failed_assertion")
+    s[:, 12] = i64("flatten_ties")            # r5: extensions whose last-slice minimum is attained in more than one node (the tie whose order this build defines)
+    s[:, 13] = i64("flatten_ties_long")
     return s

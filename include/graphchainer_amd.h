@@ -244,6 +244,15 @@ typedef struct gc_result {
 	uint64_t* out_path_off;  char* out_path_text;     /* [n_out+1]; GAF column 6, e.g. ">12>13<7" (device_output & 3) */
 	uint64_t* out_cigar_off; char* out_cigar_text;    /* [n_out+1]; the cg:Z: value (device_output & 3) */
 	uint64_t* out_vg_off;    uint8_t* out_vg_path;    /* [n_out+1]; the alignment's vg::Path in proto3 wire format, src/vg.proto:52-109 (device_output & 4) */
+	/* r5 (appended: the layout above is unchanged). How often this read exercised the ONE rule this library defines instead of reproducing: the reference's
+	 * flattenLastSliceEnd (src/GraphAlignerBitvectorCommon.h:1170-1229) takes the last partial slice's minimum cell with a strict '<' in the iteration order of a
+	 * parallel-hashmap (src/NodeSlice.h:54) - a library absent from the reference tree here - so when the minimum is attained in MORE THAN ONE NODE the cell the
+	 * reference starts its backtrace from depends on that order; this library takes the node that entered the slice's band first. flatten_ties[r] /
+	 * flatten_ties_long[r] = the extensions of read r (fragment pass / whole-read pass; only extensions the reference would have run) with such a tie.
+	 * 0 for a read means: nothing in its result depends on the defined order. DESIGN.md §7 says how often a tie changes an output. */
+	uint32_t* flatten_ties;       /* [n_reads] */
+	uint32_t* flatten_ties_long;  /* [n_reads] */
+	int32_t device_output;        /* the gc_params::device_output the batch ran with: gc_format_gaf refuses a cigar_match_mismatch_merge that differs from the pieces' style */
 } gc_result;
 
 /* Runs seeding, fragment seed-extension, anchor construction and co-linear chaining (and, with
@@ -253,7 +262,8 @@ int gc_align_batch(const gc_graph* g, const gc_seeder* s, gc_stream* st, const g
 void gc_result_free(gc_result* r);
 
 /* gc_result_free keeps the large arrays of freed results (trace cells, output text: up to 24 GB in all) for the next batch's result - fresh memory of that size is
- * mapped and zero-filled page by page every batch otherwise; gc_result_cache_trim gives what is held back to the allocator (e.g. when a host stops aligning). */
+ * mapped and zero-filled page by page every batch otherwise; gc_reads_destroy and the device deflate keep their device / pinned blocks the same way (up to 24 GB and 4 GB per cache).
+ * gc_result_cache_trim gives everything that is held back to the allocator (e.g. when a host stops aligning). */
 void gc_result_cache_trim(void);
 
 const char* gc_last_error(void);
@@ -280,6 +290,7 @@ int gc_evalue(double min_identity, uint64_t database_size, uint64_t query_size, 
  * alignmentStart, src/Aligner.cpp:1022, written by writeGAFToQueue :300-311). `result` must come from gc_align_batch with
  * long_pass, keep_traces, edit_distances and chain_traces >= 1; bases/offsets are the read batch as given to gc_reads_upload;
  * (or, r4, with device_output instead of keep_traces: the lines are then put together from the pieces the device wrote - no trace comes down);
+ * with device_output the pieces' CIGAR style is the one the batch was aligned with: cigar_match_mismatch_merge must agree with it (GC_ERR_INVALID otherwise);
  * read_names[i] is the FASTQ id. A read whose chained alignment won (chained_better) is written from its chain_trace_*
  * (src/Aligner.cpp:901-920); n_chained_skipped counts winners the result holds no trace for (0 unless chain_traces was 0).
  * *out_text is malloc'd (gc_free), NUL-terminated, *out_len bytes long. */
@@ -302,11 +313,16 @@ int gc_format_gam(const gc_graph* g, const gc_result* result, const char* const*
  *   gc_format_gaf_trace  GraphAlignerGAFAlignment::traceToAlignment (src/GraphAlignerGAFAlignment.h:38-196): the GAF line, no newline.
  *   gc_format_vg_trace   GraphAlignerVGAlignment::traceToAlignment + AddAlignment's sequence / query_position + replaceDigraphNodeIdsWithOriginalNodeIds
  *                        (src/GraphAlignerVGAlignment.h:36-163, src/GraphAligner.h:205-212, src/Aligner.cpp:152-165): the vg::Alignment message, proto3 wire bytes.
+ *   gc_format_vg_trace_digraph   the same message as AddAlignment alone leaves it (src/GraphAligner.h:205-212): position.node_id = the digraph node id (2 x segment index
+ *                        + strand) and no position.name - for a host that keeps the reference's own call to replaceDigraphNodeIdsWithOriginalNodeIds right after AddAlignment
+ *                        (src/Aligner.cpp:1009; include/graphchainer_amd_shim.hpp's AddAlignment goes here, so that an unchanged src/Aligner.cpp:1006-1012 gives the reference's ids).
  *   gc_graph_letters     the graph letter under each (node id, offset): TraceItem's graphCharacter (src/GraphAlignerCommon.h:148-153). */
 int gc_format_gaf_trace(const gc_graph* g, const char* read_name, const char* sequence, uint64_t sequence_len, const int32_t* node, const uint32_t* offset, const uint32_t* seqpos,
                         const uint8_t* node_switch, uint64_t n, int cigar_match_mismatch_merge, char** out_text, uint64_t* out_len);
 int gc_format_vg_trace(const gc_graph* g, const char* read_name, const char* sequence, uint64_t sequence_len, const int32_t* node, const uint32_t* offset, const uint32_t* seqpos,
                        const uint8_t* node_switch, uint64_t n, int32_t score, uint64_t alignment_start, uint64_t alignment_end, char** out_bytes, uint64_t* out_len);
+int gc_format_vg_trace_digraph(const gc_graph* g, const char* read_name, const char* sequence, uint64_t sequence_len, const int32_t* node, const uint32_t* offset, const uint32_t* seqpos,
+                               const uint8_t* node_switch, uint64_t n, int32_t score, uint64_t alignment_start, uint64_t alignment_end, char** out_bytes, uint64_t* out_len);
 int gc_graph_letters(const gc_graph* g, const int32_t* node, const uint32_t* offset, uint64_t n, char* out);
 
 /* gc_format_gam with the zlib level of the gzip members chosen by the caller (-1 = Z_DEFAULT_COMPRESSION, what the reference's GzipOutputStream uses and gc_format_gam

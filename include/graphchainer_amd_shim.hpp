@@ -148,14 +148,16 @@ inline void AddGAFLine(const AlignmentGraph&, const std::string& seq_id, const s
 	gc_free(text);
 }
 
-// AddAlignment, src/GraphAlignerWrapper.h:43 (GraphAligner::AddAlignment, src/GraphAligner.h:205-212, followed by replaceDigraphNodeIdsWithOriginalNodeIds, src/Aligner.cpp:152-165,1009):
-// alignment.alignment = the vg::Alignment of the trace, parsed from the message bytes the library builds (the reference's vg::Alignment is a protobuf message)
+// AddAlignment, src/GraphAlignerWrapper.h:43 (GraphAligner::AddAlignment, src/GraphAligner.h:205-212): alignment.alignment = the vg::Alignment of the trace, parsed from the message
+// bytes the library builds (the reference's vg::Alignment is a protobuf message). As in the reference the positions hold DIGRAPH node ids and no names: the caller's own
+// replaceDigraphNodeIdsWithOriginalNodeIds (src/Aligner.cpp:152-165), which src/Aligner.cpp:1009 calls right after AddAlignment, turns them into segment indices and names.
+// (r4 returned the ids already replaced - an unchanged Aligner.cpp then halved them a second time: ADVICE r4.)
 inline void AddAlignment(const std::string& seq_id, const std::string& sequence, AlignmentResult::AlignmentItem& alignment)
 {
 	if (!alignment.trace || alignment.trace->trace.empty()) throw std::logic_error("gcshim::AddAlignment: the alignment has no trace");
 	const TraceArrays t(alignment.trace->trace);
 	char* bytes = nullptr; uint64_t len = 0;
-	if (gc_format_vg_trace(binding().graph, seq_id.c_str(), sequence.data(), sequence.size(), t.node.data(), t.offset.data(), t.seqPos.data(), t.nodeSwitch.data(), t.node.size(), (int32_t)alignment.trace->score,
+	if (gc_format_vg_trace_digraph(binding().graph, seq_id.c_str(), sequence.data(), sequence.size(), t.node.data(), t.offset.data(), t.seqPos.data(), t.nodeSwitch.data(), t.node.size(), (int32_t)alignment.trace->score,
 			alignment.alignmentStart, alignment.alignmentEnd, &bytes, &len) != GC_OK)
 		throw std::runtime_error(gc_last_error());
 	alignment.alignment = std::make_shared<typename decltype(alignment.alignment)::element_type>();

@@ -49,6 +49,7 @@ def load_oracle_lib():
     lib.gco_edit_path.argtypes = [C.c_char_p, u64, C.c_char_p, u64, C.c_void_p, u64, C.POINTER(C.c_longlong)]
     lib.gco_evalue.argtypes = [C.c_double, u64, u64, u64, u64, C.c_void_p]
     lib.gco_set_e_cutoff.argtypes = [C.c_void_p, C.c_double]
+    lib.gco_set_tie_order.argtypes = [C.c_void_p, C.c_int]
     lib.gco_extend.restype = C.c_int
     lib.gco_extend.argtypes = [C.c_void_p, C.c_char_p, u64, C.c_int, u64]
     lib.gco_align_timed.restype = C.c_double
@@ -74,7 +75,7 @@ RESULT_ARRAYS = [
     "read_path_off", "path_node", "path_offset",
     "long_edit_distance", "chain_edit_distance", "chained_better", "failed_assertion", "seeds_extended",
     "read_chain_ops_off", "chain_ops", "read_chain_trace_off", "chain_trace_node", "chain_trace_offset", "chain_trace_seqpos", "chain_trace_switch",
-    "chain_aln_start", "chain_aln_end",
+    "chain_aln_start", "chain_aln_end", "flatten_ties", "flatten_ties_long", "flatten_counters",
     "counters", "stage_microseconds",
 ]
 
@@ -83,7 +84,7 @@ class Oracle:
     """CPU restatement of the per-read hot path (reference defaults: src/AlignerMain.cpp:186-209)."""
 
     def __init__(self, gfa_path, k=15, w=20, density=10.0, discard_fraction=0.001, bandwidth=10,
-                 split_len=35, split_gap=35, colinear_gap=10000, long_pass=True, shrink_mpc=True, e_cutoff=-1.0):
+                 split_len=35, split_gap=35, colinear_gap=10000, long_pass=True, shrink_mpc=True, e_cutoff=-1.0, tie_order=0):
         self.lib = load_oracle_lib()
         self.h = self.lib.gco_create(gfa_path.encode(), k, w, density, discard_fraction, bandwidth,
                                      split_len, split_gap, colinear_gap, int(long_pass), int(shrink_mpc))
@@ -91,6 +92,9 @@ class Oracle:
         if err:
             raise RuntimeError(err)
         self.lib.gco_set_e_cutoff(self.h, float(e_cutoff))
+        # tie_order: the node order in which flattenLastSliceEnd takes its strict minimum (oracle/bitvector_aligner.hpp header): 0 = band-entry order, the order this build
+        # DEFINES in place of the reference's parallel-hashmap iteration order; 1 = the reverse, for the sensitivity runs that say how many outputs depend on the definition
+        self.lib.gco_set_tie_order(self.h, int(tie_order))
 
     def close(self):
         if self.h:
@@ -137,17 +141,17 @@ class Oracle:
         return float(wall), stage
 
     SUMMARY_FIELDS = ["anchors", "chain_len", "chain_hash", "chain_score", "long_edit_distance", "chain_edit_distance", "chained_better",
-                      "longall", "longall_hash", "selected", "selected_hash", "failed_assertion"]
+                      "longall", "longall_hash", "selected", "selected_hash", "failed_assertion", "flatten_ties", "flatten_ties_long"]
 
     def align_summary(self, reads, threads=1, gaf_hash=False):
-        """align_timed that keeps 12 values per read (SUMMARY_FIELDS; see gco_align_summary) for bench.py's parity sample.
-        Returns (wall seconds, stage seconds, int64 array [n, 12]); with gaf_hash a 13th column: the hash of the GAF lines the
+        """align_timed that keeps 14 values per read (SUMMARY_FIELDS; see gco_align_summary) for bench.py's parity sample.
+        Returns (wall seconds, stage seconds, int64 array [n, 14]); with gaf_hash a 15th column: the hash of the GAF lines the
         reference would write for the read (gco_align_summary2), which bench.py's end-to-end leg compares with the product's text."""
         bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
         off = np.zeros(len(bs) + 1, dtype=np.uint64)
         off[1:] = np.cumsum([len(b) for b in bs])
         stage = np.zeros(5, dtype=np.float64)
-        summary = np.zeros((len(bs), 12), dtype=np.int64)
+        summary = np.zeros((len(bs), 14), dtype=np.int64)
         hashes = np.zeros(len(bs), dtype=np.int64)
         wall = self.lib.gco_align_summary2(self.h, b"".join(bs), off.ctypes.data, len(bs), int(threads), stage.ctypes.data, summary.ctypes.data, hashes.ctypes.data if gaf_hash else None)
         if gaf_hash:
@@ -183,6 +187,17 @@ class Oracle:
         self.lib.gco_json.restype = C.c_char_p
         self.lib.gco_json.argtypes = [C.c_void_p]
         return self.lib.gco_json(self.h)
+
+
+    def gam_groups(self):
+        """The final alignments of the last align() call as the reference's GAM stream before the gzip layer (src/Aligner.cpp:261-281): one bytes object
+        per read with output, holding varint count + (varint size, vg::Alignment proto3 bytes) per alignment. The reference deflates each into its own gzip member."""
+        n, ng, off = C.c_uint64(0), C.c_uint64(0), C.POINTER(C.c_uint64)()
+        self.lib.gco_gam.restype = C.POINTER(C.c_char)
+        self.lib.gco_gam.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64)]
+        ptr = self.lib.gco_gam(self.h, C.byref(n), C.byref(off), C.byref(ng))
+        raw = C.string_at(ptr, n.value)
+        return [raw[off[i]:off[i + 1]] for i in range(ng.value)]
 
 
 class RefUnits:

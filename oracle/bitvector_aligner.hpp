@@ -165,6 +165,7 @@ struct DPSlice {   // reference: src/GraphAlignerBitvectorCommon.h:138-214
 	size_t j = SIZE_MAX;
 	size_t cellsProcessed = 0;
 	size_t bandwidth = 0;
+	bool flattenTie = false;   // (this build's bookkeeping, not the reference's) flattenLastSliceEnd found its minimum in more than one node: minScoreNode / minScoreNodeOffset depend on the iteration order
 };
 struct DPTable { std::vector<DPSlice> slices; };
 
@@ -197,12 +198,17 @@ struct EdgeWithPriority {   // reference: src/GraphAlignerCommon.h:30-50
 // Work counters in the unit SURVEY.md §8d prices (tiles of one node x one 64-row slice).
 struct AlignerCounters {
 	uint64_t dpTiles = 0, recomputeTiles = 0, columnSteps = 0, traceItems = 0, extensions = 0;
+	// r5: how often the one rule this build DEFINES instead of reproducing is exercised (the header's PARITY UNPINNED note): calls of flattenLastSliceEnd, and the
+	// extensions whose backtrace STARTED from a flattened slice whose minimum is attained in more than one node - only there can the reference's parallel-hashmap
+	// iteration order pick a different cell than band-entry order does
+	uint64_t flattenCalls = 0, flattenTies = 0;
 };
 
 // Per-thread reusable state. reference: src/GraphAlignerCommon.h:51-93 (AlignerGraphsizedState)
 struct AlignerState {
 	std::vector<bool> currentBand, previousBand;
 	AlignerCounters counters;
+	int tieOrder = 0;   // flattenLastSliceEnd's iteration order over the slice's nodes: 0 band-entry order (the defined order), 1 the reverse (the sensitivity runs of tests/test_oracle_golden.py)
 	explicit AlignerState(const AlignmentGraph& g) : currentBand(g.NodeSize(), false), previousBand(g.NodeSize(), false) {}
 	void clear() { currentBand.assign(currentBand.size(), false); previousBand.assign(previousBand.size(), false); }
 };
@@ -225,7 +231,11 @@ public:
 		// getReverseTraceFromTableStartLastRow, ...Common.h:385-390
 		const DPSlice& last = table.slices.back();
 		MatrixPosition startPos { last.minScoreNode, last.minScoreNodeOffset, std::min(last.j + 63, sequence.size() - 1) };
-		return getReverseTraceFromTable(sequence, table, startPos, last.minScore, state);
+		OnewayTrace trace = getReverseTraceFromTable(sequence, table, startPos, last.minScore, state);
+		// the tie counts where it can change an output: the flattened slice is the one the backtrace starts in (a slice the correctness estimate dropped or trimmed has
+		// handed on nothing but its minimum SCORE, which no order changes) and the extension produced a trace
+		if (last.flattenTie) state.counters.flattenTies++;
+		return trace;
 	}
 
 	static EqVector getEqVector(std::string_view sequence, size_t j)   // ...Common.h:280-319
@@ -288,7 +298,7 @@ private:
 		return result;
 	}
 
-	struct NodeCalculationResult { int32_t minScore; size_t minScoreNode, minScoreNodeOffset, cellsProcessed; };
+	struct NodeCalculationResult { int32_t minScore; size_t minScoreNode, minScoreNodeOffset, cellsProcessed; bool flattenTie = false; };
 
 	// reference: ...Common.h:885-1168 with PreciseClipping=false. `columns` (non-null) collects every
 	// column's WordSlice and corresponds to AllowEarlyLeave=false (recalcNodeWordslice).
@@ -440,19 +450,27 @@ private:
 		sliceCalc.minScoreNodeOffset = SIZE_MAX;
 		size_t offset = sequence.size() - j;
 		EqVector EqV = getEqVector(sequence, j);
-		for (const auto& entry : slice.items) {   // DEFINED order: band-entry order (see header)
+		size_t nodesAtMinimum = 0;
+		for (size_t at = 0; at < slice.items.size(); at++) {   // DEFINED order: band-entry order (see header); state.tieOrder == 1 walks it backwards
+			const auto& entry = slice.items[state.tieOrder == 1 ? slice.items.size() - 1 - at : at];
 			NodeSliceItem old = previousSlice.hasNode(entry.first) ? previousSlice.node(entry.first) : absentPrevious();
 			std::vector<WordSlice> cols = recalcNodeWordslice(entry.first, entry.second, EqV, old, state);
+			int32_t nodeMinimum = INT32_MAX;
 			for (size_t i = 0; i < cols.size(); i++) {
 				WordSlice flat = flattenWordSlice(cols[i], offset);
+				if (flat.scoreEnd < nodeMinimum) nodeMinimum = flat.scoreEnd;
 				if (flat.scoreEnd < sliceCalc.minScore) {
 					sliceCalc.minScore = flat.scoreEnd;
 					sliceCalc.minScoreNode = entry.first;
 					sliceCalc.minScoreNodeOffset = i;
+					nodesAtMinimum = 0;
 				}
 			}
+			if (nodeMinimum == sliceCalc.minScore) nodesAtMinimum++;
 		}
 		ORACLE_ASSERT(sliceCalc.minScore != INT32_MAX);
+		state.counters.flattenCalls++;
+		sliceCalc.flattenTie = nodesAtMinimum > 1;
 	}
 
 	// Node scheduling inside one slice. reference: src/ComponentPriorityQueue.h. Items are ordered by
@@ -591,6 +609,7 @@ inline DPTable BitvectorAligner::getViterbiSlices(std::string_view sequence, con
 			newSlice.minScoreNode = r.minScoreNode;
 			newSlice.minScoreNodeOffset = r.minScoreNodeOffset;
 			newSlice.minScore = r.minScore;
+			newSlice.flattenTie = r.flattenTie;
 			ORACLE_ASSERT(newSlice.minScore >= lastSlice.minScore);
 			newSlice.correctness = newSlice.correctness.NextState(newSlice.minScore - lastSlice.minScore);
 			newSlice.bandwidth = bandwidth;

@@ -33,6 +33,9 @@ struct ReadResult {
 	bool chainedBetter = false;
 	bool failedAssertion = false;
 	size_t seedsExtended = 0;
+	// r5: flattenLastSliceEnd calls of this read whose minimum was attained in more than one node (the one rule whose tie order is defined, not reproduced:
+	// oracle/bitvector_aligner.hpp header), in the fragment pass and in the whole-read pass
+	size_t flattenTies = 0, flattenTiesLong = 0;
 };
 
 // reference: src/AlignmentSelection.cpp (GreedySelectAlignments with alignmentLengthCompare, :42-50,
@@ -129,6 +132,7 @@ public:
 		// tested after every fragment (:702-703): once the whole-read pass has thrown, no fragment of the read adds an anchor.
 		bool cont = false;
 		// ---- A. whole-read pass (src/Aligner.cpp:630-654 -> align_fn :531-594)
+		const uint64_t tiesAtStart = state.counters.flattenTies;
 		if (params.longPass) {
 			auto t0 = clk::now();
 			std::vector<SeedHit> seeds = getSeeds(graph, index, sequence, params.seedDensity);
@@ -152,6 +156,7 @@ public:
 			if (!res.longAlignments.empty()) res.longEditDistance = editDistanceNW(traceToSequence(graph, res.longAlignments[0]), sequence);
 			stageSeconds[1] += secs(t1, clk::now());
 		}
+		res.flattenTiesLong = state.counters.flattenTies - tiesAtStart;
 		// ---- B. fragment pass (:658-730)
 		auto t2 = clk::now();
 		res.seeds = getSeeds(graph, index, sequence, params.seedDensity);
@@ -204,6 +209,7 @@ public:
 		}
 		auto t4 = clk::now();
 		stageSeconds[2] += secs(t3, t4);
+		res.flattenTies = state.counters.flattenTies - tiesAtStart - res.flattenTiesLong;
 		// ---- chaining (:735)
 		auto chained = colinearChaining(graph, res.anchors);
 		res.chain = chained.first;
@@ -314,7 +320,10 @@ struct OracleHandle {
 	Export ex;
 	std::string gaf[2];   // GAF text of the last gco_align call (read ids r0, r1, ...): [0] =/X cigar, [1] merged M cigar
 	std::string json;     // JSON lines of the same alignments
+	std::string gam;      // the same alignments as the INFLATED GAM stream: per read with output one group (varint count, then varint size + vg::Alignment bytes each), src/Aligner.cpp:261-281
+	std::vector<uint64_t> gamGroupOff { 0 };   // group boundaries in gam (the reference deflates every group into its own gzip member)
 	std::string error;
+	int tieOrder = 0;     // flattenLastSliceEnd's node order (AlignerState::tieOrder): 0 the defined order, 1 reversed (sensitivity runs)
 };
 
 extern "C" {
@@ -347,9 +356,10 @@ int gco_align(void* hv, const char* bases, const uint64_t* off, int n)
 	Export& ex = h->ex;
 	ex.clear();
 	AlignerState state(h->o.graph);
+	state.tieOrder = h->tieOrder;
 	h->o.counters = AlignerCounters();
 	for (double& s : h->o.stageSeconds) s = 0;
-	h->gaf[0].clear(); h->gaf[1].clear(); h->json.clear();
+	h->gaf[0].clear(); h->gaf[1].clear(); h->json.clear(); h->gam.clear(); h->gamGroupOff.assign(1, 0);
 	const char* names[] = { "read_seed_off", "read_frag_off", "read_anchor_off", "read_chain_off", "read_long_off", "read_longall_off", "read_path_off", "anchor_path_off", "anchor_trace_off", "long_trace_off", "read_chain_ops_off", "read_chain_trace_off" };
 	for (const char* nm : names) ex[nm].push_back(0);
 	for (int r = 0; r < n; r++) {
@@ -401,10 +411,17 @@ int gco_align(void* hv, const char* bases, const uint64_t* off, int n)
 			auto byStart = [](const AlignmentItem& l, const AlignmentItem& rr) { return l.alignmentStart < rr.alignmentStart; };
 			std::sort(finalAlns.begin(), finalAlns.end(), byStart);   // :1003
 			std::sort(finalAlns.begin(), finalAlns.end(), byStart);   // :1023 (AddAlignment / AddGAFLine in between do not reorder)
+			std::vector<std::string> messages;
 			for (const AlignmentItem& a : finalAlns) {
 				for (int m = 0; m < 2; m++) { h->gaf[m] += traceToGaf(h->o.graph, "r" + std::to_string(r), seq, *a.trace, m == 1); h->gaf[m] += '\n'; }
-				h->json += alignmentToJson(h->o.graph, "r" + std::to_string(r), seq, a);
+				OraAlignment vg = buildVgAlignment(h->o.graph, "r" + std::to_string(r), seq, a);
+				h->json += vgAlignmentToJson(vg);
 				h->json += '\n';
+				messages.push_back(vgAlignmentToProto(vg));
+			}
+			if (!messages.empty()) {   // a read without alignments leaves runComponentMappings before the writers (src/Aligner.cpp:977-992)
+				h->gam += gamGroup(messages);
+				h->gamGroupOff.push_back(h->gam.size());
 			}
 		}
 		for (unsigned char c : res.chainOps) ex["chain_ops"].push_back(c);
@@ -446,9 +463,12 @@ int gco_align(void* hv, const char* bases, const uint64_t* off, int n)
 		ex["chained_better"].push_back(res.chainedBetter ? 1 : 0);
 		ex["failed_assertion"].push_back(res.failedAssertion ? 1 : 0);
 		ex["seeds_extended"].push_back((int64_t)res.seedsExtended);
+		ex["flatten_ties"].push_back((int64_t)res.flattenTies);
+		ex["flatten_ties_long"].push_back((int64_t)res.flattenTiesLong);
 	}
 	const AlignerCounters& c = state.counters;
 	ex["counters"] = { (int64_t)c.dpTiles, (int64_t)c.recomputeTiles, (int64_t)c.columnSteps, (int64_t)c.traceItems, (int64_t)c.extensions };
+	ex["flatten_counters"] = { (int64_t)c.flattenCalls, (int64_t)c.flattenTies };   // calls of flattenLastSliceEnd; extensions whose backtrace started from a tied minimum
 	for (double s : h->o.stageSeconds) ex["stage_microseconds"].push_back((int64_t)(s * 1e6));
 	return 0;
 }
@@ -456,9 +476,10 @@ int gco_align(void* hv, const char* bases, const uint64_t* off, int n)
 // CPU baseline leg of bench.py: the reference's threading model (src/Aligner.cpp:1267-1270: one worker per thread over a shared
 // read queue, each with its own reusable state). Returns the wall seconds; stage5 (may be NULL) receives the per-stage CPU seconds
 // summed over the workers, in the order seed / whole-read pass / fragments / chaining / stitch + edlib. `summary` (may be NULL)
-// receives 12 values per read - what bench.py's parity sample compares with the timed GPU output after the timed region
+// receives 14 values per read - what bench.py's parity sample compares with the timed GPU output after the timed region
 // (src/Aligner.cpp:630-654,735,901-905): anchors, chain length, chain hash, chain score, whole-read NW distance, chain NW distance,
-// chained_better, whole-read alignments, their (start, end, score) hash, selected alignments, their hash, failed assertion.
+// chained_better, whole-read alignments, their (start, end, score) hash, selected alignments, their hash, failed assertion, and (r5) the read's
+// flattenLastSliceEnd ties in the fragment pass and in the whole-read pass (ReadResult::flattenTies / flattenTiesLong).
 // hash of a list v[0..m) = sum (v[i] + 1) * (i + 1) * 2654435761 mod 2^64 (bench.py computes the same with numpy).
 static uint64_t listHashStep(uint64_t h, uint64_t index, int64_t v) { return h + ((uint64_t)v + 1) * ((index + 1) * 2654435761ull); }
 // gafHash (optional, r4): per read one more value - the hash of the GAF lines the reference would write for it (the final alignments in output order, =/X CIGAR;
@@ -475,9 +496,10 @@ double gco_align_summary2(void* hv, const char* bases, const uint64_t* off, int 
 	auto t0 = std::chrono::steady_clock::now();
 	auto worker = [&](int t) {
 		AlignerState state(h->o.graph);
+		state.tieOrder = h->tieOrder;
 		for (int r; (r = next.fetch_add(1)) < n;) {
 			std::string seq(bases + off[r], bases + off[r + 1]);
-			int64_t* out = summary ? summary + 12 * (size_t)r : nullptr;
+			int64_t* out = summary ? summary + 14 * (size_t)r : nullptr;
 			try {
 				ReadResult res = h->o.alignRead(seq, state, false, stages[t].data());
 				if (gafHash) {
@@ -509,7 +531,8 @@ double gco_align_summary2(void* hv, const char* bases, const uint64_t* off, int 
 				out[5] = res.chainEditDistance == SIZE_MAX ? -1 : (int64_t)res.chainEditDistance;
 				out[6] = res.chainedBetter ? 1 : 0; out[7] = (int64_t)res.longAll.size(); out[8] = (int64_t)ha;
 				out[9] = (int64_t)res.longAlignments.size(); out[10] = (int64_t)hs; out[11] = res.failedAssertion ? 1 : 0;
-			} catch (const std::exception&) { state.clear(); if (out) { for (int k = 0; k < 12; k++) out[k] = 0; out[11] = 2; } if (gafHash) gafHash[r] = 0; }
+				out[12] = (int64_t)res.flattenTies; out[13] = (int64_t)res.flattenTiesLong;
+			} catch (const std::exception&) { state.clear(); if (out) { for (int k = 0; k < 14; k++) out[k] = 0; out[11] = 2; } if (gafHash) gafHash[r] = 0; }
 		}
 	};
 	std::vector<std::thread> pool;
@@ -524,6 +547,13 @@ double gco_align_timed(void* hv, const char* bases, const uint64_t* off, int n, 
 
 const char* gco_gaf(void* hv, int merge) { return ((OracleHandle*)hv)->gaf[merge ? 1 : 0].c_str(); }
 const char* gco_json(void* hv) { return ((OracleHandle*)hv)->json.c_str(); }
+// the inflated GAM stream of the last gco_align call; *groupOff / *nGroups: the groups' boundaries (nGroups + 1 offsets)
+const char* gco_gam(void* hv, uint64_t* len, const uint64_t** groupOff, uint64_t* nGroups)
+{
+	OracleHandle* h = (OracleHandle*)hv;
+	*len = h->gam.size(); *groupOff = h->gamGroupOff.data(); *nGroups = h->gamGroupOff.size() - 1;
+	return h->gam.data();
+}
 
 const int64_t* gco_array(void* hv, const char* name, uint64_t* count)
 {
@@ -658,6 +688,7 @@ int gco_extend(void* hv, const char* seq, uint64_t len, int bigraphNodeId, uint6
 		return 2;
 	}
 }
+void gco_set_tie_order(void* hv, int order) { ((OracleHandle*)hv)->tieOrder = order; }   // 0: band-entry order (the defined order), 1: reversed
 void gco_set_e_cutoff(void* hv, double cutoff) { ((OracleHandle*)hv)->o.params.eCutoff = cutoff; }
 uint64_t gco_edit_distance(const char* a, uint64_t na, const char* b, uint64_t nb) { return editDistanceNW(std::string(a, a + na), std::string(b, b + nb)); }
 uint64_t gco_minimizer_hash(uint64_t k) { return gc::minimizerHash(k); }

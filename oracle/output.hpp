@@ -7,6 +7,7 @@
 #include "pipeline.hpp"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -133,10 +134,14 @@ inline std::string oraJsonEscape(const std::string& in)
 	return out + "\"";
 }
 
-inline std::string alignmentToJson(const AlignmentGraph& graph, const std::string& seq_id, const std::string& sequence, const AlignmentItem& item)
+// the vg::Alignment the reference holds for one final alignment after AddAlignment + replaceDigraphNodeIdsWithOriginalNodeIds: exactly the fields it sets
+struct OraAlignment { std::string sequence; std::vector<OraMapping> mapping; std::string name; int score = 0; int query_position = 0; double identity = 0; };
+
+inline OraAlignment buildVgAlignment(const AlignmentGraph& graph, const std::string& seq_id, const std::string& sequence, const AlignmentItem& item)
 {
 	const auto& trace = item.trace->trace;
-	std::vector<OraMapping> mapping;
+	OraAlignment aln;
+	std::vector<OraMapping>& mapping = aln.mapping;
 	enum { Match, Mismatch, Insertion, Deletion, Empty } currentEdit = Empty;
 	size_t mismatches = 0, deletions = 0, insertions = 0, matches = 0;
 	int curNode = (int)trace[0].DPposition.node;
@@ -184,8 +189,20 @@ inline std::string alignmentToJson(const AlignmentGraph& graph, const std::strin
 		m.node_id = digraphNodeId / 2;
 		m.name = graph.OriginalNodeName(digraphNodeId);
 	}
-	std::string alignedSequence = sequence.substr(item.alignmentStart, item.alignmentEnd - item.alignmentStart);
-	// print
+	aln.sequence = sequence.substr(item.alignmentStart, item.alignmentEnd - item.alignmentStart);   // src/GraphAligner.h:210
+	aln.name = seq_id;                                  // src/GraphAlignerVGAlignment.h:42
+	aln.score = item.trace->score;                      // :43
+	aln.query_position = (int)item.alignmentStart;      // src/GraphAligner.h:211
+	aln.identity = identity;                            // src/GraphAlignerVGAlignment.h:162
+	return aln;
+}
+
+inline std::string vgAlignmentToJson(const OraAlignment& aln)
+{
+	const std::vector<OraMapping>& mapping = aln.mapping;
+	const std::string& alignedSequence = aln.sequence;
+	const std::string& seq_id = aln.name;
+	double identity = aln.identity;
 	std::string js = "{";
 	auto field = [&](std::string& s, bool& first, const std::string& key) { if (!first) s += ","; first = false; s += "\"" + key + "\":"; };
 	bool first = true;
@@ -224,9 +241,9 @@ inline std::string alignmentToJson(const AlignmentGraph& graph, const std::strin
 	}
 	js += "}";
 	if (!seq_id.empty()) { field(js, first, "name"); js += oraJsonEscape(seq_id); }
-	int score = item.trace->score;
+	int score = aln.score;
 	if (score) { field(js, first, "score"); js += std::to_string(score); }
-	if (item.alignmentStart) { field(js, first, "query_position"); js += std::to_string((int)item.alignmentStart); }
+	if (aln.query_position) { field(js, first, "query_position"); js += std::to_string(aln.query_position); }
 	if (identity != 0) {
 		char buf[40];
 		snprintf(buf, sizeof buf, "%.15g", identity);
@@ -235,6 +252,73 @@ inline std::string alignmentToJson(const AlignmentGraph& graph, const std::strin
 	}
 	js += "}";
 	return js;
+}
+
+inline std::string alignmentToJson(const AlignmentGraph& graph, const std::string& seq_id, const std::string& sequence, const AlignmentItem& item)
+{
+	return vgAlignmentToJson(buildVgAlignment(graph, seq_id, sequence, item));
+}
+
+// ---- vg::Alignment -> GAM. reference: writeGAMToQueue (src/Aligner.cpp:261-281): per read one gzip member holding
+// varint64 count, then per alignment varint32 size + Alignment::SerializeToString. The message bytes are proto3's canonical
+// serialisation of src/vg.proto:52-154: fields in field-number order, scalar fields with their default value omitted, a
+// sub-message that was set (set_allocated_path, set_allocated_position, add_mapping, add_edit) written even when it is empty.
+// r5: PINNED against the reference's own generated descriptor - tests/golden/make_gam_golden.py parses these bytes with
+// /root/reference/scripts/vg_pb2.py through the reader of scripts/summary.py:63-75 and requires that every message
+// re-serialises to itself; the decoded messages are the committed *.expected.gam.json fixtures.
+inline void pbVarint(std::string& out, uint64_t v) { while (v >= 0x80) { out += (char)(v | 0x80); v >>= 7; } out += (char)v; }
+inline void pbKey(std::string& out, int fieldNumber, int wireType) { pbVarint(out, ((uint64_t)fieldNumber << 3) | (uint64_t)wireType); }
+inline void pbInt(std::string& out, int fieldNumber, long long v) { if (v == 0) return; pbKey(out, fieldNumber, 0); pbVarint(out, (uint64_t)v); }   // int32 / int64: negative values sign-extend to ten bytes
+inline void pbBool(std::string& out, int fieldNumber, bool v) { if (!v) return; pbKey(out, fieldNumber, 0); out += (char)1; }
+inline void pbString(std::string& out, int fieldNumber, const std::string& v) { if (v.empty()) return; pbKey(out, fieldNumber, 2); pbVarint(out, v.size()); out += v; }
+inline void pbMessage(std::string& out, int fieldNumber, const std::string& body) { pbKey(out, fieldNumber, 2); pbVarint(out, body.size()); out += body; }
+inline void pbDouble(std::string& out, int fieldNumber, double v)
+{
+	uint64_t bits;
+	memcpy(&bits, &v, 8);
+	if (bits == 0) return;
+	pbKey(out, fieldNumber, 1);
+	for (int i = 0; i < 8; i++) out += (char)(bits >> (8 * i));
+}
+
+inline std::string vgAlignmentToProto(const OraAlignment& aln)
+{
+	std::string path;                                   // Path { repeated Mapping mapping = 2 }
+	for (const OraMapping& m : aln.mapping) {
+		std::string position;                           // Position { node_id = 1, offset = 2, is_reverse = 4, name = 5 }
+		pbInt(position, 1, m.node_id);
+		pbInt(position, 2, m.offset);
+		pbBool(position, 4, m.is_reverse);
+		pbString(position, 5, m.name);
+		std::string mapping;                            // Mapping { position = 1, repeated edit = 2, rank = 5 }
+		pbMessage(mapping, 1, position);
+		for (const OraEdit& e : m.edit) {
+			std::string edit;                           // Edit { from_length = 1, to_length = 2, sequence = 3 }
+			pbInt(edit, 1, e.from_length);
+			pbInt(edit, 2, e.to_length);
+			pbString(edit, 3, e.sequence);
+			pbMessage(mapping, 2, edit);
+		}
+		pbInt(mapping, 5, m.rank);
+		pbMessage(path, 2, mapping);
+	}
+	std::string out;                                    // Alignment { sequence = 1, path = 2, name = 3, score = 6, query_position = 7, identity = 16 }
+	pbString(out, 1, aln.sequence);
+	pbMessage(out, 2, path);
+	pbString(out, 3, aln.name);
+	pbInt(out, 6, aln.score);
+	pbInt(out, 7, aln.query_position);
+	pbDouble(out, 16, aln.identity);
+	return out;
+}
+
+// one read's group as the reference frames it BEFORE the gzip layer (the inflated bytes of its member)
+inline std::string gamGroup(const std::vector<std::string>& messages)
+{
+	std::string out;
+	pbVarint(out, messages.size());
+	for (const std::string& m : messages) { pbVarint(out, m.size()); out += m; }
+	return out;
 }
 
 } // namespace oracle

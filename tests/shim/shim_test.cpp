@@ -98,6 +98,11 @@ int main(int argc, char** argv)
 			unsigned long long h = 1469598103934665603ull;
 			for (unsigned char c : item.alignment->bytes) { h ^= c; h *= 1099511628211ull; }
 			printf("gaf %d %zu %zu %zu %016llx %zu\t%s\n", a - 2, i, item.alignmentStart, item.alignmentEnd, h, item.corrected.size(), item.GAFline.c_str());
+			// the vg::Alignment bytes AddAlignment left (digraph node ids, no names: the caller's replaceDigraphNodeIdsWithOriginalNodeIds comes next, src/Aligner.cpp:1009);
+			// the GPU test decodes them, applies that step as the reference states it (:152-165) and compares with the batch's GAM
+			printf("vg %d %zu ", a - 2, i);
+			for (unsigned char c : item.alignment->bytes) printf("%02x", c);
+			printf("\n");
 		}
 		std::vector<size_t> ids = gcshim::colinearChaining(sequence, A, 10000);                        // :735
 		printf("read %d: seeds %zu long %zu anchors %zu chain %zu :", a - 2, seeds.size(), longAlignments.alignments.size(), A.size(), ids.size());

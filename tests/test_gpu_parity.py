@@ -14,6 +14,7 @@ COMPARE_KEYS = [
     "anchor_trace_off", "anchor_trace_node", "anchor_trace_offset", "anchor_trace_seqpos", "anchor_trace_switch",
     "read_chain_off", "chain", "chain_score", "failed_assertion", "seeds_extended",
     "read_path_off", "path_node", "path_offset",
+    "flatten_ties",      # r5: per read, the fragment extensions whose backtrace started from a last-slice minimum tied between nodes (the one rule whose order this build defines)
 ] + ["chain_edit_distance", "chained_better"] + [
     # the chained alignment's trace = edlib's alignment path walked over the stitched path (src/Aligner.cpp:845-897); run_case asks for it for every read
     "read_chain_trace_off", "chain_trace_node", "chain_trace_offset", "chain_trace_seqpos", "chain_trace_switch", "chain_aln_start", "chain_aln_end",
@@ -39,7 +40,7 @@ def gca():
 
 LONG_KEYS = ["read_long_off", "long_start", "long_end", "long_score", "long_edit_distance",
              "read_longall_off", "longall_start", "longall_end", "longall_score",
-             "long_trace_off", "long_trace_node", "long_trace_offset", "long_trace_seqpos", "long_trace_switch"]
+             "long_trace_off", "long_trace_node", "long_trace_offset", "long_trace_seqpos", "long_trace_switch", "flatten_ties_long"]
 
 
 def run_case(gca, gfa, reads, long_pass=False, **kw):
@@ -695,6 +696,35 @@ def test_shim_replays_the_reference_call_sequence(gca, tmp_path, golden_dir):
     for l in gaf_lines:
         head = l.split("\t", 1)[0].split()
         assert int(head[6]) > 0 and len(head[5]) == 16           # corrected letters; hash of the message bytes
+    # r5: AddAlignment leaves DIGRAPH node ids and no names, as the reference's does (src/GraphAligner.h:205-212); the caller's own
+    # replaceDigraphNodeIdsWithOriginalNodeIds (src/Aligner.cpp:152-165, called at :1009) - restated here on the decoded message - must give exactly the message the batch's GAM holds
+    import gzip
+    from vg_descriptor import alignment_class, decode_gam_stream
+    Alignment = alignment_class()
+    seg_names = [l.split("\t")[1] for l in open(gfa) if l.startswith("S\t")]             # first-appearance order = segment index (src/GfaGraph.cpp:146-174)
+    shim_messages = {}
+    for l in all_lines:
+        if not l.startswith("vg "):
+            continue
+        _, r, i, hexbytes = l.split()
+        msg = Alignment()
+        msg.ParseFromString(bytes.fromhex(hexbytes))
+        for m in msg.path.mapping:
+            assert m.position.name == "" and (m.position.node_id & 1) == int(m.position.is_reverse)      # digraph ids: 2 x segment index + strand
+            digraph_id = m.position.node_id                                                             # src/Aligner.cpp:156-162
+            m.position.node_id = digraph_id // 2
+            m.position.name = seg_names[digraph_id // 2]
+        shim_messages.setdefault(int(r), []).append(msg.SerializeToString())
+    gam = gca.Aligner(graph, gca.MinimizerSeeder(graph), long_pass=True, keep_traces=True).align_reads([r.encode() for r in reads], gaf_names=[f"r{i}" for i in range(len(reads))], formats=("gam",))["gam"]
+    raw, at, batch_messages = gzip.decompress(gam), 0, []
+    while at < len(raw):
+        count, at = _read_varint(raw, at)
+        for _ in range(count):
+            size, at = _read_varint(raw, at)
+            batch_messages.append(raw[at:at + size])
+            at += size
+    shim_all = {m for ms in shim_messages.values() for m in ms}
+    assert batch_messages and all(m in shim_all for m in batch_messages)                                  # (the shim encodes every whole-read alignment, the batch writes the selected ones)
     assert len(lines) == len(reads)
     for r, line in enumerate(lines):
         head, chain = line.split(":", 2)[1:]
@@ -765,42 +795,15 @@ def test_edit_path_kernel(gca):
 
 
 def _vg_alignment_class():
-    """vg::Alignment (the fields the reference sets, src/vg.proto:52-154) built for the protobuf Python runtime."""
-    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
-    F = descriptor_pb2.FieldDescriptorProto
-    fdp = descriptor_pb2.FileDescriptorProto(name="vg_subset_for_tests.proto", package="vgtest", syntax="proto3")
-
-    def message(name, fields):
-        m = fdp.message_type.add(name=name)
-        for fname, number, ftype, label, type_name in fields:
-            f = m.field.add(name=fname, number=number, type=ftype, label=label)
-            if type_name:
-                f.type_name = ".vgtest." + type_name
-    opt, rep = F.LABEL_OPTIONAL, F.LABEL_REPEATED
-    message("Edit", [("from_length", 1, F.TYPE_INT32, opt, None), ("to_length", 2, F.TYPE_INT32, opt, None), ("sequence", 3, F.TYPE_STRING, opt, None)])
-    message("Position", [("node_id", 1, F.TYPE_INT64, opt, None), ("offset", 2, F.TYPE_INT64, opt, None), ("is_reverse", 4, F.TYPE_BOOL, opt, None), ("name", 5, F.TYPE_STRING, opt, None)])
-    message("Mapping", [("position", 1, F.TYPE_MESSAGE, opt, "Position"), ("edit", 2, F.TYPE_MESSAGE, rep, "Edit"), ("rank", 5, F.TYPE_INT64, opt, None)])
-    message("Path", [("name", 1, F.TYPE_STRING, opt, None), ("mapping", 2, F.TYPE_MESSAGE, rep, "Mapping"), ("is_circular", 3, F.TYPE_BOOL, opt, None), ("length", 4, F.TYPE_INT64, opt, None)])
-    message("Alignment", [("sequence", 1, F.TYPE_STRING, opt, None), ("path", 2, F.TYPE_MESSAGE, opt, "Path"), ("name", 3, F.TYPE_STRING, opt, None),
-                          ("score", 6, F.TYPE_INT32, opt, None), ("query_position", 7, F.TYPE_INT32, opt, None), ("identity", 16, F.TYPE_DOUBLE, opt, None)])
-    pool = descriptor_pool.DescriptorPool()
-    pool.Add(fdp)
-    desc = pool.FindMessageTypeByName("vgtest.Alignment")
-    try:
-        return message_factory.GetMessageClass(desc)
-    except AttributeError:
-        return message_factory.MessageFactory(pool).GetPrototype(desc)
+    """vg::Alignment (the fields the reference sets, src/vg.proto:52-154) built for the protobuf Python runtime: tests/vg_descriptor.py, checked on the CPU against the
+    field table of the reference's own generated descriptor (tests/golden/vg_schema.expected.json)."""
+    from vg_descriptor import alignment_class
+    return alignment_class()
 
 
 def _read_varint(buf, at):
-    value, shift = 0, 0
-    while True:
-        b = buf[at]
-        at += 1
-        value |= (b & 0x7F) << shift
-        if not b & 0x80:
-            return value, at
-        shift += 7
+    from vg_descriptor import read_varint
+    return read_varint(buf, at)
 
 
 def test_json_and_gam_output(gca, tmp_path):
@@ -933,6 +936,75 @@ def test_output_against_golden_files(gca, golden_dir):
     assert dev["gaf"] == out["gaf"] and dev["json"] == out["json"] and gzip.decompress(dev["gam"]) == gzip.decompress(out["gam"])
     dev_merged = gca.Aligner(graph, seeder, long_pass=True, device_output=2).align_reads(reads, gaf_names=names, cigar_match_mismatch_merge=True)
     assert dev_merged["gaf"] == merged["gaf"]
+    # r5: the pieces' CIGAR style is fixed when the batch is aligned; asking gc_format_gaf for the other one is refused, not answered with mixed styles
+    for mode, merge in ((1, True), (2, False)):
+        with pytest.raises(RuntimeError, match="cigar_match_mismatch_merge"):
+            gca.Aligner(graph, seeder, long_pass=True, device_output=mode).align_reads(reads, gaf_names=names, cigar_match_mismatch_merge=merge)
+
+
+def test_flatten_tie_counts_equal_the_oracles(gca, tmp_path):
+    """r5: both extension cores count the extensions whose backtrace started from a flattenLastSliceEnd minimum attained in more than one node -
+    the only place where the reference's parallel-hashmap iteration order (absent here; band-entry order stands in) can choose another cell. gc_result::flatten_ties /
+    flatten_ties_long per read equal the oracle's, in the lazy and the eager fragment pipeline and through the plain-layout fallback; the counts are not zero on 10 kb reads
+    (about one tie per hundred extensions), so the comparison has something to compare."""
+    from graphchainer_amd.synth import SynthGraph
+    sg = SynthGraph(300_000, seed=7)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(48, 10_000, seed=11)
+    got, want = run_case(gca, gfa, reads, long_pass=True)
+    compare(got, want)
+    compare(got, want, LONG_KEYS)
+    assert int(want["flatten_ties"].sum()) >= 20 and int(want["flatten_ties_long"].sum()) >= 1
+    assert int((got["flatten_ties"] + got["flatten_ties_long"] > 0).sum()) >= 10      # most 10 kb reads meet the rule at least once
+    for env in ({"GC_EXT_LAZY": "0"}, {"GC_LONG_FORCE_FALLBACK": "1"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            again, _ = run_case(gca, gfa, reads[:16], long_pass=True)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        assert np.array_equal(again["flatten_ties"], want["flatten_ties"][:16]), env
+        assert np.array_equal(again["flatten_ties_long"], want["flatten_ties_long"][:16]), env
+
+
+@pytest.mark.parametrize("case", ["ref_test", "syn20k", "syn20k_more"])
+def test_gam_against_the_reference_decoded_fixture(gca, case):
+    """r5: the product's GAM - the host encoder over the traces, the device encoder's vg::Path bytes (k_out_encode) wrapped by the host, and the members deflated on the
+    device - inflates to the stream the REFERENCE'S OWN descriptor and reader decoded (tests/golden/make_gam_golden.py: /root/reference/scripts/vg_pb2.py through the
+    reader of scripts/summary.py:63-75), byte for byte, and decodes to the committed messages; one gzip member per read with output, as writeGAMToQueue frames them."""
+    import gzip
+    import zlib
+    from vg_descriptor import decode_gam_stream, golden_case
+    gfa, reads, want_groups, want_stream, want_better = golden_case(case)
+    graph = gca.AlignmentGraph(gfa)
+    seeder = gca.MinimizerSeeder(graph)
+    names = [f"r{i}" for i in range(len(reads))]
+    legs = {
+        "host encoder": (dict(keep_traces=True), {}),
+        "device encoder": (dict(device_output=1 | 4), {}),
+        "device encoder, device deflate": (dict(device_output=1 | 4), dict(gam_level=gca.GAM_DEVICE_HUFFMAN)),
+        "host encoder, device deflate": (dict(keep_traces=True), dict(gam_level=gca.GAM_DEVICE_HUFFMAN)),
+    }
+    for leg, (akw, fkw) in legs.items():
+        out = gca.Aligner(graph, seeder, long_pass=True, **akw).align_reads(reads, gaf_names=names, formats=("gam",), **fkw)
+        assert [int(x) for x in out["chained_better"]] == want_better, leg
+        raw = gzip.decompress(out["gam"])
+        assert raw == want_stream, leg
+        assert decode_gam_stream(raw) == want_groups, leg
+        # the framing: as many gzip members as reads with output, each inflating to one group
+        members, rest = 0, out["gam"]
+        while rest:
+            d = zlib.decompressobj(31)
+            group = d.decompress(rest)
+            assert d.eof and len(decode_gam_stream(group)) == 1, leg
+            rest = d.unused_data
+            members += 1
+        assert members == len(want_groups), leg
 
 
 @pytest.mark.parametrize("env,kw,host_expected", [

@@ -265,7 +265,7 @@ def test_gaf_hash_of_the_bench_check_equals_the_oracles():
     _, _, summary = oracle.align_summary(reads, 2, gaf_hash=True)
     lines = np.where(w["chained_better"] > 0, 1, np.diff(w["read_long_off"]))
     hashes = gaf_read_hashes(text, lines)
-    assert summary.shape[1] == 13 and np.array_equal(hashes, summary[:, 12]) and len(set(hashes.tolist())) > len(reads) // 2
+    assert summary.shape[1] == 15 and np.array_equal(hashes, summary[:, 14]) and len(set(hashes.tolist())) > len(reads) // 2
     # names do not enter: other read ids, same hashes
     renamed = b"\n".join(b"someothername" + l[l.index(b"\t"):] for l in text.split(b"\n") if l) + b"\n"
     assert np.array_equal(gaf_read_hashes(renamed, lines), hashes)
