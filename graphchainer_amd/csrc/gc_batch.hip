@@ -340,7 +340,7 @@ struct BatchRun {
 			// (10k reads): 1 group 367 ms/step, 2 groups 517, 4 groups 477, 8 groups 607 - the groups' big rounds coincide and
 			// their tails too, so nothing overlaps usefully and the kernels slow each other down. Default: one group.
 			nGroups = 1;
-			if (const char* env = getenv("GC_LONG_GROUPS")) nGroups = (uint32_t)std::max(1, std::min(16, atoi(env)));
+			if (const char* env = expEnv("GC_LONG_GROUPS")) nGroups = (uint32_t)std::max(1, std::min(16, atoi(env)));   // (experiments build only)
 			if (n < 64ull * nGroups) nGroups = 1;
 			while (st->groupStreams.size() < nGroups) {
 				hipStream_t q = nullptr;
@@ -416,6 +416,7 @@ struct BatchRun {
 		return true;
 	}
 
+#ifdef GC_EXPERIMENTS
 	// The round loop without a host round trip per round (r4; an experiment, GC_LONG_ROUNDS=1 - see roundsOnDevice): per round ONE kernel between two extension launches - k_long_round: the previous round's merge,
 	// this round's select, the execution order, the work count to the device and to pinned host memory - and the extension kernel takes its item count from the device
 	// (its grid is sized by a bound: 2 items per read, which the device-side speculation rule respects). Rounds are queued several at a time; the host looks at the published
@@ -496,11 +497,15 @@ struct BatchRun {
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] whole-read rounds (queued ahead): %.1f ms in all, %.1f ms waiting at the chunks' ends, %d rounds with work, %d queued\n", (nowUs() - dbgT0) / 1e3, dbgWaitUs / 1e3, done, queued);
 	}
 
+#endif
+
 	void runLongGroup(uint32_t g)   // the round loop of one read group: select -> extend -> merge until no read has a seed left to extend (see gc_kernels.hip, "K3-long in rounds")
 	{
 		const uint64_t r0 = groupBegin[g], nG = groupBegin[g + 1] - r0;
 		if (nG == 0) return;
+#ifdef GC_EXPERIMENTS
 		if (roundsOnDevice(g)) { runLongGroupOnDevice(g); return; }
+#endif
 		unsigned long long* dLongScratch = nullptr;   // (set when the token is taken - before the first extension launch; round token: under the lock, every round)
 		hipStream_t q = st->groupStreams[g];
 		hipEvent_t* ring = st->groupEvents.data() + (size_t)2 * LONG_EVENT_RING * g;
@@ -520,7 +525,7 @@ struct BatchRun {
 		// that kernel has finished - so that the small kernels and the host round trip between two rounds of one batch run beside another batch's extension kernel
 		int deviceNow = 0;
 		HIP_CHECK(hipGetDevice(&deviceNow));
-		const bool roundToken = getenv("GC_LONG_TOKEN") && atoi(getenv("GC_LONG_TOKEN")) == 2;   // (read per batch: the tests switch modes inside one process)
+		const bool roundToken = expEnv("GC_LONG_TOKEN") && atoi(expEnv("GC_LONG_TOKEN")) == 2;   // (experiments build only; read per batch: the tests switch modes inside one process)
 		std::unique_lock<std::mutex> roundLock(g_longRoundToken[deviceNow & 15], std::defer_lock);
 		hipEvent_t roundExtendDone = nullptr;
 
@@ -539,12 +544,14 @@ struct BatchRun {
 			// and the trace budget (at most nG / 2... reads x candidates <= 4 nG). Why: rounds 3-5 of cfg2 hold fewer work items than the chip has wave slots and cost one
 			// extension's latency (~17 ms) each - 98 % of the reads extend a second seed and 81 % a third, so asking for two seeds per read from round 0 on
 			// merges rounds at a few per cent of wasted extensions (k_long_merge drops a candidate that an alignment accepted before it explains).
+#ifdef GC_EXPERIMENTS
 			{
 				static const std::vector<int> plan = []() { std::vector<int> v; const char* e = getenv("GC_LONG_PLAN"); std::string t = e ? e : GC_LONG_PLAN_DEFAULT; size_t at = 0; while (at < t.size()) { v.push_back(std::max(1, std::min(8, atoi(t.c_str() + at)))); size_t c = t.find(',', at); if (c == std::string::npos) break; at = c + 1; } if (v.empty()) v.push_back(1); return v; }();
 				const uint32_t floorCand = (uint32_t)plan[std::min<size_t>((size_t)round, plan.size() - 1)];
 				const uint64_t active = round == 0 ? nG : std::max<uint64_t>(1, std::min<uint64_t>(nG, lastWork / 2));
 				if (!getenv("GC_LONG_SPECULATE")) maxCand = (uint32_t)std::min<uint64_t>(std::max(maxCand, floorCand), std::max<uint64_t>(1, (4 * nG) / active));
 			}
+#endif
 			launchLongSelect(q, G->dev, dLongJobs + r0, (uint32_t)nG, dLongSeeds, R->totalBases, (uint32_t)P->min_cluster_size, maxCand, dLongState + r0, dLongAlns, dLongCells, dLongWork + w0, dWorkLen + w0, dCandSeed + w0, cursor, capacity);
 			{
 				// execution order: longest extensions first, so the round's tail is made of short ones (GC_LONG_ORDER=0: as emitted)
@@ -572,18 +579,12 @@ struct BatchRun {
 			if (timedRounds >= LONG_EVENT_RING) collect(timedRounds % LONG_EVENT_RING);
 			hipEvent_t ev0 = ring[2 * (timedRounds % LONG_EVENT_RING)], ev1 = ring[2 * (timedRounds % LONG_EVENT_RING) + 1];
 			HIP_CHECK(hipEventRecord(ev0, q));
-			// GC_LONG_SM=1 (experiment, off by default: 6x slower as measured): one extension per LANE as per-lane state machines (k_long_extend_sm, gc_sm.hip);
-			// what outgrows that layout's tables (EXT_SM_DECLINED: more than 32 nodes in a slice, 16 pending, no room for the reserved trace)
-			// is listed and rerun one extension per wave, like the register-table overflows below
+			// The experiments build (`make -C graphchainer_amd/csrc experiments`) can replace the extension step by one of the two measured-and-rejected layouts:
+			// GC_LONG_SM=1 (one extension per LANE as per-lane state machines, k_long_extend_sm in gc_sm.hip, 6x slower; what outgrows its tables -
+			// EXT_SM_DECLINED - is listed and rerun one extension per wave) or GC_LONG_LANE=1 (one extension per LANE with the plain-layout core and a per-lane HBM slab, 6.9x slower)
 #ifdef GC_EXPERIMENTS
 			const bool useSm = team == 1 && getenv("GC_LONG_SM") && atoi(getenv("GC_LONG_SM")) == 1;
-#else
-			const bool useSm = false;   // (the state-machine kernel is not part of the product library since r4: `make -C graphchainer_amd/csrc experiments` builds libgraphchainer_amd_exp.so with it)
-			if (getenv("GC_LONG_SM") && atoi(getenv("GC_LONG_SM")) == 1) throw std::runtime_error("GC_LONG_SM=1: the state-machine experiment is not in this build (make -C graphchainer_amd/csrc experiments; GC_LIBRARY=.../libgraphchainer_amd_exp.so)");
-#endif
-			// GC_LONG_LANE=1 (measurement, off by default): one extension per LANE with the plain-layout core and its band state in a per-lane HBM slab
 			const bool useLane = !useSm && team == 1 && getenv("GC_LONG_LANE") && atoi(getenv("GC_LONG_LANE")) == 1;
-#ifdef GC_EXPERIMENTS
 			if (useSm) {
 				launchLongExtendSm(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, (uint8_t*)(dLongScratch + (uint64_t)g * scratchLanes * waveWords), scratchLanes * waveWords * 8,
 					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2);
@@ -592,12 +593,13 @@ struct BatchRun {
 				const uint32_t declinedBlocks = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nWorkItems, 8192), std::max<uint64_t>(1, scratchLanes - 64));
 				launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dRetryList + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 1, declinedBlocks,
 					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, 6u, cursor + 3);
-			} else
-#endif
-			if (useLane) {
+			} else if (useLane) {
 				launchLongExtendLane(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, (uint8_t*)(dLongScratch + (uint64_t)g * scratchLanes * waveWords), scratchLanes * waveWords * 8,
 					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8);
 			} else
+#else
+			const bool useSm = false, useLane = false;
+#endif
 			launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, team, blocks,
 				dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, 0, nullptr, team == 1 ? dRetryList + w0 : nullptr, cursor + 3);
 			if (team == 1 && !useLane) {
@@ -607,7 +609,9 @@ struct BatchRun {
 				// one wave per pair of work items that looks at a status and leaves: that cost 0.5-2 ms of every round)
 				if (useSm || (uint64_t)blocks * team < nWorkItems) {   // (the list is the extension kernel's own, unless the state-machine path or persistent waves used the slot counter)
 					launchZeroWords(q, cursor + 2, useSm ? 2 : 1);   // [2] next slot, [3] length of the retry list
+#ifdef GC_EXPERIMENTS
 					if (useSm) launchLongRetryList(q, dLongWorkResults + w0, nWorkItems, EXT_LDS_CAP, dRetryList + w0, cursor + 3);
+#endif
 				}
 				uint32_t retryBlocks = std::min<uint32_t>(16, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / 2));   // (persistent waves over a list that is almost always empty)
 				launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dRetryList + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 2, retryBlocks,
@@ -827,9 +831,12 @@ struct BatchRun {
 					TokenHold token;
 					try {
 						HIP_CHECK(hipSetDevice(device));
-						const int tokenMode = getenv("GC_LONG_TOKEN") ? atoi(getenv("GC_LONG_TOKEN")) : 1;   // 0 none, 1 one pass at a time, 2 one round's extension kernel at a time
+						int tokenMode = getenv("GC_LONG_TOKEN") ? atoi(getenv("GC_LONG_TOKEN")) : 1;   // 0 none, 1 one pass at a time (2, experiments build: one round's extension kernel at a time)
+#ifndef GC_EXPERIMENTS
+						if (tokenMode != 0) tokenMode = 1;
+#endif
 						const double tTokenAsk = nowUs();
-						const bool early = getenv("GC_LONG_TOKEN_EARLY") && atoi(getenv("GC_LONG_TOKEN_EARLY")) == 1;
+						const bool early = expEnv("GC_LONG_TOKEN_EARLY") && atoi(expEnv("GC_LONG_TOKEN_EARLY")) == 1;
 						bool held = false;   // between take and drop (with or without a token to hold: GC_LONG_TOKEN=0 has none)
 						auto stampBegin = [&]() { double now = nowUs(), seen = longWallBeginUs.load(); while ((seen == 0.0 || now < seen) && !longWallBeginUs.compare_exchange_weak(seen, now)) {} };
 						auto stampEnd = [&]() { double now = nowUs(), seen = longWallEndUs.load(); while (now > seen && !longWallEndUs.compare_exchange_weak(seen, now)) {} };

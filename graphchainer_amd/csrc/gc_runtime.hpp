@@ -114,7 +114,14 @@ struct TokenHold {
 	void unlock() { if (slot >= 0) { tokens->release(slot); slot = -1; } }
 	~TokenHold() { unlock(); }
 };
-inline int longTokenCount() { const char* e = getenv("GC_LONG_TOKENS"); return e ? std::max(1, std::min(LONG_TOKENS_MAX, atoi(e))) : 1; }   // (read per use: the tests switch inside one process)
+// Switches of measured-and-rejected alternatives (two tokens, a token per round, read groups, the lane-per-extension kernel, ...) exist only in the experiments build
+// (`make -C graphchainer_amd/csrc experiments`, -DGC_EXPERIMENTS): the product library does not read them. INTEGRATION.md §7 lists the switches that remain.
+#ifdef GC_EXPERIMENTS
+inline const char* expEnv(const char* name) { return getenv(name); }
+#else
+inline const char* expEnv(const char*) { return nullptr; }
+#endif
+inline int longTokenCount() { const char* e = expEnv("GC_LONG_TOKENS"); return e ? std::max(1, std::min(LONG_TOKENS_MAX, atoi(e))) : 1; }   // (read per use: the tests switch inside one process)
 inline std::mutex g_longRoundToken[16];   // GC_LONG_TOKEN=2 (experiment): the token handed over per round
 // The pass's extension scratch (up to 48 GB: one region per resident wave) is only touched while the token is held, so the gc_streams of a device share ONE
 // (r3: 85 -> 37 GB per stream for 10 k x 10 kb batches, which is what lets five batches be in flight on a 288 GB device instead of three). It belongs to the
@@ -807,7 +814,7 @@ inline uint32_t editDistanceUnit(uint32_t k, uint32_t readLen)
 // whatever shares the device with it runs on what is left.
 inline void createStream(hipStream_t* q, int role)
 {
-	static const int mode = []() { const char* e = getenv("GC_STREAM_PRIORITY"); return !e ? 0 : !strcmp(e, "frag") ? 1 : !strcmp(e, "long") ? 2 : 0; }();
+	static const int mode = []() { const char* e = expEnv("GC_STREAM_PRIORITY"); return !e ? 0 : !strcmp(e, "frag") ? 1 : !strcmp(e, "long") ? 2 : 0; }();
 	int least = 0, greatest = 0;
 	if (mode && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
 		const bool high = (mode == 1 && role == 0) || (mode == 2 && role == 1);

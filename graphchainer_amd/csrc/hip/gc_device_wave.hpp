@@ -21,41 +21,40 @@
 namespace gcdev {
 
 
-// Experiment (r2): the column's match mask fetched with two v_readlane from lanes 0-3 instead of eight scalar selects: 10 scalar
-// instructions fewer per column (66 -> 56), yet the kernel measured 239 ms against 231-235 (two more VGPRs, longer dependent
-// chain through the vector pipe). Off.
-#ifndef GC_EQ_IN_LANES
-#define GC_EQ_IN_LANES 0
+// The scalar-lean forms of the one-extension-per-wave instantiation's hot loops (r2 / r3): each GC_LEAN_* names one rewrite whose plain twin stays in the source as
+// the readable statement of the same step, as the code of the multi-lane instantiations (the register-table retry runs LANES = 2) and of the host compile. The product build
+// always takes the lean forms; only the experiments build (-DGC_EXPERIMENTS) may switch one off for an A/B (`make variant FLAGS="-DGC_EXPERIMENTS -DGC_LEAN_WALK=0"`).
+#ifndef GC_EXPERIMENTS
+#if defined(GC_LEAN_COLUMNS) || defined(GC_LEAN_WALK) || defined(GC_LEAN_PUSH) || defined(GC_LEAN_TABLES) || defined(GC_LEAN_COLMIN) || defined(GC_LEAN_MERGE) || defined(GC_LEAN_POP) || defined(GC_LEAN_KINDS) || defined(GC_LEAN_DIAGRUN)
+#error "GC_LEAN_* can only be set in the experiments build (-DGC_EXPERIMENTS)"
+#endif
 #endif
 #ifndef GC_LEAN_COLUMNS
-#define GC_LEAN_COLUMNS 1
+#define GC_LEAN_COLUMNS 1   // column loop: match mask by s_cselect_b64, carries by s_bfe_u64, the column's consumers in one vector epilogue per tile
 #endif
 #ifndef GC_LEAN_WALK
-#define GC_LEAN_WALK 1
+#define GC_LEAN_WALK 1      // backtrace walk on bit masks made by one vector pass per tile
 #endif
 #ifndef GC_LEAN_PUSH
-#define GC_LEAN_PUSH 1
+#define GC_LEAN_PUSH 1      // trace cells through v_writelane
 #endif
 #ifndef GC_LEAN_TABLES
-#define GC_LEAN_TABLES 1
+#define GC_LEAN_TABLES 1    // band-table entries through v_writelane
 #endif
 #ifndef GC_LEAN_COLMIN
-#define GC_LEAN_COLMIN 1
+#define GC_LEAN_COLMIN 1    // minimum of a tile's end column with lane = row
 #endif
 #ifndef GC_LEAN_MERGE
-#define GC_LEAN_MERGE 1
+#define GC_LEAN_MERGE 1     // mergeTwoSlices with lane = row
 #endif
 #ifndef GC_LEAN_POP
-#define GC_LEAN_POP 1   // the pop of the pending queue as a wave minimum over the lanes' component numbers (r3)
+#define GC_LEAN_POP 1       // the pop of the pending queue as a wave minimum over the lanes' component numbers (r3)
 #endif
 #ifndef GC_LEAN_KINDS
-#define GC_LEAN_KINDS 1   // three copies of the column loop: general / node in the previous slice with nothing forced / node new in this slice (constant carries)
+#define GC_LEAN_KINDS 1     // three copies of the column loop: general / node in the previous slice with nothing forced / node new in this slice (constant carries)
 #endif
 #ifndef GC_LEAN_UNROLL
 #define GC_LEAN_UNROLL 1
-#endif
-#ifndef GC_LEAN_EDGES
-#define GC_LEAN_EDGES 0   // r4, measured and off: a tile's first two out-edges fetched together before they are pushed - 162-166 ms per batch against 152-155 (seven more spilled VGPRs under the 64-register cap)
 #endif
 #ifndef GC_LEAN_DIAGRUN
 #define GC_LEAN_DIAGRUN 1   // the backtrace's diagonal runs inside a tile resolved by one ballot and emitted by the vector pipe
@@ -225,15 +224,8 @@ struct LaneLdsT {   // one lane's view
 	// backtrace columns (alias the LDS table words, or registers across the lanes): column c: VP, VN, score
 	mutable uint32_t cr[5];
 	mutable uint32_t idCur, idPrev;
-	// REGCOLS: the slice's four match masks (A, C, G, T) in lanes 0-3
-	static constexpr bool eqInLanes = REGCOLS;
-	mutable uint32_t eqLo = 0, eqHi = 0;
-	__device__ __forceinline__ void setEq(uint64_t a, uint64_t c, uint64_t g, uint64_t t) const
-	{
-		const uint32_t l = threadIdx.x;
-		const uint64_t v = l == 0 ? a : l == 1 ? c : l == 2 ? g : t;
-		eqLo = (uint32_t)v; eqHi = (uint32_t)(v >> 32);
-	}   // REGCOLS: node ids of the items of the backtrace's current / previous slice, item i in lane i
+	static constexpr bool eqInLanes = REGCOLS;   // (the name is historical: "this is the one-extension-per-wave instantiation", whose lean column loop and walk masks apply)
+	// REGCOLS: node ids of the items of the backtrace's current / previous slice, item i in lane i (idCur / idPrev above)
 	// REGCOLS backtrace: per column c >= 1 of the recomputed tile (lane c), for all 64 rows at once: "the diagonal predecessor fits" and
 	// "the left predecessor fits" (see setWalkMasks); valid only after a recompute that went through the lean column loop
 	mutable uint32_t wm[4] = { 0, 0, 0, 0 };
@@ -335,31 +327,9 @@ __device__ __forceinline__ WSlice loadSlice(const WaveScratch& ws, uint32_t s)
 	x.j = (int32_t)(e >> 32); x.flags = (uint32_t)e;
 	return x;
 }
-#ifndef GC_LEAN_ITEMSTORE
-#define GC_LEAN_ITEMSTORE 0   // r4, measured and off: the 64-byte item record as ONE store from lanes 0-7 (sixteen v_writelane) instead of eight 8-byte stores from lane 0 - 192-202 ms per batch against 152-155: 65 spilled VGPRs instead of 35
-#endif
 __device__ __forceinline__ void storeItem(const WaveScratch& ws, uint32_t i, const NodeItem& it)
 {
 	uint64_t b = ws.itemBase(i);
-#if GC_LEAN_ITEMSTORE && defined(__HIP_DEVICE_COMPILE__)
-	if (ws.allLanes && ws.lanes == 1) {
-		// the eight words are uniform (scalar registers): word l goes to lane l of a register pair with v_writelane (the lane select is an inline constant), lanes 0-7 store 8 bytes each
-		const uint64_t w0 = gcUniform64(it.sVP), w1 = gcUniform64(it.sVN), w2 = gcUniform64(it.eVP), w3 = gcUniform64(it.eVN), w4 = gcUniform64(it.HP), w5 = gcUniform64(it.HN);
-		const uint64_t w6 = gcUniform64(((unsigned long long)(uint32_t)it.sScore << 32) | (uint32_t)it.eScore), w7 = gcUniform64(((unsigned long long)(uint32_t)it.minScore << 32) | it.node);
-		uint32_t lo = (uint32_t)w0, hi = (uint32_t)(w0 >> 32);
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-		asm("v_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %1, %3, 1\n\tv_writelane_b32 %0, %4, 2\n\tv_writelane_b32 %1, %5, 2\n\tv_writelane_b32 %0, %6, 3\n\tv_writelane_b32 %1, %7, 3\n\t"
-			"v_writelane_b32 %0, %8, 4\n\tv_writelane_b32 %1, %9, 4\n\tv_writelane_b32 %0, %10, 5\n\tv_writelane_b32 %1, %11, 5\n\tv_writelane_b32 %0, %12, 6\n\tv_writelane_b32 %1, %13, 6\n\t"
-			"v_writelane_b32 %0, %14, 7\n\tv_writelane_b32 %1, %15, 7"
-			: "+v"(lo), "+v"(hi)
-			: "s"((uint32_t)w1), "s"((uint32_t)(w1 >> 32)), "s"((uint32_t)w2), "s"((uint32_t)(w2 >> 32)), "s"((uint32_t)w3), "s"((uint32_t)(w3 >> 32)), "s"((uint32_t)w4), "s"((uint32_t)(w4 >> 32)),
-			  "s"((uint32_t)w5), "s"((uint32_t)(w5 >> 32)), "s"((uint32_t)w6), "s"((uint32_t)(w6 >> 32)), "s"((uint32_t)w7), "s"((uint32_t)(w7 >> 32)));
-#pragma clang diagnostic pop
-		if (threadIdx.x < 8) ws.base[b + threadIdx.x] = (unsigned long long)lo | ((unsigned long long)hi << 32);
-		return;
-	}
-#endif
 	if (!ws.storer()) return;
 	ws.word(b) = it.sVP; ws.word(b + 1) = it.sVN; ws.word(b + 2) = it.eVP; ws.word(b + 3) = it.eVN; ws.word(b + 4) = it.HP; ws.word(b + 5) = it.HN;
 	ws.word(b + 6) = ((unsigned long long)(uint32_t)it.sScore << 32) | (uint32_t)it.eScore;
@@ -584,14 +554,6 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 	uint64_t HP = 0, HN = 0;
 	for (int pos = 1; pos < nodeLength; pos++) {
 		uint64_t Eq;
-#if GC_EQ_IN_LANES
-		// one extension per wave: the four match masks sit in lanes 0-3 of a register pair and the column's mask is two v_readlane with
-		// the base code as lane index (vector pipe, idle here) instead of a chain of eight scalar selects
-		if (LANE_TABLES::eqInLanes && !seq.ambiguous) {
-			const uint32_t code = (uint32_t)((pos < 32 ? seq.w0 : seq.w1) >> ((pos & 31) * 2)) & 3u;
-			Eq = (uint64_t)(uint32_t)GC_READLANE(tables.eqLo, code) | ((uint64_t)(uint32_t)GC_READLANE(tables.eqHi, code) << 32);
-		} else
-#endif
 		Eq = eqOfColumn(eq, seq, pos);
 		Eq &= forceEq;
 		uint64_t hp, hn;
@@ -656,15 +618,13 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 	for (int slice = 0; slice < numSlices; slice++) {
 		int j = prevJ + 64;
 		eqVectorBits(eqSrc, len, j, eq);
-		if (REGCOLS) L.setEq(eq.a, eq.c, eq.g, eq.t);
 		int32_t previousQuitScore = prevMinScore + prevBandwidth;
 		int bandwidth = bandwidthCfg;
 		int flatRows = (j + 64 > len) ? (len - j) : 0;
 		const int cb = REGCOLS ? 1 : (buf ^ 1);   // table buffer `cb` = current slice
 		auto prevFind = [&](uint32_t node) __attribute__((always_inline)) -> int { return L.find((uint32_t)(REGCOLS ? 0 : buf), nPrev, node); };
 		uint32_t nPending = 0;
-		// (preSeq / preComp: the target's sequence words and topological rank when the caller has already fetched them - the tile's out-edges are loaded together, see below)
-		auto pushEdge = [&](uint32_t target, WS incoming, bool skipFirst, const NodeSeq* preSeq = nullptr, uint32_t preComp = 0) __attribute__((always_inline)) {
+		auto pushEdge = [&](uint32_t target, WS incoming, bool skipFirst) __attribute__((always_inline)) {
 			int found = L.find(2u, nPending, target);
 			uint32_t slot = found >= 0 ? (uint32_t)found : nPending;
 			WS add = incoming;
@@ -679,7 +639,7 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 					else if (prevStart > before) { hinP = 1; hinN = 0; }
 					else { hinP = 0; hinN = 0; }
 				} else { hinP = 1; hinN = 0; }
-				NodeSeq nseq = preSeq ? *preSeq : loadNodeSeq(g, target);
+				NodeSeq nseq = loadNodeSeq(g, target);
 				uint64_t hp, hn;
 #if GC_LEAN_COLUMNS && defined(__HIP_DEVICE_COMPILE__)
 				uint64_t eqFirst;
@@ -698,7 +658,7 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 			}
 			if (slot == nPending) {
 				if (nPending >= L.maxEntries()) { status = EXT_LDS_CAP; return; }
-				L.qSet(slot, target, preSeq ? preComp : g.componentNumber[target], add);
+				L.qSet(slot, target, g.componentNumber[target], add);
 				nPending++;
 			} else {
 #if GC_LEAN_MERGE && defined(__HIP_DEVICE_COMPILE__)
@@ -792,28 +752,10 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 			if (newEndMin < prevMinScore) return EXT_ASSERT;
 			if (newEndMin <= currentMin + bandwidth) {
 				GC_MARK(3);   // item store + bookkeeping
-#if GC_LEAN_EDGES
-				{
-					// the first two out-edges' targets, sequence words and ranks are fetched TOGETHER before either edge is pushed (r4): a bubble's node has two
-					// successors, and edge by edge their loads - adjacency entry, then the target's sequence and rank - were two dependent chains one after the other
-					const uint32_t e0 = g.outOff[pnode], e1 = g.outOff[pnode + 1];
-					const uint32_t nE = e1 - e0;
-					const uint32_t tA = nE > 0 ? g.outAdj[e0] : pnode, tB = nE > 1 ? g.outAdj[e0 + 1] : pnode;
-					const NodeSeq sA = loadNodeSeq(g, tA), sB = loadNodeSeq(g, tB);
-					const uint32_t cA = g.componentNumber[tA], cB = g.componentNumber[tB];
-					if (nE > 0) { pushEdge(tA, newEnd, false, &sA, cA); if (status != EXT_OK) return status; }
-					if (nE > 1) { pushEdge(tB, newEnd, false, &sB, cB); if (status != EXT_OK) return status; }
-					for (uint32_t e = e0 + 2; e < e1; e++) {
-						pushEdge(g.outAdj[e], newEnd, false);
-						if (status != EXT_OK) return status;
-					}
-				}
-#else
 				for (uint32_t e = g.outOff[pnode]; e < g.outOff[pnode + 1]; e++) {
 					pushEdge(g.outAdj[e], newEnd, false);
 					if (status != EXT_OK) return status;
 				}
-#endif
 				GC_MARK(4);   // out-edge pushes
 			} else GC_MARK(3);
 		}
@@ -985,7 +927,7 @@ __device__ __forceinline__ uint32_t extendSeedWave(const DGraph& g, const Correc
 		if (s >= nSlices) return EXT_ASSERT;
 		if (s != curSliceIdx || here.node != curNode) {
 			GC_MARK(10);  // walking inside a tile / corner rules
-			if (s != curSliceIdx) { cs = loadSlice(wsx, s); ps = loadSlice(wsx, s - 1); eqVectorBits(eqSrc, len, cs.j, eq); if (REGCOLS) L.setEq(eq.a, eq.c, eq.g, eq.t); fillIds(cs, idsCurBase); fillIds(ps, idsPrevBase); }
+			if (s != curSliceIdx) { cs = loadSlice(wsx, s); ps = loadSlice(wsx, s - 1); eqVectorBits(eqSrc, len, cs.j, eq); fillIds(cs, idsCurBase); fillIds(ps, idsPrevBase); }
 			GC_MARK(6);   // backtrace: slice change
 			curSliceIdx = s;
 			curNode = here.node;

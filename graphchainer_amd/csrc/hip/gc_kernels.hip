@@ -1134,6 +1134,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LANES =
 	}
 }
 
+#ifdef GC_EXPERIMENTS   // (`make -C graphchainer_amd/csrc experiments`: measured and rejected alternatives are not part of the product library)
 // The measurement VERDICT r3 asked for (GC_LONG_LANE=1, off by default): the same rounds, but every LANE takes one work item and runs the
 // plain-layout core (extendSeedT, gc_device.hpp: the core of k_extend and k_long_pass) with its band state in a per-lane HBM slab - no LDS tables, no
 // state machine, <= 128 VGPRs (4 waves per SIMD). Work items arrive longest first (k_long_order), so a wave's 64 extensions have about the same number of
@@ -1180,6 +1181,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 		atomicAdd(&counters[5], cnt.backtraceTiles);
 	}
 }
+
+#endif
 
 // One wave per read: the decisions are taken redundantly by all lanes (uniform control flow, lane 0 does the single
 // writes), the trace -> cell conversion - the bulk of the work, ~1.5 cells per read base - runs 64 cells at a time.
@@ -1310,6 +1313,7 @@ __global__ void __launch_bounds__(GC_ORDER_THREADS) k_long_order(const uint32_t*
 	for (uint32_t i = tid; i < n; i += T) { uint32_t b = workLen[i] >> shift; order[atomicAdd(&start[1023 - (b < 1023 ? b : 1023)], 1u)] = i; }
 }
 
+#ifdef GC_EXPERIMENTS
 // One launch per round instead of five (r4): the previous round's merge, this round's select, the execution order and the hand-over of the round's work count.
 // One wave per read runs the read's merge and then its select (both only touch that read's state); every wave then takes a ticket, and the wave that takes the
 // last one - all work items of the round are in place by then - sorts them into execution order (longest first, 64 lanes over an LDS histogram of 1024 length
@@ -1381,6 +1385,8 @@ __global__ void __launch_bounds__(64) k_long_round(DGraph g, const LongJob* __re
 		__threadfence_system();
 	}
 }
+
+#endif
 
 // copies a few cursor words into pinned host memory through the compute queue (a copy-engine transfer would queue behind bulk uploads)
 __global__ void k_publish(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst, uint32_t nWords)
@@ -1515,8 +1521,12 @@ void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTabl
 	const bool persistent = (nWorkOnDevice && !gridCoversCount) || (uint64_t)blocks * lanes < nWork;
 	// GC_LONG_WAVES_PER_SIMD=w (experiment): an unused dynamic LDS allocation per wave caps the kernel at w waves per SIMD, leaving wave slots
 	// and registers to the fragment pipeline's kernels that share the device with it
+#ifdef GC_EXPERIMENTS
 	static const uint32_t ldsPad = []() { const char* e = getenv("GC_LONG_WAVES_PER_SIMD"); int w = e ? atoi(e) : 0; return (w >= 1 && w <= 7) ? (uint32_t)((160u * 1024u / (4u * (uint32_t)w)) & ~255u) : 0u; }();
 	const uint32_t pad = lanes == 1 ? ldsPad : 0;
+#else
+	const uint32_t pad = 0;
+#endif
 #define GC_LAUNCH_TEAM(N) do { if (persistent) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, true>), dim3(blocks), dim3(64), pad, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot, retryStatus, nWorkOnDevice, capListOut, capCountOut); \
 	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_long_extend<N, false>), dim3(blocks), dim3(64), pad, stream, g, ct, masks, cfg, work, order, nWork, scratch, words, tracePool, traceCursor, traceCapacity, results, counters, nextSlot, retryStatus, nWorkOnDevice, capListOut, capCountOut); } while (0)
 	switch (lanes) {
@@ -1530,6 +1540,7 @@ void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTabl
 	}
 #undef GC_LAUNCH_TEAM
 }
+#ifdef GC_EXPERIMENTS
 void launchLongExtendLane(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
 	uint8_t* scratch, uint64_t scratchBytes, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters)
 {
@@ -1542,6 +1553,7 @@ void launchLongExtendLane(hipStream_t stream, const DGraph& g, const Correctness
 	if (lanes == 0) return;
 	hipLaunchKernelGGL(k_long_extend_lane, dim3((uint32_t)(lanes / 64)), dim3(64), 0, stream, g, ct, masks, cfg, work, order, nWork, scratch, slab, tracePool, traceCursor, traceCapacity, results, counters);
 }
+#endif
 // Work items of the fragment pass, built where they are used (src/GraphAligner.h:499-511 per seed of a fragment window): the host sorts each
 // read's seeds and cuts the windows (order-critical, host/gc_glue.cpp) and hands over 16 B per fragment and per seed; one thread per fragment
 // expands its seed window into the per-slot records - the seed in fragment order and the two extensions (backward: reverse complement of the
@@ -1584,6 +1596,7 @@ void launchBuildFragmentWork(hipStream_t stream, const DGraph& g, const Fragment
 {
 	if (nFrags) hipLaunchKernelGGL(k_build_fragment_work, dim3((nFrags + 255) / 256), dim3(256), 0, stream, g, frags, fragFirstSeed, nFrags, readSeeds, readOffsets, totalBases, splitLen, fragSeeds, work, results);
 }
+#ifdef GC_EXPERIMENTS   // (only the state-machine experiment lists its declined items this way; the product's extension kernel writes its own retry list)
 // work items of a round whose extension ended with `status` (EXT_LDS_CAP: the band outgrew the register tables), as a list for the retry launch:
 // almost always empty, so the retry costs one small kernel and a handful of waves instead of one wave per pair of work items
 __global__ void __launch_bounds__(256) k_long_retry_list(const LongWorkResult* __restrict__ results, uint32_t nWork, uint32_t status, uint32_t* __restrict__ list, unsigned long long* __restrict__ listCount)
@@ -1595,11 +1608,13 @@ void launchLongRetryList(hipStream_t stream, const LongWorkResult* results, uint
 {
 	if (nWork) hipLaunchKernelGGL(k_long_retry_list, dim3((nWork + 255) / 256), dim3(256), 0, stream, results, nWork, status, list, listCount);
 }
+#endif
 void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, const uint32_t* candSeed, const LongWorkResult* results,
 	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity)
 {
 	if (nReads) hipLaunchKernelGGL(k_long_merge, dim3(nReads), dim3(64), 0, stream, g, jobs, nReads, seeds, candSeed, results, tracePool, maxAlignments, state, alns, cellPool, cellCursor, cellCapacity);
 }
+#ifdef GC_EXPERIMENTS
 void launchLongRound(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, uint32_t minClusterSize, uint32_t round, uint32_t forceCand, uint32_t gridLimit,
 	LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity, uint32_t maxAlignments, LongWork* work, uint32_t* workLen, uint32_t* candSeed,
 	const LongWorkResult* results, const unsigned long long* tracePool, unsigned long long* cursorSets, unsigned long long* roundInfo, unsigned long long* ticket, uint32_t* order, uint32_t maxLen, uint32_t orderMode,
@@ -1611,6 +1626,7 @@ void launchLongRound(hipStream_t stream, const DGraph& g, const LongJob* jobs, u
 	hipLaunchKernelGGL(k_long_round, dim3(nReads), dim3(64), 0, stream, g, jobs, nReads, seeds, minClusterSize, round, forceCand, gridLimit, state, alns, cellPool, cellCursor, cellCapacity, maxAlignments,
 		work, workLen, candSeed, results, tracePool, cursorSets, roundInfo, ticket, order, shift, orderMode, (volatile unsigned long long*)hostInfo, workCapacity);
 }
+#endif
 void launchLongOrder(hipStream_t stream, const uint32_t* workLen, const unsigned long long* workCount, uint32_t* order, uint32_t maxLen, uint32_t mode)
 {
 	uint32_t shift = 0;

@@ -199,6 +199,7 @@ void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTabl
 	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters,
 	unsigned long long* nextSlot, uint32_t retryStatus = 0, const unsigned long long* nWorkOnDevice = nullptr, uint32_t* capListOut = nullptr, unsigned long long* capCountOut = nullptr,
 	bool gridCoversCount = false);   // nWorkOnDevice: `order` is a list whose length only the device knows (then nWork is its upper bound; gridCoversCount: blocks x lanes >= that bound, no fetch loop needed)
+#ifdef GC_EXPERIMENTS   // measured and rejected alternatives of the whole-read pass: only in `make experiments`
 // the whole inter-round step in one launch: merge of the previous round + select + execution order + work count to device and host (k_long_round)
 void launchLongRound(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, uint32_t minClusterSize, uint32_t round, uint32_t forceCand, uint32_t gridLimit,
 	LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity, uint32_t maxAlignments, LongWork* work, uint32_t* workLen, uint32_t* candSeed,
@@ -212,6 +213,7 @@ uint64_t longSmSlabBytes(const ExtendConfig& cfg);
 void launchLongExtendSm(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
 	uint8_t* scratch, uint64_t scratchBytes, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters, unsigned long long* nextSlot);
 void launchLongRetryList(hipStream_t stream, const LongWorkResult* results, uint32_t nWork, uint32_t status, uint32_t* list, unsigned long long* listCount);   // retryStatus != 0: only work items whose result has that status (e.g. EXT_LDS_CAP) are run
+#endif
 void launchLongMerge(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, const uint32_t* candSeed, const LongWorkResult* results,
 	const unsigned long long* tracePool, uint32_t maxAlignments, LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity);
 // ---- path sequences + NW edit distances (gc_editdist.hip)

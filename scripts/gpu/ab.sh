@@ -9,7 +9,8 @@ for r in $(seq 1 $rounds); do
   for v in "$@"; do
     lib=$GRAFT_REPO_ROOT/graphchainer_amd/libgraphchainer_amd_$v.so
     if [ "$v" = prod ]; then lib=$GRAFT_REPO_ROOT/graphchainer_amd/libgraphchainer_amd.so; fi
-    GC_LIBRARY=$lib timeout 600 python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 5 --warmup 2 $AB_BENCH_ARGS > $out/${v}_$r.json 2> $out/${v}_$r.err
+    envvar="AB_ENV_$v"                       # AB_ENV_<variant>="K=V K=V": environment switches of that variant only
+    env ${!envvar} GC_LIBRARY=$lib timeout 600 python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 5 --warmup 2 $AB_BENCH_ARGS > $out/${v}_$r.json 2> $out/${v}_$r.err
     python3 - $out/${v}_$r.json $v <<'PY'
 import json, sys
 try:

@@ -212,7 +212,7 @@ def test_whole_read_assertion_drops_the_read(gca, tmp_path, monkeypatch):
     assert got["chained_better"][3] == 0 and got["chain_edit_distance"][3] == -1 and got["long_edit_distance"][3] == -1
 
 
-@pytest.mark.parametrize("env", [{"GC_LONG_GROUPS": "2"}, {"GC_LONG_TEAM": "8"}, {"GC_LONG_TEAM": "64", "GC_LONG_ORDER": "0"}, {"GC_LONG_MAX_BLOCKS": "7"}, {"GC_LONG_MAX_BLOCKS": "3", "GC_LONG_TEAM": "4"}, {"GC_LONG_REG_CAP": "3"}, {"GC_LONG_REG_CAP": "6", "GC_LONG_MAX_BLOCKS": "5"}])
+@pytest.mark.parametrize("env", [{"GC_LONG_TEAM": "8"}, {"GC_LONG_TEAM": "64", "GC_LONG_ORDER": "0"}, {"GC_LONG_MAX_BLOCKS": "7"}, {"GC_LONG_MAX_BLOCKS": "3", "GC_LONG_TEAM": "4"}, {"GC_LONG_REG_CAP": "3"}, {"GC_LONG_REG_CAP": "6", "GC_LONG_MAX_BLOCKS": "5"}])
 def test_whole_read_pass_launch_shapes(gca, tmp_path, monkeypatch, env):
     """Launch-shape knobs of the whole-read pass (concurrent read groups, lanes per wave, execution order, persistent waves, register-table cap -> LDS-table retry) never change results."""
     from graphchainer_amd.synth import SynthGraph
@@ -1055,18 +1055,16 @@ def _normalise(out, node_length):
     return got
 
 
-@pytest.mark.parametrize("token", ["0", "1", "2", "two"])
+@pytest.mark.parametrize("token", ["0", "1"])
 def test_batches_in_flight_equal_serial_and_oracle(gca, tmp_path, monkeypatch, token):
     """The mode bench.py times: several gc_align_batch calls in flight on ONE device, each on its own gc_stream and host thread
     (run_queue with workers > 1, the reference's -t workers over one queue, src/Aligner.cpp:1267-1270), whole-read pass on, with the
-    three settings of the per-device whole-read token (none / per pass / per round; r4 "two": two tokens, each with a scratch of its own - GC_LONG_TOKENS=2). Four different read sets go through three
+    two settings of the per-device whole-read token (none / per pass; the per-round token and the two-token variant live in the experiments build since r5). Four different read sets go through three
     Aligners concurrently, twice each; every result array must equal the oracle's AND the same Aligner's serial answer."""
     from graphchainer_amd.synth import SynthGraph
     from graphchainer_amd.workqueue import ReadQueue, run_queue
     from oracle import Oracle
-    monkeypatch.setenv("GC_LONG_TOKEN", "1" if token == "two" else token)
-    if token == "two":
-        monkeypatch.setenv("GC_LONG_TOKENS", "2")
+    monkeypatch.setenv("GC_LONG_TOKEN", token)
     sg = SynthGraph(300_000, seed=17, repeats=3, repeat_len=1500)
     gfa = str(tmp_path / "g.gfa")
     sg.write_gfa(gfa)
