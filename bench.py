@@ -66,6 +66,9 @@ def parse_args():
                          "(k_edit_path, chained traces, the winners' output), with the oracle's summary of the first 1 000 for the parity check; 0 skips it")
     ap.add_argument("--repeats-leg-steps", type=int, default=int(os.environ.get("GC_BENCH_REPEATS_STEPS", 3)),
                     help="after that: this many steps on a second graph with pasted repeats (several seeds per fragment window), a quarter of the backbone; 0 skips it")
+    ap.add_argument("--setup-dir", default=os.environ.get("GC_BENCH_SETUP_DIR"),
+                    help="keep the GFA, the reads and the index cache of this workload in this directory and reuse them when a later run asks for the same workload "
+                         "(N=1; profiling runs of one gpurun call: a 960 Mbp graph costs five minutes to generate, build and save, 85 s to load)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("GC_BENCH_INFLIGHT", 5)),
                     help="batches in flight per GPU, each on its own gc_stream and host thread (like the reference's -t worker threads): one batch's seeding, fragment "
                          "pipeline, distances and assembly run beside another's whole-read pass (r3, ms per 10 k x 10 kb batch: 1 -> 204, 2 -> 189, 3 -> 173, 4 -> 165, 5 -> 157, 6 -> 159; "
@@ -184,7 +187,22 @@ def main():
     tmp = tempfile.mkdtemp(prefix="gcbench_")
     gfa = os.path.join(tmp, "graph.gfa")
     strong = args.strong and world > 1
-    if args.config == 5:
+    # --setup-dir: GFA, reads and index cache kept between runs of the same workload (one rank; nothing of a run's RESULTS is kept)
+    setup_key = {"config": args.config, "chromosomes": args.chromosomes, "backbone": args.backbone, "reads": args.reads, "read_len": args.read_len, "sv_fraction": args.sv_fraction}
+    setup_reused = False
+    if args.setup_dir and world == 1:
+        os.makedirs(args.setup_dir, exist_ok=True)
+        gfa = os.path.join(args.setup_dir, "graph.gfa")
+        try:
+            setup_reused = json.load(open(os.path.join(args.setup_dir, "key.json"))) == setup_key and os.path.exists(os.path.join(args.setup_dir, "index.gcidx"))
+        except (OSError, ValueError):
+            setup_reused = False
+    if setup_reused:
+        blob = np.load(os.path.join(args.setup_dir, "reads.npy"))
+        offs = np.load(os.path.join(args.setup_dir, "read_offsets.npy"))
+        reads = [blob[offs[i]:offs[i + 1]].tobytes() for i in range(len(offs) - 1)]
+        sg = None
+    elif args.config == 5:
         # several chromosomes in one GFA (the cross-component rule of src/AlignmentGraph.cpp:1722-1733), multi-allelic and nested sites (cover width > 2),
         # reverse-strand links, repeats; reads at PacBio-CLR-like error rates
         sg = SynthGenome(args.chromosomes, args.backbone, seed=7, multi_allelic=0.1, nested=0.1, minus_links=0.3, repeats=4, repeat_len=3000)
@@ -196,9 +214,12 @@ def main():
             sg.write_gfa(gfa)                              # only rank 0 builds from the GFA; the others load its index cache
         # weak scaling: every rank draws its own reads; strong scaling: all ranks draw the same set and the work queue divides it
         reads = sg.sample_reads(args.reads, args.read_len, seed=11 + (0 if strong else rank), sv_fraction=args.sv_fraction)
+    if args.setup_dir and world == 1 and not setup_reused:
+        np.save(os.path.join(args.setup_dir, "reads.npy"), np.frombuffer(b"".join(reads), dtype=np.uint8))
+        np.save(os.path.join(args.setup_dir, "read_offsets.npy"), np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64))
     t_gen = time.time() - t0
     # two short legs after the headline (N=1, config 2, outside `value`): reads whose chained alignment wins, and a graph with repeats
-    legs = world == 1 and args.config == 2 and long_pass and not args.no_cpu_baseline
+    legs = world == 1 and args.config == 2 and long_pass and not args.no_cpu_baseline and sg is not None
     sv_reads = rep_reads = rep_gfa = None
     if legs and args.sv_leg_steps > 0:
         sv_reads = sg.sample_reads(args.reads, args.read_len, seed=13, sv_fraction=0.2)
@@ -252,9 +273,11 @@ def main():
     # Start-up: rank 0 builds the graph, MPC index and minimizer index from the GFA and writes the index cache;
     # the other ranks load that file instead of repeating the build. Rank 0 also loads it once, to report the load time.
     cache = os.path.join(tempfile.gettempdir(), f"gcbench_{os.environ.get('MASTER_PORT', 'single')}_{os.getuid()}.gcidx")
+    if args.setup_dir and world == 1:
+        cache = os.path.join(args.setup_dir, "index.gcidx")
     t_graph = t_index = t_save = t_load = 0.0
     cache_bytes = 0
-    if rank == 0:
+    if rank == 0 and not setup_reused:
         t0 = time.time()
         graph = gca.AlignmentGraph(gfa)
         t_graph = time.time() - t0
@@ -270,7 +293,7 @@ def main():
     t0 = time.time()
     loaded_graph, loaded_seeder = gca.api.load_index_cache(cache)
     t_load = time.time() - t0
-    if rank == 0:
+    if rank == 0 and not setup_reused:
         if loaded_graph.NodeSize() != graph.NodeSize() or not np.array_equal(loaded_seeder.array("positions"), seeder.array("positions")):
             raise SystemExit("index cache does not reproduce the built index")
         loaded_seeder.close()
@@ -279,8 +302,10 @@ def main():
         graph, seeder = loaded_graph, loaded_seeder
     if dist is not None:
         dist.barrier()
-    if rank == 0:
+    if rank == 0 and not (args.setup_dir and world == 1):
         os.remove(cache)
+    if args.setup_dir and world == 1 and not setup_reused:
+        json.dump(setup_key, open(os.path.join(args.setup_dir, "key.json"), "w"))
 
     inflight = max(1, args.inflight)
     mem_free_start, mem_total = gca.device_memory()
@@ -664,7 +689,8 @@ def main():
                          "wall_seed_lookup_and_copies": round(host_us[2] / 1e3, 3), "wall_extend_to_chain_and_copies": round(host_us[3] / 1e3, 3)},
             "device_memory_gb": {"total": round(mem_total / 2**30, 1), "graph_and_index": round((mem_total - mem_free_start) / 2**30, 1), "in_use_after_timed_steps": round((mem_total - mem_free_end) / 2**30, 1)},
             "setup_s": {"generate": round(t_gen, 1), "graph_build_upload": round(t_graph, 1), "minimizer_index": round(t_index, 1),
-                        "index_cache_save": round(t_save, 1), "index_cache_load_upload": round(t_load, 1), "index_cache_bytes": cache_bytes},
+                        "index_cache_save": round(t_save, 1), "index_cache_load_upload": round(t_load, 1), "index_cache_bytes": cache_bytes or (os.path.getsize(cache) if os.path.exists(cache) else 0),
+                        "reused_from_setup_dir": setup_reused},
             "inflight_for_device_memory": memory_choice,
             "host_peak_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 2**20, 1),   # (this process: the GFA in memory, the host graph and index, the batches)
             "reads_with_chain": int(reads_with_chain / steps), "extensions_per_step": int(counters[4]),

@@ -1715,6 +1715,19 @@ struct BatchRun {
 		});
 		assembleOutput();
 		res->host_us[1] = nowUs() - tAsm;
+		if (getenv("GC_DEBUG_TIMES")) {
+			// what the stream holds on the device, largest first, and how much of the pools this batch used
+			std::vector<std::pair<size_t, const char*>> sizes;
+			size_t total = 0;
+			st->forEachDeviceBuffer([&](const char* name, size_t bytes) { if (bytes) sizes.emplace_back(bytes, name); total += bytes; });
+			std::sort(sizes.begin(), sizes.end(), [](const auto& l, const auto& r) { return l.first > r.first; });
+			std::string line;
+			for (size_t i = 0; i < sizes.size() && i < 14; i++) { char buf[96]; snprintf(buf, sizeof buf, " %s %.2f", sizes[i].second, sizes[i].first / 1073741824.0); line += buf; }
+			fprintf(stderr, "[gc mem] stream %p holds %.2f GB on the device:%s\n", (void*)st, total / 1073741824.0, line.c_str());
+			fprintf(stderr, "[gc mem] %llu reads, %llu seed occurrences, %llu fragments, %llu anchor slots (%llu extensions run); trace pool %.2f of %.2f G cells, anchor path pool %.2f of %.2f G words, whole-read cells %.2f of %.2f G\n",
+				(unsigned long long)n, (unsigned long long)nSeedsTotal, (unsigned long long)nFrags, (unsigned long long)nSlots, (unsigned long long)res->counters[4], hSmall[1] / 1e9, traceBudget / 1e9, hSmall[2] / 1e9, pathCapacity / 1e9,
+				P->long_pass ? hLongSmall[0] / 1e9 : 0.0, cellBudget / 1e9);
+		}
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc cpu] %.0f ms up to the end of the batch (the join came at %.0f)\n", processCpuMs() - cpuCall, cpuJoined - cpuCall);
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc times] batch timeline (ms from the call): whole-read pass started %.1f, joined %.1f, assembly began %.1f, done %.1f\n", (tLongWall0 - tTotal) / 1e3, (tJoined - tTotal) / 1e3, (tAsm - tTotal) / 1e3, (nowUs() - tTotal) / 1e3);
 	}

@@ -545,6 +545,28 @@ struct gc_stream {
 	DeviceBuffer longState, longWork, longWorkResults, longRoundTrace, longCandSeed, longWorkLen, longOrder, longRoundInfo;
 	PinnedBuffer hLongRoundInfo;
 	PinnedBuffer hLongSeeds, hLongJobs, hLongAlns, hLongResults, hLongSmall, hLongCells;
+	// every device allocation of the stream with its size (GC_DEBUG_TIMES: "[gc mem]" lines; the whole-read decision's and the edit-distance runs' own buffers are listed by their owners)
+	template <typename F> void forEachDeviceBuffer(F f) const
+	{
+		f("tmp", tmp.bytes); f("matches", matches.bytes); f("readMatchOff", readMatchOff.bytes); f("readMatchCount", readMatchCount.bytes); f("cursors", cursors.bytes); f("readSeeds", readSeeds.bytes);
+		f("fragFirstSeed", fragFirstSeed.bytes); f("longRetryList", longRetryList.bytes); f("extLists", extLists.bytes); f("pendingFrags", pendingFrags.bytes); f("fragNext", fragNext.bytes);
+		f("roundCounts", roundCounts.bytes); f("work", work.bytes); f("results", results.bytes); f("scratch", scratch.bytes); f("scratchRetry", scratchRetry.bytes); f("tracePool", tracePool.bytes);
+		f("frags", frags.bytes); f("fragSeeds", fragSeeds.bytes); f("anchors", anchors.bytes); f("fragStatus", fragStatus.bytes); f("fragExtended", fragExtended.bytes); f("readTies", readTies.bytes);
+		f("pathPool", pathPool.bytes); f("jobs", jobs.bytes); f("chainOut", chainOut.bytes); f("chainLen", chainLen.bytes); f("chainScore", chainScore.bytes); f("chainStatus", chainStatus.bytes);
+		f("chainScratch", chainScratch.bytes); f("counters", counters.bytes); f("edPathNodes", edPathNodes.bytes); f("edJobs", edJobs.bytes); f("edLetters", edLetters.bytes);
+		f("edLettersLen", edLettersLen.bytes); f("edPairs", edPairs.bytes); f("edOut", edOut.bytes); f("outJobs", outJobs.bytes); f("outRecs", outRecs.bytes); f("outOffsets", outOffsets.bytes);
+		f("outMapSizes", outMapSizes.bytes); f("outPathText", outPathText.bytes); f("outCigarText", outCigarText.bytes); f("outVgBytes", outVgBytes.bytes); f("outTotals", outTotals.bytes);
+		f("stitchSlotOf", stitchSlotOf.bytes); f("stitchRegions", stitchRegions.bytes); f("stitchNodes", stitchNodes.bytes); f("stitchInfo", stitchInfo.bytes); f("stitchCursor", stitchCursor.bytes);
+		f("edPathJobs", edPathJobs.bytes); f("edPathOps", edPathOps.bytes); f("edPathLen", edPathLen.bytes); f("edPathScratch", edPathScratch.bytes); f("longSeeds", longSeeds.bytes);
+		f("longJobs", longJobs.bytes); f("longAlns", longAlns.bytes); f("longResults", longResults.bytes); f("longScratch", longScratch.bytes); f("longCells", longCells.bytes);
+		f("longCursor", longCursor.bytes); f("longJobsFallback", longJobsFallback.bytes); f("longResultsFallback", longResultsFallback.bytes); f("longScratchFallback", longScratchFallback.bytes);
+		f("gluePerRead", gluePerRead.bytes); f("glueCursors", glueCursors.bytes); f("glueOut", glueOut.bytes); f("glueSeedCap", glueSeedCap.bytes); f("glueSeedOff", glueSeedOff.bytes);
+		f("glueWinCapOff", glueWinCapOff.bytes); f("glueU32[0]", glueU32[0].bytes); f("glueU32[1]", glueU32[1].bytes); f("glueU32[2]", glueU32[2].bytes); f("glueU32[3]", glueU32[3].bytes);
+		f("glueU32[4]", glueU32[4].bytes); f("glueU32[5]", glueU32[5].bytes); f("glueU32[6]", glueU32[6].bytes); f("glueU32[7]", glueU32[7].bytes); f("glueSort", glueSort.bytes);
+		f("gluePos", gluePos.bytes); f("glueWin", glueWin.bytes); f("longState", longState.bytes); f("longWork", longWork.bytes); f("longWorkResults", longWorkResults.bytes);
+		f("longRoundTrace", longRoundTrace.bytes); f("longCandSeed", longCandSeed.bytes); f("longWorkLen", longWorkLen.bytes); f("longOrder", longOrder.bytes); f("longRoundInfo", longRoundInfo.bytes);
+		for (int k = 0; k < 2; k++) { f("edLong.letters", edLong[k].letters.bytes); f("edLong.jobs+pairs+out", edLong[k].jobs.bytes + edLong[k].lettersLen.bytes + edLong[k].pairs.bytes + edLong[k].out.bytes); }
+	}
 	~gc_stream()
 	{
 		for (auto& e : ev) if (e) (void)hipEventDestroy(e);
