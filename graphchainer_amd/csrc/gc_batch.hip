@@ -85,6 +85,9 @@ struct BatchRun {
 	AnchorRec* dAnchors = nullptr;
 	uint32_t* dFragStatus = nullptr;
 	uint32_t* dFragExtended = nullptr;
+	uint64_t traceWorst = 0, pathWorst = 0;   // the pools' worst-case sizes (every slot's extensions at full length, 24 path words per slot)
+	bool poolsSized = false;
+	uint32_t poolReruns = 0;
 	uint32_t* dReadTies = nullptr;     // per read: fragment extensions whose flattenLastSliceEnd minimum was tied between nodes (k_build_anchors adds them up; gc_result::flatten_ties)
 	uint64_t pathCapacity = 0;
 	uint32_t* dPathPool = nullptr;
@@ -138,6 +141,10 @@ struct BatchRun {
 		startWholeReadPass();
 		fragmentPipeline();
 		resultsBack();
+		// r5: the trace pool and the anchor path pool are sized by what the stream's batches have used, not by every slot's worst case (a 2 000 x 50 kb batch on a 960 Mbp
+		// graph has 21 M slots: 26 GB of trace pool by worst case); a batch that needs more than its stream has seen so far runs its fragment pipeline again with the room it asked for
+		while (fragmentPoolsOverflowed()) { fragmentPipeline(); resultsBack(); }
+		res->counters[6] = poolReruns;
 		stitchAndChainDistances();
 		joinWholeReadPass();
 		chainedAlignments();
@@ -380,7 +387,9 @@ struct BatchRun {
 			// (bounded by a memory budget: 0.8 MB per lane for 10 kb reads, 2.4 MB for 50 kb reads; GC_LONG_SCRATCH_GB overrides the 48 GB)
 			uint64_t scratchBudget = P->capacity.long_scratch_bytes > 0 ? (uint64_t)P->capacity.long_scratch_bytes : (48ull << 30) / (uint64_t)longTokenCount();
 			if (const char* env = getenv("GC_LONG_SCRATCH_GB")) scratchBudget = (uint64_t)std::max(1, atoi(env)) << 30;
-			scratchLanes = std::min<uint64_t>(workCapacity + 64, std::max<uint64_t>(2048, std::min<uint64_t>(65536 + 64, scratchBudget / (waveWords * 8))));
+			// (r5: no more lanes than a round can hold without speculation - two work items per read; the late rounds' speculation stays below that, and a round that does exceed
+			// it runs persistent waves. A 2 000 x 50 kb batch reserved 48 GB for rounds of 4 000 extensions, a 10 k x 10 kb batch 48 GB for 20 000: now 20 and 27 GB)
+			scratchLanes = std::min<uint64_t>(std::min<uint64_t>(workCapacity + 64, 2 * n + 128), std::max<uint64_t>(2048, std::min<uint64_t>(65536 + 64, scratchBudget / (waveWords * 8))));
 			// one pass at a time (the default) works in the device's shared scratch; the experiments that let passes overlap keep a scratch per stream
 			longScratchWords = (uint64_t)nGroups * scratchLanes * waveWords;
 			shareLongScratch = nGroups == 1 && (getenv("GC_LONG_TOKEN") ? atoi(getenv("GC_LONG_TOKEN")) : 1) >= 1;   // (token per pass or per round: whoever holds it owns the scratch)
@@ -406,7 +415,13 @@ struct BatchRun {
 		bool overflowed = false;
 		for (uint64_t r = 0; r < n && !overflowed; r++) overflowed = hLongResults[r].status == 4;
 		if (!overflowed || cellPoolPinned) return false;   // (a pinned pool flags the reads instead: the caller asked for that much and no more)
-		const uint64_t next = st->longCellsPerBase * 3;
+		// r5: by what the pass asked for, not three times the last size (8 -> 24 cells per read base put 38 GB into a 2 000 x 50 kb batch in flight): the pool's cursor counts every
+		// request, refused ones included; a read that was refused stops asking, so the count is a lower bound - half as much again, and the loop comes back if that is still short
+		HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
+		syncStream(ls);
+		const uint64_t asked = hLongSmall[0], bases = std::max<uint64_t>(1, R->totalBases);
+		const uint64_t next = std::max<uint64_t>(st->longCellsPerBase + 2, (asked + asked / 2 + bases - 1) / bases);
+		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc mem] the whole-read pass runs again: %.2f G merged-trace cells asked for, %.2f G reserved (%llu per read base), now %llu per base\n", asked / 1e9, cellBudget / 1e9, (unsigned long long)st->longCellsPerBase, (unsigned long long)next);
 		if (next > 256 || cellBudgetFor(next) * sizeof(LongCell) > (64ull << 30)) return false;
 		st->longCellsPerBase = next;
 		cellBudget = cellBudgetFor(next);
@@ -944,7 +959,18 @@ struct BatchRun {
 		for (uint64_t r = 0; r < n; r++) maxSlotsPerRead = std::max(maxSlotsPerRead, jobs[r].nSlots);
 		}
 		if (2 * nSlots >= 0xffffffffull) throw std::runtime_error("batch too large: more than 2^31 fragment seeds; split the batch");
-		traceBudget += traceBudget / 4 + (1u << 20);   // room for the extensions that only fit the retry launch's larger trace buffers
+		if (!poolsSized) {
+			traceWorst = traceBudget + traceBudget / 4 + (1u << 20);   // every slot's two extensions at full length + room for the extensions that only fit the retry launch's larger trace buffers
+			pathWorst = nSlots * 24 + 4096;
+			// by use (device glue; GC_POOLS_WORST_CASE=1 and the host glue path keep the worst case): what the stream's earlier batches needed per slot, with a quarter of slack;
+			// a stream's first batch starts from what cfg2's and config 5's batches use (25-35 trace cells and 3-4 path words per slot of the 103 and 24 the worst case reserves)
+			const bool byUse = deviceGlue && !(getenv("GC_POOLS_WORST_CASE") && atoi(getenv("GC_POOLS_WORST_CASE")) == 1);
+			double traceGuess = 48.0, pathGuess = 6.0, slackCells = (double)(1u << 20), slackWords = 4096.0;
+			if (const char* env = getenv("GC_POOL_FIRST_GUESS")) { traceGuess = std::max(0.0, atof(env)); pathGuess = traceGuess / 8; slackCells = slackWords = 64; }   // test hook: a stream's first batch outgrows its pools
+			traceBudget = byUse ? std::min<uint64_t>(traceWorst, (uint64_t)((double)nSlots * (st->traceCellsPerSlot > 0 ? st->traceCellsPerSlot : traceGuess) * 1.25 + slackCells)) : traceWorst;
+			pathCapacity = byUse ? std::min<uint64_t>(pathWorst, (uint64_t)((double)nSlots * (st->pathWordsPerSlot > 0 ? st->pathWordsPerSlot : pathGuess) * 1.25 + slackWords)) : pathWorst;
+			poolsSized = true;
+		}
 		ChainCaps caps { 1, 1, 1, 1 };
 		caps.capAnchors = std::max(1u, maxSlotsPerRead);
 		caps.capEndpoints = (uint32_t)std::min<uint64_t>(0x7fffffffull, (uint64_t)caps.capAnchors * G->maxPathsPerNode);   // entries: one per path through an anchor's end node
@@ -957,6 +983,9 @@ struct BatchRun {
 
 		// ---------------- K3 / K3b / K4
 		tDev = nowUs();
+		evIdx = 2;                                   // (this stage may run twice: see fragmentPoolsOverflowed)
+		launchZeroWords(stream, dCursors + 1, 2);   // [1] trace pool cursor, [2] anchor path pool cursor ([0] is the seed lookup's)
+		launchZeroWords(stream, dCounters, 8);
 		ExtendConfig cfg;
 		cfg.bandwidth = P->bandwidth;
 		cfg.maxSlices = 3;
@@ -980,7 +1009,6 @@ struct BatchRun {
 		dFragExtended = st->fragExtended.reserve<uint32_t>(nFrags);
 		dReadTies = st->readTies.reserve<uint32_t>(n);
 		if (n) HIP_CHECK(hipMemsetAsync(dReadTies, 0, n * sizeof(uint32_t), stream));
-		pathCapacity = nSlots * 24 + 4096;
 		dPathPool = st->pathPool.reserve<uint32_t>(pathCapacity);
 		if (!deviceGlue) dJobs = st->jobs.reserve<ReadChainJob>(n);
 		dChainOut = st->chainOut.reserve<uint32_t>(nSlots);
@@ -1066,17 +1094,39 @@ struct BatchRun {
 			stitchInfo = st->hStitchInfo.reserve<StitchInfo>(n);
 			hStitchCursor = st->hStitchCursor.reserve<unsigned long long>(1);
 			HIP_CHECK(hipMemsetAsync(dCursor, 0, sizeof(unsigned long long), stream));
+			int stitchClass = maxReadLen > 16384 ? 3 : 0;
+			if (const char* env = getenv("GC_STITCH_CLASS")) stitchClass = atoi(env) == 3 ? 3 : 0;
+#ifdef GC_EXPERIMENTS
+			if (getenv("GC_STITCH_SMALL") && atoi(getenv("GC_STITCH_SMALL")) && maxReadLen <= 16384) stitchClass = 1;   // (r4: the half-size search tables, measured and not kept)
+#endif
 			launchStitch(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, dChainOut, dChainLen, dChainStatus, dPathPool, pathCapacity, (long long)P->colinear_gap, dSlotOf,
 				dRegions, dStitchNodes, stitchDenseCap, dCursor, dStitchInfo,
 				(uint32_t)capacityOr("GC_STITCH_SET_MAX", P->capacity.stitch_set_max, 0), (uint32_t)capacityOr("GC_STITCH_BFS_CAP", P->capacity.stitch_bfs_cap, 0),
-				// (GC_STITCH_SMALL=1: the half-size search tables, measured in r4 and not kept - see gc_stitch.hip. GC_STITCH_LARGE=1: the large tables for reads beyond 16 kb - a 50 kb
-				// read's piece holds more split nodes than the default node set, so config 5's reads are all stitched by the host; with 107 KB of LDS one wave runs per CU and a batch's
-				// 2 000 reads take 1.1 s there against 1-2 s of 16 host threads that overlap the other batches' kernels: 2 541 reads/s against 2 676, measured, not kept)
-				(getenv("GC_STITCH_LARGE") && atoi(getenv("GC_STITCH_LARGE")) == 1 && maxReadLen > 16384) ? 2 : (getenv("GC_STITCH_SMALL") && atoi(getenv("GC_STITCH_SMALL")) && maxReadLen <= 16384 ? 1 : 0));
+				// reads beyond 16 kb: the class whose node set and wide bridge searches live in HBM scratch (r5; gc_stitch.hip) - a 50 kb read's piece holds ~2 500 split nodes, more than the
+				// default class's LDS node set, and every read of config 5 used to be stitched by the host. GC_STITCH_CLASS=0 / 3 forces a class (tests, A/B)
+				stitchClass, stitchClass == 3 ? st->stitchSpill.reserve<unsigned long long>((uint64_t)stitchSpillBlocks((uint32_t)n) * stitchSpillWordsPerBlock()) : nullptr);
 			HIP_CHECK(hipMemcpyAsync(stitchInfo, dStitchInfo, n * sizeof(StitchInfo), hipMemcpyDeviceToHost, stream));
 			HIP_CHECK(hipMemcpyAsync(hStitchCursor, dCursor, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		}
 
+	}
+
+	// the stream learns what its batches use of the two pools; true: this batch needed more than it was given (and less than the worst case): sized again, the stage runs again
+	bool fragmentPoolsOverflowed()
+	{
+		const uint64_t traceNeed = hSmall[1], pathNeed = hSmall[2];
+		if (nSlots) {
+			st->traceCellsPerSlot = std::max(st->traceCellsPerSlot, (double)std::min(traceNeed, traceWorst) / (double)nSlots);
+			st->pathWordsPerSlot = std::max(st->pathWordsPerSlot, (double)std::min(pathNeed, pathWorst) / (double)nSlots);
+		}
+		const bool traceShort = traceNeed > traceBudget && traceBudget < traceWorst, pathShort = pathNeed > pathCapacity && pathCapacity < pathWorst;
+		if (!traceShort && !pathShort) return false;
+		// (the cursors count every request, the refused ones included - but a fragment whose extension was refused stops asking, so the need seen is a lower bound: half as much again)
+		if (traceShort) traceBudget = std::min<uint64_t>(traceWorst, traceNeed + traceNeed / 2 + (1u << 20));
+		if (pathShort) pathCapacity = std::min<uint64_t>(pathWorst, pathNeed + pathNeed / 2 + 4096);
+		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc mem] the fragment pipeline runs again: trace pool %.2f G cells needed (now %.2f), anchor path pool %.2f G words needed (now %.2f)\n", traceNeed / 1e9, traceBudget / 1e9, pathNeed / 1e9, pathCapacity / 1e9);
+		poolReruns++;
+		return true;
 	}
 
 	// ---------------- anchors, chains and stitched paths come down (pinned staging)

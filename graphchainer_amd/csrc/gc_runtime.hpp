@@ -523,7 +523,7 @@ struct gc_stream {
 	PinnedBuffer hEdPathNodes, hEdJobs, hEdPairs, hEdOut;
 	DeviceBuffer outJobs, outRecs, outOffsets, outMapSizes, outPathText, outCigarText, outVgBytes, outTotals;   // output encoding on the device (gc_output.hip)
 	PinnedBuffer hOutJobs, hOutRecs, hOutOffsets, hOutPathText, hOutCigarText, hOutVgBytes, hOutTotals;
-	DeviceBuffer stitchSlotOf, stitchRegions, stitchNodes, stitchInfo, stitchCursor;   // chain stitching on the device (gc_stitch.hip)
+	DeviceBuffer stitchSlotOf, stitchRegions, stitchNodes, stitchInfo, stitchCursor, stitchSpill;   // chain stitching on the device (gc_stitch.hip)
 	PinnedBuffer hStitchNodes, hStitchInfo, hStitchCursor;
 	EditDistanceRun edChainRun;
 	DeviceBuffer edPathJobs, edPathOps, edPathLen, edPathScratch;   // alignment path of the chained alignment (gc_edpath.hip)
@@ -536,7 +536,8 @@ struct gc_stream {
 		std::vector<uint32_t> pairRead;
 		uint32_t nPairs = 0;
 	} edLong[2];
-	uint64_t longCellsPerBase = 8;           // merged-trace cells per read base the whole-read pass reserves (grows when a batch needs more)
+	uint64_t longCellsPerBase = 4;           // merged-trace cells per read base the whole-read pass reserves (10 kb ONT-like reads use 1.1, 50 kb CLR-like reads on a genome with repeats 9-10; grows by what a batch asks for)
+	double traceCellsPerSlot = 0, pathWordsPerSlot = 0;   // what this stream's batches have used of the fragment pipeline's trace pool / anchor path pool per anchor slot (0: no batch yet)
 	std::vector<hipStream_t> groupStreams;   // read groups of the whole-read pass run their round loops concurrently
 	std::vector<hipEvent_t> groupEvents;     // 2 * LONG_EVENT_RING per group
 	DeviceBuffer longSeeds, longJobs, longAlns, longResults, longScratch, longCells, longCursor, longJobsFallback, longResultsFallback, longScratchFallback;
@@ -556,7 +557,7 @@ struct gc_stream {
 		f("chainScratch", chainScratch.bytes); f("counters", counters.bytes); f("edPathNodes", edPathNodes.bytes); f("edJobs", edJobs.bytes); f("edLetters", edLetters.bytes);
 		f("edLettersLen", edLettersLen.bytes); f("edPairs", edPairs.bytes); f("edOut", edOut.bytes); f("outJobs", outJobs.bytes); f("outRecs", outRecs.bytes); f("outOffsets", outOffsets.bytes);
 		f("outMapSizes", outMapSizes.bytes); f("outPathText", outPathText.bytes); f("outCigarText", outCigarText.bytes); f("outVgBytes", outVgBytes.bytes); f("outTotals", outTotals.bytes);
-		f("stitchSlotOf", stitchSlotOf.bytes); f("stitchRegions", stitchRegions.bytes); f("stitchNodes", stitchNodes.bytes); f("stitchInfo", stitchInfo.bytes); f("stitchCursor", stitchCursor.bytes);
+		f("stitchSlotOf", stitchSlotOf.bytes); f("stitchRegions", stitchRegions.bytes); f("stitchNodes", stitchNodes.bytes); f("stitchInfo", stitchInfo.bytes); f("stitchCursor", stitchCursor.bytes); f("stitchSpill", stitchSpill.bytes);
 		f("edPathJobs", edPathJobs.bytes); f("edPathOps", edPathOps.bytes); f("edPathLen", edPathLen.bytes); f("edPathScratch", edPathScratch.bytes); f("longSeeds", longSeeds.bytes);
 		f("longJobs", longJobs.bytes); f("longAlns", longAlns.bytes); f("longResults", longResults.bytes); f("longScratch", longScratch.bytes); f("longCells", longCells.bytes);
 		f("longCursor", longCursor.bytes); f("longJobsFallback", longJobsFallback.bytes); f("longResultsFallback", longResultsFallback.bytes); f("longScratchFallback", longScratchFallback.bytes);

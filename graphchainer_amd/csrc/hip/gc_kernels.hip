@@ -526,6 +526,8 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 	__shared__ ChainEntry sEnt[LDS ? LDS_ENTRIES : 1];
 	__shared__ int32_t sThr[LDS ? LDS_WIDTH : 1];
 	__shared__ uint32_t bKey[LDS ? 1 : CHAIN_BUCKETS], bStart[LDS ? 1 : CHAIN_BUCKETS + 1], bFilled[LDS ? 1 : CHAIN_BUCKETS], bUsed;   // bucket -> component, first entry, entries of earlier fragments
+	constexpr uint32_t SCRATCH_THR = 2048;
+	__shared__ int32_t sThrScratch[LDS ? 1 : SCRATCH_THR];   // (r5) the scratch launch's threshold table stays in LDS whenever the graph's widest path cover fits: it is scattered into, read per scanned entry and cleared for every anchor
 	const int lane = threadIdx.x;
 	// (16-bit indices: at most 65535 anchors, entries and threshold-list items per read, cover width and components below 65536; beyond that the read is flagged)
 	const uint32_t capA = LDS ? LDS_ANCHORS : (caps.capAnchors < 65535u ? caps.capAnchors : 65535u);
@@ -542,6 +544,7 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 		A.aStart = (uint32_t*)base; base += 4ull * capA;
 		A.backBegin = (uint32_t*)base; base += 4ull * (capA + 1);
 		A.thr = (int32_t*)base; base += 4ull * capW;
+		if (capW <= SCRATCH_THR) A.thr = sThrScratch;
 		A.aFrag = (uint16_t*)base; base += 2ull * capA;
 		A.aComp = (uint16_t*)base; base += 2ull * capA;
 		A.entBegin = (uint16_t*)base; base += 2ull * (capA + 1);
@@ -639,10 +642,21 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 				__syncthreads();
 				for (uint32_t k = 0; k < CHAIN_BUCKETS / 64; k++) { bStart[lane * (CHAIN_BUCKETS / 64) + k] = at; at += mine[k]; }
 				__syncthreads();
-				if (lane == 0) {
-					for (uint32_t a = 0; a < nA; a++) { const uint32_t slot = A.aBucket[a]; A.entByCompBegin[a] = (uint16_t)(bStart[slot] + bFilled[slot]); bFilled[slot] += (uint32_t)A.entBegin[a + 1] - (uint32_t)A.entBegin[a]; }
-					for (uint32_t b = 0; b < CHAIN_BUCKETS; b++) bFilled[b] = 0;
+				// every anchor's place in its bucket, in anchor order (r5: 64 anchors at a time - a lane adds up the entries of the chunk's earlier anchors that share its bucket from
+				// the other lanes' registers, the buckets' fill counts advance by LDS atomics between chunks; r4 walked the read's ~10 000 anchors on lane 0 through its HBM scratch)
+				for (uint32_t a0 = 0; a0 < nA; a0 += 64) {
+					const uint32_t a = a0 + lane;
+					const bool have = a < nA;
+					const uint32_t slot = have ? (uint32_t)A.aBucket[a] : 0xffffffffu;
+					const uint32_t cnt = have ? (uint32_t)A.entBegin[a + 1] - (uint32_t)A.entBegin[a] : 0u;
+					uint32_t before = 0;
+					for (int l = 0; l < 63; l++) { const uint32_t s = __shfl(slot, l), c = __shfl(cnt, l); if (l < lane && s == slot) before += c; }
+					if (have) A.entByCompBegin[a] = (uint16_t)(bStart[slot] + bFilled[slot] + before);
+					__syncthreads();
+					if (have && cnt) atomicAdd(&bFilled[slot], cnt);
+					__syncthreads();
 				}
+				for (uint32_t b = lane; b < CHAIN_BUCKETS; b += 64) bFilled[b] = 0;
 				__syncthreads();
 				for (uint32_t a = lane; a < nA; a += 64)
 					for (uint32_t e = A.entBegin[a], to = A.entByCompBegin[a]; e < A.entBegin[a + 1]; e++, to++) A.entByComp[to] = A.ent[e];
@@ -662,6 +676,9 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 				g0 = j; entPrefix = A.entBegin[j]; __syncthreads();   // C of the previous fragment's anchors is now final and visible
 			}
 			if (g0 == 0) continue;
+			// (r5) nothing of j's component lies in an earlier fragment: C[j] stays the anchor's own length - on a genome-sized graph most of a long read's anchors are such strays
+			// (chance minimizer hits on other chromosomes), and each used to pay the threshold scatter, three barriers and their round trips to the scratch
+			if (LDS == 0 && bucketed && bFilled[A.aBucket[j]] == 0) continue;
 			const uint32_t b0 = A.backBegin[j], b1 = A.backBegin[j + 1];
 			// thr[k] = last position on path k that may precede start(j)
 			if (b1 <= w0 + 64 || (b1 - b0 <= 64 && (w0 = b0, win = b0 + lane < nB ? A.back[b0 + lane] : make_uint2(0, 0), true))) {
@@ -702,37 +719,29 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 			}
 		}
 		__syncthreads();
+		// The read's chain (:1713-1733, :1847-1862): per component the lexicographic maximum of (coverage, anchor index); over the components, visited in ascending id, the first
+		// strictly greater coverage - i.e. the largest coverage, among equals the smallest component id, inside it the largest anchor index: ONE wave maximum over the anchors of
+		// coverage << 32 | (65535 - component) << 16 | anchor (r5; r4 let lane 0 walk all anchors twice per component - a million loads from the scratch for a 50 kb read that
+		// touches fifty components, most of the kernel's time on a genome-sized graph)
+		unsigned long long top = 0;
+		for (uint32_t a = lane; a < nA; a += 64) {
+			const unsigned long long key = ((unsigned long long)unpackScore(A.C[a]) << 32) | ((unsigned long long)(65535u - (uint32_t)A.aComp[a]) << 16) | a;
+			top = key > top ? key : top;
+		}
+		for (int d = 32; d > 0; d >>= 1) { const unsigned long long o = __shfl_xor(top, d); top = o > top ? o : top; }
 		if (lane == 0) {
 			uint32_t status = 0;
-			long long best = 0; bool first = true;
+			const long long best = nA ? (long long)(top >> 32) : 0;
 			uint32_t bestLen = 0;
 			uint32_t* out = chainOut + job.chainBegin;
-			long long lastCid = -1;
-			while (nA > 0) {   // components in ascending id; keep the first strictly greater score (:1713-1733)
-				long long cid = -1;
-				for (uint32_t a = 0; a < nA; a++) {
-					long long c = A.aComp[a];
-					if (c > lastCid && (cid < 0 || c < cid)) cid = c;
+			if (nA) {
+				uint32_t n = 0;
+				for (long long i = (long long)(top & 0xffffu); i != -1; i = unpackAnchor(A.C[i])) {   // :1851-1862
+					if (n >= job.nSlots) { status = 1; break; }
+					out[n++] = (uint32_t)i;
 				}
-				if (cid < 0) break;
-				lastCid = cid;
-				long long score = 0, anchor = -1;   // :1847-1849, lexicographic max of (coverage, index)
-				for (uint32_t a = 0; a < nA; a++) {
-					if ((long long)A.aComp[a] != cid) continue;
-					long long sc = unpackScore(A.C[a]);
-					if (sc > score || (sc == score && (long long)a > anchor)) { score = sc; anchor = a; }
-				}
-				if (first || score > best) {
-					first = false;
-					best = score;
-					uint32_t n = 0;
-					for (long long i = anchor; i != -1; i = unpackAnchor(A.C[i])) {   // :1851-1862
-						if (n >= job.nSlots) { status = 1; break; }
-						out[n++] = (uint32_t)i;
-					}
-					for (uint32_t i = 0; i < n / 2; i++) { uint32_t t = out[i]; out[i] = out[n - 1 - i]; out[n - 1 - i] = t; }
-					bestLen = n;
-				}
+				for (uint32_t i = 0; i < n / 2; i++) { uint32_t t = out[i]; out[i] = out[n - 1 - i]; out[n - 1 - i] = t; }
+				bestLen = n;
 			}
 			chainLen[r] = bestLen;
 			chainScore[r] = (unsigned long long)best;

@@ -247,7 +247,9 @@ struct StitchInfo {   // the longest stitched piece of a read's chain
 void launchStitch(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
 	const uint32_t* chainOut, const uint32_t* chainLen, const uint32_t* chainStatus, const uint32_t* pathPool, uint64_t pathCapacity, long long colinearGap, uint32_t* slotOf,
 	uint32_t* regions, uint32_t* dense, uint64_t denseCap, unsigned long long* denseCursor, StitchInfo* info,
-	uint32_t setMax = 0, uint32_t bfsCap = 0, int sizeClass = 0);   // smaller table limits (tests: forces reads onto the host path); 0 = the kernel's own. sizeClass: 0 default, 1 the half-size search (reads up to 16 kb), 2 the tables of long reads
+	uint32_t setMax = 0, uint32_t bfsCap = 0, int sizeClass = 0, unsigned long long* spill = nullptr);   // smaller table limits (tests: forces reads onto the host path); 0 = the kernel's own. sizeClass: 0 default, 3 (r5) long reads: node set and wide searches in `spill`
+uint64_t stitchSpillWordsPerBlock();       // 64-bit words of HBM scratch per block of a class-3 launch ...
+uint32_t stitchSpillBlocks(uint32_t nReads);   // ... and its blocks
 uint64_t stitchRegionWords(uint64_t totalSlots, uint64_t nReads);
 uint64_t stitchDenseWords(uint64_t totalSlots, uint64_t nReads);
 // srcOff with bit 63 set reads its nodes from altNodes (host-stitched reads) instead of pathNodes

@@ -50,18 +50,27 @@ struct StitchAnchor {
 	uint32_t flags;               // 1: firstNode is an out-neighbour of prevLast, 2: unusable record (the host stitches the read)
 };
 
-template <uint32_t STITCH_SET_SIZE, uint32_t STITCH_BFS_CAP>
+// SPILL (r5, the class of long reads): a 50 kb read's piece holds ~2 500 split nodes and a failed bridge search inside a 50 kb gap budget visits a few thousand - neither fits
+// the LDS tables, and tables four times the size (r4's class 2: 107 KB, one wave per CU) lost to sixteen host threads. Here the LDS stays what the default class uses (five waves
+// per CU): the piece's node set moves to a generation-stamped hash table in the block's HBM scratch behind a 32 K-bit membership filter in LDS - most look-ups ask for a node that
+// is NOT on the piece and end at the filter without touching memory; a new piece bumps the generation and clears the filter, nothing in HBM - and a bridge search that outgrows the
+// LDS queue is run again with queue, distances, predecessors and visited table in the scratch (same code, same visiting order; rare: one search in a few hundred).
+__host__ __device__ constexpr uint64_t stitchSpillWordsPerBlockC() { return 16384ull /* node set, 64-bit slots */ + (2ull * 16384ull /* visited table */ + 3ull * 16384ull /* queue, distances, predecessors */) / 2; }
+#define STITCH_SPILL_SET_SLOTS 16384u     // node set in HBM: 64-bit slots (generation << 32 | node); at most half are used
+#define STITCH_SPILL_BFS_CAP 16384u       // visited nodes of a bridge search that runs in HBM
+#define STITCH_FILTER_WORDS 1024u
+template <uint32_t STITCH_SET_SIZE, uint32_t STITCH_BFS_CAP, bool SPILL>
 __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __restrict__ jobs, uint32_t nReads, const AnchorRec* __restrict__ anchors,
 	const Fragment* __restrict__ frags, const uint32_t* __restrict__ fragStatus, const uint32_t* __restrict__ chainOut, const uint32_t* __restrict__ chainLen,
 	const uint32_t* __restrict__ chainStatus, const uint32_t* __restrict__ pathPool, uint64_t pathCapacity, long long colinearGap, uint32_t setMax, uint32_t bfsCap,
 	uint32_t* __restrict__ slotOf, uint32_t* __restrict__ regions, uint32_t* __restrict__ dense, uint64_t denseCap, unsigned long long* __restrict__ denseCursor,
-	StitchInfo* __restrict__ info)
+	StitchInfo* __restrict__ info, unsigned long long* __restrict__ spill)
 {
 	GC_RAISE_PRIO();
 	constexpr uint32_t STITCH_BFS_TABLE = 2 * STITCH_BFS_CAP;
 	constexpr uint32_t INDEX_BITS = STITCH_BFS_CAP <= 1024 ? 11u : 13u, INDEX_MASK = (1u << INDEX_BITS) - 1u;   // a table entry: (generation << INDEX_BITS) | (queue index + 1)
 	static_assert(STITCH_BFS_CAP < (1u << INDEX_BITS), "queue index + 1 must fit its bits");
-	__shared__ uint32_t setKey[STITCH_SET_SIZE];
+	__shared__ uint32_t setKey[SPILL ? STITCH_FILTER_WORDS : STITCH_SET_SIZE];   // SPILL: the membership filter (one bit per hashed node) in front of the HBM table
 	__shared__ uint32_t bfsTable[STITCH_BFS_TABLE];   // (generation << INDEX_BITS) | (queue index + 1)
 	__shared__ uint32_t qNode[STITCH_BFS_CAP], qDis[STITCH_BFS_CAP];
 	__shared__ uint16_t qPre[STITCH_BFS_CAP];
@@ -71,6 +80,13 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 	__shared__ long long sSearchLimit;
 	__shared__ unsigned long long sDenseAt;
 	const uint32_t lane = threadIdx.x;
+	// SPILL: this block's HBM scratch (zeroed by the launcher): the node set, then the wide search's visited table, queue, distances, predecessors
+	unsigned long long* const spillSet = SPILL ? spill + (uint64_t)blockIdx.x * stitchSpillWordsPerBlockC() : nullptr;
+	uint32_t* const spillTable = (uint32_t*)(spillSet + STITCH_SPILL_SET_SLOTS);
+	uint32_t* const spillNode = spillTable + 2 * STITCH_SPILL_BFS_CAP;
+	uint32_t* const spillDis = spillNode + STITCH_SPILL_BFS_CAP;
+	uint32_t* const spillPre = spillDis + STITCH_SPILL_BFS_CAP;
+	uint32_t pieceGen = 0, spillSearches = 0;   // generations of the node set (one per piece) and of the wide search's table (one per wide search), counted across the block's reads
 	for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
 		const ReadChainJob job = jobs[r];
 		const uint32_t len = chainLen[r];
@@ -89,9 +105,10 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 			if (valid) slotOf[job.slotBegin + nA + (uint32_t)__popcll(ballot & ((1ull << lane) - 1))] = s;
 			nA += (uint32_t)__popcll(ballot);
 		}
-		for (uint32_t i = lane; i < STITCH_SET_SIZE; i += 64) setKey[i] = STITCH_EMPTY;
+		for (uint32_t i = lane; i < (SPILL ? STITCH_FILTER_WORDS : STITCH_SET_SIZE); i += 64) setKey[i] = SPILL ? 0u : STITCH_EMPTY;
 		for (uint32_t i = lane; i < STITCH_BFS_TABLE; i += 64) bfsTable[i] = 0;
 		if (lane == 0) sOverflow = 0;
+		pieceGen++;
 		__syncthreads();
 
 		// ---- lane 0's state: the current piece and the best one so far
@@ -104,6 +121,16 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 		bool overflow = false;
 		uint32_t why = 0;   // 1 piece/region full, 2 bridge search too wide, 3 unusable anchor record, 4 output array full
 		auto contains = [&](uint32_t node) {
+			if (SPILL) {
+				const uint32_t bit = (node * 0x9E3779B1u) >> 17;   // 15 bits
+				if (!((setKey[bit >> 5] >> (bit & 31u)) & 1u)) return false;
+				const unsigned long long key = ((unsigned long long)pieceGen << 32) | node;
+				for (uint32_t h = stitchHash(node, STITCH_SPILL_SET_SLOTS - 1);; h = (h + 1) & (STITCH_SPILL_SET_SLOTS - 1)) {
+					const unsigned long long k = spillSet[h];
+					if (k == key) return true;
+					if ((uint32_t)(k >> 32) != pieceGen) return false;
+				}
+			}
 			for (uint32_t h = stitchHash(node, STITCH_SET_SIZE - 1);; h = (h + 1) & (STITCH_SET_SIZE - 1)) {
 				uint32_t k = setKey[h];
 				if (k == node) return true;
@@ -113,9 +140,17 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 		// appends a node that is known not to be on the piece; nodeLen 0 = not known
 		auto push = [&](uint32_t node, uint32_t nodeLen) {
 			if (setCount >= setMax || pieceStart + posLen >= regionCap) { overflow = true; why = 1; return; }
-			uint32_t h = stitchHash(node, STITCH_SET_SIZE - 1);
-			while (setKey[h] != STITCH_EMPTY) h = (h + 1) & (STITCH_SET_SIZE - 1);
-			setKey[h] = node;
+			if (SPILL) {
+				const uint32_t bit = (node * 0x9E3779B1u) >> 17;
+				setKey[bit >> 5] |= 1u << (bit & 31u);
+				uint32_t h = stitchHash(node, STITCH_SPILL_SET_SLOTS - 1);
+				while ((uint32_t)(spillSet[h] >> 32) == pieceGen) h = (h + 1) & (STITCH_SPILL_SET_SLOTS - 1);
+				spillSet[h] = ((unsigned long long)pieceGen << 32) | node;
+			} else {
+				uint32_t h = stitchHash(node, STITCH_SET_SIZE - 1);
+				while (setKey[h] != STITCH_EMPTY) h = (h + 1) & (STITCH_SET_SIZE - 1);
+				setKey[h] = node;
+			}
 			setCount++;
 			region[pieceStart + posLen] = node;
 			if (nodeLen == 0) nodeLen = g.nodeLength[node];
@@ -143,14 +178,17 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 		// loads), then all lanes replay the insertions in the reference's order - entry by entry, neighbours in CSR order -
 		// executing the same LDS operations on the same values, so the visiting order, and with it every predecessor, is the
 		// sequential one. Entries appended during a batch are expanded in a later batch, which is still queue order.
-		auto findBridge = [&](uint32_t S, uint32_t T, long long sepLimit, bool& tooWide) -> uint32_t {
+		// (the tables are parameters: the LDS ones, or - SPILL, for a search that outgrew them - the block's HBM scratch)
+		auto searchIn = [&](auto* qPre, uint32_t* qNode, uint32_t* qDis, uint32_t* bfsTable, const uint32_t tableSlots, const uint32_t indexBits, uint32_t& generation, const uint32_t bfsCap,
+			uint32_t S, uint32_t T, long long sepLimit, bool& tooWide) -> uint32_t {
+			uint32_t* const bridge = qDis;
 			generation++;
-			const uint32_t tag = generation << INDEX_BITS;
+			const uint32_t tag = generation << indexBits, indexMask = (1u << indexBits) - 1u;
 			auto visit = [&](uint32_t node, uint32_t index) -> bool {   // true: seen before; otherwise recorded as queue entry `index`
-				for (uint32_t h = stitchHash(node, STITCH_BFS_TABLE - 1);; h = (h + 1) & (STITCH_BFS_TABLE - 1)) {
+				for (uint32_t h = stitchHash(node, tableSlots - 1);; h = (h + 1) & (tableSlots - 1)) {
 					uint32_t e = bfsTable[h];
-					if ((e >> INDEX_BITS) != generation) { bfsTable[h] = tag | (index + 1); return false; }
-					if (qNode[(e & INDEX_MASK) - 1] == node) return true;
+					if ((e >> indexBits) != generation) { bfsTable[h] = tag | (index + 1); return false; }
+					if (qNode[(e & indexMask) - 1] == node) return true;
 				}
 			};
 			// Pruning that cannot change the result: componentNumber never decreases along an edge (it is the topological rank of
@@ -189,7 +227,7 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 						else { t = g.outAdj[el + k]; if (g.componentNumber[t] > rankT) continue; tLen = g.nodeLength[t]; }
 						if (qLen >= bfsCap) { tooWide = true; return 0; }
 						if (visit(t, qLen)) continue;
-						qNode[qLen] = t; qDis[qLen] = dl + tLen; qPre[qLen] = (uint16_t)(i0 + l);
+						qNode[qLen] = t; qDis[qLen] = dl + tLen; qPre[qLen] = (std::remove_reference_t<decltype(qPre[0])>)(i0 + l);
 						qLen++;
 						// the reference finishes s's neighbours before it notices that T was reached; the ones after T cannot
 						// change pre[T] or anything before it on the path, so the search can stop here
@@ -204,6 +242,9 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 			for (uint32_t i = found - 1; i != 0; i = qPre[i]) bridge[at--] = qNode[i];
 			bridge[0] = S;
 			return hops + 1;
+		};
+		auto findBridge = [&](uint32_t S, uint32_t T, long long sepLimit, bool& tooWide) -> uint32_t {
+			return searchIn(qPre, qNode, qDis, bfsTable, STITCH_BFS_TABLE, INDEX_BITS, generation, bfsCap, S, T, sepLimit, tooWide);
 		};
 
 		const uint32_t* chain = chainOut + job.chainBegin;
@@ -279,10 +320,19 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 					}
 				}
 				// all lanes: the bridge search, when lane 0 asked for one
+				const uint32_t* bridgeNow = bridge;   // where this anchor's bridge is: the LDS search's array, or the scratch's after a wide search
 				if (__shfl((uint32_t)search, 0)) {
 					__syncthreads();
 					bool tooWide = false;
 					uint32_t n = findBridge(sSearchFrom, a.firstNode, sSearchLimit, tooWide);
+					if (SPILL && tooWide) {
+						// the search outgrew the LDS queue: once more in the scratch (a search whose target is unreachable walks everything downstream within the gap budget)
+						if (spillSearches >= (1u << 17) - 2u) { for (uint32_t k = lane; k < 2 * STITCH_SPILL_BFS_CAP; k += 64) spillTable[k] = 0; spillSearches = 0; __syncthreads(); }
+						tooWide = false;
+						n = searchIn(spillPre, spillNode, spillDis, spillTable, 2 * STITCH_SPILL_BFS_CAP, 15u, spillSearches, STITCH_SPILL_BFS_CAP, sSearchFrom, a.firstNode, sSearchLimit, tooWide);
+						bridgeNow = spillDis;
+						__syncthreads();
+					}
 					if (lane == 0) {
 						nBridge = n;
 						if (tooWide) { overflow = true; why = 2; }
@@ -301,12 +351,13 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 					firstOffset = a.firstOffset;
 				}
 				if (__shfl((uint32_t)newPiece, 0)) {
-					for (uint32_t k = lane; k < STITCH_SET_SIZE; k += 64) setKey[k] = STITCH_EMPTY;
+					if (SPILL) { pieceGen++; for (uint32_t k = lane; k < STITCH_FILTER_WORDS; k += 64) setKey[k] = 0; }   // (the HBM table is stamped: the new generation finds it empty)
+					else for (uint32_t k = lane; k < STITCH_SET_SIZE; k += 64) setKey[k] = STITCH_EMPTY;
 					__syncthreads();
 				}
 				// lane 0, second half: the bridge (when the piece goes on) and the anchor's own path
 				if (lane == 0 && rest && !overflow) {
-					if (!gap) for (uint32_t k = 0; k < nBridge && !overflow; k++) if (!contains(bridge[k])) push(bridge[k], bridge[k] == head ? pathNodeLen(0) : 0u);
+					if (!gap) for (uint32_t k = 0; k < nBridge && !overflow; k++) if (!contains(bridgeNow[k])) push(bridgeNow[k], bridgeNow[k] == head ? pathNodeLen(0) : 0u);
 					for (uint32_t k = 0; k < a.pathLen && !overflow; k++) { uint32_t node = pathNode(k); if (!contains(node)) push(node, pathNodeLen(k)); }
 					lastOffset = a.lastOffset;
 				}
@@ -336,25 +387,34 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 	}
 }
 
-// sizeClass: 0 the default tables (2 048-slot node set, 1 024 visited nodes per bridge search), 1 the half-size search (measured in r4, not kept), 2 (r4) the tables of long reads -
-// 8 192 slots and 4 095 visited nodes, 107 KB of LDS, one wave per CU: a 50 kb read's piece holds ~2 500 split nodes and its failed searches walk as many
+// sizeClass: 0 the default tables (2 048-slot node set, 1 024 visited nodes per bridge search: reads up to ~16 kb), 1 the half-size search (measured in r4, not kept: experiments build),
+// 3 (r5) the class of long reads: the default class's LDS plus a node set and a wide-search area in HBM scratch (`spill`: stitchSpillWordsPerBlock() words per block of the launch,
+// stitchSpillBlocks(nReads) blocks; zeroed here before every launch - the tables' generation stamps start again with each launch)
 void launchStitch(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
 	const uint32_t* chainOut, const uint32_t* chainLen, const uint32_t* chainStatus, const uint32_t* pathPool, uint64_t pathCapacity, long long colinearGap, uint32_t* slotOf,
-	uint32_t* regions, uint32_t* dense, uint64_t denseCap, unsigned long long* denseCursor, StitchInfo* info, uint32_t setMax, uint32_t bfsCap, int sizeClass)
+	uint32_t* regions, uint32_t* dense, uint64_t denseCap, unsigned long long* denseCursor, StitchInfo* info, uint32_t setMax, uint32_t bfsCap, int sizeClass, unsigned long long* spill)
 {
 	if (!nReads) return;
-	const uint32_t setSize = sizeClass == 2 ? 4 * STITCH_SET_SIZE_LARGE : STITCH_SET_SIZE_LARGE, capBfs = sizeClass == 2 ? 4 * STITCH_BFS_CAP_LARGE - 1 : sizeClass == 1 ? STITCH_BFS_CAP_LARGE / 2 : STITCH_BFS_CAP_LARGE;
+	if (sizeClass == 3 && !spill) sizeClass = 0;
+	const uint32_t setSize = sizeClass == 3 ? STITCH_SPILL_SET_SLOTS : STITCH_SET_SIZE_LARGE, capBfs = sizeClass == 1 ? STITCH_BFS_CAP_LARGE / 2 : STITCH_BFS_CAP_LARGE;
 	setMax = setMax && setMax < setSize / 2 ? setMax : setSize / 2;
-	bfsCap = bfsCap && bfsCap < capBfs ? bfsCap : capBfs;
-	uint32_t blocks = nReads < 16384u ? nReads : 16384u;
-#define GC_LAUNCH_STITCH(SET, CAP) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stitch<SET, CAP>), dim3(blocks), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, chainOut, chainLen, chainStatus, pathPool, pathCapacity, colinearGap, setMax, bfsCap, \
-		slotOf, regions, dense, denseCap, denseCursor, info)
-	if (sizeClass == 2) GC_LAUNCH_STITCH(4 * STITCH_SET_SIZE_LARGE, 4 * STITCH_BFS_CAP_LARGE);
-	else if (sizeClass == 1) GC_LAUNCH_STITCH(STITCH_SET_SIZE_LARGE, STITCH_BFS_CAP_LARGE / 2);
-	else GC_LAUNCH_STITCH(STITCH_SET_SIZE_LARGE, STITCH_BFS_CAP_LARGE);
+	bfsCap = bfsCap && bfsCap < capBfs ? bfsCap : capBfs;   // (of the LDS search; the wide search of class 3 holds STITCH_SPILL_BFS_CAP)
+	uint32_t blocks = sizeClass == 3 ? stitchSpillBlocks(nReads) : (nReads < 16384u ? nReads : 16384u);
+#define GC_LAUNCH_STITCH(SET, CAP, SPILL) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stitch<SET, CAP, SPILL>), dim3(blocks), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, chainOut, chainLen, chainStatus, pathPool, pathCapacity, colinearGap, setMax, bfsCap, \
+		slotOf, regions, dense, denseCap, denseCursor, info, spill)
+	if (sizeClass == 3) {
+		(void)hipMemsetAsync(spill, 0, (size_t)blocks * stitchSpillWordsPerBlock() * sizeof(unsigned long long), stream);
+		GC_LAUNCH_STITCH(STITCH_SET_SIZE_LARGE, STITCH_BFS_CAP_LARGE, true);
+	}
+#ifdef GC_EXPERIMENTS
+	else if (sizeClass == 1) GC_LAUNCH_STITCH(STITCH_SET_SIZE_LARGE, STITCH_BFS_CAP_LARGE / 2, false);
+#endif
+	else GC_LAUNCH_STITCH(STITCH_SET_SIZE_LARGE, STITCH_BFS_CAP_LARGE, false);
 #undef GC_LAUNCH_STITCH
 }
+uint32_t stitchSpillBlocks(uint32_t nReads) { return nReads < 1024u ? nReads : 1024u; }   // (blocks loop over the reads: four waves per CU on the chip's 256 CUs)
 
+uint64_t stitchSpillWordsPerBlock() { return stitchSpillWordsPerBlockC(); }
 uint64_t stitchRegionWords(uint64_t totalSlots, uint64_t nReads) { return 2 * totalSlots + 64 * nReads; }
 uint64_t stitchDenseWords(uint64_t totalSlots, uint64_t nReads) { return stitchRegionWords(totalSlots, nReads); }   // a piece is at most its read's region; only the used part is downloaded
 

@@ -223,6 +223,7 @@ typedef struct gc_result {
 	uint32_t* chain_aln_start; uint32_t* chain_aln_end;   /* [n_reads]; 0,0 where there is no chained alignment */
 	/* work counters of the fragment pass: [0] dp tiles, [1] recompute tiles (last-slice flatten + backtrace),
 	 * [2] column steps, [3] trace items, [4] extensions, [5] backtrace tiles (subset of [1]);
+	 * [6] (r5) times the batch's fragment pipeline ran again because its trace pool or anchor path pool - sized by what the stream's earlier batches used - was too small;
 	 * [7] reads whose chain was stitched on the host because it did not fit the stitching kernel's tables */
 	uint64_t counters[8];
 	uint64_t counters_long[8];    /* the same for the whole-read pass */

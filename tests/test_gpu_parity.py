@@ -942,6 +942,32 @@ def test_output_against_golden_files(gca, golden_dir):
             gca.Aligner(graph, seeder, long_pass=True, device_output=mode).align_reads(reads, gaf_names=names, cigar_match_mismatch_merge=merge)
 
 
+def test_fragment_pools_sized_by_use_rerun_when_too_small(gca, tmp_path, monkeypatch):
+    """r5: the fragment pipeline's trace pool and anchor path pool are sized by what the stream's batches have used (not by every slot's worst case: 26 GB per batch on a 960 Mbp
+    graph); a batch that outgrows them runs the stage again with the room it asked for. GC_POOL_FIRST_GUESS makes a stream's first batch far too small: same results as the
+    oracle, counters[6] says the stage ran again, and the stream's next batch (same Aligner) fits at once."""
+    from graphchainer_amd.synth import SynthGraph
+    from oracle import Oracle
+    sg = SynthGraph(150_000, seed=5)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(40, 3000, seed=2)
+    monkeypatch.setenv("GC_POOL_FIRST_GUESS", "0.5")
+    graph = gca.AlignmentGraph(gfa)
+    seeder = gca.MinimizerSeeder(graph)
+    aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, long_pass=True, chain_traces=2)
+    want = Oracle(gfa, long_pass=True).align(reads)
+    reruns = []
+    for _ in range(2):
+        got = {k: (v.astype(np.int64) if v.dtype.kind in "ui" and k not in ("counters", "counters_long") else v) for k, v in aligner.align_reads(reads).items()}
+        reruns.append(int(got["counters"][6]))
+        expand_stitched_path(got, graph.array("nodeLength"))
+        mark_missing_chain_alignments(got)
+        compare(got, want)
+        assert not got["capacity_exceeded"].any()
+    assert reruns[0] >= 1 and reruns[1] == 0, reruns
+
+
 def test_flatten_tie_counts_equal_the_oracles(gca, tmp_path):
     """r5: both extension cores count the extensions whose backtrace started from a flattenLastSliceEnd minimum attained in more than one node -
     the only place where the reference's parallel-hashmap iteration order (absent here; band-entry order stands in) can choose another cell. gc_result::flatten_ties /
@@ -1009,7 +1035,10 @@ def test_gam_against_the_reference_decoded_fixture(gca, case):
 
 @pytest.mark.parametrize("env,kw,host_expected", [
     ({}, {}, "none"),
-    ({"GC_STITCH_SMALL": "1"}, {}, "few"),       # r4 experiment: half-size search tables - a chimeric read's search for an unreachable anchor may outgrow them
+    ({"GC_STITCH_CLASS": "3"}, {}, "none"),          # r5: the long-read class (node set in HBM scratch behind an LDS filter) forced on short reads
+    ({"GC_STITCH_CLASS": "3", "GC_STITCH_BFS_CAP": "2"}, {}, "none"),   # ... with an LDS search that may visit 2 nodes: every longer bridge search runs again in the scratch, none on the host
+    ({"GC_STITCH_CLASS": "3", "GC_STITCH_BFS_CAP": "6"}, {"colinear_gap": 150}, "none"),
+    ({"GC_STITCH_CLASS": "3"}, {"colinear_gap": -1}, "any"),
     ({"GC_HOST_STITCH": "1"}, {}, "all"),
     ({"GC_STITCH_BFS_CAP": "2"}, {}, "some"),        # a bridge search may visit 2 nodes: most reads fall back to the host
     ({"GC_STITCH_SET_MAX": "40"}, {}, "some"),       # a piece may hold 40 nodes
