@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "gc_params_default", "gc_graph_create_from_gfa", "gc_graph_create", "gc_graph_destroy", "gc_graph_num_nodes",
     "gc_graph_size_bp", "gc_graph_array", "gc_seeder_create", "gc_seeder_destroy", "gc_seeder_array",
     "gc_stream_create", "gc_stream_destroy", "gc_reads_upload", "gc_reads_destroy", "gc_align_batch",
-    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_device_memory", "gc_edit_distance", "gc_edit_path", "gc_evalue", "gc_format_gaf", "gc_format_json", "gc_format_gam", "gc_format_gam_level", "gc_gzip_streams", "gc_format_gaf_trace", "gc_format_vg_trace", "gc_format_vg_trace_digraph", "gc_graph_letters",
+    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_device_memory", "gc_edit_distance", "gc_edit_path", "gc_evalue", "gc_format_gaf", "gc_format_json", "gc_format_gam", "gc_format_gam_level", "gc_gzip_streams", "gc_format_gaf_trace", "gc_format_vg_trace", "gc_format_vg_trace_digraph", "gc_graph_letters", "gc_std_sort_permutations",
     "gc_index_build", "gc_index_save", "gc_index_load", "gc_index_check", "gc_result_cache_trim",
 ]
 
@@ -170,6 +170,19 @@ def edit_path(a_list, b_list):
 
 
 GAM_DEVICE_HUFFMAN = 100   # GC_GAM_DEVICE_HUFFMAN: gam_level value that has the gzip members deflated on the device
+
+
+def std_sort_permutations(arrays, depth_limit=-1):
+    """Test entry: the permutations the device's wave-cooperative replay of libstdc++'s std::sort (csrc/hip/gc_stdsort_wave.hpp) gives for arrays of uint32 keys."""
+    lib = load_library()
+    arrays = [np.ascontiguousarray(a, dtype=np.uint32) for a in arrays]
+    off = np.zeros(len(arrays) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(a) for a in arrays])
+    keys = np.concatenate(arrays) if arrays else np.zeros(0, dtype=np.uint32)
+    perm = np.zeros(len(keys), dtype=np.uint32)
+    lib.gc_std_sort_permutations.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p]
+    _check(lib.gc_std_sort_permutations(keys.ctypes.data, off.ctypes.data, len(arrays), int(depth_limit), perm.ctypes.data))
+    return [perm[int(off[i]):int(off[i + 1])] for i in range(len(arrays))]
 
 
 def gzip_streams(streams):

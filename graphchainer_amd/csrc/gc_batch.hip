@@ -87,6 +87,7 @@ struct BatchRun {
 	uint32_t* dFragExtended = nullptr;
 	uint64_t traceWorst = 0, pathWorst = 0;   // the pools' worst-case sizes (every slot's extensions at full length, 24 path words per slot)
 	bool poolsSized = false;
+	uint32_t nExtendPairs = 0, nAnchorPairs = 0;   // event pairs recorded around the rounds' k_extend / k_build_anchors launches
 	uint32_t poolReruns = 0;
 	uint32_t* dReadTies = nullptr;     // per read: fragment extensions whose flattenLastSliceEnd minimum was tied between nodes (k_build_anchors adds them up; gc_result::flatten_ties)
 	uint64_t pathCapacity = 0;
@@ -211,7 +212,7 @@ struct BatchRun {
 			uint32_t** u32s[8] = { &stg.mPos, &stg.mStartLo, &stg.mStartHi, &stg.sSeqPos, &stg.sNode, &stg.sOffset, &stg.sGood, &stg.sCluster };
 			for (int k = 0; k < 8; k++) *u32s[k] = st->glueU32[k].reserve<uint32_t>(seedCap);
 			stg.sortBuf = (GlueElem*)st->glueSort.reserve<uint8_t>(seedCap * glueElemBytes());
-			stg.posBuf = st->gluePos.reserve<uint32_t>(seedCap);
+			stg.sortScratch = st->gluePos.reserve<uint32_t>(3 * seedCap + 64 * n + 64);
 			stg.winBuf = st->glueWin.reserve<uint32_t>(4 * winCap);
 			dLongSeeds = st->longSeeds.reserve<LongSeed>(P->long_pass ? seedCap : 0);
 			dReadSeeds = st->readSeeds.reserve<FragSeed>(seedCap);
@@ -306,7 +307,8 @@ struct BatchRun {
 			// noisy 50 kb CLR reads on a genome with repeats collect 8-9 alignments each and overflowed it (a quarter of the reads flagged, which reads
 			// depending on timing). The stream remembers what its batches needed, and a batch that overflows reruns its pass with three times the room.
 			cellPoolPinned = getenv("GC_LONG_CELLS_PER_BASE") || P->capacity.long_cells_per_base > 0;
-			const uint64_t cellsPerBase = (uint64_t)std::max<int64_t>(2, capacityOr("GC_LONG_CELLS_PER_BASE", P->capacity.long_cells_per_base, (int64_t)st->longCellsPerBase));
+			uint64_t cellsPerBase = (uint64_t)std::max<int64_t>(2, capacityOr("GC_LONG_CELLS_PER_BASE", P->capacity.long_cells_per_base, (int64_t)st->longCellsPerBase));
+			if (getenv("GC_LONG_FORCE_FALLBACK") && !cellPoolPinned) cellsPerBase *= 3;   // (test hook: every read's alignments are made twice, by the rounds and by the fallback kernel, into the same pool)
 			cellBudget = cellBudgetFor(cellsPerBase);
 			pool.run(n, [&](size_t r, size_t) {
 				const ReadGlue& gl = glue[r];
@@ -686,6 +688,11 @@ struct BatchRun {
 			HIP_CHECK(hipMemcpyAsync(subResults.data(), dSubResults, redo.size() * sizeof(LongReadResult), hipMemcpyDeviceToHost, ls));
 			syncStream(ls);
 			for (size_t i = 0; i < redo.size(); i++) hLongResults[redo[i]] = subResults[i];
+			// the reruns append their cells to the pool the rounds have filled: when that did not fit (the pool is sized by use since r5), the reads are flagged (status 4) and
+			// the stream's next batch gets the room
+			bool shortOfCells = false;
+			for (size_t i = 0; i < redo.size() && !shortOfCells; i++) shortOfCells = subResults[i].status == 4;
+			if (shortOfCells && !cellPoolPinned) st->longCellsPerBase = std::min<uint64_t>(256, st->longCellsPerBase * 2);
 		}
 		if (n) HIP_CHECK(hipMemcpyAsync(hLongAlns, dLongAlns, n * maxAlignments * sizeof(LongAln), hipMemcpyDeviceToHost, ls));
 		HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
@@ -1042,14 +1049,24 @@ struct BatchRun {
 		if (const char* env = getenv("GC_EXT_RETRY_MAX_ITEMS")) big.maxItems = (uint32_t)std::max(8, atoi(env));   // test hook: make the retry overflow too
 		const uint32_t retryLanes = 2048;
 		uint8_t* dRetryScratch = st->scratchRetry.reserve<uint8_t>((uint64_t)retryLanes * extendSlabBytes(big));
+		// (r5: every round's extension launches and every k_build_anchors launch sit between an event pair of their own - r4 bracketed "round 0's extensions" and "everything up to
+		// the chaining kernel", so the later rounds' k_extend launches were charged to the anchors stage and roofline_other did not follow from the kernel trace)
+		nExtendPairs = nAnchorPairs = 0;
 		auto extendRound = [&](const ExtSelection& sel) {
+			if (nExtendPairs < 4) HIP_CHECK(hipEventRecord(st->fragEv[2 * nExtendPairs], stream));
 			launchExtend(stream, G->dev, G->devTables, G->devIupac, cfg, dWork, nWork, R->devBases, dResults, dScratch, slabBytes, dTrace, dCursors + 1, traceBudget, dCounters, 0, 4096, sel);
 			launchExtend(stream, G->dev, G->devTables, G->devIupac, big, dWork, nWork, R->devBases, dResults, dRetryScratch, extendSlabBytes(big), dTrace, dCursors + 1, traceBudget, dCounters, EXT_OVERFLOW, retryLanes, sel);
+			if (nExtendPairs < 4) { HIP_CHECK(hipEventRecord(st->fragEv[2 * nExtendPairs + 1], stream)); nExtendPairs++; }
+		};
+		auto anchorsTimed = [&](const AnchorRounds& ar) {
+			if (nAnchorPairs < 4) HIP_CHECK(hipEventRecord(st->fragEv[8 + 2 * nAnchorPairs], stream));
+			launchBuildAnchors(stream, G->dev, dFrags, (uint32_t)nFrags, dFragSeeds, dResults, dTrace, P->split_len, dAnchors, dFragStatus, dFragExtended, dPathPool, dCursors + 2, pathCapacity, ar, dReadTies);
+			if (nAnchorPairs < 4) { HIP_CHECK(hipEventRecord(st->fragEv[8 + 2 * nAnchorPairs + 1], stream)); nAnchorPairs++; }
 		};
 		if (!lazyExtend) {
 			extendRound(ExtSelection());
 			mark();   // 3
-			launchBuildAnchors(stream, G->dev, dFrags, (uint32_t)nFrags, dFragSeeds, dResults, dTrace, P->split_len, dAnchors, dFragStatus, dFragExtended, dPathPool, dCursors + 2, pathCapacity, AnchorRounds(), dReadTies);
+			anchorsTimed(AnchorRounds());
 		} else {
 			uint32_t* dLists = st->extLists.reserve<uint32_t>(2ull * nWork);           // two work lists, used in turn
 			uint32_t* dPending = st->pendingFrags.reserve<uint32_t>(2ull * nFrags);     // two pending-fragment lists
@@ -1075,7 +1092,7 @@ struct BatchRun {
 				ar.nextList = dLists + (uint64_t)nxt * nWork; ar.nextListCount = dRoundCounts + 2 * nxt;
 				ar.nextPending = dPending + (uint64_t)nxt * nFrags; ar.nextPendingCount = dRoundCounts + 2 * nxt + 1;
 				ar.fragNext = dFragNext;
-				launchBuildAnchors(stream, G->dev, dFrags, (uint32_t)nFrags, dFragSeeds, dResults, dTrace, P->split_len, dAnchors, dFragStatus, dFragExtended, dPathPool, dCursors + 2, pathCapacity, ar, dReadTies);
+				anchorsTimed(ar);
 			}
 		}
 		mark();   // 4
@@ -1152,8 +1169,12 @@ struct BatchRun {
 		HIP_CHECK(hipMemcpyAsync(hSmall, dCursors, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		HIP_CHECK(hipMemcpyAsync(hSmall + 8, dCounters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
 		syncStream(stream);
-		res->kernel_us[1] = elapsedUs(2, 3);
-		res->kernel_us[2] = elapsedUs(3, 4);
+		{
+			auto pairUs = [&](int k) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, st->fragEv[2 * k], st->fragEv[2 * k + 1])); return (double)ms * 1000.0; };
+			res->kernel_us[1] = res->kernel_us[2] = 0;
+			for (uint32_t k = 0; k < nExtendPairs; k++) res->kernel_us[1] += pairUs((int)k);          // k_extend, all rounds (with their retry launches)
+			for (uint32_t k = 0; k < nAnchorPairs; k++) res->kernel_us[2] += pairUs(4 + (int)k);      // k_build_anchors, all rounds
+		}
 		res->kernel_us[3] = elapsedUs(4, 5);
 		for (int i = 0; i < 8; i++) res->counters[i] = hSmall[8 + i];
 		// (the cursors overshoot when a pool is full: the extensions / fragments that did not fit carry an overflow status and their reads are flagged)
@@ -1299,8 +1320,9 @@ struct BatchRun {
 			if (!longPostInThread) afterLongPass();
 			for (uint64_t r = 0; r < n; r++) if (glue[r].capacityExceededLong) glue[r].capacityExceeded = true;
 			if (P->keep_traces) {
-				LongCell* staged = st->hLongCells.reserve<LongCell>(hLongSmall[0]);
-				if (hLongSmall[0]) HIP_CHECK(hipMemcpyAsync(staged, dLongCells, hLongSmall[0] * sizeof(LongCell), hipMemcpyDeviceToHost, st->longStream));
+				const uint64_t cellsUsed = std::min<uint64_t>(hLongSmall[0], cellBudget);   // (the cursor counts refused requests too: a full pool leaves it beyond the pool's end)
+				LongCell* staged = st->hLongCells.reserve<LongCell>(cellsUsed);
+				if (cellsUsed) HIP_CHECK(hipMemcpyAsync(staged, dLongCells, cellsUsed * sizeof(LongCell), hipMemcpyDeviceToHost, st->longStream));
 				syncStream(st->longStream);
 				longCells = staged;
 			}

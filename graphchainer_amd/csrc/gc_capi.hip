@@ -364,6 +364,35 @@ int gc_gzip_streams(const uint8_t* bytes, const uint64_t* offsets, uint64_t n, c
 	});
 }
 
+// Test entry: the permutation the device's replay of libstdc++'s std::sort (hip/gc_stdsort_wave.hpp, what k_seed_glue runs for the reference's three order-critical unstable sorts)
+// gives for arrays of 32-bit keys: array s = keys[offsets[s] .. offsets[s + 1]), perm_out likewise - perm_out[offsets[s] + i] = the index (inside its array) of the element
+// that ends at place i. depth_limit < 0: the reference's 2 floor(log2 n); smaller values force the heapsort path.
+int gc_std_sort_permutations(const uint32_t* keys, const uint64_t* offsets, uint64_t n_arrays, int64_t depth_limit, uint32_t* perm_out)
+{
+	if (!offsets || !perm_out || (!keys && n_arrays && offsets[n_arrays] > 0)) return fail(GC_ERR_INVALID, "null argument");
+	return guarded([&]() {
+		requireDevice();
+		const uint64_t total = offsets[n_arrays];
+		if (n_arrays >= 0xffffffffull) throw std::runtime_error("too many arrays");
+		std::vector<unsigned long long> elems(total);
+		for (uint64_t s = 0; s < n_arrays; s++) {
+			if (offsets[s + 1] < offsets[s] || offsets[s + 1] - offsets[s] >= 0xffffffffull) throw std::runtime_error("bad offsets");
+			for (uint64_t i = offsets[s]; i < offsets[s + 1]; i++) elems[i] = ((unsigned long long)keys[i] << 32) | (i - offsets[s]);
+		}
+		DeviceBuffer dElems, dOff, dScratch;
+		unsigned long long* de = dElems.reserve<unsigned long long>(total);
+		uint64_t* dof = dOff.reserve<uint64_t>(n_arrays + 1);
+		uint32_t* ds = dScratch.reserve<uint32_t>(3 * total + 64 * n_arrays + 64);
+		if (total) HIP_CHECK(hipMemcpy(de, elems.data(), total * sizeof(unsigned long long), hipMemcpyHostToDevice));
+		HIP_CHECK(hipMemcpy(dof, offsets, (n_arrays + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+		launchTestStdSort(nullptr, de, dof, (uint32_t)n_arrays, ds, (long)depth_limit);
+		HIP_CHECK(hipDeviceSynchronize());
+		if (total) HIP_CHECK(hipMemcpy(elems.data(), de, total * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		for (uint64_t i = 0; i < total; i++) perm_out[i] = (uint32_t)elems[i];
+		return (int)GC_OK;
+	});
+}
+
 int gc_device_count(void)
 {
 	int n = 0;
@@ -766,6 +795,7 @@ int gc_stream_create(gc_stream** out)
 		createStream(&st->stream, 0);       // non-blocking: uploads of another batch on the null stream do not serialise with this one
 		createStream(&st->longStream, 0);
 		for (auto& e : st->ev) HIP_CHECK(hipEventCreate(&e));
+		for (auto& e : st->fragEv) HIP_CHECK(hipEventCreate(&e));
 		for (auto& e : st->longEv) HIP_CHECK(hipEventCreate(&e));
 		return (int)GC_OK;
 	});

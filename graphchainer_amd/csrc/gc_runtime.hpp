@@ -514,6 +514,7 @@ struct gc_stream {
 	int device = 0;             // the device the stream was created on; gc_align_batch selects it for the calling thread
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[12] {};
+	hipEvent_t fragEv[16] {};   // r5: a (begin, end) pair around each of the lazy rounds' k_extend launches [0..7] and k_build_anchors launches [8..15]: kernel_us[1] / [2] are sums of exactly those
 	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, readSeeds, fragFirstSeed, longRetryList, extLists, pendingFrags, fragNext, roundCounts, work, results, scratch, scratchRetry, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, readTies, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
 	PinnedBuffer hMatches, hReadSeeds, hFragFirstSeed, hFrags, hJobs, hAnchors, hFragStatus, hFragExtended, hReadTies, hChainOut, hChainLen, hChainScore, hChainStatus, hPathPool, hSmall;
 	// whole-read pass: runs on its own stream, concurrently with the fragment kernels
@@ -571,6 +572,7 @@ struct gc_stream {
 	~gc_stream()
 	{
 		for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+		for (auto& e : fragEv) if (e) (void)hipEventDestroy(e);
 		for (auto& e : longEv) if (e) (void)hipEventDestroy(e);
 		for (auto& e : groupEvents) if (e) (void)hipEventDestroy(e);
 		for (auto& q : groupStreams) if (q) (void)hipStreamDestroy(q);

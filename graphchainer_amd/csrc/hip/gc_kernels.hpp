@@ -104,7 +104,7 @@ struct GlueElem;
 struct GlueStaging {   // per-seed staging arrays (capacity: the sum over reads of their hits' occurrence counts), per-read window staging
 	uint32_t *mPos, *mStartLo, *mStartHi;                       // per hit (a read's hits use the first slots of its seed range)
 	uint32_t *sSeqPos, *sNode, *sOffset, *sGood, *sCluster;     // per seed, expansion order
-	GlueElem* sortBuf; uint32_t* posBuf;                        // sort arrays of reads beyond the LDS capacity
+	GlueElem* sortBuf; uint32_t* sortScratch;                   // reads beyond the LDS capacity: their sort array, and 3 words per seed occurrence + 64 per read for the wave sort's lists (gc_stdsort_wave.hpp) / the cluster sums
 	uint32_t* winBuf;                                           // (l, sl, sr, first slot) per window, at 4 * winCapOff[read]
 };
 
@@ -168,6 +168,8 @@ void launchSeedGlue(hipStream_t stream, const SeedIndex& idx, const DGraph& g, c
 	const uint32_t* readMatchCount, const uint32_t* readSeedOff, const uint32_t* winCapOff, double density, uint32_t splitLen, uint32_t splitGap, bool longPass, const GlueStaging& st,
 	uint32_t* perRead /* 6 x (nReads + 1) words of scratch */, LongSeed* longSeeds, FragSeed* readSeeds, Fragment* frags, uint32_t* fragFirstSeed, ReadChainJob* jobs, GlueRead* out, unsigned long long* cursors);
 uint64_t glueElemBytes();
+// test entry: arrays of (key << 32 | index) elements sorted by key with the wave-cooperative replay of std::sort (gc_stdsort_wave.hpp); scratch: 3 words per element + 64 per array
+void launchTestStdSort(hipStream_t stream, unsigned long long* elems, const uint64_t* off, uint32_t nArrays, uint32_t* scratch, long depthLimit);
 
 uint64_t extendSlabBytes(const ExtendConfig& cfg);
 uint32_t extendGridLanes(uint32_t nWork);

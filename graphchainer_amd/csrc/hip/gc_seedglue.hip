@@ -11,6 +11,7 @@
 // The sort's working array (16 B elements) lives in LDS for reads of up to GLUE_LDS_ELEMS seeds, in HBM beyond.
 #include "gc_kernels.hpp"
 #include "gc_stdsort.hpp"
+#include "gc_stdsort_wave.hpp"
 #include <climits>
 
 namespace gcdev {
@@ -84,6 +85,79 @@ __device__ __forceinline__ void glueWindows(Key key, uint32_t nS, uint32_t len, 
 	nFout = nF; slotsOut = slots; budgetOut = budget; widestOut = widest;
 }
 
+// The same windows by all lanes (r5). The two pointers of src/Aligner.cpp:672-679 do not depend on the window before: sr(l) = the seeds with key + matchLen <= l + splitLen - an upper
+// bound in the sorted keys - and sl(l) = min(sr(l), first seed with key >= l): the pointer sl only ever waits at sr, and what it waits for is monotone in l. So a lane takes a
+// fragment position, two binary searches give its window, and ballots / wave scans number the non-empty windows and their anchor slots in position order.
+template <class Key>
+__device__ __forceinline__ void glueWindowsWave(Key key, uint32_t nS, uint32_t len, uint32_t splitLen, uint32_t splitGap, uint32_t matchLen, uint32_t* win, uint32_t lane,
+	uint32_t& nFout, uint32_t& slotsOut, unsigned long long& budgetOut, uint32_t& widestOut)
+{
+	uint32_t nF = 0, slots = 0, widest = 0;
+	unsigned long long budget = 0;
+	const uint64_t nPos = len >= splitLen ? (uint64_t)(len - splitLen) / splitGap + 1 : 0;
+	for (uint64_t f0 = 0; f0 < nPos; f0 += 64) {
+		const uint64_t f = f0 + lane;
+		const uint64_t l = f * splitGap;
+		uint32_t sl = 0, sr = 0;
+		if (f < nPos) {
+			uint32_t lo = 0, hi = nS;   // first seed with key + matchLen > l + splitLen
+			while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)key(mid) + matchLen <= l + splitLen) lo = mid + 1; else hi = mid; }
+			sr = lo;
+			lo = 0; hi = sr;            // first seed with key >= l (not beyond sr)
+			while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)key(mid) < l) lo = mid + 1; else hi = mid; }
+			sl = lo;
+		}
+		const bool has = sl < sr;
+		const unsigned long long which = __ballot(has);
+		const uint32_t mine = sr - sl;
+		uint32_t incl = has ? mine : 0u;
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if ((int)lane >= d) incl += o; }
+		unsigned long long b = 0;
+		if (has) {
+			const uint32_t at = nF + (uint32_t)__popcll(which & ((1ull << lane) - 1ull));
+			win[4 * at] = (uint32_t)l; win[4 * at + 1] = sl; win[4 * at + 2] = sr; win[4 * at + 3] = slots + incl - mine;
+			for (uint32_t k = sl; k < sr; k++) {   // trace cells the two extensions of this seed may need: backward p rows, forward split_len - 1 - p (src/GraphAligner.h:499-511)
+				const uint32_t p = key(k) - (uint32_t)l, q = splitLen - 1 - p;
+				b += (p ? p + 24 : 0) + (q ? q + 24 : 0);
+			}
+		}
+		uint32_t w = has ? mine : 0u;
+		for (int d = 32; d > 0; d >>= 1) { b += __shfl_xor(b, d); const uint32_t o = __shfl_xor(w, d); w = o > w ? o : w; }
+		budget += b;
+		widest = w > widest ? w : widest;
+		slots += __shfl(incl, 63);
+		nF += (uint32_t)__popcll(which);
+	}
+	nFout = nF; slotsOut = slots; budgetOut = budget; widestOut = widest;
+}
+
+// addMinimizers' cut-off over the hits sorted by occurrence count (src/MinimizerSeeder.cpp:501-519): hit k is expanded unless seedsHere >= maxHits and its count is larger than
+// the previous hit's (`allowed`) - i.e. the list ends at the first k whose exclusive prefix sum of counts has reached maxHits and whose count exceeds its predecessor's (hit 0
+// exceeds the initial 0). All lanes: count(k) reads hit k's count, place(k, sum) notes where its seeds start; returns the kept hits and the seeds they expand to.
+template <class Count, class Place>
+__device__ __forceinline__ void glueDensityCut(uint32_t nM, uint64_t maxHits, uint32_t lane, Count count, Place place, uint32_t& keptOut, uint64_t& seedsOut)
+{
+	uint64_t running = 0;
+	uint32_t kept = nM, prevTail = 0;
+	for (uint32_t base = 0; base < nM; base += 64) {
+		const uint32_t k = base + lane;
+		const uint32_t cnt = k < nM ? count(k) : 0u;
+		uint64_t incl = cnt;
+		for (int d = 1; d < 64; d <<= 1) { const uint64_t o = __shfl_up(incl, d); if ((int)lane >= d) incl += o; }
+		const uint64_t before = running + incl - cnt;
+		uint32_t prev = __shfl_up(cnt, 1);
+		if (lane == 0) prev = prevTail;
+		const bool stop = k < nM && before >= maxHits && cnt > prev;
+		const unsigned long long stops = __ballot(stop);
+		const uint32_t firstStop = stops ? (uint32_t)__ffsll((unsigned long long)stops) - 1u : 64u;
+		if (k < nM && lane < firstStop) place(k, before);
+		if (stops) { kept = base + firstStop; running = __shfl(before, (int)firstStop); break; }
+		running += __shfl(incl, 63);
+		prevTail = __shfl(cnt, 63);
+	}
+	keptOut = kept; seedsOut = running;
+}
+
 // Two instantiations: GLUE_LDS_ELEMS = 1024 (24 KB of LDS, six blocks per CU) takes the reads whose seed bound fits it - every 10 kb read; the other one
 // (no LDS image, so as many blocks per CU as wave slots) takes the rest on HBM arrays (50 kb reads carry ~2 200 seeds). The serial sorts are bound by
 // the latency of a lane's dependent accesses, so what counts for the long reads is how many run at once: a 4096-element LDS image (96 KB, one block
@@ -106,6 +180,9 @@ __global__ void __launch_bounds__(64) k_seed_glue(SeedIndex idx, DGraph g, const
 	glue_lds_u32* const sSum = (glue_lds_u32*)&lds[4 * GLUE_LDS_ELEMS];
 	glue_lds_u32* const sCnt = (glue_lds_u32*)&lds[5 * GLUE_LDS_ELEMS];
 	glue_lds_u64* const s64 = (glue_lds_u64*)&lds[GLUE_LDS_ELEMS];
+	// scratch of the wave sort for the reads of the LDS image: [3] id, [4], [5] are dead whenever one of the three order-critical sorts runs (3 x GLUE_LDS_ELEMS words >= waveSortScratchWords)
+	uint32_t* const sortScratch = &lds[GLUE_LDS_ELEMS > 1 ? 3 * GLUE_LDS_ELEMS : 0];
+	static_assert(GLUE_LDS_ELEMS == 1 || 3 * GLUE_LDS_ELEMS >= 2 * GLUE_LDS_ELEMS + 12 * (GLUE_LDS_ELEMS / 17 + 4) + 8, "the wave sort's scratch must fit the three idle arrays");
 	const uint32_t lane = threadIdx.x;
 	const uint32_t matchLen = (uint32_t)idx.k;
 	for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
@@ -133,23 +210,15 @@ __global__ void __launch_bounds__(64) k_seed_glue(SeedIndex idx, DGraph g, const
 			}
 			__threadfence();
 			__syncthreads();
-			if (lane == 0) {
-				glue_lds_u64* a = s64;
-				gcsort::gcStdSort<uint64_t>(a, (long)nM, HiLess());   // "prefer less common minimizers": the reference's unstable sort by count (:497)
-				uint64_t seedsHere = 0; uint32_t allowed = 0, kept = 0;
-				for (uint32_t k = 0; k < nM; k++) {
-					const uint32_t cnt = (uint32_t)(s64[k] >> 32);
-					if (seedsHere >= maxHits && cnt > allowed) break;
-					allowed = cnt;
-					eK0[k] = (uint32_t)seedsHere;
-					seedsHere += cnt;
-					kept++;
-				}
-				shared[0] = kept; shared[1] = (uint32_t)seedsHere;
+			// "prefer less common minimizers": the reference's unstable sort by count (:497), replayed by the whole wave (gc_stdsort_wave.hpp; r3 / r4: lane 0 alone)
+			gcsort::gcStdSortWave<uint64_t>(s64, nM, HiLess(), sortScratch, lane);
+			uint32_t kept = 0;
+			{
+				uint64_t seedsHere = 0;
+				glueDensityCut(nM, maxHits, lane, [&](uint32_t k) { return (uint32_t)(s64[k] >> 32); }, [&](uint32_t k, uint64_t sum) { eK0[k] = (uint32_t)sum; }, kept, seedsHere);
+				nS = (uint32_t)seedsHere;
 			}
 			__syncthreads();
-			const uint32_t kept = shared[0];
-			nS = shared[1];
 			// ---- hit expansion (:509-516, matchToSeedHit :546-555)
 			for (uint32_t k = lane; k < kept; k += 64) {
 				const uint64_t e = s64[k];
@@ -226,11 +295,8 @@ __global__ void __launch_bounds__(64) k_seed_glue(SeedIndex idx, DGraph g, const
 					for (uint32_t s = lane; s < nS; s += 64) s64[s] = ((uint64_t)st.sGood[sOff + s] << 32) | s;
 					__syncthreads();
 					// ---- seeds by goodness, best first (:293-294): the unstable sort runs on the seeds in expansion order, then the list is reversed
-					if (lane == 0) {
-						glue_lds_u64* a = s64;
-						gcsort::gcStdSort<uint64_t>(a, (long)nS, HiLess());
-						for (uint32_t i = 0, j = nS - 1; i < j; i++, j--) { const uint64_t t = s64[i]; s64[i] = s64[j]; s64[j] = t; }
-					}
+					gcsort::gcStdSortWave<uint64_t>(s64, nS, HiLess(), sortScratch, lane);
+					for (uint32_t i = lane; i < nS / 2; i += 64) { const uint32_t j = nS - 1 - i; const uint64_t t = s64[i]; s64[i] = s64[j]; s64[j] = t; }
 					__syncthreads();
 					// the whole-read pass's seed list, and the next sort's keys (it runs on this order, src/Aligner.cpp:667)
 					for (uint32_t i = lane; i < nS; i += 64) {
@@ -244,22 +310,20 @@ __global__ void __launch_bounds__(64) k_seed_glue(SeedIndex idx, DGraph g, const
 						s64[i] = ((uint64_t)pos << 32) | id;
 					}
 					__syncthreads();
-					if (lane == 0) {
-						glue_lds_u64* a = s64;
-						gcsort::gcStdSort<uint64_t>(a, (long)nS, HiLess());   // seeds by read position, the reference's unstable sort (src/Aligner.cpp:667)
-					}
-					__syncthreads();
+					gcsort::gcStdSortWave<uint64_t>(s64, nS, HiLess(), sortScratch, lane);   // seeds by read position, the reference's unstable sort (src/Aligner.cpp:667)
 					for (uint32_t i = lane; i < nS; i += 64) {
 						const uint32_t s = sOff + (uint32_t)s64[i];
 						readSeeds[sOff + i] = FragSeed { st.sNode[s], st.sOffset[s], st.sSeqPos[s], st.sGood[s] };   // (pad carries the goodness: the seed_* result arrays)
 					}
-					if (lane == 0) glueWindows([&](uint32_t i) { return (uint32_t)(s64[i] >> 32); }, nS, len, splitLen, splitGap, matchLen, win, nF, slots, budget, widest);
+					glueWindowsWave([&](uint32_t i) { return (uint32_t)(s64[i] >> 32); }, nS, len, splitLen, splitGap, matchLen, win, lane, nF, slots, budget, widest);
 				}
 			}
 		} else if (nM > 0) {
-			// ================= a read with more seed occurrences than the LDS image holds: the same steps on HBM arrays (serial parts on lane 0)
+			// ================= a read with more seed occurrences than the LDS image holds: the same steps on HBM arrays. r5: the sorts run on the whole wave
+			// (gc_stdsort_wave.hpp), the density cut-off and the clusters are wave scans; r3 / r4 ran all of it on lane 0 (650 ms for the 18 000 seed occurrences of a 50 kb
+			// read on a 960 Mbp graph)
 			GlueElem* a = st.sortBuf + sOff;
-			uint32_t* posBuf = st.posBuf + sOff;
+			uint32_t* const scratch = st.sortScratch + 3ull * sOff + 64ull * r;   // waveSortScratchWords(cap) <= 3 cap + 64; between the sorts: cluster sums and sizes
 			for (uint32_t i = lane; i < nM; i += 64) {
 				const uint2 m = matches[mOff + i];
 				const uint64_t start = idx.startPos[m.y];
@@ -267,25 +331,17 @@ __global__ void __launch_bounds__(64) k_seed_glue(SeedIndex idx, DGraph g, const
 				a[i] = GlueElem { cnt, 0, 0, i };
 				st.mPos[sOff + i] = m.x; st.mStartLo[sOff + i] = (uint32_t)start; st.mStartHi[sOff + i] = (uint32_t)(start >> 32);
 			}
-			__threadfence();
+			__threadfence_block();
 			__syncthreads();
-			if (lane == 0) {
-				gcsort::gcStdSort<GlueElem>(a, (long)nM, ByK0());
-				uint64_t seedsHere = 0; uint32_t allowed = 0, kept = 0;
-				for (uint32_t k = 0; k < nM; k++) {
-					const uint32_t cnt = a[k].k0;
-					if (seedsHere >= maxHits && cnt > allowed) break;
-					allowed = cnt;
-					a[k].k1lo = (uint32_t)seedsHere;
-					seedsHere += cnt;
-					kept++;
-				}
-				shared[0] = kept; shared[1] = (uint32_t)seedsHere;
-				__threadfence();
+			gcsort::gcStdSortWave<GlueElem>(a, nM, ByK0(), scratch, lane);
+			uint32_t kept = 0;
+			{
+				uint64_t seedsHere = 0;
+				glueDensityCut(nM, maxHits, lane, [&](uint32_t k) { return a[k].k0; }, [&](uint32_t k, uint64_t sum) { a[k].k1lo = (uint32_t)sum; }, kept, seedsHere);
+				nS = (uint32_t)seedsHere;
 			}
+			__threadfence_block();
 			__syncthreads();
-			const uint32_t kept = shared[0];
-			nS = shared[1];
 			for (uint32_t k = lane; k < kept; k += 64) {
 				const GlueElem e = a[k];
 				const uint32_t mi = e.id, cnt = e.k0;
@@ -297,7 +353,7 @@ __global__ void __launch_bounds__(64) k_seed_glue(SeedIndex idx, DGraph g, const
 					st.sSeqPos[s] = pos; st.sNode[s] = (uint32_t)(p >> 6); st.sOffset[s] = (uint32_t)(p & 63); st.sGood[s] = idx.maxCount - cnt;
 				}
 			}
-			__threadfence();
+			__threadfence_block();
 			__syncthreads();
 			if (nS > 0) {
 				uint32_t bad = 0;
@@ -309,46 +365,63 @@ __global__ void __launch_bounds__(64) k_seed_glue(SeedIndex idx, DGraph g, const
 					a[s] = GlueElem { g.chainNumber[node], (uint32_t)diagonal, (uint32_t)(diagonal >> 32), s };
 				}
 				failed = __any(bad != 0);
-				__threadfence();
+				__threadfence_block();
 				__syncthreads();
 				if (!failed) {
-					if (lane == 0) {
-						gcsort::gcStdSort<GlueElem>(a, (long)nS, ByChainDiagonal());
-						uint32_t clusterStart = 0;
-						for (uint32_t i = 1; i <= nS; i++) {
-							if (i < nS) {
-								const GlueElem x = a[i], y = a[i - 1];
-								const uint64_t dx = (uint64_t)x.k1lo | ((uint64_t)x.k1hi << 32), dy = (uint64_t)y.k1lo | ((uint64_t)y.k1hi << 32);
-								if (x.k0 == y.k0 && dx <= dy + 100) continue;
-							}
-							const uint32_t size = i - clusterStart;
-							for (uint32_t j = 0; j < size; j++) posBuf[j] = st.sSeqPos[sOff + a[clusterStart + j].id];
-							gcsort::gcStdSort<uint32_t>(posBuf, (long)size, U32Less());
-							uint64_t matchingBps = 0;
-							int lastEnd = INT_MIN;
-							for (uint32_t j = 0; j < size; j++) {
-								const int thisStart = (int)posBuf[j] - (int)matchLen + 1, thisEnd = (int)posBuf[j];
-								matchingBps += (uint64_t)(thisEnd - (thisStart > lastEnd ? thisStart : lastEnd));
-								lastEnd = thisEnd;
-							}
-							for (uint32_t j = 0; j < size; j++) {
-								const uint32_t s = sOff + a[clusterStart + j].id;
-								st.sGood[s] = (uint32_t)(matchingBps + st.sGood[s]);
-								st.sCluster[s] = size < 65535 ? size : 65535;
-							}
-							clusterStart = i;
-						}
-						__threadfence();
+					// clusters (:263-292): same chain, neighbouring diagonals at most 100 apart. A cluster's goodness depends only on the multiset of its seeds' read positions, so
+					// any sort by (chain, diagonal) and any sort by (cluster, position) give the reference's values (the LDS path uses bitonic sorts for the same reason)
+					gcsort::gcStdSortWave<GlueElem>(a, nS, ByChainDiagonal(), scratch, lane);
+					uint32_t cidBefore = 0, tailChain = 0;
+					uint64_t tailDiag = 0;
+					for (uint32_t base = 0; base < nS; base += 64) {
+						const uint32_t i = base + lane;
+						GlueElem x = GlueElem { 0, 0, 0, 0 };
+						if (i < nS) x = a[i];
+						const uint64_t dx = (uint64_t)x.k1lo | ((uint64_t)x.k1hi << 32);
+						uint32_t pChain = __shfl_up(x.k0, 1);
+						uint64_t pDiag = __shfl_up(dx, 1);
+						if (lane == 0) { pChain = tailChain; pDiag = tailDiag; }
+						const bool opens = i < nS && i > 0 && !(x.k0 == pChain && dx <= pDiag + 100);
+						const unsigned long long opened = __ballot(opens);
+						const uint32_t cid = cidBefore + (uint32_t)__popcll(opened & ((2ull << lane) - 1ull));
+						tailChain = __shfl(x.k0, 63); tailDiag = __shfl(dx, 63);   // (before the elements are overwritten: the next 64 compare with this one's last)
+						if (i < nS) a[i] = GlueElem { cid, st.sSeqPos[sOff + x.id], 0, x.id };
+						cidBefore += (uint32_t)__popcll(opened);
 					}
+					const uint32_t nClusters = cidBefore + 1;
+					__threadfence_block();
+					__syncthreads();
+					gcsort::gcStdSortWave<GlueElem>(a, nS, ByChainDiagonal(), scratch, lane);   // by (cluster, read position)
+					uint32_t* const cSum = scratch;
+					uint32_t* const cCnt = scratch + nS;
+					for (uint32_t c = lane; c < nClusters; c += 64) { cSum[c] = 0; cCnt[c] = 0; }
+					__threadfence_block();
+					__syncthreads();
+					// a cluster's matching base pairs: a seed adds the part of its k-mer that the previous one (by position) does not cover (:270-284)
+					for (uint32_t i = lane; i < nS; i += 64) {
+						const GlueElem x = a[i];
+						uint32_t add = matchLen - 1;
+						if (i > 0) { const GlueElem y = a[i - 1]; if (y.k0 == x.k0) { const uint32_t d = x.k1lo - y.k1lo; add = d < add ? d : add; } }
+						atomicAdd(&cSum[x.k0], add);
+						atomicAdd(&cCnt[x.k0], 1u);
+					}
+					__threadfence_block();
+					__syncthreads();
+					for (uint32_t i = lane; i < nS; i += 64) {
+						const GlueElem x = a[i];
+						const uint32_t s = sOff + x.id, size = cCnt[x.k0];
+						st.sGood[s] = cSum[x.k0] + st.sGood[s];
+						st.sCluster[s] = size < 65535 ? size : 65535;
+					}
+					__threadfence_block();
 					__syncthreads();
 					for (uint32_t s = lane; s < nS; s += 64) a[s] = GlueElem { st.sGood[sOff + s], 0, 0, s };
-					__threadfence();
+					__threadfence_block();
 					__syncthreads();
-					if (lane == 0) {
-						gcsort::gcStdSort<GlueElem>(a, (long)nS, ByK0());
-						for (uint32_t i = 0, j = nS - 1; i < j; i++, j--) { const GlueElem t = a[i]; a[i] = a[j]; a[j] = t; }
-						__threadfence();
-					}
+					// ---- seeds by goodness, best first (:293-294): the unstable sort on the seeds in expansion order, then the list reversed
+					gcsort::gcStdSortWave<GlueElem>(a, nS, ByK0(), scratch, lane);
+					for (uint32_t i = lane; i < nS / 2; i += 64) { const uint32_t j = nS - 1 - i; const GlueElem t = a[i]; a[i] = a[j]; a[j] = t; }
+					__threadfence_block();
 					__syncthreads();
 					for (uint32_t i = lane; i < nS; i += 64) {
 						const uint32_t s = sOff + a[i].id;
@@ -359,15 +432,16 @@ __global__ void __launch_bounds__(64) k_seed_glue(SeedIndex idx, DGraph g, const
 						}
 						a[i].k0 = st.sSeqPos[s];
 					}
-					__threadfence();
+					__threadfence_block();
 					__syncthreads();
-					if (lane == 0) { gcsort::gcStdSort<GlueElem>(a, (long)nS, ByK0()); __threadfence(); }
-					__syncthreads();
+					gcsort::gcStdSortWave<GlueElem>(a, nS, ByK0(), scratch, lane);   // seeds by read position (src/Aligner.cpp:667)
 					for (uint32_t i = lane; i < nS; i += 64) {
 						const uint32_t s = sOff + a[i].id;
 						readSeeds[sOff + i] = FragSeed { st.sNode[s], st.sOffset[s], st.sSeqPos[s], st.sGood[s] };
 					}
-					if (lane == 0) glueWindows([&](uint32_t i) { return a[i].k0; }, nS, len, splitLen, splitGap, matchLen, win, nF, slots, budget, widest);
+					__threadfence_block();
+					__syncthreads();
+					glueWindowsWave([&](uint32_t i) { return a[i].k0; }, nS, len, splitLen, splitGap, matchLen, win, lane, nF, slots, budget, widest);
 				}
 			}
 		}
@@ -447,6 +521,32 @@ __global__ void __launch_bounds__(1024) k_exclusive_scan_u32(const uint32_t* __r
 	for (uint32_t i = b; i < e; i++) { out[i] = (uint32_t)(run > 0xffffffffull ? 0xffffffffull : run); run += in[i]; }
 }
 uint64_t glueElemBytes() { return sizeof(GlueElem); }
+
+// test entry (gc_std_sort_permutations): array s = elems[off[s] .. off[s + 1]) of (key << 32 | index) elements sorted by key alone with the wave sort, in place; one wave per array.
+// Arrays of up to 1024 elements are sorted in LDS (the seed glue's usual case), longer ones where they lie, in HBM.
+__global__ void __launch_bounds__(64) k_test_std_sort(unsigned long long* __restrict__ elems, const uint64_t* __restrict__ off, uint32_t nArrays, uint32_t* __restrict__ scratch, long depthLimit)
+{
+	__shared__ uint64_t image[1024];
+	__shared__ uint32_t ldsScratch[3 * 1024];
+	const uint32_t lane = threadIdx.x;
+	for (uint32_t s = blockIdx.x; s < nArrays; s += gridDim.x) {
+		const uint64_t b = off[s];
+		const uint32_t n = (uint32_t)(off[s + 1] - b);
+		__syncthreads();
+		if (n <= 1024) {
+			for (uint32_t i = lane; i < n; i += 64) image[i] = elems[b + i];
+			__syncthreads();
+			gcsort::gcStdSortWave<uint64_t>((glue_lds_u64*)&image[0], n, HiLess(), ldsScratch, lane, depthLimit);
+			for (uint32_t i = lane; i < n; i += 64) elems[b + i] = image[i];
+		} else {
+			gcsort::gcStdSortWave<uint64_t>((uint64_t*)(elems + b), n, HiLess(), scratch + 3ull * b + 64ull * s, lane, depthLimit);
+		}
+	}
+}
+void launchTestStdSort(hipStream_t stream, unsigned long long* elems, const uint64_t* off, uint32_t nArrays, uint32_t* scratch, long depthLimit)
+{
+	if (nArrays) hipLaunchKernelGGL(k_test_std_sort, dim3(nArrays < 4096 ? nArrays : 4096), dim3(64), 0, stream, elems, off, nArrays, scratch, depthLimit);
+}
 void launchSeedCaps(hipStream_t stream, const SeedIndex& idx, uint32_t nReads, const uint8_t* invalidRead, const uint2* matches, const uint32_t* readMatchOff, const uint32_t* readMatchCount,
 	uint32_t* readSeedCap, uint32_t* readSeedOff, unsigned long long* total)
 {

@@ -145,4 +145,69 @@ GC_SORT_FN void gcStdSort(A& a, long n, Less less, long depthLimit = -1)   // de
 	} else insertionSort<T>(a, 0, n, less);
 }
 
+// ---- the same sort as a set of INDEPENDENT steps (r5: what gc_stdsort_wave.hpp runs on the 64 lanes of a wave; kept here as plain C++ so that tests/stdsort can hold it
+// against the local libstdc++ permutation for permutation) --------------------------------------------------------------------------------------------------------
+// (1) __unguarded_partition as two lists. The loop  { while (a[lo] < pivot) ++lo; --hi; while (pivot < a[hi]) --hi; if (!(lo < hi)) return lo; swap; ++lo; }  never reads a
+//     position it has written: lo only moves right of its own swaps and stays left of hi's, hi the mirror image. So its stops are those of the ORIGINAL array: L = the indices
+//     in (first, last) with a[i] >= pivot, ascending; R = the indices in [first, last) with a[i] <= pivot, descending (a[first] is the pivot: the scan from the right stops there at
+//     the latest). Stop k of either side is swapped with stop k of the other while L[k] < R[k]; K = the number of such k (the condition is monotone). The scan that then runs on
+//     stops either at its own next stop or at the other side's last swapped position (which now holds an element of its kind), so cut = min(L[K], R[K - 1]) (a missing term = infinity).
+// (2) The ranges [cut, last) and [first, cut) are disjoint: any order of working them off gives the same array (the reference recurses into the right one and loops on the left).
+// (3) __final_insertion_sort over the whole array = an insertion sort of every leaf range (<= 16 elements, where introsort stops) on its own: every element of an earlier range
+//     is <= every element of a later one, and the insertion stops at the first element that is not greater.
+template <class T, class A, class Less>
+GC_SORT_FN long partitionByLists(A& a, long first, long last, Less less, long* listL, long* listR)   // pivot already at a[first]; returns the cut
+{
+	long nL = 0, nR = 0;
+	for (long i = first + 1; i < last; i++) if (!less(a[i], a[first])) listL[nL++] = i;
+	for (long i = last - 1; i >= first; i--) if (!less(a[first], a[i])) listR[nR++] = i;
+	long K = 0;
+	while (K < nL && K < nR && listL[K] < listR[K]) K++;
+	for (long k = 0; k < K; k++) { T t = a[listL[k]]; a[listL[k]] = a[listR[k]]; a[listR[k]] = t; }
+	long cut = -1;
+	if (K < nL) cut = listL[K];
+	if (K >= 1 && (cut < 0 || listR[K - 1] < cut)) cut = listR[K - 1];
+	return cut;
+}
+
+template <class T, class A, class Less>
+GC_SORT_FN void gcStdSortBySteps(A& a, long n, Less less, long* work /* 2 n + 3 (n / 16 + 2) words */, long depthLimit = -1)
+{
+	if (n <= 0) return;
+	if (n <= 16) { insertionSort<T>(a, 0, n, less); return; }
+	long depth0 = 0;
+	for (long m = n; m > 1; m >>= 1) depth0++;
+	depth0 *= 2;
+	if (depthLimit >= 0) depth0 = depthLimit;
+	long* listL = work; long* listR = work + n; long* ranges = work + 2 * n;   // pending ranges, three words each, worked off in ANY order (here: last in, first out)
+	long nRanges = 0;
+	ranges[0] = 0; ranges[1] = n; ranges[2] = depth0; nRanges = 1;
+	while (nRanges > 0) {
+		nRanges--;
+		const long first = ranges[3 * nRanges], last = ranges[3 * nRanges + 1];
+		long depth = ranges[3 * nRanges + 2];
+		if (depth == 0) { heapSort<T>(a, first, last, less); continue; }
+		--depth;
+		const long mid = first + (last - first) / 2;
+		{
+			const long ia = first + 1, ib = mid, ic = last - 1;
+			long pick;
+			if (less(a[ia], a[ib])) {
+				if (less(a[ib], a[ic])) pick = ib;
+				else if (less(a[ia], a[ic])) pick = ic;
+				else pick = ia;
+			} else if (less(a[ia], a[ic])) pick = ia;
+			else if (less(a[ib], a[ic])) pick = ic;
+			else pick = ib;
+			T t = a[first]; a[first] = a[pick]; a[pick] = t;
+		}
+		const long cut = partitionByLists<T>(a, first, last, less, listL, listR);
+		const long childFirst[2] = { cut, first }, childLast[2] = { last, cut };
+		for (int c = 0; c < 2; c++) {
+			if (childLast[c] - childFirst[c] > 16) { ranges[3 * nRanges] = childFirst[c]; ranges[3 * nRanges + 1] = childLast[c]; ranges[3 * nRanges + 2] = depth; nRanges++; }
+			else insertionSort<T>(a, childFirst[c], childLast[c], less);   // a leaf: its share of the final insertion pass
+		}
+	}
+}
+
 } // namespace gcsort

@@ -228,7 +228,8 @@ typedef struct gc_result {
 	uint64_t counters[8];
 	uint64_t counters_long[8];    /* the same for the whole-read pass */
 	/* device time of each kernel of this batch in microseconds (HIP events on the stream):
-	 * [0] seed lookup, [1] fragment extension, [2] anchor build, [3] chaining, [4] whole-read extension kernels, summed over all
+	 * [0] seed lookup, [1] fragment extension (k_extend: every lazy round's launches with their retry launches, each between an event pair of its own), [2] anchor build
+	 * (k_build_anchors, every round, likewise), [3] chaining, [4] whole-read extension kernels, summed over all
 	 * rounds of all read groups (the groups run concurrently on their own streams, so this can exceed the wall clock),
 	 * [5] whole-read pass wall clock, first group's start to last group's end (host clock; overlaps 1-3) */
 	double kernel_us[8];
@@ -338,6 +339,13 @@ int gc_format_gam_level(const gc_graph* g, const gc_result* result, const char* 
 /* The device deflate behind GC_GAM_DEVICE_HUFFMAN on the caller's own byte streams: stream i = bytes[offsets[i] .. offsets[i+1]) becomes the gzip member
  * out_bytes[out_offsets[i] .. out_offsets[i+1]) (out_offsets: n + 1 entries, caller's; out_bytes: gc_free). */
 int gc_gzip_streams(const uint8_t* bytes, const uint64_t* offsets, uint64_t n, char** out_bytes, uint64_t* out_offsets);
+
+/* Test entry (no counterpart in the reference): the permutation the device's replay of libstdc++'s std::sort gives for arrays of 32-bit keys. The reference feeds three UNSTABLE
+ * std::sort calls into order-sensitive logic (src/MinimizerSeeder.cpp:497, src/GraphAligner.h:293, src/Aligner.cpp:667), so the permutation libstdc++ produces for equal keys is
+ * part of its behaviour; the seed kernels replay that algorithm on the 64 lanes of a wave (csrc/hip/gc_stdsort_wave.hpp) and the tests hold this entry against the local std::sort.
+ * Array s = keys[offsets[s] .. offsets[s + 1]); perm_out[offsets[s] + i] = index inside its array of the element that ends at place i. depth_limit < 0: the reference's
+ * 2 floor(log2 n); a small value forces introsort's heapsort path. */
+int gc_std_sort_permutations(const uint32_t* keys, const uint64_t* offsets, uint64_t n_arrays, int64_t depth_limit, uint32_t* perm_out);
 
 int gc_device_count(void);
 int gc_set_device(int device);

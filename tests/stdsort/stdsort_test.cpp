@@ -22,6 +22,12 @@ int main() {
 		E* p = b.data();
 		gcsort::gcStdSort<E>(p, (long)n, [](const E& l, const E& r) { return l.key < r.key; });
 		for (int i = 0; i < n; i++) if (a[i].id != b[i].id) { printf("MISMATCH iter %d n %d mode %d at %d\n", iter, n, mode, i); return 1; }
+		// the same sort as independent steps (partition by stop lists, ranges in any order, leaf-wise insertion): what the wave-cooperative device sort runs
+		std::vector<E> c = v;
+		std::vector<long> work(2 * n + 3 * (n / 16 + 2) + 8);
+		E* q = c.data();
+		gcsort::gcStdSortBySteps<E>(q, (long)n, [](const E& l, const E& r) { return l.key < r.key; }, work.data());
+		for (int i = 0; i < n; i++) if (a[i].id != c[i].id) { printf("MISMATCH (by steps) iter %d n %d mode %d at %d\n", iter, n, mode, i); return 1; }
 		checked += n;
 	}
 	// a depth-limit case: median-of-three killer sequences are hard to make by hand; force the heapsort path through a tiny depth by sorting
@@ -34,6 +40,11 @@ int main() {
 		E* p = b.data();
 		gcsort::gcStdSort<E>(p, (long)n, [](const E& l, const E& r) { return l.key < r.key; });
 		for (int i = 0; i < n; i++) if (a[i].id != b[i].id) { printf("MISMATCH big n %d at %d\n", n, i); return 1; }
+		std::vector<E> c = v;
+		std::vector<long> work(2 * n + 3 * (n / 16 + 2) + 8);
+		E* q = c.data();
+		gcsort::gcStdSortBySteps<E>(q, (long)n, [](const E& l, const E& r) { return l.key < r.key; }, work.data());
+		for (int i = 0; i < n; i++) if (a[i].id != c[i].id) { printf("MISMATCH (by steps) big n %d at %d\n", n, i); return 1; }
 	}
 	for (int iter = 0; iter < 3000; iter++) {   // the heapsort path: libstdc++'s own internals with a small depth limit
 		int n = 17 + (int)(rng() % 2000);
@@ -47,6 +58,11 @@ int main() {
 		E* p = b.data();
 		gcsort::gcStdSort<E>(p, (long)n, cmp, depth);
 		for (int i = 0; i < n; i++) if (a[i].id != b[i].id) { printf("MISMATCH heap iter %d n %d depth %ld at %d\n", iter, n, depth, i); return 1; }
+		std::vector<E> c = v;
+		std::vector<long> work(2 * n + 3 * (n / 16 + 2) + 8);
+		E* q = c.data();
+		gcsort::gcStdSortBySteps<E>(q, (long)n, cmp, work.data(), depth);
+		for (int i = 0; i < n; i++) if (a[i].id != c[i].id) { printf("MISMATCH (by steps) heap iter %d n %d depth %ld at %d\n", iter, n, depth, i); return 1; }
 	}
 	printf("STDSORT_OK %ld elements\n", checked);
 	return 0;

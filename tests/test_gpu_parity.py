@@ -736,6 +736,44 @@ def test_shim_replays_the_reference_call_sequence(gca, tmp_path, golden_dir):
         assert [int(x) for x in chain.split()] == [int(c) for c in res["chain"][int(res["read_chain_off"][r]):int(res["read_chain_off"][r + 1])]] and n_chain == len(chain.split())
 
 
+def test_single_process_two_devices_four_streams(gca, tmp_path):
+    """the reference is ONE process with -t worker threads (src/Aligner.cpp:1267-1270); on a node with several GPUs that is a worker thread per gc_stream, a
+    replica of the graph per device (gc_set_device + gc_index_load on the device's first thread) and one shared atomic batch cursor - tests/multigpu/multi_gpu_host.cpp, C ABI only.
+    Here: two LOGICAL devices (both on the box's one GPU: two gc_graph handles in one process) x two threads each, batches of 7 reads; every read's anchors, chain, chain score,
+    whole-read alignments, both NW distances, decision and tie counts equal the oracle's, and both devices took batches."""
+    import subprocess
+    import sys
+    from graphchainer_amd.synth import SynthGraph
+    from oracle import Oracle
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_library_exports import _build_multi_gpu_host
+    exe = _build_multi_gpu_host(tmp_path)
+    sg = SynthGraph(200_000, seed=21)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(60, 3000, seed=5) + sg.sample_reads(10, 6000, seed=6, sv_fraction=0.5)
+    with open(tmp_path / "reads.txt", "wb") as f:
+        f.write(b"\n".join(reads) + b"\n")
+    out = subprocess.run([exe, gfa, str(tmp_path / "reads.txt"), "2", "2", "7"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == len(reads) + 1
+    want = Oracle(gfa, long_pass=True).align(reads)
+    for r, line in enumerate(lines[:-1]):
+        f = line.split()
+        assert f[0] == "read" and int(f[1]) == r
+        chain = want["chain"][int(want["read_chain_off"][r]):int(want["read_chain_off"][r + 1])]
+        h = 0
+        for c in chain:
+            h = (h * 1000003 + int(c) + 1) % (1 << 64)
+        expected = [int(want["read_anchor_off"][r + 1] - want["read_anchor_off"][r]), len(chain), h, int(want["chain_score"][r]), int(want["read_longall_off"][r + 1] - want["read_longall_off"][r]),
+                    int(want["long_edit_distance"][r]), int(want["chain_edit_distance"][r]), int(want["chained_better"][r]), int(want["flatten_ties"][r]), int(want["flatten_ties_long"][r])]
+        got = [int(f[3]), int(f[5]), int(f[6]), int(f[8]), int(f[10]), int(f[12]), int(f[13]), int(f[15]), int(f[17]), int(f[18])]
+        assert got == expected, (r, line)
+    per_device = [int(x) for x in lines[-1].split()[1:]]
+    assert sum(per_device) == 10 and all(x > 0 for x in per_device), per_device
+
+
 def _path_pairs(rng):
     """(path letters, read) shapes the chained alignment meets: similar strings, a path covering only part of the read, a path
     with a stretch the read lacks, unrelated strings, repeats (many optimal alignments), other letters, tiny / empty sides,
@@ -940,6 +978,51 @@ def test_output_against_golden_files(gca, golden_dir):
     for mode, merge in ((1, True), (2, False)):
         with pytest.raises(RuntimeError, match="cigar_match_mismatch_merge"):
             gca.Aligner(graph, seeder, long_pass=True, device_output=mode).align_reads(reads, gaf_names=names, cigar_match_mismatch_merge=merge)
+
+
+def test_wave_sort_gives_libstdcxx_permutations(gca, tmp_path):
+    """r5: the reference's three order-critical UNSTABLE std::sort calls (matches by count, seeds by goodness, seeds by read position) are replayed on the 64 lanes of a wave
+    (csrc/hip/gc_stdsort_wave.hpp: stop-list partitions by the whole wave, independent ranges on one lane each, leaf-wise insertion) instead of on lane 0. Through the test
+    entry gc_std_sort_permutations: the permutation equals the REAL std::sort's (tests/stdsort/std_sort_perm.cpp, built here with the local g++) on keys with many ties, saw-tooth
+    and organ-pipe inputs, sizes on both sides of the LDS image (1 024) and of the cooperative threshold, and with small depth limits (introsort's heapsort path against
+    libstdc++'s own __introsort_loop is the CPU test's part: tests/stdsort/stdsort_test.cpp checks the same decomposition step for step)."""
+    import ctypes
+    import subprocess
+    so = str(tmp_path / "libstd_sort_perm.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(os.path.dirname(os.path.abspath(__file__)), "stdsort", "std_sort_perm.cpp")])
+    ref = ctypes.CDLL(so)
+    ref.std_sort_perm.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+
+    def reference(keys):
+        k = np.ascontiguousarray(keys, dtype=np.uint64)
+        perm = np.zeros(len(k), dtype=np.int64)
+        ref.std_sort_perm(k.ctypes.data, len(k), perm.ctypes.data)
+        return perm
+
+    rng = np.random.default_rng(9)
+    arrays = []
+    for n in list(range(0, 40)) + [63, 64, 65, 255, 256, 257, 258, 511, 700, 1023, 1024, 1025, 1500, 4097, 18_000, 70_000]:
+        for mode in range(6):
+            if mode == 0:
+                k = np.ones(n)
+            elif mode == 1:
+                k = rng.integers(0, 3, n)
+            elif mode == 2:
+                k = rng.integers(0, 50, n)
+            elif mode == 3:
+                k = rng.integers(0, 2**32, n)
+            elif mode == 4:
+                k = np.arange(n) // 7
+            else:
+                k = np.minimum(np.arange(n), n - np.arange(n))          # organ pipe
+            arrays.append(k.astype(np.uint32))
+    for n in (5000, 20000):
+        i = np.arange(n)
+        arrays.append(np.where(i % 2 == 1, i, n - i).astype(np.uint32))   # saw-tooth: bad pivots, deep recursion
+    got = gca.std_sort_permutations(arrays)
+    for k, g in zip(arrays, got):
+        want = reference(k)
+        assert np.array_equal(g.astype(np.int64), want), (len(k), int(np.flatnonzero(g != want)[0]) if len(k) else -1)
 
 
 def test_fragment_pools_sized_by_use_rerun_when_too_small(gca, tmp_path, monkeypatch):

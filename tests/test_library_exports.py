@@ -70,3 +70,27 @@ def test_shim_header_compiles_against_the_reference_type_names(tmp_path):
         pytest.skip("a GPU is present: the gpu test runs the program")
     out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "ref_test_graph.gfa"), "ACGTACGT"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip() == "NO_DEVICE", out.stdout + out.stderr
+
+
+def _build_multi_gpu_host(tmp_path):
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "multi_gpu_host")
+    lib_dir = os.path.join(ROOT, "graphchainer_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "tests", "multigpu", "multi_gpu_host.cpp"),
+                           "-L" + lib_dir, "-lgraphchainer_amd", "-lpthread", "-Wl,-rpath," + lib_dir])
+    return exe
+
+
+def test_single_process_multi_gpu_host_builds_and_refuses_to_run_without_a_gpu(tmp_path):
+    """tests/multigpu/multi_gpu_host.cpp (one process, a worker thread per stream, a replica of the graph per device, one atomic batch cursor) builds against
+    the C ABI alone; without a GPU it says so and stops (no CPU fallback). The GPU test runs it with two logical devices and compares with the oracle."""
+    import subprocess
+    import graphchainer_amd as gca
+    exe = _build_multi_gpu_host(tmp_path)
+    if gca.device_count() > 0:
+        pytest.skip("a GPU is present: the gpu test runs the program")
+    out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "syn20k.gfa"), os.path.join(ROOT, "tests", "golden", "syn20k.fa"), "2", "2", "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "NO_DEVICE", out.stdout + out.stderr
