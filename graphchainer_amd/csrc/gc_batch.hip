@@ -1096,7 +1096,10 @@ struct BatchRun {
 			}
 		}
 		mark();   // 4
-		launchChain(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, P->split_len, P->split_gap, caps, dChainScratch, dChainOut, dChainLen, dChainScore, dChainStatus, getenv("GC_CHAIN_FORCE_SCRATCH") != nullptr);
+		uint32_t fewestSlots = 0xffffffffu;
+		for (uint64_t r = 0; r < n; r++) fewestSlots = std::min(fewestSlots, jobs[r].nSlots);
+		launchChain(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, P->split_len, P->split_gap, caps, dChainScratch, dChainOut, dChainLen, dChainScore, dChainStatus, getenv("GC_CHAIN_FORCE_SCRATCH") != nullptr,
+			n ? fewestSlots : 0u);
 		mark();   // 5
 		// chain stitching (src/Aligner.cpp:754-822) on the device, right behind the chaining kernel; GC_HOST_STITCH=1 keeps it on the
 		// host workers (the path also taken by reads that do not fit the kernel's tables)
@@ -1280,6 +1283,11 @@ struct BatchRun {
 			launchEditDistances(st->edChainRun, stream, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen, readLenOf);
 			finishChainEditDistances = [=, &pairRead]() {   // waits for the kernels (they run beside the whole-read pass) and reruns the few pairs that need a wider band
 				finishEditDistances(st->edChainRun, stream, hPairs, hOut, nPairs, dPairs, dOut, R->devEdReads, R->devBases, R->devEqMasks, dLetters, dLettersLen);
+				if (getenv("GC_DEBUG_ED")) for (uint32_t i = 0; i < nPairs && i < 400; i++) {
+					const uint32_t r = pairRead[i];
+					fprintf(stderr, "[gc ed] read %u len %llu path %llu chain %u scoreSum %u onDevice %d distance %lld\n", r, (unsigned long long)(R->offsets[r + 1] - R->offsets[r]), (unsigned long long)glue[r].stitched.cells,
+						chainLen[r], deviceStitch ? stitchInfo[r].scoreSum : 0u, (int)glue[r].stitchedOnDevice, (long long)hOut[i]);
+				}
 				for (uint32_t i = 0; i < nPairs; i++) {
 					ReadGlue& gl = glue[pairRead[i]];
 					gl.chainEditDistance = hOut[i];

@@ -143,12 +143,18 @@ inline void syncStream(hipStream_t q)
 	static const int mode = getenv("GC_SPIN_SYNC") ? atoi(getenv("GC_SPIN_SYNC")) : 2;
 	if (mode == 1) { HIP_CHECK(hipStreamSynchronize(q)); return; }
 	if (mode == 2) {
+		// r5: the sleep between polls backs off from 40 us (GC_SYNC_POLL_US) to four times that once a wait has lasted a millisecond: a batch's threads wait ~1 s in all per 150 ms
+		// step, mostly for kernels of tens of milliseconds, and every poll is a runtime call and a nanosleep
 		static const int pollUs = getenv("GC_SYNC_POLL_US") ? std::max(1, atoi(getenv("GC_SYNC_POLL_US"))) : 40;
+		int sleepUs = pollUs;
 		for (int spins = 0;; spins++) {
 			const hipError_t e = hipStreamQuery(q);
 			if (e == hipSuccess) return;
 			if (e != hipErrorNotReady) HIP_CHECK(e);
-			if (spins >= 4) std::this_thread::sleep_for(std::chrono::microseconds(pollUs));   // (the first few polls back to back: many waits are for kernels of a few microseconds)
+			if (spins >= 4) {   // (the first few polls back to back: many waits are for kernels of a few microseconds)
+				std::this_thread::sleep_for(std::chrono::microseconds(sleepUs));
+				if (spins >= 12 && sleepUs < 4 * pollUs) sleepUs += sleepUs / 4 + 1;
+			}
 		}
 	}
 	// one blocking-sync event per device this thread has waited on, destroyed with the thread (the whole-read pass threads live for one batch)
@@ -166,11 +172,15 @@ inline void syncStream(hipStream_t q)
 inline void syncEvent(hipEvent_t ev)
 {
 	static const int pollUs = getenv("GC_SYNC_POLL_US") ? std::max(1, atoi(getenv("GC_SYNC_POLL_US"))) : 40;
+	int sleepUs = pollUs;
 	for (int spins = 0;; spins++) {
 		const hipError_t e = hipEventQuery(ev);
 		if (e == hipSuccess) return;
 		if (e != hipErrorNotReady) HIP_CHECK(e);
-		if (spins >= 4) std::this_thread::sleep_for(std::chrono::microseconds(pollUs));
+		if (spins >= 4) {
+			std::this_thread::sleep_for(std::chrono::microseconds(sleepUs));
+			if (spins >= 12 && sleepUs < 4 * pollUs) sleepUs += sleepUs / 4 + 1;
+		}
 	}
 }
 

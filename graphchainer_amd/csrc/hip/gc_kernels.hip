@@ -502,6 +502,7 @@ struct ChainArrays {   // one read's working set: LDS (template LDS) or this blo
 	uint16_t* aFrag; uint16_t* aComp; uint16_t* entBegin; uint32_t* backBegin;
 	ChainEntry* ent; uint2* back; int32_t* thr;   // back: the anchors' threshold lists (path, position), always in this block's HBM scratch (a wide cover makes them long)
 	ChainEntry* entByComp; uint16_t* aBucket; uint16_t* entByCompBegin;   // scratch launch only (r4): the entries grouped by weakly connected component, see CHAIN_BUCKETS
+	uint16_t* anchorByBucket;                                              // ... and (r5) the anchors grouped the same way, in anchor order inside a bucket
 };
 // r4, the scratch launch (reads with more anchors than the LDS classes hold - every 50 kb read): an anchor is only ever chained to anchors of its own weakly connected component, but the scan
 // above visits the entries of ALL earlier anchors and drops the others one by one. On a 1 Gbp graph a 15-mer has a chance hit somewhere in the genome as often as not: a 50 kb read brings ~10 000
@@ -526,6 +527,7 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 	__shared__ ChainEntry sEnt[LDS ? LDS_ENTRIES : 1];
 	__shared__ int32_t sThr[LDS ? LDS_WIDTH : 1];
 	__shared__ uint32_t bKey[LDS ? 1 : CHAIN_BUCKETS], bStart[LDS ? 1 : CHAIN_BUCKETS + 1], bFilled[LDS ? 1 : CHAIN_BUCKETS], bUsed;   // bucket -> component, first entry, entries of earlier fragments
+	__shared__ uint32_t bAnchors[LDS ? 1 : CHAIN_BUCKETS], bAnchorStart[LDS ? 1 : CHAIN_BUCKETS + 1], bAnchorsPlaced[LDS ? 1 : CHAIN_BUCKETS];   // (r5) anchors per bucket, and where the bucket's anchors begin in anchorByBucket
 	constexpr uint32_t SCRATCH_THR = 2048;
 	__shared__ int32_t sThrScratch[LDS ? 1 : SCRATCH_THR];   // (r5) the scratch launch's threshold table stays in LDS whenever the graph's widest path cover fits: it is scattered into, read per scanned entry and cleared for every anchor
 	const int lane = threadIdx.x;
@@ -550,6 +552,7 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 		A.entBegin = (uint16_t*)base; base += 2ull * (capA + 1);
 		A.aBucket = (uint16_t*)base; base += 2ull * (capA + 1);
 		A.entByCompBegin = (uint16_t*)base; base += 2ull * (capA + 1);
+		A.anchorByBucket = (uint16_t*)base; base += 2ull * (capA + 1);
 		base = (uint8_t*)(((uintptr_t)base + 7) & ~(uintptr_t)7);
 		A.entByComp = (ChainEntry*)base;
 	}
@@ -557,7 +560,9 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 	__syncthreads();
 	for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
 		ReadChainJob job = jobs[r];
-		if (!LDS && chainStatus[r] != CHAIN_NEEDS_SCRATCH) continue;   // second launch: only the reads the LDS launch passed on
+		if (!LDS && !(forceScratch & 4u) && chainStatus[r] != CHAIN_NEEDS_SCRATCH) continue;   // second launch: only the reads the LDS launch passed on (bit 2: there was no LDS launch - every read)
+		// (r5) a read with more than twice the class's anchors in SLOTS is sent on without a look at its anchors: routing only - the scratch launch takes any read
+		if (LDS && job.nSlots > 2 * LDS_ANCHORS) { if (lane == 0) { chainStatus[r] = CHAIN_NEEDS_SCRATCH; chainLen[r] = 0; chainScore[r] = 0; } continue; }
 		// the reference never resets its `cont` flag after a fragment whose extension threw, so fragments after the
 		// first failed one contribute no anchors (src/Aligner.cpp:695-703): slots from that fragment on are cut off
 		uint32_t cut = job.nSlots;
@@ -615,7 +620,7 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 		__syncthreads();
 		bool bucketed = false;
 		if (LDS == 0) {
-			for (uint32_t b = lane; b < CHAIN_BUCKETS; b += 64) { bKey[b] = 0xffffffffu; bStart[b] = 0; bFilled[b] = 0; }
+			for (uint32_t b = lane; b < CHAIN_BUCKETS; b += 64) { bKey[b] = 0xffffffffu; bStart[b] = 0; bFilled[b] = 0; bAnchors[b] = 0; bAnchorsPlaced[b] = 0; }
 			if (lane == 0) { bUsed = 0; bStart[CHAIN_BUCKETS] = 0; }
 			__syncthreads();
 			// component -> bucket (the slot its id hashes to), entries per bucket
@@ -629,18 +634,19 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 				}
 				A.aBucket[a] = (uint16_t)slot;
 				atomicAdd(&bStart[slot], (uint32_t)A.entBegin[a + 1] - (uint32_t)A.entBegin[a]);
+				atomicAdd(&bAnchors[slot], 1u);
 			}
 			__syncthreads();
 			bucketed = bUsed <= CHAIN_BUCKETS / 2 && !(forceScratch & 2u);   // (beyond that the probing may have wrapped: plain scan; bit 1 of forceScratch: test hook, plain scan)
 			if (bucketed) {
 				// exclusive scan of the counts (one wave, eight buckets per lane), then every anchor's place in its bucket in anchor order - lane 0, one pass
-				uint32_t mine[CHAIN_BUCKETS / 64], sum = 0;
-				for (uint32_t k = 0; k < CHAIN_BUCKETS / 64; k++) { mine[k] = bStart[lane * (CHAIN_BUCKETS / 64) + k]; sum += mine[k]; }
-				uint32_t incl = sum;
-				for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-				uint32_t at = incl - sum;
+				uint32_t mine[CHAIN_BUCKETS / 64], sum = 0, mineA[CHAIN_BUCKETS / 64], sumA = 0;
+				for (uint32_t k = 0; k < CHAIN_BUCKETS / 64; k++) { mine[k] = bStart[lane * (CHAIN_BUCKETS / 64) + k]; sum += mine[k]; mineA[k] = bAnchors[lane * (CHAIN_BUCKETS / 64) + k]; sumA += mineA[k]; }
+				uint32_t incl = sum, inclA = sumA;
+				for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d), oa = __shfl_up(inclA, d); if (lane >= d) { incl += o; inclA += oa; } }
+				uint32_t at = incl - sum, atA = inclA - sumA;
 				__syncthreads();
-				for (uint32_t k = 0; k < CHAIN_BUCKETS / 64; k++) { bStart[lane * (CHAIN_BUCKETS / 64) + k] = at; at += mine[k]; }
+				for (uint32_t k = 0; k < CHAIN_BUCKETS / 64; k++) { bStart[lane * (CHAIN_BUCKETS / 64) + k] = at; at += mine[k]; bAnchorStart[lane * (CHAIN_BUCKETS / 64) + k] = atA; atA += mineA[k]; }
 				__syncthreads();
 				// every anchor's place in its bucket, in anchor order (r5: 64 anchors at a time - a lane adds up the entries of the chunk's earlier anchors that share its bucket from
 				// the other lanes' registers, the buckets' fill counts advance by LDS atomics between chunks; r4 walked the read's ~10 000 anchors on lane 0 through its HBM scratch)
@@ -649,11 +655,14 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 					const bool have = a < nA;
 					const uint32_t slot = have ? (uint32_t)A.aBucket[a] : 0xffffffffu;
 					const uint32_t cnt = have ? (uint32_t)A.entBegin[a + 1] - (uint32_t)A.entBegin[a] : 0u;
-					uint32_t before = 0;
-					for (int l = 0; l < 63; l++) { const uint32_t s = __shfl(slot, l), c = __shfl(cnt, l); if (l < lane && s == slot) before += c; }
-					if (have) A.entByCompBegin[a] = (uint16_t)(bStart[slot] + bFilled[slot] + before);
+					uint32_t before = 0, anchorsBefore = 0;
+					for (int l = 0; l < 63; l++) { const uint32_t s = __shfl(slot, l), c = __shfl(cnt, l); if (l < lane && s == slot) { before += c; anchorsBefore++; } }
+					if (have) {
+						A.entByCompBegin[a] = (uint16_t)(bStart[slot] + bFilled[slot] + before);
+						A.anchorByBucket[bAnchorStart[slot] + bAnchorsPlaced[slot] + anchorsBefore] = (uint16_t)a;
+					}
 					__syncthreads();
-					if (have && cnt) atomicAdd(&bFilled[slot], cnt);
+					if (have) { if (cnt) atomicAdd(&bFilled[slot], cnt); atomicAdd(&bAnchorsPlaced[slot], 1u); }
 					__syncthreads();
 				}
 				for (uint32_t b = lane; b < CHAIN_BUCKETS; b += 64) bFilled[b] = 0;
@@ -666,21 +675,12 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 		// anchors are ordered by fragment; g0 = first anchor of j's fragment, the entries of anchors < g0 are a prefix. The threshold lists
 		// of consecutive anchors are consecutive in `back`: a 64-item window of them is kept in registers (item w0 + lane), refilled with one
 		// coalesced load when an anchor's list runs past it - the only global access of the DP loop, a few times per hundred anchors on a narrow cover.
-		uint32_t g0 = 0, entPrefix = 0;
 		uint32_t w0 = 0;
 		uint2 win = (uint32_t)lane < nB ? A.back[lane] : make_uint2(0, 0);
-		for (uint32_t j = 0; j < nA; j++) {
-			const uint32_t fj = A.aFrag[j];
-			if (j > 0 && fj != A.aFrag[j - 1]) {
-				if (LDS == 0 && bucketed) for (uint32_t a = g0 + lane; a < j; a += 64) atomicAdd(&bFilled[A.aBucket[a]], (uint32_t)A.entBegin[a + 1] - (uint32_t)A.entBegin[a]);   // the fragment that just ended joins its buckets' prefixes
-				g0 = j; entPrefix = A.entBegin[j]; __syncthreads();   // C of the previous fragment's anchors is now final and visible
-			}
-			if (g0 == 0) continue;
-			// (r5) nothing of j's component lies in an earlier fragment: C[j] stays the anchor's own length - on a genome-sized graph most of a long read's anchors are such strays
-			// (chance minimizer hits on other chromosomes), and each used to pay the threshold scatter, three barriers and their round trips to the scratch
-			if (LDS == 0 && bucketed && bFilled[A.aBucket[j]] == 0) continue;
+		// one anchor's step: thr[k] = the last position on path k that may precede start(j) (its threshold list scattered into the table), the scan of the entries
+		// [scanBegin, scanEnd) - earlier fragments' anchors - the wave maximum into C[j], the table cleared again. sameComponent: the entries are j's component's already
+		auto relax = [&](uint32_t j, uint32_t fj, const ChainEntry* entries, uint32_t scanBegin, uint32_t scanEnd, bool sameComponent) {
 			const uint32_t b0 = A.backBegin[j], b1 = A.backBegin[j + 1];
-			// thr[k] = last position on path k that may precede start(j)
 			if (b1 <= w0 + 64 || (b1 - b0 <= 64 && (w0 = b0, win = b0 + lane < nB ? A.back[b0 + lane] : make_uint2(0, 0), true))) {
 				const uint32_t t = w0 + lane;
 				if (t >= b0 && t < b1) atomicMax(&A.thr[win.x], (int32_t)win.y);
@@ -691,13 +691,10 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 			const uint32_t compV = A.aComp[j];
 			const long long xj = (long long)fj * splitGap, yj = xj + splitLen - 1;
 			unsigned long long best = 0;
-			const ChainEntry* entries = A.ent;
-			uint32_t scanBegin = 0, scanEnd = entPrefix;
-			if (LDS == 0 && bucketed) { const uint32_t slot = A.aBucket[j]; entries = A.entByComp; scanBegin = bStart[slot]; scanEnd = scanBegin + bFilled[slot]; }
 			for (uint32_t e = scanBegin + lane; e < scanEnd; e += 64) {
 				const ChainEntry en = entries[e];
 				const uint32_t i = en.anchor;
-				if (A.aComp[i] != compV || (int32_t)en.pos > A.thr[en.k]) continue;   // (path ids are per component)
+				if ((!sameComponent && A.aComp[i] != compV) || (int32_t)en.pos > A.thr[en.k]) continue;   // (path ids are per component)
 				const long long yi = (long long)A.aFrag[i] * splitGap + splitLen - 1;
 				const long long ci = unpackScore(A.C[i]);
 				unsigned long long cand;
@@ -717,18 +714,71 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 			} else {
 				for (uint32_t t = b0 + lane; t < b1; t += 64) A.thr[A.back[t].x] = -1;
 			}
-		}
-		__syncthreads();
+		};
 		// The read's chain (:1713-1733, :1847-1862): per component the lexicographic maximum of (coverage, anchor index); over the components, visited in ascending id, the first
-		// strictly greater coverage - i.e. the largest coverage, among equals the smallest component id, inside it the largest anchor index: ONE wave maximum over the anchors of
+		// strictly greater coverage - i.e. the largest coverage, among equals the smallest component id, inside it the largest anchor index: a wave maximum over the anchors of
 		// coverage << 32 | (65535 - component) << 16 | anchor (r5; r4 let lane 0 walk all anchors twice per component - a million loads from the scratch for a 50 kb read that
-		// touches fifty components, most of the kernel's time on a genome-sized graph)
+		// touches fifty components)
 		unsigned long long top = 0;
-		for (uint32_t a = lane; a < nA; a += 64) {
-			const unsigned long long key = ((unsigned long long)unpackScore(A.C[a]) << 32) | ((unsigned long long)(65535u - (uint32_t)A.aComp[a]) << 16) | a;
-			top = key > top ? key : top;
+		auto topOver = [&](uint32_t count, auto anchorAt) {
+			unsigned long long mine = 0;
+			for (uint32_t q = lane; q < count; q += 64) {
+				const uint32_t a = anchorAt(q);
+				const unsigned long long key = ((unsigned long long)unpackScore(A.C[a]) << 32) | ((unsigned long long)(65535u - (uint32_t)A.aComp[a]) << 16) | a;
+				mine = key > mine ? key : mine;
+			}
+			for (int d = 32; d > 0; d >>= 1) { const unsigned long long o = __shfl_xor(mine, d); mine = o > mine ? o : mine; }
+			top = mine > top ? mine : top;
+		};
+		if (LDS == 0 && bucketed) {
+			// r5: component by component, the one with the most anchors first - and only while a component can still win: an anchor adds at most splitLen to a chain's coverage, so a
+			// bucket of c anchors cannot reach more than c x splitLen. On a genome-sized graph a 50 kb read brings ~10 000 anchors of which ~1 400 lie where it comes from; the strays
+			// on the other chromosomes' components (a few hundred each) never come near that component's coverage and used to cost six sevenths of the kernel. What is skipped has no
+			// part in the result: the chain and its coverage are the winner's, C of the other components is never output.
+			while (true) {
+				uint32_t pick = 0;   // anchors << 10 | (1023 - slot): the fullest bucket not yet done, the lowest slot among equals
+				for (uint32_t k = 0; k < CHAIN_BUCKETS / 64; k++) { const uint32_t slot = lane * (CHAIN_BUCKETS / 64) + k, c = bAnchors[slot]; const uint32_t key = c ? (c << 10) | (1023u - slot) : 0u; pick = key > pick ? key : pick; }
+				for (int d = 32; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(pick, d); pick = o > pick ? o : pick; }
+				const uint32_t count = pick >> 10, slot = 1023u - (pick & 1023u);
+				if (count == 0) break;
+				if ((unsigned long long)count * (unsigned long long)splitLen < (top >> 32)) break;   // (an equal bound could still tie, and the smaller component id wins a tie: only strictly less is safe)
+				__syncthreads();
+				if (lane == 0) bAnchors[slot] = 0;
+				const uint16_t* list = A.anchorByBucket + bAnchorStart[slot];
+				const uint32_t entFirst = bStart[slot];
+				uint32_t filled = 0, groupFrom = 0, fragPrev = 0;
+				for (uint32_t q = 0; q < count; q++) {
+					const uint32_t j = list[q];
+					const uint32_t fj = A.aFrag[j];
+					if (q > 0 && fj != fragPrev) {   // the fragment that just ended joins the prefix: C of its anchors is final
+						uint32_t add = 0;
+						for (uint32_t x = groupFrom + lane; x < q; x += 64) { const uint32_t a = list[x]; add += (uint32_t)A.entBegin[a + 1] - (uint32_t)A.entBegin[a]; }
+						for (int d = 32; d > 0; d >>= 1) add += __shfl_xor(add, d);
+						filled += add;
+						groupFrom = q;
+						__syncthreads();
+					}
+					fragPrev = fj;
+					if (filled == 0) continue;
+					relax(j, fj, A.entByComp, entFirst, entFirst + filled, true);
+				}
+				__syncthreads();
+				topOver(count, [&](uint32_t q) { return (uint32_t)list[q]; });
+			}
+		} else {
+			// anchors are ordered by fragment; g0 = first anchor of j's fragment, the entries of anchors < g0 are a prefix. The threshold lists
+			// of consecutive anchors are consecutive in `back`: a 64-item window of them is kept in registers (item w0 + lane), refilled with one
+			// coalesced load when an anchor's list runs past it - the only global access of the DP loop, a few times per hundred anchors on a narrow cover.
+			uint32_t g0 = 0, entPrefix = 0;
+			for (uint32_t j = 0; j < nA; j++) {
+				const uint32_t fj = A.aFrag[j];
+				if (j > 0 && fj != A.aFrag[j - 1]) { g0 = j; entPrefix = A.entBegin[j]; __syncthreads(); }   // C of the previous fragment's anchors is now final and visible
+				if (g0 == 0) continue;
+				relax(j, fj, A.ent, 0, entPrefix, false);
+			}
+			__syncthreads();
+			topOver(nA, [&](uint32_t q) { return q; });
 		}
-		for (int d = 32; d > 0; d >>= 1) { const unsigned long long o = __shfl_xor(top, d); top = o > top ? o : top; }
 		if (lane == 0) {
 			uint32_t status = 0;
 			const long long best = nA ? (long long)(top >> 32) : 0;
@@ -1293,7 +1343,7 @@ __global__ void __launch_bounds__(64) k_long_merge(DGraph g, const LongJob* __re
 // Execution order of a round's work items: longest extensions first (a counting sort over 1024 length classes, one block;
 // the order inside a class is whatever the atomics give - results do not depend on it). mode 0: identity.
 #ifndef GC_ORDER_THREADS
-#define GC_ORDER_THREADS 1024   // threads of the ordering block (-DGC_ORDER_THREADS=256: a wave scan of the histogram and a block that finds its wave slots sooner among five batches' kernels - measured, 147.8 / 151.7 / 150.5 ms per batch against 150.8 / 150.2 / 149.8, `gpurun_out/r4_ord`: no effect)
+#define GC_ORDER_THREADS 256    // threads of the ordering block (r5: 256 - under config 5 the 1 024-thread block waited up to 150 ms per round for sixteen free wave slots on one CU, with the whole-read token held; r4 note: (-DGC_ORDER_THREADS=256: a wave scan of the histogram and a block that finds its wave slots sooner among five batches' kernels - measured, 147.8 / 151.7 / 150.5 ms per batch against 150.8 / 150.2 / 149.8, `gpurun_out/r4_ord`: no effect)
 #endif
 __global__ void __launch_bounds__(GC_ORDER_THREADS) k_long_order(const uint32_t* __restrict__ workLen, const unsigned long long* __restrict__ workCount, uint32_t* __restrict__ order, uint32_t shift, uint32_t mode)
 {
@@ -1473,7 +1523,7 @@ uint64_t chainScratchBytes(const ChainCaps& caps)
 {
 	// the scratch launch's arrays for one read: anchors (capAnchors), entries (capEndpoints), threshold table (capTable)
 	uint64_t b = 8ull * caps.capBack + 8ull * caps.capAnchors + 8ull * caps.capEndpoints + 4ull * caps.capAnchors + 4ull * (caps.capAnchors + 1) + 4ull * caps.capTable + 6ull * (caps.capAnchors + 1) + 256;
-	b += 4ull * (caps.capAnchors + 1) + 8ull * caps.capEndpoints + 64;   // r4: bucket of every anchor, its entries' place by component, the entries in that order
+	b += 6ull * (caps.capAnchors + 1) + 8ull * caps.capEndpoints + 64;   // r4: bucket of every anchor, its entries' place by component, the entries in that order; r5: the anchors by bucket
 	return (b + 63) & ~63ull;
 }
 
@@ -1481,19 +1531,24 @@ uint32_t chainGridBlocks(uint32_t nReads) { return nReads < 2048 ? nReads : 2048
 uint32_t chainScratchBlocks(uint32_t nReads) { return nReads < 2048 ? nReads : 2048; }   // reads that do not fit the LDS tables: few on 10 kb reads (waves whose read is done leave at once), ALL of them on 50 kb reads (config 5: 256 blocks took 727 ms per 2 000 reads)
 
 void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
-	int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* scratch, uint32_t* chainOut, uint32_t* chainLen, unsigned long long* chainScore, uint32_t* chainStatus, bool forceScratch)
+	int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* scratch, uint32_t* chainOut, uint32_t* chainLen, unsigned long long* chainScore, uint32_t* chainStatus, bool forceScratch, uint32_t fewestSlots)
 {
 	if (nReads == 0) return;
+	// (r5) fewestSlots: the batch's smallest read in anchor slots. When even that one is beyond twice the large LDS class, the LDS launch would send every read on - 2 048 blocks of
+	// 53 KB that waited up to 570 ms for LDS room among config 5's kernels to do nothing (`gpurun_out/r5_cfg5_c`): skipped, the scratch launch takes every read
+	const bool ldsLaunch = forceScratch || fewestSlots <= 2 * CHAIN_LDS_ANCHORS;
+	const uint32_t scratchFlags = ((getenv("GC_CHAIN_PLAIN_SCAN") && atoi(getenv("GC_CHAIN_PLAIN_SCAN")) == 1) ? 2u : 0u) | (ldsLaunch ? 0u : 4u);
 	// the half-size LDS class when the batch's largest read fits it (its entries are checked per read: a read with more goes to the scratch launch below)
 	static const bool largeOnly = getenv("GC_CHAIN_LARGE") && atoi(getenv("GC_CHAIN_LARGE"));   // (the r3 launch, for A/B)
 	const bool small = !largeOnly && caps.capAnchors <= CHAIN_LDS_ANCHORS / 2 && caps.capTable <= CHAIN_LDS_WIDTH / 2;
-	if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<2>), dim3(chainGridBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, forceScratch ? 1u : 0u);
+	if (!ldsLaunch) {}
+	else if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<2>), dim3(chainGridBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, forceScratch ? 1u : 0u);
 	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<1>), dim3(chainGridBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, forceScratch ? 1u : 0u);
 	// reads with more anchors / entries than the LDS tables hold, or on a cover wider than the LDS threshold table (waves whose read is done leave at once).
 	// The batch's bounds tell when no read can need it (cfg2: 400 slots per read at most, cover width 2): 2 048 waves that look and leave cost 7 ms of queueing per batch.
 	// (it is then a safety net of eight waves for what the bounds do not show - a graph with more than 65 535 components, a read beyond 65 535 fragment positions)
 	const bool cannotBeNeeded = !forceScratch && caps.capAnchors <= CHAIN_LDS_ANCHORS / (small ? 2 : 1) && caps.capEndpoints <= CHAIN_LDS_ENTRIES / (small ? 2 : 1) && caps.capTable <= CHAIN_LDS_WIDTH / (small ? 2 : 1);
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<0>), dim3(cannotBeNeeded ? (nReads < 8 ? nReads : 8) : chainScratchBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, (getenv("GC_CHAIN_PLAIN_SCAN") && atoi(getenv("GC_CHAIN_PLAIN_SCAN")) == 1) ? 2u : 0u);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<0>), dim3(cannotBeNeeded ? (nReads < 8 ? nReads : 8) : chainScratchBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, scratchFlags);
 }
 
 uint64_t longWaveWordsPerLane(const ExtendConfig& cfg) { return waveScratchWords(cfg.maxSlices, cfg.maxItems, cfg.maxTrace, cfg.maxCols); }

@@ -186,7 +186,8 @@ uint64_t chainScratchBytes(const ChainCaps& caps);
 uint32_t chainGridBlocks(uint32_t nReads);
 uint32_t chainScratchBlocks(uint32_t nReads);
 void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
-	int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* scratch, uint32_t* chainOut, uint32_t* chainLen, unsigned long long* chainScore, uint32_t* chainStatus, bool forceScratch = false);
+	int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* scratch, uint32_t* chainOut, uint32_t* chainLen, unsigned long long* chainScore, uint32_t* chainStatus, bool forceScratch = false,
+	uint32_t fewestSlots = 0);   // fewestSlots: the batch's smallest read in anchor slots (0: unknown) - when no read can fit an LDS class that launch is skipped
 
 void launchLongPass(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg, const LongJob* jobs, uint32_t nReads,
 	const LongSeed* seeds, const char* bases, uint64_t rcBase, uint32_t minClusterSize, uint32_t maxAlignments, uint8_t* scratch, uint64_t slabBytes,
@@ -243,6 +244,8 @@ struct StitchInfo {   // the longest stitched piece of a read's chain
 	uint32_t firstOffset, lastOffset;
 	uint32_t status;              // != 0: did not fit the kernel's tables (1 piece or region full, 2 bridge search too wide, 3 unusable anchor
 	                              // record, 4 output array full), the host stitches this read
+	uint32_t scoreSum;            // (r5) the chain's anchors' alignment scores added up: the edits the fragments' extensions found, from which the chain's NW edit distance gets its first band
+	uint32_t pad;
 };
 // slotOf: [total anchor slots] scratch; regions: stitchRegionWords(total slots, reads) words of scratch; dense: the results,
 // stitchDenseWords(...) words, filled from *denseCursor (zeroed by the caller) upwards; StitchInfo.start indexes dense

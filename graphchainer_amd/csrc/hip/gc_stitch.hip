@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 	for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
 		const ReadChainJob job = jobs[r];
 		const uint32_t len = chainLen[r];
-		StitchInfo result = { 0, 0, 0, 0, 0, 0 };
+		StitchInfo result = { 0, 0, 0, 0, 0, 0, 0, 0 };
 		if (chainStatus[r] != 0 || len == 0) { if (lane == 0) info[r] = result; continue; }
 		// ---- all lanes: cut-off after the first failed fragment, numbering of the valid anchors (same as k_chain), clear tables
 		uint32_t cut = job.nSlots;
@@ -249,17 +249,19 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 
 		const uint32_t* chain = chainOut + job.chainBegin;
 		uint32_t carryLast = 0;   // last path node of the anchor before this batch
+		uint32_t scoreSum = 0;    // (all lanes) the chain's anchors' scores
 		for (uint32_t c0 = 0; c0 < len; c0 += 64) {
 			// ---- all lanes: stage the next 64 chain anchors (record, first path nodes and their lengths, and whether the
 			// anchor starts in an out-neighbour of the previous anchor's last node - the common bridge, one hop)
 			const uint32_t c = c0 + lane;
-			uint32_t myLast = 0;
+			uint32_t myLast = 0, myScore = 0;
 			StitchAnchor sa = {};
 			if (c < len) {
 				uint32_t index = chain[c];
 				if (index >= nA) sa.flags = 2;   // cannot happen; leaves the read to the host rather than reading outside
 				else {
 					const AnchorRec a = anchors[job.slotBegin + slotOf[job.slotBegin + index]];
+					myScore = a.score > 0 ? (uint32_t)a.score : 0u;
 					sa.firstNode = a.firstNode; sa.firstOffset = a.firstOffset; sa.lastOffset = a.lastOffset; sa.pathLen = a.pathLen;
 					sa.pathOffLo = (uint32_t)a.pathOff; sa.pathOffHi = (uint32_t)(a.pathOff >> 32);
 					if (a.pathLen == 0 || a.pathOff + a.pathLen > pathCapacity) sa.flags = 2;   // anchor path pool overflow: the host reports it
@@ -275,6 +277,8 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 					}
 				}
 			}
+			for (int d = 32; d > 0; d >>= 1) myScore += __shfl_xor(myScore, d);
+			scoreSum += myScore;
 			uint32_t prevLast = __shfl_up(myLast, 1);
 			if (lane == 0) prevLast = carryLast;
 			carryLast = __shfl(myLast, 63);
@@ -375,8 +379,8 @@ __global__ void __launch_bounds__(64) k_stitch(DGraph g, const ReadChainJob* __r
 				at = atomicAdd(denseCursor, (unsigned long long)result.len);
 				if (at + result.len > denseCap) { overflow = true; why = 4; }
 			}
-			if (overflow) { result = StitchInfo { 0, 0, 0, 0, 0, why }; sBestLen = 0; }
-			else { result.start = at; sBestLen = result.len; }
+			if (overflow) { result = StitchInfo { 0, 0, 0, 0, 0, why, scoreSum, 0 }; sBestLen = 0; }
+			else { result.start = at; sBestLen = result.len; result.scoreSum = scoreSum; }
 			sBestStart = bestStart;
 			sDenseAt = at;
 			info[r] = result;
