@@ -343,7 +343,7 @@ struct BatchRun {
 			dLongJobs = st->longJobs.reserve<LongJob>(n);
 			dLongAlns = st->longAlns.reserve<LongAln>(n * maxAlignments);
 			LongReadResult* dLongResults = st->longResults.reserve<LongReadResult>(n);
-			dLongCells = st->longCells.reserve<LongCell>(cellBudget);
+			dLongCells = st->longCells.reserve<LongCell>(cellBudget, true);
 			// Read groups: the rounds of one group are serial (select -> extend -> merge, host decides when to stop). Groups can
 			// run their round loops concurrently, each on its own stream and host thread (GC_LONG_GROUPS). Measured on cfg2
 			// (10k reads): 1 group 367 ms/step, 2 groups 517, 4 groups 477, 8 groups 607 - the groups' big rounds coincide and
@@ -427,7 +427,7 @@ struct BatchRun {
 		if (next > 256 || cellBudgetFor(next) * sizeof(LongCell) > (64ull << 30)) return false;
 		st->longCellsPerBase = next;
 		cellBudget = cellBudgetFor(next);
-		dLongCells = st->longCells.reserve<LongCell>(cellBudget);
+		dLongCells = st->longCells.reserve<LongCell>(cellBudget, true);
 		HIP_CHECK(hipMemsetAsync(dLongCursor, 0, cursorWords * sizeof(unsigned long long), ls));
 		syncStream(ls);
 		return true;
@@ -602,6 +602,15 @@ struct BatchRun {
 #ifdef GC_EXPERIMENTS
 			const bool useSm = team == 1 && getenv("GC_LONG_SM") && atoi(getenv("GC_LONG_SM")) == 1;
 			const bool useLane = !useSm && team == 1 && getenv("GC_LONG_LANE") && atoi(getenv("GC_LONG_LANE")) == 1;
+			// GC_LONG_SPLIT=p (r5 experiment, VERDICT r4 item 3: "use the idle vector issue port"): the round's last p % of the work items (the shortest - the list is sorted
+			// longest first) go to the multi-lane instantiation (GC_LONG_SPLIT_TEAM lanes per wave, 16: divergent lanes, i.e. vector instructions, LDS tables) on a second
+			// stream, beside the one-extension-per-wave kernel that saturates the CUs' scalar units
+			uint32_t nVector = 0, vectorTeam = 16;
+			if (const char* env = getenv("GC_LONG_SPLIT_TEAM")) { const int v = atoi(env); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) vectorTeam = (uint32_t)v; }
+			if (const char* env = getenv("GC_LONG_SPLIT")) {
+				const uint64_t want = (uint64_t)nWorkItems * (uint64_t)std::max(0, std::min(90, atoi(env))) / 100 / vectorTeam * vectorTeam;
+				if (team == 1 && nGroups == 1 && nWorkItems >= 4096 && want >= vectorTeam && (uint64_t)nWorkItems + vectorTeam + 64 <= scratchLanes && (uint64_t)blocks * team >= nWorkItems) nVector = (uint32_t)want;
+			}
 			if (useSm) {
 				launchLongExtendSm(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, (uint8_t*)(dLongScratch + (uint64_t)g * scratchLanes * waveWords), scratchLanes * waveWords * 8,
 					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2);
@@ -613,6 +622,17 @@ struct BatchRun {
 			} else if (useLane) {
 				launchLongExtendLane(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nWorkItems, (uint8_t*)(dLongScratch + (uint64_t)g * scratchLanes * waveWords), scratchLanes * waveWords * 8,
 					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8);
+			} else if (nVector) {
+				if (!st->splitStream) { createStream(&st->splitStream, 1); for (auto& e : st->splitEv) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+				const uint32_t nScalar = nWorkItems - nVector;
+				HIP_CHECK(hipEventRecord(st->splitEv[0], q));
+				HIP_CHECK(hipStreamWaitEvent(st->splitStream, st->splitEv[0], 0));
+				launchLongExtend(st->splitStream, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0 + nScalar, nVector, dLongScratch + (uint64_t)nScalar * waveWords, vectorTeam, nVector / vectorTeam,
+					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, 0, nullptr, nullptr, nullptr);
+				HIP_CHECK(hipEventRecord(st->splitEv[1], st->splitStream));
+				launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dOrder + w0, nScalar, dLongScratch, 1, nScalar,
+					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, 0, nullptr, dRetryList + w0, cursor + 3);
+				HIP_CHECK(hipStreamWaitEvent(q, st->splitEv[1], 0));
 			} else
 #else
 			const bool useSm = false, useLane = false;
@@ -969,13 +989,14 @@ struct BatchRun {
 		if (!poolsSized) {
 			traceWorst = traceBudget + traceBudget / 4 + (1u << 20);   // every slot's two extensions at full length + room for the extensions that only fit the retry launch's larger trace buffers
 			pathWorst = nSlots * 24 + 4096;
-			// by use (device glue; GC_POOLS_WORST_CASE=1 and the host glue path keep the worst case): what the stream's earlier batches needed per slot, with a quarter of slack;
-			// a stream's first batch starts from what cfg2's and config 5's batches use (25-35 trace cells and 3-4 path words per slot of the 103 and 24 the worst case reserves)
+			// by use (device glue; GC_POOLS_WORST_CASE=1 and the host glue path keep the worst case): what the stream's earlier batches needed per slot, with 15 % of slack; a
+			// stream's first batch starts from a low guess (28 trace cells and 4 path words per slot of the 103 and 24 the worst case reserves; config 5 at 960 Mbp uses 36 and 2) and
+			// runs its fragment pipeline again with what it asked for when that was short - in the warm-up batch, once per stream - so that the pools are never larger than a batch needs
 			const bool byUse = deviceGlue && !(getenv("GC_POOLS_WORST_CASE") && atoi(getenv("GC_POOLS_WORST_CASE")) == 1);
-			double traceGuess = 48.0, pathGuess = 6.0, slackCells = (double)(1u << 20), slackWords = 4096.0;
+			double traceGuess = 28.0, pathGuess = 4.0, slackCells = (double)(1u << 20), slackWords = 4096.0;
 			if (const char* env = getenv("GC_POOL_FIRST_GUESS")) { traceGuess = std::max(0.0, atof(env)); pathGuess = traceGuess / 8; slackCells = slackWords = 64; }   // test hook: a stream's first batch outgrows its pools
-			traceBudget = byUse ? std::min<uint64_t>(traceWorst, (uint64_t)((double)nSlots * (st->traceCellsPerSlot > 0 ? st->traceCellsPerSlot : traceGuess) * 1.25 + slackCells)) : traceWorst;
-			pathCapacity = byUse ? std::min<uint64_t>(pathWorst, (uint64_t)((double)nSlots * (st->pathWordsPerSlot > 0 ? st->pathWordsPerSlot : pathGuess) * 1.25 + slackWords)) : pathWorst;
+			traceBudget = byUse ? std::min<uint64_t>(traceWorst, (uint64_t)((double)nSlots * (st->traceCellsPerSlot > 0 ? st->traceCellsPerSlot * 1.15 : traceGuess) + slackCells)) : traceWorst;
+			pathCapacity = byUse ? std::min<uint64_t>(pathWorst, (uint64_t)((double)nSlots * (st->pathWordsPerSlot > 0 ? st->pathWordsPerSlot * 1.15 : pathGuess) + slackWords)) : pathWorst;
 			poolsSized = true;
 		}
 		ChainCaps caps { 1, 1, 1, 1 };
@@ -1008,7 +1029,7 @@ struct BatchRun {
 		ExtItem* dWork = st->work.reserve<ExtItem>(nWork);
 		dResults = st->results.reserve<ExtResult>(nWork);
 		uint8_t* dScratch = st->scratch.reserve<uint8_t>((uint64_t)lanes * slabBytes);
-		dTrace = st->tracePool.reserve<TraceCell>(traceBudget);
+		dTrace = st->tracePool.reserve<TraceCell>(traceBudget, true);
 		if (!deviceGlue) dFrags = st->frags.reserve<Fragment>(nFrags);
 		FragSeed* dFragSeeds = st->fragSeeds.reserve<FragSeed>(nSlots);
 		dAnchors = st->anchors.reserve<AnchorRec>(nSlots);
@@ -1016,13 +1037,18 @@ struct BatchRun {
 		dFragExtended = st->fragExtended.reserve<uint32_t>(nFrags);
 		dReadTies = st->readTies.reserve<uint32_t>(n);
 		if (n) HIP_CHECK(hipMemsetAsync(dReadTies, 0, n * sizeof(uint32_t), stream));
-		dPathPool = st->pathPool.reserve<uint32_t>(pathCapacity);
+		dPathPool = st->pathPool.reserve<uint32_t>(pathCapacity, true);
 		if (!deviceGlue) dJobs = st->jobs.reserve<ReadChainJob>(n);
 		dChainOut = st->chainOut.reserve<uint32_t>(nSlots);
 		dChainLen = st->chainLen.reserve<uint32_t>(n);
 		dChainScore = st->chainScore.reserve<unsigned long long>(n);
 		dChainStatus = st->chainStatus.reserve<uint32_t>(n);
-		uint32_t chainBlocks = std::max(chainGridBlocks((uint32_t)n), chainScratchBlocks((uint32_t)n));   // both launches index the scratch by block
+		uint32_t fewestSlots = 0xffffffffu;
+		for (uint64_t r = 0; r < n; r++) fewestSlots = std::min(fewestSlots, jobs[r].nSlots);
+		if (!n) fewestSlots = 0;
+		const bool forceChainScratch = getenv("GC_CHAIN_FORCE_SCRATCH") != nullptr;
+		// both launches index the scratch by block (the LDS launch keeps its threshold lists there); a batch of long reads has no LDS launch
+		uint32_t chainBlocks = chainLdsLaunch(fewestSlots, forceChainScratch) ? std::max(chainGridBlocks((uint32_t)n), chainScratchBlocks((uint32_t)n)) : chainScratchBlocks((uint32_t)n);
 		uint8_t* dChainScratch = st->chainScratch.reserve<uint8_t>((uint64_t)std::max(1u, chainBlocks) * chainScratchBytes(caps));
 		if (!deviceGlue) {
 			dReadSeeds = st->readSeeds.reserve<FragSeed>(nSeedsTotal);
@@ -1096,10 +1122,7 @@ struct BatchRun {
 			}
 		}
 		mark();   // 4
-		uint32_t fewestSlots = 0xffffffffu;
-		for (uint64_t r = 0; r < n; r++) fewestSlots = std::min(fewestSlots, jobs[r].nSlots);
-		launchChain(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, P->split_len, P->split_gap, caps, dChainScratch, dChainOut, dChainLen, dChainScore, dChainStatus, getenv("GC_CHAIN_FORCE_SCRATCH") != nullptr,
-			n ? fewestSlots : 0u);
+		launchChain(stream, G->dev, dJobs, (uint32_t)n, dAnchors, dFrags, dFragStatus, P->split_len, P->split_gap, caps, dChainScratch, dChainOut, dChainLen, dChainScore, dChainStatus, forceChainScratch, fewestSlots);
 		mark();   // 5
 		// chain stitching (src/Aligner.cpp:754-822) on the device, right behind the chaining kernel; GC_HOST_STITCH=1 keeps it on the
 		// host workers (the path also taken by reads that do not fit the kernel's tables)
@@ -1141,9 +1164,9 @@ struct BatchRun {
 		}
 		const bool traceShort = traceNeed > traceBudget && traceBudget < traceWorst, pathShort = pathNeed > pathCapacity && pathCapacity < pathWorst;
 		if (!traceShort && !pathShort) return false;
-		// (the cursors count every request, the refused ones included - but a fragment whose extension was refused stops asking, so the need seen is a lower bound: half as much again)
-		if (traceShort) traceBudget = std::min<uint64_t>(traceWorst, traceNeed + traceNeed / 2 + (1u << 20));
-		if (pathShort) pathCapacity = std::min<uint64_t>(pathWorst, pathNeed + pathNeed / 2 + 4096);
+		// (the cursors count every request, the refused ones included - but a fragment whose extension was refused stops asking, so the need seen is a lower bound: a fifth more, and the loop comes back when that is still short)
+		if (traceShort) traceBudget = std::min<uint64_t>(traceWorst, traceNeed + traceNeed / 5 + (1u << 20));
+		if (pathShort) pathCapacity = std::min<uint64_t>(pathWorst, pathNeed + pathNeed / 5 + 4096);
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc mem] the fragment pipeline runs again: trace pool %.2f G cells needed (now %.2f), anchor path pool %.2f G words needed (now %.2f)\n", traceNeed / 1e9, traceBudget / 1e9, pathNeed / 1e9, pathCapacity / 1e9);
 		poolReruns++;
 		return true;

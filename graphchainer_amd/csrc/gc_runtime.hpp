@@ -66,14 +66,14 @@ T* uploadVector(const std::vector<T>& v)
 struct DeviceBuffer {   // growable device allocation owned by a stream object
 	void* ptr = nullptr;
 	size_t bytes = 0;
-	template <typename T> T* reserve(size_t count)
+	template <typename T> T* reserve(size_t count, bool tight = false)   // tight: no head room (the pools that are sized by use bring their own slack)
 	{
 		size_t need = std::max<size_t>(count, 1) * sizeof(T);
 		if (need > bytes) {
 			if (ptr) HIP_CHECK(hipFree(ptr));
 			ptr = nullptr;
 			bytes = 0;
-			size_t want = need + need / 8 + 256;
+			size_t want = tight ? need + 256 : need + need / 8 + 256;
 			HIP_CHECK(hipMalloc(&ptr, want));
 			bytes = want;
 		}
@@ -530,6 +530,8 @@ struct gc_stream {
 	// whole-read pass: runs on its own stream, concurrently with the fragment kernels
 	hipStream_t longStream = nullptr;
 	hipEvent_t longEv[2] {};
+	hipStream_t splitStream = nullptr;   // experiments build (GC_LONG_SPLIT): the multi-lane share of a whole-read round
+	hipEvent_t splitEv[2] {};
 	DeviceBuffer edPathNodes, edJobs, edLetters, edLettersLen, edPairs, edOut;
 	PinnedBuffer hEdPathNodes, hEdJobs, hEdPairs, hEdOut;
 	DeviceBuffer outJobs, outRecs, outOffsets, outMapSizes, outPathText, outCigarText, outVgBytes, outTotals;   // output encoding on the device (gc_output.hip)
@@ -588,6 +590,8 @@ struct gc_stream {
 		for (auto& q : groupStreams) if (q) (void)hipStreamDestroy(q);
 		if (stream) (void)hipStreamDestroy(stream);
 		if (longStream) (void)hipStreamDestroy(longStream);
+		if (splitStream) (void)hipStreamDestroy(splitStream);
+		for (auto& e : splitEv) if (e) (void)hipEventDestroy(e);
 	}
 };
 

@@ -1528,7 +1528,9 @@ uint64_t chainScratchBytes(const ChainCaps& caps)
 }
 
 uint32_t chainGridBlocks(uint32_t nReads) { return nReads < 2048 ? nReads : 2048; }   // three blocks fit a CU (LDS); every block owns a threshold-list region in HBM
-uint32_t chainScratchBlocks(uint32_t nReads) { return nReads < 2048 ? nReads : 2048; }   // reads that do not fit the LDS tables: few on 10 kb reads (waves whose read is done leave at once), ALL of them on 50 kb reads (config 5: 256 blocks took 727 ms per 2 000 reads)
+uint32_t chainScratchBlocks(uint32_t nReads) { return nReads < 1024 ? nReads : 1024; }   // (r5: 1 024 - every block owns ~1.8 MB of scratch at config 5's read sizes, and the scratch launch is short since its DP runs per component)  r4:   // reads that do not fit the LDS tables: few on 10 kb reads (waves whose read is done leave at once), ALL of them on 50 kb reads (config 5: 256 blocks took 727 ms per 2 000 reads)
+
+bool chainLdsLaunch(uint32_t fewestSlots, bool forceScratch) { return forceScratch || fewestSlots <= 2 * CHAIN_LDS_ANCHORS; }
 
 void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
 	int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* scratch, uint32_t* chainOut, uint32_t* chainLen, unsigned long long* chainScore, uint32_t* chainStatus, bool forceScratch, uint32_t fewestSlots)
@@ -1536,7 +1538,7 @@ void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, 
 	if (nReads == 0) return;
 	// (r5) fewestSlots: the batch's smallest read in anchor slots. When even that one is beyond twice the large LDS class, the LDS launch would send every read on - 2 048 blocks of
 	// 53 KB that waited up to 570 ms for LDS room among config 5's kernels to do nothing (`gpurun_out/r5_cfg5_c`): skipped, the scratch launch takes every read
-	const bool ldsLaunch = forceScratch || fewestSlots <= 2 * CHAIN_LDS_ANCHORS;
+	const bool ldsLaunch = chainLdsLaunch(fewestSlots, forceScratch);
 	const uint32_t scratchFlags = ((getenv("GC_CHAIN_PLAIN_SCAN") && atoi(getenv("GC_CHAIN_PLAIN_SCAN")) == 1) ? 2u : 0u) | (ldsLaunch ? 0u : 4u);
 	// the half-size LDS class when the batch's largest read fits it (its entries are checked per read: a read with more goes to the scratch launch below)
 	static const bool largeOnly = getenv("GC_CHAIN_LARGE") && atoi(getenv("GC_CHAIN_LARGE"));   // (the r3 launch, for A/B)

@@ -185,6 +185,7 @@ void launchBuildAnchors(hipStream_t stream, const DGraph& g, const Fragment* fra
 uint64_t chainScratchBytes(const ChainCaps& caps);
 uint32_t chainGridBlocks(uint32_t nReads);
 uint32_t chainScratchBlocks(uint32_t nReads);
+bool chainLdsLaunch(uint32_t fewestSlots, bool forceScratch);   // does launchChain run its LDS launch for a batch whose smallest read has this many anchor slots?
 void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const Fragment* frags, const uint32_t* fragStatus,
 	int32_t splitLen, int32_t splitGap, ChainCaps caps, uint8_t* scratch, uint32_t* chainOut, uint32_t* chainLen, unsigned long long* chainScore, uint32_t* chainStatus, bool forceScratch = false,
 	uint32_t fewestSlots = 0);   // fewestSlots: the batch's smallest read in anchor slots (0: unknown) - when no read can fit an LDS class that launch is skipped

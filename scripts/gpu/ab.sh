@@ -7,11 +7,12 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for r in $(seq 1 $rounds); do
   for v in "$@"; do
-    lib=$GRAFT_REPO_ROOT/graphchainer_amd/libgraphchainer_amd_$v.so
-    if [ "$v" = prod ]; then lib=$GRAFT_REPO_ROOT/graphchainer_amd/libgraphchainer_amd.so; fi
-    envvar="AB_ENV_$v"                       # AB_ENV_<variant>="K=V K=V": environment switches of that variant only
-    env ${!envvar} GC_LIBRARY=$lib timeout 600 python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 5 --warmup 2 $AB_BENCH_ARGS > $out/${v}_$r.json 2> $out/${v}_$r.err
-    python3 - $out/${v}_$r.json $v <<'PY'
+    libname=${v%%:*}; tag=${v##*:}           # "exp:split20" = library exp, environment AB_ENV_split20; a plain name is both
+    lib=$GRAFT_REPO_ROOT/graphchainer_amd/libgraphchainer_amd_$libname.so
+    if [ "$libname" = prod ]; then lib=$GRAFT_REPO_ROOT/graphchainer_amd/libgraphchainer_amd.so; fi
+    envvar="AB_ENV_$tag"                     # AB_ENV_<tag>="K=V K=V": environment switches of that variant only
+    env ${!envvar} GC_LIBRARY=$lib timeout 600 python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 5 --warmup 2 $AB_BENCH_ARGS > $out/${tag}_$r.json 2> $out/${tag}_$r.err
+    python3 - $out/${tag}_$r.json $v <<'PY'
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
