@@ -309,10 +309,11 @@ def main():
 
     inflight = max(1, args.inflight)
     mem_free_start, mem_total = gca.device_memory()
-    # batches in flight that fit the device beside the graph and the index: a batch in flight holds ~450 bytes per read base (r3 / r4: 31 GB for 10 k x 10 kb, 42 GB for
-    # 2 k x 50 kb), the device's one whole-read scratch up to 48 GB
+    # batches in flight that fit the device beside the graph and the index: a batch in flight holds at most ~450 bytes per read base (r5, pools sized by use: 19 GB for
+    # 10 k x 10 kb, 44 GB for 2 k x 50 kb on a 960 Mbp graph), the device's one whole-read scratch and the result blocks ~20 GB; streams whose first batches do not fit
+    # after all are dropped one at a time in the warm-up below
     batch_bytes = 450 * min(args.batch, args.reads) * args.read_len
-    fit = int((mem_free_start - (56 << 30)) // max(1, batch_bytes))
+    fit = int((mem_free_start - (20 << 30)) // max(1, batch_bytes))
     memory_choice = None
     if fit < inflight:
         memory_choice = {"asked": inflight, "chosen": max(1, fit), "free_gb_after_graph_and_index": round(mem_free_start / 2**30, 1), "estimated_gb_per_batch_in_flight": round(batch_bytes / 2**30, 1)}

@@ -73,6 +73,7 @@ struct BatchRun {
 	uint64_t maxReadLen = 1;
 	// startWholeReadPass()
 	std::vector<std::thread> longThreads;
+	double passThreadCpuMs = 0;   // GC_DEBUG_TIMES: CPU time of the pass thread (read after the join)
 	std::vector<std::exception_ptr> longErrors;
 	double tLongWall0 = 0;
 	std::atomic<double> longWallBeginUs { 0.0 };   // when the pass got the device's token (waiting for another batch's pass is not its own time)
@@ -137,20 +138,37 @@ struct BatchRun {
 	{
 		res->n_reads = n;
 		tTotal = nowUs();
-		seeds();
-		prepareWholeReadPass();
-		startWholeReadPass();
-		fragmentPipeline();
-		resultsBack();
+		// GC_DEBUG_TIMES: CPU time of THIS thread per stage (the waits poll: what a stage costs the host is not its wall time)
+		const bool cpuStages = getenv("GC_DEBUG_TIMES") != nullptr;
+		double cpuAt = cpuStages ? threadCpuMs() : 0, cpuStage[10] = {}, poolStage[10] = {};
+		uint64_t poolAt = pool.cpuUs.load();
+		const double processAt = processCpuMs();
+		auto stageDone = [&](int k) {
+			if (!cpuStages) return;
+			const double now = threadCpuMs(); const uint64_t poolNow = pool.cpuUs.load();
+			cpuStage[k] += now - cpuAt; poolStage[k] += (poolNow - poolAt) / 1e3;
+			cpuAt = now; poolAt = poolNow;
+		};
+		seeds(); stageDone(0);
+		prepareWholeReadPass(); stageDone(1);
+		startWholeReadPass(); stageDone(2);
+		fragmentPipeline(); stageDone(3);
+		resultsBack(); stageDone(4);
 		// r5: the trace pool and the anchor path pool are sized by what the stream's batches have used, not by every slot's worst case (a 2 000 x 50 kb batch on a 960 Mbp
 		// graph has 21 M slots: 26 GB of trace pool by worst case); a batch that needs more than its stream has seen so far runs its fragment pipeline again with the room it asked for
-		while (fragmentPoolsOverflowed()) { fragmentPipeline(); resultsBack(); }
+		while (fragmentPoolsOverflowed()) { fragmentPipeline(); resultsBack(); stageDone(3); }
 		res->counters[6] = poolReruns;
-		stitchAndChainDistances();
-		joinWholeReadPass();
-		chainedAlignments();
-		encodeOutput();
-		assemble();
+		stitchAndChainDistances(); stageDone(5);
+		joinWholeReadPass(); stageDone(6);
+		chainedAlignments(); stageDone(7);
+		encodeOutput(); stageDone(8);
+		assemble(); stageDone(9);
+		if (cpuStages)
+			fprintf(stderr, "[gc cpu] main thread, ms of its own CPU: seeds %.1f, whole-read set-up %.1f + start %.1f, fragment pipeline %.1f, results back %.1f, stitching + chain distances %.1f, join %.1f, chained alignments %.1f, output %.1f, assembly %.1f; pass thread %.1f\n",
+				cpuStage[0], cpuStage[1], cpuStage[2], cpuStage[3], cpuStage[4], cpuStage[5], cpuStage[6], cpuStage[7], cpuStage[8], cpuStage[9], passThreadCpuMs);
+		if (cpuStages)   // (with one batch in flight: this call's own; the pool's figure includes this thread's share of the jobs, which the line above counts too)
+			fprintf(stderr, "[gc cpu] worker pool jobs, ms of CPU over all threads, by stage: %.1f %.1f %.1f %.1f %.1f %.1f %.1f %.1f %.1f %.1f; the process in all %.1f\n",
+				poolStage[0], poolStage[1], poolStage[2], poolStage[3], poolStage[4], poolStage[5], poolStage[6], poolStage[7], poolStage[8], poolStage[9], processCpuMs() - processAt);
 	}
 
 	// ---------------- K1 seed lookup, then the glue between it and the extension kernels (on the device; GC_DEVICE_GLUE=0: on the host)
@@ -909,6 +927,7 @@ struct BatchRun {
 						if (longGroups == 1) { longTokenTake = nullptr; longTokenDrop = nullptr; drop(); }
 						else stampEnd();
 						if (longPostInThread) afterLongPass();
+						passThreadCpuMs = threadCpuMs();   // (the thread's whole life: it is created per batch)
 					} catch (...) {
 						longErrors[g] = std::current_exception();
 						if (longGroups == 1) { longTokenTake = nullptr; longTokenDrop = nullptr; }   // (they refer to this thread's locals)

@@ -132,6 +132,7 @@ inline std::mutex g_longScratchCount;
 
 inline double nowUs() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // CPU time of the whole process (all threads), for GC_DEBUG_TIMES' host budget lines
+inline double threadCpuMs() { timespec ts {}; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; }
 inline double processCpuMs() { timespec ts {}; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; }
 
 // Waiting for a stream. hipStreamSynchronize spins on a CPU, and a batch has two host threads waiting most of its 200 ms (two batches in
@@ -233,9 +234,12 @@ private:
 	void work(size_t id)
 	{
 		const size_t chunk = 4;
+		static const bool account = getenv("GC_DEBUG_TIMES") != nullptr;
+		const double cpu0 = account ? threadCpuMs() : 0;
 		try {
 			for (size_t i; (i = next.fetch_add(chunk)) < total;)
 				for (size_t k = i; k < std::min(total, i + chunk); k++) (*job)(k, id);
+			if (account) cpuUs.fetch_add((uint64_t)((threadCpuMs() - cpu0) * 1e3));
 		} catch (...) {
 			next.store(total);   // the first failure ends the job: the other threads stop fetching, the caller rethrows
 			std::unique_lock<std::mutex> lock(mutex);
@@ -262,6 +266,9 @@ private:
 	std::condition_variable wake, done;
 	const std::function<void(size_t, size_t)>* job = nullptr;
 	std::atomic<size_t> next { 0 };
+public:
+	std::atomic<uint64_t> cpuUs { 0 };   // GC_DEBUG_TIMES: CPU time spent inside jobs by all threads (what a stage costs beside its own thread)
+private:
 	size_t total = 0, pending = 0, generation = 0;
 	std::exception_ptr failure;
 	bool stop = false;

@@ -681,7 +681,7 @@ __global__ void __launch_bounds__(64) k_chain(DGraph g, const ReadChainJob* __re
 		// [scanBegin, scanEnd) - earlier fragments' anchors - the wave maximum into C[j], the table cleared again. sameComponent: the entries are j's component's already
 		auto relax = [&](uint32_t j, uint32_t fj, const ChainEntry* entries, uint32_t scanBegin, uint32_t scanEnd, bool sameComponent) {
 			const uint32_t b0 = A.backBegin[j], b1 = A.backBegin[j + 1];
-			if (b1 <= w0 + 64 || (b1 - b0 <= 64 && (w0 = b0, win = b0 + lane < nB ? A.back[b0 + lane] : make_uint2(0, 0), true))) {
+			if ((b0 >= w0 && b1 <= w0 + 64) || (b1 - b0 <= 64 && (w0 = b0, win = b0 + lane < nB ? A.back[b0 + lane] : make_uint2(0, 0), true))) {
 				const uint32_t t = w0 + lane;
 				if (t >= b0 && t < b1) atomicMax(&A.thr[win.x], (int32_t)win.y);
 			} else {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # config 5 at one or more sizes: the bench line with the CPU leg and the parity sample (GC_DEBUG_TIMES: stage times and "[gc mem]" lines), then a rocprofv3 kernel trace of the same
 # workload from the kept set-up (bench.py --setup-dir: the second process loads the index cache instead of building again).
-# usage: bash scripts/gpu/cfg5_profile.sh <tag> [backbone bp per chromosome ...]      (8000000 = 192 Mbp, 40000000 = 960 Mbp); CFG5_ARGS adds bench flags; CFG5_PMC=1 adds a counter pass
+# usage: bash scripts/gpu/cfg5_profile.sh <tag> [backbone bp per chromosome ...]      (8000000 = 192 Mbp, 40000000 = 960 Mbp); CFG5_ARGS adds bench flags; CFG5_ALONE=1 adds the trace with one batch in flight, CFG5_PMC=1 a counter pass
 tag=$1; shift
 sizes=${@:-8000000}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
@@ -34,6 +34,12 @@ except Exception as e:
     print("no kernel stats:", e)
 PY
   rm -rf $out/stats_$b
+  if [ -n "$CFG5_ALONE" ]; then   # the same trace with ONE batch in flight: what every kernel takes when nothing runs beside it
+    timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/alone_$b -o s -- python3 $GRAFT_REPO_ROOT/bench.py --config 5 --backbone $b --setup-dir $setup --no-cpu-baseline --e2e-steps 0 --steps 2 --warmup 1 $CFG5_ARGS --inflight 1 > $out/alone_$b.log 2>&1
+    f=$(find $out/alone_$b -name "*kernel_stats.csv" | head -1)
+    [ -n "$f" ] && cp $f $out/kernel_stats_alone_$b.csv
+    rm -rf $out/alone_$b
+  fi
   if [ -n "$CFG5_PMC" ]; then
     timeout 1500 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY --kernel-trace --output-format csv -d $out/pmc_$b -o p -- python3 $GRAFT_REPO_ROOT/bench.py --config 5 --backbone $b --setup-dir $setup --no-cpu-baseline --e2e-steps 0 --steps 1 --warmup 0 --inflight 1 $CFG5_ARGS > $out/pmc_$b.log 2>&1
     python3 - $out pmc_$b <<'PY'
