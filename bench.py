@@ -375,7 +375,22 @@ def main():
                 memory_choice = {"asked": (memory_choice or {}).get("asked", inflight), "chosen": inflight - 1, "why": "the first batches of that many streams did not fit the device's memory"}
                 inflight -= 1
                 aligners[:] = [gca.Aligner(graph, seeder, split_gap=args.split_gap, colinear_gap=args.colinear_gap, long_pass=long_pass) for _ in range(inflight)]
+    def thread_cpu():
+        """{(tid, name): CPU seconds} of this process's threads (GC_DEBUG_TIMES: which threads the host CPU per step goes to)"""
+        out = {}
+        tick = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                fields = open(f"/proc/self/task/{tid}/stat").read().rsplit(")", 1)
+                name = fields[0].split("(", 1)[1]
+                rest = fields[1].split()
+                out[(int(tid), name)] = (int(rest[11]) + int(rest[12])) / tick
+            except (OSError, IndexError, ValueError):
+                pass
+        return out
+
     sync()
+    threads_start = thread_cpu() if os.environ.get("GC_DEBUG_TIMES") else None
     cpu_start = cpu_seconds()
     rank_cpu_start = time.process_time()
     t_start = time.perf_counter()
@@ -384,6 +399,11 @@ def main():
     elapsed = time.perf_counter() - t_start
     host_cpu_s = cpu_seconds() - cpu_start
     rank_cpu_s = time.process_time() - rank_cpu_start               # this rank's process alone (the cgroup figure above is the whole container's)
+    if threads_start is not None:
+        now = thread_cpu()
+        used = sorted(((now[k] - threads_start.get(k, 0.0), k) for k in now), reverse=True)
+        print("[bench cpu] per step, by thread (s): " + ", ".join(f"{name}/{tid} {d / args.steps:.3f}" for d, (tid, name) in used[:14] if d > 0)
+              + f"; all threads {sum(d for d, _ in used) / args.steps:.3f}, process {rank_cpu_s / args.steps:.3f}, container {host_cpu_s / args.steps:.3f}", file=sys.stderr)
     mem_free_end, _ = gca.device_memory()
     # Parity of the timed mode (src/Aligner.cpp:630-654,735,901-905): the reads the CPU leg aligned with the oracle are compared, value
     # for value, with what EVERY timed batch returned for them - chain, chain score, both NW distances, the decision, the whole-read

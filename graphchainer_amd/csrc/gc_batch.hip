@@ -668,7 +668,7 @@ struct BatchRun {
 					if (useSm) launchLongRetryList(q, dLongWorkResults + w0, nWorkItems, EXT_LDS_CAP, dRetryList + w0, cursor + 3);
 #endif
 				}
-				uint32_t retryBlocks = std::min<uint32_t>(16, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / 2));   // (persistent waves over a list that is almost always empty)
+				uint32_t retryBlocks = std::min<uint32_t>(128, (uint32_t)std::max<uint64_t>(1, (scratchLanes - 64) / 2));   // (persistent waves over a list that is almost always empty on 10 kb reads; 50 kb CLR-like reads on a genome-sized graph list a few dozen per round, and one such extension lasts 10-50 ms)
 				launchLongExtend(q, G->dev, G->devTables, R->devMasks, lcfg, dLongWork + w0, dRetryList + w0, nWorkItems, dLongScratch + (uint64_t)g * scratchLanes * waveWords, 2, retryBlocks,
 					dRoundTrace + groupTraceBegin[g], cursor + 1, traceBudget, dLongWorkResults + w0, dLongCursor + 8, cursor + 2, EXT_LDS_CAP, cursor + 3);
 			}
@@ -1097,9 +1097,10 @@ struct BatchRun {
 		// (r5: every round's extension launches and every k_build_anchors launch sit between an event pair of their own - r4 bracketed "round 0's extensions" and "everything up to
 		// the chaining kernel", so the later rounds' k_extend launches were charged to the anchors stage and roofline_other did not follow from the kernel trace)
 		nExtendPairs = nAnchorPairs = 0;
+		static const uint32_t extendChunkItems = getenv("GC_EXTEND_CHUNK") ? (uint32_t)std::max(0, atoi(getenv("GC_EXTEND_CHUNK"))) : 0u;   // extensions per k_extend launch (0: one launch per round)
 		auto extendRound = [&](const ExtSelection& sel) {
 			if (nExtendPairs < 4) HIP_CHECK(hipEventRecord(st->fragEv[2 * nExtendPairs], stream));
-			launchExtend(stream, G->dev, G->devTables, G->devIupac, cfg, dWork, nWork, R->devBases, dResults, dScratch, slabBytes, dTrace, dCursors + 1, traceBudget, dCounters, 0, 4096, sel);
+			launchExtend(stream, G->dev, G->devTables, G->devIupac, cfg, dWork, nWork, R->devBases, dResults, dScratch, slabBytes, dTrace, dCursors + 1, traceBudget, dCounters, 0, 4096, sel, extendChunkItems);
 			launchExtend(stream, G->dev, G->devTables, G->devIupac, big, dWork, nWork, R->devBases, dResults, dRetryScratch, extendSlabBytes(big), dTrace, dCursors + 1, traceBudget, dCounters, EXT_OVERFLOW, retryLanes, sel);
 			if (nExtendPairs < 4) { HIP_CHECK(hipEventRecord(st->fragEv[2 * nExtendPairs + 1], stream)); nExtendPairs++; }
 		};
