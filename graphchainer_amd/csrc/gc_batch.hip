@@ -113,6 +113,12 @@ struct BatchRun {
 	unsigned long long* chainScore = nullptr;
 	uint32_t* chainStatus = nullptr;
 	uint32_t* pathPool = nullptr;
+	// r5: the result's dense anchor arrays are made on the device (gc_results.hip) unless the anchors' traces are asked for (keep_traces == 1: the host walks the slots for them anyway)
+	bool deviceAnchors = false;
+	uint4* hAnchorPerRead = nullptr;                  // (anchors kept, path words, seeds extended, flags) per read
+	unsigned long long* hAnchorOff = nullptr;         // [2 r] anchors, [2 r + 1] path words before read r; totals at [2 n], [2 n + 1]
+	uint8_t* hAnchorDense = nullptr;                  // the dense arrays as they came down: nine 4-byte arrays, the 8-byte path offsets, the path words
+	uint64_t denseAnchors = 0, densePathWords = 0;
 	std::vector<ExtResult> extResults;
 	std::vector<TraceCell> tracePool;
 	bool anchorTraces = false;
@@ -158,6 +164,7 @@ struct BatchRun {
 		// graph has 21 M slots: 26 GB of trace pool by worst case); a batch that needs more than its stream has seen so far runs its fragment pipeline again with the room it asked for
 		while (fragmentPoolsOverflowed()) { fragmentPipeline(); resultsBack(); stageDone(3); }
 		res->counters[6] = poolReruns;
+		compactAnchors(); stageDone(4);
 		stitchAndChainDistances(); stageDone(5);
 		joinWholeReadPass(); stageDone(6);
 		chainedAlignments(); stageDone(7);
@@ -1178,11 +1185,11 @@ struct BatchRun {
 	bool fragmentPoolsOverflowed()
 	{
 		const uint64_t traceNeed = hSmall[1], pathNeed = hSmall[2];
-		if (nSlots) {
-			st->traceCellsPerSlot = std::max(st->traceCellsPerSlot, (double)std::min(traceNeed, traceWorst) / (double)nSlots);
-			st->pathWordsPerSlot = std::max(st->pathWordsPerSlot, (double)std::min(pathNeed, pathWorst) / (double)nSlots);
-		}
 		const bool traceShort = traceNeed > traceBudget && traceBudget < traceWorst, pathShort = pathNeed > pathCapacity && pathCapacity < pathWorst;
+		// what the stream learns is a run's use when the pool held it: the cursor of a run that overflowed also counts the requests of the retry launch, which runs every refused
+		// extension again (config 5 at 960 Mbp learned 44 cells per slot from such a run where 36 are used: 2.4 GB per batch in flight)
+		if (nSlots && !traceShort) st->traceCellsPerSlot = std::max(st->traceCellsPerSlot, (double)std::min(traceNeed, traceWorst) / (double)nSlots);
+		if (nSlots && !pathShort) st->pathWordsPerSlot = std::max(st->pathWordsPerSlot, (double)std::min(pathNeed, pathWorst) / (double)nSlots);
 		if (!traceShort && !pathShort) return false;
 		// (the cursors count every request, the refused ones included - but a fragment whose extension was refused stops asking, so the need seen is a lower bound: a fifth more, and the loop comes back when that is still short)
 		if (traceShort) traceBudget = std::min<uint64_t>(traceWorst, traceNeed + traceNeed / 5 + (1u << 20));
@@ -1196,17 +1203,20 @@ struct BatchRun {
 	void resultsBack()
 	{
 		// ---------------- results back (pinned staging)
-		anchors = st->hAnchors.reserve<AnchorRec>(nSlots);
-		fragStatus = st->hFragStatus.reserve<uint32_t>(nFrags);
-		fragExtended = st->hFragExtended.reserve<uint32_t>(nFrags);
+		deviceAnchors = P->keep_traces != 1 && !(getenv("GC_HOST_ANCHORS") && atoi(getenv("GC_HOST_ANCHORS")) == 1);   // (GC_HOST_ANCHORS=1: test hook, the host's walk over the slots as before r5)
+		anchors = st->hAnchors.reserve<AnchorRec>(deviceAnchors ? 1 : nSlots);
+		fragStatus = st->hFragStatus.reserve<uint32_t>(deviceAnchors ? 1 : nFrags);
+		fragExtended = st->hFragExtended.reserve<uint32_t>(deviceAnchors ? 1 : nFrags);
 		readTies = st->hReadTies.reserve<uint32_t>(n);
 		chainOut = st->hChainOut.reserve<uint32_t>(nSlots);
 		chainLen = st->hChainLen.reserve<uint32_t>(n);
 		chainScore = st->hChainScore.reserve<unsigned long long>(n);
 		chainStatus = st->hChainStatus.reserve<uint32_t>(n);
-		if (nSlots) HIP_CHECK(hipMemcpyAsync(anchors, dAnchors, nSlots * sizeof(AnchorRec), hipMemcpyDeviceToHost, stream));
-		if (nFrags) HIP_CHECK(hipMemcpyAsync(fragStatus, dFragStatus, nFrags * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-		if (nFrags) HIP_CHECK(hipMemcpyAsync(fragExtended, dFragExtended, nFrags * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		if (!deviceAnchors) {
+			if (nSlots) HIP_CHECK(hipMemcpyAsync(anchors, dAnchors, nSlots * sizeof(AnchorRec), hipMemcpyDeviceToHost, stream));
+			if (nFrags) HIP_CHECK(hipMemcpyAsync(fragStatus, dFragStatus, nFrags * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+			if (nFrags) HIP_CHECK(hipMemcpyAsync(fragExtended, dFragExtended, nFrags * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		}
 		if (n) HIP_CHECK(hipMemcpyAsync(readTies, dReadTies, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		if (nSlots) HIP_CHECK(hipMemcpyAsync(chainOut, dChainOut, nSlots * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		if (n) HIP_CHECK(hipMemcpyAsync(chainLen, dChainLen, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -1225,8 +1235,8 @@ struct BatchRun {
 		for (int i = 0; i < 8; i++) res->counters[i] = hSmall[8 + i];
 		// (the cursors overshoot when a pool is full: the extensions / fragments that did not fit carry an overflow status and their reads are flagged)
 		uint64_t traceUsed = std::min<uint64_t>(hSmall[1], traceBudget), pathUsed = std::min<uint64_t>(hSmall[2], pathCapacity);
-		pathPool = st->hPathPool.reserve<uint32_t>(pathUsed);
-		if (pathUsed) HIP_CHECK(hipMemcpyAsync(pathPool, dPathPool, pathUsed * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+		pathPool = st->hPathPool.reserve<uint32_t>(deviceAnchors ? 1 : pathUsed);
+		if (pathUsed && !deviceAnchors) HIP_CHECK(hipMemcpyAsync(pathPool, dPathPool, pathUsed * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 		anchorTraces = P->keep_traces == 1;   // (keep_traces == 2: the alignments' traces only - what the output encoders read)
 		if (anchorTraces) {
 			extResults.resize(nWork);
@@ -1245,6 +1255,39 @@ struct BatchRun {
 		}
 
 	}
+
+	// ---------------- r5: the anchors the reference keeps of every read as the result's dense arrays, made on the device (gc_results.hip)
+	void compactAnchors()
+	{
+		if (!deviceAnchors) return;
+		uint4* dPerRead = st->anchorPerRead.reserve<uint4>(n);
+		uint32_t* dSlotEnd = st->anchorSlotEnd.reserve<uint32_t>(n);
+		unsigned long long* dOff = st->anchorOff.reserve<unsigned long long>(2 * n + 2);
+		hAnchorPerRead = st->hAnchorPerRead.reserve<uint4>(n);
+		hAnchorOff = st->hAnchorOff.reserve<unsigned long long>(2 * n + 4);
+		unsigned long long* hTotals = hAnchorOff + 2 * n + 2;
+		hTotals[0] = hTotals[1] = 0;
+		launchAnchorCounts(stream, dJobs, (uint32_t)n, dFrags, dFragStatus, dFragExtended, dAnchors, dPerRead, dSlotEnd, dOff, hTotals);
+		if (n) HIP_CHECK(hipMemcpyAsync(hAnchorPerRead, dPerRead, n * sizeof(uint4), hipMemcpyDeviceToHost, stream));
+		if (n) HIP_CHECK(hipMemcpyAsync(hAnchorOff, dOff, (2 * n + 2) * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+		syncStream(stream);
+		denseAnchors = n ? hAnchorOff[2 * n] : 0; densePathWords = n ? hAnchorOff[2 * n + 1] : 0;
+		// one block for the eleven arrays: nine of 4 bytes per anchor, the 8-byte path offsets, the path words
+		const uint64_t A = denseAnchors, bytes = A * 44 + densePathWords * 4 + 64;
+		uint8_t* dDense = st->anchorDense.reserve<uint8_t>(bytes);
+		hAnchorDense = st->hAnchorDense.reserve<uint8_t>(bytes);
+		AnchorArrays out;
+		out.pathOff = (unsigned long long*)dDense;
+		uint32_t* w = (uint32_t*)(dDense + 8 * A);
+		out.x = w; out.y = w + A; out.firstNode = w + 2 * A; out.firstOffset = w + 3 * A; out.firstSeqPos = w + 4 * A; out.lastNode = w + 5 * A; out.lastOffset = w + 6 * A; out.lastSeqPos = w + 7 * A;
+		out.score = (int32_t*)(w + 8 * A); out.path = w + 9 * A;
+		launchAnchorCompact(stream, dJobs, (uint32_t)n, dAnchors, dPathPool, dSlotEnd, dOff, out);
+		if (A) HIP_CHECK(hipMemcpyAsync(hAnchorDense, dDense, A * 44 + densePathWords * 4, hipMemcpyDeviceToHost, stream));
+		syncStream(stream);
+	}
+	// the dense arrays in the staging block (the layout compactAnchors gave the device's)
+	const unsigned long long* densePathOff() const { return (const unsigned long long*)hAnchorDense; }
+	const uint32_t* denseWords(int k) const { return (const uint32_t*)(hAnchorDense + 8 * denseAnchors) + (uint64_t)k * denseAnchors; }   // 0 x, 1 y, 2-4 first node / offset / seqPos, 5-7 last, 8 score, 9 the path words
 
 	// ---------------- host stitching of what the kernel declined; NW distance of every stitched path against its read
 	void stitchAndChainDistances()
@@ -1267,6 +1310,24 @@ struct BatchRun {
 				hostStitched++;
 				if (deviceStitch && getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc stitch] read %zu goes to the host: reason %u, chain of %u anchors\n", r, stitchInfo[r].status, chainLen[r]);
 				std::vector<uint32_t> slots;
+				if (deviceAnchors) {   // the read's kept anchors are the dense arrays' [a0, a1): chain index = dense index
+					const uint64_t a0 = hAnchorOff[2 * r], a1 = hAnchorOff[2 * r + 2];
+					std::vector<AnchorRec> recs(a1 - a0);
+					slots.resize(a1 - a0);
+					for (uint64_t a = a0; a < a1; a++) {
+						AnchorRec& rec = recs[a - a0];
+						rec.valid = 1; rec.x = denseWords(0)[a]; rec.y = denseWords(1)[a];
+						rec.firstNode = denseWords(2)[a]; rec.firstOffset = denseWords(3)[a]; rec.firstSeqPos = denseWords(4)[a] - rec.x;
+						rec.lastNode = denseWords(5)[a]; rec.lastOffset = denseWords(6)[a]; rec.lastSeqPos = denseWords(7)[a] - rec.x;
+						rec.score = (int32_t)denseWords(8)[a];
+						rec.pathOff = densePathOff()[a];
+						rec.pathLen = (uint32_t)((a + 1 < denseAnchors ? densePathOff()[a + 1] : densePathWords) - densePathOff()[a]);
+						rec.pad = 0;
+						slots[a - a0] = (uint32_t)(a - a0);
+					}
+					stitchChain(hg, (long long)P->colinear_gap, chainOut + jobs[r].chainBegin, chainLen[r], slots.data(), recs.data(), denseWords(9), gl.stitched);
+					return;
+				}
 				uint64_t slot = gl.slotBegin;
 				for (size_t f = 0; f < gl.nWindows; f++) {
 					uint64_t F = gl.fragBegin + f;
@@ -1659,6 +1720,13 @@ struct BatchRun {
 				return;
 			}
 			if (chainStatus[r] != 0) { gl.capacityExceeded = true; chainLen[r] = 0; chainScore[r] = 0; }
+			if (deviceAnchors) {   // k_anchor_counts walked the read's fragments and slots
+				const uint4 pr = hAnchorPerRead[r];
+				if (pr.w & 2u) gl.capacityExceeded = true;
+				if (pr.w & 1u) failedAssertion[r] = 1;
+				seedsExtended[r] += pr.z;
+				gl.nAnchors = pr.x; gl.nPath = pr.y;
+			} else
 			for (size_t f = 0; f < gl.nWindows; f++) {
 				uint64_t F = gl.fragBegin + f;
 				if (fragStatus[F] == 2) gl.capacityExceeded = true;   // an extension or the anchor path pool overflowed even in the retry: this fragment gave no anchors
@@ -1669,7 +1737,7 @@ struct BatchRun {
 				seedsExtendedLong[r] = hLongResults[r].seedsExtended;
 				if (hLongResults[r].status == 1) failedAssertion[r] = 1;
 			}
-			forEachAnchor(r, [&](uint64_t slot, uint64_t F) {
+			if (!deviceAnchors) forEachAnchor(r, [&](uint64_t slot, uint64_t F) {
 				gl.nAnchors++;
 				gl.nPath += anchors[slot].pathLen;
 				if (anchorTraces) {
@@ -1791,7 +1859,15 @@ struct BatchRun {
 			}
 			for (uint32_t i = 0; i < chainLen[r]; i++) res->chain[gl.chainBegin + i] = chainOut[jobs[r].chainBegin + i];
 			uint64_t a = gl.anchorBegin, pathAt = gl.pathBegin, traceAt = gl.traceBegin;
-			forEachAnchor(r, [&](uint64_t slot, uint64_t F) {
+			if (deviceAnchors && gl.nAnchors) {   // the read's share of the dense arrays, to its place (the same place unless an earlier read of the batch lost its anchors to the whole-read pass)
+				const uint64_t a0 = hAnchorOff[2 * r], w0 = hAnchorOff[2 * r + 1], cnt = gl.nAnchors;
+				uint32_t* const to[9] = { res->anchor_x, res->anchor_y, res->anchor_first_node, res->anchor_first_offset, res->anchor_first_seqpos, res->anchor_last_node, res->anchor_last_offset, res->anchor_last_seqpos, (uint32_t*)res->anchor_score };
+				for (int k = 0; k < 9; k++) memcpy(to[k] + gl.anchorBegin, denseWords(k) + a0, cnt * sizeof(uint32_t));
+				const unsigned long long* off = densePathOff() + a0;
+				for (uint64_t i = 0; i < cnt; i++) res->anchor_path_off[gl.anchorBegin + i] = off[i] - w0 + gl.pathBegin;
+				memcpy(res->anchor_path + gl.pathBegin, denseWords(9) + w0, gl.nPath * sizeof(uint32_t));
+			}
+			if (!deviceAnchors) forEachAnchor(r, [&](uint64_t slot, uint64_t F) {
 				const AnchorRec& rec = anchors[slot];
 				res->anchor_x[a] = rec.x; res->anchor_y[a] = rec.y;
 				res->anchor_path_off[a] = pathAt;

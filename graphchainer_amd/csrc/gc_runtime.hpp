@@ -69,6 +69,7 @@ struct DeviceBuffer {   // growable device allocation owned by a stream object
 	template <typename T> T* reserve(size_t count, bool tight = false)   // tight: no head room (the pools that are sized by use bring their own slack)
 	{
 		size_t need = std::max<size_t>(count, 1) * sizeof(T);
+		if (tight && bytes > need + need / 4 + (64u << 20)) release();   // a pool that a rerun sized from an overshooting request count comes back to what its batches use (once: hipFree drains the device)
 		if (need > bytes) {
 			if (ptr) HIP_CHECK(hipFree(ptr));
 			ptr = nullptr;
@@ -544,6 +545,8 @@ struct gc_stream {
 	DeviceBuffer outJobs, outRecs, outOffsets, outMapSizes, outPathText, outCigarText, outVgBytes, outTotals;   // output encoding on the device (gc_output.hip)
 	PinnedBuffer hOutJobs, hOutRecs, hOutOffsets, hOutPathText, hOutCigarText, hOutVgBytes, hOutTotals;
 	DeviceBuffer stitchSlotOf, stitchRegions, stitchNodes, stitchInfo, stitchCursor, stitchSpill;   // chain stitching on the device (gc_stitch.hip)
+	DeviceBuffer anchorPerRead, anchorSlotEnd, anchorOff, anchorDense;   // the result's dense anchor arrays made on the device (gc_results.hip)
+	PinnedBuffer hAnchorPerRead, hAnchorOff, hAnchorDense;
 	PinnedBuffer hStitchNodes, hStitchInfo, hStitchCursor;
 	EditDistanceRun edChainRun;
 	DeviceBuffer edPathJobs, edPathOps, edPathLen, edPathScratch;   // alignment path of the chained alignment (gc_edpath.hip)
@@ -578,6 +581,7 @@ struct gc_stream {
 		f("edLettersLen", edLettersLen.bytes); f("edPairs", edPairs.bytes); f("edOut", edOut.bytes); f("outJobs", outJobs.bytes); f("outRecs", outRecs.bytes); f("outOffsets", outOffsets.bytes);
 		f("outMapSizes", outMapSizes.bytes); f("outPathText", outPathText.bytes); f("outCigarText", outCigarText.bytes); f("outVgBytes", outVgBytes.bytes); f("outTotals", outTotals.bytes);
 		f("stitchSlotOf", stitchSlotOf.bytes); f("stitchRegions", stitchRegions.bytes); f("stitchNodes", stitchNodes.bytes); f("stitchInfo", stitchInfo.bytes); f("stitchCursor", stitchCursor.bytes); f("stitchSpill", stitchSpill.bytes);
+		f("anchorPerRead", anchorPerRead.bytes); f("anchorSlotEnd", anchorSlotEnd.bytes); f("anchorOff", anchorOff.bytes); f("anchorDense", anchorDense.bytes);
 		f("edPathJobs", edPathJobs.bytes); f("edPathOps", edPathOps.bytes); f("edPathLen", edPathLen.bytes); f("edPathScratch", edPathScratch.bytes); f("longSeeds", longSeeds.bytes);
 		f("longJobs", longJobs.bytes); f("longAlns", longAlns.bytes); f("longResults", longResults.bytes); f("longScratch", longScratch.bytes); f("longCells", longCells.bytes);
 		f("longCursor", longCursor.bytes); f("longJobsFallback", longJobsFallback.bytes); f("longResultsFallback", longResultsFallback.bytes); f("longScratchFallback", longScratchFallback.bytes);

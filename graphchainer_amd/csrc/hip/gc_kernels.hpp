@@ -182,6 +182,13 @@ void launchBuildAnchors(hipStream_t stream, const DGraph& g, const Fragment* fra
 	const TraceCell* tracePool, int32_t splitLen, AnchorRec* anchors, uint32_t* fragStatus, uint32_t* fragExtended,
 	uint32_t* pathPool, unsigned long long* pathCursor, uint64_t pathCapacity, AnchorRounds rounds = AnchorRounds(), uint32_t* readTies = nullptr);   // readTies [reads], zeroed by the caller: += the ExtResult::pad flags of the extensions the reference would have run
 
+// gc_results.hip (r5): the result's dense anchor arrays made on the device. perRead[r] = (anchors kept, path words, seeds extended, bit 0 a fragment failed | bit 1 capacity),
+// readOff[2 r] / [2 r + 1] = anchors / path words before read r (totals behind the last read and in hostTotals[0..1], pinned)
+struct AnchorArrays { uint32_t *x, *y, *firstNode, *firstOffset, *firstSeqPos, *lastNode, *lastOffset, *lastSeqPos; int32_t* score; unsigned long long* pathOff; uint32_t* path; };
+void launchAnchorCounts(hipStream_t stream, const ReadChainJob* jobs, uint32_t nReads, const Fragment* frags, const uint32_t* fragStatus, const uint32_t* fragExtended, const AnchorRec* anchors,
+	uint4* perRead, uint32_t* readSlotEnd, unsigned long long* readOff, unsigned long long* hostTotals);
+void launchAnchorCompact(hipStream_t stream, const ReadChainJob* jobs, uint32_t nReads, const AnchorRec* anchors, const uint32_t* pathPool, const uint32_t* readSlotEnd, const unsigned long long* readOff, const AnchorArrays& out);
+
 uint64_t chainScratchBytes(const ChainCaps& caps);
 uint32_t chainGridBlocks(uint32_t nReads);
 uint32_t chainScratchBlocks(uint32_t nReads);

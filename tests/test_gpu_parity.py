@@ -48,7 +48,8 @@ def run_case(gca, gfa, reads, long_pass=False, **kw):
     graph = gca.AlignmentGraph(gfa)
     seeder = gca.MinimizerSeeder(graph)
     capacities = kw.pop("capacities", None)
-    aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, long_pass=long_pass, chain_traces=2, capacities=capacities, **kw)
+    keep_traces = kw.pop("keep_traces", True)
+    aligner = gca.Aligner(graph, seeder, keep_traces=keep_traces, keep_seeds=True, long_pass=long_pass, chain_traces=2, capacities=capacities, **kw)
     got = {k: (v.astype(np.int64) if v.dtype.kind in "ui" and k not in ("counters", "counters_long") else v) for k, v in aligner.align_reads(reads).items()}
     expand_stitched_path(got, graph.array("nodeLength"))
     mark_missing_chain_alignments(got)
@@ -520,6 +521,28 @@ def test_config3_shape_with_whole_read_pass(gca, tmp_path):
     got, want = run_case(gca, gfa, reads, long_pass=True, split_gap=18)
     compare(got, want, COMPARE_KEYS + LONG_KEYS)
     assert int(got["read_anchor_off"][-1]) > 24 * 200
+
+
+@pytest.mark.parametrize("host_anchors", ["0", "1"])
+def test_anchor_arrays_made_on_the_device(gca, tmp_path, monkeypatch, host_anchors):
+    """r5: without the anchors' traces (keep_traces 0 or 2: what bench.py and the output encoders run) the result's anchor_* arrays are compacted per read on the
+    device (gc_results.hip: every valid anchor up to the first fragment that threw, in fragment and seed order) and come down as they are; GC_HOST_ANCHORS=1 keeps
+    the host's walk over the slots. Both against the oracle: 10 kb reads with the whole-read pass, overlapping fragments, chimeric reads, a read too short for a fragment,
+    an empty read, a read of N."""
+    from graphchainer_amd.synth import SynthGraph
+    monkeypatch.setenv("GC_HOST_ANCHORS", host_anchors)
+    sg = SynthGraph(300_000, seed=17, repeats=4, repeat_len=2000, multi_allelic=0.1)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(40, 10_000, seed=3)
+    reads += [reads[0][:3000] + reads[1][2000:6000], "ACGT" * 5, "", "N" * 400, reads[2][:36]]
+    keys = [k for k in COMPARE_KEYS + LONG_KEYS if "trace" not in k]
+    for kw in ({}, {"split_gap": 18}):
+        got, want = run_case(gca, gfa, reads, long_pass=True, keep_traces=False, **kw)
+        compare(got, want, keys)
+        assert int(got["read_anchor_off"][-1]) > 40 * 100
+    got, want = run_case(gca, gfa, reads[:12], long_pass=False, keep_traces=False)
+    compare(got, want, [k for k in COMPARE_KEYS if "trace" not in k])
 
 
 @pytest.mark.parametrize("plain_scan", ["0", "1"])
