@@ -86,7 +86,7 @@ def parse_args():
     if args.config == 5 and args.batch == 10_000:
         args.batch = 2_000
     if args.config == 5 and "GC_BENCH_INFLIGHT" not in os.environ and not any(a.startswith("--inflight") for a in sys.argv[1:]):
-        args.inflight = 4                                  # 2 000 x 50 kb batches: 42 GB each + the shared 48 GB whole-read scratch (r3: 2 -> 1 355, 3 -> 795, 4 -> 685 ms per batch)
+        args.inflight = 5                                  # 2 000 x 50 kb batches: 42 GB each on a 960 Mbp graph + the device's one 21 GB whole-read scratch + 31 GB of graph and index (r5, 960 Mbp: 4 -> 663, 5 -> 649 ms per batch; a sixth does not fit)
     if args.split_gap is None:
         args.split_gap = 18 if args.config == 3 else 35
     return args
