@@ -402,7 +402,7 @@ def main():
     if threads_start is not None:
         now = thread_cpu()
         used = sorted(((now[k] - threads_start.get(k, 0.0), k) for k in now), reverse=True)
-        print("[bench cpu] per step, by thread (s): " + ", ".join(f"{name}/{tid} {d / args.steps:.3f}" for d, (tid, name) in used[:14] if d > 0)
+        print(f"[bench cpu] pid {os.getpid()}; per step, by thread (s): " + ", ".join(f"{name}/{tid} {d / args.steps:.3f}" for d, (tid, name) in used[:14] if d > 0)
               + f"; all threads {sum(d for d, _ in used) / args.steps:.3f}, process {rank_cpu_s / args.steps:.3f}, container {host_cpu_s / args.steps:.3f}", file=sys.stderr)
     mem_free_end, _ = gca.device_memory()
     # Parity of the timed mode (src/Aligner.cpp:630-654,735,901-905): the reads the CPU leg aligned with the oracle are compared, value

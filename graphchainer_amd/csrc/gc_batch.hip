@@ -131,7 +131,7 @@ struct BatchRun {
 	const LongCell* longCells = nullptr;   // keep_traces: the merged traces in pinned staging (a pageable destination made this copy 2-3 s per 10 k reads)
 
 	BatchRun(const gc_graph* G, const gc_seeder* S, gc_stream* st, const gc_reads* R, const gc_params* P, gc_result* res, double tCall, double cpuCall)
-		: G(G), S(S), st(st), R(R), P(P), res(res), tCall(tCall), cpuCall(cpuCall), cpuJoined(cpuCall), n(R->offsets.size() - 1), hg(G->host), pool(WorkerPool::instance()), glue(st->glue),
+		: G(G), S(S), st(st), R(R), P(P), res(res), tCall(tCall), cpuCall(cpuCall), cpuJoined(cpuCall), n(R->offsets.size() - 1), hg(G->host), pool(WorkerPool::batch()), glue(st->glue),
 		  stream(st->stream), longErrors(16) {}
 	~BatchRun() { for (auto& t : longThreads) if (t.joinable()) t.join(); }   // (an exception on the main thread must not leave the pass thread behind with dangling state)
 	BatchRun(const BatchRun&) = delete;

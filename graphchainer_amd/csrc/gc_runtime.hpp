@@ -189,7 +189,11 @@ inline void syncEvent(hipEvent_t ev)
 // Persistent worker pool for the per-read host glue (threads are created once per process).
 class WorkerPool {
 public:
-	static WorkerPool& instance() { static WorkerPool p; return p; }
+	static WorkerPool& instance() { static WorkerPool p(0); return p; }
+	// r5: the batch pipeline's own, smaller pool. Its jobs became short (the seed glue, the stitching and the anchor arrays are kernels now: what is left is a few ms of per-read
+	// bookkeeping and memcpy per stage), and a job wakes every thread of its pool: with 32 workers a batch cost 0.29 CPU-seconds, with 8 0.185 at the same rate (`gpurun_out/r5_hostcpu`).
+	// The output encoders (GAF text, zlib) keep the wide pool.
+	static WorkerPool& batch() { static WorkerPool p(1); return p; }
 	size_t size() const { return workers.size() + 1; }
 	// runs body(i, worker) for i in [0, n); worker in [0, size())
 	void run(size_t n, const std::function<void(size_t, size_t)>& body)
@@ -214,7 +218,7 @@ public:
 		if (failure) { std::exception_ptr e = failure; failure = nullptr; std::rethrow_exception(e); }   // (an exception in a pool thread used to end the process)
 	}
 private:
-	WorkerPool()
+	explicit WorkerPool(int kind)
 	{
 		size_t n = std::max(1u, std::thread::hardware_concurrency());
 		n = std::min<size_t>(n, 96);   // the glue is memory-bound; more threads stop helping
@@ -224,6 +228,10 @@ private:
 		const double quota = gc::cpuQuota();
 		if (quota > 0) n = std::min<size_t>(n, std::max<size_t>(4, (size_t)(2 * quota + 0.5)));
 		if (const char* env = getenv("GC_HOST_THREADS")) n = (size_t)std::max(1, atoi(env));
+		if (kind == 1) {
+			n = std::min<size_t>(n, quota > 0 ? std::max<size_t>(4, (size_t)(quota / 2 + 0.5)) : 8);
+			if (const char* env = getenv("GC_BATCH_THREADS")) n = (size_t)std::max(1, atoi(env));
+		}
 		for (size_t t = 1; t < n; t++) workers.emplace_back([this, t]() { loop(t); });
 	}
 	~WorkerPool()
