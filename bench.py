@@ -121,10 +121,10 @@ def usable_cpus():
     return max(1, n)
 
 
-# Host CPU a batch costs and the batch period by batches in flight (r3 measurements on this pool's boxes, 10 k x 10 kb: host_cpu_s_per_step and the --inflight sweep):
-# a rank keeps k batches in flight fed when it has HOST_CPU_S_PER_BATCH / period(k) CPUs to itself.
-HOST_CPU_S_PER_BATCH = 0.41
-BATCH_MS_BY_INFLIGHT = {1: 204.0, 2: 189.0, 3: 173.0, 4: 165.0, 5: 157.0}
+# Host CPU a batch costs and the batch period by batches in flight (r5 measurements on this pool's boxes, 10 k x 10 kb: host_cpu_s_per_step and the --inflight sweep,
+# `gpurun_out/r5_inflight`; r3: 0.41 CPU-s and 204 / 189 / 173 / 165 / 157 ms): a rank keeps k batches in flight fed when it has HOST_CPU_S_PER_BATCH / period(k) CPUs to itself.
+HOST_CPU_S_PER_BATCH = 0.24
+BATCH_MS_BY_INFLIGHT = {1: 157.0, 2: 148.0, 3: 149.0, 4: 145.0, 5: 146.0}
 
 
 def choose_inflight(asked, cpus, world):

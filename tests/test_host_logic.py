@@ -235,18 +235,18 @@ def test_state_machine_extension_core_equals_oracle(tmp_path):
 
 def test_bench_inflight_rule_follows_the_cpu_budget():
     """bench.py's batches-in-flight rule: from the host CPU a batch costs and the batch period, not from a fixed ranks-to-CPUs ratio.
-    Two ranks on a 16-CPU box keep five batches in flight each; eight ranks there are host-bound whatever they do and keep two (host work overlapping
-    device work) instead of the one the old rule forced; the record says why."""
+    r5 (0.24 CPU-s per batch, 146 ms per batch): eight ranks on a 16-CPU box keep five batches in flight each (1.6 CPUs of the 2 a rank has; r3's 0.41 CPU-s made them
+    host-bound); eight ranks on 8 CPUs are host-bound whatever they do and keep two (host work overlapping device work) instead of one; the record says why."""
     sys.path.insert(0, ROOT)
     import bench
     k, rec = bench.choose_inflight(5, 16, 2)
     assert k == 5 and rec["chosen"] == 5 and rec["cpus_per_rank"] == 8.0 and "5 in flight need" in rec["why"]
     k, rec = bench.choose_inflight(5, 16, 8)
+    assert k == 5 and "host-bound" not in rec["why"]
+    k, rec = bench.choose_inflight(5, 8, 8)
     assert k == 2 and "host-bound" in rec["why"]
-    k, rec = bench.choose_inflight(5, 64, 8)
-    assert k == 5
-    k, rec = bench.choose_inflight(5, 18, 8)          # 2.25 CPUs per rank: two in flight need 2.17
-    assert k == 2 and "host-bound" not in rec["why"]
+    k, rec = bench.choose_inflight(5, 13, 8)          # 1.625 CPUs per rank: one or two in flight need 1.53 / 1.62, three 1.61, four 1.66
+    assert k == 3 and "host-bound" not in rec["why"]
     k, rec = bench.choose_inflight(1, 256, 1)
     assert k == 1
 
