@@ -582,6 +582,8 @@ struct BatchRun {
 			// at most lastWork/2 reads are still active, so this keeps the round within the work arrays (8 per read) and the trace budget (4 seeds' worth per read)
 			if (round > 0 && lastWork > 0) maxCand = (uint32_t)std::min<uint64_t>(maxCand, std::max<uint64_t>(1, (8 * nG) / lastWork));
 			if (const char* env = getenv("GC_LONG_SPECULATE")) maxCand = (uint32_t)std::min(2, std::max(1, atoi(env)));   // test hook: speculate from round 0
+			static const uint32_t candCap = getenv("GC_LONG_CAND_MAX") ? (uint32_t)std::max(1, std::min(8, atoi(getenv("GC_LONG_CAND_MAX")))) : 8u;   // measurement hook: fewer speculated seeds per read and round
+			maxCand = std::min(maxCand, candCap);
 			// speculation plan (r4): candidates per read in rounds 0, 1, 2, ... (the last entry repeats), a floor under the rule above; still bounded by the work arrays
 			// and the trace budget (at most nG / 2... reads x candidates <= 4 nG). Why: rounds 3-5 of cfg2 hold fewer work items than the chip has wave slots and cost one
 			// extension's latency (~17 ms) each - 98 % of the reads extend a second seed and 81 % a third, so asking for two seeds per read from round 0 on

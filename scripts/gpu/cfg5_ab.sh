@@ -9,7 +9,7 @@ setup=/tmp/gcsetup_ab_$b
 for r in $(seq 1 ${CFG5_ROUNDS:-1}); do
   for v in "$@"; do
     envvar="AB_ENV_$v"
-    env ${!envvar} timeout 1500 python3 $GRAFT_REPO_ROOT/bench.py --config 5 --backbone $b --setup-dir $setup --steps 4 --warmup 1 --e2e-steps 0 --no-cpu-baseline ${CFG5_ARGS:---inflight 5} > $out/${v}_$r.json 2> $out/${v}_$r.err
+    env ${!envvar} timeout 1500 python3 $GRAFT_REPO_ROOT/bench.py --config 5 --backbone $b --setup-dir $setup --steps ${CFG5_STEPS:-15} --warmup ${CFG5_WARMUP:-5} --e2e-steps 0 --no-cpu-baseline ${CFG5_ARGS:---inflight 5} > $out/${v}_$r.json 2> $out/${v}_$r.err
     python3 - $out/${v}_$r.json $v <<'PY'
 import json, sys
 try:

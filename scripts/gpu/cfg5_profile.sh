@@ -9,7 +9,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for b in $sizes; do
   setup=/tmp/gcsetup_$b
-  GC_DEBUG_TIMES=1 timeout ${CFG5_TIMEOUT:-2400} python3 $GRAFT_REPO_ROOT/bench.py --config 5 --backbone $b --setup-dir $setup --steps 4 --warmup 1 --e2e-steps ${CFG5_E2E:-0} $CFG5_ARGS > $out/cfg5_$b.json 2> $out/cfg5_$b.err
+  GC_DEBUG_TIMES=1 timeout ${CFG5_TIMEOUT:-2400} python3 $GRAFT_REPO_ROOT/bench.py --config 5 --backbone $b --setup-dir $setup --steps ${CFG5_STEPS:-15} --warmup ${CFG5_WARMUP:-5} --e2e-steps ${CFG5_E2E:-0} $CFG5_ARGS > $out/cfg5_$b.json 2> $out/cfg5_$b.err
   echo "size $b rc $?"
   grep "gc mem" $out/cfg5_$b.err | tail -4
   python3 - $out/cfg5_$b.json <<'PY'

@@ -4,7 +4,7 @@ tag=$1; b=$2; shift 2
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-GC_DEBUG_TIMES=1 timeout ${CFG5_TIMEOUT:-2400} python3 $GRAFT_REPO_ROOT/bench.py --config 5 --backbone $b --steps 4 --warmup 1 --e2e-steps ${CFG5_E2E:-0} "$@" > $out/cfg5_$b.json 2> $out/cfg5_$b.err
+GC_DEBUG_TIMES=1 timeout ${CFG5_TIMEOUT:-2400} python3 $GRAFT_REPO_ROOT/bench.py --config 5 --backbone $b --steps ${CFG5_STEPS:-15} --warmup ${CFG5_WARMUP:-5} --e2e-steps ${CFG5_E2E:-0} "$@" > $out/cfg5_$b.json 2> $out/cfg5_$b.err
 echo "size $b rc $?"
 grep "gc mem" $out/cfg5_$b.err | tail -3
 grep "gc ed" $out/cfg5_$b.err | head -300 > $out/ed_$b.txt
