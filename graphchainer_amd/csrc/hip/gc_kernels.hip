@@ -255,7 +255,7 @@ __device__ inline void mergedCell(const DGraph& g, const MergedView& v, uint32_t
 	}
 }
 
-__global__ void __launch_bounds__(64) k_build_anchors(DGraph g, const Fragment* __restrict__ frags, uint32_t nFrags, const FragSeed* __restrict__ seeds,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) k_build_anchors(DGraph g, const Fragment* __restrict__ frags, uint32_t nFrags, const FragSeed* __restrict__ seeds,
 	const ExtResult* __restrict__ ext, const TraceCell* __restrict__ tracePool, int32_t splitLen,
 	AnchorRec* __restrict__ anchors, uint32_t* __restrict__ fragStatus, uint32_t* __restrict__ fragExtended,
 	uint32_t* __restrict__ pathPool, unsigned long long* __restrict__ pathCursor, uint64_t pathCapacity, AnchorRounds rounds, uint32_t* __restrict__ readTies)
@@ -273,7 +273,8 @@ __global__ void __launch_bounds__(64) k_build_anchors(DGraph g, const Fragment* 
 	Fragment fr = frags[f];
 	uint32_t status = 0;       // 0 ok, 1 the reference would throw in this fragment, 2 capacity overflow
 	uint32_t extended = 0;
-	uint32_t ties = 0;         // extensions consumed in this launch whose flattenLastSliceEnd minimum was tied between nodes (ExtResult::pad), added to the read's count on the way out
+	// (extensions consumed in this launch whose flattenLastSliceEnd minimum was tied between nodes - ExtResult::pad, one in thirty - are added to the read's count where they are met:
+	// a counter kept across the seed loop cost six registers and a wave per SIMD)
 	uint32_t nSeeds = fr.seedEnd - fr.seedBegin;
 	uint32_t firstSeed = 0;
 	if (rounds.lazy && rounds.round > 0) { firstSeed = rounds.fragNext[f]; extended = fragExtended[f]; }
@@ -340,14 +341,13 @@ __global__ void __launch_bounds__(64) k_build_anchors(DGraph g, const Fragment* 
 			rounds.nextPending[atomicAdd(rounds.nextPendingCount, 1ull)] = f;
 			rounds.fragNext[f] = k;
 			fragExtended[f] = extended;
-			if (ties && readTies) atomicAdd(&readTies[fr.read], ties);
 			return;
 		}
 		extended++;
 		bool runB = p > 0, runF = p < splitLen - 1;
 		// (the reference runs the backward extension first and the forward one only if that did not throw, src/GraphAligner.h:499-511)
-		if (runB) ties += eb.pad & 1u;
-		if (runF && !(runB && eb.status == EXT_ASSERT)) ties += ef.pad & 1u;
+		if (readTies && runB && (eb.pad & 1u)) atomicAdd(&readTies[fr.read], 1u);
+		if (readTies && runF && !(runB && eb.status == EXT_ASSERT) && (ef.pad & 1u)) atomicAdd(&readTies[fr.read], 1u);
 		if ((runB && eb.status == EXT_ASSERT) || (runF && ef.status == EXT_ASSERT)) { status = 1; break; }
 		if ((runB && eb.status == EXT_OVERFLOW) || (runF && ef.status == EXT_OVERFLOW)) { status = 2; break; }
 		bool hasB = runB && eb.status == EXT_OK, hasF = runF && ef.status == EXT_OK;
@@ -438,7 +438,6 @@ __global__ void __launch_bounds__(64) k_build_anchors(DGraph g, const Fragment* 
 	if (status != 0) for (uint32_t k = 0; k < nSeeds; k++) anchors[fr.seedBegin + k].valid = 0;   // a throwing AlignOneWay returns nothing
 	fragStatus[f] = status;
 	fragExtended[f] = extended;
-	if (ties && readTies) atomicAdd(&readTies[fr.read], ties);
 }
 
 // =====================================================================================================
