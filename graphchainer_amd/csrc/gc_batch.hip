@@ -470,7 +470,7 @@ struct BatchRun {
 		if (nGroups != 1 || longExtendTeamSize(1) != 1) return false;
 		for (const char* name : { "GC_LONG_SM", "GC_LONG_LANE", "GC_LONG_MAX_BLOCKS", "GC_LONG_PLAN" }) if (getenv(name)) return false;   // experiments and test hooks of the host-driven loop
 		if (getenv("GC_LONG_TOKEN") && atoi(getenv("GC_LONG_TOKEN")) == 2) return false;
-		if (!(getenv("GC_LONG_ROUNDS") && atoi(getenv("GC_LONG_ROUNDS")) == 1)) return false;   // GC_LONG_ROUNDS=1 selects it: measured 4-6 % SLOWER than the host-driven loop (DESIGN.md §4f), which stays the default
+		if (!(getenv("GC_LONG_ROUNDS") && atoi(getenv("GC_LONG_ROUNDS")) == 1)) return false;   // GC_LONG_ROUNDS=1 selects it: measured 4-6 % SLOWER than the host-driven loop (DESIGN.md §11), which stays the default
 		(void)g;
 		return true;
 	}
@@ -624,7 +624,7 @@ struct BatchRun {
 			hipEvent_t ev0 = ring[2 * (timedRounds % LONG_EVENT_RING)], ev1 = ring[2 * (timedRounds % LONG_EVENT_RING) + 1];
 			HIP_CHECK(hipEventRecord(ev0, q));
 			// The experiments build (`make -C graphchainer_amd/csrc experiments`) can replace the extension step by one of the two measured-and-rejected layouts:
-			// GC_LONG_SM=1 (DESIGN.md §4: one extension per LANE as per-lane state machines, k_long_extend_sm in gc_sm.hip, 6x slower; what outgrows its tables -
+			// GC_LONG_SM=1 (DESIGN.md §11: one extension per LANE as per-lane state machines, k_long_extend_sm in gc_sm.hip, 6x slower; what outgrows its tables -
 			// EXT_SM_DECLINED - is listed and rerun one extension per wave) or GC_LONG_LANE=1 (one extension per LANE with the plain-layout core and a per-lane HBM slab, 6.9x slower)
 #ifdef GC_EXPERIMENTS
 			const bool useSm = team == 1 && getenv("GC_LONG_SM") && atoi(getenv("GC_LONG_SM")) == 1;

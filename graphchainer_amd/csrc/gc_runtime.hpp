@@ -89,7 +89,7 @@ struct DeviceBuffer {   // growable device allocation owned by a stream object
 // seeding, host glue and fragment pipeline overlap the first batch's whole-read pass, and its own pass starts the moment the first
 // one ends - a software pipeline over batches (GC_LONG_TOKEN=0 turns it off).
 // r4: GC_LONG_TOKENS=2 (experiment) - two tokens per device, each with a scratch of its own (half the budget): a pass's tail rounds hold fewer extensions than the chip has wave
-// slots and cost one extension's latency each; a second pass side by side fills them (measured: DESIGN.md §4)
+// slots and cost one extension's latency each; a second pass side by side fills them (measured: DESIGN.md §11)
 inline constexpr int LONG_TOKENS_MAX = 2;
 struct PassTokens {
 	std::mutex m;
@@ -868,7 +868,7 @@ inline uint32_t editDistanceUnit(uint32_t k, uint32_t readLen)
 	return unit;
 }
 // Streams of the fragment pipeline / the edit distances (role 0) and of the whole-read rounds (role 1). GC_STREAM_PRIORITY=frag|long raises one
-// side's queue priority (experiment, DESIGN.md §4): the whole-read kernel holds 7 of a SIMD's 8 wave slots for milliseconds per wave, so
+// side's queue priority (experiment, DESIGN.md §11): the whole-read kernel holds 7 of a SIMD's 8 wave slots for milliseconds per wave, so
 // whatever shares the device with it runs on what is left.
 inline void createStream(hipStream_t* q, int role)
 {

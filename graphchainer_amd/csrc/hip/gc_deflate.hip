@@ -2,7 +2,7 @@
 //
 // The reference writes a read's alignments as ONE gzip member (writeGAMToQueue, src/Aligner.cpp:261-281: protobuf's GzipOutputStream at zlib's default level). At the hot path's rate
 // that deflate is the host's bound: ~1 ms of CPU per 10 kb read, 10-11 CPU-seconds per 10 k reads, 14.6 k reads/s end to end on the 16 CPUs of the pool's boxes against 60 k for GAF
-// (DESIGN.md §11). A GAM stream is read bases (four letters) and varint-coded path messages: most of what deflate gains on it comes from the Huffman stage, not from LZ77 matches.
+// (DESIGN.md §3.9, §10). A GAM stream is read bases (four letters) and varint-coded path messages: most of what deflate gains on it comes from the Huffman stage, not from LZ77 matches.
 // So the device writes every stream as one dynamic-Huffman block of literals (RFC 1951 §3.2.7, no length / distance codes): any inflate reads it, the inflated bytes are the
 // reference's, the file is ~1.3x the size zlib's level 6 gives, and the host only frames the member (gzip header, CRC-32, length).
 //

@@ -1,6 +1,6 @@
 // Device-side data layout and the banded bit-vector seed-extension core for gfx950 (MI355X).
 //
-// Mapping (DESIGN.md §kernels): one LANE per seed extension. The inner loop of the reference is a chain of
+// Mapping (DESIGN.md §3.1): one LANE per seed extension. The inner loop of the reference is a chain of
 // up to 63 dependent 64-bit Myers column steps per (node, 64-row slice) tile
 // (reference: src/GraphAlignerBitvectorCommon.h:1118-1161): rows are already packed in the 64-bit word, columns
 // are serial, slices are serial and the band of the next slice depends on this slice's minimum, so the
@@ -198,7 +198,7 @@ struct LaneScratch {
 	Pending* pending;
 	WCol* columns;      // one node's recomputed columns for the backtrace: column c at columns[(c & colMask) * colStride]
 	uint32_t colMask;   // 63: the whole tile (per-lane slab in HBM). Smaller (r4, k_extend): a ring of the last colMask + 1 columns in LDS - the walk only moves left, and when it leaves
-	uint32_t colStride; // the ring the tile is recomputed up to the column it stands on (DESIGN.md §3)
+	uint32_t colStride; // the ring the tile is recomputed up to the column it stands on (DESIGN.md §3.1)
 	TraceCell* trace;
 	uint32_t* itemNodes; // the items' node ids again, packed (r4): "is this node in that slice" scans 4 B per item instead of pulling a 64 B item record per probe
 };

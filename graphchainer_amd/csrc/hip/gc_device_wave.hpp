@@ -21,7 +21,7 @@
 namespace gcdev {
 
 
-// The scalar-lean forms of the one-extension-per-wave instantiation's hot loops (r2 / r3, DESIGN.md §4): each GC_LEAN_* names one rewrite whose plain twin stays in the source as
+// The scalar-lean forms of the one-extension-per-wave instantiation's hot loops (r2 / r3, DESIGN.md §3.2): each GC_LEAN_* names one rewrite whose plain twin stays in the source as
 // the readable statement of the same step, as the code of the multi-lane instantiations (the register-table retry runs LANES = 2) and of the host compile. The product build
 // always takes the lean forms; only the experiments build (-DGC_EXPERIMENTS) may switch one off for an A/B (`make variant FLAGS="-DGC_EXPERIMENTS -DGC_LEAN_WALK=0"`).
 #ifndef GC_EXPERIMENTS

@@ -1115,7 +1115,7 @@ __global__ void __launch_bounds__(64) k_long_select(DGraph g, const LongJob* __r
 template <int LANES, bool PERSISTENT>
 #ifndef GC_LONG_WAVES_ONE
 #define GC_LONG_WAVES_ONE 5   // waves per SIMD the one-extension-per-wave instantiation is compiled for. 8: 64 VGPRs, 35 of them spilled to 112 B of scratch per lane; 7: 72 / 80 B; 6: 80 / 48 B;
-                              // 5 (and 4): 87 VGPRs, no scratch. The kernel is bound by the CU's scalar unit, not by latency: all five measure the same (DESIGN.md §4e), so the build without scratch is kept
+                              // 5 (and 4): 87 VGPRs, no scratch. The kernel is bound by the CU's scalar unit, not by latency: all five measure the same (DESIGN.md §11), so the build without scratch is kept
 #endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LANES == 1 ? GC_LONG_WAVES_ONE : GC_LONG_MIN_WAVES, 8))) k_long_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint64_t* __restrict__ masks, ExtendConfig cfg,
 	const LongWork* __restrict__ work, const uint32_t* __restrict__ order, uint32_t nWork, unsigned long long* __restrict__ scratch, uint64_t wordsPerLane,
@@ -1196,7 +1196,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LANES =
 }
 
 #ifdef GC_EXPERIMENTS   // (`make -C graphchainer_amd/csrc experiments`: measured and rejected alternatives are not part of the product library)
-// The measurement VERDICT r3 asked for (GC_LONG_LANE=1, off by default): the same rounds, but every LANE takes one work item and runs the
+// The measurement VERDICT r3 asked for (GC_LONG_LANE=1, experiments build): the same rounds, but every LANE takes one work item and runs the
 // plain-layout core (extendSeedT, gc_device.hpp: the core of k_extend and k_long_pass) with its band state in a per-lane HBM slab - no LDS tables, no
 // state machine, <= 128 VGPRs (4 waves per SIMD). Work items arrive longest first (k_long_order), so a wave's 64 extensions have about the same number of
 // slices. What outgrows the slab answers EXT_OVERFLOW and its read goes to the plain-layout fallback like any other overflow.

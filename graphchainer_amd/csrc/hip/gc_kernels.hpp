@@ -210,13 +210,13 @@ void launchLongExtend(hipStream_t stream, const DGraph& g, const CorrectnessTabl
 	unsigned long long* scratch, uint32_t lanes, uint32_t blocks, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters,
 	unsigned long long* nextSlot, uint32_t retryStatus = 0, const unsigned long long* nWorkOnDevice = nullptr, uint32_t* capListOut = nullptr, unsigned long long* capCountOut = nullptr,
 	bool gridCoversCount = false);   // nWorkOnDevice: `order` is a list whose length only the device knows (then nWork is its upper bound; gridCoversCount: blocks x lanes >= that bound, no fetch loop needed)
-#ifdef GC_EXPERIMENTS   // measured and rejected alternatives of the whole-read pass (DESIGN.md §4): only in `make experiments`
+#ifdef GC_EXPERIMENTS   // measured and rejected alternatives of the whole-read pass (DESIGN.md §11): only in `make experiments`
 // the whole inter-round step in one launch: merge of the previous round + select + execution order + work count to device and host (k_long_round)
 void launchLongRound(hipStream_t stream, const DGraph& g, const LongJob* jobs, uint32_t nReads, const LongSeed* seeds, uint32_t minClusterSize, uint32_t round, uint32_t forceCand, uint32_t gridLimit,
 	LongState* state, LongAln* alns, LongCell* cellPool, unsigned long long* cellCursor, uint64_t cellCapacity, uint32_t maxAlignments, LongWork* work, uint32_t* workLen, uint32_t* candSeed,
 	const LongWorkResult* results, const unsigned long long* tracePool, unsigned long long* cursorSets, unsigned long long* roundInfo, unsigned long long* ticket, uint32_t* order, uint32_t maxLen, uint32_t orderMode,
 	unsigned long long* hostInfo, uint64_t workCapacity);
-// the same extensions one per LANE with the plain-layout core and a per-lane HBM slab (k_long_extend_lane: the layout measurement of DESIGN.md §4e, GC_LONG_LANE=1)
+// the same extensions one per LANE with the plain-layout core and a per-lane HBM slab (k_long_extend_lane: the layout measurement of DESIGN.md §11, GC_LONG_LANE=1)
 void launchLongExtendLane(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint64_t* masks, const ExtendConfig& cfg, const LongWork* work, const uint32_t* order, uint32_t nWork,
 	uint8_t* scratch, uint64_t scratchBytes, unsigned long long* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, LongWorkResult* results, unsigned long long* counters);
 // the same extensions one per LANE as per-lane state machines (gc_sm.hip); what outgrows its tables answers EXT_SM_DECLINED (6) and is rerun by launchLongExtend
