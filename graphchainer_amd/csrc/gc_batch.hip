@@ -1057,6 +1057,11 @@ struct BatchRun {
 		ExtItem* dWork = st->work.reserve<ExtItem>(nWork);
 		dResults = st->results.reserve<ExtResult>(nWork);
 		uint8_t* dScratch = st->scratch.reserve<uint8_t>((uint64_t)lanes * slabBytes);
+		if (st->poolsRerun && poolReruns == 0) {   // (the batch after a rerun: see DeviceBuffer::shrinkTo)
+			st->tracePool.shrinkTo(traceBudget * sizeof(TraceCell));
+			st->pathPool.shrinkTo(pathCapacity * sizeof(uint32_t));
+			st->poolsRerun = false;
+		}
 		dTrace = st->tracePool.reserve<TraceCell>(traceBudget, true);
 		if (!deviceGlue) dFrags = st->frags.reserve<Fragment>(nFrags);
 		FragSeed* dFragSeeds = st->fragSeeds.reserve<FragSeed>(nSlots);
@@ -1198,6 +1203,7 @@ struct BatchRun {
 		if (pathShort) pathCapacity = std::min<uint64_t>(pathWorst, pathNeed + pathNeed / 5 + 4096);
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc mem] the fragment pipeline runs again: trace pool %.2f G cells needed (now %.2f), anchor path pool %.2f G words needed (now %.2f)\n", traceNeed / 1e9, traceBudget / 1e9, pathNeed / 1e9, pathCapacity / 1e9);
 		poolReruns++;
+		st->poolsRerun = true;
 		return true;
 	}
 

@@ -69,7 +69,6 @@ struct DeviceBuffer {   // growable device allocation owned by a stream object
 	template <typename T> T* reserve(size_t count, bool tight = false)   // tight: no head room (the pools that are sized by use bring their own slack)
 	{
 		size_t need = std::max<size_t>(count, 1) * sizeof(T);
-		if (tight && bytes > need + need / 4 + (64u << 20)) release();   // a pool that a rerun sized from an overshooting request count comes back to what its batches use (once: hipFree drains the device)
 		if (need > bytes) {
 			if (ptr) HIP_CHECK(hipFree(ptr));
 			ptr = nullptr;
@@ -81,6 +80,13 @@ struct DeviceBuffer {   // growable device allocation owned by a stream object
 		return (T*)ptr;
 	}
 	void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; bytes = 0; }
+	// a pool that a rerun sized from an overshooting request count comes back to what its batches use: called once, by the batch after the rerun (hipFree drains the device)
+	void shrinkTo(size_t needBytes)
+	{
+		const char* env = getenv("GC_POOL_SHRINK_FLOOR");   // (test hook, read per call - the tests set it mid-process: small pools shrink too)
+		const size_t floor = env ? (size_t)std::max(0ll, atoll(env)) : (size_t)(64u << 20);
+		if (bytes > needBytes + needBytes / 4 + floor) release();
+	}
 	~DeviceBuffer() { if (ptr) (void)hipFree(ptr); }
 };
 
@@ -568,6 +574,7 @@ struct gc_stream {
 		uint32_t nPairs = 0;
 	} edLong[2];
 	uint64_t longCellsPerBase = 4;           // merged-trace cells per read base the whole-read pass reserves (10 kb ONT-like reads use 1.1, 50 kb CLR-like reads on a genome with repeats 9-10; grows by what a batch asks for)
+	bool poolsRerun = false;                  // the last batch ran its fragment pipeline again with larger pools: the next one gives back what that overshot
 	double traceCellsPerSlot = 0, pathWordsPerSlot = 0;   // what this stream's batches have used of the fragment pipeline's trace pool / anchor path pool per anchor slot (0: no batch yet)
 	std::vector<hipStream_t> groupStreams;   // read groups of the whole-read pass run their round loops concurrently
 	std::vector<hipEvent_t> groupEvents;     // 2 * LONG_EVENT_RING per group

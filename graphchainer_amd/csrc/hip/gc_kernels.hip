@@ -1559,9 +1559,10 @@ void launchChain(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs, 
 	else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<1>), dim3(chainGridBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, forceScratch ? 1u : 0u);
 	// reads with more anchors / entries than the LDS tables hold, or on a cover wider than the LDS threshold table (waves whose read is done leave at once).
 	// The batch's bounds tell when no read can need it (cfg2: 400 slots per read at most, cover width 2): 2 048 waves that look and leave cost 7 ms of queueing per batch.
-	// (it is then a safety net of eight waves for what the bounds do not show - a graph with more than 65 535 components, a read beyond 65 535 fragment positions)
+	// (it is then a safety net of 64 waves for what the bounds do not show - a graph with more than 65 535 components, a read beyond 65 535 fragment positions; r5: eight waves
+	// took 9-12 ms to look at 10 000 reads' status words, two dependent loads per read, in the fragment pipeline's critical path)
 	const bool cannotBeNeeded = !forceScratch && caps.capAnchors <= CHAIN_LDS_ANCHORS / (small ? 2 : 1) && caps.capEndpoints <= CHAIN_LDS_ENTRIES / (small ? 2 : 1) && caps.capTable <= CHAIN_LDS_WIDTH / (small ? 2 : 1);
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<0>), dim3(cannotBeNeeded ? (nReads < 8 ? nReads : 8) : chainScratchBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, scratchFlags);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chain<0>), dim3(cannotBeNeeded ? (nReads < 64 ? nReads : 64) : chainScratchBlocks(nReads)), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, splitLen, splitGap, caps, scratch, chainScratchBytes(caps), chainOut, chainLen, chainScore, chainStatus, scratchFlags);
 }
 
 uint64_t longWaveWordsPerLane(const ExtendConfig& cfg) { return waveScratchWords(cfg.maxSlices, cfg.maxItems, cfg.maxTrace, cfg.maxCols); }

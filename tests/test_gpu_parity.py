@@ -1059,6 +1059,7 @@ def test_fragment_pools_sized_by_use_rerun_when_too_small(gca, tmp_path, monkeyp
     sg.write_gfa(gfa)
     reads = sg.sample_reads(40, 3000, seed=2)
     monkeypatch.setenv("GC_POOL_FIRST_GUESS", "0.5")
+    monkeypatch.setenv("GC_POOL_SHRINK_FLOOR", "0")      # (the batch after a rerun gives back what the rerun's sizing overshot: here small pools do too)
     graph = gca.AlignmentGraph(gfa)
     seeder = gca.MinimizerSeeder(graph)
     aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, long_pass=True, chain_traces=2)
@@ -1072,6 +1073,16 @@ def test_fragment_pools_sized_by_use_rerun_when_too_small(gca, tmp_path, monkeyp
         compare(got, want)
         assert not got["capacity_exceeded"].any()
     assert reruns[0] >= 1 and reruns[1] == 0, reruns
+    # a new stream whose first batch reruns, then a much smaller batch (the pools come back to what it needs), then the big one again (they grow): every time the oracle's results
+    aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, long_pass=True, chain_traces=2)
+    few = reads[:3]
+    want_few = Oracle(gfa, long_pass=True).align(few)
+    for batch, expect in ((reads, want), (few, want_few), (reads, want), (few, want_few)):
+        got = {k: (v.astype(np.int64) if v.dtype.kind in "ui" and k not in ("counters", "counters_long") else v) for k, v in aligner.align_reads(batch).items()}
+        expand_stitched_path(got, graph.array("nodeLength"))
+        mark_missing_chain_alignments(got)
+        compare(got, expect)
+        assert not got["capacity_exceeded"].any()
 
 
 def test_flatten_tie_counts_equal_the_oracles(gca, tmp_path):
