@@ -812,7 +812,7 @@ void gc_stream_destroy(gc_stream* st)
 		SharedLongScratch& shared = g_longScratch[st->device & 15];
 		if (--shared.streams == 0) {   // the device's last stream: nobody can hold the token any more
 			TokenHold tokens[LONG_TOKENS_MAX];
-			for (int t = 0; t < longTokenCount(); t++) tokens[t].lock(g_longPassToken[st->device & 15], longTokenCount());
+			for (int t = 0; t < LONG_TOKENS_MAX; t++) tokens[t].lock(g_longPassToken[st->device & 15], LONG_TOKENS_MAX);
 			int current = 0;
 			if (hipGetDevice(&current) == hipSuccess) { (void)hipSetDevice(st->device); for (auto& b : shared.buffer) b.release(); (void)hipSetDevice(current); }
 		}

@@ -94,8 +94,7 @@ struct DeviceBuffer {   // growable device allocation owned by a stream object
 // (two batches in flight on two gc_streams) only take turns at a finer grain and both finish late. With the token the second batch's
 // seeding, host glue and fragment pipeline overlap the first batch's whole-read pass, and its own pass starts the moment the first
 // one ends - a software pipeline over batches (GC_LONG_TOKEN=0 turns it off).
-// r4: GC_LONG_TOKENS=2 (experiment) - two tokens per device, each with a scratch of its own (half the budget): a pass's tail rounds hold fewer extensions than the chip has wave
-// slots and cost one extension's latency each; a second pass side by side fills them (measured: DESIGN.md §11)
+// r4 / r5: two tokens per device, each with a scratch of its own, for passes that cannot fill the chip (longTokenCount below)
 inline constexpr int LONG_TOKENS_MAX = 2;
 struct PassTokens {
 	std::mutex m;
@@ -128,7 +127,16 @@ inline const char* expEnv(const char* name) { return getenv(name); }
 #else
 inline const char* expEnv(const char*) { return nullptr; }
 #endif
-inline int longTokenCount() { const char* e = expEnv("GC_LONG_TOKENS"); return e ? std::max(1, std::min(LONG_TOKENS_MAX, atoi(e))) : 1; }   // (read per use: the tests switch inside one process)
+// r5: how many passes may run side by side on a device is decided per batch. A pass whose rounds cannot fill the chip - round 0 holds two work items per read, k_long_extend<1> has
+// 5 120 wave slots (256 CUs x 4 SIMDs x 5 waves) - shares the device with a second one: 2 000 x 50 kb reads on a 192 Mbp graph 4.0-4.2 k -> 5.0-5.3 k reads/s (`gpurun_out/r5_cfg5_tok`);
+// a pass that fills it (10 k x 10 kb: 20 000 items) keeps the device to itself (two side by side measured slower in r4). GC_LONG_TOKENS=1|2 overrides (read per batch: the tests switch
+// inside one process). The second token has a scratch of its own and is only taken when the device has the memory for it.
+inline constexpr uint64_t LONG_WAVE_SLOTS = 5120;
+inline int longTokenCount(uint64_t nReads)
+{
+	if (const char* e = getenv("GC_LONG_TOKENS")) return std::max(1, std::min(LONG_TOKENS_MAX, atoi(e)));
+	return 2 * nReads + 128 <= LONG_WAVE_SLOTS ? 2 : 1;
+}
 inline std::mutex g_longRoundToken[16];   // GC_LONG_TOKEN=2 (experiment): the token handed over per round
 // The pass's extension scratch (up to 48 GB: one region per resident wave) is only touched while the token is held, so the gc_streams of a device share ONE
 // (r3: 85 -> 37 GB per stream for 10 k x 10 kb batches, which is what lets five batches be in flight on a 288 GB device instead of three). It belongs to the

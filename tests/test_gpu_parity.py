@@ -1201,16 +1201,19 @@ def _normalise(out, node_length):
     return got
 
 
-@pytest.mark.parametrize("token", ["0", "1"])
+@pytest.mark.parametrize("token", ["0", "1", "one", "two"])
 def test_batches_in_flight_equal_serial_and_oracle(gca, tmp_path, monkeypatch, token):
     """The mode bench.py times: several gc_align_batch calls in flight on ONE device, each on its own gc_stream and host thread
     (run_queue with workers > 1, the reference's -t workers over one queue, src/Aligner.cpp:1267-1270), whole-read pass on, with the
-    two settings of the per-device whole-read token (none / per pass; the per-round token and the two-token variant live in the experiments build since r5). Four different read sets go through three
+    settings of the per-device whole-read token: none ("0"), per pass with the r5 rule ("1": batches this small may run two passes side by side, each in a scratch of its
+    own), and the rule overridden to one or two tokens ("one", "two"; the per-round token lives in the experiments build). Four different read sets go through three
     Aligners concurrently, twice each; every result array must equal the oracle's AND the same Aligner's serial answer."""
     from graphchainer_amd.synth import SynthGraph
     from graphchainer_amd.workqueue import ReadQueue, run_queue
     from oracle import Oracle
-    monkeypatch.setenv("GC_LONG_TOKEN", token)
+    monkeypatch.setenv("GC_LONG_TOKEN", "0" if token == "0" else "1")
+    if token in ("one", "two"):
+        monkeypatch.setenv("GC_LONG_TOKENS", "1" if token == "one" else "2")
     sg = SynthGraph(300_000, seed=17, repeats=3, repeat_len=1500)
     gfa = str(tmp_path / "g.gfa")
     sg.write_gfa(gfa)
