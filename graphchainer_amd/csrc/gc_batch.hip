@@ -170,6 +170,7 @@ struct BatchRun {
 		chainedAlignments(); stageDone(7);
 		encodeOutput(); stageDone(8);
 		assemble(); stageDone(9);
+		st->batchesDone++;
 		if (cpuStages)
 			fprintf(stderr, "[gc cpu] main thread, ms of its own CPU: seeds %.1f, whole-read set-up %.1f + start %.1f, fragment pipeline %.1f, results back %.1f, stitching + chain distances %.1f, join %.1f, chained alignments %.1f, output %.1f, assembly %.1f; pass thread %.1f\n",
 				cpuStage[0], cpuStage[1], cpuStage[2], cpuStage[3], cpuStage[4], cpuStage[5], cpuStage[6], cpuStage[7], cpuStage[8], cpuStage[9], passThreadCpuMs);
@@ -412,7 +413,7 @@ struct BatchRun {
 			dRoundTrace = st->longRoundTrace.reserve<unsigned long long>(groupTraceBegin[nGroups]);
 			// extension scratch: one region per lane of a resident wave (persistent waves fetch work items), per read group
 			// (bounded by a memory budget: 0.8 MB per lane for 10 kb reads, 2.4 MB for 50 kb reads; GC_LONG_SCRATCH_GB overrides the 48 GB)
-			uint64_t scratchBudget = P->capacity.long_scratch_bytes > 0 ? (uint64_t)P->capacity.long_scratch_bytes : (48ull << 30) / (uint64_t)longTokenCount(n);
+			uint64_t scratchBudget = P->capacity.long_scratch_bytes > 0 ? (uint64_t)P->capacity.long_scratch_bytes : (48ull << 30) / (uint64_t)longTokenCount(n, st->batchesDone);
 			if (const char* env = getenv("GC_LONG_SCRATCH_GB")) scratchBudget = (uint64_t)std::max(1, atoi(env)) << 30;
 			// (r5: no more lanes than a round can hold without speculation - two work items per read; the late rounds' speculation stays below that, and a round that does exceed
 			// it runs persistent waves. A 2 000 x 50 kb batch reserved 48 GB for rounds of 4 000 extensions, a 10 k x 10 kb batch 48 GB for 20 000: now 20 and 27 GB)
@@ -913,7 +914,7 @@ struct BatchRun {
 							if (held) return;
 							const double tAsk = nowUs();
 							if (tokenMode == 1 && longGroups == 1) {
-								token.lock(g_longPassToken[device & 15], longTokenCount(n));
+								token.lock(g_longPassToken[device & 15], longTokenCount(n, st->batchesDone));
 								if (token.slot > 0 && shareLongScratch) {   // the second token's scratch is only grown when the device has the room: otherwise this pass waits for the first token like any other
 									const DeviceBuffer& have = g_longScratch[device & 15].buffer[token.slot];
 									size_t freeBytes = 0, totalBytes = 0;
