@@ -120,7 +120,7 @@ struct TokenHold {
 	void unlock() { if (slot >= 0) { tokens->release(slot); slot = -1; } }
 	~TokenHold() { unlock(); }
 };
-// Switches of measured-and-rejected alternatives (two tokens, a token per round, read groups, the lane-per-extension kernel, ...) exist only in the experiments build
+// Switches of measured-and-rejected alternatives (a token per round, read groups, the lane-per-extension kernel, ...) exist only in the experiments build
 // (`make -C graphchainer_amd/csrc experiments`, -DGC_EXPERIMENTS): the product library does not read them. INTEGRATION.md §7 lists the switches that remain.
 #ifdef GC_EXPERIMENTS
 inline const char* expEnv(const char* name) { return getenv(name); }
