@@ -47,6 +47,30 @@ def test_product_does_not_touch_the_oracle():
             assert "oracle/" not in text.replace("under oracle/", "") and "from oracle" not in text and "import oracle" not in text, os.path.join(dirpath, f)
 
 
+def test_every_environment_switch_of_the_product_is_documented():
+    """the product library reads a fixed set of GC_* variables, and INTEGRATION.md §7 is the one table that lists them. Every name the sources read
+    (getenv / capacityOr; expEnv names exist only in the experiments build and are listed there as such) must appear in INTEGRATION.md, and DESIGN.md stays one
+    document with one numbering below 100 KB."""
+    import re
+    names = set()
+    csrc = os.path.join(ROOT, "graphchainer_amd", "csrc")
+    for dirpath, _, files in os.walk(csrc):
+        if os.path.basename(dirpath) == "build":
+            continue
+        for f in files:
+            if f.endswith((".hip", ".hpp", ".cpp", ".h")):
+                names.update(re.findall(r'(?:getenv|expEnv|capacityOr)\("(GC_[A-Z0-9_]+)"', open(os.path.join(dirpath, f), errors="ignore").read()))
+    assert len(names) > 30
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    shorthand = {"GC_EXT_MAX_PENDING": "GC_EXT_MAX_ITEMS / _PENDING / _TRACE", "GC_EXT_MAX_TRACE": "GC_EXT_MAX_ITEMS / _PENDING / _TRACE"}
+    missing = sorted(n for n in names if n not in doc and shorthand.get(n, "\0") not in doc)
+    assert not missing, f"not in INTEGRATION.md: {missing}"
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert len(design.encode()) < 100_000
+    heads = re.findall(r"^## (\d+)\. ", design, flags=re.M)
+    assert heads == [str(i) for i in range(len(heads))], heads      # sections 0, 1, 2, ... once each, in order
+
+
 def _build_shim_test(tmp_path):
     import shutil
     import subprocess
