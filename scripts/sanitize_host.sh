@@ -5,6 +5,7 @@
 #   ASan + UBSan: the oracle itself (whole pipeline, stitching, encoders) under its golden and unit tests
 #   ASan + UBSan: the encoders' split-node cursor over every letter of a graph
 #   TSan, ASan + UBSan (r4): the flat first build of a graph on 8 threads against the literal builder; the hash-order replay against the real containers
+#   ASan + UBSan (r5): the libstdc++ sort replays; the whole product library's host side behind ctypes (non-GPU tests)
 # Usage (repo root): bash scripts/sanitize_host.sh
 set -eu
 root=$(cd "$(dirname "$0")/.." && pwd)
@@ -28,4 +29,15 @@ g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I$H 
 for f in $work/genome.gfa $root/tests/golden/syn20k.gfa $root/tests/golden/ref_test_graph.gfa; do GC_BUILD_THREADS=8 ASAN_OPTIONS=detect_leaks=0 $work/build_compare_asan $f; done
 g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I$H $root/tests/hashorder/hashorder_test.cpp -o $work/hashorder_asan
 ASAN_OPTIONS=detect_leaks=0 $work/hashorder_asan
+# r5: the libstdc++ sort replays (one lane; the independent-steps form the wave kernel runs) against std::sort under ASan + UBSan
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I$root/graphchainer_amd/csrc/hip $root/tests/stdsort/stdsort_test.cpp -o $work/stdsort_asan
+ASAN_OPTIONS=detect_leaks=0 $work/stdsort_asan
+# r5: the whole product library's host side (hipcc, -fno-gpu-sanitize) behind ctypes: the non-GPU tests that load it - both graph builders, the index cache and its mutated files, the ABI tests
+make -C $root/graphchainer_amd/csrc variant NAME=asan FLAGS="-fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer -g -shared-libsan" > /dev/null
+RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+(cd $root && ASAN_OPTIONS=detect_leaks=0:halt_on_error=0:verify_asan_link_order=0 UBSAN_OPTIONS=print_stacktrace=1 LD_PRELOAD=$RT GC_LIBRARY=$root/graphchainer_amd/libgraphchainer_amd_asan.so \
+  python3 -m pytest tests/test_index_cache.py tests/test_graph_build.py tests/test_library_exports.py tests/test_host_logic.py -q -s -m "not gpu" > $work/library_asan.log 2>&1 || true)
+tail -1 $work/library_asan.log
+echo "sanitizer reports in the library run: $(grep -c 'runtime error\|AddressSanitizer' $work/library_asan.log)"
+rm -f $root/graphchainer_amd/libgraphchainer_amd_asan.so
 echo "sanitizers: clean"
