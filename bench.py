@@ -71,8 +71,8 @@ def parse_args():
                          "(N=1; profiling runs of one gpurun call: a 960 Mbp graph costs five minutes to generate, build and save, 85 s to load)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("GC_BENCH_INFLIGHT", 5)),
                     help="batches in flight per GPU, each on its own gc_stream and host thread (like the reference's -t worker threads): one batch's seeding, fragment "
-                         "pipeline, distances and assembly run beside another's whole-read pass (r3, ms per 10 k x 10 kb batch: 1 -> 204, 2 -> 189, 3 -> 173, 4 -> 165, 5 -> 157, 6 -> 159; "
-                         "a batch in flight holds 31 GB of device memory, the whole-read scratch of 48 GB is shared per device)")
+                         "pipeline, distances and assembly run beside another's whole-read pass (r5, ms per 10 k x 10 kb batch: 1 -> 157, 2 -> 148, 3 -> 149, 4 -> 145, 5 -> 147, 6 -> 144; "
+                         "a batch in flight holds 19 GB of device memory, the whole-read scratch of 27 GB is shared per device)")
     args = ap.parse_args()
     # config 5 on one GPU (BASELINE configs[4] is the whole genome over eight): 24 chromosome graphs, 2 000 CLR-like 50 kb reads, --colinear-gap 50000
     if args.reads is None:
@@ -366,7 +366,7 @@ def main():
                 break
             except RuntimeError as e:
                 # the streams' first batches size their buffers: when they do not all fit the device beside the graph and the index, one batch fewer is kept in flight
-                # (config 5 on a 1 Gbp graph: 41 GB of graph and index, ~40 GB per 2 000 x 50 kb batch in flight, the 48 GB whole-read scratch)
+                # (config 5 on a 960 Mbp graph: 31 GB of graph and index, 42 GB per 2 000 x 50 kb batch in flight, the 21 GB whole-read scratch)
                 if "out of memory" not in str(e) or inflight <= 1:
                     raise
                 for a in aligners:

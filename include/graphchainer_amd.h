@@ -349,7 +349,7 @@ int gc_std_sort_permutations(const uint32_t* keys, const uint64_t* offsets, uint
 
 int gc_device_count(void);
 int gc_set_device(int device);
-/* free / total bytes of the current device's memory (a host that sizes its batches: a 10 k x 10 kb batch in flight holds ~31 GB, beside the device's one shared whole-read scratch of up to 48 GB) */
+/* free / total bytes of the current device's memory (a host that sizes its batches: a 10 k x 10 kb batch in flight holds ~19 GB, a 2 k x 50 kb batch 28-42 GB, beside the device's shared whole-read scratch of 21-27 GB - two of them when small batches run two passes side by side) */
 int gc_device_memory(uint64_t* free_bytes, uint64_t* total_bytes);
 
 #ifdef __cplusplus
