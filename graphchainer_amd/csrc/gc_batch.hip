@@ -1065,7 +1065,16 @@ struct BatchRun {
 		uint32_t lanes = extendGridLanes(nWork);
 		ExtItem* dWork = st->work.reserve<ExtItem>(nWork);
 		dResults = st->results.reserve<ExtResult>(nWork);
-		uint8_t* dScratch = st->scratch.reserve<uint8_t>((uint64_t)lanes * slabBytes);
+		// r6: fragments of up to 65 bases (one slice per extension) go through the lockstep kernel (gc_extend_frag.hip); what it declines and every longer fragment through the
+		// plain-layout kernel on per-lane slabs. GC_EXTEND_SLAB=1: the plain-layout kernel for everything, as up to r5 (A/B)
+		const bool fragKernel = P->split_len <= 65 && !(getenv("GC_EXTEND_SLAB") && atoi(getenv("GC_EXTEND_SLAB")) == 1);
+		uint8_t* dScratch = fragKernel ? nullptr : st->scratch.reserve<uint8_t>((uint64_t)lanes * slabBytes);
+		const uint32_t fragWaves = fragKernel ? extendFragWaves() : 0;
+		uint4* dFragItems = fragKernel ? st->fragItems.reserve<uint4>(extendFragScratchBytes(fragWaves) / sizeof(uint4)) : nullptr;
+		uint32_t* dFragRetry = fragKernel ? st->fragRetryList.reserve<uint32_t>(std::max<uint32_t>(1, nWork)) : nullptr;
+		unsigned long long* dFragClaims = st->fragClaims.reserve<unsigned long long>(8);   // per extension round: [2 k] the waves' claim cursor, [2 k + 1] the number of declined items
+		if (fragKernel) launchZeroWords(stream, dFragClaims, 8);
+		const FragReads fragReads { R->devMasks, R->devMaskOff, R->devMaskWords, R->devOffsets, R->totalBases };
 		if (st->poolsRerun && poolReruns == 0) {   // (the batch after a rerun: see DeviceBuffer::shrinkTo)
 			st->tracePool.shrinkTo(traceBudget * sizeof(TraceCell));
 			st->pathPool.shrinkTo(pathCapacity * sizeof(uint32_t));
@@ -1120,11 +1129,21 @@ struct BatchRun {
 		// (r5: every round's extension launches and every k_build_anchors launch sit between an event pair of their own - r4 bracketed "round 0's extensions" and "everything up to
 		// the chaining kernel", so the later rounds' k_extend launches were charged to the anchors stage and roofline_other did not follow from the kernel trace)
 		nExtendPairs = nAnchorPairs = 0;
+		uint32_t nExtendRounds = 0;
 		static const uint32_t extendChunkItems = getenv("GC_EXTEND_CHUNK") ? (uint32_t)std::max(0, atoi(getenv("GC_EXTEND_CHUNK"))) : 0u;   // extensions per k_extend launch (0: one launch per round)
 		auto extendRound = [&](const ExtSelection& sel) {
 			if (nExtendPairs < 4) HIP_CHECK(hipEventRecord(st->fragEv[2 * nExtendPairs], stream));
-			launchExtend(stream, G->dev, G->devTables, G->devIupac, cfg, dWork, nWork, R->devBases, dResults, dScratch, slabBytes, dTrace, dCursors + 1, traceBudget, dCounters, 0, 4096, sel, extendChunkItems);
-			launchExtend(stream, G->dev, G->devTables, G->devIupac, big, dWork, nWork, R->devBases, dResults, dRetryScratch, extendSlabBytes(big), dTrace, dCursors + 1, traceBudget, dCounters, EXT_OVERFLOW, retryLanes, sel);
+			if (fragKernel) {
+				unsigned long long* claims = dFragClaims + 2 * (nExtendRounds++ & 3u);
+				if (nExtendRounds > 4) launchZeroWords(stream, claims, 2);
+				launchExtendFrag(stream, G->dev, G->devTables, cfg.bandwidth, dWork, nWork, fragReads, dResults, dFragItems, fragWaves, dTrace, dCursors + 1, traceBudget, dCounters, sel, claims, dFragRetry, claims + 1);
+				ExtSelection declined;
+				declined.mode = 2; declined.list = dFragRetry; declined.listCount = claims + 1;
+				launchExtend(stream, G->dev, G->devTables, G->devIupac, big, dWork, nWork, R->devBases, dResults, dRetryScratch, extendSlabBytes(big), dTrace, dCursors + 1, traceBudget, dCounters, EXT_OVERFLOW, retryLanes, declined);
+			} else {
+				launchExtend(stream, G->dev, G->devTables, G->devIupac, cfg, dWork, nWork, R->devBases, dResults, dScratch, slabBytes, dTrace, dCursors + 1, traceBudget, dCounters, 0, 4096, sel, extendChunkItems);
+				launchExtend(stream, G->dev, G->devTables, G->devIupac, big, dWork, nWork, R->devBases, dResults, dRetryScratch, extendSlabBytes(big), dTrace, dCursors + 1, traceBudget, dCounters, EXT_OVERFLOW, retryLanes, sel);
+			}
 			if (nExtendPairs < 4) { HIP_CHECK(hipEventRecord(st->fragEv[2 * nExtendPairs + 1], stream)); nExtendPairs++; }
 		};
 		auto anchorsTimed = [&](const AnchorRounds& ar) {

@@ -861,6 +861,7 @@ int gc_reads_upload(const char* bases, const uint64_t* offsets, uint64_t n, gc_r
 		uint32_t* pMaskWords = (uint32_t*)(D + oMaskWords);
 		uint64_t* pEqOff = (uint64_t*)(D + oEqOff);
 		uint8_t* pInvalid = R->devReadInvalid;
+		R->devMaskOff = pMaskOff; R->devMaskWords = pMaskWords;
 		// staging: the bases and the five small arrays in one pinned block, copied asynchronously on a stream of the calling thread's own (a synchronous copy from pageable
 		// memory goes through the runtime's bounce buffers at a few GB/s and its null-stream semantics)
 		size_t hat = 0;

@@ -480,6 +480,7 @@ struct gc_reads {
 	uint64_t* devMasks = nullptr;
 	std::vector<uint64_t> maskOff;   // [n] word offset of read r's masks
 	std::vector<uint32_t> maskWords; // [n] words per bit vector
+	const uint64_t* devMaskOff = nullptr; const uint32_t* devMaskWords = nullptr;   // the two on the device (the fragment extension kernel reads its rows' masks through them)
 	// exact-match bit vectors of the forward strand [A,C,G,T][words] and the per-read records of the NW kernel (rows = read bases)
 	uint64_t* devEqMasks = nullptr;
 	EdRead* devEdReads = nullptr;
@@ -556,7 +557,7 @@ struct gc_stream {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[12] {};
 	hipEvent_t fragEv[16] {};   // r5: a (begin, end) pair around each of the lazy rounds' k_extend launches [0..7] and k_build_anchors launches [8..15]: kernel_us[1] / [2] are sums of exactly those
-	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, readSeeds, fragFirstSeed, longRetryList, extLists, pendingFrags, fragNext, roundCounts, work, results, scratch, scratchRetry, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, readTies, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
+	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, readSeeds, fragFirstSeed, longRetryList, extLists, fragItems, fragRetryList, fragClaims, pendingFrags, fragNext, roundCounts, work, results, scratch, scratchRetry, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, readTies, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
 	PinnedBuffer hMatches, hReadSeeds, hFragFirstSeed, hFrags, hJobs, hAnchors, hFragStatus, hFragExtended, hReadTies, hChainOut, hChainLen, hChainScore, hChainStatus, hPathPool, hSmall;
 	// whole-read pass: runs on its own stream, concurrently with the fragment kernels
 	hipStream_t longStream = nullptr;
@@ -599,7 +600,7 @@ struct gc_stream {
 	{
 		f("tmp", tmp.bytes); f("matches", matches.bytes); f("readMatchOff", readMatchOff.bytes); f("readMatchCount", readMatchCount.bytes); f("cursors", cursors.bytes); f("readSeeds", readSeeds.bytes);
 		f("fragFirstSeed", fragFirstSeed.bytes); f("longRetryList", longRetryList.bytes); f("extLists", extLists.bytes); f("pendingFrags", pendingFrags.bytes); f("fragNext", fragNext.bytes);
-		f("roundCounts", roundCounts.bytes); f("work", work.bytes); f("results", results.bytes); f("scratch", scratch.bytes); f("scratchRetry", scratchRetry.bytes); f("tracePool", tracePool.bytes);
+		f("roundCounts", roundCounts.bytes); f("fragItems", fragItems.bytes); f("fragRetryList", fragRetryList.bytes); f("work", work.bytes); f("results", results.bytes); f("scratch", scratch.bytes); f("scratchRetry", scratchRetry.bytes); f("tracePool", tracePool.bytes);
 		f("frags", frags.bytes); f("fragSeeds", fragSeeds.bytes); f("anchors", anchors.bytes); f("fragStatus", fragStatus.bytes); f("fragExtended", fragExtended.bytes); f("readTies", readTies.bytes);
 		f("pathPool", pathPool.bytes); f("jobs", jobs.bytes); f("chainOut", chainOut.bytes); f("chainLen", chainLen.bytes); f("chainScore", chainScore.bytes); f("chainStatus", chainStatus.bytes);
 		f("chainScratch", chainScratch.bytes); f("counters", counters.bytes); f("edPathNodes", edPathNodes.bytes); f("edJobs", edJobs.bytes); f("edLetters", edLetters.bytes);
@@ -763,6 +764,15 @@ inline void uploadGraph(gc_graph* G)
 		nameBytes.push_back(0);
 		G->devNames.nameOff = G->up(nameOff);
 		G->devNames.nameBytes = G->up(nameBytes);
+	}
+	{
+		NodeRec* recs = nullptr;
+		HIP_CHECK(hipMalloc((void**)&recs, std::max<size_t>(1, n) * sizeof(NodeRec)));
+		G->allocations.push_back(recs);
+		launchBuildNodeRecs(nullptr, d, recs);
+		HIP_CHECK(hipGetLastError());
+		HIP_CHECK(hipDeviceSynchronize());
+		d.nodeRec = recs;
 	}
 	CorrectnessTables t;
 	buildCorrectnessTables(t);

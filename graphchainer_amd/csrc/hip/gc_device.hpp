@@ -15,6 +15,17 @@
 
 namespace gcdev {
 
+// Everything the fragment extension kernel asks about a split node, in one aligned 32-byte load (r6): the node's arrays lie in five places, i.e. five cache lines per
+// node a seed's chance hit lands on; the records of neighbouring nodes (ids a few apart) share a line.
+struct NodeRec {
+	uint32_t comp;     // componentNumber
+	uint32_t outOff;   // first out-edge in outAdj
+	uint32_t inOff;    // first in-edge in inAdj
+	uint32_t meta;     // bits 0-6 length (1..64), bit 7 NODEREC_SLOW (an ambiguous node: its letters are not in w0 / w1), bits 8-15 out-degree, bits 16-23 in-degree (255: or more)
+	uint64_t w0, w1;   // nodeSeq[2 * node], [2 * node + 1]
+};
+enum : uint32_t { NODEREC_SLOW = 128u };
+
 struct DGraph {
 	uint32_t nNodes;
 	uint32_t firstAmbiguous;
@@ -39,6 +50,7 @@ struct DGraph {
 	// seed clustering (orderSeedsByChaining, src/GraphAligner.h:245-262): chain of every split node and its approximate position on it
 	const uint32_t* chainNumber;      // [n]
 	const uint64_t* chainApproxPos;   // [n]
+	const NodeRec* nodeRec;           // [n] (r6) the per-node record of the fragment extension kernel
 };
 
 struct WS {   // one DP column over 64 read rows (reference: src/WordSlice.h:150-166)

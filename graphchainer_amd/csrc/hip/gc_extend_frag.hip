@@ -1,0 +1,210 @@
+// K3 (r6) - fragment seed extension: one extension per lane, the lanes of a wave in lockstep phases (the core and the reasons: gc_frag_core.hpp).
+// reference: GraphAlignerBitvectorBanded::getReverseTraceFromSeed, src/GraphAlignerBitvectorBanded.h:46-71, called per seed and direction from
+// src/GraphAligner.h:499-511. What this kernel declines (EXT_OVERFLOW: more than 64 rows, an ambiguous graph node, more pending nodes / tiles than its tables hold)
+// is rerun by the plain-layout kernel k_extend_slab (gc_kernels.hip) right behind it.
+#include "gc_kernels.hpp"
+#include "gc_frag_core.hpp"
+
+namespace gcdev {
+using namespace gcfrag;
+
+// lanes waiting at a tile boundary (or for a work item) before the wave leaves the column loop for a sweep of the handlers: a sweep costs the sum of its handlers'
+// instructions whatever the number of lanes in them, a column step costs one step whatever the number of lanes still inside a tile
+#ifndef GC_FRAG_SWEEP
+#define GC_FRAG_SWEEP 24
+#endif
+#define GC_FRAG_CLAIM 256u   // work items a wave claims at a time (neighbouring items are neighbouring fragments of a read: neighbouring graph nodes)
+
+struct FragDevStore {
+	uint32_t* lds;       // this lane's column of the wave's LDS words: word w at lds[64 w]
+	uint4* items;        // this lane's column of the wave's item planes: item k = [3 k] start column, [3 k + 1] end column, [3 k + 2] { start score, node, end score, - }, each plane 64 lanes wide
+	TraceCell* pool;
+	__device__ __forceinline__ uint32_t ld(uint32_t w) const { return lds[64 * w]; }
+	__device__ __forceinline__ void st(uint32_t w, uint32_t v) const { lds[64 * w] = v; }
+	__device__ __forceinline__ void itemSetStart(uint32_t k, uint64_t VP, uint64_t VN, int32_t score, uint32_t node) const
+	{
+		items[64 * (3 * k)] = make_uint4((uint32_t)VP, (uint32_t)(VP >> 32), (uint32_t)VN, (uint32_t)(VN >> 32));
+		*(uint2*)&items[64 * (3 * k + 2)] = make_uint2((uint32_t)score, node);
+	}
+	__device__ __forceinline__ void itemSetEnd(uint32_t k, uint64_t VP, uint64_t VN, int32_t score) const
+	{
+		items[64 * (3 * k + 1)] = make_uint4((uint32_t)VP, (uint32_t)(VP >> 32), (uint32_t)VN, (uint32_t)(VN >> 32));
+		((uint32_t*)&items[64 * (3 * k + 2)])[2] = (uint32_t)score;
+	}
+	__device__ __forceinline__ WS itemStart(uint32_t k) const
+	{
+		const uint4 c = items[64 * (3 * k)];
+		return WS { (uint64_t)c.x | ((uint64_t)c.y << 32), (uint64_t)c.z | ((uint64_t)c.w << 32), (int32_t)((const uint32_t*)&items[64 * (3 * k + 2)])[0] };
+	}
+	__device__ __forceinline__ WS itemEnd(uint32_t k) const
+	{
+		const uint4 c = items[64 * (3 * k + 1)];
+		return WS { (uint64_t)c.x | ((uint64_t)c.y << 32), (uint64_t)c.z | ((uint64_t)c.w << 32), (int32_t)((const uint32_t*)&items[64 * (3 * k + 2)])[2] };
+	}
+	__device__ __forceinline__ uint32_t itemNode(uint32_t k) const { return ((const uint32_t*)&items[64 * (3 * k + 2)])[1]; }
+	__device__ __forceinline__ void traceSet(uint64_t at, uint32_t node, int32_t seqPos, uint32_t offsetAndSwitch) const { pool[at] = TraceCell { node, seqPos, offsetAndSwitch }; }
+};
+
+uint64_t extendFragScratchBytes(uint32_t waves) { return (uint64_t)waves * FRAG_I * 3 * 64 * sizeof(uint4); }
+
+// 127 VGPRs or fewer: four waves per SIMD, which is also what the LDS words of four waves per SIMD leave room for
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_extend(DGraph g, const CorrectnessTables* __restrict__ ct, int32_t bandwidth,
+	const ExtItem* __restrict__ work, uint32_t nWork, const FragReads reads, ExtResult* __restrict__ results, uint4* __restrict__ itemScratch,
+	TraceCell* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, unsigned long long* __restrict__ counters, ExtSelection sel,
+	unsigned long long* __restrict__ claim, uint32_t* __restrict__ retryList, unsigned long long* __restrict__ retryCount)
+{
+	__shared__ uint32_t ldsWords[FRAG_WORDS * 64];
+	__shared__ uint32_t waveCounters[8];
+	const uint32_t lane = threadIdx.x;
+	if (lane < 8) waveCounters[lane] = 0;
+	FragParams P;
+	P.bandwidth = bandwidth;
+	P.keepMask = __ballot(fragSliceKept(*ct, (int)lane));
+	FragMem<FragDevStore> m;
+	m.lds = ldsWords + lane;
+	m.items = itemScratch + (uint64_t)blockIdx.x * (FRAG_I * 3 * 64) + lane;
+	m.pool = tracePool;
+	Lane L;
+	L.phase = PH_FETCH;
+	L.work = 0xffffffffu;
+	const uint32_t nSelected = sel.mode == 0 ? nWork : sel.mode == 1 ? 2 * sel.nFrags : (uint32_t)*sel.listCount;
+	unsigned long long blockNext = 0, blockEnd = 0;   // the wave's claimed range of the selection (uniform)
+	const uint64_t below = (1ull << lane) - 1;
+	__syncthreads();
+	for (;;) {
+		const uint32_t nIdle = (uint32_t)__popcll(__ballot(L.phase == PH_IDLE));
+		if (nIdle == 64) break;
+		const uint32_t nActive = 64 - nIdle;
+		const uint32_t sweepAt = nActive < GC_FRAG_SWEEP ? nActive : GC_FRAG_SWEEP;
+		uint32_t nWait = nActive - (uint32_t)__popcll(__ballot(L.phase == PH_COLS));
+		// ---- the column loop: while fewer than sweepAt lanes wait at a boundary
+		while (nWait < sweepAt) {
+			if (L.phase == PH_COLS) fragColumn(L, m);
+			nWait = nActive - (uint32_t)__popcll(__ballot(L.phase == PH_COLS));
+		}
+		// ---- one sweep of the handlers, each with every lane that is in its phase
+		const uint64_t fetching = __ballot(L.phase == PH_FETCH);
+		if (fetching) {
+			if (L.phase == PH_FETCH) {
+				if (L.work != 0xffffffffu) {
+					ExtResult res;
+					res.status = L.status;
+					res.score = L.resultScore;
+					res.traceOff = L.status == EXT_OK ? L.traceBase : 0;
+					res.traceLen = L.status == EXT_OK ? L.nTrace : 0;
+					res.pad = L.status == EXT_OK ? L.tie : 0;
+					results[L.work] = res;
+					if (L.status == EXT_OVERFLOW) retryList[atomicAdd(retryCount, 1ull)] = L.work;   // declined: the plain-layout kernel runs it (and counts it)
+					else {
+						const bool flat = L.len < 64;
+						atomicAdd(&waveCounters[0], L.dpTiles);
+						atomicAdd(&waveCounters[1], (flat ? L.dpTiles : 0u) + L.btTiles);
+						atomicAdd(&waveCounters[2], (flat ? 2u : 1u) * L.dpCols + L.btCols);
+						atomicAdd(&waveCounters[3], L.status == EXT_OK ? L.nTrace : 0u);
+						atomicAdd(&waveCounters[4], 1u);
+						atomicAdd(&waveCounters[5], L.btTiles);
+					}
+					L.work = 0xffffffffu;
+				}
+			}
+			// the fetching lanes take consecutive items of the wave's claimed range, and of a new one when it runs out
+			const uint32_t need = (uint32_t)__popcll(fetching);
+			const unsigned long long avail = blockEnd - blockNext;
+			unsigned long long fresh = 0;
+			if (need > avail) {
+				const int first = __ffsll((long long)fetching) - 1;
+				if ((int)lane == first) fresh = atomicAdd(claim, (unsigned long long)GC_FRAG_CLAIM);
+				fresh = __shfl(fresh, first);
+			}
+			if (L.phase == PH_FETCH) {
+				const uint32_t rank = (uint32_t)__popcll(fetching & below);
+				const unsigned long long at = rank < avail ? blockNext + rank : fresh + (rank - avail);
+				if (at >= nSelected) L.phase = PH_IDLE;
+				else {
+					const uint32_t w = sel.mode == 0 ? (uint32_t)at : sel.mode == 1 ? 2 * sel.frags[at >> 1].seedBegin + ((uint32_t)at & 1u) : sel.list[at];
+					const ExtItem it = work[w];
+					// the rows' match masks come from the read's bit vectors (built at upload): strand 1 = the reverse complement, whose bases lie behind all forward bases
+					const uint32_t strand = it.seqOff >= reads.totalBases ? 1u : 0u;
+					const uint32_t words = reads.maskWords[it.pad];
+					EqSource src;
+					src.masks = reads.masks + reads.maskOff[it.pad] + (uint64_t)strand * 4 * words;
+					src.words = words;
+					src.startBit = (uint32_t)(it.seqOff - (strand ? reads.totalBases : 0) - reads.readOff[it.pad]);
+					fragBegin(g, P, L, m, w, it.seqLen, it.node, it.offset, src);
+				}
+			}
+			if (need > avail) { blockNext = fresh + (need - avail); blockEnd = fresh + GC_FRAG_CLAIM; }
+			else blockNext += need;
+		}
+		if (L.phase == PH_TILE_END) fragTileEnd(g, P, L, m);
+		if (L.phase == PH_POP) fragPop(g, P, L, m);
+		{
+			bool walk = false;
+			if (L.phase == PH_FINISH) walk = fragFinish(P, L);
+			const uint64_t walking = __ballot(walk);
+			if (walking) {
+				// one request to the trace pool for the lanes that start their walk in this sweep
+				uint32_t incl = walk ? L.traceCap : 0u;
+				for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+				const uint32_t total = __shfl(incl, 63);
+				unsigned long long base = 0;
+				if (lane == 0) base = atomicAdd(traceCursor, (unsigned long long)total);
+				base = __shfl(base, 0);
+				if (walk) {
+					L.traceBase = base + incl - L.traceCap;
+					if (L.traceBase + L.traceCap > traceCapacity) fragRetire(L, EXT_OVERFLOW);   // the pool is full: the host sizes it again and runs the stage again (fragmentPoolsOverflowed)
+					else fragWalkBegin(L, m);
+				}
+			}
+		}
+		while (L.phase == PH_WALK) fragWalkStep(g, P, L, m);
+	}
+	__syncthreads();
+	if (lane < 6 && waveCounters[lane]) atomicAdd(&counters[lane], (unsigned long long)waveCounters[lane]);
+}
+
+// the per-node records, made on the device from the arrays already there (at upload)
+__global__ void __launch_bounds__(256) k_build_node_rec(DGraph g, NodeRec* __restrict__ out)
+{
+	const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+	if (v >= g.nNodes) return;
+	NodeRec r;
+	const uint32_t outBegin = g.outOff[v], inBegin = g.inOff[v];
+	const uint32_t outDeg = g.outOff[v + 1] - outBegin, inDeg = g.inOff[v + 1] - inBegin;
+	const bool plain = v < g.firstAmbiguous;
+	r.comp = g.componentNumber[v]; r.outOff = outBegin; r.inOff = inBegin;
+	r.meta = (uint32_t)g.nodeLength[v] | (plain ? 0u : NODEREC_SLOW) | ((outDeg < 255u ? outDeg : 255u) << 8) | ((inDeg < 255u ? inDeg : 255u) << 16);
+	r.w0 = plain ? g.nodeSeq[2 * (size_t)v] : 0ull;
+	r.w1 = plain ? g.nodeSeq[2 * (size_t)v + 1] : 0ull;
+	out[v] = r;
+}
+void launchBuildNodeRecs(hipStream_t stream, const DGraph& g, NodeRec* out)
+{
+	if (g.nNodes) hipLaunchKernelGGL(k_build_node_rec, dim3((g.nNodes + 255) / 256), dim3(256), 0, stream, g, out);
+}
+
+uint32_t extendFragWaves()
+{
+	static const uint32_t waves = []() {
+		int perCu = 0, dev = 0, cus = 256;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_extend, 64, 0) != hipSuccess || perCu <= 0) perCu = 12;
+		hipDeviceProp_t prop;
+		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+		return (uint32_t)(perCu * cus);
+	}();
+	return waves;
+}
+
+void launchExtendFrag(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, int32_t bandwidth, const ExtItem* work, uint32_t nWork, const FragReads& reads, ExtResult* results,
+	uint4* itemScratch, uint32_t scratchWaves, TraceCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters, ExtSelection sel, unsigned long long* claim,
+	uint32_t* retryList, unsigned long long* retryCount)
+{
+	if (nWork == 0) return;
+	const uint32_t upper = sel.mode == 1 ? 2 * sel.nFrags : nWork;
+	uint32_t waves = (upper + 63) / 64;
+	if (waves > scratchWaves) waves = scratchWaves;
+	if (waves == 0) return;
+	hipLaunchKernelGGL(k_extend, dim3(waves), dim3(64), 0, stream, g, ct, bandwidth, work, nWork, reads, results, itemScratch, tracePool, traceCursor, traceCapacity, counters, sel, claim, retryList, retryCount);
+}
+
+} // namespace gcdev

@@ -157,7 +157,7 @@ __device__ __forceinline__ LaneScratch laneScratch(uint8_t* slab, const ExtendCo
 #endif
 // 4 waves per SIMD (<= 128 VGPRs; the kernel wanted 131 and ran 3): it waits on memory 56 % of the time, so the extra wave
 // pays for the 4 spilled registers: 34.2 -> 29.0 ms alone on cfg2 (5 or 6 waves spill 57 / 196 registers and lose).
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_extend(DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_extend_slab(DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg,
 	const ExtItem* __restrict__ work, uint32_t nWork, const char* __restrict__ bases, ExtResult* __restrict__ results,
 	uint8_t* __restrict__ scratch, uint64_t slabBytes, TraceCell* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity,
 	unsigned long long* __restrict__ counters, uint32_t retryStatus, ExtSelection sel, uint32_t chunkBegin, uint32_t chunkItems)
@@ -1513,13 +1513,13 @@ void launchExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* 
 	const uint32_t upper = sel.mode == 1 ? 2 * sel.nFrags : nWork;   // (a device-side list holds at most nWork items; waves beyond its count leave at once)
 	uint32_t lanes = retryStatus ? retryLanes : extendGridLanes(upper);
 	if (retryStatus || chunkItems == 0 || upper <= chunkItems) {
-		hipLaunchKernelGGL(k_extend, dim3(lanes / 64), dim3(64), 0, stream, g, ct, iupac, cfg, work, nWork, bases, results, scratch, slabBytes, tracePool, traceCursor, traceCapacity, counters, retryStatus, sel, 0u, 0u);
+		hipLaunchKernelGGL(k_extend_slab, dim3(lanes / 64), dim3(64), 0, stream, g, ct, iupac, cfg, work, nWork, bases, results, scratch, slabBytes, tracePool, traceCursor, traceCapacity, counters, retryStatus, sel, 0u, 0u);
 		return;
 	}
 	// the selection in pieces of chunkItems, one launch each, back to back on the stream: between two of them every wave slot is given up (a list's count is only known on the
 	// device: the launches beyond it find nothing and leave)
 	for (uint64_t begin = 0; begin < upper; begin += chunkItems)
-		hipLaunchKernelGGL(k_extend, dim3(lanes / 64), dim3(64), 0, stream, g, ct, iupac, cfg, work, nWork, bases, results, scratch, slabBytes, tracePool, traceCursor, traceCapacity, counters, retryStatus, sel, (uint32_t)begin, chunkItems);
+		hipLaunchKernelGGL(k_extend_slab, dim3(lanes / 64), dim3(64), 0, stream, g, ct, iupac, cfg, work, nWork, bases, results, scratch, slabBytes, tracePool, traceCursor, traceCapacity, counters, retryStatus, sel, (uint32_t)begin, chunkItems);
 }
 
 void launchBuildAnchors(hipStream_t stream, const DGraph& g, const Fragment* frags, uint32_t nFrags, const FragSeed* seeds, const ExtResult* ext,
@@ -1654,13 +1654,13 @@ __global__ void __launch_bounds__(256) k_build_fragment_work(DGraph g, const Fra
 		b.seqOff = totalBases + readOff + (len - fr.l - p);
 		b.seqLen = p;
 		twinOf(g, s.node, s.offset, b.node, b.offset);
-		b.pad = 0;
+		b.pad = fr.read;
 		ExtItem f;
 		f.seqOff = readOff + fr.l + p + 1;
 		f.seqLen = splitLen - 1 - p;
 		f.node = s.node;
 		f.offset = s.offset;
-		f.pad = 0;
+		f.pad = fr.read;
 		work[2 * (size_t)slot] = b;
 		work[2 * (size_t)slot + 1] = f;
 		if (results) {   // lazy extension: nothing has run yet

@@ -44,7 +44,7 @@ struct ExtItem {     // one seed extension: align bases[seqOff .. seqOff+seqLen)
 	uint32_t seqLen;
 	uint32_t node;
 	uint32_t offset;
-	uint32_t pad;
+	uint32_t pad;       // (r6) the read the sequence belongs to
 };
 
 struct ExtResult {
@@ -171,6 +171,15 @@ uint64_t glueElemBytes();
 // test entry: arrays of (key << 32 | index) elements sorted by key with the wave-cooperative replay of std::sort (gc_stdsort_wave.hpp); scratch: 3 words per element + 64 per array
 void launchTestStdSort(hipStream_t stream, unsigned long long* elems, const uint64_t* off, uint32_t nArrays, uint32_t* scratch, long depthLimit);
 
+// the read batch as the fragment extension kernel sees it: per read and strand four match-mask bit vectors (gc_reads.hip)
+struct FragReads { const uint64_t* masks; const uint64_t* maskOff; const uint32_t* maskWords; const uint64_t* readOff; uint64_t totalBases; };
+// fragment extensions, one per lane in lockstep phases (gc_extend_frag.hip); what it declines carries EXT_OVERFLOW and is rerun by launchExtend (k_extend_slab)
+uint32_t extendFragWaves();                        // resident waves of the kernel on this device: the grid, and the size of its item scratch
+uint64_t extendFragScratchBytes(uint32_t waves);
+void launchExtendFrag(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, int32_t bandwidth, const ExtItem* work, uint32_t nWork, const FragReads& reads, ExtResult* results,
+	uint4* itemScratch, uint32_t scratchWaves, TraceCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters, ExtSelection sel, unsigned long long* claim,
+	uint32_t* retryList, unsigned long long* retryCount);   // claim, retryCount: zeroed words of this launch's own; retryList [nWork]: the declined items, for launchExtend with a list selection
+void launchBuildNodeRecs(hipStream_t stream, const DGraph& g, NodeRec* out);   // DGraph::nodeRec from the arrays already uploaded
 uint64_t extendSlabBytes(const ExtendConfig& cfg);
 uint32_t extendGridLanes(uint32_t nWork);
 void launchExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg,

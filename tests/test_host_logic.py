@@ -233,6 +233,29 @@ def test_state_machine_extension_core_equals_oracle(tmp_path):
         assert equal > 60, out.stdout
 
 
+def test_fragment_extension_core_equals_oracle(tmp_path):
+    """The per-lane state machine of the fragment extension kernel k_extend (graphchainer_amd/csrc/hip/gc_frag_core.hpp, r6) is plain C++ over a memory policy:
+    tests/frag_host/frag_host_test.cpp compiles its phase functions with g++, drives ONE lane on the CPU over the kernel's own word layout (queue and ring overlaid,
+    poisoned at the hand-over) and compares status, score, every trace cell, the tie flag and the work counters of tens of thousands of extensions of 1..64 rows
+    (fragment-sized and longer, both directions, graphs with and without multi-allelic sites, two band widths) with the oracle's getReverseTraceFromSeed; an
+    extension the core hands to the plain-layout kernel must have a reason (more than 64 rows, more tiles or pending nodes than its tables hold)."""
+    exe = tmp_path / "frag_host_test"
+    src = os.path.join(ROOT, "tests", "frag_host", "frag_host_test.cpp")
+    host = os.path.join(ROOT, "graphchainer_amd", "csrc", "host")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-w", "-I/opt/rocm/include", src, os.path.join(host, "gc_graph.cpp"), os.path.join(host, "gc_minimizer.cpp"), "-o", str(exe), "-lpthread"], check=True, timeout=600)
+    cases = [(SynthGraph(300_000, seed=43, repeats=4, repeat_len=2000, multi_allelic=0.1), ["300", "10"], 2000), (SynthGraph(400_000, seed=5), ["150", "5"], 3000)]
+    for i, (sg, args, least) in enumerate(cases):
+        gfa = str(tmp_path / f"g{i}.gfa")
+        sg.write_gfa(gfa)
+        reads = sg.sample_reads(12, 8000, seed=8 + i) + sg.sample_reads(3, 8000, seed=9, sv_fraction=1.0)
+        (tmp_path / f"reads{i}.txt").write_bytes(b"\n".join(reads) + b"\n")
+        out = subprocess.run([str(exe), gfa, str(tmp_path / f"reads{i}.txt")] + args, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "FRAG_HOST_OK" in out.stdout, out.stdout + out.stderr
+        fields = out.stdout.split()
+        equal, declined, total = (int(fields[fields.index(k) + 1]) for k in ("equal", "declined", "extensions"))
+        assert equal > least and declined < total // 8, out.stdout
+
+
 def test_bench_inflight_rule_follows_the_cpu_budget():
     """bench.py's batches-in-flight rule: from the host CPU a batch costs and the batch period, not from a fixed ranks-to-CPUs ratio.
     r5 (0.24 CPU-s per batch, 146 ms per batch): eight ranks on a 16-CPU box keep five batches in flight each (1.6 CPUs of the 2 a rank has; r3's 0.41 CPU-s made them
