@@ -1068,7 +1068,8 @@ struct BatchRun {
 		// r6: fragments of up to 65 bases (one slice per extension) go through the lockstep kernel (gc_extend_frag.hip); what it declines and every longer fragment through the
 		// plain-layout kernel on per-lane slabs. GC_EXTEND_SLAB=1: the plain-layout kernel for everything, as up to r5 (A/B)
 		const bool fragKernel = P->split_len <= 65 && !(getenv("GC_EXTEND_SLAB") && atoi(getenv("GC_EXTEND_SLAB")) == 1);
-		uint8_t* dScratch = fragKernel ? nullptr : st->scratch.reserve<uint8_t>((uint64_t)lanes * slabBytes);
+		const uint32_t declinedLanes = 16384;   // the plain-layout kernel's grid over what the lockstep kernel declined (half a per cent of cfg2's extensions)
+		uint8_t* dScratch = st->scratch.reserve<uint8_t>((uint64_t)(fragKernel ? declinedLanes : lanes) * slabBytes);
 		const uint32_t fragWaves = fragKernel ? extendFragWaves() : 0;
 		uint4* dFragItems = fragKernel ? st->fragItems.reserve<uint4>(extendFragScratchBytes(fragWaves) / sizeof(uint4)) : nullptr;
 		uint32_t* dFragRetry = fragKernel ? st->fragRetryList.reserve<uint32_t>(std::max<uint32_t>(1, nWork)) : nullptr;
@@ -1139,6 +1140,7 @@ struct BatchRun {
 				launchExtendFrag(stream, G->dev, G->devTables, cfg.bandwidth, dWork, nWork, fragReads, dResults, dFragItems, fragWaves, dTrace, dCursors + 1, traceBudget, dCounters, sel, claims, dFragRetry, claims + 1);
 				ExtSelection declined;
 				declined.mode = 2; declined.list = dFragRetry; declined.listCount = claims + 1;
+				launchExtend(stream, G->dev, G->devTables, G->devIupac, cfg, dWork, nWork, R->devBases, dResults, dScratch, slabBytes, dTrace, dCursors + 1, traceBudget, dCounters, EXT_OVERFLOW, declinedLanes, declined);
 				launchExtend(stream, G->dev, G->devTables, G->devIupac, big, dWork, nWork, R->devBases, dResults, dRetryScratch, extendSlabBytes(big), dTrace, dCursors + 1, traceBudget, dCounters, EXT_OVERFLOW, retryLanes, declined);
 			} else {
 				launchExtend(stream, G->dev, G->devTables, G->devIupac, cfg, dWork, nWork, R->devBases, dResults, dScratch, slabBytes, dTrace, dCursors + 1, traceBudget, dCounters, 0, 4096, sel, extendChunkItems);
@@ -1269,6 +1271,7 @@ struct BatchRun {
 		}
 		res->kernel_us[3] = elapsedUs(4, 5);
 		for (int i = 0; i < 8; i++) res->counters[i] = hSmall[8 + i];
+		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc frag] %llu of %llu fragment extensions handed to the plain-layout kernel\n", hSmall[8 + 6], hSmall[8 + 4]);
 		// (the cursors overshoot when a pool is full: the extensions / fragments that did not fit carry an overflow status and their reads are flagged)
 		uint64_t traceUsed = std::min<uint64_t>(hSmall[1], traceBudget), pathUsed = std::min<uint64_t>(hSmall[2], pathCapacity);
 		pathPool = st->hPathPool.reserve<uint32_t>(deviceAnchors ? 1 : pathUsed);

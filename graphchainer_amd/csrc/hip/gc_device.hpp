@@ -13,6 +13,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// GC_LOOP_TICK(i): a hook of the host-side schedule simulator (tests/frag_host/frag_wave_sim.cpp), which counts the turns of the data-dependent loops; nothing in the product
+#ifndef GC_LOOP_TICK
+#define GC_LOOP_TICK(i) ((void)0)
+#endif
+
 namespace gcdev {
 
 // Everything the fragment extension kernel asks about a split node, in one aligned 32-byte load (r6): the node's arrays lie in five places, i.e. five cache lines per
@@ -74,6 +79,7 @@ __device__ inline WS wsMerge(const WS& a, const WS& b)
 	uint64_t diff = (a.VP ^ b.VP) | (a.VN ^ b.VN);
 	int pos = 0;
 	while (diff) {
+		GC_LOOP_TICK(0);
 		int r = __ffsll((long long)diff) - 1;
 		diff &= diff - 1;
 		uint64_t bit = 1ull << r;
@@ -108,6 +114,7 @@ __device__ inline int32_t wsColumnMin(const WS& w)
 	int32_t best = before;
 	uint64_t vn = w.VN;
 	while (vn) {
+		GC_LOOP_TICK(1);
 		int r = __ffsll((long long)vn) - 1;
 		// skip to the end of this run of VN bits: the value is lowest there
 		uint64_t run = vn & ~(vn + (1ull << r));   // the contiguous run starting at r

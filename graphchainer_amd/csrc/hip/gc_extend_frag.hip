@@ -8,10 +8,15 @@
 namespace gcdev {
 using namespace gcfrag;
 
-// lanes waiting at a tile boundary (or for a work item) before the wave leaves the column loop for a sweep of the handlers: a sweep costs the sum of its handlers'
-// instructions whatever the number of lanes in them, a column step costs one step whatever the number of lanes still inside a tile
-#ifndef GC_FRAG_SWEEP
-#define GC_FRAG_SWEEP 24
+// The schedule: a run of a handler costs its instructions whatever the number of lanes in it, a column step costs one step whatever the number of lanes still inside
+// a tile. The wave stays in the column loop until enough lanes wait for one of the two handler groups: the DP's (fetch, tile end, pop, finish: GC_FRAG_DP_AT lanes) or
+// the walk's (GC_FRAG_WALK_AT lanes - an extension spends a third of its handler visits there, so walkers are gathered longer). Priced on the CPU by
+// tests/frag_host/frag_wave_sim.cpp (one trigger of 24 lanes for everything: 89 k vector instructions per 64 extensions; 16 / 32: 59 k).
+#ifndef GC_FRAG_DP_AT
+#define GC_FRAG_DP_AT 16
+#endif
+#ifndef GC_FRAG_WALK_AT
+#define GC_FRAG_WALK_AT 32
 #endif
 #define GC_FRAG_CLAIM 256u   // work items a wave claims at a time (neighbouring items are neighbouring fragments of a read: neighbouring graph nodes)
 
@@ -75,15 +80,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 		const uint32_t nIdle = (uint32_t)__popcll(__ballot(L.phase == PH_IDLE));
 		if (nIdle == 64) break;
 		const uint32_t nActive = 64 - nIdle;
-		const uint32_t sweepAt = nActive < GC_FRAG_SWEEP ? nActive : GC_FRAG_SWEEP;
-		uint32_t nWait = nActive - (uint32_t)__popcll(__ballot(L.phase == PH_COLS));
-		// ---- the column loop: while fewer than sweepAt lanes wait at a boundary
-		while (nWait < sweepAt) {
+		// ---- the column loop: until one of the handler groups has its lanes together (or nobody is inside a tile)
+		bool runDp, runWalk;
+		for (;;) {
+			const uint32_t nCols = (uint32_t)__popcll(__ballot(L.phase == PH_COLS)), nWalk = (uint32_t)__popcll(__ballot(L.phase == PH_WALK));
+			const uint32_t nDp = nActive - nCols - nWalk;
+			const uint32_t dpAt = nActive - nWalk < GC_FRAG_DP_AT ? nActive - nWalk : GC_FRAG_DP_AT, walkAt = nActive < GC_FRAG_WALK_AT ? nActive : GC_FRAG_WALK_AT;
+			runDp = nDp > 0 && nDp >= dpAt;
+			runWalk = nWalk >= walkAt;
+			if (runDp || runWalk) break;
+			if (nCols == 0) { runDp = nDp >= nWalk; runWalk = !runDp; break; }
 			if (L.phase == PH_COLS) fragColumn(L, m);
-			nWait = nActive - (uint32_t)__popcll(__ballot(L.phase == PH_COLS));
 		}
 		// ---- one sweep of the handlers, each with every lane that is in its phase
-		const uint64_t fetching = __ballot(L.phase == PH_FETCH);
+		const uint64_t fetching = runDp ? __ballot(L.phase == PH_FETCH) : 0ull;
 		if (fetching) {
 			if (L.phase == PH_FETCH) {
 				if (L.work != 0xffffffffu) {
@@ -94,7 +104,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 					res.traceLen = L.status == EXT_OK ? L.nTrace : 0;
 					res.pad = L.status == EXT_OK ? L.tie : 0;
 					results[L.work] = res;
-					if (L.status == EXT_OVERFLOW) retryList[atomicAdd(retryCount, 1ull)] = L.work;   // declined: the plain-layout kernel runs it (and counts it)
+					if (L.status == EXT_OVERFLOW) { retryList[atomicAdd(retryCount, 1ull)] = L.work; atomicAdd(&waveCounters[6], 1u); }   // declined: the plain-layout kernel runs it (and counts its work)
 					else {
 						const bool flat = L.len < 64;
 						atomicAdd(&waveCounters[0], L.dpTiles);
@@ -136,9 +146,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 			if (need > avail) { blockNext = fresh + (need - avail); blockEnd = fresh + GC_FRAG_CLAIM; }
 			else blockNext += need;
 		}
-		if (L.phase == PH_TILE_END) fragTileEnd(g, P, L, m);
-		if (L.phase == PH_POP) fragPop(g, P, L, m);
-		{
+		if (runDp && L.phase == PH_TILE_END) fragTileEnd(g, P, L, m);
+		if (runDp && L.phase == PH_POP) fragPop(g, P, L, m);
+		if (runDp) {
 			bool walk = false;
 			if (L.phase == PH_FINISH) walk = fragFinish(P, L);
 			const uint64_t walking = __ballot(walk);
@@ -157,10 +167,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 				}
 			}
 		}
-		while (L.phase == PH_WALK) fragWalkStep(g, P, L, m);
+		if (runWalk) while (L.phase == PH_WALK) fragWalkStep(g, P, L, m);
 	}
 	__syncthreads();
-	if (lane < 6 && waveCounters[lane]) atomicAdd(&counters[lane], (unsigned long long)waveCounters[lane]);
+	if (lane < 7 && waveCounters[lane]) atomicAdd(&counters[lane], (unsigned long long)waveCounters[lane]);   // [6]: extensions handed to the plain-layout kernel
 }
 
 // the per-node records, made on the device from the arrays already there (at upload)

@@ -99,6 +99,7 @@ struct Lane {
 	// the tile in the column loop (DP: a popped node; walk: the recompute of the tile the walk stands in)
 	uint32_t node, pos, tileLen, tileFlags, nodeLen;
 	uint64_t VP, VN; int32_t score;
+	int32_t flat;             // DP: the column's value at the sequence's last row (what flattenLastSliceEnd reads, ...Common.h:1210-1218), kept by its horizontal deltas
 	uint64_t w0, w1;
 	int32_t tileMin;
 	uint32_t outBegin, outDeg;
@@ -126,10 +127,9 @@ __device__ inline void fragRetire(Lane& L, uint32_t status) { L.status = status;
 __device__ inline uint64_t fragFlatMask(uint32_t len) { return len >= 64 ? ~0ull : ((1ull << len) - 1); }
 
 // the fused flattenLastSliceEnd (...Common.h:1210-1218), slice-wide: strict '<' in pop order and column order; a column AT the minimum in another node is the tie
-__device__ inline void fragFlatUpdate(Lane& L, uint64_t VP, uint64_t VN, int32_t score, uint32_t pos)
+__device__ inline void fragFlatUpdate(Lane& L, uint32_t pos)
 {
-	const uint64_t above = ~fragFlatMask(L.len);
-	const int32_t f = score - popc64(VP & above) + popc64(VN & above);
+	const int32_t f = L.flat;
 	if (f < L.flatMin) { L.flatMin = f; L.flatNode = L.node; L.flatOffset = pos; }
 	else if (f == L.flatMin && L.node != L.flatNode) L.flatOffset |= 0x80000000u;
 }
@@ -162,7 +162,7 @@ __device__ inline void fragPop(const DGraph& g, const FragParams& P, Lane& L, M&
 {
 	if (L.nPending == 0) { L.phase = PH_FINISH; return; }
 	uint32_t best = 0, bestComp = m.qComp(0);
-	for (uint32_t i = 1; i < L.nPending; i++) { const uint32_t c = m.qComp(i); if (c < bestComp) { best = i; bestComp = c; } }
+	for (uint32_t i = 1; i < L.nPending; i++) { GC_LOOP_TICK(2); const uint32_t c = m.qComp(i); if (c < bestComp) { best = i; bestComp = c; } }
 	const uint32_t node = m.qNode(best);
 	uint64_t VP = m.qVP(best), VN = m.qVN(best); int32_t score = m.qScore(best);
 	const uint32_t last = L.nPending - 1;
@@ -180,7 +180,11 @@ __device__ inline void fragPop(const DGraph& g, const FragParams& P, Lane& L, M&
 	L.VP = VP; L.VN = VN; L.score = score;
 	L.tileMin = score;   // (sic) the tile's minimum starts from the first column before any merge, ...Common.h:968
 	m.itemSetStart(L.nItems, VP, VN, score, node);
-	fragFlatUpdate(L, VP, VN, score, 0);
+	{
+		const uint64_t above = ~fragFlatMask(L.len);
+		L.flat = score - popc64(VP & above) + popc64(VN & above);
+	}
+	fragFlatUpdate(L, 0);
 	L.pos = 1; L.tileLen = nodeLength; L.nodeLen = nodeLength; L.tileFlags = isStart ? TF_START : 0u;
 	L.dpTiles++; L.dpCols += nodeLength;
 	L.phase = nodeLength > 1 ? PH_COLS : PH_TILE_END;
@@ -215,9 +219,11 @@ __device__ inline void fragColumn(Lane& L, M& m)
 		m.ringSet(pos, VP & rows, VN & rows, L.len > 32);
 		L.HP |= ((Ph >> top) & 1ull) << pos; L.HN |= ((Mh >> top) & 1ull) << pos;
 	} else {
+		const uint32_t top = L.len - 1;
 		L.score += (int32_t)(Ph >> 63) - (int32_t)(Mh >> 63);
+		L.flat += (int32_t)((Ph >> top) & 1ull) - (int32_t)((Mh >> top) & 1ull);   // (forcing the first row's delta below does not move any row's value, only the implied row above)
 		if (L.score < L.tileMin) L.tileMin = L.score;
-		fragFlatUpdate(L, VP, VN, L.score, pos);
+		fragFlatUpdate(L, pos);
 	}
 	L.pos = pos + 1;
 	if (L.pos >= L.tileLen) L.phase = (L.tileFlags & TF_WALK) ? PH_WALK : PH_TILE_END;
@@ -234,7 +240,7 @@ __device__ inline void fragPush(const DGraph& g, Lane& L, M& m, uint32_t target,
 	WS add = myersStep(eqOfColumn2(L.eq, r.w0, r.w1, 0), end, 1, 0, hp, hn);
 	add.VP &= ~1ull; add.VN |= 1ull;
 	uint32_t slot = L.nPending;
-	for (uint32_t i = 0; i < L.nPending; i++) if (m.qNode(i) == target) { slot = i; break; }
+	for (uint32_t i = 0; i < L.nPending; i++) { GC_LOOP_TICK(3); if (m.qNode(i) == target) { slot = i; break; } }
 	if (slot == L.nPending) {
 		if (L.nPending >= GC_FRAG_QUEUE) { fragRetire(L, EXT_OVERFLOW); return; }
 		m.qSet(slot, add.VP, add.VN, add.score, target, r.comp);
@@ -299,7 +305,7 @@ __device__ inline void fragWalkBegin(Lane& L, M& m)
 template <class M>
 __device__ inline int fragFindItem(const Lane& L, M& m, uint32_t node)
 {
-	for (uint32_t k = 0; k < L.nItems; k++) if (m.itemNode(k) == node) return (int)k;
+	for (uint32_t k = 0; k < L.nItems; k++) { GC_LOOP_TICK(4); if (m.itemNode(k) == node) return (int)k; }
 	return -1;
 }
 
@@ -514,6 +520,7 @@ __device__ inline void fragWalkStep(const DGraph& g, const FragParams& P, Lane& 
 		uint32_t hori = L.hereOffset;
 		int vert = row;
 		while (hori > 0 && vert > 0) {
+			GC_LOOP_TICK(5);
 			if (hori - 1 < L.ringLo) { L.refillTo = hori; break; }
 			const WS colHere = column(hori), colLeft = column(hori - 1);
 			const int32_t scoreHere = wsValue(colHere, vert);

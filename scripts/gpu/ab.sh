@@ -16,7 +16,7 @@ for r in $(seq 1 $rounds); do
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    print(sys.argv[2], d["value"], d["ms_per_step"], d["stage_ms"]["k_long_extend_all_rounds"], d["stage_ms"]["whole_read_pass_wall"])
+    print(sys.argv[2], d["value"], d["ms_per_step"], "long", d["stage_ms"]["k_long_extend_all_rounds"], "wall", d["stage_ms"]["whole_read_pass_wall"], "k_extend", d["stage_ms"]["k_extend"], "anchors", d["stage_ms"]["k_build_anchors"], "parity", (d.get("parity_check") or {}).get("mismatches"))
 except Exception as e:
     print(sys.argv[2], "failed", e)
 PY
