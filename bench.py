@@ -14,8 +14,11 @@ For N>1 (weak scaling) every rank aligns its own reads against its own replica o
 --strong divides one read set over the ranks instead (BASELINE config 4's shape) with the product's work queue
 (graphchainer_amd/workqueue.py): length-sorted batches handed out dynamically.
 
-Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3] [--sv-fraction F]
-       (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|5] [--sv-fraction F]
+       --gpus N > 1 run plainly (no WORLD_SIZE in the environment) starts the N ranks itself: a fresh child process
+       `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py <same arguments>`, before this process has
+       touched the GPU; rank 0's JSON line comes through and the exit code is the child's. Fewer than N visible devices: a loud refusal, not an N=1 number.
+       (Under torch.distributed.run - the driver's form for N > 1 - the ranks are already there and nothing is started.)
 """
 import argparse
 import glob
@@ -40,6 +43,7 @@ BYTES_PER_TRACE_ITEM = 32
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 without WORLD_SIZE: print the command that would start the N ranks, and stop")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=int(os.environ.get("GC_BENCH_CONFIG", 2)), choices=[2, 3, 5])
@@ -174,8 +178,35 @@ def cpu_baseline_leg(args, gfa, reads, long_pass):
             "single_thread_stage_share": {k: round(float(v) / total, 3) for k, v in zip(stage_names, stage1)}}, summary
 
 
+def launch_ranks(args, argv):
+    """--gpus N > 1 without a launcher around us: the reference is ONE command (`-t N`, src/Aligner.cpp:1267-1270), so is this. Starts
+    `python -m torch.distributed.run` as a child process (never an exec: this process may not have touched the GPU yet, and must not replace itself
+    after it has) and returns its exit code; None when there is nothing to start (N == 1, or the ranks exist already)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    forwarded = [a for a in argv if a != "--dry-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + forwarded
+    if args.dry_launch:
+        print(" ".join(cmd))
+        return 0
+    import torch   # (counting devices does not initialise the GPU)
+    visible = torch.cuda.device_count()
+    if visible < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} asked, {visible} device(s) visible: refusing to measure fewer GPUs than asked", file=sys.stderr)
+        return 2
+    return subprocess.run(cmd).returncode
+
+
 def main():
     args = parse_args()
+    rc = launch_ranks(args, sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before anything touches HIP: a batch in flight uses a dozen streams, five batches share the device (INTEGRATION.md §7)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -1073,8 +1073,8 @@ struct BatchRun {
 		const uint32_t fragWaves = fragKernel ? extendFragWaves() : 0;
 		uint4* dFragItems = fragKernel ? st->fragItems.reserve<uint4>(extendFragScratchBytes(fragWaves) / sizeof(uint4)) : nullptr;
 		uint32_t* dFragRetry = fragKernel ? st->fragRetryList.reserve<uint32_t>(std::max<uint32_t>(1, nWork)) : nullptr;
-		unsigned long long* dFragClaims = st->fragClaims.reserve<unsigned long long>(8);   // per extension round: [2 k] the waves' claim cursor, [2 k + 1] the number of declined items
-		if (fragKernel) launchZeroWords(stream, dFragClaims, 8);
+		unsigned long long* dFragClaims = st->fragClaims.reserve<unsigned long long>(16);   // ([8..15]: the profiling build's section cycles)   // per extension round: [2 k] the waves' claim cursor, [2 k + 1] the number of declined items
+		if (fragKernel) launchZeroWords(stream, dFragClaims, 16);
 		const FragReads fragReads { R->devMasks, R->devMaskOff, R->devMaskWords, R->devOffsets, R->totalBases };
 		if (st->poolsRerun && poolReruns == 0) {   // (the batch after a rerun: see DeviceBuffer::shrinkTo)
 			st->tracePool.shrinkTo(traceBudget * sizeof(TraceCell));
@@ -1137,7 +1137,7 @@ struct BatchRun {
 			if (fragKernel) {
 				unsigned long long* claims = dFragClaims + 2 * (nExtendRounds++ & 3u);
 				if (nExtendRounds > 4) launchZeroWords(stream, claims, 2);
-				launchExtendFrag(stream, G->dev, G->devTables, cfg.bandwidth, dWork, nWork, fragReads, dResults, dFragItems, fragWaves, dTrace, dCursors + 1, traceBudget, dCounters, sel, claims, dFragRetry, claims + 1);
+				launchExtendFrag(stream, G->dev, G->devTables, cfg.bandwidth, dWork, nWork, fragReads, dResults, dFragItems, fragWaves, dTrace, dCursors + 1, traceBudget, dCounters, sel, claims, dFragRetry, claims + 1, dFragClaims + 8);
 				ExtSelection declined;
 				declined.mode = 2; declined.list = dFragRetry; declined.listCount = claims + 1;
 				launchExtend(stream, G->dev, G->devTables, G->devIupac, cfg, dWork, nWork, R->devBases, dResults, dScratch, slabBytes, dTrace, dCursors + 1, traceBudget, dCounters, EXT_OVERFLOW, declinedLanes, declined);
@@ -1272,6 +1272,13 @@ struct BatchRun {
 		res->kernel_us[3] = elapsedUs(4, 5);
 		for (int i = 0; i < 8; i++) res->counters[i] = hSmall[8 + i];
 		if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc frag] %llu of %llu fragment extensions handed to the plain-layout kernel\n", hSmall[8 + 6], hSmall[8 + 4]);
+#ifdef GC_FRAG_STAMPS
+		{
+			unsigned long long cyc[8] = { 0 };
+			HIP_CHECK(hipMemcpy(cyc, (unsigned long long*)st->fragClaims.ptr + 8, sizeof(cyc), hipMemcpyDeviceToHost));
+			fprintf(stderr, "[gc frag stamps] wave-cycles: columns %llu fetch %llu tile_end %llu pop %llu finish %llu walk %llu\n", cyc[0], cyc[1], cyc[2], cyc[3], cyc[4], cyc[5]);
+		}
+#endif
 		// (the cursors overshoot when a pool is full: the extensions / fragments that did not fit carry an overflow status and their reads are flagged)
 		uint64_t traceUsed = std::min<uint64_t>(hSmall[1], traceBudget), pathUsed = std::min<uint64_t>(hSmall[2], pathCapacity);
 		pathPool = st->hPathPool.reserve<uint32_t>(deviceAnchors ? 1 : pathUsed);

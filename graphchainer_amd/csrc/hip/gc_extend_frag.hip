@@ -18,7 +18,17 @@ using namespace gcfrag;
 #ifndef GC_FRAG_WALK_AT
 #define GC_FRAG_WALK_AT 32
 #endif
-#define GC_FRAG_CLAIM 256u   // work items a wave claims at a time (neighbouring items are neighbouring fragments of a read: neighbouring graph nodes)
+#ifndef GC_FRAG_BURST
+#define GC_FRAG_BURST 4      // column steps between two looks at the triggers
+#endif
+#define GC_FRAG_CLAIM 256u
+#define GC_FRAG_TRACE_PIECE 1024u   // trace cells a wave takes from the pool at a time (a sweep's walkers ask for ~40 each)
+// profiling build (make variant NAME=fragstamps FLAGS=-DGC_FRAG_STAMPS): wave-cycles per section of the loop below, added up into stamps[0..7] (columns, fetch, tile end, pop, finish, walk)
+#ifdef GC_FRAG_STAMPS
+#define GC_FRAG_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); stampCycles[i] += now_ - stampAt; stampAt = now_; } while (0)
+#else
+#define GC_FRAG_MARK(i) ((void)0)
+#endif   // work items a wave claims at a time (neighbouring items are neighbouring fragments of a read: neighbouring graph nodes)
 
 struct FragDevStore {
 	uint32_t* lds;       // this lane's column of the wave's LDS words: word w at lds[64 w]
@@ -56,7 +66,7 @@ uint64_t extendFragScratchBytes(uint32_t waves) { return (uint64_t)waves * FRAG_
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_extend(DGraph g, const CorrectnessTables* __restrict__ ct, int32_t bandwidth,
 	const ExtItem* __restrict__ work, uint32_t nWork, const FragReads reads, ExtResult* __restrict__ results, uint4* __restrict__ itemScratch,
 	TraceCell* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, unsigned long long* __restrict__ counters, ExtSelection sel,
-	unsigned long long* __restrict__ claim, uint32_t* __restrict__ retryList, unsigned long long* __restrict__ retryCount)
+	unsigned long long* __restrict__ claim, uint32_t* __restrict__ retryList, unsigned long long* __restrict__ retryCount, unsigned long long* __restrict__ stamps)
 {
 	__shared__ uint32_t ldsWords[FRAG_WORDS * 64];
 	__shared__ uint32_t waveCounters[8];
@@ -74,7 +84,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 	L.work = 0xffffffffu;
 	const uint32_t nSelected = sel.mode == 0 ? nWork : sel.mode == 1 ? 2 * sel.nFrags : (uint32_t)*sel.listCount;
 	unsigned long long blockNext = 0, blockEnd = 0;   // the wave's claimed range of the selection (uniform)
+	unsigned long long pieceNext = 0, pieceEnd = 0;   // the wave's piece of the trace pool (uniform)
 	const uint64_t below = (1ull << lane) - 1;
+#ifdef GC_FRAG_STAMPS
+	unsigned long long stampCycles[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stampAt = __builtin_readcyclecounter();
+#endif
 	__syncthreads();
 	for (;;) {
 		const uint32_t nIdle = (uint32_t)__popcll(__ballot(L.phase == PH_IDLE));
@@ -90,8 +104,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 			runWalk = nWalk >= walkAt;
 			if (runDp || runWalk) break;
 			if (nCols == 0) { runDp = nDp >= nWalk; runWalk = !runDp; break; }
-			if (L.phase == PH_COLS) fragColumn(L, m);
+			if (L.phase == PH_COLS) fragColumns<GC_FRAG_BURST>(L, m);
 		}
+		GC_FRAG_MARK(0);
 		// ---- one sweep of the handlers, each with every lane that is in its phase
 		const uint64_t fetching = runDp ? __ballot(L.phase == PH_FETCH) : 0ull;
 		if (fetching) {
@@ -107,12 +122,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 					if (L.status == EXT_OVERFLOW) { retryList[atomicAdd(retryCount, 1ull)] = L.work; atomicAdd(&waveCounters[6], 1u); }   // declined: the plain-layout kernel runs it (and counts its work)
 					else {
 						const bool flat = L.len < 64;
-						atomicAdd(&waveCounters[0], L.dpTiles);
-						atomicAdd(&waveCounters[1], (flat ? L.dpTiles : 0u) + L.btTiles);
-						atomicAdd(&waveCounters[2], (flat ? 2u : 1u) * L.dpCols + L.btCols);
+						const uint32_t dpTiles = L.cntTiles & 0xffffu, btTiles = L.cntTiles >> 16, dpCols = L.cntCols & 0xffffu, btCols = L.cntCols >> 16;
+						atomicAdd(&waveCounters[0], dpTiles);
+						atomicAdd(&waveCounters[1], (flat ? dpTiles : 0u) + btTiles);
+						atomicAdd(&waveCounters[2], (flat ? 2u : 1u) * dpCols + btCols);
 						atomicAdd(&waveCounters[3], L.status == EXT_OK ? L.nTrace : 0u);
 						atomicAdd(&waveCounters[4], 1u);
-						atomicAdd(&waveCounters[5], L.btTiles);
+						atomicAdd(&waveCounters[5], btTiles);
 					}
 					L.work = 0xffffffffu;
 				}
@@ -146,20 +162,30 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 			if (need > avail) { blockNext = fresh + (need - avail); blockEnd = fresh + GC_FRAG_CLAIM; }
 			else blockNext += need;
 		}
+		GC_FRAG_MARK(1);
 		if (runDp && L.phase == PH_TILE_END) fragTileEnd(g, P, L, m);
+		GC_FRAG_MARK(2);
 		if (runDp && L.phase == PH_POP) fragPop(g, P, L, m);
+		GC_FRAG_MARK(3);
 		if (runDp) {
 			bool walk = false;
 			if (L.phase == PH_FINISH) walk = fragFinish(P, L);
 			const uint64_t walking = __ballot(walk);
 			if (walking) {
-				// one request to the trace pool for the lanes that start their walk in this sweep
+				// trace cells for the lanes that start their walk in this sweep, out of the wave's own piece of the pool (a new piece - one atomic on the pool's cursor,
+				// a round trip to memory with every lane waiting - only when the piece runs out; what is left of the old one stays unused)
 				uint32_t incl = walk ? L.traceCap : 0u;
 				for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if (lane >= d) incl += up; }
 				const uint32_t total = __shfl(incl, 63);
-				unsigned long long base = 0;
-				if (lane == 0) base = atomicAdd(traceCursor, (unsigned long long)total);
-				base = __shfl(base, 0);
+				if (pieceEnd - pieceNext < total) {
+					const unsigned long long take = total > GC_FRAG_TRACE_PIECE ? total : GC_FRAG_TRACE_PIECE;
+					unsigned long long got = 0;
+					if (lane == 0) got = atomicAdd(traceCursor, take);
+					pieceNext = __shfl(got, 0);
+					pieceEnd = pieceNext + take;
+				}
+				const unsigned long long base = pieceNext;
+				pieceNext += total;
 				if (walk) {
 					L.traceBase = base + incl - L.traceCap;
 					if (L.traceBase + L.traceCap > traceCapacity) fragRetire(L, EXT_OVERFLOW);   // the pool is full: the host sizes it again and runs the stage again (fragmentPoolsOverflowed)
@@ -167,9 +193,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 				}
 			}
 		}
+		GC_FRAG_MARK(4);
 		if (runWalk) while (L.phase == PH_WALK) fragWalkStep(g, P, L, m);
+		GC_FRAG_MARK(5);
 	}
 	__syncthreads();
+#ifdef GC_FRAG_STAMPS
+	if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&stamps[i], stampCycles[i]);
+#endif
 	if (lane < 7 && waveCounters[lane]) atomicAdd(&counters[lane], (unsigned long long)waveCounters[lane]);   // [6]: extensions handed to the plain-layout kernel
 }
 
@@ -207,14 +238,14 @@ uint32_t extendFragWaves()
 
 void launchExtendFrag(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, int32_t bandwidth, const ExtItem* work, uint32_t nWork, const FragReads& reads, ExtResult* results,
 	uint4* itemScratch, uint32_t scratchWaves, TraceCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters, ExtSelection sel, unsigned long long* claim,
-	uint32_t* retryList, unsigned long long* retryCount)
+	uint32_t* retryList, unsigned long long* retryCount, unsigned long long* stamps)
 {
 	if (nWork == 0) return;
 	const uint32_t upper = sel.mode == 1 ? 2 * sel.nFrags : nWork;
 	uint32_t waves = (upper + 63) / 64;
 	if (waves > scratchWaves) waves = scratchWaves;
 	if (waves == 0) return;
-	hipLaunchKernelGGL(k_extend, dim3(waves), dim3(64), 0, stream, g, ct, bandwidth, work, nWork, reads, results, itemScratch, tracePool, traceCursor, traceCapacity, counters, sel, claim, retryList, retryCount);
+	hipLaunchKernelGGL(k_extend, dim3(waves), dim3(64), 0, stream, g, ct, bandwidth, work, nWork, reads, results, itemScratch, tracePool, traceCursor, traceCapacity, counters, sel, claim, retryList, retryCount, stamps);
 }
 
 } // namespace gcdev

@@ -82,8 +82,13 @@ struct FragMem : S {
 		if (wide) { st64(2 * (c & 7u), VP); st64(16 + 2 * (c & 7u), VN); }
 		else { this->st(c & 15u, (uint32_t)VP); this->st(16 + (c & 15u), (uint32_t)VN); }
 	}
+	__device__ uint32_t idGet(uint32_t k) { return this->ld(GC_FRAG_RING_WORDS + k); }
+	__device__ void idSet(uint32_t k, uint32_t node) { this->st(GC_FRAG_RING_WORDS + k, node); }
 };
 __device__ inline uint32_t fragRingColumns(uint32_t len) { return len > 32 ? 8u : 16u; }
+// the words the ring leaves of the queue's region hold the first items' node ids during the walk ("which item is node v": asked at every tile the walk enters and for every
+// in-neighbour at a crossing - from the item planes that is one dependent load per item looked at)
+constexpr uint32_t FRAG_IDS = FRAG_WORDS - GC_FRAG_RING_WORDS;
 
 struct Lane {
 	uint32_t phase;
@@ -102,15 +107,28 @@ struct Lane {
 	int32_t flat;             // DP: the column's value at the sequence's last row (what flattenLastSliceEnd reads, ...Common.h:1210-1218), kept by its horizontal deltas
 	uint64_t w0, w1;
 	int32_t tileMin;
-	uint32_t outBegin, outDeg;
+	uint32_t outBegin, outDeg, t0, t1;   // the tile's out-edges; the first two targets are fetched when the tile is popped and used when it ends
 	// the walk
-	uint64_t HP, HN; int32_t colStart;   // the recomputed columns' scores at the sequence's LAST row: the first column's and the deltas from column to column (the walk never looks above that row)
-	uint32_t hereNode, hereOffset; int32_t hereSeqPos;
-	uint32_t curItem, ringLo, refillTo, inBegin, inDeg;
+	uint64_t HP, HN;                     // the recomputed columns' scores at the sequence's LAST row: the first column's and the deltas from column to column (the walk never looks above that row)
+	uint32_t n0, n1;          // the first two in-neighbours of the walk's tile (fetched when it is entered)
+	// the rest of the walk's state lives in the registers the DP has left (a lane is in one of the two parts of an extension at a time; the kernel sits at the register
+	// count of four waves per SIMD): where the walk stands, the item of its tile, the ring's lowest column, a pending refill, the tile's in-edges, the first column's score
+	__device__ uint32_t& hereNode() { return flatNode; }
+	__device__ uint32_t& hereOffset() { return flatOffset; }
+	__device__ int32_t& hereSeqPos() { return flatMin; }
+	__device__ uint32_t& curItem() { return nPending; }
+	__device__ uint32_t& ringLo() { return outBegin; }
+	__device__ uint32_t& refillTo() { return outDeg; }
+	__device__ uint32_t& inBegin() { return t0; }
+	__device__ uint32_t& inDeg() { return t1; }
+	__device__ int32_t& colStart() { return tileMin; }
+	__device__ uint32_t curItem() const { return nPending; }
+	__device__ uint32_t inBegin() const { return t0; }
+	__device__ uint32_t inDeg() const { return t1; }
 	uint32_t nTrace, traceCap; uint64_t traceBase;
 	int32_t resultScore; uint32_t tie;
-	// counters of this extension, in the reference's units (ExtCounters)
-	uint32_t dpTiles, dpCols, btTiles, btCols;
+	// counters of this extension, in the reference's units (ExtCounters): tiles and columns, the DP's in the low halves, the walk's in the high halves
+	uint32_t cntTiles, cntCols;
 };
 
 __device__ inline uint64_t eqOfColumn2(const Eq4& eq, uint64_t w0, uint64_t w1, uint32_t pos)
@@ -140,7 +158,7 @@ __device__ inline void fragBegin(const DGraph& g, const FragParams& P, Lane& L, 
 {
 	L.work = work; L.status = EXT_OK; L.len = len; L.startNode = node; L.startOffset = offset;
 	L.nTrace = 0; L.resultScore = 0; L.tie = 0;
-	L.dpTiles = L.dpCols = L.btTiles = L.btCols = 0;
+	L.cntTiles = L.cntCols = 0;
 	if (len == 0) { fragRetire(L, EXT_FAILED); return; }      // no slice: table.slices.size() <= 1
 	if (len > 64) { fragRetire(L, EXT_OVERFLOW); return; }    // more than one slice: the plain-layout core
 	const NodeRec r = g.nodeRec[node];
@@ -177,6 +195,8 @@ __device__ inline void fragPop(const DGraph& g, const FragParams& P, Lane& L, M&
 	if (isStart && !(VP == ~0ull && VN == 0ull && score == (int32_t)L.startOffset + 64)) { fragRetire(L, EXT_OVERFLOW); return; }
 	L.node = node; L.w0 = r.w0; L.w1 = r.w1;
 	L.outBegin = r.outOff; L.outDeg = (r.meta >> 8) & 255u;
+	L.t0 = L.outDeg > 0 ? g.outAdj[r.outOff] : 0u;
+	L.t1 = L.outDeg > 1 ? g.outAdj[r.outOff + 1] : 0u;
 	L.VP = VP; L.VN = VN; L.score = score;
 	L.tileMin = score;   // (sic) the tile's minimum starts from the first column before any merge, ...Common.h:968
 	m.itemSetStart(L.nItems, VP, VN, score, node);
@@ -186,20 +206,23 @@ __device__ inline void fragPop(const DGraph& g, const FragParams& P, Lane& L, M&
 	}
 	fragFlatUpdate(L, 0);
 	L.pos = 1; L.tileLen = nodeLength; L.nodeLen = nodeLength; L.tileFlags = isStart ? TF_START : 0u;
-	L.dpTiles++; L.dpCols += nodeLength;
+	L.cntTiles++; L.cntCols += nodeLength;
 	L.phase = nodeLength > 1 ? PH_COLS : PH_TILE_END;
 }
 
-// ---- PH_COLS: one column of the tile (getNextSlice, ...Common.h:243-263, with the carries of ...Common.h:1118-1161)
+// ---- PH_COLS: one column of the tile (getNextSlice, ...Common.h:243-263, with the carries of ...Common.h:1118-1161). Written with selects instead of branches: the
+// lanes of a wave are in DP tiles and walk tiles, seed tiles and others at the same time, and every branch that assigns loop-carried state costs register copies
 template <class M>
-__device__ inline void fragColumn(Lane& L, M& m)
+__device__ inline void fragColumnStep(Lane& L, M& m)
 {
 	const uint32_t pos = L.pos;
+	const bool isStart = (L.tileFlags & TF_START) != 0, walk = (L.tileFlags & TF_WALK) != 0;
 	uint64_t Eq = eqOfColumn2(L.eq, L.w0, L.w1, pos);
-	uint64_t hinP, hinN;
-	const bool isStart = (L.tileFlags & TF_START) != 0;
-	if (isStart) { hinN = pos <= L.startOffset ? 1ull : 0ull; hinP = hinN ^ 1ull; }   // the initial slice's ramp: -1 up to the seed's column, +1 behind it
-	else { hinP = 1; hinN = 0; Eq &= ~1ull; }
+	// the row above: the seed's tile has the initial slice's ramp (-1 up to the seed's column, +1 behind it), every other tile nothing (+1, and the first row forced)
+	const uint64_t hinN = (isStart && pos <= L.startOffset) ? 1ull : 0ull;
+	const uint64_t hinP = hinN ^ 1ull;
+	const uint64_t force = isStart ? 0ull : 1ull;
+	Eq &= ~force;
 	// myersStep (gc_device.hpp) with the horizontal deltas of every row left in Ph / Mh
 	const uint64_t VP0 = L.VP, VN0 = L.VN;
 	const uint64_t Xv = Eq | VN0;
@@ -208,33 +231,53 @@ __device__ inline void fragColumn(Lane& L, M& m)
 	const uint64_t Ph = VN0 | ~(Xh | VP0);
 	const uint64_t Mh = VP0 & Xh;
 	const uint64_t sMh = (Mh << 1) | hinN, sPh = (Ph << 1) | hinP;
-	uint64_t VP = sMh | ~(Xv | sPh);
-	uint64_t VN = sPh & Xv;
-	if (!isStart) { VP &= ~1ull; VN |= 1ull; }
+	const uint64_t VP = (sMh | ~(Xv | sPh)) & ~force;
+	const uint64_t VN = (sPh & Xv) | force;
 	L.VP = VP; L.VN = VN;
-	if (L.tileFlags & TF_WALK) {
+	const uint32_t top = L.len - 1;
+	const int32_t dTop = (int32_t)((Ph >> top) & 1ull) - (int32_t)((Mh >> top) & 1ull);   // the step of the sequence's last row from the previous column to this one
+	if (walk) {
 		// the walk's columns: cut to the sequence's rows, their score taken at its last row
-		const uint32_t top = L.len - 1;
 		const uint64_t rows = fragFlatMask(L.len);
 		m.ringSet(pos, VP & rows, VN & rows, L.len > 32);
 		L.HP |= ((Ph >> top) & 1ull) << pos; L.HN |= ((Mh >> top) & 1ull) << pos;
-	} else {
-		const uint32_t top = L.len - 1;
-		L.score += (int32_t)(Ph >> 63) - (int32_t)(Mh >> 63);
-		L.flat += (int32_t)((Ph >> top) & 1ull) - (int32_t)((Mh >> top) & 1ull);   // (forcing the first row's delta below does not move any row's value, only the implied row above)
-		if (L.score < L.tileMin) L.tileMin = L.score;
-		fragFlatUpdate(L, pos);
+	}
+	// the DP's bookkeeping (its registers hold the walk's state during a walk: selects keep that in place)
+	const int32_t score = L.score + (int32_t)(Ph >> 63) - (int32_t)(Mh >> 63);
+	const int32_t flat = L.flat + dTop;   // (forcing the first row's delta does not move any row's value, only the implied row above)
+	L.score = score;
+	L.flat = walk ? L.flat : flat;
+	L.tileMin = (!walk && score < L.tileMin) ? score : L.tileMin;
+	{
+		// the fused flattenLastSliceEnd, as fragFlatUpdate
+		const bool lower = !walk && flat < L.flatMin, tied = !walk && flat == L.flatMin && L.node != L.flatNode;
+		L.flatMin = lower ? flat : L.flatMin;
+		L.flatNode = lower ? L.node : L.flatNode;
+		L.flatOffset = lower ? pos : (tied ? (L.flatOffset | 0x80000000u) : L.flatOffset);
 	}
 	L.pos = pos + 1;
+}
+template <class M>
+__device__ inline void fragColumn(Lane& L, M& m)
+{
+	fragColumnStep(L, m);
+	if (L.pos >= L.tileLen) L.phase = (L.tileFlags & TF_WALK) ? PH_WALK : PH_TILE_END;
+}
+// up to BURST columns of the tile before the lane looks up: the kernel's column loop checks its triggers once per burst (a lane whose tile ends inside a burst idles
+// for the rest of it - it would wait for the sweep anyway)
+template <int BURST, class M>
+__device__ inline void fragColumns(Lane& L, M& m)
+{
+#pragma unroll
+	for (int u = 0; u < BURST; u++) if (L.pos < L.tileLen) fragColumnStep(L, m);
 	if (L.pos >= L.tileLen) L.phase = (L.tileFlags & TF_WALK) ? PH_WALK : PH_TILE_END;
 }
 
 // one out-edge of a finished tile folded into the queue (the per-edge part of calculateNodeInner, ...Common.h:903-964, for a target without a previous-slice twin)
 template <class M>
-__device__ inline void fragPush(const DGraph& g, Lane& L, M& m, uint32_t target, const WS& end)
+__device__ inline void fragPush(Lane& L, M& m, uint32_t target, const NodeRec& r, const WS& end)
 {
 	if (target == L.startNode) { fragRetire(L, EXT_OVERFLOW); return; }   // a cycle through the seed's node: not this core's case
-	const NodeRec r = g.nodeRec[target];
 	if (r.meta & NODEREC_SLOW) { fragRetire(L, EXT_OVERFLOW); return; }
 	uint64_t hp, hn;
 	WS add = myersStep(eqOfColumn2(L.eq, r.w0, r.w1, 0), end, 1, 0, hp, hn);
@@ -265,7 +308,14 @@ __device__ inline void fragTileEnd(const DGraph& g, const FragParams& P, Lane& L
 	L.phase = PH_POP;
 	if (endMin <= L.curMin + P.bandwidth) {
 		if (L.outDeg == 255u) { fragRetire(L, EXT_OVERFLOW); return; }
-		for (uint32_t e = 0; e < L.outDeg && L.phase == PH_POP; e++) fragPush(g, L, m, g.outAdj[L.outBegin + e], end);
+		// (the records of the first two targets are asked for together: one round trip for the common node instead of one per edge)
+		const uint32_t deg = L.outDeg;
+		NodeRec r0 {}, r1 {};
+		if (deg > 0) r0 = g.nodeRec[L.t0];
+		if (deg > 1) r1 = g.nodeRec[L.t1];
+		if (deg > 0) fragPush(L, m, L.t0, r0, end);
+		if (deg > 1 && L.phase == PH_POP) fragPush(L, m, L.t1, r1, end);
+		for (uint32_t e = 2; e < deg && L.phase == PH_POP; e++) { const uint32_t t = g.outAdj[L.outBegin + e]; fragPush(L, m, t, g.nodeRec[t], end); }
 	}
 }
 
@@ -296,16 +346,24 @@ __device__ inline bool fragTracePush(Lane& L, M& m, uint32_t node, uint32_t offs
 template <class M>
 __device__ inline void fragWalkBegin(Lane& L, M& m)
 {
-	L.hereNode = L.flatNode; L.hereOffset = L.flatOffset & 0x7fffffffu; L.hereSeqPos = (int32_t)L.len - 1;
-	L.node = 0xffffffffu; L.refillTo = 0xffffffffu; L.ringLo = 0; L.curItem = 0;
+	{
+		// the first items' node ids into the words the queue has left (all loads first, then the stores)
+		uint32_t id[FRAG_IDS];
+		for (uint32_t k = 0; k < FRAG_IDS; k++) id[k] = m.itemNode(k < L.nItems ? k : 0u);
+		for (uint32_t k = 0; k < FRAG_IDS; k++) m.idSet(k, id[k]);
+	}
+	L.hereNode() = L.flatNode; L.hereOffset() = L.flatOffset & 0x7fffffffu; L.hereSeqPos() = (int32_t)L.len - 1;   // (the first two are where they already are)
+	L.node = 0xffffffffu; L.refillTo() = 0xffffffffu; L.ringLo() = 0; L.curItem() = 0;
 	L.phase = PH_WALK;
-	fragTracePush(L, m, L.hereNode, L.hereOffset, L.hereSeqPos, false);
+	fragTracePush(L, m, L.hereNode(), L.hereOffset(), L.hereSeqPos(), false);
 }
 
 template <class M>
 __device__ inline int fragFindItem(const Lane& L, M& m, uint32_t node)
 {
-	for (uint32_t k = 0; k < L.nItems; k++) { GC_LOOP_TICK(4); if (m.itemNode(k) == node) return (int)k; }
+	const uint32_t inLds = L.nItems < FRAG_IDS ? L.nItems : FRAG_IDS;
+	for (uint32_t k = 0; k < inLds; k++) { GC_LOOP_TICK(4); if (m.idGet(k) == node) return (int)k; }
+	for (uint32_t k = FRAG_IDS; k < L.nItems; k++) { GC_LOOP_TICK(4); if (m.itemNode(k) == node) return (int)k; }
 	return -1;
 }
 
@@ -318,7 +376,7 @@ __device__ inline bool fragCorner(const DGraph& g, const FragParams& P, const La
 	const uint32_t node = L.node;
 	const int32_t quitScore = L.resultScore + P.bandwidth;
 	const int32_t previousQuitScore = 1;
-	const int32_t scoreHere = wsValue(m.itemStart(L.curItem), 0);
+	const int32_t scoreHere = wsValue(m.itemStart(L.curItem()), 0);
 	const bool prevSelf = node == L.startNode;
 	const int32_t initStart = (int32_t)L.startOffset, initEnd = (int32_t)L.startLen - 1 - (int32_t)L.startOffset;   // the initial item's first and last score
 	if (scoreHere > quitScore) {
@@ -326,8 +384,8 @@ __device__ inline bool fragCorner(const DGraph& g, const FragParams& P, const La
 		out = FragCell { 0, 0, 0 };
 		nodeSwitch = false;
 		if (prevSelf) { smallest = initStart; out = FragCell { node, 0, -1 }; }
-		for (uint32_t e = 0; e < L.inDeg; e++) {
-			const uint32_t nb = g.inAdj[L.inBegin + e];
+		for (uint32_t e = 0; e < L.inDeg(); e++) {
+			const uint32_t nb = e == 0 ? L.n0 : e == 1 ? L.n1 : g.inAdj[L.inBegin() + e];
 			if (nb == L.startNode && initEnd <= smallest) { smallest = initEnd; out = FragCell { nb, L.startLen - 1, -1 }; nodeSwitch = true; }
 			const int c = fragFindItem(L, m, nb);
 			if (c >= 0 && nb != node) {
@@ -341,8 +399,8 @@ __device__ inline bool fragCorner(const DGraph& g, const FragParams& P, const La
 	if (prevSelf && initStart == scoreHere - 1) { out = FragCell { node, 0, -1 }; nodeSwitch = false; return true; }
 	FragCell bestInvalid { 0xffffffffu, 0xffffffffu, -1 };
 	int32_t bestInvalidScore = scoreHere + 1;
-	for (uint32_t e = 0; e < L.inDeg; e++) {
-		const uint32_t nb = g.inAdj[L.inBegin + e];
+	for (uint32_t e = 0; e < L.inDeg(); e++) {
+		const uint32_t nb = e == 0 ? L.n0 : e == 1 ? L.n1 : g.inAdj[L.inBegin() + e];
 		const int c = fragFindItem(L, m, nb);
 		if (c >= 0 && wsValue(m.itemEnd((uint32_t)c), 0) == scoreHere - 1) { out = FragCell { nb, (uint32_t)g.nodeLength[nb] - 1, 0 }; nodeSwitch = true; return true; }
 		if (nb == L.startNode) {
@@ -364,83 +422,85 @@ template <class M>
 __device__ inline void fragWalkStep(const DGraph& g, const FragParams& P, Lane& L, M& m)
 {
 	const uint32_t NO_REFILL = 0xffffffffu;
-	if (L.hereSeqPos == -1) {
+	if (L.hereSeqPos() == -1) {
 		// row -1: left along the initial ramp towards the seed's column (...Common.h:508-542; the in-neighbour hop needs a second node in the initial slice)
-		if (L.hereNode != L.startNode) { fragRetire(L, EXT_ASSERT); return; }
-		uint32_t off = L.hereOffset;
+		if (L.hereNode() != L.startNode) { fragRetire(L, EXT_ASSERT); return; }
+		uint32_t off = L.hereOffset();
 		while (true) {
 			int32_t b = (int32_t)off - (int32_t)L.startOffset; if (b < 0) b = -b;
 			int32_t bl = (int32_t)off - 1 - (int32_t)L.startOffset; if (bl < 0) bl = -bl;
 			if (!(b != 0 && off > 0 && bl == b - 1)) break;
 			off--;
-			if (!fragTracePush(L, m, L.hereNode, off, -1, false)) return;
+			if (!fragTracePush(L, m, L.hereNode(), off, -1, false)) return;
 		}
 		fragRetire(L, EXT_OK);
 		return;
 	}
-	const bool entering = L.hereNode != L.node;
+	const bool entering = L.hereNode() != L.node;
 	if (entering) {
-		const int item = fragFindItem(L, m, L.hereNode);
+		const int item = fragFindItem(L, m, L.hereNode());
 		if (item < 0) { fragRetire(L, EXT_ASSERT); return; }
-		const NodeRec r = g.nodeRec[L.hereNode];
-		L.curItem = (uint32_t)item; L.node = L.hereNode;
+		const NodeRec r = g.nodeRec[L.hereNode()];
+		L.curItem() = (uint32_t)item; L.node = L.hereNode();
 		L.w0 = r.w0; L.w1 = r.w1;
-		L.inBegin = r.inOff; L.inDeg = (r.meta >> 16) & 255u;
-		L.tileFlags = TF_WALK | (L.hereNode == L.startNode ? TF_START : 0u);
+		L.inBegin() = r.inOff; L.inDeg() = (r.meta >> 16) & 255u;
+		L.tileFlags = TF_WALK | (L.hereNode() == L.startNode ? TF_START : 0u);
 		L.nodeLen = r.meta & 127u;
-		L.btTiles++; L.btCols += L.nodeLen;
-		if (L.inDeg == 255u) { fragRetire(L, EXT_OVERFLOW); return; }
+		L.cntTiles += 1u << 16; L.cntCols += L.nodeLen << 16;
+		if (L.inDeg() == 255u) { fragRetire(L, EXT_OVERFLOW); return; }
+		L.n0 = L.inDeg() > 0 ? g.inAdj[r.inOff] : 0u;
+		L.n1 = L.inDeg() > 1 ? g.inAdj[r.inOff + 1] : 0u;
 	}
-	if (entering || L.refillTo != NO_REFILL) {
+	if (entering || L.refillTo() != NO_REFILL) {
 		// recalcNodeWordslice (...Common.h:828-852) into the ring: the columns up to the one the walk stands on (it only moves left)
-		const uint32_t upTo = entering ? L.hereOffset : L.refillTo;
-		const WS start = m.itemStart(L.curItem);
+		const uint32_t upTo = entering ? L.hereOffset() : L.refillTo();
+		const WS start = m.itemStart(L.curItem());
 		const uint64_t rows = fragFlatMask(L.len);
 		L.VP = start.VP; L.VN = start.VN;
-		L.colStart = wsValue(start, (int)L.len - 1); L.HP = 0; L.HN = 0;
+		L.colStart() = wsValue(start, (int)L.len - 1); L.HP = 0; L.HN = 0;
 		m.ringSet(0, start.VP & rows, start.VN & rows, L.len > 32);
 		const uint32_t ring = fragRingColumns(L.len);
-		L.ringLo = upTo > ring - 1 ? upTo - (ring - 1) : 0;
-		L.refillTo = NO_REFILL;
+		L.ringLo() = upTo > ring - 1 ? upTo - (ring - 1) : 0;
+		L.refillTo() = NO_REFILL;
 		L.pos = 1;
 		L.tileLen = upTo + 1 < L.nodeLen ? upTo + 1 : L.nodeLen;
 		if (L.tileLen > 1) { L.phase = PH_COLS; return; }
 	}
 	auto column = [&](uint32_t c) -> WS {
 		const uint64_t mask = (c >= 63 ? ~0ull : ((2ull << c) - 1)) & ~1ull;
-		return WS { m.ringVP(c, L.len > 32), m.ringVN(c, L.len > 32), L.colStart + popc64(L.HP & mask) - popc64(L.HN & mask) };   // (a column of rows 0..len-1: the rows above hold zeros)
+		return WS { m.ringVP(c, L.len > 32), m.ringVN(c, L.len > 32), L.colStart() + popc64(L.HP & mask) - popc64(L.HN & mask) };   // (a column of rows 0..len-1: the rows above hold zeros)
 	};
 	const uint32_t curNode = L.node;
-	const int row = L.hereSeqPos;   // (the only slice starts at row 0)
+	const int row = L.hereSeqPos();   // (the only slice starts at row 0)
 	const int32_t quitScore = L.resultScore + P.bandwidth, previousQuitScore = 1;
-	if (row == 0 && L.hereOffset == 0) {
+	if (row == 0 && L.hereOffset() == 0) {
 		FragCell nxt; bool sw;
 		if (!fragCorner(g, P, L, m, nxt, sw)) { fragRetire(L, EXT_ASSERT); return; }
 		if (!fragTracePush(L, m, nxt.node, nxt.offset, nxt.seqPos, sw)) return;
-		L.hereNode = nxt.node; L.hereOffset = nxt.offset; L.hereSeqPos = nxt.seqPos;
+		L.hereNode() = nxt.node; L.hereOffset() = nxt.offset; L.hereSeqPos() = nxt.seqPos;
 		return;
 	}
 	if (row == 0) {
 		// vertical crossing into the initial slice (...Common.h:451-477, pickBacktraceVerticalCrossing :665-708)
 		if (curNode != L.startNode) {
-			L.hereOffset = 0;
-			fragTracePush(L, m, curNode, 0, L.hereSeqPos, false);
+			L.hereOffset() = 0;
+			fragTracePush(L, m, curNode, 0, L.hereSeqPos(), false);
 			return;
 		}
-		uint32_t off = L.hereOffset;
+		uint32_t off = L.hereOffset();
 		while (off > 0) {
-			if (off - 1 < L.ringLo) { L.refillTo = off; break; }
+			if (off - 1 < L.ringLo()) { L.refillTo() = off; break; }
 			if (wsValue(column(off - 1), 0) != wsValue(column(off), 0) - 1) break;
 			off--;
-			if (!fragTracePush(L, m, curNode, off, L.hereSeqPos, false)) return;
+			if (!fragTracePush(L, m, curNode, off, L.hereSeqPos(), false)) return;
 		}
-		L.hereOffset = off;
-		if (L.refillTo != NO_REFILL) return;
+		L.hereOffset() = off;
+		if (L.refillTo() != NO_REFILL) return;
 		if (off == 0) {
 			FragCell nxt; bool sw;
 			if (!fragCorner(g, P, L, m, nxt, sw)) { fragRetire(L, EXT_ASSERT); return; }
 			if (!fragTracePush(L, m, nxt.node, nxt.offset, nxt.seqPos, sw)) return;
-			L.hereNode = nxt.node; L.hereOffset = nxt.offset; L.hereSeqPos = nxt.seqPos;
+			L.hereNode() = nxt.node; L.hereOffset() = nxt.offset; L.hereSeqPos() = nxt.seqPos;
 			return;
 		}
 		// the initial item: scores |column - startOffset|, i.e. deltas -1 up to the seed's column and +1 behind it
@@ -454,32 +514,32 @@ __device__ inline void fragWalkStep(const DGraph& g, const FragParams& P, Lane& 
 		const int32_t scoreUp = scoreDiagonal + (int32_t)((pnHP >> off) & 1) - (int32_t)((pnHN >> off) & 1);
 		FragCell nxt;
 		if (scoreHere > quitScore || scoreDiagonal > previousQuitScore || scoreUp > previousQuitScore) {
-			nxt = scoreDiagonal < scoreUp ? FragCell { curNode, off - 1, L.hereSeqPos - 1 } : FragCell { curNode, off, L.hereSeqPos - 1 };
+			nxt = scoreDiagonal < scoreUp ? FragCell { curNode, off - 1, L.hereSeqPos() - 1 } : FragCell { curNode, off, L.hereSeqPos() - 1 };
 		} else {
 			const int eqBit = (int)(eqOfColumn2(L.eq, L.w0, L.w1, off) & 1);
-			if (scoreUp == scoreHere - 1) nxt = FragCell { curNode, off, L.hereSeqPos - 1 };
-			else if (scoreDiagonal == scoreHere - (eqBit ? 0 : 1)) nxt = FragCell { curNode, off - 1, L.hereSeqPos - 1 };
+			if (scoreUp == scoreHere - 1) nxt = FragCell { curNode, off, L.hereSeqPos() - 1 };
+			else if (scoreDiagonal == scoreHere - (eqBit ? 0 : 1)) nxt = FragCell { curNode, off - 1, L.hereSeqPos() - 1 };
 			else { fragRetire(L, EXT_ASSERT); return; }
 		}
 		if (!fragTracePush(L, m, nxt.node, nxt.offset, nxt.seqPos, false)) return;
-		L.hereNode = nxt.node; L.hereOffset = nxt.offset; L.hereSeqPos = nxt.seqPos;
+		L.hereNode() = nxt.node; L.hereOffset() = nxt.offset; L.hereSeqPos() = nxt.seqPos;
 		return;
 	}
-	if (L.hereOffset == 0) {
+	if (L.hereOffset() == 0) {
 		// horizontal crossing into an in-neighbour (...Common.h:478-499, pickBacktraceHorizontalCrossing :599-663)
-		const WS start = m.itemStart(L.curItem);
-		int32_t sp = L.hereSeqPos;
+		const WS start = m.itemStart(L.curItem());
+		int32_t sp = L.hereSeqPos();
 		while ((sp & 63) != 0 && (start.VP & (1ull << (sp & 63)))) {
 			sp--;
 			if (!fragTracePush(L, m, curNode, 0, sp, false)) return;
 		}
-		L.hereSeqPos = sp;
+		L.hereSeqPos() = sp;
 		const int offset = sp & 63;
 		if (offset == 0) {
 			FragCell nxt; bool sw;
 			if (!fragCorner(g, P, L, m, nxt, sw)) { fragRetire(L, EXT_ASSERT); return; }
 			if (!fragTracePush(L, m, nxt.node, nxt.offset, nxt.seqPos, sw)) return;
-			L.hereNode = nxt.node; L.hereOffset = nxt.offset; L.hereSeqPos = nxt.seqPos;
+			L.hereNode() = nxt.node; L.hereOffset() = nxt.offset; L.hereSeqPos() = nxt.seqPos;
 			return;
 		}
 		const int eqBit = (int)((eqOfColumn2(L.eq, L.w0, L.w1, 0) >> offset) & 1);
@@ -489,8 +549,8 @@ __device__ inline void fragWalkStep(const DGraph& g, const FragParams& P, Lane& 
 		if (scoreHere > quitScore) {
 			int32_t smallest = wsValue(start, offset - 1);
 			nxt = FragCell { curNode, 0, sp - 1 };
-			for (uint32_t e = 0; e < L.inDeg; e++) {
-				const uint32_t nb = g.inAdj[L.inBegin + e];
+			for (uint32_t e = 0; e < L.inDeg(); e++) {
+				const uint32_t nb = e == 0 ? L.n0 : e == 1 ? L.n1 : g.inAdj[L.inBegin() + e];
 				const int c = fragFindItem(L, m, nb);
 				if (c < 0) continue;
 				const WS ne = m.itemEnd((uint32_t)c);
@@ -500,8 +560,8 @@ __device__ inline void fragWalkStep(const DGraph& g, const FragParams& P, Lane& 
 			}
 			found = true;
 		} else {
-			for (uint32_t e = 0; e < L.inDeg && !found; e++) {
-				const uint32_t nb = g.inAdj[L.inBegin + e];
+			for (uint32_t e = 0; e < L.inDeg() && !found; e++) {
+				const uint32_t nb = e == 0 ? L.n0 : e == 1 ? L.n1 : g.inAdj[L.inBegin() + e];
 				const int c = fragFindItem(L, m, nb);
 				if (c < 0) continue;
 				const WS ne = m.itemEnd((uint32_t)c);
@@ -512,16 +572,16 @@ __device__ inline void fragWalkStep(const DGraph& g, const FragParams& P, Lane& 
 		}
 		if (!found) { fragRetire(L, EXT_ASSERT); return; }
 		if (!fragTracePush(L, m, nxt.node, nxt.offset, nxt.seqPos, sw)) return;
-		L.hereNode = nxt.node; L.hereOffset = nxt.offset; L.hereSeqPos = nxt.seqPos;
+		L.hereNode() = nxt.node; L.hereOffset() = nxt.offset; L.hereSeqPos() = nxt.seqPos;
 		return;
 	}
 	// inside the tile (pickBacktraceInside, ...Common.h:556-597): vertical, then diagonal, then horizontal
 	{
-		uint32_t hori = L.hereOffset;
+		uint32_t hori = L.hereOffset();
 		int vert = row;
 		while (hori > 0 && vert > 0) {
 			GC_LOOP_TICK(5);
-			if (hori - 1 < L.ringLo) { L.refillTo = hori; break; }
+			if (hori - 1 < L.ringLo()) { L.refillTo() = hori; break; }
 			const WS colHere = column(hori), colLeft = column(hori - 1);
 			const int32_t scoreHere = wsValue(colHere, vert);
 			const int32_t vertical = wsValue(colHere, vert - 1);
@@ -535,7 +595,7 @@ __device__ inline void fragWalkStep(const DGraph& g, const FragParams& P, Lane& 
 			}
 			if (!fragTracePush(L, m, curNode, hori, vert, false)) return;
 		}
-		L.hereOffset = hori; L.hereSeqPos = vert;
+		L.hereOffset() = hori; L.hereSeqPos() = vert;
 	}
 }
 

@@ -178,7 +178,7 @@ uint32_t extendFragWaves();                        // resident waves of the kern
 uint64_t extendFragScratchBytes(uint32_t waves);
 void launchExtendFrag(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, int32_t bandwidth, const ExtItem* work, uint32_t nWork, const FragReads& reads, ExtResult* results,
 	uint4* itemScratch, uint32_t scratchWaves, TraceCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters, ExtSelection sel, unsigned long long* claim,
-	uint32_t* retryList, unsigned long long* retryCount);   // claim, retryCount: zeroed words of this launch's own; retryList [nWork]: the declined items, for launchExtend with a list selection
+	uint32_t* retryList, unsigned long long* retryCount, unsigned long long* stamps = nullptr);   // (stamps: eight words of the profiling build, -DGC_FRAG_STAMPS) claim, retryCount: zeroed words of this launch's own; retryList [nWork]: the declined items, for launchExtend with a list selection
 void launchBuildNodeRecs(hipStream_t stream, const DGraph& g, NodeRec* out);   // DGraph::nodeRec from the arrays already uploaded
 uint64_t extendSlabBytes(const ExtendConfig& cfg);
 uint32_t extendGridLanes(uint32_t nWork);

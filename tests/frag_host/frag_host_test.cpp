@@ -39,7 +39,7 @@ static Run runLane(const gcdev::DGraph& g, const gcfrag::FragParams& P, const ui
 		}
 	}
 	out.status = L.status; out.score = L.resultScore; out.tie = L.status == gcdev::EXT_OK ? L.tie : 0;
-	out.dpTiles = L.dpTiles; out.dpCols = L.dpCols; out.btTiles = L.btTiles; out.btCols = L.btCols; out.nItems = L.nItems; out.traceCap = L.traceCap;
+	out.dpTiles = L.cntTiles & 0xffffu; out.dpCols = L.cntCols & 0xffffu; out.btTiles = L.cntTiles >> 16; out.btCols = L.cntCols >> 16; out.nItems = L.nItems; out.traceCap = L.traceCap;
 	if (L.status == gcdev::EXT_OK) out.trace.assign(m.trace.begin(), m.trace.begin() + L.nTrace);
 	return out;
 }

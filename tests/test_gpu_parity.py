@@ -761,7 +761,7 @@ def test_shim_replays_the_reference_call_sequence(gca, tmp_path, golden_dir):
 
 def test_single_process_two_devices_four_streams(gca, tmp_path):
     """the reference is ONE process with -t worker threads (src/Aligner.cpp:1267-1270); on a node with several GPUs that is a worker thread per gc_stream, a
-    replica of the graph per device (gc_set_device + gc_index_load on the device's first thread) and one shared atomic batch cursor - tests/multigpu/multi_gpu_host.cpp, C ABI only.
+    replica of the graph per device (gc_set_device + gc_index_load on the device's first thread) and one shared atomic batch cursor - examples/multi_gpu_host.cpp, C ABI only.
     Here: two LOGICAL devices (both on the box's one GPU: two gc_graph handles in one process) x two threads each, batches of 7 reads; every read's anchors, chain, chain score,
     whole-read alignments, both NW distances, decision and tie counts equal the oracle's, and both devices took batches."""
     import subprocess

@@ -256,6 +256,25 @@ def test_fragment_extension_core_equals_oracle(tmp_path):
         assert equal > least and declined < total // 8, out.stdout
 
 
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus N` run plainly must measure N GPUs or say why not (the flag was parsed and never read, so the plain command reported
+    n_gpus 1). --dry-launch prints the child command - torch.distributed.run on 127.0.0.1 with the same arguments; without enough devices the real launch refuses
+    with a non-zero exit code and no JSON line; under a launcher (WORLD_SIZE set) nothing is started."""
+    bench = os.path.join(ROOT, "bench.py")
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-launch", "--steps", "3", "--strong"], capture_output=True, text=True, timeout=300)
+    words = out.stdout.split()
+    assert out.returncode == 0 and "torch.distributed.run" in words and "--nproc-per-node=2" in words and "127.0.0.1" in words, out.stdout + out.stderr
+    assert words[-5:] == ["--gpus", "2", "--steps", "3", "--strong"] and "--dry-launch" not in words[words.index(bench):]
+    import torch
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and "refusing" in out.stderr and "n_gpus" not in out.stdout, out.stdout + out.stderr
+    env = dict(os.environ, WORLD_SIZE="2")
+    probe = "import sys, os; sys.path.insert(0, %r); sys.argv = ['bench.py', '--gpus', '2']; import bench; print(bench.launch_ranks(bench.parse_args(), sys.argv[1:]))" % ROOT
+    out = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, timeout=300, env=env)
+    assert out.stdout.strip() == "None", out.stdout + out.stderr
+
+
 def test_bench_inflight_rule_follows_the_cpu_budget():
     """bench.py's batches-in-flight rule: from the host CPU a batch costs and the batch period, not from a fixed ranks-to-CPUs ratio.
     r5 (0.24 CPU-s per batch, 146 ms per batch): eight ranks on a 16-CPU box keep five batches in flight each (1.6 CPUs of the 2 a rank has; r3's 0.41 CPU-s made them

@@ -103,13 +103,13 @@ def _build_multi_gpu_host(tmp_path):
         pytest.skip("no g++")
     exe = str(tmp_path / "multi_gpu_host")
     lib_dir = os.path.join(ROOT, "graphchainer_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "tests", "multigpu", "multi_gpu_host.cpp"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "examples", "multi_gpu_host.cpp"),
                            "-L" + lib_dir, "-lgraphchainer_amd", "-lpthread", "-Wl,-rpath," + lib_dir])
     return exe
 
 
 def test_single_process_multi_gpu_host_builds_and_refuses_to_run_without_a_gpu(tmp_path):
-    """tests/multigpu/multi_gpu_host.cpp (one process, a worker thread per stream, a replica of the graph per device, one atomic batch cursor) builds against
+    """examples/multi_gpu_host.cpp (one process, a worker thread per stream, a replica of the graph per device, one atomic batch cursor) builds against
     the C ABI alone; without a GPU it says so and stops (no CPU fallback). The GPU test runs it with two logical devices and compares with the oracle."""
     import subprocess
     import graphchainer_amd as gca
