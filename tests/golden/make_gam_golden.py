@@ -86,6 +86,48 @@ def revcomp(s):
     return s.translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1]
 
 
+def load_gfa_segments(filename):
+    """scripts/summary.py:19-33 restated (the S lines; its edge table is never read): segment sequences by node id. The harness keys VL by the S line's integer NAME and
+    looks it up by position.node_id, i.e. it expects a GFA whose names ARE the aligner's node ids; the aligner numbers segments in order of first appearance on an S or L
+    line (src/GfaGraph.cpp:164-173; numberBackToIntegers is commented out, :324-328) and the fixtures' GFAs count their names from 1, so the key here is that order of
+    appearance - what the S line's name would be in a GFA written the way the harness expects."""
+    ids = {}
+    VL = {}
+    for line in open(filename).readlines():
+        if line[0] == "S":
+            i, s = line[1:].strip().split()[:2]
+            VL[ids.setdefault(i, len(ids))] = s
+        elif line[0] == "L":
+            li, _, ri = line[1:].strip().split()[:3]
+            ids.setdefault(li, len(ids))
+            ids.setdefault(ri, len(ids))
+    return VL
+
+
+def parse_alignment(aln, VL):
+    """scripts/summary.py:77-91 restated: the alignment's path SPELLED through the GFA - every mapping's whole segment, reverse-complemented when
+    position.is_reverse - with the counts the reference's harness tabulates. (Its `revc` maps A, C, G, T only, as this does.)"""
+    revc = lambda s: "".join({"A": "T", "T": "A", "C": "G", "G": "C"}[c] for c in s[::-1])
+    name = aln.name.split()[0]
+    seq = ""
+    rev_cnt = 0
+    for x in aln.path.mapping:
+        ll = VL[x.position.node_id]
+        if x.position.is_reverse:
+            rev_cnt += 1
+            seq += revc(ll)
+        else:
+            seq += ll
+    return {"name": name, "seq": seq, "path_cnt": len(aln.path.mapping), "revcnt": rev_cnt, "path_bps": len(seq)}
+
+
+def aligned_part(aln, spelled):
+    """The letters of the spelled path the alignment covers: from the first mapping's offset, as many as its edits consume of the graph (from_length)."""
+    start = aln.path.mapping[0].position.offset
+    used = sum(e.from_length for m in aln.path.mapping for e in m.edit)
+    return spelled[start:start + used]
+
+
 def cases():
     from graphchainer_amd.synth import SynthGraph
     read = open(os.path.join(HERE, "ref_test_read.fa")).read().split("\n")[1].encode()
@@ -130,6 +172,31 @@ def main():
         for line, msg in zip(lines, flat):
             from_json = json_format.Parse(line, vg_pb2.Alignment())
             assert from_json == msg and from_json.SerializeToString() == msg.SerializeToString()
+        # the second harness row of SURVEY.md §8(c): every alignment's path spelled through the GFA as scripts/summary.py:77-91 does it. What the spelled path is held to:
+        # cut to the part the alignment covers, its NW edit distance to the read is the distance the pipeline reports (whole-read alignment: the first of the
+        # read's selection, src/Aligner.cpp:376-408; chained alignment: src/Aligner.cpp:845) - the alignment's CONTENT read back through the reference's own reader
+        VL = load_gfa_segments(gfa)
+        from oracle import Oracle as _O  # noqa: F401
+        from oracle.binding import load_oracle_lib
+        olib = load_oracle_lib()
+        spelled_doc = []
+        with_output = [r for r in range(len(reads)) if res["chained_better"][r] or res["read_long_off"][r + 1] > res["read_long_off"][r]]
+        assert len(with_output) == len(decoded), name
+        for r, group in zip(with_output, decoded):
+            rows = []
+            for k, aln in enumerate(group):
+                p = parse_alignment(aln, VL)
+                part = aligned_part(aln, p["seq"])
+                a, b = part.encode(), reads[r]
+                d = int(olib.gco_edit_distance(a, len(a), b, len(b)))
+                rows.append(dict(p, aligned_from=int(aln.path.mapping[0].position.offset), aligned_bps=len(part), nw_distance_to_read=d))
+            # (a chimeric read's group holds its alignments in output order; the reported distance is that of the selection's first, src/Aligner.cpp:376-408)
+            want = int(res["chain_edit_distance"][r]) if res["chained_better"][r] else int(res["long_edit_distance"][r])
+            assert want in [row["nw_distance_to_read"] for row in rows] and (len(rows) > 1 or rows[0]["nw_distance_to_read"] == want), (name, r, want, [row["nw_distance_to_read"] for row in rows])
+            spelled_doc.append({"read": r, "reported_distance": want, "alignments": rows})
+        with open(os.path.join(HERE, name + ".expected.paths.json"), "w") as f:
+            json.dump({"case": name, "what": "scripts/summary.py:77-91 over the reference-decoded GAM: per alignment the spelled path and its counts; nw_distance_to_read = NW edit distance of the part the alignment covers (aligned_from, aligned_bps) to the whole read", "reads": spelled_doc}, f, separators=(",", ":"), sort_keys=True)
+            f.write("\n")
         doc = {"case": name, "reads": len(reads), "chained_better": [int(x) for x in res["chained_better"]],
                "groups": [[json_format.MessageToDict(m, preserving_proto_field_name=True) for m in g] for g in decoded]}
         with open(os.path.join(HERE, name + ".expected.gam.json"), "w") as f:

@@ -1150,6 +1150,39 @@ def test_gam_against_the_reference_decoded_fixture(gca, case):
         assert members == len(want_groups), leg
 
 
+@pytest.mark.parametrize("case", ["ref_test", "syn20k", "syn20k_more"])
+def test_gam_paths_spelled_through_the_gfa_give_the_reported_distances(gca, case):
+    """r6: the product's GAM read back the way the reference's harness reads it (scripts/summary.py:77-91; tests/golden/make_gam_golden.py committed what the restated
+    reader saw through the reference's own descriptor): every alignment's path spelled through the GFA equals the fixture's, the NW edit distance (the product's own
+    gc_edit_distance) of the part the alignment covers to the read equals the fixture's, and the distance the result reports for the read is that of its first
+    selected / its chained alignment - output content, not schema."""
+    import gzip
+    from vg_descriptor import decode_gam_stream, golden_case, golden_paths, load_gfa_segments, spell_alignment
+    gfa, reads, _, _, _ = golden_case(case)
+    graph = gca.AlignmentGraph(gfa)
+    seeder = gca.MinimizerSeeder(graph)
+    names = [f"r{i}" for i in range(len(reads))]
+    out = gca.Aligner(graph, seeder, long_pass=True, device_output=1 | 4).align_reads(reads, gaf_names=names, formats=("gam",))
+    groups = decode_gam_stream(gzip.decompress(out["gam"]))
+    want = golden_paths(case)
+    VL = load_gfa_segments(gfa)
+    assert len(groups) == len(want)
+    parts, part_reads = [], []
+    for group, row in zip(groups, want):
+        assert len(group) == len(row["alignments"])
+        for aln, want_aln in zip(group, row["alignments"]):
+            got, part = spell_alignment(aln, VL)
+            assert got == {k: want_aln[k] for k in got}, (case, row["read"])
+            parts.append(part.encode())
+            part_reads.append(reads[row["read"]])
+    distances = [int(d) for d in gca.edit_distance(parts, part_reads)]
+    assert distances == [a["nw_distance_to_read"] for row in want for a in row["alignments"]]
+    for row in want:
+        r = row["read"]
+        reported = int(out["chain_edit_distance"][r]) if out["chained_better"][r] else int(out["long_edit_distance"][r])
+        assert reported == row["reported_distance"], (case, r)
+
+
 @pytest.mark.parametrize("env,kw,host_expected", [
     ({}, {}, "none"),
     ({"GC_STITCH_CLASS": "3"}, {}, "none"),          # r5: the long-read class (node set in HBM scratch behind an LDS filter) forced on short reads

@@ -541,6 +541,35 @@ def test_oracle_gam_equals_the_reference_decoded_fixture(case):
         assert any(m["position"].get("is_reverse") for g in want_groups for a in g for m in a["path"]["mapping"])
 
 
+@pytest.mark.parametrize("case", ["ref_test", "syn20k", "syn20k_more"])
+def test_oracle_paths_spelled_through_the_gfa_give_the_reported_distances(case):
+    """The CONTENT of the output read back the way the reference's own harness reads it (scripts/summary.py:77-91, restated next to the reference's descriptor in
+    tests/golden/make_gam_golden.py, which committed what it saw): every alignment's path spelled through the GFA by node_id / is_reverse equals the fixture's, and the
+    part of it the alignment covers has the NW edit distance to the read that the pipeline REPORTS (long_edit_distance of the selection's first alignment,
+    src/Aligner.cpp:376-408; chain_edit_distance of the chained one, :845) - the harness's global_ed_read_long / global_ed_read_clcs columns on the covered part."""
+    from vg_descriptor import decode_gam_stream, golden_case, golden_paths, load_gfa_segments, spell_alignment
+    from oracle.binding import load_oracle_lib
+    gfa, reads, _, _, want_better = golden_case(case)
+    ora = Oracle(gfa, long_pass=True)
+    res = ora.align(reads)
+    groups = decode_gam_stream(b"".join(ora.gam_groups()))
+    want = golden_paths(case)
+    VL = load_gfa_segments(gfa)
+    lib = load_oracle_lib()
+    assert len(groups) == len(want)
+    for group, row in zip(groups, want):
+        r = row["read"]
+        distances = []
+        for aln, want_aln in zip(group, row["alignments"]):
+            got, part = spell_alignment(aln, VL)
+            assert got == {k: want_aln[k] for k in got}, (case, r)
+            distances.append(int(lib.gco_edit_distance(part.encode(), len(part), reads[r], len(reads[r]))))
+        assert distances == [a["nw_distance_to_read"] for a in row["alignments"]]
+        reported = int(res["chain_edit_distance"][r]) if res["chained_better"][r] else int(res["long_edit_distance"][r])
+        assert reported == row["reported_distance"] and reported in distances and (len(distances) > 1 or distances[0] == reported)
+    assert sum(len(row["alignments"]) for row in want) >= len(want) >= 1
+
+
 # ---- the one DEFINED rule, measured (r5): flattenLastSliceEnd's tie order ---------------------------------------------------------------------
 
 def _tie_sensitivity(gfa, reads, **kw):

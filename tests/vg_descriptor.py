@@ -82,3 +82,42 @@ def golden_case(name):
         gfa = os.path.join(gold, "syn20k.gfa")
     assert len(reads) == doc["reads"]
     return gfa, reads, doc["groups"], open(os.path.join(gold, name + ".expected.gam"), "rb").read(), doc["chained_better"]
+
+
+# ---- the second harness row of SURVEY.md §8(c): an alignment's path spelled through the GFA, as the reference's scripts/summary.py:77-91 does it (restated in
+# tests/golden/make_gam_golden.py beside the reference's own descriptor; here over the decoded message dictionaries, for the boxes where the reference is absent)
+
+def load_gfa_segments(filename):
+    """Segment sequences by the aligner's node id = order of first appearance on an S or L line (src/GfaGraph.cpp:164-173): see make_gam_golden.py's load_gfa_segments."""
+    ids, VL = {}, {}
+    for line in open(filename):
+        if line[0] == "S":
+            i, s = line[1:].strip().split()[:2]
+            VL[ids.setdefault(i, len(ids))] = s
+        elif line[0] == "L":
+            li, _, ri = line[1:].strip().split()[:3]
+            ids.setdefault(li, len(ids))
+            ids.setdefault(ri, len(ids))
+    return VL
+
+
+def spell_alignment(aln, VL):
+    """summary.py's parse_alignment over MessageToDict(aln): whole segments in path order, reverse-complemented when position.is_reverse; plus the part the alignment covers."""
+    comp = {"A": "T", "T": "A", "C": "G", "G": "C"}
+    seq, rev_cnt = "", 0
+    mapping = aln["path"]["mapping"]
+    for x in mapping:
+        ll = VL[int(x["position"].get("node_id", 0))]
+        if x["position"].get("is_reverse"):
+            rev_cnt += 1
+            seq += "".join(comp[c] for c in ll[::-1])
+        else:
+            seq += ll
+    start = int(mapping[0]["position"].get("offset", 0))
+    used = sum(int(e.get("from_length", 0)) for m in mapping for e in m.get("edit", []))
+    return {"name": aln["name"].split()[0], "seq": seq, "path_cnt": len(mapping), "revcnt": rev_cnt, "path_bps": len(seq), "aligned_from": start, "aligned_bps": len(seq[start:start + used])}, seq[start:start + used]
+
+
+def golden_paths(name):
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return json.load(open(os.path.join(gold, name + ".expected.paths.json")))["reads"]
