@@ -75,7 +75,7 @@ def parse_args():
                          "(N=1; profiling runs of one gpurun call: a 960 Mbp graph costs five minutes to generate, build and save, 85 s to load)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("GC_BENCH_INFLIGHT", 5)),
                     help="batches in flight per GPU, each on its own gc_stream and host thread (like the reference's -t worker threads): one batch's seeding, fragment "
-                         "pipeline, distances and assembly run beside another's whole-read pass (r5, ms per 10 k x 10 kb batch: 1 -> 157, 2 -> 148, 3 -> 149, 4 -> 145, 5 -> 147, 6 -> 144; "
+                         "pipeline, distances and assembly run beside another's whole-read pass (r5, ms per 10 k x 10 kb batch: " + ", ".join(f"{k} -> {v:.0f}" for k, v in sorted(BATCH_MS_BY_INFLIGHT.items())) + "; "
                          "a batch in flight holds 19 GB of device memory, the whole-read scratch of 27 GB is shared per device)")
     args = ap.parse_args()
     # config 5 on one GPU (BASELINE configs[4] is the whole genome over eight): 24 chromosome graphs, 2 000 CLR-like 50 kb reads, --colinear-gap 50000
@@ -219,7 +219,9 @@ def main():
     gfa = os.path.join(tmp, "graph.gfa")
     strong = args.strong and world > 1
     # --setup-dir: GFA, reads and index cache kept between runs of the same workload (one rank; nothing of a run's RESULTS is kept)
-    setup_key = {"config": args.config, "chromosomes": args.chromosomes, "backbone": args.backbone, "reads": args.reads, "read_len": args.read_len, "sv_fraction": args.sv_fraction}
+    setup_key = {"config": args.config, "chromosomes": args.chromosomes, "backbone": args.backbone, "reads": args.reads, "read_len": args.read_len, "sv_fraction": args.sv_fraction,
+                 # (what the generators below are called with, and a version of this layout: a change of either must not find a stale graph, reads or index - ADVICE r5)
+                 "generator": "SynthGenome(seed=7, multi_allelic=0.1, nested=0.1, minus_links=0.3, repeats=4, repeat_len=3000) / SynthGraph(seed=7); setup format 2"}
     setup_reused = False
     if args.setup_dir and world == 1:
         os.makedirs(args.setup_dir, exist_ok=True)

@@ -82,7 +82,7 @@ struct BatchRun {
 	double tDev = 0;
 	uint32_t nWork = 0;
 	ExtResult* dResults = nullptr;
-	TraceCell* dTrace = nullptr;
+	PoolCell* dTrace = nullptr;
 	AnchorRec* dAnchors = nullptr;
 	uint32_t* dFragStatus = nullptr;
 	uint32_t* dFragExtended = nullptr;
@@ -120,7 +120,7 @@ struct BatchRun {
 	uint8_t* hAnchorDense = nullptr;                  // the dense arrays as they came down: nine 4-byte arrays, the 8-byte path offsets, the path words
 	uint64_t denseAnchors = 0, densePathWords = 0;
 	std::vector<ExtResult> extResults;
-	std::vector<TraceCell> tracePool;
+	std::vector<PoolCell> tracePool;
 	bool anchorTraces = false;
 	bool stitchNodesPending = false;
 	// stitchAndChainDistances()
@@ -720,27 +720,45 @@ struct BatchRun {
 		// (the plain-layout kernel below gets four times the room)
 		for (uint64_t r = 0; r < n; r++) if (hLongResults[r].status == 5 || hLongResults[r].status == 2 || forceAll) redo.push_back((uint32_t)r);
 		if (!redo.empty()) {
-			std::vector<LongJob> subJobs(redo.size());
-			for (size_t i = 0; i < redo.size(); i++) subJobs[i] = hJobs[redo[i]];
 			ExtendConfig fcfg = lcfg;
 			fcfg.maxItems = 4 * lcfg.maxItems; fcfg.maxTrace = 2 * lcfg.maxTrace; fcfg.maxPending = 4 * lcfg.maxPending;
 			uint64_t lslab = longSlabBytes(fcfg);
-			uint64_t lanes = (redo.size() + 63) / 64 * 64;
-			LongJob* dSubJobs = st->longJobsFallback.reserve<LongJob>(redo.size());
-			LongReadResult* dSubResults = st->longResultsFallback.reserve<LongReadResult>(redo.size());
-			uint8_t* dSlab = st->longScratchFallback.reserve<uint8_t>(lanes * lslab);
-			HIP_CHECK(hipMemcpyAsync(dSubJobs, subJobs.data(), redo.size() * sizeof(LongJob), hipMemcpyHostToDevice, ls));
-			launchLongPass(ls, G->dev, G->devTables, G->devIupac, fcfg, dSubJobs, (uint32_t)redo.size(), dLongSeeds, R->devBases, R->totalBases, (uint32_t)P->min_cluster_size, maxAlignments,
-				dSlab, lslab, dLongCells, dLongCursor, cellBudget, dLongAlns, dSubResults, dLongCursor + 8);
-			std::vector<LongReadResult> subResults(redo.size());
-			HIP_CHECK(hipMemcpyAsync(subResults.data(), dSubResults, redo.size() * sizeof(LongReadResult), hipMemcpyDeviceToHost, ls));
-			syncStream(ls);
-			for (size_t i = 0; i < redo.size(); i++) hLongResults[redo[i]] = subResults[i];
-			// the reruns append their cells to the pool the rounds have filled: when that did not fit (the pool is sized by use since r5), the reads are flagged (status 4) and
-			// the stream's next batch gets the room
-			bool shortOfCells = false;
-			for (size_t i = 0; i < redo.size() && !shortOfCells; i++) shortOfCells = subResults[i].status == 4;
-			if (shortOfCells && !cellPoolPinned) st->longCellsPerBase = std::min<uint64_t>(256, st->longCellsPerBase * 2);
+			// The reruns append their cells to the pool the rounds have filled, and the pool is sized by use: a rerun that finds it full answers status 4. The round loop's
+			// overflow runs the pass again (growLongCells); here the pool grows IN PLACE - a larger block, the cells already written copied over - and only the reads that were
+			// refused run again, in this batch (r5 flagged them and gave the room to the stream's next batch: a read's output depended on its stream's history - ADVICE r5)
+			std::vector<uint32_t> now = redo;
+			for (int attempt = 0; !now.empty(); attempt++) {
+				std::vector<LongJob> subJobs(now.size());
+				for (size_t i = 0; i < now.size(); i++) subJobs[i] = hJobs[now[i]];
+				uint64_t lanes = (now.size() + 63) / 64 * 64;
+				LongJob* dSubJobs = st->longJobsFallback.reserve<LongJob>(now.size());
+				LongReadResult* dSubResults = st->longResultsFallback.reserve<LongReadResult>(now.size());
+				uint8_t* dSlab = st->longScratchFallback.reserve<uint8_t>(lanes * lslab);
+				HIP_CHECK(hipMemcpyAsync(dSubJobs, subJobs.data(), now.size() * sizeof(LongJob), hipMemcpyHostToDevice, ls));
+				launchLongPass(ls, G->dev, G->devTables, G->devIupac, fcfg, dSubJobs, (uint32_t)now.size(), dLongSeeds, R->devBases, R->totalBases, (uint32_t)P->min_cluster_size, maxAlignments,
+					dSlab, lslab, dLongCells, dLongCursor, cellBudget, dLongAlns, dSubResults, dLongCursor + 8);
+				std::vector<LongReadResult> subResults(now.size());
+				HIP_CHECK(hipMemcpyAsync(subResults.data(), dSubResults, now.size() * sizeof(LongReadResult), hipMemcpyDeviceToHost, ls));
+				HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
+				syncStream(ls);
+				std::vector<uint32_t> refused;
+				for (size_t i = 0; i < now.size(); i++) { hLongResults[now[i]] = subResults[i]; if (subResults[i].status == 4) refused.push_back(now[i]); }
+				if (refused.empty() || cellPoolPinned || attempt >= 3) break;   // (a pinned pool flags the reads: the caller asked for that much and no more)
+				const uint64_t used = std::min<uint64_t>(hLongSmall[0], cellBudget), next = std::min<uint64_t>(256, st->longCellsPerBase * 2);
+				if (next == st->longCellsPerBase || cellBudgetFor(next) * sizeof(LongCell) > (64ull << 30)) break;
+				if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc mem] the plain-layout reruns of %zu reads found the merged-trace pool full: %llu -> %llu cells per read base, %.2f G cells kept\n", refused.size(), (unsigned long long)st->longCellsPerBase, (unsigned long long)next, used / 1e9);
+				DeviceBuffer larger;
+				LongCell* dLarger = larger.reserve<LongCell>(cellBudgetFor(next), true);
+				if (used) HIP_CHECK(hipMemcpyAsync(dLarger, dLongCells, used * sizeof(LongCell), hipMemcpyDeviceToDevice, ls));
+				const unsigned long long cursor = used;   // (the refused requests are given back: the reruns ask again)
+				HIP_CHECK(hipMemcpyAsync(dLongCursor, &cursor, sizeof(cursor), hipMemcpyHostToDevice, ls));
+				syncStream(ls);
+				std::swap(st->longCells.ptr, larger.ptr); std::swap(st->longCells.bytes, larger.bytes);
+				st->longCellsPerBase = next;
+				cellBudget = cellBudgetFor(next);
+				dLongCells = (LongCell*)st->longCells.ptr;
+				now.swap(refused);
+			}
 		}
 		if (n) HIP_CHECK(hipMemcpyAsync(hLongAlns, dLongAlns, n * maxAlignments * sizeof(LongAln), hipMemcpyDeviceToHost, ls));
 		HIP_CHECK(hipMemcpyAsync(hLongSmall, dLongCursor, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
@@ -914,17 +932,28 @@ struct BatchRun {
 							if (held) return;
 							const double tAsk = nowUs();
 							if (tokenMode == 1 && longGroups == 1) {
-								token.lock(g_longPassToken[device & 15], longTokenCount(n, st->batchesDone));
+								const int passesSideBySide = longTokenCount(n, st->batchesDone);
+								token.lock(g_longPassToken[device & 15], passesSideBySide, passesSideBySide == 1);   // (a pass that fills the chip: alone on the device)
 								if (token.slot > 0 && shareLongScratch) {   // the second token's scratch is only grown when the device has the room: otherwise this pass waits for the first token like any other
 									const DeviceBuffer& have = g_longScratch[device & 15].buffer[token.slot];
 									size_t freeBytes = 0, totalBytes = 0;
 									const uint64_t need = longScratchWords * sizeof(unsigned long long);
-									if (have.bytes < need && (hipMemGetInfo(&freeBytes, &totalBytes) != hipSuccess || freeBytes + have.bytes < need + need / 8 + (6ull << 30))) { token.unlock(); token.lock(g_longPassToken[device & 15], 1); }
+									if (have.bytes < need && (hipMemGetInfo(&freeBytes, &totalBytes) != hipSuccess || freeBytes + have.bytes < need + need / 8 + (6ull << 30))) { token.unlock(); token.lock(g_longPassToken[device & 15], 1, false); }
 								}
 							}
 							if (shareLongScratch && tokenMode == 1) {
 								if (!token.owns_lock()) throw std::runtime_error("internal: shared whole-read scratch without the token");
-								longScratchOfToken = g_longScratch[device & 15].buffer[token.slot].reserve<unsigned long long>(longScratchWords);
+								try {
+									longScratchOfToken = g_longScratch[device & 15].buffer[token.slot].reserve<unsigned long long>(longScratchWords);
+								} catch (const DeviceError&) {
+									// (the check above and this reservation are not one step: another stream may have taken the memory in between) - the second token's scratch does not
+									// fit after all: this pass takes its turn on the first token's instead of failing the batch
+									if (token.slot == 0) throw;
+									(void)hipGetLastError();
+									token.unlock();
+									token.lock(g_longPassToken[device & 15], 1, false);
+									longScratchOfToken = g_longScratch[device & 15].buffer[0].reserve<unsigned long long>(longScratchWords);
+								}
 							}
 							held = true;
 							if (getenv("GC_DEBUG_TIMES")) fprintf(stderr, "[gc token] stream %p pass began %.1f asked %.1f got %.1f (call began %.1f)\n", (void*)st, tTokenAsk / 1e3, tAsk / 1e3, nowUs() / 1e3, tCall / 1e3);
@@ -962,7 +991,7 @@ struct BatchRun {
 	{
 		double tLongStarted = nowUs();
 		double tWindows = tLongStarted, tReserved = tLongStarted;
-		if (!deviceGlue) {
+		if (!deviceGlue && !poolsSized) {   // (this stage may run twice - fragmentPoolsOverflowed - and the block below builds sums and arrays that the second run finds as they are: ADVICE r5)
 		pool.run(n, [&](size_t r, size_t) {
 			ReadGlue& gl = glue[r];
 			if (gl.seeds.empty()) return;
@@ -1027,10 +1056,10 @@ struct BatchRun {
 			traceWorst = traceBudget + traceBudget / 4 + (1u << 20);   // every slot's two extensions at full length + room for the extensions that only fit the retry launch's larger trace buffers
 			pathWorst = nSlots * 24 + 4096;
 			// by use (device glue; GC_POOLS_WORST_CASE=1 and the host glue path keep the worst case): what the stream's earlier batches needed per slot, with 15 % of slack; a
-			// stream's first batch starts from a low guess (28 trace cells and 4 path words per slot of the 103 and 24 the worst case reserves; config 5 at 960 Mbp uses 36 and 2) and
+			// stream's first batch starts from a low guess (36 trace cells - 8 bytes each since r6 - and 4 path words per slot of the 103 and 24 the worst case reserves) and
 			// runs its fragment pipeline again with what it asked for when that was short - in the warm-up batch, once per stream - so that the pools are never larger than a batch needs
 			const bool byUse = deviceGlue && !(getenv("GC_POOLS_WORST_CASE") && atoi(getenv("GC_POOLS_WORST_CASE")) == 1);
-			double traceGuess = 28.0, pathGuess = 4.0, slackCells = (double)(1u << 20), slackWords = 4096.0;
+			double traceGuess = 36.0, pathGuess = 4.0, slackCells = (double)(1u << 20), slackWords = 4096.0;
 			if (const char* env = getenv("GC_POOL_FIRST_GUESS")) { traceGuess = std::max(0.0, atof(env)); pathGuess = traceGuess / 8; slackCells = slackWords = 64; }   // test hook: a stream's first batch outgrows its pools
 			traceBudget = byUse ? std::min<uint64_t>(traceWorst, (uint64_t)((double)nSlots * (st->traceCellsPerSlot > 0 ? st->traceCellsPerSlot * 1.15 : traceGuess) + slackCells)) : traceWorst;
 			pathCapacity = byUse ? std::min<uint64_t>(pathWorst, (uint64_t)((double)nSlots * (st->pathWordsPerSlot > 0 ? st->pathWordsPerSlot * 1.15 : pathGuess) + slackWords)) : pathWorst;
@@ -1068,20 +1097,20 @@ struct BatchRun {
 		// r6: fragments of up to 65 bases (one slice per extension) go through the lockstep kernel (gc_extend_frag.hip); what it declines and every longer fragment through the
 		// plain-layout kernel on per-lane slabs. GC_EXTEND_SLAB=1: the plain-layout kernel for everything, as up to r5 (A/B)
 		const bool fragKernel = P->split_len <= 65 && !(getenv("GC_EXTEND_SLAB") && atoi(getenv("GC_EXTEND_SLAB")) == 1);
-		const uint32_t declinedLanes = 16384;   // the plain-layout kernel's grid over what the lockstep kernel declined (half a per cent of cfg2's extensions)
-		uint8_t* dScratch = st->scratch.reserve<uint8_t>((uint64_t)(fragKernel ? declinedLanes : lanes) * slabBytes);
+		uint8_t* dScratch = fragKernel ? nullptr : st->scratch.reserve<uint8_t>((uint64_t)lanes * slabBytes);
 		const uint32_t fragWaves = fragKernel ? extendFragWaves() : 0;
 		uint4* dFragItems = fragKernel ? st->fragItems.reserve<uint4>(extendFragScratchBytes(fragWaves) / sizeof(uint4)) : nullptr;
 		uint32_t* dFragRetry = fragKernel ? st->fragRetryList.reserve<uint32_t>(std::max<uint32_t>(1, nWork)) : nullptr;
 		unsigned long long* dFragClaims = st->fragClaims.reserve<unsigned long long>(16);   // ([8..15]: the profiling build's section cycles)   // per extension round: [2 k] the waves' claim cursor, [2 k + 1] the number of declined items
 		if (fragKernel) launchZeroWords(stream, dFragClaims, 16);
+		unsigned long long* hFragDeclined = st->hFragDeclined.reserve<unsigned long long>(1);
 		const FragReads fragReads { R->devMasks, R->devMaskOff, R->devMaskWords, R->devOffsets, R->totalBases };
 		if (st->poolsRerun && poolReruns == 0) {   // (the batch after a rerun: see DeviceBuffer::shrinkTo)
-			st->tracePool.shrinkTo(traceBudget * sizeof(TraceCell));
+			st->tracePool.shrinkTo(traceBudget * sizeof(PoolCell));
 			st->pathPool.shrinkTo(pathCapacity * sizeof(uint32_t));
 			st->poolsRerun = false;
 		}
-		dTrace = st->tracePool.reserve<TraceCell>(traceBudget, true);
+		dTrace = st->tracePool.reserve<PoolCell>(traceBudget, true);
 		if (!deviceGlue) dFrags = st->frags.reserve<Fragment>(nFrags);
 		FragSeed* dFragSeeds = st->fragSeeds.reserve<FragSeed>(nSlots);
 		dAnchors = st->anchors.reserve<AnchorRec>(nSlots);
@@ -1140,8 +1169,13 @@ struct BatchRun {
 				launchExtendFrag(stream, G->dev, G->devTables, cfg.bandwidth, dWork, nWork, fragReads, dResults, dFragItems, fragWaves, dTrace, dCursors + 1, traceBudget, dCounters, sel, claims, dFragRetry, claims + 1, dFragClaims + 8);
 				ExtSelection declined;
 				declined.mode = 2; declined.list = dFragRetry; declined.listCount = claims + 1;
-				launchExtend(stream, G->dev, G->devTables, G->devIupac, cfg, dWork, nWork, R->devBases, dResults, dScratch, slabBytes, dTrace, dCursors + 1, traceBudget, dCounters, EXT_OVERFLOW, declinedLanes, declined);
-				launchExtend(stream, G->dev, G->devTables, G->devIupac, big, dWork, nWork, R->devBases, dResults, dRetryScratch, extendSlabBytes(big), dTrace, dCursors + 1, traceBudget, dCounters, EXT_OVERFLOW, retryLanes, declined);
+				// What the kernel declined (233 of cfg2's 4.4 M extensions) goes to the plain-layout kernel on the large slabs - when there is anything: its count comes to the host
+				// first. A launch of that kernel with nothing to do still waits 2-7 ms for a SIMD to free a quarter of its registers beside the whole-read kernel's resident waves
+				// (`gpurun_out/r6_f`: 12 ms per batch for six near-empty launches), the round trip costs the batch a few tens of microseconds while the other batches' kernels run
+				HIP_CHECK(hipMemcpyAsync(hFragDeclined, claims + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+				syncStream(stream);
+				if (*hFragDeclined > 0)
+					launchExtend(stream, G->dev, G->devTables, G->devIupac, big, dWork, nWork, R->devBases, dResults, dRetryScratch, extendSlabBytes(big), dTrace, dCursors + 1, traceBudget, dCounters, EXT_OVERFLOW, retryLanes, declined);
 			} else {
 				launchExtend(stream, G->dev, G->devTables, G->devIupac, cfg, dWork, nWork, R->devBases, dResults, dScratch, slabBytes, dTrace, dCursors + 1, traceBudget, dCounters, 0, 4096, sel, extendChunkItems);
 				launchExtend(stream, G->dev, G->devTables, G->devIupac, big, dWork, nWork, R->devBases, dResults, dRetryScratch, extendSlabBytes(big), dTrace, dCursors + 1, traceBudget, dCounters, EXT_OVERFLOW, retryLanes, sel);
@@ -1288,7 +1322,7 @@ struct BatchRun {
 			extResults.resize(nWork);
 			tracePool.resize(traceUsed);
 			if (nWork) HIP_CHECK(hipMemcpyAsync(extResults.data(), dResults, (size_t)nWork * sizeof(ExtResult), hipMemcpyDeviceToHost, stream));
-			if (traceUsed) HIP_CHECK(hipMemcpyAsync(tracePool.data(), dTrace, traceUsed * sizeof(TraceCell), hipMemcpyDeviceToHost, stream));
+			if (traceUsed) HIP_CHECK(hipMemcpyAsync(tracePool.data(), dTrace, traceUsed * sizeof(PoolCell), hipMemcpyDeviceToHost, stream));
 		}
 		syncStream(stream);
 		res->host_us[3] = nowUs() - tDev;   // K3..K4 + their transfers, wall
@@ -1932,7 +1966,7 @@ struct BatchRun {
 					if (hasB) {
 						uint32_t use = hasF ? eb.traceLen - 1 : eb.traceLen;
 						for (uint32_t i = 0; i < use; i++) {
-							const TraceCell& c = tracePool[eb.traceOff + i];
+							const PoolCell& c = tracePool[eb.traceOff + i];
 							uint32_t off = c.offsetAndSwitch & 255u;
 							auto rev = hg.GetReversePosition(hg.nodeIDs[c.node], hg.nodeOffset[c.node] + off);
 							res->anchor_trace_node[traceAt] = rev.first;
@@ -1945,7 +1979,7 @@ struct BatchRun {
 					}
 					if (hasF) {
 						for (uint32_t i = ef.traceLen; i-- > 0;) {
-							const TraceCell& c = tracePool[ef.traceOff + i];
+							const PoolCell& c = tracePool[ef.traceOff + i];
 							uint32_t off = c.offsetAndSwitch & 255u;
 							res->anchor_trace_node[traceAt] = hg.nodeIDs[c.node];
 							res->anchor_trace_offset[traceAt] = (uint32_t)(hg.nodeOffset[c.node] + off);

@@ -811,8 +811,8 @@ void gc_stream_destroy(gc_stream* st)
 		std::lock_guard<std::mutex> count(g_longScratchCount);
 		SharedLongScratch& shared = g_longScratch[st->device & 15];
 		if (--shared.streams == 0) {   // the device's last stream: nobody can hold the token any more
-			TokenHold tokens[LONG_TOKENS_MAX];
-			for (int t = 0; t < LONG_TOKENS_MAX; t++) tokens[t].lock(g_longPassToken[st->device & 15], LONG_TOKENS_MAX);
+			TokenHold alone;
+			alone.lock(g_longPassToken[st->device & 15], 1, true);   // (every slot free and nobody beside: as a pass that fills the chip waits)
 			int current = 0;
 			if (hipGetDevice(&current) == hipSuccess) { (void)hipSetDevice(st->device); for (auto& b : shared.buffer) b.release(); (void)hipSetDevice(current); }
 		}

@@ -100,22 +100,33 @@ struct PassTokens {
 	std::mutex m;
 	std::condition_variable cv;
 	bool busy[LONG_TOKENS_MAX] = { false, false };
-	int acquire(int n)
+	bool exclusive = false;       // slot 0 is held by a pass that fills the chip: nobody beside it
+	int exclusiveWaiting = 0;     // such passes waiting (sharers let them go first: a stream of small batches must not starve a large one)
+	// n: the slots the pass may take (1 or 2). alone: the pass fills the chip and runs with NO other pass beside it (r5 decided the count per batch but a count of 1 only
+	// restricted the caller's choice of slot, so a large batch could run beside a small one holding slot 1 - ADVICE r5); a sharer never starts beside such a pass
+	int acquire(int n, bool alone)
 	{
 		std::unique_lock<std::mutex> l(m);
+		if (alone) {
+			exclusiveWaiting++;
+			cv.wait(l, [&]() { for (int s = 0; s < LONG_TOKENS_MAX; s++) if (busy[s]) return false; return true; });
+			exclusiveWaiting--;
+			busy[0] = true; exclusive = true;
+			return 0;
+		}
 		int slot = -1;
-		cv.wait(l, [&]() { for (int s = 0; s < n; s++) if (!busy[s]) { slot = s; return true; } return false; });
+		cv.wait(l, [&]() { if (exclusive || exclusiveWaiting > 0) return false; for (int s = 0; s < n; s++) if (!busy[s]) { slot = s; return true; } return false; });
 		busy[slot] = true;
 		return slot;
 	}
-	void release(int slot) { { std::lock_guard<std::mutex> l(m); busy[slot] = false; } cv.notify_all(); }
+	void release(int slot) { { std::lock_guard<std::mutex> l(m); busy[slot] = false; if (slot == 0) exclusive = false; } cv.notify_all(); }
 };
 inline PassTokens g_longPassToken[16];
 // what std::unique_lock was for the single token: released when the holder goes out of scope
 struct TokenHold {
 	PassTokens* tokens = nullptr;
 	int slot = -1;
-	void lock(PassTokens& t, int n) { tokens = &t; slot = t.acquire(n); }
+	void lock(PassTokens& t, int n, bool alone) { tokens = &t; slot = t.acquire(n, alone); }
 	bool owns_lock() const { return slot >= 0; }
 	void unlock() { if (slot >= 0) { tokens->release(slot); slot = -1; } }
 	~TokenHold() { unlock(); }
@@ -558,7 +569,7 @@ struct gc_stream {
 	hipEvent_t ev[12] {};
 	hipEvent_t fragEv[16] {};   // r5: a (begin, end) pair around each of the lazy rounds' k_extend launches [0..7] and k_build_anchors launches [8..15]: kernel_us[1] / [2] are sums of exactly those
 	DeviceBuffer tmp, matches, readMatchOff, readMatchCount, cursors, readSeeds, fragFirstSeed, longRetryList, extLists, fragItems, fragRetryList, fragClaims, pendingFrags, fragNext, roundCounts, work, results, scratch, scratchRetry, tracePool, frags, fragSeeds, anchors, fragStatus, fragExtended, readTies, pathPool, jobs, chainOut, chainLen, chainScore, chainStatus, chainScratch, counters;
-	PinnedBuffer hMatches, hReadSeeds, hFragFirstSeed, hFrags, hJobs, hAnchors, hFragStatus, hFragExtended, hReadTies, hChainOut, hChainLen, hChainScore, hChainStatus, hPathPool, hSmall;
+	PinnedBuffer hFragDeclined, hMatches, hReadSeeds, hFragFirstSeed, hFrags, hJobs, hAnchors, hFragStatus, hFragExtended, hReadTies, hChainOut, hChainLen, hChainScore, hChainStatus, hPathPool, hSmall;
 	// whole-read pass: runs on its own stream, concurrently with the fragment kernels
 	hipStream_t longStream = nullptr;
 	hipEvent_t longEv[2] {};

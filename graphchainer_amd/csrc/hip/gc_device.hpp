@@ -182,6 +182,15 @@ struct TraceCell {  // one cell of a backtrace, split-node coordinates
 	uint32_t offsetAndSwitch;   // offset in split node | nodeSwitch << 8
 };
 
+// A cell of the fragment pass's shared trace pool (r6): 8 bytes instead of the cores' 12-byte working format - the pool is the largest buffer of a batch in flight (18 GB of
+// 42 for 2 000 x 50 kb reads on a 960 Mbp graph), every cell is written once by an extension kernel and read by k_build_anchors. seqPos is a row of a fragment's extension:
+// -1 .. --colinear-split-len - 1 (gc_align_batch takes split lengths of 16 .. 64: one slice per fragment extension).
+struct PoolCell {
+	uint32_t node;
+	uint16_t offsetAndSwitch;   // offset in split node | nodeSwitch << 8
+	int16_t seqPos;
+};
+
 struct CorrectnessTables {   // reference: src/AlignmentCorrectnessEstimation.cpp:15-70, built on the host with libm
 	double correctOdds[64], wrongOdds[64];
 	double f2c, f2f, c2f, c2c;

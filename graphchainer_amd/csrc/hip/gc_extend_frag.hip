@@ -33,7 +33,7 @@ using namespace gcfrag;
 struct FragDevStore {
 	uint32_t* lds;       // this lane's column of the wave's LDS words: word w at lds[64 w]
 	uint4* items;        // this lane's column of the wave's item planes: item k = [3 k] start column, [3 k + 1] end column, [3 k + 2] { start score, node, end score, - }, each plane 64 lanes wide
-	TraceCell* pool;
+	PoolCell* pool;
 	__device__ __forceinline__ uint32_t ld(uint32_t w) const { return lds[64 * w]; }
 	__device__ __forceinline__ void st(uint32_t w, uint32_t v) const { lds[64 * w] = v; }
 	__device__ __forceinline__ void itemSetStart(uint32_t k, uint64_t VP, uint64_t VN, int32_t score, uint32_t node) const
@@ -57,7 +57,7 @@ struct FragDevStore {
 		return WS { (uint64_t)c.x | ((uint64_t)c.y << 32), (uint64_t)c.z | ((uint64_t)c.w << 32), (int32_t)((const uint32_t*)&items[64 * (3 * k + 2)])[2] };
 	}
 	__device__ __forceinline__ uint32_t itemNode(uint32_t k) const { return ((const uint32_t*)&items[64 * (3 * k + 2)])[1]; }
-	__device__ __forceinline__ void traceSet(uint64_t at, uint32_t node, int32_t seqPos, uint32_t offsetAndSwitch) const { pool[at] = TraceCell { node, seqPos, offsetAndSwitch }; }
+	__device__ __forceinline__ void traceSet(uint64_t at, uint32_t node, int32_t seqPos, uint32_t offsetAndSwitch) const { pool[at] = PoolCell { node, (uint16_t)offsetAndSwitch, (int16_t)seqPos }; }
 };
 
 uint64_t extendFragScratchBytes(uint32_t waves) { return (uint64_t)waves * FRAG_I * 3 * 64 * sizeof(uint4); }
@@ -65,7 +65,7 @@ uint64_t extendFragScratchBytes(uint32_t waves) { return (uint64_t)waves * FRAG_
 // 127 VGPRs or fewer: four waves per SIMD, which is also what the LDS words of four waves per SIMD leave room for
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_extend(DGraph g, const CorrectnessTables* __restrict__ ct, int32_t bandwidth,
 	const ExtItem* __restrict__ work, uint32_t nWork, const FragReads reads, ExtResult* __restrict__ results, uint4* __restrict__ itemScratch,
-	TraceCell* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, unsigned long long* __restrict__ counters, ExtSelection sel,
+	PoolCell* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, unsigned long long* __restrict__ counters, ExtSelection sel,
 	unsigned long long* __restrict__ claim, uint32_t* __restrict__ retryList, unsigned long long* __restrict__ retryCount, unsigned long long* __restrict__ stamps)
 {
 	__shared__ uint32_t ldsWords[FRAG_WORDS * 64];
@@ -237,7 +237,7 @@ uint32_t extendFragWaves()
 }
 
 void launchExtendFrag(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, int32_t bandwidth, const ExtItem* work, uint32_t nWork, const FragReads& reads, ExtResult* results,
-	uint4* itemScratch, uint32_t scratchWaves, TraceCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters, ExtSelection sel, unsigned long long* claim,
+	uint4* itemScratch, uint32_t scratchWaves, PoolCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters, ExtSelection sel, unsigned long long* claim,
 	uint32_t* retryList, unsigned long long* retryCount, unsigned long long* stamps)
 {
 	if (nWork == 0) return;

@@ -34,7 +34,7 @@ enum : uint32_t { TF_START = 1u, TF_WALK = 2u };   // Lane::tileFlags: the tile 
 #define GC_FRAG_QUEUE 6      // pending nodes of a slice per lane (LDS)
 #endif
 #ifndef GC_FRAG_ITEMS
-#define GC_FRAG_ITEMS 16     // tiles of a slice per lane (HBM, lane-interleaved)
+#define GC_FRAG_ITEMS 24     // tiles of a slice per lane (HBM, lane-interleaved; 0.4 % of cfg2's extensions hold 17-22, tests/frag_host)
 #endif
 // the walk keeps the last columns of its current tile in a ring of 32 words per lane: only the rows of the sequence matter to it, so an extension of up to 32 rows
 // keeps 16 columns of 2 x 32 bits and a longer one 8 columns of 2 x 64 bits (a refill recomputes the tile from its first column: 133 -> 80 recomputed columns per
@@ -416,14 +416,144 @@ __device__ inline bool fragCorner(const DGraph& g, const FragParams& P, const La
 	return false;   // the reference asserts here
 }
 
-// ---- PH_WALK: one turn of getReverseTraceFromTable's loop (...Common.h:392-544); leaves the phase for PH_COLS when the tile's columns have to be (re)computed
-// and for PH_FETCH when the trace is complete or the extension gives up
+// ---- PH_WALK: getReverseTraceFromTable's loop (...Common.h:392-544) from where the lane stands up to the next tile whose columns have to be (re)computed (PH_COLS) or to
+// the end of the trace (PH_FETCH). The reference's loop does ONE thing per turn, chosen by where it stands: recompute the tile it enters / a corner / a vertical crossing /
+// a horizontal crossing / steps inside the tile. Here the cases are laid out in the order a walk meets them - inside the tile, then the crossing at its edge, then the ramp
+// of row -1 or the next tile - and each is guarded by the loop's own condition, re-read where it stands: one call is several turns of that loop, and the lanes of a wave,
+// which come back from the column loop together, run each case's code once per call instead of once per turn (r6: 70 turns per 64 extensions -> 21, 33 % of the kernel's
+// wave-cycles in this handler before)
 template <class M>
 __device__ inline void fragWalkStep(const DGraph& g, const FragParams& P, Lane& L, M& m)
 {
 	const uint32_t NO_REFILL = 0xffffffffu;
-	if (L.hereSeqPos() == -1) {
-		// row -1: left along the initial ramp towards the seed's column (...Common.h:508-542; the in-neighbour hop needs a second node in the initial slice)
+	auto column = [&](uint32_t c) -> WS {
+		const uint64_t mask = (c >= 63 ? ~0ull : ((2ull << c) - 1)) & ~1ull;
+		return WS { m.ringVP(c, L.len > 32), m.ringVN(c, L.len > 32), L.colStart() + popc64(L.HP & mask) - popc64(L.HN & mask) };   // (a column of rows 0..len-1: the rows above hold zeros)
+	};
+	// the tile the walk stands in has its columns in the ring: the cases below may run
+	auto inTile = [&]() { return L.phase == PH_WALK && L.hereSeqPos() != -1 && L.hereNode() == L.node && L.refillTo() == NO_REFILL; };
+	auto moveTo = [&](const FragCell& c) { L.hereNode() = c.node; L.hereOffset() = c.offset; L.hereSeqPos() = c.seqPos; };
+	auto corner = [&]() {
+		FragCell nxt; bool sw;
+		if (!fragCorner(g, P, L, m, nxt, sw)) { fragRetire(L, EXT_ASSERT); return; }
+		if (!fragTracePush(L, m, nxt.node, nxt.offset, nxt.seqPos, sw)) return;
+		moveTo(nxt);
+	};
+	const int32_t quitScore = L.resultScore + P.bandwidth, previousQuitScore = 1;
+
+	// ---- inside the tile (pickBacktraceInside, ...Common.h:556-597): vertical, then diagonal, then horizontal
+	if (inTile() && L.hereSeqPos() > 0 && L.hereOffset() > 0) {
+		const uint32_t curNode = L.node;
+		uint32_t hori = L.hereOffset();
+		int vert = L.hereSeqPos();   // (the only slice starts at row 0)
+		while (hori > 0 && vert > 0) {
+			GC_LOOP_TICK(5);
+			if (hori - 1 < L.ringLo()) { L.refillTo() = hori; break; }
+			const WS colHere = column(hori), colLeft = column(hori - 1);
+			const int32_t scoreHere = wsValue(colHere, vert);
+			const int32_t vertical = wsValue(colHere, vert - 1);
+			const int32_t diagonal = wsValue(colLeft, vert - 1);
+			const int eqBit = (int)((eqOfColumn2(L.eq, L.w0, L.w1, hori) >> vert) & 1);
+			if (vertical == scoreHere - 1) { vert--; }
+			else if (diagonal == scoreHere - (eqBit ? 0 : 1)) { hori--; vert--; }
+			else {
+				if (wsValue(colLeft, vert) != scoreHere - 1) { fragRetire(L, EXT_ASSERT); break; }
+				hori--;
+			}
+			if (!fragTracePush(L, m, curNode, hori, vert, false)) break;
+		}
+		if (L.phase == PH_WALK) { L.hereOffset() = hori; L.hereSeqPos() = vert; }
+	}
+	// ---- first row, not the first column: vertical crossing into the initial slice (...Common.h:451-477, pickBacktraceVerticalCrossing :665-708)
+	if (inTile() && L.hereSeqPos() == 0 && L.hereOffset() > 0) {
+		const uint32_t curNode = L.node;
+		if (curNode != L.startNode) {
+			// the node is not in the initial slice: along the first row to the tile's first column (the corner below)
+			L.hereOffset() = 0;
+			fragTracePush(L, m, curNode, 0, 0, false);
+		} else {
+			uint32_t off = L.hereOffset();
+			while (off > 0) {
+				if (off - 1 < L.ringLo()) { L.refillTo() = off; break; }
+				if (wsValue(column(off - 1), 0) != wsValue(column(off), 0) - 1) break;
+				off--;
+				if (!fragTracePush(L, m, curNode, off, 0, false)) break;
+			}
+			if (L.phase == PH_WALK) L.hereOffset() = off;
+			if (L.phase == PH_WALK && L.refillTo() == NO_REFILL && off > 0) {
+				// the initial item: scores |column - startOffset|, i.e. deltas -1 up to the seed's column and +1 behind it
+				const uint64_t upToOffset = L.startOffset >= 63 ? ~0ull : ((1ull << (L.startOffset + 1)) - 1);
+				const uint64_t nodeMask = L.startLen >= 64 ? ~0ull : ((1ull << L.startLen) - 1);
+				const uint64_t pnHN = upToOffset & ~1ull, pnHP = nodeMask & ~upToOffset;
+				const int32_t scoreHere = wsValue(column(off), 0);
+				int32_t scoreDiagonal = (int32_t)L.startOffset;
+				const uint64_t lowMask = off >= 1 ? (((1ull << off) - 1) & ~1ull) : 0ull;
+				scoreDiagonal += popc64(pnHP & lowMask) - popc64(pnHN & lowMask);
+				const int32_t scoreUp = scoreDiagonal + (int32_t)((pnHP >> off) & 1) - (int32_t)((pnHN >> off) & 1);
+				FragCell nxt { curNode, off, -1 };
+				bool ok = true;
+				if (scoreHere > quitScore || scoreDiagonal > previousQuitScore || scoreUp > previousQuitScore) {
+					nxt = scoreDiagonal < scoreUp ? FragCell { curNode, off - 1, -1 } : FragCell { curNode, off, -1 };
+				} else {
+					const int eqBit = (int)(eqOfColumn2(L.eq, L.w0, L.w1, off) & 1);
+					if (scoreUp == scoreHere - 1) nxt = FragCell { curNode, off, -1 };
+					else if (scoreDiagonal == scoreHere - (eqBit ? 0 : 1)) nxt = FragCell { curNode, off - 1, -1 };
+					else { fragRetire(L, EXT_ASSERT); ok = false; }
+				}
+				if (ok && fragTracePush(L, m, nxt.node, nxt.offset, nxt.seqPos, false)) moveTo(nxt);
+			}
+		}
+	}
+	// ---- first column, not the first row: horizontal crossing into an in-neighbour (...Common.h:478-499, pickBacktraceHorizontalCrossing :599-663)
+	if (inTile() && L.hereSeqPos() > 0 && L.hereOffset() == 0) {
+		const uint32_t curNode = L.node;
+		const WS start = m.itemStart(L.curItem());
+		int32_t sp = L.hereSeqPos();
+		while ((sp & 63) != 0 && (start.VP & (1ull << (sp & 63)))) {
+			sp--;
+			if (!fragTracePush(L, m, curNode, 0, sp, false)) break;
+		}
+		if (L.phase == PH_WALK) {
+			L.hereSeqPos() = sp;
+			const int offset = sp & 63;
+			if (offset != 0) {   // (row 0: the corner below)
+				const int eqBit = (int)((eqOfColumn2(L.eq, L.w0, L.w1, 0) >> offset) & 1);
+				const int32_t scoreHere = wsValue(start, offset);
+				FragCell nxt { 0, 0, 0 };
+				bool sw = false, found = false;
+				if (scoreHere > quitScore) {
+					int32_t smallest = wsValue(start, offset - 1);
+					nxt = FragCell { curNode, 0, sp - 1 };
+					for (uint32_t e = 0; e < L.inDeg(); e++) {
+						const uint32_t nb = e == 0 ? L.n0 : e == 1 ? L.n1 : g.inAdj[L.inBegin() + e];
+						const int c = fragFindItem(L, m, nb);
+						if (c < 0) continue;
+						const WS ne = m.itemEnd((uint32_t)c);
+						const uint32_t nbLast = (uint32_t)g.nodeLength[nb] - 1;
+						if (wsValue(ne, offset - 1) <= smallest) { smallest = wsValue(ne, offset - 1); nxt = FragCell { nb, nbLast, sp - 1 }; sw = true; }
+						if (wsValue(ne, offset) < smallest && nb != curNode) { smallest = wsValue(ne, offset); nxt = FragCell { nb, nbLast, sp }; sw = true; }
+					}
+					found = true;
+				} else {
+					for (uint32_t e = 0; e < L.inDeg() && !found; e++) {
+						const uint32_t nb = e == 0 ? L.n0 : e == 1 ? L.n1 : g.inAdj[L.inBegin() + e];
+						const int c = fragFindItem(L, m, nb);
+						if (c < 0) continue;
+						const WS ne = m.itemEnd((uint32_t)c);
+						const uint32_t nbLast = (uint32_t)g.nodeLength[nb] - 1;
+						if (wsValue(ne, offset) == scoreHere - 1) { nxt = FragCell { nb, nbLast, sp }; sw = true; found = true; }
+						else if (wsValue(ne, offset - 1) == scoreHere - (eqBit ? 0 : 1)) { nxt = FragCell { nb, nbLast, sp - 1 }; sw = true; found = true; }
+					}
+				}
+				if (!found) fragRetire(L, EXT_ASSERT);
+				else if (fragTracePush(L, m, nxt.node, nxt.offset, nxt.seqPos, sw)) moveTo(nxt);
+			}
+		}
+	}
+	// ---- first row, first column: the corner (pickBacktraceCorner)
+	if (inTile() && L.hereSeqPos() == 0 && L.hereOffset() == 0) corner();
+	// ---- row -1: left along the initial ramp towards the seed's column (...Common.h:508-542; the in-neighbour hop needs a second node in the initial slice)
+	if (L.phase == PH_WALK && L.hereSeqPos() == -1) {
 		if (L.hereNode() != L.startNode) { fragRetire(L, EXT_ASSERT); return; }
 		uint32_t off = L.hereOffset();
 		while (true) {
@@ -436,6 +566,8 @@ __device__ inline void fragWalkStep(const DGraph& g, const FragParams& P, Lane& 
 		fragRetire(L, EXT_OK);
 		return;
 	}
+	// ---- the next tile, or more columns of this one: recalcNodeWordslice (...Common.h:828-852) into the ring, up to the column the walk stands on (it only moves left)
+	if (L.phase != PH_WALK) return;
 	const bool entering = L.hereNode() != L.node;
 	if (entering) {
 		const int item = fragFindItem(L, m, L.hereNode());
@@ -452,7 +584,6 @@ __device__ inline void fragWalkStep(const DGraph& g, const FragParams& P, Lane& 
 		L.n1 = L.inDeg() > 1 ? g.inAdj[r.inOff + 1] : 0u;
 	}
 	if (entering || L.refillTo() != NO_REFILL) {
-		// recalcNodeWordslice (...Common.h:828-852) into the ring: the columns up to the one the walk stands on (it only moves left)
 		const uint32_t upTo = entering ? L.hereOffset() : L.refillTo();
 		const WS start = m.itemStart(L.curItem());
 		const uint64_t rows = fragFlatMask(L.len);
@@ -464,138 +595,7 @@ __device__ inline void fragWalkStep(const DGraph& g, const FragParams& P, Lane& 
 		L.refillTo() = NO_REFILL;
 		L.pos = 1;
 		L.tileLen = upTo + 1 < L.nodeLen ? upTo + 1 : L.nodeLen;
-		if (L.tileLen > 1) { L.phase = PH_COLS; return; }
-	}
-	auto column = [&](uint32_t c) -> WS {
-		const uint64_t mask = (c >= 63 ? ~0ull : ((2ull << c) - 1)) & ~1ull;
-		return WS { m.ringVP(c, L.len > 32), m.ringVN(c, L.len > 32), L.colStart() + popc64(L.HP & mask) - popc64(L.HN & mask) };   // (a column of rows 0..len-1: the rows above hold zeros)
-	};
-	const uint32_t curNode = L.node;
-	const int row = L.hereSeqPos();   // (the only slice starts at row 0)
-	const int32_t quitScore = L.resultScore + P.bandwidth, previousQuitScore = 1;
-	if (row == 0 && L.hereOffset() == 0) {
-		FragCell nxt; bool sw;
-		if (!fragCorner(g, P, L, m, nxt, sw)) { fragRetire(L, EXT_ASSERT); return; }
-		if (!fragTracePush(L, m, nxt.node, nxt.offset, nxt.seqPos, sw)) return;
-		L.hereNode() = nxt.node; L.hereOffset() = nxt.offset; L.hereSeqPos() = nxt.seqPos;
-		return;
-	}
-	if (row == 0) {
-		// vertical crossing into the initial slice (...Common.h:451-477, pickBacktraceVerticalCrossing :665-708)
-		if (curNode != L.startNode) {
-			L.hereOffset() = 0;
-			fragTracePush(L, m, curNode, 0, L.hereSeqPos(), false);
-			return;
-		}
-		uint32_t off = L.hereOffset();
-		while (off > 0) {
-			if (off - 1 < L.ringLo()) { L.refillTo() = off; break; }
-			if (wsValue(column(off - 1), 0) != wsValue(column(off), 0) - 1) break;
-			off--;
-			if (!fragTracePush(L, m, curNode, off, L.hereSeqPos(), false)) return;
-		}
-		L.hereOffset() = off;
-		if (L.refillTo() != NO_REFILL) return;
-		if (off == 0) {
-			FragCell nxt; bool sw;
-			if (!fragCorner(g, P, L, m, nxt, sw)) { fragRetire(L, EXT_ASSERT); return; }
-			if (!fragTracePush(L, m, nxt.node, nxt.offset, nxt.seqPos, sw)) return;
-			L.hereNode() = nxt.node; L.hereOffset() = nxt.offset; L.hereSeqPos() = nxt.seqPos;
-			return;
-		}
-		// the initial item: scores |column - startOffset|, i.e. deltas -1 up to the seed's column and +1 behind it
-		const uint64_t upToOffset = L.startOffset >= 63 ? ~0ull : ((1ull << (L.startOffset + 1)) - 1);
-		const uint64_t nodeMask = L.startLen >= 64 ? ~0ull : ((1ull << L.startLen) - 1);
-		const uint64_t pnHN = upToOffset & ~1ull, pnHP = nodeMask & ~upToOffset;
-		const int32_t scoreHere = wsValue(column(off), 0);
-		int32_t scoreDiagonal = (int32_t)L.startOffset;
-		const uint64_t lowMask = off >= 1 ? (((1ull << off) - 1) & ~1ull) : 0ull;
-		scoreDiagonal += popc64(pnHP & lowMask) - popc64(pnHN & lowMask);
-		const int32_t scoreUp = scoreDiagonal + (int32_t)((pnHP >> off) & 1) - (int32_t)((pnHN >> off) & 1);
-		FragCell nxt;
-		if (scoreHere > quitScore || scoreDiagonal > previousQuitScore || scoreUp > previousQuitScore) {
-			nxt = scoreDiagonal < scoreUp ? FragCell { curNode, off - 1, L.hereSeqPos() - 1 } : FragCell { curNode, off, L.hereSeqPos() - 1 };
-		} else {
-			const int eqBit = (int)(eqOfColumn2(L.eq, L.w0, L.w1, off) & 1);
-			if (scoreUp == scoreHere - 1) nxt = FragCell { curNode, off, L.hereSeqPos() - 1 };
-			else if (scoreDiagonal == scoreHere - (eqBit ? 0 : 1)) nxt = FragCell { curNode, off - 1, L.hereSeqPos() - 1 };
-			else { fragRetire(L, EXT_ASSERT); return; }
-		}
-		if (!fragTracePush(L, m, nxt.node, nxt.offset, nxt.seqPos, false)) return;
-		L.hereNode() = nxt.node; L.hereOffset() = nxt.offset; L.hereSeqPos() = nxt.seqPos;
-		return;
-	}
-	if (L.hereOffset() == 0) {
-		// horizontal crossing into an in-neighbour (...Common.h:478-499, pickBacktraceHorizontalCrossing :599-663)
-		const WS start = m.itemStart(L.curItem());
-		int32_t sp = L.hereSeqPos();
-		while ((sp & 63) != 0 && (start.VP & (1ull << (sp & 63)))) {
-			sp--;
-			if (!fragTracePush(L, m, curNode, 0, sp, false)) return;
-		}
-		L.hereSeqPos() = sp;
-		const int offset = sp & 63;
-		if (offset == 0) {
-			FragCell nxt; bool sw;
-			if (!fragCorner(g, P, L, m, nxt, sw)) { fragRetire(L, EXT_ASSERT); return; }
-			if (!fragTracePush(L, m, nxt.node, nxt.offset, nxt.seqPos, sw)) return;
-			L.hereNode() = nxt.node; L.hereOffset() = nxt.offset; L.hereSeqPos() = nxt.seqPos;
-			return;
-		}
-		const int eqBit = (int)((eqOfColumn2(L.eq, L.w0, L.w1, 0) >> offset) & 1);
-		const int32_t scoreHere = wsValue(start, offset);
-		FragCell nxt { 0, 0, 0 };
-		bool sw = false, found = false;
-		if (scoreHere > quitScore) {
-			int32_t smallest = wsValue(start, offset - 1);
-			nxt = FragCell { curNode, 0, sp - 1 };
-			for (uint32_t e = 0; e < L.inDeg(); e++) {
-				const uint32_t nb = e == 0 ? L.n0 : e == 1 ? L.n1 : g.inAdj[L.inBegin() + e];
-				const int c = fragFindItem(L, m, nb);
-				if (c < 0) continue;
-				const WS ne = m.itemEnd((uint32_t)c);
-				const uint32_t nbLast = (uint32_t)g.nodeLength[nb] - 1;
-				if (wsValue(ne, offset - 1) <= smallest) { smallest = wsValue(ne, offset - 1); nxt = FragCell { nb, nbLast, sp - 1 }; sw = true; }
-				if (wsValue(ne, offset) < smallest && nb != curNode) { smallest = wsValue(ne, offset); nxt = FragCell { nb, nbLast, sp }; sw = true; }
-			}
-			found = true;
-		} else {
-			for (uint32_t e = 0; e < L.inDeg() && !found; e++) {
-				const uint32_t nb = e == 0 ? L.n0 : e == 1 ? L.n1 : g.inAdj[L.inBegin() + e];
-				const int c = fragFindItem(L, m, nb);
-				if (c < 0) continue;
-				const WS ne = m.itemEnd((uint32_t)c);
-				const uint32_t nbLast = (uint32_t)g.nodeLength[nb] - 1;
-				if (wsValue(ne, offset) == scoreHere - 1) { nxt = FragCell { nb, nbLast, sp }; sw = true; found = true; }
-				else if (wsValue(ne, offset - 1) == scoreHere - (eqBit ? 0 : 1)) { nxt = FragCell { nb, nbLast, sp - 1 }; sw = true; found = true; }
-			}
-		}
-		if (!found) { fragRetire(L, EXT_ASSERT); return; }
-		if (!fragTracePush(L, m, nxt.node, nxt.offset, nxt.seqPos, sw)) return;
-		L.hereNode() = nxt.node; L.hereOffset() = nxt.offset; L.hereSeqPos() = nxt.seqPos;
-		return;
-	}
-	// inside the tile (pickBacktraceInside, ...Common.h:556-597): vertical, then diagonal, then horizontal
-	{
-		uint32_t hori = L.hereOffset();
-		int vert = row;
-		while (hori > 0 && vert > 0) {
-			GC_LOOP_TICK(5);
-			if (hori - 1 < L.ringLo()) { L.refillTo() = hori; break; }
-			const WS colHere = column(hori), colLeft = column(hori - 1);
-			const int32_t scoreHere = wsValue(colHere, vert);
-			const int32_t vertical = wsValue(colHere, vert - 1);
-			const int32_t diagonal = wsValue(colLeft, vert - 1);
-			const int eqBit = (int)((eqOfColumn2(L.eq, L.w0, L.w1, hori) >> vert) & 1);
-			if (vertical == scoreHere - 1) { vert--; }
-			else if (diagonal == scoreHere - (eqBit ? 0 : 1)) { hori--; vert--; }
-			else {
-				if (wsValue(colLeft, vert) != scoreHere - 1) { fragRetire(L, EXT_ASSERT); return; }
-				hori--;
-			}
-			if (!fragTracePush(L, m, curNode, hori, vert, false)) return;
-		}
-		L.hereOffset() = hori; L.hereSeqPos() = vert;
+		if (L.tileLen > 1) L.phase = PH_COLS;
 	}
 }
 

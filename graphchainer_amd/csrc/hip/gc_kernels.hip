@@ -157,10 +157,8 @@ __device__ __forceinline__ LaneScratch laneScratch(uint8_t* slab, const ExtendCo
 #endif
 // 4 waves per SIMD (<= 128 VGPRs; the kernel wanted 131 and ran 3): it waits on memory 56 % of the time, so the extra wave
 // pays for the 4 spilled registers: 34.2 -> 29.0 ms alone on cfg2 (5 or 6 waves spill 57 / 196 registers and lose).
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_extend_slab(DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg,
-	const ExtItem* __restrict__ work, uint32_t nWork, const char* __restrict__ bases, ExtResult* __restrict__ results,
-	uint8_t* __restrict__ scratch, uint64_t slabBytes, TraceCell* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity,
-	unsigned long long* __restrict__ counters, uint32_t retryStatus, ExtSelection sel, uint32_t chunkBegin, uint32_t chunkItems)
+#define GC_EXTEND_SLAB_PARAMS DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg, 	const ExtItem* __restrict__ work, uint32_t nWork, const char* __restrict__ bases, ExtResult* __restrict__ results, 	uint8_t* __restrict__ scratch, uint64_t slabBytes, PoolCell* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, 	unsigned long long* __restrict__ counters, uint32_t retryStatus, ExtSelection sel, uint32_t chunkBegin, uint32_t chunkItems
+__device__ __forceinline__ void extendSlabBody(GC_EXTEND_SLAB_PARAMS)
 {
 #if defined(GC_EXTEND_PRIO) && GC_EXTEND_PRIO
 	__builtin_amdgcn_s_setprio(GC_EXTEND_PRIO);   // (experiment, -DGC_EXTEND_PRIO=3: the fragment extension's waves ahead of the whole-read kernel's - 149.9 / 149.2 / 152.3 ms per batch against 154.0 / 147.2 / 151.6, `gpurun_out/r4_extprio`: no effect, off)
@@ -196,7 +194,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 		if (status == EXT_OK) {
 			unsigned long long base = atomicAdd(traceCursor, (unsigned long long)nTrace);
 			if (base + nTrace <= traceCapacity) {
-				for (uint32_t i = 0; i < nTrace; i++) tracePool[base + i] = sc.trace[i];
+				for (uint32_t i = 0; i < nTrace; i++) { const TraceCell c = sc.trace[i]; tracePool[base + i] = PoolCell { c.node, (uint16_t)c.offsetAndSwitch, (int16_t)c.seqPos }; }
 				res.traceOff = base;
 				res.traceLen = nTrace;
 			} else {
@@ -216,6 +214,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 	}
 }
 
+// 4 waves per SIMD (<= 128 VGPRs): everything, when the lockstep kernel is switched off (GC_EXTEND_SLAB=1)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_extend_slab(GC_EXTEND_SLAB_PARAMS)
+{
+	extendSlabBody(g, ct, iupac, cfg, work, nWork, bases, results, scratch, slabBytes, tracePool, traceCursor, traceCapacity, counters, retryStatus, sel, chunkBegin, chunkItems);
+}
 // =====================================================================================================
 // K3b - fragment post-pass: merges the two one-way traces of every seed, replays the reference's serial
 // "seed already lies on an earlier alignment" filter inside each fragment, and emits anchors.
@@ -226,8 +229,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 __device__ __forceinline__ void twinOf(const DGraph& g, uint32_t node, uint32_t offset, uint32_t& twinNode, uint32_t& twinOffset);
 
 struct MergedView {   // virtual view of a seed's merged trace (backward cells, then forward cells) in forward-strand split coords
-	const TraceCell* bw; uint32_t nBw;   // backward device trace without its final row -1 cell (nBw cells used)
-	const TraceCell* fw; uint32_t nFw;   // forward device trace (used in reverse order)
+	const PoolCell* bw; uint32_t nBw;   // backward device trace without its final row -1 cell (nBw cells used)
+	const PoolCell* fw; uint32_t nFw;   // forward device trace (used in reverse order)
 	int32_t p;                            // seed position inside the fragment
 	__device__ uint32_t size() const { return nBw + nFw; }
 };
@@ -236,7 +239,7 @@ struct MergedView {   // virtual view of a seed's merged trace (backward cells, 
 __device__ inline void mergedCell(const DGraph& g, const MergedView& v, uint32_t i, uint32_t& node, uint32_t& offset, int32_t& seqPos)
 {
 	if (i < v.nBw) {
-		const TraceCell& c = v.bw[i];
+		const PoolCell& c = v.bw[i];
 		// backward rows count away from the seed: row b -> fragment position p-1-b (fixReverseTraceSeqPosAndOrder, :543-565)
 		seqPos = v.p - 1 - c.seqPos;
 		// reverse-strand twin of the cell (GetReversePosition + GetUnitigNode)
@@ -248,7 +251,7 @@ __device__ inline void mergedCell(const DGraph& g, const MergedView& v, uint32_t
 		node = twin;
 		offset = rev - g.nodeOffset[twin];
 	} else {
-		const TraceCell& c = v.fw[v.nFw - 1 - (i - v.nBw)];
+		const PoolCell& c = v.fw[v.nFw - 1 - (i - v.nBw)];
 		seqPos = v.p + 1 + c.seqPos;   // row -1 -> p
 		node = c.node;
 		offset = c.offsetAndSwitch & 255u;
@@ -256,7 +259,7 @@ __device__ inline void mergedCell(const DGraph& g, const MergedView& v, uint32_t
 }
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) k_build_anchors(DGraph g, const Fragment* __restrict__ frags, uint32_t nFrags, const FragSeed* __restrict__ seeds,
-	const ExtResult* __restrict__ ext, const TraceCell* __restrict__ tracePool, int32_t splitLen,
+	const ExtResult* __restrict__ ext, const PoolCell* __restrict__ tracePool, int32_t splitLen,
 	AnchorRec* __restrict__ anchors, uint32_t* __restrict__ fragStatus, uint32_t* __restrict__ fragExtended,
 	uint32_t* __restrict__ pathPool, unsigned long long* __restrict__ pathCursor, uint64_t pathCapacity, AnchorRounds rounds, uint32_t* __restrict__ readTies)
 {
@@ -309,7 +312,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8)))
 				uint32_t lo = 0, hi = v.nBw;      // first cell with seqPos <= row
 				while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (v.bw[mid].seqPos > row) lo = mid + 1; else hi = mid; }
 				for (uint32_t i = lo; i < v.nBw && !skip; i++) {
-					const TraceCell c = v.bw[i];
+					const PoolCell c = v.bw[i];
 					if (c.seqPos != row) break;
 					if (c.node == twinNode && (c.offsetAndSwitch & 255u) == twinOffset) skip = true;
 				}
@@ -319,7 +322,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8)))
 				uint32_t lo = 0, hi = v.nFw;
 				while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (v.fw[mid].seqPos > row) lo = mid + 1; else hi = mid; }
 				for (uint32_t i = lo; i < v.nFw && !skip; i++) {
-					const TraceCell c = v.fw[i];
+					const PoolCell c = v.fw[i];
 					if (c.seqPos != row) break;
 					if (c.node == sd.node && (c.offsetAndSwitch & 255u) == sd.offset) skip = true;
 				}
@@ -380,7 +383,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8)))
 		{
 			uint32_t cachedNode = 0xffffffffu, nodeOff = 0, origSz = 0, lookupBase = 0, cachedBlock = 0xffffffffu, twin = 0, twinBase = 0;
 			for (uint32_t i0 = 0; i0 < v.nBw; i0 += 8) {
-				TraceCell c[8];
+				PoolCell c[8];
 #pragma unroll
 				for (uint32_t u = 0; u < 8; u++) c[u] = v.bw[min(i0 + u, v.nBw - 1)];
 #pragma unroll
@@ -398,7 +401,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8)))
 				}
 			}
 			for (uint32_t i0 = 0; i0 < v.nFw; i0 += 8) {   // the forward trace runs towards the seed: used back to front
-				TraceCell c[8];
+				PoolCell c[8];
 #pragma unroll
 				for (uint32_t u = 0; u < 8; u++) c[u] = v.fw[v.nFw - 1 - min(i0 + u, v.nFw - 1)];
 #pragma unroll
@@ -1507,7 +1510,7 @@ uint32_t extendGridLanes(uint32_t nWork)
 
 void launchExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg,
 	const ExtItem* work, uint32_t nWork, const char* bases, ExtResult* results, uint8_t* scratch, uint64_t slabBytes,
-	TraceCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters, uint32_t retryStatus, uint32_t retryLanes, ExtSelection sel, uint32_t chunkItems)
+	PoolCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters, uint32_t retryStatus, uint32_t retryLanes, ExtSelection sel, uint32_t chunkItems)
 {
 	if (nWork == 0) return;
 	const uint32_t upper = sel.mode == 1 ? 2 * sel.nFrags : nWork;   // (a device-side list holds at most nWork items; waves beyond its count leave at once)
@@ -1523,7 +1526,7 @@ void launchExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* 
 }
 
 void launchBuildAnchors(hipStream_t stream, const DGraph& g, const Fragment* frags, uint32_t nFrags, const FragSeed* seeds, const ExtResult* ext,
-	const TraceCell* tracePool, int32_t splitLen, AnchorRec* anchors, uint32_t* fragStatus, uint32_t* fragExtended,
+	const PoolCell* tracePool, int32_t splitLen, AnchorRec* anchors, uint32_t* fragStatus, uint32_t* fragExtended,
 	uint32_t* pathPool, unsigned long long* pathCursor, uint64_t pathCapacity, AnchorRounds rounds, uint32_t* readTies)
 {
 	if (nFrags == 0) return;

@@ -177,18 +177,18 @@ struct FragReads { const uint64_t* masks; const uint64_t* maskOff; const uint32_
 uint32_t extendFragWaves();                        // resident waves of the kernel on this device: the grid, and the size of its item scratch
 uint64_t extendFragScratchBytes(uint32_t waves);
 void launchExtendFrag(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, int32_t bandwidth, const ExtItem* work, uint32_t nWork, const FragReads& reads, ExtResult* results,
-	uint4* itemScratch, uint32_t scratchWaves, TraceCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters, ExtSelection sel, unsigned long long* claim,
+	uint4* itemScratch, uint32_t scratchWaves, PoolCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters, ExtSelection sel, unsigned long long* claim,
 	uint32_t* retryList, unsigned long long* retryCount, unsigned long long* stamps = nullptr);   // (stamps: eight words of the profiling build, -DGC_FRAG_STAMPS) claim, retryCount: zeroed words of this launch's own; retryList [nWork]: the declined items, for launchExtend with a list selection
 void launchBuildNodeRecs(hipStream_t stream, const DGraph& g, NodeRec* out);   // DGraph::nodeRec from the arrays already uploaded
 uint64_t extendSlabBytes(const ExtendConfig& cfg);
 uint32_t extendGridLanes(uint32_t nWork);
 void launchExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg,
 	const ExtItem* work, uint32_t nWork, const char* bases, ExtResult* results, uint8_t* scratch, uint64_t slabBytes,
-	TraceCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters,
+	PoolCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters,
 	uint32_t retryStatus = 0, uint32_t retryLanes = 4096, ExtSelection sel = ExtSelection(), uint32_t chunkItems = 0);   // retryStatus != 0: a small grid of `retryLanes` lanes reruns only the items whose result has that status (with the larger slabs of `cfg`)
 
 void launchBuildAnchors(hipStream_t stream, const DGraph& g, const Fragment* frags, uint32_t nFrags, const FragSeed* seeds, const ExtResult* ext,
-	const TraceCell* tracePool, int32_t splitLen, AnchorRec* anchors, uint32_t* fragStatus, uint32_t* fragExtended,
+	const PoolCell* tracePool, int32_t splitLen, AnchorRec* anchors, uint32_t* fragStatus, uint32_t* fragExtended,
 	uint32_t* pathPool, unsigned long long* pathCursor, uint64_t pathCapacity, AnchorRounds rounds = AnchorRounds(), uint32_t* readTies = nullptr);   // readTies [reads], zeroed by the caller: += the ExtResult::pad flags of the extensions the reference would have run
 
 // gc_results.hip (r5): the result's dense anchor arrays made on the device. perRead[r] = (anchors kept, path words, seeds extended, bit 0 a fragment failed | bit 1 capacity),

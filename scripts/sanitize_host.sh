@@ -33,11 +33,20 @@ ASAN_OPTIONS=detect_leaks=0 $work/hashorder_asan
 g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I$root/graphchainer_amd/csrc/hip $root/tests/stdsort/stdsort_test.cpp -o $work/stdsort_asan
 ASAN_OPTIONS=detect_leaks=0 $work/stdsort_asan
 # r5: the whole product library's host side (hipcc, -fno-gpu-sanitize) behind ctypes: the non-GPU tests that load it - both graph builders, the index cache and its mutated files, the ABI tests
-make -C $root/graphchainer_amd/csrc variant NAME=asan FLAGS="-fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer -g -shared-libsan" > /dev/null
+make -C $root/graphchainer_amd/csrc variant NAME=asan FLAGS="-fsanitize=address,undefined -fsanitize-recover=address -fno-gpu-sanitize -fno-omit-frame-pointer -g -shared-libsan" > /dev/null
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+set +e
 (cd $root && ASAN_OPTIONS=detect_leaks=0:halt_on_error=0:verify_asan_link_order=0 UBSAN_OPTIONS=print_stacktrace=1 LD_PRELOAD=$RT GC_LIBRARY=$root/graphchainer_amd/libgraphchainer_amd_asan.so \
-  python3 -m pytest tests/test_index_cache.py tests/test_graph_build.py tests/test_library_exports.py tests/test_host_logic.py -q -s -m "not gpu" > $work/library_asan.log 2>&1 || true)
+  python3 -m pytest tests/test_index_cache.py tests/test_graph_build.py tests/test_library_exports.py tests/test_host_logic.py -q -s -m "not gpu" > $work/library_asan.log 2>&1)
+library_rc=$?     # (set -e is off for this one command: its exit code and its report count decide below - ADVICE r5: "|| true" and an unconditional "clean" hid both)
+set -e
 tail -1 $work/library_asan.log
-echo "sanitizer reports in the library run: $(grep -c 'runtime error\|AddressSanitizer' $work/library_asan.log)"
+reports=$(grep -c 'runtime error\|AddressSanitizer' $work/library_asan.log || true)
+echo "sanitizer reports in the library run: $reports (pytest exit code $library_rc)"
 rm -f $root/graphchainer_amd/libgraphchainer_amd_asan.so
+if [ "$library_rc" -ne 0 ] || [ "$reports" -ne 0 ]; then
+  echo "sanitizers: FAILED - see $work/library_asan.log"
+  grep -n 'runtime error\|AddressSanitizer' $work/library_asan.log | head -20
+  exit 1
+fi
 echo "sanitizers: clean"
