@@ -43,6 +43,8 @@ BYTES_PER_TRACE_ITEM = 32
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--distinct-batches", type=int, default=None, help="read sets the timed steps cycle through (config 2: 4 - step s aligns set s mod 4, every set drawn with its own seed and checked "
+                    "against the oracle's rows for its first reads; 1: every step re-aligns the same reads, as up to r5, whose graph lines then stay warm in L2 / Infinity Cache from step to step)")
     ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 without WORLD_SIZE: print the command that would start the N ranks, and stop")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
@@ -64,7 +66,7 @@ def parse_args():
     ap.add_argument("--e2e-steps", type=int, default=int(os.environ.get("GC_BENCH_E2E_STEPS", 16)),
                     help="after the timed steps (N=1): this many steps with the read upload (gc_reads_upload) and the GAF encoding of every batch inside the step "
                          "(the whole boundary: host bases in, GAF text out); 0 skips it")
-    ap.add_argument("--e2e-formats", default=os.environ.get("GC_BENCH_E2E_FORMATS", "gaf,gam"), help="end-to-end legs to run: gaf, gam (comma separated)")
+    ap.add_argument("--e2e-formats", default=os.environ.get("GC_BENCH_E2E_FORMATS", "gaf,gam,json"), help="end-to-end legs to run: gaf, gam, json (comma separated)")
     ap.add_argument("--sv-leg-steps", type=int, default=int(os.environ.get("GC_BENCH_SV_STEPS", 3)),
                     help="after the timed steps (N=1, config 2): this many steps over reads of which 20 %% carry a 1.5 kb deletion - the reads whose chained alignment wins "
                          "(k_edit_path, chained traces, the winners' output), with the oracle's summary of the first 1 000 for the parity check; 0 skips it")
@@ -254,9 +256,16 @@ def main():
     # two short legs after the headline (N=1, config 2, outside `value`): reads whose chained alignment wins, and a graph with repeats
     legs = world == 1 and args.config == 2 and long_pass and not args.no_cpu_baseline and sg is not None
     sv_reads = rep_reads = rep_gfa = None
+    # r6: the timed steps cycle through several read sets instead of re-aligning one (same shape, own seeds; each set's first reads go through the oracle too)
+    if args.distinct_batches is None:
+        args.distinct_batches = 4 if (args.config == 2 and sg is not None) else 1
+    if sg is None or args.config != 2:
+        args.distinct_batches = 1
+    extra_sets = [sg.sample_reads(args.reads, args.read_len, seed=11 + 1000 * d + (0 if strong else rank), sv_fraction=args.sv_fraction) for d in range(1, args.distinct_batches)]
+    args.extra_cpu_reads = {f"set{d + 1}": rs[:1000] for d, rs in enumerate(extra_sets)} if (rank == 0 and world == 1) else {}
     if legs and args.sv_leg_steps > 0:
         sv_reads = sg.sample_reads(args.reads, args.read_len, seed=13, sv_fraction=0.2)
-        args.extra_cpu_reads = {"sv": sv_reads[:1000]}
+        args.extra_cpu_reads["sv"] = sv_reads[:1000]
     if legs and args.repeats_leg_steps > 0:
         rep_sg = SynthGraph(max(2_000_000, args.backbone // 4), seed=9, repeats=600, repeat_len=3000)
         rep_gfa = os.path.join(tmp, "repeats.gfa")
@@ -360,6 +369,16 @@ def main():
     upload_s = time.perf_counter() - t0
     total_bases = int(sum(int(b.lengths.sum()) for b in batches))
     queue = ReadQueue(len(batches), rank, world, dist if strong else None)
+    # the read sets the timed steps cycle through, flat: set d's batches at [d * per_step, (d + 1) * per_step), each with the oracle's rows for ITS set's first reads
+    per_step = len(batches)
+    extra_summaries = getattr(args, "extra_cpu_summaries", None) or {}
+    flat_chunks, flat_batches, flat_summaries = list(chunks), list(batches), [cpu_summary] * per_step
+    for d, rs in enumerate(extra_sets):
+        set_chunks = length_sorted_batches(rs, args.batch)
+        flat_chunks += set_chunks
+        flat_batches += [gca.ReadBatch([rs[i] for i in idx]) for idx in set_chunks]
+        flat_summaries += [extra_summaries.get(f"set{d + 1}")] * len(set_chunks)
+    n_sets = 1 + len(extra_sets)
 
     def sync():
         if dist is not None:
@@ -367,11 +386,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run_steps(count):
-        """`count` passes over the rank's batches: `inflight` host threads (one gc_stream each, like the reference's -t workers) pull
+    def run_steps(count, sets=None):
+        """`count` passes over the rank's batches (step s: read set s mod `sets`): `inflight` host threads (one gc_stream each, like the reference's -t workers) pull
         (step, batch) items from one queue, so with more than one batch in flight consecutive steps overlap - a stream of batches."""
-        queue.reset(count * len(batches))
-        return run_queue(queue, lambda i, item: (item % len(batches), aligners[i].align_batch(batches[item % len(batches)])), inflight)   # align_batch returns after its streams are drained
+        sets = n_sets if sets is None else sets
+        queue.reset(count * per_step)
+        flat = lambda item: ((item // per_step) % sets) * per_step + item % per_step
+        return run_queue(queue, lambda i, item: (flat(item), aligners[i].align_batch(flat_batches[flat(item)])), inflight)   # align_batch returns after its streams are drained
 
     def cpu_seconds():
         """CPU time of this container so far (cgroup v2 cpu.stat), or of this process when there is no such file."""
@@ -438,6 +459,16 @@ def main():
         print(f"[bench cpu] pid {os.getpid()}; per step, by thread (s): " + ", ".join(f"{name}/{tid} {d / args.steps:.3f}" for d, (tid, name) in used[:14] if d > 0)
               + f"; all threads {sum(d for d, _ in used) / args.steps:.3f}, process {rank_cpu_s / args.steps:.3f}, container {host_cpu_s / args.steps:.3f}", file=sys.stderr)
     mem_free_end, _ = gca.device_memory()
+    # what re-aligning ONE read set step after step (the bench up to r5) is worth: a few steps of it, timed the same way, outside `value`
+    same_batch = None
+    if n_sets > 1 and dist is None:
+        k = max(1, args.steps)                             # (as many steps as the timed region: a short run would be mostly pipeline fill)
+        sync()
+        t_same = time.perf_counter()
+        run_steps(k, sets=1)
+        sync()
+        same_batch = {"ms_per_step": round((time.perf_counter() - t_same) / k * 1e3, 2), "steps": k,
+                      "what": "the same steps with ONE read set re-aligned every step (its graph lines stay in L2 / Infinity Cache between steps); `value` cycles through distinct_read_sets sets"}
     # Parity of the timed mode (src/Aligner.cpp:630-654,735,901-905): the reads the CPU leg aligned with the oracle are compared, value
     # for value, with what EVERY timed batch returned for them - chain, chain score, both NW distances, the decision, the whole-read
     # alignments and the selection. Outside the timed region; a mismatch fails the run.
@@ -446,16 +477,19 @@ def main():
         mismatches, checked, fields_bad = 0, 0, {}
         for _item, (b, out) in results:
             original = np.asarray(chunk_list[b], dtype=np.int64)
-            rows = np.nonzero(original < len(summary))[0]
+            rows_of = summary[b] if isinstance(summary, list) else summary      # (the timed steps: one summary per read set)
+            if rows_of is None:
+                continue
+            rows = np.nonzero(original < len(rows_of))[0]
             if not len(rows):
                 continue
             got = read_summary(out)[rows]
-            bad = got != summary[original[rows], :SUMMARY_WIDTH]
+            bad = got != rows_of[original[rows], :SUMMARY_WIDTH]
             checked += len(rows)
             mismatches += int(bad.any(axis=1).sum())
             for k in np.nonzero(bad.any(axis=0))[0]:
                 fields_bad[SUMMARY_FIELDS[k]] = fields_bad.get(SUMMARY_FIELDS[k], 0) + int(bad[:, k].sum())
-        rec = {"reads": int(len(summary)), "timed_batches_checked": len(results), "read_results_compared": checked, "mismatches": mismatches,
+        rec = {"reads": int(sum(len(x) for x in {id(x): x for x in summary if x is not None}.values())) if isinstance(summary, list) else int(len(summary)), "timed_batches_checked": len(results), "read_results_compared": checked, "mismatches": mismatches,
                "fields": "anchors, chain, chain score, whole-read and chain NW distance, chained_better, whole-read alignments (start, end, score), selection, failed_assertion, flatten ties (fragments, whole read)",
                "against": "oracle (CPU leg of this run), same reads"}
         if mismatches:
@@ -471,7 +505,7 @@ def main():
         hashes = gaf_read_hashes(text, np.diff(np.asarray(out["read_out_off"]).astype(np.int64)))
         return len(rows), int((hashes[rows] != summary[original[rows], SUMMARY_WIDTH]).sum())
 
-    parity_check = summary_check(outs, chunks, cpu_summary) if cpu_summary is not None else None
+    parity_check = summary_check(outs, flat_chunks, flat_summaries) if cpu_summary is not None else None
     failures = []
     if parity_check is not None and parity_check["mismatches"]:
         failures.append(f"parity check failed: {parity_check['mismatches']} of {parity_check['read_results_compared']} timed read results differ from the oracle")
@@ -492,10 +526,13 @@ def main():
         legs = [("gaf", "gaf", None)] if "gaf" in args.e2e_formats.split(",") else []
         if "gam" in args.e2e_formats.split(","):
             legs += [("gam", "gam", None), ("gam_level1", "gam", 1), ("gam_device_huffman", "gam", gca.GAM_DEVICE_HUFFMAN)]
+        if "json" in args.e2e_formats.split(","):
+            legs += [("json", "json", None)]                          # (r6; src/Aligner.cpp:286-293: one vg::Alignment per line through protobuf's JSON mapping)
+        json_seen = {}
         gam_inflated = {}                                             # leg -> (bytes, CRC-32) of batch 0's inflated GAM stream: the same at every level
         for leg, fmt, level in legs:
             for a in aligners:
-                a.params.device_output = 1 if fmt == "gaf" else 4
+                a.params.device_output = 1 if fmt == "gaf" else 4   # (GAM and JSON: the vg::Path bytes of every final alignment)
             free_streams = queue_mod.SimpleQueue()
             for a in aligners:
                 free_streams.put(a)
@@ -519,6 +556,12 @@ def main():
                 t_e = time.perf_counter()
                 if checking[0] and fmt == "gaf" and cpu_summary is not None:
                     kept[item] = gaf_check(texts["gaf"], out, chunks[b], cpu_summary)
+                elif checking[0] and fmt == "json" and item == 0:
+                    lines = texts["json"].split(b"\n")[:-1]
+                    first = json.loads(lines[0]) if lines else {}
+                    json_seen["lines"], json_seen["final_alignments"] = len(lines), int(np.asarray(out["read_out_off"])[-1])
+                    json_seen["every_line_parses"] = all(isinstance(json.loads(l), dict) for l in lines[:2000])
+                    json_seen["first_line_keys"] = sorted(first.keys())
                 elif checking[0] and fmt == "gam" and item == 0:
                     import gzip
                     import zlib
@@ -541,6 +584,10 @@ def main():
                    "bytes_per_step": int(sum(n for _i, (n, _s) in done) / args.e2e_steps), "chained_winners_without_trace": int(sum(s for _i, (_n, s) in done)),
                    "ms_per_batch_in": dict(zip(("upload", "waiting_for_a_stream", "gc_align_batch", "format"), (np.round(spent / max(1, len(done)) * 1e3, 1)).tolist())),
                    "includes": f"gc_reads_upload (PCIe + packing kernels) + hot path + output encoding on the device (k_out_encode) + gc_format_{fmt}" + (f"_level(level {level})" if level is not None else "") + " of every batch"}
+            if fmt == "json":
+                rec["json_check"] = dict(json_seen, what="first batch: one line per final alignment, every line a JSON object (the GPU tests hold the lines to the reference-decoded fixtures: tests/test_gpu_parity.py)")
+                if json_seen.get("lines") != json_seen.get("final_alignments") or not json_seen.get("every_line_parses"):
+                    failures.append(f"e2e json: {json_seen}")
             if fmt == "gam":
                 if level == gca.GAM_DEVICE_HUFFMAN:
                     rec["gzip"] = "deflated on the device (hip/gc_deflate.hip: one dynamic-Huffman block of literals per read, no LZ77 matches); the host frames the members and computes their CRC-32s"
@@ -614,7 +661,7 @@ def main():
         chain_len = np.diff(out["read_chain_off"])
         n_long = np.diff(out["read_longall_off"])
         reads_done += len(chain_len)
-        aligned_bases += int(batches[b].lengths[(chain_len > 0) | (n_long > 0)].sum())
+        aligned_bases += int(flat_batches[b].lengths[(chain_len > 0) | (n_long > 0)].sum())
         chained_better += int(np.sum(out["chained_better"]))
         reads_with_chain += int((chain_len > 0).sum())
         reads_with_long += int((n_long > 0).sum())
@@ -654,10 +701,12 @@ def main():
 
     # roofline of the dominant kernel (most device time per step: k_long_extend when the whole-read pass runs, else k_extend):
     # algorithmic bytes per launch (SURVEY.md §8d unit x the counts the kernel reports) / its HIP-event duration
-    def kernel_roofline(name, cnt, us, launches=1.0):
+    def kernel_roofline(name, cnt, us, launches=1.0, reference_share=1.0):
         # `us` = the kernel's HIP-event time summed over its launches of one step (k_long_extend: one launch per round and batch)
+        # reference_share (r6): the part of the kernel's extensions the reference would run - the whole-read pass extends some seeds speculatively (late rounds; on
+        # config 5 a third more than the reference's count), and work the reference does not do is not algorithmic work: its bytes are left out of `achieved`
         dp_tiles, recompute_tiles, column_steps, trace_items, _ext, backtrace_tiles = cnt[:6]
-        nbytes = BYTES_PER_TILE * (dp_tiles + recompute_tiles) + BYTES_PER_BACKTRACE_TILE * backtrace_tiles + BYTES_PER_TRACE_ITEM * trace_items
+        nbytes = (BYTES_PER_TILE * (dp_tiles + recompute_tiles) + BYTES_PER_BACKTRACE_TILE * backtrace_tiles + BYTES_PER_TRACE_ITEM * trace_items) * reference_share
         seconds = us * 1e-6
         achieved = nbytes / seconds / 1e9 if seconds > 0 else 0.0
         launches = max(1.0, launches)
@@ -682,7 +731,11 @@ def main():
 
     n_batches_step = len(outs) / steps
     roof_extend = kernel_roofline("k_extend", counters, kernel_us[1], n_batches_step)
-    roof_long = kernel_roofline("k_long_extend", counters_long, kernel_us[4], counters_long[6]) if long_pass else None
+    # (two extensions - backward, forward - per seed the reference extends: gc_result::seeds_extended_long)
+    long_reference_share = min(1.0, 2.0 * float(sum(float(x.sum()) for x in seeds_ext_long)) / steps / max(1.0, counters_long[4])) if long_pass else 1.0
+    roof_long = kernel_roofline("k_long_extend", counters_long, kernel_us[4], counters_long[6], long_reference_share) if long_pass else None
+    if roof_long is not None:
+        roof_long["extensions_the_reference_runs_share"] = round(long_reference_share, 4)
     roofline = roof_long if (long_pass and kernel_us[4] >= kernel_us[1]) else roof_extend
     if args.config == 2 and args.reads == 10_000:
         roofline["traffic"], roofline["traffic_source"] = measured_traffic(roofline["kernel"], roofline["launches_per_step"])
@@ -692,7 +745,7 @@ def main():
         # a second graph (pasted repeats: several seeds per fragment window, clusters to order): this run's streams and graph go first - HBM holds one set
         for a in aligners:
             a.close()
-        for b in batches:
+        for b in flat_batches:
             b.close()
         seeder.close()
         graph.close()
@@ -736,6 +789,7 @@ def main():
             "inflight_choice": inflight_choice,
             "per_rank": per_rank,
             # inputs are resident before the timed region; what putting them there costs (host-side packing + PCIe), and the rate with it included
+            "distinct_read_sets": n_sets, "same_read_set_every_step": same_batch,
             "reads_upload": {"ms_per_step": round(upload_s * 1e3, 2), "bases": total_bases, "reads_per_s_including_upload": round(reads_total / (elapsed + upload_s * steps * (1 if not strong else 1)), 2)},
             "host_cpu_s_per_step": round(host_cpu_s / max(1, args.steps), 3),   # CPU time the container spent per step (all threads, this rank's box)
             "stage_ms": {"k_seed_probe+compact": round(kernel_us[0] / 1e3, 3), "k_extend": round(kernel_us[1] / 1e3, 3), "k_build_anchors": round(kernel_us[2] / 1e3, 3),

@@ -41,6 +41,13 @@ with open(os.path.join(out, f"{prefix}_pmc_all_kernels.txt"), "w") as f:
     f.write(header)
     for (k, c), v in sorted(rows.items()):
         f.write(f"{k[:32]:34s} {c:24s} {v:.4e}\n")
+with open(os.path.join(out, f"{prefix}_pmc_extend.txt"), "w") as f:   # (r6: the lockstep fragment kernel and what it declines)
+    f.write(header)
+    for (k, c), v in sorted(rows.items()):
+        if k == "k_extend" or k.startswith("k_extend_slab") or k.startswith("k_build_anchors"):
+            f.write(f"{k[:32]:34s} {c:24s} {v:.4e}\n")
+if os.path.exists(os.path.join(src, "frag_stamps.txt")):
+    shutil.copy(os.path.join(src, "frag_stamps.txt"), os.path.join(out, f"{prefix}_stamps_extend.txt"))
 with open(os.path.join(out, f"{prefix}_pmc_long_extend.txt"), "w") as f:
     f.write(header)
     for (k, c), v in sorted(rows.items()):

@@ -1151,6 +1151,30 @@ def test_gam_against_the_reference_decoded_fixture(gca, case):
 
 
 @pytest.mark.parametrize("case", ["ref_test", "syn20k", "syn20k_more"])
+def test_json_lines_against_the_reference_decoded_fixture(gca, case):
+    """r6: the JSON output (src/Aligner.cpp:286-293: one vg::Alignment per line through protobuf's JSON mapping) of the host encoder over the traces and of the device
+    path (k_out_encode's vg::Path bytes, device_output 4) parses - with the field names and types of the descriptor - into the messages the reference's own descriptor
+    decoded from the GAM of the same alignments (tests/golden/*.expected.gam.json), line for line in output order. What the fixture cannot hold is the C++ printer's
+    spelling of `identity` (compared as a parsed double)."""
+    from google.protobuf import json_format
+    from vg_descriptor import alignment_class, golden_case
+    gfa, reads, want_groups, _, want_better = golden_case(case)
+    Alignment = alignment_class()
+    graph = gca.AlignmentGraph(gfa)
+    seeder = gca.MinimizerSeeder(graph)
+    names = [f"r{i}" for i in range(len(reads))]
+    want = [m for g in want_groups for m in g]
+    for leg, akw in (("host encoder", dict(keep_traces=True)), ("device encoder", dict(device_output=1 | 4))):
+        out = gca.Aligner(graph, seeder, long_pass=True, **akw).align_reads(reads, gaf_names=names, formats=("json",))
+        lines = out["json"].split(b"\n")[:-1]
+        assert len(lines) == len(want) >= 1, leg
+        for line, message in zip(lines, want):
+            got = json_format.MessageToDict(json_format.Parse(line.decode(), Alignment()), preserving_proto_field_name=True)
+            assert got == message, (leg, line[:120])
+        assert [int(x) for x in out["chained_better"]] == want_better, leg
+
+
+@pytest.mark.parametrize("case", ["ref_test", "syn20k", "syn20k_more"])
 def test_gam_paths_spelled_through_the_gfa_give_the_reported_distances(gca, case):
     """r6: the product's GAM read back the way the reference's harness reads it (scripts/summary.py:77-91; tests/golden/make_gam_golden.py committed what the restated
     reader saw through the reference's own descriptor): every alignment's path spelled through the GFA equals the fixture's, the NW edit distance (the product's own
