@@ -602,7 +602,7 @@ static void uploadSeeder(gc_seeder* S)
 	// 2^25 bits = 4 MB, which stays in every XCD's L2 (a 32 MB filter missed to the fabric on every probe)
 	uint32_t filterBits = 20;
 	while (filterBits < 28 && (1ull << filterBits) < 8 * nKeys) filterBits++;
-	if (const char* env = getenv("GC_SEED_FILTER_BITS")) filterBits = (uint32_t)std::max(10, std::min(30, atoi(env)));
+	if (const char* env = getenv("GC_TEST_SEED_FILTER_BITS")) filterBits = (uint32_t)std::max(10, std::min(30, atoi(env)));
 	std::vector<uint32_t> filter((1ull << filterBits) / 32, 0);
 	for (size_t i = 0; i < nKeys; i++) { uint32_t fb = (uint32_t)((S->host.kmers[i] * 0xD6E8FEB86659FD93ull) >> (64 - filterBits)); filter[fb >> 5] |= 1u << (fb & 31); }
 	S->dev.filterShift = 64 - filterBits;

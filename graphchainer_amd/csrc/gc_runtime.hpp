@@ -83,7 +83,7 @@ struct DeviceBuffer {   // growable device allocation owned by a stream object
 	// a pool that a rerun sized from an overshooting request count comes back to what its batches use: called once, by the batch after the rerun (hipFree drains the device)
 	void shrinkTo(size_t needBytes)
 	{
-		const char* env = getenv("GC_POOL_SHRINK_FLOOR");   // (test hook, read per call - the tests set it mid-process: small pools shrink too)
+		const char* env = getenv("GC_TEST_POOL_SHRINK_FLOOR");   // (test hook, read per call - the tests set it mid-process: small pools shrink too)
 		const size_t floor = env ? (size_t)std::max(0ll, atoll(env)) : (size_t)(64u << 20);
 		if (bytes > needBytes + needBytes / 4 + floor) release();
 	}
@@ -335,10 +335,10 @@ template <typename T> inline T* mallocArray(size_t n) { return (T*)malloc(std::m
 // assembly of a traced batch cost). Every array carries a 64-byte header with its size, so gc_result_free knows what it holds.
 struct ResultBlockCache {
 	static constexpr size_t HEADER = 64, MAX_HELD = 24ull << 30;
-	// test hooks: GC_RESULT_CACHE_MIN=bytes recycles arrays from that size on (default 32 MB), GC_RESULT_CACHE_POISON=1 fills every array with 0xA5 when it is handed out -
+	// test hooks: GC_RESULT_CACHE_MIN=bytes recycles arrays from that size on (default 32 MB), GC_TEST_RESULT_CACHE_POISON=1 fills every array with 0xA5 when it is handed out -
 	// together they show any reader that counts on an array's unwritten part being zero (fresh pages are, recycled ones are not)
 	const size_t BIG = getenv("GC_RESULT_CACHE_MIN") ? (size_t)std::max(1ll, atoll(getenv("GC_RESULT_CACHE_MIN"))) : (32ull << 20);
-	const bool poison = getenv("GC_RESULT_CACHE_POISON") != nullptr;
+	const bool poison = getenv("GC_TEST_RESULT_CACHE_POISON") != nullptr;
 	std::mutex mutex;
 	std::vector<std::pair<char*, size_t>> blocks;   // (base, capacity in bytes without the header)
 	size_t held = 0;

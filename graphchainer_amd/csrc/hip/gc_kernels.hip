@@ -157,7 +157,7 @@ __device__ __forceinline__ LaneScratch laneScratch(uint8_t* slab, const ExtendCo
 #endif
 // 4 waves per SIMD (<= 128 VGPRs; the kernel wanted 131 and ran 3): it waits on memory 56 % of the time, so the extra wave
 // pays for the 4 spilled registers: 34.2 -> 29.0 ms alone on cfg2 (5 or 6 waves spill 57 / 196 registers and lose).
-#define GC_EXTEND_SLAB_PARAMS DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg, 	const ExtItem* __restrict__ work, uint32_t nWork, const char* __restrict__ bases, ExtResult* __restrict__ results, 	uint8_t* __restrict__ scratch, uint64_t slabBytes, PoolCell* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, 	unsigned long long* __restrict__ counters, uint32_t retryStatus, ExtSelection sel, uint32_t chunkBegin, uint32_t chunkItems
+#define GC_EXTEND_SLAB_PARAMS DGraph g, const CorrectnessTables* __restrict__ ct, const uint8_t* __restrict__ iupac, ExtendConfig cfg, 	const ExtItem* __restrict__ work, uint32_t nWork, const char* __restrict__ bases, ExtResult* __restrict__ results, 	uint8_t* __restrict__ scratch, uint64_t slabBytes, PoolCell* __restrict__ tracePool, unsigned long long* __restrict__ traceCursor, uint64_t traceCapacity, 	unsigned long long* __restrict__ counters, uint32_t retryStatus, ExtSelection sel
 __device__ __forceinline__ void extendSlabBody(GC_EXTEND_SLAB_PARAMS)
 {
 #if defined(GC_EXTEND_PRIO) && GC_EXTEND_PRIO
@@ -175,10 +175,7 @@ __device__ __forceinline__ void extendSlabBody(GC_EXTEND_SLAB_PARAMS)
 	ExtCounters cnt {};
 	// which work items: all of them, the two extensions of every fragment's first seed, or a list written by k_build_anchors (count on the device)
 	const uint32_t nSelected = sel.mode == 0 ? nWork : sel.mode == 1 ? 2 * sel.nFrags : (uint32_t)*sel.listCount;
-	// (r5: a launch covers the items [chunkBegin, chunkBegin + chunkItems) of the selection: the waves of this kernel are persistent, and one launch over the 14 M extensions of a
-	// 2 000 x 50 kb batch on a 960 Mbp graph held its wave slots for a third of a second while the other batches' small kernels waited for one)
-	const uint32_t chunkEnd = chunkItems && nSelected - (chunkBegin < nSelected ? chunkBegin : nSelected) > chunkItems ? chunkBegin + chunkItems : nSelected;
-	for (uint32_t at = chunkBegin + tid; at < chunkEnd; at += stride) {
+	for (uint32_t at = tid; at < nSelected; at += stride) {
 		const uint32_t w = sel.mode == 0 ? at : sel.mode == 1 ? 2 * sel.frags[at >> 1].seedBegin + (at & 1u) : sel.list[at];
 		if (retryStatus != 0 && results[w].status != retryStatus) continue;   // retry launch (larger slabs): only the items the first launch gave up on
 		ExtItem it = work[w];
@@ -217,7 +214,7 @@ __device__ __forceinline__ void extendSlabBody(GC_EXTEND_SLAB_PARAMS)
 // 4 waves per SIMD (<= 128 VGPRs): everything, when the lockstep kernel is switched off (GC_EXTEND_SLAB=1)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_extend_slab(GC_EXTEND_SLAB_PARAMS)
 {
-	extendSlabBody(g, ct, iupac, cfg, work, nWork, bases, results, scratch, slabBytes, tracePool, traceCursor, traceCapacity, counters, retryStatus, sel, chunkBegin, chunkItems);
+	extendSlabBody(g, ct, iupac, cfg, work, nWork, bases, results, scratch, slabBytes, tracePool, traceCursor, traceCapacity, counters, retryStatus, sel);
 }
 // =====================================================================================================
 // K3b - fragment post-pass: merges the two one-way traces of every seed, replays the reference's serial
@@ -1502,27 +1499,18 @@ uint32_t extendGridLanes(uint32_t nWork)
 {
 	// 256 CUs x 16 resident waves is plenty to hide latency for this register-heavy kernel; never more lanes than work
 	uint32_t lanes = 256u * 16u * 64u;
-	static const uint32_t capWaves = getenv("GC_EXTEND_WAVES") ? (uint32_t)std::max(64, std::min(4096, atoi(getenv("GC_EXTEND_WAVES")))) : 4096u;   // (measurement hook: fewer persistent waves)
-	lanes = capWaves * 64u;
 	uint32_t need = (nWork + 63) / 64 * 64;
 	return need < lanes ? need : lanes;
 }
 
 void launchExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg,
 	const ExtItem* work, uint32_t nWork, const char* bases, ExtResult* results, uint8_t* scratch, uint64_t slabBytes,
-	PoolCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters, uint32_t retryStatus, uint32_t retryLanes, ExtSelection sel, uint32_t chunkItems)
+	PoolCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters, uint32_t retryStatus, uint32_t retryLanes, ExtSelection sel)
 {
 	if (nWork == 0) return;
 	const uint32_t upper = sel.mode == 1 ? 2 * sel.nFrags : nWork;   // (a device-side list holds at most nWork items; waves beyond its count leave at once)
 	uint32_t lanes = retryStatus ? retryLanes : extendGridLanes(upper);
-	if (retryStatus || chunkItems == 0 || upper <= chunkItems) {
-		hipLaunchKernelGGL(k_extend_slab, dim3(lanes / 64), dim3(64), 0, stream, g, ct, iupac, cfg, work, nWork, bases, results, scratch, slabBytes, tracePool, traceCursor, traceCapacity, counters, retryStatus, sel, 0u, 0u);
-		return;
-	}
-	// the selection in pieces of chunkItems, one launch each, back to back on the stream: between two of them every wave slot is given up (a list's count is only known on the
-	// device: the launches beyond it find nothing and leave)
-	for (uint64_t begin = 0; begin < upper; begin += chunkItems)
-		hipLaunchKernelGGL(k_extend_slab, dim3(lanes / 64), dim3(64), 0, stream, g, ct, iupac, cfg, work, nWork, bases, results, scratch, slabBytes, tracePool, traceCursor, traceCapacity, counters, retryStatus, sel, (uint32_t)begin, chunkItems);
+	hipLaunchKernelGGL(k_extend_slab, dim3(lanes / 64), dim3(64), 0, stream, g, ct, iupac, cfg, work, nWork, bases, results, scratch, slabBytes, tracePool, traceCursor, traceCapacity, counters, retryStatus, sel);
 }
 
 void launchBuildAnchors(hipStream_t stream, const DGraph& g, const Fragment* frags, uint32_t nFrags, const FragSeed* seeds, const ExtResult* ext,
@@ -1585,8 +1573,8 @@ uint32_t longExtendTeamSize(uint32_t nWork)
 {
 	// Measured on MI355X (cfg2, 20k extensions in the first round): 1 lane per wave 260 ms, 2 lanes 352 ms, 4 lanes 397 ms,
 	// 8 lanes 555 ms for the whole pass. The extension core is branchy serial code; lanes sharing a wave pay for the
-	// union of their paths, and the chip has far more wave slots than a round has extensions. GC_LONG_TEAM overrides.
-	if (const char* env = getenv("GC_LONG_TEAM")) { int v = atoi(env); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return (uint32_t)v; }
+	// union of their paths, and the chip has far more wave slots than a round has extensions. GC_TEST_LONG_TEAM overrides.
+	if (const char* env = getenv("GC_TEST_LONG_TEAM")) { int v = atoi(env); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return (uint32_t)v; }
 	(void)nWork;
 	return 1;
 }

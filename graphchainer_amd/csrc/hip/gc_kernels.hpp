@@ -185,7 +185,7 @@ uint32_t extendGridLanes(uint32_t nWork);
 void launchExtend(hipStream_t stream, const DGraph& g, const CorrectnessTables* ct, const uint8_t* iupac, const ExtendConfig& cfg,
 	const ExtItem* work, uint32_t nWork, const char* bases, ExtResult* results, uint8_t* scratch, uint64_t slabBytes,
 	PoolCell* tracePool, unsigned long long* traceCursor, uint64_t traceCapacity, unsigned long long* counters,
-	uint32_t retryStatus = 0, uint32_t retryLanes = 4096, ExtSelection sel = ExtSelection(), uint32_t chunkItems = 0);   // retryStatus != 0: a small grid of `retryLanes` lanes reruns only the items whose result has that status (with the larger slabs of `cfg`)
+	uint32_t retryStatus = 0, uint32_t retryLanes = 4096, ExtSelection sel = ExtSelection());   // retryStatus != 0: a small grid of `retryLanes` lanes reruns only the items whose result has that status (with the larger slabs of `cfg`)
 
 void launchBuildAnchors(hipStream_t stream, const DGraph& g, const Fragment* frags, uint32_t nFrags, const FragSeed* seeds, const ExtResult* ext,
 	const PoolCell* tracePool, int32_t splitLen, AnchorRec* anchors, uint32_t* fragStatus, uint32_t* fragExtended,

@@ -44,16 +44,16 @@ typedef struct gc_reads gc_reads;     /* a batch of reads uploaded to HBM */
  * 0 = automatic (the values in brackets, derived from the batch's longest read L); set a field only to trade memory against reruns on unusual inputs
  * (dense variant clusters, very noisy long reads). The same knobs exist as GC_* environment variables for experiments; the environment wins. */
 typedef struct gc_capacities {
-	int64_t ext_max_items;          /* fragment extensions (k_extend): (slice, node) tiles per extension [72; the retry launch has 16x] (GC_EXT_MAX_ITEMS) */
-	int64_t ext_max_pending;        /* ... entries of the per-slice node queue [48; retry 16x] (GC_EXT_MAX_PENDING) */
-	int64_t ext_max_trace;          /* ... trace cells per extension [192; retry 16x] (GC_EXT_MAX_TRACE) */
-	int64_t long_max_items;         /* whole-read extensions (k_long_extend): tiles per extension [max(8192, 24 per slice)] (GC_LONG_MAX_ITEMS) */
-	int64_t long_column_store;      /* ... DP columns kept for the backtrace per extension [3 L + 4096]; -1: keep none, the backtrace recomputes its tiles (GC_LONG_MAX_COLS) */
+	int64_t ext_max_items;          /* fragment extensions (k_extend): (slice, node) tiles per extension [72; the retry launch has 16x] (GC_TEST_EXT_MAX_ITEMS) */
+	int64_t ext_max_pending;        /* ... entries of the per-slice node queue [48; retry 16x] (GC_TEST_EXT_MAX_PENDING) */
+	int64_t ext_max_trace;          /* ... trace cells per extension [192; retry 16x] (GC_TEST_EXT_MAX_TRACE) */
+	int64_t long_max_items;         /* whole-read extensions (k_long_extend): tiles per extension [max(8192, 24 per slice)] (GC_TEST_LONG_MAX_ITEMS) */
+	int64_t long_column_store;      /* ... DP columns kept for the backtrace per extension [3 L + 4096]; -1: keep none, the backtrace recomputes its tiles (GC_TEST_LONG_MAX_COLS) */
 	int64_t long_cells_per_base;    /* merged trace cells per read base in the batch's pool [8, tripled and the pass rerun when a batch overflows it; the stream remembers]
-	                                 * (GC_LONG_CELLS_PER_BASE; setting it pins the pool: overflowing reads are flagged instead) */
-	int64_t long_scratch_bytes;     /* upper bound of the whole-read pass's per-wave scratch [48 GiB; 0.8 MB per resident wave at L = 10 kb, 2.4 MB at 50 kb] (GC_LONG_SCRATCH_GB) */
-	int64_t stitch_set_max;         /* chain stitching (k_stitch): nodes of one bridged region searched on the device [automatic]; larger regions go to the host (GC_STITCH_SET_MAX) */
-	int64_t stitch_bfs_cap;         /* ... frontier entries of one bridge search [automatic] (GC_STITCH_BFS_CAP) */
+	                                 * (GC_TEST_LONG_CELLS_PER_BASE; setting it pins the pool: overflowing reads are flagged instead) */
+	int64_t long_scratch_bytes;     /* upper bound of the whole-read pass's per-wave scratch [48 GiB; 0.8 MB per resident wave at L = 10 kb, 2.4 MB at 50 kb] (GC_TEST_LONG_SCRATCH_GB) */
+	int64_t stitch_set_max;         /* chain stitching (k_stitch): nodes of one bridged region searched on the device [automatic]; larger regions go to the host (GC_TEST_STITCH_SET_MAX) */
+	int64_t stitch_bfs_cap;         /* ... frontier entries of one bridge search [automatic] (GC_TEST_STITCH_BFS_CAP) */
 	int64_t reserved[3];            /* must be 0 */
 } gc_capacities;
 

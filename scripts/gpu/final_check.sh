@@ -5,7 +5,7 @@ mkdir -p $out
 timeout 1500 python -m pytest tests -q -m gpu -x > $out/pytest_all.log 2>&1
 tail -3 $out/pytest_all.log
 # the same tests with every result array recycled and filled with 0xA5 before use: nothing may count on unwritten parts being zero
-GC_RESULT_CACHE_MIN=1 GC_RESULT_CACHE_POISON=1 timeout 1500 python -m pytest tests -q -m gpu -x > $out/pytest_poison.log 2>&1
+GC_RESULT_CACHE_MIN=1 GC_TEST_RESULT_CACHE_POISON=1 timeout 1500 python -m pytest tests -q -m gpu -x > $out/pytest_poison.log 2>&1
 tail -2 $out/pytest_poison.log
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 cd /tmp && export TMPDIR=/tmp

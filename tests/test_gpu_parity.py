@@ -171,7 +171,7 @@ def test_whole_read_pass_parity(gca, tmp_path, backbone, n_reads, read_len):
 def test_whole_read_pass_plain_layout_fallback(gca, tmp_path, monkeypatch):
     """Reads whose band does not fit the LDS tables are rerun with the plain-layout kernel; force that path for all."""
     from graphchainer_amd.synth import SynthGraph
-    monkeypatch.setenv("GC_LONG_FORCE_FALLBACK", "1")
+    monkeypatch.setenv("GC_TEST_LONG_FORCE_FALLBACK", "1")
     sg = SynthGraph(60_000, seed=8)
     gfa = str(tmp_path / "g.gfa")
     sg.write_gfa(gfa)
@@ -184,7 +184,7 @@ def test_whole_read_pass_plain_layout_fallback(gca, tmp_path, monkeypatch):
 def test_whole_read_pass_speculative_rounds(gca, tmp_path, monkeypatch):
     """Tail rounds extend several seeds of a read at once and re-check them in order; force that from round 0."""
     from graphchainer_amd.synth import SynthGraph
-    monkeypatch.setenv("GC_LONG_SPECULATE", "2")
+    monkeypatch.setenv("GC_TEST_LONG_SPECULATE", "2")
     sg = SynthGraph(100_000, seed=12)
     gfa = str(tmp_path / "g.gfa")
     sg.write_gfa(gfa)
@@ -213,7 +213,7 @@ def test_whole_read_assertion_drops_the_read(gca, tmp_path, monkeypatch):
     assert got["chained_better"][3] == 0 and got["chain_edit_distance"][3] == -1 and got["long_edit_distance"][3] == -1
 
 
-@pytest.mark.parametrize("env", [{"GC_LONG_TEAM": "8"}, {"GC_LONG_TEAM": "64", "GC_LONG_ORDER": "0"}, {"GC_LONG_MAX_BLOCKS": "7"}, {"GC_LONG_MAX_BLOCKS": "3", "GC_LONG_TEAM": "4"}, {"GC_LONG_REG_CAP": "3"}, {"GC_LONG_REG_CAP": "6", "GC_LONG_MAX_BLOCKS": "5"}])
+@pytest.mark.parametrize("env", [{"GC_TEST_LONG_TEAM": "8"}, {"GC_TEST_LONG_TEAM": "64", "GC_TEST_LONG_ORDER": "0"}, {"GC_TEST_LONG_MAX_BLOCKS": "7"}, {"GC_TEST_LONG_MAX_BLOCKS": "3", "GC_TEST_LONG_TEAM": "4"}, {"GC_TEST_LONG_REG_CAP": "3"}, {"GC_TEST_LONG_REG_CAP": "6", "GC_TEST_LONG_MAX_BLOCKS": "5"}])
 def test_whole_read_pass_launch_shapes(gca, tmp_path, monkeypatch, env):
     """Launch-shape knobs of the whole-read pass (concurrent read groups, lanes per wave, execution order, persistent waves, register-table cap -> LDS-table retry) never change results."""
     from graphchainer_amd.synth import SynthGraph
@@ -552,7 +552,7 @@ def test_chain_kernel_scratch_path(gca, tmp_path, monkeypatch, plain_scan):
     weakly connected component (the default) or all earlier entries (GC_CHAIN_PLAIN_SCAN=1: what a read touching more than 256 components gets);
     chimeric reads put anchors of several components into one read."""
     from graphchainer_amd.synth import SynthGenome
-    monkeypatch.setenv("GC_CHAIN_FORCE_SCRATCH", "1")
+    monkeypatch.setenv("GC_TEST_CHAIN_FORCE_SCRATCH", "1")
     monkeypatch.setenv("GC_CHAIN_PLAIN_SCAN", plain_scan)
     gen = SynthGenome(6, 20_000, seed=29, multi_allelic=0.3, nested=0.3, repeats=4, repeat_len=1500)
     gfa = str(tmp_path / "g.gfa")
@@ -677,7 +677,7 @@ def test_capacity_overflow_flags_the_read_not_the_batch(gca, tmp_path, monkeypat
     want = Oracle(gfa, long_pass=True).align(reads)
     flagged_total = 0
     # (gc_params::capacity where the knob is public; the retry's own size is a test hook in the environment)
-    for env, cap in (({"GC_EXT_RETRY_MAX_ITEMS": "10"}, {"ext_max_items": 8}), ({}, {"long_max_items": 64}), ({}, {"long_cells_per_base": 2})):
+    for env, cap in (({"GC_TEST_EXT_RETRY_MAX_ITEMS": "10"}, {"ext_max_items": 8}), ({}, {"long_max_items": 64}), ({}, {"long_cells_per_base": 2})):
         with monkeypatch.context() as m:
             for k, v in env.items():
                 m.setenv(k, v)
@@ -966,7 +966,7 @@ def test_long_reads(gca, tmp_path, monkeypatch):
     """30 kb reads: per-extension scratch scales with the read length, persistent waves under a small scratch budget,
     edit-distance bands that need more than one block per lane."""
     from graphchainer_amd.synth import SynthGraph
-    monkeypatch.setenv("GC_LONG_SCRATCH_GB", "1")
+    monkeypatch.setenv("GC_TEST_LONG_SCRATCH_GB", "1")
     sg = SynthGraph(300_000, seed=29)
     gfa = str(tmp_path / "g.gfa")
     sg.write_gfa(gfa)
@@ -1050,7 +1050,7 @@ def test_wave_sort_gives_libstdcxx_permutations(gca, tmp_path):
 
 def test_fragment_pools_sized_by_use_rerun_when_too_small(gca, tmp_path, monkeypatch):
     """r5: the fragment pipeline's trace pool and anchor path pool are sized by what the stream's batches have used (not by every slot's worst case: 26 GB per batch on a 960 Mbp
-    graph); a batch that outgrows them runs the stage again with the room it asked for. GC_POOL_FIRST_GUESS makes a stream's first batch far too small: same results as the
+    graph); a batch that outgrows them runs the stage again with the room it asked for. GC_TEST_POOL_FIRST_GUESS makes a stream's first batch far too small: same results as the
     oracle, counters[6] says the stage ran again, and the stream's next batch (same Aligner) fits at once."""
     from graphchainer_amd.synth import SynthGraph
     from oracle import Oracle
@@ -1058,8 +1058,8 @@ def test_fragment_pools_sized_by_use_rerun_when_too_small(gca, tmp_path, monkeyp
     gfa = str(tmp_path / "g.gfa")
     sg.write_gfa(gfa)
     reads = sg.sample_reads(40, 3000, seed=2)
-    monkeypatch.setenv("GC_POOL_FIRST_GUESS", "0.5")
-    monkeypatch.setenv("GC_POOL_SHRINK_FLOOR", "0")      # (the batch after a rerun gives back what the rerun's sizing overshot: here small pools do too)
+    monkeypatch.setenv("GC_TEST_POOL_FIRST_GUESS", "0.5")
+    monkeypatch.setenv("GC_TEST_POOL_SHRINK_FLOOR", "0")      # (the batch after a rerun gives back what the rerun's sizing overshot: here small pools do too)
     graph = gca.AlignmentGraph(gfa)
     seeder = gca.MinimizerSeeder(graph)
     aligner = gca.Aligner(graph, seeder, keep_traces=True, keep_seeds=True, long_pass=True, chain_traces=2)
@@ -1100,7 +1100,7 @@ def test_flatten_tie_counts_equal_the_oracles(gca, tmp_path):
     compare(got, want, LONG_KEYS)
     assert int(want["flatten_ties"].sum()) >= 20 and int(want["flatten_ties_long"].sum()) >= 1
     assert int((got["flatten_ties"] + got["flatten_ties_long"] > 0).sum()) >= 10      # most 10 kb reads meet the rule at least once
-    for env in ({"GC_EXT_LAZY": "0"}, {"GC_LONG_FORCE_FALLBACK": "1"}):
+    for env in ({"GC_EXT_LAZY": "0"}, {"GC_TEST_LONG_FORCE_FALLBACK": "1"}):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -1210,15 +1210,15 @@ def test_gam_paths_spelled_through_the_gfa_give_the_reported_distances(gca, case
 @pytest.mark.parametrize("env,kw,host_expected", [
     ({}, {}, "none"),
     ({"GC_STITCH_CLASS": "3"}, {}, "none"),          # r5: the long-read class (node set in HBM scratch behind an LDS filter) forced on short reads
-    ({"GC_STITCH_CLASS": "3", "GC_STITCH_BFS_CAP": "2"}, {}, "none"),   # ... with an LDS search that may visit 2 nodes: every longer bridge search runs again in the scratch, none on the host
-    ({"GC_STITCH_CLASS": "3", "GC_STITCH_BFS_CAP": "6"}, {"colinear_gap": 150}, "none"),
+    ({"GC_STITCH_CLASS": "3", "GC_TEST_STITCH_BFS_CAP": "2"}, {}, "none"),   # ... with an LDS search that may visit 2 nodes: every longer bridge search runs again in the scratch, none on the host
+    ({"GC_STITCH_CLASS": "3", "GC_TEST_STITCH_BFS_CAP": "6"}, {"colinear_gap": 150}, "none"),
     ({"GC_STITCH_CLASS": "3"}, {"colinear_gap": -1}, "any"),
     ({"GC_HOST_STITCH": "1"}, {}, "all"),
-    ({"GC_STITCH_BFS_CAP": "2"}, {}, "some"),        # a bridge search may visit 2 nodes: most reads fall back to the host
-    ({"GC_STITCH_SET_MAX": "40"}, {}, "some"),       # a piece may hold 40 nodes
+    ({"GC_TEST_STITCH_BFS_CAP": "2"}, {}, "some"),        # a bridge search may visit 2 nodes: most reads fall back to the host
+    ({"GC_TEST_STITCH_SET_MAX": "40"}, {}, "some"),       # a piece may hold 40 nodes
     ({}, {"colinear_gap": 150}, "none"),             # small --colinear-gap: bridges fail, chains break into pieces
     ({}, {"colinear_gap": -1}, "any"),               # no limit: a search for an unreachable anchor walks the whole graph downstream, on the host
-    ({"GC_STITCH_BFS_CAP": "6"}, {"colinear_gap": 150}, "some"),
+    ({"GC_TEST_STITCH_BFS_CAP": "6"}, {"colinear_gap": 150}, "some"),
 ])
 def test_chain_stitching_device_and_host(gca, tmp_path, monkeypatch, env, kw, host_expected):
     """Row f3: k_stitch against the oracle's stitching (src/Aligner.cpp:754-822); the host path that takes the reads the
