@@ -491,7 +491,12 @@ __device__ __forceinline__ TileResult computeTileW(const DGraph& g, uint32_t nod
 				const uint64_t sPh = (Ph << 1) | hinP, sMh = KIND != 2 ? ((Mh << 1) | hinN) : (Mh << 1);
 				if (KIND == 0) { VP = (sMh | ~(Xv | sPh)) & ~f; VN = (sPh & Xv) | f; }
 				else if (KIND == 1) { VP = sMh | ~(Xv | sPh); VN = sPh & Xv; }
-				else { VP = (sMh | ~(Xv | sPh)) & ~1ull; VN = (sPh & Xv) | 1ull; }
+				else {
+					// (r6) a node that is new in this slice enters with its first row forced (VP bit 0 clear, VN bit 0 set: every incoming column was forced when it was pushed, and the
+					// pointwise minimum of forced columns is forced), its match masks have bit 0 cleared (forceEq) and its carries are (+1, 0): then Xv and sPh both have bit 0 set,
+					// sMh has it clear, and the recurrence itself leaves VP bit 0 clear and VN bit 0 set - the two forcing operations of the general copy are no-ops here
+					VP = sMh | ~(Xv | sPh); VN = sPh & Xv;
+				}
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 				// (two SGPR operands exceed gfx9's constant bus; M0 as lane select does not count)

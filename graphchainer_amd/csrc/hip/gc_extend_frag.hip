@@ -113,13 +113,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 			if (L.phase == PH_FETCH) {
 				if (L.work != 0xffffffffu) {
 					ExtResult res;
-					res.status = L.status;
+					// (a full trace pool answers EXT_OVERFLOW like anything else that did not fit, but is not handed to the plain-layout kernel: that would find the same pool full - a stream's
+					// first batch on a 960 Mbp graph sent 7.5 M of 42 M extensions through its 2 048 lanes for 2.4 s before the host sized the pool again)
+					const bool poolFull = L.status == EXT_POOL_FULL;
+					res.status = poolFull ? (uint32_t)EXT_OVERFLOW : L.status;
 					res.score = L.resultScore;
 					res.traceOff = L.status == EXT_OK ? L.traceBase : 0;
 					res.traceLen = L.status == EXT_OK ? L.nTrace : 0;
 					res.pad = L.status == EXT_OK ? L.tie : 0;
 					results[L.work] = res;
-					if (L.status == EXT_OVERFLOW) { retryList[atomicAdd(retryCount, 1ull)] = L.work; atomicAdd(&waveCounters[6], 1u); }   // declined: the plain-layout kernel runs it (and counts its work)
+					if (poolFull) {}
+					else if (L.status == EXT_OVERFLOW) { retryList[atomicAdd(retryCount, 1ull)] = L.work; atomicAdd(&waveCounters[6], 1u); }   // declined: the plain-layout kernel runs it (and counts its work)
 					else {
 						const bool flat = L.len < 64;
 						const uint32_t dpTiles = L.cntTiles & 0xffffu, btTiles = L.cntTiles >> 16, dpCols = L.cntCols & 0xffffu, btCols = L.cntCols >> 16;
@@ -188,7 +192,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 				pieceNext += total;
 				if (walk) {
 					L.traceBase = base + incl - L.traceCap;
-					if (L.traceBase + L.traceCap > traceCapacity) fragRetire(L, EXT_OVERFLOW);   // the pool is full: the host sizes it again and runs the stage again (fragmentPoolsOverflowed)
+					if (L.traceBase + L.traceCap > traceCapacity) fragRetire(L, EXT_POOL_FULL);   // the pool is full: the host sizes it again and runs the stage again (fragmentPoolsOverflowed)
 					else fragWalkBegin(L, m);
 				}
 			}

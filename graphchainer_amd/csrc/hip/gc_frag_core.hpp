@@ -28,6 +28,7 @@ namespace gcfrag {
 using namespace gcdev;
 
 enum : uint32_t { PH_IDLE = 0, PH_FETCH = 1, PH_POP = 2, PH_COLS = 3, PH_TILE_END = 4, PH_FINISH = 5, PH_WALK = 6 };
+enum : uint32_t { EXT_POOL_FULL = 8u };   // (inside the kernel only: the shared trace pool had no room for the walk's cells)
 enum : uint32_t { TF_START = 1u, TF_WALK = 2u };   // Lane::tileFlags: the tile is the seed's node (the only one with a previous-slice twin); the column loop refills the walk's ring
 
 #ifndef GC_FRAG_QUEUE

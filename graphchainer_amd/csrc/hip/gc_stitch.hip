@@ -403,7 +403,10 @@ void launchStitch(hipStream_t stream, const DGraph& g, const ReadChainJob* jobs,
 	const uint32_t setSize = sizeClass == 3 ? STITCH_SPILL_SET_SLOTS : STITCH_SET_SIZE_LARGE, capBfs = sizeClass == 1 ? STITCH_BFS_CAP_LARGE / 2 : STITCH_BFS_CAP_LARGE;
 	setMax = setMax && setMax < setSize / 2 ? setMax : setSize / 2;
 	bfsCap = bfsCap && bfsCap < capBfs ? bfsCap : capBfs;   // (of the LDS search; the wide search of class 3 holds STITCH_SPILL_BFS_CAP)
-	uint32_t blocks = sizeClass == 3 ? stitchSpillBlocks(nReads) : (nReads < 16384u ? nReads : 16384u);
+#ifndef GC_STITCH_BLOCKS
+#define GC_STITCH_BLOCKS 16384u
+#endif
+	uint32_t blocks = sizeClass == 3 ? stitchSpillBlocks(nReads) : (nReads < GC_STITCH_BLOCKS ? nReads : GC_STITCH_BLOCKS);
 #define GC_LAUNCH_STITCH(SET, CAP, SPILL) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stitch<SET, CAP, SPILL>), dim3(blocks), dim3(64), 0, stream, g, jobs, nReads, anchors, frags, fragStatus, chainOut, chainLen, chainStatus, pathPool, pathCapacity, colinearGap, setMax, bfsCap, \
 		slotOf, regions, dense, denseCap, denseCursor, info, spill)
 	if (sizeClass == 3) {

@@ -21,7 +21,7 @@ try:
 except Exception as e:
     print("no bench line:", e)
 PY
-  timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$b -o s -- python3 $GRAFT_REPO_ROOT/bench.py --config 5 --backbone $b --setup-dir $setup --no-cpu-baseline --e2e-steps 0 --steps 3 --warmup 1 $CFG5_ARGS > $out/stats_$b.log 2>&1
+  timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$b -o s -- python3 $GRAFT_REPO_ROOT/bench.py --config 5 --backbone $b --setup-dir $setup --no-cpu-baseline --e2e-steps 0 --steps ${CFG5_TRACE_STEPS:-8} --warmup 5 $CFG5_ARGS > $out/stats_$b.log 2>&1   # (r6: a steady state - warm-up batches first)
   f=$(find $out/stats_$b -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $out/kernel_stats_$b.csv
   python3 - $out/kernel_stats_$b.csv <<'PY'
@@ -42,11 +42,15 @@ PY
   fi
   if [ -n "$CFG5_PMC" ]; then
     timeout 1500 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY --kernel-trace --output-format csv -d $out/pmc_$b -o p -- python3 $GRAFT_REPO_ROOT/bench.py --config 5 --backbone $b --setup-dir $setup --no-cpu-baseline --e2e-steps 0 --steps 1 --warmup 0 --inflight 1 $CFG5_ARGS > $out/pmc_$b.log 2>&1
+    # r6: HBM traffic, one counter per pass
+    for c in FETCH_SIZE WRITE_SIZE; do
+      timeout 1500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${b}_$c -o p -- python3 $GRAFT_REPO_ROOT/bench.py --config 5 --backbone $b --setup-dir $setup --no-cpu-baseline --e2e-steps 0 --steps 1 --warmup 0 --inflight 1 $CFG5_ARGS > $out/pmc_${b}_$c.log 2>&1
+    done
     python3 - $out pmc_$b <<'PY'
 import csv, glob, sys, collections
 out, sub = sys.argv[1], sys.argv[2]
 tot = collections.defaultdict(float)
-for f in glob.glob(f"{out}/{sub}/**/*counter_collection.csv", recursive=True):
+for f in glob.glob(f"{out}/{sub}*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void gcdev::", "").replace("gcdev::", "")
         tot[(name[:34], r["Counter_Name"])] += float(r["Counter_Value"])
@@ -55,7 +59,7 @@ with open(f"{out}/{sub}_summary.txt", "w") as o:
         o.write(f"{k[0]:36s} {k[1]:22s} {tot[k]:.4e}\n")
 print("pmc summary written")
 PY
-    rm -rf $out/pmc_$b
+    rm -rf $out/pmc_$b $out/pmc_${b}_FETCH_SIZE $out/pmc_${b}_WRITE_SIZE
   fi
   rm -rf $setup
 done
