@@ -525,7 +525,8 @@ def main():
         e2e_workers = inflight + 3
         legs = [("gaf", "gaf", None)] if "gaf" in args.e2e_formats.split(",") else []
         if "gam" in args.e2e_formats.split(","):
-            legs += [("gam", "gam", None), ("gam_level1", "gam", 1), ("gam_device_huffman", "gam", gca.GAM_DEVICE_HUFFMAN)]
+            # (r6: gc_format_gam's own default is the device's LZ77 + Huffman deflate; level -1 = zlib's default on the host, the reference's setting)
+            legs += [("gam", "gam", None), ("gam_zlib_default", "gam", -1), ("gam_level1", "gam", 1), ("gam_device_huffman", "gam", gca.GAM_DEVICE_HUFFMAN)]
         if "json" in args.e2e_formats.split(","):
             legs += [("json", "json", None)]                          # (r6; src/Aligner.cpp:286-293: one vg::Alignment per line through protobuf's JSON mapping)
         json_seen = {}
@@ -591,8 +592,10 @@ def main():
             if fmt == "gam":
                 if level == gca.GAM_DEVICE_HUFFMAN:
                     rec["gzip"] = "deflated on the device (hip/gc_deflate.hip: one dynamic-Huffman block of literals per read, no LZ77 matches); the host frames the members and computes their CRC-32s"
+                elif level is None:
+                    rec["gzip"] = "gc_format_gam's default (r6): deflated on the device with LZ77 matches in front of the Huffman stage (GC_GAM_DEVICE_LZ, hip/gc_deflate.hip); the host frames the members and computes their CRC-32s"
                 else:
-                    rec["gzip"] = "zlib level " + ("default (6), as the reference's GzipOutputStream" if level is None else str(level)) + ": deflate is host work the reference pays too, ~1 ms of CPU per 10 kb read at the default level"
+                    rec["gzip"] = "zlib level " + ("default (6), as the reference's GzipOutputStream" if level == -1 else str(level)) + ": deflate is host work the reference pays too, ~1 ms of CPU per 10 kb read at the default level"
                 if leg in gam_inflated:
                     rec["inflated_bytes_batch0"], rec["inflated_crc32_batch0"] = gam_inflated[leg]
             if fmt == "gaf" and kept:

@@ -5,4 +5,4 @@ this package is its Python host side. Importing the package does not load the li
 loudly when the library or a GPU is missing.
 """
 from . import api  # noqa: F401
-from .api import GAM_DEVICE_HUFFMAN, Aligner, AlignmentGraph, MinimizerSeeder, ReadBatch, device_count, device_memory, edit_distance, gzip_streams, load_library, set_device, std_sort_permutations  # noqa: F401
+from .api import GAM_DEVICE_HUFFMAN, GAM_DEVICE_LZ, Aligner, AlignmentGraph, MinimizerSeeder, ReadBatch, device_count, device_memory, edit_distance, gzip_streams, load_library, set_device, std_sort_permutations  # noqa: F401

@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "gc_params_default", "gc_graph_create_from_gfa", "gc_graph_create", "gc_graph_destroy", "gc_graph_num_nodes",
     "gc_graph_size_bp", "gc_graph_array", "gc_seeder_create", "gc_seeder_destroy", "gc_seeder_array",
     "gc_stream_create", "gc_stream_destroy", "gc_reads_upload", "gc_reads_destroy", "gc_align_batch",
-    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_device_memory", "gc_edit_distance", "gc_edit_path", "gc_evalue", "gc_format_gaf", "gc_format_json", "gc_format_gam", "gc_format_gam_level", "gc_gzip_streams", "gc_format_gaf_trace", "gc_format_vg_trace", "gc_format_vg_trace_digraph", "gc_graph_letters", "gc_std_sort_permutations",
+    "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_device_memory", "gc_edit_distance", "gc_edit_path", "gc_evalue", "gc_format_gaf", "gc_format_json", "gc_format_gam", "gc_format_gam_level", "gc_gzip_streams", "gc_gzip_streams_lz", "gc_format_gaf_trace", "gc_format_vg_trace", "gc_format_vg_trace_digraph", "gc_graph_letters", "gc_std_sort_permutations",
     "gc_index_build", "gc_index_save", "gc_index_load", "gc_index_check", "gc_result_cache_trim",
 ]
 
@@ -170,6 +170,7 @@ def edit_path(a_list, b_list):
 
 
 GAM_DEVICE_HUFFMAN = 100   # GC_GAM_DEVICE_HUFFMAN: gam_level value that has the gzip members deflated on the device
+GAM_DEVICE_LZ = 101        # GC_GAM_DEVICE_LZ (r6): ... with LZ77 matches in front of the Huffman stage
 
 
 def std_sort_permutations(arrays, depth_limit=-1):
@@ -185,8 +186,9 @@ def std_sort_permutations(arrays, depth_limit=-1):
     return [perm[int(off[i]):int(off[i + 1])] for i in range(len(arrays))]
 
 
-def gzip_streams(streams):
-    """One gzip member per byte string, deflated on the GPU as one dynamic-Huffman block of literals (what gam_level=GAM_DEVICE_HUFFMAN does with a batch's GAM groups)."""
+def gzip_streams(streams, lz=False):
+    """One gzip member per byte string, deflated on the GPU as one dynamic-Huffman block of literals (what gam_level=GAM_DEVICE_HUFFMAN does with a batch's GAM groups);
+    lz: with LZ77 matches in front of the Huffman stage (GAM_DEVICE_LZ)."""
     lib = load_library()
     n = len(streams)
     raw = b"".join(streams)
@@ -194,9 +196,10 @@ def gzip_streams(streams):
     off[1:] = np.cumsum([len(x) for x in streams], dtype=np.uint64) if n else []
     out_off = np.zeros(n + 1, dtype=np.uint64)
     ptr = C.c_void_p()
-    lib.gc_gzip_streams.restype = C.c_int
-    lib.gc_gzip_streams.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, _P(C.c_void_p), C.c_void_p]
-    _check(lib.gc_gzip_streams(raw, off.ctypes.data, n, C.byref(ptr), out_off.ctypes.data))
+    fn = lib.gc_gzip_streams_lz if lz else lib.gc_gzip_streams
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, _P(C.c_void_p), C.c_void_p]
+    _check(fn(raw, off.ctypes.data, n, C.byref(ptr), out_off.ctypes.data))
     data = C.string_at(ptr.value, int(out_off[n]))
     lib.gc_free(ptr)
     return [data[int(out_off[i]):int(out_off[i + 1])] for i in range(n)]

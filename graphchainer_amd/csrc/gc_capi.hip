@@ -106,7 +106,7 @@ enum OutputKind { OUT_GAF, OUT_JSON, OUT_GAM };
 
 // GC_GAM_DEVICE_HUFFMAN: every non-empty element of `groups` (a read's uncompressed group) becomes its gzip member, deflated on the device (hip/gc_deflate.hip: one
 // dynamic-Huffman block of literals per read). The host stages the bytes in pinned memory, frames the members and computes their CRC-32s.
-static void gzipGroupsOnDevice(std::vector<std::string>& groups, bool skipEmpty = true)
+static void gzipGroupsOnDevice(std::vector<std::string>& groups, bool skipEmpty = true, bool lz = false)   // lz (r6, GC_GAM_DEVICE_LZ): LZ77 matches in front of the Huffman stage
 {
 	std::vector<uint32_t> which;
 	std::vector<uint64_t> rawOff { 0 };
@@ -120,7 +120,7 @@ static void gzipGroupsOnDevice(std::vector<std::string>& groups, bool skipEmpty 
 	const uint64_t outBound = rawTotal + 5 * (rawTotal / 65535 + m) + 4 * m;   // stored blocks are the worst case the plan accepts; 4-byte placement
 	size_t at = 0;
 	auto part = [&](size_t bytes) { const size_t here = at; at += (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; return here; };
-	const size_t oRaw = part(rawTotal), oRawOff = part((m + 1) * sizeof(uint64_t)), oLens = part(m * 260), oPlan = part(m * sizeof(uint2)), oOutOff = part((m + 1) * sizeof(uint64_t)), oOut = part(outBound);
+	const size_t oRaw = part(rawTotal), oRawOff = part((m + 1) * sizeof(uint64_t)), oLens = part(m * (size_t)std::max(260u, deflateLzLensStride())), oPlan = part(m * sizeof(uint2)), oOutOff = part((m + 1) * sizeof(uint64_t)), oOut = part(outBound);
 	size_t deviceBytes = 0, pinnedBytes = 0;
 	hipStream_t q = threadStream(device);
 	// (the guards wait for the stream before a block goes back to its cache: on an exception between a launch and the wait below the block would otherwise be handed to the next caller
@@ -136,7 +136,7 @@ static void gzipGroupsOnDevice(std::vector<std::string>& groups, bool skipEmpty 
 	memcpy(H + hRawOff, rawOff.data(), (m + 1) * sizeof(uint64_t));
 	if (rawTotal) HIP_CHECK(hipMemcpyAsync(D + oRaw, H + hRaw, rawTotal, hipMemcpyHostToDevice, q));
 	HIP_CHECK(hipMemcpyAsync(D + oRawOff, H + hRawOff, (m + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, q));
-	launchDeflatePlan(q, (const uint8_t*)(D + oRaw), (const uint64_t*)(D + oRawOff), (uint32_t)m, (uint8_t*)(D + oLens), (uint2*)(D + oPlan));
+	(lz ? launchDeflateLzPlan : launchDeflatePlan)(q, (const uint8_t*)(D + oRaw), (const uint64_t*)(D + oRawOff), (uint32_t)m, (uint8_t*)(D + oLens), (uint2*)(D + oPlan));
 	HIP_CHECK(hipMemcpyAsync(H + hPlan, D + oPlan, m * sizeof(uint2), hipMemcpyDeviceToHost, q));
 	HIP_CHECK(hipStreamSynchronize(q));
 	const uint2* plan = (const uint2*)(H + hPlan);
@@ -145,7 +145,7 @@ static void gzipGroupsOnDevice(std::vector<std::string>& groups, bool skipEmpty 
 	for (size_t k = 0; k < m; k++) outOff[k + 1] = outOff[k] + (((uint64_t)plan[k].x + 3) & ~(uint64_t)3);
 	if (outOff[m] > outBound) throw std::runtime_error("device deflate: planned sizes exceed the bound");
 	HIP_CHECK(hipMemcpyAsync(D + oOutOff, outOff, (m + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, q));
-	launchDeflateWrite(q, (const uint8_t*)(D + oRaw), (const uint64_t*)(D + oRawOff), (uint32_t)m, (const uint8_t*)(D + oLens), (const uint2*)(D + oPlan), (uint8_t*)(D + oOut), (const uint64_t*)(D + oOutOff));
+	(lz ? launchDeflateLzWrite : launchDeflateWrite)(q, (const uint8_t*)(D + oRaw), (const uint64_t*)(D + oRawOff), (uint32_t)m, (const uint8_t*)(D + oLens), (const uint2*)(D + oPlan), (uint8_t*)(D + oOut), (const uint64_t*)(D + oOutOff));
 	HIP_CHECK(hipMemcpyAsync(H + hRaw, D + oOut, outOff[m], hipMemcpyDeviceToHost, q));
 	HIP_CHECK(hipStreamSynchronize(q));
 	WorkerPool::instance().run(m, [&](size_t k, size_t) { std::string& g = groups[which[k]]; g = gc::gzipMember((const uint8_t*)(H + hRaw + outOff[k]), plan[k].x, g); });
@@ -170,7 +170,7 @@ static int formatBatch(const gc_graph* G, const gc_result* r, const char* const*
 		const uint64_t n = r->n_reads;
 		std::vector<std::string> perRead(n);
 		std::atomic<uint64_t> skipped { 0 };
-		const bool onDevice = gamLevel == GC_GAM_DEVICE_HUFFMAN;
+		const bool onDevice = gamLevel == GC_GAM_DEVICE_HUFFMAN || gamLevel == GC_GAM_DEVICE_LZ;
 		auto group = [&](const std::vector<std::string>& messages) { return onDevice ? gc::gamGroupRaw(messages) : gc::gamGroup(messages, gamLevel); };
 		WorkerPool::instance().run(n, [&](size_t i, size_t) {
 			std::string& text = perRead[i];
@@ -238,7 +238,7 @@ static int formatBatch(const gc_graph* G, const gc_result* r, const char* const*
 			}
 			if (kind == OUT_GAM) text = group(messages);
 		});
-		if (kind == OUT_GAM && onDevice) gzipGroupsOnDevice(perRead);
+		if (kind == OUT_GAM && onDevice) gzipGroupsOnDevice(perRead, true, gamLevel == GC_GAM_DEVICE_LZ);
 		uint64_t total = 0;
 		for (const auto& t : perRead) total += t.size();
 		char* buf = (char*)malloc(total + 1);
@@ -264,7 +264,9 @@ int gc_format_json(const gc_graph* G, const gc_result* r, const char* const* rea
 }
 int gc_format_gam(const gc_graph* G, const gc_result* r, const char* const* read_names, const char* bases, const uint64_t* offsets, char** out_bytes, uint64_t* out_len, uint64_t* n_chained_skipped)
 {
-	return formatBatch(G, r, read_names, bases, offsets, OUT_GAM, 0, out_bytes, out_len, n_chained_skipped);
+	// r6: without a level the members are deflated on the device with LZ77 matches (GC_GAM_DEVICE_LZ): the inflated stream is the contract - the reference's own bytes depend on its
+	// zlib build - and zlib's default level on the host is a fifth of the hot path's rate (gc_format_gam_level(-1) still gives it)
+	return formatBatch(G, r, read_names, bases, offsets, OUT_GAM, 0, out_bytes, out_len, n_chained_skipped, GC_GAM_DEVICE_LZ);
 }
 
 // gc_result_free keeps the large arrays of freed results (up to 24 GB) for the next batch instead of returning them to the allocator; this returns them.
@@ -341,19 +343,22 @@ int gc_graph_letters(const gc_graph* G, const int32_t* node, const uint32_t* off
 
 int gc_format_gam_level(const gc_graph* G, const gc_result* r, const char* const* read_names, const char* bases, const uint64_t* offsets, int level, char** out_bytes, uint64_t* out_len, uint64_t* n_chained_skipped)
 {
-	if ((level < -1 || level > 9) && level != GC_GAM_DEVICE_HUFFMAN) return fail(GC_ERR_INVALID, "gc_format_gam_level: zlib levels are -1 (default) and 0..9, or GC_GAM_DEVICE_HUFFMAN");
+	if ((level < -1 || level > 9) && level != GC_GAM_DEVICE_HUFFMAN && level != GC_GAM_DEVICE_LZ) return fail(GC_ERR_INVALID, "gc_format_gam_level: zlib levels are -1 (default) and 0..9, or GC_GAM_DEVICE_HUFFMAN / GC_GAM_DEVICE_LZ");
 	return formatBatch(G, r, read_names, bases, offsets, OUT_GAM, 0, out_bytes, out_len, n_chained_skipped, level);
 }
 
-// gzip members of independent byte streams, deflated on the device as GC_GAM_DEVICE_HUFFMAN does for the GAM groups (an empty stream gives an empty member)
-int gc_gzip_streams(const uint8_t* bytes, const uint64_t* offsets, uint64_t n, char** out_bytes, uint64_t* out_offsets)
+// gzip members of independent byte streams, deflated on the device as GC_GAM_DEVICE_HUFFMAN / GC_GAM_DEVICE_LZ do for the GAM groups (an empty stream gives an empty member)
+static int gzipStreams(const uint8_t* bytes, const uint64_t* offsets, uint64_t n, char** out_bytes, uint64_t* out_offsets, bool lz);
+int gc_gzip_streams(const uint8_t* bytes, const uint64_t* offsets, uint64_t n, char** out_bytes, uint64_t* out_offsets) { return gzipStreams(bytes, offsets, n, out_bytes, out_offsets, false); }
+int gc_gzip_streams_lz(const uint8_t* bytes, const uint64_t* offsets, uint64_t n, char** out_bytes, uint64_t* out_offsets) { return gzipStreams(bytes, offsets, n, out_bytes, out_offsets, true); }
+static int gzipStreams(const uint8_t* bytes, const uint64_t* offsets, uint64_t n, char** out_bytes, uint64_t* out_offsets, bool lz)
 {
 	if (!offsets || !out_bytes || !out_offsets || (offsets[n] && !bytes)) return fail(GC_ERR_INVALID, "null argument");
 	for (uint64_t i = 0; i < n; i++) if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] >= (1ull << 32)) return fail(GC_ERR_INVALID, "gc_gzip_streams: offsets must ascend, streams below 4 GB");
 	return guarded([&]() {
 		std::vector<std::string> groups(n);
 		for (uint64_t i = 0; i < n; i++) groups[i].assign((const char*)bytes + offsets[i], (const char*)bytes + offsets[i + 1]);
-		gzipGroupsOnDevice(groups, false);
+		gzipGroupsOnDevice(groups, false, lz);
 		out_offsets[0] = 0;
 		for (uint64_t i = 0; i < n; i++) out_offsets[i + 1] = out_offsets[i] + groups[i].size();
 		char* buf = (char*)malloc(out_offsets[n] + 1);

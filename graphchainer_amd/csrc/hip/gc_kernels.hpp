@@ -311,6 +311,10 @@ void launchOutWrite(hipStream_t stream, const DGraph& g, const OutNames& names, 
 // would be deeper than 15 bits). plan[s] = { deflate bytes, mode }, lens[260 * s + symbol]; the caller places stream s at a 4-byte aligned outOff[s] with room for plan[s].x rounded up to 4
 void launchDeflatePlan(hipStream_t stream, const uint8_t* raw, const uint64_t* rawOff, uint32_t nStreams, uint8_t* lens, uint2* plan);
 void launchDeflateWrite(hipStream_t stream, const uint8_t* raw, const uint64_t* rawOff, uint32_t nStreams, const uint8_t* lens, const uint2* plan, uint8_t* out, const uint64_t* outOff);
+// r6: the same with LZ77 matches in front of the Huffman stage (one probe of a hash of 4-byte prefixes per position, greedy); lens: deflateLzLensStride() bytes per stream
+uint32_t deflateLzLensStride();
+void launchDeflateLzPlan(hipStream_t stream, const uint8_t* raw, const uint64_t* rawOff, uint32_t nStreams, uint8_t* lens, uint2* plan);
+void launchDeflateLzWrite(hipStream_t stream, const uint8_t* raw, const uint64_t* rawOff, uint32_t nStreams, const uint8_t* lens, const uint2* plan, uint8_t* out, const uint64_t* outOff);
 // ---- minimizer index construction on the device (gc_minimizer.hip): the graph's window minimizers as (k-mer << 34 | reversed
 // arrival index, packed position) pairs, sorted; returns their number (~0 on failure: the caller builds on the host), arrays are hipMalloc'd
 uint64_t buildMinimizerPairsDevice(const DGraph& g, const int32_t* idOrderDev, uint32_t nIds, uint32_t k, uint32_t w, uint64_t** outKeys, uint64_t** outValues);

@@ -303,7 +303,8 @@ int gc_format_gaf(const gc_graph* g, const gc_result* result, const char* const*
  * replaceDigraphNodeIdsWithOriginalNodeIds): JSON lines as MessageToJsonString(preserve_proto_field_names) prints them
  * (writeJSONToQueue, src/Aligner.cpp:283-298), or GAM: per read one gzip member holding varint count + (varint size, proto3
  * bytes) per alignment (writeGAMToQueue, src/Aligner.cpp:261-281; the gzip bytes depend on the zlib build, the inflated
- * stream is the reference's). */
+ * stream is the reference's). r6: gc_format_gam deflates the members on the device (GC_GAM_DEVICE_LZ below; needs the GPU);
+ * gc_format_gam_level(-1) is zlib's default level on the host, the reference's own setting. */
 int gc_format_json(const gc_graph* g, const gc_result* result, const char* const* read_names, const char* bases, const uint64_t* offsets,
                    char** out_text, uint64_t* out_len, uint64_t* n_chained_skipped);
 int gc_format_gam(const gc_graph* g, const gc_result* result, const char* const* read_names, const char* bases, const uint64_t* offsets,
@@ -333,12 +334,17 @@ int gc_graph_letters(const gc_graph* g, const int32_t* node, const uint32_t* off
  * deflated on the device, every read's group as one dynamic-Huffman block of literals (no LZ77 matches: a larger file than zlib's, the same inflated stream, and the host
  * only frames the members and computes their CRC-32s). */
 #define GC_GAM_DEVICE_HUFFMAN 100
+/* r6: the same with LZ77 matches in front of the Huffman stage (one probe of a hash of 4-byte prefixes per position, greedy parse): ~1.2 x zlib's default bytes instead of 2 x,
+ * the same inflated stream; what the reference's GzipOutputStream costs the host (src/Aligner.cpp:261-281) stays on the device. */
+#define GC_GAM_DEVICE_LZ 101
 int gc_format_gam_level(const gc_graph* g, const gc_result* result, const char* const* read_names, const char* bases, const uint64_t* offsets, int level,
                         char** out_bytes, uint64_t* out_len, uint64_t* n_chained_skipped);
 
 /* The device deflate behind GC_GAM_DEVICE_HUFFMAN on the caller's own byte streams: stream i = bytes[offsets[i] .. offsets[i+1]) becomes the gzip member
  * out_bytes[out_offsets[i] .. out_offsets[i+1]) (out_offsets: n + 1 entries, caller's; out_bytes: gc_free). */
 int gc_gzip_streams(const uint8_t* bytes, const uint64_t* offsets, uint64_t n, char** out_bytes, uint64_t* out_offsets);
+/* ... and the deflate behind GC_GAM_DEVICE_LZ (r6; no counterpart in the reference: its gzip layer is protobuf's GzipOutputStream, src/Aligner.cpp:261-281) */
+int gc_gzip_streams_lz(const uint8_t* bytes, const uint64_t* offsets, uint64_t n, char** out_bytes, uint64_t* out_offsets);
 
 /* Test entry (no counterpart in the reference): the permutation the device's replay of libstdc++'s std::sort gives for arrays of 32-bit keys. The reference feeds three UNSTABLE
  * std::sort calls into order-sensitive logic (src/MinimizerSeeder.cpp:497, src/GraphAligner.h:293, src/Aligner.cpp:667), so the permutation libstdc++ produces for equal keys is

@@ -956,10 +956,48 @@ def test_gam_deflated_on_device(gca, tmp_path):
     seeder = gca.MinimizerSeeder(graph)
     for kw in ({"keep_traces": True}, {"device_output": 1 | 4}):
         aligner = gca.Aligner(graph, seeder, long_pass=True, **kw)
-        want = aligner.align_reads(reads, gaf_names=names, formats=("gam",))["gam"]
+        want = aligner.align_reads(reads, gaf_names=names, formats=("gam",), gam_level=-1)["gam"]      # zlib's default level on the host, the reference's own setting
         got = aligner.align_reads(reads, gaf_names=names, formats=("gam",), gam_level=gca.GAM_DEVICE_HUFFMAN)["gam"]
         assert got != want and gzip.decompress(got) == gzip.decompress(want) and len(gzip.decompress(got)) > 30_000
         assert len(got) < 0.6 * len(gzip.decompress(got))
+        # r6: LZ77 matches in front of the Huffman stage - the same inflated stream, within 1.35 x of zlib's default level where literal-only blocks are ~2 x
+        lz = aligner.align_reads(reads, gaf_names=names, formats=("gam",), gam_level=gca.GAM_DEVICE_LZ)["gam"]
+        assert gzip.decompress(lz) == gzip.decompress(want) and len(lz) < 0.8 * len(got) and len(lz) < 1.35 * len(want), (len(lz), len(got), len(want))
+        assert aligner.align_reads(reads, gaf_names=names, formats=("gam",))["gam"] == lz                  # ... and what gc_format_gam gives when no level is asked for
+
+
+def test_device_lz_deflate_equals_its_model(gca):
+    """The device's LZ77 + dynamic-Huffman deflate (GC_GAM_DEVICE_LZ, hip/gc_deflate.hip) against tests/deflate_model.py, the same algorithm in plain Python whose output zlib
+    inflates: every stream's member inflates to the stream, and its deflate bytes are the model's byte for byte - empty and tiny streams (stored blocks), one letter repeated
+    (overlapping matches of the maximum length), random bytes (no matches: an empty distance alphabet), text with repeats, lengths around the 64-position chunks, a stream
+    beyond one stored block's 65 535 bytes."""
+    import gzip
+    import random
+    import sys
+    import zlib
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from deflate_model import deflate
+    rnd = random.Random(5)
+    text = b"Mapping{position{node_id:%d offset:%d} edit{from_length:%d to_length:%d}} "
+    streams = [b"", b"a", b"abc", b"abcd", b"A" * 5000, bytes(rnd.randrange(256) for _ in range(3000)),
+               b"".join(text % (rnd.randrange(900), rnd.randrange(64), rnd.randrange(40), rnd.randrange(40)) for _ in range(400)),
+               bytes(rnd.choice(b"ACGT") for _ in range(10_000)), b"xyz" * 21 + b"q", b"0123456789abcdef" * 4, b"0123456789abcdef" * 4 + b"0",
+               bytes(rnd.choice(b"ACGT") for _ in range(40_000)) + b"".join(text % (i % 7, i % 5, 3, 3) for i in range(600))]
+    for lz in (True, False):
+        members = gca.gzip_streams(streams, lz=lz)
+        assert len(members) == len(streams)
+        for raw, member in zip(streams, members):
+            assert gzip.decompress(member) == raw
+    members = gca.gzip_streams(streams, lz=True)
+    for raw, member in zip(streams, members):
+        body = member[10:-8]                               # between the ten-byte gzip header and CRC-32 + length
+        assert zlib.decompress(body, -15) == raw
+        want, _tokens = deflate(raw) if raw else (b"", None)
+        stored = len(raw) + 5 * max(1, (len(raw) + 65534) // 65535)
+        if raw and len(want) < stored:
+            assert body == want, (len(raw), len(body), len(want))
+        else:
+            assert len(body) == stored
 
 
 def test_long_reads(gca, tmp_path, monkeypatch):
