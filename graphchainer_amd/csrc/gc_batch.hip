@@ -170,6 +170,7 @@ struct BatchRun {
 		chainedAlignments(); stageDone(7);
 		encodeOutput(); stageDone(8);
 		assemble(); stageDone(9);
+		st->fragShare = (double)res->counters[4] / (double)std::max<uint64_t>(1, R->totalBases);
 		st->batchesDone++;
 		if (cpuStages)
 			fprintf(stderr, "[gc cpu] main thread, ms of its own CPU: seeds %.1f, whole-read set-up %.1f + start %.1f, fragment pipeline %.1f, results back %.1f, stitching + chain distances %.1f, join %.1f, chained alignments %.1f, output %.1f, assembly %.1f; pass thread %.1f\n",

@@ -143,11 +143,14 @@ inline const char* expEnv(const char*) { return nullptr; }
 // a pass that fills it (10 k x 10 kb: 20 000 items) keeps the device to itself (two side by side measured slower in r4). GC_LONG_TOKENS=1|2 overrides (read per batch: the tests switch
 // inside one process). The second token has a scratch of its own and is only taken when the device has the memory for it.
 inline constexpr uint64_t LONG_WAVE_SLOTS = 5120;
-inline int longTokenCount(uint64_t nReads, uint64_t streamBatchesDone)
+// r6: ... and only while the fragment pipeline leaves the device room for it, told by the fragment extensions the stream's previous batch ran per read base (a count, not a time:
+// times under five batches in flight are residencies, and a rule on them would feed back on itself). On a 192 Mbp graph that is 0.09 and two passes side by side gave 4.2 -> 5.0 k
+// reads/s (r5); at 960 Mbp, where chance hits of 15-mers make it 0.42, the second pass that r6's freed memory suddenly had room for cost 4.31 -> 3.63 k (`gpurun_out/r6_cfg5_960p` / `_960q`)
+inline int longTokenCount(uint64_t nReads, uint64_t streamBatchesDone, double extensionsPerBase)
 {
 	if (const char* e = getenv("GC_LONG_TOKENS")) return std::max(1, std::min(LONG_TOKENS_MAX, atoi(e)));
 	// (a stream's first batch sizes its buffers - pools that rerun and grow: a second scratch taken while the device still looks empty cost config 5 at 960 Mbp its fifth stream)
-	return streamBatchesDone > 0 && 2 * nReads + 128 <= LONG_WAVE_SLOTS ? 2 : 1;
+	return streamBatchesDone > 0 && 2 * nReads + 128 <= LONG_WAVE_SLOTS && extensionsPerBase < 0.2 ? 2 : 1;
 }
 inline std::mutex g_longRoundToken[16];   // GC_LONG_TOKEN=2 (experiment): the token handed over per round
 // The pass's extension scratch (up to 48 GB: one region per resident wave) is only touched while the token is held, so the gc_streams of a device share ONE
@@ -595,6 +598,7 @@ struct gc_stream {
 		uint32_t nPairs = 0;
 	} edLong[2];
 	uint64_t longCellsPerBase = 4;           // merged-trace cells per read base the whole-read pass reserves (10 kb ONT-like reads use 1.1, 50 kb CLR-like reads on a genome with repeats 9-10; grows by what a batch asks for)
+	double fragShare = 0;                     // fragment extensions per read base in the stream's last batch (longTokenCount)
 	uint64_t batchesDone = 0;                 // batches this stream has finished (a second whole-read token is only taken from the second batch on: the first sizes the stream's buffers)
 	bool poolsRerun = false;                  // the last batch ran its fragment pipeline again with larger pools: the next one gives back what that overshot
 	double traceCellsPerSlot = 0, pathWordsPerSlot = 0;   // what this stream's batches have used of the fragment pipeline's trace pool / anchor path pool per anchor slot (0: no batch yet)
