@@ -1,8 +1,8 @@
 #!/bin/bash
-# r6: the fragment extension kernels with ONE batch in flight (the whole-read pass of the same batch still runs beside them): kernel stats, counters and HBM traffic of k_extend*
-# usage: bash scripts/gpu/r6_alone.sh <tag> [slab]      (slab: also the plain-layout kernel for everything, GC_EXTEND_SLAB=1)
+# the fragment extension kernels with ONE batch in flight (the whole-read pass of the same batch still runs beside them): kernel stats, counters and HBM traffic of k_extend*
+# usage: bash scripts/gpu/frag_alone.sh <tag> [slab]      (slab: also the plain-layout kernel for everything, GC_EXTEND_SLAB=1)
 cd $GRAFT_REPO_ROOT
-tag=${1:-r6_alone}
+tag=${1:-frag_alone}
 BENCH_ARGS="--inflight 1" bash scripts/gpu/kstats.sh ${tag}_frag | grep -i "extend\|build_anchors\|stitch\|edit\|chain\|glue"
 PMC_KERNELS="k_extend" BENCH_ARGS="--inflight 1" bash scripts/gpu/pmc.sh ${tag}_pmc_frag
 if [ "$2" = slab ]; then
