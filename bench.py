@@ -26,7 +26,9 @@ import json
 import os
 import sys
 import tempfile
+import threading
 import time
+import zlib
 
 import numpy as np
 
@@ -75,6 +77,10 @@ def parse_args():
     ap.add_argument("--setup-dir", default=os.environ.get("GC_BENCH_SETUP_DIR"),
                     help="keep the GFA, the reads and the index cache of this workload in this directory and reuse them when a later run asks for the same workload "
                          "(N=1; profiling runs of one gpurun call: a 960 Mbp graph costs five minutes to generate, build and save, 85 s to load)")
+    ap.add_argument("--no-index-cache", action="store_true", help="one rank: align on the graph and index as built, without writing the index cache and loading it back (config 5 at 3.1 Gbp: "
+                    "a 59 GB file, ~8 min of set-up)")
+    ap.add_argument("--host-memory-cap-gb", type=float, default=float(os.environ.get("GC_BENCH_HOST_CAP_GB", 0)), help="stop the run (exit 3) when the process's resident memory passes this: "
+                    "a run that would otherwise take its host out of memory ends by itself (0: 92 %% of the cgroup's memory.max when that is readable, else no cap)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("GC_BENCH_INFLIGHT", 5)),
                     help="batches in flight per GPU, each on its own gc_stream and host thread (like the reference's -t worker threads): one batch's seeding, fragment "
                          "pipeline, distances and assembly run beside another's whole-read pass (r5, ms per 10 k x 10 kb batch: " + ", ".join(f"{k} -> {v:.0f}" for k, v in sorted(BATCH_MS_BY_INFLIGHT.items())) + "; "
@@ -204,11 +210,65 @@ def launch_ranks(args, argv):
     return subprocess.run(cmd).returncode
 
 
+def host_memory_limit_bytes():
+    """The cgroup's memory limit (v2, then v1), None when there is none or it cannot be read."""
+    for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            text = open(path).read().strip()
+        except OSError:
+            continue
+        if text.isdigit() and int(text) < (1 << 60):
+            return int(text)
+    return None
+
+
+def resident_bytes():
+    """What counts against that limit and cannot be reclaimed: the cgroup's anonymous + shared memory when memory.stat is readable, else this process's VmRSS."""
+    try:
+        stat = dict(line.split() for line in open("/sys/fs/cgroup/memory.stat"))
+        return int(stat["anon"]) + int(stat.get("shmem", 0))
+    except (OSError, KeyError, ValueError):
+        pass
+    try:
+        for line in open("/proc/self/status"):
+            if line.startswith("VmRSS:"):
+                return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 0
+
+
+def start_host_memory_watchdog(cap_gb):
+    """A thread that ends the process (exit 3, one line on stderr) when resident memory passes the cap: the kernel's OOM kill takes more than the process with it on a shared box."""
+    cap = int(cap_gb * 2**30) if cap_gb > 0 else None
+    if cap is None:
+        limit = host_memory_limit_bytes()
+        cap = int(limit * 0.92) if limit else None
+    if cap is None:
+        return None
+    state = {"peak": 0}
+
+    def watch():
+        while True:
+            now = resident_bytes()
+            state["peak"] = max(state["peak"], now)
+            if now > cap:
+                sys.stderr.write(f"[bench] host memory {now / 2**30:.1f} GiB passed the cap of {cap / 2**30:.1f} GiB: stopping\n")
+                sys.stderr.flush()
+                os._exit(3)
+            time.sleep(0.25)
+
+    threading.Thread(target=watch, daemon=True).start()
+    state["cap_gb"] = round(cap / 2**30, 1)
+    return state
+
+
 def main():
     args = parse_args()
     rc = launch_ranks(args, sys.argv[1:])
     if rc is not None:
         sys.exit(rc)
+    memory_watch = start_host_memory_watchdog(args.host_memory_cap_gb)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before anything touches HIP: a batch in flight uses a dozen streams, five batches share the device (INTEGRATION.md §7)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -243,6 +303,7 @@ def main():
         sg = SynthGenome(args.chromosomes, args.backbone, seed=7, multi_allelic=0.1, nested=0.1, minus_links=0.3, repeats=4, repeat_len=3000)
         sg.write_gfa(gfa)
         reads = sg.sample_reads(args.reads, args.read_len, seed=11 + (0 if strong else rank), p_del=0.04, p_sub=0.02, p_ins=0.09)
+        sg = None                                          # (3.5 bytes per graph base: nothing below draws from it again)
     else:
         sg = SynthGraph(args.backbone, seed=7)
         if rank == 0:
@@ -319,6 +380,8 @@ def main():
         cache = os.path.join(args.setup_dir, "index.gcidx")
     t_graph = t_index = t_save = t_load = 0.0
     cache_bytes = 0
+    use_cache = not (args.no_index_cache and world == 1)
+    built = None
     if rank == 0 and not setup_reused:
         t0 = time.time()
         graph = gca.AlignmentGraph(gfa)
@@ -326,25 +389,34 @@ def main():
         t0 = time.time()
         seeder = gca.MinimizerSeeder(graph)
         t_index = time.time() - t0
+        if use_cache:
+            t0 = time.time()
+            gca.api.save_index_cache(graph, seeder, cache)
+            t_save = time.time() - t0
+            cache_bytes = os.path.getsize(cache)
+            # ONE host copy of graph and index at a time (r6): up to r5 the built objects stayed while the cache was loaded beside them to be compared, and that - 2 x 74 B of host
+            # memory per graph base + the upload's staging copies - was the "175 B per base" that kept config 5 at 1.25 Gbp on a 300 GiB host. What the comparison needs is kept instead.
+            positions = seeder.array("positions")
+            built = (graph.NodeSize(), len(positions), zlib.crc32(positions.tobytes() if len(positions) < (1 << 27) else positions[:: max(1, len(positions) >> 26)].tobytes()))
+            del positions
+            seeder.close(); graph.close()
+            graph = seeder = None
+    if dist is not None:
+        dist.barrier()
+    if use_cache:
         t0 = time.time()
-        gca.api.save_index_cache(graph, seeder, cache)
-        t_save = time.time() - t0
-        cache_bytes = os.path.getsize(cache)
+        graph, seeder = gca.api.load_index_cache(cache)
+        t_load = time.time() - t0
+        if built is not None:
+            positions = seeder.array("positions")
+            loaded = (graph.NodeSize(), len(positions), zlib.crc32(positions.tobytes() if len(positions) < (1 << 27) else positions[:: max(1, len(positions) >> 26)].tobytes()))
+            del positions
+            if loaded != built:
+                raise SystemExit("index cache does not reproduce the built index")
+    graph.trim_host()   # nothing below writes the cache again: the host copy of the MPC index (33 B per graph base) goes back to the system
     if dist is not None:
         dist.barrier()
-    t0 = time.time()
-    loaded_graph, loaded_seeder = gca.api.load_index_cache(cache)
-    t_load = time.time() - t0
-    if rank == 0 and not setup_reused:
-        if loaded_graph.NodeSize() != graph.NodeSize() or not np.array_equal(loaded_seeder.array("positions"), seeder.array("positions")):
-            raise SystemExit("index cache does not reproduce the built index")
-        loaded_seeder.close()
-        loaded_graph.close()
-    else:
-        graph, seeder = loaded_graph, loaded_seeder
-    if dist is not None:
-        dist.barrier()
-    if rank == 0 and not (args.setup_dir and world == 1):
+    if rank == 0 and use_cache and not (args.setup_dir and world == 1):
         os.remove(cache)
     if args.setup_dir and world == 1 and not setup_reused:
         json.dump(setup_key, open(os.path.join(args.setup_dir, "key.json"), "w"))
@@ -803,6 +875,7 @@ def main():
                         "index_cache_save": round(t_save, 1), "index_cache_load_upload": round(t_load, 1), "index_cache_bytes": cache_bytes or (os.path.getsize(cache) if os.path.exists(cache) else 0),
                         "reused_from_setup_dir": setup_reused},
             "inflight_for_device_memory": memory_choice,
+            "host_memory_watch": memory_watch and {"cap_gb": memory_watch["cap_gb"], "peak_gb": round(memory_watch["peak"] / 2**30, 1), "what": "anonymous + shared memory of the cgroup (memory.stat), else VmRSS, sampled every 0.25 s"},
             "host_peak_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 2**20, 1),   # (this process: the GFA in memory, the host graph and index, the batches)
             "reads_with_chain": int(reads_with_chain / steps), "extensions_per_step": int(counters[4]),
             "decision": {"chained_better": int(chained_better / steps), "mean_long_edit_distance": round(float(long_ed.mean()), 1) if len(long_ed) else None,

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("GC_LIBRARY") or os.path.join(_HERE, "libgraphchainer_
 
 EXPORTED_SYMBOLS = [
     "gc_params_default", "gc_graph_create_from_gfa", "gc_graph_create", "gc_graph_destroy", "gc_graph_num_nodes",
-    "gc_graph_size_bp", "gc_graph_array", "gc_seeder_create", "gc_seeder_destroy", "gc_seeder_array",
+    "gc_graph_size_bp", "gc_graph_array", "gc_graph_trim_host", "gc_seeder_create", "gc_seeder_destroy", "gc_seeder_array",
     "gc_stream_create", "gc_stream_destroy", "gc_reads_upload", "gc_reads_destroy", "gc_align_batch",
     "gc_result_free", "gc_last_error", "gc_free", "gc_device_count", "gc_set_device", "gc_device_memory", "gc_edit_distance", "gc_edit_path", "gc_evalue", "gc_format_gaf", "gc_format_json", "gc_format_gam", "gc_format_gam_level", "gc_gzip_streams", "gc_gzip_streams_lz", "gc_format_gaf_trace", "gc_format_vg_trace", "gc_format_vg_trace_digraph", "gc_graph_letters", "gc_std_sort_permutations",
     "gc_index_build", "gc_index_save", "gc_index_load", "gc_index_check", "gc_result_cache_trim",
@@ -88,6 +88,7 @@ def load_library():
     lib.gc_graph_size_bp.restype = C.c_uint64
     lib.gc_graph_size_bp.argtypes = [C.c_void_p]
     lib.gc_graph_array.argtypes = [C.c_void_p, C.c_char_p, _P(_P(C.c_int64)), _P(C.c_uint64)]
+    lib.gc_graph_trim_host.argtypes = [C.c_void_p]
     lib.gc_seeder_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double, _P(C.c_void_p)]
     lib.gc_seeder_destroy.argtypes = [C.c_void_p]
     lib.gc_seeder_array.argtypes = [C.c_void_p, C.c_char_p, _P(_P(C.c_int64)), _P(C.c_uint64)]
@@ -310,6 +311,10 @@ class AlignmentGraph:
 
     def array(self, name):
         return _fetch_array(self.lib.gc_graph_array, self.handle, name)
+
+    def trim_host(self):
+        """Release the host copy of the MPC index (gc_graph_trim_host): aligning does not read it, saving the index cache does."""
+        _check(self.lib.gc_graph_trim_host(self.handle))
 
     def close(self):
         if self.handle:

@@ -1,5 +1,7 @@
 // The C entry points of include/graphchainer_amd.h except gc_align_batch (gc_batch.hip): graphs, seeders, index cache, read batches, streams, edit distances, output formats.
 #include "gc_runtime.hpp"
+#include "host/gc_stageclock.hpp"
+#include <malloc.h>
 
 extern "C" {
 
@@ -450,9 +452,13 @@ int gc_graph_create_from_gfa(const char* gfa_path, gc_graph** out)
 	gc_graph* G = new gc_graph();
 	try {
 		requireDevice();
+		gc::StageClock clock;
 		G->host = gc::AlignmentGraph::BuildFromGFAFile(gfa_path);
 		G->host.buildMPC(true);
+		malloc_trim(0);   // (the builders' freed small blocks back to the system: the host graph stays, and at config 5's sizes the host's memory is what bounds the graph)
+		clock.lap("graph + MPC built");
 		uploadGraph(G);
+		clock.lap("graph uploaded");
 	} catch (const DeviceError& e) {
 		delete G;
 		return fail(GC_ERR_DEVICE, e.what());
@@ -536,9 +542,26 @@ void gc_graph_destroy(gc_graph* g) { delete g; }
 uint64_t gc_graph_num_nodes(const gc_graph* g) { return g ? g->host.NodeSize() : 0; }
 uint64_t gc_graph_size_bp(const gc_graph* g) { return g ? g->host.SizeInBP() : 0; }
 
+int gc_graph_trim_host(gc_graph* G)
+{
+	if (!G) return fail(GC_ERR_INVALID, "null argument");
+	gc::AlignmentGraph& h = G->host;
+	std::vector<std::vector<std::vector<size_t>>>().swap(h.mpc);
+	std::vector<std::vector<std::vector<size_t>>>().swap(h.paths);
+	std::vector<std::vector<std::vector<std::pair<size_t, size_t>>>>().swap(h.backwards);
+	std::vector<std::vector<size_t>>().swap(h.topo);
+	std::vector<std::vector<size_t>>().swap(h.topo_ids);
+	std::vector<std::vector<size_t>>().swap(h.component_ids);
+	G->hostMpcTrimmed = true;
+	malloc_trim(0);
+	return GC_OK;
+}
+
 int gc_graph_array(const gc_graph* G, const char* name, int64_t** out, uint64_t* count)
 {
 	if (!G || !name || !out || !count) return fail(GC_ERR_INVALID, "null argument");
+	if (G->hostMpcTrimmed && (strncmp(name, "mpc_", 4) == 0 || strncmp(name, "paths", 5) == 0 || strncmp(name, "back_", 5) == 0 || strcmp(name, "topo_id") == 0))
+		return fail(GC_ERR_INVALID, "the host copy of the MPC index was released (gc_graph_trim_host)");
 	const gc::AlignmentGraph& g = G->host;
 	std::vector<int64_t> v;
 	std::string nm = name;
@@ -711,6 +734,7 @@ int gc_index_save(const gc_graph* g, const gc_seeder* s, const char* cache_path)
 {
 	if (!g || !cache_path) return fail(GC_ERR_INVALID, "null argument");
 	try {
+		if (g->hostMpcTrimmed) return fail(GC_ERR_INVALID, "the host copy of the MPC index was released (gc_graph_trim_host): nothing to write the cache from");
 		gc::SaveIndexCache(cache_path, g->host, s ? &s->host : nullptr);
 	} catch (const std::exception& e) {
 		return fail(GC_ERR_GRAPH, e.what());

@@ -397,6 +397,7 @@ using namespace gcrt;
 // ----------------------------------------------------------------------------------------------------
 struct gc_graph {
 	gc::AlignmentGraph host;
+	bool hostMpcTrimmed = false;   // gc_graph_trim_host: host.mpc / paths / backwards / topo / topo_ids / component_ids are empty
 	// dense-by-bigraph-node-id copies of the twin lookup tables (the same arrays the device gets): original node size, and the
 	// split nodes of every bigraph node in offset order (chunk k covers offsets [64k, 64k+64))
 	std::vector<uint32_t> hOrigSize, hLookupOff, hLookup;
@@ -664,67 +665,95 @@ inline void uploadGraph(gc_graph* G)
 	const gc::AlignmentGraph& h = G->host;
 	size_t n = h.NodeSize();
 	if (n >= 0xfffffff0ull) throw std::runtime_error("graph too large for 32-bit node ids");
-	std::vector<uint8_t> nodeLength(n);
-	std::vector<uint32_t> nodeOffset(n), componentNumber(n), componentMap(n), topoId(n);
-	std::vector<int32_t> nodeIDs(n);
+	// Every staging array is uploaded and released before the next one is made: at 3.1 Gbp the flattened copies are ~90 GB together (28 B per graph base) beside a host graph
+	// of ~230 GB - too much for a 300 GiB host when they all live until the function returns, as they did up to r5
+	DGraph& d = G->dev;
+	d.nNodes = (uint32_t)n;
+	d.firstAmbiguous = (uint32_t)h.firstAmbiguous;
 	int maxId = -1;
-	for (size_t i = 0; i < n; i++) {
-		nodeLength[i] = (uint8_t)h.nodeLength[i];
-		nodeOffset[i] = (uint32_t)h.nodeOffset[i];
-		nodeIDs[i] = h.nodeIDs[i];
-		componentNumber[i] = (uint32_t)h.componentNumber[i];
-		componentMap[i] = (uint32_t)h.component_map[i];
-		topoId[i] = (uint32_t)h.topo_ids[h.component_map[i]][h.component_idx[i]];
-		maxId = std::max(maxId, h.nodeIDs[i]);
+	{
+		std::vector<uint8_t> nodeLength(n);
+		std::vector<uint32_t> nodeOffset(n);
+		std::vector<int32_t> nodeIDs(n);
+		for (size_t i = 0; i < n; i++) {
+			nodeLength[i] = (uint8_t)h.nodeLength[i];
+			nodeOffset[i] = (uint32_t)h.nodeOffset[i];
+			nodeIDs[i] = h.nodeIDs[i];
+			maxId = std::max(maxId, h.nodeIDs[i]);
+		}
+		d.nodeLength = G->up(nodeLength);
+		d.nodeOffset = G->up(nodeOffset);
+		d.nodeIDs = G->up(nodeIDs);
 	}
-	std::vector<uint64_t> nodeSeq(2 * h.firstAmbiguous), ambSeq(4 * (n - h.firstAmbiguous));
-	for (size_t i = 0; i < h.firstAmbiguous; i++) { nodeSeq[2 * i] = h.nodeSequences[i][0]; nodeSeq[2 * i + 1] = h.nodeSequences[i][1]; }
-	for (size_t i = h.firstAmbiguous; i < n; i++) {
-		const gc::AmbiguousSeq& s = h.ambiguousNodeSequences[i - h.firstAmbiguous];
-		size_t at = 4 * (i - h.firstAmbiguous);
-		ambSeq[at] = s.A; ambSeq[at + 1] = s.C; ambSeq[at + 2] = s.G; ambSeq[at + 3] = s.T;
+	{
+		std::vector<uint32_t> componentNumber(n), componentMap(n), topoId(n);
+		for (size_t i = 0; i < n; i++) {
+			componentNumber[i] = (uint32_t)h.componentNumber[i];
+			componentMap[i] = (uint32_t)h.component_map[i];
+			topoId[i] = (uint32_t)h.topo_ids[h.component_map[i]][h.component_idx[i]];
+		}
+		d.componentNumber = G->up(componentNumber);
+		d.componentMap = G->up(componentMap);
+		d.topoId = G->up(topoId);
 	}
-	auto csr = [&](const std::vector<std::vector<size_t>>& adj, std::vector<uint32_t>& off, std::vector<uint32_t>& flat) {
-		off.assign(n + 1, 0);
+	{
+		std::vector<uint64_t> nodeSeq(2 * h.firstAmbiguous);
+		for (size_t i = 0; i < h.firstAmbiguous; i++) { nodeSeq[2 * i] = h.nodeSequences[i][0]; nodeSeq[2 * i + 1] = h.nodeSequences[i][1]; }
+		d.nodeSeq = G->up(nodeSeq);
+	}
+	{
+		std::vector<uint64_t> ambSeq(4 * (n - h.firstAmbiguous));
+		for (size_t i = h.firstAmbiguous; i < n; i++) {
+			const gc::AmbiguousSeq& s = h.ambiguousNodeSequences[i - h.firstAmbiguous];
+			size_t at = 4 * (i - h.firstAmbiguous);
+			ambSeq[at] = s.A; ambSeq[at + 1] = s.C; ambSeq[at + 2] = s.G; ambSeq[at + 3] = s.T;
+		}
+		d.ambSeq = G->up(ambSeq);
+	}
+	auto csr = [&](const std::vector<std::vector<size_t>>& adj, const uint32_t*& devOff, const uint32_t*& devFlat) {
+		std::vector<uint32_t> off(n + 1, 0), flat;
 		for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + (uint32_t)adj[i].size();
-		flat.clear();
 		flat.reserve(off[n]);
 		for (size_t i = 0; i < n; i++) for (size_t v : adj[i]) flat.push_back((uint32_t)v);
+		devOff = G->up(off); devFlat = G->up(flat);
 	};
-	std::vector<uint32_t> inOff, inAdj, outOff, outAdj;
-	csr(h.inNeighbors, inOff, inAdj);
-	csr(h.outNeighbors, outOff, outAdj);
-	size_t nB = (size_t)maxId + 1;
-	std::vector<uint32_t> origSize(nB, 0), lookupOff(nB + 1, 0), lookup;
-	for (size_t id = 0; id < nB; id++) {
-		const bool known = h.nodeLookup.contains((int)id);
-		lookupOff[id + 1] = lookupOff[id] + (known ? (uint32_t)h.nodeLookup.at((int)id).size() : 0u);
-		if (known) {
-			origSize[id] = (uint32_t)h.originalNodeSize.at((int)id);
-			for (size_t s : h.nodeLookup.at((int)id)) lookup.push_back((uint32_t)s);
-		}
-	}
-	for (size_t id = 0; id < nB; id++)
-		for (uint32_t k = lookupOff[id]; k < lookupOff[id + 1]; k++)
-			if (h.nodeOffset[lookup[k]] != 64ull * (k - lookupOff[id])) throw std::runtime_error("split nodes are not 64-aligned chunks of their original node");
-	G->hOrigSize = origSize; G->hLookupOff = lookupOff; G->hLookup = lookup;
-	// MPC index, flattened to global node ids
-	std::vector<uint32_t> pathsOff(n + 1, 0), pathsFlat, pathsPos, backOff(n + 1, 0), backNode, backPath, backPos, mpcWidth(h.mpc.size());
-	for (size_t c = 0; c < h.mpc.size(); c++) { mpcWidth[c] = (uint32_t)h.mpc[c].size(); G->maxMpcWidth = std::max(G->maxMpcWidth, mpcWidth[c]); }
-	for (size_t i = 0; i < n; i++) {
-		size_t c = h.component_map[i], x = h.component_idx[i];
-		for (size_t k : h.paths[c][x]) pathsFlat.push_back((uint32_t)k);
-		pathsOff[i + 1] = (uint32_t)pathsFlat.size();
-		G->maxPathsPerNode = std::max(G->maxPathsPerNode, pathsOff[i + 1] - pathsOff[i]);
-		for (const auto& b : h.backwards[c][x]) { backNode.push_back((uint32_t)h.component_ids[c][b.first]); backPath.push_back((uint32_t)b.second); }
-		backOff[i + 1] = (uint32_t)backNode.size();
-		G->maxBackPerNode = std::max(G->maxBackPerNode, backOff[i + 1] - backOff[i]);
-	}
-	// position of every node on every path through it (paths[v] lists path ids in ascending order, and a path visits
-	// its nodes in order, so walking path k in order fills the (v,k) entries)
-	pathsPos.assign(pathsFlat.size(), 0);
-	backPos.assign(backNode.size(), 0);
+	csr(h.inNeighbors, d.inOff, d.inAdj);
+	csr(h.outNeighbors, d.outOff, d.outAdj);
+	const size_t nB = (size_t)maxId + 1;
 	{
+		std::vector<uint32_t> origSize(nB, 0), lookupOff(nB + 1, 0), lookup;
+		lookup.reserve(n);
+		for (size_t id = 0; id < nB; id++) {
+			const bool known = h.nodeLookup.contains((int)id);
+			lookupOff[id + 1] = lookupOff[id] + (known ? (uint32_t)h.nodeLookup.at((int)id).size() : 0u);
+			if (known) {
+				origSize[id] = (uint32_t)h.originalNodeSize.at((int)id);
+				for (size_t s : h.nodeLookup.at((int)id)) lookup.push_back((uint32_t)s);
+			}
+		}
+		for (size_t id = 0; id < nB; id++)
+			for (uint32_t k = lookupOff[id]; k < lookupOff[id + 1]; k++)
+				if (h.nodeOffset[lookup[k]] != 64ull * (k - lookupOff[id])) throw std::runtime_error("split nodes are not 64-aligned chunks of their original node");
+		d.origSize = G->up(origSize); d.lookupOff = G->up(lookupOff); d.lookup = G->up(lookup);
+		G->hOrigSize = std::move(origSize); G->hLookupOff = std::move(lookupOff); G->hLookup = std::move(lookup);
+	}
+	{
+		// MPC index, flattened to global node ids
+		std::vector<uint32_t> pathsOff(n + 1, 0), pathsFlat, pathsPos, backOff(n + 1, 0), backNode, backPath, backPos, mpcWidth(h.mpc.size());
+		for (size_t c = 0; c < h.mpc.size(); c++) { mpcWidth[c] = (uint32_t)h.mpc[c].size(); G->maxMpcWidth = std::max(G->maxMpcWidth, mpcWidth[c]); }
+		for (size_t i = 0; i < n; i++) {
+			size_t c = h.component_map[i], x = h.component_idx[i];
+			for (size_t k : h.paths[c][x]) pathsFlat.push_back((uint32_t)k);
+			pathsOff[i + 1] = (uint32_t)pathsFlat.size();
+			G->maxPathsPerNode = std::max(G->maxPathsPerNode, pathsOff[i + 1] - pathsOff[i]);
+			for (const auto& b : h.backwards[c][x]) { backNode.push_back((uint32_t)h.component_ids[c][b.first]); backPath.push_back((uint32_t)b.second); }
+			backOff[i + 1] = (uint32_t)backNode.size();
+			G->maxBackPerNode = std::max(G->maxBackPerNode, backOff[i + 1] - backOff[i]);
+		}
+		// position of every node on every path through it (paths[v] lists path ids in ascending order, and a path visits
+		// its nodes in order, so walking path k in order fills the (v,k) entries)
+		pathsPos.assign(pathsFlat.size(), 0);
+		backPos.assign(backNode.size(), 0);
 		auto posOf = [&](uint32_t node, uint32_t k) -> uint32_t {
 			for (uint32_t e = pathsOff[node]; e < pathsOff[node + 1]; e++) if (pathsFlat[e] == k) return pathsPos[e];
 			throw std::runtime_error("MPC index: node not on path");
@@ -737,24 +766,10 @@ inline void uploadGraph(gc_graph* G)
 				}
 		for (size_t i = 0; i < n; i++)
 			for (uint32_t e = backOff[i]; e < backOff[i + 1]; e++) backPos[e] = posOf(backNode[e], backPath[e]);
+		d.pathsOff = G->up(pathsOff); d.paths = G->up(pathsFlat); d.pathsPos = G->up(pathsPos);
+		d.backOff = G->up(backOff); d.backNode = G->up(backNode); d.backPath = G->up(backPath); d.backPos = G->up(backPos);
+		d.mpcWidth = G->up(mpcWidth);
 	}
-	DGraph& d = G->dev;
-	d.nNodes = (uint32_t)n;
-	d.firstAmbiguous = (uint32_t)h.firstAmbiguous;
-	d.nodeLength = G->up(nodeLength);
-	d.nodeOffset = G->up(nodeOffset);
-	d.nodeIDs = G->up(nodeIDs);
-	d.nodeSeq = G->up(nodeSeq);
-	d.ambSeq = G->up(ambSeq);
-	d.inOff = G->up(inOff); d.inAdj = G->up(inAdj);
-	d.outOff = G->up(outOff); d.outAdj = G->up(outAdj);
-	d.componentNumber = G->up(componentNumber);
-	d.origSize = G->up(origSize); d.lookupOff = G->up(lookupOff); d.lookup = G->up(lookup);
-	d.componentMap = G->up(componentMap);
-	d.topoId = G->up(topoId);
-	d.pathsOff = G->up(pathsOff); d.paths = G->up(pathsFlat); d.pathsPos = G->up(pathsPos);
-	d.backOff = G->up(backOff); d.backNode = G->up(backNode); d.backPath = G->up(backPath); d.backPos = G->up(backPos);
-	d.mpcWidth = G->up(mpcWidth);
 	{
 		std::vector<uint32_t> chainNumber(n);
 		std::vector<uint64_t> chainApproxPos(n);

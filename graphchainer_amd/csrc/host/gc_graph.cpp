@@ -1,6 +1,7 @@
 // Host-side construction of the alignment graph ("A0" data).
 // Restates the behaviour of the reference's loaders; every function cites the lines it follows.
 #include "gc_graph.hpp"
+#include "gc_stageclock.hpp"
 #include <cstring>
 #include <cstdio>
 #include <chrono>
@@ -53,19 +54,6 @@ std::string ReverseComplement(const std::string& s)   // reference: src/CommonUt
 	return out;
 }
 
-namespace {
-// start-up stage timing on stderr (GC_DEBUG_TIMES)
-struct StageClock {
-	std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-	const bool on = getenv("GC_DEBUG_TIMES") != nullptr;
-	void lap(const char* what)
-	{
-		auto now = std::chrono::steady_clock::now();
-		if (on) fprintf(stderr, "[gc build] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
-		t = now;
-	}
-};
-}
 
 // ------------------------------------------------------------------ GFA parsing
 

@@ -11,6 +11,7 @@
 // (4) split nodes - lengths, offsets, ids, 2-bit / one-hot sequences of both strands - by all threads into their final positions; (5) the links' edges
 // in the order AddEdgeNodeId would be called, adjacency lists filled by node range on all threads; (6) Finalize() as before.
 #include "gc_graph.hpp"
+#include "gc_stageclock.hpp"
 #include "gc_hashorder.hpp"
 
 #include <algorithm>
@@ -30,17 +31,6 @@
 namespace gc {
 
 namespace {
-
-struct Clock {
-	std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-	const bool on = getenv("GC_DEBUG_TIMES") != nullptr;
-	void lap(const char* what)
-	{
-		auto now = std::chrono::steady_clock::now();
-		if (on) fprintf(stderr, "[gc build] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
-		t = now;
-	}
-};
 
 // body(begin, end, worker) over [0, n) in contiguous shares, one per thread; the first exception is rethrown
 void parallelRanges(size_t n, size_t threads, const std::function<void(size_t, size_t, size_t)>& body)
@@ -226,7 +216,7 @@ inline uint32_t complementSet(uint32_t s) { return ((s & 1) << 3) | ((s & 2) << 
 AlignmentGraph AlignmentGraph::BuildFromGFAFile(const std::string& path)
 {
 	if (const char* env = getenv("GC_BUILD_REFERENCE_CONTAINERS")) if (atoi(env) == 1) { GfaGraph gfa = GfaGraph::LoadFromFile(path); return BuildFromGFA(gfa); }
-	Clock clock;
+	StageClock clock;
 	const size_t threads = buildThreads();
 	// ---- (1) the file, its lines, their fields
 	std::unique_ptr<char[]> file;   // (not a vector: resize() would fill 3.8 GB with zeros at 960 Mbp before fread overwrites them)

@@ -1,5 +1,6 @@
 // Index cache; see gc_index_cache.hpp for the format.
 #include "gc_index_cache.hpp"
+#include "gc_stageclock.hpp"
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -301,20 +302,9 @@ void validateSeeder(const MinimizerIndex& idx, const AlignmentGraph& g)
 	if (!idx.kmers.empty() && (idx.kmers.back() >> (2 * idx.k)) != 0) bad("k-mer wider than 2k bits");
 }
 
-struct LoadClock {   // GC_DEBUG_TIMES: the stages of a load on stderr
-	std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-	const bool on = getenv("GC_DEBUG_TIMES") != nullptr;
-	void lap(const char* what)
-	{
-		auto now = std::chrono::steady_clock::now();
-		if (on) fprintf(stderr, "[gc cache] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
-		t = now;
-	}
-};
-
 IndexCacheInfo parse(const Mapping& file, AlignmentGraph& g, MinimizerIndex& idx)
 {
-	LoadClock clock;
+	StageClock clock("gc cache");
 	if (memcmp(file.p, MAGIC, 8) != 0) throw std::runtime_error("not an index cache (bad magic)");
 	size_t payload = file.n - 8;
 	uint64_t stored = 0;

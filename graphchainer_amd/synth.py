@@ -13,6 +13,9 @@ insertion that itself carries a SNP), links written from the reverse strand ("L 
 windows pasted elsewhere in the backbone with a little divergence: many seeds per fragment), and SynthGenome: several
 such chromosomes in one GFA (separate weakly connected components, BASELINE config 5's shape).
 """
+import os
+import shutil
+
 import numpy as np
 
 _BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -210,14 +213,19 @@ class SynthGenome:
         self.backbone_len = backbone_len
 
     def write_gfa(self, path):
+        """All S lines, then all L lines (the reference's node numbering follows the order of first appearance). One chromosome's lines in memory at a time: its
+        links wait in a file of their own (at 3.1 Gbp the lines of the whole genome are ~45 GB of Python objects)."""
         first = 1
-        segs, links = [], []
-        for chrom in self.chromosomes:
-            s, l, first = chrom.gfa_lines(first)
-            segs.extend(s); links.extend(l)
-        with open(path, "wb") as f:
-            f.writelines(segs)
-            f.writelines(links)
+        links_path = path + ".links"
+        with open(path, "wb") as f, open(links_path, "wb") as lf:
+            for chrom in self.chromosomes:
+                s, l, first = chrom.gfa_lines(first)
+                f.writelines(s)
+                lf.writelines(l)
+                del s, l
+        with open(path, "ab") as f, open(links_path, "rb") as lf:
+            shutil.copyfileobj(lf, f, 64 << 20)
+        os.remove(links_path)
         return first - 1
 
     def sample_reads(self, n_reads, read_len, seed=11, **kw):

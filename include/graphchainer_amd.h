@@ -132,6 +132,10 @@ uint64_t gc_graph_size_bp(const gc_graph* g);
  * "mpc_path_off","mpc_path_nodes","paths_off","paths","back_off","back_node","back_path"}; returns a malloc'd int64 array
  * (free with gc_free). */
 int gc_graph_array(const gc_graph* g, const char* name, int64_t** out, uint64_t* count);
+/* Frees the HOST copy of the MPC index (path cover, per-node path lists, backward links, topological orders: ~33 bytes of host memory per graph base, 100 GB at 3.1 Gbp);
+ * the device keeps its own and aligning reads nothing of it. For hosts that do not write the index cache afterwards: gc_index_save and the MPC arrays of gc_graph_array
+ * ("mpc_*", "paths*", "back_*", "topo_id") return GC_ERR_INVALID on a trimmed graph. No reference counterpart (the reference's AlignmentGraph keeps everything). */
+int gc_graph_trim_host(gc_graph* g);
 
 /* ---- seeder (replaces MinimizerSeeder::MinimizerSeeder, src/Aligner.cpp:1162) --------------------- */
 int gc_seeder_create(const gc_graph* g, int32_t k, int32_t w, double keep_least_frequent_fraction, gc_seeder** out);

@@ -106,6 +106,36 @@ def test_reference_fixture(gca, golden_dir):
     assert list(got["anchor_path"]) == [6, 4, 0] and list(got["chain"]) == [0]
 
 
+def test_host_copy_of_the_mpc_index_can_be_released(gca, tmp_path):
+    """gc_graph_trim_host: aligning reads nothing of the host's MPC copy (the device has its own); saving the cache and the MPC views refuse afterwards."""
+    from graphchainer_amd.synth import SynthGenome
+    sg = SynthGenome(3, 30_000, seed=7, multi_allelic=0.1, nested=0.1, minus_links=0.3, repeats=4, repeat_len=3000)
+    gfa = str(tmp_path / "g.gfa")
+    sg.write_gfa(gfa)
+    reads = sg.sample_reads(9, 4000, seed=11)
+    graph = gca.AlignmentGraph(gfa)
+    seeder = gca.MinimizerSeeder(graph)
+    aligner = gca.Aligner(graph, seeder, keep_traces=True, long_pass=True, chain_traces=2, colinear_gap=50000)
+    before = {k: np.array(v) for k, v in aligner.align_reads(reads).items()}   # (copies: the arrays are views of the result block)
+    width = graph.array("mpc_width")
+    graph.trim_host()
+    after = {k: np.array(v) for k, v in aligner.align_reads(reads).items()}
+    fresh = gca.Aligner(graph, seeder, keep_traces=True, long_pass=True, chain_traces=2, colinear_gap=50000).align_reads(reads)
+    assert len(width) == 6 and int(before["read_chain_off"][-1]) > 0
+    for key in before:
+        if key in ("counters", "counters_long", "kernel_us", "host_us"):
+            continue
+        assert np.array_equal(before[key], after[key]), key
+        assert np.array_equal(before[key], fresh[key]), key
+    for name in ("mpc_width", "paths", "back_node", "topo_id", "mpc_path_nodes"):
+        with pytest.raises(Exception, match="released"):
+            graph.array(name)
+    assert len(graph.array("nodeLength")) == graph.NodeSize()
+    with pytest.raises(Exception, match="released"):
+        gca.api.save_index_cache(graph, seeder, str(tmp_path / "x.gcidx"))
+    assert not os.path.exists(str(tmp_path / "x.gcidx"))
+
+
 @pytest.mark.parametrize("backbone,n_reads,read_len,kw", [
     (40_000, 6, 2000, {}),
     (120_000, 12, 5000, {}),
