@@ -238,6 +238,13 @@ def resident_bytes():
     return 0
 
 
+def note_memory(what):
+    """GC_DEBUG_TIMES: one line per set-up stage with the host memory in use (what bounds config 5's graph size)."""
+    if os.environ.get("GC_DEBUG_TIMES"):
+        sys.stderr.write(f"[bench] {what}: {resident_bytes() / 2**30:.1f} GiB of host memory resident\n")
+        sys.stderr.flush()
+
+
 def start_host_memory_watchdog(cap_gb):
     """A thread that ends the process (exit 3, one line on stderr) when resident memory passes the cap: the kernel's OOM kill takes more than the process with it on a shared box."""
     cap = int(cap_gb * 2**30) if cap_gb > 0 else None
@@ -314,6 +321,7 @@ def main():
         np.save(os.path.join(args.setup_dir, "reads.npy"), np.frombuffer(b"".join(reads), dtype=np.uint8))
         np.save(os.path.join(args.setup_dir, "read_offsets.npy"), np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64))
     t_gen = time.time() - t0
+    note_memory("GFA written, reads drawn")
     # two short legs after the headline (N=1, config 2, outside `value`): reads whose chained alignment wins, and a graph with repeats
     legs = world == 1 and args.config == 2 and long_pass and not args.no_cpu_baseline and sg is not None
     sv_reads = rep_reads = rep_gfa = None
@@ -386,9 +394,14 @@ def main():
         t0 = time.time()
         graph = gca.AlignmentGraph(gfa)
         t_graph = time.time() - t0
+        note_memory("graph built and uploaded")
+        if not use_cache:
+            graph.trim_host()   # before the index is built beside it (its hash table and the sorted pairs are ~20 B of host memory per graph base while they are made)
+            note_memory("host's MPC copy released")
         t0 = time.time()
         seeder = gca.MinimizerSeeder(graph)
         t_index = time.time() - t0
+        note_memory("minimizer index built")
         if use_cache:
             t0 = time.time()
             gca.api.save_index_cache(graph, seeder, cache)
@@ -413,7 +426,9 @@ def main():
             del positions
             if loaded != built:
                 raise SystemExit("index cache does not reproduce the built index")
+    note_memory("before the host's MPC copy is released")
     graph.trim_host()   # nothing below writes the cache again: the host copy of the MPC index (33 B per graph base) goes back to the system
+    note_memory("set-up done")
     if dist is not None:
         dist.barrier()
     if rank == 0 and use_cache and not (args.setup_dir and world == 1):
