@@ -438,10 +438,12 @@ def main():
 
     inflight = max(1, args.inflight)
     mem_free_start, mem_total = gca.device_memory()
-    # batches in flight that fit the device beside the graph and the index: a batch in flight holds at most ~450 bytes per read base (r5, pools sized by use: 19 GB for
-    # 10 k x 10 kb, 44 GB for 2 k x 50 kb on a 960 Mbp graph), the device's one whole-read scratch and the result blocks ~20 GB; streams whose first batches do not fit
-    # after all are dropped one at a time in the warm-up below
-    batch_bytes = 450 * min(args.batch, args.reads) * args.read_len
+    # batches in flight that fit the device beside the graph and the index. A batch in flight holds (r6, measured with pools sized by use) 17 GB for 10 k x 10 kb on 51 Mbp,
+    # and for 2 k x 50 kb: 28 GB on 192 Mbp, 41 on 960 Mbp, 46 on 1.25 Gbp, 81 on 3.1 Gbp - linear in the graph's size, because chance minimizer hits (and the fragment
+    # extensions run from them) are: 245 + 183 x Gbp bytes per read base. Beside them the device's one whole-read scratch and the result blocks, ~20 GB. Streams whose
+    # first batches do not fit after all are dropped one at a time in the warm-up below
+    graph_gbp = (args.chromosomes if args.config == 5 else 1) * args.backbone / 1e9
+    batch_bytes = int((245 + 183 * graph_gbp) * min(args.batch, args.reads) * args.read_len)
     fit = int((mem_free_start - (20 << 30)) // max(1, batch_bytes))
     memory_choice = None
     if fit < inflight:
@@ -500,7 +502,9 @@ def main():
         # every stream of every rank has done its first-batch allocations before the timed steps, whatever the dynamic queue would do
         from concurrent.futures import ThreadPoolExecutor
         while True:
-            n_items = max(args.warmup, inflight) * (1 if strong else len(batches))
+            # (config 5: two batches per stream - a stream's pools reach their size with its second batch, and at 3.1 Gbp, where ONE 81 GB batch fits beside 119 GB of graph
+            # and index, a second stream got through a single warm-up batch and ran out of memory in the timed steps)
+            n_items = max(args.warmup, (2 if args.config == 5 else 1) * inflight) * (1 if strong else len(batches))
             try:
                 with ThreadPoolExecutor(max_workers=inflight) as warm:
                     list(warm.map(lambda i: [aligners[i].align_batch(batches[(item + rank) % len(batches)]) and None for item in range(i, n_items, inflight)], range(inflight)))
