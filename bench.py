@@ -80,7 +80,7 @@ def parse_args():
     ap.add_argument("--no-index-cache", action="store_true", help="one rank: align on the graph and index as built, without writing the index cache and loading it back (config 5 at 3.1 Gbp: "
                     "a 59 GB file, ~8 min of set-up)")
     ap.add_argument("--host-memory-cap-gb", type=float, default=float(os.environ.get("GC_BENCH_HOST_CAP_GB", 0)), help="stop the run (exit 3) when the process's resident memory passes this: "
-                    "a run that would otherwise take its host out of memory ends by itself (0: 92 %% of the cgroup's memory.max when that is readable, else no cap)")
+                    "a run that would otherwise take its host out of memory ends by itself (0, the default: no cap; config 5 at 3.1 Gbp was run with 290 on a 300 GiB host)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("GC_BENCH_INFLIGHT", 5)),
                     help="batches in flight per GPU, each on its own gc_stream and host thread (like the reference's -t worker threads): one batch's seeding, fragment "
                          "pipeline, distances and assembly run beside another's whole-read pass (r5, ms per 10 k x 10 kb batch: " + ", ".join(f"{k} -> {v:.0f}" for k, v in sorted(BATCH_MS_BY_INFLIGHT.items())) + "; "
@@ -210,18 +210,6 @@ def launch_ranks(args, argv):
     return subprocess.run(cmd).returncode
 
 
-def host_memory_limit_bytes():
-    """The cgroup's memory limit (v2, then v1), None when there is none or it cannot be read."""
-    for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
-        try:
-            text = open(path).read().strip()
-        except OSError:
-            continue
-        if text.isdigit() and int(text) < (1 << 60):
-            return int(text)
-    return None
-
-
 def resident_bytes():
     """What counts against that limit and cannot be reclaimed: the cgroup's anonymous + shared memory when memory.stat is readable, else this process's VmRSS."""
     try:
@@ -247,12 +235,9 @@ def note_memory(what):
 
 def start_host_memory_watchdog(cap_gb):
     """A thread that ends the process (exit 3, one line on stderr) when resident memory passes the cap: the kernel's OOM kill takes more than the process with it on a shared box."""
-    cap = int(cap_gb * 2**30) if cap_gb > 0 else None
-    if cap is None:
-        limit = host_memory_limit_bytes()
-        cap = int(limit * 0.92) if limit else None
-    if cap is None:
+    if cap_gb <= 0:
         return None
+    cap = int(cap_gb * 2**30)
     state = {"peak": 0}
 
     def watch():
@@ -388,7 +373,7 @@ def main():
         cache = os.path.join(args.setup_dir, "index.gcidx")
     t_graph = t_index = t_save = t_load = 0.0
     cache_bytes = 0
-    use_cache = not (args.no_index_cache and world == 1)
+    use_cache = not (args.no_index_cache and world == 1 and not setup_reused)
     built = None
     if rank == 0 and not setup_reused:
         t0 = time.time()

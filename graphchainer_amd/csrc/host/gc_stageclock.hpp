@@ -8,7 +8,7 @@
 
 namespace gc {
 
-inline double residentGB()   // VmRSS of /proc/self/status; 0 when unreadable
+inline double residentGiB()   // VmRSS of /proc/self/status; 0 when unreadable
 {
 	FILE* f = fopen("/proc/self/status", "r");
 	if (!f) return 0;
@@ -27,7 +27,7 @@ struct StageClock {
 	void lap(const char* what)
 	{
 		auto now = std::chrono::steady_clock::now();
-		if (on) fprintf(stderr, "[%s] %-28s %8.1f ms  %7.2f GB resident\n", tag, what, std::chrono::duration<double, std::milli>(now - t).count(), residentGB());
+		if (on) fprintf(stderr, "[%s] %-28s %8.1f ms  %7.2f GiB resident\n", tag, what, std::chrono::duration<double, std::milli>(now - t).count(), residentGiB());
 		t = now;
 	}
 };
