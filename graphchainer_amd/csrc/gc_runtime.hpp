@@ -741,6 +741,13 @@ inline void uploadGraph(gc_graph* G)
 		// MPC index, flattened to global node ids
 		std::vector<uint32_t> pathsOff(n + 1, 0), pathsFlat, pathsPos, backOff(n + 1, 0), backNode, backPath, backPos, mpcWidth(h.mpc.size());
 		for (size_t c = 0; c < h.mpc.size(); c++) { mpcWidth[c] = (uint32_t)h.mpc[c].size(); G->maxMpcWidth = std::max(G->maxMpcWidth, mpcWidth[c]); }
+		{
+			// (sizes first: vectors grown by push_back would hold up to twice their contents, and thrice while they move - 30 GB of the host's peak at 3.1 Gbp)
+			size_t nPaths = 0, nBack = 0;
+			for (size_t i = 0; i < n; i++) { const size_t c = h.component_map[i], x = h.component_idx[i]; nPaths += h.paths[c][x].size(); nBack += h.backwards[c][x].size(); }
+			if (nPaths >= 0xffffffffull || nBack >= 0xffffffffull) throw std::runtime_error("MPC index too large for 32-bit offsets");
+			pathsFlat.reserve(nPaths); backNode.reserve(nBack); backPath.reserve(nBack);
+		}
 		for (size_t i = 0; i < n; i++) {
 			size_t c = h.component_map[i], x = h.component_idx[i];
 			for (size_t k : h.paths[c][x]) pathsFlat.push_back((uint32_t)k);
@@ -785,6 +792,11 @@ inline void uploadGraph(gc_graph* G)
 		// the names the output encoders print (OriginalNodeName; empty: they print id / 2), by bigraph node id
 		std::vector<uint32_t> nameOff(nB + 1, 0);
 		std::vector<char> nameBytes;
+		{
+			size_t total = 1;
+			for (size_t id = 0; id < nB; id++) if (const std::string* name = h.originalNodeName.find((int)id)) total += name->size();
+			nameBytes.reserve(total);
+		}
 		for (size_t id = 0; id < nB; id++) {
 			const std::string* name = h.originalNodeName.find((int)id);
 			if (name) nameBytes.insert(nameBytes.end(), name->begin(), name->end());
