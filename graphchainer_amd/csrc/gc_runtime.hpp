@@ -738,43 +738,61 @@ inline void uploadGraph(gc_graph* G)
 		G->hOrigSize = std::move(origSize); G->hLookupOff = std::move(lookupOff); G->hLookup = std::move(lookup);
 	}
 	{
-		// MPC index, flattened to global node ids
-		std::vector<uint32_t> pathsOff(n + 1, 0), pathsFlat, pathsPos, backOff(n + 1, 0), backNode, backPath, backPos, mpcWidth(h.mpc.size());
+		// MPC index, flattened to global node ids. The per-node path lists stay on the host while the backward links - 12 bytes each, 4.5 per node - are made and sent in slices of
+		// nodes: all of them at once were 37 GB of staging at 3.1 Gbp, the top of the host's peak (235 GiB of 300)
+		std::vector<uint32_t> pathsOff(n + 1, 0), pathsFlat, pathsPos, backOff(n + 1, 0), mpcWidth(h.mpc.size());
 		for (size_t c = 0; c < h.mpc.size(); c++) { mpcWidth[c] = (uint32_t)h.mpc[c].size(); G->maxMpcWidth = std::max(G->maxMpcWidth, mpcWidth[c]); }
-		{
-			// (sizes first: vectors grown by push_back would hold up to twice their contents, and thrice while they move - 30 GB of the host's peak at 3.1 Gbp)
-			size_t nPaths = 0, nBack = 0;
-			for (size_t i = 0; i < n; i++) { const size_t c = h.component_map[i], x = h.component_idx[i]; nPaths += h.paths[c][x].size(); nBack += h.backwards[c][x].size(); }
-			if (nPaths >= 0xffffffffull || nBack >= 0xffffffffull) throw std::runtime_error("MPC index too large for 32-bit offsets");
-			pathsFlat.reserve(nPaths); backNode.reserve(nBack); backPath.reserve(nBack);
-		}
+		size_t nPaths = 0, nBack = 0;
+		for (size_t i = 0; i < n; i++) { const size_t c = h.component_map[i], x = h.component_idx[i]; nPaths += h.paths[c][x].size(); nBack += h.backwards[c][x].size(); }
+		if (nPaths >= 0xffffffffull || nBack >= 0xffffffffull) throw std::runtime_error("MPC index too large for 32-bit offsets");
+		pathsFlat.reserve(nPaths);
 		for (size_t i = 0; i < n; i++) {
 			size_t c = h.component_map[i], x = h.component_idx[i];
 			for (size_t k : h.paths[c][x]) pathsFlat.push_back((uint32_t)k);
 			pathsOff[i + 1] = (uint32_t)pathsFlat.size();
 			G->maxPathsPerNode = std::max(G->maxPathsPerNode, pathsOff[i + 1] - pathsOff[i]);
-			for (const auto& b : h.backwards[c][x]) { backNode.push_back((uint32_t)h.component_ids[c][b.first]); backPath.push_back((uint32_t)b.second); }
-			backOff[i + 1] = (uint32_t)backNode.size();
+			backOff[i + 1] = backOff[i] + (uint32_t)h.backwards[c][x].size();
 			G->maxBackPerNode = std::max(G->maxBackPerNode, backOff[i + 1] - backOff[i]);
 		}
 		// position of every node on every path through it (paths[v] lists path ids in ascending order, and a path visits
 		// its nodes in order, so walking path k in order fills the (v,k) entries)
 		pathsPos.assign(pathsFlat.size(), 0);
-		backPos.assign(backNode.size(), 0);
-		auto posOf = [&](uint32_t node, uint32_t k) -> uint32_t {
-			for (uint32_t e = pathsOff[node]; e < pathsOff[node + 1]; e++) if (pathsFlat[e] == k) return pathsPos[e];
-			throw std::runtime_error("MPC index: node not on path");
-		};
 		for (size_t c = 0; c < h.mpc.size(); c++)
 			for (size_t k = 0; k < h.mpc[c].size(); k++)
 				for (size_t j = 0; j < h.mpc[c][k].size(); j++) {
 					size_t node = h.mpc[c][k][j];
 					for (uint32_t e = pathsOff[node]; e < pathsOff[node + 1]; e++) if (pathsFlat[e] == k) pathsPos[e] = (uint32_t)j;   // last visit wins, as in last2reach (:1340-1345)
 				}
-		for (size_t i = 0; i < n; i++)
-			for (uint32_t e = backOff[i]; e < backOff[i + 1]; e++) backPos[e] = posOf(backNode[e], backPath[e]);
+		auto posOf = [&](uint32_t node, uint32_t k) -> uint32_t {
+			for (uint32_t e = pathsOff[node]; e < pathsOff[node + 1]; e++) if (pathsFlat[e] == k) return pathsPos[e];
+			throw std::runtime_error("MPC index: node not on path");
+		};
+		uint32_t *dBackNode = nullptr, *dBackPath = nullptr, *dBackPos = nullptr;
+		for (uint32_t** p : { &dBackNode, &dBackPath, &dBackPos }) { HIP_CHECK(hipMalloc((void**)p, std::max<size_t>(nBack, 1) * sizeof(uint32_t))); G->allocations.push_back(*p); }
+		size_t sliceLinks = (size_t)64 << 20;
+		if (const char* env = getenv("GC_TEST_UPLOAD_SLICE")) sliceLinks = (size_t)std::max(1, atoi(env));   // test hook: many small slices
+		std::vector<uint32_t> backNode, backPath, backPos;
+		for (size_t first = 0; first < n;) {
+			size_t last = first;
+			while (last < n && (last == first || (size_t)(backOff[last + 1] - backOff[first]) <= sliceLinks)) last++;
+			backNode.clear(); backPath.clear(); backPos.clear();
+			for (size_t i = first; i < last; i++) {
+				const size_t c = h.component_map[i], x = h.component_idx[i];
+				for (const auto& b : h.backwards[c][x]) {
+					const uint32_t node = (uint32_t)h.component_ids[c][b.first], path = (uint32_t)b.second;
+					backNode.push_back(node); backPath.push_back(path); backPos.push_back(posOf(node, path));
+				}
+			}
+			if (backNode.size() != (size_t)(backOff[last] - backOff[first])) throw std::runtime_error("MPC index: backward links counted differently");
+			if (!backNode.empty()) {
+				HIP_CHECK(hipMemcpy(dBackNode + backOff[first], backNode.data(), backNode.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+				HIP_CHECK(hipMemcpy(dBackPath + backOff[first], backPath.data(), backPath.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+				HIP_CHECK(hipMemcpy(dBackPos + backOff[first], backPos.data(), backPos.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+			}
+			first = last;
+		}
 		d.pathsOff = G->up(pathsOff); d.paths = G->up(pathsFlat); d.pathsPos = G->up(pathsPos);
-		d.backOff = G->up(backOff); d.backNode = G->up(backNode); d.backPath = G->up(backPath); d.backPos = G->up(backPos);
+		d.backOff = G->up(backOff); d.backNode = dBackNode; d.backPath = dBackPath; d.backPos = dBackPos;
 		d.mpcWidth = G->up(mpcWidth);
 	}
 	{

@@ -463,8 +463,10 @@ def test_chained_alignment_wins(gca, tmp_path):
     assert int(np.sum(dev["out_source"])) == int(np.sum(got["chained_better"]))
 
 
-def test_config5_shape(gca, tmp_path):
-    """BASELINE config 5 in miniature: several chromosomes in one GFA (6 weakly connected components: the cross-component rule of
+@pytest.mark.parametrize("upload_slice", [None, "7"])
+def test_config5_shape(gca, tmp_path, monkeypatch, upload_slice):
+    """(upload_slice: the MPC index's backward links reach the device in slices of nodes - 64 M links each; the hook makes them 7.)
+    BASELINE config 5 in miniature: several chromosomes in one GFA (6 weakly connected components: the cross-component rule of
     src/AlignmentGraph.cpp:1722-1733), path-cover width > 2 (multi-allelic and nested bubbles), links written from the reverse
     strand, repeats, 50 kb reads at PacBio-CLR-like error rates (4 % deletions, 2 % substitutions, 9 % insertions),
     --colinear-gap 50000, whole-read pass on."""
@@ -474,6 +476,8 @@ def test_config5_shape(gca, tmp_path):
     gen.write_gfa(gfa)
     reads = gen.sample_reads(5, 50_000, seed=6, p_del=0.04, p_sub=0.02, p_ins=0.09)
     reads.append(reads[0][:20_000] + reads[1][:25_000])      # a read spanning two chromosomes
+    if upload_slice:
+        monkeypatch.setenv("GC_TEST_UPLOAD_SLICE", upload_slice)
     got, want = run_case(gca, gfa, reads, long_pass=True, colinear_gap=50000)
     compare(got, want, COMPARE_KEYS + LONG_KEYS)
     graph = gca.AlignmentGraph(gfa)
