@@ -13,4 +13,6 @@ timeout 900 python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 > $out/bench
 timeout 900 python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 > $out/bench_b.json 2> $out/bench_b.err
 for f in bench_a bench_b; do python3 -c "
 import json
-d=json.loads(open('$out/$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['frac'], d['cpu_baseline']['value'], d['cpu_baseline']['cores'], d['stage_ms']['k_long_extend_all_rounds'], d['parity_check']['mismatches'], d['e2e']['reads_per_s'])"; done
+d=json.loads(open('$out/$f.json').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['roofline']['frac'], d['cpu_baseline']['value'], d['cpu_baseline']['cores'], d['stage_ms']['k_long_extend_all_rounds'], d['parity_check']['mismatches'], {k: v.get('reads_per_s') for k, v in d['e2e'].items() if isinstance(v, dict) and 'reads_per_s' in v})"; done
+# the multi-rank path on this one-GPU box (both ranks share the device: not a measurement)
+bash $GRAFT_REPO_ROOT/scripts/gpu/tworank.sh $1_tworank 2>&1 | grep -v "^$" | cut -c1-700
