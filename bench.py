@@ -805,7 +805,8 @@ def main():
             prof = json.load(f)
         for name, rec in prof.get("kernels", {}).items():
             if name.split("<")[0] == kernel and "FETCH_SIZE_KB_per_step" in rec and "WRITE_SIZE_KB_per_step" in rec:
-                return int((rec["FETCH_SIZE_KB_per_step"] + rec["WRITE_SIZE_KB_per_step"]) * 1024 / max(1.0, launches)), os.path.basename(files[-1])
+                # (by the pass's own launch count: an r6 pass over `--steps 1` holds two batches - the timed step and the same-read-set leg)
+                return int((rec["FETCH_SIZE_KB_per_step"] + rec["WRITE_SIZE_KB_per_step"]) * 1024 / max(1.0, float(rec.get("launches_per_step", launches)))), os.path.basename(files[-1])
         return None, None
 
     n_batches_step = len(outs) / steps
