@@ -538,7 +538,7 @@ int gc_graph_create(const gc_graph_desc* desc, gc_graph** out)
 	return GC_OK;
 }
 
-void gc_graph_destroy(gc_graph* g) { delete g; }
+void gc_graph_destroy(gc_graph* g) { delete g; malloc_trim(0); }   // (the host graph's many small blocks back to the system, not to the allocator's free lists: a graph loaded next would sit beside them)
 uint64_t gc_graph_num_nodes(const gc_graph* g) { return g ? g->host.NodeSize() : 0; }
 uint64_t gc_graph_size_bp(const gc_graph* g) { return g ? g->host.SizeInBP() : 0; }
 
@@ -790,7 +790,7 @@ int gc_index_load(const char* cache_path, gc_graph** graph_out, gc_seeder** seed
 	return GC_OK;
 }
 
-void gc_seeder_destroy(gc_seeder* s) { delete s; }
+void gc_seeder_destroy(gc_seeder* s) { delete s; malloc_trim(0); }
 
 int gc_seeder_array(const gc_seeder* s, const char* name, int64_t** out, uint64_t* count)
 {

@@ -109,6 +109,16 @@ class In {
 public:
 	In(const uint8_t* p, size_t n) : base(p), end(n) {}
 	size_t at = 0;
+	// the mapped pages behind the cursor go back to the system every 256 MB: a 59 GB cache (3.1 Gbp) would otherwise sit in the process's resident memory beside the
+	// graph it is parsed into (clean file pages: a later reader - CheckIndexCache's comparison - faults them in again)
+	void dropConsumed()
+	{
+		const size_t page = 4096, upTo = at & ~(page - 1);
+		if (upTo < dropped + ((size_t)256 << 20)) return;
+		const uintptr_t from = ((uintptr_t)base + dropped + page - 1) & ~(uintptr_t)(page - 1), to = ((uintptr_t)base + upTo) & ~(uintptr_t)(page - 1);
+		if (to > from) (void)madvise((void*)from, (size_t)(to - from), MADV_DONTNEED);
+		dropped = upTo;
+	}
 	void raw(void* p, size_t n) { need(n); memcpy(p, base + at, n); at += n; }
 	uint64_t num()
 	{
@@ -126,6 +136,7 @@ public:
 	{
 		uint64_t n = num();
 		if (n > (uint64_t)(end - at) * 8 / minBits + 8) throw std::runtime_error("index cache: element count exceeds the file size");
+		dropConsumed();
 		return (size_t)n;
 	}
 	void operator()(uint64_t& v) { v = num(); }
@@ -148,6 +159,7 @@ private:
 	void need(size_t n) const { if (n > end - at) throw std::runtime_error("index cache: truncated"); }
 	const uint8_t* base;
 	size_t end;
+	size_t dropped = 0;
 };
 
 // The one list of fields, shared by both directions. The three id-keyed hash maps travel as parallel vectors in
@@ -310,6 +322,7 @@ IndexCacheInfo parse(const Mapping& file, AlignmentGraph& g, MinimizerIndex& idx
 	uint64_t stored = 0;
 	for (int i = 0; i < 8; i++) stored |= (uint64_t)file.p[payload + i] << (8 * i);
 	if (fnv(FNV_SEED, file.p, payload) != stored) throw std::runtime_error("index cache checksum mismatch (truncated or damaged file)");
+	(void)madvise((void*)file.p, file.n, MADV_DONTNEED);   // (mmap returns page-aligned memory: the pages the checksum touched go back before the graph is parsed beside them)
 	clock.lap("checksum");
 	In in(file.p, payload);
 	in.at = 8;
