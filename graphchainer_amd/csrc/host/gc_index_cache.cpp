@@ -9,6 +9,7 @@
 #include <stdexcept>
 #include <unordered_map>
 #include <fcntl.h>
+#include <malloc.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -347,6 +348,8 @@ IndexCacheInfo parse(const Mapping& file, AlignmentGraph& g, MinimizerIndex& idx
 	}
 	if (g.nodeLookup.size() != t.ids.size()) throw std::runtime_error("index cache: duplicate node id");
 	g.nodeLookupOrder = std::move(t.ids);
+	t = GraphTables();   // (the per-id staging lists - 20 GiB at 3.1 Gbp - go before the minimizer index is read beside the graph)
+	malloc_trim(0);
 	clock.lap("node tables");
 	IndexCacheInfo info;
 	info.hasSeeder = in.num() != 0;
