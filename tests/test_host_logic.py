@@ -331,3 +331,16 @@ def test_genome_gfa_is_written_chromosome_by_chromosome_with_the_same_bytes(tmp_
         links += l
     assert open(path, "rb").read() == b"".join(segs) + b"".join(links)
     assert last == first - 1 == len(segs) and not os.path.exists(path + ".links")
+
+
+def test_bench_host_memory_cap_ends_the_process_itself():
+    """bench.py --host-memory-cap-gb (config 5 at 3.1 Gbp was run with 290 on a 300 GiB host): a watchdog thread ends the process with exit code 3 and one line on stderr when
+    resident memory passes the cap - before the kernel's OOM kill would; without the flag there is no watchdog."""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "assert bench.start_host_memory_watchdog(0) is None\n"
+            "state = bench.start_host_memory_watchdog(0.05)\n"
+            "block = bytearray(200 << 20)\n"
+            "time.sleep(5)\n"
+            "print('still here')\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 3 and "passed the cap" in out.stderr and "still here" not in out.stdout, out.stdout + out.stderr
