@@ -105,11 +105,14 @@ MinimizerIndex MinimizerIndex::Build(const AlignmentGraph& g, size_t k, size_t w
 	idx.k = k;
 	idx.w = w;
 	// minimizers that end inside an overlap prefix are skipped (:323-340,369); zero for 0M graphs
-	std::unordered_map<int, size_t> nodeMinimizerStart;
+	// (by node id, flat: the reference's unordered_map holds one entry per bigraph node - 25 GB of nodes and buckets at 3.1 Gbp)
+	int maxId = -1;
+	for (size_t i = 0; i < g.NodeSize(); i++) maxId = std::max(maxId, g.nodeIDs[i]);
+	std::vector<uint32_t> nodeMinimizerStart((size_t)(maxId + 1), 0);
 	for (size_t i = 0; i < g.NodeSize(); i++) {
-		size_t& start = nodeMinimizerStart[g.nodeIDs[i]];
+		uint32_t& start = nodeMinimizerStart[(size_t)g.nodeIDs[i]];
 		for (size_t nb : g.inNeighbors[i])
-			if (g.nodeIDs[nb] != g.nodeIDs[i]) { start = std::max(start, g.nodeOffset[i]); break; }
+			if (g.nodeIDs[nb] != g.nodeIDs[i]) { start = std::max(start, (uint32_t)g.nodeOffset[i]); break; }
 	}
 	const std::vector<int>& idOrder = g.nodeLookupOrder;   // arrival order at -t 1: nodeLookup iteration order (:354-357)
 	if (idOrder.size() != g.nodeLookup.size()) throw std::runtime_error("MinimizerIndex::Build: the graph's node lookup order is missing");
@@ -124,7 +127,7 @@ MinimizerIndex MinimizerIndex::Build(const AlignmentGraph& g, size_t k, size_t w
 			size_t filled = 0;
 			for (size_t split : splitNodes)
 				for (size_t j = 0; j < g.nodeLength[split]; j++) sequence[filled++] = g.NodeSequences(split, j);
-			size_t minStart = nodeMinimizerStart.at(nodeId);
+			size_t minStart = nodeMinimizerStart.at((size_t)nodeId);
 			forEachWindowMinimizer(sequence, k, w, [&](size_t pos, uint64_t kmer) {
 				if (pos < minStart) return;
 				size_t split = g.GetUnitigNode(nodeId, pos);
